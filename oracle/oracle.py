@@ -1,0 +1,303 @@
+"""ctypes front-end for the two CPU oracles (TEST INFRASTRUCTURE ONLY — see oracle/README.md).
+
+    Oracle("ref")   -> oracle/_ref/libreforacle.so : the reference's own mtracklib, compiled in place
+    Oracle("port")  -> oracle/libedgeport.so       : our plain C++ restatement (oracle/port/)
+
+Both export the ABI in oracle/oracle_abi.h.  Only tests/, __graft_entry__.smoke() and bench.py's
+cpu_baseline leg may import this module; the product (rebvo_amd/) never does.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+
+KEYLINE_DTYPE = np.dtype(
+    [
+        ("p_inx", "<i4"),
+        ("m_m", "<f4", (2,)),
+        ("u_m", "<f4", (2,)),
+        ("n_m", "<f4"),
+        ("score", "<f4"),
+        ("c_p", "<f4", (2,)),
+        ("_pad0", "<i4"),
+        ("rho", "<f8"),
+        ("s_rho", "<f8"),
+        ("rho_nr", "<f8"),
+        ("s_rho_nr", "<f8"),
+        ("rho0", "<f8"),
+        ("s_rho0", "<f8"),
+        ("p_m", "<f4", (2,)),
+        ("p_m_0", "<f4", (2,)),
+        ("m_id", "<i4"),
+        ("m_id_f", "<i4"),
+        ("m_id_kf", "<i4"),
+        ("m_num", "<i4"),
+        ("m_m0", "<f4", (2,)),
+        ("n_m0", "<f8"),
+        ("p_id", "<i4"),
+        ("n_id", "<i4"),
+        ("net_id", "<i4"),
+        ("stereo_m_id", "<i4"),
+        ("stereo_rho", "<f8"),
+        ("stereo_s_rho", "<f8"),
+    ]
+)
+assert KEYLINE_DTYPE.itemsize == 168
+
+
+class Params(C.Structure):
+    """Mirror of OrcParams (oracle_abi.h).  Defaults = app/rebvorun/GlobalConfig_EuRoC + TrackPoints."""
+
+    _fields_ = [
+        ("w", C.c_int32), ("h", C.c_int32),
+        ("ppx", C.c_double), ("ppy", C.c_double), ("zfx", C.c_double), ("zfy", C.c_double),
+        ("kc", C.c_double * 5),
+        ("sigma0", C.c_double), ("ksigma", C.c_double),
+        ("plane_fit_size", C.c_int32),
+        ("pos_neg_thresh", C.c_double), ("dog_thresh", C.c_double),
+        ("max_points", C.c_int32), ("reference_points", C.c_int32), ("track_points", C.c_int32),
+        ("detector_thresh", C.c_double), ("auto_gain", C.c_double),
+        ("max_thresh", C.c_double), ("min_thresh", C.c_double),
+        ("search_range", C.c_int32), ("qcut_nbins", C.c_int32),
+        ("qcut_quantile", C.c_double),
+        ("tracker_iter_num", C.c_int32), ("tracker_init_type", C.c_int32),
+        ("tracker_init_iter_num", C.c_int32),
+        ("tracker_match_thresh", C.c_double), ("match_thresh_module", C.c_double),
+        ("match_thresh_angle", C.c_double),
+        ("match_num_thresh", C.c_uint32), ("do_rescaling", C.c_int32),
+        ("reweight_distance", C.c_double), ("regularize_thresh", C.c_double),
+        ("loc_unc_match", C.c_double), ("reshape_q_abs", C.c_double),
+        ("reshape_q_rel", C.c_double), ("loc_unc", C.c_double),
+        ("global_match_threshold", C.c_int32), ("pad0", C.c_int32),
+        ("config_fps", C.c_double),
+    ]
+
+
+def euroc_params(w=752, h=480, **over):
+    """GlobalConfig_EuRoC values (reference app/rebvorun/GlobalConfig_EuRoC:9-52, 61-72), ImuMode=0."""
+    p = Params()
+    p.w, p.h = w, h
+    # principal point / focal scaled with the image when a reduced test size is used
+    sx, sy = w / 752.0, h / 480.0
+    p.ppx, p.ppy, p.zfx, p.zfy = 367.215 * sx, 248.375 * sy, 458.654 * sx, 457.296 * sy
+    p.kc[:] = [-0.28340811, 0.07395907, 0.0, 0.00019359, 1.76187114e-05]
+    p.sigma0, p.ksigma = 1.7818, 1.2599
+    p.plane_fit_size = 2
+    p.pos_neg_thresh, p.dog_thresh = 0.4, 0.095259868922420
+    p.max_points, p.reference_points, p.track_points = 16000, 12000, 12000
+    p.detector_thresh, p.auto_gain, p.max_thresh, p.min_thresh = 0.01, 5e-7, 0.5, 0.005
+    p.search_range, p.qcut_nbins, p.qcut_quantile = 40, 100, 0.9
+    p.tracker_iter_num, p.tracker_init_type, p.tracker_init_iter_num = 5, 2, 2
+    p.tracker_match_thresh, p.match_thresh_module, p.match_thresh_angle = 0.5, 1.0, 45.0
+    p.match_num_thresh, p.do_rescaling = 0, 0
+    p.reweight_distance, p.regularize_thresh = 2.0, 0.5
+    p.loc_unc_match, p.reshape_q_abs, p.reshape_q_rel, p.loc_unc = 2.0, 1e-4, 1.6968e-04, 1.0
+    p.global_match_threshold = 500
+    p.config_fps = 20.0
+    for k, v in over.items():
+        setattr(p, k, v)
+    return p
+
+
+class Nav(C.Structure):
+    _fields_ = [
+        ("t", C.c_double), ("dt", C.c_double),
+        ("V", C.c_double * 3), ("W", C.c_double * 3),
+        ("P_V", C.c_double * 9), ("P_W", C.c_double * 9),
+        ("Rot", C.c_double * 9), ("RotLie", C.c_double * 3), ("Vel", C.c_double * 3),
+        ("Pose", C.c_double * 9), ("PoseLie", C.c_double * 3), ("Pos", C.c_double * 3),
+        ("Kp", C.c_double), ("RKp", C.c_double), ("s_rho_q", C.c_double),
+        ("tresh", C.c_double),
+        ("score", C.c_double), ("rel_error", C.c_double), ("rel_error_score", C.c_double),
+        ("dtp0", C.c_double), ("dtp1", C.c_double),
+        ("retuned_thresh", C.c_float),
+        ("kn", C.c_int32), ("klm_fwd", C.c_int32), ("klm_num", C.c_int32), ("kf_matchs", C.c_int32),
+        ("estimation_ok", C.c_int32), ("frame", C.c_int32), ("pad0", C.c_int32),
+    ]
+
+    def as_dict(self):
+        out = {}
+        for name, typ in self._fields_:
+            v = getattr(self, name)
+            out[name] = np.array(v[:]) if hasattr(v, "__len__") else v
+        return out
+
+
+_LIBS = {"ref": os.path.join(HERE, "_ref", "libreforacle.so"), "port": os.path.join(HERE, "libedgeport.so")}
+
+
+def available(kind):
+    return os.path.exists(_LIBS[kind])
+
+
+def _dp(a):
+    return a.ctypes.data_as(C.POINTER(C.c_double))
+
+
+class Oracle:
+    """One oracle context = one image sequence with the reference's 8-slot PipeBuffer ring."""
+
+    def __init__(self, kind, params, nslots=8):
+        if not available(kind):
+            raise FileNotFoundError(f"{_LIBS[kind]} missing: run `make -C oracle`")
+        self.kind, self.p = kind, params
+        self.lib = C.CDLL(_LIBS[kind], mode=C.RTLD_GLOBAL)
+        self.w, self.h = params.w, params.h
+        L, P = self.lib, kind
+        vp, i, d, u = C.c_void_p, C.c_int, C.c_double, C.c_uint
+        pd, pi = C.POINTER(C.c_double), C.POINTER(C.c_int)
+
+        def fn(name, res, *args):
+            f = getattr(L, f"{P}_{name}")
+            f.restype, f.argtypes = res, list(args)
+            return f
+
+        self._create = fn("create", vp, C.POINTER(Params), i)
+        self._destroy = fn("destroy", None, vp)
+        self._stage_a = fn("stage_a", i, vp, i, C.c_void_p, pd, pi)
+        self._plane = fn("plane", C.POINTER(C.c_float), vp, i, i)
+        self._mask = fn("mask", C.POINTER(C.c_int32), vp, i)
+        self._kn = fn("kn", i, vp, i)
+        self._keylines = fn("keylines", C.c_void_p, vp, i)
+        self._retuned = fn("retuned", C.c_float, vp, i)
+        self._set_keylines = fn("set_keylines", None, vp, i, C.c_void_p, i, C.c_void_p, C.c_float)
+        self._get_fc = fn("get_framecount", u, vp, i)
+        self._set_fc = fn("set_framecount", None, vp, i, u)
+        self._quantile = fn("quantile", d, vp, i, d, d, d, i)
+        self._build_field = fn("build_field", None, vp, i, i, C.c_float)
+        self._field = fn("field", C.POINTER(C.c_int32), vp, i)
+        self._try_velrot = fn("try_velrot", d, vp, i, i, pd, i, i, d, d, u, d, pd, pd, pd, pd)
+        self._minimizer_rv = fn("minimizer_rv", d, vp, i, i, pd, pd, pd, pd, d, i, i, d, pd, pd, d, u, d, pd)
+        self._forward_match = fn("forward_match", i, vp, i, i)
+        self._rotate = fn("rotate_keylines", None, vp, i, pd)
+        self._directed = fn("directed_matching", i, vp, i, i, pd, pd, pd, pi, d, d, d, d)
+        self._regularize = fn("regularize", i, vp, i, d)
+        self._ekf = fn("ekf", None, vp, i, pd, pd, pd, d, d, d)
+        self._rescale = fn("rescale", d, vp, i, pd, d, u, i)
+        self._process = fn("process_frame", i, vp, C.c_void_p, d, C.POINTER(Nav))
+        self._cur_slot = fn("cur_slot", i, vp)
+        self._reset = fn("reset_sequence", None, vp)
+        self.ctx = self._create(C.byref(params), nslots)
+
+    def close(self):
+        if self.ctx:
+            self._destroy(self.ctx)
+            self.ctx = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # ---- stage A -------------------------------------------------------------------------------
+    def stage_a(self, slot, rgb, tresh, l_kl_num):
+        rgb = np.ascontiguousarray(rgb, dtype=np.uint8)
+        assert rgb.shape == (self.h, self.w, 3)
+        t, l = C.c_double(tresh), C.c_int(l_kl_num)
+        kn = self._stage_a(self.ctx, slot, rgb.ctypes.data, C.byref(t), C.byref(l))
+        return kn, t.value, l.value
+
+    def plane(self, slot, which):
+        idx = {"img0": 0, "img1": 1, "dog": 2, "dx": 3, "dy": 4, "bw": 5}[which]
+        p = self._plane(self.ctx, slot, idx)
+        return np.ctypeslib.as_array(p, shape=(self.h, self.w)).copy()
+
+    def mask(self, slot):
+        return np.ctypeslib.as_array(self._mask(self.ctx, slot), shape=(self.h, self.w)).copy()
+
+    def kn(self, slot):
+        return self._kn(self.ctx, slot)
+
+    def keylines(self, slot):
+        kn = self.kn(slot)
+        buf = (C.c_char * (168 * kn)).from_address(self._keylines(self.ctx, slot)) if kn else b""
+        return np.frombuffer(buf, dtype=KEYLINE_DTYPE, count=kn).copy()
+
+    def retuned(self, slot):
+        return self._retuned(self.ctx, slot)
+
+    def set_keylines(self, slot, kl, mask=None, retuned=0.0):
+        kl = np.ascontiguousarray(kl, dtype=KEYLINE_DTYPE)
+        m = None if mask is None else np.ascontiguousarray(mask, dtype=np.int32)
+        self._set_keylines(self.ctx, slot, kl.ctypes.data, len(kl), None if m is None else m.ctypes.data, retuned)
+
+    def get_framecount(self, slot):
+        return self._get_fc(self.ctx, slot)
+
+    def set_framecount(self, slot, fc):
+        self._set_fc(self.ctx, slot, fc)
+
+    # ---- stage B -------------------------------------------------------------------------------
+    def quantile(self, slot, smin=1e-3, smax=20.0, pct=0.9, n=100):
+        return self._quantile(self.ctx, slot, smin, smax, pct, n)
+
+    def build_field(self, slot, radius, min_mod):
+        self._build_field(self.ctx, slot, radius, min_mod)
+
+    def field(self, slot):
+        return np.ctypeslib.as_array(self._field(self.ctx, slot), shape=(self.h, self.w, 2)).copy()
+
+    def try_velrot(self, slot_new, slot_old, X, reweight, procjf, match_thresh, s_rho_min, match_num_thresh,
+                   k_huber, resid_in=None, resid_out=None):
+        kn = self.kn(slot_old)
+        X = np.ascontiguousarray(X, dtype=np.float64)
+        rin = np.zeros(kn) if resid_in is None else np.ascontiguousarray(resid_in, dtype=np.float64)
+        rout = np.zeros(kn) if resid_out is None else np.array(resid_out, dtype=np.float64)
+        JtJ, JtF = np.zeros((6, 6)), np.zeros(6)
+        F = self._try_velrot(self.ctx, slot_new, slot_old, _dp(X), int(reweight), int(procjf), match_thresh,
+                             s_rho_min, match_num_thresh, k_huber, _dp(rin), _dp(rout), _dp(JtJ), _dp(JtF))
+        return F, JtJ, JtF, rout
+
+    def minimizer_rv(self, slot_new, slot_old, V, W, match_thresh, iter_max, init_type, reweight_distance,
+                     max_s_rho, match_num_thresh, init_iter):
+        V, W = np.array(V, dtype=np.float64), np.array(W, dtype=np.float64)
+        RV, RW, WX = np.eye(3) * 1e50, np.eye(3) * 1e50, np.zeros((6, 6))
+        re, res = C.c_double(0), C.c_double(0)
+        F = self._minimizer_rv(self.ctx, slot_new, slot_old, _dp(V), _dp(W), _dp(RV), _dp(RW), match_thresh,
+                               iter_max, init_type, reweight_distance, C.byref(re), C.byref(res), max_s_rho,
+                               match_num_thresh, float(init_iter), _dp(WX))
+        return dict(F=F, V=V, W=W, RVel=RV, RW0=RW, W_X=WX, rel_error=re.value, rel_error_score=res.value)
+
+    # ---- stage C -------------------------------------------------------------------------------
+    def forward_match(self, slot_old, slot_new):
+        return self._forward_match(self.ctx, slot_old, slot_new)
+
+    def rotate_keylines(self, slot, R):
+        R = np.ascontiguousarray(R, dtype=np.float64)
+        self._rotate(self.ctx, slot, _dp(R))
+
+    def directed_matching(self, slot_new, slot_old, V, RVel, BackRot, min_thr_mod, min_thr_ang, max_radius, loc_unc):
+        V, RVel, BackRot = (np.ascontiguousarray(a, dtype=np.float64) for a in (V, RVel, BackRot))
+        kf = C.c_int(0)
+        n = self._directed(self.ctx, slot_new, slot_old, _dp(V), _dp(RVel), _dp(BackRot), C.byref(kf),
+                           min_thr_mod, min_thr_ang, max_radius, loc_unc)
+        return n, kf.value
+
+    def regularize(self, slot, thresh):
+        return self._regularize(self.ctx, slot, thresh)
+
+    def ekf(self, slot, V, RVel, RW0, q_abs, q_rel, loc_unc):
+        V, RVel, RW0 = (np.ascontiguousarray(a, dtype=np.float64) for a in (V, RVel, RW0))
+        self._ekf(self.ctx, slot, _dp(V), _dp(RVel), _dp(RW0), q_abs, q_rel, loc_unc)
+
+    def rescale(self, slot, s_rho_min=20.0, match_num_min=1, re_escale=False):
+        rkp = C.c_double(0)
+        kp = self._rescale(self.ctx, slot, C.byref(rkp), s_rho_min, match_num_min, int(re_escale))
+        return kp, rkp.value
+
+    # ---- whole frame -----------------------------------------------------------------------------
+    def process_frame(self, rgb, t):
+        rgb = np.ascontiguousarray(rgb, dtype=np.uint8)
+        assert rgb.shape == (self.h, self.w, 3)
+        nav = Nav()
+        ran = self._process(self.ctx, rgb.ctypes.data, float(t), C.byref(nav))
+        return ran, nav
+
+    def cur_slot(self):
+        return self._cur_slot(self.ctx)
+
+    def reset_sequence(self):
+        self._reset(self.ctx)

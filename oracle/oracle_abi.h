@@ -1,0 +1,125 @@
+/* oracle_abi.h — C ABI shared by the two CPU oracles (TEST INFRASTRUCTURE ONLY).
+ *
+ *   ref_*  : oracle/_ref/libreforacle.so — the reference's own mtracklib classes, compiled in place from
+ *            /root/reference and driven by oracle/ref_harness.cpp.
+ *   port_* : oracle/libedgeport.so — our plain C++ restatement of the same algorithm (oracle/port/).
+ *
+ * Both export the same entry points with the prefix swapped, so tests can run either behind one Python
+ * wrapper (oracle/oracle.py).  Nothing under rebvo_amd/ may include, link or load anything from oracle/.
+ */
+#ifndef ORACLE_ABI_H
+#define ORACLE_ABI_H
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* Byte-for-byte mirror of rebvo::KeyLine (reference include/mtracklib/edge_finder.h:45-91), 168 B. */
+typedef struct OrcKeyLine {
+    int32_t p_inx;
+    float m_m[2];
+    float u_m[2];
+    float n_m;
+    float score;
+    float c_p[2];
+    double rho, s_rho, rho_nr, s_rho_nr, rho0, s_rho0;
+    float p_m[2];
+    float p_m_0[2];
+    int32_t m_id, m_id_f, m_id_kf, m_num;
+    float m_m0[2];
+    double n_m0;
+    int32_t p_id, n_id, net_id;
+    int32_t stereo_m_id;
+    double stereo_rho, stereo_s_rho;
+} OrcKeyLine;
+
+/* Subset of rebvo::REBVOParameters (reference include/rebvo/rebvo.h:64-235) that reaches the hot path. */
+typedef struct OrcParams {
+    int32_t w, h;
+    double ppx, ppy, zfx, zfy;
+    double kc[5];
+    double sigma0, ksigma;
+    int32_t plane_fit_size;
+    double pos_neg_thresh, dog_thresh;
+    int32_t max_points, reference_points, track_points;
+    double detector_thresh, auto_gain, max_thresh, min_thresh;
+    int32_t search_range, qcut_nbins;
+    double qcut_quantile;
+    int32_t tracker_iter_num, tracker_init_type, tracker_init_iter_num;
+    double tracker_match_thresh, match_thresh_module, match_thresh_angle;
+    uint32_t match_num_thresh;
+    int32_t do_rescaling;
+    double reweight_distance, regularize_thresh;
+    double loc_unc_match, reshape_q_abs, reshape_q_rel, loc_unc;
+    int32_t global_match_threshold;
+    int32_t pad0;
+    double config_fps;
+} OrcParams;
+
+/* Per-frame record: what SecondThread leaves in PipeBuffer/NavData (rebvo_second_t.cpp:550-606). */
+typedef struct OrcNav {
+    double t, dt;
+    double V[3], W[3];          /* tracker output of this frame (state carried to the next) */
+    double P_V[9], P_W[9];      /* RVel, RW0 as returned by Minimizer_RV (before the /dt^2) */
+    double Rot[9], RotLie[3], Vel[3], Pose[9], PoseLie[3], Pos[3];
+    double Kp, RKp, s_rho_q;
+    double tresh;               /* detector threshold after UpdateThresh */
+    double score, rel_error, rel_error_score;
+    double dtp0, dtp1;          /* CPU seconds spent in stage A / stage B+C */
+    float retuned_thresh;
+    int32_t kn, klm_fwd, klm_num, kf_matchs, estimation_ok, frame;
+    int32_t pad0;
+} OrcNav;
+
+#define ORC_DECLARE(P)                                                                                   \
+    void *P##_create(const OrcParams *p, int nslots);                                                    \
+    void P##_destroy(void *ctx);                                                                         \
+    /* stage A: ConvertRGB2BW + sspace::build + edge_finder::detect + reEstimateThresh */               \
+    int P##_stage_a(void *ctx, int slot, const uint8_t *rgb24, double *tresh_io, int *l_kl_num_io);      \
+    const float *P##_plane(void *ctx, int slot, int which); /* 0 img0 1 img1 2 dog 3 dx 4 dy 5 bw */    \
+    const int32_t *P##_mask(void *ctx, int slot);                                                        \
+    int P##_kn(void *ctx, int slot);                                                                     \
+    OrcKeyLine *P##_keylines(void *ctx, int slot);                                                       \
+    float P##_retuned(void *ctx, int slot);                                                              \
+    void P##_set_keylines(void *ctx, int slot, const OrcKeyLine *kl, int kn, const int32_t *mask,        \
+                          float retuned);                                                                \
+    unsigned P##_get_framecount(void *ctx, int slot);                                                    \
+    void P##_set_framecount(void *ctx, int slot, unsigned fc);                                           \
+    /* stage B */                                                                                        \
+    double P##_quantile(void *ctx, int slot, double smin, double smax, double pct, int n);               \
+    void P##_build_field(void *ctx, int slot, int radius, float min_mod);                                \
+    const int32_t *P##_field(void *ctx, int slot); /* {dist, ikl} per pixel */                           \
+    double P##_try_velrot(void *ctx, int slot_new, int slot_old, const double X[6], int reweight,        \
+                          int procjf, double match_thresh, double s_rho_min, unsigned match_num_thresh,  \
+                          double k_huber, const double *resid_in, double *resid_out, double JtJ[36],     \
+                          double JtF[6]);                                                                \
+    double P##_minimizer_rv(void *ctx, int slot_new, int slot_old, double V[3], double W[3],             \
+                            double RVel[9], double RW0[9], double match_thresh, int iter_max,            \
+                            int init_type, double reweight_distance, double *rel_error,                  \
+                            double *rel_error_score, double max_s_rho, unsigned match_num_thresh,        \
+                            double init_iter, double W_X[36]);                                           \
+    /* stage C */                                                                                        \
+    int P##_forward_match(void *ctx, int slot_old, int slot_new);                                        \
+    void P##_rotate_keylines(void *ctx, int slot, const double R[9]);                                    \
+    int P##_directed_matching(void *ctx, int slot_new, int slot_old, const double V[3],                  \
+                              const double RVel[9], const double BackRot[9], int *kf_matchs,             \
+                              double min_thr_mod, double min_thr_ang, double max_radius,                 \
+                              double loc_unc);                                                           \
+    int P##_regularize(void *ctx, int slot, double thresh);                                              \
+    void P##_ekf(void *ctx, int slot, const double V[3], const double RVel[9], const double RW0[9],      \
+                 double q_abs, double q_rel, double loc_unc);                                            \
+    double P##_rescale(void *ctx, int slot, double *RKp, double s_rho_min, unsigned match_num_min,       \
+                       int re_escale);                                                                   \
+    /* whole frame, non-IMU branch of FirstThr + SecondThread; state lives in ctx */                     \
+    int P##_process_frame(void *ctx, const uint8_t *rgb24, double t, OrcNav *nav);                       \
+    int P##_cur_slot(void *ctx);                                                                         \
+    void P##_reset_sequence(void *ctx);
+
+ORC_DECLARE(ref)
+ORC_DECLARE(port)
+
+#ifdef __cplusplus
+}
+#endif
+#endif

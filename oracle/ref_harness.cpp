@@ -1,0 +1,388 @@
+// ref_harness.cpp — C-ABI driver over the REFERENCE's own mtracklib classes.
+//
+// TEST INFRASTRUCTURE ONLY.  This file is ours; every algorithmic line it executes lives in
+// /root/reference (compiled in place by oracle/Makefile, never copied).  It exists so that the parity
+// tests can ask "what does the reference compute for this input?" stage by stage, and so that bench.py
+// can time the reference CPU path (`cpu_baseline.kind = "reference"`).
+//
+// The per-frame sequencing in ref_process_frame() restates, single-threaded, what the reference does in
+//   REBVO::FirstThr      src/rebvo/rebvo_first_t.cpp:259-272   (stage A)
+//   REBVO::SecondThread  src/rebvo/rebvo_second_t.cpp:128-629  (stage B/C, ImuMode==0 branch)
+// including the 8-slot PipeBuffer ring (one sspace/edge_tracker/global_tracker per slot,
+// src/rebvo/rebvo.cpp:297-312) because global_tracker::FrameCount is per slot.
+
+#include <cstring>
+#include <cmath>
+#include <chrono>
+#include <vector>
+
+#include "mtracklib/sspace.h"
+#include "mtracklib/edge_finder.h"
+#include "mtracklib/edge_tracker.h"
+#include "mtracklib/global_tracker.h"
+// TryVelRot<> is only defined in the .cpp; include it so the harness can instantiate it directly.
+#include "src/mtracklib/global_tracker.cpp"
+
+#include <TooN/so3.h>
+#include "oracle_abi.h"
+
+using namespace rebvo;
+using namespace TooN;
+
+static_assert(sizeof(OrcKeyLine) == sizeof(KeyLine), "OrcKeyLine must mirror rebvo::KeyLine");
+static_assert(offsetof(OrcKeyLine, rho) == offsetof(KeyLine, rho), "layout");
+static_assert(offsetof(OrcKeyLine, p_m) == offsetof(KeyLine, p_m), "layout");
+static_assert(offsetof(OrcKeyLine, m_id) == offsetof(KeyLine, m_id), "layout");
+static_assert(offsetof(OrcKeyLine, n_m0) == offsetof(KeyLine, n_m0), "layout");
+static_assert(offsetof(OrcKeyLine, p_id) == offsetof(KeyLine, p_id), "layout");
+static_assert(offsetof(OrcKeyLine, stereo_rho) == offsetof(KeyLine, stereo_rho), "layout");
+static_assert(sizeof(gt_field_data) == 8, "field layout");
+
+#ifdef REF_HARNESS_DGESVD_SHIM
+// Fallback when no LAPACK is installed: one-sided Jacobi SVD with the dgesvd_ signature TooN calls.
+extern "C" void dgesvd_(const char *jobu, const char *jobvt, int *m, int *n, double *a, int *lda, double *s,
+                        double *u, int *ldu, double *vt, int *ldvt, double *work, int *lwork, int *info);
+#include "dgesvd_shim.inc"
+#endif
+
+namespace {
+
+struct Slot {
+    sspace *ss;
+    edge_tracker *ef;
+    global_tracker *gt;
+    Image<float> *img;
+    Image<RGB24Pixel> *imgc;
+};
+
+struct Ctx {
+    OrcParams p;
+    cam_model cam;
+    std::vector<Slot> slots;
+    // FirstThr state
+    double tresh;
+    int l_kl_num;
+    // SecondThread state
+    int frame;
+    double t_prev;
+    double Kp, K, P_Kp;
+    Vector<3> V, W, Pos;
+    Matrix<3, 3> Pose;
+    std::vector<float> bw;
+};
+
+void reset_seq(Ctx *c) {
+    c->tresh = c->p.detector_thresh;
+    c->l_kl_num = 0;
+    c->frame = 0;
+    c->t_prev = 0;
+    c->Kp = 1;
+    c->K = 1;
+    c->P_Kp = 5e-6;
+    c->V = Zeros;
+    c->W = Zeros;
+    c->Pos = Zeros;
+    c->Pose = Identity;
+    for (Slot &s : c->slots) s.gt->FrameCount = 0;
+}
+
+inline Matrix<3, 3> m3(const double *r) {
+    Matrix<3, 3> M;
+    for (int i = 0; i < 3; i++)
+        for (int j = 0; j < 3; j++) M(i, j) = r[i * 3 + j];
+    return M;
+}
+inline void put3(double *r, const Matrix<3, 3> &M) {
+    for (int i = 0; i < 3; i++)
+        for (int j = 0; j < 3; j++) r[i * 3 + j] = M(i, j);
+}
+inline Vector<3> v3(const double *v) { return makeVector(v[0], v[1], v[2]); }
+inline void putv(double *r, const Vector<3> &v) {
+    for (int i = 0; i < 3; i++) r[i] = v[i];
+}
+inline double now() {
+    return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count();
+}
+
+}  // namespace
+
+extern "C" {
+
+void *ref_create(const OrcParams *p, int nslots) {
+    Ctx *c = new Ctx;
+    c->p = *p;
+    cam_model::rad_tan_distortion kc = {p->kc[0], p->kc[1], p->kc[2], p->kc[3], p->kc[4]};
+    // REBVOParameters keeps pp/zf as float (rebvo.h:108-111); cam_model as in rebvo.cpp:231
+    Size2D sz = {(u_int)p->w, (u_int)p->h};
+    c->cam = cam_model({(float)p->ppx, (float)p->ppy}, {(float)p->zfx, (float)p->zfy}, kc, sz);
+    c->slots.resize(nslots);
+    for (Slot &s : c->slots) {  // rebvo.cpp:297-312
+        s.ss = new sspace(p->sigma0, p->ksigma, c->cam.sz, 3);
+        s.ef = new edge_tracker(c->cam, 255 * 3);
+        s.gt = new global_tracker(s.ef->GetCam());
+        s.img = new Image<float>(c->cam.sz);
+        s.imgc = new Image<RGB24Pixel>(c->cam.sz);
+        // the reference leaves these heap planes uninitialised; zero them so dumps are deterministic
+        memset(s.ss->ImgDx().Data(), 0, sizeof(float) * p->w * p->h);
+        memset(s.ss->ImgDy().Data(), 0, sizeof(float) * p->w * p->h);
+        memset(s.gt->field.Data(), 0, sizeof(gt_field_data) * p->w * p->h);
+    }
+    reset_seq(c);
+    return c;
+}
+
+void ref_destroy(void *ctx) {
+    Ctx *c = (Ctx *)ctx;
+    for (Slot &s : c->slots) {
+        delete s.gt;
+        delete s.ef;
+        delete s.ss;
+        delete s.img;
+        delete s.imgc;
+    }
+    delete c;
+}
+
+void ref_reset_sequence(void *ctx) { reset_seq((Ctx *)ctx); }
+int ref_cur_slot(void *ctx) {
+    Ctx *c = (Ctx *)ctx;
+    return (c->frame + (int)c->slots.size() - 1) % (int)c->slots.size();
+}
+
+int ref_stage_a(void *ctx, int slot, const uint8_t *rgb24, double *tresh_io, int *l_kl_num_io) {
+    Ctx *c = (Ctx *)ctx;
+    Slot &s = c->slots[slot];
+    const OrcParams &p = c->p;
+    memcpy(s.imgc->Data(), rgb24, (size_t)p.w * p.h * 3);         // rebvo_first_t.cpp:250
+    Image<float>::ConvertRGB2BW(*s.img, *s.imgc);                  // :259
+    s.ss->build(*s.img);                                           // :263
+    s.ef->detect(s.ss, p.plane_fit_size, p.pos_neg_thresh, p.dog_thresh, p.max_points, *tresh_io,
+                 *l_kl_num_io, p.reference_points, p.auto_gain, p.max_thresh, p.min_thresh);  // :266
+    s.ef->reEstimateThresh(p.track_points, p.qcut_nbins);          // :272
+    return s.ef->KNum();
+}
+
+const float *ref_plane(void *ctx, int slot, int which) {
+    Slot &s = ((Ctx *)ctx)->slots[slot];
+    switch (which) {
+        case 0: return s.ss->Img(0).Data();
+        case 1: return s.ss->Img(1).Data();
+        case 2: return s.ss->ImgDOG().Data();
+        case 3: return s.ss->ImgDx().Data();
+        case 4: return s.ss->ImgDy().Data();
+        default: return s.img->Data();
+    }
+}
+const int32_t *ref_mask(void *ctx, int slot) { return ((Ctx *)ctx)->slots[slot].ef->img_mask_kl.Data(); }
+int ref_kn(void *ctx, int slot) { return ((Ctx *)ctx)->slots[slot].ef->KNum(); }
+OrcKeyLine *ref_keylines(void *ctx, int slot) { return (OrcKeyLine *)((Ctx *)ctx)->slots[slot].ef->kl; }
+float ref_retuned(void *ctx, int slot) { return ((Ctx *)ctx)->slots[slot].ef->reTunedThresh; }
+
+void ref_set_keylines(void *ctx, int slot, const OrcKeyLine *kl, int kn, const int32_t *mask, float retuned) {
+    Ctx *c = (Ctx *)ctx;
+    edge_tracker *ef = c->slots[slot].ef;
+    memcpy(ef->kl, kl, sizeof(KeyLine) * kn);
+    ef->kn = kn;
+    if (mask) memcpy(ef->img_mask_kl.Data(), mask, sizeof(int) * c->p.w * c->p.h);
+    ef->reTunedThresh = retuned;
+}
+unsigned ref_get_framecount(void *ctx, int slot) { return ((Ctx *)ctx)->slots[slot].gt->FrameCount; }
+void ref_set_framecount(void *ctx, int slot, unsigned fc) { ((Ctx *)ctx)->slots[slot].gt->FrameCount = fc; }
+
+double ref_quantile(void *ctx, int slot, double smin, double smax, double pct, int n) {
+    return ((Ctx *)ctx)->slots[slot].ef->EstimateQuantile(smin, smax, pct, n);
+}
+void ref_build_field(void *ctx, int slot, int radius, float min_mod) {
+    Slot &s = ((Ctx *)ctx)->slots[slot];
+    s.gt->build_field(*s.ef, radius, min_mod);
+}
+const int32_t *ref_field(void *ctx, int slot) { return (const int32_t *)((Ctx *)ctx)->slots[slot].gt->field.Data(); }
+
+// One evaluation of global_tracker::TryVelRot<double,...> (global_tracker.cpp:289-543) at state X.
+double ref_try_velrot(void *ctx, int slot_new, int slot_old, const double X[6], int reweight, int procjf,
+                      double match_thresh, double s_rho_min, unsigned match_num_thresh, double k_huber,
+                      const double *resid_in, double *resid_out, double JtJo[36], double JtFo[6]) {
+    Ctx *c = (Ctx *)ctx;
+    global_tracker *gt = c->slots[slot_new].gt;
+    edge_tracker &klist = *c->slots[slot_old].ef;
+    int kn = klist.KNum();
+    int pnum = (kn + 0x3) & (~0x3);                                  // global_tracker.cpp:608
+    std::vector<double> P0Im(pnum * 3), P0m(pnum * 3), rin(pnum, 0.0), rout(pnum, 0.0);
+    KltoI3PMatrix<double>(klist, pnum, P0Im.data());                 // :615
+    Ne10::ProyI3Pto3PMatrix<double>(P0m.data(), P0Im.data(), gt->cam_mod.zfm, pnum);  // :617
+    if (resid_in) memcpy(rin.data(), resid_in, sizeof(double) * kn);
+    if (resid_out) memcpy(rout.data(), resid_out, sizeof(double) * kn);
+    Matrix<6, 6, double> JtJ = Zeros;
+    Vector<6, double> JtF = Zeros, Xv;
+    for (int i = 0; i < 6; i++) Xv[i] = X[i];
+    Vector<3> V0 = Zeros, W0 = Zeros;
+    Matrix<3, 3> P0 = Identity;
+    double F;
+    if (reweight) {
+        if (procjf)
+            F = gt->TryVelRot<double, true, true, false>(JtJ, JtF, Xv, V0, P0, W0, P0, klist, P0m.data(), pnum,
+                                                         match_thresh, s_rho_min, match_num_thresh, k_huber,
+                                                         rin.data(), rout.data());
+        else
+            F = gt->TryVelRot<double, true, false, false>(JtJ, JtF, Xv, V0, P0, W0, P0, klist, P0m.data(), pnum,
+                                                          match_thresh, s_rho_min, match_num_thresh, k_huber,
+                                                          rin.data(), rout.data());
+    } else {
+        if (procjf)
+            F = gt->TryVelRot<double, false, true, false>(JtJ, JtF, Xv, V0, P0, W0, P0, klist, P0m.data(), pnum,
+                                                          match_thresh, s_rho_min, match_num_thresh, k_huber,
+                                                          rin.data(), rout.data());
+        else
+            F = gt->TryVelRot<double, false, false, false>(JtJ, JtF, Xv, V0, P0, W0, P0, klist, P0m.data(), pnum,
+                                                           match_thresh, s_rho_min, match_num_thresh, k_huber,
+                                                           rin.data(), rout.data());
+    }
+    if (resid_out) memcpy(resid_out, rout.data(), sizeof(double) * kn);
+    for (int i = 0; i < 6; i++) {
+        JtFo[i] = JtF[i];
+        for (int j = 0; j < 6; j++) JtJo[i * 6 + j] = JtJ(i, j);
+    }
+    return F;
+}
+
+double ref_minimizer_rv(void *ctx, int slot_new, int slot_old, double V[3], double W[3], double RVel[9],
+                        double RW0[9], double match_thresh, int iter_max, int init_type,
+                        double reweight_distance, double *rel_error, double *rel_error_score, double max_s_rho,
+                        unsigned match_num_thresh, double init_iter, double W_Xo[36]) {
+    Ctx *c = (Ctx *)ctx;
+    Vector<3> Vv = v3(V), Wv = v3(W);
+    Matrix<3, 3> RV = m3(RVel), RW = m3(RW0);
+    Matrix<6, 6, double> W_X = Zeros;
+    double F = c->slots[slot_new].gt->Minimizer_RV<double>(Vv, Wv, RV, RW, *c->slots[slot_old].ef, match_thresh,
+                                                           iter_max, init_type, reweight_distance, *rel_error,
+                                                           *rel_error_score, max_s_rho, match_num_thresh,
+                                                           init_iter, W_X);
+    putv(V, Vv);
+    putv(W, Wv);
+    put3(RVel, RV);
+    put3(RW0, RW);
+    for (int i = 0; i < 6; i++)
+        for (int j = 0; j < 6; j++) W_Xo[i * 6 + j] = W_X(i, j);
+    return F;
+}
+
+int ref_forward_match(void *ctx, int slot_old, int slot_new) {
+    Ctx *c = (Ctx *)ctx;
+    return c->slots[slot_old].ef->FordwardMatch(c->slots[slot_new].ef);
+}
+void ref_rotate_keylines(void *ctx, int slot, const double R[9]) {
+    ((Ctx *)ctx)->slots[slot].ef->rotate_keylines(m3(R));
+}
+int ref_directed_matching(void *ctx, int slot_new, int slot_old, const double V[3], const double RVel[9],
+                          const double BackRot[9], int *kf_matchs, double min_thr_mod, double min_thr_ang,
+                          double max_radius, double loc_unc) {
+    Ctx *c = (Ctx *)ctx;
+    return c->slots[slot_new].ef->directed_matching(v3(V), m3(RVel), m3(BackRot), c->slots[slot_old].ef, *kf_matchs,
+                                                    min_thr_mod, min_thr_ang, max_radius, loc_unc, false);
+}
+int ref_regularize(void *ctx, int slot, double thresh) {
+    return ((Ctx *)ctx)->slots[slot].ef->Regularize_1_iter(thresh);
+}
+void ref_ekf(void *ctx, int slot, const double V[3], const double RVel[9], const double RW0[9], double q_abs,
+             double q_rel, double loc_unc) {
+    ((Ctx *)ctx)->slots[slot].ef->UpdateInverseDepthKalman(v3(V), m3(RVel), m3(RW0), q_abs, q_rel, loc_unc);
+}
+double ref_rescale(void *ctx, int slot, double *RKp, double s_rho_min, unsigned match_num_min, int re_escale) {
+    return ((Ctx *)ctx)->slots[slot].ef->EstimateReScalingOpt(*RKp, s_rho_min, match_num_min, re_escale != 0);
+}
+
+// One frame through FirstThr + SecondThread (ImuMode==0).  Returns 1 when stage B/C ran (frame>=1).
+int ref_process_frame(void *ctx, const uint8_t *rgb24, double t, OrcNav *nav) {
+    Ctx *c = (Ctx *)ctx;
+    const OrcParams &p = c->p;
+    const int ns = (int)c->slots.size();
+    const int sn = c->frame % ns, so = (c->frame + ns - 1) % ns;
+    memset(nav, 0, sizeof(*nav));
+
+    double t0 = now();
+    ref_stage_a(ctx, sn, rgb24, &c->tresh, &c->l_kl_num);
+    nav->dtp0 = now() - t0;
+    Slot &nb = c->slots[sn];
+    nav->frame = c->frame;
+    nav->t = t;
+    nav->kn = nb.ef->KNum();
+    nav->tresh = c->tresh;
+    nav->retuned_thresh = nb.ef->getThresh();
+
+    if (c->frame == 0) {  // "dummy processing of the first frame" rebvo_second_t.cpp:108-121
+        c->frame++;
+        c->t_prev = t;
+        return 0;
+    }
+    Slot &ob = c->slots[so];
+    double t1 = now();
+    bool EstimationOk = true;
+    double dt_frame = t - c->t_prev;                                 // :145
+    if (dt_frame < 0.001) dt_frame = 1 / p.config_fps;
+    int klm_num = 0, num_kf_back_m = 0;
+    Matrix<3, 3> P_V = Identity * 1e50, P_W = Identity * 1e50, R = Identity;  // :166-168
+    Vector<3> &V = c->V, &W = c->W;
+    double error_vel = 0, error_score = 0;
+
+    double s_rho_q = ob.ef->EstimateQuantile(RHO_MIN, RHO_MAX, p.qcut_quantile, p.qcut_nbins);  // :172
+    nb.gt->build_field(*nb.ef, p.search_range, nb.ef->getThresh());                            // :177
+    TooN::Matrix<6, 6, double> W_X;
+    nav->score = nb.gt->Minimizer_RV<double>(V, W, P_V, P_W, *ob.ef, p.tracker_match_thresh, p.tracker_iter_num,
+                                             p.tracker_init_type, p.reweight_distance, error_vel, error_score,
+                                             s_rho_q, p.match_num_thresh, p.tracker_init_iter_num, W_X);  // :346
+    nav->klm_fwd = ob.ef->FordwardMatch(nb.ef);                      // :354
+    SO3<> R0(W);                                                     // :360
+    R.T() = R0.get_matrix() * R.T();                                 // :361
+    ob.ef->rotate_keylines(R0.get_matrix());                         // :369
+    putv(nav->V, V);
+    putv(nav->W, W);
+    put3(nav->P_V, P_V);
+    put3(nav->P_W, P_W);
+
+    if (util::isNaN(V) || util::isNaN(W)) {                          // :387-397
+        P_V = Identity * 1e50;
+        V = Zeros;
+        c->Kp = 1;
+        c->P_Kp = 1e50;
+        EstimationOk = false;
+    } else {
+        klm_num = nb.ef->directed_matching(V, P_V, R, ob.ef, num_kf_back_m, p.match_thresh_module,
+                                           p.match_thresh_angle, p.search_range, p.loc_unc_match, false);  // :410
+        if (klm_num < p.global_match_threshold) {                    // :412-422
+            P_V = Identity * 1e50;
+            V = Zeros;
+            c->Kp = 1;
+            c->P_Kp = 10;
+            EstimationOk = false;
+        } else {
+            nb.ef->Regularize_1_iter(p.regularize_thresh);           // :453
+            nb.ef->UpdateInverseDepthKalman(V, P_V, P_W, p.reshape_q_abs, p.reshape_q_rel, p.loc_unc);  // :460
+            c->Kp = nb.ef->EstimateReScalingOpt(c->P_Kp, RHO_MAX, 1, p.do_rescaling > 0);             // :487
+        }
+    }
+    c->Pose = c->Pose * R;                                           // :550
+    c->Pos += -c->Pose * V * c->K;                                   // :551
+    nav->dtp1 = now() - t1;
+
+    nav->dt = dt_frame;
+    nav->Kp = c->Kp;
+    nav->RKp = c->P_Kp;
+    nav->s_rho_q = s_rho_q;
+    nav->rel_error = error_vel;
+    nav->rel_error_score = error_score;
+    put3(nav->Rot, R);
+    putv(nav->RotLie, SO3<>(R).ln());
+    putv(nav->Vel, -V * c->K / dt_frame);
+    put3(nav->Pose, c->Pose);
+    putv(nav->PoseLie, SO3<>(c->Pose).ln());
+    putv(nav->Pos, c->Pos);
+    nav->klm_num = klm_num;
+    nav->kf_matchs = num_kf_back_m;
+    nav->estimation_ok = EstimationOk;
+    // nav->V/W above are the tracker outputs; the state carried forward may have been reset (V=0)
+    c->frame++;
+    c->t_prev = t;
+    return 1;
+}
+
+}  // extern "C"
