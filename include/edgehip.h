@@ -1,0 +1,223 @@
+/* edgehip.h — C ABI of libedgehip.so: REBVO's per-frame edge pipeline as hand-written HIP for gfx950.
+ *
+ * This is the drop-in boundary.  Every entry point replaces one call that the reference's
+ * REBVO::FirstThr / REBVO::SecondThread make into mtracklib; the file:line each one replaces is cited at
+ * its declaration (paths relative to the reference tree).  Plain pointers and sizes only — no C++ or
+ * torch types — so the same library binds from C++ (rebvo_amd/host), ctypes (rebvo_amd/edgehip.py) or
+ * any other FFI.
+ *
+ * Model.  One context = `nseq` independent image sequences that advance in lock-step on ONE GPU (the
+ * sequence index is the batch dimension of every kernel launch), each with a ring of `nslots` frame
+ * slots — the device-side counterpart of the reference's PipeBuffer ring (src/rebvo/rebvo.cpp:297-312).
+ * All KeyLine lists, masks, auxiliary fields and the tracker/mapper state live in HBM as
+ * structure-of-arrays; the 168-byte AoS `KeyLine` is materialised only by edgehip_download_keylines()
+ * for callback consumers and parity tests.
+ *
+ * Calls enqueue work on the context's HIP stream and return immediately unless documented as
+ * synchronising.  Every function returns 0 on success or a negative edgehip_status; the message of the
+ * last failure on the calling thread is available from edgehip_last_error().  Nothing here ever falls
+ * back to a CPU implementation: if no gfx950 device is usable, edgehip_create() fails.
+ */
+#ifndef EDGEHIP_H
+#define EDGEHIP_H
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define EDGEHIP_ABI_VERSION 1
+#define EDGEHIP_KEYLINE_MAX 50000 /* KEYLINE_MAX, include/mtracklib/edge_finder.h:43 */
+
+typedef enum edgehip_status {
+    EDGEHIP_OK = 0,
+    EDGEHIP_ERR_ARG = -1,     /* bad argument (slot/sequence out of range, null pointer, size mismatch) */
+    EDGEHIP_ERR_DEVICE = -2,  /* no usable gfx950 device / HIP runtime error */
+    EDGEHIP_ERR_MEMORY = -3,  /* hipMalloc / hipHostMalloc failed */
+    EDGEHIP_ERR_STATE = -4    /* call sequence error (e.g. track before two frames were detected) */
+} edgehip_status;
+
+typedef struct edgehip_ctx edgehip_ctx;
+
+/* The REBVOParameters fields (include/rebvo/rebvo.h:64-235) that reach the hot path.  Same meaning and
+ * units as the reference's config keys (app/rebvorun/GlobalConfig_EuRoC). */
+typedef struct edgehip_params {
+    int32_t w, h;                 /* ImageWidth, ImageHeight */
+    double ppx, ppy, zfx, zfy;    /* PPx, PPy, ZfX, ZfY (stored as float like REBVOParameters does) */
+    double kc[5];                 /* KcR2 KcR4 KcR6 KcP1 KcP2 */
+    double sigma0, ksigma;        /* Sigma0, KSigma */
+    int32_t plane_fit_size;       /* DetectorPlaneFitSize (only 2 is supported: 5x5 window) */
+    double pos_neg_thresh, dog_thresh;
+    int32_t max_points, reference_points, track_points;
+    double detector_thresh, auto_gain, max_thresh, min_thresh;
+    int32_t search_range, qcut_nbins;
+    double qcut_quantile;
+    int32_t tracker_iter_num, tracker_init_type, tracker_init_iter_num;
+    double tracker_match_thresh, match_thresh_module, match_thresh_angle;
+    uint32_t match_num_thresh;
+    int32_t do_rescaling;
+    double reweight_distance, regularize_thresh;
+    double loc_unc_match, reshape_q_abs, reshape_q_rel, loc_unc;
+    int32_t global_match_threshold;
+    int32_t debug_planes;         /* !=0: also store img0/img1/dog/dx/dy planes (parity tests) */
+    double config_fps;
+} edgehip_params;
+
+/* Byte-for-byte the reference's rebvo::KeyLine (include/mtracklib/edge_finder.h:45-91), 168 B. */
+typedef struct edgehip_keyline {
+    int32_t p_inx;
+    float m_m[2], u_m[2], n_m, score, c_p[2];
+    double rho, s_rho, rho_nr, s_rho_nr, rho0, s_rho0;
+    float p_m[2], p_m_0[2];
+    int32_t m_id, m_id_f, m_id_kf, m_num;
+    float m_m0[2];
+    double n_m0;
+    int32_t p_id, n_id, net_id, stereo_m_id;
+    double stereo_rho, stereo_s_rho;
+} edgehip_keyline;
+
+/* Per-sequence tracker/mapper state: the locals of FirstThr (rebvo_first_t.cpp:92-94) and SecondThread
+ * (rebvo_second_t.cpp:54-66) that persist from frame to frame, kept in HBM so that a whole frame can be
+ * enqueued without a host round trip. */
+typedef struct edgehip_seq_state {
+    double tresh;               /* detector threshold (P-controller state) */
+    double V[3], W[3];          /* velocity / rotation estimate carried to the next frame */
+    double P_V[9], P_W[9];      /* RVel, RW0 of the last Minimizer_RV */
+    double R[9];                /* back-rotation of the last frame pair */
+    double Pose[9], Pos[3];     /* integrated pose */
+    double Kp, P_Kp, K;
+    double s_rho_q;             /* EstimateQuantile result of the last frame pair */
+    double score, rel_error, rel_error_score;
+    double t_prev, dt;
+    float retuned_thresh;       /* edge_finder::reTunedThresh of the newest slot */
+    int32_t l_kl_num;           /* KeyLines on the last edge map (P-controller input) */
+    int32_t frame;              /* frames detected so far */
+    int32_t klm_fwd, klm_num, kf_matchs;
+    int32_t estimation_ok;
+    int32_t minimizer_evals;    /* TryVelRot evaluations spent on the last frame pair */
+} edgehip_seq_state;
+
+/* What SecondThread leaves in PipeBuffer/NavData per frame (rebvo_second_t.cpp:550-606). */
+typedef struct edgehip_nav {
+    double t, dt;
+    double V[3], W[3], P_V[9], P_W[9];
+    double Rot[9], RotLie[3], Vel[3], Pose[9], PoseLie[3], Pos[3];
+    double Kp, RKp, s_rho_q, tresh, score, rel_error, rel_error_score;
+    float retuned_thresh;
+    int32_t kn, klm_fwd, klm_num, kf_matchs, estimation_ok, frame, minimizer_evals;
+} edgehip_nav;
+
+/* ---- lifetime -------------------------------------------------------------------------------------- */
+/* Replaces the per-slot `new sspace / new edge_tracker / new global_tracker` of REBVO::construct
+ * (src/rebvo/rebvo.cpp:297-312).  `device` is the HIP device ordinal. */
+int edgehip_create(const edgehip_params *params, int nseq, int nslots, int device, edgehip_ctx **out);
+int edgehip_destroy(edgehip_ctx *ctx);
+const char *edgehip_last_error(void);
+int edgehip_abi_version(void);
+/* Block the caller until everything enqueued so far has finished. */
+int edgehip_sync(edgehip_ctx *ctx);
+/* The hipStream_t the context launches on, as an opaque pointer (for event timing by the caller). */
+void *edgehip_stream(edgehip_ctx *ctx);
+/* Device box-filter widths chosen for (sigma0, ksigma), as iigauss::iigauss does
+ * (src/mtracklib/iigauss.cpp:43-81): out[0..2] filter0, out[3..5] filter1. */
+int edgehip_box_widths(edgehip_ctx *ctx, int out[6]);
+
+/* ---- frame input ----------------------------------------------------------------------------------- */
+/* Copy RGB24 frames (host memory, [count][h][w][3]) into slot `slot` of sequences [seq_first,
+ * seq_first+count): the `(*pbuf.imgc) = data` of rebvo_first_t.cpp:250.  Asynchronous through a pinned
+ * staging buffer; the source may be reused when the call returns. */
+int edgehip_upload_rgb(edgehip_ctx *ctx, int slot, const uint8_t *rgb24, int seq_first, int count);
+/* Same, from device memory ([nseq][h][w][3], all sequences), device-to-device on the context stream. */
+int edgehip_upload_rgb_device(edgehip_ctx *ctx, int slot, const void *rgb24_dev);
+
+/* ---- stage A: scale space + KeyLine extraction ----------------------------------------------------- */
+/* Image<float>::ConvertRGB2BW + sspace::build + edge_finder::detect + reEstimateThresh for every
+ * sequence's slot `slot` (rebvo_first_t.cpp:259-272; sspace.cpp:52-85; edge_finder.cpp:67-405).
+ * Reads and updates seq_state.tresh / l_kl_num exactly as detect()'s UpdateThresh does. */
+int edgehip_stage_a(edgehip_ctx *ctx, int slot);
+/* Number of KeyLines per sequence in `slot` (edge_finder::KNum).  Synchronises.  kn_out[nseq]. */
+int edgehip_get_kn(edgehip_ctx *ctx, int slot, int32_t *kn_out);
+
+/* ---- stage B: tracker ------------------------------------------------------------------------------ */
+/* edge_tracker::EstimateQuantile(RHO_MIN,RHO_MAX,pct,nbins) on slot (rebvo_second_t.cpp:172;
+ * edge_tracker.cpp:1148-1186).  Result in seq_state.s_rho_q. */
+int edgehip_quantile(edgehip_ctx *ctx, int slot, double s_rho_min, double s_rho_max, double pct, int nbins);
+/* global_tracker::build_field (rebvo_second_t.cpp:177; global_tracker.cpp:61-105).  min_mod < 0 takes
+ * each sequence's retuned threshold of that slot (what the reference passes: new_buf.ef->getThresh()). */
+int edgehip_build_field(edgehip_ctx *ctx, int slot, int radius, float min_mod);
+/* One global_tracker::TryVelRot<double,ReWeight,ProcJF,false> evaluation (global_tracker.cpp:289-543) of
+ * the old slot's KeyLines against the new slot's field, at state X[nseq][6].  Residual buffers are
+ * device-resident and named by index 0..2 (Res0/Res1/Rest of Minimizer_RV, :611-612); resid_in < 0 means
+ * all-zero.  out[nseq][43] = JtJ(36, row-major, sign-fixed and symmetrised) | JtF(6) | score.
+ * Synchronises. */
+int edgehip_try_velrot(edgehip_ctx *ctx, int slot_new, int slot_old, const double *X, int reweight, int procjf,
+                       double match_thresh, const double *s_rho_min, uint32_t match_num_thresh, double k_huber,
+                       int resid_in, int resid_out, double *out);
+/* Copy a residual buffer to the host (resid[nseq][cap] with cap = max_points).  Synchronises. */
+int edgehip_download_resid(edgehip_ctx *ctx, int which, double *resid);
+/* global_tracker::Minimizer_RV<double,false> (rebvo_second_t.cpp:346; global_tracker.cpp:580-819): the
+ * whole Levenberg-Marquardt loop runs on the device (evaluate kernels + a one-wave solve kernel between
+ * them, no host round trip).  Reads seq_state.V/W/s_rho_q, writes V, W, P_V, P_W, score, rel_error*. */
+int edgehip_minimizer_rv(edgehip_ctx *ctx, int slot_new, int slot_old);
+
+/* ---- stage C: matching + mapping ------------------------------------------------------------------- */
+/* edge_tracker::FordwardMatch (rebvo_second_t.cpp:354; edge_tracker.cpp:380-436). */
+int edgehip_forward_match(edgehip_ctx *ctx, int slot_old, int slot_new);
+/* edge_tracker::rotate_keylines (rebvo_second_t.cpp:369; edge_tracker.cpp:42-76).  R == NULL rotates
+ * each sequence by exp(seq_state.W) and stores the back-rotation in seq_state.R (:360-361). */
+int edgehip_rotate_keylines(edgehip_ctx *ctx, int slot, const double *R /* [nseq][9] or NULL */);
+/* edge_tracker::directed_matching (rebvo_second_t.cpp:410; edge_tracker.cpp:302-374, 158-295) with
+ * V, P_V, R taken from seq_state; the match count lands in seq_state.klm_num / kf_matchs. */
+int edgehip_directed_matching(edgehip_ctx *ctx, int slot_new, int slot_old);
+/* Regularize_1_iter + UpdateInverseDepthKalman fused (rebvo_second_t.cpp:453, 460;
+ * edge_tracker.cpp:87-148, 695-724, 954-1055).  do_regularize/do_ekf select either half (tests). */
+int edgehip_regularize_ekf(edgehip_ctx *ctx, int slot, int do_regularize, int do_ekf);
+/* EstimateReScalingOpt (rebvo_second_t.cpp:487; edge_tracker.cpp:1104-1140) -> seq_state.Kp, P_Kp. */
+int edgehip_rescale(edgehip_ctx *ctx, int slot);
+
+/* ---- whole frame ------------------------------------------------------------------------------------ */
+/* Everything FirstThr + SecondThread (ImuMode==0) do for one new frame of every sequence, on the
+ * context's current ring slot, enqueued back to back without host synchronisation: stage A on the new
+ * slot, then (from the second frame on) quantile, build_field, Minimizer_RV, FordwardMatch, rotate,
+ * directed_matching, Regularize, EKF, rescale and the pose integration of rebvo_second_t.cpp:550-551.
+ * The frame must have been uploaded into edgehip_next_slot() first.  t[nseq] = frame time stamps. */
+int edgehip_process_frame(edgehip_ctx *ctx, const double *t);
+int edgehip_next_slot(edgehip_ctx *ctx);
+int edgehip_cur_slot(edgehip_ctx *ctx);
+/* Per-sequence record of the last processed frame.  Synchronises.  nav[nseq]. */
+int edgehip_read_nav(edgehip_ctx *ctx, edgehip_nav *nav);
+/* REBVO::Reset semantics for every sequence (rebvo_second_t.cpp:609-620) + restart of the ring. */
+int edgehip_reset(edgehip_ctx *ctx);
+
+/* ---- state / data exchange (callback consumers, parity tests) ---------------------------------------- */
+int edgehip_get_state(edgehip_ctx *ctx, int seq, edgehip_seq_state *out);       /* synchronises */
+int edgehip_set_state(edgehip_ctx *ctx, int seq, const edgehip_seq_state *in);
+int edgehip_get_framecount(edgehip_ctx *ctx, int seq, int slot, uint32_t *fc);  /* global_tracker::FrameCount */
+int edgehip_set_framecount(edgehip_ctx *ctx, int seq, int slot, uint32_t fc);
+/* AoS KeyLine list + img_mask_kl of one sequence/slot, as the output callback sees them
+ * (PipeBuffer::ef, include/rebvo/rebvo.h:312-351).  kl has room for max_points entries; mask (h*w int32)
+ * may be NULL.  Synchronises.  Returns kn through *kn_out. */
+int edgehip_download_keylines(edgehip_ctx *ctx, int seq, int slot, edgehip_keyline *kl, int32_t *mask,
+                              int32_t *kn_out);
+/* Inject a KeyLine list (+ mask) into a slot: stage-isolated parity tests. */
+int edgehip_upload_keylines(edgehip_ctx *ctx, int seq, int slot, const edgehip_keyline *kl, int32_t kn,
+                            const int32_t *mask, float retuned_thresh);
+/* Planes of the scale space (debug_planes must be set): which = 0 img0, 1 img1, 2 dog, 3 dx, 4 dy.
+ * out[h*w] float.  Synchronises. */
+int edgehip_download_plane(edgehip_ctx *ctx, int seq, int which, float *out);
+/* Auxiliary field of the tracker in the reference's {dist, ikl} form (global_tracker.h:33-36); out[h*w*2]. */
+int edgehip_download_field(edgehip_ctx *ctx, int seq, int32_t *out);
+
+/* ---- measurement ------------------------------------------------------------------------------------- */
+/* Names of the kernel groups timed by the built-in HIP-event profiler, and their accumulated device time.
+ * edgehip_profile_enable(ctx, 1) brackets every launch group with events on the context stream (adds host
+ * overhead: use for attribution, not for throughput).  ms[n], calls[n] with n = edgehip_profile_count(). */
+int edgehip_profile_enable(edgehip_ctx *ctx, int on);
+int edgehip_profile_count(void);
+const char *edgehip_profile_name(int i);
+int edgehip_profile_read(edgehip_ctx *ctx, double *ms, int64_t *calls); /* synchronises, then resets */
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* EDGEHIP_H */

@@ -1,0 +1,543 @@
+// api.hip — C-ABI entry points of libedgehip.so (include/edgehip.h): context lifetime, HBM layout,
+// frame/KeyLine/state exchange and the built-in HIP-event profiler.  Kernels live in stage_*.hip.
+
+#include <math.h>
+#include <stdio.h>
+#include <string.h>
+
+#include <algorithm>
+
+#include "ctx.h"
+
+namespace edgehip {
+
+static thread_local std::string g_err;
+void set_error(const std::string &m) { g_err = m; }
+int hip_fail(hipError_t e, const char *what, const char *file, int line) {
+    char buf[512];
+    snprintf(buf, sizeof buf, "%s:%d: %s -> %s", file, line, what, hipGetErrorString(e));
+    g_err = buf;
+    return EDGEHIP_ERR_DEVICE;
+}
+
+static const char *kProfNames[PROF_COUNT] = {
+    "A.rgb_rowscan", "A.colscan", "A.avg_rowscan", "A.detect", "A.compact", "A.join_retune",
+    "B.quantile", "B.build_field", "B.tvr_prepare", "B.try_velrot", "B.lm_step",
+    "C.forward_match", "C.rotate", "C.directed_matching", "C.regularize_ekf", "C.rescale", "C.pose"};
+
+ProfScope::ProfScope(edgehip_ctx *ctx, int pid) : c(ctx), id(pid) {
+    Profiler *p = c->prof;
+    if (!p || !p->on) return;
+    auto get = [&]() {
+        hipEvent_t e;
+        if (!p->pool.empty()) { e = p->pool.back(); p->pool.pop_back(); }
+        else (void)hipEventCreate(&e);
+        return e;
+    };
+    a = get();
+    b = get();
+    (void)hipEventRecord(a, c->stream);
+}
+ProfScope::~ProfScope() {
+    if (!a) return;
+    (void)hipEventRecord(b, c->stream);
+    c->prof->pending.push_back({a, b, id});
+}
+
+// Box widths exactly as iigauss::iigauss picks them (src/mtracklib/iigauss.cpp:51-71).
+static double kovesi_boxes(double sigma, int box_num, int *box_d) {
+    double wideal = sqrt(12 * sigma * sigma / box_num + 1);
+    int wl = (int)wideal;
+    int tmp = wl / 2;
+    if (tmp * 2 == wl) wl--;
+    int m = (int)round((3 * box_num + 4 * box_num * wl + box_num * wl * wl - 12 * sigma * sigma) / (4 + 4 * wl));
+    int i;
+    for (i = 0; i < m; i++) box_d[i] = wl;
+    for (; i < box_num; i++) box_d[i] = wl + 2;
+    return sqrt((m * wl * wl + (box_num - m) * (wl + 2.0) * (wl + 2.0) - box_num) / 12.0);
+}
+
+// Plane-fit pseudo inverse, PInv = Matrix3x3Inv(Phi^T Phi) * Phi^T (edge_finder.cpp:83-100,
+// toon_util.h:32-41), evaluated with the same operation order in double.
+static void plane_fit_pinv(int win_s, double *pinv /*[3][nn]*/) {
+    const int nn = (2 * win_s + 1) * (2 * win_s + 1);
+    std::vector<double> Phi(nn * 3);
+    for (int i = -win_s, k = 0; i <= win_s; i++)
+        for (int j = -win_s; j <= win_s; j++, k++) {
+            Phi[k * 3 + 0] = j;
+            Phi[k * 3 + 1] = i;
+            Phi[k * 3 + 2] = 1;
+        }
+    double A[3][3];
+    for (int r = 0; r < 3; r++)
+        for (int cidx = 0; cidx < 3; cidx++) {
+            double s = 0;
+            for (int k = 0; k < nn; k++) s += Phi[k * 3 + r] * Phi[k * 3 + cidx];
+            A[r][cidx] = s;
+        }
+    double Bm[3][3];
+    Bm[0][0] = A[2][2] * A[1][1] - A[2][1] * A[1][2];
+    Bm[0][1] = -(A[2][2] * A[0][1] - A[2][1] * A[0][2]);
+    Bm[0][2] = A[1][2] * A[0][1] - A[1][1] * A[0][2];
+    Bm[1][0] = -(A[2][2] * A[1][0] - A[2][0] * A[1][2]);
+    Bm[1][1] = A[2][2] * A[0][0] - A[2][0] * A[0][2];
+    Bm[1][2] = -(A[1][2] * A[0][0] - A[1][0] * A[0][2]);
+    Bm[2][0] = A[2][1] * A[1][0] - A[2][0] * A[1][1];
+    Bm[2][1] = -(A[2][1] * A[0][0] - A[2][0] * A[0][1]);
+    Bm[2][2] = A[1][1] * A[0][0] - A[1][0] * A[0][1];
+    // Phi^T Phi is diagonal for a symmetric window, so Gaussian elimination returns the plain product
+    const double det = A[0][0] * A[1][1] * A[2][2];
+    for (int r = 0; r < 3; r++)
+        for (int cidx = 0; cidx < 3; cidx++) Bm[r][cidx] = Bm[r][cidx] / det;
+    for (int r = 0; r < 3; r++)
+        for (int k = 0; k < nn; k++) {
+            double s = 0;
+            for (int j = 0; j < 3; j++) s += Bm[r][j] * Phi[k * 3 + j];
+            pinv[r * nn + k] = s;
+        }
+}
+
+template <typename T>
+static int dmalloc(edgehip_ctx *c, T **p, size_t count, std::vector<void *> &track, int fill = -2) {
+    void *q = nullptr;
+    size_t bytes = std::max<size_t>(count * sizeof(T), 256);
+    if (hipMalloc(&q, bytes) != hipSuccess) {
+        set_error("hipMalloc failed (" + std::to_string(bytes) + " bytes)");
+        return EDGEHIP_ERR_MEMORY;
+    }
+    track.push_back(q);
+    if (fill != -2) {
+        if (hipMemsetAsync(q, fill, bytes, c->stream) != hipSuccess) return EDGEHIP_ERR_DEVICE;
+    }
+    *p = (T *)q;
+    return 0;
+}
+
+struct CtxAllocs {
+    std::vector<void *> dev;
+    std::vector<void *> host;
+};
+static std::vector<std::pair<edgehip_ctx *, CtxAllocs *>> g_allocs;
+
+static void init_state(const edgehip_params &p, SeqDev *s) {
+    memset(s, 0, sizeof(*s));
+    s->pub.tresh = p.detector_thresh;       // rebvo_first_t.cpp:94
+    s->pub.Kp = 1; s->pub.K = 1; s->pub.P_Kp = 5e-6;  // rebvo_second_t.cpp:54, 65
+    for (int i = 0; i < 3; i++) {
+        s->pub.Pose[i * 4] = 1;
+        s->pub.R[i * 4] = 1;
+        s->pub.P_V[i * 4] = 1e50;
+        s->pub.P_W[i * 4] = 1e-10;
+    }
+    s->band_trunc = -1;
+}
+
+// ---- AoS <-> SoA KeyLine exchange ---------------------------------------------------------------------
+template <typename T>
+static int d2h(edgehip_ctx *c, std::vector<T> &dst, const T *src, size_t count) {
+    dst.resize(count);
+    if (count == 0) return 0;
+    EH_CHECK(hipMemcpyAsync(dst.data(), src, sizeof(T) * count, hipMemcpyDeviceToHost, c->stream));
+    return 0;
+}
+template <typename T>
+static int h2d(edgehip_ctx *c, T *dst, const std::vector<T> &src) {
+    if (src.empty()) return 0;
+    EH_CHECK(hipMemcpyAsync(dst, src.data(), sizeof(T) * src.size(), hipMemcpyHostToDevice, c->stream));
+    return 0;
+}
+
+
+}  // namespace edgehip
+
+using namespace edgehip;
+
+extern "C" {
+
+int edgehip_abi_version(void) { return EDGEHIP_ABI_VERSION; }
+const char *edgehip_last_error(void) { return g_err.c_str(); }
+
+int edgehip_create(const edgehip_params *params, int nseq, int nslots, int device, edgehip_ctx **out) {
+    if (!params || !out || nseq < 1 || nslots < 2) { set_error("edgehip_create: bad argument"); return EDGEHIP_ERR_ARG; }
+    const edgehip_params &p = *params;
+    if (p.w < 16 || p.h < 16 || (p.w % 4) != 0 || p.w > 1024) {
+        set_error("edgehip_create: image width must be a multiple of 4 in [16,1024], height >= 16");
+        return EDGEHIP_ERR_ARG;
+    }
+    if (p.plane_fit_size != 2) { set_error("edgehip_create: only DetectorPlaneFitSize=2 is supported"); return EDGEHIP_ERR_ARG; }
+    if (p.max_points < 1 || p.qcut_nbins < 1 || p.qcut_nbins > 256 || p.search_range < 1 || p.search_range > 255) {
+        set_error("edgehip_create: max_points>=1, 1<=QCutOffNumBins<=256, 1<=SearchRange<=255 required");
+        return EDGEHIP_ERR_ARG;
+    }
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= device || device < 0) {
+        set_error("edgehip_create: no usable HIP device (libedgehip has no CPU fallback)");
+        return EDGEHIP_ERR_DEVICE;
+    }
+    EH_CHECK(hipSetDevice(device));
+    edgehip_ctx *c = new edgehip_ctx();
+    CtxAllocs *al = new CtxAllocs();
+    g_allocs.push_back({c, al});
+    c->p = p;
+    c->device = device;
+    c->frame_slot = -1;
+    c->frames_seen = 0;
+    c->prof = new Profiler();
+    EH_CHECK(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
+
+    DevicePlan &pl = c->plan;
+    pl.w = p.w; pl.h = p.h; pl.n = p.w * p.h; pl.nseq = nseq; pl.nslots = nslots;
+    pl.cap = std::min(p.max_points, EDGEHIP_KEYLINE_MAX);  // build_mask clamps kl_max to kl_size
+    const double sr0 = kovesi_boxes(p.sigma0, kMaxBoxes, pl.box[0]);       // sspace.cpp:45
+    kovesi_boxes(sr0 * p.ksigma, kMaxBoxes, pl.box[1]);
+    for (int f = 0; f < 2; f++)
+        for (int i = 0; i < kMaxBoxes; i++) {
+            if (pl.box[f][i] < 1 || pl.box[f][i] * pl.box[f][i] >= kDivLutMax) {
+                set_error("edgehip_create: box width out of range for these sigmas");
+                return EDGEHIP_ERR_ARG;
+            }
+            pl.box_a[f][i] = (float)(1.0 / (pl.box[f][i] * pl.box[f][i]));
+        }
+    pl.ppx = (float)p.ppx; pl.ppy = (float)p.ppy; pl.zfx = (float)p.zfx; pl.zfy = (float)p.zfy;
+    pl.zfm = (double)((pl.zfx + pl.zfy) / 2);  // cam_model.h:57: float sum, float /2, then double
+
+    const size_t B = nseq, S = nslots, N = pl.n, CAP = pl.cap;
+    int e;
+#define EH_TRY(x) if ((e = (x)) != 0) return e
+    EH_TRY(dmalloc(c, &c->rgb, S * B * N * 3, al->dev, 0));
+    EH_TRY(dmalloc(c, &c->ii, 4 * B * N, al->dev, 0));
+    c->planes = nullptr;
+    if (p.debug_planes) EH_TRY(dmalloc(c, &c->planes, 5 * B * N, al->dev, 0));
+    EH_TRY(dmalloc(c, &c->mask, S * B * N, al->dev, 0xFF));       // img_mask_kl.Reset(-1)
+    EH_TRY(dmalloc(c, &c->field, B * N, al->dev, 0xFF));
+    EH_TRY(dmalloc(c, &c->div_lut, kDivLutMax, al->dev));
+    EH_TRY(dmalloc(c, &c->pinv, 75, al->dev));
+    EH_TRY(dmalloc(c, &c->seq, B, al->dev, 0));
+    EH_TRY(dmalloc(c, &c->framecount, S * B, al->dev, 0));
+    EH_TRY(dmalloc(c, &c->kn_slot, S * B, al->dev, 0));
+    EH_TRY(dmalloc(c, &c->retuned_slot, S * B, al->dev, 0));
+    c->nbands = (p.h - 4 + kBandRows - 1) / kBandRows;
+    {
+        const int npx = kBandRows * p.w, nchunk = (npx + 63) / 64, cpw = (nchunk + 3) / 4;
+        c->band_cap = cpw * 64;
+    }
+    const size_t nstrips = (size_t)c->nbands * 4;
+    EH_TRY(dmalloc(c, &c->band_cnt, B * nstrips, al->dev, 0));
+    EH_TRY(dmalloc(c, &c->band_off, B * (nstrips + 1), al->dev, 0));
+    {
+        char *bs;
+        EH_TRY(dmalloc(c, &bs, B * nstrips * c->band_cap * 20, al->dev));
+        c->band_stage = bs;
+    }
+    EH_TRY(dmalloc(c, &c->histo, B * 256, al->dev, 0));
+    c->nblk_tvr = (int)((CAP + kTvrBlock - 1) / kTvrBlock);
+    EH_TRY(dmalloc(c, &c->P0, B * 3 * CAP, al->dev, 0));
+    EH_TRY(dmalloc(c, &c->resid, (size_t)kResidBufs * B * CAP, al->dev, 0));
+    EH_TRY(dmalloc(c, &c->resid_carry, (size_t)kResidBufs * B * c->nblk_tvr, al->dev, 0));
+    EH_TRY(dmalloc(c, &c->partials, B * c->nblk_tvr * kNumSums, al->dev, 0));
+    EH_TRY(dmalloc(c, &c->fwd_key, B * CAP, al->dev, 0));
+    EH_TRY(dmalloc(c, &c->fwd_win, B * CAP, al->dev, 0xFF));
+    EH_TRY(dmalloc(c, &c->rs_tmp, B * 2 * CAP, al->dev, 0));
+
+    // KeyLine SoA arena
+    {
+        const size_t al256 = 256;
+        auto up = [&](size_t x) { return (x + al256 - 1) / al256 * al256; };
+        const size_t per = up(CAP * 4) * 8 /* p_inx, n_m, m_id, m_id_f, m_id_kf, m_num, p_id, n_id */ +
+                           up(CAP * 8) * 6 /* float2 */ + up(CAP * 8) * 7 /* double */ + up(CAP * 32);
+        char *arena;
+        EH_TRY(dmalloc(c, &arena, per * S * B, al->dev, 0));
+        c->kl_arena = arena;
+        c->kl.resize(S * B);
+        for (size_t sb = 0; sb < S * B; sb++) {
+            char *q = arena + sb * per;
+            KlSoA &k = c->kl[sb];
+            auto take = [&](size_t bytes) { char *r = q; q += up(bytes); return r; };
+            k.p_inx = (int32_t *)take(CAP * 4);
+            k.m_m = (float2 *)take(CAP * 8); k.u_m = (float2 *)take(CAP * 8); k.c_p = (float2 *)take(CAP * 8);
+            k.p_m = (float2 *)take(CAP * 8); k.p_m_0 = (float2 *)take(CAP * 8); k.m_m0 = (float2 *)take(CAP * 8);
+            k.n_m = (float *)take(CAP * 4);
+            k.rho = (double *)take(CAP * 8); k.s_rho = (double *)take(CAP * 8); k.rho_nr = (double *)take(CAP * 8);
+            k.s_rho_nr = (double *)take(CAP * 8); k.rho0 = (double *)take(CAP * 8); k.s_rho0 = (double *)take(CAP * 8);
+            k.n_m0 = (double *)take(CAP * 8);
+            k.m_id = (int32_t *)take(CAP * 4); k.m_id_f = (int32_t *)take(CAP * 4); k.m_id_kf = (int32_t *)take(CAP * 4);
+            k.m_num = (int32_t *)take(CAP * 4); k.p_id = (int32_t *)take(CAP * 4); k.n_id = (int32_t *)take(CAP * 4);
+            k.rec = (MatchRec *)take(CAP * 32);
+        }
+        EH_TRY(dmalloc(c, &c->kl_dev, S * B, al->dev));
+        EH_CHECK(hipMemcpyAsync(c->kl_dev, c->kl.data(), sizeof(KlSoA) * S * B, hipMemcpyHostToDevice, c->stream));
+    }
+    // constant tables
+    {
+        std::vector<float> lut(kDivLutMax, 0.f);
+        for (int k = 1; k < kDivLutMax; k++) lut[k] = (float)(1.0 / (double)(float)k);  // iimage.cpp:176-178
+        EH_CHECK(hipMemcpyAsync(c->div_lut, lut.data(), sizeof(float) * kDivLutMax, hipMemcpyHostToDevice, c->stream));
+        double pinv[75];
+        plane_fit_pinv(2, pinv);
+        EH_CHECK(hipMemcpyAsync(c->pinv, pinv, sizeof pinv, hipMemcpyHostToDevice, c->stream));
+        EH_CHECK(hipStreamSynchronize(c->stream));  // lut/pinv are stack temporaries
+    }
+    // pinned staging
+    c->pinned_rgb_bytes = B * N * 3;
+    {
+        void *q;
+        EH_CHECK(hipHostMalloc(&q, c->pinned_rgb_bytes, hipHostMallocDefault)); al->host.push_back(q); c->pinned_rgb = (uint8_t *)q;
+        EH_CHECK(hipHostMalloc(&q, sizeof(SeqDev) * B, hipHostMallocDefault)); al->host.push_back(q); c->pinned_seq = (SeqDev *)q;
+        EH_CHECK(hipHostMalloc(&q, sizeof(double) * B * 64, hipHostMallocDefault)); al->host.push_back(q); c->pinned_out = (double *)q;
+    }
+    for (size_t i = 0; i < B; i++) init_state(p, &c->pinned_seq[i]);
+    EH_CHECK(hipMemcpyAsync(c->seq, c->pinned_seq, sizeof(SeqDev) * B, hipMemcpyHostToDevice, c->stream));
+    EH_CHECK(hipStreamSynchronize(c->stream));
+#undef EH_TRY
+    *out = c;
+    return 0;
+}
+
+int edgehip_destroy(edgehip_ctx *c) {
+    if (!c) return EDGEHIP_ERR_ARG;
+    (void)hipSetDevice(c->device);
+    (void)hipStreamSynchronize(c->stream);
+    for (size_t i = 0; i < g_allocs.size(); i++) {
+        if (g_allocs[i].first != c) continue;
+        for (void *q : g_allocs[i].second->dev) (void)hipFree(q);
+        for (void *q : g_allocs[i].second->host) (void)hipHostFree(q);
+        delete g_allocs[i].second;
+        g_allocs.erase(g_allocs.begin() + i);
+        break;
+    }
+    if (c->prof) {
+        for (auto &r : c->prof->pending) { (void)hipEventDestroy(r.a); (void)hipEventDestroy(r.b); }
+        for (auto e : c->prof->pool) (void)hipEventDestroy(e);
+        delete c->prof;
+    }
+    (void)hipStreamDestroy(c->stream);
+    delete c;
+    return 0;
+}
+
+int edgehip_sync(edgehip_ctx *c) {
+    if (!c) return EDGEHIP_ERR_ARG;
+    EH_CHECK(hipStreamSynchronize(c->stream));
+    return 0;
+}
+void *edgehip_stream(edgehip_ctx *c) { return c ? (void *)c->stream : nullptr; }
+
+int edgehip_box_widths(edgehip_ctx *c, int out[6]) {
+    if (!c || !out) return EDGEHIP_ERR_ARG;
+    for (int f = 0; f < 2; f++)
+        for (int i = 0; i < 3; i++) out[f * 3 + i] = c->plan.box[f][i];
+    return 0;
+}
+
+static int check_slot(edgehip_ctx *c, int slot) {
+    if (!c || slot < 0 || slot >= c->plan.nslots) { set_error("slot out of range"); return EDGEHIP_ERR_ARG; }
+    return 0;
+}
+static int check_seq(edgehip_ctx *c, int seq) {
+    if (!c || seq < 0 || seq >= c->plan.nseq) { set_error("sequence out of range"); return EDGEHIP_ERR_ARG; }
+    return 0;
+}
+
+int edgehip_upload_rgb(edgehip_ctx *c, int slot, const uint8_t *rgb24, int seq_first, int count) {
+    if (int e = check_slot(c, slot)) return e;
+    if (!rgb24 || seq_first < 0 || count < 1 || seq_first + count > c->plan.nseq) { set_error("upload_rgb: bad range"); return EDGEHIP_ERR_ARG; }
+    const size_t fb = (size_t)c->plan.n * 3;
+    // the pinned buffer is reused: wait for the previous copy out of it
+    EH_CHECK(hipStreamSynchronize(c->stream));
+    memcpy(c->pinned_rgb + fb * seq_first, rgb24, fb * count);
+    EH_CHECK(hipMemcpyAsync(rgbof(c, slot) + fb * seq_first, c->pinned_rgb + fb * seq_first, fb * count,
+                            hipMemcpyHostToDevice, c->stream));
+    return 0;
+}
+
+int edgehip_upload_rgb_device(edgehip_ctx *c, int slot, const void *rgb24_dev) {
+    if (int e = check_slot(c, slot)) return e;
+    if (!rgb24_dev) return EDGEHIP_ERR_ARG;
+    EH_CHECK(hipMemcpyAsync(rgbof(c, slot), rgb24_dev, (size_t)c->plan.nseq * c->plan.n * 3, hipMemcpyDeviceToDevice, c->stream));
+    return 0;
+}
+
+int edgehip_stage_a(edgehip_ctx *c, int slot) {
+    if (int e = check_slot(c, slot)) return e;
+    return stage_a_enqueue(c, slot);
+}
+
+static int fetch_states(edgehip_ctx *c) {
+    EH_CHECK(hipMemcpyAsync(c->pinned_seq, c->seq, sizeof(SeqDev) * c->plan.nseq, hipMemcpyDeviceToHost, c->stream));
+    EH_CHECK(hipStreamSynchronize(c->stream));
+    return 0;
+}
+
+int edgehip_get_kn(edgehip_ctx *c, int slot, int32_t *kn_out) {
+    if (int e = check_slot(c, slot)) return e;
+    if (!kn_out) return EDGEHIP_ERR_ARG;
+    EH_CHECK(hipMemcpyAsync(c->pinned_out, c->kn_slot + (size_t)slot * c->plan.nseq, sizeof(int32_t) * c->plan.nseq,
+                            hipMemcpyDeviceToHost, c->stream));
+    EH_CHECK(hipStreamSynchronize(c->stream));
+    memcpy(kn_out, c->pinned_out, sizeof(int32_t) * c->plan.nseq);
+    return 0;
+}
+
+int edgehip_get_state(edgehip_ctx *c, int seq, edgehip_seq_state *out) {
+    if (int e = check_seq(c, seq)) return e;
+    if (!out) return EDGEHIP_ERR_ARG;
+    if (int e = fetch_states(c)) return e;
+    *out = c->pinned_seq[seq].pub;
+    return 0;
+}
+
+int edgehip_set_state(edgehip_ctx *c, int seq, const edgehip_seq_state *in) {
+    if (int e = check_seq(c, seq)) return e;
+    if (!in) return EDGEHIP_ERR_ARG;
+    if (int e = fetch_states(c)) return e;
+    c->pinned_seq[seq].pub = *in;
+    EH_CHECK(hipMemcpyAsync(c->seq + seq, c->pinned_seq + seq, sizeof(SeqDev), hipMemcpyHostToDevice, c->stream));
+    EH_CHECK(hipStreamSynchronize(c->stream));
+    return 0;
+}
+
+int edgehip_get_framecount(edgehip_ctx *c, int seq, int slot, uint32_t *fc) {
+    if (int e = check_seq(c, seq)) return e;
+    if (int e = check_slot(c, slot)) return e;
+    EH_CHECK(hipMemcpyAsync(fc, c->framecount + (size_t)slot * c->plan.nseq + seq, 4, hipMemcpyDeviceToHost, c->stream));
+    EH_CHECK(hipStreamSynchronize(c->stream));
+    return 0;
+}
+int edgehip_set_framecount(edgehip_ctx *c, int seq, int slot, uint32_t fc) {
+    if (int e = check_seq(c, seq)) return e;
+    if (int e = check_slot(c, slot)) return e;
+    EH_CHECK(hipMemcpyAsync(c->framecount + (size_t)slot * c->plan.nseq + seq, &fc, 4, hipMemcpyHostToDevice, c->stream));
+    EH_CHECK(hipStreamSynchronize(c->stream));
+    return 0;
+}
+
+int edgehip_download_keylines(edgehip_ctx *c, int seq, int slot, edgehip_keyline *kl, int32_t *mask, int32_t *kn_out) {
+    if (int e = check_seq(c, seq)) return e;
+    if (int e = check_slot(c, slot)) return e;
+    if (!kl || !kn_out) return EDGEHIP_ERR_ARG;
+    int32_t kn = 0;
+    EH_CHECK(hipMemcpyAsync(&kn, c->kn_slot + (size_t)slot * c->plan.nseq + seq, 4, hipMemcpyDeviceToHost, c->stream));
+    EH_CHECK(hipStreamSynchronize(c->stream));
+    const KlSoA &k = klof(c, slot, seq);
+    std::vector<int32_t> p_inx, m_id, m_id_f, m_id_kf, m_num, p_id, n_id;
+    std::vector<float2> m_m, u_m, c_p, p_m, p_m_0, m_m0;
+    std::vector<float> n_m;
+    std::vector<double> rho, s_rho, rho_nr, s_rho_nr, rho0, s_rho0, n_m0;
+    int e = 0;
+    e |= d2h(c, p_inx, k.p_inx, kn); e |= d2h(c, m_id, k.m_id, kn); e |= d2h(c, m_id_f, k.m_id_f, kn);
+    e |= d2h(c, m_id_kf, k.m_id_kf, kn); e |= d2h(c, m_num, k.m_num, kn); e |= d2h(c, p_id, k.p_id, kn);
+    e |= d2h(c, n_id, k.n_id, kn);
+    e |= d2h(c, m_m, k.m_m, kn); e |= d2h(c, u_m, k.u_m, kn); e |= d2h(c, c_p, k.c_p, kn);
+    e |= d2h(c, p_m, k.p_m, kn); e |= d2h(c, p_m_0, k.p_m_0, kn); e |= d2h(c, m_m0, k.m_m0, kn);
+    e |= d2h(c, n_m, k.n_m, kn);
+    e |= d2h(c, rho, k.rho, kn); e |= d2h(c, s_rho, k.s_rho, kn); e |= d2h(c, rho_nr, k.rho_nr, kn);
+    e |= d2h(c, s_rho_nr, k.s_rho_nr, kn); e |= d2h(c, rho0, k.rho0, kn); e |= d2h(c, s_rho0, k.s_rho0, kn);
+    e |= d2h(c, n_m0, k.n_m0, kn);
+    if (e) return EDGEHIP_ERR_DEVICE;
+    if (mask) EH_CHECK(hipMemcpyAsync(mask, maskof(c, slot) + (size_t)seq * c->plan.n, sizeof(int32_t) * c->plan.n, hipMemcpyDeviceToHost, c->stream));
+    EH_CHECK(hipStreamSynchronize(c->stream));
+    for (int i = 0; i < kn; i++) {
+        edgehip_keyline &o = kl[i];
+        memset(&o, 0, sizeof o);
+        o.p_inx = p_inx[i];
+        o.m_m[0] = m_m[i].x; o.m_m[1] = m_m[i].y; o.u_m[0] = u_m[i].x; o.u_m[1] = u_m[i].y;
+        o.n_m = n_m[i]; o.score = 0.f;
+        o.c_p[0] = c_p[i].x; o.c_p[1] = c_p[i].y;
+        o.rho = rho[i]; o.s_rho = s_rho[i]; o.rho_nr = rho_nr[i]; o.s_rho_nr = s_rho_nr[i];
+        o.rho0 = rho0[i]; o.s_rho0 = s_rho0[i];
+        o.p_m[0] = p_m[i].x; o.p_m[1] = p_m[i].y; o.p_m_0[0] = p_m_0[i].x; o.p_m_0[1] = p_m_0[i].y;
+        o.m_id = m_id[i]; o.m_id_f = m_id_f[i]; o.m_id_kf = m_id_kf[i]; o.m_num = m_num[i];
+        o.m_m0[0] = m_m0[i].x; o.m_m0[1] = m_m0[i].y; o.n_m0 = n_m0[i];
+        o.p_id = p_id[i]; o.n_id = n_id[i];
+        o.net_id = -1; o.stereo_m_id = -1; o.stereo_rho = 1.0; o.stereo_s_rho = 20.0;  // edge_finder.cpp:183-194
+    }
+    *kn_out = kn;
+    return 0;
+}
+
+int edgehip_upload_keylines(edgehip_ctx *c, int seq, int slot, const edgehip_keyline *kl, int32_t kn, const int32_t *mask, float retuned) {
+    if (int e = check_seq(c, seq)) return e;
+    if (int e = check_slot(c, slot)) return e;
+    if (!kl || kn < 0 || kn > c->plan.cap) { set_error("upload_keylines: kn exceeds capacity"); return EDGEHIP_ERR_ARG; }
+    const KlSoA &k = klof(c, slot, seq);
+    std::vector<int32_t> p_inx(kn), m_id(kn), m_id_f(kn), m_id_kf(kn), m_num(kn), p_id(kn), n_id(kn);
+    std::vector<float2> m_m(kn), u_m(kn), c_p(kn), p_m(kn), p_m_0(kn), m_m0(kn);
+    std::vector<float> n_m(kn);
+    std::vector<double> rho(kn), s_rho(kn), rho_nr(kn), s_rho_nr(kn), rho0(kn), s_rho0(kn), n_m0(kn);
+    std::vector<MatchRec> rec(kn);
+    for (int i = 0; i < kn; i++) {
+        const edgehip_keyline &o = kl[i];
+        p_inx[i] = o.p_inx;
+        m_m[i] = make_float2(o.m_m[0], o.m_m[1]); u_m[i] = make_float2(o.u_m[0], o.u_m[1]);
+        n_m[i] = o.n_m; c_p[i] = make_float2(o.c_p[0], o.c_p[1]);
+        rho[i] = o.rho; s_rho[i] = o.s_rho; rho_nr[i] = o.rho_nr; s_rho_nr[i] = o.s_rho_nr; rho0[i] = o.rho0; s_rho0[i] = o.s_rho0;
+        p_m[i] = make_float2(o.p_m[0], o.p_m[1]); p_m_0[i] = make_float2(o.p_m_0[0], o.p_m_0[1]);
+        m_id[i] = o.m_id; m_id_f[i] = o.m_id_f; m_id_kf[i] = o.m_id_kf; m_num[i] = o.m_num;
+        m_m0[i] = make_float2(o.m_m0[0], o.m_m0[1]); n_m0[i] = o.n_m0; p_id[i] = o.p_id; n_id[i] = o.n_id;
+        MatchRec r; r.c_px = o.c_p[0]; r.c_py = o.c_p[1]; r.u_mx = o.u_m[0]; r.u_my = o.u_m[1];
+        r.m_mx = o.m_m[0]; r.m_my = o.m_m[1]; r.n_m = o.n_m; r.pad = 0.f;
+        rec[i] = r;
+    }
+    int e = 0;
+    e |= h2d(c, k.p_inx, p_inx); e |= h2d(c, k.m_id, m_id); e |= h2d(c, k.m_id_f, m_id_f); e |= h2d(c, k.m_id_kf, m_id_kf);
+    e |= h2d(c, k.m_num, m_num); e |= h2d(c, k.p_id, p_id); e |= h2d(c, k.n_id, n_id);
+    e |= h2d(c, k.m_m, m_m); e |= h2d(c, k.u_m, u_m); e |= h2d(c, k.c_p, c_p); e |= h2d(c, k.p_m, p_m);
+    e |= h2d(c, k.p_m_0, p_m_0); e |= h2d(c, k.m_m0, m_m0); e |= h2d(c, k.n_m, n_m);
+    e |= h2d(c, k.rho, rho); e |= h2d(c, k.s_rho, s_rho); e |= h2d(c, k.rho_nr, rho_nr); e |= h2d(c, k.s_rho_nr, s_rho_nr);
+    e |= h2d(c, k.rho0, rho0); e |= h2d(c, k.s_rho0, s_rho0); e |= h2d(c, k.n_m0, n_m0); e |= h2d(c, k.rec, rec);
+    if (e) return EDGEHIP_ERR_DEVICE;
+    EH_CHECK(hipMemcpyAsync(c->kn_slot + (size_t)slot * c->plan.nseq + seq, &kn, 4, hipMemcpyHostToDevice, c->stream));
+    if (mask) EH_CHECK(hipMemcpyAsync(maskof(c, slot) + (size_t)seq * c->plan.n, mask, sizeof(int32_t) * c->plan.n, hipMemcpyHostToDevice, c->stream));
+    EH_CHECK(hipMemcpyAsync(c->retuned_slot + (size_t)slot * c->plan.nseq + seq, &retuned, 4, hipMemcpyHostToDevice, c->stream));
+    EH_CHECK(hipStreamSynchronize(c->stream));
+    return 0;
+}
+
+int edgehip_download_plane(edgehip_ctx *c, int seq, int which, float *out) {
+    if (int e = check_seq(c, seq)) return e;
+    if (!c->planes) { set_error("download_plane: context was created without debug_planes"); return EDGEHIP_ERR_STATE; }
+    if (which < 0 || which > 4 || !out) return EDGEHIP_ERR_ARG;
+    const size_t n = c->plan.n;
+    EH_CHECK(hipMemcpyAsync(out, c->planes + ((size_t)which * c->plan.nseq + seq) * n, sizeof(float) * n, hipMemcpyDeviceToHost, c->stream));
+    EH_CHECK(hipStreamSynchronize(c->stream));
+    return 0;
+}
+
+int edgehip_download_field(edgehip_ctx *c, int seq, int32_t *out) {
+    if (int e = check_seq(c, seq)) return e;
+    if (!out) return EDGEHIP_ERR_ARG;
+    const size_t n = c->plan.n;
+    std::vector<uint32_t> f(n);
+    EH_CHECK(hipMemcpyAsync(f.data(), c->field + (size_t)seq * n, 4 * n, hipMemcpyDeviceToHost, c->stream));
+    EH_CHECK(hipStreamSynchronize(c->stream));
+    for (size_t i = 0; i < n; i++) {
+        if (f[i] == 0xFFFFFFFFu) { out[2 * i] = 0; out[2 * i + 1] = -1; }
+        else { out[2 * i] = (int32_t)(f[i] >> 16); out[2 * i + 1] = (int32_t)(0xFFFFu - (f[i] & 0xFFFFu)); }
+    }
+    return 0;
+}
+
+// ---- profiler -------------------------------------------------------------------------------------------
+int edgehip_profile_enable(edgehip_ctx *c, int on) {
+    if (!c) return EDGEHIP_ERR_ARG;
+    c->prof->on = on != 0;
+    return 0;
+}
+int edgehip_profile_count(void) { return PROF_COUNT; }
+const char *edgehip_profile_name(int i) { return (i >= 0 && i < PROF_COUNT) ? kProfNames[i] : ""; }
+int edgehip_profile_read(edgehip_ctx *c, double *ms, int64_t *calls) {
+    if (!c || !ms || !calls) return EDGEHIP_ERR_ARG;
+    EH_CHECK(hipStreamSynchronize(c->stream));
+    Profiler *p = c->prof;
+    for (auto &r : p->pending) {
+        float t = 0.f;
+        if (hipEventElapsedTime(&t, r.a, r.b) == hipSuccess) { p->ms[r.id] += t; p->calls[r.id]++; }
+        p->pool.push_back(r.a);
+        p->pool.push_back(r.b);
+    }
+    p->pending.clear();
+    for (int i = 0; i < PROF_COUNT; i++) { ms[i] = p->ms[i]; calls[i] = p->calls[i]; p->ms[i] = 0; p->calls[i] = 0; }
+    return 0;
+}
+
+}  // extern "C"

@@ -1,0 +1,174 @@
+// ctx.h — internal layout of an edgehip context (device-resident SoA) and small host helpers.
+//
+// HBM layout (per context; B = nseq, S = nslots, N = w*h, CAP = KeyLine capacity = max_points):
+//   rgb      [S][B][N*3] u8      input frames (one per ring slot, like PipeBuffer::imgc)
+//   ii       [4][B][N]  f32      integral-image scratch of the box-filter chain (stage A only)
+//   planes   [5][B][N]  f32      img0,img1,dog,dx,dy — only when params.debug_planes
+//   mask     [S][B][N]  i32      img_mask_kl
+//   field    [B][N]     u32      tracker auxiliary image, packed (dist<<16 | 0xFFFF-ikl), 0xFFFFFFFF = empty
+//   KeyLines [S][B][CAP] per field (structure of arrays, see KlSoA)
+//   stage buffers for the raster-order compaction, LM scratch, residual buffers, per-sequence state.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <string>
+#include <vector>
+
+#include "edgehip.h"
+
+namespace edgehip {
+
+constexpr int kMaxBoxes = 3;        // bf_num of sspace (rebvo.cpp:299 passes 3)
+constexpr int kBandRows = 4;        // rows per detect block (raster-order compaction granule)
+constexpr int kDivLutMax = 256;     // reciprocal-count LUT entries (box width up to 15)
+constexpr int kTvrBlock = 256;      // threads per TryVelRot block
+constexpr int kNumSums = 28;        // 21 JtJ + 6 JtF + score
+constexpr int kResidBufs = 3;       // Res0, Res1, Rest (global_tracker.cpp:611)
+
+// "inherit the last valid residual of the previous blocks" marker in residual buffers (see stage_b.hip)
+__host__ __device__ inline uint64_t resid_carry_bits() { return 0x7FF8C0DEC0DEC0DEull; }
+
+// One record per KeyLine gathered at random by TryVelRot / search_match: 32 B, one 2x16-B load.
+struct __attribute__((aligned(16))) MatchRec {
+    float c_px, c_py, u_mx, u_my, m_mx, m_my, n_m, pad;
+};
+
+// Structure-of-arrays KeyLine storage of one (slot, sequence): every pointer addresses CAP elements.
+struct KlSoA {
+    int32_t *p_inx;
+    float2 *m_m, *u_m, *c_p, *p_m, *p_m_0, *m_m0;
+    float *n_m;
+    double *rho, *s_rho, *rho_nr, *s_rho_nr, *rho0, *s_rho0, *n_m0;
+    int32_t *m_id, *m_id_f, *m_id_kf, *m_num, *p_id, *n_id;
+    MatchRec *rec;  // (c_p, u_m, m_m, n_m) packed for gathers; kept in sync with the fields above
+};
+
+// Device-side per-sequence state (superset of edgehip_seq_state).
+struct SeqDev {
+    edgehip_seq_state pub;
+    // stage A scratch
+    int32_t kn_new;            // KeyLines of the slot just detected
+    int32_t band_trunc;        // band index where kl_max truncation happened (-1: none)
+    float nm_max, nm_min;      // reEstimateThresh extremes
+    double tresh_used;         // threshold used by the running detect
+    // minimiser scratch (global_tracker::Minimizer_RV locals)
+    double X[6], Xnew[6], Xt[6], h[6];
+    double JtJ[36], JtF[6], JtJnew[36], JtFnew[6];
+    double F, Fnew, F0, Ft, F0t, u, v, ut, vt, gain;
+    int32_t eff_steps, eff_steps_t, res_cur, res_new, res_t, lm_phase;
+    int32_t kn_old, pad1;
+    double s_rho_min_eval;     // s_rho threshold of the running evaluation
+    double Rt[9], Vt[3], RM[4];  // rotation / translation / z-rotation of the running evaluation
+    int32_t nmatch_tmp, kf_tmp;
+};
+
+struct DevicePlan {  // everything a kernel needs that is constant for the context
+    int w, h, n, cap, nseq, nslots;
+    int box[2][kMaxBoxes];          // box widths of filter0 / filter1
+    float box_a[2][kMaxBoxes];      // (float)(1.0/(d*d))
+    float ppx, ppy, zfx, zfy;       // cam_model keeps these as float (cam_model.h:51-52)
+    double zfm;                     // (double)((zfx+zfy)/2) computed in float (cam_model.h:57)
+};
+
+struct Profiler;
+
+}  // namespace edgehip
+
+struct edgehip_ctx {
+    edgehip_params p;
+    edgehip::DevicePlan plan;
+    int device;
+    hipStream_t stream;
+    int frame_slot;        // ring position of the newest slot (-1 before the first frame)
+    int frames_seen;
+    // device buffers
+    uint8_t *rgb;          // [S][B][N*3]
+    float *ii;             // [4][B][N]
+    float *planes;         // [5][B][N] or null
+    int32_t *mask;         // [S][B][N]
+    uint32_t *field;       // [B][N]
+    float *div_lut;        // [kDivLutMax] (float)(1.0/count)
+    double *pinv;          // [3*25] plane-fit pseudo inverse
+    void *kl_arena;        // one allocation carved into KlSoA arrays
+    std::vector<edgehip::KlSoA> kl;   // [S*B] host copies of the carved pointers
+    edgehip::KlSoA *kl_dev;           // [S*B] same, on device
+    edgehip::SeqDev *seq;             // [B]
+    uint32_t *framecount;             // [S][B] global_tracker::FrameCount per slot
+    int32_t *kn_slot;                 // [S][B] edge_finder::kn per slot
+    float *retuned_slot;              // [S][B] edge_finder::reTunedThresh per slot
+    // stage A compaction staging
+    int32_t *band_cnt;     // [B][nbands]
+    int32_t *band_off;     // [B][nbands]
+    void *band_stage;      // [B][nbands][band_cap] candidate records
+    int nbands, band_cap;
+    int32_t *histo;        // [B][256] scratch histograms
+    // stage B scratch
+    double *P0;            // [B][3][CAP]
+    double *resid;         // [kResidBufs][B][CAP]
+    double *resid_carry;   // [kResidBufs][B][nblk_tvr] last valid residual per block
+    double *partials;      // [B][nblk_tvr][kNumSums]
+    int nblk_tvr;
+    unsigned long long *fwd_key;  // [B][CAP] forward-match arbitration keys
+    int32_t *fwd_win;      // [B][CAP]
+    double *rs_tmp;        // [B][2][CAP] regularised (rho, s_rho) ping-pong
+    // host staging
+    uint8_t *pinned_rgb;   // [B][N*3]
+    size_t pinned_rgb_bytes;
+    edgehip::SeqDev *pinned_seq;  // [B]
+    double *pinned_out;    // misc readback
+    edgehip::Profiler *prof;
+};
+
+namespace edgehip {
+
+void set_error(const std::string &msg);
+int hip_fail(hipError_t e, const char *what, const char *file, int line);
+
+#define EH_CHECK(expr)                                                                      \
+    do {                                                                                    \
+        hipError_t _e = (expr);                                                             \
+        if (_e != hipSuccess) return ::edgehip::hip_fail(_e, #expr, __FILE__, __LINE__);    \
+    } while (0)
+
+#define EH_LAUNCH_CHECK() EH_CHECK(hipGetLastError())
+
+inline KlSoA &klof(edgehip_ctx *c, int slot, int seq) { return c->kl[(size_t)slot * c->plan.nseq + seq]; }
+inline KlSoA *kldev(edgehip_ctx *c, int slot) { return c->kl_dev + (size_t)slot * c->plan.nseq; }
+inline int32_t *maskof(edgehip_ctx *c, int slot) { return c->mask + (size_t)slot * c->plan.nseq * c->plan.n; }
+inline uint8_t *rgbof(edgehip_ctx *c, int slot) { return c->rgb + (size_t)slot * c->plan.nseq * c->plan.n * 3; }
+
+// ---- profiler: HIP events around kernel groups on the context stream ---------------------------------
+enum ProfId {
+    PROF_A_ROWSCAN = 0, PROF_A_COLSCAN, PROF_A_AVGROW, PROF_A_DETECT, PROF_A_COMPACT, PROF_A_JOIN,
+    PROF_B_QUANTILE, PROF_B_FIELD, PROF_B_PREP, PROF_B_TRYVELROT, PROF_B_LMSTEP,
+    PROF_C_FORWARD, PROF_C_ROTATE, PROF_C_DIRECTED, PROF_C_REGEKF, PROF_C_RESCALE, PROF_C_POSE,
+    PROF_COUNT
+};
+struct Profiler {
+    bool on = false;
+    struct Rec { hipEvent_t a, b; int id; };
+    std::vector<Rec> pending;
+    std::vector<hipEvent_t> pool;
+    double ms[PROF_COUNT] = {0};
+    int64_t calls[PROF_COUNT] = {0};
+};
+struct ProfScope {  // RAII bracket; no-op unless profiling is enabled
+    edgehip_ctx *c; int id; hipEvent_t a = nullptr, b = nullptr;
+    ProfScope(edgehip_ctx *ctx, int pid);
+    ~ProfScope();
+};
+
+// stage entry points shared between translation units (all enqueue on c->stream)
+int stage_a_enqueue(edgehip_ctx *c, int slot);
+int quantile_enqueue(edgehip_ctx *c, int slot, double smin, double smax, double pct, int nbins);
+int build_field_enqueue(edgehip_ctx *c, int slot, int radius, float min_mod);
+int tvr_prepare_enqueue(edgehip_ctx *c, int slot_old);
+int minimizer_enqueue(edgehip_ctx *c, int slot_new, int slot_old);
+int forward_match_enqueue(edgehip_ctx *c, int slot_old, int slot_new);
+int rotate_enqueue(edgehip_ctx *c, int slot, const double *R_host);
+int directed_enqueue(edgehip_ctx *c, int slot_new, int slot_old);
+int regekf_enqueue(edgehip_ctx *c, int slot, int do_reg, int do_ekf);
+int rescale_enqueue(edgehip_ctx *c, int slot);
+int pose_enqueue(edgehip_ctx *c, int slot_new, const double *t_host);
+
+}  // namespace edgehip

@@ -1,0 +1,731 @@
+// stage_a.hip — scale space + KeyLine extraction on the GPU, bit-exact with the reference CPU path.
+//
+// Replaces (reference file:line)
+//   Image<float>::ConvertRGB2BW            include/VideoLib/image.h:197-203
+//   iimage::load / iimage::average         src/mtracklib/iimage.cpp:53-71, 86-128
+//   iigauss::smooth                        src/mtracklib/iigauss.cpp:91-101
+//   sspace::build/build_dog/calc_gradient  src/mtracklib/sspace.cpp:52-85
+//   edge_finder::build_mask/join_edges/detect/reEstimateThresh   src/mtracklib/edge_finder.cpp:67-405
+//
+// Why it is laid out this way.  The reference smooths with iterated box filters on a *float32* integral
+// image whose entries exceed 2^24, so every prefix-sum add rounds and the result depends on the
+// sequential left-to-right / top-to-bottom order.  Bit-exact edge masks therefore need the same serial
+// order inside each row and each column; the parallelism is across rows (row pass), across columns
+// (column pass), across the two filters and across the nseq batched sequences.  Row passes go through an
+// LDS transpose tile so that global traffic stays coalesced while one lane walks one row.
+//
+// Launch sequence per frame (all batched over blockIdx.z = sequence):
+//   k_rgb_rowscan      RGB24 -> grey -> exact integer row prefix (row sums < 2^24, so order-free)
+//   k_colscan          serial column prefix, one thread per column            (x nlevels+1)
+//   k_avg_rowscan      box average from 4 integral taps fused with the next serial row prefix (x nlevels)
+//   k_detect           last box average of both filters + DoG + gradient + build_mask tests + plane fit;
+//                      candidates are staged per (band, wave) strip in raster order
+//   k_strip_scan       exclusive scan of strip counts, kl_max truncation, P-controller state update
+//   k_emit             raster-order KeyLine SoA + img_mask_kl ids, n_m extremes
+//   k_join_histo       join_edges (n_id, atomicMax p_id) + reEstimateThresh histogram
+//   k_retune           reEstimateThresh tail (incl. its off-by-one accumulation quirk)
+//
+// Compile with -ffp-contract=off: the reference is built without FMA contraction.
+
+#include <math.h>
+#include <string.h>
+
+#include "ctx.h"
+
+namespace edgehip {
+
+// ---------------------------------------------------------------------------------------------------
+// k_rgb_rowscan: one wave per image row.  b+g+r <= 765 and a row has <= 2^14 pixels, so the row prefix
+// stays below 2^24 and float addition of these integers is exact: any order gives the reference's bits
+// (iimage.cpp:56-61).  Each lane owns CH consecutive pixels; wave-level exclusive scan of lane totals.
+// ---------------------------------------------------------------------------------------------------
+template <int CH>
+__global__ __launch_bounds__(256) void k_rgb_rowscan(const uint8_t *__restrict__ rgb, float *__restrict__ dst,
+                                                     int w, int h, size_t n) {
+    const int seq = blockIdx.z;
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int y = blockIdx.x * 4 + wave;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    // per-wave staging of one RGB row (w*3 bytes, dword padded)
+    const int row_bytes = w * 3;
+    const int row_dw = (row_bytes + 3) >> 2;
+    uint32_t *stage = reinterpret_cast<uint32_t *>(smem) + (size_t)wave * row_dw;
+    if (y < h) {
+        const uint32_t *src = reinterpret_cast<const uint32_t *>(rgb + (size_t)seq * n * 3 + (size_t)y * row_bytes);
+        for (int i = lane; i < row_dw; i += 64) stage[i] = src[i];  // w % 4 == 0 -> rows are dword aligned
+    }
+    __syncthreads();
+    if (y >= h) return;
+    const unsigned char *sb = reinterpret_cast<const unsigned char *>(stage);
+    const int x0 = lane * CH;
+    int v[CH];
+    int run = 0;
+#pragma unroll
+    for (int i = 0; i < CH; i++) {
+        const int x = x0 + i;
+        int s = 0;
+        if (x < w) s = (int)sb[x * 3] + (int)sb[x * 3 + 1] + (int)sb[x * 3 + 2];
+        run += s;
+        v[i] = run;
+    }
+    // exclusive scan of lane totals across the wave
+    int tot = run;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+        int t = __shfl_up(tot, off, 64);
+        if (lane >= off) tot += t;
+    }
+    const int base = tot - run;
+    float *out = dst + (size_t)seq * n + (size_t)y * w + x0;
+#pragma unroll
+    for (int i = 0; i < CH; i += 4) {
+        if (x0 + i < w) {  // w % 4 == 0: whole float4 or nothing
+            float4 o;
+            o.x = (float)(v[i] + base);
+            o.y = (float)(v[i + 1] + base);
+            o.z = (float)(v[i + 2] + base);
+            o.w = (float)(v[i + 3] + base);
+            *reinterpret_cast<float4 *>(out + i) = o;
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------
+// k_colscan: img(x,y) += img(x,y-1) for y = 1..h-1, serial per column (iimage.cpp:63-67).  One thread per
+// column; rows are fetched UNR at a time so the loads (independent of the add chain) overlap it.
+// blockIdx.y selects the plane.
+// ---------------------------------------------------------------------------------------------------
+struct PlanePtrs {
+    float *p[2];
+};
+
+template <int UNR>
+__global__ __launch_bounds__(64) void k_colscan(PlanePtrs planes, int w, int h, size_t n) {
+    const int x = blockIdx.x * 64 + threadIdx.x;
+    if (x >= w) return;
+    float *img = planes.p[blockIdx.y] + (size_t)blockIdx.z * n + x;
+    float run = img[0];
+    int y = 1;
+    float cur[UNR], nxt[UNR];
+    if (y + UNR <= h) {
+#pragma unroll
+        for (int i = 0; i < UNR; i++) cur[i] = img[(size_t)(y + i) * w];
+    }
+    for (; y + UNR <= h; y += UNR) {
+        const bool more = (y + 2 * UNR <= h);
+        if (more) {
+#pragma unroll
+            for (int i = 0; i < UNR; i++) nxt[i] = img[(size_t)(y + UNR + i) * w];
+        }
+#pragma unroll
+        for (int i = 0; i < UNR; i++) {
+            run = cur[i] + run;  // img(x,y) += img(x,y-1): operand order irrelevant for IEEE add
+            img[(size_t)(y + i) * w] = run;
+        }
+        if (more) {
+#pragma unroll
+            for (int i = 0; i < UNR; i++) cur[i] = nxt[i];
+        }
+    }
+    for (; y < h; y++) {
+        run = img[(size_t)y * w] + run;
+        img[(size_t)y * w] = run;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------
+// Box average from an integral image: iimage::average's nine border regions collapse to one formula
+// with zero-substituted taps (x - 0 and x + 0 are exact), EXCEPT that the bottom band (y >= h-d2)
+// subtracts the upper tap before the left tap (iimage.cpp:118-126 vs :105-113).  The multiplier is
+// div(x,y) = (float)(1.0/count); in the interior the reference uses a = (float)(1.0/(d*d)), which is the
+// same float, so one LUT indexed by count serves both.
+// ---------------------------------------------------------------------------------------------------
+__device__ __forceinline__ float box_avg(const float *__restrict__ ii, int x, int y, int w, int h, int d, int d2,
+                                         const float *__restrict__ lut) {
+    int xr = x + d2, yb = y + d2;
+    const int xl = x - d2 - 1, yt = y - d2 - 1;
+    int cx = d, cy = d;
+    if (xl < 0) cx = x + d2 + 1;
+    if (xr > w - 1) { xr = w - 1; cx = w - x + d2; }
+    if (yt < 0) cy = y + d2 + 1;
+    const bool bottom = yb > h - 1;
+    if (bottom) { yb = h - 1; cy = h - y + d2; }
+    const float A = ii[(size_t)yb * w + xr];
+    const float B = xl >= 0 ? ii[(size_t)yb * w + xl] : 0.f;
+    const float C = yt >= 0 ? ii[(size_t)yt * w + xr] : 0.f;
+    const float D = (xl >= 0 && yt >= 0) ? ii[(size_t)yt * w + xl] : 0.f;
+    const float t = bottom ? ((A - C) - B) + D : ((A - B) - C) + D;
+    return t * lut[cx * cy];
+}
+
+// ---------------------------------------------------------------------------------------------------
+// k_avg_rowscan: dst(x,y) = sum_{x'<=x} avg(src)(x',y), the box average fused with the serial row prefix
+// of the next iimage::load (iigauss.cpp:95-98).  A block owns RB rows; it walks the row in TC-column
+// tiles: all threads compute the averages of the tile into LDS (coalesced taps), the first wave walks
+// one row per lane through LDS (conflict-free: row stride TC+1), all threads store the tile coalesced.
+// blockIdx.y selects (src, dst, d).
+// ---------------------------------------------------------------------------------------------------
+struct AvgJob {
+    const float *src[2];
+    float *dst[2];
+    int d[2];
+};
+
+template <int NT, int RB, int TC>
+__global__ __launch_bounds__(NT) void k_avg_rowscan(AvgJob job, const float *__restrict__ lut, int w, int h, size_t n) {
+    __shared__ float tile[RB][TC + 1];
+    const int seq = blockIdx.z;
+    const float *src = job.src[blockIdx.y] + (size_t)seq * n;
+    float *dst = job.dst[blockIdx.y] + (size_t)seq * n;
+    const int d = job.d[blockIdx.y], d2 = d / 2;
+    const int y0 = blockIdx.x * RB;
+    const int tid = threadIdx.x;
+    float run = 0.f;  // running row sum of lane's row (first wave only)
+    for (int x0 = 0; x0 < w; x0 += TC) {
+        for (int idx = tid; idx < RB * TC; idx += NT) {
+            const int r = idx / TC, c = idx - r * TC;
+            const int x = x0 + c, y = y0 + r;
+            float v = 0.f;
+            if (x < w && y < h) v = box_avg(src, x, y, w, h, d, d2, lut);
+            tile[r][c] = v;
+        }
+        __syncthreads();
+        if (tid < RB) {
+            float vals[TC];
+#pragma unroll
+            for (int c = 0; c < TC; c++) vals[c] = tile[tid][c];
+#pragma unroll
+            for (int c = 0; c < TC; c++) {
+                run = (x0 + c == 0) ? vals[c] : run + vals[c];  // img(0,y)=l(0,y); img(x,y)=img(x-1,y)+l(x,y)
+                vals[c] = run;
+            }
+#pragma unroll
+            for (int c = 0; c < TC; c++) tile[tid][c] = vals[c];
+        }
+        __syncthreads();
+        for (int idx = tid; idx < RB * TC; idx += NT) {
+            const int r = idx / TC, c = idx - r * TC;
+            const int x = x0 + c, y = y0 + r;
+            if (x < w && y < h) dst[(size_t)y * w + x] = tile[r][c];
+        }
+        __syncthreads();
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------
+// k_detect: one block per band of kBandRows image rows (rows 2..h-3 are scanned, edge_finder.cpp:105).
+// Phase 1 builds img0 (=G(sigma0)) and DoG for the band plus a 2-row halo in LDS from the last integral
+// images of both filters (last iimage::average of iigauss::smooth + sspace::build_dog).
+// Phase 2: wave v owns the v-th quarter of the band's raster order and walks it in 64-pixel chunks; a
+// lane tests one pixel (edge_finder.cpp:117-159) and survivors are appended, in raster order, to the
+// (band, wave) strip of the staging area using the wave ballot.
+// ---------------------------------------------------------------------------------------------------
+struct CandStage {  // SoA staging of candidates: [B][nstrips][strip_cap]
+    int32_t *p_inx;
+    float2 *m;   // (theta0, theta1) as float
+    float2 *s;   // (xs, ys)
+};
+
+struct DetectArgs {
+    const float *iic0, *iic1;  // last integral image of filter0 / filter1, [B][N]
+    int d0, d1;                // last box widths
+    const float *lut;
+    const double *pinv;        // [3][25]
+    float *planes;             // optional debug planes [5][B][N]
+    int32_t *mask;             // [B][N] of the slot
+    SeqDev *seq;
+    CandStage st;
+    int32_t *strip_cnt;        // [B][nstrips]
+    int w, h, nseq, strip_cap;
+    size_t n;
+    // thresholds (edge_finder::detect arguments)
+    double gain, tmax, tmin;
+    int kl_ref;
+    float dog_thresh_f;        // (float)DetectorDoGThresh
+    double pn_thresh;          // (double)(25.0f * (float)DetectorPosNegThresh)
+};
+
+__device__ __forceinline__ double update_thresh(double tresh, int l_kl_num, int kl_ref, double gain, double tmax,
+                                                double tmin) {
+    // UpdateThresh, edge_finder.cpp:330-335
+    if (gain > 0) {
+        tresh -= gain * (double)(kl_ref - l_kl_num);
+        tresh = tresh > tmax ? tmax : (tresh < tmin ? tmin : tresh);
+    }
+    return tresh;
+}
+
+__global__ __launch_bounds__(256) void k_detect(DetectArgs a) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int w = a.w, h = a.h;
+    constexpr int HR = kBandRows + 4;  // rows held in LDS
+    float *s_img0 = reinterpret_cast<float *>(smem);   // [HR][w]
+    float *s_dog = s_img0 + (size_t)HR * w;            // [HR][w]
+    __shared__ double s_pinv[75];
+    const int seq = blockIdx.z, band = blockIdx.x;
+    const int tid = threadIdx.x;
+    const int y0 = 2 + band * kBandRows;  // first output row of the band
+    const int yb0 = y0 - 2;               // first LDS row
+    const size_t so = (size_t)seq * a.n;
+    const float *iic0 = a.iic0 + so, *iic1 = a.iic1 + so;
+    if (tid < 75) s_pinv[tid] = a.pinv[tid];
+
+    // ---- phase 1: img0, img1 -> LDS (+ optional debug planes) ----
+    const int d20 = a.d0 / 2, d21 = a.d1 / 2;
+    for (int idx = tid; idx < HR * w; idx += 256) {
+        const int r = idx / w, x = idx - r * w;
+        const int y = yb0 + r;
+        float g0 = 0.f, g1 = 0.f;
+        if (y < h) {
+            g0 = box_avg(iic0, x, y, w, h, a.d0, d20, a.lut);
+            g1 = box_avg(iic1, x, y, w, h, a.d1, d21, a.lut);
+        }
+        s_img0[idx] = g0;
+        s_dog[idx] = g1 - g0;  // sspace.cpp:66
+        if (a.planes && y < h) {
+            // every image row is written by exactly one band: rows [y0, y0+BR) + the image borders
+            const bool own = (y >= y0 && y < y0 + kBandRows) || (band == 0 && y < 2) ||
+                             (y >= 2 + (int)gridDim.x * kBandRows);
+            if (own) {
+                float *pl = a.planes + so;
+                const size_t pstride = (size_t)a.nseq * a.n;
+                pl[0 * pstride + (size_t)y * w + x] = g0;
+                pl[1 * pstride + (size_t)y * w + x] = g1;
+                pl[2 * pstride + (size_t)y * w + x] = g1 - g0;
+            }
+        }
+    }
+    __syncthreads();
+
+    SeqDev *sq = a.seq + seq;
+    const double tresh = update_thresh(sq->pub.tresh, sq->pub.l_kl_num, a.kl_ref, a.gain, a.tmax, a.tmin);
+    const float grad_thresh = (float)tresh;                      // build_mask takes float grad_thesh
+    const float gt1 = grad_thresh * 765;                         // grad_thesh*max_img_value (int 765 -> float)
+    const float thr_g = gt1 * gt1;                               // util::square(...)
+    const float gt2 = gt1 * a.dog_thresh_f;
+    const float thr_d = gt2 * gt2;
+
+    // ---- phase 2: tests, raster order inside the wave's quarter of the band ----
+    const int wave = tid >> 6, lane = tid & 63;
+    const int npx = kBandRows * w;
+    const int nchunk = (npx + 63) >> 6;
+    const int cpw = (nchunk + 3) >> 2;  // chunks per wave
+    const int strip = band * 4 + wave;
+    const int nstrips = gridDim.x * 4;
+    const size_t sbase = ((size_t)seq * nstrips + strip) * a.strip_cap;
+    int32_t *mask = a.mask + so;
+    int count = 0;  // wave-uniform running count of the strip
+    for (int ci = 0; ci < cpw; ci++) {
+        const int q = (wave * cpw + ci) * 64 + lane;
+        const int r = q / w, x = q - r * w;
+        const int y = y0 + r;
+        const bool inband = q < npx && y < h - 2;
+        bool cand = false;
+        float mx = 0.f, my = 0.f, xs = 0.f, ys = 0.f;
+        if (inband) {
+            // default: no KeyLine (edge_finder.cpp:109); border columns are never KeyLines either
+            mask[(size_t)y * w + x] = -1;
+            if (x >= 2 && x < w - 2) {
+                const int lr = r + 2;  // LDS row of the pixel
+                const float *c0 = s_img0 + (size_t)lr * w + x;
+                const float dx = c0[1] - c0[-1];   // sspace.cpp:80
+                const float dy = c0[w] - c0[-w];   // sspace.cpp:81
+                if (a.planes) {
+                    float *pl = a.planes + so;
+                    const size_t pstride = (size_t)a.nseq * a.n;
+                    pl[3 * pstride + (size_t)y * w + x] = dx;
+                    pl[4 * pstride + (size_t)y * w + x] = dy;
+                }
+                const float n2g = dx * dx + dy * dy;
+                if (!(n2g < thr_g)) {
+                    const float *dg = s_dog + (size_t)lr * w + x;
+                    int pn = 0;
+                    double t0 = 0, t1 = 0, t2 = 0;
+#pragma unroll
+                    for (int i = -2, k = 0; i <= 2; i++) {
+#pragma unroll
+                        for (int j = -2; j <= 2; j++, k++) {
+                            const float v = dg[i * w + j];
+                            pn += (v > 0) ? 1 : -1;
+                            const double yv = (double)v;
+                            t0 += s_pinv[k] * yv;          // TooN dot product: result += a[i]*b[i]
+                            t1 += s_pinv[25 + k] * yv;
+                            t2 += s_pinv[50 + k] * yv;
+                        }
+                    }
+                    const int apn = pn < 0 ? -pn : pn;
+                    if (!((double)apn > a.pn_thresh)) {
+                        const double den = t0 * t0 + t1 * t1;
+                        xs = (float)(-t0 * t2 / den);
+                        ys = (float)(-t1 * t2 / den);
+                        if (!(fabsf(xs) > 0.5f || fabsf(ys) > 0.5f)) {
+                            mx = (float)t0;
+                            my = (float)t1;
+                            const float n2m = mx * mx + my * my;
+                            if (!(n2m < thr_d)) cand = true;
+                        }
+                    }
+                }
+            }
+        }
+        const unsigned long long bal = __ballot(cand);
+        if (cand) {
+            const int rank = count + __popcll(bal & ((1ull << lane) - 1ull));
+            a.st.p_inx[sbase + rank] = y * w + x;
+            a.st.m[sbase + rank] = make_float2(mx, my);
+            a.st.s[sbase + rank] = make_float2(xs, ys);
+        }
+        count += __popcll(bal);
+    }
+    if (lane == 0) a.strip_cnt[(size_t)seq * nstrips + strip] = count;
+}
+
+// ---------------------------------------------------------------------------------------------------
+// k_strip_scan: one block per sequence.  Exclusive scan of the strip counts = raster-order KeyLine ids;
+// kn = min(total, kl_max) (edge_finder.cpp:203-209); stores the P-controller state (detect(), :355-364).
+// ---------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_strip_scan(const int32_t *__restrict__ strip_cnt, int32_t *__restrict__ strip_off,
+                                                    SeqDev *seqs, int32_t *__restrict__ kn_out, int nstrips, int kl_max,
+                                                    int kl_ref, double gain, double tmax, double tmin) {
+    __shared__ int s_part[256];
+    const int seq = blockIdx.x, tid = threadIdx.x;
+    const int32_t *cnt = strip_cnt + (size_t)seq * nstrips;
+    int32_t *off = strip_off + (size_t)seq * (nstrips + 1);
+    const int per = (nstrips + 255) / 256;
+    int loc = 0;
+    for (int i = 0; i < per; i++) {
+        const int s = tid * per + i;
+        if (s < nstrips) loc += cnt[s];
+    }
+    s_part[tid] = loc;
+    __syncthreads();
+    for (int o = 1; o < 256; o <<= 1) {
+        int t = tid >= o ? s_part[tid - o] : 0;
+        __syncthreads();
+        s_part[tid] += t;
+        __syncthreads();
+    }
+    int run = s_part[tid] - loc;
+    for (int i = 0; i < per; i++) {
+        const int s = tid * per + i;
+        if (s < nstrips) {
+            off[s] = run;
+            run += cnt[s];
+        }
+    }
+    if (tid == 255) {
+        const int total = s_part[255];
+        off[nstrips] = total;
+        SeqDev *sq = seqs + seq;
+        const int kn = total < kl_max ? total : kl_max;
+        const double t = update_thresh(sq->pub.tresh, sq->pub.l_kl_num, kl_ref, gain, tmax, tmin);
+        sq->pub.tresh = t;
+        sq->tresh_used = t;
+        sq->pub.l_kl_num = kn;
+        sq->kn_new = kn;
+        kn_out[seq] = kn;
+        sq->nm_max = 0.f;                       // n_m > 0: integer atomics on the float bits order correctly
+        sq->nm_min = __int_as_float(0x7f800000);
+    }
+}
+
+
+// ---------------------------------------------------------------------------------------------------
+// k_emit: thread i < kn builds KeyLine i (edge_finder.cpp:166-200) from its staged candidate and writes
+// the mask id.  Also reduces max/min of n_m for reEstimateThresh (:376-382) and clears the histogram.
+// ---------------------------------------------------------------------------------------------------
+struct EmitArgs {
+    CandStage st;
+    const int32_t *strip_off;  // [B][nstrips+1]
+    KlSoA *kl;                 // [B] of the slot
+    int32_t *mask;             // [B][N]
+    SeqDev *seq;
+    int32_t *histo;            // [B][256]
+    int nstrips, strip_cap, w;
+    size_t n;
+    float ppx, ppy;
+};
+
+__global__ __launch_bounds__(256) void k_emit(EmitArgs a) {
+    const int seq = blockIdx.z;
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    SeqDev *sq = a.seq + seq;
+    const int kn = sq->kn_new;
+    if (blockIdx.x == 0) a.histo[(size_t)seq * 256 + threadIdx.x] = 0;
+    float nm = 0.f;
+    const bool valid = i < kn;
+    if (valid) {
+        const int32_t *off = a.strip_off + (size_t)seq * (a.nstrips + 1);
+        int lo = 0, hi = a.nstrips;  // largest s with off[s] <= i (empty strips share an offset: skip them)
+        while (hi - lo > 1) {
+            const int mid = (lo + hi) >> 1;
+            if (off[mid] <= i) lo = mid; else hi = mid;
+        }
+        const size_t src = ((size_t)seq * a.nstrips + lo) * a.strip_cap + (i - off[lo]);
+        const int p = a.st.p_inx[src];
+        const float2 m = a.st.m[src];
+        const float2 s = a.st.s[src];
+        const KlSoA &k = a.kl[seq];
+        const int y = p / a.w, x = p - y * a.w;
+        const float n2m = m.x * m.x + m.y * m.y;             // util::norm2(mn.x,mn.y)
+        nm = sqrtf(n2m);                                     // kl.n_m = sqrt(n2_m)
+        const float2 u = make_float2(m.x / nm, m.y / nm);
+        const float2 cp = make_float2((float)x + s.x, (float)y + s.y);    // {x+xs, y+ys}
+        const float2 pm = make_float2(cp.x - a.ppx, cp.y - a.ppy);        // cam_model::Img2Hom
+        k.p_inx[i] = p;
+        k.m_m[i] = m;
+        k.n_m[i] = nm;
+        k.u_m[i] = u;
+        k.c_p[i] = cp;
+        k.p_m[i] = pm;
+        k.p_m_0[i] = pm;
+        k.rho[i] = 1.0;          // RhoInit
+        k.s_rho[i] = 20.0;       // RHO_MAX
+        k.rho0[i] = 1.0;
+        k.s_rho0[i] = 20.0;
+        k.rho_nr[i] = 1.0;
+        k.s_rho_nr[i] = 20.0;
+        k.m_num[i] = 0;
+        k.n_id[i] = -1;
+        k.p_id[i] = -1;
+        k.m_id[i] = -1;
+        k.m_id_f[i] = -1;
+        k.m_id_kf[i] = -1;
+        k.m_m0[i] = make_float2(0.f, 0.f);
+        k.n_m0[i] = 0.0;
+        MatchRec rec;
+        rec.c_px = cp.x; rec.c_py = cp.y; rec.u_mx = u.x; rec.u_my = u.y;
+        rec.m_mx = m.x; rec.m_my = m.y; rec.n_m = nm; rec.pad = 0.f;
+        k.rec[i] = rec;
+        a.mask[(size_t)seq * a.n + p] = i;
+    }
+    __shared__ float s_mx[4], s_mn[4];
+    float mx = valid ? nm : 0.f, mn = valid ? nm : __int_as_float(0x7f800000);
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        mx = fmaxf(mx, __shfl_xor(mx, o, 64));
+        mn = fminf(mn, __shfl_xor(mn, o, 64));
+    }
+    if ((threadIdx.x & 63) == 0) { s_mx[threadIdx.x >> 6] = mx; s_mn[threadIdx.x >> 6] = mn; }
+    __syncthreads();
+    if (threadIdx.x == 0 && blockIdx.x * 256 < kn) {
+        mx = fmaxf(fmaxf(s_mx[0], s_mx[1]), fmaxf(s_mx[2], s_mx[3]));
+        mn = fminf(fminf(s_mn[0], s_mn[1]), fminf(s_mn[2], s_mn[3]));
+        atomicMax(reinterpret_cast<int *>(&sq->nm_max), __float_as_int(mx));
+        atomicMin(reinterpret_cast<int *>(&sq->nm_min), __float_as_int(mn));
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------
+// k_join_histo: join_edges + NextPoint (edge_finder.cpp:221-320) and the histogram of reEstimateThresh
+// (:384-398).  kl[ikl2].p_id = ikl is last-writer-wins in KeyLine order  ==  atomicMax.
+// ---------------------------------------------------------------------------------------------------
+__device__ __forceinline__ int x86_cvttss2si(float f) {
+    // (int)float as x86-64 does it: NaN / out of range -> 0x80000000
+    if (!(f > -2147483904.0f && f < 2147483648.0f)) return (int)0x80000000;
+    return (int)f;
+}
+
+__global__ __launch_bounds__(256) void k_join_histo(KlSoA *kls, const int32_t *__restrict__ masks, SeqDev *seqs,
+                                                    int32_t *histo, int w, size_t n, int nbins) {
+    const int seq = blockIdx.z;
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    SeqDev *sq = seqs + seq;
+    const int kn = sq->kn_new;
+    __shared__ int s_h[256];
+    s_h[threadIdx.x] = 0;
+    __syncthreads();
+    if (i < kn) {
+        const KlSoA &k = kls[seq];
+        const int32_t *mask = masks + (size_t)seq * n;
+        const float2 cp = k.c_p[i];
+        const float2 m = k.m_m[i];
+        const int x = (int)((double)cp.x + 0.5);  // util::round2int_positive: float + 0.5 (double)
+        const int y = (int)((double)cp.y + 0.5);
+        const float tx = -m.y, ty = m.x;
+        int sx, sy;
+        if (ty > 0) { sy = 1; sx = (tx > 0) ? 1 : -1; }
+        else        { sy = -1; sx = (tx < 0) ? -1 : 1; }
+        int j = mask[(size_t)y * w + (x + sx)];
+        if (j < 0) j = mask[(size_t)(y + sy) * w + x];
+        if (j < 0) j = mask[(size_t)(y + sy) * w + (x + sx)];
+        if (j >= 0) {
+            k.n_id[i] = j;
+            atomicMax(&k.p_id[j], i);
+        }
+        // histogram position, edge_finder.cpp:392
+        const float mxd = sq->nm_max, mnd = sq->nm_min;
+        int b = x86_cvttss2si((float)nbins * (mxd - k.n_m[i]) / (mxd - mnd));
+        b = b > nbins - 1 ? nbins - 1 : b;
+        b = b < 0 ? 0 : b;
+        atomicAdd(&s_h[b], 1);
+    }
+    __syncthreads();
+    if (threadIdx.x < nbins && s_h[threadIdx.x] != 0 && blockIdx.x * 256 < kn)
+        atomicAdd(&histo[(size_t)seq * 256 + threadIdx.x], s_h[threadIdx.x]);
+}
+
+// k_retune: tail of reEstimateThresh (edge_finder.cpp:400-403).  The reference loop
+//     for(int a=0; i<n && a<knum; i++, a+=histo[i]);
+// accumulates histo[i] AFTER incrementing i, i.e. bin 0 is never counted (and histo[n] is read past the
+// end on the last step, where it no longer matters).
+__global__ void k_retune(SeqDev *seqs, const int32_t *__restrict__ histo, float *__restrict__ retuned_out, int nseq,
+                         int knum, int nbins) {
+    const int seq = blockIdx.x * blockDim.x + threadIdx.x;
+    if (seq >= nseq) return;
+    SeqDev *sq = seqs + seq;
+    const int32_t *hs = histo + (size_t)seq * 256;
+    int i = 0;
+    for (int acc = 0; i < nbins && acc < knum;) {
+        i++;
+        if (i < nbins) acc += hs[i];
+    }
+    const float mxd = sq->nm_max, mnd = sq->nm_min;
+    float r = mxd - (float)i * (mxd - mnd) / (float)nbins;
+    if (sq->kn_new <= 0) r = 0.f;
+    sq->pub.retuned_thresh = r;
+    retuned_out[seq] = r;
+}
+
+// ---------------------------------------------------------------------------------------------------
+// host side
+// ---------------------------------------------------------------------------------------------------
+static int rowscan_ch(int w) { return 4 * ((w + 255) / 256); }
+
+int stage_a_enqueue(edgehip_ctx *c, int slot) {
+    const DevicePlan &pl = c->plan;
+    const int w = pl.w, h = pl.h, B = pl.nseq;
+    const size_t n = pl.n;
+    float *ii[4];
+    for (int i = 0; i < 4; i++) ii[i] = c->ii + (size_t)i * B * n;
+    hipStream_t st = c->stream;
+
+    // 1. grey + exact row prefix, then serial column prefix: iimage::load of the input (shared by both
+    //    filters: filter0.smooth(data) and filter1.smooth(data) start from the same integral image).
+    {
+        ProfScope ps(c, PROF_A_ROWSCAN);
+        const int ch = rowscan_ch(w);
+        const size_t sm = (size_t)4 * ((w * 3 + 3) / 4) * 4;
+        dim3 g((h + 3) / 4, 1, B);
+        switch (ch) {
+            case 4: hipLaunchKernelGGL(k_rgb_rowscan<4>, g, dim3(256), sm, st, rgbof(c, slot), ii[0], w, h, n); break;
+            case 8: hipLaunchKernelGGL(k_rgb_rowscan<8>, g, dim3(256), sm, st, rgbof(c, slot), ii[0], w, h, n); break;
+            case 12: hipLaunchKernelGGL(k_rgb_rowscan<12>, g, dim3(256), sm, st, rgbof(c, slot), ii[0], w, h, n); break;
+            case 16: hipLaunchKernelGGL(k_rgb_rowscan<16>, g, dim3(256), sm, st, rgbof(c, slot), ii[0], w, h, n); break;
+            case 20: hipLaunchKernelGGL(k_rgb_rowscan<20>, g, dim3(256), sm, st, rgbof(c, slot), ii[0], w, h, n); break;
+            case 24: hipLaunchKernelGGL(k_rgb_rowscan<24>, g, dim3(256), sm, st, rgbof(c, slot), ii[0], w, h, n); break;
+            case 28: hipLaunchKernelGGL(k_rgb_rowscan<28>, g, dim3(256), sm, st, rgbof(c, slot), ii[0], w, h, n); break;
+            default: hipLaunchKernelGGL(k_rgb_rowscan<32>, g, dim3(256), sm, st, rgbof(c, slot), ii[0], w, h, n); break;
+        }
+        EH_LAUNCH_CHECK();
+    }
+    auto colscan = [&](float *a, float *b) -> int {
+        ProfScope ps(c, PROF_A_COLSCAN);
+        PlanePtrs pp;
+        pp.p[0] = a;
+        pp.p[1] = b ? b : a;
+        hipLaunchKernelGGL(k_colscan<16>, dim3((w + 63) / 64, b ? 2 : 1, B), dim3(64), 0, st, pp, w, h, n);
+        EH_LAUNCH_CHECK();
+        return 0;
+    };
+    if (int e = colscan(ii[0], nullptr)) return e;
+
+    // 2. the remaining box passes.  Levels that have identical box-width prefixes in both filters are
+    //    computed once (EuRoC: {3,3,5} / {3,5,5} share the first level).
+    //    cur[f] = integral image that filter f averages next.
+    float *cur[2] = {ii[0], ii[0]};
+    int next_free = 1;
+    bool shared = true;
+    for (int lvl = 0; lvl < kMaxBoxes - 1; lvl++) {
+        const int d0 = pl.box[0][lvl], d1 = pl.box[1][lvl];
+        AvgJob job;
+        int njobs;
+        if (shared && d0 == d1) {
+            float *dst = ii[next_free++];
+            job.src[0] = cur[0]; job.dst[0] = dst; job.d[0] = d0;
+            job.src[1] = cur[0]; job.dst[1] = dst; job.d[1] = d0;
+            njobs = 1;
+            cur[0] = cur[1] = dst;
+        } else {
+            shared = false;
+            // two destinations; reuse planes that are no longer read
+            float *dst0 = nullptr, *dst1 = nullptr;
+            for (int i = 0; i < 4 && !dst1; i++) {
+                if (ii[i] == cur[0] || ii[i] == cur[1]) continue;
+                if (!dst0) dst0 = ii[i]; else dst1 = ii[i];
+            }
+            job.src[0] = cur[0]; job.dst[0] = dst0; job.d[0] = d0;
+            job.src[1] = cur[1]; job.dst[1] = dst1; job.d[1] = d1;
+            njobs = 2;
+            cur[0] = dst0;
+            cur[1] = dst1;
+        }
+        {
+            ProfScope ps(c, PROF_A_AVGROW);
+            hipLaunchKernelGGL((k_avg_rowscan<256, 64, 64>), dim3((h + 63) / 64, njobs, B), dim3(256), 0, st, job,
+                               c->div_lut, w, h, n);
+            EH_LAUNCH_CHECK();
+        }
+        if (int e = colscan(cur[0], njobs == 2 ? cur[1] : nullptr)) return e;
+    }
+
+    // 3. last average + DoG + gradient + detection
+    const int nbands = c->nbands, nstrips = nbands * 4;
+    CandStage cs;
+    {
+        char *base = (char *)c->band_stage;
+        const size_t cnt = (size_t)B * nstrips * c->band_cap;
+        cs.p_inx = (int32_t *)base;
+        cs.m = (float2 *)(base + cnt * 4);
+        cs.s = (float2 *)(base + cnt * 12);
+    }
+    {
+        ProfScope ps(c, PROF_A_DETECT);
+        DetectArgs a;
+        a.iic0 = cur[0]; a.iic1 = cur[1];
+        a.d0 = pl.box[0][kMaxBoxes - 1]; a.d1 = pl.box[1][kMaxBoxes - 1];
+        a.lut = c->div_lut; a.pinv = c->pinv;
+        a.planes = c->planes;
+        a.mask = maskof(c, slot);
+        a.seq = c->seq;
+        a.st = cs;
+        a.strip_cnt = c->band_cnt;
+        a.w = w; a.h = h; a.nseq = B; a.strip_cap = c->band_cap; a.n = n;
+        a.gain = c->p.auto_gain; a.tmax = c->p.max_thresh; a.tmin = c->p.min_thresh;
+        a.kl_ref = c->p.reference_points;
+        a.dog_thresh_f = (float)c->p.dog_thresh;
+        const int ws = c->p.plane_fit_size;
+        a.pn_thresh = (double)(((float)((2.0 * ws + 1.0) * (2.0 * ws + 1.0))) * (float)c->p.pos_neg_thresh);
+        const size_t sm = (size_t)2 * (kBandRows + 4) * w * sizeof(float);
+        hipLaunchKernelGGL(k_detect, dim3(nbands, 1, B), dim3(256), sm, st, a);
+        EH_LAUNCH_CHECK();
+    }
+    {
+        ProfScope ps(c, PROF_A_COMPACT);
+        int kl_max = c->p.max_points;
+        if (kl_max > pl.cap) kl_max = pl.cap;
+        hipLaunchKernelGGL(k_strip_scan, dim3(B), dim3(256), 0, st, c->band_cnt, c->band_off, c->seq,
+                           c->kn_slot + (size_t)slot * B, nstrips, kl_max,
+                           c->p.reference_points, c->p.auto_gain, c->p.max_thresh, c->p.min_thresh);
+        EH_LAUNCH_CHECK();
+        EmitArgs e;
+        e.st = cs; e.strip_off = c->band_off; e.kl = kldev(c, slot); e.mask = maskof(c, slot); e.seq = c->seq;
+        e.histo = c->histo; e.nstrips = nstrips; e.strip_cap = c->band_cap; e.w = w; e.n = n;
+        e.ppx = pl.ppx; e.ppy = pl.ppy;
+        hipLaunchKernelGGL(k_emit, dim3((pl.cap + 255) / 256, 1, B), dim3(256), 0, st, e);
+        EH_LAUNCH_CHECK();
+    }
+    {
+        ProfScope ps(c, PROF_A_JOIN);
+        hipLaunchKernelGGL(k_join_histo, dim3((pl.cap + 255) / 256, 1, B), dim3(256), 0, st, kldev(c, slot),
+                           maskof(c, slot), c->seq, c->histo, w, n, c->p.qcut_nbins);
+        EH_LAUNCH_CHECK();
+        hipLaunchKernelGGL(k_retune, dim3((B + 63) / 64), dim3(64), 0, st, c->seq, c->histo,
+                           c->retuned_slot + (size_t)slot * B, B, c->p.track_points,
+                           c->p.qcut_nbins);
+        EH_LAUNCH_CHECK();
+    }
+    return 0;
+}
+
+}  // namespace edgehip

@@ -1,0 +1,321 @@
+"""ctypes binding of libedgehip.so (include/edgehip.h) — the HIP/gfx950 edge pipeline.
+
+This module is only glue: every call goes straight to the C ABI.  There is no CPU fallback; importing
+works anywhere (so the CPU test-suite can check the exported symbols) but creating a context needs an
+MI355X.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(HERE, "lib", "libedgehip.so")
+
+KEYLINE_DTYPE = np.dtype(
+    [
+        ("p_inx", "<i4"), ("m_m", "<f4", (2,)), ("u_m", "<f4", (2,)), ("n_m", "<f4"), ("score", "<f4"),
+        ("c_p", "<f4", (2,)), ("_pad0", "<i4"),
+        ("rho", "<f8"), ("s_rho", "<f8"), ("rho_nr", "<f8"), ("s_rho_nr", "<f8"), ("rho0", "<f8"), ("s_rho0", "<f8"),
+        ("p_m", "<f4", (2,)), ("p_m_0", "<f4", (2,)),
+        ("m_id", "<i4"), ("m_id_f", "<i4"), ("m_id_kf", "<i4"), ("m_num", "<i4"),
+        ("m_m0", "<f4", (2,)), ("n_m0", "<f8"),
+        ("p_id", "<i4"), ("n_id", "<i4"), ("net_id", "<i4"), ("stereo_m_id", "<i4"),
+        ("stereo_rho", "<f8"), ("stereo_s_rho", "<f8"),
+    ]
+)
+assert KEYLINE_DTYPE.itemsize == 168
+
+
+class Params(C.Structure):
+    _fields_ = [
+        ("w", C.c_int32), ("h", C.c_int32),
+        ("ppx", C.c_double), ("ppy", C.c_double), ("zfx", C.c_double), ("zfy", C.c_double),
+        ("kc", C.c_double * 5),
+        ("sigma0", C.c_double), ("ksigma", C.c_double),
+        ("plane_fit_size", C.c_int32),
+        ("pos_neg_thresh", C.c_double), ("dog_thresh", C.c_double),
+        ("max_points", C.c_int32), ("reference_points", C.c_int32), ("track_points", C.c_int32),
+        ("detector_thresh", C.c_double), ("auto_gain", C.c_double),
+        ("max_thresh", C.c_double), ("min_thresh", C.c_double),
+        ("search_range", C.c_int32), ("qcut_nbins", C.c_int32),
+        ("qcut_quantile", C.c_double),
+        ("tracker_iter_num", C.c_int32), ("tracker_init_type", C.c_int32), ("tracker_init_iter_num", C.c_int32),
+        ("tracker_match_thresh", C.c_double), ("match_thresh_module", C.c_double), ("match_thresh_angle", C.c_double),
+        ("match_num_thresh", C.c_uint32), ("do_rescaling", C.c_int32),
+        ("reweight_distance", C.c_double), ("regularize_thresh", C.c_double),
+        ("loc_unc_match", C.c_double), ("reshape_q_abs", C.c_double), ("reshape_q_rel", C.c_double),
+        ("loc_unc", C.c_double),
+        ("global_match_threshold", C.c_int32), ("debug_planes", C.c_int32),
+        ("config_fps", C.c_double),
+    ]
+
+
+def euroc_params(w=752, h=480, **over):
+    """app/rebvorun/GlobalConfig_EuRoC of the reference (+ TrackPoints=12000, ImuMode=0)."""
+    p = Params()
+    p.w, p.h = w, h
+    sx, sy = w / 752.0, h / 480.0
+    p.ppx, p.ppy, p.zfx, p.zfy = 367.215 * sx, 248.375 * sy, 458.654 * sx, 457.296 * sy
+    p.kc[:] = [-0.28340811, 0.07395907, 0.0, 0.00019359, 1.76187114e-05]
+    p.sigma0, p.ksigma = 1.7818, 1.2599
+    p.plane_fit_size = 2
+    p.pos_neg_thresh, p.dog_thresh = 0.4, 0.095259868922420
+    p.max_points, p.reference_points, p.track_points = 16000, 12000, 12000
+    p.detector_thresh, p.auto_gain, p.max_thresh, p.min_thresh = 0.01, 5e-7, 0.5, 0.005
+    p.search_range, p.qcut_nbins, p.qcut_quantile = 40, 100, 0.9
+    p.tracker_iter_num, p.tracker_init_type, p.tracker_init_iter_num = 5, 2, 2
+    p.tracker_match_thresh, p.match_thresh_module, p.match_thresh_angle = 0.5, 1.0, 45.0
+    p.match_num_thresh, p.do_rescaling = 0, 0
+    p.reweight_distance, p.regularize_thresh = 2.0, 0.5
+    p.loc_unc_match, p.reshape_q_abs, p.reshape_q_rel, p.loc_unc = 2.0, 1e-4, 1.6968e-04, 1.0
+    p.global_match_threshold = 500
+    p.debug_planes = 0
+    p.config_fps = 20.0
+    for k, v in over.items():
+        setattr(p, k, v)
+    return p
+
+
+class SeqState(C.Structure):
+    _fields_ = [
+        ("tresh", C.c_double),
+        ("V", C.c_double * 3), ("W", C.c_double * 3),
+        ("P_V", C.c_double * 9), ("P_W", C.c_double * 9),
+        ("R", C.c_double * 9),
+        ("Pose", C.c_double * 9), ("Pos", C.c_double * 3),
+        ("Kp", C.c_double), ("P_Kp", C.c_double), ("K", C.c_double),
+        ("s_rho_q", C.c_double),
+        ("score", C.c_double), ("rel_error", C.c_double), ("rel_error_score", C.c_double),
+        ("t_prev", C.c_double), ("dt", C.c_double),
+        ("retuned_thresh", C.c_float),
+        ("l_kl_num", C.c_int32), ("frame", C.c_int32),
+        ("klm_fwd", C.c_int32), ("klm_num", C.c_int32), ("kf_matchs", C.c_int32),
+        ("estimation_ok", C.c_int32), ("minimizer_evals", C.c_int32),
+    ]
+
+
+class Nav(C.Structure):
+    _fields_ = [
+        ("t", C.c_double), ("dt", C.c_double),
+        ("V", C.c_double * 3), ("W", C.c_double * 3), ("P_V", C.c_double * 9), ("P_W", C.c_double * 9),
+        ("Rot", C.c_double * 9), ("RotLie", C.c_double * 3), ("Vel", C.c_double * 3),
+        ("Pose", C.c_double * 9), ("PoseLie", C.c_double * 3), ("Pos", C.c_double * 3),
+        ("Kp", C.c_double), ("RKp", C.c_double), ("s_rho_q", C.c_double), ("tresh", C.c_double),
+        ("score", C.c_double), ("rel_error", C.c_double), ("rel_error_score", C.c_double),
+        ("retuned_thresh", C.c_float),
+        ("kn", C.c_int32), ("klm_fwd", C.c_int32), ("klm_num", C.c_int32), ("kf_matchs", C.c_int32),
+        ("estimation_ok", C.c_int32), ("frame", C.c_int32), ("minimizer_evals", C.c_int32),
+    ]
+
+
+# every symbol include/edgehip.h declares (checked by tests/test_abi.py without a GPU)
+EXPORTS = [
+    "edgehip_create", "edgehip_destroy", "edgehip_last_error", "edgehip_abi_version", "edgehip_sync",
+    "edgehip_stream", "edgehip_box_widths", "edgehip_upload_rgb", "edgehip_upload_rgb_device",
+    "edgehip_stage_a", "edgehip_get_kn", "edgehip_quantile", "edgehip_build_field", "edgehip_try_velrot",
+    "edgehip_download_resid", "edgehip_minimizer_rv", "edgehip_forward_match", "edgehip_rotate_keylines",
+    "edgehip_directed_matching", "edgehip_regularize_ekf", "edgehip_rescale", "edgehip_process_frame",
+    "edgehip_next_slot", "edgehip_cur_slot", "edgehip_read_nav", "edgehip_reset", "edgehip_get_state",
+    "edgehip_set_state", "edgehip_get_framecount", "edgehip_set_framecount", "edgehip_download_keylines",
+    "edgehip_upload_keylines", "edgehip_download_plane", "edgehip_download_field", "edgehip_profile_enable",
+    "edgehip_profile_count", "edgehip_profile_name", "edgehip_profile_read",
+]
+
+_lib = None
+
+
+def load_library():
+    """dlopen libedgehip.so; raises if the HIP extension was not built (no silent fallback)."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise RuntimeError(f"{LIB_PATH} is missing: build it with `make -C rebvo_amd/csrc` "
+                               "(or __graft_entry__.build()); rebvo_amd has no CPU fallback")
+        _lib = C.CDLL(LIB_PATH)
+        _lib.edgehip_last_error.restype = C.c_char_p
+        _lib.edgehip_profile_name.restype = C.c_char_p
+        _lib.edgehip_stream.restype = C.c_void_p
+    return _lib
+
+
+class EdgeHipError(RuntimeError):
+    pass
+
+
+def _dp(a):
+    return a.ctypes.data_as(C.POINTER(C.c_double))
+
+
+class EdgeHip:
+    """nseq image sequences advancing in lock-step on one MI355X."""
+
+    def __init__(self, params, nseq=1, nslots=3, device=0):
+        self.lib = load_library()
+        self.p, self.nseq, self.nslots = params, nseq, nslots
+        self.w, self.h, self.cap = params.w, params.h, min(params.max_points, 50000)
+        self.ctx = C.c_void_p()
+        self._ck(self.lib.edgehip_create(C.byref(params), nseq, nslots, device, C.byref(self.ctx)))
+
+    def _ck(self, rc):
+        if rc != 0:
+            raise EdgeHipError(f"edgehip error {rc}: {self.lib.edgehip_last_error().decode()}")
+
+    def close(self):
+        if getattr(self, "ctx", None):
+            self.lib.edgehip_destroy(self.ctx)
+            self.ctx = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # ---- input ----
+    def upload_rgb(self, slot, rgb, seq_first=0):
+        rgb = np.ascontiguousarray(rgb, dtype=np.uint8)
+        if rgb.ndim == 3:
+            rgb = rgb[None]
+        assert rgb.shape[1:] == (self.h, self.w, 3)
+        self._ck(self.lib.edgehip_upload_rgb(self.ctx, slot, rgb.ctypes.data_as(C.c_void_p), seq_first, rgb.shape[0]))
+
+    def upload_rgb_device(self, slot, dev_ptr):
+        self._ck(self.lib.edgehip_upload_rgb_device(self.ctx, slot, C.c_void_p(dev_ptr)))
+
+    def sync(self):
+        self._ck(self.lib.edgehip_sync(self.ctx))
+
+    def stream(self):
+        return self.lib.edgehip_stream(self.ctx)
+
+    def box_widths(self):
+        out = (C.c_int * 6)()
+        self._ck(self.lib.edgehip_box_widths(self.ctx, out))
+        return list(out)
+
+    # ---- stages ----
+    def stage_a(self, slot):
+        self._ck(self.lib.edgehip_stage_a(self.ctx, slot))
+
+    def get_kn(self, slot):
+        out = np.zeros(self.nseq, np.int32)
+        self._ck(self.lib.edgehip_get_kn(self.ctx, slot, out.ctypes.data_as(C.c_void_p)))
+        return out
+
+    def quantile(self, slot, smin=1e-3, smax=20.0, pct=0.9, nbins=100):
+        self._ck(self.lib.edgehip_quantile(self.ctx, slot, C.c_double(smin), C.c_double(smax), C.c_double(pct), nbins))
+
+    def build_field(self, slot, radius, min_mod=-1.0):
+        self._ck(self.lib.edgehip_build_field(self.ctx, slot, radius, C.c_float(min_mod)))
+
+    def try_velrot(self, slot_new, slot_old, X, reweight, procjf, match_thresh, s_rho_min, match_num_thresh, k_huber,
+                   resid_in=-1, resid_out=0):
+        X = np.ascontiguousarray(np.broadcast_to(np.asarray(X, np.float64), (self.nseq, 6)))
+        smin = np.ascontiguousarray(np.broadcast_to(np.asarray(s_rho_min, np.float64), (self.nseq,)))
+        out = np.zeros((self.nseq, 43))
+        self._ck(self.lib.edgehip_try_velrot(self.ctx, slot_new, slot_old, _dp(X), int(reweight), int(procjf),
+                                             C.c_double(match_thresh), _dp(smin), C.c_uint32(match_num_thresh),
+                                             C.c_double(k_huber), resid_in, resid_out, _dp(out)))
+        return out[:, 42].copy(), out[:, :36].reshape(self.nseq, 6, 6).copy(), out[:, 36:42].copy()
+
+    def download_resid(self, which):
+        out = np.zeros((self.nseq, self.cap))
+        self._ck(self.lib.edgehip_download_resid(self.ctx, which, _dp(out)))
+        return out
+
+    def minimizer_rv(self, slot_new, slot_old):
+        self._ck(self.lib.edgehip_minimizer_rv(self.ctx, slot_new, slot_old))
+
+    def forward_match(self, slot_old, slot_new):
+        self._ck(self.lib.edgehip_forward_match(self.ctx, slot_old, slot_new))
+
+    def rotate_keylines(self, slot, R=None):
+        if R is None:
+            self._ck(self.lib.edgehip_rotate_keylines(self.ctx, slot, None))
+        else:
+            R = np.ascontiguousarray(np.broadcast_to(np.asarray(R, np.float64).reshape(-1, 9), (self.nseq, 9)))
+            self._ck(self.lib.edgehip_rotate_keylines(self.ctx, slot, _dp(R)))
+
+    def directed_matching(self, slot_new, slot_old):
+        self._ck(self.lib.edgehip_directed_matching(self.ctx, slot_new, slot_old))
+
+    def regularize_ekf(self, slot, do_regularize=True, do_ekf=True):
+        self._ck(self.lib.edgehip_regularize_ekf(self.ctx, slot, int(do_regularize), int(do_ekf)))
+
+    def rescale(self, slot):
+        self._ck(self.lib.edgehip_rescale(self.ctx, slot))
+
+    # ---- whole frame ----
+    def next_slot(self):
+        return self.lib.edgehip_next_slot(self.ctx)
+
+    def cur_slot(self):
+        return self.lib.edgehip_cur_slot(self.ctx)
+
+    def process_frame(self, t):
+        t = np.ascontiguousarray(np.broadcast_to(np.asarray(t, np.float64), (self.nseq,)))
+        self._ck(self.lib.edgehip_process_frame(self.ctx, _dp(t)))
+
+    def read_nav(self):
+        nav = (Nav * self.nseq)()
+        self._ck(self.lib.edgehip_read_nav(self.ctx, nav))
+        return list(nav)
+
+    def reset(self):
+        self._ck(self.lib.edgehip_reset(self.ctx))
+
+    # ---- state / data ----
+    def get_state(self, seq=0):
+        s = SeqState()
+        self._ck(self.lib.edgehip_get_state(self.ctx, seq, C.byref(s)))
+        return s
+
+    def set_state(self, seq, s):
+        self._ck(self.lib.edgehip_set_state(self.ctx, seq, C.byref(s)))
+
+    def get_framecount(self, seq, slot):
+        v = C.c_uint32(0)
+        self._ck(self.lib.edgehip_get_framecount(self.ctx, seq, slot, C.byref(v)))
+        return v.value
+
+    def set_framecount(self, seq, slot, fc):
+        self._ck(self.lib.edgehip_set_framecount(self.ctx, seq, slot, C.c_uint32(fc)))
+
+    def download_keylines(self, seq, slot, want_mask=True):
+        kl = np.zeros(self.cap, KEYLINE_DTYPE)
+        mask = np.zeros((self.h, self.w), np.int32) if want_mask else None
+        kn = C.c_int32(0)
+        self._ck(self.lib.edgehip_download_keylines(self.ctx, seq, slot, kl.ctypes.data_as(C.c_void_p),
+                                                    None if mask is None else mask.ctypes.data_as(C.c_void_p),
+                                                    C.byref(kn)))
+        return kl[:kn.value].copy(), mask
+
+    def upload_keylines(self, seq, slot, kl, mask=None, retuned=0.0):
+        kl = np.ascontiguousarray(kl, dtype=KEYLINE_DTYPE)
+        m = None if mask is None else np.ascontiguousarray(mask, dtype=np.int32)
+        self._ck(self.lib.edgehip_upload_keylines(self.ctx, seq, slot, kl.ctypes.data_as(C.c_void_p), len(kl),
+                                                  None if m is None else m.ctypes.data_as(C.c_void_p),
+                                                  C.c_float(retuned)))
+
+    def download_plane(self, seq, which):
+        idx = {"img0": 0, "img1": 1, "dog": 2, "dx": 3, "dy": 4}[which]
+        out = np.zeros((self.h, self.w), np.float32)
+        self._ck(self.lib.edgehip_download_plane(self.ctx, seq, idx, out.ctypes.data_as(C.c_void_p)))
+        return out
+
+    def download_field(self, seq):
+        out = np.zeros((self.h, self.w, 2), np.int32)
+        self._ck(self.lib.edgehip_download_field(self.ctx, seq, out.ctypes.data_as(C.c_void_p)))
+        return out
+
+    # ---- measurement ----
+    def profile_enable(self, on=True):
+        self._ck(self.lib.edgehip_profile_enable(self.ctx, int(on)))
+
+    def profile_read(self):
+        n = self.lib.edgehip_profile_count()
+        ms = np.zeros(n)
+        calls = np.zeros(n, np.int64)
+        self._ck(self.lib.edgehip_profile_read(self.ctx, _dp(ms), calls.ctypes.data_as(C.c_void_p)))
+        return {self.lib.edgehip_profile_name(i).decode(): (float(ms[i]), int(calls[i])) for i in range(n)}

@@ -1,0 +1,108 @@
+"""Stage A parity (GPU): scale space + KeyLine extraction must be BIT-EXACT with the reference.
+
+Oracle = oracle/_ref (the reference's own sspace/edge_finder compiled in place).  Compared per frame:
+img0/img1/DoG planes, gradient planes (interior, where build_mask reads them), img_mask_kl, kn, every
+KeyLine field that stage A defines, the auto-threshold state and reTunedThresh.
+"""
+import numpy as np
+import pytest
+
+from rebvo_amd import edgehip, synth
+
+pytestmark = pytest.mark.gpu
+
+STAGE_A_FIELDS = ["p_inx", "m_m", "u_m", "n_m", "c_p", "rho", "s_rho", "rho_nr", "s_rho_nr", "rho0", "s_rho0",
+                  "p_m", "p_m_0", "m_id", "m_id_f", "m_id_kf", "m_num", "p_id", "n_id", "net_id"]
+
+
+def _oracle(w, h, **over):
+    from oracle import oracle
+    if not oracle.available("ref"):
+        pytest.skip("oracle/_ref/libreforacle.so not built")
+    return oracle.Oracle("ref", oracle.euroc_params(w, h, **over))
+
+
+def _bits(a):
+    return np.ascontiguousarray(a).view(np.uint32 if a.dtype == np.float32 else np.uint64)
+
+
+def _run(w, h, frames, over=None, check_planes=True):
+    over = over or {}
+    orc = _oracle(w, h, **over)
+    eh = edgehip.EdgeHip(edgehip.euroc_params(w, h, debug_planes=1, **over), nseq=1, nslots=3)
+    tresh, lkl = orc.p.detector_thresh, 0
+    for k, f in enumerate(frames):
+        slot = k % 3
+        kn_ref, tresh, lkl = orc.stage_a(slot % 8, f, tresh, lkl)
+        eh.upload_rgb(slot, f)
+        eh.stage_a(slot)
+        kl, mask = eh.download_keylines(0, slot)
+        st = eh.get_state(0)
+        assert len(kl) == kn_ref, f"frame {k}: kn {len(kl)} vs {kn_ref}"
+        assert st.tresh == tresh and st.l_kl_num == lkl
+        if check_planes:
+            for name in ("img0", "img1", "dog"):
+                a, b = eh.download_plane(0, name), orc.plane(slot % 8, name)
+                assert np.array_equal(_bits(a), _bits(b)), f"frame {k}: plane {name} differs"
+            for name in ("dx", "dy"):
+                a, b = eh.download_plane(0, name), orc.plane(slot % 8, name)
+                assert np.array_equal(_bits(a[2:-2, 2:-2]), _bits(b[2:-2, 2:-2])), f"frame {k}: plane {name}"
+        assert np.array_equal(mask, orc.mask(slot % 8)), f"frame {k}: img_mask_kl differs"
+        rk = orc.keylines(slot % 8)
+        for fld in STAGE_A_FIELDS:
+            assert np.array_equal(kl[fld], rk[fld]), f"frame {k}: KeyLine.{fld} differs"
+        if kn_ref > 0:  # with kn == 0 the reference reads an uninitialised KeyLine (edge_finder.cpp:376)
+            assert np.float32(st.retuned_thresh) == np.float32(orc.retuned(slot % 8)), f"frame {k}: reTunedThresh"
+    eh.close()
+    return kn_ref
+
+
+def test_stage_a_small_rects():
+    frames = list(synth.rects_sequence(192, 144, 4, seed=3))
+    _run(192, 144, frames)
+
+
+def test_stage_a_small_ragged_height():
+    # height not a multiple of the band size, width not a multiple of 64
+    frames = list(synth.rects_sequence(200, 150, 3, seed=5))
+    _run(200, 150, frames)
+
+
+def test_stage_a_euroc_size_billboards():
+    frames = [f for f, _, _ in synth.billboard_sequence(752, 480, 4)]
+    kn = _run(752, 480, frames)
+    assert kn > 5000
+
+
+def test_stage_a_kl_max_truncation():
+    # MaxPoints far below the number of candidates: raster-order truncation + mask clearing
+    frames = list(synth.rects_sequence(320, 240, 2, seed=9))
+    _run(320, 240, frames, over=dict(max_points=700, reference_points=600, track_points=600))
+
+
+def test_stage_a_empty_image():
+    f = np.full((144, 192, 3), 77, np.uint8)
+    _run(192, 144, [f, f])
+
+
+def test_stage_a_batch_matches_single():
+    # the batch dimension must not change results: sequence s of a 3-sequence context == single runs
+    w, h = 192, 144
+    seqs = [list(synth.rects_sequence(w, h, 2, seed=s)) for s in (1, 2, 3)]
+    eh = edgehip.EdgeHip(edgehip.euroc_params(w, h), nseq=3, nslots=2)
+    singles = []
+    for s in range(3):
+        e1 = edgehip.EdgeHip(edgehip.euroc_params(w, h), nseq=1, nslots=2)
+        for k in range(2):
+            e1.upload_rgb(k, seqs[s][k])
+            e1.stage_a(k)
+        singles.append(e1.download_keylines(0, 1))
+        e1.close()
+    for k in range(2):
+        eh.upload_rgb(k, np.stack([seqs[s][k] for s in range(3)]))
+        eh.stage_a(k)
+    for s in range(3):
+        kl, mask = eh.download_keylines(s, 1)
+        assert np.array_equal(mask, singles[s][1])
+        assert kl.tobytes() == singles[s][0].tobytes()
+    eh.close()
