@@ -235,6 +235,8 @@ int edgehip_create(const edgehip_params *params, int nseq, int nslots, int devic
     EH_TRY(dmalloc(c, &c->resid, (size_t)kResidBufs * B * CAP, al->dev, 0));
     EH_TRY(dmalloc(c, &c->resid_carry, (size_t)kResidBufs * B * c->nblk_tvr, al->dev, 0));
     EH_TRY(dmalloc(c, &c->partials, B * c->nblk_tvr * kNumSums, al->dev, 0));
+    EH_TRY(dmalloc(c, &c->block_last, B * c->nblk_tvr, al->dev, 0));
+    c->field_radius = p.search_range;
     EH_TRY(dmalloc(c, &c->fwd_key, B * CAP, al->dev, 0));
     EH_TRY(dmalloc(c, &c->fwd_win, B * CAP, al->dev, 0xFF));
     EH_TRY(dmalloc(c, &c->rs_tmp, B * 2 * CAP, al->dev, 0));

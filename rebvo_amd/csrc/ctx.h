@@ -107,6 +107,8 @@ struct edgehip_ctx {
     double *resid;         // [kResidBufs][B][CAP]
     double *resid_carry;   // [kResidBufs][B][nblk_tvr] last valid residual per block
     double *partials;      // [B][nblk_tvr][kNumSums]
+    double *block_last;    // [B][nblk_tvr] last valid residual of each block of the running evaluation
+    int field_radius;      // radius of the last build_field (global_tracker::max_r)
     int nblk_tvr;
     unsigned long long *fwd_key;  // [B][CAP] forward-match arbitration keys
     int32_t *fwd_win;      // [B][CAP]

@@ -1,16 +1,901 @@
-// stage_b.hip — tracker: EstimateQuantile, build_field, TryVelRot, Minimizer_RV (placeholder, see below)
+// stage_b.hip — the tracker: uncertainty quantile, auxiliary distance field, TryVelRot evaluation and the
+// Levenberg-Marquardt driver of Minimizer_RV, all device resident.
+//
+// Replaces (reference file:line)
+//   edge_tracker::EstimateQuantile          src/mtracklib/edge_tracker.cpp:1148-1186
+//   global_tracker::build_field             src/mtracklib/global_tracker.cpp:61-105
+//   KltoI3PMatrix / Ne10::ProyI3Pto3PMatrix  global_tracker.cpp:553-570, include/UtilLib/ne10wrapper.h:414-424
+//   global_tracker::TryVelRot<double,...>   global_tracker.cpp:289-543 (+ Calc_f_J2 :228-271, Test_f_k .h:90-104)
+//   global_tracker::Minimizer_RV<double>    global_tracker.cpp:580-819
+//
+// Design.  The evaluation is ONE fused kernel (thread per old KeyLine): SE(3) transform, projection, field
+// lookup (random 4-byte read), gather of the matched KeyLine's 32-byte record, residual, Jacobian row and
+// the 21+6+1 sums of J^T J, J^T f, f^T f reduced with wavefront shuffles, LDS across the 4 waves, and one
+// 28-double partial per block (fixed order => run-to-run deterministic; no float atomics).
+// Between evaluations a one-wave kernel per sequence (k_lm_step) finishes the reduction and runs the LM
+// logic (6x6 Jacobi-SVD / LDL^T solves, gain ratio, accept/reject, buffer swaps) so the host never waits
+// inside a frame.
+//
+// Sequential quirks of the reference restated as parallel rules:
+//  * DResidualNew[ikl] = fi where `fi` is only refreshed by a successful match (global_tracker.cpp:344,
+//    391, 406): an unmatched KeyLine inherits the residual of the last matched KeyLine before it.  Inside
+//    a block this is a "last valid" scan (ballot + shuffle, then LDS across waves); across blocks the
+//    value is written as a marker NaN and resolved by the next reader from per-block carries that
+//    k_lm_step prefixes.
+//  * build_field keeps, per pixel, the smallest |t| and among equals the LAST KeyLine: one atomicMin on
+//    (dist << 16 | 0xFFFF - ikl).
+//  * kl.m_id_f reflects the last EVALUATED state, accepted or not (:354, :265).
+
+#include <math.h>
+#include <string.h>
+
 #include "ctx.h"
+
 namespace edgehip {
-int quantile_enqueue(edgehip_ctx *, int, double, double, double, int) { set_error("not implemented"); return EDGEHIP_ERR_STATE; }
-int build_field_enqueue(edgehip_ctx *, int, int, float) { set_error("not implemented"); return EDGEHIP_ERR_STATE; }
-int tvr_prepare_enqueue(edgehip_ctx *, int) { set_error("not implemented"); return EDGEHIP_ERR_STATE; }
-int minimizer_enqueue(edgehip_ctx *, int, int) { set_error("not implemented"); return EDGEHIP_ERR_STATE; }
+
+__device__ __forceinline__ int x86_cvttsd2si(double f) {
+    if (!(f > -2147483649.0 && f < 2147483648.0)) return (int)0x80000000;
+    return (int)f;
 }
+
+// ---------------------------------------------------------------------------------------------------
+// EstimateQuantile
+// ---------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_quantile(const KlSoA *kls, const int32_t *__restrict__ kns, SeqDev *seqs,
+                                                  double smin, double smax, double pct, int nbins) {
+    __shared__ int s_h[256];
+    const int seq = blockIdx.x, tid = threadIdx.x;
+    s_h[tid] = 0;
+    __syncthreads();
+    const int kn = kns[seq];
+    const double *s_rho = kls[seq].s_rho;
+    for (int i = tid; i < kn; i += 256) {
+        int b = x86_cvttsd2si((double)nbins * (s_rho[i] - smin) / (smax - smin));
+        b = b > nbins - 1 ? nbins - 1 : b;
+        b = b < 0 ? 0 : b;
+        atomicAdd(&s_h[b], 1);
+    }
+    __syncthreads();
+    if (tid == 0) {
+        double q = 1e3;
+        for (int i = 0, a = 0; i < nbins; i++) {
+            if ((double)a > pct * (double)kn) {
+                q = (double)i * (smax - smin) / (double)nbins + smin;
+                break;
+            }
+            a += s_h[i];
+        }
+        seqs[seq].pub.s_rho_q = q;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------
+// build_field: thread per (KeyLine, t) pair, t in [-r, r)
+// ---------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_field_scatter(const KlSoA *kls, const int32_t *__restrict__ kns,
+                                                       const float *__restrict__ retuned, uint32_t *__restrict__ field,
+                                                       int w, int h, size_t n, int radius, float min_mod_arg) {
+    const int seq = blockIdx.z;
+    const int kn = kns[seq];
+    const int idx = blockIdx.x * 256 + threadIdx.x;
+    const int span = 2 * radius;
+    const int ikl = idx / span;
+    if (ikl >= kn) return;
+    const int t = idx - ikl * span - radius;
+    const KlSoA &k = kls[seq];
+    const float min_mod = min_mod_arg < 0.f ? retuned[seq] : min_mod_arg;
+    const MatchRec r = k.rec[ikl];
+    if (min_mod > 0 && r.n_m < min_mod) return;
+    const float fx = r.u_mx * (float)t + r.c_px;
+    const float fy = r.u_my * (float)t + r.c_py;
+    const int xi = (int)roundf(fx), yi = (int)roundf(fy);  // Image::GetIndexRC uses round()
+    if (xi >= w || yi >= h || xi < 0 || yi < 0) return;
+    const uint32_t at = (uint32_t)(t < 0 ? -t : t);
+    atomicMin(&field[(size_t)seq * n + (size_t)yi * w + xi], (at << 16) | (uint32_t)(0xFFFF - ikl));
+}
+
+// ---------------------------------------------------------------------------------------------------
+// KltoI3PMatrix + ProyI3Pto3PMatrix: P0 = (x*z/zf, y*z/zf, z), z = 1/rho  (once per frame pair)
+// ---------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_tvr_prepare(const KlSoA *kls, const int32_t *__restrict__ kns, double *__restrict__ P0,
+                                                     double *__restrict__ resid0, double *__restrict__ carry0, SeqDev *seqs,
+                                                     int cap, int nblk, double zfm) {
+    const int seq = blockIdx.z;
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    const int kn = kns[seq];
+    if (i == 0) seqs[seq].kn_old = kn;
+    if (threadIdx.x == 0) carry0[(size_t)seq * nblk + blockIdx.x] = 0.0;
+    if (i >= kn) return;
+    const KlSoA &k = kls[seq];
+    const float2 pm = k.p_m[i];
+    const double z = 1 / k.rho[i];
+    const double pz_zf = (1 / zfm) * z;
+    double *p = P0 + (size_t)seq * 3 * cap;
+    p[i] = pz_zf * (double)pm.x;
+    p[cap + i] = pz_zf * (double)pm.y;
+    p[2 * cap + i] = z;
+    resid0[(size_t)seq * cap + i] = 0.0;  // "Init residuals", global_tracker.cpp:625
+}
+
+// ---------------------------------------------------------------------------------------------------
+// SO3 exponential as TooN::SO3<>::exp + rodrigues_so3_exp (TooN so3.h:203-285)
+// ---------------------------------------------------------------------------------------------------
+__device__ inline void so3_exp(const double w[3], double R[9]) {
+    const double one_6th = 1.0 / 6.0, one_20th = 1.0 / 20.0;
+    const double theta_sq = w[0] * w[0] + w[1] * w[1] + w[2] * w[2];
+    const double theta = sqrt(theta_sq);
+    double A, B;
+    if (theta_sq < 1e-8) {
+        A = 1.0 - one_6th * theta_sq;
+        B = 0.5;
+    } else if (theta_sq < 1e-6) {
+        B = 0.5 - 0.25 * one_6th * theta_sq;
+        A = 1.0 - theta_sq * one_6th * (1.0 - one_20th * theta_sq);
+    } else {
+        const double inv_theta = 1.0 / theta;
+        A = sin(theta) * inv_theta;
+        B = (1 - cos(theta)) * (inv_theta * inv_theta);
+    }
+    const double wx2 = w[0] * w[0], wy2 = w[1] * w[1], wz2 = w[2] * w[2];
+    R[0] = 1.0 - B * (wy2 + wz2);
+    R[4] = 1.0 - B * (wx2 + wz2);
+    R[8] = 1.0 - B * (wx2 + wy2);
+    double a = A * w[2], b = B * (w[0] * w[1]);
+    R[1] = b - a; R[3] = b + a;
+    a = A * w[1]; b = B * (w[0] * w[2]);
+    R[2] = b + a; R[6] = b - a;
+    a = A * w[0]; b = B * (w[1] * w[2]);
+    R[5] = b - a; R[7] = b + a;
+}
+
+// Per-evaluation constants of TryVelRot (global_tracker.cpp:309-341): R0 = exp(W), RM = 2x2 block of
+// exp((0,0,W_z)), Vt = V.
+__device__ inline void tvr_setup(SeqDev *sq, const double X[6]) {
+    double R0[9], Rz[9];
+    so3_exp(X + 3, R0);
+    const double wz[3] = {0.0, 0.0, X[5]};
+    so3_exp(wz, Rz);
+    for (int i = 0; i < 9; i++) sq->Rt[i] = R0[i];  // row-major R0(i,j)
+    sq->RM[0] = Rz[0]; sq->RM[1] = Rz[1]; sq->RM[2] = Rz[3]; sq->RM[3] = Rz[4];
+    for (int i = 0; i < 3; i++) sq->Vt[i] = X[i];
+}
+
+// ---------------------------------------------------------------------------------------------------
+// TryVelRot
+// ---------------------------------------------------------------------------------------------------
+struct TvrArgs {
+    const KlSoA *kl_old;       // [B]
+    const KlSoA *kl_new;       // [B]  (field KeyLines)
+    const int32_t *kn_old;     // [B]
+    const uint32_t *field;     // [B][N]
+    const double *P0;          // [B][3][CAP]
+    double *resid;             // [kResidBufs][B][CAP]
+    double *resid_carry;       // [kResidBufs][B][nblk]  resolved carry-in per block
+    double *block_last;        // [B][nblk] last valid fi of each block (marker NaN if none) of THIS call
+    double *partials;          // [B][nblk][kNumSums]
+    SeqDev *seq;
+    const uint32_t *framecount;  // [B] of the new slot
+    int w, h, cap, nblk, nseq;
+    size_t n;
+    double zfm, max_r, match_thresh, k_huber;
+    float ppx, ppy;
+    uint32_t match_num_thresh;
+    int write_mid;             // store kl.m_id_f (only the last evaluation of a minimisation needs to)
+};
+
+__device__ __forceinline__ bool is_carry(double v) { return __double_as_longlong(v) == (long long)resid_carry_bits(); }
+
+template <bool REWEIGHT, bool PROCJF>
+__global__ __launch_bounds__(kTvrBlock) void k_try_velrot(TvrArgs a) {
+    const int seq = blockIdx.z, blk = blockIdx.x, tid = threadIdx.x;
+    const int lane = tid & 63, wave = tid >> 6;
+    SeqDev *sq = a.seq + seq;
+    const int kn = a.kn_old[seq];
+    const int ikl = blk * kTvrBlock + tid;
+    if (blk * kTvrBlock >= kn) return;  // whole block beyond the list (block-uniform)
+    const KlSoA &ko = a.kl_old[seq];
+    const int res_in = sq->res_cur, res_out = sq->lm_phase == 0 ? sq->res_t : sq->res_new;
+    const double *rin = a.resid + ((size_t)res_in * a.nseq + seq) * a.cap;
+    double *rout = a.resid + ((size_t)res_out * a.nseq + seq) * a.cap;
+    const double carry_in_prev = a.resid_carry[((size_t)res_in * a.nseq + seq) * a.nblk + blk];
+
+    double J[6] = {0, 0, 0, 0, 0, 0};
+    double fm = 0, dfx = 0, dfy = 0;
+    double ptx = 0, pty = 0, ptz = 1, pix = 0, piy = 0, rho_p = 1, s_rho = 1;
+    int mid_f = -1;
+    // status: 0 = skipped (no residual written), 1 = out of image (max_r), 2 = evaluated & matched (own fi),
+    //         3 = evaluated, unmatched (inherits the previous valid fi)
+    int status = 0;
+    double fi = 0;
+    if (ikl < kn) {
+        s_rho = ko.s_rho[ikl];
+        const uint32_t fc = a.framecount[seq];
+        const uint32_t mthr = a.match_num_thresh < fc ? a.match_num_thresh : fc;
+        const bool skip = s_rho > sq->s_rho_min_eval || (uint32_t)ko.m_num[ikl] < mthr;  // int vs uint compare
+        if (!skip) {
+            const double *p0 = a.P0 + (size_t)seq * 3 * a.cap;
+            const double sx = p0[ikl], sy = p0[a.cap + ikl], sz = p0[2 * a.cap + ikl];
+            const double *R = sq->Rt, *V = sq->Vt;
+            // Ne10::SE3on3PMatrix: dst = R(i,0)*x; dst += R(i,1)*y; dst += R(i,2)*z; dst = V + dst
+            ptx = R[0] * sx; ptx += R[1] * sy; ptx += R[2] * sz; ptx = V[0] + ptx;
+            pty = R[3] * sx; pty += R[4] * sy; pty += R[5] * sz; pty = V[1] + pty;
+            ptz = R[6] * sx; ptz += R[7] * sy; ptz += R[8] * sz; ptz = V[2] + ptz;
+            // Ne10::ProyP3toI3PMatrix
+            rho_p = 1 / ptz;
+            const double pz_zf = a.zfm * rho_p;
+            pix = pz_zf * ptx;
+            piy = pz_zf * pty;
+            const double px = pix + (double)a.ppx, py = piy + (double)a.ppy;  // cam_model::Hom2Img
+            const int x = x86_cvttsd2si(px + 0.5), y = x86_cvttsd2si(py + 0.5);
+            double weight = 1;
+            if (REWEIGHT) {
+                double rprev = rin[ikl];
+                if (is_carry(rprev)) rprev = carry_in_prev;
+                if (fabs(rprev) > a.k_huber) weight = a.k_huber / fabs(rprev);
+            }
+            if (x < 1 || y < 1 || x >= a.w - 1 || y >= a.h - 1) {
+                fm = a.max_r;
+                if (REWEIGHT) fm *= weight;
+                status = 1;
+            } else {
+                status = 3;
+                fm = a.max_r;
+                const float2 klm = ko.m_m[ikl];
+                const float knm = ko.n_m[ikl];
+                // temporarily z-rotated gradient, stored back into a float Point2DF (:386-388)
+                const float rmx = (float)(sq->RM[0] * (double)klm.x + sq->RM[1] * (double)klm.y);
+                const float rmy = (float)(sq->RM[2] * (double)klm.x + sq->RM[3] * (double)klm.y);
+                const uint32_t f = a.field[(size_t)seq * a.n + (size_t)y * a.w + x];
+                if (f != 0xFFFFFFFFu) {
+                    const int ikf = 0xFFFF - (int)(f & 0xFFFFu);
+                    const MatchRec fr = a.kl_new[seq].rec[ikf];
+                    // Test_f_k (float arithmetic inside, compared in double)
+                    const double p_n2 = (double)(knm * knm);
+                    const double p_esc = (double)(rmx * fr.m_mx + rmy * fr.m_my);
+                    if (!(fabs(p_esc - p_n2) > a.match_thresh * p_n2)) {
+                        const double dx = px - (double)fr.c_px, dy = py - (double)fr.c_py;
+                        fi = dx * (double)fr.u_mx + dy * (double)fr.u_my;
+                        dfx = (double)fr.u_mx;
+                        dfy = (double)fr.u_my;
+                        fm = fi;
+                        mid_f = ikf;
+                        status = 2;
+                    }
+                }
+                if (REWEIGHT) {
+                    fm *= weight;
+                    dfx *= weight;
+                    dfy *= weight;
+                }
+            }
+        }
+    }
+
+    // ---- DResidualNew: "last valid fi" propagation ----
+    __shared__ double s_wlast[4];
+    __shared__ int s_whas[4];
+    {
+        const unsigned long long vmask = __ballot(status == 2);
+        const unsigned long long below = vmask & ((1ull << lane) - 1ull);
+        const int src = below ? 63 - __clzll(below) : 0;
+        const double inh = __shfl(fi, src, 64);
+        if (lane == 0) {
+            s_whas[wave] = vmask != 0;
+        }
+        const int top = vmask ? 63 - __clzll(vmask) : 0;
+        const double wl = __shfl(fi, top, 64);
+        if (lane == 0) s_wlast[wave] = wl;
+        __syncthreads();
+        if (status == 3) {
+            double v;
+            bool have = false;
+            if (below) { v = inh; have = true; }
+            else {
+                for (int pw = wave - 1; pw >= 0 && !have; pw--)
+                    if (s_whas[pw]) { v = s_wlast[pw]; have = true; }
+            }
+            if (have) rout[ikl] = v;
+            else rout[ikl] = __longlong_as_double((long long)resid_carry_bits());
+        } else if (status == 2) {
+            rout[ikl] = fi;
+        } else if (status == 1) {
+            rout[ikl] = a.max_r;
+        }
+        if (tid == 0) {
+            double bl = __longlong_as_double((long long)resid_carry_bits());
+            for (int pw = 3; pw >= 0; pw--)
+                if (s_whas[pw]) { bl = s_wlast[pw]; break; }
+            a.block_last[(size_t)seq * a.nblk + blk] = bl;
+        }
+    }
+    if (a.write_mid && ikl < kn) ko.m_id_f[ikl] = mid_f;
+
+    // ---- Jacobian row, uncertainty scaling (global_tracker.cpp:419-463) ----
+    double sums[kNumSums];
+    if (ikl < kn) {
+        if (PROCJF) {
+            double t0 = a.zfm * rho_p;
+            J[0] = t0 * dfx;
+            J[1] = t0 * dfy;
+            t0 = rho_p * pix;
+            J[2] = t0 * dfx;
+            t0 = rho_p * piy;
+            J[2] += t0 * dfy;
+            J[3] = J[1] * ptz; J[3] += J[2] * pty;
+            J[4] = J[0] * ptz; J[4] += J[2] * ptx;
+            t0 = J[0] * pty;
+            J[5] = -1 * t0; J[5] += J[1] * ptx;
+        }
+        const double qvel = (a.zfm * dfx * sq->Vt[0] + a.zfm * dfy * sq->Vt[1] + (pix * dfx + piy * dfy) * sq->Vt[2]);
+        double q_rho = sqrt(s_rho * qvel * s_rho * qvel + 1);
+        if (!REWEIGHT) q_rho = s_rho;
+        if (PROCJF) {
+#pragma unroll
+            for (int j = 0; j < 6; j++) J[j] /= q_rho;
+        }
+        fm /= q_rho;
+    }
+    int ns = 0;
+    if (PROCJF) {
+#pragma unroll
+        for (int i = 0; i < 6; i++)
+#pragma unroll
+            for (int j = i; j < 6; j++) sums[ns++] = J[i] * J[j];
+#pragma unroll
+        for (int i = 0; i < 6; i++) sums[ns++] = J[i] * fm;
+    }
+    sums[ns++] = fm * fm;
+
+    // ---- block reduction: wave shuffles, then LDS across waves, one partial per block ----
+    __shared__ double s_red[4][kNumSums];
+    const int nsum = PROCJF ? kNumSums : 1;
+#pragma unroll
+    for (int s = 0; s < (PROCJF ? kNumSums : 1); s++) {
+        double v = sums[s];
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+        if (lane == 0) s_red[wave][s] = v;
+    }
+    __syncthreads();
+    if (tid < nsum) {
+        const double v = ((s_red[0][tid] + s_red[1][tid]) + s_red[2][tid]) + s_red[3][tid];
+        a.partials[((size_t)seq * a.nblk + blk) * kNumSums + (PROCJF ? tid : kNumSums - 1)] = v;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------
+// 6x6 linear algebra for the LM step (single lane)
+// ---------------------------------------------------------------------------------------------------
+// Symmetric eigen-decomposition by cyclic Jacobi; A = V diag(e) V^T.  Stands in for LAPACK dgesvd_ behind
+// TooN::SVD<> (for a symmetric matrix singular values = |e|, U = V*sign(e)).
+__device__ inline void jacobi_eig6(const double Ain[36], double V[36], double e[6]) {
+    double A[36];
+    for (int i = 0; i < 36; i++) { A[i] = Ain[i]; V[i] = 0; }
+    for (int i = 0; i < 6; i++) V[i * 7] = 1;
+    for (int sweep = 0; sweep < 30; sweep++) {
+        double off = 0, diag = 0;
+        for (int p = 0; p < 6; p++) {
+            diag += A[p * 7] * A[p * 7];
+            for (int q = p + 1; q < 6; q++) off += A[p * 6 + q] * A[p * 6 + q];
+        }
+        if (!(off > 1e-60 * diag) || !(off > 0)) break;
+        for (int p = 0; p < 5; p++)
+            for (int q = p + 1; q < 6; q++) {
+                const double apq = A[p * 6 + q];
+                if (apq == 0) continue;
+                const double theta = (A[q * 7] - A[p * 7]) / (2 * apq);
+                const double t = (theta >= 0 ? 1.0 : -1.0) / (fabs(theta) + sqrt(theta * theta + 1));
+                const double c = 1 / sqrt(t * t + 1), s = t * c;
+                for (int k = 0; k < 6; k++) {
+                    const double akp = A[k * 6 + p], akq = A[k * 6 + q];
+                    A[k * 6 + p] = c * akp - s * akq;
+                    A[k * 6 + q] = s * akp + c * akq;
+                }
+                for (int k = 0; k < 6; k++) {
+                    const double apk = A[p * 6 + k], aqk = A[q * 6 + k];
+                    A[p * 6 + k] = c * apk - s * aqk;
+                    A[q * 6 + k] = s * apk + c * aqk;
+                }
+                for (int k = 0; k < 6; k++) {
+                    const double vkp = V[k * 6 + p], vkq = V[k * 6 + q];
+                    V[k * 6 + p] = c * vkp - s * vkq;
+                    V[k * 6 + q] = s * vkp + c * vkq;
+                }
+            }
+    }
+    for (int i = 0; i < 6; i++) e[i] = A[i * 7];
+}
+
+// h = SVD(A).backsub(b) with TooN's conditioning (SVD.h:176-196, 264-272; condition_no = 1e9)
+__device__ inline void svd_backsub6(const double A[36], const double b[6], double h[6]) {
+    double V[36], e[6];
+    jacobi_eig6(A, V, e);
+    double smax = 0;
+    for (int i = 0; i < 6; i++) smax = fmax(smax, fabs(e[i]));
+    double y[6];
+    for (int i = 0; i < 6; i++) {
+        double d = 0;
+        for (int k = 0; k < 6; k++) d += V[k * 6 + i] * b[k];
+        const double inv = (fabs(e[i]) * 1e9 <= smax) ? 0.0 : 1.0 / e[i];
+        y[i] = d * inv;
+    }
+    for (int k = 0; k < 6; k++) {
+        double d = 0;
+        for (int i = 0; i < 6; i++) d += V[k * 6 + i] * y[i];
+        h[k] = d;
+    }
+}
+
+// TooN::Cholesky<6> (LDL^T, Cholesky.h:88-125) and its vector backsub (:131-160)
+__device__ inline void chol6(const double A[36], double L[36]) {
+    for (int i = 0; i < 36; i++) L[i] = A[i];
+    for (int col = 0; col < 6; col++) {
+        double inv_diag = 1;
+        for (int row = col; row < 6; row++) {
+            double val = L[row * 6 + col];
+            for (int col2 = 0; col2 < col; col2++) val -= L[col2 * 6 + col] * L[row * 6 + col2];
+            if (row == col) {
+                L[row * 6 + col] = val;
+                if (val == 0) return;  // rank deficient: TooN stops here
+                inv_diag = 1 / val;
+            } else {
+                L[col * 6 + row] = val;
+                L[row * 6 + col] = val * inv_diag;
+            }
+        }
+    }
+}
+__device__ inline void chol6_backsub(const double L[36], const double v[6], double r[6]) {
+    double y[6];
+    for (int i = 0; i < 6; i++) {
+        double val = v[i];
+        for (int j = 0; j < i; j++) val -= L[i * 6 + j] * y[j];
+        y[i] = val;
+    }
+    for (int i = 0; i < 6; i++) y[i] /= L[i * 7];
+    for (int i = 5; i >= 0; i--) {
+        double val = y[i];
+        for (int j = i + 1; j < 6; j++) val -= L[j * 6 + i] * r[j];
+        r[i] = val;
+    }
+}
+// matrix backsub of the identity: get_inverse() (Cholesky.h:165-200); note y[i] *= (1/d) here, not y[i] /= d
+__device__ inline void chol6_inverse(const double L[36], double Inv[36]) {
+    for (int c = 0; c < 6; c++) {
+        double y[6], r[6];
+        for (int i = 0; i < 6; i++) {
+            double val = (i == c) ? 1.0 : 0.0;
+            for (int j = 0; j < i; j++) val -= L[i * 6 + j] * y[j];
+            y[i] = val;
+        }
+        for (int i = 0; i < 6; i++) y[i] *= (1 / L[i * 7]);
+        for (int i = 5; i >= 0; i--) {
+            double val = y[i];
+            for (int j = i + 1; j < 6; j++) val -= L[j * 6 + i] * r[j];
+            r[i] = val;
+        }
+        for (int i = 0; i < 6; i++) Inv[i * 6 + c] = r[i];
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------
+// k_lm_step: everything Minimizer_RV does between two TryVelRot evaluations (global_tracker.cpp:631-816).
+// The host knows the (static) call sequence and passes it as a bit mask of operations.
+// ---------------------------------------------------------------------------------------------------
+enum LmOps : unsigned {
+    LM_REDUCE_CUR = 1u << 0,   // partials -> F, JtJ, JtF
+    LM_REDUCE_NEW = 1u << 1,   // partials -> Fnew, JtJnew, JtFnew
+    LM_NOJAC = 1u << 2,        // the evaluation had ProcJF=false (score only)
+    LM_INIT = 1u << 3,         // F0 = F; u = tau*max(JtJ)
+    LM_RESET_V = 1u << 4,      // v = 2
+    LM_GAIN_RATIO = 1u << 5,   // gain = (F-Fnew)/(0.5*h*(u*h-JtF)); accept / reject
+    LM_GAIN_DIFF = 1u << 6,    // gain = F-Fnew; accept / reject
+    LM_SWAP_ON_ACCEPT = 1u << 7,
+    LM_SAVE_T = 1u << 8,       // stash zero-init result, restart from the prior (Vel, W0)
+    LM_PICK = 1u << 9,         // keep the better of the two initialisations, swap residual buffers
+    LM_SOLVE_SVD = 1u << 10,
+    LM_SOLVE_CHOL = 1u << 11,
+    LM_SETUP_X = 1u << 12,     // next evaluation at X
+    LM_SETUP_XNEW = 1u << 13,  // next evaluation at Xnew
+    LM_FINISH = 1u << 14,
+    LM_BEGIN = 1u << 15,       // start of a minimisation (init state, X from init_type)
+    LM_PHASE_A = 1u << 16,     // next evaluation writes Rest (zero-init trial of init_type 2)
+    LM_PHASE_BC = 1u << 17,    // next evaluation writes ResidualNew
+};
+
+struct LmArgs {
+    SeqDev *seq;
+    const double *partials;   // [B][nblk][kNumSums]
+    const double *block_last; // [B][nblk]
+    double *resid_carry;      // [kResidBufs][B][nblk]
+    uint32_t *framecount;     // [B] of the new slot
+    int nblk, nseq;
+    unsigned ops;
+    int init_type;
+};
+
+__global__ __launch_bounds__(64) void k_lm_step(LmArgs a) {
+    const int seq = blockIdx.x;
+    SeqDev *sq = a.seq + seq;
+    const int lane = threadIdx.x;
+    const unsigned ops = a.ops;
+    const int kn = sq->kn_old;
+    if (ops & LM_BEGIN) {
+        if (lane == 0) {
+            sq->eff_steps = 0;
+            sq->v = 2;
+            sq->res_cur = 0; sq->res_new = 1; sq->res_t = 2;
+            sq->pub.minimizer_evals = 0;
+            if (a.init_type == 1) {
+                for (int i = 0; i < 3; i++) { sq->X[i] = sq->pub.V[i]; sq->X[3 + i] = sq->pub.W[i]; }
+            } else {
+                for (int i = 0; i < 6; i++) sq->X[i] = 0;
+            }
+            sq->s_rho_min_eval = sq->pub.s_rho_q;
+        }
+    }
+    if (kn <= 0) return;  // Minimizer_RV returns immediately on an empty list (global_tracker.cpp:597-598)
+    const int nblk_used = (kn + kTvrBlock - 1) / kTvrBlock;
+
+    // ---- finish the reduction of the evaluation that just ran (fixed order: deterministic) ----
+    __shared__ double s_sum[kNumSums];
+    if (ops & (LM_REDUCE_CUR | LM_REDUCE_NEW)) {
+        const double *pp = a.partials + (size_t)seq * a.nblk * kNumSums;
+        if (lane < kNumSums) {
+            double s = 0;
+            if (!(ops & LM_NOJAC) || lane == kNumSums - 1)
+                for (int b = 0; b < nblk_used; b++) s += pp[(size_t)b * kNumSums + lane];
+            s_sum[lane] = s;
+        }
+        // resolve the per-block residual carries of the buffer that was just written
+        if (lane == 32) {
+            const int res_out = sq->lm_phase == 0 ? sq->res_t : sq->res_new;
+            double *cr = a.resid_carry + ((size_t)res_out * a.nseq + seq) * a.nblk;
+            const double *bl = a.block_last + (size_t)seq * a.nblk;
+            double run = 0;  // T fi=0 at the top of TryVelRot
+            for (int b = 0; b < nblk_used; b++) {
+                cr[b] = run;
+                const double v = bl[b];
+                if (!is_carry(v)) run = v;
+            }
+        }
+    }
+    __syncthreads();
+    if (lane != 0) return;
+
+    if (ops & (LM_REDUCE_CUR | LM_REDUCE_NEW)) {
+        double *JtJ = (ops & LM_REDUCE_CUR) ? sq->JtJ : sq->JtJnew;
+        double *JtF = (ops & LM_REDUCE_CUR) ? sq->JtF : sq->JtFnew;
+        if (!(ops & LM_NOJAC)) {
+            int ns = 0;
+            for (int i = 0; i < 6; i++)
+                for (int j = i; j < 6; j++) JtJ[i * 6 + j] = s_sum[ns++];
+            for (int i = 0; i < 6; i++) JtF[i] = s_sum[ns++];
+            for (int i = 0; i < 2; i++) {  // sign fix-ups, global_tracker.cpp:484-490
+                JtF[i + 2] = -JtF[i + 2];
+                for (int j = 0; j < 2; j++) {
+                    JtJ[(i + 0) * 6 + j + 2] = -JtJ[(i + 0) * 6 + j + 2];
+                    JtJ[(i + 2) * 6 + j + 4] = -JtJ[(i + 2) * 6 + j + 4];
+                }
+            }
+            for (int i = 0; i < 6; i++)
+                for (int j = i + 1; j < 6; j++) JtJ[j * 6 + i] = JtJ[i * 6 + j];
+        }
+        if (ops & LM_REDUCE_CUR) sq->F = s_sum[kNumSums - 1]; else sq->Fnew = s_sum[kNumSums - 1];
+        sq->pub.minimizer_evals++;
+    }
+    const double tau = 1e-3;
+    if (ops & LM_INIT) {
+        sq->F0 = sq->F;
+        double mx = sq->JtJ[0];
+        for (int i = 1; i < 36; i++) mx = sq->JtJ[i] > mx ? sq->JtJ[i] : mx;  // TooN::max_element(JtJ).first
+        sq->u = tau * mx;
+    }
+    if (ops & LM_RESET_V) sq->v = 2;
+    if (ops & (LM_GAIN_RATIO | LM_GAIN_DIFF)) {
+        double gain;
+        if (ops & LM_GAIN_DIFF) gain = sq->F - sq->Fnew;
+        else {
+            double den = 0;  // (0.5*h) * (u*h - JtF)
+            for (int i = 0; i < 6; i++) den += (0.5 * sq->h[i]) * (sq->u * sq->h[i] - sq->JtF[i]);
+            gain = (sq->F - sq->Fnew) / den;
+        }
+        sq->gain = gain;
+        if (gain > 0) {
+            sq->F = sq->Fnew;
+            for (int i = 0; i < 6; i++) { sq->X[i] = sq->Xnew[i]; sq->JtF[i] = sq->JtFnew[i]; }
+            for (int i = 0; i < 36; i++) sq->JtJ[i] = sq->JtJnew[i];
+            const double g = 2 * gain - 1;
+            const double m = 1 - (g * g * g);
+            sq->u *= (0.33 > m ? 0.33 : m);   // std::max(0.33, ...)
+            sq->v = 2;
+            sq->eff_steps++;
+            if (ops & LM_SWAP_ON_ACCEPT) { const int t = sq->res_new; sq->res_new = sq->res_cur; sq->res_cur = t; }
+        } else {
+            sq->u *= sq->v;
+            sq->v *= 2;
+        }
+    }
+    if (ops & LM_SAVE_T) {
+        for (int i = 0; i < 6; i++) sq->Xt[i] = sq->X[i];
+        sq->Ft = sq->F; sq->F0t = sq->F0; sq->ut = sq->u; sq->vt = sq->v; sq->eff_steps_t = sq->eff_steps;
+        sq->eff_steps = 0;
+        for (int i = 0; i < 3; i++) { sq->X[i] = sq->pub.V[i]; sq->X[3 + i] = sq->pub.W[i]; }
+    }
+    if (ops & LM_PICK) {
+        if (sq->F > sq->Ft) {
+            for (int i = 0; i < 6; i++) sq->X[i] = sq->Xt[i];
+            sq->F = sq->Ft; sq->F0 = sq->F0t; sq->u = sq->ut; sq->v = sq->vt; sq->eff_steps = sq->eff_steps_t;
+            const int t = sq->res_new; sq->res_new = sq->res_t; sq->res_t = t;   // ResidualNew = Rest
+        }
+        const int t = sq->res_new; sq->res_new = sq->res_cur; sq->res_cur = t;       // std::swap
+    }
+    if (ops & (LM_SOLVE_SVD | LM_SOLVE_CHOL)) {
+        double ApI[36], nb[6];
+        for (int i = 0; i < 36; i++) ApI[i] = sq->JtJ[i];
+        for (int i = 0; i < 6; i++) { ApI[i * 7] = sq->JtJ[i * 7] + 1.0 * sq->u; nb[i] = -sq->JtF[i]; }
+        if (ops & LM_SOLVE_SVD) svd_backsub6(ApI, nb, sq->h);
+        else {
+            double L[36];
+            chol6(ApI, L);
+            chol6_backsub(L, nb, sq->h);
+        }
+        for (int i = 0; i < 6; i++) sq->Xnew[i] = sq->X[i] + sq->h[i];
+    }
+    if (ops & LM_PHASE_A) sq->lm_phase = 0;
+    if (ops & LM_PHASE_BC) sq->lm_phase = 1;
+    if (ops & LM_SETUP_X) tvr_setup(sq, sq->X);
+    if (ops & LM_SETUP_XNEW) tvr_setup(sq, sq->Xnew);
+    if (ops & LM_FINISH) {
+        double L[36], Inv[36];
+        chol6(sq->JtJ, L);
+        chol6_inverse(L, Inv);
+        for (int i = 0; i < 3; i++) { sq->pub.V[i] = sq->X[i]; sq->pub.W[i] = sq->X[3 + i]; }
+        for (int i = 0; i < 3; i++)
+            for (int j = 0; j < 3; j++) {
+                sq->pub.P_V[i * 3 + j] = Inv[i * 6 + j];
+                sq->pub.P_W[i * 3 + j] = Inv[(i + 3) * 6 + j + 3];
+            }
+        if (sq->eff_steps > 0) {
+            double nh = 0, nx = 0;
+            for (int i = 0; i < 6; i++) { nh += sq->h[i] * sq->h[i]; nx += sq->X[i] * sq->X[i]; }
+            sq->pub.rel_error = sqrt(nh) / (sqrt(nx) + 1e-30);
+            sq->pub.rel_error_score = sq->F / sq->F0;
+        } else {
+            sq->pub.rel_error = 1e20;
+            sq->pub.rel_error_score = 1e20;
+        }
+        sq->pub.score = sq->F;
+        a.framecount[seq]++;
+    }
+}
+
+// standalone evaluation helper: X given by the host -> setup
+__global__ void k_tvr_setup_from_host(SeqDev *seqs, const double *__restrict__ X, const double *__restrict__ smin, int nseq,
+                                      int res_in, int res_out) {
+    const int seq = blockIdx.x * blockDim.x + threadIdx.x;
+    if (seq >= nseq) return;
+    SeqDev *sq = seqs + seq;
+    double x[6];
+    for (int i = 0; i < 6; i++) x[i] = X[seq * 6 + i];
+    tvr_setup(sq, x);
+    sq->s_rho_min_eval = smin[seq];
+    sq->res_cur = res_in < 0 ? 0 : res_in;
+    sq->res_new = res_out;
+    sq->lm_phase = 1;
+}
+
+// ---------------------------------------------------------------------------------------------------
+// host side
+// ---------------------------------------------------------------------------------------------------
+int quantile_enqueue(edgehip_ctx *c, int slot, double smin, double smax, double pct, int nbins) {
+    ProfScope ps(c, PROF_B_QUANTILE);
+    if (nbins < 1 || nbins > 256) { set_error("quantile: 1 <= nbins <= 256"); return EDGEHIP_ERR_ARG; }
+    hipLaunchKernelGGL(k_quantile, dim3(c->plan.nseq), dim3(256), 0, c->stream, kldev(c, slot),
+                       c->kn_slot + (size_t)slot * c->plan.nseq, c->seq, smin, smax, pct, nbins);
+    EH_LAUNCH_CHECK();
+    return 0;
+}
+
+int build_field_enqueue(edgehip_ctx *c, int slot, int radius, float min_mod) {
+    ProfScope ps(c, PROF_B_FIELD);
+    const DevicePlan &pl = c->plan;
+    if (radius < 1 || radius > 255) { set_error("build_field: 1 <= radius <= 255"); return EDGEHIP_ERR_ARG; }
+    c->field_radius = radius;
+    EH_CHECK(hipMemsetAsync(c->field, 0xFF, sizeof(uint32_t) * pl.nseq * pl.n, c->stream));
+    const long long threads = (long long)pl.cap * 2 * radius;
+    hipLaunchKernelGGL(k_field_scatter, dim3((unsigned)((threads + 255) / 256), 1, pl.nseq), dim3(256), 0, c->stream,
+                       kldev(c, slot), c->kn_slot + (size_t)slot * pl.nseq, c->retuned_slot + (size_t)slot * pl.nseq,
+                       c->field, pl.w, pl.h, (size_t)pl.n, radius, min_mod);
+    EH_LAUNCH_CHECK();
+    return 0;
+}
+
+int tvr_prepare_enqueue(edgehip_ctx *c, int slot_old) {
+    ProfScope ps(c, PROF_B_PREP);
+    const DevicePlan &pl = c->plan;
+    hipLaunchKernelGGL(k_tvr_prepare, dim3(c->nblk_tvr, 1, pl.nseq), dim3(256), 0, c->stream, kldev(c, slot_old),
+                       c->kn_slot + (size_t)slot_old * pl.nseq, c->P0, c->resid, c->resid_carry, c->seq, pl.cap,
+                       c->nblk_tvr, pl.zfm);
+    EH_LAUNCH_CHECK();
+    return 0;
+}
+
+static TvrArgs make_tvr_args(edgehip_ctx *c, int slot_new, int slot_old, double match_thresh, double k_huber,
+                             uint32_t match_num_thresh, int write_mid) {
+    const DevicePlan &pl = c->plan;
+    TvrArgs a;
+    a.kl_old = kldev(c, slot_old); a.kl_new = kldev(c, slot_new);
+    a.kn_old = c->kn_slot + (size_t)slot_old * pl.nseq;
+    a.field = c->field; a.P0 = c->P0; a.resid = c->resid; a.resid_carry = c->resid_carry;
+    a.block_last = c->block_last; a.partials = c->partials; a.seq = c->seq;
+    a.framecount = c->framecount + (size_t)slot_new * pl.nseq;
+    a.w = pl.w; a.h = pl.h; a.cap = pl.cap; a.nblk = c->nblk_tvr; a.nseq = pl.nseq; a.n = pl.n;
+    a.zfm = pl.zfm; a.max_r = (double)c->field_radius; a.match_thresh = match_thresh; a.k_huber = k_huber;
+    a.ppx = pl.ppx; a.ppy = pl.ppy; a.match_num_thresh = match_num_thresh; a.write_mid = write_mid;
+    return a;
+}
+
+static int launch_tvr(edgehip_ctx *c, const TvrArgs &a, bool reweight, bool procjf) {
+    ProfScope ps(c, PROF_B_TRYVELROT);
+    dim3 g(c->nblk_tvr, 1, c->plan.nseq), b(kTvrBlock);
+    if (reweight && procjf) hipLaunchKernelGGL((k_try_velrot<true, true>), g, b, 0, c->stream, a);
+    else if (reweight) hipLaunchKernelGGL((k_try_velrot<true, false>), g, b, 0, c->stream, a);
+    else if (procjf) hipLaunchKernelGGL((k_try_velrot<false, true>), g, b, 0, c->stream, a);
+    else hipLaunchKernelGGL((k_try_velrot<false, false>), g, b, 0, c->stream, a);
+    EH_LAUNCH_CHECK();
+    return 0;
+}
+
+static int launch_lm(edgehip_ctx *c, int slot_new, unsigned ops) {
+    ProfScope ps(c, PROF_B_LMSTEP);
+    LmArgs a;
+    a.seq = c->seq; a.partials = c->partials; a.block_last = c->block_last; a.resid_carry = c->resid_carry;
+    a.framecount = c->framecount + (size_t)slot_new * c->plan.nseq;
+    a.nblk = c->nblk_tvr; a.nseq = c->plan.nseq; a.ops = ops; a.init_type = c->p.tracker_init_type;
+    hipLaunchKernelGGL(k_lm_step, dim3(c->plan.nseq), dim3(64), 0, c->stream, a);
+    EH_LAUNCH_CHECK();
+    return 0;
+}
+
+// Minimizer_RV<double,false>: the static evaluation/step schedule of global_tracker.cpp:631-816
+int minimizer_enqueue(edgehip_ctx *c, int slot_new, int slot_old) {
+    const edgehip_params &p = c->p;
+    int e;
+    if ((e = tvr_prepare_enqueue(c, slot_old))) return e;
+    const int I = p.tracker_init_iter_num, M = p.tracker_iter_num;
+    const int total_evals = (p.tracker_init_type >= 2 ? 2 * (1 + (I > 0 ? I : 0)) : 0) + 1 + (M > 0 ? M : 0);
+    int evals = 0;
+    auto eval = [&](bool rw, bool jf) -> int {
+        evals++;
+        TvrArgs a = make_tvr_args(c, slot_new, slot_old, p.tracker_match_thresh, p.reweight_distance, p.match_num_thresh,
+                                  evals == total_evals);
+        return launch_tvr(c, a, rw, jf);
+    };
+#define EH_TRY(x) if ((e = (x)) != 0) return e
+    if (p.tracker_init_type >= 2) {
+        for (int trial = 0; trial < 2; trial++) {
+            const unsigned phase = trial == 0 ? LM_PHASE_A : LM_PHASE_BC;
+            if (trial == 0) EH_TRY(launch_lm(c, slot_new, LM_BEGIN | LM_SETUP_X | phase));
+            EH_TRY(eval(false, true));
+            unsigned ops = LM_REDUCE_CUR | LM_INIT | (trial == 1 ? LM_RESET_V : 0);
+            if (I > 0) ops |= LM_SOLVE_SVD | LM_SETUP_XNEW;
+            unsigned tail = trial == 0 ? (LM_SAVE_T | LM_SETUP_X | LM_PHASE_BC) : (LM_PICK | LM_SETUP_X);
+            if (I <= 0) ops |= tail;
+            EH_TRY(launch_lm(c, slot_new, ops));
+            for (int i = 0; i < I; i++) {
+                const bool last = (i == I - 1);
+                EH_TRY(eval(false, !last));
+                ops = LM_REDUCE_NEW | (last ? (LM_NOJAC | LM_GAIN_DIFF) : LM_GAIN_RATIO);
+                if (!last) ops |= LM_SOLVE_SVD | LM_SETUP_XNEW;
+                else ops |= tail;
+                EH_TRY(launch_lm(c, slot_new, ops));
+            }
+        }
+    } else {
+        EH_TRY(launch_lm(c, slot_new, LM_BEGIN | LM_SETUP_X | LM_PHASE_BC));
+    }
+    // reweighted Levenberg-Marquardt
+    EH_TRY(eval(true, true));
+    {
+        unsigned ops = LM_REDUCE_CUR | LM_INIT | LM_RESET_V;
+        if (M > 0) ops |= LM_SOLVE_CHOL | LM_SETUP_XNEW; else ops |= LM_FINISH;
+        EH_TRY(launch_lm(c, slot_new, ops));
+    }
+    for (int it = 0; it < M; it++) {
+        EH_TRY(eval(true, true));
+        unsigned ops = LM_REDUCE_NEW | LM_GAIN_RATIO | LM_SWAP_ON_ACCEPT;
+        if (it < M - 1) ops |= LM_SOLVE_CHOL | LM_SETUP_XNEW; else ops |= LM_FINISH;
+        EH_TRY(launch_lm(c, slot_new, ops));
+    }
+#undef EH_TRY
+    return 0;
+}
+
+}  // namespace edgehip
+
 using namespace edgehip;
+
 extern "C" {
-int edgehip_quantile(edgehip_ctx *c, int slot, double a, double b, double p, int n) { return quantile_enqueue(c, slot, a, b, p, n); }
-int edgehip_build_field(edgehip_ctx *c, int slot, int r, float m) { return build_field_enqueue(c, slot, r, m); }
-int edgehip_try_velrot(edgehip_ctx *, int, int, const double *, int, int, double, const double *, uint32_t, double, int, int, double *) { return EDGEHIP_ERR_STATE; }
-int edgehip_download_resid(edgehip_ctx *, int, double *) { return EDGEHIP_ERR_STATE; }
-int edgehip_minimizer_rv(edgehip_ctx *c, int a, int b) { return minimizer_enqueue(c, a, b); }
+
+int edgehip_quantile(edgehip_ctx *c, int slot, double a, double b, double pct, int n) {
+    if (!c || slot < 0 || slot >= c->plan.nslots) return EDGEHIP_ERR_ARG;
+    return quantile_enqueue(c, slot, a, b, pct, n);
 }
+int edgehip_build_field(edgehip_ctx *c, int slot, int r, float m) {
+    if (!c || slot < 0 || slot >= c->plan.nslots) return EDGEHIP_ERR_ARG;
+    return build_field_enqueue(c, slot, r, m);
+}
+
+int edgehip_try_velrot(edgehip_ctx *c, int slot_new, int slot_old, const double *X, int reweight, int procjf,
+                       double match_thresh, const double *s_rho_min, uint32_t match_num_thresh, double k_huber,
+                       int resid_in, int resid_out, double *out) {
+    if (!c || !X || !s_rho_min || !out || slot_new < 0 || slot_old < 0 || slot_new >= c->plan.nslots ||
+        slot_old >= c->plan.nslots || resid_in >= kResidBufs || resid_out < 0 || resid_out >= kResidBufs) {
+        set_error("try_velrot: bad argument");
+        return EDGEHIP_ERR_ARG;
+    }
+    const int B = c->plan.nseq;
+    int e;
+    // P0 is rebuilt every call (the old slot may have been edited through upload_keylines)
+    if (resid_in < 0) {
+        if ((e = tvr_prepare_enqueue(c, slot_old))) return e;  // also zeroes buffer 0
+        if (resid_out == 0) { set_error("try_velrot: resid_out 0 is the zero buffer when resid_in < 0"); return EDGEHIP_ERR_ARG; }
+    } else {
+        // keep residual buffers; only refresh P0/kn_old: prepare writes resid0, so save/restore is avoided by
+        // launching prepare with a scratch destination when buffer 0 is live
+        const DevicePlan &pl = c->plan;
+        hipLaunchKernelGGL(k_tvr_prepare, dim3(c->nblk_tvr, 1, pl.nseq), dim3(256), 0, c->stream, kldev(c, slot_old),
+                           c->kn_slot + (size_t)slot_old * pl.nseq, c->P0, c->rs_tmp /*scratch*/, c->block_last /*scratch*/,
+                           c->seq, pl.cap, c->nblk_tvr, pl.zfm);
+        EH_LAUNCH_CHECK();
+    }
+    double *dX = c->pinned_out, *dS = c->pinned_out + (size_t)B * 6;
+    memcpy(dX, X, sizeof(double) * 6 * B);
+    memcpy(dS, s_rho_min, sizeof(double) * B);
+    double *devX = c->rs_tmp + (size_t)B * c->plan.cap;  // second half of the scratch
+    EH_CHECK(hipMemcpyAsync(devX, dX, sizeof(double) * 7 * B, hipMemcpyHostToDevice, c->stream));
+    hipLaunchKernelGGL(k_tvr_setup_from_host, dim3((B + 63) / 64), dim3(64), 0, c->stream, c->seq, devX, devX + (size_t)B * 6,
+                       B, resid_in, resid_out);
+    EH_LAUNCH_CHECK();
+    TvrArgs a = make_tvr_args(c, slot_new, slot_old, match_thresh, k_huber, match_num_thresh, 1);
+    if ((e = launch_tvr(c, a, reweight != 0, procjf != 0))) return e;
+    if ((e = launch_lm(c, slot_new, LM_REDUCE_CUR | (procjf ? 0 : LM_NOJAC)))) return e;
+    EH_CHECK(hipMemcpyAsync(c->pinned_seq, c->seq, sizeof(SeqDev) * B, hipMemcpyDeviceToHost, c->stream));
+    EH_CHECK(hipStreamSynchronize(c->stream));
+    for (int s = 0; s < B; s++) {
+        memcpy(out + (size_t)s * 43, c->pinned_seq[s].JtJ, sizeof(double) * 36);
+        memcpy(out + (size_t)s * 43 + 36, c->pinned_seq[s].JtF, sizeof(double) * 6);
+        out[(size_t)s * 43 + 42] = c->pinned_seq[s].F;
+    }
+    return 0;
+}
+
+__global__ void k_resolve_resid(const double *__restrict__ resid, const double *__restrict__ carry, double *__restrict__ out,
+                                int cap, int nblk) {
+    const int seq = blockIdx.z;
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= cap) return;
+    double v = resid[(size_t)seq * cap + i];
+    if (is_carry(v)) v = carry[(size_t)seq * nblk + i / kTvrBlock];
+    out[(size_t)seq * cap + i] = v;
+}
+
+int edgehip_download_resid(edgehip_ctx *c, int which, double *resid) {
+    if (!c || !resid || which < 0 || which >= kResidBufs) return EDGEHIP_ERR_ARG;
+    const DevicePlan &pl = c->plan;
+    hipLaunchKernelGGL(k_resolve_resid, dim3((pl.cap + 255) / 256, 1, pl.nseq), dim3(256), 0, c->stream,
+                       c->resid + (size_t)which * pl.nseq * pl.cap, c->resid_carry + (size_t)which * pl.nseq * c->nblk_tvr,
+                       c->rs_tmp, pl.cap, c->nblk_tvr);
+    EH_LAUNCH_CHECK();
+    EH_CHECK(hipMemcpyAsync(resid, c->rs_tmp, sizeof(double) * pl.nseq * pl.cap, hipMemcpyDeviceToHost, c->stream));
+    EH_CHECK(hipStreamSynchronize(c->stream));
+    return 0;
+}
+
+int edgehip_minimizer_rv(edgehip_ctx *c, int slot_new, int slot_old) {
+    if (!c || slot_new < 0 || slot_old < 0 || slot_new >= c->plan.nslots || slot_old >= c->plan.nslots) return EDGEHIP_ERR_ARG;
+    return minimizer_enqueue(c, slot_new, slot_old);
+}
+
+}  // extern "C"
