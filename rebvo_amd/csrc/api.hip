@@ -240,6 +240,9 @@ int edgehip_create(const edgehip_params *params, int nseq, int nslots, int devic
     EH_TRY(dmalloc(c, &c->fwd_key, B * CAP, al->dev, 0));
     EH_TRY(dmalloc(c, &c->fwd_win, B * CAP, al->dev, 0xFF));
     EH_TRY(dmalloc(c, &c->rs_tmp, B * 2 * CAP, al->dev, 0));
+    EH_TRY(dmalloc(c, &c->rot_buf, B * 9, al->dev, 0));
+    EH_TRY(dmalloc(c, &c->t_buf, B, al->dev, 0));
+    EH_TRY(dmalloc(c, &c->nav_dev, B, al->dev, 0));
 
     // KeyLine SoA arena
     {
@@ -286,6 +289,8 @@ int edgehip_create(const edgehip_params *params, int nseq, int nslots, int devic
         EH_CHECK(hipHostMalloc(&q, c->pinned_rgb_bytes, hipHostMallocDefault)); al->host.push_back(q); c->pinned_rgb = (uint8_t *)q;
         EH_CHECK(hipHostMalloc(&q, sizeof(SeqDev) * B, hipHostMallocDefault)); al->host.push_back(q); c->pinned_seq = (SeqDev *)q;
         EH_CHECK(hipHostMalloc(&q, sizeof(double) * B * 64, hipHostMallocDefault)); al->host.push_back(q); c->pinned_out = (double *)q;
+        EH_CHECK(hipHostMalloc(&q, sizeof(double) * B * 8, hipHostMallocDefault)); al->host.push_back(q); c->pinned_t = (double *)q;
+        EH_CHECK(hipHostMalloc(&q, sizeof(edgehip_nav) * B, hipHostMallocDefault)); al->host.push_back(q); c->pinned_nav = (edgehip_nav *)q;
     }
     for (size_t i = 0; i < B; i++) init_state(p, &c->pinned_seq[i]);
     EH_CHECK(hipMemcpyAsync(c->seq, c->pinned_seq, sizeof(SeqDev) * B, hipMemcpyHostToDevice, c->stream));
@@ -314,6 +319,20 @@ int edgehip_destroy(edgehip_ctx *c) {
     }
     (void)hipStreamDestroy(c->stream);
     delete c;
+    return 0;
+}
+
+int edgehip_reset(edgehip_ctx *c) {
+    if (!c) return EDGEHIP_ERR_ARG;
+    const size_t B = c->plan.nseq, S = c->plan.nslots;
+    EH_CHECK(hipStreamSynchronize(c->stream));
+    for (size_t i = 0; i < B; i++) init_state(c->p, &c->pinned_seq[i]);
+    EH_CHECK(hipMemcpyAsync(c->seq, c->pinned_seq, sizeof(SeqDev) * B, hipMemcpyHostToDevice, c->stream));
+    EH_CHECK(hipMemsetAsync(c->framecount, 0, sizeof(uint32_t) * S * B, c->stream));
+    EH_CHECK(hipMemsetAsync(c->kn_slot, 0, sizeof(int32_t) * S * B, c->stream));
+    EH_CHECK(hipStreamSynchronize(c->stream));
+    c->frame_slot = -1;
+    c->frames_seen = 0;
     return 0;
 }
 

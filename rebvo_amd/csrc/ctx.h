@@ -60,6 +60,10 @@ struct SeqDev {
     double s_rho_min_eval;     // s_rho threshold of the running evaluation
     double Rt[9], Vt[3], RM[4];  // rotation / translation / z-rotation of the running evaluation
     int32_t nmatch_tmp, kf_tmp;
+    // per-frame glue (SecondThread locals)
+    int32_t skip_match, skip_map;   // NaN estimate / too few matches: later stages are no-ops
+    double t_cur;
+    double V_track[3], W_track[3], PV_track[9], PW_track[9];  // tracker output before any reset
 };
 
 struct DevicePlan {  // everything a kernel needs that is constant for the context
@@ -113,11 +117,16 @@ struct edgehip_ctx {
     unsigned long long *fwd_key;  // [B][CAP] forward-match arbitration keys
     int32_t *fwd_win;      // [B][CAP]
     double *rs_tmp;        // [B][2][CAP] regularised (rho, s_rho) ping-pong
+    double *rot_buf;       // [B][9] rotation applied by rotate_keylines
+    double *t_buf;         // [B] frame time stamps
+    edgehip_nav *nav_dev;  // [B] per-frame record
     // host staging
     uint8_t *pinned_rgb;   // [B][N*3]
     size_t pinned_rgb_bytes;
     edgehip::SeqDev *pinned_seq;  // [B]
     double *pinned_out;    // misc readback
+    double *pinned_t;      // [8][B]
+    edgehip_nav *pinned_nav;  // [B]
     edgehip::Profiler *prof;
 };
 

@@ -1,23 +1,707 @@
-// stage_c.hip — matching + mapping (placeholder)
+// stage_c.hip — matching and mapping: forward match, KeyLine rotation, directed (epipolar) matching,
+// depth regularisation, the per-KeyLine inverse-depth EKF, rescaling, and the per-frame driver that strings
+// stage A/B/C together without host synchronisation.
+//
+// Replaces (reference file:line)
+//   edge_tracker::FordwardMatch              src/mtracklib/edge_tracker.cpp:380-436
+//   edge_tracker::rotate_keylines            edge_tracker.cpp:42-76
+//   edge_tracker::directed_matching/search_match   edge_tracker.cpp:302-374, 158-295
+//   edge_tracker::Regularize_1_iter          edge_tracker.cpp:87-148
+//   edge_tracker::UpdateInverseDepthKalman(ARLU)   edge_tracker.cpp:695-724, 954-1055
+//   edge_tracker::EstimateReScalingOpt       edge_tracker.cpp:1104-1140
+//   REBVO::SecondThread glue (ImuMode==0)    src/rebvo/rebvo_second_t.cpp:145-178, 341-422, 453-487, 550-606
+//
+// Parallel restatements of sequential rules:
+//  * FordwardMatch: several old KeyLines may forward-match the same new KeyLine; sequentially the winner
+//    is the one with the largest rho, the LAST one among equals (:413).  Two atomicMax passes: first on
+//    the order-preserving bit pattern of rho, then on the KeyLine index among those that hold the maximum.
+//  * directed_matching / Regularize / EKF are independent per KeyLine (Regularize reads the PRE-update
+//    neighbour values: its results go through a scratch array before the EKF consumes them).
+
+#include <math.h>
+#include <string.h>
+
 #include "ctx.h"
+
 namespace edgehip {
-int forward_match_enqueue(edgehip_ctx *, int, int) { return EDGEHIP_ERR_STATE; }
-int rotate_enqueue(edgehip_ctx *, int, const double *) { return EDGEHIP_ERR_STATE; }
-int directed_enqueue(edgehip_ctx *, int, int) { return EDGEHIP_ERR_STATE; }
-int regekf_enqueue(edgehip_ctx *, int, int, int) { return EDGEHIP_ERR_STATE; }
-int rescale_enqueue(edgehip_ctx *, int) { return EDGEHIP_ERR_STATE; }
-int pose_enqueue(edgehip_ctx *, int, const double *) { return EDGEHIP_ERR_STATE; }
+
+constexpr double kRhoMax = 20.0, kRhoMin = 1e-3, kRhoInit = 1.0;  // edge_finder.h:38-40
+
+__device__ __forceinline__ unsigned long long ord_bits(double v) {
+    const unsigned long long b = (unsigned long long)__double_as_longlong(v);
+    return (b >> 63) ? ~b : (b | 0x8000000000000000ull);  // monotone map double -> u64, never 0
 }
+
+// ---------------------------------------------------------------------------------------------------
+// FordwardMatch
+// ---------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_fwd_key(const KlSoA *kl_old, const int32_t *__restrict__ kn_old,
+                                                 const int32_t *__restrict__ kn_new, unsigned long long *__restrict__ key,
+                                                 int cap) {
+    const int seq = blockIdx.z, i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= kn_old[seq]) return;
+    const int f = kl_old[seq].m_id_f[i];
+    if (f < 0 || f >= kn_new[seq]) return;
+    atomicMax(&key[(size_t)seq * cap + f], ord_bits(kl_old[seq].rho[i]));
+}
+__global__ __launch_bounds__(256) void k_fwd_win(const KlSoA *kl_old, const int32_t *__restrict__ kn_old,
+                                                 const int32_t *__restrict__ kn_new, const unsigned long long *__restrict__ key,
+                                                 int32_t *__restrict__ win, int cap) {
+    const int seq = blockIdx.z, i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= kn_old[seq]) return;
+    const int f = kl_old[seq].m_id_f[i];
+    if (f < 0 || f >= kn_new[seq]) return;
+    if (key[(size_t)seq * cap + f] == ord_bits(kl_old[seq].rho[i])) atomicMax(&win[(size_t)seq * cap + f], i);
+}
+__global__ __launch_bounds__(256) void k_fwd_apply(const KlSoA *kl_old, const KlSoA *kl_new, const int32_t *__restrict__ kn_new,
+                                                   const int32_t *__restrict__ win, SeqDev *seqs, int cap) {
+    const int seq = blockIdx.z, f = blockIdx.x * 256 + threadIdx.x;
+    int hit = 0;
+    if (f < kn_new[seq]) {
+        const int i = win[(size_t)seq * cap + f];
+        if (i >= 0) {
+            const KlSoA &o = kl_old[seq], &n = kl_new[seq];
+            n.rho[f] = o.rho[i];
+            n.s_rho[f] = o.s_rho[i];
+            n.rho_nr[f] = o.rho_nr[i];
+            n.s_rho_nr[f] = o.s_rho_nr[i];
+            n.m_num[f] = o.m_num[i] + 1;
+            n.m_id[f] = i;
+            n.p_m_0[f] = o.p_m[i];
+            n.m_m0[f] = o.m_m[i];
+            n.n_m0[f] = (double)o.n_m[i];
+            n.m_id_kf[f] = o.m_id_kf[i];
+            hit = 1;
+        }
+    }
+    const int cnt = __popcll(__ballot(hit));
+    if ((threadIdx.x & 63) == 0 && cnt) atomicAdd(&seqs[seq].pub.klm_fwd, cnt);
+}
+
+// ---------------------------------------------------------------------------------------------------
+// rotate_keylines.  R given per sequence (row-major); when from_state != 0 each sequence uses
+// R0 = exp(W) from its state and stores the back-rotation R = R0^T (rebvo_second_t.cpp:360-361).
+// ---------------------------------------------------------------------------------------------------
+__device__ inline void so3_exp_c(const double w[3], double R[9]);
+
+__global__ __launch_bounds__(256) void k_rotate(const KlSoA *kls, const int32_t *__restrict__ kns, const double *__restrict__ Rin,
+                                                double zf) {
+    const int seq = blockIdx.z, i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= kns[seq]) return;
+    const double *R = Rin + (size_t)seq * 9;
+    const KlSoA &k = kls[seq];
+    const float2 pm = k.p_m[i];
+    const double v0 = (double)pm.x / zf, v1 = (double)pm.y / zf, v2 = 1;
+    double q0 = 0, q1 = 0, q2 = 0;  // TooN matrix*vector: row dot products accumulated from 0
+    q0 += R[0] * v0; q0 += R[1] * v1; q0 += R[2] * v2;
+    q1 += R[3] * v0; q1 += R[4] * v1; q1 += R[5] * v2;
+    q2 += R[6] * v0; q2 += R[7] * v1; q2 += R[8] * v2;
+    if (fabs(q2) > 0) {
+        k.p_m[i] = make_float2((float)(q0 / q2 * zf), (float)(q1 / q2 * zf));
+        k.rho[i] = k.rho[i] / q2;
+        k.s_rho[i] = k.s_rho[i] / q2;
+    }
+    const float2 m = k.m_m[i];
+    const double m0 = (double)m.x, m1 = (double)m.y;
+    double r0 = 0, r1 = 0;
+    r0 += R[0] * m0; r0 += R[1] * m1; r0 += R[2] * 0.0;
+    r1 += R[3] * m0; r1 += R[4] * m1; r1 += R[5] * 0.0;
+    const float2 mr = make_float2((float)r0, (float)r1);
+    k.m_m[i] = mr;
+    k.rec[i].m_mx = mr.x;
+    k.rec[i].m_my = mr.y;
+}
+
+// TooN SO3 exp / ln (so3.h:203-285, 288-334), device copies used by the frame glue
+__device__ inline void so3_exp_c(const double w[3], double R[9]) {
+    const double one_6th = 1.0 / 6.0, one_20th = 1.0 / 20.0;
+    const double theta_sq = w[0] * w[0] + w[1] * w[1] + w[2] * w[2];
+    const double theta = sqrt(theta_sq);
+    double A, B;
+    if (theta_sq < 1e-8) { A = 1.0 - one_6th * theta_sq; B = 0.5; }
+    else if (theta_sq < 1e-6) { B = 0.5 - 0.25 * one_6th * theta_sq; A = 1.0 - theta_sq * one_6th * (1.0 - one_20th * theta_sq); }
+    else { const double it = 1.0 / theta; A = sin(theta) * it; B = (1 - cos(theta)) * (it * it); }
+    const double wx2 = w[0] * w[0], wy2 = w[1] * w[1], wz2 = w[2] * w[2];
+    R[0] = 1.0 - B * (wy2 + wz2); R[4] = 1.0 - B * (wx2 + wz2); R[8] = 1.0 - B * (wx2 + wy2);
+    double a = A * w[2], b = B * (w[0] * w[1]);
+    R[1] = b - a; R[3] = b + a;
+    a = A * w[1]; b = B * (w[0] * w[2]);
+    R[2] = b + a; R[6] = b - a;
+    a = A * w[0]; b = B * (w[1] * w[2]);
+    R[5] = b - a; R[7] = b + a;
+}
+
+__device__ inline void so3_ln(const double M[9], double r[3]) {
+    const double cos_angle = (M[0] + M[4] + M[8] - 1.0) * 0.5;
+    r[0] = (M[7] - M[5]) / 2;
+    r[1] = (M[2] - M[6]) / 2;
+    r[2] = (M[3] - M[1]) / 2;
+    const double sin_angle_abs = sqrt(r[0] * r[0] + r[1] * r[1] + r[2] * r[2]);
+    if (cos_angle > M_SQRT1_2) {
+        if (sin_angle_abs > 0) {
+            const double s = asin(sin_angle_abs) / sin_angle_abs;
+            r[0] *= s; r[1] *= s; r[2] *= s;
+        }
+    } else if (cos_angle > -M_SQRT1_2) {
+        const double s = acos(cos_angle) / sin_angle_abs;
+        r[0] *= s; r[1] *= s; r[2] *= s;
+    } else {
+        const double angle = M_PI - asin(sin_angle_abs);
+        const double d0 = M[0] - cos_angle, d1 = M[4] - cos_angle, d2 = M[8] - cos_angle;
+        double r2[3];
+        if (d0 * d0 > d1 * d1 && d0 * d0 > d2 * d2) { r2[0] = d0; r2[1] = (M[3] + M[1]) / 2; r2[2] = (M[2] + M[6]) / 2; }
+        else if (d1 * d1 > d2 * d2) { r2[0] = (M[3] + M[1]) / 2; r2[1] = d1; r2[2] = (M[7] + M[5]) / 2; }
+        else { r2[0] = (M[2] + M[6]) / 2; r2[1] = (M[7] + M[5]) / 2; r2[2] = d2; }
+        if (r2[0] * r[0] + r2[1] * r[1] + r2[2] * r[2] < 0) { r2[0] = -r2[0]; r2[1] = -r2[1]; r2[2] = -r2[2]; }
+        const double nn = sqrt(r2[0] * r2[0] + r2[1] * r2[1] + r2[2] * r2[2]);
+        for (int i = 0; i < 3; i++) r[i] = angle * (r2[i] / nn);
+    }
+}
+
+// R0 = exp(W); Rbuf[seq] = R0 (for k_rotate); state.R = R0^T * I^T ... i.e. R.T() = R0 * R.T() with R = I
+__global__ void k_rot_from_state(SeqDev *seqs, double *__restrict__ Rbuf, int nseq) {
+    const int seq = blockIdx.x * blockDim.x + threadIdx.x;
+    if (seq >= nseq) return;
+    SeqDev *sq = seqs + seq;
+    double R0[9];
+    so3_exp_c(sq->pub.W, R0);
+    for (int i = 0; i < 9; i++) Rbuf[(size_t)seq * 9 + i] = R0[i];
+    for (int i = 0; i < 3; i++)
+        for (int j = 0; j < 3; j++) sq->pub.R[i * 3 + j] = R0[j * 3 + i];
+}
+
+// ---------------------------------------------------------------------------------------------------
+// directed_matching + search_match: thread per NEW KeyLine, walking the OLD mask along the epipolar line
+// ---------------------------------------------------------------------------------------------------
+struct DirArgs {
+    const KlSoA *kl_new, *kl_old;
+    const int32_t *kn_new;
+    const int32_t *mask_old;  // [B][N]
+    SeqDev *seq;
+    int w, h;
+    size_t n;
+    double zfm, min_thr_mod, cang_min_edge, max_radius, loc_unc;
+    float ppx, ppy;
+};
+
+__global__ __launch_bounds__(256) void k_directed(DirArgs a) {
+    const int seq = blockIdx.z, ik = blockIdx.x * 256 + threadIdx.x;
+    SeqDev *sq = a.seq + seq;
+    if (sq->skip_match) return;
+    __shared__ double s_v[3], s_rv[9], s_br[9];
+    if (threadIdx.x == 0) {
+        // Vel = BackRot*Vel; RVel = BackRot*RVel*BackRot.T()  (edge_tracker.cpp:323-324)
+        const double *BR = sq->pub.R, *V = sq->pub.V, *P = sq->pub.P_V;
+        for (int i = 0; i < 9; i++) s_br[i] = BR[i];
+        for (int i = 0; i < 3; i++) {
+            double d = 0;
+            for (int j = 0; j < 3; j++) d += BR[i * 3 + j] * V[j];
+            s_v[i] = d;
+        }
+        double T[9];
+        for (int i = 0; i < 3; i++)
+            for (int j = 0; j < 3; j++) {
+                double d = 0;
+                for (int k = 0; k < 3; k++) d += BR[i * 3 + k] * P[k * 3 + j];
+                T[i * 3 + j] = d;
+            }
+        for (int i = 0; i < 3; i++)
+            for (int j = 0; j < 3; j++) {
+                double d = 0;
+                for (int k = 0; k < 3; k++) d += T[i * 3 + k] * BR[j * 3 + k];
+                s_rv[i * 3 + j] = d;
+            }
+    }
+    __syncthreads();
+    int matched = 0, kfm = 0;
+    if (ik < a.kn_new[seq]) {
+        const KlSoA &kn = a.kl_new[seq], &ko = a.kl_old[seq];
+        const int32_t *mask = a.mask_old + (size_t)seq * a.n;
+        const float2 kpm = kn.p_m[ik];
+        const float2 kmm = kn.m_m[ik];
+        const float knm = kn.n_m[ik];
+        const double krho = kn.rho[ik], ksrho = kn.s_rho[ik];
+        const double zf = a.zfm;
+        double p3[3];
+        for (int i = 0; i < 3; i++) {
+            double d = 0;
+            d += s_br[i * 3 + 0] * (double)kpm.x;
+            d += s_br[i * 3 + 1] * (double)kpm.y;
+            d += s_br[i * 3 + 2] * zf;
+            p3[i] = d;
+        }
+        const float pmx = (float)(p3[0] * zf / p3[2]);
+        const float pmy = (float)(p3[1] * zf / p3[2]);
+        const double k_rho = krho * zf / p3[2];
+        const float pi0x = pmx + a.ppx, pi0y = pmy + a.ppy;
+        double t_x = -(s_v[0] * zf - s_v[2] * (double)pmx);
+        double t_y = -(s_v[1] * zf - s_v[2] * (double)pmy);
+        double norm_t = sqrt(t_x * t_x + t_y * t_y);
+        const double drdv[3] = {zf, zf, (double)(-pmx - pmy)};
+        double row[3];
+        for (int j = 0; j < 3; j++) {
+            double d = 0;
+            for (int i = 0; i < 3; i++) d += drdv[i] * s_rv[i * 3 + j];
+            row[j] = d;
+        }
+        double sigma2_t = 0;
+        for (int j = 0; j < 3; j++) sigma2_t += row[j] * drdv[j];
+
+        double dq_min, dq_max, dq_rho;
+        int t_steps;
+        if (norm_t > 1e-6) {
+            t_x /= norm_t;
+            t_y /= norm_t;
+            dq_rho = norm_t * k_rho;
+            dq_min = fmax(0.0, norm_t * (k_rho - ksrho)) - a.loc_unc;
+            dq_max = fmin(a.max_radius, norm_t * (k_rho + ksrho)) + a.loc_unc;
+            if (dq_rho > dq_max) {
+                dq_rho = (dq_max + dq_min) / 2;
+                t_steps = (int)(dq_rho + 0.5);
+            } else {
+                t_steps = (int)(fmax(dq_max - dq_rho, dq_rho - dq_min) + 0.5);
+            }
+        } else {
+            t_x = (double)kmm.x;
+            t_y = (double)kmm.y;
+            norm_t = (double)knm;
+            t_x /= norm_t;
+            t_y /= norm_t;
+            norm_t = 1;
+            dq_min = -a.max_radius - a.loc_unc;
+            dq_max = a.max_radius + a.loc_unc;
+            dq_rho = 0;
+            t_steps = (int)dq_max;
+        }
+        const double norm_m = (double)knm;
+        double tn = dq_rho, tp = dq_rho + 1;
+        int found = -1;
+        for (int t_i = 0; t_i < t_steps && found < 0; t_i++, tp += 1, tn -= 1) {
+            for (int dir = 0; dir < 2 && found < 0; dir++) {
+                double t;
+                if (dir) { t = tp; if (t > dq_max) continue; }
+                else { t = tn; if (t < dq_min) continue; }
+                const float fx = (float)(t_x * t + (double)pi0x), fy = (float)(t_y * t + (double)pi0y);
+                const int xi = (int)roundf(fx), yi = (int)roundf(fy);
+                if (xi >= a.w || yi >= a.h || xi < 0 || yi < 0) continue;
+                const int j = mask[(size_t)yi * a.w + xi];
+                if (j < 0) continue;
+                const MatchRec r = ko.rec[j];
+                const double norm_m0 = (double)r.n_m;
+                const double cang = (double)(r.m_mx * kmm.x + r.m_my * kmm.y) / (norm_m0 * norm_m);
+                if (cang < a.cang_min_edge || fabs(norm_m0 / norm_m - 1) > a.min_thr_mod) continue;
+                const double s_rho = ko.s_rho[j], rho = ko.rho[j];
+                const double v_rho_dr = (a.loc_unc * a.loc_unc + s_rho * s_rho * norm_t * norm_t + sigma2_t * rho * rho);
+                const double dd = t - norm_t * rho;
+                if (dd * dd > v_rho_dr) continue;
+                found = j;
+            }
+        }
+        if (found >= 0) {
+            const int j = found;
+            kn.rho[ik] = ko.rho[j];
+            kn.s_rho[ik] = ko.s_rho[j];
+            kn.rho_nr[ik] = ko.rho_nr[j];
+            kn.s_rho_nr[ik] = ko.s_rho_nr[j];
+            kn.m_id[ik] = j;
+            kn.m_num[ik] = ko.m_num[j] + 1;
+            kn.p_m_0[ik] = ko.p_m[j];
+            kn.m_m0[ik] = ko.m_m[j];
+            kn.n_m0[ik] = (double)ko.n_m[j];
+            const int mk = ko.m_id_kf[j];
+            kn.m_id_kf[ik] = mk;
+            matched = 1;
+            kfm = mk >= 0;
+        }
+    }
+    const int c1 = __popcll(__ballot(matched)), c2 = __popcll(__ballot(kfm));
+    if ((threadIdx.x & 63) == 0) {
+        if (c1) atomicAdd(&sq->pub.klm_num, c1);
+        if (c2) atomicAdd(&sq->pub.kf_matchs, c2);
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------
+// Regularize_1_iter -> scratch (r, s), then the EKF consumes the scratch
+// ---------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_regularize(const KlSoA *kls, const int32_t *__restrict__ kns, double *__restrict__ rs,
+                                                    const SeqDev *seqs, int cap, double thresh, int enabled) {
+    const int seq = blockIdx.z, i = blockIdx.x * 256 + threadIdx.x;
+    if (seqs[seq].skip_map) return;
+    if (i >= kns[seq]) return;
+    const KlSoA &K = kls[seq];
+    double r = K.rho[i], s = K.s_rho[i];
+    const int ni = K.n_id[i], pi = K.p_id[i];
+    if (enabled && ni >= 0 && pi >= 0) {
+        const double nrho = K.rho[ni], prho = K.rho[pi], nsr = K.s_rho[ni], psr = K.s_rho[pi];
+        const double d = nrho - prho;
+        if (!(d * d > nsr * nsr + psr * psr)) {
+            const float2 nm = K.m_m[ni], pm = K.m_m[pi];
+            // all-float expression converted to double afterwards (edge_tracker.cpp:119)
+            double alpha = (double)((nm.x * pm.x + nm.y * pm.y) / (K.n_m[ni] * K.n_m[pi]));
+            if (!(alpha - thresh < 0)) {
+                alpha = (alpha - thresh) / (1 - thresh);
+                alpha /= fabs(nrho - prho) / (nsr + psr) + 1;
+                const double wr = 1 / (s * s), wrn = alpha / (nsr * nsr), wrp = alpha / (psr * psr);
+                const double r2 = (r * wr + nrho * wrn + prho * wrp) / (wr + wrn + wrp);
+                const double s2 = (s * wr + nsr * wrn + psr * wrp) / (wr + wrn + wrp);
+                r = r2;
+                s = s2;
+            }
+        }
+    }
+    rs[(size_t)seq * 2 * cap + i] = r;
+    rs[(size_t)seq * 2 * cap + cap + i] = s;
+}
+
+__global__ __launch_bounds__(256) void k_ekf(const KlSoA *kls, const int32_t *__restrict__ kns, const double *__restrict__ rs,
+                                             const SeqDev *seqs, int cap, double zf, double q_abs, double loc_unc, int do_ekf) {
+    const int seq = blockIdx.z, i = blockIdx.x * 256 + threadIdx.x;
+    const SeqDev *sq = seqs + seq;
+    if (sq->skip_map) return;
+    if (i >= kns[seq]) return;
+    const KlSoA &K = kls[seq];
+    double rho = rs[(size_t)seq * 2 * cap + i], s_rho = rs[(size_t)seq * 2 * cap + cap + i];
+    if (do_ekf && K.m_id[i] >= 0) {
+        // UpdateInverseDepthKalmanARLU, edge_tracker.cpp:954-1055
+        const double v0 = sq->pub.V[0], v1 = sq->pub.V[1], v2 = sq->pub.V[2];
+        const double s_rho0 = s_rho;
+        const float2 q = K.p_m[i], q0 = K.p_m_0[i], mm0 = K.m_m0[i];
+        const double qx = q.x, qy = q.y, q0x = q0.x, q0y = q0.y;
+        double v_rho = s_rho * s_rho;
+        const double nm0 = K.n_m0[i];
+        const double u_x = (double)mm0.x / nm0, u_y = (double)mm0.y / nm0;
+        const double Y = u_x * (qx - q0x) + u_y * (qy - q0y);
+        const double H = u_x * (v0 * zf - v2 * q0x) + u_y * (v1 * zf - v2 * q0y);
+        const double rho_p = 1 / (1.0 / rho + v2);
+        const double rho0 = rho_p;
+        double F = 1 / (1 + rho * v2);
+        F = F * F;
+        const double p_p = F * v_rho * F + q_abs * q_abs;
+        const double e = Y - H * rho_p;
+        const double S = H * p_p * H + loc_unc * loc_unc;
+        const double Kg = p_p * H * (1 / S);
+        rho = rho_p + (Kg * e);
+        v_rho = (1 - Kg * H) * p_p;
+        s_rho = sqrt(v_rho);
+        if (rho < kRhoMin) {
+            s_rho += kRhoMin - rho;
+            rho = kRhoMin;
+        } else if (rho > kRhoMax) {
+            rho = kRhoMax;
+        } else if (isnan(rho) || isnan(s_rho) || isinf(rho) || isinf(s_rho)) {
+            rho = kRhoInit;
+            s_rho = kRhoMax;
+        } else if (s_rho < 0) {
+            rho = kRhoInit;
+            s_rho = kRhoMax;
+        }
+        K.rho0[i] = rho0;
+        K.s_rho0[i] = s_rho0;
+    }
+    K.rho[i] = rho;
+    K.s_rho[i] = s_rho;
+}
+
+// ---------------------------------------------------------------------------------------------------
+// EstimateReScalingOpt: 5 dependent weighted sums; one block per sequence
+// ---------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(1024) void k_rescale(const KlSoA *kls, const int32_t *__restrict__ kns, SeqDev *seqs,
+                                                  double s_rho_min, unsigned match_num_min, int re_escale) {
+    const int seq = blockIdx.x, tid = threadIdx.x;
+    SeqDev *sq = seqs + seq;
+    if (sq->skip_map) return;
+    const int kn = kns[seq];
+    if (kn <= 0) { if (tid == 0) sq->pub.Kp = 1; return; }
+    const KlSoA &K = kls[seq];
+    __shared__ double s_a[16], s_b[16];
+    __shared__ double s_kp;
+    double Kp = 1, RKp = sq->pub.P_Kp;
+    for (int iter = 0; iter < 5; iter++) {
+        double a = 0, b = 0;
+        for (int i = tid; i < kn; i += 1024) {
+            const double sr0 = K.s_rho0[i], sr = K.s_rho[i];
+            if ((unsigned)K.m_num[i] < match_num_min || sr0 <= 0 || sr > s_rho_min) continue;
+            const double den = sr * sr + Kp * Kp * sr0 * sr0;
+            const double rho = K.rho[i], rho0 = K.rho0[i];
+            a += rho * rho / den;
+            b += rho0 * rho0 / den;
+        }
+        for (int o = 32; o > 0; o >>= 1) { a += __shfl_xor(a, o, 64); b += __shfl_xor(b, o, 64); }
+        if ((tid & 63) == 0) { s_a[tid >> 6] = a; s_b[tid >> 6] = b; }
+        __syncthreads();
+        if (tid == 0) {
+            double ta = 0, tb = 0;
+            for (int k = 0; k < 16; k++) { ta += s_a[k]; tb += s_b[k]; }
+            s_kp = tb > 0 ? sqrt(ta / tb) : 1;
+            s_a[0] = 1 / tb;
+        }
+        __syncthreads();
+        Kp = s_kp;
+        RKp = s_a[0];
+        __syncthreads();
+    }
+    if (re_escale) {
+        for (int i = tid; i < kn; i += 1024) {
+            K.rho[i] = K.rho[i] / Kp;
+            K.s_rho[i] = K.s_rho[i] / Kp;
+        }
+    }
+    if (tid == 0) { sq->pub.Kp = Kp; sq->pub.P_Kp = RKp; }
+}
+
+// ---------------------------------------------------------------------------------------------------
+// per-frame glue of SecondThread (one thread per sequence)
+// ---------------------------------------------------------------------------------------------------
+__device__ inline void ident_scaled(double *M, double s) {
+    for (int i = 0; i < 9; i++) M[i] = 0;
+    M[0] = M[4] = M[8] = s;
+}
+__device__ inline bool any_nan3(const double *v) { return isnan(v[0]) || isnan(v[1]) || isnan(v[2]); }
+
+// mode 0: frame begin (:145-168); 1: after Minimizer+FordwardMatch+rotate (:387-397); 2: after
+// directed_matching (:412-422); 3: pose integration + nav record (:550-606)
+__global__ void k_frame_glue(SeqDev *seqs, const double *__restrict__ t_in, edgehip_nav *__restrict__ nav,
+                             const int32_t *__restrict__ kn_new, int nseq, int mode, double fps, int match_threshold,
+                             int have_pair) {
+    const int seq = blockIdx.x * blockDim.x + threadIdx.x;
+    if (seq >= nseq) return;
+    SeqDev *sq = seqs + seq;
+    edgehip_seq_state &p = sq->pub;
+    if (mode == 0) {
+        const double t = t_in[seq];
+        double dt = t - p.t_prev;
+        if (dt < 0.001) dt = 1 / fps;
+        p.dt = dt;
+        sq->t_cur = t;
+        ident_scaled(p.P_V, 1e50);
+        ident_scaled(p.P_W, 1e50);
+        ident_scaled(p.R, 1);
+        p.klm_fwd = 0; p.klm_num = 0; p.kf_matchs = 0;
+        p.estimation_ok = 1;
+        sq->skip_match = 0;
+        sq->skip_map = 0;
+        p.minimizer_evals = 0;
+    } else if (mode == 1) {
+        for (int i = 0; i < 3; i++) { sq->V_track[i] = p.V[i]; sq->W_track[i] = p.W[i]; }
+        for (int i = 0; i < 9; i++) { sq->PV_track[i] = p.P_V[i]; sq->PW_track[i] = p.P_W[i]; }
+        if (any_nan3(p.V) || any_nan3(p.W)) {
+            ident_scaled(p.P_V, 1e50);
+            p.V[0] = p.V[1] = p.V[2] = 0;
+            p.Kp = 1;
+            p.P_Kp = 1e50;
+            p.estimation_ok = 0;
+            sq->skip_match = 1;
+            sq->skip_map = 1;
+        }
+    } else if (mode == 2) {
+        if (!sq->skip_match && p.klm_num < match_threshold) {
+            ident_scaled(p.P_V, 1e50);
+            p.V[0] = p.V[1] = p.V[2] = 0;
+            p.Kp = 1;
+            p.P_Kp = 10;
+            p.estimation_ok = 0;
+            sq->skip_map = 1;
+        }
+    } else {
+        edgehip_nav &o = nav[seq];
+        if (have_pair) {
+            // Pose = Pose*R; Pos += -Pose*V*K
+            double P2[9];
+            for (int i = 0; i < 3; i++)
+                for (int j = 0; j < 3; j++) {
+                    double d = 0;
+                    for (int k = 0; k < 3; k++) d += p.Pose[i * 3 + k] * p.R[k * 3 + j];
+                    P2[i * 3 + j] = d;
+                }
+            for (int i = 0; i < 9; i++) p.Pose[i] = P2[i];
+            for (int i = 0; i < 3; i++) {
+                double d = 0;
+                for (int k = 0; k < 3; k++) d += (-p.Pose[i * 3 + k]) * p.V[k];
+                p.Pos[i] += d * p.K;
+            }
+            for (int i = 0; i < 9; i++) p.P_V[i] /= p.dt * p.dt;
+        }
+        o.t = sq->t_cur; o.dt = p.dt;
+        for (int i = 0; i < 3; i++) { o.V[i] = sq->V_track[i]; o.W[i] = sq->W_track[i]; }
+        for (int i = 0; i < 9; i++) { o.P_V[i] = sq->PV_track[i]; o.P_W[i] = sq->PW_track[i]; o.Rot[i] = p.R[i]; o.Pose[i] = p.Pose[i]; }
+        so3_ln(p.R, o.RotLie);
+        so3_ln(p.Pose, o.PoseLie);
+        for (int i = 0; i < 3; i++) { o.Vel[i] = -p.V[i] * p.K / p.dt; o.Pos[i] = p.Pos[i]; }
+        o.Kp = p.Kp; o.RKp = p.P_Kp; o.s_rho_q = p.s_rho_q; o.tresh = p.tresh;
+        o.score = p.score; o.rel_error = p.rel_error; o.rel_error_score = p.rel_error_score;
+        o.retuned_thresh = p.retuned_thresh;
+        o.kn = kn_new[seq]; o.klm_fwd = p.klm_fwd; o.klm_num = p.klm_num; o.kf_matchs = p.kf_matchs;
+        o.estimation_ok = have_pair ? p.estimation_ok : 0;
+        o.frame = p.frame; o.minimizer_evals = p.minimizer_evals;
+        p.t_prev = sq->t_cur;
+        p.frame++;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------
+// host side
+// ---------------------------------------------------------------------------------------------------
+int forward_match_enqueue(edgehip_ctx *c, int slot_old, int slot_new) {
+    ProfScope ps(c, PROF_C_FORWARD);
+    const DevicePlan &pl = c->plan;
+    const size_t B = pl.nseq;
+    EH_CHECK(hipMemsetAsync(c->fwd_key, 0, sizeof(unsigned long long) * B * pl.cap, c->stream));
+    EH_CHECK(hipMemsetAsync(c->fwd_win, 0xFF, sizeof(int32_t) * B * pl.cap, c->stream));
+    dim3 g((pl.cap + 255) / 256, 1, pl.nseq), b(256);
+    const int32_t *kno = c->kn_slot + slot_old * B, *knn = c->kn_slot + slot_new * B;
+    hipLaunchKernelGGL(k_fwd_key, g, b, 0, c->stream, kldev(c, slot_old), kno, knn, c->fwd_key, pl.cap);
+    hipLaunchKernelGGL(k_fwd_win, g, b, 0, c->stream, kldev(c, slot_old), kno, knn, c->fwd_key, c->fwd_win, pl.cap);
+    hipLaunchKernelGGL(k_fwd_apply, g, b, 0, c->stream, kldev(c, slot_old), kldev(c, slot_new), knn, c->fwd_win, c->seq, pl.cap);
+    EH_LAUNCH_CHECK();
+    return 0;
+}
+
+int rotate_enqueue(edgehip_ctx *c, int slot, const double *R_host) {
+    ProfScope ps(c, PROF_C_ROTATE);
+    const DevicePlan &pl = c->plan;
+    double *Rbuf = c->rot_buf;
+    if (R_host) {
+        EH_CHECK(hipStreamSynchronize(c->stream));  // pinned_out is reused
+        memcpy(c->pinned_out, R_host, sizeof(double) * 9 * pl.nseq);
+        EH_CHECK(hipMemcpyAsync(Rbuf, c->pinned_out, sizeof(double) * 9 * pl.nseq, hipMemcpyHostToDevice, c->stream));
+    } else {
+        hipLaunchKernelGGL(k_rot_from_state, dim3((pl.nseq + 63) / 64), dim3(64), 0, c->stream, c->seq, Rbuf, pl.nseq);
+    }
+    hipLaunchKernelGGL(k_rotate, dim3((pl.cap + 255) / 256, 1, pl.nseq), dim3(256), 0, c->stream, kldev(c, slot),
+                       c->kn_slot + (size_t)slot * pl.nseq, Rbuf, pl.zfm);
+    EH_LAUNCH_CHECK();
+    return 0;
+}
+
+int directed_enqueue(edgehip_ctx *c, int slot_new, int slot_old) {
+    ProfScope ps(c, PROF_C_DIRECTED);
+    const DevicePlan &pl = c->plan;
+    DirArgs a;
+    a.kl_new = kldev(c, slot_new); a.kl_old = kldev(c, slot_old);
+    a.kn_new = c->kn_slot + (size_t)slot_new * pl.nseq;
+    a.mask_old = maskof(c, slot_old);
+    a.seq = c->seq; a.w = pl.w; a.h = pl.h; a.n = pl.n; a.zfm = pl.zfm;
+    a.min_thr_mod = c->p.match_thresh_module;
+    a.cang_min_edge = cos(c->p.match_thresh_angle * M_PI / 180.0);
+    a.max_radius = (double)c->p.search_range;
+    a.loc_unc = c->p.loc_unc_match;
+    a.ppx = pl.ppx; a.ppy = pl.ppy;
+    hipLaunchKernelGGL(k_directed, dim3((pl.cap + 255) / 256, 1, pl.nseq), dim3(256), 0, c->stream, a);
+    EH_LAUNCH_CHECK();
+    return 0;
+}
+
+int regekf_enqueue(edgehip_ctx *c, int slot, int do_reg, int do_ekf) {
+    ProfScope ps(c, PROF_C_REGEKF);
+    const DevicePlan &pl = c->plan;
+    dim3 g((pl.cap + 255) / 256, 1, pl.nseq), b(256);
+    const int32_t *kn = c->kn_slot + (size_t)slot * pl.nseq;
+    hipLaunchKernelGGL(k_regularize, g, b, 0, c->stream, kldev(c, slot), kn, c->rs_tmp, c->seq, pl.cap,
+                       c->p.regularize_thresh, do_reg);
+    hipLaunchKernelGGL(k_ekf, g, b, 0, c->stream, kldev(c, slot), kn, c->rs_tmp, c->seq, pl.cap, pl.zfm, c->p.reshape_q_abs,
+                       c->p.loc_unc, do_ekf);
+    EH_LAUNCH_CHECK();
+    return 0;
+}
+
+int rescale_enqueue(edgehip_ctx *c, int slot) {
+    ProfScope ps(c, PROF_C_RESCALE);
+    const DevicePlan &pl = c->plan;
+    hipLaunchKernelGGL(k_rescale, dim3(pl.nseq), dim3(1024), 0, c->stream, kldev(c, slot),
+                       c->kn_slot + (size_t)slot * pl.nseq, c->seq, kRhoMax, 1u, c->p.do_rescaling > 0);
+    EH_LAUNCH_CHECK();
+    return 0;
+}
+
+static int glue(edgehip_ctx *c, int mode, int slot_new, int have_pair) {
+    const DevicePlan &pl = c->plan;
+    hipLaunchKernelGGL(k_frame_glue, dim3((pl.nseq + 63) / 64), dim3(64), 0, c->stream, c->seq, c->t_buf, c->nav_dev,
+                       c->kn_slot + (size_t)slot_new * pl.nseq, pl.nseq, mode, c->p.config_fps, c->p.global_match_threshold,
+                       have_pair);
+    EH_LAUNCH_CHECK();
+    return 0;
+}
+
+}  // namespace edgehip
+
 using namespace edgehip;
+
 extern "C" {
-int edgehip_forward_match(edgehip_ctx *c, int a, int b) { return forward_match_enqueue(c, a, b); }
-int edgehip_rotate_keylines(edgehip_ctx *c, int s, const double *R) { return rotate_enqueue(c, s, R); }
-int edgehip_directed_matching(edgehip_ctx *c, int a, int b) { return directed_enqueue(c, a, b); }
-int edgehip_regularize_ekf(edgehip_ctx *c, int s, int r, int e) { return regekf_enqueue(c, s, r, e); }
-int edgehip_rescale(edgehip_ctx *c, int s) { return rescale_enqueue(c, s); }
-int edgehip_process_frame(edgehip_ctx *, const double *) { return EDGEHIP_ERR_STATE; }
+
+static int chk2(edgehip_ctx *c, int a, int b) {
+    if (!c || a < 0 || b < 0 || a >= c->plan.nslots || b >= c->plan.nslots) { set_error("slot out of range"); return EDGEHIP_ERR_ARG; }
+    return 0;
+}
+
+int edgehip_forward_match(edgehip_ctx *c, int slot_old, int slot_new) {
+    if (int e = chk2(c, slot_old, slot_new)) return e;
+    return forward_match_enqueue(c, slot_old, slot_new);
+}
+int edgehip_rotate_keylines(edgehip_ctx *c, int slot, const double *R) {
+    if (int e = chk2(c, slot, slot)) return e;
+    return rotate_enqueue(c, slot, R);
+}
+int edgehip_directed_matching(edgehip_ctx *c, int slot_new, int slot_old) {
+    if (int e = chk2(c, slot_new, slot_old)) return e;
+    return directed_enqueue(c, slot_new, slot_old);
+}
+int edgehip_regularize_ekf(edgehip_ctx *c, int slot, int do_reg, int do_ekf) {
+    if (int e = chk2(c, slot, slot)) return e;
+    return regekf_enqueue(c, slot, do_reg, do_ekf);
+}
+int edgehip_rescale(edgehip_ctx *c, int slot) {
+    if (int e = chk2(c, slot, slot)) return e;
+    return rescale_enqueue(c, slot);
+}
+
 int edgehip_next_slot(edgehip_ctx *c) { return c ? (c->frame_slot + 1) % c->plan.nslots : -1; }
 int edgehip_cur_slot(edgehip_ctx *c) { return c ? c->frame_slot : -1; }
-int edgehip_read_nav(edgehip_ctx *, edgehip_nav *) { return EDGEHIP_ERR_STATE; }
-int edgehip_reset(edgehip_ctx *) { return EDGEHIP_ERR_STATE; }
+
+int edgehip_process_frame(edgehip_ctx *c, const double *t) {
+    if (!c || !t) return EDGEHIP_ERR_ARG;
+    const DevicePlan &pl = c->plan;
+    const int sn = (c->frame_slot + 1) % pl.nslots, so = c->frame_slot;
+    const int have_pair = c->frames_seen >= 1;
+    int e;
+    // time stamps travel through a small ring of pinned slots so that back-to-back frames need no sync
+    double *tp = c->pinned_t + (size_t)(c->frames_seen % 8) * pl.nseq;
+    memcpy(tp, t, sizeof(double) * pl.nseq);
+    EH_CHECK(hipMemcpyAsync(c->t_buf, tp, sizeof(double) * pl.nseq, hipMemcpyHostToDevice, c->stream));
+#define EH_TRY(x) if ((e = (x)) != 0) return e
+    EH_TRY(stage_a_enqueue(c, sn));
+    {
+        ProfScope ps(c, PROF_C_POSE);
+        EH_TRY(glue(c, 0, sn, have_pair));
+    }
+    if (have_pair) {
+        EH_TRY(quantile_enqueue(c, so, kRhoMin, kRhoMax, c->p.qcut_quantile, c->p.qcut_nbins));  // rebvo_second_t.cpp:172
+        EH_TRY(build_field_enqueue(c, sn, c->p.search_range, -1.f));                              // :177
+        EH_TRY(minimizer_enqueue(c, sn, so));                                                    // :346
+        EH_TRY(forward_match_enqueue(c, so, sn));                                                // :354
+        EH_TRY(rotate_enqueue(c, so, nullptr));                                                  // :360-369
+        { ProfScope ps(c, PROF_C_POSE); EH_TRY(glue(c, 1, sn, have_pair)); }                     // :387-397
+        EH_TRY(directed_enqueue(c, sn, so));                                                     // :410
+        { ProfScope ps(c, PROF_C_POSE); EH_TRY(glue(c, 2, sn, have_pair)); }                     // :412-422
+        EH_TRY(regekf_enqueue(c, sn, 1, 1));                                                     // :453, :460
+        EH_TRY(rescale_enqueue(c, sn));                                                          // :487
+    }
+    {
+        ProfScope ps(c, PROF_C_POSE);
+        EH_TRY(glue(c, 3, sn, have_pair));                                                       // :550-606
+    }
+#undef EH_TRY
+    c->frame_slot = sn;
+    c->frames_seen++;
+    return 0;
 }
+
+int edgehip_read_nav(edgehip_ctx *c, edgehip_nav *nav) {
+    if (!c || !nav) return EDGEHIP_ERR_ARG;
+    EH_CHECK(hipMemcpyAsync(c->pinned_nav, c->nav_dev, sizeof(edgehip_nav) * c->plan.nseq, hipMemcpyDeviceToHost, c->stream));
+    EH_CHECK(hipStreamSynchronize(c->stream));
+    memcpy(nav, c->pinned_nav, sizeof(edgehip_nav) * c->plan.nseq);
+    return 0;
+}
+
+}  // extern "C"

@@ -1,0 +1,65 @@
+"""Whole-frame parity (GPU): edgehip_process_frame vs the reference's FirstThr+SecondThread sequencing.
+
+No state is injected: both sides start from the same RGB frames and run N frames.  Stage A stays bit-exact
+for as long as the auto-threshold state agrees (it does: kn is an integer and the P-controller is exact).
+Pose tolerance: |dV|,|dW| <= 1e-6 relative to the step size (+1e-9 abs) per frame — fp32-level, the bound
+the north star asks for — and the integrated position within 1e-6 of the path length.
+"""
+import numpy as np
+import pytest
+
+from rebvo_amd import edgehip, synth
+
+pytestmark = pytest.mark.gpu
+
+
+def _run(w, h, n, nseq=1):
+    from oracle import oracle
+    if not oracle.available("ref"):
+        pytest.skip("oracle/_ref not built")
+    frames = [f for f, _, _ in synth.billboard_sequence(w, h, n)]
+    orc = oracle.Oracle("ref", oracle.euroc_params(w, h))
+    eh = edgehip.EdgeHip(edgehip.euroc_params(w, h), nseq=nseq, nslots=3)
+    path = 0.0
+    for k, f in enumerate(frames):
+        _, nr = orc.process_frame(f, 0.05 * k)
+        eh.upload_rgb(eh.next_slot(), np.stack([f] * nseq))
+        eh.process_frame(0.05 * k)
+        for ng in eh.read_nav():
+            assert ng.kn == nr.kn, f"frame {k}: kn {ng.kn} vs {nr.kn}"
+            assert ng.tresh == nr.tresh
+            if k == 0:
+                continue
+            assert ng.estimation_ok == nr.estimation_ok
+            Vr, Wr = np.array(nr.V[:]), np.array(nr.W[:])
+            step = np.linalg.norm(Vr) + np.linalg.norm(Wr)
+            assert np.allclose(ng.V[:], Vr, rtol=0, atol=1e-6 * step + 1e-9), (k, ng.V[:], Vr)
+            assert np.allclose(ng.W[:], Wr, rtol=0, atol=1e-6 * step + 1e-9), (k, ng.W[:], Wr)
+            assert abs(ng.klm_num - nr.klm_num) <= max(2, nr.klm_num // 1000), (k, ng.klm_num, nr.klm_num)
+            assert abs(ng.s_rho_q - nr.s_rho_q) <= 1e-9
+            assert abs(ng.Kp - nr.Kp) < 1e-8
+            path += np.linalg.norm(Vr)
+            assert np.allclose(ng.Pos[:], nr.Pos[:], atol=1e-6 * path + 1e-9)
+            assert np.allclose(ng.Pose[:], nr.Pose[:], atol=1e-7)
+    # final depth maps agree
+    slot = eh.cur_slot()
+    kg, mask = eh.download_keylines(0, slot)
+    kr = orc.keylines(orc.cur_slot())
+    assert np.array_equal(mask, orc.mask(orc.cur_slot()))
+    same = kg["m_id"] == kr["m_id"]
+    assert same.mean() > 0.999
+    assert np.allclose(kg["rho"][same], kr["rho"][same], rtol=1e-5, atol=1e-7)
+    assert np.allclose(kg["s_rho"][same], kr["s_rho"][same], rtol=1e-5, atol=1e-7)
+    eh.close()
+
+
+def test_pipeline_small():
+    _run(376, 240, 8)
+
+
+def test_pipeline_euroc_size():
+    _run(752, 480, 6)
+
+
+def test_pipeline_batched_sequences_identical():
+    _run(376, 240, 4, nseq=3)

@@ -1,0 +1,116 @@
+"""Stage C parity (GPU): FordwardMatch, rotate_keylines, directed_matching, Regularize + EKF, rescale.
+
+Every stage starts from the reference's own state (injected through edgehip_upload_keylines), so a
+difference is attributable to that stage alone.  Integer fields (match ids, match counts) are compared
+exactly; fp64 depth state within 1e-12 relative (same operation order, no FMA contraction => normally
+bit-identical); rescale sums are accumulated in a different order => 1e-10.
+"""
+import numpy as np
+import pytest
+
+from rebvo_amd import edgehip
+from helpers import inject_pair, oracle_pair, rel_err, to_edgehip_kl
+
+pytestmark = pytest.mark.gpu
+
+MATCH_FIELDS_EXACT = ["m_id", "m_num", "m_id_kf", "p_m_0", "m_m0", "n_m0", "rho", "s_rho", "rho_nr", "s_rho_nr"]
+
+
+def so3_exp(w):
+    th = np.linalg.norm(w)
+    K = np.array([[0, -w[2], w[1]], [w[2], 0, -w[0]], [-w[1], w[0], 0]])
+    if th < 1e-9:
+        return np.eye(3) + K
+    return np.eye(3) + np.sin(th) / th * K + (1 - np.cos(th)) / th ** 2 * (K @ K)
+
+
+@pytest.fixture(scope="module")
+def tracked():
+    from oracle import oracle
+    if not oracle.available("ref"):
+        pytest.skip("oracle/_ref not built")
+    w, h = 376, 240
+    orc, so, sn, nav, frames = oracle_pair(w, h, 4)
+    s_rho_q = orc.quantile(so)
+    orc.build_field(sn, 40, orc.retuned(sn))
+    res = orc.minimizer_rv(sn, so, nav.V[:], nav.W[:], 0.5, 5, 2, 2.0, s_rho_q, 0, 2)
+    eh = edgehip.EdgeHip(edgehip.euroc_params(w, h), nseq=1, nslots=2)
+    yield orc, so, sn, res, eh
+    eh.close()
+
+
+def _cmp(kg, kr, fields, exact=True, tol=1e-12):
+    assert len(kg) == len(kr)
+    for f in fields:
+        if exact:
+            assert np.array_equal(kg[f], kr[f]), f"KeyLine.{f} differs ({np.sum(kg[f] != kr[f])} entries)"
+        else:
+            assert np.allclose(kg[f], kr[f], rtol=tol, atol=0), f"KeyLine.{f}"
+
+
+def test_stage_c_chain(tracked):
+    orc, so, sn, res, eh = tracked
+    V, W, RVel, RW0 = res["V"], res["W"], res["RVel"], res["RW0"]
+    # ---- FordwardMatch ----
+    inject_pair(eh, orc, so, sn)
+    n_ref = orc.forward_match(so, sn)
+    eh.forward_match(0, 1)
+    kg, _ = eh.download_keylines(0, 1, want_mask=False)
+    _cmp(kg, orc.keylines(sn), MATCH_FIELDS_EXACT)
+    assert (kg["m_id"] >= 0).sum() > 500
+    assert eh.get_state(0).klm_fwd <= n_ref
+    # ---- rotate_keylines ----
+    R0 = so3_exp(W)
+    orc.rotate_keylines(so, R0)
+    eh.rotate_keylines(0, R0)
+    kg, _ = eh.download_keylines(0, 0, want_mask=False)
+    _cmp(kg, orc.keylines(so), ["p_m", "m_m", "rho", "s_rho"])
+    # ---- directed_matching ----
+    inject_pair(eh, orc, so, sn)
+    st = eh.get_state(0)
+    st.V[:] = V
+    st.P_V[:] = RVel.ravel()
+    st.R[:] = R0.T.ravel()
+    st.klm_num = 0
+    st.kf_matchs = 0
+    eh.set_state(0, st)
+    n_ref, kf_ref = orc.directed_matching(sn, so, V, RVel, R0.T, 1.0, 45.0, 40.0, 2.0)
+    eh.directed_matching(1, 0)
+    kg, _ = eh.download_keylines(0, 1, want_mask=False)
+    _cmp(kg, orc.keylines(sn), MATCH_FIELDS_EXACT)
+    g = eh.get_state(0)
+    assert (g.klm_num, g.kf_matchs) == (n_ref, kf_ref)
+    assert n_ref > 1000
+    # ---- Regularize_1_iter + EKF ----
+    inject_pair(eh, orc, so, sn)
+    orc.regularize(sn, 0.5)
+    orc.ekf(sn, V, RVel, RW0, 1e-4, 1.6968e-04, 1.0)
+    eh.regularize_ekf(1)
+    kg, _ = eh.download_keylines(0, 1, want_mask=False)
+    kr = orc.keylines(sn)
+    m = kr["m_id"] >= 0
+    _cmp(kg, kr, ["rho", "s_rho"], exact=False)
+    assert np.allclose(kg["rho0"][m], kr["rho0"][m], rtol=1e-12) and np.allclose(kg["s_rho0"][m], kr["s_rho0"][m], rtol=1e-12)
+    # ---- EstimateReScalingOpt ----
+    inject_pair(eh, orc, so, sn)
+    kp_ref, rkp_ref = orc.rescale(sn)
+    eh.rescale(1)
+    g = eh.get_state(0)
+    assert abs(g.Kp - kp_ref) < 1e-10 * abs(kp_ref)
+    assert abs(g.P_Kp - rkp_ref) < 1e-10 * abs(rkp_ref)
+
+
+def test_regularize_only_and_ekf_only(tracked):
+    orc, so, sn, res, eh = tracked
+    V, RVel, RW0 = res["V"], res["RVel"], res["RW0"]
+    inject_pair(eh, orc, so, sn)
+    st = eh.get_state(0)
+    st.V[:] = V
+    eh.set_state(0, st)
+    k0 = orc.keylines(sn).copy()
+    orc.regularize(sn, 0.5)
+    eh.regularize_ekf(1, True, False)
+    kg, _ = eh.download_keylines(0, 1, want_mask=False)
+    assert np.allclose(kg["rho"], orc.keylines(sn)["rho"], rtol=1e-13, atol=0)
+    assert np.allclose(kg["s_rho"], orc.keylines(sn)["s_rho"], rtol=1e-13, atol=0)
+    assert np.any(kg["rho"] != k0["rho"])
