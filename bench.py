@@ -1,0 +1,236 @@
+#!/usr/bin/env python3
+"""bench.py — frames/sec of the REBVO edge pipeline (DoG + extract + track + depth EKF) on MI355X.
+
+Contract (see the task statement): `python bench.py --gpus N --steps K --warmup W`; for N>1 it is launched
+by torch.distributed.run with one rank per GPU.  One JSON line on rank 0.
+
+Workload (BASELINE.json configs[1]/[2] at the EuRoC size): `--nseq` independent synthetic 752x480 sequences
+per GPU ("billboards": textured quads at different depths seen by a moving pinhole camera, EuRoC
+intrinsics and GlobalConfig_EuRoC parameters, ImuMode=0).  One step = one new frame of EVERY sequence
+through the full path: RGB->grey, scale space, DoG, KeyLine extraction, distance field, Minimizer_RV
+(12 TryVelRot evaluations + device-side LM), forward match, rotate, directed matching, regularise, EKF,
+rescale, pose integration.  Frames are resident in HBM before the timed region (a pool of rendered frames
+gathered per sequence by a device kernel); nothing is skipped inside it and there is no host
+synchronisation per step.  Sequences shard across GPUs with no data-path collective ("weak" scaling: the
+per-GPU work is fixed); the per-frame nav records are gathered to rank 0 over RCCL at the end of the
+timed region.
+
+Extra objects on the JSON line:
+  roofline     dominant kernel group (by HIP-event time on the context stream, measured over the timed
+               region), its algorithmic bytes per launch / mean launch duration vs 8 TB/s
+  cpu_baseline the reference's own mtracklib (oracle/_ref, compiled in place from the reference sources)
+               timed on one host core over a bounded sample of the same frames
+"""
+import argparse
+import ctypes
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+W, H = 752, 480
+HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+
+
+def tri(k, n):
+    """Triangle wave over [0, n-1]: forward then backward through the frame pool (continuous motion)."""
+    p = 2 * (n - 1)
+    k = k % p
+    return k if k < n else p - k
+
+
+def algorithmic_bytes(group, kn, n_px, radius, nseq):
+    """Compulsory bytes per launch of a kernel group, for `nseq` batched sequences."""
+    per_seq = {
+        # stage A pieces: inputs/outputs each kernel cannot avoid
+        "A.rgb_rowscan": 3 * n_px + 4 * n_px,                 # RGB24 in, row-prefix plane out
+        "A.colscan": 2 * 4 * n_px,                           # plane in, plane out (per plane)
+        "A.avg_rowscan": 2 * 4 * n_px,                       # integral in, integral out (per plane)
+        "A.detect": 2 * 4 * n_px + 4 * n_px + 20 * kn,       # two integrals in, mask + candidates out
+        "A.compact": 20 * kn + 168 * kn,                     # candidates in, KeyLine SoA out
+        "A.join_retune": (8 + 8 + 4 + 3 * 4 + 8) * kn,
+        # 84 B per KeyLine and evaluation (fp64 variant)
+        "B.try_velrot": 84 * kn,
+        "B.build_field": 4 * n_px + 4 * 2 * radius * kn,     # clear + scattered 4-byte atomics (packed field)
+        "B.tvr_prepare": (8 + 8 + 24 + 8) * kn,
+        "B.lm_step": 0,
+        "B.quantile": 8 * kn,
+        "C.forward_match": (4 + 8 + 8 + 4 + 100) * kn,
+        "C.rotate": (8 + 16 + 8 + 8 + 16 + 8 + 8) * kn,
+        "C.directed_matching": (4 * 40 + 2 * 168) * kn,
+        "C.regularize_ekf": (3 * 16 + 16 + 100) * kn,
+        "C.rescale": 5 * 32 * kn,
+        "C.pose": 0,
+    }
+    return per_seq.get(group, 0) * nseq
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=40)
+    ap.add_argument("--warmup", type=int, default=24)
+    ap.add_argument("--nseq", type=int, default=64, help="independent sequences per GPU (batch dimension)")
+    ap.add_argument("--pool", type=int, default=24, help="rendered frames in the HBM pool")
+    ap.add_argument("--cpu-frames", type=int, default=200, help="frames of the CPU-baseline sample (0 = skip)")
+    ap.add_argument("--no-roofline-events", action="store_true")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if rank == 0:
+            print(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}; launch with torch.distributed.run", file=sys.stderr)
+        args.gpus = world
+
+    import torch
+    import torch.distributed as dist
+
+    from rebvo_amd import edgehip, synth
+
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X (torch.cuda.is_available() is False); there is no CPU path")
+    torch.cuda.set_device(local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+
+    B, K, Wm = args.nseq, args.steps, args.warmup
+    # ---- synthetic frame pool, resident in HBM ----
+    frames = [f for f, _, _ in synth.billboard_sequence(W, H, args.pool, seed=11 + rank)]
+    pool = torch.from_numpy(np.stack(frames)).cuda()
+    torch.cuda.synchronize()
+
+    eh = edgehip.EdgeHip(edgehip.euroc_params(W, H), nseq=B, nslots=3, device=local_rank)
+    eh.set_nav_log(K)
+    offs = np.arange(B, dtype=np.int64) % (2 * (args.pool - 1))  # every sequence starts at its own phase
+
+    def step(k):
+        idx = np.array([tri(k + o, args.pool) for o in offs], dtype=np.int32)
+        eh.upload_rgb_indexed(eh.next_slot(), pool.data_ptr(), args.pool, idx)
+        eh.process_frame(0.05 * k)
+
+    def barrier():
+        eh.sync()
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+
+    # ---- warmup (also finds the dominant kernel group with the built-in HIP-event profiler) ----
+    prof_steps = min(4, max(1, Wm // 4))
+    for k in range(Wm - prof_steps):
+        step(k)
+    eh.sync()
+    eh.profile_enable(True)
+    eh.profile_select(None)
+    for k in range(Wm - prof_steps, Wm):
+        step(k)
+    prof = eh.profile_read()
+    eh.profile_enable(False)
+    groups = {g: (ms, calls) for g, (ms, calls) in prof.items() if calls}
+    dominant = max(groups, key=lambda g: groups[g][0]) if groups else None
+    breakdown = {g: round(ms / prof_steps * 1e3, 1) for g, (ms, calls) in groups.items()}  # us per step
+
+    # ---- timed region: EXACTLY K steps between barriers ----
+    if dominant and not args.no_roofline_events:
+        eh.profile_select([dominant])
+        eh.profile_enable(True)
+    barrier()
+    t0 = time.perf_counter()
+    for k in range(Wm, Wm + K):
+        step(k)
+    navs = eh.read_nav_log(Wm, K) if world > 1 else None
+    if world > 1:
+        # nav records of every step -> rank 0 over RCCL (tiny: ~0.5 KB per frame)
+        rec = np.array([[(n.frame, n.kn, n.klm_num, n.estimation_ok) + tuple(n.Pos[:]) + tuple(n.V[:]) + tuple(n.W[:])
+                         for n in row] for row in navs], dtype=np.float64)
+        tsr = torch.from_numpy(rec).cuda()
+        out = [torch.empty_like(tsr) for _ in range(world)] if rank == 0 else None
+        dist.gather(tsr, out, dst=0)
+    barrier()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        tmax = torch.tensor([dt], dtype=torch.float64, device="cuda")
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        dt = float(tmax.item())
+
+    dom_ms, dom_calls = (0.0, 0)
+    if dominant and not args.no_roofline_events:
+        dom_ms, dom_calls = eh.profile_read()[dominant]
+        eh.profile_enable(False)
+    last = eh.read_nav()
+    kn_mean = float(np.mean([n.kn for n in last]))
+    ok = int(sum(n.estimation_ok for n in last))
+    evals = last[0].minimizer_evals
+
+    if rank != 0:
+        if world > 1:
+            dist.barrier()
+            dist.destroy_process_group()
+        return
+
+    value = B * world * K / dt
+    # ---- roofline of the dominant kernel group ----
+    roof = None
+    if dominant and dom_calls:
+        per_launch_s = dom_ms * 1e-3 / dom_calls
+        abytes = algorithmic_bytes(dominant, kn_mean, W * H, 40, B)
+        ach = abytes / per_launch_s / 1e9 if per_launch_s > 0 else 0.0
+        roof = {"bound": "hbm", "kernel": dominant, "achieved": round(ach, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                "frac": round(ach / HBM_PEAK_GBS, 5), "traffic": None,
+                "launch_us": round(per_launch_s * 1e6, 2), "algorithmic_bytes_per_launch": int(abytes),
+                "launches_timed": dom_calls}
+    # whole-frame algorithmic bytes, SURVEY.md §8(d) formulas with the measured kn and evaluation count
+    n_px, r = W * H, 40
+    frame_bytes = (3 * n_px + 4 * n_px + 168 * kn_mean) + (8 * n_px + 8 * 2 * r * kn_mean + evals * 84 * kn_mean) + \
+                  ((4 * 40 + 2 * 168) * kn_mean + 100 * kn_mean + 64 * kn_mean + 160 * kn_mean)
+
+    # ---- CPU baseline: the reference's own code on one host core, bounded sample ----
+    cpu = None
+    if args.cpu_frames > 0:
+        try:
+            from oracle import oracle
+            kind = "reference" if oracle.available("ref") else ("port" if oracle.available("port") else None)
+            if kind:
+                orc = oracle.Oracle("ref" if kind == "reference" else "port", oracle.euroc_params(W, H))
+                for k in range(10):  # first-touch of the 8 ring slots + MKL init, untimed
+                    orc.process_frame(frames[tri(k, args.pool)], 0.05 * k)
+                tc = 0.0
+                for k in range(10, 10 + args.cpu_frames):
+                    _, nav = orc.process_frame(frames[tri(k, args.pool)], 0.05 * k)
+                    tc += nav.dtp0 + nav.dtp1
+                cpu = {"value": round(args.cpu_frames / tc, 2), "unit": "frames/s", "cores": 1, "kind": kind,
+                       "sample": f"{args.cpu_frames} frames of sequence 0 (same 752x480 pool), serial stage A + B/C "
+                                 f"on 1 of {os.cpu_count()} host cores; reference threading overlaps the two stages "
+                                 "on 2 cores",
+                       "ms_per_frame": round(tc / args.cpu_frames * 1e3, 2)}
+        except Exception as e:  # the oracle is optional test infrastructure; never fatal for the bench
+            cpu = {"value": None, "error": str(e)[:200]}
+
+    line = {
+        "metric": "frames/sec (DoG+extract+track+depth) 752x480 EuRoC",
+        "value": round(value, 1), "unit": "frames/s", "n_gpus": world, "steps": K, "warmup": Wm,
+        "ms_per_step": round(dt / K * 1e3, 4), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "dtype": "f32 scale-space / f64 tracker+EKF", "data": "synthetic",
+        "config": {"workload": "full path (configs[2] at configs[1] size): 752x480 synthetic EuRoC-intrinsics "
+                               "sequences, GlobalConfig_EuRoC params, ImuMode=0",
+                   "sequences_per_gpu": B, "frames_per_step": B * world, "keylines_per_frame": round(kn_mean, 1),
+                   "tryvelrot_evals_per_frame": evals, "estimation_ok": f"{ok}/{B}",
+                   "algorithmic_MB_per_frame": round(frame_bytes / 1e6, 2),
+                   "whole_path_hbm_frac": round(frame_bytes * value / world / 1e9 / HBM_PEAK_GBS, 5)},
+        "roofline": roof, "cpu_baseline": cpu, "kernel_us_per_step": breakdown,
+    }
+    print(json.dumps(line))
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

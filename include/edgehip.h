@@ -130,6 +130,10 @@ int edgehip_upload_rgb(edgehip_ctx *ctx, int slot, const uint8_t *rgb24, int seq
 /* Same, from device memory ([nseq][h][w][3], all sequences), device-to-device on the context stream. */
 int edgehip_upload_rgb_device(edgehip_ctx *ctx, int slot, const void *rgb24_dev);
 
+/* Bench/replay helper: frame pool resident in HBM ([pool_frames][h][w][3]); sequence s takes frame
+ * idx[s] (host array, nseq entries).  One gather kernel on the context stream. */
+int edgehip_upload_rgb_indexed(edgehip_ctx *ctx, int slot, const void *pool_dev, int pool_frames, const int32_t *idx);
+
 /* ---- stage A: scale space + KeyLine extraction ----------------------------------------------------- */
 /* Image<float>::ConvertRGB2BW + sspace::build + edge_finder::detect + reEstimateThresh for every
  * sequence's slot `slot` (rebvo_first_t.cpp:259-272; sspace.cpp:52-85; edge_finder.cpp:67-405).
@@ -186,6 +190,11 @@ int edgehip_next_slot(edgehip_ctx *ctx);
 int edgehip_cur_slot(edgehip_ctx *ctx);
 /* Per-sequence record of the last processed frame.  Synchronises.  nav[nseq]. */
 int edgehip_read_nav(edgehip_ctx *ctx, edgehip_nav *nav);
+/* Keep the last `len` per-frame records of every sequence in HBM (ring indexed by frame number) so that a
+ * replay can run many frames without reading back; edgehip_read_nav_log copies records of frames
+ * [first, first+count) as out[count][nseq].  Synchronises. */
+int edgehip_set_nav_log(edgehip_ctx *ctx, int len);
+int edgehip_read_nav_log(edgehip_ctx *ctx, int first, int count, edgehip_nav *out);
 /* REBVO::Reset semantics for every sequence (rebvo_second_t.cpp:609-620) + restart of the ring. */
 int edgehip_reset(edgehip_ctx *ctx);
 
@@ -213,6 +222,8 @@ int edgehip_download_field(edgehip_ctx *ctx, int seq, int32_t *out);
  * edgehip_profile_enable(ctx, 1) brackets every launch group with events on the context stream (adds host
  * overhead: use for attribution, not for throughput).  ms[n], calls[n] with n = edgehip_profile_count(). */
 int edgehip_profile_enable(edgehip_ctx *ctx, int on);
+/* Restrict the profiler to the groups whose bit is set (bit i = group i); default: all. */
+int edgehip_profile_select(edgehip_ctx *ctx, uint64_t mask);
 int edgehip_profile_count(void);
 const char *edgehip_profile_name(int i);
 int edgehip_profile_read(edgehip_ctx *ctx, double *ms, int64_t *calls); /* synchronises, then resets */

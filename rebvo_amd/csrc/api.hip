@@ -27,7 +27,7 @@ static const char *kProfNames[PROF_COUNT] = {
 
 ProfScope::ProfScope(edgehip_ctx *ctx, int pid) : c(ctx), id(pid) {
     Profiler *p = c->prof;
-    if (!p || !p->on) return;
+    if (!p || !p->on || !((p->mask >> pid) & 1ull)) return;
     auto get = [&]() {
         hipEvent_t e;
         if (!p->pool.empty()) { e = p->pool.back(); p->pool.pop_back(); }
@@ -148,6 +148,14 @@ static int h2d(edgehip_ctx *c, T *dst, const std::vector<T> &src) {
 }
 
 
+__global__ void k_gather_frames(const uint4 *__restrict__ pool, const int32_t *__restrict__ idx, uint4 *__restrict__ dst,
+                                size_t frame_vec) {
+    const int seq = blockIdx.y;
+    const uint4 *src = pool + (size_t)idx[seq] * frame_vec;
+    uint4 *d = dst + (size_t)seq * frame_vec;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < frame_vec; i += (size_t)gridDim.x * blockDim.x) d[i] = src[i];
+}
+
 }  // namespace edgehip
 
 using namespace edgehip;
@@ -160,6 +168,7 @@ const char *edgehip_last_error(void) { return g_err.c_str(); }
 int edgehip_create(const edgehip_params *params, int nseq, int nslots, int device, edgehip_ctx **out) {
     if (!params || !out || nseq < 1 || nslots < 2) { set_error("edgehip_create: bad argument"); return EDGEHIP_ERR_ARG; }
     const edgehip_params &p = *params;
+    if (((size_t)p.w * p.h * 3) % 16 != 0) { set_error("edgehip_create: w*h*3 must be a multiple of 16"); return EDGEHIP_ERR_ARG; }
     if (p.w < 16 || p.h < 16 || (p.w % 4) != 0 || p.w > 1024) {
         set_error("edgehip_create: image width must be a multiple of 4 in [16,1024], height >= 16");
         return EDGEHIP_ERR_ARG;
@@ -243,6 +252,9 @@ int edgehip_create(const edgehip_params *params, int nseq, int nslots, int devic
     EH_TRY(dmalloc(c, &c->rot_buf, B * 9, al->dev, 0));
     EH_TRY(dmalloc(c, &c->t_buf, B, al->dev, 0));
     EH_TRY(dmalloc(c, &c->nav_dev, B, al->dev, 0));
+    EH_TRY(dmalloc(c, &c->idx_dev, B, al->dev, 0));
+    c->nav_log = nullptr;
+    c->nav_log_len = 0;
 
     // KeyLine SoA arena
     {
@@ -289,7 +301,7 @@ int edgehip_create(const edgehip_params *params, int nseq, int nslots, int devic
         EH_CHECK(hipHostMalloc(&q, c->pinned_rgb_bytes, hipHostMallocDefault)); al->host.push_back(q); c->pinned_rgb = (uint8_t *)q;
         EH_CHECK(hipHostMalloc(&q, sizeof(SeqDev) * B, hipHostMallocDefault)); al->host.push_back(q); c->pinned_seq = (SeqDev *)q;
         EH_CHECK(hipHostMalloc(&q, sizeof(double) * B * 64, hipHostMallocDefault)); al->host.push_back(q); c->pinned_out = (double *)q;
-        EH_CHECK(hipHostMalloc(&q, sizeof(double) * B * 8, hipHostMallocDefault)); al->host.push_back(q); c->pinned_t = (double *)q;
+        EH_CHECK(hipHostMalloc(&q, sizeof(double) * B * 8 + sizeof(int32_t) * B * 8, hipHostMallocDefault)); al->host.push_back(q); c->pinned_t = (double *)q;
         EH_CHECK(hipHostMalloc(&q, sizeof(edgehip_nav) * B, hipHostMallocDefault)); al->host.push_back(q); c->pinned_nav = (edgehip_nav *)q;
     }
     for (size_t i = 0; i < B; i++) init_state(p, &c->pinned_seq[i]);
@@ -317,6 +329,7 @@ int edgehip_destroy(edgehip_ctx *c) {
         for (auto e : c->prof->pool) (void)hipEventDestroy(e);
         delete c->prof;
     }
+    if (c->nav_log) (void)hipFree(c->nav_log);
     (void)hipStreamDestroy(c->stream);
     delete c;
     return 0;
@@ -375,6 +388,50 @@ int edgehip_upload_rgb_device(edgehip_ctx *c, int slot, const void *rgb24_dev) {
     if (int e = check_slot(c, slot)) return e;
     if (!rgb24_dev) return EDGEHIP_ERR_ARG;
     EH_CHECK(hipMemcpyAsync(rgbof(c, slot), rgb24_dev, (size_t)c->plan.nseq * c->plan.n * 3, hipMemcpyDeviceToDevice, c->stream));
+    return 0;
+}
+
+int edgehip_upload_rgb_indexed(edgehip_ctx *c, int slot, const void *pool_dev, int pool_frames, const int32_t *idx) {
+    if (int e = check_slot(c, slot)) return e;
+    if (!pool_dev || !idx || pool_frames < 1) return EDGEHIP_ERR_ARG;
+    const int B = c->plan.nseq;
+    int32_t *pi = (int32_t *)(c->pinned_t + (size_t)8 * B) ;  // tail of the pinned time ring (see create)
+    pi += (size_t)(c->frames_seen % 8) * B;
+    for (int s = 0; s < B; s++) {
+        if (idx[s] < 0 || idx[s] >= pool_frames) { set_error("upload_rgb_indexed: index out of range"); return EDGEHIP_ERR_ARG; }
+        pi[s] = idx[s];
+    }
+    EH_CHECK(hipMemcpyAsync(c->idx_dev, pi, sizeof(int32_t) * B, hipMemcpyHostToDevice, c->stream));
+    const size_t frame_vec = (size_t)c->plan.n * 3 / 16;  // w % 4 == 0 => n*3 % 4 == 0; need %16: checked at create
+    hipLaunchKernelGGL(k_gather_frames, dim3(64, B), dim3(256), 0, c->stream, (const uint4 *)pool_dev, c->idx_dev,
+                       (uint4 *)rgbof(c, slot), frame_vec);
+    EH_LAUNCH_CHECK();
+    return 0;
+}
+
+int edgehip_set_nav_log(edgehip_ctx *c, int len) {
+    if (!c || len < 0) return EDGEHIP_ERR_ARG;
+    EH_CHECK(hipStreamSynchronize(c->stream));
+    if (c->nav_log) { (void)hipFree(c->nav_log); c->nav_log = nullptr; }
+    c->nav_log_len = 0;
+    if (len > 0) {
+        void *q;
+        if (hipMalloc(&q, sizeof(edgehip_nav) * (size_t)len * c->plan.nseq) != hipSuccess) { set_error("nav log alloc failed"); return EDGEHIP_ERR_MEMORY; }
+        EH_CHECK(hipMemset(q, 0, sizeof(edgehip_nav) * (size_t)len * c->plan.nseq));
+        c->nav_log = (edgehip_nav *)q;
+        c->nav_log_len = len;
+    }
+    return 0;
+}
+
+int edgehip_read_nav_log(edgehip_ctx *c, int first, int count, edgehip_nav *out) {
+    if (!c || !out || !c->nav_log || first < 0 || count < 1 || count > c->nav_log_len) { set_error("read_nav_log: bad range or log disabled"); return EDGEHIP_ERR_ARG; }
+    const size_t B = c->plan.nseq;
+    for (int k = 0; k < count; k++) {
+        const int slot = (first + k) % c->nav_log_len;
+        EH_CHECK(hipMemcpyAsync(out + (size_t)k * B, c->nav_log + (size_t)slot * B, sizeof(edgehip_nav) * B, hipMemcpyDeviceToHost, c->stream));
+    }
+    EH_CHECK(hipStreamSynchronize(c->stream));
     return 0;
 }
 
@@ -542,6 +599,11 @@ int edgehip_download_field(edgehip_ctx *c, int seq, int32_t *out) {
 int edgehip_profile_enable(edgehip_ctx *c, int on) {
     if (!c) return EDGEHIP_ERR_ARG;
     c->prof->on = on != 0;
+    return 0;
+}
+int edgehip_profile_select(edgehip_ctx *c, uint64_t mask) {
+    if (!c) return EDGEHIP_ERR_ARG;
+    c->prof->mask = mask;
     return 0;
 }
 int edgehip_profile_count(void) { return PROF_COUNT; }

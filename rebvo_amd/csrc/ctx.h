@@ -120,6 +120,9 @@ struct edgehip_ctx {
     double *rot_buf;       // [B][9] rotation applied by rotate_keylines
     double *t_buf;         // [B] frame time stamps
     edgehip_nav *nav_dev;  // [B] per-frame record
+    edgehip_nav *nav_log;  // [nav_log_len][B] ring of per-frame records (optional)
+    int nav_log_len;
+    int32_t *idx_dev;      // [B] frame-pool indices of upload_rgb_indexed
     // host staging
     uint8_t *pinned_rgb;   // [B][N*3]
     size_t pinned_rgb_bytes;
@@ -157,6 +160,7 @@ enum ProfId {
 };
 struct Profiler {
     bool on = false;
+    uint64_t mask = ~0ull;
     struct Rec { hipEvent_t a, b; int id; };
     std::vector<Rec> pending;
     std::vector<hipEvent_t> pool;

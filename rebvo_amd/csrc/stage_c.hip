@@ -463,7 +463,7 @@ __device__ inline bool any_nan3(const double *v) { return isnan(v[0]) || isnan(v
 // directed_matching (:412-422); 3: pose integration + nav record (:550-606)
 __global__ void k_frame_glue(SeqDev *seqs, const double *__restrict__ t_in, edgehip_nav *__restrict__ nav,
                              const int32_t *__restrict__ kn_new, int nseq, int mode, double fps, int match_threshold,
-                             int have_pair) {
+                             int have_pair, edgehip_nav *__restrict__ nav_log, int nav_log_len) {
     const int seq = blockIdx.x * blockDim.x + threadIdx.x;
     if (seq >= nseq) return;
     SeqDev *sq = seqs + seq;
@@ -534,6 +534,7 @@ __global__ void k_frame_glue(SeqDev *seqs, const double *__restrict__ t_in, edge
         o.kn = kn_new[seq]; o.klm_fwd = p.klm_fwd; o.klm_num = p.klm_num; o.kf_matchs = p.kf_matchs;
         o.estimation_ok = have_pair ? p.estimation_ok : 0;
         o.frame = p.frame; o.minimizer_evals = p.minimizer_evals;
+        if (nav_log_len > 0) nav_log[(size_t)(p.frame % nav_log_len) * nseq + seq] = o;
         p.t_prev = sq->t_cur;
         p.frame++;
     }
@@ -618,7 +619,7 @@ static int glue(edgehip_ctx *c, int mode, int slot_new, int have_pair) {
     const DevicePlan &pl = c->plan;
     hipLaunchKernelGGL(k_frame_glue, dim3((pl.nseq + 63) / 64), dim3(64), 0, c->stream, c->seq, c->t_buf, c->nav_dev,
                        c->kn_slot + (size_t)slot_new * pl.nseq, pl.nseq, mode, c->p.config_fps, c->p.global_match_threshold,
-                       have_pair);
+                       have_pair, c->nav_log, c->nav_log_len);
     EH_LAUNCH_CHECK();
     return 0;
 }

@@ -119,7 +119,8 @@ EXPORTS = [
     "edgehip_next_slot", "edgehip_cur_slot", "edgehip_read_nav", "edgehip_reset", "edgehip_get_state",
     "edgehip_set_state", "edgehip_get_framecount", "edgehip_set_framecount", "edgehip_download_keylines",
     "edgehip_upload_keylines", "edgehip_download_plane", "edgehip_download_field", "edgehip_profile_enable",
-    "edgehip_profile_count", "edgehip_profile_name", "edgehip_profile_read",
+    "edgehip_profile_count", "edgehip_profile_name", "edgehip_profile_read", "edgehip_profile_select",
+    "edgehip_upload_rgb_indexed", "edgehip_set_nav_log", "edgehip_read_nav_log",
 ]
 
 _lib = None
@@ -182,6 +183,20 @@ class EdgeHip:
 
     def upload_rgb_device(self, slot, dev_ptr):
         self._ck(self.lib.edgehip_upload_rgb_device(self.ctx, slot, C.c_void_p(dev_ptr)))
+
+    def upload_rgb_indexed(self, slot, pool_dev_ptr, pool_frames, idx):
+        idx = np.ascontiguousarray(idx, dtype=np.int32)
+        assert idx.shape == (self.nseq,)
+        self._ck(self.lib.edgehip_upload_rgb_indexed(self.ctx, slot, C.c_void_p(pool_dev_ptr), pool_frames,
+                                                     idx.ctypes.data_as(C.c_void_p)))
+
+    def set_nav_log(self, length):
+        self._ck(self.lib.edgehip_set_nav_log(self.ctx, length))
+
+    def read_nav_log(self, first, count):
+        out = (Nav * (count * self.nseq))()
+        self._ck(self.lib.edgehip_read_nav_log(self.ctx, first, count, out))
+        return [[out[k * self.nseq + s] for s in range(self.nseq)] for k in range(count)]
 
     def sync(self):
         self._ck(self.lib.edgehip_sync(self.ctx))
@@ -312,6 +327,14 @@ class EdgeHip:
     # ---- measurement ----
     def profile_enable(self, on=True):
         self._ck(self.lib.edgehip_profile_enable(self.ctx, int(on)))
+
+    def profile_select(self, names=None):
+        n = self.lib.edgehip_profile_count()
+        mask = 0
+        for i in range(n):
+            if names is None or self.lib.edgehip_profile_name(i).decode() in names:
+                mask |= 1 << i
+        self._ck(self.lib.edgehip_profile_select(self.ctx, C.c_uint64(mask)))
 
     def profile_read(self):
         n = self.lib.edgehip_profile_count()
