@@ -92,7 +92,7 @@ def main():
     import torch
     import torch.distributed as dist
 
-    from rebvo_amd import edgehip, synth
+    from rebvo_amd import edgehip, shard, synth
 
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X (torch.cuda.is_available() is False); there is no CPU path")
@@ -148,11 +148,8 @@ def main():
     navs = eh.read_nav_log(Wm, K) if world > 1 else None
     if world > 1:
         # nav records of every step -> rank 0 over RCCL (tiny: ~0.5 KB per frame)
-        rec = np.array([[(n.frame, n.kn, n.klm_num, n.estimation_ok) + tuple(n.Pos[:]) + tuple(n.V[:]) + tuple(n.W[:])
-                         for n in row] for row in navs], dtype=np.float64)
-        tsr = torch.from_numpy(rec).cuda()
-        out = [torch.empty_like(tsr) for _ in range(world)] if rank == 0 else None
-        dist.gather(tsr, out, dst=0)
+        seq_ids = list(range(rank * B, (rank + 1) * B))
+        shard.gather_records(shard.nav_records(navs, rank, seq_ids), dst=0)
     barrier()
     dt = time.perf_counter() - t0
     if world > 1:

@@ -1,0 +1,53 @@
+"""GPU: the HIP path against the committed golden vectors (independent of any oracle .so)."""
+import glob
+import hashlib
+import os
+
+import numpy as np
+import pytest
+
+from rebvo_amd import edgehip
+
+pytestmark = pytest.mark.gpu
+GOLD = sorted(glob.glob(os.path.join(os.path.dirname(__file__), "golden", "*.npz")))
+
+
+def _sha(a):
+    return hashlib.sha256(np.ascontiguousarray(a).tobytes()).hexdigest()
+
+
+@pytest.mark.parametrize("path", GOLD, ids=[os.path.basename(p) for p in GOLD])
+def test_hip_matches_golden(path):
+    g = np.load(path)
+    over = dict(eval(str(g["over"])))
+    frames = g["frames"]
+    n, h, w = frames.shape
+    eh = edgehip.EdgeHip(edgehip.euroc_params(w, h, debug_planes=1, **over), nseq=1, nslots=3)
+    for k in range(n):
+        f = np.repeat(frames[k][:, :, None], 3, axis=2)
+        eh.upload_rgb(eh.next_slot(), f)
+        eh.process_frame(0.05 * k)
+        nav = eh.read_nav()[0]
+        assert nav.kn == g["kn"][k] and nav.tresh == g["tresh"][k]
+        _, mask = eh.download_keylines(0, eh.cur_slot())
+        assert _sha(mask) == str(g["mask_sha"][k]), f"frame {k}: img_mask_kl"
+        assert _sha(eh.download_plane(0, "dog")) == str(g["dog_sha"][k]), f"frame {k}: DoG"
+        assert _sha(eh.download_plane(0, "img0")) == str(g["img0_sha"][k])
+        if nav.kn:
+            assert np.float32(nav.retuned_thresh) == np.float32(g["retuned"][k])
+        if k == 0:
+            continue
+        step = np.linalg.norm(g["V"][k]) + np.linalg.norm(g["W"][k])
+        assert np.allclose(nav.V[:], g["V"][k], rtol=0, atol=1e-6 * step + 1e-9)
+        assert np.allclose(nav.W[:], g["W"][k], rtol=0, atol=1e-6 * step + 1e-9)
+        assert abs(nav.klm_num - g["klm_num"][k]) <= 2
+        assert nav.estimation_ok == g["ok"][k]
+    kl, mask = eh.download_keylines(0, eh.cur_slot())
+    gk = np.frombuffer(g["last_keylines"].tobytes(), dtype=edgehip.KEYLINE_DTYPE)
+    assert np.array_equal(mask, g["last_mask"])
+    for fld in ("p_inx", "m_m", "u_m", "n_m", "c_p", "p_m", "p_id", "n_id"):
+        assert np.array_equal(kl[fld], gk[fld]), fld
+    same = kl["m_id"] == gk["m_id"]
+    assert same.mean() > 0.995
+    assert np.allclose(kl["rho"][same], gk["rho"][same], rtol=1e-6, atol=1e-8)
+    eh.close()

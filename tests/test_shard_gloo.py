@@ -1,0 +1,60 @@
+"""CPU: the N>1 path of bench.py (sequence sharding + nav-record gather) with world_size 2 over gloo."""
+import os
+import socket
+
+import numpy as np
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from rebvo_amd import shard
+
+
+def test_partition_is_balanced_and_complete():
+    for n, world in ((8, 8), (10, 4), (3, 2), (1, 2)):
+        parts = [shard.shard_sequences(n, r, world) for r in range(world)]
+        assert sorted(sum(parts, [])) == list(range(n))
+        assert max(map(len, parts)) - min(map(len, parts)) <= 1
+
+
+class _Nav:
+    def __init__(self, frame, seq):
+        self.frame, self.kn, self.klm_num, self.estimation_ok = frame, 100 + seq, 90 + seq, 1
+        self.Pos, self.V, self.W = [seq, frame, 0.5], [0.1 * seq] * 3, [0.01 * frame] * 3
+
+
+def _worker(rank, world, port, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    ids = shard.shard_sequences(4, rank, world)
+    navs = [[_Nav(k, s) for s in ids] for k in range(3)]
+    rec = shard.nav_records(navs, rank, ids)
+    out = shard.gather_records(rec, dst=0)
+    t = torch.tensor([1.0 + rank])
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)  # the max-over-ranks timing reduction of bench.py
+    if rank == 0:
+        q.put((out, float(t)))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_gather_world2_gloo():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    out, tmax = q.get(timeout=120)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert tmax == 2.0
+    assert out.shape == (2, 3, 2, shard.NAV_FIELDS)
+    assert sorted(out[:, 0, :, 13].ravel().tolist()) == [0, 1, 2, 3]   # every sequence reported once
+    assert np.all(out[1, :, :, 14] == 1) and np.all(out[0, :, :, 14] == 0)
+    assert np.allclose(out[1, 2, 0, 4:7], [2, 2, 0.5])

@@ -1,0 +1,58 @@
+#!/usr/bin/env python3
+"""Generate tests/golden/*.npz from the REFERENCE oracle (oracle/_ref, built in place from /root/reference).
+
+Run in the build container (needs /root/reference):  python tools/make_golden.py
+The fixtures are small (< 1 MB): per-frame scalars and hashes for a short sequence plus the complete
+KeyLine list / mask of the last frame, so that tests can pin (a) the CPU restatement oracle/port and
+(b) the HIP path even where oracle/_ref is not available.
+"""
+import hashlib
+import os
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from oracle import oracle  # noqa: E402
+from rebvo_amd import synth  # noqa: E402
+
+
+def sha(a):
+    return hashlib.sha256(np.ascontiguousarray(a).tobytes()).hexdigest()
+
+
+def make(name, w, h, frames, **over):
+    orc = oracle.Oracle("ref", oracle.euroc_params(w, h, **over))
+    rec = dict(kn=[], tresh=[], retuned=[], mask_sha=[], dog_sha=[], img0_sha=[], V=[], W=[], Pos=[], klm_num=[],
+               klm_fwd=[], s_rho_q=[], Kp=[], RKp=[], ok=[], score=[])
+    for k, f in enumerate(frames):
+        _, nav = orc.process_frame(f, 0.05 * k)
+        s = orc.cur_slot()
+        rec["kn"].append(nav.kn); rec["tresh"].append(nav.tresh); rec["retuned"].append(nav.retuned_thresh)
+        rec["mask_sha"].append(sha(orc.mask(s))); rec["dog_sha"].append(sha(orc.plane(s, "dog")))
+        rec["img0_sha"].append(sha(orc.plane(s, "img0")))
+        rec["V"].append(nav.V[:]); rec["W"].append(nav.W[:]); rec["Pos"].append(nav.Pos[:])
+        rec["klm_num"].append(nav.klm_num); rec["klm_fwd"].append(nav.klm_fwd); rec["s_rho_q"].append(nav.s_rho_q)
+        rec["Kp"].append(nav.Kp); rec["RKp"].append(nav.RKp); rec["ok"].append(nav.estimation_ok)
+        rec["score"].append(nav.score)
+    s = orc.cur_slot()
+    kl = orc.keylines(s)
+    out = {k: np.array(v) for k, v in rec.items()}
+    out["last_keylines"] = np.frombuffer(kl.tobytes(), dtype=np.uint8)
+    out["last_mask"] = orc.mask(s).astype(np.int32)
+    out["frames"] = np.stack([f[:, :, 0] for f in frames]).astype(np.uint8)  # r=g=b
+    out["over"] = np.array(repr(sorted(over.items())))
+    path = os.path.join(ROOT, "tests", "golden", name + ".npz")
+    np.savez_compressed(path, **out)
+    print(name, "kn", rec["kn"], "klm", rec["klm_num"], os.path.getsize(path), "bytes")
+
+
+if __name__ == "__main__":
+    if not oracle.available("ref"):
+        raise SystemExit("oracle/_ref/libreforacle.so missing: run `make -C oracle ref` where /root/reference exists")
+    make("rects_192x144", 192, 144, list(synth.rects_sequence(192, 144, 6, seed=3)))
+    make("billboard_256x192", 256, 192, [f for f, _, _ in synth.billboard_sequence(256, 192, 7)],
+         max_points=4000, reference_points=3000, track_points=3000, global_match_threshold=200)
+    make("truncate_200x150", 200, 150, list(synth.rects_sequence(200, 150, 3, seed=5)),
+         max_points=300, reference_points=250, track_points=250, global_match_threshold=50)
