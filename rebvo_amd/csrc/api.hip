@@ -3,6 +3,7 @@
 
 #include <math.h>
 #include <stdio.h>
+#include <stdlib.h>
 #include <string.h>
 
 #include <algorithm>
@@ -245,7 +246,13 @@ int edgehip_create(const edgehip_params *params, int nseq, int nslots, int devic
     EH_TRY(dmalloc(c, &c->resid_carry, (size_t)kResidBufs * B * c->nblk_tvr, al->dev, 0));
     EH_TRY(dmalloc(c, &c->partials, B * c->nblk_tvr * kNumSums, al->dev, 0));
     EH_TRY(dmalloc(c, &c->block_last, B * c->nblk_tvr, al->dev, 0));
+    EH_TRY(dmalloc(c, &c->bin_cnt, B * 256, al->dev, 0));
+    {
+        const size_t ntiles = (size_t)((p.w + 63) / 64) * ((p.h + 63) / 64);
+        EH_TRY(dmalloc(c, &c->bins, B * ntiles * CAP, al->dev));
+    }
     c->field_radius = p.search_range;
+    c->field_mode = getenv("EDGEHIP_FIELD_MODE") ? atoi(getenv("EDGEHIP_FIELD_MODE")) : 0;
     EH_TRY(dmalloc(c, &c->fwd_key, B * CAP, al->dev, 0));
     EH_TRY(dmalloc(c, &c->fwd_win, B * CAP, al->dev, 0xFF));
     EH_TRY(dmalloc(c, &c->rs_tmp, B * 2 * CAP, al->dev, 0));

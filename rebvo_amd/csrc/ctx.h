@@ -113,6 +113,9 @@ struct edgehip_ctx {
     double *partials;      // [B][nblk_tvr][kNumSums]
     double *block_last;    // [B][nblk_tvr] last valid residual of each block of the running evaluation
     int field_radius;      // radius of the last build_field (global_tracker::max_r)
+    int field_mode;        // 0 = binned tiles (default), 1 = global-atomic scatter, 2 = mask-scan tiles (A/B)
+    int32_t *bin_cnt;      // [B][256] KeyLines binned per field tile
+    int32_t *bins;         // [B][256][CAP] KeyLine ids per field tile (allocated for the tiles in use)
     int nblk_tvr;
     unsigned long long *fwd_key;  // [B][CAP] forward-match arbitration keys
     int32_t *fwd_win;      // [B][CAP]

@@ -28,6 +28,7 @@
 // Compile with -ffp-contract=off: the reference is built without FMA contraction.
 
 #include <math.h>
+#include <stdlib.h>
 #include <string.h>
 
 #include "ctx.h"
@@ -150,12 +151,51 @@ __device__ __forceinline__ float box_avg(const float *__restrict__ ii, int x, in
     if (yt < 0) cy = y + d2 + 1;
     const bool bottom = yb > h - 1;
     if (bottom) { yb = h - 1; cy = h - y + d2; }
+    // unconditional (clamped) loads + selects: no divergent branches, all four taps in flight together
+    const int xlc = xl < 0 ? 0 : xl, ytc = yt < 0 ? 0 : yt;
     const float A = ii[(size_t)yb * w + xr];
-    const float B = xl >= 0 ? ii[(size_t)yb * w + xl] : 0.f;
-    const float C = yt >= 0 ? ii[(size_t)yt * w + xr] : 0.f;
-    const float D = (xl >= 0 && yt >= 0) ? ii[(size_t)yt * w + xl] : 0.f;
+    float B = ii[(size_t)yb * w + xlc];
+    float C = ii[(size_t)ytc * w + xr];
+    float D = ii[(size_t)ytc * w + xlc];
+    const float m = lut[cx * cy];
+    B = xl >= 0 ? B : 0.f;
+    C = yt >= 0 ? C : 0.f;
+    D = (xl >= 0 && yt >= 0) ? D : 0.f;
     const float t = bottom ? ((A - C) - B) + D : ((A - B) - C) + D;
-    return t * lut[cx * cy];
+    return t * m;
+}
+
+// Same arithmetic, split so that callers can put the tap loads of several pixels in flight before any use.
+struct BoxTaps {
+    float A, B, C, D, m;
+    bool bottom;
+};
+__device__ __forceinline__ BoxTaps box_taps(const float *__restrict__ ii, int x, int y, int w, int h, int d, int d2,
+                                            const float *__restrict__ lut, float a_int) {
+    int xr = x + d2, yb = y + d2;
+    const int xl = x - d2 - 1, yt = y - d2 - 1;
+    int cx = d, cy = d;
+    if (xl < 0) cx = x + d2 + 1;
+    if (xr > w - 1) { xr = w - 1; cx = w - x + d2; }
+    if (yt < 0) cy = y + d2 + 1;
+    BoxTaps t;
+    t.bottom = yb > h - 1;
+    if (t.bottom) { yb = h - 1; cy = h - y + d2; }
+    const int xlc = xl < 0 ? 0 : xl, ytc = yt < 0 ? 0 : yt;
+    t.A = ii[(size_t)yb * w + xr];
+    t.B = ii[(size_t)yb * w + xlc];
+    t.C = ii[(size_t)ytc * w + xr];
+    t.D = ii[(size_t)ytc * w + xlc];
+    t.m = a_int;                                  // interior: a = (float)(1.0/(d*d)) == lut[d*d]
+    if (cx * cy != d * d) t.m = lut[cx * cy];     // border pixels only (rare, mostly wave-uniform)
+    t.B = xl >= 0 ? t.B : 0.f;
+    t.C = yt >= 0 ? t.C : 0.f;
+    t.D = (xl >= 0 && yt >= 0) ? t.D : 0.f;
+    return t;
+}
+__device__ __forceinline__ float box_combine(const BoxTaps &t) {
+    const float s = t.bottom ? ((t.A - t.C) - t.B) + t.D : ((t.A - t.B) - t.C) + t.D;
+    return s * t.m;
 }
 
 // ---------------------------------------------------------------------------------------------------
@@ -229,6 +269,7 @@ struct CandStage {  // SoA staging of candidates: [B][nstrips][strip_cap]
 struct DetectArgs {
     const float *iic0, *iic1;  // last integral image of filter0 / filter1, [B][N]
     int d0, d1;                // last box widths
+    float a0, a1;              // (float)(1.0/(d*d)) of the last boxes
     const float *lut;
     const double *pinv;        // [3][25]
     float *planes;             // optional debug planes [5][B][N]
@@ -243,6 +284,7 @@ struct DetectArgs {
     int kl_ref;
     float dog_thresh_f;        // (float)DetectorDoGThresh
     double pn_thresh;          // (double)(25.0f * (float)DetectorPosNegThresh)
+    int ablate;                // debug: bit0 skip phase 1 math, bit1 skip 2a, bit2 skip 2b
 };
 
 __device__ __forceinline__ double update_thresh(double tresh, int l_kl_num, int kl_ref, double gain, double tmax,
@@ -272,26 +314,40 @@ __global__ __launch_bounds__(256) void k_detect(DetectArgs a) {
 
     // ---- phase 1: img0, img1 -> LDS (+ optional debug planes) ----
     const int d20 = a.d0 / 2, d21 = a.d1 / 2;
-    for (int idx = tid; idx < HR * w; idx += 256) {
-        const int r = idx / w, x = idx - r * w;
+    for (int r = 0; r < HR; r++) {
         const int y = yb0 + r;
-        float g0 = 0.f, g1 = 0.f;
-        if (y < h) {
-            g0 = box_avg(iic0, x, y, w, h, a.d0, d20, a.lut);
-            g1 = box_avg(iic1, x, y, w, h, a.d1, d21, a.lut);
+        if (y >= h) {
+            for (int x = tid; x < w; x += 256) { s_img0[r * w + x] = 0.f; s_dog[r * w + x] = 0.f; }
+            continue;
         }
-        s_img0[idx] = g0;
-        s_dog[idx] = g1 - g0;  // sspace.cpp:66
-        if (a.planes && y < h) {
-            // every image row is written by exactly one band: rows [y0, y0+BR) + the image borders
-            const bool own = (y >= y0 && y < y0 + kBandRows) || (band == 0 && y < 2) ||
-                             (y >= 2 + (int)gridDim.x * kBandRows);
-            if (own) {
-                float *pl = a.planes + so;
-                const size_t pstride = (size_t)a.nseq * a.n;
-                pl[0 * pstride + (size_t)y * w + x] = g0;
-                pl[1 * pstride + (size_t)y * w + x] = g1;
-                pl[2 * pstride + (size_t)y * w + x] = g1 - g0;
+        // every image row is written to the debug planes by exactly one band
+        const bool own = a.planes && ((y >= y0 && y < y0 + kBandRows) || (band == 0 && y < 2) ||
+                                      (y >= 2 + (int)gridDim.x * kBandRows));
+        // all tap loads of up to PX pixels x 2 filters are issued before the first use
+        constexpr int PX = 4;
+        for (int xb = 0; xb < w; xb += 256 * PX) {
+            BoxTaps t0[PX], t1[PX];
+#pragma unroll
+            for (int j = 0; j < PX; j++) {
+                int x = xb + j * 256 + tid;
+                x = x < w ? x : w - 1;
+                t0[j] = box_taps(iic0, x, y, w, h, a.d0, d20, a.lut, a.a0);
+                t1[j] = box_taps(iic1, x, y, w, h, a.d1, d21, a.lut, a.a1);
+            }
+#pragma unroll
+            for (int j = 0; j < PX; j++) {
+                const int x = xb + j * 256 + tid;
+                if (x >= w) continue;
+                const float g0 = box_combine(t0[j]), g1 = box_combine(t1[j]);
+                s_img0[r * w + x] = g0;
+                s_dog[r * w + x] = g1 - g0;  // sspace.cpp:66
+                if (own) {
+                    float *pl = a.planes + so;
+                    const size_t pstride = (size_t)a.nseq * a.n;
+                    pl[0 * pstride + (size_t)y * w + x] = g0;
+                    pl[1 * pstride + (size_t)y * w + x] = g1;
+                    pl[2 * pstride + (size_t)y * w + x] = g1 - g0;
+                }
             }
         }
     }
@@ -314,64 +370,82 @@ __global__ __launch_bounds__(256) void k_detect(DetectArgs a) {
     const int nstrips = gridDim.x * 4;
     const size_t sbase = ((size_t)seq * nstrips + strip) * a.strip_cap;
     int32_t *mask = a.mask + so;
+    // 2a: cheap gradient gate on every pixel of the strip; survivors are compacted (raster order kept)
+    //     into a per-wave LDS list so that the expensive window tests run with full lanes.
+    uint16_t *s_list = reinterpret_cast<uint16_t *>(s_dog + (size_t)HR * w) + (size_t)wave * cpw * 64;
+    int nlist = 0;
+    if (!(a.ablate & 2)) {
+        int q = wave * cpw * 64 + lane;
+        int r = q / w, x = q - r * w;  // one division per thread; then advance by 64 pixels per chunk
+        for (int ci = 0; ci < cpw; ci++, q += 64, x += 64) {
+            while (x >= w) { x -= w; r++; }
+            const int y = y0 + r;
+            bool pass = false;
+            if (q < npx && y < h - 2) {
+                // default: no KeyLine (edge_finder.cpp:109); border columns are never KeyLines either
+                mask[(size_t)y * w + x] = -1;
+                if (x >= 2 && x < w - 2) {
+                    const float *c0 = s_img0 + (size_t)(r + 2) * w + x;
+                    const float dx = c0[1] - c0[-1];   // sspace.cpp:80
+                    const float dy = c0[w] - c0[-w];   // sspace.cpp:81
+                    if (a.planes) {
+                        float *pl = a.planes + so;
+                        const size_t pstride = (size_t)a.nseq * a.n;
+                        pl[3 * pstride + (size_t)y * w + x] = dx;
+                        pl[4 * pstride + (size_t)y * w + x] = dy;
+                    }
+                    const float n2g = dx * dx + dy * dy;
+                    pass = !(n2g < thr_g);
+                }
+            }
+            const unsigned long long bal = __ballot(pass);
+            if (pass) s_list[nlist + __popcll(bal & ((1ull << lane) - 1ull))] = (uint16_t)q;
+            nlist += __popcll(bal);
+        }
+    }
+    // 2b: DoG sign balance, plane fit, sub-pixel zero crossing, DoG-gradient gate (edge_finder.cpp:125-159)
     int count = 0;  // wave-uniform running count of the strip
-    for (int ci = 0; ci < cpw; ci++) {
-        const int q = (wave * cpw + ci) * 64 + lane;
-        const int r = q / w, x = q - r * w;
-        const int y = y0 + r;
-        const bool inband = q < npx && y < h - 2;
+    for (int base = 0; base < ((a.ablate & 4) ? 0 : nlist); base += 64) {
+        const int li = base + lane;
         bool cand = false;
         float mx = 0.f, my = 0.f, xs = 0.f, ys = 0.f;
-        if (inband) {
-            // default: no KeyLine (edge_finder.cpp:109); border columns are never KeyLines either
-            mask[(size_t)y * w + x] = -1;
-            if (x >= 2 && x < w - 2) {
-                const int lr = r + 2;  // LDS row of the pixel
-                const float *c0 = s_img0 + (size_t)lr * w + x;
-                const float dx = c0[1] - c0[-1];   // sspace.cpp:80
-                const float dy = c0[w] - c0[-w];   // sspace.cpp:81
-                if (a.planes) {
-                    float *pl = a.planes + so;
-                    const size_t pstride = (size_t)a.nseq * a.n;
-                    pl[3 * pstride + (size_t)y * w + x] = dx;
-                    pl[4 * pstride + (size_t)y * w + x] = dy;
+        int pix = 0;
+        if (li < nlist) {
+            const int q = s_list[li];
+            const int r = q / w, x = q - r * w;
+            pix = (y0 + r) * w + x;
+            const float *dg = s_dog + (size_t)(r + 2) * w + x;
+            int pn = 0;
+            double t0 = 0, t1 = 0, t2 = 0;
+#pragma unroll
+            for (int i = -2, k = 0; i <= 2; i++) {
+#pragma unroll
+                for (int j = -2; j <= 2; j++, k++) {
+                    const float v = dg[i * w + j];
+                    pn += (v > 0) ? 1 : -1;
+                    const double yv = (double)v;
+                    t0 += s_pinv[k] * yv;          // TooN dot product: result += a[i]*b[i]
+                    t1 += s_pinv[25 + k] * yv;
+                    t2 += s_pinv[50 + k] * yv;
                 }
-                const float n2g = dx * dx + dy * dy;
-                if (!(n2g < thr_g)) {
-                    const float *dg = s_dog + (size_t)lr * w + x;
-                    int pn = 0;
-                    double t0 = 0, t1 = 0, t2 = 0;
-#pragma unroll
-                    for (int i = -2, k = 0; i <= 2; i++) {
-#pragma unroll
-                        for (int j = -2; j <= 2; j++, k++) {
-                            const float v = dg[i * w + j];
-                            pn += (v > 0) ? 1 : -1;
-                            const double yv = (double)v;
-                            t0 += s_pinv[k] * yv;          // TooN dot product: result += a[i]*b[i]
-                            t1 += s_pinv[25 + k] * yv;
-                            t2 += s_pinv[50 + k] * yv;
-                        }
-                    }
-                    const int apn = pn < 0 ? -pn : pn;
-                    if (!((double)apn > a.pn_thresh)) {
-                        const double den = t0 * t0 + t1 * t1;
-                        xs = (float)(-t0 * t2 / den);
-                        ys = (float)(-t1 * t2 / den);
-                        if (!(fabsf(xs) > 0.5f || fabsf(ys) > 0.5f)) {
-                            mx = (float)t0;
-                            my = (float)t1;
-                            const float n2m = mx * mx + my * my;
-                            if (!(n2m < thr_d)) cand = true;
-                        }
-                    }
+            }
+            const int apn = pn < 0 ? -pn : pn;
+            if (!((double)apn > a.pn_thresh)) {
+                const double den = t0 * t0 + t1 * t1;
+                xs = (float)(-t0 * t2 / den);
+                ys = (float)(-t1 * t2 / den);
+                if (!(fabsf(xs) > 0.5f || fabsf(ys) > 0.5f)) {
+                    mx = (float)t0;
+                    my = (float)t1;
+                    const float n2m = mx * mx + my * my;
+                    if (!(n2m < thr_d)) cand = true;
                 }
             }
         }
         const unsigned long long bal = __ballot(cand);
         if (cand) {
             const int rank = count + __popcll(bal & ((1ull << lane) - 1ull));
-            a.st.p_inx[sbase + rank] = y * w + x;
+            a.st.p_inx[sbase + rank] = pix;
             a.st.m[sbase + rank] = make_float2(mx, my);
             a.st.s[sbase + rank] = make_float2(xs, ys);
         }
@@ -569,16 +643,18 @@ __global__ __launch_bounds__(256) void k_join_histo(KlSoA *kls, const int32_t *_
 //     for(int a=0; i<n && a<knum; i++, a+=histo[i]);
 // accumulates histo[i] AFTER incrementing i, i.e. bin 0 is never counted (and histo[n] is read past the
 // end on the last step, where it no longer matters).
-__global__ void k_retune(SeqDev *seqs, const int32_t *__restrict__ histo, float *__restrict__ retuned_out, int nseq,
-                         int knum, int nbins) {
-    const int seq = blockIdx.x * blockDim.x + threadIdx.x;
-    if (seq >= nseq) return;
+__global__ __launch_bounds__(256) void k_retune(SeqDev *seqs, const int32_t *__restrict__ histo, float *__restrict__ retuned_out,
+                                                int nseq, int knum, int nbins) {
+    const int seq = blockIdx.x;
+    __shared__ int s_h[256];
+    s_h[threadIdx.x] = histo[(size_t)seq * 256 + threadIdx.x];
+    __syncthreads();
+    if (threadIdx.x != 0) return;
     SeqDev *sq = seqs + seq;
-    const int32_t *hs = histo + (size_t)seq * 256;
     int i = 0;
     for (int acc = 0; i < nbins && acc < knum;) {
         i++;
-        if (i < nbins) acc += hs[i];
+        if (i < nbins) acc += s_h[i];
     }
     const float mxd = sq->nm_max, mnd = sq->nm_min;
     float r = mxd - (float)i * (mxd - mnd) / (float)nbins;
@@ -684,6 +760,7 @@ int stage_a_enqueue(edgehip_ctx *c, int slot) {
         DetectArgs a;
         a.iic0 = cur[0]; a.iic1 = cur[1];
         a.d0 = pl.box[0][kMaxBoxes - 1]; a.d1 = pl.box[1][kMaxBoxes - 1];
+        a.a0 = pl.box_a[0][kMaxBoxes - 1]; a.a1 = pl.box_a[1][kMaxBoxes - 1];
         a.lut = c->div_lut; a.pinv = c->pinv;
         a.planes = c->planes;
         a.mask = maskof(c, slot);
@@ -696,7 +773,9 @@ int stage_a_enqueue(edgehip_ctx *c, int slot) {
         a.dog_thresh_f = (float)c->p.dog_thresh;
         const int ws = c->p.plane_fit_size;
         a.pn_thresh = (double)(((float)((2.0 * ws + 1.0) * (2.0 * ws + 1.0))) * (float)c->p.pos_neg_thresh);
-        const size_t sm = (size_t)2 * (kBandRows + 4) * w * sizeof(float);
+        a.ablate = getenv("EDGEHIP_ABLATE") ? atoi(getenv("EDGEHIP_ABLATE")) : 0;
+        const int npx_b = kBandRows * w, cpw_b = (((npx_b + 63) >> 6) + 3) >> 2;
+        const size_t sm = (size_t)2 * (kBandRows + 4) * w * sizeof(float) + (size_t)4 * cpw_b * 64 * sizeof(uint16_t);
         hipLaunchKernelGGL(k_detect, dim3(nbands, 1, B), dim3(256), sm, st, a);
         EH_LAUNCH_CHECK();
     }
@@ -720,7 +799,7 @@ int stage_a_enqueue(edgehip_ctx *c, int slot) {
         hipLaunchKernelGGL(k_join_histo, dim3((pl.cap + 255) / 256, 1, B), dim3(256), 0, st, kldev(c, slot),
                            maskof(c, slot), c->seq, c->histo, w, n, c->p.qcut_nbins);
         EH_LAUNCH_CHECK();
-        hipLaunchKernelGGL(k_retune, dim3((B + 63) / 64), dim3(64), 0, st, c->seq, c->histo,
+        hipLaunchKernelGGL(k_retune, dim3(B), dim3(256), 0, st, c->seq, c->histo,
                            c->retuned_slot + (size_t)slot * B, B, c->p.track_points,
                            c->p.qcut_nbins);
         EH_LAUNCH_CHECK();

@@ -95,6 +95,220 @@ __global__ __launch_bounds__(256) void k_field_scatter(const KlSoA *kls, const i
 }
 
 // ---------------------------------------------------------------------------------------------------
+// build_field, tiled: one block per FT x FT pixel tile.  The per-pixel result of the sequential scatter is
+// order independent (min over dist<<16 | 0xFFFF-ikl), so instead of ~kn*2r global atomics the block
+//   1. walks img_mask_kl over the tile grown by the radius (the only KeyLines whose segment can reach it),
+//      FG rows at a time, compacting the KeyLine ids it finds into an LDS list,
+//   2. lets each thread take KeyLines off the list and rasterise only the t-range that can fall in the tile
+//      (same float expression as the reference, :78), min-reducing into an LDS copy of the tile,
+//   3. stores the tile coalesced (which also replaces the field clear).
+// ---------------------------------------------------------------------------------------------------
+constexpr int FT = 64;    // tile edge
+constexpr int FG = 12;    // mask rows scanned per list fill
+
+__global__ __launch_bounds__(256) void k_field_tiles(const KlSoA *kls, const int32_t *__restrict__ masks,
+                                                     const float *__restrict__ retuned, uint32_t *__restrict__ field,
+                                                     int w, int h, size_t n, int radius, float min_mod_arg) {
+    __shared__ uint32_t s_tile[FT * FT];
+    __shared__ int s_list[4096];
+    __shared__ int s_cnt;
+    const int seq = blockIdx.z, tid = threadIdx.x, lane = tid & 63;
+    const int tx0 = blockIdx.x * FT, ty0 = blockIdx.y * FT;
+    const KlSoA &k = kls[seq];
+    const int32_t *mask = masks + (size_t)seq * n;
+    const float min_mod = min_mod_arg < 0.f ? retuned[seq] : min_mod_arg;
+    for (int i = tid; i < FT * FT; i += 256) s_tile[i] = 0xFFFFFFFFu;
+    if (tid == 0) s_cnt = 0;
+    // region of KeyLine centres that can reach the tile: c_p = pixel + (xs,ys), |xs|,|ys| <= 0.5, |u*t| <= r
+    const int rx0 = max(tx0 - radius - 1, 0), rx1 = min(tx0 + FT + radius + 1, w);
+    const int ry0 = max(ty0 - radius - 1, 0), ry1 = min(ty0 + FT + radius + 1, h);
+    const int rw = rx1 - rx0;
+    const int rows_per_fill = max(1, min(FG, 4096 / rw));
+    __syncthreads();
+    for (int yg = ry0; yg < ry1; yg += rows_per_fill) {
+        const int ye = min(yg + rows_per_fill, ry1);
+        const int npx = (ye - yg) * rw;
+        for (int base = 0; base < npx; base += 256) {
+            const int idx = base + tid;
+            int id = -1;
+            if (idx < npx) {
+                const int yy = yg + idx / rw, xx = rx0 + idx % rw;
+                id = mask[(size_t)yy * w + xx];
+            }
+            const unsigned long long bal = __ballot(id >= 0);
+            int wbase = 0;
+            if (lane == 0 && bal) wbase = atomicAdd(&s_cnt, __popcll(bal));
+            wbase = __shfl(wbase, 0, 64);
+            if (id >= 0) s_list[wbase + __popcll(bal & ((1ull << lane) - 1ull))] = id;
+        }
+        __syncthreads();
+        const int cnt = s_cnt;
+        for (int li = tid; li < cnt; li += 256) {
+            const int ikl = s_list[li];
+            const MatchRec r = k.rec[ikl];
+            if (min_mod > 0 && r.n_m < min_mod) continue;
+            // conservative t-range whose samples can land inside the tile (exact test per sample below)
+            float tlo = (float)(-radius), thi = (float)(radius - 1);
+            const float bx0 = (float)tx0 - 1.f - r.c_px, bx1 = (float)(tx0 + FT) - r.c_px;
+            const float by0 = (float)ty0 - 1.f - r.c_py, by1 = (float)(ty0 + FT) - r.c_py;
+            if (fabsf(r.u_mx) > 1e-6f) {
+                const float a = bx0 / r.u_mx, b = bx1 / r.u_mx;
+                tlo = fmaxf(tlo, fminf(a, b) - 1.f);
+                thi = fminf(thi, fmaxf(a, b) + 1.f);
+            } else if (bx0 > 0.f || bx1 < 0.f) continue;
+            if (fabsf(r.u_my) > 1e-6f) {
+                const float a = by0 / r.u_my, b = by1 / r.u_my;
+                tlo = fmaxf(tlo, fminf(a, b) - 1.f);
+                thi = fminf(thi, fmaxf(a, b) + 1.f);
+            } else if (by0 > 0.f || by1 < 0.f) continue;
+            const int t0 = (int)floorf(tlo), t1 = (int)ceilf(thi);
+            const uint32_t idk = (uint32_t)(0xFFFF - ikl);
+            for (int t = max(t0, -radius); t <= min(t1, radius - 1); t++) {
+                const float fx = r.u_mx * (float)t + r.c_px;
+                const float fy = r.u_my * (float)t + r.c_py;
+                const int xi = (int)roundf(fx), yi = (int)roundf(fy);  // Image::GetIndexRC uses round()
+                if (xi >= w || yi >= h || xi < 0 || yi < 0) continue;
+                const int lx = xi - tx0, ly = yi - ty0;
+                if ((unsigned)lx >= (unsigned)FT || (unsigned)ly >= (unsigned)FT) continue;
+                const uint32_t at = (uint32_t)(t < 0 ? -t : t);
+                atomicMin(&s_tile[ly * FT + lx], (at << 16) | idk);
+            }
+        }
+        __syncthreads();
+        if (tid == 0) s_cnt = 0;
+        __syncthreads();
+    }
+    uint32_t *out = field + (size_t)seq * n;
+    for (int i = tid; i < FT * FT; i += 256) {
+        const int ly = i / FT, lx = i % FT;
+        const int x = tx0 + lx, y = ty0 + ly;
+        if (x < w && y < h) out[(size_t)y * w + x] = s_tile[i];
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------
+// build_field, binned: (1) k_field_bin — thread per KeyLine: which FT x FT tiles can its +-radius segment
+// touch?  Ids are appended to per-tile bins; the 256 KeyLines of a block are raster neighbours and hit the
+// same few tiles, so ranks are taken from LDS counters and only one global atomic per (block, tile) reserves
+// the slots.  (2) k_field_raster — block per tile: rasterise the binned KeyLines' in-tile t-ranges into an
+// LDS tile with atomicMin, then store the tile coalesced (no separate clear pass).  Bin order is
+// irrelevant: the per-pixel result is a min.
+// ---------------------------------------------------------------------------------------------------
+constexpr int kMaxTiles = 256;
+
+__device__ __forceinline__ bool tile_trange(const MatchRec &r, int tx0, int ty0, int radius, int &t0, int &t1) {
+    // conservative t-range whose samples round into the tile [tx0,tx0+FT) x [ty0,ty0+FT)
+    float tlo = (float)(-radius), thi = (float)(radius - 1);
+    const float bx0 = (float)tx0 - 1.f - r.c_px, bx1 = (float)(tx0 + FT) - r.c_px;
+    const float by0 = (float)ty0 - 1.f - r.c_py, by1 = (float)(ty0 + FT) - r.c_py;
+    if (fabsf(r.u_mx) > 1e-6f) {
+        const float a = bx0 / r.u_mx, b = bx1 / r.u_mx;
+        tlo = fmaxf(tlo, fminf(a, b) - 1.f);
+        thi = fminf(thi, fmaxf(a, b) + 1.f);
+    } else if (bx0 > 0.f || bx1 < 0.f) return false;
+    if (fabsf(r.u_my) > 1e-6f) {
+        const float a = by0 / r.u_my, b = by1 / r.u_my;
+        tlo = fmaxf(tlo, fminf(a, b) - 1.f);
+        thi = fminf(thi, fmaxf(a, b) + 1.f);
+    } else if (by0 > 0.f || by1 < 0.f) return false;
+    t0 = max((int)floorf(tlo), -radius);
+    t1 = min((int)ceilf(thi), radius - 1);
+    return t0 <= t1;
+}
+
+__global__ __launch_bounds__(256) void k_field_bin(const KlSoA *kls, const int32_t *__restrict__ kns,
+                                                   const float *__restrict__ retuned, int32_t *__restrict__ bin_cnt,
+                                                   int32_t *__restrict__ bins, int w, int h, int radius, float min_mod_arg,
+                                                   int ntx, int nty, int bin_cap) {
+    __shared__ int s_cnt[kMaxTiles], s_base[kMaxTiles];
+    const int seq = blockIdx.z, tid = threadIdx.x;
+    const int i = blockIdx.x * 256 + tid;
+    const int kn = kns[seq];
+    if (blockIdx.x * 256 >= kn) return;
+    const int ntiles = ntx * nty;
+    for (int t = tid; t < ntiles; t += 256) s_cnt[t] = 0;
+    __syncthreads();
+    bool active = i < kn;
+    MatchRec r;
+    int txa = 0, txb = -1, tya = 0, tyb = -1;
+    if (active) {
+        r = kls[seq].rec[i];
+        const float min_mod = min_mod_arg < 0.f ? retuned[seq] : min_mod_arg;
+        if (min_mod > 0 && r.n_m < min_mod) active = false;
+    }
+    if (active) {
+        const float rr = (float)radius + 1.5f;
+        const float xa = r.c_px - fabsf(r.u_mx) * rr, xb = r.c_px + fabsf(r.u_mx) * rr;
+        const float ya = r.c_py - fabsf(r.u_my) * rr, yb = r.c_py + fabsf(r.u_my) * rr;
+        txa = max((int)floorf(xa) / FT, 0); txb = min((int)floorf(xb) / FT, ntx - 1);
+        tya = max((int)floorf(ya) / FT, 0); tyb = min((int)floorf(yb) / FT, nty - 1);
+        if (xb < 0.f || yb < 0.f) txb = -1;
+    }
+    // pass A: count per tile (LDS)
+    for (int ty = tya; ty <= tyb; ty++)
+        for (int tx = txa; tx <= txb; tx++) {
+            int t0, t1;
+            if (tile_trange(r, tx * FT, ty * FT, radius, t0, t1)) atomicAdd(&s_cnt[ty * ntx + tx], 1);
+        }
+    __syncthreads();
+    for (int t = tid; t < ntiles; t += 256) {
+        const int c = s_cnt[t];
+        s_base[t] = c ? atomicAdd(&bin_cnt[(size_t)seq * kMaxTiles + t], c) : 0;
+        s_cnt[t] = 0;
+    }
+    __syncthreads();
+    // pass B: write ids
+    for (int ty = tya; ty <= tyb; ty++)
+        for (int tx = txa; tx <= txb; tx++) {
+            int t0, t1;
+            if (tile_trange(r, tx * FT, ty * FT, radius, t0, t1)) {
+                const int t = ty * ntx + tx;
+                const int pos = s_base[t] + atomicAdd(&s_cnt[t], 1);
+                if (pos < bin_cap) bins[((size_t)seq * ntiles + t) * bin_cap + pos] = i;
+            }
+        }
+}
+
+__global__ __launch_bounds__(256) void k_field_raster(const KlSoA *kls, const int32_t *__restrict__ bin_cnt,
+                                                      const int32_t *__restrict__ bins, uint32_t *__restrict__ field,
+                                                      int w, int h, size_t n, int radius, int ntx, int bin_cap) {
+    __shared__ uint32_t s_tile[FT * FT];
+    const int ntiles = ntx * gridDim.y;
+    const int seq = blockIdx.z, tid = threadIdx.x;
+    const int tx0 = blockIdx.x * FT, ty0 = blockIdx.y * FT;
+    const int tile = blockIdx.y * ntx + blockIdx.x;
+    for (int i = tid; i < FT * FT; i += 256) s_tile[i] = 0xFFFFFFFFu;
+    __syncthreads();
+    const int cnt = min(bin_cnt[(size_t)seq * kMaxTiles + tile], bin_cap);
+    const int32_t *list = bins + ((size_t)seq * ntiles + tile) * bin_cap;
+    const KlSoA &k = kls[seq];
+    for (int li = tid; li < cnt; li += 256) {
+        const int ikl = list[li];
+        const MatchRec r = k.rec[ikl];
+        int t0, t1;
+        if (!tile_trange(r, tx0, ty0, radius, t0, t1)) continue;
+        const uint32_t idk = (uint32_t)(0xFFFF - ikl);
+        for (int t = t0; t <= t1; t++) {
+            const float fx = r.u_mx * (float)t + r.c_px;   // global_tracker.cpp:78, same float expression
+            const float fy = r.u_my * (float)t + r.c_py;
+            const int xi = (int)roundf(fx), yi = (int)roundf(fy);  // Image::GetIndexRC uses round()
+            if (xi >= w || yi >= h || xi < 0 || yi < 0) continue;
+            const int lx = xi - tx0, ly = yi - ty0;
+            if ((unsigned)lx >= (unsigned)FT || (unsigned)ly >= (unsigned)FT) continue;
+            const uint32_t at = (uint32_t)(t < 0 ? -t : t);
+            atomicMin(&s_tile[ly * FT + lx], (at << 16) | idk);
+        }
+    }
+    __syncthreads();
+    uint32_t *out = field + (size_t)seq * n;
+    for (int i = tid; i < FT * FT; i += 256) {
+        const int ly = i / FT, lx = i % FT;
+        const int x = tx0 + lx, y = ty0 + ly;
+        if (x < w && y < h) out[(size_t)y * w + x] = s_tile[i];
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------
 // KltoI3PMatrix + ProyI3Pto3PMatrix: P0 = (x*z/zf, y*z/zf, z), z = 1/rho  (once per frame pair)
 // ---------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void k_tvr_prepare(const KlSoA *kls, const int32_t *__restrict__ kns, double *__restrict__ P0,
@@ -158,6 +372,41 @@ __device__ inline void tvr_setup(SeqDev *sq, const double X[6]) {
     for (int i = 0; i < 9; i++) sq->Rt[i] = R0[i];  // row-major R0(i,j)
     sq->RM[0] = Rz[0]; sq->RM[1] = Rz[1]; sq->RM[2] = Rz[3]; sq->RM[3] = Rz[4];
     for (int i = 0; i < 3; i++) sq->Vt[i] = X[i];
+}
+
+// ---------------------------------------------------------------------------------------------------
+// Sum 28 per-lane values across the 64 lanes of a wave with 29 double shuffles instead of 28*6: at every
+// butterfly step a lane keeps one half of its values and hands the other half to its partner, so the
+// number of live values halves (28 -> 14 -> 7 -> 4 -> 2 -> 1) while the partial sums double in coverage.
+// On return v[0] of lane l is the full sum of value
+//     idx = b1 + 2*b2 + 4*b3 + 7*b4 + 14*b5      (b_k = bit k of l; lanes with b1+2*b2+4*b3 == 7 hold padding)
+// and lanes l, l^1 hold the same value.  Fixed order => bit-reproducible from run to run.
+// ---------------------------------------------------------------------------------------------------
+template <int N>
+__device__ __forceinline__ void halve_step(double *v, int lane, int off) {
+    const bool hi = (lane & off) != 0;
+#pragma unroll
+    for (int i = 0; i < N; i++) {
+        const double send = hi ? v[i] : v[i + N];
+        const double keep = hi ? v[i + N] : v[i];
+        v[i] = keep + __shfl_xor(send, off, 64);
+    }
+}
+__device__ __forceinline__ int wave_reduce28(double (&s)[kNumSums], int lane) {
+    double v[32];
+#pragma unroll
+    for (int i = 0; i < kNumSums; i++) v[i] = s[i];
+    halve_step<14>(v, lane, 32);   // 28 -> 14
+    halve_step<7>(v, lane, 16);    // 14 -> 7
+    v[7] = 0.0;
+    halve_step<4>(v, lane, 8);     // 8 -> 4
+    halve_step<2>(v, lane, 4);     // 4 -> 2
+    halve_step<1>(v, lane, 2);     // 2 -> 1
+    v[0] += __shfl_xor(v[0], 1, 64);
+    s[0] = v[0];
+    const int b1 = (lane >> 1) & 1, b2 = (lane >> 2) & 1, b3 = (lane >> 3) & 1, b4 = (lane >> 4) & 1, b5 = (lane >> 5) & 1;
+    const int low = b1 + 2 * b2 + 4 * b3;
+    return low == 7 ? 31 : low + 7 * b4 + 14 * b5;
 }
 
 // ---------------------------------------------------------------------------------------------------
@@ -346,20 +595,21 @@ __global__ __launch_bounds__(kTvrBlock) void k_try_velrot(TvrArgs a) {
     }
     sums[ns++] = fm * fm;
 
-    // ---- block reduction: wave shuffles, then LDS across waves, one partial per block ----
-    __shared__ double s_red[4][kNumSums];
-    const int nsum = PROCJF ? kNumSums : 1;
-#pragma unroll
-    for (int s = 0; s < (PROCJF ? kNumSums : 1); s++) {
-        double v = sums[s];
+    // ---- block reduction: transposed (halving) wave reduction, LDS across waves, one partial per block ----
+    __shared__ double s_red[4][32];
+    if (PROCJF) {
+        const int idx = wave_reduce28(sums, lane);
+        if ((lane & 1) == 0) s_red[wave][idx] = sums[0];
+    } else {
+        double v = sums[0];
 #pragma unroll
         for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
-        if (lane == 0) s_red[wave][s] = v;
+        if (lane == 0) s_red[wave][kNumSums - 1] = v;
     }
     __syncthreads();
-    if (tid < nsum) {
+    if (PROCJF ? tid < kNumSums : tid == kNumSums - 1) {
         const double v = ((s_red[0][tid] + s_red[1][tid]) + s_red[2][tid]) + s_red[3][tid];
-        a.partials[((size_t)seq * a.nblk + blk) * kNumSums + (PROCJF ? tid : kNumSums - 1)] = v;
+        a.partials[((size_t)seq * a.nblk + blk) * kNumSums + tid] = v;
     }
 }
 
@@ -370,32 +620,41 @@ __global__ __launch_bounds__(kTvrBlock) void k_try_velrot(TvrArgs a) {
 // TooN::SVD<> (for a symmetric matrix singular values = |e|, U = V*sign(e)).
 __device__ inline void jacobi_eig6(const double Ain[36], double V[36], double e[6]) {
     double A[36];
+#pragma unroll
     for (int i = 0; i < 36; i++) { A[i] = Ain[i]; V[i] = 0; }
+#pragma unroll
     for (int i = 0; i < 6; i++) V[i * 7] = 1;
     for (int sweep = 0; sweep < 30; sweep++) {
         double off = 0, diag = 0;
+#pragma unroll
         for (int p = 0; p < 6; p++) {
             diag += A[p * 7] * A[p * 7];
+#pragma unroll
             for (int q = p + 1; q < 6; q++) off += A[p * 6 + q] * A[p * 6 + q];
         }
-        if (!(off > 1e-60 * diag) || !(off > 0)) break;
+        if (!(off > 1e-32 * diag) || !(off > 0)) break;  // off-diagonal energy below fp64 roundoff of the diagonal
+#pragma unroll
         for (int p = 0; p < 5; p++)
+#pragma unroll
             for (int q = p + 1; q < 6; q++) {
                 const double apq = A[p * 6 + q];
                 if (apq == 0) continue;
                 const double theta = (A[q * 7] - A[p * 7]) / (2 * apq);
                 const double t = (theta >= 0 ? 1.0 : -1.0) / (fabs(theta) + sqrt(theta * theta + 1));
                 const double c = 1 / sqrt(t * t + 1), s = t * c;
+#pragma unroll
                 for (int k = 0; k < 6; k++) {
                     const double akp = A[k * 6 + p], akq = A[k * 6 + q];
                     A[k * 6 + p] = c * akp - s * akq;
                     A[k * 6 + q] = s * akp + c * akq;
                 }
+#pragma unroll
                 for (int k = 0; k < 6; k++) {
                     const double apk = A[p * 6 + k], aqk = A[q * 6 + k];
                     A[p * 6 + k] = c * apk - s * aqk;
                     A[q * 6 + k] = s * apk + c * aqk;
                 }
+#pragma unroll
                 for (int k = 0; k < 6; k++) {
                     const double vkp = V[k * 6 + p], vkq = V[k * 6 + q];
                     V[k * 6 + p] = c * vkp - s * vkq;
@@ -403,6 +662,7 @@ __device__ inline void jacobi_eig6(const double Ain[36], double V[36], double e[
                 }
             }
     }
+#pragma unroll
     for (int i = 0; i < 6; i++) e[i] = A[i * 7];
 }
 
@@ -411,16 +671,21 @@ __device__ inline void svd_backsub6(const double A[36], const double b[6], doubl
     double V[36], e[6];
     jacobi_eig6(A, V, e);
     double smax = 0;
+#pragma unroll
     for (int i = 0; i < 6; i++) smax = fmax(smax, fabs(e[i]));
     double y[6];
+#pragma unroll
     for (int i = 0; i < 6; i++) {
         double d = 0;
+#pragma unroll
         for (int k = 0; k < 6; k++) d += V[k * 6 + i] * b[k];
         const double inv = (fabs(e[i]) * 1e9 <= smax) ? 0.0 : 1.0 / e[i];
         y[i] = d * inv;
     }
+#pragma unroll
     for (int k = 0; k < 6; k++) {
         double d = 0;
+#pragma unroll
         for (int i = 0; i < 6; i++) d += V[k * 6 + i] * y[i];
         h[k] = d;
     }
@@ -428,11 +693,15 @@ __device__ inline void svd_backsub6(const double A[36], const double b[6], doubl
 
 // TooN::Cholesky<6> (LDL^T, Cholesky.h:88-125) and its vector backsub (:131-160)
 __device__ inline void chol6(const double A[36], double L[36]) {
+#pragma unroll
     for (int i = 0; i < 36; i++) L[i] = A[i];
+#pragma unroll
     for (int col = 0; col < 6; col++) {
         double inv_diag = 1;
+#pragma unroll
         for (int row = col; row < 6; row++) {
             double val = L[row * 6 + col];
+#pragma unroll
             for (int col2 = 0; col2 < col; col2++) val -= L[col2 * 6 + col] * L[row * 6 + col2];
             if (row == col) {
                 L[row * 6 + col] = val;
@@ -447,33 +716,45 @@ __device__ inline void chol6(const double A[36], double L[36]) {
 }
 __device__ inline void chol6_backsub(const double L[36], const double v[6], double r[6]) {
     double y[6];
+#pragma unroll
     for (int i = 0; i < 6; i++) {
         double val = v[i];
+#pragma unroll
         for (int j = 0; j < i; j++) val -= L[i * 6 + j] * y[j];
         y[i] = val;
     }
+#pragma unroll
     for (int i = 0; i < 6; i++) y[i] /= L[i * 7];
+#pragma unroll
     for (int i = 5; i >= 0; i--) {
         double val = y[i];
+#pragma unroll
         for (int j = i + 1; j < 6; j++) val -= L[j * 6 + i] * r[j];
         r[i] = val;
     }
 }
 // matrix backsub of the identity: get_inverse() (Cholesky.h:165-200); note y[i] *= (1/d) here, not y[i] /= d
 __device__ inline void chol6_inverse(const double L[36], double Inv[36]) {
+#pragma unroll
     for (int c = 0; c < 6; c++) {
         double y[6], r[6];
+#pragma unroll
         for (int i = 0; i < 6; i++) {
             double val = (i == c) ? 1.0 : 0.0;
+#pragma unroll
             for (int j = 0; j < i; j++) val -= L[i * 6 + j] * y[j];
             y[i] = val;
         }
+#pragma unroll
         for (int i = 0; i < 6; i++) y[i] *= (1 / L[i * 7]);
+#pragma unroll
         for (int i = 5; i >= 0; i--) {
             double val = y[i];
+#pragma unroll
             for (int j = i + 1; j < 6; j++) val -= L[j * 6 + i] * r[j];
             r[i] = val;
         }
+#pragma unroll
         for (int i = 0; i < 6; i++) Inv[i * 6 + c] = r[i];
     }
 }
@@ -514,7 +795,7 @@ struct LmArgs {
     int init_type;
 };
 
-__global__ __launch_bounds__(64) void k_lm_step(LmArgs a) {
+__global__ __launch_bounds__(256) void k_lm_step(LmArgs a) {
     const int seq = blockIdx.x;
     SeqDev *sq = a.seq + seq;
     const int lane = threadIdx.x;
@@ -538,25 +819,38 @@ __global__ __launch_bounds__(64) void k_lm_step(LmArgs a) {
     const int nblk_used = (kn + kTvrBlock - 1) / kTvrBlock;
 
     // ---- finish the reduction of the evaluation that just ran (fixed order: deterministic) ----
+    // 8 thread groups x 32 value slots: group g sums blocks g, g+8, ... (independent loads, one latency),
+    // then slot v adds the 8 group sums in order.
+    __shared__ double s_part[8][32];
     __shared__ double s_sum[kNumSums];
+    __shared__ double s_bl[256];
     if (ops & (LM_REDUCE_CUR | LM_REDUCE_NEW)) {
         const double *pp = a.partials + (size_t)seq * a.nblk * kNumSums;
-        if (lane < kNumSums) {
-            double s = 0;
-            if (!(ops & LM_NOJAC) || lane == kNumSums - 1)
-                for (int b = 0; b < nblk_used; b++) s += pp[(size_t)b * kNumSums + lane];
-            s_sum[lane] = s;
+        const int v = lane & 31, g = lane >> 5;
+        double acc = 0;
+        if (v < kNumSums && (!(ops & LM_NOJAC) || v == kNumSums - 1)) {
+#pragma unroll 4
+            for (int b = g; b < nblk_used; b += 8) acc += pp[(size_t)b * kNumSums + v];
         }
-        // resolve the per-block residual carries of the buffer that was just written
-        if (lane == 32) {
+        s_part[g][v] = acc;
+        // per-block last residuals of the buffer that was just written -> LDS
+        const double *bl = a.block_last + (size_t)seq * a.nblk;
+        for (int b = lane; b < nblk_used; b += 256) s_bl[b & 255] = bl[b];
+        __syncthreads();
+        if (lane < kNumSums) {
+            double t = 0;
+#pragma unroll
+            for (int k = 0; k < 8; k++) t += s_part[k][lane];
+            s_sum[lane] = t;
+        }
+        if (lane == 32) {  // resolve the carries: prefix "last valid" over the blocks (T fi=0 at the top)
             const int res_out = sq->lm_phase == 0 ? sq->res_t : sq->res_new;
             double *cr = a.resid_carry + ((size_t)res_out * a.nseq + seq) * a.nblk;
-            const double *bl = a.block_last + (size_t)seq * a.nblk;
-            double run = 0;  // T fi=0 at the top of TryVelRot
+            double run = 0;
             for (int b = 0; b < nblk_used; b++) {
                 cr[b] = run;
-                const double v = bl[b];
-                if (!is_carry(v)) run = v;
+                const double v2 = nblk_used <= 256 ? s_bl[b] : bl[b];
+                if (!is_carry(v2)) run = v2;
             }
         }
     }
@@ -702,11 +996,25 @@ int build_field_enqueue(edgehip_ctx *c, int slot, int radius, float min_mod) {
     const DevicePlan &pl = c->plan;
     if (radius < 1 || radius > 255) { set_error("build_field: 1 <= radius <= 255"); return EDGEHIP_ERR_ARG; }
     c->field_radius = radius;
-    EH_CHECK(hipMemsetAsync(c->field, 0xFF, sizeof(uint32_t) * pl.nseq * pl.n, c->stream));
-    const long long threads = (long long)pl.cap * 2 * radius;
-    hipLaunchKernelGGL(k_field_scatter, dim3((unsigned)((threads + 255) / 256), 1, pl.nseq), dim3(256), 0, c->stream,
-                       kldev(c, slot), c->kn_slot + (size_t)slot * pl.nseq, c->retuned_slot + (size_t)slot * pl.nseq,
-                       c->field, pl.w, pl.h, (size_t)pl.n, radius, min_mod);
+    const int ntx = (pl.w + FT - 1) / FT, nty = (pl.h + FT - 1) / FT;
+    if (c->field_mode == 0 && ntx * nty <= kMaxTiles) {
+        EH_CHECK(hipMemsetAsync(c->bin_cnt, 0, sizeof(int32_t) * pl.nseq * kMaxTiles, c->stream));
+        hipLaunchKernelGGL(k_field_bin, dim3((pl.cap + 255) / 256, 1, pl.nseq), dim3(256), 0, c->stream, kldev(c, slot),
+                           c->kn_slot + (size_t)slot * pl.nseq, c->retuned_slot + (size_t)slot * pl.nseq, c->bin_cnt, c->bins,
+                           pl.w, pl.h, radius, min_mod, ntx, nty, pl.cap);
+        hipLaunchKernelGGL(k_field_raster, dim3(ntx, nty, pl.nseq), dim3(256), 0, c->stream, kldev(c, slot), c->bin_cnt,
+                           c->bins, c->field, pl.w, pl.h, (size_t)pl.n, radius, ntx, pl.cap);
+    } else if (c->field_mode == 2 || c->field_mode == 0) {  // mask-scan tiles (any image size)
+        hipLaunchKernelGGL(k_field_tiles, dim3((pl.w + FT - 1) / FT, (pl.h + FT - 1) / FT, pl.nseq), dim3(256), 0, c->stream,
+                           kldev(c, slot), maskof(c, slot), c->retuned_slot + (size_t)slot * pl.nseq, c->field, pl.w, pl.h,
+                           (size_t)pl.n, radius, min_mod);
+    } else {  // reference-shaped scatter with global atomics (kept for A/B measurements: EDGEHIP_FIELD_MODE=1)
+        EH_CHECK(hipMemsetAsync(c->field, 0xFF, sizeof(uint32_t) * pl.nseq * pl.n, c->stream));
+        const long long threads = (long long)pl.cap * 2 * radius;
+        hipLaunchKernelGGL(k_field_scatter, dim3((unsigned)((threads + 255) / 256), 1, pl.nseq), dim3(256), 0, c->stream,
+                           kldev(c, slot), c->kn_slot + (size_t)slot * pl.nseq, c->retuned_slot + (size_t)slot * pl.nseq,
+                           c->field, pl.w, pl.h, (size_t)pl.n, radius, min_mod);
+    }
     EH_LAUNCH_CHECK();
     return 0;
 }
@@ -753,7 +1061,7 @@ static int launch_lm(edgehip_ctx *c, int slot_new, unsigned ops) {
     a.seq = c->seq; a.partials = c->partials; a.block_last = c->block_last; a.resid_carry = c->resid_carry;
     a.framecount = c->framecount + (size_t)slot_new * c->plan.nseq;
     a.nblk = c->nblk_tvr; a.nseq = c->plan.nseq; a.ops = ops; a.init_type = c->p.tracker_init_type;
-    hipLaunchKernelGGL(k_lm_step, dim3(c->plan.nseq), dim3(64), 0, c->stream, a);
+    hipLaunchKernelGGL(k_lm_step, dim3(c->plan.nseq), dim3(256), 0, c->stream, a);
     EH_LAUNCH_CHECK();
     return 0;
 }

@@ -416,13 +416,35 @@ __global__ __launch_bounds__(1024) void k_rescale(const KlSoA *kls, const int32_
     const KlSoA &K = kls[seq];
     __shared__ double s_a[16], s_b[16];
     __shared__ double s_kp;
+    // per-KeyLine constants of the five passes are read once: rho^2, rho0^2, s_rho^2, s_rho0^2
+    constexpr int PER = 6;   // first 1024*PER KeyLines from registers (VGPR budget of a 1024-thread block); rest streams
+    double r2[PER], r02[PER], s2[PER], s02[PER];
+#pragma unroll
+    for (int j = 0; j < PER; j++) {
+        const int i = tid + j * 1024;
+        r2[j] = 0; r02[j] = 0; s2[j] = 1; s02[j] = 0;
+        if (i < kn) {
+            const double sr0 = K.s_rho0[i], sr = K.s_rho[i];
+            if (!((unsigned)K.m_num[i] < match_num_min || sr0 <= 0 || sr > s_rho_min)) {
+                const double rho = K.rho[i], rho0 = K.rho0[i];
+                r2[j] = rho * rho; r02[j] = rho0 * rho0; s2[j] = sr * sr; s02[j] = sr0 * sr0;
+            }
+        }
+    }
     double Kp = 1, RKp = sq->pub.P_Kp;
     for (int iter = 0; iter < 5; iter++) {
         double a = 0, b = 0;
-        for (int i = tid; i < kn; i += 1024) {
+        const double kp2 = Kp * Kp;
+#pragma unroll
+        for (int j = 0; j < PER; j++) {
+            const double den = s2[j] + kp2 * s02[j];
+            a += r2[j] / den;
+            b += r02[j] / den;
+        }
+        for (int i = tid + PER * 1024; i < kn; i += 1024) {
             const double sr0 = K.s_rho0[i], sr = K.s_rho[i];
             if ((unsigned)K.m_num[i] < match_num_min || sr0 <= 0 || sr > s_rho_min) continue;
-            const double den = sr * sr + Kp * Kp * sr0 * sr0;
+            const double den = sr * sr + kp2 * sr0 * sr0;
             const double rho = K.rho[i], rho0 = K.rho0[i];
             a += rho * rho / den;
             b += rho0 * rho0 / den;
