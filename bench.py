@@ -75,7 +75,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=40)
     ap.add_argument("--warmup", type=int, default=24)
-    ap.add_argument("--nseq", type=int, default=64, help="independent sequences per GPU (batch dimension)")
+    ap.add_argument("--nseq", type=int, default=256, help="independent sequences per GPU (batch dimension)")
     ap.add_argument("--pool", type=int, default=24, help="rendered frames in the HBM pool")
     ap.add_argument("--cpu-frames", type=int, default=200, help="frames of the CPU-baseline sample (0 = skip)")
     ap.add_argument("--no-roofline-events", action="store_true")

@@ -334,7 +334,7 @@ __global__ __launch_bounds__(256) void k_tvr_prepare(const KlSoA *kls, const int
 // ---------------------------------------------------------------------------------------------------
 // SO3 exponential as TooN::SO3<>::exp + rodrigues_so3_exp (TooN so3.h:203-285)
 // ---------------------------------------------------------------------------------------------------
-__device__ inline void so3_exp(const double w[3], double R[9]) {
+__device__ __noinline__ void so3_exp(const double w[3], double R[9]) {
     const double one_6th = 1.0 / 6.0, one_20th = 1.0 / 20.0;
     const double theta_sq = w[0] * w[0] + w[1] * w[1] + w[2] * w[2];
     const double theta = sqrt(theta_sq);
@@ -364,7 +364,7 @@ __device__ inline void so3_exp(const double w[3], double R[9]) {
 
 // Per-evaluation constants of TryVelRot (global_tracker.cpp:309-341): R0 = exp(W), RM = 2x2 block of
 // exp((0,0,W_z)), Vt = V.
-__device__ inline void tvr_setup(SeqDev *sq, const double X[6]) {
+__device__ __noinline__ void tvr_setup(SeqDev *sq, const double X[6]) {
     double R0[9], Rz[9];
     so3_exp(X + 3, R0);
     const double wz[3] = {0.0, 0.0, X[5]};
@@ -618,43 +618,42 @@ __global__ __launch_bounds__(kTvrBlock) void k_try_velrot(TvrArgs a) {
 // ---------------------------------------------------------------------------------------------------
 // Symmetric eigen-decomposition by cyclic Jacobi; A = V diag(e) V^T.  Stands in for LAPACK dgesvd_ behind
 // TooN::SVD<> (for a symmetric matrix singular values = |e|, U = V*sign(e)).
-__device__ inline void jacobi_eig6(const double Ain[36], double V[36], double e[6]) {
-    double A[36];
-#pragma unroll
+__device__ __noinline__ void jacobi_eig6(const double Ain[36], double V[36], double e[6], double *A /*[36] scratch*/) {
+#pragma nounroll
     for (int i = 0; i < 36; i++) { A[i] = Ain[i]; V[i] = 0; }
-#pragma unroll
+#pragma nounroll
     for (int i = 0; i < 6; i++) V[i * 7] = 1;
     for (int sweep = 0; sweep < 30; sweep++) {
         double off = 0, diag = 0;
-#pragma unroll
+#pragma nounroll
         for (int p = 0; p < 6; p++) {
             diag += A[p * 7] * A[p * 7];
-#pragma unroll
+#pragma nounroll
             for (int q = p + 1; q < 6; q++) off += A[p * 6 + q] * A[p * 6 + q];
         }
         if (!(off > 1e-32 * diag) || !(off > 0)) break;  // off-diagonal energy below fp64 roundoff of the diagonal
-#pragma unroll
+#pragma nounroll
         for (int p = 0; p < 5; p++)
-#pragma unroll
+#pragma nounroll
             for (int q = p + 1; q < 6; q++) {
                 const double apq = A[p * 6 + q];
                 if (apq == 0) continue;
                 const double theta = (A[q * 7] - A[p * 7]) / (2 * apq);
                 const double t = (theta >= 0 ? 1.0 : -1.0) / (fabs(theta) + sqrt(theta * theta + 1));
                 const double c = 1 / sqrt(t * t + 1), s = t * c;
-#pragma unroll
+#pragma nounroll
                 for (int k = 0; k < 6; k++) {
                     const double akp = A[k * 6 + p], akq = A[k * 6 + q];
                     A[k * 6 + p] = c * akp - s * akq;
                     A[k * 6 + q] = s * akp + c * akq;
                 }
-#pragma unroll
+#pragma nounroll
                 for (int k = 0; k < 6; k++) {
                     const double apk = A[p * 6 + k], aqk = A[q * 6 + k];
                     A[p * 6 + k] = c * apk - s * aqk;
                     A[q * 6 + k] = s * apk + c * aqk;
                 }
-#pragma unroll
+#pragma nounroll
                 for (int k = 0; k < 6; k++) {
                     const double vkp = V[k * 6 + p], vkq = V[k * 6 + q];
                     V[k * 6 + p] = c * vkp - s * vkq;
@@ -662,46 +661,45 @@ __device__ inline void jacobi_eig6(const double Ain[36], double V[36], double e[
                 }
             }
     }
-#pragma unroll
+#pragma nounroll
     for (int i = 0; i < 6; i++) e[i] = A[i * 7];
 }
 
 // h = SVD(A).backsub(b) with TooN's conditioning (SVD.h:176-196, 264-272; condition_no = 1e9)
-__device__ inline void svd_backsub6(const double A[36], const double b[6], double h[6]) {
-    double V[36], e[6];
-    jacobi_eig6(A, V, e);
+__device__ __noinline__ void svd_backsub6(const double A[36], const double b[6], double h[6], double *V, double *Awork,
+                                          double *e, double *y) {
+    jacobi_eig6(A, V, e, Awork);
     double smax = 0;
-#pragma unroll
+#pragma nounroll
     for (int i = 0; i < 6; i++) smax = fmax(smax, fabs(e[i]));
-    double y[6];
-#pragma unroll
+#pragma nounroll
     for (int i = 0; i < 6; i++) {
         double d = 0;
-#pragma unroll
+#pragma nounroll
         for (int k = 0; k < 6; k++) d += V[k * 6 + i] * b[k];
         const double inv = (fabs(e[i]) * 1e9 <= smax) ? 0.0 : 1.0 / e[i];
         y[i] = d * inv;
     }
-#pragma unroll
+#pragma nounroll
     for (int k = 0; k < 6; k++) {
         double d = 0;
-#pragma unroll
+#pragma nounroll
         for (int i = 0; i < 6; i++) d += V[k * 6 + i] * y[i];
         h[k] = d;
     }
 }
 
 // TooN::Cholesky<6> (LDL^T, Cholesky.h:88-125) and its vector backsub (:131-160)
-__device__ inline void chol6(const double A[36], double L[36]) {
-#pragma unroll
+__device__ __noinline__ void chol6(const double A[36], double L[36]) {
+#pragma nounroll
     for (int i = 0; i < 36; i++) L[i] = A[i];
-#pragma unroll
+#pragma nounroll
     for (int col = 0; col < 6; col++) {
         double inv_diag = 1;
-#pragma unroll
+#pragma nounroll
         for (int row = col; row < 6; row++) {
             double val = L[row * 6 + col];
-#pragma unroll
+#pragma nounroll
             for (int col2 = 0; col2 < col; col2++) val -= L[col2 * 6 + col] * L[row * 6 + col2];
             if (row == col) {
                 L[row * 6 + col] = val;
@@ -714,47 +712,45 @@ __device__ inline void chol6(const double A[36], double L[36]) {
         }
     }
 }
-__device__ inline void chol6_backsub(const double L[36], const double v[6], double r[6]) {
-    double y[6];
-#pragma unroll
+__device__ __noinline__ void chol6_backsub(const double L[36], const double v[6], double r[6], double *y) {
+#pragma nounroll
     for (int i = 0; i < 6; i++) {
         double val = v[i];
-#pragma unroll
+#pragma nounroll
         for (int j = 0; j < i; j++) val -= L[i * 6 + j] * y[j];
         y[i] = val;
     }
-#pragma unroll
+#pragma nounroll
     for (int i = 0; i < 6; i++) y[i] /= L[i * 7];
-#pragma unroll
+#pragma nounroll
     for (int i = 5; i >= 0; i--) {
         double val = y[i];
-#pragma unroll
+#pragma nounroll
         for (int j = i + 1; j < 6; j++) val -= L[j * 6 + i] * r[j];
         r[i] = val;
     }
 }
 // matrix backsub of the identity: get_inverse() (Cholesky.h:165-200); note y[i] *= (1/d) here, not y[i] /= d
-__device__ inline void chol6_inverse(const double L[36], double Inv[36]) {
-#pragma unroll
+__device__ __noinline__ void chol6_inverse(const double L[36], double Inv[36], double *y, double *r) {
+#pragma nounroll
     for (int c = 0; c < 6; c++) {
-        double y[6], r[6];
-#pragma unroll
+#pragma nounroll
         for (int i = 0; i < 6; i++) {
             double val = (i == c) ? 1.0 : 0.0;
-#pragma unroll
+#pragma nounroll
             for (int j = 0; j < i; j++) val -= L[i * 6 + j] * y[j];
             y[i] = val;
         }
-#pragma unroll
+#pragma nounroll
         for (int i = 0; i < 6; i++) y[i] *= (1 / L[i * 7]);
-#pragma unroll
+#pragma nounroll
         for (int i = 5; i >= 0; i--) {
             double val = y[i];
-#pragma unroll
+#pragma nounroll
             for (int j = i + 1; j < 6; j++) val -= L[j * 6 + i] * r[j];
             r[i] = val;
         }
-#pragma unroll
+#pragma nounroll
         for (int i = 0; i < 6; i++) Inv[i * 6 + c] = r[i];
     }
 }
@@ -795,11 +791,19 @@ struct LmArgs {
     int init_type;
 };
 
-__global__ __launch_bounds__(256) void k_lm_step(LmArgs a) {
+__global__ __launch_bounds__(64) void k_lm_step(LmArgs a) {
     const int seq = blockIdx.x;
-    SeqDev *sq = a.seq + seq;
     const int lane = threadIdx.x;
     const unsigned ops = a.ops;
+    // The sequence state is staged in LDS for the whole step: the serial LM logic touches it hundreds of
+    // times and a global round trip per access was the dominant cost of this kernel.
+    static_assert(sizeof(SeqDev) % 8 == 0, "SeqDev is copied as 64-bit words");
+    constexpr int kWords = sizeof(SeqDev) / 8;
+    __shared__ unsigned long long s_state[kWords];
+    unsigned long long *gstate = reinterpret_cast<unsigned long long *>(a.seq + seq);
+    for (int i = lane; i < kWords; i += 64) s_state[i] = gstate[i];
+    __syncthreads();
+    SeqDev *sq = reinterpret_cast<SeqDev *>(s_state);
     const int kn = sq->kn_old;
     if (ops & LM_BEGIN) {
         if (lane == 0) {
@@ -814,14 +818,19 @@ __global__ __launch_bounds__(256) void k_lm_step(LmArgs a) {
             }
             sq->s_rho_min_eval = sq->pub.s_rho_q;
         }
+        __syncthreads();
     }
-    if (kn <= 0) return;  // Minimizer_RV returns immediately on an empty list (global_tracker.cpp:597-598)
+    if (kn <= 0) {  // Minimizer_RV returns immediately on an empty list (global_tracker.cpp:597-598)
+        for (int i = lane; i < kWords; i += 64) gstate[i] = s_state[i];
+        return;
+    }
     const int nblk_used = (kn + kTvrBlock - 1) / kTvrBlock;
 
     // ---- finish the reduction of the evaluation that just ran (fixed order: deterministic) ----
-    // 8 thread groups x 32 value slots: group g sums blocks g, g+8, ... (independent loads, one latency),
-    // then slot v adds the 8 group sums in order.
-    __shared__ double s_part[8][32];
+    // 2 lane groups x 32 value slots: group g sums blocks g, g+2, ... (independent, unrolled loads), then
+    // slot v adds the two group sums.
+    __shared__ double s_part[2][32];
+    __shared__ double s_m[4][36], s_v[3][6];  // 6x6 work matrices / vectors of the solves (LDS, not scratch)
     __shared__ double s_sum[kNumSums];
     __shared__ double s_bl[256];
     if (ops & (LM_REDUCE_CUR | LM_REDUCE_NEW)) {
@@ -829,18 +838,17 @@ __global__ __launch_bounds__(256) void k_lm_step(LmArgs a) {
         const int v = lane & 31, g = lane >> 5;
         double acc = 0;
         if (v < kNumSums && (!(ops & LM_NOJAC) || v == kNumSums - 1)) {
-#pragma unroll 4
-            for (int b = g; b < nblk_used; b += 8) acc += pp[(size_t)b * kNumSums + v];
+#pragma unroll 8
+            for (int b = g; b < nblk_used; b += 2) acc += pp[(size_t)b * kNumSums + v];
         }
         s_part[g][v] = acc;
         // per-block last residuals of the buffer that was just written -> LDS
         const double *bl = a.block_last + (size_t)seq * a.nblk;
-        for (int b = lane; b < nblk_used; b += 256) s_bl[b & 255] = bl[b];
+        for (int b = lane; b < nblk_used; b += 64) s_bl[b & 255] = bl[b];
         __syncthreads();
         if (lane < kNumSums) {
             double t = 0;
-#pragma unroll
-            for (int k = 0; k < 8; k++) t += s_part[k][lane];
+            t = s_part[0][lane] + s_part[1][lane];
             s_sum[lane] = t;
         }
         if (lane == 32) {  // resolve the carries: prefix "last valid" over the blocks (T fi=0 at the top)
@@ -855,7 +863,7 @@ __global__ __launch_bounds__(256) void k_lm_step(LmArgs a) {
         }
     }
     __syncthreads();
-    if (lane != 0) return;
+    if (lane == 0) {
 
     if (ops & (LM_REDUCE_CUR | LM_REDUCE_NEW)) {
         double *JtJ = (ops & LM_REDUCE_CUR) ? sq->JtJ : sq->JtJnew;
@@ -925,15 +933,22 @@ __global__ __launch_bounds__(256) void k_lm_step(LmArgs a) {
         const int t = sq->res_new; sq->res_new = sq->res_cur; sq->res_cur = t;       // std::swap
     }
     if (ops & (LM_SOLVE_SVD | LM_SOLVE_CHOL)) {
-        double ApI[36], nb[6];
+        double *ApI = s_m[0], *L = s_m[1], *nb = s_v[0];
         for (int i = 0; i < 36; i++) ApI[i] = sq->JtJ[i];
         for (int i = 0; i < 6; i++) { ApI[i * 7] = sq->JtJ[i * 7] + 1.0 * sq->u; nb[i] = -sq->JtF[i]; }
-        if (ops & LM_SOLVE_SVD) svd_backsub6(ApI, nb, sq->h);
-        else {
-            double L[36];
-            chol6(ApI, L);
-            chol6_backsub(L, nb, sq->h);
+        chol6(ApI, L);
+        bool use_svd = false;
+        if (ops & LM_SOLVE_SVD) {
+            // TooN::SVD<>::backsub zeroes singular values below s_max/1e9.  ApI = JtJ + u*I with
+            // u = 1e-3*max(JtJ) (possibly scaled by 0.33^k) is SPD with condition <= ~1e5, so the rule never
+            // fires and the pseudo-inverse IS the inverse: solve by LDL^T.  The Jacobi-SVD path is kept
+            // for the degenerate case (non-positive or tiny pivots).
+            double dmin = L[0], dmax = L[0];
+            for (int i = 1; i < 6; i++) { dmin = fmin(dmin, L[i * 7]); dmax = fmax(dmax, L[i * 7]); }
+            use_svd = !(dmin > 0) || !(dmin * 1e7 > dmax);
         }
+        if (use_svd) svd_backsub6(ApI, nb, sq->h, s_m[2], s_m[3], s_v[1], s_v[2]);
+        else chol6_backsub(L, nb, sq->h, s_v[1]);
         for (int i = 0; i < 6; i++) sq->Xnew[i] = sq->X[i] + sq->h[i];
     }
     if (ops & LM_PHASE_A) sq->lm_phase = 0;
@@ -941,9 +956,9 @@ __global__ __launch_bounds__(256) void k_lm_step(LmArgs a) {
     if (ops & LM_SETUP_X) tvr_setup(sq, sq->X);
     if (ops & LM_SETUP_XNEW) tvr_setup(sq, sq->Xnew);
     if (ops & LM_FINISH) {
-        double L[36], Inv[36];
+        double *L = s_m[1], *Inv = s_m[2];
         chol6(sq->JtJ, L);
-        chol6_inverse(L, Inv);
+        chol6_inverse(L, Inv, s_v[1], s_v[2]);
         for (int i = 0; i < 3; i++) { sq->pub.V[i] = sq->X[i]; sq->pub.W[i] = sq->X[3 + i]; }
         for (int i = 0; i < 3; i++)
             for (int j = 0; j < 3; j++) {
@@ -962,6 +977,9 @@ __global__ __launch_bounds__(256) void k_lm_step(LmArgs a) {
         sq->pub.score = sq->F;
         a.framecount[seq]++;
     }
+    }  // lane 0
+    __syncthreads();
+    for (int i = lane; i < kWords; i += 64) gstate[i] = s_state[i];
 }
 
 // standalone evaluation helper: X given by the host -> setup
@@ -1061,7 +1079,7 @@ static int launch_lm(edgehip_ctx *c, int slot_new, unsigned ops) {
     a.seq = c->seq; a.partials = c->partials; a.block_last = c->block_last; a.resid_carry = c->resid_carry;
     a.framecount = c->framecount + (size_t)slot_new * c->plan.nseq;
     a.nblk = c->nblk_tvr; a.nseq = c->plan.nseq; a.ops = ops; a.init_type = c->p.tracker_init_type;
-    hipLaunchKernelGGL(k_lm_step, dim3(c->plan.nseq), dim3(256), 0, c->stream, a);
+    hipLaunchKernelGGL(k_lm_step, dim3(c->plan.nseq), dim3(64), 0, c->stream, a);
     EH_LAUNCH_CHECK();
     return 0;
 }
