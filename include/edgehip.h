@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define EDGEHIP_ABI_VERSION 1
+#define EDGEHIP_ABI_VERSION 2
 #define EDGEHIP_KEYLINE_MAX 50000 /* KEYLINE_MAX, include/mtracklib/edge_finder.h:43 */
 
 typedef enum edgehip_status {
@@ -61,6 +61,12 @@ typedef struct edgehip_params {
     int32_t global_match_threshold;
     int32_t debug_planes;         /* !=0: also store img0/img1/dog/dx/dy planes (parity tests) */
     double config_fps;
+    /* UseUndistort: resample every input frame through the radial-tangential model `kc` before RGB->grey,
+     * i.e. image_undistort::undistort<true> of rebvo_first_t.cpp:231 (include/VideoLib/image_undistort.h:
+     * 66-79, 105-122; map as built by src/VideoLib/image_undistort.cpp:29-95), fused into the first
+     * stage-A kernel: the bilinear map (4 taps, 16.16 integer weights) is built once at create time. */
+    int32_t use_undistort;
+    int32_t reserved0;
 } edgehip_params;
 
 /* Byte-for-byte the reference's rebvo::KeyLine (include/mtracklib/edge_finder.h:45-91), 168 B. */
@@ -195,8 +201,13 @@ int edgehip_read_nav(edgehip_ctx *ctx, edgehip_nav *nav);
  * [first, first+count) as out[count][nseq].  Synchronises. */
 int edgehip_set_nav_log(edgehip_ctx *ctx, int len);
 int edgehip_read_nav_log(edgehip_ctx *ctx, int first, int count, edgehip_nav *out);
-/* REBVO::Reset semantics for every sequence (rebvo_second_t.cpp:609-620) + restart of the ring. */
+/* Restart every sequence from scratch: state as after edgehip_create (thresholds, priors, pose, frame
+ * counters) and an empty ring.  Not something the reference does at run time (it would re-construct REBVO). */
 int edgehip_reset(edgehip_ctx *ctx);
+/* REBVO::Reset() as SecondThread executes it after a frame (rebvo_second_t.cpp:609-620): depth reset of the
+ * newest edge map (rho = RhoInit, s_rho = RHO_MAX for every KeyLine), Pose = I, Pos = V = W = 0.  Everything
+ * else (detector threshold, K, frame counters) carries on.  seq < 0 applies it to all sequences. */
+int edgehip_depth_reset(edgehip_ctx *ctx, int seq);
 
 /* ---- state / data exchange (callback consumers, parity tests) ---------------------------------------- */
 int edgehip_get_state(edgehip_ctx *ctx, int seq, edgehip_seq_state *out);       /* synchronises */
@@ -216,6 +227,12 @@ int edgehip_upload_keylines(edgehip_ctx *ctx, int seq, int slot, const edgehip_k
 int edgehip_download_plane(edgehip_ctx *ctx, int seq, int which, float *out);
 /* Auxiliary field of the tracker in the reference's {dist, ikl} form (global_tracker.h:33-36); out[h*w*2]. */
 int edgehip_download_field(edgehip_ctx *ctx, int seq, int32_t *out);
+/* The undistortion map edgehip_create() builds for `params` (host-only, needs no device), in the reference's
+ * undistMapPoint form (image_undistort.h:41-47): inx[h*w*4] valid taps first, -1 beyond `num`; iw[h*w*4]. */
+int edgehip_build_undistort_map(const edgehip_params *params, int32_t *inx, int32_t *iw);
+/* Debug: the undistorted RGB24 frame that stage A consumed for sequence `seq` in `slot`, recomputed on the
+ * device with the same integer arithmetic (what PipeBuffer::imgc holds after rebvo_first_t.cpp:231). */
+int edgehip_download_undistorted(edgehip_ctx *ctx, int seq, int slot, uint8_t *rgb24);
 
 /* ---- measurement ------------------------------------------------------------------------------------- */
 /* Names of the kernel groups timed by the built-in HIP-event profiler, and their accumulated device time.

@@ -70,7 +70,7 @@ class Params(C.Structure):
         ("reweight_distance", C.c_double), ("regularize_thresh", C.c_double),
         ("loc_unc_match", C.c_double), ("reshape_q_abs", C.c_double),
         ("reshape_q_rel", C.c_double), ("loc_unc", C.c_double),
-        ("global_match_threshold", C.c_int32), ("pad0", C.c_int32),
+        ("global_match_threshold", C.c_int32), ("use_undistort", C.c_int32),
         ("config_fps", C.c_double),
     ]
 
@@ -100,6 +100,25 @@ def euroc_params(w=752, h=480, **over):
         setattr(p, k, v)
     return p
 
+
+def tum_params(w=640, h=480, **over):
+    """app/rebvorun/GlobalConfig_desk.txt of the reference (TUM fr2/desk, ImuMode=0): BASELINE config 4.
+    The shipped file has Kc=0/UseUndistort=0; config 4 exercises the undistorter, so callers pass
+    use_undistort=1 and a distortion (the EuRoC coefficients by default, SURVEY.md section 8d scene S3)."""
+    p = euroc_params(w, h)
+    sx, sy = w / 640.0, h / 480.0
+    p.ppx, p.ppy, p.zfx, p.zfy = 320.0 * sx, 240.0 * sy, 525.0 * sx, 525.0 * sy
+    p.max_points, p.reference_points, p.track_points = 25000, 15000, 12000
+    p.detector_thresh, p.auto_gain, p.max_thresh, p.min_thresh = 0.01, 1e-6, 0.05, 0.03
+    p.search_range = 20
+    p.tracker_iter_num, p.tracker_init_type, p.tracker_init_iter_num = 10, 2, 2
+    p.tracker_match_thresh = 1.0
+    p.match_num_thresh = 4
+    p.reshape_q_rel = 1e-2
+    p.config_fps = 50.0
+    for k, v in over.items():
+        setattr(p, k, v)
+    return p
 
 class Nav(C.Structure):
     _fields_ = [
@@ -158,6 +177,8 @@ class Oracle:
         self._destroy = fn("destroy", None, vp)
         self._stage_a = fn("stage_a", i, vp, i, C.c_void_p, pd, pi)
         self._plane = fn("plane", C.POINTER(C.c_float), vp, i, i)
+        self._imgc = fn("imgc", C.POINTER(C.c_uint8), vp, i)
+        self._undistort_map = fn("undistort_map", i, vp, C.c_void_p, C.c_void_p)
         self._mask = fn("mask", C.POINTER(C.c_int32), vp, i)
         self._kn = fn("kn", i, vp, i)
         self._keylines = fn("keylines", C.c_void_p, vp, i)
@@ -204,6 +225,18 @@ class Oracle:
         idx = {"img0": 0, "img1": 1, "dog": 2, "dx": 3, "dy": 4, "bw": 5}[which]
         p = self._plane(self.ctx, slot, idx)
         return np.ctypeslib.as_array(p, shape=(self.h, self.w)).copy()
+
+    def imgc(self, slot):
+        """RGB24 frame that stage A consumed (undistorted when params.use_undistort)."""
+        return np.ctypeslib.as_array(self._imgc(self.ctx, slot), shape=(self.h, self.w, 3)).copy()
+
+    def undistort_map(self):
+        """image_undistort's map as (inx[h*w,4] with -1 beyond num, iw[h*w,4])."""
+        inx = np.empty((self.h * self.w, 4), np.int32)
+        iw = np.empty((self.h * self.w, 4), np.int32)
+        if self._undistort_map(self.ctx, inx.ctypes.data, iw.ctypes.data) != 0:
+            raise RuntimeError("oracle was created without use_undistort")
+        return inx, iw
 
     def mask(self, slot):
         return np.ctypeslib.as_array(self._mask(self.ctx, slot), shape=(self.h, self.w)).copy()

@@ -53,7 +53,7 @@ typedef struct OrcParams {
     double reweight_distance, regularize_thresh;
     double loc_unc_match, reshape_q_abs, reshape_q_rel, loc_unc;
     int32_t global_match_threshold;
-    int32_t pad0;
+    int32_t use_undistort;   /* Camera/UseUndistort: image_undistort::undistort<true> before RGB->grey */
     double config_fps;
 } OrcParams;
 
@@ -78,6 +78,8 @@ typedef struct OrcNav {
     /* stage A: ConvertRGB2BW + sspace::build + edge_finder::detect + reEstimateThresh */               \
     int P##_stage_a(void *ctx, int slot, const uint8_t *rgb24, double *tresh_io, int *l_kl_num_io);      \
     const float *P##_plane(void *ctx, int slot, int which); /* 0 img0 1 img1 2 dog 3 dx 4 dy 5 bw */    \
+    const uint8_t *P##_imgc(void *ctx, int slot);           /* RGB24 frame stage A consumed */          \
+    int P##_undistort_map(void *ctx, int32_t *inx, int32_t *iw); /* [n*4] each; -1 if not enabled */   \
     const int32_t *P##_mask(void *ctx, int slot);                                                        \
     int P##_kn(void *ctx, int slot);                                                                     \
     OrcKeyLine *P##_keylines(void *ctx, int slot);                                                       \

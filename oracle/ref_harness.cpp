@@ -20,6 +20,7 @@
 #include "mtracklib/edge_finder.h"
 #include "mtracklib/edge_tracker.h"
 #include "mtracklib/global_tracker.h"
+#include "VideoLib/image_undistort.h"
 // TryVelRot<> is only defined in the .cpp; include it so the harness can instantiate it directly.
 #include "src/mtracklib/global_tracker.cpp"
 
@@ -69,6 +70,8 @@ struct Ctx {
     Vector<3> V, W, Pos;
     Matrix<3, 3> Pose;
     std::vector<float> bw;
+    image_undistort *undist;          // rebvo_first_t.cpp:125 (only when use_undistort)
+    Image<RGB24Pixel> *img_dist;      // the distorted input frame (rebvo_first_t.cpp:112)
 };
 
 void reset_seq(Ctx *c) {
@@ -127,6 +130,12 @@ void *ref_create(const OrcParams *p, int nslots) {
         memset(s.ss->ImgDy().Data(), 0, sizeof(float) * p->w * p->h);
         memset(s.gt->field.Data(), 0, sizeof(gt_field_data) * p->w * p->h);
     }
+    c->undist = nullptr;
+    c->img_dist = nullptr;
+    if (p->use_undistort) {
+        c->undist = new image_undistort(c->cam);
+        c->img_dist = new Image<RGB24Pixel>(c->cam.sz);
+    }
     reset_seq(c);
     return c;
 }
@@ -140,6 +149,8 @@ void ref_destroy(void *ctx) {
         delete s.img;
         delete s.imgc;
     }
+    delete c->undist;
+    delete c->img_dist;
     delete c;
 }
 
@@ -153,13 +164,37 @@ int ref_stage_a(void *ctx, int slot, const uint8_t *rgb24, double *tresh_io, int
     Ctx *c = (Ctx *)ctx;
     Slot &s = c->slots[slot];
     const OrcParams &p = c->p;
-    memcpy(s.imgc->Data(), rgb24, (size_t)p.w * p.h * 3);         // rebvo_first_t.cpp:250
+    if (c->undist) {
+        memcpy(c->img_dist->Data(), rgb24, (size_t)p.w * p.h * 3);   // rebvo_first_t.cpp:218
+        c->undist->undistort<true>(*s.imgc, *c->img_dist);           // :231
+    } else {
+        memcpy(s.imgc->Data(), rgb24, (size_t)p.w * p.h * 3);        // :250
+    }
     Image<float>::ConvertRGB2BW(*s.img, *s.imgc);                  // :259
     s.ss->build(*s.img);                                           // :263
     s.ef->detect(s.ss, p.plane_fit_size, p.pos_neg_thresh, p.dog_thresh, p.max_points, *tresh_io,
                  *l_kl_num_io, p.reference_points, p.auto_gain, p.max_thresh, p.min_thresh);  // :266
     s.ef->reEstimateThresh(p.track_points, p.qcut_nbins);          // :272
     return s.ef->KNum();
+}
+
+const uint8_t *ref_imgc(void *ctx, int slot) {  // PipeBuffer::imgc (undistorted when use_undistort)
+    return (const uint8_t *)((Ctx *)ctx)->slots[slot].imgc->Data();
+}
+
+// the undistortion map in the reference's own form: inx[n*4] (-1 beyond num), iw[n*4]
+int ref_undistort_map(void *ctx, int32_t *inx, int32_t *iw) {
+    Ctx *c = (Ctx *)ctx;
+    if (!c->undist) return -1;
+    const int n = c->p.w * c->p.h;
+    for (int i = 0; i < n; i++) {
+        const auto &u = c->undist->umap[i];
+        for (int k = 0; k < 4; k++) {
+            inx[i * 4 + k] = k < u.num ? u.inx[k] : -1;
+            iw[i * 4 + k] = k < u.num ? u.iw[k] : 0;
+        }
+    }
+    return 0;
 }
 
 const float *ref_plane(void *ctx, int slot, int which) {

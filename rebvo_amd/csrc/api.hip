@@ -98,6 +98,71 @@ static void plane_fit_pinv(int win_s, double *pinv /*[3][nn]*/) {
         }
 }
 
+// Undistortion map exactly as image_undistort::image_undistort builds it (src/VideoLib/image_undistort.cpp:
+// 29-95) with cam_model::Img2Hom / distortHom2Hom / Hom2Img (include/UtilLib/cam_model.h:76-98): float
+// Point2D arithmetic, double inside distortHom2Hom, weights normalised in float, iw = (int)(w * 65536.f).
+// Output per pixel: base = index of tap p00 = floor(id) (kept even when that tap is invalid: taps are at
+// base, base+1, base+w, base+w+1) and the four integer weights in tap order, 0 for an invalid tap.  The
+// reference compacts valid taps to the front; the integer sum is order independent.
+void build_undistort_map(const edgehip_params &p, std::vector<int32_t> &base, std::vector<uint32_t> &iw,
+                         std::vector<int32_t> *ref_inx, std::vector<int32_t> *ref_iw) {
+    const int w = p.w, h = p.h;
+    const float ppx = (float)p.ppx, ppy = (float)p.ppy, zfx = (float)p.zfx, zfy = (float)p.zfy;
+    const double zfm = (double)((zfx + zfy) / 2);
+    const double Kc2 = p.kc[0], Kc4 = p.kc[1], Kc6 = p.kc[2], P1 = p.kc[3], P2 = p.kc[4];
+    base.assign((size_t)w * h, 0);
+    iw.assign((size_t)w * h * 4, 0);
+    if (ref_inx) ref_inx->assign((size_t)w * h * 4, -1);
+    if (ref_iw) ref_iw->assign((size_t)w * h * 4, 0);
+    auto valid = [&](float fx, float fy) {
+        // Image::isInxValid(const uint&, const uint&): the float arguments convert to unsigned the x86-64 way
+        // (cvttss2si to 64 bit, low 32 bits kept): negatives become huge and fail the range test.
+        const uint32_t ux = (uint32_t)(int64_t)fx, uy = (uint32_t)(int64_t)fy;
+        return ux < (uint32_t)w && uy < (uint32_t)h;
+    };
+    for (int y = 0; y < h; y++)
+        for (int x = 0; x < w; x++) {
+            float qx = (float)x - ppx, qy = (float)y - ppy;            // Img2Hom
+            {
+                const double xp = qx / zfm, yp = qy / zfm;             // distortHom2Hom
+                const double r2 = xp * xp + yp * yp;
+                const double xpp = xp * (1 + r2 * (Kc2 + r2 * (Kc4 + r2 * Kc6))) + 2 * P1 * xp * yp + P2 * (r2 + 2 * xp * xp);
+                const double ypp = yp * (1 + r2 * (Kc2 + r2 * (Kc4 + r2 * Kc6))) + P1 * (r2 + 2 * yp * yp) + 2 * P2 * xp * yp;
+                qx = (float)(xpp * zfx);
+                qy = (float)(ypp * zfy);
+            }
+            const float idx = qx + ppx, idy = qy + ppy;                // Hom2Img
+            const float fx0 = floorf(idx), fy0 = floorf(idy);
+            const float p00x = fx0, p00y = fy0, p11x = fx0 + 1, p11y = fy0 + 1;
+            const float tx[4] = {p00x, p11x, p00x, p11x}, ty[4] = {p00y, p00y, p11y, p11y};
+            float wgt[4];
+            wgt[0] = (p11x - idx) * (p11y - idy);
+            wgt[1] = (idx - p00x) * (p11y - idy);
+            wgt[2] = (p11x - idx) * (idy - p00y);
+            wgt[3] = (idx - p00x) * (idy - p00y);
+            bool ok[4];
+            float sum_w = 0;
+            for (int i = 0; i < 4; i++) {
+                ok[i] = valid(tx[i], ty[i]);
+                if (ok[i]) sum_w += wgt[i];
+            }
+            const size_t pix = (size_t)y * w + x;
+            // floor coordinates that are far outside still give a well-defined (unused) base
+            const long long b = (long long)fy0 * w + (long long)fx0;
+            base[pix] = (int32_t)std::max<long long>(std::min<long long>(b, 0x3fffffff), -0x3fffffff);
+            int k = 0;
+            for (int i = 0; i < 4; i++) {
+                if (!ok[i]) continue;
+                const float wn = wgt[i] / sum_w;
+                const int iwv = (int)(wn * 65536.0f);
+                iw[pix * 4 + i] = (uint32_t)iwv;
+                if (ref_inx) (*ref_inx)[pix * 4 + k] = (int)roundf(ty[i]) * w + (int)roundf(tx[i]);
+                if (ref_iw) (*ref_iw)[pix * 4 + k] = iwv;
+                k++;
+            }
+        }
+}
+
 template <typename T>
 static int dmalloc(edgehip_ctx *c, T **p, size_t count, std::vector<void *> &track, int fill = -2) {
     void *q = nullptr;
@@ -220,10 +285,23 @@ int edgehip_create(const edgehip_params *params, int nseq, int nslots, int devic
     if (p.debug_planes) EH_TRY(dmalloc(c, &c->planes, 5 * B * N, al->dev, 0));
     EH_TRY(dmalloc(c, &c->mask, S * B * N, al->dev, 0xFF));       // img_mask_kl.Reset(-1)
     EH_TRY(dmalloc(c, &c->field, B * N, al->dev, 0xFF));
+    c->und_base = nullptr;
+    c->und_iw = nullptr;
+    if (p.use_undistort) {
+        EH_TRY(dmalloc(c, &c->und_base, N, al->dev));
+        EH_TRY(dmalloc(c, &c->und_iw, N, al->dev));
+        std::vector<int32_t> base;
+        std::vector<uint32_t> iw;
+        build_undistort_map(p, base, iw, nullptr, nullptr);
+        EH_CHECK(hipMemcpy(c->und_base, base.data(), sizeof(int32_t) * N, hipMemcpyHostToDevice));
+        EH_CHECK(hipMemcpy(c->und_iw, iw.data(), sizeof(uint32_t) * 4 * N, hipMemcpyHostToDevice));
+    }
     EH_TRY(dmalloc(c, &c->div_lut, kDivLutMax, al->dev));
     EH_TRY(dmalloc(c, &c->pinv, 75, al->dev));
     EH_TRY(dmalloc(c, &c->seq, B, al->dev, 0));
-    EH_TRY(dmalloc(c, &c->framecount, S * B, al->dev, 0));
+    c->fc_rows = std::max<int>(nslots, kRefRing);
+    c->fc_index = 0;
+    EH_TRY(dmalloc(c, &c->framecount, (size_t)c->fc_rows * B, al->dev, 0));
     EH_TRY(dmalloc(c, &c->kn_slot, S * B, al->dev, 0));
     EH_TRY(dmalloc(c, &c->retuned_slot, S * B, al->dev, 0));
     c->nbands = (p.h - 4 + kBandRows - 1) / kBandRows;
@@ -348,7 +426,7 @@ int edgehip_reset(edgehip_ctx *c) {
     EH_CHECK(hipStreamSynchronize(c->stream));
     for (size_t i = 0; i < B; i++) init_state(c->p, &c->pinned_seq[i]);
     EH_CHECK(hipMemcpyAsync(c->seq, c->pinned_seq, sizeof(SeqDev) * B, hipMemcpyHostToDevice, c->stream));
-    EH_CHECK(hipMemsetAsync(c->framecount, 0, sizeof(uint32_t) * S * B, c->stream));
+    EH_CHECK(hipMemsetAsync(c->framecount, 0, sizeof(uint32_t) * c->fc_rows * B, c->stream));
     EH_CHECK(hipMemsetAsync(c->kn_slot, 0, sizeof(int32_t) * S * B, c->stream));
     EH_CHECK(hipStreamSynchronize(c->stream));
     c->frame_slot = -1;
@@ -599,6 +677,28 @@ int edgehip_download_field(edgehip_ctx *c, int seq, int32_t *out) {
         if (f[i] == 0xFFFFFFFFu) { out[2 * i] = 0; out[2 * i + 1] = -1; }
         else { out[2 * i] = (int32_t)(f[i] >> 16); out[2 * i + 1] = (int32_t)(0xFFFFu - (f[i] & 0xFFFFu)); }
     }
+    return 0;
+}
+
+int edgehip_build_undistort_map(const edgehip_params *params, int32_t *inx, int32_t *iw) {
+    if (!params || !inx || !iw || params->w < 1 || params->h < 1) return EDGEHIP_ERR_ARG;
+    std::vector<int32_t> base, rinx, riw;
+    std::vector<uint32_t> w4;
+    build_undistort_map(*params, base, w4, &rinx, &riw);
+    memcpy(inx, rinx.data(), sizeof(int32_t) * rinx.size());
+    memcpy(iw, riw.data(), sizeof(int32_t) * riw.size());
+    return 0;
+}
+
+int edgehip_download_undistorted(edgehip_ctx *c, int seq, int slot, uint8_t *rgb24) {
+    if (int e = check_seq(c, seq)) return e;
+    if (int e = check_slot(c, slot)) return e;
+    if (!rgb24) return EDGEHIP_ERR_ARG;
+    if (!c->p.use_undistort) { set_error("download_undistorted: context was created without use_undistort"); return EDGEHIP_ERR_STATE; }
+    uint8_t *tmp = reinterpret_cast<uint8_t *>(c->ii);  // stage-A scratch: free between frames
+    if (int e = undistort_frame_enqueue(c, seq, slot, tmp)) return e;
+    EH_CHECK(hipMemcpyAsync(rgb24, tmp, (size_t)c->plan.n * 3, hipMemcpyDeviceToHost, c->stream));
+    EH_CHECK(hipStreamSynchronize(c->stream));
     return 0;
 }
 

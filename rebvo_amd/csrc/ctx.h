@@ -23,6 +23,7 @@ constexpr int kBandRows = 4;        // rows per detect block (raster-order compa
 constexpr int kDivLutMax = 256;     // reciprocal-count LUT entries (box width up to 15)
 constexpr int kTvrBlock = 256;      // threads per TryVelRot block
 constexpr int kNumSums = 28;        // 21 JtJ + 6 JtF + score
+constexpr int kRefRing = 8;         // CBUFSIZE of the reference (frame ring length that FrameCount semantics follow)
 constexpr int kResidBufs = 3;       // Res0, Res1, Rest (global_tracker.cpp:611)
 
 // "inherit the last valid residual of the previous blocks" marker in residual buffers (see stage_b.hip)
@@ -91,13 +92,21 @@ struct edgehip_ctx {
     float *planes;         // [5][B][N] or null
     int32_t *mask;         // [S][B][N]
     uint32_t *field;       // [B][N]
+    int32_t *und_base;     // [N] undistortion map: pixel index of the p00 tap (may lie outside the image), or null
+    uint4 *und_iw;         // [N] 16.16 integer weights of taps p00,p01,p10,p11 (0 = tap not valid)
     float *div_lut;        // [kDivLutMax] (float)(1.0/count)
     double *pinv;          // [3*25] plane-fit pseudo inverse
     void *kl_arena;        // one allocation carved into KlSoA arrays
     std::vector<edgehip::KlSoA> kl;   // [S*B] host copies of the carved pointers
     edgehip::KlSoA *kl_dev;           // [S*B] same, on device
     edgehip::SeqDev *seq;             // [B]
-    uint32_t *framecount;             // [S][B] global_tracker::FrameCount per slot
+    // global_tracker::FrameCount lives in the reference's PipeBuffer slot objects, of which there are CBUFSIZE=8
+    // (include/rebvo/rebvo.h:51, src/rebvo/rebvo.cpp:297-312): the counter a frame sees depends on that ring
+    // length, not on ours.  [max(S,8)][B]; process_frame indexes it by (frame number % 8), the stage-level
+    // entry points by the slot they are given.
+    uint32_t *framecount;
+    int fc_rows;                      // max(S, kRefRing)
+    int fc_index;                     // row used by the running minimisation
     int32_t *kn_slot;                 // [S][B] edge_finder::kn per slot
     float *retuned_slot;              // [S][B] edge_finder::reTunedThresh per slot
     // stage A compaction staging
@@ -178,10 +187,11 @@ struct ProfScope {  // RAII bracket; no-op unless profiling is enabled
 
 // stage entry points shared between translation units (all enqueue on c->stream)
 int stage_a_enqueue(edgehip_ctx *c, int slot);
+int undistort_frame_enqueue(edgehip_ctx *c, int seq, int slot, uint8_t *out_dev);
 int quantile_enqueue(edgehip_ctx *c, int slot, double smin, double smax, double pct, int nbins);
 int build_field_enqueue(edgehip_ctx *c, int slot, int radius, float min_mod);
 int tvr_prepare_enqueue(edgehip_ctx *c, int slot_old);
-int minimizer_enqueue(edgehip_ctx *c, int slot_new, int slot_old);
+int minimizer_enqueue(edgehip_ctx *c, int slot_new, int slot_old, int fc_index);
 int forward_match_enqueue(edgehip_ctx *c, int slot_old, int slot_new);
 int rotate_enqueue(edgehip_ctx *c, int slot, const double *R_host);
 int directed_enqueue(edgehip_ctx *c, int slot_new, int slot_old);

@@ -40,9 +40,27 @@ namespace edgehip {
 // stays below 2^24 and float addition of these integers is exact: any order gives the reference's bits
 // (iimage.cpp:56-61).  Each lane owns CH consecutive pixels; wave-level exclusive scan of lane totals.
 // ---------------------------------------------------------------------------------------------------
-template <int CH>
+// image_undistort::biInterp for RGB24 (include/VideoLib/image_undistort.h:66-79): integer 16.16 weights, >>16,
+// truncation to 8 bits.  Taps sit at base, base+1, base+w, base+w+1; an invalid tap has weight 0.
+__device__ __forceinline__ uchar3 undist_rgb(const uint8_t *__restrict__ frame, int32_t base, uint4 iw, int w) {
+    int r = 0, g = 0, b = 0;
+    const uint32_t wt[4] = {iw.x, iw.y, iw.z, iw.w};
+    const int off[4] = {0, 1, w, w + 1};
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+        if (wt[i] == 0) continue;
+        const uint8_t *q = frame + (size_t)(base + off[i]) * 3;
+        r += (int)wt[i] * (int)q[0];
+        g += (int)wt[i] * (int)q[1];
+        b += (int)wt[i] * (int)q[2];
+    }
+    return make_uchar3((unsigned char)(r >> 16), (unsigned char)(g >> 16), (unsigned char)(b >> 16));
+}
+
+template <int CH, bool UNDIST>
 __global__ __launch_bounds__(256) void k_rgb_rowscan(const uint8_t *__restrict__ rgb, float *__restrict__ dst,
-                                                     int w, int h, size_t n) {
+                                                     int w, int h, size_t n, const int32_t *__restrict__ und_base,
+                                                     const uint4 *__restrict__ und_iw) {
     const int seq = blockIdx.z;
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int y = blockIdx.x * 4 + wave;
@@ -52,8 +70,19 @@ __global__ __launch_bounds__(256) void k_rgb_rowscan(const uint8_t *__restrict__
     const int row_dw = (row_bytes + 3) >> 2;
     uint32_t *stage = reinterpret_cast<uint32_t *>(smem) + (size_t)wave * row_dw;
     if (y < h) {
-        const uint32_t *src = reinterpret_cast<const uint32_t *>(rgb + (size_t)seq * n * 3 + (size_t)y * row_bytes);
-        for (int i = lane; i < row_dw; i += 64) stage[i] = src[i];  // w % 4 == 0 -> rows are dword aligned
+        if (UNDIST) {
+            // undistortion fused into the load: lane x resamples pixel (x, y) from the distorted frame
+            const uint8_t *frame = rgb + (size_t)seq * n * 3;
+            unsigned char *sbw = reinterpret_cast<unsigned char *>(stage);
+            for (int x = lane; x < w; x += 64) {
+                const size_t pix = (size_t)y * w + x;
+                const uchar3 c = undist_rgb(frame, und_base[pix], und_iw[pix], w);
+                sbw[x * 3] = c.x; sbw[x * 3 + 1] = c.y; sbw[x * 3 + 2] = c.z;
+            }
+        } else {
+            const uint32_t *src = reinterpret_cast<const uint32_t *>(rgb + (size_t)seq * n * 3 + (size_t)y * row_bytes);
+            for (int i = lane; i < row_dw; i += 64) stage[i] = src[i];  // w % 4 == 0 -> rows are dword aligned
+        }
     }
     __syncthreads();
     if (y >= h) return;
@@ -663,9 +692,25 @@ __global__ __launch_bounds__(256) void k_retune(SeqDev *seqs, const int32_t *__r
     retuned_out[seq] = r;
 }
 
+__global__ void k_undistort_frame(const uint8_t *__restrict__ frame, uint8_t *__restrict__ out, int w, int n,
+                                  const int32_t *__restrict__ und_base, const uint4 *__restrict__ und_iw) {
+    const int pix = blockIdx.x * blockDim.x + threadIdx.x;
+    if (pix >= n) return;
+    const uchar3 c = undist_rgb(frame, und_base[pix], und_iw[pix], w);
+    out[(size_t)pix * 3] = c.x; out[(size_t)pix * 3 + 1] = c.y; out[(size_t)pix * 3 + 2] = c.z;
+}
+
 // ---------------------------------------------------------------------------------------------------
 // host side
 // ---------------------------------------------------------------------------------------------------
+int undistort_frame_enqueue(edgehip_ctx *c, int seq, int slot, uint8_t *out_dev) {
+    const DevicePlan &pl = c->plan;
+    hipLaunchKernelGGL(k_undistort_frame, dim3((pl.n + 255) / 256), dim3(256), 0, c->stream,
+                       rgbof(c, slot) + (size_t)seq * pl.n * 3, out_dev, pl.w, pl.n, c->und_base, c->und_iw);
+    EH_LAUNCH_CHECK();
+    return 0;
+}
+
 static int rowscan_ch(int w) { return 4 * ((w + 255) / 256); }
 
 int stage_a_enqueue(edgehip_ctx *c, int slot) {
@@ -683,16 +728,24 @@ int stage_a_enqueue(edgehip_ctx *c, int slot) {
         const int ch = rowscan_ch(w);
         const size_t sm = (size_t)4 * ((w * 3 + 3) / 4) * 4;
         dim3 g((h + 3) / 4, 1, B);
+        const bool und = c->und_base != nullptr;
+#define EH_ROWSCAN(CHV)                                                                                              \
+    case CHV:                                                                                                        \
+        if (und) hipLaunchKernelGGL((k_rgb_rowscan<CHV, true>), g, dim3(256), sm, st, rgbof(c, slot), ii[0], w, h, n, \
+                                    c->und_base, c->und_iw);                                                         \
+        else hipLaunchKernelGGL((k_rgb_rowscan<CHV, false>), g, dim3(256), sm, st, rgbof(c, slot), ii[0], w, h, n,   \
+                                c->und_base, c->und_iw);                                                             \
+        break;
         switch (ch) {
-            case 4: hipLaunchKernelGGL(k_rgb_rowscan<4>, g, dim3(256), sm, st, rgbof(c, slot), ii[0], w, h, n); break;
-            case 8: hipLaunchKernelGGL(k_rgb_rowscan<8>, g, dim3(256), sm, st, rgbof(c, slot), ii[0], w, h, n); break;
-            case 12: hipLaunchKernelGGL(k_rgb_rowscan<12>, g, dim3(256), sm, st, rgbof(c, slot), ii[0], w, h, n); break;
-            case 16: hipLaunchKernelGGL(k_rgb_rowscan<16>, g, dim3(256), sm, st, rgbof(c, slot), ii[0], w, h, n); break;
-            case 20: hipLaunchKernelGGL(k_rgb_rowscan<20>, g, dim3(256), sm, st, rgbof(c, slot), ii[0], w, h, n); break;
-            case 24: hipLaunchKernelGGL(k_rgb_rowscan<24>, g, dim3(256), sm, st, rgbof(c, slot), ii[0], w, h, n); break;
-            case 28: hipLaunchKernelGGL(k_rgb_rowscan<28>, g, dim3(256), sm, st, rgbof(c, slot), ii[0], w, h, n); break;
-            default: hipLaunchKernelGGL(k_rgb_rowscan<32>, g, dim3(256), sm, st, rgbof(c, slot), ii[0], w, h, n); break;
+            EH_ROWSCAN(4) EH_ROWSCAN(8) EH_ROWSCAN(12) EH_ROWSCAN(16) EH_ROWSCAN(20) EH_ROWSCAN(24) EH_ROWSCAN(28)
+            default:
+                if (und) hipLaunchKernelGGL((k_rgb_rowscan<32, true>), g, dim3(256), sm, st, rgbof(c, slot), ii[0], w, h, n,
+                                            c->und_base, c->und_iw);
+                else hipLaunchKernelGGL((k_rgb_rowscan<32, false>), g, dim3(256), sm, st, rgbof(c, slot), ii[0], w, h, n,
+                                        c->und_base, c->und_iw);
+                break;
         }
+#undef EH_ROWSCAN
         EH_LAUNCH_CHECK();
     }
     auto colscan = [&](float *a, float *b) -> int {

@@ -1055,7 +1055,7 @@ static TvrArgs make_tvr_args(edgehip_ctx *c, int slot_new, int slot_old, double 
     a.kn_old = c->kn_slot + (size_t)slot_old * pl.nseq;
     a.field = c->field; a.P0 = c->P0; a.resid = c->resid; a.resid_carry = c->resid_carry;
     a.block_last = c->block_last; a.partials = c->partials; a.seq = c->seq;
-    a.framecount = c->framecount + (size_t)slot_new * pl.nseq;
+    a.framecount = c->framecount + (size_t)c->fc_index * pl.nseq;
     a.w = pl.w; a.h = pl.h; a.cap = pl.cap; a.nblk = c->nblk_tvr; a.nseq = pl.nseq; a.n = pl.n;
     a.zfm = pl.zfm; a.max_r = (double)c->field_radius; a.match_thresh = match_thresh; a.k_huber = k_huber;
     a.ppx = pl.ppx; a.ppy = pl.ppy; a.match_num_thresh = match_num_thresh; a.write_mid = write_mid;
@@ -1077,7 +1077,7 @@ static int launch_lm(edgehip_ctx *c, int slot_new, unsigned ops) {
     ProfScope ps(c, PROF_B_LMSTEP);
     LmArgs a;
     a.seq = c->seq; a.partials = c->partials; a.block_last = c->block_last; a.resid_carry = c->resid_carry;
-    a.framecount = c->framecount + (size_t)slot_new * c->plan.nseq;
+    a.framecount = c->framecount + (size_t)c->fc_index * c->plan.nseq;
     a.nblk = c->nblk_tvr; a.nseq = c->plan.nseq; a.ops = ops; a.init_type = c->p.tracker_init_type;
     hipLaunchKernelGGL(k_lm_step, dim3(c->plan.nseq), dim3(64), 0, c->stream, a);
     EH_LAUNCH_CHECK();
@@ -1085,8 +1085,9 @@ static int launch_lm(edgehip_ctx *c, int slot_new, unsigned ops) {
 }
 
 // Minimizer_RV<double,false>: the static evaluation/step schedule of global_tracker.cpp:631-816
-int minimizer_enqueue(edgehip_ctx *c, int slot_new, int slot_old) {
+int minimizer_enqueue(edgehip_ctx *c, int slot_new, int slot_old, int fc_index) {
     const edgehip_params &p = c->p;
+    c->fc_index = fc_index;
     int e;
     if ((e = tvr_prepare_enqueue(c, slot_old))) return e;
     const int I = p.tracker_init_iter_num, M = p.tracker_iter_num;
@@ -1163,6 +1164,7 @@ int edgehip_try_velrot(edgehip_ctx *c, int slot_new, int slot_old, const double 
     }
     const int B = c->plan.nseq;
     int e;
+    c->fc_index = slot_new;
     // P0 is rebuilt every call (the old slot may have been edited through upload_keylines)
     if (resid_in < 0) {
         if ((e = tvr_prepare_enqueue(c, slot_old))) return e;  // also zeroes buffer 0
@@ -1221,7 +1223,7 @@ int edgehip_download_resid(edgehip_ctx *c, int which, double *resid) {
 
 int edgehip_minimizer_rv(edgehip_ctx *c, int slot_new, int slot_old) {
     if (!c || slot_new < 0 || slot_old < 0 || slot_new >= c->plan.nslots || slot_old >= c->plan.nslots) return EDGEHIP_ERR_ARG;
-    return minimizer_enqueue(c, slot_new, slot_old);
+    return minimizer_enqueue(c, slot_new, slot_old, slot_new);
 }
 
 }  // extern "C"

@@ -562,6 +562,20 @@ __global__ void k_frame_glue(SeqDev *seqs, const double *__restrict__ t_in, edge
     }
 }
 
+// REBVO::Reset() as executed by SecondThread after a frame (rebvo_second_t.cpp:609-620)
+__global__ __launch_bounds__(256) void k_depth_reset(const KlSoA *kls, const int32_t *__restrict__ kns, SeqDev *seqs, int only_seq) {
+    const int seq = blockIdx.z, i = blockIdx.x * 256 + threadIdx.x;
+    if (only_seq >= 0 && seq != only_seq) return;
+    if (i == 0) {
+        edgehip_seq_state &p = seqs[seq].pub;
+        ident_scaled(p.Pose, 1);
+        for (int k = 0; k < 3; k++) { p.Pos[k] = 0; p.V[k] = 0; p.W[k] = 0; }
+    }
+    if (i >= kns[seq]) return;
+    kls[seq].rho[i] = kRhoInit;
+    kls[seq].s_rho[i] = kRhoMax;
+}
+
 // ---------------------------------------------------------------------------------------------------
 // host side
 // ---------------------------------------------------------------------------------------------------
@@ -678,6 +692,16 @@ int edgehip_rescale(edgehip_ctx *c, int slot) {
     return rescale_enqueue(c, slot);
 }
 
+int edgehip_depth_reset(edgehip_ctx *c, int seq) {
+    if (!c || seq >= c->plan.nseq) return EDGEHIP_ERR_ARG;
+    if (c->frame_slot < 0) return 0;  // nothing detected yet: the initial state already is the reset state
+    const DevicePlan &pl = c->plan;
+    hipLaunchKernelGGL(k_depth_reset, dim3((pl.cap + 255) / 256, 1, pl.nseq), dim3(256), 0, c->stream,
+                       kldev(c, c->frame_slot), c->kn_slot + (size_t)c->frame_slot * pl.nseq, c->seq, seq);
+    EH_LAUNCH_CHECK();
+    return 0;
+}
+
 int edgehip_next_slot(edgehip_ctx *c) { return c ? (c->frame_slot + 1) % c->plan.nslots : -1; }
 int edgehip_cur_slot(edgehip_ctx *c) { return c ? c->frame_slot : -1; }
 
@@ -700,7 +724,7 @@ int edgehip_process_frame(edgehip_ctx *c, const double *t) {
     if (have_pair) {
         EH_TRY(quantile_enqueue(c, so, kRhoMin, kRhoMax, c->p.qcut_quantile, c->p.qcut_nbins));  // rebvo_second_t.cpp:172
         EH_TRY(build_field_enqueue(c, sn, c->p.search_range, -1.f));                              // :177
-        EH_TRY(minimizer_enqueue(c, sn, so));                                                    // :346
+        EH_TRY(minimizer_enqueue(c, sn, so, c->frames_seen % kRefRing));                                                    // :346
         EH_TRY(forward_match_enqueue(c, so, sn));                                                // :354
         EH_TRY(rotate_enqueue(c, so, nullptr));                                                  // :360-369
         { ProfScope ps(c, PROF_C_POSE); EH_TRY(glue(c, 1, sn, have_pair)); }                     // :387-397

@@ -48,6 +48,7 @@ class Params(C.Structure):
         ("loc_unc", C.c_double),
         ("global_match_threshold", C.c_int32), ("debug_planes", C.c_int32),
         ("config_fps", C.c_double),
+        ("use_undistort", C.c_int32), ("reserved0", C.c_int32),
     ]
 
 
@@ -76,6 +77,25 @@ def euroc_params(w=752, h=480, **over):
         setattr(p, k, v)
     return p
 
+
+def tum_params(w=640, h=480, **over):
+    """app/rebvorun/GlobalConfig_desk.txt of the reference (TUM fr2/desk, ImuMode=0): BASELINE config 4.
+    The shipped file has Kc=0/UseUndistort=0; config 4 exercises the undistorter, so callers pass
+    use_undistort=1 and a distortion (the EuRoC coefficients by default, SURVEY.md section 8d scene S3)."""
+    p = euroc_params(w, h)
+    sx, sy = w / 640.0, h / 480.0
+    p.ppx, p.ppy, p.zfx, p.zfy = 320.0 * sx, 240.0 * sy, 525.0 * sx, 525.0 * sy
+    p.max_points, p.reference_points, p.track_points = 25000, 15000, 12000
+    p.detector_thresh, p.auto_gain, p.max_thresh, p.min_thresh = 0.01, 1e-6, 0.05, 0.03
+    p.search_range = 20
+    p.tracker_iter_num, p.tracker_init_type, p.tracker_init_iter_num = 10, 2, 2
+    p.tracker_match_thresh = 1.0
+    p.match_num_thresh = 4
+    p.reshape_q_rel = 1e-2
+    p.config_fps = 50.0
+    for k, v in over.items():
+        setattr(p, k, v)
+    return p
 
 class SeqState(C.Structure):
     _fields_ = [
@@ -121,6 +141,7 @@ EXPORTS = [
     "edgehip_upload_keylines", "edgehip_download_plane", "edgehip_download_field", "edgehip_profile_enable",
     "edgehip_profile_count", "edgehip_profile_name", "edgehip_profile_read", "edgehip_profile_select",
     "edgehip_upload_rgb_indexed", "edgehip_set_nav_log", "edgehip_read_nav_log",
+    "edgehip_build_undistort_map", "edgehip_download_undistorted", "edgehip_depth_reset",
 ]
 
 _lib = None
@@ -142,6 +163,18 @@ def load_library():
 
 class EdgeHipError(RuntimeError):
     pass
+
+
+def build_undistort_map(params):
+    """Host-only: the bilinear undistortion map edgehip_create() builds for `params`, in the reference's
+    undistMapPoint form -> (inx[h*w,4] with -1 beyond num, iw[h*w,4])."""
+    lib = load_library()
+    n = params.w * params.h
+    inx, iw = np.empty((n, 4), np.int32), np.empty((n, 4), np.int32)
+    rc = lib.edgehip_build_undistort_map(C.byref(params), C.c_void_p(inx.ctypes.data), C.c_void_p(iw.ctypes.data))
+    if rc != 0:
+        raise EdgeHipError(f"edgehip_build_undistort_map: {rc}")
+    return inx, iw
 
 
 def _dp(a):
@@ -172,6 +205,15 @@ class EdgeHip:
             self.close()
         except Exception:
             pass
+
+    def depth_reset(self, seq=-1):
+        """REBVO::Reset() (rebvo_second_t.cpp:609-620) for one sequence or all (-1)."""
+        self._ck(self.lib.edgehip_depth_reset(self.ctx, seq))
+
+    def download_undistorted(self, seq, slot):
+        out = np.empty((self.h, self.w, 3), np.uint8)
+        self._ck(self.lib.edgehip_download_undistorted(self.ctx, seq, slot, C.c_void_p(out.ctypes.data)))
+        return out
 
     # ---- input ----
     def upload_rgb(self, slot, rgb, seq_first=0):

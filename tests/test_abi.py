@@ -21,15 +21,22 @@ def test_library_exports_every_symbol():
     lib = edgehip.load_library()
     missing = [s for s in _declared() if not hasattr(lib, s)]
     assert not missing, missing
-    assert lib.edgehip_abi_version() == 1
+    assert lib.edgehip_abi_version() == 2
 
 
-def test_struct_sizes_match_header():
+def test_struct_sizes_match_header(tmp_path):
+    """sizeof() of every struct in include/edgehip.h, as gcc lays it out, equals the ctypes mirrors."""
     import ctypes as C
-    # edgehip_keyline is the reference's 168-byte KeyLine; params/state/nav mirror the header field by field
-    assert edgehip.KEYLINE_DTYPE.itemsize == 168
-    assert C.sizeof(edgehip.Params) == 8 + 4 * 8 + 5 * 8 + 2 * 8 + 8 + 2 * 8 + 3 * 4 + 4 + 4 * 8 + 2 * 4 + 8 + 3 * 4 + 4 + 3 * 8 + 2 * 4 + 6 * 8 + 2 * 4 + 8
-    assert C.sizeof(edgehip.SeqState) % 8 == 0 and C.sizeof(edgehip.Nav) % 8 == 0
+    import subprocess
+    src = tmp_path / "sz.c"
+    src.write_text('#include <stdio.h>\n#include "edgehip.h"\nint main(void){printf("%zu %zu %zu %zu\\n",'
+                   'sizeof(edgehip_params),sizeof(edgehip_keyline),sizeof(edgehip_seq_state),sizeof(edgehip_nav));return 0;}\n')
+    exe = tmp_path / "sz"
+    subprocess.run(["gcc", "-std=c99", "-I", os.path.join(ROOT, "include"), str(src), "-o", str(exe)], check=True)
+    sizes = [int(x) for x in subprocess.run([str(exe)], check=True, capture_output=True, text=True).stdout.split()]
+    assert sizes == [C.sizeof(edgehip.Params), edgehip.KEYLINE_DTYPE.itemsize, C.sizeof(edgehip.SeqState),
+                     C.sizeof(edgehip.Nav)]
+    assert edgehip.KEYLINE_DTYPE.itemsize == 168   # the reference's KeyLine
 
 
 def test_create_fails_loudly_without_gpu_or_on_bad_args():

@@ -63,3 +63,49 @@ def test_pipeline_euroc_size():
 
 def test_pipeline_batched_sequences_identical():
     _run(376, 240, 4, nseq=3)
+
+
+def test_framecount_follows_reference_ring():
+    """MatchNumThresh > 0 makes TryVelRot skip KeyLines with m_num < min(MatchNumThresh, FrameCount)
+    (global_tracker.cpp:356); FrameCount lives in the reference's 8 PipeBuffer slots, so the value a frame
+    sees depends on THAT ring length, whatever nslots the GPU context uses."""
+    from oracle import oracle
+    if not oracle.available("ref"):
+        pytest.skip("oracle/_ref not built")
+    w, h, n = 376, 240, 19
+    frames = [f for f, _, _ in synth.billboard_sequence(w, h, n)]
+    orc = oracle.Oracle("ref", oracle.euroc_params(w, h, match_num_thresh=2))
+    eh = edgehip.EdgeHip(edgehip.euroc_params(w, h, match_num_thresh=2), nseq=1, nslots=3)
+    for k, f in enumerate(frames):
+        _, nr = orc.process_frame(f, 0.05 * k)
+        eh.upload_rgb(eh.next_slot(), f)
+        eh.process_frame(0.05 * k)
+        ng = eh.read_nav()[0]
+        assert ng.kn == nr.kn
+        if k:
+            step = np.linalg.norm(nr.V[:]) + np.linalg.norm(nr.W[:])
+            assert np.allclose(ng.V[:], nr.V[:], rtol=0, atol=1e-6 * step + 1e-9), k
+            assert np.allclose(ng.W[:], nr.W[:], rtol=0, atol=1e-6 * step + 1e-9), k
+    eh.close()
+
+
+def test_depth_reset_semantics():
+    """edgehip_depth_reset == REBVO::Reset() as SecondThread runs it (rebvo_second_t.cpp:609-620)."""
+    w, h = 376, 240
+    frames = [f for f, _, _ in synth.billboard_sequence(w, h, 4)]
+    eh = edgehip.EdgeHip(edgehip.euroc_params(w, h), nseq=2, nslots=3)
+    for k, f in enumerate(frames):
+        eh.upload_rgb(eh.next_slot(), np.stack([f, f]))
+        eh.process_frame(0.05 * k)
+    before = eh.get_state(0)
+    eh.depth_reset(1)
+    s0, s1 = eh.get_state(0), eh.get_state(1)
+    assert list(s0.Pos[:]) == list(before.Pos[:]) and np.linalg.norm(s0.Pos[:]) > 0   # sequence 0 untouched
+    assert list(s1.Pos[:]) == [0, 0, 0] and list(s1.V[:]) == [0, 0, 0] and list(s1.W[:]) == [0, 0, 0]
+    assert np.array_equal(np.array(s1.Pose[:]).reshape(3, 3), np.eye(3))
+    assert s1.tresh == s0.tresh                                 # detector state carries on
+    k0, _ = eh.download_keylines(0, eh.cur_slot())
+    k1, _ = eh.download_keylines(1, eh.cur_slot())
+    assert (k1["rho"] == 1.0).all() and (k1["s_rho"] == 20.0).all()
+    assert (k0["s_rho"] < 20.0).any()
+    eh.close()

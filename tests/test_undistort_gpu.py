@@ -1,0 +1,76 @@
+"""BASELINE config 4 (GPU): TUM 640x480 with the undistorter fused into the first stage-A kernel.
+
+* the undistorted RGB frame recomputed on the device == image_undistort::undistort<true> of the reference
+  (integer arithmetic: bit-exact);
+* stage A on the distorted input == the reference's undistort -> ConvertRGB2BW -> build -> detect, bit-exact
+  (DoG plane, mask, KeyLines);
+* the whole pipeline over several frames stays within the pose tolerance of test_pipeline_gpu.py.
+"""
+import numpy as np
+import pytest
+
+from rebvo_amd import edgehip, synth
+
+pytestmark = pytest.mark.gpu
+
+KCS = [(-0.28340811, 0.07395907, 0.0, 0.00019359, 1.76187114e-05), (0.35, 0.1, 0.0, 1e-3, -2e-3)]
+
+
+def _mk(kc, **over):
+    from oracle import oracle
+    po, pe = oracle.tum_params(use_undistort=1, **over), edgehip.tum_params(use_undistort=1, **over)
+    po.kc[:] = kc
+    pe.kc[:] = kc
+    return po, pe
+
+
+@pytest.mark.parametrize("kc", KCS, ids=["barrel", "pincushion"])
+def test_stage_a_with_undistort_bit_exact(kc):
+    from oracle import oracle
+    if not oracle.available("ref"):
+        pytest.skip("oracle/_ref not built")
+    po, pe = _mk(kc)
+    pe.debug_planes = 1
+    frames = [f for f, _, _ in synth.billboard_sequence(640, 480, 2)]
+    orc = oracle.Oracle("ref", po)
+    eh = edgehip.EdgeHip(pe, nseq=2, nslots=2)
+    tr, lr = po.detector_thresh, 0
+    for k, f in enumerate(frames):
+        kn, tr, lr = orc.stage_a(k, f, tr, lr)
+        eh.upload_rgb(k, np.stack([f, f]))
+        eh.stage_a(k)
+        assert list(eh.get_kn(k)) == [kn, kn]
+        assert np.array_equal(eh.download_undistorted(1, k), orc.imgc(k))
+        assert np.array_equal(eh.download_plane(0, "dog"), orc.plane(k, "dog"))
+        kg, mask = eh.download_keylines(1, k)
+        assert np.array_equal(mask, orc.mask(k))
+        kr = orc.keylines(k)
+        for fld in ("p_inx", "m_m", "u_m", "n_m", "c_p", "p_m", "p_id", "n_id"):
+            assert np.array_equal(kg[fld], kr[fld]), fld
+    eh.close()
+
+
+def test_pipeline_tum_undistort():
+    from oracle import oracle
+    if not oracle.available("ref"):
+        pytest.skip("oracle/_ref not built")
+    po, pe = _mk(KCS[0])
+    frames = [f for f, _, _ in synth.billboard_sequence(640, 480, 11)]  # > 8: wraps the reference's FrameCount ring
+    orc = oracle.Oracle("ref", po)
+    eh = edgehip.EdgeHip(pe, nseq=1, nslots=3)
+    for k, f in enumerate(frames):
+        _, nr = orc.process_frame(f, 0.02 * k)
+        eh.upload_rgb(eh.next_slot(), f)
+        eh.process_frame(0.02 * k)
+        ng = eh.read_nav()[0]
+        assert ng.kn == nr.kn and ng.tresh == nr.tresh
+        if k == 0:
+            continue
+        assert ng.estimation_ok == nr.estimation_ok
+        Vr, Wr = np.array(nr.V[:]), np.array(nr.W[:])
+        step = np.linalg.norm(Vr) + np.linalg.norm(Wr)
+        assert np.allclose(ng.V[:], Vr, rtol=0, atol=1e-6 * step + 1e-9)
+        assert np.allclose(ng.W[:], Wr, rtol=0, atol=1e-6 * step + 1e-9)
+    _, mask = eh.download_keylines(0, eh.cur_slot())
+    assert np.array_equal(mask, orc.mask(orc.cur_slot()))
+    eh.close()

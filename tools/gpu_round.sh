@@ -1,0 +1,42 @@
+#!/bin/bash
+# One gpurun call: GPU parity tests, the default bench line, a rocprofv3 kernel trace of the same bench
+# command, and two separate PMC passes (FETCH_SIZE / WRITE_SIZE cannot share a pass on gfx950).
+# usage: tools/gpu_round.sh <tag> [skip-tests]
+# Outputs land in gpurun_out/<tag>/ ; copy what should be judged into profiles/.
+set -u
+TAG=${1:-r01}
+SKIP_TESTS=${2:-}
+OUT=$PWD/gpurun_out/$TAG
+mkdir -p "$OUT"
+export TMPDIR=/tmp
+BENCH_ARGS=${BENCH_ARGS:-}
+
+if [ -z "$SKIP_TESTS" ]; then
+  timeout 900 python -m pytest tests -m gpu -x -q > "$OUT/pytest_gpu.log" 2>&1
+  echo "pytest exit $?" >> "$OUT/pytest_gpu.log"
+  tail -5 "$OUT/pytest_gpu.log"
+fi
+
+timeout 600 python bench.py $BENCH_ARGS > "$OUT/bench.json" 2> "$OUT/bench.err"
+echo "bench exit $?"; tail -c 3000 "$OUT/bench.json"
+
+# kernel trace of the same command (CPU baseline skipped: it is host work and only lengthens the trace)
+( cd /tmp && timeout 600 rocprofv3 --kernel-trace --stats -d "$OUT/trace" -o bench -- \
+    python "$GRAFT_REPO_ROOT/bench.py" $BENCH_ARGS --cpu-frames 0 > "$OUT/trace_bench.json" 2> "$OUT/trace.err" )
+echo "trace exit $?"
+DB=$(ls "$OUT"/trace/*.db "$OUT"/trace/*/*.db 2>/dev/null | head -1)
+[ -n "$DB" ] && python tools/rocpd_summary.py "$DB" "$OUT/kernel_stats.txt" > /dev/null
+ls "$OUT/trace" | head
+
+# PMC passes: short run, counters only (no trace domains besides kernel-trace)
+for C in FETCH_SIZE WRITE_SIZE; do
+  ( cd /tmp && timeout 600 rocprofv3 --kernel-trace --pmc $C --output-format csv -d "$OUT/pmc_$C" -o pmc -- \
+      python "$GRAFT_REPO_ROOT/bench.py" $BENCH_ARGS --steps 6 --warmup 12 --cpu-frames 0 --no-roofline-events \
+      > "$OUT/pmc_$C.json" 2> "$OUT/pmc_$C.err" )
+  echo "pmc $C exit $?"
+  python tools/pmc_summary.py "$OUT/pmc_$C" "$OUT/pmc_$C.txt" > /dev/null
+  find "$OUT/pmc_$C" -name '*.csv' -size +5M -delete
+done
+# raw traces are large; keep only the summaries
+find "$OUT" -name '*.db' -size +20M -delete
+du -sh "$OUT"
