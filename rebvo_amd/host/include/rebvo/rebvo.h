@@ -1,0 +1,353 @@
+// rebvo.h — host-side mirror of the reference's library surface (include/rebvo/rebvo.h:64-640) on top of
+// libedgehip.so.  An application written against the reference (app/rebvorun/main_custom_cam_example.cpp,
+// ros/src/rebvo_ros/src/rebvo_nodelet.cpp) keeps its calls:
+//
+//     rebvo::REBVO cf("GlobalConfig");  cf.Init();
+//     cf.setOutputCallback(&callback);
+//     cf.requestCustomCamBuffer(ptr, tstamp);  (*ptr).copyFrom(data);  cf.releaseCustomCamBuffer();
+//     NavData n = cf.getNav();  ...  cf.CleanUp();
+//
+// Same names, argument meaning, ownership and error behaviour (bool returns, InitOK on a bad config, false on
+// a request time-out); the per-frame edge pipeline behind it runs on the GPU through include/edgehip.h.
+//
+// Differences, all forced by what is out of scope here:
+//  * CameraType must be 3 (custom camera: the application feeds frames); V4L / SimCam / DataSetCam are device
+//    and file I/O that this repository does not rebuild.  ImuMode must be 0 (the IMU branch is "next").
+//  * PipeBuffer::ss and ::gt are null (scale space and auxiliary field stay in HBM); PipeBuffer::ef is a
+//    host view with the edge_finder members consumers use: KNum(), operator[], begin()/end(), GetCam(),
+//    getThresh(), NumMatches().
+//  * Vectors/matrices are minimal POD types (Vector3, Matrix3x3: operator[] / operator()(i,j)) with the
+//    layout of TooN::Vector<3> / TooN::Matrix<3,3>; compile with -DREBVO_HAVE_TOON to get the TooN types.
+//  * Only the config keys that reach this path are mandatory; keys of subsystems that do not exist here
+//    (UDP, encoders, SimuCamera, ProcesorConfig ...) are accepted and ignored.  Optional section:
+//        &GPU  Device=0
+#ifndef REBVO_AMD_HOST_REBVO_H
+#define REBVO_AMD_HOST_REBVO_H
+
+#include <atomic>
+#include <cstdint>
+#include <cstring>
+#include <functional>
+#include <memory>
+#include <mutex>
+#include <stdexcept>
+#include <string>
+#include <thread>
+#include <vector>
+
+#include "rebvo/pipeline.h"
+
+#ifdef REBVO_HAVE_TOON
+#include <TooN/TooN.h>
+#endif
+
+struct edgehip_ctx;
+
+namespace rebvo {
+
+typedef unsigned int uint;
+
+// ---- small value types (reference: include/VideoLib/video_io.h:45-68) ------------------------------------
+union RGB24Pixel {
+    struct { uint8_t r, g, b; } pix;
+    uint8_t dat[3];
+};
+struct Size2D { uint w, h; };
+struct Point2DF { float x, y; };
+struct Point2DI { int x, y; };
+
+#ifdef REBVO_HAVE_TOON
+typedef TooN::Vector<3> Vector3;
+typedef TooN::Matrix<3, 3> Matrix3x3;
+inline Vector3 Zeros3() { return TooN::Zeros; }
+inline Matrix3x3 Identity3() { return TooN::Identity; }
+#else
+struct Vector3 {
+    double v[3] = {0, 0, 0};
+    double &operator[](int i) { return v[i]; }
+    const double &operator[](int i) const { return v[i]; }
+};
+struct Matrix3x3 {  // row-major, like TooN::Matrix<3,3>
+    double m[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1};
+    double &operator()(int r, int c) { return m[r * 3 + c]; }
+    const double &operator()(int r, int c) const { return m[r * 3 + c]; }
+    double *operator[](int r) { return m + r * 3; }
+    const double *operator[](int r) const { return m + r * 3; }
+};
+inline Vector3 Zeros3() { return Vector3(); }
+inline Matrix3x3 Identity3() { return Matrix3x3(); }
+#endif
+
+// ---- Image<T> (reference: include/VideoLib/image.h:42-217; the members applications use) ---------------
+template <typename DataType>
+class Image {
+    DataType *data = nullptr;
+    Size2D size = {0, 0};
+    uint bsize = 0;
+    bool data_owned = false;
+
+public:
+    Image() {}
+    explicit Image(const Size2D &i_size) : data(new DataType[(size_t)i_size.w * i_size.h]), size(i_size), bsize(i_size.w * i_size.h), data_owned(true) {}
+    Image(DataType *i_data, const Size2D &i_size) : data(i_data), size(i_size), bsize(i_size.w * i_size.h), data_owned(false) {}
+    Image(const Image &img) : data(new DataType[img.bsize]), size(img.size), bsize(img.bsize), data_owned(true) {
+        std::memcpy(data, img.data, sizeof(DataType) * bsize);
+    }
+    Image &operator=(const Image &img) {
+        if (img.size.w != size.w || img.size.h != size.h) throw std::length_error("Image: size mismatch");
+        std::memcpy(data, img.data, sizeof(DataType) * bsize);
+        return *this;
+    }
+    ~Image() { if (data_owned) delete[] data; }
+    DataType *Data() { return data; }
+    const DataType *Data() const { return data; }
+    DataType &operator[](const uint inx) { return data[inx]; }
+    const DataType &operator[](const uint inx) const { return data[inx]; }
+    DataType &operator()(const uint x, const uint y) { return data[(size_t)y * size.w + x]; }
+    uint GetIndex(const uint x, const uint y) const { return y * size.w + x; }
+    bool isInxValid(const uint &x, const uint &y) const { return x < size.w && y < size.h; }
+    const Size2D &Size() const { return size; }
+    const uint &bSize() const { return bsize; }
+    Image &operator=(DataType *img) { std::memcpy(data, img, sizeof(DataType) * bsize); return *this; }
+    void copyTo(DataType *img) const { std::memcpy(img, data, sizeof(DataType) * bsize); }
+    void copyFrom(const DataType *img) { std::memcpy(data, img, sizeof(DataType) * bsize); }
+    void Reset(DataType d) { for (uint i = 0; i < bsize; i++) data[i] = d; }
+};
+
+// ---- camera model (reference: include/UtilLib/cam_model.h:33-179; projection helpers consumers call) -----
+class cam_model {
+public:
+    struct rad_tan_distortion { double Kc2 = 0, Kc4 = 0, Kc6 = 0, P1 = 0, P2 = 0; };
+    Point2DF pp = {0, 0};
+    Point2DF zf = {1, 1};
+    double zfm = 1;
+    rad_tan_distortion Kc;
+    Size2D sz = {0, 0};
+    cam_model() {}
+    cam_model(Point2DF prin_point, Point2DF focal_dist, rad_tan_distortion DistKc, Size2D ImageSize)
+        : pp(prin_point), zf(focal_dist), zfm((focal_dist.x + focal_dist.y) / 2), Kc(DistKc), sz(ImageSize) {}
+    template <typename P> P Hom2Img(const P &ph) const { return {ph.x + pp.x, ph.y + pp.y}; }
+    template <typename P> P Img2Hom(const P &pi) const { return {pi.x - pp.x, pi.y - pp.y}; }
+    // p = (x_hom, y_hom, rho) -> 3D point, as cam_model::unprojectHomCordVec
+    Vector3 unprojectHomCordVec(double x, double y, double rho) const {
+        Vector3 r;
+        r[0] = x / rho / zfm; r[1] = y / rho / zfm; r[2] = 1 / rho;
+        return r;
+    }
+};
+
+// ---- KeyLine: byte-for-byte the reference's struct (include/mtracklib/edge_finder.h:45-91), 168 bytes -----
+struct KeyLine {
+    int p_inx;
+    Point2DF m_m;
+    Point2DF u_m;
+    float n_m;
+    float score;
+    Point2DF c_p;
+    double rho, s_rho, rho_nr, s_rho_nr, rho0, s_rho0;
+    Point2DF p_m;
+    Point2DF p_m_0;
+    int m_id, m_id_f, m_id_kf;
+    uint m_num;
+    Point2DF m_m0;
+    double n_m0;
+    int p_id, n_id, net_id;
+    int stereo_m_id;
+    double stereo_rho, stereo_s_rho;
+};
+static_assert(sizeof(KeyLine) == 168, "KeyLine must keep the reference layout");
+
+class sspace;          // stay on the device: PipeBuffer::ss / ::gt are null
+class global_tracker;
+
+// Host view of one frame's edge map: what the output callback iterates.
+class edge_tracker {
+    cam_model cam_mod;
+    std::vector<KeyLine> kl;
+    int kn = 0;
+    int nmatch = 0;
+    float reTunedThresh = 0;
+    friend class REBVO;
+
+public:
+    edge_tracker(const cam_model &cam, int kl_num_max) : cam_mod(cam), kl(kl_num_max) {}
+    cam_model &GetCam() { return cam_mod; }
+    int KNum() const { return kn; }
+    int NumMatches() const { return nmatch; }
+    KeyLine &operator[](uint inx) { return kl[inx]; }
+    float getThresh() const { return reTunedThresh; }
+    typedef KeyLine *iterator;
+    typedef const KeyLine *const_iterator;
+    iterator begin() { return kl.data(); }
+    iterator end() { return kl.data() + kn; }
+};
+
+// ---- REBVOParameters (reference: include/rebvo/rebvo.h:64-235, same member names) ----------------------
+struct REBVOParameters {
+    int CameraType = 3;
+    std::string VideoNetHost; int VideoNetPort = 0; bool VideoNetEnabled = false; bool BlockingUDP = false;
+    int VideoSave = 0; std::string VideoSaveFile; int VideoSaveBuffersize = 0;
+    int encoder_type = 0; std::string encoder_dev; uint EdgeMapDelay = 0;
+    bool SaveLog = false; std::string LogFile; std::string TrayFile;
+    bool TrackKeyFrames = false; double KFSavePercent = 0; bool StereoAvaiable = false;
+    std::string DataSetFile, DataSetDir, DataSetFileStereo, DataSetDirStereo; double CamTimeScale = 1;
+    Size2D ImageSize = {0, 0};
+    float z_f_x = 0, z_f_y = 0, pp_y = 0, pp_x = 0;
+    cam_model::rad_tan_distortion kc;
+    double config_fps = 30, soft_fps = 30;
+    bool useUndistort = false, rotatedCam = false;
+    std::string CameraDevice;
+    std::string SimFile; double sim_save_nframes = 0; int simu_time_on = 0, simu_time_step = 0;
+    double simu_time_sweep = 0, simu_time_start = 0;
+    int ImuMode = 0; std::string ImuFile; bool UseCamIMUSE3File = false; std::string SE3File; double ImuTimeScale = 1;
+    int cpuSetAffinity = 0, cpu0 = 0, cpu1 = 0, cpu2 = 0;
+    // Detector
+    double Sigma0 = 1.7818, KSigma = 1.2599;
+    int DetectorPlaneFitSize = 2; double DetectorPosNegThresh = 0.4, DetectorDoGThresh = 0.095259868922420;
+    int ReferencePoints = 12000, TrackPoints = 12000, MaxPoints = 16000;
+    double DetectorThresh = 0.01, DetectorAutoGain = 5e-7, DetectorMaxThresh = 0.5, DetectorMinThresh = 0.005;
+    // Tracker-Mapper
+    int MatchThreshold = 500;
+    double SearchRange = 40, QCutOffNumBins = 100, QCutOffQuantile = 0.9;
+    int TrackerIterNum = 5, TrackerInitIterNum = 2, TrackerInitType = 2;
+    double TrackerMatchThresh = 0.5, LocationUncertaintyMatch = 2, MatchThreshModule = 1, MatchThreshAngle = 45;
+    double ReweigthDistance = 2;
+    uint MatchNumThresh = 0;
+    double RegularizeThresh = 0.5, ReshapeQAbsolute = 1e-4, ReshapeQRelative = 1.6968e-04, LocationUncertainty = 1;
+    double DoReScaling = 0;
+    // extension: HIP device ordinal (optional config section &GPU, key Device)
+    int GpuDevice = 0;
+};
+
+struct IMUState {  // kept so that consumers referring to PipeBuffer::imustate compile; unused with ImuMode=0
+    Vector3 Vg, dVv, dWv, Bg, Av, As, g_est, b_est, Posgv, Posgva;
+};
+struct ImuData { double tstamp = 0; Vector3 giro, acel, comp; };
+struct IntegratedImuData { int n = 0; Vector3 giro, acel, cacel, dgiro; double dt = 0; };
+
+struct NavData {
+    double t = 0, dt = 0, scale = 1;
+    Matrix3x3 Rot = Identity3();
+    Vector3 RotLie = Zeros3(), RotGiro = Zeros3(), Vel = Zeros3(), g = Zeros3();
+    Matrix3x3 Pose = Identity3();
+    Vector3 PoseLie = Zeros3(), Pos = Zeros3();
+};
+
+struct PipeBuffer {
+    sspace *ss = nullptr;
+    global_tracker *gt = nullptr;
+    edge_tracker *ef = nullptr;
+    Image<RGB24Pixel> *imgc = nullptr;
+    Image<float> *img = nullptr;
+    sspace *ss_pair = nullptr;
+    edge_tracker *ef_pair = nullptr;
+    Image<RGB24Pixel> *imgc_pair = nullptr;
+    Image<float> *img_pair = nullptr;
+    double t = 0, dt = 0, s_rho_p = 0;
+    NavData nav;
+    IMUState imustate;
+    double dtp0 = 0, dtp1 = 0;
+    double K = 1, Kp = 1, RKp = 0;
+    int p_id = 0;
+    bool EstimationOK = false;
+    bool quit = false;
+    int stereo_match_num = 0;
+    IntegratedImuData imu;
+};
+
+namespace customCam {
+struct CustomCamPipeBuffer {
+    std::shared_ptr<Image<RGB24Pixel>> img;
+    double timestamp = 0;
+};
+}  // namespace customCam
+
+constexpr int CBUFSIZE = 0x08;
+constexpr int CCAMBUFSIZE = 0x04;
+
+class REBVO {
+    REBVOParameters params;
+    std::thread Thr0;
+    bool InitOK = true;
+    std::mutex nav_mutex;
+    NavData nav;
+    std::atomic_bool quit;
+    Pipeline<PipeBuffer> pipe;
+    std::atomic_bool system_reset;
+    Pipeline<customCam::CustomCamPipeBuffer> cam_pipe;
+    cam_model cam;
+    std::mutex call_mutex;
+    std::function<bool(PipeBuffer &)> outputFunc;
+    edgehip_ctx *hip = nullptr;
+    std::string last_error;
+
+    bool callCallBack(PipeBuffer &pbuf) {
+        std::lock_guard<std::mutex> locker(call_mutex);
+        if (outputFunc) return outputFunc(pbuf);
+        return true;
+    }
+    bool haveCallBack() {
+        std::lock_guard<std::mutex> locker(call_mutex);
+        return (bool)outputFunc;
+    }
+    void pushNav(const NavData &navdat) {
+        std::lock_guard<std::mutex> locker(nav_mutex);
+        nav = navdat;
+    }
+    void construct();
+    static void TrackThread(REBVO *cf);   // FirstThr + SecondThread of the reference: one GPU frame per loop
+    static void ThirdThread(REBVO *cf);   // output: log, trajectory, callback
+
+public:
+    REBVO(const char *configFile);
+    REBVO(const REBVOParameters &parameters);
+    ~REBVO();
+    bool Init();
+    bool CleanUp();
+
+    void StartSimSave() {}
+    void TakeSnapshot() {}
+    void Reset() { system_reset = true; }
+    bool Running() { return !quit; }
+    void startKeyFrames() {}
+    void endKeyFrames() {}
+    bool toggleKeyFrames() { return false; }
+    bool toggleFrameByFrame() { return false; }
+    bool advanceFrameByFrame() { return false; }
+
+    NavData getNav() {
+        std::lock_guard<std::mutex> locker(nav_mutex);
+        NavData navdat = nav;
+        return navdat;
+    }
+    const REBVOParameters &getParams() { return params; }
+    bool setCamImuSE3(const Matrix3x3 &, const Vector3 &) { return false; }  // no IMU on this path
+    bool pushIMU(const ImuData &) { return false; }                         // reference returns false without an ImuGrabber
+
+    bool requestCustomCamBuffer(std::shared_ptr<Image<RGB24Pixel>> &ptr, double time_stamp, double timeout_secs = 0) {
+        customCam::CustomCamPipeBuffer *ccpb = cam_pipe.RequestBufferTimeoutable(0, timeout_secs);
+        if (ccpb == nullptr) return false;
+        ptr = (*ccpb).img;
+        (*ccpb).timestamp = time_stamp;
+        return true;
+    }
+    void releaseCustomCamBuffer() { cam_pipe.ReleaseBuffer(0); }
+
+    template <typename T>
+    void setOutputCallback(bool (T::*method)(PipeBuffer &), T *obj) {
+        std::lock_guard<std::mutex> locker(call_mutex);
+        outputFunc = std::bind(method, obj, std::placeholders::_1);
+    }
+    void setOutputCallback(bool (*func)(PipeBuffer &)) {
+        std::lock_guard<std::mutex> locker(call_mutex);
+        if (func) outputFunc = std::bind(func, std::placeholders::_1);
+        else outputFunc = nullptr;
+    }
+    bool isInitOk() const { return InitOK; }
+    const std::string &lastError() const { return last_error; }
+    Matrix3x3 getCam2ImuRot() { return Identity3(); }
+    Vector3 getCam2ImuPos() { return Zeros3(); }
+};
+
+}  // namespace rebvo
+#endif

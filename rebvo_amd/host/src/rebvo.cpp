@@ -1,0 +1,424 @@
+// rebvo.cpp — host runtime behind the rebvo::REBVO surface: config parsing, the custom-camera ring, one
+// tracking thread that drives libedgehip (what FirstThr + SecondThread do in the reference,
+// src/rebvo/rebvo_first_t.cpp:87-337, src/rebvo/rebvo_second_t.cpp:43-636) and the output thread
+// (src/rebvo/rebvo_third_t.cpp:48-410: .m log, TUM trajectory, user callback).
+//
+// Hand-off order mirrors the reference's 4-player ring: a frame's PipeBuffer reaches the output thread only
+// after the NEXT frame has been tracked against it (the reference releases `old_buf` to player 3,
+// rebvo_second_t.cpp:622-623), so the KeyLines a callback sees are the previous edge map after
+// rotate_keylines/FordwardMatch touched it, and the last frame of a run is never delivered.
+
+#include "rebvo/rebvo.h"
+
+#include <chrono>
+#include <cmath>
+#include <fstream>
+#include <iomanip>
+#include <iostream>
+#include <map>
+#include <sstream>
+
+#include "edgehip.h"
+
+namespace rebvo {
+
+// ---- configuration file: "&Section", "name = value", "//" comments (src/UtilLib/configurator.cpp:82-160) --
+namespace {
+
+std::string shrink_ws(const std::string &s) {
+    size_t a = 0, b = s.size();
+    while (a < b && isspace((unsigned char)s[a])) a++;
+    while (b > a && isspace((unsigned char)s[b - 1])) b--;
+    return s.substr(a, b - a);
+}
+
+class Configurator {
+    std::map<std::string, std::map<std::string, std::string>> sections;
+
+public:
+    bool ParseConfigFile(const char *filename) {
+        std::ifstream file(filename);
+        if (!file.is_open()) {
+            std::cout << "\nConfigurator: cannot open the configuration file " << filename << "\n";
+            return false;
+        }
+        std::string s, current;
+        int line = 0;
+        while (std::getline(file, s)) {
+            line++;
+            const size_t c = s.find("//");
+            if (c != std::string::npos) s.resize(c);
+            s = shrink_ws(s);
+            if (s.empty()) continue;
+            if (s[0] == '&') { current = shrink_ws(s.substr(1)); sections[current]; continue; }
+            const size_t pos = s.find('=');
+            if (pos == 0) { std::cout << "Configurator: syntax error line " << line << ", empty name\n"; return false; }
+            if (pos == std::string::npos) { std::cout << "Configurator: syntax error line " << line << ", use name = value\n"; return false; }
+            const std::string name = shrink_ws(s.substr(0, pos));
+            // first definition wins, like the reference's linear search over the parameter list
+            sections[current].emplace(name, s.substr(pos + 1));
+        }
+        return true;
+    }
+    bool raw(const char *sec, const char *name, std::string &out, bool complain) const {
+        auto s = sections.find(sec);
+        if (s == sections.end()) {
+            if (complain) std::cout << "\nConfigurator: error, section " << sec << " not found in the configuration file\n";
+            return false;
+        }
+        auto p = s->second.find(name);
+        if (p == s->second.end()) {
+            if (complain) std::cout << "\nConfigurator: error, parameter " << name << " not found in section " << sec << "\n";
+            return false;
+        }
+        out = p->second;
+        return true;
+    }
+    template <typename T>
+    bool get(const char *sec, const char *name, T &param, bool complain = true) const {
+        std::string v;
+        if (!raw(sec, name, v, complain)) return false;
+        std::istringstream iss(v);
+        iss >> param;   // trailing characters ("100;") are ignored, as with the reference's stream extraction
+        return !iss.fail();
+    }
+    bool get(const char *sec, const char *name, std::string &param, bool complain = true) const {
+        std::string v;
+        if (!raw(sec, name, v, complain)) return false;
+        param = shrink_ws(v);
+        return true;
+    }
+};
+
+double now_s() {
+    return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count();
+}
+
+void fill_hip_params(const REBVOParameters &p, edgehip_params &h) {
+    std::memset(&h, 0, sizeof h);
+    h.w = (int)p.ImageSize.w; h.h = (int)p.ImageSize.h;
+    h.ppx = p.pp_x; h.ppy = p.pp_y; h.zfx = p.z_f_x; h.zfy = p.z_f_y;
+    h.kc[0] = p.kc.Kc2; h.kc[1] = p.kc.Kc4; h.kc[2] = p.kc.Kc6; h.kc[3] = p.kc.P1; h.kc[4] = p.kc.P2;
+    h.sigma0 = p.Sigma0; h.ksigma = p.KSigma;
+    h.plane_fit_size = p.DetectorPlaneFitSize;
+    h.pos_neg_thresh = p.DetectorPosNegThresh; h.dog_thresh = p.DetectorDoGThresh;
+    h.max_points = p.MaxPoints; h.reference_points = p.ReferencePoints; h.track_points = p.TrackPoints;
+    h.detector_thresh = p.DetectorThresh; h.auto_gain = p.DetectorAutoGain;
+    h.max_thresh = p.DetectorMaxThresh; h.min_thresh = p.DetectorMinThresh;
+    h.search_range = (int)p.SearchRange; h.qcut_nbins = (int)p.QCutOffNumBins; h.qcut_quantile = p.QCutOffQuantile;
+    h.tracker_iter_num = p.TrackerIterNum; h.tracker_init_type = p.TrackerInitType;
+    h.tracker_init_iter_num = p.TrackerInitIterNum;
+    h.tracker_match_thresh = p.TrackerMatchThresh; h.match_thresh_module = p.MatchThreshModule;
+    h.match_thresh_angle = p.MatchThreshAngle; h.match_num_thresh = p.MatchNumThresh;
+    h.do_rescaling = p.DoReScaling > 0 ? 1 : 0;
+    h.reweight_distance = p.ReweigthDistance; h.regularize_thresh = p.RegularizeThresh;
+    h.loc_unc_match = p.LocationUncertaintyMatch; h.reshape_q_abs = p.ReshapeQAbsolute;
+    h.reshape_q_rel = p.ReshapeQRelative; h.loc_unc = p.LocationUncertainty;
+    h.global_match_threshold = p.MatchThreshold;
+    h.config_fps = p.config_fps;
+    h.use_undistort = p.useUndistort ? 1 : 0;
+}
+
+// util::LieRot2Quaternion (include/UtilLib/toon_util.h:63-72)
+void lie2quat(const Vector3 &W, double q[4]) {
+    const double angle = std::sqrt(W[0] * W[0] + W[1] * W[1] + W[2] * W[2]);
+    for (int i = 0; i < 3; i++) q[i] = angle > 0 ? W[i] / angle * std::sin(angle / 2) : 0.0;
+    q[3] = std::cos(angle / 2);
+}
+
+}  // namespace
+
+// ---- construction -------------------------------------------------------------------------------------------
+REBVO::REBVO(const char *configFile)
+    : quit(true), pipe(CBUFSIZE, 3), system_reset(false), cam_pipe(CCAMBUFSIZE, 2), outputFunc(nullptr) {
+    Configurator config;
+    if (!(InitOK = config.ParseConfigFile(configFile))) return;
+    REBVOParameters &p = params;
+    // keys that reach this path are mandatory, exactly as in REBVO::REBVO (src/rebvo/rebvo.cpp:57-193)
+    InitOK &= config.get("REBVO", "CameraType", p.CameraType);
+    InitOK &= config.get("Camera", "ImageWidth", p.ImageSize.w);
+    InitOK &= config.get("Camera", "ImageHeight", p.ImageSize.h);
+    InitOK &= config.get("Camera", "ZfX", p.z_f_x);
+    InitOK &= config.get("Camera", "ZfY", p.z_f_y);
+    InitOK &= config.get("Camera", "PPx", p.pp_x);
+    InitOK &= config.get("Camera", "PPy", p.pp_y);
+    InitOK &= config.get("Camera", "KcR2", p.kc.Kc2);
+    InitOK &= config.get("Camera", "KcR4", p.kc.Kc4);
+    InitOK &= config.get("Camera", "KcR6", p.kc.Kc6);
+    InitOK &= config.get("Camera", "KcP1", p.kc.P1);
+    InitOK &= config.get("Camera", "KcP2", p.kc.P2);
+    InitOK &= config.get("Camera", "UseUndistort", p.useUndistort);
+    InitOK &= config.get("Camera", "FPS", p.config_fps);
+    if (!config.get("Camera", "SoftFPS", p.soft_fps, false)) p.soft_fps = p.config_fps;
+    InitOK &= config.get("Detector", "Sigma0", p.Sigma0);
+    InitOK &= config.get("Detector", "KSigma", p.KSigma);
+    InitOK &= config.get("Detector", "ReferencePoints", p.ReferencePoints);
+    InitOK &= config.get("Detector", "MaxPoints", p.MaxPoints);
+    InitOK &= config.get("Detector", "TrackPoints", p.TrackPoints);
+    InitOK &= config.get("Detector", "DetectorThresh", p.DetectorThresh);
+    InitOK &= config.get("Detector", "DetectorAutoGain", p.DetectorAutoGain);
+    InitOK &= config.get("Detector", "DetectorMaxThresh", p.DetectorMaxThresh);
+    InitOK &= config.get("Detector", "DetectorMinThresh", p.DetectorMinThresh);
+    InitOK &= config.get("Detector", "DetectorPlaneFitSize", p.DetectorPlaneFitSize);
+    InitOK &= config.get("Detector", "DetectorPosNegThresh", p.DetectorPosNegThresh);
+    InitOK &= config.get("Detector", "DetectorDoGThresh", p.DetectorDoGThresh);
+    InitOK &= config.get("TrackMaper", "SearchRange", p.SearchRange);
+    InitOK &= config.get("TrackMaper", "QCutOffNumBins", p.QCutOffNumBins);
+    InitOK &= config.get("TrackMaper", "QCutOffQuantile", p.QCutOffQuantile);
+    InitOK &= config.get("TrackMaper", "TrackerIterNum", p.TrackerIterNum);
+    InitOK &= config.get("TrackMaper", "TrackerInitIterNum", p.TrackerInitIterNum);
+    InitOK &= config.get("TrackMaper", "TrackerInitType", p.TrackerInitType);
+    InitOK &= config.get("TrackMaper", "TrackerMatchThresh", p.TrackerMatchThresh);
+    InitOK &= config.get("TrackMaper", "MatchThreshModule", p.MatchThreshModule);
+    InitOK &= config.get("TrackMaper", "MatchThreshAngle", p.MatchThreshAngle);
+    InitOK &= config.get("TrackMaper", "MatchNumThresh", p.MatchNumThresh);
+    InitOK &= config.get("TrackMaper", "RegularizeThresh", p.RegularizeThresh);
+    InitOK &= config.get("TrackMaper", "ReweigthDistance", p.ReweigthDistance);
+    InitOK &= config.get("TrackMaper", "ReshapeQAbsolute", p.ReshapeQAbsolute);
+    InitOK &= config.get("TrackMaper", "ReshapeQRelative", p.ReshapeQRelative);
+    InitOK &= config.get("TrackMaper", "LocationUncertainty", p.LocationUncertainty);
+    InitOK &= config.get("TrackMaper", "LocationUncertaintyMatch", p.LocationUncertaintyMatch);
+    InitOK &= config.get("TrackMaper", "DoReScaling", p.DoReScaling);
+    InitOK &= config.get("TrackMaper", "GlobalMatchThreshold", p.MatchThreshold);
+    InitOK &= config.get("REBVO", "SaveLog", p.SaveLog);
+    InitOK &= config.get("REBVO", "LogFile", p.LogFile);
+    InitOK &= config.get("REBVO", "TrayFile", p.TrayFile);
+    InitOK &= config.get("IMU", "ImuMode", p.ImuMode);
+    if (p.ImuMode == 2) config.get("IMU", "TimeScale", p.ImuTimeScale, false);
+    // accepted and ignored (subsystems that do not exist on this path)
+    config.get("Camera", "Rotate180", p.rotatedCam, false);
+    config.get("REBVO", "VideoNetEnabled", p.VideoNetEnabled, false);
+    config.get("REBVO", "TrackKeyFrames", p.TrackKeyFrames, false);
+    config.get("REBVO", "StereoAvaiable", p.StereoAvaiable, false);
+    config.get("GPU", "Device", p.GpuDevice, false);
+    construct();
+}
+
+REBVO::REBVO(const REBVOParameters &parameters)
+    : params(parameters), quit(true), pipe(CBUFSIZE, 3), system_reset(false), cam_pipe(CCAMBUFSIZE, 2), outputFunc(nullptr) {
+    construct();
+}
+
+void REBVO::construct() {
+    if (!InitOK) return;
+    cam = cam_model({params.pp_x, params.pp_y}, {params.z_f_x, params.z_f_y}, params.kc, params.ImageSize);
+    if (params.ImageSize.w == 0 || params.ImageSize.h == 0) { InitOK = false; return; }
+    for (unsigned i = 0; i < cam_pipe.Size(); i++)   // rebvo.cpp:284-285
+        cam_pipe[i].img = std::make_shared<Image<RGB24Pixel>>(params.ImageSize);
+    for (PipeBuffer &pbuf : pipe) {                  // rebvo.cpp:297-312 (host views only; the rest lives in HBM)
+        pbuf.ef = new edge_tracker(cam, params.MaxPoints > 0 ? params.MaxPoints : 1);
+        pbuf.img = new Image<float>(params.ImageSize);
+        pbuf.imgc = new Image<RGB24Pixel>(params.ImageSize);
+        pbuf.ss = nullptr;
+        pbuf.gt = nullptr;
+    }
+}
+
+REBVO::~REBVO() {
+    if (!quit) CleanUp();
+    if (InitOK)
+        for (PipeBuffer &pbuf : pipe) {
+            delete pbuf.ef;
+            delete pbuf.img;
+            delete pbuf.imgc;
+        }
+}
+
+bool REBVO::Init() {
+    if (!InitOK) return false;
+    if (!quit) return true;
+    if (params.CameraType != 3) {
+        last_error = "REBVO(hip): only CameraType=3 (custom camera) is available; feed frames with requestCustomCamBuffer()";
+        std::cout << last_error << "\n";
+        return false;
+    }
+    if (params.ImuMode != 0) {
+        last_error = "REBVO(hip): ImuMode must be 0 (the IMU branch Minimizer_V/ExtRotVel is not built yet)";
+        std::cout << last_error << "\n";
+        return false;
+    }
+    edgehip_params hp;
+    fill_hip_params(params, hp);
+    const int rc = edgehip_create(&hp, 1, 3, params.GpuDevice, &hip);
+    if (rc != 0) {   // no CPU fallback: fail loudly
+        last_error = std::string("REBVO(hip): edgehip_create failed: ") + edgehip_last_error();
+        std::cout << last_error << "\n";
+        hip = nullptr;
+        return false;
+    }
+    quit = false;
+    Thr0 = std::thread(TrackThread, this);
+    return true;
+}
+
+bool REBVO::CleanUp() {
+    quit = true;
+    if (Thr0.joinable()) Thr0.join();
+    if (hip) { edgehip_destroy(hip); hip = nullptr; }
+    return true;
+}
+
+// ---- tracking thread ----------------------------------------------------------------------------------------
+static void fill_nav(const edgehip_nav &n, NavData &nav) {
+    nav.t = n.t; nav.dt = n.dt; nav.scale = 1;
+    for (int i = 0; i < 3; i++) {
+        nav.RotLie[i] = n.RotLie[i]; nav.Vel[i] = n.Vel[i]; nav.PoseLie[i] = n.PoseLie[i]; nav.Pos[i] = n.Pos[i];
+        nav.RotGiro[i] = 0; nav.g[i] = 0;
+        for (int j = 0; j < 3; j++) { nav.Rot(i, j) = n.Rot[i * 3 + j]; nav.Pose(i, j) = n.Pose[i * 3 + j]; }
+    }
+}
+
+void REBVO::TrackThread(REBVO *cf) {
+    std::thread Thr2(ThirdThread, cf);
+    const size_t frame_bytes = (size_t)cf->params.ImageSize.w * cf->params.ImageSize.h * 3;
+    static_assert(sizeof(KeyLine) == sizeof(edgehip_keyline), "KeyLine mirrors edgehip_keyline");
+    double t0 = 0;
+    const double min_frame_dt = 1.0 / cf->params.soft_fps - 0.5 / cf->params.config_fps;   // rebvo_first_t.cpp:146
+    PipeBuffer *old_buf = nullptr;   // previous frame: held (player 1) until the next frame has been tracked
+    int p_num = 0;
+    bool failed = false;
+    while (!cf->quit && !failed) {
+        PipeBuffer &new_buf = cf->pipe.RequestBuffer(0);
+        // ---- grab (customCam::GrabBuffer, src/VideoLib/customcam.cpp:56-68: 1 ms time-out, retry) ----
+        customCam::CustomCamPipeBuffer *cbuf = nullptr;
+        double t = 0;
+        while (true) {
+            while ((cbuf = cf->cam_pipe.RequestBufferTimeoutable(1, 0.001)) == nullptr)
+                if (cf->quit) break;
+            if (!cbuf) break;
+            t = cbuf->timestamp;
+            p_num++;
+            if (t - t0 < min_frame_dt) { cf->cam_pipe.ReleaseBuffer(1); continue; }   // soft-FPS drop (t0 starts at 0), :89, :172-177
+            break;
+        }
+        if (!cbuf) {   // quitting: pass the flag down the ring (rebvo_first_t.cpp:165-170)
+            new_buf.quit = true;
+            cf->pipe.ReleaseBuffer(0);
+            break;
+        }
+        const double tp0 = now_s();
+        const int slot = edgehip_next_slot(cf->hip);
+        int rc = edgehip_upload_rgb(cf->hip, slot, reinterpret_cast<const uint8_t *>(cbuf->img->Data()), 0, 1);
+        std::memcpy(new_buf.imgc->Data(), cbuf->img->Data(), frame_bytes);
+        cf->cam_pipe.ReleaseBuffer(1);
+        t0 = t;
+        // ---- the whole frame on the GPU: stage A + (from the second frame on) tracking and mapping ----
+        if (rc == 0) rc = edgehip_process_frame(cf->hip, &t);
+        edgehip_nav n;
+        if (rc == 0) rc = edgehip_read_nav(cf->hip, &n);
+        if (rc != 0) {
+            std::cout << "REBVO(hip): " << edgehip_last_error() << "\n";
+            failed = true;
+            new_buf.quit = true;
+            cf->pipe.ReleaseBuffer(0);
+            break;
+        }
+        const double tp1 = now_s();
+        new_buf.t = t;
+        new_buf.dt = n.dt;
+        new_buf.p_id = p_num - 1;
+        new_buf.quit = false;
+        new_buf.dtp0 = 0;
+        new_buf.dtp1 = tp1 - tp0;
+        new_buf.K = 1; new_buf.Kp = n.Kp; new_buf.RKp = n.RKp;
+        new_buf.s_rho_p = n.s_rho_q;
+        new_buf.EstimationOK = n.estimation_ok != 0;
+        new_buf.ef->nmatch = n.klm_num;
+        new_buf.ef->reTunedThresh = n.retuned_thresh;
+        if (old_buf) {
+            fill_nav(n, new_buf.nav);
+            cf->pushNav(new_buf.nav);
+        } else {
+            new_buf.nav = NavData();   // first frame: "dummy processing", no estimate (rebvo_second_t.cpp:108-121)
+        }
+        // ---- hand the PREVIOUS frame to the output thread, with its edge map as the tracker left it ----
+        if (old_buf) {
+            const bool want = cf->haveCallBack();
+            if (want) {
+                const int so = (slot + 2) % 3;   // ring of 3: the slot before `slot`
+                int32_t kn = 0;
+                rc = edgehip_download_keylines(cf->hip, 0, so, reinterpret_cast<edgehip_keyline *>(old_buf->ef->kl.data()), nullptr, &kn);
+                old_buf->ef->kn = rc == 0 ? kn : 0;
+                // Image<float>::ConvertRGB2BW (include/VideoLib/image.h:197-203)
+                const RGB24Pixel *c = old_buf->imgc->Data();
+                float *bw = old_buf->img->Data();
+                for (uint i = 0; i < old_buf->img->bSize(); i++) bw[i] = (float)(c[i].pix.r + c[i].pix.g + c[i].pix.b);
+            } else {
+                old_buf->ef->kn = 0;
+            }
+            cf->pipe.ReleaseBuffer(1);
+        }
+        if (cf->system_reset) {   // rebvo_second_t.cpp:609-620
+            edgehip_depth_reset(cf->hip, -1);
+            cf->system_reset = false;
+        }
+        // new_buf becomes old_buf: player 1 takes the slot player 0 releases now
+        cf->pipe.ReleaseBuffer(0);
+        old_buf = &cf->pipe.RequestBuffer(1);
+    }
+    // shutdown: the frame still held as old_buf is not delivered (as in the reference); pass the quit flag on
+    if (old_buf) {
+        old_buf->quit = true;
+        cf->pipe.ReleaseBuffer(1);
+    } else {
+        PipeBuffer &b = cf->pipe.RequestBuffer(1);
+        b.quit = true;
+        cf->pipe.ReleaseBuffer(1);
+    }
+    cf->quit = true;
+    Thr2.join();
+}
+
+// ---- output thread (src/rebvo/rebvo_third_t.cpp:172-347) -------------------------------------------------------
+void REBVO::ThirdThread(REBVO *cf) {
+    std::ofstream a_log, t_log;
+    if (cf->params.SaveLog) {
+        a_log.open(cf->params.LogFile.c_str());
+        t_log.open(cf->params.TrayFile.c_str());
+        if (!a_log.is_open() || !t_log.is_open()) {
+            std::cout << "REBVO: Cannot open log files\n";
+            cf->quit = true;
+        }
+    }
+    int a_log_inx = 0;
+    double t_proc_last = 0;
+    while (true) {
+        PipeBuffer pbuf = cf->pipe.RequestBuffer(2);   // struct copy; pointers alias the ring slot (:174)
+        if (pbuf.quit) { cf->pipe.ReleaseBuffer(2); break; }
+        const double ts = now_s();
+        if (cf->params.SaveLog) {
+            a_log_inx++;
+            const NavData &nv = pbuf.nav;
+            a_log << "Kp_cv(" << a_log_inx << ",:)=" << pbuf.Kp << ";\n";
+            a_log << "RKp_cv(" << a_log_inx << ",:)=" << pbuf.RKp << ";\n";
+            a_log << "Rot_cv(" << a_log_inx << ",:,:)=[" << nv.Rot(0, 0) << "," << nv.Rot(0, 1) << "," << nv.Rot(0, 2) << ";"
+                  << nv.Rot(1, 0) << "," << nv.Rot(1, 1) << "," << nv.Rot(1, 2) << ";" << nv.Rot(2, 0) << "," << nv.Rot(2, 1) << ","
+                  << nv.Rot(2, 2) << "];\n";
+            a_log << "Vel_cv(" << a_log_inx << ",:)=[" << nv.Vel[0] << "," << nv.Vel[1] << "," << nv.Vel[2] << "];\n";
+            a_log << "t_cv(" << a_log_inx << ",:)=" << pbuf.t << ";\n";
+            a_log << "dt_cv(" << a_log_inx << ",:)=" << pbuf.dt << ";\n";
+            a_log << "i_cv(" << a_log_inx << ",:)=" << pbuf.p_id << ";\n";
+            a_log << "Pose_cv(" << a_log_inx << ",:,:)=[" << nv.Pose(0, 0) << "," << nv.Pose(0, 1) << "," << nv.Pose(0, 2) << ";"
+                  << nv.Pose(1, 0) << "," << nv.Pose(1, 1) << "," << nv.Pose(1, 2) << ";" << nv.Pose(2, 0) << "," << nv.Pose(2, 1)
+                  << "," << nv.Pose(2, 2) << "];\n";
+            a_log << "Pos_cv(" << a_log_inx << ",:)=[" << nv.Pos[0] << "," << nv.Pos[1] << "," << nv.Pos[2] << "];\n";
+            a_log << "K_cv(" << a_log_inx << ",:)=" << pbuf.K << ";\n";
+            a_log << "KLN_cv(" << a_log_inx << ",:)=" << pbuf.ef->KNum() << ";\n";
+            a_log << "TProc0_cv(" << a_log_inx << ",:)=" << pbuf.dtp0 << ";\n";
+            a_log << "TProc1_cv(" << a_log_inx << ",:)=" << pbuf.dtp1 << ";\n";
+            a_log << "TProc2_cv(" << a_log_inx << ",:)=" << t_proc_last << ";\n";
+            // trajectory in TUM format: t pos quat (:311)
+            double q[4];
+            lie2quat(nv.PoseLie, q);
+            t_log << std::scientific << std::setprecision(18) << pbuf.t / cf->params.ImuTimeScale << " " << nv.Pos[0] << " "
+                  << nv.Pos[1] << " " << nv.Pos[2] << " " << q[0] << " " << q[1] << " " << q[2] << " " << q[3] << "\n";
+        }
+        cf->callCallBack(pbuf);   // :329, under call_mutex
+        t_proc_last = now_s() - ts;
+        cf->pipe.ReleaseBuffer(2);
+    }
+    if (a_log.is_open()) a_log.close();
+    if (t_log.is_open()) t_log.close();
+}
+
+}  // namespace rebvo

@@ -1,0 +1,54 @@
+"""CPU-only checks of the C++ host mirror of rebvo::REBVO (rebvo_amd/host): it builds, loads, parses the
+reference's GlobalConfig format with the reference's error behaviour (missing mandatory key -> isInitOk()
+false), and Init() fails loudly without a GPU (no CPU fallback)."""
+import os
+import subprocess
+
+import pytest
+
+from rebvo_amd import edgehip
+from tests.conftest import HAVE_GPU
+from tests.helpers import write_global_config
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+EXE = os.path.join(ROOT, "rebvo_amd", "lib", "custom_cam_replay")
+
+
+def _run(*args):
+    return subprocess.run([EXE, *map(str, args)], capture_output=True, text=True, timeout=120)
+
+
+@pytest.fixture(scope="module")
+def exe():
+    if not os.path.exists(EXE):
+        pytest.skip("rebvo_amd/lib/custom_cam_replay not built (make -C rebvo_amd/host)")
+    return EXE
+
+
+def test_missing_mandatory_key_sets_initok_false(exe, tmp_path):
+    cfg = tmp_path / "cfg"
+    write_global_config(cfg, edgehip.euroc_params(376, 240), drop=("Detector/TrackPoints",))
+    r = _run(cfg, "/dev/null", 0, 1.0, 0.05)
+    assert r.returncode == 3 and "TrackPoints" in r.stdout
+
+
+def test_syntax_error_and_missing_file(exe, tmp_path):
+    bad = tmp_path / "bad"
+    bad.write_text("&Camera\n  ImageWidth 376\n")
+    assert _run(bad, "/dev/null", 0, 1.0, 0.05).returncode == 3
+    assert _run(tmp_path / "nope", "/dev/null", 0, 1.0, 0.05).returncode == 3
+
+
+def test_unsupported_camera_type_refused(exe, tmp_path):
+    cfg = tmp_path / "cfg"
+    write_global_config(cfg, edgehip.euroc_params(376, 240), camera_type=2)
+    r = _run(cfg, "/dev/null", 0, 1.0, 0.05)
+    assert r.returncode == 4 and "CameraType=3" in r.stdout
+
+
+@pytest.mark.skipif(HAVE_GPU, reason="checks the no-GPU failure mode")
+def test_init_fails_loudly_without_gpu(exe, tmp_path):
+    cfg = tmp_path / "cfg"
+    write_global_config(cfg, edgehip.euroc_params(376, 240))
+    r = _run(cfg, "/dev/null", 0, 1.0, 0.05)
+    assert r.returncode == 4 and "edgehip_create failed" in r.stdout

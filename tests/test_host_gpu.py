@@ -1,0 +1,63 @@
+"""GPU: the C++ rebvo::REBVO mirror end to end — frames enter through requestCustomCamBuffer, results leave
+through the output callback and the TUM trajectory file — against the reference oracle on the same frames.
+
+Delivery rule mirrored from the reference's 4-player ring (rebvo_second_t.cpp:622-623): frame j reaches the
+callback after frame j+1 was tracked, carrying its own nav record and its edge map as the tracker left it
+(rotated by frame j+1's estimate); the last frame is never delivered."""
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+from rebvo_amd import edgehip, synth
+from tests.helpers import write_global_config
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+EXE = os.path.join(ROOT, "rebvo_amd", "lib", "custom_cam_replay")
+
+
+def test_custom_cam_replay_matches_reference(tmp_path):
+    from oracle import oracle
+    if not oracle.available("ref"):
+        pytest.skip("oracle/_ref not built")
+    if not os.path.exists(EXE):
+        pytest.skip("custom_cam_replay not built")
+    w, h, n, t0, dt = 376, 240, 9, 1.0, 0.05
+    frames = [f for f, _, _ in synth.billboard_sequence(w, h, n)]
+    np.stack(frames).tofile(tmp_path / "frames.rgb24")
+    cfg, dump, tray = tmp_path / "cfg", tmp_path / "dump.txt", tmp_path / "tray.txt"
+    write_global_config(cfg, edgehip.euroc_params(w, h), log_file=str(tmp_path / "log.m"), tray_file=str(tray), save_log=1)
+    r = subprocess.run([EXE, str(cfg), str(tmp_path / "frames.rgb24"), str(n), str(t0), str(dt), str(dump)],
+                       capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stdout + r.stderr
+    rows = np.loadtxt(dump, ndmin=2)
+    assert len(rows) == n - 1, r.stdout                    # the last frame is never delivered
+    orc = oracle.Oracle("ref", oracle.euroc_params(w, h))
+    navs = []
+    path = 0.0
+    for k, f in enumerate(frames):
+        _, nav = orc.process_frame(f, t0 + dt * k)
+        navs.append(nav)
+        if k == 0:
+            continue
+        j = k - 1                                          # frame delivered once frame k has been tracked
+        row = rows[j]
+        assert int(row[0]) == j and abs(row[1] - (t0 + dt * j)) < 1e-12
+        kl = orc.keylines(j % 8)                           # old slot, after rotate_keylines/FordwardMatch of frame k
+        assert int(row[2]) == len(kl)
+        if j > 0:
+            assert int(row[4]) == navs[j].estimation_ok
+            path += np.linalg.norm(navs[j].V[:])
+            assert np.allclose(row[5:8], navs[j].Pos[:], atol=1e-6 * path + 1e-9)
+            assert np.allclose(row[8:11], navs[j].PoseLie[:], atol=1e-7)
+            assert np.allclose(row[11:14], navs[j].Vel[:], rtol=1e-5, atol=1e-9)
+        assert abs(row[14] - kl["rho"].sum()) <= 1e-6 * abs(kl["rho"].sum()) + 1e-9
+        assert abs(row[15] - kl["s_rho"].sum()) <= 1e-6 * abs(kl["s_rho"].sum()) + 1e-9
+    # TUM trajectory: one line per delivered frame: t x y z qx qy qz qw
+    tr = np.loadtxt(tray, ndmin=2)
+    assert tr.shape == (n - 1, 8)
+    assert np.allclose(tr[:, 0], t0 + dt * np.arange(n - 1))
+    assert np.allclose(np.linalg.norm(tr[:, 4:8], axis=1), 1.0)
+    assert np.allclose(tr[-1, 1:4], navs[n - 2].Pos[:], atol=1e-6 * path + 1e-9)
