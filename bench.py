@@ -25,6 +25,7 @@ import argparse
 import ctypes
 import json
 import os
+import re
 import sys
 import time
 
@@ -68,6 +69,47 @@ def algorithmic_bytes(group, kn, n_px, radius, nseq):
         "C.pose": 0,
     }
     return per_seq.get(group, 0) * nseq
+
+
+# kernel names (substrings of the rocprofv3 kernel name) behind each HIP-event group
+GROUP_KERNELS = {
+    "A.rgb_rowscan": ["k_rgb_rowscan"], "A.colscan": ["k_colscan"], "A.avg_rowscan": ["k_avg_rowscan"],
+    "A.detect": ["k_detect"], "A.compact": ["k_strip_scan", "k_emit"], "A.join_retune": ["k_join_histo", "k_retune"],
+    "A.level": ["k_level"],
+    "B.quantile": ["k_quantile"], "B.build_field": ["k_field_bin", "k_field_raster"], "B.tvr_prepare": ["k_tvr_prepare"],
+    "B.try_velrot": ["k_try_velrot"], "B.lm_step": ["k_lm_step"], "B.minimizer": ["k_minimizer"],
+    "C.forward_match": ["k_fwd_key", "k_fwd_win", "k_fwd_apply"], "C.rotate": ["k_rot_from_state", "k_rotate"],
+    "C.directed_matching": ["k_directed"], "C.regularize_ekf": ["k_regularize", "k_ekf"], "C.rescale": ["k_rescale"],
+}
+
+
+def pmc_traffic(group, nseq):
+    """HBM bytes per launch of `group` from the committed rocprofv3 PMC passes (profiles/pmc_latest.json, made by
+    tools/gpu_round.sh: separate `--pmc FETCH_SIZE` and `--pmc WRITE_SIZE` runs of this same command).
+    FETCH_SIZE/WRITE_SIZE are KiB; FETCH_SIZE is doubled (gfx950 note in MI355X_MICROARCH.md).  None when the
+    file is missing, was taken at another batch size, or lacks the kernel."""
+    path = os.path.join(ROOT, "profiles", "pmc_latest.json")
+    if not os.path.exists(path):
+        return None
+    js = json.load(open(path))
+    if js.get("_nseq") != nseq:
+        return None
+    total, found = 0.0, False
+    for sub in GROUP_KERNELS.get(group, []):
+        # template instantiations of one kernel (e.g. k_try_velrot<true,true>) are averaged by call count
+        f = w = n = 0.0
+        for name, c in js.items():
+            if not isinstance(c, dict) or not re.search(r"\b" + sub + r"\b", name):
+                continue
+            if "FETCH_SIZE" in c and "WRITE_SIZE" in c:
+                k = c["FETCH_SIZE"]["calls"]
+                f += c["FETCH_SIZE"]["mean"] * k
+                w += c["WRITE_SIZE"]["mean"] * k
+                n += k
+        if n:
+            total += (2.0 * f / n + w / n) * 1024.0
+            found = True
+    return int(total) if found else None
 
 
 def main():
@@ -180,7 +222,7 @@ def main():
         abytes = algorithmic_bytes(dominant, kn_mean, W * H, 40, B)
         ach = abytes / per_launch_s / 1e9 if per_launch_s > 0 else 0.0
         roof = {"bound": "hbm", "kernel": dominant, "achieved": round(ach, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                "frac": round(ach / HBM_PEAK_GBS, 5), "traffic": None,
+                "frac": round(ach / HBM_PEAK_GBS, 5), "traffic": pmc_traffic(dominant, B),
                 "launch_us": round(per_launch_s * 1e6, 2), "algorithmic_bytes_per_launch": int(abytes),
                 "launches_timed": dom_calls}
     # whole-frame algorithmic bytes, SURVEY.md §8(d) formulas with the measured kn and evaluation count

@@ -34,9 +34,21 @@ for C in FETCH_SIZE WRITE_SIZE; do
       python "$GRAFT_REPO_ROOT/bench.py" $BENCH_ARGS --steps 6 --warmup 12 --cpu-frames 0 --no-roofline-events \
       > "$OUT/pmc_$C.json" 2> "$OUT/pmc_$C.err" )
   echo "pmc $C exit $?"
-  python tools/pmc_summary.py "$OUT/pmc_$C" "$OUT/pmc_$C.txt" > /dev/null
+  python tools/pmc_summary.py "$OUT/pmc_$C" "$OUT/pmc_$C.txt" "$OUT/pmc.json" > /dev/null
   find "$OUT/pmc_$C" -name '*.csv' -size +5M -delete
 done
+# stamp the batch size the counters were taken at (bench.py only uses them at the same --nseq)
+python - "$OUT/pmc.json" <<'PY'
+import json, re, sys
+p = sys.argv[1]
+try:
+    js = json.load(open(p))
+    line = open(p.replace("pmc.json", "pmc_FETCH_SIZE.json")).read()
+    js["_nseq"] = json.loads(line[line.index("{"):])["config"]["sequences_per_gpu"]
+    json.dump(js, open(p, "w"), indent=0, sort_keys=True)
+except Exception as e:
+    print("pmc.json not stamped:", e)
+PY
 # raw traces are large; keep only the summaries
 find "$OUT" -name '*.db' -size +20M -delete
 du -sh "$OUT"

@@ -36,6 +36,15 @@ def main():
     print(out)
     if len(sys.argv) > 2:
         open(sys.argv[2], "w").write(out + "\n")
+    if len(sys.argv) > 3:   # machine-readable: {kernel: {counter: {"calls": n, "mean": m}}}, merged into an existing file
+        import json
+        js = {}
+        if os.path.exists(sys.argv[3]):
+            js = json.load(open(sys.argv[3]))
+        for k in acc:
+            for c, (n, s) in acc[k].items():
+                js.setdefault(k, {})[c] = {"calls": n, "mean": s / n}
+        json.dump(js, open(sys.argv[3], "w"), indent=0, sort_keys=True)
 
 
 if __name__ == "__main__":
