@@ -24,7 +24,8 @@ int hip_fail(hipError_t e, const char *what, const char *file, int line) {
 static const char *kProfNames[PROF_COUNT] = {
     "A.rgb_rowscan", "A.colscan", "A.avg_rowscan", "A.detect", "A.compact", "A.join_retune",
     "B.quantile", "B.build_field", "B.tvr_prepare", "B.try_velrot", "B.lm_step",
-    "C.forward_match", "C.rotate", "C.directed_matching", "C.regularize_ekf", "C.rescale", "C.pose"};
+    "C.forward_match", "C.rotate", "C.directed_matching", "C.regularize_ekf", "C.rescale", "C.pose",
+    "A.level", "B.minimizer"};
 
 ProfScope::ProfScope(edgehip_ctx *ctx, int pid) : c(ctx), id(pid) {
     Profiler *p = c->prof;
@@ -279,7 +280,7 @@ int edgehip_create(const edgehip_params *params, int nseq, int nslots, int devic
     const size_t B = nseq, S = nslots, N = pl.n, CAP = pl.cap;
     int e;
 #define EH_TRY(x) if ((e = (x)) != 0) return e
-    EH_TRY(dmalloc(c, &c->rgb, S * B * N * 3, al->dev, 0));
+    EH_TRY(dmalloc(c, &c->rgb, S * B * N * 3 + 16, al->dev, 0));   // + slack: k_level reads pixels as aligned 8-byte words
     EH_TRY(dmalloc(c, &c->ii, 4 * B * N, al->dev, 0));
     c->planes = nullptr;
     if (p.debug_planes) EH_TRY(dmalloc(c, &c->planes, 5 * B * N, al->dev, 0));
@@ -331,6 +332,7 @@ int edgehip_create(const edgehip_params *params, int nseq, int nslots, int devic
     }
     c->field_radius = p.search_range;
     c->field_mode = getenv("EDGEHIP_FIELD_MODE") ? atoi(getenv("EDGEHIP_FIELD_MODE")) : 0;
+    c->level_mode = getenv("EDGEHIP_LEVEL_MODE") ? atoi(getenv("EDGEHIP_LEVEL_MODE")) : 0;
     EH_TRY(dmalloc(c, &c->fwd_key, B * CAP, al->dev, 0));
     EH_TRY(dmalloc(c, &c->fwd_win, B * CAP, al->dev, 0xFF));
     EH_TRY(dmalloc(c, &c->rs_tmp, B * 2 * CAP, al->dev, 0));

@@ -123,6 +123,7 @@ struct edgehip_ctx {
     double *block_last;    // [B][nblk_tvr] last valid residual of each block of the running evaluation
     int field_radius;      // radius of the last build_field (global_tracker::max_r)
     int field_mode;        // 0 = binned tiles (default), 1 = global-atomic scatter, 2 = mask-scan tiles (A/B)
+    int level_mode;        // stage A box levels: 0 = auto (one-pass k_level when >= 192 planes in flight), 1 = multi-pass, 2 = k_level
     int32_t *bin_cnt;      // [B][256] KeyLines binned per field tile
     int32_t *bins;         // [B][256][CAP] KeyLine ids per field tile (allocated for the tiles in use)
     int nblk_tvr;
@@ -168,6 +169,7 @@ enum ProfId {
     PROF_A_ROWSCAN = 0, PROF_A_COLSCAN, PROF_A_AVGROW, PROF_A_DETECT, PROF_A_COMPACT, PROF_A_JOIN,
     PROF_B_QUANTILE, PROF_B_FIELD, PROF_B_PREP, PROF_B_TRYVELROT, PROF_B_LMSTEP,
     PROF_C_FORWARD, PROF_C_ROTATE, PROF_C_DIRECTED, PROF_C_REGEKF, PROF_C_RESCALE, PROF_C_POSE,
+    PROF_A_LEVEL, PROF_B_MINIMIZER,
     PROF_COUNT
 };
 struct Profiler {

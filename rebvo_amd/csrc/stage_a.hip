@@ -282,6 +282,266 @@ __global__ __launch_bounds__(NT) void k_avg_rowscan(AvgJob job, const float *__r
 }
 
 // ---------------------------------------------------------------------------------------------------
+// k_level: one level of the box chain for a whole plane in ONE pass — source values (grey of the RGB frame,
+// or the box average of the previous integral image), serial row prefix, serial column prefix — written once.
+// Replaces k_rgb_rowscan / k_avg_rowscan + k_colscan when enough planes are in flight to fill the GPU
+// (one workgroup per (sequence, plane); HBM traffic per level drops from 16N to 8N bytes per plane).
+//
+// The float32 rounding order is the reference's: along a row img(x,y) = img(x-1,y) + l(x,y) strictly left to
+// right, then down a column img(x,y) += img(x,y-1) strictly top to bottom (iimage.cpp:56-67).  A block walks
+// the plane in batches of LV_RB rows through two LDS buffers:
+//     waves 1..12   thread <-> column: produce the batch's source values (coalesced), later add the scanned
+//                   batch onto the running column sums held in registers and store the rows (coalesced)
+//     wave 0        lane <-> row: serial left-to-right prefix of the batch's rows in LDS (float4 steps; the row
+//                   stride WP has WP/4 odd, so the 16 lanes hit 16 disjoint bank quads)
+// and the phases are software-pipelined: scan(k+1) runs while the column threads finish batch k and produce
+// batch k+2 — one barrier per batch.
+// ---------------------------------------------------------------------------------------------------
+constexpr int LV_RB = 16;                 // rows per batch
+constexpr int LV_NT = 832;                // 13 waves
+constexpr int LV_NC = LV_NT - 64;         // column-owner threads
+constexpr int LV_MAXCOL = 2;              // max columns per owner thread (w <= 1536); template parameter MC picks 1 or 2
+
+__host__ __device__ inline int level_row_stride(int w) {
+    int wp = (w + 3) & ~3;
+    if (((wp >> 2) & 1) == 0) wp += 4;
+    return wp;
+}
+
+struct LevelJob {
+    const float *src[2];
+    float *dst[2];
+    int d[2];
+    float a[2];
+};
+
+// Workgroup barrier that orders LDS traffic only.  __syncthreads() also drains vmcnt, i.e. waits for every
+// outstanding global load AND store of the wave; in k_level the threads exchange data through LDS alone, and
+// letting the global prefetches / row stores stay in flight across the barrier is the whole point.
+__device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+
+template <int SRC, int MC>   // SRC 0: box average of job.src; 1: grey of the RGB24 frame; 2: grey of the undistorted frame
+__global__ __launch_bounds__(LV_NT) void k_level(LevelJob job, const uint8_t *__restrict__ rgb,
+                                                 const int32_t *__restrict__ und_base, const uint4 *__restrict__ und_iw,
+                                                 const float *__restrict__ lut, int w, int h, size_t n, int ablate) {
+    extern __shared__ __attribute__((aligned(16))) float s_T[];   // [2][LV_RB][WP]
+    const int WP = level_row_stride(w);
+    const int seq = blockIdx.z, jb = blockIdx.x;
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    const float *src = SRC == 0 ? job.src[jb] + (size_t)seq * n : nullptr;
+    float *dst = job.dst[jb] + (size_t)seq * n;
+    const uint8_t *frame = SRC != 0 ? rgb + (size_t)seq * n * 3 : nullptr;
+    const int d = job.d[jb], d2 = d / 2;
+    const float a_int = job.a[jb];
+    const int nb = (h + LV_RB - 1) / LV_RB;
+    const int ct = tid - 64;              // column-owner index (waves 1..12)
+    float *s_lut = s_T + (size_t)2 * LV_RB * WP + 32;   // [kDivLutMax] reciprocal-count table (after the scan's tail pad)
+    if (SRC == 0 && tid < kDivLutMax) s_lut[tid] = lut[tid];
+    float run[MC];                        // running column sums of the owned columns
+#pragma unroll
+    for (int j = 0; j < MC; j++) run[j] = 0.f;
+
+    // Source values of a batch are produced in two steps so that the global-load latency of batch k+1 hides
+    // behind the column work and the barrier of batch k: issue(k) starts the loads into registers, commit(k)
+    // (one iteration later) turns them into the batch's LDS rows.
+    //   SRC 0: 4 integral-image taps per pixel, iimage::average with the column geometry hoisted out of the
+    //          row loop (which taps exist and the box width along x depend on the column only; the clipped rows
+    //          and the box height on the wave-uniform row).
+    //   SRC 1: the 3 bytes of the RGB pixel.     SRC 2: undistorted on the fly at commit time (no prefetch).
+    float tp[MC][LV_RB][4];
+    auto issue = [&](int k) {
+        if ((ablate & 2) || SRC == 2) return;
+        const int y0 = k * LV_RB;
+#pragma unroll
+        for (int j = 0; j < MC; j++) {
+            const int x = ct + j * LV_NC;
+            if (x >= w) break;
+            if constexpr (SRC == 0) {
+                const int xl = x - d2 - 1;
+                const int xlc = xl >= 0 ? xl : 0;
+                const int xr = x + d2 > w - 1 ? w - 1 : x + d2;
+#pragma unroll
+                for (int r = 0; r < LV_RB; r++) {
+                    int y = y0 + r;
+                    y = y < h ? y : h - 1;                           // rows past the image: harmless duplicates
+                    const int yb = y + d2 > h - 1 ? h - 1 : y + d2;
+                    const int yt = y - d2 - 1;
+                    const float *rowb = src + (size_t)yb * w;
+                    const float *rowt = src + (size_t)(yt < 0 ? 0 : yt) * w;
+                    tp[j][r][0] = rowb[xr];
+                    tp[j][r][1] = rowb[xlc];
+                    tp[j][r][2] = rowt[xr];
+                    tp[j][r][3] = rowt[xlc];
+                }
+            } else {
+#pragma unroll
+                for (int r = 0; r < LV_RB; r++) {
+                    int y = y0 + r;
+                    y = y < h ? y : h - 1;
+                    // the pixel's 3 bytes sit inside the 8 bytes that start at its dword-aligned address: one
+                    // 64-bit load per pixel instead of three byte loads (the rgb allocation has 16 B of slack)
+                    const size_t byte0 = ((size_t)y * w + x) * 3;
+                    const uint2 q = *reinterpret_cast<const uint2 *>(frame + (byte0 & ~(size_t)3));
+                    tp[j][r][0] = __uint_as_float(q.x);
+                    tp[j][r][1] = __uint_as_float(q.y);
+                }
+            }
+        }
+    };
+    auto commit = [&](int k) {
+        if (ablate & 2) return;
+        float *T = s_T + (size_t)(k & 1) * LV_RB * WP;
+        const int y0 = k * LV_RB;
+#pragma unroll
+        for (int j = 0; j < MC; j++) {
+            const int x = ct + j * LV_NC;
+            if (x >= w) break;
+            if (SRC == 0) {
+                const bool hasL = x - d2 - 1 >= 0;
+                int cx = d;
+                if (!hasL) cx = x + d2 + 1;
+                if (x + d2 > w - 1) cx = w - x + d2;
+#pragma unroll
+                for (int r = 0; r < LV_RB; r++) {
+                    int y = y0 + r;
+                    y = y < h ? y : h - 1;
+                    int cy = d;
+                    const int yt = y - d2 - 1;
+                    if (yt < 0) cy = y + d2 + 1;
+                    const bool bot = y + d2 > h - 1;
+                    if (bot) cy = h - y + d2;
+                    const float A = tp[j][r][0];
+                    float Bv = tp[j][r][1], C = tp[j][r][2], D = tp[j][r][3];
+                    if (!hasL) { Bv = 0.f; D = 0.f; }
+                    if (yt < 0) { C = 0.f; D = 0.f; }
+                    // div(x,y) = (float)(1.0/count) from the LDS copy of the table: a global load here would sit
+                    // behind the row stores of finish() in the vmcnt queue.  Interior: lut[d*d] == a.
+                    const float m = s_lut[cx * cy];
+                    const float sum = bot ? ((A - C) - Bv) + D : ((A - Bv) - C) + D;
+                    T[r * WP + x] = sum * m;
+                }
+            } else if (SRC == 1) {
+#pragma unroll
+                for (int r = 0; r < LV_RB; r++) {   // b+g+r (image.h:197-203): integers, exact in float
+                    int y = y0 + r;
+                    y = y < h ? y : h - 1;
+                    const unsigned sh = (unsigned)((((size_t)y * w + x) * 3) & 3) * 8;
+                    const unsigned long long q8 = ((unsigned long long)__float_as_uint(tp[j][r][1]) << 32) | __float_as_uint(tp[j][r][0]);
+                    const unsigned p = (unsigned)(q8 >> sh);
+                    T[r * WP + x] = (float)((int)(p & 0xFF) + (int)((p >> 8) & 0xFF) + (int)((p >> 16) & 0xFF));
+                }
+            } else {
+#pragma unroll 4
+                for (int r = 0; r < LV_RB; r++) {
+                    const int y = y0 + r;
+                    float v = 0.f;
+                    if (y < h) {
+                        const size_t pix = (size_t)y * w + x;
+                        const uchar3 c = undist_rgb(frame, und_base[pix], und_iw[pix], w);
+                        v = (float)((int)c.x + (int)c.y + (int)c.z);
+                    }
+                    T[r * WP + x] = v;
+                }
+            }
+        }
+    };
+    // serial row prefix of batch k (wave 0, one lane per row)
+    auto scan = [&](int k) {
+        if (lane >= LV_RB || k * LV_RB + lane >= h || (ablate & 1)) return;
+        float *row = s_T + (size_t)(k & 1) * LV_RB * WP + (size_t)lane * WP;
+        // LV_SC floats per step; the next step's LDS reads are issued (unconditionally: the row pad / the next row /
+        // the tail pad of the allocation absorb the overrun) before this step's add chain so their latency hides
+        // behind it, and the loop body stays branch-free.
+        constexpr int LV_SC = 16;
+        const int nfull = w / LV_SC;
+        float acc = 0.f;
+        int c = 0;
+        if (nfull > 0) {
+            float4 cur[LV_SC / 4], nxt[LV_SC / 4];
+#pragma unroll
+            for (int i = 0; i < LV_SC / 4; i++) cur[i] = *reinterpret_cast<float4 *>(row + 4 * i);
+            for (int ch = 0; ch < nfull; ch++, c += LV_SC) {
+#pragma unroll
+                for (int i = 0; i < LV_SC / 4; i++) nxt[i] = *reinterpret_cast<float4 *>(row + c + LV_SC + 4 * i);
+                // img(0,y) = l(0,y); img(x,y) = img(x-1,y) + l(x,y)
+                cur[0].x = acc = ch == 0 ? cur[0].x : acc + cur[0].x;
+                cur[0].y = acc = acc + cur[0].y;
+                cur[0].z = acc = acc + cur[0].z;
+                cur[0].w = acc = acc + cur[0].w;
+#pragma unroll
+                for (int i = 1; i < LV_SC / 4; i++) {
+                    cur[i].x = acc = acc + cur[i].x;
+                    cur[i].y = acc = acc + cur[i].y;
+                    cur[i].z = acc = acc + cur[i].z;
+                    cur[i].w = acc = acc + cur[i].w;
+                }
+#pragma unroll
+                for (int i = 0; i < LV_SC / 4; i++) *reinterpret_cast<float4 *>(row + c + 4 * i) = cur[i];
+#pragma unroll
+                for (int i = 0; i < LV_SC / 4; i++) cur[i] = nxt[i];
+            }
+        }
+        for (; c < w; c += 4) {   // w % 16 != 0: up to three more float4 steps
+            float4 v = *reinterpret_cast<float4 *>(row + c);
+            v.x = acc = c == 0 ? v.x : acc + v.x;
+            v.y = acc = acc + v.y;
+            v.z = acc = acc + v.z;
+            v.w = acc = acc + v.w;
+            *reinterpret_cast<float4 *>(row + c) = v;
+        }
+    };
+    // column prefix of batch k onto the running sums + store
+    auto finish = [&](int k) {
+        if (ablate & 4) return;
+        const float *T = s_T + (size_t)(k & 1) * LV_RB * WP;
+        const int y0 = k * LV_RB;
+#pragma unroll
+        for (int j = 0; j < MC; j++) {
+            const int x = ct + j * LV_NC;
+            if (x >= w) break;
+            float v[LV_RB];
+#pragma unroll
+            for (int r = 0; r < LV_RB; r++) v[r] = T[r * WP + x];
+            float acc = run[j];
+#pragma unroll
+            for (int r = 0; r < LV_RB; r++) {
+                acc = (y0 + r == 0) ? v[r] : v[r] + acc;    // img(x,y) += img(x,y-1)
+                v[r] = acc;
+            }
+            run[j] = acc;
+#pragma unroll
+            for (int r = 0; r < LV_RB; r++)
+                if (y0 + r < h) dst[(size_t)(y0 + r) * w + x] = v[r];
+        }
+    };
+
+    if (wave == 0) {
+        __builtin_amdgcn_s_setprio(3);   // the serial scan is the critical path: let it win issue arbitration
+    } else {
+        issue(0);
+        commit(0);
+        if (nb > 1) issue(1);
+    }
+    lds_barrier();
+    if (wave == 0) scan(0);
+    else if (nb > 1) {
+        commit(1);
+        if (nb > 2) issue(2);
+    }
+    lds_barrier();
+    for (int k = 0; k < nb; k++) {
+        if (wave == 0) {
+            if (k + 1 < nb) scan(k + 1);
+        } else {
+            finish(k);                               // reads buffer k&1 ...
+            if (k + 2 < nb) commit(k + 2);           // ... which batch k+2 then overwrites (same thread, same columns)
+            if (k + 3 < nb) issue(k + 3);
+        }
+        lds_barrier();
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------
 // k_detect: one block per band of kBandRows image rows (rows 2..h-3 are scanned, edge_finder.cpp:105).
 // Phase 1 builds img0 (=G(sigma0)) and DoG for the band plus a 2-row halo in LDS from the last integral
 // images of both filters (last iimage::average of iigauss::smooth + sspace::build_dog).
@@ -721,81 +981,142 @@ int stage_a_enqueue(edgehip_ctx *c, int slot) {
     for (int i = 0; i < 4; i++) ii[i] = c->ii + (size_t)i * B * n;
     hipStream_t st = c->stream;
 
-    // 1. grey + exact row prefix, then serial column prefix: iimage::load of the input (shared by both
-    //    filters: filter0.smooth(data) and filter1.smooth(data) start from the same integral image).
-    {
-        ProfScope ps(c, PROF_A_ROWSCAN);
-        const int ch = rowscan_ch(w);
-        const size_t sm = (size_t)4 * ((w * 3 + 3) / 4) * 4;
-        dim3 g((h + 3) / 4, 1, B);
-        const bool und = c->und_base != nullptr;
-#define EH_ROWSCAN(CHV)                                                                                              \
-    case CHV:                                                                                                        \
-        if (und) hipLaunchKernelGGL((k_rgb_rowscan<CHV, true>), g, dim3(256), sm, st, rgbof(c, slot), ii[0], w, h, n, \
-                                    c->und_base, c->und_iw);                                                         \
-        else hipLaunchKernelGGL((k_rgb_rowscan<CHV, false>), g, dim3(256), sm, st, rgbof(c, slot), ii[0], w, h, n,   \
-                                c->und_base, c->und_iw);                                                             \
-        break;
-        switch (ch) {
-            EH_ROWSCAN(4) EH_ROWSCAN(8) EH_ROWSCAN(12) EH_ROWSCAN(16) EH_ROWSCAN(20) EH_ROWSCAN(24) EH_ROWSCAN(28)
-            default:
-                if (und) hipLaunchKernelGGL((k_rgb_rowscan<32, true>), g, dim3(256), sm, st, rgbof(c, slot), ii[0], w, h, n,
-                                            c->und_base, c->und_iw);
-                else hipLaunchKernelGGL((k_rgb_rowscan<32, false>), g, dim3(256), sm, st, rgbof(c, slot), ii[0], w, h, n,
-                                        c->und_base, c->und_iw);
-                break;
-        }
-#undef EH_ROWSCAN
-        EH_LAUNCH_CHECK();
-    }
-    auto colscan = [&](float *a, float *b) -> int {
-        ProfScope ps(c, PROF_A_COLSCAN);
-        PlanePtrs pp;
-        pp.p[0] = a;
-        pp.p[1] = b ? b : a;
-        hipLaunchKernelGGL(k_colscan<16>, dim3((w + 63) / 64, b ? 2 : 1, B), dim3(64), 0, st, pp, w, h, n);
-        EH_LAUNCH_CHECK();
-        return 0;
-    };
-    if (int e = colscan(ii[0], nullptr)) return e;
-
-    // 2. the remaining box passes.  Levels that have identical box-width prefixes in both filters are
-    //    computed once (EuRoC: {3,3,5} / {3,5,5} share the first level).
-    //    cur[f] = integral image that filter f averages next.
     float *cur[2] = {ii[0], ii[0]};
-    int next_free = 1;
-    bool shared = true;
-    for (int lvl = 0; lvl < kMaxBoxes - 1; lvl++) {
-        const int d0 = pl.box[0][lvl], d1 = pl.box[1][lvl];
-        AvgJob job;
-        int njobs;
-        if (shared && d0 == d1) {
-            float *dst = ii[next_free++];
-            job.src[0] = cur[0]; job.dst[0] = dst; job.d[0] = d0;
-            job.src[1] = cur[0]; job.dst[1] = dst; job.d[1] = d0;
-            njobs = 1;
-            cur[0] = cur[1] = dst;
-        } else {
-            shared = false;
-            // two destinations; reuse planes that are no longer read
-            float *dst0 = nullptr, *dst1 = nullptr;
-            for (int i = 0; i < 4 && !dst1; i++) {
-                if (ii[i] == cur[0] || ii[i] == cur[1]) continue;
-                if (!dst0) dst0 = ii[i]; else dst1 = ii[i];
+    const int planes_in_flight = B * 2;
+    const bool use_level = c->level_mode == 2 || (c->level_mode == 0 && planes_in_flight >= 192 && w <= LV_NC * LV_MAXCOL);
+    if (use_level) {
+        // one pass per level and plane (k_level): grey -> integral #1, then the box levels
+        const size_t sm = ((size_t)2 * LV_RB * level_row_stride(w) + 32 + kDivLutMax) * sizeof(float);   // + scan tail pad + LUT copy
+        const int lv_ablate = getenv("EDGEHIP_LEVEL_ABLATE") ? atoi(getenv("EDGEHIP_LEVEL_ABLATE")) : 0;   // timing experiments only
+        if (sm > 64 * 1024) {   // more than the default dynamic-LDS limit: opt in once per kernel
+            static bool done = false;
+            if (!done) {
+                const void *fns[6] = {(const void *)&k_level<0, 1>, (const void *)&k_level<1, 1>, (const void *)&k_level<2, 1>,
+                                      (const void *)&k_level<0, 2>, (const void *)&k_level<1, 2>, (const void *)&k_level<2, 2>};
+                for (const void *f : fns) EH_CHECK(hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+                done = true;
             }
-            job.src[0] = cur[0]; job.dst[0] = dst0; job.d[0] = d0;
-            job.src[1] = cur[1]; job.dst[1] = dst1; job.d[1] = d1;
-            njobs = 2;
-            cur[0] = dst0;
-            cur[1] = dst1;
         }
         {
-            ProfScope ps(c, PROF_A_AVGROW);
-            hipLaunchKernelGGL((k_avg_rowscan<256, 64, 64>), dim3((h + 63) / 64, njobs, B), dim3(256), 0, st, job,
-                               c->div_lut, w, h, n);
+            ProfScope ps(c, PROF_A_LEVEL);
+            LevelJob job = {};
+            job.dst[0] = ii[0]; job.d[0] = 1; job.a[0] = 1.f;
+#define EH_LEVEL(SRCV, GRID)                                                                                                   \
+    do {                                                                                                                      \
+        if (w <= LV_NC) hipLaunchKernelGGL((k_level<SRCV, 1>), GRID, dim3(LV_NT), sm, st, job, rgbof(c, slot), c->und_base,    \
+                                           c->und_iw, c->div_lut, w, h, n, lv_ablate);                                        \
+        else hipLaunchKernelGGL((k_level<SRCV, 2>), GRID, dim3(LV_NT), sm, st, job, rgbof(c, slot), c->und_base, c->und_iw,   \
+                                c->div_lut, w, h, n, lv_ablate);                                                              \
+    } while (0)
+            if (c->und_base) EH_LEVEL(2, dim3(1, 1, B));
+            else EH_LEVEL(1, dim3(1, 1, B));
             EH_LAUNCH_CHECK();
         }
-        if (int e = colscan(cur[0], njobs == 2 ? cur[1] : nullptr)) return e;
+        int next_free = 1;
+        bool shared = true;
+        for (int lvl = 0; lvl < kMaxBoxes - 1; lvl++) {
+            const int d0 = pl.box[0][lvl], d1 = pl.box[1][lvl];
+            LevelJob job = {};
+            int njobs;
+            if (shared && d0 == d1) {
+                float *dst = ii[next_free++];
+                job.src[0] = cur[0]; job.dst[0] = dst; job.d[0] = d0; job.a[0] = pl.box_a[0][lvl];
+                njobs = 1;
+                cur[0] = cur[1] = dst;
+            } else {
+                shared = false;
+                float *dst0 = nullptr, *dst1 = nullptr;
+                for (int i = 0; i < 4 && !dst1; i++) {
+                    if (ii[i] == cur[0] || ii[i] == cur[1]) continue;
+                    if (!dst0) dst0 = ii[i]; else dst1 = ii[i];
+                }
+                job.src[0] = cur[0]; job.dst[0] = dst0; job.d[0] = d0; job.a[0] = pl.box_a[0][lvl];
+                job.src[1] = cur[1]; job.dst[1] = dst1; job.d[1] = d1; job.a[1] = pl.box_a[1][lvl];
+                njobs = 2;
+                cur[0] = dst0;
+                cur[1] = dst1;
+            }
+            ProfScope ps(c, PROF_A_LEVEL);
+            EH_LEVEL(0, dim3(njobs, 1, B));
+            EH_LAUNCH_CHECK();
+        }
+    } else {
+        // 1. grey + exact row prefix, then serial column prefix: iimage::load of the input (shared by both
+        //    filters: filter0.smooth(data) and filter1.smooth(data) start from the same integral image).
+        {
+            ProfScope ps(c, PROF_A_ROWSCAN);
+            const int ch = rowscan_ch(w);
+            const size_t sm = (size_t)4 * ((w * 3 + 3) / 4) * 4;
+            dim3 g((h + 3) / 4, 1, B);
+            const bool und = c->und_base != nullptr;
+    #define EH_ROWSCAN(CHV)                                                                                              \
+        case CHV:                                                                                                        \
+            if (und) hipLaunchKernelGGL((k_rgb_rowscan<CHV, true>), g, dim3(256), sm, st, rgbof(c, slot), ii[0], w, h, n, \
+                                        c->und_base, c->und_iw);                                                         \
+            else hipLaunchKernelGGL((k_rgb_rowscan<CHV, false>), g, dim3(256), sm, st, rgbof(c, slot), ii[0], w, h, n,   \
+                                    c->und_base, c->und_iw);                                                             \
+            break;
+            switch (ch) {
+                EH_ROWSCAN(4) EH_ROWSCAN(8) EH_ROWSCAN(12) EH_ROWSCAN(16) EH_ROWSCAN(20) EH_ROWSCAN(24) EH_ROWSCAN(28)
+                default:
+                    if (und) hipLaunchKernelGGL((k_rgb_rowscan<32, true>), g, dim3(256), sm, st, rgbof(c, slot), ii[0], w, h, n,
+                                                c->und_base, c->und_iw);
+                    else hipLaunchKernelGGL((k_rgb_rowscan<32, false>), g, dim3(256), sm, st, rgbof(c, slot), ii[0], w, h, n,
+                                            c->und_base, c->und_iw);
+                    break;
+            }
+    #undef EH_ROWSCAN
+            EH_LAUNCH_CHECK();
+        }
+        auto colscan = [&](float *a, float *b) -> int {
+            ProfScope ps(c, PROF_A_COLSCAN);
+            PlanePtrs pp;
+            pp.p[0] = a;
+            pp.p[1] = b ? b : a;
+            hipLaunchKernelGGL(k_colscan<16>, dim3((w + 63) / 64, b ? 2 : 1, B), dim3(64), 0, st, pp, w, h, n);
+            EH_LAUNCH_CHECK();
+            return 0;
+        };
+        if (int e = colscan(ii[0], nullptr)) return e;
+
+        // 2. the remaining box passes.  Levels that have identical box-width prefixes in both filters are
+        //    computed once (EuRoC: {3,3,5} / {3,5,5} share the first level).
+        //    cur[f] = integral image that filter f averages next.
+        int next_free = 1;
+        bool shared = true;
+        for (int lvl = 0; lvl < kMaxBoxes - 1; lvl++) {
+            const int d0 = pl.box[0][lvl], d1 = pl.box[1][lvl];
+            AvgJob job;
+            int njobs;
+            if (shared && d0 == d1) {
+                float *dst = ii[next_free++];
+                job.src[0] = cur[0]; job.dst[0] = dst; job.d[0] = d0;
+                job.src[1] = cur[0]; job.dst[1] = dst; job.d[1] = d0;
+                njobs = 1;
+                cur[0] = cur[1] = dst;
+            } else {
+                shared = false;
+                // two destinations; reuse planes that are no longer read
+                float *dst0 = nullptr, *dst1 = nullptr;
+                for (int i = 0; i < 4 && !dst1; i++) {
+                    if (ii[i] == cur[0] || ii[i] == cur[1]) continue;
+                    if (!dst0) dst0 = ii[i]; else dst1 = ii[i];
+                }
+                job.src[0] = cur[0]; job.dst[0] = dst0; job.d[0] = d0;
+                job.src[1] = cur[1]; job.dst[1] = dst1; job.d[1] = d1;
+                njobs = 2;
+                cur[0] = dst0;
+                cur[1] = dst1;
+            }
+            {
+                ProfScope ps(c, PROF_A_AVGROW);
+                hipLaunchKernelGGL((k_avg_rowscan<256, 64, 64>), dim3((h + 63) / 64, njobs, B), dim3(256), 0, st, job,
+                                   c->div_lut, w, h, n);
+                EH_LAUNCH_CHECK();
+            }
+            if (int e = colscan(cur[0], njobs == 2 ? cur[1] : nullptr)) return e;
+        }
+
     }
 
     // 3. last average + DoG + gradient + detection

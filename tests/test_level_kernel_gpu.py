@@ -1,0 +1,58 @@
+"""GPU: the one-pass box-level kernel (k_level, EDGEHIP_LEVEL_MODE=2) against the reference scale space.
+The multi-pass kernels are the default for small batches and are covered by test_stage_a_gpu.py; bench-size
+batches switch to k_level automatically, so it gets the same bit-exact bar: img0 / img1 / DoG planes, mask,
+kn and KeyLines, on sizes that exercise a partial last row batch (h % 16 != 0), both row strides
+(w/4 even and odd) and the undistorting source."""
+import os
+
+import numpy as np
+import pytest
+
+from rebvo_amd import edgehip, synth
+
+pytestmark = pytest.mark.gpu
+
+CASES = [
+    ("euroc_752x480", 752, 480, False),
+    ("small_376x240", 376, 240, False),
+    ("odd_rows_200x150", 200, 150, False),
+    ("tum_undistort_640x480", 640, 480, True),
+]
+
+
+@pytest.fixture
+def level_mode_2():
+    old = os.environ.get("EDGEHIP_LEVEL_MODE")
+    os.environ["EDGEHIP_LEVEL_MODE"] = "2"
+    yield
+    if old is None:
+        del os.environ["EDGEHIP_LEVEL_MODE"]
+    else:
+        os.environ["EDGEHIP_LEVEL_MODE"] = old
+
+
+@pytest.mark.parametrize("name,w,h,und", CASES, ids=[c[0] for c in CASES])
+def test_level_kernel_bit_exact(level_mode_2, name, w, h, und):
+    from oracle import oracle
+    kind = "ref" if oracle.available("ref") else "port"
+    if und:
+        po, pe = oracle.tum_params(w, h, use_undistort=1), edgehip.tum_params(w, h, use_undistort=1)
+    else:
+        po, pe = oracle.euroc_params(w, h), edgehip.euroc_params(w, h)
+    pe.debug_planes = 1
+    frames = [f for f, _, _ in synth.billboard_sequence(w, h, 3)]
+    orc = oracle.Oracle(kind, po)
+    eh = edgehip.EdgeHip(pe, nseq=3, nslots=3)
+    tr, lr = po.detector_thresh, 0
+    for k, f in enumerate(frames):
+        kn, tr, lr = orc.stage_a(k, f, tr, lr)
+        eh.upload_rgb(k, np.stack([frames[(k + s) % 3] for s in range(3)]))   # different frame per sequence
+        eh.stage_a(k)
+        for pl in ("img0", "img1", "dog"):
+            assert np.array_equal(eh.download_plane(0, pl), orc.plane(k, pl)), (k, pl)
+        kg, mask = eh.download_keylines(0, k)
+        assert len(kg) == kn and np.array_equal(mask, orc.mask(k))
+        kr = orc.keylines(k)
+        for fld in ("p_inx", "m_m", "n_m", "c_p", "p_id", "n_id"):
+            assert np.array_equal(kg[fld], kr[fld]), fld
+    eh.close()
