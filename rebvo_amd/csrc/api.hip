@@ -307,10 +307,10 @@ int edgehip_create(const edgehip_params *params, int nseq, int nslots, int devic
     EH_TRY(dmalloc(c, &c->retuned_slot, S * B, al->dev, 0));
     c->nbands = (p.h - 4 + kBandRows - 1) / kBandRows;
     {
-        const int npx = kBandRows * p.w, nchunk = (npx + 63) / 64, cpw = (nchunk + 3) / 4;
+        const int npx = kBandRows * p.w, nchunk = (npx + 63) / 64, cpw = (nchunk + kDetWaves - 1) / kDetWaves;
         c->band_cap = cpw * 64;
     }
-    const size_t nstrips = (size_t)c->nbands * 4;
+    const size_t nstrips = (size_t)c->nbands * kDetWaves;
     EH_TRY(dmalloc(c, &c->band_cnt, B * nstrips, al->dev, 0));
     EH_TRY(dmalloc(c, &c->band_off, B * (nstrips + 1), al->dev, 0));
     {
@@ -378,6 +378,16 @@ int edgehip_create(const edgehip_params *params, int nseq, int nslots, int devic
         EH_CHECK(hipMemcpyAsync(c->div_lut, lut.data(), sizeof(float) * kDivLutMax, hipMemcpyHostToDevice, c->stream));
         double pinv[75];
         plane_fit_pinv(2, pinv);
+        // k_detect keeps PInv as 5 + 5 + 1 coefficients: row 0 varies with the window column only, row 1 with the
+        // window row only, row 2 is constant (symmetric window).  Verify instead of assuming.
+        for (int i = 0; i < 5; i++)
+            for (int j = 0; j < 5; j++) {
+                const int k = i * 5 + j;
+                if (!(pinv[k] == pinv[j] && pinv[25 + k] == pinv[25 + 5 * i] && pinv[50 + k] == pinv[50])) {
+                    set_error("edgehip_create: plane-fit pseudo inverse lost its separable structure");
+                    return EDGEHIP_ERR_STATE;
+                }
+            }
         EH_CHECK(hipMemcpyAsync(c->pinv, pinv, sizeof pinv, hipMemcpyHostToDevice, c->stream));
         EH_CHECK(hipStreamSynchronize(c->stream));  // lut/pinv are stack temporaries
     }

@@ -19,7 +19,8 @@
 namespace edgehip {
 
 constexpr int kMaxBoxes = 3;        // bf_num of sspace (rebvo.cpp:299 passes 3)
-constexpr int kBandRows = 4;        // rows per detect block (raster-order compaction granule)
+constexpr int kBandRows = 12;       // rows per detect block (+4 halo rows in LDS)
+constexpr int kDetWaves = 16;       // waves per detect block; a (band, wave) strip is the raster-order compaction granule
 constexpr int kDivLutMax = 256;     // reciprocal-count LUT entries (box width up to 15)
 constexpr int kTvrBlock = 256;      // threads per TryVelRot block
 constexpr int kNumSums = 28;        // 21 JtJ + 6 JtF + score

@@ -332,7 +332,6 @@ __global__ __launch_bounds__(LV_NT) void k_level(LevelJob job, const uint8_t *__
     float *dst = job.dst[jb] + (size_t)seq * n;
     const uint8_t *frame = SRC != 0 ? rgb + (size_t)seq * n * 3 : nullptr;
     const int d = job.d[jb], d2 = d / 2;
-    const float a_int = job.a[jb];
     const int nb = (h + LV_RB - 1) / LV_RB;
     const int ct = tid - 64;              // column-owner index (waves 1..12)
     float *s_lut = s_T + (size_t)2 * LV_RB * WP + 32;   // [kDivLutMax] reciprocal-count table (after the scan's tail pad)
@@ -586,13 +585,14 @@ __device__ __forceinline__ double update_thresh(double tresh, int l_kl_num, int 
     return tresh;
 }
 
-__global__ __launch_bounds__(256) void k_detect(DetectArgs a) {
+__global__ __launch_bounds__(kDetWaves * 64) void k_detect(DetectArgs a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int w = a.w, h = a.h;
     constexpr int HR = kBandRows + 4;  // rows held in LDS
     float *s_img0 = reinterpret_cast<float *>(smem);   // [HR][w]
     float *s_dog = s_img0 + (size_t)HR * w;            // [HR][w]
     __shared__ double s_pinv[75];
+    __shared__ float s_lut[kDivLutMax];
     const int seq = blockIdx.z, band = blockIdx.x;
     const int tid = threadIdx.x;
     const int y0 = 2 + band * kBandRows;  // first output row of the band
@@ -600,42 +600,78 @@ __global__ __launch_bounds__(256) void k_detect(DetectArgs a) {
     const size_t so = (size_t)seq * a.n;
     const float *iic0 = a.iic0 + so, *iic1 = a.iic1 + so;
     if (tid < 75) s_pinv[tid] = a.pinv[tid];
+    if (tid < kDivLutMax) s_lut[tid] = a.lut[tid];
+    __syncthreads();
 
-    // ---- phase 1: img0, img1 -> LDS (+ optional debug planes) ----
-    const int d20 = a.d0 / 2, d21 = a.d1 / 2;
-    for (int r = 0; r < HR; r++) {
-        const int y = yb0 + r;
-        if (y >= h) {
-            for (int x = tid; x < w; x += 256) { s_img0[r * w + x] = 0.f; s_dog[r * w + x] = 0.f; }
-            continue;
-        }
-        // every image row is written to the debug planes by exactly one band
-        const bool own = a.planes && ((y >= y0 && y < y0 + kBandRows) || (band == 0 && y < 2) ||
-                                      (y >= 2 + (int)gridDim.x * kBandRows));
-        // all tap loads of up to PX pixels x 2 filters are issued before the first use
-        constexpr int PX = 4;
-        for (int xb = 0; xb < w; xb += 256 * PX) {
-            BoxTaps t0[PX], t1[PX];
+    // ---- phase 1: img0 = G(sigma0), DoG = G(sigma1) - G(sigma0) for the band + halo -> LDS -------------------
+    // thread <-> column: which taps exist and the box width along x are column properties, hoisted out of the
+    // row loop; clipped rows and the box height are wave-uniform.  The tap loads of 4 rows x 2 filters (32 per
+    // thread) are all in flight before the first is used; no global load sits inside a branch.
+    for (int x = tid; x < w; x += kDetWaves * 64) {
+        int xlc[2], xr[2], cx[2], dd[2], dh[2];
+        bool hasL[2];
+        const float *ii[2] = {iic0, iic1};
+        dd[0] = a.d0; dd[1] = a.d1;
 #pragma unroll
-            for (int j = 0; j < PX; j++) {
-                int x = xb + j * 256 + tid;
-                x = x < w ? x : w - 1;
-                t0[j] = box_taps(iic0, x, y, w, h, a.d0, d20, a.lut, a.a0);
-                t1[j] = box_taps(iic1, x, y, w, h, a.d1, d21, a.lut, a.a1);
+        for (int f = 0; f < 2; f++) {
+            dh[f] = dd[f] / 2;
+            const int xl = x - dh[f] - 1;
+            hasL[f] = xl >= 0;
+            xlc[f] = hasL[f] ? xl : 0;
+            xr[f] = x + dh[f];
+            cx[f] = dd[f];
+            if (!hasL[f]) cx[f] = x + dh[f] + 1;
+            if (xr[f] > w - 1) { xr[f] = w - 1; cx[f] = w - x + dh[f]; }
+        }
+#pragma nounroll
+        for (int r0 = 0; r0 < HR; r0 += 4) {
+            float tp[4][2][4];
+#pragma unroll
+            for (int i = 0; i < 4; i++) {
+                int y = yb0 + r0 + i;
+                y = y < h ? y : h - 1;
+#pragma unroll
+                for (int f = 0; f < 2; f++) {
+                    const int yb = y + dh[f] > h - 1 ? h - 1 : y + dh[f];
+                    const int yt = y - dh[f] - 1;
+                    const float *rowb = ii[f] + (size_t)yb * w;
+                    const float *rowt = ii[f] + (size_t)(yt < 0 ? 0 : yt) * w;
+                    tp[i][f][0] = rowb[xr[f]];
+                    tp[i][f][1] = rowb[xlc[f]];
+                    tp[i][f][2] = rowt[xr[f]];
+                    tp[i][f][3] = rowt[xlc[f]];
+                }
             }
 #pragma unroll
-            for (int j = 0; j < PX; j++) {
-                const int x = xb + j * 256 + tid;
-                if (x >= w) continue;
-                const float g0 = box_combine(t0[j]), g1 = box_combine(t1[j]);
-                s_img0[r * w + x] = g0;
-                s_dog[r * w + x] = g1 - g0;  // sspace.cpp:66
-                if (own) {
+            for (int i = 0; i < 4; i++) {
+                const int r = r0 + i, y = yb0 + r;
+                float g[2];
+#pragma unroll
+                for (int f = 0; f < 2; f++) {
+                    const int yc = y < h ? y : h - 1;
+                    int cy = dd[f];
+                    const int yt = yc - dh[f] - 1;
+                    if (yt < 0) cy = yc + dh[f] + 1;
+                    const bool bot = yc + dh[f] > h - 1;
+                    if (bot) cy = h - yc + dh[f];
+                    const float A = tp[i][f][0];
+                    float Bv = tp[i][f][1], C = tp[i][f][2], D = tp[i][f][3];
+                    if (!hasL[f]) { Bv = 0.f; D = 0.f; }
+                    if (yt < 0) { C = 0.f; D = 0.f; }
+                    const float sum = bot ? ((A - C) - Bv) + D : ((A - Bv) - C) + D;   // iimage.cpp:105-126
+                    g[f] = sum * s_lut[cx[f] * cy];                                    // div(x,y); interior == a
+                }
+                const bool inimg = y < h;
+                s_img0[r * w + x] = inimg ? g[0] : 0.f;
+                s_dog[r * w + x] = inimg ? g[1] - g[0] : 0.f;                          // sspace.cpp:66
+                // every image row is written to the debug planes by exactly one band
+                if (a.planes && inimg && ((y >= y0 && y < y0 + kBandRows) || (band == 0 && y < 2) ||
+                                          (y >= 2 + (int)gridDim.x * kBandRows))) {
                     float *pl = a.planes + so;
                     const size_t pstride = (size_t)a.nseq * a.n;
-                    pl[0 * pstride + (size_t)y * w + x] = g0;
-                    pl[1 * pstride + (size_t)y * w + x] = g1;
-                    pl[2 * pstride + (size_t)y * w + x] = g1 - g0;
+                    pl[0 * pstride + (size_t)y * w + x] = g[0];
+                    pl[1 * pstride + (size_t)y * w + x] = g[1];
+                    pl[2 * pstride + (size_t)y * w + x] = g[1] - g[0];
                 }
             }
         }
@@ -654,9 +690,9 @@ __global__ __launch_bounds__(256) void k_detect(DetectArgs a) {
     const int wave = tid >> 6, lane = tid & 63;
     const int npx = kBandRows * w;
     const int nchunk = (npx + 63) >> 6;
-    const int cpw = (nchunk + 3) >> 2;  // chunks per wave
-    const int strip = band * 4 + wave;
-    const int nstrips = gridDim.x * 4;
+    const int cpw = (nchunk + kDetWaves - 1) / kDetWaves;  // chunks per wave
+    const int strip = band * kDetWaves + wave;
+    const int nstrips = gridDim.x * kDetWaves;
     const size_t sbase = ((size_t)seq * nstrips + strip) * a.strip_cap;
     int32_t *mask = a.mask + so;
     // 2a: cheap gradient gate on every pixel of the strip; survivors are compacted (raster order kept)
@@ -693,6 +729,13 @@ __global__ __launch_bounds__(256) void k_detect(DetectArgs a) {
         }
     }
     // 2b: DoG sign balance, plane fit, sub-pixel zero crossing, DoG-gradient gate (edge_finder.cpp:125-159)
+    // PInv(0,k) depends on the window column only, PInv(1,k) on the window row only, PInv(2,k) is constant (the
+    // window is symmetric; checked on the host when the table is built): 11 coefficients live in registers
+    // instead of 75 LDS reads per candidate.  The accumulation order over k is unchanged.
+    double pc0[5], pc1[5];
+#pragma unroll
+    for (int j = 0; j < 5; j++) { pc0[j] = s_pinv[j]; pc1[j] = s_pinv[25 + 5 * j]; }
+    const double pc2 = s_pinv[50];
     int count = 0;  // wave-uniform running count of the strip
     for (int base = 0; base < ((a.ablate & 4) ? 0 : nlist); base += 64) {
         const int li = base + lane;
@@ -713,9 +756,9 @@ __global__ __launch_bounds__(256) void k_detect(DetectArgs a) {
                     const float v = dg[i * w + j];
                     pn += (v > 0) ? 1 : -1;
                     const double yv = (double)v;
-                    t0 += s_pinv[k] * yv;          // TooN dot product: result += a[i]*b[i]
-                    t1 += s_pinv[25 + k] * yv;
-                    t2 += s_pinv[50 + k] * yv;
+                    t0 += pc0[j + 2] * yv;         // TooN dot product: result += a[i]*b[i], k = 0..24 in order
+                    t1 += pc1[i + 2] * yv;
+                    t2 += pc2 * yv;
                 }
             }
             const int apn = pn < 0 ? -pn : pn;
@@ -1120,7 +1163,7 @@ int stage_a_enqueue(edgehip_ctx *c, int slot) {
     }
 
     // 3. last average + DoG + gradient + detection
-    const int nbands = c->nbands, nstrips = nbands * 4;
+    const int nbands = c->nbands, nstrips = nbands * kDetWaves;
     CandStage cs;
     {
         char *base = (char *)c->band_stage;
@@ -1148,9 +1191,16 @@ int stage_a_enqueue(edgehip_ctx *c, int slot) {
         const int ws = c->p.plane_fit_size;
         a.pn_thresh = (double)(((float)((2.0 * ws + 1.0) * (2.0 * ws + 1.0))) * (float)c->p.pos_neg_thresh);
         a.ablate = getenv("EDGEHIP_ABLATE") ? atoi(getenv("EDGEHIP_ABLATE")) : 0;
-        const int npx_b = kBandRows * w, cpw_b = (((npx_b + 63) >> 6) + 3) >> 2;
-        const size_t sm = (size_t)2 * (kBandRows + 4) * w * sizeof(float) + (size_t)4 * cpw_b * 64 * sizeof(uint16_t);
-        hipLaunchKernelGGL(k_detect, dim3(nbands, 1, B), dim3(256), sm, st, a);
+        const int npx_b = kBandRows * w, cpw_b = (((npx_b + 63) >> 6) + kDetWaves - 1) / kDetWaves;
+        const size_t sm = (size_t)2 * (kBandRows + 4) * w * sizeof(float) + (size_t)kDetWaves * cpw_b * 64 * sizeof(uint16_t);
+        if (sm > 64 * 1024) {
+            static bool done = false;
+            if (!done) {
+                EH_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_detect), hipFuncAttributeMaxDynamicSharedMemorySize, 158 * 1024));
+                done = true;
+            }
+        }
+        hipLaunchKernelGGL(k_detect, dim3(nbands, 1, B), dim3(kDetWaves * 64), sm, st, a);
         EH_LAUNCH_CHECK();
     }
     {

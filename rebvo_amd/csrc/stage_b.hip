@@ -364,7 +364,7 @@ __device__ __noinline__ void so3_exp(const double w[3], double R[9]) {
 
 // Per-evaluation constants of TryVelRot (global_tracker.cpp:309-341): R0 = exp(W), RM = 2x2 block of
 // exp((0,0,W_z)), Vt = V.
-__device__ __noinline__ void tvr_setup(SeqDev *sq, const double X[6]) {
+__device__ __noinline__ void tvr_setup(SeqDev *sq, const double *X) {
     double R0[9], Rz[9];
     so3_exp(X + 3, R0);
     const double wz[3] = {0.0, 0.0, X[5]};
@@ -755,6 +755,77 @@ __device__ __noinline__ void chol6_inverse(const double L[36], double Inv[36], d
     }
 }
 
+// Register-resident versions (arrays indexed only by unrolled constants) of chol6 / backsub / inverse above.
+__device__ __forceinline__ void chol6_r(const double (&A)[36], double (&L)[36]) {
+#pragma unroll
+    for (int i = 0; i < 36; i++) L[i] = A[i];
+    bool alive = true;   // TooN returns at the first zero pivot, leaving the rest untouched
+#pragma unroll
+    for (int col = 0; col < 6; col++) {
+        double inv_diag = 1;
+#pragma unroll
+        for (int row = col; row < 6; row++) {
+            double val = L[row * 6 + col];
+#pragma unroll
+            for (int col2 = 0; col2 < col; col2++) val -= L[col2 * 6 + col] * L[row * 6 + col2];
+            if (row == col) {
+                if (alive) L[row * 6 + col] = val;
+                if (val == 0) alive = false;
+                inv_diag = 1 / val;
+            } else if (alive) {
+                L[col * 6 + row] = val;
+                L[row * 6 + col] = val * inv_diag;
+            }
+        }
+    }
+}
+__device__ __forceinline__ void chol6_backsub_r(const double (&L)[36], const double (&vv)[6], double (&r)[6]) {
+    double y[6];
+#pragma unroll
+    for (int i = 0; i < 6; i++) {
+        double val = vv[i];
+#pragma unroll
+        for (int j = 0; j < i; j++) val -= L[i * 6 + j] * y[j];
+        y[i] = val;
+    }
+#pragma unroll
+    for (int i = 0; i < 6; i++) y[i] /= L[i * 7];
+#pragma unroll
+    for (int i = 5; i >= 0; i--) {
+        double val = y[i];
+#pragma unroll
+        for (int j = i + 1; j < 6; j++) val -= L[j * 6 + i] * r[j];
+        r[i] = val;
+    }
+}
+__device__ __forceinline__ void chol6_inverse_r(const double (&L)[36], double (&Inv)[36]) {
+    double invd[6];
+#pragma unroll
+    for (int i = 0; i < 6; i++) invd[i] = 1 / L[i * 7];
+#pragma unroll
+    for (int c = 0; c < 6; c++) {
+        double y[6], r[6];
+#pragma unroll
+        for (int i = 0; i < 6; i++) {
+            double val = (i == c) ? 1.0 : 0.0;
+#pragma unroll
+            for (int j = 0; j < i; j++) val -= L[i * 6 + j] * y[j];
+            y[i] = val;
+        }
+#pragma unroll
+        for (int i = 0; i < 6; i++) y[i] *= invd[i];   // y[i] *= (1/d), Cholesky.h:165-200
+#pragma unroll
+        for (int i = 5; i >= 0; i--) {
+            double val = y[i];
+#pragma unroll
+            for (int j = i + 1; j < 6; j++) val -= L[j * 6 + i] * r[j];
+            r[i] = val;
+        }
+#pragma unroll
+        for (int i = 0; i < 6; i++) Inv[i * 6 + c] = r[i];
+    }
+}
+
 // ---------------------------------------------------------------------------------------------------
 // k_lm_step: everything Minimizer_RV does between two TryVelRot evaluations (global_tracker.cpp:631-816).
 // The host knows the (static) call sequence and passes it as a bit mask of operations.
@@ -864,79 +935,116 @@ __global__ __launch_bounds__(64) void k_lm_step(LmArgs a) {
     }
     __syncthreads();
     if (lane == 0) {
+    // The serial LM logic runs on register copies of the hot state (fully unrolled 6x6 algebra): with the state
+    // left in LDS every one of its ~1000 dependent accesses paid an LDS round trip (~25 us per step).
+    double JtJ[36], JtF[6], X[6], Xn[6], hh[6];
+#pragma unroll
+    for (int i = 0; i < 36; i++) JtJ[i] = sq->JtJ[i];
+#pragma unroll
+    for (int i = 0; i < 6; i++) { JtF[i] = sq->JtF[i]; X[i] = sq->X[i]; Xn[i] = sq->Xnew[i]; hh[i] = sq->h[i]; }
+    double F = sq->F, Fnew = sq->Fnew, F0 = sq->F0, u = sq->u, v = sq->v;
+    int eff_steps = sq->eff_steps, res_cur = sq->res_cur, res_new = sq->res_new, res_t = sq->res_t;
 
     if (ops & (LM_REDUCE_CUR | LM_REDUCE_NEW)) {
-        double *JtJ = (ops & LM_REDUCE_CUR) ? sq->JtJ : sq->JtJnew;
-        double *JtF = (ops & LM_REDUCE_CUR) ? sq->JtF : sq->JtFnew;
+        double Jn[36], Fn6[6];
         if (!(ops & LM_NOJAC)) {
-            int ns = 0;
-            for (int i = 0; i < 6; i++)
-                for (int j = i; j < 6; j++) JtJ[i * 6 + j] = s_sum[ns++];
-            for (int i = 0; i < 6; i++) JtF[i] = s_sum[ns++];
+            {
+                int ns = 0;
+#pragma unroll
+                for (int i = 0; i < 6; i++)
+#pragma unroll
+                    for (int j = i; j < 6; j++) Jn[i * 6 + j] = s_sum[ns++];
+#pragma unroll
+                for (int i = 0; i < 6; i++) Fn6[i] = s_sum[ns++];
+            }
+#pragma unroll
             for (int i = 0; i < 2; i++) {  // sign fix-ups, global_tracker.cpp:484-490
-                JtF[i + 2] = -JtF[i + 2];
+                Fn6[i + 2] = -Fn6[i + 2];
+#pragma unroll
                 for (int j = 0; j < 2; j++) {
-                    JtJ[(i + 0) * 6 + j + 2] = -JtJ[(i + 0) * 6 + j + 2];
-                    JtJ[(i + 2) * 6 + j + 4] = -JtJ[(i + 2) * 6 + j + 4];
+                    Jn[(i + 0) * 6 + j + 2] = -Jn[(i + 0) * 6 + j + 2];
+                    Jn[(i + 2) * 6 + j + 4] = -Jn[(i + 2) * 6 + j + 4];
                 }
             }
+#pragma unroll
             for (int i = 0; i < 6; i++)
-                for (int j = i + 1; j < 6; j++) JtJ[j * 6 + i] = JtJ[i * 6 + j];
+#pragma unroll
+                for (int j = i + 1; j < 6; j++) Jn[j * 6 + i] = Jn[i * 6 + j];
+            if (ops & LM_REDUCE_CUR) {
+#pragma unroll
+                for (int i = 0; i < 36; i++) JtJ[i] = Jn[i];
+#pragma unroll
+                for (int i = 0; i < 6; i++) JtF[i] = Fn6[i];
+            } else {
+#pragma unroll
+                for (int i = 0; i < 36; i++) sq->JtJnew[i] = Jn[i];
+#pragma unroll
+                for (int i = 0; i < 6; i++) sq->JtFnew[i] = Fn6[i];
+            }
         }
-        if (ops & LM_REDUCE_CUR) sq->F = s_sum[kNumSums - 1]; else sq->Fnew = s_sum[kNumSums - 1];
+        if (ops & LM_REDUCE_CUR) F = s_sum[kNumSums - 1]; else Fnew = s_sum[kNumSums - 1];
         sq->pub.minimizer_evals++;
     }
     const double tau = 1e-3;
     if (ops & LM_INIT) {
-        sq->F0 = sq->F;
-        double mx = sq->JtJ[0];
-        for (int i = 1; i < 36; i++) mx = sq->JtJ[i] > mx ? sq->JtJ[i] : mx;  // TooN::max_element(JtJ).first
-        sq->u = tau * mx;
+        F0 = F;
+        double mx = JtJ[0];
+#pragma unroll
+        for (int i = 1; i < 36; i++) mx = JtJ[i] > mx ? JtJ[i] : mx;  // TooN::max_element(JtJ).first
+        u = tau * mx;
     }
-    if (ops & LM_RESET_V) sq->v = 2;
+    if (ops & LM_RESET_V) v = 2;
     if (ops & (LM_GAIN_RATIO | LM_GAIN_DIFF)) {
         double gain;
-        if (ops & LM_GAIN_DIFF) gain = sq->F - sq->Fnew;
+        if (ops & LM_GAIN_DIFF) gain = F - Fnew;
         else {
             double den = 0;  // (0.5*h) * (u*h - JtF)
-            for (int i = 0; i < 6; i++) den += (0.5 * sq->h[i]) * (sq->u * sq->h[i] - sq->JtF[i]);
-            gain = (sq->F - sq->Fnew) / den;
+#pragma unroll
+            for (int i = 0; i < 6; i++) den += (0.5 * hh[i]) * (u * hh[i] - JtF[i]);
+            gain = (F - Fnew) / den;
         }
         sq->gain = gain;
         if (gain > 0) {
-            sq->F = sq->Fnew;
-            for (int i = 0; i < 6; i++) { sq->X[i] = sq->Xnew[i]; sq->JtF[i] = sq->JtFnew[i]; }
-            for (int i = 0; i < 36; i++) sq->JtJ[i] = sq->JtJnew[i];
+            F = Fnew;
+#pragma unroll
+            for (int i = 0; i < 6; i++) { X[i] = Xn[i]; JtF[i] = sq->JtFnew[i]; }
+#pragma unroll
+            for (int i = 0; i < 36; i++) JtJ[i] = sq->JtJnew[i];
             const double g = 2 * gain - 1;
             const double m = 1 - (g * g * g);
-            sq->u *= (0.33 > m ? 0.33 : m);   // std::max(0.33, ...)
-            sq->v = 2;
-            sq->eff_steps++;
-            if (ops & LM_SWAP_ON_ACCEPT) { const int t = sq->res_new; sq->res_new = sq->res_cur; sq->res_cur = t; }
+            u *= (0.33 > m ? 0.33 : m);   // std::max(0.33, ...)
+            v = 2;
+            eff_steps++;
+            if (ops & LM_SWAP_ON_ACCEPT) { const int t = res_new; res_new = res_cur; res_cur = t; }
         } else {
-            sq->u *= sq->v;
-            sq->v *= 2;
+            u *= v;
+            v *= 2;
         }
     }
     if (ops & LM_SAVE_T) {
-        for (int i = 0; i < 6; i++) sq->Xt[i] = sq->X[i];
-        sq->Ft = sq->F; sq->F0t = sq->F0; sq->ut = sq->u; sq->vt = sq->v; sq->eff_steps_t = sq->eff_steps;
-        sq->eff_steps = 0;
-        for (int i = 0; i < 3; i++) { sq->X[i] = sq->pub.V[i]; sq->X[3 + i] = sq->pub.W[i]; }
+#pragma unroll
+        for (int i = 0; i < 6; i++) sq->Xt[i] = X[i];
+        sq->Ft = F; sq->F0t = F0; sq->ut = u; sq->vt = v; sq->eff_steps_t = eff_steps;
+        eff_steps = 0;
+#pragma unroll
+        for (int i = 0; i < 3; i++) { X[i] = sq->pub.V[i]; X[3 + i] = sq->pub.W[i]; }
     }
     if (ops & LM_PICK) {
-        if (sq->F > sq->Ft) {
-            for (int i = 0; i < 6; i++) sq->X[i] = sq->Xt[i];
-            sq->F = sq->Ft; sq->F0 = sq->F0t; sq->u = sq->ut; sq->v = sq->vt; sq->eff_steps = sq->eff_steps_t;
-            const int t = sq->res_new; sq->res_new = sq->res_t; sq->res_t = t;   // ResidualNew = Rest
+        if (F > sq->Ft) {
+#pragma unroll
+            for (int i = 0; i < 6; i++) X[i] = sq->Xt[i];
+            F = sq->Ft; F0 = sq->F0t; u = sq->ut; v = sq->vt; eff_steps = sq->eff_steps_t;
+            const int t = res_new; res_new = res_t; res_t = t;   // ResidualNew = Rest
         }
-        const int t = sq->res_new; sq->res_new = sq->res_cur; sq->res_cur = t;       // std::swap
+        const int t = res_new; res_new = res_cur; res_cur = t;       // std::swap
     }
     if (ops & (LM_SOLVE_SVD | LM_SOLVE_CHOL)) {
-        double *ApI = s_m[0], *L = s_m[1], *nb = s_v[0];
-        for (int i = 0; i < 36; i++) ApI[i] = sq->JtJ[i];
-        for (int i = 0; i < 6; i++) { ApI[i * 7] = sq->JtJ[i * 7] + 1.0 * sq->u; nb[i] = -sq->JtF[i]; }
-        chol6(ApI, L);
+        double ApI[36], L[36], nb[6];
+#pragma unroll
+        for (int i = 0; i < 36; i++) ApI[i] = JtJ[i];
+#pragma unroll
+        for (int i = 0; i < 6; i++) { ApI[i * 7] = JtJ[i * 7] + 1.0 * u; nb[i] = -JtF[i]; }
+        chol6_r(ApI, L);
         bool use_svd = false;
         if (ops & LM_SOLVE_SVD) {
             // TooN::SVD<>::backsub zeroes singular values below s_max/1e9.  ApI = JtJ + u*I with
@@ -944,39 +1052,60 @@ __global__ __launch_bounds__(64) void k_lm_step(LmArgs a) {
             // fires and the pseudo-inverse IS the inverse: solve by LDL^T.  The Jacobi-SVD path is kept
             // for the degenerate case (non-positive or tiny pivots).
             double dmin = L[0], dmax = L[0];
+#pragma unroll
             for (int i = 1; i < 6; i++) { dmin = fmin(dmin, L[i * 7]); dmax = fmax(dmax, L[i * 7]); }
             use_svd = !(dmin > 0) || !(dmin * 1e7 > dmax);
         }
-        if (use_svd) svd_backsub6(ApI, nb, sq->h, s_m[2], s_m[3], s_v[1], s_v[2]);
-        else chol6_backsub(L, nb, sq->h, s_v[1]);
-        for (int i = 0; i < 6; i++) sq->Xnew[i] = sq->X[i] + sq->h[i];
+        if (use_svd) {
+            double *A_l = s_m[0], *b_l = s_v[0], *h_l = s_v[2] + 0;
+            for (int i = 0; i < 36; i++) A_l[i] = ApI[i];
+            for (int i = 0; i < 6; i++) b_l[i] = nb[i];
+            svd_backsub6(A_l, b_l, h_l, s_m[2], s_m[3], s_v[1], s_m[1]);
+#pragma unroll
+            for (int i = 0; i < 6; i++) hh[i] = h_l[i];
+        } else {
+            chol6_backsub_r(L, nb, hh);
+        }
+#pragma unroll
+        for (int i = 0; i < 6; i++) Xn[i] = X[i] + hh[i];
     }
     if (ops & LM_PHASE_A) sq->lm_phase = 0;
     if (ops & LM_PHASE_BC) sq->lm_phase = 1;
-    if (ops & LM_SETUP_X) tvr_setup(sq, sq->X);
-    if (ops & LM_SETUP_XNEW) tvr_setup(sq, sq->Xnew);
+    if (ops & LM_SETUP_X) tvr_setup(sq, X);
+    if (ops & LM_SETUP_XNEW) tvr_setup(sq, Xn);
     if (ops & LM_FINISH) {
-        double *L = s_m[1], *Inv = s_m[2];
-        chol6(sq->JtJ, L);
-        chol6_inverse(L, Inv, s_v[1], s_v[2]);
-        for (int i = 0; i < 3; i++) { sq->pub.V[i] = sq->X[i]; sq->pub.W[i] = sq->X[3 + i]; }
+        double L[36], Inv[36];
+        chol6_r(JtJ, L);
+        chol6_inverse_r(L, Inv);
+#pragma unroll
+        for (int i = 0; i < 3; i++) { sq->pub.V[i] = X[i]; sq->pub.W[i] = X[3 + i]; }
+#pragma unroll
         for (int i = 0; i < 3; i++)
+#pragma unroll
             for (int j = 0; j < 3; j++) {
                 sq->pub.P_V[i * 3 + j] = Inv[i * 6 + j];
                 sq->pub.P_W[i * 3 + j] = Inv[(i + 3) * 6 + j + 3];
             }
-        if (sq->eff_steps > 0) {
+        if (eff_steps > 0) {
             double nh = 0, nx = 0;
-            for (int i = 0; i < 6; i++) { nh += sq->h[i] * sq->h[i]; nx += sq->X[i] * sq->X[i]; }
+#pragma unroll
+            for (int i = 0; i < 6; i++) { nh += hh[i] * hh[i]; nx += X[i] * X[i]; }
             sq->pub.rel_error = sqrt(nh) / (sqrt(nx) + 1e-30);
-            sq->pub.rel_error_score = sq->F / sq->F0;
+            sq->pub.rel_error_score = F / F0;
         } else {
             sq->pub.rel_error = 1e20;
             sq->pub.rel_error_score = 1e20;
         }
-        sq->pub.score = sq->F;
+        sq->pub.score = F;
         a.framecount[seq]++;
     }
+    // registers -> state
+#pragma unroll
+    for (int i = 0; i < 36; i++) sq->JtJ[i] = JtJ[i];
+#pragma unroll
+    for (int i = 0; i < 6; i++) { sq->JtF[i] = JtF[i]; sq->X[i] = X[i]; sq->Xnew[i] = Xn[i]; sq->h[i] = hh[i]; }
+    sq->F = F; sq->Fnew = Fnew; sq->F0 = F0; sq->u = u; sq->v = v;
+    sq->eff_steps = eff_steps; sq->res_cur = res_cur; sq->res_new = res_new; sq->res_t = res_t;
     }  // lane 0
     __syncthreads();
     for (int i = lane; i < kWords; i += 64) gstate[i] = s_state[i];

@@ -1,0 +1,6 @@
+#!/bin/bash
+timeout 900 python -m pytest tests -m gpu -x -q 2>&1 | tail -3
+python bench.py --steps 20 --warmup 12 --cpu-frames 0 | python -c "
+import json,sys
+d=json.loads(sys.stdin.read())
+print(d['value'], d['ms_per_step'], d['roofline']); print(d['kernel_us_per_step'])"
