@@ -53,6 +53,8 @@ def algorithmic_bytes(group, kn, n_px, radius, nseq):
         "A.colscan": 2 * 4 * n_px,                           # plane in, plane out (per plane)
         "A.avg_rowscan": 2 * 4 * n_px,                       # integral in, integral out (per plane)
         "A.detect": 2 * 4 * n_px + 4 * n_px + 20 * kn,       # two integrals in, mask + candidates out
+        # one-pass level kernel, mean of its three launches: (3N in + 4N out) + (4N + 4N) + 2 * (4N + 4N)
+        "A.level": (7 * n_px + 8 * n_px + 16 * n_px) / 3.0,
         "A.compact": 20 * kn + 168 * kn,                     # candidates in, KeyLine SoA out
         "A.join_retune": (8 + 8 + 4 + 3 * 4 + 8) * kn,
         # 84 B per KeyLine and evaluation (fp64 variant)
@@ -117,7 +119,11 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=40)
     ap.add_argument("--warmup", type=int, default=24)
-    ap.add_argument("--nseq", type=int, default=256, help="independent sequences per GPU (batch dimension)")
+    ap.add_argument("--nseq", type=int, default=512, help="independent sequences per GPU (all contexts together)")
+    ap.add_argument("--contexts", type=int, default=1,
+                    help="edgehip contexts (= HIP streams) the sequences are split over: kernels of different contexts "
+                         "run concurrently, which hides the serial LM-step kernels and launch tails of one context "
+                         "behind the bandwidth-bound kernels of the other")
     ap.add_argument("--pool", type=int, default=24, help="rendered frames in the HBM pool")
     ap.add_argument("--cpu-frames", type=int, default=200, help="frames of the CPU-baseline sample (0 = skip)")
     ap.add_argument("--no-roofline-events", action="store_true")
@@ -143,23 +149,29 @@ def main():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
 
-    B, K, Wm = args.nseq, args.steps, args.warmup
+    C = max(1, args.contexts)
+    B, K, Wm = args.nseq // C, args.steps, args.warmup   # B = sequences per context
     # ---- synthetic frame pool, resident in HBM ----
     frames = [f for f, _, _ in synth.billboard_sequence(W, H, args.pool, seed=11 + rank)]
     pool = torch.from_numpy(np.stack(frames)).cuda()
     torch.cuda.synchronize()
 
-    eh = edgehip.EdgeHip(edgehip.euroc_params(W, H), nseq=B, nslots=3, device=local_rank)
-    eh.set_nav_log(K)
-    offs = np.arange(B, dtype=np.int64) % (2 * (args.pool - 1))  # every sequence starts at its own phase
+    ehs = [edgehip.EdgeHip(edgehip.euroc_params(W, H), nseq=B, nslots=3, device=local_rank) for _ in range(C)]
+    eh = ehs[0]   # the context whose stream carries the HIP-event profiler
+    for e in ehs:
+        e.set_nav_log(K)
+    # every sequence starts at its own phase of the pool
+    offs = [(np.arange(B, dtype=np.int64) + ci * B) % (2 * (args.pool - 1)) for ci in range(C)]
 
     def step(k):
-        idx = np.array([tri(k + o, args.pool) for o in offs], dtype=np.int32)
-        eh.upload_rgb_indexed(eh.next_slot(), pool.data_ptr(), args.pool, idx)
-        eh.process_frame(0.05 * k)
+        for e, off in zip(ehs, offs):
+            idx = np.array([tri(k + o, args.pool) for o in off], dtype=np.int32)
+            e.upload_rgb_indexed(e.next_slot(), pool.data_ptr(), args.pool, idx)
+            e.process_frame(0.05 * k)
 
     def barrier():
-        eh.sync()
+        for e in ehs:
+            e.sync()
         torch.cuda.synchronize()
         if world > 1:
             dist.barrier()
@@ -168,7 +180,8 @@ def main():
     prof_steps = min(4, max(1, Wm // 4))
     for k in range(Wm - prof_steps):
         step(k)
-    eh.sync()
+    for e in ehs:
+        e.sync()
     eh.profile_enable(True)
     eh.profile_select(None)
     for k in range(Wm - prof_steps, Wm):
@@ -187,11 +200,12 @@ def main():
     t0 = time.perf_counter()
     for k in range(Wm, Wm + K):
         step(k)
-    navs = eh.read_nav_log(Wm, K) if world > 1 else None
     if world > 1:
         # nav records of every step -> rank 0 over RCCL (tiny: ~0.5 KB per frame)
-        seq_ids = list(range(rank * B, (rank + 1) * B))
-        shard.gather_records(shard.nav_records(navs, rank, seq_ids), dst=0)
+        for ci, e in enumerate(ehs):
+            navs = e.read_nav_log(Wm, K)
+            seq_ids = list(range((rank * C + ci) * B, (rank * C + ci + 1) * B))
+            shard.gather_records(shard.nav_records(navs, rank, seq_ids), dst=0)
     barrier()
     dt = time.perf_counter() - t0
     if world > 1:
@@ -203,7 +217,7 @@ def main():
     if dominant and not args.no_roofline_events:
         dom_ms, dom_calls = eh.profile_read()[dominant]
         eh.profile_enable(False)
-    last = eh.read_nav()
+    last = [n for e in ehs for n in e.read_nav()]
     kn_mean = float(np.mean([n.kn for n in last]))
     ok = int(sum(n.estimation_ok for n in last))
     evals = last[0].minimizer_evals
@@ -214,7 +228,7 @@ def main():
             dist.destroy_process_group()
         return
 
-    value = B * world * K / dt
+    value = B * C * world * K / dt
     # ---- roofline of the dominant kernel group ----
     roof = None
     if dominant and dom_calls:
@@ -259,8 +273,9 @@ def main():
         "dtype": "f32 scale-space / f64 tracker+EKF", "data": "synthetic",
         "config": {"workload": "full path (configs[2] at configs[1] size): 752x480 synthetic EuRoC-intrinsics "
                                "sequences, GlobalConfig_EuRoC params, ImuMode=0",
-                   "sequences_per_gpu": B, "frames_per_step": B * world, "keylines_per_frame": round(kn_mean, 1),
-                   "tryvelrot_evals_per_frame": evals, "estimation_ok": f"{ok}/{B}",
+                   "sequences_per_gpu": B * C, "contexts_per_gpu": C, "sequences_per_launch": B,
+                   "frames_per_step": B * C * world, "keylines_per_frame": round(kn_mean, 1),
+                   "tryvelrot_evals_per_frame": evals, "estimation_ok": f"{ok}/{B * C}",
                    "algorithmic_MB_per_frame": round(frame_bytes / 1e6, 2),
                    "whole_path_hbm_frac": round(frame_bytes * value / world / 1e9 / HBM_PEAK_GBS, 5)},
         "roofline": roof, "cpu_baseline": cpu, "kernel_us_per_step": breakdown,

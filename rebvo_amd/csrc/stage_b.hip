@@ -578,11 +578,15 @@ __global__ __launch_bounds__(kTvrBlock) void k_try_velrot(TvrArgs a) {
         const double qvel = (a.zfm * dfx * sq->Vt[0] + a.zfm * dfy * sq->Vt[1] + (pix * dfx + piy * dfy) * sq->Vt[2]);
         double q_rho = sqrt(s_rho * qvel * s_rho * qvel + 1);
         if (!REWEIGHT) q_rho = s_rho;
+        // The reference divides the seven values by q_rho one by one; one reciprocal and seven products differ
+        // from that by at most one ulp per value (well inside the fp32-level pose tolerance) and remove six fp64
+        // divisions (~10 double-rate instructions each) from a kernel that is bound by fp64 issue.
+        const double inv_q = 1.0 / q_rho;
         if (PROCJF) {
 #pragma unroll
-            for (int j = 0; j < 6; j++) J[j] /= q_rho;
+            for (int j = 0; j < 6; j++) J[j] *= inv_q;
         }
-        fm /= q_rho;
+        fm *= inv_q;
     }
     int ns = 0;
     if (PROCJF) {

@@ -10,8 +10,9 @@ pool = torch.from_numpy(np.stack(frames)).cuda()
 def tri(k, n):
     p = 2 * (n - 1); k %= p
     return k if k < n else p - k
-for C in [int(a) for a in sys.argv[1:]] or [1, 2, 4]:
-    B = 256 // C
+for spec in sys.argv[1:] or ["1x256", "2x128"]:
+    C, B = (int(v) for v in spec.split("x"))
+    TOT = C * B
     ehs = [edgehip.EdgeHip(edgehip.euroc_params(W, H), nseq=B, nslots=3) for _ in range(C)]
     offs = [(np.arange(B) + i * B) % (2 * (POOL - 1)) for i in range(C)]
     def step(k):
@@ -27,5 +28,5 @@ for C in [int(a) for a in sys.argv[1:]] or [1, 2, 4]:
     for eh in ehs: eh.sync()
     dt = time.perf_counter() - t0
     ok = sum(n.estimation_ok for eh in ehs for n in eh.read_nav())
-    print(f"contexts={C} x nseq={B}: {256*K/dt:.0f} frames/s  ({dt/K*1e3:.3f} ms/step)  ok={ok}/256", flush=True)
+    print(f"contexts={C} x nseq={B}: {TOT*K/dt:.0f} frames/s  ({dt/K*1e3:.3f} ms/step)  ok={ok}/{TOT}", flush=True)
     for eh in ehs: eh.close()

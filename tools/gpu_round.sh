@@ -44,7 +44,7 @@ p = sys.argv[1]
 try:
     js = json.load(open(p))
     line = open(p.replace("pmc.json", "pmc_FETCH_SIZE.json")).read()
-    js["_nseq"] = json.loads(line[line.index("{"):])["config"]["sequences_per_gpu"]
+    js["_nseq"] = json.loads(line[line.index("{"):])["config"]["sequences_per_launch"]
     json.dump(js, open(p, "w"), indent=0, sort_keys=True)
 except Exception as e:
     print("pmc.json not stamped:", e)
