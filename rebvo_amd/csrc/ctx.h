@@ -22,7 +22,9 @@ constexpr int kMaxBoxes = 3;        // bf_num of sspace (rebvo.cpp:299 passes 3)
 constexpr int kBandRows = 12;       // rows per detect block (+4 halo rows in LDS)
 constexpr int kDetWaves = 16;       // waves per detect block; a (band, wave) strip is the raster-order compaction granule
 constexpr int kDivLutMax = 256;     // reciprocal-count LUT entries (box width up to 15)
-constexpr int kTvrBlock = 256;      // threads per TryVelRot block
+constexpr int kTvrThreads = 256;    // threads per TryVelRot block (more KeyLines per block — bigger blocks or several passes — measured slower: the kernel lives on occupancy to hide its two dependent gathers)
+constexpr int kTvrPasses = 1;       // KeyLines per thread
+constexpr int kTvrBlock = kTvrThreads * kTvrPasses;   // KeyLines per block = granule of the residual carries
 constexpr int kNumSums = 28;        // 21 JtJ + 6 JtF + score
 constexpr int kRefRing = 8;         // CBUFSIZE of the reference (frame ring length that FrameCount semantics follow)
 constexpr int kResidBufs = 3;       // Res0, Res1, Rest (global_tracker.cpp:611)

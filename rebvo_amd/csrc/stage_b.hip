@@ -318,7 +318,7 @@ __global__ __launch_bounds__(256) void k_tvr_prepare(const KlSoA *kls, const int
     const int i = blockIdx.x * 256 + threadIdx.x;
     const int kn = kns[seq];
     if (i == 0) seqs[seq].kn_old = kn;
-    if (threadIdx.x == 0) carry0[(size_t)seq * nblk + blockIdx.x] = 0.0;
+    if ((i % kTvrBlock) == 0 && i / kTvrBlock < nblk) carry0[(size_t)seq * nblk + i / kTvrBlock] = 0.0;
     if (i >= kn) return;
     const KlSoA &k = kls[seq];
     const float2 pm = k.p_m[i];
@@ -435,184 +435,205 @@ struct TvrArgs {
 __device__ __forceinline__ bool is_carry(double v) { return __double_as_longlong(v) == (long long)resid_carry_bits(); }
 
 template <bool REWEIGHT, bool PROCJF>
-__global__ __launch_bounds__(kTvrBlock) void k_try_velrot(TvrArgs a) {
+__global__ __launch_bounds__(kTvrThreads) void k_try_velrot(TvrArgs a) {
     const int seq = blockIdx.z, blk = blockIdx.x, tid = threadIdx.x;
     const int lane = tid & 63, wave = tid >> 6;
     SeqDev *sq = a.seq + seq;
     const int kn = a.kn_old[seq];
-    const int ikl = blk * kTvrBlock + tid;
     if (blk * kTvrBlock >= kn) return;  // whole block beyond the list (block-uniform)
     const KlSoA &ko = a.kl_old[seq];
     const int res_in = sq->res_cur, res_out = sq->lm_phase == 0 ? sq->res_t : sq->res_new;
     const double *rin = a.resid + ((size_t)res_in * a.nseq + seq) * a.cap;
     double *rout = a.resid + ((size_t)res_out * a.nseq + seq) * a.cap;
     const double carry_in_prev = a.resid_carry[((size_t)res_in * a.nseq + seq) * a.nblk + blk];
+    const double marker = __longlong_as_double((long long)resid_carry_bits());
 
-    double J[6] = {0, 0, 0, 0, 0, 0};
-    double fm = 0, dfx = 0, dfy = 0;
-    double ptx = 0, pty = 0, ptz = 1, pix = 0, piy = 0, rho_p = 1, s_rho = 1;
-    int mid_f = -1;
-    // status: 0 = skipped (no residual written), 1 = out of image (max_r), 2 = evaluated & matched (own fi),
-    //         3 = evaluated, unmatched (inherits the previous valid fi)
-    int status = 0;
-    double fi = 0;
-    if (ikl < kn) {
-        s_rho = ko.s_rho[ikl];
-        const uint32_t fc = a.framecount[seq];
-        const uint32_t mthr = a.match_num_thresh < fc ? a.match_num_thresh : fc;
-        const bool skip = s_rho > sq->s_rho_min_eval || (uint32_t)ko.m_num[ikl] < mthr;  // int vs uint compare
-        if (!skip) {
-            const double *p0 = a.P0 + (size_t)seq * 3 * a.cap;
-            const double sx = p0[ikl], sy = p0[a.cap + ikl], sz = p0[2 * a.cap + ikl];
-            const double *R = sq->Rt, *V = sq->Vt;
-            // Ne10::SE3on3PMatrix: dst = R(i,0)*x; dst += R(i,1)*y; dst += R(i,2)*z; dst = V + dst
-            ptx = R[0] * sx; ptx += R[1] * sy; ptx += R[2] * sz; ptx = V[0] + ptx;
-            pty = R[3] * sx; pty += R[4] * sy; pty += R[5] * sz; pty = V[1] + pty;
-            ptz = R[6] * sx; ptz += R[7] * sy; ptz += R[8] * sz; ptz = V[2] + ptz;
-            // Ne10::ProyP3toI3PMatrix
-            rho_p = 1 / ptz;
-            const double pz_zf = a.zfm * rho_p;
-            pix = pz_zf * ptx;
-            piy = pz_zf * pty;
-            const double px = pix + (double)a.ppx, py = piy + (double)a.ppy;  // cam_model::Hom2Img
-            const int x = x86_cvttsd2si(px + 0.5), y = x86_cvttsd2si(py + 0.5);
-            double weight = 1;
-            if (REWEIGHT) {
-                double rprev = rin[ikl];
-                if (is_carry(rprev)) rprev = carry_in_prev;
-                if (fabs(rprev) > a.k_huber) weight = a.k_huber / fabs(rprev);
-            }
-            if (x < 1 || y < 1 || x >= a.w - 1 || y >= a.h - 1) {
-                fm = a.max_r;
-                if (REWEIGHT) fm *= weight;
-                status = 1;
-            } else {
-                status = 3;
-                fm = a.max_r;
-                const float2 klm = ko.m_m[ikl];
-                const float knm = ko.n_m[ikl];
-                // temporarily z-rotated gradient, stored back into a float Point2DF (:386-388)
-                const float rmx = (float)(sq->RM[0] * (double)klm.x + sq->RM[1] * (double)klm.y);
-                const float rmy = (float)(sq->RM[2] * (double)klm.x + sq->RM[3] * (double)klm.y);
-                const uint32_t f = a.field[(size_t)seq * a.n + (size_t)y * a.w + x];
-                if (f != 0xFFFFFFFFu) {
-                    const int ikf = 0xFFFF - (int)(f & 0xFFFFu);
-                    const MatchRec fr = a.kl_new[seq].rec[ikf];
-                    // Test_f_k (float arithmetic inside, compared in double)
-                    const double p_n2 = (double)(knm * knm);
-                    const double p_esc = (double)(rmx * fr.m_mx + rmy * fr.m_my);
-                    if (!(fabs(p_esc - p_n2) > a.match_thresh * p_n2)) {
-                        const double dx = px - (double)fr.c_px, dy = py - (double)fr.c_py;
-                        fi = dx * (double)fr.u_mx + dy * (double)fr.u_my;
-                        dfx = (double)fr.u_mx;
-                        dfy = (double)fr.u_my;
-                        fm = fi;
-                        mid_f = ikf;
-                        status = 2;
+    // A block owns kTvrBlock consecutive KeyLines and walks them in kTvrPasses passes of kTvrThreads (pass p, thread
+    // t -> KeyLine blk*kTvrBlock + p*kTvrThreads + t: coalesced, and KeyLine order = (pass, thread) order).  The 28
+    // products of every pass accumulate in registers; the cross-lane reduction runs once per block instead of once
+    // per KeyLine.
+    constexpr int NW = kTvrThreads / 64;   // waves per block
+    __shared__ double s_wlast[kTvrPasses][NW];
+    __shared__ int s_whas[kTvrPasses][NW];
+    double sums[kNumSums];
+#pragma unroll
+    for (int i = 0; i < kNumSums; i++) sums[i] = 0;
+
+#pragma unroll 1
+    for (int pass = 0; pass < kTvrPasses; pass++) {
+        const int base = blk * kTvrBlock + pass * kTvrThreads;
+        if (base >= kn) break;               // block-uniform
+        const int ikl = base + tid;
+        double J[6] = {0, 0, 0, 0, 0, 0};
+        double fm = 0, dfx = 0, dfy = 0;
+        double ptx = 0, pty = 0, ptz = 1, pix = 0, piy = 0, rho_p = 1, s_rho = 1;
+        int mid_f = -1;
+        // status: 0 = skipped (no residual written), 1 = out of image (max_r), 2 = evaluated & matched (own fi),
+        //         3 = evaluated, unmatched (inherits the previous valid fi)
+        int status = 0;
+        double fi = 0;
+        if (ikl < kn) {
+            s_rho = ko.s_rho[ikl];
+            const uint32_t fc = a.framecount[seq];
+            const uint32_t mthr = a.match_num_thresh < fc ? a.match_num_thresh : fc;
+            const bool skip = s_rho > sq->s_rho_min_eval || (uint32_t)ko.m_num[ikl] < mthr;  // int vs uint compare
+            if (!skip) {
+                const double *p0 = a.P0 + (size_t)seq * 3 * a.cap;
+                const double sx = p0[ikl], sy = p0[a.cap + ikl], sz = p0[2 * a.cap + ikl];
+                const double *R = sq->Rt, *V = sq->Vt;
+                // Ne10::SE3on3PMatrix: dst = R(i,0)*x; dst += R(i,1)*y; dst += R(i,2)*z; dst = V + dst
+                ptx = R[0] * sx; ptx += R[1] * sy; ptx += R[2] * sz; ptx = V[0] + ptx;
+                pty = R[3] * sx; pty += R[4] * sy; pty += R[5] * sz; pty = V[1] + pty;
+                ptz = R[6] * sx; ptz += R[7] * sy; ptz += R[8] * sz; ptz = V[2] + ptz;
+                // Ne10::ProyP3toI3PMatrix
+                rho_p = 1 / ptz;
+                const double pz_zf = a.zfm * rho_p;
+                pix = pz_zf * ptx;
+                piy = pz_zf * pty;
+                const double px = pix + (double)a.ppx, py = piy + (double)a.ppy;  // cam_model::Hom2Img
+                const int x = x86_cvttsd2si(px + 0.5), y = x86_cvttsd2si(py + 0.5);
+                double weight = 1;
+                if (REWEIGHT) {
+                    double rprev = rin[ikl];
+                    if (is_carry(rprev)) rprev = carry_in_prev;
+                    if (fabs(rprev) > a.k_huber) weight = a.k_huber / fabs(rprev);
+                }
+                if (x < 1 || y < 1 || x >= a.w - 1 || y >= a.h - 1) {
+                    fm = a.max_r;
+                    if (REWEIGHT) fm *= weight;
+                    status = 1;
+                } else {
+                    status = 3;
+                    fm = a.max_r;
+                    const float2 klm = ko.m_m[ikl];
+                    const float knm = ko.n_m[ikl];
+                    // temporarily z-rotated gradient, stored back into a float Point2DF (:386-388)
+                    const float rmx = (float)(sq->RM[0] * (double)klm.x + sq->RM[1] * (double)klm.y);
+                    const float rmy = (float)(sq->RM[2] * (double)klm.x + sq->RM[3] * (double)klm.y);
+                    const uint32_t f = a.field[(size_t)seq * a.n + (size_t)y * a.w + x];
+                    if (f != 0xFFFFFFFFu) {
+                        const int ikf = 0xFFFF - (int)(f & 0xFFFFu);
+                        const MatchRec fr = a.kl_new[seq].rec[ikf];
+                        // Test_f_k (float arithmetic inside, compared in double)
+                        const double p_n2 = (double)(knm * knm);
+                        const double p_esc = (double)(rmx * fr.m_mx + rmy * fr.m_my);
+                        if (!(fabs(p_esc - p_n2) > a.match_thresh * p_n2)) {
+                            const double dx = px - (double)fr.c_px, dy = py - (double)fr.c_py;
+                            fi = dx * (double)fr.u_mx + dy * (double)fr.u_my;
+                            dfx = (double)fr.u_mx;
+                            dfy = (double)fr.u_my;
+                            fm = fi;
+                            mid_f = ikf;
+                            status = 2;
+                        }
+                    }
+                    if (REWEIGHT) {
+                        fm *= weight;
+                        dfx *= weight;
+                        dfy *= weight;
                     }
                 }
-                if (REWEIGHT) {
-                    fm *= weight;
-                    dfx *= weight;
-                    dfy *= weight;
-                }
             }
+        }
+
+        // ---- DResidualNew: "last valid fi" propagation (KeyLine order = pass, wave, lane) ----
+        {
+            const unsigned long long vmask = __ballot(status == 2);
+            const unsigned long long below = vmask & ((1ull << lane) - 1ull);
+            const int src = below ? 63 - __clzll(below) : 0;
+            const double inh = __shfl(fi, src, 64);
+            const int top = vmask ? 63 - __clzll(vmask) : 0;
+            const double wl = __shfl(fi, top, 64);
+            if (lane == 0) {
+                s_whas[pass][wave] = vmask != 0;
+                s_wlast[pass][wave] = wl;
+            }
+            __syncthreads();   // entries of earlier passes were published by earlier barriers
+            if (status == 3) {
+                double v = marker;   // no valid KeyLine before this one inside the block: resolved from the block carries
+                bool have = false;
+                if (below) { v = inh; have = true; }
+                for (int pp = pass; pp >= 0 && !have; pp--)
+                    for (int pw = (pp == pass ? wave - 1 : NW - 1); pw >= 0 && !have; pw--)
+                        if (s_whas[pp][pw]) { v = s_wlast[pp][pw]; have = true; }
+                rout[ikl] = v;
+            } else if (status == 2) {
+                rout[ikl] = fi;
+            } else if (status == 1) {
+                rout[ikl] = a.max_r;
+            }
+        }
+        if (a.write_mid && ikl < kn) ko.m_id_f[ikl] = mid_f;
+
+        // ---- Jacobian row, uncertainty scaling (global_tracker.cpp:419-463) ----
+        if (ikl < kn) {
+            if (PROCJF) {
+                double t0 = a.zfm * rho_p;
+                J[0] = t0 * dfx;
+                J[1] = t0 * dfy;
+                t0 = rho_p * pix;
+                J[2] = t0 * dfx;
+                t0 = rho_p * piy;
+                J[2] += t0 * dfy;
+                J[3] = J[1] * ptz; J[3] += J[2] * pty;
+                J[4] = J[0] * ptz; J[4] += J[2] * ptx;
+                t0 = J[0] * pty;
+                J[5] = -1 * t0; J[5] += J[1] * ptx;
+            }
+            const double qvel = (a.zfm * dfx * sq->Vt[0] + a.zfm * dfy * sq->Vt[1] + (pix * dfx + piy * dfy) * sq->Vt[2]);
+            double q_rho = sqrt(s_rho * qvel * s_rho * qvel + 1);
+            if (!REWEIGHT) q_rho = s_rho;
+            // The reference divides the seven values by q_rho one by one; one reciprocal and seven products differ
+            // from that by at most one ulp per value (well inside the fp32-level pose tolerance) and remove six fp64
+            // divisions from a kernel that is bound by fp64 issue.
+            const double inv_q = 1.0 / q_rho;
+            if (PROCJF) {
+#pragma unroll
+                for (int j = 0; j < 6; j++) J[j] *= inv_q;
+            }
+            fm *= inv_q;
+        }
+        {
+            int ns = 0;
+            if (PROCJF) {
+#pragma unroll
+                for (int i = 0; i < 6; i++)
+#pragma unroll
+                    for (int j = i; j < 6; j++) sums[ns++] += J[i] * J[j];
+#pragma unroll
+                for (int i = 0; i < 6; i++) sums[ns++] += J[i] * fm;
+            }
+            sums[PROCJF ? ns : kNumSums - 1] += fm * fm;
         }
     }
 
-    // ---- DResidualNew: "last valid fi" propagation ----
-    __shared__ double s_wlast[4];
-    __shared__ int s_whas[4];
-    {
-        const unsigned long long vmask = __ballot(status == 2);
-        const unsigned long long below = vmask & ((1ull << lane) - 1ull);
-        const int src = below ? 63 - __clzll(below) : 0;
-        const double inh = __shfl(fi, src, 64);
-        if (lane == 0) {
-            s_whas[wave] = vmask != 0;
+    // last valid fi of the whole block (marker if none), for the carries of the following blocks
+    if (tid == 0) {
+        double bl = marker;
+        for (int pp = kTvrPasses - 1; pp >= 0 && is_carry(bl); pp--) {
+            if (blk * kTvrBlock + pp * kTvrThreads >= kn) continue;
+            for (int pw = NW - 1; pw >= 0; pw--)
+                if (s_whas[pp][pw]) { bl = s_wlast[pp][pw]; break; }
         }
-        const int top = vmask ? 63 - __clzll(vmask) : 0;
-        const double wl = __shfl(fi, top, 64);
-        if (lane == 0) s_wlast[wave] = wl;
-        __syncthreads();
-        if (status == 3) {
-            double v;
-            bool have = false;
-            if (below) { v = inh; have = true; }
-            else {
-                for (int pw = wave - 1; pw >= 0 && !have; pw--)
-                    if (s_whas[pw]) { v = s_wlast[pw]; have = true; }
-            }
-            if (have) rout[ikl] = v;
-            else rout[ikl] = __longlong_as_double((long long)resid_carry_bits());
-        } else if (status == 2) {
-            rout[ikl] = fi;
-        } else if (status == 1) {
-            rout[ikl] = a.max_r;
-        }
-        if (tid == 0) {
-            double bl = __longlong_as_double((long long)resid_carry_bits());
-            for (int pw = 3; pw >= 0; pw--)
-                if (s_whas[pw]) { bl = s_wlast[pw]; break; }
-            a.block_last[(size_t)seq * a.nblk + blk] = bl;
-        }
+        a.block_last[(size_t)seq * a.nblk + blk] = bl;
     }
-    if (a.write_mid && ikl < kn) ko.m_id_f[ikl] = mid_f;
-
-    // ---- Jacobian row, uncertainty scaling (global_tracker.cpp:419-463) ----
-    double sums[kNumSums];
-    if (ikl < kn) {
-        if (PROCJF) {
-            double t0 = a.zfm * rho_p;
-            J[0] = t0 * dfx;
-            J[1] = t0 * dfy;
-            t0 = rho_p * pix;
-            J[2] = t0 * dfx;
-            t0 = rho_p * piy;
-            J[2] += t0 * dfy;
-            J[3] = J[1] * ptz; J[3] += J[2] * pty;
-            J[4] = J[0] * ptz; J[4] += J[2] * ptx;
-            t0 = J[0] * pty;
-            J[5] = -1 * t0; J[5] += J[1] * ptx;
-        }
-        const double qvel = (a.zfm * dfx * sq->Vt[0] + a.zfm * dfy * sq->Vt[1] + (pix * dfx + piy * dfy) * sq->Vt[2]);
-        double q_rho = sqrt(s_rho * qvel * s_rho * qvel + 1);
-        if (!REWEIGHT) q_rho = s_rho;
-        // The reference divides the seven values by q_rho one by one; one reciprocal and seven products differ
-        // from that by at most one ulp per value (well inside the fp32-level pose tolerance) and remove six fp64
-        // divisions (~10 double-rate instructions each) from a kernel that is bound by fp64 issue.
-        const double inv_q = 1.0 / q_rho;
-        if (PROCJF) {
-#pragma unroll
-            for (int j = 0; j < 6; j++) J[j] *= inv_q;
-        }
-        fm *= inv_q;
-    }
-    int ns = 0;
-    if (PROCJF) {
-#pragma unroll
-        for (int i = 0; i < 6; i++)
-#pragma unroll
-            for (int j = i; j < 6; j++) sums[ns++] = J[i] * J[j];
-#pragma unroll
-        for (int i = 0; i < 6; i++) sums[ns++] = J[i] * fm;
-    }
-    sums[ns++] = fm * fm;
 
     // ---- block reduction: transposed (halving) wave reduction, LDS across waves, one partial per block ----
-    __shared__ double s_red[4][32];
+    __shared__ double s_red[NW][32];
     if (PROCJF) {
         const int idx = wave_reduce28(sums, lane);
         if ((lane & 1) == 0) s_red[wave][idx] = sums[0];
     } else {
-        double v = sums[0];
+        double v = sums[kNumSums - 1];
 #pragma unroll
         for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
         if (lane == 0) s_red[wave][kNumSums - 1] = v;
     }
     __syncthreads();
     if (PROCJF ? tid < kNumSums : tid == kNumSums - 1) {
-        const double v = ((s_red[0][tid] + s_red[1][tid]) + s_red[2][tid]) + s_red[3][tid];
+        double v = s_red[0][tid];
+#pragma unroll
+        for (int wv = 1; wv < NW; wv++) v += s_red[wv][tid];   // fixed order: deterministic
         a.partials[((size_t)seq * a.nblk + blk) * kNumSums + tid] = v;
     }
 }
@@ -1173,7 +1194,7 @@ int build_field_enqueue(edgehip_ctx *c, int slot, int radius, float min_mod) {
 int tvr_prepare_enqueue(edgehip_ctx *c, int slot_old) {
     ProfScope ps(c, PROF_B_PREP);
     const DevicePlan &pl = c->plan;
-    hipLaunchKernelGGL(k_tvr_prepare, dim3(c->nblk_tvr, 1, pl.nseq), dim3(256), 0, c->stream, kldev(c, slot_old),
+    hipLaunchKernelGGL(k_tvr_prepare, dim3((pl.cap + 255) / 256, 1, pl.nseq), dim3(256), 0, c->stream, kldev(c, slot_old),
                        c->kn_slot + (size_t)slot_old * pl.nseq, c->P0, c->resid, c->resid_carry, c->seq, pl.cap,
                        c->nblk_tvr, pl.zfm);
     EH_LAUNCH_CHECK();
@@ -1197,7 +1218,7 @@ static TvrArgs make_tvr_args(edgehip_ctx *c, int slot_new, int slot_old, double 
 
 static int launch_tvr(edgehip_ctx *c, const TvrArgs &a, bool reweight, bool procjf) {
     ProfScope ps(c, PROF_B_TRYVELROT);
-    dim3 g(c->nblk_tvr, 1, c->plan.nseq), b(kTvrBlock);
+    dim3 g(c->nblk_tvr, 1, c->plan.nseq), b(kTvrThreads);
     if (reweight && procjf) hipLaunchKernelGGL((k_try_velrot<true, true>), g, b, 0, c->stream, a);
     else if (reweight) hipLaunchKernelGGL((k_try_velrot<true, false>), g, b, 0, c->stream, a);
     else if (procjf) hipLaunchKernelGGL((k_try_velrot<false, true>), g, b, 0, c->stream, a);
@@ -1306,7 +1327,7 @@ int edgehip_try_velrot(edgehip_ctx *c, int slot_new, int slot_old, const double 
         // keep residual buffers; only refresh P0/kn_old: prepare writes resid0, so save/restore is avoided by
         // launching prepare with a scratch destination when buffer 0 is live
         const DevicePlan &pl = c->plan;
-        hipLaunchKernelGGL(k_tvr_prepare, dim3(c->nblk_tvr, 1, pl.nseq), dim3(256), 0, c->stream, kldev(c, slot_old),
+        hipLaunchKernelGGL(k_tvr_prepare, dim3((pl.cap + 255) / 256, 1, pl.nseq), dim3(256), 0, c->stream, kldev(c, slot_old),
                            c->kn_slot + (size_t)slot_old * pl.nseq, c->P0, c->rs_tmp /*scratch*/, c->block_last /*scratch*/,
                            c->seq, pl.cap, c->nblk_tvr, pl.zfm);
         EH_LAUNCH_CHECK();

@@ -274,27 +274,49 @@ __global__ __launch_bounds__(256) void k_directed(DirArgs a) {
             t_steps = (int)dq_max;
         }
         const double norm_m = (double)knm;
-        double tn = dq_rho, tp = dq_rho + 1;
         int found = -1;
-        for (int t_i = 0; t_i < t_steps && found < 0; t_i++, tp += 1, tn -= 1) {
-            for (int dir = 0; dir < 2 && found < 0; dir++) {
-                double t;
-                if (dir) { t = tp; if (t > dq_max) continue; }
-                else { t = tn; if (t < dq_min) continue; }
-                const float fx = (float)(t_x * t + (double)pi0x), fy = (float)(t_y * t + (double)pi0y);
-                const int xi = (int)roundf(fx), yi = (int)roundf(fy);
-                if (xi >= a.w || yi >= a.h || xi < 0 || yi < 0) continue;
-                const int j = mask[(size_t)yi * a.w + xi];
-                if (j < 0) continue;
-                const MatchRec r = ko.rec[j];
-                const double norm_m0 = (double)r.n_m;
-                const double cang = (double)(r.m_mx * kmm.x + r.m_my * kmm.y) / (norm_m0 * norm_m);
-                if (cang < a.cang_min_edge || fabs(norm_m0 / norm_m - 1) > a.min_thr_mod) continue;
-                const double s_rho = ko.s_rho[j], rho = ko.rho[j];
-                const double v_rho_dr = (a.loc_unc * a.loc_unc + s_rho * s_rho * norm_t * norm_t + sigma2_t * rho * rho);
-                const double dd = t - norm_t * rho;
-                if (dd * dd > v_rho_dr) continue;
-                found = j;
+        // search_match walks t_i = 0,1,2,... probing first tn = dq_rho - t_i, then tp = dq_rho + 1 + t_i, and stops at
+        // the first candidate that passes the tests (edge_tracker.cpp:239-292).  The probe POSITIONS do not depend
+        // on earlier probes, so the mask reads of DM_CH steps (2*DM_CH gathers) are issued together and only then
+        // examined in the reference's order: the dependent-latency chain shrinks DM_CH-fold, the result is identical.
+        constexpr int DM_CH = 2;
+        double tn = dq_rho, tp = dq_rho + 1;   // advanced by repeated -= 1 / += 1 exactly as the reference does
+        for (int t0i = 0; t0i < t_steps && found < 0; t0i += DM_CH) {
+            double tv[DM_CH][2];
+            int jm[DM_CH][2];
+#pragma unroll
+            for (int c = 0; c < DM_CH; c++) {
+                tv[c][0] = tn; tv[c][1] = tp;
+                tn -= 1; tp += 1;
+#pragma unroll
+                for (int dir = 0; dir < 2; dir++) {
+                    const double t = tv[c][dir];
+                    jm[c][dir] = -1;
+                    if (t0i + c >= t_steps) continue;
+                    if (dir ? t > dq_max : t < dq_min) continue;
+                    const float fx = (float)(t_x * t + (double)pi0x), fy = (float)(t_y * t + (double)pi0y);
+                    const int xi = (int)roundf(fx), yi = (int)roundf(fy);
+                    if (xi >= a.w || yi >= a.h || xi < 0 || yi < 0) continue;
+                    jm[c][dir] = mask[(size_t)yi * a.w + xi];
+                }
+            }
+#pragma unroll
+            for (int c = 0; c < DM_CH; c++) {
+#pragma unroll
+                for (int dir = 0; dir < 2; dir++) {
+                    const int j = jm[c][dir];
+                    if (j < 0 || found >= 0) continue;
+                    const double t = tv[c][dir];
+                    const MatchRec r = ko.rec[j];
+                    const double norm_m0 = (double)r.n_m;
+                    const double cang = (double)(r.m_mx * kmm.x + r.m_my * kmm.y) / (norm_m0 * norm_m);
+                    if (cang < a.cang_min_edge || fabs(norm_m0 / norm_m - 1) > a.min_thr_mod) continue;
+                    const double s_rho = ko.s_rho[j], rho = ko.rho[j];
+                    const double v_rho_dr = (a.loc_unc * a.loc_unc + s_rho * s_rho * norm_t * norm_t + sigma2_t * rho * rho);
+                    const double dd = t - norm_t * rho;
+                    if (dd * dd > v_rho_dr) continue;
+                    found = j;
+                }
             }
         }
         if (found >= 0) {
