@@ -736,6 +736,34 @@ __global__ __launch_bounds__(kDetWaves * 64) void k_detect(DetectArgs a) {
 #pragma unroll
     for (int j = 0; j < 5; j++) { pc0[j] = s_pinv[j]; pc1[j] = s_pinv[25 + 5 * j]; }
     const double pc2 = s_pinv[50];
+    // 2b': the DoG sign-balance test (:125-137) needs no arithmetic: run it first and compact the list once more
+    // (in place: the write index never passes the read index), so the fp64 plane fit below runs with full lanes on
+    // the pixels that can still become KeyLines.
+    if (!(a.ablate & 4)) {
+        int nkeep = 0;
+        for (int base = 0; base < nlist; base += 64) {
+            const int li = base + lane;
+            bool keep = false;
+            uint16_t qv = 0;
+            if (li < nlist) {
+                qv = s_list[li];
+                const int q = qv;
+                const int r = q / w, x = q - r * w;
+                const float *dg = s_dog + (size_t)(r + 2) * w + x;
+                int pn = 0;
+#pragma unroll
+                for (int i = -2; i <= 2; i++)
+#pragma unroll
+                    for (int j = -2; j <= 2; j++) pn += (dg[i * w + j] > 0) ? 1 : -1;
+                const int apn = pn < 0 ? -pn : pn;
+                keep = !((double)apn > a.pn_thresh);
+            }
+            const unsigned long long bal = __ballot(keep);   // every lane has read its entry before any lane writes
+            if (keep) s_list[nkeep + __popcll(bal & ((1ull << lane) - 1ull))] = qv;
+            nkeep += __popcll(bal);
+        }
+        nlist = nkeep;
+    }
     int count = 0;  // wave-uniform running count of the strip
     for (int base = 0; base < ((a.ablate & 4) ? 0 : nlist); base += 64) {
         const int li = base + lane;
@@ -747,22 +775,19 @@ __global__ __launch_bounds__(kDetWaves * 64) void k_detect(DetectArgs a) {
             const int r = q / w, x = q - r * w;
             pix = (y0 + r) * w + x;
             const float *dg = s_dog + (size_t)(r + 2) * w + x;
-            int pn = 0;
             double t0 = 0, t1 = 0, t2 = 0;
 #pragma unroll
             for (int i = -2, k = 0; i <= 2; i++) {
 #pragma unroll
                 for (int j = -2; j <= 2; j++, k++) {
                     const float v = dg[i * w + j];
-                    pn += (v > 0) ? 1 : -1;
                     const double yv = (double)v;
                     t0 += pc0[j + 2] * yv;         // TooN dot product: result += a[i]*b[i], k = 0..24 in order
                     t1 += pc1[i + 2] * yv;
                     t2 += pc2 * yv;
                 }
             }
-            const int apn = pn < 0 ? -pn : pn;
-            if (!((double)apn > a.pn_thresh)) {
+            {
                 const double den = t0 * t0 + t1 * t1;
                 xs = (float)(-t0 * t2 / den);
                 ys = (float)(-t1 * t2 / den);
