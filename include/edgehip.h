@@ -170,6 +170,15 @@ int edgehip_download_resid(edgehip_ctx *ctx, int which, double *resid);
  * them, no host round trip).  Reads seq_state.V/W/s_rho_q, writes V, W, P_V, P_W, score, rel_error*. */
 int edgehip_minimizer_rv(edgehip_ctx *ctx, int slot_new, int slot_old);
 
+/* global_tracker::Minimizer_V<double> (IMU branch, rebvo_second_t.cpp:223; global_tracker.cpp:1037-1093 with
+ * TryVel :830-934 and Calc_f_J :178-219): translation-only Levenberg-Marquardt of the old slot's KeyLines (already
+ * rotated by the gyro estimate) against the new slot's field.  V[nseq][3] in/out, s_rho_min[nseq], min_mod < 0
+ * takes each sequence's retuned threshold of the OLD slot (old_buf.ef->getThresh()); RVel[nseq][9] and F[nseq]
+ * may be NULL.  FrameCount is read, not incremented (as in the reference).  Synchronises. */
+int edgehip_minimizer_v(edgehip_ctx *ctx, int slot_new, int slot_old, double *V, const double *s_rho_min, float min_mod,
+                        double match_thresh, int iter_max, uint32_t match_num_thresh, double reweight_distance,
+                        double *RVel, double *F);
+
 /* ---- stage C: matching + mapping ------------------------------------------------------------------- */
 /* edge_tracker::FordwardMatch (rebvo_second_t.cpp:354; edge_tracker.cpp:380-436). */
 int edgehip_forward_match(edgehip_ctx *ctx, int slot_old, int slot_new);

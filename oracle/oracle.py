@@ -191,6 +191,7 @@ class Oracle:
         self._field = fn("field", C.POINTER(C.c_int32), vp, i)
         self._try_velrot = fn("try_velrot", d, vp, i, i, pd, i, i, d, d, u, d, pd, pd, pd, pd)
         self._minimizer_rv = fn("minimizer_rv", d, vp, i, i, pd, pd, pd, pd, d, i, i, d, pd, pd, d, u, d, pd)
+        self._minimizer_v = fn("minimizer_v", d, vp, i, i, pd, pd, d, i, d, u, d, C.c_float)
         self._forward_match = fn("forward_match", i, vp, i, i)
         self._rotate = fn("rotate_keylines", None, vp, i, pd)
         self._directed = fn("directed_matching", i, vp, i, i, pd, pd, pd, pi, d, d, d, d)
@@ -293,6 +294,14 @@ class Oracle:
                                iter_max, init_type, reweight_distance, C.byref(re), C.byref(res), max_s_rho,
                                match_num_thresh, float(init_iter), _dp(WX))
         return dict(F=F, V=V, W=W, RVel=RV, RW0=RW, W_X=WX, rel_error=re.value, rel_error_score=res.value)
+
+    def minimizer_v(self, slot_new, slot_old, V, match_thresh, iter_max, s_rho_min, match_num_thresh, reweight_distance, min_mod):
+        """global_tracker::Minimizer_V<double> (IMU branch) -> dict(F, V, RVel)."""
+        V = np.array(V, dtype=np.float64)
+        RV = np.zeros((3, 3))
+        F = self._minimizer_v(self.ctx, slot_new, slot_old, _dp(V), _dp(RV), match_thresh, iter_max, s_rho_min, match_num_thresh,
+                              reweight_distance, min_mod)
+        return dict(F=F, V=V, RVel=RV)
 
     # ---- stage C -------------------------------------------------------------------------------
     def forward_match(self, slot_old, slot_new):

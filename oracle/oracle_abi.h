@@ -101,6 +101,10 @@ typedef struct OrcNav {
                             int init_type, double reweight_distance, double *rel_error,                  \
                             double *rel_error_score, double max_s_rho, unsigned match_num_thresh,        \
                             double init_iter, double W_X[36]);                                           \
+    /* global_tracker::Minimizer_V<double> (IMU branch): V in/out, RVel out; returns the score F */     \
+    double P##_minimizer_v(void *ctx, int slot_new, int slot_old, double V[3], double RVel[9],           \
+                           double match_thresh, int iter_max, double s_rho_min,                          \
+                           unsigned match_num_thresh, double reweight_distance, float min_mod);          \
     /* stage C */                                                                                        \
     int P##_forward_match(void *ctx, int slot_old, int slot_new);                                        \
     void P##_rotate_keylines(void *ctx, int slot, const double R[9]);                                    \

@@ -73,6 +73,9 @@ double minimizer_rv(Ctx &c, Slot &gt, Slot &klist, double Vel[3], double W0[3], 
                     int iter_max, int init_type, double reweigth_distance, double &rel_error, double &rel_error_score,
                     double max_s_rho, unsigned MatchNumThresh, double init_iter, double W_X[36]);
 
+double minimizer_v(Ctx &c, Slot &gt, Slot &klist, double Vel[3], double RVel[9], double match_thresh, int iter_max,
+                   double s_rho_min, unsigned MatchNumThresh, double reweigth_distance, float min_mod);
+
 // stage C (edgeport_c.cpp)
 int forward_match(Slot &from, Slot &et);
 void rotate_keylines(const Ctx &c, Slot &s, const double RotF[9]);

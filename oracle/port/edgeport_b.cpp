@@ -354,4 +354,142 @@ double minimizer_rv(Ctx &c, Slot &gt, Slot &klist, double Vel[3], double W0[3], 
     return F;
 }
 
+// ---- util::Matrix3x3Inv (include/UtilLib/toon_util.h:32-41) with TooN::determinant = Gaussian elimination with
+// partial pivoting (TooN/determinant.h:91-146; TOON_DETERMINANT_LAPACK is not set in the vendored config) ---------
+static double det3_ge(const double Ain[9]) {
+    double A[9];
+    for (int i = 0; i < 9; i++) A[i] = Ain[i];
+    double det = 1;
+    for (int i = 0; i < 3; i++) {
+        int argmax = i;
+        double maxval = std::fabs(A[i * 3 + i]);
+        for (int ii = i + 1; ii < 3; ii++) {
+            const double v = std::fabs(A[ii * 3 + i]);
+            if (v > maxval) { maxval = v; argmax = ii; }
+        }
+        const double pivot = A[argmax * 3 + i];
+        if (argmax != i) {
+            det *= -1;
+            for (int j = i; j < 3; j++) std::swap(A[i * 3 + j], A[argmax * 3 + j]);
+        }
+        det *= A[i * 3 + i];
+        if (det == 0) return 0;
+        for (int u = i + 1; u < 3; u++) {
+            const double factor = A[u * 3 + i] / pivot;
+            for (int j = i + 1; j < 3; j++) A[u * 3 + j] = A[u * 3 + j] - factor * A[i * 3 + j];
+        }
+    }
+    return det;
+}
+static void mat3_inv(const double A[9], double B[9]) {
+    B[0] = A[8] * A[4] - A[7] * A[5]; B[1] = -(A[8] * A[1] - A[7] * A[2]); B[2] = A[5] * A[1] - A[4] * A[2];
+    B[3] = -(A[8] * A[3] - A[6] * A[5]); B[4] = A[8] * A[0] - A[6] * A[2]; B[5] = -(A[5] * A[0] - A[3] * A[2]);
+    B[6] = A[7] * A[3] - A[6] * A[4]; B[7] = -(A[7] * A[0] - A[6] * A[1]); B[8] = A[4] * A[0] - A[3] * A[1];
+    const double det = det3_ge(A);
+    for (int i = 0; i < 9; i++) B[i] = B[i] / det;
+}
+
+// ---- global_tracker::TryVel<double> + Calc_f_J (global_tracker.cpp:830-934, 178-219) -----------------------------------
+static double try_vel(Ctx &c, Slot &gt, Slot &klist, double JtJ[9], double JtF[3], const double Vel[3], double match_thresh,
+                      double s_rho_min, unsigned MatchNumThresh, double *Residuals, double reweigth_distance, float min_mod) {
+    const int w = c.p.w, h = c.p.h;
+    const Slot &fl = c.slots[gt.field_slot];
+    double score = 0, f;
+    for (int i = 0; i < 9; i++) JtJ[i] = 0;
+    for (int i = 0; i < 3; i++) JtF[i] = 0;
+    double fi = 0;
+    const double max_r = gt.max_r;
+    const unsigned mthr = std::min(MatchNumThresh, gt.FrameCount);
+    for (int ikl = 0; ikl < klist.kn; ikl++) {
+        OrcKeyLine &kl = klist.kl[ikl];
+        kl.m_id_f = -1;
+        if (min_mod > 0 && kl.n_m < min_mod) continue;
+        if (kl.s_rho > s_rho_min || (unsigned)kl.m_num < mthr) continue;
+        double weight = 1;
+        if (Residuals[ikl] > reweigth_distance) weight = reweigth_distance / Residuals[ikl];
+        const double z_p = 1.0 / kl.rho + Vel[2];
+        if (z_p <= 0) {
+            f = (1 / (kl.s_rho)) * max_r * weight;
+            score += f * f;
+            continue;
+        }
+        const double rho_p = 1.0 / z_p;
+        const double pjx = rho_p * (Vel[0] * c.zfm - Vel[2] * kl.p_m[0]) + kl.p_m[0];
+        const double pjy = rho_p * (Vel[1] * c.zfm - Vel[2] * kl.p_m[1]) + kl.p_m[1];
+        const double pix = pjx + c.ppx, piy = pjy + c.ppy;                      // cam_model::Hom2Img
+        const int x = (int)(pix + 0.5), y = (int)(piy + 0.5);
+        if (x < 1 || y < 1 || x >= w - 1 || y >= h - 1) {
+            f = (1 / (kl.s_rho)) * max_r * weight;
+            score += f * f;
+            continue;
+        }
+        double df_dx = 0, df_dy = 0;
+        f = max_r / kl.s_rho;                                                    // Calc_f_J
+        const int fikl = gt.field[2 * ((size_t)y * w + x) + 1];
+        if (fikl >= 0) {
+            const OrcKeyLine &f_kl = fl.kl[fikl];
+            const double p_n2 = (kl.n_m * kl.n_m);
+            const double p_esc = kl.m_m[0] * f_kl.m_m[0] + kl.m_m[1] * f_kl.m_m[1];
+            if (!(std::fabs(p_esc - p_n2) > match_thresh * p_n2)) {
+                const double dx = pix - f_kl.c_p[0], dy = piy - f_kl.c_p[1];
+                fi = (dx * f_kl.u_m[0] + dy * f_kl.u_m[1]);
+                df_dx = f_kl.u_m[0] / kl.s_rho;
+                df_dy = f_kl.u_m[1] / kl.s_rho;
+                kl.m_id_f = fikl;
+                f = fi / kl.s_rho;
+            }
+        }
+        f *= weight;
+        score += f * f;
+        const double jx = rho_p * c.zfm * df_dx * weight;
+        const double jy = rho_p * c.zfm * df_dy * weight;
+        const double jz = -rho_p * (pjx * df_dx + pjy * df_dy) * weight;
+        JtJ[0] += jx * jx; JtJ[4] += jy * jy; JtJ[8] += jz * jz;
+        JtJ[1] += jx * jy; JtJ[2] += jx * jz; JtJ[5] += jy * jz;
+        JtF[0] += jx * f; JtF[1] += jy * f; JtF[2] += jz * f;
+        Residuals[ikl] = std::fabs(fi);
+    }
+    JtJ[3] = JtJ[1]; JtJ[6] = JtJ[2]; JtJ[7] = JtJ[5];
+    return score;
+}
+
+// ---- global_tracker::Minimizer_V<double> (global_tracker.cpp:1037-1093) -------------------------------------------------
+double minimizer_v(Ctx &c, Slot &gt, Slot &klist, double Vel[3], double RVel[9], double match_thresh, int iter_max,
+                   double s_rho_min, unsigned MatchNumThresh, double reweigth_distance, float min_mod) {
+    double JtJ[9], ApI[9], JtJnew[9], JtF[3], JtFnew[3], h[3], Vnew[3], Inv[9];
+    std::vector<double> residuals(std::max(klist.kn, 1), 0.0);
+    double F = try_vel(c, gt, klist, JtJ, JtF, Vel, match_thresh, s_rho_min, MatchNumThresh, residuals.data(), reweigth_distance, min_mod), Fnew;
+    double v = 2, tau = 1e-3;
+    double mx = JtJ[0];
+    for (int i = 1; i < 9; i++) mx = JtJ[i] > mx ? JtJ[i] : mx;
+    double u = tau * mx, gain;
+    for (int lm_iter = 0; lm_iter < iter_max; lm_iter++) {
+        for (int i = 0; i < 9; i++) ApI[i] = JtJ[i] + ((i % 4 == 0) ? 1.0 * u : 0.0);
+        mat3_inv(ApI, Inv);
+        for (int i = 0; i < 3; i++) {
+            double d = 0;
+            for (int k = 0; k < 3; k++) d += Inv[i * 3 + k] * (-JtF[k]);
+            h[i] = d;
+            Vnew[i] = Vel[i] + h[i];
+        }
+        Fnew = try_vel(c, gt, klist, JtJnew, JtFnew, Vnew, match_thresh, s_rho_min, MatchNumThresh, residuals.data(), reweigth_distance, min_mod);
+        double den = 0;
+        for (int i = 0; i < 3; i++) den += (0.5 * h[i]) * (u * h[i] - JtF[i]);
+        gain = (F - Fnew) / den;
+        if (gain > 0) {
+            F = Fnew;
+            for (int i = 0; i < 3; i++) { Vel[i] = Vnew[i]; JtF[i] = JtFnew[i]; }
+            for (int i = 0; i < 9; i++) JtJ[i] = JtJnew[i];
+            const double g = 2 * gain - 1;
+            u *= std::max(0.33, 1 - (g * g * g));
+            v = 2;
+        } else {
+            u *= v;
+            v *= 2;
+        }
+    }
+    mat3_inv(JtJ, RVel);
+    return F;
+}
+
 }  // namespace port

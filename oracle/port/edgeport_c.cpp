@@ -363,6 +363,12 @@ double port_minimizer_rv(void *ctx, int slot_new, int slot_old, double V[3], dou
     return minimizer_rv(*c, c->slots[slot_new], c->slots[slot_old], V, W, RVel, RW0, match_thresh, iter_max, init_type,
                         reweight_distance, *rel_error, *rel_error_score, max_s_rho, match_num_thresh, init_iter, W_X);
 }
+double port_minimizer_v(void *ctx, int slot_new, int slot_old, double V[3], double RVel[9], double match_thresh, int iter_max,
+                        double s_rho_min, unsigned match_num_thresh, double reweight_distance, float min_mod) {
+    Ctx *c = (Ctx *)ctx;
+    return minimizer_v(*c, c->slots[slot_new], c->slots[slot_old], V, RVel, match_thresh, iter_max, s_rho_min, match_num_thresh,
+                       reweight_distance, min_mod);
+}
 int port_forward_match(void *ctx, int slot_old, int slot_new) {
     Ctx *c = (Ctx *)ctx;
     return forward_match(c->slots[slot_old], c->slots[slot_new]);

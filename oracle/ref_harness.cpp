@@ -301,6 +301,18 @@ double ref_minimizer_rv(void *ctx, int slot_new, int slot_old, double V[3], doub
     return F;
 }
 
+double ref_minimizer_v(void *ctx, int slot_new, int slot_old, double V[3], double RVel[9], double match_thresh,
+                       int iter_max, double s_rho_min, unsigned match_num_thresh, double reweight_distance, float min_mod) {
+    Ctx *c = (Ctx *)ctx;
+    Vector<3> Vv = v3(V);
+    Matrix<3, 3> RV = Identity;
+    double F = c->slots[slot_new].gt->Minimizer_V<double>(Vv, RV, *c->slots[slot_old].ef, match_thresh, iter_max, s_rho_min,
+                                                          match_num_thresh, reweight_distance, min_mod);   // rebvo_second_t.cpp:223
+    putv(V, Vv);
+    put3(RVel, RV);
+    return F;
+}
+
 int ref_forward_match(void *ctx, int slot_old, int slot_new) {
     Ctx *c = (Ctx *)ctx;
     return c->slots[slot_old].ef->FordwardMatch(c->slots[slot_new].ef);

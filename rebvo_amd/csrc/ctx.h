@@ -64,6 +64,10 @@ struct SeqDev {
     double s_rho_min_eval;     // s_rho threshold of the running evaluation
     double Rt[9], Vt[3], RM[4];  // rotation / translation / z-rotation of the running evaluation
     int32_t nmatch_tmp, kf_tmp;
+    // 3-DoF minimiser scratch (global_tracker::Minimizer_V locals)
+    double mv_V[3], mv_Vnew[3], mv_h[3], mv_JtJ[9], mv_JtF[3], mv_JtJnew[9], mv_JtFnew[3], mv_RVel[9];
+    double mv_F, mv_Fnew, mv_u, mv_v, mv_s_rho_min;
+    float mv_min_mod; int32_t mv_pad;
     // per-frame glue (SecondThread locals)
     int32_t skip_match, skip_map;   // NaN estimate / too few matches: later stages are no-ops
     double t_cur;
@@ -77,6 +81,15 @@ struct DevicePlan {  // everything a kernel needs that is constant for the conte
     float ppx, ppy, zfx, zfy;       // cam_model keeps these as float (cam_model.h:51-52)
     double zfm;                     // (double)((zfx+zfy)/2) computed in float (cam_model.h:57)
 };
+
+// round() as Image::GetIndexRC uses it (half away from zero), without the library call: round-to-nearest-even is
+// one instruction and differs from round() only on exact .5 ties, which are detected exactly (v - r is exact).
+__device__ __forceinline__ int round_half_away_i(float v) {
+    float r = rintf(v);
+    const float d = v - r;
+    if (fabsf(d) == 0.5f && (d > 0.f) == (v > 0.f)) r = v + d;   // tie that rintf resolved towards zero: take the other neighbour
+    return (int)r;
+}
 
 struct Profiler;
 
@@ -197,6 +210,8 @@ int quantile_enqueue(edgehip_ctx *c, int slot, double smin, double smax, double 
 int build_field_enqueue(edgehip_ctx *c, int slot, int radius, float min_mod);
 int tvr_prepare_enqueue(edgehip_ctx *c, int slot_old);
 int minimizer_enqueue(edgehip_ctx *c, int slot_new, int slot_old, int fc_index);
+int minimizer_v_enqueue(edgehip_ctx *c, int slot_new, int slot_old, int fc_index, int iter_max, double match_thresh,
+                         uint32_t match_num_thresh, double reweight_distance);
 int forward_match_enqueue(edgehip_ctx *c, int slot_old, int slot_new);
 int rotate_enqueue(edgehip_ctx *c, int slot, const double *R_host);
 int directed_enqueue(edgehip_ctx *c, int slot_new, int slot_old);

@@ -29,6 +29,8 @@
 #include <math.h>
 #include <string.h>
 
+#include <vector>
+
 #include "ctx.h"
 
 namespace edgehip {
@@ -88,7 +90,7 @@ __global__ __launch_bounds__(256) void k_field_scatter(const KlSoA *kls, const i
     if (min_mod > 0 && r.n_m < min_mod) return;
     const float fx = r.u_mx * (float)t + r.c_px;
     const float fy = r.u_my * (float)t + r.c_py;
-    const int xi = (int)roundf(fx), yi = (int)roundf(fy);  // Image::GetIndexRC uses round()
+    const int xi = round_half_away_i(fx), yi = round_half_away_i(fy);  // Image::GetIndexRC uses round()
     if (xi >= w || yi >= h || xi < 0 || yi < 0) return;
     const uint32_t at = (uint32_t)(t < 0 ? -t : t);
     atomicMin(&field[(size_t)seq * n + (size_t)yi * w + xi], (at << 16) | (uint32_t)(0xFFFF - ikl));
@@ -166,7 +168,7 @@ __global__ __launch_bounds__(256) void k_field_tiles(const KlSoA *kls, const int
             for (int t = max(t0, -radius); t <= min(t1, radius - 1); t++) {
                 const float fx = r.u_mx * (float)t + r.c_px;
                 const float fy = r.u_my * (float)t + r.c_py;
-                const int xi = (int)roundf(fx), yi = (int)roundf(fy);  // Image::GetIndexRC uses round()
+                const int xi = round_half_away_i(fx), yi = round_half_away_i(fy);  // Image::GetIndexRC uses round()
                 if (xi >= w || yi >= h || xi < 0 || yi < 0) continue;
                 const int lx = xi - tx0, ly = yi - ty0;
                 if ((unsigned)lx >= (unsigned)FT || (unsigned)ly >= (unsigned)FT) continue;
@@ -282,6 +284,9 @@ __global__ __launch_bounds__(256) void k_field_raster(const KlSoA *kls, const in
     const int cnt = min(bin_cnt[(size_t)seq * kMaxTiles + tile], bin_cap);
     const int32_t *list = bins + ((size_t)seq * ntiles + tile) * bin_cap;
     const KlSoA &k = kls[seq];
+    // in-tile AND in-image in two unsigned compares: lx >= 0 implies xi >= tx0 >= 0, and the tile is clipped to
+    // the image once per block
+    const unsigned ex = (unsigned)min(FT, w - tx0), ey = (unsigned)min(FT, h - ty0);
     for (int li = tid; li < cnt; li += 256) {
         const int ikl = list[li];
         const MatchRec r = k.rec[ikl];
@@ -291,10 +296,8 @@ __global__ __launch_bounds__(256) void k_field_raster(const KlSoA *kls, const in
         for (int t = t0; t <= t1; t++) {
             const float fx = r.u_mx * (float)t + r.c_px;   // global_tracker.cpp:78, same float expression
             const float fy = r.u_my * (float)t + r.c_py;
-            const int xi = (int)roundf(fx), yi = (int)roundf(fy);  // Image::GetIndexRC uses round()
-            if (xi >= w || yi >= h || xi < 0 || yi < 0) continue;
-            const int lx = xi - tx0, ly = yi - ty0;
-            if ((unsigned)lx >= (unsigned)FT || (unsigned)ly >= (unsigned)FT) continue;
+            const int lx = round_half_away_i(fx) - tx0, ly = round_half_away_i(fy) - ty0;  // Image::GetIndexRC uses round()
+            if ((unsigned)lx >= ex || (unsigned)ly >= ey) continue;
             const uint32_t at = (uint32_t)(t < 0 ? -t : t);
             atomicMin(&s_tile[ly * FT + lx], (at << 16) | idk);
         }
@@ -1136,6 +1139,259 @@ __global__ __launch_bounds__(64) void k_lm_step(LmArgs a) {
     for (int i = lane; i < kWords; i += 64) gstate[i] = s_state[i];
 }
 
+// ---------------------------------------------------------------------------------------------------
+// IMU-branch tracker: global_tracker::TryVel<double> + Calc_f_J (global_tracker.cpp:830-934, 178-219) and
+// Minimizer_V<double> (:1037-1093) — translation only (the rotation was applied to the KeyLines beforehand),
+// weights 1/s_rho, one residual buffer updated in place (Residuals[ikl] = |fi|).
+// The reference accumulates the 9 sums + score sequentially in double; here: wave butterfly + fixed-order
+// partials (deterministic; agrees to fp64 rounding, not bit for bit — tolerance stated in the test).
+// ---------------------------------------------------------------------------------------------------
+constexpr int kTvNum = 10;   // JtJ(0,0) (1,1) (2,2) (0,1) (0,2) (1,2), JtF[0..2], score
+
+template <bool USE_NEW>
+__global__ __launch_bounds__(256) void k_try_vel(TvrArgs a) {
+    const int seq = blockIdx.z, blk = blockIdx.x, tid = threadIdx.x;
+    const int lane = tid & 63, wave = tid >> 6;
+    SeqDev *sq = a.seq + seq;
+    const int kn = a.kn_old[seq];
+    if (blk * 256 >= kn) return;
+    const int ikl = blk * 256 + tid;
+    const KlSoA &ko = a.kl_old[seq];
+    double *res = a.resid + (size_t)seq * a.cap;            // residual buffer 0, updated in place
+    const double marker = __longlong_as_double((long long)resid_carry_bits());
+    const double *V = USE_NEW ? sq->mv_Vnew : sq->mv_V;
+    const double v0 = V[0], v1 = V[1], v2 = V[2];
+    double s[kTvNum];
+#pragma unroll
+    for (int i = 0; i < kTvNum; i++) s[i] = 0;
+    // status: 0 skipped / no residual written, 2 matched (own fi), 3 evaluated but unmatched (inherits fi)
+    int status = 0, mid_f = -1;
+    double fi = 0;
+    if (ikl < kn) {
+        const float nm = ko.n_m[ikl];
+        const double s_rho = ko.s_rho[ikl];
+        const uint32_t fc = a.framecount[seq];
+        const uint32_t mthr = a.match_num_thresh < fc ? a.match_num_thresh : fc;
+        const float min_mod = sq->mv_min_mod;
+        const bool skip = (min_mod > 0 && nm < min_mod) || s_rho > sq->mv_s_rho_min || (uint32_t)ko.m_num[ikl] < mthr;
+        if (!skip) {
+            double weight = 1;
+            const double rprev = res[ikl];
+            if (rprev > a.k_huber) weight = a.k_huber / rprev;
+            const float2 pm = ko.p_m[ikl];
+            const double z_p = 1.0 / ko.rho[ikl] + v2;
+            bool done = false;
+            double f = 0, rho_p = 0, pjx = 0, pjy = 0;
+            int x = 0, y = 0;
+            double pix = 0, piy = 0;
+            if (z_p <= 0) {
+                f = (1 / s_rho) * a.max_r * weight;
+                done = true;
+            } else {
+                rho_p = 1.0 / z_p;
+                pjx = rho_p * (v0 * a.zfm - v2 * (double)pm.x) + (double)pm.x;
+                pjy = rho_p * (v1 * a.zfm - v2 * (double)pm.y) + (double)pm.y;
+                pix = pjx + (double)a.ppx; piy = pjy + (double)a.ppy;       // cam_model::Hom2Img
+                x = x86_cvttsd2si(pix + 0.5); y = x86_cvttsd2si(piy + 0.5);
+                if (x < 1 || y < 1 || x >= a.w - 1 || y >= a.h - 1) {
+                    f = (1 / s_rho) * a.max_r * weight;
+                    done = true;
+                }
+            }
+            if (done) {
+                s[9] = f * f;
+            } else {
+                status = 3;
+                double dfx = 0, dfy = 0;
+                f = a.max_r / s_rho;                                       // Calc_f_J: no KeyLine / no similarity
+                const uint32_t fv = a.field[(size_t)seq * a.n + (size_t)y * a.w + x];
+                if (fv != 0xFFFFFFFFu) {
+                    const int ikf = 0xFFFF - (int)(fv & 0xFFFFu);
+                    const MatchRec fr = a.kl_new[seq].rec[ikf];
+                    const float2 klm = ko.m_m[ikl];
+                    const double p_n2 = (double)(nm * nm);                 // Test_f_k
+                    const double p_esc = (double)(klm.x * fr.m_mx + klm.y * fr.m_my);
+                    if (!(fabs(p_esc - p_n2) > a.match_thresh * p_n2)) {
+                        const double dx = pix - (double)fr.c_px, dy = piy - (double)fr.c_py;
+                        fi = dx * (double)fr.u_mx + dy * (double)fr.u_my;
+                        dfx = (double)fr.u_mx / s_rho;
+                        dfy = (double)fr.u_my / s_rho;
+                        f = fi / s_rho;
+                        mid_f = ikf;
+                        status = 2;
+                    }
+                }
+                f *= weight;
+                const double jx = rho_p * a.zfm * dfx * weight;
+                const double jy = rho_p * a.zfm * dfy * weight;
+                const double jz = -rho_p * (pjx * dfx + pjy * dfy) * weight;
+                s[0] = jx * jx; s[1] = jy * jy; s[2] = jz * jz; s[3] = jx * jy; s[4] = jx * jz; s[5] = jy * jz;
+                s[6] = jx * f; s[7] = jy * f; s[8] = jz * f; s[9] = f * f;
+            }
+        }
+    }
+    // Residuals[ikl] = fabs(fi) with fi only refreshed by a match: "last valid" propagation as in k_try_velrot
+    __shared__ double s_wlast[4];
+    __shared__ int s_whas[4];
+    {
+        const double afi = fabs(fi);
+        const unsigned long long vmask = __ballot(status == 2);
+        const unsigned long long below = vmask & ((1ull << lane) - 1ull);
+        const int src = below ? 63 - __clzll(below) : 0;
+        const double inh = __shfl(afi, src, 64);
+        const int top = vmask ? 63 - __clzll(vmask) : 0;
+        const double wl = __shfl(afi, top, 64);
+        if (lane == 0) { s_whas[wave] = vmask != 0; s_wlast[wave] = wl; }
+        __syncthreads();
+        if (status == 3) {
+            double v = marker;
+            bool have = false;
+            if (below) { v = inh; have = true; }
+            for (int pw = wave - 1; pw >= 0 && !have; pw--)
+                if (s_whas[pw]) { v = s_wlast[pw]; have = true; }
+            res[ikl] = v;
+        } else if (status == 2) {
+            res[ikl] = afi;
+        }
+        if (tid == 0) {
+            double bl = marker;
+            for (int pw = 3; pw >= 0; pw--)
+                if (s_whas[pw]) { bl = s_wlast[pw]; break; }
+            a.block_last[(size_t)seq * a.nblk + blk] = bl;
+        }
+    }
+    if (ikl < kn) ko.m_id_f[ikl] = mid_f;                      // kl.m_id_f = -1 / match, every evaluation
+    __shared__ double s_red[4][kTvNum];
+#pragma unroll
+    for (int i = 0; i < kTvNum; i++) {
+        double v = s[i];
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+        if (lane == 0) s_red[wave][i] = v;
+    }
+    __syncthreads();
+    if (tid < kTvNum)
+        a.partials[((size_t)seq * a.nblk + blk) * kNumSums + tid] = ((s_red[0][tid] + s_red[1][tid]) + s_red[2][tid]) + s_red[3][tid];
+}
+
+// markers left by k_try_vel -> |fi| of the last matched KeyLine of the preceding blocks (carry computed by k_lmv_step)
+__global__ __launch_bounds__(256) void k_tv_resolve(double *__restrict__ resid, const double *__restrict__ carry,
+                                                    const int32_t *__restrict__ kns, int cap, int nblk) {
+    const int seq = blockIdx.z, i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= kns[seq]) return;
+    double *r = resid + (size_t)seq * cap;
+    if (is_carry(r[i])) r[i] = carry[(size_t)seq * nblk + blockIdx.x];
+}
+
+// util::Matrix3x3Inv (include/UtilLib/toon_util.h:32-41): adjugate / TooN::determinant, the latter by Gaussian
+// elimination with partial pivoting (TooN/determinant.h:91-146)
+__device__ inline double det3_ge(const double Ain[9]) {
+    double A[9];
+    for (int i = 0; i < 9; i++) A[i] = Ain[i];
+    double det = 1;
+    for (int i = 0; i < 3; i++) {
+        int argmax = i;
+        double maxval = fabs(A[i * 3 + i]);
+        for (int ii = i + 1; ii < 3; ii++) {
+            const double v = fabs(A[ii * 3 + i]);
+            if (v > maxval) { maxval = v; argmax = ii; }
+        }
+        const double pivot = A[argmax * 3 + i];
+        if (argmax != i) {
+            det *= -1;
+            for (int j = i; j < 3; j++) { const double t = A[i * 3 + j]; A[i * 3 + j] = A[argmax * 3 + j]; A[argmax * 3 + j] = t; }
+        }
+        det *= A[i * 3 + i];
+        if (det == 0) return 0;
+        for (int u = i + 1; u < 3; u++) {
+            const double factor = A[u * 3 + i] / pivot;
+            for (int j = i + 1; j < 3; j++) A[u * 3 + j] = A[u * 3 + j] - factor * A[i * 3 + j];
+        }
+    }
+    return det;
+}
+__device__ inline void mat3_inv(const double A[9], double B[9]) {
+    B[0] = A[8] * A[4] - A[7] * A[5]; B[1] = -(A[8] * A[1] - A[7] * A[2]); B[2] = A[5] * A[1] - A[4] * A[2];
+    B[3] = -(A[8] * A[3] - A[6] * A[5]); B[4] = A[8] * A[0] - A[6] * A[2]; B[5] = -(A[5] * A[0] - A[3] * A[2]);
+    B[6] = A[7] * A[3] - A[6] * A[4]; B[7] = -(A[7] * A[0] - A[6] * A[1]); B[8] = A[4] * A[0] - A[3] * A[1];
+    const double det = det3_ge(A);
+    for (int i = 0; i < 9; i++) B[i] = B[i] / det;
+}
+
+enum LmvOps : unsigned { LMV_BEGIN = 1, LMV_REDUCE_CUR = 2, LMV_REDUCE_NEW = 4, LMV_GAIN = 8, LMV_SOLVE = 16, LMV_FINISH = 32 };
+
+__global__ __launch_bounds__(64) void k_lmv_step(SeqDev *seqs, const double *__restrict__ partials, const double *__restrict__ block_last,
+                                                 double *__restrict__ carry, const int32_t *__restrict__ kn_old, int nblk, unsigned ops) {
+    const int seq = blockIdx.x, lane = threadIdx.x;
+    SeqDev *sq = seqs + seq;
+    const int kn = kn_old[seq];
+    const int nblk_used = (kn + 255) / 256;
+    __shared__ double s_sum[kTvNum];
+    if (ops & (LMV_REDUCE_CUR | LMV_REDUCE_NEW)) {
+        if (lane < kTvNum) {
+            double acc = 0;
+            for (int b = 0; b < nblk_used; b++) acc += partials[((size_t)seq * nblk + b) * kNumSums + lane];
+            s_sum[lane] = acc;
+        }
+        if (lane == 32) {   // carries: |fi| of the last matched KeyLine before each block (0 at the top: double fi=0)
+            double run = 0;
+            for (int b = 0; b < nblk_used; b++) {
+                carry[(size_t)seq * nblk + b] = run;
+                const double v = block_last[(size_t)seq * nblk + b];
+                if (!is_carry(v)) run = v;
+            }
+        }
+    }
+    __syncthreads();
+    if (lane != 0) return;
+    const double tau = 1e-3;
+    if (ops & LMV_BEGIN) { sq->mv_v = 2; }
+    if (ops & (LMV_REDUCE_CUR | LMV_REDUCE_NEW)) {
+        double *JtJ = (ops & LMV_REDUCE_CUR) ? sq->mv_JtJ : sq->mv_JtJnew;
+        double *JtF = (ops & LMV_REDUCE_CUR) ? sq->mv_JtF : sq->mv_JtFnew;
+        JtJ[0] = s_sum[0]; JtJ[4] = s_sum[1]; JtJ[8] = s_sum[2];
+        JtJ[1] = JtJ[3] = s_sum[3]; JtJ[2] = JtJ[6] = s_sum[4]; JtJ[5] = JtJ[7] = s_sum[5];
+        JtF[0] = s_sum[6]; JtF[1] = s_sum[7]; JtF[2] = s_sum[8];
+        if (ops & LMV_REDUCE_CUR) {
+            sq->mv_F = s_sum[9];
+            double mx = JtJ[0];
+            for (int i = 1; i < 9; i++) mx = JtJ[i] > mx ? JtJ[i] : mx;   // TooN::max_element(JtJ).first
+            sq->mv_u = tau * mx;
+        } else {
+            sq->mv_Fnew = s_sum[9];
+        }
+    }
+    if (ops & LMV_GAIN) {
+        double den = 0;
+        for (int i = 0; i < 3; i++) den += (0.5 * sq->mv_h[i]) * (sq->mv_u * sq->mv_h[i] - sq->mv_JtF[i]);
+        const double gain = (sq->mv_F - sq->mv_Fnew) / den;
+        if (gain > 0) {
+            sq->mv_F = sq->mv_Fnew;
+            for (int i = 0; i < 3; i++) { sq->mv_V[i] = sq->mv_Vnew[i]; sq->mv_JtF[i] = sq->mv_JtFnew[i]; }
+            for (int i = 0; i < 9; i++) sq->mv_JtJ[i] = sq->mv_JtJnew[i];
+            const double g = 2 * gain - 1;
+            const double m = 1 - (g * g * g);
+            sq->mv_u *= (0.33 > m ? 0.33 : m);
+            sq->mv_v = 2;
+        } else {
+            sq->mv_u *= sq->mv_v;
+            sq->mv_v *= 2;
+        }
+    }
+    if (ops & LMV_SOLVE) {
+        double ApI[9], Inv[9];
+        for (int i = 0; i < 9; i++) ApI[i] = sq->mv_JtJ[i] + ((i % 4 == 0) ? 1.0 * sq->mv_u : 0.0);
+        mat3_inv(ApI, Inv);
+        for (int i = 0; i < 3; i++) {
+            double d = 0;
+            for (int k = 0; k < 3; k++) d += Inv[i * 3 + k] * (-sq->mv_JtF[k]);
+            sq->mv_h[i] = d;
+            sq->mv_Vnew[i] = sq->mv_V[i] + d;
+        }
+    }
+    if (ops & LMV_FINISH) mat3_inv(sq->mv_JtJ, sq->mv_RVel);
+}
+
 // standalone evaluation helper: X given by the host -> setup
 __global__ void k_tvr_setup_from_host(SeqDev *seqs, const double *__restrict__ X, const double *__restrict__ smin, int nseq,
                                       int res_in, int res_out) {
@@ -1293,6 +1549,40 @@ int minimizer_enqueue(edgehip_ctx *c, int slot_new, int slot_old, int fc_index) 
     return 0;
 }
 
+// Minimizer_V<double>: evaluate, then iter_max x (solve, evaluate at Vnew, gain test)
+int minimizer_v_enqueue(edgehip_ctx *c, int slot_new, int slot_old, int fc_index, int iter_max, double match_thresh,
+                        uint32_t match_num_thresh, double reweight_distance) {
+    const DevicePlan &pl = c->plan;
+    c->fc_index = fc_index;
+    const int nblk256 = (pl.cap + 255) / 256;
+    if (nblk256 > c->nblk_tvr * (kTvrBlock / 256)) { set_error("minimizer_v: block tables too small"); return EDGEHIP_ERR_STATE; }
+    // per-256-KeyLine tables live in the buffers sized for TryVelRot (nblk_tvr >= nblk256 because kTvrBlock == 256)
+    static_assert(kTvrBlock == 256, "k_try_vel shares the per-block tables of k_try_velrot");
+    EH_CHECK(hipMemsetAsync(c->resid, 0, sizeof(double) * pl.nseq * pl.cap, c->stream));   // residuals[i] = 0
+    TvrArgs a = make_tvr_args(c, slot_new, slot_old, match_thresh, reweight_distance, match_num_thresh, 1);
+    const int32_t *kn_old = c->kn_slot + (size_t)slot_old * pl.nseq;
+    auto eval = [&](bool use_new) {
+        dim3 g(nblk256, 1, pl.nseq), b(256);
+        if (use_new) hipLaunchKernelGGL((k_try_vel<true>), g, b, 0, c->stream, a);
+        else hipLaunchKernelGGL((k_try_vel<false>), g, b, 0, c->stream, a);
+    };
+    auto step = [&](unsigned ops) {
+        hipLaunchKernelGGL(k_lmv_step, dim3(pl.nseq), dim3(64), 0, c->stream, c->seq, c->partials, c->block_last, c->resid_carry,
+                           kn_old, c->nblk_tvr, ops);
+        if (ops & (LMV_REDUCE_CUR | LMV_REDUCE_NEW))
+            hipLaunchKernelGGL(k_tv_resolve, dim3(nblk256, 1, pl.nseq), dim3(256), 0, c->stream, c->resid, c->resid_carry, kn_old,
+                               pl.cap, c->nblk_tvr);
+    };
+    eval(false);
+    step(LMV_BEGIN | LMV_REDUCE_CUR | (iter_max > 0 ? LMV_SOLVE : LMV_FINISH));
+    for (int it = 0; it < iter_max; it++) {
+        eval(true);
+        step(LMV_REDUCE_NEW | LMV_GAIN | (it < iter_max - 1 ? LMV_SOLVE : LMV_FINISH));
+    }
+    EH_LAUNCH_CHECK();
+    return 0;
+}
+
 }  // namespace edgehip
 
 using namespace edgehip;
@@ -1372,6 +1662,43 @@ int edgehip_download_resid(edgehip_ctx *c, int which, double *resid) {
     EH_LAUNCH_CHECK();
     EH_CHECK(hipMemcpyAsync(resid, c->rs_tmp, sizeof(double) * pl.nseq * pl.cap, hipMemcpyDeviceToHost, c->stream));
     EH_CHECK(hipStreamSynchronize(c->stream));
+    return 0;
+}
+
+int edgehip_minimizer_v(edgehip_ctx *c, int slot_new, int slot_old, double *V, const double *s_rho_min, float min_mod,
+                        double match_thresh, int iter_max, uint32_t match_num_thresh, double reweight_distance, double *RVel,
+                        double *F) {
+    if (!c || !V || !s_rho_min || slot_new < 0 || slot_old < 0 || slot_new >= c->plan.nslots || slot_old >= c->plan.nslots ||
+        iter_max < 0) {
+        set_error("minimizer_v: bad argument");
+        return EDGEHIP_ERR_ARG;
+    }
+    const int B = c->plan.nseq;
+    EH_CHECK(hipMemcpyAsync(c->pinned_seq, c->seq, sizeof(SeqDev) * B, hipMemcpyDeviceToHost, c->stream));
+    EH_CHECK(hipStreamSynchronize(c->stream));
+    for (int s = 0; s < B; s++) {
+        SeqDev &q = c->pinned_seq[s];
+        for (int i = 0; i < 3; i++) q.mv_V[i] = V[s * 3 + i];
+        q.mv_s_rho_min = s_rho_min[s];
+        q.mv_min_mod = min_mod < 0.f ? 0.f : min_mod;
+    }
+    EH_CHECK(hipMemcpyAsync(c->seq, c->pinned_seq, sizeof(SeqDev) * B, hipMemcpyHostToDevice, c->stream));
+    if (min_mod < 0.f) {   // old_buf.ef->getThresh(): each sequence's retuned threshold of the old slot
+        std::vector<float> rt(B);
+        EH_CHECK(hipMemcpyAsync(rt.data(), c->retuned_slot + (size_t)slot_old * B, sizeof(float) * B, hipMemcpyDeviceToHost, c->stream));
+        EH_CHECK(hipStreamSynchronize(c->stream));
+        for (int s = 0; s < B; s++) c->pinned_seq[s].mv_min_mod = rt[s];
+        EH_CHECK(hipMemcpyAsync(c->seq, c->pinned_seq, sizeof(SeqDev) * B, hipMemcpyHostToDevice, c->stream));
+    }
+    if (int e = minimizer_v_enqueue(c, slot_new, slot_old, slot_new, iter_max, match_thresh, match_num_thresh, reweight_distance)) return e;
+    EH_CHECK(hipMemcpyAsync(c->pinned_seq, c->seq, sizeof(SeqDev) * B, hipMemcpyDeviceToHost, c->stream));
+    EH_CHECK(hipStreamSynchronize(c->stream));
+    for (int s = 0; s < B; s++) {
+        const SeqDev &q = c->pinned_seq[s];
+        for (int i = 0; i < 3; i++) V[s * 3 + i] = q.mv_V[i];
+        if (RVel) for (int i = 0; i < 9; i++) RVel[s * 9 + i] = q.mv_RVel[i];
+        if (F) F[s] = q.mv_F;
+    }
     return 0;
 }
 

@@ -295,7 +295,7 @@ __global__ __launch_bounds__(256) void k_directed(DirArgs a) {
                     if (t0i + c >= t_steps) continue;
                     if (dir ? t > dq_max : t < dq_min) continue;
                     const float fx = (float)(t_x * t + (double)pi0x), fy = (float)(t_y * t + (double)pi0y);
-                    const int xi = (int)roundf(fx), yi = (int)roundf(fy);
+                    const int xi = round_half_away_i(fx), yi = round_half_away_i(fy);
                     if (xi >= a.w || yi >= a.h || xi < 0 || yi < 0) continue;
                     jm[c][dir] = mask[(size_t)yi * a.w + xi];
                 }

@@ -141,7 +141,7 @@ EXPORTS = [
     "edgehip_upload_keylines", "edgehip_download_plane", "edgehip_download_field", "edgehip_profile_enable",
     "edgehip_profile_count", "edgehip_profile_name", "edgehip_profile_read", "edgehip_profile_select",
     "edgehip_upload_rgb_indexed", "edgehip_set_nav_log", "edgehip_read_nav_log",
-    "edgehip_build_undistort_map", "edgehip_download_undistorted", "edgehip_depth_reset",
+    "edgehip_build_undistort_map", "edgehip_download_undistorted", "edgehip_depth_reset", "edgehip_minimizer_v",
 ]
 
 _lib = None
@@ -205,6 +205,15 @@ class EdgeHip:
             self.close()
         except Exception:
             pass
+
+    def minimizer_v(self, slot_new, slot_old, V, s_rho_min, min_mod, match_thresh, iter_max, match_num_thresh, reweight_distance):
+        """global_tracker::Minimizer_V<double> for every sequence -> (V[nseq,3], RVel[nseq,3,3], F[nseq])."""
+        V = np.ascontiguousarray(np.broadcast_to(np.asarray(V, np.float64), (self.nseq, 3))).copy()
+        smin = np.ascontiguousarray(np.broadcast_to(np.asarray(s_rho_min, np.float64), (self.nseq,))).copy()
+        RV, F = np.zeros((self.nseq, 3, 3)), np.zeros(self.nseq)
+        self._ck(self.lib.edgehip_minimizer_v(self.ctx, slot_new, slot_old, _dp(V), _dp(smin), C.c_float(min_mod), C.c_double(match_thresh),
+                                              iter_max, C.c_uint32(match_num_thresh), C.c_double(reweight_distance), _dp(RV), _dp(F)))
+        return V, RV, F
 
     def depth_reset(self, seq=-1):
         """REBVO::Reset() (rebvo_second_t.cpp:609-620) for one sequence or all (-1)."""

@@ -81,3 +81,26 @@ def test_stage_b_pieces_bit_exact():
             if jf:
                 assert np.array_equal(JJa, JJb) and np.array_equal(JFa, JFb)
             assert np.array_equal(a.keylines(so)["m_id_f"], b.keylines(so)["m_id_f"])
+
+
+def test_minimizer_v_bit_exact():
+    """IMU-branch Minimizer_V / TryVel: the port follows the reference's sequential fp64 accumulation, so V, RVel,
+    the score and the forward matches are identical."""
+    w, h = 376, 240
+    frames = [f for f, _, _ in synth.billboard_sequence(w, h, 6)]
+    a, b = oracle.Oracle("ref", oracle.euroc_params(w, h)), oracle.Oracle("port", oracle.euroc_params(w, h))
+    nav = None
+    for k in range(5):
+        _, nav = a.process_frame(frames[k], 0.05 * k)
+    so, sn = 4, 5
+    a.stage_a(sn, frames[5], nav.tresh, nav.kn)
+    for s in (so, sn):
+        b.set_keylines(s, a.keylines(s), a.mask(s), a.retuned(s))
+        b.set_framecount(s, a.get_framecount(s))
+    a.build_field(sn, 40, a.retuned(sn))
+    b.build_field(sn, 40, b.retuned(sn))
+    for V0, it, mnt in (((0, 0, 0), 5, 0), ((1e-3, -5e-4, 2e-4), 10, 3)):
+        ra = a.minimizer_v(sn, so, V0, 0.5, it, a.quantile(so), mnt, 2.0, a.retuned(so))
+        rb = b.minimizer_v(sn, so, V0, 0.5, it, b.quantile(so), mnt, 2.0, b.retuned(so))
+        assert ra["F"] == rb["F"] and np.array_equal(ra["V"], rb["V"]) and np.array_equal(ra["RVel"], rb["RVel"])
+        assert np.array_equal(a.keylines(so)["m_id_f"], b.keylines(so)["m_id_f"])

@@ -100,3 +100,27 @@ def test_minimizer_rv(pair):
     kl_ref = orc.keylines(so)
     kl_gpu, _ = eh.download_keylines(0, 0, want_mask=False)
     assert np.array_equal(kl_ref["m_id_f"], kl_gpu["m_id_f"])
+
+
+@pytest.mark.parametrize("V0,iters,mnt", [((0.0, 0.0, 0.0), 5, 0), ((1e-3, -5e-4, 2e-4), 10, 0), ((2e-3, 1e-3, -3e-4), 3, 2)])
+def test_minimizer_v(pair, V0, iters, mnt):
+    """IMU-branch tracker (SURVEY.md section 8 row b6): global_tracker::Minimizer_V<double> + TryVel + Calc_f_J.
+    The reference sums 9 + 1 terms sequentially in fp64, the GPU with a wave butterfly and fixed-order block
+    partials: V within 1e-9 relative (+1e-12), score 1e-11, RVel 1e-8; forward matches of the last evaluation
+    (kl.m_id_f) identical."""
+    orc, so, sn, nav, eh = pair
+    inject_pair(eh, orc, so, sn)                       # fresh KeyLines (m_id_f is overwritten by every minimiser run)
+    orc.build_field(sn, 40, orc.retuned(sn))
+    eh.build_field(1, 40, -1.0)
+    s_rho_q = orc.quantile(so)
+    fc = 3 if mnt else 0
+    orc.set_framecount(sn, fc)
+    eh.set_framecount(0, 1, fc)
+    ref = orc.minimizer_v(sn, so, V0, 0.5, iters, s_rho_q, mnt, 2.0, orc.retuned(so))
+    V, RV, F = eh.minimizer_v(1, 0, V0, s_rho_q, -1.0, 0.5, iters, mnt, 2.0)
+    assert np.allclose(V[0], ref["V"], rtol=1e-9, atol=1e-12), (V[0], ref["V"])
+    assert abs(F[0] - ref["F"]) <= 1e-11 * abs(ref["F"])
+    assert rel_err(RV[0], ref["RVel"]) < 1e-8
+    kg, _ = eh.download_keylines(0, 0)
+    assert np.array_equal(kg["m_id_f"], orc.keylines(so)["m_id_f"])
+    assert orc.get_framecount(sn) == fc                 # Minimizer_V does not count frames
