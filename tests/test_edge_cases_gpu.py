@@ -1,0 +1,111 @@
+"""GPU edge cases the reference handles in-band (failure detection): empty edge maps, a scene cut
+(too few matches -> estimation restart, rebvo_second_t.cpp:412-422), a batch whose sequences are in different
+states at the same time, and the largest supported width."""
+import numpy as np
+import pytest
+
+from rebvo_amd import edgehip, synth
+
+pytestmark = pytest.mark.gpu
+
+
+def _oracle(w, h, **kw):
+    from oracle import oracle
+    kind = "ref" if oracle.available("ref") else "port"
+    return oracle.Oracle(kind, oracle.euroc_params(w, h, **kw))
+
+
+def _check(ng, nr, k):
+    assert (ng.kn, ng.tresh) == (nr.kn, nr.tresh), k
+    if k == 0:
+        return
+    assert ng.estimation_ok == nr.estimation_ok, k
+    assert abs(ng.klm_num - nr.klm_num) <= max(2, nr.klm_num // 1000), k
+    Vr, Wr = np.array(nr.V[:]), np.array(nr.W[:])
+    if np.all(np.isfinite(Vr)):
+        step = np.linalg.norm(Vr) + np.linalg.norm(Wr)
+        assert np.allclose(ng.V[:], Vr, rtol=0, atol=1e-6 * step + 1e-9), (k, ng.V[:], Vr)
+        assert np.allclose(ng.W[:], Wr, rtol=0, atol=1e-6 * step + 1e-9), (k, ng.W[:], Wr)
+    else:
+        assert np.array_equal(np.isnan(ng.V[:]), np.isnan(Vr))
+
+
+def test_empty_frames_then_texture():
+    """Uniform frames give kn == 0 (Minimizer_RV returns at once, EstimateReScalingOpt returns 1, nothing to match);
+    then texture appears.  Every frame must agree with the reference, including the restart flags."""
+    w, h = 376, 240
+    tex = [f for f, _, _ in synth.billboard_sequence(w, h, 4)]
+    flat = np.full((h, w, 3), 90, np.uint8)
+    frames = [flat, flat, tex[0], tex[1], flat, tex[2], tex[3]]
+    orc = _oracle(w, h)
+    eh = edgehip.EdgeHip(edgehip.euroc_params(w, h), nseq=1, nslots=3)
+    for k, f in enumerate(frames):
+        _, nr = orc.process_frame(f, 0.05 * k)
+        eh.upload_rgb(eh.next_slot(), f)
+        eh.process_frame(0.05 * k)
+        _check(eh.read_nav()[0], nr, k)
+    _, mask = eh.download_keylines(0, eh.cur_slot())
+    assert np.array_equal(mask, orc.mask(orc.cur_slot()))
+    eh.close()
+
+
+@pytest.mark.parametrize("gmt", [500, 20000], ids=["default_threshold", "always_restart"])
+def test_scene_cut_and_restart(gmt):
+    """A hard scene cut, once with the shipped GlobalMatchThreshold and once with a threshold no frame can reach, so
+    that every frame takes the restart branch (V = 0, P_V = 1e50*I, Kp = 1, P_Kp = 10, EstimationOK = false)."""
+    w, h = 376, 240
+    a = [f for f, _, _ in synth.billboard_sequence(w, h, 4, seed=3)]
+    b = list(synth.rects_sequence(w, h, 4))
+    frames = a + b                                     # cut between frame 3 and 4
+    orc = _oracle(w, h, global_match_threshold=gmt)
+    eh = edgehip.EdgeHip(edgehip.euroc_params(w, h, global_match_threshold=gmt), nseq=1, nslots=3)
+    oks = []
+    for k, f in enumerate(frames):
+        _, nr = orc.process_frame(f, 0.05 * k)
+        eh.upload_rgb(eh.next_slot(), f)
+        eh.process_frame(0.05 * k)
+        ng = eh.read_nav()[0]
+        _check(ng, nr, k)
+        if k:   # the first frame has no estimate on either side
+            assert abs(ng.Kp - nr.Kp) < 1e-8 and (ng.RKp == nr.RKp or abs(ng.RKp - nr.RKp) <= 1e-8 * abs(nr.RKp))
+        oks.append(nr.estimation_ok)
+    if gmt > 10000:
+        assert not any(oks[1:])
+    eh.close()
+
+
+def test_batch_with_sequences_in_different_states():
+    """Three sequences in one launch: textured, empty, and a scene cut — each must equal its own reference run."""
+    w, h, n = 376, 240, 6
+    tex = [f for f, _, _ in synth.billboard_sequence(w, h, n)]
+    flat = np.full((h, w, 3), 40, np.uint8)
+    rects = list(synth.rects_sequence(w, h, n))
+    seqs = [tex, [flat] * n, tex[:3] + rects[3:]]
+    orcs = [_oracle(w, h) for _ in seqs]
+    eh = edgehip.EdgeHip(edgehip.euroc_params(w, h), nseq=3, nslots=3)
+    for k in range(n):
+        eh.upload_rgb(eh.next_slot(), np.stack([s[k] for s in seqs]))
+        eh.process_frame(0.05 * k)
+        navs = eh.read_nav()
+        for s in range(3):
+            _, nr = orcs[s].process_frame(seqs[s][k], 0.05 * k)
+            _check(navs[s], nr, (s, k))
+    eh.close()
+
+
+def test_max_width_1024_and_max_points_cap():
+    """w = 1024 is the widest frame the context accepts; MaxPoints small enough to truncate (kl_max, edge_finder.cpp:203-209)."""
+    w, h = 1024, 64
+    frames = list(synth.rects_sequence(w, h, 3))
+    orc = _oracle(w, h, max_points=600, reference_points=500)
+    eh = edgehip.EdgeHip(edgehip.euroc_params(w, h, max_points=600, reference_points=500), nseq=1, nslots=3)
+    for k, f in enumerate(frames):
+        _, nr = orc.process_frame(f, 0.05 * k)
+        eh.upload_rgb(eh.next_slot(), f)
+        eh.process_frame(0.05 * k)
+        ng = eh.read_nav()[0]
+        assert (ng.kn, ng.tresh) == (nr.kn, nr.tresh), k
+    assert orc.kn(orc.cur_slot()) == 600, "case must hit the MaxPoints cap"
+    _, mask = eh.download_keylines(0, eh.cur_slot())
+    assert np.array_equal(mask, orc.mask(orc.cur_slot()))
+    eh.close()
