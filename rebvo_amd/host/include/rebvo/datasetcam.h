@@ -1,0 +1,45 @@
+// datasetcam.h — image-list camera for EuRoC / TUM style datasets: same constructor, list-file format and
+// GrabBuffer/ReleaseBuffer contract as the reference's DataSetCam (include/VideoLib/datasetcam.h:36-74,
+// src/VideoLib/datasetcam.cpp:32-220), without libgd: PNG (what both datasets ship) is decoded with zlib by
+// png_reader.cpp; binary PGM/PPM are accepted too.  JPEG is not (the reference relies on libgd for it).
+#ifndef REBVO_AMD_HOST_DATASETCAM_H
+#define REBVO_AMD_HOST_DATASETCAM_H
+
+#include <string>
+#include <vector>
+
+#include "rebvo/rebvo.h"
+
+namespace rebvo {
+
+// Decode a PNG / PGM / PPM file into RGB24 (grey replicated, alpha dropped, 16-bit samples reduced to their high
+// byte — what libgd's truecolor conversion yields).  Returns false with a message in `err`.
+bool LoadImageRGB24(const std::string &file, std::vector<RGB24Pixel> &out, unsigned &w, unsigned &h, std::string &err);
+
+class DataSetCam {
+    bool error = true;
+    bool frm_pending = false;
+    Image<RGB24Pixel> buffer;
+    double time = 0;
+    std::string strDir;
+    std::vector<std::string> img_list;
+    std::vector<double> img_time;
+    unsigned img_inx = 0;
+    unsigned paknum = 0;
+
+public:
+    // List file: one "<timestamp>[,| ]<file name>" per line, '#' comments (EuRoC data.csv, TUM rgb.txt);
+    // timestamps are multiplied by time_scale (1e-9 for EuRoC nanoseconds), names are prefixed with DataSetDir.
+    DataSetCam(const char *DataSetDir, const char *DataSetFile, Size2D frame_size, double time_scale, const char *log_name = nullptr);
+    int WaitFrame(bool drop_frames = true);
+    int LoadImage(const std::string &i_name);
+    int GrabFrame(RGB24Pixel *data, double &tstamp, bool drop_frames = true);
+    RGB24Pixel *GrabBuffer(double &tstamp, bool drop_frames = true);
+    int ReleaseBuffer() { return 0; }
+    const bool &Error() { return error; }
+    unsigned PakNum() const { return paknum; }
+    size_t NumFrames() const { return img_list.size() < img_time.size() ? img_list.size() : img_time.size(); }
+};
+
+}  // namespace rebvo
+#endif

@@ -11,8 +11,9 @@
 // a request time-out); the per-frame edge pipeline behind it runs on the GPU through include/edgehip.h.
 //
 // Differences, all forced by what is out of scope here:
-//  * CameraType must be 3 (custom camera: the application feeds frames); V4L / SimCam / DataSetCam are device
-//    and file I/O that this repository does not rebuild.  ImuMode must be 0 (the IMU branch is "next").
+//  * CameraType 3 (custom camera: the application feeds frames) and 2 (DataSetCam: EuRoC data.csv / TUM rgb.txt
+//    image lists, PNG/PGM/PPM decoded without libgd, rebvo/datasetcam.h) are available; V4L and SimCam are
+//    device I/O that this repository does not rebuild.  ImuMode must be 0 (the rest of the IMU branch is "next").
 //  * PipeBuffer::ss and ::gt are null (scale space and auxiliary field stay in HBM); PipeBuffer::ef is a
 //    host view with the edge_finder members consumers use: KNum(), operator[], begin()/end(), GetCam(),
 //    getThresh(), NumMatches().
@@ -44,6 +45,8 @@
 struct edgehip_ctx;
 
 namespace rebvo {
+
+class DataSetCam;
 
 typedef unsigned int uint;
 
@@ -279,6 +282,7 @@ class REBVO {
     std::mutex call_mutex;
     std::function<bool(PipeBuffer &)> outputFunc;
     edgehip_ctx *hip = nullptr;
+    DataSetCam *dscam = nullptr;   // CameraType == 2
     std::string last_error;
 
     bool callCallBack(PipeBuffer &pbuf) {

@@ -19,6 +19,7 @@
 #include <sstream>
 
 #include "edgehip.h"
+#include "rebvo/datasetcam.h"
 
 namespace rebvo {
 
@@ -184,6 +185,11 @@ REBVO::REBVO(const char *configFile)
     InitOK &= config.get("REBVO", "LogFile", p.LogFile);
     InitOK &= config.get("REBVO", "TrayFile", p.TrayFile);
     InitOK &= config.get("IMU", "ImuMode", p.ImuMode);
+    if (p.CameraType == 2) {   // DataSetCam keys (src/rebvo/rebvo.cpp:68-70)
+        InitOK &= config.get("DataSetCamera", "DataSetDir", p.DataSetDir);
+        InitOK &= config.get("DataSetCamera", "DataSetFile", p.DataSetFile);
+        InitOK &= config.get("DataSetCamera", "TimeScale", p.CamTimeScale);
+    }
     if (p.ImuMode == 2) config.get("IMU", "TimeScale", p.ImuTimeScale, false);
     // accepted and ignored (subsystems that do not exist on this path)
     config.get("Camera", "Rotate180", p.rotatedCam, false);
@@ -227,10 +233,20 @@ REBVO::~REBVO() {
 bool REBVO::Init() {
     if (!InitOK) return false;
     if (!quit) return true;
-    if (params.CameraType != 3) {
-        last_error = "REBVO(hip): only CameraType=3 (custom camera) is available; feed frames with requestCustomCamBuffer()";
+    if (params.CameraType != 3 && params.CameraType != 2) {
+        last_error = "REBVO(hip): only CameraType=3 (custom camera) and CameraType=2 (dataset camera) are available";
         std::cout << last_error << "\n";
         return false;
+    }
+    if (params.CameraType == 2) {   // REBVO::initCamera, src/rebvo/rebvo.cpp:256-258
+        dscam = new DataSetCam(params.DataSetDir.data(), params.DataSetFile.data(), params.ImageSize, params.CamTimeScale);
+        if (dscam->Error()) {
+            last_error = "REBVO: Failed to initialize the main camera (dataset list " + params.DataSetFile + ")";
+            std::cout << last_error << "\n";
+            delete dscam;
+            dscam = nullptr;
+            return false;
+        }
     }
     if (params.ImuMode != 0) {
         last_error = "REBVO(hip): ImuMode must be 0 (the IMU branch Minimizer_V/ExtRotVel is not built yet)";
@@ -255,6 +271,7 @@ bool REBVO::CleanUp() {
     quit = true;
     if (Thr0.joinable()) Thr0.join();
     if (hip) { edgehip_destroy(hip); hip = nullptr; }
+    if (dscam) { delete dscam; dscam = nullptr; }
     return true;
 }
 
@@ -279,28 +296,40 @@ void REBVO::TrackThread(REBVO *cf) {
     bool failed = false;
     while (!cf->quit && !failed) {
         PipeBuffer &new_buf = cf->pipe.RequestBuffer(0);
-        // ---- grab (customCam::GrabBuffer, src/VideoLib/customcam.cpp:56-68: 1 ms time-out, retry) ----
+        // ---- grab: custom camera ring (src/VideoLib/customcam.cpp:56-68: 1 ms time-out, retry) or dataset list ----
         customCam::CustomCamPipeBuffer *cbuf = nullptr;
+        const RGB24Pixel *data = nullptr;
         double t = 0;
         while (true) {
+            if (cf->dscam) {
+                double ts = 0;
+                data = cf->dscam->GrabBuffer(ts, false);
+                if (!data) break;                  // end of the list / unreadable image: camera error -> quit
+                t = ts;
+                p_num = (int)cf->dscam->PakNum();
+                if (t - t0 < min_frame_dt) { cf->dscam->ReleaseBuffer(); data = nullptr; if (cf->quit) break; continue; }
+                break;
+            }
             while ((cbuf = cf->cam_pipe.RequestBufferTimeoutable(1, 0.001)) == nullptr)
                 if (cf->quit) break;
             if (!cbuf) break;
             t = cbuf->timestamp;
             p_num++;
-            if (t - t0 < min_frame_dt) { cf->cam_pipe.ReleaseBuffer(1); continue; }   // soft-FPS drop (t0 starts at 0), :89, :172-177
+            if (t - t0 < min_frame_dt) { cf->cam_pipe.ReleaseBuffer(1); cbuf = nullptr; continue; }   // soft-FPS drop (t0 starts at 0), :89, :172-177
+            data = cbuf->img->Data();
             break;
         }
-        if (!cbuf) {   // quitting: pass the flag down the ring (rebvo_first_t.cpp:165-170)
+        if (!data) {   // quitting or camera error: pass the flag down the ring (rebvo_first_t.cpp:165-170)
             new_buf.quit = true;
             cf->pipe.ReleaseBuffer(0);
             break;
         }
         const double tp0 = now_s();
         const int slot = edgehip_next_slot(cf->hip);
-        int rc = edgehip_upload_rgb(cf->hip, slot, reinterpret_cast<const uint8_t *>(cbuf->img->Data()), 0, 1);
-        std::memcpy(new_buf.imgc->Data(), cbuf->img->Data(), frame_bytes);
-        cf->cam_pipe.ReleaseBuffer(1);
+        int rc = edgehip_upload_rgb(cf->hip, slot, reinterpret_cast<const uint8_t *>(data), 0, 1);
+        std::memcpy(new_buf.imgc->Data(), data, frame_bytes);
+        if (cbuf) cf->cam_pipe.ReleaseBuffer(1);
+        else cf->dscam->ReleaseBuffer();
         t0 = t;
         // ---- the whole frame on the GPU: stage A + (from the second frame on) tracking and mapping ----
         if (rc == 0) rc = edgehip_process_frame(cf->hip, &t);

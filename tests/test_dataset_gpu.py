@@ -1,0 +1,60 @@
+"""GPU: CameraType=2 end to end — an EuRoC-layout dataset (mav0/cam0/data.csv with nanosecond stamps + grey PNGs)
+is read by the library's own DataSetCam, tracked on the GPU and compared with the reference oracle fed the same
+frames.  SURVEY.md section 8f1."""
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+from rebvo_amd import edgehip, synth
+from tests.helpers import write_global_config
+
+pytestmark = pytest.mark.gpu
+PIL = pytest.importorskip("PIL.Image")
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+EXE = os.path.join(ROOT, "rebvo_amd", "lib", "dataset_replay")
+
+
+def test_euroc_layout_replay(tmp_path):
+    from oracle import oracle
+    if not oracle.available("ref") or not os.path.exists(EXE):
+        pytest.skip("needs oracle/_ref and dataset_replay")
+    w, h, n = 376, 240, 8
+    frames = [f for f, _, _ in synth.billboard_sequence(w, h, n)]
+    cam0 = tmp_path / "mav0" / "cam0"
+    (cam0 / "data").mkdir(parents=True)
+    t_ns = [1403636579763555584 + 50_000_000 * k for k in range(n)]
+    with open(cam0 / "data.csv", "w") as f:
+        f.write("#timestamp [ns],filename\r\n")
+        for k, fr in enumerate(frames):
+            PIL.fromarray(fr[:, :, 0], "L").save(cam0 / "data" / f"{t_ns[k]}.png")
+            f.write(f"{t_ns[k]},{t_ns[k]}.png\r\n")                  # CR LF line ends as in the real files
+    cfg, dump, tray = tmp_path / "cfg", tmp_path / "dump.txt", tmp_path / "tray.txt"
+    p = edgehip.euroc_params(w, h)
+    write_global_config(cfg, p, log_file=str(tmp_path / "log.m"), tray_file=str(tray), save_log=1, camera_type=2,
+                        dataset=(str(cam0 / "data") + "/", str(cam0 / "data.csv"), 1e-9))
+    r = subprocess.run([EXE, str(cfg), str(dump)], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert f"Loaded {n} File names" in r.stdout
+    rows = np.loadtxt(dump, ndmin=2)
+    assert len(rows) == n - 1
+    orc = oracle.Oracle("ref", oracle.euroc_params(w, h))
+    path = 0.0
+    for k, fr in enumerate(frames):
+        t = float(np.float64(t_ns[k]) * 1e-9)                         # std::stod(line) * time_scale
+        _, nav = orc.process_frame(fr, t)
+        if k >= 1 and k < n:
+            pass
+        if k == 0:
+            prev = nav
+            continue
+        row = rows[k - 1]                                             # frame k-1 is delivered after frame k was tracked
+        assert int(row[0]) == k - 1
+        kl = orc.keylines((k - 1) % 8)
+        assert int(row[2]) == len(kl)
+        if k - 1 > 0:
+            path += np.linalg.norm(prev.V[:])
+            assert np.allclose(row[5:8], prev.Pos[:], atol=1e-6 * path + 1e-9)
+        assert abs(row[14] - kl["rho"].sum()) <= 1e-6 * abs(kl["rho"].sum()) + 1e-9
+        prev = nav

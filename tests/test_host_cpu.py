@@ -41,9 +41,12 @@ def test_syntax_error_and_missing_file(exe, tmp_path):
 
 def test_unsupported_camera_type_refused(exe, tmp_path):
     cfg = tmp_path / "cfg"
-    write_global_config(cfg, edgehip.euroc_params(376, 240), camera_type=2)
+    write_global_config(cfg, edgehip.euroc_params(376, 240), camera_type=0)   # V4L: device I/O, not rebuilt here
     r = _run(cfg, "/dev/null", 0, 1.0, 0.05)
     assert r.returncode == 4 and "CameraType=3" in r.stdout
+    # a dataset camera without its mandatory keys is a config error, as in REBVO::REBVO (src/rebvo/rebvo.cpp:68-70)
+    write_global_config(cfg, edgehip.euroc_params(376, 240), camera_type=2)
+    assert _run(cfg, "/dev/null", 0, 1.0, 0.05).returncode == 3
 
 
 @pytest.mark.skipif(HAVE_GPU, reason="checks the no-GPU failure mode")
