@@ -191,6 +191,13 @@ int edgehip_directed_matching(edgehip_ctx *ctx, int slot_new, int slot_old);
 /* Regularize_1_iter + UpdateInverseDepthKalman fused (rebvo_second_t.cpp:453, 460;
  * edge_tracker.cpp:87-148, 695-724, 954-1055).  do_regularize/do_ekf select either half (tests). */
 int edgehip_regularize_ekf(edgehip_ctx *ctx, int slot, int do_regularize, int do_ekf);
+/* edge_tracker::ExtRotVel (IMU branch, rebvo_second_t.cpp:237; edge_tracker.cpp:1207-1296): linear 6-DoF
+ * roto-translation increment from the forward matches of `slot` (the new edge map after edgehip_forward_match),
+ * given the translation estimate vel[nseq][3].  X[nseq][6]; Wx[nseq][36] = Phi^T Phi and Rx[nseq][36] = its
+ * pseudo inverse may be NULL; ok[nseq] (may be NULL) is the function's return value (false on a NaN result).
+ * The per-KeyLine rows and the 27 sums run on the device, the 6x6 SVD solve on the host.  Synchronises. */
+int edgehip_ext_rot_vel(edgehip_ctx *ctx, int slot, const double *vel, double loc_unc, double hub_reweight, double *X,
+                        double *Wx, double *Rx, int32_t *ok);
 /* EstimateReScalingOpt (rebvo_second_t.cpp:487; edge_tracker.cpp:1104-1140) -> seq_state.Kp, P_Kp. */
 int edgehip_rescale(edgehip_ctx *ctx, int slot);
 

@@ -192,6 +192,7 @@ class Oracle:
         self._try_velrot = fn("try_velrot", d, vp, i, i, pd, i, i, d, d, u, d, pd, pd, pd, pd)
         self._minimizer_rv = fn("minimizer_rv", d, vp, i, i, pd, pd, pd, pd, d, i, i, d, pd, pd, d, u, d, pd)
         self._minimizer_v = fn("minimizer_v", d, vp, i, i, pd, pd, d, i, d, u, d, C.c_float)
+        self._ext_rot_vel = fn("ext_rot_vel", i, vp, i, pd, d, d, pd, pd, pd)
         self._forward_match = fn("forward_match", i, vp, i, i)
         self._rotate = fn("rotate_keylines", None, vp, i, pd)
         self._directed = fn("directed_matching", i, vp, i, i, pd, pd, pd, pi, d, d, d, d)
@@ -302,6 +303,13 @@ class Oracle:
         F = self._minimizer_v(self.ctx, slot_new, slot_old, _dp(V), _dp(RV), match_thresh, iter_max, s_rho_min, match_num_thresh,
                               reweight_distance, min_mod)
         return dict(F=F, V=V, RVel=RV)
+
+    def ext_rot_vel(self, slot, vel, loc_unc, hub_reweight):
+        """edge_tracker::ExtRotVel -> dict(ok, X, Wx, Rx)."""
+        vel = np.array(vel, dtype=np.float64)
+        X, Wx, Rx = np.zeros(6), np.zeros((6, 6)), np.zeros((6, 6))
+        ok = self._ext_rot_vel(self.ctx, slot, _dp(vel), loc_unc, hub_reweight, _dp(X), _dp(Wx), _dp(Rx))
+        return dict(ok=bool(ok), X=X, Wx=Wx, Rx=Rx)
 
     # ---- stage C -------------------------------------------------------------------------------
     def forward_match(self, slot_old, slot_new):

@@ -105,6 +105,9 @@ typedef struct OrcNav {
     double P##_minimizer_v(void *ctx, int slot_new, int slot_old, double V[3], double RVel[9],           \
                            double match_thresh, int iter_max, double s_rho_min,                          \
                            unsigned match_num_thresh, double reweight_distance, float min_mod);          \
+    /* edge_tracker::ExtRotVel (IMU branch): returns its bool; X[6], Wx[36], Rx[36] */                   \
+    int P##_ext_rot_vel(void *ctx, int slot, const double vel[3], double loc_unc, double hub_reweight,   \
+                        double X[6], double Wx[36], double Rx[36]);                                      \
     /* stage C */                                                                                        \
     int P##_forward_match(void *ctx, int slot_old, int slot_new);                                        \
     void P##_rotate_keylines(void *ctx, int slot, const double R[9]);                                    \

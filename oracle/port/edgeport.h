@@ -83,6 +83,7 @@ int directed_matching(const Ctx &c, Slot &s, const double Vel[3], const double R
                       int &kf_matchs, double min_thr_mod, double min_thr_ang, double max_radius, double loc_uncertainty);
 int regularize_1_iter(Slot &s, double thresh);
 void update_inverse_depth_kalman(const Ctx &c, Slot &s, const double vel[3], double ReshapeQAbsolute, double LocationUncertainty);
+bool ext_rot_vel(const Ctx &c, Slot &s, const double vel[3], double Wx[36], double Rx[36], double X[6], double LocUncert, double HubReweigth);
 double estimate_rescaling_opt(Slot &s, double &RKp, double s_rho_min, unsigned MatchNumMin, bool re_escale);
 
 }  // namespace port

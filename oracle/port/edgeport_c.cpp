@@ -223,6 +223,46 @@ void update_inverse_depth_kalman(const Ctx &c, Slot &s, const double vel[3], dou
     }
 }
 
+// ---- edge_tracker::ExtRotVel (edge_tracker.cpp:1207-1296) ------------------------------------------------------------------
+bool ext_rot_vel(const Ctx &c, Slot &s, const double vel[3], double Wx[36], double Rx[36], double X[6], double LocUncert, double HubReweigth) {
+    const double zf = c.zfm;
+    double JtJ[36], JtF[6];
+    for (int i = 0; i < 36; i++) JtJ[i] = 0;
+    for (int i = 0; i < 6; i++) JtF[i] = 0;
+    for (int i = 0; i < s.kn; i++) {
+        const OrcKeyLine &k = s.kl[i];
+        if (k.m_id < 0) continue;
+        const float u_x = k.u_m[0], u_y = k.u_m[1];
+        const double rho_t = 1 / (1 / k.rho + vel[2]);
+        const float qt_x = k.p_m_0[0] + rho_t * (vel[0] * zf - vel[2] * k.p_m_0[0]);
+        const float qt_y = k.p_m_0[1] + rho_t * (vel[1] * zf - vel[2] * k.p_m_0[1]);
+        const float q_x = k.p_m[0], q_y = k.p_m[1];
+        double phi[6];
+        phi[0] = u_x * rho_t * zf;
+        phi[1] = u_y * rho_t * zf;
+        phi[2] = u_x * (-rho_t * q_x) + u_y * (-rho_t * q_y);
+        phi[3] = -u_x * q_x * q_y / zf - u_y * (zf + q_y * q_y / zf);
+        phi[4] = +u_y * q_x * q_y / zf + u_x * (zf + q_x * q_x / zf);
+        phi[5] = -u_x * q_y + u_y * q_x;
+        double y = u_x * (k.p_m[0] - qt_x) + u_y * (k.p_m[1] - qt_y);
+        const float dqvel = u_x * (vel[0] * zf - vel[2] * k.p_m_0[0]) + u_y * (vel[1] * zf - vel[2] * k.p_m_0[1]);
+        const float s_y = std::sqrt(k.s_rho * k.s_rho * dqvel * dqvel + LocUncert * LocUncert);
+        double weigth = 1;
+        if (std::fabs(y) > HubReweigth) weigth = std::fabs(y) / HubReweigth;
+        for (int a = 0; a < 6; a++) phi[a] /= s_y * weigth;
+        y /= s_y * weigth;
+        for (int a = 0; a < 6; a++) {                      // Phi.T()*Phi and Phi.T()*Y, row by row
+            for (int b = 0; b < 6; b++) JtJ[a * 6 + b] += phi[a] * phi[b];
+            JtF[a] += phi[a] * y;
+        }
+    }
+    svd6_solve_pinv(JtJ, JtF, X, Rx);
+    for (int i = 0; i < 36; i++) Wx[i] = JtJ[i];
+    for (int i = 0; i < 36; i++) if (std::isnan(Rx[i])) return false;
+    for (int i = 0; i < 6; i++) if (std::isnan(X[i])) return false;
+    return true;
+}
+
 // ---- edge_tracker::EstimateReScalingOpt (edge_tracker.cpp:1104-1140) ----------------------------------------------------
 double estimate_rescaling_opt(Slot &s, double &RKp, double s_rho_min, unsigned MatchNumMin, bool re_escale) {
     if (s.kn <= 0) return 1;
@@ -368,6 +408,10 @@ double port_minimizer_v(void *ctx, int slot_new, int slot_old, double V[3], doub
     Ctx *c = (Ctx *)ctx;
     return minimizer_v(*c, c->slots[slot_new], c->slots[slot_old], V, RVel, match_thresh, iter_max, s_rho_min, match_num_thresh,
                        reweight_distance, min_mod);
+}
+int port_ext_rot_vel(void *ctx, int slot, const double vel[3], double loc_unc, double hub_reweight, double X[6], double Wx[36], double Rx[36]) {
+    Ctx *c = (Ctx *)ctx;
+    return ext_rot_vel(*c, c->slots[slot], vel, Wx, Rx, X, loc_unc, hub_reweight);
 }
 int port_forward_match(void *ctx, int slot_old, int slot_new) {
     Ctx *c = (Ctx *)ctx;

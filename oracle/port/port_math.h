@@ -172,6 +172,45 @@ inline void svd6_backsub(const double Ain[36], const double b[6], double h[6]) {
     }
 }
 
+// x = SVD(A).backsub(b) and pinv = SVD(A).get_pinv() for a symmetric 6x6 A (TooN/SVD.h:176-207), Jacobi eigen-solve
+inline void svd6_solve_pinv(const double Ain[36], const double b[6], double x[6], double pinv[36]) {
+    double A[36], V[36], e[6], inv[6];
+    for (int i = 0; i < 36; i++) { A[i] = Ain[i]; V[i] = 0; }
+    for (int i = 0; i < 6; i++) V[i * 7] = 1;
+    for (int sweep = 0; sweep < 60; sweep++) {
+        double off = 0, diag = 0;
+        for (int p = 0; p < 6; p++) {
+            diag += A[p * 7] * A[p * 7];
+            for (int q = p + 1; q < 6; q++) off += A[p * 6 + q] * A[p * 6 + q];
+        }
+        if (!(off > 1e-34 * diag) || !(off > 0)) break;
+        for (int p = 0; p < 5; p++)
+            for (int q = p + 1; q < 6; q++) {
+                const double apq = A[p * 6 + q];
+                if (apq == 0) continue;
+                const double theta = (A[q * 7] - A[p * 7]) / (2 * apq);
+                const double t = (theta >= 0 ? 1.0 : -1.0) / (std::fabs(theta) + std::sqrt(theta * theta + 1));
+                const double c = 1 / std::sqrt(t * t + 1), s = t * c;
+                for (int k = 0; k < 6; k++) { const double a = A[k * 6 + p], bb = A[k * 6 + q]; A[k * 6 + p] = c * a - s * bb; A[k * 6 + q] = s * a + c * bb; }
+                for (int k = 0; k < 6; k++) { const double a = A[p * 6 + k], bb = A[q * 6 + k]; A[p * 6 + k] = c * a - s * bb; A[q * 6 + k] = s * a + c * bb; }
+                for (int k = 0; k < 6; k++) { const double a = V[k * 6 + p], bb = V[k * 6 + q]; V[k * 6 + p] = c * a - s * bb; V[k * 6 + q] = s * a + c * bb; }
+            }
+    }
+    double smax = 0;
+    for (int i = 0; i < 6; i++) { e[i] = A[i * 7]; smax = std::fmax(smax, std::fabs(e[i])); }
+    for (int i = 0; i < 6; i++) inv[i] = (std::fabs(e[i]) * 1e9 <= smax) ? 0.0 : 1.0 / e[i];
+    for (int r = 0; r < 6; r++) {
+        double acc = 0;
+        for (int cc = 0; cc < 6; cc++) {
+            double p = 0;
+            for (int i = 0; i < 6; i++) p += V[r * 6 + i] * inv[i] * V[cc * 6 + i];
+            pinv[r * 6 + cc] = p;
+            acc += p * b[cc];
+        }
+        x[r] = acc;
+    }
+}
+
 // 3x3 helpers with TooN's accumulation order (row dot products summed from 0)
 inline void mat3_mul(const double A[9], const double B[9], double C[9]) {
     for (int i = 0; i < 3; i++)

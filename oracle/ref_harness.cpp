@@ -313,6 +313,19 @@ double ref_minimizer_v(void *ctx, int slot_new, int slot_old, double V[3], doubl
     return F;
 }
 
+int ref_ext_rot_vel(void *ctx, int slot, const double vel[3], double loc_unc, double hub_reweight, double X[6], double Wx[36],
+                    double Rx[36]) {
+    Ctx *c = (Ctx *)ctx;
+    Matrix<6, 6> W, R;
+    Vector<6> Xv;
+    const bool ok = c->slots[slot].ef->ExtRotVel(v3(vel), W, R, Xv, loc_unc, hub_reweight);   // rebvo_second_t.cpp:237
+    for (int i = 0; i < 6; i++) {
+        X[i] = Xv[i];
+        for (int j = 0; j < 6; j++) { Wx[i * 6 + j] = W(i, j); Rx[i * 6 + j] = R(i, j); }
+    }
+    return ok;
+}
+
 int ref_forward_match(void *ctx, int slot_old, int slot_new) {
     Ctx *c = (Ctx *)ctx;
     return c->slots[slot_old].ef->FordwardMatch(c->slots[slot_new].ef);

@@ -21,6 +21,8 @@
 #include <math.h>
 #include <string.h>
 
+#include <vector>
+
 #include "ctx.h"
 
 namespace edgehip {
@@ -584,6 +586,67 @@ __global__ void k_frame_glue(SeqDev *seqs, const double *__restrict__ t_in, edge
     }
 }
 
+// ---------------------------------------------------------------------------------------------------
+// edge_tracker::ExtRotVel (edge_tracker.cpp:1207-1296): one row of the linear 6-DoF system per forward-matched
+// KeyLine, normalised by its expected error and a Huber-like weight; 21 + 6 sums of Phi^T Phi, Phi^T Y (+ the row
+// count) reduced with wave shuffles to one partial per block.  The 6x6 SVD solve stays with the caller.
+// ---------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_ext_rotvel(const KlSoA *kls, const int32_t *__restrict__ kns, const double *__restrict__ vel,
+                                                    double *__restrict__ partials, int nblk, double zf, double loc_unc, double hub) {
+    const int seq = blockIdx.z, i = blockIdx.x * 256 + threadIdx.x;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const double v0 = vel[seq * 3 + 0], v1 = vel[seq * 3 + 1], v2 = vel[seq * 3 + 2];
+    double row[6] = {0, 0, 0, 0, 0, 0}, y = 0, used = 0;
+    if (i < kns[seq] && kls[seq].m_id[i] >= 0) {
+        const KlSoA &K = kls[seq];
+        const float2 u = K.u_m[i], pm = K.p_m[i], pm0 = K.p_m_0[i];
+        const double rho_t = 1 / (1 / K.rho[i] + v2);
+        const float qt_x = (float)((double)pm0.x + rho_t * (v0 * zf - v2 * (double)pm0.x));
+        const float qt_y = (float)((double)pm0.y + rho_t * (v1 * zf - v2 * (double)pm0.y));
+        const double s_rho = K.s_rho[i];
+        const float q_x = pm.x, q_y = pm.y;
+        row[0] = (double)u.x * rho_t * zf;
+        row[1] = (double)u.y * rho_t * zf;
+        row[2] = (double)u.x * (-rho_t * (double)q_x) + (double)u.y * (-rho_t * (double)q_y);
+        row[3] = (double)(-u.x * q_x * q_y) / zf - (double)u.y * (zf + (double)(q_y * q_y) / zf);
+        row[4] = (double)(+u.y * q_x * q_y) / zf + (double)u.x * (zf + (double)(q_x * q_x) / zf);
+        row[5] = (double)(-u.x * q_y + u.y * q_x);
+        y = (double)(u.x * (pm.x - qt_x) + u.y * (pm.y - qt_y));
+        const float dqvel = (float)((double)u.x * (v0 * zf - v2 * (double)pm0.x) + (double)u.y * (v1 * zf - v2 * (double)pm0.y));
+        const float s_y = (float)sqrt(s_rho * s_rho * (double)dqvel * (double)dqvel + loc_unc * loc_unc);
+        double weigth = 1;
+        if (fabs(y) > hub) weigth = fabs(y) / hub;
+        const double den = (double)s_y * weigth;
+#pragma unroll
+        for (int k = 0; k < 6; k++) row[k] /= den;
+        y /= den;
+        used = 1;
+    }
+    double sums[kNumSums];
+    {
+        int ns = 0;
+#pragma unroll
+        for (int a = 0; a < 6; a++)
+#pragma unroll
+            for (int b = a; b < 6; b++) sums[ns++] = row[a] * row[b];
+#pragma unroll
+        for (int a = 0; a < 6; a++) sums[ns++] = row[a] * y;
+        sums[ns++] = used;
+    }
+    __shared__ double s_red[4][kNumSums];
+#pragma unroll
+    for (int k = 0; k < kNumSums; k++) {
+        double v = sums[k];
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+        if (lane == 0) s_red[wave][k] = v;
+    }
+    __syncthreads();
+    if (threadIdx.x < kNumSums)
+        partials[((size_t)seq * nblk + blockIdx.x) * kNumSums + threadIdx.x] =
+            ((s_red[0][threadIdx.x] + s_red[1][threadIdx.x]) + s_red[2][threadIdx.x]) + s_red[3][threadIdx.x];
+}
+
 // REBVO::Reset() as executed by SecondThread after a frame (rebvo_second_t.cpp:609-620)
 __global__ __launch_bounds__(256) void k_depth_reset(const KlSoA *kls, const int32_t *__restrict__ kns, SeqDev *seqs, int only_seq) {
     const int seq = blockIdx.z, i = blockIdx.x * 256 + threadIdx.x;
@@ -712,6 +775,84 @@ int edgehip_regularize_ekf(edgehip_ctx *c, int slot, int do_reg, int do_ekf) {
 int edgehip_rescale(edgehip_ctx *c, int slot) {
     if (int e = chk2(c, slot, slot)) return e;
     return rescale_enqueue(c, slot);
+}
+
+// Host-side 6x6 symmetric eigen-decomposition (cyclic Jacobi), standing in for LAPACK dgesvd_ behind TooN::SVD<>
+static void jacobi_eig6_host(const double Ain[36], double V[36], double e[6]) {
+    double A[36];
+    for (int i = 0; i < 36; i++) { A[i] = Ain[i]; V[i] = 0; }
+    for (int i = 0; i < 6; i++) V[i * 7] = 1;
+    for (int sweep = 0; sweep < 60; sweep++) {
+        double off = 0, diag = 0;
+        for (int p = 0; p < 6; p++) {
+            diag += A[p * 7] * A[p * 7];
+            for (int q = p + 1; q < 6; q++) off += A[p * 6 + q] * A[p * 6 + q];
+        }
+        if (!(off > 1e-34 * diag) || !(off > 0)) break;
+        for (int p = 0; p < 5; p++)
+            for (int q = p + 1; q < 6; q++) {
+                const double apq = A[p * 6 + q];
+                if (apq == 0) continue;
+                const double theta = (A[q * 7] - A[p * 7]) / (2 * apq);
+                const double t = (theta >= 0 ? 1.0 : -1.0) / (fabs(theta) + sqrt(theta * theta + 1));
+                const double cs = 1 / sqrt(t * t + 1), sn = t * cs;
+                for (int k = 0; k < 6; k++) { const double a = A[k * 6 + p], b = A[k * 6 + q]; A[k * 6 + p] = cs * a - sn * b; A[k * 6 + q] = sn * a + cs * b; }
+                for (int k = 0; k < 6; k++) { const double a = A[p * 6 + k], b = A[q * 6 + k]; A[p * 6 + k] = cs * a - sn * b; A[q * 6 + k] = sn * a + cs * b; }
+                for (int k = 0; k < 6; k++) { const double a = V[k * 6 + p], b = V[k * 6 + q]; V[k * 6 + p] = cs * a - sn * b; V[k * 6 + q] = sn * a + cs * b; }
+            }
+    }
+    for (int i = 0; i < 6; i++) e[i] = A[i * 7];
+}
+
+int edgehip_ext_rot_vel(edgehip_ctx *c, int slot, const double *vel, double loc_unc, double hub_reweight, double *X, double *Wx,
+                        double *Rx, int32_t *ok) {
+    if (int e = chk2(c, slot, slot)) return e;
+    if (!vel || !X) return EDGEHIP_ERR_ARG;
+    const DevicePlan &pl = c->plan;
+    const int B = pl.nseq, nblk = (pl.cap + 255) / 256;
+    if (nblk > c->nblk_tvr) { set_error("ext_rot_vel: partial table too small"); return EDGEHIP_ERR_STATE; }
+    EH_CHECK(hipStreamSynchronize(c->stream));
+    memcpy(c->pinned_out, vel, sizeof(double) * 3 * B);
+    double *dvel = c->rot_buf;                                      // [B][9] scratch, 3 used
+    EH_CHECK(hipMemcpyAsync(dvel, c->pinned_out, sizeof(double) * 3 * B, hipMemcpyHostToDevice, c->stream));
+    EH_CHECK(hipMemsetAsync(c->partials, 0, sizeof(double) * (size_t)B * c->nblk_tvr * kNumSums, c->stream));
+    hipLaunchKernelGGL(k_ext_rotvel, dim3(nblk, 1, B), dim3(256), 0, c->stream, kldev(c, slot), c->kn_slot + (size_t)slot * B, dvel,
+                       c->partials, c->nblk_tvr, pl.zfm, loc_unc, hub_reweight);
+    EH_LAUNCH_CHECK();
+    std::vector<double> part((size_t)B * c->nblk_tvr * kNumSums);
+    EH_CHECK(hipMemcpyAsync(part.data(), c->partials, sizeof(double) * part.size(), hipMemcpyDeviceToHost, c->stream));
+    EH_CHECK(hipStreamSynchronize(c->stream));
+    for (int s = 0; s < B; s++) {
+        double sum[kNumSums] = {0};
+        for (int b = 0; b < nblk; b++)
+            for (int k = 0; k < kNumSums; k++) sum[k] += part[((size_t)s * c->nblk_tvr + b) * kNumSums + k];
+        double JtJ[36], JtF[6];
+        int ns = 0;
+        for (int a = 0; a < 6; a++)
+            for (int b = a; b < 6; b++) { JtJ[a * 6 + b] = sum[ns]; JtJ[b * 6 + a] = sum[ns]; ns++; }
+        for (int a = 0; a < 6; a++) JtF[a] = sum[ns++];
+        // X = SVD(JtJ).backsub(JtF), Rx = SVD(JtJ).get_pinv() with TooN's conditioning (SVD.h:176-207, 1e9)
+        double V[36], e[6], inv[6], smax = 0;
+        jacobi_eig6_host(JtJ, V, e);
+        for (int i = 0; i < 6; i++) smax = fmax(smax, fabs(e[i]));
+        for (int i = 0; i < 6; i++) inv[i] = (fabs(e[i]) * 1e9 <= smax) ? 0.0 : 1.0 / e[i];
+        bool good = true;
+        for (int r = 0; r < 6; r++) {
+            double x = 0;
+            for (int cc = 0; cc < 6; cc++) {
+                double p = 0;
+                for (int i = 0; i < 6; i++) p += V[r * 6 + i] * inv[i] * V[cc * 6 + i];
+                if (Rx) Rx[(size_t)s * 36 + r * 6 + cc] = p;
+                if (p != p) good = false;
+                x += p * JtF[cc];
+            }
+            X[(size_t)s * 6 + r] = x;
+            if (x != x) good = false;
+        }
+        if (Wx) memcpy(Wx + (size_t)s * 36, JtJ, sizeof JtJ);
+        if (ok) ok[s] = good ? 1 : 0;
+    }
+    return 0;
 }
 
 int edgehip_depth_reset(edgehip_ctx *c, int seq) {

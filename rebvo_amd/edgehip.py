@@ -141,7 +141,7 @@ EXPORTS = [
     "edgehip_upload_keylines", "edgehip_download_plane", "edgehip_download_field", "edgehip_profile_enable",
     "edgehip_profile_count", "edgehip_profile_name", "edgehip_profile_read", "edgehip_profile_select",
     "edgehip_upload_rgb_indexed", "edgehip_set_nav_log", "edgehip_read_nav_log",
-    "edgehip_build_undistort_map", "edgehip_download_undistorted", "edgehip_depth_reset", "edgehip_minimizer_v",
+    "edgehip_build_undistort_map", "edgehip_download_undistorted", "edgehip_depth_reset", "edgehip_minimizer_v", "edgehip_ext_rot_vel",
 ]
 
 _lib = None
@@ -214,6 +214,15 @@ class EdgeHip:
         self._ck(self.lib.edgehip_minimizer_v(self.ctx, slot_new, slot_old, _dp(V), _dp(smin), C.c_float(min_mod), C.c_double(match_thresh),
                                               iter_max, C.c_uint32(match_num_thresh), C.c_double(reweight_distance), _dp(RV), _dp(F)))
         return V, RV, F
+
+    def ext_rot_vel(self, slot, vel, loc_unc, hub_reweight):
+        """edge_tracker::ExtRotVel for every sequence -> (X[nseq,6], Wx[nseq,6,6], Rx[nseq,6,6], ok[nseq])."""
+        vel = np.ascontiguousarray(np.broadcast_to(np.asarray(vel, np.float64), (self.nseq, 3))).copy()
+        X, Wx, Rx = np.zeros((self.nseq, 6)), np.zeros((self.nseq, 6, 6)), np.zeros((self.nseq, 6, 6))
+        ok = np.zeros(self.nseq, np.int32)
+        self._ck(self.lib.edgehip_ext_rot_vel(self.ctx, slot, _dp(vel), C.c_double(loc_unc), C.c_double(hub_reweight), _dp(X), _dp(Wx),
+                                              _dp(Rx), C.c_void_p(ok.ctypes.data)))
+        return X, Wx, Rx, ok
 
     def depth_reset(self, seq=-1):
         """REBVO::Reset() (rebvo_second_t.cpp:609-620) for one sequence or all (-1)."""

@@ -104,3 +104,21 @@ def test_minimizer_v_bit_exact():
         rb = b.minimizer_v(sn, so, V0, 0.5, it, b.quantile(so), mnt, 2.0, b.retuned(so))
         assert ra["F"] == rb["F"] and np.array_equal(ra["V"], rb["V"]) and np.array_equal(ra["RVel"], rb["RVel"])
         assert np.array_equal(a.keylines(so)["m_id_f"], b.keylines(so)["m_id_f"])
+
+
+def test_ext_rot_vel():
+    """IMU-branch ExtRotVel: Phi^T Phi identical (same row-by-row fp64 accumulation); X and the pseudo inverse agree to
+    the difference between LAPACK's SVD and the Jacobi eigen-solve (1e-12)."""
+    w, h = 376, 240
+    frames = [f for f, _, _ in synth.billboard_sequence(w, h, 6)]
+    a, b = oracle.Oracle("ref", oracle.euroc_params(w, h)), oracle.Oracle("port", oracle.euroc_params(w, h))
+    for k, f in enumerate(frames):
+        a.process_frame(f, 0.05 * k)
+    s = a.cur_slot()
+    b.set_keylines(s, a.keylines(s), a.mask(s), a.retuned(s))
+    for vel in ((1e-3, -4e-4, 3e-4), (0, 0, 0)):
+        ra, rb = a.ext_rot_vel(s, vel, 1.0, 2.0), b.ext_rot_vel(s, vel, 1.0, 2.0)
+        assert ra["ok"] and rb["ok"]
+        assert np.array_equal(ra["Wx"], rb["Wx"])
+        assert np.allclose(ra["X"], rb["X"], rtol=1e-11, atol=1e-18)
+        assert np.allclose(ra["Rx"], rb["Rx"], rtol=1e-11, atol=1e-12 * np.abs(ra["Rx"]).max())

@@ -8,7 +8,7 @@ bit-identical); rescale sums are accumulated in a different order => 1e-10.
 import numpy as np
 import pytest
 
-from rebvo_amd import edgehip
+from rebvo_amd import edgehip, synth
 from helpers import inject_pair, oracle_pair, rel_err, to_edgehip_kl
 
 pytestmark = pytest.mark.gpu
@@ -114,3 +114,29 @@ def test_regularize_only_and_ekf_only(tracked):
     assert np.allclose(kg["rho"], orc.keylines(sn)["rho"], rtol=1e-13, atol=0)
     assert np.allclose(kg["s_rho"], orc.keylines(sn)["s_rho"], rtol=1e-13, atol=0)
     assert np.any(kg["rho"] != k0["rho"])
+
+
+def test_ext_rot_vel():
+    """IMU-branch ExtRotVel: rows + 27 sums on the GPU, 6x6 SVD solve on the host.
+    Phi^T Phi within 1e-11 (tree vs sequential fp64 summation), X within 1e-8 relative."""
+    from oracle import oracle
+    if not oracle.available("ref"):
+        pytest.skip("oracle/_ref not built")
+    w, h = 376, 240
+    frames = [f for f, _, _ in synth.billboard_sequence(w, h, 6)]
+    orc = oracle.Oracle("ref", oracle.euroc_params(w, h))
+    for k, f in enumerate(frames):
+        orc.process_frame(f, 0.05 * k)
+    s = orc.cur_slot()
+    eh = edgehip.EdgeHip(edgehip.euroc_params(w, h), nseq=2, nslots=2)
+    for q in range(2):
+        eh.upload_keylines(q, 1, to_edgehip_kl(orc.keylines(s)), orc.mask(s), orc.retuned(s))
+    for vel in ((1e-3, -4e-4, 3e-4), (0.0, 0.0, 0.0)):
+        ref = orc.ext_rot_vel(s, vel, 1.0, 2.0)
+        X, Wx, Rx, ok = eh.ext_rot_vel(1, vel, 1.0, 2.0)
+        assert ref["ok"] and ok.all()
+        for q in range(2):
+            assert rel_err(Wx[q], ref["Wx"]) < 1e-11
+            assert np.allclose(X[q], ref["X"], rtol=1e-8, atol=1e-14)
+            assert rel_err(Rx[q], ref["Rx"]) < 1e-8
+    eh.close()
