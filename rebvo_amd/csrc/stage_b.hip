@@ -287,11 +287,20 @@ __global__ __launch_bounds__(256) void k_field_raster(const KlSoA *kls, const in
     // in-tile AND in-image in two unsigned compares: lx >= 0 implies xi >= tx0 >= 0, and the tile is clipped to
     // the image once per block
     const unsigned ex = (unsigned)min(FT, w - tx0), ey = (unsigned)min(FT, h - ty0);
-    for (int li = tid; li < cnt; li += 256) {
+    // FSPLIT threads share one KeyLine's in-tile t-range: a bin holds ~170 KeyLines with ranges of 1..2r samples, so
+    // one thread per KeyLine leaves a third of the lanes idle and the rest waiting for the longest range.
+    constexpr int FSPLIT = 4;
+    for (int wi = tid; wi < cnt * FSPLIT; wi += 256) {
+        const int li = wi / FSPLIT, part = wi - li * FSPLIT;
         const int ikl = list[li];
         const MatchRec r = k.rec[ikl];
         int t0, t1;
         if (!tile_trange(r, tx0, ty0, radius, t0, t1)) continue;
+        {
+            const int chunk = (t1 - t0 + FSPLIT) / FSPLIT;   // ceil(len / FSPLIT)
+            t0 += part * chunk;
+            t1 = min(t1, t0 + chunk - 1);
+        }
         const uint32_t idk = (uint32_t)(0xFFFF - ikl);
         for (int t = t0; t <= t1; t++) {
             const float fx = r.u_mx * (float)t + r.c_px;   // global_tracker.cpp:78, same float expression
