@@ -114,6 +114,33 @@ def pmc_traffic(group, nseq):
     return int(total) if found else None
 
 
+def _usable_cores():
+    """Cores this process may actually use: affinity mask capped by the cgroup CPU quota (cpu.max)."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        if quota != "max":
+            n = min(n, max(1, int(int(quota) / int(period))))
+    except (OSError, ValueError):
+        pass
+    return n
+
+
+def _cpu_worker(job):
+    """One CPU-reference sequence in its own process: returns the seconds spent in stage A + B/C of the timed frames."""
+    kind, nfr, npool, seed = job
+    from oracle import oracle
+    from rebvo_amd import synth
+    frames = [f for f, _, _ in synth.billboard_sequence(W, H, min(npool, 12), seed=seed)]
+    orc = oracle.Oracle("ref" if kind == "reference" else "port", oracle.euroc_params(W, H))
+    for k in range(6):
+        orc.process_frame(frames[tri(k, len(frames))], 0.05 * k)
+    t0 = time.perf_counter()
+    for k in range(6, 6 + nfr):
+        orc.process_frame(frames[tri(k, len(frames))], 0.05 * k)
+    return time.perf_counter() - t0
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -126,6 +153,9 @@ def main():
                          "behind the bandwidth-bound kernels of the other")
     ap.add_argument("--pool", type=int, default=24, help="rendered frames in the HBM pool")
     ap.add_argument("--cpu-frames", type=int, default=200, help="frames of the CPU-baseline sample (0 = skip)")
+    ap.add_argument("--cpu-procs", type=int, default=0,
+                    help="also time the CPU reference node-saturating: this many independent sequences in parallel "
+                         "processes (SURVEY.md section 8d mode iii; 0 = skip, -1 = one per usable host core)")
     ap.add_argument("--no-roofline-events", action="store_true")
     args = ap.parse_args()
 
@@ -260,11 +290,29 @@ def main():
                     tc += nav.dtp0 + nav.dtp1
                 cpu = {"value": round(args.cpu_frames / tc, 2), "unit": "frames/s", "cores": 1, "kind": kind,
                        "sample": f"{args.cpu_frames} frames of sequence 0 (same 752x480 pool), serial stage A + B/C "
-                                 f"on 1 of {os.cpu_count()} host cores; reference threading overlaps the two stages "
+                                 f"on 1 of {_usable_cores()} usable host cores; reference threading overlaps the two stages "
                                  "on 2 cores",
                        "ms_per_frame": round(tc / args.cpu_frames * 1e3, 2)}
         except Exception as e:  # the oracle is optional test infrastructure; never fatal for the bench
             cpu = {"value": None, "error": str(e)[:200]}
+        if cpu and cpu.get("value") and args.cpu_procs:
+            # node-saturating mode: P independent sequences, one process each (the reference needs up to 3 threads per
+            # sequence; its 2 compute stages are run back to back here, so P = cores // 3 is conservative for the CPU)
+            try:
+                import multiprocessing as mp
+                ncpu = _usable_cores()
+                P = args.cpu_procs if args.cpu_procs > 0 else max(1, ncpu)   # one core per sequence (stages run back to back)
+                nfr = max(20, args.cpu_frames // 4)
+                with mp.get_context("spawn").Pool(P) as pool_:   # spawn: never fork a process that holds a HIP context
+                    t0c = time.perf_counter()
+                    res = pool_.map(_cpu_worker, [(kind, nfr, args.pool, 11 + i) for i in range(P)])
+                    wall = time.perf_counter() - t0c
+                busy = max(r for r in res)
+                cpu["node"] = {"value": round(P * nfr / busy, 1), "unit": "frames/s", "processes": P, "cores": ncpu,
+                               "sample": f"{P} sequences x {nfr} frames in parallel processes (slowest process {busy:.2f} s, "
+                                         f"wall incl. start-up {wall:.2f} s)"}
+            except Exception as e:
+                cpu["node"] = {"value": None, "error": str(e)[:200]}
 
     line = {
         "metric": "frames/sec (DoG+extract+track+depth) 752x480 EuRoC",
