@@ -13,6 +13,22 @@
 namespace edgehip {
 
 static thread_local std::string g_err;
+
+int order_a_after_bc(edgehip_ctx *c) {
+    EH_CHECK(hipEventRecord(c->ev_tmp, c->stream));
+    EH_CHECK(hipStreamWaitEvent(c->stream_a, c->ev_tmp, 0));
+    return 0;
+}
+int order_bc_after_a(edgehip_ctx *c) {
+    EH_CHECK(hipEventRecord(c->ev_tmp, c->stream_a));
+    EH_CHECK(hipStreamWaitEvent(c->stream, c->ev_tmp, 0));
+    return 0;
+}
+int sync_all(edgehip_ctx *c) {
+    EH_CHECK(hipStreamSynchronize(c->stream_a));
+    EH_CHECK(hipStreamSynchronize(c->stream));
+    return 0;
+}
 void set_error(const std::string &m) { g_err = m; }
 int hip_fail(hipError_t e, const char *what, const char *file, int line) {
     char buf[512];
@@ -27,7 +43,7 @@ static const char *kProfNames[PROF_COUNT] = {
     "C.forward_match", "C.rotate", "C.directed_matching", "C.regularize_ekf", "C.rescale", "C.pose",
     "A.level", "B.minimizer"};
 
-ProfScope::ProfScope(edgehip_ctx *ctx, int pid) : c(ctx), id(pid) {
+ProfScope::ProfScope(edgehip_ctx *ctx, int pid, hipStream_t stream) : c(ctx), id(pid), st(stream ? stream : ctx->stream) {
     Profiler *p = c->prof;
     if (!p || !p->on || !((p->mask >> pid) & 1ull)) return;
     auto get = [&]() {
@@ -38,11 +54,11 @@ ProfScope::ProfScope(edgehip_ctx *ctx, int pid) : c(ctx), id(pid) {
     };
     a = get();
     b = get();
-    (void)hipEventRecord(a, c->stream);
+    (void)hipEventRecord(a, st);
 }
 ProfScope::~ProfScope() {
     if (!a) return;
-    (void)hipEventRecord(b, c->stream);
+    (void)hipEventRecord(b, st);
     c->prof->pending.push_back({a, b, id});
 }
 
@@ -186,6 +202,11 @@ struct CtxAllocs {
 };
 static std::vector<std::pair<edgehip_ctx *, CtxAllocs *>> g_allocs;
 
+static void init_state_a(const edgehip_params &p, SeqA *s) {
+    memset(s, 0, sizeof(*s));
+    s->tresh = p.detector_thresh;           // rebvo_first_t.cpp:94
+    s->band_trunc = -1;
+}
 static void init_state(const edgehip_params &p, SeqDev *s) {
     memset(s, 0, sizeof(*s));
     s->pub.tresh = p.detector_thresh;       // rebvo_first_t.cpp:94
@@ -260,6 +281,14 @@ int edgehip_create(const edgehip_params *params, int nseq, int nslots, int devic
     c->frames_seen = 0;
     c->prof = new Profiler();
     EH_CHECK(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
+    EH_CHECK(hipStreamCreateWithFlags(&c->stream_a, hipStreamNonBlocking));
+    for (int i = 0; i < 4; i++) {
+        EH_CHECK(hipEventCreateWithFlags(&c->ev_a[i], hipEventDisableTiming));
+        EH_CHECK(hipEventCreateWithFlags(&c->ev_use[i], hipEventDisableTiming));
+        c->use_valid[i] = false;
+    }
+    EH_CHECK(hipEventCreateWithFlags(&c->ev_tmp, hipEventDisableTiming));
+    if (nslots > 4) { set_error("edgehip_create: at most 4 frame slots"); return EDGEHIP_ERR_ARG; }
 
     DevicePlan &pl = c->plan;
     pl.w = p.w; pl.h = p.h; pl.n = p.w * p.h; pl.nseq = nseq; pl.nslots = nslots;
@@ -300,6 +329,8 @@ int edgehip_create(const edgehip_params *params, int nseq, int nslots, int devic
     EH_TRY(dmalloc(c, &c->div_lut, kDivLutMax, al->dev));
     EH_TRY(dmalloc(c, &c->pinv, 75, al->dev));
     EH_TRY(dmalloc(c, &c->seq, B, al->dev, 0));
+    EH_TRY(dmalloc(c, &c->seqa, B, al->dev, 0));
+    EH_TRY(dmalloc(c, &c->tresh_slot, S * B, al->dev, 0));
     c->fc_rows = std::max<int>(nslots, kRefRing);
     c->fc_index = 0;
     EH_TRY(dmalloc(c, &c->framecount, (size_t)c->fc_rows * B, al->dev, 0));
@@ -397,12 +428,14 @@ int edgehip_create(const edgehip_params *params, int nseq, int nslots, int devic
         void *q;
         EH_CHECK(hipHostMalloc(&q, c->pinned_rgb_bytes, hipHostMallocDefault)); al->host.push_back(q); c->pinned_rgb = (uint8_t *)q;
         EH_CHECK(hipHostMalloc(&q, sizeof(SeqDev) * B, hipHostMallocDefault)); al->host.push_back(q); c->pinned_seq = (SeqDev *)q;
+        EH_CHECK(hipHostMalloc(&q, sizeof(SeqA) * B, hipHostMallocDefault)); al->host.push_back(q); c->pinned_seqa = (SeqA *)q;
         EH_CHECK(hipHostMalloc(&q, sizeof(double) * B * 64, hipHostMallocDefault)); al->host.push_back(q); c->pinned_out = (double *)q;
         EH_CHECK(hipHostMalloc(&q, sizeof(double) * B * 8 + sizeof(int32_t) * B * 8, hipHostMallocDefault)); al->host.push_back(q); c->pinned_t = (double *)q;
         EH_CHECK(hipHostMalloc(&q, sizeof(edgehip_nav) * B, hipHostMallocDefault)); al->host.push_back(q); c->pinned_nav = (edgehip_nav *)q;
     }
-    for (size_t i = 0; i < B; i++) init_state(p, &c->pinned_seq[i]);
+    for (size_t i = 0; i < B; i++) { init_state(p, &c->pinned_seq[i]); init_state_a(p, &c->pinned_seqa[i]); }
     EH_CHECK(hipMemcpyAsync(c->seq, c->pinned_seq, sizeof(SeqDev) * B, hipMemcpyHostToDevice, c->stream));
+    EH_CHECK(hipMemcpyAsync(c->seqa, c->pinned_seqa, sizeof(SeqA) * B, hipMemcpyHostToDevice, c->stream));
     EH_CHECK(hipStreamSynchronize(c->stream));
 #undef EH_TRY
     *out = c;
@@ -412,6 +445,7 @@ int edgehip_create(const edgehip_params *params, int nseq, int nslots, int devic
 int edgehip_destroy(edgehip_ctx *c) {
     if (!c) return EDGEHIP_ERR_ARG;
     (void)hipSetDevice(c->device);
+    (void)hipStreamSynchronize(c->stream_a);
     (void)hipStreamSynchronize(c->stream);
     for (size_t i = 0; i < g_allocs.size(); i++) {
         if (g_allocs[i].first != c) continue;
@@ -427,6 +461,9 @@ int edgehip_destroy(edgehip_ctx *c) {
         delete c->prof;
     }
     if (c->nav_log) (void)hipFree(c->nav_log);
+    for (int i = 0; i < 4; i++) { (void)hipEventDestroy(c->ev_a[i]); (void)hipEventDestroy(c->ev_use[i]); }
+    (void)hipEventDestroy(c->ev_tmp);
+    (void)hipStreamDestroy(c->stream_a);
     (void)hipStreamDestroy(c->stream);
     delete c;
     return 0;
@@ -435,9 +472,11 @@ int edgehip_destroy(edgehip_ctx *c) {
 int edgehip_reset(edgehip_ctx *c) {
     if (!c) return EDGEHIP_ERR_ARG;
     const size_t B = c->plan.nseq, S = c->plan.nslots;
-    EH_CHECK(hipStreamSynchronize(c->stream));
-    for (size_t i = 0; i < B; i++) init_state(c->p, &c->pinned_seq[i]);
+    if (int e = sync_all(c)) return e;
+    for (size_t i = 0; i < B; i++) { init_state(c->p, &c->pinned_seq[i]); init_state_a(c->p, &c->pinned_seqa[i]); }
+    for (int i = 0; i < 4; i++) c->use_valid[i] = false;
     EH_CHECK(hipMemcpyAsync(c->seq, c->pinned_seq, sizeof(SeqDev) * B, hipMemcpyHostToDevice, c->stream));
+    EH_CHECK(hipMemcpyAsync(c->seqa, c->pinned_seqa, sizeof(SeqA) * B, hipMemcpyHostToDevice, c->stream));
     EH_CHECK(hipMemsetAsync(c->framecount, 0, sizeof(uint32_t) * c->fc_rows * B, c->stream));
     EH_CHECK(hipMemsetAsync(c->kn_slot, 0, sizeof(int32_t) * S * B, c->stream));
     EH_CHECK(hipStreamSynchronize(c->stream));
@@ -448,8 +487,7 @@ int edgehip_reset(edgehip_ctx *c) {
 
 int edgehip_sync(edgehip_ctx *c) {
     if (!c) return EDGEHIP_ERR_ARG;
-    EH_CHECK(hipStreamSynchronize(c->stream));
-    return 0;
+    return sync_all(c);
 }
 void *edgehip_stream(edgehip_ctx *c) { return c ? (void *)c->stream : nullptr; }
 
@@ -474,17 +512,17 @@ int edgehip_upload_rgb(edgehip_ctx *c, int slot, const uint8_t *rgb24, int seq_f
     if (!rgb24 || seq_first < 0 || count < 1 || seq_first + count > c->plan.nseq) { set_error("upload_rgb: bad range"); return EDGEHIP_ERR_ARG; }
     const size_t fb = (size_t)c->plan.n * 3;
     // the pinned buffer is reused: wait for the previous copy out of it
-    EH_CHECK(hipStreamSynchronize(c->stream));
+    EH_CHECK(hipStreamSynchronize(c->stream_a));
     memcpy(c->pinned_rgb + fb * seq_first, rgb24, fb * count);
     EH_CHECK(hipMemcpyAsync(rgbof(c, slot) + fb * seq_first, c->pinned_rgb + fb * seq_first, fb * count,
-                            hipMemcpyHostToDevice, c->stream));
+                            hipMemcpyHostToDevice, c->stream_a));
     return 0;
 }
 
 int edgehip_upload_rgb_device(edgehip_ctx *c, int slot, const void *rgb24_dev) {
     if (int e = check_slot(c, slot)) return e;
     if (!rgb24_dev) return EDGEHIP_ERR_ARG;
-    EH_CHECK(hipMemcpyAsync(rgbof(c, slot), rgb24_dev, (size_t)c->plan.nseq * c->plan.n * 3, hipMemcpyDeviceToDevice, c->stream));
+    EH_CHECK(hipMemcpyAsync(rgbof(c, slot), rgb24_dev, (size_t)c->plan.nseq * c->plan.n * 3, hipMemcpyDeviceToDevice, c->stream_a));
     return 0;
 }
 
@@ -498,9 +536,9 @@ int edgehip_upload_rgb_indexed(edgehip_ctx *c, int slot, const void *pool_dev, i
         if (idx[s] < 0 || idx[s] >= pool_frames) { set_error("upload_rgb_indexed: index out of range"); return EDGEHIP_ERR_ARG; }
         pi[s] = idx[s];
     }
-    EH_CHECK(hipMemcpyAsync(c->idx_dev, pi, sizeof(int32_t) * B, hipMemcpyHostToDevice, c->stream));
+    EH_CHECK(hipMemcpyAsync(c->idx_dev, pi, sizeof(int32_t) * B, hipMemcpyHostToDevice, c->stream_a));
     const size_t frame_vec = (size_t)c->plan.n * 3 / 16;  // w % 4 == 0 => n*3 % 4 == 0; need %16: checked at create
-    hipLaunchKernelGGL(k_gather_frames, dim3(64, B), dim3(256), 0, c->stream, (const uint4 *)pool_dev, c->idx_dev,
+    hipLaunchKernelGGL(k_gather_frames, dim3(64, B), dim3(256), 0, c->stream_a, (const uint4 *)pool_dev, c->idx_dev,
                        (uint4 *)rgbof(c, slot), frame_vec);
     EH_LAUNCH_CHECK();
     return 0;
@@ -534,18 +572,28 @@ int edgehip_read_nav_log(edgehip_ctx *c, int first, int count, edgehip_nav *out)
 
 int edgehip_stage_a(edgehip_ctx *c, int slot) {
     if (int e = check_slot(c, slot)) return e;
-    return stage_a_enqueue(c, slot);
+    if (int e = order_a_after_bc(c)) return e;
+    if (int e = stage_a_enqueue(c, slot)) return e;
+    return order_bc_after_a(c);
 }
 
 static int fetch_states(edgehip_ctx *c) {
+    if (int e = sync_all(c)) return e;
     EH_CHECK(hipMemcpyAsync(c->pinned_seq, c->seq, sizeof(SeqDev) * c->plan.nseq, hipMemcpyDeviceToHost, c->stream));
+    EH_CHECK(hipMemcpyAsync(c->pinned_seqa, c->seqa, sizeof(SeqA) * c->plan.nseq, hipMemcpyDeviceToHost, c->stream));
     EH_CHECK(hipStreamSynchronize(c->stream));
+    for (int s = 0; s < c->plan.nseq; s++) {   // the public record shows the detector state too
+        c->pinned_seq[s].pub.tresh = c->pinned_seqa[s].tresh;
+        c->pinned_seq[s].pub.l_kl_num = c->pinned_seqa[s].l_kl_num;
+        c->pinned_seq[s].pub.retuned_thresh = c->pinned_seqa[s].retuned;
+    }
     return 0;
 }
 
 int edgehip_get_kn(edgehip_ctx *c, int slot, int32_t *kn_out) {
     if (int e = check_slot(c, slot)) return e;
     if (!kn_out) return EDGEHIP_ERR_ARG;
+    if (int e = sync_all(c)) return e;
     EH_CHECK(hipMemcpyAsync(c->pinned_out, c->kn_slot + (size_t)slot * c->plan.nseq, sizeof(int32_t) * c->plan.nseq,
                             hipMemcpyDeviceToHost, c->stream));
     EH_CHECK(hipStreamSynchronize(c->stream));
@@ -566,7 +614,11 @@ int edgehip_set_state(edgehip_ctx *c, int seq, const edgehip_seq_state *in) {
     if (!in) return EDGEHIP_ERR_ARG;
     if (int e = fetch_states(c)) return e;
     c->pinned_seq[seq].pub = *in;
+    c->pinned_seqa[seq].tresh = in->tresh;
+    c->pinned_seqa[seq].l_kl_num = in->l_kl_num;
+    c->pinned_seqa[seq].retuned = in->retuned_thresh;
     EH_CHECK(hipMemcpyAsync(c->seq + seq, c->pinned_seq + seq, sizeof(SeqDev), hipMemcpyHostToDevice, c->stream));
+    EH_CHECK(hipMemcpyAsync(c->seqa + seq, c->pinned_seqa + seq, sizeof(SeqA), hipMemcpyHostToDevice, c->stream));
     EH_CHECK(hipStreamSynchronize(c->stream));
     return 0;
 }
@@ -590,6 +642,7 @@ int edgehip_download_keylines(edgehip_ctx *c, int seq, int slot, edgehip_keyline
     if (int e = check_seq(c, seq)) return e;
     if (int e = check_slot(c, slot)) return e;
     if (!kl || !kn_out) return EDGEHIP_ERR_ARG;
+    if (int e = sync_all(c)) return e;
     int32_t kn = 0;
     EH_CHECK(hipMemcpyAsync(&kn, c->kn_slot + (size_t)slot * c->plan.nseq + seq, 4, hipMemcpyDeviceToHost, c->stream));
     EH_CHECK(hipStreamSynchronize(c->stream));
@@ -634,6 +687,7 @@ int edgehip_upload_keylines(edgehip_ctx *c, int seq, int slot, const edgehip_key
     if (int e = check_seq(c, seq)) return e;
     if (int e = check_slot(c, slot)) return e;
     if (!kl || kn < 0 || kn > c->plan.cap) { set_error("upload_keylines: kn exceeds capacity"); return EDGEHIP_ERR_ARG; }
+    if (int e = sync_all(c)) return e;
     const KlSoA &k = klof(c, slot, seq);
     std::vector<int32_t> p_inx(kn), m_id(kn), m_id_f(kn), m_id_kf(kn), m_num(kn), p_id(kn), n_id(kn);
     std::vector<float2> m_m(kn), u_m(kn), c_p(kn), p_m(kn), p_m_0(kn), m_m0(kn);
@@ -672,6 +726,7 @@ int edgehip_download_plane(edgehip_ctx *c, int seq, int which, float *out) {
     if (int e = check_seq(c, seq)) return e;
     if (!c->planes) { set_error("download_plane: context was created without debug_planes"); return EDGEHIP_ERR_STATE; }
     if (which < 0 || which > 4 || !out) return EDGEHIP_ERR_ARG;
+    if (int e = sync_all(c)) return e;
     const size_t n = c->plan.n;
     EH_CHECK(hipMemcpyAsync(out, c->planes + ((size_t)which * c->plan.nseq + seq) * n, sizeof(float) * n, hipMemcpyDeviceToHost, c->stream));
     EH_CHECK(hipStreamSynchronize(c->stream));
@@ -708,9 +763,10 @@ int edgehip_download_undistorted(edgehip_ctx *c, int seq, int slot, uint8_t *rgb
     if (!rgb24) return EDGEHIP_ERR_ARG;
     if (!c->p.use_undistort) { set_error("download_undistorted: context was created without use_undistort"); return EDGEHIP_ERR_STATE; }
     uint8_t *tmp = reinterpret_cast<uint8_t *>(c->ii);  // stage-A scratch: free between frames
+    if (int e = sync_all(c)) return e;
     if (int e = undistort_frame_enqueue(c, seq, slot, tmp)) return e;
-    EH_CHECK(hipMemcpyAsync(rgb24, tmp, (size_t)c->plan.n * 3, hipMemcpyDeviceToHost, c->stream));
-    EH_CHECK(hipStreamSynchronize(c->stream));
+    EH_CHECK(hipMemcpyAsync(rgb24, tmp, (size_t)c->plan.n * 3, hipMemcpyDeviceToHost, c->stream_a));
+    EH_CHECK(hipStreamSynchronize(c->stream_a));
     return 0;
 }
 
@@ -729,7 +785,7 @@ int edgehip_profile_count(void) { return PROF_COUNT; }
 const char *edgehip_profile_name(int i) { return (i >= 0 && i < PROF_COUNT) ? kProfNames[i] : ""; }
 int edgehip_profile_read(edgehip_ctx *c, double *ms, int64_t *calls) {
     if (!c || !ms || !calls) return EDGEHIP_ERR_ARG;
-    EH_CHECK(hipStreamSynchronize(c->stream));
+    if (int e = sync_all(c)) return e;
     Profiler *p = c->prof;
     for (auto &r : p->pending) {
         float t = 0.f;

@@ -74,6 +74,18 @@ struct SeqDev {
     double V_track[3], W_track[3], PV_track[9], PW_track[9];  // tracker output before any reset
 };
 
+// Detector state of one sequence: the locals of FirstThr (rebvo_first_t.cpp:92-94) plus stage-A scratch.  Kept apart
+// from SeqDev because stage A of frame k+1 runs on its own stream while stages B/C of frame k still use SeqDev.
+struct SeqA {
+    double tresh;              // detector threshold (P-controller state)
+    double tresh_used;         // threshold used by the running detect
+    int32_t l_kl_num;          // KeyLines on the last edge map (P-controller input)
+    int32_t kn_new;            // KeyLines of the slot being detected
+    int32_t band_trunc, pad0;
+    float nm_max, nm_min;      // reEstimateThresh extremes
+    float retuned, pad1;       // edge_finder::reTunedThresh of the newest slot
+};
+
 struct DevicePlan {  // everything a kernel needs that is constant for the context
     int w, h, n, cap, nseq, nslots;
     int box[2][kMaxBoxes];          // box widths of filter0 / filter1
@@ -99,7 +111,12 @@ struct edgehip_ctx {
     edgehip_params p;
     edgehip::DevicePlan plan;
     int device;
-    hipStream_t stream;
+    hipStream_t stream;    // stages B and C, state exchange
+    hipStream_t stream_a;  // uploads and stage A: frame k+1 is detected while frame k is still being tracked
+    hipEvent_t ev_a[4];    // [slot] stage A of the frame in this slot has finished
+    hipEvent_t ev_use[4];  // [slot] the last B/C work that read this slot has finished
+    hipEvent_t ev_tmp;     // ordering of the stage-level entry points
+    bool use_valid[4];
     int frame_slot;        // ring position of the newest slot (-1 before the first frame)
     int frames_seen;
     // device buffers
@@ -116,6 +133,8 @@ struct edgehip_ctx {
     std::vector<edgehip::KlSoA> kl;   // [S*B] host copies of the carved pointers
     edgehip::KlSoA *kl_dev;           // [S*B] same, on device
     edgehip::SeqDev *seq;             // [B]
+    edgehip::SeqA *seqa;              // [B] detector state (stage-A stream)
+    double *tresh_slot;               // [S][B] detector threshold each slot was detected with
     // global_tracker::FrameCount lives in the reference's PipeBuffer slot objects, of which there are CBUFSIZE=8
     // (include/rebvo/rebvo.h:51, src/rebvo/rebvo.cpp:297-312): the counter a frame sees depends on that ring
     // length, not on ours.  [max(S,8)][B]; process_frame indexes it by (frame number % 8), the stage-level
@@ -156,6 +175,7 @@ struct edgehip_ctx {
     uint8_t *pinned_rgb;   // [B][N*3]
     size_t pinned_rgb_bytes;
     edgehip::SeqDev *pinned_seq;  // [B]
+    edgehip::SeqA *pinned_seqa;   // [B]
     double *pinned_out;    // misc readback
     double *pinned_t;      // [8][B]
     edgehip_nav *pinned_nav;  // [B]
@@ -198,13 +218,18 @@ struct Profiler {
     int64_t calls[PROF_COUNT] = {0};
 };
 struct ProfScope {  // RAII bracket; no-op unless profiling is enabled
-    edgehip_ctx *c; int id; hipEvent_t a = nullptr, b = nullptr;
-    ProfScope(edgehip_ctx *ctx, int pid);
+    edgehip_ctx *c; int id; hipEvent_t a = nullptr, b = nullptr; hipStream_t st = nullptr;
+    ProfScope(edgehip_ctx *ctx, int pid, hipStream_t stream = nullptr);
     ~ProfScope();
 };
 
 // stage entry points shared between translation units (all enqueue on c->stream)
 int stage_a_enqueue(edgehip_ctx *c, int slot);
+// ordering between the two streams for entry points that are not edgehip_process_frame: everything enqueued so far on
+// one stream is finished before anything enqueued afterwards on the other starts
+int order_a_after_bc(edgehip_ctx *c);
+int order_bc_after_a(edgehip_ctx *c);
+int sync_all(edgehip_ctx *c);
 int undistort_frame_enqueue(edgehip_ctx *c, int seq, int slot, uint8_t *out_dev);
 int quantile_enqueue(edgehip_ctx *c, int slot, double smin, double smax, double pct, int nbins);
 int build_field_enqueue(edgehip_ctx *c, int slot, int radius, float min_mod);

@@ -562,7 +562,7 @@ struct DetectArgs {
     const double *pinv;        // [3][25]
     float *planes;             // optional debug planes [5][B][N]
     int32_t *mask;             // [B][N] of the slot
-    SeqDev *seq;
+    SeqA *seq;
     CandStage st;
     int32_t *strip_cnt;        // [B][nstrips]
     int w, h, nseq, strip_cap;
@@ -678,8 +678,8 @@ __global__ __launch_bounds__(kDetWaves * 64) void k_detect(DetectArgs a) {
     }
     __syncthreads();
 
-    SeqDev *sq = a.seq + seq;
-    const double tresh = update_thresh(sq->pub.tresh, sq->pub.l_kl_num, a.kl_ref, a.gain, a.tmax, a.tmin);
+    SeqA *sq = a.seq + seq;
+    const double tresh = update_thresh(sq->tresh, sq->l_kl_num, a.kl_ref, a.gain, a.tmax, a.tmin);
     const float grad_thresh = (float)tresh;                      // build_mask takes float grad_thesh
     const float gt1 = grad_thresh * 765;                         // grad_thesh*max_img_value (int 765 -> float)
     const float thr_g = gt1 * gt1;                               // util::square(...)
@@ -816,7 +816,8 @@ __global__ __launch_bounds__(kDetWaves * 64) void k_detect(DetectArgs a) {
 // kn = min(total, kl_max) (edge_finder.cpp:203-209); stores the P-controller state (detect(), :355-364).
 // ---------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void k_strip_scan(const int32_t *__restrict__ strip_cnt, int32_t *__restrict__ strip_off,
-                                                    SeqDev *seqs, int32_t *__restrict__ kn_out, int nstrips, int kl_max,
+                                                    SeqA *seqs, int32_t *__restrict__ kn_out, double *__restrict__ tresh_out,
+                                                    int nstrips, int kl_max,
                                                     int kl_ref, double gain, double tmax, double tmin) {
     __shared__ int s_part[256];
     const int seq = blockIdx.x, tid = threadIdx.x;
@@ -847,12 +848,13 @@ __global__ __launch_bounds__(256) void k_strip_scan(const int32_t *__restrict__ 
     if (tid == 255) {
         const int total = s_part[255];
         off[nstrips] = total;
-        SeqDev *sq = seqs + seq;
+        SeqA *sq = seqs + seq;
         const int kn = total < kl_max ? total : kl_max;
-        const double t = update_thresh(sq->pub.tresh, sq->pub.l_kl_num, kl_ref, gain, tmax, tmin);
-        sq->pub.tresh = t;
+        const double t = update_thresh(sq->tresh, sq->l_kl_num, kl_ref, gain, tmax, tmin);
+        sq->tresh = t;
         sq->tresh_used = t;
-        sq->pub.l_kl_num = kn;
+        tresh_out[seq] = t;
+        sq->l_kl_num = kn;
         sq->kn_new = kn;
         kn_out[seq] = kn;
         sq->nm_max = 0.f;                       // n_m > 0: integer atomics on the float bits order correctly
@@ -870,7 +872,7 @@ struct EmitArgs {
     const int32_t *strip_off;  // [B][nstrips+1]
     KlSoA *kl;                 // [B] of the slot
     int32_t *mask;             // [B][N]
-    SeqDev *seq;
+    SeqA *seq;
     int32_t *histo;            // [B][256]
     int nstrips, strip_cap, w;
     size_t n;
@@ -880,7 +882,7 @@ struct EmitArgs {
 __global__ __launch_bounds__(256) void k_emit(EmitArgs a) {
     const int seq = blockIdx.z;
     const int i = blockIdx.x * 256 + threadIdx.x;
-    SeqDev *sq = a.seq + seq;
+    SeqA *sq = a.seq + seq;
     const int kn = sq->kn_new;
     if (blockIdx.x == 0) a.histo[(size_t)seq * 256 + threadIdx.x] = 0;
     float nm = 0.f;
@@ -957,11 +959,11 @@ __device__ __forceinline__ int x86_cvttss2si(float f) {
     return (int)f;
 }
 
-__global__ __launch_bounds__(256) void k_join_histo(KlSoA *kls, const int32_t *__restrict__ masks, SeqDev *seqs,
+__global__ __launch_bounds__(256) void k_join_histo(KlSoA *kls, const int32_t *__restrict__ masks, SeqA *seqs,
                                                     int32_t *histo, int w, size_t n, int nbins) {
     const int seq = blockIdx.z;
     const int i = blockIdx.x * 256 + threadIdx.x;
-    SeqDev *sq = seqs + seq;
+    SeqA *sq = seqs + seq;
     const int kn = sq->kn_new;
     __shared__ int s_h[256];
     s_h[threadIdx.x] = 0;
@@ -1000,14 +1002,14 @@ __global__ __launch_bounds__(256) void k_join_histo(KlSoA *kls, const int32_t *_
 //     for(int a=0; i<n && a<knum; i++, a+=histo[i]);
 // accumulates histo[i] AFTER incrementing i, i.e. bin 0 is never counted (and histo[n] is read past the
 // end on the last step, where it no longer matters).
-__global__ __launch_bounds__(256) void k_retune(SeqDev *seqs, const int32_t *__restrict__ histo, float *__restrict__ retuned_out,
+__global__ __launch_bounds__(256) void k_retune(SeqA *seqs, const int32_t *__restrict__ histo, float *__restrict__ retuned_out,
                                                 int nseq, int knum, int nbins) {
     const int seq = blockIdx.x;
     __shared__ int s_h[256];
     s_h[threadIdx.x] = histo[(size_t)seq * 256 + threadIdx.x];
     __syncthreads();
     if (threadIdx.x != 0) return;
-    SeqDev *sq = seqs + seq;
+    SeqA *sq = seqs + seq;
     int i = 0;
     for (int acc = 0; i < nbins && acc < knum;) {
         i++;
@@ -1016,7 +1018,7 @@ __global__ __launch_bounds__(256) void k_retune(SeqDev *seqs, const int32_t *__r
     const float mxd = sq->nm_max, mnd = sq->nm_min;
     float r = mxd - (float)i * (mxd - mnd) / (float)nbins;
     if (sq->kn_new <= 0) r = 0.f;
-    sq->pub.retuned_thresh = r;
+    sq->retuned = r;
     retuned_out[seq] = r;
 }
 
@@ -1033,7 +1035,7 @@ __global__ void k_undistort_frame(const uint8_t *__restrict__ frame, uint8_t *__
 // ---------------------------------------------------------------------------------------------------
 int undistort_frame_enqueue(edgehip_ctx *c, int seq, int slot, uint8_t *out_dev) {
     const DevicePlan &pl = c->plan;
-    hipLaunchKernelGGL(k_undistort_frame, dim3((pl.n + 255) / 256), dim3(256), 0, c->stream,
+    hipLaunchKernelGGL(k_undistort_frame, dim3((pl.n + 255) / 256), dim3(256), 0, c->stream_a,
                        rgbof(c, slot) + (size_t)seq * pl.n * 3, out_dev, pl.w, pl.n, c->und_base, c->und_iw);
     EH_LAUNCH_CHECK();
     return 0;
@@ -1047,7 +1049,7 @@ int stage_a_enqueue(edgehip_ctx *c, int slot) {
     const size_t n = pl.n;
     float *ii[4];
     for (int i = 0; i < 4; i++) ii[i] = c->ii + (size_t)i * B * n;
-    hipStream_t st = c->stream;
+    hipStream_t st = c->stream_a;
 
     float *cur[2] = {ii[0], ii[0]};
     const int planes_in_flight = B * 2;
@@ -1066,7 +1068,7 @@ int stage_a_enqueue(edgehip_ctx *c, int slot) {
             }
         }
         {
-            ProfScope ps(c, PROF_A_LEVEL);
+            ProfScope ps(c, PROF_A_LEVEL, st);
             LevelJob job = {};
             job.dst[0] = ii[0]; job.d[0] = 1; job.a[0] = 1.f;
 #define EH_LEVEL(SRCV, GRID)                                                                                                   \
@@ -1104,7 +1106,7 @@ int stage_a_enqueue(edgehip_ctx *c, int slot) {
                 cur[0] = dst0;
                 cur[1] = dst1;
             }
-            ProfScope ps(c, PROF_A_LEVEL);
+            ProfScope ps(c, PROF_A_LEVEL, st);
             EH_LEVEL(0, dim3(njobs, 1, B));
             EH_LAUNCH_CHECK();
         }
@@ -1112,7 +1114,7 @@ int stage_a_enqueue(edgehip_ctx *c, int slot) {
         // 1. grey + exact row prefix, then serial column prefix: iimage::load of the input (shared by both
         //    filters: filter0.smooth(data) and filter1.smooth(data) start from the same integral image).
         {
-            ProfScope ps(c, PROF_A_ROWSCAN);
+            ProfScope ps(c, PROF_A_ROWSCAN, st);
             const int ch = rowscan_ch(w);
             const size_t sm = (size_t)4 * ((w * 3 + 3) / 4) * 4;
             dim3 g((h + 3) / 4, 1, B);
@@ -1137,7 +1139,7 @@ int stage_a_enqueue(edgehip_ctx *c, int slot) {
             EH_LAUNCH_CHECK();
         }
         auto colscan = [&](float *a, float *b) -> int {
-            ProfScope ps(c, PROF_A_COLSCAN);
+            ProfScope ps(c, PROF_A_COLSCAN, st);
             PlanePtrs pp;
             pp.p[0] = a;
             pp.p[1] = b ? b : a;
@@ -1177,7 +1179,7 @@ int stage_a_enqueue(edgehip_ctx *c, int slot) {
                 cur[1] = dst1;
             }
             {
-                ProfScope ps(c, PROF_A_AVGROW);
+                ProfScope ps(c, PROF_A_AVGROW, st);
                 hipLaunchKernelGGL((k_avg_rowscan<256, 64, 64>), dim3((h + 63) / 64, njobs, B), dim3(256), 0, st, job,
                                    c->div_lut, w, h, n);
                 EH_LAUNCH_CHECK();
@@ -1198,7 +1200,7 @@ int stage_a_enqueue(edgehip_ctx *c, int slot) {
         cs.s = (float2 *)(base + cnt * 12);
     }
     {
-        ProfScope ps(c, PROF_A_DETECT);
+        ProfScope ps(c, PROF_A_DETECT, st);
         DetectArgs a;
         a.iic0 = cur[0]; a.iic1 = cur[1];
         a.d0 = pl.box[0][kMaxBoxes - 1]; a.d1 = pl.box[1][kMaxBoxes - 1];
@@ -1206,7 +1208,7 @@ int stage_a_enqueue(edgehip_ctx *c, int slot) {
         a.lut = c->div_lut; a.pinv = c->pinv;
         a.planes = c->planes;
         a.mask = maskof(c, slot);
-        a.seq = c->seq;
+        a.seq = c->seqa;
         a.st = cs;
         a.strip_cnt = c->band_cnt;
         a.w = w; a.h = h; a.nseq = B; a.strip_cap = c->band_cap; a.n = n;
@@ -1229,26 +1231,26 @@ int stage_a_enqueue(edgehip_ctx *c, int slot) {
         EH_LAUNCH_CHECK();
     }
     {
-        ProfScope ps(c, PROF_A_COMPACT);
+        ProfScope ps(c, PROF_A_COMPACT, st);
         int kl_max = c->p.max_points;
         if (kl_max > pl.cap) kl_max = pl.cap;
-        hipLaunchKernelGGL(k_strip_scan, dim3(B), dim3(256), 0, st, c->band_cnt, c->band_off, c->seq,
-                           c->kn_slot + (size_t)slot * B, nstrips, kl_max,
+        hipLaunchKernelGGL(k_strip_scan, dim3(B), dim3(256), 0, st, c->band_cnt, c->band_off, c->seqa,
+                           c->kn_slot + (size_t)slot * B, c->tresh_slot + (size_t)slot * B, nstrips, kl_max,
                            c->p.reference_points, c->p.auto_gain, c->p.max_thresh, c->p.min_thresh);
         EH_LAUNCH_CHECK();
         EmitArgs e;
-        e.st = cs; e.strip_off = c->band_off; e.kl = kldev(c, slot); e.mask = maskof(c, slot); e.seq = c->seq;
+        e.st = cs; e.strip_off = c->band_off; e.kl = kldev(c, slot); e.mask = maskof(c, slot); e.seq = c->seqa;
         e.histo = c->histo; e.nstrips = nstrips; e.strip_cap = c->band_cap; e.w = w; e.n = n;
         e.ppx = pl.ppx; e.ppy = pl.ppy;
         hipLaunchKernelGGL(k_emit, dim3((pl.cap + 255) / 256, 1, B), dim3(256), 0, st, e);
         EH_LAUNCH_CHECK();
     }
     {
-        ProfScope ps(c, PROF_A_JOIN);
+        ProfScope ps(c, PROF_A_JOIN, st);
         hipLaunchKernelGGL(k_join_histo, dim3((pl.cap + 255) / 256, 1, B), dim3(256), 0, st, kldev(c, slot),
-                           maskof(c, slot), c->seq, c->histo, w, n, c->p.qcut_nbins);
+                           maskof(c, slot), c->seqa, c->histo, w, n, c->p.qcut_nbins);
         EH_LAUNCH_CHECK();
-        hipLaunchKernelGGL(k_retune, dim3(B), dim3(256), 0, st, c->seq, c->histo,
+        hipLaunchKernelGGL(k_retune, dim3(B), dim3(256), 0, st, c->seqa, c->histo,
                            c->retuned_slot + (size_t)slot * B, B, c->p.track_points,
                            c->p.qcut_nbins);
         EH_LAUNCH_CHECK();

@@ -508,7 +508,8 @@ __device__ inline bool any_nan3(const double *v) { return isnan(v[0]) || isnan(v
 // mode 0: frame begin (:145-168); 1: after Minimizer+FordwardMatch+rotate (:387-397); 2: after
 // directed_matching (:412-422); 3: pose integration + nav record (:550-606)
 __global__ void k_frame_glue(SeqDev *seqs, const double *__restrict__ t_in, edgehip_nav *__restrict__ nav,
-                             const int32_t *__restrict__ kn_new, int nseq, int mode, double fps, int match_threshold,
+                             const int32_t *__restrict__ kn_new, const double *__restrict__ tresh_new,
+                             const float *__restrict__ retuned_new, int nseq, int mode, double fps, int match_threshold,
                              int have_pair, edgehip_nav *__restrict__ nav_log, int nav_log_len) {
     const int seq = blockIdx.x * blockDim.x + threadIdx.x;
     if (seq >= nseq) return;
@@ -574,9 +575,9 @@ __global__ void k_frame_glue(SeqDev *seqs, const double *__restrict__ t_in, edge
         so3_ln(p.R, o.RotLie);
         so3_ln(p.Pose, o.PoseLie);
         for (int i = 0; i < 3; i++) { o.Vel[i] = -p.V[i] * p.K / p.dt; o.Pos[i] = p.Pos[i]; }
-        o.Kp = p.Kp; o.RKp = p.P_Kp; o.s_rho_q = p.s_rho_q; o.tresh = p.tresh;
+        o.Kp = p.Kp; o.RKp = p.P_Kp; o.s_rho_q = p.s_rho_q; o.tresh = tresh_new[seq];
         o.score = p.score; o.rel_error = p.rel_error; o.rel_error_score = p.rel_error_score;
-        o.retuned_thresh = p.retuned_thresh;
+        o.retuned_thresh = retuned_new[seq];
         o.kn = kn_new[seq]; o.klm_fwd = p.klm_fwd; o.klm_num = p.klm_num; o.kf_matchs = p.kf_matchs;
         o.estimation_ok = have_pair ? p.estimation_ok : 0;
         o.frame = p.frame; o.minimizer_evals = p.minimizer_evals;
@@ -739,7 +740,8 @@ int rescale_enqueue(edgehip_ctx *c, int slot) {
 static int glue(edgehip_ctx *c, int mode, int slot_new, int have_pair) {
     const DevicePlan &pl = c->plan;
     hipLaunchKernelGGL(k_frame_glue, dim3((pl.nseq + 63) / 64), dim3(64), 0, c->stream, c->seq, c->t_buf, c->nav_dev,
-                       c->kn_slot + (size_t)slot_new * pl.nseq, pl.nseq, mode, c->p.config_fps, c->p.global_match_threshold,
+                       c->kn_slot + (size_t)slot_new * pl.nseq, c->tresh_slot + (size_t)slot_new * pl.nseq,
+                       c->retuned_slot + (size_t)slot_new * pl.nseq, pl.nseq, mode, c->p.config_fps, c->p.global_match_threshold,
                        have_pair, c->nav_log, c->nav_log_len);
     EH_LAUNCH_CHECK();
     return 0;
@@ -879,7 +881,13 @@ int edgehip_process_frame(edgehip_ctx *c, const double *t) {
     memcpy(tp, t, sizeof(double) * pl.nseq);
     EH_CHECK(hipMemcpyAsync(c->t_buf, tp, sizeof(double) * pl.nseq, hipMemcpyHostToDevice, c->stream));
 #define EH_TRY(x) if ((e = (x)) != 0) return e
+    // Stage A of this frame runs on its own stream: it only has to wait for the B/C work that still reads the slot it
+    // overwrites (two frames back), so it overlaps the tracking/mapping of the previous frame — what the reference's
+    // first and second thread do (rebvo_first_t.cpp:134, rebvo_second_t.cpp:102).
+    if (c->use_valid[sn]) EH_CHECK(hipStreamWaitEvent(c->stream_a, c->ev_use[sn], 0));
     EH_TRY(stage_a_enqueue(c, sn));
+    EH_CHECK(hipEventRecord(c->ev_a[sn], c->stream_a));
+    EH_CHECK(hipStreamWaitEvent(c->stream, c->ev_a[sn], 0));
     {
         ProfScope ps(c, PROF_C_POSE);
         EH_TRY(glue(c, 0, sn, have_pair));
@@ -901,6 +909,13 @@ int edgehip_process_frame(edgehip_ctx *c, const double *t) {
         EH_TRY(glue(c, 3, sn, have_pair));                                                       // :550-606
     }
 #undef EH_TRY
+    // B/C of this frame were the last readers of both slots
+    EH_CHECK(hipEventRecord(c->ev_use[sn], c->stream));
+    c->use_valid[sn] = true;
+    if (so >= 0) {
+        EH_CHECK(hipEventRecord(c->ev_use[so], c->stream));
+        c->use_valid[so] = true;
+    }
     c->frame_slot = sn;
     c->frames_seen++;
     return 0;
