@@ -206,7 +206,10 @@ int edgehip_rescale(edgehip_ctx *ctx, int slot);
  * context's current ring slot, enqueued back to back without host synchronisation: stage A on the new
  * slot, then (from the second frame on) quantile, build_field, Minimizer_RV, FordwardMatch, rotate,
  * directed_matching, Regularize, EKF, rescale and the pose integration of rebvo_second_t.cpp:550-551.
- * The frame must have been uploaded into edgehip_next_slot() first.  t[nseq] = frame time stamps. */
+ * The frame must have been uploaded into edgehip_next_slot() first.  t[nseq] = frame time stamps.
+ * Uploads and stage A are enqueued on a second HIP stream; with EDGEHIP_OVERLAP=1 in the environment at
+ * edgehip_create() time, stage A of this frame only waits for the B/C work that still reads the slot it overwrites
+ * and so runs under the tracking/mapping of the previous frame (the reference's T0 || T1 pipelining). */
 int edgehip_process_frame(edgehip_ctx *ctx, const double *t);
 int edgehip_next_slot(edgehip_ctx *ctx);
 int edgehip_cur_slot(edgehip_ctx *ctx);

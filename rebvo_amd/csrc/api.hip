@@ -364,6 +364,7 @@ int edgehip_create(const edgehip_params *params, int nseq, int nslots, int devic
     c->field_radius = p.search_range;
     c->field_mode = getenv("EDGEHIP_FIELD_MODE") ? atoi(getenv("EDGEHIP_FIELD_MODE")) : 0;
     c->level_mode = getenv("EDGEHIP_LEVEL_MODE") ? atoi(getenv("EDGEHIP_LEVEL_MODE")) : 0;
+    c->overlap = getenv("EDGEHIP_OVERLAP") ? atoi(getenv("EDGEHIP_OVERLAP")) : 0;
     EH_TRY(dmalloc(c, &c->fwd_key, B * CAP, al->dev, 0));
     EH_TRY(dmalloc(c, &c->fwd_win, B * CAP, al->dev, 0xFF));
     EH_TRY(dmalloc(c, &c->rs_tmp, B * 2 * CAP, al->dev, 0));

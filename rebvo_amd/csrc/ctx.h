@@ -117,6 +117,7 @@ struct edgehip_ctx {
     hipEvent_t ev_use[4];  // [slot] the last B/C work that read this slot has finished
     hipEvent_t ev_tmp;     // ordering of the stage-level entry points
     bool use_valid[4];
+    int overlap;           // 1: stage A of frame k+1 may run under stages B/C of frame k (EDGEHIP_OVERLAP=1); 0: one after the other
     int frame_slot;        // ring position of the newest slot (-1 before the first frame)
     int frames_seen;
     // device buffers

@@ -884,7 +884,12 @@ int edgehip_process_frame(edgehip_ctx *c, const double *t) {
     // Stage A of this frame runs on its own stream: it only has to wait for the B/C work that still reads the slot it
     // overwrites (two frames back), so it overlaps the tracking/mapping of the previous frame — what the reference's
     // first and second thread do (rebvo_first_t.cpp:134, rebvo_second_t.cpp:102).
-    if (c->use_valid[sn]) EH_CHECK(hipStreamWaitEvent(c->stream_a, c->ev_use[sn], 0));
+    // With overlap off (the default: per-kernel timings stay attributable) stage A simply follows everything before it.
+    if (!c->overlap) {
+        EH_TRY(order_a_after_bc(c));
+    } else if (c->use_valid[sn]) {
+        EH_CHECK(hipStreamWaitEvent(c->stream_a, c->ev_use[sn], 0));
+    }
     EH_TRY(stage_a_enqueue(c, sn));
     EH_CHECK(hipEventRecord(c->ev_a[sn], c->stream_a));
     EH_CHECK(hipStreamWaitEvent(c->stream, c->ev_a[sn], 0));

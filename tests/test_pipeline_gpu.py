@@ -109,3 +109,28 @@ def test_depth_reset_semantics():
     assert (k1["rho"] == 1.0).all() and (k1["s_rho"] == 20.0).all()
     assert (k0["s_rho"] < 20.0).any()
     eh.close()
+
+
+def test_pipeline_with_stream_overlap(monkeypatch):
+    """EDGEHIP_OVERLAP=1: stage A of frame k+1 runs on its own stream under stages B/C of frame k (the reference's
+    T0 || T1 pipelining).  Ordering is by events only, so the results must not change: same parity bars, and the
+    records must equal the serialised run bit for bit."""
+    monkeypatch.setenv("EDGEHIP_OVERLAP", "1")
+    _run(376, 240, 8)
+    _run(376, 240, 5, nseq=3)
+    frames = [f for f, _, _ in synth.billboard_sequence(376, 240, 6)]
+
+    def records(overlap):
+        monkeypatch.setenv("EDGEHIP_OVERLAP", overlap)
+        eh = edgehip.EdgeHip(edgehip.euroc_params(376, 240), nseq=2, nslots=3)
+        out = []
+        for k, f in enumerate(frames):
+            eh.upload_rgb(eh.next_slot(), np.stack([f, frames[(k + 1) % 6]]))
+            eh.process_frame(0.05 * k)            # no read-back in between: frames are enqueued back to back
+        for n in eh.read_nav():
+            out.append((n.kn, n.klm_num, tuple(n.V[:]), tuple(n.W[:]), tuple(n.Pos[:]), n.tresh))
+        kl, mask = eh.download_keylines(1, eh.cur_slot())
+        eh.close()
+        return out, kl.tobytes(), mask.tobytes()
+
+    assert records("0") == records("1")
