@@ -153,6 +153,9 @@ def main():
                          "behind the bandwidth-bound kernels of the other")
     ap.add_argument("--pool", type=int, default=24, help="rendered frames in the HBM pool")
     ap.add_argument("--cpu-frames", type=int, default=200, help="frames of the CPU-baseline sample (0 = skip)")
+    ap.add_argument("--overlap", action="store_true",
+                    help="EDGEHIP_OVERLAP=1: stage A of frame k+1 under stages B/C of frame k (two streams per context). "
+                         "Faster, but per-kernel HIP-event times (the roofline object) stop being attributable, so off by default")
     ap.add_argument("--cpu-procs", type=int, default=0,
                     help="also time the CPU reference node-saturating: this many independent sequences in parallel "
                          "processes (SURVEY.md section 8d mode iii; 0 = skip, -1 = one per usable host core)")
@@ -179,6 +182,8 @@ def main():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
 
+    if args.overlap:
+        os.environ["EDGEHIP_OVERLAP"] = "1"
     C = max(1, args.contexts)
     B, K, Wm = args.nseq // C, args.steps, args.warmup   # B = sequences per context
     # ---- synthetic frame pool, resident in HBM ----
@@ -322,6 +327,7 @@ def main():
         "config": {"workload": "full path (configs[2] at configs[1] size): 752x480 synthetic EuRoC-intrinsics "
                                "sequences, GlobalConfig_EuRoC params, ImuMode=0",
                    "sequences_per_gpu": B * C, "contexts_per_gpu": C, "sequences_per_launch": B,
+                   "stream_overlap": bool(args.overlap),
                    "frames_per_step": B * C * world, "keylines_per_frame": round(kn_mean, 1),
                    "tryvelrot_evals_per_frame": evals, "estimation_ok": f"{ok}/{B * C}",
                    "algorithmic_MB_per_frame": round(frame_bytes / 1e6, 2),
