@@ -202,6 +202,7 @@ class Oracle:
         self._process = fn("process_frame", i, vp, C.c_void_p, d, C.POINTER(Nav))
         self._cur_slot = fn("cur_slot", i, vp)
         self._reset = fn("reset_sequence", None, vp)
+        self._depth_reset = fn("depth_reset", None, vp)
         self.ctx = self._create(C.byref(params), nslots)
 
     def close(self):
@@ -348,6 +349,10 @@ class Oracle:
 
     def cur_slot(self):
         return self._cur_slot(self.ctx)
+
+    def depth_reset(self):
+        """REBVO::Reset() semantics (rebvo_second_t.cpp:609-620) applied after the last processed frame."""
+        self._depth_reset(self.ctx)
 
     def reset_sequence(self):
         self._reset(self.ctx)

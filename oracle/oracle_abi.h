@@ -123,6 +123,8 @@ typedef struct OrcNav {
     /* whole frame, non-IMU branch of FirstThr + SecondThread; state lives in ctx */                     \
     int P##_process_frame(void *ctx, const uint8_t *rgb24, double t, OrcNav *nav);                       \
     int P##_cur_slot(void *ctx);                                                                         \
+    /* REBVO::Reset() as SecondThread runs it after a frame (rebvo_second_t.cpp:609-620) */              \
+    void P##_depth_reset(void *ctx);                                                                     \
     void P##_reset_sequence(void *ctx);
 
 ORC_DECLARE(ref)

@@ -329,6 +329,14 @@ void *port_create(const OrcParams *p, int nslots) {
 }
 void port_destroy(void *ctx) { delete (Ctx *)ctx; }
 void port_reset_sequence(void *ctx) { reset_seq((Ctx *)ctx); }
+void port_depth_reset(void *ctx) {   // rebvo_second_t.cpp:609-620: depth reset of the newest edge map, pose and velocity reset
+    Ctx *c = (Ctx *)ctx;
+    if (c->frame == 0) return;
+    Slot &nb = c->slots[(c->frame + (int)c->slots.size() - 1) % (int)c->slots.size()];
+    for (int i = 0; i < nb.kn; i++) { nb.kl[i].rho = kRhoInit; nb.kl[i].s_rho = kRhoMax; }
+    for (int i = 0; i < 9; i++) c->Pose[i] = (i % 4 == 0) ? 1 : 0;
+    for (int i = 0; i < 3; i++) { c->Pos[i] = 0; c->W[i] = 0; c->V[i] = 0; }
+}
 int port_cur_slot(void *ctx) {
     Ctx *c = (Ctx *)ctx;
     return (c->frame + (int)c->slots.size() - 1) % (int)c->slots.size();

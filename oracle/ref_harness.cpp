@@ -155,6 +155,19 @@ void ref_destroy(void *ctx) {
 }
 
 void ref_reset_sequence(void *ctx) { reset_seq((Ctx *)ctx); }
+void ref_depth_reset(void *ctx) {   // the `if(cf->system_reset)` block of rebvo_second_t.cpp:609-620, on the newest slot
+    Ctx *c = (Ctx *)ctx;
+    if (c->frame == 0) return;
+    Slot &nb = c->slots[(c->frame + (int)c->slots.size() - 1) % (int)c->slots.size()];
+    for (auto &kl : (*nb.ef)) {
+        kl.rho = RhoInit;
+        kl.s_rho = RHO_MAX;
+    }
+    c->Pose = Identity;
+    c->Pos = Zeros;
+    c->W = Zeros;
+    c->V = Zeros;
+}
 int ref_cur_slot(void *ctx) {
     Ctx *c = (Ctx *)ctx;
     return (c->frame + (int)c->slots.size() - 1) % (int)c->slots.size();

@@ -134,3 +134,35 @@ def test_pipeline_with_stream_overlap(monkeypatch):
         return out, kl.tobytes(), mask.tobytes()
 
     assert records("0") == records("1")
+
+
+def test_reset_mid_sequence_matches_reference():
+    """REBVO::Reset() (depth reset of the newest edge map + pose/velocity reset, rebvo_second_t.cpp:609-620) after frame 3:
+    the following frames must track like the reference does after the same reset."""
+    from oracle import oracle
+    if not oracle.available("ref"):
+        pytest.skip("oracle/_ref not built")
+    w, h, n = 376, 240, 8
+    frames = [f for f, _, _ in synth.billboard_sequence(w, h, n)]
+    orc = oracle.Oracle("ref", oracle.euroc_params(w, h))
+    eh = edgehip.EdgeHip(edgehip.euroc_params(w, h), nseq=1, nslots=3)
+    for k, f in enumerate(frames):
+        _, nr = orc.process_frame(f, 0.05 * k)
+        eh.upload_rgb(eh.next_slot(), f)
+        eh.process_frame(0.05 * k)
+        ng = eh.read_nav()[0]
+        assert ng.kn == nr.kn
+        if k:
+            step = np.linalg.norm(nr.V[:]) + np.linalg.norm(nr.W[:])
+            assert np.allclose(ng.V[:], nr.V[:], rtol=0, atol=1e-6 * step + 1e-9), k
+            assert np.allclose(ng.W[:], nr.W[:], rtol=0, atol=1e-6 * step + 1e-9), k
+            assert np.allclose(ng.Pos[:], nr.Pos[:], atol=1e-7), k
+            assert abs(ng.klm_num - nr.klm_num) <= max(2, nr.klm_num // 1000), k
+        if k == 3:
+            orc.depth_reset()
+            eh.depth_reset()
+    kg, _ = eh.download_keylines(0, eh.cur_slot())
+    kr = orc.keylines(orc.cur_slot())
+    same = kg["m_id"] == kr["m_id"]
+    assert same.mean() > 0.999 and np.allclose(kg["rho"][same], kr["rho"][same], rtol=1e-5, atol=1e-7)
+    eh.close()
