@@ -17,6 +17,9 @@ if [ -z "$SKIP_TESTS" ]; then
   tail -5 "$OUT/pytest_gpu.log"
 fi
 
+timeout 300 python -c "import __graft_entry__ as g; g.smoke()" > "$OUT/smoke.log" 2>&1
+echo "smoke exit $?"; tail -1 "$OUT/smoke.log"
+
 timeout 600 python bench.py $BENCH_ARGS > "$OUT/bench.json" 2> "$OUT/bench.err"
 echo "bench exit $?"; tail -c 3000 "$OUT/bench.json"
 
