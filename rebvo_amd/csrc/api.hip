@@ -292,6 +292,8 @@ int edgehip_create(const edgehip_params *params, int nseq, int nslots, int devic
 
     DevicePlan &pl = c->plan;
     pl.w = p.w; pl.h = p.h; pl.n = p.w * p.h; pl.nseq = nseq; pl.nslots = nslots;
+    pl.ftx = (p.w + 3) / 4;
+    pl.fstride = (size_t)pl.ftx * (size_t)((p.h + 3) / 4) * 16;
     pl.cap = std::min(p.max_points, EDGEHIP_KEYLINE_MAX);  // build_mask clamps kl_max to kl_size
     const double sr0 = kovesi_boxes(p.sigma0, kMaxBoxes, pl.box[0]);       // sspace.cpp:45
     kovesi_boxes(sr0 * p.ksigma, kMaxBoxes, pl.box[1]);
@@ -314,7 +316,7 @@ int edgehip_create(const edgehip_params *params, int nseq, int nslots, int devic
     c->planes = nullptr;
     if (p.debug_planes) EH_TRY(dmalloc(c, &c->planes, 5 * B * N, al->dev, 0));
     EH_TRY(dmalloc(c, &c->mask, S * B * N, al->dev, 0xFF));       // img_mask_kl.Reset(-1)
-    EH_TRY(dmalloc(c, &c->field, B * N, al->dev, 0xFF));
+    EH_TRY(dmalloc(c, &c->field, B * pl.fstride, al->dev, 0xFF));
     c->und_base = nullptr;
     c->und_iw = nullptr;
     if (p.use_undistort) {
@@ -738,13 +740,18 @@ int edgehip_download_field(edgehip_ctx *c, int seq, int32_t *out) {
     if (int e = check_seq(c, seq)) return e;
     if (!out) return EDGEHIP_ERR_ARG;
     const size_t n = c->plan.n;
-    std::vector<uint32_t> f(n);
-    EH_CHECK(hipMemcpyAsync(f.data(), c->field + (size_t)seq * n, 4 * n, hipMemcpyDeviceToHost, c->stream));
+    const size_t fs = c->plan.fstride;
+    std::vector<uint32_t> f(fs);
+    EH_CHECK(hipMemcpyAsync(f.data(), c->field + (size_t)seq * fs, 4 * fs, hipMemcpyDeviceToHost, c->stream));
     EH_CHECK(hipStreamSynchronize(c->stream));
-    for (size_t i = 0; i < n; i++) {
-        if (f[i] == 0xFFFFFFFFu) { out[2 * i] = 0; out[2 * i + 1] = -1; }
-        else { out[2 * i] = (int32_t)(f[i] >> 16); out[2 * i + 1] = (int32_t)(0xFFFFu - (f[i] & 0xFFFFu)); }
-    }
+    for (int y = 0; y < c->plan.h; y++)
+        for (int x = 0; x < c->plan.w; x++) {   // tiled device layout -> row-major (dist, ikl) pairs
+            const uint32_t v = f[edgehip::field_index(x, y, c->plan.ftx)];
+            const size_t i = (size_t)y * c->plan.w + x;
+            if (v == 0xFFFFFFFFu) { out[2 * i] = 0; out[2 * i + 1] = -1; }
+            else { out[2 * i] = (int32_t)(v >> 16); out[2 * i + 1] = (int32_t)(0xFFFFu - (v & 0xFFFFu)); }
+        }
+    (void)n;
     return 0;
 }
 

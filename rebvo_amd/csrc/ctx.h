@@ -5,7 +5,8 @@
 //   ii       [4][B][N]  f32      integral-image scratch of the box-filter chain (stage A only)
 //   planes   [5][B][N]  f32      img0,img1,dog,dx,dy — only when params.debug_planes
 //   mask     [S][B][N]  i32      img_mask_kl
-//   field    [B][N]     u32      tracker auxiliary image, packed (dist<<16 | 0xFFFF-ikl), 0xFFFFFFFF = empty
+//   field    [B][FS]    u32      tracker auxiliary image, packed (dist<<16 | 0xFFFF-ikl), 0xFFFFFFFF = empty;
+//                               4x4-pixel tiles (field_index), FS = ceil(w/4)*ceil(h/4)*16
 //   KeyLines [S][B][CAP] per field (structure of arrays, see KlSoA)
 //   stage buffers for the raster-order compaction, LM scratch, residual buffers, per-sequence state.
 #pragma once
@@ -88,6 +89,8 @@ struct SeqA {
 
 struct DevicePlan {  // everything a kernel needs that is constant for the context
     int w, h, n, cap, nseq, nslots;
+    int ftx;                        // field layout: 4x4-pixel tiles per tile row = ceil(w/4)
+    size_t fstride;                 // field elements per sequence = ftx * ceil(h/4) * 16
     int box[2][kMaxBoxes];          // box widths of filter0 / filter1
     float box_a[2][kMaxBoxes];      // (float)(1.0/(d*d))
     float ppx, ppy, zfx, zfy;       // cam_model keeps these as float (cam_model.h:51-52)
@@ -101,6 +104,13 @@ __device__ __forceinline__ int round_half_away_i(float v) {
     const float d = v - r;
     if (fabsf(d) == 0.5f && (d > 0.f) == (v > 0.f)) r = v + d;   // tie that rintf resolved towards zero: take the other neighbour
     return (int)r;
+}
+
+// The tracker field is stored in 4x4-pixel tiles of 64 B (tile-row-major, pixels row-major inside a tile): the
+// TryVelRot gather touches one pixel per KeyLine, and the KeyLines of one edge sit on consecutive rows, so with a
+// row-major plane every gather pulls its own 64-B line while here up to four rows of an edge share one.
+__host__ __device__ __forceinline__ size_t field_index(int x, int y, int ftx) {
+    return (((size_t)(y >> 2) * (size_t)ftx + (size_t)(x >> 2)) << 4) | (size_t)(((y & 3) << 2) | (x & 3));
 }
 
 struct Profiler;
@@ -125,7 +135,7 @@ struct edgehip_ctx {
     float *ii;             // [4][B][N]
     float *planes;         // [5][B][N] or null
     int32_t *mask;         // [S][B][N]
-    uint32_t *field;       // [B][N]
+    uint32_t *field;       // [B][plan.fstride], tiled (field_index)
     int32_t *und_base;     // [N] undistortion map: pixel index of the p00 tap (may lie outside the image), or null
     uint4 *und_iw;         // [N] 16.16 integer weights of taps p00,p01,p10,p11 (0 = tap not valid)
     float *div_lut;        // [kDivLutMax] (float)(1.0/count)

@@ -76,7 +76,7 @@ __global__ __launch_bounds__(256) void k_quantile(const KlSoA *kls, const int32_
 // ---------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void k_field_scatter(const KlSoA *kls, const int32_t *__restrict__ kns,
                                                        const float *__restrict__ retuned, uint32_t *__restrict__ field,
-                                                       int w, int h, size_t n, int radius, float min_mod_arg) {
+                                                       int w, int h, size_t fstride, int ftx, int radius, float min_mod_arg) {
     const int seq = blockIdx.z;
     const int kn = kns[seq];
     const int idx = blockIdx.x * 256 + threadIdx.x;
@@ -93,7 +93,7 @@ __global__ __launch_bounds__(256) void k_field_scatter(const KlSoA *kls, const i
     const int xi = round_half_away_i(fx), yi = round_half_away_i(fy);  // Image::GetIndexRC uses round()
     if (xi >= w || yi >= h || xi < 0 || yi < 0) return;
     const uint32_t at = (uint32_t)(t < 0 ? -t : t);
-    atomicMin(&field[(size_t)seq * n + (size_t)yi * w + xi], (at << 16) | (uint32_t)(0xFFFF - ikl));
+    atomicMin(&field[(size_t)seq * fstride + field_index(xi, yi, ftx)], (at << 16) | (uint32_t)(0xFFFF - ikl));
 }
 
 // ---------------------------------------------------------------------------------------------------
@@ -110,14 +110,14 @@ constexpr int FG = 12;    // mask rows scanned per list fill
 
 __global__ __launch_bounds__(256) void k_field_tiles(const KlSoA *kls, const int32_t *__restrict__ masks,
                                                      const float *__restrict__ retuned, uint32_t *__restrict__ field,
-                                                     int w, int h, size_t n, int radius, float min_mod_arg) {
+                                                     int w, int h, size_t fstride, int ftx, int radius, float min_mod_arg) {
     __shared__ uint32_t s_tile[FT * FT];
     __shared__ int s_list[4096];
     __shared__ int s_cnt;
     const int seq = blockIdx.z, tid = threadIdx.x, lane = tid & 63;
     const int tx0 = blockIdx.x * FT, ty0 = blockIdx.y * FT;
     const KlSoA &k = kls[seq];
-    const int32_t *mask = masks + (size_t)seq * n;
+    const int32_t *mask = masks + (size_t)seq * ((size_t)w * h);
     const float min_mod = min_mod_arg < 0.f ? retuned[seq] : min_mod_arg;
     for (int i = tid; i < FT * FT; i += 256) s_tile[i] = 0xFFFFFFFFu;
     if (tid == 0) s_cnt = 0;
@@ -180,11 +180,14 @@ __global__ __launch_bounds__(256) void k_field_tiles(const KlSoA *kls, const int
         if (tid == 0) s_cnt = 0;
         __syncthreads();
     }
-    uint32_t *out = field + (size_t)seq * n;
+    // store in the 4x4-tiled layout: 16 consecutive threads write one 64-B tile, a tile row of the block is 1 KB
+    // contiguous (FT and the block origin are multiples of 4)
+    uint32_t *out = field + (size_t)seq * fstride;
     for (int i = tid; i < FT * FT; i += 256) {
-        const int ly = i / FT, lx = i % FT;
+        const int st = i >> 4, in = i & 15;
+        const int lx = ((st % (FT / 4)) << 2) | (in & 3), ly = ((st / (FT / 4)) << 2) | (in >> 2);
         const int x = tx0 + lx, y = ty0 + ly;
-        if (x < w && y < h) out[(size_t)y * w + x] = s_tile[i];
+        if (x < w && y < h) out[field_index(x, y, ftx)] = s_tile[ly * FT + lx];
     }
 }
 
@@ -273,7 +276,7 @@ __global__ __launch_bounds__(256) void k_field_bin(const KlSoA *kls, const int32
 
 __global__ __launch_bounds__(256) void k_field_raster(const KlSoA *kls, const int32_t *__restrict__ bin_cnt,
                                                       const int32_t *__restrict__ bins, uint32_t *__restrict__ field,
-                                                      int w, int h, size_t n, int radius, int ntx, int bin_cap) {
+                                                      int w, int h, size_t fstride, int ftx, int radius, int ntx, int bin_cap) {
     __shared__ uint32_t s_tile[FT * FT];
     const int ntiles = ntx * gridDim.y;
     const int seq = blockIdx.z, tid = threadIdx.x;
@@ -312,11 +315,14 @@ __global__ __launch_bounds__(256) void k_field_raster(const KlSoA *kls, const in
         }
     }
     __syncthreads();
-    uint32_t *out = field + (size_t)seq * n;
+    // store in the 4x4-tiled layout: 16 consecutive threads write one 64-B tile, a tile row of the block is 1 KB
+    // contiguous (FT and the block origin are multiples of 4)
+    uint32_t *out = field + (size_t)seq * fstride;
     for (int i = tid; i < FT * FT; i += 256) {
-        const int ly = i / FT, lx = i % FT;
+        const int st = i >> 4, in = i & 15;
+        const int lx = ((st % (FT / 4)) << 2) | (in & 3), ly = ((st / (FT / 4)) << 2) | (in >> 2);
         const int x = tx0 + lx, y = ty0 + ly;
-        if (x < w && y < h) out[(size_t)y * w + x] = s_tile[i];
+        if (x < w && y < h) out[field_index(x, y, ftx)] = s_tile[ly * FT + lx];
     }
 }
 
@@ -428,7 +434,7 @@ struct TvrArgs {
     const KlSoA *kl_old;       // [B]
     const KlSoA *kl_new;       // [B]  (field KeyLines)
     const int32_t *kn_old;     // [B]
-    const uint32_t *field;     // [B][N]
+    const uint32_t *field;     // [B][fstride]
     const double *P0;          // [B][3][CAP]
     double *resid;             // [kResidBufs][B][CAP]
     double *resid_carry;       // [kResidBufs][B][nblk]  resolved carry-in per block
@@ -437,7 +443,8 @@ struct TvrArgs {
     SeqDev *seq;
     const uint32_t *framecount;  // [B] of the new slot
     int w, h, cap, nblk, nseq;
-    size_t n;
+    size_t fstride;            // field elements per sequence (4x4-tiled layout, ctx.h field_index)
+    int ftx;
     double zfm, max_r, match_thresh, k_huber;
     float ppx, ppy;
     uint32_t match_num_thresh;
@@ -522,7 +529,7 @@ __global__ __launch_bounds__(kTvrThreads) void k_try_velrot(TvrArgs a) {
                     // temporarily z-rotated gradient, stored back into a float Point2DF (:386-388)
                     const float rmx = (float)(sq->RM[0] * (double)klm.x + sq->RM[1] * (double)klm.y);
                     const float rmy = (float)(sq->RM[2] * (double)klm.x + sq->RM[3] * (double)klm.y);
-                    const uint32_t f = a.field[(size_t)seq * a.n + (size_t)y * a.w + x];
+                    const uint32_t f = a.field[(size_t)seq * a.fstride + field_index(x, y, a.ftx)];
                     if (f != 0xFFFFFFFFu) {
                         const int ikf = 0xFFFF - (int)(f & 0xFFFFu);
                         const MatchRec fr = a.kl_new[seq].rec[ikf];
@@ -1213,7 +1220,7 @@ __global__ __launch_bounds__(256) void k_try_vel(TvrArgs a) {
                 status = 3;
                 double dfx = 0, dfy = 0;
                 f = a.max_r / s_rho;                                       // Calc_f_J: no KeyLine / no similarity
-                const uint32_t fv = a.field[(size_t)seq * a.n + (size_t)y * a.w + x];
+                const uint32_t fv = a.field[(size_t)seq * a.fstride + field_index(x, y, a.ftx)];
                 if (fv != 0xFFFFFFFFu) {
                     const int ikf = 0xFFFF - (int)(fv & 0xFFFFu);
                     const MatchRec fr = a.kl_new[seq].rec[ikf];
@@ -1440,17 +1447,17 @@ int build_field_enqueue(edgehip_ctx *c, int slot, int radius, float min_mod) {
                            c->kn_slot + (size_t)slot * pl.nseq, c->retuned_slot + (size_t)slot * pl.nseq, c->bin_cnt, c->bins,
                            pl.w, pl.h, radius, min_mod, ntx, nty, pl.cap);
         hipLaunchKernelGGL(k_field_raster, dim3(ntx, nty, pl.nseq), dim3(256), 0, c->stream, kldev(c, slot), c->bin_cnt,
-                           c->bins, c->field, pl.w, pl.h, (size_t)pl.n, radius, ntx, pl.cap);
+                           c->bins, c->field, pl.w, pl.h, pl.fstride, pl.ftx, radius, ntx, pl.cap);
     } else if (c->field_mode == 2 || c->field_mode == 0) {  // mask-scan tiles (any image size)
         hipLaunchKernelGGL(k_field_tiles, dim3((pl.w + FT - 1) / FT, (pl.h + FT - 1) / FT, pl.nseq), dim3(256), 0, c->stream,
                            kldev(c, slot), maskof(c, slot), c->retuned_slot + (size_t)slot * pl.nseq, c->field, pl.w, pl.h,
-                           (size_t)pl.n, radius, min_mod);
+                           pl.fstride, pl.ftx, radius, min_mod);
     } else {  // reference-shaped scatter with global atomics (kept for A/B measurements: EDGEHIP_FIELD_MODE=1)
-        EH_CHECK(hipMemsetAsync(c->field, 0xFF, sizeof(uint32_t) * pl.nseq * pl.n, c->stream));
+        EH_CHECK(hipMemsetAsync(c->field, 0xFF, sizeof(uint32_t) * pl.nseq * pl.fstride, c->stream));
         const long long threads = (long long)pl.cap * 2 * radius;
         hipLaunchKernelGGL(k_field_scatter, dim3((unsigned)((threads + 255) / 256), 1, pl.nseq), dim3(256), 0, c->stream,
                            kldev(c, slot), c->kn_slot + (size_t)slot * pl.nseq, c->retuned_slot + (size_t)slot * pl.nseq,
-                           c->field, pl.w, pl.h, (size_t)pl.n, radius, min_mod);
+                           c->field, pl.w, pl.h, pl.fstride, pl.ftx, radius, min_mod);
     }
     EH_LAUNCH_CHECK();
     return 0;
@@ -1475,7 +1482,7 @@ static TvrArgs make_tvr_args(edgehip_ctx *c, int slot_new, int slot_old, double 
     a.field = c->field; a.P0 = c->P0; a.resid = c->resid; a.resid_carry = c->resid_carry;
     a.block_last = c->block_last; a.partials = c->partials; a.seq = c->seq;
     a.framecount = c->framecount + (size_t)c->fc_index * pl.nseq;
-    a.w = pl.w; a.h = pl.h; a.cap = pl.cap; a.nblk = c->nblk_tvr; a.nseq = pl.nseq; a.n = pl.n;
+    a.w = pl.w; a.h = pl.h; a.cap = pl.cap; a.nblk = c->nblk_tvr; a.nseq = pl.nseq; a.fstride = pl.fstride; a.ftx = pl.ftx;
     a.zfm = pl.zfm; a.max_r = (double)c->field_radius; a.match_thresh = match_thresh; a.k_huber = k_huber;
     a.ppx = pl.ppx; a.ppy = pl.ppy; a.match_num_thresh = match_num_thresh; a.write_mid = write_mid;
     return a;
