@@ -227,6 +227,9 @@ int edgehip_reset(edgehip_ctx *ctx);
  * newest edge map (rho = RhoInit, s_rho = RHO_MAX for every KeyLine), Pose = I, Pos = V = W = 0.  Everything
  * else (detector threshold, K, frame counters) carries on.  seq < 0 applies it to all sequences. */
 int edgehip_depth_reset(edgehip_ctx *ctx, int seq);
+/* The same on an explicit ring slot, for callers that drive the stages one by one (the host's IMU branch) instead of
+ * through edgehip_process_frame. */
+int edgehip_depth_reset_slot(edgehip_ctx *ctx, int seq, int slot);
 
 /* ---- state / data exchange (callback consumers, parity tests) ---------------------------------------- */
 int edgehip_get_state(edgehip_ctx *ctx, int seq, edgehip_seq_state *out);       /* synchronises */

@@ -21,6 +21,8 @@
 #include "mtracklib/edge_tracker.h"
 #include "mtracklib/global_tracker.h"
 #include "VideoLib/image_undistort.h"
+#include "mtracklib/scaleestimator.h"
+#include "UtilLib/imugrabber.h"
 // TryVelRot<> is only defined in the .cpp; include it so the harness can instantiate it directly.
 #include "src/mtracklib/global_tracker.cpp"
 
@@ -48,6 +50,27 @@ extern "C" void dgesvd_(const char *jobu, const char *jobvt, int *m, int *n, dou
 
 namespace {
 
+// The members of rebvo::IMUState (include/rebvo/rebvo.h:239-290) the IMU branch uses.  Declared here because that
+// header pulls in the visualizer / video / network stack, which does not build in this image.
+struct IMUState {
+    Vector<3> Vg = Zeros, dVv = Zeros, dWv = Zeros, dVgv = Zeros, dWgv = Zeros, Vgv = Zeros, Wgv = Zeros;
+    Vector<3> dVgva = Zeros, dWgva = Zeros, Vgva = Zeros;
+    Matrix<3, 3> P_Vg = Identity * 1e50, RGiro = Identity, RGBias = Identity;
+    Vector<3> Bg = Zeros;
+    Matrix<3, 3> W_Bg = Identity;
+    Vector<3> Av = Zeros, As = Zeros;
+    Vector<7> X;
+    Matrix<7, 7> P;
+    Matrix<3, 3> Qrot, Qg, Qbias;
+    double QKp, Rg;
+    Matrix<3, 3> Rs, Rv;
+    Vector<3> g_est, u_est, b_est;
+    Matrix<6, 6> Wvw;
+    Vector<6> Xvw;
+    Vector<3> Posgv = Zeros, Posgva = Zeros;
+    bool init = false;
+};
+
 struct Slot {
     sspace *ss;
     edge_tracker *ef;
@@ -72,6 +95,12 @@ struct Ctx {
     std::vector<float> bw;
     image_undistort *undist;          // rebvo_first_t.cpp:125 (only when use_undistort)
     Image<RGB24Pixel> *img_dist;      // the distorted input frame (rebvo_first_t.cpp:112)
+    // IMU branch of SecondThread (rebvo_second_t.cpp:54-94)
+    OrcImuParams ip;
+    IMUState istate;
+    int n_frame, n_giro_init;
+    Vector<3> giro_init, g_init;
+    Matrix<3, 3> Rgva;
 };
 
 void reset_seq(Ctx *c) {
@@ -454,6 +483,257 @@ int ref_process_frame(void *ctx, const uint8_t *rgb24, double t, OrcNav *nav) {
     nav->estimation_ok = EstimationOk;
     // nav->V/W above are the tracker outputs; the state carried forward may have been reset (V=0)
     c->frame++;
+    c->t_prev = t;
+    return 1;
+}
+
+}  // extern "C"
+
+// ---------------------------------------------------------------------------------------------------------------
+// IMU branch: the reference's filters and grabber behind flat entry points, and the ImuMode > 0 frame sequence
+// ---------------------------------------------------------------------------------------------------------------
+namespace {
+template <int N> Vector<N> vN(const double *p) { Vector<N> v; for (int i = 0; i < N; i++) v[i] = p[i]; return v; }
+template <int N> Matrix<N, N> mN(const double *p) { Matrix<N, N> m; for (int i = 0; i < N; i++) for (int j = 0; j < N; j++) m(i, j) = p[i * N + j]; return m; }
+template <int N> void putN(double *p, const Vector<N> &v) { for (int i = 0; i < N; i++) p[i] = v[i]; }
+template <int N> void putM(double *p, const Matrix<N, N> &m) { for (int i = 0; i < N; i++) for (int j = 0; j < N; j++) p[i * N + j] = m(i, j); }
+void put_imu(OrcImuIntegrated *o, const IntegratedImuData &d) {
+    o->n = d.n; o->pad = 0; o->dt = d.dt;
+    putM<3>(o->Rot, d.Rot); putN<3>(o->giro, d.giro); putN<3>(o->acel, d.acel); putN<3>(o->comp, d.comp);
+    putN<3>(o->dgiro, d.dgiro); putN<3>(o->cacel, d.cacel);
+}
+}  // namespace
+
+extern "C" {
+
+void ref_imu_bias_correct(double *X, double *Wx, double *Gb, double *Wb, const double *Rg, const double *Rb) {
+    Vector<6> x = vN<6>(X);
+    Matrix<6, 6> wx = mN<6>(Wx);
+    Vector<3> gb = vN<3>(Gb);
+    Matrix<3, 3> wb = mN<3>(Wb);
+    edge_tracker::BiasCorrect(x, wx, gb, wb, mN<3>(Rg), mN<3>(Rb));
+    putN<6>(X, x); putM<6>(Wx, wx); putN<3>(Gb, gb); putM<3>(Wb, wb);
+}
+void ref_est_acel_lsq4(const double *vel, double *acel, const double *R, double dt) {
+    Vector<3> a = vN<3>(acel);
+    ScaleEstimator::EstAcelLsq4(vN<3>(vel), a, mN<3>(R), dt);
+    putN<3>(acel, a);
+}
+void ref_mean_acel4(const double *s_acel, double *acel, const double *R) {
+    Vector<3> a = vN<3>(acel);
+    ScaleEstimator::MeanAcel4(vN<3>(s_acel), a, mN<3>(R));
+    putN<3>(acel, a);
+}
+double ref_est_ka_gmek_bias(const double *s_acel, const double *f_acel, double kP, const double *Rot, double *X, double *P,
+                            const double *Qg, const double *Qrot, const double *Qbias, double QKp, double Rg,
+                            const double *Rs, const double *Rf, double *g_est, double *b_est, const double *Wvw,
+                            double *Xvw, double g_gravit) {
+    Vector<7> x = vN<7>(X);
+    Matrix<7, 7> p = mN<7>(P);
+    Vector<3> g = vN<3>(g_est), b = vN<3>(b_est);
+    Vector<6> xvw = vN<6>(Xvw);
+    const double k = ScaleEstimator::estKaGMEKBias(vN<3>(s_acel), vN<3>(f_acel), kP, mN<3>(Rot), x, p, mN<3>(Qg), mN<3>(Qrot),
+                                                   mN<3>(Qbias), QKp, Rg, mN<3>(Rs), mN<3>(Rf), g, b, mN<6>(Wvw), xvw, g_gravit);
+    putN<7>(X, x); putM<7>(P, p); putN<3>(g_est, g); putN<3>(b_est, b); putN<6>(Xvw, xvw);
+    return k;
+}
+
+void *ref_imu_grabber_new(int list_size, double tsamp) { return new ImuGrabber(list_size, tsamp); }
+void *ref_imu_grabber_load(const char *csv_file, double time_scale) {
+    bool error = false;
+    std::vector<ImuData> d = ImuGrabber::LoadDataSet(csv_file, false, time_scale, error);
+    if (error) return nullptr;
+    return new ImuGrabber(d);
+}
+void ref_imu_grabber_free(void *g) { delete (ImuGrabber *)g; }
+int ref_imu_grabber_set_se3(void *g, const double *R, const double *T) { return ((ImuGrabber *)g)->LoadCamImuSE3(mN<3>(R), vN<3>(T)) ? 1 : 0; }
+int ref_imu_grabber_load_se3(void *g, const char *se3_file) {
+    try { return ((ImuGrabber *)g)->LoadCamImuSE3(se3_file) ? 1 : 0; } catch (...) { return 0; }
+}
+int ref_imu_grabber_push(void *g, double tstamp, const double *giro, const double *acel) {
+    try { return ((ImuGrabber *)g)->PushData(ImuData(tstamp, vN<3>(giro), vN<3>(acel))) ? 1 : 0; } catch (const std::overflow_error &) { return -1; }
+}
+void ref_imu_grabber_grab(void *g, double tstart, double tend, OrcImuIntegrated *out) {
+    put_imu(out, ((ImuGrabber *)g)->GrabAndIntegrate(tstart, tend));
+}
+double ref_imu_grabber_tsample(void *g) { return ((ImuGrabber *)g)->tsample; }
+
+// rebvo_second_t.cpp:66-84: IMUState set-up (members the reference leaves to the heap are zeroed here)
+void ref_imu_setup(void *ctx, const OrcImuParams *ip) {
+    Ctx *c = (Ctx *)ctx;
+    c->ip = *ip;
+    c->istate = IMUState();
+    IMUState &is = c->istate;
+    is.g_est = Zeros; is.b_est = Zeros; is.Qrot = Identity; is.Rv = Identity; is.QKp = 0; is.Wvw = Zeros; is.Xvw = Zeros;
+    is.W_Bg = util::Matrix3x3Inv(is.RGBias * 100);
+    is.Qg = Identity * ip->g_uncert * ip->g_uncert;
+    is.Rg = ip->g_module_uncer * ip->g_module_uncer;
+    is.Rs = Identity * ip->acel_meas_std * ip->acel_meas_std;
+    is.Qbias = Identity * ip->vbias_std * ip->vbias_std;
+    is.X = makeVector(M_PI / 4, 0, ip->g_module, 0, 0, 0, 0);
+    is.P = makeVector(ip->scale_std_init * ip->scale_std_init, 100, 100, 100, ip->vbias_std * ip->vbias_std * 1e1,
+                      ip->vbias_std * ip->vbias_std * 1e1, ip->vbias_std * ip->vbias_std * 1e1).as_diagonal();
+    is.u_est = makeVector(1, 0, 0);
+    c->n_frame = 0;
+    c->n_giro_init = 0;
+    c->giro_init = Zeros;
+    c->g_init = Zeros;
+    c->Rgva = Identity;
+}
+
+// One frame through FirstThr + SecondThread with ImuMode > 0 (rebvo_second_t.cpp:128-606).  The pose-graph log and
+// key frames are left out (they do not feed back).  Returns 1 when stage B/C ran.
+int ref_process_frame_imu(void *ctx, const uint8_t *rgb24, double t, const OrcImuIntegrated *imu_in, OrcNavImu *nav) {
+    Ctx *c = (Ctx *)ctx;
+    const OrcParams &p = c->p;
+    const OrcImuParams &ip = c->ip;
+    IMUState &istate = c->istate;
+    const int ns = (int)c->slots.size();
+    const int sn = c->frame % ns, so = (c->frame + ns - 1) % ns;
+    memset(nav, 0, sizeof(*nav));
+    ref_stage_a(ctx, sn, rgb24, &c->tresh, &c->l_kl_num);
+    Slot &nb = c->slots[sn];
+    nav->kn = nb.ef->KNum();
+    if (c->frame == 0) {
+        c->frame++;
+        c->t_prev = t;
+        return 0;
+    }
+    Slot &ob = c->slots[so];
+    IntegratedImuData imu;
+    imu.n = imu_in->n; imu.dt = imu_in->dt; imu.Rot = mN<3>(imu_in->Rot); imu.giro = vN<3>(imu_in->giro);
+    imu.acel = vN<3>(imu_in->acel); imu.comp = vN<3>(imu_in->comp); imu.dgiro = vN<3>(imu_in->dgiro); imu.cacel = vN<3>(imu_in->cacel);
+
+    bool EstimationOk = true;
+    double dt_frame = t - c->t_prev;
+    if (dt_frame < 0.001) dt_frame = 1 / p.config_fps;
+    int klm_num = 0, num_kf_back_m = 0;
+    Matrix<3, 3> P_V = Identity * 1e50, P_W = Identity * 1e50, R = Identity;
+    Vector<3> &V = c->V, &W = c->W;
+    Matrix<3, 3> &Rgva = c->Rgva;
+    double &K = c->K, &Kp = c->Kp, &P_Kp = c->P_Kp;
+    const int n_frame = c->n_frame;
+
+    double s_rho_q = ob.ef->EstimateQuantile(RHO_MIN, RHO_MAX, p.qcut_quantile, p.qcut_nbins);   // :172
+    nb.gt->build_field(*nb.ef, p.search_range, nb.ef->getThresh());                             // :177
+    if (!istate.init && n_frame > 0) {                                                          // :183-203
+        if (ip.init_bias > 0) {
+            c->giro_init += imu.giro * imu.dt;
+            c->g_init -= imu.cacel;
+            if (++c->n_giro_init > ip.init_bias_frame_num) {
+                istate.Bg = c->giro_init / c->n_giro_init;
+                istate.init = true;
+                istate.W_Bg = util::Matrix3x3Inv(istate.RGBias * 1e2);
+                istate.X.slice<1, 3>() = c->g_init / c->n_giro_init;
+            }
+        } else {
+            istate.init = true;
+            istate.Bg = vN<3>(ip.bias_init_guess) * imu.dt;
+        }
+    }
+    R = imu.Rot;                                                                                // :208
+    R.T() = TooN::SO3<>(istate.Bg) * R.T();
+    ob.ef->rotate_keylines(R.T());
+    if (p.tracker_init_type == 0) istate.Vg = Zeros;
+    nb.gt->Minimizer_V<double>(istate.Vg, istate.P_Vg, *ob.ef, p.tracker_match_thresh, p.tracker_iter_num, s_rho_q,
+                               p.match_num_thresh, p.reweight_distance, ob.ef->getThresh());   // :223
+    ob.ef->FordwardMatch(nb.ef);                                                                // :230
+    Matrix<6, 6> R_Xv, R_Xgv, W_Xv, W_Xgv;
+    Vector<6> Xv, Xgv, Xgva;
+    EstimationOk &= nb.ef->ExtRotVel(istate.Vg, W_Xv, R_Xv, Xv, p.loc_unc, p.reweight_distance);   // :237
+    istate.dVv = Xv.slice<0, 3>();
+    istate.dWv = Xv.slice<3, 3>();
+    Xgv = Xv;
+    W_Xgv = W_Xv;
+    istate.RGBias = Identity * ip.giro_bias_std * ip.giro_bias_std * dt_frame * dt_frame;
+    istate.RGiro = Identity * ip.giro_meas_std * ip.giro_meas_std * dt_frame * dt_frame;
+    Vector<3> dgbias = Zeros;
+    edge_tracker::BiasCorrect(Xgv, W_Xgv, dgbias, istate.W_Bg, istate.RGiro, istate.RGBias);     // :254
+    istate.Bg += dgbias;
+    istate.dVgv = Xgv.slice<0, 3>();
+    istate.dWgv = Xgv.slice<3, 3>();
+    Rgva = R;
+    SO3<> R0(istate.dWgv);
+    R.T() = R0.get_matrix() * R.T();
+    istate.Vgv = R0 * istate.Vg + istate.dVgv;
+    V = istate.Vgv;
+    istate.Wgv = SO3<>(R).ln();
+    R_Xgv = Cholesky<6>(W_Xgv).get_inverse();
+    P_V = R_Xgv.slice<0, 0, 3, 3>();
+    P_W = R_Xgv.slice<3, 3, 3, 3>();
+    ScaleEstimator::EstAcelLsq4(-istate.Vgv / dt_frame, istate.Av, R, dt_frame);                // :280
+    ScaleEstimator::MeanAcel4(imu.cacel, istate.As, R);
+    Xgva = Xgv;
+    istate.Rv = (P_V / (dt_frame * dt_frame * dt_frame * dt_frame));
+    istate.Qrot = P_W;
+    istate.QKp = P_Kp;
+    if (n_frame > 4 + ip.init_bias_frame_num) {                                                 // :291-312
+        K = ScaleEstimator::estKaGMEKBias(istate.As, istate.Av, 1, R, istate.X, istate.P, istate.Qg, istate.Qrot, istate.Qbias,
+                                          istate.QKp, istate.Rg, istate.Rs, istate.Rv, istate.g_est, istate.b_est, W_Xgv, Xgva,
+                                          ip.g_module);
+        istate.dVgva = Xgva.slice<0, 3>();
+        istate.dWgva = Xgva.slice<3, 3>();
+        SO3<> R0gva(istate.dWgva);
+        Rgva.T() = R0gva.get_matrix() * Rgva.T();
+        istate.Vgva = R0gva * istate.Vg + istate.dVgva;
+    } else {
+        istate.dVgva = istate.dVgv;
+        istate.dWgva = istate.dWgv;
+        Rgva = R;
+        istate.Vgva = istate.Vgv;
+    }
+    ob.ef->rotate_keylines(R0.get_matrix());                                                    // :319
+
+    if (util::isNaN(V) || util::isNaN(W)) {                                                     // :387-397
+        P_V = Identity * 1e50;
+        V = Zeros;
+        Kp = 1;
+        P_Kp = 1e50;
+        EstimationOk = false;
+    } else {
+        klm_num = nb.ef->directed_matching(V, P_V, R, ob.ef, num_kf_back_m, p.match_thresh_module, p.match_thresh_angle,
+                                           p.search_range, p.loc_unc_match, false);            // :410
+        if (klm_num < p.global_match_threshold) {
+            P_V = Identity * 1e50;
+            V = Zeros;
+            Kp = 1;
+            P_Kp = 10;
+            EstimationOk = false;
+        } else {
+            nb.ef->Regularize_1_iter(p.regularize_thresh);
+            nb.ef->UpdateInverseDepthKalman(V, P_V, P_W, p.reshape_q_abs, p.reshape_q_rel, p.loc_unc);
+            Kp = nb.ef->EstimateReScalingOpt(P_Kp, RHO_MAX, 1, p.do_rescaling > 0);
+        }
+    }
+    if (n_frame > 4 + ip.init_bias_frame_num) {                                                 // :521-541
+        istate.u_est = Rgva.T() * istate.u_est;
+        istate.u_est = istate.u_est - (istate.u_est * istate.g_est) / (istate.g_est * istate.g_est) * istate.g_est;
+        TooN::normalize(istate.u_est);
+        Matrix<3> PoseP1 = TooN::SO3<>(istate.g_est, makeVector(0, 1, 0)).get_matrix();
+        Matrix<3> PoseP2 = TooN::SO3<>(PoseP1 * istate.u_est, makeVector(1, 0, 0)).get_matrix();
+        c->Pose = PoseP2 * PoseP1;
+        c->Pos += -c->Pose * istate.Vgva * K;
+        istate.Posgva = c->Pos;
+        istate.Posgv += -c->Pose * istate.Vgv * K;
+    }
+    nav->dt = dt_frame; nav->K = K; nav->Kp = Kp; nav->RKp = P_Kp; nav->s_rho_q = s_rho_q;
+    put3(nav->Rot, R);
+    putv(nav->RotLie, SO3<>(R).ln());
+    putv(nav->RotGiro, SO3<>(Rgva).ln() / dt_frame);
+    putv(nav->Vel, -V * K / dt_frame);
+    put3(nav->Pose, c->Pose);
+    putv(nav->PoseLie, SO3<>(c->Pose).ln());
+    putv(nav->Pos, c->Pos);
+    putv(nav->g, istate.g_est);
+    nav->scale = K;
+    putv(nav->Vg, istate.Vg); putv(nav->Bg, istate.Bg); putv(nav->dVv, istate.dVv); putv(nav->dWv, istate.dWv);
+    putv(nav->Vgv, istate.Vgv); putv(nav->Vgva, istate.Vgva); putv(nav->Av, istate.Av); putv(nav->As, istate.As);
+    putN<7>(nav->X, istate.X); putv(nav->b_est, istate.b_est); putv(nav->u_est, istate.u_est);
+    nav->klm_num = klm_num;
+    nav->estimation_ok = EstimationOk;
+    nav->init = istate.init;
+    c->frame++;
+    c->n_frame++;
     c->t_prev = t;
     return 1;
 }

@@ -867,6 +867,15 @@ int edgehip_depth_reset(edgehip_ctx *c, int seq) {
     return 0;
 }
 
+int edgehip_depth_reset_slot(edgehip_ctx *c, int seq, int slot) {
+    if (!c || seq >= c->plan.nseq || slot < 0 || slot >= c->plan.nslots) return EDGEHIP_ERR_ARG;
+    const DevicePlan &pl = c->plan;
+    hipLaunchKernelGGL(k_depth_reset, dim3((pl.cap + 255) / 256, 1, pl.nseq), dim3(256), 0, c->stream, kldev(c, slot),
+                       c->kn_slot + (size_t)slot * pl.nseq, c->seq, seq);
+    EH_LAUNCH_CHECK();
+    return 0;
+}
+
 int edgehip_next_slot(edgehip_ctx *c) { return c ? (c->frame_slot + 1) % c->plan.nslots : -1; }
 int edgehip_cur_slot(edgehip_ctx *c) { return c ? c->frame_slot : -1; }
 

@@ -141,7 +141,7 @@ EXPORTS = [
     "edgehip_upload_keylines", "edgehip_download_plane", "edgehip_download_field", "edgehip_profile_enable",
     "edgehip_profile_count", "edgehip_profile_name", "edgehip_profile_read", "edgehip_profile_select",
     "edgehip_upload_rgb_indexed", "edgehip_set_nav_log", "edgehip_read_nav_log",
-    "edgehip_build_undistort_map", "edgehip_download_undistorted", "edgehip_depth_reset", "edgehip_minimizer_v", "edgehip_ext_rot_vel",
+    "edgehip_build_undistort_map", "edgehip_download_undistorted", "edgehip_depth_reset", "edgehip_depth_reset_slot", "edgehip_minimizer_v", "edgehip_ext_rot_vel",
 ]
 
 _lib = None
@@ -227,6 +227,9 @@ class EdgeHip:
     def depth_reset(self, seq=-1):
         """REBVO::Reset() (rebvo_second_t.cpp:609-620) for one sequence or all (-1)."""
         self._ck(self.lib.edgehip_depth_reset(self.ctx, seq))
+
+    def depth_reset_slot(self, slot, seq=-1):
+        self._ck(self.lib.edgehip_depth_reset_slot(self.ctx, seq, slot))
 
     def download_undistorted(self, seq, slot):
         out = np.empty((self.h, self.w, 3), np.uint8)

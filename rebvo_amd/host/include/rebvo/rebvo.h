@@ -13,7 +13,10 @@
 // Differences, all forced by what is out of scope here:
 //  * CameraType 3 (custom camera: the application feeds frames) and 2 (DataSetCam: EuRoC data.csv / TUM rgb.txt
 //    image lists, PNG/PGM/PPM decoded without libgd, rebvo/datasetcam.h) are available; V4L and SimCam are
-//    device I/O that this repository does not rebuild.  ImuMode must be 0 (the rest of the IMU branch is "next").
+//    device I/O that this repository does not rebuild.
+//  * ImuMode 1 (samples pushed with pushIMU) and 2 (IMU csv data set) run the IMU branch of SecondThread
+//    (rebvo_second_t.cpp:182-336, 519-544): gyro pre-rotation, Minimizer_V and ExtRotVel on the GPU, BiasCorrect and
+//    the ScaleEstimator filters on the host (rebvo/imu.h).  The pose-graph log (cf->poses) and key frames do not exist.
 //  * PipeBuffer::ss and ::gt are null (scale space and auxiliary field stay in HBM); PipeBuffer::ef is a
 //    host view with the edge_finder members consumers use: KNum(), operator[], begin()/end(), GetCam(),
 //    getThresh(), NumMatches().
@@ -36,6 +39,7 @@
 #include <thread>
 #include <vector>
 
+#include "rebvo/imu.h"
 #include "rebvo/pipeline.h"
 
 #ifdef REBVO_HAVE_TOON
@@ -80,6 +84,11 @@ struct Matrix3x3 {  // row-major, like TooN::Matrix<3,3>
 inline Vector3 Zeros3() { return Vector3(); }
 inline Matrix3x3 Identity3() { return Matrix3x3(); }
 #endif
+inline Matrix3x3 scaled_identity3(double s) {
+    Matrix3x3 m = Identity3();
+    for (int i = 0; i < 3; i++) m(i, i) = s;
+    return m;
+}
 
 // ---- Image<T> (reference: include/VideoLib/image.h:42-217; the members applications use) ---------------
 template <typename DataType>
@@ -203,6 +212,13 @@ struct REBVOParameters {
     std::string SimFile; double sim_save_nframes = 0; int simu_time_on = 0, simu_time_step = 0;
     double simu_time_sweep = 0, simu_time_start = 0;
     int ImuMode = 0; std::string ImuFile; bool UseCamIMUSE3File = false; std::string SE3File; double ImuTimeScale = 1;
+    // IMU branch (reference include/rebvo/rebvo.h:150-173)
+    double GiroMeasStdDev = 1.6968e-04, GiroBiasStdDev = 1.9393e-05;
+    bool InitBias = false; int InitBiasFrameNum = 10;
+    Vector3 BiasInitGuess = Zeros3();
+    double AcelMeasStdDev = 2e-3, g_module = 9.8, g_module_uncer = 0.2e3, g_uncert = 2e-3, VBiasStdDev = 1e-7;
+    double ScaleStdDevMult = 1e-2, ScaleStdDevMax = 1e-4, ScaleStdDevInit = 1.2e-3;
+    double SampleTime = 0.00125; int CircBufferSize = 1000; double TimeDesinc = 0;
     int cpuSetAffinity = 0, cpu0 = 0, cpu1 = 0, cpu2 = 0;
     // Detector
     double Sigma0 = 1.7818, KSigma = 1.2599;
@@ -222,11 +238,30 @@ struct REBVOParameters {
     int GpuDevice = 0;
 };
 
-struct IMUState {  // kept so that consumers referring to PipeBuffer::imustate compile; unused with ImuMode=0
-    Vector3 Vg, dVv, dWv, Bg, Av, As, g_est, b_est, Posgv, Posgva;
+// Filter state SecondThread keeps in the IMU branch (reference include/rebvo/rebvo.h:239-290, same member names).
+// Unlike the reference every member starts initialised (the reference leaves g_est, b_est, X, P ... to the heap).
+struct IMUState {
+    Vector3 Vg = Zeros3();                              // translation from Minimizer_V (gyro-rotated frame)
+    Vector3 dVv = Zeros3(), dWv = Zeros3();             // visual increment (ExtRotVel)
+    Vector3 dVgv = Zeros3(), dWgv = Zeros3();           // after the gyro prior (BiasCorrect)
+    Vector3 Vgv = Zeros3(), Wgv = Zeros3();
+    Vector3 dVgva = Zeros3(), dWgva = Zeros3(), Vgva = Zeros3();   // after the accelerometer filter
+    Matrix3x3 P_Vg = scaled_identity3(1e50);
+    Matrix3x3 RGiro = Identity3(), RGBias = Identity3();
+    Vector3 Bg = Zeros3();                              // gyro bias
+    Matrix3x3 W_Bg = Identity3();                       // its information
+    Vector3 Av = Zeros3(), As = Zeros3();               // visual / accelerometer acceleration
+    la::Vec<7> X = la::Vec<7>::zeros();                 // (scale angle, g, visual bias)
+    la::Mat<7, 7> P = la::Mat<7, 7>::zeros();
+    Matrix3x3 Qrot = Identity3(), Qg = Identity3(), Qbias = Identity3();
+    double QKp = 0, Rg = 0;
+    Matrix3x3 Rs = Identity3(), Rv = Identity3();
+    Vector3 g_est = Zeros3(), u_est = Zeros3(), b_est = Zeros3();
+    la::Mat<6, 6> Wvw = la::Mat<6, 6>::zeros();
+    la::Vec<6> Xvw = la::Vec<6>::zeros();
+    Vector3 Posgv = Zeros3(), Posgva = Zeros3();
+    bool init = false;
 };
-struct ImuData { double tstamp = 0; Vector3 giro, acel, comp; };
-struct IntegratedImuData { int n = 0; Vector3 giro, acel, cacel, dgiro; double dt = 0; };
 
 struct NavData {
     double t = 0, dt = 0, scale = 1;
@@ -283,6 +318,9 @@ class REBVO {
     std::function<bool(PipeBuffer &)> outputFunc;
     edgehip_ctx *hip = nullptr;
     DataSetCam *dscam = nullptr;   // CameraType == 2
+    ImuGrabber *imu = nullptr;     // ImuMode > 0
+    struct ImuTrack;               // SecondThread's IMU-branch locals (rebvo_imu.cpp)
+    ImuTrack *imutrack = nullptr;
     std::string last_error;
 
     bool callCallBack(PipeBuffer &pbuf) {
@@ -300,6 +338,12 @@ class REBVO {
     }
     void construct();
     static void TrackThread(REBVO *cf);   // FirstThr + SecondThread of the reference: one GPU frame per loop
+    // IMU branch of one frame: stage A, then (from the second frame on) the tracker / filters / mapper sequence of
+    // rebvo_second_t.cpp:128-606 with ImuMode > 0.  Returns 0 or an edgehip error code.
+    int trackFrameImu(int slot_new, int slot_old, bool have_pair, double t, PipeBuffer &new_buf);
+    void imuTrackInit();
+    void imuTrackFree();
+    void resetImuTrack(int slot_new);   // REBVO::Reset() in the IMU branch: depth reset of the newest map, pose to identity
     static void ThirdThread(REBVO *cf);   // output: log, trajectory, callback
 
 public:
@@ -325,8 +369,14 @@ public:
         return navdat;
     }
     const REBVOParameters &getParams() { return params; }
-    bool setCamImuSE3(const Matrix3x3 &, const Vector3 &) { return false; }  // no IMU on this path
-    bool pushIMU(const ImuData &) { return false; }                         // reference returns false without an ImuGrabber
+    // Cam-IMU transformation, Pimu = RCam2IMU * Pcam + TCam2IMU (rebvo.h:519-526); false without an ImuGrabber
+    bool setCamImuSE3(const Matrix3x3 &RCam2IMU, const Vector3 &TCam2IMU);
+    // Push one IMU sample (ImuMode 1; rebvo.h:534-539).  ImuGrabber::PushData throws std::overflow_error when the
+    // circular buffer is full, as in the reference.
+    bool pushIMU(const ImuData &data) {
+        if (imu) return imu->PushData(data);
+        return false;
+    }
 
     bool requestCustomCamBuffer(std::shared_ptr<Image<RGB24Pixel>> &ptr, double time_stamp, double timeout_secs = 0) {
         customCam::CustomCamPipeBuffer *ccpb = cam_pipe.RequestBufferTimeoutable(0, timeout_secs);
@@ -349,8 +399,8 @@ public:
     }
     bool isInitOk() const { return InitOK; }
     const std::string &lastError() const { return last_error; }
-    Matrix3x3 getCam2ImuRot() { return Identity3(); }
-    Vector3 getCam2ImuPos() { return Zeros3(); }
+    Matrix3x3 getCam2ImuRot();
+    Vector3 getCam2ImuPos();
 };
 
 }  // namespace rebvo

@@ -17,6 +17,7 @@
 #include <iostream>
 #include <map>
 #include <sstream>
+#include <thread>
 
 #include "edgehip.h"
 #include "rebvo/datasetcam.h"
@@ -190,7 +191,33 @@ REBVO::REBVO(const char *configFile)
         InitOK &= config.get("DataSetCamera", "DataSetFile", p.DataSetFile);
         InitOK &= config.get("DataSetCamera", "TimeScale", p.CamTimeScale);
     }
-    if (p.ImuMode == 2) config.get("IMU", "TimeScale", p.ImuTimeScale, false);
+    if (p.ImuMode > 0) {   // src/rebvo/rebvo.cpp:160-183
+        InitOK &= config.get("IMU", "GiroMeasStdDev", p.GiroMeasStdDev);
+        InitOK &= config.get("IMU", "GiroBiasStdDev", p.GiroBiasStdDev);
+        InitOK &= config.get("IMU", "InitBias", p.InitBias);
+        InitOK &= config.get("IMU", "InitBiasFrameNum", p.InitBiasFrameNum);
+        InitOK &= config.get("IMU", "BiasHintX", p.BiasInitGuess[0]);
+        InitOK &= config.get("IMU", "BiasHintY", p.BiasInitGuess[1]);
+        InitOK &= config.get("IMU", "BiasHintZ", p.BiasInitGuess[2]);
+        InitOK &= config.get("IMU", "g_module", p.g_module);
+        InitOK &= config.get("IMU", "AcelMeasStdDev", p.AcelMeasStdDev);
+        InitOK &= config.get("IMU", "g_module_uncer", p.g_module_uncer);
+        InitOK &= config.get("IMU", "g_uncert", p.g_uncert);
+        InitOK &= config.get("IMU", "VBiasStdDev", p.VBiasStdDev);
+        InitOK &= config.get("IMU", "ScaleStdDevMult", p.ScaleStdDevMult);
+        InitOK &= config.get("IMU", "ScaleStdDevMax", p.ScaleStdDevMax);
+        InitOK &= config.get("IMU", "ScaleStdDevInit", p.ScaleStdDevInit);
+        p.UseCamIMUSE3File = config.get("IMU", "CamImuSE3File", p.SE3File, false);
+        InitOK &= config.get("IMU", "TimeDesinc", p.TimeDesinc);
+    }
+    if (p.ImuMode == 2) {
+        InitOK &= config.get("IMU", "ImuFile", p.ImuFile);
+        InitOK &= config.get("IMU", "TimeScale", p.ImuTimeScale);
+    } else if (p.ImuMode == 1) {
+        InitOK &= config.get("IMU", "SampleTime", p.SampleTime);
+        InitOK &= config.get("IMU", "CircBufferSize", p.CircBufferSize);
+        p.ImuTimeScale = 1;
+    }
     // accepted and ignored (subsystems that do not exist on this path)
     config.get("Camera", "Rotate180", p.rotatedCam, false);
     config.get("REBVO", "VideoNetEnabled", p.VideoNetEnabled, false);
@@ -209,6 +236,32 @@ void REBVO::construct() {
     if (!InitOK) return;
     cam = cam_model({params.pp_x, params.pp_y}, {params.z_f_x, params.z_f_y}, params.kc, params.ImageSize);
     if (params.ImageSize.w == 0 || params.ImageSize.h == 0) { InitOK = false; return; }
+    switch (params.ImuMode) {   // IMU grabber (src/rebvo/rebvo.cpp:248-281)
+    case 1:   // the application pushes samples (pushIMU)
+        imu = new ImuGrabber(params.CircBufferSize, params.SampleTime);
+        if (params.UseCamIMUSE3File && !imu->LoadCamImuSE3(params.SE3File.data())) {
+            std::cout << "REBVO: Failed to load cam-imu transformation \n";
+            InitOK = false;
+            return;
+        }
+        break;
+    case 2: {   // whole data set from a csv file
+        bool error = false;
+        imu = new ImuGrabber(ImuGrabber::LoadDataSet(params.ImuFile.data(), false, params.ImuTimeScale, error));
+        if (error) {
+            std::cout << "REBVO: Failed to initialize the imu grabber\n";
+            InitOK = false;
+            return;
+        }
+        if (params.UseCamIMUSE3File && !imu->LoadCamImuSE3(params.SE3File.data())) {
+            std::cout << "Failed to load cam-imu transformation \n";
+            InitOK = false;
+            return;
+        }
+        break;
+    }
+    default: break;
+    }
     for (unsigned i = 0; i < cam_pipe.Size(); i++)   // rebvo.cpp:284-285
         cam_pipe[i].img = std::make_shared<Image<RGB24Pixel>>(params.ImageSize);
     for (PipeBuffer &pbuf : pipe) {                  // rebvo.cpp:297-312 (host views only; the rest lives in HBM)
@@ -222,6 +275,7 @@ void REBVO::construct() {
 
 REBVO::~REBVO() {
     if (!quit) CleanUp();
+    delete imu;
     if (InitOK)
         for (PipeBuffer &pbuf : pipe) {
             delete pbuf.ef;
@@ -248,11 +302,12 @@ bool REBVO::Init() {
             return false;
         }
     }
-    if (params.ImuMode != 0) {
-        last_error = "REBVO(hip): ImuMode must be 0 (the IMU branch Minimizer_V/ExtRotVel is not built yet)";
+    if (params.ImuMode < 0 || params.ImuMode > 2) {
+        last_error = "REBVO(hip): ImuMode must be 0, 1 (pushIMU) or 2 (IMU data set file)";
         std::cout << last_error << "\n";
         return false;
     }
+    if (params.ImuMode > 0) imuTrackInit();
     edgehip_params hp;
     fill_hip_params(params, hp);
     const int rc = edgehip_create(&hp, 1, 3, params.GpuDevice, &hip);
@@ -271,6 +326,7 @@ bool REBVO::CleanUp() {
     quit = true;
     if (Thr0.joinable()) Thr0.join();
     if (hip) { edgehip_destroy(hip); hip = nullptr; }
+    imuTrackFree();
     if (dscam) { delete dscam; dscam = nullptr; }
     return true;
 }
@@ -293,6 +349,7 @@ void REBVO::TrackThread(REBVO *cf) {
     const double min_frame_dt = 1.0 / cf->params.soft_fps - 0.5 / cf->params.config_fps;   // rebvo_first_t.cpp:146
     PipeBuffer *old_buf = nullptr;   // previous frame: held (player 1) until the next frame has been tracked
     int p_num = 0;
+    int n_frames = 0;   // frames detected so far
     bool failed = false;
     while (!cf->quit && !failed) {
         PipeBuffer &new_buf = cf->pipe.RequestBuffer(0);
@@ -325,16 +382,44 @@ void REBVO::TrackThread(REBVO *cf) {
             break;
         }
         const double tp0 = now_s();
-        const int slot = edgehip_next_slot(cf->hip);
+        const bool imu_mode = cf->imu != nullptr;
+        // ring of 3 device slots; without the IMU branch the library's own whole-frame driver advances it
+        const int slot = imu_mode ? n_frames % 3 : edgehip_next_slot(cf->hip);
         int rc = edgehip_upload_rgb(cf->hip, slot, reinterpret_cast<const uint8_t *>(data), 0, 1);
         std::memcpy(new_buf.imgc->Data(), data, frame_bytes);
         if (cbuf) cf->cam_pipe.ReleaseBuffer(1);
         else cf->dscam->ReleaseBuffer();
+        if (imu_mode) {   // inter-frame IMU data, waiting for the samples to arrive (rebvo_first_t.cpp:294-304)
+            while (!cf->quit) {
+                new_buf.imu = cf->imu->GrabAndIntegrate(t0 + cf->params.TimeDesinc, t + cf->params.TimeDesinc);
+                if (new_buf.imu.n > 0) break;
+                std::this_thread::sleep_for(std::chrono::duration<double>(cf->params.SampleTime));
+            }
+        }
         t0 = t;
-        // ---- the whole frame on the GPU: stage A + (from the second frame on) tracking and mapping ----
-        if (rc == 0) rc = edgehip_process_frame(cf->hip, &t);
-        edgehip_nav n;
-        if (rc == 0) rc = edgehip_read_nav(cf->hip, &n);
+        new_buf.t = t;
+        new_buf.p_id = p_num - 1;
+        new_buf.quit = false;
+        new_buf.dtp0 = 0;
+        if (imu_mode) {
+            // ---- IMU branch: GPU stages driven one by one, host filters in between ----
+            if (rc == 0) rc = cf->trackFrameImu(slot, (slot + 2) % 3, old_buf != nullptr, t, new_buf);
+        } else {
+            // ---- the whole frame on the GPU: stage A + (from the second frame on) tracking and mapping ----
+            if (rc == 0) rc = edgehip_process_frame(cf->hip, &t);
+            edgehip_nav n;
+            if (rc == 0) rc = edgehip_read_nav(cf->hip, &n);
+            if (rc == 0) {
+                new_buf.dt = n.dt;
+                new_buf.K = 1; new_buf.Kp = n.Kp; new_buf.RKp = n.RKp;
+                new_buf.s_rho_p = n.s_rho_q;
+                new_buf.EstimationOK = n.estimation_ok != 0;
+                new_buf.ef->nmatch = n.klm_num;
+                new_buf.ef->reTunedThresh = n.retuned_thresh;
+                if (old_buf) fill_nav(n, new_buf.nav);
+                else new_buf.nav = NavData();   // first frame: "dummy processing", no estimate (rebvo_second_t.cpp:108-121)
+            }
+        }
         if (rc != 0) {
             std::cout << "REBVO(hip): " << edgehip_last_error() << "\n";
             failed = true;
@@ -342,24 +427,9 @@ void REBVO::TrackThread(REBVO *cf) {
             cf->pipe.ReleaseBuffer(0);
             break;
         }
-        const double tp1 = now_s();
-        new_buf.t = t;
-        new_buf.dt = n.dt;
-        new_buf.p_id = p_num - 1;
-        new_buf.quit = false;
-        new_buf.dtp0 = 0;
-        new_buf.dtp1 = tp1 - tp0;
-        new_buf.K = 1; new_buf.Kp = n.Kp; new_buf.RKp = n.RKp;
-        new_buf.s_rho_p = n.s_rho_q;
-        new_buf.EstimationOK = n.estimation_ok != 0;
-        new_buf.ef->nmatch = n.klm_num;
-        new_buf.ef->reTunedThresh = n.retuned_thresh;
-        if (old_buf) {
-            fill_nav(n, new_buf.nav);
-            cf->pushNav(new_buf.nav);
-        } else {
-            new_buf.nav = NavData();   // first frame: "dummy processing", no estimate (rebvo_second_t.cpp:108-121)
-        }
+        n_frames++;
+        new_buf.dtp1 = now_s() - tp0;
+        if (old_buf) cf->pushNav(new_buf.nav);
         // ---- hand the PREVIOUS frame to the output thread, with its edge map as the tracker left it ----
         if (old_buf) {
             const bool want = cf->haveCallBack();
@@ -378,7 +448,8 @@ void REBVO::TrackThread(REBVO *cf) {
             cf->pipe.ReleaseBuffer(1);
         }
         if (cf->system_reset) {   // rebvo_second_t.cpp:609-620
-            edgehip_depth_reset(cf->hip, -1);
+            if (imu_mode) cf->resetImuTrack(slot);
+            else edgehip_depth_reset(cf->hip, -1);
             cf->system_reset = false;
         }
         // new_buf becomes old_buf: player 1 takes the slot player 0 releases now
