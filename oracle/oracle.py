@@ -356,3 +356,85 @@ class Oracle:
 
     def reset_sequence(self):
         self._reset(self.ctx)
+
+
+# ---- IMU branch (reference only; see oracle_abi.h) ----------------------------------------------------------------
+class ImuIntegrated(C.Structure):
+    """OrcImuIntegrated = rebvo::IntegratedImuData."""
+    _fields_ = [("n", C.c_int32), ("pad", C.c_int32), ("dt", C.c_double), ("Rot", C.c_double * 9), ("giro", C.c_double * 3),
+                ("acel", C.c_double * 3), ("comp", C.c_double * 3), ("dgiro", C.c_double * 3), ("cacel", C.c_double * 3)]
+
+    def as_row(self):
+        return np.concatenate([[self.n, self.dt], self.Rot, self.giro, self.acel, self.comp, self.dgiro, self.cacel])
+
+    @classmethod
+    def from_row(cls, r):
+        o = cls()
+        o.n, o.dt = int(r[0]), float(r[1])
+        o.Rot[:] = r[2:11]; o.giro[:] = r[11:14]; o.acel[:] = r[14:17]; o.comp[:] = r[17:20]; o.dgiro[:] = r[20:23]; o.cacel[:] = r[23:26]
+        return o
+
+
+class ImuParams(C.Structure):
+    """OrcImuParams; defaults = the &IMU section of app/rebvorun/GlobalConfig_EuRoC."""
+    _fields_ = [("giro_meas_std", C.c_double), ("giro_bias_std", C.c_double), ("init_bias", C.c_int32),
+                ("init_bias_frame_num", C.c_int32), ("bias_init_guess", C.c_double * 3), ("acel_meas_std", C.c_double),
+                ("g_module", C.c_double), ("g_module_uncer", C.c_double), ("g_uncert", C.c_double), ("vbias_std", C.c_double),
+                ("scale_std_mult", C.c_double), ("scale_std_max", C.c_double), ("scale_std_init", C.c_double)]
+
+
+def euroc_imu_params(**over):
+    p = ImuParams()
+    p.giro_meas_std, p.giro_bias_std = 1.6968e-04, 1.9393e-05
+    p.init_bias, p.init_bias_frame_num = 1, 10
+    p.bias_init_guess[:] = [0.0188, 0.0037, 0.0776]
+    p.acel_meas_std, p.g_module, p.g_module_uncer, p.g_uncert, p.vbias_std = 2.0e-3, 9.8, 0.2e3, 2e-3, 1e-7
+    p.scale_std_mult, p.scale_std_max, p.scale_std_init = 1e-2, 1e-4, 1.2e-3
+    for k, v in over.items():
+        if k == "bias_init_guess":
+            p.bias_init_guess[:] = v
+        else:
+            setattr(p, k, v)
+    return p
+
+
+class NavImu(C.Structure):
+    """OrcNavImu."""
+    _fields_ = [("Rot", C.c_double * 9), ("RotLie", C.c_double * 3), ("RotGiro", C.c_double * 3), ("Vel", C.c_double * 3),
+                ("Pose", C.c_double * 9), ("PoseLie", C.c_double * 3), ("Pos", C.c_double * 3), ("g", C.c_double * 3),
+                ("scale", C.c_double), ("dt", C.c_double), ("K", C.c_double), ("Kp", C.c_double), ("RKp", C.c_double),
+                ("s_rho_q", C.c_double), ("Vg", C.c_double * 3), ("Bg", C.c_double * 3), ("dVv", C.c_double * 3),
+                ("dWv", C.c_double * 3), ("Vgv", C.c_double * 3), ("Vgva", C.c_double * 3), ("Av", C.c_double * 3),
+                ("As", C.c_double * 3), ("X", C.c_double * 7), ("b_est", C.c_double * 3), ("u_est", C.c_double * 3),
+                ("kn", C.c_int32), ("klm_num", C.c_int32), ("estimation_ok", C.c_int32), ("init", C.c_int32)]
+
+
+def run_imu_sequence(frames, t, imu_rows, params, imu_params, nslots=8):
+    """ref_process_frame_imu over a sequence (frames[k], t[k], imu_rows[k] = ImuIntegrated.as_row()) -> dict of arrays.
+    Call it in a fresh process: the reference's acceleration histories are process-wide statics."""
+    orc = Oracle("ref", params, nslots)
+    L = orc.lib
+    L.ref_imu_setup.argtypes = [C.c_void_p, C.POINTER(ImuParams)]
+    L.ref_imu_setup.restype = None
+    L.ref_process_frame_imu.argtypes = [C.c_void_p, C.c_void_p, C.c_double, C.POINTER(ImuIntegrated), C.POINTER(NavImu)]
+    L.ref_process_frame_imu.restype = C.c_int
+    L.ref_imu_setup(orc.ctx, C.byref(imu_params))
+    out = {name: [] for name, _ in NavImu._fields_}
+    out["kl_rho_sum"], out["kl_srho_sum"] = [], []
+    out["klprev_n"], out["klprev_rho_sum"], out["klprev_srho_sum"] = [], [], []
+    for k in range(len(frames)):
+        nav = NavImu()
+        f = np.ascontiguousarray(frames[k], np.uint8)
+        L.ref_process_frame_imu(orc.ctx, f.ctypes.data, float(t[k]), C.byref(ImuIntegrated.from_row(imu_rows[k])), C.byref(nav))
+        for name, ct in NavImu._fields_:
+            v = getattr(nav, name)
+            out[name].append(np.array(v[:]) if hasattr(v, "__len__") else v)
+        kl = orc.keylines(orc.cur_slot())
+        out["kl_rho_sum"].append(float(kl["rho"].sum()))
+        out["kl_srho_sum"].append(float(kl["s_rho"].sum()))
+        # the previous edge map as this frame's tracking left it (what the output callback sees one frame late)
+        klp = orc.keylines((k - 1) % nslots) if k >= 1 else kl[:0]
+        out["klprev_n"].append(len(klp))
+        out["klprev_rho_sum"].append(float(klp["rho"].sum()))
+        out["klprev_srho_sum"].append(float(klp["s_rho"].sum()))
+    return {k: np.array(v) for k, v in out.items()}

@@ -1,11 +1,14 @@
 // custom_cam_replay — the reference's custom-camera example (app/rebvorun/main_custom_cam_example.cpp:46-118)
 // against the HIP-backed library: frames come from a raw file instead of DataSetCam.
 //
-//   custom_cam_replay <GlobalConfig> <frames.rgb24> <n_frames> <t0> <dt> [dump.txt]
+//   custom_cam_replay <GlobalConfig> <frames.rgb24> <n_frames> <t0> <dt> [dump.txt [imu.csv]]
 //
 // frames.rgb24 = n_frames x ImageHeight x ImageWidth x 3 bytes.  Every frame goes through
 // requestCustomCamBuffer / releaseCustomCamBuffer; the output callback (third thread) appends one line per
-// delivered frame to dump.txt:  p_id t kn nmatch EstimationOK Pos[3] PoseLie[3] Vel[3] sum(rho) sum(s_rho)
+// delivered frame to dump.txt:  p_id t kn nmatch EstimationOK Pos[3] PoseLie[3] Vel[3] sum(rho) sum(s_rho) and the
+// columns dataset_replay adds (RotLie, RotGiro, g, scale, K, Kp, RKp, IMU state, dt).
+// With ImuMode=1 in the config, imu.csv ("t,gx,gy,gz,ax,ay,az", seconds) is fed through pushIMU the way an
+// application would: every sample up to a little past a frame's time stamp is pushed before that frame is submitted.
 #include <cstdio>
 #include <fstream>
 #include <iomanip>
@@ -29,13 +32,23 @@ static bool callback(PipeBuffer &p) {
     for (int i = 0; i < 3; i++) g_dump << " " << p.nav.Pos[i];
     for (int i = 0; i < 3; i++) g_dump << " " << p.nav.PoseLie[i];
     for (int i = 0; i < 3; i++) g_dump << " " << p.nav.Vel[i];
-    g_dump << " " << sr << " " << ss << "\n";
+    g_dump << " " << sr << " " << ss;
+    for (int i = 0; i < 3; i++) g_dump << " " << p.nav.RotLie[i];
+    for (int i = 0; i < 3; i++) g_dump << " " << p.nav.RotGiro[i];
+    for (int i = 0; i < 3; i++) g_dump << " " << p.nav.g[i];
+    g_dump << " " << p.nav.scale << " " << p.K << " " << p.Kp << " " << p.RKp;
+    for (int i = 0; i < 3; i++) g_dump << " " << p.imustate.Vg[i];
+    for (int i = 0; i < 3; i++) g_dump << " " << p.imustate.Bg[i];
+    for (int i = 0; i < 7; i++) g_dump << " " << p.imustate.X[i];
+    for (int i = 0; i < 3; i++) g_dump << " " << p.imustate.b_est[i];
+    for (int i = 0; i < 3; i++) g_dump << " " << p.imustate.u_est[i];
+    g_dump << " " << p.dt << "\n";
     return true;
 }
 
 int main(int argn, char **argv) {
     if (argn < 6) {
-        std::cout << "usage: custom_cam_replay <GlobalConfig> <frames.rgb24> <n_frames> <t0> <dt> [dump.txt]\n";
+        std::cout << "usage: custom_cam_replay <GlobalConfig> <frames.rgb24> <n_frames> <t0> <dt> [dump.txt [imu.csv]]\n";
         return 2;
     }
     REBVO cf(argv[1]);
@@ -51,9 +64,27 @@ int main(int argn, char **argv) {
     std::ifstream in(argv[2], std::ios::binary);
     if (!in.is_open()) { std::cout << "cannot open " << argv[2] << "\n"; cf.CleanUp(); return 5; }
     std::vector<RGB24Pixel> frame((size_t)sz.w * sz.h);
+    std::vector<ImuData> imu_samples;
+    if (argn > 7) {
+        bool error = false;
+        imu_samples = ImuGrabber::LoadDataSet(argv[7], false, 1.0, error);
+        if (error) { cf.CleanUp(); return 5; }
+    }
+    size_t imu_next = 0;
+    const double imu_ahead = 2.5 * cf.getParams().SampleTime;   // the grabber needs a sample at or past the frame time
     for (int k = 0; k < n && cf.Running(); k++) {
         in.read(reinterpret_cast<char *>(frame.data()), fb);
         if ((size_t)in.gcount() != fb) break;
+        while (imu_next < imu_samples.size() && imu_samples[imu_next].tstamp <= t0 + dt * k + imu_ahead) {
+            try {
+                cf.pushIMU(imu_samples[imu_next]);
+            } catch (const std::overflow_error &e) {
+                std::cout << "pushIMU: " << e.what() << "\n";
+                cf.CleanUp();
+                return 7;
+            }
+            imu_next++;
+        }
         std::shared_ptr<Image<RGB24Pixel>> ptr;
         while (!cf.requestCustomCamBuffer(ptr, t0 + dt * k, 0.1))
             if (!cf.Running()) break;

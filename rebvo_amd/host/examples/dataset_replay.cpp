@@ -27,7 +27,18 @@ static bool callback(PipeBuffer &p) {
     for (int i = 0; i < 3; i++) g_dump << " " << p.nav.Pos[i];
     for (int i = 0; i < 3; i++) g_dump << " " << p.nav.PoseLie[i];
     for (int i = 0; i < 3; i++) g_dump << " " << p.nav.Vel[i];
-    g_dump << " " << sr << " " << ss << "\n";
+    g_dump << " " << sr << " " << ss;
+    // columns 16..: RotLie, RotGiro, g, scale, K, Kp, RKp, then the IMU-branch state (zero with ImuMode = 0)
+    for (int i = 0; i < 3; i++) g_dump << " " << p.nav.RotLie[i];
+    for (int i = 0; i < 3; i++) g_dump << " " << p.nav.RotGiro[i];
+    for (int i = 0; i < 3; i++) g_dump << " " << p.nav.g[i];
+    g_dump << " " << p.nav.scale << " " << p.K << " " << p.Kp << " " << p.RKp;
+    for (int i = 0; i < 3; i++) g_dump << " " << p.imustate.Vg[i];
+    for (int i = 0; i < 3; i++) g_dump << " " << p.imustate.Bg[i];
+    for (int i = 0; i < 7; i++) g_dump << " " << p.imustate.X[i];
+    for (int i = 0; i < 3; i++) g_dump << " " << p.imustate.b_est[i];
+    for (int i = 0; i < 3; i++) g_dump << " " << p.imustate.u_est[i];
+    g_dump << " " << p.dt << "\n";
     return true;
 }
 

@@ -38,9 +38,10 @@ def rel_err(a, b):
     return float(np.max(np.abs(a - b)) / (np.max(np.abs(b)) + 1e-300))
 
 
-def write_global_config(path, p, log_file="", tray_file="", save_log=0, camera_type=3, drop=(), dataset=None):
+def write_global_config(path, p, log_file="", tray_file="", save_log=0, camera_type=3, drop=(), dataset=None, imu=None):
     """A GlobalConfig file in the reference's format (app/rebvorun/GlobalConfig_EuRoC) from a Params struct.
-    `drop` lists "Section/Key" entries to leave out (missing-key error tests)."""
+    `drop` lists "Section/Key" entries to leave out (missing-key error tests).  `imu` = dict(mode=1|2, file=..., se3=...,
+    time_scale=..., plus any key of the &IMU section to override) switches the IMU branch on."""
     sec = {
         "Detector": [("Sigma0", p.sigma0), ("KSigma", p.ksigma), ("ReferencePoints", p.reference_points),
                      ("MaxPoints", p.max_points), ("TrackPoints", p.track_points), ("DetectorThresh", p.detector_thresh),
@@ -64,6 +65,18 @@ def write_global_config(path, p, log_file="", tray_file="", save_log=0, camera_t
                   ("TrayFile", tray_file), ("TrackKeyFrames", 0), ("StereoAvaiable", 0)],
         "IMU": [("ImuMode", 0)],
     }
+    if imu is not None:       # the &IMU section of app/rebvorun/GlobalConfig_EuRoC
+        keys = dict(TimeDesinc=0, InitBias=1, InitBiasFrameNum=10, BiasHintX=0.0188, BiasHintY=0.0037, BiasHintZ=0.0776,
+                    GiroMeasStdDev=1.6968e-04, GiroBiasStdDev=1.9393e-05, AcelMeasStdDev=2.0000e-3, g_module=9.8,
+                    g_module_uncer=0.2e3, g_uncert=2e-3, VBiasStdDev=1e-7, ScaleStdDevMult=1e-2, ScaleStdDevMax=1e-4,
+                    ScaleStdDevInit=1.2e-3, CircBufferSize=1000, SampleTime=0.00125)
+        keys.update({k: v for k, v in imu.items() if k not in ("mode", "file", "se3", "time_scale")})
+        sec["IMU"] = [("ImuMode", imu["mode"])]
+        if "file" in imu:
+            sec["IMU"] += [("ImuFile", imu["file"]), ("TimeScale", imu.get("time_scale", 1))]
+        if "se3" in imu:
+            sec["IMU"].append(("CamImuSE3File", imu["se3"]))
+        sec["IMU"] += list(keys.items())
     if dataset is not None:   # (DataSetDir, DataSetFile, TimeScale)
         sec["DataSetCamera"] = [("DataSetDir", dataset[0]), ("DataSetFile", dataset[1]), ("TimeScale", dataset[2])]
     with open(path, "w") as f:

@@ -4,7 +4,8 @@ process in which the oracle has not been called before.
 
     imu_ref_runner.py acel                      -> JSON {calls, max_abs_diff_lsq, max_abs_diff_mean, nonzero}
     imu_ref_runner.py sequence <in.npz> <out.npz>  -> reference IMU-branch sequence (ref_process_frame_imu) on the frames,
-                                                   time stamps and integrated IMU data of in.npz
+                                                   time stamps and integrated IMU data of in.npz (keys frames, t, imu,
+                                                   w, h, over / imu_over = JSON parameter overrides)
 """
 import ctypes as C
 import json
@@ -50,7 +51,10 @@ def run_acel():
 def run_sequence(inp, outp):
     from oracle import oracle
     d = np.load(inp)
-    res = oracle.run_imu_sequence(d["frames"], d["t"], d["imu"], json.loads(str(d["params"])), json.loads(str(d["imu_params"])))
+    w, h = int(d["w"]), int(d["h"])
+    params = oracle.euroc_params(w, h, **json.loads(str(d["over"])))
+    imu_params = oracle.euroc_imu_params(**json.loads(str(d["imu_over"])))
+    res = oracle.run_imu_sequence(d["frames"], d["t"], d["imu"], params, imu_params)
     np.savez(outp, **res)
 
 

@@ -55,3 +55,28 @@ def test_init_fails_loudly_without_gpu(exe, tmp_path):
     write_global_config(cfg, edgehip.euroc_params(376, 240))
     r = _run(cfg, "/dev/null", 0, 1.0, 0.05)
     assert r.returncode == 4 and "edgehip_create failed" in r.stdout
+
+
+def test_imu_config_errors(exe, tmp_path):
+    """ImuMode > 0 makes the &IMU keys mandatory and builds the ImuGrabber in the constructor
+    (src/rebvo/rebvo.cpp:159-183, 248-281): a missing key, an unreadable IMU file or an unreadable Cam-IMU file all
+    leave isInitOk() false."""
+    cfg = tmp_path / "cfg"
+    p = edgehip.euroc_params(376, 240)
+    imu_csv = tmp_path / "imu.csv"
+    imu_csv.write_text("#t,gx,gy,gz,ax,ay,az\n1.0,0,0,0,0,9.8,0\n1.01,0,0,0,0,9.8,0\n")
+    write_global_config(cfg, p, imu=dict(mode=2, file=str(imu_csv), time_scale=1), drop=("IMU/g_module",))
+    r = _run(cfg, "/dev/null", 0, 1.0, 0.05)
+    assert r.returncode == 3 and "g_module" in r.stdout
+    write_global_config(cfg, p, imu=dict(mode=2, file=str(tmp_path / "missing.csv"), time_scale=1))
+    r = _run(cfg, "/dev/null", 0, 1.0, 0.05)
+    assert r.returncode == 3 and "Failed to open file" in r.stdout
+    write_global_config(cfg, p, imu=dict(mode=2, file=str(imu_csv), time_scale=1, se3=str(tmp_path / "missing_se3.csv")))
+    r = _run(cfg, "/dev/null", 0, 1.0, 0.05)
+    assert r.returncode == 3 and "cam-imu" in r.stdout
+    write_global_config(cfg, p, imu=dict(mode=1), drop=("IMU/SampleTime",))
+    assert _run(cfg, "/dev/null", 0, 1.0, 0.05).returncode == 3
+    # a complete IMU configuration gets as far as the device (and fails loudly there when there is no GPU)
+    write_global_config(cfg, p, imu=dict(mode=2, file=str(imu_csv), time_scale=1))
+    r = _run(cfg, "/dev/null", 0, 1.0, 0.05)
+    assert "Loaded 2 datums" in r.stdout and r.returncode in (0, 4)

@@ -1,0 +1,189 @@
+"""GPU: the IMU branch end to end.  An EuRoC-layout data set with a synthetic IMU csv
+(ImuMode=2) goes through the host library: DataSetCam + ImuGrabber, gyro pre-rotation, Minimizer_V / ExtRotVel and
+the mapper on the GPU, BiasCorrect and the scale filter on the host.  The oracle runs the reference's own classes in
+the ImuMode > 0 order of rebvo_second_t.cpp (ref_process_frame_imu) on the same frames and the same integrated IMU
+data, in a fresh process (its acceleration histories are process-wide statics).
+
+Tolerance: the GPU sums fp64 in tree order and solves the 6x6 / 7x7 systems by Jacobi instead of LAPACK -> 1e-6
+relative on velocities / rotations, 1e-5 on the filter state."""
+import ctypes as C
+import json
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+from rebvo_amd import edgehip, synth
+from tests.helpers import write_global_config
+
+pytestmark = pytest.mark.gpu
+PIL = pytest.importorskip("PIL.Image")
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+EXE = os.path.join(ROOT, "rebvo_amd", "lib", "dataset_replay")
+
+W, H, N = 376, 240, 22
+DT_NS = 50_000_000
+T0_NS = 1403636579763555584
+IMU_NS = 5_000_000
+INIT_BIAS_FRAMES = 3
+
+
+def _so3(w):
+    th = np.linalg.norm(w)
+    if th < 1e-12:
+        return np.eye(3)
+    K = np.array([[0, -w[2], w[1]], [w[2], 0, -w[0]], [-w[1], w[0], 0]])
+    return np.eye(3) + np.sin(th) / th * K + (1 - np.cos(th)) / th ** 2 * K @ K
+
+
+def _write_dataset(tmp_path):
+    seq = list(synth.billboard_sequence(W, H, N))
+    frames = [f for f, _, _ in seq]
+    tw = synth.smooth_trajectory(N, 13)
+    cam0 = tmp_path / "mav0" / "cam0"
+    (cam0 / "data").mkdir(parents=True)
+    t_ns = [T0_NS + DT_NS * k for k in range(N)]
+    with open(cam0 / "data.csv", "w") as f:
+        f.write("#timestamp [ns],filename\n")
+        for k, fr in enumerate(frames):
+            PIL.fromarray(fr[:, :, 0], "L").save(cam0 / "data" / f"{t_ns[k]}.png")
+            f.write(f"{t_ns[k]},{t_ns[k]}.png\n")
+    # IMU: the camera turns by exp(tw_rot[k]) (points) between frames k and k+1, i.e. the body rate is -tw_rot/dt; a
+    # constant gyro bias and a little noise on top; the accelerometer sees gravity in the camera frame.
+    rng = np.random.default_rng(21)
+    bias = np.array([0.004, -0.002, 0.003])
+    imu_csv = tmp_path / "imu.csv"
+    with open(imu_csv, "w") as f:
+        f.write("#timestamp [ns],w_RS_S_x,w_y,w_z,a_x,a_y,a_z\n")
+        ts = T0_NS - 12 * IMU_NS
+        while ts < t_ns[-1] + 20 * IMU_NS:
+            k = min(max((ts - T0_NS) // DT_NS, 0), N - 1)
+            gyro = -tw[int(k), 3:] / (DT_NS * 1e-9) + bias + rng.normal(size=3) * 1e-4
+            g_cam = seq[int(k)][1] @ np.array([0.0, 9.8, 0.0])
+            acc = -g_cam + rng.normal(size=3) * 2e-3
+            f.write("%d,%.17g,%.17g,%.17g,%.17g,%.17g,%.17g\n" % (ts, *gyro, *acc))
+            ts += IMU_NS
+    se3 = tmp_path / "se3.csv"
+    Rci, Tci = _so3(np.array([0.01, -0.02, 0.015])), np.array([0.02, -0.01, 0.005])
+    with open(se3, "w") as f:
+        for i in range(3):
+            f.write(",".join("%.17g" % v for v in Rci[i]) + ",%.17g,\n" % Tci[i])
+    return frames, t_ns, cam0, imu_csv, se3
+
+
+def test_imu_mode2_replay_matches_reference(tmp_path):
+    from oracle import oracle
+    if not oracle.available("ref") or not os.path.exists(EXE):
+        pytest.skip("needs oracle/_ref and dataset_replay")
+    frames, t_ns, cam0, imu_csv, se3 = _write_dataset(tmp_path)
+    cfg, dump = tmp_path / "cfg", tmp_path / "dump.txt"
+    p = edgehip.euroc_params(W, H)
+    write_global_config(cfg, p, log_file=str(tmp_path / "log.m"), tray_file=str(tmp_path / "tray.txt"), save_log=1, camera_type=2,
+                        dataset=(str(cam0 / "data") + "/", str(cam0 / "data.csv"), 1e-9),
+                        imu=dict(mode=2, file=str(imu_csv), se3=str(se3), time_scale=1e-9, InitBiasFrameNum=INIT_BIAS_FRAMES))
+    r = subprocess.run([EXE, str(cfg), str(dump)], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
+    rows = np.loadtxt(dump, ndmin=2)
+    assert len(rows) == N - 1, r.stdout[-2000:]
+
+    # the integrated IMU data of every frame, from the REFERENCE's grabber (no process-wide state there)
+    ref = C.CDLL(os.path.join(ROOT, "oracle", "_ref", "libreforacle.so"), mode=C.RTLD_GLOBAL)
+    ref.ref_imu_grabber_load.restype = C.c_void_p
+    g = C.c_void_p(ref.ref_imu_grabber_load(str(imu_csv).encode(), C.c_double(1e-9)))
+    assert g.value and ref.ref_imu_grabber_load_se3(g, str(se3).encode()) == 1
+    t = [float(np.float64(v) * 1e-9) for v in t_ns]
+    imu_rows, t_prev = [], 0.0
+    for k in range(N):
+        d = oracle.ImuIntegrated()
+        ref.ref_imu_grabber_grab(g, C.c_double(t_prev), C.c_double(t[k]), C.byref(d))
+        assert d.n > 0
+        imu_rows.append(d.as_row())
+        t_prev = t[k]
+    o = _run_reference(tmp_path, frames, t, imu_rows, {"init_bias_frame_num": INIT_BIAS_FRAMES})
+    _compare(rows, o)
+
+
+def _compare(rows, o):
+    def close(a, b, rtol, atol):
+        return np.allclose(a, b, rtol=rtol, atol=atol)
+
+    filter_frames = 0
+    for k in range(1, N - 1):                     # row k = frame k, delivered after frame k+1 was tracked
+        row = rows[k]
+        assert int(row[0]) == k
+        assert int(row[2]) == int(o["klprev_n"][k + 1])                      # KeyLine count of frame k's edge map
+        assert int(row[4]) == int(o["estimation_ok"][k]) and int(row[3]) == int(o["klm_num"][k]), k
+        assert abs(row[48] - o["dt"][k]) < 1e-12
+        assert close(row[11:14], o["Vel"][k], 1e-6, 1e-7), (k, row[11:14], o["Vel"][k])
+        assert close(row[16:19], o["RotLie"][k], 1e-6, 1e-8), (k, row[16:19], o["RotLie"][k])
+        assert close(row[19:22], o["RotGiro"][k], 1e-6, 1e-7)
+        assert close(row[29:32], o["Vg"][k], 1e-6, 1e-9) and close(row[32:35], o["Bg"][k], 1e-6, 1e-10)
+        assert close(row[5:8], o["Pos"][k], 1e-5, 1e-7) and close(row[8:11], o["PoseLie"][k], 1e-5, 1e-7)
+        assert close(row[25:29], [o["scale"][k], o["K"][k], o["Kp"][k], o["RKp"][k]], 1e-5, 1e-12)
+        assert close(row[35:42], o["X"][k], 1e-5, 1e-8) and close(row[22:25], o["g"][k], 1e-5, 1e-7)
+        assert close(row[45:48], o["u_est"][k], 1e-5, 1e-8)
+        sr = o["klprev_rho_sum"][k + 1]
+        assert abs(row[14] - sr) <= 1e-6 * abs(sr) + 1e-9
+        filter_frames += int(o["scale"][k] != 1.0)
+    assert int(o["estimation_ok"][1:N - 1].sum()) >= N - 6     # the sequence actually tracks
+    assert int(o["init"][N - 2]) == 1 and filter_frames >= 5   # bias start-up finished, scale filter ran
+    assert np.abs(o["Pos"][N - 2]).max() > 0                   # and the IMU pose integration moved
+
+
+def _run_reference(tmp_path, frames, t, imu_rows, imu_over):
+    inp, outp = tmp_path / "in.npz", tmp_path / "out.npz"
+    np.savez(inp, frames=np.stack(frames), t=np.array(t), imu=np.stack(imu_rows), w=W, h=H, over=json.dumps({}),
+             imu_over=json.dumps(imu_over))
+    rr = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "imu_ref_runner.py"), "sequence", str(inp), str(outp)],
+                        capture_output=True, text=True, timeout=600, cwd=ROOT)
+    assert rr.returncode == 0, rr.stdout[-2000:] + rr.stderr[-2000:]
+    return np.load(outp)
+
+
+def test_imu_mode1_pushimu_matches_reference(tmp_path):
+    """ImuMode=1: the application pushes samples (REBVO::pushIMU) while it feeds frames through the custom-camera ring;
+    a 96-slot sample ring wraps several times over the run."""
+    from oracle import oracle
+    exe = os.path.join(ROOT, "rebvo_amd", "lib", "custom_cam_replay")
+    if not oracle.available("ref") or not os.path.exists(exe):
+        pytest.skip("needs oracle/_ref and custom_cam_replay")
+    frames, t_ns, cam0, imu_csv_ns, se3 = _write_dataset(tmp_path)
+    t0, dt = 10.0, 0.05
+    t = [t0 + dt * k for k in range(N)]
+    # the same samples, re-stamped in seconds relative to the custom camera's clock
+    raw = np.loadtxt(imu_csv_ns, delimiter=",", comments="#")
+    raw[:, 0] = t0 + (raw[:, 0] - T0_NS) * 1e-9
+    imu_csv = tmp_path / "imu_s.csv"
+    with open(imu_csv, "w") as f:
+        for r in raw:
+            f.write(",".join("%.17g" % v for v in r) + "\n")
+    raw = np.loadtxt(imu_csv, delimiter=",")            # what both sides parse
+    np.stack(frames).tofile(tmp_path / "frames.rgb24")
+    cfg, dump = tmp_path / "cfg", tmp_path / "dump.txt"
+    write_global_config(cfg, edgehip.euroc_params(W, H), camera_type=3,
+                        imu=dict(mode=1, se3=str(se3), InitBiasFrameNum=INIT_BIAS_FRAMES, SampleTime=0.005, CircBufferSize=96))
+    r = subprocess.run([exe, str(cfg), str(tmp_path / "frames.rgb24"), str(N), repr(t0), repr(dt), str(dump), str(imu_csv)],
+                       capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
+    rows = np.loadtxt(dump, ndmin=2)
+    assert len(rows) == N - 1, r.stdout[-2000:]
+    # reference grabber fed the same way (a big ring: what is compared is the integration, not the ring size)
+    ref = C.CDLL(os.path.join(ROOT, "oracle", "_ref", "libreforacle.so"), mode=C.RTLD_GLOBAL)
+    ref.ref_imu_grabber_new.restype = C.c_void_p
+    g = C.c_void_p(ref.ref_imu_grabber_new(4096, C.c_double(0.005)))
+    assert ref.ref_imu_grabber_load_se3(g, str(se3).encode()) == 1
+    for rw in raw:
+        gy, ac = np.ascontiguousarray(rw[1:4]), np.ascontiguousarray(rw[4:7])
+        assert ref.ref_imu_grabber_push(g, C.c_double(rw[0]), gy.ctypes.data_as(C.POINTER(C.c_double)),
+                                        ac.ctypes.data_as(C.POINTER(C.c_double))) == 1
+    imu_rows, t_prev = [], 0.0
+    for k in range(N):
+        d = oracle.ImuIntegrated()
+        ref.ref_imu_grabber_grab(g, C.c_double(t_prev), C.c_double(t[k]), C.byref(d))
+        assert d.n > 0
+        imu_rows.append(d.as_row())
+        t_prev = t[k]
+    o = _run_reference(tmp_path, frames, t, imu_rows, {"init_bias_frame_num": INIT_BIAS_FRAMES})
+    _compare(rows, o)
