@@ -623,6 +623,13 @@ __global__ __launch_bounds__(kDetWaves * 64) void k_detect(DetectArgs a) {
             if (!hasL[f]) cx[f] = x + dh[f] + 1;
             if (xr[f] > w - 1) { xr[f] = w - 1; cx[f] = w - x + dh[f]; }
         }
+        // bands whose rows all have the full box height (all but the first and last of an image) take the short form of
+        // the average: no clipped taps, no bottom-row operand order, div(x,y) = the column's table entry read once
+        const int dhm = dh[0] > dh[1] ? dh[0] : dh[1];
+        const bool interior = yb0 - dhm - 1 >= 0 && yb0 + HR - 1 + dhm <= h - 1;   // block-uniform
+        float lut_in[2];
+#pragma unroll
+        for (int f = 0; f < 2; f++) lut_in[f] = s_lut[cx[f] * dd[f]];
 #pragma nounroll
         for (int r0 = 0; r0 < HR; r0 += 4) {
             float tp[4][2][4];
@@ -646,6 +653,24 @@ __global__ __launch_bounds__(kDetWaves * 64) void k_detect(DetectArgs a) {
             for (int i = 0; i < 4; i++) {
                 const int r = r0 + i, y = yb0 + r;
                 float g[2];
+                if (interior) {
+#pragma unroll
+                    for (int f = 0; f < 2; f++) {
+                        const float Bv = hasL[f] ? tp[i][f][1] : 0.f, D = hasL[f] ? tp[i][f][3] : 0.f;
+                        g[f] = (((tp[i][f][0] - Bv) - tp[i][f][2]) + D) * lut_in[f];   // iimage.cpp:119-126
+                    }
+                    s_img0[r * w + x] = g[0];
+                    s_dog[r * w + x] = g[1] - g[0];                                    // sspace.cpp:66
+                    if (a.planes && ((y >= y0 && y < y0 + kBandRows) || (band == 0 && y < 2) ||
+                                     (y >= 2 + (int)gridDim.x * kBandRows))) {
+                        float *pl = a.planes + so;
+                        const size_t pstride = (size_t)a.nseq * a.n;
+                        pl[0 * pstride + (size_t)y * w + x] = g[0];
+                        pl[1 * pstride + (size_t)y * w + x] = g[1];
+                        pl[2 * pstride + (size_t)y * w + x] = g[1] - g[0];
+                    }
+                    continue;
+                }
 #pragma unroll
                 for (int f = 0; f < 2; f++) {
                     const int yc = y < h ? y : h - 1;
