@@ -146,7 +146,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=40)
     ap.add_argument("--warmup", type=int, default=24)
-    ap.add_argument("--nseq", type=int, default=512, help="independent sequences per GPU (all contexts together)")
+    ap.add_argument("--nseq", type=int, default=1024, help="independent sequences per GPU (all contexts together)")
     ap.add_argument("--contexts", type=int, default=1,
                     help="edgehip contexts (= HIP streams) the sequences are split over: kernels of different contexts "
                          "run concurrently, which hides the serial LM-step kernels and launch tails of one context "
