@@ -66,7 +66,11 @@ typedef struct edgehip_params {
      * 66-79, 105-122; map as built by src/VideoLib/image_undistort.cpp:29-95), fused into the first
      * stage-A kernel: the bilinear map (4 taps, 16.16 integer weights) is built once at create time. */
     int32_t use_undistort;
-    int32_t reserved0;
+    /* REBVO/StereoAvaiable: allocate the stereo KeyLine fields (stereo_m_id, stereo_rho, stereo_s_rho), and run
+     * directed_matching in its stereo mode (the match copies rho0/s_rho0 instead of rho/s_rho and leaves rho_nr alone,
+     * edge_tracker.cpp:343-351).  The pair image's edge map lives in a ring slot of its own (see
+     * edgehip_directed_matching_stereo). */
+    int32_t stereo_available;
 } edgehip_params;
 
 /* Byte-for-byte the reference's rebvo::KeyLine (include/mtracklib/edge_finder.h:45-91), 168 B. */
@@ -200,6 +204,24 @@ int edgehip_ext_rot_vel(edgehip_ctx *ctx, int slot, const double *vel, double lo
                         double *Wx, double *Rx, int32_t *ok);
 /* EstimateReScalingOpt (rebvo_second_t.cpp:487; edge_tracker.cpp:1104-1140) -> seq_state.Kp, P_Kp. */
 int edgehip_rescale(edgehip_ctx *ctx, int slot);
+
+/* ---- stereo depth (REBVO/StereoAvaiable, experimental upstream) ------------- */
+/* Intrinsics of the camera whose frames go into `slot` when they differ from the context's (the pair camera of a
+ * stereo rig, cam_stereo of rebvo.cpp:202-216): stage A of that slot forms p_m with this principal point, and the
+ * stereo search projects with this focal length.  zfm is taken as (float)((zfx + zfy) / 2), like cam_model. */
+int edgehip_set_slot_camera(edgehip_ctx *ctx, int slot, double ppx, double ppy, double zfx, double zfy);
+/* edge_tracker::directed_matching_stereo (rebvo_second_t.cpp:471; edge_tracker.cpp:580-618 with search_match_stereo
+ * :453-571 and getDepthFromStereo :622-668): every KeyLine of `slot` walks, in the pair slot's edge mask, the segment
+ * its depth interval [rho - s_rho, rho + s_rho] projects to through p1 = R p0 + t, keeps a match only when it is
+ * unique (or all candidates lie within loc_unc of each other) and triangulates stereo_rho / stereo_s_rho from it.
+ * t[3], R[9] are shared by all sequences; nmatch[nseq] (may be NULL) returns the function's result per sequence.
+ * q_abs / q_rel are accepted and unused, as in the reference.  Needs params.stereo_available.  Synchronises. */
+int edgehip_directed_matching_stereo(edgehip_ctx *ctx, int slot, int slot_pair, const double *t, const double *R,
+                                     double min_thr_mod, double min_thr_ang, double max_radius, double loc_unc,
+                                     double q_abs, double q_rel, double loc_unc_model, int32_t *nmatch);
+/* edge_tracker::fuseStereoDepth (rebvo_second_t.cpp:484; edge_tracker.cpp:670-688): rho0/s_rho0 = rho/s_rho, then the
+ * information-weighted mean with the stereo depth where a stereo match exists. */
+int edgehip_fuse_stereo_depth(edgehip_ctx *ctx, int slot);
 
 /* ---- whole frame ------------------------------------------------------------------------------------ */
 /* Everything FirstThr + SecondThread (ImuMode==0) do for one new frame of every sequence, on the

@@ -350,6 +350,30 @@ class Oracle:
     def cur_slot(self):
         return self._cur_slot(self.ctx)
 
+    # ---- stereo (reference oracle only) ---------------------------------------------------------------
+    def set_slot_cam(self, slot, ppx, ppy, zfx, zfy):
+        f = self.lib.ref_set_slot_cam
+        f.restype, f.argtypes = None, [C.c_void_p, C.c_int] + [C.c_double] * 4
+        f(self.ctx, slot, ppx, ppy, zfx, zfy)
+
+    def set_stereo_mode(self, on):
+        f = self.lib.ref_set_stereo_mode
+        f.restype, f.argtypes = None, [C.c_void_p, C.c_int]
+        f(self.ctx, int(on))
+
+    def directed_matching_stereo(self, slot, slot_pair, t, R, min_thr_mod, min_thr_ang, max_radius, loc_unc, q_abs, q_rel, loc_unc_model):
+        f = self.lib.ref_directed_matching_stereo
+        pd = C.POINTER(C.c_double)
+        f.restype, f.argtypes = C.c_int, [C.c_void_p, C.c_int, C.c_int, pd, pd] + [C.c_double] * 7
+        t = np.ascontiguousarray(t, np.float64).reshape(3)
+        R = np.ascontiguousarray(R, np.float64).reshape(9)
+        return f(self.ctx, slot, slot_pair, _dp(t), _dp(R), min_thr_mod, min_thr_ang, max_radius, loc_unc, q_abs, q_rel, loc_unc_model)
+
+    def fuse_stereo_depth(self, slot):
+        f = self.lib.ref_fuse_stereo_depth
+        f.restype, f.argtypes = None, [C.c_void_p, C.c_int]
+        f(self.ctx, slot)
+
     def depth_reset(self):
         """REBVO::Reset() semantics (rebvo_second_t.cpp:609-620) applied after the last processed frame."""
         self._depth_reset(self.ctx)

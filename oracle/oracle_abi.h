@@ -130,6 +130,14 @@ typedef struct OrcNav {
 ORC_DECLARE(ref)
 ORC_DECLARE(port)
 
+/* ---- stereo depth (REBVO/StereoAvaiable): reference only ---- */
+void ref_set_slot_cam(void *ctx, int slot, double ppx, double ppy, double zfx, double zfy);   /* pair camera intrinsics */
+void ref_set_stereo_mode(void *ctx, int on);   /* the stereo_mode argument ref_directed_matching passes on */
+int ref_directed_matching_stereo(void *ctx, int slot, int slot_pair, const double t[3], const double R[9], double min_thr_mod,
+                                 double min_thr_ang, double max_radius, double loc_unc, double q_abs, double q_rel,
+                                 double loc_unc_model);
+void ref_fuse_stereo_depth(void *ctx, int slot);
+
 /* ---- IMU branch: reference only.  The restatement under test is the host library
  * (rebvo_amd/host/src/imu.cpp, rebvo_imu.cpp); these entry points run the reference's own ImuGrabber, BiasCorrect and
  * ScaleEstimator, and ref_process_frame_imu restates the ImuMode > 0 sequencing of rebvo_second_t.cpp over them.

@@ -101,6 +101,7 @@ struct Ctx {
     int n_frame, n_giro_init;
     Vector<3> giro_init, g_init;
     Matrix<3, 3> Rgva;
+    bool stereo_mode;                 // REBVO/StereoAvaiable as directed_matching sees it
 };
 
 void reset_seq(Ctx *c) {
@@ -161,6 +162,7 @@ void *ref_create(const OrcParams *p, int nslots) {
     }
     c->undist = nullptr;
     c->img_dist = nullptr;
+    c->stereo_mode = false;
     if (p->use_undistort) {
         c->undist = new image_undistort(c->cam);
         c->img_dist = new Image<RGB24Pixel>(c->cam.sz);
@@ -380,8 +382,37 @@ int ref_directed_matching(void *ctx, int slot_new, int slot_old, const double V[
                           double max_radius, double loc_unc) {
     Ctx *c = (Ctx *)ctx;
     return c->slots[slot_new].ef->directed_matching(v3(V), m3(RVel), m3(BackRot), c->slots[slot_old].ef, *kf_matchs,
-                                                    min_thr_mod, min_thr_ang, max_radius, loc_unc, false);
+                                                    min_thr_mod, min_thr_ang, max_radius, loc_unc, c->stereo_mode);
 }
+// ---- stereo (REBVO/StereoAvaiable; reference only) ----
+// the pair camera's own cam_model: re-creates the slot's objects the way rebvo.cpp:303-311 builds ss_pair / ef_pair
+void ref_set_slot_cam(void *ctx, int slot, double ppx, double ppy, double zfx, double zfy) {
+    Ctx *c = (Ctx *)ctx;
+    Slot &s = c->slots[slot];
+    const OrcParams &p = c->p;
+    cam_model::rad_tan_distortion kc = {p.kc[0], p.kc[1], p.kc[2], p.kc[3], p.kc[4]};
+    Size2D sz = {(u_int)p.w, (u_int)p.h};
+    cam_model cam({(float)ppx, (float)ppy}, {(float)zfx, (float)zfy}, kc, sz);
+    delete s.gt; delete s.ef; delete s.ss;
+    s.ss = new sspace(p.sigma0, p.ksigma, cam.sz, 3);
+    s.ef = new edge_tracker(cam, 255 * 3);
+    s.gt = new global_tracker(s.ef->GetCam());
+    memset(s.ss->ImgDx().Data(), 0, sizeof(float) * p.w * p.h);
+    memset(s.ss->ImgDy().Data(), 0, sizeof(float) * p.w * p.h);
+    memset(s.gt->field.Data(), 0, sizeof(gt_field_data) * p.w * p.h);
+}
+void ref_set_stereo_mode(void *ctx, int on) { ((Ctx *)ctx)->stereo_mode = on != 0; }
+int ref_directed_matching_stereo(void *ctx, int slot, int slot_pair, const double t[3], const double R[9], double min_thr_mod,
+                                 double min_thr_ang, double max_radius, double loc_unc, double q_abs, double q_rel,
+                                 double loc_unc_model) {
+    Ctx *c = (Ctx *)ctx;
+    Vector<3> tv = v3(t);
+    Matrix<3, 3> Rm = m3(R);
+    return c->slots[slot].ef->directed_matching_stereo(tv, Rm, c->slots[slot_pair].ef, min_thr_mod, min_thr_ang, max_radius, loc_unc,
+                                                       q_abs, q_rel, loc_unc_model);
+}
+void ref_fuse_stereo_depth(void *ctx, int slot) { ((Ctx *)ctx)->slots[slot].ef->fuseStereoDepth(); }
+
 int ref_regularize(void *ctx, int slot, double thresh) {
     return ((Ctx *)ctx)->slots[slot].ef->Regularize_1_iter(thresh);
 }

@@ -374,6 +374,8 @@ int edgehip_create(const edgehip_params *params, int nseq, int nslots, int devic
     EH_TRY(dmalloc(c, &c->t_buf, B, al->dev, 0));
     EH_TRY(dmalloc(c, &c->nav_dev, B, al->dev, 0));
     EH_TRY(dmalloc(c, &c->idx_dev, B, al->dev, 0));
+    c->stereo_cnt = nullptr;
+    if (p.stereo_available) EH_TRY(dmalloc(c, &c->stereo_cnt, B, al->dev, 0));
     c->nav_log = nullptr;
     c->nav_log_len = 0;
 
@@ -381,8 +383,10 @@ int edgehip_create(const edgehip_params *params, int nseq, int nslots, int devic
     {
         const size_t al256 = 256;
         auto up = [&](size_t x) { return (x + al256 - 1) / al256 * al256; };
+        const bool stereo = p.stereo_available != 0;
         const size_t per = up(CAP * 4) * 8 /* p_inx, n_m, m_id, m_id_f, m_id_kf, m_num, p_id, n_id */ +
-                           up(CAP * 8) * 6 /* float2 */ + up(CAP * 8) * 7 /* double */ + up(CAP * 32);
+                           up(CAP * 8) * 6 /* float2 */ + up(CAP * 8) * 7 /* double */ + up(CAP * 32) +
+                           (stereo ? up(CAP * 4) + 2 * up(CAP * 8) : 0);
         char *arena;
         EH_TRY(dmalloc(c, &arena, per * S * B, al->dev, 0));
         c->kl_arena = arena;
@@ -401,7 +405,13 @@ int edgehip_create(const edgehip_params *params, int nseq, int nslots, int devic
             k.m_id = (int32_t *)take(CAP * 4); k.m_id_f = (int32_t *)take(CAP * 4); k.m_id_kf = (int32_t *)take(CAP * 4);
             k.m_num = (int32_t *)take(CAP * 4); k.p_id = (int32_t *)take(CAP * 4); k.n_id = (int32_t *)take(CAP * 4);
             k.rec = (MatchRec *)take(CAP * 32);
+            k.stereo_m_id = nullptr; k.stereo_rho = nullptr; k.stereo_s_rho = nullptr;
+            if (stereo) {
+                k.stereo_m_id = (int32_t *)take(CAP * 4);
+                k.stereo_rho = (double *)take(CAP * 8); k.stereo_s_rho = (double *)take(CAP * 8);
+            }
         }
+        c->slot_cam.assign(S, edgehip_ctx::SlotCam{pl.ppx, pl.ppy, pl.zfm});
         EH_TRY(dmalloc(c, &c->kl_dev, S * B, al->dev));
         EH_CHECK(hipMemcpyAsync(c->kl_dev, c->kl.data(), sizeof(KlSoA) * S * B, hipMemcpyHostToDevice, c->stream));
     }
@@ -664,6 +674,9 @@ int edgehip_download_keylines(edgehip_ctx *c, int seq, int slot, edgehip_keyline
     e |= d2h(c, rho, k.rho, kn); e |= d2h(c, s_rho, k.s_rho, kn); e |= d2h(c, rho_nr, k.rho_nr, kn);
     e |= d2h(c, s_rho_nr, k.s_rho_nr, kn); e |= d2h(c, rho0, k.rho0, kn); e |= d2h(c, s_rho0, k.s_rho0, kn);
     e |= d2h(c, n_m0, k.n_m0, kn);
+    std::vector<int32_t> st_id;
+    std::vector<double> st_rho, st_srho;
+    if (k.stereo_m_id) { e |= d2h(c, st_id, k.stereo_m_id, kn); e |= d2h(c, st_rho, k.stereo_rho, kn); e |= d2h(c, st_srho, k.stereo_s_rho, kn); }
     if (e) return EDGEHIP_ERR_DEVICE;
     if (mask) EH_CHECK(hipMemcpyAsync(mask, maskof(c, slot) + (size_t)seq * c->plan.n, sizeof(int32_t) * c->plan.n, hipMemcpyDeviceToHost, c->stream));
     EH_CHECK(hipStreamSynchronize(c->stream));
@@ -681,6 +694,7 @@ int edgehip_download_keylines(edgehip_ctx *c, int seq, int slot, edgehip_keyline
         o.m_m0[0] = m_m0[i].x; o.m_m0[1] = m_m0[i].y; o.n_m0 = n_m0[i];
         o.p_id = p_id[i]; o.n_id = n_id[i];
         o.net_id = -1; o.stereo_m_id = -1; o.stereo_rho = 1.0; o.stereo_s_rho = 20.0;  // edge_finder.cpp:183-194
+        if (k.stereo_m_id) { o.stereo_m_id = st_id[i]; o.stereo_rho = st_rho[i]; o.stereo_s_rho = st_srho[i]; }
     }
     *kn_out = kn;
     return 0;
@@ -717,6 +731,12 @@ int edgehip_upload_keylines(edgehip_ctx *c, int seq, int slot, const edgehip_key
     e |= h2d(c, k.p_m_0, p_m_0); e |= h2d(c, k.m_m0, m_m0); e |= h2d(c, k.n_m, n_m);
     e |= h2d(c, k.rho, rho); e |= h2d(c, k.s_rho, s_rho); e |= h2d(c, k.rho_nr, rho_nr); e |= h2d(c, k.s_rho_nr, s_rho_nr);
     e |= h2d(c, k.rho0, rho0); e |= h2d(c, k.s_rho0, s_rho0); e |= h2d(c, k.n_m0, n_m0); e |= h2d(c, k.rec, rec);
+    if (k.stereo_m_id) {
+        std::vector<int32_t> st_id(kn);
+        std::vector<double> st_rho(kn), st_srho(kn);
+        for (int i = 0; i < kn; i++) { st_id[i] = kl[i].stereo_m_id; st_rho[i] = kl[i].stereo_rho; st_srho[i] = kl[i].stereo_s_rho; }
+        e |= h2d(c, k.stereo_m_id, st_id); e |= h2d(c, k.stereo_rho, st_rho); e |= h2d(c, k.stereo_s_rho, st_srho);
+    }
     if (e) return EDGEHIP_ERR_DEVICE;
     EH_CHECK(hipMemcpyAsync(c->kn_slot + (size_t)slot * c->plan.nseq + seq, &kn, 4, hipMemcpyHostToDevice, c->stream));
     if (mask) EH_CHECK(hipMemcpyAsync(maskof(c, slot) + (size_t)seq * c->plan.n, mask, sizeof(int32_t) * c->plan.n, hipMemcpyHostToDevice, c->stream));

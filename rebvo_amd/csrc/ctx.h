@@ -46,6 +46,9 @@ struct KlSoA {
     double *rho, *s_rho, *rho_nr, *s_rho_nr, *rho0, *s_rho0, *n_m0;
     int32_t *m_id, *m_id_f, *m_id_kf, *m_num, *p_id, *n_id;
     MatchRec *rec;  // (c_p, u_m, m_m, n_m) packed for gathers; kept in sync with the fields above
+    // stereo fields (null unless params.stereo_available)
+    int32_t *stereo_m_id;
+    double *stereo_rho, *stereo_s_rho;
 };
 
 // Device-side per-sequence state (superset of edgehip_seq_state).
@@ -172,6 +175,8 @@ struct edgehip_ctx {
     double *resid_carry;   // [kResidBufs][B][nblk_tvr] last valid residual per block
     double *partials;      // [B][nblk_tvr][kNumSums]
     double *block_last;    // [B][nblk_tvr] last valid residual of each block of the running evaluation
+    struct SlotCam { float ppx, ppy; double zfm; };
+    std::vector<SlotCam> slot_cam;   // per ring slot: principal point stage A uses, focal length of that camera (stereo pair slot)
     int field_radius;      // radius of the last build_field (global_tracker::max_r)
     int field_mode;        // 0 = binned tiles (default), 1 = global-atomic scatter, 2 = mask-scan tiles (A/B)
     int level_mode;        // stage A box levels: 0 = auto (one-pass k_level when >= 192 planes in flight), 1 = multi-pass, 2 = k_level
@@ -187,6 +192,7 @@ struct edgehip_ctx {
     edgehip_nav *nav_log;  // [nav_log_len][B] ring of per-frame records (optional)
     int nav_log_len;
     int32_t *idx_dev;      // [B] frame-pool indices of upload_rgb_indexed
+    int32_t *stereo_cnt;   // [B] stereo match counters (params.stereo_available)
     // host staging
     uint8_t *pinned_rgb;   // [B][N*3]
     size_t pinned_rgb_bytes;

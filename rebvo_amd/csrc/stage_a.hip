@@ -947,6 +947,7 @@ __global__ __launch_bounds__(256) void k_emit(EmitArgs a) {
         k.n_id[i] = -1;
         k.p_id[i] = -1;
         k.m_id[i] = -1;
+        if (k.stereo_m_id) { k.stereo_m_id[i] = -1; k.stereo_rho[i] = 1.0; k.stereo_s_rho[i] = 20.0; }   // edge_finder.cpp:192-194
         k.m_id_f[i] = -1;
         k.m_id_kf[i] = -1;
         k.m_m0[i] = make_float2(0.f, 0.f);
@@ -1266,7 +1267,7 @@ int stage_a_enqueue(edgehip_ctx *c, int slot) {
         EmitArgs e;
         e.st = cs; e.strip_off = c->band_off; e.kl = kldev(c, slot); e.mask = maskof(c, slot); e.seq = c->seqa;
         e.histo = c->histo; e.nstrips = nstrips; e.strip_cap = c->band_cap; e.w = w; e.n = n;
-        e.ppx = pl.ppx; e.ppy = pl.ppy;
+        e.ppx = c->slot_cam[slot].ppx; e.ppy = c->slot_cam[slot].ppy;   // the slot's camera (a stereo pair slot may differ)
         hipLaunchKernelGGL(k_emit, dim3((pl.cap + 255) / 256, 1, B), dim3(256), 0, st, e);
         EH_LAUNCH_CHECK();
     }

@@ -184,6 +184,7 @@ struct DirArgs {
     size_t n;
     double zfm, min_thr_mod, cang_min_edge, max_radius, loc_unc;
     float ppx, ppy;
+    int stereo_mode;          // REBVO/StereoAvaiable: clone rho0/s_rho0 instead of rho/s_rho (edge_tracker.cpp:343-351)
 };
 
 __global__ __launch_bounds__(256) void k_directed(DirArgs a) {
@@ -323,10 +324,15 @@ __global__ __launch_bounds__(256) void k_directed(DirArgs a) {
         }
         if (found >= 0) {
             const int j = found;
-            kn.rho[ik] = ko.rho[j];
-            kn.s_rho[ik] = ko.s_rho[j];
-            kn.rho_nr[ik] = ko.rho_nr[j];
-            kn.s_rho_nr[ik] = ko.s_rho_nr[j];
+            if (a.stereo_mode) {
+                kn.rho[ik] = ko.rho0[j];
+                kn.s_rho[ik] = ko.s_rho0[j];
+            } else {
+                kn.rho[ik] = ko.rho[j];
+                kn.s_rho[ik] = ko.s_rho[j];
+                kn.rho_nr[ik] = ko.rho_nr[j];
+                kn.s_rho_nr[ik] = ko.s_rho_nr[j];
+            }
             kn.m_id[ik] = j;
             kn.m_num[ik] = ko.m_num[j] + 1;
             kn.p_m_0[ik] = ko.p_m[j];
@@ -697,6 +703,137 @@ int rotate_enqueue(edgehip_ctx *c, int slot, const double *R_host) {
     return 0;
 }
 
+// ---------------------------------------------------------------------------------------------------
+// Stereo depth (REBVO/StereoAvaiable): directed_matching_stereo / search_match_stereo / getDepthFromStereo
+// (edge_tracker.cpp:453-668) and fuseStereoDepth (:670-688).  Thread per KeyLine of the main camera; the walk over the
+// pair's edge mask is sequential per KeyLine because the "exactly one candidate" rule depends on the order.
+// ---------------------------------------------------------------------------------------------------
+struct StereoArgs {
+    const KlSoA *kl, *kl_pair;
+    const int32_t *kn;
+    const int32_t *mask_pair;   // [B][N]
+    int32_t *nmatch;            // [B]
+    int w, h;
+    size_t n;
+    double t[3], R[9];
+    double zfm0, zfm1;          // focal lengths of the main / pair camera
+    float pp1x, pp1y;           // principal point of the pair camera
+    double min_thr_mod, cang_min_edge, max_radius, loc_unc, loc_unc_model;
+};
+
+__global__ __launch_bounds__(256) void k_stereo_match(StereoArgs a) {
+    const int seq = blockIdx.z, i = blockIdx.x * 256 + threadIdx.x;
+    int matched = 0;
+    if (i < a.kn[seq]) {
+        const KlSoA &k = a.kl[seq], &kp = a.kl_pair[seq];
+        const int32_t *mask = a.mask_pair + (size_t)seq * a.n;
+        const float2 pm = k.p_m[i], mm = k.m_m[i];
+        const float nm = k.n_m[i];
+        const double rho = k.rho[i], s_rho = k.s_rho[i];
+        const double min_rho = fmax(rho - s_rho, 1e-3), max_rho = fmin(rho + s_rho, 20.0);   // RHO_MIN, RHO_MAX
+        double q1[2][3];
+#pragma unroll
+        for (int e = 0; e < 2; e++) {
+            const double r = e ? max_rho : min_rho;
+            // cam0.unprojectHomCordVec (cam_model.h:163-169), p1 = R p0 + t, cam1.projectHomCordVec (:146-152)
+            const double p0[3] = {(double)pm.x / r / a.zfm0, (double)pm.y / r / a.zfm0, 1.0 / r};
+            double p1[3];
+#pragma unroll
+            for (int c = 0; c < 3; c++) {
+                double d = 0;
+                d += a.R[c * 3 + 0] * p0[0]; d += a.R[c * 3 + 1] * p0[1]; d += a.R[c * 3 + 2] * p0[2];
+                p1[c] = d + a.t[c];
+            }
+            q1[e][0] = p1[0] / p1[2] * a.zfm1; q1[e][1] = p1[1] / p1[2] * a.zfm1; q1[e][2] = 1 / p1[2];
+        }
+        const double dqx = q1[1][0] - q1[0][0], dqy = q1[1][1] - q1[0][1];
+        const double pi0x = q1[0][0] + (double)a.pp1x, pi0y = q1[0][1] + (double)a.pp1y;   // Hom2Img<Point2D<double>>
+        double norm_t = sqrt(dqx * dqx + dqy * dqy);
+        double t_x, t_y, dq_min, dq_max;
+        if (norm_t > 1e-6) {
+            t_x = dqx / norm_t;
+            t_y = dqy / norm_t;
+            dq_min = -a.loc_unc;
+            dq_max = fmin(a.max_radius, norm_t + a.loc_unc);
+        } else {   // no displacement: search across the edge
+            t_x = (double)mm.x;
+            t_y = (double)mm.y;
+            norm_t = (double)nm;
+            t_x /= norm_t;
+            t_y /= norm_t;
+            norm_t = 1;
+            dq_min = -a.max_radius / 2 - a.loc_unc;
+            dq_max = a.max_radius / 2 + a.loc_unc;
+        }
+        const double norm_m = (double)nm;
+        int match = -1;
+        bool ambiguous = false;
+        float2 pm_match = make_float2(0.f, 0.f);
+        for (int t = (int)dq_min; (double)t < dq_max; t++) {
+            const float fx = (float)(t_x * (double)(float)t + pi0x), fy = (float)(t_y * (double)(float)t + pi0y);
+            const int xi = round_half_away_i(fx), yi = round_half_away_i(fy);
+            if (xi >= a.w || yi >= a.h || xi < 0 || yi < 0) continue;
+            const int j = mask[(size_t)yi * a.w + xi];
+            if (j < 0) continue;
+            const MatchRec r = kp.rec[j];
+            const double norm_m0 = (double)r.n_m;
+            const double cang = (double)(r.m_mx * mm.x + r.m_my * mm.y) / (norm_m0 * norm_m);
+            if (cang < a.cang_min_edge || fabs(norm_m0 / norm_m - 1) > a.min_thr_mod) continue;
+            const float2 pj = kp.p_m[j];
+            if (match >= 0) {   // a second candidate: only acceptable next to the first one, else no match at all
+                const float dx = pj.x - pm_match.x, dy = pj.y - pm_match.y;
+                if ((double)(dx * dx + dy * dy) > a.loc_unc * a.loc_unc) { ambiguous = true; break; }
+            }
+            match = j;
+            pm_match = pj;
+        }
+        if (ambiguous) {
+            match = -1;            // search_match_stereo returns before touching stereo_rho / stereo_s_rho
+        } else if (match >= 0) {   // getDepthFromStereo
+            const double qh0[3] = {(double)pm.x / a.zfm0, (double)pm.y / a.zfm0, 1.0};
+            double qh1[3];
+#pragma unroll
+            for (int c = 0; c < 3; c++) {
+                double d = 0;
+                d += a.R[c * 3 + 0] * qh0[0]; d += a.R[c * 3 + 1] * qh0[1]; d += a.R[c * 3 + 2] * qh0[2];
+                qh1[c] = d;
+            }
+            const float2 u = kp.u_m[match];
+            const double qx = (double)pm_match.x, qy = (double)pm_match.y, ux = (double)u.x, uy = (double)u.y, zf1 = a.zfm1;
+            const double div = ux * (zf1 * a.t[0] - qx * a.t[2]) + uy * (zf1 * a.t[1] - qy * a.t[2]);
+            const double mul = (double)(-u.x) * (zf1 * qh1[0] - qx * qh1[2]) - uy * (zf1 * qh1[1] - qy * qh1[2]);
+            double srho = mul / div;
+            const double den = qh1[2] + a.t[2] * srho;
+            const double df = ux * zf1 * (a.t[0] * den - a.t[2] * (qh1[0] + a.t[0] * srho)) / (den * den) +
+                              uy * zf1 * (a.t[1] * den - a.t[2] * (qh1[1] + a.t[1] * srho)) / (den * den);
+            double I_rho = (df / a.loc_unc_model) * (df / a.loc_unc_model);
+            if (srho != srho || df != df) { srho = 1; I_rho = 1e-10; }
+            double ss = 1 / sqrt(I_rho);
+            if (srho < 0) { ss = 1e3; srho = 1.0; match = -1; }   // RhoInit
+            k.stereo_rho[i] = srho;
+            k.stereo_s_rho[i] = ss;
+        }
+        k.stereo_m_id[i] = match;
+        matched = match >= 0;
+    }
+    const int c1 = __popcll(__ballot(matched));
+    if ((threadIdx.x & 63) == 0 && c1) atomicAdd(&a.nmatch[seq], c1);
+}
+
+__global__ __launch_bounds__(256) void k_fuse_stereo(const KlSoA *kls, const int32_t *__restrict__ kns) {
+    const int seq = blockIdx.z, i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= kns[seq]) return;
+    const KlSoA &k = kls[seq];
+    const double r0 = k.rho[i], s0 = k.s_rho[i];
+    k.rho0[i] = r0;
+    k.s_rho0[i] = s0;
+    if (k.stereo_m_id[i] < 0) return;
+    const double sr = k.stereo_rho[i], ss = k.stereo_s_rho[i];
+    const double s = sqrt(1.0 / (1.0 / (s0 * s0) + 1.0 / (ss * ss)));
+    k.s_rho[i] = s;
+    k.rho[i] = (r0 / (s0 * s0) + sr / (ss * ss)) * (s * s);
+}
+
 int directed_enqueue(edgehip_ctx *c, int slot_new, int slot_old) {
     ProfScope ps(c, PROF_C_DIRECTED);
     const DevicePlan &pl = c->plan;
@@ -710,6 +847,7 @@ int directed_enqueue(edgehip_ctx *c, int slot_new, int slot_old) {
     a.max_radius = (double)c->p.search_range;
     a.loc_unc = c->p.loc_unc_match;
     a.ppx = pl.ppx; a.ppy = pl.ppy;
+    a.stereo_mode = c->p.stereo_available != 0;
     hipLaunchKernelGGL(k_directed, dim3((pl.cap + 255) / 256, 1, pl.nseq), dim3(256), 0, c->stream, a);
     EH_LAUNCH_CHECK();
     return 0;
@@ -777,6 +915,52 @@ int edgehip_regularize_ekf(edgehip_ctx *c, int slot, int do_reg, int do_ekf) {
 int edgehip_rescale(edgehip_ctx *c, int slot) {
     if (int e = chk2(c, slot, slot)) return e;
     return rescale_enqueue(c, slot);
+}
+
+int edgehip_set_slot_camera(edgehip_ctx *c, int slot, double ppx, double ppy, double zfx, double zfy) {
+    if (int e = chk2(c, slot, slot)) return e;
+    // REBVOParameters / cam_model keep these as float (cam_model.h:51-57)
+    c->slot_cam[slot].ppx = (float)ppx;
+    c->slot_cam[slot].ppy = (float)ppy;
+    c->slot_cam[slot].zfm = (double)(((float)zfx + (float)zfy) / 2);
+    return 0;
+}
+
+int edgehip_directed_matching_stereo(edgehip_ctx *c, int slot, int slot_pair, const double *t, const double *R, double min_thr_mod,
+                                     double min_thr_ang, double max_radius, double loc_unc, double q_abs, double q_rel,
+                                     double loc_unc_model, int32_t *nmatch) {
+    (void)q_abs; (void)q_rel;
+    if (int e = chk2(c, slot, slot_pair)) return e;
+    if (!t || !R) return EDGEHIP_ERR_ARG;
+    if (!c->p.stereo_available) { set_error("directed_matching_stereo: context created without stereo_available"); return EDGEHIP_ERR_STATE; }
+    const DevicePlan &pl = c->plan;
+    StereoArgs a;
+    a.kl = kldev(c, slot); a.kl_pair = kldev(c, slot_pair);
+    a.kn = c->kn_slot + (size_t)slot * pl.nseq;
+    a.mask_pair = maskof(c, slot_pair);
+    a.nmatch = c->stereo_cnt;
+    a.w = pl.w; a.h = pl.h; a.n = pl.n;
+    memcpy(a.t, t, sizeof a.t); memcpy(a.R, R, sizeof a.R);
+    a.zfm0 = c->slot_cam[slot].zfm; a.zfm1 = c->slot_cam[slot_pair].zfm;
+    a.pp1x = c->slot_cam[slot_pair].ppx; a.pp1y = c->slot_cam[slot_pair].ppy;
+    a.min_thr_mod = min_thr_mod; a.cang_min_edge = cos(min_thr_ang * M_PI / 180.0); a.max_radius = max_radius;
+    a.loc_unc = loc_unc; a.loc_unc_model = loc_unc_model;
+    EH_CHECK(hipMemsetAsync(c->stereo_cnt, 0, sizeof(int32_t) * pl.nseq, c->stream));
+    hipLaunchKernelGGL(k_stereo_match, dim3((pl.cap + 255) / 256, 1, pl.nseq), dim3(256), 0, c->stream, a);
+    EH_LAUNCH_CHECK();
+    if (nmatch) EH_CHECK(hipMemcpyAsync(nmatch, c->stereo_cnt, sizeof(int32_t) * pl.nseq, hipMemcpyDeviceToHost, c->stream));
+    EH_CHECK(hipStreamSynchronize(c->stream));
+    return 0;
+}
+
+int edgehip_fuse_stereo_depth(edgehip_ctx *c, int slot) {
+    if (int e = chk2(c, slot, slot)) return e;
+    if (!c->p.stereo_available) { set_error("fuse_stereo_depth: context created without stereo_available"); return EDGEHIP_ERR_STATE; }
+    const DevicePlan &pl = c->plan;
+    hipLaunchKernelGGL(k_fuse_stereo, dim3((pl.cap + 255) / 256, 1, pl.nseq), dim3(256), 0, c->stream, kldev(c, slot),
+                       c->kn_slot + (size_t)slot * pl.nseq);
+    EH_LAUNCH_CHECK();
+    return 0;
 }
 
 // Host-side 6x6 symmetric eigen-decomposition (cyclic Jacobi), standing in for LAPACK dgesvd_ behind TooN::SVD<>

@@ -48,7 +48,7 @@ class Params(C.Structure):
         ("loc_unc", C.c_double),
         ("global_match_threshold", C.c_int32), ("debug_planes", C.c_int32),
         ("config_fps", C.c_double),
-        ("use_undistort", C.c_int32), ("reserved0", C.c_int32),
+        ("use_undistort", C.c_int32), ("stereo_available", C.c_int32),
     ]
 
 
@@ -141,7 +141,8 @@ EXPORTS = [
     "edgehip_upload_keylines", "edgehip_download_plane", "edgehip_download_field", "edgehip_profile_enable",
     "edgehip_profile_count", "edgehip_profile_name", "edgehip_profile_read", "edgehip_profile_select",
     "edgehip_upload_rgb_indexed", "edgehip_set_nav_log", "edgehip_read_nav_log",
-    "edgehip_build_undistort_map", "edgehip_download_undistorted", "edgehip_depth_reset", "edgehip_depth_reset_slot", "edgehip_minimizer_v", "edgehip_ext_rot_vel",
+    "edgehip_build_undistort_map", "edgehip_download_undistorted", "edgehip_depth_reset", "edgehip_depth_reset_slot", "edgehip_set_slot_camera", "edgehip_directed_matching_stereo",
+    "edgehip_fuse_stereo_depth", "edgehip_minimizer_v", "edgehip_ext_rot_vel",
 ]
 
 _lib = None
@@ -230,6 +231,23 @@ class EdgeHip:
 
     def depth_reset_slot(self, slot, seq=-1):
         self._ck(self.lib.edgehip_depth_reset_slot(self.ctx, seq, slot))
+
+    def set_slot_camera(self, slot, ppx, ppy, zfx, zfy):
+        self._ck(self.lib.edgehip_set_slot_camera(self.ctx, slot, C.c_double(ppx), C.c_double(ppy), C.c_double(zfx), C.c_double(zfy)))
+
+    def directed_matching_stereo(self, slot, slot_pair, t, R, min_thr_mod, min_thr_ang, max_radius, loc_unc, q_abs, q_rel, loc_unc_model):
+        """edge_tracker::directed_matching_stereo for every sequence -> nmatch[nseq]."""
+        t = np.ascontiguousarray(t, np.float64).reshape(3)
+        R = np.ascontiguousarray(R, np.float64).reshape(9)
+        nm = np.zeros(self.nseq, np.int32)
+        self._ck(self.lib.edgehip_directed_matching_stereo(self.ctx, slot, slot_pair, _dp(t), _dp(R), C.c_double(min_thr_mod),
+                                                           C.c_double(min_thr_ang), C.c_double(max_radius), C.c_double(loc_unc),
+                                                           C.c_double(q_abs), C.c_double(q_rel), C.c_double(loc_unc_model),
+                                                           C.c_void_p(nm.ctypes.data)))
+        return nm
+
+    def fuse_stereo_depth(self, slot):
+        self._ck(self.lib.edgehip_fuse_stereo_depth(self.ctx, slot))
 
     def download_undistorted(self, seq, slot):
         out = np.empty((self.h, self.w, 3), np.uint8)

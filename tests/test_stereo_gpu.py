@@ -1,0 +1,166 @@
+"""GPU: stereo depth (REBVO/StereoAvaiable) — stage A of the pair image with the pair
+camera's own intrinsics, directed_matching_stereo (+ search_match_stereo, getDepthFromStereo), fuseStereoDepth and
+directed_matching in stereo mode — against the reference's own classes.
+
+A main-camera sequence gives KeyLines with converged depth; the pair image is the last frame's scene rendered from the
+EuRoC-like baseline hard-coded in rebvo_second_t.cpp:466-470, through slightly different intrinsics.
+Match ids and counts: exact.  stereo_rho / stereo_s_rho and the fused depth: the same fp64 expressions -> 1e-12."""
+import copy
+
+import numpy as np
+import pytest
+
+from rebvo_amd import edgehip, synth
+from tests.helpers import to_edgehip_kl
+
+pytestmark = pytest.mark.gpu
+W, H, NF = 376, 240, 6
+R_PAIR = np.array([[0.999997256477450, 0.002312067192420, 0.000376008102351],
+                   [-0.002317135723285, 0.999898048506528, 0.014089835846697],
+                   [-0.000343393120589, -0.014090668452670, 0.999900662638179]])
+T_PAIR = np.array([-0.110073808127139, 0.000399121547014, -0.000853702503351])
+
+
+def make_data():
+    p = edgehip.euroc_params(W, H)
+    scene = synth.BillboardScene(W, H, p.zfx, p.zfy, p.ppx, p.ppy, seed=11, ss=2)
+    tw = synth.smooth_trajectory(NF, 13)
+    R, t = np.eye(3), np.zeros(3)
+    frames = []
+    for k in range(NF):
+        frames.append(np.repeat(scene.render(R, t)[:, :, None], 3, axis=2).copy())
+        Rl, tl = R.copy(), t.copy()
+        dR = synth._so3_exp(tw[k, 3:])
+        R, t = dR @ R, dR @ t + tw[k, :3]
+    # the pair camera: X_pair = R_PAIR X_cam + T_PAIR, focal length / principal point of its own
+    pair_cam = dict(ppx=p.ppx + 6.4, ppy=p.ppy + 3.4, zfx=p.zfx - 0.53, zfy=p.zfy - 0.58)
+    s2 = copy.copy(scene)
+    s2.fx, s2.fy, s2.cx, s2.cy = pair_cam["zfx"], pair_cam["zfy"], pair_cam["ppx"], pair_cam["ppy"]
+    pair = np.repeat(s2.render(R_PAIR @ Rl, R_PAIR @ tl + T_PAIR)[:, :, None], 3, axis=2).copy()
+    return p, frames, pair, pair_cam
+
+
+def run_reference(p_unused, frames, pair, pair_cam):
+    from oracle import oracle
+    orc = oracle.Oracle("ref", oracle.euroc_params(W, H))
+    for k, f in enumerate(frames):
+        orc.process_frame(f, 0.05 * k)
+    s = orc.cur_slot()
+    ps = (s + 3) % 8
+    orc.set_slot_cam(ps, pair_cam["ppx"], pair_cam["ppy"], pair_cam["zfx"], pair_cam["zfy"])
+    return orc, s, ps
+
+
+def test_stereo_matches_reference():
+    from oracle import oracle
+    if not oracle.available("ref"):
+        pytest.skip("oracle/_ref not built")
+    p, frames, pair, pair_cam = make_data()
+    orc, s, ps = run_reference(p, frames, pair, pair_cam)
+
+    eh = edgehip.EdgeHip(edgehip.euroc_params(W, H, stereo_available=1), nseq=2, nslots=3)
+    # ---- stage A of the pair image through the pair camera: same detector state on both sides ----
+    tresh, lkn = oracle.euroc_params(W, H).detector_thresh, 0
+    o2 = oracle.Oracle("ref", oracle.euroc_params(W, H))
+    o2.set_slot_cam(2, pair_cam["ppx"], pair_cam["ppy"], pair_cam["zfx"], pair_cam["zfy"])
+    for k, f in enumerate(frames):
+        tresh, lkn = o2.stage_a(k % 2, f, tresh, lkn)[-2:]
+        eh.upload_rgb(k % 2, np.stack([f, f]))
+        eh.stage_a(k % 2)
+    eh.set_slot_camera(2, pair_cam["ppx"], pair_cam["ppy"], pair_cam["zfx"], pair_cam["zfy"])
+    o2.stage_a(2, pair, tresh, lkn)
+    eh.upload_rgb(2, np.stack([pair, pair]))
+    eh.stage_a(2)
+    kg, mg = eh.download_keylines(1, 2)
+    kr = o2.keylines(2)
+    assert len(kg) == len(kr) > 3000
+    for f in ("p_inx", "m_m", "u_m", "n_m", "c_p", "p_m", "rho", "s_rho", "p_id", "n_id", "stereo_m_id", "stereo_rho", "stereo_s_rho"):
+        assert np.array_equal(kg[f], kr[f]), f
+    assert np.array_equal(mg, o2.mask(2).reshape(H, W))
+    assert not np.array_equal(kr["p_m"], kr["c_p"] - np.array([p.ppx, p.ppy], np.float32))   # the pair's own principal point
+
+    # ---- directed_matching_stereo on the tracked edge map of the main camera ----
+    # pair edge map for the main oracle: copy the one just detected (KeyLines + mask) into its pair slot
+    orc.set_keylines(ps, kr, o2.mask(2), o2.retuned(2))
+    k_main = orc.keylines(s).copy()
+    assert (k_main["s_rho"] < 10).sum() > 1000                         # depth has started to converge
+    for seq in range(2):
+        eh.upload_keylines(seq, 0, to_edgehip_kl(k_main), orc.mask(s), orc.retuned(s))
+        eh.upload_keylines(seq, 1, to_edgehip_kl(kr), o2.mask(2), o2.retuned(2))
+    eh.set_slot_camera(1, pair_cam["ppx"], pair_cam["ppy"], pair_cam["zfx"], pair_cam["zfy"])
+    args = (T_PAIR, R_PAIR, p.match_thresh_module, p.match_thresh_angle, 100.0, p.loc_unc_match, p.reshape_q_abs, p.reshape_q_rel, p.loc_unc)
+    n_ref = orc.directed_matching_stereo(s, ps, *args)
+    n_gpu = eh.directed_matching_stereo(0, 1, *args)
+    assert list(n_gpu) == [n_ref, n_ref] and n_ref > 300
+    kg, _ = eh.download_keylines(1, 0, want_mask=False)
+    kr1 = orc.keylines(s).copy()
+    assert np.array_equal(kg["stereo_m_id"], kr1["stereo_m_id"])
+    m = kr1["stereo_m_id"] >= 0
+    assert np.allclose(kg["stereo_rho"], kr1["stereo_rho"], rtol=1e-12, atol=0)
+    assert np.allclose(kg["stereo_s_rho"], kr1["stereo_s_rho"], rtol=1e-12, atol=0)
+    assert (kr1["stereo_s_rho"][m] < 5).sum() > 100                    # informative depths came out of it
+    # ambiguous / rejected candidates leave the initial values in place
+    assert np.all(kr1["stereo_rho"][~m & (kr1["stereo_s_rho"] == 20.0)] == 1.0)
+
+    # ---- fuseStereoDepth ----
+    orc.fuse_stereo_depth(s)
+    eh.fuse_stereo_depth(0)
+    kg, _ = eh.download_keylines(0, 0, want_mask=False)
+    kr2 = orc.keylines(s)
+    for f in ("rho0", "s_rho0"):
+        assert np.array_equal(kg[f], kr2[f]), f
+    assert np.allclose(kg["rho"], kr2["rho"], rtol=1e-13, atol=0) and np.allclose(kg["s_rho"], kr2["s_rho"], rtol=1e-13, atol=0)
+    assert np.any(kr2["rho"][m] != kr2["rho0"][m])
+
+    # ---- without stereo_available the entry points refuse ----
+    eh0 = edgehip.EdgeHip(edgehip.euroc_params(W, H), nseq=1, nslots=2)
+    with pytest.raises(RuntimeError):
+        eh0.fuse_stereo_depth(0)
+
+
+
+def test_directed_matching_stereo_mode():
+    """directed_matching with StereoAvaiable: a match clones rho0 / s_rho0 and leaves rho_nr alone."""
+    from oracle import oracle
+    if not oracle.available("ref"):
+        pytest.skip("oracle/_ref not built")
+    p, frames, pair, pair_cam = make_data()
+    orc = oracle.Oracle("ref", oracle.euroc_params(W, H))
+    for k, f in enumerate(frames[:-1]):
+        orc.process_frame(f, 0.05 * k)
+    so = orc.cur_slot()
+    sn = (so + 1) % 8
+    # detect the last frame without tracking it, then run the tracker stages by hand
+    _, nav = orc.process_frame(frames[-1], 0.05 * (NF - 1))
+    sn = orc.cur_slot()
+    so = (sn + 7) % 8
+    V, RVel = np.array(nav.V[:]), np.array(nav.P_V[:]).reshape(3, 3)
+    R0 = np.array(nav.Rot[:]).reshape(3, 3)
+    # make rho0 differ from rho on the old map so that the two modes are distinguishable
+    ko = orc.keylines(so).copy()
+    ko["rho0"] = ko["rho"] * 1.25
+    ko["s_rho0"] = ko["s_rho"] * 0.5
+    kn = orc.keylines(sn).copy()
+    kn["m_id"] = -1
+    eh = edgehip.EdgeHip(edgehip.euroc_params(W, H, stereo_available=1), nseq=1, nslots=2)
+    orc.set_stereo_mode(1)
+    orc.set_keylines(so, ko, orc.mask(so), orc.retuned(so))
+    orc.set_keylines(sn, kn, orc.mask(sn), orc.retuned(sn))
+    eh.upload_keylines(0, 0, to_edgehip_kl(ko), orc.mask(so), orc.retuned(so))
+    eh.upload_keylines(0, 1, to_edgehip_kl(kn), orc.mask(sn), orc.retuned(sn))
+    st = eh.get_state(0)
+    st.V[:] = V
+    st.P_V[:] = RVel.ravel()
+    st.R[:] = R0.ravel()
+    st.klm_num = 0
+    st.kf_matchs = 0
+    eh.set_state(0, st)
+    n_ref, _ = orc.directed_matching(sn, so, V, RVel, R0, 1.0, 45.0, 40.0, 2.0)
+    eh.directed_matching(1, 0)
+    kg, _ = eh.download_keylines(0, 1, want_mask=False)
+    kr = orc.keylines(sn)
+    assert eh.get_state(0).klm_num == n_ref > 1000
+    for f in ("m_id", "rho", "s_rho", "rho_nr", "s_rho_nr", "m_num"):
+        assert np.array_equal(kg[f], kr[f]), f
+    m = kr["m_id"] >= 0
+    assert np.array_equal(kr["rho"][m], ko["rho0"][kr["m_id"][m]])
