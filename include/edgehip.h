@@ -222,6 +222,15 @@ int edgehip_directed_matching_stereo(edgehip_ctx *ctx, int slot, int slot_pair, 
 /* edge_tracker::fuseStereoDepth (rebvo_second_t.cpp:484; edge_tracker.cpp:670-688): rho0/s_rho0 = rho/s_rho, then the
  * information-weighted mean with the stereo depth where a stereo match exists. */
 int edgehip_fuse_stereo_depth(edgehip_ctx *ctx, int slot);
+/* Stereo inside edgehip_process_frame (what SecondThread does with StereoAvaiable, rebvo_second_t.cpp:410, 465-486):
+ * the last ring slot becomes the pair slot (the frame ring then cycles through the others); the caller uploads the pair
+ * image into it before every edgehip_process_frame, which then also runs stage A on it (after the main image, sharing
+ * the detector threshold state like rebvo_first_t.cpp:283-289) and, after the depth EKF, directed_matching_stereo with
+ * (t, R, max_radius) and the context's matching thresholds, fuseStereoDepth, and Kp = 1 in place of
+ * EstimateReScalingOpt.  Set edgehip_set_slot_camera for the pair slot first when the cameras differ.
+ * slot_pair < 0 switches the rig off.  edgehip_get_stereo_matches: stereo_match_num of the last frame.  Synchronises. */
+int edgehip_set_stereo_rig(edgehip_ctx *ctx, int slot_pair, const double *t, const double *R, double max_radius);
+int edgehip_get_stereo_matches(edgehip_ctx *ctx, int32_t *nmatch);
 
 /* ---- whole frame ------------------------------------------------------------------------------------ */
 /* Everything FirstThr + SecondThread (ImuMode==0) do for one new frame of every sequence, on the

@@ -374,6 +374,23 @@ class Oracle:
         f.restype, f.argtypes = None, [C.c_void_p, C.c_int]
         f(self.ctx, slot)
 
+    def enable_stereo(self, ppx, ppy, zfx, zfy, t, R, max_radius=100.0):
+        f = self.lib.ref_enable_stereo
+        pd = C.POINTER(C.c_double)
+        f.restype, f.argtypes = None, [C.c_void_p] + [C.c_double] * 4 + [pd, pd, C.c_double]
+        t = np.ascontiguousarray(t, np.float64).reshape(3)
+        R = np.ascontiguousarray(R, np.float64).reshape(9)
+        f(self.ctx, ppx, ppy, zfx, zfy, _dp(t), _dp(R), max_radius)
+
+    def process_frame_stereo(self, rgb, rgb_pair, t):
+        f = self.lib.ref_process_frame_stereo
+        f.restype, f.argtypes = C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_double, C.POINTER(Nav)]
+        rgb = np.ascontiguousarray(rgb, dtype=np.uint8)
+        rgb_pair = np.ascontiguousarray(rgb_pair, dtype=np.uint8)
+        nav = Nav()
+        ran = f(self.ctx, rgb.ctypes.data, rgb_pair.ctypes.data, float(t), C.byref(nav))
+        return ran, nav
+
     def depth_reset(self):
         """REBVO::Reset() semantics (rebvo_second_t.cpp:609-620) applied after the last processed frame."""
         self._depth_reset(self.ctx)

@@ -137,6 +137,11 @@ int ref_directed_matching_stereo(void *ctx, int slot, int slot_pair, const doubl
                                  double min_thr_ang, double max_radius, double loc_unc, double q_abs, double q_rel,
                                  double loc_unc_model);
 void ref_fuse_stereo_depth(void *ctx, int slot);
+/* whole frame with StereoAvaiable: pair camera + rig, then ref_process_frame_stereo per frame pair of images;
+ * OrcNav::pad0 carries stereo_match_num */
+void ref_enable_stereo(void *ctx, double ppx, double ppy, double zfx, double zfy, const double t[3], const double R[9],
+                       double max_radius);
+int ref_process_frame_stereo(void *ctx, const uint8_t *rgb24, const uint8_t *rgb24_pair, double t, OrcNav *nav);
 
 /* ---- IMU branch: reference only.  The restatement under test is the host library
  * (rebvo_amd/host/src/imu.cpp, rebvo_imu.cpp); these entry points run the reference's own ImuGrabber, BiasCorrect and

@@ -102,6 +102,12 @@ struct Ctx {
     Vector<3> giro_init, g_init;
     Matrix<3, 3> Rgva;
     bool stereo_mode;                 // REBVO/StereoAvaiable as directed_matching sees it
+    int ring;                         // slots of the frame ring (a stereo pair slot, if any, sits behind them)
+    bool rig;                         // whole-frame stereo (ref_enable_stereo)
+    Vector<3> rig_t;
+    Matrix<3, 3> rig_R;
+    double rig_radius;
+    const uint8_t *pair_rgb;          // pair image of the frame being processed
 };
 
 void reset_seq(Ctx *c) {
@@ -163,6 +169,9 @@ void *ref_create(const OrcParams *p, int nslots) {
     c->undist = nullptr;
     c->img_dist = nullptr;
     c->stereo_mode = false;
+    c->ring = nslots;
+    c->rig = false;
+    c->pair_rgb = nullptr;
     if (p->use_undistort) {
         c->undist = new image_undistort(c->cam);
         c->img_dist = new Image<RGB24Pixel>(c->cam.sz);
@@ -189,7 +198,7 @@ void ref_reset_sequence(void *ctx) { reset_seq((Ctx *)ctx); }
 void ref_depth_reset(void *ctx) {   // the `if(cf->system_reset)` block of rebvo_second_t.cpp:609-620, on the newest slot
     Ctx *c = (Ctx *)ctx;
     if (c->frame == 0) return;
-    Slot &nb = c->slots[(c->frame + (int)c->slots.size() - 1) % (int)c->slots.size()];
+    Slot &nb = c->slots[(c->frame + c->ring - 1) % c->ring];
     for (auto &kl : (*nb.ef)) {
         kl.rho = RhoInit;
         kl.s_rho = RHO_MAX;
@@ -201,7 +210,7 @@ void ref_depth_reset(void *ctx) {   // the `if(cf->system_reset)` block of rebvo
 }
 int ref_cur_slot(void *ctx) {
     Ctx *c = (Ctx *)ctx;
-    return (c->frame + (int)c->slots.size() - 1) % (int)c->slots.size();
+    return (c->frame + c->ring - 1) % c->ring;
 }
 
 int ref_stage_a(void *ctx, int slot, const uint8_t *rgb24, double *tresh_io, int *l_kl_num_io) {
@@ -412,6 +421,21 @@ int ref_directed_matching_stereo(void *ctx, int slot, int slot_pair, const doubl
                                                        q_abs, q_rel, loc_unc_model);
 }
 void ref_fuse_stereo_depth(void *ctx, int slot) { ((Ctx *)ctx)->slots[slot].ef->fuseStereoDepth(); }
+// whole-frame stereo: one more slot behind the ring for the pair image's edge map, built with the pair camera
+void ref_enable_stereo(void *ctx, double ppx, double ppy, double zfx, double zfy, const double t[3], const double R[9],
+                       double max_radius) {
+    Ctx *c = (Ctx *)ctx;
+    if (!c->rig) {
+        Slot s = {nullptr, nullptr, nullptr, new Image<float>(c->cam.sz), new Image<RGB24Pixel>(c->cam.sz)};
+        c->slots.push_back(s);
+    }
+    ref_set_slot_cam(ctx, c->ring, ppx, ppy, zfx, zfy);
+    c->rig = true;
+    c->stereo_mode = true;
+    c->rig_t = v3(t);
+    c->rig_R = m3(R);
+    c->rig_radius = max_radius;
+}
 
 int ref_regularize(void *ctx, int slot, double thresh) {
     return ((Ctx *)ctx)->slots[slot].ef->Regularize_1_iter(thresh);
@@ -428,12 +452,13 @@ double ref_rescale(void *ctx, int slot, double *RKp, double s_rho_min, unsigned 
 int ref_process_frame(void *ctx, const uint8_t *rgb24, double t, OrcNav *nav) {
     Ctx *c = (Ctx *)ctx;
     const OrcParams &p = c->p;
-    const int ns = (int)c->slots.size();
+    const int ns = c->ring;
     const int sn = c->frame % ns, so = (c->frame + ns - 1) % ns;
     memset(nav, 0, sizeof(*nav));
 
     double t0 = now();
     ref_stage_a(ctx, sn, rgb24, &c->tresh, &c->l_kl_num);
+    if (c->rig && c->pair_rgb) ref_stage_a(ctx, c->ring, c->pair_rgb, &c->tresh, &c->l_kl_num);   // rebvo_first_t.cpp:275-290
     nav->dtp0 = now() - t0;
     Slot &nb = c->slots[sn];
     nav->frame = c->frame;
@@ -480,7 +505,7 @@ int ref_process_frame(void *ctx, const uint8_t *rgb24, double t, OrcNav *nav) {
         EstimationOk = false;
     } else {
         klm_num = nb.ef->directed_matching(V, P_V, R, ob.ef, num_kf_back_m, p.match_thresh_module,
-                                           p.match_thresh_angle, p.search_range, p.loc_unc_match, false);  // :410
+                                           p.match_thresh_angle, p.search_range, p.loc_unc_match, c->stereo_mode);  // :410
         if (klm_num < p.global_match_threshold) {                    // :412-422
             P_V = Identity * 1e50;
             V = Zeros;
@@ -490,7 +515,15 @@ int ref_process_frame(void *ctx, const uint8_t *rgb24, double t, OrcNav *nav) {
         } else {
             nb.ef->Regularize_1_iter(p.regularize_thresh);           // :453
             nb.ef->UpdateInverseDepthKalman(V, P_V, P_W, p.reshape_q_abs, p.reshape_q_rel, p.loc_unc);  // :460
-            c->Kp = nb.ef->EstimateReScalingOpt(c->P_Kp, RHO_MAX, 1, p.do_rescaling > 0);             // :487
+            if (c->rig) {                                                                               // :465-486
+                nav->pad0 = nb.ef->directed_matching_stereo(c->rig_t, c->rig_R, c->slots[c->ring].ef, p.match_thresh_module,
+                                                            p.match_thresh_angle, c->rig_radius, p.loc_unc_match, p.reshape_q_abs,
+                                                            p.reshape_q_rel, p.loc_unc);               // stereo_match_num
+                nb.ef->fuseStereoDepth();
+                c->Kp = 1;
+            } else {
+                c->Kp = nb.ef->EstimateReScalingOpt(c->P_Kp, RHO_MAX, 1, p.do_rescaling > 0);         // :487
+            }
         }
     }
     c->Pose = c->Pose * R;                                           // :550
@@ -519,6 +552,14 @@ int ref_process_frame(void *ctx, const uint8_t *rgb24, double t, OrcNav *nav) {
 }
 
 }  // extern "C"
+
+extern "C" int ref_process_frame_stereo(void *ctx, const uint8_t *rgb24, const uint8_t *rgb24_pair, double t, OrcNav *nav) {
+    Ctx *c = (Ctx *)ctx;
+    c->pair_rgb = rgb24_pair;
+    const int r = ref_process_frame(ctx, rgb24, t, nav);
+    c->pair_rgb = nullptr;
+    return r;
+}
 
 // ---------------------------------------------------------------------------------------------------------------
 // IMU branch: the reference's filters and grabber behind flat entry points, and the ImuMode > 0 frame sequence
@@ -619,7 +660,7 @@ int ref_process_frame_imu(void *ctx, const uint8_t *rgb24, double t, const OrcIm
     const OrcParams &p = c->p;
     const OrcImuParams &ip = c->ip;
     IMUState &istate = c->istate;
-    const int ns = (int)c->slots.size();
+    const int ns = c->ring;
     const int sn = c->frame % ns, so = (c->frame + ns - 1) % ns;
     memset(nav, 0, sizeof(*nav));
     ref_stage_a(ctx, sn, rgb24, &c->tresh, &c->l_kl_num);

@@ -279,6 +279,7 @@ int edgehip_create(const edgehip_params *params, int nseq, int nslots, int devic
     c->device = device;
     c->frame_slot = -1;
     c->frames_seen = 0;
+    c->ring_slots = nslots;
     c->prof = new Profiler();
     EH_CHECK(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
     EH_CHECK(hipStreamCreateWithFlags(&c->stream_a, hipStreamNonBlocking));

@@ -175,6 +175,12 @@ struct edgehip_ctx {
     double *resid_carry;   // [kResidBufs][B][nblk_tvr] last valid residual per block
     double *partials;      // [B][nblk_tvr][kNumSums]
     double *block_last;    // [B][nblk_tvr] last valid residual of each block of the running evaluation
+    struct StereoRig {                // edgehip_set_stereo_rig: the pair camera of edgehip_process_frame
+        bool enabled = false;
+        int slot_pair = -1;
+        double t[3], R[9], max_radius;
+    } rig;
+    int ring_slots;                   // slots the frame ring cycles through (nslots, or nslots - 1 with a stereo rig)
     struct SlotCam { float ppx, ppy; double zfm; };
     std::vector<SlotCam> slot_cam;   // per ring slot: principal point stage A uses, focal length of that camera (stereo pair slot)
     int field_radius;      // radius of the last build_field (global_tracker::max_r)

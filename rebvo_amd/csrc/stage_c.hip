@@ -719,10 +719,12 @@ struct StereoArgs {
     double zfm0, zfm1;          // focal lengths of the main / pair camera
     float pp1x, pp1y;           // principal point of the pair camera
     double min_thr_mod, cang_min_edge, max_radius, loc_unc, loc_unc_model;
+    const SeqDev *seqs;         // whole-frame driver: sequences whose mapping step is skipped this frame (else null)
 };
 
 __global__ __launch_bounds__(256) void k_stereo_match(StereoArgs a) {
     const int seq = blockIdx.z, i = blockIdx.x * 256 + threadIdx.x;
+    if (a.seqs && a.seqs[seq].skip_map) return;
     int matched = 0;
     if (i < a.kn[seq]) {
         const KlSoA &k = a.kl[seq], &kp = a.kl_pair[seq];
@@ -820,8 +822,12 @@ __global__ __launch_bounds__(256) void k_stereo_match(StereoArgs a) {
     if ((threadIdx.x & 63) == 0 && c1) atomicAdd(&a.nmatch[seq], c1);
 }
 
-__global__ __launch_bounds__(256) void k_fuse_stereo(const KlSoA *kls, const int32_t *__restrict__ kns) {
+__global__ __launch_bounds__(256) void k_fuse_stereo(const KlSoA *kls, const int32_t *__restrict__ kns, SeqDev *seqs) {
     const int seq = blockIdx.z, i = blockIdx.x * 256 + threadIdx.x;
+    if (seqs) {   // whole-frame driver (rebvo_second_t.cpp:483-486): fuse, and Kp = 1 instead of the re-scaling estimate
+        if (seqs[seq].skip_map) return;
+        if (i == 0) seqs[seq].pub.Kp = 1;
+    }
     if (i >= kns[seq]) return;
     const KlSoA &k = kls[seq];
     const double r0 = k.rho[i], s0 = k.s_rho[i];
@@ -926,13 +932,8 @@ int edgehip_set_slot_camera(edgehip_ctx *c, int slot, double ppx, double ppy, do
     return 0;
 }
 
-int edgehip_directed_matching_stereo(edgehip_ctx *c, int slot, int slot_pair, const double *t, const double *R, double min_thr_mod,
-                                     double min_thr_ang, double max_radius, double loc_unc, double q_abs, double q_rel,
-                                     double loc_unc_model, int32_t *nmatch) {
-    (void)q_abs; (void)q_rel;
-    if (int e = chk2(c, slot, slot_pair)) return e;
-    if (!t || !R) return EDGEHIP_ERR_ARG;
-    if (!c->p.stereo_available) { set_error("directed_matching_stereo: context created without stereo_available"); return EDGEHIP_ERR_STATE; }
+static int stereo_enqueue(edgehip_ctx *c, int slot, int slot_pair, const double *t, const double *R, double min_thr_mod,
+                          double min_thr_ang, double max_radius, double loc_unc, double loc_unc_model, bool frame_driver) {
     const DevicePlan &pl = c->plan;
     StereoArgs a;
     a.kl = kldev(c, slot); a.kl_pair = kldev(c, slot_pair);
@@ -945,10 +946,29 @@ int edgehip_directed_matching_stereo(edgehip_ctx *c, int slot, int slot_pair, co
     a.pp1x = c->slot_cam[slot_pair].ppx; a.pp1y = c->slot_cam[slot_pair].ppy;
     a.min_thr_mod = min_thr_mod; a.cang_min_edge = cos(min_thr_ang * M_PI / 180.0); a.max_radius = max_radius;
     a.loc_unc = loc_unc; a.loc_unc_model = loc_unc_model;
+    a.seqs = frame_driver ? c->seq : nullptr;
     EH_CHECK(hipMemsetAsync(c->stereo_cnt, 0, sizeof(int32_t) * pl.nseq, c->stream));
     hipLaunchKernelGGL(k_stereo_match, dim3((pl.cap + 255) / 256, 1, pl.nseq), dim3(256), 0, c->stream, a);
     EH_LAUNCH_CHECK();
-    if (nmatch) EH_CHECK(hipMemcpyAsync(nmatch, c->stereo_cnt, sizeof(int32_t) * pl.nseq, hipMemcpyDeviceToHost, c->stream));
+    return 0;
+}
+static int fuse_stereo_enqueue(edgehip_ctx *c, int slot, bool frame_driver) {
+    const DevicePlan &pl = c->plan;
+    hipLaunchKernelGGL(k_fuse_stereo, dim3((pl.cap + 255) / 256, 1, pl.nseq), dim3(256), 0, c->stream, kldev(c, slot),
+                       c->kn_slot + (size_t)slot * pl.nseq, frame_driver ? c->seq : nullptr);
+    EH_LAUNCH_CHECK();
+    return 0;
+}
+
+int edgehip_directed_matching_stereo(edgehip_ctx *c, int slot, int slot_pair, const double *t, const double *R, double min_thr_mod,
+                                     double min_thr_ang, double max_radius, double loc_unc, double q_abs, double q_rel,
+                                     double loc_unc_model, int32_t *nmatch) {
+    (void)q_abs; (void)q_rel;
+    if (int e = chk2(c, slot, slot_pair)) return e;
+    if (!t || !R) return EDGEHIP_ERR_ARG;
+    if (!c->p.stereo_available) { set_error("directed_matching_stereo: context created without stereo_available"); return EDGEHIP_ERR_STATE; }
+    if (int e = stereo_enqueue(c, slot, slot_pair, t, R, min_thr_mod, min_thr_ang, max_radius, loc_unc, loc_unc_model, false)) return e;
+    if (nmatch) EH_CHECK(hipMemcpyAsync(nmatch, c->stereo_cnt, sizeof(int32_t) * c->plan.nseq, hipMemcpyDeviceToHost, c->stream));
     EH_CHECK(hipStreamSynchronize(c->stream));
     return 0;
 }
@@ -956,10 +976,37 @@ int edgehip_directed_matching_stereo(edgehip_ctx *c, int slot, int slot_pair, co
 int edgehip_fuse_stereo_depth(edgehip_ctx *c, int slot) {
     if (int e = chk2(c, slot, slot)) return e;
     if (!c->p.stereo_available) { set_error("fuse_stereo_depth: context created without stereo_available"); return EDGEHIP_ERR_STATE; }
-    const DevicePlan &pl = c->plan;
-    hipLaunchKernelGGL(k_fuse_stereo, dim3((pl.cap + 255) / 256, 1, pl.nseq), dim3(256), 0, c->stream, kldev(c, slot),
-                       c->kn_slot + (size_t)slot * pl.nseq);
-    EH_LAUNCH_CHECK();
+    return fuse_stereo_enqueue(c, slot, false);
+}
+
+int edgehip_set_stereo_rig(edgehip_ctx *c, int slot_pair, const double *t, const double *R, double max_radius) {
+    if (!c) return EDGEHIP_ERR_ARG;
+    if (slot_pair < 0) {   // switch the rig off: the whole ring is available again
+        c->rig.enabled = false;
+        c->ring_slots = c->plan.nslots;
+        return 0;
+    }
+    if (!t || !R) return EDGEHIP_ERR_ARG;
+    if (!c->p.stereo_available) { set_error("set_stereo_rig: context created without stereo_available"); return EDGEHIP_ERR_STATE; }
+    if (slot_pair != c->plan.nslots - 1 || c->plan.nslots < 3) {
+        set_error("set_stereo_rig: the pair slot is the last of at least three slots");
+        return EDGEHIP_ERR_ARG;
+    }
+    if (c->frames_seen != 0) { set_error("set_stereo_rig: set the rig before the first frame (or after edgehip_reset)"); return EDGEHIP_ERR_STATE; }
+    c->rig.enabled = true;
+    c->rig.slot_pair = slot_pair;
+    memcpy(c->rig.t, t, sizeof c->rig.t);
+    memcpy(c->rig.R, R, sizeof c->rig.R);
+    c->rig.max_radius = max_radius;
+    c->ring_slots = c->plan.nslots - 1;
+    return 0;
+}
+
+int edgehip_get_stereo_matches(edgehip_ctx *c, int32_t *nmatch) {
+    if (!c || !nmatch) return EDGEHIP_ERR_ARG;
+    if (!c->stereo_cnt) { set_error("get_stereo_matches: context created without stereo_available"); return EDGEHIP_ERR_STATE; }
+    EH_CHECK(hipMemcpyAsync(nmatch, c->stereo_cnt, sizeof(int32_t) * c->plan.nseq, hipMemcpyDeviceToHost, c->stream));
+    EH_CHECK(hipStreamSynchronize(c->stream));
     return 0;
 }
 
@@ -1060,13 +1107,14 @@ int edgehip_depth_reset_slot(edgehip_ctx *c, int seq, int slot) {
     return 0;
 }
 
-int edgehip_next_slot(edgehip_ctx *c) { return c ? (c->frame_slot + 1) % c->plan.nslots : -1; }
+int edgehip_next_slot(edgehip_ctx *c) { return c ? (c->frame_slot + 1) % c->ring_slots : -1; }
 int edgehip_cur_slot(edgehip_ctx *c) { return c ? c->frame_slot : -1; }
 
 int edgehip_process_frame(edgehip_ctx *c, const double *t) {
     if (!c || !t) return EDGEHIP_ERR_ARG;
     const DevicePlan &pl = c->plan;
-    const int sn = (c->frame_slot + 1) % pl.nslots, so = c->frame_slot;
+    const int sn = (c->frame_slot + 1) % c->ring_slots, so = c->frame_slot;
+    const int sp = c->rig.enabled ? c->rig.slot_pair : -1;   // stereo pair slot (its frame was uploaded by the caller)
     const int have_pair = c->frames_seen >= 1;
     int e;
     // time stamps travel through a small ring of pinned slots so that back-to-back frames need no sync
@@ -1083,7 +1131,9 @@ int edgehip_process_frame(edgehip_ctx *c, const double *t) {
     } else if (c->use_valid[sn]) {
         EH_CHECK(hipStreamWaitEvent(c->stream_a, c->ev_use[sn], 0));
     }
+    if (sp >= 0 && c->overlap && c->use_valid[sp]) EH_CHECK(hipStreamWaitEvent(c->stream_a, c->ev_use[sp], 0));
     EH_TRY(stage_a_enqueue(c, sn));
+    if (sp >= 0) EH_TRY(stage_a_enqueue(c, sp));   // the pair image, after the main one as in rebvo_first_t.cpp:259-290
     EH_CHECK(hipEventRecord(c->ev_a[sn], c->stream_a));
     EH_CHECK(hipStreamWaitEvent(c->stream, c->ev_a[sn], 0));
     {
@@ -1100,7 +1150,13 @@ int edgehip_process_frame(edgehip_ctx *c, const double *t) {
         EH_TRY(directed_enqueue(c, sn, so));                                                     // :410
         { ProfScope ps(c, PROF_C_POSE); EH_TRY(glue(c, 2, sn, have_pair)); }                     // :412-422
         EH_TRY(regekf_enqueue(c, sn, 1, 1));                                                     // :453, :460
-        EH_TRY(rescale_enqueue(c, sn));                                                          // :487
+        if (sp >= 0) {                                                                           // :465-486
+            EH_TRY(stereo_enqueue(c, sn, sp, c->rig.t, c->rig.R, c->p.match_thresh_module, c->p.match_thresh_angle, c->rig.max_radius,
+                                  c->p.loc_unc_match, c->p.loc_unc, true));
+            EH_TRY(fuse_stereo_enqueue(c, sn, true));
+        } else {
+            EH_TRY(rescale_enqueue(c, sn));                                                      // :487
+        }
     }
     {
         ProfScope ps(c, PROF_C_POSE);
@@ -1113,6 +1169,10 @@ int edgehip_process_frame(edgehip_ctx *c, const double *t) {
     if (so >= 0) {
         EH_CHECK(hipEventRecord(c->ev_use[so], c->stream));
         c->use_valid[so] = true;
+    }
+    if (sp >= 0) {
+        EH_CHECK(hipEventRecord(c->ev_use[sp], c->stream));
+        c->use_valid[sp] = true;
     }
     c->frame_slot = sn;
     c->frames_seen++;

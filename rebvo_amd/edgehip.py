@@ -142,7 +142,7 @@ EXPORTS = [
     "edgehip_profile_count", "edgehip_profile_name", "edgehip_profile_read", "edgehip_profile_select",
     "edgehip_upload_rgb_indexed", "edgehip_set_nav_log", "edgehip_read_nav_log",
     "edgehip_build_undistort_map", "edgehip_download_undistorted", "edgehip_depth_reset", "edgehip_depth_reset_slot", "edgehip_set_slot_camera", "edgehip_directed_matching_stereo",
-    "edgehip_fuse_stereo_depth", "edgehip_minimizer_v", "edgehip_ext_rot_vel",
+    "edgehip_fuse_stereo_depth", "edgehip_set_stereo_rig", "edgehip_get_stereo_matches", "edgehip_minimizer_v", "edgehip_ext_rot_vel",
 ]
 
 _lib = None
@@ -248,6 +248,19 @@ class EdgeHip:
 
     def fuse_stereo_depth(self, slot):
         self._ck(self.lib.edgehip_fuse_stereo_depth(self.ctx, slot))
+
+    def set_stereo_rig(self, slot_pair, t=None, R=None, max_radius=100.0):
+        if slot_pair < 0:
+            self._ck(self.lib.edgehip_set_stereo_rig(self.ctx, -1, None, None, C.c_double(0)))
+            return
+        t = np.ascontiguousarray(t, np.float64).reshape(3)
+        R = np.ascontiguousarray(R, np.float64).reshape(9)
+        self._ck(self.lib.edgehip_set_stereo_rig(self.ctx, slot_pair, _dp(t), _dp(R), C.c_double(max_radius)))
+
+    def get_stereo_matches(self):
+        nm = np.zeros(self.nseq, np.int32)
+        self._ck(self.lib.edgehip_get_stereo_matches(self.ctx, C.c_void_p(nm.ctypes.data)))
+        return nm
 
     def download_undistorted(self, seq, slot):
         out = np.empty((self.h, self.w, 3), np.uint8)

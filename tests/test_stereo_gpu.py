@@ -21,23 +21,23 @@ R_PAIR = np.array([[0.999997256477450, 0.002312067192420, 0.000376008102351],
 T_PAIR = np.array([-0.110073808127139, 0.000399121547014, -0.000853702503351])
 
 
-def make_data():
+def make_data(all_pairs=False, nf=NF):
     p = edgehip.euroc_params(W, H)
     scene = synth.BillboardScene(W, H, p.zfx, p.zfy, p.ppx, p.ppy, seed=11, ss=2)
-    tw = synth.smooth_trajectory(NF, 13)
-    R, t = np.eye(3), np.zeros(3)
-    frames = []
-    for k in range(NF):
-        frames.append(np.repeat(scene.render(R, t)[:, :, None], 3, axis=2).copy())
-        Rl, tl = R.copy(), t.copy()
-        dR = synth._so3_exp(tw[k, 3:])
-        R, t = dR @ R, dR @ t + tw[k, :3]
     # the pair camera: X_pair = R_PAIR X_cam + T_PAIR, focal length / principal point of its own
     pair_cam = dict(ppx=p.ppx + 6.4, ppy=p.ppy + 3.4, zfx=p.zfx - 0.53, zfy=p.zfy - 0.58)
     s2 = copy.copy(scene)
     s2.fx, s2.fy, s2.cx, s2.cy = pair_cam["zfx"], pair_cam["zfy"], pair_cam["ppx"], pair_cam["ppy"]
-    pair = np.repeat(s2.render(R_PAIR @ Rl, R_PAIR @ tl + T_PAIR)[:, :, None], 3, axis=2).copy()
-    return p, frames, pair, pair_cam
+    tw = synth.smooth_trajectory(nf, 13)
+    R, t = np.eye(3), np.zeros(3)
+    frames, pairs = [], []
+    for k in range(nf):
+        frames.append(np.repeat(scene.render(R, t)[:, :, None], 3, axis=2).copy())
+        if all_pairs or k == nf - 1:
+            pairs.append(np.repeat(s2.render(R_PAIR @ R, R_PAIR @ t + T_PAIR)[:, :, None], 3, axis=2).copy())
+        dR = synth._so3_exp(tw[k, 3:])
+        R, t = dR @ R, dR @ t + tw[k, :3]
+    return p, frames, (pairs if all_pairs else pairs[-1]), pair_cam
 
 
 def run_reference(p_unused, frames, pair, pair_cam):
@@ -164,3 +164,52 @@ def test_directed_matching_stereo_mode():
         assert np.array_equal(kg[f], kr[f]), f
     m = kr["m_id"] >= 0
     assert np.array_equal(kr["rho"][m], ko["rho0"][kr["m_id"][m]])
+
+
+def test_stereo_whole_frame_matches_reference():
+    """edgehip_process_frame with a stereo rig (stage A of the pair image, stereo-mode directed matching, stereo match,
+    fuse, Kp = 1) against the reference's SecondThread order with StereoAvaiable, frame by frame; two sequences in the
+    batch stay identical."""
+    from oracle import oracle
+    if not oracle.available("ref"):
+        pytest.skip("oracle/_ref not built")
+    nf = 8
+    p, frames, pairs, pc = make_data(all_pairs=True, nf=nf)
+    orc = oracle.Oracle("ref", oracle.euroc_params(W, H))
+    orc.enable_stereo(pc["ppx"], pc["ppy"], pc["zfx"], pc["zfy"], T_PAIR, R_PAIR, 100.0)
+    eh = edgehip.EdgeHip(edgehip.euroc_params(W, H, stereo_available=1), nseq=2, nslots=4)
+    eh.set_slot_camera(3, pc["ppx"], pc["ppy"], pc["zfx"], pc["zfy"])
+    eh.set_stereo_rig(3, T_PAIR, R_PAIR, 100.0)
+    path = 0.0
+    for k in range(nf):
+        _, nr = orc.process_frame_stereo(frames[k], pairs[k], 0.05 * k)
+        assert eh.next_slot() == k % 3                     # the ring leaves the pair slot alone
+        eh.upload_rgb(eh.next_slot(), np.stack([frames[k]] * 2))
+        eh.upload_rgb(3, np.stack([pairs[k]] * 2))
+        eh.process_frame(0.05 * k)
+        navs = eh.read_nav()
+        nm = eh.get_stereo_matches()
+        for s, ng in enumerate(navs):
+            assert ng.kn == nr.kn and ng.tresh == nr.tresh, k   # the pair image went through the shared threshold state
+            if k == 0:
+                continue
+            assert ng.estimation_ok == nr.estimation_ok == 1
+            Vr, Wr = np.array(nr.V[:]), np.array(nr.W[:])
+            step = np.linalg.norm(Vr) + np.linalg.norm(Wr)
+            assert np.allclose(ng.V[:], Vr, rtol=0, atol=1e-6 * step + 1e-9), (k, ng.V[:], Vr)
+            assert np.allclose(ng.W[:], Wr, rtol=0, atol=1e-6 * step + 1e-9)
+            assert ng.Kp == nr.Kp == 1.0
+            assert abs(int(nm[s]) - nr.pad0) <= max(2, nr.pad0 // 500), (k, nm, nr.pad0)
+            assert abs(ng.klm_num - nr.klm_num) <= max(2, nr.klm_num // 1000)
+        if k:
+            path += np.linalg.norm(Vr)
+            assert np.allclose(navs[0].Pos[:], nr.Pos[:], atol=1e-6 * path + 1e-9)
+        assert navs[0].V[:] == navs[1].V[:]
+    assert nr.pad0 > 1000
+    kg, mask = eh.download_keylines(0, eh.cur_slot())
+    kr = orc.keylines(orc.cur_slot())
+    assert np.array_equal(mask, orc.mask(orc.cur_slot()).reshape(H, W))
+    same = (kg["m_id"] == kr["m_id"]) & (kg["stereo_m_id"] == kr["stereo_m_id"])
+    assert same.mean() > 0.995
+    for f in ("rho", "s_rho", "rho0", "s_rho0", "stereo_rho", "stereo_s_rho"):
+        assert np.allclose(kg[f][same], kr[f][same], rtol=1e-5, atol=1e-7), f
