@@ -17,6 +17,10 @@
 //  * ImuMode 1 (samples pushed with pushIMU) and 2 (IMU csv data set) run the IMU branch of SecondThread
 //    (rebvo_second_t.cpp:182-336, 519-544): gyro pre-rotation, Minimizer_V and ExtRotVel on the GPU, BiasCorrect and
 //    the ScaleEstimator filters on the host (rebvo/imu.h).  The pose-graph log (cf->poses) and key frames do not exist.
+//  * StereoAvaiable runs the stereo depth steps of SecondThread (pair image through stage A with the &Stereo
+//    intrinsics, stereo-mode directed matching, directed_matching_stereo with the rig hard-coded in
+//    rebvo_second_t.cpp:466-470, fuseStereoDepth, Kp = 1) on the GPU; PipeBuffer::imgc_pair is filled, ::ef_pair /
+//    ::ss_pair stay null, ::stereo_match_num is set.
 //  * PipeBuffer::ss and ::gt are null (scale space and auxiliary field stay in HBM); PipeBuffer::ef is a
 //    host view with the edge_finder members consumers use: KNum(), operator[], begin()/end(), GetCam(),
 //    getThresh(), NumMatches().
@@ -206,6 +210,8 @@ struct REBVOParameters {
     Size2D ImageSize = {0, 0};
     float z_f_x = 0, z_f_y = 0, pp_y = 0, pp_x = 0;
     cam_model::rad_tan_distortion kc;
+    float z_f_x_stereo = 0, z_f_y_stereo = 0, pp_y_stereo = 0, pp_x_stereo = 0;   // &Stereo section (StereoAvaiable)
+    cam_model::rad_tan_distortion kc_stereo;
     double config_fps = 30, soft_fps = 30;
     bool useUndistort = false, rotatedCam = false;
     std::string CameraDevice;
@@ -313,15 +319,21 @@ class REBVO {
     Pipeline<PipeBuffer> pipe;
     std::atomic_bool system_reset;
     Pipeline<customCam::CustomCamPipeBuffer> cam_pipe;
+    Pipeline<customCam::CustomCamPipeBuffer> cam_pipe_stereo;   // pair camera (StereoAvaiable, CameraType 3)
     cam_model cam;
+    cam_model cam_stereo;
     std::mutex call_mutex;
     std::function<bool(PipeBuffer &)> outputFunc;
     edgehip_ctx *hip = nullptr;
     DataSetCam *dscam = nullptr;   // CameraType == 2
+    DataSetCam *dscam_pair = nullptr;   // its stereo pair (DataSetDirStereo / DataSetFileStereo)
     ImuGrabber *imu = nullptr;     // ImuMode > 0
     struct ImuTrack;               // SecondThread's IMU-branch locals (rebvo_imu.cpp)
     ImuTrack *imutrack = nullptr;
     std::string last_error;
+
+    // the stereo rig SecondThread hard-codes (rebvo_second_t.cpp:466-470; EuRoC cam0 -> cam1)
+    static const double kRCam2Pair[9], kTCam2Pair[3];
 
     bool callCallBack(PipeBuffer &pbuf) {
         std::lock_guard<std::mutex> locker(call_mutex);
@@ -386,6 +398,15 @@ public:
         return true;
     }
     void releaseCustomCamBuffer() { cam_pipe.ReleaseBuffer(0); }
+    // the pair camera's ring (reference rebvo.h:570-586); one pair frame is consumed per accepted main frame
+    bool requestStereoCustomCamBuffer(std::shared_ptr<Image<RGB24Pixel>> &ptr, double time_stamp, double timeout_secs = 0) {
+        customCam::CustomCamPipeBuffer *ccpb = cam_pipe_stereo.RequestBufferTimeoutable(0, timeout_secs);
+        if (ccpb == nullptr) return false;
+        ptr = (*ccpb).img;
+        (*ccpb).timestamp = time_stamp;
+        return true;
+    }
+    void releaseStereoCustomCamBuffer() { cam_pipe_stereo.ReleaseBuffer(0); }
 
     template <typename T>
     void setOutputCallback(bool (T::*method)(PipeBuffer &), T *obj) {

@@ -130,9 +130,14 @@ void lie2quat(const Vector3 &W, double q[4]) {
 
 }  // namespace
 
+const double REBVO::kRCam2Pair[9] = {0.999997256477450, 0.002312067192420, 0.000376008102351,
+                                     -0.002317135723285, 0.999898048506528, 0.014089835846697,
+                                     -0.000343393120589, -0.014090668452670, 0.999900662638179};
+const double REBVO::kTCam2Pair[3] = {-0.110073808127139, 0.000399121547014, -0.000853702503351};
+
 // ---- construction -------------------------------------------------------------------------------------------
 REBVO::REBVO(const char *configFile)
-    : quit(true), pipe(CBUFSIZE, 3), system_reset(false), cam_pipe(CCAMBUFSIZE, 2), outputFunc(nullptr) {
+    : quit(true), pipe(CBUFSIZE, 3), system_reset(false), cam_pipe(CCAMBUFSIZE, 2), cam_pipe_stereo(CCAMBUFSIZE, 2), outputFunc(nullptr) {
     Configurator config;
     if (!(InitOK = config.ParseConfigFile(configFile))) return;
     REBVOParameters &p = params;
@@ -222,13 +227,28 @@ REBVO::REBVO(const char *configFile)
     config.get("Camera", "Rotate180", p.rotatedCam, false);
     config.get("REBVO", "VideoNetEnabled", p.VideoNetEnabled, false);
     config.get("REBVO", "TrackKeyFrames", p.TrackKeyFrames, false);
-    config.get("REBVO", "StereoAvaiable", p.StereoAvaiable, false);
+    if (config.get("REBVO", "StereoAvaiable", p.StereoAvaiable, false) && p.StereoAvaiable) {   // src/rebvo/rebvo.cpp:195-216
+        InitOK &= config.get("DataSetCamera", "DataSetDirStereo", p.DataSetDirStereo);
+        InitOK &= config.get("DataSetCamera", "DataSetFileStereo", p.DataSetFileStereo);
+        InitOK &= config.get("Stereo", "ZfX", p.z_f_x_stereo);
+        InitOK &= config.get("Stereo", "ZfY", p.z_f_y_stereo);
+        InitOK &= config.get("Stereo", "PPx", p.pp_x_stereo);
+        InitOK &= config.get("Stereo", "PPy", p.pp_y_stereo);
+        InitOK &= config.get("Stereo", "KcR2", p.kc_stereo.Kc2);
+        InitOK &= config.get("Stereo", "KcR4", p.kc_stereo.Kc4);
+        InitOK &= config.get("Stereo", "KcR6", p.kc_stereo.Kc6);
+        InitOK &= config.get("Stereo", "KcP1", p.kc_stereo.P1);
+        InitOK &= config.get("Stereo", "KcP2", p.kc_stereo.P2);
+    } else {
+        p.StereoAvaiable = false;
+    }
     config.get("GPU", "Device", p.GpuDevice, false);
     construct();
 }
 
 REBVO::REBVO(const REBVOParameters &parameters)
-    : params(parameters), quit(true), pipe(CBUFSIZE, 3), system_reset(false), cam_pipe(CCAMBUFSIZE, 2), outputFunc(nullptr) {
+    : params(parameters), quit(true), pipe(CBUFSIZE, 3), system_reset(false), cam_pipe(CCAMBUFSIZE, 2), cam_pipe_stereo(CCAMBUFSIZE, 2),
+      outputFunc(nullptr) {
     construct();
 }
 
@@ -264,10 +284,18 @@ void REBVO::construct() {
     }
     for (unsigned i = 0; i < cam_pipe.Size(); i++)   // rebvo.cpp:284-285
         cam_pipe[i].img = std::make_shared<Image<RGB24Pixel>>(params.ImageSize);
+    cam_stereo = cam;
+    if (params.StereoAvaiable) {
+        cam_stereo = cam_model({params.pp_x_stereo, params.pp_y_stereo}, {params.z_f_x_stereo, params.z_f_y_stereo}, params.kc_stereo,
+                               params.ImageSize);
+        for (unsigned i = 0; i < cam_pipe_stereo.Size(); i++)
+            cam_pipe_stereo[i].img = std::make_shared<Image<RGB24Pixel>>(params.ImageSize);
+    }
     for (PipeBuffer &pbuf : pipe) {                  // rebvo.cpp:297-312 (host views only; the rest lives in HBM)
         pbuf.ef = new edge_tracker(cam, params.MaxPoints > 0 ? params.MaxPoints : 1);
         pbuf.img = new Image<float>(params.ImageSize);
         pbuf.imgc = new Image<RGB24Pixel>(params.ImageSize);
+        pbuf.imgc_pair = params.StereoAvaiable ? new Image<RGB24Pixel>(params.ImageSize) : nullptr;
         pbuf.ss = nullptr;
         pbuf.gt = nullptr;
     }
@@ -281,6 +309,7 @@ REBVO::~REBVO() {
             delete pbuf.ef;
             delete pbuf.img;
             delete pbuf.imgc;
+            delete pbuf.imgc_pair;
         }
 }
 
@@ -308,12 +337,30 @@ bool REBVO::Init() {
         return false;
     }
     if (params.ImuMode > 0) imuTrackInit();
+    if (params.CameraType == 2 && params.StereoAvaiable) {   // REBVO::initPairCamera, src/rebvo/rebvo_first_t.cpp:64-76
+        dscam_pair = new DataSetCam(params.DataSetDirStereo.data(), params.DataSetFileStereo.data(), params.ImageSize, params.CamTimeScale);
+        if (dscam_pair->Error()) {
+            last_error = "REBVO: Failed to initialize the stereo camera (dataset list " + params.DataSetFileStereo + ")";
+            std::cout << last_error << "\n";
+            delete dscam_pair;
+            dscam_pair = nullptr;
+            return false;
+        }
+    }
     edgehip_params hp;
     fill_hip_params(params, hp);
-    const int rc = edgehip_create(&hp, 1, 3, params.GpuDevice, &hip);
+    hp.stereo_available = params.StereoAvaiable ? 1 : 0;
+    // ring of 3 frame slots; with a stereo pair one more slot, behind the ring, holds the pair image's edge map
+    int rc = edgehip_create(&hp, 1, params.StereoAvaiable ? 4 : 3, params.GpuDevice, &hip);
+    if (rc == 0 && params.StereoAvaiable) {
+        // search radius 100 (rebvo_second_t.cpp:473); with the IMU branch the host drives the stereo stages itself
+        rc = edgehip_set_slot_camera(hip, 3, params.pp_x_stereo, params.pp_y_stereo, params.z_f_x_stereo, params.z_f_y_stereo);
+        if (rc == 0 && params.ImuMode == 0) rc = edgehip_set_stereo_rig(hip, 3, kTCam2Pair, kRCam2Pair, 100.0);
+    }
     if (rc != 0) {   // no CPU fallback: fail loudly
         last_error = std::string("REBVO(hip): edgehip_create failed: ") + edgehip_last_error();
         std::cout << last_error << "\n";
+        if (hip) edgehip_destroy(hip);
         hip = nullptr;
         return false;
     }
@@ -328,6 +375,7 @@ bool REBVO::CleanUp() {
     if (hip) { edgehip_destroy(hip); hip = nullptr; }
     imuTrackFree();
     if (dscam) { delete dscam; dscam = nullptr; }
+    if (dscam_pair) { delete dscam_pair; dscam_pair = nullptr; }
     return true;
 }
 
@@ -376,6 +424,27 @@ void REBVO::TrackThread(REBVO *cf) {
             data = cbuf->img->Data();
             break;
         }
+        // ---- the stereo pair: one frame per accepted main frame, no drop logic (rebvo_first_t.cpp:183-199) ----
+        customCam::CustomCamPipeBuffer *cbuf_pair = nullptr;
+        const RGB24Pixel *data_pair = nullptr;
+        if (data && cf->params.StereoAvaiable) {
+            double t_stereo = 0;
+            if (cf->dscam_pair) {
+                data_pair = cf->dscam_pair->GrabBuffer(t_stereo, false);
+            } else {
+                while ((cbuf_pair = cf->cam_pipe_stereo.RequestBufferTimeoutable(1, 0.001)) == nullptr)
+                    if (cf->quit) break;
+                if (cbuf_pair) { data_pair = cbuf_pair->img->Data(); t_stereo = cbuf_pair->timestamp; }
+            }
+            if (!data_pair) {
+                std::cout << "bye bye cruel world on stereo\n";
+                if (cbuf) cf->cam_pipe.ReleaseBuffer(1);
+                else cf->dscam->ReleaseBuffer();
+                data = nullptr;
+            } else if (std::fabs(t - t_stereo) > 0.5 / cf->params.config_fps) {
+                std::cout << "REBVO Warning: cameras are unsync: " << t - t_stereo << "\n";
+            }
+        }
         if (!data) {   // quitting or camera error: pass the flag down the ring (rebvo_first_t.cpp:165-170)
             new_buf.quit = true;
             cf->pipe.ReleaseBuffer(0);
@@ -389,6 +458,12 @@ void REBVO::TrackThread(REBVO *cf) {
         std::memcpy(new_buf.imgc->Data(), data, frame_bytes);
         if (cbuf) cf->cam_pipe.ReleaseBuffer(1);
         else cf->dscam->ReleaseBuffer();
+        if (data_pair) {   // the pair image goes to the slot behind the ring
+            if (rc == 0) rc = edgehip_upload_rgb(cf->hip, 3, reinterpret_cast<const uint8_t *>(data_pair), 0, 1);
+            std::memcpy(new_buf.imgc_pair->Data(), data_pair, frame_bytes);
+            if (cbuf_pair) cf->cam_pipe_stereo.ReleaseBuffer(1);
+            else cf->dscam_pair->ReleaseBuffer();
+        }
         if (imu_mode) {   // inter-frame IMU data, waiting for the samples to arrive (rebvo_first_t.cpp:294-304)
             while (!cf->quit) {
                 new_buf.imu = cf->imu->GrabAndIntegrate(t0 + cf->params.TimeDesinc, t + cf->params.TimeDesinc);
@@ -418,6 +493,11 @@ void REBVO::TrackThread(REBVO *cf) {
                 new_buf.ef->reTunedThresh = n.retuned_thresh;
                 if (old_buf) fill_nav(n, new_buf.nav);
                 else new_buf.nav = NavData();   // first frame: "dummy processing", no estimate (rebvo_second_t.cpp:108-121)
+                new_buf.stereo_match_num = 0;
+                if (cf->params.StereoAvaiable && old_buf && n.estimation_ok) {
+                    int32_t nm = 0;
+                    if (edgehip_get_stereo_matches(cf->hip, &nm) == 0) new_buf.stereo_match_num = nm;
+                }
             }
         }
         if (rc != 0) {

@@ -102,6 +102,8 @@ int REBVO::trackFrameImu(int sn, int so, bool have_pair, double t, PipeBuffer &n
     ImuTrack &s = *imutrack;
     int rc = 0;
     EH(edgehip_stage_a(hip, sn));   // FirstThr: scale space, KeyLines, auto threshold (rebvo_first_t.cpp:259-272)
+    if (p.StereoAvaiable) EH(edgehip_stage_a(hip, 3));   // the pair image (slot behind the ring), :275-290
+    new_buf.stereo_match_num = 0;
     int32_t kn = 0;
     edgehip_seq_state st;
     if (!have_pair) {               // "dummy processing of the first frame" (rebvo_second_t.cpp:108-121)
@@ -247,10 +249,20 @@ int REBVO::trackFrameImu(int sn, int so, bool have_pair, double t, PipeBuffer &n
             std::printf("\nCamara Frontal: restarting the estimation, match threshold low (%d,%d)?\n", kn, klm_num);
         } else {
             EH(edgehip_regularize_ekf(hip, sn, 1, 1));                        // :453, :460
-            EH(edgehip_rescale(hip, sn));                                     // :487
-            EH(edgehip_get_state(hip, 0, &st));
-            s.Kp = st.Kp;
-            s.P_Kp = st.P_Kp;
+            if (p.StereoAvaiable) {                                           // :465-486
+                int32_t nm = 0;
+                EH(edgehip_directed_matching_stereo(hip, sn, 3, kTCam2Pair, kRCam2Pair, p.MatchThreshModule, p.MatchThreshAngle, 100,
+                                                    p.LocationUncertaintyMatch, p.ReshapeQAbsolute, p.ReshapeQRelative,
+                                                    p.LocationUncertainty, &nm));
+                new_buf.stereo_match_num = nm;
+                EH(edgehip_fuse_stereo_depth(hip, sn));
+                s.Kp = 1;
+            } else {
+                EH(edgehip_rescale(hip, sn));                                 // :487
+                EH(edgehip_get_state(hip, 0, &st));
+                s.Kp = st.Kp;
+                s.P_Kp = st.P_Kp;
+            }
         }
     }
 

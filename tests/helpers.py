@@ -38,10 +38,11 @@ def rel_err(a, b):
     return float(np.max(np.abs(a - b)) / (np.max(np.abs(b)) + 1e-300))
 
 
-def write_global_config(path, p, log_file="", tray_file="", save_log=0, camera_type=3, drop=(), dataset=None, imu=None):
+def write_global_config(path, p, log_file="", tray_file="", save_log=0, camera_type=3, drop=(), dataset=None, imu=None, stereo=None):
     """A GlobalConfig file in the reference's format (app/rebvorun/GlobalConfig_EuRoC) from a Params struct.
     `drop` lists "Section/Key" entries to leave out (missing-key error tests).  `imu` = dict(mode=1|2, file=..., se3=...,
-    time_scale=..., plus any key of the &IMU section to override) switches the IMU branch on."""
+    time_scale=..., plus any key of the &IMU section to override) switches the IMU branch on.  `stereo` = dict(dir=..., file=...,
+    ppx=, ppy=, zfx=, zfy=) sets StereoAvaiable with the pair camera's list and the &Stereo intrinsics."""
     sec = {
         "Detector": [("Sigma0", p.sigma0), ("KSigma", p.ksigma), ("ReferencePoints", p.reference_points),
                      ("MaxPoints", p.max_points), ("TrackPoints", p.track_points), ("DetectorThresh", p.detector_thresh),
@@ -77,8 +78,14 @@ def write_global_config(path, p, log_file="", tray_file="", save_log=0, camera_t
         if "se3" in imu:
             sec["IMU"].append(("CamImuSE3File", imu["se3"]))
         sec["IMU"] += list(keys.items())
+    if stereo is not None:
+        sec["REBVO"] = [(k, (1 if k == "StereoAvaiable" else v)) for k, v in sec["REBVO"]]
+        sec["Stereo"] = [("ZfX", stereo["zfx"]), ("ZfY", stereo["zfy"]), ("PPx", stereo["ppx"]), ("PPy", stereo["ppy"]),
+                         ("KcR2", 0), ("KcR4", 0), ("KcR6", 0), ("KcP1", 0), ("KcP2", 0)]
     if dataset is not None:   # (DataSetDir, DataSetFile, TimeScale)
         sec["DataSetCamera"] = [("DataSetDir", dataset[0]), ("DataSetFile", dataset[1]), ("TimeScale", dataset[2])]
+        if stereo is not None:
+            sec["DataSetCamera"] += [("DataSetDirStereo", stereo["dir"]), ("DataSetFileStereo", stereo["file"])]
     with open(path, "w") as f:
         f.write("// generated by tests/helpers.py\n")
         for name, items in sec.items():

@@ -6,12 +6,14 @@ A main-camera sequence gives KeyLines with converged depth; the pair image is th
 EuRoC-like baseline hard-coded in rebvo_second_t.cpp:466-470, through slightly different intrinsics.
 Match ids and counts: exact.  stereo_rho / stereo_s_rho and the fused depth: the same fp64 expressions -> 1e-12."""
 import copy
+import os
+import subprocess
 
 import numpy as np
 import pytest
 
 from rebvo_amd import edgehip, synth
-from tests.helpers import to_edgehip_kl
+from tests.helpers import to_edgehip_kl, write_global_config
 
 pytestmark = pytest.mark.gpu
 W, H, NF = 376, 240, 6
@@ -213,3 +215,54 @@ def test_stereo_whole_frame_matches_reference():
     assert same.mean() > 0.995
     for f in ("rho", "s_rho", "rho0", "s_rho0", "stereo_rho", "stereo_s_rho"):
         assert np.allclose(kg[f][same], kr[f][same], rtol=1e-5, atol=1e-7), f
+
+
+def test_host_stereo_replay(tmp_path):
+    """StereoAvaiable through the host library: an EuRoC-layout data set with cam0 and cam1 lists, the &Stereo
+    intrinsics and the hard-coded rig, replayed by dataset_replay and compared with the reference's stereo sequence."""
+    from oracle import oracle
+    PIL = pytest.importorskip("PIL.Image")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exe = os.path.join(root, "rebvo_amd", "lib", "dataset_replay")
+    if not oracle.available("ref") or not os.path.exists(exe):
+        pytest.skip("needs oracle/_ref and dataset_replay")
+    nf = 8
+    p, frames, pairs, pc = make_data(all_pairs=True, nf=nf)
+    t_ns = [1403636579763555584 + 50_000_000 * k for k in range(nf)]
+    dirs = {}
+    for cam, imgs in (("cam0", frames), ("cam1", pairs)):
+        d = tmp_path / "mav0" / cam
+        (d / "data").mkdir(parents=True)
+        with open(d / "data.csv", "w") as f:
+            f.write("#timestamp [ns],filename\n")
+            for k, fr in enumerate(imgs):
+                PIL.fromarray(fr[:, :, 0], "L").save(d / "data" / f"{t_ns[k]}.png")
+                f.write(f"{t_ns[k]},{t_ns[k]}.png\n")
+        dirs[cam] = d
+    cfg, dump = tmp_path / "cfg", tmp_path / "dump.txt"
+    write_global_config(cfg, edgehip.euroc_params(W, H), camera_type=2,
+                        dataset=(str(dirs["cam0"] / "data") + "/", str(dirs["cam0"] / "data.csv"), 1e-9),
+                        stereo=dict(dir=str(dirs["cam1"] / "data") + "/", file=str(dirs["cam1"] / "data.csv"), **pc))
+    r = subprocess.run([exe, str(cfg), str(dump)], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
+    rows = np.loadtxt(dump, ndmin=2)
+    assert len(rows) == nf - 1
+    orc = oracle.Oracle("ref", oracle.euroc_params(W, H))
+    orc.enable_stereo(pc["ppx"], pc["ppy"], pc["zfx"], pc["zfy"], T_PAIR, R_PAIR, 100.0)
+    path, prev = 0.0, None
+    for k in range(nf):
+        t = float(np.float64(t_ns[k]) * 1e-9)
+        _, nav = orc.process_frame_stereo(frames[k], pairs[k], t)
+        if k == 0:
+            prev = nav
+            continue
+        row = rows[k - 1]                       # frame k-1 is delivered after frame k was tracked
+        kl = orc.keylines((k - 1) % 8)
+        assert int(row[0]) == k - 1 and int(row[2]) == len(kl)
+        if k - 1 > 0:
+            path += np.linalg.norm(prev.V[:])
+            assert np.allclose(row[5:8], prev.Pos[:], atol=1e-6 * path + 1e-9)
+            assert row[27] == 1.0              # Kp = 1 with stereo
+        assert abs(row[14] - kl["rho"].sum()) <= 1e-6 * abs(kl["rho"].sum()) + 1e-9
+        prev = nav
+    assert "Loaded 8 File names" in r.stdout
