@@ -143,6 +143,10 @@ void ref_enable_stereo(void *ctx, double ppx, double ppy, double zfx, double zfy
                        double max_radius);
 int ref_process_frame_stereo(void *ctx, const uint8_t *rgb24, const uint8_t *rgb24_pair, double t, OrcNav *nav);
 
+/* ---- visualizer wire format: copy_net_keyline / copy_net_keyline_nextid, 15-byte records ---- */
+int ref_copy_net_keyline(void *ctx, int slot, int slot_pair /* -1: none */, void *out, int kl_size, double k_prof);
+int ref_copy_net_keyline_nextid(void *ctx, int slot, void *out, int kl_size);
+
 /* ---- IMU branch: reference only.  The restatement under test is the host library
  * (rebvo_amd/host/src/imu.cpp, rebvo_imu.cpp); these entry points run the reference's own ImuGrabber, BiasCorrect and
  * ScaleEstimator, and ref_process_frame_imu restates the ImuMode > 0 sequencing of rebvo_second_t.cpp over them.

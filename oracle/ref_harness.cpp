@@ -23,6 +23,7 @@
 #include "VideoLib/image_undistort.h"
 #include "mtracklib/scaleestimator.h"
 #include "UtilLib/imugrabber.h"
+#include "CommLib/net_keypoint.h"
 // TryVelRot<> is only defined in the .cpp; include it so the harness can instantiate it directly.
 #include "src/mtracklib/global_tracker.cpp"
 
@@ -552,6 +553,15 @@ int ref_process_frame(void *ctx, const uint8_t *rgb24, double t, OrcNav *nav) {
 }
 
 }  // extern "C"
+
+// the visualizer wire format (src/CommLib/net_keypoint.cpp:29-108); 15-byte records
+extern "C" int ref_copy_net_keyline(void *ctx, int slot, int slot_pair, void *out, int kl_size, double k_prof) {
+    Ctx *c = (Ctx *)ctx;
+    return copy_net_keyline(*c->slots[slot].ef, slot_pair >= 0 ? c->slots[slot_pair].ef : nullptr, (net_keyline *)out, kl_size, k_prof);
+}
+extern "C" int ref_copy_net_keyline_nextid(void *ctx, int slot, void *out, int kl_size) {
+    return copy_net_keyline_nextid(*((Ctx *)ctx)->slots[slot].ef, (net_keyline *)out, kl_size);
+}
 
 extern "C" int ref_process_frame_stereo(void *ctx, const uint8_t *rgb24, const uint8_t *rgb24_pair, double t, OrcNav *nav) {
     Ctx *c = (Ctx *)ctx;
