@@ -139,6 +139,12 @@ int edgehip_box_widths(edgehip_ctx *ctx, int out[6]);
 int edgehip_upload_rgb(edgehip_ctx *ctx, int slot, const uint8_t *rgb24, int seq_first, int count);
 /* Same, from device memory ([nseq][h][w][3], all sequences), device-to-device on the context stream. */
 int edgehip_upload_rgb_device(edgehip_ctx *ctx, int slot, const void *rgb24_dev);
+/* Host frames without the staging copy: the source is page-locked memory from edgehip_alloc_pinned (count frames for
+ * sequences seq_first .. seq_first+count-1) and is read by an asynchronous copy — leave it untouched until the next
+ * call that synchronises (edgehip_sync, edgehip_read_nav, ...) or write the next frames into a second buffer. */
+int edgehip_alloc_pinned(size_t bytes, void **out);
+int edgehip_free_pinned(void *p);
+int edgehip_upload_rgb_pinned(edgehip_ctx *ctx, int slot, const uint8_t *rgb24_pinned, int seq_first, int count);
 
 /* Bench/replay helper: frame pool resident in HBM ([pool_frames][h][w][3]); sequence s takes frame
  * idx[s] (host array, nseq entries).  One gather kernel on the context stream. */

@@ -533,6 +533,24 @@ int edgehip_upload_rgb(edgehip_ctx *c, int slot, const uint8_t *rgb24, int seq_f
     return 0;
 }
 
+// Page-locked host memory for frames that go straight to the device (no staging copy)
+int edgehip_alloc_pinned(size_t bytes, void **out) {
+    if (!out || bytes == 0) return EDGEHIP_ERR_ARG;
+    EH_CHECK(hipHostMalloc(out, bytes, hipHostMallocDefault));
+    return 0;
+}
+int edgehip_free_pinned(void *p) {
+    if (p) EH_CHECK(hipHostFree(p));
+    return 0;
+}
+int edgehip_upload_rgb_pinned(edgehip_ctx *c, int slot, const uint8_t *rgb24_pinned, int seq_first, int count) {
+    if (int e = check_slot(c, slot)) return e;
+    if (!rgb24_pinned || seq_first < 0 || count < 1 || seq_first + count > c->plan.nseq) { set_error("upload_rgb_pinned: bad range"); return EDGEHIP_ERR_ARG; }
+    const size_t fb = (size_t)c->plan.n * 3;
+    EH_CHECK(hipMemcpyAsync(rgbof(c, slot) + fb * seq_first, rgb24_pinned, fb * count, hipMemcpyHostToDevice, c->stream_a));
+    return 0;
+}
+
 int edgehip_upload_rgb_device(edgehip_ctx *c, int slot, const void *rgb24_dev) {
     if (int e = check_slot(c, slot)) return e;
     if (!rgb24_dev) return EDGEHIP_ERR_ARG;

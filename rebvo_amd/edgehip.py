@@ -142,7 +142,7 @@ EXPORTS = [
     "edgehip_profile_count", "edgehip_profile_name", "edgehip_profile_read", "edgehip_profile_select",
     "edgehip_upload_rgb_indexed", "edgehip_set_nav_log", "edgehip_read_nav_log",
     "edgehip_build_undistort_map", "edgehip_download_undistorted", "edgehip_depth_reset", "edgehip_depth_reset_slot", "edgehip_set_slot_camera", "edgehip_directed_matching_stereo",
-    "edgehip_fuse_stereo_depth", "edgehip_set_stereo_rig", "edgehip_get_stereo_matches", "edgehip_minimizer_v", "edgehip_ext_rot_vel",
+    "edgehip_alloc_pinned", "edgehip_free_pinned", "edgehip_upload_rgb_pinned", "edgehip_fuse_stereo_depth", "edgehip_set_stereo_rig", "edgehip_get_stereo_matches", "edgehip_minimizer_v", "edgehip_ext_rot_vel",
 ]
 
 _lib = None
@@ -361,6 +361,22 @@ class EdgeHip:
 
     def cur_slot(self):
         return self.lib.edgehip_cur_slot(self.ctx)
+
+    def alloc_pinned_frames(self, count=None):
+        """Page-locked uint8 array [count][h][w][3] for upload_rgb_pinned (free with free_pinned)."""
+        count = self.nseq if count is None else count
+        nbytes = count * self.h * self.w * 3
+        ptr = C.c_void_p()
+        self._ck(self.lib.edgehip_alloc_pinned(C.c_size_t(nbytes), C.byref(ptr)))
+        buf = (C.c_uint8 * nbytes).from_address(ptr.value)
+        arr = np.frombuffer(buf, np.uint8).reshape(count, self.h, self.w, 3)
+        return arr, ptr
+
+    def free_pinned(self, ptr):
+        self._ck(self.lib.edgehip_free_pinned(ptr))
+
+    def upload_rgb_pinned(self, slot, ptr, seq_first=0, count=None):
+        self._ck(self.lib.edgehip_upload_rgb_pinned(self.ctx, slot, ptr, seq_first, self.nseq if count is None else count))
 
     def process_frame(self, t):
         t = np.ascontiguousarray(np.broadcast_to(np.asarray(t, np.float64), (self.nseq,)))
