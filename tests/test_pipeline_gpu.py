@@ -166,3 +166,44 @@ def test_reset_mid_sequence_matches_reference():
     same = kg["m_id"] == kr["m_id"]
     assert same.mean() > 0.999 and np.allclose(kg["rho"][same], kr["rho"][same], rtol=1e-5, atol=1e-7)
     eh.close()
+
+
+def test_pipeline_batch_of_different_sequences():
+    """Three DIFFERENT sequences in one batch (different scenes and trajectories, different KeyLine counts, one of them
+    starting from a blank frame): every sequence must follow its own reference run — nothing leaks between the
+    per-sequence slices of the batched buffers."""
+    from oracle import oracle
+    if not oracle.available("ref"):
+        pytest.skip("oracle/_ref not built")
+    w, h, n = 376, 240, 7
+    seqs = [[f for f, _, _ in synth.billboard_sequence(w, h, n, seed=11, traj_seed=13)],
+            [f for f, _, _ in synth.billboard_sequence(w, h, n, seed=5, traj_seed=3)],
+            [np.repeat(f[:, :, None], 3, axis=2) if f.ndim == 2 else f for f in synth.rects_sequence(w, h, n)]]
+    seqs[2][0] = np.full_like(seqs[2][0], 40)          # a blank first frame: no KeyLines, then a hard start
+    orcs = [oracle.Oracle("ref", oracle.euroc_params(w, h)) for _ in seqs]
+    eh = edgehip.EdgeHip(edgehip.euroc_params(w, h), nseq=3, nslots=3)
+    kns = set()
+    for k in range(n):
+        refs = [orc.process_frame(s[k], 0.05 * k)[1] for orc, s in zip(orcs, seqs)]
+        eh.upload_rgb(eh.next_slot(), np.stack([s[k] for s in seqs]))
+        eh.process_frame(0.05 * k)
+        for ng, nr in zip(eh.read_nav(), refs):
+            assert ng.kn == nr.kn and ng.tresh == nr.tresh, k
+            kns.add(nr.kn)
+            if k == 0:
+                continue
+            assert ng.estimation_ok == nr.estimation_ok
+            Vr, Wr = np.array(nr.V[:]), np.array(nr.W[:])
+            step = np.linalg.norm(Vr) + np.linalg.norm(Wr)
+            assert np.allclose(ng.V[:], Vr, rtol=0, atol=1e-6 * step + 1e-9), (k, ng.V[:], Vr)
+            assert np.allclose(ng.W[:], Wr, rtol=0, atol=1e-6 * step + 1e-9)
+            assert abs(ng.klm_num - nr.klm_num) <= max(2, nr.klm_num // 1000)
+    assert len(kns) > 2 * n          # the sequences really differ
+    for s, orc in enumerate(orcs):
+        kg, mask = eh.download_keylines(s, eh.cur_slot())
+        kr = orc.keylines(orc.cur_slot())
+        assert np.array_equal(mask, orc.mask(orc.cur_slot()))
+        same = kg["m_id"] == kr["m_id"]
+        assert same.mean() > 0.995
+        assert np.allclose(kg["rho"][same], kr["rho"][same], rtol=1e-5, atol=1e-7)
+    eh.close()
