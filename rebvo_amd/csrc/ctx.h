@@ -100,18 +100,16 @@ struct DevicePlan {  // everything a kernel needs that is constant for the conte
     double zfm;                     // (double)((zfx+zfy)/2) computed in float (cam_model.h:57)
 };
 
-// round() as Image::GetIndexRC uses it (half away from zero), without the library call:
-//     copysign(floor(|v| + 0.5), v), with |v| < 0.5 -> 0.
-// In float32 the sum |v| + 0.5 is exact or rounds within the same integer cell for every |v| >= 0.5 (the operand and
-// the sum share a binade next to an integer boundary, or the sum's rounding step is below the distance to it); the
-// one value whose sum rounds ACROSS an integer is the predecessor of 0.5, which the explicit |v| < 0.5 case covers.
-// Checked against round() for every float in [0, 1), +-4 ulp around every multiple of 0.5 up to 1200 and 2 M random
-// values; 5 instructions instead of 8.
+// round() as Image::GetIndexRC uses it (half away from zero) for pixel coordinates, in 3 instructions.
+// v_cvt_rpi_i32_f32 converts with "round to nearest, ties towards +infinity", evaluated exactly (not as a float
+// addition of 0.5): for v >= 0 that IS half-away-from-zero; for v < 0 the two differ only on exact ties, where both
+// results are negative (an out-of-image coordinate either way) except v == -0.5 -> 0 instead of -1, fixed up below.
+// tools/experiments/cvt_rpi_check.hip compares it with round() over all 2^32 float bit patterns with |v| < 4096 on the
+// GPU: -0.5 is the only input whose result could select a different pixel.
 __device__ __forceinline__ int round_half_away_i(float v) {
-    const float a = fabsf(v);
-    float t = floorf(a + 0.5f);
-    t = a < 0.5f ? 0.f : t;
-    return (int)copysignf(t, v);
+    int r;
+    asm("v_cvt_rpi_i32_f32 %0, %1" : "=v"(r) : "v"(v));
+    return v == -0.5f ? -1 : r;
 }
 
 // The tracker field is stored in 4x4-pixel tiles of 64 B (tile-row-major, pixels row-major inside a tile): the
