@@ -106,11 +106,12 @@ struct DevicePlan {  // everything a kernel needs that is constant for the conte
 // results are negative (an out-of-image coordinate either way) except v == -0.5 -> 0 instead of -1, fixed up below.
 // tools/experiments/cvt_rpi_check.hip compares it with round() over all 2^32 float bit patterns with |v| < 4096 on the
 // GPU: -0.5 is the only input whose result could select a different pixel.
-__device__ __forceinline__ int round_half_away_i(float v) {
+__device__ __forceinline__ int round_ties_up_i(float v) {   // the bare conversion: differs from round() only as described above
     int r;
     asm("v_cvt_rpi_i32_f32 %0, %1" : "=v"(r) : "v"(v));
-    return v == -0.5f ? -1 : r;
+    return r;
 }
+__device__ __forceinline__ int round_half_away_i(float v) { return v == -0.5f ? -1 : round_ties_up_i(v); }
 
 // The tracker field is stored in 4x4-pixel tiles of 64 B (tile-row-major, pixels row-major inside a tile): the
 // TryVelRot gather touches one pixel per KeyLine, and the KeyLines of one edge sit on consecutive rows, so with a

@@ -31,6 +31,8 @@
 
 #include <vector>
 
+#include <type_traits>
+
 #include "ctx.h"
 
 namespace edgehip {
@@ -293,27 +295,38 @@ __global__ __launch_bounds__(256) void k_field_raster(const KlSoA *kls, const in
     // FSPLIT threads share one KeyLine's in-tile t-range: a bin holds ~170 KeyLines with ranges of 1..2r samples, so
     // one thread per KeyLine leaves a third of the lanes idle and the rest waiting for the longest range.
     constexpr int FSPLIT = 4;
-    for (int wi = tid; wi < cnt * FSPLIT; wi += 256) {
-        const int li = wi / FSPLIT, part = wi - li * FSPLIT;
-        const int ikl = list[li];
-        const MatchRec r = k.rec[ikl];
-        int t0, t1;
-        if (!tile_trange(r, tx0, ty0, radius, t0, t1)) continue;
-        {
-            const int chunk = (t1 - t0 + FSPLIT) / FSPLIT;   // ceil(len / FSPLIT)
-            t0 += part * chunk;
-            t1 = min(t1, t0 + chunk - 1);
+    // The hardware rounding differs from round() in a way that matters only for a coordinate of exactly -0.5 (pixel 0
+    // instead of -1, ctx.h): that can only be accepted by a tile that starts at column / row 0, so only the tiles on
+    // the left / top image border pay for the fix-up.  (Block-uniform choice of one of four loop bodies.)
+    auto raster = [&](auto fix_x, auto fix_y) {
+        for (int wi = tid; wi < cnt * FSPLIT; wi += 256) {
+            const int li = wi / FSPLIT, part = wi - li * FSPLIT;
+            const int ikl = list[li];
+            const MatchRec r = k.rec[ikl];
+            int t0, t1;
+            if (!tile_trange(r, tx0, ty0, radius, t0, t1)) continue;
+            {
+                const int chunk = (t1 - t0 + FSPLIT) / FSPLIT;   // ceil(len / FSPLIT)
+                t0 += part * chunk;
+                t1 = min(t1, t0 + chunk - 1);
+            }
+            const uint32_t idk = (uint32_t)(0xFFFF - ikl);
+            for (int t = t0; t <= t1; t++) {
+                const float fx = r.u_mx * (float)t + r.c_px;   // global_tracker.cpp:78, same float expression
+                const float fy = r.u_my * (float)t + r.c_py;
+                // Image::GetIndexRC uses round()
+                const int lx = (decltype(fix_x)::value ? round_half_away_i(fx) : round_ties_up_i(fx)) - tx0;
+                const int ly = (decltype(fix_y)::value ? round_half_away_i(fy) : round_ties_up_i(fy)) - ty0;
+                if ((unsigned)lx >= ex || (unsigned)ly >= ey) continue;
+                const uint32_t at = (uint32_t)(t < 0 ? -t : t);
+                atomicMin(&s_tile[ly * FT + lx], (at << 16) | idk);
+            }
         }
-        const uint32_t idk = (uint32_t)(0xFFFF - ikl);
-        for (int t = t0; t <= t1; t++) {
-            const float fx = r.u_mx * (float)t + r.c_px;   // global_tracker.cpp:78, same float expression
-            const float fy = r.u_my * (float)t + r.c_py;
-            const int lx = round_half_away_i(fx) - tx0, ly = round_half_away_i(fy) - ty0;  // Image::GetIndexRC uses round()
-            if ((unsigned)lx >= ex || (unsigned)ly >= ey) continue;
-            const uint32_t at = (uint32_t)(t < 0 ? -t : t);
-            atomicMin(&s_tile[ly * FT + lx], (at << 16) | idk);
-        }
-    }
+    };
+    using T = std::true_type;
+    using F = std::false_type;
+    if (tx0 == 0) { if (ty0 == 0) raster(T{}, T{}); else raster(T{}, F{}); }
+    else { if (ty0 == 0) raster(F{}, T{}); else raster(F{}, F{}); }
     __syncthreads();
     // store in the 4x4-tiled layout: 16 consecutive threads write one 64-B tile, a tile row of the block is 1 KB
     // contiguous (FT and the block origin are multiples of 4)
