@@ -725,24 +725,29 @@ __global__ __launch_bounds__(kDetWaves * 64) void k_detect(DetectArgs a) {
     uint16_t *s_list = reinterpret_cast<uint16_t *>(s_dog + (size_t)HR * w) + (size_t)wave * cpw * 64;
     int nlist = 0;
     if (!(a.ablate & 2)) {
+        // A band is a contiguous run of image rows and its LDS planes have the image's row pitch: pixel q of the band (in
+        // raster order) is image pixel y0*w + q and LDS element 2*w + q — no (row, column) arithmetic per pixel.  Only
+        // the column is tracked, for the two border columns on either side.
         int q = wave * cpw * 64 + lane;
-        int r = q / w, x = q - r * w;  // one division per thread; then advance by 64 pixels per chunk
+        int x = q % w;                                           // one division per thread; then advance by 64 pixels per chunk
+        const int q_end = min(npx, (h - 2 - y0) * w);            // rows y >= h-2 are not scanned (edge_finder.cpp:105)
+        int32_t *mrow = mask + (size_t)y0 * w;
+        const float *img0c = s_img0 + 2 * w;
         for (int ci = 0; ci < cpw; ci++, q += 64, x += 64) {
-            while (x >= w) { x -= w; r++; }
-            const int y = y0 + r;
+            while (x >= w) x -= w;
             bool pass = false;
-            if (q < npx && y < h - 2) {
+            if (q < q_end) {
                 // default: no KeyLine (edge_finder.cpp:109); border columns are never KeyLines either
-                mask[(size_t)y * w + x] = -1;
+                mrow[q] = -1;
                 if (x >= 2 && x < w - 2) {
-                    const float *c0 = s_img0 + (size_t)(r + 2) * w + x;
+                    const float *c0 = img0c + q;
                     const float dx = c0[1] - c0[-1];   // sspace.cpp:80
                     const float dy = c0[w] - c0[-w];   // sspace.cpp:81
                     if (a.planes) {
                         float *pl = a.planes + so;
                         const size_t pstride = (size_t)a.nseq * a.n;
-                        pl[3 * pstride + (size_t)y * w + x] = dx;
-                        pl[4 * pstride + (size_t)y * w + x] = dy;
+                        pl[3 * pstride + (size_t)y0 * w + q] = dx;
+                        pl[4 * pstride + (size_t)y0 * w + q] = dy;
                     }
                     const float n2g = dx * dx + dy * dy;
                     pass = !(n2g < thr_g);
@@ -772,9 +777,7 @@ __global__ __launch_bounds__(kDetWaves * 64) void k_detect(DetectArgs a) {
             uint16_t qv = 0;
             if (li < nlist) {
                 qv = s_list[li];
-                const int q = qv;
-                const int r = q / w, x = q - r * w;
-                const float *dg = s_dog + (size_t)(r + 2) * w + x;
+                const float *dg = s_dog + 2 * w + (int)qv;   // band pixel q = LDS element 2*w + q
                 int pn = 0;
 #pragma unroll
                 for (int i = -2; i <= 2; i++)
@@ -797,9 +800,8 @@ __global__ __launch_bounds__(kDetWaves * 64) void k_detect(DetectArgs a) {
         int pix = 0;
         if (li < nlist) {
             const int q = s_list[li];
-            const int r = q / w, x = q - r * w;
-            pix = (y0 + r) * w + x;
-            const float *dg = s_dog + (size_t)(r + 2) * w + x;
+            pix = y0 * w + q;                                // = (y0 + r) * w + x
+            const float *dg = s_dog + 2 * w + q;
             double t0 = 0, t1 = 0, t2 = 0;
 #pragma unroll
             for (int i = -2, k = 0; i <= 2; i++) {
