@@ -778,11 +778,12 @@ __global__ __launch_bounds__(kDetWaves * 64) void k_detect(DetectArgs a) {
             if (li < nlist) {
                 qv = s_list[li];
                 const float *dg = s_dog + 2 * w + (int)qv;   // band pixel q = LDS element 2*w + q
-                int pn = 0;
+                int npos = 0;   // pn = (#positive) - (#not positive) = 2*npos - 25
 #pragma unroll
                 for (int i = -2; i <= 2; i++)
 #pragma unroll
-                    for (int j = -2; j <= 2; j++) pn += (dg[i * w + j] > 0) ? 1 : -1;
+                    for (int j = -2; j <= 2; j++) npos += (dg[i * w + j] > 0) ? 1 : 0;
+                const int pn = 2 * npos - 25;
                 const int apn = pn < 0 ? -pn : pn;
                 keep = !((double)apn > a.pn_thresh);
             }
