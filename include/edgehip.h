@@ -246,7 +246,9 @@ int edgehip_get_stereo_matches(edgehip_ctx *ctx, int32_t *nmatch);
  * The frame must have been uploaded into edgehip_next_slot() first.  t[nseq] = frame time stamps.
  * Uploads and stage A are enqueued on a second HIP stream; with EDGEHIP_OVERLAP=1 in the environment at
  * edgehip_create() time, stage A of this frame only waits for the B/C work that still reads the slot it overwrites
- * and so runs under the tracking/mapping of the previous frame (the reference's T0 || T1 pipelining). */
+ * and so runs under the tracking/mapping of the previous frame (the reference's T0 || T1 pipelining).
+ * With EDGEHIP_GRAPH=1 the launches of a frame are captured into HIP graphs (one per ring-slot / FrameCount-row
+ * combination) the first time they occur and replayed afterwards. */
 int edgehip_process_frame(edgehip_ctx *ctx, const double *t);
 int edgehip_next_slot(edgehip_ctx *ctx);
 int edgehip_cur_slot(edgehip_ctx *ctx);

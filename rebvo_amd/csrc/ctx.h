@@ -13,6 +13,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <string>
+#include <map>
 #include <vector>
 
 #include "edgehip.h"
@@ -174,6 +175,11 @@ struct edgehip_ctx {
     double *resid_carry;   // [kResidBufs][B][nblk_tvr] last valid residual per block
     double *partials;      // [B][nblk_tvr][kNumSums]
     double *block_last;    // [B][nblk_tvr] last valid residual of each block of the running evaluation
+    // Whole-frame HIP graphs (edgehip_process_frame): a frame is ~75 launches whose arguments repeat with the ring slot
+    // and the FrameCount row, i.e. with period lcm(ring, 8); each variant is captured the first time it comes up and
+    // replayed afterwards.  Pays when the batch is small and the frame is launch-bound (a single live camera).
+    bool use_graph;
+    std::map<int, hipGraphExec_t> frame_graphs;
     struct StereoRig {                // edgehip_set_stereo_rig: the pair camera of edgehip_process_frame
         bool enabled = false;
         int slot_pair = -1;
@@ -254,6 +260,7 @@ struct ProfScope {  // RAII bracket; no-op unless profiling is enabled
 int stage_a_enqueue(edgehip_ctx *c, int slot);
 // ordering between the two streams for entry points that are not edgehip_process_frame: everything enqueued so far on
 // one stream is finished before anything enqueued afterwards on the other starts
+void drop_frame_graphs(edgehip_ctx *c);   // after anything that changes what a captured frame would enqueue
 int order_a_after_bc(edgehip_ctx *c);
 int order_bc_after_a(edgehip_ctx *c);
 int sync_all(edgehip_ctx *c);

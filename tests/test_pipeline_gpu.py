@@ -207,3 +207,10 @@ def test_pipeline_batch_of_different_sequences():
         assert same.mean() > 0.995
         assert np.allclose(kg["rho"][same], kr["rho"][same], rtol=1e-5, atol=1e-7)
     eh.close()
+
+
+def test_pipeline_with_frame_graphs(monkeypatch):
+    """EDGEHIP_GRAPH=1: the frame's launches are captured into HIP graphs (24 variants: ring slot x FrameCount row) and
+    replayed; 30 frames so that every variant is captured AND replayed, results as without graphs."""
+    monkeypatch.setenv("EDGEHIP_GRAPH", "1")
+    _run(376, 240, 30)
