@@ -109,3 +109,33 @@ def test_max_width_1024_and_max_points_cap():
     _, mask = eh.download_keylines(0, eh.cur_slot())
     assert np.array_equal(mask, orc.mask(orc.cur_slot()))
     eh.close()
+
+
+def test_pinned_upload_equals_staged_upload():
+    """edgehip_upload_rgb_pinned (page-locked source, no staging copy) puts the same frames on the device as
+    edgehip_upload_rgb: stage A results are identical, for a sub-range of the batch too."""
+    w, h = 376, 240
+    frames = [f for f, _, _ in synth.billboard_sequence(w, h, 3)]
+    eh = edgehip.EdgeHip(edgehip.euroc_params(w, h), nseq=3, nslots=2)
+    arr, ptr = eh.alloc_pinned_frames()
+    arr[0], arr[1], arr[2] = frames[0], frames[1], frames[2]
+    eh.upload_rgb(0, np.stack(frames))
+    eh.upload_rgb_pinned(1, ptr)
+    eh.stage_a(0)
+    st0 = eh.get_state(0)
+    kns = eh.get_kn(0).copy()
+    ref = [eh.download_keylines(s, 0)[0] for s in range(3)]
+    # same detector state for the second run
+    for s in range(3):
+        st = eh.get_state(s)
+        st.tresh, st.l_kl_num = edgehip.euroc_params(w, h).detector_thresh, 0
+        eh.set_state(s, st)
+    eh.stage_a(1)
+    assert np.array_equal(eh.get_kn(1), kns) and kns.min() > 3000
+    for s in range(3):
+        k1 = eh.download_keylines(s, 1)[0]
+        for f in ("p_inx", "m_m", "c_p", "n_m"):
+            assert np.array_equal(k1[f], ref[s][f]), (s, f)
+    eh.sync()
+    eh.free_pinned(ptr)
+    eh.close()

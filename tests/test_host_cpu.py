@@ -80,3 +80,20 @@ def test_imu_config_errors(exe, tmp_path):
     write_global_config(cfg, p, imu=dict(mode=2, file=str(imu_csv), time_scale=1))
     r = _run(cfg, "/dev/null", 0, 1.0, 0.05)
     assert "Loaded 2 datums" in r.stdout and r.returncode in (0, 4)
+
+
+def test_stereo_config_errors(exe, tmp_path):
+    """StereoAvaiable makes the pair camera's list and the &Stereo intrinsics mandatory (src/rebvo/rebvo.cpp:195-216)."""
+    cfg = tmp_path / "cfg"
+    p = edgehip.euroc_params(376, 240)
+    st = dict(dir=str(tmp_path) + "/", file=str(tmp_path / "cam1.csv"), ppx=190.0, ppy=127.0, zfx=228.0, zfy=228.0)
+    ds = (str(tmp_path) + "/", str(tmp_path / "cam0.csv"), 1e-9)
+    write_global_config(cfg, p, camera_type=2, dataset=ds, stereo=st, drop=("Stereo/PPx",))
+    r = _run(cfg, "/dev/null", 0, 1.0, 0.05)
+    assert r.returncode == 3 and "PPx" in r.stdout
+    write_global_config(cfg, p, camera_type=2, dataset=ds, stereo=st, drop=("DataSetCamera/DataSetFileStereo",))
+    assert _run(cfg, "/dev/null", 0, 1.0, 0.05).returncode == 3
+    # complete stereo configuration, but the image lists do not exist: Init() reports the main camera first
+    write_global_config(cfg, p, camera_type=2, dataset=ds, stereo=st)
+    r = _run(cfg, "/dev/null", 0, 1.0, 0.05)
+    assert r.returncode == 4 and "Failed to initialize the main camera" in r.stdout
