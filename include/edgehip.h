@@ -149,6 +149,11 @@ int edgehip_upload_rgb_pinned(edgehip_ctx *ctx, int slot, const uint8_t *rgb24_p
 /* Bench/replay helper: frame pool resident in HBM ([pool_frames][h][w][3]); sequence s takes frame
  * idx[s] (host array, nseq entries).  One gather kernel on the context stream. */
 int edgehip_upload_rgb_indexed(edgehip_ctx *ctx, int slot, const void *pool_dev, int pool_frames, const int32_t *idx);
+/* The same selection without the copy: stage A of `slot` reads sequence s's frame directly at
+ * pool_dev + idx[s] * w*h*3 (what ConvertRGB2BW does with the camera buffer, rebvo_first_t.cpp:259).  The pool must
+ * stay valid and unchanged until that stage A has run, and must extend at least 16 bytes past its last frame (pixels
+ * are fetched as aligned 8-byte words).  Any edgehip_upload_rgb* call on the slot returns it to its own storage. */
+int edgehip_bind_rgb_indexed(edgehip_ctx *ctx, int slot, const void *pool_dev, int pool_frames, const int32_t *idx);
 
 /* ---- stage A: scale space + KeyLine extraction ----------------------------------------------------- */
 /* Image<float>::ConvertRGB2BW + sspace::build + edge_finder::detect + reEstimateThresh for every

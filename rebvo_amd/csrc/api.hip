@@ -383,6 +383,8 @@ int edgehip_create(const edgehip_params *params, int nseq, int nslots, int devic
     EH_TRY(dmalloc(c, &c->t_buf, B, al->dev, 0));
     EH_TRY(dmalloc(c, &c->nav_dev, B, al->dev, 0));
     EH_TRY(dmalloc(c, &c->idx_dev, B, al->dev, 0));
+    EH_TRY(dmalloc(c, &c->frame_idx, S * B, al->dev, 0));
+    c->slot_src.assign(S, edgehip_ctx::SlotSrc());
     c->stereo_cnt = nullptr;
     if (p.stereo_available) EH_TRY(dmalloc(c, &c->stereo_cnt, B, al->dev, 0));
     c->nav_log = nullptr;
@@ -530,8 +532,14 @@ static int check_seq(edgehip_ctx *c, int seq) {
     return 0;
 }
 
+// the slot reads its own storage again (after edgehip_bind_rgb_indexed)
+static void unbind_rgb(edgehip_ctx *c, int slot) {
+    if (c->slot_src[slot].base) { c->slot_src[slot].base = nullptr; c->slot_src[slot].host_idx.clear(); drop_frame_graphs(c); }
+}
+
 int edgehip_upload_rgb(edgehip_ctx *c, int slot, const uint8_t *rgb24, int seq_first, int count) {
     if (int e = check_slot(c, slot)) return e;
+    unbind_rgb(c, slot);
     if (!rgb24 || seq_first < 0 || count < 1 || seq_first + count > c->plan.nseq) { set_error("upload_rgb: bad range"); return EDGEHIP_ERR_ARG; }
     const size_t fb = (size_t)c->plan.n * 3;
     // the pinned buffer is reused: wait for the previous copy out of it
@@ -554,6 +562,7 @@ int edgehip_free_pinned(void *p) {
 }
 int edgehip_upload_rgb_pinned(edgehip_ctx *c, int slot, const uint8_t *rgb24_pinned, int seq_first, int count) {
     if (int e = check_slot(c, slot)) return e;
+    unbind_rgb(c, slot);
     if (!rgb24_pinned || seq_first < 0 || count < 1 || seq_first + count > c->plan.nseq) { set_error("upload_rgb_pinned: bad range"); return EDGEHIP_ERR_ARG; }
     const size_t fb = (size_t)c->plan.n * 3;
     EH_CHECK(hipMemcpyAsync(rgbof(c, slot) + fb * seq_first, rgb24_pinned, fb * count, hipMemcpyHostToDevice, c->stream_a));
@@ -562,6 +571,7 @@ int edgehip_upload_rgb_pinned(edgehip_ctx *c, int slot, const uint8_t *rgb24_pin
 
 int edgehip_upload_rgb_device(edgehip_ctx *c, int slot, const void *rgb24_dev) {
     if (int e = check_slot(c, slot)) return e;
+    unbind_rgb(c, slot);
     if (!rgb24_dev) return EDGEHIP_ERR_ARG;
     EH_CHECK(hipMemcpyAsync(rgbof(c, slot), rgb24_dev, (size_t)c->plan.nseq * c->plan.n * 3, hipMemcpyDeviceToDevice, c->stream_a));
     return 0;
@@ -569,6 +579,7 @@ int edgehip_upload_rgb_device(edgehip_ctx *c, int slot, const void *rgb24_dev) {
 
 int edgehip_upload_rgb_indexed(edgehip_ctx *c, int slot, const void *pool_dev, int pool_frames, const int32_t *idx) {
     if (int e = check_slot(c, slot)) return e;
+    unbind_rgb(c, slot);
     if (!pool_dev || !idx || pool_frames < 1) return EDGEHIP_ERR_ARG;
     const int B = c->plan.nseq;
     int32_t *pi = (int32_t *)(c->pinned_t + (size_t)8 * B) ;  // tail of the pinned time ring (see create)
@@ -582,6 +593,24 @@ int edgehip_upload_rgb_indexed(edgehip_ctx *c, int slot, const void *pool_dev, i
     hipLaunchKernelGGL(k_gather_frames, dim3(64, B), dim3(256), 0, c->stream_a, (const uint4 *)pool_dev, c->idx_dev,
                        (uint4 *)rgbof(c, slot), frame_vec);
     EH_LAUNCH_CHECK();
+    return 0;
+}
+
+int edgehip_bind_rgb_indexed(edgehip_ctx *c, int slot, const void *pool_dev, int pool_frames, const int32_t *idx) {
+    if (int e = check_slot(c, slot)) return e;
+    if (!pool_dev || !idx || pool_frames < 1) return EDGEHIP_ERR_ARG;
+    const int B = c->plan.nseq;
+    int32_t *pi = (int32_t *)(c->pinned_t + (size_t)8 * B);   // tail of the pinned time ring (see create)
+    pi += (size_t)(c->frames_seen % 8) * B;
+    for (int s = 0; s < B; s++) {
+        if (idx[s] < 0 || idx[s] >= pool_frames) { set_error("bind_rgb_indexed: index out of range"); return EDGEHIP_ERR_ARG; }
+        pi[s] = idx[s];
+    }
+    EH_CHECK(hipMemcpyAsync(c->frame_idx + (size_t)slot * B, pi, sizeof(int32_t) * B, hipMemcpyHostToDevice, c->stream_a));
+    edgehip_ctx::SlotSrc &ss = c->slot_src[slot];
+    if (ss.base != (const uint8_t *)pool_dev) drop_frame_graphs(c);   // the frame source is a kernel argument
+    ss.base = (const uint8_t *)pool_dev;
+    ss.host_idx.assign(idx, idx + B);
     return 0;
 }
 

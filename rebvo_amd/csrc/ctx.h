@@ -186,6 +186,9 @@ struct edgehip_ctx {
         double t[3], R[9], max_radius;
     } rig;
     int ring_slots;                   // slots the frame ring cycles through (nslots, or nslots - 1 with a stereo rig)
+    struct SlotSrc { const uint8_t *base = nullptr; std::vector<int32_t> host_idx; };   // base == nullptr: the slot's own storage
+    std::vector<SlotSrc> slot_src;   // per ring slot: where stage A reads its frames from
+    int32_t *frame_idx;              // [S][B] frame index of every sequence inside a bound pool
     struct SlotCam { float ppx, ppy; double zfm; };
     std::vector<SlotCam> slot_cam;   // per ring slot: principal point stage A uses, focal length of that camera (stereo pair slot)
     int field_radius;      // radius of the last build_field (global_tracker::max_r)

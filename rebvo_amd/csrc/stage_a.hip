@@ -58,10 +58,11 @@ __device__ __forceinline__ uchar3 undist_rgb(const uint8_t *__restrict__ frame, 
 }
 
 template <int CH, bool UNDIST>
-__global__ __launch_bounds__(256) void k_rgb_rowscan(const uint8_t *__restrict__ rgb, float *__restrict__ dst,
-                                                     int w, int h, size_t n, const int32_t *__restrict__ und_base,
-                                                     const uint4 *__restrict__ und_iw) {
+__global__ __launch_bounds__(256) void k_rgb_rowscan(const uint8_t *__restrict__ rgb, const int32_t *__restrict__ fidx,
+                                                     float *__restrict__ dst, int w, int h, size_t n,
+                                                     const int32_t *__restrict__ und_base, const uint4 *__restrict__ und_iw) {
     const int seq = blockIdx.z;
+    rgb += (size_t)(fidx ? fidx[seq] : seq) * n * 3;   // this sequence's frame: its slice of the slot, or a frame of a bound pool
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int y = blockIdx.x * 4 + wave;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -72,7 +73,7 @@ __global__ __launch_bounds__(256) void k_rgb_rowscan(const uint8_t *__restrict__
     if (y < h) {
         if (UNDIST) {
             // undistortion fused into the load: lane x resamples pixel (x, y) from the distorted frame
-            const uint8_t *frame = rgb + (size_t)seq * n * 3;
+            const uint8_t *frame = rgb;
             unsigned char *sbw = reinterpret_cast<unsigned char *>(stage);
             for (int x = lane; x < w; x += 64) {
                 const size_t pix = (size_t)y * w + x;
@@ -80,7 +81,7 @@ __global__ __launch_bounds__(256) void k_rgb_rowscan(const uint8_t *__restrict__
                 sbw[x * 3] = c.x; sbw[x * 3 + 1] = c.y; sbw[x * 3 + 2] = c.z;
             }
         } else {
-            const uint32_t *src = reinterpret_cast<const uint32_t *>(rgb + (size_t)seq * n * 3 + (size_t)y * row_bytes);
+            const uint32_t *src = reinterpret_cast<const uint32_t *>(rgb + (size_t)y * row_bytes);
             for (int i = lane; i < row_dw; i += 64) stage[i] = src[i];  // w % 4 == 0 -> rows are dword aligned
         }
     }
@@ -321,7 +322,7 @@ struct LevelJob {
 __device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 
 template <int SRC, int MC>   // SRC 0: box average of job.src; 1: grey of the RGB24 frame; 2: grey of the undistorted frame
-__global__ __launch_bounds__(LV_NT) void k_level(LevelJob job, const uint8_t *__restrict__ rgb,
+__global__ __launch_bounds__(LV_NT) void k_level(LevelJob job, const uint8_t *__restrict__ rgb, const int32_t *__restrict__ fidx,
                                                  const int32_t *__restrict__ und_base, const uint4 *__restrict__ und_iw,
                                                  const float *__restrict__ lut, int w, int h, size_t n, int ablate) {
     extern __shared__ __attribute__((aligned(16))) float s_T[];   // [2][LV_RB][WP]
@@ -330,7 +331,7 @@ __global__ __launch_bounds__(LV_NT) void k_level(LevelJob job, const uint8_t *__
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
     const float *src = SRC == 0 ? job.src[jb] + (size_t)seq * n : nullptr;
     float *dst = job.dst[jb] + (size_t)seq * n;
-    const uint8_t *frame = SRC != 0 ? rgb + (size_t)seq * n * 3 : nullptr;
+    const uint8_t *frame = SRC != 0 ? rgb + (size_t)(fidx ? fidx[seq] : seq) * n * 3 : nullptr;
     const int d = job.d[jb], d2 = d / 2;
     const int nb = (h + LV_RB - 1) / LV_RB;
     const int ct = tid - 64;              // column-owner index (waves 1..12)
@@ -1065,7 +1066,9 @@ __global__ void k_undistort_frame(const uint8_t *__restrict__ frame, uint8_t *__
 int undistort_frame_enqueue(edgehip_ctx *c, int seq, int slot, uint8_t *out_dev) {
     const DevicePlan &pl = c->plan;
     hipLaunchKernelGGL(k_undistort_frame, dim3((pl.n + 255) / 256), dim3(256), 0, c->stream_a,
-                       rgbof(c, slot) + (size_t)seq * pl.n * 3, out_dev, pl.w, pl.n, c->und_base, c->und_iw);
+                       c->slot_src[slot].base ? c->slot_src[slot].base + (size_t)c->slot_src[slot].host_idx[seq] * pl.n * 3
+                                              : rgbof(c, slot) + (size_t)seq * pl.n * 3,
+                       out_dev, pl.w, pl.n, c->und_base, c->und_iw);
     EH_LAUNCH_CHECK();
     return 0;
 }
@@ -1079,6 +1082,9 @@ int stage_a_enqueue(edgehip_ctx *c, int slot) {
     float *ii[4];
     for (int i = 0; i < 4; i++) ii[i] = c->ii + (size_t)i * B * n;
     hipStream_t st = c->stream_a;
+    // where the slot's frames are: its own storage (sequence-major) or frames of a bound device pool (edgehip_bind_rgb_indexed)
+    const uint8_t *rgb_base = c->slot_src[slot].base ? c->slot_src[slot].base : rgbof(c, slot);
+    const int32_t *rgb_idx = c->slot_src[slot].base ? c->frame_idx + (size_t)slot * c->plan.nseq : nullptr;
 
     float *cur[2] = {ii[0], ii[0]};
     const int planes_in_flight = B * 2;
@@ -1102,9 +1108,9 @@ int stage_a_enqueue(edgehip_ctx *c, int slot) {
             job.dst[0] = ii[0]; job.d[0] = 1; job.a[0] = 1.f;
 #define EH_LEVEL(SRCV, GRID)                                                                                                   \
     do {                                                                                                                      \
-        if (w <= LV_NC) hipLaunchKernelGGL((k_level<SRCV, 1>), GRID, dim3(LV_NT), sm, st, job, rgbof(c, slot), c->und_base,    \
+        if (w <= LV_NC) hipLaunchKernelGGL((k_level<SRCV, 1>), GRID, dim3(LV_NT), sm, st, job, rgb_base, rgb_idx, c->und_base,    \
                                            c->und_iw, c->div_lut, w, h, n, lv_ablate);                                        \
-        else hipLaunchKernelGGL((k_level<SRCV, 2>), GRID, dim3(LV_NT), sm, st, job, rgbof(c, slot), c->und_base, c->und_iw,   \
+        else hipLaunchKernelGGL((k_level<SRCV, 2>), GRID, dim3(LV_NT), sm, st, job, rgb_base, rgb_idx, c->und_base, c->und_iw,   \
                                 c->div_lut, w, h, n, lv_ablate);                                                              \
     } while (0)
             if (c->und_base) EH_LEVEL(2, dim3(1, 1, B));
@@ -1150,17 +1156,17 @@ int stage_a_enqueue(edgehip_ctx *c, int slot) {
             const bool und = c->und_base != nullptr;
     #define EH_ROWSCAN(CHV)                                                                                              \
         case CHV:                                                                                                        \
-            if (und) hipLaunchKernelGGL((k_rgb_rowscan<CHV, true>), g, dim3(256), sm, st, rgbof(c, slot), ii[0], w, h, n, \
+            if (und) hipLaunchKernelGGL((k_rgb_rowscan<CHV, true>), g, dim3(256), sm, st, rgb_base, rgb_idx, ii[0], w, h, n, \
                                         c->und_base, c->und_iw);                                                         \
-            else hipLaunchKernelGGL((k_rgb_rowscan<CHV, false>), g, dim3(256), sm, st, rgbof(c, slot), ii[0], w, h, n,   \
+            else hipLaunchKernelGGL((k_rgb_rowscan<CHV, false>), g, dim3(256), sm, st, rgb_base, rgb_idx, ii[0], w, h, n,   \
                                     c->und_base, c->und_iw);                                                             \
             break;
             switch (ch) {
                 EH_ROWSCAN(4) EH_ROWSCAN(8) EH_ROWSCAN(12) EH_ROWSCAN(16) EH_ROWSCAN(20) EH_ROWSCAN(24) EH_ROWSCAN(28)
                 default:
-                    if (und) hipLaunchKernelGGL((k_rgb_rowscan<32, true>), g, dim3(256), sm, st, rgbof(c, slot), ii[0], w, h, n,
+                    if (und) hipLaunchKernelGGL((k_rgb_rowscan<32, true>), g, dim3(256), sm, st, rgb_base, rgb_idx, ii[0], w, h, n,
                                                 c->und_base, c->und_iw);
-                    else hipLaunchKernelGGL((k_rgb_rowscan<32, false>), g, dim3(256), sm, st, rgbof(c, slot), ii[0], w, h, n,
+                    else hipLaunchKernelGGL((k_rgb_rowscan<32, false>), g, dim3(256), sm, st, rgb_base, rgb_idx, ii[0], w, h, n,
                                             c->und_base, c->und_iw);
                     break;
             }

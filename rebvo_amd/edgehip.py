@@ -140,7 +140,7 @@ EXPORTS = [
     "edgehip_set_state", "edgehip_get_framecount", "edgehip_set_framecount", "edgehip_download_keylines",
     "edgehip_upload_keylines", "edgehip_download_plane", "edgehip_download_field", "edgehip_profile_enable",
     "edgehip_profile_count", "edgehip_profile_name", "edgehip_profile_read", "edgehip_profile_select",
-    "edgehip_upload_rgb_indexed", "edgehip_set_nav_log", "edgehip_read_nav_log",
+    "edgehip_upload_rgb_indexed", "edgehip_bind_rgb_indexed", "edgehip_set_nav_log", "edgehip_read_nav_log",
     "edgehip_build_undistort_map", "edgehip_download_undistorted", "edgehip_depth_reset", "edgehip_depth_reset_slot", "edgehip_set_slot_camera", "edgehip_directed_matching_stereo",
     "edgehip_alloc_pinned", "edgehip_free_pinned", "edgehip_upload_rgb_pinned", "edgehip_fuse_stereo_depth", "edgehip_set_stereo_rig", "edgehip_get_stereo_matches", "edgehip_minimizer_v", "edgehip_ext_rot_vel",
 ]
@@ -277,6 +277,13 @@ class EdgeHip:
 
     def upload_rgb_device(self, slot, dev_ptr):
         self._ck(self.lib.edgehip_upload_rgb_device(self.ctx, slot, C.c_void_p(dev_ptr)))
+
+    def bind_rgb_indexed(self, slot, pool_dev_ptr, pool_frames, idx):
+        """Stage A of `slot` reads frame idx[s] of a device pool in place (no copy); the pool needs 16 B of slack."""
+        idx = np.ascontiguousarray(idx, np.int32)
+        assert idx.shape == (self.nseq,)
+        self._ck(self.lib.edgehip_bind_rgb_indexed(self.ctx, slot, C.c_void_p(pool_dev_ptr), pool_frames,
+                                                   idx.ctypes.data_as(C.c_void_p)))
 
     def upload_rgb_indexed(self, slot, pool_dev_ptr, pool_frames, idx):
         idx = np.ascontiguousarray(idx, dtype=np.int32)

@@ -139,3 +139,36 @@ def test_pinned_upload_equals_staged_upload():
     eh.sync()
     eh.free_pinned(ptr)
     eh.close()
+
+
+def test_bound_pool_frames_equal_copied_frames():
+    """edgehip_bind_rgb_indexed (stage A reads each sequence's frame in place from a device pool) against
+    edgehip_upload_rgb_indexed (the same selection copied into the slot) over a few frames of the whole path, including
+    the last frame of the pool (whose pixels are read as 8-byte words into the 16 B of slack) and a switch back to
+    ordinary uploads."""
+    import torch
+    w, h, npool = 376, 240, 5
+    frames = [f for f, _, _ in synth.billboard_sequence(w, h, npool)]
+    host = np.stack(frames)
+    pool = torch.empty(host.size + 16, dtype=torch.uint8, device="cuda")
+    pool[:host.size] = torch.from_numpy(host.reshape(-1)).cuda()
+    pool[host.size:] = 255
+    a = edgehip.EdgeHip(edgehip.euroc_params(w, h), nseq=3, nslots=3)
+    b = edgehip.EdgeHip(edgehip.euroc_params(w, h), nseq=3, nslots=3)
+    for k in range(6):
+        idx = np.array([(k + s) % npool for s in (0, 2, 4)], np.int32)
+        if k < 5:
+            a.bind_rgb_indexed(a.next_slot(), pool.data_ptr(), npool, idx)
+        else:
+            a.upload_rgb(a.next_slot(), np.stack([frames[i] for i in idx]))   # back to the slot's own storage
+        b.upload_rgb_indexed(b.next_slot(), pool.data_ptr(), npool, idx)
+        a.process_frame(0.05 * k)
+        b.process_frame(0.05 * k)
+        for na, nb in zip(a.read_nav(), b.read_nav()):
+            assert na.kn == nb.kn and na.tresh == nb.tresh
+            assert na.V[:] == nb.V[:] and na.W[:] == nb.W[:] and na.Pos[:] == nb.Pos[:], k
+    for s in range(3):
+        ka, ma = a.download_keylines(s, a.cur_slot())
+        kb, mb = b.download_keylines(s, b.cur_slot())
+        assert np.array_equal(ma, mb) and np.array_equal(ka["rho"], kb["rho"]) and len(ka) > 3000
+    a.close(); b.close()
