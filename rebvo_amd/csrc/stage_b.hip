@@ -311,14 +311,17 @@ __global__ __launch_bounds__(256) void k_field_raster(const KlSoA *kls, const in
                 t1 = min(t1, t0 + chunk - 1);
             }
             const uint32_t idk = (uint32_t)(0xFFFF - ikl);
-            for (int t = t0; t <= t1; t++) {
-                const float fx = r.u_mx * (float)t + r.c_px;   // global_tracker.cpp:78, same float expression
-                const float fy = r.u_my * (float)t + r.c_py;
+            // t runs as a float (|t| <= 255: every value and the increment are exact), so the reference's (float)t costs
+            // nothing and |t| is an operand modifier of the one conversion back
+            const float t1f = (float)t1;
+            for (float tf = (float)t0; tf <= t1f; tf += 1.f) {
+                const float fx = r.u_mx * tf + r.c_px;   // global_tracker.cpp:78, same float expression
+                const float fy = r.u_my * tf + r.c_py;
                 // Image::GetIndexRC uses round()
                 const int lx = (decltype(fix_x)::value ? round_half_away_i(fx) : round_ties_up_i(fx)) - tx0;
                 const int ly = (decltype(fix_y)::value ? round_half_away_i(fy) : round_ties_up_i(fy)) - ty0;
                 if ((unsigned)lx >= ex || (unsigned)ly >= ey) continue;
-                const uint32_t at = (uint32_t)(t < 0 ? -t : t);
+                const uint32_t at = (uint32_t)fabsf(tf);
                 atomicMin(&s_tile[ly * FT + lx], (at << 16) | idk);
             }
         }
