@@ -141,6 +141,30 @@ def _cpu_worker(job):
     return time.perf_counter() - t0
 
 
+def pose_rmse(gpu_traj, cpu_traj, kind):
+    """BASELINE.json's "pose RMSE vs CPU ref": sequence 0's trajectory over the timed frames, HIP path against the CPU
+    reference run on the same frames from the same start (frame 0).  Position in the (up-to-scale) map units of
+    NavData::Pos, rotation as the angle of Pose_gpu * Pose_cpu^T, V/W = the per-frame tracker outputs."""
+    ks = sorted(k for k in cpu_traj if gpu_traj and k < len(gpu_traj))
+    if not ks:
+        return None
+    dp, dr, dv, dw, path = [], [], [], [], 0.0
+    for i, k in enumerate(ks):
+        gp, gR, gv, gw = gpu_traj[k]
+        cp, cR, cv, cw = cpu_traj[k]
+        dp.append(float(np.sum((gp - cp) ** 2)))
+        c = (np.trace(gR @ cR.T) - 1.0) / 2.0
+        dr.append(float(np.arccos(min(1.0, max(-1.0, c))) ** 2))
+        dv.append(float(np.sum((gv - cv) ** 2)))
+        dw.append(float(np.sum((gw - cw) ** 2)))
+        if i:
+            path += float(np.linalg.norm(cp - cpu_traj[ks[i - 1]][0]))
+    rms = lambda a: float(np.sqrt(np.mean(a)))
+    return {"position": rms(dp), "rotation_rad": rms(dr), "V": rms(dv), "W": rms(dw), "frames": len(ks),
+            "path_length": path, "position_rel": rms(dp) / path if path > 0 else None, "sequence": 0,
+            "vs": "CPU " + kind + " on the same frames, both started at frame 0 (tests state the tolerance: 1e-6 rel.)"}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -256,6 +280,12 @@ def main():
     if dominant and not args.no_roofline_events:
         dom_ms, dom_calls = eh.profile_read()[dominant]
         eh.profile_enable(False)
+    # trajectory of sequence 0 over the timed frames (for pose_rmse against the CPU reference below)
+    gpu_traj = None
+    if rank == 0:
+        log0 = eh.read_nav_log(Wm, K)
+        gpu_traj = [(np.array(r[0].Pos[:]), np.array(r[0].Pose[:]).reshape(3, 3), np.array(r[0].V[:]), np.array(r[0].W[:]))
+                    for r in log0]
     last = [n for e in ehs for n in e.read_nav()]
     kn_mean = float(np.mean([n.kn for n in last]))
     ok = int(sum(n.estimation_ok for n in last))
@@ -285,18 +315,23 @@ def main():
 
     # ---- CPU baseline: the reference's own code on one host core, bounded sample ----
     cpu = None
+    pose = None
     if args.cpu_frames > 0:
         try:
             from oracle import oracle
             kind = "reference" if oracle.available("ref") else ("port" if oracle.available("port") else None)
             if kind:
                 orc = oracle.Oracle("ref" if kind == "reference" else "port", oracle.euroc_params(W, H))
-                for k in range(10):  # first-touch of the 8 ring slots + MKL init, untimed
-                    orc.process_frame(frames[tri(k, args.pool)], 0.05 * k)
+                cpu_traj = {}
                 tc = 0.0
-                for k in range(10, 10 + args.cpu_frames):
+                for k in range(10 + args.cpu_frames):  # the first 10: first-touch of the 8 ring slots + MKL init, untimed
                     _, nav = orc.process_frame(frames[tri(k, args.pool)], 0.05 * k)
-                    tc += nav.dtp0 + nav.dtp1
+                    if k >= 10:
+                        tc += nav.dtp0 + nav.dtp1
+                    if Wm <= k < Wm + K:
+                        cpu_traj[k - Wm] = (np.array(nav.Pos[:]), np.array(nav.Pose[:]).reshape(3, 3), np.array(nav.V[:]),
+                                            np.array(nav.W[:]))
+                pose = pose_rmse(gpu_traj, cpu_traj, kind)
                 cpu = {"value": round(args.cpu_frames / tc, 2), "unit": "frames/s", "cores": 1, "kind": kind,
                        "sample": f"{args.cpu_frames} frames of sequence 0 (same 752x480 pool), serial stage A + B/C "
                                  f"on 1 of {_usable_cores()} usable host cores; reference threading overlaps the two stages "
@@ -336,7 +371,7 @@ def main():
                    "tryvelrot_evals_per_frame": evals, "estimation_ok": f"{ok}/{B * C}",
                    "algorithmic_MB_per_frame": round(frame_bytes / 1e6, 2),
                    "whole_path_hbm_frac": round(frame_bytes * value / world / 1e9 / HBM_PEAK_GBS, 5)},
-        "roofline": roof, "cpu_baseline": cpu, "kernel_us_per_step": breakdown,
+        "roofline": roof, "cpu_baseline": cpu, "pose_rmse": pose, "kernel_us_per_step": breakdown,
     }
     print(json.dumps(line))
     if world > 1:

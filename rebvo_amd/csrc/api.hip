@@ -14,6 +14,15 @@ namespace edgehip {
 
 static thread_local std::string g_err;
 
+// The pinned rings (time stamps, frame indices) have 8 entries and the copies out of them are asynchronous: a caller
+// that enqueues frames without synchronising may be more than 8 frames ahead of the device, so wait for the frame that
+// last used the entry before overwriting it.
+int wait_pinned_ring(edgehip_ctx *c) {
+    const int r = c->frames_seen % 8;
+    if (c->ring_valid[r]) EH_CHECK(hipEventSynchronize(c->ev_ring[r]));
+    return 0;
+}
+
 void drop_frame_graphs(edgehip_ctx *c) {
     for (auto &kv : c->frame_graphs) (void)hipGraphExecDestroy(kv.second);
     c->frame_graphs.clear();
@@ -297,6 +306,7 @@ int edgehip_create(const edgehip_params *params, int nseq, int nslots, int devic
         c->use_valid[i] = false;
     }
     EH_CHECK(hipEventCreateWithFlags(&c->ev_tmp, hipEventDisableTiming));
+    for (int i = 0; i < 8; i++) { EH_CHECK(hipEventCreateWithFlags(&c->ev_ring[i], hipEventDisableTiming)); c->ring_valid[i] = false; }
     if (nslots > 4) { set_error("edgehip_create: at most 4 frame slots"); return EDGEHIP_ERR_ARG; }
 
     DevicePlan &pl = c->plan;
@@ -488,6 +498,7 @@ int edgehip_destroy(edgehip_ctx *c) {
     if (c->nav_log) (void)hipFree(c->nav_log);
     for (int i = 0; i < 4; i++) { (void)hipEventDestroy(c->ev_a[i]); (void)hipEventDestroy(c->ev_use[i]); }
     (void)hipEventDestroy(c->ev_tmp);
+    for (int i = 0; i < 8; i++) (void)hipEventDestroy(c->ev_ring[i]);
     (void)hipStreamDestroy(c->stream_a);
     (void)hipStreamDestroy(c->stream);
     delete c;
@@ -584,6 +595,7 @@ int edgehip_upload_rgb_indexed(edgehip_ctx *c, int slot, const void *pool_dev, i
     const int B = c->plan.nseq;
     int32_t *pi = (int32_t *)(c->pinned_t + (size_t)8 * B) ;  // tail of the pinned time ring (see create)
     pi += (size_t)(c->frames_seen % 8) * B;
+    if (int e = wait_pinned_ring(c)) return e;
     for (int s = 0; s < B; s++) {
         if (idx[s] < 0 || idx[s] >= pool_frames) { set_error("upload_rgb_indexed: index out of range"); return EDGEHIP_ERR_ARG; }
         pi[s] = idx[s];
@@ -602,6 +614,7 @@ int edgehip_bind_rgb_indexed(edgehip_ctx *c, int slot, const void *pool_dev, int
     const int B = c->plan.nseq;
     int32_t *pi = (int32_t *)(c->pinned_t + (size_t)8 * B);   // tail of the pinned time ring (see create)
     pi += (size_t)(c->frames_seen % 8) * B;
+    if (int e = wait_pinned_ring(c)) return e;
     for (int s = 0; s < B; s++) {
         if (idx[s] < 0 || idx[s] >= pool_frames) { set_error("bind_rgb_indexed: index out of range"); return EDGEHIP_ERR_ARG; }
         pi[s] = idx[s];

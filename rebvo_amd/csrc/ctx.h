@@ -134,6 +134,8 @@ struct edgehip_ctx {
     hipEvent_t ev_a[4];    // [slot] stage A of the frame in this slot has finished
     hipEvent_t ev_use[4];  // [slot] the last B/C work that read this slot has finished
     hipEvent_t ev_tmp;     // ordering of the stage-level entry points
+    hipEvent_t ev_ring[8]; // [frame % 8] the frame that used this entry of the pinned time-stamp / frame-index rings is done
+    bool ring_valid[8];
     bool use_valid[4];
     int overlap;           // 1: stage A of frame k+1 may run under stages B/C of frame k (EDGEHIP_OVERLAP=1); 0: one after the other
     int frame_slot;        // ring position of the newest slot (-1 before the first frame)
@@ -263,6 +265,7 @@ struct ProfScope {  // RAII bracket; no-op unless profiling is enabled
 int stage_a_enqueue(edgehip_ctx *c, int slot);
 // ordering between the two streams for entry points that are not edgehip_process_frame: everything enqueued so far on
 // one stream is finished before anything enqueued afterwards on the other starts
+int wait_pinned_ring(edgehip_ctx *c);     // before writing entry frames_seen % 8 of the pinned time-stamp / frame-index rings
 void drop_frame_graphs(edgehip_ctx *c);   // after anything that changes what a captured frame would enqueue
 int order_a_after_bc(edgehip_ctx *c);
 int order_bc_after_a(edgehip_ctx *c);

@@ -244,9 +244,12 @@ __global__ __launch_bounds__(256) void k_field_bin(const KlSoA *kls, const int32
         if (min_mod > 0 && r.n_m < min_mod) active = false;
     }
     if (active) {
+        // bounding box of the pixels the samples can round into: +-1 px beyond the segment's ends (a sample at
+        // x = 383.5 lands on pixel 384, i.e. in the NEXT tile column, however flat the segment is; tile_trange then
+        // decides exactly)
         const float rr = (float)radius + 1.5f;
-        const float xa = r.c_px - fabsf(r.u_mx) * rr, xb = r.c_px + fabsf(r.u_mx) * rr;
-        const float ya = r.c_py - fabsf(r.u_my) * rr, yb = r.c_py + fabsf(r.u_my) * rr;
+        const float xa = r.c_px - fabsf(r.u_mx) * rr - 1.f, xb = r.c_px + fabsf(r.u_mx) * rr + 1.f;
+        const float ya = r.c_py - fabsf(r.u_my) * rr - 1.f, yb = r.c_py + fabsf(r.u_my) * rr + 1.f;
         txa = max((int)floorf(xa) / FT, 0); txb = min((int)floorf(xb) / FT, ntx - 1);
         tya = max((int)floorf(ya) / FT, 0); tyb = min((int)floorf(yb) / FT, nty - 1);
         if (xb < 0.f || yb < 0.f) txb = -1;

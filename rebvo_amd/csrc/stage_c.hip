@@ -1181,6 +1181,7 @@ int edgehip_process_frame(edgehip_ctx *c, const double *t) {
     const int have_pair = c->frames_seen >= 1;
     // time stamps travel through a small ring of pinned slots so that back-to-back frames need no sync
     double *tp = c->pinned_t + (size_t)(c->frames_seen % 8) * pl.nseq;
+    if (int e = wait_pinned_ring(c)) return e;
     memcpy(tp, t, sizeof(double) * pl.nseq);
     const bool profiling = c->prof && c->prof->on;
     // the first frames run eagerly (one-time kernel attributes, no frame pair yet); then every (slot, FrameCount row,
@@ -1209,6 +1210,9 @@ int edgehip_process_frame(edgehip_ctx *c, const double *t) {
     } else {
         if (int e = frame_enqueue(c, sn, so, sp, have_pair, tp)) return e;
     }
+    // the pinned ring entries of this frame (time stamps, bound frame indices) are free once it has run
+    EH_CHECK(hipEventRecord(c->ev_ring[c->frames_seen % 8], c->stream));
+    c->ring_valid[c->frames_seen % 8] = true;
     c->frame_slot = sn;
     c->frames_seen++;
     return 0;

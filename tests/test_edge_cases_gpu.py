@@ -172,3 +172,36 @@ def test_bound_pool_frames_equal_copied_frames():
         kb, mb = b.download_keylines(s, b.cur_slot())
         assert np.array_equal(ma, mb) and np.array_equal(ka["rho"], kb["rho"]) and len(ka) > 3000
     a.close(); b.close()
+
+
+def test_replay_without_host_sync_runs_ahead_of_the_device():
+    """A replay that never synchronises between frames (bench.py's loop: bind the frames, process, next) lets the host
+    get more than 8 frames ahead of the device, past the depth of the pinned time-stamp / frame-index rings.  Every
+    frame must still see its own time stamp and its own pool indices: the nav log of two sequences equals the CPU
+    reference run on the same frame order (the reference is fed synchronously)."""
+    import torch
+    w, h, npool, nf, B = 752, 480, 6, 14, 4
+    frames = [f for f, _, _ in synth.billboard_sequence(w, h, npool, seed=11)]
+    host = np.stack(frames)
+    pool = torch.empty(host.size + 16, dtype=torch.uint8, device="cuda")
+    pool[:host.size] = torch.from_numpy(host.reshape(-1)).cuda()
+    torch.cuda.synchronize()
+    tri = lambda k: (k % (2 * (npool - 1))) if (k % (2 * (npool - 1))) < npool else 2 * (npool - 1) - (k % (2 * (npool - 1)))
+    t = lambda k: 0.05 * k + 0.003 * (k % 3)   # uneven stamps: a stale ring entry would change dt
+    eh = edgehip.EdgeHip(edgehip.euroc_params(w, h), nseq=B, nslots=3)
+    eh.set_nav_log(nf)
+    for k in range(nf):
+        idx = np.array([tri(k + s) for s in range(B)], np.int32)
+        eh.bind_rgb_indexed(eh.next_slot(), pool.data_ptr(), npool, idx)
+        eh.process_frame(t(k))
+    log = eh.read_nav_log(0, nf)
+    for s in (0, B - 1):
+        orc = _oracle(w, h)
+        for k in range(nf):
+            _, nr = orc.process_frame(frames[tri(k + s)], t(k))
+            ng = log[k][s]
+            assert ng.kn == nr.kn and ng.frame == k, (s, k, ng.kn, nr.kn)
+            assert np.allclose(ng.V[:], nr.V[:], rtol=0, atol=1e-9) and np.allclose(ng.W[:], nr.W[:], rtol=0, atol=1e-9), (s, k)
+            assert np.allclose(ng.Pos[:], nr.Pos[:], rtol=0, atol=1e-9), (s, k)
+            assert k == 0 or abs(ng.dt - nr.dt) < 1e-12, (s, k, ng.dt, nr.dt)   # frame 0 has no predecessor
+    eh.close()

@@ -124,3 +124,44 @@ def test_minimizer_v(pair, V0, iters, mnt):
     kg, _ = eh.download_keylines(0, 0)
     assert np.array_equal(kg["m_id_f"], orc.keylines(so)["m_id_f"])
     assert orc.get_framecount(sn) == fc                 # Minimizer_V does not count frames
+
+
+def test_build_field_segments_that_round_across_a_tile_boundary():
+    """The binned build_field works in 64 x 64 tiles.  A nearly axis-parallel segment whose centre sits within half a
+    pixel of a tile boundary reaches the neighbouring tile only through round() (x = 383.5 -> pixel 384): such KeyLines
+    must be binned into that tile too.  Crafted KeyLines on both sides of every tile boundary (and of the image
+    border), field compared exactly with the reference's build_field (global_tracker.cpp:61-105)."""
+    from oracle import oracle
+    if not oracle.available("ref"):
+        pytest.skip("oracle/_ref not built")
+    w, h, r = 376, 240, 40
+    orc = oracle.Oracle("ref", oracle.euroc_params(w, h))
+    rs = np.random.RandomState(5)
+    kls = np.zeros(6000, oracle.KEYLINE_DTYPE)
+    n = len(kls)
+    bx = rs.randint(0, w // 64 + 2, n) * 64.0          # a tile boundary (or the image border) ...
+    by = rs.randint(0, h // 64 + 2, n) * 64.0
+    off = rs.uniform(-0.75, 0.75, n)                   # ... and a centre within 3/4 px of it
+    vertical = rs.rand(n) < 0.5
+    cx = np.where(vertical, bx + off, rs.uniform(1, w - 2, n))
+    cy = np.where(vertical, rs.uniform(1, h - 2, n), by + off)
+    small = rs.uniform(-0.03, 0.03, n) * (rs.rand(n) < 0.8)   # some exactly axis-parallel
+    ux = np.where(vertical, small, np.sign(rs.randn(n)) * np.sqrt(1 - small ** 2))
+    uy = np.where(vertical, np.sign(rs.randn(n)) * np.sqrt(1 - small ** 2), small)
+    kls["c_p"] = np.stack([np.clip(cx, 0, w - 1), np.clip(cy, 0, h - 1)], 1).astype(np.float32)
+    kls["u_m"] = np.stack([ux, uy], 1).astype(np.float32)
+    kls["n_m"] = rs.uniform(1, 10, n).astype(np.float32)
+    kls["m_m"] = kls["u_m"] * kls["n_m"][:, None]
+    kls["rho"], kls["s_rho"] = 1.0, 1.0
+    orc.set_keylines(0, kls, None, 0.0)
+    eh = edgehip.EdgeHip(edgehip.euroc_params(w, h), nseq=1, nslots=2)
+    from helpers import to_edgehip_kl
+    eh.upload_keylines(0, 1, to_edgehip_kl(kls), None, 0.0)
+    orc.build_field(0, r, 0.0)
+    eh.build_field(1, r, 0.0)
+    f_ref, f_gpu = orc.field(0), eh.download_field(0)
+    assert np.array_equal(f_ref[..., 1], f_gpu[..., 1]), "field ikl differs"
+    m = f_ref[..., 1] >= 0
+    assert m.sum() > 5000
+    assert np.array_equal(f_ref[..., 0][m], f_gpu[..., 0][m]), "field dist differs"
+    eh.close()
