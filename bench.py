@@ -20,6 +20,8 @@ Extra objects on the JSON line:
                region), its algorithmic bytes per launch / mean launch duration vs 8 TB/s
   cpu_baseline the reference's own mtracklib (oracle/_ref, compiled in place from the reference sources)
                timed on one host core over a bounded sample of the same frames
+  pose_rmse    BASELINE.json's "pose RMSE vs CPU ref": the trajectories of the first, middle and last sequence of the
+               batch over the timed frames against the CPU reference replaying the same frame order from frame 0
 """
 import argparse
 import ctypes
@@ -141,28 +143,33 @@ def _cpu_worker(job):
     return time.perf_counter() - t0
 
 
-def pose_rmse(gpu_traj, cpu_traj, kind):
-    """BASELINE.json's "pose RMSE vs CPU ref": sequence 0's trajectory over the timed frames, HIP path against the CPU
-    reference run on the same frames from the same start (frame 0).  Position in the (up-to-scale) map units of
-    NavData::Pos, rotation as the angle of Pose_gpu * Pose_cpu^T, V/W = the per-frame tracker outputs."""
-    ks = sorted(k for k in cpu_traj if gpu_traj and k < len(gpu_traj))
-    if not ks:
+def pose_rmse(gpu_trajs, cpu_trajs, kind):
+    """BASELINE.json's "pose RMSE vs CPU ref": trajectories of a few sequences of the batch over the timed frames, HIP
+    path against the CPU reference run on the same frame order from the same start (frame 0).  Position in the
+    (up-to-scale) map units of NavData::Pos, rotation as the angle of Pose_gpu * Pose_cpu^T, V/W = the per-frame tracker
+    outputs.  RMS over all checked frames of all checked sequences."""
+    dp, dr, dv, dw, path, nfr = [], [], [], [], 0.0, 0
+    for s, cpu_traj in cpu_trajs.items():
+        gpu_traj = gpu_trajs.get(s) if gpu_trajs else None
+        ks = sorted(k for k in cpu_traj if gpu_traj and k < len(gpu_traj))
+        for i, k in enumerate(ks):
+            gp, gR, gv, gw = gpu_traj[k]
+            cp, cR, cv, cw = cpu_traj[k]
+            dp.append(float(np.sum((gp - cp) ** 2)))
+            # angle of gR * cR^T: ||gR - cR||_F = 2*sqrt(2)*sin(angle/2) (no arccos of a number next to 1)
+            dr.append(float((2.0 * np.arcsin(min(1.0, np.linalg.norm(gR - cR) / (2.0 * np.sqrt(2.0))))) ** 2))
+            dv.append(float(np.sum((gv - cv) ** 2)))
+            dw.append(float(np.sum((gw - cw) ** 2)))
+            if i:
+                path += float(np.linalg.norm(cp - cpu_traj[ks[i - 1]][0]))
+        nfr += len(ks)
+    if not nfr:
         return None
-    dp, dr, dv, dw, path = [], [], [], [], 0.0
-    for i, k in enumerate(ks):
-        gp, gR, gv, gw = gpu_traj[k]
-        cp, cR, cv, cw = cpu_traj[k]
-        dp.append(float(np.sum((gp - cp) ** 2)))
-        c = (np.trace(gR @ cR.T) - 1.0) / 2.0
-        dr.append(float(np.arccos(min(1.0, max(-1.0, c))) ** 2))
-        dv.append(float(np.sum((gv - cv) ** 2)))
-        dw.append(float(np.sum((gw - cw) ** 2)))
-        if i:
-            path += float(np.linalg.norm(cp - cpu_traj[ks[i - 1]][0]))
     rms = lambda a: float(np.sqrt(np.mean(a)))
-    return {"position": rms(dp), "rotation_rad": rms(dr), "V": rms(dv), "W": rms(dw), "frames": len(ks),
-            "path_length": path, "position_rel": rms(dp) / path if path > 0 else None, "sequence": 0,
-            "vs": "CPU " + kind + " on the same frames, both started at frame 0 (tests state the tolerance: 1e-6 rel.)"}
+    return {"position": rms(dp), "rotation_rad": rms(dr), "V": rms(dv), "W": rms(dw), "frames": nfr,
+            "sequences": sorted(cpu_trajs), "path_length": path,
+            "position_rel": rms(dp) / path * len(cpu_trajs) if path > 0 else None,
+            "vs": "CPU " + kind + " on the same frames, both started at frame 0 (tests bound |dV|,|dW| by 1e-6 relative)"}
 
 
 def main():
@@ -282,10 +289,11 @@ def main():
         eh.profile_enable(False)
     # trajectory of sequence 0 over the timed frames (for pose_rmse against the CPU reference below)
     gpu_traj = None
+    check_seqs = sorted({0, B // 2, B - 1})   # sequences of context 0 compared with the CPU reference below
     if rank == 0:
         log0 = eh.read_nav_log(Wm, K)
-        gpu_traj = [(np.array(r[0].Pos[:]), np.array(r[0].Pose[:]).reshape(3, 3), np.array(r[0].V[:]), np.array(r[0].W[:]))
-                    for r in log0]
+        gpu_traj = {s: [(np.array(r[s].Pos[:]), np.array(r[s].Pose[:]).reshape(3, 3), np.array(r[s].V[:]), np.array(r[s].W[:]))
+                        for r in log0] for s in check_seqs}
     last = [n for e in ehs for n in e.read_nav()]
     kn_mean = float(np.mean([n.kn for n in last]))
     ok = int(sum(n.estimation_ok for n in last))
@@ -331,7 +339,17 @@ def main():
                     if Wm <= k < Wm + K:
                         cpu_traj[k - Wm] = (np.array(nav.Pos[:]), np.array(nav.Pose[:]).reshape(3, 3), np.array(nav.V[:]),
                                             np.array(nav.W[:]))
-                pose = pose_rmse(gpu_traj, cpu_traj, kind)
+                cpu_trajs = {0: cpu_traj}
+                for s_ in check_seqs[1:]:   # the other checked sequences: replay their frame order from frame 0
+                    o2 = oracle.Oracle("ref" if kind == "reference" else "port", oracle.euroc_params(W, H))
+                    cpu_trajs[s_] = {}
+                    for k in range(Wm + K):
+                        _, nav = o2.process_frame(frames[tri(k + int(offs[0][s_]), args.pool)], 0.05 * k)
+                        if k >= Wm:
+                            cpu_trajs[s_][k - Wm] = (np.array(nav.Pos[:]), np.array(nav.Pose[:]).reshape(3, 3),
+                                                     np.array(nav.V[:]), np.array(nav.W[:]))
+                    o2.close()
+                pose = pose_rmse(gpu_traj, cpu_trajs, kind)
                 cpu = {"value": round(args.cpu_frames / tc, 2), "unit": "frames/s", "cores": 1, "kind": kind,
                        "sample": f"{args.cpu_frames} frames of sequence 0 (same 752x480 pool), serial stage A + B/C "
                                  f"on 1 of {_usable_cores()} usable host cores; reference threading overlaps the two stages "
