@@ -1207,6 +1207,9 @@ int edgehip_process_frame(edgehip_ctx *c, const double *t) {
             it = c->frame_graphs.emplace(key, exec).first;
         }
         EH_CHECK(hipGraphLaunch(it->second, c->stream));
+        // stage A ran inside the graph, on this stream: the caller's next uploads (stage-A stream) may overwrite a
+        // frame slot only after the graphs that read it (a caller that never synchronises is several frames ahead)
+        if (int e = order_a_after_bc(c)) return e;
     } else {
         if (int e = frame_enqueue(c, sn, so, sp, have_pair, tp)) return e;
     }

@@ -59,7 +59,13 @@ def test_tum_parameters_with_undistortion():
     _replay(frames, edgehip.tum_params(640, 480, use_undistort=1), oracle.tum_params(640, 480, use_undistort=1), 30, [0, 4], 0.02)
 
 
-def test_small_frames_sixty_deep():
+@pytest.mark.parametrize("mode", ["default", "EDGEHIP_OVERLAP", "EDGEHIP_GRAPH"])
+def test_small_frames_sixty_deep(mode, monkeypatch):
+    """Also under the two optional execution modes read at edgehip_create() time: stage A of frame k+1 overlapped with
+    B/C of frame k on a second stream, and the per-frame HIP graphs (whose stage A runs on the main stream: uploads for
+    later frames must not overtake the graphs that still read a slot)."""
     from oracle import oracle
+    if mode != "default":
+        monkeypatch.setenv(mode, "1")
     frames = [f for f, _, _ in synth.billboard_sequence(376, 240, 12, seed=5)]
     _replay(frames, edgehip.euroc_params(376, 240), oracle.euroc_params(376, 240), 60, [0, 2, 7], 0.05)
