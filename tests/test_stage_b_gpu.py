@@ -126,19 +126,24 @@ def test_minimizer_v(pair, V0, iters, mnt):
     assert orc.get_framecount(sn) == fc                 # Minimizer_V does not count frames
 
 
-def test_build_field_segments_that_round_across_a_tile_boundary():
+@pytest.mark.parametrize("w,h,mode", [(376, 240, None), (376, 240, "1"), (376, 240, "2"), (1024, 1104, None)])
+def test_build_field_segments_that_round_across_a_tile_boundary(w, h, mode, monkeypatch):
     """The binned build_field works in 64 x 64 tiles.  A nearly axis-parallel segment whose centre sits within half a
     pixel of a tile boundary reaches the neighbouring tile only through round() (x = 383.5 -> pixel 384): such KeyLines
     must be binned into that tile too.  Crafted KeyLines on both sides of every tile boundary (and of the image
-    border), field compared exactly with the reference's build_field (global_tracker.cpp:61-105)."""
+    border), field compared exactly with the reference's build_field (global_tracker.cpp:61-105).
+    Also for the two other field builders: EDGEHIP_FIELD_MODE=1 (reference-shaped scatter with global atomics, kept for
+    A/B measurements) and =2 (tiles that scan the KeyLine mask, chosen automatically when the image has more than 256
+    tiles: the 1024 x 1104 case)."""
     from oracle import oracle
     if not oracle.available("ref"):
         pytest.skip("oracle/_ref not built")
-    w, h, r = 376, 240, 40
-    orc = oracle.Oracle("ref", oracle.euroc_params(w, h))
+    if mode is not None:
+        monkeypatch.setenv("EDGEHIP_FIELD_MODE", mode)
+    r = 40
     rs = np.random.RandomState(5)
-    kls = np.zeros(6000, oracle.KEYLINE_DTYPE)
-    n = len(kls)
+    n = 6000 if w < 1000 else 40000
+    kls = np.zeros(n, oracle.KEYLINE_DTYPE)
     bx = rs.randint(0, w // 64 + 2, n) * 64.0          # a tile boundary (or the image border) ...
     by = rs.randint(0, h // 64 + 2, n) * 64.0
     off = rs.uniform(-0.75, 0.75, n)                   # ... and a centre within 3/4 px of it
@@ -153,10 +158,22 @@ def test_build_field_segments_that_round_across_a_tile_boundary():
     kls["n_m"] = rs.uniform(1, 10, n).astype(np.float32)
     kls["m_m"] = kls["u_m"] * kls["n_m"][:, None]
     kls["rho"], kls["s_rho"] = 1.0, 1.0
-    orc.set_keylines(0, kls, None, 0.0)
-    eh = edgehip.EdgeHip(edgehip.euroc_params(w, h), nseq=1, nslots=2)
+    # the mask-scan builder finds KeyLines through img_mask_kl: one KeyLine per pixel, raster ids like the detector's
+    pix = np.round(kls["c_p"][:, 1]).astype(np.int64) * w + np.round(kls["c_p"][:, 0]).astype(np.int64)
+    _, first = np.unique(pix, return_index=True)
+    kls, pix = kls[np.sort(first)], pix[np.sort(first)]
+    order = np.argsort(pix, kind="stable")
+    kls, pix = kls[order], pix[order]
+    kls["p_inx"] = pix
+    mask = np.full(w * h, -1, np.int32)
+    mask[pix] = np.arange(len(kls), dtype=np.int32)
+    mask = mask.reshape(h, w)
+    cap = max(16000, len(kls) + 64)
+    orc = oracle.Oracle("ref", oracle.euroc_params(w, h, max_points=cap))
+    orc.set_keylines(0, kls, mask, 0.0)
+    eh = edgehip.EdgeHip(edgehip.euroc_params(w, h, max_points=cap), nseq=1, nslots=2)
     from helpers import to_edgehip_kl
-    eh.upload_keylines(0, 1, to_edgehip_kl(kls), None, 0.0)
+    eh.upload_keylines(0, 1, to_edgehip_kl(kls), mask, 0.0)
     orc.build_field(0, r, 0.0)
     eh.build_field(1, r, 0.0)
     f_ref, f_gpu = orc.field(0), eh.download_field(0)
