@@ -31,14 +31,13 @@ def level_mode_2():
         os.environ["EDGEHIP_LEVEL_MODE"] = old
 
 
-@pytest.mark.parametrize("name,w,h,und", CASES, ids=[c[0] for c in CASES])
-def test_level_kernel_bit_exact(level_mode_2, name, w, h, und):
+def _scale_space_case(name, w, h, und, over):
     from oracle import oracle
     kind = "ref" if oracle.available("ref") else "port"
     if und:
-        po, pe = oracle.tum_params(w, h, use_undistort=1), edgehip.tum_params(w, h, use_undistort=1)
+        po, pe = oracle.tum_params(w, h, use_undistort=1, **over), edgehip.tum_params(w, h, use_undistort=1, **over)
     else:
-        po, pe = oracle.euroc_params(w, h), edgehip.euroc_params(w, h)
+        po, pe = oracle.euroc_params(w, h, **over), edgehip.euroc_params(w, h, **over)
     pe.debug_planes = 1
     frames = [f for f, _, _ in synth.billboard_sequence(w, h, 3)]
     orc = oracle.Oracle(kind, po)
@@ -56,3 +55,24 @@ def test_level_kernel_bit_exact(level_mode_2, name, w, h, und):
         for fld in ("p_inx", "m_m", "n_m", "c_p", "p_id", "n_id"):
             assert np.array_equal(kg[fld], kr[fld]), fld
     eh.close()
+
+
+@pytest.mark.parametrize("name,w,h,und", CASES, ids=[c[0] for c in CASES])
+def test_level_kernel_bit_exact(level_mode_2, name, w, h, und):
+    _scale_space_case(name, w, h, und, {})
+
+
+# Other Sigma0 / KSigma than the shipped configs: box widths {5,7,7}/{7,7,9} and {1,3,3}/{3,3,5} instead of
+# {3,3,5}/{3,5,5} (iigauss.cpp:51-71) -- k_level's register reuse of the vertical taps is specialised for widths 3
+# and 5 and must fall back; the LUT of border divisors and the tap geometry depend on the widths everywhere.
+SIGMAS = [("wide", dict(sigma0=3.2, ksigma=1.2599)), ("narrow", dict(sigma0=1.2, ksigma=1.5))]
+
+
+@pytest.mark.parametrize("sname,over", SIGMAS, ids=[c[0] for c in SIGMAS])
+def test_other_sigmas_level_kernel(level_mode_2, sname, over):
+    _scale_space_case(sname, 376, 240, False, over)
+
+
+@pytest.mark.parametrize("sname,over", SIGMAS, ids=[c[0] for c in SIGMAS])
+def test_other_sigmas_multi_pass_kernels(sname, over):
+    _scale_space_case(sname, 376, 240, False, over)
