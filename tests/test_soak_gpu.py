@@ -69,3 +69,24 @@ def test_small_frames_sixty_deep(mode, monkeypatch):
         monkeypatch.setenv(mode, "1")
     frames = [f for f, _, _ in synth.billboard_sequence(376, 240, 12, seed=5)]
     _replay(frames, edgehip.euroc_params(376, 240), oracle.euroc_params(376, 240), 60, [0, 2, 7], 0.05)
+
+
+# Parameter values the shipped GlobalConfig files do not use: every branch they select must still follow the reference
+# (TrackerInitType 0/1, other iteration counts, DoReScaling, a KeyLine budget small enough to truncate, a
+# GlobalMatchThreshold nothing can meet so that every estimate is rejected, ...).
+VARIANTS = [
+    dict(tracker_init_type=0), dict(tracker_init_type=1), dict(tracker_init_iter_num=3), dict(tracker_init_iter_num=1),
+    dict(do_rescaling=1), dict(search_range=12), dict(search_range=64), dict(match_num_thresh=2), dict(match_num_thresh=6),
+    dict(pos_neg_thresh=0.2), dict(dog_thresh=0.2), dict(reweight_distance=1.0), dict(tracker_match_thresh=1.0),
+    dict(regularize_thresh=0.2), dict(max_points=3000, reference_points=2500), dict(global_match_threshold=20000),
+    dict(tracker_iter_num=1), dict(tracker_iter_num=12), dict(match_thresh_angle=20.0, match_thresh_module=0.3),
+    dict(loc_unc_match=1.0, loc_unc=2.0), dict(reshape_q_abs=1e-2, reshape_q_rel=1e-2), dict(qcut_quantile=0.5),
+    dict(qcut_nbins=50), dict(auto_gain=5e-6), dict(detector_thresh=0.05, auto_gain=0.0), dict(track_points=2000),
+]
+
+
+@pytest.mark.parametrize("over", VARIANTS, ids=[",".join(f"{k}={v}" for k, v in o.items()) for o in VARIANTS])
+def test_parameter_variants(over):
+    from oracle import oracle
+    frames = [f for f, _, _ in synth.billboard_sequence(376, 240, 14, seed=21)]
+    _replay(frames, edgehip.euroc_params(376, 240, **over), oracle.euroc_params(376, 240, **over), 14, [0], 0.05)
