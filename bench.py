@@ -273,7 +273,7 @@ def main():
     if world > 1:
         # nav records of every step -> rank 0 over RCCL (tiny: ~0.5 KB per frame)
         for ci, e in enumerate(ehs):
-            navs = e.read_nav_log(Wm, K)
+            navs = e.read_nav_log_array(Wm, K)
             seq_ids = list(range((rank * C + ci) * B, (rank * C + ci + 1) * B))
             shard.gather_records(shard.nav_records(navs, rank, seq_ids), dst=0)
     barrier()

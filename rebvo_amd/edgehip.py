@@ -129,6 +129,9 @@ class Nav(C.Structure):
     ]
 
 
+NAV_DTYPE = np.dtype(Nav)   # numpy view of edgehip_nav (same offsets as the ctypes struct)
+assert NAV_DTYPE.itemsize == C.sizeof(Nav)
+
 # every symbol include/edgehip.h declares (checked by tests/test_abi.py without a GPU)
 EXPORTS = [
     "edgehip_create", "edgehip_destroy", "edgehip_last_error", "edgehip_abi_version", "edgehip_sync",
@@ -298,6 +301,13 @@ class EdgeHip:
         out = (Nav * (count * self.nseq))()
         self._ck(self.lib.edgehip_read_nav_log(self.ctx, first, count, out))
         return [[out[k * self.nseq + s] for s in range(self.nseq)] for k in range(count)]
+
+    def read_nav_log_array(self, first, count):
+        """Same records as read_nav_log, as one numpy structured array [count, nseq] (fields = edgehip_nav's): no
+        per-record Python objects, for logs of many sequences."""
+        out = np.zeros((count, self.nseq), dtype=NAV_DTYPE)
+        self._ck(self.lib.edgehip_read_nav_log(self.ctx, first, count, out.ctypes.data_as(C.c_void_p)))
+        return out
 
     def sync(self):
         self._ck(self.lib.edgehip_sync(self.ctx))

@@ -19,6 +19,13 @@ def shard_sequences(n_total, rank, world):
 def nav_records(navs, rank, seq_ids):
     """navs: [steps][nseq] objects with frame/kn/klm_num/estimation_ok/Pos/V/W -> float64 [steps, nseq, 16]."""
     rec = np.zeros((len(navs), len(seq_ids), NAV_FIELDS))
+    if isinstance(navs, np.ndarray) and navs.dtype.names:   # structured array (EdgeHip.read_nav_log_array): no Python loop
+        for j, f in enumerate(("frame", "kn", "klm_num", "estimation_ok")):
+            rec[:, :, j] = navs[f]
+        rec[:, :, 4:7], rec[:, :, 7:10], rec[:, :, 10:13] = navs["Pos"], navs["V"], navs["W"]
+        rec[:, :, 13] = np.asarray(seq_ids)[None, :]
+        rec[:, :, 14] = rank
+        return rec
     for k, row in enumerate(navs):
         for s, n in enumerate(row):
             rec[k, s, :4] = (n.frame, n.kn, n.klm_num, n.estimation_ok)

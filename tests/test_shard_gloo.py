@@ -58,3 +58,26 @@ def test_gather_world2_gloo():
     assert sorted(out[:, 0, :, 13].ravel().tolist()) == [0, 1, 2, 3]   # every sequence reported once
     assert np.all(out[1, :, :, 14] == 1) and np.all(out[0, :, :, 14] == 0)
     assert np.allclose(out[1, 2, 0, 4:7], [2, 2, 0.5])
+
+
+def test_nav_records_from_structured_log_equals_object_path():
+    """bench.py reads the per-frame nav log of a 1024-sequence batch as one numpy structured array
+    (EdgeHip.read_nav_log_array): the records built from it equal the per-object path, field for field."""
+    import numpy as np
+    from rebvo_amd import edgehip, shard
+    K, B = 5, 7
+    rs = np.random.RandomState(3)
+    arr = np.zeros((K, B), dtype=edgehip.NAV_DTYPE)
+    arr["frame"] = np.arange(K)[:, None]
+    arr["kn"] = rs.randint(0, 16000, (K, B))
+    arr["klm_num"] = rs.randint(0, 16000, (K, B))
+    arr["estimation_ok"] = rs.randint(0, 2, (K, B))
+    for f in ("Pos", "V", "W"):
+        arr[f] = rs.normal(size=(K, B, 3))
+    objs = (edgehip.Nav * (K * B)).from_buffer(bytearray(arr.tobytes()))
+    rows = [[objs[k * B + s] for s in range(B)] for k in range(K)]
+    seq_ids = list(range(100, 100 + B))
+    a = shard.nav_records(arr, 3, seq_ids)
+    b = shard.nav_records(rows, 3, seq_ids)
+    assert a.shape == (K, B, shard.NAV_FIELDS) and np.array_equal(a, b)
+    assert np.array_equal(a[..., 13], np.tile(np.arange(100, 100 + B), (K, 1))) and (a[..., 14] == 3).all()
