@@ -208,10 +208,18 @@ def main():
 
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X (torch.cuda.is_available() is False); there is no CPU path")
+    # BENCH_BACKEND=gloo is a dry run of the multi-rank control flow on a box with fewer GPUs than ranks (ranks share
+    # devices); the real thing is nccl (= RCCL), one rank per GPU
+    backend = os.environ.get("BENCH_BACKEND", "nccl")
+    if backend != "nccl":
+        local_rank %= torch.cuda.device_count()
     torch.cuda.set_device(local_rank)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+        if backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group(backend, rank=rank, world_size=world)
 
     if args.overlap:
         os.environ["EDGEHIP_OVERLAP"] = "1"
@@ -279,7 +287,7 @@ def main():
     barrier()
     dt = time.perf_counter() - t0
     if world > 1:
-        tmax = torch.tensor([dt], dtype=torch.float64, device="cuda")
+        tmax = torch.tensor([dt], dtype=torch.float64, device="cuda" if backend == "nccl" else "cpu")
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         dt = float(tmax.item())
 
@@ -324,7 +332,7 @@ def main():
     # ---- CPU baseline: the reference's own code on one host core, bounded sample ----
     cpu = None
     pose = None
-    if args.cpu_frames > 0:
+    if args.cpu_frames > 0 and (world == 1 or os.environ.get("BENCH_CPU_BASELINE_ALWAYS")):   # rank 0 at N=1 only
         try:
             from oracle import oracle
             kind = "reference" if oracle.available("ref") else ("port" if oracle.available("port") else None)
