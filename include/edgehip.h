@@ -141,7 +141,9 @@ int edgehip_upload_rgb(edgehip_ctx *ctx, int slot, const uint8_t *rgb24, int seq
 int edgehip_upload_rgb_device(edgehip_ctx *ctx, int slot, const void *rgb24_dev);
 /* Host frames without the staging copy: the source is page-locked memory from edgehip_alloc_pinned (count frames for
  * sequences seq_first .. seq_first+count-1) and is read by an asynchronous copy — leave it untouched until the next
- * call that synchronises (edgehip_sync, edgehip_read_nav, ...) or write the next frames into a second buffer. */
+ * call that synchronises (edgehip_sync, edgehip_read_nav, ...) or write the next frames into a second buffer.
+ * The copy is enqueued on a dedicated upload stream: it runs under stage A and stages B/C of the frames before, waits
+ * by itself for the frame that last used the slot, and stage A of the slot waits for it. */
 int edgehip_alloc_pinned(size_t bytes, void **out);
 int edgehip_free_pinned(void *p);
 int edgehip_upload_rgb_pinned(edgehip_ctx *ctx, int slot, const uint8_t *rgb24_pinned, int seq_first, int count);

@@ -23,6 +23,14 @@ int wait_pinned_ring(edgehip_ctx *c) {
     return 0;
 }
 
+int wait_upload(edgehip_ctx *c, int slot, hipStream_t st) {
+    if (slot >= 0 && slot < 4 && c->up_valid[slot]) {
+        EH_CHECK(hipStreamWaitEvent(st, c->ev_up[slot], 0));
+        c->up_valid[slot] = false;
+    }
+    return 0;
+}
+
 void drop_frame_graphs(edgehip_ctx *c) {
     for (auto &kv : c->frame_graphs) (void)hipGraphExecDestroy(kv.second);
     c->frame_graphs.clear();
@@ -38,6 +46,7 @@ int order_bc_after_a(edgehip_ctx *c) {
     return 0;
 }
 int sync_all(edgehip_ctx *c) {
+    EH_CHECK(hipStreamSynchronize(c->stream_up));
     EH_CHECK(hipStreamSynchronize(c->stream_a));
     EH_CHECK(hipStreamSynchronize(c->stream));
     return 0;
@@ -300,6 +309,8 @@ int edgehip_create(const edgehip_params *params, int nseq, int nslots, int devic
     c->prof = new Profiler();
     EH_CHECK(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
     EH_CHECK(hipStreamCreateWithFlags(&c->stream_a, hipStreamNonBlocking));
+    EH_CHECK(hipStreamCreateWithFlags(&c->stream_up, hipStreamNonBlocking));
+    for (int i = 0; i < 4; i++) { EH_CHECK(hipEventCreateWithFlags(&c->ev_up[i], hipEventDisableTiming)); c->up_valid[i] = false; c->slot_ring[i] = -1; c->a_api_valid[i] = false; }
     for (int i = 0; i < 4; i++) {
         EH_CHECK(hipEventCreateWithFlags(&c->ev_a[i], hipEventDisableTiming));
         EH_CHECK(hipEventCreateWithFlags(&c->ev_use[i], hipEventDisableTiming));
@@ -480,6 +491,7 @@ int edgehip_destroy(edgehip_ctx *c) {
     if (c) drop_frame_graphs(c);
     if (!c) return EDGEHIP_ERR_ARG;
     (void)hipSetDevice(c->device);
+    (void)hipStreamSynchronize(c->stream_up);
     (void)hipStreamSynchronize(c->stream_a);
     (void)hipStreamSynchronize(c->stream);
     for (size_t i = 0; i < g_allocs.size(); i++) {
@@ -499,6 +511,8 @@ int edgehip_destroy(edgehip_ctx *c) {
     for (int i = 0; i < 4; i++) { (void)hipEventDestroy(c->ev_a[i]); (void)hipEventDestroy(c->ev_use[i]); }
     (void)hipEventDestroy(c->ev_tmp);
     for (int i = 0; i < 8; i++) (void)hipEventDestroy(c->ev_ring[i]);
+    for (int i = 0; i < 4; i++) (void)hipEventDestroy(c->ev_up[i]);
+    (void)hipStreamDestroy(c->stream_up);
     (void)hipStreamDestroy(c->stream_a);
     (void)hipStreamDestroy(c->stream);
     delete c;
@@ -551,6 +565,7 @@ static void unbind_rgb(edgehip_ctx *c, int slot) {
 int edgehip_upload_rgb(edgehip_ctx *c, int slot, const uint8_t *rgb24, int seq_first, int count) {
     if (int e = check_slot(c, slot)) return e;
     unbind_rgb(c, slot);
+    if (int e = wait_upload(c, slot, c->stream_a)) return e;
     if (!rgb24 || seq_first < 0 || count < 1 || seq_first + count > c->plan.nseq) { set_error("upload_rgb: bad range"); return EDGEHIP_ERR_ARG; }
     const size_t fb = (size_t)c->plan.n * 3;
     // the pinned buffer is reused: wait for the previous copy out of it
@@ -576,13 +591,20 @@ int edgehip_upload_rgb_pinned(edgehip_ctx *c, int slot, const uint8_t *rgb24_pin
     unbind_rgb(c, slot);
     if (!rgb24_pinned || seq_first < 0 || count < 1 || seq_first + count > c->plan.nseq) { set_error("upload_rgb_pinned: bad range"); return EDGEHIP_ERR_ARG; }
     const size_t fb = (size_t)c->plan.n * 3;
-    EH_CHECK(hipMemcpyAsync(rgbof(c, slot) + fb * seq_first, rgb24_pinned, fb * count, hipMemcpyHostToDevice, c->stream_a));
+    // On the upload stream: the copy of frame k+1 runs under stage A AND stages B/C of frame k.  It may start once the
+    // last frame that was processed in this slot is done (nothing reads a slot's RGB after its own stage A).
+    if (c->slot_ring[slot] >= 0) EH_CHECK(hipStreamWaitEvent(c->stream_up, c->ev_ring[c->slot_ring[slot]], 0));
+    if (c->a_api_valid[slot]) { EH_CHECK(hipStreamWaitEvent(c->stream_up, c->ev_a[slot], 0)); c->a_api_valid[slot] = false; }
+    EH_CHECK(hipMemcpyAsync(rgbof(c, slot) + fb * seq_first, rgb24_pinned, fb * count, hipMemcpyHostToDevice, c->stream_up));
+    EH_CHECK(hipEventRecord(c->ev_up[slot], c->stream_up));
+    c->up_valid[slot] = true;
     return 0;
 }
 
 int edgehip_upload_rgb_device(edgehip_ctx *c, int slot, const void *rgb24_dev) {
     if (int e = check_slot(c, slot)) return e;
     unbind_rgb(c, slot);
+    if (int e = wait_upload(c, slot, c->stream_a)) return e;
     if (!rgb24_dev) return EDGEHIP_ERR_ARG;
     EH_CHECK(hipMemcpyAsync(rgbof(c, slot), rgb24_dev, (size_t)c->plan.nseq * c->plan.n * 3, hipMemcpyDeviceToDevice, c->stream_a));
     return 0;
@@ -591,6 +613,7 @@ int edgehip_upload_rgb_device(edgehip_ctx *c, int slot, const void *rgb24_dev) {
 int edgehip_upload_rgb_indexed(edgehip_ctx *c, int slot, const void *pool_dev, int pool_frames, const int32_t *idx) {
     if (int e = check_slot(c, slot)) return e;
     unbind_rgb(c, slot);
+    if (int e = wait_upload(c, slot, c->stream_a)) return e;
     if (!pool_dev || !idx || pool_frames < 1) return EDGEHIP_ERR_ARG;
     const int B = c->plan.nseq;
     int32_t *pi = (int32_t *)(c->pinned_t + (size_t)8 * B) ;  // tail of the pinned time ring (see create)
@@ -657,7 +680,10 @@ int edgehip_read_nav_log(edgehip_ctx *c, int first, int count, edgehip_nav *out)
 int edgehip_stage_a(edgehip_ctx *c, int slot) {
     if (int e = check_slot(c, slot)) return e;
     if (int e = order_a_after_bc(c)) return e;
+    if (int e = wait_upload(c, slot, c->stream_a)) return e;
     if (int e = stage_a_enqueue(c, slot)) return e;
+    EH_CHECK(hipEventRecord(c->ev_a[slot], c->stream_a));
+    c->a_api_valid[slot] = true;
     return order_bc_after_a(c);
 }
 

@@ -134,6 +134,11 @@ struct edgehip_ctx {
     hipEvent_t ev_a[4];    // [slot] stage A of the frame in this slot has finished
     hipEvent_t ev_use[4];  // [slot] the last B/C work that read this slot has finished
     hipEvent_t ev_tmp;     // ordering of the stage-level entry points
+    hipStream_t stream_up; // uploads of page-locked frames: they overlap stage A as well as B/C of the frames before
+    hipEvent_t ev_up[4];   // [slot] the last upload into this slot on stream_up has finished
+    bool up_valid[4];
+    int slot_ring[4];      // [slot] ev_ring entry of the last frame processed in this slot (-1: none)
+    bool a_api_valid[4];   // [slot] ev_a was recorded by the stage-level edgehip_stage_a (an upload must wait for it)
     hipEvent_t ev_ring[8]; // [frame % 8] the frame that used this entry of the pinned time-stamp / frame-index rings is done
     bool ring_valid[8];
     bool use_valid[4];
@@ -265,6 +270,7 @@ struct ProfScope {  // RAII bracket; no-op unless profiling is enabled
 int stage_a_enqueue(edgehip_ctx *c, int slot);
 // ordering between the two streams for entry points that are not edgehip_process_frame: everything enqueued so far on
 // one stream is finished before anything enqueued afterwards on the other starts
+int wait_upload(edgehip_ctx *c, int slot, hipStream_t st);   // make `st` wait for a pending stream_up upload into the slot
 int wait_pinned_ring(edgehip_ctx *c);     // before writing entry frames_seen % 8 of the pinned time-stamp / frame-index rings
 void drop_frame_graphs(edgehip_ctx *c);   // after anything that changes what a captured frame would enqueue
 int order_a_after_bc(edgehip_ctx *c);

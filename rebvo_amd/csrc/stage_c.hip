@@ -1184,9 +1184,13 @@ int edgehip_process_frame(edgehip_ctx *c, const double *t) {
     if (int e = wait_pinned_ring(c)) return e;
     memcpy(tp, t, sizeof(double) * pl.nseq);
     const bool profiling = c->prof && c->prof->on;
+    const bool graph_path = c->use_graph && !c->overlap && !profiling && c->frames_seen >= 2;
+    // frames uploaded on the upload stream (edgehip_upload_rgb_pinned): stage A waits for the copy into its slot
+    if (int e = wait_upload(c, sn, graph_path ? c->stream : c->stream_a)) return e;
+    if (sp >= 0) { if (int e = wait_upload(c, sp, graph_path ? c->stream : c->stream_a)) return e; }
     // the first frames run eagerly (one-time kernel attributes, no frame pair yet); then every (slot, FrameCount row,
     // pinned time-stamp slot) combination — period lcm(ring, 8) — is captured once and replayed
-    if (c->use_graph && !c->overlap && !profiling && c->frames_seen >= 2) {
+    if (graph_path) {
         const int key = sn + 8 * (c->frames_seen % 8) + 64 * (sp + 1);
         if (int e = order_bc_after_a(c)) return e;   // the caller's uploads (stage-A stream) precede the graph
         auto it = c->frame_graphs.find(key);
@@ -1216,6 +1220,9 @@ int edgehip_process_frame(edgehip_ctx *c, const double *t) {
     // the pinned ring entries of this frame (time stamps, bound frame indices) are free once it has run
     EH_CHECK(hipEventRecord(c->ev_ring[c->frames_seen % 8], c->stream));
     c->ring_valid[c->frames_seen % 8] = true;
+    c->slot_ring[sn] = c->frames_seen % 8;
+    c->a_api_valid[sn] = false;
+    if (sp >= 0) { c->slot_ring[sp] = c->frames_seen % 8; c->a_api_valid[sp] = false; }
     c->frame_slot = sn;
     c->frames_seen++;
     return 0;

@@ -174,7 +174,8 @@ def test_bound_pool_frames_equal_copied_frames():
     a.close(); b.close()
 
 
-def test_replay_without_host_sync_runs_ahead_of_the_device():
+@pytest.mark.parametrize("source", ["bound_pool", "pinned_upload"])
+def test_replay_without_host_sync_runs_ahead_of_the_device(source):
     """A replay that never synchronises between frames (bench.py's loop: bind the frames, process, next) lets the host
     get more than 8 frames ahead of the device, past the depth of the pinned time-stamp / frame-index rings.  Every
     frame must still see its own time stamp and its own pool indices: the nav log of two sequences equals the CPU
@@ -190,11 +191,22 @@ def test_replay_without_host_sync_runs_ahead_of_the_device():
     t = lambda k: 0.05 * k + 0.003 * (k % 3)   # uneven stamps: a stale ring entry would change dt
     eh = edgehip.EdgeHip(edgehip.euroc_params(w, h), nseq=B, nslots=3)
     eh.set_nav_log(nf)
+    pinned = []
     for k in range(nf):
         idx = np.array([tri(k + s) for s in range(B)], np.int32)
-        eh.bind_rgb_indexed(eh.next_slot(), pool.data_ptr(), npool, idx)
+        if source == "bound_pool":
+            eh.bind_rgb_indexed(eh.next_slot(), pool.data_ptr(), npool, idx)
+        else:
+            # page-locked frames go over the upload stream, under stage A and B/C of the frames before: the copy into a
+            # slot must wait for the frame that used the slot three frames earlier, and stage A for the copy
+            arr, ptr = eh.alloc_pinned_frames()
+            arr[...] = np.stack([frames[i] for i in idx])
+            pinned.append(ptr)
+            eh.upload_rgb_pinned(eh.next_slot(), ptr)
         eh.process_frame(t(k))
     log = eh.read_nav_log(0, nf)
+    for ptr in pinned:
+        eh.free_pinned(ptr)
     for s in (0, B - 1):
         orc = _oracle(w, h)
         for k in range(nf):
