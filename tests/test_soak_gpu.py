@@ -90,3 +90,35 @@ def test_parameter_variants(over):
     from oracle import oracle
     frames = [f for f, _, _ in synth.billboard_sequence(376, 240, 14, seed=21)]
     _replay(frames, edgehip.euroc_params(376, 240, **over), oracle.euroc_params(376, 240, **over), 14, [0], 0.05)
+
+
+def test_stereo_thirty_frames_without_sync():
+    """StereoAvaiable: main and pair frames uploaded, 30 frames enqueued back to back (the pair slot sits outside the
+    frame ring and is rewritten every frame), nav log against the reference's stereo frame order."""
+    from oracle import oracle
+    if not oracle.available("ref"):
+        pytest.skip("oracle/_ref not built")
+    import test_stereo_gpu as T
+    nf = 30
+    p, frames, pairs, pc = T.make_data(all_pairs=True, nf=nf)
+    orc = oracle.Oracle("ref", oracle.euroc_params(T.W, T.H))
+    orc.enable_stereo(pc["ppx"], pc["ppy"], pc["zfx"], pc["zfy"], T.T_PAIR, T.R_PAIR, 100.0)
+    eh = edgehip.EdgeHip(edgehip.euroc_params(T.W, T.H, stereo_available=1), nseq=2, nslots=4)
+    eh.set_slot_camera(3, pc["ppx"], pc["ppy"], pc["zfx"], pc["zfy"])
+    eh.set_stereo_rig(3, T.T_PAIR, T.R_PAIR, 100.0)
+    eh.set_nav_log(nf)
+    for k in range(nf):
+        eh.upload_rgb(eh.next_slot(), np.stack([frames[k]] * 2))
+        eh.upload_rgb(3, np.stack([pairs[k]] * 2))
+        eh.process_frame(0.05 * k)
+    log = eh.read_nav_log(0, nf)
+    eh.close()
+    for k in range(nf):
+        _, nr = orc.process_frame_stereo(frames[k], pairs[k], 0.05 * k)
+        for ng in log[k]:
+            assert ng.kn == nr.kn
+            if k == 0:
+                continue
+            assert (ng.estimation_ok, ng.klm_num) == (nr.estimation_ok, nr.klm_num), k
+            assert np.allclose(ng.V[:], nr.V[:], rtol=0, atol=1e-9) and np.allclose(ng.W[:], nr.W[:], rtol=0, atol=1e-9), k
+            assert np.allclose(ng.Pos[:], nr.Pos[:], rtol=0, atol=1e-8), k
