@@ -310,7 +310,7 @@ int edgehip_create(const edgehip_params *params, int nseq, int nslots, int devic
     EH_CHECK(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
     EH_CHECK(hipStreamCreateWithFlags(&c->stream_a, hipStreamNonBlocking));
     EH_CHECK(hipStreamCreateWithFlags(&c->stream_up, hipStreamNonBlocking));
-    for (int i = 0; i < 4; i++) { EH_CHECK(hipEventCreateWithFlags(&c->ev_up[i], hipEventDisableTiming)); c->up_valid[i] = false; c->slot_ring[i] = -1; c->a_api_valid[i] = false; }
+    for (int i = 0; i < 4; i++) { EH_CHECK(hipEventCreateWithFlags(&c->ev_up[i], hipEventDisableTiming)); c->up_valid[i] = false; c->slot_ring[i] = -1; c->a_api_valid[i] = false; c->grec_ok[i] = false; }
     for (int i = 0; i < 4; i++) {
         EH_CHECK(hipEventCreateWithFlags(&c->ev_a[i], hipEventDisableTiming));
         EH_CHECK(hipEventCreateWithFlags(&c->ev_use[i], hipEventDisableTiming));
@@ -395,6 +395,7 @@ int edgehip_create(const edgehip_params *params, int nseq, int nslots, int devic
     }
     c->field_radius = p.search_range;
     c->field_mode = getenv("EDGEHIP_FIELD_MODE") ? atoi(getenv("EDGEHIP_FIELD_MODE")) : 0;
+    c->no_grec = getenv("EDGEHIP_NO_GREC") && atoi(getenv("EDGEHIP_NO_GREC")) != 0;
     c->level_mode = getenv("EDGEHIP_LEVEL_MODE") ? atoi(getenv("EDGEHIP_LEVEL_MODE")) : 0;
     c->overlap = getenv("EDGEHIP_OVERLAP") ? atoi(getenv("EDGEHIP_OVERLAP")) : 0;
     EH_TRY(dmalloc(c, &c->fwd_key, B * CAP, al->dev, 0));
@@ -417,7 +418,7 @@ int edgehip_create(const edgehip_params *params, int nseq, int nslots, int devic
         auto up = [&](size_t x) { return (x + al256 - 1) / al256 * al256; };
         const bool stereo = p.stereo_available != 0;
         const size_t per = up(CAP * 4) * 8 /* p_inx, n_m, m_id, m_id_f, m_id_kf, m_num, p_id, n_id */ +
-                           up(CAP * 8) * 6 /* float2 */ + up(CAP * 8) * 7 /* double */ + up(CAP * 32) +
+                           up(CAP * 8) * 6 /* float2 */ + up(CAP * 8) * 7 /* double */ + up(CAP * 32) + up(CAP * 16) /* grec */ +
                            (stereo ? up(CAP * 4) + 2 * up(CAP * 8) : 0);
         char *arena;
         EH_TRY(dmalloc(c, &arena, per * S * B, al->dev, 0));
@@ -437,6 +438,7 @@ int edgehip_create(const edgehip_params *params, int nseq, int nslots, int devic
             k.m_id = (int32_t *)take(CAP * 4); k.m_id_f = (int32_t *)take(CAP * 4); k.m_id_kf = (int32_t *)take(CAP * 4);
             k.m_num = (int32_t *)take(CAP * 4); k.p_id = (int32_t *)take(CAP * 4); k.n_id = (int32_t *)take(CAP * 4);
             k.rec = (MatchRec *)take(CAP * 32);
+            k.grec = (float4 *)take(CAP * 16);
             k.stereo_m_id = nullptr; k.stereo_rho = nullptr; k.stereo_s_rho = nullptr;
             if (stereo) {
                 k.stereo_m_id = (int32_t *)take(CAP * 4);
@@ -808,6 +810,8 @@ int edgehip_upload_keylines(edgehip_ctx *c, int seq, int slot, const edgehip_key
     std::vector<float> n_m(kn);
     std::vector<double> rho(kn), s_rho(kn), rho_nr(kn), s_rho_nr(kn), rho0(kn), s_rho0(kn), n_m0(kn);
     std::vector<MatchRec> rec(kn);
+    std::vector<float4> grec(kn);
+    bool consistent = true;   // u_m == m_m / sqrt(m_m . m_m) in float arithmetic, for every KeyLine
     for (int i = 0; i < kn; i++) {
         const edgehip_keyline &o = kl[i];
         p_inx[i] = o.p_inx;
@@ -820,6 +824,15 @@ int edgehip_upload_keylines(edgehip_ctx *c, int seq, int slot, const edgehip_key
         MatchRec r; r.c_px = o.c_p[0]; r.c_py = o.c_p[1]; r.u_mx = o.u_m[0]; r.u_my = o.u_m[1];
         r.m_mx = o.m_m[0]; r.m_my = o.m_m[1]; r.n_m = o.n_m; r.pad = 0.f;
         rec[i] = r;
+        grec[i] = make_float4(o.c_p[0], o.c_p[1], o.m_m[0], o.m_m[1]);
+        {
+            volatile float n2 = o.m_m[0] * o.m_m[0];   // volatile: no contraction, no excess precision
+            volatile float t2 = o.m_m[1] * o.m_m[1];
+            n2 = n2 + t2;
+            const float nn = sqrtf(n2);
+            volatile float ux = o.m_m[0] / nn, uy = o.m_m[1] / nn;
+            if (!(ux == o.u_m[0] && uy == o.u_m[1])) consistent = false;
+        }
     }
     int e = 0;
     e |= h2d(c, k.p_inx, p_inx); e |= h2d(c, k.m_id, m_id); e |= h2d(c, k.m_id_f, m_id_f); e |= h2d(c, k.m_id_kf, m_id_kf);
@@ -827,7 +840,7 @@ int edgehip_upload_keylines(edgehip_ctx *c, int seq, int slot, const edgehip_key
     e |= h2d(c, k.m_m, m_m); e |= h2d(c, k.u_m, u_m); e |= h2d(c, k.c_p, c_p); e |= h2d(c, k.p_m, p_m);
     e |= h2d(c, k.p_m_0, p_m_0); e |= h2d(c, k.m_m0, m_m0); e |= h2d(c, k.n_m, n_m);
     e |= h2d(c, k.rho, rho); e |= h2d(c, k.s_rho, s_rho); e |= h2d(c, k.rho_nr, rho_nr); e |= h2d(c, k.s_rho_nr, s_rho_nr);
-    e |= h2d(c, k.rho0, rho0); e |= h2d(c, k.s_rho0, s_rho0); e |= h2d(c, k.n_m0, n_m0); e |= h2d(c, k.rec, rec);
+    e |= h2d(c, k.rho0, rho0); e |= h2d(c, k.s_rho0, s_rho0); e |= h2d(c, k.n_m0, n_m0); e |= h2d(c, k.rec, rec); e |= h2d(c, k.grec, grec);
     if (k.stereo_m_id) {
         std::vector<int32_t> st_id(kn);
         std::vector<double> st_rho(kn), st_srho(kn);
@@ -835,6 +848,8 @@ int edgehip_upload_keylines(edgehip_ctx *c, int seq, int slot, const edgehip_key
         e |= h2d(c, k.stereo_m_id, st_id); e |= h2d(c, k.stereo_rho, st_rho); e |= h2d(c, k.stereo_s_rho, st_srho);
     }
     if (e) return EDGEHIP_ERR_DEVICE;
+    // the 16-byte gather records stand for the slot only if they do for every sequence in it
+    c->grec_ok[slot] = consistent && (c->plan.nseq == 1 || c->grec_ok[slot]);
     EH_CHECK(hipMemcpyAsync(c->kn_slot + (size_t)slot * c->plan.nseq + seq, &kn, 4, hipMemcpyHostToDevice, c->stream));
     if (mask) EH_CHECK(hipMemcpyAsync(maskof(c, slot) + (size_t)seq * c->plan.n, mask, sizeof(int32_t) * c->plan.n, hipMemcpyHostToDevice, c->stream));
     EH_CHECK(hipMemcpyAsync(c->retuned_slot + (size_t)slot * c->plan.nseq + seq, &retuned, 4, hipMemcpyHostToDevice, c->stream));

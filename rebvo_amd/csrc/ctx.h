@@ -47,6 +47,10 @@ struct KlSoA {
     double *rho, *s_rho, *rho_nr, *s_rho_nr, *rho0, *s_rho0, *n_m0;
     int32_t *m_id, *m_id_f, *m_id_kf, *m_num, *p_id, *n_id;
     MatchRec *rec;  // (c_p, u_m, m_m, n_m) packed for gathers; kept in sync with the fields above
+    // (c_p, m_m): the 16 bytes TryVelRot needs of the KeyLine it matched, when u_m == m_m / sqrt(m_m . m_m) holds bit for
+    // bit (every freshly detected KeyLine: edge_finder.cpp:166-200) and can be recomputed instead of fetched.  Valid
+    // only while edgehip_ctx::grec_ok[slot] (cleared by rotate_keylines, which turns m_m but not u_m).
+    float4 *grec;
     // stereo fields (null unless params.stereo_available)
     int32_t *stereo_m_id;
     double *stereo_rho, *stereo_s_rho;
@@ -138,6 +142,8 @@ struct edgehip_ctx {
     hipEvent_t ev_up[4];   // [slot] the last upload into this slot on stream_up has finished
     bool up_valid[4];
     int slot_ring[4];      // [slot] ev_ring entry of the last frame processed in this slot (-1: none)
+    bool no_grec;          // EDGEHIP_NO_GREC=1: always gather the 32-byte record (A/B measurements)
+    bool grec_ok[4];       // [slot] KlSoA::grec describes the slot's KeyLines (all sequences)
     bool a_api_valid[4];   // [slot] ev_a was recorded by the stage-level edgehip_stage_a (an upload must wait for it)
     hipEvent_t ev_ring[8]; // [frame % 8] the frame that used this entry of the pinned time-stamp / frame-index rings is done
     bool ring_valid[8];

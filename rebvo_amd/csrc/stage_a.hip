@@ -975,6 +975,7 @@ __global__ __launch_bounds__(256) void k_emit(EmitArgs a) {
         rec.c_px = cp.x; rec.c_py = cp.y; rec.u_mx = u.x; rec.u_my = u.y;
         rec.m_mx = m.x; rec.m_my = m.y; rec.n_m = nm; rec.pad = 0.f;
         k.rec[i] = rec;
+        k.grec[i] = make_float4(cp.x, cp.y, m.x, m.y);
         a.mask[(size_t)seq * a.n + p] = i;
     }
     __shared__ float s_mx[4], s_mn[4];
@@ -1294,6 +1295,7 @@ int stage_a_enqueue(edgehip_ctx *c, int slot) {
         e.ppx = c->slot_cam[slot].ppx; e.ppy = c->slot_cam[slot].ppy;   // the slot's camera (a stereo pair slot may differ)
         hipLaunchKernelGGL(k_emit, dim3((pl.cap + 255) / 256, 1, B), dim3(256), 0, st, e);
         EH_LAUNCH_CHECK();
+        c->grec_ok[slot] = true;   // freshly detected KeyLines: u_m = m_m / |m_m| holds for all of them
     }
     {
         ProfScope ps(c, PROF_A_JOIN, st);

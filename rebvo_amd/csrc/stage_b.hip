@@ -468,11 +468,12 @@ struct TvrArgs {
     float ppx, ppy;
     uint32_t match_num_thresh;
     int write_mid;             // store kl.m_id_f (only the last evaluation of a minimisation needs to)
+    int use_grec;   // host-side choice of the gather record (edgehip_ctx::grec_ok of the new slot)
 };
 
 __device__ __forceinline__ bool is_carry(double v) { return __double_as_longlong(v) == (long long)resid_carry_bits(); }
 
-template <bool REWEIGHT, bool PROCJF>
+template <bool REWEIGHT, bool PROCJF, bool GREC>
 __global__ __launch_bounds__(kTvrThreads) void k_try_velrot(TvrArgs a) {
     const int seq = blockIdx.z, blk = blockIdx.x, tid = threadIdx.x;
     const int lane = tid & 63, wave = tid >> 6;
@@ -551,15 +552,30 @@ __global__ __launch_bounds__(kTvrThreads) void k_try_velrot(TvrArgs a) {
                     const uint32_t f = a.field[(size_t)seq * a.fstride + field_index(x, y, a.ftx)];
                     if (f != 0xFFFFFFFFu) {
                         const int ikf = 0xFFFF - (int)(f & 0xFFFFu);
-                        const MatchRec fr = a.kl_new[seq].rec[ikf];
+                        // The matched KeyLine's c_p, m_m, u_m.  GREC: a 16-byte record (four records share the 64 bytes
+                        // a random gather moves, instead of two) and u_m recomputed with the detector's own float
+                        // expressions (k_emit; edge_finder.cpp:166-200), valid for KeyLines nothing has rotated since.
+                        float f_cpx, f_cpy, f_mx, f_my, f_ux, f_uy;
+                        if (GREC) {
+                            const float4 g = a.kl_new[seq].grec[ikf];
+                            f_cpx = g.x; f_cpy = g.y; f_mx = g.z; f_my = g.w;
+                        } else {
+                            const MatchRec fr = a.kl_new[seq].rec[ikf];
+                            f_cpx = fr.c_px; f_cpy = fr.c_py; f_mx = fr.m_mx; f_my = fr.m_my; f_ux = fr.u_mx; f_uy = fr.u_my;
+                        }
                         // Test_f_k (float arithmetic inside, compared in double)
                         const double p_n2 = (double)(knm * knm);
-                        const double p_esc = (double)(rmx * fr.m_mx + rmy * fr.m_my);
+                        const double p_esc = (double)(rmx * f_mx + rmy * f_my);
                         if (!(fabs(p_esc - p_n2) > a.match_thresh * p_n2)) {
-                            const double dx = px - (double)fr.c_px, dy = py - (double)fr.c_py;
-                            fi = dx * (double)fr.u_mx + dy * (double)fr.u_my;
-                            dfx = (double)fr.u_mx;
-                            dfy = (double)fr.u_my;
+                            if (GREC) {
+                                const float n2m = f_mx * f_mx + f_my * f_my;
+                                const float nm = sqrtf(n2m);
+                                f_ux = f_mx / nm; f_uy = f_my / nm;
+                            }
+                            const double dx = px - (double)f_cpx, dy = py - (double)f_cpy;
+                            fi = dx * (double)f_ux + dy * (double)f_uy;
+                            dfx = (double)f_ux;
+                            dfy = (double)f_uy;
                             fm = fi;
                             mid_f = ikf;
                             status = 2;
@@ -1504,16 +1520,24 @@ static TvrArgs make_tvr_args(edgehip_ctx *c, int slot_new, int slot_old, double 
     a.w = pl.w; a.h = pl.h; a.cap = pl.cap; a.nblk = c->nblk_tvr; a.nseq = pl.nseq; a.fstride = pl.fstride; a.ftx = pl.ftx;
     a.zfm = pl.zfm; a.max_r = (double)c->field_radius; a.match_thresh = match_thresh; a.k_huber = k_huber;
     a.ppx = pl.ppx; a.ppy = pl.ppy; a.match_num_thresh = match_num_thresh; a.write_mid = write_mid;
+    a.use_grec = c->grec_ok[slot_new] && !c->no_grec;
     return a;
 }
 
 static int launch_tvr(edgehip_ctx *c, const TvrArgs &a, bool reweight, bool procjf) {
     ProfScope ps(c, PROF_B_TRYVELROT);
     dim3 g(c->nblk_tvr, 1, c->plan.nseq), b(kTvrThreads);
-    if (reweight && procjf) hipLaunchKernelGGL((k_try_velrot<true, true>), g, b, 0, c->stream, a);
-    else if (reweight) hipLaunchKernelGGL((k_try_velrot<true, false>), g, b, 0, c->stream, a);
-    else if (procjf) hipLaunchKernelGGL((k_try_velrot<false, true>), g, b, 0, c->stream, a);
-    else hipLaunchKernelGGL((k_try_velrot<false, false>), g, b, 0, c->stream, a);
+    if (a.use_grec) {
+        if (reweight && procjf) hipLaunchKernelGGL((k_try_velrot<true, true, true>), g, b, 0, c->stream, a);
+        else if (reweight) hipLaunchKernelGGL((k_try_velrot<true, false, true>), g, b, 0, c->stream, a);
+        else if (procjf) hipLaunchKernelGGL((k_try_velrot<false, true, true>), g, b, 0, c->stream, a);
+        else hipLaunchKernelGGL((k_try_velrot<false, false, true>), g, b, 0, c->stream, a);
+    } else {
+        if (reweight && procjf) hipLaunchKernelGGL((k_try_velrot<true, true, false>), g, b, 0, c->stream, a);
+        else if (reweight) hipLaunchKernelGGL((k_try_velrot<true, false, false>), g, b, 0, c->stream, a);
+        else if (procjf) hipLaunchKernelGGL((k_try_velrot<false, true, false>), g, b, 0, c->stream, a);
+        else hipLaunchKernelGGL((k_try_velrot<false, false, false>), g, b, 0, c->stream, a);
+    }
     EH_LAUNCH_CHECK();
     return 0;
 }

@@ -687,6 +687,7 @@ int forward_match_enqueue(edgehip_ctx *c, int slot_old, int slot_new) {
 }
 
 int rotate_enqueue(edgehip_ctx *c, int slot, const double *R_host) {
+    c->grec_ok[slot] = false;   // m_m turns, u_m does not (edge_tracker.cpp:42-76): u_m can no longer be recomputed from m_m
     ProfScope ps(c, PROF_C_ROTATE);
     const DevicePlan &pl = c->plan;
     double *Rbuf = c->rot_buf;
