@@ -182,3 +182,38 @@ def test_build_field_segments_that_round_across_a_tile_boundary(w, h, mode, monk
     assert m.sum() > 5000
     assert np.array_equal(f_ref[..., 0][m], f_gpu[..., 0][m]), "field dist differs"
     eh.close()
+
+
+def test_try_velrot_gather_record_variants(pair, monkeypatch):
+    """k_try_velrot gathers either a 16-byte record (c_p, m_m; u_m recomputed) or, when the new slot's KeyLines may have
+    been rotated (or EDGEHIP_NO_GREC=1), the 32-byte record with the stored u_m.  On detector KeyLines both must give
+    the same sums, residuals and forward matches bit for bit; after rotate_keylines of the NEW slot (m_m turns, u_m does
+    not: edge_tracker.cpp:42-76) the context must fall back by itself and still follow the reference."""
+    orc, so, sn, nav, eh_unused = pair
+    w, h = 376, 240
+    s_rho_q = orc.quantile(so)
+    X = np.r_[np.array(nav.V[:]), np.array(nav.W[:])]
+    outs = []
+    for no_grec in ("0", "1"):
+        monkeypatch.setenv("EDGEHIP_NO_GREC", no_grec)
+        eh = edgehip.EdgeHip(edgehip.euroc_params(w, h), nseq=1, nslots=2)
+        inject_pair(eh, orc, so, sn)
+        eh.build_field(1, 40, -1.0)
+        eh.try_velrot(1, 0, X * 0.5, False, True, 0.5, s_rho_q, 0, 2.0, resid_in=-1, resid_out=1)
+        F, JtJ, JtF = eh.try_velrot(1, 0, X, True, True, 0.5, s_rho_q, 0, 2.0, resid_in=1, resid_out=2)
+        kl, _ = eh.download_keylines(0, 0, want_mask=False)
+        outs.append((F.copy(), JtJ.copy(), JtF.copy(), eh.download_resid(2).copy(), kl["m_id_f"].copy()))
+        if no_grec == "0":
+            # rotate the NEW slot: the 16-byte record no longer describes it; the reference keeps the stale u_m
+            Rz = np.array([[np.cos(0.02), -np.sin(0.02), 0], [np.sin(0.02), np.cos(0.02), 0], [0, 0, 1.0]])
+            eh.rotate_keylines(1, Rz)
+            orc2_kl = orc.keylines(sn).copy()
+            orc.rotate_keylines(sn, Rz)
+            orc.build_field(sn, 40, orc.retuned(sn)); eh.build_field(1, 40, -1.0)
+            Fr, JtJr, JtFr, _ = orc.try_velrot(sn, so, X, False, True, 0.5, s_rho_q, 0, 2.0)
+            Fg, JtJg, JtFg = eh.try_velrot(1, 0, X, False, True, 0.5, s_rho_q, 0, 2.0, resid_in=-1, resid_out=1)
+            assert rel_err(Fg[0], Fr) < TOL_SUMS and rel_err(JtJg[0], JtJr) < TOL_SUMS
+            orc.set_keylines(sn, orc2_kl, orc.mask(sn), orc.retuned(sn))   # put the fixture back
+        eh.close()
+    for a, b in zip(outs[0], outs[1]):
+        assert np.array_equal(a, b)
