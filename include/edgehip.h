@@ -293,7 +293,9 @@ int edgehip_upload_keylines(edgehip_ctx *ctx, int seq, int slot, const edgehip_k
 /* Planes of the scale space (debug_planes must be set): which = 0 img0, 1 img1, 2 dog, 3 dx, 4 dy.
  * out[h*w] float.  Synchronises. */
 int edgehip_download_plane(edgehip_ctx *ctx, int seq, int which, float *out);
-/* Auxiliary field of the tracker in the reference's {dist, ikl} form (global_tracker.h:33-36); out[h*w*2]. */
+/* Auxiliary field of the tracker in the reference's {dist, ikl} form (global_tracker.h:33-36); out[h*w*2].
+ * The tracker only ever reads ikl, so the device keeps a 2-byte KeyLine-index plane; dist is stored as well (and
+ * returned here) when params.debug_planes is set, otherwise it is reported as -1 (0 where the pixel is empty). */
 int edgehip_download_field(edgehip_ctx *ctx, int seq, int32_t *out);
 /* The undistortion map edgehip_create() builds for `params` (host-only, needs no device), in the reference's
  * undistMapPoint form (image_undistort.h:41-47): inx[h*w*4] valid taps first, -1 beyond `num`; iw[h*w*4]. */

@@ -324,6 +324,8 @@ int edgehip_create(const edgehip_params *params, int nseq, int nslots, int devic
     pl.w = p.w; pl.h = p.h; pl.n = p.w * p.h; pl.nseq = nseq; pl.nslots = nslots;
     pl.ftx = (p.w + 3) / 4;
     pl.fstride = (size_t)pl.ftx * (size_t)((p.h + 3) / 4) * 16;
+    pl.f16tx = (p.w + 7) / 8;
+    pl.f16stride = (size_t)pl.f16tx * (size_t)((p.h + 3) / 4) * 32;
     pl.cap = std::min(p.max_points, EDGEHIP_KEYLINE_MAX);  // build_mask clamps kl_max to kl_size
     const double sr0 = kovesi_boxes(p.sigma0, kMaxBoxes, pl.box[0]);       // sspace.cpp:45
     kovesi_boxes(sr0 * p.ksigma, kMaxBoxes, pl.box[1]);
@@ -347,6 +349,8 @@ int edgehip_create(const edgehip_params *params, int nseq, int nslots, int devic
     if (p.debug_planes) EH_TRY(dmalloc(c, &c->planes, 5 * B * N, al->dev, 0));
     EH_TRY(dmalloc(c, &c->mask, S * B * N, al->dev, 0xFF));       // img_mask_kl.Reset(-1)
     EH_TRY(dmalloc(c, &c->field, B * pl.fstride, al->dev, 0xFF));
+    EH_TRY(dmalloc(c, &c->field16, B * pl.f16stride, al->dev, 0));
+    c->field32_valid = false;
     c->und_base = nullptr;
     c->und_iw = nullptr;
     if (p.use_undistort) {
@@ -873,6 +877,21 @@ int edgehip_download_field(edgehip_ctx *c, int seq, int32_t *out) {
     if (!out) return EDGEHIP_ERR_ARG;
     const size_t n = c->plan.n;
     const size_t fs = c->plan.fstride;
+    if (!c->field32_valid) {
+        // the product path keeps only the KeyLine-index plane the tracker gathers: ikl from it, dist reported as -1
+        const size_t fs16 = c->plan.f16stride;
+        std::vector<uint16_t> f16(fs16);
+        EH_CHECK(hipMemcpyAsync(f16.data(), c->field16 + (size_t)seq * fs16, 2 * fs16, hipMemcpyDeviceToHost, c->stream));
+        EH_CHECK(hipStreamSynchronize(c->stream));
+        for (int y = 0; y < c->plan.h; y++)
+            for (int x = 0; x < c->plan.w; x++) {
+                const uint16_t v = f16[edgehip::field16_index(x, y, c->plan.f16tx)];
+                const size_t i = (size_t)y * c->plan.w + x;
+                out[2 * i] = v ? -1 : 0;
+                out[2 * i + 1] = v ? (int32_t)v - 1 : -1;
+            }
+        return 0;
+    }
     std::vector<uint32_t> f(fs);
     EH_CHECK(hipMemcpyAsync(f.data(), c->field + (size_t)seq * fs, 4 * fs, hipMemcpyDeviceToHost, c->stream));
     EH_CHECK(hipStreamSynchronize(c->stream));

@@ -99,6 +99,8 @@ struct DevicePlan {  // everything a kernel needs that is constant for the conte
     int w, h, n, cap, nseq, nslots;
     int ftx;                        // field layout: 4x4-pixel tiles per tile row = ceil(w/4)
     size_t fstride;                 // field elements per sequence = ftx * ceil(h/4) * 16
+    int f16tx;                      // index plane: 8x4-pixel tiles per tile row = ceil(w/8)
+    size_t f16stride;               // index-plane elements per sequence = f16tx * ceil(h/4) * 32
     int box[2][kMaxBoxes];          // box widths of filter0 / filter1
     float box_a[2][kMaxBoxes];      // (float)(1.0/(d*d))
     float ppx, ppy, zfx, zfy;       // cam_model keeps these as float (cam_model.h:51-52)
@@ -123,6 +125,12 @@ __device__ __forceinline__ int round_half_away_i(float v) { return v == -0.5f ? 
 // row-major plane every gather pulls its own 64-B line while here up to four rows of an edge share one.
 __host__ __device__ __forceinline__ size_t field_index(int x, int y, int ftx) {
     return (((size_t)(y >> 2) * (size_t)ftx + (size_t)(x >> 2)) << 4) | (size_t)(((y & 3) << 2) | (x & 3));
+}
+
+// The KeyLine-index plane of the field alone, 2 bytes per pixel (0 = empty, ikl + 1 otherwise) in 8x4-pixel tiles of 64 B:
+// what TryVelRot / TryVel gather (they never use the distance).
+__host__ __device__ __forceinline__ size_t field16_index(int x, int y, int f16tx) {
+    return (((size_t)(y >> 2) * (size_t)f16tx + (size_t)(x >> 3)) << 5) | (size_t)(((y & 3) << 3) | (x & 7));
 }
 
 struct Profiler;
@@ -156,7 +164,9 @@ struct edgehip_ctx {
     float *ii;             // [4][B][N]
     float *planes;         // [5][B][N] or null
     int32_t *mask;         // [S][B][N]
-    uint32_t *field;       // [B][plan.fstride], tiled (field_index)
+    uint32_t *field;       // [B][plan.fstride], tiled (field_index): {dist, ikl}, for download_field / the other builders
+    uint16_t *field16;     // [B][plan.f16stride], KeyLine-index plane (field16_index)
+    bool field32_valid;    // the {dist, ikl} field was written by the last build_field (debug_planes, or the other builders)
     int32_t *und_base;     // [N] undistortion map: pixel index of the p00 tap (may lie outside the image), or null
     uint4 *und_iw;         // [N] 16.16 integer weights of taps p00,p01,p10,p11 (0 = tap not valid)
     float *div_lut;        // [kDivLutMax] (float)(1.0/count)

@@ -281,6 +281,7 @@ __global__ __launch_bounds__(256) void k_field_bin(const KlSoA *kls, const int32
 
 __global__ __launch_bounds__(256) void k_field_raster(const KlSoA *kls, const int32_t *__restrict__ bin_cnt,
                                                       const int32_t *__restrict__ bins, uint32_t *__restrict__ field,
+                                                      uint16_t *__restrict__ field16, size_t f16stride, int f16tx, int keep32,
                                                       int w, int h, size_t fstride, int ftx, int radius, int ntx, int bin_cap) {
     __shared__ uint32_t s_tile[FT * FT];
     const int ntiles = ntx * gridDim.y;
@@ -336,13 +337,48 @@ __global__ __launch_bounds__(256) void k_field_raster(const KlSoA *kls, const in
     __syncthreads();
     // store in the 4x4-tiled layout: 16 consecutive threads write one 64-B tile, a tile row of the block is 1 KB
     // contiguous (FT and the block origin are multiples of 4)
-    uint32_t *out = field + (size_t)seq * fstride;
-    for (int i = tid; i < FT * FT; i += 256) {
-        const int st = i >> 4, in = i & 15;
-        const int lx = ((st % (FT / 4)) << 2) | (in & 3), ly = ((st / (FT / 4)) << 2) | (in >> 2);
-        const int x = tx0 + lx, y = ty0 + ly;
-        if (x < w && y < h) out[field_index(x, y, ftx)] = s_tile[ly * FT + lx];
+    // (the {dist, ikl} form is kept only for edgehip_download_field: params.debug_planes)
+    if (keep32) {
+        uint32_t *out = field + (size_t)seq * fstride;
+        for (int i = tid; i < FT * FT; i += 256) {
+            const int st = i >> 4, in = i & 15;
+            const int lx = ((st % (FT / 4)) << 2) | (in & 3), ly = ((st / (FT / 4)) << 2) | (in >> 2);
+            const int x = tx0 + lx, y = ty0 + ly;
+            if (x < w && y < h) out[field_index(x, y, ftx)] = s_tile[ly * FT + lx];
+        }
     }
+    // What the tracker gathers: the KeyLine-index plane, ikl + 1 (0 = empty) in 8x4-pixel tiles of 64 B; a thread
+    // stores two pixels (w is a multiple of 4: a pair is inside or outside the image together), 16 consecutive threads
+    // one tile
+    uint16_t *o16 = field16 + (size_t)seq * f16stride;
+    for (int i = tid; i < FT * FT / 2; i += 256) {
+        const int st = i >> 4, in = i & 15;
+        const int lx = ((st % (FT / 8)) << 3) | ((in & 3) << 1), ly = ((st / (FT / 8)) << 2) | (in >> 2);
+        const int x = tx0 + lx, y = ty0 + ly;
+        if (x < w && y < h) {
+            const uint32_t v0 = s_tile[ly * FT + lx], v1 = s_tile[ly * FT + lx + 1];
+            // low half = 0xFFFF - ikl  ->  ikl + 1 = 0x10000 - low half (mod 2^16); empty (all ones) -> 0
+            const uint32_t a0 = v0 == 0xFFFFFFFFu ? 0u : ((0x10000u - (v0 & 0xFFFFu)) & 0xFFFFu);
+            const uint32_t a1 = v1 == 0xFFFFFFFFu ? 0u : ((0x10000u - (v1 & 0xFFFFu)) & 0xFFFFu);
+            *reinterpret_cast<uint32_t *>(o16 + field16_index(x, y, f16tx)) = a0 | (a1 << 16);
+        }
+    }
+}
+
+// u32 field (dist<<16 | 0xFFFF-ikl, 4x4 tiles) -> u16 KeyLine-index plane (ikl+1, 8x4 tiles): thread per pixel pair
+__global__ __launch_bounds__(256) void k_field_to16(const uint32_t *__restrict__ field, uint16_t *__restrict__ f16, int w, int h,
+                                                    size_t fstride, int ftx, size_t f16stride, int f16tx) {
+    const int seq = blockIdx.z;
+    const size_t e = (size_t)blockIdx.x * 256 + threadIdx.x;   // element of the u16 plane
+    if (e >= f16stride) return;
+    const size_t tile = e >> 5; const int in = (int)(e & 31);
+    const int x = (int)(tile % (size_t)f16tx) * 8 + (in & 7), y = (int)(tile / (size_t)f16tx) * 4 + (in >> 3);
+    uint16_t v = 0;
+    if (x < w && y < h) {
+        const uint32_t f = field[(size_t)seq * fstride + field_index(x, y, ftx)];
+        if (f != 0xFFFFFFFFu) v = (uint16_t)(0xFFFF - (int)(f & 0xFFFFu) + 1);
+    }
+    f16[(size_t)seq * f16stride + e] = v;
 }
 
 // ---------------------------------------------------------------------------------------------------
@@ -468,6 +504,7 @@ struct TvrArgs {
     float ppx, ppy;
     uint32_t match_num_thresh;
     int write_mid;             // store kl.m_id_f (only the last evaluation of a minimisation needs to)
+    const uint16_t *field16; size_t f16stride; int f16tx;
     int use_grec;   // host-side choice of the gather record (edgehip_ctx::grec_ok of the new slot)
 };
 
@@ -549,9 +586,9 @@ __global__ __launch_bounds__(kTvrThreads) void k_try_velrot(TvrArgs a) {
                     // temporarily z-rotated gradient, stored back into a float Point2DF (:386-388)
                     const float rmx = (float)(sq->RM[0] * (double)klm.x + sq->RM[1] * (double)klm.y);
                     const float rmy = (float)(sq->RM[2] * (double)klm.x + sq->RM[3] * (double)klm.y);
-                    const uint32_t f = a.field[(size_t)seq * a.fstride + field_index(x, y, a.ftx)];
-                    if (f != 0xFFFFFFFFu) {
-                        const int ikf = 0xFFFF - (int)(f & 0xFFFFu);
+                    const uint32_t f = a.field16[(size_t)seq * a.f16stride + field16_index(x, y, a.f16tx)];
+                    if (f != 0u) {
+                        const int ikf = (int)f - 1;
                         // The matched KeyLine's c_p, m_m, u_m.  GREC: a 16-byte record (four records share the 64 bytes
                         // a random gather moves, instead of two) and u_m recomputed with the detector's own float
                         // expressions (k_emit; edge_finder.cpp:166-200), valid for KeyLines nothing has rotated since.
@@ -1255,9 +1292,9 @@ __global__ __launch_bounds__(256) void k_try_vel(TvrArgs a) {
                 status = 3;
                 double dfx = 0, dfy = 0;
                 f = a.max_r / s_rho;                                       // Calc_f_J: no KeyLine / no similarity
-                const uint32_t fv = a.field[(size_t)seq * a.fstride + field_index(x, y, a.ftx)];
-                if (fv != 0xFFFFFFFFu) {
-                    const int ikf = 0xFFFF - (int)(fv & 0xFFFFu);
+                const uint32_t fv = a.field16[(size_t)seq * a.f16stride + field16_index(x, y, a.f16tx)];
+                if (fv != 0u) {
+                    const int ikf = (int)fv - 1;
                     const MatchRec fr = a.kl_new[seq].rec[ikf];
                     const float2 klm = ko.m_m[ikl];
                     const double p_n2 = (double)(nm * nm);                 // Test_f_k
@@ -1482,7 +1519,11 @@ int build_field_enqueue(edgehip_ctx *c, int slot, int radius, float min_mod) {
                            c->kn_slot + (size_t)slot * pl.nseq, c->retuned_slot + (size_t)slot * pl.nseq, c->bin_cnt, c->bins,
                            pl.w, pl.h, radius, min_mod, ntx, nty, pl.cap);
         hipLaunchKernelGGL(k_field_raster, dim3(ntx, nty, pl.nseq), dim3(256), 0, c->stream, kldev(c, slot), c->bin_cnt,
-                           c->bins, c->field, pl.w, pl.h, pl.fstride, pl.ftx, radius, ntx, pl.cap);
+                           c->bins, c->field, c->field16, pl.f16stride, pl.f16tx, c->p.debug_planes ? 1 : 0, pl.w, pl.h,
+                           pl.fstride, pl.ftx, radius, ntx, pl.cap);
+        c->field32_valid = c->p.debug_planes != 0;
+        EH_LAUNCH_CHECK();
+        return 0;
     } else if (c->field_mode == 2 || c->field_mode == 0) {  // mask-scan tiles (any image size)
         hipLaunchKernelGGL(k_field_tiles, dim3((pl.w + FT - 1) / FT, (pl.h + FT - 1) / FT, pl.nseq), dim3(256), 0, c->stream,
                            kldev(c, slot), maskof(c, slot), c->retuned_slot + (size_t)slot * pl.nseq, c->field, pl.w, pl.h,
@@ -1494,6 +1535,11 @@ int build_field_enqueue(edgehip_ctx *c, int slot, int radius, float min_mod) {
                            kldev(c, slot), c->kn_slot + (size_t)slot * pl.nseq, c->retuned_slot + (size_t)slot * pl.nseq,
                            c->field, pl.w, pl.h, pl.fstride, pl.ftx, radius, min_mod);
     }
+    EH_LAUNCH_CHECK();
+    // the other two builders produce the {dist, ikl} field; the tracker's index plane is derived from it
+    hipLaunchKernelGGL(k_field_to16, dim3((unsigned)((pl.f16stride + 255) / 256), 1, pl.nseq), dim3(256), 0, c->stream, c->field,
+                       c->field16, pl.w, pl.h, pl.fstride, pl.ftx, pl.f16stride, pl.f16tx);
+    c->field32_valid = true;
     EH_LAUNCH_CHECK();
     return 0;
 }
@@ -1514,7 +1560,7 @@ static TvrArgs make_tvr_args(edgehip_ctx *c, int slot_new, int slot_old, double 
     TvrArgs a;
     a.kl_old = kldev(c, slot_old); a.kl_new = kldev(c, slot_new);
     a.kn_old = c->kn_slot + (size_t)slot_old * pl.nseq;
-    a.field = c->field; a.P0 = c->P0; a.resid = c->resid; a.resid_carry = c->resid_carry;
+    a.field = c->field; a.field16 = c->field16; a.f16stride = pl.f16stride; a.f16tx = pl.f16tx; a.P0 = c->P0; a.resid = c->resid; a.resid_carry = c->resid_carry;
     a.block_last = c->block_last; a.partials = c->partials; a.seq = c->seq;
     a.framecount = c->framecount + (size_t)c->fc_index * pl.nseq;
     a.w = pl.w; a.h = pl.h; a.cap = pl.cap; a.nblk = c->nblk_tvr; a.nseq = pl.nseq; a.fstride = pl.fstride; a.ftx = pl.ftx;

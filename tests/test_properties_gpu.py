@@ -96,7 +96,8 @@ def test_max_points_truncation_is_a_prefix(frames):
 
 
 def test_field_idempotent_and_consistent(frames):
-    eh = edgehip.EdgeHip(edgehip.euroc_params(W, H), nseq=1, nslots=2)
+    # debug_planes: keep the field's distances on the device (the tracker only gathers the KeyLine-index plane)
+    eh = edgehip.EdgeHip(edgehip.euroc_params(W, H, debug_planes=1), nseq=1, nslots=2)
     eh.upload_rgb(0, frames[0])
     eh.stage_a(0)
     eh.build_field(0, 40, -1.0)

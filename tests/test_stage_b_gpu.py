@@ -25,7 +25,9 @@ def pair():
         pytest.skip("oracle/_ref not built")
     w, h = 376, 240
     orc, so, sn, nav, frames = oracle_pair(w, h, 4)
-    eh = edgehip.EdgeHip(edgehip.euroc_params(w, h), nseq=1, nslots=2)
+    # debug_planes: the device then keeps the field's distances too (the tracker itself only gathers a KeyLine-index
+    # plane), so that test_build_field_exact can compare the whole {dist, ikl} field
+    eh = edgehip.EdgeHip(edgehip.euroc_params(w, h, debug_planes=1), nseq=1, nslots=2)
     inject_pair(eh, orc, so, sn)
     yield orc, so, sn, nav, eh
     eh.close()
@@ -126,7 +128,7 @@ def test_minimizer_v(pair, V0, iters, mnt):
     assert orc.get_framecount(sn) == fc                 # Minimizer_V does not count frames
 
 
-@pytest.mark.parametrize("w,h,mode", [(376, 240, None), (376, 240, "1"), (376, 240, "2"), (1024, 1104, None)])
+@pytest.mark.parametrize("w,h,mode", [(376, 240, None), (376, 240, "debug"), (376, 240, "1"), (376, 240, "2"), (1024, 1104, None)])
 def test_build_field_segments_that_round_across_a_tile_boundary(w, h, mode, monkeypatch):
     """The binned build_field works in 64 x 64 tiles.  A nearly axis-parallel segment whose centre sits within half a
     pixel of a tile boundary reaches the neighbouring tile only through round() (x = 383.5 -> pixel 384): such KeyLines
@@ -138,7 +140,7 @@ def test_build_field_segments_that_round_across_a_tile_boundary(w, h, mode, monk
     from oracle import oracle
     if not oracle.available("ref"):
         pytest.skip("oracle/_ref not built")
-    if mode is not None:
+    if mode in ("1", "2"):
         monkeypatch.setenv("EDGEHIP_FIELD_MODE", mode)
     r = 40
     rs = np.random.RandomState(5)
@@ -171,7 +173,9 @@ def test_build_field_segments_that_round_across_a_tile_boundary(w, h, mode, monk
     cap = max(16000, len(kls) + 64)
     orc = oracle.Oracle("ref", oracle.euroc_params(w, h, max_points=cap))
     orc.set_keylines(0, kls, mask, 0.0)
-    eh = edgehip.EdgeHip(edgehip.euroc_params(w, h, max_points=cap), nseq=1, nslots=2)
+    # the binned builder keeps the distances only with debug_planes ("debug"); without, download_field reports the
+    # KeyLine-index plane the tracker gathers and dist = -1
+    eh = edgehip.EdgeHip(edgehip.euroc_params(w, h, max_points=cap, debug_planes=int(mode == "debug")), nseq=1, nslots=2)
     from helpers import to_edgehip_kl
     eh.upload_keylines(0, 1, to_edgehip_kl(kls), mask, 0.0)
     orc.build_field(0, r, 0.0)
@@ -180,7 +184,10 @@ def test_build_field_segments_that_round_across_a_tile_boundary(w, h, mode, monk
     assert np.array_equal(f_ref[..., 1], f_gpu[..., 1]), "field ikl differs"
     m = f_ref[..., 1] >= 0
     assert m.sum() > 5000
-    assert np.array_equal(f_ref[..., 0][m], f_gpu[..., 0][m]), "field dist differs"
+    if mode is None and w * h <= 64 * 64 * 256:
+        assert (f_gpu[..., 0][m] == -1).all()     # product path: no distances kept
+    else:
+        assert np.array_equal(f_ref[..., 0][m], f_gpu[..., 0][m]), "field dist differs"
     eh.close()
 
 
