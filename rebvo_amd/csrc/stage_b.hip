@@ -489,7 +489,7 @@ struct TvrArgs {
     const KlSoA *kl_old;       // [B]
     const KlSoA *kl_new;       // [B]  (field KeyLines)
     const int32_t *kn_old;     // [B]
-    const uint32_t *field;     // [B][fstride]
+    const uint16_t *field16;   // [B][f16stride] KeyLine-index plane of the field (ctx.h field16_index)
     const double *P0;          // [B][3][CAP]
     double *resid;             // [kResidBufs][B][CAP]
     double *resid_carry;       // [kResidBufs][B][nblk]  resolved carry-in per block
@@ -498,13 +498,12 @@ struct TvrArgs {
     SeqDev *seq;
     const uint32_t *framecount;  // [B] of the new slot
     int w, h, cap, nblk, nseq;
-    size_t fstride;            // field elements per sequence (4x4-tiled layout, ctx.h field_index)
-    int ftx;
+    size_t f16stride;          // index-plane elements per sequence
+    int f16tx;                 // 8x4-pixel tiles per tile row
     double zfm, max_r, match_thresh, k_huber;
     float ppx, ppy;
     uint32_t match_num_thresh;
     int write_mid;             // store kl.m_id_f (only the last evaluation of a minimisation needs to)
-    const uint16_t *field16; size_t f16stride; int f16tx;
     int use_grec;   // host-side choice of the gather record (edgehip_ctx::grec_ok of the new slot)
 };
 
@@ -1560,10 +1559,10 @@ static TvrArgs make_tvr_args(edgehip_ctx *c, int slot_new, int slot_old, double 
     TvrArgs a;
     a.kl_old = kldev(c, slot_old); a.kl_new = kldev(c, slot_new);
     a.kn_old = c->kn_slot + (size_t)slot_old * pl.nseq;
-    a.field = c->field; a.field16 = c->field16; a.f16stride = pl.f16stride; a.f16tx = pl.f16tx; a.P0 = c->P0; a.resid = c->resid; a.resid_carry = c->resid_carry;
+    a.field16 = c->field16; a.f16stride = pl.f16stride; a.f16tx = pl.f16tx; a.P0 = c->P0; a.resid = c->resid; a.resid_carry = c->resid_carry;
     a.block_last = c->block_last; a.partials = c->partials; a.seq = c->seq;
     a.framecount = c->framecount + (size_t)c->fc_index * pl.nseq;
-    a.w = pl.w; a.h = pl.h; a.cap = pl.cap; a.nblk = c->nblk_tvr; a.nseq = pl.nseq; a.fstride = pl.fstride; a.ftx = pl.ftx;
+    a.w = pl.w; a.h = pl.h; a.cap = pl.cap; a.nblk = c->nblk_tvr; a.nseq = pl.nseq;
     a.zfm = pl.zfm; a.max_r = (double)c->field_radius; a.match_thresh = match_thresh; a.k_huber = k_huber;
     a.ppx = pl.ppx; a.ppy = pl.ppy; a.match_num_thresh = match_num_thresh; a.write_mid = write_mid;
     a.use_grec = c->grec_ok[slot_new] && !c->no_grec;
