@@ -1108,7 +1108,11 @@ int stage_a_enqueue(edgehip_ctx *c, int slot) {
     if (use_level) {
         // one pass per level and plane (k_level): grey -> integral #1, then the box levels
         const size_t sm = ((size_t)2 * LV_RB * level_row_stride(w) + 32 + kDivLutMax) * sizeof(float);   // + scan tail pad + LUT copy
-        const int lv_ablate = getenv("EDGEHIP_LEVEL_ABLATE") ? atoi(getenv("EDGEHIP_LEVEL_ABLATE")) : 0;   // timing experiments only
+#ifdef EDGEHIP_EXPERIMENTS   // make EXPERIMENTS=1: phase ablation for timing experiments (wrong results by design)
+        const int lv_ablate = getenv("EDGEHIP_LEVEL_ABLATE") ? atoi(getenv("EDGEHIP_LEVEL_ABLATE")) : 0;
+#else
+        const int lv_ablate = 0;
+#endif
         if (sm > 64 * 1024) {   // more than the default dynamic-LDS limit: opt in once per kernel
             static bool done = false;
             if (!done) {
@@ -1268,7 +1272,11 @@ int stage_a_enqueue(edgehip_ctx *c, int slot) {
         a.dog_thresh_f = (float)c->p.dog_thresh;
         const int ws = c->p.plane_fit_size;
         a.pn_thresh = (double)(((float)((2.0 * ws + 1.0) * (2.0 * ws + 1.0))) * (float)c->p.pos_neg_thresh);
+#ifdef EDGEHIP_EXPERIMENTS
         a.ablate = getenv("EDGEHIP_ABLATE") ? atoi(getenv("EDGEHIP_ABLATE")) : 0;
+#else
+        a.ablate = 0;
+#endif
         const int npx_b = kBandRows * w, cpw_b = (((npx_b + 63) >> 6) + kDetWaves - 1) / kDetWaves;
         const size_t sm = (size_t)2 * (kBandRows + 4) * w * sizeof(float) + (size_t)kDetWaves * cpw_b * 64 * sizeof(uint16_t);
         if (sm > 64 * 1024) {
