@@ -5,8 +5,11 @@
 //   ii       [4][B][N]  f32      integral-image scratch of the box-filter chain (stage A only)
 //   planes   [5][B][N]  f32      img0,img1,dog,dx,dy — only when params.debug_planes
 //   mask     [S][B][N]  i32      img_mask_kl
-//   field    [B][FS]    u32      tracker auxiliary image, packed (dist<<16 | 0xFFFF-ikl), 0xFFFFFFFF = empty;
-//                               4x4-pixel tiles (field_index), FS = ceil(w/4)*ceil(h/4)*16
+//   field16  [B][FS16]  u16      tracker auxiliary image as the tracker reads it: KeyLine index + 1, 0 = empty;
+//                               8x4-pixel tiles (field16_index), FS16 = ceil(w/8)*ceil(h/4)*32
+//   field    [B][FS]    u32      the same with distances, packed (dist<<16 | 0xFFFF-ikl), 0xFFFFFFFF = empty, 4x4-pixel
+//                               tiles (field_index), FS = ceil(w/4)*ceil(h/4)*16 — written only for download_field
+//                               (params.debug_planes) and by the alternative builders
 //   KeyLines [S][B][CAP] per field (structure of arrays, see KlSoA)
 //   stage buffers for the raster-order compaction, LM scratch, residual buffers, per-sequence state.
 #pragma once

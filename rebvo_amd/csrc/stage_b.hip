@@ -23,7 +23,10 @@
 //    value is written as a marker NaN and resolved by the next reader from per-block carries that
 //    k_lm_step prefixes.
 //  * build_field keeps, per pixel, the smallest |t| and among equals the LAST KeyLine: one atomicMin on
-//    (dist << 16 | 0xFFFF - ikl).
+//    (dist << 16 | 0xFFFF - ikl) in an LDS tile; what reaches HBM is the winner's index alone (2 bytes: the evaluation
+//    never reads the distance), 8x4-pixel tiles so that the KeyLines of an edge share cache lines.
+//  * The matched KeyLine is gathered as 16 bytes (c_p, m_m) with u_m recomputed when the new slot's KeyLines are
+//    unrotated (GREC), else as the 32-byte MatchRec.
 //  * kl.m_id_f reflects the last EVALUATED state, accepted or not (:354, :265).
 
 #include <math.h>
@@ -365,7 +368,7 @@ __global__ __launch_bounds__(256) void k_field_raster(const KlSoA *kls, const in
     }
 }
 
-// u32 field (dist<<16 | 0xFFFF-ikl, 4x4 tiles) -> u16 KeyLine-index plane (ikl+1, 8x4 tiles): thread per pixel pair
+// u32 field (dist<<16 | 0xFFFF-ikl, 4x4 tiles) -> u16 KeyLine-index plane (ikl+1, 8x4 tiles): thread per pixel
 __global__ __launch_bounds__(256) void k_field_to16(const uint32_t *__restrict__ field, uint16_t *__restrict__ f16, int w, int h,
                                                     size_t fstride, int ftx, size_t f16stride, int f16tx) {
     const int seq = blockIdx.z;
