@@ -275,6 +275,8 @@ extern "C" {
 int edgehip_abi_version(void) { return EDGEHIP_ABI_VERSION; }
 const char *edgehip_last_error(void) { return g_err.c_str(); }
 
+static int create_body(edgehip_ctx *c, CtxAllocs *al, const edgehip_params &p, int nseq, int nslots, int device);
+
 int edgehip_create(const edgehip_params *params, int nseq, int nslots, int device, edgehip_ctx **out) {
     if (!params || !out || nseq < 1 || nslots < 2) { set_error("edgehip_create: bad argument"); return EDGEHIP_ERR_ARG; }
     const edgehip_params &p = *params;
@@ -297,6 +299,20 @@ int edgehip_create(const edgehip_params *params, int nseq, int nslots, int devic
     edgehip_ctx *c = new edgehip_ctx();
     CtxAllocs *al = new CtxAllocs();
     g_allocs.push_back({c, al});
+    // everything below may fail half-way (out of device memory with a large batch, ...): the partial context is torn
+    // down again instead of being leaked
+    const int rc = create_body(c, al, p, nseq, nslots, device);
+    if (rc != 0) {
+        const std::string why = g_err;
+        (void)edgehip_destroy(c);
+        g_err = why;
+        return rc;
+    }
+    *out = c;
+    return 0;
+}
+
+static int create_body(edgehip_ctx *c, CtxAllocs *al, const edgehip_params &p, int nseq, int nslots, int device) {
     c->p = p;
     c->device = device;
     c->frame_slot = -1;
@@ -489,7 +505,6 @@ int edgehip_create(const edgehip_params *params, int nseq, int nslots, int devic
     EH_CHECK(hipMemcpyAsync(c->seqa, c->pinned_seqa, sizeof(SeqA) * B, hipMemcpyHostToDevice, c->stream));
     EH_CHECK(hipStreamSynchronize(c->stream));
 #undef EH_TRY
-    *out = c;
     return 0;
 }
 

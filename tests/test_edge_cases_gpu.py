@@ -217,3 +217,17 @@ def test_replay_without_host_sync_runs_ahead_of_the_device(source):
             assert np.allclose(ng.Pos[:], nr.Pos[:], rtol=0, atol=1e-9), (s, k)
             assert k == 0 or abs(ng.dt - nr.dt) < 1e-12, (s, k, ng.dt, nr.dt)   # frame 0 has no predecessor
     eh.close()
+
+
+def test_create_that_runs_out_of_memory_leaves_nothing_behind():
+    """edgehip_create for a batch no GPU can hold fails with an error code half-way through its allocations; the partial
+    context is torn down (device memory returns to what it was) and the next create works."""
+    import torch
+    torch.cuda.synchronize()
+    free0, _ = torch.cuda.mem_get_info()
+    with pytest.raises(edgehip.EdgeHipError):
+        edgehip.EdgeHip(edgehip.euroc_params(752, 480), nseq=400000, nslots=3)
+    free1, _ = torch.cuda.mem_get_info()
+    assert abs(free0 - free1) < (64 << 20), (free0, free1)
+    eh = edgehip.EdgeHip(edgehip.euroc_params(376, 240), nseq=1, nslots=2)
+    eh.close()
