@@ -298,10 +298,10 @@ def main():
     # trajectory of sequence 0 over the timed frames (for pose_rmse against the CPU reference below)
     gpu_traj = None
     check_seqs = sorted({0, B // 2, B - 1})   # sequences of context 0 compared with the CPU reference below
-    if rank == 0:
-        log0 = eh.read_nav_log(Wm, K)
-        gpu_traj = {s: [(np.array(r[s].Pos[:]), np.array(r[s].Pose[:]).reshape(3, 3), np.array(r[s].V[:]), np.array(r[s].W[:]))
-                        for r in log0] for s in check_seqs}
+    if rank == 0 and args.cpu_frames > 0 and (world == 1 or os.environ.get("BENCH_CPU_BASELINE_ALWAYS")):
+        log0 = eh.read_nav_log_array(Wm, K)
+        gpu_traj = {s: [(log0[k, s]["Pos"].copy(), log0[k, s]["Pose"].reshape(3, 3).copy(), log0[k, s]["V"].copy(),
+                         log0[k, s]["W"].copy()) for k in range(K)] for s in check_seqs}
     last = [n for e in ehs for n in e.read_nav()]
     kn_mean = float(np.mean([n.kn for n in last]))
     ok = int(sum(n.estimation_ok for n in last))
