@@ -868,7 +868,11 @@ int edgehip_upload_keylines(edgehip_ctx *c, int seq, int slot, const edgehip_key
     }
     if (e) return EDGEHIP_ERR_DEVICE;
     // the 16-byte gather records stand for the slot only if they do for every sequence in it
-    c->grec_ok[slot] = consistent && (c->plan.nseq == 1 || c->grec_ok[slot]);
+    {
+        const bool was = c->grec_ok[slot];
+        c->grec_ok[slot] = consistent && (c->plan.nseq == 1 || c->grec_ok[slot]);
+        if (was != c->grec_ok[slot]) drop_frame_graphs(c);   // captured frames chose their TryVelRot variant by this flag
+    }
     EH_CHECK(hipMemcpyAsync(c->kn_slot + (size_t)slot * c->plan.nseq + seq, &kn, 4, hipMemcpyHostToDevice, c->stream));
     if (mask) EH_CHECK(hipMemcpyAsync(maskof(c, slot) + (size_t)seq * c->plan.n, mask, sizeof(int32_t) * c->plan.n, hipMemcpyHostToDevice, c->stream));
     EH_CHECK(hipMemcpyAsync(c->retuned_slot + (size_t)slot * c->plan.nseq + seq, &retuned, 4, hipMemcpyHostToDevice, c->stream));
