@@ -1215,6 +1215,11 @@ int edgehip_process_frame(edgehip_ctx *c, const double *t) {
         // stage A ran inside the graph, on this stream: the caller's next uploads (stage-A stream) may overwrite a
         // frame slot only after the graphs that read it (a caller that never synchronises is several frames ahead)
         if (int e = order_a_after_bc(c)) return e;
+        // host-side bookkeeping the replayed enqueue code would have done (stage A: fresh KeyLines; rotate_keylines
+        // of the old slot)
+        c->grec_ok[sn] = true;
+        if (sp >= 0) c->grec_ok[sp] = true;
+        if (have_pair && so >= 0) c->grec_ok[so] = false;
     } else {
         if (int e = frame_enqueue(c, sn, so, sp, have_pair, tp)) return e;
     }
