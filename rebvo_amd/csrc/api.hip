@@ -7,6 +7,7 @@
 #include <string.h>
 
 #include <algorithm>
+#include <mutex>
 
 #include "ctx.h"
 
@@ -56,7 +57,17 @@ int hip_fail(hipError_t e, const char *what, const char *file, int line) {
     char buf[512];
     snprintf(buf, sizeof buf, "%s:%d: %s -> %s", file, line, what, hipGetErrorString(e));
     g_err = buf;
+    (void)hipGetLastError();   // reported: take it out of the thread's last-error slot (it would stay there, ROCm 7)
     return EDGEHIP_ERR_DEVICE;
+}
+void enter_ctx(edgehip_ctx *c) {
+    static thread_local int cur_dev = -1;      // device this thread last made current through us
+    int dev = -1;
+    if (cur_dev != c->device || hipGetDevice(&dev) != hipSuccess || dev != c->device) {
+        (void)hipSetDevice(c->device);
+        cur_dev = c->device;
+    }
+    (void)hipGetLastError();
 }
 
 static const char *kProfNames[PROF_COUNT] = {
@@ -207,13 +218,12 @@ static int dmalloc(edgehip_ctx *c, T **p, size_t count, std::vector<void *> &tra
     void *q = nullptr;
     size_t bytes = std::max<size_t>(count * sizeof(T), 256);
     if (hipMalloc(&q, bytes) != hipSuccess) {
+        (void)hipGetLastError();   // the failure is reported here; do not leave it in the thread's last-error slot
         set_error("hipMalloc failed (" + std::to_string(bytes) + " bytes)");
         return EDGEHIP_ERR_MEMORY;
     }
     track.push_back(q);
-    if (fill != -2) {
-        if (hipMemsetAsync(q, fill, bytes, c->stream) != hipSuccess) return EDGEHIP_ERR_DEVICE;
-    }
+    if (fill != -2) EH_CHECK(hipMemsetAsync(q, fill, bytes, c->stream));
     *p = (T *)q;
     return 0;
 }
@@ -223,6 +233,7 @@ struct CtxAllocs {
     std::vector<void *> host;
 };
 static std::vector<std::pair<edgehip_ctx *, CtxAllocs *>> g_allocs;
+static std::mutex g_allocs_mu;   // contexts are created and destroyed from any thread (one rebvo::REBVO per GPU)
 
 static void init_state_a(const edgehip_params &p, SeqA *s) {
     memset(s, 0, sizeof(*s));
@@ -298,13 +309,17 @@ int edgehip_create(const edgehip_params *params, int nseq, int nslots, int devic
     EH_CHECK(hipSetDevice(device));
     edgehip_ctx *c = new edgehip_ctx();
     CtxAllocs *al = new CtxAllocs();
-    g_allocs.push_back({c, al});
+    {
+        std::lock_guard<std::mutex> lk(g_allocs_mu);
+        g_allocs.push_back({c, al});
+    }
     // everything below may fail half-way (out of device memory with a large batch, ...): the partial context is torn
     // down again instead of being leaked
     const int rc = create_body(c, al, p, nseq, nslots, device);
     if (rc != 0) {
         const std::string why = g_err;
         (void)edgehip_destroy(c);
+        (void)hipGetLastError();   // whatever made create fail has been reported through rc / edgehip_last_error
         g_err = why;
         return rc;
     }
@@ -497,7 +512,8 @@ static int create_body(edgehip_ctx *c, CtxAllocs *al, const edgehip_params &p, i
         EH_CHECK(hipHostMalloc(&q, sizeof(SeqDev) * B, hipHostMallocDefault)); al->host.push_back(q); c->pinned_seq = (SeqDev *)q;
         EH_CHECK(hipHostMalloc(&q, sizeof(SeqA) * B, hipHostMallocDefault)); al->host.push_back(q); c->pinned_seqa = (SeqA *)q;
         EH_CHECK(hipHostMalloc(&q, sizeof(double) * B * 64, hipHostMallocDefault)); al->host.push_back(q); c->pinned_out = (double *)q;
-        EH_CHECK(hipHostMalloc(&q, sizeof(double) * B * 8 + sizeof(int32_t) * B * 8, hipHostMallocDefault)); al->host.push_back(q); c->pinned_t = (double *)q;
+        EH_CHECK(hipHostMalloc(&q, sizeof(double) * B * 8, hipHostMallocDefault)); al->host.push_back(q); c->pinned_t = (double *)q;
+        EH_CHECK(hipHostMalloc(&q, sizeof(int32_t) * B * 8 * 4, hipHostMallocDefault)); al->host.push_back(q); c->pinned_idx = (int32_t *)q;
         EH_CHECK(hipHostMalloc(&q, sizeof(edgehip_nav) * B, hipHostMallocDefault)); al->host.push_back(q); c->pinned_nav = (edgehip_nav *)q;
     }
     for (size_t i = 0; i < B; i++) { init_state(p, &c->pinned_seq[i]); init_state_a(p, &c->pinned_seqa[i]); }
@@ -515,13 +531,20 @@ int edgehip_destroy(edgehip_ctx *c) {
     (void)hipStreamSynchronize(c->stream_up);
     (void)hipStreamSynchronize(c->stream_a);
     (void)hipStreamSynchronize(c->stream);
-    for (size_t i = 0; i < g_allocs.size(); i++) {
-        if (g_allocs[i].first != c) continue;
-        for (void *q : g_allocs[i].second->dev) (void)hipFree(q);
-        for (void *q : g_allocs[i].second->host) (void)hipHostFree(q);
-        delete g_allocs[i].second;
-        g_allocs.erase(g_allocs.begin() + i);
-        break;
+    CtxAllocs *mine = nullptr;
+    {
+        std::lock_guard<std::mutex> lk(g_allocs_mu);
+        for (size_t i = 0; i < g_allocs.size(); i++) {
+            if (g_allocs[i].first != c) continue;
+            mine = g_allocs[i].second;
+            g_allocs.erase(g_allocs.begin() + i);
+            break;
+        }
+    }
+    if (mine) {
+        for (void *q : mine->dev) (void)hipFree(q);
+        for (void *q : mine->host) (void)hipHostFree(q);
+        delete mine;
     }
     if (c->prof) {
         for (auto &r : c->prof->pending) { (void)hipEventDestroy(r.a); (void)hipEventDestroy(r.b); }
@@ -541,6 +564,7 @@ int edgehip_destroy(edgehip_ctx *c) {
 }
 
 int edgehip_reset(edgehip_ctx *c) {
+    EH_ENTER(c);
     if (!c) return EDGEHIP_ERR_ARG;
     const size_t B = c->plan.nseq, S = c->plan.nslots;
     if (int e = sync_all(c)) return e;
@@ -557,12 +581,14 @@ int edgehip_reset(edgehip_ctx *c) {
 }
 
 int edgehip_sync(edgehip_ctx *c) {
+    EH_ENTER(c);
     if (!c) return EDGEHIP_ERR_ARG;
     return sync_all(c);
 }
 void *edgehip_stream(edgehip_ctx *c) { return c ? (void *)c->stream : nullptr; }
 
 int edgehip_box_widths(edgehip_ctx *c, int out[6]) {
+    EH_ENTER(c);
     if (!c || !out) return EDGEHIP_ERR_ARG;
     for (int f = 0; f < 2; f++)
         for (int i = 0; i < 3; i++) out[f * 3 + i] = c->plan.box[f][i];
@@ -584,6 +610,7 @@ static void unbind_rgb(edgehip_ctx *c, int slot) {
 }
 
 int edgehip_upload_rgb(edgehip_ctx *c, int slot, const uint8_t *rgb24, int seq_first, int count) {
+    EH_ENTER(c);
     if (int e = check_slot(c, slot)) return e;
     unbind_rgb(c, slot);
     if (int e = wait_upload(c, slot, c->stream_a)) return e;
@@ -608,6 +635,7 @@ int edgehip_free_pinned(void *p) {
     return 0;
 }
 int edgehip_upload_rgb_pinned(edgehip_ctx *c, int slot, const uint8_t *rgb24_pinned, int seq_first, int count) {
+    EH_ENTER(c);
     if (int e = check_slot(c, slot)) return e;
     unbind_rgb(c, slot);
     if (!rgb24_pinned || seq_first < 0 || count < 1 || seq_first + count > c->plan.nseq) { set_error("upload_rgb_pinned: bad range"); return EDGEHIP_ERR_ARG; }
@@ -623,6 +651,7 @@ int edgehip_upload_rgb_pinned(edgehip_ctx *c, int slot, const uint8_t *rgb24_pin
 }
 
 int edgehip_upload_rgb_device(edgehip_ctx *c, int slot, const void *rgb24_dev) {
+    EH_ENTER(c);
     if (int e = check_slot(c, slot)) return e;
     unbind_rgb(c, slot);
     if (int e = wait_upload(c, slot, c->stream_a)) return e;
@@ -632,13 +661,13 @@ int edgehip_upload_rgb_device(edgehip_ctx *c, int slot, const void *rgb24_dev) {
 }
 
 int edgehip_upload_rgb_indexed(edgehip_ctx *c, int slot, const void *pool_dev, int pool_frames, const int32_t *idx) {
+    EH_ENTER(c);
     if (int e = check_slot(c, slot)) return e;
     unbind_rgb(c, slot);
     if (int e = wait_upload(c, slot, c->stream_a)) return e;
     if (!pool_dev || !idx || pool_frames < 1) return EDGEHIP_ERR_ARG;
     const int B = c->plan.nseq;
-    int32_t *pi = (int32_t *)(c->pinned_t + (size_t)8 * B) ;  // tail of the pinned time ring (see create)
-    pi += (size_t)(c->frames_seen % 8) * B;
+    int32_t *pi = c->pinned_idx + ((size_t)(c->frames_seen % 8) * 4 + slot) * B;   // one row per (ring entry, slot)
     if (int e = wait_pinned_ring(c)) return e;
     for (int s = 0; s < B; s++) {
         if (idx[s] < 0 || idx[s] >= pool_frames) { set_error("upload_rgb_indexed: index out of range"); return EDGEHIP_ERR_ARG; }
@@ -653,11 +682,13 @@ int edgehip_upload_rgb_indexed(edgehip_ctx *c, int slot, const void *pool_dev, i
 }
 
 int edgehip_bind_rgb_indexed(edgehip_ctx *c, int slot, const void *pool_dev, int pool_frames, const int32_t *idx) {
+    EH_ENTER(c);
     if (int e = check_slot(c, slot)) return e;
     if (!pool_dev || !idx || pool_frames < 1) return EDGEHIP_ERR_ARG;
     const int B = c->plan.nseq;
-    int32_t *pi = (int32_t *)(c->pinned_t + (size_t)8 * B);   // tail of the pinned time ring (see create)
-    pi += (size_t)(c->frames_seen % 8) * B;
+    // One pinned row per (ring entry, slot): several slots may be bound between two process_frame calls (main slot and
+    // stereo pair slot, a prefetch), and each copy out of the ring is asynchronous.
+    int32_t *pi = c->pinned_idx + ((size_t)(c->frames_seen % 8) * 4 + slot) * B;
     if (int e = wait_pinned_ring(c)) return e;
     for (int s = 0; s < B; s++) {
         if (idx[s] < 0 || idx[s] >= pool_frames) { set_error("bind_rgb_indexed: index out of range"); return EDGEHIP_ERR_ARG; }
@@ -672,6 +703,7 @@ int edgehip_bind_rgb_indexed(edgehip_ctx *c, int slot, const void *pool_dev, int
 }
 
 int edgehip_set_nav_log(edgehip_ctx *c, int len) {
+    EH_ENTER(c);
     if (!c || len < 0) return EDGEHIP_ERR_ARG;
     EH_CHECK(hipStreamSynchronize(c->stream));
     drop_frame_graphs(c);   // the per-frame record kernel takes the log pointer as an argument
@@ -679,7 +711,11 @@ int edgehip_set_nav_log(edgehip_ctx *c, int len) {
     c->nav_log_len = 0;
     if (len > 0) {
         void *q;
-        if (hipMalloc(&q, sizeof(edgehip_nav) * (size_t)len * c->plan.nseq) != hipSuccess) { set_error("nav log alloc failed"); return EDGEHIP_ERR_MEMORY; }
+        if (hipMalloc(&q, sizeof(edgehip_nav) * (size_t)len * c->plan.nseq) != hipSuccess) {
+            (void)hipGetLastError();
+            set_error("nav log alloc failed");
+            return EDGEHIP_ERR_MEMORY;
+        }
         EH_CHECK(hipMemset(q, 0, sizeof(edgehip_nav) * (size_t)len * c->plan.nseq));
         c->nav_log = (edgehip_nav *)q;
         c->nav_log_len = len;
@@ -688,6 +724,7 @@ int edgehip_set_nav_log(edgehip_ctx *c, int len) {
 }
 
 int edgehip_read_nav_log(edgehip_ctx *c, int first, int count, edgehip_nav *out) {
+    EH_ENTER(c);
     if (!c || !out || !c->nav_log || first < 0 || count < 1 || count > c->nav_log_len) { set_error("read_nav_log: bad range or log disabled"); return EDGEHIP_ERR_ARG; }
     const size_t B = c->plan.nseq;
     for (int k = 0; k < count; k++) {
@@ -699,6 +736,7 @@ int edgehip_read_nav_log(edgehip_ctx *c, int first, int count, edgehip_nav *out)
 }
 
 int edgehip_stage_a(edgehip_ctx *c, int slot) {
+    EH_ENTER(c);
     if (int e = check_slot(c, slot)) return e;
     if (int e = order_a_after_bc(c)) return e;
     if (int e = wait_upload(c, slot, c->stream_a)) return e;
@@ -722,6 +760,7 @@ static int fetch_states(edgehip_ctx *c) {
 }
 
 int edgehip_get_kn(edgehip_ctx *c, int slot, int32_t *kn_out) {
+    EH_ENTER(c);
     if (int e = check_slot(c, slot)) return e;
     if (!kn_out) return EDGEHIP_ERR_ARG;
     if (int e = sync_all(c)) return e;
@@ -733,6 +772,7 @@ int edgehip_get_kn(edgehip_ctx *c, int slot, int32_t *kn_out) {
 }
 
 int edgehip_get_state(edgehip_ctx *c, int seq, edgehip_seq_state *out) {
+    EH_ENTER(c);
     if (int e = check_seq(c, seq)) return e;
     if (!out) return EDGEHIP_ERR_ARG;
     if (int e = fetch_states(c)) return e;
@@ -741,6 +781,7 @@ int edgehip_get_state(edgehip_ctx *c, int seq, edgehip_seq_state *out) {
 }
 
 int edgehip_set_state(edgehip_ctx *c, int seq, const edgehip_seq_state *in) {
+    EH_ENTER(c);
     if (int e = check_seq(c, seq)) return e;
     if (!in) return EDGEHIP_ERR_ARG;
     if (int e = fetch_states(c)) return e;
@@ -755,6 +796,7 @@ int edgehip_set_state(edgehip_ctx *c, int seq, const edgehip_seq_state *in) {
 }
 
 int edgehip_get_framecount(edgehip_ctx *c, int seq, int slot, uint32_t *fc) {
+    EH_ENTER(c);
     if (int e = check_seq(c, seq)) return e;
     if (int e = check_slot(c, slot)) return e;
     EH_CHECK(hipMemcpyAsync(fc, c->framecount + (size_t)slot * c->plan.nseq + seq, 4, hipMemcpyDeviceToHost, c->stream));
@@ -762,6 +804,7 @@ int edgehip_get_framecount(edgehip_ctx *c, int seq, int slot, uint32_t *fc) {
     return 0;
 }
 int edgehip_set_framecount(edgehip_ctx *c, int seq, int slot, uint32_t fc) {
+    EH_ENTER(c);
     if (int e = check_seq(c, seq)) return e;
     if (int e = check_slot(c, slot)) return e;
     EH_CHECK(hipMemcpyAsync(c->framecount + (size_t)slot * c->plan.nseq + seq, &fc, 4, hipMemcpyHostToDevice, c->stream));
@@ -770,6 +813,7 @@ int edgehip_set_framecount(edgehip_ctx *c, int seq, int slot, uint32_t fc) {
 }
 
 int edgehip_download_keylines(edgehip_ctx *c, int seq, int slot, edgehip_keyline *kl, int32_t *mask, int32_t *kn_out) {
+    EH_ENTER(c);
     if (int e = check_seq(c, seq)) return e;
     if (int e = check_slot(c, slot)) return e;
     if (!kl || !kn_out) return EDGEHIP_ERR_ARG;
@@ -819,6 +863,7 @@ int edgehip_download_keylines(edgehip_ctx *c, int seq, int slot, edgehip_keyline
 }
 
 int edgehip_upload_keylines(edgehip_ctx *c, int seq, int slot, const edgehip_keyline *kl, int32_t kn, const int32_t *mask, float retuned) {
+    EH_ENTER(c);
     if (int e = check_seq(c, seq)) return e;
     if (int e = check_slot(c, slot)) return e;
     if (!kl || kn < 0 || kn > c->plan.cap) { set_error("upload_keylines: kn exceeds capacity"); return EDGEHIP_ERR_ARG; }
@@ -860,9 +905,10 @@ int edgehip_upload_keylines(edgehip_ctx *c, int seq, int slot, const edgehip_key
     e |= h2d(c, k.p_m_0, p_m_0); e |= h2d(c, k.m_m0, m_m0); e |= h2d(c, k.n_m, n_m);
     e |= h2d(c, k.rho, rho); e |= h2d(c, k.s_rho, s_rho); e |= h2d(c, k.rho_nr, rho_nr); e |= h2d(c, k.s_rho_nr, s_rho_nr);
     e |= h2d(c, k.rho0, rho0); e |= h2d(c, k.s_rho0, s_rho0); e |= h2d(c, k.n_m0, n_m0); e |= h2d(c, k.rec, rec); e |= h2d(c, k.grec, grec);
+    std::vector<int32_t> st_id;          // function scope: the asynchronous copies out of them end at the sync below
+    std::vector<double> st_rho, st_srho;
     if (k.stereo_m_id) {
-        std::vector<int32_t> st_id(kn);
-        std::vector<double> st_rho(kn), st_srho(kn);
+        st_id.resize(kn); st_rho.resize(kn); st_srho.resize(kn);
         for (int i = 0; i < kn; i++) { st_id[i] = kl[i].stereo_m_id; st_rho[i] = kl[i].stereo_rho; st_srho[i] = kl[i].stereo_s_rho; }
         e |= h2d(c, k.stereo_m_id, st_id); e |= h2d(c, k.stereo_rho, st_rho); e |= h2d(c, k.stereo_s_rho, st_srho);
     }
@@ -881,6 +927,7 @@ int edgehip_upload_keylines(edgehip_ctx *c, int seq, int slot, const edgehip_key
 }
 
 int edgehip_download_plane(edgehip_ctx *c, int seq, int which, float *out) {
+    EH_ENTER(c);
     if (int e = check_seq(c, seq)) return e;
     if (!c->planes) { set_error("download_plane: context was created without debug_planes"); return EDGEHIP_ERR_STATE; }
     if (which < 0 || which > 4 || !out) return EDGEHIP_ERR_ARG;
@@ -892,6 +939,7 @@ int edgehip_download_plane(edgehip_ctx *c, int seq, int which, float *out) {
 }
 
 int edgehip_download_field(edgehip_ctx *c, int seq, int32_t *out) {
+    EH_ENTER(c);
     if (int e = check_seq(c, seq)) return e;
     if (!out) return EDGEHIP_ERR_ARG;
     const size_t n = c->plan.n;
@@ -936,6 +984,7 @@ int edgehip_build_undistort_map(const edgehip_params *params, int32_t *inx, int3
 }
 
 int edgehip_download_undistorted(edgehip_ctx *c, int seq, int slot, uint8_t *rgb24) {
+    EH_ENTER(c);
     if (int e = check_seq(c, seq)) return e;
     if (int e = check_slot(c, slot)) return e;
     if (!rgb24) return EDGEHIP_ERR_ARG;
@@ -950,11 +999,13 @@ int edgehip_download_undistorted(edgehip_ctx *c, int seq, int slot, uint8_t *rgb
 
 // ---- profiler -------------------------------------------------------------------------------------------
 int edgehip_profile_enable(edgehip_ctx *c, int on) {
+    EH_ENTER(c);
     if (!c) return EDGEHIP_ERR_ARG;
     c->prof->on = on != 0;
     return 0;
 }
 int edgehip_profile_select(edgehip_ctx *c, uint64_t mask) {
+    EH_ENTER(c);
     if (!c) return EDGEHIP_ERR_ARG;
     c->prof->mask = mask;
     return 0;
@@ -962,6 +1013,7 @@ int edgehip_profile_select(edgehip_ctx *c, uint64_t mask) {
 int edgehip_profile_count(void) { return PROF_COUNT; }
 const char *edgehip_profile_name(int i) { return (i >= 0 && i < PROF_COUNT) ? kProfNames[i] : ""; }
 int edgehip_profile_read(edgehip_ctx *c, double *ms, int64_t *calls) {
+    EH_ENTER(c);
     if (!c || !ms || !calls) return EDGEHIP_ERR_ARG;
     if (int e = sync_all(c)) return e;
     Profiler *p = c->prof;

@@ -160,6 +160,7 @@ struct edgehip_ctx {
     bool ring_valid[8];
     bool use_valid[4];
     int overlap;           // 1: stage A of frame k+1 may run under stages B/C of frame k (EDGEHIP_OVERLAP=1); 0: one after the other
+    bool lds_optin_level = false, lds_optin_detect = false;   // > 64 KB dynamic LDS opted in for this context's device
     int frame_slot;        // ring position of the newest slot (-1 before the first frame)
     int frames_seen;
     // device buffers
@@ -239,7 +240,8 @@ struct edgehip_ctx {
     edgehip::SeqDev *pinned_seq;  // [B]
     edgehip::SeqA *pinned_seqa;   // [B]
     double *pinned_out;    // misc readback
-    double *pinned_t;      // [8][B]
+    double *pinned_t;      // [8][B] time stamps, one row per frame ring entry
+    int32_t *pinned_idx;   // [8][4][B] frame-pool indices, one row per (frame ring entry, slot)
     edgehip_nav *pinned_nav;  // [B]
     edgehip::Profiler *prof;
 };
@@ -256,6 +258,18 @@ int hip_fail(hipError_t e, const char *what, const char *file, int line);
     } while (0)
 
 #define EH_LAUNCH_CHECK() EH_CHECK(hipGetLastError())
+
+// First statement of every entry point that takes a context.  (i) The calls below go to the context's device whatever
+// device the calling thread had current (one rebvo::REBVO per GPU in one process).  (ii) HIP keeps the last error of a
+// thread until somebody reads it (ROCm 7: later successful calls do not clear it), and EH_LAUNCH_CHECK reads that slot
+// after a kernel launch: an error some earlier call left behind — a failed hipMalloc of an edgehip_create that ran out of
+// memory, or another library's — must not be reported by the next launch, so the slot is emptied on the way in.
+void enter_ctx(edgehip_ctx *c);
+#define EH_ENTER(c)                                                                         \
+    do {                                                                                    \
+        if (!(c)) { ::edgehip::set_error("null context"); return EDGEHIP_ERR_ARG; }         \
+        ::edgehip::enter_ctx(c);                                                            \
+    } while (0)
 
 inline KlSoA &klof(edgehip_ctx *c, int slot, int seq) { return c->kl[(size_t)slot * c->plan.nseq + seq]; }
 inline KlSoA *kldev(edgehip_ctx *c, int slot) { return c->kl_dev + (size_t)slot * c->plan.nseq; }

@@ -1113,8 +1113,8 @@ int stage_a_enqueue(edgehip_ctx *c, int slot) {
 #else
         const int lv_ablate = 0;
 #endif
-        if (sm > 64 * 1024) {   // more than the default dynamic-LDS limit: opt in once per kernel
-            static bool done = false;
+        if (sm > 64 * 1024) {   // more than the default dynamic-LDS limit: opt in once per kernel and context (= per device)
+            bool &done = c->lds_optin_level;
             if (!done) {
                 const void *fns[6] = {(const void *)&k_level<0, 1>, (const void *)&k_level<1, 1>, (const void *)&k_level<2, 1>,
                                       (const void *)&k_level<0, 2>, (const void *)&k_level<1, 2>, (const void *)&k_level<2, 2>};
@@ -1280,7 +1280,7 @@ int stage_a_enqueue(edgehip_ctx *c, int slot) {
         const int npx_b = kBandRows * w, cpw_b = (((npx_b + 63) >> 6) + kDetWaves - 1) / kDetWaves;
         const size_t sm = (size_t)2 * (kBandRows + 4) * w * sizeof(float) + (size_t)kDetWaves * cpw_b * 64 * sizeof(uint16_t);
         if (sm > 64 * 1024) {
-            static bool done = false;
+            bool &done = c->lds_optin_detect;
             if (!done) {
                 EH_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_detect), hipFuncAttributeMaxDynamicSharedMemorySize, 158 * 1024));
                 done = true;

@@ -1697,10 +1697,12 @@ using namespace edgehip;
 extern "C" {
 
 int edgehip_quantile(edgehip_ctx *c, int slot, double a, double b, double pct, int n) {
+    EH_ENTER(c);
     if (!c || slot < 0 || slot >= c->plan.nslots) return EDGEHIP_ERR_ARG;
     return quantile_enqueue(c, slot, a, b, pct, n);
 }
 int edgehip_build_field(edgehip_ctx *c, int slot, int r, float m) {
+    EH_ENTER(c);
     if (!c || slot < 0 || slot >= c->plan.nslots) return EDGEHIP_ERR_ARG;
     return build_field_enqueue(c, slot, r, m);
 }
@@ -1708,6 +1710,7 @@ int edgehip_build_field(edgehip_ctx *c, int slot, int r, float m) {
 int edgehip_try_velrot(edgehip_ctx *c, int slot_new, int slot_old, const double *X, int reweight, int procjf,
                        double match_thresh, const double *s_rho_min, uint32_t match_num_thresh, double k_huber,
                        int resid_in, int resid_out, double *out) {
+    EH_ENTER(c);
     if (!c || !X || !s_rho_min || !out || slot_new < 0 || slot_old < 0 || slot_new >= c->plan.nslots ||
         slot_old >= c->plan.nslots || resid_in >= kResidBufs || resid_out < 0 || resid_out >= kResidBufs) {
         set_error("try_velrot: bad argument");
@@ -1761,6 +1764,7 @@ __global__ void k_resolve_resid(const double *__restrict__ resid, const double *
 }
 
 int edgehip_download_resid(edgehip_ctx *c, int which, double *resid) {
+    EH_ENTER(c);
     if (!c || !resid || which < 0 || which >= kResidBufs) return EDGEHIP_ERR_ARG;
     const DevicePlan &pl = c->plan;
     hipLaunchKernelGGL(k_resolve_resid, dim3((pl.cap + 255) / 256, 1, pl.nseq), dim3(256), 0, c->stream,
@@ -1775,6 +1779,7 @@ int edgehip_download_resid(edgehip_ctx *c, int which, double *resid) {
 int edgehip_minimizer_v(edgehip_ctx *c, int slot_new, int slot_old, double *V, const double *s_rho_min, float min_mod,
                         double match_thresh, int iter_max, uint32_t match_num_thresh, double reweight_distance, double *RVel,
                         double *F) {
+    EH_ENTER(c);
     if (!c || !V || !s_rho_min || slot_new < 0 || slot_old < 0 || slot_new >= c->plan.nslots || slot_old >= c->plan.nslots ||
         iter_max < 0) {
         set_error("minimizer_v: bad argument");
@@ -1810,6 +1815,7 @@ int edgehip_minimizer_v(edgehip_ctx *c, int slot_new, int slot_old, double *V, c
 }
 
 int edgehip_minimizer_rv(edgehip_ctx *c, int slot_new, int slot_old) {
+    EH_ENTER(c);
     if (!c || slot_new < 0 || slot_old < 0 || slot_new >= c->plan.nslots || slot_old >= c->plan.nslots) return EDGEHIP_ERR_ARG;
     return minimizer_enqueue(c, slot_new, slot_old, slot_new);
 }

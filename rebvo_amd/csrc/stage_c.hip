@@ -904,27 +904,33 @@ static int chk2(edgehip_ctx *c, int a, int b) {
 }
 
 int edgehip_forward_match(edgehip_ctx *c, int slot_old, int slot_new) {
+    EH_ENTER(c);
     if (int e = chk2(c, slot_old, slot_new)) return e;
     return forward_match_enqueue(c, slot_old, slot_new);
 }
 int edgehip_rotate_keylines(edgehip_ctx *c, int slot, const double *R) {
+    EH_ENTER(c);
     if (int e = chk2(c, slot, slot)) return e;
     return rotate_enqueue(c, slot, R);
 }
 int edgehip_directed_matching(edgehip_ctx *c, int slot_new, int slot_old) {
+    EH_ENTER(c);
     if (int e = chk2(c, slot_new, slot_old)) return e;
     return directed_enqueue(c, slot_new, slot_old);
 }
 int edgehip_regularize_ekf(edgehip_ctx *c, int slot, int do_reg, int do_ekf) {
+    EH_ENTER(c);
     if (int e = chk2(c, slot, slot)) return e;
     return regekf_enqueue(c, slot, do_reg, do_ekf);
 }
 int edgehip_rescale(edgehip_ctx *c, int slot) {
+    EH_ENTER(c);
     if (int e = chk2(c, slot, slot)) return e;
     return rescale_enqueue(c, slot);
 }
 
 int edgehip_set_slot_camera(edgehip_ctx *c, int slot, double ppx, double ppy, double zfx, double zfy) {
+    EH_ENTER(c);
     if (int e = chk2(c, slot, slot)) return e;
     drop_frame_graphs(c);
     // REBVOParameters / cam_model keep these as float (cam_model.h:51-57)
@@ -965,6 +971,7 @@ static int fuse_stereo_enqueue(edgehip_ctx *c, int slot, bool frame_driver) {
 int edgehip_directed_matching_stereo(edgehip_ctx *c, int slot, int slot_pair, const double *t, const double *R, double min_thr_mod,
                                      double min_thr_ang, double max_radius, double loc_unc, double q_abs, double q_rel,
                                      double loc_unc_model, int32_t *nmatch) {
+    EH_ENTER(c);
     (void)q_abs; (void)q_rel;
     if (int e = chk2(c, slot, slot_pair)) return e;
     if (!t || !R) return EDGEHIP_ERR_ARG;
@@ -976,12 +983,14 @@ int edgehip_directed_matching_stereo(edgehip_ctx *c, int slot, int slot_pair, co
 }
 
 int edgehip_fuse_stereo_depth(edgehip_ctx *c, int slot) {
+    EH_ENTER(c);
     if (int e = chk2(c, slot, slot)) return e;
     if (!c->p.stereo_available) { set_error("fuse_stereo_depth: context created without stereo_available"); return EDGEHIP_ERR_STATE; }
     return fuse_stereo_enqueue(c, slot, false);
 }
 
 int edgehip_set_stereo_rig(edgehip_ctx *c, int slot_pair, const double *t, const double *R, double max_radius) {
+    EH_ENTER(c);
     if (!c) return EDGEHIP_ERR_ARG;
     drop_frame_graphs(c);
     if (slot_pair < 0) {   // switch the rig off: the whole ring is available again
@@ -1006,6 +1015,7 @@ int edgehip_set_stereo_rig(edgehip_ctx *c, int slot_pair, const double *t, const
 }
 
 int edgehip_get_stereo_matches(edgehip_ctx *c, int32_t *nmatch) {
+    EH_ENTER(c);
     if (!c || !nmatch) return EDGEHIP_ERR_ARG;
     if (!c->stereo_cnt) { set_error("get_stereo_matches: context created without stereo_available"); return EDGEHIP_ERR_STATE; }
     EH_CHECK(hipMemcpyAsync(nmatch, c->stereo_cnt, sizeof(int32_t) * c->plan.nseq, hipMemcpyDeviceToHost, c->stream));
@@ -1042,6 +1052,7 @@ static void jacobi_eig6_host(const double Ain[36], double V[36], double e[6]) {
 
 int edgehip_ext_rot_vel(edgehip_ctx *c, int slot, const double *vel, double loc_unc, double hub_reweight, double *X, double *Wx,
                         double *Rx, int32_t *ok) {
+    EH_ENTER(c);
     if (int e = chk2(c, slot, slot)) return e;
     if (!vel || !X) return EDGEHIP_ERR_ARG;
     const DevicePlan &pl = c->plan;
@@ -1092,6 +1103,7 @@ int edgehip_ext_rot_vel(edgehip_ctx *c, int slot, const double *vel, double loc_
 }
 
 int edgehip_depth_reset(edgehip_ctx *c, int seq) {
+    EH_ENTER(c);
     if (!c || seq >= c->plan.nseq) return EDGEHIP_ERR_ARG;
     if (c->frame_slot < 0) return 0;  // nothing detected yet: the initial state already is the reset state
     const DevicePlan &pl = c->plan;
@@ -1102,6 +1114,7 @@ int edgehip_depth_reset(edgehip_ctx *c, int seq) {
 }
 
 int edgehip_depth_reset_slot(edgehip_ctx *c, int seq, int slot) {
+    EH_ENTER(c);
     if (!c || seq >= c->plan.nseq || slot < 0 || slot >= c->plan.nslots) return EDGEHIP_ERR_ARG;
     const DevicePlan &pl = c->plan;
     hipLaunchKernelGGL(k_depth_reset, dim3((pl.cap + 255) / 256, 1, pl.nseq), dim3(256), 0, c->stream, kldev(c, slot),
@@ -1175,6 +1188,7 @@ static int frame_enqueue(edgehip_ctx *c, int sn, int so, int sp, int have_pair, 
 }
 
 int edgehip_process_frame(edgehip_ctx *c, const double *t) {
+    EH_ENTER(c);
     if (!c || !t) return EDGEHIP_ERR_ARG;
     const DevicePlan &pl = c->plan;
     const int sn = (c->frame_slot + 1) % c->ring_slots, so = c->frame_slot;
@@ -1235,6 +1249,7 @@ int edgehip_process_frame(edgehip_ctx *c, const double *t) {
 }
 
 int edgehip_read_nav(edgehip_ctx *c, edgehip_nav *nav) {
+    EH_ENTER(c);
     if (!c || !nav) return EDGEHIP_ERR_ARG;
     EH_CHECK(hipMemcpyAsync(c->pinned_nav, c->nav_dev, sizeof(edgehip_nav) * c->plan.nseq, hipMemcpyDeviceToHost, c->stream));
     EH_CHECK(hipStreamSynchronize(c->stream));

@@ -231,3 +231,63 @@ def test_create_that_runs_out_of_memory_leaves_nothing_behind():
     assert abs(free0 - free1) < (64 << 20), (free0, free1)
     eh = edgehip.EdgeHip(edgehip.euroc_params(376, 240), nseq=1, nslots=2)
     eh.close()
+
+
+def test_failed_create_does_not_poison_the_next_frames():
+    """Regression (round 1, GPUTEST_r01): HIP keeps a thread's last error until it is read, and the launch checks read
+    that slot — the hipMalloc that failed inside an out-of-memory edgehip_create was reported, as "out of memory", by
+    the first kernel launch of the NEXT context in the process.  Failed create -> successful create -> frames, in one
+    process and one thread, checked against the reference."""
+    w, h = 256, 192
+    with pytest.raises(edgehip.EdgeHipError):
+        edgehip.EdgeHip(edgehip.euroc_params(752, 480), nseq=400000, nslots=3)
+    orc = _oracle(w, h)
+    eh = edgehip.EdgeHip(edgehip.euroc_params(w, h), nseq=1, nslots=3)
+    for k, (f, _, _) in enumerate(synth.billboard_sequence(w, h, 3)):
+        _, nr = orc.process_frame(f, 0.05 * k)
+        eh.upload_rgb(eh.next_slot(), f)
+        eh.process_frame(0.05 * k)            # round 1: "hipGetLastError() -> out of memory" here
+        _check(eh.read_nav()[0], nr, k)
+    # a foreign error left in the slot by someone else's HIP call must not surface either
+    import ctypes
+    hip = ctypes.CDLL("libamdhip64.so")
+    p = ctypes.c_void_p()
+    assert hip.hipMalloc(ctypes.byref(p), ctypes.c_size_t(1 << 60)) != 0      # fails, stays in the last-error slot
+    f = next(iter(synth.billboard_sequence(w, h, 1)))[0]
+    eh.upload_rgb(eh.next_slot(), f)
+    eh.process_frame(0.2)
+    eh.stage_a(eh.cur_slot())
+    eh.close()
+
+
+def test_two_slots_bound_between_frames_keep_their_own_indices():
+    """Regression: edgehip_bind_rgb_indexed staged the index vector of every bind between two process_frame
+    calls in the same pinned row, so a second bind (the stereo pair slot, a prefetch of the next frame) could overwrite
+    the indices of the first while its asynchronous copy was still pending."""
+    import torch
+    w, h, npool, B = 256, 192, 6, 64
+    frames = [f for f, _, _ in synth.billboard_sequence(w, h, npool, seed=5)]
+    host = np.stack(frames)
+    pool = torch.empty(host.size + 16, dtype=torch.uint8, device="cuda")
+    pool[:host.size] = torch.from_numpy(host.reshape(-1)).cuda()
+    torch.cuda.synchronize()
+    eh = edgehip.EdgeHip(edgehip.euroc_params(w, h, auto_gain=0.0), nseq=B, nslots=3)   # fixed threshold: kn depends on the frame only
+    ia = np.array([s % npool for s in range(B)], np.int32)
+    ib = np.array([(s + 3) % npool for s in range(B)], np.int32)
+    for rep in range(20):                     # the race needs the first copy to be still pending: try a few times
+        eh.bind_rgb_indexed(0, pool.data_ptr(), npool, ia)
+        eh.bind_rgb_indexed(1, pool.data_ptr(), npool, ib)
+        eh.stage_a(0)
+        eh.stage_a(1)
+        kn0, kn1 = eh.get_kn(0), eh.get_kn(1)
+        if rep == 0:
+            # what each pool frame gives on its own
+            ref = []
+            for i in range(npool):
+                eh.bind_rgb_indexed(2, pool.data_ptr(), npool, np.full(B, i, np.int32))
+                eh.stage_a(2)
+                ref.append(int(eh.get_kn(2)[0]))
+            assert len(set(ref)) > 1, ref     # the frames are distinguishable by their KeyLine count
+        assert [int(v) for v in kn0] == [ref[i] for i in ia], rep
+        assert [int(v) for v in kn1] == [ref[i] for i in ib], rep
+    eh.close()
