@@ -74,7 +74,7 @@ static const char *kProfNames[PROF_COUNT] = {
     "A.rgb_rowscan", "A.colscan", "A.avg_rowscan", "A.detect", "A.compact", "A.join_retune",
     "B.quantile", "B.build_field", "B.tvr_prepare", "B.try_velrot", "B.lm_step",
     "C.forward_match", "C.rotate", "C.directed_matching", "C.regularize_ekf", "C.rescale", "C.pose",
-    "A.level", "B.minimizer"};
+    "A.level", "B.minimizer", "A.fused"};
 
 ProfScope::ProfScope(edgehip_ctx *ctx, int pid, hipStream_t stream) : c(ctx), id(pid), st(stream ? stream : ctx->stream) {
     Profiler *p = c->prof;
@@ -432,6 +432,7 @@ static int create_body(edgehip_ctx *c, CtxAllocs *al, const edgehip_params &p, i
     c->field_mode = getenv("EDGEHIP_FIELD_MODE") ? atoi(getenv("EDGEHIP_FIELD_MODE")) : 0;
     c->no_grec = getenv("EDGEHIP_NO_GREC") && atoi(getenv("EDGEHIP_NO_GREC")) != 0;
     c->level_mode = getenv("EDGEHIP_LEVEL_MODE") ? atoi(getenv("EDGEHIP_LEVEL_MODE")) : 0;
+    c->fused_min_batch = getenv("EDGEHIP_FUSED_MIN_BATCH") ? atoi(getenv("EDGEHIP_FUSED_MIN_BATCH")) : (1 << 30);   // off by default until it beats the multi-kernel path
     c->overlap = getenv("EDGEHIP_OVERLAP") ? atoi(getenv("EDGEHIP_OVERLAP")) : 0;
     EH_TRY(dmalloc(c, &c->fwd_key, B * CAP, al->dev, 0));
     EH_TRY(dmalloc(c, &c->fwd_win, B * CAP, al->dev, 0xFF));
@@ -501,6 +502,7 @@ static int create_body(edgehip_ctx *c, CtxAllocs *al, const edgehip_params &p, i
                     return EDGEHIP_ERR_STATE;
                 }
             }
+        memcpy(c->pinv_host, pinv, sizeof pinv);
         EH_CHECK(hipMemcpyAsync(c->pinv, pinv, sizeof pinv, hipMemcpyHostToDevice, c->stream));
         EH_CHECK(hipStreamSynchronize(c->stream));  // lut/pinv are stack temporaries
     }

@@ -160,7 +160,7 @@ struct edgehip_ctx {
     bool ring_valid[8];
     bool use_valid[4];
     int overlap;           // 1: stage A of frame k+1 may run under stages B/C of frame k (EDGEHIP_OVERLAP=1); 0: one after the other
-    bool lds_optin_level = false, lds_optin_detect = false;   // > 64 KB dynamic LDS opted in for this context's device
+    bool lds_optin_level = false, lds_optin_detect = false, lds_optin_fused = false;   // > 64 KB dynamic LDS opted in for this context's device
     int frame_slot;        // ring position of the newest slot (-1 before the first frame)
     int frames_seen;
     // device buffers
@@ -220,7 +220,9 @@ struct edgehip_ctx {
     std::vector<SlotCam> slot_cam;   // per ring slot: principal point stage A uses, focal length of that camera (stereo pair slot)
     int field_radius;      // radius of the last build_field (global_tracker::max_r)
     int field_mode;        // 0 = binned tiles (default), 1 = global-atomic scatter, 2 = mask-scan tiles (A/B)
-    int level_mode;        // stage A box levels: 0 = auto (one-pass k_level when >= 192 planes in flight), 1 = multi-pass, 2 = k_level
+    int level_mode;        // stage A: 0 = auto (fused kernel from fused_min_batch sequences on, else one-pass k_level when >= 192 planes in flight), 1 = multi-pass, 2 = k_level, 3 = fused
+    int fused_min_batch;   // EDGEHIP_FUSED_MIN_BATCH
+    double pinv_host[75];  // plane-fit pseudo inverse (kernel argument of the fused stage A)
     int32_t *bin_cnt;      // [B][256] KeyLines binned per field tile
     int32_t *bins;         // [B][256][CAP] KeyLine ids per field tile (allocated for the tiles in use)
     int nblk_tvr;
@@ -281,7 +283,7 @@ enum ProfId {
     PROF_A_ROWSCAN = 0, PROF_A_COLSCAN, PROF_A_AVGROW, PROF_A_DETECT, PROF_A_COMPACT, PROF_A_JOIN,
     PROF_B_QUANTILE, PROF_B_FIELD, PROF_B_PREP, PROF_B_TRYVELROT, PROF_B_LMSTEP,
     PROF_C_FORWARD, PROF_C_ROTATE, PROF_C_DIRECTED, PROF_C_REGEKF, PROF_C_RESCALE, PROF_C_POSE,
-    PROF_A_LEVEL, PROF_B_MINIMIZER,
+    PROF_A_LEVEL, PROF_B_MINIMIZER, PROF_A_FUSED,
     PROF_COUNT
 };
 struct Profiler {

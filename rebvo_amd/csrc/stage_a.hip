@@ -34,6 +34,7 @@
 #include <type_traits>
 
 #include "ctx.h"
+#include "stage_a_dev.h"
 
 namespace edgehip {
 
@@ -318,11 +319,6 @@ struct LevelJob {
     float a[2];
 };
 
-// Workgroup barrier that orders LDS traffic only.  __syncthreads() also drains vmcnt, i.e. waits for every
-// outstanding global load AND store of the wave; in k_level the threads exchange data through LDS alone, and
-// letting the global prefetches / row stores stay in flight across the barrier is the whole point.
-__device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
-
 template <int SRC, int MC>   // SRC 0: box average of job.src; 1: grey of the RGB24 frame; 2: grey of the undistorted frame
 __global__ __launch_bounds__(LV_NT) void k_level(LevelJob job, const uint8_t *__restrict__ rgb, const int32_t *__restrict__ fidx,
                                                  const int32_t *__restrict__ und_base, const uint4 *__restrict__ und_iw,
@@ -590,16 +586,6 @@ struct DetectArgs {
     double pn_thresh;          // (double)(25.0f * (float)DetectorPosNegThresh)
     int ablate;                // debug: bit0 skip phase 1 math, bit1 skip 2a, bit2 skip 2b
 };
-
-__device__ __forceinline__ double update_thresh(double tresh, int l_kl_num, int kl_ref, double gain, double tmax,
-                                                double tmin) {
-    // UpdateThresh, edge_finder.cpp:330-335
-    if (gain > 0) {
-        tresh -= gain * (double)(kl_ref - l_kl_num);
-        tresh = tresh > tmax ? tmax : (tresh < tmin ? tmin : tresh);
-    }
-    return tresh;
-}
 
 __global__ __launch_bounds__(kDetWaves * 64) void k_detect(DetectArgs a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -1101,6 +1087,22 @@ int stage_a_enqueue(edgehip_ctx *c, int slot) {
     // where the slot's frames are: its own storage (sequence-major) or frames of a bound device pool (edgehip_bind_rgb_indexed)
     const uint8_t *rgb_base = c->slot_src[slot].base ? c->slot_src[slot].base : rgbof(c, slot);
     const int32_t *rgb_idx = c->slot_src[slot].base ? c->frame_idx + (size_t)slot * c->plan.nseq : nullptr;
+
+    // Batches that fill the GPU with one workgroup per sequence: the whole of stage A up to the KeyLine records in one
+    // kernel (stage_a_fused.hip); level_mode 3 forces it, 1 / 2 keep the multi-kernel path (A/B measurements, tests).
+    const bool use_fused = fused_supported(c) && (c->level_mode == 3 || (c->level_mode == 0 && B >= c->fused_min_batch));
+    if (use_fused) {
+        if (int e = stage_a_fused_enqueue(c, slot, rgb_base, rgb_idx)) return e;
+        ProfScope ps(c, PROF_A_JOIN, st);
+        hipLaunchKernelGGL(k_join_histo, dim3((pl.cap + 255) / 256, 1, B), dim3(256), 0, st, kldev(c, slot),
+                           maskof(c, slot), c->seqa, c->histo, w, n, c->p.qcut_nbins);
+        EH_LAUNCH_CHECK();
+        hipLaunchKernelGGL(k_retune, dim3(B), dim3(256), 0, st, c->seqa, c->histo,
+                           c->retuned_slot + (size_t)slot * B, B, c->p.track_points,
+                           c->p.qcut_nbins);
+        EH_LAUNCH_CHECK();
+        return 0;
+    }
 
     float *cur[2] = {ii[0], ii[0]};
     const int planes_in_flight = B * 2;

@@ -1,0 +1,56 @@
+// stage_a_dev.h — device helpers and launch records shared by stage_a.hip and stage_a_fused.hip.
+#pragma once
+#include "ctx.h"
+
+namespace edgehip {
+
+// UpdateThresh, edge_finder.cpp:330-335
+__device__ __forceinline__ double update_thresh(double tresh, int l_kl_num, int kl_ref, double gain, double tmax,
+                                                double tmin) {
+    if (gain > 0) {
+        tresh -= gain * (double)(kl_ref - l_kl_num);
+        tresh = tresh > tmax ? tmax : (tresh < tmin ? tmin : tresh);
+    }
+    return tresh;
+}
+
+// Workgroup barrier that orders LDS traffic only.  __syncthreads() also drains vmcnt, i.e. waits for every
+// outstanding global load AND store of the wave; the stage-A kernels exchange data between threads through LDS alone,
+// and letting the global prefetches / row stores stay in flight across the barrier is the whole point.
+__device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+
+// LDS rows of the fused kernel: kFusedPad zero floats left of column 0 (the taps x-r-1 < 0 of iimage::average read 0),
+// row stride with (stride / 4) odd so that the scan wave's lanes (one row each, float4 steps) spread over the banks.
+constexpr int kFusedPad = 4;
+__host__ __device__ inline int fused_row_stride(int w) {
+    int wp = (w + kFusedPad + 3) & ~3;
+    if (((wp >> 2) & 1) == 0) wp += 4;
+    return wp;
+}
+
+struct FusedArgs {
+    const uint8_t *rgb;        // frames of the slot (sequence-major) or a bound pool
+    const int32_t *fidx;       // [B] frame index inside the pool, or null
+    const float *lut;          // [kDivLutMax] (float)(1.0/count)
+    float *planes;             // optional debug planes [5][B][N]
+    int32_t *mask;             // [B][N] of the slot
+    SeqA *seq;
+    KlSoA *kl;                 // [B] of the slot
+    int32_t *histo;            // [B][256]
+    int32_t *kn_out;           // [B] edge_finder::kn of the slot
+    double *tresh_out;         // [B] threshold the slot was detected with
+    int w, h, nseq;
+    size_t n;
+    double gain, tmax, tmin;   // edge_finder::detect arguments
+    int kl_ref, kl_max;
+    float dog_thresh_f;        // (float)DetectorDoGThresh
+    double pn_thresh;          // (double)(25.0f * (float)DetectorPosNegThresh)
+    double pc0[5], pc1[5], pc2;   // plane-fit pseudo inverse: row 0 by window column, row 1 by window row, row 2 constant
+    float ppx, ppy;
+    int ablate;                // timing experiments (EXPERIMENTS builds only)
+};
+
+bool fused_supported(const edgehip_ctx *c);
+int stage_a_fused_enqueue(edgehip_ctx *c, int slot, const uint8_t *rgb_base, const int32_t *rgb_idx);
+
+}  // namespace edgehip
