@@ -991,6 +991,10 @@ __device__ __forceinline__ int x86_cvttss2si(float f) {
     return (int)f;
 }
 
+// DEFAULTS: also give KeyLine i the constant fields of a freshly detected KeyLine (edge_finder.cpp:176-196) — after the fused
+// stage-A kernel, which writes only the computed fields and p_id (the atomicMax below needs p_id = -1 before any thread
+// runs): a full-wave streaming store here instead of a partial-wave one there.
+template <bool DEFAULTS>
 __global__ __launch_bounds__(256) void k_join_histo(KlSoA *kls, const int32_t *__restrict__ masks, SeqA *seqs,
                                                     int32_t *histo, int w, size_t n, int nbins) {
     const int seq = blockIdx.z;
@@ -1014,10 +1018,23 @@ __global__ __launch_bounds__(256) void k_join_histo(KlSoA *kls, const int32_t *_
         int j = mask[(size_t)y * w + (x + sx)];
         if (j < 0) j = mask[(size_t)(y + sy) * w + x];
         if (j < 0) j = mask[(size_t)(y + sy) * w + (x + sx)];
-        if (j >= 0) {
-            k.n_id[i] = j;
-            atomicMax(&k.p_id[j], i);
-        }
+        if (DEFAULTS) {
+            k.rho[i] = 1.0;          // RhoInit
+            k.s_rho[i] = 20.0;       // RHO_MAX
+            k.rho0[i] = 1.0;
+            k.s_rho0[i] = 20.0;
+            k.rho_nr[i] = 1.0;
+            k.s_rho_nr[i] = 20.0;
+            k.m_num[i] = 0;
+            k.m_id[i] = -1;
+            if (k.stereo_m_id) { k.stereo_m_id[i] = -1; k.stereo_rho[i] = 1.0; k.stereo_s_rho[i] = 20.0; }
+            k.m_id_f[i] = -1;
+            k.m_id_kf[i] = -1;
+            k.m_m0[i] = make_float2(0.f, 0.f);
+            k.n_m0[i] = 0.0;
+            k.n_id[i] = j;           // -1 without a neighbour
+        } else if (j >= 0) k.n_id[i] = j;
+        if (j >= 0) atomicMax(&k.p_id[j], i);
         // histogram position, edge_finder.cpp:392
         const float mxd = sq->nm_max, mnd = sq->nm_min;
         int b = x86_cvttss2si((float)nbins * (mxd - k.n_m[i]) / (mxd - mnd));
@@ -1094,7 +1111,7 @@ int stage_a_enqueue(edgehip_ctx *c, int slot) {
     if (use_fused) {
         if (int e = stage_a_fused_enqueue(c, slot, rgb_base, rgb_idx)) return e;
         ProfScope ps(c, PROF_A_JOIN, st);
-        hipLaunchKernelGGL(k_join_histo, dim3((pl.cap + 255) / 256, 1, B), dim3(256), 0, st, kldev(c, slot),
+        hipLaunchKernelGGL(k_join_histo<true>, dim3((pl.cap + 255) / 256, 1, B), dim3(256), 0, st, kldev(c, slot),
                            maskof(c, slot), c->seqa, c->histo, w, n, c->p.qcut_nbins);
         EH_LAUNCH_CHECK();
         hipLaunchKernelGGL(k_retune, dim3(B), dim3(256), 0, st, c->seqa, c->histo,
@@ -1309,7 +1326,7 @@ int stage_a_enqueue(edgehip_ctx *c, int slot) {
     }
     {
         ProfScope ps(c, PROF_A_JOIN, st);
-        hipLaunchKernelGGL(k_join_histo, dim3((pl.cap + 255) / 256, 1, B), dim3(256), 0, st, kldev(c, slot),
+        hipLaunchKernelGGL(k_join_histo<false>, dim3((pl.cap + 255) / 256, 1, B), dim3(256), 0, st, kldev(c, slot),
                            maskof(c, slot), c->seqa, c->histo, w, n, c->p.qcut_nbins);
         EH_LAUNCH_CHECK();
         hipLaunchKernelGGL(k_retune, dim3(B), dim3(256), 0, st, c->seqa, c->histo,

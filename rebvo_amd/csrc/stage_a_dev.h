@@ -21,11 +21,10 @@ __device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(
 
 // LDS rows of the fused kernel: kFusedPad zero floats left of column 0 (the taps x-r-1 < 0 of iimage::average read 0),
 // row stride with (stride / 4) odd so that the scan wave's lanes (one row each, float4 steps) spread over the banks.
-constexpr int kFusedPad = 4;
-__host__ __device__ inline int fused_row_stride(int w) {
-    int wp = (w + kFusedPad + 3) & ~3;
-    if (((wp >> 2) & 1) == 0) wp += 4;
-    return wp;
+constexpr int kFusedPad = 4;   // also the right pad: the scan wave copies the last value of the row there (taps right of column w-1)
+__host__ __device__ constexpr inline int fused_row_stride(int w) {
+    const int wp = (w + 2 * kFusedPad + 3) & ~3;
+    return ((wp >> 2) & 1) == 0 ? wp + 4 : wp;
 }
 
 struct FusedArgs {

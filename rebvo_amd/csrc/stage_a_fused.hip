@@ -17,8 +17,11 @@
 //   * the serial top-to-bottom column prefix (iimage.cpp:63-67) is a running sum; the thread that owns column x keeps the
 //     running sums of ITS TWO TAP COLUMNS x+r and x-r-1 (every column sum is therefore computed by two threads, with the
 //     same operands in the same order, hence the same bits) — no exchange of integral values between threads;
-//   * the top taps of output row y are the bottom taps of output row y-d: a register history of d entries per tap column.
-// So a level costs, per pixel: two LDS reads of row-prefixed values, two adds, the four-tap combine.  The levels are
+//   * the top taps of output row y are the bottom taps of output row y-d: a register ring per tap column with static
+//     positions (the tick loop is unrolled over two ticks = 2 RB rows and the ring lengths divide 2 RB, so nothing is moved).
+// A thread owns two ADJACENT columns and computes them with packed fp32 instructions (v_pk_add_f32 / v_pk_mul_f32: two
+// IEEE operations per lane and instruction, each rounded exactly like the scalar one), tap pairs come out of LDS with one
+// ds_read2_b32.  So a level costs, per pixel pair: two LDS reads, two packed adds, the packed four-tap combine.  The levels are
 // chained through LDS row buffers that hold RB rows each: produced in tick t, row-scanned in tick t+1, consumed in
 // tick t+2 (two buffer sets, alternating).  Level l's rows trail its input by r rows, so img0 = G(sigma0) trails the
 // input by r1+r2a+r3a rows and img1 by r1+r2b+r3b; the kernel is instantiated for the box widths of the shipped
@@ -48,58 +51,72 @@
 
 namespace edgehip {
 
-// Running column sums of a level's two tap columns x+r and x-r-1 (age 0) and their values of the last D integral rows.
-template <int D>
-struct TapHist {
-    float a[D + 1], b[D + 1];
+typedef float v2f __attribute__((ext_vector_type(2)));   // the two adjacent columns of a thread: packed fp32 math
+
+// Running column sums of a level's tap columns x+r (a) and x-r-1 (b), for the last L integral rows, as a ring with static
+// positions: row q of the unrolled tick pair lives at position q % L.
+template <int L>
+struct TapRing {
+    v2f a[L], b[L];
 };
 
-// One row arrives for a level: yin = its index as a row of the level's input, vr / vl = the row-prefixed input values at the
-// tap columns x+r / x-r-1 (prow = the LDS row).  Returns the box average of output row yin - r (0 for rows that do not
-// exist) — iimage::average (iimage.cpp:86-128) on an integral image that is never stored:
-//   image rows (0 <= yin < h) add onto the running column sums (iimage.cpp:63-67: img(x,y) += img(x,y-1));
-//   the r virtual rows below the image leave them on row h-1 and take the bottom band's operand order ((A-C)-B)+D;
-//   top taps above the image are the zeros the history starts with (x - 0 is exact); taps left of the image read the
-//   zero pad of the LDS row.
-// Every condition is wave-uniform (a scalar branch); the branches also keep the instruction scheduler from pulling the
-// tap loads of all rows to the front, which costs more registers than there are.
-template <int D>
-__device__ __forceinline__ float level_row(TapHist<D> &H, const float *prow, int xr, int xl, int cx, bool xclip, float mu,
-                                           const float *s_lut, int yin, int h) {
+__device__ __forceinline__ v2f ld2(const float *p) { v2f v; v.x = p[0]; v.y = p[1]; return v; }   // -> ds_read2_b32
+
+// One input row arrives for a level (ring position P): vr / vl are the row-prefixed input values at the tap columns.
+// Returns the box average of output row (input row - r) — iimage::average (iimage.cpp:86-128) on an integral image that is
+// never stored.  Steady form: image row whose box is clipped neither above nor below; m = div(x,y) of the two columns.
+template <int D, int L>
+__device__ __forceinline__ v2f ring_row_steady(TapRing<L> &H, int P, v2f vr, v2f vl, v2f m) {
+    const int P1 = (P + L - 1) % L, PD = (P + L - D) % L;
+    H.a[P] = H.a[P1] + vr;                                       // img(x,y) += img(x,y-1), iimage.cpp:63-67
+    H.b[P] = H.b[P1] + vl;
+    return (((H.a[P] - H.b[P]) - H.a[PD]) + H.b[PD]) * m;        // ((A-B)-C)+D, iimage.cpp:119-126
+}
+// General form; every condition is wave-uniform.  Rows above the image leave the sums at 0 (their taps are the zeros x - 0
+// needs); the r virtual rows below it leave the bottom taps on row h-1 and take the bottom band's operand order
+// ((A-C)-B)+D (iimage.cpp:105-113); div(x,y) = 1/count comes from the table.
+template <int D, int L>
+__device__ __forceinline__ v2f ring_row_general(TapRing<L> &H, int P, v2f vr, v2f vl, int cx0, int cx1, const float *s_lut,
+                                                int yin, int h) {
     constexpr int R = D / 2;
-    float out = 0.f;
-    if (yin >= 0 && yin < h + R) {
-#pragma unroll
-        for (int k = D; k >= 1; k--) { H.a[k] = H.a[k - 1]; H.b[k] = H.b[k - 1]; }
-        if (yin < h) {
-            H.a[0] = H.a[0] + prow[xr];
-            H.b[0] = H.b[0] + prow[xl];
-            float m = mu;
-            if (yin < D) m = s_lut[cx * (yin + 1)];          // box clipped by the top border: div(x,y) = 1/count
-            else if (xclip) m = s_lut[cx * D];
-            out = (((H.a[0] - H.b[0]) - H.a[D]) + H.b[D]) * m;
-        } else {
-            const float m = s_lut[cx * (h - yin + D - 1)];
-            out = (((H.a[0] - H.a[D]) - H.b[0]) + H.b[D]) * m;
+    const int P1 = (P + L - 1) % L, PD = (P + L - D) % L;
+    v2f out = {0.f, 0.f};
+    if (yin >= 0 && yin < h) {
+        H.a[P] = H.a[P1] + vr;
+        H.b[P] = H.b[P1] + vl;
+        const int cy = yin < D ? yin + 1 : D;
+        v2f m; m.x = s_lut[cx0 * cy]; m.y = s_lut[cx1 * cy];
+        out = (((H.a[P] - H.b[P]) - H.a[PD]) + H.b[PD]) * m;
+    } else {
+        H.a[P] = H.a[P1];
+        H.b[P] = H.b[P1];
+        if (yin >= h && yin < h + R) {
+            const int cy = h - yin + D - 1;
+            v2f m; m.x = s_lut[cx0 * cy]; m.y = s_lut[cx1 * cy];
+            out = (((H.a[P] - H.a[PD]) - H.b[P]) + H.b[PD]) * m;
         }
     }
     return out;
 }
 
-// build_mask's plane fit on the 5x5 DoG window (edge_finder.cpp:139-159), from the LDS ring.  rs[k] = ring row of window
-// row k.  Same operation order as k_detect (TooN dot product, k = 0..24).
+// build_mask's plane fit on the 5x5 DoG window (edge_finder.cpp:139-159) from the LDS ring: ro[k] = element offset of
+// window row k, x = column.  Same operation order as k_detect (TooN dot product, k = 0..24).
 struct FitOut { bool cand; float mx, my, xs, ys; };
-__device__ __forceinline__ FitOut plane_fit5(const float *const rs[5], int x, const FusedArgs &a, float thr_d) {
+__device__ __forceinline__ FitOut plane_fit5(const float *s_dog, const int ro[5], int x, const FusedArgs &a, float thr_d) {
     double t0 = 0, t1 = 0, t2 = 0;
 #pragma unroll
     for (int i = 0; i < 5; i++) {
+        float v[5];                                     // one window row at a time: 25 values in flight cost too many registers
+#pragma unroll
+        for (int j = 0; j < 5; j++) v[j] = s_dog[ro[i] + x + j - 2];
 #pragma unroll
         for (int j = 0; j < 5; j++) {
-            const double yv = (double)rs[i][x + j - 2];
+            const double yv = (double)v[j];
             t0 += a.pc0[j] * yv;
             t1 += a.pc1[i] * yv;
             t2 += a.pc2 * yv;
         }
+        __builtin_amdgcn_sched_barrier(0);
     }
     FitOut o;
     o.cand = false;
@@ -115,14 +132,20 @@ __device__ __forceinline__ FitOut plane_fit5(const float *const rs[5], int x, co
     return o;
 }
 
-template <int RB, int MC, int D1, int D2A, int D2B, int D3A, int D3B>
+// W = image width known at compile time (LDS offsets become instruction immediates), 0 = taken from the arguments.
+// DBG = also write the img0 / img1 / DoG / dx / dy planes (debug_planes contexts: tests).
+template <int W, bool DBG, int RB, int D1, int D2A, int D2B, int D3A, int D3B>
 __global__ __launch_bounds__(512) void k_stage_a_fused(FusedArgs a) {
     constexpr int R1 = D1 / 2, R2A = D2A / 2, R2B = D2B / 2, R3A = D3A / 2, R3B = D3B / 2;
     constexpr int LB = R1 + R2B + R3B;                  // rows img1 trails the input by
     static_assert(R1 + R2A + R3A + 1 == LB, "img0 must lead img1 by exactly one row (it is held for one step)");
     constexpr int RING = 2 * RB + 4;                    // DoG rows in LDS: RB being written + RB + 4 being read
-    constexpr int S = RB * MC;                          // (row, column group) segments a wave tests per tick
     constexpr int PAD = kFusedPad;
+    // ring lengths: the smallest divisor of 2 RB that holds D + 1 rows
+    constexpr int L1 = D1 + 1 <= RB ? RB : 2 * RB, L2A = D2A + 1 <= RB ? RB : 2 * RB, L2B = D2B + 1 <= RB ? RB : 2 * RB;
+    constexpr int L3A = D3A + 1 <= RB ? RB : 2 * RB, L3B = D3B + 1 <= RB ? RB : 2 * RB;
+    static_assert(D1 + 1 <= L1 && D2A + 1 <= L2A && D2B + 1 <= L2B && D3A + 1 <= L3A && D3B + 1 <= L3B, "box wider than two ticks");
+    static_assert(R1 <= 3 && R2A <= 3 && R2B <= 3 && R3A <= 3 && R3B <= 3, "taps must stay inside the row pads");
 #ifdef EDGEHIP_EXPERIMENTS   // make EXPERIMENTS=1: phase ablation for timing experiments (wrong results by design)
     const int ABL = a.ablate;
 #else
@@ -130,73 +153,100 @@ __global__ __launch_bounds__(512) void k_stage_a_fused(FusedArgs a) {
 #endif
 
     extern __shared__ __attribute__((aligned(16))) float smem[];
-    const int w = a.w, h = a.h;
+    const int w = W ? W : a.w, h = a.h;
     const int WP = fused_row_stride(w);
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
-    const int NW = (blockDim.x >> 6) - 1;               // column waves
-    const int NC = NW * 64;
-    const int G = MC * NW;                              // column groups of 64 per row
+    const int NW = (blockDim.x >> 6) - 1;               // column waves (128 columns each)
     const int seq = blockIdx.x;
     const size_t so = (size_t)seq * a.n;
 
     float *s_set = smem;                                            // [2][4][RB][WP]
     float *s_dog = s_set + (size_t)2 * 4 * RB * WP;                 // [RING][WP]
     float *s_lut = s_dog + (size_t)RING * WP + 32;                  // [kDivLutMax]   (+32: read overrun of the last scanned row)
-    float *s_edge = s_lut + kDivLutMax;                             // [RB][G][2] img0 at the first / last lane of every group
-    int *s_cnt = reinterpret_cast<int *>(s_edge + (size_t)RB * G * 2);   // [RB*G] final candidates per segment, raster order
-    float *s_red = reinterpret_cast<float *>(s_cnt + RB * G);       // [2][NW] n_m extremes, then the frame's candidate count
-    uint16_t *s_list = reinterpret_cast<uint16_t *>(s_red + 2 * NW + 2);     // [NW][S*64] per-wave candidate lists
-    uint16_t *s_res = s_list + (size_t)NW * S * 64;                 // [NW][S*64] id + 1 of the KeyLine at a tested pixel, 0 = none
+    float *s_edge = s_lut + kDivLutMax;                             // [RB][NW][2] img0 at the first / last column of every wave
+    int *s_sedge = reinterpret_cast<int *>(s_edge + (size_t)RB * NW * 2);   // [RB][NW][2] DoG sign bits of the first / last column pair of every wave
+    int *s_cnt = s_sedge + RB * NW * 2;                              // [RB*NW] final candidates per (row, wave), raster order
+    float *s_red = reinterpret_cast<float *>(s_cnt + RB * NW);      // [2][NW] n_m extremes, then the frame's candidate count
+    uint16_t *s_list = reinterpret_cast<uint16_t *>(s_red + 2 * NW + 2);     // [NW][RB*128] per-wave candidate lists
+    uint16_t *s_res = s_list + (size_t)NW * RB * 128;               // [NW][RB*128] id + 1 of the KeyLine at a tested pixel, 0 = none
+    float4 *s_fin = reinterpret_cast<float4 *>(s_res + (size_t)NW * RB * 128);   // [NW][64] plane-fit results of a wave's first 64 finals
 
     // ---- set-up -------------------------------------------------------------------------------------------------------
     for (int i = tid; i < 2 * 4 * RB * PAD; i += blockDim.x) s_set[(size_t)(i / PAD) * WP + (i % PAD)] = 0.f;   // left pads: taps left of column 0
     for (int i = tid; i < kDivLutMax; i += blockDim.x) s_lut[i] = a.lut[i];
-    for (int i = tid; i < NW * S * 64; i += blockDim.x) s_res[i] = 0;
-    for (int i = tid; i < RB * G; i += blockDim.x) s_cnt[i] = 0;
+    for (int i = tid; i < NW * RB * 128; i += blockDim.x) s_res[i] = 0;
+    for (int i = tid; i < RB * NW; i += blockDim.x) s_cnt[i] = 0;
     for (int i = tid; i < 256; i += blockDim.x) a.histo[(size_t)seq * 256 + i] = 0;   // reEstimateThresh's histogram (k_join_histo fills it)
     SeqA *sq = a.seq + seq;
-    const double tresh = update_thresh(sq->tresh, sq->l_kl_num, a.kl_ref, a.gain, a.tmax, a.tmin);
-    const float grad_thresh = (float)tresh;                         // build_mask takes float grad_thesh
-    const float gt1 = grad_thresh * 765;                            // grad_thesh*max_img_value
-    const float thr_g = gt1 * gt1;
-    const float gt2 = gt1 * a.dog_thresh_f;
-    const float thr_d = gt2 * gt2;
+    // wave-uniform floats are computed by the vector ALU and would sit in (scarce) vector registers: readfirstlane moves them
+    // to scalar registers
+    auto uni = [](float v) { return __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(v))); };
+    float thr_g, thr_d;
+    {
+        const double tresh = update_thresh(sq->tresh, sq->l_kl_num, a.kl_ref, a.gain, a.tmax, a.tmin);
+        const float grad_thresh = (float)tresh;                     // build_mask takes float grad_thesh
+        const float gt1 = grad_thresh * 765;                        // grad_thesh*max_img_value
+        const float gt2 = gt1 * a.dog_thresh_f;
+        thr_g = uni(gt1 * gt1);
+        thr_d = uni(gt2 * gt2);
+    }
     __syncthreads();
 
     // number of ticks: the tests of tick t cover rows (t-6)*RB - LB - 2 + [0, RB), their KeyLines are emitted in tick t+1
     const int t_last = 6 + (h - 1 + LB + 2) / RB;                   // tick that tests row h-1
-    const int nticks = t_last + 2;
+    const int nticks = (t_last + 2 + 1) & ~1;                       // the tick loop is unrolled by two
 
-    if (wave == 0) {
-        // ---- the scan wave: lane l row-scans row l of the buffer set (plane-major, RB rows per plane) -------------------
+    // The scan wave is wave 3 when there are that many: waves go to the four SIMDs of a CU round-robin, so with up to 7 waves it
+    // has SIMD 3 to itself and its add chain (one dependent VALU instruction after the other, at raised priority) does not
+    // starve a column wave, which every other wave would then wait for at the barriers.
+    const int scan_wave = NW >= 3 ? 3 : NW;
+    if (wave == scan_wave) {
+        // ---- the scan wave: lane l row-scans row l of the buffer set (plane-major, RB rows per plane): the serial
+        // left-to-right prefix of iimage::load (iimage.cpp:56-61), 16 floats per step with the next step's LDS reads in
+        // flight under the add chain; then the row's last value goes into the right pad (taps right of column w-1).
         __builtin_amdgcn_s_setprio(3);
         const int n16 = w >> 4;                 // 16-float steps
         const int half16 = n16 >> 1;
+        const bool on = lane < 4 * RB && !(ABL & 1);
         for (int t = 0; t < nticks; t++) {
-            float *row = s_set + ((size_t)((t + 1) & 1) * 4 * RB + lane) * WP + PAD;
+            float *row = s_set + ((size_t)((t + 1) & 1) * 4 * RB + (lane < 4 * RB ? lane : 0)) * WP + PAD;
             float acc = 0.f;
-            const bool on = lane < 4 * RB;
-            auto steps16 = [&](int c0, int c1) {
-                if (!on || (ABL & 1)) return;
-                for (int c = c0; c < c1; c++) {
-                    float4 v[4];
+            float4 cur[4], nxt[4];
+            if (on) {
 #pragma unroll
-                    for (int i = 0; i < 4; i++) v[i] = *reinterpret_cast<float4 *>(row + c * 16 + 4 * i);
+                for (int i = 0; i < 4; i++) cur[i] = *reinterpret_cast<float4 *>(row + 4 * i);
+            }
+            // one 16-float step: issue the LDS reads of the step after it, then the add chain, then the stores
+            auto step = [&](float4 (&cu)[4], float4 (&nx)[4], int c) __attribute__((always_inline)) {
 #pragma unroll
-                    for (int i = 0; i < 4; i++) {   // img(x,y) = img(x-1,y) + l(x,y), iimage.cpp:58-60
-                        v[i].x = acc = acc + v[i].x;
-                        v[i].y = acc = acc + v[i].y;
-                        v[i].z = acc = acc + v[i].z;
-                        v[i].w = acc = acc + v[i].w;
-                    }
+                for (int i = 0; i < 4; i++) nx[i] = *reinterpret_cast<float4 *>(row + (c + 1) * 16 + 4 * i);   // overrun: pad / next row
 #pragma unroll
-                    for (int i = 0; i < 4; i++) *reinterpret_cast<float4 *>(row + c * 16 + 4 * i) = v[i];
+                for (int i = 0; i < 4; i++) {   // img(x,y) = img(x-1,y) + l(x,y)
+                    cu[i].x = acc = acc + cu[i].x;
+                    cu[i].y = acc = acc + cu[i].y;
+                    cu[i].z = acc = acc + cu[i].z;
+                    cu[i].w = acc = acc + cu[i].w;
+                }
+#pragma unroll
+                for (int i = 0; i < 4; i++) *reinterpret_cast<float4 *>(row + c * 16 + 4 * i) = cu[i];
+            };
+            auto steps16 = [&](int c0, int c1) __attribute__((always_inline)) {   // c1 - c0 even or odd: ends with the data in `cur`
+                if (!on) return;
+                int c = c0;
+                for (; c + 1 < c1; c += 2) {
+                    step(cur, nxt, c);
+                    step(nxt, cur, c + 1);
+                }
+                if (c < c1) {
+                    step(cur, nxt, c);
+#pragma unroll
+                    for (int i = 0; i < 4; i++) cur[i] = nxt[i];
                 }
             };
             steps16(0, half16);
             lds_barrier();
             steps16(half16, n16);
-            if (on && !(ABL & 1)) {
+            if (on) {
                 for (int c = n16 * 16; c < w; c += 4) {   // w % 16 != 0: up to three float4 steps
                     float4 v = *reinterpret_cast<float4 *>(row + c);
                     v.x = acc = acc + v.x;
@@ -205,51 +255,71 @@ __global__ __launch_bounds__(512) void k_stage_a_fused(FusedArgs a) {
                     v.w = acc = acc + v.w;
                     *reinterpret_cast<float4 *>(row + c) = v;
                 }
+                *reinterpret_cast<float4 *>(row + w) = make_float4(acc, acc, acc, acc);
             }
             lds_barrier();
         }
     } else {
     // ---- column waves ---------------------------------------------------------------------------------------------------
-    const int wv = wave - 1;                    // 0..NW-1
-    const int ct = tid - 64;
-    int xc[MC];                                 // owned columns
-    bool act[MC];
-#pragma unroll
-    for (int m = 0; m < MC; m++) { xc[m] = ct + m * NC; act[m] = xc[m] < w; }
-    auto XR = [&](int x, int r) { const int v = x + r; return v < w - 1 ? v : w - 1; };
-    auto XL = [&](int x, int r) { const int v = x - r - 1; return v < w - 1 ? v : w - 1; };      // >= -PAD: the zero pad
-    auto CX = [&](int x, int r) { const int l = x - r - 1; return XR(x, r) - (l > -1 ? l : -1); };   // box width along x
-    // div(x,y) of rows with the full box height: (float)(1.0/(d*d)) except in the few columns whose box is clipped in x
-    const float mu1 = s_lut[D1 * D1], mu2a = s_lut[D2A * D2A], mu2b = s_lut[D2B * D2B], mu3a = s_lut[D3A * D3A], mu3b = s_lut[D3B * D3B];
+    const int wv = wave < scan_wave ? wave : wave - 1;   // 0..NW-1
+    const int x0 = 2 * (wv * 64 + lane);        // owned columns x0, x0 + 1
+    const bool act = x0 < w;                    // w % 4 == 0: both or neither
+    const int xr0 = act ? x0 : w - 2;           // address column of inactive threads
+    auto CX = [&](int x, int r) { const int rr = x + r < w - 1 ? x + r : w - 1; const int l = x - r - 1; return rr - (l > -1 ? l : -1); };   // box width along x
+    // div(x,y) of rows with the full box height: (float)(1.0/(d*d)), except in the few columns at the left and right image border
+    // whose box is clipped in x; the waves that own such columns (wave-uniform) read it from the table per row.
+    const float mu1 = uni(s_lut[D1 * D1]), mu2a = uni(s_lut[D2A * D2A]), mu2b = uni(s_lut[D2B * D2B]), mu3a = uni(s_lut[D3A * D3A]), mu3b = uni(s_lut[D3B * D3B]);
     constexpr int RMAX = R3B > R2B ? (R3B > R1 ? R3B : R1) : (R2B > R1 ? R2B : R1);
-    bool xclip[MC];                             // some box of this column is clipped by the left or right image border
-    TapHist<D1> H1[MC];
-    TapHist<D2A> H2A[MC];
-    TapHist<D2B> H2B[MC];
-    TapHist<D3A> H3A[MC];
-    TapHist<D3B> H3B[MC];
-    float iv[MC][RB + 2];                       // img0 of the last RB + 2 rows (own column): iv[k] = img0(row of step k-2 + 1)
-    uint32_t gbits[MC];                         // gradient-gate results of the last rows, newest in bit 0
+    const bool wave_clip = wv * 128 - RMAX - 1 < 0 || wv * 128 + 127 + RMAX > w - 1;
+    // box widths along x of the owned columns for r = 1, 2, 3 (3 bits each; column x0 in bits 0-8, x0+1 in bits 9-17)
+    uint32_t cxpack = 0;
 #pragma unroll
-    for (int m = 0; m < MC; m++) {
-        xclip[m] = xc[m] - RMAX - 1 < 0 || xc[m] + RMAX > w - 1;
+    for (int r = 1; r <= 3; r++) cxpack |= ((uint32_t)CX(xr0, r) << (3 * (r - 1))) | ((uint32_t)CX(xr0 + 1, r) << (9 + 3 * (r - 1)));
+    auto MROW = [&](int r, int d, float mu) __attribute__((always_inline)) {   // div(x,y) of the two owned columns, full box height d
+        v2f m = {mu, mu};
+        if (wave_clip) {
+            m.x = s_lut[((cxpack >> (3 * (r - 1))) & 7u) * d];
+            m.y = s_lut[((cxpack >> (9 + 3 * (r - 1))) & 7u) * d];
+        }
+        return m;
+    };
+    TapRing<L1> H1;
+    TapRing<L2A> H2A;
+    TapRing<L2B> H2B;
+    TapRing<L3A> H3A;
+    TapRing<L3B> H3B;
+    const v2f zero2 = {0.f, 0.f};
 #pragma unroll
-        for (int k = 0; k <= D1; k++) H1[m].a[k] = H1[m].b[k] = 0.f;
+    for (int k = 0; k < L1; k++) H1.a[k] = H1.b[k] = zero2;
 #pragma unroll
-        for (int k = 0; k <= D2A; k++) H2A[m].a[k] = H2A[m].b[k] = 0.f;
+    for (int k = 0; k < L2A; k++) H2A.a[k] = H2A.b[k] = zero2;
 #pragma unroll
-        for (int k = 0; k <= D2B; k++) H2B[m].a[k] = H2B[m].b[k] = 0.f;
+    for (int k = 0; k < L2B; k++) H2B.a[k] = H2B.b[k] = zero2;
 #pragma unroll
-        for (int k = 0; k <= D3A; k++) H3A[m].a[k] = H3A[m].b[k] = 0.f;
+    for (int k = 0; k < L3A; k++) H3A.a[k] = H3A.b[k] = zero2;
 #pragma unroll
-        for (int k = 0; k <= D3B; k++) H3B[m].a[k] = H3B[m].b[k] = 0.f;
+    for (int k = 0; k < L3B; k++) H3B.a[k] = H3B.b[k] = zero2;
+    v2f iv[RB + 2];                             // img0 of the last RB + 2 rows: iv[k] = img0(DoG row of step k - 1)
 #pragma unroll
-        for (int k = 0; k < RB + 2; k++) iv[m][k] = 0.f;
-        gbits[m] = 0;
+    for (int k = 0; k < RB + 2; k++) iv[k] = zero2;
+    uint32_t gbits0 = 0, gbits1 = 0;            // gradient-gate results of the last rows, newest in bit 0, per owned column
+    // DoG sign balance (edge_finder.cpp:125-137), incrementally: per owned column the number of positive DoG values in the
+    // 5-wide strip of each of the last five rows (3 bits each, newest lowest) and their sum = positives in the 5x5 window
+    // of the row two above the newest; bbits = the test's outcome, newest in bit 0
+    uint32_t hh0 = 0, hh1 = 0, ws0 = 0, ws1 = 0, bbits0 = 0, bbits1 = 0;
+    // pn = 2 npos - 25 passes unless (double)|pn| > pn_thresh: the admissible npos range
+    int np_lo = 26, np_hi = -1;
+    for (int np = 0; np <= 25; np++) {
+        const int pn = 2 * np - 25, apn = pn < 0 ? -pn : pn;
+        if (!((double)apn > a.pn_thresh)) { np_lo = np < np_lo ? np : np_lo; np_hi = np; }
     }
+    np_lo = __builtin_amdgcn_readfirstlane(np_lo);
+    np_hi = __builtin_amdgcn_readfirstlane(np_hi);
     const uint8_t *frame = a.rgb + (size_t)(a.fidx ? a.fidx[seq] : seq) * a.n * 3;
-    uint16_t *my_list = s_list + (size_t)wv * S * 64;
-    uint16_t *my_res = s_res + (size_t)wv * S * 64;
+
+    uint16_t *my_list = s_list + (size_t)wv * RB * 128;
+    uint16_t *my_res = s_res + (size_t)wv * RB * 128;
+    float4 *my_fin = s_fin + (size_t)wv * 64;
     int nfinal = 0;                             // final candidates of the previous tick in my_list
     int total = 0;                              // KeyLine candidates of the frame so far (workgroup-uniform)
     int rq0 = 0;                                // ring slot of this tick's first DoG row
@@ -257,29 +327,35 @@ __global__ __launch_bounds__(512) void k_stage_a_fused(FusedArgs a) {
     float nm_mx = 0.f, nm_mn = __int_as_float(0x7f800000);
     int32_t *mask = a.mask + so;
     const KlSoA &kl = a.kl[seq];
-    float *pl = a.planes ? a.planes + so : nullptr;
+    float *pl = DBG && a.planes ? a.planes + so : nullptr;
     const size_t pstride = (size_t)a.nseq * a.n;
+    // number of set bits of a wave mask below this lane (v_mbcnt: no lane-mask register to keep)
+    auto below = [&](unsigned long long m) __attribute__((always_inline)) {
+        return (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
+    };
 
-    // ring rows of the 5x5 window of test row i (rows y_i-2 .. y_i+2), for the tick whose first DoG row sits in slot rq
-    auto window_rows = [&](int rq, int i, const float *rs[5]) {
+    // element offsets (from s_dog) of the 5x5 window rows y_i-2 .. y_i+2 of test row i, for the tick whose first DoG row
+    // sits in ring slot rq
+    auto window_rows = [&](int rq, int i, int ro[5]) {
         int s0 = rq + i - 4;                    // slot of y_i - 2 = (last DoG row of the tick) - (RB - 1 - i) - 4
         s0 += s0 < 0 ? RING : 0;
 #pragma unroll
         for (int k = 0; k < 5; k++) {
             int sk = s0 + k;
             sk -= sk >= RING ? RING : 0;
-            rs[k] = s_dog + (size_t)sk * WP + PAD;
+            ro[k] = sk * WP + PAD;
         }
     };
 
-    for (int t = 0; t < nticks; t++) {
-        const int set = t & 1;
+    auto tick = [&](const int t, auto tt_tag) __attribute__((always_inline)) {
+        constexpr int TT = decltype(tt_tag)::value;     // t & 1: the buffer set, and the half of the long tap rings this tick writes
+        constexpr int set = TT;
         // ================= phase 1a: KeyLines of the rows tested in tick t-1, and those rows of img_mask_kl ==============
         {
             const int ytest0 = (t - 7) * RB - LB - 2;           // first row tested in tick t-1
             if (ytest0 + RB - 1 >= 0 && ytest0 < h && !(ABL & 8)) {
-                // exclusive scan of the segment counts in raster order (row-major, then column group)
-                const int nseg = RB * G;                        // <= 64 (checked on the host)
+                // exclusive scan of the (row, wave) segment counts in raster order
+                const int nseg = RB * NW;                       // <= 64 (checked on the host)
                 const int c = lane < nseg ? s_cnt[lane] : 0;
                 int incl = c;
 #pragma unroll
@@ -288,28 +364,29 @@ __global__ __launch_bounds__(512) void k_stage_a_fused(FusedArgs a) {
                     if (lane >= o) incl += v;
                 }
                 const int excl = incl - c;
-                const int tick_total = __shfl(incl, 63, 64);
+                const int tick_total = __builtin_amdgcn_readlane(incl, 63);
+                int myc[RB];                                    // this wave's counts per row
+#pragma unroll
+                for (int i = 0; i < RB; i++) myc[i] = __shfl(c, i * NW + wv, 64);
                 for (int base = 0; base < nfinal; base += 64) {
                     const int e = base + lane;
                     const bool on = e < nfinal;
                     const int code = on ? my_list[e] : 0;
-                    const int s = code >> 6, i = s / MC, m = s - i * MC, ln = code & 63;
-                    const int ridx = i * G + m * NW + wv;
-                    const int off = __shfl(excl, ridx, 64);
-                    // rank inside the segment: the list is segment-ordered, so e minus the entries of the wave's earlier segments
+                    const int i = code >> 7, xin = code & 127;
+                    const int off = __shfl(excl, i * NW + wv, 64);
+                    // rank inside the segment: the list is segment-ordered, so e minus the entries of the wave's earlier rows
                     int before = 0;
 #pragma unroll
-                    for (int s2 = 0; s2 < S; s2++) {
-                        const int i2 = s2 / MC, m2 = s2 - i2 * MC;
-                        const int c2 = __shfl(c, i2 * G + m2 * NW + wv, 64);
-                        before += s2 < s ? c2 : 0;
-                    }
+                    for (int i2 = 0; i2 < RB; i2++) before += i2 < i ? myc[i2] : 0;
                     const int id = total + off + (e - before);
                     if (on && id < a.kl_max) {
-                        const float *rs[5];
-                        window_rows(rq_prev, i, rs);
-                        const int x = ln + m * NC + wv * 64, y = ytest0 + i;
-                        const FitOut f = plane_fit5(rs, x, a, thr_d);
+                        int ro[5];
+                        window_rows(rq_prev, i, ro);
+                        const int x = wv * 128 + xin, y = ytest0 + i;
+                        // the plane fit of the wave's first 64 finals was kept in LDS; later ones (rare) are fitted again
+                        FitOut f;
+                        if (base == 0) { const float4 q = my_fin[lane]; f.mx = q.x; f.my = q.y; f.xs = q.z; f.ys = q.w; }
+                        else f = plane_fit5(s_dog, ro, x, a, thr_d);
                         // KeyLine `id` (edge_finder.cpp:166-200)
                         const int p = y * w + x;
                         const float n2m = f.mx * f.mx + f.my * f.my;
@@ -325,21 +402,7 @@ __global__ __launch_bounds__(512) void k_stage_a_fused(FusedArgs a) {
                         kl.c_p[id] = cp;
                         kl.p_m[id] = pm;
                         kl.p_m_0[id] = pm;
-                        kl.rho[id] = 1.0;        // RhoInit
-                        kl.s_rho[id] = 20.0;     // RHO_MAX
-                        kl.rho0[id] = 1.0;
-                        kl.s_rho0[id] = 20.0;
-                        kl.rho_nr[id] = 1.0;
-                        kl.s_rho_nr[id] = 20.0;
-                        kl.m_num[id] = 0;
-                        kl.n_id[id] = -1;
-                        kl.p_id[id] = -1;
-                        kl.m_id[id] = -1;
-                        if (kl.stereo_m_id) { kl.stereo_m_id[id] = -1; kl.stereo_rho[id] = 1.0; kl.stereo_s_rho[id] = 20.0; }
-                        kl.m_id_f[id] = -1;
-                        kl.m_id_kf[id] = -1;
-                        kl.m_m0[id] = make_float2(0.f, 0.f);
-                        kl.n_m0[id] = 0.0;
+                        kl.p_id[id] = -1;        // the other constant fields of a new KeyLine: k_join_histo<true>
                         MatchRec rec;
                         rec.c_px = cp.x; rec.c_py = cp.y; rec.u_mx = u.x; rec.u_my = u.y;
                         rec.m_mx = mm.x; rec.m_my = mm.y; rec.n_m = nm; rec.pad = 0.f;
@@ -347,7 +410,7 @@ __global__ __launch_bounds__(512) void k_stage_a_fused(FusedArgs a) {
                         kl.grec[id] = make_float4(cp.x, cp.y, mm.x, mm.y);
                         nm_mx = fmaxf(nm_mx, nm);
                         nm_mn = fminf(nm_mn, nm);
-                        my_res[s * 64 + ln] = (uint16_t)(id + 1);
+                        my_res[i * 128 + xin] = (uint16_t)(id + 1);
                     }
                 }
                 total += tick_total;
@@ -355,93 +418,98 @@ __global__ __launch_bounds__(512) void k_stage_a_fused(FusedArgs a) {
 #pragma unroll
                 for (int i = 0; i < RB; i++) {
                     const int y = ytest0 + i;
-#pragma unroll
-                    for (int m = 0; m < MC; m++) {
-                        const int r = my_res[(i * MC + m) * 64 + lane];
-                        my_res[(i * MC + m) * 64 + lane] = 0;
-                        if (y >= 0 && y < h && act[m]) mask[(size_t)y * w + xc[m]] = r - 1;
-                    }
+                    uint32_t *rp = reinterpret_cast<uint32_t *>(my_res + i * 128) + lane;
+                    const uint32_t r2 = *rp;
+                    *rp = 0;
+                    if (y >= 0 && y < h && act)
+                        *reinterpret_cast<int2 *>(mask + (uint32_t)(y * w + x0)) = make_int2((int)(r2 & 0xFFFFu) - 1, (int)(r2 >> 16) - 1);
                 }
             }
         }
         // ================= phase 1b: the box chain on the scanned rows of buffer set `set` ==================================
-        float l1[MC][RB], l2a[MC][RB], l2b[MC][RB];
-        const float *P0 = s_set + ((size_t)(set * 4 + 0) * RB) * WP + PAD;
-        const float *P1 = s_set + ((size_t)(set * 4 + 1) * RB) * WP + PAD;
-        const float *P2A = s_set + ((size_t)(set * 4 + 2) * RB) * WP + PAD;
-        const float *P2B = s_set + ((size_t)(set * 4 + 3) * RB) * WP + PAD;
+        v2f l1[RB], l2a[RB], l2b[RB];
+        uint32_t ppack = 0;                             // DoG > 0 of the tick's rows at the owned columns, 2 bits per row
+        const float *P0 = s_set + ((size_t)(set * 4 + 0) * RB) * WP + PAD + xr0;
+        const float *P1 = s_set + ((size_t)(set * 4 + 1) * RB) * WP + PAD + xr0;
+        const float *P2A = s_set + ((size_t)(set * 4 + 2) * RB) * WP + PAD + xr0;
+        const float *P2B = s_set + ((size_t)(set * 4 + 3) * RB) * WP + PAD + xr0;
         const int y1in0 = (t - 2) * RB;                 // level 1 input row (image row) of slot 0
         const int y2in0 = (t - 4) * RB - R1;            // level 2 input row (level-1 row) of slot 0
         const int y3ain0 = (t - 6) * RB - R1 - R2A;     // level 3 input rows
         const int y3bin0 = (t - 6) * RB - R1 - R2B;
         const int ydog0 = (t - 6) * RB - LB;            // DoG / img1 row of slot 0 (img0 row is one below)
+        // steady ticks: every row of every level is an image row with its full box height
+        const bool steady = y3bin0 >= D3B && y3ain0 >= D3A && y1in0 + RB - 1 <= h - 1;
 #pragma unroll
         for (int j = 0; j < RB; j++) {
-            if (ABL & 2) { for (int m = 0; m < MC; m++) l1[m][j] = l2a[m][j] = l2b[m][j] = 0.f; continue; }
+            if (ABL & 2) { l1[j] = l2a[j] = l2b[j] = zero2; continue; }
+            constexpr int dummy = 0; (void)dummy;
+            const int q = TT * RB + j;                  // row of the unrolled tick pair: ring positions
             const int slot = rq0 + j >= RING ? rq0 + j - RING : rq0 + j;
-            float *dogrow = s_dog + (size_t)slot * WP + PAD;
-#pragma unroll
-            for (int m = 0; m < MC; m++) {
-                const int x = act[m] ? xc[m] : w - 1;
-                // ---- level 3: img0 = G(sigma0) of row ydog+1, img1 = G(sigma1) of row ydog ----
-                const float i0n = level_row<D3A>(H3A[m], P2A + j * WP, XR(x, R3A), XL(x, R3A), CX(x, R3A), xclip[m], mu3a, s_lut, y3ain0 + j, h);
-                const float i1 = level_row<D3B>(H3B[m], P2B + j * WP, XR(x, R3B), XL(x, R3B), CX(x, R3B), xclip[m], mu3b, s_lut, y3bin0 + j, h);
-                {
-                    const int yd = ydog0 + j;                   // DoG row; iv[j+1] = img0 of that row
-                    const float dg = i1 - iv[m][j + 1];         // sspace.cpp:66
-                    if (act[m]) dogrow[x] = dg;
-                    iv[m][j + 2] = i0n;
-                    if (pl && act[m]) {
-                        if (yd >= 0 && yd < h) {
-                            pl[1 * pstride + (size_t)yd * w + x] = i1;
-                            pl[2 * pstride + (size_t)yd * w + x] = dg;
-                        }
-                        if (yd + 1 >= 0 && yd + 1 < h) pl[0 * pstride + (size_t)(yd + 1) * w + x] = i0n;
+            // the row's ten tap pairs (unconditional: rows that do not exist read garbage that is never used)
+            const v2f t3a_r = ld2(P2A + j * WP + R3A), t3a_l = ld2(P2A + j * WP - R3A - 1);
+            const v2f t3b_r = ld2(P2B + j * WP + R3B), t3b_l = ld2(P2B + j * WP - R3B - 1);
+            const v2f t2a_r = ld2(P1 + j * WP + R2A), t2a_l = ld2(P1 + j * WP - R2A - 1);
+            const v2f t2b_r = ld2(P1 + j * WP + R2B), t2b_l = ld2(P1 + j * WP - R2B - 1);
+            const v2f t1_r = ld2(P0 + j * WP + R1), t1_l = ld2(P0 + j * WP - R1 - 1);
+            v2f i0n, i1;
+            if (steady) {
+                i0n = ring_row_steady<D3A, L3A>(H3A, q % L3A, t3a_r, t3a_l, MROW(R3A, D3A, mu3a));   // img0 = G(sigma0) of row ydog+1
+                i1 = ring_row_steady<D3B, L3B>(H3B, q % L3B, t3b_r, t3b_l, MROW(R3B, D3B, mu3b));    // img1 = G(sigma1) of row ydog
+                l2a[j] = ring_row_steady<D2A, L2A>(H2A, q % L2A, t2a_r, t2a_l, MROW(R2A, D2A, mu2a));   // the two filters part ways at level 2
+                l2b[j] = ring_row_steady<D2B, L2B>(H2B, q % L2B, t2b_r, t2b_l, MROW(R2B, D2B, mu2b));
+                l1[j] = ring_row_steady<D1, L1>(H1, q % L1, t1_r, t1_l, MROW(R1, D1, mu1));          // level 1 is shared by both filters
+            } else {
+                i0n = ring_row_general<D3A, L3A>(H3A, q % L3A, t3a_r, t3a_l, CX(xr0, R3A), CX(xr0 + 1, R3A), s_lut, y3ain0 + j, h);
+                i1 = ring_row_general<D3B, L3B>(H3B, q % L3B, t3b_r, t3b_l, CX(xr0, R3B), CX(xr0 + 1, R3B), s_lut, y3bin0 + j, h);
+                l2a[j] = ring_row_general<D2A, L2A>(H2A, q % L2A, t2a_r, t2a_l, CX(xr0, R2A), CX(xr0 + 1, R2A), s_lut, y2in0 + j, h);
+                l2b[j] = ring_row_general<D2B, L2B>(H2B, q % L2B, t2b_r, t2b_l, CX(xr0, R2B), CX(xr0 + 1, R2B), s_lut, y2in0 + j, h);
+                l1[j] = ring_row_general<D1, L1>(H1, q % L1, t1_r, t1_l, CX(xr0, R1), CX(xr0 + 1, R1), s_lut, y1in0 + j, h);
+            }
+            {
+                const int yd = ydog0 + j;                   // DoG row; iv[j+1] = img0 of that row
+                const v2f dg = i1 - iv[j + 1];              // sspace.cpp:66
+                if (act) *reinterpret_cast<v2f *>(s_dog + (size_t)slot * WP + PAD + x0) = dg;
+                ppack |= ((act && dg.x > 0 ? 1u : 0u) | (act && dg.y > 0 ? 2u : 0u)) << (2 * j);
+                iv[j + 2] = i0n;
+                if (DBG && pl && act) {
+                    if (yd >= 0 && yd < h) {
+                        *reinterpret_cast<v2f *>(pl + 1 * pstride + (size_t)yd * w + x0) = i1;
+                        *reinterpret_cast<v2f *>(pl + 2 * pstride + (size_t)yd * w + x0) = dg;
                     }
+                    if (yd + 1 >= 0 && yd + 1 < h) *reinterpret_cast<v2f *>(pl + 0 * pstride + (size_t)(yd + 1) * w + x0) = i0n;
                 }
-                // ---- level 2: the two filters part ways (same input, box widths D2A / D2B) ----
-                l2a[m][j] = level_row<D2A>(H2A[m], P1 + j * WP, XR(x, R2A), XL(x, R2A), CX(x, R2A), xclip[m], mu2a, s_lut, y2in0 + j, h);
-                l2b[m][j] = level_row<D2B>(H2B[m], P1 + j * WP, XR(x, R2B), XL(x, R2B), CX(x, R2B), xclip[m], mu2b, s_lut, y2in0 + j, h);
-                // ---- level 1 (shared by both filters) ----
-                l1[m][j] = level_row<D1>(H1[m], P0 + j * WP, XR(x, R1), XL(x, R1), CX(x, R1), xclip[m], mu1, s_lut, y1in0 + j, h);
             }
         }
-        // img0 at the first / last lane of every column group, rows of steps 0..RB-1 (iv[1..RB]): the gate's x-neighbours
+        // img0 at the first / last column of every wave, rows of steps 0..RB-1 (iv[1..RB]): the gate's x-neighbours
         if (lane == 0 || lane == 63) {
 #pragma unroll
-            for (int m = 0; m < MC; m++)
-#pragma unroll
-                for (int j = 0; j < RB; j++) s_edge[((size_t)j * G + m * NW + wv) * 2 + (lane ? 1 : 0)] = iv[m][j + 1];
+            for (int j = 0; j < RB; j++) {
+                s_edge[((size_t)j * NW + wv) * 2 + (lane ? 1 : 0)] = lane ? iv[j + 1].y : iv[j + 1].x;
+                s_sedge[((size_t)j * NW + wv) * 2 + (lane ? 1 : 0)] = (int)((ppack >> (2 * j)) & 3u);
+            }
         }
         lds_barrier();
         // ================= phase 2 ==============================================================================================
         // RGB rows of batch t: the loads fly under the stores and tests below and are used at the end of the phase
-        uint2 pre[MC][RB];                      // the 8 bytes that hold the pixel's 3
+        uint2 pre[RB];                          // the 8 bytes that hold the two pixels' 6
 #pragma unroll
         for (int j = 0; j < RB; j++) {
-            if (ABL & 16) { for (int m = 0; m < MC; m++) pre[m][j] = make_uint2(0, 0); continue; }
+            if (ABL & 16) { pre[j] = make_uint2(0, 0); continue; }
             int y = t * RB + j;
             y = y < h ? y : h - 1;
-#pragma unroll
-            for (int m = 0; m < MC; m++) {
-                const int x = act[m] ? xc[m] : w - 1;
-                const size_t byte0 = ((size_t)y * w + x) * 3;
-                pre[m][j] = *reinterpret_cast<const uint2 *>(frame + (byte0 & ~(size_t)3));
-            }
+            const uint32_t byte0 = (uint32_t)(y * w + xr0) * 3u;     // < 2^31: the frame is w*h*3 bytes
+            pre[j] = *reinterpret_cast<const uint2 *>(frame + (byte0 & ~3u));
         }
-        {
-            float *Q1 = s_set + ((size_t)(set * 4 + 1) * RB) * WP + PAD;
-            float *Q2A = s_set + ((size_t)(set * 4 + 2) * RB) * WP + PAD;
-            float *Q2B = s_set + ((size_t)(set * 4 + 3) * RB) * WP + PAD;
+        if (act) {
+            float *Q1 = s_set + ((size_t)(set * 4 + 1) * RB) * WP + PAD + x0;
+            float *Q2A = s_set + ((size_t)(set * 4 + 2) * RB) * WP + PAD + x0;
+            float *Q2B = s_set + ((size_t)(set * 4 + 3) * RB) * WP + PAD + x0;
 #pragma unroll
-            for (int m = 0; m < MC; m++) {
-                if (!act[m]) continue;
-#pragma unroll
-                for (int j = 0; j < RB; j++) {
-                    Q1[j * WP + xc[m]] = l1[m][j];
-                    Q2A[j * WP + xc[m]] = l2a[m][j];
-                    Q2B[j * WP + xc[m]] = l2b[m][j];
-                }
+            for (int j = 0; j < RB; j++) {
+                *reinterpret_cast<v2f *>(Q1 + j * WP) = l1[j];
+                *reinterpret_cast<v2f *>(Q2A + j * WP) = l2a[j];
+                *reinterpret_cast<v2f *>(Q2B + j * WP) = l2b[j];
             }
         }
         // gradient gate of the rows of steps 0..RB-1 (edge_finder.cpp:117-119, sspace.cpp:80-81)
@@ -449,134 +517,135 @@ __global__ __launch_bounds__(512) void k_stage_a_fused(FusedArgs a) {
         for (int j = 0; j < RB; j++) {
             if (ABL & 32) continue;
             const int y = ydog0 + j;
-#pragma unroll
-            for (int m = 0; m < MC; m++) {
-                const float cv = iv[m][j + 1];
-                float rgt = __shfl_down(cv, 1, 64), lft = __shfl_up(cv, 1, 64);
-                const int g = m * NW + wv;
-                if (lane == 63 && g + 1 < G) rgt = s_edge[((size_t)j * G + g + 1) * 2 + 0];
-                if (lane == 0 && g > 0) lft = s_edge[((size_t)j * G + g - 1) * 2 + 1];
-                const int x = xc[m];
-                const bool valid = y >= 2 && y < h - 2 && x >= 2 && x < w - 2;
-                const float dx = rgt - lft;                      // sspace.cpp:80
-                const float dy = iv[m][j + 2] - iv[m][j];        // sspace.cpp:81
-                if (pl && valid) {
-                    pl[3 * pstride + (size_t)y * w + x] = dx;
-                    pl[4 * pstride + (size_t)y * w + x] = dy;
-                }
-                const float n2g = dx * dx + dy * dy;
-                const bool pass = valid && !(n2g < thr_g);
-                gbits[m] = (gbits[m] << 1) | (pass ? 1u : 0u);
+            const v2f cv = iv[j + 1];                       // img0 of row y at columns x0, x0+1
+            // neighbours in x: lane l-1 / l+1 of the wave (DPP wave shifts), the adjacent wave's edge lane through LDS
+            float lft = __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(cv.y), 0x138, 0xf, 0xf, false));   // wave_shr:1 -> column x0 - 1
+            float rgt = __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(cv.x), 0x130, 0xf, 0xf, false));   // wave_shl:1 -> column x0 + 2
+            const uint32_t pj = (ppack >> (2 * j)) & 3u;    // DoG > 0 at (x0, x0+1) in row y
+            uint32_t pL = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)pj, 0x138, 0xf, 0xf, false);
+            uint32_t pR = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)pj, 0x130, 0xf, 0xf, false);
+            if (lane == 0) {
+                lft = wv > 0 ? s_edge[((size_t)j * NW + wv - 1) * 2 + 1] : 0.f;
+                pL = wv > 0 ? (uint32_t)s_sedge[((size_t)j * NW + wv - 1) * 2 + 1] : 0u;
             }
+            if (lane == 63) {
+                rgt = wv + 1 < NW ? s_edge[((size_t)j * NW + wv + 1) * 2 + 0] : 0.f;
+                pR = wv + 1 < NW ? (uint32_t)s_sedge[((size_t)j * NW + wv + 1) * 2 + 0] : 0u;
+            }
+            {   // positives among columns x-2..x+2 of this row, for x = x0 (pL, pj, low bit of pR) and x0+1 (high bit of pL, pj, pR)
+                const uint32_t he = __popc((pL & 3u) | (pj << 2) | ((pR & 1u) << 4));
+                const uint32_t ho = __popc(((pL >> 1) & 1u) | (pj << 1) | ((pR & 3u) << 3));
+                ws0 = ws0 + he - ((hh0 >> 12) & 7u);        // window sum over the last five rows = npos of row y - 2
+                ws1 = ws1 + ho - ((hh1 >> 12) & 7u);
+                hh0 = ((hh0 << 3) | he) & 0x7FFFu;
+                hh1 = ((hh1 << 3) | ho) & 0x7FFFu;
+                bbits0 = (bbits0 << 1) | (((int)ws0 >= np_lo && (int)ws0 <= np_hi) ? 1u : 0u);
+                bbits1 = (bbits1 << 1) | (((int)ws1 >= np_lo && (int)ws1 <= np_hi) ? 1u : 0u);
+            }
+            const bool yok = y >= 2 && y < h - 2;
+            const bool v0 = yok && x0 >= 2 && x0 < w - 2, v1 = yok && x0 + 1 >= 2 && x0 + 1 < w - 2;
+            const float dx0 = cv.y - lft, dx1 = rgt - cv.x;  // sspace.cpp:80
+            const v2f dy = iv[j + 2] - iv[j];                // sspace.cpp:81
+            if (DBG && pl) {
+                if (v0) { pl[3 * pstride + (size_t)y * w + x0] = dx0; pl[4 * pstride + (size_t)y * w + x0] = dy.x; }
+                if (v1) { pl[3 * pstride + (size_t)y * w + x0 + 1] = dx1; pl[4 * pstride + (size_t)y * w + x0 + 1] = dy.y; }
+            }
+            const float n0 = dx0 * dx0 + dy.x * dy.x, n1 = dx1 * dx1 + dy.y * dy.y;
+            gbits0 = (gbits0 << 1) | ((v0 && !(n0 < thr_g)) ? 1u : 0u);
+            gbits1 = (gbits1 << 1) | ((v1 && !(n1 < thr_g)) ? 1u : 0u);
         }
-#pragma unroll
-        for (int m = 0; m < MC; m++) { iv[m][0] = iv[m][RB]; iv[m][1] = iv[m][RB + 1]; }
-        // build_mask's window tests on rows ydog0 + RB - 1 - 2 - (RB - 1 - i), i = 0..RB-1 (their DoG windows are complete)
+        iv[0] = iv[RB];
+        iv[1] = iv[RB + 1];
+        // build_mask's window tests on rows ydog0 - 2 + i, i = 0..RB-1 (their DoG windows are complete)
         if (!(ABL & 4)) {
             int nlist = 0;
 #pragma unroll
-            for (int i = 0; i < RB; i++)
-#pragma unroll
-                for (int m = 0; m < MC; m++) {
-                    const bool pass = (gbits[m] >> (2 + RB - 1 - i)) & 1u;
-                    const unsigned long long bal = __ballot(pass);
-                    if (pass) my_list[nlist + __popcll(bal & ((1ull << lane) - 1ull))] = (uint16_t)(((i * MC + m) << 6) | lane);
-                    nlist += __popcll(bal);
-                }
-            // DoG sign balance (edge_finder.cpp:125-137): compact in place
-            int nkeep = 0;
-            for (int base = 0; base < nlist; base += 64) {
-                const int li = base + lane;
-                bool keep = false;
-                int code = 0;
-                if (li < nlist) {
-                    code = my_list[li];
-                    const int s = code >> 6, i = s / MC, m = s - i * MC;
-                    const int x = (code & 63) + m * NC + wv * 64;
-                    const float *rs[5];
-                    window_rows(rq0, i, rs);
-                    int npos = 0;
-#pragma unroll
-                    for (int r = 0; r < 5; r++)
-#pragma unroll
-                        for (int q = -2; q <= 2; q++) npos += (rs[r][x + q] > 0) ? 1 : 0;
-                    const int pn = 2 * npos - 25;
-                    const int apn = pn < 0 ? -pn : pn;
-                    keep = !((double)apn > a.pn_thresh);
-                }
-                const unsigned long long bal = __ballot(keep);
-                if (keep) my_list[nkeep + __popcll(bal & ((1ull << lane) - 1ull))] = (uint16_t)code;
-                nkeep += __popcll(bal);
+            for (int i = 0; i < RB; i++) {
+                // gradient gate of row y_i (bit 2 + RB-1-i) and sign balance of its window (complete with the newest row: bit RB-1-i)
+                const bool p0 = (gbits0 >> (2 + RB - 1 - i)) & (bbits0 >> (RB - 1 - i)) & 1u, p1 = (gbits1 >> (2 + RB - 1 - i)) & (bbits1 >> (RB - 1 - i)) & 1u;
+                const unsigned long long b0 = __ballot(p0), b1 = __ballot(p1);
+                const int pos = nlist + below(b0) + below(b1);     // raster order: (lane, column of the pair)
+                if (p0) my_list[pos] = (uint16_t)((i << 7) | (lane << 1));
+                if (p1) my_list[pos + (p0 ? 1 : 0)] = (uint16_t)((i << 7) | (lane << 1) | 1);
+                nlist += __popcll(b0) + __popcll(b1);
             }
-            // plane fit, sub-pixel position, DoG-gradient gate (:139-159): keep the finals, count them per segment
+            const int nkeep = nlist;
+            // plane fit, sub-pixel position, DoG-gradient gate (:139-159): keep the finals, count them per row
             int nfin = 0;
-            int cnt[S];
+            int cnt[RB];
 #pragma unroll
-            for (int s = 0; s < S; s++) cnt[s] = 0;
+            for (int i = 0; i < RB; i++) cnt[i] = 0;
             for (int base = 0; base < nkeep; base += 64) {
                 const int li = base + lane;
                 bool cand = false;
                 int code = 0;
+                float4 fo = make_float4(0.f, 0.f, 0.f, 0.f);
                 if (li < nkeep) {
                     code = my_list[li];
-                    const int s = code >> 6, i = s / MC, m = s - i * MC;
-                    const int x = (code & 63) + m * NC + wv * 64;
-                    const float *rs[5];
-                    window_rows(rq0, i, rs);
-                    cand = plane_fit5(rs, x, a, thr_d).cand;
+                    const int i = code >> 7, x = wv * 128 + (code & 127);
+                    int ro[5];
+                    window_rows(rq0, i, ro);
+                    const FitOut f = plane_fit5(s_dog, ro, x, a, thr_d);
+                    cand = f.cand;
+                    fo = make_float4(f.mx, f.my, f.xs, f.ys);
                 }
                 const unsigned long long bal = __ballot(cand);
-                if (cand) my_list[nfin + __popcll(bal & ((1ull << lane) - 1ull))] = (uint16_t)code;
+                if (cand) {
+                    const int pos = nfin + below(bal);
+                    my_list[pos] = (uint16_t)code;
+                    if (pos < 64) my_fin[pos] = fo;
+                }
                 nfin += __popcll(bal);
 #pragma unroll
-                for (int s = 0; s < S; s++) cnt[s] += __popcll(__ballot(cand && (code >> 6) == s));
+                for (int i = 0; i < RB; i++) cnt[i] += __popcll(__ballot(cand && (code >> 7) == i));
             }
             nfinal = nfin;
             if (lane == 0) {
 #pragma unroll
-                for (int s = 0; s < S; s++) {
-                    const int i = s / MC, m = s - i * MC;
-                    s_cnt[i * G + m * NW + wv] = cnt[s];
-                }
+                for (int i = 0; i < RB; i++) s_cnt[i * NW + wv] = cnt[i];
             }
         }
-        {   // grey of batch t -> plane 0 of the buffer set (b+g+r, image.h:197-203: integers, exact in float)
-            float *Q0 = s_set + ((size_t)(set * 4 + 0) * RB) * WP + PAD;
+        if (act) {   // grey of batch t -> plane 0 of the buffer set (b+g+r, image.h:197-203: integers, exact in float)
+            float *Q0 = s_set + ((size_t)(set * 4 + 0) * RB) * WP + PAD + x0;
 #pragma unroll
             for (int j = 0; j < RB; j++) {
                 int y = t * RB + j;
                 y = y < h ? y : h - 1;
-#pragma unroll
-                for (int m = 0; m < MC; m++) {
-                    const int x = act[m] ? xc[m] : w - 1;
-                    const unsigned sh = (unsigned)((((size_t)y * w + x) * 3) & 3) * 8;
-                    const unsigned long long q8 = ((unsigned long long)pre[m][j].y << 32) | pre[m][j].x;
-                    const unsigned p = (unsigned)(q8 >> sh);
-                    if (act[m]) Q0[j * WP + x] = (float)((int)(p & 0xFF) + (int)((p >> 8) & 0xFF) + (int)((p >> 16) & 0xFF));
-                }
+                const unsigned sh = (((uint32_t)(y * w + x0) * 3u) & 3u) * 8u;   // 0 or 16
+                const unsigned long long q8 = (((unsigned long long)pre[j].y << 32) | pre[j].x) >> sh;
+                const unsigned lo = (unsigned)q8, hi = (unsigned)(q8 >> 24);
+                v2f g;
+                g.x = (float)((int)(lo & 0xFF) + (int)((lo >> 8) & 0xFF) + (int)((lo >> 16) & 0xFF));
+                g.y = (float)((int)(hi & 0xFF) + (int)((hi >> 8) & 0xFF) + (int)((hi >> 16) & 0xFF));
+                *reinterpret_cast<v2f *>(Q0 + j * WP) = g;
             }
         }
         rq_prev = rq0;
         rq0 += RB;
         rq0 -= rq0 >= RING ? RING : 0;
         lds_barrier();
+    };
+    for (int t = 0; t < nticks; t += 2) {
+        tick(t, std::integral_constant<int, 0>{});
+        tick(t + 1, std::integral_constant<int, 1>{});
     }
 
-    // ---- end of frame: kn, the P-controller state (edge_finder.cpp:355-364), reEstimateThresh's extremes (:376-382) ----
+    // ---- end of frame: reEstimateThresh's extremes (edge_finder.cpp:376-382) and the candidate count -----------------------
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) {
         nm_mx = fmaxf(nm_mx, __shfl_xor(nm_mx, o, 64));
         nm_mn = fminf(nm_mn, __shfl_xor(nm_mn, o, 64));
     }
     if (lane == 0) { s_red[wv] = nm_mx; s_red[NW + wv] = nm_mn; }
-    if (tid == 64) s_red[2 * NW] = __int_as_float(total);
+    if (wv == 0 && lane == 0) s_red[2 * NW] = __int_as_float(total);
     }   // column waves
     __syncthreads();
-    if (tid == 64) {
+    if (tid == 0) {   // kn and the P-controller state (edge_finder.cpp:355-364)
         float nm_mx = s_red[0], nm_mn = s_red[NW];
         for (int i = 1; i < NW; i++) { nm_mx = fmaxf(nm_mx, s_red[i]); nm_mn = fminf(nm_mn, s_red[NW + i]); }
         const int total = __float_as_int(s_red[2 * NW]);
         const int kn = total < a.kl_max ? total : a.kl_max;
+        const double tresh = update_thresh(sq->tresh, sq->l_kl_num, a.kl_ref, a.gain, a.tmax, a.tmin);   // as at the top: nothing wrote the state in between
         sq->tresh = tresh;
         sq->tresh_used = tresh;
         a.tresh_out[seq] = tresh;
@@ -589,12 +658,14 @@ __global__ __launch_bounds__(512) void k_stage_a_fused(FusedArgs a) {
 }
 
 // ---- host side ---------------------------------------------------------------------------------------------------------------
-constexpr int kFusedRB = 4, kFusedMC = 2;
+constexpr int kFusedRB = 4;
 
-size_t fused_lds_bytes(int w, int nw) {
-    const int WP = fused_row_stride(w), RB = kFusedRB, MC = kFusedMC, G = MC * nw, S = RB * MC;
-    size_t fl = (size_t)2 * 4 * RB * WP + (size_t)(2 * RB + 4) * WP + 32 + kDivLutMax + (size_t)RB * G * 2 + RB * G + 2 * nw + 2;
-    return fl * 4 + (size_t)2 * nw * S * 64 * 2;
+static int fused_col_waves(int w) { return (w + 127) / 128; }
+
+size_t fused_lds_bytes(int w) {
+    const int nw = fused_col_waves(w), WP = fused_row_stride(w), RB = kFusedRB;
+    const size_t fl = (size_t)2 * 4 * RB * WP + (size_t)(2 * RB + 4) * WP + 32 + kDivLutMax + (size_t)RB * nw * 4 + RB * nw + 2 * nw + 2;
+    return fl * 4 + (size_t)2 * nw * RB * 128 * 2 + (size_t)nw * 64 * 16;
 }
 
 bool fused_supported(const edgehip_ctx *c) {
@@ -603,17 +674,17 @@ bool fused_supported(const edgehip_ctx *c) {
     if (pl.box[1][0] != 3 || pl.box[1][1] != 5 || pl.box[1][2] != 5) return false;
     if (c->und_base) return false;                          // the undistorting source keeps the multi-kernel path
     if (c->p.plane_fit_size != 2) return false;
-    const int nw = (pl.w + 64 * kFusedMC - 1) / (64 * kFusedMC);
+    const int nw = fused_col_waves(pl.w);
     if (nw + 1 > 8) return false;                           // 256 VGPRs per thread need <= 8 waves per workgroup
-    if (kFusedRB * kFusedMC * nw > 64) return false;        // one lane per segment in the id scan
+    if (kFusedRB * nw > 64) return false;                   // one lane per (row, wave) segment in the id scan
     if (pl.cap > 65534) return false;                       // ids travel through LDS as uint16
-    return fused_lds_bytes(pl.w, nw) <= 160 * 1024;
+    return fused_lds_bytes(pl.w) <= 160 * 1024;
 }
 
 int stage_a_fused_enqueue(edgehip_ctx *c, int slot, const uint8_t *rgb_base, const int32_t *rgb_idx) {
     const DevicePlan &pl = c->plan;
     const int B = pl.nseq;
-    const int nw = (pl.w + 64 * kFusedMC - 1) / (64 * kFusedMC);
+    const int nw = fused_col_waves(pl.w);
     FusedArgs a;
     a.rgb = rgb_base; a.fidx = rgb_idx;
     a.lut = c->div_lut;
@@ -639,10 +710,17 @@ int stage_a_fused_enqueue(edgehip_ctx *c, int slot, const uint8_t *rgb_base, con
 #else
     a.ablate = 0;
 #endif
-    const size_t sm = fused_lds_bytes(pl.w, nw);
-    auto fn = k_stage_a_fused<kFusedRB, kFusedMC, 3, 3, 5, 5, 5>;
+    const size_t sm = fused_lds_bytes(pl.w);
+    // the shipped image sizes get their own instantiation (EuRoC 752, TUM 640), any other width — and contexts with debug
+    // planes — the generic one
+    void (*fn)(FusedArgs) = k_stage_a_fused<0, false, kFusedRB, 3, 3, 5, 5, 5>;
+    if (c->planes) fn = k_stage_a_fused<0, true, kFusedRB, 3, 3, 5, 5, 5>;
+    else if (pl.w == 752) fn = k_stage_a_fused<752, false, kFusedRB, 3, 3, 5, 5, 5>;
+    else if (pl.w == 640) fn = k_stage_a_fused<640, false, kFusedRB, 3, 3, 5, 5, 5>;
     if (!c->lds_optin_fused) {
-        EH_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(fn), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        const void *fns[4] = {(const void *)k_stage_a_fused<0, false, kFusedRB, 3, 3, 5, 5, 5>, (const void *)k_stage_a_fused<0, true, kFusedRB, 3, 3, 5, 5, 5>,
+                              (const void *)k_stage_a_fused<752, false, kFusedRB, 3, 3, 5, 5, 5>, (const void *)k_stage_a_fused<640, false, kFusedRB, 3, 3, 5, 5, 5>};
+        for (const void *f : fns) EH_CHECK(hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         c->lds_optin_fused = true;
     }
     {

@@ -38,6 +38,14 @@ def test_fused_planes_mask_keylines_bit_exact(w, h):
     tsa._run(w, h, frames)
 
 
+@pytest.mark.parametrize("w,h", [(752, 480), (640, 480)], ids=["euroc_752", "tum_640"])
+def test_fused_product_instantiations_without_debug_planes(w, h):
+    """The shipped widths have their own instantiation (compile-time LDS offsets, no debug-plane code): mask, kn, KeyLines,
+    threshold state against the reference."""
+    frames = [f for f, _, _ in synth.billboard_sequence(w, h, 4, seed=2)]
+    tsa._run(w, h, frames, check_planes=False)
+
+
 def test_fused_kl_max_truncation():
     frames = list(synth.rects_sequence(320, 240, 2, seed=9))
     tsa._run(320, 240, frames, over=dict(max_points=700, reference_points=600, track_points=600))

@@ -29,7 +29,7 @@ def _bits(a):
 def _run(w, h, frames, over=None, check_planes=True):
     over = over or {}
     orc = _oracle(w, h, **over)
-    eh = edgehip.EdgeHip(edgehip.euroc_params(w, h, debug_planes=1, **over), nseq=1, nslots=3)
+    eh = edgehip.EdgeHip(edgehip.euroc_params(w, h, debug_planes=1 if check_planes else 0, **over), nseq=1, nslots=3)
     tresh, lkl = orc.p.detector_thresh, 0
     for k, f in enumerate(frames):
         slot = k % 3
