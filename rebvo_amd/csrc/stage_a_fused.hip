@@ -146,8 +146,8 @@ __global__ __launch_bounds__(512) void k_stage_a_fused(FusedArgs a) {
     constexpr int L3A = D3A + 1 <= RB ? RB : 2 * RB, L3B = D3B + 1 <= RB ? RB : 2 * RB;
     static_assert(D1 + 1 <= L1 && D2A + 1 <= L2A && D2B + 1 <= L2B && D3A + 1 <= L3A && D3B + 1 <= L3B, "box wider than two ticks");
     static_assert(R1 <= 3 && R2A <= 3 && R2B <= 3 && R3A <= 3 && R3B <= 3, "taps must stay inside the row pads");
-#ifdef EDGEHIP_EXPERIMENTS   // make EXPERIMENTS=1: phase ablation for timing experiments (wrong results by design)
-    const int ABL = a.ablate;
+#ifdef EDGEHIP_FUSED_ABL    // tools/experiments/exp_fused_ablate.sh: phase ablation for timing experiments (wrong results by design)
+    constexpr int ABL = EDGEHIP_FUSED_ABL;
 #else
     constexpr int ABL = 0;
 #endif
@@ -201,36 +201,51 @@ __global__ __launch_bounds__(512) void k_stage_a_fused(FusedArgs a) {
     // starve a column wave, which every other wave would then wait for at the barriers.
     const int scan_wave = NW >= 3 ? 3 : NW;
     if (wave == scan_wave) {
-        // ---- the scan wave: lane l row-scans row l of the buffer set (plane-major, RB rows per plane): the serial
-        // left-to-right prefix of iimage::load (iimage.cpp:56-61), 16 floats per step with the next step's LDS reads in
-        // flight under the add chain; then the row's last value goes into the right pad (taps right of column w-1).
+        // ---- the scan wave: the serial left-to-right prefix of iimage::load (iimage.cpp:56-61) for the 4 RB rows of the buffer
+        // set (plane-major, RB rows per plane), in place.  An LDS instruction costs the wave ~16 cycles of register-file time
+        // whatever the number of active lanes, a dependent add ~7 (tools/experiments/ubench_scan.hip), so all 64 lanes carry
+        // data: the four lanes of a quad share a row, lane q of the quad holds floats 4q..4q+3 of the row's current 16-float
+        // step (one ds_read_b128 per step and wave instead of four).  Every lane of the quad runs the same add chain, taking
+        // the operand from the lane that holds it (DPP quad_perm broadcast, folded into the add), and keeps the four sums
+        // that belong to its own floats.  After the last step the row's total goes into the right pad (taps right of w-1).
         __builtin_amdgcn_s_setprio(3);
+        static_assert(4 * RB <= 16, "one quad per row");
         const int n16 = w >> 4;                 // 16-float steps
         const int half16 = n16 >> 1;
-        const bool on = lane < 4 * RB && !(ABL & 1);
+        const int srow = lane >> 2, sq = lane & 3;
+        const bool on = srow < 4 * RB && !(ABL & 1);
+        const bool q0 = sq == 0, q1 = sq == 1, q2 = sq == 2;
         for (int t = 0; t < nticks; t++) {
-            float *row = s_set + ((size_t)((t + 1) & 1) * 4 * RB + (lane < 4 * RB ? lane : 0)) * WP + PAD;
+            float *row = s_set + ((size_t)((t + 1) & 1) * 4 * RB + (srow < 4 * RB ? srow : 0)) * WP + PAD;
             float acc = 0.f;
-            float4 cur[4], nxt[4];
-            if (on) {
-#pragma unroll
-                for (int i = 0; i < 4; i++) cur[i] = *reinterpret_cast<float4 *>(row + 4 * i);
-            }
-            // one 16-float step: issue the LDS reads of the step after it, then the add chain, then the stores
-            auto step = [&](float4 (&cu)[4], float4 (&nx)[4], int c) __attribute__((always_inline)) {
-#pragma unroll
-                for (int i = 0; i < 4; i++) nx[i] = *reinterpret_cast<float4 *>(row + (c + 1) * 16 + 4 * i);   // overrun: pad / next row
-#pragma unroll
-                for (int i = 0; i < 4; i++) {   // img(x,y) = img(x-1,y) + l(x,y)
-                    cu[i].x = acc = acc + cu[i].x;
-                    cu[i].y = acc = acc + cu[i].y;
-                    cu[i].z = acc = acc + cu[i].z;
-                    cu[i].w = acc = acc + cu[i].w;
-                }
-#pragma unroll
-                for (int i = 0; i < 4; i++) *reinterpret_cast<float4 *>(row + c * 16 + 4 * i) = cu[i];
+            float4 cur, nxt;
+            if (on) cur = *reinterpret_cast<float4 *>(row + 4 * sq);
+            // one 16-float step on `v` (read one step earlier); the next step's read is issued first
+#define EH_BC(val, k) __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(val), (k) * 0x55, 0xf, 0xf, false))
+            auto step = [&](float4 &v, float4 &nx, int c) __attribute__((always_inline)) {
+                nx = *reinterpret_cast<float4 *>(row + (c + 1) * 16 + 4 * sq);   // overrun past the row: pad / next row, never used
+                float4 o;
+                float s;
+                // img(x,y) = img(x-1,y) + l(x,y): floats 0..3 sit in lane 0 of the quad, 4..7 in lane 1, ...
+                s = acc = acc + EH_BC(v.x, 0); o.x = s;
+                s = acc = acc + EH_BC(v.y, 0); o.y = s;
+                s = acc = acc + EH_BC(v.z, 0); o.z = s;
+                s = acc = acc + EH_BC(v.w, 0); o.w = s;
+                s = acc = acc + EH_BC(v.x, 1); o.x = q0 ? o.x : s;
+                s = acc = acc + EH_BC(v.y, 1); o.y = q0 ? o.y : s;
+                s = acc = acc + EH_BC(v.z, 1); o.z = q0 ? o.z : s;
+                s = acc = acc + EH_BC(v.w, 1); o.w = q0 ? o.w : s;
+                s = acc = acc + EH_BC(v.x, 2); o.x = (q0 || q1) ? o.x : s;
+                s = acc = acc + EH_BC(v.y, 2); o.y = (q0 || q1) ? o.y : s;
+                s = acc = acc + EH_BC(v.z, 2); o.z = (q0 || q1) ? o.z : s;
+                s = acc = acc + EH_BC(v.w, 2); o.w = (q0 || q1) ? o.w : s;
+                s = acc = acc + EH_BC(v.x, 3); o.x = (q0 || q1 || q2) ? o.x : s;
+                s = acc = acc + EH_BC(v.y, 3); o.y = (q0 || q1 || q2) ? o.y : s;
+                s = acc = acc + EH_BC(v.z, 3); o.z = (q0 || q1 || q2) ? o.z : s;
+                s = acc = acc + EH_BC(v.w, 3); o.w = (q0 || q1 || q2) ? o.w : s;
+                *reinterpret_cast<float4 *>(row + c * 16 + 4 * sq) = o;
             };
-            auto steps16 = [&](int c0, int c1) __attribute__((always_inline)) {   // c1 - c0 even or odd: ends with the data in `cur`
+            auto steps16 = [&](int c0, int c1) __attribute__((always_inline)) {   // ends with the next step's data in `cur`
                 if (!on) return;
                 int c = c0;
                 for (; c + 1 < c1; c += 2) {
@@ -239,24 +254,31 @@ __global__ __launch_bounds__(512) void k_stage_a_fused(FusedArgs a) {
                 }
                 if (c < c1) {
                     step(cur, nxt, c);
-#pragma unroll
-                    for (int i = 0; i < 4; i++) cur[i] = nxt[i];
+                    cur = nxt;
                 }
             };
             steps16(0, half16);
             lds_barrier();
             steps16(half16, n16);
             if (on) {
-                for (int c = n16 * 16; c < w; c += 4) {   // w % 16 != 0: up to three float4 steps
-                    float4 v = *reinterpret_cast<float4 *>(row + c);
-                    v.x = acc = acc + v.x;
-                    v.y = acc = acc + v.y;
-                    v.z = acc = acc + v.z;
-                    v.w = acc = acc + v.w;
-                    *reinterpret_cast<float4 *>(row + c) = v;
+                const int rem4 = (w & 15) >> 2;   // w % 16 != 0: a last step of rem4 < 4 float4s (lanes q < rem4 hold data)
+                if (rem4) {
+                    float4 o = cur;
+                    float s;
+#define EH_TAIL(k)                                                                  \
+    if ((k) < rem4) {                                                               \
+        s = acc = acc + EH_BC(cur.x, k); o.x = sq == (k) ? s : o.x;                 \
+        s = acc = acc + EH_BC(cur.y, k); o.y = sq == (k) ? s : o.y;                 \
+        s = acc = acc + EH_BC(cur.z, k); o.z = sq == (k) ? s : o.z;                 \
+        s = acc = acc + EH_BC(cur.w, k); o.w = sq == (k) ? s : o.w;                 \
+    }
+                    EH_TAIL(0) EH_TAIL(1) EH_TAIL(2)
+#undef EH_TAIL
+                    if (sq < rem4) *reinterpret_cast<float4 *>(row + n16 * 16 + 4 * sq) = o;
                 }
-                *reinterpret_cast<float4 *>(row + w) = make_float4(acc, acc, acc, acc);
+                if (sq == 3) *reinterpret_cast<float4 *>(row + w) = make_float4(acc, acc, acc, acc);
             }
+#undef EH_BC
             lds_barrier();
         }
     } else {
@@ -354,30 +376,34 @@ __global__ __launch_bounds__(512) void k_stage_a_fused(FusedArgs a) {
         {
             const int ytest0 = (t - 7) * RB - LB - 2;           // first row tested in tick t-1
             if (ytest0 + RB - 1 >= 0 && ytest0 < h && !(ABL & 8)) {
-                // exclusive scan of the (row, wave) segment counts in raster order
-                const int nseg = RB * NW;                       // <= 64 (checked on the host)
+                // ids: running total + exclusive prefix of the (row, wave) segment counts in raster order.  The counts are few
+                // (RB * NW <= 64, one per lane) and the prefix is wave-uniform: read them lane by lane into scalar registers
+                // (v_readlane) instead of a shuffle scan through the LDS crossbar, whose steps each cost an LDS round trip.
+                const int nseg = RB * NW;
                 const int c = lane < nseg ? s_cnt[lane] : 0;
-                int incl = c;
+                int offs[RB], myc[RB];
+                int run = 0;
 #pragma unroll
-                for (int o = 1; o < 64; o <<= 1) {
-                    const int v = __shfl_up(incl, o, 64);
-                    if (lane >= o) incl += v;
+                for (int i = 0; i < RB; i++) {
+                    for (int g = 0; g < NW; g++) {
+                        const int cg = __builtin_amdgcn_readlane(c, i * NW + g);
+                        if (g == wv) { offs[i] = run; myc[i] = cg; }
+                        run += cg;
+                    }
                 }
-                const int excl = incl - c;
-                const int tick_total = __builtin_amdgcn_readlane(incl, 63);
-                int myc[RB];                                    // this wave's counts per row
-#pragma unroll
-                for (int i = 0; i < RB; i++) myc[i] = __shfl(c, i * NW + wv, 64);
+                const int tick_total = run;
                 for (int base = 0; base < nfinal; base += 64) {
                     const int e = base + lane;
                     const bool on = e < nfinal;
                     const int code = on ? my_list[e] : 0;
                     const int i = code >> 7, xin = code & 127;
-                    const int off = __shfl(excl, i * NW + wv, 64);
                     // rank inside the segment: the list is segment-ordered, so e minus the entries of the wave's earlier rows
-                    int before = 0;
+                    int off = offs[0], before = 0;
 #pragma unroll
-                    for (int i2 = 0; i2 < RB; i2++) before += i2 < i ? myc[i2] : 0;
+                    for (int i2 = 1; i2 < RB; i2++) {
+                        before = i2 <= i ? before + myc[i2 - 1] : before;
+                        off = i2 <= i ? offs[i2] : off;
+                    }
                     const int id = total + off + (e - before);
                     if (on && id < a.kl_max) {
                         int ro[5];
@@ -429,10 +455,13 @@ __global__ __launch_bounds__(512) void k_stage_a_fused(FusedArgs a) {
         // ================= phase 1b: the box chain on the scanned rows of buffer set `set` ==================================
         v2f l1[RB], l2a[RB], l2b[RB];
         uint32_t ppack = 0;                             // DoG > 0 of the tick's rows at the owned columns, 2 bits per row
-        const float *P0 = s_set + ((size_t)(set * 4 + 0) * RB) * WP + PAD + xr0;
-        const float *P1 = s_set + ((size_t)(set * 4 + 1) * RB) * WP + PAD + xr0;
-        const float *P2A = s_set + ((size_t)(set * 4 + 2) * RB) * WP + PAD + xr0;
-        const float *P2B = s_set + ((size_t)(set * 4 + 3) * RB) * WP + PAD + xr0;
+        // one per-thread address (column xr0 of the LDS array) + non-negative constants: the offsets fold into the DS
+        // instructions' immediates instead of costing an address register each
+        const float *lb = smem + xr0;
+        const float *P0 = lb + ((set * 4 + 0) * RB) * WP;
+        const float *P1 = lb + ((set * 4 + 1) * RB) * WP;
+        const float *P2A = lb + ((set * 4 + 2) * RB) * WP;
+        const float *P2B = lb + ((set * 4 + 3) * RB) * WP;
         const int y1in0 = (t - 2) * RB;                 // level 1 input row (image row) of slot 0
         const int y2in0 = (t - 4) * RB - R1;            // level 2 input row (level-1 row) of slot 0
         const int y3ain0 = (t - 6) * RB - R1 - R2A;     // level 3 input rows
@@ -447,11 +476,11 @@ __global__ __launch_bounds__(512) void k_stage_a_fused(FusedArgs a) {
             const int q = TT * RB + j;                  // row of the unrolled tick pair: ring positions
             const int slot = rq0 + j >= RING ? rq0 + j - RING : rq0 + j;
             // the row's ten tap pairs (unconditional: rows that do not exist read garbage that is never used)
-            const v2f t3a_r = ld2(P2A + j * WP + R3A), t3a_l = ld2(P2A + j * WP - R3A - 1);
-            const v2f t3b_r = ld2(P2B + j * WP + R3B), t3b_l = ld2(P2B + j * WP - R3B - 1);
-            const v2f t2a_r = ld2(P1 + j * WP + R2A), t2a_l = ld2(P1 + j * WP - R2A - 1);
-            const v2f t2b_r = ld2(P1 + j * WP + R2B), t2b_l = ld2(P1 + j * WP - R2B - 1);
-            const v2f t1_r = ld2(P0 + j * WP + R1), t1_l = ld2(P0 + j * WP - R1 - 1);
+            const v2f t3a_r = ld2(P2A + j * WP + (PAD + R3A)), t3a_l = ld2(P2A + j * WP + (PAD - R3A - 1));
+            const v2f t3b_r = ld2(P2B + j * WP + (PAD + R3B)), t3b_l = ld2(P2B + j * WP + (PAD - R3B - 1));
+            const v2f t2a_r = ld2(P1 + j * WP + (PAD + R2A)), t2a_l = ld2(P1 + j * WP + (PAD - R2A - 1));
+            const v2f t2b_r = ld2(P1 + j * WP + (PAD + R2B)), t2b_l = ld2(P1 + j * WP + (PAD - R2B - 1));
+            const v2f t1_r = ld2(P0 + j * WP + (PAD + R1)), t1_l = ld2(P0 + j * WP + (PAD - R1 - 1));
             v2f i0n, i1;
             if (steady) {
                 i0n = ring_row_steady<D3A, L3A>(H3A, q % L3A, t3a_r, t3a_l, MROW(R3A, D3A, mu3a));   // img0 = G(sigma0) of row ydog+1
@@ -469,7 +498,7 @@ __global__ __launch_bounds__(512) void k_stage_a_fused(FusedArgs a) {
             {
                 const int yd = ydog0 + j;                   // DoG row; iv[j+1] = img0 of that row
                 const v2f dg = i1 - iv[j + 1];              // sspace.cpp:66
-                if (act) *reinterpret_cast<v2f *>(s_dog + (size_t)slot * WP + PAD + x0) = dg;
+                if (act) *reinterpret_cast<v2f *>(smem + x0 + (2 * 4 * RB * WP + PAD) + slot * WP) = dg;
                 ppack |= ((act && dg.x > 0 ? 1u : 0u) | (act && dg.y > 0 ? 2u : 0u)) << (2 * j);
                 iv[j + 2] = i0n;
                 if (DBG && pl && act) {
@@ -502,9 +531,9 @@ __global__ __launch_bounds__(512) void k_stage_a_fused(FusedArgs a) {
             pre[j] = *reinterpret_cast<const uint2 *>(frame + (byte0 & ~3u));
         }
         if (act) {
-            float *Q1 = s_set + ((size_t)(set * 4 + 1) * RB) * WP + PAD + x0;
-            float *Q2A = s_set + ((size_t)(set * 4 + 2) * RB) * WP + PAD + x0;
-            float *Q2B = s_set + ((size_t)(set * 4 + 3) * RB) * WP + PAD + x0;
+            float *Q1 = smem + x0 + (((set * 4 + 1) * RB) * WP + PAD);
+            float *Q2A = smem + x0 + (((set * 4 + 2) * RB) * WP + PAD);
+            float *Q2B = smem + x0 + (((set * 4 + 3) * RB) * WP + PAD);
 #pragma unroll
             for (int j = 0; j < RB; j++) {
                 *reinterpret_cast<v2f *>(Q1 + j * WP) = l1[j];
@@ -606,7 +635,7 @@ __global__ __launch_bounds__(512) void k_stage_a_fused(FusedArgs a) {
             }
         }
         if (act) {   // grey of batch t -> plane 0 of the buffer set (b+g+r, image.h:197-203: integers, exact in float)
-            float *Q0 = s_set + ((size_t)(set * 4 + 0) * RB) * WP + PAD + x0;
+            float *Q0 = smem + x0 + (((set * 4 + 0) * RB) * WP + PAD);
 #pragma unroll
             for (int j = 0; j < RB; j++) {
                 int y = t * RB + j;

@@ -1,9 +1,27 @@
 #!/bin/bash
-# fused stage-A kernel: phase ablations (needs a `make EXPERIMENTS=1` build).  bits: 1 scan, 2 box chain, 4 window tests,
-# 8 KeyLine emit + mask rows, 16 RGB loads, 32 gradient gate
+# Fused stage-A kernel: phase ablations, one library per variant (compile-time switch, so that the compiler drops the dead
+# code and the register allocation of what is left is the real one).  Build here (no GPU needed):
+#   tools/experiments/exp_fused_ablate.sh build
+# then on the GPU box:  tools/experiments/exp_fused_ablate.sh [nseq]
+# bits: 1 scan, 2 box chain, 4 window tests, 8 KeyLine emit + mask rows, 16 RGB loads, 32 gradient gate + sign balance
+VARIANTS="0 1 4 8 12 32 63 62"
+ROOT=$(cd "$(dirname "$0")/../.." && pwd)
+if [ "$1" = build ]; then
+  mkdir -p $ROOT/tools/experiments/bin
+  for A in $VARIANTS; do
+    ( cd $ROOT/rebvo_amd/csrc && /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=off -I../../include -I. \
+        -DEDGEHIP_FUSED_ABL=$A -c stage_a_fused.hip -o /tmp/fused_abl$A.o && \
+      /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o $ROOT/tools/experiments/bin/libedgehip_abl$A.so \
+        ../lib/obj/api.o ../lib/obj/stage_a.o /tmp/fused_abl$A.o ../lib/obj/stage_b.o ../lib/obj/stage_c.o ) &
+  done
+  wait; ls -la $ROOT/tools/experiments/bin/ | grep abl; exit 0
+fi
 cd "$GRAFT_REPO_ROOT"
 B=${1:-1024}
-for A in 0 1 2 4 8 16 32 63 62; do
-  echo "== EDGEHIP_FUSED_ABLATE=$A"
-  EDGEHIP_FUSED_ABLATE=$A python tools/prof_stage_a.py $B 2>&1 | grep -E "stage A|fused"
+cp rebvo_amd/lib/libedgehip.so /tmp/libedgehip_keep.so
+for A in $VARIANTS; do
+  cp tools/experiments/bin/libedgehip_abl$A.so rebvo_amd/lib/libedgehip.so
+  echo -n "ABL=$A  "
+  EDGEHIP_LEVEL_MODE=3 python tools/prof_stage_a.py $B 2>&1 | grep -E "fused" | awk '{print $2, $3}'
 done
+cp /tmp/libedgehip_keep.so rebvo_amd/lib/libedgehip.so

@@ -73,6 +73,40 @@ __global__ void k_scanstep(float *out, long long *cyc) {
     out[threadIdx.x] = acc;
     if (threadIdx.x == 0) cyc[0] = t1 - t0;
 }
+// the same scan with the LDS reads issued DIST 16-float steps ahead of their use (NB = DIST + 1 register buffers, statically rotated)
+template <int NB>
+__global__ void k_scanpipe(float *out, long long *cyc) {
+    extern __shared__ float sm[];
+    const int lane = threadIdx.x, WP = 764;
+    for (int i = lane; i < 16 * WP + 256; i += 64) sm[i] = 1.f;
+    __syncthreads();
+    float acc = 0.f;
+    long long t0 = __builtin_readcyclecounter();
+    if (lane < 16) {
+        float *row = sm + lane * WP + 4;
+        float4 buf[NB][4];
+#pragma unroll
+        for (int b = 0; b < NB - 1; b++)
+#pragma unroll
+            for (int i = 0; i < 4; i++) buf[b][i] = *reinterpret_cast<float4 *>(row + b * 16 + 4 * i);
+#pragma unroll 1
+        for (int c = 0; c + NB <= 46 + NB; c += NB) {
+#pragma unroll
+            for (int b = 0; b < NB; b++) {
+                const int nb = (b + NB - 1) % NB;
+#pragma unroll
+                for (int i = 0; i < 4; i++) buf[nb][i] = *reinterpret_cast<float4 *>(row + (c + b + NB - 1) * 16 + 4 * i);
+#pragma unroll
+                for (int i = 0; i < 4; i++) { buf[b][i].x = acc = acc + buf[b][i].x; buf[b][i].y = acc = acc + buf[b][i].y; buf[b][i].z = acc = acc + buf[b][i].z; buf[b][i].w = acc = acc + buf[b][i].w; }
+#pragma unroll
+                for (int i = 0; i < 4; i++) *reinterpret_cast<float4 *>(row + (c + b) * 16 + 4 * i) = buf[b][i];
+            }
+        }
+    }
+    long long t1 = __builtin_readcyclecounter();
+    out[threadIdx.x] = acc;
+    if (threadIdx.x == 0) cyc[0] = t1 - t0;
+}
 int main() {
     float *out; long long *cyc, h;
     hipMalloc(&out, 4096); hipMalloc(&cyc, 64);
@@ -87,6 +121,14 @@ int main() {
         printf("scan of 736 floats per lane, 16 lanes: %lld cycles = %.1f per element\n", h, h / 736.0);
         hipLaunchKernelGGL(k_scanstep<64>, dim3(1), dim3(64), 16 * 764 * 4 + 1024, 0, out, cyc); hipMemcpy(&h, cyc, 8, hipMemcpyDeviceToHost);
         printf("scan of 736 floats per lane, 64 lanes: %lld cycles = %.1f per element\n", h, h / 736.0);
+        hipLaunchKernelGGL(k_scanpipe<2>, dim3(1), dim3(64), 16 * 764 * 4 + 2048, 0, out, cyc); hipMemcpy(&h, cyc, 8, hipMemcpyDeviceToHost);
+        printf("pipelined scan, reads 1 step ahead: %lld cycles = %.1f per element\n", h, h / 768.0);
+        hipLaunchKernelGGL(k_scanpipe<3>, dim3(1), dim3(64), 16 * 764 * 4 + 2048, 0, out, cyc); hipMemcpy(&h, cyc, 8, hipMemcpyDeviceToHost);
+        printf("pipelined scan, reads 2 steps ahead: %lld cycles = %.1f per element\n", h, h / 768.0);
+        hipLaunchKernelGGL(k_scanpipe<4>, dim3(1), dim3(64), 16 * 764 * 4 + 2048, 0, out, cyc); hipMemcpy(&h, cyc, 8, hipMemcpyDeviceToHost);
+        printf("pipelined scan, reads 3 steps ahead: %lld cycles = %.1f per element\n", h, h / 768.0);
+        hipLaunchKernelGGL(k_scanpipe<6>, dim3(1), dim3(64), 16 * 764 * 4 + 2048, 0, out, cyc); hipMemcpy(&h, cyc, 8, hipMemcpyDeviceToHost);
+        printf("pipelined scan, reads 5 steps ahead: %lld cycles = %.1f per element\n", h, h / 768.0);
     }
     return 0;
 }
