@@ -4,27 +4,35 @@
 Contract (see the task statement): `python bench.py --gpus N --steps K --warmup W`; for N>1 it is launched
 by torch.distributed.run with one rank per GPU.  One JSON line on rank 0.
 
-Workload (BASELINE.json configs[1]/[2] at the EuRoC size): `--nseq` independent synthetic 752x480 sequences
-per GPU ("billboards": textured quads at different depths seen by a moving pinhole camera, EuRoC
-intrinsics and GlobalConfig_EuRoC parameters, ImuMode=0).  One step = one new frame of EVERY sequence
-through the full path: RGB->grey, scale space, DoG, KeyLine extraction, distance field, Minimizer_RV
-(12 TryVelRot evaluations + device-side LM), forward match, rotate, directed matching, regularise, EKF,
-rescale, pose integration.  Frames are resident in HBM before the timed region (a pool of rendered frames,
-read in place by the first kernel of each sequence); nothing is skipped inside it and there is no host
-synchronisation per step.  Sequences shard across GPUs with no data-path collective ("weak" scaling: the
-per-GPU work is fixed); the per-frame nav records are gathered to rank 0 over RCCL at the end of the
-timed region.
+Workload of the default line (BASELINE.json configs[2] at the EuRoC size of configs[1]): `--nseq` independent synthetic
+752x480 sequences per GPU ("billboards": textured quads at different depths seen by a moving pinhole camera, EuRoC
+intrinsics and GlobalConfig_EuRoC parameters, ImuMode=0).  One step = one new frame of EVERY sequence through the full
+path: RGB->grey, scale space, DoG, KeyLine extraction, distance field, Minimizer_RV (12 TryVelRot evaluations +
+device-side LM), forward match, rotate, directed matching, regularise, EKF, rescale, pose integration.  Frames are
+resident in HBM before the timed region (a pool of rendered frames, read in place by the first kernel of each sequence);
+nothing is skipped inside it and there is no host synchronisation per step.  Sequences shard across GPUs with no
+data-path collective ("weak" scaling: the per-GPU work is fixed); the per-frame nav records go to rank 0 over RCCL on a
+side stream, double buffered, off the timed critical path.
 
-Extra objects on the JSON line:
-  roofline     dominant kernel group (by HIP-event time on the context stream, measured over the timed
-               region), its algorithmic bytes per launch / mean launch duration vs 8 TB/s
-  cpu_baseline the reference's own mtracklib (oracle/_ref, compiled in place from the reference sources)
-               timed on one host core over a bounded sample of the same frames
-  pose_rmse    BASELINE.json's "pose RMSE vs CPU ref": the trajectories of the first, middle and last sequence of the
-               batch over the timed frames against the CPU reference replaying the same frame order from frame 0
+Extra objects on the JSON line (rank 0, N = 1):
+  roofline         the kernel group with the most time (HIP events on the stream it runs on, over the timed region): its
+                   algorithmic bytes per launch / mean launch duration against 8 TB/s; `traffic` =
+                   HBM bytes per launch from the committed rocprofv3 PMC passes of this same command (a replayed number:
+                   `traffic_source`), with the calibration of the FETCH_SIZE counter it uses
+  roofline_kernels the same figure for every kernel group of the step
+  cpu_baseline     the reference's own mtracklib (oracle/_ref, compiled in place from the reference sources) on the host
+                   cores of this box, three ways: one core, the reference's own two-thread overlap,
+                   node-saturating; median and p95 per frame
+  pose_rmse        BASELINE.json's "pose RMSE vs CPU ref": sequences of the batch against the CPU reference on the same frames
+  batch_sweep      the same full path with 1 / 8 / 64 sequences per launch (1 = a single camera: `single_sequence_ms_per_frame`)
+  heterogeneous    the same batch size with every sequence in its own state: six different scenes, different phases,
+                   a scene cut (estimation restart) in some, KeyLine counts spread — throughput and pose RMSE
+
+`--config stage_a` (BASELINE configs[1]): DoG + edge_finder KeyLine extraction alone, reported as HBM GB/s.
+`--config tum_undistort` (BASELINE configs[3]): TUM 640x480, GlobalConfig_desk.txt parameters, the undistortion fused
+into the stage-A load.
 """
 import argparse
-import ctypes
 import json
 import os
 import re
@@ -48,7 +56,7 @@ def tri(k, n):
 
 
 def algorithmic_bytes(group, kn, n_px, radius, nseq):
-    """Compulsory bytes per launch of a kernel group (DESIGN.md §4), for `nseq` batched sequences."""
+    """Compulsory bytes per launch of a kernel group (DESIGN.md section 3), for `nseq` batched sequences."""
     per_seq = {
         # stage A pieces: inputs/outputs each kernel cannot avoid
         "A.rgb_rowscan": 3 * n_px + 4 * n_px,                 # RGB24 in, row-prefix plane out
@@ -58,7 +66,10 @@ def algorithmic_bytes(group, kn, n_px, radius, nseq):
         # one-pass level kernel, mean of its three launches: (3N in + 4N out) + (4N + 4N) + 2 * (4N + 4N)
         "A.level": (7 * n_px + 8 * n_px + 16 * n_px) / 3.0,
         "A.compact": 20 * kn + 168 * kn,                     # candidates in, KeyLine SoA out
-        "A.join_retune": (8 + 8 + 4 + 3 * 4 + 8) * kn,
+        # the fused stage-A kernel: SURVEY.md 8(d) stage A = RGB24 in + img_mask_kl out + the KeyLine records, of which
+        # the constant fields (88 B) are written by the join kernel that follows
+        "A.fused": 3 * n_px + 4 * n_px + (168 - 88) * kn,
+        "A.join_retune": (8 + 8 + 4 + 3 * 4 + 8) * kn + 88 * kn,
         # 84 B per KeyLine and evaluation (fp64 variant)
         "B.try_velrot": 84 * kn,
         "B.build_field": 4 * n_px + 4 * 2 * radius * kn,     # clear + scattered 4-byte atomics (packed field)
@@ -79,20 +90,38 @@ def algorithmic_bytes(group, kn, n_px, radius, nseq):
 GROUP_KERNELS = {
     "A.rgb_rowscan": ["k_rgb_rowscan"], "A.colscan": ["k_colscan"], "A.avg_rowscan": ["k_avg_rowscan"],
     "A.detect": ["k_detect"], "A.compact": ["k_strip_scan", "k_emit"], "A.join_retune": ["k_join_histo", "k_retune"],
-    "A.level": ["k_level"],
+    "A.level": ["k_level"], "A.fused": ["k_stage_a_fused"],
     "B.quantile": ["k_quantile"], "B.build_field": ["k_field_bin", "k_field_raster"], "B.tvr_prepare": ["k_tvr_prepare"],
     "B.try_velrot": ["k_try_velrot"], "B.lm_step": ["k_lm_step"], "B.minimizer": ["k_minimizer"],
     "C.forward_match": ["k_fwd_key", "k_fwd_win", "k_fwd_apply"], "C.rotate": ["k_rot_from_state", "k_rotate"],
     "C.directed_matching": ["k_directed"], "C.regularize_ekf": ["k_regularize", "k_ekf"], "C.rescale": ["k_rescale"],
 }
 
+PMC_FILE = os.path.join("profiles", "pmc_latest.json")
 
-def pmc_traffic(group, nseq):
+
+def fetch_calibration():
+    """true bytes / FETCH_SIZE-reported bytes for the access patterns of this path, measured with known byte counts
+    (tools/experiments/ubench_fetch.hip -> profiles/fetch_calibration.json): {"stream": f, "gather16": f, "gather2": f}.
+    Falls back to the doubling MI355X_MICROARCH.md prescribes for wide streams."""
+    path = os.path.join(ROOT, "profiles", "fetch_calibration.json")
+    try:
+        js = json.load(open(path))
+        return {k: float(v) for k, v in js["factor"].items()}, "profiles/fetch_calibration.json"
+    except (OSError, KeyError, ValueError):
+        return {"stream": 2.0}, "MI355X_MICROARCH.md (gfx950: FETCH_SIZE x 2, calibrated for wide coalesced streams only)"
+
+
+# which calibration entry fits a kernel group's reads (default: wide coalesced streams)
+GROUP_FETCH_PATTERN = {"B.try_velrot": "gather_mix", "C.directed_matching": "gather_mix"}
+
+
+def pmc_traffic(group, nseq, factor=2.0):
     """HBM bytes per launch of `group` from the committed rocprofv3 PMC passes (profiles/pmc_latest.json, made by
     tools/gpu_round.sh: separate `--pmc FETCH_SIZE` and `--pmc WRITE_SIZE` runs of this same command).
-    FETCH_SIZE/WRITE_SIZE are KiB; FETCH_SIZE is doubled (gfx950 note in MI355X_MICROARCH.md).  None when the
-    file is missing, was taken at another batch size, or lacks the kernel."""
-    path = os.path.join(ROOT, "profiles", "pmc_latest.json")
+    FETCH_SIZE/WRITE_SIZE are KiB; FETCH_SIZE is scaled by `factor` (2 = the gfx950 note in MI355X_MICROARCH.md).  None
+    when the file is missing, was taken at another batch size, or lacks the kernel."""
+    path = os.path.join(ROOT, PMC_FILE)
     if not os.path.exists(path):
         return None
     js = json.load(open(path))
@@ -111,7 +140,7 @@ def pmc_traffic(group, nseq):
                 w += c["WRITE_SIZE"]["mean"] * k
                 n += k
         if n:
-            total += (2.0 * f / n + w / n) * 1024.0
+            total += (factor * f / n + w / n) * 1024.0
             found = True
     return int(total) if found else None
 
@@ -128,19 +157,35 @@ def _usable_cores():
     return n
 
 
+def _cpu_model():
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name"):
+                return line.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return "unknown"
+
+
+def frame_stats(done_s, skip):
+    """Per-frame intervals of a replay (seconds at which each frame was finished) after `skip` warm-up frames."""
+    iv = np.diff(np.asarray(done_s)[skip - 1:]) if skip > 0 else np.diff(np.concatenate([[0.0], done_s]))
+    return {"value": round(len(iv) / float(iv.sum()), 2), "unit": "frames/s", "ms_per_frame": round(float(iv.mean()) * 1e3, 3),
+            "median_ms": round(float(np.median(iv)) * 1e3, 3), "p95_ms": round(float(np.percentile(iv, 95)) * 1e3, 3),
+            "frames": int(len(iv))}
+
+
 def _cpu_worker(job):
-    """One CPU-reference sequence in its own process: returns the seconds spent in stage A + B/C of the timed frames."""
-    kind, nfr, npool, seed = job
+    """One CPU-reference sequence in its own process (node-saturating mode): the reference's own two-thread overlap on
+    `nfr` frames; returns the seconds from the first timed frame to the last."""
+    kind, nfr, npool, seed, threads, w, h = job
     from oracle import oracle
     from rebvo_amd import synth
-    frames = [f for f, _, _ in synth.billboard_sequence(W, H, min(npool, 12), seed=seed)]
-    orc = oracle.Oracle("ref" if kind == "reference" else "port", oracle.euroc_params(W, H))
-    for k in range(6):
-        orc.process_frame(frames[tri(k, len(frames))], 0.05 * k)
-    t0 = time.perf_counter()
-    for k in range(6, 6 + nfr):
-        orc.process_frame(frames[tri(k, len(frames))], 0.05 * k)
-    return time.perf_counter() - t0
+    frames = np.stack([f for f, _, _ in synth.billboard_sequence(w, h, min(npool, 8), seed=seed)])
+    orc = oracle.Oracle("ref", oracle.euroc_params(w, h))
+    idx = [tri(k, len(frames)) for k in range(8 + nfr)]
+    done, _ = orc.run_sequence(frames, idx, threads=threads)
+    return float(done[-1] - done[7])
 
 
 def pose_rmse(gpu_trajs, cpu_trajs, kind):
@@ -172,24 +217,96 @@ def pose_rmse(gpu_trajs, cpu_trajs, kind):
             "vs": "CPU " + kind + " on the same frames, both started at frame 0 (tests bound |dV|,|dW| by 1e-6 relative)"}
 
 
+def _traj_of_log(log, s):
+    return [(log[k, s]["Pos"].copy(), log[k, s]["Pose"].reshape(3, 3).copy(), log[k, s]["V"].copy(), log[k, s]["W"].copy())
+            for k in range(log.shape[0])]
+
+
+def _cpu_traj(oracle, params, frames_of_step, first, count):
+    """The CPU reference on frames_of_step(0..first+count-1); its trajectory over the last `count` frames."""
+    orc = oracle.Oracle("ref" if oracle.available("ref") else "port", params)
+    out = {}
+    for k in range(first + count):
+        _, nav = orc.process_frame(frames_of_step(k), 0.05 * k)
+        if k >= first:
+            out[k - first] = (np.array(nav.Pos[:]), np.array(nav.Pose[:]).reshape(3, 3), np.array(nav.V[:]), np.array(nav.W[:]))
+    orc.close()
+    return out
+
+
+class Replay:
+    """`nseq` sequences in lock-step out of an HBM-resident frame pool: frame index of sequence s at step k =
+    index_of(k)[s]."""
+
+    def __init__(self, edgehip, params, nseq, pool_t, pool_frames, index_of, device, contexts=1):
+        self.C = max(1, contexts)
+        self.B = nseq // self.C
+        self.ehs = [edgehip.EdgeHip(params, nseq=self.B, nslots=3, device=device) for _ in range(self.C)]
+        self.pool_t, self.pool_frames, self.index_of = pool_t, pool_frames, index_of
+
+    def step(self, k):
+        idx = np.ascontiguousarray(self.index_of(k), dtype=np.int32)
+        for ci, e in enumerate(self.ehs):
+            e.bind_rgb_indexed(e.next_slot(), self.pool_t.data_ptr(), self.pool_frames, idx[ci * self.B:(ci + 1) * self.B])
+            e.process_frame(0.05 * k)
+
+    def sync(self):
+        for e in self.ehs:
+            e.sync()
+
+    def close(self):
+        for e in self.ehs:
+            e.close()
+
+
+def timed_replay(rp, K, Wm, profile=False):
+    """Wm warm-up steps, then K steps between synchronisations; returns (seconds, breakdown in us per step or None)."""
+    eh = rp.ehs[0]
+    breakdown = None
+    if profile:
+        prof_steps = min(4, max(1, Wm // 4))
+        for k in range(Wm - prof_steps):
+            rp.step(k)
+        rp.sync()
+        eh.profile_enable(True)
+        eh.profile_select(None)
+        for k in range(Wm - prof_steps, Wm):
+            rp.step(k)
+        prof = eh.profile_read()
+        eh.profile_enable(False)
+        breakdown = {g: (ms / prof_steps * 1e3, calls // prof_steps) for g, (ms, calls) in prof.items() if calls}
+    else:
+        for k in range(Wm):
+            rp.step(k)
+    rp.sync()
+    t0 = time.perf_counter()
+    for k in range(Wm, Wm + K):
+        rp.step(k)
+    rp.sync()
+    return time.perf_counter() - t0, breakdown
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=40)
     ap.add_argument("--warmup", type=int, default=24)
+    ap.add_argument("--config", default="full", choices=["full", "stage_a", "tum_undistort"],
+                    help="full = BASELINE configs[2]/[4] (the default line); stage_a = configs[1]; tum_undistort = configs[3]")
     ap.add_argument("--nseq", type=int, default=1024, help="independent sequences per GPU (all contexts together)")
     ap.add_argument("--contexts", type=int, default=1,
                     help="edgehip contexts (= HIP streams) the sequences are split over: kernels of different contexts "
                          "run concurrently, which hides the serial LM-step kernels and launch tails of one context "
                          "behind the bandwidth-bound kernels of the other")
     ap.add_argument("--pool", type=int, default=24, help="rendered frames in the HBM pool")
-    ap.add_argument("--cpu-frames", type=int, default=200, help="frames of the CPU-baseline sample (0 = skip)")
+    ap.add_argument("--cpu-frames", type=int, default=200, help="frames of the CPU-baseline sample (0 = skip the CPU legs)")
     ap.add_argument("--overlap", action="store_true",
                     help="EDGEHIP_OVERLAP=1: stage A of frame k+1 under stages B/C of frame k (two streams per context). "
                          "Faster, but per-kernel HIP-event times (the roofline object) stop being attributable, so off by default")
-    ap.add_argument("--cpu-procs", type=int, default=0,
-                    help="also time the CPU reference node-saturating: this many independent sequences in parallel "
-                         "processes (SURVEY.md section 8d mode iii; 0 = skip, -1 = one per usable host core)")
+    ap.add_argument("--cpu-procs", type=int, default=-1,
+                    help="processes of the node-saturating CPU leg (SURVEY.md section 8d mode iii; -1 = usable cores // 3 "
+                         "sequences, each with the reference's two compute threads; 0 = skip)")
+    ap.add_argument("--no-extras", action="store_true", help="skip the batch sweep and the heterogeneous batch")
     ap.add_argument("--no-roofline-events", action="store_true")
     args = ap.parse_args()
 
@@ -223,33 +340,110 @@ def main():
 
     if args.overlap:
         os.environ["EDGEHIP_OVERLAP"] = "1"
+    tum = args.config == "tum_undistort"
+    w, h = (640, 480) if tum else (W, H)
+    n_px = w * h
+    params = edgehip.tum_params(w, h, use_undistort=1) if tum else edgehip.euroc_params(w, h)
+    radius = params.search_range
     C = max(1, args.contexts)
     B, K, Wm = args.nseq // C, args.steps, args.warmup   # B = sequences per context
-    # ---- synthetic frame pool, resident in HBM ----
-    frames = [f for f, _, _ in synth.billboard_sequence(W, H, args.pool, seed=11 + rank)]
-    # HBM-resident frame pool; stage A reads each sequence's frame in place (edgehip_bind_rgb_indexed: no gather copy,
-    # like ConvertRGB2BW reading the camera buffer).  16 B of slack: pixels are fetched as aligned 8-byte words.
-    host_pool = np.stack(frames)
-    pool = torch.empty(host_pool.size + 16, dtype=torch.uint8, device="cuda")
-    pool[:host_pool.size] = torch.from_numpy(host_pool.reshape(-1)).cuda()
-    torch.cuda.synchronize()
+    cpu_legs = rank == 0 and args.cpu_frames > 0 and (world == 1 or os.environ.get("BENCH_CPU_BASELINE_ALWAYS"))
 
-    ehs = [edgehip.EdgeHip(edgehip.euroc_params(W, H), nseq=B, nslots=3, device=local_rank) for _ in range(C)]
-    eh = ehs[0]   # the context whose stream carries the HIP-event profiler
+    def to_pool(frames_list):
+        """HBM-resident frame pool; stage A reads each sequence's frame in place (edgehip_bind_rgb_indexed: no gather
+        copy, like ConvertRGB2BW reading the camera buffer).  16 B of slack: pixels are fetched as aligned 8-byte words."""
+        host = np.stack(frames_list)
+        t = torch.empty(host.size + 16, dtype=torch.uint8, device="cuda")
+        t[:host.size] = torch.from_numpy(host.reshape(-1)).cuda()
+        return t
+
+    # ---- synthetic frame pool, resident in HBM ----
+    intr = dict(fx=float(params.zfx), fy=float(params.zfy), cx=float(params.ppx), cy=float(params.ppy))
+    frames = [f for f, _, _ in synth.billboard_sequence(w, h, args.pool, seed=11 + rank, **intr)]
+    pool = to_pool(frames)
+    torch.cuda.synchronize()
+    # every sequence starts at its own phase of the pool
+    offs = np.arange(B * C, dtype=np.int64) % (2 * (args.pool - 1))
+    rp = Replay(edgehip, params, B * C, pool, args.pool, lambda k: [tri(k + o, args.pool) for o in offs], local_rank, C)
+    ehs, eh = rp.ehs, rp.ehs[0]   # eh: the context whose streams carry the HIP-event profiler
+
+    # ============================ --config stage_a: DoG + KeyLine extraction alone (configs[1]) ============================
+    if args.config == "stage_a":
+        def stage_a_step(k):
+            idx = np.array([tri(k + o, args.pool) for o in offs[:B]], dtype=np.int32)
+            for e in ehs:
+                s = k % 3
+                e.bind_rgb_indexed(s, pool.data_ptr(), args.pool, idx)
+                e.stage_a(s)
+        for k in range(Wm):
+            stage_a_step(k)
+        rp.sync()
+        eh.profile_enable(True)
+        eh.profile_select(None)
+        if world > 1:
+            dist.barrier()
+        t0 = time.perf_counter()
+        for k in range(Wm, Wm + K):
+            stage_a_step(k)
+        rp.sync()
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        dt = time.perf_counter() - t0
+        prof = {g: (ms, calls) for g, (ms, calls) in eh.profile_read().items() if calls}
+        kn_mean = float(np.mean([v for e in ehs for v in e.get_kn((Wm + K - 1) % 3)]))
+        if world > 1:
+            tmax = torch.tensor([dt], dtype=torch.float64, device="cuda" if backend == "nccl" else "cpu")
+            dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+            dt = float(tmax.item())
+        if rank == 0:
+            fbytes = 3 * n_px + 4 * n_px + 168 * kn_mean       # SURVEY.md 8(d): stage A
+            fps = B * C * world * K / dt
+            dom = max(prof, key=lambda g: prof[g][0])
+            per_launch = prof[dom][0] * 1e-3 / prof[dom][1]
+            ab = algorithmic_bytes(dom, kn_mean, n_px, radius, B)
+            cpu = None
+            if cpu_legs:
+                from oracle import oracle
+                orc = oracle.Oracle("ref", oracle.euroc_params(w, h))
+                tr, lr, ts = orc.p.detector_thresh, 0, []
+                for k in range(8 + min(args.cpu_frames, 100)):
+                    t1 = time.perf_counter()
+                    _, tr, lr = orc.stage_a(k % 8, frames[tri(k, args.pool)], tr, lr)
+                    ts.append(time.perf_counter() - t1)
+                ts = np.array(ts[8:])
+                cpu = {"value": round(fbytes / float(ts.mean()) / 1e9, 3), "unit": "GB/s", "cores": 1, "kind": "reference",
+                       "sample": f"{len(ts)} frames of stage A (sspace::build + edge_finder::detect) on 1 core of {_usable_cores()} "
+                                 f"({_cpu_model()})", "ms_per_frame": round(float(ts.mean()) * 1e3, 3),
+                       "median_ms": round(float(np.median(ts)) * 1e3, 3), "p95_ms": round(float(np.percentile(ts, 95)) * 1e3, 3)}
+            print(json.dumps({
+                "metric": "HBM GB/s (DoG + edge_finder KeyLine extraction) 752x480", "value": round(fbytes * fps / world / 1e9, 2),
+                "unit": "GB/s", "n_gpus": world, "steps": K, "warmup": Wm, "ms_per_step": round(dt / K * 1e3, 4),
+                "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32 scale space / f64 plane fit",
+                "data": "synthetic",
+                "config": {"workload": "BASELINE configs[1]: stage A only (RGB->grey, box-filter scale space, DoG, KeyLine extraction, "
+                                       "join_edges, threshold control), 752x480, GlobalConfig_EuRoC detector parameters; value = "
+                                       "SURVEY 8(d) stage-A bytes (3N + 4N + 168 kn) x frames/s per GPU",
+                           "sequences_per_gpu": B * C, "frames_per_step": B * C * world, "keylines_per_frame": round(kn_mean, 1),
+                           "frames_per_s": round(fps, 1), "algorithmic_MB_per_frame": round(fbytes / 1e6, 3)},
+                "roofline": {"bound": "hbm", "kernel": dom, "achieved": round(ab / per_launch / 1e9, 2), "peak": HBM_PEAK_GBS,
+                             "unit": "GB/s", "frac": round(ab / per_launch / 1e9 / HBM_PEAK_GBS, 5), "traffic": None,
+                             "launch_us": round(per_launch * 1e6, 2), "algorithmic_bytes_per_launch": int(ab),
+                             "launches_timed": prof[dom][1]},
+                "stage_a_hbm_frac": round(fbytes * fps / world / 1e9 / HBM_PEAK_GBS, 5),
+                "cpu_baseline": cpu,
+                "kernel_us_per_step": {g: round(ms / K * 1e3, 1) for g, (ms, calls) in prof.items()}}))
+        if world > 1:
+            dist.barrier()
+            dist.destroy_process_group()
+        return
+
+    # ============================ the full path ============================
     for e in ehs:
         e.set_nav_log(K)
-    # every sequence starts at its own phase of the pool
-    offs = [(np.arange(B, dtype=np.int64) + ci * B) % (2 * (args.pool - 1)) for ci in range(C)]
-
-    def step(k):
-        for e, off in zip(ehs, offs):
-            idx = np.array([tri(k + o, args.pool) for o in off], dtype=np.int32)
-            e.bind_rgb_indexed(e.next_slot(), pool.data_ptr(), args.pool, idx)
-            e.process_frame(0.05 * k)
 
     def barrier():
-        for e in ehs:
-            e.sync()
+        rp.sync()
         torch.cuda.synchronize()
         if world > 1:
             dist.barrier()
@@ -257,13 +451,12 @@ def main():
     # ---- warmup (also finds the dominant kernel group with the built-in HIP-event profiler) ----
     prof_steps = min(4, max(1, Wm // 4))
     for k in range(Wm - prof_steps):
-        step(k)
-    for e in ehs:
-        e.sync()
+        rp.step(k)
+    rp.sync()
     eh.profile_enable(True)
     eh.profile_select(None)
     for k in range(Wm - prof_steps, Wm):
-        step(k)
+        rp.step(k)
     prof = eh.profile_read()
     eh.profile_enable(False)
     groups = {g: (ms, calls) for g, (ms, calls) in prof.items() if calls}
@@ -274,16 +467,22 @@ def main():
     if dominant and not args.no_roofline_events:
         eh.profile_select([dominant])
         eh.profile_enable(True)
+    # N > 1: the nav records of a step travel to rank 0 in blocks of `blk` steps on a side stream (RCCL gather issued
+    # while the next block is being computed; two buffers), the last block after the timed region's last step
+    mover = shard.NavMover(world, rank, backend, device=local_rank if backend == "nccl" else None) if world > 1 else None
+    blk = max(1, K // 4)
     barrier()
     t0 = time.perf_counter()
+    posted = 0
     for k in range(Wm, Wm + K):
-        step(k)
-    if world > 1:
-        # nav records of every step -> rank 0 over RCCL (tiny: ~0.5 KB per frame)
-        for ci, e in enumerate(ehs):
-            navs = e.read_nav_log_array(Wm, K)
-            seq_ids = list(range((rank * C + ci) * B, (rank * C + ci + 1) * B))
-            shard.gather_records(shard.nav_records(navs, rank, seq_ids), dst=0)
+        rp.step(k)
+        done = k - Wm + 1
+        if mover and (done % blk == 0 or done == K):   # the block just enqueued: the mover's thread waits for it, this one does not
+            for ci, e in enumerate(ehs):
+                mover.post(e, Wm + posted, done - posted, [(rank * C + ci) * B + s for s in range(B)])
+            posted = done
+    if mover:
+        mover.finish()      # every record has reached rank 0 inside the timed region; all but the last block under compute
     barrier()
     dt = time.perf_counter() - t0
     if world > 1:
@@ -295,13 +494,11 @@ def main():
     if dominant and not args.no_roofline_events:
         dom_ms, dom_calls = eh.profile_read()[dominant]
         eh.profile_enable(False)
-    # trajectory of sequence 0 over the timed frames (for pose_rmse against the CPU reference below)
-    gpu_traj = None
     check_seqs = sorted({0, B // 2, B - 1})   # sequences of context 0 compared with the CPU reference below
-    if rank == 0 and args.cpu_frames > 0 and (world == 1 or os.environ.get("BENCH_CPU_BASELINE_ALWAYS")):
+    gpu_traj = None
+    if cpu_legs:
         log0 = eh.read_nav_log_array(Wm, K)
-        gpu_traj = {s: [(log0[k, s]["Pos"].copy(), log0[k, s]["Pose"].reshape(3, 3).copy(), log0[k, s]["V"].copy(),
-                         log0[k, s]["W"].copy()) for k in range(K)] for s in check_seqs}
+        gpu_traj = {s: _traj_of_log(log0, s) for s in check_seqs}
     last = [n for e in ehs for n in e.read_nav()]
     kn_mean = float(np.mean([n.kn for n in last]))
     ok = int(sum(n.estimation_ok for n in last))
@@ -314,83 +511,160 @@ def main():
         return
 
     value = B * C * world * K / dt
-    # ---- roofline of the dominant kernel group ----
+    # ---- roofline of the dominant kernel group, and of all of them ----
+    calib, calib_src = fetch_calibration()
+    def fetch_factor(group):
+        return calib.get(GROUP_FETCH_PATTERN.get(group, "stream"), calib.get("stream", 2.0))
     roof = None
     if dominant and dom_calls:
         per_launch_s = dom_ms * 1e-3 / dom_calls
-        abytes = algorithmic_bytes(dominant, kn_mean, W * H, 40, B)
+        abytes = algorithmic_bytes(dominant, kn_mean, n_px, radius, B)
         ach = abytes / per_launch_s / 1e9 if per_launch_s > 0 else 0.0
+        traffic = pmc_traffic(dominant, B, fetch_factor(dominant))
         roof = {"bound": "hbm", "kernel": dominant, "achieved": round(ach, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                "frac": round(ach / HBM_PEAK_GBS, 5), "traffic": pmc_traffic(dominant, B),
+                "frac": round(ach / HBM_PEAK_GBS, 5), "traffic": traffic,
+                "traffic_source": PMC_FILE + " (rocprofv3 --pmc passes of this command committed with the code; not measured in this run)",
+                "traffic_calibration": {"fetch_factor": round(fetch_factor(dominant), 3), "source": calib_src},
                 "launch_us": round(per_launch_s * 1e6, 2), "algorithmic_bytes_per_launch": int(abytes),
                 "launches_timed": dom_calls}
+    roof_all = {}
+    for g, (ms, calls) in groups.items():
+        ab = algorithmic_bytes(g, kn_mean, n_px, radius, B)
+        if ab and calls:
+            per = ms * 1e-3 / calls
+            tr = pmc_traffic(g, B, fetch_factor(g))
+            roof_all[g] = {"launch_us": round(per * 1e6, 1), "launches_per_step": calls // prof_steps,
+                           "achieved_GBs": round(ab / per / 1e9, 1), "frac": round(ab / per / 1e9 / HBM_PEAK_GBS, 4),
+                           "traffic_over_algorithmic": round(tr / ab, 2) if tr else None}
     # whole-frame algorithmic bytes, SURVEY.md §8(d) formulas with the measured kn and evaluation count
-    n_px, r = W * H, 40
+    r = radius
     frame_bytes = (3 * n_px + 4 * n_px + 168 * kn_mean) + (8 * n_px + 8 * 2 * r * kn_mean + evals * 84 * kn_mean) + \
                   ((4 * 40 + 2 * 168) * kn_mean + 100 * kn_mean + 64 * kn_mean + 160 * kn_mean)
+    if tum:
+        frame_bytes += 36 * n_px    # the undistortion map read
+    rp.close()
 
-    # ---- CPU baseline: the reference's own code on one host core, bounded sample ----
+    # ---- CPU baseline: the reference's own code on the host cores of this box, three ways; pose RMSE ----
     cpu = None
     pose = None
-    if args.cpu_frames > 0 and (world == 1 or os.environ.get("BENCH_CPU_BASELINE_ALWAYS")):   # rank 0 at N=1 only
+    oparams = None
+    if cpu_legs:
         try:
             from oracle import oracle
+            oparams = oracle.tum_params(w, h, use_undistort=1) if tum else oracle.euroc_params(w, h)
             kind = "reference" if oracle.available("ref") else ("port" if oracle.available("port") else None)
             if kind:
-                orc = oracle.Oracle("ref" if kind == "reference" else "port", oracle.euroc_params(W, H))
-                cpu_traj = {}
-                tc = 0.0
-                for k in range(10 + args.cpu_frames):  # the first 10: first-touch of the 8 ring slots + MKL init, untimed
-                    _, nav = orc.process_frame(frames[tri(k, args.pool)], 0.05 * k)
-                    if k >= 10:
-                        tc += nav.dtp0 + nav.dtp1
-                    if Wm <= k < Wm + K:
-                        cpu_traj[k - Wm] = (np.array(nav.Pos[:]), np.array(nav.Pose[:]).reshape(3, 3), np.array(nav.V[:]),
-                                            np.array(nav.W[:]))
-                cpu_trajs = {0: cpu_traj}
-                for s_ in check_seqs[1:]:   # the other checked sequences: replay their frame order from frame 0
-                    o2 = oracle.Oracle("ref" if kind == "reference" else "port", oracle.euroc_params(W, H))
-                    cpu_trajs[s_] = {}
-                    for k in range(Wm + K):
-                        _, nav = o2.process_frame(frames[tri(k + int(offs[0][s_]), args.pool)], 0.05 * k)
-                        if k >= Wm:
-                            cpu_trajs[s_][k - Wm] = (np.array(nav.Pos[:]), np.array(nav.Pose[:]).reshape(3, 3),
-                                                     np.array(nav.V[:]), np.array(nav.W[:]))
-                    o2.close()
+                cpu_trajs = {s_: _cpu_traj(oracle, oparams, lambda k, s_=s_: frames[tri(k + int(offs[s_]), args.pool)], Wm, K)
+                             for s_ in check_seqs}
                 pose = pose_rmse(gpu_traj, cpu_trajs, kind)
-                cpu = {"value": round(args.cpu_frames / tc, 2), "unit": "frames/s", "cores": 1, "kind": kind,
-                       "sample": f"{args.cpu_frames} frames of sequence 0 (same 752x480 pool), serial stage A + B/C "
-                                 f"on 1 of {_usable_cores()} usable host cores; reference threading overlaps the two stages "
-                                 "on 2 cores",
-                       "ms_per_frame": round(tc / args.cpu_frames * 1e3, 2)}
+                ncores, model = _usable_cores(), _cpu_model()
+                if kind == "reference":
+                    host_pool = np.stack(frames)
+                    idx = [tri(k, args.pool) for k in range(10 + args.cpu_frames)]   # the first 10: first touch of the ring + MKL init
+                    modes = {}
+                    for name, th in (("serial_1_core", 1), ("reference_threads_2_cores", 2)):
+                        orc = oracle.Oracle("ref", oparams)
+                        done, _ = orc.run_sequence(host_pool, idx, threads=th)
+                        orc.close()
+                        modes[name] = frame_stats(done, 10)
+                        modes[name]["cores"] = th
+                    cpu = dict(modes["serial_1_core"])
+                    cpu.update({"cores": 1, "kind": kind, "cpu_model": model, "usable_cores": ncores,
+                                "sample": f"{args.cpu_frames} frames of sequence 0 (same {w}x{h} pool), stage A + B/C back to back on 1 "
+                                          f"of {ncores} usable host cores ({model}); `modes` adds the reference's own threading "
+                                          "(FirstThr next to SecondThread, rebvo_first_t.cpp:134 / rebvo_second_t.cpp:102) and the "
+                                          "node-saturating run",
+                                "modes": modes})
+                else:
+                    orc = oracle.Oracle("port", oparams)
+                    ts = []
+                    for k in range(10 + args.cpu_frames):
+                        _, nav = orc.process_frame(frames[tri(k, args.pool)], 0.05 * k)
+                        ts.append(nav.dtp0 + nav.dtp1)
+                    done = np.cumsum(ts)
+                    cpu = frame_stats(done, 10)
+                    cpu.update({"cores": 1, "kind": kind, "cpu_model": model, "usable_cores": ncores,
+                                "sample": f"{args.cpu_frames} frames of sequence 0, restatement oracle on 1 core"})
         except Exception as e:  # the oracle is optional test infrastructure; never fatal for the bench
             cpu = {"value": None, "error": str(e)[:200]}
-        if cpu and cpu.get("value") and args.cpu_procs:
-            # node-saturating mode: P independent sequences, one process each (the reference needs up to 3 threads per
-            # sequence; its 2 compute stages are run back to back here, so P = cores // 3 is conservative for the CPU)
+        if cpu and cpu.get("value") and cpu.get("kind") == "reference" and args.cpu_procs and not tum:
+            # node-saturating mode (SURVEY 8d iii): P independent sequences in parallel processes, each with the
+            # reference's two compute threads (its third thread only ships results)
             try:
                 import multiprocessing as mp
                 ncpu = _usable_cores()
-                P = args.cpu_procs if args.cpu_procs > 0 else max(1, ncpu)   # one core per sequence (stages run back to back)
-                nfr = max(20, args.cpu_frames // 4)
+                P = args.cpu_procs if args.cpu_procs > 0 else max(1, ncpu // 3)
+                nfr = max(30, args.cpu_frames // 3)
                 with mp.get_context("spawn").Pool(P) as pool_:   # spawn: never fork a process that holds a HIP context
-                    t0c = time.perf_counter()
-                    res = pool_.map(_cpu_worker, [(kind, nfr, args.pool, 11 + i) for i in range(P)])
-                    wall = time.perf_counter() - t0c
-                busy = max(r for r in res)
-                cpu["node"] = {"value": round(P * nfr / busy, 1), "unit": "frames/s", "processes": P, "cores": ncpu,
-                               "sample": f"{P} sequences x {nfr} frames in parallel processes (slowest process {busy:.2f} s, "
-                                         f"wall incl. start-up {wall:.2f} s)"}
+                    res = pool_.map(_cpu_worker, [(cpu["kind"], nfr, args.pool, 11 + i, 2, w, h) for i in range(P)])
+                cpu["modes"]["node_saturating"] = {
+                    "value": round(P * nfr / max(res), 1), "unit": "frames/s", "processes": P, "threads_per_process": 2,
+                    "cores": min(ncpu, 2 * P), "frames": P * nfr,
+                    "sample": f"{P} sequences x {nfr} frames, one process each with the reference's two compute threads "
+                              f"(slowest process {max(res):.2f} s)"}
             except Exception as e:
-                cpu["node"] = {"value": None, "error": str(e)[:200]}
+                cpu["modes"]["node_saturating"] = {"value": None, "error": str(e)[:200]}
+
+    # ---- the other batch shapes (N = 1, after the timed region) ----
+    sweep = hetero = None
+    if world == 1 and not args.no_extras:
+        sweep = []
+        for n in (1, 8, 64):
+            o = np.arange(n, dtype=np.int64) % (2 * (args.pool - 1))
+            r2 = Replay(edgehip, params, n, pool, args.pool, lambda k, o=o: [tri(k + x, args.pool) for x in o], local_rank)
+            k2 = 200 if n == 1 else 60
+            dt2, _ = timed_replay(r2, k2, 12)
+            sweep.append({"sequences_per_launch": n, "frames_per_s": round(n * k2 / dt2, 1), "ms_per_step": round(dt2 / k2 * 1e3, 4)})
+            r2.close()
+        sweep.append({"sequences_per_launch": B, "frames_per_s": round(value, 1), "ms_per_step": round(dt / K * 1e3, 4)})
+        # heterogeneous batch: six scenes with their own trajectories, every sequence at its own phase of its scene, one
+        # sequence in sixteen cuts to another scene half-way through the timed region (estimation restart)
+        try:
+            S, PF = 6, 12
+            scenes = [[f for f, _, _ in synth.billboard_sequence(w, h, PF, seed=101 + 7 * s, traj_seed=29 + s, **intr)] for s in range(S)]
+            hpool = to_pool([f for sc in scenes for f in sc])
+            n = B * C
+            scene_of = np.arange(n) % S
+            phase = (np.arange(n) // S) % (2 * (PF - 1))
+            cut = (np.arange(n) % 16) == 5
+            kcut = Wm + K // 2
+
+            def hidx(k, s=None):
+                sc = np.where(cut & (k >= kcut), (scene_of + 1) % S, scene_of)
+                fr = np.array([tri(k + p, PF) for p in phase])
+                out = sc * PF + fr
+                return out if s is None else int(out[s])
+            r3 = Replay(edgehip, params, n, hpool, S * PF, hidx, local_rank)
+            r3.ehs[0].set_nav_log(K)
+            dt3, _ = timed_replay(r3, K, Wm)
+            lst = r3.ehs[0].read_nav()
+            kns = np.array([x.kn for x in lst])
+            hetero = {"value": round(n * K / dt3, 1), "unit": "frames/s", "ms_per_step": round(dt3 / K * 1e3, 4), "scenes": S,
+                      "sequences_with_scene_cut": int(cut.sum()), "keylines_min_mean_max": [int(kns.min()), round(float(kns.mean()), 1), int(kns.max())],
+                      "estimation_ok": f"{int(sum(x.estimation_ok for x in lst))}/{n}"}
+            if cpu_legs and oparams is not None:
+                from oracle import oracle
+                hs = sorted({0, 5, n - 1})   # 5: a sequence with the scene cut
+                hframes = [f for sc in scenes for f in sc]
+                logh = r3.ehs[0].read_nav_log_array(Wm, K)
+                hetero["pose_rmse"] = pose_rmse({s: _traj_of_log(logh, s) for s in hs},
+                                                {s: _cpu_traj(oracle, oparams, lambda k, s=s: hframes[hidx(k, s)], Wm, K) for s in hs},
+                                                "reference")
+            r3.close()
+        except Exception as e:
+            hetero = {"value": None, "error": str(e)[:200]}
 
     line = {
-        "metric": "frames/sec (DoG+extract+track+depth) 752x480 EuRoC",
+        "metric": "frames/sec (DoG+extract+track+depth) 752x480 EuRoC" if not tum else
+                  "frames/sec (undistort+DoG+extract+track+depth) 640x480 TUM",
         "value": round(value, 1), "unit": "frames/s", "n_gpus": world, "steps": K, "warmup": Wm,
         "ms_per_step": round(dt / K * 1e3, 4), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
         "dtype": "f32 scale-space / f64 tracker+EKF", "data": "synthetic",
-        "config": {"workload": "full path (configs[2] at configs[1] size): 752x480 synthetic EuRoC-intrinsics "
-                               "sequences, GlobalConfig_EuRoC params, ImuMode=0",
+        "config": {"workload": ("full path (configs[2] at configs[1] size): 752x480 synthetic EuRoC-intrinsics "
+                                "sequences, GlobalConfig_EuRoC params, ImuMode=0") if not tum else
+                               ("BASELINE configs[3]: 640x480 synthetic TUM-intrinsics sequences taken as the distorted camera "
+                                "image, GlobalConfig_desk.txt params, UseUndistort=1 with the EuRoC distortion (SURVEY 8d scene S3), "
+                                "undistortion fused into the stage-A load"),
                    "sequences_per_gpu": B * C, "contexts_per_gpu": C, "sequences_per_launch": B,
                    "stream_overlap": bool(args.overlap),
                    "frames_per_step": B * C * world, "keylines_per_frame": round(kn_mean, 1),
@@ -398,7 +672,13 @@ def main():
                    "algorithmic_MB_per_frame": round(frame_bytes / 1e6, 2),
                    "whole_path_hbm_frac": round(frame_bytes * value / world / 1e9 / HBM_PEAK_GBS, 5)},
         "roofline": roof, "cpu_baseline": cpu, "pose_rmse": pose, "kernel_us_per_step": breakdown,
+        "roofline_kernels": roof_all,
     }
+    if sweep:
+        line["batch_sweep"] = sweep
+        line["single_sequence_ms_per_frame"] = sweep[0]["ms_per_step"]
+    if hetero:
+        line["heterogeneous"] = hetero
     print(json.dumps(line))
     if world > 1:
         dist.barrier()

@@ -201,6 +201,8 @@ class Oracle:
         self._rescale = fn("rescale", d, vp, i, pd, d, u, i)
         self._process = fn("process_frame", i, vp, C.c_void_p, d, C.POINTER(Nav))
         self._cur_slot = fn("cur_slot", i, vp)
+        self._run_sequence = fn("run_sequence", i, vp, C.c_void_p, C.c_ulonglong, C.c_void_p, i, d, d, i, C.c_void_p,
+                                C.c_void_p) if kind == "ref" else None
         self._reset = fn("reset_sequence", None, vp)
         self._depth_reset = fn("depth_reset", None, vp)
         self.ctx = self._create(C.byref(params), nslots)
@@ -346,6 +348,17 @@ class Oracle:
         nav = Nav()
         ran = self._process(self.ctx, rgb.ctypes.data, float(t), C.byref(nav))
         return ran, nav
+
+    def run_sequence(self, pool, idx, t0=0.0, dt=0.05, threads=1, want_navs=False):
+        """(_ref only) Replay frames pool[idx[k]] and time them like the reference runs them: threads=1 stage A + B/C back to
+        back, threads=2 the reference's FirstThr/SecondThread overlap.  Returns (seconds at which each frame was done, navs)."""
+        pool = np.ascontiguousarray(pool, np.uint8)
+        idx = np.ascontiguousarray(idx, np.int32)
+        done = np.zeros(len(idx), np.float64)
+        navs = (Nav * len(idx))() if want_navs else None
+        self._run_sequence(self.ctx, pool.ctypes.data, pool[0].nbytes, idx.ctypes.data, len(idx), t0, dt, threads,
+                           done.ctypes.data, C.cast(navs, C.c_void_p) if want_navs else None)
+        return done, navs
 
     def cur_slot(self):
         return self._cur_slot(self.ctx)

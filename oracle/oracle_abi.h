@@ -142,6 +142,10 @@ void ref_fuse_stereo_depth(void *ctx, int slot);
 void ref_enable_stereo(void *ctx, double ppx, double ppy, double zfx, double zfy, const double t[3], const double R[9],
                        double max_radius);
 int ref_process_frame_stereo(void *ctx, const uint8_t *rgb24, const uint8_t *rgb24_pair, double t, OrcNav *nav);
+/* (_ref only) replay n frames out of a frame pool and time them: threads 1 = stage A + B/C back to back, 2 = the reference's
+   FirstThr / SecondThread overlap; done_s[k] = seconds after the start at which frame k was finished */
+int ref_run_sequence(void *ctx, const uint8_t *pool, unsigned long long frame_bytes, const int *idx, int n, double t0, double dt,
+                     int threads, double *done_s, OrcNav *navs);
 
 /* ---- visualizer wire format: copy_net_keyline / copy_net_keyline_nextid, 15-byte records ---- */
 int ref_copy_net_keyline(void *ctx, int slot, int slot_pair /* -1: none */, void *out, int kl_size, double k_prof);

@@ -15,6 +15,8 @@
 #include <cmath>
 #include <chrono>
 #include <vector>
+#include <atomic>
+#include <thread>
 
 #include "mtracklib/sspace.h"
 #include "mtracklib/edge_finder.h"
@@ -450,23 +452,42 @@ double ref_rescale(void *ctx, int slot, double *RKp, double s_rho_min, unsigned 
 }
 
 // One frame through FirstThr + SecondThread (ImuMode==0).  Returns 1 when stage B/C ran (frame>=1).
+// FirstThr's part of a frame (rebvo_first_t.cpp:259-290): stage A of frame number `frame` into its ring slot.  What
+// SecondThread reports of it is parked with the slot (in the reference both threads see the same PipeBuffer).
+struct ARec { int kn; double tresh; float retuned; double dtp0; };
+static ARec g_unused_arec;
+static void frame_a(Ctx *c, int frame, const uint8_t *rgb24, ARec *rec) {
+    const int sn = frame % c->ring;
+    const double t0 = now();
+    ref_stage_a(c, sn, rgb24, &c->tresh, &c->l_kl_num);
+    if (c->rig && c->pair_rgb) ref_stage_a(c, c->ring, c->pair_rgb, &c->tresh, &c->l_kl_num);   // rebvo_first_t.cpp:275-290
+    rec->dtp0 = now() - t0;
+    rec->kn = c->slots[sn].ef->KNum();
+    rec->tresh = c->tresh;
+    rec->retuned = c->slots[sn].ef->getThresh();
+}
+static int frame_bc(Ctx *c, const ARec &rec, double t, OrcNav *nav);
+
 int ref_process_frame(void *ctx, const uint8_t *rgb24, double t, OrcNav *nav) {
     Ctx *c = (Ctx *)ctx;
+    ARec rec;
+    frame_a(c, c->frame, rgb24, &rec);
+    return frame_bc(c, rec, t, nav);
+}
+
+// SecondThread's part (rebvo_second_t.cpp:128-629, ImuMode == 0): frame c->frame against frame c->frame - 1.
+static int frame_bc(Ctx *c, const ARec &rec, double t, OrcNav *nav) {
     const OrcParams &p = c->p;
     const int ns = c->ring;
     const int sn = c->frame % ns, so = (c->frame + ns - 1) % ns;
     memset(nav, 0, sizeof(*nav));
-
-    double t0 = now();
-    ref_stage_a(ctx, sn, rgb24, &c->tresh, &c->l_kl_num);
-    if (c->rig && c->pair_rgb) ref_stage_a(ctx, c->ring, c->pair_rgb, &c->tresh, &c->l_kl_num);   // rebvo_first_t.cpp:275-290
-    nav->dtp0 = now() - t0;
+    nav->dtp0 = rec.dtp0;
     Slot &nb = c->slots[sn];
     nav->frame = c->frame;
     nav->t = t;
-    nav->kn = nb.ef->KNum();
-    nav->tresh = c->tresh;
-    nav->retuned_thresh = nb.ef->getThresh();
+    nav->kn = rec.kn;
+    nav->tresh = rec.tresh;
+    nav->retuned_thresh = rec.retuned;
 
     if (c->frame == 0) {  // "dummy processing of the first frame" rebvo_second_t.cpp:108-121
         c->frame++;
@@ -550,6 +571,45 @@ int ref_process_frame(void *ctx, const uint8_t *rgb24, double t, OrcNav *nav) {
     c->frame++;
     c->t_prev = t;
     return 1;
+}
+
+// Replay n frames (frame k = pool + idx[k] * frame_bytes, time stamp t0 + k * dt) and time them like the reference runs
+// them: threads == 1: stage A and stages B/C back to back on the calling thread; threads == 2: the reference's own
+// threading — FirstThr (stage A of frame k+1) next to SecondThread (B/C of frame k), rebvo_first_t.cpp:134 /
+// rebvo_second_t.cpp:102, coupled through the frame ring like Pipeline<PipeBuffer> (a slot is handed on when its
+// predecessor stage released it).  done_s[k] = seconds since the start at which frame k left stage B/C.
+int ref_run_sequence(void *ctx, const uint8_t *pool, unsigned long long frame_bytes, const int *idx, int n, double t0, double dt,
+                     int threads, double *done_s, OrcNav *navs) {
+    Ctx *c = (Ctx *)ctx;
+    std::vector<ARec> recs(n);
+    OrcNav scratch;
+    const double start = now();
+    if (threads <= 1) {
+        for (int k = 0; k < n; k++) {
+            frame_a(c, c->frame, pool + (size_t)idx[k] * frame_bytes, &recs[k]);
+            frame_bc(c, recs[k], t0 + k * dt, navs ? &navs[k] : &scratch);
+            done_s[k] = now() - start;
+        }
+        return n;
+    }
+    const int first = c->frame;
+    std::atomic<int> a_done(0), bc_done(0);
+    std::thread first_thr([&]() {
+        for (int k = 0; k < n; k++) {
+            // the slot of frame k still serves as the "old" frame of k - ring + 1: wait for SecondThread
+            while (k - bc_done.load(std::memory_order_acquire) > c->ring - 2) std::this_thread::yield();
+            frame_a(c, first + k, pool + (size_t)idx[k] * frame_bytes, &recs[k]);
+            a_done.store(k + 1, std::memory_order_release);
+        }
+    });
+    for (int k = 0; k < n; k++) {
+        while (a_done.load(std::memory_order_acquire) <= k) std::this_thread::yield();
+        frame_bc(c, recs[k], t0 + k * dt, navs ? &navs[k] : &scratch);
+        bc_done.store(k + 1, std::memory_order_release);
+        done_s[k] = now() - start;
+    }
+    first_thr.join();
+    return n;
 }
 
 }  // extern "C"

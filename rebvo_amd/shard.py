@@ -37,16 +37,71 @@ def nav_records(navs, rank, seq_ids):
     return rec
 
 
-def gather_records(rec, dst=0):
+def gather_records(rec, dst=0, group=None):
     """Gather equally-shaped record tensors to `dst` (torch.distributed must be initialised).
 
     Returns [world, ...] on dst, None elsewhere.  Tensors live on the GPU for nccl(=RCCL), on the host for gloo."""
     import torch
     import torch.distributed as dist
-    world, rank = dist.get_world_size(), dist.get_rank()
+    world, rank = dist.get_world_size(group), dist.get_rank()
     t = torch.as_tensor(rec)
-    if dist.get_backend() == "nccl":
+    if dist.get_backend(group) == "nccl":
         t = t.cuda()
     out = [torch.empty_like(t) for _ in range(world)] if rank == dst else None
-    dist.gather(t, out, dst=dst)
+    dist.gather(t, out, dst=dst, group=group)
     return torch.stack(out).cpu().numpy() if rank == dst else None
+
+
+class NavMover:
+    """Ships the per-frame nav records of a replay to rank 0 while the replay goes on (the
+    payload is ~0.5 KB per frame, i.e. pure latency, so it must stay off the critical path).
+
+    A worker thread takes blocks of steps, reads them out of the context's device-side nav log (a small copy ordered
+    after the frames it covers; the thread waits for it, the thread that enqueues frames does not), and gathers them to
+    rank 0 over its OWN process group / communicator (RCCL for backend "nccl": its own stream, never interleaved with the
+    collectives of the main thread).  At most two blocks are in flight (double buffering): `post` only blocks when the
+    transport falls two blocks behind.  Every rank must post the same blocks in the same order."""
+
+    def __init__(self, world, rank, backend=None, dst=0, device=None):
+        import queue
+        import threading
+        import torch.distributed as dist
+        self.rank, self.dst, self.device = rank, dst, device
+        self.group = dist.new_group(ranks=list(range(world)), backend=backend)   # collective: all ranks call it
+        self.blocks = []                      # on dst: one [world, steps, nseq, NAV_FIELDS] array per posted block
+        self.error = None
+        self._q = queue.Queue(maxsize=2)
+        self._t = threading.Thread(target=self._run, daemon=True)
+        self._t.start()
+
+    def post(self, log_reader, first, count, seq_ids):
+        """log_reader.read_nav_log_array(first, count) -> structured array [count, nseq] (EdgeHip does)."""
+        if self.error is not None:
+            raise self.error
+        self._q.put((log_reader, first, count, list(seq_ids)))
+
+    def _run(self):
+        if self.device is not None:           # the current device is per thread
+            import torch
+            torch.cuda.set_device(self.device)
+        while True:
+            item = self._q.get()
+            if item is None:
+                return
+            try:
+                reader, first, count, seq_ids = item
+                rec = nav_records(reader.read_nav_log_array(first, count), self.rank, seq_ids)
+                out = gather_records(rec, dst=self.dst, group=self.group)
+                if out is not None:
+                    self.blocks.append(out)
+            except Exception as e:            # surfaces in finish(); the replay itself must not be torn down by the transport
+                self.error = e
+                return
+
+    def finish(self):
+        """Waits until every posted block has arrived; returns the blocks (on dst) in posting order."""
+        self._q.put(None)
+        self._t.join()
+        if self.error is not None:
+            raise self.error
+        return self.blocks

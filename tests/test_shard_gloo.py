@@ -81,3 +81,68 @@ def test_nav_records_from_structured_log_equals_object_path():
     b = shard.nav_records(rows, 3, seq_ids)
     assert a.shape == (K, B, shard.NAV_FIELDS) and np.array_equal(a, b)
     assert np.array_equal(a[..., 13], np.tile(np.arange(100, 100 + B), (K, 1))) and (a[..., 14] == 3).all()
+
+
+class _FakeLog:
+    """What bench.py hands the NavMover: something with EdgeHip.read_nav_log_array(first, count)."""
+
+    def __init__(self, rank, nseq):
+        self.rank, self.nseq = rank, nseq
+
+    def read_nav_log_array(self, first, count):
+        from rebvo_amd import edgehip
+        arr = np.zeros((count, self.nseq), dtype=edgehip.NAV_DTYPE)
+        arr["frame"] = np.arange(first, first + count)[:, None]
+        arr["kn"] = 1000 * self.rank + np.arange(self.nseq)[None, :]
+        arr["Pos"][:, :, 0] = self.rank
+        return arr
+
+
+def _mover_worker(rank, world, port, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    B, K, Wm = 3, 10, 5
+    mover = shard.NavMover(world, rank, "gloo")
+    log = _FakeLog(rank, B)
+    blk, posted = max(1, K // 4), 0
+    dist.barrier()
+    for k in range(Wm, Wm + K):                     # bench.py's posting pattern (N > 1 branch)
+        done = k - Wm + 1
+        if done % blk == 0 or done == K:
+            mover.post(log, Wm + posted, done - posted, [rank * B + s for s in range(B)])
+            posted = done
+    blocks = mover.finish()
+    t = torch.tensor([1.0 + rank])
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)        # the default group stays usable next to the mover's own
+    dist.barrier()
+    if rank == 0:
+        q.put((blocks, float(t)))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_nav_mover_world4_gloo_delivers_every_step_once():
+    """bench.py's N > 1 control flow over 4 ranks: blocks of steps posted while the replay goes on, gathered on a second
+    process group by the mover's thread, the default group free for the timing reduction."""
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    world = 4
+    procs = [ctx.Process(target=_mover_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    blocks, tmax = q.get(timeout=180)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert tmax == 4.0
+    allrec = np.concatenate(blocks, axis=1)         # [world, K, B, fields]
+    assert allrec.shape == (world, 10, 3, shard.NAV_FIELDS)
+    for r in range(world):
+        assert np.array_equal(allrec[r, :, 0, 0], np.arange(5, 15))          # every timed step once, in order
+        assert np.all(allrec[r, :, :, 14] == r) and np.all(allrec[r, :, :, 4] == r)
+        assert sorted(set(allrec[r, 0, :, 13].tolist())) == [3 * r, 3 * r + 1, 3 * r + 2]
