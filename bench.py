@@ -112,8 +112,54 @@ def fetch_calibration():
         return {"stream": 2.0}, "MI355X_MICROARCH.md (gfx950: FETCH_SIZE x 2, calibrated for wide coalesced streams only)"
 
 
-# which calibration entry fits a kernel group's reads (default: wide coalesced streams)
-GROUP_FETCH_PATTERN = {"B.try_velrot": "gather_mix", "C.directed_matching": "gather_mix"}
+# Kernel groups whose reads are a mix of coalesced streams and small random gathers: bytes per KeyLine they read as
+# streams.  FETCH_SIZE counts a request of a wide stream at half its bytes and a small random read at the 64 bytes it
+# moves (profiles/fetch_calibration.json), so the counter R of such a kernel is stream/f_stream + gather/f_gather and the
+# bytes it really moved are  stream + f_gather * (R - stream / f_stream)  with the stream bytes known exactly.
+GROUP_STREAM_BYTES_PER_KL = {"B.try_velrot": 8 + 4 + 8 + 8 + 8 + 4 + 8}   # s_rho, m_num, p_m, rho, m_m, n_m, residual in
+
+
+def pmc_counters(group, nseq):
+    """(FETCH_SIZE, WRITE_SIZE) in bytes per launch of `group`, raw, from the committed PMC passes; None if unavailable."""
+    path = os.path.join(ROOT, PMC_FILE)
+    if not os.path.exists(path):
+        return None
+    js = json.load(open(path))
+    if js.get("_nseq") != nseq:
+        return None
+    ft = wt = 0.0
+    found = False
+    for sub in GROUP_KERNELS.get(group, []):
+        f = w = n = 0.0
+        for name, c in js.items():
+            if not isinstance(c, dict) or not re.search(r"\b" + sub + r"\b", name):
+                continue
+            if "FETCH_SIZE" in c and "WRITE_SIZE" in c:
+                k = c["FETCH_SIZE"]["calls"]
+                f += c["FETCH_SIZE"]["mean"] * k
+                w += c["WRITE_SIZE"]["mean"] * k
+                n += k
+        if n:
+            ft += f / n * 1024.0
+            wt += w / n * 1024.0
+            found = True
+    return (ft, wt) if found else None
+
+
+def calibrated_traffic(group, nseq, kn, calib):
+    """HBM bytes per launch of `group` from the committed counters and the calibration of profiles/fetch_calibration.json
+    (see GROUP_STREAM_BYTES_PER_KL); (bytes, description of the formula) or (None, None)."""
+    c = pmc_counters(group, nseq)
+    if c is None:
+        return None, None
+    fetch, write = c
+    fs, fg, fw = calib.get("stream", 2.0), calib.get("gather16", 1.0), calib.get("write", 1.0)
+    if group in GROUP_STREAM_BYTES_PER_KL and "gather16" in calib:
+        stream = GROUP_STREAM_BYTES_PER_KL[group] * kn * nseq
+        gather = max(0.0, fetch - stream / fs) * fg
+        return int(stream + gather + fw * write), (f"streams {stream / 1e6:.0f} MB (known) + {fg:.2f} x (FETCH_SIZE - streams / {fs:.2f}) "
+                                                   f"= {gather / 1e6:.0f} MB of gathers + {fw:.2f} x WRITE_SIZE")
+    return int(fs * fetch + fw * write), f"{fs:.2f} x FETCH_SIZE + {fw:.2f} x WRITE_SIZE (coalesced streams)"
 
 
 def pmc_traffic(group, nseq, factor=2.0):
@@ -513,18 +559,17 @@ def main():
     value = B * C * world * K / dt
     # ---- roofline of the dominant kernel group, and of all of them ----
     calib, calib_src = fetch_calibration()
-    def fetch_factor(group):
-        return calib.get(GROUP_FETCH_PATTERN.get(group, "stream"), calib.get("stream", 2.0))
     roof = None
     if dominant and dom_calls:
         per_launch_s = dom_ms * 1e-3 / dom_calls
         abytes = algorithmic_bytes(dominant, kn_mean, n_px, radius, B)
         ach = abytes / per_launch_s / 1e9 if per_launch_s > 0 else 0.0
-        traffic = pmc_traffic(dominant, B, fetch_factor(dominant))
+        traffic, formula = calibrated_traffic(dominant, B, kn_mean, calib)
         roof = {"bound": "hbm", "kernel": dominant, "achieved": round(ach, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": round(ach / HBM_PEAK_GBS, 5), "traffic": traffic,
                 "traffic_source": PMC_FILE + " (rocprofv3 --pmc passes of this command committed with the code; not measured in this run)",
-                "traffic_calibration": {"fetch_factor": round(fetch_factor(dominant), 3), "source": calib_src},
+                "traffic_calibration": {"factors_true_over_reported": {k: round(v, 3) for k, v in calib.items()}, "formula": formula,
+                                        "source": calib_src},
                 "launch_us": round(per_launch_s * 1e6, 2), "algorithmic_bytes_per_launch": int(abytes),
                 "launches_timed": dom_calls}
     roof_all = {}
@@ -532,7 +577,7 @@ def main():
         ab = algorithmic_bytes(g, kn_mean, n_px, radius, B)
         if ab and calls:
             per = ms * 1e-3 / calls
-            tr = pmc_traffic(g, B, fetch_factor(g))
+            tr, _ = calibrated_traffic(g, B, kn_mean, calib)
             roof_all[g] = {"launch_us": round(per * 1e6, 1), "launches_per_step": calls // prof_steps,
                            "achieved_GBs": round(ab / per / 1e9, 1), "frac": round(ab / per / 1e9 / HBM_PEAK_GBS, 4),
                            "traffic_over_algorithmic": round(tr / ab, 2) if tr else None}

@@ -396,14 +396,7 @@ __global__ __launch_bounds__(256) void k_tvr_prepare(const KlSoA *kls, const int
     if (i == 0) seqs[seq].kn_old = kn;
     if ((i % kTvrBlock) == 0 && i / kTvrBlock < nblk) carry0[(size_t)seq * nblk + i / kTvrBlock] = 0.0;
     if (i >= kn) return;
-    const KlSoA &k = kls[seq];
-    const float2 pm = k.p_m[i];
-    const double z = 1 / k.rho[i];
-    const double pz_zf = (1 / zfm) * z;
-    double *p = P0 + (size_t)seq * 3 * cap;
-    p[i] = pz_zf * (double)pm.x;
-    p[cap + i] = pz_zf * (double)pm.y;
-    p[2 * cap + i] = z;
+    // (P0 itself is not stored any more: k_try_velrot / k_try_vel rebuild it from p_m and rho, 16 B instead of 24 B per read)
     resid0[(size_t)seq * cap + i] = 0.0;  // "Init residuals", global_tracker.cpp:625
 }
 
@@ -551,13 +544,26 @@ __global__ __launch_bounds__(kTvrThreads) void k_try_velrot(TvrArgs a) {
         int status = 0;
         double fi = 0;
         if (ikl < kn) {
+            // Everything the KeyLine streams in is requested here, before the first use: the skip test, the projection, the
+            // in-image test and the two gathers are a chain of dependent memory round trips, and with the loads inside the
+            // branches each level of the chain paid its own.  (The ~10 % of KeyLines the tests drop load 36 B in vain.)
             s_rho = ko.s_rho[ikl];
+            const int32_t mnum = ko.m_num[ikl];
+            const float2 pm0 = ko.p_m[ikl];
+            const double rho0 = ko.rho[ikl];
+            const float2 klm = ko.m_m[ikl];
+            const float knm = ko.n_m[ikl];
+            double rprev = 0;
+            if (REWEIGHT) rprev = rin[ikl];
             const uint32_t fc = a.framecount[seq];
             const uint32_t mthr = a.match_num_thresh < fc ? a.match_num_thresh : fc;
-            const bool skip = s_rho > sq->s_rho_min_eval || (uint32_t)ko.m_num[ikl] < mthr;  // int vs uint compare
+            const bool skip = s_rho > sq->s_rho_min_eval || (uint32_t)mnum < mthr;  // int vs uint compare
             if (!skip) {
-                const double *p0 = a.P0 + (size_t)seq * 3 * a.cap;
-                const double sx = p0[ikl], sy = p0[a.cap + ikl], sz = p0[2 * a.cap + ikl];
+                // KltoI3PMatrix + ProyI3Pto3PMatrix (global_tracker.cpp:553-570, ne10wrapper.h:414-424): P0 = (x z / zf, y z / zf, z),
+                // z = 1 / rho — from p_m and rho (16 B) instead of a stored P0 (24 B): one fp64 division for a third less traffic
+                const double sz = 1 / rho0;
+                const double pz_zf0 = (1 / a.zfm) * sz;
+                const double sx = pz_zf0 * (double)pm0.x, sy = pz_zf0 * (double)pm0.y;
                 const double *R = sq->Rt, *V = sq->Vt;
                 // Ne10::SE3on3PMatrix: dst = R(i,0)*x; dst += R(i,1)*y; dst += R(i,2)*z; dst = V + dst
                 ptx = R[0] * sx; ptx += R[1] * sy; ptx += R[2] * sz; ptx = V[0] + ptx;
@@ -572,7 +578,6 @@ __global__ __launch_bounds__(kTvrThreads) void k_try_velrot(TvrArgs a) {
                 const int x = x86_cvttsd2si(px + 0.5), y = x86_cvttsd2si(py + 0.5);
                 double weight = 1;
                 if (REWEIGHT) {
-                    double rprev = rin[ikl];
                     if (is_carry(rprev)) rprev = carry_in_prev;
                     if (fabs(rprev) > a.k_huber) weight = a.k_huber / fabs(rprev);
                 }
@@ -583,8 +588,6 @@ __global__ __launch_bounds__(kTvrThreads) void k_try_velrot(TvrArgs a) {
                 } else {
                     status = 3;
                     fm = a.max_r;
-                    const float2 klm = ko.m_m[ikl];
-                    const float knm = ko.n_m[ikl];
                     // temporarily z-rotated gradient, stored back into a float Point2DF (:386-388)
                     const float rmx = (float)(sq->RM[0] * (double)klm.x + sq->RM[1] * (double)klm.y);
                     const float rmy = (float)(sq->RM[2] * (double)klm.x + sq->RM[3] * (double)klm.y);

@@ -4,7 +4,7 @@
 cd "$GRAFT_REPO_ROOT"
 for v in A B A B; do
   cp tools/experiments/bin/libedgehip_$v.so rebvo_amd/lib/libedgehip.so
-  python bench.py --steps 10 --warmup 3 > gpurun_out/ab_$v.json 2>gpurun_out/ab_$v.err
+  python bench.py --steps 10 --warmup 4 --no-extras --cpu-frames 0 > gpurun_out/ab_$v.json 2>gpurun_out/ab_$v.err
   python - <<PY
 import json
 d=json.loads(open("gpurun_out/ab_$v.json").read().strip().splitlines()[-1])
