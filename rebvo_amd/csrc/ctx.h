@@ -226,6 +226,8 @@ struct edgehip_ctx {
     int32_t *bin_cnt;      // [B][256] KeyLines binned per field tile
     int32_t *bins;         // [B][256][CAP] KeyLine ids per field tile (allocated for the tiles in use)
     int nblk_tvr;
+    int persist_lm_max;    // batches up to this many sequences fuse every TryVelRot evaluation with the LM step after it (EDGEHIP_PERSIST_LM, 0 = never)
+    unsigned *sync_cnt;    // [B] per-sequence block tickets of k_try_velrot_lm (0 between launches)
     unsigned long long *fwd_key;  // [B][CAP] forward-match arbitration keys
     int32_t *fwd_win;      // [B][CAP]
     double *rs_tmp;        // [B][2][CAP] regularised (rho, s_rho) ping-pong

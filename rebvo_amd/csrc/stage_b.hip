@@ -506,8 +506,7 @@ struct TvrArgs {
 __device__ __forceinline__ bool is_carry(double v) { return __double_as_longlong(v) == (long long)resid_carry_bits(); }
 
 template <bool REWEIGHT, bool PROCJF, bool GREC>
-__global__ __launch_bounds__(kTvrThreads) void k_try_velrot(TvrArgs a) {
-    const int seq = blockIdx.z, blk = blockIdx.x, tid = threadIdx.x;
+__device__ __forceinline__ void tvr_body(const TvrArgs &a, const int seq, const int blk, const int tid) {
     const int lane = tid & 63, wave = tid >> 6;
     SeqDev *sq = a.seq + seq;
     const int kn = a.kn_old[seq];
@@ -732,6 +731,11 @@ __global__ __launch_bounds__(kTvrThreads) void k_try_velrot(TvrArgs a) {
         for (int wv = 1; wv < NW; wv++) v += s_red[wv][tid];   // fixed order: deterministic
         a.partials[((size_t)seq * a.nblk + blk) * kNumSums + tid] = v;
     }
+}
+
+template <bool REWEIGHT, bool PROCJF, bool GREC>
+__global__ __launch_bounds__(kTvrThreads) void k_try_velrot(TvrArgs a) {
+    tvr_body<REWEIGHT, PROCJF, GREC>(a, blockIdx.z, blockIdx.x, threadIdx.x);
 }
 
 // ---------------------------------------------------------------------------------------------------
@@ -983,9 +987,20 @@ struct LmArgs {
     int init_type;
 };
 
-__global__ __launch_bounds__(64) void k_lm_step(LmArgs a) {
-    const int seq = blockIdx.x;
-    const int lane = threadIdx.x;
+template <bool WAVE_ONLY>
+__device__ __forceinline__ void lm_sync() {
+    if (WAVE_ONLY) {
+        __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");   // LDS traffic of one wave is in order; keep the compiler from moving it
+        __builtin_amdgcn_wave_barrier();
+    } else {
+        __syncthreads();
+    }
+}
+
+// One wave per sequence.  WAVE_ONLY: the caller is a single wave of a larger workgroup (k_minimizer_persistent), so the
+// points where the lanes hand data to each other through LDS are wave-level fences instead of workgroup barriers.
+template <bool WAVE_ONLY>
+__device__ __forceinline__ void lm_body(const LmArgs &a, const int seq, const int lane) {
     const unsigned ops = a.ops;
     // The sequence state is staged in LDS for the whole step: the serial LM logic touches it hundreds of
     // times and a global round trip per access was the dominant cost of this kernel.
@@ -994,7 +1009,7 @@ __global__ __launch_bounds__(64) void k_lm_step(LmArgs a) {
     __shared__ unsigned long long s_state[kWords];
     unsigned long long *gstate = reinterpret_cast<unsigned long long *>(a.seq + seq);
     for (int i = lane; i < kWords; i += 64) s_state[i] = gstate[i];
-    __syncthreads();
+    lm_sync<WAVE_ONLY>();
     SeqDev *sq = reinterpret_cast<SeqDev *>(s_state);
     const int kn = sq->kn_old;
     if (ops & LM_BEGIN) {
@@ -1010,7 +1025,7 @@ __global__ __launch_bounds__(64) void k_lm_step(LmArgs a) {
             }
             sq->s_rho_min_eval = sq->pub.s_rho_q;
         }
-        __syncthreads();
+        lm_sync<WAVE_ONLY>();
     }
     if (kn <= 0) {  // Minimizer_RV returns immediately on an empty list (global_tracker.cpp:597-598)
         for (int i = lane; i < kWords; i += 64) gstate[i] = s_state[i];
@@ -1037,7 +1052,7 @@ __global__ __launch_bounds__(64) void k_lm_step(LmArgs a) {
         // per-block last residuals of the buffer that was just written -> LDS
         const double *bl = a.block_last + (size_t)seq * a.nblk;
         for (int b = lane; b < nblk_used; b += 64) s_bl[b & 255] = bl[b];
-        __syncthreads();
+        lm_sync<WAVE_ONLY>();
         if (lane < kNumSums) {
             double t = 0;
             t = s_part[0][lane] + s_part[1][lane];
@@ -1054,7 +1069,7 @@ __global__ __launch_bounds__(64) void k_lm_step(LmArgs a) {
             }
         }
     }
-    __syncthreads();
+    lm_sync<WAVE_ONLY>();
     if (lane == 0) {
     // The serial LM logic runs on register copies of the hot state (fully unrolled 6x6 algebra): with the state
     // left in LDS every one of its ~1000 dependent accesses paid an LDS round trip (~25 us per step).
@@ -1228,8 +1243,38 @@ __global__ __launch_bounds__(64) void k_lm_step(LmArgs a) {
     sq->F = F; sq->Fnew = Fnew; sq->F0 = F0; sq->u = u; sq->v = v;
     sq->eff_steps = eff_steps; sq->res_cur = res_cur; sq->res_new = res_new; sq->res_t = res_t;
     }  // lane 0
-    __syncthreads();
+    lm_sync<WAVE_ONLY>();
     for (int i = lane; i < kWords; i += 64) gstate[i] = s_state[i];
+}
+
+__global__ __launch_bounds__(64) void k_lm_step(LmArgs a) { lm_body<false>(a, blockIdx.x, threadIdx.x); }
+
+// ---------------------------------------------------------------------------------------------------
+// k_try_velrot_lm: an evaluation and the LM step that follows it in ONE launch, for small batches.  A single camera (or
+// one sequence per GPU, BASELINE config 5) is bound by the chain of dependent launches of the minimiser (evaluate -> LM
+// step -> evaluate ..., ~25 of them, ~8-10 us from one dependent kernel to the next whatever it does; HIP graphs do not
+// remove that).  The block that finishes a sequence's evaluation last (a counter per sequence, the usual fence + atomic
+// hand-over) runs the step in its first wave: half the launches.  Same code (tvr_body / lm_body), same schedule, same
+// reduction order as the separate kernels, so the results are identical bit for bit.  Only for small batches: the LM
+// step needs ~230 vector registers, which would cut the occupancy the bandwidth-bound evaluation lives on.
+// (A fully persistent minimiser — all blocks resident, meeting at a device-memory barrier between evaluations — was
+// measured slower than the launch chain: agent-scope fences between the XCDs' L2s at every barrier, 386 vs 356 us.)
+// ---------------------------------------------------------------------------------------------------
+template <bool REWEIGHT, bool PROCJF, bool GREC>
+__global__ __launch_bounds__(kTvrThreads) void k_try_velrot_lm(TvrArgs a, LmArgs l, unsigned *cnt) {
+    const int seq = blockIdx.z, tid = threadIdx.x;
+    tvr_body<REWEIGHT, PROCJF, GREC>(a, seq, blockIdx.x, tid);
+    __shared__ int s_last;
+    __syncthreads();
+    if (tid == 0) {
+        __threadfence();                                           // this block's partials are visible before its ticket is
+        s_last = atomicAdd(&cnt[seq], 1u) == gridDim.x - 1;
+    }
+    __syncthreads();
+    if (!s_last || tid >= 64) return;
+    __threadfence();                                               // see the partials of the blocks that came before
+    lm_body<true>(l, seq, tid);
+    if (tid == 0) cnt[seq] = 0;                                    // for the next launch (stream order)
 }
 
 // ---------------------------------------------------------------------------------------------------
@@ -1613,11 +1658,41 @@ int minimizer_enqueue(edgehip_ctx *c, int slot_new, int slot_old, int fc_index) 
     const int I = p.tracker_init_iter_num, M = p.tracker_iter_num;
     const int total_evals = (p.tracker_init_type >= 2 ? 2 * (1 + (I > 0 ? I : 0)) : 0) + 1 + (M > 0 ? M : 0);
     int evals = 0;
+    // Small batches: an evaluation is held back until the LM step that follows it is known, and both go out as one launch.
+    const bool fuse = c->persist_lm_max > 0 && c->plan.nseq <= c->persist_lm_max;
+    struct { bool on, rw, jf; int write_mid; } held = {false, false, false, 0};
     auto eval = [&](bool rw, bool jf) -> int {
         evals++;
+        if (fuse) {
+            held = {true, rw, jf, evals == total_evals};
+            return 0;
+        }
         TvrArgs a = make_tvr_args(c, slot_new, slot_old, p.tracker_match_thresh, p.reweight_distance, p.match_num_thresh,
                                   evals == total_evals);
         return launch_tvr(c, a, rw, jf);
+    };
+    auto launch_lm = [&](edgehip_ctx *cc, int sn, unsigned ops) -> int {   // shadows the free function
+        if (!held.on) return edgehip::launch_lm(cc, sn, ops);
+        held.on = false;
+        ProfScope ps(c, PROF_B_MINIMIZER);
+        TvrArgs a = make_tvr_args(c, slot_new, slot_old, p.tracker_match_thresh, p.reweight_distance, p.match_num_thresh, held.write_mid);
+        LmArgs l;
+        l.seq = c->seq; l.partials = c->partials; l.block_last = c->block_last; l.resid_carry = c->resid_carry;
+        l.framecount = c->framecount + (size_t)c->fc_index * c->plan.nseq;
+        l.nblk = c->nblk_tvr; l.nseq = c->plan.nseq; l.ops = ops; l.init_type = c->p.tracker_init_type;
+        dim3 g(c->nblk_tvr, 1, c->plan.nseq), b(kTvrThreads);
+#define EH_TVLM(RW, JF)                                                                                                     \
+    do {                                                                                                                   \
+        if (a.use_grec) hipLaunchKernelGGL((k_try_velrot_lm<RW, JF, true>), g, b, 0, c->stream, a, l, c->sync_cnt);        \
+        else hipLaunchKernelGGL((k_try_velrot_lm<RW, JF, false>), g, b, 0, c->stream, a, l, c->sync_cnt);                  \
+    } while (0)
+        if (held.rw && held.jf) EH_TVLM(true, true);
+        else if (held.rw) EH_TVLM(true, false);
+        else if (held.jf) EH_TVLM(false, true);
+        else EH_TVLM(false, false);
+#undef EH_TVLM
+        EH_LAUNCH_CHECK();
+        return 0;
     };
 #define EH_TRY(x) if ((e = (x)) != 0) return e
     if (p.tracker_init_type >= 2) {

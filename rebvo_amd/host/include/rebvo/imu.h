@@ -23,6 +23,7 @@
 #include <vector>
 
 #include "rebvo/linalg.h"
+#include "rebvo/imu_filters.h"   // BiasCorrect, ScaleEstimator (host + device)
 
 namespace rebvo {
 
@@ -73,34 +74,6 @@ public:
     std::pair<int, int> SeachByTimeStamp(double tstart, double tend);
     IntegratedImuData GrabAndIntegrate(double tstart, double tend);
     double SampleTime() const { return tsample; }
-};
-
-namespace imufilter {
-// edge_tracker::BiasCorrect: fuse the visual roto-translation (X, Wx) with the gyro prior; Gb/Wb = bias and its
-// information, Rg / Rb = gyro measurement / bias random-walk covariances.  X, Wx, Gb, Wb are in/out.
-void BiasCorrect(la::Vec<6> &X, la::Mat<6, 6> &Wx, la::Vec<3> &Gb, la::Mat<3, 3> &Wb, const la::Mat<3, 3> &Rg,
-                 const la::Mat<3, 3> &Rb);
-}  // namespace imufilter
-
-class ScaleEstimator {
-    // histories (function-local statics in the reference)
-    la::Vec<3> V = la::Vec<3>::zeros(), V0 = la::Vec<3>::zeros(), V1 = la::Vec<3>::zeros(), V2 = la::Vec<3>::zeros(),
-               V3 = la::Vec<3>::zeros();
-    double T[5] = {0, 0, 0, 0, 0};
-    double Dt[4] = {0, 0, 0, 0};
-    la::Vec<3> A = la::Vec<3>::zeros(), A0 = la::Vec<3>::zeros(), A1 = la::Vec<3>::zeros(), A2 = la::Vec<3>::zeros();
-
-public:
-    // least-squares slope of the last five (rotated) visual velocities: the visual acceleration
-    void EstAcelLsq4(const la::Vec<3> &vel, la::Vec<3> &acel, const la::Mat<3, 3> &R, const double &dt);
-    // mean of the last four (rotated) accelerometer readings
-    void MeanAcel4(const la::Vec<3> &s_acel, la::Vec<3> &acel, const la::Mat<3, 3> &R);
-    // Bayesian scale / gravity / visual-bias filter: linear prior, 20 Gauss-Newton steps on the 11-row problem
-    static double estKaGMEKBias(const la::Vec<3> &s_acel, const la::Vec<3> &f_acel, double kP, la::Mat<3, 3> Rot,
-                                la::Vec<7> &X, la::Mat<7, 7> &P, const la::Mat<3, 3> &Qg, const la::Mat<3, 3> &Qrot,
-                                const la::Mat<3, 3> &Qbias, const double &QKp, const double &Rg, const la::Mat<3, 3> &Rs,
-                                const la::Mat<3, 3> &Rf, la::Vec<3> &g_est, la::Vec<3> &b_est, const la::Mat<6, 6> &Wvw,
-                                la::Vec<6> &Xvw, double g_gravit);
 };
 
 }  // namespace rebvo

@@ -10,24 +10,33 @@
 
 #include <cmath>
 
+// The same header serves the host library (g++) and the device code of libedgehip (hipcc): the batched IMU branch runs these
+// filters on the GPU, one thread per sequence.
+#if defined(__HIPCC__)
+#include <hip/hip_runtime.h>
+#define REBVO_HD __host__ __device__
+#else
+#define REBVO_HD
+#endif
+
 namespace rebvo {
 namespace la {
 
 template <int N>
 struct Vec {
     double v[N];
-    double &operator[](int i) { return v[i]; }
-    const double &operator[](int i) const { return v[i]; }
-    static Vec zeros() { Vec r; for (int i = 0; i < N; i++) r.v[i] = 0; return r; }
+    REBVO_HD double &operator[](int i) { return v[i]; }
+    REBVO_HD const double &operator[](int i) const { return v[i]; }
+    REBVO_HD static Vec zeros() { Vec r; for (int i = 0; i < N; i++) r.v[i] = 0; return r; }
 };
 
 template <int R, int C>
 struct Mat {
     double a[R * C];
-    double &operator()(int r, int c) { return a[r * C + c]; }
-    const double &operator()(int r, int c) const { return a[r * C + c]; }
-    static Mat zeros() { Mat m; for (int i = 0; i < R * C; i++) m.a[i] = 0; return m; }
-    static Mat identity(double s = 1) {
+    REBVO_HD double &operator()(int r, int c) { return a[r * C + c]; }
+    REBVO_HD const double &operator()(int r, int c) const { return a[r * C + c]; }
+    REBVO_HD static Mat zeros() { Mat m; for (int i = 0; i < R * C; i++) m.a[i] = 0; return m; }
+    REBVO_HD static Mat identity(double s = 1) {
         Mat m = zeros();
         for (int i = 0; i < (R < C ? R : C); i++) m(i, i) = s;
         return m;
@@ -35,69 +44,69 @@ struct Mat {
 };
 
 // ---- element-wise -------------------------------------------------------------------------------------------
-template <int N> inline Vec<N> operator+(const Vec<N> &a, const Vec<N> &b) { Vec<N> r; for (int i = 0; i < N; i++) r[i] = a[i] + b[i]; return r; }
-template <int N> inline Vec<N> operator-(const Vec<N> &a, const Vec<N> &b) { Vec<N> r; for (int i = 0; i < N; i++) r[i] = a[i] - b[i]; return r; }
-template <int N> inline Vec<N> operator-(const Vec<N> &a) { Vec<N> r; for (int i = 0; i < N; i++) r[i] = -a[i]; return r; }
-template <int N> inline Vec<N> operator*(const Vec<N> &a, double s) { Vec<N> r; for (int i = 0; i < N; i++) r[i] = a[i] * s; return r; }
-template <int N> inline Vec<N> operator*(double s, const Vec<N> &a) { Vec<N> r; for (int i = 0; i < N; i++) r[i] = s * a[i]; return r; }
-template <int N> inline Vec<N> operator/(const Vec<N> &a, double s) { Vec<N> r; for (int i = 0; i < N; i++) r[i] = a[i] / s; return r; }
-template <int R, int C> inline Mat<R, C> operator+(const Mat<R, C> &a, const Mat<R, C> &b) { Mat<R, C> r; for (int i = 0; i < R * C; i++) r.a[i] = a.a[i] + b.a[i]; return r; }
-template <int R, int C> inline Mat<R, C> operator-(const Mat<R, C> &a, const Mat<R, C> &b) { Mat<R, C> r; for (int i = 0; i < R * C; i++) r.a[i] = a.a[i] - b.a[i]; return r; }
-template <int R, int C> inline Mat<R, C> operator-(const Mat<R, C> &a) { Mat<R, C> r; for (int i = 0; i < R * C; i++) r.a[i] = -a.a[i]; return r; }
-template <int R, int C> inline Mat<R, C> operator*(const Mat<R, C> &a, double s) { Mat<R, C> r; for (int i = 0; i < R * C; i++) r.a[i] = a.a[i] * s; return r; }
-template <int R, int C> inline Mat<R, C> operator*(double s, const Mat<R, C> &a) { Mat<R, C> r; for (int i = 0; i < R * C; i++) r.a[i] = s * a.a[i]; return r; }
-template <int R, int C> inline Mat<R, C> operator/(const Mat<R, C> &a, double s) { Mat<R, C> r; for (int i = 0; i < R * C; i++) r.a[i] = a.a[i] / s; return r; }
+template <int N> REBVO_HD inline Vec<N> operator+(const Vec<N> &a, const Vec<N> &b) { Vec<N> r; for (int i = 0; i < N; i++) r[i] = a[i] + b[i]; return r; }
+template <int N> REBVO_HD inline Vec<N> operator-(const Vec<N> &a, const Vec<N> &b) { Vec<N> r; for (int i = 0; i < N; i++) r[i] = a[i] - b[i]; return r; }
+template <int N> REBVO_HD inline Vec<N> operator-(const Vec<N> &a) { Vec<N> r; for (int i = 0; i < N; i++) r[i] = -a[i]; return r; }
+template <int N> REBVO_HD inline Vec<N> operator*(const Vec<N> &a, double s) { Vec<N> r; for (int i = 0; i < N; i++) r[i] = a[i] * s; return r; }
+template <int N> REBVO_HD inline Vec<N> operator*(double s, const Vec<N> &a) { Vec<N> r; for (int i = 0; i < N; i++) r[i] = s * a[i]; return r; }
+template <int N> REBVO_HD inline Vec<N> operator/(const Vec<N> &a, double s) { Vec<N> r; for (int i = 0; i < N; i++) r[i] = a[i] / s; return r; }
+template <int R, int C> REBVO_HD inline Mat<R, C> operator+(const Mat<R, C> &a, const Mat<R, C> &b) { Mat<R, C> r; for (int i = 0; i < R * C; i++) r.a[i] = a.a[i] + b.a[i]; return r; }
+template <int R, int C> REBVO_HD inline Mat<R, C> operator-(const Mat<R, C> &a, const Mat<R, C> &b) { Mat<R, C> r; for (int i = 0; i < R * C; i++) r.a[i] = a.a[i] - b.a[i]; return r; }
+template <int R, int C> REBVO_HD inline Mat<R, C> operator-(const Mat<R, C> &a) { Mat<R, C> r; for (int i = 0; i < R * C; i++) r.a[i] = -a.a[i]; return r; }
+template <int R, int C> REBVO_HD inline Mat<R, C> operator*(const Mat<R, C> &a, double s) { Mat<R, C> r; for (int i = 0; i < R * C; i++) r.a[i] = a.a[i] * s; return r; }
+template <int R, int C> REBVO_HD inline Mat<R, C> operator*(double s, const Mat<R, C> &a) { Mat<R, C> r; for (int i = 0; i < R * C; i++) r.a[i] = s * a.a[i]; return r; }
+template <int R, int C> REBVO_HD inline Mat<R, C> operator/(const Mat<R, C> &a, double s) { Mat<R, C> r; for (int i = 0; i < R * C; i++) r.a[i] = a.a[i] / s; return r; }
 
 // ---- products (sum over k ascending, starting from 0) -----------------------------------------------------------
-template <int N> inline double dot(const Vec<N> &a, const Vec<N> &b) { double s = 0; for (int i = 0; i < N; i++) s += a[i] * b[i]; return s; }
-template <int R, int K, int C> inline Mat<R, C> operator*(const Mat<R, K> &a, const Mat<K, C> &b) {
+template <int N> REBVO_HD inline double dot(const Vec<N> &a, const Vec<N> &b) { double s = 0; for (int i = 0; i < N; i++) s += a[i] * b[i]; return s; }
+template <int R, int K, int C> REBVO_HD inline Mat<R, C> operator*(const Mat<R, K> &a, const Mat<K, C> &b) {
     Mat<R, C> r;
     for (int i = 0; i < R; i++)
         for (int j = 0; j < C; j++) { double s = 0; for (int k = 0; k < K; k++) s += a(i, k) * b(k, j); r(i, j) = s; }
     return r;
 }
-template <int R, int C> inline Vec<R> operator*(const Mat<R, C> &a, const Vec<C> &x) {
+template <int R, int C> REBVO_HD inline Vec<R> operator*(const Mat<R, C> &a, const Vec<C> &x) {
     Vec<R> r;
     for (int i = 0; i < R; i++) { double s = 0; for (int k = 0; k < C; k++) s += a(i, k) * x[k]; r[i] = s; }
     return r;
 }
-template <int R, int C> inline Vec<C> operator*(const Vec<R> &x, const Mat<R, C> &a) {   // row vector * matrix
+template <int R, int C> REBVO_HD inline Vec<C> operator*(const Vec<R> &x, const Mat<R, C> &a) {   // row vector * matrix
     Vec<C> r;
     for (int j = 0; j < C; j++) { double s = 0; for (int k = 0; k < R; k++) s += x[k] * a(k, j); r[j] = s; }
     return r;
 }
-template <int R, int C> inline Mat<C, R> transpose(const Mat<R, C> &a) {
+template <int R, int C> REBVO_HD inline Mat<C, R> transpose(const Mat<R, C> &a) {
     Mat<C, R> r;
     for (int i = 0; i < R; i++) for (int j = 0; j < C; j++) r(j, i) = a(i, j);
     return r;
 }
-template <int N> inline double norm(const Vec<N> &a) { return std::sqrt(dot(a, a)); }
-inline Vec<3> cross(const Vec<3> &a, const Vec<3> &b) {   // TooN operator^ (operators.hh:210-222)
+template <int N> REBVO_HD inline double norm(const Vec<N> &a) { return std::sqrt(dot(a, a)); }
+REBVO_HD inline Vec<3> cross(const Vec<3> &a, const Vec<3> &b) {   // TooN operator^ (operators.hh:210-222)
     Vec<3> r;
     r[0] = a[1] * b[2] - a[2] * b[1];
     r[1] = a[2] * b[0] - a[0] * b[2];
     r[2] = a[0] * b[1] - a[1] * b[0];
     return r;
 }
-template <int N> inline Vec<N> unit(const Vec<N> &a) { return a * (1 / std::sqrt(dot(a, a))); }   // TooN::unit: v * (1/sqrt(v*v))
-template <int N> inline bool has_nan(const Vec<N> &a) { for (int i = 0; i < N; i++) if (std::isnan(a[i])) return true; return false; }
-template <int R, int C> inline bool has_nan(const Mat<R, C> &a) { for (int i = 0; i < R * C; i++) if (std::isnan(a.a[i])) return true; return false; }
+template <int N> REBVO_HD inline Vec<N> unit(const Vec<N> &a) { return a * (1 / std::sqrt(dot(a, a))); }   // TooN::unit: v * (1/sqrt(v*v))
+template <int N> REBVO_HD inline bool has_nan(const Vec<N> &a) { for (int i = 0; i < N; i++) if (std::isnan(a[i])) return true; return false; }
+template <int R, int C> REBVO_HD inline bool has_nan(const Mat<R, C> &a) { for (int i = 0; i < R * C; i++) if (std::isnan(a.a[i])) return true; return false; }
 
 // ---- block access -------------------------------------------------------------------------------------------
-template <int BR, int BC, int R, int C> inline Mat<BR, BC> block(const Mat<R, C> &a, int r0, int c0) {
+template <int BR, int BC, int R, int C> REBVO_HD inline Mat<BR, BC> block(const Mat<R, C> &a, int r0, int c0) {
     Mat<BR, BC> r;
     for (int i = 0; i < BR; i++) for (int j = 0; j < BC; j++) r(i, j) = a(r0 + i, c0 + j);
     return r;
 }
-template <int BR, int BC, int R, int C> inline void set_block(Mat<R, C> &a, int r0, int c0, const Mat<BR, BC> &b) {
+template <int BR, int BC, int R, int C> REBVO_HD inline void set_block(Mat<R, C> &a, int r0, int c0, const Mat<BR, BC> &b) {
     for (int i = 0; i < BR; i++) for (int j = 0; j < BC; j++) a(r0 + i, c0 + j) = b(i, j);
 }
-template <int BN, int N> inline Vec<BN> slice(const Vec<N> &a, int i0) { Vec<BN> r; for (int i = 0; i < BN; i++) r[i] = a[i0 + i]; return r; }
-template <int BN, int N> inline void set_slice(Vec<N> &a, int i0, const Vec<BN> &b) { for (int i = 0; i < BN; i++) a[i0 + i] = b[i]; }
+template <int BN, int N> REBVO_HD inline Vec<BN> slice(const Vec<N> &a, int i0) { Vec<BN> r; for (int i = 0; i < BN; i++) r[i] = a[i0 + i]; return r; }
+template <int BN, int N> REBVO_HD inline void set_slice(Vec<N> &a, int i0, const Vec<BN> &b) { for (int i = 0; i < BN; i++) a[i0 + i] = b[i]; }
 
 // ---- 3x3 inverse: util::Matrix3x3Inv (include/UtilLib/toon_util.h:32-41) = adjugate / TooN::determinant, and the
 //      determinant of a 3x3 goes through determinant_gaussian_elimination (TooN/determinant.h:90-147, partial pivoting)
-inline double det3_gauss(const Mat<3, 3> &Ain) {
+REBVO_HD inline double det3_gauss(const Mat<3, 3> &Ain) {
     Mat<3, 3> A = Ain;
     double det = 1;
     for (int i = 0; i < 3; i++) {
@@ -121,7 +130,7 @@ inline double det3_gauss(const Mat<3, 3> &Ain) {
     }
     return det;
 }
-inline Mat<3, 3> inv3(const Mat<3, 3> &A) {
+REBVO_HD inline Mat<3, 3> inv3(const Mat<3, 3> &A) {
     Mat<3, 3> B;
     B(0, 0) = A(2, 2) * A(1, 1) - A(2, 1) * A(1, 2); B(0, 1) = -(A(2, 2) * A(0, 1) - A(2, 1) * A(0, 2)); B(0, 2) = A(1, 2) * A(0, 1) - A(1, 1) * A(0, 2);
     B(1, 0) = -(A(2, 2) * A(1, 0) - A(2, 0) * A(1, 2)); B(1, 1) = A(2, 2) * A(0, 0) - A(2, 0) * A(0, 2); B(1, 2) = -(A(1, 2) * A(0, 0) - A(1, 0) * A(0, 2));
@@ -133,7 +142,7 @@ inline Mat<3, 3> inv3(const Mat<3, 3> &A) {
 template <int N>
 struct Cholesky {
     Mat<N, N> L;
-    explicit Cholesky(const Mat<N, N> &A) : L(A) {
+    REBVO_HD explicit Cholesky(const Mat<N, N> &A) : L(A) {
         for (int col = 0; col < N; col++) {
             double inv_diag = 1;
             for (int row = col; row < N; row++) {
@@ -150,7 +159,7 @@ struct Cholesky {
             }
         }
     }
-    Vec<N> backsub(const Vec<N> &v) const {
+    REBVO_HD Vec<N> backsub(const Vec<N> &v) const {
         Vec<N> y, r;
         for (int i = 0; i < N; i++) {
             double val = v[i];
@@ -165,7 +174,7 @@ struct Cholesky {
         }
         return r;
     }
-    Mat<N, N> inverse() const {   // matrix backsub of the identity; the diagonal step multiplies by 1/d (:180-185)
+    REBVO_HD Mat<N, N> inverse() const {   // matrix backsub of the identity; the diagonal step multiplies by 1/d (:180-185)
         Mat<N, N> inv;
         for (int c = 0; c < N; c++) {
             double y[N], r[N];
@@ -193,7 +202,7 @@ template <int N>
 struct SymSVD {
     Mat<N, N> V;
     double e[N], inv[N];
-    explicit SymSVD(const Mat<N, N> &Ain, double condition = 1e9) {
+    REBVO_HD explicit SymSVD(const Mat<N, N> &Ain, double condition = 1e9) {
         Mat<N, N> A = Ain;
         V = Mat<N, N>::identity();
         for (int sweep = 0; sweep < 60; sweep++) {
@@ -219,13 +228,13 @@ struct SymSVD {
         for (int i = 0; i < N; i++) { e[i] = A(i, i); smax = std::fmax(smax, std::fabs(e[i])); }
         for (int i = 0; i < N; i++) inv[i] = (std::fabs(e[i]) * condition <= smax) ? 0.0 : 1.0 / e[i];
     }
-    Vec<N> backsub(const Vec<N> &b) const {
+    REBVO_HD Vec<N> backsub(const Vec<N> &b) const {
         Vec<N> y, x;
         for (int i = 0; i < N; i++) { double d = 0; for (int k = 0; k < N; k++) d += V(k, i) * b[k]; y[i] = d * inv[i]; }
         for (int k = 0; k < N; k++) { double d = 0; for (int i = 0; i < N; i++) d += V(k, i) * y[i]; x[k] = d; }
         return x;
     }
-    Mat<N, N> pinv() const {
+    REBVO_HD Mat<N, N> pinv() const {
         Mat<N, N> P;
         for (int r = 0; r < N; r++)
             for (int c = 0; c < N; c++) { double p = 0; for (int i = 0; i < N; i++) p += V(r, i) * inv[i] * V(c, i); P(r, c) = p; }
@@ -234,8 +243,8 @@ struct SymSVD {
 };
 
 // ---- SO(3): TooN::SO3<>::exp (so3.h:203-285), ln (:288-334), coerce (:110-118), SO3(a, b) (:78-98) -------------
-inline Mat<3, 3> so3_exp(const Vec<3> &w) {
-    static const double one_6th = 1.0 / 6.0, one_20th = 1.0 / 20.0;
+REBVO_HD inline Mat<3, 3> so3_exp(const Vec<3> &w) {
+    const double one_6th = 1.0 / 6.0, one_20th = 1.0 / 20.0;
     const double theta_sq = dot(w, w);
     const double theta = std::sqrt(theta_sq);
     double A, B;
@@ -263,7 +272,7 @@ inline Mat<3, 3> so3_exp(const Vec<3> &w) {
     R(1, 2) = b - a; R(2, 1) = b + a;
     return R;
 }
-inline Mat<3, 3> so3_coerce(const Mat<3, 3> &Min) {   // what SO3<>(Matrix) does before anything else
+REBVO_HD inline Mat<3, 3> so3_coerce(const Mat<3, 3> &Min) {   // what SO3<>(Matrix) does before anything else
     Vec<3> r0 = {{Min(0, 0), Min(0, 1), Min(0, 2)}}, r1 = {{Min(1, 0), Min(1, 1), Min(1, 2)}}, r2 = {{Min(2, 0), Min(2, 1), Min(2, 2)}};
     r0 = unit(r0);
     r1 = r1 - r0 * dot(r0, r1);
@@ -275,7 +284,7 @@ inline Mat<3, 3> so3_coerce(const Mat<3, 3> &Min) {   // what SO3<>(Matrix) does
     for (int j = 0; j < 3; j++) { M(0, j) = r0[j]; M(1, j) = r1[j]; M(2, j) = r2[j]; }
     return M;
 }
-inline Vec<3> so3_ln_raw(const Mat<3, 3> &M) {   // ln() of a matrix that already is the SO3's my_matrix
+REBVO_HD inline Vec<3> so3_ln_raw(const Mat<3, 3> &M) {   // ln() of a matrix that already is the SO3's my_matrix
     Vec<3> r;
     const double cos_angle = (M(0, 0) + M(1, 1) + M(2, 2) - 1.0) * 0.5;
     r[0] = (M(2, 1) - M(1, 2)) / 2;
@@ -299,9 +308,9 @@ inline Vec<3> so3_ln_raw(const Mat<3, 3> &M) {   // ln() of a matrix that alread
     }
     return r;
 }
-inline Vec<3> so3_ln(const Mat<3, 3> &M) { return so3_ln_raw(so3_coerce(M)); }   // SO3<>(M).ln()
+REBVO_HD inline Vec<3> so3_ln(const Mat<3, 3> &M) { return so3_ln_raw(so3_coerce(M)); }   // SO3<>(M).ln()
 // SO3<>(a, b): the rotation about a x b that takes the direction of a to the direction of b
-inline Mat<3, 3> so3_from_to(const Vec<3> &a, const Vec<3> &b) {
+REBVO_HD inline Mat<3, 3> so3_from_to(const Vec<3> &a, const Vec<3> &b) {
     Vec<3> n = cross(a, b);
     if (dot(n, n) == 0) return Mat<3, 3>::identity();
     n = unit(n);

@@ -1,3 +1,4 @@
+#include <new>
 // png_reader.cpp — minimal PNG (and binary PGM/PPM) reader for the dataset camera: zlib inflate + the five PNG
 // scan-line filters; colour types 0/2/3/4/6, bit depths 8 and 16 (1/2/4 for grey and palette), no interlace.
 // Output follows what the reference obtains through libgd's truecolor accessors (src/VideoLib/datasetcam.cpp:
@@ -31,6 +32,10 @@ inline int paeth(int a, int b, int c) {
     return (pa <= pb && pa <= pc) ? a : (pb <= pc ? b : c);
 }
 
+// Header-supplied dimensions size every buffer below: a corrupt file must not wrap size_t or ask for gigabytes (the camera
+// sizes this library handles are at most 1024 wide; 16384 x 16384 leaves any real dataset plenty of room).
+inline bool sane_size(unsigned w, unsigned h) { return w >= 1 && h >= 1 && w <= 16384 && h <= 16384; }
+
 bool decode_png(const std::vector<unsigned char> &d, std::vector<RGB24Pixel> &out, unsigned &w, unsigned &h, std::string &err) {
     static const unsigned char sig[8] = {137, 80, 78, 71, 13, 10, 26, 10};
     if (d.size() < 33 || memcmp(d.data(), sig, 8) != 0) { err = "not a PNG"; return false; }
@@ -57,6 +62,7 @@ bool decode_png(const std::vector<unsigned char> &d, std::vector<RGB24Pixel> &ou
         pos += 12 + (size_t)len;
     }
     if (!have_hdr || w == 0 || h == 0) { err = "PNG without a valid IHDR"; return false; }
+    if (!sane_size(w, h)) { err = "PNG header declares an implausible image size"; return false; }   // before any allocation sized by it
     if (interlace) { err = "interlaced PNG is not supported"; return false; }
     int channels;
     switch (ctype) {
@@ -135,6 +141,7 @@ bool decode_pnm(const std::vector<unsigned char> &d, std::vector<RGB24Pixel> &ou
     };
     unsigned maxv = 0;
     if (!next_int(w) || !next_int(h) || !next_int(maxv) || maxv == 0 || maxv > 255) { err = "bad PNM header"; return false; }
+    if (!sane_size(w, h)) { err = "PNM header declares an implausible image size"; return false; }
     pos++;   // single whitespace after maxval
     const int ch = d[1] == '5' ? 1 : 3;
     if (pos + (size_t)w * h * ch > d.size()) { err = "truncated PNM"; return false; }
@@ -151,8 +158,13 @@ bool decode_pnm(const std::vector<unsigned char> &d, std::vector<RGB24Pixel> &ou
 bool LoadImageRGB24(const std::string &file, std::vector<RGB24Pixel> &out, unsigned &w, unsigned &h, std::string &err) {
     std::vector<unsigned char> d;
     if (!read_file(file, d, err)) return false;
-    if (d.size() > 8 && d[0] == 137 && d[1] == 'P') return decode_png(d, out, w, h, err);
-    if (d.size() > 2 && d[0] == 'P' && (d[1] == '5' || d[1] == '6')) return decode_pnm(d, out, w, h, err);
+    try {   // an allocation failure is a camera error (DataSetCam ends the sequence), not std::terminate in the track thread
+        if (d.size() > 8 && d[0] == 137 && d[1] == 'P') return decode_png(d, out, w, h, err);
+        if (d.size() > 2 && d[0] == 'P' && (d[1] == '5' || d[1] == '6')) return decode_pnm(d, out, w, h, err);
+    } catch (const std::bad_alloc &) {
+        err = "out of memory while decoding " + file;
+        return false;
+    }
     err = "unsupported image format (PNG, PGM, PPM are read; the reference's JPEG path needs libgd): " + file;
     return false;
 }

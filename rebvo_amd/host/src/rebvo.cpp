@@ -491,6 +491,7 @@ void REBVO::TrackThread(REBVO *cf) {
                 new_buf.EstimationOK = n.estimation_ok != 0;
                 new_buf.ef->nmatch = n.klm_num;
                 new_buf.ef->reTunedThresh = n.retuned_thresh;
+                new_buf.ef->kn = n.kn;   // edge_finder::KNum() of this frame (the .m log reports it even without a callback)
                 if (old_buf) fill_nav(n, new_buf.nav);
                 else new_buf.nav = NavData();   // first frame: "dummy processing", no estimate (rebvo_second_t.cpp:108-121)
                 new_buf.stereo_match_num = 0;
@@ -517,13 +518,20 @@ void REBVO::TrackThread(REBVO *cf) {
                 const int so = (slot + 2) % 3;   // ring of 3: the slot before `slot`
                 int32_t kn = 0;
                 rc = edgehip_download_keylines(cf->hip, 0, so, reinterpret_cast<edgehip_keyline *>(old_buf->ef->kl.data()), nullptr, &kn);
-                old_buf->ef->kn = rc == 0 ? kn : 0;
+                if (rc != 0) {   // a failed download is a device error like any other: report it and stop (no silent empty map)
+                    std::cout << "\nREBVO: edgehip_download_keylines failed: " << edgehip_last_error() << "\n";
+                    failed = true;
+                    old_buf->ef->kn = 0;
+                } else {
+                    old_buf->ef->kn = kn;
+                }
                 // Image<float>::ConvertRGB2BW (include/VideoLib/image.h:197-203)
                 const RGB24Pixel *c = old_buf->imgc->Data();
                 float *bw = old_buf->img->Data();
                 for (uint i = 0; i < old_buf->img->bSize(); i++) bw[i] = (float)(c[i].pix.r + c[i].pix.g + c[i].pix.b);
             } else {
-                old_buf->ef->kn = 0;
+                // nobody reads the KeyLine payload: skip the download, but keep edge_finder::KNum() as it was set when the frame was
+                // detected — the .m log reports it (rebvo_third_t.cpp:280)
             }
             cf->pipe.ReleaseBuffer(1);
         }

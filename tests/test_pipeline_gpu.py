@@ -214,3 +214,33 @@ def test_pipeline_with_frame_graphs(monkeypatch):
     replayed; 30 frames so that every variant is captured AND replayed, results as without graphs."""
     monkeypatch.setenv("EDGEHIP_GRAPH", "1")
     _run(376, 240, 30)
+
+
+@pytest.mark.parametrize("nseq", [1, 4])
+def test_fused_evaluation_and_lm_step_is_bit_identical_to_the_launch_chain(monkeypatch, nseq):
+    """Small batches launch every TryVelRot evaluation together with the LM step that follows it (k_try_velrot_lm: the block
+    that finishes last runs the step; EDGEHIP_PERSIST_LM = largest batch that does; off by default: it measured no faster).  Same code, same schedule,
+    same reduction order as the chain of separate launches: every nav record and the depth map must be identical bit for
+    bit — and both follow the reference."""
+    w, h, n = 376, 240, 10
+    frames = [f for f, _, _ in synth.billboard_sequence(w, h, n + nseq)]
+    outs = []
+    for mode in ("0", "8"):
+        monkeypatch.setenv("EDGEHIP_PERSIST_LM", mode)
+        eh = edgehip.EdgeHip(edgehip.euroc_params(w, h), nseq=nseq, nslots=3)
+        eh.set_nav_log(n)
+        for k in range(n):
+            eh.upload_rgb(eh.next_slot(), np.stack([frames[k + s] for s in range(nseq)]))   # a different sequence per slot
+            eh.process_frame(0.05 * k)
+        log = eh.read_nav_log_array(0, n)
+        kl = [eh.download_keylines(s, eh.cur_slot())[0] for s in range(nseq)]
+        outs.append((log, kl))
+        eh.close()
+    (la, ka), (lb, kb) = outs
+    assert la.tobytes() == lb.tobytes()
+    for x, y in zip(ka, kb):
+        assert x.tobytes() == y.tobytes()
+    assert np.all(la["estimation_ok"][2:] == 1) and np.all(la["minimizer_evals"][1:] == 12)
+    if nseq == 1:
+        monkeypatch.setenv("EDGEHIP_PERSIST_LM", "8")
+        _run(w, h, 6)     # the fused path against the reference
