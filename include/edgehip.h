@@ -117,6 +117,30 @@ typedef struct edgehip_nav {
     int32_t kn, klm_fwd, klm_num, kf_matchs, estimation_ok, frame, minimizer_evals;
 } edgehip_nav;
 
+/* ---- IMU branch on the device (ImuMode > 0 for whole batches) -------------------------------------------------------
+ * The &IMU parameters REBVO::SecondThread uses (include/rebvo/rebvo.h:172-199; GlobalConfig_EuRoC:107-140). */
+typedef struct edgehip_imu_params {
+    double giro_meas_std, giro_bias_std;       /* GiroMeasStdDev, GiroBiasStdDev */
+    int32_t init_bias, init_bias_frame_num;    /* InitBias, InitBiasFrameNum */
+    double bias_init_guess[3];                 /* BiasHintX/Y/Z */
+    double acel_meas_std, g_module, g_module_uncer, g_uncert, vbias_std;   /* AcelMeasStdDev, g_module, g_module_uncer, g_uncert, VBiasStdDev */
+    double scale_std_mult, scale_std_max, scale_std_init;                  /* ScaleStdDevMult, ScaleStdDevMax, ScaleStdDevInit */
+} edgehip_imu_params;
+/* rebvo::IntegratedImuData (include/UtilLib/imugrabber.h:57-69): what ImuGrabber::GrabAndIntegrate hands the tracker
+ * for the interval between two frames. */
+typedef struct edgehip_imu_integrated {
+    int32_t n, pad;
+    double dt, Rot[9], giro[3], acel[3], comp[3], dgiro[3], cacel[3];
+} edgehip_imu_integrated;
+/* What the IMU branch adds to the per-frame record: NavData's IMU fields (rebvo.h:292-308) and the IMUState members the
+ * reference logs (rebvo_second_t.cpp:550-606). */
+typedef struct edgehip_nav_imu {
+    double Rot[9], RotLie[3], RotGiro[3], Vel[3], Pose[9], PoseLie[3], Pos[3], g[3];
+    double scale, dt, K, Kp, RKp, s_rho_q;
+    double Vg[3], Bg[3], dVv[3], dWv[3], Vgv[3], Vgva[3], Av[3], As[3], X[7], b_est[3], u_est[3];
+    int32_t kn, klm_num, estimation_ok, init;
+} edgehip_nav_imu;
+
 /* ---- lifetime -------------------------------------------------------------------------------------- */
 /* Replaces the per-slot `new sspace / new edge_tracker / new global_tracker` of REBVO::construct
  * (src/rebvo/rebvo.cpp:297-312).  `device` is the HIP device ordinal. */
@@ -261,6 +285,16 @@ int edgehip_next_slot(edgehip_ctx *ctx);
 int edgehip_cur_slot(edgehip_ctx *ctx);
 /* Per-sequence record of the last processed frame.  Synchronises.  nav[nseq]. */
 int edgehip_read_nav(edgehip_ctx *ctx, edgehip_nav *nav);
+/* ImuMode > 0 for every sequence of the context (rebvo_second_t.cpp:54-94 set-up, :182-336 tracker + filters, :519-544
+ * pose): from the next frame on edgehip_process_frame takes the IMU branch — gyro pre-rotation, Minimizer_V, FordwardMatch,
+ * ExtRotVel, BiasCorrect, rotate, the mapper, the scale filter and the gravity-aligned pose — entirely on the device, no
+ * host synchronisation, one thread per sequence for the 3..11-dimensional filters.  Call before the first frame. */
+int edgehip_imu_enable(edgehip_ctx *ctx, const edgehip_imu_params *imu);
+/* The integrated IMU data of the interval that ends with the NEXT edgehip_process_frame, one record per sequence
+ * (ImuGrabber::GrabAndIntegrate stays with the caller: it is I/O).  Asynchronous; the records are copied before return. */
+int edgehip_set_imu(edgehip_ctx *ctx, const edgehip_imu_integrated *per_seq);
+/* The IMU part of the newest frame's record, one per sequence (synchronises like edgehip_read_nav). */
+int edgehip_read_nav_imu(edgehip_ctx *ctx, edgehip_nav_imu *out);
 /* Keep the last `len` per-frame records of every sequence in HBM (ring indexed by frame number) so that a
  * replay can run many frames without reading back; edgehip_read_nav_log copies records of frames
  * [first, first+count) as out[count][nseq].  Synchronises. */

@@ -556,6 +556,11 @@ int edgehip_destroy(edgehip_ctx *c) {
         delete c->prof;
     }
     if (c->nav_log) (void)hipFree(c->nav_log);
+    if (c->imu_track) (void)hipFree(c->imu_track);
+    if (c->imu_in_dev) (void)hipFree(c->imu_in_dev);
+    if (c->nav_imu_dev) (void)hipFree(c->nav_imu_dev);
+    if (c->pinned_imu) (void)hipHostFree(c->pinned_imu);
+    if (c->pinned_nav_imu) (void)hipHostFree(c->pinned_nav_imu);
     for (int i = 0; i < 4; i++) { (void)hipEventDestroy(c->ev_a[i]); (void)hipEventDestroy(c->ev_use[i]); }
     (void)hipEventDestroy(c->ev_tmp);
     for (int i = 0; i < 8; i++) (void)hipEventDestroy(c->ev_ring[i]);

@@ -248,6 +248,14 @@ struct edgehip_ctx {
     int32_t *pinned_idx;   // [8][4][B] frame-pool indices, one row per (frame ring entry, slot)
     edgehip_nav *pinned_nav;  // [B]
     edgehip::Profiler *prof;
+    // the IMU branch of the frame driver (edgehip_imu_enable; stage_imu.hip)
+    bool imu_enabled = false, imu_pending = false;
+    edgehip_imu_params imu_params;
+    void *imu_track = nullptr;                       // [B] ImuTrackDev
+    edgehip_imu_integrated *imu_in_dev = nullptr;    // [B] integrated IMU data of the frame being enqueued
+    edgehip_nav_imu *nav_imu_dev = nullptr;          // [B]
+    edgehip_imu_integrated *pinned_imu = nullptr;    // [8][B] ring, like the time stamps
+    edgehip_nav_imu *pinned_nav_imu = nullptr;       // [B]
 };
 
 namespace edgehip {
@@ -326,5 +334,8 @@ int directed_enqueue(edgehip_ctx *c, int slot_new, int slot_old);
 int regekf_enqueue(edgehip_ctx *c, int slot, int do_reg, int do_ekf);
 int rescale_enqueue(edgehip_ctx *c, int slot);
 int pose_enqueue(edgehip_ctx *c, int slot_new, const double *t_host);
+int imu_pre_enqueue(edgehip_ctx *c, int slot_old);     // stage_imu.hip
+int imu_mid_enqueue(edgehip_ctx *c);
+int imu_post_enqueue(edgehip_ctx *c, int slot_new, int have_pair);
 
 }  // namespace edgehip

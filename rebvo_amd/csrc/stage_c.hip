@@ -599,10 +599,13 @@ __global__ void k_frame_glue(SeqDev *seqs, const double *__restrict__ t_in, edge
 // count) reduced with wave shuffles to one partial per block.  The 6x6 SVD solve stays with the caller.
 // ---------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void k_ext_rotvel(const KlSoA *kls, const int32_t *__restrict__ kns, const double *__restrict__ vel,
-                                                    double *__restrict__ partials, int nblk, double zf, double loc_unc, double hub) {
+                                                    const SeqDev *__restrict__ seqs, double *__restrict__ partials, int nblk, double zf,
+                                                    double loc_unc, double hub) {
     const int seq = blockIdx.z, i = blockIdx.x * 256 + threadIdx.x;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const double v0 = vel[seq * 3 + 0], v1 = vel[seq * 3 + 1], v2 = vel[seq * 3 + 2];
+    // the velocity Minimizer_V found: from the caller (stage entry point) or straight from the sequence state (frame driver)
+    const double *vp = seqs ? seqs[seq].mv_V : vel + seq * 3;
+    const double v0 = vp[0], v1 = vp[1], v2 = vp[2];
     double row[6] = {0, 0, 0, 0, 0, 0}, y = 0, used = 0;
     if (i < kns[seq] && kls[seq].m_id[i] >= 0) {
         const KlSoA &K = kls[seq];
@@ -882,6 +885,27 @@ int rescale_enqueue(edgehip_ctx *c, int slot) {
     return 0;
 }
 
+// rotate_keylines with the rotations a device kernel left in rot_buf (the IMU branch of the frame driver)
+static int rotate_buf_enqueue(edgehip_ctx *c, int slot) {
+    c->grec_ok[slot] = false;
+    ProfScope ps(c, PROF_C_ROTATE);
+    const DevicePlan &pl = c->plan;
+    hipLaunchKernelGGL(k_rotate, dim3((pl.cap + 255) / 256, 1, pl.nseq), dim3(256), 0, c->stream, kldev(c, slot),
+                       c->kn_slot + (size_t)slot * pl.nseq, c->rot_buf, pl.zfm);
+    EH_LAUNCH_CHECK();
+    return 0;
+}
+// ExtRotVel's sums with the velocity taken from the sequence state; the solve is k_imu_mid's
+static int ext_rotvel_enqueue(edgehip_ctx *c, int slot) {
+    const DevicePlan &pl = c->plan;
+    const int B = pl.nseq, nblk = (pl.cap + 255) / 256;
+    if (nblk > c->nblk_tvr) { set_error("ext_rot_vel: partial table too small"); return EDGEHIP_ERR_STATE; }
+    hipLaunchKernelGGL(k_ext_rotvel, dim3(nblk, 1, B), dim3(256), 0, c->stream, kldev(c, slot), c->kn_slot + (size_t)slot * B,
+                       (const double *)nullptr, c->seq, c->partials, c->nblk_tvr, pl.zfm, c->p.loc_unc, c->p.reweight_distance);
+    EH_LAUNCH_CHECK();
+    return 0;
+}
+
 static int glue(edgehip_ctx *c, int mode, int slot_new, int have_pair) {
     const DevicePlan &pl = c->plan;
     hipLaunchKernelGGL(k_frame_glue, dim3((pl.nseq + 63) / 64), dim3(64), 0, c->stream, c->seq, c->t_buf, c->nav_dev,
@@ -1064,7 +1088,7 @@ int edgehip_ext_rot_vel(edgehip_ctx *c, int slot, const double *vel, double loc_
     EH_CHECK(hipMemcpyAsync(dvel, c->pinned_out, sizeof(double) * 3 * B, hipMemcpyHostToDevice, c->stream));
     EH_CHECK(hipMemsetAsync(c->partials, 0, sizeof(double) * (size_t)B * c->nblk_tvr * kNumSums, c->stream));
     hipLaunchKernelGGL(k_ext_rotvel, dim3(nblk, 1, B), dim3(256), 0, c->stream, kldev(c, slot), c->kn_slot + (size_t)slot * B, dvel,
-                       c->partials, c->nblk_tvr, pl.zfm, loc_unc, hub_reweight);
+                       (const SeqDev *)nullptr, c->partials, c->nblk_tvr, pl.zfm, loc_unc, hub_reweight);
     EH_LAUNCH_CHECK();
     std::vector<double> part((size_t)B * c->nblk_tvr * kNumSums);
     EH_CHECK(hipMemcpyAsync(part.data(), c->partials, sizeof(double) * part.size(), hipMemcpyDeviceToHost, c->stream));
@@ -1150,7 +1174,26 @@ static int frame_enqueue(edgehip_ctx *c, int sn, int so, int sp, int have_pair, 
         ProfScope ps(c, PROF_C_POSE);
         EH_TRY(glue(c, 0, sn, have_pair));
     }
-    if (have_pair) {
+    if (c->imu_enabled) {
+        // ---- ImuMode > 0 (rebvo_second_t.cpp:182-336, 387-493, 519-606): everything on the device, stage_imu.hip has the filters ----
+        if (have_pair) {
+            EH_TRY(quantile_enqueue(c, so, kRhoMin, kRhoMax, c->p.qcut_quantile, c->p.qcut_nbins));  // :172
+            EH_TRY(build_field_enqueue(c, sn, c->p.search_range, -1.f));                              // :177
+            { ProfScope ps(c, PROF_C_POSE); EH_TRY(imu_pre_enqueue(c, so)); }                         // :183-213
+            EH_TRY(rotate_buf_enqueue(c, so));                                                       // :215 gyro pre-rotation
+            EH_TRY(minimizer_v_enqueue(c, sn, so, c->frames_seen % kRefRing, c->p.tracker_iter_num, c->p.tracker_match_thresh,
+                                       c->p.match_num_thresh, c->p.reweight_distance));              // :223
+            EH_TRY(forward_match_enqueue(c, so, sn));                                                // :230
+            EH_TRY(ext_rotvel_enqueue(c, sn));                                                       // :237
+            { ProfScope ps(c, PROF_C_POSE); EH_TRY(imu_mid_enqueue(c)); }                             // :237-272, :387-397
+            EH_TRY(rotate_buf_enqueue(c, so));                                                       // :319
+            EH_TRY(directed_enqueue(c, sn, so));                                                     // :410
+            { ProfScope ps(c, PROF_C_POSE); EH_TRY(glue(c, 2, sn, have_pair)); }                     // :412-422
+            EH_TRY(regekf_enqueue(c, sn, 1, 1));                                                     // :453, :460
+            EH_TRY(rescale_enqueue(c, sn));                                                          // :487
+        }
+        { ProfScope ps(c, PROF_C_POSE); EH_TRY(imu_post_enqueue(c, sn, have_pair)); }                 // :280-312, :519-606
+    } else if (have_pair) {
         EH_TRY(quantile_enqueue(c, so, kRhoMin, kRhoMax, c->p.qcut_quantile, c->p.qcut_nbins));  // rebvo_second_t.cpp:172
         EH_TRY(build_field_enqueue(c, sn, c->p.search_range, -1.f));                              // :177
         EH_TRY(minimizer_enqueue(c, sn, so, c->frames_seen % kRefRing));                                                    // :346
@@ -1168,7 +1211,7 @@ static int frame_enqueue(edgehip_ctx *c, int sn, int so, int sp, int have_pair, 
             EH_TRY(rescale_enqueue(c, sn));                                                      // :487
         }
     }
-    {
+    if (!c->imu_enabled) {
         ProfScope ps(c, PROF_C_POSE);
         EH_TRY(glue(c, 3, sn, have_pair));                                                       // :550-606
     }

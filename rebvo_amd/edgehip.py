@@ -129,6 +129,54 @@ class Nav(C.Structure):
     ]
 
 
+class ImuParams(C.Structure):
+    """edgehip_imu_params; defaults = the &IMU section of app/rebvorun/GlobalConfig_EuRoC."""
+    _fields_ = [("giro_meas_std", C.c_double), ("giro_bias_std", C.c_double), ("init_bias", C.c_int32),
+                ("init_bias_frame_num", C.c_int32), ("bias_init_guess", C.c_double * 3), ("acel_meas_std", C.c_double),
+                ("g_module", C.c_double), ("g_module_uncer", C.c_double), ("g_uncert", C.c_double), ("vbias_std", C.c_double),
+                ("scale_std_mult", C.c_double), ("scale_std_max", C.c_double), ("scale_std_init", C.c_double)]
+
+
+def euroc_imu_params(**over):
+    p = ImuParams()
+    p.giro_meas_std, p.giro_bias_std = 1.6968e-04, 1.9393e-05
+    p.init_bias, p.init_bias_frame_num = 1, 10
+    p.bias_init_guess[:] = [0.0188, 0.0037, 0.0776]
+    p.acel_meas_std, p.g_module, p.g_module_uncer, p.g_uncert, p.vbias_std = 2.0e-3, 9.8, 0.2e3, 2e-3, 1e-7
+    p.scale_std_mult, p.scale_std_max, p.scale_std_init = 1e-2, 1e-4, 1.2e-3
+    for k, v in over.items():
+        if k == "bias_init_guess":
+            p.bias_init_guess[:] = v
+        else:
+            setattr(p, k, v)
+    return p
+
+
+class ImuIntegrated(C.Structure):
+    """edgehip_imu_integrated = rebvo::IntegratedImuData."""
+    _fields_ = [("n", C.c_int32), ("pad", C.c_int32), ("dt", C.c_double), ("Rot", C.c_double * 9), ("giro", C.c_double * 3),
+                ("acel", C.c_double * 3), ("comp", C.c_double * 3), ("dgiro", C.c_double * 3), ("cacel", C.c_double * 3)]
+
+    @classmethod
+    def from_row(cls, r):
+        """row = [n, dt, Rot(9), giro(3), acel(3), comp(3), dgiro(3), cacel(3)] (oracle.ImuIntegrated.as_row)"""
+        o = cls()
+        o.n, o.dt = int(r[0]), float(r[1])
+        o.Rot[:] = r[2:11]; o.giro[:] = r[11:14]; o.acel[:] = r[14:17]; o.comp[:] = r[17:20]; o.dgiro[:] = r[20:23]; o.cacel[:] = r[23:26]
+        return o
+
+
+class NavImu(C.Structure):
+    """edgehip_nav_imu."""
+    _fields_ = [("Rot", C.c_double * 9), ("RotLie", C.c_double * 3), ("RotGiro", C.c_double * 3), ("Vel", C.c_double * 3),
+                ("Pose", C.c_double * 9), ("PoseLie", C.c_double * 3), ("Pos", C.c_double * 3), ("g", C.c_double * 3),
+                ("scale", C.c_double), ("dt", C.c_double), ("K", C.c_double), ("Kp", C.c_double), ("RKp", C.c_double),
+                ("s_rho_q", C.c_double), ("Vg", C.c_double * 3), ("Bg", C.c_double * 3), ("dVv", C.c_double * 3),
+                ("dWv", C.c_double * 3), ("Vgv", C.c_double * 3), ("Vgva", C.c_double * 3), ("Av", C.c_double * 3),
+                ("As", C.c_double * 3), ("X", C.c_double * 7), ("b_est", C.c_double * 3), ("u_est", C.c_double * 3),
+                ("kn", C.c_int32), ("klm_num", C.c_int32), ("estimation_ok", C.c_int32), ("init", C.c_int32)]
+
+
 NAV_DTYPE = np.dtype(Nav)   # numpy view of edgehip_nav (same offsets as the ctypes struct)
 assert NAV_DTYPE.itemsize == C.sizeof(Nav)
 
@@ -146,6 +194,7 @@ EXPORTS = [
     "edgehip_upload_rgb_indexed", "edgehip_bind_rgb_indexed", "edgehip_set_nav_log", "edgehip_read_nav_log",
     "edgehip_build_undistort_map", "edgehip_download_undistorted", "edgehip_depth_reset", "edgehip_depth_reset_slot", "edgehip_set_slot_camera", "edgehip_directed_matching_stereo",
     "edgehip_alloc_pinned", "edgehip_free_pinned", "edgehip_upload_rgb_pinned", "edgehip_fuse_stereo_depth", "edgehip_set_stereo_rig", "edgehip_get_stereo_matches", "edgehip_minimizer_v", "edgehip_ext_rot_vel",
+    "edgehip_imu_enable", "edgehip_set_imu", "edgehip_read_nav_imu",
 ]
 
 _lib = None
@@ -403,6 +452,20 @@ class EdgeHip:
         nav = (Nav * self.nseq)()
         self._ck(self.lib.edgehip_read_nav(self.ctx, nav))
         return list(nav)
+
+    # ---- IMU branch on the device ----
+    def imu_enable(self, imu_params):
+        self._ck(self.lib.edgehip_imu_enable(self.ctx, C.byref(imu_params)))
+
+    def set_imu(self, records):
+        """records: one ImuIntegrated per sequence, for the interval that ends with the next process_frame."""
+        arr = (ImuIntegrated * self.nseq)(*records)
+        self._ck(self.lib.edgehip_set_imu(self.ctx, arr))
+
+    def read_nav_imu(self):
+        out = (NavImu * self.nseq)()
+        self._ck(self.lib.edgehip_read_nav_imu(self.ctx, out))
+        return list(out)
 
     def reset(self):
         self._ck(self.lib.edgehip_reset(self.ctx))
