@@ -284,16 +284,23 @@ class Replay:
     """`nseq` sequences in lock-step out of an HBM-resident frame pool: frame index of sequence s at step k =
     index_of(k)[s]."""
 
-    def __init__(self, edgehip, params, nseq, pool_t, pool_frames, index_of, device, contexts=1):
+    def __init__(self, edgehip, params, nseq, pool_t, pool_frames, index_of, device, contexts=1, imu_params=None, imu_of=None):
         self.C = max(1, contexts)
         self.B = nseq // self.C
         self.ehs = [edgehip.EdgeHip(params, nseq=self.B, nslots=3, device=device) for _ in range(self.C)]
         self.pool_t, self.pool_frames, self.index_of = pool_t, pool_frames, index_of
+        self.imu_of = imu_of          # k -> integrated IMU records of all sequences for the interval that ends with frame k
+        if imu_params is not None:
+            for e in self.ehs:
+                e.imu_enable(imu_params)
 
     def step(self, k):
         idx = np.ascontiguousarray(self.index_of(k), dtype=np.int32)
+        imu = self.imu_of(k) if self.imu_of else None
         for ci, e in enumerate(self.ehs):
             e.bind_rgb_indexed(e.next_slot(), self.pool_t.data_ptr(), self.pool_frames, idx[ci * self.B:(ci + 1) * self.B])
+            if imu is not None:
+                e.set_imu(imu[ci * self.B:(ci + 1) * self.B])
             e.process_frame(0.05 * k)
 
     def sync(self):
@@ -352,6 +359,10 @@ def main():
     ap.add_argument("--cpu-procs", type=int, default=-1,
                     help="processes of the node-saturating CPU leg (SURVEY.md section 8d mode iii; -1 = usable cores // 3 "
                          "sequences, each with the reference's two compute threads; 0 = skip)")
+    ap.add_argument("--imu", action="store_true",
+                    help="ImuMode=2 (what the shipped GlobalConfig_EuRoC runs): the IMU branch of the tracker — gyro pre-rotation, "
+                         "Minimizer_V, ExtRotVel, BiasCorrect, scale filter, gravity-aligned pose — batched on the device; the "
+                         "integrated IMU data of every frame interval is synthesised from the known camera motion")
     ap.add_argument("--no-extras", action="store_true", help="skip the batch sweep and the heterogeneous batch")
     ap.add_argument("--no-roofline-events", action="store_true")
     args = ap.parse_args()
@@ -393,7 +404,9 @@ def main():
     radius = params.search_range
     C = max(1, args.contexts)
     B, K, Wm = args.nseq // C, args.steps, args.warmup   # B = sequences per context
-    cpu_legs = rank == 0 and args.cpu_frames > 0 and (world == 1 or os.environ.get("BENCH_CPU_BASELINE_ALWAYS"))
+    cpu_legs = rank == 0 and args.cpu_frames > 0 and (world == 1 or os.environ.get("BENCH_CPU_BASELINE_ALWAYS")) and not args.imu
+    if args.imu:
+        args.no_extras = True   # the CPU legs and the other batch shapes are those of the ImuMode=0 line
 
     def to_pool(frames_list):
         """HBM-resident frame pool; stage A reads each sequence's frame in place (edgehip_bind_rgb_indexed: no gather
@@ -410,7 +423,37 @@ def main():
     torch.cuda.synchronize()
     # every sequence starts at its own phase of the pool
     offs = np.arange(B * C, dtype=np.int64) % (2 * (args.pool - 1))
-    rp = Replay(edgehip, params, B * C, pool, args.pool, lambda k: [tri(k + o, args.pool) for o in offs], local_rank, C)
+    imu_params = imu_of = None
+    if args.imu:
+        # Integrated IMU data (rebvo::IntegratedImuData) of every transition between two pool frames, from the known motion:
+        # the camera turns by exp(tw_rot) (points) from pool frame i to i+1, i.e. the body rate is -tw_rot / dt; a constant
+        # gyro bias on top; the accelerometer sees gravity in the camera frame of the frame it arrives at.
+        tw = synth.smooth_trajectory(args.pool, 13)
+        poses = [R for _, R, _ in synth.billboard_sequence(8, 8, args.pool, seed=11 + rank)]   # the rotations only (tiny render)
+        bias, dt_f, nsamp = np.array([0.004, -0.002, 0.003]), 0.05, 10
+        imu_params = edgehip.euroc_imu_params(init_bias_frame_num=3)
+
+        def imu_record(i_from, i_to):
+            rot = tw[i_from, 3:] if i_to > i_from else -tw[i_to, 3:]
+            giro = -rot / dt_f + bias
+            r = edgehip.ImuIntegrated()
+            r.n, r.dt = nsamp, nsamp * dt_f / nsamp
+            r.Rot[:] = synth._so3_exp(giro * dt_f).reshape(-1)
+            r.giro[:] = giro
+            acc = -(poses[i_to] @ np.array([0.0, 9.8, 0.0]))
+            r.acel[:] = acc
+            r.cacel[:] = acc
+            return r
+        trans = {}
+        for i in range(args.pool):
+            for j in (i - 1, i, i + 1):
+                if 0 <= j < args.pool:
+                    trans[(i, j)] = imu_record(i, j) if i != j else imu_record(i, min(i + 1, args.pool - 1))
+
+        def imu_of(k):
+            return [trans[(tri(k - 1 + o, args.pool) if k > 0 else tri(k + o, args.pool), tri(k + o, args.pool))] for o in offs]
+    rp = Replay(edgehip, params, B * C, pool, args.pool, lambda k: [tri(k + o, args.pool) for o in offs], local_rank, C,
+                imu_params=imu_params, imu_of=imu_of)
     ehs, eh = rp.ehs, rp.ehs[0]   # eh: the context whose streams carry the HIP-event profiler
 
     # ============================ --config stage_a: DoG + KeyLine extraction alone (configs[1]) ============================
@@ -708,13 +751,16 @@ def main():
             hetero = {"value": None, "error": str(e)[:200]}
 
     line = {
-        "metric": "frames/sec (DoG+extract+track+depth) 752x480 EuRoC" if not tum else
+        "metric": ("frames/sec (DoG+extract+track+depth, ImuMode=2) 752x480 EuRoC" if args.imu else
+                   "frames/sec (DoG+extract+track+depth) 752x480 EuRoC") if not tum else
                   "frames/sec (undistort+DoG+extract+track+depth) 640x480 TUM",
         "value": round(value, 1), "unit": "frames/s", "n_gpus": world, "steps": K, "warmup": Wm,
         "ms_per_step": round(dt / K * 1e3, 4), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
         "dtype": "f32 scale-space / f64 tracker+EKF", "data": "synthetic",
         "config": {"workload": ("full path (configs[2] at configs[1] size): 752x480 synthetic EuRoC-intrinsics "
-                                "sequences, GlobalConfig_EuRoC params, ImuMode=0") if not tum else
+                                "sequences, GlobalConfig_EuRoC params, " + ("ImuMode=2: the IMU branch of SecondThread (gyro pre-rotation, "
+                                "Minimizer_V, ExtRotVel, BiasCorrect, scale filter, gravity-aligned pose) batched on the device, integrated "
+                                "IMU data synthesised from the camera motion" if args.imu else "ImuMode=0")) if not tum else
                                ("BASELINE configs[3]: 640x480 synthetic TUM-intrinsics sequences taken as the distorted camera "
                                 "image, GlobalConfig_desk.txt params, UseUndistort=1 with the EuRoC distortion (SURVEY 8d scene S3), "
                                 "undistortion fused into the stage-A load"),

@@ -1071,6 +1071,21 @@ __global__ __launch_bounds__(256) void k_retune(SeqA *seqs, const int32_t *__res
     retuned_out[seq] = r;
 }
 
+// image_undistort::undistort<true> (image_undistort.h:105-122) fused with ConvertRGB2BW (image.h:197-203): b+g+r of the
+// resampled pixel as a 16-bit plane — the input of the fused stage-A kernel when UseUndistort is set (the four bilinear taps
+// are data-dependent gathers, which that kernel's thread <-> column-pair layout cannot prefetch; here they are plain loads
+// of a streaming kernel: 36 N map bytes + the frame in, 2 N out).
+__global__ __launch_bounds__(256) void k_undistort_grey(const uint8_t *__restrict__ rgb, const int32_t *__restrict__ fidx,
+                                                        uint16_t *__restrict__ out, int w, int n, const int32_t *__restrict__ und_base,
+                                                        const uint4 *__restrict__ und_iw) {
+    const int seq = blockIdx.z;
+    const uint8_t *frame = rgb + (size_t)(fidx ? fidx[seq] : seq) * (size_t)n * 3;
+    const int pix = blockIdx.x * 256 + threadIdx.x;
+    if (pix >= n) return;
+    const uchar3 c = undist_rgb(frame, und_base[pix], und_iw[pix], w);
+    out[(size_t)seq * n + pix] = (uint16_t)((int)c.x + (int)c.y + (int)c.z);
+}
+
 __global__ void k_undistort_frame(const uint8_t *__restrict__ frame, uint8_t *__restrict__ out, int w, int n,
                                   const int32_t *__restrict__ und_base, const uint4 *__restrict__ und_iw) {
     const int pix = blockIdx.x * blockDim.x + threadIdx.x;
@@ -1109,7 +1124,16 @@ int stage_a_enqueue(edgehip_ctx *c, int slot) {
     // kernel (stage_a_fused.hip); level_mode 3 forces it, 1 / 2 keep the multi-kernel path (A/B measurements, tests).
     const bool use_fused = fused_supported(c) && (c->level_mode == 3 || (c->level_mode == 0 && B >= c->fused_min_batch));
     if (use_fused) {
-        if (int e = stage_a_fused_enqueue(c, slot, rgb_base, rgb_idx)) return e;
+        const uint16_t *grey16 = nullptr;
+        if (c->und_base) {   // UseUndistort: resample + grey first (the integral-image scratch is free on this path)
+            ProfScope ps(c, PROF_A_ROWSCAN, st);
+            uint16_t *g16 = reinterpret_cast<uint16_t *>(c->ii);
+            hipLaunchKernelGGL(k_undistort_grey, dim3((unsigned)((n + 255) / 256), 1, B), dim3(256), 0, st, rgb_base, rgb_idx, g16, w,
+                               (int)n, c->und_base, c->und_iw);
+            EH_LAUNCH_CHECK();
+            grey16 = g16;
+        }
+        if (int e = stage_a_fused_enqueue(c, slot, rgb_base, rgb_idx, grey16)) return e;
         ProfScope ps(c, PROF_A_JOIN, st);
         hipLaunchKernelGGL(k_join_histo<true>, dim3((pl.cap + 255) / 256, 1, B), dim3(256), 0, st, kldev(c, slot),
                            maskof(c, slot), c->seqa, c->histo, w, n, c->p.qcut_nbins);

@@ -30,6 +30,7 @@ __host__ __device__ constexpr inline int fused_row_stride(int w) {
 struct FusedArgs {
     const uint8_t *rgb;        // frames of the slot (sequence-major) or a bound pool
     const int32_t *fidx;       // [B] frame index inside the pool, or null
+    const uint16_t *grey16;    // [B][N] b+g+r of the undistorted frame (GREY16 instantiations), or null
     const float *lut;          // [kDivLutMax] (float)(1.0/count)
     float *planes;             // optional debug planes [5][B][N]
     int32_t *mask;             // [B][N] of the slot
@@ -50,6 +51,6 @@ struct FusedArgs {
 };
 
 bool fused_supported(const edgehip_ctx *c);
-int stage_a_fused_enqueue(edgehip_ctx *c, int slot, const uint8_t *rgb_base, const int32_t *rgb_idx);
+int stage_a_fused_enqueue(edgehip_ctx *c, int slot, const uint8_t *rgb_base, const int32_t *rgb_idx, const uint16_t *grey16);
 
 }  // namespace edgehip

@@ -134,7 +134,9 @@ __device__ __forceinline__ FitOut plane_fit5(const float *s_dog, const int ro[5]
 
 // W = image width known at compile time (LDS offsets become instruction immediates), 0 = taken from the arguments.
 // DBG = also write the img0 / img1 / DoG / dx / dy planes (debug_planes contexts: tests).
-template <int W, bool DBG, int RB, int D1, int D2A, int D2B, int D3A, int D3B>
+// GREY16 = the input is a plane of 16-bit grey values b+g+r (a.grey16: the frame after k_undistort_grey, image_undistort
+// fused with ConvertRGB2BW) instead of the RGB24 frame.
+template <int W, bool DBG, bool GREY16, int RB, int D1, int D2A, int D2B, int D3A, int D3B>
 __global__ __launch_bounds__(512) void k_stage_a_fused(FusedArgs a) {
     constexpr int R1 = D1 / 2, R2A = D2A / 2, R2B = D2B / 2, R3A = D3A / 2, R3B = D3B / 2;
     constexpr int LB = R1 + R2B + R3B;                  // rows img1 trails the input by
@@ -337,7 +339,8 @@ __global__ __launch_bounds__(512) void k_stage_a_fused(FusedArgs a) {
     }
     np_lo = __builtin_amdgcn_readfirstlane(np_lo);
     np_hi = __builtin_amdgcn_readfirstlane(np_hi);
-    const uint8_t *frame = a.rgb + (size_t)(a.fidx ? a.fidx[seq] : seq) * a.n * 3;
+    const uint8_t *frame = GREY16 ? reinterpret_cast<const uint8_t *>(a.grey16 + (size_t)seq * a.n)
+                                  : a.rgb + (size_t)(a.fidx ? a.fidx[seq] : seq) * a.n * 3;
 
     uint16_t *my_list = s_list + (size_t)wv * RB * 128;
     uint16_t *my_res = s_res + (size_t)wv * RB * 128;
@@ -527,8 +530,12 @@ __global__ __launch_bounds__(512) void k_stage_a_fused(FusedArgs a) {
             if (ABL & 16) { pre[j] = make_uint2(0, 0); continue; }
             int y = t * RB + j;
             y = y < h ? y : h - 1;
-            const uint32_t byte0 = (uint32_t)(y * w + xr0) * 3u;     // < 2^31: the frame is w*h*3 bytes
-            pre[j] = *reinterpret_cast<const uint2 *>(frame + (byte0 & ~3u));
+            if (GREY16) {
+                pre[j] = make_uint2(*reinterpret_cast<const uint32_t *>(frame + (uint32_t)(y * w + xr0) * 2u), 0u);   // two 16-bit values
+            } else {
+                const uint32_t byte0 = (uint32_t)(y * w + xr0) * 3u;     // < 2^31: the frame is w*h*3 bytes
+                pre[j] = *reinterpret_cast<const uint2 *>(frame + (byte0 & ~3u));
+            }
         }
         if (act) {
             float *Q1 = smem + x0 + (((set * 4 + 1) * RB) * WP + PAD);
@@ -640,12 +647,17 @@ __global__ __launch_bounds__(512) void k_stage_a_fused(FusedArgs a) {
             for (int j = 0; j < RB; j++) {
                 int y = t * RB + j;
                 y = y < h ? y : h - 1;
-                const unsigned sh = (((uint32_t)(y * w + x0) * 3u) & 3u) * 8u;   // 0 or 16
-                const unsigned long long q8 = (((unsigned long long)pre[j].y << 32) | pre[j].x) >> sh;
-                const unsigned lo = (unsigned)q8, hi = (unsigned)(q8 >> 24);
                 v2f g;
-                g.x = (float)((int)(lo & 0xFF) + (int)((lo >> 8) & 0xFF) + (int)((lo >> 16) & 0xFF));
-                g.y = (float)((int)(hi & 0xFF) + (int)((hi >> 8) & 0xFF) + (int)((hi >> 16) & 0xFF));
+                if (GREY16) {
+                    g.x = (float)(int)(pre[j].x & 0xFFFFu);
+                    g.y = (float)(int)(pre[j].x >> 16);
+                } else {
+                    const unsigned sh = (((uint32_t)(y * w + x0) * 3u) & 3u) * 8u;   // 0 or 16
+                    const unsigned long long q8 = (((unsigned long long)pre[j].y << 32) | pre[j].x) >> sh;
+                    const unsigned lo = (unsigned)q8, hi = (unsigned)(q8 >> 24);
+                    g.x = (float)((int)(lo & 0xFF) + (int)((lo >> 8) & 0xFF) + (int)((lo >> 16) & 0xFF));
+                    g.y = (float)((int)(hi & 0xFF) + (int)((hi >> 8) & 0xFF) + (int)((hi >> 16) & 0xFF));
+                }
                 *reinterpret_cast<v2f *>(Q0 + j * WP) = g;
             }
         }
@@ -701,7 +713,6 @@ bool fused_supported(const edgehip_ctx *c) {
     const DevicePlan &pl = c->plan;
     if (pl.box[0][0] != 3 || pl.box[0][1] != 3 || pl.box[0][2] != 5) return false;
     if (pl.box[1][0] != 3 || pl.box[1][1] != 5 || pl.box[1][2] != 5) return false;
-    if (c->und_base) return false;                          // the undistorting source keeps the multi-kernel path
     if (c->p.plane_fit_size != 2) return false;
     const int nw = fused_col_waves(pl.w);
     if (nw + 1 > 8) return false;                           // 256 VGPRs per thread need <= 8 waves per workgroup
@@ -710,7 +721,7 @@ bool fused_supported(const edgehip_ctx *c) {
     return fused_lds_bytes(pl.w) <= 160 * 1024;
 }
 
-int stage_a_fused_enqueue(edgehip_ctx *c, int slot, const uint8_t *rgb_base, const int32_t *rgb_idx) {
+int stage_a_fused_enqueue(edgehip_ctx *c, int slot, const uint8_t *rgb_base, const int32_t *rgb_idx, const uint16_t *grey16) {
     const DevicePlan &pl = c->plan;
     const int B = pl.nseq;
     const int nw = fused_col_waves(pl.w);
@@ -740,15 +751,25 @@ int stage_a_fused_enqueue(edgehip_ctx *c, int slot, const uint8_t *rgb_base, con
     a.ablate = 0;
 #endif
     const size_t sm = fused_lds_bytes(pl.w);
-    // the shipped image sizes get their own instantiation (EuRoC 752, TUM 640), any other width — and contexts with debug
-    // planes — the generic one
-    void (*fn)(FusedArgs) = k_stage_a_fused<0, false, kFusedRB, 3, 3, 5, 5, 5>;
-    if (c->planes) fn = k_stage_a_fused<0, true, kFusedRB, 3, 3, 5, 5, 5>;
-    else if (pl.w == 752) fn = k_stage_a_fused<752, false, kFusedRB, 3, 3, 5, 5, 5>;
-    else if (pl.w == 640) fn = k_stage_a_fused<640, false, kFusedRB, 3, 3, 5, 5, 5>;
+    a.grey16 = grey16;
+    // the shipped image sizes get their own instantiation (EuRoC 752 from RGB, TUM 640 from the undistorted grey plane), any
+    // other width — and contexts with debug planes — the generic ones
+    void (*fn)(FusedArgs);
+    if (grey16) {
+        fn = k_stage_a_fused<0, false, true, kFusedRB, 3, 3, 5, 5, 5>;
+        if (c->planes) fn = k_stage_a_fused<0, true, true, kFusedRB, 3, 3, 5, 5, 5>;
+        else if (pl.w == 640) fn = k_stage_a_fused<640, false, true, kFusedRB, 3, 3, 5, 5, 5>;
+    } else {
+        fn = k_stage_a_fused<0, false, false, kFusedRB, 3, 3, 5, 5, 5>;
+        if (c->planes) fn = k_stage_a_fused<0, true, false, kFusedRB, 3, 3, 5, 5, 5>;
+        else if (pl.w == 752) fn = k_stage_a_fused<752, false, false, kFusedRB, 3, 3, 5, 5, 5>;
+        else if (pl.w == 640) fn = k_stage_a_fused<640, false, false, kFusedRB, 3, 3, 5, 5, 5>;
+    }
     if (!c->lds_optin_fused) {
-        const void *fns[4] = {(const void *)k_stage_a_fused<0, false, kFusedRB, 3, 3, 5, 5, 5>, (const void *)k_stage_a_fused<0, true, kFusedRB, 3, 3, 5, 5, 5>,
-                              (const void *)k_stage_a_fused<752, false, kFusedRB, 3, 3, 5, 5, 5>, (const void *)k_stage_a_fused<640, false, kFusedRB, 3, 3, 5, 5, 5>};
+        const void *fns[7] = {(const void *)k_stage_a_fused<0, false, false, kFusedRB, 3, 3, 5, 5, 5>, (const void *)k_stage_a_fused<0, true, false, kFusedRB, 3, 3, 5, 5, 5>,
+                              (const void *)k_stage_a_fused<752, false, false, kFusedRB, 3, 3, 5, 5, 5>, (const void *)k_stage_a_fused<640, false, false, kFusedRB, 3, 3, 5, 5, 5>,
+                              (const void *)k_stage_a_fused<0, false, true, kFusedRB, 3, 3, 5, 5, 5>, (const void *)k_stage_a_fused<0, true, true, kFusedRB, 3, 3, 5, 5, 5>,
+                              (const void *)k_stage_a_fused<640, false, true, kFusedRB, 3, 3, 5, 5, 5>};
         for (const void *f : fns) EH_CHECK(hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         c->lds_optin_fused = true;
     }

@@ -1179,20 +1179,23 @@ static int frame_enqueue(edgehip_ctx *c, int sn, int so, int sp, int have_pair, 
         if (have_pair) {
             EH_TRY(quantile_enqueue(c, so, kRhoMin, kRhoMax, c->p.qcut_quantile, c->p.qcut_nbins));  // :172
             EH_TRY(build_field_enqueue(c, sn, c->p.search_range, -1.f));                              // :177
-            { ProfScope ps(c, PROF_C_POSE); EH_TRY(imu_pre_enqueue(c, so)); }                         // :183-213
+            { ProfScope ps(c, PROF_IMU_FILTERS); EH_TRY(imu_pre_enqueue(c, so)); }                         // :183-213
             EH_TRY(rotate_buf_enqueue(c, so));                                                       // :215 gyro pre-rotation
-            EH_TRY(minimizer_v_enqueue(c, sn, so, c->frames_seen % kRefRing, c->p.tracker_iter_num, c->p.tracker_match_thresh,
-                                       c->p.match_num_thresh, c->p.reweight_distance));              // :223
+            {
+                ProfScope ps(c, PROF_B_MINIMIZER_V);
+                EH_TRY(minimizer_v_enqueue(c, sn, so, c->frames_seen % kRefRing, c->p.tracker_iter_num, c->p.tracker_match_thresh,
+                                           c->p.match_num_thresh, c->p.reweight_distance));          // :223
+            }
             EH_TRY(forward_match_enqueue(c, so, sn));                                                // :230
-            EH_TRY(ext_rotvel_enqueue(c, sn));                                                       // :237
-            { ProfScope ps(c, PROF_C_POSE); EH_TRY(imu_mid_enqueue(c)); }                             // :237-272, :387-397
+            { ProfScope ps(c, PROF_C_EXTROTVEL); EH_TRY(ext_rotvel_enqueue(c, sn)); }                 // :237
+            { ProfScope ps(c, PROF_IMU_FILTERS); EH_TRY(imu_mid_enqueue(c)); }                             // :237-272, :387-397
             EH_TRY(rotate_buf_enqueue(c, so));                                                       // :319
             EH_TRY(directed_enqueue(c, sn, so));                                                     // :410
             { ProfScope ps(c, PROF_C_POSE); EH_TRY(glue(c, 2, sn, have_pair)); }                     // :412-422
             EH_TRY(regekf_enqueue(c, sn, 1, 1));                                                     // :453, :460
             EH_TRY(rescale_enqueue(c, sn));                                                          // :487
         }
-        { ProfScope ps(c, PROF_C_POSE); EH_TRY(imu_post_enqueue(c, sn, have_pair)); }                 // :280-312, :519-606
+        { ProfScope ps(c, PROF_IMU_SCALE_POSE); EH_TRY(imu_post_enqueue(c, sn, have_pair)); }                 // :280-312, :519-606
     } else if (have_pair) {
         EH_TRY(quantile_enqueue(c, so, kRhoMin, kRhoMax, c->p.qcut_quantile, c->p.qcut_nbins));  // rebvo_second_t.cpp:172
         EH_TRY(build_field_enqueue(c, sn, c->p.search_range, -1.f));                              // :177

@@ -88,3 +88,32 @@ def test_fused_is_the_default_for_large_batches_and_matches_the_multi_kernel_pat
         assert x.kn == y.kn and x.tresh == y.tresh and x.V[:] == y.V[:] and x.W[:] == y.W[:] and x.Pos[:] == y.Pos[:]
     for (k1, m1), (k2, m2) in zip(ka, kb):
         assert np.array_equal(m1, m2) and k1.tobytes() == k2.tobytes()
+
+
+def test_fused_with_the_undistorting_source():
+    """UseUndistort (BASELINE config 4): image_undistort + ConvertRGB2BW in k_undistort_grey, then the fused kernel on the 16-bit
+    grey plane — planes, mask and KeyLines against the reference, with the reference's own undistortion map semantics."""
+    tlk._scale_space_case("tum_undistort_640x480", 640, 480, True, {})
+
+
+def test_fused_tum_product_instantiation_matches_the_multi_kernel_path():
+    """TUM 640x480 + undistort at a batch that takes the fused path by default (the W = 640 / grey-plane instantiation, no debug
+    planes) against the same batch on the forced multi-kernel path: identical nav records and depth maps."""
+    w, h, B = 640, 480, 192
+    pool = [f for f, _, _ in synth.billboard_sequence(w, h, 4, fx=525.0, fy=525.0, cx=320.0, cy=240.0)]
+    outs = []
+    for mode in ("0", "2"):
+        os.environ["EDGEHIP_LEVEL_MODE"] = mode
+        eh = edgehip.EdgeHip(edgehip.tum_params(w, h, use_undistort=1), nseq=B, nslots=3)
+        for k in range(3):
+            eh.upload_rgb(eh.next_slot(), np.stack([pool[(k + s) % 4] for s in range(B)]))
+            eh.process_frame(0.05 * k)
+        navs = eh.read_nav()
+        kls = [eh.download_keylines(s, eh.cur_slot()) for s in (0, 1, B - 1)]
+        outs.append((navs, kls))
+        eh.close()
+    (na, ka), (nb, kb) = outs
+    for x, y in zip(na, nb):
+        assert x.kn == y.kn and x.kn > 5000 and x.tresh == y.tresh and x.V[:] == y.V[:] and x.W[:] == y.W[:] and x.Pos[:] == y.Pos[:]
+    for (k1, m1), (k2, m2) in zip(ka, kb):
+        assert np.array_equal(m1, m2) and k1.tobytes() == k2.tobytes()
