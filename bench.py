@@ -469,6 +469,7 @@ def main():
         rp.sync()
         eh.profile_enable(True)
         eh.profile_select(None)
+        # ---- timed region (stage A only): EXACTLY K steps between barriers ----
         if world > 1:
             dist.barrier()
         t0 = time.perf_counter()
@@ -479,6 +480,7 @@ def main():
         if world > 1:
             dist.barrier()
         dt = time.perf_counter() - t0
+        # ---- end of timed region ----
         prof = {g: (ms, calls) for g, (ms, calls) in eh.profile_read().items() if calls}
         kn_mean = float(np.mean([v for e in ehs for v in e.get_kn((Wm + K - 1) % 3)]))
         if world > 1:
@@ -574,6 +576,7 @@ def main():
         mover.finish()      # every record has reached rank 0 inside the timed region; all but the last block under compute
     barrier()
     dt = time.perf_counter() - t0
+    # ---- end of timed region ----
     if world > 1:
         tmax = torch.tensor([dt], dtype=torch.float64, device="cuda" if backend == "nccl" else "cpu")
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
