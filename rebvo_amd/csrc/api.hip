@@ -47,6 +47,7 @@ int order_bc_after_a(edgehip_ctx *c) {
     return 0;
 }
 int sync_all(edgehip_ctx *c) {
+    if (c->stream_imu) EH_CHECK(hipStreamSynchronize(c->stream_imu));   // it waits for main-stream events: no work is left behind it
     EH_CHECK(hipStreamSynchronize(c->stream_up));
     EH_CHECK(hipStreamSynchronize(c->stream_a));
     EH_CHECK(hipStreamSynchronize(c->stream));
@@ -556,7 +557,10 @@ int edgehip_destroy(edgehip_ctx *c) {
         delete c->prof;
     }
     if (c->nav_log) (void)hipFree(c->nav_log);
+    if (c->stream_imu) { (void)hipStreamSynchronize(c->stream_imu); (void)hipStreamDestroy(c->stream_imu); for (int i = 0; i < 2; i++) { (void)hipEventDestroy(c->ev_imu_snap[i]); (void)hipEventDestroy(c->ev_imu_post[i]); } }
     if (c->imu_track) (void)hipFree(c->imu_track);
+    if (c->imu_filter) (void)hipFree(c->imu_filter);
+    if (c->imu_snap) (void)hipFree(c->imu_snap);
     if (c->imu_in_dev) (void)hipFree(c->imu_in_dev);
     if (c->nav_imu_dev) (void)hipFree(c->nav_imu_dev);
     if (c->pinned_imu) (void)hipHostFree(c->pinned_imu);
@@ -583,6 +587,7 @@ int edgehip_reset(edgehip_ctx *c) {
     EH_CHECK(hipMemcpyAsync(c->seqa, c->pinned_seqa, sizeof(SeqA) * B, hipMemcpyHostToDevice, c->stream));
     EH_CHECK(hipMemsetAsync(c->framecount, 0, sizeof(uint32_t) * c->fc_rows * B, c->stream));
     EH_CHECK(hipMemsetAsync(c->kn_slot, 0, sizeof(int32_t) * S * B, c->stream));
+    if (c->imu_enabled) { if (int e = imu_reset_enqueue(c)) return e; }
     EH_CHECK(hipStreamSynchronize(c->stream));
     c->frame_slot = -1;
     c->frames_seen = 0;
@@ -736,6 +741,7 @@ int edgehip_read_nav_log(edgehip_ctx *c, int first, int count, edgehip_nav *out)
     EH_ENTER(c);
     if (!c || !out || !c->nav_log || first < 0 || count < 1 || count > c->nav_log_len) { set_error("read_nav_log: bad range or log disabled"); return EDGEHIP_ERR_ARG; }
     const size_t B = c->plan.nseq;
+    if (c->stream_imu) EH_CHECK(hipStreamSynchronize(c->stream_imu));   // ImuMode > 0: the records are written on the IMU stream
     for (int k = 0; k < count; k++) {
         const int slot = (first + k) % c->nav_log_len;
         EH_CHECK(hipMemcpyAsync(out + (size_t)k * B, c->nav_log + (size_t)slot * B, sizeof(edgehip_nav) * B, hipMemcpyDeviceToHost, c->stream));

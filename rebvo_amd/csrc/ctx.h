@@ -251,7 +251,12 @@ struct edgehip_ctx {
     // the IMU branch of the frame driver (edgehip_imu_enable; stage_imu.hip)
     bool imu_enabled = false, imu_pending = false;
     edgehip_imu_params imu_params;
-    void *imu_track = nullptr;                       // [B] ImuTrackDev
+    void *imu_track = nullptr;                       // [B] ImuTrackDev (main stream)
+    void *imu_filter = nullptr;                      // [B] ImuFilterDev (IMU stream)
+    void *imu_snap = nullptr;                        // [2][B] ImuSnap: a frame's hand-over from the main to the IMU stream
+    hipStream_t stream_imu = nullptr;                // scale filter + pose + nav record of frame k, under frame k+1
+    hipEvent_t ev_imu_snap[2], ev_imu_post[2];       // [frame & 1] snapshot written (main) / consumed (IMU stream)
+    bool imu_post_valid[2] = {false, false};
     edgehip_imu_integrated *imu_in_dev = nullptr;    // [B] integrated IMU data of the frame being enqueued
     edgehip_nav_imu *nav_imu_dev = nullptr;          // [B]
     edgehip_imu_integrated *pinned_imu = nullptr;    // [8][B] ring, like the time stamps
@@ -334,7 +339,10 @@ int directed_enqueue(edgehip_ctx *c, int slot_new, int slot_old);
 int regekf_enqueue(edgehip_ctx *c, int slot, int do_reg, int do_ekf);
 int rescale_enqueue(edgehip_ctx *c, int slot);
 int pose_enqueue(edgehip_ctx *c, int slot_new, const double *t_host);
-int imu_pre_enqueue(edgehip_ctx *c, int slot_old);     // stage_imu.hip
+int imu_begin_enqueue(edgehip_ctx *c);                // stage_imu.hip
+int imu_reset_enqueue(edgehip_ctx *c);
+int imu_pose_reset_enqueue(edgehip_ctx *c, int seq);   // REBVO::Reset()'s pose part, on the IMU stream
+int imu_pre_enqueue(edgehip_ctx *c, int slot_old);
 int imu_mid_enqueue(edgehip_ctx *c);
 int imu_post_enqueue(edgehip_ctx *c, int slot_new, int have_pair);
 

@@ -658,13 +658,17 @@ __global__ __launch_bounds__(256) void k_ext_rotvel(const KlSoA *kls, const int3
 }
 
 // REBVO::Reset() as executed by SecondThread after a frame (rebvo_second_t.cpp:609-620)
-__global__ __launch_bounds__(256) void k_depth_reset(const KlSoA *kls, const int32_t *__restrict__ kns, SeqDev *seqs, int only_seq) {
+__global__ __launch_bounds__(256) void k_depth_reset(const KlSoA *kls, const int32_t *__restrict__ kns, SeqDev *seqs, int only_seq,
+                                                      int pose_too) {
     const int seq = blockIdx.z, i = blockIdx.x * 256 + threadIdx.x;
     if (only_seq >= 0 && seq != only_seq) return;
     if (i == 0) {
         edgehip_seq_state &p = seqs[seq].pub;
-        ident_scaled(p.Pose, 1);
-        for (int k = 0; k < 3; k++) { p.Pos[k] = 0; p.V[k] = 0; p.W[k] = 0; }
+        if (pose_too) {   // ImuMode > 0: the pose belongs to the IMU stream (imu_pose_reset_enqueue)
+            ident_scaled(p.Pose, 1);
+            for (int k = 0; k < 3; k++) p.Pos[k] = 0;
+        }
+        for (int k = 0; k < 3; k++) { p.V[k] = 0; p.W[k] = 0; }
     }
     if (i >= kns[seq]) return;
     kls[seq].rho[i] = kRhoInit;
@@ -1132,8 +1136,9 @@ int edgehip_depth_reset(edgehip_ctx *c, int seq) {
     if (c->frame_slot < 0) return 0;  // nothing detected yet: the initial state already is the reset state
     const DevicePlan &pl = c->plan;
     hipLaunchKernelGGL(k_depth_reset, dim3((pl.cap + 255) / 256, 1, pl.nseq), dim3(256), 0, c->stream,
-                       kldev(c, c->frame_slot), c->kn_slot + (size_t)c->frame_slot * pl.nseq, c->seq, seq);
+                       kldev(c, c->frame_slot), c->kn_slot + (size_t)c->frame_slot * pl.nseq, c->seq, seq, c->imu_enabled ? 0 : 1);
     EH_LAUNCH_CHECK();
+    if (c->imu_enabled) return imu_pose_reset_enqueue(c, seq);
     return 0;
 }
 
@@ -1142,8 +1147,9 @@ int edgehip_depth_reset_slot(edgehip_ctx *c, int seq, int slot) {
     if (!c || seq >= c->plan.nseq || slot < 0 || slot >= c->plan.nslots) return EDGEHIP_ERR_ARG;
     const DevicePlan &pl = c->plan;
     hipLaunchKernelGGL(k_depth_reset, dim3((pl.cap + 255) / 256, 1, pl.nseq), dim3(256), 0, c->stream, kldev(c, slot),
-                       c->kn_slot + (size_t)slot * pl.nseq, c->seq, seq);
+                       c->kn_slot + (size_t)slot * pl.nseq, c->seq, seq, c->imu_enabled ? 0 : 1);
     EH_LAUNCH_CHECK();
+    if (c->imu_enabled) return imu_pose_reset_enqueue(c, seq);
     return 0;
 }
 
@@ -1176,6 +1182,7 @@ static int frame_enqueue(edgehip_ctx *c, int sn, int so, int sp, int have_pair, 
     }
     if (c->imu_enabled) {
         // ---- ImuMode > 0 (rebvo_second_t.cpp:182-336, 387-493, 519-606): everything on the device, stage_imu.hip has the filters ----
+        EH_TRY(imu_begin_enqueue(c));
         if (have_pair) {
             EH_TRY(quantile_enqueue(c, so, kRhoMin, kRhoMax, c->p.qcut_quantile, c->p.qcut_nbins));  // :172
             EH_TRY(build_field_enqueue(c, sn, c->p.search_range, -1.f));                              // :177
@@ -1195,7 +1202,7 @@ static int frame_enqueue(edgehip_ctx *c, int sn, int so, int sp, int have_pair, 
             EH_TRY(regekf_enqueue(c, sn, 1, 1));                                                     // :453, :460
             EH_TRY(rescale_enqueue(c, sn));                                                          // :487
         }
-        { ProfScope ps(c, PROF_IMU_SCALE_POSE); EH_TRY(imu_post_enqueue(c, sn, have_pair)); }                 // :280-312, :519-606
+        EH_TRY(imu_post_enqueue(c, sn, have_pair));                                                  // :280-312, :519-606
     } else if (have_pair) {
         EH_TRY(quantile_enqueue(c, so, kRhoMin, kRhoMax, c->p.qcut_quantile, c->p.qcut_nbins));  // rebvo_second_t.cpp:172
         EH_TRY(build_field_enqueue(c, sn, c->p.search_range, -1.f));                              // :177
@@ -1297,6 +1304,7 @@ int edgehip_process_frame(edgehip_ctx *c, const double *t) {
 int edgehip_read_nav(edgehip_ctx *c, edgehip_nav *nav) {
     EH_ENTER(c);
     if (!c || !nav) return EDGEHIP_ERR_ARG;
+    if (c->stream_imu) EH_CHECK(hipStreamSynchronize(c->stream_imu));   // ImuMode > 0: the records are written on the IMU stream
     EH_CHECK(hipMemcpyAsync(c->pinned_nav, c->nav_dev, sizeof(edgehip_nav) * c->plan.nseq, hipMemcpyDeviceToHost, c->stream));
     EH_CHECK(hipStreamSynchronize(c->stream));
     memcpy(nav, c->pinned_nav, sizeof(edgehip_nav) * c->plan.nseq);

@@ -14,11 +14,14 @@
 //
 // The filters are 3..11-dimensional dense algebra with data-dependent control flow and no parallelism worth a wave: one
 // THREAD per sequence runs the very code the host library runs for a single live camera (rebvo/imu_filters.h over
-// rebvo/linalg.h, both host+device), so the two paths cannot drift apart.  Slow per thread (the scale filter is 20
-// Gauss-Newton steps on an 11-row problem, ~1 ms on one lane) but the batch dimension fills the lanes, and nothing in
-// the tracker or mapper waits for it: it only feeds the pose and the record of the frame.
+// rebvo/linalg.h, both host+device), so the two paths cannot drift apart.  The batch dimension fills the lanes; the kernels
+// are bounded to 64 threads so that a lane gets the full register file, and the file is compiled with a high unroll
+// threshold (Makefile) so that the small matrices index statically and stay in registers.  Measured at 1024 sequences:
+// k_imu_post 20 ms with the default 128-VGPR budget (12 KB of scratch per lane), 6.9 ms bounded to 64 threads, 2.5 ms
+// unrolled — and nothing in the tracker or mapper waits for it (see ImuSnap below).
 
 #include <math.h>
+#include <stdlib.h>
 #include <string.h>
 
 #include "ctx.h"
@@ -30,19 +33,42 @@ namespace la = rebvo::la;
 using la::Mat;
 using la::Vec;
 
-// SecondThread's IMU-branch locals that persist from frame to frame (REBVO::ImuTrack of the host library), per sequence.
-struct ImuTrackDev {
+// SecondThread's IMU-branch locals that persist from frame to frame (REBVO::ImuTrack of the host library), per sequence,
+// in two halves that never share a writer.  The tracker half lives on the context's main stream.  The scale filter and the
+// pose (20 Gauss-Newton steps on an 11-row problem per frame: ~10 ms on one lane, whatever the batch) feed nothing back
+// into the tracker or the mapper, so they live on a stream of their own (k_imu_post) and run under the NEXT frame's stage A
+// and tracker; what they need of a frame travels in an ImuSnap (two of them per sequence, alternating), ordered by events.
+struct ImuTrackDev {            // main stream: k_imu_pre / k_imu_mid
     int32_t n_frame, init, n_giro_init, est_ok;
-    double K, QKp, Rg, dt_frame;
-    Vec<3> Vg, Bg, Av, As, dVv, dWv, dVgv, dWgv, Vgv, Wgv, dVgva, dWgva, Vgva;
-    Vec<3> g_est, u_est, b_est, Posgv, Posgva, giro_init, g_init;
-    Mat<3, 3> P_Vg, RGiro, RGBias, W_Bg, Qrot, Qg, Qbias, Rs, Rv, Rgva, R, R0;
+    double dt_frame;
+    Vec<3> Vg, Bg, giro_init, g_init;
+    Mat<3, 3> P_Vg, RGiro, RGBias, W_Bg, R;
+    edgehip_imu_integrated imud;   // integrated IMU data of the running frame
+};
+struct ImuSnap {                // written on the main stream (k_imu_pre, k_imu_mid, k_imu_snap), read by k_imu_post
+    int32_t have_pair, est_ok, init, x_grav_set;
+    double dt, QKp;
+    Vec<3> x_grav;              // gyro start-up finished in this frame: the gravity estimate X[1..3] starts from here (:196)
+    Vec<3> Vg, Bg, dVv, dWv, dVgv, dWgv, Vgv, cacel;
+    Mat<3, 3> R, R_pre, Rv, Qrot;   // frame rotation after / before the visual correction R0
+    Vec<6> Xgv;                 // fused roto-translation and its information
+    Mat<6, 6> W_Xgv;
+    // the sequence state as the mapper left it
+    double V[3], Kp, P_Kp, s_rho_q, t_cur, V_track[3], W_track[3], PV_track[9], PW_track[9], score, rel_error, rel_error_score;
+    int32_t klm_num, klm_fwd, kf_matchs, estimation_ok, frame, minimizer_evals;
+    // and of the new edge map (its slot is recycled before k_imu_post is guaranteed to have run)
+    int32_t kn, pad;
+    double tresh;
+    float retuned, padf;
+};
+struct ImuFilterDev {           // side stream: k_imu_post
+    int32_t n_frame, pad;
+    double K, Rg;
+    Vec<3> Av, As, g_est, u_est, b_est, Posgv, Posgva, dVgva, dWgva, Vgva, Pos;
+    Mat<3, 3> Qg, Qbias, Rs, Rgva, Pose;
     Vec<7> X;
     Mat<7, 7> P;
-    Vec<6> Xgv;        // fused roto-translation and its information: handed from k_imu_mid to k_imu_post
-    Mat<6, 6> W_Xgv;
     rebvo::ScaleEstimator se;
-    edgehip_imu_integrated imud;   // integrated IMU data of the running frame
 };
 
 __device__ inline Vec<3> v3(const double *p) { Vec<3> r; r[0] = p[0]; r[1] = p[1]; r[2] = p[2]; return r; }
@@ -51,44 +77,48 @@ __device__ inline void put(double *d, const Vec<3> &v) { d[0] = v[0]; d[1] = v[1
 __device__ inline void put(double *d, const Mat<3, 3> &m) { for (int i = 0; i < 9; i++) d[i] = m.a[i]; }
 
 // rebvo_second_t.cpp:68-84 (the state a REBVO object starts its IMU branch with)
-__global__ void k_imu_init(ImuTrackDev *tracks, edgehip_imu_params ip, int nseq) {
+__global__ __launch_bounds__(64) void k_imu_init(ImuTrackDev *tracks, ImuFilterDev *filters, ImuSnap *snaps, edgehip_imu_params ip, int nseq) {
     const int seq = blockIdx.x * blockDim.x + threadIdx.x;
     if (seq >= nseq) return;
-    ImuTrackDev &s = tracks[seq];
-    s.n_frame = 0; s.init = 0; s.n_giro_init = 0; s.est_ok = 1;
-    s.K = 1; s.QKp = 0; s.dt_frame = 0;
     const Vec<3> z = Vec<3>::zeros();
-    s.Vg = s.Bg = s.Av = s.As = s.dVv = s.dWv = s.dVgv = s.dWgv = s.Vgv = s.Wgv = s.dVgva = s.dWgva = s.Vgva = z;
-    s.g_est = s.b_est = s.Posgv = s.Posgva = s.giro_init = s.g_init = z;
-    s.u_est = z; s.u_est[0] = 1;
     const Mat<3, 3> I3 = Mat<3, 3>::identity();
+    ImuTrackDev &s = tracks[seq];
+    s.n_frame = 0; s.init = 0; s.n_giro_init = 0; s.est_ok = 1; s.dt_frame = 0;
+    s.Vg = s.Bg = s.giro_init = s.g_init = z;
     s.P_Vg = Mat<3, 3>::identity(1e50);
-    s.RGiro = I3; s.RGBias = I3; s.Qrot = I3; s.Rv = I3; s.Rgva = I3; s.R = I3; s.R0 = I3;
+    s.RGiro = I3; s.RGBias = I3; s.R = I3;
     s.W_Bg = la::inv3(s.RGBias * 100.0);
-    s.Qg = I3 * ip.g_uncert * ip.g_uncert;
-    s.Rg = ip.g_module_uncer * ip.g_module_uncer;
-    s.Rs = I3 * ip.acel_meas_std * ip.acel_meas_std;
-    s.Qbias = I3 * ip.vbias_std * ip.vbias_std;
-    s.X = Vec<7>::zeros();
-    s.X[0] = M_PI / 4;
-    s.X[2] = ip.g_module;
-    s.P = Mat<7, 7>::zeros();
-    s.P(0, 0) = ip.scale_std_init * ip.scale_std_init;
-    s.P(1, 1) = s.P(2, 2) = s.P(3, 3) = 100;
-    s.P(4, 4) = s.P(5, 5) = s.P(6, 6) = ip.vbias_std * ip.vbias_std * 1e1;
-    s.Xgv = Vec<6>::zeros();
-    s.W_Xgv = Mat<6, 6>::zeros();
-    s.se = rebvo::ScaleEstimator();
+    ImuFilterDev &f = filters[seq];
+    f.n_frame = 0; f.pad = 0; f.K = 1;
+    f.Av = f.As = f.g_est = f.b_est = f.Posgv = f.Posgva = f.dVgva = f.dWgva = f.Vgva = f.Pos = z;
+    f.u_est = z; f.u_est[0] = 1;
+    f.Rgva = I3; f.Pose = I3;
+    f.Qg = I3 * ip.g_uncert * ip.g_uncert;
+    f.Rg = ip.g_module_uncer * ip.g_module_uncer;
+    f.Rs = I3 * ip.acel_meas_std * ip.acel_meas_std;
+    f.Qbias = I3 * ip.vbias_std * ip.vbias_std;
+    f.X = Vec<7>::zeros();
+    f.X[0] = M_PI / 4;
+    f.X[2] = ip.g_module;
+    f.P = Mat<7, 7>::zeros();
+    f.P(0, 0) = ip.scale_std_init * ip.scale_std_init;
+    f.P(1, 1) = f.P(2, 2) = f.P(3, 3) = 100;
+    f.P(4, 4) = f.P(5, 5) = f.P(6, 6) = ip.vbias_std * ip.vbias_std * 1e1;
+    f.se = rebvo::ScaleEstimator();
+    for (int b = 0; b < 2; b++) memset(&snaps[(size_t)b * nseq + seq], 0, sizeof(ImuSnap));
 }
 
 // After the frame-begin glue and EstimateQuantile: gyro bias start-up, R = SO3(Bg)-corrected inter-frame rotation, the
 // rotation k_rotate applies to the old KeyLines (R^T), the inputs of Minimizer_V.
-__global__ void k_imu_pre(SeqDev *seqs, ImuTrackDev *tracks, const edgehip_imu_integrated *__restrict__ imu_in, double *__restrict__ rot_buf,
-                          const float *__restrict__ retuned_old, edgehip_imu_params ip, int tracker_init_type, int nseq) {
+__global__ __launch_bounds__(64) void k_imu_pre(SeqDev *seqs, ImuTrackDev *tracks, ImuSnap *snaps, const edgehip_imu_integrated *__restrict__ imu_in,
+                          double *__restrict__ rot_buf, const float *__restrict__ retuned_old, edgehip_imu_params ip, int tracker_init_type,
+                          int nseq) {
     const int seq = blockIdx.x * blockDim.x + threadIdx.x;
     if (seq >= nseq) return;
     SeqDev *sq = seqs + seq;
     ImuTrackDev &s = tracks[seq];
+    ImuSnap &sn = snaps[seq];
+    sn.x_grav_set = 0;
     s.imud = imu_in[seq];
     const Vec<3> giro = v3(s.imud.giro), cacel = v3(s.imud.cacel);
     s.dt_frame = sq->pub.dt;
@@ -101,7 +131,8 @@ __global__ void k_imu_pre(SeqDev *seqs, ImuTrackDev *tracks, const edgehip_imu_i
                 s.Bg = s.giro_init / (double)s.n_giro_init;
                 s.init = 1;
                 s.W_Bg = la::inv3(s.RGBias * 1e2);
-                la::set_slice(s.X, 1, s.g_init / (double)s.n_giro_init);
+                sn.x_grav_set = 1;                                              // istate.X.slice<1,3>() = g_init / n: the filter's state
+                sn.x_grav = s.g_init / (double)s.n_giro_init;                   // is k_imu_post's, so the value travels with the frame
             }
         } else {
             s.init = 1;
@@ -121,13 +152,14 @@ __global__ void k_imu_pre(SeqDev *seqs, ImuTrackDev *tracks, const edgehip_imu_i
 // After Minimizer_V, FordwardMatch and the ExtRotVel sums: the 6x6 solve, BiasCorrect, the fused roto-translation and its
 // covariances (rebvo_second_t.cpp:237-272), the second rotation of the old KeyLines, and what the mapper reads from the
 // sequence state (V, P_V, P_W, R); the NaN restart of :387-397.
-__global__ void k_imu_mid(SeqDev *seqs, ImuTrackDev *tracks, const double *__restrict__ partials, double *__restrict__ rot_buf,
-                          edgehip_imu_params ip, int nblk, int nblk_stride, int nseq) {
+__global__ __launch_bounds__(64) void k_imu_mid(SeqDev *seqs, ImuTrackDev *tracks, ImuSnap *snaps, const double *__restrict__ partials,
+                          double *__restrict__ rot_buf, edgehip_imu_params ip, int nblk, int nblk_stride, int nseq) {
     const int seq = blockIdx.x * blockDim.x + threadIdx.x;
     if (seq >= nseq) return;
     SeqDev *sq = seqs + seq;
     edgehip_seq_state &p = sq->pub;
     ImuTrackDev &s = tracks[seq];
+    ImuSnap &sn = snaps[seq];
     const double dt = s.dt_frame;
     s.Vg = v3(sq->mv_V);                                                        // Minimizer_V's result
     s.P_Vg = m3(sq->mv_RVel);
@@ -149,8 +181,8 @@ __global__ void k_imu_mid(SeqDev *seqs, ImuTrackDev *tracks, const double *__res
     const Mat<6, 6> R_Xv = svd.pinv();
     Vec<6> Xv = R_Xv * JtF;
     bool ok = !(la::has_nan(Xv) || la::has_nan(R_Xv));
-    s.dVv = la::slice<3>(Xv, 0);
-    s.dWv = la::slice<3>(Xv, 3);
+    sn.dVv = la::slice<3>(Xv, 0);
+    sn.dWv = la::slice<3>(Xv, 3);
     Vec<6> Xgv = Xv;
     Mat<6, 6> W_Xgv = W_Xv;
     const Mat<3, 3> I3 = Mat<3, 3>::identity();
@@ -159,27 +191,28 @@ __global__ void k_imu_mid(SeqDev *seqs, ImuTrackDev *tracks, const double *__res
     Vec<3> dgbias = Vec<3>::zeros();
     rebvo::imufilter::BiasCorrect(Xgv, W_Xgv, dgbias, s.W_Bg, s.RGiro, s.RGBias);
     s.Bg = s.Bg + dgbias;
-    s.dVgv = la::slice<3>(Xgv, 0);
-    s.dWgv = la::slice<3>(Xgv, 3);
+    const Vec<3> dVgv = la::slice<3>(Xgv, 0), dWgv = la::slice<3>(Xgv, 3);
     Mat<3, 3> R = s.R;
-    s.Rgva = R;
-    const Mat<3, 3> R0 = la::so3_exp(s.dWgv);                                   // forward rotation
+    sn.R_pre = R;                                                               // Rgva = R (:257)
+    const Mat<3, 3> R0 = la::so3_exp(dWgv);                                     // forward rotation
     R = la::transpose(R0 * la::transpose(R));
     s.R = R;
-    s.R0 = R0;
-    s.Vgv = R0 * s.Vg + s.dVgv;
-    s.Wgv = la::so3_ln(R);
+    const Vec<3> Vgv = R0 * s.Vg + dVgv;
     const Mat<6, 6> R_Xgv = la::Cholesky<6>(W_Xgv).inverse();
     Mat<3, 3> P_V = la::block<3, 3>(R_Xgv, 0, 0), P_W = la::block<3, 3>(R_Xgv, 3, 3);
-    s.Xgv = Xgv;
-    s.W_Xgv = W_Xgv;
-    s.Rv = P_V / (dt * dt * dt * dt);                                           // :284-286
-    s.Qrot = P_W;
-    s.QKp = p.P_Kp;
+    sn.dt = dt; sn.R = R; sn.Vg = s.Vg; sn.Bg = s.Bg; sn.dVgv = dVgv; sn.dWgv = dWgv; sn.Vgv = Vgv; sn.cacel = v3(s.imud.cacel);
+    sn.Xgv = Xgv;
+    sn.W_Xgv = W_Xgv;
+    sn.Rv = P_V / (dt * dt * dt * dt);                                          // :284-286
+    sn.Qrot = P_W;
+    sn.QKp = p.P_Kp;
+    sn.est_ok = ok ? 1 : 0;
+    sn.init = s.init;
     s.est_ok = ok ? 1 : 0;
+    s.n_frame++;
     put(rot_buf + (size_t)seq * 9, R0);                                         // :319 forward-rotate the old KeyLines
     // what the mapper kernels read; W stays zero in this branch
-    Vec<3> V = s.Vgv;
+    Vec<3> V = Vgv;
     put(sq->V_track, V);
     sq->W_track[0] = sq->W_track[1] = sq->W_track[2] = 0;
     for (int i = 0; i < 9; i++) { sq->PV_track[i] = P_V.a[i]; sq->PW_track[i] = P_W.a[i]; }
@@ -200,42 +233,66 @@ __global__ void k_imu_mid(SeqDev *seqs, ImuTrackDev *tracks, const double *__res
     put(p.R, R);
 }
 
-// After the mapper: the accelerometer / scale filter (:280-312 — it reads what the tracker left, nothing of the mapper
-// except P_Kp of the frame before), the gravity-aligned pose (:519-544) and the record of the frame (:550-606).
-__global__ void k_imu_post(SeqDev *seqs, ImuTrackDev *tracks, edgehip_nav *__restrict__ nav, edgehip_nav_imu *__restrict__ nav_imu,
-                           const int32_t *__restrict__ kn_new, const double *__restrict__ tresh_new, const float *__restrict__ retuned_new,
-                           edgehip_imu_params ip, int have_pair, edgehip_nav *__restrict__ nav_log, int nav_log_len, int nseq) {
+// End of the frame on the main stream: what k_imu_post needs of the sequence state goes into the frame's ImuSnap (the next
+// frame's kernels overwrite the state while k_imu_post still runs), and the frame counter / time stamp move on (:585-606).
+__global__ __launch_bounds__(64) void k_imu_snap(SeqDev *seqs, ImuTrackDev *tracks, ImuSnap *snaps, const int32_t *__restrict__ kn_new,
+                           const double *__restrict__ tresh_new, const float *__restrict__ retuned_new, int have_pair, int nseq) {
     const int seq = blockIdx.x * blockDim.x + threadIdx.x;
     if (seq >= nseq) return;
     SeqDev *sq = seqs + seq;
     edgehip_seq_state &p = sq->pub;
-    ImuTrackDev &s = tracks[seq];
+    ImuSnap &sn = snaps[seq];
+    sn.have_pair = have_pair;
+    if (!have_pair) { sn.x_grav_set = 0; sn.init = tracks[seq].init; sn.est_ok = 0; sn.R = m3(p.R); sn.dt = p.dt; }
+    sn.kn = kn_new[seq]; sn.tresh = tresh_new[seq]; sn.retuned = retuned_new[seq];
+    for (int i = 0; i < 3; i++) { sn.V[i] = p.V[i]; sn.V_track[i] = sq->V_track[i]; sn.W_track[i] = sq->W_track[i]; }
+    for (int i = 0; i < 9; i++) { sn.PV_track[i] = sq->PV_track[i]; sn.PW_track[i] = sq->PW_track[i]; }
+    sn.Kp = p.Kp; sn.P_Kp = p.P_Kp; sn.s_rho_q = p.s_rho_q; sn.t_cur = sq->t_cur;
+    sn.score = p.score; sn.rel_error = p.rel_error; sn.rel_error_score = p.rel_error_score;
+    sn.klm_num = p.klm_num; sn.klm_fwd = p.klm_fwd; sn.kf_matchs = p.kf_matchs; sn.estimation_ok = p.estimation_ok;
+    sn.frame = p.frame; sn.minimizer_evals = p.minimizer_evals;
+    p.t_prev = sq->t_cur;
+    p.frame++;
+}
+
+// On the IMU stream, after the frame's snapshot: the accelerometer / scale filter (:280-312 — it reads what the tracker left,
+// nothing of the mapper except P_Kp of the frame before), the gravity-aligned pose (:519-544) and the record of the frame
+// (:550-606).
+__global__ __launch_bounds__(64) void k_imu_post(SeqDev *seqs, ImuFilterDev *filters, const ImuSnap *__restrict__ snaps, edgehip_nav *__restrict__ nav,
+                           edgehip_nav_imu *__restrict__ nav_imu, edgehip_imu_params ip, edgehip_nav *__restrict__ nav_log, int nav_log_len,
+                           int nseq) {
+    const int seq = blockIdx.x * blockDim.x + threadIdx.x;
+    if (seq >= nseq) return;
+    edgehip_seq_state &p = seqs[seq].pub;      // Pose, Pos, K: written here only (edgehip_get_state reads them)
+    ImuFilterDev &s = filters[seq];
+    const ImuSnap &sn = snaps[seq];
     edgehip_nav &o = nav[seq];
     edgehip_nav_imu &oi = nav_imu[seq];
     memset(&oi, 0, sizeof oi);
-    oi.kn = kn_new[seq];
+    oi.kn = sn.kn;
+    const int have_pair = sn.have_pair;
     if (have_pair) {
-        const double dt = s.dt_frame;
-        const Mat<3, 3> R = s.R;
-        s.se.EstAcelLsq4((-s.Vgv) / dt, s.Av, R, dt);                           // :280
-        s.se.MeanAcel4(v3(s.imud.cacel), s.As, R);
-        Vec<6> Xgva = s.Xgv;
+        const double dt = sn.dt;
+        const Mat<3, 3> R = sn.R;
+        if (sn.x_grav_set) la::set_slice(s.X, 1, sn.x_grav);
+        s.se.EstAcelLsq4((-sn.Vgv) / dt, s.Av, R, dt);                          // :280
+        s.se.MeanAcel4(sn.cacel, s.As, R);
+        Vec<6> Xgva = sn.Xgv;
+        s.Rgva = sn.R_pre;
         if (s.n_frame > 4 + ip.init_bias_frame_num) {                           // :291-312
-            s.K = rebvo::ScaleEstimator::estKaGMEKBias(s.As, s.Av, 1, R, s.X, s.P, s.Qg, s.Qrot, s.Qbias, s.QKp, s.Rg, s.Rs, s.Rv,
-                                                       s.g_est, s.b_est, s.W_Xgv, Xgva, ip.g_module);
+            s.K = rebvo::ScaleEstimator::estKaGMEKBias(s.As, s.Av, 1, R, s.X, s.P, s.Qg, sn.Qrot, s.Qbias, sn.QKp, s.Rg, s.Rs, sn.Rv,
+                                                       s.g_est, s.b_est, sn.W_Xgv, Xgva, ip.g_module);
             s.dVgva = la::slice<3>(Xgva, 0);
             s.dWgva = la::slice<3>(Xgva, 3);
             const Mat<3, 3> R0gva = la::so3_exp(s.dWgva);
             s.Rgva = la::transpose(R0gva * la::transpose(s.Rgva));
-            s.Vgva = R0gva * s.Vg + s.dVgva;
+            s.Vgva = R0gva * sn.Vg + s.dVgva;
         } else {
-            s.dVgva = s.dVgv;
-            s.dWgva = s.dWgv;
+            s.dVgva = sn.dVgv;
+            s.dWgva = sn.dWgv;
             s.Rgva = R;
-            s.Vgva = s.Vgv;
+            s.Vgva = sn.Vgv;
         }
-        Mat<3, 3> Pose = m3(p.Pose);
-        Vec<3> Pos = v3(p.Pos);
         if (s.n_frame > 4 + ip.init_bias_frame_num) {                           // :521-541
             s.u_est = la::transpose(s.Rgva) * s.u_est;
             s.u_est = s.u_est - s.g_est * (la::dot(s.u_est, s.g_est) / la::dot(s.g_est, s.g_est));
@@ -244,71 +301,116 @@ __global__ void k_imu_post(SeqDev *seqs, ImuTrackDev *tracks, edgehip_nav *__res
             ey[1] = 1; ex[0] = 1;
             const Mat<3, 3> PoseP1 = la::so3_from_to(s.g_est, ey);
             const Mat<3, 3> PoseP2 = la::so3_from_to(PoseP1 * s.u_est, ex);
-            Pose = PoseP2 * PoseP1;
-            Pos = Pos + (-Pose) * s.Vgva * s.K;
-            s.Posgva = Pos;
-            s.Posgv = s.Posgv + (-Pose) * s.Vgv * s.K;
+            s.Pose = PoseP2 * PoseP1;
+            s.Pos = s.Pos + (-s.Pose) * s.Vgva * s.K;
+            s.Posgva = s.Pos;
+            s.Posgv = s.Posgv + (-s.Pose) * sn.Vgv * s.K;
         }
-        put(p.Pose, Pose);
-        put(p.Pos, Pos);
+        put(p.Pose, s.Pose);
+        put(p.Pos, s.Pos);
         p.K = s.K;
-        const Vec<3> V = v3(p.V);
+        const Vec<3> V = v3(sn.V);
         // the record (:550-606)
-        oi.dt = dt; oi.K = s.K; oi.Kp = p.Kp; oi.RKp = p.P_Kp; oi.s_rho_q = p.s_rho_q; oi.scale = s.K;
+        oi.dt = dt; oi.K = s.K; oi.Kp = sn.Kp; oi.RKp = sn.P_Kp; oi.s_rho_q = sn.s_rho_q; oi.scale = s.K;
         put(oi.Rot, R);
         put(oi.RotLie, la::so3_ln(R));
         put(oi.RotGiro, la::so3_ln(s.Rgva) / dt);
         put(oi.Vel, ((-V) * s.K) / dt);
-        put(oi.Pose, Pose);
-        put(oi.PoseLie, la::so3_ln(Pose));
-        put(oi.Pos, Pos);
+        put(oi.Pose, s.Pose);
+        put(oi.PoseLie, la::so3_ln(s.Pose));
+        put(oi.Pos, s.Pos);
         put(oi.g, s.g_est);
-        put(oi.Vg, s.Vg); put(oi.Bg, s.Bg); put(oi.dVv, s.dVv); put(oi.dWv, s.dWv); put(oi.Vgv, s.Vgv); put(oi.Vgva, s.Vgva);
+        put(oi.Vg, sn.Vg); put(oi.Bg, sn.Bg); put(oi.dVv, sn.dVv); put(oi.dWv, sn.dWv); put(oi.Vgv, sn.Vgv); put(oi.Vgva, s.Vgva);
         put(oi.Av, s.Av); put(oi.As, s.As);
         for (int i = 0; i < 7; i++) oi.X[i] = s.X[i];
         put(oi.b_est, s.b_est); put(oi.u_est, s.u_est);
-        oi.klm_num = p.klm_num;
-        oi.estimation_ok = p.estimation_ok && s.est_ok;
-        oi.init = s.init;
+        oi.klm_num = sn.klm_num;
+        oi.estimation_ok = sn.estimation_ok && sn.est_ok;
+        oi.init = sn.init;
         s.n_frame++;
     }
     // the common record, as k_frame_glue (mode 3) fills it
-    o.t = sq->t_cur; o.dt = p.dt;
-    for (int i = 0; i < 3; i++) { o.V[i] = sq->V_track[i]; o.W[i] = sq->W_track[i]; }
-    for (int i = 0; i < 9; i++) { o.P_V[i] = sq->PV_track[i]; o.P_W[i] = sq->PW_track[i]; o.Rot[i] = p.R[i]; o.Pose[i] = p.Pose[i]; }
-    for (int i = 0; i < 3; i++) { o.RotLie[i] = oi.RotLie[i]; o.PoseLie[i] = oi.PoseLie[i]; o.Vel[i] = oi.Vel[i]; o.Pos[i] = p.Pos[i]; }
-    o.Kp = p.Kp; o.RKp = p.P_Kp; o.s_rho_q = p.s_rho_q; o.tresh = tresh_new[seq];
-    o.score = p.score; o.rel_error = p.rel_error; o.rel_error_score = p.rel_error_score;
-    o.retuned_thresh = retuned_new[seq];
-    o.kn = kn_new[seq]; o.klm_fwd = p.klm_fwd; o.klm_num = p.klm_num; o.kf_matchs = p.kf_matchs;
+    o.t = sn.t_cur; o.dt = sn.dt;
+    for (int i = 0; i < 3; i++) { o.V[i] = sn.V_track[i]; o.W[i] = sn.W_track[i]; }
+    for (int i = 0; i < 9; i++) { o.P_V[i] = sn.PV_track[i]; o.P_W[i] = sn.PW_track[i]; o.Rot[i] = sn.R.a[i]; o.Pose[i] = s.Pose.a[i]; }
+    for (int i = 0; i < 3; i++) { o.RotLie[i] = oi.RotLie[i]; o.PoseLie[i] = oi.PoseLie[i]; o.Vel[i] = oi.Vel[i]; o.Pos[i] = s.Pos[i]; }
+    o.Kp = sn.Kp; o.RKp = sn.P_Kp; o.s_rho_q = sn.s_rho_q; o.tresh = sn.tresh;
+    o.score = sn.score; o.rel_error = sn.rel_error; o.rel_error_score = sn.rel_error_score;
+    o.retuned_thresh = sn.retuned;
+    o.kn = sn.kn; o.klm_fwd = sn.klm_fwd; o.klm_num = sn.klm_num; o.kf_matchs = sn.kf_matchs;
     o.estimation_ok = have_pair ? oi.estimation_ok : 0;
-    o.frame = p.frame; o.minimizer_evals = p.minimizer_evals;
-    if (nav_log_len > 0) nav_log[(size_t)(p.frame % nav_log_len) * nseq + seq] = o;
-    p.t_prev = sq->t_cur;
-    p.frame++;
+    o.frame = sn.frame; o.minimizer_evals = sn.minimizer_evals;
+    if (nav_log_len > 0) nav_log[(size_t)(sn.frame % nav_log_len) * nseq + seq] = o;
+}
+
+// REBVO::Reset() (rebvo_second_t.cpp:609-620): pose and position start over; they are this stream's
+__global__ void k_imu_pose_reset(SeqDev *seqs, ImuFilterDev *filters, int only_seq, int nseq) {
+    const int seq = blockIdx.x * blockDim.x + threadIdx.x;
+    if (seq >= nseq || (only_seq >= 0 && seq != only_seq)) return;
+    ImuFilterDev &s = filters[seq];
+    s.Pose = Mat<3, 3>::identity();
+    s.Pos = Vec<3>::zeros();
+    put(seqs[seq].pub.Pose, s.Pose);
+    put(seqs[seq].pub.Pos, s.Pos);
 }
 
 // ---- host side ---------------------------------------------------------------------------------------------------------------
+// edgehip_reset: the IMU branch starts over with the sequences (both streams are idle when this is called)
+int imu_reset_enqueue(edgehip_ctx *c) {
+    const int B = c->plan.nseq;
+    hipLaunchKernelGGL(k_imu_init, dim3((unsigned)((B + 63) / 64)), dim3(64), 0, c->stream, (ImuTrackDev *)c->imu_track,
+                       (ImuFilterDev *)c->imu_filter, (ImuSnap *)c->imu_snap, c->imu_params, B);
+    EH_LAUNCH_CHECK();
+    c->imu_post_valid[0] = c->imu_post_valid[1] = false;
+    c->imu_pending = false;
+    return 0;
+}
+int imu_pose_reset_enqueue(edgehip_ctx *c, int seq) {
+    const int B = c->plan.nseq;
+    hipLaunchKernelGGL(k_imu_pose_reset, dim3((unsigned)((B + 63) / 64)), dim3(64), 0, c->stream_imu, c->seq, (ImuFilterDev *)c->imu_filter, seq, B);
+    EH_LAUNCH_CHECK();
+    return 0;
+}
+static ImuSnap *snap_of(edgehip_ctx *c) { return (ImuSnap *)c->imu_snap + (size_t)(c->frames_seen & 1) * c->plan.nseq; }
+
+// start of a frame's IMU work on the main stream: its snapshot slot was last read by k_imu_post two frames ago
+int imu_begin_enqueue(edgehip_ctx *c) {
+    const int b = c->frames_seen & 1;
+    if (c->imu_post_valid[b]) EH_CHECK(hipStreamWaitEvent(c->stream, c->ev_imu_post[b], 0));
+    return 0;
+}
 int imu_pre_enqueue(edgehip_ctx *c, int slot_old) {
     const int B = c->plan.nseq;
-    hipLaunchKernelGGL(k_imu_pre, dim3((B + 63) / 64), dim3(64), 0, c->stream, c->seq, (ImuTrackDev *)c->imu_track, c->imu_in_dev,
-                       c->rot_buf, c->retuned_slot + (size_t)slot_old * B, c->imu_params, c->p.tracker_init_type, B);
+    hipLaunchKernelGGL(k_imu_pre, dim3((B + 63) / 64), dim3(64), 0, c->stream, c->seq, (ImuTrackDev *)c->imu_track, snap_of(c),
+                       c->imu_in_dev, c->rot_buf, c->retuned_slot + (size_t)slot_old * B, c->imu_params, c->p.tracker_init_type, B);
     EH_LAUNCH_CHECK();
     return 0;
 }
 int imu_mid_enqueue(edgehip_ctx *c) {
     const int B = c->plan.nseq, nblk = (c->plan.cap + 255) / 256;
-    hipLaunchKernelGGL(k_imu_mid, dim3((B + 63) / 64), dim3(64), 0, c->stream, c->seq, (ImuTrackDev *)c->imu_track, c->partials,
-                       c->rot_buf, c->imu_params, nblk, c->nblk_tvr, B);
+    hipLaunchKernelGGL(k_imu_mid, dim3((B + 63) / 64), dim3(64), 0, c->stream, c->seq, (ImuTrackDev *)c->imu_track, snap_of(c),
+                       c->partials, c->rot_buf, c->imu_params, nblk, c->nblk_tvr, B);
     EH_LAUNCH_CHECK();
     return 0;
 }
+// end of the frame: snapshot on the main stream, then scale filter + pose + record on the IMU stream (they overlap the next
+// frame; the nav records are complete once that stream is — every reader synchronises both)
 int imu_post_enqueue(edgehip_ctx *c, int slot_new, int have_pair) {
-    const int B = c->plan.nseq;
-    hipLaunchKernelGGL(k_imu_post, dim3((B + 63) / 64), dim3(64), 0, c->stream, c->seq, (ImuTrackDev *)c->imu_track, c->nav_dev,
-                       c->nav_imu_dev, c->kn_slot + (size_t)slot_new * B, c->tresh_slot + (size_t)slot_new * B,
-                       c->retuned_slot + (size_t)slot_new * B, c->imu_params, have_pair, c->nav_log, c->nav_log_len, B);
+    const int B = c->plan.nseq, b = c->frames_seen & 1;
+    hipLaunchKernelGGL(k_imu_snap, dim3((B + 63) / 64), dim3(64), 0, c->stream, c->seq, (ImuTrackDev *)c->imu_track, snap_of(c),
+                       c->kn_slot + (size_t)slot_new * B, c->tresh_slot + (size_t)slot_new * B, c->retuned_slot + (size_t)slot_new * B, have_pair, B);
     EH_LAUNCH_CHECK();
+    EH_CHECK(hipEventRecord(c->ev_imu_snap[b], c->stream));
+    EH_CHECK(hipStreamWaitEvent(c->stream_imu, c->ev_imu_snap[b], 0));
+    {
+        ProfScope ps(c, PROF_IMU_SCALE_POSE, c->stream_imu);
+        static const int bs = []() { const char *e = getenv("EDGEHIP_IMU_BLOCK"); const int v = e ? atoi(e) : 64; return v > 0 && v <= 64 ? v : 64; }();
+        hipLaunchKernelGGL(k_imu_post, dim3((B + bs - 1) / bs), dim3(bs), 0, c->stream_imu, c->seq, (ImuFilterDev *)c->imu_filter, snap_of(c),
+                           c->nav_dev, c->nav_imu_dev, c->imu_params, c->nav_log, c->nav_log_len, B);
+        EH_LAUNCH_CHECK();
+    }
+    EH_CHECK(hipEventRecord(c->ev_imu_post[b], c->stream_imu));
+    c->imu_post_valid[b] = true;
     return 0;
 }
 
@@ -328,6 +430,16 @@ int edgehip_imu_enable(edgehip_ctx *c, const edgehip_imu_params *imu) {
         void *q;
         if (hipMalloc(&q, sizeof(ImuTrackDev) * B) != hipSuccess) { (void)hipGetLastError(); set_error("imu state alloc failed"); return EDGEHIP_ERR_MEMORY; }
         c->imu_track = q;
+        if (hipMalloc(&q, sizeof(ImuFilterDev) * B) != hipSuccess) { (void)hipGetLastError(); set_error("imu filter state alloc failed"); return EDGEHIP_ERR_MEMORY; }
+        c->imu_filter = q;
+        if (hipMalloc(&q, sizeof(ImuSnap) * B * 2) != hipSuccess) { (void)hipGetLastError(); set_error("imu snapshot alloc failed"); return EDGEHIP_ERR_MEMORY; }
+        c->imu_snap = q;
+        EH_CHECK(hipStreamCreateWithFlags(&c->stream_imu, hipStreamNonBlocking));
+        for (int i = 0; i < 2; i++) {
+            EH_CHECK(hipEventCreateWithFlags(&c->ev_imu_snap[i], hipEventDisableTiming));
+            EH_CHECK(hipEventCreateWithFlags(&c->ev_imu_post[i], hipEventDisableTiming));
+            c->imu_post_valid[i] = false;
+        }
         if (hipMalloc(&q, sizeof(edgehip_imu_integrated) * B) != hipSuccess) { (void)hipGetLastError(); set_error("imu input alloc failed"); return EDGEHIP_ERR_MEMORY; }
         c->imu_in_dev = (edgehip_imu_integrated *)q;
         if (hipMalloc(&q, sizeof(edgehip_nav_imu) * B) != hipSuccess) { (void)hipGetLastError(); set_error("imu nav alloc failed"); return EDGEHIP_ERR_MEMORY; }
@@ -342,7 +454,9 @@ int edgehip_imu_enable(edgehip_ctx *c, const edgehip_imu_params *imu) {
     c->imu_enabled = true;
     c->imu_pending = false;
     drop_frame_graphs(c);
-    hipLaunchKernelGGL(k_imu_init, dim3((unsigned)((B + 63) / 64)), dim3(64), 0, c->stream, (ImuTrackDev *)c->imu_track, c->imu_params, (int)B);
+    c->use_graph = false;   // the IMU stream runs past the end of a frame: that is not a capturable fork/join
+    hipLaunchKernelGGL(k_imu_init, dim3((unsigned)((B + 63) / 64)), dim3(64), 0, c->stream, (ImuTrackDev *)c->imu_track,
+                       (ImuFilterDev *)c->imu_filter, (ImuSnap *)c->imu_snap, c->imu_params, (int)B);
     EH_LAUNCH_CHECK();
     return 0;
 }
