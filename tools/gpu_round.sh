@@ -23,6 +23,14 @@ echo "smoke exit $?"; tail -1 "$OUT/smoke.log"
 timeout 600 python bench.py $BENCH_ARGS > "$OUT/bench.json" 2> "$OUT/bench.err"
 echo "bench exit $?"; tail -c 3000 "$OUT/bench.json"
 
+# the other BASELINE configurations and the ImuMode=2 line (bench lines only; their own CPU legs are short)
+if [ -z "${SKIP_CONFIGS:-}" ]; then
+  timeout 400 python bench.py --config stage_a --no-extras > "$OUT/bench_stage_a.json" 2> "$OUT/bench_stage_a.err"; echo "stage_a exit $?"
+  timeout 400 python bench.py --config tum_undistort --no-extras --cpu-procs 0 > "$OUT/bench_tum_undistort.json" 2> "$OUT/bench_tum.err"; echo "tum exit $?"
+  timeout 400 python bench.py --imu --no-extras --cpu-frames 0 > "$OUT/bench_imu.json" 2> "$OUT/bench_imu.err"; echo "imu exit $?"
+  tail -c 400 "$OUT/bench_stage_a.json"; tail -c 400 "$OUT/bench_tum_undistort.json"; tail -c 400 "$OUT/bench_imu.json"
+fi
+
 # kernel trace of the same command (CPU baseline skipped: it is host work and only lengthens the trace)
 ( cd /tmp && timeout 600 rocprofv3 --kernel-trace --stats -d "$OUT/trace" -o bench -- \
     python "$GRAFT_REPO_ROOT/bench.py" $BENCH_ARGS --cpu-frames 0 > "$OUT/trace_bench.json" 2> "$OUT/trace.err" )
