@@ -33,7 +33,7 @@ fi
 
 # kernel trace of the same command (CPU baseline skipped: it is host work and only lengthens the trace)
 ( cd /tmp && timeout 600 rocprofv3 --kernel-trace --stats -d "$OUT/trace" -o bench -- \
-    python "$GRAFT_REPO_ROOT/bench.py" $BENCH_ARGS --cpu-frames 0 > "$OUT/trace_bench.json" 2> "$OUT/trace.err" )
+    python "$GRAFT_REPO_ROOT/bench.py" $BENCH_ARGS --cpu-frames 0 --no-extras > "$OUT/trace_bench.json" 2> "$OUT/trace.err" )
 echo "trace exit $?"
 DB=$(ls "$OUT"/trace/*.db "$OUT"/trace/*/*.db 2>/dev/null | head -1)
 [ -n "$DB" ] && python tools/rocpd_summary.py "$DB" "$OUT/kernel_stats.txt" > /dev/null
@@ -42,7 +42,7 @@ ls "$OUT/trace" | head
 # PMC passes: short run, counters only (no trace domains besides kernel-trace)
 for C in FETCH_SIZE WRITE_SIZE; do
   ( cd /tmp && timeout 600 rocprofv3 --kernel-trace --pmc $C --output-format csv -d "$OUT/pmc_$C" -o pmc -- \
-      python "$GRAFT_REPO_ROOT/bench.py" $BENCH_ARGS --steps 6 --warmup 12 --cpu-frames 0 --no-roofline-events \
+      python "$GRAFT_REPO_ROOT/bench.py" $BENCH_ARGS --steps 6 --warmup 12 --cpu-frames 0 --no-extras --no-roofline-events \
       > "$OUT/pmc_$C.json" 2> "$OUT/pmc_$C.err" )
   echo "pmc $C exit $?"
   python tools/pmc_summary.py "$OUT/pmc_$C" "$OUT/pmc_$C.txt" "$OUT/pmc.json" > /dev/null
