@@ -211,6 +211,30 @@ int edgehip_download_resid(edgehip_ctx *ctx, int which, double *resid);
  * them, no host round trip).  Reads seq_state.V/W/s_rho_q, writes V, W, P_V, P_W, score, rel_error*. */
 int edgehip_minimizer_rv(edgehip_ctx *ctx, int slot_new, int slot_old);
 
+/* kfvo::Minimizer_RV_KF<double,false> with kfvo::TryVelRot<double,true,true,false> and global_tracker::Calc_f_J_Complete
+ * (src/mtracklib/kfvo.cpp:1679-1825, 1389-1668; global_tracker.cpp:116-165) — the key-frame tracker of SURVEY section 8 row
+ * f4: the KeyLines of slot_cur (the current frame, `klist`) against the field of slot_kf's KeyLines (the key frame's
+ * global_tracker), relative pose X = [translation, rotation] starting from X0, scale ratio Kr.  Reached in the reference
+ * through kfvo::OptimizePosGT (kfvo.cpp:58-113), which has no caller upstream; built to the letter of the scope row and
+ * checked against the reference's own function.  The field of slot_kf is (re)built inside the call; KeyLine m_id_f of
+ * slot_cur is left as the last evaluation wrote it, mnum counts its non-negative entries (kfvo.cpp:76-82).  req/res are
+ * host arrays of nseq entries.  Synchronises. */
+typedef struct edgehip_kf_request {
+    double X0[6];        /* BRelPos, BRelRotW (kfvo.cpp:63-69) */
+    double Kr;           /* K / mkf.K */
+    double max_s_rho;    /* s_rho_q */
+} edgehip_kf_request;
+typedef struct edgehip_kf_result {
+    double X[6];
+    double RRV[36];      /* Cholesky<6>(JtJ).get_inverse() */
+    double score_ratio;  /* F / F0, the function's return value */
+    double F, F0;
+    int32_t evals, mnum;
+} edgehip_kf_result;
+int edgehip_minimizer_rv_kf(edgehip_ctx *ctx, int slot_kf, int slot_cur, const edgehip_kf_request *req, double match_mod,
+                            double match_ang, double rho_tol, int iter_max, double reweight_distance, uint32_t match_num_thresh,
+                            edgehip_kf_result *res);
+
 /* global_tracker::Minimizer_V<double> (IMU branch, rebvo_second_t.cpp:223; global_tracker.cpp:1037-1093 with
  * TryVel :830-934 and Calc_f_J :178-219): translation-only Levenberg-Marquardt of the old slot's KeyLines (already
  * rotated by the gyro estimate) against the new slot's field.  V[nseq][3] in/out, s_rho_min[nseq], min_mod < 0

@@ -203,6 +203,7 @@ class Oracle:
         self._cur_slot = fn("cur_slot", i, vp)
         self._run_sequence = fn("run_sequence", i, vp, C.c_void_p, C.c_ulonglong, C.c_void_p, i, d, d, i, C.c_void_p,
                                 C.c_void_p) if kind == "ref" else None
+        self._minimizer_rv_kf = fn("minimizer_rv_kf", d, vp, i, i, pd, d, d, d, d, i, d, d, u, pd, pi) if kind == "ref" else None
         self._reset = fn("reset_sequence", None, vp)
         self._depth_reset = fn("depth_reset", None, vp)
         self.ctx = self._create(C.byref(params), nslots)
@@ -306,6 +307,16 @@ class Oracle:
         F = self._minimizer_v(self.ctx, slot_new, slot_old, _dp(V), _dp(RV), match_thresh, iter_max, s_rho_min, match_num_thresh,
                               reweight_distance, min_mod)
         return dict(F=F, V=V, RVel=RV)
+
+    def minimizer_rv_kf(self, slot_kf, slot_cur, X0, Kr, max_s_rho, match_mod, match_ang, rho_tol, iter_max, reweight_distance,
+                        match_num_thresh):
+        """kfvo::Minimizer_RV_KF<double,false> as kfvo::OptimizePosGT calls it (reference only) -> dict(X, RRV, score_ratio, mnum)."""
+        X = np.array(X0, dtype=np.float64)
+        RRV = np.zeros((6, 6))
+        mnum = C.c_int(0)
+        r = self._minimizer_rv_kf(self.ctx, slot_kf, slot_cur, _dp(X), Kr, match_mod, match_ang, rho_tol, iter_max, reweight_distance,
+                                  max_s_rho, match_num_thresh, _dp(RRV), C.byref(mnum))
+        return dict(X=X, RRV=RRV, score_ratio=r, mnum=mnum.value)
 
     def ext_rot_vel(self, slot, vel, loc_unc, hub_reweight):
         """edge_tracker::ExtRotVel -> dict(ok, X, Wx, Rx)."""

@@ -130,6 +130,13 @@ typedef struct OrcNav {
 ORC_DECLARE(ref)
 ORC_DECLARE(port)
 
+/* ---- key-frame tracker: reference only.  kfvo::Minimizer_RV_KF<double,false> (kfvo.cpp:1679-1825),
+ * called directly with the arguments kfvo::OptimizePosGT passes (kfvo.cpp:74): gt = slot_kf's global_tracker (its field as
+ * built for that frame), klist = slot_cur's edge_tracker.  X in/out ([translation, rotation]); returns F/F0. ---- */
+double ref_minimizer_rv_kf(void *ctx, int slot_kf, int slot_cur, double X[6], double Kr, double match_mod, double match_ang,
+                           double rho_tol, int iter_max, double reweight_distance, double max_s_rho, unsigned match_num_thresh,
+                           double RRV[36], int *mnum);
+
 /* ---- stereo depth (REBVO/StereoAvaiable): reference only ---- */
 void ref_set_slot_cam(void *ctx, int slot, double ppx, double ppy, double zfx, double zfy);   /* pair camera intrinsics */
 void ref_set_stereo_mode(void *ctx, int on);   /* the stereo_mode argument ref_directed_matching passes on */

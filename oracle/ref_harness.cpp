@@ -28,6 +28,13 @@
 #include "CommLib/net_keypoint.h"
 // TryVelRot<> is only defined in the .cpp; include it so the harness can instantiate it directly.
 #include "src/mtracklib/global_tracker.cpp"
+// kfvo::Minimizer_RV_KF<> / kfvo::TryVelRot<> likewise live in kfvo.cpp.  Its header chain (kfvo.h -> keyframe.h ->
+// visualizer/depth_filler.h) does not compile with this image's g++ 11 (depth_filler.h:141: std::max(float, double));
+// the key-frame tracker uses nothing of depth_filler — class keyframe only holds a shared_ptr to it and names its
+// bound_modes enum in one declaration — so the header's include guard is taken and a stand-in with that enum declared.
+#define DEPTH_FILLER_H
+namespace rebvo { class depth_filler { public: enum bound_modes { BOUND_NONE }; }; }
+#include "src/mtracklib/kfvo.cpp"
 
 #include <TooN/so3.h>
 #include "oracle_abi.h"
@@ -355,6 +362,28 @@ double ref_minimizer_rv(void *ctx, int slot_new, int slot_old, double V[3], doub
     for (int i = 0; i < 6; i++)
         for (int j = 0; j < 6; j++) W_Xo[i * 6 + j] = W_X(i, j);
     return F;
+}
+
+double ref_minimizer_rv_kf(void *ctx, int slot_kf, int slot_cur, double X[6], double Kr, double match_mod, double match_ang,
+                           double rho_tol, int iter_max, double reweight_distance, double max_s_rho, unsigned match_num_thresh,
+                           double RRV[36], int *mnum) {
+    Ctx *c = (Ctx *)ctx;
+    edge_tracker &et = *c->slots[slot_cur].ef;
+    Vector<3> Vel = makeVector(X[0], X[1], X[2]), W0 = makeVector(X[3], X[4], X[5]);
+    Matrix<3, 3> RVel = Identity * 1e50, RW0 = Identity * 1e50;       // kfvo.cpp:66-67
+    for (KeyLine &kl : et) kl.m_id_f = -1;                             // kfvo.cpp:71-72
+    Vector<6, double> Xv;
+    Matrix<6> R;
+    const double r = kfvo::Minimizer_RV_KF<double>(Vel, W0, RVel, RW0, *c->slots[slot_kf].gt, et, c->cam, Kr, match_mod, match_ang, rho_tol,
+                                                   iter_max, reweight_distance, max_s_rho, match_num_thresh, Xv, R);   // kfvo.cpp:74
+    int n = 0;
+    for (KeyLine &kl : et) n += kl.m_id_f >= 0;                        // kfvo.cpp:76-82
+    *mnum = n;
+    for (int i = 0; i < 6; i++) {
+        X[i] = i < 3 ? Vel[i] : W0[i - 3];
+        for (int j = 0; j < 6; j++) RRV[i * 6 + j] = R(i, j);
+    }
+    return r;
 }
 
 double ref_minimizer_v(void *ctx, int slot_new, int slot_old, double V[3], double RVel[9], double match_thresh,

@@ -558,6 +558,8 @@ int edgehip_destroy(edgehip_ctx *c) {
     }
     if (c->nav_log) (void)hipFree(c->nav_log);
     if (c->stream_imu) { (void)hipStreamSynchronize(c->stream_imu); (void)hipStreamDestroy(c->stream_imu); for (int i = 0; i < 2; i++) { (void)hipEventDestroy(c->ev_imu_snap[i]); (void)hipEventDestroy(c->ev_imu_post[i]); } }
+    if (c->kf_req_dev) (void)hipFree(c->kf_req_dev);
+    if (c->kf_res_dev) (void)hipFree(c->kf_res_dev);
     if (c->imu_track) (void)hipFree(c->imu_track);
     if (c->imu_filter) (void)hipFree(c->imu_filter);
     if (c->imu_snap) (void)hipFree(c->imu_snap);

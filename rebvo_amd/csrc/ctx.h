@@ -251,6 +251,8 @@ struct edgehip_ctx {
     // the IMU branch of the frame driver (edgehip_imu_enable; stage_imu.hip)
     bool imu_enabled = false, imu_pending = false;
     edgehip_imu_params imu_params;
+    edgehip_kf_request *kf_req_dev = nullptr;        // [B] edgehip_minimizer_rv_kf (allocated on first use)
+    edgehip_kf_result *kf_res_dev = nullptr;
     void *imu_track = nullptr;                       // [B] ImuTrackDev (main stream)
     void *imu_filter = nullptr;                      // [B] ImuFilterDev (IMU stream)
     void *imu_snap = nullptr;                        // [2][B] ImuSnap: a frame's hand-over from the main to the IMU stream

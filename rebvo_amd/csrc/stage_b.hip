@@ -501,11 +501,20 @@ struct TvrArgs {
     uint32_t match_num_thresh;
     int write_mid;             // store kl.m_id_f (only the last evaluation of a minimisation needs to)
     int use_grec;   // host-side choice of the gather record (edgehip_ctx::grec_ok of the new slot)
+    // KF instantiation (kfvo::TryVelRot): per-sequence scale ratio, the thresholds of Calc_f_J_Complete
+    const edgehip_kf_request *kf;   // [B]
+    double kf_match_mod, kf_match_cang, kf_rho_tol;
 };
 
 __device__ __forceinline__ bool is_carry(double v) { return __double_as_longlong(v) == (long long)resid_carry_bits(); }
 
-template <bool REWEIGHT, bool PROCJF, bool GREC>
+// KF = kfvo::TryVelRot (src/mtracklib/kfvo.cpp:1389-1668), the key-frame flavour of the same evaluation: the KeyLines of the
+// current frame (kl_old here) against the field of a key frame (kl_new).  It differs from global_tracker::TryVelRot in four
+// places: the match-count gate ignores FrameCount (:1441), the gradient is not z-rotated (:1476-1478 are commented out),
+// the match test is Calc_f_J_Complete (global_tracker.cpp:116-165: angle, modulus ratio and inverse-depth consistency
+// against the matched KeyLine, with the transformed inverse depth divided by the scale ratio Kr), and the gate radius is
+// the field's own (gt.getMaxSRadius()).
+template <bool REWEIGHT, bool PROCJF, bool GREC, bool KF = false>
 __device__ __forceinline__ void tvr_body(const TvrArgs &a, const int seq, const int blk, const int tid) {
     const int lane = tid & 63, wave = tid >> 6;
     SeqDev *sq = a.seq + seq;
@@ -554,7 +563,7 @@ __device__ __forceinline__ void tvr_body(const TvrArgs &a, const int seq, const 
             const float knm = ko.n_m[ikl];
             double rprev = 0;
             if (REWEIGHT) rprev = rin[ikl];
-            const uint32_t fc = a.framecount[seq];
+            const uint32_t fc = KF ? 0xFFFFFFFFu : a.framecount[seq];
             const uint32_t mthr = a.match_num_thresh < fc ? a.match_num_thresh : fc;
             const bool skip = s_rho > sq->s_rho_min_eval || (uint32_t)mnum < mthr;  // int vs uint compare
             if (!skip) {
@@ -588,10 +597,31 @@ __device__ __forceinline__ void tvr_body(const TvrArgs &a, const int seq, const 
                     status = 3;
                     fm = a.max_r;
                     // temporarily z-rotated gradient, stored back into a float Point2DF (:386-388)
-                    const float rmx = (float)(sq->RM[0] * (double)klm.x + sq->RM[1] * (double)klm.y);
-                    const float rmy = (float)(sq->RM[2] * (double)klm.x + sq->RM[3] * (double)klm.y);
+                    const float rmx = KF ? klm.x : (float)(sq->RM[0] * (double)klm.x + sq->RM[1] * (double)klm.y);
+                    const float rmy = KF ? klm.y : (float)(sq->RM[2] * (double)klm.x + sq->RM[3] * (double)klm.y);
                     const uint32_t f = a.field16[(size_t)seq * a.f16stride + field16_index(x, y, a.f16tx)];
-                    if (f != 0u) {
+                    if (KF) {
+                        if (f != 0u) {
+                            const int ikf = (int)f - 1;
+                            const KlSoA &kf = a.kl_new[seq];
+                            const MatchRec fr = kf.rec[ikf];
+                            const double f_rho = kf.rho[ikf], f_srho = kf.s_rho[ikf];
+                            // Calc_f_J_Complete (global_tracker.cpp:138-147): float products and quotients, compared in double
+                            const double cang = (double)((klm.x * fr.m_mx + klm.y * fr.m_my) / knm);
+                            const double rho_t = rho_p / a.kf[seq].Kr;          // PtIm[2*pnum+ikl]/Kr (kfvo.cpp:1481)
+                            const bool reject = cang < a.kf_match_cang || (double)fabsf(knm / fr.n_m - 1) > a.kf_match_mod ||
+                                                fabs(rho_t - f_rho) > a.kf_rho_tol * (f_srho + s_rho * rho_t / rho0);
+                            if (!reject) {
+                                const double dx = px - (double)fr.c_px, dy = py - (double)fr.c_py;
+                                fi = dx * (double)fr.u_mx + dy * (double)fr.u_my;
+                                dfx = (double)fr.u_mx;
+                                dfy = (double)fr.u_my;
+                                fm = fi;
+                                mid_f = ikf;
+                                status = 2;
+                            }
+                        }
+                    } else if (f != 0u) {
                         const int ikf = (int)f - 1;
                         // The matched KeyLine's c_p, m_m, u_m.  GREC: a 16-byte record (four records share the 64 bytes
                         // a random gather moves, instead of two) and u_m recomputed with the detector's own float
@@ -736,6 +766,10 @@ __device__ __forceinline__ void tvr_body(const TvrArgs &a, const int seq, const 
 template <bool REWEIGHT, bool PROCJF, bool GREC>
 __global__ __launch_bounds__(kTvrThreads) void k_try_velrot(TvrArgs a) {
     tvr_body<REWEIGHT, PROCJF, GREC>(a, blockIdx.z, blockIdx.x, threadIdx.x);
+}
+// kfvo::TryVelRot<double, true, true, false>: the only instantiation Minimizer_RV_KF uses (kfvo.cpp:1744, 1772)
+__global__ __launch_bounds__(kTvrThreads) void k_try_velrot_kf(TvrArgs a) {
+    tvr_body<true, true, false, true>(a, blockIdx.z, blockIdx.x, threadIdx.x);
 }
 
 // ---------------------------------------------------------------------------------------------------
@@ -974,6 +1008,8 @@ enum LmOps : unsigned {
     LM_BEGIN = 1u << 15,       // start of a minimisation (init state, X from init_type)
     LM_PHASE_A = 1u << 16,     // next evaluation writes Rest (zero-init trial of init_type 2)
     LM_PHASE_BC = 1u << 17,    // next evaluation writes ResidualNew
+    LM_BEGIN_KF = 1u << 18,    // kfvo::Minimizer_RV_KF: X and the uncertainty gate come with the request (kfvo.cpp:1737-1738)
+    LM_FINISH_KF = 1u << 19,   // ... and the result goes to the caller, not into the sequence state (:1808-1821)
 };
 
 struct LmArgs {
@@ -985,6 +1021,8 @@ struct LmArgs {
     int nblk, nseq;
     unsigned ops;
     int init_type;
+    const edgehip_kf_request *kf_in;   // [B] (LM_BEGIN_KF)
+    edgehip_kf_result *kf_out;         // [B] (LM_FINISH_KF)
 };
 
 template <bool WAVE_ONLY>
@@ -1026,6 +1064,23 @@ __device__ __forceinline__ void lm_body(const LmArgs &a, const int seq, const in
             sq->s_rho_min_eval = sq->pub.s_rho_q;
         }
         lm_sync<WAVE_ONLY>();
+    }
+    if (ops & LM_BEGIN_KF) {
+        if (lane == 0) {
+            sq->eff_steps = 0;
+            sq->v = 2;
+            sq->res_cur = 0; sq->res_new = 1; sq->res_t = 2;
+            sq->pub.minimizer_evals = 0;
+            for (int i = 0; i < 6; i++) sq->X[i] = a.kf_in[seq].X0[i];
+            sq->s_rho_min_eval = a.kf_in[seq].max_s_rho;
+        }
+        lm_sync<WAVE_ONLY>();
+    }
+    if (kn <= 0 && (ops & LM_FINISH_KF) && lane == 0) {   // Minimizer_RV_KF returns 0 on an empty list (kfvo.cpp:1700-1701)
+        edgehip_kf_result &o = a.kf_out[seq];
+        for (int i = 0; i < 6; i++) o.X[i] = a.kf_in[seq].X0[i];
+        for (int i = 0; i < 36; i++) o.RRV[i] = 0;
+        o.score_ratio = 0; o.F = 0; o.F0 = 0; o.evals = 0; o.mnum = 0;
     }
     if (kn <= 0) {  // Minimizer_RV returns immediately on an empty list (global_tracker.cpp:597-598)
         for (int i = lane; i < kWords; i += 64) gstate[i] = s_state[i];
@@ -1234,6 +1289,18 @@ __device__ __forceinline__ void lm_body(const LmArgs &a, const int seq, const in
         }
         sq->pub.score = F;
         a.framecount[seq]++;
+    }
+    if (ops & LM_FINISH_KF) {
+        double L[36], Inv[36];
+        chol6_r(JtJ, L);
+        chol6_inverse_r(L, Inv);          // RRV = Cholesky<6>(JtJ).get_inverse()
+        edgehip_kf_result &o = a.kf_out[seq];
+#pragma unroll
+        for (int i = 0; i < 6; i++) o.X[i] = X[i];
+#pragma unroll
+        for (int i = 0; i < 36; i++) o.RRV[i] = Inv[i];
+        o.score_ratio = F / F0; o.F = F; o.F0 = F0;
+        o.evals = sq->pub.minimizer_evals;
     }
     // registers -> state
 #pragma unroll
@@ -1617,6 +1684,7 @@ static TvrArgs make_tvr_args(edgehip_ctx *c, int slot_new, int slot_old, double 
     a.zfm = pl.zfm; a.max_r = (double)c->field_radius; a.match_thresh = match_thresh; a.k_huber = k_huber;
     a.ppx = pl.ppx; a.ppy = pl.ppy; a.match_num_thresh = match_num_thresh; a.write_mid = write_mid;
     a.use_grec = c->grec_ok[slot_new] && !c->no_grec;
+    a.kf = nullptr; a.kf_match_mod = a.kf_match_cang = a.kf_rho_tol = 0;
     return a;
 }
 
@@ -1644,8 +1712,60 @@ static int launch_lm(edgehip_ctx *c, int slot_new, unsigned ops) {
     a.seq = c->seq; a.partials = c->partials; a.block_last = c->block_last; a.resid_carry = c->resid_carry;
     a.framecount = c->framecount + (size_t)c->fc_index * c->plan.nseq;
     a.nblk = c->nblk_tvr; a.nseq = c->plan.nseq; a.ops = ops; a.init_type = c->p.tracker_init_type;
+    a.kf_in = c->kf_req_dev; a.kf_out = c->kf_res_dev;
     hipLaunchKernelGGL(k_lm_step, dim3(c->plan.nseq), dim3(64), 0, c->stream, a);
     EH_LAUNCH_CHECK();
+    return 0;
+}
+
+// m_id_f >= 0 over a KeyLine list (kfvo::OptimizePosGT's count after the minimisation, kfvo.cpp:76-82)
+__global__ __launch_bounds__(256) void k_count_forward(const KlSoA *kls, const int32_t *__restrict__ kns, edgehip_kf_result *out) {
+    __shared__ int s_n[4];
+    const int seq = blockIdx.x, kn = kns[seq];
+    int n = 0;
+    for (int i = threadIdx.x; i < kn; i += 256) n += kls[seq].m_id_f[i] >= 0;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) n += __shfl_xor(n, o, 64);
+    if ((threadIdx.x & 63) == 0) s_n[threadIdx.x >> 6] = n;
+    __syncthreads();
+    if (threadIdx.x == 0) out[seq].mnum = s_n[0] + s_n[1] + s_n[2] + s_n[3];
+}
+
+// kfvo::Minimizer_RV_KF<double,false> (kfvo.cpp:1679-1825): the schedule is the reweighted Levenberg-Marquardt loop of
+// Minimizer_RV without an initialisation phase — every evaluation with ReWeight and ProcJF, Cholesky solves throughout.
+int minimizer_kf_enqueue(edgehip_ctx *c, int slot_kf, int slot_cur, double match_mod, double match_ang, double rho_tol, int iter_max,
+                         double reweight_distance, uint32_t match_num_thresh) {
+    int e;
+    c->fc_index = slot_kf;   // not read by the KF evaluation, not written by LM_FINISH_KF
+#define EH_TRY(x) if ((e = (x)) != 0) return e
+    EH_TRY(tvr_prepare_enqueue(c, slot_cur));
+    auto eval = [&](bool last) -> int {
+        TvrArgs a = make_tvr_args(c, slot_kf, slot_cur, 0.0, reweight_distance, match_num_thresh, last ? 1 : 0);
+        a.kf = c->kf_req_dev; a.kf_match_mod = match_mod; a.kf_match_cang = cos(match_ang); a.kf_rho_tol = rho_tol;
+        a.use_grec = 0;
+        ProfScope ps(c, PROF_B_TRYVELROT);
+        hipLaunchKernelGGL(k_try_velrot_kf, dim3(c->nblk_tvr, 1, c->plan.nseq), dim3(kTvrThreads), 0, c->stream, a);
+        EH_LAUNCH_CHECK();
+        return 0;
+    };
+    const int M = iter_max;
+    EH_TRY(launch_lm(c, slot_kf, LM_BEGIN_KF | LM_SETUP_X | LM_PHASE_BC));
+    EH_TRY(eval(M <= 0));
+    {
+        unsigned ops = LM_REDUCE_CUR | LM_INIT | LM_RESET_V;
+        if (M > 0) ops |= LM_SOLVE_CHOL | LM_SETUP_XNEW; else ops |= LM_FINISH_KF;
+        EH_TRY(launch_lm(c, slot_kf, ops));
+    }
+    for (int it = 0; it < M; it++) {
+        EH_TRY(eval(it == M - 1));
+        unsigned ops = LM_REDUCE_NEW | LM_GAIN_RATIO | LM_SWAP_ON_ACCEPT;
+        if (it < M - 1) ops |= LM_SOLVE_CHOL | LM_SETUP_XNEW; else ops |= LM_FINISH_KF;
+        EH_TRY(launch_lm(c, slot_kf, ops));
+    }
+    hipLaunchKernelGGL(k_count_forward, dim3(c->plan.nseq), dim3(256), 0, c->stream, kldev(c, slot_cur),
+                       c->kn_slot + (size_t)slot_cur * c->plan.nseq, c->kf_res_dev);
+    EH_LAUNCH_CHECK();
+#undef EH_TRY
     return 0;
 }
 
@@ -1680,6 +1800,7 @@ int minimizer_enqueue(edgehip_ctx *c, int slot_new, int slot_old, int fc_index) 
         l.seq = c->seq; l.partials = c->partials; l.block_last = c->block_last; l.resid_carry = c->resid_carry;
         l.framecount = c->framecount + (size_t)c->fc_index * c->plan.nseq;
         l.nblk = c->nblk_tvr; l.nseq = c->plan.nseq; l.ops = ops; l.init_type = c->p.tracker_init_type;
+        l.kf_in = nullptr; l.kf_out = nullptr;
         dim3 g(c->nblk_tvr, 1, c->plan.nseq), b(kTvrThreads);
 #define EH_TVLM(RW, JF)                                                                                                     \
     do {                                                                                                                   \
@@ -1889,6 +2010,30 @@ int edgehip_minimizer_v(edgehip_ctx *c, int slot_new, int slot_old, double *V, c
         if (RVel) for (int i = 0; i < 9; i++) RVel[s * 9 + i] = q.mv_RVel[i];
         if (F) F[s] = q.mv_F;
     }
+    return 0;
+}
+
+int edgehip_minimizer_rv_kf(edgehip_ctx *c, int slot_kf, int slot_cur, const edgehip_kf_request *req, double match_mod, double match_ang,
+                            double rho_tol, int iter_max, double reweight_distance, uint32_t match_num_thresh, edgehip_kf_result *res) {
+    EH_ENTER(c);
+    if (!c || !req || !res || slot_kf < 0 || slot_cur < 0 || slot_kf >= c->plan.nslots || slot_cur >= c->plan.nslots || slot_kf == slot_cur)
+        return EDGEHIP_ERR_ARG;
+    const size_t B = c->plan.nseq;
+    if (!c->kf_req_dev) {
+        void *q = nullptr;
+        if (hipMalloc(&q, sizeof(edgehip_kf_request) * B) != hipSuccess) { (void)hipGetLastError(); set_error("kf request alloc failed"); return EDGEHIP_ERR_MEMORY; }
+        c->kf_req_dev = (edgehip_kf_request *)q;
+        if (hipMalloc(&q, sizeof(edgehip_kf_result) * B) != hipSuccess) { (void)hipGetLastError(); set_error("kf result alloc failed"); return EDGEHIP_ERR_MEMORY; }
+        c->kf_res_dev = (edgehip_kf_result *)q;
+    }
+    if (int e = sync_all(c)) return e;   // the request comes from pageable memory and the field is about to be rebuilt
+    EH_CHECK(hipMemcpy(c->kf_req_dev, req, sizeof(edgehip_kf_request) * B, hipMemcpyHostToDevice));
+    // the key frame's global_tracker: the field of ITS KeyLines, as built when the frame was current (rebvo_second_t.cpp:177;
+    // keyframe.cpp:31 copies it).  The context has one field, so it is rebuilt here; the next frame rebuilds its own.
+    if (int e = build_field_enqueue(c, slot_kf, c->p.search_range, -1.f)) return e;
+    if (int e = minimizer_kf_enqueue(c, slot_kf, slot_cur, match_mod, match_ang, rho_tol, iter_max, reweight_distance, match_num_thresh)) return e;
+    EH_CHECK(hipStreamSynchronize(c->stream));
+    EH_CHECK(hipMemcpy(res, c->kf_res_dev, sizeof(edgehip_kf_result) * B, hipMemcpyDeviceToHost));
     return 0;
 }
 

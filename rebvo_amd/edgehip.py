@@ -129,6 +129,17 @@ class Nav(C.Structure):
     ]
 
 
+class KfRequest(C.Structure):
+    """edgehip_kf_request (include/edgehip.h)."""
+    _fields_ = [("X0", C.c_double * 6), ("Kr", C.c_double), ("max_s_rho", C.c_double)]
+
+
+class KfResult(C.Structure):
+    """edgehip_kf_result (include/edgehip.h)."""
+    _fields_ = [("X", C.c_double * 6), ("RRV", C.c_double * 36), ("score_ratio", C.c_double), ("F", C.c_double), ("F0", C.c_double),
+                ("evals", C.c_int32), ("mnum", C.c_int32)]
+
+
 class ImuParams(C.Structure):
     """edgehip_imu_params; defaults = the &IMU section of app/rebvorun/GlobalConfig_EuRoC."""
     _fields_ = [("giro_meas_std", C.c_double), ("giro_bias_std", C.c_double), ("init_bias", C.c_int32),
@@ -194,7 +205,7 @@ EXPORTS = [
     "edgehip_upload_rgb_indexed", "edgehip_bind_rgb_indexed", "edgehip_set_nav_log", "edgehip_read_nav_log",
     "edgehip_build_undistort_map", "edgehip_download_undistorted", "edgehip_depth_reset", "edgehip_depth_reset_slot", "edgehip_set_slot_camera", "edgehip_directed_matching_stereo",
     "edgehip_alloc_pinned", "edgehip_free_pinned", "edgehip_upload_rgb_pinned", "edgehip_fuse_stereo_depth", "edgehip_set_stereo_rig", "edgehip_get_stereo_matches", "edgehip_minimizer_v", "edgehip_ext_rot_vel",
-    "edgehip_imu_enable", "edgehip_set_imu", "edgehip_read_nav_imu",
+    "edgehip_imu_enable", "edgehip_set_imu", "edgehip_read_nav_imu", "edgehip_minimizer_rv_kf",
 ]
 
 _lib = None
@@ -267,6 +278,25 @@ class EdgeHip:
         self._ck(self.lib.edgehip_minimizer_v(self.ctx, slot_new, slot_old, _dp(V), _dp(smin), C.c_float(min_mod), C.c_double(match_thresh),
                                               iter_max, C.c_uint32(match_num_thresh), C.c_double(reweight_distance), _dp(RV), _dp(F)))
         return V, RV, F
+
+    def minimizer_rv_kf(self, slot_kf, slot_cur, X0, Kr, max_s_rho, match_mod, match_ang, rho_tol, iter_max, reweight_distance,
+                        match_num_thresh):
+        """kfvo::Minimizer_RV_KF<double,false> for every sequence: the KeyLines of slot_cur against the field of slot_kf's
+        KeyLines -> dict(X[nseq,6], RRV[nseq,6,6], score_ratio, F, F0, evals, mnum)."""
+        req = (KfRequest * self.nseq)()
+        X0 = np.broadcast_to(np.asarray(X0, np.float64), (self.nseq, 6))
+        Kr = np.broadcast_to(np.asarray(Kr, np.float64), (self.nseq,))
+        ms = np.broadcast_to(np.asarray(max_s_rho, np.float64), (self.nseq,))
+        for s in range(self.nseq):
+            req[s].X0[:] = list(X0[s])
+            req[s].Kr, req[s].max_s_rho = float(Kr[s]), float(ms[s])
+        res = (KfResult * self.nseq)()
+        self._ck(self.lib.edgehip_minimizer_rv_kf(self.ctx, slot_kf, slot_cur, req, C.c_double(match_mod), C.c_double(match_ang),
+                                                  C.c_double(rho_tol), iter_max, C.c_double(reweight_distance),
+                                                  C.c_uint32(match_num_thresh), res))
+        return dict(X=np.array([list(r.X) for r in res]), RRV=np.array([list(r.RRV) for r in res]).reshape(self.nseq, 6, 6),
+                    score_ratio=np.array([r.score_ratio for r in res]), F=np.array([r.F for r in res]), F0=np.array([r.F0 for r in res]),
+                    evals=np.array([r.evals for r in res]), mnum=np.array([r.mnum for r in res]))
 
     def ext_rot_vel(self, slot, vel, loc_unc, hub_reweight):
         """edge_tracker::ExtRotVel for every sequence -> (X[nseq,6], Wx[nseq,6,6], Rx[nseq,6,6], ok[nseq])."""

@@ -29,13 +29,16 @@ def test_struct_sizes_match_header(tmp_path):
     import ctypes as C
     import subprocess
     src = tmp_path / "sz.c"
-    src.write_text('#include <stdio.h>\n#include "edgehip.h"\nint main(void){printf("%zu %zu %zu %zu\\n",'
-                   'sizeof(edgehip_params),sizeof(edgehip_keyline),sizeof(edgehip_seq_state),sizeof(edgehip_nav));return 0;}\n')
+    src.write_text('#include <stdio.h>\n#include "edgehip.h"\nint main(void){printf("%zu %zu %zu %zu %zu %zu %zu %zu %zu\\n",'
+                   'sizeof(edgehip_params),sizeof(edgehip_keyline),sizeof(edgehip_seq_state),sizeof(edgehip_nav),'
+                   'sizeof(edgehip_imu_params),sizeof(edgehip_imu_integrated),sizeof(edgehip_nav_imu),'
+                   'sizeof(edgehip_kf_request),sizeof(edgehip_kf_result));return 0;}\n')
     exe = tmp_path / "sz"
     subprocess.run(["gcc", "-std=c99", "-I", os.path.join(ROOT, "include"), str(src), "-o", str(exe)], check=True)
     sizes = [int(x) for x in subprocess.run([str(exe)], check=True, capture_output=True, text=True).stdout.split()]
     assert sizes == [C.sizeof(edgehip.Params), edgehip.KEYLINE_DTYPE.itemsize, C.sizeof(edgehip.SeqState),
-                     C.sizeof(edgehip.Nav)]
+                     C.sizeof(edgehip.Nav), C.sizeof(edgehip.ImuParams), C.sizeof(edgehip.ImuIntegrated), C.sizeof(edgehip.NavImu),
+                     C.sizeof(edgehip.KfRequest), C.sizeof(edgehip.KfResult)]
     assert edgehip.KEYLINE_DTYPE.itemsize == 168   # the reference's KeyLine
 
 

@@ -128,6 +128,60 @@ def test_minimizer_v(pair, V0, iters, mnt):
     assert orc.get_framecount(sn) == fc                 # Minimizer_V does not count frames
 
 
+@pytest.mark.parametrize("X0,Kr,rho_tol,match_mod,iters,mnt", [
+    ((0, 0, 0, 0, 0, 0), 1.0, 5.0, 5.0, 6, 0),                       # the arguments kfvo::OptimizePosGT passes (match_mod 5, 30 degrees)
+    ((0.004, -0.002, 0.003, 0.002, -0.003, 0.001), 1.0, 5.0, 5.0, 8, 0),
+    ((0.004, -0.002, 0.003, 0.002, -0.003, 0.001), 1.15, 0.5, 0.3, 5, 2),   # scale ratio, strict depth / modulus gates, match-count gate
+    ((0, 0, 0, 0, 0, 0), 0.9, 1.0, 5.0, 0, 0),                       # iter_max = 0: one evaluation
+])
+def test_minimizer_rv_kf(pair, X0, Kr, rho_tol, match_mod, iters, mnt):
+    """Key-frame tracker (SURVEY.md section 8 row f4): kfvo::Minimizer_RV_KF<double,false> + kfvo::TryVelRot +
+    global_tracker::Calc_f_J_Complete (kfvo.cpp:1389-1825, global_tracker.cpp:116-165), the KeyLines of one slot against
+    the field of another slot's KeyLines.  Same tolerances as the frame-to-frame tracker (different but fixed fp64
+    summation order): X 1e-9 relative (+1e-12), F/F0 1e-9, RRV 1e-7; forward matches of the last evaluation (m_id_f) and
+    their count identical."""
+    orc, so, sn, nav, eh = pair
+    inject_pair(eh, orc, so, sn)
+    orc.build_field(sn, 40, orc.retuned(sn))
+    s_rho_q = orc.quantile(so)
+    ang = 30.0 * np.pi / 180.0
+    ref = orc.minimizer_rv_kf(sn, so, X0, Kr, s_rho_q, match_mod, ang, rho_tol, iters, 2.0, mnt)
+    got = eh.minimizer_rv_kf(1, 0, X0, Kr, s_rho_q, match_mod, ang, rho_tol, iters, 2.0, mnt)
+    assert ref["mnum"] > 500, ref["mnum"]                 # the case exercises the match path
+    assert got["mnum"][0] == ref["mnum"], (got["mnum"][0], ref["mnum"])
+    kg, _ = eh.download_keylines(0, 0)
+    assert np.array_equal(kg["m_id_f"], orc.keylines(so)["m_id_f"])
+    assert np.allclose(got["X"][0], ref["X"], rtol=1e-9, atol=1e-12), (got["X"][0], ref["X"])
+    assert abs(got["score_ratio"][0] - ref["score_ratio"]) <= 1e-9 * abs(ref["score_ratio"]), (got["score_ratio"][0], ref["score_ratio"])
+    assert rel_err(got["RRV"][0], ref["RRV"]) < 1e-7
+    assert got["evals"][0] == iters + 1
+
+
+def test_minimizer_rv_kf_batched_requests(pair):
+    """Three sequences with the same KeyLines and three different requests (start pose, scale ratio, uncertainty gate) in
+    one call: every sequence must come out as the reference does for ITS request."""
+    orc, so, sn, nav, _ = pair
+    eh = edgehip.EdgeHip(edgehip.euroc_params(376, 240), nseq=3, nslots=2)
+    try:
+        for s in range(3):
+            inject_pair(eh, orc, so, sn, seq=s)
+        s_rho_q = orc.quantile(so)
+        X0 = np.array([[0, 0, 0, 0, 0, 0], [0.003, 0.001, -0.002, -0.002, 0.001, 0.002], [-0.002, 0.002, 0.001, 0.001, 0.002, -0.001]], np.float64)
+        Kr = np.array([1.0, 1.1, 0.95])
+        gate = np.array([s_rho_q, 0.5 * s_rho_q, 2.0 * s_rho_q])
+        ang = 30.0 * np.pi / 180.0
+        got = eh.minimizer_rv_kf(1, 0, X0, Kr, gate, 5.0, ang, 2.0, 5, 2.0, 0)
+        for s in range(3):
+            orc.build_field(sn, 40, orc.retuned(sn))
+            ref = orc.minimizer_rv_kf(sn, so, X0[s], float(Kr[s]), float(gate[s]), 5.0, ang, 2.0, 5, 2.0, 0)
+            assert got["mnum"][s] == ref["mnum"], (s, got["mnum"][s], ref["mnum"])
+            assert np.allclose(got["X"][s], ref["X"], rtol=1e-9, atol=1e-12), (s, got["X"][s], ref["X"])
+            assert rel_err(got["RRV"][s], ref["RRV"]) < 1e-7
+        assert len({int(m) for m in got["mnum"]}) > 1          # the requests did make a difference
+    finally:
+        eh.close()
+
+
 @pytest.mark.parametrize("w,h,mode", [(376, 240, None), (376, 240, "debug"), (376, 240, "1"), (376, 240, "2"), (1024, 1104, None)])
 def test_build_field_segments_that_round_across_a_tile_boundary(w, h, mode, monkeypatch):
     """The binned build_field works in 64 x 64 tiles.  A nearly axis-parallel segment whose centre sits within half a
