@@ -110,6 +110,15 @@ struct DevicePlan {  // everything a kernel needs that is constant for the conte
     double zfm;                     // (double)((zfx+zfy)/2) computed in float (cam_model.h:57)
 };
 
+// (int)double as the reference's x86-64 build converts it (cvttsd2si): out-of-range values and NaN give INT_MIN, where the
+// GPU's v_cvt_i32_f64 saturates to INT_MAX / 0.  Matters wherever the reference turns an unbounded double into a loop count
+// or an index: search_match's t_steps (edge_tracker.cpp:211-213) becomes negative there — no iterations — and 2^31
+// iterations with a saturating conversion.
+__device__ __forceinline__ int x86_cvttsd2si(double f) {
+    if (!(f > -2147483649.0 && f < 2147483648.0)) return (int)0x80000000;
+    return (int)f;
+}
+
 // round() as Image::GetIndexRC uses it (half away from zero) for pixel coordinates, in 3 instructions.
 // v_cvt_rpi_i32_f32 converts with "round to nearest, ties towards +infinity", evaluated exactly (not as a float
 // addition of 0.5): for v >= 0 that IS half-away-from-zero; for v < 0 the two differ only on exact ties, where both

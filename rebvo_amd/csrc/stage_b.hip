@@ -40,11 +40,6 @@
 
 namespace edgehip {
 
-__device__ __forceinline__ int x86_cvttsd2si(double f) {
-    if (!(f > -2147483649.0 && f < 2147483648.0)) return (int)0x80000000;
-    return (int)f;
-}
-
 // ---------------------------------------------------------------------------------------------------
 // EstimateQuantile
 // ---------------------------------------------------------------------------------------------------
@@ -514,8 +509,12 @@ __device__ __forceinline__ bool is_carry(double v) { return __double_as_longlong
 // the match test is Calc_f_J_Complete (global_tracker.cpp:116-165: angle, modulus ratio and inverse-depth consistency
 // against the matched KeyLine, with the transformed inverse depth divided by the scale ratio Kr), and the gate radius is
 // the field's own (gt.getMaxSRadius()).
+#ifndef EDGEHIP_TVR_ABL
+#define EDGEHIP_TVR_ABL 0   // timing experiments only (tools/experiments/exp_tvr_ablate.sh): 1 no cross-lane reduction, 2 no div/sqrt,
+#endif                      // 4 no matched-KeyLine gather, 8 no field gather, 16 no residual stream
 template <bool REWEIGHT, bool PROCJF, bool GREC, bool KF = false>
 __device__ __forceinline__ void tvr_body(const TvrArgs &a, const int seq, const int blk, const int tid) {
+    constexpr int ABL = KF ? 0 : EDGEHIP_TVR_ABL;
     const int lane = tid & 63, wave = tid >> 6;
     SeqDev *sq = a.seq + seq;
     const int kn = a.kn_old[seq];
@@ -562,7 +561,7 @@ __device__ __forceinline__ void tvr_body(const TvrArgs &a, const int seq, const 
             const float2 klm = ko.m_m[ikl];
             const float knm = ko.n_m[ikl];
             double rprev = 0;
-            if (REWEIGHT) rprev = rin[ikl];
+            if (REWEIGHT && !(ABL & 16)) rprev = rin[ikl];
             const uint32_t fc = KF ? 0xFFFFFFFFu : a.framecount[seq];
             const uint32_t mthr = a.match_num_thresh < fc ? a.match_num_thresh : fc;
             const bool skip = s_rho > sq->s_rho_min_eval || (uint32_t)mnum < mthr;  // int vs uint compare
@@ -587,7 +586,7 @@ __device__ __forceinline__ void tvr_body(const TvrArgs &a, const int seq, const 
                 double weight = 1;
                 if (REWEIGHT) {
                     if (is_carry(rprev)) rprev = carry_in_prev;
-                    if (fabs(rprev) > a.k_huber) weight = a.k_huber / fabs(rprev);
+                    if (fabs(rprev) > a.k_huber && !(ABL & 2)) weight = a.k_huber / fabs(rprev);
                 }
                 if (x < 1 || y < 1 || x >= a.w - 1 || y >= a.h - 1) {
                     fm = a.max_r;
@@ -599,7 +598,7 @@ __device__ __forceinline__ void tvr_body(const TvrArgs &a, const int seq, const 
                     // temporarily z-rotated gradient, stored back into a float Point2DF (:386-388)
                     const float rmx = KF ? klm.x : (float)(sq->RM[0] * (double)klm.x + sq->RM[1] * (double)klm.y);
                     const float rmy = KF ? klm.y : (float)(sq->RM[2] * (double)klm.x + sq->RM[3] * (double)klm.y);
-                    const uint32_t f = a.field16[(size_t)seq * a.f16stride + field16_index(x, y, a.f16tx)];
+                    const uint32_t f = (ABL & 8) ? (uint32_t)(ikl + 1) : a.field16[(size_t)seq * a.f16stride + field16_index(x, y, a.f16tx)];
                     if (KF) {
                         if (f != 0u) {
                             const int ikf = (int)f - 1;
@@ -627,7 +626,9 @@ __device__ __forceinline__ void tvr_body(const TvrArgs &a, const int seq, const 
                         // a random gather moves, instead of two) and u_m recomputed with the detector's own float
                         // expressions (k_emit; edge_finder.cpp:166-200), valid for KeyLines nothing has rotated since.
                         float f_cpx, f_cpy, f_mx, f_my, f_ux, f_uy;
-                        if (GREC) {
+                        if (ABL & 4) {
+                            f_cpx = (float)px; f_cpy = (float)py; f_mx = klm.x; f_my = klm.y; f_ux = 1.f; f_uy = 0.f;
+                        } else if (GREC) {
                             const float4 g = a.kl_new[seq].grec[ikf];
                             f_cpx = g.x; f_cpy = g.y; f_mx = g.z; f_my = g.w;
                         } else {
@@ -706,12 +707,12 @@ __device__ __forceinline__ void tvr_body(const TvrArgs &a, const int seq, const 
                 J[5] = -1 * t0; J[5] += J[1] * ptx;
             }
             const double qvel = (a.zfm * dfx * sq->Vt[0] + a.zfm * dfy * sq->Vt[1] + (pix * dfx + piy * dfy) * sq->Vt[2]);
-            double q_rho = sqrt(s_rho * qvel * s_rho * qvel + 1);
+            double q_rho = (ABL & 2) ? s_rho * qvel + 1 : sqrt(s_rho * qvel * s_rho * qvel + 1);
             if (!REWEIGHT) q_rho = s_rho;
             // The reference divides the seven values by q_rho one by one; one reciprocal and seven products differ
             // from that by at most one ulp per value (well inside the fp32-level pose tolerance) and remove six fp64
             // divisions from a kernel that is bound by fp64 issue.
-            const double inv_q = 1.0 / q_rho;
+            const double inv_q = (ABL & 2) ? q_rho : 1.0 / q_rho;
             if (PROCJF) {
 #pragma unroll
                 for (int j = 0; j < 6; j++) J[j] *= inv_q;
@@ -745,7 +746,9 @@ __device__ __forceinline__ void tvr_body(const TvrArgs &a, const int seq, const 
 
     // ---- block reduction: transposed (halving) wave reduction, LDS across waves, one partial per block ----
     __shared__ double s_red[NW][32];
-    if (PROCJF) {
+    if (PROCJF && (ABL & 1)) {
+        if (lane < kNumSums) s_red[wave][lane] = sums[lane % 4];
+    } else if (PROCJF) {
         const int idx = wave_reduce28(sums, lane);
         if ((lane & 1) == 0) s_red[wave][idx] = sums[0];
     } else {

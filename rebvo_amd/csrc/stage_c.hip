@@ -260,9 +260,9 @@ __global__ __launch_bounds__(256) void k_directed(DirArgs a) {
             dq_max = fmin(a.max_radius, norm_t * (k_rho + ksrho)) + a.loc_unc;
             if (dq_rho > dq_max) {
                 dq_rho = (dq_max + dq_min) / 2;
-                t_steps = (int)(dq_rho + 0.5);
+                t_steps = x86_cvttsd2si(dq_rho + 0.5);       // util::round2int_positive on x86-64 (see ctx.h)
             } else {
-                t_steps = (int)(fmax(dq_max - dq_rho, dq_rho - dq_min) + 0.5);
+                t_steps = x86_cvttsd2si(fmax(dq_max - dq_rho, dq_rho - dq_min) + 0.5);
             }
         } else {
             t_x = (double)kmm.x;
@@ -284,7 +284,10 @@ __global__ __launch_bounds__(256) void k_directed(DirArgs a) {
         // examined in the reference's order: the dependent-latency chain shrinks DM_CH-fold, the result is identical.
         constexpr int DM_CH = 2;
         double tn = dq_rho, tp = dq_rho + 1;   // advanced by repeated -= 1 / += 1 exactly as the reference does
-        for (int t0i = 0; t0i < t_steps && found < 0; t0i += DM_CH) {
+        // tn only falls and tp only rises: once tn < dq_min and tp > dq_max no later step can probe anything.  The reference
+        // spins through the remaining t_steps doing nothing (a wild velocity estimate makes that up to 2^31 steps per
+        // KeyLine: dq_rho = (dq_max + dq_min) / 2 with dq_min far above dq_max); leaving the loop there changes no result.
+        for (int t0i = 0; t0i < t_steps && found < 0 && !(tn < dq_min && tp > dq_max); t0i += DM_CH) {
             double tv[DM_CH][2];
             int jm[DM_CH][2];
 #pragma unroll

@@ -146,3 +146,35 @@ def test_ext_rot_vel():
             assert np.allclose(X[q], ref["X"], rtol=1e-8, atol=1e-14)
             assert rel_err(Rx[q], ref["Rx"]) < 1e-8
     eh.close()
+
+
+@pytest.mark.parametrize("V,against_reference", [((-4.1, -3.2, -0.47), True), ((3.0e7, -2.0e7, 1.0e6), False), ((float("nan"), 0.0, 0.0), True)])
+def test_directed_matching_with_a_wild_velocity_estimate(tracked, V, against_reference):
+    """search_match turns norm_t * rho into a loop count (edge_tracker.cpp:211-213).  With a velocity estimate gone wild
+    (a diverged minimiser) that count reaches millions — steps that probe nothing — or leaves the int range, where the
+    reference's x86-64 conversion yields INT_MIN (no steps) and the GPU's saturating one would yield 2^31 steps: the kernel
+    once spun for 50 s on such a frame.  Results must still be the reference's, in bounded time.  (The middle case is not
+    run on the CPU reference: there the empty steps are executed one by one, up to 2^31 per KeyLine.)"""
+    import time
+    orc, so, sn, res, eh = tracked
+    RVel, W = res["RVel"], res["W"]
+    R0 = so3_exp(W)
+    inject_pair(eh, orc, so, sn)
+    st = eh.get_state(0)
+    st.V[:] = V
+    st.P_V[:] = RVel.ravel()
+    st.R[:] = R0.T.ravel()
+    st.klm_num = 0
+    st.kf_matchs = 0
+    eh.set_state(0, st)
+    t0 = time.perf_counter()
+    eh.directed_matching(1, 0)
+    eh.sync()
+    dt = time.perf_counter() - t0
+    assert dt < 1.0, f"k_directed took {dt:.1f} s"
+    if against_reference:
+        n_ref, kf_ref = orc.directed_matching(sn, so, np.array(V, np.float64), RVel, R0.T, 1.0, 45.0, 40.0, 2.0)
+        kg, _ = eh.download_keylines(0, 1, want_mask=False)
+        _cmp(kg, orc.keylines(sn), MATCH_FIELDS_EXACT, tag="directed, wild V")
+        g = eh.get_state(0)
+        assert (g.klm_num, g.kf_matchs) == (n_ref, kf_ref)
