@@ -283,11 +283,39 @@ __global__ __launch_bounds__(256) void k_directed(DirArgs a) {
         // on earlier probes, so the mask reads of DM_CH steps (2*DM_CH gathers) are issued together and only then
         // examined in the reference's order: the dependent-latency chain shrinks DM_CH-fold, the result is identical.
         constexpr int DM_CH = 2;
-        double tn = dq_rho, tp = dq_rho + 1;   // advanced by repeated -= 1 / += 1 exactly as the reference does
-        // tn only falls and tp only rises: once tn < dq_min and tp > dq_max no later step can probe anything.  The reference
-        // spins through the remaining t_steps doing nothing (a wild velocity estimate makes that up to 2^31 steps per
-        // KeyLine: dq_rho = (dq_max + dq_min) / 2 with dq_min far above dq_max); leaving the loop there changes no result.
-        for (int t0i = 0; t0i < t_steps && found < 0 && !(tn < dq_min && tp > dq_max); t0i += DM_CH) {
+        // A step probes the old mask only if its position lies inside the image, i.e. |t| <= Tmax (the direction is a unit
+        // vector).  With a sane velocity estimate every step qualifies.  With a diverged one norm_t * rho reaches 1e8 and
+        // beyond and the reference walks through all of it: tn comes down from dq_rho to dq_min one pixel at a time, millions
+        // of steps that fall outside the image, before (and after) the few hundred that can see the mask — the kernel once
+        // took 50 s for one frame.  Only the steps that can see the mask are executed here: at most two runs of step
+        // indices (one where tn is within Tmax of the image, one where tp is), each entered with tn / tp computed directly.
+        // That is the value the reference's repeated -= 1 / += 1 arrives at: moving towards zero in unit steps is exact in
+        // fp64 (the grid only gets finer), and a counter that moves away from zero is beyond Tmax for good.
+        const double Tmax = (double)(a.w + a.h) + fabs((double)pi0x) + fabs((double)pi0y) + 4.0;
+        int seg0[2] = {0, 0}, seg1[2] = {t_steps, 0};   // [seg0[k], seg1[k]) step-index runs; default: everything
+        int nseg = 1;
+        if (t_steps > 256 && fabs(dq_rho) < 1e15 && Tmax < 1e15) {
+            // steps at which tn = dq_rho - i (>= dq_min) resp. tp = dq_rho + 1 + i (<= dq_max) is within Tmax of zero
+            const double n0 = fmax(0.0, floor(dq_rho - Tmax) - 2.0), n1 = fmin((double)t_steps, ceil(fmin(dq_rho + Tmax, dq_rho - dq_min)) + 2.0);
+            const double p0 = fmax(0.0, floor(-Tmax - dq_rho - 1.0) - 2.0), p1 = fmin((double)t_steps, ceil(fmin(Tmax - dq_rho - 1.0, dq_max - dq_rho - 1.0)) + 2.0);
+            const bool hn = n1 > n0, hp = p1 > p0;
+            nseg = 0;
+            if (hn && hp && !(n1 < p0 || p1 < n0)) {   // overlapping: one run
+                seg0[0] = (int)fmin(n0, p0); seg1[0] = (int)fmax(n1, p1); nseg = 1;
+            } else {
+                if (hn) { seg0[nseg] = (int)n0; seg1[nseg] = (int)n1; nseg++; }
+                if (hp) { seg0[nseg] = (int)p0; seg1[nseg] = (int)p1; nseg++; }
+                if (nseg == 2 && seg0[1] < seg0[0]) {
+                    const int s0 = seg0[0], s1 = seg1[0];
+                    seg0[0] = seg0[1]; seg1[0] = seg1[1]; seg0[1] = s0; seg1[1] = s1;
+                }
+            }
+        }
+        for (int sg = 0; sg < nseg && found < 0; sg++) {
+        // counters as the reference's repeated -= 1 / += 1 leave them at step seg0[sg]
+        double tn = dq_rho - (double)seg0[sg], tp = (dq_rho + 1) + (double)seg0[sg];
+        const int t_end = seg1[sg];
+        for (int t0i = seg0[sg]; t0i < t_end && found < 0; t0i += DM_CH) {
             double tv[DM_CH][2];
             int jm[DM_CH][2];
 #pragma unroll
@@ -298,7 +326,7 @@ __global__ __launch_bounds__(256) void k_directed(DirArgs a) {
                 for (int dir = 0; dir < 2; dir++) {
                     const double t = tv[c][dir];
                     jm[c][dir] = -1;
-                    if (t0i + c >= t_steps) continue;
+                    if (t0i + c >= t_end) continue;
                     if (dir ? t > dq_max : t < dq_min) continue;
                     const float fx = (float)(t_x * t + (double)pi0x), fy = (float)(t_y * t + (double)pi0y);
                     const int xi = round_half_away_i(fx), yi = round_half_away_i(fy);
@@ -324,6 +352,7 @@ __global__ __launch_bounds__(256) void k_directed(DirArgs a) {
                     found = j;
                 }
             }
+        }
         }
         if (found >= 0) {
             const int j = found;

@@ -148,17 +148,20 @@ def test_ext_rot_vel():
     eh.close()
 
 
-@pytest.mark.parametrize("V,against_reference", [((-4.1, -3.2, -0.47), True), ((3.0e7, -2.0e7, 1.0e6), False), ((float("nan"), 0.0, 0.0), True)])
-def test_directed_matching_with_a_wild_velocity_estimate(tracked, V, against_reference):
+@pytest.mark.parametrize("V,flip,against_reference", [((-4.1, -3.2, -0.47), False, True), ((3.0e7, -2.0e7, 1.0e6), False, False),
+                                                       ((float("nan"), 0.0, 0.0), False, True), ((0.8, -0.5, 0.3), True, True),
+                                                       ((-40.0, 25.0, 3.0), True, True)])
+def test_directed_matching_with_a_wild_velocity_estimate(tracked, V, flip, against_reference):
     """search_match turns norm_t * rho into a loop count (edge_tracker.cpp:211-213).  With a velocity estimate gone wild
     (a diverged minimiser) that count reaches millions — steps that probe nothing — or leaves the int range, where the
     reference's x86-64 conversion yields INT_MIN (no steps) and the GPU's saturating one would yield 2^31 steps: the kernel
     once spun for 50 s on such a frame.  Results must still be the reference's, in bounded time.  (The middle case is not
-    run on the CPU reference: there the empty steps are executed one by one, up to 2^31 per KeyLine.)"""
+    run on the CPU reference: there the empty steps are executed one by one, up to 2^31 per KeyLine.)  `flip`: a back-rotation
+    by pi about x, which puts every KeyLine behind the camera (negative inverse depth): long walks that do reach the image."""
     import time
     orc, so, sn, res, eh = tracked
     RVel, W = res["RVel"], res["W"]
-    R0 = so3_exp(W)
+    R0 = np.diag([1.0, -1.0, -1.0]) if flip else so3_exp(W)
     inject_pair(eh, orc, so, sn)
     st = eh.get_state(0)
     st.V[:] = V
