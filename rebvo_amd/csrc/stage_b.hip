@@ -509,6 +509,9 @@ __device__ __forceinline__ bool is_carry(double v) { return __double_as_longlong
 // the match test is Calc_f_J_Complete (global_tracker.cpp:116-165: angle, modulus ratio and inverse-depth consistency
 // against the matched KeyLine, with the transformed inverse depth divided by the scale ratio Kr), and the gate radius is
 // the field's own (gt.getMaxSRadius()).
+#ifndef EDGEHIP_TVR_MFMA
+#define EDGEHIP_TVR_MFMA 0   // 1: the 28 sums as a Gram matrix on the f64 matrix core (measured 4 % slower on gfx950, see tvr_body)
+#endif
 #ifndef EDGEHIP_TVR_ABL
 #define EDGEHIP_TVR_ABL 0   // timing experiments only (tools/experiments/exp_tvr_ablate.sh): 1 no cross-lane reduction, 2 no div/sqrt,
 #endif                      // 4 no matched-KeyLine gather, 8 no field gather, 16 no residual stream
@@ -531,6 +534,8 @@ __device__ __forceinline__ void tvr_body(const TvrArgs &a, const int seq, const 
     // products of every pass accumulate in registers; the cross-lane reduction runs once per block instead of once
     // per KeyLine.
     constexpr int NW = kTvrThreads / 64;   // waves per block
+    constexpr bool GRAM_MFMA = PROCJF && kTvrPasses == 1 && EDGEHIP_TVR_MFMA && !(ABL & 1);
+    __shared__ double s_rows[GRAM_MFMA ? NW : 1][GRAM_MFMA ? 64 : 1][8];
     __shared__ double s_wlast[kTvrPasses][NW];
     __shared__ int s_whas[kTvrPasses][NW];
     double sums[kNumSums];
@@ -719,7 +724,14 @@ __device__ __forceinline__ void tvr_body(const TvrArgs &a, const int seq, const 
             }
             fm *= inv_q;
         }
-        {
+        if (GRAM_MFMA) {
+            // the KeyLine's row (J0..J5, fm, 0) for the Gram matrix below; rows of skipped / absent KeyLines are zero
+            double2 *row = reinterpret_cast<double2 *>(&s_rows[wave][lane][0]);
+            row[0] = make_double2(J[0], J[1]);
+            row[1] = make_double2(J[2], J[3]);
+            row[2] = make_double2(J[4], J[5]);
+            row[3] = make_double2(fm, 0.0);
+        } else {
             int ns = 0;
             if (PROCJF) {
 #pragma unroll
@@ -746,7 +758,36 @@ __device__ __forceinline__ void tvr_body(const TvrArgs &a, const int seq, const 
 
     // ---- block reduction: transposed (halving) wave reduction, LDS across waves, one partial per block ----
     __shared__ double s_red[NW][32];
-    if (PROCJF && (ABL & 1)) {
+    if (GRAM_MFMA) {
+        // J^T J, J^T f and f^T f of the wave's 64 KeyLines are the Gram matrix A^T A of its 64 x 7 rows: 16 issues of
+        // v_mfma_f64_16x16x4_f64 (k = 4 KeyLines each; A and B operand are the same register: lane (m, kk) holds element m of
+        // KeyLine 4s + kk, zero for m >= 7) instead of 27 products per lane and a 28-value cross-lane reduction (~300 of the
+        // kernel's ~1000 instructions).  Deterministic (fixed k order), sums within rounding of the butterfly's, all parity
+        // tests pass — and 4 % SLOWER (3300 -> 3440 us per 12 evaluations, same box): gfx950 runs f64 MFMA at the vector
+        // rate (32 flop/cycle/SIMD), a 16x16x4 issue occupies the matrix pipe for 64 cycles, and only 7 x 7 of its 16 x 16
+        // outputs are wanted: 1024 pipe cycles per wave, more than the vector instructions it replaces.  Off by default.
+        typedef double v4d __attribute__((ext_vector_type(4)));
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        const int m = (lane & 15) < 7 ? (lane & 15) : 7, kk = lane >> 4;
+        const double *src = &s_rows[wave][kk][m];
+        v4d acc = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+        for (int st = 0; st < 16; st++) {
+            const double v = src[st * 4 * 8];
+            acc = __builtin_amdgcn_mfma_f64_16x16x4f64(v, v, acc, 0, 0, 0);
+        }
+        // D(i, j): column j = lane & 15, row i = (lane >> 4) + 4 * reg   (f64 16x16x4 accumulator layout)
+        const int j = lane & 15;
+#pragma unroll
+        for (int r = 0; r < 2; r++) {
+            const int i = (lane >> 4) + 4 * r;
+            if (j < 7 && i <= j) {
+                const int idx = j < 6 ? i * 6 - (i * (i - 1)) / 2 + (j - i) : (i < 6 ? 21 + i : 27);
+                s_red[wave][idx] = acc[r];
+            }
+        }
+    } else if (PROCJF && (ABL & 1)) {
         if (lane < kNumSums) s_red[wave][lane] = sums[lane % 4];
     } else if (PROCJF) {
         const int idx = wave_reduce28(sums, lane);
