@@ -291,3 +291,30 @@ def test_two_slots_bound_between_frames_keep_their_own_indices():
         assert [int(v) for v in kn0] == [ref[i] for i in ia], rep
         assert [int(v) for v in kn1] == [ref[i] for i in ib], rep
     eh.close()
+
+
+@pytest.mark.parametrize("kind", ["noise", "shuffled"])
+def test_frames_the_tracker_cannot_explain_finish_in_bounded_time(kind):
+    """White noise, and a scene that jumps by a hundred pixels every frame: the minimiser diverges, velocity estimates go
+    wild, and every data-dependent loop of the path (search_match's walk above all) must still terminate quickly —
+    a frame of four small sequences takes ~1 ms, the bound is 1 s."""
+    import time
+    from rebvo_amd import synth
+    w, h, n = 376, 240, 4
+    rs = np.random.RandomState(11)
+    scene = [f for f, _, _ in synth.billboard_sequence(w, h, 4)]
+    eh = edgehip.EdgeHip(edgehip.euroc_params(w, h), nseq=n, nslots=3)
+    try:
+        for k in range(8):
+            if kind == "noise":
+                fr = rs.randint(0, 256, (n, h, w, 3), dtype=np.uint8)
+            else:
+                fr = np.stack([np.roll(scene[(k + s) % 4], 97 * k * (s + 1), axis=1) for s in range(n)])
+            eh.upload_rgb(eh.next_slot(), np.ascontiguousarray(fr))
+            t0 = time.perf_counter()
+            eh.process_frame(0.05 * k)
+            eh.sync()
+            assert time.perf_counter() - t0 < 1.0, (kind, k)
+        assert all(x.kn > 0 for x in eh.read_nav())
+    finally:
+        eh.close()
