@@ -565,6 +565,7 @@ def main():
     # N > 1: the nav records of a step travel to rank 0 in blocks of `blk` steps on a side stream (RCCL gather issued
     # while the next block is being computed; two buffers), the last block after the timed region's last step
     mover = shard.NavMover(world, rank, backend, device=local_rank if backend == "nccl" else None) if world > 1 else None
+    nav_gather = None
     blk = max(1, K // 4)
     barrier()
     t0 = time.perf_counter()
@@ -573,11 +574,18 @@ def main():
         rp.step(k)
         done = k - Wm + 1
         if mover and (done % blk == 0 or done == K):   # the block just enqueued: the mover's thread waits for it, this one does not
-            for ci, e in enumerate(ehs):
-                mover.post(e, Wm + posted, done - posted, [(rank * C + ci) * B + s for s in range(B)])
+            try:
+                for ci, e in enumerate(ehs):
+                    mover.post(e, Wm + posted, done - posted, [(rank * C + ci) * B + s for s in range(B)])
+            except Exception as ex:     # the records are a by-product: a broken transport must not take the measurement down
+                nav_gather, mover = f"failed: {str(ex)[:120]}", None
             posted = done
     if mover:
-        mover.finish()      # every record has reached rank 0 inside the timed region; all but the last block under compute
+        try:
+            mover.finish(timeout=120)   # every record has reached rank 0 inside the timed region; all but the last block under compute
+            nav_gather = "ok"
+        except Exception as ex:
+            nav_gather = f"failed: {str(ex)[:120]}"
     barrier()
     dt = time.perf_counter() - t0
     # ---- end of timed region ----
@@ -775,7 +783,7 @@ def main():
                                 "image, GlobalConfig_desk.txt params, UseUndistort=1 with the EuRoC distortion (SURVEY 8d scene S3), "
                                 "undistortion fused into the stage-A load"),
                    "sequences_per_gpu": B * C, "contexts_per_gpu": C, "sequences_per_launch": B,
-                   "stream_overlap": bool(args.overlap),
+                   "stream_overlap": bool(args.overlap), "nav_gather": nav_gather,
                    "frames_per_step": B * C * world, "keylines_per_frame": round(kn_mean, 1),
                    "tryvelrot_evals_per_frame": evals, "estimation_ok": f"{ok}/{B * C}",
                    "algorithmic_MB_per_frame": round(frame_bytes / 1e6, 2),

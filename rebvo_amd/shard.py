@@ -98,10 +98,14 @@ class NavMover:
                 self.error = e
                 return
 
-    def finish(self):
-        """Waits until every posted block has arrived; returns the blocks (on dst) in posting order."""
+    def finish(self, timeout=None):
+        """Waits until every posted block has arrived; returns the blocks (on dst) in posting order.  With a timeout
+        (seconds) a transport that does not come back raises TimeoutError instead of blocking the caller for ever (the
+        worker is a daemon thread)."""
         self._q.put(None)
-        self._t.join()
+        self._t.join(timeout)
+        if self._t.is_alive():
+            raise TimeoutError(f"nav gather still running after {timeout} s")
         if self.error is not None:
             raise self.error
         return self.blocks
