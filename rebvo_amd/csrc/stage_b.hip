@@ -206,13 +206,17 @@ __device__ __forceinline__ bool tile_trange(const MatchRec &r, int tx0, int ty0,
     float tlo = (float)(-radius), thi = (float)(radius - 1);
     const float bx0 = (float)tx0 - 1.f - r.c_px, bx1 = (float)(tx0 + FT) - r.c_px;
     const float by0 = (float)ty0 - 1.f - r.c_py, by1 = (float)(ty0 + FT) - r.c_py;
+    // (v_rcp_f32 + products instead of IEEE divisions: the range is conservative by a whole sample on either side, and both
+    // users — the binning and the rasteriser — go through this one function)
     if (fabsf(r.u_mx) > 1e-6f) {
-        const float a = bx0 / r.u_mx, b = bx1 / r.u_mx;
+        const float iu = __builtin_amdgcn_rcpf(r.u_mx);
+        const float a = bx0 * iu, b = bx1 * iu;
         tlo = fmaxf(tlo, fminf(a, b) - 1.f);
         thi = fminf(thi, fmaxf(a, b) + 1.f);
     } else if (bx0 > 0.f || bx1 < 0.f) return false;
     if (fabsf(r.u_my) > 1e-6f) {
-        const float a = by0 / r.u_my, b = by1 / r.u_my;
+        const float iu = __builtin_amdgcn_rcpf(r.u_my);
+        const float a = by0 * iu, b = by1 * iu;
         tlo = fmaxf(tlo, fminf(a, b) - 1.f);
         thi = fminf(thi, fmaxf(a, b) + 1.f);
     } else if (by0 > 0.f || by1 < 0.f) return false;
@@ -491,7 +495,7 @@ struct TvrArgs {
     int w, h, cap, nblk, nseq;
     size_t f16stride;          // index-plane elements per sequence
     int f16tx;                 // 8x4-pixel tiles per tile row
-    double zfm, max_r, match_thresh, k_huber;
+    double zfm, max_r, match_thresh, k_huber, inv_k_huber;
     float ppx, ppy;
     uint32_t match_num_thresh;
     int write_mid;             // store kl.m_id_f (only the last evaluation of a minimisation needs to)
@@ -500,6 +504,15 @@ struct TvrArgs {
     const edgehip_kf_request *kf;   // [B]
     double kf_match_mod, kf_match_cang, kf_rho_tol;
 };
+
+// 1 / sqrt(x) for x >= 1: hardware estimate + two Newton steps (relative error of a few 1e-16; x < 1e300)
+__device__ __forceinline__ double rsqrt_f64(double x) {
+    double y = __builtin_amdgcn_rsq(x);
+    const double hx = 0.5 * x;
+    y = y * (1.5 - hx * y * y);
+    y = y * (1.5 - hx * y * y);
+    return x > 1e300 ? 0.0 : y;   // 1 / sqrt(inf) = 0 as the reference's x / sqrt(inf) gives; NaN stays NaN
+}
 
 __device__ __forceinline__ bool is_carry(double v) { return __double_as_longlong(v) == (long long)resid_carry_bits(); }
 
@@ -550,6 +563,7 @@ __device__ __forceinline__ void tvr_body(const TvrArgs &a, const int seq, const 
         double J[6] = {0, 0, 0, 0, 0, 0};
         double fm = 0, dfx = 0, dfy = 0;
         double ptx = 0, pty = 0, ptz = 1, pix = 0, piy = 0, rho_p = 1, s_rho = 1;
+        double inv_w2 = 1;   // 1 / weight^2 (REWEIGHT)
         int mid_f = -1;
         // status: 0 = skipped (no residual written), 1 = out of image (max_r), 2 = evaluated & matched (own fi),
         //         3 = evaluated, unmatched (inherits the previous valid fi)
@@ -588,14 +602,17 @@ __device__ __forceinline__ void tvr_body(const TvrArgs &a, const int seq, const 
                 piy = pz_zf * pty;
                 const double px = pix + (double)a.ppx, py = piy + (double)a.ppy;  // cam_model::Hom2Img
                 const int x = x86_cvttsd2si(px + 0.5), y = x86_cvttsd2si(py + 0.5);
-                double weight = 1;
+                // Huber weight k / |r| of the previous iteration's residual (global_tracker.cpp:370-372).  It multiplies the
+                // residual and the gradient, the uncertainty scaling q_rho = sqrt((s_rho w qvel)^2 + 1) divides them again
+                // (:452-463): together w / q_rho = 1 / sqrt((s_rho qvel)^2 + 1 / w^2) — one reciprocal square root instead of
+                // a division, a square root and a division, all fp64 (8 % of the reweighted evaluation by the ablation).
+                // Differs from the reference's order of roundings by an ulp or two of the scale factor.
                 if (REWEIGHT) {
                     if (is_carry(rprev)) rprev = carry_in_prev;
-                    if (fabs(rprev) > a.k_huber && !(ABL & 2)) weight = a.k_huber / fabs(rprev);
+                    if (fabs(rprev) > a.k_huber && !(ABL & 2)) { const double rk = fabs(rprev) * a.inv_k_huber; inv_w2 = rk * rk; }
                 }
                 if (x < 1 || y < 1 || x >= a.w - 1 || y >= a.h - 1) {
                     fm = a.max_r;
-                    if (REWEIGHT) fm *= weight;
                     status = 1;
                 } else {
                     status = 3;
@@ -658,11 +675,6 @@ __device__ __forceinline__ void tvr_body(const TvrArgs &a, const int seq, const 
                             status = 2;
                         }
                     }
-                    if (REWEIGHT) {
-                        fm *= weight;
-                        dfx *= weight;
-                        dfy *= weight;
-                    }
                 }
             }
         }
@@ -712,12 +724,16 @@ __device__ __forceinline__ void tvr_body(const TvrArgs &a, const int seq, const 
                 J[5] = -1 * t0; J[5] += J[1] * ptx;
             }
             const double qvel = (a.zfm * dfx * sq->Vt[0] + a.zfm * dfy * sq->Vt[1] + (pix * dfx + piy * dfy) * sq->Vt[2]);
-            double q_rho = (ABL & 2) ? s_rho * qvel + 1 : sqrt(s_rho * qvel * s_rho * qvel + 1);
-            if (!REWEIGHT) q_rho = s_rho;
-            // The reference divides the seven values by q_rho one by one; one reciprocal and seven products differ
-            // from that by at most one ulp per value (well inside the fp32-level pose tolerance) and remove six fp64
-            // divisions from a kernel that is bound by fp64 issue.
-            const double inv_q = (ABL & 2) ? q_rho : 1.0 / q_rho;
+            // The reference divides the seven values by q_rho one by one; one scale factor and seven products differ
+            // from that by at most an ulp or two per value (well inside the fp32-level pose tolerance) and remove the fp64
+            // divisions from a kernel that is bound by fp64 issue.  (qvel here is the unweighted one, see above.)
+            double inv_q;
+            if (REWEIGHT) {
+                const double sq = s_rho * qvel;
+                inv_q = (ABL & 2) ? sq + inv_w2 : rsqrt_f64(sq * sq + inv_w2);
+            } else {
+                inv_q = 1.0 / s_rho;
+            }
             if (PROCJF) {
 #pragma unroll
                 for (int j = 0; j < 6; j++) J[j] *= inv_q;
@@ -1725,7 +1741,7 @@ static TvrArgs make_tvr_args(edgehip_ctx *c, int slot_new, int slot_old, double 
     a.block_last = c->block_last; a.partials = c->partials; a.seq = c->seq;
     a.framecount = c->framecount + (size_t)c->fc_index * pl.nseq;
     a.w = pl.w; a.h = pl.h; a.cap = pl.cap; a.nblk = c->nblk_tvr; a.nseq = pl.nseq;
-    a.zfm = pl.zfm; a.max_r = (double)c->field_radius; a.match_thresh = match_thresh; a.k_huber = k_huber;
+    a.zfm = pl.zfm; a.max_r = (double)c->field_radius; a.match_thresh = match_thresh; a.k_huber = k_huber; a.inv_k_huber = 1.0 / k_huber;
     a.ppx = pl.ppx; a.ppy = pl.ppy; a.match_num_thresh = match_num_thresh; a.write_mid = write_mid;
     a.use_grec = c->grec_ok[slot_new] && !c->no_grec;
     a.kf = nullptr; a.kf_match_mod = a.kf_match_cang = a.kf_rho_tol = 0;
