@@ -27,8 +27,11 @@ def _run(kind, g, exact_pose):
     frames = g["frames"]
     n, h, w = frames.shape
     orc = oracle.Oracle(kind, oracle.euroc_params(w, h, **over))
+    prev = -1
     for k in range(n):
         f = np.repeat(frames[k][:, :, None], 3, axis=2)
+        if k == n - 1:
+            prev = orc.cur_slot()
         _, nav = orc.process_frame(f, 0.05 * k)
         s = orc.cur_slot()
         assert nav.kn == g["kn"][k] and nav.tresh == g["tresh"][k]
@@ -60,6 +63,17 @@ def _run(kind, g, exact_pose):
         same = kl["m_id"] == gk["m_id"]
         assert same.mean() > 0.995
         assert np.allclose(kl["rho"][same], gk["rho"][same], rtol=1e-6, atol=1e-8)
+    if kind == "ref" and "kf_X" in g.files:   # the key-frame tracker (kfvo::Minimizer_RV_KF), requests as in tools/make_golden.py
+        import importlib.util
+        spec = importlib.util.spec_from_file_location("make_golden", os.path.join(os.path.dirname(__file__), "..", "tools", "make_golden.py"))
+        mg = importlib.util.module_from_spec(spec)
+        spec.loader.exec_module(mg)
+        for q, (X0, Kr) in enumerate(mg.KF_REQUESTS):
+            r = orc.minimizer_rv_kf(s, prev, X0, Kr, float(g["s_rho_q"][-1]), *mg.KF_ARGS)
+            assert r["mnum"] == g["kf_mnum"][q]
+            assert _sha(orc.keylines(prev)["m_id_f"]) == str(g["kf_mid_sha"][q])
+            assert np.allclose(r["X"], g["kf_X"][q], rtol=1e-12, atol=1e-15) and np.allclose(r["RRV"], g["kf_RRV"][q], rtol=1e-10)
+            assert abs(r["score_ratio"] - g["kf_ratio"][q]) <= 1e-12 * abs(g["kf_ratio"][q])
 
 
 @pytest.mark.parametrize("path", GOLD, ids=[os.path.basename(p) for p in GOLD])

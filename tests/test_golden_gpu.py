@@ -50,4 +50,16 @@ def test_hip_matches_golden(path):
     same = kl["m_id"] == gk["m_id"]
     assert same.mean() > 0.995
     assert np.allclose(kl["rho"][same], gk["rho"][same], rtol=1e-6, atol=1e-8)
+    if "kf_X" in g.files:
+        # key-frame tracker against the reference's results stored with the fixture (tools/make_golden.py): the previous
+        # frame's KeyLines against the field of the last frame's.  The inputs are the device's own KeyLines after the replay
+        # (depths within 1e-6 of the reference's), hence tolerances instead of identities.
+        KF_REQUESTS = [((0, 0, 0, 0, 0, 0), 1.0), ((0.003, -0.002, 0.001, 0.001, 0.002, -0.001), 1.1)]
+        cur = eh.cur_slot()
+        for q, (X0, Kr) in enumerate(KF_REQUESTS):
+            r = eh.minimizer_rv_kf(cur, (cur + 2) % 3, X0, Kr, float(g["s_rho_q"][-1]), 5.0, 30.0 * np.pi / 180.0, 5.0, 5, 2.0, 0)
+            assert abs(int(r["mnum"][0]) - int(g["kf_mnum"][q])) <= max(2, int(g["kf_mnum"][q]) // 500), (r["mnum"][0], g["kf_mnum"][q])
+            scale = np.abs(g["kf_X"][q]).max()
+            assert np.allclose(r["X"][0], g["kf_X"][q], rtol=0, atol=1e-5 * scale + 1e-9), (r["X"][0], g["kf_X"][q])
+            assert abs(r["score_ratio"][0] - g["kf_ratio"][q]) <= 1e-4 * abs(g["kf_ratio"][q])
     eh.close()

@@ -18,6 +18,10 @@ from oracle import oracle  # noqa: E402
 from rebvo_amd import synth  # noqa: E402
 
 
+KF_REQUESTS = [((0, 0, 0, 0, 0, 0), 1.0), ((0.003, -0.002, 0.001, 0.001, 0.002, -0.001), 1.1)]
+KF_ARGS = (5.0, 30.0 * np.pi / 180.0, 5.0, 5, 2.0, 0)   # match_mod, match_ang, rho_tol, iter_max, reweight_distance, match_num_thresh
+
+
 def sha(a):
     return hashlib.sha256(np.ascontiguousarray(a).tobytes()).hexdigest()
 
@@ -26,7 +30,10 @@ def make(name, w, h, frames, **over):
     orc = oracle.Oracle("ref", oracle.euroc_params(w, h, **over))
     rec = dict(kn=[], tresh=[], retuned=[], mask_sha=[], dog_sha=[], img0_sha=[], V=[], W=[], Pos=[], klm_num=[],
                klm_fwd=[], s_rho_q=[], Kp=[], RKp=[], ok=[], score=[])
+    prev = -1
     for k, f in enumerate(frames):
+        if k == len(frames) - 1:
+            prev = orc.cur_slot()
         _, nav = orc.process_frame(f, 0.05 * k)
         s = orc.cur_slot()
         rec["kn"].append(nav.kn); rec["tresh"].append(nav.tresh); rec["retuned"].append(nav.retuned_thresh)
@@ -43,6 +50,15 @@ def make(name, w, h, frames, **over):
     out["last_mask"] = orc.mask(s).astype(np.int32)
     out["frames"] = np.stack([f[:, :, 0] for f in frames]).astype(np.uint8)  # r=g=b
     out["over"] = np.array(repr(sorted(over.items())))
+    # key-frame tracker (kfvo::Minimizer_RV_KF): the previous frame's KeyLines against the field of the last
+    # frame's, with the arguments kfvo::OptimizePosGT passes (kfvo.cpp:74) and two start poses
+    kf = dict(X=[], RRV=[], ratio=[], mnum=[], mid_sha=[])
+    for X0, Kr in KF_REQUESTS:
+        r = orc.minimizer_rv_kf(s, prev, X0, Kr, float(rec["s_rho_q"][-1]), *KF_ARGS)
+        kf["X"].append(r["X"]); kf["RRV"].append(r["RRV"]); kf["ratio"].append(r["score_ratio"]); kf["mnum"].append(r["mnum"])
+        kf["mid_sha"].append(sha(orc.keylines(prev)["m_id_f"]))
+    for k2, v in kf.items():
+        out["kf_" + k2] = np.array(v)
     path = os.path.join(ROOT, "tests", "golden", name + ".npz")
     np.savez_compressed(path, **out)
     print(name, "kn", rec["kn"], "klm", rec["klm_num"], os.path.getsize(path), "bytes")
