@@ -299,8 +299,12 @@ __global__ __launch_bounds__(256) void k_field_raster(const KlSoA *kls, const in
     // the image once per block
     const unsigned ex = (unsigned)min(FT, w - tx0), ey = (unsigned)min(FT, h - ty0);
     // FSPLIT threads share one KeyLine's in-tile t-range: a bin holds ~170 KeyLines with ranges of 1..2r samples, so
-    // one thread per KeyLine leaves a third of the lanes idle and the rest waiting for the longest range.
-    constexpr int FSPLIT = 4;
+    // one thread per KeyLine leaves lanes idle and the rest waiting for the longest range; every further split pays the
+    // per-part set-up again.
+#ifndef EDGEHIP_FSPLIT
+#define EDGEHIP_FSPLIT 2   // measured at r = 40 after the cheaper tile range: 1: 1296, 2: 1260, 3: 1292, 4: 1310, 8: 1538, 16: 2054 us per 1024 frames
+#endif
+    constexpr int FSPLIT = EDGEHIP_FSPLIT;
     // The hardware rounding differs from round() in a way that matters only for a coordinate of exactly -0.5 (pixel 0
     // instead of -1, ctx.h): that can only be accepted by a tile that starts at column / row 0, so only the tiles on
     // the left / top image border pay for the fix-up.  (Block-uniform choice of one of four loop bodies.)
