@@ -256,11 +256,18 @@ __global__ __launch_bounds__(256) void k_field_bin(const KlSoA *kls, const int32
         tya = max((int)floorf(ya) / FT, 0); tyb = min((int)floorf(yb) / FT, nty - 1);
         if (xb < 0.f || yb < 0.f) txb = -1;
     }
-    // pass A: count per tile (LDS)
+    // pass A: count per tile (LDS).  Which tiles of the bounding box the segment really touches is remembered in a bit mask
+    // for pass B (up to 32 tiles: always at the shipped search ranges, where a segment spans at most 3 x 3)
+    const int bw = txb - txa + 1;
+    const bool cached = bw > 0 && (tyb - tya + 1) * bw <= 32;
+    uint32_t hitmask = 0;
     for (int ty = tya; ty <= tyb; ty++)
         for (int tx = txa; tx <= txb; tx++) {
             int t0, t1;
-            if (tile_trange(r, tx * FT, ty * FT, radius, t0, t1)) atomicAdd(&s_cnt[ty * ntx + tx], 1);
+            if (tile_trange(r, tx * FT, ty * FT, radius, t0, t1)) {
+                atomicAdd(&s_cnt[ty * ntx + tx], 1);
+                if (cached) hitmask |= 1u << ((ty - tya) * bw + (tx - txa));
+            }
         }
     __syncthreads();
     for (int t = tid; t < ntiles; t += 256) {
@@ -273,7 +280,7 @@ __global__ __launch_bounds__(256) void k_field_bin(const KlSoA *kls, const int32
     for (int ty = tya; ty <= tyb; ty++)
         for (int tx = txa; tx <= txb; tx++) {
             int t0, t1;
-            if (tile_trange(r, tx * FT, ty * FT, radius, t0, t1)) {
+            if (cached ? ((hitmask >> ((ty - tya) * bw + (tx - txa))) & 1u) != 0u : tile_trange(r, tx * FT, ty * FT, radius, t0, t1)) {
                 const int t = ty * ntx + tx;
                 const int pos = s_base[t] + atomicAdd(&s_cnt[t], 1);
                 if (pos < bin_cap) bins[((size_t)seq * ntiles + t) * bin_cap + pos] = i;
