@@ -202,26 +202,28 @@ __global__ __launch_bounds__(256) void k_field_tiles(const KlSoA *kls, const int
 constexpr int kMaxTiles = 256;
 
 __device__ __forceinline__ bool tile_trange(const MatchRec &r, int tx0, int ty0, int radius, int &t0, int &t1) {
-    // conservative t-range whose samples round into the tile [tx0,tx0+FT) x [ty0,ty0+FT)
+    // t-range whose samples can round into the tile [tx0,tx0+FT) x [ty0,ty0+FT): pixel x = round(u t + c) is inside iff
+    // u t + c lies in [tx0 - 0.5, tx0 + FT - 0.5]; conservative by 0.01 px (the sample is evaluated in float: < 1e-4 px off)
+    // and by a slack on t that covers the rounding of the bounds (c and the reciprocal: relative 1e-7, amplified by 1/u).
+    // Every sample kept here is still tested against the tile exactly; a sample dropped here must be outside.  Both users —
+    // the binning and the rasteriser — go through this one function.  (v_rcp_f32 + products instead of IEEE divisions.)
     float tlo = (float)(-radius), thi = (float)(radius - 1);
-    const float bx0 = (float)tx0 - 1.f - r.c_px, bx1 = (float)(tx0 + FT) - r.c_px;
-    const float by0 = (float)ty0 - 1.f - r.c_py, by1 = (float)(ty0 + FT) - r.c_py;
-    // (v_rcp_f32 + products instead of IEEE divisions: the range is conservative by a whole sample on either side, and both
-    // users — the binning and the rasteriser — go through this one function)
+    const float bx0 = (float)tx0 - 0.51f - r.c_px, bx1 = (float)(tx0 + FT) - 0.49f - r.c_px;
+    const float by0 = (float)ty0 - 0.51f - r.c_py, by1 = (float)(ty0 + FT) - 0.49f - r.c_py;
     if (fabsf(r.u_mx) > 1e-6f) {
         const float iu = __builtin_amdgcn_rcpf(r.u_mx);
-        const float a = bx0 * iu, b = bx1 * iu;
-        tlo = fmaxf(tlo, fminf(a, b) - 1.f);
-        thi = fminf(thi, fmaxf(a, b) + 1.f);
+        const float a = bx0 * iu, b = bx1 * iu, sl = 0.25f + 1e-4f * fabsf(iu);
+        tlo = fmaxf(tlo, fminf(a, b) - sl);
+        thi = fminf(thi, fmaxf(a, b) + sl);
     } else if (bx0 > 0.f || bx1 < 0.f) return false;
     if (fabsf(r.u_my) > 1e-6f) {
         const float iu = __builtin_amdgcn_rcpf(r.u_my);
-        const float a = by0 * iu, b = by1 * iu;
-        tlo = fmaxf(tlo, fminf(a, b) - 1.f);
-        thi = fminf(thi, fmaxf(a, b) + 1.f);
+        const float a = by0 * iu, b = by1 * iu, sl = 0.25f + 1e-4f * fabsf(iu);
+        tlo = fmaxf(tlo, fminf(a, b) - sl);
+        thi = fminf(thi, fmaxf(a, b) + sl);
     } else if (by0 > 0.f || by1 < 0.f) return false;
-    t0 = max((int)floorf(tlo), -radius);
-    t1 = min((int)ceilf(thi), radius - 1);
+    t0 = max((int)ceilf(tlo), -radius);
+    t1 = min((int)floorf(thi), radius - 1);
     return t0 <= t1;
 }
 
