@@ -453,6 +453,7 @@ int edgehip_imu_enable(edgehip_ctx *c, const edgehip_imu_params *imu) {
     c->imu_params = *imu;
     c->imu_enabled = true;
     c->imu_pending = false;
+    c->imu_post_valid[0] = c->imu_post_valid[1] = false;
     drop_frame_graphs(c);
     c->use_graph = false;   // the IMU stream runs past the end of a frame: that is not a capturable fork/join
     hipLaunchKernelGGL(k_imu_init, dim3((unsigned)((B + 63) / 64)), dim3(64), 0, c->stream, (ImuTrackDev *)c->imu_track,
