@@ -45,7 +45,9 @@ struct FusedArgs {
     int kl_ref, kl_max;
     float dog_thresh_f;        // (float)DetectorDoGThresh
     double pn_thresh;          // (double)(25.0f * (float)DetectorPosNegThresh)
-    double pc0[5], pc1[5], pc2;   // plane-fit pseudo inverse: row 0 by window column, row 1 by window row, row 2 constant
+    const double *pinv;           // [3][25] plane-fit pseudo inverse (device): row 0 depends on the window column only, row 1 on the
+                                  // window row, row 2 is constant (checked at create) — read with scalar loads where it is used,
+                                  // not carried in 22 scalar registers through the whole kernel
     float ppx, ppy;
     int ablate;                // timing experiments (EXPERIMENTS builds only)
 };

@@ -104,6 +104,11 @@ __device__ __forceinline__ v2f ring_row_general(TapRing<L> &H, int P, v2f vr, v2
 struct FitOut { bool cand; float mx, my, xs, ys; };
 __device__ __forceinline__ FitOut plane_fit5(const float *s_dog, const int ro[5], int x, const FusedArgs &a, float thr_d) {
     double t0 = 0, t1 = 0, t2 = 0;
+    const double *__restrict__ pinv = a.pinv;
+    double pc0[5], pc1[5];
+#pragma unroll
+    for (int j = 0; j < 5; j++) { pc0[j] = pinv[j]; pc1[j] = pinv[25 + 5 * j]; }
+    const double pc2 = pinv[50];
 #pragma unroll
     for (int i = 0; i < 5; i++) {
         float v[5];                                     // one window row at a time: 25 values in flight cost too many registers
@@ -112,9 +117,9 @@ __device__ __forceinline__ FitOut plane_fit5(const float *s_dog, const int ro[5]
 #pragma unroll
         for (int j = 0; j < 5; j++) {
             const double yv = (double)v[j];
-            t0 += a.pc0[j] * yv;
-            t1 += a.pc1[i] * yv;
-            t2 += a.pc2 * yv;
+            t0 += pc0[j] * yv;
+            t1 += pc1[i] * yv;
+            t2 += pc2 * yv;
         }
         __builtin_amdgcn_sched_barrier(0);
     }
@@ -742,8 +747,7 @@ int stage_a_fused_enqueue(edgehip_ctx *c, int slot, const uint8_t *rgb_base, con
     a.dog_thresh_f = (float)c->p.dog_thresh;
     const int ws = c->p.plane_fit_size;
     a.pn_thresh = (double)(((float)((2.0 * ws + 1.0) * (2.0 * ws + 1.0))) * (float)c->p.pos_neg_thresh);
-    for (int j = 0; j < 5; j++) { a.pc0[j] = c->pinv_host[j]; a.pc1[j] = c->pinv_host[25 + 5 * j]; }
-    a.pc2 = c->pinv_host[50];
+    a.pinv = c->pinv;
     a.ppx = c->slot_cam[slot].ppx; a.ppy = c->slot_cam[slot].ppy;
 #ifdef EDGEHIP_EXPERIMENTS
     a.ablate = getenv("EDGEHIP_FUSED_ABLATE") ? atoi(getenv("EDGEHIP_FUSED_ABLATE")) : 0;
