@@ -180,7 +180,7 @@ __global__ __launch_bounds__(512) void k_stage_a_fused(FusedArgs a) {
 
     // ---- set-up -------------------------------------------------------------------------------------------------------
     for (int i = tid; i < 2 * 4 * RB * PAD; i += blockDim.x) s_set[(size_t)(i / PAD) * WP + (i % PAD)] = 0.f;   // left pads: taps left of column 0
-    for (int i = tid; i < kDivLutMax; i += blockDim.x) s_lut[i] = a.lut[i];
+    for (int i = tid; i < kDivLutMax - 2; i += blockDim.x) s_lut[i] = a.lut[i];   // (indices reach 15 * 15; the last two entries carry the threshold, below)
     for (int i = tid; i < NW * RB * 128; i += blockDim.x) s_res[i] = 0;
     for (int i = tid; i < RB * NW; i += blockDim.x) s_cnt[i] = 0;
     for (int i = tid; i < 256; i += blockDim.x) a.histo[(size_t)seq * 256 + i] = 0;   // reEstimateThresh's histogram (k_join_histo fills it)
@@ -191,6 +191,9 @@ __global__ __launch_bounds__(512) void k_stage_a_fused(FusedArgs a) {
     float thr_g, thr_d;
     {
         const double tresh = update_thresh(sq->tresh, sq->l_kl_num, a.kl_ref, a.gain, a.tmax, a.tmin);
+        // kept in two unused entries of the reciprocal table for the end of the frame: the controller's constants then need
+        // no scalar registers through the frame loop
+        if (tid == 0) { s_lut[kDivLutMax - 2] = __int_as_float(__double2loint(tresh)); s_lut[kDivLutMax - 1] = __int_as_float(__double2hiint(tresh)); }
         const float grad_thresh = (float)tresh;                     // build_mask takes float grad_thesh
         const float gt1 = grad_thresh * 765;                        // grad_thesh*max_img_value
         const float gt2 = gt1 * a.dog_thresh_f;
@@ -691,7 +694,7 @@ __global__ __launch_bounds__(512) void k_stage_a_fused(FusedArgs a) {
         for (int i = 1; i < NW; i++) { nm_mx = fmaxf(nm_mx, s_red[i]); nm_mn = fminf(nm_mn, s_red[NW + i]); }
         const int total = __float_as_int(s_red[2 * NW]);
         const int kn = total < a.kl_max ? total : a.kl_max;
-        const double tresh = update_thresh(sq->tresh, sq->l_kl_num, a.kl_ref, a.gain, a.tmax, a.tmin);   // as at the top: nothing wrote the state in between
+        const double tresh = __hiloint2double(__float_as_int(s_lut[kDivLutMax - 1]), __float_as_int(s_lut[kDivLutMax - 2]));   // update_thresh, computed at the top
         sq->tresh = tresh;
         sq->tresh_used = tresh;
         a.tresh_out[seq] = tresh;
