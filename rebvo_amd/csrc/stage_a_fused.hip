@@ -162,7 +162,10 @@ __global__ __launch_bounds__(512) void k_stage_a_fused(FusedArgs a) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int w = W ? W : a.w, h = a.h;
     const int WP = fused_row_stride(w);
-    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    const int tid = threadIdx.x, lane = tid & 63;
+    // wave-uniform by construction; telling the compiler so moves everything derived from it (list / result pointers, clipping
+    // flags, column offsets of the wave) from vector to scalar registers
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int NW = (blockDim.x >> 6) - 1;               // column waves (128 columns each)
     const int seq = blockIdx.x;
     const size_t so = (size_t)seq * a.n;
