@@ -4,15 +4,15 @@
 #   tools/experiments/exp_fused_ablate.sh build
 # then on the GPU box:  tools/experiments/exp_fused_ablate.sh [nseq]
 # bits: 1 scan, 2 box chain, 4 window tests, 8 KeyLine emit + mask rows, 16 RGB loads, 32 gradient gate + sign balance
-VARIANTS="0 1 4 8 12 32 63 62"
+VARIANTS=${VARIANTS:-"0 1 4 8 12 32 63 62"}
 ROOT=$(cd "$(dirname "$0")/../.." && pwd)
 if [ "$1" = build ]; then
   mkdir -p $ROOT/tools/experiments/bin
   for A in $VARIANTS; do
-    ( cd $ROOT/rebvo_amd/csrc && /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=off -I../../include -I. \
+    ( cd $ROOT/rebvo_amd/csrc && /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=off -I../../include -I. -I../host/include \
         -DEDGEHIP_FUSED_ABL=$A -c stage_a_fused.hip -o /tmp/fused_abl$A.o && \
       /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o $ROOT/tools/experiments/bin/libedgehip_abl$A.so \
-        ../lib/obj/api.o ../lib/obj/stage_a.o /tmp/fused_abl$A.o ../lib/obj/stage_b.o ../lib/obj/stage_c.o ) &
+        $(ls ../lib/obj/*.o | grep -v stage_a_fused.o) /tmp/fused_abl$A.o ) &
   done
   wait; ls -la $ROOT/tools/experiments/bin/ | grep abl; exit 0
 fi
