@@ -215,85 +215,95 @@ __global__ __launch_bounds__(512) void k_stage_a_fused(FusedArgs a) {
     const int scan_wave = NW >= 3 ? 3 : NW;
     if (wave == scan_wave) {
         // ---- the scan wave: the serial left-to-right prefix of iimage::load (iimage.cpp:56-61) for the 4 RB rows of the buffer
-        // set (plane-major, RB rows per plane), in place.  An LDS instruction costs the wave ~16 cycles of register-file time
-        // whatever the number of active lanes, a dependent add ~7 (tools/experiments/ubench_scan.hip), so all 64 lanes carry
-        // data: the four lanes of a quad share a row, lane q of the quad holds floats 4q..4q+3 of the row's current 16-float
-        // step (one ds_read_b128 per step and wave instead of four).  Every lane of the quad runs the same add chain, taking
-        // the operand from the lane that holds it (DPP quad_perm broadcast, folded into the add), and keeps the four sums
-        // that belong to its own floats.  After the last step the row's total goes into the right pad (taps right of w-1).
+        // set (plane-major, RB rows per plane), in place.  The adds of a row are one dependent chain (~7 cycles each,
+        // tools/experiments/ubench_scan.hip) and an LDS instruction costs the wave ~16 cycles of issue whatever the number of
+        // active lanes, so all 64 lanes carry data: the four lanes of a quad share a row and every lane owns one 16-float chunk
+        // of the row's current 64-float step (four ds_read_b128 per step and wave).  The chunks are chained in time, not in
+        // space: the quad's lanes take turns (exec mask), lane p runs its 16 plain adds from the carry lane p-1 left, then its
+        // total is broadcast to the quad (one DPP move) as the carry of lane p+1.  Per element: one add on the chain and nothing
+        // else (the earlier form — every lane running the whole chain and selecting its four sums — spent 28 vector
+        // instructions per 16 floats, 13-15 cycles per element; this one is bound by the chain).  After the last chunk the
+        // row's total goes into the right pad (taps right of w-1).
         __builtin_amdgcn_s_setprio(3);
         static_assert(4 * RB <= 16, "one quad per row");
-        const int n16 = w >> 4;                 // 16-float steps
-        const int half16 = n16 >> 1;
+        const int n16 = w >> 4;                 // full 16-float chunks
+        const int rem4 = (w & 15) >> 2;         // float4s of the last, partial chunk (w % 4 == 0)
+        const int nch = n16 + (rem4 ? 1 : 0);   // chunks per row
+        const int nss = (nch + 3) >> 2;         // 64-float steps
+        const int half_ss = nss >> 1;
         const int srow = lane >> 2, sq = lane & 3;
         const bool on = srow < 4 * RB && !(ABL & 1);
-        const bool q0 = sq == 0, q1 = sq == 1, q2 = sq == 2;
+#define EH_BC(val, k) __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(val), (k) * 0x55, 0xf, 0xf, false))
         for (int t = 0; t < nticks; t++) {
             float *row = s_set + ((size_t)((t + 1) & 1) * 4 * RB + (srow < 4 * RB ? srow : 0)) * WP + PAD;
             float acc = 0.f;
-            float4 cur, nxt;
-            if (on) cur = *reinterpret_cast<float4 *>(row + 4 * sq);
-            // one 16-float step on `v` (read one step earlier); the next step's read is issued first
-#define EH_BC(val, k) __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(val), (k) * 0x55, 0xf, 0xf, false))
-            auto step = [&](float4 &v, float4 &nx, int c) __attribute__((always_inline)) {
-                nx = *reinterpret_cast<float4 *>(row + (c + 1) * 16 + 4 * sq);   // overrun past the row: pad / next row, never used
-                float4 o;
-                float s;
-                // img(x,y) = img(x-1,y) + l(x,y): floats 0..3 sit in lane 0 of the quad, 4..7 in lane 1, ...
-                s = acc = acc + EH_BC(v.x, 0); o.x = s;
-                s = acc = acc + EH_BC(v.y, 0); o.y = s;
-                s = acc = acc + EH_BC(v.z, 0); o.z = s;
-                s = acc = acc + EH_BC(v.w, 0); o.w = s;
-                s = acc = acc + EH_BC(v.x, 1); o.x = q0 ? o.x : s;
-                s = acc = acc + EH_BC(v.y, 1); o.y = q0 ? o.y : s;
-                s = acc = acc + EH_BC(v.z, 1); o.z = q0 ? o.z : s;
-                s = acc = acc + EH_BC(v.w, 1); o.w = q0 ? o.w : s;
-                s = acc = acc + EH_BC(v.x, 2); o.x = (q0 || q1) ? o.x : s;
-                s = acc = acc + EH_BC(v.y, 2); o.y = (q0 || q1) ? o.y : s;
-                s = acc = acc + EH_BC(v.z, 2); o.z = (q0 || q1) ? o.z : s;
-                s = acc = acc + EH_BC(v.w, 2); o.w = (q0 || q1) ? o.w : s;
-                s = acc = acc + EH_BC(v.x, 3); o.x = (q0 || q1 || q2) ? o.x : s;
-                s = acc = acc + EH_BC(v.y, 3); o.y = (q0 || q1 || q2) ? o.y : s;
-                s = acc = acc + EH_BC(v.z, 3); o.z = (q0 || q1 || q2) ? o.z : s;
-                s = acc = acc + EH_BC(v.w, 3); o.w = (q0 || q1 || q2) ? o.w : s;
-                *reinterpret_cast<float4 *>(row + c * 16 + 4 * sq) = o;
+            float4 cur[4], nxt[4];
+            // chunk c of the row lives at row + 16 c; reads past the row's end fetch pad / the next row and are never used
+            auto load = [&](float4 (&v)[4], int ss) __attribute__((always_inline)) {
+                const float *p = row + (4 * ss + sq) * 16;
+#pragma unroll
+                for (int i = 0; i < 4; i++) v[i] = *reinterpret_cast<const float4 *>(p + 4 * i);
             };
-            auto steps16 = [&](int c0, int c1) __attribute__((always_inline)) {   // ends with the next step's data in `cur`
-                if (!on) return;
-                int c = c0;
-                for (; c + 1 < c1; c += 2) {
-                    step(cur, nxt, c);
-                    step(nxt, cur, c + 1);
-                }
-                if (c < c1) {
-                    step(cur, nxt, c);
-                    cur = nxt;
-                }
-            };
-            steps16(0, half16);
-            lds_barrier();
-            steps16(half16, n16);
-            if (on) {
-                const int rem4 = (w & 15) >> 2;   // w % 16 != 0: a last step of rem4 < 4 float4s (lanes q < rem4 hold data)
-                if (rem4) {
-                    float4 o = cur;
-                    float s;
-#define EH_TAIL(k)                                                                  \
-    if ((k) < rem4) {                                                               \
-        s = acc = acc + EH_BC(cur.x, k); o.x = sq == (k) ? s : o.x;                 \
-        s = acc = acc + EH_BC(cur.y, k); o.y = sq == (k) ? s : o.y;                 \
-        s = acc = acc + EH_BC(cur.z, k); o.z = sq == (k) ? s : o.z;                 \
-        s = acc = acc + EH_BC(cur.w, k); o.w = sq == (k) ? s : o.w;                 \
+            // one 64-float step on `v` (read one step earlier); the next step's reads are issued first
+            auto step = [&](float4 (&v)[4], float4 (&nx)[4], int ss) __attribute__((always_inline)) {
+                load(nx, ss + 1);
+// the chain runs through the elements' own registers (x' = carry + x, y' = x' + y, ...): one instruction per element
+#define EH_ADDC(DST, PREV) asm volatile("v_add_f32 %0, %1, %0" : "+v"(DST) : "v"(PREV));
+#define EH_ADD4(I, CARRY) EH_ADDC(v[I].x, CARRY) EH_ADDC(v[I].y, v[I].x) EH_ADDC(v[I].z, v[I].y) EH_ADDC(v[I].w, v[I].z)
+#define EH_PHASE(P)                                                                                  \
+    {                                                                                                \
+        const int c = 4 * ss + (P);               /* wave-uniform */                                 \
+        float tot = acc;                                                                             \
+        if (c < n16) {                                                                               \
+            if (sq == (P)) { EH_ADD4(0, acc) EH_ADD4(1, v[0].w) EH_ADD4(2, v[1].w) EH_ADD4(3, v[2].w) } \
+            tot = v[3].w;                         /* lane P's: the other lanes' is never looked at */ \
+        } else if (c == n16 && rem4) {                                                               \
+            if (sq == (P)) {                                                                         \
+                if (0 < rem4) { EH_ADD4(0, acc) }                                                    \
+                if (1 < rem4) { EH_ADD4(1, v[0].w) }                                                 \
+                if (2 < rem4) { EH_ADD4(2, v[1].w) }                                                 \
+            }                                                                                        \
+            tot = rem4 == 1 ? v[0].w : (rem4 == 2 ? v[1].w : v[2].w);                                \
+        }                                                                                            \
+        acc = EH_BC(tot, P);                      /* the running total so far: lane P's, for the whole quad */ \
     }
-                    EH_TAIL(0) EH_TAIL(1) EH_TAIL(2)
-#undef EH_TAIL
-                    if (sq < rem4) *reinterpret_cast<float4 *>(row + n16 * 16 + 4 * sq) = o;
+                EH_PHASE(0) EH_PHASE(1) EH_PHASE(2) EH_PHASE(3)
+#undef EH_PHASE
+#undef EH_ADD4
+#undef EH_ADDC
+                // store the chunk (all of it, or the float4s the row still has)
+                const int c = 4 * ss + sq;
+                float *q = row + c * 16;
+                if (c < n16) {
+#pragma unroll
+                    for (int i = 0; i < 4; i++) *reinterpret_cast<float4 *>(q + 4 * i) = v[i];
+                } else if (c == n16) {
+#pragma unroll
+                    for (int i = 0; i < 3; i++)
+                        if (i < rem4) *reinterpret_cast<float4 *>(q + 4 * i) = v[i];
                 }
-                if (sq == 3) *reinterpret_cast<float4 *>(row + w) = make_float4(acc, acc, acc, acc);
-            }
-#undef EH_BC
+            };
+            auto steps64 = [&](int s0, int s1) __attribute__((always_inline)) {   // ends with the next step's data in `cur`
+                if (!on) return;
+                int ss = s0;
+                for (; ss + 1 < s1; ss += 2) {
+                    step(cur, nxt, ss);
+                    step(nxt, cur, ss + 1);
+                }
+                if (ss < s1) {
+                    step(cur, nxt, ss);
+#pragma unroll
+                    for (int i = 0; i < 4; i++) cur[i] = nxt[i];
+                }
+            };
+            if (on) load(cur, 0);
+            steps64(0, half_ss);
+            lds_barrier();
+            steps64(half_ss, nss);
+            if (on && sq == 3) *reinterpret_cast<float4 *>(row + w) = make_float4(acc, acc, acc, acc);
             lds_barrier();
         }
+#undef EH_BC
     } else {
     // ---- column waves ---------------------------------------------------------------------------------------------------
     const int wv = wave < scan_wave ? wave : wave - 1;   // 0..NW-1
