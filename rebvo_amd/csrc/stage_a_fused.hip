@@ -401,20 +401,25 @@ __global__ __launch_bounds__(512) void k_stage_a_fused(FusedArgs a) {
             const int ytest0 = (t - 7) * RB - LB - 2;           // first row tested in tick t-1
             if (ytest0 + RB - 1 >= 0 && ytest0 < h && !(ABL & 8)) {
                 // ids: running total + exclusive prefix of the (row, wave) segment counts in raster order.  The counts are few
-                // (RB * NW <= 64, one per lane) and the prefix is wave-uniform: read them lane by lane into scalar registers
-                // (v_readlane) instead of a shuffle scan through the LDS crossbar, whose steps each cost an LDS round trip.
+                // (RB * NW <= 64, one per lane): a DPP scan over the lanes (six vector instructions, no LDS round trips), then
+                // the wave's own RB offsets and counts come out as scalars (v_readlane at lane row * NW + wave).
                 const int nseg = RB * NW;
                 const int c = lane < nseg ? s_cnt[lane] : 0;
+                int inc = c;
+                inc += __builtin_amdgcn_update_dpp(0, inc, 0x111, 0xf, 0xf, true);    // row_shr:1, zeros shifted in
+                inc += __builtin_amdgcn_update_dpp(0, inc, 0x112, 0xf, 0xf, true);    // row_shr:2
+                inc += __builtin_amdgcn_update_dpp(0, inc, 0x114, 0xf, 0xf, true);    // row_shr:4
+                inc += __builtin_amdgcn_update_dpp(0, inc, 0x118, 0xf, 0xf, true);    // row_shr:8  -> inclusive scan inside each row of 16
+                inc += __builtin_amdgcn_update_dpp(0, inc, 0x142, 0xa, 0xf, false);   // row_bcast:15 into rows 1 and 3
+                inc += __builtin_amdgcn_update_dpp(0, inc, 0x143, 0xc, 0xf, false);   // row_bcast:31 into rows 2 and 3
+                const int exc = inc - c;
                 int offs[RB], myc[RB];
-                int run = 0;
 #pragma unroll
                 for (int i = 0; i < RB; i++) {
-                    for (int g = 0; g < NW; g++) {
-                        const int cg = __builtin_amdgcn_readlane(c, i * NW + g);
-                        if (g == wv) { offs[i] = run; myc[i] = cg; }
-                        run += cg;
-                    }
+                    offs[i] = __builtin_amdgcn_readlane(exc, i * NW + wv);
+                    myc[i] = __builtin_amdgcn_readlane(c, i * NW + wv);
                 }
+                const int run = __builtin_amdgcn_readlane(inc, nseg - 1);
                 const int tick_total = run;
                 for (int base = 0; base < nfinal; base += 64) {
                     const int e = base + lane;
