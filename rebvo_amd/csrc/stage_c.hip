@@ -24,6 +24,7 @@
 #include <vector>
 
 #include "ctx.h"
+#include "wave_reduce.h"
 
 namespace edgehip {
 
@@ -675,13 +676,10 @@ __global__ __launch_bounds__(256) void k_ext_rotvel(const KlSoA *kls, const int3
         for (int a = 0; a < 6; a++) sums[ns++] = row[a] * y;
         sums[ns++] = used;
     }
-    __shared__ double s_red[4][kNumSums];
-#pragma unroll
-    for (int k = 0; k < kNumSums; k++) {
-        double v = sums[k];
-#pragma unroll
-        for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
-        if (lane == 0) s_red[wave][k] = v;
+    __shared__ double s_red[4][32];
+    {
+        const int idx = wave_reduce28(sums, lane);   // the xor butterfly's pairs and order, a sixth of its shuffles
+        if ((lane & 1) == 0) s_red[wave][idx] = sums[0];
     }
     __syncthreads();
     if (threadIdx.x < kNumSums)
