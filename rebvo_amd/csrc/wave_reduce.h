@@ -6,12 +6,16 @@
 namespace edgehip {
 
 // ---------------------------------------------------------------------------------------------------
-// Sum 28 per-lane values across the 64 lanes of a wave with 29 double shuffles instead of 28*6: at every
-// butterfly step a lane keeps one half of its values and hands the other half to its partner, so the
-// number of live values halves (28 -> 14 -> 7 -> 4 -> 2 -> 1) while the partial sums double in coverage.
-// On return v[0] of lane l is the full sum of value
+// Sum 28 per-lane values across the 64 lanes of a wave in 29 pair exchanges instead of 28 * 6: at every butterfly step a
+// lane keeps one half of its values and hands the other half to its partner, so the number of live values halves
+// (28 -> 14 -> 7 -> 4 -> 2 -> 1) while the partial sums double in coverage.  The pairs and their order are those of the plain
+// xor butterfly (lane ^ 32, 16, 8, 4, 2, 1), so the sums are the butterfly's bit for bit.  On return v[0] of lane l is the
+// full sum of value
 //     idx = b1 + 2*b2 + 4*b3 + 7*b4 + 14*b5      (b_k = bit k of l; lanes with b1+2*b2+4*b3 == 7 hold padding)
 // and lanes l, l^1 hold the same value.  Fixed order => bit-reproducible from run to run.
+// The exchanges themselves: v_permlane32_swap / v_permlane16_swap (gfx950) for the two big steps, DPP moves for lane ^ 8, 2, 1,
+// ds_bpermute only for lane ^ 4 — a shuffle through the LDS crossbar costs an LDS instruction each way and was most of the
+// reduction's time when every step used it.
 // ---------------------------------------------------------------------------------------------------
 template <int N>
 __device__ __forceinline__ void halve_step(double *v, int lane, int off) {
