@@ -115,10 +115,13 @@ __device__ __forceinline__ FitOut plane_fit5(const float *s_dog, const int ro[5]
 #pragma unroll
         for (int j = 0; j < 5; j++) v[j] = s_dog[ro[i] + x + j - 2];
 #pragma unroll
+        // The middle column of row 0 and the middle row of row 1 are exactly zero (fused_supported checks it): a product with
+        // them is +-0, and adding that changes nothing — a partial sum is never -0 (it starts at +0, and x + (-x) = +0) — so those
+        // ten terms are skipped; the sums keep their bits.
         for (int j = 0; j < 5; j++) {
             const double yv = (double)v[j];
-            t0 += pc0[j] * yv;
-            t1 += pc1[i] * yv;
+            if (j != 2) t0 += pc0[j] * yv;
+            if (i != 2) t1 += pc1[i] * yv;
             t2 += pc2 * yv;
         }
         __builtin_amdgcn_sched_barrier(0);
@@ -740,6 +743,7 @@ bool fused_supported(const edgehip_ctx *c) {
     if (pl.box[0][0] != 3 || pl.box[0][1] != 3 || pl.box[0][2] != 5) return false;
     if (pl.box[1][0] != 3 || pl.box[1][1] != 5 || pl.box[1][2] != 5) return false;
     if (c->p.plane_fit_size != 2) return false;
+    if (c->pinv_host[2] != 0.0 || c->pinv_host[25 + 10] != 0.0) return false;   // plane_fit5 skips these terms
     const int nw = fused_col_waves(pl.w);
     if (nw + 1 > 8) return false;                           // 256 VGPRs per thread need <= 8 waves per workgroup
     if (kFusedRB * nw > 64) return false;                   // one lane per (row, wave) segment in the id scan
