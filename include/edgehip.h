@@ -210,6 +210,12 @@ int edgehip_download_resid(edgehip_ctx *ctx, int which, double *resid);
  * whole Levenberg-Marquardt loop runs on the device (evaluate kernels + a one-wave solve kernel between
  * them, no host round trip).  Reads seq_state.V/W/s_rho_q, writes V, W, P_V, P_W, score, rel_error*. */
 int edgehip_minimizer_rv(edgehip_ctx *ctx, int slot_new, int slot_old);
+/* The 6x6 solve between two evaluations, n independent systems (A [n][36] row-major, b [n][6], h [n][6], host pointers):
+ * svd_rule = 0: h = TooN::Cholesky<6>(A).backsub(b) (global_tracker.cpp:767-768); svd_rule = 1: h = TooN::SVD<>(A).backsub(b) with
+ * its condition_no = 1e9 cut-off (global_tracker.cpp:660-661, 711-712; TooN/SVD.h:37, 179).  Exposed so that the parity tests can
+ * feed the device ill-conditioned systems on either side of the cut-off; edgehip_minimizer_rv runs the same device function.
+ * Synchronises. */
+int edgehip_lm_solve(edgehip_ctx *ctx, const double *A, const double *b, int n, int svd_rule, double *h);
 
 /* kfvo::Minimizer_RV_KF<double,false> with kfvo::TryVelRot<double,true,true,false> and global_tracker::Calc_f_J_Complete
  * (src/mtracklib/kfvo.cpp:1679-1825, 1389-1668; global_tracker.cpp:116-165) — the key-frame tracker of SURVEY section 8 row

@@ -147,6 +147,48 @@ class Nav(C.Structure):
 _LIBS = {"ref": os.path.join(HERE, "_ref", "libreforacle.so"), "port": os.path.join(HERE, "libedgeport.so")}
 
 
+class SeqState(C.Structure):
+    """OrcSeqState (oracle_abi.h): the locals of FirstThr / SecondThread that persist from frame to frame."""
+    _fields_ = [("tresh", C.c_double), ("t_prev", C.c_double), ("Kp", C.c_double), ("K", C.c_double), ("P_Kp", C.c_double),
+                ("V", C.c_double * 3), ("W", C.c_double * 3), ("Pos", C.c_double * 3), ("Pose", C.c_double * 9),
+                ("l_kl_num", C.c_int32), ("frame", C.c_int32)]
+
+
+def half_pixel_keylines(old_kl, field_ikl, ppx, ppy, s_rho_q, w, h):
+    """KeyLines of the OLD edge map whose first evaluation in Minimizer_RV is decided by rounding noise.
+
+    init_type 2 always evaluates TryVelRot at X = 0 first (global_tracker.cpp:650-651).  There the re-projected position is
+    p_m * z / zf * zf / z = p_m up to a few ulp (ne10wrapper.h:414-424, 433-447), Hom2Img adds the principal point — a *float*
+    (cam_model.h:45) — and round2int_positive picks the pixel (global_tracker.cpp:363-364).  A KeyLine detected exactly on a
+    half pixel (c_p = n + 0.5: the plane fit's sub-pixel offset is +-0.5, accepted by edge_finder.cpp:146-150) has
+    p_m = c_p - pp exactly, so p_m + pp lands exactly on n + 0.5 again and the ulp of noise — which depends on the last bits of
+    rho — picks n or n + 1.  When the field holds different KeyLines at the two pixels, the reference's own result for the
+    frame depends on those bits: any two implementations whose poses differ in the 16th digit may disagree by one match
+    (measured: |dV| ~ 1e-6 on that frame, after which discrete match decisions differ and the trajectories drift apart).
+
+    old_kl: KeyLine records BEFORE the frame is processed; field_ikl: [h, w] KeyLine index plane of the NEW frame's field
+    (-1 = empty); s_rho_q: the frame's EstimateQuantile gate.  Returns [(ikl, sorted field entries at the candidate pixels)].
+    """
+    if len(old_kl) == 0:
+        return []
+    fx, fy = float(np.float32(ppx)), float(np.float32(ppy))
+    px = old_kl["p_m"][:, 0].astype(np.float64) + fx
+    py = old_kl["p_m"][:, 1].astype(np.float64) + fy
+    hx = (px + 0.5) == np.floor(px + 0.5)
+    hy = (py + 0.5) == np.floor(py + 0.5)
+    out = []
+    for i in np.where((old_kl["s_rho"] <= s_rho_q) & (hx | hy))[0]:
+        xs = [int(px[i] + 0.5)] + ([int(px[i] + 0.5) - 1] if hx[i] else [])
+        ys = [int(py[i] + 0.5)] + ([int(py[i] + 0.5) - 1] if hy[i] else [])
+        vals = {int(field_ikl[y, x]) if (1 <= x < w - 1 and 1 <= y < h - 1) else -2 for x in xs for y in ys}
+        if len(vals) > 1:
+            out.append((int(i), sorted(vals)))
+    return out
+
+
+SVD_REC = np.dtype([("rows", np.int32), ("cols", np.int32), ("A", np.float64, (6, 6)), ("s", np.float64, 6)])
+
+
 def available(kind):
     return os.path.exists(_LIBS[kind])
 
@@ -206,7 +248,45 @@ class Oracle:
         self._minimizer_rv_kf = fn("minimizer_rv_kf", d, vp, i, i, pd, d, d, d, d, i, d, d, u, pd, pi) if kind == "ref" else None
         self._reset = fn("reset_sequence", None, vp)
         self._depth_reset = fn("depth_reset", None, vp)
+        self._svd_trace = fn("svd_trace", None, C.c_void_p, i)
+        self._svd_trace_count = fn("svd_trace_count", i)
+        self._svd_buf = None
         self.ctx = self._create(C.byref(params), nslots)
+
+    # ---- parity diagnostics: the 6x6 decompositions of Minimizer_RV's init phase ------------------------
+    def svd_trace_start(self, cap=64):
+        """Record the next `cap` decompositions the minimiser asks for (process-wide per oracle library)."""
+        self._svd_buf = np.zeros(cap, dtype=SVD_REC)
+        self._svd_trace(self._svd_buf.ctypes.data, cap)
+
+    def svd_trace_stop(self):
+        """-> structured array (rows, cols, A[6,6], s[6]) in call order."""
+        n = self._svd_trace_count()
+        self._svd_trace(None, 0)
+        out, self._svd_buf = self._svd_buf[:n].copy(), None
+        return out
+
+    def seq_state(self):
+        f = getattr(self.lib, f"{self.kind}_get_seq_state")
+        f.restype, f.argtypes = None, [C.c_void_p, C.POINTER(SeqState)]
+        st = SeqState()
+        f(self.ctx, C.byref(st))
+        return st
+
+    def svd_backsub(self, A, b, chol=False):
+        """(_ref only) TooN::SVD<>(A).backsub(b) / TooN::Cholesky<6>(A).backsub(b) as Minimizer_RV calls them."""
+        f = self.lib.ref_chol_backsub if chol else self.lib.ref_svd_backsub
+        pd = C.POINTER(C.c_double)
+        f.restype, f.argtypes = None, [pd, pd, pd]
+        A, b, hh = np.ascontiguousarray(A, dtype=np.float64), np.ascontiguousarray(b, dtype=np.float64), np.zeros(6)
+        f(_dp(A), _dp(b), _dp(hh))
+        return hh
+
+    def svd_backend(self, which):
+        """(_ref only) 0 = LAPACK dgesvd_ (MKL), 1 = the harness's one-sided Jacobi; returns the previous one."""
+        f = self.lib.ref_svd_backend
+        f.restype, f.argtypes = C.c_int, [C.c_int]
+        return f(which)
 
     def close(self):
         if self.ctx:

@@ -72,6 +72,22 @@ typedef struct OrcNav {
     int32_t pad0;
 } OrcNav;
 
+/* One 6x6 (or smaller) decomposition the minimiser asked for, in call order (parity diagnostics: the systems of
+ * Minimizer_RV's init phase, global_tracker.cpp:659-661, 710-712, and their singular values as the back end returned them). */
+typedef struct OrcSvdRec {
+    int32_t rows, cols;
+    double A[36];   /* row-major, leading dimension 6 */
+    double s[6];    /* ref: singular values, descending; port: eigenvalues in Jacobi order (symmetric input) */
+} OrcSvdRec;
+
+/* The FirstThr / SecondThread locals that persist from frame to frame (rebvo_first_t.cpp:92-94, rebvo_second_t.cpp:54-66):
+ * what a teacher-forced replay hands to the path under test before every frame. */
+typedef struct OrcSeqState {
+    double tresh, t_prev, Kp, K, P_Kp;
+    double V[3], W[3], Pos[3], Pose[9];
+    int32_t l_kl_num, frame;
+} OrcSeqState;
+
 #define ORC_DECLARE(P)                                                                                   \
     void *P##_create(const OrcParams *p, int nslots);                                                    \
     void P##_destroy(void *ctx);                                                                         \
@@ -125,10 +141,21 @@ typedef struct OrcNav {
     int P##_cur_slot(void *ctx);                                                                         \
     /* REBVO::Reset() as SecondThread runs it after a frame (rebvo_second_t.cpp:609-620) */              \
     void P##_depth_reset(void *ctx);                                                                     \
-    void P##_reset_sequence(void *ctx);
+    void P##_reset_sequence(void *ctx);                                                                  \
+    void P##_get_seq_state(void *ctx, OrcSeqState *out);                                                 \
+    /* record the next `cap` decompositions into buf (NULL stops); process-wide, not thread-safe */     \
+    void P##_svd_trace(OrcSvdRec *buf, int cap);                                                         \
+    int P##_svd_trace_count(void);
 
 ORC_DECLARE(ref)
 ORC_DECLARE(port)
+
+/* (_ref only) the two 6x6 solves of Minimizer_RV exactly as it spells them: h = TooN::SVD<>(A).backsub(b)
+ * (global_tracker.cpp:660-661; condition_no = 1e9, TooN/SVD.h:37,179) and h = TooN::Cholesky<6>(A).backsub(b) (:767-768). */
+void ref_svd_backsub(const double A[36], const double b[6], double h[6]);
+void ref_chol_backsub(const double A[36], const double b[6], double h[6]);
+/* (_ref only) which dgesvd_ serves TooN::SVD<>: 0 = LAPACK (MKL), 1 = the harness's one-sided Jacobi.  Returns the old one. */
+int ref_svd_backend(int which);
 
 /* ---- key-frame tracker: reference only.  kfvo::Minimizer_RV_KF<double,false> (kfvo.cpp:1679-1825),
  * called directly with the arguments kfvo::OptimizePosGT passes (kfvo.cpp:74): gt = slot_kf's global_tracker (its field as

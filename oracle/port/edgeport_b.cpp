@@ -9,6 +9,19 @@
 
 namespace port {
 
+// parity diagnostics: the decompositions the minimiser asked for (port_svd_trace, oracle_abi.h)
+static OrcSvdRec *g_svd_buf = nullptr;
+static int g_svd_cap = 0, g_svd_n = 0;
+void svd_trace_record(const double A[36], const double e[6]) {
+    if (!g_svd_buf || g_svd_n >= g_svd_cap) return;
+    OrcSvdRec *r = &g_svd_buf[g_svd_n++];
+    r->rows = r->cols = 6;
+    for (int i = 0; i < 36; i++) r->A[i] = A[i];
+    for (int i = 0; i < 6; i++) r->s[i] = e[i];
+}
+void svd_trace_set(OrcSvdRec *buf, int cap) { g_svd_buf = buf; g_svd_cap = cap; g_svd_n = 0; }
+int svd_trace_count() { return g_svd_n; }
+
 // ---- edge_tracker::EstimateQuantile (src/mtracklib/edge_tracker.cpp:1148-1186) ----------------------------------
 double estimate_quantile(const Slot &s, double s_rho_min, double s_rho_max, double percentile, int n) {
     std::vector<int> histo(n, 0);

@@ -329,6 +329,15 @@ void *port_create(const OrcParams *p, int nslots) {
 }
 void port_destroy(void *ctx) { delete (Ctx *)ctx; }
 void port_reset_sequence(void *ctx) { reset_seq((Ctx *)ctx); }
+void port_get_seq_state(void *ctx, OrcSeqState *o) {
+    Ctx *c = (Ctx *)ctx;
+    o->tresh = c->tresh; o->t_prev = c->t_prev; o->Kp = c->Kp; o->K = c->K; o->P_Kp = c->P_Kp;
+    for (int i = 0; i < 3; i++) { o->V[i] = c->V[i]; o->W[i] = c->W[i]; o->Pos[i] = c->Pos[i]; }
+    for (int i = 0; i < 9; i++) o->Pose[i] = c->Pose[i];
+    o->l_kl_num = c->l_kl_num; o->frame = c->frame;
+}
+void port_svd_trace(OrcSvdRec *buf, int cap) { svd_trace_set(buf, cap); }
+int port_svd_trace_count(void) { return svd_trace_count(); }
 void port_depth_reset(void *ctx) {   // rebvo_second_t.cpp:609-620: depth reset of the newest edge map, pose and velocity reset
     Ctx *c = (Ctx *)ctx;
     if (c->frame == 0) return;

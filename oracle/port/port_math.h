@@ -117,6 +117,11 @@ inline void chol6_inverse(const double L[36], double Inv[36]) {
     }
 }
 
+// parity diagnostics (port_svd_trace, oracle_abi.h): defined in edgeport_b.cpp
+void svd_trace_record(const double A[36], const double e[6]);
+void svd_trace_set(struct OrcSvdRec *buf, int cap);
+int svd_trace_count();
+
 // h = TooN::SVD<>(A).backsub(b) for a symmetric 6x6 A (TooN/SVD.h:176-196, 264-272: singular values below
 // s_max/condition_no, condition_no = 1e9, are zeroed).  TooN calls LAPACK dgesvd_ (an un-vendored system
 // dependency of the reference, no version pinned); here the decomposition is a cyclic Jacobi eigen-solve
@@ -157,6 +162,7 @@ inline void svd6_backsub(const double Ain[36], const double b[6], double h[6]) {
             }
     }
     for (int i = 0; i < 6; i++) e[i] = A[i * 7];
+    svd_trace_record(Ain, e);
     double smax = 0;
     for (int i = 0; i < 6; i++) smax = std::fmax(smax, std::fabs(e[i]));
     double y[6];
@@ -198,6 +204,7 @@ inline void svd6_solve_pinv(const double Ain[36], const double b[6], double x[6]
     }
     double smax = 0;
     for (int i = 0; i < 6; i++) { e[i] = A[i * 7]; smax = std::fmax(smax, std::fabs(e[i])); }
+    svd_trace_record(Ain, e);
     for (int i = 0; i < 6; i++) inv[i] = (std::fabs(e[i]) * 1e9 <= smax) ? 0.0 : 1.0 / e[i];
     for (int r = 0; r < 6; r++) {
         double acc = 0;

@@ -1025,6 +1025,47 @@ __device__ __forceinline__ void chol6_inverse_r(const double (&L)[36], double (&
     }
 }
 
+// The 6x6 solve of one LM step: h = TooN::Cholesky<6>(ApI).backsub(nb) (global_tracker.cpp:767-768) or, in the init phase,
+// h = TooN::SVD<>(ApI).backsub(nb) (:660-661, 711-712).  Shared by lm_body and edgehip_lm_solve (the parity test of the rule below).
+__device__ __forceinline__ void lm_solve6(const double (&ApI)[36], const double (&nb)[6], const bool svd_rule, double (&hh)[6],
+                                          double (*s_m)[36], double (*s_v)[6]) {
+    double L[36];
+    chol6_r(ApI, L);
+    bool use_svd = false;
+    if (svd_rule) {
+        // TooN::SVD<>::backsub zeroes singular values below s_max/1e9.  ApI = JtJ + u*I with
+        // u = 1e-3*max(JtJ) (possibly scaled by 0.33^k) is SPD with condition <= ~1e5, so the rule never
+        // fires and the pseudo-inverse IS the inverse: solve by LDL^T.  The Jacobi-SVD path is kept
+        // for the degenerate case (non-positive or tiny pivots).
+        double dmin = L[0], dmax = L[0];
+#pragma unroll
+        for (int i = 1; i < 6; i++) { dmin = fmin(dmin, L[i * 7]); dmax = fmax(dmax, L[i * 7]); }
+        use_svd = !(dmin > 0) || !(dmin * 1e7 > dmax);
+    }
+    if (use_svd) {
+        double *A_l = s_m[0], *b_l = s_v[0], *h_l = s_v[2] + 0;
+        for (int i = 0; i < 36; i++) A_l[i] = ApI[i];
+        for (int i = 0; i < 6; i++) b_l[i] = nb[i];
+        svd_backsub6(A_l, b_l, h_l, s_m[2], s_m[3], s_v[1], s_m[1]);
+#pragma unroll
+        for (int i = 0; i < 6; i++) hh[i] = h_l[i];
+    } else {
+        chol6_backsub_r(L, nb, hh);
+    }
+}
+
+// edgehip_lm_solve: n independent systems through lm_solve6, one wave each (lane 0 does the algebra, like k_lm_step)
+__global__ __launch_bounds__(64) void k_lm_solve(const double *__restrict__ A, const double *__restrict__ b, double *__restrict__ h,
+                                                  int svd_rule) {
+    __shared__ double s_m[4][36], s_v[3][6];
+    if (threadIdx.x != 0) return;
+    double ApI[36], nb[6], hh[6];
+    for (int i = 0; i < 36; i++) ApI[i] = A[(size_t)blockIdx.x * 36 + i];
+    for (int i = 0; i < 6; i++) nb[i] = b[(size_t)blockIdx.x * 6 + i];
+    lm_solve6(ApI, nb, svd_rule != 0, hh, s_m, s_v);
+    for (int i = 0; i < 6; i++) h[(size_t)blockIdx.x * 6 + i] = hh[i];
+}
+
 // ---------------------------------------------------------------------------------------------------
 // k_lm_step: everything Minimizer_RV does between two TryVelRot evaluations (global_tracker.cpp:631-816).
 // The host knows the (static) call sequence and passes it as a bit mask of operations.
@@ -1270,33 +1311,12 @@ __device__ __forceinline__ void lm_body(const LmArgs &a, const int seq, const in
         const int t = res_new; res_new = res_cur; res_cur = t;       // std::swap
     }
     if (ops & (LM_SOLVE_SVD | LM_SOLVE_CHOL)) {
-        double ApI[36], L[36], nb[6];
+        double ApI[36], nb[6];
 #pragma unroll
         for (int i = 0; i < 36; i++) ApI[i] = JtJ[i];
 #pragma unroll
         for (int i = 0; i < 6; i++) { ApI[i * 7] = JtJ[i * 7] + 1.0 * u; nb[i] = -JtF[i]; }
-        chol6_r(ApI, L);
-        bool use_svd = false;
-        if (ops & LM_SOLVE_SVD) {
-            // TooN::SVD<>::backsub zeroes singular values below s_max/1e9.  ApI = JtJ + u*I with
-            // u = 1e-3*max(JtJ) (possibly scaled by 0.33^k) is SPD with condition <= ~1e5, so the rule never
-            // fires and the pseudo-inverse IS the inverse: solve by LDL^T.  The Jacobi-SVD path is kept
-            // for the degenerate case (non-positive or tiny pivots).
-            double dmin = L[0], dmax = L[0];
-#pragma unroll
-            for (int i = 1; i < 6; i++) { dmin = fmin(dmin, L[i * 7]); dmax = fmax(dmax, L[i * 7]); }
-            use_svd = !(dmin > 0) || !(dmin * 1e7 > dmax);
-        }
-        if (use_svd) {
-            double *A_l = s_m[0], *b_l = s_v[0], *h_l = s_v[2] + 0;
-            for (int i = 0; i < 36; i++) A_l[i] = ApI[i];
-            for (int i = 0; i < 6; i++) b_l[i] = nb[i];
-            svd_backsub6(A_l, b_l, h_l, s_m[2], s_m[3], s_v[1], s_m[1]);
-#pragma unroll
-            for (int i = 0; i < 6; i++) hh[i] = h_l[i];
-        } else {
-            chol6_backsub_r(L, nb, hh);
-        }
+        lm_solve6(ApI, nb, (ops & LM_SOLVE_SVD) != 0, hh, s_m, s_v);
 #pragma unroll
         for (int i = 0; i < 6; i++) Xn[i] = X[i] + hh[i];
     }
@@ -1944,6 +1964,27 @@ int edgehip_build_field(edgehip_ctx *c, int slot, int r, float m) {
     EH_ENTER(c);
     if (!c || slot < 0 || slot >= c->plan.nslots) return EDGEHIP_ERR_ARG;
     return build_field_enqueue(c, slot, r, m);
+}
+
+int edgehip_lm_solve(edgehip_ctx *c, const double *A, const double *b, int n, int svd_rule, double *h) {
+    EH_ENTER(c);
+    if (!A || !b || !h || n <= 0) {
+        set_error("lm_solve: bad argument");
+        return EDGEHIP_ERR_ARG;
+    }
+    double *d = nullptr;
+    EH_CHECK(hipMalloc(&d, sizeof(double) * 48 * (size_t)n));
+    hipError_t e = hipMemcpyAsync(d, A, sizeof(double) * 36 * (size_t)n, hipMemcpyHostToDevice, c->stream);
+    if (e == hipSuccess) e = hipMemcpyAsync(d + 36 * (size_t)n, b, sizeof(double) * 6 * (size_t)n, hipMemcpyHostToDevice, c->stream);
+    if (e == hipSuccess) {
+        hipLaunchKernelGGL(k_lm_solve, dim3(n), dim3(64), 0, c->stream, d, d + 36 * (size_t)n, d + 42 * (size_t)n, svd_rule);
+        e = hipGetLastError();
+    }
+    if (e == hipSuccess) e = hipMemcpyAsync(h, d + 42 * (size_t)n, sizeof(double) * 6 * (size_t)n, hipMemcpyDeviceToHost, c->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+    (void)hipFree(d);
+    EH_CHECK(e);
+    return 0;
 }
 
 int edgehip_try_velrot(edgehip_ctx *c, int slot_new, int slot_old, const double *X, int reweight, int procjf,

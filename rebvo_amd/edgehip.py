@@ -205,7 +205,7 @@ EXPORTS = [
     "edgehip_upload_rgb_indexed", "edgehip_bind_rgb_indexed", "edgehip_set_nav_log", "edgehip_read_nav_log",
     "edgehip_build_undistort_map", "edgehip_download_undistorted", "edgehip_depth_reset", "edgehip_depth_reset_slot", "edgehip_set_slot_camera", "edgehip_directed_matching_stereo",
     "edgehip_alloc_pinned", "edgehip_free_pinned", "edgehip_upload_rgb_pinned", "edgehip_fuse_stereo_depth", "edgehip_set_stereo_rig", "edgehip_get_stereo_matches", "edgehip_minimizer_v", "edgehip_ext_rot_vel",
-    "edgehip_imu_enable", "edgehip_set_imu", "edgehip_read_nav_imu", "edgehip_minimizer_rv_kf",
+    "edgehip_imu_enable", "edgehip_set_imu", "edgehip_read_nav_imu", "edgehip_minimizer_rv_kf", "edgehip_lm_solve",
 ]
 
 _lib = None
@@ -428,6 +428,14 @@ class EdgeHip:
         out = np.zeros((self.nseq, self.cap))
         self._ck(self.lib.edgehip_download_resid(self.ctx, which, _dp(out)))
         return out
+
+    def lm_solve(self, A, b, svd_rule):
+        """h = the 6x6 solve of an LM step for every system of A [n, 6, 6], b [n, 6]; svd_rule: the init phase's TooN::SVD<>::backsub."""
+        A = np.ascontiguousarray(A, np.float64).reshape(-1, 36)
+        b = np.ascontiguousarray(b, np.float64).reshape(-1, 6)
+        h = np.zeros_like(b)
+        self._ck(self.lib.edgehip_lm_solve(self.ctx, _dp(A), _dp(b), len(A), int(bool(svd_rule)), _dp(h)))
+        return h
 
     def minimizer_rv(self, slot_new, slot_old):
         self._ck(self.lib.edgehip_minimizer_rv(self.ctx, slot_new, slot_old))

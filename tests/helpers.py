@@ -94,3 +94,31 @@ def write_global_config(path, p, log_file="", tray_file="", save_log=0, camera_t
                 if f"{name}/{k}" in drop:
                     continue
                 f.write(f"    {k}={v!r}" .replace("'", "") + "    //comment\n")
+
+
+def require_ref():
+    """GPU parity tests need oracle/_ref (the reference compiled in place; it travels to the GPU box prebuilt).  Its absence
+    is a broken snapshot, not a reason to go green by skipping."""
+    import pytest
+    from oracle import oracle
+    if not oracle.available("ref"):
+        pytest.fail("oracle/_ref/libreforacle.so is missing: run `make -C oracle` where /root/reference exists (the GPU box "
+                    "receives the prebuilt library with the snapshot)")
+    return oracle
+
+
+def tri(k, n):
+    p = 2 * (n - 1)
+    k = k % p
+    return k if k < n else p - k
+
+
+def hetero_sequence(s, w=752, h=480, scenes=6, pool=12):
+    """Sequence `s` of bench.py's heterogeneous batch: scene s % 6 (its own texture and trajectory), started at phase
+    (s // 6) of the scene's 12-frame pool.  Returns frame_of(k)."""
+    from rebvo_amd import edgehip, synth
+    p = edgehip.euroc_params(w, h)
+    intr = dict(fx=float(p.zfx), fy=float(p.zfy), cx=float(p.ppx), cy=float(p.ppy))
+    frames = [f for f, _, _ in synth.billboard_sequence(w, h, pool, seed=101 + 7 * (s % scenes), traj_seed=29 + (s % scenes), **intr)]
+    ph = (s // scenes) % (2 * (pool - 1))
+    return lambda k: frames[tri(k + ph, pool)]
