@@ -803,7 +803,8 @@ def main():
             if r3 is not None:
                 r3.close()
         except Exception as e:
-            hetero = {"value": None, "error": str(e)[:200]}
+            hetero = dict(hetero or {"value": None})
+            hetero["error"] = f"{type(e).__name__}: {e}"[:300]
 
     line = {
         "metric": ("frames/sec (DoG+extract+track+depth, ImuMode=2) 752x480 EuRoC" if args.imu else

@@ -556,6 +556,7 @@ int edgehip_destroy(edgehip_ctx *c) {
         for (auto e : c->prof->pool) (void)hipEventDestroy(e);
         delete c->prof;
     }
+    if (c->stream_log) { (void)hipStreamSynchronize(c->stream_log); (void)hipStreamDestroy(c->stream_log); (void)hipEventDestroy(c->ev_log); }
     if (c->nav_log) (void)hipFree(c->nav_log);
     if (c->stream_imu) { (void)hipStreamSynchronize(c->stream_imu); (void)hipStreamDestroy(c->stream_imu); for (int i = 0; i < 2; i++) { (void)hipEventDestroy(c->ev_imu_snap[i]); (void)hipEventDestroy(c->ev_imu_post[i]); } }
     if (c->kf_req_dev) (void)hipFree(c->kf_req_dev);
@@ -723,8 +724,14 @@ int edgehip_set_nav_log(edgehip_ctx *c, int len) {
     if (!c || len < 0) return EDGEHIP_ERR_ARG;
     EH_CHECK(hipStreamSynchronize(c->stream));
     drop_frame_graphs(c);   // the per-frame record kernel takes the log pointer as an argument
+    if (c->stream_log) EH_CHECK(hipStreamSynchronize(c->stream_log));
     if (c->nav_log) { (void)hipFree(c->nav_log); c->nav_log = nullptr; }
     c->nav_log_len = 0;
+    c->frames_logged = 0;
+    if (len > 0 && !c->stream_log) {
+        EH_CHECK(hipStreamCreateWithFlags(&c->stream_log, hipStreamNonBlocking));
+        EH_CHECK(hipEventCreateWithFlags(&c->ev_log, hipEventDisableTiming));
+    }
     if (len > 0) {
         void *q;
         if (hipMalloc(&q, sizeof(edgehip_nav) * (size_t)len * c->plan.nseq) != hipSuccess) {
@@ -742,13 +749,19 @@ int edgehip_set_nav_log(edgehip_ctx *c, int len) {
 int edgehip_read_nav_log(edgehip_ctx *c, int first, int count, edgehip_nav *out) {
     EH_ENTER(c);
     if (!c || !out || !c->nav_log || first < 0 || count < 1 || count > c->nav_log_len) { set_error("read_nav_log: bad range or log disabled"); return EDGEHIP_ERR_ARG; }
+    // Records of frames that were never enqueued do not exist; `first` counts frames since edgehip_reset / the first frame
+    // (edgehip_nav::frame), the counter frames since edgehip_set_nav_log — equal when the log is set before the first frame.
     const size_t B = c->plan.nseq;
-    if (c->stream_imu) EH_CHECK(hipStreamSynchronize(c->stream_imu));   // ImuMode > 0: the records are written on the IMU stream
+    {
+        std::lock_guard<std::mutex> g(c->log_mu);
+        if (c->frames_logged.load() < 1) { set_error("read_nav_log: no frame has been enqueued since the log was set"); return EDGEHIP_ERR_STATE; }
+        EH_CHECK(hipStreamWaitEvent(c->stream_log, c->ev_log, 0));   // every frame enqueued so far, on whichever stream wrote its record
+    }
     for (int k = 0; k < count; k++) {
         const int slot = (first + k) % c->nav_log_len;
-        EH_CHECK(hipMemcpyAsync(out + (size_t)k * B, c->nav_log + (size_t)slot * B, sizeof(edgehip_nav) * B, hipMemcpyDeviceToHost, c->stream));
+        EH_CHECK(hipMemcpyAsync(out + (size_t)k * B, c->nav_log + (size_t)slot * B, sizeof(edgehip_nav) * B, hipMemcpyDeviceToHost, c->stream_log));
     }
-    EH_CHECK(hipStreamSynchronize(c->stream));
+    EH_CHECK(hipStreamSynchronize(c->stream_log));
     return 0;
 }
 

@@ -18,6 +18,8 @@
 #include <string>
 #include <map>
 #include <vector>
+#include <mutex>
+#include <atomic>
 
 #include "edgehip.h"
 
@@ -245,6 +247,13 @@ struct edgehip_ctx {
     edgehip_nav *nav_dev;  // [B] per-frame record
     edgehip_nav *nav_log;  // [nav_log_len][B] ring of per-frame records (optional)
     int nav_log_len;
+    // The log is read by a thread of its own while another enqueues frames (shard.NavMover): the read-out has its own stream,
+    // ordered after the frames it covers by ev_log (re-recorded behind every frame on the stream that writes the records);
+    // it never touches c->stream, which may be capturing a frame graph.  log_mu orders the record / wait pair on the event.
+    hipStream_t stream_log = nullptr;
+    hipEvent_t ev_log = nullptr;
+    std::mutex log_mu;
+    std::atomic<long long> frames_logged{0};   // frames enqueued since the log was set
     int32_t *idx_dev;      // [B] frame-pool indices of upload_rgb_indexed
     int32_t *stereo_cnt;   // [B] stereo match counters (params.stereo_available)
     // host staging
@@ -259,6 +268,7 @@ struct edgehip_ctx {
     edgehip::Profiler *prof;
     // the IMU branch of the frame driver (edgehip_imu_enable; stage_imu.hip)
     bool imu_enabled = false, imu_pending = false;
+    bool imu_pinned_ok = false;   // every buffer / stream / event of the IMU branch exists (edgehip_imu_enable is all-or-nothing)
     edgehip_imu_params imu_params;
     edgehip_kf_request *kf_req_dev = nullptr;        // [B] edgehip_minimizer_rv_kf (allocated on first use)
     edgehip_kf_result *kf_res_dev = nullptr;

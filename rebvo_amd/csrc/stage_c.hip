@@ -1033,6 +1033,7 @@ int edgehip_directed_matching_stereo(edgehip_ctx *c, int slot, int slot_pair, co
     (void)q_abs; (void)q_rel;
     if (int e = chk2(c, slot, slot_pair)) return e;
     if (!t || !R) return EDGEHIP_ERR_ARG;
+    if (c->imu_enabled) { set_error("set_stereo_rig: the device IMU branch does not run the stereo rig (edgehip_imu_enable was called)"); return EDGEHIP_ERR_STATE; }
     if (!c->p.stereo_available) { set_error("directed_matching_stereo: context created without stereo_available"); return EDGEHIP_ERR_STATE; }
     if (int e = stereo_enqueue(c, slot, slot_pair, t, R, min_thr_mod, min_thr_ang, max_radius, loc_unc, loc_unc_model, false)) return e;
     if (nmatch) EH_CHECK(hipMemcpyAsync(nmatch, c->stereo_cnt, sizeof(int32_t) * c->plan.nseq, hipMemcpyDeviceToHost, c->stream));
@@ -1274,6 +1275,9 @@ int edgehip_process_frame(edgehip_ctx *c, const double *t) {
     EH_ENTER(c);
     if (!c || !t) return EDGEHIP_ERR_ARG;
     const DevicePlan &pl = c->plan;
+    // ImuMode > 0: the reference grabs the IMU data of the interval for every frame (rebvo_first_t.cpp:232-246); a frame without
+    // edgehip_set_imu would silently integrate the previous interval's record again
+    if (c->imu_enabled && !c->imu_pending) { set_error("process_frame: edgehip_set_imu was not called for this frame"); return EDGEHIP_ERR_STATE; }
     const int sn = (c->frame_slot + 1) % c->ring_slots, so = c->frame_slot;
     const int sp = c->rig.enabled ? c->rig.slot_pair : -1;   // stereo pair slot (its frame was uploaded by the caller)
     const int have_pair = c->frames_seen >= 1;
@@ -1328,6 +1332,12 @@ int edgehip_process_frame(edgehip_ctx *c, const double *t) {
     if (sp >= 0) { c->slot_ring[sp] = c->frames_seen % 8; c->a_api_valid[sp] = false; }
     c->frame_slot = sn;
     c->frames_seen++;
+    c->imu_pending = false;
+    if (c->nav_log) {   // edgehip_read_nav_log (possibly another thread) orders its copies after this frame's record
+        std::lock_guard<std::mutex> g(c->log_mu);
+        EH_CHECK(hipEventRecord(c->ev_log, c->stream_imu ? c->stream_imu : c->stream));
+        c->frames_logged++;
+    }
     return 0;
 }
 

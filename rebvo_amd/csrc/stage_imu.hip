@@ -426,29 +426,36 @@ int edgehip_imu_enable(edgehip_ctx *c, const edgehip_imu_params *imu) {
     if (c->frames_seen != 0) { set_error("edgehip_imu_enable: call before the first frame"); return EDGEHIP_ERR_STATE; }
     if (c->rig.enabled) { set_error("edgehip_imu_enable: the device IMU branch does not run the stereo rig (use the stage entry points)"); return EDGEHIP_ERR_STATE; }
     const size_t B = c->plan.nseq;
-    if (!c->imu_track) {
-        void *q;
-        if (hipMalloc(&q, sizeof(ImuTrackDev) * B) != hipSuccess) { (void)hipGetLastError(); set_error("imu state alloc failed"); return EDGEHIP_ERR_MEMORY; }
-        c->imu_track = q;
-        if (hipMalloc(&q, sizeof(ImuFilterDev) * B) != hipSuccess) { (void)hipGetLastError(); set_error("imu filter state alloc failed"); return EDGEHIP_ERR_MEMORY; }
-        c->imu_filter = q;
-        if (hipMalloc(&q, sizeof(ImuSnap) * B * 2) != hipSuccess) { (void)hipGetLastError(); set_error("imu snapshot alloc failed"); return EDGEHIP_ERR_MEMORY; }
-        c->imu_snap = q;
-        EH_CHECK(hipStreamCreateWithFlags(&c->stream_imu, hipStreamNonBlocking));
-        for (int i = 0; i < 2; i++) {
-            EH_CHECK(hipEventCreateWithFlags(&c->ev_imu_snap[i], hipEventDisableTiming));
-            EH_CHECK(hipEventCreateWithFlags(&c->ev_imu_post[i], hipEventDisableTiming));
-            c->imu_post_valid[i] = false;
+    if (!c->imu_pinned_ok) {
+        // All or nothing: a call that fails half-way leaves the context without IMU buffers, so that a second call starts over
+        // instead of enabling the branch with null pointers.
+        void *track = nullptr, *filter = nullptr, *snap = nullptr, *in_dev = nullptr, *nav_dev = nullptr, *pin_in = nullptr, *pin_nav = nullptr;
+        hipStream_t st = nullptr;
+        hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
+        bool ok = hipMalloc(&track, sizeof(ImuTrackDev) * B) == hipSuccess && hipMalloc(&filter, sizeof(ImuFilterDev) * B) == hipSuccess &&
+                  hipMalloc(&snap, sizeof(ImuSnap) * B * 2) == hipSuccess && hipMalloc(&in_dev, sizeof(edgehip_imu_integrated) * B) == hipSuccess &&
+                  hipMalloc(&nav_dev, sizeof(edgehip_nav_imu) * B) == hipSuccess &&
+                  hipHostMalloc(&pin_in, sizeof(edgehip_imu_integrated) * B * 8, hipHostMallocDefault) == hipSuccess &&
+                  hipHostMalloc(&pin_nav, sizeof(edgehip_nav_imu) * B, hipHostMallocDefault) == hipSuccess &&
+                  hipStreamCreateWithFlags(&st, hipStreamNonBlocking) == hipSuccess;
+        for (int i = 0; ok && i < 4; i++) ok = hipEventCreateWithFlags(&ev[i], hipEventDisableTiming) == hipSuccess;
+        if (ok) ok = hipMemsetAsync(nav_dev, 0, sizeof(edgehip_nav_imu) * B, c->stream) == hipSuccess;
+        if (!ok) {
+            (void)hipGetLastError();
+            for (int i = 0; i < 4; i++) if (ev[i]) (void)hipEventDestroy(ev[i]);
+            if (st) (void)hipStreamDestroy(st);
+            if (pin_nav) (void)hipHostFree(pin_nav);
+            if (pin_in) (void)hipHostFree(pin_in);
+            for (void *q : {nav_dev, in_dev, snap, filter, track}) if (q) (void)hipFree(q);
+            set_error("edgehip_imu_enable: allocating the IMU branch's state failed");
+            return EDGEHIP_ERR_MEMORY;
         }
-        if (hipMalloc(&q, sizeof(edgehip_imu_integrated) * B) != hipSuccess) { (void)hipGetLastError(); set_error("imu input alloc failed"); return EDGEHIP_ERR_MEMORY; }
-        c->imu_in_dev = (edgehip_imu_integrated *)q;
-        if (hipMalloc(&q, sizeof(edgehip_nav_imu) * B) != hipSuccess) { (void)hipGetLastError(); set_error("imu nav alloc failed"); return EDGEHIP_ERR_MEMORY; }
-        c->nav_imu_dev = (edgehip_nav_imu *)q;
-        EH_CHECK(hipMemsetAsync(c->nav_imu_dev, 0, sizeof(edgehip_nav_imu) * B, c->stream));
-        EH_CHECK(hipHostMalloc(&q, sizeof(edgehip_imu_integrated) * B * 8, hipHostMallocDefault));
-        c->pinned_imu = (edgehip_imu_integrated *)q;
-        EH_CHECK(hipHostMalloc(&q, sizeof(edgehip_nav_imu) * B, hipHostMallocDefault));
-        c->pinned_nav_imu = (edgehip_nav_imu *)q;
+        c->imu_track = track; c->imu_filter = filter; c->imu_snap = snap;
+        c->imu_in_dev = (edgehip_imu_integrated *)in_dev; c->nav_imu_dev = (edgehip_nav_imu *)nav_dev;
+        c->pinned_imu = (edgehip_imu_integrated *)pin_in; c->pinned_nav_imu = (edgehip_nav_imu *)pin_nav;
+        c->stream_imu = st;
+        for (int i = 0; i < 2; i++) { c->ev_imu_snap[i] = ev[i]; c->ev_imu_post[i] = ev[2 + i]; c->imu_post_valid[i] = false; }
+        c->imu_pinned_ok = true;
     }
     c->imu_params = *imu;
     c->imu_enabled = true;

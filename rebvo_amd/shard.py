@@ -74,36 +74,82 @@ class NavMover:
         self._t = threading.Thread(target=self._run, daemon=True)
         self._t.start()
 
-    def post(self, log_reader, first, count, seq_ids):
+    def _put(self, item, timeout):
+        """Blocking put that keeps looking at the worker: a dead or failed worker never drains the queue."""
+        import queue
+        import time
+        t_end = None if timeout is None else time.monotonic() + timeout
+        while True:
+            if self.error is not None:
+                raise self.error
+            if not self._t.is_alive():
+                raise RuntimeError("nav mover thread is gone")
+            try:
+                self._q.put(item, timeout=0.2)
+                return
+            except queue.Full:
+                if t_end is not None and time.monotonic() > t_end:
+                    raise TimeoutError(f"nav gather is more than two blocks behind after {timeout} s")
+
+    def post(self, log_reader, first, count, seq_ids, timeout=None):
         """log_reader.read_nav_log_array(first, count) -> structured array [count, nseq] (EdgeHip does)."""
-        if self.error is not None:
-            raise self.error
-        self._q.put((log_reader, first, count, list(seq_ids)))
+        self._put((log_reader, first, count, list(seq_ids)), timeout)
 
     def _run(self):
+        import torch
+        import torch.distributed as dist
         if self.device is not None:           # the current device is per thread
-            import torch
             torch.cuda.set_device(self.device)
+        failed = False
         while True:
             item = self._q.get()
             if item is None:
                 return
+            if failed:
+                continue                      # keep draining: a post() blocked on the full queue must wake up and see the error
+            rec = None
             try:
                 reader, first, count, seq_ids = item
                 rec = nav_records(reader.read_nav_log_array(first, count), self.rank, seq_ids)
+            except Exception as e:            # surfaces in post() / finish(); the replay itself must not be torn down by the transport
+                self.error = e
+            try:
+                # Every rank reaches the same collectives in the same order whatever happened locally: a status word first,
+                # so that one rank's failure stops the transport on all of them instead of leaving the others in the gather.
+                ok = torch.tensor([0 if rec is None else 1], dtype=torch.int32)
+                if dist.get_backend(self.group) == "nccl":
+                    ok = ok.cuda()
+                dist.all_reduce(ok, op=dist.ReduceOp.MIN, group=self.group)
+                if int(ok.item()) == 0:
+                    if self.error is None:
+                        self.error = RuntimeError("nav gather stopped: another rank failed to read its records")
+                    failed = True
+                    continue
                 out = gather_records(rec, dst=self.dst, group=self.group)
                 if out is not None:
                     self.blocks.append(out)
-            except Exception as e:            # surfaces in finish(); the replay itself must not be torn down by the transport
-                self.error = e
-                return
+            except Exception as e:
+                if self.error is None:
+                    self.error = e
+                failed = True
 
     def finish(self, timeout=None):
         """Waits until every posted block has arrived; returns the blocks (on dst) in posting order.  With a timeout
         (seconds) a transport that does not come back raises TimeoutError instead of blocking the caller for ever (the
         worker is a daemon thread)."""
-        self._q.put(None)
-        self._t.join(timeout)
+        import time
+        t0 = time.monotonic()
+        try:
+            self._put(None, timeout)
+        except Exception:
+            try:
+                self._q.put_nowait(None)      # let a draining worker end
+            except Exception:
+                pass
+            if self.error is not None:
+                raise self.error
+            raise
+        self._t.join(None if timeout is None else max(0.0, timeout - (time.monotonic() - t0)))
         if self._t.is_alive():
             raise TimeoutError(f"nav gather still running after {timeout} s")
         if self.error is not None:

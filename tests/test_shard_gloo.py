@@ -146,3 +146,57 @@ def test_nav_mover_world4_gloo_delivers_every_step_once():
         assert np.array_equal(allrec[r, :, 0, 0], np.arange(5, 15))          # every timed step once, in order
         assert np.all(allrec[r, :, :, 14] == r) and np.all(allrec[r, :, :, 4] == r)
         assert sorted(set(allrec[r, 0, :, 13].tolist())) == [3 * r, 3 * r + 1, 3 * r + 2]
+
+
+class _FailingLog(_FakeLog):
+    """A reader that fails on the second block of one rank (a device error under edgehip_read_nav_log)."""
+
+    def __init__(self, rank, nseq, bad_rank):
+        super().__init__(rank, nseq)
+        self.bad, self.calls = rank == bad_rank, 0
+
+    def read_nav_log_array(self, first, count):
+        self.calls += 1
+        if self.bad and self.calls == 2:
+            raise RuntimeError("read_nav_log: injected failure")
+        return super().read_nav_log_array(first, count)
+
+
+def _failing_mover_worker(rank, world, port, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    mover = shard.NavMover(world, rank, "gloo")
+    log = _FailingLog(rank, 3, bad_rank=1)
+    dist.barrier()
+    outcome = "no error"
+    try:
+        for b in range(8):                               # more posts than the queue holds: a dead worker must not block them
+            mover.post(log, 5 * b, 5, [0, 1, 2], timeout=30)
+        mover.finish(timeout=30)
+    except Exception as e:
+        outcome = f"{type(e).__name__}: {e}"
+    dist.barrier()                                        # every rank got out: nobody sits in a gather or a queue.put
+    q.put((rank, outcome, len(mover.blocks)))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_nav_mover_reader_failure_on_one_rank_stops_all_ranks_without_hanging():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    world = 2
+    procs = [ctx.Process(target=_failing_mover_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = dict((r, (o, n)) for r, o, n in (q.get(timeout=120) for _ in range(world)))
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert "injected failure" in res[1][0]                # the failing rank reports its own error
+    assert "another rank failed" in res[0][0]             # the other one is told, instead of waiting in dist.gather
+    assert res[0][1] == 1                                 # the block before the failure arrived on rank 0
