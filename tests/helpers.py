@@ -102,7 +102,7 @@ def require_ref():
     import pytest
     from oracle import oracle
     if not oracle.available("ref"):
-        pytest.fail("oracle/_ref/libreforacle.so is missing: run `make -C oracle` where /root/reference exists (the GPU box "
+        pytest.fail("oracle/_ref/libreforacle.so is missing: run `make -C oracle` where the reference tree is present (the GPU box "
                     "receives the prebuilt library with the snapshot)")
     return oracle
 

@@ -19,7 +19,7 @@ EXE = os.path.join(ROOT, "rebvo_amd", "lib", "dataset_replay")
 def test_euroc_layout_replay(tmp_path):
     from oracle import oracle
     if not oracle.available("ref") or not os.path.exists(EXE):
-        pytest.fail("needs oracle/_ref and dataset_replay" " — a broken snapshot, not a reason to skip: run __graft_entry__.build() where /root/reference exists")
+        pytest.fail("needs oracle/_ref and dataset_replay" " — a broken snapshot, not a reason to skip: run __graft_entry__.build(), where the reference tree is present")
     w, h, n = 376, 240, 8
     frames = [f for f, _, _ in synth.billboard_sequence(w, h, n)]
     cam0 = tmp_path / "mav0" / "cam0"

@@ -21,9 +21,9 @@ EXE = os.path.join(ROOT, "rebvo_amd", "lib", "custom_cam_replay")
 def test_custom_cam_replay_matches_reference(tmp_path):
     from oracle import oracle
     if not oracle.available("ref"):
-        pytest.fail("oracle/_ref not built" " — a broken snapshot, not a reason to skip: run __graft_entry__.build() where /root/reference exists")
+        pytest.fail("oracle/_ref not built" " — a broken snapshot, not a reason to skip: run __graft_entry__.build(), where the reference tree is present")
     if not os.path.exists(EXE):
-        pytest.fail("custom_cam_replay not built" " — a broken snapshot, not a reason to skip: run __graft_entry__.build() where /root/reference exists")
+        pytest.fail("custom_cam_replay not built" " — a broken snapshot, not a reason to skip: run __graft_entry__.build(), where the reference tree is present")
     w, h, n, t0, dt = 376, 240, 9, 1.0, 0.05
     frames = [f for f, _, _ in synth.billboard_sequence(w, h, n)]
     np.stack(frames).tofile(tmp_path / "frames.rgb24")

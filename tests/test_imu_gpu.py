@@ -76,7 +76,7 @@ def _write_dataset(tmp_path):
 def test_imu_mode2_replay_matches_reference(tmp_path):
     from oracle import oracle
     if not oracle.available("ref") or not os.path.exists(EXE):
-        pytest.fail("needs oracle/_ref and dataset_replay" " — a broken snapshot, not a reason to skip: run __graft_entry__.build() where /root/reference exists")
+        pytest.fail("needs oracle/_ref and dataset_replay" " — a broken snapshot, not a reason to skip: run __graft_entry__.build(), where the reference tree is present")
     frames, t_ns, cam0, imu_csv, se3 = _write_dataset(tmp_path)
     cfg, dump = tmp_path / "cfg", tmp_path / "dump.txt"
     p = edgehip.euroc_params(W, H)
@@ -152,7 +152,7 @@ def test_imu_mode1_pushimu_matches_reference(tmp_path):
     from oracle import oracle
     exe = os.path.join(ROOT, "rebvo_amd", "lib", "custom_cam_replay")
     if not oracle.available("ref") or not os.path.exists(exe):
-        pytest.fail("needs oracle/_ref and custom_cam_replay" " — a broken snapshot, not a reason to skip: run __graft_entry__.build() where /root/reference exists")
+        pytest.fail("needs oracle/_ref and custom_cam_replay" " — a broken snapshot, not a reason to skip: run __graft_entry__.build(), where the reference tree is present")
     frames, t_ns, cam0, imu_csv_ns, se3 = _write_dataset(tmp_path)
     t0, dt = 10.0, 0.05
     t = [t0 + dt * k for k in range(N)]
@@ -201,7 +201,7 @@ def test_imu_branch_batched_on_the_device_matches_reference(tmp_path):
     (ref_process_frame_imu, a fresh process per sequence: its acceleration histories are process-wide statics)."""
     from oracle import oracle
     if not oracle.available("ref"):
-        pytest.fail("needs oracle/_ref" " — a broken snapshot, not a reason to skip: run __graft_entry__.build() where /root/reference exists")
+        pytest.fail("needs oracle/_ref" " — a broken snapshot, not a reason to skip: run __graft_entry__.build(), where the reference tree is present")
     global N
     B, n_run = 8, N
     n_all = n_run + B - 1

@@ -16,7 +16,7 @@ pytestmark = pytest.mark.gpu
 def _run(w, h, n, nseq=1):
     from oracle import oracle
     if not oracle.available("ref"):
-        pytest.fail("oracle/_ref not built" " — a broken snapshot, not a reason to skip: run __graft_entry__.build() where /root/reference exists")
+        pytest.fail("oracle/_ref not built" " — a broken snapshot, not a reason to skip: run __graft_entry__.build(), where the reference tree is present")
     frames = [f for f, _, _ in synth.billboard_sequence(w, h, n)]
     orc = oracle.Oracle("ref", oracle.euroc_params(w, h))
     eh = edgehip.EdgeHip(edgehip.euroc_params(w, h), nseq=nseq, nslots=3)
@@ -71,7 +71,7 @@ def test_framecount_follows_reference_ring():
     sees depends on THAT ring length, whatever nslots the GPU context uses."""
     from oracle import oracle
     if not oracle.available("ref"):
-        pytest.fail("oracle/_ref not built" " — a broken snapshot, not a reason to skip: run __graft_entry__.build() where /root/reference exists")
+        pytest.fail("oracle/_ref not built" " — a broken snapshot, not a reason to skip: run __graft_entry__.build(), where the reference tree is present")
     w, h, n = 376, 240, 19
     frames = [f for f, _, _ in synth.billboard_sequence(w, h, n)]
     orc = oracle.Oracle("ref", oracle.euroc_params(w, h, match_num_thresh=2))
@@ -141,7 +141,7 @@ def test_reset_mid_sequence_matches_reference():
     the following frames must track like the reference does after the same reset."""
     from oracle import oracle
     if not oracle.available("ref"):
-        pytest.fail("oracle/_ref not built" " — a broken snapshot, not a reason to skip: run __graft_entry__.build() where /root/reference exists")
+        pytest.fail("oracle/_ref not built" " — a broken snapshot, not a reason to skip: run __graft_entry__.build(), where the reference tree is present")
     w, h, n = 376, 240, 8
     frames = [f for f, _, _ in synth.billboard_sequence(w, h, n)]
     orc = oracle.Oracle("ref", oracle.euroc_params(w, h))
@@ -174,7 +174,7 @@ def test_pipeline_batch_of_different_sequences():
     per-sequence slices of the batched buffers."""
     from oracle import oracle
     if not oracle.available("ref"):
-        pytest.fail("oracle/_ref not built" " — a broken snapshot, not a reason to skip: run __graft_entry__.build() where /root/reference exists")
+        pytest.fail("oracle/_ref not built" " — a broken snapshot, not a reason to skip: run __graft_entry__.build(), where the reference tree is present")
     w, h, n = 376, 240, 7
     seqs = [[f for f, _, _ in synth.billboard_sequence(w, h, n, seed=11, traj_seed=13)],
             [f for f, _, _ in synth.billboard_sequence(w, h, n, seed=5, traj_seed=3)],

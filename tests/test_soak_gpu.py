@@ -23,7 +23,7 @@ def _tri(k, n):
 def _replay(frames, gp, op, nf, phases, dt):
     from oracle import oracle
     if not oracle.available("ref"):
-        pytest.fail("oracle/_ref not built" " — a broken snapshot, not a reason to skip: run __graft_entry__.build() where /root/reference exists")
+        pytest.fail("oracle/_ref not built" " — a broken snapshot, not a reason to skip: run __graft_entry__.build(), where the reference tree is present")
     npool = len(frames)
     eh = edgehip.EdgeHip(gp, nseq=len(phases), nslots=3)
     eh.set_nav_log(nf)
@@ -97,7 +97,7 @@ def test_stereo_thirty_frames_without_sync():
     frame ring and is rewritten every frame), nav log against the reference's stereo frame order."""
     from oracle import oracle
     if not oracle.available("ref"):
-        pytest.fail("oracle/_ref not built" " — a broken snapshot, not a reason to skip: run __graft_entry__.build() where /root/reference exists")
+        pytest.fail("oracle/_ref not built" " — a broken snapshot, not a reason to skip: run __graft_entry__.build(), where the reference tree is present")
     import test_stereo_gpu as T
     nf = 30
     p, frames, pairs, pc = T.make_data(all_pairs=True, nf=nf)

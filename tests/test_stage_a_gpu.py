@@ -18,7 +18,7 @@ STAGE_A_FIELDS = ["p_inx", "m_m", "u_m", "n_m", "c_p", "rho", "s_rho", "rho_nr",
 def _oracle(w, h, **over):
     from oracle import oracle
     if not oracle.available("ref"):
-        pytest.fail("oracle/_ref/libreforacle.so not built" " — a broken snapshot, not a reason to skip: run __graft_entry__.build() where /root/reference exists")
+        pytest.fail("oracle/_ref/libreforacle.so not built" " — a broken snapshot, not a reason to skip: run __graft_entry__.build(), where the reference tree is present")
     return oracle.Oracle("ref", oracle.euroc_params(w, h, **over))
 
 

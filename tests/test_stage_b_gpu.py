@@ -22,7 +22,7 @@ TOL_POSE_REL, TOL_POSE_ABS = 1e-7, 1e-9
 def pair():
     from oracle import oracle
     if not oracle.available("ref"):
-        pytest.fail("oracle/_ref not built" " — a broken snapshot, not a reason to skip: run __graft_entry__.build() where /root/reference exists")
+        pytest.fail("oracle/_ref not built" " — a broken snapshot, not a reason to skip: run __graft_entry__.build(), where the reference tree is present")
     w, h = 376, 240
     orc, so, sn, nav, frames = oracle_pair(w, h, 4)
     # debug_planes: the device then keeps the field's distances too (the tracker itself only gathers a KeyLine-index
@@ -193,7 +193,7 @@ def test_build_field_segments_that_round_across_a_tile_boundary(w, h, mode, monk
     tiles: the 1024 x 1104 case)."""
     from oracle import oracle
     if not oracle.available("ref"):
-        pytest.fail("oracle/_ref not built" " — a broken snapshot, not a reason to skip: run __graft_entry__.build() where /root/reference exists")
+        pytest.fail("oracle/_ref not built" " — a broken snapshot, not a reason to skip: run __graft_entry__.build(), where the reference tree is present")
     if mode in ("1", "2"):
         monkeypatch.setenv("EDGEHIP_FIELD_MODE", mode)
     r = 40

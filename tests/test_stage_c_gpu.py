@@ -28,7 +28,7 @@ def so3_exp(w):
 def tracked():
     from oracle import oracle
     if not oracle.available("ref"):
-        pytest.fail("oracle/_ref not built" " — a broken snapshot, not a reason to skip: run __graft_entry__.build() where /root/reference exists")
+        pytest.fail("oracle/_ref not built" " — a broken snapshot, not a reason to skip: run __graft_entry__.build(), where the reference tree is present")
     w, h = 376, 240
     orc, so, sn, nav, frames = oracle_pair(w, h, 4)
     s_rho_q = orc.quantile(so)
@@ -127,7 +127,7 @@ def test_ext_rot_vel():
     Phi^T Phi within 1e-11 (tree vs sequential fp64 summation), X within 1e-8 relative."""
     from oracle import oracle
     if not oracle.available("ref"):
-        pytest.fail("oracle/_ref not built" " — a broken snapshot, not a reason to skip: run __graft_entry__.build() where /root/reference exists")
+        pytest.fail("oracle/_ref not built" " — a broken snapshot, not a reason to skip: run __graft_entry__.build(), where the reference tree is present")
     w, h = 376, 240
     frames = [f for f, _, _ in synth.billboard_sequence(w, h, 6)]
     orc = oracle.Oracle("ref", oracle.euroc_params(w, h))

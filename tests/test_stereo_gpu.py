@@ -56,7 +56,7 @@ def run_reference(p_unused, frames, pair, pair_cam):
 def test_stereo_matches_reference():
     from oracle import oracle
     if not oracle.available("ref"):
-        pytest.fail("oracle/_ref not built" " — a broken snapshot, not a reason to skip: run __graft_entry__.build() where /root/reference exists")
+        pytest.fail("oracle/_ref not built" " — a broken snapshot, not a reason to skip: run __graft_entry__.build(), where the reference tree is present")
     p, frames, pair, pair_cam = make_data()
     orc, s, ps = run_reference(p, frames, pair, pair_cam)
 
@@ -125,7 +125,7 @@ def test_directed_matching_stereo_mode():
     """directed_matching with StereoAvaiable: a match clones rho0 / s_rho0 and leaves rho_nr alone."""
     from oracle import oracle
     if not oracle.available("ref"):
-        pytest.fail("oracle/_ref not built" " — a broken snapshot, not a reason to skip: run __graft_entry__.build() where /root/reference exists")
+        pytest.fail("oracle/_ref not built" " — a broken snapshot, not a reason to skip: run __graft_entry__.build(), where the reference tree is present")
     p, frames, pair, pair_cam = make_data()
     orc = oracle.Oracle("ref", oracle.euroc_params(W, H))
     for k, f in enumerate(frames[:-1]):
@@ -174,7 +174,7 @@ def test_stereo_whole_frame_matches_reference():
     batch stay identical."""
     from oracle import oracle
     if not oracle.available("ref"):
-        pytest.fail("oracle/_ref not built" " — a broken snapshot, not a reason to skip: run __graft_entry__.build() where /root/reference exists")
+        pytest.fail("oracle/_ref not built" " — a broken snapshot, not a reason to skip: run __graft_entry__.build(), where the reference tree is present")
     nf = 8
     p, frames, pairs, pc = make_data(all_pairs=True, nf=nf)
     orc = oracle.Oracle("ref", oracle.euroc_params(W, H))
@@ -225,7 +225,7 @@ def test_host_stereo_replay(tmp_path):
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     exe = os.path.join(root, "rebvo_amd", "lib", "dataset_replay")
     if not oracle.available("ref") or not os.path.exists(exe):
-        pytest.fail("needs oracle/_ref and dataset_replay" " — a broken snapshot, not a reason to skip: run __graft_entry__.build() where /root/reference exists")
+        pytest.fail("needs oracle/_ref and dataset_replay" " — a broken snapshot, not a reason to skip: run __graft_entry__.build(), where the reference tree is present")
     nf = 8
     p, frames, pairs, pc = make_data(all_pairs=True, nf=nf)
     t_ns = [1403636579763555584 + 50_000_000 * k for k in range(nf)]

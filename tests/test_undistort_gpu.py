@@ -28,7 +28,7 @@ def _mk(kc, **over):
 def test_stage_a_with_undistort_bit_exact(kc):
     from oracle import oracle
     if not oracle.available("ref"):
-        pytest.fail("oracle/_ref not built" " — a broken snapshot, not a reason to skip: run __graft_entry__.build() where /root/reference exists")
+        pytest.fail("oracle/_ref not built" " — a broken snapshot, not a reason to skip: run __graft_entry__.build(), where the reference tree is present")
     po, pe = _mk(kc)
     pe.debug_planes = 1
     frames = [f for f, _, _ in synth.billboard_sequence(640, 480, 2)]
@@ -53,7 +53,7 @@ def test_stage_a_with_undistort_bit_exact(kc):
 def test_pipeline_tum_undistort():
     from oracle import oracle
     if not oracle.available("ref"):
-        pytest.fail("oracle/_ref not built" " — a broken snapshot, not a reason to skip: run __graft_entry__.build() where /root/reference exists")
+        pytest.fail("oracle/_ref not built" " — a broken snapshot, not a reason to skip: run __graft_entry__.build(), where the reference tree is present")
     po, pe = _mk(KCS[0])
     frames = [f for f, _, _ in synth.billboard_sequence(640, 480, 11)]  # > 8: wraps the reference's FrameCount ring
     orc = oracle.Oracle("ref", po)
