@@ -1033,14 +1033,20 @@ __device__ __forceinline__ void lm_solve6(const double (&ApI)[36], const double 
     chol6_r(ApI, L);
     bool use_svd = false;
     if (svd_rule) {
-        // TooN::SVD<>::backsub zeroes singular values below s_max/1e9.  ApI = JtJ + u*I with
-        // u = 1e-3*max(JtJ) (possibly scaled by 0.33^k) is SPD with condition <= ~1e5, so the rule never
-        // fires and the pseudo-inverse IS the inverse: solve by LDL^T.  The Jacobi-SVD path is kept
-        // for the degenerate case (non-positive or tiny pivots).
-        double dmin = L[0], dmax = L[0];
+        // TooN::SVD<>::backsub zeroes singular values s_i with s_i * 1e9 <= s_max (SVD.h:264-272); when none is, the
+        // pseudo-inverse IS the inverse and LDL^T gives the same h.  A bound that needs no decomposition: for SPD A with LDL^T
+        // pivots d_i and trace T, s_max <= T and det A = prod d_i, so s_min >= prod d_i / T^5 and
+        // cond(A) <= prod (T / d_i).  ApI = JtJ + u I with u ~ 1e-3 max(JtJ) has condition 10..1e4 and passes; anything the bound
+        // cannot clear (or that is not positive definite) takes the Jacobi path, which applies TooN's rule value by value.
+        // (Round 2 compared the pivot ratio with 1e7: unsound — pivots 8e9..4e3 at condition 1.7e9 — found by
+        // tests/test_knife_edge_gpu.py::test_lm_solve_against_toon_either_side_of_the_svd_cutoff.)
+        double dmin = L[0], tr = ApI[0];
 #pragma unroll
-        for (int i = 1; i < 6; i++) { dmin = fmin(dmin, L[i * 7]); dmax = fmax(dmax, L[i * 7]); }
-        use_svd = !(dmin > 0) || !(dmin * 1e7 > dmax);
+        for (int i = 1; i < 6; i++) { dmin = fmin(dmin, L[i * 7]); tr += ApI[i * 7]; }
+        double bound = 1;
+#pragma unroll
+        for (int i = 0; i < 6; i++) bound *= tr / L[i * 7];
+        use_svd = !(dmin > 0) || !(bound < 0.99e9);
     }
     if (use_svd) {
         double *A_l = s_m[0], *b_l = s_v[0], *h_l = s_v[2] + 0;

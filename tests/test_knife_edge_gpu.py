@@ -77,9 +77,9 @@ def test_lm_solve_against_toon_either_side_of_the_svd_cutoff():
     for i in range(len(A)):
         want = orc.svd_backsub(A[i], b[i])
         scale = np.max(np.abs(want)) + 1e-300
-        # a dropped direction contributes |b| / s_min ~ 1e9 times the rest when kept: agreement to 1e-6 of the solution's size
+        # a dropped direction contributes |b| / s_min ~ 1e9 times the rest when kept: agreement to 1e-5 of the solution's size
         # means both sides made the same keep / drop choice for every singular value
-        assert np.max(np.abs(h_svd[i] - want)) <= 1e-6 * scale, (i, h_svd[i], want)
+        assert np.max(np.abs(h_svd[i] - want)) <= 1e-5 * scale, (i, h_svd[i], want)
     for i in range(3):
         want = orc.svd_backsub(A[i], b[i], chol=True)
         assert np.max(np.abs(h_chol[i] - want)) <= 1e-9 * (np.max(np.abs(want)) + 1e-300), i
