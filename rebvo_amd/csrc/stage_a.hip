@@ -998,9 +998,12 @@ __device__ __forceinline__ int x86_cvttss2si(float f) {
 // DEFAULTS: also give KeyLine i the constant fields of a freshly detected KeyLine (edge_finder.cpp:176-196) — after the fused
 // stage-A kernel, which writes only the computed fields and p_id (the atomicMax below needs p_id = -1 before any thread
 // runs): a full-wave streaming store here instead of a partial-wave one there.
-template <bool DEFAULTS>
+// DERIVE (with DEFAULTS): the fused kernel's fit wave left only what the plane fit produced — p_inx and {xs, ys, m_m} in
+// the grec slot — and every field that follows from them (edge_finder.cpp:166-200: n_m, u_m, c_p, p_m, p_m_0, the gather
+// records) is computed here, at full lanes and streaming, instead of by one wave of the detector at a third of its lanes.
+template <bool DEFAULTS, bool DERIVE = false>
 __global__ __launch_bounds__(256) void k_join_histo(KlSoA *kls, const int32_t *__restrict__ masks, SeqA *seqs,
-                                                    int32_t *histo, int w, size_t n, int nbins) {
+                                                    int32_t *histo, int w, size_t n, int nbins, float ppx = 0.f, float ppy = 0.f) {
     const int seq = blockIdx.z;
     const int i = blockIdx.x * 256 + threadIdx.x;
     SeqA *sq = seqs + seq;
@@ -1011,8 +1014,34 @@ __global__ __launch_bounds__(256) void k_join_histo(KlSoA *kls, const int32_t *_
     if (i < kn) {
         const KlSoA &k = kls[seq];
         const int32_t *mask = masks + (size_t)seq * n;
-        const float2 cp = k.c_p[i];
-        const float2 m = k.m_m[i];
+        float2 cp, m;
+        float nm_i;
+        if (DERIVE) {
+            const float4 raw = k.grec[i];           // xs, ys, m_m.x, m_m.y
+            const int p = k.p_inx[i];
+            const int py = p / w, px = p - py * w;
+            m = make_float2(raw.z, raw.w);
+            const float n2m = m.x * m.x + m.y * m.y;
+            nm_i = sqrtf(n2m);
+            const float2 u = make_float2(m.x / nm_i, m.y / nm_i);
+            cp = make_float2((float)px + raw.x, (float)py + raw.y);
+            const float2 pm = make_float2(cp.x - ppx, cp.y - ppy);      // cam_model::Img2Hom
+            k.m_m[i] = m;
+            k.n_m[i] = nm_i;
+            k.u_m[i] = u;
+            k.c_p[i] = cp;
+            k.p_m[i] = pm;
+            k.p_m_0[i] = pm;
+            MatchRec rec;
+            rec.c_px = cp.x; rec.c_py = cp.y; rec.u_mx = u.x; rec.u_my = u.y;
+            rec.m_mx = m.x; rec.m_my = m.y; rec.n_m = nm_i; rec.pad = 0.f;
+            k.rec[i] = rec;
+            k.grec[i] = make_float4(cp.x, cp.y, m.x, m.y);
+        } else {
+            cp = k.c_p[i];
+            m = k.m_m[i];
+            nm_i = k.n_m[i];
+        }
         const int x = (int)((double)cp.x + 0.5);  // util::round2int_positive: float + 0.5 (double)
         const int y = (int)((double)cp.y + 0.5);
         const float tx = -m.y, ty = m.x;
@@ -1041,7 +1070,7 @@ __global__ __launch_bounds__(256) void k_join_histo(KlSoA *kls, const int32_t *_
         if (j >= 0) atomicMax(&k.p_id[j], i);
         // histogram position, edge_finder.cpp:392
         const float mxd = sq->nm_max, mnd = sq->nm_min;
-        int b = x86_cvttss2si((float)nbins * (mxd - k.n_m[i]) / (mxd - mnd));
+        int b = x86_cvttss2si((float)nbins * (mxd - nm_i) / (mxd - mnd));
         b = b > nbins - 1 ? nbins - 1 : b;
         b = b < 0 ? 0 : b;
         atomicAdd(&s_h[b], 1);
@@ -1139,8 +1168,8 @@ int stage_a_enqueue(edgehip_ctx *c, int slot) {
         }
         if (int e = stage_a_fused_enqueue(c, slot, rgb_base, rgb_idx, grey16)) return e;
         ProfScope ps(c, PROF_A_JOIN, st);
-        hipLaunchKernelGGL(k_join_histo<true>, dim3((pl.cap + 255) / 256, 1, B), dim3(256), 0, st, kldev(c, slot),
-                           maskof(c, slot), c->seqa, c->histo, w, n, c->p.qcut_nbins);
+        hipLaunchKernelGGL((k_join_histo<true, true>), dim3((pl.cap + 255) / 256, 1, B), dim3(256), 0, st, kldev(c, slot),
+                           maskof(c, slot), c->seqa, c->histo, w, n, c->p.qcut_nbins, c->slot_cam[slot].ppx, c->slot_cam[slot].ppy);
         EH_LAUNCH_CHECK();
         hipLaunchKernelGGL(k_retune, dim3(B), dim3(256), 0, st, c->seqa, c->histo,
                            c->retuned_slot + (size_t)slot * B, B, c->p.track_points,

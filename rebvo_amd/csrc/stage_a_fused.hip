@@ -102,29 +102,42 @@ __device__ __forceinline__ v2f ring_row_general(TapRing<L> &H, int P, v2f vr, v2
 // build_mask's plane fit on the 5x5 DoG window (edge_finder.cpp:139-159) from the LDS ring: ro[k] = element offset of
 // window row k, x = column.  Same operation order as k_detect (TooN dot product, k = 0..24).
 struct FitOut { bool cand; float mx, my, xs, ys; };
-__device__ __forceinline__ FitOut plane_fit5(const float *s_dog, const int ro[5], int x, const FusedArgs &a, float thr_d) {
-    double t0 = 0, t1 = 0, t2 = 0;
-    const double *__restrict__ pinv = a.pinv;
-    double pc0[5], pc1[5];
+// The 11 coefficients of the pseudo inverse that are not zero / not repeated (row 0 depends on the window column only, row 1
+// on the window row, row 2 is constant: checked at create), loaded ONCE by the wave that fits — a load inside the fit would
+// sit in the chunk loop behind an s_waitcnt vmcnt(0), i.e. behind every KeyLine store still in flight.
+struct FitCoef { double pc0[5], pc1[5], pc2; };
+__device__ __forceinline__ FitCoef load_fit_coef(const double *__restrict__ pinv) {
+    FitCoef c;
 #pragma unroll
-    for (int j = 0; j < 5; j++) { pc0[j] = pinv[j]; pc1[j] = pinv[25 + 5 * j]; }
-    const double pc2 = pinv[50];
+    for (int j = 0; j < 5; j++) { c.pc0[j] = pinv[j]; c.pc1[j] = pinv[25 + 5 * j]; }
+    c.pc2 = pinv[50];
+    return c;
+}
+// The window is loaded (fit_load) and evaluated (fit_eval) separately so that the fit wave can request the next chunk's 25
+// values before it evaluates the current one: it is a single wave, nobody else hides its LDS round trips.
+__device__ __forceinline__ void fit_load(const float *s_dog, const int ro[5], int x, float (&v)[25]) {
+#pragma unroll
+    for (int i = 0; i < 5; i++)
+#pragma unroll
+        for (int j = 0; j < 5; j++) v[i * 5 + j] = s_dog[ro[i] + x + j - 2];
+}
+__device__ __forceinline__ FitOut fit_eval(const float (&v)[25], const FitCoef &fc, float thr_d) {
+    double t0 = 0, t1 = 0, t2 = 0;
+    const double (&pc0)[5] = fc.pc0;
+    const double (&pc1)[5] = fc.pc1;
+    const double pc2 = fc.pc2;
 #pragma unroll
     for (int i = 0; i < 5; i++) {
-        float v[5];                                     // one window row at a time: 25 values in flight cost too many registers
-#pragma unroll
-        for (int j = 0; j < 5; j++) v[j] = s_dog[ro[i] + x + j - 2];
 #pragma unroll
         // The middle column of row 0 and the middle row of row 1 are exactly zero (fused_supported checks it): a product with
         // them is +-0, and adding that changes nothing — a partial sum is never -0 (it starts at +0, and x + (-x) = +0) — so those
-        // ten terms are skipped; the sums keep their bits.
+        // ten terms are skipped; the sums keep their bits.  Same operation order as k_detect (TooN dot product, k = 0..24).
         for (int j = 0; j < 5; j++) {
-            const double yv = (double)v[j];
+            const double yv = (double)v[i * 5 + j];
             if (j != 2) t0 += pc0[j] * yv;
             if (i != 2) t1 += pc1[i] * yv;
             t2 += pc2 * yv;
         }
-        __builtin_amdgcn_sched_barrier(0);
     }
     FitOut o;
     o.cand = false;
@@ -169,7 +182,7 @@ __global__ __launch_bounds__(512) void k_stage_a_fused(FusedArgs a) {
     // wave-uniform by construction; telling the compiler so moves everything derived from it (list / result pointers, clipping
     // flags, column offsets of the wave) from vector to scalar registers
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int NW = (blockDim.x >> 6) - 1;               // column waves (128 columns each)
+    const int NW = W ? (W + 127) / 128 : (int)(blockDim.x >> 6) - 2;   // column waves (128 columns each); + the scan wave + the fit wave
     const int seq = blockIdx.x;
     const size_t so = (size_t)seq * a.n;
 
@@ -178,17 +191,17 @@ __global__ __launch_bounds__(512) void k_stage_a_fused(FusedArgs a) {
     float *s_lut = s_dog + (size_t)RING * WP + 32;                  // [kDivLutMax]   (+32: read overrun of the last scanned row)
     float *s_edge = s_lut + kDivLutMax;                             // [RB][NW][2] img0 at the first / last column of every wave
     int *s_sedge = reinterpret_cast<int *>(s_edge + (size_t)RB * NW * 2);   // [RB][NW][2] DoG sign bits of the first / last column pair of every wave
-    int *s_cnt = s_sedge + RB * NW * 2;                              // [RB*NW] final candidates per (row, wave), raster order
-    float *s_red = reinterpret_cast<float *>(s_cnt + RB * NW);      // [2][NW] n_m extremes, then the frame's candidate count
-    uint16_t *s_list = reinterpret_cast<uint16_t *>(s_red + 2 * NW + 2);     // [NW][RB*128] per-wave candidate lists
-    uint16_t *s_res = s_list + (size_t)NW * RB * 128;               // [NW][RB*128] id + 1 of the KeyLine at a tested pixel, 0 = none
-    float4 *s_fin = reinterpret_cast<float4 *>(s_res + (size_t)NW * RB * 128);   // [NW][64] plane-fit results of a wave's first 64 finals
-
+    float *s_red = reinterpret_cast<float *>(s_sedge + RB * NW * 2);   // [4] n_m extremes, the frame's candidate count (end of frame)
+    // candidate bits of a tick's tested rows, published by the column waves for the fit wave: [2 (tick parity)][RB][NW] x
+    // {even columns, odd columns} of the wave's 128 columns
+    unsigned long long *s_bits = reinterpret_cast<unsigned long long *>(s_red + 4);
+    uint16_t *s_clist = reinterpret_cast<uint16_t *>(s_bits + (size_t)2 * RB * NW * 2);   // [RB*NW*128] the fit wave's candidate list (row << 10 | x)
+    uint16_t *s_res = s_clist + (size_t)NW * RB * 128;              // [2 (tick parity)][RB][NW*128] id + 1 of the KeyLine at a tested pixel, 0 = none
     // ---- set-up -------------------------------------------------------------------------------------------------------
     for (int i = tid; i < 2 * 4 * RB * PAD; i += blockDim.x) s_set[(size_t)(i / PAD) * WP + (i % PAD)] = 0.f;   // left pads: taps left of column 0
     for (int i = tid; i < kDivLutMax - 2; i += blockDim.x) s_lut[i] = a.lut[i];   // (indices reach 15 * 15; the last two entries carry the threshold, below)
-    for (int i = tid; i < NW * RB * 128; i += blockDim.x) s_res[i] = 0;
-    for (int i = tid; i < RB * NW; i += blockDim.x) s_cnt[i] = 0;
+    for (int i = tid; i < 2 * NW * RB * 128; i += blockDim.x) s_res[i] = 0;
+    for (int i = tid; i < 2 * RB * NW * 2; i += blockDim.x) s_bits[i] = 0ull;
     for (int i = tid; i < 256; i += blockDim.x) a.histo[(size_t)seq * 256 + i] = 0;   // reEstimateThresh's histogram (k_join_histo fills it)
     SeqA *sq = a.seq + seq;
     // wave-uniform floats are computed by the vector ALU and would sit in (scarce) vector registers: readfirstlane moves them
@@ -210,12 +223,20 @@ __global__ __launch_bounds__(512) void k_stage_a_fused(FusedArgs a) {
 
     // number of ticks: the tests of tick t cover rows (t-6)*RB - LB - 2 + [0, RB), their KeyLines are emitted in tick t+1
     const int t_last = 6 + (h - 1 + LB + 2) / RB;                   // tick that tests row h-1
-    const int nticks = (t_last + 2 + 1) & ~1;                       // the tick loop is unrolled by two
+    // + 1: the fit wave works on its rows, + 2: the column waves write their img_mask_kl rows; the tick loop is unrolled by two
+    const int nticks = (t_last + 3 + 1) & ~1;
 
-    // The scan wave is wave 3 when there are that many: waves go to the four SIMDs of a CU round-robin, so with up to 7 waves it
-    // has SIMD 3 to itself and its add chain (one dependent VALU instruction after the other, at raised priority) does not
-    // starve a column wave, which every other wave would then wait for at the barriers.
-    const int scan_wave = NW >= 3 ? 3 : NW;
+    // Who shares a SIMD with whom (waves go to the four SIMDs of a CU round-robin).  The scan wave (a dependent add chain at
+    // raised priority) and the fit wave (one wave's worth of serial fp64) are the two long poles of a tick next to the column
+    // waves; put on the same SIMD (scan = wave 3, fit = wave 7) they pay for each other's issue slots, so the scan wave is
+    // wave 2: SIMD 2 = scan + a column wave, SIMD 3 = a column wave + fit, SIMDs 0 / 1 two column waves each (-2 %, same box).
+#ifndef EDGEHIP_FUSED_SCANW
+#define EDGEHIP_FUSED_SCANW 2
+#endif
+#ifndef EDGEHIP_FUSED_FITPRIO
+#define EDGEHIP_FUSED_FITPRIO 2
+#endif
+    const int scan_wave = NW >= EDGEHIP_FUSED_SCANW ? EDGEHIP_FUSED_SCANW : NW;
     if (wave == scan_wave) {
         // ---- the scan wave: the serial left-to-right prefix of iimage::load (iimage.cpp:56-61) for the 4 RB rows of the buffer
         // set (plane-major, RB rows per plane), in place.  The adds of a row are one dependent chain (~7 cycles each,
@@ -307,6 +328,134 @@ __global__ __launch_bounds__(512) void k_stage_a_fused(FusedArgs a) {
             lds_barrier();
         }
 #undef EH_BC
+    } else if (wave == NW + 1) {
+        // ---- the fit wave: the sparse part of build_mask (edge_finder.cpp:139-209), one tick behind the column waves ----------
+        // Of the ~360 k pixels of a frame ~25 k pass the gradient gate and the sign balance and ~13 k become KeyLines.  Inside the
+        // column waves that work ran at a third of the lanes (each wave compacting, fitting and emitting its own 128 columns) and
+        // dragged the id bookkeeping of six waves with it; here ONE wave sees all candidates of the tick's RB rows in raster
+        // order: list from the published bits, fp64 plane fits 64 at a time, ids as a running count (the KeyLine id IS the raster
+        // rank, edge_finder.cpp:166-200 — no cross-wave scan), KeyLine records and the tested rows of img_mask_kl.  Nothing of
+        // this is on the column waves' critical path any more; the wave shares its SIMD with the scan wave, whose dependent add
+        // chain leaves the issue slots free.
+        int total = 0;                              // KeyLine candidates of the frame so far
+        float nm_mx = 0.f, nm_mn = __int_as_float(0x7f800000);
+        // the three arrays the wave stores to, and the fit's coefficients: fetched once, before the tick loop (inside it every
+        // load would wait for the KeyLine stores in flight: vmcnt counts loads and stores alike)
+        const KlSoA &klr = a.kl[seq];
+        int32_t *const k_pinx = klr.p_inx;
+        int32_t *const k_pid = klr.p_id;
+        float4 *const k_grec = klr.grec;
+        const FitCoef fc = load_fit_coef(a.pinv);
+        const int WRES = NW * 128;                  // row stride of s_res
+        __builtin_amdgcn_s_setprio(EDGEHIP_FUSED_FITPRIO);   // behind the scan wave's chain, ahead of the column waves
+        auto below = [&](unsigned long long m) __attribute__((always_inline)) {   // set bits of a wave mask below this lane
+            return (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
+        };
+        for (int t = 0; t < nticks; t++) {
+            // the rows tested in tick t-1: ytest0 + [0, RB); their 5x5 DoG windows sit in ring slots rq - 4 .. rq + RB - 1 with
+            // rq = slot of tick t-1's first DoG row, untouched by the rows tick t writes (slots rq + RB ..)
+            const int ytest0 = (t - 7) * RB - LB - 2;
+            const bool live = t >= 1 && ytest0 + RB - 1 >= 0 && ytest0 < h && !(ABL & 8);
+            int rq = ((t - 1) * RB) % RING;
+            rq += rq < 0 ? RING : 0;
+            int ncand = 0;
+            if (live) {
+                // raster order: row, then wave, then column.  With a compile-time width the loop unrolls and the RB * NW bit
+                // pairs are requested up front (one LDS round trip instead of one per segment); everything stays in the
+                // vector ALU (v_mbcnt / v_bcnt take the wave-uniform words from vector registers).
+                const unsigned long long *bits = s_bits + (size_t)((t - 1) & 1) * RB * NW * 2;
+                auto segment = [&](int sgm, int i, int xb) __attribute__((always_inline)) {
+                    const unsigned long long b0 = bits[2 * sgm], b1 = bits[2 * sgm + 1];   // wave-uniform
+                    const bool p0 = (b0 >> lane) & 1ull, p1 = (b1 >> lane) & 1ull;
+                    const int pos = ncand + below(b0) + below(b1);
+                    if (p0) s_clist[pos] = (uint16_t)((i << 10) | (xb + 2 * lane));
+                    if (p1) s_clist[pos + (p0 ? 1 : 0)] = (uint16_t)((i << 10) | (xb + 2 * lane + 1));
+                    ncand += __popcll(b0) + __popcll(b1);
+                };
+                if (W) {
+                    constexpr int CNW = W ? (W + 127) / 128 : 1;
+#pragma unroll
+                    for (int sgm = 0; sgm < RB * CNW; sgm++) segment(sgm, sgm / CNW, (sgm % CNW) * 128);
+                } else {
+                    for (int sgm = 0; sgm < RB * NW; sgm++) { const int i = sgm / NW; segment(sgm, i, (sgm - i * NW) * 128); }
+                }
+            }
+            if (ABL & 64) ncand = 0;                // (timing experiments: 64 no fits / emission, 128 no emission, 256 no plane fit)
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+            __builtin_amdgcn_wave_barrier();
+            const int nchunks = (ncand + 63) >> 6;
+            // Software pipeline over the chunks of 64 candidates: while chunk c is evaluated, the 25 window values of chunk
+            // c+1 and the list entries of chunk c+2 are on their way (LDS returns a wave's requests in order).
+            float wv_cur[25], wv_nxt[25];
+            int code_cur = 0, code_nxt = 0, code_nn = 0;
+            auto code_of = [&](int c) __attribute__((always_inline)) {
+                const int li = c * 64 + lane;
+                return li < ncand ? (int)s_clist[li] : 2;    // row 0, column 2: an address that exists
+            };
+            auto request = [&](int code, float (&v)[25]) __attribute__((always_inline)) {
+                const int i = code >> 10, x = code & 1023;
+                int ro[5];
+                int s0 = rq + i - 4;                    // slot of y_i - 2
+                s0 += s0 < 0 ? RING : 0;
+#pragma unroll
+                for (int k = 0; k < 5; k++) {
+                    int sk = s0 + k;
+                    sk -= sk >= RING ? RING : 0;
+                    ro[k] = sk * WP + PAD;
+                }
+                fit_load(s_dog, ro, x, v);
+            };
+            if (nchunks > 0) {
+                code_cur = code_of(0);
+                code_nxt = code_of(1);
+                request(code_cur, wv_cur);
+            }
+            auto chunks = [&](int c0, int c1) __attribute__((always_inline)) {
+                for (int c = c0; c < c1; c++) {
+                    if (c + 1 < nchunks) request(code_nxt, wv_nxt);
+                    code_nn = code_of(c + 2);
+                    __builtin_amdgcn_sched_barrier(0);
+                    const bool on = c * 64 + lane < ncand;
+                    const int code = code_cur;
+                    const int i = code >> 10, x = code & 1023;
+                    FitOut f;
+                    if (ABL & 256) { f.cand = (code & 1) != 0; f.mx = 3.f; f.my = 4.f; f.xs = 0.f; f.ys = 0.f; }
+                    else f = fit_eval(wv_cur, fc, thr_d);
+                    const bool fin = on && f.cand;
+                    const unsigned long long bal = __ballot(fin);
+                    const int id = total + below(bal);
+                    if (fin && id < a.kl_max && !(ABL & 128)) {
+                        // KeyLine `id` (edge_finder.cpp:166-200): what the fit produced; k_join_histo<true, true> derives the rest
+                        const int y = ytest0 + i;
+                        k_pinx[id] = y * w + x;
+                        k_grec[id] = make_float4(f.xs, f.ys, f.mx, f.my);
+                        k_pid[id] = -1;        // join_edges' atomicMax needs it before any thread of k_join_histo runs
+                        const float n2m = f.mx * f.mx + f.my * f.my;   // n_m = sqrtf(n2m) is monotonic in n2m: extremes of n2m here,
+                        nm_mx = fmaxf(nm_mx, n2m);                     // one square root at the end of the frame
+                        nm_mn = fminf(nm_mn, n2m);
+                        s_res[((t & 1) * RB + i) * WRES + x] = (uint16_t)(id + 1);
+                    }
+                    total += __popcll(bal);
+                    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                    for (int k = 0; k < 25; k++) wv_cur[k] = wv_nxt[k];
+                    code_cur = code_nxt;
+                    code_nxt = code_nn;
+                }
+            };
+            const int half = nchunks >> 1;
+            chunks(0, half);
+            lds_barrier();
+            chunks(half, nchunks);
+            lds_barrier();
+        }
+        // end of frame: reEstimateThresh's extremes (edge_finder.cpp:376-382) and the candidate count
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) {
+            nm_mx = fmaxf(nm_mx, __shfl_xor(nm_mx, o, 64));
+            nm_mn = fminf(nm_mn, __shfl_xor(nm_mn, o, 64));
+        }
+        if (lane == 0) { s_red[0] = sqrtf(nm_mx); s_red[1] = sqrtf(nm_mn); s_red[2] = __int_as_float(total); }
     } else {
     // ---- column waves ---------------------------------------------------------------------------------------------------
     const int wv = wave < scan_wave ? wave : wave - 1;   // 0..NW-1
@@ -366,119 +515,26 @@ __global__ __launch_bounds__(512) void k_stage_a_fused(FusedArgs a) {
     const uint8_t *frame = GREY16 ? reinterpret_cast<const uint8_t *>(a.grey16 + (size_t)seq * a.n)
                                   : a.rgb + (size_t)(a.fidx ? a.fidx[seq] : seq) * a.n * 3;
 
-    uint16_t *my_list = s_list + (size_t)wv * RB * 128;
-    uint16_t *my_res = s_res + (size_t)wv * RB * 128;
-    float4 *my_fin = s_fin + (size_t)wv * 64;
-    int nfinal = 0;                             // final candidates of the previous tick in my_list
-    int total = 0;                              // KeyLine candidates of the frame so far (workgroup-uniform)
     int rq0 = 0;                                // ring slot of this tick's first DoG row
-    int rq_prev = 0;
-    float nm_mx = 0.f, nm_mn = __int_as_float(0x7f800000);
     int32_t *mask = a.mask + so;
-    const KlSoA &kl = a.kl[seq];
     float *pl = DBG && a.planes ? a.planes + so : nullptr;
     const size_t pstride = (size_t)a.nseq * a.n;
-    // number of set bits of a wave mask below this lane (v_mbcnt: no lane-mask register to keep)
-    auto below = [&](unsigned long long m) __attribute__((always_inline)) {
-        return (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
-    };
-
-    // element offsets (from s_dog) of the 5x5 window rows y_i-2 .. y_i+2 of test row i, for the tick whose first DoG row
-    // sits in ring slot rq
-    auto window_rows = [&](int rq, int i, int ro[5]) {
-        int s0 = rq + i - 4;                    // slot of y_i - 2 = (last DoG row of the tick) - (RB - 1 - i) - 4
-        s0 += s0 < 0 ? RING : 0;
-#pragma unroll
-        for (int k = 0; k < 5; k++) {
-            int sk = s0 + k;
-            sk -= sk >= RING ? RING : 0;
-            ro[k] = sk * WP + PAD;
-        }
-    };
 
     auto tick = [&](const int t, auto tt_tag) __attribute__((always_inline)) {
         constexpr int TT = decltype(tt_tag)::value;     // t & 1: the buffer set, and the half of the long tap rings this tick writes
         constexpr int set = TT;
-        // ================= phase 1a: KeyLines of the rows tested in tick t-1, and those rows of img_mask_kl ==============
+        // ================= phase 1a: img_mask_kl rows of the rows tested in tick t-2 ====================================
+        // (the fit wave put the ids of their KeyLines into s_res during tick t-1), written once: KeyLine id or -1
+        // (edge_finder.cpp:109, 198, 203-209)
         {
-            const int ytest0 = (t - 7) * RB - LB - 2;           // first row tested in tick t-1
-            if (ytest0 + RB - 1 >= 0 && ytest0 < h && !(ABL & 8)) {
-                // ids: running total + exclusive prefix of the (row, wave) segment counts in raster order.  The counts are few
-                // (RB * NW <= 64, one per lane): a DPP scan over the lanes (six vector instructions, no LDS round trips), then
-                // the wave's own RB offsets and counts come out as scalars (v_readlane at lane row * NW + wave).
-                const int nseg = RB * NW;
-                const int c = lane < nseg ? s_cnt[lane] : 0;
-                int inc = c;
-                inc += __builtin_amdgcn_update_dpp(0, inc, 0x111, 0xf, 0xf, true);    // row_shr:1, zeros shifted in
-                inc += __builtin_amdgcn_update_dpp(0, inc, 0x112, 0xf, 0xf, true);    // row_shr:2
-                inc += __builtin_amdgcn_update_dpp(0, inc, 0x114, 0xf, 0xf, true);    // row_shr:4
-                inc += __builtin_amdgcn_update_dpp(0, inc, 0x118, 0xf, 0xf, true);    // row_shr:8  -> inclusive scan inside each row of 16
-                inc += __builtin_amdgcn_update_dpp(0, inc, 0x142, 0xa, 0xf, false);   // row_bcast:15 into rows 1 and 3
-                inc += __builtin_amdgcn_update_dpp(0, inc, 0x143, 0xc, 0xf, false);   // row_bcast:31 into rows 2 and 3
-                const int exc = inc - c;
-                int offs[RB], myc[RB];
+            const int ym0 = (t - 8) * RB - LB - 2;
+            if (ym0 + RB - 1 >= 0 && ym0 < h && !(ABL & 8)) {
+                uint32_t *rp = reinterpret_cast<uint32_t *>(s_res + (size_t)(((t - 1) & 1) * RB) * (NW * 128) + wv * 128) + lane;
 #pragma unroll
                 for (int i = 0; i < RB; i++) {
-                    offs[i] = __builtin_amdgcn_readlane(exc, i * NW + wv);
-                    myc[i] = __builtin_amdgcn_readlane(c, i * NW + wv);
-                }
-                const int run = __builtin_amdgcn_readlane(inc, nseg - 1);
-                const int tick_total = run;
-                for (int base = 0; base < nfinal; base += 64) {
-                    const int e = base + lane;
-                    const bool on = e < nfinal;
-                    const int code = on ? my_list[e] : 0;
-                    const int i = code >> 7, xin = code & 127;
-                    // rank inside the segment: the list is segment-ordered, so e minus the entries of the wave's earlier rows
-                    int off = offs[0], before = 0;
-#pragma unroll
-                    for (int i2 = 1; i2 < RB; i2++) {
-                        before = i2 <= i ? before + myc[i2 - 1] : before;
-                        off = i2 <= i ? offs[i2] : off;
-                    }
-                    const int id = total + off + (e - before);
-                    if (on && id < a.kl_max) {
-                        int ro[5];
-                        window_rows(rq_prev, i, ro);
-                        const int x = wv * 128 + xin, y = ytest0 + i;
-                        // the plane fit of the wave's first 64 finals was kept in LDS; later ones (rare) are fitted again
-                        FitOut f;
-                        if (base == 0) { const float4 q = my_fin[lane]; f.mx = q.x; f.my = q.y; f.xs = q.z; f.ys = q.w; }
-                        else f = plane_fit5(s_dog, ro, x, a, thr_d);
-                        // KeyLine `id` (edge_finder.cpp:166-200)
-                        const int p = y * w + x;
-                        const float n2m = f.mx * f.mx + f.my * f.my;
-                        const float nm = sqrtf(n2m);
-                        const float2 mm = make_float2(f.mx, f.my);
-                        const float2 u = make_float2(f.mx / nm, f.my / nm);
-                        const float2 cp = make_float2((float)x + f.xs, (float)y + f.ys);
-                        const float2 pm = make_float2(cp.x - a.ppx, cp.y - a.ppy);      // cam_model::Img2Hom
-                        kl.p_inx[id] = p;
-                        kl.m_m[id] = mm;
-                        kl.n_m[id] = nm;
-                        kl.u_m[id] = u;
-                        kl.c_p[id] = cp;
-                        kl.p_m[id] = pm;
-                        kl.p_m_0[id] = pm;
-                        kl.p_id[id] = -1;        // the other constant fields of a new KeyLine: k_join_histo<true>
-                        MatchRec rec;
-                        rec.c_px = cp.x; rec.c_py = cp.y; rec.u_mx = u.x; rec.u_my = u.y;
-                        rec.m_mx = mm.x; rec.m_my = mm.y; rec.n_m = nm; rec.pad = 0.f;
-                        kl.rec[id] = rec;
-                        kl.grec[id] = make_float4(cp.x, cp.y, mm.x, mm.y);
-                        nm_mx = fmaxf(nm_mx, nm);
-                        nm_mn = fminf(nm_mn, nm);
-                        my_res[i * 128 + xin] = (uint16_t)(id + 1);
-                    }
-                }
-                total += tick_total;
-                // the tested rows of img_mask_kl, written once: KeyLine id or -1 (edge_finder.cpp:109, 198, 203-209)
-#pragma unroll
-                for (int i = 0; i < RB; i++) {
-                    const int y = ytest0 + i;
-                    uint32_t *rp = reinterpret_cast<uint32_t *>(my_res + i * 128) + lane;
-                    const uint32_t r2 = *rp;
-                    *rp = 0;
+                    const int y = ym0 + i;
+                    const uint32_t r2 = rp[i * (NW * 64)];
+                    rp[i * (NW * 64)] = 0;
                     if (y >= 0 && y < h && act)
                         *reinterpret_cast<int2 *>(mask + (uint32_t)(y * w + x0)) = make_int2((int)(r2 & 0xFFFFu) - 1, (int)(r2 >> 16) - 1);
                 }
@@ -621,53 +677,20 @@ __global__ __launch_bounds__(512) void k_stage_a_fused(FusedArgs a) {
         }
         iv[0] = iv[RB];
         iv[1] = iv[RB + 1];
-        // build_mask's window tests on rows ydog0 - 2 + i, i = 0..RB-1 (their DoG windows are complete)
+        // build_mask's gates on rows ydog0 - 2 + i, i = 0..RB-1 (their DoG windows are complete with this tick's rows): the
+        // survivors of the gradient gate and the sign balance go to the fit wave as one bit per pixel — the sparse rest of
+        // build_mask (plane fit, sub-pixel test, ids, KeyLines, mask rows) runs there at full lanes, one tick behind
         if (!(ABL & 4)) {
-            int nlist = 0;
 #pragma unroll
             for (int i = 0; i < RB; i++) {
                 // gradient gate of row y_i (bit 2 + RB-1-i) and sign balance of its window (complete with the newest row: bit RB-1-i)
                 const bool p0 = (gbits0 >> (2 + RB - 1 - i)) & (bbits0 >> (RB - 1 - i)) & 1u, p1 = (gbits1 >> (2 + RB - 1 - i)) & (bbits1 >> (RB - 1 - i)) & 1u;
                 const unsigned long long b0 = __ballot(p0), b1 = __ballot(p1);
-                const int pos = nlist + below(b0) + below(b1);     // raster order: (lane, column of the pair)
-                if (p0) my_list[pos] = (uint16_t)((i << 7) | (lane << 1));
-                if (p1) my_list[pos + (p0 ? 1 : 0)] = (uint16_t)((i << 7) | (lane << 1) | 1);
-                nlist += __popcll(b0) + __popcll(b1);
-            }
-            const int nkeep = nlist;
-            // plane fit, sub-pixel position, DoG-gradient gate (:139-159): keep the finals, count them per row
-            int nfin = 0;
-            int cnt[RB];
-#pragma unroll
-            for (int i = 0; i < RB; i++) cnt[i] = 0;
-            for (int base = 0; base < nkeep; base += 64) {
-                const int li = base + lane;
-                bool cand = false;
-                int code = 0;
-                float4 fo = make_float4(0.f, 0.f, 0.f, 0.f);
-                if (li < nkeep) {
-                    code = my_list[li];
-                    const int i = code >> 7, x = wv * 128 + (code & 127);
-                    int ro[5];
-                    window_rows(rq0, i, ro);
-                    const FitOut f = plane_fit5(s_dog, ro, x, a, thr_d);
-                    cand = f.cand;
-                    fo = make_float4(f.mx, f.my, f.xs, f.ys);
+                if (lane == 0) {
+                    unsigned long long *q = s_bits + ((size_t)(set * RB + i) * NW + wv) * 2;
+                    q[0] = b0;
+                    q[1] = b1;
                 }
-                const unsigned long long bal = __ballot(cand);
-                if (cand) {
-                    const int pos = nfin + below(bal);
-                    my_list[pos] = (uint16_t)code;
-                    if (pos < 64) my_fin[pos] = fo;
-                }
-                nfin += __popcll(bal);
-#pragma unroll
-                for (int i = 0; i < RB; i++) cnt[i] += __popcll(__ballot(cand && (code >> 7) == i));
-            }
-            nfinal = nfin;
-            if (lane == 0) {
-#pragma unroll
-                for (int i = 0; i < RB; i++) s_cnt[i * NW + wv] = cnt[i];
             }
         }
         if (act) {   // grey of batch t -> plane 0 of the buffer set (b+g+r, image.h:197-203: integers, exact in float)
@@ -690,7 +713,6 @@ __global__ __launch_bounds__(512) void k_stage_a_fused(FusedArgs a) {
                 *reinterpret_cast<v2f *>(Q0 + j * WP) = g;
             }
         }
-        rq_prev = rq0;
         rq0 += RB;
         rq0 -= rq0 >= RING ? RING : 0;
         lds_barrier();
@@ -700,20 +722,11 @@ __global__ __launch_bounds__(512) void k_stage_a_fused(FusedArgs a) {
         tick(t + 1, std::integral_constant<int, 1>{});
     }
 
-    // ---- end of frame: reEstimateThresh's extremes (edge_finder.cpp:376-382) and the candidate count -----------------------
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) {
-        nm_mx = fmaxf(nm_mx, __shfl_xor(nm_mx, o, 64));
-        nm_mn = fminf(nm_mn, __shfl_xor(nm_mn, o, 64));
-    }
-    if (lane == 0) { s_red[wv] = nm_mx; s_red[NW + wv] = nm_mn; }
-    if (wv == 0 && lane == 0) s_red[2 * NW] = __int_as_float(total);
     }   // column waves
     __syncthreads();
-    if (tid == 0) {   // kn and the P-controller state (edge_finder.cpp:355-364)
-        float nm_mx = s_red[0], nm_mn = s_red[NW];
-        for (int i = 1; i < NW; i++) { nm_mx = fmaxf(nm_mx, s_red[i]); nm_mn = fminf(nm_mn, s_red[NW + i]); }
-        const int total = __float_as_int(s_red[2 * NW]);
+    if (tid == 0) {   // kn and the P-controller state (edge_finder.cpp:355-364); reEstimateThresh's extremes (:376-382)
+        const float nm_mx = s_red[0], nm_mn = s_red[1];
+        const int total = __float_as_int(s_red[2]);
         const int kn = total < a.kl_max ? total : a.kl_max;
         const double tresh = __hiloint2double(__float_as_int(s_lut[kDivLutMax - 1]), __float_as_int(s_lut[kDivLutMax - 2]));   // update_thresh, computed at the top
         sq->tresh = tresh;
@@ -734,8 +747,8 @@ static int fused_col_waves(int w) { return (w + 127) / 128; }
 
 size_t fused_lds_bytes(int w) {
     const int nw = fused_col_waves(w), WP = fused_row_stride(w), RB = kFusedRB;
-    const size_t fl = (size_t)2 * 4 * RB * WP + (size_t)(2 * RB + 4) * WP + 32 + kDivLutMax + (size_t)RB * nw * 4 + RB * nw + 2 * nw + 2;
-    return fl * 4 + (size_t)2 * nw * RB * 128 * 2 + (size_t)nw * 64 * 16;
+    const size_t fl = (size_t)2 * 4 * RB * WP + (size_t)(2 * RB + 4) * WP + 32 + kDivLutMax + (size_t)RB * nw * 4 + 4;   // all even counts: s_bits is 8-byte aligned
+    return fl * 4 + (size_t)2 * RB * nw * 2 * 8 + (size_t)3 * nw * RB * 128 * 2;
 }
 
 bool fused_supported(const edgehip_ctx *c) {
@@ -745,8 +758,8 @@ bool fused_supported(const edgehip_ctx *c) {
     if (c->p.plane_fit_size != 2) return false;
     if (c->pinv_host[2] != 0.0 || c->pinv_host[25 + 10] != 0.0) return false;   // plane_fit5 skips these terms
     const int nw = fused_col_waves(pl.w);
-    if (nw + 1 > 8) return false;                           // 256 VGPRs per thread need <= 8 waves per workgroup
-    if (kFusedRB * nw > 64) return false;                   // one lane per (row, wave) segment in the id scan
+    if (nw + 2 > 8) return false;                           // column waves + scan wave + fit wave; 256 VGPRs per thread need <= 8 waves per workgroup
+    if (pl.w > 1023) return false;                          // candidate codes carry x in 10 bits
     if (pl.cap > 65534) return false;                       // ids travel through LDS as uint16
     return fused_lds_bytes(pl.w) <= 160 * 1024;
 }
@@ -804,7 +817,7 @@ int stage_a_fused_enqueue(edgehip_ctx *c, int slot, const uint8_t *rgb_base, con
     }
     {
         ProfScope ps(c, PROF_A_FUSED, c->stream_a);
-        hipLaunchKernelGGL(fn, dim3(B), dim3((nw + 1) * 64), sm, c->stream_a, a);
+        hipLaunchKernelGGL(fn, dim3(B), dim3((nw + 2) * 64), sm, c->stream_a, a);
         EH_LAUNCH_CHECK();
     }
     c->grec_ok[slot] = true;   // freshly detected KeyLines: u_m = m_m / |m_m| holds for all of them

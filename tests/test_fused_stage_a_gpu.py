@@ -26,7 +26,7 @@ def fused_mode():
         os.environ["EDGEHIP_LEVEL_MODE"] = old
 
 
-SIZES = [(192, 144), (200, 150), (752, 480), (376, 240), (640, 480), (100, 36), (896, 64), (64, 19), (16, 16)]
+SIZES = [(192, 144), (200, 150), (752, 480), (376, 240), (640, 480), (100, 36), (768, 64), (896, 64), (64, 19), (16, 16)]
 
 
 @pytest.mark.parametrize("w,h", SIZES, ids=[f"{w}x{h}" for w, h in SIZES])

@@ -3,7 +3,8 @@
 # code and the register allocation of what is left is the real one).  Build here (no GPU needed):
 #   tools/experiments/exp_fused_ablate.sh build
 # then on the GPU box:  tools/experiments/exp_fused_ablate.sh [nseq]
-# bits: 1 scan, 2 box chain, 4 window tests, 8 KeyLine emit + mask rows, 16 RGB loads, 32 gradient gate + sign balance
+# bits: 1 scan, 2 box chain, 4 gate bits to the fit wave, 8 fit wave + mask rows off, 16 RGB loads, 32 gradient gate + sign balance,
+#       64 fit wave: list only, 128 fit wave: no KeyLine emission, 256 fit wave: no plane fit
 VARIANTS=${VARIANTS:-"0 1 4 8 12 32 63 62"}
 ROOT=$(cd "$(dirname "$0")/../.." && pwd)
 if [ "$1" = build ]; then
