@@ -433,6 +433,7 @@ static int create_body(edgehip_ctx *c, CtxAllocs *al, const edgehip_params &p, i
     c->field_mode = getenv("EDGEHIP_FIELD_MODE") ? atoi(getenv("EDGEHIP_FIELD_MODE")) : 0;
     c->no_grec = getenv("EDGEHIP_NO_GREC") && atoi(getenv("EDGEHIP_NO_GREC")) != 0;
     c->level_mode = getenv("EDGEHIP_LEVEL_MODE") ? atoi(getenv("EDGEHIP_LEVEL_MODE")) : 0;
+    c->fwd_mode = getenv("EDGEHIP_FWD_MODE") ? atoi(getenv("EDGEHIP_FWD_MODE")) : 0;
     c->fused_min_batch = getenv("EDGEHIP_FUSED_MIN_BATCH") ? atoi(getenv("EDGEHIP_FUSED_MIN_BATCH")) : 192;   // one workgroup per sequence: pays from about 3/4 of the 256 CUs on (tools/experiments/ab_level_mode.sh)
     c->overlap = getenv("EDGEHIP_OVERLAP") ? atoi(getenv("EDGEHIP_OVERLAP")) : 0;
     c->persist_lm_max = getenv("EDGEHIP_PERSIST_LM") ? atoi(getenv("EDGEHIP_PERSIST_LM")) : 0;   // measured: no gain (tools/experiments/exp_single_latency.py), so off

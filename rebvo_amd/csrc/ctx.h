@@ -241,6 +241,9 @@ struct edgehip_ctx {
     unsigned *sync_cnt;    // [B] per-sequence block tickets of k_try_velrot_lm (0 between launches)
     unsigned long long *fwd_key;  // [B][CAP] forward-match arbitration keys
     int32_t *fwd_win;      // [B][CAP]
+    int fwd_mode = 0;              // EDGEHIP_FWD_MODE: 0 keys by the minimiser + k_fwd_win / k_fwd_apply / k_rotate, 1 the round-2 chain (own key pass),
+                                   // 2 keys by the minimiser + k_fwd_win + k_fwd_apply_rotate (one scattering pass over the old KeyLines)
+    bool fwd_key_in_tvr = false;   // whole-frame driver: the minimiser's last evaluation also posts FordwardMatch's arbitration keys
     double *rs_tmp;        // [B][2][CAP] regularised (rho, s_rho) ping-pong
     double *rot_buf;       // [B][9] rotation applied by rotate_keylines
     double *t_buf;         // [B] frame time stamps
@@ -309,6 +312,13 @@ void enter_ctx(edgehip_ctx *c);
         ::edgehip::enter_ctx(c);                                                            \
     } while (0)
 
+// monotone map double -> u64, never 0: FordwardMatch's "larger rho wins" as an integer atomicMax
+__host__ __device__ inline unsigned long long ord_bits(double v) {
+    unsigned long long b;
+    __builtin_memcpy(&b, &v, 8);
+    return (b >> 63) ? ~b : (b | 0x8000000000000000ull);
+}
+
 inline KlSoA &klof(edgehip_ctx *c, int slot, int seq) { return c->kl[(size_t)slot * c->plan.nseq + seq]; }
 inline KlSoA *kldev(edgehip_ctx *c, int slot) { return c->kl_dev + (size_t)slot * c->plan.nseq; }
 inline int32_t *maskof(edgehip_ctx *c, int slot) { return c->mask + (size_t)slot * c->plan.nseq * c->plan.n; }
@@ -354,7 +364,8 @@ int tvr_prepare_enqueue(edgehip_ctx *c, int slot_old);
 int minimizer_enqueue(edgehip_ctx *c, int slot_new, int slot_old, int fc_index);
 int minimizer_v_enqueue(edgehip_ctx *c, int slot_new, int slot_old, int fc_index, int iter_max, double match_thresh,
                          uint32_t match_num_thresh, double reweight_distance);
-int forward_match_enqueue(edgehip_ctx *c, int slot_old, int slot_new);
+int forward_match_enqueue(edgehip_ctx *c, int slot_old, int slot_new, bool keys_posted = false);
+int forward_rotate_enqueue(edgehip_ctx *c, int slot_old, int slot_new);   // FordwardMatch (keys already posted by the minimiser) + rotate_keylines(exp(W))
 int rotate_enqueue(edgehip_ctx *c, int slot, const double *R_host);
 int directed_enqueue(edgehip_ctx *c, int slot_new, int slot_old);
 int regekf_enqueue(edgehip_ctx *c, int slot, int do_reg, int do_ekf);

@@ -480,6 +480,8 @@ struct TvrArgs {
     uint32_t match_num_thresh;
     int write_mid;             // store kl.m_id_f (only the last evaluation of a minimisation needs to)
     int use_grec;   // host-side choice of the gather record (edgehip_ctx::grec_ok of the new slot)
+    unsigned long long *fwd_key;   // [B][CAP] or null: with write_mid, also post FordwardMatch's key of the matched new KeyLine
+                                   // (edge_tracker.cpp:413: the old KeyLine with the larger rho wins) — saves k_fwd_key's pass
     // KF instantiation (kfvo::TryVelRot): per-sequence scale ratio, the thresholds of Calc_f_J_Complete
     const edgehip_kf_request *kf;   // [B]
     double kf_match_mod, kf_match_cang, kf_rho_tol;
@@ -686,7 +688,10 @@ __device__ __forceinline__ void tvr_body(const TvrArgs &a, const int seq, const 
                 rout[ikl] = a.max_r;
             }
         }
-        if (a.write_mid && ikl < kn) ko.m_id_f[ikl] = mid_f;
+        if (a.write_mid && ikl < kn) {
+            ko.m_id_f[ikl] = mid_f;
+            if (!KF && a.fwd_key && mid_f >= 0) atomicMax(&a.fwd_key[(size_t)seq * a.cap + mid_f], ord_bits(ko.rho[ikl]));
+        }
 
         // ---- Jacobian row, uncertainty scaling (global_tracker.cpp:419-463) ----
         if (ikl < kn) {
@@ -1751,6 +1756,7 @@ static TvrArgs make_tvr_args(edgehip_ctx *c, int slot_new, int slot_old, double 
     a.ppx = pl.ppx; a.ppy = pl.ppy; a.match_num_thresh = match_num_thresh; a.write_mid = write_mid;
     a.use_grec = c->grec_ok[slot_new] && !c->no_grec;
     a.kf = nullptr; a.kf_match_mod = a.kf_match_cang = a.kf_rho_tol = 0;
+    a.fwd_key = (write_mid && c->fwd_key_in_tvr) ? c->fwd_key : nullptr;
     return a;
 }
 
@@ -1841,6 +1847,7 @@ int minimizer_enqueue(edgehip_ctx *c, int slot_new, int slot_old, int fc_index) 
     c->fc_index = fc_index;
     int e;
     if ((e = tvr_prepare_enqueue(c, slot_old))) return e;
+    if (c->fwd_key_in_tvr) EH_CHECK(hipMemsetAsync(c->fwd_key, 0, sizeof(unsigned long long) * (size_t)c->plan.nseq * c->plan.cap, c->stream));
     const int I = p.tracker_init_iter_num, M = p.tracker_iter_num;
     const int total_evals = (p.tracker_init_type >= 2 ? 2 * (1 + (I > 0 ? I : 0)) : 0) + 1 + (M > 0 ? M : 0);
     int evals = 0;

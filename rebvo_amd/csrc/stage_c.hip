@@ -30,11 +30,6 @@ namespace edgehip {
 
 constexpr double kRhoMax = 20.0, kRhoMin = 1e-3, kRhoInit = 1.0;  // edge_finder.h:38-40
 
-__device__ __forceinline__ unsigned long long ord_bits(double v) {
-    const unsigned long long b = (unsigned long long)__double_as_longlong(v);
-    return (b >> 63) ? ~b : (b | 0x8000000000000000ull);  // monotone map double -> u64, never 0
-}
-
 // ---------------------------------------------------------------------------------------------------
 // FordwardMatch
 // ---------------------------------------------------------------------------------------------------
@@ -113,6 +108,61 @@ __global__ __launch_bounds__(256) void k_rotate(const KlSoA *kls, const int32_t 
     k.m_m[i] = mr;
     k.rec[i].m_mx = mr.x;
     k.rec[i].m_my = mr.y;
+}
+
+// FordwardMatch's copy (edge_tracker.cpp:396-432) and rotate_keylines (:42-76) in ONE pass over the OLD KeyLines.  The
+// reference copies first (old values), then rotates the old list in place; a thread that owns old KeyLine i does both for
+// its own KeyLine: if it is the winner of its target (win[f] == i, decided by k_fwd_win before this launch) it scatters its
+// fields to the new KeyLine f, then it rotates itself — nobody else reads old[i] in this kernel, so there is no hazard, and
+// every old field is read once instead of by a gather pass (k_fwd_apply: ten 64-byte granules per matched KeyLine) plus a
+// streaming pass (k_rotate).  Same arithmetic, same order, same bits as the two kernels it replaces.
+__global__ __launch_bounds__(256) void k_fwd_apply_rotate(const KlSoA *kl_old, const KlSoA *kl_new, const int32_t *__restrict__ kn_old,
+                                                          const int32_t *__restrict__ kn_new, const int32_t *__restrict__ win,
+                                                          SeqDev *seqs, const double *__restrict__ Rin, double zf, int cap) {
+    const int seq = blockIdx.z, i = blockIdx.x * 256 + threadIdx.x;
+    int hit = 0;
+    if (i < kn_old[seq]) {
+        const KlSoA &o = kl_old[seq];
+        const int f = o.m_id_f[i];
+        const float2 pm = o.p_m[i];
+        const float2 m = o.m_m[i];
+        const double rho = o.rho[i], s_rho = o.s_rho[i];
+        if (f >= 0 && f < kn_new[seq] && win[(size_t)seq * cap + f] == i) {
+            const KlSoA &n = kl_new[seq];
+            n.rho[f] = rho;
+            n.s_rho[f] = s_rho;
+            n.rho_nr[f] = o.rho_nr[i];
+            n.s_rho_nr[f] = o.s_rho_nr[i];
+            n.m_num[f] = o.m_num[i] + 1;
+            n.m_id[f] = i;
+            n.p_m_0[f] = pm;
+            n.m_m0[f] = m;
+            n.n_m0[f] = (double)o.n_m[i];
+            n.m_id_kf[f] = o.m_id_kf[i];
+            hit = 1;
+        }
+        const double *R = Rin + (size_t)seq * 9;
+        const double v0 = (double)pm.x / zf, v1 = (double)pm.y / zf, v2 = 1;
+        double q0 = 0, q1 = 0, q2 = 0;  // TooN matrix*vector: row dot products accumulated from 0
+        q0 += R[0] * v0; q0 += R[1] * v1; q0 += R[2] * v2;
+        q1 += R[3] * v0; q1 += R[4] * v1; q1 += R[5] * v2;
+        q2 += R[6] * v0; q2 += R[7] * v1; q2 += R[8] * v2;
+        if (fabs(q2) > 0) {
+            o.p_m[i] = make_float2((float)(q0 / q2 * zf), (float)(q1 / q2 * zf));
+            o.rho[i] = rho / q2;
+            o.s_rho[i] = s_rho / q2;
+        }
+        const double m0 = (double)m.x, m1 = (double)m.y;
+        double r0 = 0, r1 = 0;
+        r0 += R[0] * m0; r0 += R[1] * m1; r0 += R[2] * 0.0;
+        r1 += R[3] * m0; r1 += R[4] * m1; r1 += R[5] * 0.0;
+        const float2 mr = make_float2((float)r0, (float)r1);
+        o.m_m[i] = mr;
+        o.rec[i].m_mx = mr.x;
+        o.rec[i].m_my = mr.y;
+    }
+    const int cnt = __popcll(__ballot(hit));
+    if ((threadIdx.x & 63) == 0 && cnt) atomicAdd(&seqs[seq].pub.klm_fwd, cnt);
 }
 
 // TooN SO3 exp / ln (so3.h:203-285, 288-334), device copies used by the frame glue
@@ -708,17 +758,40 @@ __global__ __launch_bounds__(256) void k_depth_reset(const KlSoA *kls, const int
 // ---------------------------------------------------------------------------------------------------
 // host side
 // ---------------------------------------------------------------------------------------------------
-int forward_match_enqueue(edgehip_ctx *c, int slot_old, int slot_new) {
+// keys_posted: the minimiser's last evaluation already left the arbitration keys in fwd_key (TvrArgs::fwd_key)
+int forward_match_enqueue(edgehip_ctx *c, int slot_old, int slot_new, bool keys_posted) {
     ProfScope ps(c, PROF_C_FORWARD);
     const DevicePlan &pl = c->plan;
     const size_t B = pl.nseq;
-    EH_CHECK(hipMemsetAsync(c->fwd_key, 0, sizeof(unsigned long long) * B * pl.cap, c->stream));
+    if (!keys_posted) EH_CHECK(hipMemsetAsync(c->fwd_key, 0, sizeof(unsigned long long) * B * pl.cap, c->stream));
     EH_CHECK(hipMemsetAsync(c->fwd_win, 0xFF, sizeof(int32_t) * B * pl.cap, c->stream));
     dim3 g((pl.cap + 255) / 256, 1, pl.nseq), b(256);
     const int32_t *kno = c->kn_slot + slot_old * B, *knn = c->kn_slot + slot_new * B;
-    hipLaunchKernelGGL(k_fwd_key, g, b, 0, c->stream, kldev(c, slot_old), kno, knn, c->fwd_key, pl.cap);
+    if (!keys_posted) hipLaunchKernelGGL(k_fwd_key, g, b, 0, c->stream, kldev(c, slot_old), kno, knn, c->fwd_key, pl.cap);
     hipLaunchKernelGGL(k_fwd_win, g, b, 0, c->stream, kldev(c, slot_old), kno, knn, c->fwd_key, c->fwd_win, pl.cap);
     hipLaunchKernelGGL(k_fwd_apply, g, b, 0, c->stream, kldev(c, slot_old), kldev(c, slot_new), knn, c->fwd_win, c->seq, pl.cap);
+    EH_LAUNCH_CHECK();
+    return 0;
+}
+
+// Whole-frame driver, ImuMode == 0 (rebvo_second_t.cpp:354-369): FordwardMatch + R0 = exp(W) + rotate_keylines(R0).  The
+// arbitration keys were posted by the minimiser's last evaluation (TvrArgs::fwd_key; cleared in minimizer_enqueue).
+int forward_rotate_enqueue(edgehip_ctx *c, int slot_old, int slot_new) {
+    c->grec_ok[slot_old] = false;   // m_m turns, u_m does not
+    const DevicePlan &pl = c->plan;
+    const size_t B = pl.nseq;
+    dim3 g((pl.cap + 255) / 256, 1, pl.nseq), b(256);
+    const int32_t *kno = c->kn_slot + slot_old * B, *knn = c->kn_slot + slot_new * B;
+    {
+        ProfScope ps(c, PROF_C_FORWARD);
+        EH_CHECK(hipMemsetAsync(c->fwd_win, 0xFF, sizeof(int32_t) * B * pl.cap, c->stream));
+        hipLaunchKernelGGL(k_fwd_win, g, b, 0, c->stream, kldev(c, slot_old), kno, knn, c->fwd_key, c->fwd_win, pl.cap);
+        hipLaunchKernelGGL(k_rot_from_state, dim3((pl.nseq + 63) / 64), dim3(64), 0, c->stream, c->seq, c->rot_buf, pl.nseq);
+        EH_LAUNCH_CHECK();
+    }
+    ProfScope ps(c, PROF_C_ROTATE);
+    hipLaunchKernelGGL(k_fwd_apply_rotate, g, b, 0, c->stream, kldev(c, slot_old), kldev(c, slot_new), kno, knn, c->fwd_win, c->seq,
+                       c->rot_buf, pl.zfm, pl.cap);
     EH_LAUNCH_CHECK();
     return 0;
 }
@@ -1237,9 +1310,16 @@ static int frame_enqueue(edgehip_ctx *c, int sn, int so, int sp, int have_pair, 
     } else if (have_pair) {
         EH_TRY(quantile_enqueue(c, so, kRhoMin, kRhoMax, c->p.qcut_quantile, c->p.qcut_nbins));  // rebvo_second_t.cpp:172
         EH_TRY(build_field_enqueue(c, sn, c->p.search_range, -1.f));                              // :177
-        EH_TRY(minimizer_enqueue(c, sn, so, c->frames_seen % kRefRing));                                                    // :346
-        EH_TRY(forward_match_enqueue(c, so, sn));                                                // :354
-        EH_TRY(rotate_enqueue(c, so, nullptr));                                                  // :360-369
+        c->fwd_key_in_tvr = c->fwd_mode != 1;
+        e = minimizer_enqueue(c, sn, so, c->frames_seen % kRefRing);                              // :346
+        c->fwd_key_in_tvr = false;
+        if (e) return e;
+        if (c->fwd_mode == 2) {
+            EH_TRY(forward_rotate_enqueue(c, so, sn));                                           // :354-369
+        } else {
+            EH_TRY(forward_match_enqueue(c, so, sn, c->fwd_mode != 1));                          // :354
+            EH_TRY(rotate_enqueue(c, so, nullptr));                                              // :360-369
+        }
         { ProfScope ps(c, PROF_C_POSE); EH_TRY(glue(c, 1, sn, have_pair)); }                     // :387-397
         EH_TRY(directed_enqueue(c, sn, so));                                                     // :410
         { ProfScope ps(c, PROF_C_POSE); EH_TRY(glue(c, 2, sn, have_pair)); }                     // :412-422

@@ -59,14 +59,16 @@ def test_tum_parameters_with_undistortion():
     _replay(frames, edgehip.tum_params(640, 480, use_undistort=1), oracle.tum_params(640, 480, use_undistort=1), 30, [0, 4], 0.02)
 
 
-@pytest.mark.parametrize("mode", ["default", "EDGEHIP_OVERLAP", "EDGEHIP_GRAPH"])
+@pytest.mark.parametrize("mode", ["default", "EDGEHIP_OVERLAP", "EDGEHIP_GRAPH", "EDGEHIP_FWD_MODE=1", "EDGEHIP_FWD_MODE=2"])
 def test_small_frames_sixty_deep(mode, monkeypatch):
     """Also under the two optional execution modes read at edgehip_create() time: stage A of frame k+1 overlapped with
     B/C of frame k on a second stream, and the per-frame HIP graphs (whose stage A runs on the main stream: uploads for
-    later frames must not overtake the graphs that still read a slot)."""
+    later frames must not overtake the graphs that still read a slot); and with the two alternative arrangements of
+    FordwardMatch / rotate_keylines (EDGEHIP_FWD_MODE, ctx.h)."""
     from oracle import oracle
     if mode != "default":
-        monkeypatch.setenv(mode, "1")
+        name, _, val = mode.partition("=")
+        monkeypatch.setenv(name, val or "1")
     frames = [f for f, _, _ in synth.billboard_sequence(376, 240, 12, seed=5)]
     _replay(frames, edgehip.euroc_params(376, 240), oracle.euroc_params(376, 240), 60, [0, 2, 7], 0.05)
 
