@@ -26,7 +26,13 @@ Extra objects on the JSON line (rank 0, N = 1):
   pose_rmse        BASELINE.json's "pose RMSE vs CPU ref": sequences of the batch against the CPU reference on the same frames
   batch_sweep      the same full path with 1 / 8 / 64 sequences per launch (1 = a single camera: `single_sequence_ms_per_frame`)
   heterogeneous    the same batch size with every sequence in its own state: six different scenes, different phases,
-                   a scene cut (estimation restart) in some, KeyLine counts spread — throughput and pose RMSE
+                   a scene cut (estimation restart) in some, KeyLine counts spread — throughput, pose RMSE, and for the
+                   checked sequences a teacher-forced replay (reference state injected before every frame: every frame
+                   must agree) plus the attribution of any free-running departure to a knife-edge frame of the reference
+                   (oracle/teacher.py)
+  extras           the other BASELINE configurations and ImuMode=2, each measured by this file in a process of its own and
+                   condensed: stage_a (configs[1], HBM GB/s), tum_undistort (configs[3]), imu (what GlobalConfig_EuRoC ships),
+                   each with its roofline, cpu_baseline and (where a pose exists) pose_rmse
 
 `--config stage_a` (BASELINE configs[1]): DoG + edge_finder KeyLine extraction alone, reported as HBM GB/s.
 `--config tum_undistort` (BASELINE configs[3]): TUM 640x480, GlobalConfig_desk.txt parameters, the undistortion fused
@@ -66,14 +72,15 @@ def algorithmic_bytes(group, kn, n_px, radius, nseq):
         # one-pass level kernel, mean of its three launches: (3N in + 4N out) + (4N + 4N) + 2 * (4N + 4N)
         "A.level": (7 * n_px + 8 * n_px + 16 * n_px) / 3.0,
         "A.compact": 20 * kn + 168 * kn,                     # candidates in, KeyLine SoA out
-        # the fused stage-A kernel: SURVEY.md 8(d) stage A = RGB24 in + img_mask_kl out + the KeyLine records, of which
-        # the constant fields (88 B) are written by the join kernel that follows
-        "A.fused": 3 * n_px + 4 * n_px + (168 - 88) * kn,
-        "A.join_retune": (8 + 8 + 4 + 3 * 4 + 8) * kn + 88 * kn,
+        # the fused stage-A kernel: SURVEY.md 8(d) stage A = RGB24 in + img_mask_kl out + the KeyLine records, of which the
+        # detector writes what the plane fit produces (p_inx, {xs, ys, m_m}, p_id: 24 B) and the join kernel that follows
+        # the rest (168 - 24 B), after reading those 24 B back and probing three mask neighbours
+        "A.fused": 3 * n_px + 4 * n_px + 24 * kn,
+        "A.join_retune": (24 + 3 * 4) * kn + (168 - 24) * kn,
         # 84 B per KeyLine and evaluation (fp64 variant)
         "B.try_velrot": 84 * kn,
         "B.build_field": 4 * n_px + 4 * 2 * radius * kn,     # clear + scattered 4-byte atomics (packed field)
-        "B.tvr_prepare": (8 + 8 + 24 + 8) * kn,
+        "B.tvr_prepare": 0,   # per-sequence set-up of the minimisation since P0 is rebuilt in registers by k_try_velrot (latency, no stream)
         "B.lm_step": 0,
         "B.quantile": 8 * kn,
         "C.forward_match": (4 + 8 + 8 + 4 + 100) * kn,
@@ -93,7 +100,7 @@ GROUP_KERNELS = {
     "A.level": ["k_level"], "A.fused": ["k_stage_a_fused"],
     "B.quantile": ["k_quantile"], "B.build_field": ["k_field_bin", "k_field_raster"], "B.tvr_prepare": ["k_tvr_prepare"],
     "B.try_velrot": ["k_try_velrot"], "B.lm_step": ["k_lm_step"], "B.minimizer": ["k_minimizer"],
-    "C.forward_match": ["k_fwd_key", "k_fwd_win", "k_fwd_apply"], "C.rotate": ["k_rot_from_state", "k_rotate"],
+    "C.forward_match": ["k_fwd_key", "k_fwd_win", "k_fwd_apply"], "C.rotate": ["k_rot_from_state", "k_rotate", "k_fwd_apply_rotate"],
     "C.directed_matching": ["k_directed"], "C.regularize_ekf": ["k_regularize", "k_ekf"], "C.rescale": ["k_rescale"],
 }
 
@@ -117,6 +124,14 @@ def fetch_calibration():
 # moves (profiles/fetch_calibration.json), so the counter R of such a kernel is stream/f_stream + gather/f_gather and the
 # bytes it really moved are  stream + f_gather * (R - stream / f_stream)  with the stream bytes known exactly.
 GROUP_STREAM_BYTES_PER_KL = {"B.try_velrot": 8 + 4 + 8 + 8 + 8 + 4 + 8}   # s_rho, m_num, p_m, rho, m_m, n_m, residual in
+
+
+def pmc_kn():
+    """KeyLines per frame of the run the committed counters were taken in (tools/gpu_round.sh stamps it), or None."""
+    try:
+        return json.load(open(os.path.join(ROOT, PMC_FILE))).get("_kn")
+    except (OSError, ValueError):
+        return None
 
 
 def pmc_counters(group, nseq):
@@ -219,6 +234,35 @@ def frame_stats(done_s, skip):
     return {"value": round(len(iv) / float(iv.sum()), 2), "unit": "frames/s", "ms_per_frame": round(float(iv.mean()) * 1e3, 3),
             "median_ms": round(float(np.median(iv)) * 1e3, 3), "p95_ms": round(float(np.percentile(iv, 95)) * 1e3, 3),
             "frames": int(len(iv))}
+
+
+def _cpu_imu_worker(job):
+    """The reference's ImuMode > 0 frame order (oracle/ref_harness.cpp::ref_process_frame_imu = rebvo_second_t.cpp:182-336,
+    519-606 over the reference's own tracker, ExtRotVel, BiasCorrect and ScaleEstimator) on one sequence, in a process of its
+    own (ScaleEstimator keeps its histories in function-local statics).  Returns per-frame seconds and the trajectory."""
+    w, h, pool_frames, idx, imu_rows, dt_f, imu_over = job
+    import ctypes as C
+    from oracle import oracle
+    orc = oracle.Oracle("ref", oracle.euroc_params(w, h))
+    L = orc.lib
+    L.ref_imu_setup.argtypes = [C.c_void_p, C.POINTER(oracle.ImuParams)]
+    L.ref_imu_setup.restype = None
+    L.ref_process_frame_imu.argtypes = [C.c_void_p, C.c_void_p, C.c_double, C.POINTER(oracle.ImuIntegrated), C.POINTER(oracle.NavImu)]
+    L.ref_process_frame_imu.restype = C.c_int
+    ip = oracle.euroc_imu_params(**imu_over)
+    L.ref_imu_setup(orc.ctx, C.byref(ip))
+    secs, pos, pose, vel, rotlie, ok = [], [], [], [], [], []
+    for k, i in enumerate(idx):
+        nav = oracle.NavImu()
+        f = np.ascontiguousarray(pool_frames[i], np.uint8)
+        rec = oracle.ImuIntegrated.from_row(imu_rows[k])
+        t1 = time.perf_counter()
+        L.ref_process_frame_imu(orc.ctx, f.ctypes.data, dt_f * k, C.byref(rec), C.byref(nav))
+        secs.append(time.perf_counter() - t1)
+        pos.append(np.array(nav.Pos[:])); pose.append(np.array(nav.Pose[:])); vel.append(np.array(nav.Vel[:]))
+        rotlie.append(np.array(nav.RotLie[:])); ok.append(int(nav.estimation_ok))
+    orc.close()
+    return np.array(secs), np.array(pos), np.array(pose), np.array(vel), np.array(rotlie), np.array(ok)
 
 
 def _cpu_worker(job):
@@ -408,7 +452,9 @@ def main():
     radius = params.search_range
     C = max(1, args.contexts)
     B, K, Wm = args.nseq // C, args.steps, args.warmup   # B = sequences per context
-    cpu_legs = rank == 0 and args.cpu_frames > 0 and (world == 1 or os.environ.get("BENCH_CPU_BASELINE_ALWAYS")) and not args.imu
+    cpu_legs_any = rank == 0 and args.cpu_frames > 0 and (world == 1 or os.environ.get("BENCH_CPU_BASELINE_ALWAYS"))
+    cpu_legs = cpu_legs_any and not args.imu
+    cpu_legs_imu = cpu_legs_any and args.imu
     if args.imu:
         args.no_extras = True   # the CPU legs and the other batch shapes are those of the ImuMode=0 line
 
@@ -603,8 +649,13 @@ def main():
     if cpu_legs:
         log0 = eh.read_nav_log_array(Wm, K)
         gpu_traj = {s: _traj_of_log(log0, s) for s in check_seqs}
+    elif cpu_legs_imu:   # ImuMode > 0: the gravity-aligned pose, metric velocity and rotation of NavData (rebvo_second_t.cpp:519-606)
+        log0 = eh.read_nav_log_array(Wm, K)
+        gpu_traj = {s: [(log0[k, s]["Pos"].copy(), log0[k, s]["Pose"].reshape(3, 3).copy(), log0[k, s]["Vel"].copy(),
+                         log0[k, s]["RotLie"].copy()) for k in range(K)] for s in check_seqs}
     last = [n for e in ehs for n in e.read_nav()]
     kn_mean = float(np.mean([n.kn for n in last]))
+    kn_timed = float(np.mean(eh.read_nav_log_array(Wm, K)["kn"])) if rank == 0 else kn_mean   # over every timed frame, context 0
     ok = int(sum(n.estimation_ok for n in last))
     evals = last[0].minimizer_evals
 
@@ -615,6 +666,17 @@ def main():
         return
 
     value = B * C * world * K / dt
+    # ---- per-kernel attribution: four more steps (frames right behind the timed ones, i.e. of the same cost) with the HIP-event
+    # profiler on every group — not part of the timed region, and not the early warm-up frames whatever --warmup is ----
+    prof_steps = 4
+    eh.profile_select(None)
+    eh.profile_enable(True)
+    for k in range(Wm + K, Wm + K + prof_steps):
+        rp.step(k)
+    prof = eh.profile_read()
+    eh.profile_enable(False)
+    groups = {g: (ms, calls) for g, (ms, calls) in prof.items() if calls}
+    breakdown = {g: round(ms / prof_steps * 1e3, 1) for g, (ms, calls) in groups.items()}  # us per step
     # ---- roofline of the dominant kernel group, and of all of them ----
     calib, calib_src = fetch_calibration()
     roof = None
@@ -630,15 +692,30 @@ def main():
                                         "source": calib_src},
                 "launch_us": round(per_launch_s * 1e6, 2), "algorithmic_bytes_per_launch": int(abytes),
                 "launches_timed": dom_calls}
+    # The committed counters were taken in a run of their own: a group's traffic is compared with the algorithmic bytes at THAT
+    # run's KeyLine count (pmc_latest.json:_kn), and scaled to this run's for the absolute figure.  Where a kernel moves LESS
+    # than SURVEY 8(d)'s formula (build_field: the formula describes the reference's scatter, the LDS rasteriser writes half of
+    # it), `frac` on the algorithmic bytes flatters it: `frac_on_traffic` is the rate at which it really moves bytes.
+    kn_pmc = pmc_kn() or kn_mean
     roof_all = {}
+    traffic_step = 0.0
     for g, (ms, calls) in groups.items():
         ab = algorithmic_bytes(g, kn_mean, n_px, radius, B)
         if ab and calls:
             per = ms * 1e-3 / calls
-            tr, _ = calibrated_traffic(g, B, kn_mean, calib)
+            tr, _ = calibrated_traffic(g, B, kn_pmc, calib)
+            ab_pmc = algorithmic_bytes(g, kn_pmc, n_px, radius, B)
+            ratio = tr / ab_pmc if tr and ab_pmc else None
             roof_all[g] = {"launch_us": round(per * 1e6, 1), "launches_per_step": calls // prof_steps,
                            "achieved_GBs": round(ab / per / 1e9, 1), "frac": round(ab / per / 1e9 / HBM_PEAK_GBS, 4),
-                           "traffic_over_algorithmic": round(tr / ab, 2) if tr else None}
+                           "traffic_over_algorithmic": round(ratio, 2) if ratio else None}
+            if ratio:
+                roof_all[g]["frac_on_traffic"] = round(ratio * ab / per / 1e9 / HBM_PEAK_GBS, 4)
+                traffic_step += ratio * ab * (calls // prof_steps)
+    if roof and roof.get("traffic") and dominant in roof_all and roof_all[dominant].get("traffic_over_algorithmic"):
+        roof["traffic"] = int(roof_all[dominant]["traffic_over_algorithmic"] * roof["algorithmic_bytes_per_launch"])
+        roof["traffic_kn"] = {"counters_taken_at": round(float(kn_pmc), 1), "this_run": round(kn_mean, 1),
+                              "note": "traffic = (counter bytes / algorithmic bytes at the counters' KeyLine count) x this run's algorithmic bytes"}
     # whole-frame algorithmic bytes, SURVEY.md §8(d) formulas with the measured kn and evaluation count
     r = radius
     frame_bytes = (3 * n_px + 4 * n_px + 168 * kn_mean) + (8 * n_px + 8 * 2 * r * kn_mean + evals * 84 * kn_mean) + \
@@ -707,6 +784,61 @@ def main():
                               f"(slowest process {max(res):.2f} s)"}
             except Exception as e:
                 cpu["modes"]["node_saturating"] = {"value": None, "error": str(e)[:200]}
+
+    if cpu_legs_imu:
+        # ImuMode > 0: the same two things for the IMU branch — pose RMSE of three sequences of the batch against the reference's
+        # own ImuMode > 0 frame order on the same frames and IMU records, and that code timed on this box's host cores.  One
+        # process per sequence (the reference's filter histories are process-wide statics); the harness runs the branch on one
+        # thread (the reference's FirstThr / SecondThread split is timed on the ImuMode = 0 line).
+        try:
+            import multiprocessing as mp
+            from oracle import oracle
+            if not oracle.available("ref"):
+                raise RuntimeError("oracle/_ref not built")
+            host_pool = np.stack(frames)
+            rows = lambda rec: np.array([rec.n, rec.dt] + list(rec.Rot) + list(rec.giro) + list(rec.acel) + list(rec.comp) +
+                                        list(rec.dgiro) + list(rec.cacel), dtype=np.float64)
+            imu_over = dict(init_bias_frame_num=3)
+
+            def job_of(s_, nfr):
+                o = int(offs[s_])
+                idx = [tri(k + o, args.pool) for k in range(nfr)]
+                recs = [rows(trans[(tri(k - 1 + o, args.pool) if k > 0 else idx[0], idx[k])]) for k in range(nfr)]
+                return (w, h, host_pool, idx, np.array(recs), 0.05, imu_over)
+            ncores, model = _usable_cores(), _cpu_model()
+            nfr_t = 10 + args.cpu_frames
+            jobs = [job_of(s_, Wm + K) for s_ in check_seqs] + [job_of(0, nfr_t)]
+            with mp.get_context("spawn").Pool(min(len(jobs), max(1, ncores))) as pool_:
+                res = pool_.map(_cpu_imu_worker, jobs)
+            cpu_trajs = {}
+            for s_, (secs, pos, pose_m, vel, rotlie, ok_) in zip(check_seqs, res[:len(check_seqs)]):
+                cpu_trajs[s_] = {k: (pos[Wm + k], pose_m[Wm + k].reshape(3, 3), vel[Wm + k], rotlie[Wm + k]) for k in range(K)}
+            pose = pose_rmse(gpu_traj, cpu_trajs, "reference (ImuMode > 0 frame order)")
+            if pose:
+                pose["note"] = ("V / W here = NavData::Vel (metric, gravity frame) and RotLie; Pos / Pose = the gravity-aligned, "
+                                "scale-filtered pose of the IMU branch.  The scale filter's 7x7 / 11-row solves are ill-conditioned "
+                                "(LAPACK SVD in the reference, Jacobi on the device): tests bound whole sequences by 1e-6..1e-5")
+            secs = res[-1][0]
+            done = np.cumsum(secs)
+            cpu = frame_stats(done, 10)
+            cpu.update({"cores": 1, "kind": "reference", "cpu_model": model, "usable_cores": ncores,
+                        "sample": f"{args.cpu_frames} frames of sequence 0 (same {w}x{h} pool and IMU records) through the reference's "
+                                  f"ImuMode > 0 branch on 1 of {ncores} usable host cores ({model}), next to {len(check_seqs)} more "
+                                  "reference processes (the pose check); `modes` adds the node-saturating run",
+                        "modes": {"serial_1_core": dict(frame_stats(done, 10), cores=1)}})
+            if args.cpu_procs:
+                P = args.cpu_procs if args.cpu_procs > 0 else max(1, ncores - 1)
+                nfr = max(30, args.cpu_frames // 3)
+                with mp.get_context("spawn").Pool(P) as pool_:
+                    t_0 = time.perf_counter()
+                    res2 = pool_.map(_cpu_imu_worker, [job_of(i % (B * C), 10 + nfr) for i in range(P)])
+                slow = max(float(r_[0][10:].sum()) for r_ in res2)
+                cpu["modes"]["node_saturating"] = {
+                    "value": round(P * nfr / slow, 1), "unit": "frames/s", "processes": P, "threads_per_process": 1, "cores": min(ncores, P),
+                    "frames": P * nfr, "sample": f"{P} sequences x {nfr} frames, one single-threaded reference process each (slowest {slow:.2f} s)"}
+        except Exception as e:
+            cpu = cpu or {"value": None}
+            cpu["error"] = f"{type(e).__name__}: {e}"[:300]
 
     # ---- the other batch shapes (N = 1, after the timed region) ----
     sweep = hetero = None
@@ -823,12 +955,46 @@ def main():
                    "sequences_per_gpu": B * C, "contexts_per_gpu": C, "sequences_per_launch": B,
                    "stream_overlap": bool(args.overlap), "nav_gather": nav_gather,
                    "frames_per_step": B * C * world, "keylines_per_frame": round(kn_mean, 1),
+                   "keylines_per_frame_timed_mean": round(kn_timed, 1),
                    "tryvelrot_evals_per_frame": evals, "estimation_ok": f"{ok}/{B * C}",
                    "algorithmic_MB_per_frame": round(frame_bytes / 1e6, 2),
                    "whole_path_hbm_frac": round(frame_bytes * value / world / 1e9 / HBM_PEAK_GBS, 5)},
         "roofline": roof, "cpu_baseline": cpu, "pose_rmse": pose, "kernel_us_per_step": breakdown,
+        "kernel_us_per_step_source": "HIP events of the 4 steps that follow the timed region (profiler on every kernel group; the timed "
+                                     "region itself carries events on the dominant group only)",
         "roofline_kernels": roof_all,
     }
+    if world == 1 and not args.no_extras and args.config == "full" and not args.imu:
+        # The other BASELINE configurations and the ImuMode=2 line, each measured by this same file in a process of its own
+        # (short runs in the driver's form), so that the one default command covers configs[1], configs[3] and what
+        # GlobalConfig_EuRoC actually ships with.  Each entry is that run's own JSON line, condensed.
+        import subprocess
+        extras = {}
+        cf = str(min(args.cpu_frames, 60))
+        for name, flags in (("stage_a", ["--config", "stage_a", "--cpu-frames", cf]),
+                            ("tum_undistort", ["--config", "tum_undistort", "--cpu-frames", cf, "--cpu-procs", "0"]),
+                            ("imu", ["--imu", "--cpu-frames", cf, "--cpu-procs", "0"])):
+            try:
+                t_sub = time.perf_counter()
+                out = subprocess.run([sys.executable, os.path.abspath(__file__), "--no-extras", "--steps", "20", "--warmup", "5",
+                                      "--nseq", str(args.nseq)] + flags, capture_output=True, text=True, timeout=420)
+                js = None
+                for ln in reversed(out.stdout.splitlines()):
+                    if ln.startswith("{"):
+                        js = json.loads(ln)
+                        break
+                if js is None:
+                    raise RuntimeError(f"no JSON line (rc {out.returncode}): {out.stderr[-200:]}")
+                keep = ("metric", "value", "unit", "steps", "warmup", "ms_per_step", "roofline", "cpu_baseline", "pose_rmse",
+                        "stage_a_hbm_frac", "kernel_us_per_step")
+                extras[name] = {k: js[k] for k in keep if k in js}
+                extras[name]["workload"] = js.get("config", {}).get("workload")
+                extras[name]["keylines_per_frame"] = js.get("config", {}).get("keylines_per_frame")
+                extras[name]["command"] = "python bench.py --no-extras --steps 20 --warmup 5 " + " ".join(flags)
+                extras[name]["wall_s"] = round(time.perf_counter() - t_sub, 1)
+            except Exception as e:
+                extras[name] = {"value": None, "error": f"{type(e).__name__}: {e}"[:300]}
+        line["extras"] = extras
     if sweep:
         line["batch_sweep"] = sweep
         line["single_sequence_ms_per_frame"] = sweep[0]["ms_per_step"]

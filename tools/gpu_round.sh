@@ -39,10 +39,10 @@ DB=$(ls "$OUT"/trace/*.db "$OUT"/trace/*/*.db 2>/dev/null | head -1)
 [ -n "$DB" ] && python tools/rocpd_summary.py "$DB" "$OUT/kernel_stats.txt" > /dev/null
 ls "$OUT/trace" | head
 
-# PMC passes: short run, counters only (no trace domains besides kernel-trace)
+# PMC passes: the driver's form of the command (--steps 20 --warmup 5), counters only (no trace domains besides kernel-trace)
 for C in FETCH_SIZE WRITE_SIZE; do
   ( cd /tmp && timeout 600 rocprofv3 --kernel-trace --pmc $C --output-format csv -d "$OUT/pmc_$C" -o pmc -- \
-      python "$GRAFT_REPO_ROOT/bench.py" $BENCH_ARGS --steps 6 --warmup 12 --cpu-frames 0 --no-extras --no-roofline-events \
+      python "$GRAFT_REPO_ROOT/bench.py" $BENCH_ARGS --steps 20 --warmup 5 --cpu-frames 0 --no-extras --no-roofline-events \
       > "$OUT/pmc_$C.json" 2> "$OUT/pmc_$C.err" )
   echo "pmc $C exit $?"
   python tools/pmc_summary.py "$OUT/pmc_$C" "$OUT/pmc_$C.txt" "$OUT/pmc.json" > /dev/null
@@ -55,7 +55,9 @@ p = sys.argv[1]
 try:
     js = json.load(open(p))
     line = open(p.replace("pmc.json", "pmc_FETCH_SIZE.json")).read()
-    js["_nseq"] = json.loads(line[line.index("{"):])["config"]["sequences_per_launch"]
+    cfg = json.loads(line[line.index("{"):])["config"]
+    js["_nseq"] = cfg["sequences_per_launch"]
+    js["_kn"] = cfg.get("keylines_per_frame_timed_mean", cfg["keylines_per_frame"])   # the counters average over this run's frames
     json.dump(js, open(p, "w"), indent=0, sort_keys=True)
 except Exception as e:
     print("pmc.json not stamped:", e)
