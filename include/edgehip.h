@@ -180,6 +180,15 @@ int edgehip_upload_rgb_indexed(edgehip_ctx *ctx, int slot, const void *pool_dev,
  * stay valid and unchanged until that stage A has run, and must extend at least 16 bytes past its last frame (pixels
  * are fetched as aligned 8-byte words).  Any edgehip_upload_rgb* call on the slot returns it to its own storage. */
 int edgehip_bind_rgb_indexed(edgehip_ctx *ctx, int slot, const void *pool_dev, int pool_frames, const int32_t *idx);
+/* 8-bit mono frames, 1 byte per pixel: what a mono camera or the EuRoC data set delivers.  The reference's DataSetCam expands
+ * such an image to RGB24 with r = g = b (src/VideoLib/datasetcam.cpp:109-171) because Image<float>::ConvertRGB2BW
+ * (include/VideoLib/image.h:197-203) wants RGB24; b + g + r is then 3 v, and that is what the first load of stage A computes
+ * from the 8-bit frame directly — bit-identical results at a third of the bytes over PCIe and out of HBM.  Same three forms
+ * as the RGB24 uploads: pageable host memory (staged), page-locked host memory (asynchronous, on the upload stream), frames of
+ * a device-resident pool read in place.  A slot holds whichever format was uploaded or bound to it last. */
+int edgehip_upload_grey8(edgehip_ctx *ctx, int slot, const uint8_t *grey8, int seq_first, int count);
+int edgehip_upload_grey8_pinned(edgehip_ctx *ctx, int slot, const uint8_t *grey8_pinned, int seq_first, int count);
+int edgehip_bind_grey8_indexed(edgehip_ctx *ctx, int slot, const void *pool_dev, int pool_frames, const int32_t *idx);
 
 /* ---- stage A: scale space + KeyLine extraction ----------------------------------------------------- */
 /* Image<float>::ConvertRGB2BW + sspace::build + edge_finder::detect + reEstimateThresh for every

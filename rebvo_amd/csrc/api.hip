@@ -558,6 +558,8 @@ int edgehip_destroy(edgehip_ctx *c) {
         delete c->prof;
     }
     if (c->stream_log) { (void)hipStreamSynchronize(c->stream_log); (void)hipStreamDestroy(c->stream_log); (void)hipEventDestroy(c->ev_log); }
+    if (c->grey8) (void)hipFree(c->grey8);
+    if (c->pinned_grey8) (void)hipHostFree(c->pinned_grey8);
     if (c->nav_log) (void)hipFree(c->nav_log);
     if (c->stream_imu) { (void)hipStreamSynchronize(c->stream_imu); (void)hipStreamDestroy(c->stream_imu); for (int i = 0; i < 2; i++) { (void)hipEventDestroy(c->ev_imu_snap[i]); (void)hipEventDestroy(c->ev_imu_post[i]); } }
     if (c->kf_req_dev) (void)hipFree(c->kf_req_dev);
@@ -623,8 +625,21 @@ static int check_seq(edgehip_ctx *c, int seq) {
 }
 
 // the slot reads its own storage again (after edgehip_bind_rgb_indexed)
-static void unbind_rgb(edgehip_ctx *c, int slot) {
-    if (c->slot_src[slot].base) { c->slot_src[slot].base = nullptr; c->slot_src[slot].host_idx.clear(); drop_frame_graphs(c); }
+// the slot's frames come from its own storage again, as RGB24 (grey8 = false) or 8-bit mono (grey8 = true)
+static void unbind_rgb(edgehip_ctx *c, int slot, bool grey8 = false) {
+    edgehip_ctx::SlotSrc &ss = c->slot_src[slot];
+    if (ss.base || ss.grey8 != grey8) drop_frame_graphs(c);   // the frame source and its format are kernel arguments / choices
+    ss.base = nullptr;
+    ss.host_idx.clear();
+    ss.grey8 = grey8;
+}
+static int ensure_grey8(edgehip_ctx *c) {
+    if (c->grey8) return 0;
+    void *q = nullptr;
+    const size_t bytes = (size_t)c->plan.nslots * c->plan.nseq * c->plan.n;
+    if (hipMalloc(&q, bytes) != hipSuccess) { (void)hipGetLastError(); set_error("grey8 frame storage alloc failed"); return EDGEHIP_ERR_MEMORY; }
+    c->grey8 = (uint8_t *)q;
+    return 0;
 }
 
 int edgehip_upload_rgb(edgehip_ctx *c, int slot, const uint8_t *rgb24, int seq_first, int count) {
@@ -665,6 +680,61 @@ int edgehip_upload_rgb_pinned(edgehip_ctx *c, int slot, const uint8_t *rgb24_pin
     EH_CHECK(hipMemcpyAsync(rgbof(c, slot) + fb * seq_first, rgb24_pinned, fb * count, hipMemcpyHostToDevice, c->stream_up));
     EH_CHECK(hipEventRecord(c->ev_up[slot], c->stream_up));
     c->up_valid[slot] = true;
+    return 0;
+}
+
+// ---- 8-bit mono ingest (EuRoC is mono: datasetcam.cpp:109-171 expands it to RGB24 only because the CPU path wants that) ----
+int edgehip_upload_grey8(edgehip_ctx *c, int slot, const uint8_t *grey8, int seq_first, int count) {
+    EH_ENTER(c);
+    if (int e = check_slot(c, slot)) return e;
+    if (!grey8 || seq_first < 0 || count < 1 || seq_first + count > c->plan.nseq) { set_error("upload_grey8: bad range"); return EDGEHIP_ERR_ARG; }
+    if (int e = ensure_grey8(c)) return e;
+    unbind_rgb(c, slot, true);
+    if (int e = wait_upload(c, slot, c->stream_a)) return e;
+    const size_t fb = c->plan.n;
+    if (!c->pinned_grey8) {
+        void *q = nullptr;
+        EH_CHECK(hipHostMalloc(&q, fb * c->plan.nseq, hipHostMallocDefault));
+        c->pinned_grey8 = (uint8_t *)q;
+    }
+    EH_CHECK(hipStreamSynchronize(c->stream_a));   // the staging buffer is reused: wait for the previous copy out of it
+    memcpy(c->pinned_grey8 + fb * seq_first, grey8, fb * count);
+    EH_CHECK(hipMemcpyAsync(c->grey8 + ((size_t)slot * c->plan.nseq + seq_first) * fb, c->pinned_grey8 + fb * seq_first, fb * count,
+                            hipMemcpyHostToDevice, c->stream_a));
+    return 0;
+}
+int edgehip_upload_grey8_pinned(edgehip_ctx *c, int slot, const uint8_t *grey8_pinned, int seq_first, int count) {
+    EH_ENTER(c);
+    if (int e = check_slot(c, slot)) return e;
+    if (!grey8_pinned || seq_first < 0 || count < 1 || seq_first + count > c->plan.nseq) { set_error("upload_grey8_pinned: bad range"); return EDGEHIP_ERR_ARG; }
+    if (int e = ensure_grey8(c)) return e;
+    unbind_rgb(c, slot, true);
+    const size_t fb = c->plan.n;
+    // on the upload stream, like edgehip_upload_rgb_pinned: the copy of frame k+1 runs under the whole of frame k
+    if (c->slot_ring[slot] >= 0) EH_CHECK(hipStreamWaitEvent(c->stream_up, c->ev_ring[c->slot_ring[slot]], 0));
+    if (c->a_api_valid[slot]) { EH_CHECK(hipStreamWaitEvent(c->stream_up, c->ev_a[slot], 0)); c->a_api_valid[slot] = false; }
+    EH_CHECK(hipMemcpyAsync(c->grey8 + ((size_t)slot * c->plan.nseq + seq_first) * fb, grey8_pinned, fb * count, hipMemcpyHostToDevice, c->stream_up));
+    EH_CHECK(hipEventRecord(c->ev_up[slot], c->stream_up));
+    c->up_valid[slot] = true;
+    return 0;
+}
+int edgehip_bind_grey8_indexed(edgehip_ctx *c, int slot, const void *pool_dev, int pool_frames, const int32_t *idx) {
+    EH_ENTER(c);
+    if (int e = check_slot(c, slot)) return e;
+    if (!pool_dev || !idx || pool_frames < 1) return EDGEHIP_ERR_ARG;
+    const int B = c->plan.nseq;
+    int32_t *pi = c->pinned_idx + ((size_t)(c->frames_seen % 8) * 4 + slot) * B;
+    if (int e = wait_pinned_ring(c)) return e;
+    for (int s = 0; s < B; s++) {
+        if (idx[s] < 0 || idx[s] >= pool_frames) { set_error("bind_grey8_indexed: index out of range"); return EDGEHIP_ERR_ARG; }
+        pi[s] = idx[s];
+    }
+    EH_CHECK(hipMemcpyAsync(c->frame_idx + (size_t)slot * B, pi, sizeof(int32_t) * B, hipMemcpyHostToDevice, c->stream_a));
+    edgehip_ctx::SlotSrc &ss = c->slot_src[slot];
+    if (ss.base != (const uint8_t *)pool_dev || !ss.grey8) drop_frame_graphs(c);
+    ss.base = (const uint8_t *)pool_dev;
+    ss.grey8 = true;
+    ss.host_idx.assign(idx, idx + B);
     return 0;
 }
 
@@ -714,8 +784,9 @@ int edgehip_bind_rgb_indexed(edgehip_ctx *c, int slot, const void *pool_dev, int
     }
     EH_CHECK(hipMemcpyAsync(c->frame_idx + (size_t)slot * B, pi, sizeof(int32_t) * B, hipMemcpyHostToDevice, c->stream_a));
     edgehip_ctx::SlotSrc &ss = c->slot_src[slot];
-    if (ss.base != (const uint8_t *)pool_dev) drop_frame_graphs(c);   // the frame source is a kernel argument
+    if (ss.base != (const uint8_t *)pool_dev || ss.grey8) drop_frame_graphs(c);   // the frame source is a kernel argument
     ss.base = (const uint8_t *)pool_dev;
+    ss.grey8 = false;
     ss.host_idx.assign(idx, idx + B);
     return 0;
 }

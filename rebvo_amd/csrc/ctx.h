@@ -224,7 +224,11 @@ struct edgehip_ctx {
         double t[3], R[9], max_radius;
     } rig;
     int ring_slots;                   // slots the frame ring cycles through (nslots, or nslots - 1 with a stereo rig)
-    struct SlotSrc { const uint8_t *base = nullptr; std::vector<int32_t> host_idx; };   // base == nullptr: the slot's own storage
+    // base == nullptr: the slot's own storage.  grey8: the frames are 8-bit mono, 1 B per pixel (edgehip_upload_grey8* /
+    // edgehip_bind_grey8_indexed) — in the slot's grey8 buffer or, bound, in a pool of grey8 frames.
+    struct SlotSrc { const uint8_t *base = nullptr; std::vector<int32_t> host_idx; bool grey8 = false; };
+    uint8_t *grey8 = nullptr;        // [S][B][N] 8-bit frames of the slots (allocated by the first grey8 upload)
+    uint8_t *pinned_grey8 = nullptr; // [B][N] staging of edgehip_upload_grey8 (pageable input)
     std::vector<SlotSrc> slot_src;   // per ring slot: where stage A reads its frames from
     int32_t *frame_idx;              // [S][B] frame index of every sequence inside a bound pool
     struct SlotCam { float ppx, ppy; double zfm; };

@@ -1127,6 +1127,25 @@ __global__ void k_undistort_frame(const uint8_t *__restrict__ frame, uint8_t *__
     out[(size_t)pix * 3] = c.x; out[(size_t)pix * 3 + 1] = c.y; out[(size_t)pix * 3 + 2] = c.z;
 }
 
+// 8-bit mono frames -> the slot's RGB24 storage (r = g = b = v, what DataSetCam makes of a mono image, datasetcam.cpp:
+// 109-171) for the paths that read RGB24: the multi-kernel stage A of small batches, the undistorting load, the stereo
+// pair slot.  N bytes in, 3 N out; the one-kernel stage A of large batches reads the 8-bit frames directly (SRC_GREY8).
+__global__ __launch_bounds__(256) void k_expand_grey8(const uint8_t *__restrict__ g8, const int32_t *__restrict__ fidx,
+                                                      uint8_t *__restrict__ rgb, int n) {
+    const int seq = blockIdx.z;
+    const uint8_t *src = g8 + (size_t)(fidx ? fidx[seq] : seq) * (size_t)n;
+    uint8_t *dst = rgb + (size_t)seq * (size_t)n * 3;
+    const int q = blockIdx.x * 256 + threadIdx.x;          // four pixels per thread: 4 B in, 12 B out
+    if (q * 4 >= n) return;
+    const uint32_t v = *reinterpret_cast<const uint32_t *>(src + (size_t)q * 4);
+    const uint32_t a = v & 0xFFu, b = (v >> 8) & 0xFFu, c2 = (v >> 16) & 0xFFu, d = v >> 24;
+    uint3 o;
+    o.x = a | (a << 8) | (a << 16) | (b << 24);
+    o.y = b | (b << 8) | (c2 << 16) | (c2 << 24);
+    o.z = c2 | (d << 8) | (d << 16) | (d << 24);
+    *reinterpret_cast<uint3 *>(dst + (size_t)q * 12) = o;
+}
+
 // ---------------------------------------------------------------------------------------------------
 // host side
 // ---------------------------------------------------------------------------------------------------
@@ -1156,6 +1175,20 @@ int stage_a_enqueue(edgehip_ctx *c, int slot) {
     // Batches that fill the GPU with one workgroup per sequence: the whole of stage A up to the KeyLine records in one
     // kernel (stage_a_fused.hip); level_mode 3 forces it, 1 / 2 keep the multi-kernel path (A/B measurements, tests).
     const bool use_fused = fused_supported(c) && (c->level_mode == 3 || (c->level_mode == 0 && B >= c->fused_min_batch));
+    // 8-bit mono frames: the one-kernel stage A reads them as they are; every other path gets the RGB24 expansion first
+    const uint8_t *grey8 = nullptr;
+    if (c->slot_src[slot].grey8) {
+        const uint8_t *g8 = c->slot_src[slot].base ? c->slot_src[slot].base : c->grey8 + (size_t)slot * B * n;
+        if (use_fused && !c->und_base) {
+            grey8 = g8;
+        } else {
+            ProfScope ps(c, PROF_A_ROWSCAN, st);
+            hipLaunchKernelGGL(k_expand_grey8, dim3((unsigned)((n / 4 + 255) / 256), 1, B), dim3(256), 0, st, g8, rgb_idx, rgbof(c, slot), (int)n);
+            EH_LAUNCH_CHECK();
+            rgb_base = rgbof(c, slot);
+            rgb_idx = nullptr;
+        }
+    }
     if (use_fused) {
         const uint16_t *grey16 = nullptr;
         if (c->und_base) {   // UseUndistort: resample + grey first (the integral-image scratch is free on this path)
@@ -1166,7 +1199,7 @@ int stage_a_enqueue(edgehip_ctx *c, int slot) {
             EH_LAUNCH_CHECK();
             grey16 = g16;
         }
-        if (int e = stage_a_fused_enqueue(c, slot, rgb_base, rgb_idx, grey16)) return e;
+        if (int e = stage_a_fused_enqueue(c, slot, rgb_base, rgb_idx, grey16, grey8)) return e;
         ProfScope ps(c, PROF_A_JOIN, st);
         hipLaunchKernelGGL((k_join_histo<true, true>), dim3((pl.cap + 255) / 256, 1, B), dim3(256), 0, st, kldev(c, slot),
                            maskof(c, slot), c->seqa, c->histo, w, n, c->p.qcut_nbins, c->slot_cam[slot].ppx, c->slot_cam[slot].ppy);

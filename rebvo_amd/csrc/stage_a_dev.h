@@ -30,7 +30,8 @@ __host__ __device__ constexpr inline int fused_row_stride(int w) {
 struct FusedArgs {
     const uint8_t *rgb;        // frames of the slot (sequence-major) or a bound pool
     const int32_t *fidx;       // [B] frame index inside the pool, or null
-    const uint16_t *grey16;    // [B][N] b+g+r of the undistorted frame (GREY16 instantiations), or null
+    const uint16_t *grey16;    // [B][N] b+g+r of the undistorted frame (SRC_GREY16 instantiations), or null
+    const uint8_t *grey8;      // 8-bit mono frames, 1 B per pixel (SRC_GREY8 instantiations: frame = grey8 + (fidx ? fidx[seq] : seq) * n), or null
     const float *lut;          // [kDivLutMax] (float)(1.0/count)
     float *planes;             // optional debug planes [5][B][N]
     int32_t *mask;             // [B][N] of the slot
@@ -53,6 +54,11 @@ struct FusedArgs {
 };
 
 bool fused_supported(const edgehip_ctx *c);
-int stage_a_fused_enqueue(edgehip_ctx *c, int slot, const uint8_t *rgb_base, const int32_t *rgb_idx, const uint16_t *grey16);
+// what the fused kernel's first load reads: the RGB24 frame (ConvertRGB2BW fused: b+g+r), the 16-bit grey plane of
+// k_undistort_grey, or an 8-bit mono frame (b+g+r of r = g = b = v: 3 v, the same integer ConvertRGB2BW computes from the
+// RGB24 expansion DataSetCam makes of a mono image, image.h:197-203)
+enum FusedSrc { SRC_RGB24 = 0, SRC_GREY16 = 1, SRC_GREY8 = 2 };
+int stage_a_fused_enqueue(edgehip_ctx *c, int slot, const uint8_t *rgb_base, const int32_t *rgb_idx, const uint16_t *grey16,
+                          const uint8_t *grey8 = nullptr);
 
 }  // namespace edgehip

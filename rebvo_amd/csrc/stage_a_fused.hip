@@ -155,10 +155,11 @@ __device__ __forceinline__ FitOut fit_eval(const float (&v)[25], const FitCoef &
 
 // W = image width known at compile time (LDS offsets become instruction immediates), 0 = taken from the arguments.
 // DBG = also write the img0 / img1 / DoG / dx / dy planes (debug_planes contexts: tests).
-// GREY16 = the input is a plane of 16-bit grey values b+g+r (a.grey16: the frame after k_undistort_grey, image_undistort
-// fused with ConvertRGB2BW) instead of the RGB24 frame.
-template <int W, bool DBG, bool GREY16, int RB, int D1, int D2A, int D2B, int D3A, int D3B>
+// SRC = what the first load reads (FusedSrc, stage_a_dev.h): the RGB24 frame, a plane of 16-bit grey values b+g+r (a.grey16:
+// the frame after k_undistort_grey, image_undistort fused with ConvertRGB2BW), or an 8-bit mono frame (a.grey8: 3 v).
+template <int W, bool DBG, int SRC, int RB, int D1, int D2A, int D2B, int D3A, int D3B>
 __global__ __launch_bounds__(512) void k_stage_a_fused(FusedArgs a) {
+    constexpr bool GREY16 = SRC == SRC_GREY16, GREY8 = SRC == SRC_GREY8;
     constexpr int R1 = D1 / 2, R2A = D2A / 2, R2B = D2B / 2, R3A = D3A / 2, R3B = D3B / 2;
     constexpr int LB = R1 + R2B + R3B;                  // rows img1 trails the input by
     static_assert(R1 + R2A + R3A + 1 == LB, "img0 must lead img1 by exactly one row (it is held for one step)");
@@ -513,7 +514,8 @@ __global__ __launch_bounds__(512) void k_stage_a_fused(FusedArgs a) {
     np_lo = __builtin_amdgcn_readfirstlane(np_lo);
     np_hi = __builtin_amdgcn_readfirstlane(np_hi);
     const uint8_t *frame = GREY16 ? reinterpret_cast<const uint8_t *>(a.grey16 + (size_t)seq * a.n)
-                                  : a.rgb + (size_t)(a.fidx ? a.fidx[seq] : seq) * a.n * 3;
+                           : GREY8 ? a.grey8 + (size_t)(a.fidx ? a.fidx[seq] : seq) * a.n
+                                   : a.rgb + (size_t)(a.fidx ? a.fidx[seq] : seq) * a.n * 3;
 
     int rq0 = 0;                                // ring slot of this tick's first DoG row
     int32_t *mask = a.mask + so;
@@ -617,6 +619,8 @@ __global__ __launch_bounds__(512) void k_stage_a_fused(FusedArgs a) {
             y = y < h ? y : h - 1;
             if (GREY16) {
                 pre[j] = make_uint2(*reinterpret_cast<const uint32_t *>(frame + (uint32_t)(y * w + xr0) * 2u), 0u);   // two 16-bit values
+            } else if (GREY8) {
+                pre[j] = make_uint2(*reinterpret_cast<const uint16_t *>(frame + (uint32_t)(y * w + xr0)), 0u);        // two 8-bit values
             } else {
                 const uint32_t byte0 = (uint32_t)(y * w + xr0) * 3u;     // < 2^31: the frame is w*h*3 bytes
                 pre[j] = *reinterpret_cast<const uint2 *>(frame + (byte0 & ~3u));
@@ -703,6 +707,9 @@ __global__ __launch_bounds__(512) void k_stage_a_fused(FusedArgs a) {
                 if (GREY16) {
                     g.x = (float)(int)(pre[j].x & 0xFFFFu);
                     g.y = (float)(int)(pre[j].x >> 16);
+                } else if (GREY8) {
+                    g.x = (float)(3 * (int)(pre[j].x & 0xFFu));     // b + g + r of a mono pixel
+                    g.y = (float)(3 * (int)((pre[j].x >> 8) & 0xFFu));
                 } else {
                     const unsigned sh = (((uint32_t)(y * w + x0) * 3u) & 3u) * 8u;   // 0 or 16
                     const unsigned long long q8 = (((unsigned long long)pre[j].y << 32) | pre[j].x) >> sh;
@@ -764,7 +771,8 @@ bool fused_supported(const edgehip_ctx *c) {
     return fused_lds_bytes(pl.w) <= 160 * 1024;
 }
 
-int stage_a_fused_enqueue(edgehip_ctx *c, int slot, const uint8_t *rgb_base, const int32_t *rgb_idx, const uint16_t *grey16) {
+int stage_a_fused_enqueue(edgehip_ctx *c, int slot, const uint8_t *rgb_base, const int32_t *rgb_idx, const uint16_t *grey16,
+                          const uint8_t *grey8) {
     const DevicePlan &pl = c->plan;
     const int B = pl.nseq;
     const int nw = fused_col_waves(pl.w);
@@ -794,27 +802,35 @@ int stage_a_fused_enqueue(edgehip_ctx *c, int slot, const uint8_t *rgb_base, con
 #endif
     const size_t sm = fused_lds_bytes(pl.w);
     a.grey16 = grey16;
-    // the shipped image sizes get their own instantiation (EuRoC 752 from RGB, TUM 640 from the undistorted grey plane), any
-    // other width — and contexts with debug planes — the generic ones
+    a.grey8 = grey8;
+    // the shipped image sizes get their own instantiation (EuRoC 752 from RGB or mono, TUM 640 from the undistorted grey
+    // plane), any other width — and contexts with debug planes — the generic ones
+#define EH_FUSED(WW, DBG, SRC) k_stage_a_fused<WW, DBG, SRC, kFusedRB, 3, 3, 5, 5, 5>
     void (*fn)(FusedArgs);
     if (grey16) {
-        fn = k_stage_a_fused<0, false, true, kFusedRB, 3, 3, 5, 5, 5>;
-        if (c->planes) fn = k_stage_a_fused<0, true, true, kFusedRB, 3, 3, 5, 5, 5>;
-        else if (pl.w == 640) fn = k_stage_a_fused<640, false, true, kFusedRB, 3, 3, 5, 5, 5>;
+        fn = EH_FUSED(0, false, SRC_GREY16);
+        if (c->planes) fn = EH_FUSED(0, true, SRC_GREY16);
+        else if (pl.w == 640) fn = EH_FUSED(640, false, SRC_GREY16);
+    } else if (grey8) {
+        fn = EH_FUSED(0, false, SRC_GREY8);
+        if (c->planes) fn = EH_FUSED(0, true, SRC_GREY8);
+        else if (pl.w == 752) fn = EH_FUSED(752, false, SRC_GREY8);
     } else {
-        fn = k_stage_a_fused<0, false, false, kFusedRB, 3, 3, 5, 5, 5>;
-        if (c->planes) fn = k_stage_a_fused<0, true, false, kFusedRB, 3, 3, 5, 5, 5>;
-        else if (pl.w == 752) fn = k_stage_a_fused<752, false, false, kFusedRB, 3, 3, 5, 5, 5>;
-        else if (pl.w == 640) fn = k_stage_a_fused<640, false, false, kFusedRB, 3, 3, 5, 5, 5>;
+        fn = EH_FUSED(0, false, SRC_RGB24);
+        if (c->planes) fn = EH_FUSED(0, true, SRC_RGB24);
+        else if (pl.w == 752) fn = EH_FUSED(752, false, SRC_RGB24);
+        else if (pl.w == 640) fn = EH_FUSED(640, false, SRC_RGB24);
     }
     if (!c->lds_optin_fused) {
-        const void *fns[7] = {(const void *)k_stage_a_fused<0, false, false, kFusedRB, 3, 3, 5, 5, 5>, (const void *)k_stage_a_fused<0, true, false, kFusedRB, 3, 3, 5, 5, 5>,
-                              (const void *)k_stage_a_fused<752, false, false, kFusedRB, 3, 3, 5, 5, 5>, (const void *)k_stage_a_fused<640, false, false, kFusedRB, 3, 3, 5, 5, 5>,
-                              (const void *)k_stage_a_fused<0, false, true, kFusedRB, 3, 3, 5, 5, 5>, (const void *)k_stage_a_fused<0, true, true, kFusedRB, 3, 3, 5, 5, 5>,
-                              (const void *)k_stage_a_fused<640, false, true, kFusedRB, 3, 3, 5, 5, 5>};
+        const void *fns[10] = {(const void *)EH_FUSED(0, false, SRC_RGB24), (const void *)EH_FUSED(0, true, SRC_RGB24),
+                               (const void *)EH_FUSED(752, false, SRC_RGB24), (const void *)EH_FUSED(640, false, SRC_RGB24),
+                               (const void *)EH_FUSED(0, false, SRC_GREY16), (const void *)EH_FUSED(0, true, SRC_GREY16),
+                               (const void *)EH_FUSED(640, false, SRC_GREY16), (const void *)EH_FUSED(0, false, SRC_GREY8),
+                               (const void *)EH_FUSED(0, true, SRC_GREY8), (const void *)EH_FUSED(752, false, SRC_GREY8)};
         for (const void *f : fns) EH_CHECK(hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         c->lds_optin_fused = true;
     }
+#undef EH_FUSED
     {
         ProfScope ps(c, PROF_A_FUSED, c->stream_a);
         hipLaunchKernelGGL(fn, dim3(B), dim3((nw + 2) * 64), sm, c->stream_a, a);

@@ -206,6 +206,7 @@ EXPORTS = [
     "edgehip_build_undistort_map", "edgehip_download_undistorted", "edgehip_depth_reset", "edgehip_depth_reset_slot", "edgehip_set_slot_camera", "edgehip_directed_matching_stereo",
     "edgehip_alloc_pinned", "edgehip_free_pinned", "edgehip_upload_rgb_pinned", "edgehip_fuse_stereo_depth", "edgehip_set_stereo_rig", "edgehip_get_stereo_matches", "edgehip_minimizer_v", "edgehip_ext_rot_vel",
     "edgehip_imu_enable", "edgehip_set_imu", "edgehip_read_nav_imu", "edgehip_minimizer_rv_kf", "edgehip_lm_solve",
+    "edgehip_upload_grey8", "edgehip_upload_grey8_pinned", "edgehip_bind_grey8_indexed",
 ]
 
 _lib = None
@@ -356,6 +357,33 @@ class EdgeHip:
             rgb = rgb[None]
         assert rgb.shape[1:] == (self.h, self.w, 3)
         self._ck(self.lib.edgehip_upload_rgb(self.ctx, slot, rgb.ctypes.data_as(C.c_void_p), seq_first, rgb.shape[0]))
+
+    def upload_grey8(self, slot, grey, seq_first=0):
+        """8-bit mono frames [count][h][w] (or one [h][w]): a third of the bytes of upload_rgb, identical results."""
+        grey = np.ascontiguousarray(grey, dtype=np.uint8)
+        if grey.ndim == 2:
+            grey = grey[None]
+        assert grey.shape[1:] == (self.h, self.w)
+        self._ck(self.lib.edgehip_upload_grey8(self.ctx, slot, grey.ctypes.data_as(C.c_void_p), seq_first, grey.shape[0]))
+
+    def upload_grey8_pinned(self, slot, ptr, seq_first=0, count=None):
+        self._ck(self.lib.edgehip_upload_grey8_pinned(self.ctx, slot, ptr, seq_first, self.nseq if count is None else count))
+
+    def bind_grey8_indexed(self, slot, pool_dev_ptr, pool_frames, idx):
+        """Stage A of `slot` reads 8-bit mono frame idx[s] of a device pool in place (no copy); the pool needs 16 B of slack."""
+        idx = np.ascontiguousarray(idx, np.int32)
+        assert idx.shape == (self.nseq,)
+        self._ck(self.lib.edgehip_bind_grey8_indexed(self.ctx, slot, C.c_void_p(pool_dev_ptr), pool_frames,
+                                                     idx.ctypes.data_as(C.c_void_p)))
+
+    def alloc_pinned_grey8(self, count=None):
+        """Page-locked uint8 array [count][h][w] for upload_grey8_pinned (free with free_pinned)."""
+        count = self.nseq if count is None else count
+        nbytes = count * self.h * self.w
+        ptr = C.c_void_p()
+        self._ck(self.lib.edgehip_alloc_pinned(C.c_size_t(nbytes), C.byref(ptr)))
+        buf = (C.c_uint8 * nbytes).from_address(ptr.value)
+        return np.frombuffer(buf, np.uint8).reshape(count, self.h, self.w), ptr
 
     def upload_rgb_device(self, slot, dev_ptr):
         self._ck(self.lib.edgehip_upload_rgb_device(self.ctx, slot, C.c_void_p(dev_ptr)))

@@ -1,0 +1,109 @@
+"""8-bit mono ingest (GPU): edgehip_upload_grey8 / _pinned / edgehip_bind_grey8_indexed against the RGB24 path fed the
+r = g = b expansion of the same image — what the reference's DataSetCam hands ConvertRGB2BW for a mono data set
+(datasetcam.cpp:109-171, image.h:197-203).  b + g + r = 3 v either way, so everything downstream must be bit-identical:
+kn, img_mask_kl, every KeyLine field, the poses of a short replay.  Both stage-A paths: the one-kernel path reads the 8-bit
+frame in its first load (SRC_GREY8), the multi-kernel path gets the RGB24 expansion on the device."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from helpers import require_ref
+from rebvo_amd import edgehip, synth
+
+pytestmark = pytest.mark.gpu
+
+
+def _mono_frames(w, h, n, seed=4):
+    frames = [f for f, _, _ in synth.billboard_sequence(w, h, n, seed=seed)]
+    mono = [np.ascontiguousarray(f[:, :, 1]) for f in frames]
+    rgb = [np.ascontiguousarray(np.repeat(m[:, :, None], 3, axis=2)) for m in mono]
+    return mono, rgb
+
+
+def _replay(w, h, feed, nf, nseq=2):
+    eh = edgehip.EdgeHip(edgehip.euroc_params(w, h), nseq=nseq, nslots=3)
+    navs = []
+    for k in range(nf):
+        feed(eh, eh.next_slot(), k)
+        eh.process_frame(0.05 * k)
+        navs.append(eh.read_nav())
+    kl, mask = eh.download_keylines(nseq - 1, eh.cur_slot())
+    eh.close()
+    return navs, kl, mask
+
+
+def _same(a, b):
+    na, kla, ma = a
+    nb, klb, mb = b
+    assert np.array_equal(ma, mb)
+    assert kla.tobytes() == klb.tobytes()
+    for ra, rb in zip(na, nb):
+        for x, y in zip(ra, rb):
+            assert (x.kn, x.klm_num, x.estimation_ok) == (y.kn, y.klm_num, y.estimation_ok)
+            assert bytes(x) == bytes(y)      # the whole record, bit for bit
+
+
+@pytest.mark.parametrize("mode,w,h", [("3", 752, 480), ("3", 200, 152), ("1", 376, 240), ("0", 200, 152)],
+                         ids=["fused_752", "fused_generic", "multi_kernel", "auto_small_batch"])
+def test_grey8_upload_is_bit_identical_to_the_rgb24_expansion(mode, w, h, monkeypatch):
+    monkeypatch.setenv("EDGEHIP_LEVEL_MODE", mode)
+    mono, rgb = _mono_frames(w, h, 4)
+    a = _replay(w, h, lambda eh, s, k: eh.upload_rgb(s, np.stack([rgb[k]] * 2)), 4)
+    b = _replay(w, h, lambda eh, s, k: eh.upload_grey8(s, np.stack([mono[k]] * 2)), 4)
+    _same(a, b)
+    assert a[0][-1][0].kn > 500
+
+
+def test_grey8_against_the_reference_fed_rgb24():
+    """The device on 8-bit frames against the CPU reference on their RGB24 expansion: mask and pose."""
+    oracle = require_ref()
+    w, h = 376, 240
+    mono, rgb = _mono_frames(w, h, 4, seed=9)
+    orc = oracle.Oracle("ref", oracle.euroc_params(w, h))
+    eh = edgehip.EdgeHip(edgehip.euroc_params(w, h), nseq=1, nslots=3)
+    for k in range(4):
+        _, nr = orc.process_frame(rgb[k], 0.05 * k)
+        eh.upload_grey8(eh.next_slot(), mono[k])
+        eh.process_frame(0.05 * k)
+        ng = eh.read_nav()[0]
+        assert (ng.kn, ng.klm_num) == (nr.kn, nr.klm_num)
+        if k:
+            assert np.allclose(ng.V[:], nr.V[:], rtol=0, atol=1e-9) and np.allclose(ng.W[:], nr.W[:], rtol=0, atol=1e-9)
+    _, mask = eh.download_keylines(0, eh.cur_slot())
+    assert np.array_equal(mask, orc.mask(orc.cur_slot()))
+    eh.close()
+    orc.close()
+
+
+def test_grey8_pinned_and_bound_pool_variants(monkeypatch):
+    """Page-locked upload (upload stream) and frames read in place from a device pool, in the one-kernel stage A; and a slot that
+    changes format from frame to frame."""
+    monkeypatch.setenv("EDGEHIP_LEVEL_MODE", "3")
+    w, h, nf = 752, 480, 4
+    mono, rgb = _mono_frames(w, h, nf, seed=6)
+    ref = _replay(w, h, lambda eh, s, k: eh.upload_rgb(s, np.stack([rgb[k]] * 2)), nf)
+
+    pinned = {}
+
+    def feed_pinned(eh, s, k):
+        if "buf" not in pinned:
+            pinned["buf"] = [eh.alloc_pinned_grey8() for _ in range(2)]
+        arr, ptr = pinned["buf"][k % 2]
+        eh.sync()
+        arr[...] = np.stack([mono[k]] * 2)
+        eh.upload_grey8_pinned(s, ptr)
+    _same(ref, _replay(w, h, feed_pinned, nf))
+
+    host = np.stack(mono)
+    pool = torch.empty(host.size + 16, dtype=torch.uint8, device="cuda")
+    pool[:host.size] = torch.from_numpy(host.reshape(-1)).cuda()
+    _same(ref, _replay(w, h, lambda eh, s, k: eh.bind_grey8_indexed(s, pool.data_ptr(), nf, np.array([k, k], np.int32)), nf))
+
+    def feed_mixed(eh, s, k):
+        if k % 2:
+            eh.upload_grey8(s, np.stack([mono[k]] * 2))
+        else:
+            eh.upload_rgb(s, np.stack([rgb[k]] * 2))
+    _same(ref, _replay(w, h, feed_mixed, nf))
