@@ -14,12 +14,14 @@ namespace rebvo {
 
 // Decode a PNG / PGM / PPM file into RGB24 (grey replicated, alpha dropped, 16-bit samples reduced to their high
 // byte — what libgd's truecolor conversion yields).  Returns false with a message in `err`.
-bool LoadImageRGB24(const std::string &file, std::vector<RGB24Pixel> &out, unsigned &w, unsigned &h, std::string &err);
+// `mono` (optional): the file stores one grey channel (PNG colour types 0 / 4, PGM), i.e. r = g = b for every pixel.
+bool LoadImageRGB24(const std::string &file, std::vector<RGB24Pixel> &out, unsigned &w, unsigned &h, std::string &err, bool *mono = nullptr);
 
 class DataSetCam {
     bool error = true;
     bool frm_pending = false;
     Image<RGB24Pixel> buffer;
+    std::vector<uint8_t> grey;   // the frame as 8-bit mono when the file stores one grey channel (EuRoC), else empty
     double time = 0;
     std::string strDir;
     std::vector<std::string> img_list;
@@ -36,6 +38,10 @@ public:
     int GrabFrame(RGB24Pixel *data, double &tstamp, bool drop_frames = true);
     RGB24Pixel *GrabBuffer(double &tstamp, bool drop_frames = true);
     int ReleaseBuffer() { return 0; }
+    // The frame GrabBuffer just returned as 8-bit mono, 1 byte per pixel, or nullptr when the file was a colour image.  The
+    // reference expands mono images to RGB24 because its CPU path wants RGB24 (datasetcam.cpp:152-160); the device path takes
+    // the 8-bit plane (edgehip_upload_grey8: a third of the bytes, identical results).
+    const uint8_t *GreyBuffer() const { return grey.empty() ? nullptr : grey.data(); }
     const bool &Error() { return error; }
     unsigned PakNum() const { return paknum; }
     size_t NumFrames() const { return img_list.size() < img_time.size() ? img_list.size() : img_time.size(); }

@@ -48,7 +48,8 @@ int DataSetCam::LoadImage(const std::string &i_name) {
     std::vector<RGB24Pixel> px;
     unsigned w = 0, h = 0;
     std::string err;
-    if (!LoadImageRGB24(i_name, px, w, h, err)) {
+    bool mono = false;
+    if (!LoadImageRGB24(i_name, px, w, h, err, &mono)) {
         std::cout << "\nDataSetCam: Image " << i_name << " " << err << "\n";
         return -1;
     }
@@ -58,6 +59,11 @@ int DataSetCam::LoadImage(const std::string &i_name) {
         return -1;
     }
     buffer.copyFrom(px.data());
+    grey.clear();
+    if (mono) {
+        grey.resize(px.size());
+        for (size_t i = 0; i < px.size(); i++) grey[i] = px[i].pix.r;
+    }
     return 0;
 }
 

@@ -36,7 +36,7 @@ inline int paeth(int a, int b, int c) {
 // sizes this library handles are at most 1024 wide; 16384 x 16384 leaves any real dataset plenty of room).
 inline bool sane_size(unsigned w, unsigned h) { return w >= 1 && h >= 1 && w <= 16384 && h <= 16384; }
 
-bool decode_png(const std::vector<unsigned char> &d, std::vector<RGB24Pixel> &out, unsigned &w, unsigned &h, std::string &err) {
+bool decode_png(const std::vector<unsigned char> &d, std::vector<RGB24Pixel> &out, unsigned &w, unsigned &h, std::string &err, bool *mono) {
     static const unsigned char sig[8] = {137, 80, 78, 71, 13, 10, 26, 10};
     if (d.size() < 33 || memcmp(d.data(), sig, 8) != 0) { err = "not a PNG"; return false; }
     size_t pos = 8;
@@ -123,10 +123,11 @@ bool decode_png(const std::vector<unsigned char> &d, std::vector<RGB24Pixel> &ou
         }
         prev.swap(cur);
     }
+    if (mono) *mono = (ctype == 0 || ctype == 4);   // grey / grey + alpha: r = g = b for every pixel
     return true;
 }
 
-bool decode_pnm(const std::vector<unsigned char> &d, std::vector<RGB24Pixel> &out, unsigned &w, unsigned &h, std::string &err) {
+bool decode_pnm(const std::vector<unsigned char> &d, std::vector<RGB24Pixel> &out, unsigned &w, unsigned &h, std::string &err, bool *mono) {
     size_t pos = 2;
     auto next_int = [&](unsigned &v) {
         while (pos < d.size()) {
@@ -150,17 +151,19 @@ bool decode_pnm(const std::vector<unsigned char> &d, std::vector<RGB24Pixel> &ou
         const unsigned char *p = &d[pos + i * ch];
         out[i].pix.r = p[0]; out[i].pix.g = p[ch == 1 ? 0 : 1]; out[i].pix.b = p[ch == 1 ? 0 : 2];
     }
+    if (mono) *mono = ch == 1;
     return true;
 }
 
 }  // namespace
 
-bool LoadImageRGB24(const std::string &file, std::vector<RGB24Pixel> &out, unsigned &w, unsigned &h, std::string &err) {
+bool LoadImageRGB24(const std::string &file, std::vector<RGB24Pixel> &out, unsigned &w, unsigned &h, std::string &err, bool *mono) {
+    if (mono) *mono = false;
     std::vector<unsigned char> d;
     if (!read_file(file, d, err)) return false;
     try {   // an allocation failure is a camera error (DataSetCam ends the sequence), not std::terminate in the track thread
-        if (d.size() > 8 && d[0] == 137 && d[1] == 'P') return decode_png(d, out, w, h, err);
-        if (d.size() > 2 && d[0] == 'P' && (d[1] == '5' || d[1] == '6')) return decode_pnm(d, out, w, h, err);
+        if (d.size() > 8 && d[0] == 137 && d[1] == 'P') return decode_png(d, out, w, h, err, mono);
+        if (d.size() > 2 && d[0] == 'P' && (d[1] == '5' || d[1] == '6')) return decode_pnm(d, out, w, h, err, mono);
     } catch (const std::bad_alloc &) {
         err = "out of memory while decoding " + file;
         return false;

@@ -454,12 +454,18 @@ void REBVO::TrackThread(REBVO *cf) {
         const bool imu_mode = cf->imu != nullptr;
         // ring of 3 device slots; without the IMU branch the library's own whole-frame driver advances it
         const int slot = imu_mode ? n_frames % 3 : edgehip_next_slot(cf->hip);
-        int rc = edgehip_upload_rgb(cf->hip, slot, reinterpret_cast<const uint8_t *>(data), 0, 1);
+        // a mono data set (EuRoC) goes to the device as the 8-bit plane the file holds; the RGB24 expansion stays on the host for
+        // the callback's PipeBuffer::imgc
+        const uint8_t *grey = (!cbuf && cf->dscam) ? cf->dscam->GreyBuffer() : nullptr;
+        int rc = grey ? edgehip_upload_grey8(cf->hip, slot, grey, 0, 1)
+                      : edgehip_upload_rgb(cf->hip, slot, reinterpret_cast<const uint8_t *>(data), 0, 1);
         std::memcpy(new_buf.imgc->Data(), data, frame_bytes);
         if (cbuf) cf->cam_pipe.ReleaseBuffer(1);
         else cf->dscam->ReleaseBuffer();
         if (data_pair) {   // the pair image goes to the slot behind the ring
-            if (rc == 0) rc = edgehip_upload_rgb(cf->hip, 3, reinterpret_cast<const uint8_t *>(data_pair), 0, 1);
+            const uint8_t *grey_pair = (!cbuf_pair && cf->dscam_pair) ? cf->dscam_pair->GreyBuffer() : nullptr;
+            if (rc == 0) rc = grey_pair ? edgehip_upload_grey8(cf->hip, 3, grey_pair, 0, 1)
+                                        : edgehip_upload_rgb(cf->hip, 3, reinterpret_cast<const uint8_t *>(data_pair), 0, 1);
             std::memcpy(new_buf.imgc_pair->Data(), data_pair, frame_bytes);
             if (cbuf_pair) cf->cam_pipe_stereo.ReleaseBuffer(1);
             else cf->dscam_pair->ReleaseBuffer();
@@ -583,6 +589,7 @@ void REBVO::ThirdThread(REBVO *cf) {
                   << nv.Rot(1, 0) << "," << nv.Rot(1, 1) << "," << nv.Rot(1, 2) << ";" << nv.Rot(2, 0) << "," << nv.Rot(2, 1) << ","
                   << nv.Rot(2, 2) << "];\n";
             a_log << "Vel_cv(" << a_log_inx << ",:)=[" << nv.Vel[0] << "," << nv.Vel[1] << "," << nv.Vel[2] << "];\n";
+            a_log << "RotGiro_cv(" << a_log_inx << ",:)=[" << nv.RotGiro[0] << "," << nv.RotGiro[1] << "," << nv.RotGiro[2] << "];\n";
             a_log << "t_cv(" << a_log_inx << ",:)=" << pbuf.t << ";\n";
             a_log << "dt_cv(" << a_log_inx << ",:)=" << pbuf.dt << ";\n";
             a_log << "i_cv(" << a_log_inx << ",:)=" << pbuf.p_id << ";\n";
@@ -592,6 +599,24 @@ void REBVO::ThirdThread(REBVO *cf) {
             a_log << "Pos_cv(" << a_log_inx << ",:)=[" << nv.Pos[0] << "," << nv.Pos[1] << "," << nv.Pos[2] << "];\n";
             a_log << "K_cv(" << a_log_inx << ",:)=" << pbuf.K << ";\n";
             a_log << "KLN_cv(" << a_log_inx << ",:)=" << pbuf.ef->KNum() << ";\n";
+            // the IMU / stereo block of the reference's log (rebvo_third_t.cpp:279-300), same keys in the same order
+            auto v3log = [&](const char *key, const double *v) {
+                a_log << key << "_cv(" << a_log_inx << ",:)=[" << v[0] << "," << v[1] << "," << v[2] << "];\n";
+            };
+            const IMUState &is = pbuf.imustate;
+            v3log("Giro", &pbuf.imu.giro[0]);
+            v3log("Acel", &pbuf.imu.acel[0]);
+            v3log("CAcel", &pbuf.imu.cacel[0]);
+            v3log("DGiro", &pbuf.imu.dgiro[0]);
+            v3log("GBias", &is.Bg[0]);
+            v3log("dWv", &is.dWv[0]);
+            v3log("dWgv", &is.dWgv[0]);
+            v3log("g", &is.g_est[0]);
+            v3log("VBias", &is.b_est[0]);
+            v3log("Av", &is.Av[0]);
+            v3log("As", &is.As[0]);
+            v3log("Posgv", &is.Posgv[0]);
+            a_log << "SMM_cv(" << a_log_inx << ",:)=" << pbuf.stereo_match_num << ";\n";
             a_log << "TProc0_cv(" << a_log_inx << ",:)=" << pbuf.dtp0 << ";\n";
             a_log << "TProc1_cv(" << a_log_inx << ",:)=" << pbuf.dtp1 << ";\n";
             a_log << "TProc2_cv(" << a_log_inx << ",:)=" << t_proc_last << ";\n";

@@ -103,6 +103,45 @@ def test_imu_mode2_replay_matches_reference(tmp_path):
         t_prev = t[k]
     o = _run_reference(tmp_path, frames, t, imu_rows, {"init_bias_frame_num": INIT_BIAS_FRAMES})
     _compare(rows, o)
+    _compare_log(tmp_path / "log.m", len(rows), imu_rows, o)
+
+
+# every key the reference's ThirdThread writes per frame (rebvo_third_t.cpp:264-304), in its order
+LOG_KEYS = ["Kp", "RKp", "Rot", "Vel", "RotGiro", "t", "dt", "i", "Pose", "Pos", "K", "KLN", "Giro", "Acel", "CAcel", "DGiro", "GBias",
+            "dWv", "dWgv", "g", "VBias", "Av", "As", "Posgv", "SMM", "TProc0", "TProc1", "TProc2"]
+
+
+def _parse_log(path):
+    import re
+    out, order = {}, []
+    pat = re.compile(r"^(\w+)_cv\((\d+),[:,]+\)=\[?([^\]]*)\]?;$")
+    for line in open(path):
+        m = pat.match(line.strip())
+        assert m, line
+        key, idx = m.group(1), int(m.group(2))
+        vals = [float(v) for v in re.split(r"[;,]", m.group(3))]
+        out.setdefault(key, {})[idx] = np.array(vals)
+        if idx == 1:
+            order.append(key)
+    return out, order
+
+
+def _compare_log(path, nrows, imu_rows, o):
+    """The .m log of the same run: all 28 keys of the reference's writer, in its order, one entry per delivered frame; the IMU
+    block (the part round 2 did not write) against the reference's own values, at the log's 6 significant digits."""
+    log, order = _parse_log(path)
+    assert order == LOG_KEYS, order
+    for key in LOG_KEYS:
+        assert sorted(log[key]) == list(range(1, nrows + 1)), key
+    close = lambda a, b: np.allclose(a, b, rtol=2e-5, atol=2e-7)
+    for k in range(1, nrows - 1):                 # log entry k+1 = frame k
+        e = {key: log[key][k + 1] for key in LOG_KEYS}
+        r = np.asarray(imu_rows[k])
+        assert close(e["Giro"], r[11:14]) and close(e["Acel"], r[14:17]) and close(e["DGiro"], r[20:23]) and close(e["CAcel"], r[23:26]), k
+        assert close(e["GBias"], o["Bg"][k]) and close(e["dWv"], o["dWv"][k]) and close(e["RotGiro"], o["RotGiro"][k]), k
+        assert close(e["g"], o["g"][k]) and close(e["VBias"], o["b_est"][k]), k
+        assert close(e["Av"], o["Av"][k]) and close(e["As"], o["As"][k]), k
+        assert int(e["SMM"][0]) == 0 and int(e["KLN"][0]) > 0
 
 
 def _compare(rows, o):
