@@ -1138,6 +1138,26 @@ __device__ __forceinline__ void lm_body(const LmArgs &a, const int seq, const in
     constexpr int kWords = sizeof(SeqDev) / 8;
     __shared__ unsigned long long s_state[kWords];
     unsigned long long *gstate = reinterpret_cast<unsigned long long *>(a.seq + seq);
+    // Everything the step reads from global memory is requested here, in one go: the sequence state, the evaluation's
+    // per-block partial sums and the blocks' last residuals.  The step is one wave per sequence and nothing but latency —
+    // it used to pay the state's round trip, then (the block count comes out of the state) four more for the partials in
+    // batches of eight, then one for the residuals.  How many blocks count is decided after the state has arrived; blocks
+    // beyond it hold stale sums and are loaded in vain (a.nblk <= 64 blocks: 32 per lane; larger contexts keep the loop).
+    constexpr int kPre = 32;
+    const bool prefetch = a.nblk <= 2 * kPre && (ops & (LM_REDUCE_CUR | LM_REDUCE_NEW));
+    const int pv_v = lane & 31, pv_g = lane >> 5;
+    const bool pv_on = pv_v < kNumSums && (!(ops & LM_NOJAC) || pv_v == kNumSums - 1);
+    double pv[kPre];
+    double bl_pre = 0;
+    if (prefetch) {
+        const double *pp = a.partials + (size_t)seq * a.nblk * kNumSums;
+#pragma unroll
+        for (int j = 0; j < kPre; j++) {
+            const int b = pv_g + 2 * j;
+            pv[j] = (pv_on && b < a.nblk) ? pp[(size_t)b * kNumSums + pv_v] : 0.0;
+        }
+        if (lane < a.nblk) bl_pre = a.block_last[(size_t)seq * a.nblk + lane];
+    }
     for (int i = lane; i < kWords; i += 64) s_state[i] = gstate[i];
     lm_sync<WAVE_ONLY>();
     SeqDev *sq = reinterpret_cast<SeqDev *>(s_state);
@@ -1191,23 +1211,38 @@ __device__ __forceinline__ void lm_body(const LmArgs &a, const int seq, const in
         const double *pp = a.partials + (size_t)seq * a.nblk * kNumSums;
         const int v = lane & 31, g = lane >> 5;
         double acc = 0;
-        if (v < kNumSums && (!(ops & LM_NOJAC) || v == kNumSums - 1)) {
+        if (prefetch) {
+#pragma unroll
+            for (int j = 0; j < kPre; j++)
+                if (g + 2 * j < nblk_used) acc += pv[j];   // same blocks, same order as the loop below
+        } else if (v < kNumSums && (!(ops & LM_NOJAC) || v == kNumSums - 1)) {
 #pragma unroll 8
             for (int b = g; b < nblk_used; b += 2) acc += pp[(size_t)b * kNumSums + v];
         }
         s_part[g][v] = acc;
-        // per-block last residuals of the buffer that was just written -> LDS
+        const int res_out = sq->lm_phase == 0 ? sq->res_t : sq->res_new;
+        double *cr = a.resid_carry + ((size_t)res_out * a.nseq + seq) * a.nblk;
         const double *bl = a.block_last + (size_t)seq * a.nblk;
-        for (int b = lane; b < nblk_used; b += 64) s_bl[b & 255] = bl[b];
+        if (prefetch) {
+            // resolve the carries across the lanes: block b starts from the last valid residual of the blocks before it
+            // (fi = 0 at the top): the newest valid lane below b, found in the ballot
+            const bool valid = lane < nblk_used && !is_carry(bl_pre);
+            const unsigned long long vm = __ballot(valid);
+            const unsigned long long below = vm & ((1ull << lane) - 1ull);
+            const int src = below ? 63 - __clzll(below) : 0;
+            const double inh = __shfl(bl_pre, src, 64);
+            if (lane < nblk_used) cr[lane] = below ? inh : 0.0;
+        } else {
+            // per-block last residuals of the buffer that was just written -> LDS
+            for (int b = lane; b < nblk_used; b += 64) s_bl[b & 255] = bl[b];
+        }
         lm_sync<WAVE_ONLY>();
         if (lane < kNumSums) {
             double t = 0;
             t = s_part[0][lane] + s_part[1][lane];
             s_sum[lane] = t;
         }
-        if (lane == 32) {  // resolve the carries: prefix "last valid" over the blocks (T fi=0 at the top)
-            const int res_out = sq->lm_phase == 0 ? sq->res_t : sq->res_new;
-            double *cr = a.resid_carry + ((size_t)res_out * a.nseq + seq) * a.nblk;
+        if (!prefetch && lane == 32) {  // resolve the carries: prefix "last valid" over the blocks (T fi=0 at the top)
             double run = 0;
             for (int b = 0; b < nblk_used; b++) {
                 cr[b] = run;
