@@ -247,6 +247,7 @@ struct edgehip_ctx {
     int32_t *fwd_win;      // [B][CAP]
     int fwd_mode = 0;              // EDGEHIP_FWD_MODE: 0 keys by the minimiser + k_fwd_win / k_fwd_apply / k_rotate, 1 the round-2 chain (own key pass),
                                    // 2 keys by the minimiser + k_fwd_win + k_fwd_apply_rotate (one scattering pass over the old KeyLines)
+    bool fwd_cleared = false;      // fwd_key / fwd_win of the new edge map were reset by k_field_bin (whole-frame driver)
     bool fwd_key_in_tvr = false;   // whole-frame driver: the minimiser's last evaluation also posts FordwardMatch's arbitration keys
     double *rs_tmp;        // [B][2][CAP] regularised (rho, s_rho) ping-pong
     double *rot_buf;       // [B][9] rotation applied by rotate_keylines
@@ -363,7 +364,7 @@ int order_bc_after_a(edgehip_ctx *c);
 int sync_all(edgehip_ctx *c);
 int undistort_frame_enqueue(edgehip_ctx *c, int seq, int slot, uint8_t *out_dev);
 int quantile_enqueue(edgehip_ctx *c, int slot, double smin, double smax, double pct, int nbins);
-int build_field_enqueue(edgehip_ctx *c, int slot, int radius, float min_mod);
+int build_field_enqueue(edgehip_ctx *c, int slot, int radius, float min_mod, bool clear_fwd = false);
 int tvr_prepare_enqueue(edgehip_ctx *c, int slot_old);
 int minimizer_enqueue(edgehip_ctx *c, int slot_new, int slot_old, int fc_index);
 int minimizer_v_enqueue(edgehip_ctx *c, int slot_new, int slot_old, int fc_index, int iter_max, double match_thresh,

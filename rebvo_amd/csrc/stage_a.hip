@@ -1307,7 +1307,7 @@ int stage_a_enqueue(edgehip_ctx *c, int slot) {
             PlanePtrs pp;
             pp.p[0] = a;
             pp.p[1] = b ? b : a;
-            hipLaunchKernelGGL(k_colscan<16>, dim3((w + 63) / 64, b ? 2 : 1, B), dim3(64), 0, st, pp, w, h, n);
+            hipLaunchKernelGGL(k_colscan<32>, dim3((w + 63) / 64, b ? 2 : 1, B), dim3(64), 0, st, pp, w, h, n);
             EH_LAUNCH_CHECK();
             return 0;
         };

@@ -231,12 +231,16 @@ __device__ __forceinline__ bool tile_trange(const MatchRec &r, int tx0, int ty0,
 __global__ __launch_bounds__(256) void k_field_bin(const KlSoA *kls, const int32_t *__restrict__ kns,
                                                    const float *__restrict__ retuned, int32_t *__restrict__ bin_cnt,
                                                    int32_t *__restrict__ bins, int w, int h, int radius, float min_mod_arg,
-                                                   int ntx, int nty, int bin_cap) {
+                                                   int ntx, int nty, int bin_cap, unsigned long long *__restrict__ fwd_key,
+                                                   int32_t *__restrict__ fwd_win) {
     __shared__ int s_cnt[kMaxTiles], s_base[kMaxTiles];
     const int seq = blockIdx.z, tid = threadIdx.x;
     const int i = blockIdx.x * 256 + tid;
     const int kn = kns[seq];
     if (blockIdx.x * 256 >= kn) return;
+    // whole-frame driver: this kernel visits every KeyLine of the NEW edge map right before the minimisation, so it also
+    // resets FordwardMatch's arbitration entries of that KeyLine (12 B in a stream) instead of two memsets over [B][CAP]
+    if (fwd_key && i < kn) { fwd_key[(size_t)seq * bin_cap + i] = 0ull; fwd_win[(size_t)seq * bin_cap + i] = -1; }
     const int ntiles = ntx * nty;
     for (int t = tid; t < ntiles; t += 256) s_cnt[t] = 0;
     __syncthreads();
@@ -1730,7 +1734,8 @@ int quantile_enqueue(edgehip_ctx *c, int slot, double smin, double smax, double 
     return 0;
 }
 
-int build_field_enqueue(edgehip_ctx *c, int slot, int radius, float min_mod) {
+int build_field_enqueue(edgehip_ctx *c, int slot, int radius, float min_mod, bool clear_fwd) {
+    c->fwd_cleared = false;
     ProfScope ps(c, PROF_B_FIELD);
     const DevicePlan &pl = c->plan;
     if (radius < 1 || radius > 255) { set_error("build_field: 1 <= radius <= 255"); return EDGEHIP_ERR_ARG; }
@@ -1740,7 +1745,8 @@ int build_field_enqueue(edgehip_ctx *c, int slot, int radius, float min_mod) {
         EH_CHECK(hipMemsetAsync(c->bin_cnt, 0, sizeof(int32_t) * pl.nseq * kMaxTiles, c->stream));
         hipLaunchKernelGGL(k_field_bin, dim3((pl.cap + 255) / 256, 1, pl.nseq), dim3(256), 0, c->stream, kldev(c, slot),
                            c->kn_slot + (size_t)slot * pl.nseq, c->retuned_slot + (size_t)slot * pl.nseq, c->bin_cnt, c->bins,
-                           pl.w, pl.h, radius, min_mod, ntx, nty, pl.cap);
+                           pl.w, pl.h, radius, min_mod, ntx, nty, pl.cap, clear_fwd ? c->fwd_key : nullptr, clear_fwd ? c->fwd_win : nullptr);
+        c->fwd_cleared = clear_fwd;
         hipLaunchKernelGGL(k_field_raster, dim3(ntx, nty, pl.nseq), dim3(256), 0, c->stream, kldev(c, slot), c->bin_cnt,
                            c->bins, c->field, c->field16, pl.f16stride, pl.f16tx, c->p.debug_planes ? 1 : 0, pl.w, pl.h,
                            pl.fstride, pl.ftx, radius, ntx, pl.cap);
@@ -1882,7 +1888,7 @@ int minimizer_enqueue(edgehip_ctx *c, int slot_new, int slot_old, int fc_index) 
     c->fc_index = fc_index;
     int e;
     if ((e = tvr_prepare_enqueue(c, slot_old))) return e;
-    if (c->fwd_key_in_tvr) EH_CHECK(hipMemsetAsync(c->fwd_key, 0, sizeof(unsigned long long) * (size_t)c->plan.nseq * c->plan.cap, c->stream));
+    if (c->fwd_key_in_tvr && !c->fwd_cleared) EH_CHECK(hipMemsetAsync(c->fwd_key, 0, sizeof(unsigned long long) * (size_t)c->plan.nseq * c->plan.cap, c->stream));
     const int I = p.tracker_init_iter_num, M = p.tracker_iter_num;
     const int total_evals = (p.tracker_init_type >= 2 ? 2 * (1 + (I > 0 ? I : 0)) : 0) + 1 + (M > 0 ? M : 0);
     int evals = 0;

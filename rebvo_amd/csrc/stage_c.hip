@@ -763,8 +763,10 @@ int forward_match_enqueue(edgehip_ctx *c, int slot_old, int slot_new, bool keys_
     ProfScope ps(c, PROF_C_FORWARD);
     const DevicePlan &pl = c->plan;
     const size_t B = pl.nseq;
+    const bool cleared = keys_posted && c->fwd_cleared;   // k_field_bin reset the entries of the new edge map (whole-frame driver)
+    c->fwd_cleared = false;
     if (!keys_posted) EH_CHECK(hipMemsetAsync(c->fwd_key, 0, sizeof(unsigned long long) * B * pl.cap, c->stream));
-    EH_CHECK(hipMemsetAsync(c->fwd_win, 0xFF, sizeof(int32_t) * B * pl.cap, c->stream));
+    if (!cleared) EH_CHECK(hipMemsetAsync(c->fwd_win, 0xFF, sizeof(int32_t) * B * pl.cap, c->stream));
     dim3 g((pl.cap + 255) / 256, 1, pl.nseq), b(256);
     const int32_t *kno = c->kn_slot + slot_old * B, *knn = c->kn_slot + slot_new * B;
     if (!keys_posted) hipLaunchKernelGGL(k_fwd_key, g, b, 0, c->stream, kldev(c, slot_old), kno, knn, c->fwd_key, pl.cap);
@@ -784,7 +786,8 @@ int forward_rotate_enqueue(edgehip_ctx *c, int slot_old, int slot_new) {
     const int32_t *kno = c->kn_slot + slot_old * B, *knn = c->kn_slot + slot_new * B;
     {
         ProfScope ps(c, PROF_C_FORWARD);
-        EH_CHECK(hipMemsetAsync(c->fwd_win, 0xFF, sizeof(int32_t) * B * pl.cap, c->stream));
+        if (!c->fwd_cleared) EH_CHECK(hipMemsetAsync(c->fwd_win, 0xFF, sizeof(int32_t) * B * pl.cap, c->stream));
+        c->fwd_cleared = false;
         hipLaunchKernelGGL(k_fwd_win, g, b, 0, c->stream, kldev(c, slot_old), kno, knn, c->fwd_key, c->fwd_win, pl.cap);
         hipLaunchKernelGGL(k_rot_from_state, dim3((pl.nseq + 63) / 64), dim3(64), 0, c->stream, c->seq, c->rot_buf, pl.nseq);
         EH_LAUNCH_CHECK();
@@ -1309,7 +1312,7 @@ static int frame_enqueue(edgehip_ctx *c, int sn, int so, int sp, int have_pair, 
         EH_TRY(imu_post_enqueue(c, sn, have_pair));                                                  // :280-312, :519-606
     } else if (have_pair) {
         EH_TRY(quantile_enqueue(c, so, kRhoMin, kRhoMax, c->p.qcut_quantile, c->p.qcut_nbins));  // rebvo_second_t.cpp:172
-        EH_TRY(build_field_enqueue(c, sn, c->p.search_range, -1.f));                              // :177
+        EH_TRY(build_field_enqueue(c, sn, c->p.search_range, -1.f, c->fwd_mode != 1));            // :177
         c->fwd_key_in_tvr = c->fwd_mode != 1;
         e = minimizer_enqueue(c, sn, so, c->frames_seen % kRefRing);                              // :346
         c->fwd_key_in_tvr = false;
