@@ -54,3 +54,23 @@ def test_every_profiled_group_names_its_kernels():
     # every group bench.py may report as dominant has algorithmic bytes and a kernel list for the PMC lookup
     for g in ("A.detect", "A.level", "A.compact", "B.try_velrot", "B.build_field", "C.directed_matching", "C.forward_match"):
         assert bench.algorithmic_bytes(g, 1000, 1000, 40, 1) > 0 and bench.GROUP_KERNELS[g]
+
+
+def test_stage_a_bytes_split_between_detector_and_join_add_up_to_the_survey_figure():
+    """stage A = 3N + 4N + 168 kn.  Since round 3 the detector writes 24 B of a KeyLine and the join kernel the
+    other 144 B (after reading the 24 back and probing three mask neighbours): the two groups' algorithmic bytes must add up to
+    the survey's figure plus exactly those re-reads."""
+    kn, n = 13000, 752 * 480
+    a = bench.algorithmic_bytes("A.fused", kn, n, 40, 1) + bench.algorithmic_bytes("A.join_retune", kn, n, 40, 1)
+    assert a == 3 * n + 4 * n + 168 * kn + (24 + 3 * 4) * kn
+    assert bench.algorithmic_bytes("B.tvr_prepare", kn, n, 40, 1) == 0      # no stream left in it: latency, not priced
+
+
+def test_committed_counters_carry_the_keyline_count_they_were_taken_at():
+    js = json.load(open(os.path.join(ROOT, "profiles", "pmc_latest.json")))
+    assert js["_kn"] == bench.pmc_kn() and 5000 < js["_kn"] < 20000
+    # a KeyLine-proportional kernel's traffic is compared with the algorithmic bytes at that count
+    nseq, calib = js["_nseq"], bench.fetch_calibration()[0]
+    tr, _ = bench.calibrated_traffic("B.try_velrot", nseq, js["_kn"], calib)
+    ab = bench.algorithmic_bytes("B.try_velrot", js["_kn"], 752 * 480, 40, nseq)
+    assert 0.9 < tr / ab < 1.6

@@ -107,3 +107,28 @@ def test_grey8_pinned_and_bound_pool_variants(monkeypatch):
         else:
             eh.upload_rgb(s, np.stack([rgb[k]] * 2))
     _same(ref, _replay(w, h, feed_mixed, nf))
+
+
+@pytest.mark.parametrize("mode", ["3", "1"], ids=["fused", "multi_kernel"])
+def test_grey8_with_the_undistorting_load(mode, monkeypatch):
+    """UseUndistort (BASELINE configs[3]): the 8-bit frame is expanded on the device and resampled like the RGB24 one."""
+    monkeypatch.setenv("EDGEHIP_LEVEL_MODE", mode)
+    w, h = 640, 480
+    frames = [f for f, _, _ in synth.billboard_sequence(w, h, 3, fx=525.0, fy=525.0, cx=320.0, cy=240.0, seed=3)]
+    mono = [np.ascontiguousarray(f[:, :, 0]) for f in frames]
+    p = edgehip.tum_params(w, h, use_undistort=1)
+    res = []
+    for feed in ("rgb", "grey"):
+        eh = edgehip.EdgeHip(p, nseq=1, nslots=3)
+        navs = []
+        for k in range(3):
+            if feed == "rgb":
+                eh.upload_rgb(eh.next_slot(), frames[k])
+            else:
+                eh.upload_grey8(eh.next_slot(), mono[k])
+            eh.process_frame(0.02 * k)
+            navs.append(bytes(eh.read_nav()[0]))
+        kl, mask = eh.download_keylines(0, eh.cur_slot())
+        res.append((navs, kl.tobytes(), mask))
+        eh.close()
+    assert res[0][0] == res[1][0] and res[0][1] == res[1][1] and np.array_equal(res[0][2], res[1][2])
