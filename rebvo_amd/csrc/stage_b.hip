@@ -1804,16 +1804,22 @@ static TvrArgs make_tvr_args(edgehip_ctx *c, int slot_new, int slot_old, double 
 static int launch_tvr(edgehip_ctx *c, const TvrArgs &a, bool reweight, bool procjf) {
     ProfScope ps(c, PROF_B_TRYVELROT);
     dim3 g(c->nblk_tvr, 1, c->plan.nseq), b(kTvrThreads);
+#ifdef EDGEHIP_EXPERIMENTS
+    // occupancy experiment (tools/experiments): unused dynamic LDS per block caps the resident blocks per CU
+    static const size_t dyn_lds = getenv("EDGEHIP_TVR_LDS") ? (size_t)atoi(getenv("EDGEHIP_TVR_LDS")) : 0;
+#else
+    constexpr size_t dyn_lds = 0;
+#endif
     if (a.use_grec) {
-        if (reweight && procjf) hipLaunchKernelGGL((k_try_velrot<true, true, true>), g, b, 0, c->stream, a);
-        else if (reweight) hipLaunchKernelGGL((k_try_velrot<true, false, true>), g, b, 0, c->stream, a);
-        else if (procjf) hipLaunchKernelGGL((k_try_velrot<false, true, true>), g, b, 0, c->stream, a);
-        else hipLaunchKernelGGL((k_try_velrot<false, false, true>), g, b, 0, c->stream, a);
+        if (reweight && procjf) hipLaunchKernelGGL((k_try_velrot<true, true, true>), g, b, dyn_lds, c->stream, a);
+        else if (reweight) hipLaunchKernelGGL((k_try_velrot<true, false, true>), g, b, dyn_lds, c->stream, a);
+        else if (procjf) hipLaunchKernelGGL((k_try_velrot<false, true, true>), g, b, dyn_lds, c->stream, a);
+        else hipLaunchKernelGGL((k_try_velrot<false, false, true>), g, b, dyn_lds, c->stream, a);
     } else {
-        if (reweight && procjf) hipLaunchKernelGGL((k_try_velrot<true, true, false>), g, b, 0, c->stream, a);
-        else if (reweight) hipLaunchKernelGGL((k_try_velrot<true, false, false>), g, b, 0, c->stream, a);
-        else if (procjf) hipLaunchKernelGGL((k_try_velrot<false, true, false>), g, b, 0, c->stream, a);
-        else hipLaunchKernelGGL((k_try_velrot<false, false, false>), g, b, 0, c->stream, a);
+        if (reweight && procjf) hipLaunchKernelGGL((k_try_velrot<true, true, false>), g, b, dyn_lds, c->stream, a);
+        else if (reweight) hipLaunchKernelGGL((k_try_velrot<true, false, false>), g, b, dyn_lds, c->stream, a);
+        else if (procjf) hipLaunchKernelGGL((k_try_velrot<false, true, false>), g, b, dyn_lds, c->stream, a);
+        else hipLaunchKernelGGL((k_try_velrot<false, false, false>), g, b, dyn_lds, c->stream, a);
     }
     EH_LAUNCH_CHECK();
     return 0;
