@@ -1347,7 +1347,12 @@ int stage_a_enqueue(edgehip_ctx *c, int slot) {
                 // A few sequences (a live camera): 64-row blocks leave most CUs idle and every block pays the tap-load latency
                 // of w/64 column tiles one after the other — 16-row blocks over 256-column tiles: 4x the blocks, a quarter
                 // of the tile round trips (100 -> ~20 us per launch for one 752x480 frame).  Same operations, same order.
-                if ((size_t)B * njobs * ((h + 63) / 64) < 256)
+                // ... and for one or two sequences 4-row blocks: 240 blocks for one 752x480 frame instead of 60, a quarter of the
+                // averages per tile and block (the row prefix itself is a fixed chain of w dependent adds per row either way).
+                if ((size_t)B * njobs * ((h + 15) / 16) < 128)
+                    hipLaunchKernelGGL((k_avg_rowscan<256, 4, 256>), dim3((h + 3) / 4, njobs, B), dim3(256), 0, st, job,
+                                       c->div_lut, w, h, n);
+                else if ((size_t)B * njobs * ((h + 63) / 64) < 256)
                     hipLaunchKernelGGL((k_avg_rowscan<256, 16, 256>), dim3((h + 15) / 16, njobs, B), dim3(256), 0, st, job,
                                        c->div_lut, w, h, n);
                 else

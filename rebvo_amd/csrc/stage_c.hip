@@ -550,17 +550,19 @@ __global__ __launch_bounds__(1024) void k_rescale(const KlSoA *kls, const int32_
         const double kp2 = Kp * Kp;
 #pragma unroll
         for (int j = 0; j < PER; j++) {
-            const double den = s2[j] + kp2 * s02[j];
-            a += r2[j] / den;
-            b += r02[j] / den;
+            // one division for the two quotients (an ulp per term off the reference's rho^2 / den and rho0^2 / den, next to a
+            // summation order that already differs from its sequential one: Kp agrees to 1e-10, tests/test_stage_c_gpu.py)
+            const double inv = 1.0 / (s2[j] + kp2 * s02[j]);
+            a += r2[j] * inv;
+            b += r02[j] * inv;
         }
         for (int i = tid + PER * 1024; i < kn; i += 1024) {
             const double sr0 = K.s_rho0[i], sr = K.s_rho[i];
             if ((unsigned)K.m_num[i] < match_num_min || sr0 <= 0 || sr > s_rho_min) continue;
-            const double den = sr * sr + kp2 * sr0 * sr0;
+            const double inv = 1.0 / (sr * sr + kp2 * sr0 * sr0);
             const double rho = K.rho[i], rho0 = K.rho0[i];
-            a += rho * rho / den;
-            b += rho0 * rho0 / den;
+            a += rho * rho * inv;
+            b += rho0 * rho0 * inv;
         }
         for (int o = 32; o > 0; o >>= 1) { a += __shfl_xor(a, o, 64); b += __shfl_xor(b, o, 64); }
         if ((tid & 63) == 0) { s_a[tid >> 6] = a; s_b[tid >> 6] = b; }
