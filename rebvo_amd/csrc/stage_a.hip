@@ -1014,7 +1014,7 @@ __global__ __launch_bounds__(256) void k_join_histo(KlSoA *kls, const int32_t *_
     if (i < kn) {
         const KlSoA &k = kls[seq];
         const int32_t *mask = masks + (size_t)seq * n;
-        float2 cp, m;
+        float2 cp, m, u_d, pm_d;
         float nm_i;
         if (DERIVE) {
             const float4 raw = k.grec[i];           // xs, ys, m_m.x, m_m.y
@@ -1023,20 +1023,10 @@ __global__ __launch_bounds__(256) void k_join_histo(KlSoA *kls, const int32_t *_
             m = make_float2(raw.z, raw.w);
             const float n2m = m.x * m.x + m.y * m.y;
             nm_i = sqrtf(n2m);
-            const float2 u = make_float2(m.x / nm_i, m.y / nm_i);
+            u_d = make_float2(m.x / nm_i, m.y / nm_i);
             cp = make_float2((float)px + raw.x, (float)py + raw.y);
-            const float2 pm = make_float2(cp.x - ppx, cp.y - ppy);      // cam_model::Img2Hom
-            k.m_m[i] = m;
-            k.n_m[i] = nm_i;
-            k.u_m[i] = u;
-            k.c_p[i] = cp;
-            k.p_m[i] = pm;
-            k.p_m_0[i] = pm;
-            MatchRec rec;
-            rec.c_px = cp.x; rec.c_py = cp.y; rec.u_mx = u.x; rec.u_my = u.y;
-            rec.m_mx = m.x; rec.m_my = m.y; rec.n_m = nm_i; rec.pad = 0.f;
-            k.rec[i] = rec;
-            k.grec[i] = make_float4(cp.x, cp.y, m.x, m.y);
+            pm_d = make_float2(cp.x - ppx, cp.y - ppy);      // cam_model::Img2Hom
+            // (stored below, after the mask probes: a load issued behind stores waits for them — vmcnt counts both)
         } else {
             cp = k.c_p[i];
             m = k.m_m[i];
@@ -1051,6 +1041,19 @@ __global__ __launch_bounds__(256) void k_join_histo(KlSoA *kls, const int32_t *_
         int j = mask[(size_t)y * w + (x + sx)];
         if (j < 0) j = mask[(size_t)(y + sy) * w + x];
         if (j < 0) j = mask[(size_t)(y + sy) * w + (x + sx)];
+        if (DERIVE) {
+            k.m_m[i] = m;
+            k.n_m[i] = nm_i;
+            k.u_m[i] = u_d;
+            k.c_p[i] = cp;
+            k.p_m[i] = pm_d;
+            k.p_m_0[i] = pm_d;
+            MatchRec rec;
+            rec.c_px = cp.x; rec.c_py = cp.y; rec.u_mx = u_d.x; rec.u_my = u_d.y;
+            rec.m_mx = m.x; rec.m_my = m.y; rec.n_m = nm_i; rec.pad = 0.f;
+            k.rec[i] = rec;
+            k.grec[i] = make_float4(cp.x, cp.y, m.x, m.y);
+        }
         if (DEFAULTS) {
             k.rho[i] = 1.0;          // RhoInit
             k.s_rho[i] = 20.0;       // RHO_MAX

@@ -555,6 +555,7 @@ __device__ __forceinline__ void tvr_body(const TvrArgs &a, const int seq, const 
         //         3 = evaluated, unmatched (inherits the previous valid fi)
         int status = 0;
         double fi = 0;
+        double rho_own = 0;   // the KeyLine's rho, kept for the key post of the last evaluation (no load behind the residual store)
         if (ikl < kn) {
             // Everything the KeyLine streams in is requested here, before the first use: the skip test, the projection, the
             // in-image test and the two gathers are a chain of dependent memory round trips, and with the loads inside the
@@ -563,6 +564,7 @@ __device__ __forceinline__ void tvr_body(const TvrArgs &a, const int seq, const 
             const int32_t mnum = ko.m_num[ikl];
             const float2 pm0 = ko.p_m[ikl];
             const double rho0 = ko.rho[ikl];
+            rho_own = rho0;
             const float2 klm = ko.m_m[ikl];
             const float knm = ko.n_m[ikl];
             double rprev = 0;
@@ -694,7 +696,7 @@ __device__ __forceinline__ void tvr_body(const TvrArgs &a, const int seq, const 
         }
         if (a.write_mid && ikl < kn) {
             ko.m_id_f[ikl] = mid_f;
-            if (!KF && a.fwd_key && mid_f >= 0) atomicMax(&a.fwd_key[(size_t)seq * a.cap + mid_f], ord_bits(ko.rho[ikl]));
+            if (!KF && a.fwd_key && mid_f >= 0) atomicMax(&a.fwd_key[(size_t)seq * a.cap + mid_f], ord_bits(rho_own));
         }
 
         // ---- Jacobian row, uncertainty scaling (global_tracker.cpp:419-463) ----

@@ -59,16 +59,22 @@ __global__ __launch_bounds__(256) void k_fwd_apply(const KlSoA *kl_old, const Kl
         const int i = win[(size_t)seq * cap + f];
         if (i >= 0) {
             const KlSoA &o = kl_old[seq], &n = kl_new[seq];
-            n.rho[f] = o.rho[i];
-            n.s_rho[f] = o.s_rho[i];
-            n.rho_nr[f] = o.rho_nr[i];
-            n.s_rho_nr[f] = o.s_rho_nr[i];
-            n.m_num[f] = o.m_num[i] + 1;
+            // every gather first, then every store: a load issued behind a store waits for it (vmcnt counts loads and stores
+            // in issue order), so field-by-field copies pay one memory round trip per field
+            const double rho = o.rho[i], s_rho = o.s_rho[i], rho_nr = o.rho_nr[i], s_rho_nr = o.s_rho_nr[i];
+            const int32_t m_num = o.m_num[i], m_id_kf = o.m_id_kf[i];
+            const float2 pm = o.p_m[i], mm = o.m_m[i];
+            const float nm = o.n_m[i];
+            n.rho[f] = rho;
+            n.s_rho[f] = s_rho;
+            n.rho_nr[f] = rho_nr;
+            n.s_rho_nr[f] = s_rho_nr;
+            n.m_num[f] = m_num + 1;
             n.m_id[f] = i;
-            n.p_m_0[f] = o.p_m[i];
-            n.m_m0[f] = o.m_m[i];
-            n.n_m0[f] = (double)o.n_m[i];
-            n.m_id_kf[f] = o.m_id_kf[i];
+            n.p_m_0[f] = pm;
+            n.m_m0[f] = mm;
+            n.n_m0[f] = (double)nm;
+            n.m_id_kf[f] = m_id_kf;
             hit = 1;
         }
     }
@@ -89,6 +95,8 @@ __global__ __launch_bounds__(256) void k_rotate(const KlSoA *kls, const int32_t 
     const double *R = Rin + (size_t)seq * 9;
     const KlSoA &k = kls[seq];
     const float2 pm = k.p_m[i];
+    const float2 m = k.m_m[i];                       // all loads before the first store (a load behind a store waits for it)
+    const double rho = k.rho[i], s_rho = k.s_rho[i];
     const double v0 = (double)pm.x / zf, v1 = (double)pm.y / zf, v2 = 1;
     double q0 = 0, q1 = 0, q2 = 0;  // TooN matrix*vector: row dot products accumulated from 0
     q0 += R[0] * v0; q0 += R[1] * v1; q0 += R[2] * v2;
@@ -96,10 +104,9 @@ __global__ __launch_bounds__(256) void k_rotate(const KlSoA *kls, const int32_t 
     q2 += R[6] * v0; q2 += R[7] * v1; q2 += R[8] * v2;
     if (fabs(q2) > 0) {
         k.p_m[i] = make_float2((float)(q0 / q2 * zf), (float)(q1 / q2 * zf));
-        k.rho[i] = k.rho[i] / q2;
-        k.s_rho[i] = k.s_rho[i] / q2;
+        k.rho[i] = rho / q2;
+        k.s_rho[i] = s_rho / q2;
     }
-    const float2 m = k.m_m[i];
     const double m0 = (double)m.x, m1 = (double)m.y;
     double r0 = 0, r1 = 0;
     r0 += R[0] * m0; r0 += R[1] * m1; r0 += R[2] * 0.0;
@@ -129,16 +136,19 @@ __global__ __launch_bounds__(256) void k_fwd_apply_rotate(const KlSoA *kl_old, c
         const double rho = o.rho[i], s_rho = o.s_rho[i];
         if (f >= 0 && f < kn_new[seq] && win[(size_t)seq * cap + f] == i) {
             const KlSoA &n = kl_new[seq];
+            const double rho_nr = o.rho_nr[i], s_rho_nr = o.s_rho_nr[i];
+            const int32_t m_num = o.m_num[i], m_id_kf = o.m_id_kf[i];
+            const float nm = o.n_m[i];
             n.rho[f] = rho;
             n.s_rho[f] = s_rho;
-            n.rho_nr[f] = o.rho_nr[i];
-            n.s_rho_nr[f] = o.s_rho_nr[i];
-            n.m_num[f] = o.m_num[i] + 1;
+            n.rho_nr[f] = rho_nr;
+            n.s_rho_nr[f] = s_rho_nr;
+            n.m_num[f] = m_num + 1;
             n.m_id[f] = i;
             n.p_m_0[f] = pm;
             n.m_m0[f] = m;
-            n.n_m0[f] = (double)o.n_m[i];
-            n.m_id_kf[f] = o.m_id_kf[i];
+            n.n_m0[f] = (double)nm;
+            n.m_id_kf[f] = m_id_kf;
             hit = 1;
         }
         const double *R = Rin + (size_t)seq * 9;
@@ -407,21 +417,24 @@ __global__ __launch_bounds__(256) void k_directed(DirArgs a) {
         }
         if (found >= 0) {
             const int j = found;
-            if (a.stereo_mode) {
-                kn.rho[ik] = ko.rho0[j];
-                kn.s_rho[ik] = ko.s_rho0[j];
-            } else {
-                kn.rho[ik] = ko.rho[j];
-                kn.s_rho[ik] = ko.s_rho[j];
-                kn.rho_nr[ik] = ko.rho_nr[j];
-                kn.s_rho_nr[ik] = ko.s_rho_nr[j];
+            // gathers first, stores after (a load behind a store waits for the store)
+            const double c_rho = a.stereo_mode ? ko.rho0[j] : ko.rho[j], c_srho = a.stereo_mode ? ko.s_rho0[j] : ko.s_rho[j];
+            double c_rho_nr = 0, c_srho_nr = 0;
+            if (!a.stereo_mode) { c_rho_nr = ko.rho_nr[j]; c_srho_nr = ko.s_rho_nr[j]; }
+            const int32_t c_mnum = ko.m_num[j], mk = ko.m_id_kf[j];
+            const float2 c_pm = ko.p_m[j], c_mm = ko.m_m[j];
+            const float c_nm = ko.n_m[j];
+            kn.rho[ik] = c_rho;
+            kn.s_rho[ik] = c_srho;
+            if (!a.stereo_mode) {
+                kn.rho_nr[ik] = c_rho_nr;
+                kn.s_rho_nr[ik] = c_srho_nr;
             }
             kn.m_id[ik] = j;
-            kn.m_num[ik] = ko.m_num[j] + 1;
-            kn.p_m_0[ik] = ko.p_m[j];
-            kn.m_m0[ik] = ko.m_m[j];
-            kn.n_m0[ik] = (double)ko.n_m[j];
-            const int mk = ko.m_id_kf[j];
+            kn.m_num[ik] = c_mnum + 1;
+            kn.p_m_0[ik] = c_pm;
+            kn.m_m0[ik] = c_mm;
+            kn.n_m0[ik] = (double)c_nm;
             kn.m_id_kf[ik] = mk;
             matched = 1;
             kfm = mk >= 0;
