@@ -238,9 +238,7 @@ __global__ __launch_bounds__(256) void k_field_bin(const KlSoA *kls, const int32
     const int i = blockIdx.x * 256 + tid;
     const int kn = kns[seq];
     if (blockIdx.x * 256 >= kn) return;
-    // whole-frame driver: this kernel visits every KeyLine of the NEW edge map right before the minimisation, so it also
-    // resets FordwardMatch's arbitration entries of that KeyLine (12 B in a stream) instead of two memsets over [B][CAP]
-    if (fwd_key && i < kn) { fwd_key[(size_t)seq * bin_cap + i] = 0ull; fwd_win[(size_t)seq * bin_cap + i] = -1; }
+
     const int ntiles = ntx * nty;
     for (int t = tid; t < ntiles; t += 256) s_cnt[t] = 0;
     __syncthreads();
@@ -293,6 +291,10 @@ __global__ __launch_bounds__(256) void k_field_bin(const KlSoA *kls, const int32
                 if (pos < bin_cap) bins[((size_t)seq * ntiles + t) * bin_cap + pos] = i;
             }
         }
+    // whole-frame driver: this kernel visits every KeyLine of the NEW edge map right before the minimisation, so it also
+    // resets FordwardMatch's arbitration entries of that KeyLine (12 B in a stream) instead of two memsets over [B][CAP] —
+    // at the end: a load issued behind a store waits for it
+    if (fwd_key && i < kn) { fwd_key[(size_t)seq * bin_cap + i] = 0ull; fwd_win[(size_t)seq * bin_cap + i] = -1; }
 }
 
 __global__ __launch_bounds__(256) void k_field_raster(const KlSoA *kls, const int32_t *__restrict__ bin_cnt,
