@@ -193,16 +193,16 @@ __global__ __launch_bounds__(512) void k_stage_a_fused(FusedArgs a) {
     float *s_edge = s_lut + kDivLutMax;                             // [RB][NW][2] img0 at the first / last column of every wave
     int *s_sedge = reinterpret_cast<int *>(s_edge + (size_t)RB * NW * 2);   // [RB][NW][2] DoG sign bits of the first / last column pair of every wave
     float *s_red = reinterpret_cast<float *>(s_sedge + RB * NW * 2);   // [4] n_m extremes, the frame's candidate count (end of frame)
-    // candidate bits of a tick's tested rows, published by the column waves for the fit wave: [2 (tick parity)][RB][NW] x
-    // {even columns, odd columns} of the wave's 128 columns
-    unsigned long long *s_bits = reinterpret_cast<unsigned long long *>(s_red + 4);
-    uint16_t *s_clist = reinterpret_cast<uint16_t *>(s_bits + (size_t)2 * RB * NW * 2);   // [RB*NW*128] the fit wave's candidate list (row << 10 | x)
-    uint16_t *s_res = s_clist + (size_t)NW * RB * 128;              // [2 (tick parity)][RB][NW*128] id + 1 of the KeyLine at a tested pixel, 0 = none
+    // candidates of a tick's tested rows, published by the column waves for the fit wave, double-buffered by tick parity: per
+    // (row, wave) segment the number of survivors of the two dense gates and their codes (row << 10 | x) in column order
+    int *s_ccnt = reinterpret_cast<int *>(s_red + 4);                                   // [2][RB*NW]
+    uint16_t *s_clist = reinterpret_cast<uint16_t *>(s_ccnt + 2 * RB * NW);             // [2][RB*NW][128]
+    uint16_t *s_res = s_clist + (size_t)2 * NW * RB * 128;          // [2 (tick parity)][RB][NW*128] id + 1 of the KeyLine at a tested pixel, 0 = none
     // ---- set-up -------------------------------------------------------------------------------------------------------
     for (int i = tid; i < 2 * 4 * RB * PAD; i += blockDim.x) s_set[(size_t)(i / PAD) * WP + (i % PAD)] = 0.f;   // left pads: taps left of column 0
     for (int i = tid; i < kDivLutMax - 2; i += blockDim.x) s_lut[i] = a.lut[i];   // (indices reach 15 * 15; the last two entries carry the threshold, below)
     for (int i = tid; i < 2 * NW * RB * 128; i += blockDim.x) s_res[i] = 0;
-    for (int i = tid; i < 2 * RB * NW * 2; i += blockDim.x) s_bits[i] = 0ull;
+    for (int i = tid; i < 2 * RB * NW; i += blockDim.x) s_ccnt[i] = 0;
     for (int i = tid; i < 256; i += blockDim.x) a.histo[(size_t)seq * 256 + i] = 0;   // reEstimateThresh's histogram (k_join_histo fills it)
     SeqA *sq = a.seq + seq;
     // wave-uniform floats are computed by the vector ALU and would sit in (scarce) vector registers: readfirstlane moves them
@@ -359,27 +359,23 @@ __global__ __launch_bounds__(512) void k_stage_a_fused(FusedArgs a) {
             const bool live = t >= 1 && ytest0 + RB - 1 >= 0 && ytest0 < h && !(ABL & 8);
             int rq = ((t - 1) * RB) % RING;
             rq += rq < 0 ? RING : 0;
-            int ncand = 0;
+            // The candidates wait in per-(row, wave) segments of 128 slots (written by the column waves, raster order = segment
+            // order).  Lane s holds segment s's count; an inclusive scan over the lanes gives the list position where each
+            // segment ends, and list entry li lives at slot li + (128 s - start of s) of its segment s.
+            int ncand = 0, seg_end = 0x7fffffff, seg_shift = 0;
             if (live) {
-                // raster order: row, then wave, then column.  With a compile-time width the loop unrolls and the RB * NW bit
-                // pairs are requested up front (one LDS round trip instead of one per segment); everything stays in the
-                // vector ALU (v_mbcnt / v_bcnt take the wave-uniform words from vector registers).
-                const unsigned long long *bits = s_bits + (size_t)((t - 1) & 1) * RB * NW * 2;
-                auto segment = [&](int sgm, int i, int xb) __attribute__((always_inline)) {
-                    const unsigned long long b0 = bits[2 * sgm], b1 = bits[2 * sgm + 1];   // wave-uniform
-                    const bool p0 = (b0 >> lane) & 1ull, p1 = (b1 >> lane) & 1ull;
-                    const int pos = ncand + below(b0) + below(b1);
-                    if (p0) s_clist[pos] = (uint16_t)((i << 10) | (xb + 2 * lane));
-                    if (p1) s_clist[pos + (p0 ? 1 : 0)] = (uint16_t)((i << 10) | (xb + 2 * lane + 1));
-                    ncand += __popcll(b0) + __popcll(b1);
-                };
-                if (W) {
-                    constexpr int CNW = W ? (W + 127) / 128 : 1;
-#pragma unroll
-                    for (int sgm = 0; sgm < RB * CNW; sgm++) segment(sgm, sgm / CNW, (sgm % CNW) * 128);
-                } else {
-                    for (int sgm = 0; sgm < RB * NW; sgm++) { const int i = sgm / NW; segment(sgm, i, (sgm - i * NW) * 128); }
-                }
+                const int nseg = RB * NW;
+                const int cnt = lane < nseg ? s_ccnt[((t - 1) & 1) * nseg + lane] : 0;
+                int inc = cnt;
+                inc += __builtin_amdgcn_update_dpp(0, inc, 0x111, 0xf, 0xf, true);    // row_shr:1, zeros shifted in
+                inc += __builtin_amdgcn_update_dpp(0, inc, 0x112, 0xf, 0xf, true);    // row_shr:2
+                inc += __builtin_amdgcn_update_dpp(0, inc, 0x114, 0xf, 0xf, true);    // row_shr:4
+                inc += __builtin_amdgcn_update_dpp(0, inc, 0x118, 0xf, 0xf, true);    // row_shr:8  -> inclusive scan inside each row of 16
+                inc += __builtin_amdgcn_update_dpp(0, inc, 0x142, 0xa, 0xf, false);   // row_bcast:15 into rows 1 and 3
+                inc += __builtin_amdgcn_update_dpp(0, inc, 0x143, 0xc, 0xf, false);   // row_bcast:31 into rows 2 and 3
+                ncand = __builtin_amdgcn_readlane(inc, nseg - 1);
+                seg_end = lane < nseg ? inc : 0x7fffffff;        // lanes beyond the last segment never match
+                seg_shift = lane * 128 - (inc - cnt);
             }
             if (ABL & 64) ncand = 0;                // (timing experiments: 64 no fits / emission, 128 no emission, 256 no plane fit)
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
@@ -389,9 +385,19 @@ __global__ __launch_bounds__(512) void k_stage_a_fused(FusedArgs a) {
             // c+1 and the list entries of chunk c+2 are on their way (LDS returns a wave's requests in order).
             float wv_cur[25], wv_nxt[25];
             int code_cur = 0, code_nxt = 0, code_nn = 0;
+            const uint16_t *clist = s_clist + (size_t)((t - 1) & 1) * RB * NW * 128;
             auto code_of = [&](int c) __attribute__((always_inline)) {
                 const int li = c * 64 + lane;
-                return li < ncand ? (int)s_clist[li] : 2;    // row 0, column 2: an address that exists
+                // the segment of entry li = the first lane whose segment ends beyond li: binary search over the (non-decreasing)
+                // ends held in lanes 0..31 (RB * NW <= 32), five lane reads
+                int lo = 0;
+#pragma unroll
+                for (int step = 16; step > 0; step >>= 1) {
+                    const int e = __shfl(seg_end, lo + step - 1, 64);
+                    lo += e <= li ? step : 0;
+                }
+                const int sh = __shfl(seg_shift, lo, 64);
+                return li < ncand ? (int)clist[li + sh] : 2;    // (padding lanes: row 0, column 2, an address that exists)
             };
             auto request = [&](int code, float (&v)[25]) __attribute__((always_inline)) {
                 const int i = code >> 10, x = code & 1023;
@@ -690,11 +696,14 @@ __global__ __launch_bounds__(512) void k_stage_a_fused(FusedArgs a) {
                 // gradient gate of row y_i (bit 2 + RB-1-i) and sign balance of its window (complete with the newest row: bit RB-1-i)
                 const bool p0 = (gbits0 >> (2 + RB - 1 - i)) & (bbits0 >> (RB - 1 - i)) & 1u, p1 = (gbits1 >> (2 + RB - 1 - i)) & (bbits1 >> (RB - 1 - i)) & 1u;
                 const unsigned long long b0 = __ballot(p0), b1 = __ballot(p1);
-                if (lane == 0) {
-                    unsigned long long *q = s_bits + ((size_t)(set * RB + i) * NW + wv) * 2;
-                    q[0] = b0;
-                    q[1] = b1;
-                }
+                const int sgm = i * NW + wv;
+                uint16_t *seg = s_clist + ((size_t)set * RB * NW + sgm) * 128;
+                const int pos = (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(b0 >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)b0, 0u)) +
+                                (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(b1 >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)b1, 0u));
+                const int code = (i << 10) | (wv * 128 + 2 * lane);
+                if (p0) seg[pos] = (uint16_t)code;
+                if (p1) seg[pos + (p0 ? 1 : 0)] = (uint16_t)(code | 1);
+                if (lane == 0) s_ccnt[set * RB * NW + sgm] = __popcll(b0) + __popcll(b1);
             }
         }
         if (act) {   // grey of batch t -> plane 0 of the buffer set (b+g+r, image.h:197-203: integers, exact in float)
@@ -754,8 +763,8 @@ static int fused_col_waves(int w) { return (w + 127) / 128; }
 
 size_t fused_lds_bytes(int w) {
     const int nw = fused_col_waves(w), WP = fused_row_stride(w), RB = kFusedRB;
-    const size_t fl = (size_t)2 * 4 * RB * WP + (size_t)(2 * RB + 4) * WP + 32 + kDivLutMax + (size_t)RB * nw * 4 + 4;   // all even counts: s_bits is 8-byte aligned
-    return fl * 4 + (size_t)2 * RB * nw * 2 * 8 + (size_t)3 * nw * RB * 128 * 2;
+    const size_t fl = (size_t)2 * 4 * RB * WP + (size_t)(2 * RB + 4) * WP + 32 + kDivLutMax + (size_t)RB * nw * 4 + 4 + (size_t)2 * RB * nw;
+    return fl * 4 + (size_t)4 * nw * RB * 128 * 2;
 }
 
 bool fused_supported(const edgehip_ctx *c) {
@@ -767,6 +776,7 @@ bool fused_supported(const edgehip_ctx *c) {
     const int nw = fused_col_waves(pl.w);
     if (nw + 2 > 8) return false;                           // column waves + scan wave + fit wave; 256 VGPRs per thread need <= 8 waves per workgroup
     if (pl.w > 1023) return false;                          // candidate codes carry x in 10 bits
+    if (kFusedRB * nw > 32) return false;                   // the fit wave searches the segment ends in 32 lanes
     if (pl.cap > 65534) return false;                       // ids travel through LDS as uint16
     return fused_lds_bytes(pl.w) <= 160 * 1024;
 }
