@@ -8,7 +8,7 @@
 //   sspace::build / build_dog / calc_gradient   src/mtracklib/sspace.cpp:52-85
 //   edge_finder::build_mask + the P-controller of detect()   src/mtracklib/edge_finder.cpp:67-214, 330-365
 // The multi-kernel path (stage_a.hip) moves 31 N bytes through HBM for the three integral-image levels, another ~11 N for
-// the detector's taps and writes the mask twice; this one moves 3 N + 4 N + the KeyLine records (SURVEY 8d's stage-A bytes).
+// the detector's taps and writes the mask twice; this one moves 3 N (N for 8-bit mono input) + 4 N + 24 bytes per KeyLine.
 //
 // How the box chain stays on chip.  A box average needs four taps of the integral image: bottom row y+r and top row
 // y-r-1, columns x+r and x-r-1.  The integral image itself is never materialised:
@@ -27,17 +27,20 @@
 // input by r1+r2a+r3a rows and img1 by r1+r2b+r3b; the kernel is instantiated for the box widths of the shipped
 // configurations ({3,3,5} / {3,5,5}: Sigma0 1.7818, KSigma 1.2599), everything else takes the multi-kernel path.
 //
-// A tick (RB image rows) of the column waves:
-//   phase 1   emit the KeyLines found in the previous tick (ids need every wave's counts: published before the barrier)
-//             and their img_mask_kl rows; grey values of the prefetched RGB rows; the five box averages of the tick
-//             from the scanned rows of buffer set t&1; DoG rows into the LDS ring
+// A workgroup = ceil(w / 128) column waves + the scan wave + the fit wave.  A tick (RB image rows) of the column waves:
+//   phase 1   the img_mask_kl rows of the rows tested two ticks ago (the fit wave left their KeyLine ids in LDS); grey
+//             values of the prefetched RGB (or 8-bit mono / 16-bit grey) rows; the five box averages of the tick from the
+//             scanned rows of buffer set t&1; DoG rows into the LDS ring
 //   -- barrier (LDS only) --
-//   phase 2   store the produced rows into buffer set t&1 (all its readers are past the barrier); gradient gate;
-//             build_mask's tests on the rows whose 5x5 DoG window is complete; publish per-segment counts
+//   phase 2   store the produced rows into buffer set t&1 (all its readers are past the barrier); gradient gate and sign
+//             balance of build_mask on the rows whose 5x5 DoG window is complete; the survivors go, as (row, column) codes,
+//             into the (row, wave) segment lists of the tick
 //   -- barrier --
-// while the scan wave row-scans buffer set (t+1)&1, half before and half after the middle barrier.
-// KeyLine ids are raster-order ranks (edge_finder.cpp:166-200): the workgroup sees the rows in order, so an id is the
-// running total + an exclusive scan over the tick's (row, column group) segments — no staging, no second kernel.
+// while the scan wave row-scans buffer set (t+1)&1, half before and half after the middle barrier, and the fit wave works
+// through the previous tick's survivors: fp64 plane fit (edge_finder.cpp:139-159) 64 candidates at a time in raster order,
+// sub-pixel and DoG-gradient tests, KeyLine ids as a running count — the id IS the raster rank (edge_finder.cpp:166-200) and
+// one wave sees every candidate of the frame in order — and the fit's results (p_inx, {xs, ys, m_m}, p_id) to HBM;
+// k_join_histo<true, true> derives the other KeyLine fields.  No staging pass, no second detector kernel.
 //
 // Compile with -ffp-contract=off (the reference is built without FMA contraction).
 
