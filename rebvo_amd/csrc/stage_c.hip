@@ -97,6 +97,10 @@ __global__ __launch_bounds__(256) void k_rotate(const KlSoA *kls, const int32_t 
     const float2 pm = k.p_m[i];
     const float2 m = k.m_m[i];                       // all loads before the first store (a load behind a store waits for it)
     const double rho = k.rho[i], s_rho = k.s_rho[i];
+    // the gather record is rewritten whole (32 B per lane, full sectors) instead of patching 8 of its bytes: its other fields
+    // mirror c_p, u_m and n_m, which nothing changes after detection
+    const float2 cp = k.c_p[i], um = k.u_m[i];
+    const float nm = k.n_m[i];
     const double v0 = (double)pm.x / zf, v1 = (double)pm.y / zf, v2 = 1;
     double q0 = 0, q1 = 0, q2 = 0;  // TooN matrix*vector: row dot products accumulated from 0
     q0 += R[0] * v0; q0 += R[1] * v1; q0 += R[2] * v2;
@@ -113,8 +117,10 @@ __global__ __launch_bounds__(256) void k_rotate(const KlSoA *kls, const int32_t 
     r1 += R[3] * m0; r1 += R[4] * m1; r1 += R[5] * 0.0;
     const float2 mr = make_float2((float)r0, (float)r1);
     k.m_m[i] = mr;
-    k.rec[i].m_mx = mr.x;
-    k.rec[i].m_my = mr.y;
+    MatchRec rec;
+    rec.c_px = cp.x; rec.c_py = cp.y; rec.u_mx = um.x; rec.u_my = um.y;
+    rec.m_mx = mr.x; rec.m_my = mr.y; rec.n_m = nm; rec.pad = 0.f;
+    k.rec[i] = rec;
 }
 
 // FordwardMatch's copy (edge_tracker.cpp:396-432) and rotate_keylines (:42-76) in ONE pass over the OLD KeyLines.  The
