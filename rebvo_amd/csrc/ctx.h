@@ -247,6 +247,7 @@ struct edgehip_ctx {
     int32_t *fwd_win;      // [B][CAP]
     int fwd_mode = 0;              // EDGEHIP_FWD_MODE: 0 keys by the minimiser + k_fwd_win / k_fwd_apply / k_rotate, 1 the round-2 chain (own key pass),
                                    // 2 keys by the minimiser + k_fwd_win + k_fwd_apply_rotate (one scattering pass over the old KeyLines)
+    bool fwd_fill[4] = {false, false, false, false};   // [slot] its detector left the forwarded KeyLine fields to FordwardMatch (fill mode)
     bool fwd_cleared = false;      // fwd_key / fwd_win of the new edge map were reset by k_field_bin (whole-frame driver)
     bool fwd_key_in_tvr = false;   // whole-frame driver: the minimiser's last evaluation also posts FordwardMatch's arbitration keys
     double *rs_tmp;        // [B][2][CAP] regularised (rho, s_rho) ping-pong
@@ -353,7 +354,7 @@ struct ProfScope {  // RAII bracket; no-op unless profiling is enabled
 };
 
 // stage entry points shared between translation units (all enqueue on c->stream)
-int stage_a_enqueue(edgehip_ctx *c, int slot);
+int stage_a_enqueue(edgehip_ctx *c, int slot, bool fwd_fills = false);
 // ordering between the two streams for entry points that are not edgehip_process_frame: everything enqueued so far on
 // one stream is finished before anything enqueued afterwards on the other starts
 int wait_upload(edgehip_ctx *c, int slot, hipStream_t st);   // make `st` wait for a pending stream_up upload into the slot

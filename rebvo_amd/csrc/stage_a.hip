@@ -1001,9 +1001,12 @@ __device__ __forceinline__ int x86_cvttss2si(float f) {
 // DERIVE (with DEFAULTS): the fused kernel's fit wave left only what the plane fit produced — p_inx and {xs, ys, m_m} in
 // the grec slot — and every field that follows from them (edge_finder.cpp:166-200: n_m, u_m, c_p, p_m, p_m_0, the gather
 // records) is computed here, at full lanes and streaming, instead of by one wave of the detector at a third of its lanes.
+// fwd_fills (with DEFAULTS): the whole-frame driver's FordwardMatch will write the ten fields it forwards for EVERY new KeyLine
+// (k_fwd_apply's fill mode: the forwarded values or these defaults), so they are not written here — 68 of the 180 bytes.
 template <bool DEFAULTS, bool DERIVE = false>
 __global__ __launch_bounds__(256) void k_join_histo(KlSoA *kls, const int32_t *__restrict__ masks, SeqA *seqs,
-                                                    int32_t *histo, int w, size_t n, int nbins, float ppx = 0.f, float ppy = 0.f) {
+                                                    int32_t *histo, int w, size_t n, int nbins, float ppx = 0.f, float ppy = 0.f,
+                                                    int fwd_fills = 0) {
     const int seq = blockIdx.z;
     const int i = blockIdx.x * 256 + threadIdx.x;
     SeqA *sq = seqs + seq;
@@ -1047,7 +1050,7 @@ __global__ __launch_bounds__(256) void k_join_histo(KlSoA *kls, const int32_t *_
             k.u_m[i] = u_d;
             k.c_p[i] = cp;
             k.p_m[i] = pm_d;
-            k.p_m_0[i] = pm_d;
+            if (!fwd_fills) k.p_m_0[i] = pm_d;
             MatchRec rec;
             rec.c_px = cp.x; rec.c_py = cp.y; rec.u_mx = u_d.x; rec.u_my = u_d.y;
             rec.m_mx = m.x; rec.m_my = m.y; rec.n_m = nm_i; rec.pad = 0.f;
@@ -1055,19 +1058,21 @@ __global__ __launch_bounds__(256) void k_join_histo(KlSoA *kls, const int32_t *_
             k.grec[i] = make_float4(cp.x, cp.y, m.x, m.y);
         }
         if (DEFAULTS) {
-            k.rho[i] = 1.0;          // RhoInit
-            k.s_rho[i] = 20.0;       // RHO_MAX
+            if (!fwd_fills) {
+                k.rho[i] = 1.0;          // RhoInit
+                k.s_rho[i] = 20.0;       // RHO_MAX
+                k.rho_nr[i] = 1.0;
+                k.s_rho_nr[i] = 20.0;
+                k.m_num[i] = 0;
+                k.m_id[i] = -1;
+                k.m_id_kf[i] = -1;
+                k.m_m0[i] = make_float2(0.f, 0.f);
+                k.n_m0[i] = 0.0;
+            }
             k.rho0[i] = 1.0;
             k.s_rho0[i] = 20.0;
-            k.rho_nr[i] = 1.0;
-            k.s_rho_nr[i] = 20.0;
-            k.m_num[i] = 0;
-            k.m_id[i] = -1;
             if (k.stereo_m_id) { k.stereo_m_id[i] = -1; k.stereo_rho[i] = 1.0; k.stereo_s_rho[i] = 20.0; }
             k.m_id_f[i] = -1;
-            k.m_id_kf[i] = -1;
-            k.m_m0[i] = make_float2(0.f, 0.f);
-            k.n_m0[i] = 0.0;
             k.n_id[i] = j;           // -1 without a neighbour
         } else if (j >= 0) k.n_id[i] = j;
         if (j >= 0) atomicMax(&k.p_id[j], i);
@@ -1164,7 +1169,8 @@ int undistort_frame_enqueue(edgehip_ctx *c, int seq, int slot, uint8_t *out_dev)
 
 static int rowscan_ch(int w) { return 4 * ((w + 255) / 256); }
 
-int stage_a_enqueue(edgehip_ctx *c, int slot) {
+int stage_a_enqueue(edgehip_ctx *c, int slot, bool fwd_fills) {
+    c->fwd_fill[slot] = false;
     const DevicePlan &pl = c->plan;
     const int w = pl.w, h = pl.h, B = pl.nseq;
     const size_t n = pl.n;
@@ -1205,7 +1211,9 @@ int stage_a_enqueue(edgehip_ctx *c, int slot) {
         if (int e = stage_a_fused_enqueue(c, slot, rgb_base, rgb_idx, grey16, grey8)) return e;
         ProfScope ps(c, PROF_A_JOIN, st);
         hipLaunchKernelGGL((k_join_histo<true, true>), dim3((pl.cap + 255) / 256, 1, B), dim3(256), 0, st, kldev(c, slot),
-                           maskof(c, slot), c->seqa, c->histo, w, n, c->p.qcut_nbins, c->slot_cam[slot].ppx, c->slot_cam[slot].ppy);
+                           maskof(c, slot), c->seqa, c->histo, w, n, c->p.qcut_nbins, c->slot_cam[slot].ppx, c->slot_cam[slot].ppy,
+                           fwd_fills ? 1 : 0);
+        c->fwd_fill[slot] = fwd_fills;   // FordwardMatch into this slot must run in fill mode
         EH_LAUNCH_CHECK();
         hipLaunchKernelGGL(k_retune, dim3(B), dim3(256), 0, st, c->seqa, c->histo,
                            c->retuned_slot + (size_t)slot * B, B, c->p.track_points,

@@ -51,31 +51,44 @@ __global__ __launch_bounds__(256) void k_fwd_win(const KlSoA *kl_old, const int3
     if (f < 0 || f >= kn_new[seq]) return;
     if (key[(size_t)seq * cap + f] == ord_bits(kl_old[seq].rho[i])) atomicMax(&win[(size_t)seq * cap + f], i);
 }
+// fill: the detector of the new edge map left these ten fields unwritten (k_join_histo's fwd_fills): every new KeyLine gets
+// them here, the forwarded values or the defaults of a fresh KeyLine (edge_finder.cpp:176-196) — whole-wave stores of whole
+// lines.  (Masked stores, 85 % of the lanes, leave three lines in four partially written, which the memory system turns
+// into read-modify-write.)
+template <bool FILL>
 __global__ __launch_bounds__(256) void k_fwd_apply(const KlSoA *kl_old, const KlSoA *kl_new, const int32_t *__restrict__ kn_new,
                                                    const int32_t *__restrict__ win, SeqDev *seqs, int cap) {
     const int seq = blockIdx.z, f = blockIdx.x * 256 + threadIdx.x;
     int hit = 0;
     if (f < kn_new[seq]) {
         const int i = win[(size_t)seq * cap + f];
-        if (i >= 0) {
-            const KlSoA &o = kl_old[seq], &n = kl_new[seq];
+        const KlSoA &o = kl_old[seq], &n = kl_new[seq];
+        if (i >= 0 || FILL) {
             // every gather first, then every store: a load issued behind a store waits for it (vmcnt counts loads and stores
             // in issue order), so field-by-field copies pay one memory round trip per field
-            const double rho = o.rho[i], s_rho = o.s_rho[i], rho_nr = o.rho_nr[i], s_rho_nr = o.s_rho_nr[i];
-            const int32_t m_num = o.m_num[i], m_id_kf = o.m_id_kf[i];
-            const float2 pm = o.p_m[i], mm = o.m_m[i];
-            const float nm = o.n_m[i];
+            double rho = kRhoInit, s_rho = kRhoMax, rho_nr = kRhoInit, s_rho_nr = kRhoMax;
+            int32_t m_num = -1, m_id_kf = -1;
+            float2 pm = make_float2(0.f, 0.f), mm = make_float2(0.f, 0.f);
+            float nm = 0.f;
+            if (i >= 0) {
+                rho = o.rho[i]; s_rho = o.s_rho[i]; rho_nr = o.rho_nr[i]; s_rho_nr = o.s_rho_nr[i];
+                m_num = o.m_num[i]; m_id_kf = o.m_id_kf[i];
+                pm = o.p_m[i]; mm = o.m_m[i];
+                nm = o.n_m[i];
+            } else {
+                pm = n.p_m[f];            // p_m_0 of a fresh KeyLine is its own p_m
+            }
             n.rho[f] = rho;
             n.s_rho[f] = s_rho;
             n.rho_nr[f] = rho_nr;
             n.s_rho_nr[f] = s_rho_nr;
-            n.m_num[f] = m_num + 1;
-            n.m_id[f] = i;
+            n.m_num[f] = m_num + 1;       // 0 for a fresh KeyLine
+            n.m_id[f] = i;                // -1 for a fresh KeyLine
             n.p_m_0[f] = pm;
             n.m_m0[f] = mm;
             n.n_m0[f] = (double)nm;
             n.m_id_kf[f] = m_id_kf;
-            hit = 1;
+            hit = i >= 0;
         }
     }
     const int cnt = __popcll(__ballot(hit));
@@ -792,7 +805,9 @@ int forward_match_enqueue(edgehip_ctx *c, int slot_old, int slot_new, bool keys_
     const int32_t *kno = c->kn_slot + slot_old * B, *knn = c->kn_slot + slot_new * B;
     if (!keys_posted) hipLaunchKernelGGL(k_fwd_key, g, b, 0, c->stream, kldev(c, slot_old), kno, knn, c->fwd_key, pl.cap);
     hipLaunchKernelGGL(k_fwd_win, g, b, 0, c->stream, kldev(c, slot_old), kno, knn, c->fwd_key, c->fwd_win, pl.cap);
-    hipLaunchKernelGGL(k_fwd_apply, g, b, 0, c->stream, kldev(c, slot_old), kldev(c, slot_new), knn, c->fwd_win, c->seq, pl.cap);
+    if (c->fwd_fill[slot_new]) hipLaunchKernelGGL(k_fwd_apply<true>, g, b, 0, c->stream, kldev(c, slot_old), kldev(c, slot_new), knn, c->fwd_win, c->seq, pl.cap);
+    else hipLaunchKernelGGL(k_fwd_apply<false>, g, b, 0, c->stream, kldev(c, slot_old), kldev(c, slot_new), knn, c->fwd_win, c->seq, pl.cap);
+    c->fwd_fill[slot_new] = false;
     EH_LAUNCH_CHECK();
     return 0;
 }
@@ -1300,7 +1315,9 @@ static int frame_enqueue(edgehip_ctx *c, int sn, int so, int sp, int have_pair, 
         EH_CHECK(hipStreamWaitEvent(c->stream_a, c->ev_use[sn], 0));
     }
     if (sp >= 0 && c->overlap && c->use_valid[sp]) EH_CHECK(hipStreamWaitEvent(c->stream_a, c->ev_use[sp], 0));
-    EH_TRY(stage_a_enqueue(c, sn));
+    // (with a frame pair FordwardMatch follows below in every branch: the detector may leave the forwarded fields to it;
+    // mode 2 keeps its scattering pass, which cannot fill)
+    EH_TRY(stage_a_enqueue(c, sn, have_pair && c->fwd_mode != 2));
     if (sp >= 0) EH_TRY(stage_a_enqueue(c, sp));   // the pair image, after the main one as in rebvo_first_t.cpp:259-290
     EH_CHECK(hipEventRecord(c->ev_a[sn], c->stream_a));
     EH_CHECK(hipStreamWaitEvent(c->stream, c->ev_a[sn], 0));
