@@ -694,6 +694,11 @@ __device__ __forceinline__ void tvr_body(const TvrArgs &a, const int seq, const 
                 rout[ikl] = fi;
             } else if (status == 1) {
                 rout[ikl] = a.max_r;
+            } else if (ikl < kn) {
+                // a KeyLine the gates skip (the same ones in every evaluation of a minimisation): the reference leaves its entry
+                // alone and nothing ever reads it; it is written anyway so that the wave stores whole lines (with ~13 % of the
+                // lanes masked most lines would be written in part, which the memory system turns into read-modify-write)
+                rout[ikl] = 0.0;
             }
         }
         if (a.write_mid && ikl < kn) {
