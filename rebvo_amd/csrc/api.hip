@@ -37,11 +37,13 @@ void drop_frame_graphs(edgehip_ctx *c) {
     c->frame_graphs.clear();
 }
 int order_a_after_bc(edgehip_ctx *c) {
+    if (c->stream_a == c->stream) return 0;   // one stream under two names (no overlap): already in order
     EH_CHECK(hipEventRecord(c->ev_tmp, c->stream));
     EH_CHECK(hipStreamWaitEvent(c->stream_a, c->ev_tmp, 0));
     return 0;
 }
 int order_bc_after_a(edgehip_ctx *c) {
+    if (c->stream_a == c->stream) return 0;
     EH_CHECK(hipEventRecord(c->ev_tmp, c->stream_a));
     EH_CHECK(hipStreamWaitEvent(c->stream, c->ev_tmp, 0));
     return 0;
@@ -340,7 +342,13 @@ static int create_body(edgehip_ctx *c, CtxAllocs *al, const edgehip_params &p, i
     c->use_graph = getenv("EDGEHIP_GRAPH") ? atoi(getenv("EDGEHIP_GRAPH")) != 0 : false;
     c->prof = new Profiler();
     EH_CHECK(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
-    EH_CHECK(hipStreamCreateWithFlags(&c->stream_a, hipStreamNonBlocking));
+    // Stage A gets a stream of its own only when it may overlap stages B/C (EDGEHIP_OVERLAP=1).  Otherwise it is the main
+    // stream under another name: a hop between two streams costs a single camera 12-16 us of idle device, twice per frame.
+    if (getenv("EDGEHIP_OVERLAP") && atoi(getenv("EDGEHIP_OVERLAP")) != 0) {
+        EH_CHECK(hipStreamCreateWithFlags(&c->stream_a, hipStreamNonBlocking));
+    } else {
+        c->stream_a = c->stream;
+    }
     EH_CHECK(hipStreamCreateWithFlags(&c->stream_up, hipStreamNonBlocking));
     for (int i = 0; i < 4; i++) { EH_CHECK(hipEventCreateWithFlags(&c->ev_up[i], hipEventDisableTiming)); c->up_valid[i] = false; c->slot_ring[i] = -1; c->a_api_valid[i] = false; c->grec_ok[i] = false; }
     for (int i = 0; i < 4; i++) {
@@ -349,6 +357,8 @@ static int create_body(edgehip_ctx *c, CtxAllocs *al, const edgehip_params &p, i
         c->use_valid[i] = false;
     }
     EH_CHECK(hipEventCreateWithFlags(&c->ev_tmp, hipEventDisableTiming));
+    EH_CHECK(hipEventCreateWithFlags(&c->ev_stage, hipEventDisableTiming));
+    EH_CHECK(hipEventCreateWithFlags(&c->ev_stage8, hipEventDisableTiming));
     for (int i = 0; i < 8; i++) { EH_CHECK(hipEventCreateWithFlags(&c->ev_ring[i], hipEventDisableTiming)); c->ring_valid[i] = false; }
     if (nslots > 4) { set_error("edgehip_create: at most 4 frame slots"); return EDGEHIP_ERR_ARG; }
 
@@ -442,10 +452,8 @@ static int create_body(edgehip_ctx *c, CtxAllocs *al, const edgehip_params &p, i
     EH_TRY(dmalloc(c, &c->fwd_win, B * CAP, al->dev, 0xFF));
     EH_TRY(dmalloc(c, &c->rs_tmp, B * 2 * CAP, al->dev, 0));
     EH_TRY(dmalloc(c, &c->rot_buf, B * 9, al->dev, 0));
-    EH_TRY(dmalloc(c, &c->t_buf, B, al->dev, 0));
     EH_TRY(dmalloc(c, &c->nav_dev, B, al->dev, 0));
     EH_TRY(dmalloc(c, &c->idx_dev, B, al->dev, 0));
-    EH_TRY(dmalloc(c, &c->frame_idx, S * B, al->dev, 0));
     c->slot_src.assign(S, edgehip_ctx::SlotSrc());
     c->stereo_cnt = nullptr;
     if (p.stereo_available) EH_TRY(dmalloc(c, &c->stereo_cnt, B, al->dev, 0));
@@ -573,10 +581,12 @@ int edgehip_destroy(edgehip_ctx *c) {
     if (c->pinned_nav_imu) (void)hipHostFree(c->pinned_nav_imu);
     for (int i = 0; i < 4; i++) { (void)hipEventDestroy(c->ev_a[i]); (void)hipEventDestroy(c->ev_use[i]); }
     (void)hipEventDestroy(c->ev_tmp);
+    (void)hipEventDestroy(c->ev_stage);
+    (void)hipEventDestroy(c->ev_stage8);
     for (int i = 0; i < 8; i++) (void)hipEventDestroy(c->ev_ring[i]);
     for (int i = 0; i < 4; i++) (void)hipEventDestroy(c->ev_up[i]);
     (void)hipStreamDestroy(c->stream_up);
-    (void)hipStreamDestroy(c->stream_a);
+    if (c->stream_a != c->stream) (void)hipStreamDestroy(c->stream_a);
     (void)hipStreamDestroy(c->stream);
     delete c;
     return 0;
@@ -649,11 +659,14 @@ int edgehip_upload_rgb(edgehip_ctx *c, int slot, const uint8_t *rgb24, int seq_f
     if (int e = wait_upload(c, slot, c->stream_a)) return e;
     if (!rgb24 || seq_first < 0 || count < 1 || seq_first + count > c->plan.nseq) { set_error("upload_rgb: bad range"); return EDGEHIP_ERR_ARG; }
     const size_t fb = (size_t)c->plan.n * 3;
-    // the pinned buffer is reused: wait for the previous copy out of it
-    EH_CHECK(hipStreamSynchronize(c->stream_a));
+    // the pinned buffer is reused: wait for the previous copy out of it (an event, not the stream: with stage A on the main
+    // stream that would wait for the whole frame before)
+    if (c->stage_busy) EH_CHECK(hipEventSynchronize(c->ev_stage));
     memcpy(c->pinned_rgb + fb * seq_first, rgb24, fb * count);
     EH_CHECK(hipMemcpyAsync(rgbof(c, slot) + fb * seq_first, c->pinned_rgb + fb * seq_first, fb * count,
                             hipMemcpyHostToDevice, c->stream_a));
+    EH_CHECK(hipEventRecord(c->ev_stage, c->stream_a));
+    c->stage_busy = true;
     return 0;
 }
 
@@ -697,10 +710,12 @@ int edgehip_upload_grey8(edgehip_ctx *c, int slot, const uint8_t *grey8, int seq
         EH_CHECK(hipHostMalloc(&q, fb * c->plan.nseq, hipHostMallocDefault));
         c->pinned_grey8 = (uint8_t *)q;
     }
-    EH_CHECK(hipStreamSynchronize(c->stream_a));   // the staging buffer is reused: wait for the previous copy out of it
+    if (c->stage8_busy) EH_CHECK(hipEventSynchronize(c->ev_stage8));   // the staging buffer is reused: wait for the previous copy out of it
     memcpy(c->pinned_grey8 + fb * seq_first, grey8, fb * count);
     EH_CHECK(hipMemcpyAsync(c->grey8 + ((size_t)slot * c->plan.nseq + seq_first) * fb, c->pinned_grey8 + fb * seq_first, fb * count,
                             hipMemcpyHostToDevice, c->stream_a));
+    EH_CHECK(hipEventRecord(c->ev_stage8, c->stream_a));
+    c->stage8_busy = true;
     return 0;
 }
 int edgehip_upload_grey8_pinned(edgehip_ctx *c, int slot, const uint8_t *grey8_pinned, int seq_first, int count) {
@@ -729,8 +744,11 @@ int edgehip_bind_grey8_indexed(edgehip_ctx *c, int slot, const void *pool_dev, i
         if (idx[s] < 0 || idx[s] >= pool_frames) { set_error("bind_grey8_indexed: index out of range"); return EDGEHIP_ERR_ARG; }
         pi[s] = idx[s];
     }
-    EH_CHECK(hipMemcpyAsync(c->frame_idx + (size_t)slot * B, pi, sizeof(int32_t) * B, hipMemcpyHostToDevice, c->stream_a));
+    // stage A reads the row in place (page-locked, device-visible): no copy on the frame's critical path.  The row belongs to
+    // this ring entry until the frame that uses it has run (wait_pinned_ring).
     edgehip_ctx::SlotSrc &ss = c->slot_src[slot];
+    ss.idx_row = pi;
+    ss.idx_ring = c->frames_seen % 8;
     if (ss.base != (const uint8_t *)pool_dev || !ss.grey8) drop_frame_graphs(c);
     ss.base = (const uint8_t *)pool_dev;
     ss.grey8 = true;
@@ -782,8 +800,11 @@ int edgehip_bind_rgb_indexed(edgehip_ctx *c, int slot, const void *pool_dev, int
         if (idx[s] < 0 || idx[s] >= pool_frames) { set_error("bind_rgb_indexed: index out of range"); return EDGEHIP_ERR_ARG; }
         pi[s] = idx[s];
     }
-    EH_CHECK(hipMemcpyAsync(c->frame_idx + (size_t)slot * B, pi, sizeof(int32_t) * B, hipMemcpyHostToDevice, c->stream_a));
+    // stage A reads the row in place (page-locked, device-visible): no copy on the frame's critical path.  The row belongs to
+    // this ring entry until the frame that uses it has run (wait_pinned_ring).
     edgehip_ctx::SlotSrc &ss = c->slot_src[slot];
+    ss.idx_row = pi;
+    ss.idx_ring = c->frames_seen % 8;
     if (ss.base != (const uint8_t *)pool_dev || ss.grey8) drop_frame_graphs(c);   // the frame source is a kernel argument
     ss.base = (const uint8_t *)pool_dev;
     ss.grey8 = false;

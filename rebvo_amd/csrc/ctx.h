@@ -160,6 +160,8 @@ struct edgehip_ctx {
     hipEvent_t ev_a[4];    // [slot] stage A of the frame in this slot has finished
     hipEvent_t ev_use[4];  // [slot] the last B/C work that read this slot has finished
     hipEvent_t ev_tmp;     // ordering of the stage-level entry points
+    hipEvent_t ev_stage, ev_stage8;   // last copy out of the pageable-upload staging buffers (RGB24, 8-bit)
+    bool stage_busy = false, stage8_busy = false;
     hipStream_t stream_up; // uploads of page-locked frames: they overlap stage A as well as B/C of the frames before
     hipEvent_t ev_up[4];   // [slot] the last upload into this slot on stream_up has finished
     bool up_valid[4];
@@ -226,11 +228,11 @@ struct edgehip_ctx {
     int ring_slots;                   // slots the frame ring cycles through (nslots, or nslots - 1 with a stereo rig)
     // base == nullptr: the slot's own storage.  grey8: the frames are 8-bit mono, 1 B per pixel (edgehip_upload_grey8* /
     // edgehip_bind_grey8_indexed) — in the slot's grey8 buffer or, bound, in a pool of grey8 frames.
-    struct SlotSrc { const uint8_t *base = nullptr; std::vector<int32_t> host_idx; bool grey8 = false; };
+    struct SlotSrc { const uint8_t *base = nullptr; std::vector<int32_t> host_idx; bool grey8 = false;
+                     const int32_t *idx_row = nullptr; int idx_ring = 0; };   // idx_row: the page-locked row of the binding (stage A reads it in place)
     uint8_t *grey8 = nullptr;        // [S][B][N] 8-bit frames of the slots (allocated by the first grey8 upload)
     uint8_t *pinned_grey8 = nullptr; // [B][N] staging of edgehip_upload_grey8 (pageable input)
     std::vector<SlotSrc> slot_src;   // per ring slot: where stage A reads its frames from
-    int32_t *frame_idx;              // [S][B] frame index of every sequence inside a bound pool
     struct SlotCam { float ppx, ppy; double zfm; };
     std::vector<SlotCam> slot_cam;   // per ring slot: principal point stage A uses, focal length of that camera (stereo pair slot)
     int field_radius;      // radius of the last build_field (global_tracker::max_r)
@@ -252,7 +254,7 @@ struct edgehip_ctx {
     bool fwd_key_in_tvr = false;   // whole-frame driver: the minimiser's last evaluation also posts FordwardMatch's arbitration keys
     double *rs_tmp;        // [B][2][CAP] regularised (rho, s_rho) ping-pong
     double *rot_buf;       // [B][9] rotation applied by rotate_keylines
-    double *t_buf;         // [B] frame time stamps
+    const double *t_src = nullptr;   // page-locked time stamps of the frame being enqueued (read in place by k_frame_glue mode 0)
     edgehip_nav *nav_dev;  // [B] per-frame record
     edgehip_nav *nav_log;  // [nav_log_len][B] ring of per-frame records (optional)
     int nav_log_len;

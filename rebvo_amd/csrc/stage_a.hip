@@ -168,6 +168,45 @@ __global__ __launch_bounds__(64) void k_colscan(PlanePtrs planes, int w, int h, 
 }
 
 // ---------------------------------------------------------------------------------------------------
+// k_colscan_chain: the same serial column prefix for a few planes (a live camera), where k_colscan's one wave per
+// 64 columns pays h / UNR dependent load round trips.  NW waves per 64 columns: every wave loads its band of rows
+// at once (all h loads of a column in flight together), then the bands take turns down the column — wave k adds
+// its rows onto the carry wave k-1 left in LDS — and every wave stores its band.  The chain of h dependent float
+// adds per column is the reference's, so are its bits.
+// ---------------------------------------------------------------------------------------------------
+template <int NW, int RPW>
+__global__ __launch_bounds__(NW * 64) void k_colscan_chain(PlanePtrs planes, int w, int h, size_t n) {
+    __shared__ float carry[64];
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int x = blockIdx.x * 64 + lane;
+    const bool on = x < w;
+    float *img = planes.p[blockIdx.y] + (size_t)blockIdx.z * n + (on ? x : 0);
+    const int rpw = (h + NW - 1) / NW;
+    const int y0 = wv * rpw;
+    const int cnt = min(h - y0, rpw);   // rows of this wave (<= 0: none)
+    float v[RPW];
+#pragma unroll
+    for (int i = 0; i < RPW; i++) v[i] = (on && i < cnt) ? img[(size_t)(y0 + i) * w] : 0.f;
+    for (int k = 0; k < NW; k++) {
+        if (wv == k && cnt > 0) {
+            float run = k ? carry[lane] : 0.f;
+#pragma unroll
+            for (int i = 0; i < RPW; i++) {
+                if (i < cnt) {
+                    run = (k == 0 && i == 0) ? v[0] : v[i] + run;   // img(x,0) stays; img(x,y) += img(x,y-1)
+                    v[i] = run;
+                }
+            }
+            carry[lane] = run;
+        }
+        __syncthreads();
+    }
+#pragma unroll
+    for (int i = 0; i < RPW; i++)
+        if (on && i < cnt) img[(size_t)(y0 + i) * w] = v[i];
+}
+
+// ---------------------------------------------------------------------------------------------------
 // Box average from an integral image: iimage::average's nine border regions collapse to one formula
 // with zero-substituted taps (x - 0 and x + 0 are exact), EXCEPT that the bottom band (y >= h-d2)
 // subtracts the upper tap before the left tap (iimage.cpp:118-126 vs :105-113).  The multiplier is
@@ -286,6 +325,61 @@ __global__ __launch_bounds__(NT) void k_avg_rowscan(AvgJob job, const float *__r
             if (x < w && y < h) dst[(size_t)y * w + x] = tile[r][c];
         }
         __syncthreads();
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------
+// k_avg_rowscan_wide: k_avg_rowscan for a few planes (a live camera).  A block owns RB whole rows: the taps of all
+// its pixels are in flight at once (PT pixels per thread, registers), the averages go to LDS, RB lanes walk one row
+// each (the reference's chain of w dependent adds), everything is stored coalesced — one round trip to memory per
+// block instead of one per 256-column tile.  Same operations in the same order.
+// ---------------------------------------------------------------------------------------------------
+template <int NT, int RB, int TC>
+__global__ __launch_bounds__(NT) void k_avg_rowscan_wide(AvgJob job, const float *__restrict__ lut, int w, int h, size_t n) {
+    __shared__ float tile[RB][TC + 1];
+    constexpr int PT = RB * TC / NT;
+    const int seq = blockIdx.z;
+    const float *src = job.src[blockIdx.y] + (size_t)seq * n;
+    float *dst = job.dst[blockIdx.y] + (size_t)seq * n;
+    const int d = job.d[blockIdx.y], d2 = d / 2;
+    const float a_int = lut[d * d];
+    const int y0 = blockIdx.x * RB;
+    const int tid = threadIdx.x;
+    BoxTaps t[PT];
+#pragma unroll
+    for (int j = 0; j < PT; j++) {
+        const int idx = tid + j * NT, r = idx / TC, c = idx - r * TC;
+        const int x = min(c, w - 1), y = min(y0 + r, h - 1);
+        t[j] = box_taps(src, x, y, w, h, d, d2, lut, a_int);
+    }
+#pragma unroll
+    for (int j = 0; j < PT; j++) {
+        const int idx = tid + j * NT, r = idx / TC, c = idx - r * TC;
+        tile[r][c] = box_combine(t[j]);
+    }
+    __syncthreads();
+    if (tid < RB) {
+        float run = 0.f;
+#pragma unroll 1
+        for (int cc = 0; cc < w; cc += 64) {
+            float vals[64];
+#pragma unroll
+            for (int c = 0; c < 64; c++) vals[c] = tile[tid][min(cc + c, TC)];
+#pragma unroll
+            for (int c = 0; c < 64; c++) {
+                run = (cc + c == 0) ? vals[c] : run + vals[c];  // img(0,y)=l(0,y); img(x,y)=img(x-1,y)+l(x,y)
+                vals[c] = run;
+            }
+#pragma unroll
+            for (int c = 0; c < 64; c++)
+                if (cc + c < TC) tile[tid][cc + c] = vals[c];
+        }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int j = 0; j < PT; j++) {
+        const int idx = tid + j * NT, r = idx / TC, c = idx - r * TC;
+        if (c < w && y0 + r < h) dst[(size_t)(y0 + r) * w + c] = tile[r][c];
     }
 }
 
@@ -1179,7 +1273,7 @@ int stage_a_enqueue(edgehip_ctx *c, int slot, bool fwd_fills) {
     hipStream_t st = c->stream_a;
     // where the slot's frames are: its own storage (sequence-major) or frames of a bound device pool (edgehip_bind_rgb_indexed)
     const uint8_t *rgb_base = c->slot_src[slot].base ? c->slot_src[slot].base : rgbof(c, slot);
-    const int32_t *rgb_idx = c->slot_src[slot].base ? c->frame_idx + (size_t)slot * c->plan.nseq : nullptr;
+    const int32_t *rgb_idx = c->slot_src[slot].base ? c->slot_src[slot].idx_row : nullptr;
 
     // Batches that fill the GPU with one workgroup per sequence: the whole of stage A up to the KeyLine records in one
     // kernel (stage_a_fused.hip); level_mode 3 forces it, 1 / 2 keep the multi-kernel path (A/B measurements, tests).
@@ -1318,7 +1412,13 @@ int stage_a_enqueue(edgehip_ctx *c, int slot, bool fwd_fills) {
             PlanePtrs pp;
             pp.p[0] = a;
             pp.p[1] = b ? b : a;
-            hipLaunchKernelGGL(k_colscan<32>, dim3((w + 63) / 64, b ? 2 : 1, B), dim3(64), 0, st, pp, w, h, n);
+            const size_t nblk = (size_t)((w + 63) / 64) * (b ? 2 : 1) * B;
+            if (nblk <= 512 && h <= 16 * 32)
+                hipLaunchKernelGGL((k_colscan_chain<16, 32>), dim3((w + 63) / 64, b ? 2 : 1, B), dim3(1024), 0, st, pp, w, h, n);
+            else if (nblk <= 512 && h <= 16 * 64)
+                hipLaunchKernelGGL((k_colscan_chain<16, 64>), dim3((w + 63) / 64, b ? 2 : 1, B), dim3(1024), 0, st, pp, w, h, n);
+            else
+                hipLaunchKernelGGL(k_colscan<32>, dim3((w + 63) / 64, b ? 2 : 1, B), dim3(64), 0, st, pp, w, h, n);
             EH_LAUNCH_CHECK();
             return 0;
         };
@@ -1360,7 +1460,10 @@ int stage_a_enqueue(edgehip_ctx *c, int slot, bool fwd_fills) {
                 // of the tile round trips (100 -> ~20 us per launch for one 752x480 frame).  Same operations, same order.
                 // ... and for one or two sequences 4-row blocks: 240 blocks for one 752x480 frame instead of 60, a quarter of the
                 // averages per tile and block (the row prefix itself is a fixed chain of w dependent adds per row either way).
-                if ((size_t)B * njobs * ((h + 15) / 16) < 128)
+                if ((size_t)B * njobs * ((h + 15) / 16) < 128 && w <= 768)
+                    hipLaunchKernelGGL((k_avg_rowscan_wide<256, 4, 768>), dim3((h + 3) / 4, njobs, B), dim3(256), 0, st, job,
+                                       c->div_lut, w, h, n);
+                else if ((size_t)B * njobs * ((h + 15) / 16) < 128)
                     hipLaunchKernelGGL((k_avg_rowscan<256, 4, 256>), dim3((h + 3) / 4, njobs, B), dim3(256), 0, st, job,
                                        c->div_lut, w, h, n);
                 else if ((size_t)B * njobs * ((h + 63) / 64) < 256)

@@ -1054,7 +1054,7 @@ static int ext_rotvel_enqueue(edgehip_ctx *c, int slot) {
 
 static int glue(edgehip_ctx *c, int mode, int slot_new, int have_pair) {
     const DevicePlan &pl = c->plan;
-    hipLaunchKernelGGL(k_frame_glue, dim3((pl.nseq + 63) / 64), dim3(64), 0, c->stream, c->seq, c->t_buf, c->nav_dev,
+    hipLaunchKernelGGL(k_frame_glue, dim3((pl.nseq + 63) / 64), dim3(64), 0, c->stream, c->seq, c->t_src, c->nav_dev,
                        c->kn_slot + (size_t)slot_new * pl.nseq, c->tresh_slot + (size_t)slot_new * pl.nseq,
                        c->retuned_slot + (size_t)slot_new * pl.nseq, pl.nseq, mode, c->p.config_fps, c->p.global_match_threshold,
                        have_pair, c->nav_log, c->nav_log_len);
@@ -1301,9 +1301,8 @@ int edgehip_cur_slot(edgehip_ctx *c) { return c ? c->frame_slot : -1; }
 
 // Everything edgehip_process_frame enqueues for one frame (both streams); also what gets captured into a graph.
 static int frame_enqueue(edgehip_ctx *c, int sn, int so, int sp, int have_pair, const double *tp) {
-    const DevicePlan &pl = c->plan;
     int e;
-    EH_CHECK(hipMemcpyAsync(c->t_buf, tp, sizeof(double) * pl.nseq, hipMemcpyHostToDevice, c->stream));
+    c->t_src = tp;   // page-locked ring entry, read in place by the frame-begin glue (no copy on the critical path)
 #define EH_TRY(x) if ((e = (x)) != 0) return e
     // Stage A of this frame runs on its own stream: it only has to wait for the B/C work that still reads the slot it
     // overwrites (two frames back), so it overlaps the tracking/mapping of the previous frame — what the reference's
@@ -1320,7 +1319,7 @@ static int frame_enqueue(edgehip_ctx *c, int sn, int so, int sp, int have_pair, 
     EH_TRY(stage_a_enqueue(c, sn, have_pair && c->fwd_mode != 2));
     if (sp >= 0) EH_TRY(stage_a_enqueue(c, sp));   // the pair image, after the main one as in rebvo_first_t.cpp:259-290
     EH_CHECK(hipEventRecord(c->ev_a[sn], c->stream_a));
-    EH_CHECK(hipStreamWaitEvent(c->stream, c->ev_a[sn], 0));
+    if (c->stream_a != c->stream) EH_CHECK(hipStreamWaitEvent(c->stream, c->ev_a[sn], 0));
     {
         ProfScope ps(c, PROF_C_POSE);
         EH_TRY(glue(c, 0, sn, have_pair));
@@ -1414,7 +1413,7 @@ int edgehip_process_frame(edgehip_ctx *c, const double *t) {
     // the first frames run eagerly (one-time kernel attributes, no frame pair yet); then every (slot, FrameCount row,
     // pinned time-stamp slot) combination — period lcm(ring, 8) — is captured once and replayed
     if (graph_path) {
-        const int key = sn + 8 * (c->frames_seen % 8) + 64 * (sp + 1);
+        const int key = sn + 8 * (c->frames_seen % 8) + 64 * (sp + 1) + 512 * c->slot_src[sn].idx_ring + 4096 * (sp >= 0 ? c->slot_src[sp].idx_ring : 0);   // every pointer a node bakes in
         if (int e = order_bc_after_a(c)) return e;   // the caller's uploads (stage-A stream) precede the graph
         auto it = c->frame_graphs.find(key);
         if (it == c->frame_graphs.end()) {
