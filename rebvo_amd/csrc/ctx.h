@@ -366,17 +366,35 @@ int order_a_after_bc(edgehip_ctx *c);
 int order_bc_after_a(edgehip_ctx *c);
 int sync_all(edgehip_ctx *c);
 int undistort_frame_enqueue(edgehip_ctx *c, int seq, int slot, uint8_t *out_dev);
-int quantile_enqueue(edgehip_ctx *c, int slot, double smin, double smax, double pct, int nbins);
+// SecondThread's frame begin (rebvo_second_t.cpp:145-168): dt, the tracker's priors, the per-frame counters and flags
+__device__ inline void frame_begin(SeqDev *sq, double t, double fps) {
+    edgehip_seq_state &p = sq->pub;
+    double dt = t - p.t_prev;
+    if (dt < 0.001) dt = 1 / fps;
+    p.dt = dt;
+    sq->t_cur = t;
+    for (int i = 0; i < 9; i++) {
+        const double d = (i == 0 || i == 4 || i == 8) ? 1.0 : 0.0;
+        p.P_V[i] = d * 1e50; p.P_W[i] = d * 1e50; p.R[i] = d;
+    }
+    p.klm_fwd = 0; p.klm_num = 0; p.kf_matchs = 0;
+    p.estimation_ok = 1;
+    sq->skip_match = 0;
+    sq->skip_map = 0;
+    p.minimizer_evals = 0;
+}
+
+int quantile_enqueue(edgehip_ctx *c, int slot, double smin, double smax, double pct, int nbins, bool frame_begins = false);
 int build_field_enqueue(edgehip_ctx *c, int slot, int radius, float min_mod, bool clear_fwd = false);
 int tvr_prepare_enqueue(edgehip_ctx *c, int slot_old);
 int minimizer_enqueue(edgehip_ctx *c, int slot_new, int slot_old, int fc_index);
 int minimizer_v_enqueue(edgehip_ctx *c, int slot_new, int slot_old, int fc_index, int iter_max, double match_thresh,
                          uint32_t match_num_thresh, double reweight_distance);
-int forward_match_enqueue(edgehip_ctx *c, int slot_old, int slot_new, bool keys_posted = false);
+int forward_match_enqueue(edgehip_ctx *c, int slot_old, int slot_new, bool keys_posted = false, bool frame_tail = false);
 int forward_rotate_enqueue(edgehip_ctx *c, int slot_old, int slot_new);   // FordwardMatch (keys already posted by the minimiser) + rotate_keylines(exp(W))
-int rotate_enqueue(edgehip_ctx *c, int slot, const double *R_host);
+int rotate_enqueue(edgehip_ctx *c, int slot, const double *R_host, bool R_in_buf = false);
 int directed_enqueue(edgehip_ctx *c, int slot_new, int slot_old);
-int regekf_enqueue(edgehip_ctx *c, int slot, int do_reg, int do_ekf);
+int regekf_enqueue(edgehip_ctx *c, int slot, int do_reg, int do_ekf, bool frame_glue = false);
 int rescale_enqueue(edgehip_ctx *c, int slot);
 int pose_enqueue(edgehip_ctx *c, int slot_new, const double *t_host);
 int imu_begin_enqueue(edgehip_ctx *c);                // stage_imu.hip

@@ -359,20 +359,20 @@ __global__ __launch_bounds__(NT) void k_avg_rowscan_wide(AvgJob job, const float
     }
     __syncthreads();
     if (tid < RB) {
+        static_assert(TC % 64 == 0, "whole 64-column chunks");
         float run = 0.f;
 #pragma unroll 1
-        for (int cc = 0; cc < w; cc += 64) {
+        for (int cc = 0; cc < w; cc += 64) {   // columns >= w of the last chunk hold averages of clamped pixels: added after the row's last real column, never stored
             float vals[64];
 #pragma unroll
-            for (int c = 0; c < 64; c++) vals[c] = tile[tid][min(cc + c, TC)];
+            for (int c = 0; c < 64; c++) vals[c] = tile[tid][cc + c];
 #pragma unroll
             for (int c = 0; c < 64; c++) {
                 run = (cc + c == 0) ? vals[c] : run + vals[c];  // img(0,y)=l(0,y); img(x,y)=img(x-1,y)+l(x,y)
                 vals[c] = run;
             }
 #pragma unroll
-            for (int c = 0; c < 64; c++)
-                if (cc + c < TC) tile[tid][cc + c] = vals[c];
+            for (int c = 0; c < 64; c++) tile[tid][cc + c] = vals[c];
         }
     }
     __syncthreads();

@@ -44,31 +44,54 @@ namespace edgehip {
 // ---------------------------------------------------------------------------------------------------
 // EstimateQuantile
 // ---------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void k_quantile(const KlSoA *kls, const int32_t *__restrict__ kns, SeqDev *seqs,
-                                                  double smin, double smax, double pct, int nbins) {
+// NT = 256 for whole batches, 1024 for a few sequences (a quarter of the dependent load round trips per block).  The histogram is
+// integer, so neither the thread count nor the lane-parallel search for the first bin past the quantile changes the result.
+// t_in != null (whole-frame driver): one thread of the block also does SecondThread's frame begin for its sequence (ctx.h::frame_begin;
+// nothing here reads what it writes) — one dependent launch fewer per frame.
+template <int NT>
+__global__ __launch_bounds__(NT) void k_quantile(const KlSoA *kls, const int32_t *__restrict__ kns, SeqDev *seqs,
+                                                 double smin, double smax, double pct, int nbins, const double *__restrict__ t_in, double fps) {
     __shared__ int s_h[256];
     const int seq = blockIdx.x, tid = threadIdx.x;
-    s_h[tid] = 0;
+    if (t_in && tid == NT - 1) frame_begin(seqs + seq, t_in[seq], fps);
+    if (tid < 256) s_h[tid] = 0;
     __syncthreads();
     const int kn = kns[seq];
     const double *s_rho = kls[seq].s_rho;
-    for (int i = tid; i < kn; i += 256) {
-        int b = x86_cvttsd2si((double)nbins * (s_rho[i] - smin) / (smax - smin));
-        b = b > nbins - 1 ? nbins - 1 : b;
-        b = b < 0 ? 0 : b;
-        atomicAdd(&s_h[b], 1);
+    for (int i0 = tid; i0 < kn; i0 += 4 * NT) {
+        double v[4];
+#pragma unroll
+        for (int j = 0; j < 4; j++) v[j] = i0 + j * NT < kn ? s_rho[i0 + j * NT] : 0.0;
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+            if (i0 + j * NT >= kn) break;
+            int b = x86_cvttsd2si((double)nbins * (v[j] - smin) / (smax - smin));
+            b = b > nbins - 1 ? nbins - 1 : b;
+            b = b < 0 ? 0 : b;
+            atomicAdd(&s_h[b], 1);
+        }
     }
     __syncthreads();
-    if (tid == 0) {
-        double q = 1e3;
-        for (int i = 0, a = 0; i < nbins; i++) {
-            if ((double)a > pct * (double)kn) {
-                q = (double)i * (smax - smin) / (double)nbins + smin;
-                break;
-            }
-            a += s_h[i];
+    if (tid < 64) {
+        // first bin i whose exclusive prefix a_i = sum_{k<i} h[k] exceeds pct * kn (the loop of edge_tracker.cpp:1170-1181, all bins at once)
+        int h[4], ex[4];
+        int tot = 0;
+#pragma unroll
+        for (int j = 0; j < 4; j++) { h[j] = s_h[tid * 4 + j]; ex[j] = tot; tot += h[j]; }
+        int inc = tot;
+        for (int o = 1; o < 64; o <<= 1) {
+            const int up = __shfl_up(inc, o, 64);
+            if (tid >= o) inc += up;
         }
-        seqs[seq].pub.s_rho_q = q;
+        const int base = inc - tot;
+        int first = 1 << 30;
+#pragma unroll
+        for (int j = 3; j >= 0; j--) {
+            const int i = tid * 4 + j;
+            if (i < nbins && (double)(base + ex[j]) > pct * (double)kn) first = i;
+        }
+        for (int o = 32; o > 0; o >>= 1) first = min(first, __shfl_xor(first, o, 64));
+        if (tid == 0) seqs[seq].pub.s_rho_q = first < nbins ? (double)first * (smax - smin) / (double)nbins + smin : 1e3;
     }
 }
 
@@ -297,7 +320,7 @@ __global__ __launch_bounds__(256) void k_field_bin(const KlSoA *kls, const int32
     if (fwd_key && i < kn) { fwd_key[(size_t)seq * bin_cap + i] = 0ull; fwd_win[(size_t)seq * bin_cap + i] = -1; }
 }
 
-__global__ __launch_bounds__(256) void k_field_raster(const KlSoA *kls, const int32_t *__restrict__ bin_cnt,
+__global__ __launch_bounds__(256) void k_field_raster(const KlSoA *kls, int32_t *__restrict__ bin_cnt,
                                                       const int32_t *__restrict__ bins, uint32_t *__restrict__ field,
                                                       uint16_t *__restrict__ field16, size_t f16stride, int f16tx, int keep32,
                                                       int w, int h, size_t fstride, int ftx, int radius, int ntx, int bin_cap) {
@@ -357,6 +380,7 @@ __global__ __launch_bounds__(256) void k_field_raster(const KlSoA *kls, const in
     if (tx0 == 0) { if (ty0 == 0) raster(T{}, T{}); else raster(T{}, F{}); }
     else { if (ty0 == 0) raster(F{}, T{}); else raster(F{}, F{}); }
     __syncthreads();
+    if (tid == 0) bin_cnt[(size_t)seq * kMaxTiles + tile] = 0;   // every tile's count is consumed by exactly this block: ready for the next k_field_bin (no memset launch)
     // store in the 4x4-tiled layout: 16 consecutive threads write one 64-B tile, a tile row of the block is 1 KB
     // contiguous (FT and the block origin are multiples of 4)
     // (the {dist, ikl} form is kept only for edgehip_download_field: params.debug_planes)
@@ -1734,11 +1758,15 @@ __global__ void k_tvr_setup_from_host(SeqDev *seqs, const double *__restrict__ X
 // ---------------------------------------------------------------------------------------------------
 // host side
 // ---------------------------------------------------------------------------------------------------
-int quantile_enqueue(edgehip_ctx *c, int slot, double smin, double smax, double pct, int nbins) {
+int quantile_enqueue(edgehip_ctx *c, int slot, double smin, double smax, double pct, int nbins, bool frame_begins) {
     ProfScope ps(c, PROF_B_QUANTILE);
     if (nbins < 1 || nbins > 256) { set_error("quantile: 1 <= nbins <= 256"); return EDGEHIP_ERR_ARG; }
-    hipLaunchKernelGGL(k_quantile, dim3(c->plan.nseq), dim3(256), 0, c->stream, kldev(c, slot),
-                       c->kn_slot + (size_t)slot * c->plan.nseq, c->seq, smin, smax, pct, nbins);
+    if (c->plan.nseq <= 64)
+        hipLaunchKernelGGL(k_quantile<1024>, dim3(c->plan.nseq), dim3(1024), 0, c->stream, kldev(c, slot),
+                           c->kn_slot + (size_t)slot * c->plan.nseq, c->seq, smin, smax, pct, nbins, frame_begins ? c->t_src : (const double *)nullptr, c->p.config_fps);
+    else
+        hipLaunchKernelGGL(k_quantile<256>, dim3(c->plan.nseq), dim3(256), 0, c->stream, kldev(c, slot),
+                           c->kn_slot + (size_t)slot * c->plan.nseq, c->seq, smin, smax, pct, nbins, frame_begins ? c->t_src : (const double *)nullptr, c->p.config_fps);
     EH_LAUNCH_CHECK();
     return 0;
 }
@@ -1751,7 +1779,6 @@ int build_field_enqueue(edgehip_ctx *c, int slot, int radius, float min_mod, boo
     c->field_radius = radius;
     const int ntx = (pl.w + FT - 1) / FT, nty = (pl.h + FT - 1) / FT;
     if (c->field_mode == 0 && ntx * nty <= kMaxTiles) {
-        EH_CHECK(hipMemsetAsync(c->bin_cnt, 0, sizeof(int32_t) * pl.nseq * kMaxTiles, c->stream));
         hipLaunchKernelGGL(k_field_bin, dim3((pl.cap + 255) / 256, 1, pl.nseq), dim3(256), 0, c->stream, kldev(c, slot),
                            c->kn_slot + (size_t)slot * pl.nseq, c->retuned_slot + (size_t)slot * pl.nseq, c->bin_cnt, c->bins,
                            pl.w, pl.h, radius, min_mod, ntx, nty, pl.cap, clear_fwd ? c->fwd_key : nullptr, clear_fwd ? c->fwd_win : nullptr);

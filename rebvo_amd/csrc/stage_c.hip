@@ -42,10 +42,20 @@ __global__ __launch_bounds__(256) void k_fwd_key(const KlSoA *kl_old, const int3
     if (f < 0 || f >= kn_new[seq]) return;
     atomicMax(&key[(size_t)seq * cap + f], ord_bits(kl_old[seq].rho[i]));
 }
+__device__ inline void so3_exp_c(const double w[3], double R[9]);
+__device__ inline void rot_from_state(SeqDev *sq, double *__restrict__ Rbuf_seq);
+__device__ inline void glue_after_tracking(SeqDev *sq);
+// tail_seqs != null (whole-frame driver, ImuMode 0): the first thread of a sequence's first block also does the two pieces of
+// per-sequence scalar work that follow the minimiser — R0 = exp(W) for rotate_keylines and the NaN check of
+// rebvo_second_t.cpp:387-397 — which nothing in this kernel or in k_fwd_apply reads: two dependent launches fewer per frame.
 __global__ __launch_bounds__(256) void k_fwd_win(const KlSoA *kl_old, const int32_t *__restrict__ kn_old,
                                                  const int32_t *__restrict__ kn_new, const unsigned long long *__restrict__ key,
-                                                 int32_t *__restrict__ win, int cap) {
+                                                 int32_t *__restrict__ win, int cap, SeqDev *tail_seqs, double *__restrict__ tail_Rbuf) {
     const int seq = blockIdx.z, i = blockIdx.x * 256 + threadIdx.x;
+    if (tail_seqs && i == 0) {
+        rot_from_state(tail_seqs + seq, tail_Rbuf + (size_t)seq * 9);
+        glue_after_tracking(tail_seqs + seq);
+    }
     if (i >= kn_old[seq]) return;
     const int f = kl_old[seq].m_id_f[i];
     if (f < 0 || f >= kn_new[seq]) return;
@@ -241,15 +251,17 @@ __device__ inline void so3_ln(const double M[9], double r[3]) {
 }
 
 // R0 = exp(W); Rbuf[seq] = R0 (for k_rotate); state.R = R0^T * I^T ... i.e. R.T() = R0 * R.T() with R = I
+__device__ inline void rot_from_state(SeqDev *sq, double *__restrict__ Rbuf_seq) {
+    double R0[9];
+    so3_exp_c(sq->pub.W, R0);
+    for (int i = 0; i < 9; i++) Rbuf_seq[i] = R0[i];
+    for (int i = 0; i < 3; i++)
+        for (int j = 0; j < 3; j++) sq->pub.R[i * 3 + j] = R0[j * 3 + i];
+}
 __global__ void k_rot_from_state(SeqDev *seqs, double *__restrict__ Rbuf, int nseq) {
     const int seq = blockIdx.x * blockDim.x + threadIdx.x;
     if (seq >= nseq) return;
-    SeqDev *sq = seqs + seq;
-    double R0[9];
-    so3_exp_c(sq->pub.W, R0);
-    for (int i = 0; i < 9; i++) Rbuf[(size_t)seq * 9 + i] = R0[i];
-    for (int i = 0; i < 3; i++)
-        for (int j = 0; j < 3; j++) sq->pub.R[i * 3 + j] = R0[j * 3 + i];
+    rot_from_state(seqs + seq, Rbuf + (size_t)seq * 9);
 }
 
 // ---------------------------------------------------------------------------------------------------
@@ -469,10 +481,20 @@ __global__ __launch_bounds__(256) void k_directed(DirArgs a) {
 // ---------------------------------------------------------------------------------------------------
 // Regularize_1_iter -> scratch (r, s), then the EKF consumes the scratch
 // ---------------------------------------------------------------------------------------------------
+__device__ inline void glue_after_matching(SeqDev *sq);
+// match_threshold >= 0 (whole-frame driver): the check that follows directed_matching (rebvo_second_t.cpp:412-422, too few matches ->
+// no mapping this frame) is made here instead of in a launch of its own.  Every thread evaluates the condition from fields nothing
+// in this kernel writes; the sequence's first thread applies its consequences to the state.
 __global__ __launch_bounds__(256) void k_regularize(const KlSoA *kls, const int32_t *__restrict__ kns, double *__restrict__ rs,
-                                                    const SeqDev *seqs, int cap, double thresh, int enabled) {
+                                                    SeqDev *seqs, int cap, double thresh, int enabled, int match_threshold) {
     const int seq = blockIdx.z, i = blockIdx.x * 256 + threadIdx.x;
-    if (seqs[seq].skip_map) return;
+    SeqDev *sq = seqs + seq;
+    bool skip = sq->skip_map != 0;
+    if (match_threshold >= 0 && !sq->skip_match && sq->pub.klm_num < match_threshold) {
+        if (i == 0) glue_after_matching(sq);
+        skip = true;
+    }
+    if (skip) return;
     if (i >= kns[seq]) return;
     const KlSoA &K = kls[seq];
     double r = K.rho[i], s = K.s_rho[i];
@@ -551,8 +573,15 @@ __global__ __launch_bounds__(256) void k_ekf(const KlSoA *kls, const int32_t *__
 // ---------------------------------------------------------------------------------------------------
 // EstimateReScalingOpt: 5 dependent weighted sums; one block per sequence
 // ---------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(1024) void k_rescale(const KlSoA *kls, const int32_t *__restrict__ kns, SeqDev *seqs,
-                                                  double s_rho_min, unsigned match_num_min, int re_escale) {
+// The sums are those of 1024 "virtual" threads (KeyLine i belongs to virtual thread i % 1024, its terms are added in increasing i,
+// the 16 wave sums in wave order), whatever the block: NT = 1024 real threads with PER = 6 KeyLines each in registers over the five
+// passes (whole batches: two blocks per CU, the tail beyond 6144 KeyLines streams every pass), or NT = 512 threads that carry
+// two virtual threads with PER = 12 each (a few sequences: 256 VGPRs per thread hold 12288 KeyLines, so no pass waits for loads).
+// Same additions in the same order, same bits.
+template <int NT, int PER>
+__global__ __launch_bounds__(NT) void k_rescale(const KlSoA *kls, const int32_t *__restrict__ kns, SeqDev *seqs,
+                                                double s_rho_min, unsigned match_num_min, int re_escale) {
+    constexpr int VT = 1024 / NT;
     const int seq = blockIdx.x, tid = threadIdx.x;
     SeqDev *sq = seqs + seq;
     if (sq->skip_map) return;
@@ -562,42 +591,48 @@ __global__ __launch_bounds__(1024) void k_rescale(const KlSoA *kls, const int32_
     __shared__ double s_a[16], s_b[16];
     __shared__ double s_kp;
     // per-KeyLine constants of the five passes are read once: rho^2, rho0^2, s_rho^2, s_rho0^2
-    constexpr int PER = 6;   // first 1024*PER KeyLines from registers (VGPR budget of a 1024-thread block); rest streams
-    double r2[PER], r02[PER], s2[PER], s02[PER];
+    double r2[VT][PER], r02[VT][PER], s2[VT][PER], s02[VT][PER];
 #pragma unroll
-    for (int j = 0; j < PER; j++) {
-        const int i = tid + j * 1024;
-        r2[j] = 0; r02[j] = 0; s2[j] = 1; s02[j] = 0;
-        if (i < kn) {
-            const double sr0 = K.s_rho0[i], sr = K.s_rho[i];
-            if (!((unsigned)K.m_num[i] < match_num_min || sr0 <= 0 || sr > s_rho_min)) {
-                const double rho = K.rho[i], rho0 = K.rho0[i];
-                r2[j] = rho * rho; r02[j] = rho0 * rho0; s2[j] = sr * sr; s02[j] = sr0 * sr0;
+    for (int v = 0; v < VT; v++) {
+#pragma unroll
+        for (int j = 0; j < PER; j++) {
+            const int i = tid + v * NT + j * 1024;
+            r2[v][j] = 0; r02[v][j] = 0; s2[v][j] = 1; s02[v][j] = 0;
+            if (i < kn) {
+                const double sr0 = K.s_rho0[i], sr = K.s_rho[i];
+                if (!((unsigned)K.m_num[i] < match_num_min || sr0 <= 0 || sr > s_rho_min)) {
+                    const double rho = K.rho[i], rho0 = K.rho0[i];
+                    r2[v][j] = rho * rho; r02[v][j] = rho0 * rho0; s2[v][j] = sr * sr; s02[v][j] = sr0 * sr0;
+                }
             }
         }
     }
     double Kp = 1, RKp = sq->pub.P_Kp;
     for (int iter = 0; iter < 5; iter++) {
-        double a = 0, b = 0;
         const double kp2 = Kp * Kp;
 #pragma unroll
-        for (int j = 0; j < PER; j++) {
-            // one division for the two quotients (an ulp per term off the reference's rho^2 / den and rho0^2 / den, next to a
-            // summation order that already differs from its sequential one: Kp agrees to 1e-10, tests/test_stage_c_gpu.py)
-            const double inv = 1.0 / (s2[j] + kp2 * s02[j]);
-            a += r2[j] * inv;
-            b += r02[j] * inv;
+        for (int v = 0; v < VT; v++) {
+            double a = 0, b = 0;
+#pragma unroll
+            for (int j = 0; j < PER; j++) {
+                // one division for the two quotients (an ulp per term off the reference's rho^2 / den and rho0^2 / den, next to a
+                // summation order that already differs from its sequential one: Kp agrees to 1e-10, tests/test_stage_c_gpu.py)
+                const double inv = 1.0 / (s2[v][j] + kp2 * s02[v][j]);
+                a += r2[v][j] * inv;
+                b += r02[v][j] * inv;
+            }
+            for (int i = tid + v * NT + PER * 1024; i < kn; i += 1024) {
+                const double sr0 = K.s_rho0[i], sr = K.s_rho[i];
+                if ((unsigned)K.m_num[i] < match_num_min || sr0 <= 0 || sr > s_rho_min) continue;
+                const double s2t = sr * sr, s02t = sr0 * sr0;   // the same expressions as the register path: the result does not depend on PER
+                const double inv = 1.0 / (s2t + kp2 * s02t);
+                const double rho = K.rho[i], rho0 = K.rho0[i];
+                a += (rho * rho) * inv;
+                b += (rho0 * rho0) * inv;
+            }
+            for (int o = 32; o > 0; o >>= 1) { a += __shfl_xor(a, o, 64); b += __shfl_xor(b, o, 64); }
+            if ((tid & 63) == 0) { s_a[(tid + v * NT) >> 6] = a; s_b[(tid + v * NT) >> 6] = b; }
         }
-        for (int i = tid + PER * 1024; i < kn; i += 1024) {
-            const double sr0 = K.s_rho0[i], sr = K.s_rho[i];
-            if ((unsigned)K.m_num[i] < match_num_min || sr0 <= 0 || sr > s_rho_min) continue;
-            const double inv = 1.0 / (sr * sr + kp2 * sr0 * sr0);
-            const double rho = K.rho[i], rho0 = K.rho0[i];
-            a += rho * rho * inv;
-            b += rho0 * rho0 * inv;
-        }
-        for (int o = 32; o > 0; o >>= 1) { a += __shfl_xor(a, o, 64); b += __shfl_xor(b, o, 64); }
-        if ((tid & 63) == 0) { s_a[tid >> 6] = a; s_b[tid >> 6] = b; }
         __syncthreads();
         if (tid == 0) {
             double ta = 0, tb = 0;
@@ -611,7 +646,7 @@ __global__ __launch_bounds__(1024) void k_rescale(const KlSoA *kls, const int32_
         __syncthreads();
     }
     if (re_escale) {
-        for (int i = tid; i < kn; i += 1024) {
+        for (int i = tid; i < kn; i += NT) {
             K.rho[i] = K.rho[i] / Kp;
             K.s_rho[i] = K.s_rho[i] / Kp;
         }
@@ -628,6 +663,34 @@ __device__ inline void ident_scaled(double *M, double s) {
 }
 __device__ inline bool any_nan3(const double *v) { return isnan(v[0]) || isnan(v[1]) || isnan(v[2]); }
 
+// what follows Minimizer_RV + FordwardMatch + rotate_keylines (rebvo_second_t.cpp:387-397): the tracker's own estimate is kept
+// for the nav record, a NaN estimate switches matching and mapping off for the frame
+__device__ inline void glue_after_tracking(SeqDev *sq) {
+    edgehip_seq_state &p = sq->pub;
+    for (int i = 0; i < 3; i++) { sq->V_track[i] = p.V[i]; sq->W_track[i] = p.W[i]; }
+    for (int i = 0; i < 9; i++) { sq->PV_track[i] = p.P_V[i]; sq->PW_track[i] = p.P_W[i]; }
+    if (any_nan3(p.V) || any_nan3(p.W)) {
+        ident_scaled(p.P_V, 1e50);
+        p.V[0] = p.V[1] = p.V[2] = 0;
+        p.Kp = 1;
+        p.P_Kp = 1e50;
+        p.estimation_ok = 0;
+        sq->skip_match = 1;
+        sq->skip_map = 1;
+    }
+}
+
+// too few matches after directed_matching (rebvo_second_t.cpp:412-422)
+__device__ inline void glue_after_matching(SeqDev *sq) {
+    edgehip_seq_state &p = sq->pub;
+    ident_scaled(p.P_V, 1e50);
+    p.V[0] = p.V[1] = p.V[2] = 0;
+    p.Kp = 1;
+    p.P_Kp = 10;
+    p.estimation_ok = 0;
+    sq->skip_map = 1;
+}
+
 // mode 0: frame begin (:145-168); 1: after Minimizer+FordwardMatch+rotate (:387-397); 2: after
 // directed_matching (:412-422); 3: pose integration + nav record (:550-606)
 __global__ void k_frame_glue(SeqDev *seqs, const double *__restrict__ t_in, edgehip_nav *__restrict__ nav,
@@ -639,40 +702,11 @@ __global__ void k_frame_glue(SeqDev *seqs, const double *__restrict__ t_in, edge
     SeqDev *sq = seqs + seq;
     edgehip_seq_state &p = sq->pub;
     if (mode == 0) {
-        const double t = t_in[seq];
-        double dt = t - p.t_prev;
-        if (dt < 0.001) dt = 1 / fps;
-        p.dt = dt;
-        sq->t_cur = t;
-        ident_scaled(p.P_V, 1e50);
-        ident_scaled(p.P_W, 1e50);
-        ident_scaled(p.R, 1);
-        p.klm_fwd = 0; p.klm_num = 0; p.kf_matchs = 0;
-        p.estimation_ok = 1;
-        sq->skip_match = 0;
-        sq->skip_map = 0;
-        p.minimizer_evals = 0;
+        frame_begin(sq, t_in[seq], fps);
     } else if (mode == 1) {
-        for (int i = 0; i < 3; i++) { sq->V_track[i] = p.V[i]; sq->W_track[i] = p.W[i]; }
-        for (int i = 0; i < 9; i++) { sq->PV_track[i] = p.P_V[i]; sq->PW_track[i] = p.P_W[i]; }
-        if (any_nan3(p.V) || any_nan3(p.W)) {
-            ident_scaled(p.P_V, 1e50);
-            p.V[0] = p.V[1] = p.V[2] = 0;
-            p.Kp = 1;
-            p.P_Kp = 1e50;
-            p.estimation_ok = 0;
-            sq->skip_match = 1;
-            sq->skip_map = 1;
-        }
+        glue_after_tracking(sq);
     } else if (mode == 2) {
-        if (!sq->skip_match && p.klm_num < match_threshold) {
-            ident_scaled(p.P_V, 1e50);
-            p.V[0] = p.V[1] = p.V[2] = 0;
-            p.Kp = 1;
-            p.P_Kp = 10;
-            p.estimation_ok = 0;
-            sq->skip_map = 1;
-        }
+        if (!sq->skip_match && p.klm_num < match_threshold) glue_after_matching(sq);
     } else {
         edgehip_nav &o = nav[seq];
         if (have_pair) {
@@ -793,7 +827,7 @@ __global__ __launch_bounds__(256) void k_depth_reset(const KlSoA *kls, const int
 // host side
 // ---------------------------------------------------------------------------------------------------
 // keys_posted: the minimiser's last evaluation already left the arbitration keys in fwd_key (TvrArgs::fwd_key)
-int forward_match_enqueue(edgehip_ctx *c, int slot_old, int slot_new, bool keys_posted) {
+int forward_match_enqueue(edgehip_ctx *c, int slot_old, int slot_new, bool keys_posted, bool frame_tail) {
     ProfScope ps(c, PROF_C_FORWARD);
     const DevicePlan &pl = c->plan;
     const size_t B = pl.nseq;
@@ -804,7 +838,8 @@ int forward_match_enqueue(edgehip_ctx *c, int slot_old, int slot_new, bool keys_
     dim3 g((pl.cap + 255) / 256, 1, pl.nseq), b(256);
     const int32_t *kno = c->kn_slot + slot_old * B, *knn = c->kn_slot + slot_new * B;
     if (!keys_posted) hipLaunchKernelGGL(k_fwd_key, g, b, 0, c->stream, kldev(c, slot_old), kno, knn, c->fwd_key, pl.cap);
-    hipLaunchKernelGGL(k_fwd_win, g, b, 0, c->stream, kldev(c, slot_old), kno, knn, c->fwd_key, c->fwd_win, pl.cap);
+    hipLaunchKernelGGL(k_fwd_win, g, b, 0, c->stream, kldev(c, slot_old), kno, knn, c->fwd_key, c->fwd_win, pl.cap,
+                       frame_tail ? c->seq : (SeqDev *)nullptr, frame_tail ? c->rot_buf : (double *)nullptr);
     if (c->fwd_fill[slot_new]) hipLaunchKernelGGL(k_fwd_apply<true>, g, b, 0, c->stream, kldev(c, slot_old), kldev(c, slot_new), knn, c->fwd_win, c->seq, pl.cap);
     else hipLaunchKernelGGL(k_fwd_apply<false>, g, b, 0, c->stream, kldev(c, slot_old), kldev(c, slot_new), knn, c->fwd_win, c->seq, pl.cap);
     c->fwd_fill[slot_new] = false;
@@ -824,7 +859,8 @@ int forward_rotate_enqueue(edgehip_ctx *c, int slot_old, int slot_new) {
         ProfScope ps(c, PROF_C_FORWARD);
         if (!c->fwd_cleared) EH_CHECK(hipMemsetAsync(c->fwd_win, 0xFF, sizeof(int32_t) * B * pl.cap, c->stream));
         c->fwd_cleared = false;
-        hipLaunchKernelGGL(k_fwd_win, g, b, 0, c->stream, kldev(c, slot_old), kno, knn, c->fwd_key, c->fwd_win, pl.cap);
+        hipLaunchKernelGGL(k_fwd_win, g, b, 0, c->stream, kldev(c, slot_old), kno, knn, c->fwd_key, c->fwd_win, pl.cap,
+                           (SeqDev *)nullptr, (double *)nullptr);
         hipLaunchKernelGGL(k_rot_from_state, dim3((pl.nseq + 63) / 64), dim3(64), 0, c->stream, c->seq, c->rot_buf, pl.nseq);
         EH_LAUNCH_CHECK();
     }
@@ -835,7 +871,8 @@ int forward_rotate_enqueue(edgehip_ctx *c, int slot_old, int slot_new) {
     return 0;
 }
 
-int rotate_enqueue(edgehip_ctx *c, int slot, const double *R_host) {
+// R_in_buf: rot_buf already holds the rotations (k_fwd_win's frame tail)
+int rotate_enqueue(edgehip_ctx *c, int slot, const double *R_host, bool R_in_buf) {
     c->grec_ok[slot] = false;   // m_m turns, u_m does not (edge_tracker.cpp:42-76): u_m can no longer be recomputed from m_m
     ProfScope ps(c, PROF_C_ROTATE);
     const DevicePlan &pl = c->plan;
@@ -844,7 +881,7 @@ int rotate_enqueue(edgehip_ctx *c, int slot, const double *R_host) {
         EH_CHECK(hipStreamSynchronize(c->stream));  // pinned_out is reused
         memcpy(c->pinned_out, R_host, sizeof(double) * 9 * pl.nseq);
         EH_CHECK(hipMemcpyAsync(Rbuf, c->pinned_out, sizeof(double) * 9 * pl.nseq, hipMemcpyHostToDevice, c->stream));
-    } else {
+    } else if (!R_in_buf) {
         hipLaunchKernelGGL(k_rot_from_state, dim3((pl.nseq + 63) / 64), dim3(64), 0, c->stream, c->seq, Rbuf, pl.nseq);
     }
     hipLaunchKernelGGL(k_rotate, dim3((pl.cap + 255) / 256, 1, pl.nseq), dim3(256), 0, c->stream, kldev(c, slot),
@@ -1009,13 +1046,13 @@ int directed_enqueue(edgehip_ctx *c, int slot_new, int slot_old) {
     return 0;
 }
 
-int regekf_enqueue(edgehip_ctx *c, int slot, int do_reg, int do_ekf) {
+int regekf_enqueue(edgehip_ctx *c, int slot, int do_reg, int do_ekf, bool frame_glue) {
     ProfScope ps(c, PROF_C_REGEKF);
     const DevicePlan &pl = c->plan;
     dim3 g((pl.cap + 255) / 256, 1, pl.nseq), b(256);
     const int32_t *kn = c->kn_slot + (size_t)slot * pl.nseq;
     hipLaunchKernelGGL(k_regularize, g, b, 0, c->stream, kldev(c, slot), kn, c->rs_tmp, c->seq, pl.cap,
-                       c->p.regularize_thresh, do_reg);
+                       c->p.regularize_thresh, do_reg, frame_glue ? c->p.global_match_threshold : -1);
     hipLaunchKernelGGL(k_ekf, g, b, 0, c->stream, kldev(c, slot), kn, c->rs_tmp, c->seq, pl.cap, pl.zfm, c->p.reshape_q_abs,
                        c->p.loc_unc, do_ekf);
     EH_LAUNCH_CHECK();
@@ -1025,8 +1062,12 @@ int regekf_enqueue(edgehip_ctx *c, int slot, int do_reg, int do_ekf) {
 int rescale_enqueue(edgehip_ctx *c, int slot) {
     ProfScope ps(c, PROF_C_RESCALE);
     const DevicePlan &pl = c->plan;
-    hipLaunchKernelGGL(k_rescale, dim3(pl.nseq), dim3(1024), 0, c->stream, kldev(c, slot),
-                       c->kn_slot + (size_t)slot * pl.nseq, c->seq, kRhoMax, 1u, c->p.do_rescaling > 0);
+    if (pl.nseq <= 128)
+        hipLaunchKernelGGL((k_rescale<512, 12>), dim3(pl.nseq), dim3(512), 0, c->stream, kldev(c, slot),
+                           c->kn_slot + (size_t)slot * pl.nseq, c->seq, kRhoMax, 1u, c->p.do_rescaling > 0);
+    else
+        hipLaunchKernelGGL((k_rescale<1024, 6>), dim3(pl.nseq), dim3(1024), 0, c->stream, kldev(c, slot),
+                           c->kn_slot + (size_t)slot * pl.nseq, c->seq, kRhoMax, 1u, c->p.do_rescaling > 0);
     EH_LAUNCH_CHECK();
     return 0;
 }
@@ -1320,7 +1361,8 @@ static int frame_enqueue(edgehip_ctx *c, int sn, int so, int sp, int have_pair, 
     if (sp >= 0) EH_TRY(stage_a_enqueue(c, sp));   // the pair image, after the main one as in rebvo_first_t.cpp:259-290
     EH_CHECK(hipEventRecord(c->ev_a[sn], c->stream_a));
     if (c->stream_a != c->stream) EH_CHECK(hipStreamWaitEvent(c->stream, c->ev_a[sn], 0));
-    {
+    const bool begin_in_quantile = have_pair && !c->imu_enabled;   // k_quantile, the first kernel of stage B, does it per sequence
+    if (!begin_in_quantile) {
         ProfScope ps(c, PROF_C_POSE);
         EH_TRY(glue(c, 0, sn, have_pair));
     }
@@ -1342,13 +1384,12 @@ static int frame_enqueue(edgehip_ctx *c, int sn, int so, int sp, int have_pair, 
             { ProfScope ps(c, PROF_IMU_FILTERS); EH_TRY(imu_mid_enqueue(c)); }                             // :237-272, :387-397
             EH_TRY(rotate_buf_enqueue(c, so));                                                       // :319
             EH_TRY(directed_enqueue(c, sn, so));                                                     // :410
-            { ProfScope ps(c, PROF_C_POSE); EH_TRY(glue(c, 2, sn, have_pair)); }                     // :412-422
-            EH_TRY(regekf_enqueue(c, sn, 1, 1));                                                     // :453, :460
+            EH_TRY(regekf_enqueue(c, sn, 1, 1, true));                                               // :412-422 (in k_regularize), :453, :460
             EH_TRY(rescale_enqueue(c, sn));                                                          // :487
         }
         EH_TRY(imu_post_enqueue(c, sn, have_pair));                                                  // :280-312, :519-606
     } else if (have_pair) {
-        EH_TRY(quantile_enqueue(c, so, kRhoMin, kRhoMax, c->p.qcut_quantile, c->p.qcut_nbins));  // rebvo_second_t.cpp:172
+        EH_TRY(quantile_enqueue(c, so, kRhoMin, kRhoMax, c->p.qcut_quantile, c->p.qcut_nbins, true));  // rebvo_second_t.cpp:145-168, :172
         EH_TRY(build_field_enqueue(c, sn, c->p.search_range, -1.f, c->fwd_mode != 1));            // :177
         c->fwd_key_in_tvr = c->fwd_mode != 1;
         e = minimizer_enqueue(c, sn, so, c->frames_seen % kRefRing);                              // :346
@@ -1357,13 +1398,12 @@ static int frame_enqueue(edgehip_ctx *c, int sn, int so, int sp, int have_pair, 
         if (c->fwd_mode == 2) {
             EH_TRY(forward_rotate_enqueue(c, so, sn));                                           // :354-369
         } else {
-            EH_TRY(forward_match_enqueue(c, so, sn, c->fwd_mode != 1));                          // :354
-            EH_TRY(rotate_enqueue(c, so, nullptr));                                              // :360-369
+            EH_TRY(forward_match_enqueue(c, so, sn, c->fwd_mode != 1, true));                    // :354 (+ exp(W) and :387-397 in k_fwd_win's tail)
+            EH_TRY(rotate_enqueue(c, so, nullptr, true));                                        // :360-369
         }
-        { ProfScope ps(c, PROF_C_POSE); EH_TRY(glue(c, 1, sn, have_pair)); }                     // :387-397
+        if (c->fwd_mode == 2) { ProfScope ps(c, PROF_C_POSE); EH_TRY(glue(c, 1, sn, have_pair)); }   // :387-397
         EH_TRY(directed_enqueue(c, sn, so));                                                     // :410
-        { ProfScope ps(c, PROF_C_POSE); EH_TRY(glue(c, 2, sn, have_pair)); }                     // :412-422
-        EH_TRY(regekf_enqueue(c, sn, 1, 1));                                                     // :453, :460
+        EH_TRY(regekf_enqueue(c, sn, 1, 1, true));                                               // :412-422 (in k_regularize), :453, :460
         if (sp >= 0) {                                                                           // :465-486
             EH_TRY(stereo_enqueue(c, sn, sp, c->rig.t, c->rig.R, c->p.match_thresh_module, c->p.match_thresh_angle, c->rig.max_radius,
                                   c->p.loc_unc_match, c->p.loc_unc, true));
