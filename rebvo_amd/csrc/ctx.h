@@ -386,7 +386,7 @@ __device__ inline void frame_begin(SeqDev *sq, double t, double fps) {
 
 int quantile_enqueue(edgehip_ctx *c, int slot, double smin, double smax, double pct, int nbins, bool frame_begins = false);
 int build_field_enqueue(edgehip_ctx *c, int slot, int radius, float min_mod, bool clear_fwd = false);
-int tvr_prepare_enqueue(edgehip_ctx *c, int slot_old);
+int tvr_prepare_enqueue(edgehip_ctx *c, int slot_old, unsigned begin_ops = 0);   // begin_ops: LM ops of the step that opens a minimisation, run in the same launch
 int minimizer_enqueue(edgehip_ctx *c, int slot_new, int slot_old, int fc_index);
 int minimizer_v_enqueue(edgehip_ctx *c, int slot_new, int slot_old, int fc_index, int iter_max, double match_thresh,
                          uint32_t match_num_thresh, double reweight_distance);
@@ -395,7 +395,7 @@ int forward_rotate_enqueue(edgehip_ctx *c, int slot_old, int slot_new);   // For
 int rotate_enqueue(edgehip_ctx *c, int slot, const double *R_host, bool R_in_buf = false);
 int directed_enqueue(edgehip_ctx *c, int slot_new, int slot_old);
 int regekf_enqueue(edgehip_ctx *c, int slot, int do_reg, int do_ekf, bool frame_glue = false);
-int rescale_enqueue(edgehip_ctx *c, int slot);
+int rescale_enqueue(edgehip_ctx *c, int slot, bool frame_ends = false);
 int pose_enqueue(edgehip_ctx *c, int slot_new, const double *t_host);
 int imu_begin_enqueue(edgehip_ctx *c);                // stage_imu.hip
 int imu_reset_enqueue(edgehip_ctx *c);

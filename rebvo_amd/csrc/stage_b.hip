@@ -1152,6 +1152,8 @@ struct LmArgs {
     int init_type;
     const edgehip_kf_request *kf_in;   // [B] (LM_BEGIN_KF)
     edgehip_kf_result *kf_out;         // [B] (LM_FINISH_KF)
+    const int32_t *kn_src = nullptr;   // [B] or null: KeyLine count of the tracked edge map, when the step runs in the launch that would
+                                       // otherwise have left it in the state (k_tvr_prepare_begin)
 };
 
 template <bool WAVE_ONLY>
@@ -1198,6 +1200,10 @@ __device__ __forceinline__ void lm_body(const LmArgs &a, const int seq, const in
     for (int i = lane; i < kWords; i += 64) s_state[i] = gstate[i];
     lm_sync<WAVE_ONLY>();
     SeqDev *sq = reinterpret_cast<SeqDev *>(s_state);
+    if (a.kn_src) {
+        if (lane == 0) sq->kn_old = a.kn_src[seq];
+        lm_sync<WAVE_ONLY>();
+    }
     const int kn = sq->kn_old;
     if (ops & LM_BEGIN) {
         if (lane == 0) {
@@ -1458,6 +1464,19 @@ __device__ __forceinline__ void lm_body(const LmArgs &a, const int seq, const in
 }
 
 __global__ __launch_bounds__(64) void k_lm_step(LmArgs a) { lm_body<false>(a, blockIdx.x, threadIdx.x); }
+
+// k_tvr_prepare and the step that opens a minimisation (LM_BEGIN: initial X, the transform of the first evaluation — no
+// evaluation precedes it, so it reads nothing the preparation writes) in one launch: the first wave of a sequence's first
+// block runs the step.  One dependent launch fewer per frame pair.
+__global__ __launch_bounds__(256) void k_tvr_prepare_begin(const int32_t *__restrict__ kns, double *__restrict__ resid0,
+                                                           double *__restrict__ carry0, int cap, int nblk, LmArgs l) {
+    const int seq = blockIdx.z;
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    const int kn = kns[seq];
+    if ((i % kTvrBlock) == 0 && i / kTvrBlock < nblk) carry0[(size_t)seq * nblk + i / kTvrBlock] = 0.0;
+    if (i < kn) resid0[(size_t)seq * cap + i] = 0.0;  // "Init residuals", global_tracker.cpp:625
+    if (blockIdx.x == 0 && threadIdx.x < 64) lm_body<true>(l, seq, threadIdx.x);   // l.kn_src = kns: the state's kn_old
+}
 
 // ---------------------------------------------------------------------------------------------------
 // k_try_velrot_lm: an evaluation and the LM step that follows it in ONE launch, for small batches.  A single camera (or
@@ -1809,9 +1828,21 @@ int build_field_enqueue(edgehip_ctx *c, int slot, int radius, float min_mod, boo
     return 0;
 }
 
-int tvr_prepare_enqueue(edgehip_ctx *c, int slot_old) {
+int tvr_prepare_enqueue(edgehip_ctx *c, int slot_old, unsigned begin_ops) {
     ProfScope ps(c, PROF_B_PREP);
     const DevicePlan &pl = c->plan;
+    if (begin_ops) {
+        LmArgs l;
+        l.seq = c->seq; l.partials = c->partials; l.block_last = c->block_last; l.resid_carry = c->resid_carry;
+        l.framecount = c->framecount + (size_t)c->fc_index * pl.nseq;
+        l.nblk = c->nblk_tvr; l.nseq = pl.nseq; l.ops = begin_ops; l.init_type = c->p.tracker_init_type;
+        l.kf_in = c->kf_req_dev; l.kf_out = c->kf_res_dev;
+        l.kn_src = c->kn_slot + (size_t)slot_old * pl.nseq;
+        hipLaunchKernelGGL(k_tvr_prepare_begin, dim3((pl.cap + 255) / 256, 1, pl.nseq), dim3(256), 0, c->stream, l.kn_src, c->resid,
+                           c->resid_carry, pl.cap, c->nblk_tvr, l);
+        EH_LAUNCH_CHECK();
+        return 0;
+    }
     hipLaunchKernelGGL(k_tvr_prepare, dim3((pl.cap + 255) / 256, 1, pl.nseq), dim3(256), 0, c->stream, kldev(c, slot_old),
                        c->kn_slot + (size_t)slot_old * pl.nseq, c->P0, c->resid, c->resid_carry, c->seq, pl.cap,
                        c->nblk_tvr, pl.zfm);
@@ -1929,7 +1960,9 @@ int minimizer_enqueue(edgehip_ctx *c, int slot_new, int slot_old, int fc_index) 
     const edgehip_params &p = c->p;
     c->fc_index = fc_index;
     int e;
-    if ((e = tvr_prepare_enqueue(c, slot_old))) return e;
+    // (the step that opens the minimisation rides on the preparation's launch)
+    const unsigned begin_ops = LM_BEGIN | LM_SETUP_X | (p.tracker_init_type >= 2 ? LM_PHASE_A : LM_PHASE_BC);
+    if ((e = tvr_prepare_enqueue(c, slot_old, begin_ops))) return e;
     if (c->fwd_key_in_tvr && !c->fwd_cleared) EH_CHECK(hipMemsetAsync(c->fwd_key, 0, sizeof(unsigned long long) * (size_t)c->plan.nseq * c->plan.cap, c->stream));
     const int I = p.tracker_init_iter_num, M = p.tracker_iter_num;
     const int total_evals = (p.tracker_init_type >= 2 ? 2 * (1 + (I > 0 ? I : 0)) : 0) + 1 + (M > 0 ? M : 0);
@@ -1975,7 +2008,7 @@ int minimizer_enqueue(edgehip_ctx *c, int slot_new, int slot_old, int fc_index) 
     if (p.tracker_init_type >= 2) {
         for (int trial = 0; trial < 2; trial++) {
             const unsigned phase = trial == 0 ? LM_PHASE_A : LM_PHASE_BC;
-            if (trial == 0) EH_TRY(launch_lm(c, slot_new, LM_BEGIN | LM_SETUP_X | phase));
+            (void)phase;   // trial 0: LM_BEGIN | LM_SETUP_X | LM_PHASE_A went out with tvr_prepare_enqueue
             EH_TRY(eval(false, true));
             unsigned ops = LM_REDUCE_CUR | LM_INIT | (trial == 1 ? LM_RESET_V : 0);
             if (I > 0) ops |= LM_SOLVE_SVD | LM_SETUP_XNEW;
@@ -1991,8 +2024,6 @@ int minimizer_enqueue(edgehip_ctx *c, int slot_new, int slot_old, int fc_index) 
                 EH_TRY(launch_lm(c, slot_new, ops));
             }
         }
-    } else {
-        EH_TRY(launch_lm(c, slot_new, LM_BEGIN | LM_SETUP_X | LM_PHASE_BC));
     }
     // reweighted Levenberg-Marquardt
     EH_TRY(eval(true, true));

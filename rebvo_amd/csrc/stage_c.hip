@@ -573,37 +573,71 @@ __global__ __launch_bounds__(256) void k_ekf(const KlSoA *kls, const int32_t *__
 // ---------------------------------------------------------------------------------------------------
 // EstimateReScalingOpt: 5 dependent weighted sums; one block per sequence
 // ---------------------------------------------------------------------------------------------------
+// 1 / x for a positive normal x: v_rcp_f64 + two Newton steps (relative error of a few 1e-16)
+__device__ __forceinline__ double recip_f64(double x) {
+    double y = __builtin_amdgcn_rcp(x);
+    y = __builtin_fma(__builtin_fma(-x, y, 1.0), y, y);
+    y = __builtin_fma(__builtin_fma(-x, y, 1.0), y, y);
+    return y;
+}
+
+// what the frame's last per-sequence step needs (frame_end below: pose integration + nav record)
+struct FrameEndArgs {
+    edgehip_nav *nav;            // [B] (null: no frame end in this launch)
+    const int32_t *kn_new;
+    const double *tresh_new;
+    const float *retuned_new;
+    edgehip_nav *nav_log;
+    int nav_log_len, nseq, have_pair;
+};
+__device__ inline void frame_end(SeqDev *sq, const int seq, const FrameEndArgs &fe);
+
 // The sums are those of 1024 "virtual" threads (KeyLine i belongs to virtual thread i % 1024, its terms are added in increasing i,
 // the 16 wave sums in wave order), whatever the block: NT = 1024 real threads with PER = 6 KeyLines each in registers over the five
 // passes (whole batches: two blocks per CU, the tail beyond 6144 KeyLines streams every pass), or NT = 512 threads that carry
 // two virtual threads with PER = 12 each (a few sequences: 256 VGPRs per thread hold 12288 KeyLines, so no pass waits for loads).
 // Same additions in the same order, same bits.
+// fe.nav != null (whole-frame driver, mono, ImuMode 0): the block's first thread goes on to the frame's last step, pose integration
+// and the nav record, which reads the Kp it has just written — the frame ends with this launch.
 template <int NT, int PER>
 __global__ __launch_bounds__(NT) void k_rescale(const KlSoA *kls, const int32_t *__restrict__ kns, SeqDev *seqs,
-                                                double s_rho_min, unsigned match_num_min, int re_escale) {
+                                                double s_rho_min, unsigned match_num_min, int re_escale, FrameEndArgs fe) {
     constexpr int VT = 1024 / NT;
     const int seq = blockIdx.x, tid = threadIdx.x;
     SeqDev *sq = seqs + seq;
-    if (sq->skip_map) return;
     const int kn = kns[seq];
-    if (kn <= 0) { if (tid == 0) sq->pub.Kp = 1; return; }
+    bool run = !sq->skip_map;   // block-uniform
+    if (run && kn <= 0) { if (tid == 0) sq->pub.Kp = 1; run = false; }
+    if (run) {
     const KlSoA &K = kls[seq];
     __shared__ double s_a[16], s_b[16];
     __shared__ double s_kp;
     // per-KeyLine constants of the five passes are read once: rho^2, rho0^2, s_rho^2, s_rho0^2
     double r2[VT][PER], r02[VT][PER], s2[VT][PER], s02[VT][PER];
+    // (six KeyLines' five fields in flight together, unconditionally: a load inside a branch cannot be hoisted over the
+    // one before it, and this kernel has nothing but its own loads to wait for when the batch is small)
+    constexpr int LB = 6;
+    static_assert(PER % LB == 0, "whole load batches");
 #pragma unroll
     for (int v = 0; v < VT; v++) {
 #pragma unroll
-        for (int j = 0; j < PER; j++) {
-            const int i = tid + v * NT + j * 1024;
-            r2[v][j] = 0; r02[v][j] = 0; s2[v][j] = 1; s02[v][j] = 0;
-            if (i < kn) {
-                const double sr0 = K.s_rho0[i], sr = K.s_rho[i];
-                if (!((unsigned)K.m_num[i] < match_num_min || sr0 <= 0 || sr > s_rho_min)) {
-                    const double rho = K.rho[i], rho0 = K.rho0[i];
-                    r2[v][j] = rho * rho; r02[v][j] = rho0 * rho0; s2[v][j] = sr * sr; s02[v][j] = sr0 * sr0;
-                }
+        for (int j0 = 0; j0 < PER; j0 += LB) {
+            double l_sr0[LB], l_sr[LB], l_rho[LB], l_rho0[LB];
+            int32_t l_mn[LB];
+#pragma unroll
+            for (int q = 0; q < LB; q++) {
+                const int i = min(tid + v * NT + (j0 + q) * 1024, kn - 1);
+                l_sr0[q] = K.s_rho0[i]; l_sr[q] = K.s_rho[i]; l_mn[q] = K.m_num[i]; l_rho[q] = K.rho[i]; l_rho0[q] = K.rho0[i];
+            }
+#pragma unroll
+            for (int q = 0; q < LB; q++) {
+                const int j = j0 + q;
+                const bool use = tid + v * NT + j * 1024 < kn &&
+                                 !((unsigned)l_mn[q] < match_num_min || l_sr0[q] <= 0 || l_sr[q] > s_rho_min);
+                r2[v][j] = use ? l_rho[q] * l_rho[q] : 0.0;
+                r02[v][j] = use ? l_rho0[q] * l_rho0[q] : 0.0;
+                s2[v][j] = use ? l_sr[q] * l_sr[q] : 1.0;
+                s02[v][j] = use ? l_sr0[q] * l_sr0[q] : 0.0;
             }
         }
     }
@@ -615,9 +649,11 @@ __global__ __launch_bounds__(NT) void k_rescale(const KlSoA *kls, const int32_t 
             double a = 0, b = 0;
 #pragma unroll
             for (int j = 0; j < PER; j++) {
-                // one division for the two quotients (an ulp per term off the reference's rho^2 / den and rho0^2 / den, next to a
-                // summation order that already differs from its sequential one: Kp agrees to 1e-10, tests/test_stage_c_gpu.py)
-                const double inv = 1.0 / (s2[v][j] + kp2 * s02[v][j]);
+                // one reciprocal for the two quotients: the hardware estimate + two Newton steps (an ulp or two per term off the
+                // reference's rho^2 / den and rho0^2 / den, next to a summation order that already differs from its sequential
+                // one: Kp agrees to 1e-10, tests/test_stage_c_gpu.py).  The five passes are all this kernel does with a CU's
+                // fp64 pipe, and the IEEE division is 3x the instructions.
+                const double inv = recip_f64(s2[v][j] + kp2 * s02[v][j]);
                 a += r2[v][j] * inv;
                 b += r02[v][j] * inv;
             }
@@ -625,7 +661,7 @@ __global__ __launch_bounds__(NT) void k_rescale(const KlSoA *kls, const int32_t 
                 const double sr0 = K.s_rho0[i], sr = K.s_rho[i];
                 if ((unsigned)K.m_num[i] < match_num_min || sr0 <= 0 || sr > s_rho_min) continue;
                 const double s2t = sr * sr, s02t = sr0 * sr0;   // the same expressions as the register path: the result does not depend on PER
-                const double inv = 1.0 / (s2t + kp2 * s02t);
+                const double inv = recip_f64(s2t + kp2 * s02t);
                 const double rho = K.rho[i], rho0 = K.rho0[i];
                 a += (rho * rho) * inv;
                 b += (rho0 * rho0) * inv;
@@ -646,12 +682,25 @@ __global__ __launch_bounds__(NT) void k_rescale(const KlSoA *kls, const int32_t 
         __syncthreads();
     }
     if (re_escale) {
-        for (int i = tid; i < kn; i += NT) {
-            K.rho[i] = K.rho[i] / Kp;
-            K.s_rho[i] = K.s_rho[i] / Kp;
+        // loads of a batch before its stores (a load behind a store waits for it)
+        constexpr int SB = 8;
+        for (int i0 = tid; i0 < kn; i0 += SB * NT) {
+            double a_[SB], b_[SB];
+#pragma unroll
+            for (int q = 0; q < SB; q++) {
+                const int i = min(i0 + q * NT, kn - 1);
+                a_[q] = K.rho[i]; b_[q] = K.s_rho[i];
+            }
+#pragma unroll
+            for (int q = 0; q < SB; q++) {
+                const int i = i0 + q * NT;
+                if (i < kn) { K.rho[i] = a_[q] / Kp; K.s_rho[i] = b_[q] / Kp; }
+            }
         }
     }
     if (tid == 0) { sq->pub.Kp = Kp; sq->pub.P_Kp = RKp; }
+    }  // run
+    if (fe.nav && tid == 0) frame_end(sq, seq, fe);
 }
 
 // ---------------------------------------------------------------------------------------------------
@@ -691,6 +740,50 @@ __device__ inline void glue_after_matching(SeqDev *sq) {
     sq->skip_map = 1;
 }
 
+// pose integration + nav record (rebvo_second_t.cpp:550-606); one thread per sequence
+__device__ inline void frame_end(SeqDev *sq, const int seq, const FrameEndArgs &fe) {
+    edgehip_seq_state &p = sq->pub;
+    edgehip_nav *nav = fe.nav;
+    const int32_t *kn_new = fe.kn_new;
+    const double *tresh_new = fe.tresh_new;
+    const float *retuned_new = fe.retuned_new;
+    edgehip_nav *nav_log = fe.nav_log;
+    const int nav_log_len = fe.nav_log_len, nseq = fe.nseq, have_pair = fe.have_pair;
+    edgehip_nav &o = nav[seq];
+    if (have_pair) {
+        // Pose = Pose*R; Pos += -Pose*V*K
+        double P2[9];
+        for (int i = 0; i < 3; i++)
+            for (int j = 0; j < 3; j++) {
+                double d = 0;
+                for (int k = 0; k < 3; k++) d += p.Pose[i * 3 + k] * p.R[k * 3 + j];
+                P2[i * 3 + j] = d;
+            }
+        for (int i = 0; i < 9; i++) p.Pose[i] = P2[i];
+        for (int i = 0; i < 3; i++) {
+            double d = 0;
+            for (int k = 0; k < 3; k++) d += (-p.Pose[i * 3 + k]) * p.V[k];
+            p.Pos[i] += d * p.K;
+        }
+        for (int i = 0; i < 9; i++) p.P_V[i] /= p.dt * p.dt;
+    }
+    o.t = sq->t_cur; o.dt = p.dt;
+    for (int i = 0; i < 3; i++) { o.V[i] = sq->V_track[i]; o.W[i] = sq->W_track[i]; }
+    for (int i = 0; i < 9; i++) { o.P_V[i] = sq->PV_track[i]; o.P_W[i] = sq->PW_track[i]; o.Rot[i] = p.R[i]; o.Pose[i] = p.Pose[i]; }
+    so3_ln(p.R, o.RotLie);
+    so3_ln(p.Pose, o.PoseLie);
+    for (int i = 0; i < 3; i++) { o.Vel[i] = -p.V[i] * p.K / p.dt; o.Pos[i] = p.Pos[i]; }
+    o.Kp = p.Kp; o.RKp = p.P_Kp; o.s_rho_q = p.s_rho_q; o.tresh = tresh_new[seq];
+    o.score = p.score; o.rel_error = p.rel_error; o.rel_error_score = p.rel_error_score;
+    o.retuned_thresh = retuned_new[seq];
+    o.kn = kn_new[seq]; o.klm_fwd = p.klm_fwd; o.klm_num = p.klm_num; o.kf_matchs = p.kf_matchs;
+    o.estimation_ok = have_pair ? p.estimation_ok : 0;
+    o.frame = p.frame; o.minimizer_evals = p.minimizer_evals;
+    if (nav_log_len > 0) nav_log[(size_t)(p.frame % nav_log_len) * nseq + seq] = o;
+    p.t_prev = sq->t_cur;
+    p.frame++;
+}
+
 // mode 0: frame begin (:145-168); 1: after Minimizer+FordwardMatch+rotate (:387-397); 2: after
 // directed_matching (:412-422); 3: pose integration + nav record (:550-606)
 __global__ void k_frame_glue(SeqDev *seqs, const double *__restrict__ t_in, edgehip_nav *__restrict__ nav,
@@ -708,39 +801,10 @@ __global__ void k_frame_glue(SeqDev *seqs, const double *__restrict__ t_in, edge
     } else if (mode == 2) {
         if (!sq->skip_match && p.klm_num < match_threshold) glue_after_matching(sq);
     } else {
-        edgehip_nav &o = nav[seq];
-        if (have_pair) {
-            // Pose = Pose*R; Pos += -Pose*V*K
-            double P2[9];
-            for (int i = 0; i < 3; i++)
-                for (int j = 0; j < 3; j++) {
-                    double d = 0;
-                    for (int k = 0; k < 3; k++) d += p.Pose[i * 3 + k] * p.R[k * 3 + j];
-                    P2[i * 3 + j] = d;
-                }
-            for (int i = 0; i < 9; i++) p.Pose[i] = P2[i];
-            for (int i = 0; i < 3; i++) {
-                double d = 0;
-                for (int k = 0; k < 3; k++) d += (-p.Pose[i * 3 + k]) * p.V[k];
-                p.Pos[i] += d * p.K;
-            }
-            for (int i = 0; i < 9; i++) p.P_V[i] /= p.dt * p.dt;
-        }
-        o.t = sq->t_cur; o.dt = p.dt;
-        for (int i = 0; i < 3; i++) { o.V[i] = sq->V_track[i]; o.W[i] = sq->W_track[i]; }
-        for (int i = 0; i < 9; i++) { o.P_V[i] = sq->PV_track[i]; o.P_W[i] = sq->PW_track[i]; o.Rot[i] = p.R[i]; o.Pose[i] = p.Pose[i]; }
-        so3_ln(p.R, o.RotLie);
-        so3_ln(p.Pose, o.PoseLie);
-        for (int i = 0; i < 3; i++) { o.Vel[i] = -p.V[i] * p.K / p.dt; o.Pos[i] = p.Pos[i]; }
-        o.Kp = p.Kp; o.RKp = p.P_Kp; o.s_rho_q = p.s_rho_q; o.tresh = tresh_new[seq];
-        o.score = p.score; o.rel_error = p.rel_error; o.rel_error_score = p.rel_error_score;
-        o.retuned_thresh = retuned_new[seq];
-        o.kn = kn_new[seq]; o.klm_fwd = p.klm_fwd; o.klm_num = p.klm_num; o.kf_matchs = p.kf_matchs;
-        o.estimation_ok = have_pair ? p.estimation_ok : 0;
-        o.frame = p.frame; o.minimizer_evals = p.minimizer_evals;
-        if (nav_log_len > 0) nav_log[(size_t)(p.frame % nav_log_len) * nseq + seq] = o;
-        p.t_prev = sq->t_cur;
-        p.frame++;
+        FrameEndArgs fe;
+        fe.nav = nav; fe.kn_new = kn_new; fe.tresh_new = tresh_new; fe.retuned_new = retuned_new;
+        fe.nav_log = nav_log; fe.nav_log_len = nav_log_len; fe.nseq = nseq; fe.have_pair = have_pair;
+        frame_end(sq, seq, fe);
     }
 }
 
@@ -1059,15 +1123,23 @@ int regekf_enqueue(edgehip_ctx *c, int slot, int do_reg, int do_ekf, bool frame_
     return 0;
 }
 
-int rescale_enqueue(edgehip_ctx *c, int slot) {
+int rescale_enqueue(edgehip_ctx *c, int slot, bool frame_ends) {
     ProfScope ps(c, PROF_C_RESCALE);
     const DevicePlan &pl = c->plan;
+    FrameEndArgs fe = {};
+    if (frame_ends) {
+        fe.nav = c->nav_dev;
+        fe.kn_new = c->kn_slot + (size_t)slot * pl.nseq;
+        fe.tresh_new = c->tresh_slot + (size_t)slot * pl.nseq;
+        fe.retuned_new = c->retuned_slot + (size_t)slot * pl.nseq;
+        fe.nav_log = c->nav_log; fe.nav_log_len = c->nav_log_len; fe.nseq = pl.nseq; fe.have_pair = 1;
+    }
     if (pl.nseq <= 128)
         hipLaunchKernelGGL((k_rescale<512, 12>), dim3(pl.nseq), dim3(512), 0, c->stream, kldev(c, slot),
-                           c->kn_slot + (size_t)slot * pl.nseq, c->seq, kRhoMax, 1u, c->p.do_rescaling > 0);
+                           c->kn_slot + (size_t)slot * pl.nseq, c->seq, kRhoMax, 1u, c->p.do_rescaling > 0, fe);
     else
         hipLaunchKernelGGL((k_rescale<1024, 6>), dim3(pl.nseq), dim3(1024), 0, c->stream, kldev(c, slot),
-                           c->kn_slot + (size_t)slot * pl.nseq, c->seq, kRhoMax, 1u, c->p.do_rescaling > 0);
+                           c->kn_slot + (size_t)slot * pl.nseq, c->seq, kRhoMax, 1u, c->p.do_rescaling > 0, fe);
     EH_LAUNCH_CHECK();
     return 0;
 }
@@ -1361,6 +1433,7 @@ static int frame_enqueue(edgehip_ctx *c, int sn, int so, int sp, int have_pair, 
     if (sp >= 0) EH_TRY(stage_a_enqueue(c, sp));   // the pair image, after the main one as in rebvo_first_t.cpp:259-290
     EH_CHECK(hipEventRecord(c->ev_a[sn], c->stream_a));
     if (c->stream_a != c->stream) EH_CHECK(hipStreamWaitEvent(c->stream, c->ev_a[sn], 0));
+    bool frame_ended = false;
     const bool begin_in_quantile = have_pair && !c->imu_enabled;   // k_quantile, the first kernel of stage B, does it per sequence
     if (!begin_in_quantile) {
         ProfScope ps(c, PROF_C_POSE);
@@ -1409,10 +1482,11 @@ static int frame_enqueue(edgehip_ctx *c, int sn, int so, int sp, int have_pair, 
                                   c->p.loc_unc_match, c->p.loc_unc, true));
             EH_TRY(fuse_stereo_enqueue(c, sn, true));
         } else {
-            EH_TRY(rescale_enqueue(c, sn));                                                      // :487
+            EH_TRY(rescale_enqueue(c, sn, true));                                                // :487 and, in its tail, :550-606
+            frame_ended = true;
         }
     }
-    if (!c->imu_enabled) {
+    if (!c->imu_enabled && !frame_ended) {
         ProfScope ps(c, PROF_C_POSE);
         EH_TRY(glue(c, 3, sn, have_pair));                                                       // :550-606
     }
