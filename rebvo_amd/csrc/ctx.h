@@ -356,7 +356,7 @@ struct ProfScope {  // RAII bracket; no-op unless profiling is enabled
 };
 
 // stage entry points shared between translation units (all enqueue on c->stream)
-int stage_a_enqueue(edgehip_ctx *c, int slot, bool fwd_fills = false);
+int stage_a_enqueue(edgehip_ctx *c, int slot, bool fwd_fills = false, bool defer_retune = false);   // defer_retune: k_quantile of the same frame finishes reEstimateThresh
 // ordering between the two streams for entry points that are not edgehip_process_frame: everything enqueued so far on
 // one stream is finished before anything enqueued afterwards on the other starts
 int wait_upload(edgehip_ctx *c, int slot, hipStream_t st);   // make `st` wait for a pending stream_up upload into the slot
@@ -384,7 +384,7 @@ __device__ inline void frame_begin(SeqDev *sq, double t, double fps) {
     p.minimizer_evals = 0;
 }
 
-int quantile_enqueue(edgehip_ctx *c, int slot, double smin, double smax, double pct, int nbins, bool frame_begins = false);
+int quantile_enqueue(edgehip_ctx *c, int slot, double smin, double smax, double pct, int nbins, bool frame_begins = false, int retune_slot = -1);
 int build_field_enqueue(edgehip_ctx *c, int slot, int radius, float min_mod, bool clear_fwd = false);
 int tvr_prepare_enqueue(edgehip_ctx *c, int slot_old, unsigned begin_ops = 0);   // begin_ops: LM ops of the step that opens a minimisation, run in the same launch
 int minimizer_enqueue(edgehip_ctx *c, int slot_new, int slot_old, int fc_index);

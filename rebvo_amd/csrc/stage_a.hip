@@ -1263,7 +1263,7 @@ int undistort_frame_enqueue(edgehip_ctx *c, int seq, int slot, uint8_t *out_dev)
 
 static int rowscan_ch(int w) { return 4 * ((w + 255) / 256); }
 
-int stage_a_enqueue(edgehip_ctx *c, int slot, bool fwd_fills) {
+int stage_a_enqueue(edgehip_ctx *c, int slot, bool fwd_fills, bool defer_retune) {
     c->fwd_fill[slot] = false;
     const DevicePlan &pl = c->plan;
     const int w = pl.w, h = pl.h, B = pl.nseq;
@@ -1309,9 +1309,10 @@ int stage_a_enqueue(edgehip_ctx *c, int slot, bool fwd_fills) {
                            fwd_fills ? 1 : 0);
         c->fwd_fill[slot] = fwd_fills;   // FordwardMatch into this slot must run in fill mode
         EH_LAUNCH_CHECK();
-        hipLaunchKernelGGL(k_retune, dim3(B), dim3(256), 0, st, c->seqa, c->histo,
-                           c->retuned_slot + (size_t)slot * B, B, c->p.track_points,
-                           c->p.qcut_nbins);
+        if (!defer_retune)
+            hipLaunchKernelGGL(k_retune, dim3(B), dim3(256), 0, st, c->seqa, c->histo,
+                               c->retuned_slot + (size_t)slot * B, B, c->p.track_points,
+                               c->p.qcut_nbins);
         EH_LAUNCH_CHECK();
         return 0;
     }
@@ -1545,9 +1546,10 @@ int stage_a_enqueue(edgehip_ctx *c, int slot, bool fwd_fills) {
         hipLaunchKernelGGL(k_join_histo<false>, dim3((pl.cap + 255) / 256, 1, B), dim3(256), 0, st, kldev(c, slot),
                            maskof(c, slot), c->seqa, c->histo, w, n, c->p.qcut_nbins);
         EH_LAUNCH_CHECK();
-        hipLaunchKernelGGL(k_retune, dim3(B), dim3(256), 0, st, c->seqa, c->histo,
-                           c->retuned_slot + (size_t)slot * B, B, c->p.track_points,
-                           c->p.qcut_nbins);
+        if (!defer_retune)
+            hipLaunchKernelGGL(k_retune, dim3(B), dim3(256), 0, st, c->seqa, c->histo,
+                               c->retuned_slot + (size_t)slot * B, B, c->p.track_points,
+                               c->p.qcut_nbins);
         EH_LAUNCH_CHECK();
     }
     return 0;

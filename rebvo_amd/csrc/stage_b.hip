@@ -48,12 +48,56 @@ namespace edgehip {
 // integer, so neither the thread count nor the lane-parallel search for the first bin past the quantile changes the result.
 // t_in != null (whole-frame driver): one thread of the block also does SecondThread's frame begin for its sequence (ctx.h::frame_begin;
 // nothing here reads what it writes) — one dependent launch fewer per frame.
+// rt.seqa != null (whole-frame driver, mono): the block's last wave also finishes the detector's reEstimateThresh for the NEW edge map
+// (stage_a.hip::k_retune, whose launch stage A then leaves out): the same integer walk over its histogram, all bins at once.
+struct RetuneArgs {
+    SeqA *seqa;                 // [B] or null
+    const int32_t *histo;       // [B][256] modulus histogram of the new edge map (k_join_histo)
+    float *retuned_out;         // [B]
+    int knum, nbins;
+};
 template <int NT>
 __global__ __launch_bounds__(NT) void k_quantile(const KlSoA *kls, const int32_t *__restrict__ kns, SeqDev *seqs,
-                                                 double smin, double smax, double pct, int nbins, const double *__restrict__ t_in, double fps) {
+                                                 double smin, double smax, double pct, int nbins, const double *__restrict__ t_in, double fps,
+                                                 RetuneArgs rt) {
     __shared__ int s_h[256];
     const int seq = blockIdx.x, tid = threadIdx.x;
     if (t_in && tid == NT - 1) frame_begin(seqs + seq, t_in[seq], fps);
+    if (rt.seqa && tid >= NT - 64) {
+        // k_retune's loop: i = 0, acc = 0; while (i < n && acc < knum) { i++; if (i < n) acc += h[i]; }  ->  the first i >= 1 whose
+        // sum h[1..i] reaches knum, else n (0 when knum <= 0); bin 0 is never counted (edge_finder.cpp:400-403)
+        const int l = tid - (NT - 64);
+        int h4[4], inc4[4], tot = 0;
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+            const int b = l * 4 + j;
+            h4[j] = (b >= 1 && b < rt.nbins) ? rt.histo[(size_t)seq * 256 + b] : 0;
+            tot += h4[j];
+            inc4[j] = tot;
+        }
+        int inc = tot;
+        for (int o = 1; o < 64; o <<= 1) {
+            const int up = __shfl_up(inc, o, 64);
+            if (l >= o) inc += up;
+        }
+        const int base = inc - tot;
+        int first = rt.nbins;
+#pragma unroll
+        for (int j = 3; j >= 0; j--) {
+            const int b = l * 4 + j;
+            if (b >= 1 && b < rt.nbins && base + inc4[j] >= rt.knum) first = b;
+        }
+        for (int o = 32; o > 0; o >>= 1) first = min(first, __shfl_xor(first, o, 64));
+        if (rt.knum <= 0) first = 0;
+        if (l == 0) {
+            SeqA *sa = rt.seqa + seq;
+            const float mxd = sa->nm_max, mnd = sa->nm_min;
+            float r = mxd - (float)first * (mxd - mnd) / (float)rt.nbins;
+            if (sa->kn_new <= 0) r = 0.f;
+            sa->retuned = r;
+            rt.retuned_out[seq] = r;
+        }
+    }
     if (tid < 256) s_h[tid] = 0;
     __syncthreads();
     const int kn = kns[seq];
@@ -1777,15 +1821,20 @@ __global__ void k_tvr_setup_from_host(SeqDev *seqs, const double *__restrict__ X
 // ---------------------------------------------------------------------------------------------------
 // host side
 // ---------------------------------------------------------------------------------------------------
-int quantile_enqueue(edgehip_ctx *c, int slot, double smin, double smax, double pct, int nbins, bool frame_begins) {
+int quantile_enqueue(edgehip_ctx *c, int slot, double smin, double smax, double pct, int nbins, bool frame_begins, int retune_slot) {
+    RetuneArgs rt = {};
+    if (retune_slot >= 0) {
+        rt.seqa = c->seqa; rt.histo = c->histo; rt.retuned_out = c->retuned_slot + (size_t)retune_slot * c->plan.nseq;
+        rt.knum = c->p.track_points; rt.nbins = c->p.qcut_nbins;
+    }
     ProfScope ps(c, PROF_B_QUANTILE);
     if (nbins < 1 || nbins > 256) { set_error("quantile: 1 <= nbins <= 256"); return EDGEHIP_ERR_ARG; }
     if (c->plan.nseq <= 64)
         hipLaunchKernelGGL(k_quantile<1024>, dim3(c->plan.nseq), dim3(1024), 0, c->stream, kldev(c, slot),
-                           c->kn_slot + (size_t)slot * c->plan.nseq, c->seq, smin, smax, pct, nbins, frame_begins ? c->t_src : (const double *)nullptr, c->p.config_fps);
+                           c->kn_slot + (size_t)slot * c->plan.nseq, c->seq, smin, smax, pct, nbins, frame_begins ? c->t_src : (const double *)nullptr, c->p.config_fps, rt);
     else
         hipLaunchKernelGGL(k_quantile<256>, dim3(c->plan.nseq), dim3(256), 0, c->stream, kldev(c, slot),
-                           c->kn_slot + (size_t)slot * c->plan.nseq, c->seq, smin, smax, pct, nbins, frame_begins ? c->t_src : (const double *)nullptr, c->p.config_fps);
+                           c->kn_slot + (size_t)slot * c->plan.nseq, c->seq, smin, smax, pct, nbins, frame_begins ? c->t_src : (const double *)nullptr, c->p.config_fps, rt);
     EH_LAUNCH_CHECK();
     return 0;
 }

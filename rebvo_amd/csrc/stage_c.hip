@@ -1429,12 +1429,15 @@ static int frame_enqueue(edgehip_ctx *c, int sn, int so, int sp, int have_pair, 
     if (sp >= 0 && c->overlap && c->use_valid[sp]) EH_CHECK(hipStreamWaitEvent(c->stream_a, c->ev_use[sp], 0));
     // (with a frame pair FordwardMatch follows below in every branch: the detector may leave the forwarded fields to it;
     // mode 2 keeps its scattering pass, which cannot fill)
-    EH_TRY(stage_a_enqueue(c, sn, have_pair && c->fwd_mode != 2));
-    if (sp >= 0) EH_TRY(stage_a_enqueue(c, sp));   // the pair image, after the main one as in rebvo_first_t.cpp:259-290
-    EH_CHECK(hipEventRecord(c->ev_a[sn], c->stream_a));
-    if (c->stream_a != c->stream) EH_CHECK(hipStreamWaitEvent(c->stream, c->ev_a[sn], 0));
     bool frame_ended = false;
     const bool begin_in_quantile = have_pair && !c->imu_enabled;   // k_quantile, the first kernel of stage B, does it per sequence
+    const bool retune_in_quantile = begin_in_quantile && sp < 0;    // ... and finishes the detector's reEstimateThresh (the pair image's stage A would overwrite its histogram)
+    EH_TRY(stage_a_enqueue(c, sn, have_pair && c->fwd_mode != 2, retune_in_quantile));
+    if (sp >= 0) EH_TRY(stage_a_enqueue(c, sp));   // the pair image, after the main one as in rebvo_first_t.cpp:259-290
+    if (c->stream_a != c->stream) {   // (one stream: already in order, and an event record is a packet the device has to work through)
+        EH_CHECK(hipEventRecord(c->ev_a[sn], c->stream_a));
+        EH_CHECK(hipStreamWaitEvent(c->stream, c->ev_a[sn], 0));
+    }
     if (!begin_in_quantile) {
         ProfScope ps(c, PROF_C_POSE);
         EH_TRY(glue(c, 0, sn, have_pair));
@@ -1462,7 +1465,7 @@ static int frame_enqueue(edgehip_ctx *c, int sn, int so, int sp, int have_pair, 
         }
         EH_TRY(imu_post_enqueue(c, sn, have_pair));                                                  // :280-312, :519-606
     } else if (have_pair) {
-        EH_TRY(quantile_enqueue(c, so, kRhoMin, kRhoMax, c->p.qcut_quantile, c->p.qcut_nbins, true));  // rebvo_second_t.cpp:145-168, :172
+        EH_TRY(quantile_enqueue(c, so, kRhoMin, kRhoMax, c->p.qcut_quantile, c->p.qcut_nbins, true, retune_in_quantile ? sn : -1));  // rebvo_second_t.cpp:145-168, :172
         EH_TRY(build_field_enqueue(c, sn, c->p.search_range, -1.f, c->fwd_mode != 1));            // :177
         c->fwd_key_in_tvr = c->fwd_mode != 1;
         e = minimizer_enqueue(c, sn, so, c->frames_seen % kRefRing);                              // :346
@@ -1491,16 +1494,18 @@ static int frame_enqueue(edgehip_ctx *c, int sn, int so, int sp, int have_pair, 
         EH_TRY(glue(c, 3, sn, have_pair));                                                       // :550-606
     }
 #undef EH_TRY
-    // B/C of this frame were the last readers of both slots
-    EH_CHECK(hipEventRecord(c->ev_use[sn], c->stream));
-    c->use_valid[sn] = true;
-    if (so >= 0) {
-        EH_CHECK(hipEventRecord(c->ev_use[so], c->stream));
-        c->use_valid[so] = true;
-    }
-    if (sp >= 0) {
-        EH_CHECK(hipEventRecord(c->ev_use[sp], c->stream));
-        c->use_valid[sp] = true;
+    // B/C of this frame were the last readers of both slots (only a stage-A stream of its own has to be told)
+    if (c->stream_a != c->stream) {
+        EH_CHECK(hipEventRecord(c->ev_use[sn], c->stream));
+        c->use_valid[sn] = true;
+        if (so >= 0) {
+            EH_CHECK(hipEventRecord(c->ev_use[so], c->stream));
+            c->use_valid[so] = true;
+        }
+        if (sp >= 0) {
+            EH_CHECK(hipEventRecord(c->ev_use[sp], c->stream));
+            c->use_valid[sp] = true;
+        }
     }
     return 0;
 }
