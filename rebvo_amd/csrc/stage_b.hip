@@ -2009,9 +2009,12 @@ int minimizer_enqueue(edgehip_ctx *c, int slot_new, int slot_old, int fc_index) 
     const edgehip_params &p = c->p;
     c->fc_index = fc_index;
     int e;
-    // (the step that opens the minimisation rides on the preparation's launch)
+    // A few sequences: the step that opens the minimisation rides on the preparation's launch (one dependent launch fewer).  Whole
+    // batches: the step's ~230 registers cost the preparation more than the launch saves (measured at 1024 sequences: +90 us against -26).
     const unsigned begin_ops = LM_BEGIN | LM_SETUP_X | (p.tracker_init_type >= 2 ? LM_PHASE_A : LM_PHASE_BC);
-    if ((e = tvr_prepare_enqueue(c, slot_old, begin_ops))) return e;
+    const bool begin_rides = c->plan.nseq <= 64;
+    if ((e = tvr_prepare_enqueue(c, slot_old, begin_rides ? begin_ops : 0u))) return e;
+    if (!begin_rides && (e = edgehip::launch_lm(c, slot_new, begin_ops))) return e;
     if (c->fwd_key_in_tvr && !c->fwd_cleared) EH_CHECK(hipMemsetAsync(c->fwd_key, 0, sizeof(unsigned long long) * (size_t)c->plan.nseq * c->plan.cap, c->stream));
     const int I = p.tracker_init_iter_num, M = p.tracker_iter_num;
     const int total_evals = (p.tracker_init_type >= 2 ? 2 * (1 + (I > 0 ? I : 0)) : 0) + 1 + (M > 0 ? M : 0);
