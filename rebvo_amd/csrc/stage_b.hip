@@ -490,7 +490,7 @@ __global__ __launch_bounds__(256) void k_tvr_prepare(const KlSoA *kls, const int
 // ---------------------------------------------------------------------------------------------------
 // SO3 exponential as TooN::SO3<>::exp + rodrigues_so3_exp (TooN so3.h:203-285)
 // ---------------------------------------------------------------------------------------------------
-__device__ __noinline__ void so3_exp(const double w[3], double R[9]) {
+__device__ __forceinline__ void so3_exp_inl(const double (&w)[3], double (&R)[9]) {
     const double one_6th = 1.0 / 6.0, one_20th = 1.0 / 20.0;
     const double theta_sq = w[0] * w[0] + w[1] * w[1] + w[2] * w[2];
     const double theta = sqrt(theta_sq);
@@ -517,6 +517,13 @@ __device__ __noinline__ void so3_exp(const double w[3], double R[9]) {
     a = A * w[0]; b = B * (w[1] * w[2]);
     R[5] = b - a; R[7] = b + a;
 }
+// (out of line for the callers that are not on anybody's critical path: its arrays then live in scratch memory)
+__device__ __noinline__ void so3_exp(const double w[3], double R[9]) {
+    const double wv[3] = {w[0], w[1], w[2]};
+    double Rr[9];
+    so3_exp_inl(wv, Rr);
+    for (int i = 0; i < 9; i++) R[i] = Rr[i];
+}
 
 // Per-evaluation constants of TryVelRot (global_tracker.cpp:309-341): R0 = exp(W), RM = 2x2 block of
 // exp((0,0,W_z)), Vt = V.
@@ -528,6 +535,24 @@ __device__ __noinline__ void tvr_setup(SeqDev *sq, const double *X) {
     for (int i = 0; i < 9; i++) sq->Rt[i] = R0[i];  // row-major R0(i,j)
     sq->RM[0] = Rz[0]; sq->RM[1] = Rz[1]; sq->RM[2] = Rz[3]; sq->RM[3] = Rz[4];
     for (int i = 0; i < 3; i++) sq->Vt[i] = X[i];
+}
+
+
+// The same on two lanes of a wave: lane 0 takes exp(W) (and Vt), lane 1 exp((0,0,W_z)) — the two exponentials are the longest
+// stretch of the LM step (sin and cos in double precision, 3.6 of its 9 us for a single camera), and they do not depend on
+// each other.  X in LDS / global, visible to both lanes.
+__device__ __forceinline__ void tvr_setup2(SeqDev *sq, const double *X, const int lane) {
+    if (lane < 2) {
+        const double wv[3] = {lane == 0 ? X[3] : 0.0, lane == 0 ? X[4] : 0.0, X[5]};
+        double R[9];
+        so3_exp_inl(wv, R);   // inlined: R stays in registers (through a call it is scratch memory, a round trip each way)
+        if (lane == 0) {
+            for (int i = 0; i < 9; i++) sq->Rt[i] = R[i];
+            for (int i = 0; i < 3; i++) sq->Vt[i] = X[i];
+        } else {
+            sq->RM[0] = R[0]; sq->RM[1] = R[1]; sq->RM[2] = R[3]; sq->RM[3] = R[4];
+        }
+    }
 }
 
 
@@ -1455,8 +1480,7 @@ __device__ __forceinline__ void lm_body(const LmArgs &a, const int seq, const in
     }
     if (ops & LM_PHASE_A) sq->lm_phase = 0;
     if (ops & LM_PHASE_BC) sq->lm_phase = 1;
-    if (ops & LM_SETUP_X) tvr_setup(sq, X);
-    if (ops & LM_SETUP_XNEW) tvr_setup(sq, Xn);
+    // (the transform of the next evaluation is set up behind this block, on two lanes: tvr_setup2)
     if (ops & LM_FINISH) {
         double L[36], Inv[36];
         chol6_r(JtJ, L);
@@ -1504,6 +1528,10 @@ __device__ __forceinline__ void lm_body(const LmArgs &a, const int seq, const in
     sq->eff_steps = eff_steps; sq->res_cur = res_cur; sq->res_new = res_new; sq->res_t = res_t;
     }  // lane 0
     lm_sync<WAVE_ONLY>();
+    if (ops & (LM_SETUP_X | LM_SETUP_XNEW)) {
+        tvr_setup2(sq, (ops & LM_SETUP_XNEW) ? sq->Xnew : sq->X, lane);
+        lm_sync<WAVE_ONLY>();
+    }
     for (int i = lane; i < kWords; i += 64) gstate[i] = s_state[i];
 }
 
