@@ -174,6 +174,7 @@ struct edgehip_ctx {
     bool use_valid[4];
     int overlap;           // 1: stage A of frame k+1 may run under stages B/C of frame k (EDGEHIP_OVERLAP=1); 0: one after the other
     bool lds_optin_level = false, lds_optin_detect = false, lds_optin_fused = false;   // > 64 KB dynamic LDS opted in for this context's device
+    bool lds_optin_rescale = false;   // k_rescale<512, 12, 4>: 128 KB of dynamic LDS
     int frame_slot;        // ring position of the newest slot (-1 before the first frame)
     int frames_seen;
     // device buffers

@@ -599,10 +599,14 @@ __device__ inline void frame_end(SeqDev *sq, const int seq, const FrameEndArgs &
 // Same additions in the same order, same bits.
 // fe.nav != null (whole-frame driver, mono, ImuMode 0): the block's first thread goes on to the frame's last step, pose integration
 // and the nav record, which reads the Kp it has just written — the frame ends with this launch.
-template <int NT, int PER>
+// LJ: the next LJ KeyLines of every virtual thread (KeyLines PER*1024 ... (PER+LJ)*1024-1) keep their four constants in LDS
+// (dynamic, LJ * 32 KB) instead of streaming from memory in each of the five passes: with one block per CU and nothing else in
+// flight (a few sequences) every streamed pass is a memory round trip per KeyLine of the tail.
+template <int NT, int PER, int LJ>
 __global__ __launch_bounds__(NT) void k_rescale(const KlSoA *kls, const int32_t *__restrict__ kns, SeqDev *seqs,
                                                 double s_rho_min, unsigned match_num_min, int re_escale, FrameEndArgs fe) {
     constexpr int VT = 1024 / NT;
+    extern __shared__ double s_tail[];   // [4][LJ][1024]: r2, r02, s2, s02
     const int seq = blockIdx.x, tid = threadIdx.x;
     SeqDev *sq = seqs + seq;
     const int kn = kns[seq];
@@ -641,6 +645,31 @@ __global__ __launch_bounds__(NT) void k_rescale(const KlSoA *kls, const int32_t 
             }
         }
     }
+    // the tail's constants into LDS (defaults for KeyLines that do not count, as in the registers)
+    const int njt = LJ ? min(LJ, max(0, (kn - PER * 1024 + 1023) / 1024)) : 0;   // block-uniform
+    if (LJ) {
+#pragma unroll
+        for (int v = 0; v < VT; v++) {
+            double l_sr0[LJ ? LJ : 1], l_sr[LJ ? LJ : 1], l_rho[LJ ? LJ : 1], l_rho0[LJ ? LJ : 1];
+            int32_t l_mn[LJ ? LJ : 1];
+#pragma unroll
+            for (int q = 0; q < LJ; q++) {
+                const int i = min(tid + v * NT + (PER + q) * 1024, kn - 1);
+                l_sr0[q] = K.s_rho0[i]; l_sr[q] = K.s_rho[i]; l_mn[q] = K.m_num[i]; l_rho[q] = K.rho[i]; l_rho0[q] = K.rho0[i];
+            }
+#pragma unroll
+            for (int q = 0; q < LJ; q++) {
+                const bool use = tid + v * NT + (PER + q) * 1024 < kn &&
+                                 !((unsigned)l_mn[q] < match_num_min || l_sr0[q] <= 0 || l_sr[q] > s_rho_min);
+                const int at = q * 1024 + tid + v * NT;
+                s_tail[at] = use ? l_rho[q] * l_rho[q] : 0.0;
+                s_tail[LJ * 1024 + at] = use ? l_rho0[q] * l_rho0[q] : 0.0;
+                s_tail[2 * LJ * 1024 + at] = use ? l_sr[q] * l_sr[q] : 1.0;
+                s_tail[3 * LJ * 1024 + at] = use ? l_sr0[q] * l_sr0[q] : 0.0;
+            }
+        }
+        // (each thread reads back only what it wrote: no barrier needed)
+    }
     double Kp = 1, RKp = sq->pub.P_Kp;
     for (int iter = 0; iter < 5; iter++) {
         const double kp2 = Kp * Kp;
@@ -657,7 +686,13 @@ __global__ __launch_bounds__(NT) void k_rescale(const KlSoA *kls, const int32_t 
                 a += r2[v][j] * inv;
                 b += r02[v][j] * inv;
             }
-            for (int i = tid + v * NT + PER * 1024; i < kn; i += 1024) {
+            for (int q = 0; q < njt; q++) {
+                const int at = q * 1024 + tid + v * NT;
+                const double inv = recip_f64(s_tail[2 * LJ * 1024 + at] + kp2 * s_tail[3 * LJ * 1024 + at]);
+                a += s_tail[at] * inv;
+                b += s_tail[LJ * 1024 + at] * inv;
+            }
+            for (int i = tid + v * NT + (PER + LJ) * 1024; i < kn; i += 1024) {
                 const double sr0 = K.s_rho0[i], sr = K.s_rho[i];
                 if ((unsigned)K.m_num[i] < match_num_min || sr0 <= 0 || sr > s_rho_min) continue;
                 const double s2t = sr * sr, s02t = sr0 * sr0;   // the same expressions as the register path: the result does not depend on PER
@@ -743,45 +778,99 @@ __device__ inline void glue_after_matching(SeqDev *sq) {
 // pose integration + nav record (rebvo_second_t.cpp:550-606); one thread per sequence
 __device__ inline void frame_end(SeqDev *sq, const int seq, const FrameEndArgs &fe) {
     edgehip_seq_state &p = sq->pub;
-    edgehip_nav *nav = fe.nav;
-    const int32_t *kn_new = fe.kn_new;
-    const double *tresh_new = fe.tresh_new;
-    const float *retuned_new = fe.retuned_new;
-    edgehip_nav *nav_log = fe.nav_log;
-    const int nav_log_len = fe.nav_log_len, nseq = fe.nseq, have_pair = fe.have_pair;
-    edgehip_nav &o = nav[seq];
-    if (have_pair) {
-        // Pose = Pose*R; Pos += -Pose*V*K
-        double P2[9];
-        for (int i = 0; i < 3; i++)
-            for (int j = 0; j < 3; j++) {
+    const int have_pair = fe.have_pair;
+    edgehip_nav &o = fe.nav[seq];
+    // Two phases, each of them loads first, arithmetic in registers, stores last: one thread, nothing to hide a memory round
+    // trip behind, and a load issued behind a store waits for it (the field-by-field version paid eight round trips).  Two
+    // phases rather than one so that the live values fit the 128 registers of a 1024-thread block.
+    {   // ---- pose integration: Pose = Pose*R; Pos += -Pose*V*K; P_V /= dt^2 ----
+        double Pose[9], R[9], V[3], Pos[3], P_V[9];
+#pragma unroll
+        for (int i = 0; i < 9; i++) { Pose[i] = p.Pose[i]; R[i] = p.R[i]; P_V[i] = p.P_V[i]; }
+#pragma unroll
+        for (int i = 0; i < 3; i++) { V[i] = p.V[i]; Pos[i] = p.Pos[i]; }
+        const double K = p.K, dt = p.dt;
+        if (have_pair) {
+            double P2[9];
+#pragma unroll
+            for (int i = 0; i < 3; i++)
+#pragma unroll
+                for (int j = 0; j < 3; j++) {
+                    double d = 0;
+#pragma unroll
+                    for (int k = 0; k < 3; k++) d += Pose[i * 3 + k] * R[k * 3 + j];
+                    P2[i * 3 + j] = d;
+                }
+#pragma unroll
+            for (int i = 0; i < 9; i++) Pose[i] = P2[i];
+#pragma unroll
+            for (int i = 0; i < 3; i++) {
                 double d = 0;
-                for (int k = 0; k < 3; k++) d += p.Pose[i * 3 + k] * p.R[k * 3 + j];
-                P2[i * 3 + j] = d;
+#pragma unroll
+                for (int k = 0; k < 3; k++) d += (-Pose[i * 3 + k]) * V[k];
+                Pos[i] += d * K;
             }
-        for (int i = 0; i < 9; i++) p.Pose[i] = P2[i];
-        for (int i = 0; i < 3; i++) {
-            double d = 0;
-            for (int k = 0; k < 3; k++) d += (-p.Pose[i * 3 + k]) * p.V[k];
-            p.Pos[i] += d * p.K;
+#pragma unroll
+            for (int i = 0; i < 9; i++) P_V[i] /= dt * dt;
         }
-        for (int i = 0; i < 9; i++) p.P_V[i] /= p.dt * p.dt;
+        double RotLie[3], PoseLie[3];
+        so3_ln(R, RotLie);
+        so3_ln(Pose, PoseLie);
+        if (have_pair) {
+#pragma unroll
+            for (int i = 0; i < 9; i++) { p.Pose[i] = Pose[i]; p.P_V[i] = P_V[i]; }
+#pragma unroll
+            for (int i = 0; i < 3; i++) p.Pos[i] = Pos[i];
+        }
+#pragma unroll
+        for (int i = 0; i < 9; i++) { o.Rot[i] = R[i]; o.Pose[i] = Pose[i]; }
+#pragma unroll
+        for (int i = 0; i < 3; i++) { o.RotLie[i] = RotLie[i]; o.PoseLie[i] = PoseLie[i]; o.Vel[i] = -V[i] * K / dt; o.Pos[i] = Pos[i]; }
+        o.dt = dt;
     }
-    o.t = sq->t_cur; o.dt = p.dt;
-    for (int i = 0; i < 3; i++) { o.V[i] = sq->V_track[i]; o.W[i] = sq->W_track[i]; }
-    for (int i = 0; i < 9; i++) { o.P_V[i] = sq->PV_track[i]; o.P_W[i] = sq->PW_track[i]; o.Rot[i] = p.R[i]; o.Pose[i] = p.Pose[i]; }
-    so3_ln(p.R, o.RotLie);
-    so3_ln(p.Pose, o.PoseLie);
-    for (int i = 0; i < 3; i++) { o.Vel[i] = -p.V[i] * p.K / p.dt; o.Pos[i] = p.Pos[i]; }
-    o.Kp = p.Kp; o.RKp = p.P_Kp; o.s_rho_q = p.s_rho_q; o.tresh = tresh_new[seq];
-    o.score = p.score; o.rel_error = p.rel_error; o.rel_error_score = p.rel_error_score;
-    o.retuned_thresh = retuned_new[seq];
-    o.kn = kn_new[seq]; o.klm_fwd = p.klm_fwd; o.klm_num = p.klm_num; o.kf_matchs = p.kf_matchs;
-    o.estimation_ok = have_pair ? p.estimation_ok : 0;
-    o.frame = p.frame; o.minimizer_evals = p.minimizer_evals;
-    if (nav_log_len > 0) nav_log[(size_t)(p.frame % nav_log_len) * nseq + seq] = o;
-    p.t_prev = sq->t_cur;
-    p.frame++;
+    int frame;
+    {   // ---- the rest of the nav record ----
+        double PVt[9], PWt[9], Vt[3], Wt[3];
+#pragma unroll
+        for (int i = 0; i < 9; i++) { PVt[i] = sq->PV_track[i]; PWt[i] = sq->PW_track[i]; }
+#pragma unroll
+        for (int i = 0; i < 3; i++) { Vt[i] = sq->V_track[i]; Wt[i] = sq->W_track[i]; }
+        const double t_cur = sq->t_cur;
+        const double Kp = p.Kp, P_Kp = p.P_Kp, s_rho_q = p.s_rho_q, score = p.score, rel_error = p.rel_error, rel_error_score = p.rel_error_score;
+        const int klm_fwd = p.klm_fwd, klm_num = p.klm_num, kf_matchs = p.kf_matchs, est_ok = p.estimation_ok, evals = p.minimizer_evals;
+        frame = p.frame;
+        const double tresh = fe.tresh_new[seq];
+        const float retuned = fe.retuned_new[seq];
+        const int kn = fe.kn_new[seq];
+        o.t = t_cur;
+#pragma unroll
+        for (int i = 0; i < 3; i++) { o.V[i] = Vt[i]; o.W[i] = Wt[i]; }
+#pragma unroll
+        for (int i = 0; i < 9; i++) { o.P_V[i] = PVt[i]; o.P_W[i] = PWt[i]; }
+        o.Kp = Kp; o.RKp = P_Kp; o.s_rho_q = s_rho_q; o.tresh = tresh;
+        o.score = score; o.rel_error = rel_error; o.rel_error_score = rel_error_score;
+        o.retuned_thresh = retuned;
+        o.kn = kn; o.klm_fwd = klm_fwd; o.klm_num = klm_num; o.kf_matchs = kf_matchs;
+        o.estimation_ok = have_pair ? est_ok : 0;
+        o.frame = frame; o.minimizer_evals = evals;
+        p.t_prev = t_cur;
+        p.frame = frame + 1;
+    }
+    if (fe.nav_log_len > 0) {   // the log's copy of the record, word by word
+        static_assert(sizeof(edgehip_nav) % 8 == 0, "copied as 64-bit words");
+        const unsigned long long *src = reinterpret_cast<const unsigned long long *>(&o);
+        unsigned long long *dst = reinterpret_cast<unsigned long long *>(fe.nav_log + (size_t)(frame % fe.nav_log_len) * fe.nseq + seq);
+        constexpr int W8 = sizeof(edgehip_nav) / 8, CH = 17;
+#pragma unroll 1
+        for (int c0 = 0; c0 < W8; c0 += CH) {
+            unsigned long long wbuf[CH];
+#pragma unroll
+            for (int i = 0; i < CH; i++) wbuf[i] = src[min(c0 + i, W8 - 1)];
+#pragma unroll
+            for (int i = 0; i < CH; i++)
+                if (c0 + i < W8) dst[c0 + i] = wbuf[i];
+        }
+    }
 }
 
 // mode 0: frame begin (:145-168); 1: after Minimizer+FordwardMatch+rotate (:387-397); 2: after
@@ -1134,11 +1223,15 @@ int rescale_enqueue(edgehip_ctx *c, int slot, bool frame_ends) {
         fe.retuned_new = c->retuned_slot + (size_t)slot * pl.nseq;
         fe.nav_log = c->nav_log; fe.nav_log_len = c->nav_log_len; fe.nseq = pl.nseq; fe.have_pair = 1;
     }
+    if (pl.nseq <= 128 && !c->lds_optin_rescale) {   // 128 KB of dynamic LDS: opt in once per context (= per device)
+        EH_CHECK(hipFuncSetAttribute((const void *)&k_rescale<512, 12, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, 4 * 4 * 1024 * (int)sizeof(double)));
+        c->lds_optin_rescale = true;
+    }
     if (pl.nseq <= 128)
-        hipLaunchKernelGGL((k_rescale<512, 12>), dim3(pl.nseq), dim3(512), 0, c->stream, kldev(c, slot),
+        hipLaunchKernelGGL((k_rescale<512, 12, 4>), dim3(pl.nseq), dim3(512), 4 * 4 * 1024 * sizeof(double), c->stream, kldev(c, slot),
                            c->kn_slot + (size_t)slot * pl.nseq, c->seq, kRhoMax, 1u, c->p.do_rescaling > 0, fe);
     else
-        hipLaunchKernelGGL((k_rescale<1024, 6>), dim3(pl.nseq), dim3(1024), 0, c->stream, kldev(c, slot),
+        hipLaunchKernelGGL((k_rescale<1024, 6, 0>), dim3(pl.nseq), dim3(1024), 0, c->stream, kldev(c, slot),
                            c->kn_slot + (size_t)slot * pl.nseq, c->seq, kRhoMax, 1u, c->p.do_rescaling > 0, fe);
     EH_LAUNCH_CHECK();
     return 0;
