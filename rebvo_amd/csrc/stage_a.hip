@@ -45,19 +45,28 @@ namespace edgehip {
 // ---------------------------------------------------------------------------------------------------
 // image_undistort::biInterp for RGB24 (include/VideoLib/image_undistort.h:66-79): integer 16.16 weights, >>16,
 // truncation to 8 bits.  Taps sit at base, base+1, base+w, base+w+1; an invalid tap has weight 0.
-__device__ __forceinline__ uchar3 undist_rgb(const uint8_t *__restrict__ frame, int32_t base, uint4 iw, int w) {
-    int r = 0, g = 0, b = 0;
-    const uint32_t wt[4] = {iw.x, iw.y, iw.z, iw.w};
-    const int off[4] = {0, 1, w, w + 1};
-#pragma unroll
-    for (int i = 0; i < 4; i++) {
-        if (wt[i] == 0) continue;
-        const uint8_t *q = frame + (size_t)(base + off[i]) * 3;
-        r += (int)wt[i] * (int)q[0];
-        g += (int)wt[i] * (int)q[1];
-        b += (int)wt[i] * (int)q[2];
-    }
+// The two pixels of a tap row are six consecutive bytes: one unaligned 8-byte load per row (gfx9 global loads take any byte
+// address) instead of six byte loads behind a branch on the weight.  Unconditional: a tap with weight 0 may lie outside the frame,
+// so the load is kept inside the frame's 3n bytes and its bytes are shifted to where the taps expect them (the bytes that
+// fall off belong to pixels outside the frame, whose weight is 0); the products are exact integers either way.
+__device__ __forceinline__ uint64_t undist_row6(const uint8_t *__restrict__ frame, int pi, int n) {
+    pi = pi < -2 ? -2 : (pi > n ? n : pi);              // further out both pixels are outside
+    const int want = pi * 3, last = n * 3 - 8;
+    const int at = want < 0 ? 0 : (want < last ? want : last);
+    uint64_t v;
+    __builtin_memcpy(&v, frame + at, 8);
+    const int d = want - at;                            // -6 ... 8 bytes: the load was moved to stay inside the frame
+    return d >= 0 ? (d < 8 ? v >> (8 * d) : 0) : v << (8 * -d);   // e.g. pi = -1: pixel 0 is the row's SECOND tap
+}
+__device__ __forceinline__ uchar3 undist_mix(const uint64_t t, const uint64_t u, const uint4 iw) {
+    const int w0 = (int)iw.x, w1 = (int)iw.y, w2 = (int)iw.z, w3 = (int)iw.w;
+    const int r = w0 * (int)(t & 0xFF) + w1 * (int)((t >> 24) & 0xFF) + w2 * (int)(u & 0xFF) + w3 * (int)((u >> 24) & 0xFF);
+    const int g = w0 * (int)((t >> 8) & 0xFF) + w1 * (int)((t >> 32) & 0xFF) + w2 * (int)((u >> 8) & 0xFF) + w3 * (int)((u >> 32) & 0xFF);
+    const int b = w0 * (int)((t >> 16) & 0xFF) + w1 * (int)((t >> 40) & 0xFF) + w2 * (int)((u >> 16) & 0xFF) + w3 * (int)((u >> 40) & 0xFF);
     return make_uchar3((unsigned char)(r >> 16), (unsigned char)(g >> 16), (unsigned char)(b >> 16));
+}
+__device__ __forceinline__ uchar3 undist_rgb(const uint8_t *__restrict__ frame, int32_t base, uint4 iw, int w, int n) {
+    return undist_mix(undist_row6(frame, base, n), undist_row6(frame, base + w, n), iw);
 }
 
 template <int CH, bool UNDIST>
@@ -80,7 +89,7 @@ __global__ __launch_bounds__(256) void k_rgb_rowscan(const uint8_t *__restrict__
             unsigned char *sbw = reinterpret_cast<unsigned char *>(stage);
             for (int x = lane; x < w; x += 64) {
                 const size_t pix = (size_t)y * w + x;
-                const uchar3 c = undist_rgb(frame, und_base[pix], und_iw[pix], w);
+                const uchar3 c = undist_rgb(frame, und_base[pix], und_iw[pix], w, (int)n);
                 sbw[x * 3] = c.x; sbw[x * 3 + 1] = c.y; sbw[x * 3 + 2] = c.z;
             }
         } else {
@@ -546,7 +555,7 @@ __global__ __launch_bounds__(LV_NT) void k_level(LevelJob job, const uint8_t *__
                     float v = 0.f;
                     if (y < h) {
                         const size_t pix = (size_t)y * w + x;
-                        const uchar3 c = undist_rgb(frame, und_base[pix], und_iw[pix], w);
+                        const uchar3 c = undist_rgb(frame, und_base[pix], und_iw[pix], w, (int)n);
                         v = (float)((int)c.x + (int)c.y + (int)c.z);
                     }
                     T[r * WP + x] = v;
@@ -1210,22 +1219,38 @@ __global__ __launch_bounds__(256) void k_retune(SeqA *seqs, const int32_t *__res
 // resampled pixel as a 16-bit plane — the input of the fused stage-A kernel when UseUndistort is set (the four bilinear taps
 // are data-dependent gathers, which that kernel's thread <-> column-pair layout cannot prefetch; here they are plain loads
 // of a streaming kernel: 36 N map bytes + the frame in, 2 N out).
+// SG sequences per thread: the map entry of a pixel (20 bytes, the same for every sequence of the batch) is read once for all of
+// them — one sequence per thread had the kernel bound by 20 B of map per 6-byte pixel out of L2.  All 2 * SG tap loads in flight.
+template <int SG>
 __global__ __launch_bounds__(256) void k_undistort_grey(const uint8_t *__restrict__ rgb, const int32_t *__restrict__ fidx,
                                                         uint16_t *__restrict__ out, int w, int n, const int32_t *__restrict__ und_base,
-                                                        const uint4 *__restrict__ und_iw) {
-    const int seq = blockIdx.z;
-    const uint8_t *frame = rgb + (size_t)(fidx ? fidx[seq] : seq) * (size_t)n * 3;
+                                                        const uint4 *__restrict__ und_iw, int nseq) {
+    const int seq0 = blockIdx.z * SG;
     const int pix = blockIdx.x * 256 + threadIdx.x;
     if (pix >= n) return;
-    const uchar3 c = undist_rgb(frame, und_base[pix], und_iw[pix], w);
-    out[(size_t)seq * n + pix] = (uint16_t)((int)c.x + (int)c.y + (int)c.z);
+    const int32_t base = und_base[pix];
+    const uint4 iw = und_iw[pix];
+    uint64_t t[SG], u[SG];
+#pragma unroll
+    for (int s = 0; s < SG; s++) {
+        const int seq = min(seq0 + s, nseq - 1);
+        const uint8_t *frame = rgb + (size_t)(fidx ? fidx[seq] : seq) * (size_t)n * 3;
+        t[s] = undist_row6(frame, base, n);
+        u[s] = undist_row6(frame, base + w, n);
+    }
+#pragma unroll
+    for (int s = 0; s < SG; s++) {
+        if (seq0 + s >= nseq) break;
+        const uchar3 c = undist_mix(t[s], u[s], iw);
+        out[(size_t)(seq0 + s) * n + pix] = (uint16_t)((int)c.x + (int)c.y + (int)c.z);
+    }
 }
 
 __global__ void k_undistort_frame(const uint8_t *__restrict__ frame, uint8_t *__restrict__ out, int w, int n,
                                   const int32_t *__restrict__ und_base, const uint4 *__restrict__ und_iw) {
     const int pix = blockIdx.x * blockDim.x + threadIdx.x;
     if (pix >= n) return;
-    const uchar3 c = undist_rgb(frame, und_base[pix], und_iw[pix], w);
+    const uchar3 c = undist_rgb(frame, und_base[pix], und_iw[pix], w, (int)n);
     out[(size_t)pix * 3] = c.x; out[(size_t)pix * 3 + 1] = c.y; out[(size_t)pix * 3 + 2] = c.z;
 }
 
@@ -1297,8 +1322,8 @@ int stage_a_enqueue(edgehip_ctx *c, int slot, bool fwd_fills, bool defer_retune)
         if (c->und_base) {   // UseUndistort: resample + grey first (the integral-image scratch is free on this path)
             ProfScope ps(c, PROF_A_ROWSCAN, st);
             uint16_t *g16 = reinterpret_cast<uint16_t *>(c->ii);
-            hipLaunchKernelGGL(k_undistort_grey, dim3((unsigned)((n + 255) / 256), 1, B), dim3(256), 0, st, rgb_base, rgb_idx, g16, w,
-                               (int)n, c->und_base, c->und_iw);
+            hipLaunchKernelGGL(k_undistort_grey<8>, dim3((unsigned)((n + 255) / 256), 1, (B + 7) / 8), dim3(256), 0, st, rgb_base, rgb_idx, g16, w,
+                               (int)n, c->und_base, c->und_iw, B);
             EH_LAUNCH_CHECK();
             grey16 = g16;
         }
