@@ -19,6 +19,10 @@ void *rebvo_scale_estimator_new(void);
 void rebvo_scale_estimator_free(void *se);
 void rebvo_est_acel_lsq4(void *se, const double *vel, double *acel /* in/out */, const double *R, double dt);
 void rebvo_mean_acel4(void *se, const double *s_acel, double *acel, const double *R);
+/* test hook: problem_KaGMEKBias as the reference writes it (dense) and as the filters run it (structural zeros left out) */
+void rebvo_problem_ka_gmek_bias(const double *x /*[7]*/, const double *a_v, const double *a_s, double G, const double *x_p /*[7]*/,
+                                const double *Rv, const double *Rs, double Rg, const double *Pp /*[49]*/, double *JtJ_dense /*[49]*/,
+                                double *JtF_dense /*[7]*/, double *JtJ_sparse, double *JtF_sparse);
 double rebvo_est_ka_gmek_bias(const double *s_acel, const double *f_acel, double kP, const double *Rot, double *X /*[7] io*/,
                               double *P /*[49] io*/, const double *Qg, const double *Qrot, const double *Qbias, double QKp,
                               double Rg, const double *Rs, const double *Rf, double *g_est, double *b_est, const double *Wvw,

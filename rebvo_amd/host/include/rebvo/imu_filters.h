@@ -118,11 +118,14 @@ struct KaGMEKBiasParams {   // FunParams_KaGMEKBias (scaleestimator.cpp:115-124)
     Mat<3, 3> Rv, Rs;
     double Rg;
     Mat<7, 7> Pp;
+    Mat<7, 7> W7;   // Cholesky<7>(Pp).get_inverse(): the same for all 21 evaluations of a frame, computed once (problem_KaGMEKBias)
 };
 
 // Problem_KaGMEKBias (scaleestimator.cpp:126-199): normal equations of the 11-row residual whose weight depends on
-// the scale angle a = x[0] (hence the dW/da terms)
-REBVO_HD inline void problem_KaGMEKBias(Mat<7, 7> &JtJ, Vec<7> &JtF, const Vec<7> &x, const KaGMEKBiasParams &p) {
+// the scale angle a = x[0] (hence the dW/da terms).  This is the reference's function as it is written, dense 11x11
+// algebra and all; the filters run problem_KaGMEKBias below, which leaves out the products with structural zeros
+// (tests/test_imu_cpu.py holds the two equal).
+REBVO_HD inline void problem_KaGMEKBias_dense(Mat<7, 7> &JtJ, Vec<7> &JtF, const Vec<7> &x, const KaGMEKBiasParams &p) {
     const double a = x[0];
     const Vec<3> g = la::slice<3>(x, 1), b = la::slice<3>(x, 4);
     const Vec<3> &a_s = p.a_s, &a_v = p.a_v;
@@ -176,6 +179,115 @@ REBVO_HD inline void problem_KaGMEKBias(Mat<7, 7> &JtJ, Vec<7> &JtF, const Vec<7
     la::set_slice(JtF, 1, (Jt * W) * F);
 }
 
+// The same normal equations without the multiplications by structural zeros.  P, W, dP/da and dW/da are block diagonal
+// (3 + 1 + 7), dP/da and dW/da live in the 3x3 block only, dF/da has four non-zero entries and dF/dx1 is made of identity,
+// rotation and cross-product blocks: the reference's 11x11x11 products (5.5 k multiply-adds per evaluation, 21 evaluations
+// per frame) come down to ~600.  Every sum keeps the reference's order (k ascending from 0) over its non-zero terms, and
+// x + (+-0) = x, so the results are the dense function's bit for bit (an exactly-zero sum may differ in the sign of its
+// zero).  W7 = Cholesky<7>(Pp).get_inverse() does not depend on x and comes in with the parameters.
+REBVO_HD inline void problem_KaGMEKBias(Mat<7, 7> &JtJ, Vec<7> &JtF, const Vec<7> &x, const KaGMEKBiasParams &p) {
+    const double a = x[0];
+    const double ca = std::cos(a), sa = std::sin(a);
+    const Vec<3> g = la::slice<3>(x, 1), b = la::slice<3>(x, 4);
+    const Vec<3> &a_s = p.a_s, &a_v = p.a_v;
+    const Mat<7, 7> &W7 = p.W7;
+
+    double F[11];
+    {
+        const Vec<3> fa = (a_s + g) * ca - a_v * sa;
+        for (int i = 0; i < 3; i++) F[i] = fa[i];
+    }
+    F[3] = la::dot(g, g) - p.G * p.G;
+    F[4] = x[0] - p.x_p[0];
+    if (F[4] > M_PI) F[4] -= 2 * M_PI;
+    else if (F[4] < -M_PI) F[4] += 2 * M_PI;
+    const Mat<3, 3> Rb = la::so3_exp(b);
+    const Vec<3> Rg = Rb * g;
+    for (int i = 0; i < 3; i++) { F[5 + i] = Rg[i] - p.x_p[1 + i]; F[8 + i] = b[i] - p.x_p[4 + i]; }
+    const Vec<3> da = -(a_s + g) * sa - a_v * ca;          // dF/da, rows 0..2 (row 4 is 1, the rest 0)
+    Mat<3, 3> Gx;
+    Gx(0, 0) = 0; Gx(0, 1) = Rg[2]; Gx(0, 2) = -Rg[1];
+    Gx(1, 0) = -Rg[2]; Gx(1, 1) = 0; Gx(1, 2) = Rg[0];
+    Gx(2, 0) = Rg[1]; Gx(2, 1) = -Rg[0]; Gx(2, 2) = 0;
+
+    const Mat<3, 3> Pz = (sa * sa) * p.Rv + (ca * ca) * p.Rs;
+    const Mat<3, 3> W3 = la::Cholesky<3>(Pz).inverse();
+    const Mat<3, 3> dP3 = ((2 * sa) * ca) * (p.Rv - p.Rs);
+    const Mat<3, 3> D3 = ((-W3) * dP3) * W3;                // the non-zero block of dW/da = ((-W) dP/da) W
+    const double iRg = 1 / p.Rg;
+
+    // M2 = Jt W (6 x 11), Jt = (dF/dx1)^T
+    double M2[6][11];
+    for (int r = 0; r < 3; r++) {
+        for (int j = 0; j < 3; j++) M2[r][j] = ca * W3(r, j);
+        M2[r][3] = (2 * g[r]) * iRg;
+        for (int jj = 0; jj < 7; jj++) {
+            double t = 0;
+            for (int ii = 1; ii <= 3; ii++) t += Rb(ii - 1, r) * W7(ii, jj);
+            M2[r][4 + jj] = t;
+        }
+    }
+    for (int rr = 0; rr < 3; rr++) {
+        for (int j = 0; j < 4; j++) M2[3 + rr][j] = 0;
+        for (int jj = 0; jj < 7; jj++) {
+            double t = 0;
+            for (int ii = 1; ii <= 3; ii++) t += Gx(ii - 1, rr) * W7(ii, jj);
+            M2[3 + rr][4 + jj] = t + W7(4 + rr, jj);
+        }
+    }
+
+    // JtJ(0,0) = (((F/4) dW) P) dW . F + (dFda dW) . F + (dFda W) . dFda
+    double v1[3], v2[3], v3[3], u[3], w[3];
+    for (int j = 0; j < 3; j++) { double t = 0; for (int i = 0; i < 3; i++) t += (0.25 * F[i]) * D3(i, j); v1[j] = t; }
+    for (int j = 0; j < 3; j++) { double t = 0; for (int i = 0; i < 3; i++) t += v1[i] * Pz(i, j); v2[j] = t; }
+    for (int j = 0; j < 3; j++) { double t = 0; for (int i = 0; i < 3; i++) t += v2[i] * D3(i, j); v3[j] = t; }
+    for (int j = 0; j < 3; j++) { double t = 0; for (int i = 0; i < 3; i++) t += da[i] * D3(i, j); u[j] = t; }
+    for (int j = 0; j < 3; j++) { double t = 0; for (int i = 0; i < 3; i++) t += da[i] * W3(i, j); w[j] = t; }
+    double t1 = 0, t2 = 0, t3 = 0;
+    for (int j = 0; j < 3; j++) { t1 += v3[j] * F[j]; t2 += u[j] * F[j]; t3 += w[j] * da[j]; }
+    t3 += W7(0, 0);
+    JtJ(0, 0) = t1 + t2 + t3;
+
+    // first row / column: ((Jt/2) dW) F + (Jt W) dFda
+    for (int r = 0; r < 6; r++) {
+        double c1 = 0;
+        if (r < 3) for (int j = 0; j < 3; j++) c1 += ((0.5 * ca) * D3(r, j)) * F[j];
+        double c2 = 0;
+        for (int j = 0; j < 3; j++) c2 += M2[r][j] * da[j];
+        c2 += M2[r][4];
+        const double c = c1 + c2;
+        JtJ(1 + r, 0) = c;
+        JtJ(0, 1 + r) = c;
+    }
+    // (Jt W) dF/dx1
+    for (int r = 0; r < 6; r++) {
+        for (int c = 0; c < 3; c++) {
+            double t = M2[r][c] * ca;
+            t += M2[r][3] * (2 * g[c]);
+            for (int k = 0; k < 3; k++) t += M2[r][5 + k] * Rb(k, c);
+            JtJ(1 + r, 1 + c) = t;
+        }
+        for (int cc = 0; cc < 3; cc++) {
+            double t = 0;
+            for (int k = 0; k < 3; k++) t += M2[r][5 + k] * Gx(k, cc);
+            JtJ(1 + r, 4 + cc) = t + M2[r][8 + cc];
+        }
+    }
+    // JtF
+    {
+        double q[3], s1 = 0, s2 = 0;
+        for (int j = 0; j < 3; j++) { double t = 0; for (int i = 0; i < 3; i++) t += (0.5 * F[i]) * D3(i, j); q[j] = t; }
+        for (int j = 0; j < 3; j++) { s1 += q[j] * F[j]; s2 += w[j] * F[j]; }
+        for (int jj = 0; jj < 7; jj++) s2 += W7(0, jj) * F[4 + jj];
+        JtF[0] = s1 + s2;
+    }
+    for (int r = 0; r < 6; r++) {
+        double t = 0;
+        for (int j = 0; j < 11; j++) t += M2[r][j] * F[j];
+        JtF[1 + r] = t;
+    }
+}
+
 REBVO_HD inline double saturate(double t, double limit) { return t > limit ? limit : (t < -limit ? -limit : t); }
 
 // FunT_KaGMEKBias (scaleestimator.cpp:201-204): wrap the angle, clamp the bias to +-0.02
@@ -218,14 +330,19 @@ REBVO_HD inline double ScaleEstimator::estKaGMEKBias(const Vec<3> &s_acel, const
     params.Rs = Rs;
     params.Rv = Rf;
     params.Pp = Pp;
+    params.W7 = la::Cholesky<7>(Pp).inverse();
     params.Rg = Rg;
     params.G = g_gravit;
     params.x_p = X;
     Mat<7, 7> JtJ;
     Vec<7> JtF;
+    // (the eigen-solve of every iteration but the first starts from the eigenvectors of the one before: la::SymSVD)
+    Mat<7, 7> Vprev;
     for (int it = 0; it < 20; it++) {
         imufilter_detail::problem_KaGMEKBias(JtJ, JtF, X, params);
-        const Vec<7> h = la::SymSVD<7>(JtJ).backsub(-JtF);
+        const la::SymSVD<7> svd(JtJ, 1e9, it ? &Vprev : nullptr);
+        const Vec<7> h = svd.backsub(-JtF);
+        Vprev = svd.V;
         X = X + h;
         X = imufilter_detail::funT_KaGMEKBias(X);
     }

@@ -18,6 +18,13 @@
 #else
 #define REBVO_HD
 #endif
+// Device code: loops over fixed sizes are unrolled so that the small matrices are indexed with constants and stay in registers
+// (a dynamically indexed local array is scratch memory: a memory round trip per access for a thread that has nothing to overlap it with).
+#if defined(__HIP_DEVICE_COMPILE__)
+#define REBVO_UNROLL _Pragma("unroll")
+#else
+#define REBVO_UNROLL
+#endif
 
 namespace rebvo {
 namespace la {
@@ -61,23 +68,47 @@ template <int R, int C> REBVO_HD inline Mat<R, C> operator/(const Mat<R, C> &a, 
 template <int N> REBVO_HD inline double dot(const Vec<N> &a, const Vec<N> &b) { double s = 0; for (int i = 0; i < N; i++) s += a[i] * b[i]; return s; }
 template <int R, int K, int C> REBVO_HD inline Mat<R, C> operator*(const Mat<R, K> &a, const Mat<K, C> &b) {
     Mat<R, C> r;
-    for (int i = 0; i < R; i++)
-        for (int j = 0; j < C; j++) { double s = 0; for (int k = 0; k < K; k++) s += a(i, k) * b(k, j); r(i, j) = s; }
+    REBVO_UNROLL
+    for (int i = 0; i < R; i++) {
+        REBVO_UNROLL
+        for (int j = 0; j < C; j++) {
+            double s = 0;
+            REBVO_UNROLL
+            for (int k = 0; k < K; k++) s += a(i, k) * b(k, j);
+            r(i, j) = s;
+        }
+    }
     return r;
 }
 template <int R, int C> REBVO_HD inline Vec<R> operator*(const Mat<R, C> &a, const Vec<C> &x) {
     Vec<R> r;
-    for (int i = 0; i < R; i++) { double s = 0; for (int k = 0; k < C; k++) s += a(i, k) * x[k]; r[i] = s; }
+    REBVO_UNROLL
+    for (int i = 0; i < R; i++) {
+        double s = 0;
+        REBVO_UNROLL
+        for (int k = 0; k < C; k++) s += a(i, k) * x[k];
+        r[i] = s;
+    }
     return r;
 }
 template <int R, int C> REBVO_HD inline Vec<C> operator*(const Vec<R> &x, const Mat<R, C> &a) {   // row vector * matrix
     Vec<C> r;
-    for (int j = 0; j < C; j++) { double s = 0; for (int k = 0; k < R; k++) s += x[k] * a(k, j); r[j] = s; }
+    REBVO_UNROLL
+    for (int j = 0; j < C; j++) {
+        double s = 0;
+        REBVO_UNROLL
+        for (int k = 0; k < R; k++) s += x[k] * a(k, j);
+        r[j] = s;
+    }
     return r;
 }
 template <int R, int C> REBVO_HD inline Mat<C, R> transpose(const Mat<R, C> &a) {
     Mat<C, R> r;
-    for (int i = 0; i < R; i++) for (int j = 0; j < C; j++) r(j, i) = a(i, j);
+    REBVO_UNROLL
+    for (int i = 0; i < R; i++) {
+        REBVO_UNROLL
+        for (int j = 0; j < C; j++) r(j, i) = a(i, j);
+    }
     return r;
 }
 template <int N> REBVO_HD inline double norm(const Vec<N> &a) { return std::sqrt(dot(a, a)); }
@@ -198,29 +229,80 @@ struct Cholesky {
 // ---- TooN::SVD<N> of a SYMMETRIC matrix: backsub / get_pinv with TooN's conditioning (TooN/SVD.h:176-207,
 //      264-272: singular values below s_max / 1e9 are dropped).  A = V diag(e) V^T by cyclic Jacobi; singular values
 //      are |e|, so pinv = V diag(1/e) V^T over the kept ones.
+// On the device (one thread per sequence, nothing to hide latency behind) the parameters of a rotation — two divisions and
+// two square roots in a row, ~200 dependent instructions as IEEE operations, 3000 rotations per frame — come from the hardware
+// reciprocal / reciprocal square root with two Newton steps each (a few 1e-16 relative): the rotation is orthogonal to rounding
+// either way, and the eigen-decomposition it converges to is the same to the accuracy the sweep criterion asks for.  The pair
+// and element loops are unrolled there so that A and V stay in registers (dynamic indices would put them in scratch memory).
+#if defined(__HIP_DEVICE_COMPILE__)
+REBVO_HD inline double svd_recip(double x) {
+    double y = __builtin_amdgcn_rcp(x);
+    y = __builtin_fma(__builtin_fma(-x, y, 1.0), y, y);
+    y = __builtin_fma(__builtin_fma(-x, y, 1.0), y, y);
+    return y;
+}
+REBVO_HD inline double svd_rsqrt(double x) {   // x >= 1
+    double y = __builtin_amdgcn_rsq(x);
+    const double hx = 0.5 * x;
+    y = y * (1.5 - hx * y * y);
+    y = y * (1.5 - hx * y * y);
+    return y;
+}
+#endif
+
 template <int N>
 struct SymSVD {
     Mat<N, N> V;
     double e[N], inv[N];
-    REBVO_HD explicit SymSVD(const Mat<N, N> &Ain, double condition = 1e9) {
+    // V0: eigenvectors of a nearby matrix (the Gauss-Newton iteration before: the normal equations barely move from one
+    // iteration to the next).  The solve then starts from V0^T A V0, which is diagonal to first order, and needs a sweep or
+    // two instead of seven; the decomposition it arrives at is the same to rounding.
+    REBVO_HD explicit SymSVD(const Mat<N, N> &Ain, double condition = 1e9, const Mat<N, N> *V0 = nullptr) {
         Mat<N, N> A = Ain;
-        V = Mat<N, N>::identity();
+        if (V0) {
+            V = *V0;
+            A = transpose(V) * (Ain * V);
+            REBVO_UNROLL
+            for (int p = 0; p < N; p++) {
+                REBVO_UNROLL
+                for (int q = p + 1; q < N; q++) A(q, p) = A(p, q);   // symmetric again after the products' rounding
+            }
+        } else {
+            V = Mat<N, N>::identity();
+        }
         for (int sweep = 0; sweep < 60; sweep++) {
             double off = 0, diag = 0;
+            REBVO_UNROLL
             for (int p = 0; p < N; p++) {
                 diag += A(p, p) * A(p, p);
+                REBVO_UNROLL
                 for (int q = p + 1; q < N; q++) off += A(p, q) * A(p, q);
             }
             if (!(off > 1e-34 * diag) || !(off > 0)) break;
+            REBVO_UNROLL
             for (int p = 0; p < N - 1; p++)
+                REBVO_UNROLL
                 for (int q = p + 1; q < N; q++) {
                     const double apq = A(p, q);
                     if (apq == 0) continue;
+#if defined(__HIP_DEVICE_COMPILE__)
+                    const double d2 = 2 * apq;
+                    // |2 apq| far below |aqq - app|: theta overflows the reciprocal's range; the rotation is the identity to rounding
+                    const double theta = (A(q, q) - A(p, p)) * svd_recip(d2);
+                    const double th2 = theta * theta + 1;
+                    const double root = th2 * svd_rsqrt(th2);
+                    const double t = (std::fabs(theta) < 1e150) ? (theta >= 0 ? 1.0 : -1.0) * svd_recip(std::fabs(theta) + root) : 0.0;
+                    const double cs = svd_rsqrt(t * t + 1), sn = t * cs;
+#else
                     const double theta = (A(q, q) - A(p, p)) / (2 * apq);
                     const double t = (theta >= 0 ? 1.0 : -1.0) / (std::fabs(theta) + std::sqrt(theta * theta + 1));
                     const double cs = 1 / std::sqrt(t * t + 1), sn = t * cs;
+#endif
+                    REBVO_UNROLL
                     for (int k = 0; k < N; k++) { const double a = A(k, p), b = A(k, q); A(k, p) = cs * a - sn * b; A(k, q) = sn * a + cs * b; }
+                    REBVO_UNROLL
                     for (int k = 0; k < N; k++) { const double a = A(p, k), b = A(q, k); A(p, k) = cs * a - sn * b; A(q, k) = sn * a + cs * b; }
+                    REBVO_UNROLL
                     for (int k = 0; k < N; k++) { const double a = V(k, p), b = V(k, q); V(k, p) = cs * a - sn * b; V(k, q) = sn * a + cs * b; }
                 }
         }

@@ -52,6 +52,22 @@ double rebvo_est_ka_gmek_bias(const double *s_acel, const double *f_acel, double
     return k;
 }
 
+// problem_KaGMEKBias both ways (the reference's dense algebra / the structural zeros left out): JtJ (49), JtF (7) of each
+void rebvo_problem_ka_gmek_bias(const double *x, const double *a_v, const double *a_s, double G, const double *x_p, const double *Rv,
+                                const double *Rs, double Rg, const double *Pp, double *JtJ_dense, double *JtF_dense, double *JtJ_sparse,
+                                double *JtF_sparse) {
+    rebvo::imufilter_detail::KaGMEKBiasParams p;
+    p.a_v = vin<3>(a_v); p.a_s = vin<3>(a_s); p.G = G; p.x_p = vin<7>(x_p); p.Rv = min_<3, 3>(Rv); p.Rs = min_<3, 3>(Rs); p.Rg = Rg;
+    p.Pp = min_<7, 7>(Pp);
+    p.W7 = rebvo::la::Cholesky<7>(p.Pp).inverse();
+    Mat<7, 7> J;
+    Vec<7> F;
+    rebvo::imufilter_detail::problem_KaGMEKBias_dense(J, F, vin<7>(x), p);
+    mout(JtJ_dense, J); vout(JtF_dense, F);
+    rebvo::imufilter_detail::problem_KaGMEKBias(J, F, vin<7>(x), p);
+    mout(JtJ_sparse, J); vout(JtF_sparse, F);
+}
+
 void *rebvo_imu_grabber_new(int list_size, double tsamp) { return new ImuGrabber(list_size, tsamp); }
 void *rebvo_imu_grabber_load(const char *csv_file, double time_scale) {
     bool error = false;

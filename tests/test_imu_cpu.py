@@ -110,6 +110,25 @@ def test_scale_filter_matches_reference(libs):
         assert np.isfinite(k0) and k0 > 0
 
 
+def test_problem_without_structural_zeros_equals_the_dense_one(libs):
+    """problem_KaGMEKBias (the filters' version: block structure of P, W, dW/da and dF/dx used) against problem_KaGMEKBias_dense
+    (the reference's function as written): the same sums over the same non-zero terms in the same order, hence the same bits."""
+    host, _ = libs
+    rng = np.random.default_rng(3)
+    for it in range(40):
+        a = rng.uniform(-3, 3)
+        x = np.concatenate([[a], rng.normal(size=3) * 9.8, rng.normal(size=3) * 2e-2])
+        x_p = x + np.concatenate([[rng.normal() * (4.0 if it % 5 == 0 else 0.05)], rng.normal(size=3) * 0.1, rng.normal(size=3) * 1e-3])
+        a_v, a_s = rng.normal(size=3), rng.normal(size=3) + np.array([0, -9.8, 0])
+        Rv, Rs, Pp = spd(rng, 3, 1e-3), spd(rng, 3, 4e-6), spd(rng, 7, 1e-2)
+        Jd, Fd, Js, Fs = np.zeros(49), np.zeros(7), np.zeros(49), np.zeros(7)
+        host.rebvo_problem_ka_gmek_bias(dp(x), dp(a_v), dp(a_s), C.c_double(9.8), dp(x_p), dp(Rv), dp(Rs), C.c_double(0.2e3 ** 2),
+                                        dp(Pp), dp(Jd), dp(Fd), dp(Js), dp(Fs))
+        assert np.all(np.isfinite(Jd)) and np.abs(Jd).max() > 1
+        assert np.array_equal(Jd, Js), (it, np.abs(Jd - Js).max())
+        assert np.array_equal(Fd, Fs), (it, np.abs(Fd - Fs).max())
+
+
 def _imu_rows(rng, n, t0=1.0, dt=0.005):
     t = t0 + dt * np.arange(n)
     g = rng.normal(size=(n, 3)) * 0.2
