@@ -1606,6 +1606,8 @@ __global__ __launch_bounds__(256) void k_try_vel(TvrArgs a) {
     // status: 0 skipped / no residual written, 2 matched (own fi), 3 evaluated but unmatched (inherits fi)
     int status = 0, mid_f = -1;
     double fi = 0;
+    bool resolved = false;   // the entry held a marker: if this evaluation leaves it alone, the resolved value goes back
+    double rkeep = 0;
     if (ikl < kn) {
         const float nm = ko.n_m[ikl];
         const double s_rho = ko.s_rho[ikl];
@@ -1615,7 +1617,11 @@ __global__ __launch_bounds__(256) void k_try_vel(TvrArgs a) {
         const bool skip = (min_mod > 0 && nm < min_mod) || s_rho > sq->mv_s_rho_min || (uint32_t)ko.m_num[ikl] < mthr;
         if (!skip) {
             double weight = 1;
-            const double rprev = res[ikl];
+            double rprev = res[ikl];
+            // a marker of the evaluation before: the carry k_lmv_step resolved for this block (the pass that used to rewrite the
+            // buffer between two evaluations, k_tv_resolve, now runs after the last one only)
+            if (is_carry(rprev)) { rprev = a.resid_carry[(size_t)seq * a.nblk + blk]; resolved = true; }
+            rkeep = rprev;
             if (rprev > a.k_huber) weight = a.k_huber / rprev;
             const float2 pm = ko.p_m[ikl];
             const double z_p = 1.0 / ko.rho[ikl] + v2;
@@ -1691,6 +1697,8 @@ __global__ __launch_bounds__(256) void k_try_vel(TvrArgs a) {
             res[ikl] = v;
         } else if (status == 2) {
             res[ikl] = afi;
+        } else if (resolved) {
+            res[ikl] = rkeep;
         }
         if (tid == 0) {
             double bl = marker;
@@ -1766,69 +1774,122 @@ __global__ __launch_bounds__(64) void k_lmv_step(SeqDev *seqs, const double *__r
     const int kn = kn_old[seq];
     const int nblk_used = (kn + 255) / 256;
     __shared__ double s_sum[kTvNum];
-    if (ops & (LMV_REDUCE_CUR | LMV_REDUCE_NEW)) {
+    // One wave per sequence and nothing but latency: everything the step reads is requested before anything is used or stored —
+    // the blocks' partial sums (all of a value's up to 64 loads in flight, then summed in block order as before), their last
+    // residuals, the state — and the state is written back once at the end.  (Value by value and field by field the step paid
+    // ~50 dependent memory round trips: 16 us for a single camera.)
+    constexpr int kPre = 64;
+    const bool red = (ops & (LMV_REDUCE_CUR | LMV_REDUCE_NEW)) != 0;
+    const bool pre = nblk_used <= kPre;
+    double pv[kPre];
+    double bl = 0;
+    if (red && pre) {
+        if (lane < kTvNum) {
+#pragma unroll
+            for (int b = 0; b < kPre; b++) pv[b] = b < nblk_used ? partials[((size_t)seq * nblk + b) * kNumSums + lane] : 0.0;
+        }
+        if (lane < nblk_used) bl = block_last[(size_t)seq * nblk + lane];
+    }
+    double V[3], Vn[3], h[3], JtJ[9], JtF[3], JtJn[9], JtFn[3];
+#pragma unroll
+    for (int i = 0; i < 3; i++) { V[i] = sq->mv_V[i]; Vn[i] = sq->mv_Vnew[i]; h[i] = sq->mv_h[i]; JtF[i] = sq->mv_JtF[i]; JtFn[i] = sq->mv_JtFnew[i]; }
+#pragma unroll
+    for (int i = 0; i < 9; i++) { JtJ[i] = sq->mv_JtJ[i]; JtJn[i] = sq->mv_JtJnew[i]; }
+    double F = sq->mv_F, Fnew = sq->mv_Fnew, u = sq->mv_u, v = sq->mv_v;
+    if (red) {
         if (lane < kTvNum) {
             double acc = 0;
-            for (int b = 0; b < nblk_used; b++) acc += partials[((size_t)seq * nblk + b) * kNumSums + lane];
+            if (pre) {
+#pragma unroll
+                for (int b = 0; b < kPre; b++) if (b < nblk_used) acc += pv[b];
+            } else {
+                for (int b = 0; b < nblk_used; b++) acc += partials[((size_t)seq * nblk + b) * kNumSums + lane];
+            }
             s_sum[lane] = acc;
         }
-        if (lane == 32) {   // carries: |fi| of the last matched KeyLine before each block (0 at the top: double fi=0)
+        // carries: |fi| of the last matched KeyLine before each block (0 at the top: double fi=0)
+        if (pre) {
+            const bool valid = lane < nblk_used && !is_carry(bl);
+            const unsigned long long vm = __ballot(valid);
+            const unsigned long long below = vm & ((1ull << lane) - 1ull);
+            const int src = below ? 63 - __clzll(below) : 0;
+            const double inh = __shfl(bl, src, 64);
+            if (lane < nblk_used) carry[(size_t)seq * nblk + lane] = below ? inh : 0.0;
+        } else if (lane == 32) {
             double run = 0;
             for (int b = 0; b < nblk_used; b++) {
                 carry[(size_t)seq * nblk + b] = run;
-                const double v = block_last[(size_t)seq * nblk + b];
-                if (!is_carry(v)) run = v;
+                const double v2 = block_last[(size_t)seq * nblk + b];
+                if (!is_carry(v2)) run = v2;
             }
         }
     }
     __syncthreads();
     if (lane != 0) return;
     const double tau = 1e-3;
-    if (ops & LMV_BEGIN) { sq->mv_v = 2; }
-    if (ops & (LMV_REDUCE_CUR | LMV_REDUCE_NEW)) {
-        double *JtJ = (ops & LMV_REDUCE_CUR) ? sq->mv_JtJ : sq->mv_JtJnew;
-        double *JtF = (ops & LMV_REDUCE_CUR) ? sq->mv_JtF : sq->mv_JtFnew;
-        JtJ[0] = s_sum[0]; JtJ[4] = s_sum[1]; JtJ[8] = s_sum[2];
-        JtJ[1] = JtJ[3] = s_sum[3]; JtJ[2] = JtJ[6] = s_sum[4]; JtJ[5] = JtJ[7] = s_sum[5];
-        JtF[0] = s_sum[6]; JtF[1] = s_sum[7]; JtF[2] = s_sum[8];
+    if (ops & LMV_BEGIN) v = 2;
+    if (red) {
+        double *J = (ops & LMV_REDUCE_CUR) ? JtJ : JtJn;
+        double *Fv = (ops & LMV_REDUCE_CUR) ? JtF : JtFn;
+        J[0] = s_sum[0]; J[4] = s_sum[1]; J[8] = s_sum[2];
+        J[1] = J[3] = s_sum[3]; J[2] = J[6] = s_sum[4]; J[5] = J[7] = s_sum[5];
+        Fv[0] = s_sum[6]; Fv[1] = s_sum[7]; Fv[2] = s_sum[8];
         if (ops & LMV_REDUCE_CUR) {
-            sq->mv_F = s_sum[9];
+            F = s_sum[9];
             double mx = JtJ[0];
+#pragma unroll
             for (int i = 1; i < 9; i++) mx = JtJ[i] > mx ? JtJ[i] : mx;   // TooN::max_element(JtJ).first
-            sq->mv_u = tau * mx;
+            u = tau * mx;
         } else {
-            sq->mv_Fnew = s_sum[9];
+            Fnew = s_sum[9];
         }
     }
     if (ops & LMV_GAIN) {
         double den = 0;
-        for (int i = 0; i < 3; i++) den += (0.5 * sq->mv_h[i]) * (sq->mv_u * sq->mv_h[i] - sq->mv_JtF[i]);
-        const double gain = (sq->mv_F - sq->mv_Fnew) / den;
+#pragma unroll
+        for (int i = 0; i < 3; i++) den += (0.5 * h[i]) * (u * h[i] - JtF[i]);
+        const double gain = (F - Fnew) / den;
         if (gain > 0) {
-            sq->mv_F = sq->mv_Fnew;
-            for (int i = 0; i < 3; i++) { sq->mv_V[i] = sq->mv_Vnew[i]; sq->mv_JtF[i] = sq->mv_JtFnew[i]; }
-            for (int i = 0; i < 9; i++) sq->mv_JtJ[i] = sq->mv_JtJnew[i];
+            F = Fnew;
+#pragma unroll
+            for (int i = 0; i < 3; i++) { V[i] = Vn[i]; JtF[i] = JtFn[i]; }
+#pragma unroll
+            for (int i = 0; i < 9; i++) JtJ[i] = JtJn[i];
             const double g = 2 * gain - 1;
             const double m = 1 - (g * g * g);
-            sq->mv_u *= (0.33 > m ? 0.33 : m);
-            sq->mv_v = 2;
+            u *= (0.33 > m ? 0.33 : m);
+            v = 2;
         } else {
-            sq->mv_u *= sq->mv_v;
-            sq->mv_v *= 2;
+            u *= v;
+            v *= 2;
         }
     }
     if (ops & LMV_SOLVE) {
         double ApI[9], Inv[9];
-        for (int i = 0; i < 9; i++) ApI[i] = sq->mv_JtJ[i] + ((i % 4 == 0) ? 1.0 * sq->mv_u : 0.0);
+#pragma unroll
+        for (int i = 0; i < 9; i++) ApI[i] = JtJ[i] + ((i % 4 == 0) ? 1.0 * u : 0.0);
         mat3_inv(ApI, Inv);
+#pragma unroll
         for (int i = 0; i < 3; i++) {
             double d = 0;
-            for (int k = 0; k < 3; k++) d += Inv[i * 3 + k] * (-sq->mv_JtF[k]);
-            sq->mv_h[i] = d;
-            sq->mv_Vnew[i] = sq->mv_V[i] + d;
+#pragma unroll
+            for (int k = 0; k < 3; k++) d += Inv[i * 3 + k] * (-JtF[k]);
+            h[i] = d;
+            Vn[i] = V[i] + d;
         }
     }
-    if (ops & LMV_FINISH) mat3_inv(sq->mv_JtJ, sq->mv_RVel);
+    double RVel[9];
+    if (ops & LMV_FINISH) mat3_inv(JtJ, RVel);
+    // ---- stores ----
+#pragma unroll
+    for (int i = 0; i < 3; i++) { sq->mv_V[i] = V[i]; sq->mv_Vnew[i] = Vn[i]; sq->mv_h[i] = h[i]; sq->mv_JtF[i] = JtF[i]; sq->mv_JtFnew[i] = JtFn[i]; }
+#pragma unroll
+    for (int i = 0; i < 9; i++) { sq->mv_JtJ[i] = JtJ[i]; sq->mv_JtJnew[i] = JtJn[i]; }
+    sq->mv_F = F; sq->mv_Fnew = Fnew; sq->mv_u = u; sq->mv_v = v;
+    if (ops & LMV_FINISH) {
+#pragma unroll
+        for (int i = 0; i < 9; i++) sq->mv_RVel[i] = RVel[i];
+    }
 }
 
 // standalone evaluation helper: X given by the host -> setup
@@ -2142,7 +2203,7 @@ int minimizer_v_enqueue(edgehip_ctx *c, int slot_new, int slot_old, int fc_index
     auto step = [&](unsigned ops) {
         hipLaunchKernelGGL(k_lmv_step, dim3(pl.nseq), dim3(64), 0, c->stream, c->seq, c->partials, c->block_last, c->resid_carry,
                            kn_old, c->nblk_tvr, ops);
-        if (ops & (LMV_REDUCE_CUR | LMV_REDUCE_NEW))
+        if ((ops & (LMV_REDUCE_CUR | LMV_REDUCE_NEW)) && (ops & LMV_FINISH))   // between evaluations k_try_vel resolves the markers it meets
             hipLaunchKernelGGL(k_tv_resolve, dim3(nblk256, 1, pl.nseq), dim3(256), 0, c->stream, c->resid, c->resid_carry, kn_old,
                                pl.cap, c->nblk_tvr);
     };

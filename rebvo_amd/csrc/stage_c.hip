@@ -984,9 +984,9 @@ int forward_match_enqueue(edgehip_ctx *c, int slot_old, int slot_new, bool keys_
     ProfScope ps(c, PROF_C_FORWARD);
     const DevicePlan &pl = c->plan;
     const size_t B = pl.nseq;
-    const bool cleared = keys_posted && c->fwd_cleared;   // k_field_bin reset the entries of the new edge map (whole-frame driver)
+    const bool cleared = c->fwd_cleared;   // k_field_bin reset both arrays' entries of the new edge map (whole-frame driver)
     c->fwd_cleared = false;
-    if (!keys_posted) EH_CHECK(hipMemsetAsync(c->fwd_key, 0, sizeof(unsigned long long) * B * pl.cap, c->stream));
+    if (!keys_posted && !cleared) EH_CHECK(hipMemsetAsync(c->fwd_key, 0, sizeof(unsigned long long) * B * pl.cap, c->stream));
     if (!cleared) EH_CHECK(hipMemsetAsync(c->fwd_win, 0xFF, sizeof(int32_t) * B * pl.cap, c->stream));
     dim3 g((pl.cap + 255) / 256, 1, pl.nseq), b(256);
     const int32_t *kno = c->kn_slot + slot_old * B, *knn = c->kn_slot + slot_new * B;
@@ -1523,7 +1523,7 @@ static int frame_enqueue(edgehip_ctx *c, int sn, int so, int sp, int have_pair, 
     // (with a frame pair FordwardMatch follows below in every branch: the detector may leave the forwarded fields to it;
     // mode 2 keeps its scattering pass, which cannot fill)
     bool frame_ended = false;
-    const bool begin_in_quantile = have_pair && !c->imu_enabled;   // k_quantile, the first kernel of stage B, does it per sequence
+    const bool begin_in_quantile = have_pair != 0;                  // k_quantile, the first kernel of stage B, does it per sequence
     const bool retune_in_quantile = begin_in_quantile && sp < 0;    // ... and finishes the detector's reEstimateThresh (the pair image's stage A would overwrite its histogram)
     EH_TRY(stage_a_enqueue(c, sn, have_pair && c->fwd_mode != 2, retune_in_quantile));
     if (sp >= 0) EH_TRY(stage_a_enqueue(c, sp));   // the pair image, after the main one as in rebvo_first_t.cpp:259-290
@@ -1539,8 +1539,8 @@ static int frame_enqueue(edgehip_ctx *c, int sn, int so, int sp, int have_pair, 
         // ---- ImuMode > 0 (rebvo_second_t.cpp:182-336, 387-493, 519-606): everything on the device, stage_imu.hip has the filters ----
         EH_TRY(imu_begin_enqueue(c));
         if (have_pair) {
-            EH_TRY(quantile_enqueue(c, so, kRhoMin, kRhoMax, c->p.qcut_quantile, c->p.qcut_nbins));  // :172
-            EH_TRY(build_field_enqueue(c, sn, c->p.search_range, -1.f));                              // :177
+            EH_TRY(quantile_enqueue(c, so, kRhoMin, kRhoMax, c->p.qcut_quantile, c->p.qcut_nbins, true, retune_in_quantile ? sn : -1));  // :145-168, :172
+            EH_TRY(build_field_enqueue(c, sn, c->p.search_range, -1.f, true));                        // :177 (also resets FordwardMatch's arbitration arrays)
             { ProfScope ps(c, PROF_IMU_FILTERS); EH_TRY(imu_pre_enqueue(c, so)); }                         // :183-213
             EH_TRY(rotate_buf_enqueue(c, so));                                                       // :215 gyro pre-rotation
             {
