@@ -569,7 +569,7 @@ int edgehip_destroy(edgehip_ctx *c) {
     if (c->grey8) (void)hipFree(c->grey8);
     if (c->pinned_grey8) (void)hipHostFree(c->pinned_grey8);
     if (c->nav_log) (void)hipFree(c->nav_log);
-    if (c->stream_imu) { (void)hipStreamSynchronize(c->stream_imu); (void)hipStreamDestroy(c->stream_imu); for (int i = 0; i < 2; i++) { (void)hipEventDestroy(c->ev_imu_snap[i]); (void)hipEventDestroy(c->ev_imu_post[i]); } }
+    if (c->stream_imu) { (void)hipStreamSynchronize(c->stream_imu); (void)hipStreamDestroy(c->stream_imu); for (int i = 0; i < 2; i++) { (void)hipEventDestroy(c->ev_imu_snap[i]); (void)hipEventDestroy(c->ev_imu_post[i]); (void)hipEventDestroy(c->ev_imu_mid[i]); } }
     if (c->kf_req_dev) (void)hipFree(c->kf_req_dev);
     if (c->kf_res_dev) (void)hipFree(c->kf_res_dev);
     if (c->imu_track) (void)hipFree(c->imu_track);

@@ -289,6 +289,7 @@ struct edgehip_ctx {
     void *imu_snap = nullptr;                        // [2][B] ImuSnap: a frame's hand-over from the main to the IMU stream
     hipStream_t stream_imu = nullptr;                // scale filter + pose + nav record of frame k, under frame k+1
     hipEvent_t ev_imu_snap[2], ev_imu_post[2];       // [frame & 1] snapshot written (main) / consumed (IMU stream)
+    hipEvent_t ev_imu_mid[2];                        // [frame & 1] k_imu_mid done: the scale filter may start
     bool imu_post_valid[2] = {false, false};
     edgehip_imu_integrated *imu_in_dev = nullptr;    // [B] integrated IMU data of the frame being enqueued
     edgehip_nav_imu *nav_imu_dev = nullptr;          // [B]

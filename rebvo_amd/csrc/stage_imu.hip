@@ -17,8 +17,10 @@
 // rebvo/linalg.h, both host+device), so the two paths cannot drift apart.  The batch dimension fills the lanes; the kernels
 // are bounded to 64 threads so that a lane gets the full register file, and the file is compiled with a high unroll
 // threshold (Makefile) so that the small matrices index statically and stay in registers.  Measured at 1024 sequences:
-// k_imu_post 20 ms with the default 128-VGPR budget (12 KB of scratch per lane), 6.9 ms bounded to 64 threads, 2.5 ms
-// unrolled — and nothing in the tracker or mapper waits for it (see ImuSnap below).
+// the scale filter 20 ms with the default 128-VGPR budget (12 KB of scratch per lane), 6.9 ms bounded to 64 threads, 2.5 ms
+// unrolled, 0.7-0.9 ms after round 3 (normal equations without their structural zeros, eigen-solve in registers with hardware
+// reciprocals and a warm start: rebvo/imu_filters.h, rebvo/linalg.h) — and nothing in the tracker or mapper waits for it (see
+// ImuSnap below).
 
 #include <math.h>
 #include <stdlib.h>
@@ -36,8 +38,8 @@ using la::Vec;
 // SecondThread's IMU-branch locals that persist from frame to frame (REBVO::ImuTrack of the host library), per sequence,
 // in two halves that never share a writer.  The tracker half lives on the context's main stream.  The scale filter and the
 // pose (20 Gauss-Newton steps on an 11-row problem per frame: ~10 ms on one lane, whatever the batch) feed nothing back
-// into the tracker or the mapper, so they live on a stream of their own (k_imu_post) and run under the NEXT frame's stage A
-// and tracker; what they need of a frame travels in an ImuSnap (two of them per sequence, alternating), ordered by events.
+// into the tracker or the mapper, so they live on a stream of their own (k_imu_filter, then k_imu_record) and run under the rest of the frame
+// and the start of the next; what they need of a frame travels in an ImuSnap (two of them per sequence, alternating), ordered by events.
 struct ImuTrackDev {            // main stream: k_imu_pre / k_imu_mid
     int32_t n_frame, init, n_giro_init, est_ok;
     double dt_frame;
@@ -45,7 +47,7 @@ struct ImuTrackDev {            // main stream: k_imu_pre / k_imu_mid
     Mat<3, 3> P_Vg, RGiro, RGBias, W_Bg, R;
     edgehip_imu_integrated imud;   // integrated IMU data of the running frame
 };
-struct ImuSnap {                // written on the main stream (k_imu_pre, k_imu_mid, k_imu_snap), read by k_imu_post
+struct ImuSnap {                // written on the main stream (k_imu_pre, k_imu_mid, k_imu_snap), read by k_imu_filter / k_imu_record
     int32_t have_pair, est_ok, init, x_grav_set;
     double dt, QKp;
     Vec<3> x_grav;              // gyro start-up finished in this frame: the gravity estimate X[1..3] starts from here (:196)
@@ -56,12 +58,12 @@ struct ImuSnap {                // written on the main stream (k_imu_pre, k_imu_
     // the sequence state as the mapper left it
     double V[3], Kp, P_Kp, s_rho_q, t_cur, V_track[3], W_track[3], PV_track[9], PW_track[9], score, rel_error, rel_error_score;
     int32_t klm_num, klm_fwd, kf_matchs, estimation_ok, frame, minimizer_evals;
-    // and of the new edge map (its slot is recycled before k_imu_post is guaranteed to have run)
+    // and of the new edge map (its slot is recycled before k_imu_record is guaranteed to have run)
     int32_t kn, pad;
     double tresh;
     float retuned, padf;
 };
-struct ImuFilterDev {           // side stream: k_imu_post
+struct ImuFilterDev {           // side stream: k_imu_filter (k_imu_record reads it)
     int32_t n_frame, pad;
     double K, Rg;
     Vec<3> Av, As, g_est, u_est, b_est, Posgv, Posgva, dVgva, dWgva, Vgva, Pos;
@@ -132,7 +134,7 @@ __global__ __launch_bounds__(64) void k_imu_pre(SeqDev *seqs, ImuTrackDev *track
                 s.init = 1;
                 s.W_Bg = la::inv3(s.RGBias * 1e2);
                 sn.x_grav_set = 1;                                              // istate.X.slice<1,3>() = g_init / n: the filter's state
-                sn.x_grav = s.g_init / (double)s.n_giro_init;                   // is k_imu_post's, so the value travels with the frame
+                sn.x_grav = s.g_init / (double)s.n_giro_init;                   // is k_imu_filter's, so the value travels with the frame
             }
         } else {
             s.init = 1;
@@ -233,8 +235,8 @@ __global__ __launch_bounds__(64) void k_imu_mid(SeqDev *seqs, ImuTrackDev *track
     put(p.R, R);
 }
 
-// End of the frame on the main stream: what k_imu_post needs of the sequence state goes into the frame's ImuSnap (the next
-// frame's kernels overwrite the state while k_imu_post still runs), and the frame counter / time stamp move on (:585-606).
+// End of the frame on the main stream: what k_imu_record needs of the sequence state goes into the frame's ImuSnap (the next
+// frame's kernels overwrite the state while k_imu_record may still be waiting), and the frame counter / time stamp move on (:585-606).
 __global__ __launch_bounds__(64) void k_imu_snap(SeqDev *seqs, ImuTrackDev *tracks, ImuSnap *snaps, const int32_t *__restrict__ kn_new,
                            const double *__restrict__ tresh_new, const float *__restrict__ retuned_new, int have_pair, int nseq) {
     const int seq = blockIdx.x * blockDim.x + threadIdx.x;
@@ -255,16 +257,62 @@ __global__ __launch_bounds__(64) void k_imu_snap(SeqDev *seqs, ImuTrackDev *trac
     p.frame++;
 }
 
-// On the IMU stream, after the frame's snapshot: the accelerometer / scale filter (:280-312 — it reads what the tracker left,
-// nothing of the mapper except P_Kp of the frame before), the gravity-aligned pose (:519-544) and the record of the frame
-// (:550-606).
-__global__ __launch_bounds__(64) void k_imu_post(SeqDev *seqs, ImuFilterDev *filters, const ImuSnap *__restrict__ snaps, edgehip_nav *__restrict__ nav,
-                           edgehip_nav_imu *__restrict__ nav_imu, edgehip_imu_params ip, edgehip_nav *__restrict__ nav_log, int nav_log_len,
-                           int nseq) {
+// On the IMU stream.  k_imu_filter — the accelerometer / scale filter (:280-312) and the gravity-aligned pose (:519-544) — reads
+// what the tracker and k_imu_mid left in the snapshot and nothing of the mapper (QKp comes from P_Kp of the frame before), so it
+// starts as soon as k_imu_mid is done and runs under the same frame's matching and mapping kernels (short blocks: they flow around it;
+// under the next frame's one-workgroup-per-sequence stage A its sixteen waves held sixteen CUs back and cost that kernel a sixth of
+// its time).  k_imu_record follows the end-of-frame snapshot and writes the frame's records (:550-606).
+__global__ __launch_bounds__(64) void k_imu_filter(SeqDev *seqs, ImuFilterDev *filters, const ImuSnap *__restrict__ snaps, edgehip_imu_params ip, int nseq) {
     const int seq = blockIdx.x * blockDim.x + threadIdx.x;
     if (seq >= nseq) return;
     edgehip_seq_state &p = seqs[seq].pub;      // Pose, Pos, K: written here only (edgehip_get_state reads them)
     ImuFilterDev &s = filters[seq];
+    const ImuSnap &sn = snaps[seq];
+    const double dt = sn.dt;
+    const Mat<3, 3> R = sn.R;
+    if (sn.x_grav_set) la::set_slice(s.X, 1, sn.x_grav);
+    s.se.EstAcelLsq4((-sn.Vgv) / dt, s.Av, R, dt);                          // :280
+    s.se.MeanAcel4(sn.cacel, s.As, R);
+    Vec<6> Xgva = sn.Xgv;
+    s.Rgva = sn.R_pre;
+    if (s.n_frame > 4 + ip.init_bias_frame_num) {                           // :291-312
+        s.K = rebvo::ScaleEstimator::estKaGMEKBias(s.As, s.Av, 1, R, s.X, s.P, s.Qg, sn.Qrot, s.Qbias, sn.QKp, s.Rg, s.Rs, sn.Rv,
+                                                   s.g_est, s.b_est, sn.W_Xgv, Xgva, ip.g_module);
+        s.dVgva = la::slice<3>(Xgva, 0);
+        s.dWgva = la::slice<3>(Xgva, 3);
+        const Mat<3, 3> R0gva = la::so3_exp(s.dWgva);
+        s.Rgva = la::transpose(R0gva * la::transpose(s.Rgva));
+        s.Vgva = R0gva * sn.Vg + s.dVgva;
+    } else {
+        s.dVgva = sn.dVgv;
+        s.dWgva = sn.dWgv;
+        s.Rgva = R;
+        s.Vgva = sn.Vgv;
+    }
+    if (s.n_frame > 4 + ip.init_bias_frame_num) {                           // :521-541
+        s.u_est = la::transpose(s.Rgva) * s.u_est;
+        s.u_est = s.u_est - s.g_est * (la::dot(s.u_est, s.g_est) / la::dot(s.g_est, s.g_est));
+        s.u_est = s.u_est / sqrt(la::dot(s.u_est, s.u_est));                // TooN::normalize
+        Vec<3> ey = Vec<3>::zeros(), ex = Vec<3>::zeros();
+        ey[1] = 1; ex[0] = 1;
+        const Mat<3, 3> PoseP1 = la::so3_from_to(s.g_est, ey);
+        const Mat<3, 3> PoseP2 = la::so3_from_to(PoseP1 * s.u_est, ex);
+        s.Pose = PoseP2 * PoseP1;
+        s.Pos = s.Pos + (-s.Pose) * s.Vgva * s.K;
+        s.Posgva = s.Pos;
+        s.Posgv = s.Posgv + (-s.Pose) * sn.Vgv * s.K;
+    }
+    put(p.Pose, s.Pose);
+    put(p.Pos, s.Pos);
+    p.K = s.K;
+    s.n_frame++;
+}
+
+__global__ __launch_bounds__(64) void k_imu_record(const ImuFilterDev *__restrict__ filters, const ImuSnap *__restrict__ snaps, edgehip_nav *__restrict__ nav,
+                           edgehip_nav_imu *__restrict__ nav_imu, edgehip_nav *__restrict__ nav_log, int nav_log_len, int nseq) {
+    const int seq = blockIdx.x * blockDim.x + threadIdx.x;
+    if (seq >= nseq) return;
+    const ImuFilterDev &s = filters[seq];
     const ImuSnap &sn = snaps[seq];
     edgehip_nav &o = nav[seq];
     edgehip_nav_imu &oi = nav_imu[seq];
@@ -274,41 +322,6 @@ __global__ __launch_bounds__(64) void k_imu_post(SeqDev *seqs, ImuFilterDev *fil
     if (have_pair) {
         const double dt = sn.dt;
         const Mat<3, 3> R = sn.R;
-        if (sn.x_grav_set) la::set_slice(s.X, 1, sn.x_grav);
-        s.se.EstAcelLsq4((-sn.Vgv) / dt, s.Av, R, dt);                          // :280
-        s.se.MeanAcel4(sn.cacel, s.As, R);
-        Vec<6> Xgva = sn.Xgv;
-        s.Rgva = sn.R_pre;
-        if (s.n_frame > 4 + ip.init_bias_frame_num) {                           // :291-312
-            s.K = rebvo::ScaleEstimator::estKaGMEKBias(s.As, s.Av, 1, R, s.X, s.P, s.Qg, sn.Qrot, s.Qbias, sn.QKp, s.Rg, s.Rs, sn.Rv,
-                                                       s.g_est, s.b_est, sn.W_Xgv, Xgva, ip.g_module);
-            s.dVgva = la::slice<3>(Xgva, 0);
-            s.dWgva = la::slice<3>(Xgva, 3);
-            const Mat<3, 3> R0gva = la::so3_exp(s.dWgva);
-            s.Rgva = la::transpose(R0gva * la::transpose(s.Rgva));
-            s.Vgva = R0gva * sn.Vg + s.dVgva;
-        } else {
-            s.dVgva = sn.dVgv;
-            s.dWgva = sn.dWgv;
-            s.Rgva = R;
-            s.Vgva = sn.Vgv;
-        }
-        if (s.n_frame > 4 + ip.init_bias_frame_num) {                           // :521-541
-            s.u_est = la::transpose(s.Rgva) * s.u_est;
-            s.u_est = s.u_est - s.g_est * (la::dot(s.u_est, s.g_est) / la::dot(s.g_est, s.g_est));
-            s.u_est = s.u_est / sqrt(la::dot(s.u_est, s.u_est));                // TooN::normalize
-            Vec<3> ey = Vec<3>::zeros(), ex = Vec<3>::zeros();
-            ey[1] = 1; ex[0] = 1;
-            const Mat<3, 3> PoseP1 = la::so3_from_to(s.g_est, ey);
-            const Mat<3, 3> PoseP2 = la::so3_from_to(PoseP1 * s.u_est, ex);
-            s.Pose = PoseP2 * PoseP1;
-            s.Pos = s.Pos + (-s.Pose) * s.Vgva * s.K;
-            s.Posgva = s.Pos;
-            s.Posgv = s.Posgv + (-s.Pose) * sn.Vgv * s.K;
-        }
-        put(p.Pose, s.Pose);
-        put(p.Pos, s.Pos);
-        p.K = s.K;
         const Vec<3> V = v3(sn.V);
         // the record (:550-606)
         oi.dt = dt; oi.K = s.K; oi.Kp = sn.Kp; oi.RKp = sn.P_Kp; oi.s_rho_q = sn.s_rho_q; oi.scale = s.K;
@@ -327,7 +340,6 @@ __global__ __launch_bounds__(64) void k_imu_post(SeqDev *seqs, ImuFilterDev *fil
         oi.klm_num = sn.klm_num;
         oi.estimation_ok = sn.estimation_ok && sn.est_ok;
         oi.init = sn.init;
-        s.n_frame++;
     }
     // the common record, as k_frame_glue (mode 3) fills it
     o.t = sn.t_cur; o.dt = sn.dt;
@@ -373,7 +385,7 @@ int imu_pose_reset_enqueue(edgehip_ctx *c, int seq) {
 }
 static ImuSnap *snap_of(edgehip_ctx *c) { return (ImuSnap *)c->imu_snap + (size_t)(c->frames_seen & 1) * c->plan.nseq; }
 
-// start of a frame's IMU work on the main stream: its snapshot slot was last read by k_imu_post two frames ago
+// start of a frame's IMU work on the main stream: its snapshot slot was last read by k_imu_filter / k_imu_record two frames ago
 int imu_begin_enqueue(edgehip_ctx *c) {
     const int b = c->frames_seen & 1;
     if (c->imu_post_valid[b]) EH_CHECK(hipStreamWaitEvent(c->stream, c->ev_imu_post[b], 0));
@@ -391,10 +403,21 @@ int imu_mid_enqueue(edgehip_ctx *c) {
     hipLaunchKernelGGL(k_imu_mid, dim3((B + 63) / 64), dim3(64), 0, c->stream, c->seq, (ImuTrackDev *)c->imu_track, snap_of(c),
                        c->partials, c->rot_buf, c->imu_params, nblk, c->nblk_tvr, B);
     EH_LAUNCH_CHECK();
+    // the scale filter + pose of this frame: on the IMU stream from here on, under the frame's matching and mapping
+    const int b = c->frames_seen & 1;
+    EH_CHECK(hipEventRecord(c->ev_imu_mid[b], c->stream));
+    EH_CHECK(hipStreamWaitEvent(c->stream_imu, c->ev_imu_mid[b], 0));
+    {
+        ProfScope ps(c, PROF_IMU_SCALE_POSE, c->stream_imu);
+        static const int bs = []() { const char *e = getenv("EDGEHIP_IMU_BLOCK"); const int v = e ? atoi(e) : 64; return v > 0 && v <= 64 ? v : 64; }();
+        hipLaunchKernelGGL(k_imu_filter, dim3((B + bs - 1) / bs), dim3(bs), 0, c->stream_imu, c->seq, (ImuFilterDev *)c->imu_filter, snap_of(c),
+                           c->imu_params, B);
+        EH_LAUNCH_CHECK();
+    }
     return 0;
 }
-// end of the frame: snapshot on the main stream, then scale filter + pose + record on the IMU stream (they overlap the next
-// frame; the nav records are complete once that stream is — every reader synchronises both)
+// end of the frame: snapshot on the main stream, then the frame's records on the IMU stream, behind the scale filter + pose that
+// imu_mid_enqueue put there (the nav records are complete once that stream is — every reader synchronises both)
 int imu_post_enqueue(edgehip_ctx *c, int slot_new, int have_pair) {
     const int B = c->plan.nseq, b = c->frames_seen & 1;
     hipLaunchKernelGGL(k_imu_snap, dim3((B + 63) / 64), dim3(64), 0, c->stream, c->seq, (ImuTrackDev *)c->imu_track, snap_of(c),
@@ -402,13 +425,9 @@ int imu_post_enqueue(edgehip_ctx *c, int slot_new, int have_pair) {
     EH_LAUNCH_CHECK();
     EH_CHECK(hipEventRecord(c->ev_imu_snap[b], c->stream));
     EH_CHECK(hipStreamWaitEvent(c->stream_imu, c->ev_imu_snap[b], 0));
-    {
-        ProfScope ps(c, PROF_IMU_SCALE_POSE, c->stream_imu);
-        static const int bs = []() { const char *e = getenv("EDGEHIP_IMU_BLOCK"); const int v = e ? atoi(e) : 64; return v > 0 && v <= 64 ? v : 64; }();
-        hipLaunchKernelGGL(k_imu_post, dim3((B + bs - 1) / bs), dim3(bs), 0, c->stream_imu, c->seq, (ImuFilterDev *)c->imu_filter, snap_of(c),
-                           c->nav_dev, c->nav_imu_dev, c->imu_params, c->nav_log, c->nav_log_len, B);
-        EH_LAUNCH_CHECK();
-    }
+    hipLaunchKernelGGL(k_imu_record, dim3((B + 63) / 64), dim3(64), 0, c->stream_imu, (const ImuFilterDev *)c->imu_filter, snap_of(c),
+                       c->nav_dev, c->nav_imu_dev, c->nav_log, c->nav_log_len, B);
+    EH_LAUNCH_CHECK();
     EH_CHECK(hipEventRecord(c->ev_imu_post[b], c->stream_imu));
     c->imu_post_valid[b] = true;
     return 0;
@@ -431,18 +450,18 @@ int edgehip_imu_enable(edgehip_ctx *c, const edgehip_imu_params *imu) {
         // instead of enabling the branch with null pointers.
         void *track = nullptr, *filter = nullptr, *snap = nullptr, *in_dev = nullptr, *nav_dev = nullptr, *pin_in = nullptr, *pin_nav = nullptr;
         hipStream_t st = nullptr;
-        hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
+        hipEvent_t ev[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
         bool ok = hipMalloc(&track, sizeof(ImuTrackDev) * B) == hipSuccess && hipMalloc(&filter, sizeof(ImuFilterDev) * B) == hipSuccess &&
                   hipMalloc(&snap, sizeof(ImuSnap) * B * 2) == hipSuccess && hipMalloc(&in_dev, sizeof(edgehip_imu_integrated) * B) == hipSuccess &&
                   hipMalloc(&nav_dev, sizeof(edgehip_nav_imu) * B) == hipSuccess &&
                   hipHostMalloc(&pin_in, sizeof(edgehip_imu_integrated) * B * 8, hipHostMallocDefault) == hipSuccess &&
                   hipHostMalloc(&pin_nav, sizeof(edgehip_nav_imu) * B, hipHostMallocDefault) == hipSuccess &&
                   hipStreamCreateWithFlags(&st, hipStreamNonBlocking) == hipSuccess;
-        for (int i = 0; ok && i < 4; i++) ok = hipEventCreateWithFlags(&ev[i], hipEventDisableTiming) == hipSuccess;
+        for (int i = 0; ok && i < 6; i++) ok = hipEventCreateWithFlags(&ev[i], hipEventDisableTiming) == hipSuccess;
         if (ok) ok = hipMemsetAsync(nav_dev, 0, sizeof(edgehip_nav_imu) * B, c->stream) == hipSuccess;
         if (!ok) {
             (void)hipGetLastError();
-            for (int i = 0; i < 4; i++) if (ev[i]) (void)hipEventDestroy(ev[i]);
+            for (int i = 0; i < 6; i++) if (ev[i]) (void)hipEventDestroy(ev[i]);
             if (st) (void)hipStreamDestroy(st);
             if (pin_nav) (void)hipHostFree(pin_nav);
             if (pin_in) (void)hipHostFree(pin_in);
@@ -454,7 +473,7 @@ int edgehip_imu_enable(edgehip_ctx *c, const edgehip_imu_params *imu) {
         c->imu_in_dev = (edgehip_imu_integrated *)in_dev; c->nav_imu_dev = (edgehip_nav_imu *)nav_dev;
         c->pinned_imu = (edgehip_imu_integrated *)pin_in; c->pinned_nav_imu = (edgehip_nav_imu *)pin_nav;
         c->stream_imu = st;
-        for (int i = 0; i < 2; i++) { c->ev_imu_snap[i] = ev[i]; c->ev_imu_post[i] = ev[2 + i]; c->imu_post_valid[i] = false; }
+        for (int i = 0; i < 2; i++) { c->ev_imu_snap[i] = ev[i]; c->ev_imu_post[i] = ev[2 + i]; c->ev_imu_mid[i] = ev[4 + i]; c->imu_post_valid[i] = false; }
         c->imu_pinned_ok = true;
     }
     c->imu_params = *imu;
