@@ -341,13 +341,29 @@ static int create_body(edgehip_ctx *c, CtxAllocs *al, const edgehip_params &p, i
     // dependent kernels on the device is the same inside a graph.
     c->use_graph = getenv("EDGEHIP_GRAPH") ? atoi(getenv("EDGEHIP_GRAPH")) != 0 : false;
     c->prof = new Profiler();
-    EH_CHECK(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
     // Stage A gets a stream of its own only when it may overlap stages B/C (EDGEHIP_OVERLAP=1).  Otherwise it is the main
     // stream under another name: a hop between two streams costs a single camera 12-16 us of idle device, twice per frame.
-    if (getenv("EDGEHIP_OVERLAP") && atoi(getenv("EDGEHIP_OVERLAP")) != 0) {
-        EH_CHECK(hipStreamCreateWithFlags(&c->stream_a, hipStreamNonBlocking));
+    // EDGEHIP_A_CUS=k (with overlap): the two streams get disjoint CU sets, k of a device's CUs for stage A (bits of the CU
+    // mask in numbering order: the driver deals them round-robin over the XCDs) and the rest for the tracker / mapper.
+    const bool ovl = getenv("EDGEHIP_OVERLAP") && atoi(getenv("EDGEHIP_OVERLAP")) != 0;
+    const int a_cus = (ovl && getenv("EDGEHIP_A_CUS")) ? atoi(getenv("EDGEHIP_A_CUS")) : 0;
+    if (a_cus > 0) {
+        hipDeviceProp_t prop;
+        EH_CHECK(hipGetDeviceProperties(&prop, device));
+        const int ncu = prop.multiProcessorCount;
+        if (a_cus >= ncu) { set_error("EDGEHIP_A_CUS: must leave CUs for the tracker"); return EDGEHIP_ERR_ARG; }
+        const int words = (ncu + 31) / 32;
+        std::vector<uint32_t> ma(words, 0u), mb(words, 0u);
+        for (int i = 0; i < ncu; i++) (i < a_cus ? ma : mb)[i / 32] |= 1u << (i % 32);
+        EH_CHECK(hipExtStreamCreateWithCUMask(&c->stream, (uint32_t)words, mb.data()));
+        EH_CHECK(hipExtStreamCreateWithCUMask(&c->stream_a, (uint32_t)words, ma.data()));
     } else {
-        c->stream_a = c->stream;
+        EH_CHECK(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
+        if (ovl) {
+            EH_CHECK(hipStreamCreateWithFlags(&c->stream_a, hipStreamNonBlocking));
+        } else {
+            c->stream_a = c->stream;
+        }
     }
     EH_CHECK(hipStreamCreateWithFlags(&c->stream_up, hipStreamNonBlocking));
     for (int i = 0; i < 4; i++) { EH_CHECK(hipEventCreateWithFlags(&c->ev_up[i], hipEventDisableTiming)); c->up_valid[i] = false; c->slot_ring[i] = -1; c->a_api_valid[i] = false; c->grec_ok[i] = false; }
