@@ -1039,6 +1039,16 @@ def main():
                 extras[name]["wall_s"] = round(time.perf_counter() - t_sub, 1)
             except Exception as e:
                 extras[name] = {"value": None, "error": f"{type(e).__name__}: {e}"[:300]}
+        # ... and what GlobalConfig_EuRoC ships with for ONE camera (ImuMode=2, one sequence per launch)
+        try:
+            out = subprocess.run([sys.executable, os.path.abspath(__file__), "--no-extras", "--imu", "--nseq", "1", "--steps", "200",
+                                  "--warmup", "12", "--cpu-frames", "0"], capture_output=True, text=True, timeout=300)
+            js = next(json.loads(ln) for ln in reversed(out.stdout.splitlines()) if ln.startswith("{"))
+            if isinstance(extras.get("imu"), dict):
+                extras["imu"]["single_sequence_ms_per_frame"] = js["ms_per_step"]
+        except Exception as e:
+            if isinstance(extras.get("imu"), dict):
+                extras["imu"]["single_sequence_error"] = f"{type(e).__name__}: {e}"[:200]
         line["extras"] = extras
     if world == 1 and not args.no_extras and args.config == "full" and not args.imu:
         line["pcie_inclusive"] = pcie_inclusive(edgehip, params, frames, offs, B, K, max(Wm, 4), local_rank)
