@@ -102,7 +102,10 @@ typedef struct edgehip_seq_state {
     float retuned_thresh;       /* edge_finder::reTunedThresh of the newest slot */
     int32_t l_kl_num;           /* KeyLines on the last edge map (P-controller input) */
     int32_t frame;              /* frames detected so far */
-    int32_t klm_fwd, klm_num, kf_matchs;
+    int32_t klm_fwd;            /* KeyLines of the new edge map that received a forward match.  (edge_tracker::FordwardMatch returns the
+                                   number of assignments it made, the ones it later overwrote on a double match included; SecondThread
+                                   overwrites that value with directed_matching's before anything reads it, rebvo_second_t.cpp:354 / 410.) */
+    int32_t klm_num, kf_matchs; /* directed_matching: matched KeyLines, key-frame matches among them */
     int32_t estimation_ok;
     int32_t minimizer_evals;    /* TryVelRot evaluations spent on the last frame pair */
 } edgehip_seq_state;
