@@ -252,6 +252,7 @@ struct edgehip_ctx {
                                    // 2 keys by the minimiser + k_fwd_win + k_fwd_apply_rotate (one scattering pass over the old KeyLines)
     bool fwd_fill[4] = {false, false, false, false};   // [slot] its detector left the forwarded KeyLine fields to FordwardMatch (fill mode)
     bool fwd_cleared = false;      // fwd_key / fwd_win of the new edge map were reset by k_field_bin (whole-frame driver)
+    bool fwd_keys_posted = false;   // minimizer_v_enqueue: its last evaluation posted FordwardMatch's keys
     bool fwd_key_in_tvr = false;   // whole-frame driver: the minimiser's last evaluation also posts FordwardMatch's arbitration keys
     double *rs_tmp;        // [B][2][CAP] regularised (rho, s_rho) ping-pong
     double *rot_buf;       // [B][9] rotation applied by rotate_keylines

@@ -1607,7 +1607,7 @@ __global__ __launch_bounds__(256) void k_try_vel(TvrArgs a) {
     int status = 0, mid_f = -1;
     double fi = 0;
     bool resolved = false;   // the entry held a marker: if this evaluation leaves it alone, the resolved value goes back
-    double rkeep = 0;
+    double rkeep = 0, rho_own = 0;
     if (ikl < kn) {
         const float nm = ko.n_m[ikl];
         const double s_rho = ko.s_rho[ikl];
@@ -1624,7 +1624,8 @@ __global__ __launch_bounds__(256) void k_try_vel(TvrArgs a) {
             rkeep = rprev;
             if (rprev > a.k_huber) weight = a.k_huber / rprev;
             const float2 pm = ko.p_m[ikl];
-            const double z_p = 1.0 / ko.rho[ikl] + v2;
+            rho_own = ko.rho[ikl];
+            const double z_p = 1.0 / rho_own + v2;
             bool done = false;
             double f = 0, rho_p = 0, pjx = 0, pjy = 0;
             int x = 0, y = 0;
@@ -1708,6 +1709,9 @@ __global__ __launch_bounds__(256) void k_try_vel(TvrArgs a) {
         }
     }
     if (ikl < kn) ko.m_id_f[ikl] = mid_f;                      // kl.m_id_f = -1 / match, every evaluation
+    // the minimisation's last evaluation (the one whose m_id_f FordwardMatch will read) also posts FordwardMatch's arbitration key
+    // of the matched new KeyLine, as k_try_velrot's does: no k_fwd_key pass
+    if (a.fwd_key && mid_f >= 0) atomicMax(&a.fwd_key[(size_t)seq * a.cap + mid_f], ord_bits(rho_own));
     __shared__ double s_red[4][16];
     {
         double v[16];
@@ -2194,11 +2198,16 @@ int minimizer_v_enqueue(edgehip_ctx *c, int slot_new, int slot_old, int fc_index
     static_assert(kTvrBlock == 256, "k_try_vel shares the per-block tables of k_try_velrot");
     EH_CHECK(hipMemsetAsync(c->resid, 0, sizeof(double) * pl.nseq * pl.cap, c->stream));   // residuals[i] = 0
     TvrArgs a = make_tvr_args(c, slot_new, slot_old, match_thresh, reweight_distance, match_num_thresh, 1);
+    a.fwd_key = nullptr;
+    // the last evaluation posts FordwardMatch's keys when k_field_bin left the arbitration arrays cleared (whole-frame driver)
+    c->fwd_keys_posted = c->fwd_cleared;
     const int32_t *kn_old = c->kn_slot + (size_t)slot_old * pl.nseq;
-    auto eval = [&](bool use_new) {
+    auto eval = [&](bool use_new, bool last) {
         dim3 g(nblk256, 1, pl.nseq), b(256);
-        if (use_new) hipLaunchKernelGGL((k_try_vel<true>), g, b, 0, c->stream, a);
-        else hipLaunchKernelGGL((k_try_vel<false>), g, b, 0, c->stream, a);
+        TvrArgs al = a;
+        if (last && c->fwd_keys_posted) al.fwd_key = c->fwd_key;
+        if (use_new) hipLaunchKernelGGL((k_try_vel<true>), g, b, 0, c->stream, al);
+        else hipLaunchKernelGGL((k_try_vel<false>), g, b, 0, c->stream, al);
     };
     auto step = [&](unsigned ops) {
         hipLaunchKernelGGL(k_lmv_step, dim3(pl.nseq), dim3(64), 0, c->stream, c->seq, c->partials, c->block_last, c->resid_carry,
@@ -2207,10 +2216,10 @@ int minimizer_v_enqueue(edgehip_ctx *c, int slot_new, int slot_old, int fc_index
             hipLaunchKernelGGL(k_tv_resolve, dim3(nblk256, 1, pl.nseq), dim3(256), 0, c->stream, c->resid, c->resid_carry, kn_old,
                                pl.cap, c->nblk_tvr);
     };
-    eval(false);
+    eval(false, iter_max <= 0);
     step(LMV_BEGIN | LMV_REDUCE_CUR | (iter_max > 0 ? LMV_SOLVE : LMV_FINISH));
     for (int it = 0; it < iter_max; it++) {
-        eval(true);
+        eval(true, it == iter_max - 1);
         step(LMV_REDUCE_NEW | LMV_GAIN | (it < iter_max - 1 ? LMV_SOLVE : LMV_FINISH));
     }
     EH_LAUNCH_CHECK();

@@ -1548,7 +1548,8 @@ static int frame_enqueue(edgehip_ctx *c, int sn, int so, int sp, int have_pair, 
                 EH_TRY(minimizer_v_enqueue(c, sn, so, c->frames_seen % kRefRing, c->p.tracker_iter_num, c->p.tracker_match_thresh,
                                            c->p.match_num_thresh, c->p.reweight_distance));          // :223
             }
-            EH_TRY(forward_match_enqueue(c, so, sn));                                                // :230
+            EH_TRY(forward_match_enqueue(c, so, sn, c->fwd_keys_posted));                            // :230
+            c->fwd_keys_posted = false;
             { ProfScope ps(c, PROF_C_EXTROTVEL); EH_TRY(ext_rotvel_enqueue(c, sn)); }                 // :237
             { ProfScope ps(c, PROF_IMU_FILTERS); EH_TRY(imu_mid_enqueue(c)); }                             // :237-272, :387-397
             EH_TRY(rotate_buf_enqueue(c, so));                                                       // :319
