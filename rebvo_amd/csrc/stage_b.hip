@@ -1653,7 +1653,18 @@ __global__ __launch_bounds__(256) void k_try_vel(TvrArgs a) {
                 const uint32_t fv = a.field16[(size_t)seq * a.f16stride + field16_index(x, y, a.f16tx)];
                 if (fv != 0u) {
                     const int ikf = (int)fv - 1;
-                    const MatchRec fr = a.kl_new[seq].rec[ikf];
+                    // the matched KeyLine's c_p, m_m, u_m: the 16-byte record with u_m = m_m / |m_m| recomputed by the detector's own
+                    // float expressions when nothing has rotated the new edge map since detection (a.use_grec), as in k_try_velrot
+                    MatchRec fr;
+                    if (a.use_grec) {
+                        const float4 g = a.kl_new[seq].grec[ikf];
+                        fr.c_px = g.x; fr.c_py = g.y; fr.m_mx = g.z; fr.m_my = g.w;
+                        const float n2m = g.z * g.z + g.w * g.w;
+                        const float nmf = sqrtf(n2m);
+                        fr.u_mx = g.z / nmf; fr.u_my = g.w / nmf;
+                    } else {
+                        fr = a.kl_new[seq].rec[ikf];
+                    }
                     const float2 klm = ko.m_m[ikl];
                     const double p_n2 = (double)(nm * nm);                 // Test_f_k
                     const double p_esc = (double)(klm.x * fr.m_mx + klm.y * fr.m_my);
