@@ -1607,24 +1607,32 @@ __global__ __launch_bounds__(256) void k_try_vel(TvrArgs a) {
     int status = 0, mid_f = -1;
     double fi = 0;
     bool resolved = false;   // the entry held a marker: if this evaluation leaves it alone, the resolved value goes back
-    double rkeep = 0, rho_own = 0;
+    double rkeep = 0, rho_own = 0, res_old = 0;
     if (ikl < kn) {
+        // everything the KeyLine streams in is requested before the first use (as in k_try_velrot): with the loads inside the
+        // branches the skip test, the projection and the two gathers each paid their own memory round trip
         const float nm = ko.n_m[ikl];
         const double s_rho = ko.s_rho[ikl];
+        const int32_t mnum = ko.m_num[ikl];
+        const double res_in = res[ikl];
+        res_old = res_in;
+        const float2 pm_in = ko.p_m[ikl];
+        const double rho_in = ko.rho[ikl];
+        const float2 klm_in = ko.m_m[ikl];
         const uint32_t fc = a.framecount[seq];
         const uint32_t mthr = a.match_num_thresh < fc ? a.match_num_thresh : fc;
         const float min_mod = sq->mv_min_mod;
-        const bool skip = (min_mod > 0 && nm < min_mod) || s_rho > sq->mv_s_rho_min || (uint32_t)ko.m_num[ikl] < mthr;
+        const bool skip = (min_mod > 0 && nm < min_mod) || s_rho > sq->mv_s_rho_min || (uint32_t)mnum < mthr;
         if (!skip) {
             double weight = 1;
-            double rprev = res[ikl];
+            double rprev = res_in;
             // a marker of the evaluation before: the carry k_lmv_step resolved for this block (the pass that used to rewrite the
             // buffer between two evaluations, k_tv_resolve, now runs after the last one only)
             if (is_carry(rprev)) { rprev = a.resid_carry[(size_t)seq * a.nblk + blk]; resolved = true; }
             rkeep = rprev;
             if (rprev > a.k_huber) weight = a.k_huber / rprev;
-            const float2 pm = ko.p_m[ikl];
-            rho_own = ko.rho[ikl];
+            const float2 pm = pm_in;
+            rho_own = rho_in;
             const double z_p = 1.0 / rho_own + v2;
             bool done = false;
             double f = 0, rho_p = 0, pjx = 0, pjy = 0;
@@ -1665,7 +1673,7 @@ __global__ __launch_bounds__(256) void k_try_vel(TvrArgs a) {
                     } else {
                         fr = a.kl_new[seq].rec[ikf];
                     }
-                    const float2 klm = ko.m_m[ikl];
+                    const float2 klm = klm_in;
                     const double p_n2 = (double)(nm * nm);                 // Test_f_k
                     const double p_esc = (double)(klm.x * fr.m_mx + klm.y * fr.m_my);
                     if (!(fabs(p_esc - p_n2) > a.match_thresh * p_n2)) {
@@ -1709,8 +1717,8 @@ __global__ __launch_bounds__(256) void k_try_vel(TvrArgs a) {
             res[ikl] = v;
         } else if (status == 2) {
             res[ikl] = afi;
-        } else if (resolved) {
-            res[ikl] = rkeep;
+        } else if (ikl < kn) {
+            res[ikl] = resolved ? rkeep : res_old;   // unchanged entries are rewritten too: whole-line stores (a partial line is a read-modify-write)
         }
         if (tid == 0) {
             double bl = marker;
