@@ -345,7 +345,13 @@ static int create_body(edgehip_ctx *c, CtxAllocs *al, const edgehip_params &p, i
     // stream under another name: a hop between two streams costs a single camera 12-16 us of idle device, twice per frame.
     // EDGEHIP_A_CUS=k (with overlap): the two streams get disjoint CU sets, k of a device's CUs for stage A (bits of the CU
     // mask in numbering order: the driver deals them round-robin over the XCDs) and the rest for the tracker / mapper.
-    const bool ovl = getenv("EDGEHIP_OVERLAP") && atoi(getenv("EDGEHIP_OVERLAP")) != 0;
+    // Default: on for the batches the multi-kernel stage A serves (a live camera, a handful of sequences): their kernels leave most
+    // of the device idle, so the next frame's detection runs beside this frame's tracking and mapping — what the reference's first
+    // and second thread do — 0.36 -> 0.32 ms per frame for one sequence, 0.47 -> 0.39 for eight.  Off for whole batches, whose
+    // stage A fills every CU by itself (+-0, and per-kernel times stop being attributable), and under frame graphs (one stream).
+    const int fused_min_env = getenv("EDGEHIP_FUSED_MIN_BATCH") ? atoi(getenv("EDGEHIP_FUSED_MIN_BATCH")) : 192;
+    const bool ovl = getenv("EDGEHIP_OVERLAP") ? atoi(getenv("EDGEHIP_OVERLAP")) != 0 : (nseq < fused_min_env && !c->use_graph);
+    c->overlap = ovl ? 1 : 0;
     const int a_cus = (ovl && getenv("EDGEHIP_A_CUS")) ? atoi(getenv("EDGEHIP_A_CUS")) : 0;
     if (a_cus > 0) {
         hipDeviceProp_t prop;
@@ -461,7 +467,6 @@ static int create_body(edgehip_ctx *c, CtxAllocs *al, const edgehip_params &p, i
     c->level_mode = getenv("EDGEHIP_LEVEL_MODE") ? atoi(getenv("EDGEHIP_LEVEL_MODE")) : 0;
     c->fwd_mode = getenv("EDGEHIP_FWD_MODE") ? atoi(getenv("EDGEHIP_FWD_MODE")) : 0;
     c->fused_min_batch = getenv("EDGEHIP_FUSED_MIN_BATCH") ? atoi(getenv("EDGEHIP_FUSED_MIN_BATCH")) : 192;   // one workgroup per sequence: pays from about 3/4 of the 256 CUs on (tools/experiments/ab_level_mode.sh)
-    c->overlap = getenv("EDGEHIP_OVERLAP") ? atoi(getenv("EDGEHIP_OVERLAP")) : 0;
     c->persist_lm_max = getenv("EDGEHIP_PERSIST_LM") ? atoi(getenv("EDGEHIP_PERSIST_LM")) : 0;   // measured: no gain (tools/experiments/exp_single_latency.py), so off
     EH_TRY(dmalloc(c, &c->sync_cnt, B, al->dev, 0));
     EH_TRY(dmalloc(c, &c->fwd_key, B * CAP, al->dev, 0));

@@ -39,15 +39,21 @@ def test_a_sequence_does_not_depend_on_the_batch_it_runs_in(w, h, B):
     assert n_small[-1][0].kn > 2000 and n_small[-1][0].estimation_ok == 1
 
 
-def test_single_sequence_with_frame_graphs_matches_eager(monkeypatch):
-    """EDGEHIP_GRAPH=1 replays whole-frame graphs of the same launches (the page-locked rows of time stamps and bound frame
-    indices are baked into the nodes: one graph per ring entry)."""
+def test_single_sequence_stream_orders_agree(monkeypatch):
+    """The three ways a small batch's launches can be ordered: the default (stage A of the next frame on a stream of its own,
+    beside this frame's tracking and mapping), EDGEHIP_OVERLAP=0 (one stream, no events) and EDGEHIP_GRAPH=1 (whole-frame graphs
+    of the same launches; the page-locked rows of time stamps and bound frame indices are baked into the nodes: one graph per
+    ring entry)."""
     w, h = 376, 240
     pool = [f for f, _, _ in synth.billboard_sequence(w, h, 6, seed=4)]
     outs = []
-    for g in ("0", "1"):
-        monkeypatch.setenv("EDGEHIP_GRAPH", g)
+    for env in ({}, {"EDGEHIP_OVERLAP": "0"}, {"EDGEHIP_GRAPH": "1"}):
+        for k in ("EDGEHIP_OVERLAP", "EDGEHIP_GRAPH"):
+            monkeypatch.delenv(k, raising=False)
+        for k, v in env.items():
+            monkeypatch.setenv(k, v)
         outs.append(_run(w, h, 1, pool, 30, edgehip.euroc_params(w, h)))
-    for a, b in zip(outs[0][0], outs[1][0]):
-        assert bytes(a[0]) == bytes(b[0])
-    assert outs[0][1][0][0].tobytes() == outs[1][1][0][0].tobytes()
+    for other in outs[1:]:
+        for a, b in zip(outs[0][0], other[0]):
+            assert bytes(a[0]) == bytes(b[0])
+        assert outs[0][1][0][0].tobytes() == other[1][0][0].tobytes()
