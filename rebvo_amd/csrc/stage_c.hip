@@ -1524,7 +1524,9 @@ static int frame_enqueue(edgehip_ctx *c, int sn, int so, int sp, int have_pair, 
     // mode 2 keeps its scattering pass, which cannot fill)
     bool frame_ended = false;
     const bool begin_in_quantile = have_pair != 0;                  // k_quantile, the first kernel of stage B, does it per sequence
-    const bool retune_in_quantile = begin_in_quantile && sp < 0;    // ... and finishes the detector's reEstimateThresh (the pair image's stage A would overwrite its histogram)
+    // ... and finishes the detector's reEstimateThresh — unless something may overwrite the histogram and the detector's extremes before
+    // k_quantile has read them: the pair image's stage A, or (with overlap) the next frame's, which runs beside this frame's stage B
+    const bool retune_in_quantile = begin_in_quantile && sp < 0 && !c->overlap;
     EH_TRY(stage_a_enqueue(c, sn, have_pair && c->fwd_mode != 2, retune_in_quantile));
     if (sp >= 0) EH_TRY(stage_a_enqueue(c, sp));   // the pair image, after the main one as in rebvo_first_t.cpp:259-290
     if (c->stream_a != c->stream) {   // (one stream: already in order, and an event record is a packet the device has to work through)

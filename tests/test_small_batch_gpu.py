@@ -57,3 +57,18 @@ def test_single_sequence_stream_orders_agree(monkeypatch):
         for a, b in zip(outs[0][0], other[0]):
             assert bytes(a[0]) == bytes(b[0])
         assert outs[0][1][0][0].tobytes() == other[1][0][0].tobytes()
+
+
+def test_whole_batch_with_stage_a_overlap_matches_serial(monkeypatch):
+    """EDGEHIP_OVERLAP=1 with the one-kernel stage A: the next frame's detection runs beside this frame's stage B, so nothing of
+    stage B may read what that detection overwrites (the modulus histogram and the detector's extremes: reEstimateThresh's tail is
+    done by k_quantile only when no such overlap is possible)."""
+    w, h, B = 376, 240, 256
+    pool = [f for f, _, _ in synth.billboard_sequence(w, h, 6, seed=4)]
+    outs = []
+    for ov in ("0", "1"):
+        monkeypatch.setenv("EDGEHIP_OVERLAP", ov)
+        outs.append(_run(w, h, B, pool, 16, edgehip.euroc_params(w, h)))
+    for k, (a, b) in enumerate(zip(outs[0][0], outs[1][0])):
+        for s_ in range(B):
+            assert bytes(a[s_]) == bytes(b[s_]), (k, s_)
