@@ -1059,6 +1059,9 @@ def main():
     if sweep:
         line["batch_sweep"] = sweep
         line["single_sequence_ms_per_frame"] = sweep[0]["ms_per_step"]
+        line["single_sequence_note"] = ("rate of back-to-back frames of one sequence; for batches below the one-kernel stage A's threshold the "
+                                        "library runs the next frame's detection beside this frame's tracking and mapping (EDGEHIP_OVERLAP "
+                                        "default), so one frame's way through the path is ~15 % longer than this figure")
     if hetero:
         line["heterogeneous"] = hetero
     print(json.dumps(line))
