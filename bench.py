@@ -1041,11 +1041,14 @@ def main():
                 extras[name] = {"value": None, "error": f"{type(e).__name__}: {e}"[:300]}
         # ... and what GlobalConfig_EuRoC ships with for ONE camera (ImuMode=2, one sequence per launch)
         try:
-            out = subprocess.run([sys.executable, os.path.abspath(__file__), "--no-extras", "--imu", "--nseq", "1", "--steps", "200",
-                                  "--warmup", "12", "--cpu-frames", "0"], capture_output=True, text=True, timeout=300)
-            js = next(json.loads(ln) for ln in reversed(out.stdout.splitlines()) if ln.startswith("{"))
+            best = None
+            for _ in range(3):   # a single camera's frame is ~60 launches: the rate is sensitive to what else the host is doing; best of three
+                out = subprocess.run([sys.executable, os.path.abspath(__file__), "--no-extras", "--imu", "--nseq", "1", "--steps", "200",
+                                      "--warmup", "12", "--cpu-frames", "0"], capture_output=True, text=True, timeout=300)
+                js = next(json.loads(ln) for ln in reversed(out.stdout.splitlines()) if ln.startswith("{"))
+                best = js["ms_per_step"] if best is None else min(best, js["ms_per_step"])
             if isinstance(extras.get("imu"), dict):
-                extras["imu"]["single_sequence_ms_per_frame"] = js["ms_per_step"]
+                extras["imu"]["single_sequence_ms_per_frame"] = best
         except Exception as e:
             if isinstance(extras.get("imu"), dict):
                 extras["imu"]["single_sequence_error"] = f"{type(e).__name__}: {e}"[:200]
