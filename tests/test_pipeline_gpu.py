@@ -13,13 +13,14 @@ from rebvo_amd import edgehip, synth
 pytestmark = pytest.mark.gpu
 
 
-def _run(w, h, n, nseq=1):
+def _run(w, h, n, nseq=1, over=None, min_kn=0):
     from oracle import oracle
     if not oracle.available("ref"):
         pytest.fail("oracle/_ref not built" " — a broken snapshot, not a reason to skip: run __graft_entry__.build(), where the reference tree is present")
+    over = over or {}
     frames = [f for f, _, _ in synth.billboard_sequence(w, h, n)]
-    orc = oracle.Oracle("ref", oracle.euroc_params(w, h))
-    eh = edgehip.EdgeHip(edgehip.euroc_params(w, h), nseq=nseq, nslots=3)
+    orc = oracle.Oracle("ref", oracle.euroc_params(w, h, **over))
+    eh = edgehip.EdgeHip(edgehip.euroc_params(w, h, **over), nseq=nseq, nslots=3)
     path = 0.0
     for k, f in enumerate(frames):
         _, nr = orc.process_frame(f, 0.05 * k)
@@ -50,11 +51,19 @@ def _run(w, h, n, nseq=1):
     assert same.mean() > 0.999
     assert np.allclose(kg["rho"][same], kr["rho"][same], rtol=1e-5, atol=1e-7)
     assert np.allclose(kg["s_rho"][same], kr["s_rho"][same], rtol=1e-5, atol=1e-7)
+    assert len(kg) >= min_kn, len(kg)
     eh.close()
 
 
 def test_pipeline_small():
     _run(376, 240, 8)
+
+
+def test_pipeline_many_keylines():
+    """More than 16384 KeyLines in one sequence: the block tables of the minimiser's steps exceed what their one-go prefetch
+    covers (more than 64 blocks), and k_rescale's small-batch form streams what neither its registers nor its LDS hold."""
+    _run(752, 480, 9, over=dict(max_points=30000, reference_points=27000, track_points=24000, detector_thresh=0.005,
+                                min_thresh=1e-4), min_kn=17000)
 
 
 def test_pipeline_euroc_size():
