@@ -74,10 +74,10 @@ def test_stage_a_euroc_size_billboards():
     assert kn > 5000
 
 
-@pytest.mark.parametrize("w,h", [(320, 600), (1024, 40)], ids=["tall_600_rows", "w1024"])
+@pytest.mark.parametrize("w,h", [(320, 600), (1024, 40), (64, 19), (16, 16)], ids=["tall_600_rows", "w1024", "64x19", "16x16"])
 def test_stage_a_tall_and_wide_images(w, h):
     """More than 512 rows: the small-batch column prefix with 64 rows per wave (k_colscan_chain<16, 64>); more than 768 columns:
-    the tiled box average (k_avg_rowscan<256, 4, 256>) instead of the whole-row one."""
+    the tiled box average (k_avg_rowscan<256, 4, 256>) instead of the whole-row one; fewer rows than two per wave of the column prefix."""
     frames = list(synth.rects_sequence(w, h, 2, seed=7))
     _run(w, h, frames)
 
