@@ -153,7 +153,10 @@ const char *edgehip_last_error(void);
 int edgehip_abi_version(void);
 /* Block the caller until everything enqueued so far has finished. */
 int edgehip_sync(edgehip_ctx *ctx);
-/* The hipStream_t the context launches on, as an opaque pointer (for event timing by the caller). */
+/* The hipStream_t the tracker / mapper kernels (and, for whole batches, everything) are launched on, as an opaque pointer (for event
+ * timing by the caller).  For batches of fewer sequences than the device has CUs the detection of a frame (stage A) runs on a second
+ * stream of the context, beside the tracking and mapping of the frame before, unless EDGEHIP_OVERLAP=0 is set when the context is
+ * created; edgehip_sync and the read-back calls wait for both. */
 void *edgehip_stream(edgehip_ctx *ctx);
 /* Device box-filter widths chosen for (sigma0, ksigma), as iigauss::iigauss does
  * (src/mtracklib/iigauss.cpp:43-81): out[0..2] filter0, out[3..5] filter1. */
