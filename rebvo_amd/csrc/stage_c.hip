@@ -593,10 +593,9 @@ struct FrameEndArgs {
 __device__ inline void frame_end(SeqDev *sq, const int seq, const FrameEndArgs &fe);
 
 // The sums are those of 1024 "virtual" threads (KeyLine i belongs to virtual thread i % 1024, its terms are added in increasing i,
-// the 16 wave sums in wave order), whatever the block: NT = 1024 real threads with PER = 6 KeyLines each in registers over the five
-// passes (whole batches: two blocks per CU, the tail beyond 6144 KeyLines streams every pass), or NT = 512 threads that carry
-// two virtual threads with PER = 12 each (a few sequences: 256 VGPRs per thread hold 12288 KeyLines, so no pass waits for loads).
-// Same additions in the same order, same bits.
+// the 16 wave sums in wave order), whatever the block: NT = 1024 real threads with PER KeyLines each in registers over the five
+// passes, or NT = 512 threads that carry two virtual threads each (the form in use: PER = 12, 256 VGPRs per thread hold 12288
+// KeyLines, so no pass waits for loads).  Same additions in the same order, same bits.
 // fe.nav != null (whole-frame driver, mono, ImuMode 0): the block's first thread goes on to the frame's last step, pose integration
 // and the nav record, which reads the Kp it has just written — the frame ends with this launch.
 // LJ: the next LJ KeyLines of every virtual thread (KeyLines PER*1024 ... (PER+LJ)*1024-1) keep their four constants in LDS
@@ -1223,16 +1222,15 @@ int rescale_enqueue(edgehip_ctx *c, int slot, bool frame_ends) {
         fe.retuned_new = c->retuned_slot + (size_t)slot * pl.nseq;
         fe.nav_log = c->nav_log; fe.nav_log_len = c->nav_log_len; fe.nseq = pl.nseq; fe.have_pair = 1;
     }
-    if (pl.nseq <= 128 && !c->lds_optin_rescale) {   // 128 KB of dynamic LDS: opt in once per context (= per device)
+    // 512 threads with 12 + 12 KeyLines each in registers and the next 4096 in 128 KB of LDS, whatever the batch: for whole batches
+    // the 1024-thread form (6 KeyLines per thread in registers, two blocks per CU, the rest streamed out of L2 five times) took 265 us
+    // per 1024 sequences against 201.
+    if (!c->lds_optin_rescale) {   // 128 KB of dynamic LDS: opt in once per context (= per device)
         EH_CHECK(hipFuncSetAttribute((const void *)&k_rescale<512, 12, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, 4 * 4 * 1024 * (int)sizeof(double)));
         c->lds_optin_rescale = true;
     }
-    if (pl.nseq <= 128)
-        hipLaunchKernelGGL((k_rescale<512, 12, 4>), dim3(pl.nseq), dim3(512), 4 * 4 * 1024 * sizeof(double), c->stream, kldev(c, slot),
-                           c->kn_slot + (size_t)slot * pl.nseq, c->seq, kRhoMax, 1u, c->p.do_rescaling > 0, fe);
-    else
-        hipLaunchKernelGGL((k_rescale<1024, 6, 0>), dim3(pl.nseq), dim3(1024), 0, c->stream, kldev(c, slot),
-                           c->kn_slot + (size_t)slot * pl.nseq, c->seq, kRhoMax, 1u, c->p.do_rescaling > 0, fe);
+    hipLaunchKernelGGL((k_rescale<512, 12, 4>), dim3(pl.nseq), dim3(512), 4 * 4 * 1024 * sizeof(double), c->stream, kldev(c, slot),
+                       c->kn_slot + (size_t)slot * pl.nseq, c->seq, kRhoMax, 1u, c->p.do_rescaling > 0, fe);
     EH_LAUNCH_CHECK();
     return 0;
 }
