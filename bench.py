@@ -1042,7 +1042,10 @@ def main():
         # ... and what GlobalConfig_EuRoC ships with for ONE camera (ImuMode=2, one sequence per launch)
         try:
             best = None
-            for _ in range(3):   # a single camera's frame is ~60 launches: the rate is sensitive to what else the host is doing; best of three
+            # (a single camera's frame is ~60 small launches: its rate moves with the host's launch speed, with a second process
+            # holding the device — this one — and with the clocks a lightly loaded GPU settles at: 0.33 ms per frame measured right
+            # after a loaded phase in a lone process, ~0.5 here; best of three)
+            for _ in range(3):
                 out = subprocess.run([sys.executable, os.path.abspath(__file__), "--no-extras", "--imu", "--nseq", "1", "--steps", "200",
                                       "--warmup", "12", "--cpu-frames", "0"], capture_output=True, text=True, timeout=300)
                 js = next(json.loads(ln) for ln in reversed(out.stdout.splitlines()) if ln.startswith("{"))
