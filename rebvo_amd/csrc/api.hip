@@ -458,8 +458,8 @@ static int create_body(edgehip_ctx *c, CtxAllocs *al, const edgehip_params &p, i
     EH_TRY(dmalloc(c, &c->P0, B * 3 * CAP, al->dev, 0));
     EH_TRY(dmalloc(c, &c->resid, (size_t)kResidBufs * B * CAP, al->dev, 0));
     EH_TRY(dmalloc(c, &c->resid_carry, (size_t)kResidBufs * B * c->nblk_tvr, al->dev, 0));
-    EH_TRY(dmalloc(c, &c->partials, B * c->nblk_tvr * kNumSums, al->dev, 0));
-    EH_TRY(dmalloc(c, &c->block_last, B * c->nblk_tvr, al->dev, 0));
+    EH_TRY(dmalloc(c, &c->partials, 2 * B * c->nblk_tvr * kNumSums, al->dev, 0));   // [2]: running chain, zero-init chain (k_try_velrot2)
+    EH_TRY(dmalloc(c, &c->block_last, 2 * B * c->nblk_tvr, al->dev, 0));
     EH_TRY(dmalloc(c, &c->bin_cnt, B * 256, al->dev, 0));
     {
         const size_t ntiles = (size_t)((p.w + 63) / 64) * ((p.h + 63) / 64);
@@ -471,6 +471,7 @@ static int create_body(edgehip_ctx *c, CtxAllocs *al, const edgehip_params &p, i
     c->level_mode = getenv("EDGEHIP_LEVEL_MODE") ? atoi(getenv("EDGEHIP_LEVEL_MODE")) : 0;
     c->fwd_mode = getenv("EDGEHIP_FWD_MODE") ? atoi(getenv("EDGEHIP_FWD_MODE")) : 0;
     c->fused_min_batch = getenv("EDGEHIP_FUSED_MIN_BATCH") ? atoi(getenv("EDGEHIP_FUSED_MIN_BATCH")) : 192;   // one workgroup per sequence: pays from about 3/4 of the 256 CUs on (tools/experiments/ab_level_mode.sh)
+    c->dual_init = getenv("EDGEHIP_DUAL_INIT") ? atoi(getenv("EDGEHIP_DUAL_INIT")) : 1;
     c->persist_lm_max = getenv("EDGEHIP_PERSIST_LM") ? atoi(getenv("EDGEHIP_PERSIST_LM")) : 0;   // measured: no gain (tools/experiments/exp_single_latency.py), so off
     EH_TRY(dmalloc(c, &c->sync_cnt, B, al->dev, 0));
     EH_TRY(dmalloc(c, &c->fwd_key, B * CAP, al->dev, 0));

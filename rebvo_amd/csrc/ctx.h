@@ -78,6 +78,14 @@ struct SeqDev {
     double s_rho_min_eval;     // s_rho threshold of the running evaluation
     double Rt[9], Vt[3], RM[4];  // rotation / translation / z-rotation of the running evaluation
     int32_t nmatch_tmp, kf_tmp;
+    // The zero-init chain of Minimizer_RV's double initialisation (global_tracker.cpp:649-692) while it runs beside the
+    // prior-init chain (:698-738) in the same launches (k_try_velrot2 / k_lm_step2): the two chains share nothing but their
+    // inputs, so each evaluation launch serves both and this is the second chain's copy of the locals above.
+    double zX[6], zXnew[6], zh[6];
+    double zJtJ[36], zJtF[6], zJtJnew[36], zJtFnew[6];
+    double zF, zFnew, zF0, zu, zv, zgain;
+    double zRt[9], zVt[3], zRM[4];
+    int32_t z_eff_steps, z_pad;
     // 3-DoF minimiser scratch (global_tracker::Minimizer_V locals)
     double mv_V[3], mv_Vnew[3], mv_h[3], mv_JtJ[9], mv_JtF[3], mv_JtJnew[9], mv_JtFnew[3], mv_RVel[9];
     double mv_F, mv_Fnew, mv_u, mv_v, mv_s_rho_min;
@@ -244,6 +252,7 @@ struct edgehip_ctx {
     int32_t *bin_cnt;      // [B][256] KeyLines binned per field tile
     int32_t *bins;         // [B][256][CAP] KeyLine ids per field tile (allocated for the tiles in use)
     int nblk_tvr;
+    int dual_init;         // EDGEHIP_DUAL_INIT (default 1): the two initialisation chains of TrackerInitType = 2 share their launches (stage_b.hip tvr2_body)
     int persist_lm_max;    // batches up to this many sequences fuse every TryVelRot evaluation with the LM step after it (EDGEHIP_PERSIST_LM, 0 = never)
     unsigned *sync_cnt;    // [B] per-sequence block tickets of k_try_velrot_lm (0 between launches)
     unsigned long long *fwd_key;  // [B][CAP] forward-match arbitration keys

@@ -541,16 +541,19 @@ __device__ __noinline__ void tvr_setup(SeqDev *sq, const double *X) {
 // The same on two lanes of a wave: lane 0 takes exp(W) (and Vt), lane 1 exp((0,0,W_z)) — the two exponentials are the longest
 // stretch of the LM step (sin and cos in double precision, 3.6 of its 9 us for a single camera), and they do not depend on
 // each other.  X in LDS / global, visible to both lanes.
-__device__ __forceinline__ void tvr_setup2(SeqDev *sq, const double *X, const int lane) {
-    if (lane < 2) {
-        const double wv[3] = {lane == 0 ? X[3] : 0.0, lane == 0 ? X[4] : 0.0, X[5]};
+// `zero`: the transform of the zero-init chain (zRt / zVt / zRM) instead of the running one; the pair of lanes is (l0, l0 + 1).
+__device__ __forceinline__ void tvr_setup2(SeqDev *sq, const double *X, const int lane, const bool zero = false, const int l0 = 0) {
+    if (lane >= l0 && lane < l0 + 2) {
+        const bool first = lane == l0;
+        const double wv[3] = {first ? X[3] : 0.0, first ? X[4] : 0.0, X[5]};
         double R[9];
         so3_exp_inl(wv, R);   // inlined: R stays in registers (through a call it is scratch memory, a round trip each way)
-        if (lane == 0) {
-            for (int i = 0; i < 9; i++) sq->Rt[i] = R[i];
-            for (int i = 0; i < 3; i++) sq->Vt[i] = X[i];
+        double *Rt = zero ? sq->zRt : sq->Rt, *Vt = zero ? sq->zVt : sq->Vt, *RM = zero ? sq->zRM : sq->RM;
+        if (first) {
+            for (int i = 0; i < 9; i++) Rt[i] = R[i];
+            for (int i = 0; i < 3; i++) Vt[i] = X[i];
         } else {
-            sq->RM[0] = R[0]; sq->RM[1] = R[1]; sq->RM[2] = R[3]; sq->RM[3] = R[4];
+            RM[0] = R[0]; RM[1] = R[1]; RM[2] = R[3]; RM[3] = R[4];
         }
     }
 }
@@ -569,6 +572,8 @@ struct TvrArgs {
     double *resid_carry;       // [kResidBufs][B][nblk]  resolved carry-in per block
     double *block_last;        // [B][nblk] last valid fi of each block (marker NaN if none) of THIS call
     double *partials;          // [B][nblk][kNumSums]
+    double *block_last_z;      // the same two for the zero-init chain of a two-chain evaluation (k_try_velrot2)
+    double *partials_z;
     SeqDev *seq;
     const uint32_t *framecount;  // [B] of the new slot
     int w, h, cap, nblk, nseq;
@@ -924,6 +929,267 @@ __global__ __launch_bounds__(kTvrThreads) void k_try_velrot_kf(TvrArgs a) {
 }
 
 // ---------------------------------------------------------------------------------------------------
+// Two evaluations in one launch: TrackerInitType = 2 runs `init_iter + 1` un-reweighted evaluations from X = 0 and the same
+// number from the prior (Vel, W0) and keeps the better end point (global_tracker.cpp:649-692, 698-738, 740-749).  The two
+// chains are independent: neither reads a residual buffer (ReWeight = false), they write different ones (Rest /
+// ResidualNew), and `FrameCount`, the uncertainty gate and the KeyLines are the same for both.  So evaluation i of the
+// zero-init chain and evaluation i of the prior-init chain go out as ONE launch: the KeyLine's streams (s_rho, m_num, p_m,
+// rho, m_m, n_m: 40 of the evaluation's 84 bytes) are loaded once, P0 is rebuilt once, and the two transforms walk the two
+// dependent gathers side by side (both field reads in flight together, then both record reads) — 12 dependent launches
+// become 9.  Per chain the arithmetic is tvr_body<false, PROCJF, GREC>'s, expression for expression, and each chain keeps
+// its own partial sums / last-residual rows in the same block order: results identical bit for bit to the launch chain
+// (tests/test_pipeline_gpu.py::test_two_chain_evaluation_is_bit_identical_to_the_launch_chain).
+// Chain 0 = zero-init (transform zRt / zVt / zRM, residuals -> res_t, sums -> partials_z), chain 1 = prior-init (Rt / Vt /
+// RM, residuals -> res_new, sums -> partials).
+// ---------------------------------------------------------------------------------------------------
+#ifndef EDGEHIP_TVR2_PARK
+#define EDGEHIP_TVR2_PARK 1   // the second chain's Jacobian row waits in LDS while the first chain's products are reduced
+#endif
+template <bool PROCJF, bool GREC>
+__device__ __forceinline__ void tvr2_body(const TvrArgs &a, const int seq, const int blk, const int tid) {
+    const int lane = tid & 63, wave = tid >> 6;
+    SeqDev *sq = a.seq + seq;
+    const int kn = a.kn_old[seq];
+    if (blk * kTvrBlock >= kn) return;  // whole block beyond the list (block-uniform)
+    static_assert(kTvrPasses == 1, "one KeyLine per thread");
+    const KlSoA &ko = a.kl_old[seq];
+    double *rout0 = a.resid + ((size_t)sq->res_t * a.nseq + seq) * a.cap;
+    double *rout1 = a.resid + ((size_t)sq->res_new * a.nseq + seq) * a.cap;
+    const double marker = __longlong_as_double((long long)resid_carry_bits());
+    constexpr int NW = kTvrThreads / 64;
+    __shared__ double s_wlast[2][NW];
+    __shared__ int s_whas[2][NW];
+
+    const int ikl = blk * kTvrBlock + tid;
+    // per chain: what tvr_body keeps per KeyLine
+    double fm[2] = {0, 0}, dfx[2] = {0, 0}, dfy[2] = {0, 0}, fi[2] = {0, 0};
+    double ptx[2] = {0, 0}, pty[2] = {0, 0}, ptz[2] = {1, 1}, pix[2] = {0, 0}, piy[2] = {0, 0}, rho_p[2] = {1, 1};
+    int status[2] = {0, 0};   // 0 skipped, 1 out of image, 2 matched, 3 evaluated and unmatched (tvr_body)
+    double s_rho = 1;
+    if (ikl < kn) {
+        s_rho = ko.s_rho[ikl];
+        const int32_t mnum = ko.m_num[ikl];
+        const float2 pm0 = ko.p_m[ikl];
+        const double rho0 = ko.rho[ikl];
+        const float2 klm = ko.m_m[ikl];
+        const float knm = ko.n_m[ikl];
+        const uint32_t fc = a.framecount[seq];
+        const uint32_t mthr = a.match_num_thresh < fc ? a.match_num_thresh : fc;
+        const bool skip = s_rho > sq->s_rho_min_eval || (uint32_t)mnum < mthr;  // int vs uint compare
+        if (!skip) {
+            const double sz = 1 / rho0;
+            const double pz_zf0 = (1 / a.zfm) * sz;
+            const double sx = pz_zf0 * (double)pm0.x, sy = pz_zf0 * (double)pm0.y;
+            double px[2], py[2];
+            bool inimg[2];
+            size_t fidx[2];
+            float rmx[2], rmy[2];
+#pragma unroll
+            for (int c = 0; c < 2; c++) {
+                const double *R = c ? sq->Rt : sq->zRt, *V = c ? sq->Vt : sq->zVt, *RM = c ? sq->RM : sq->zRM;
+                ptx[c] = R[0] * sx; ptx[c] += R[1] * sy; ptx[c] += R[2] * sz; ptx[c] = V[0] + ptx[c];
+                pty[c] = R[3] * sx; pty[c] += R[4] * sy; pty[c] += R[5] * sz; pty[c] = V[1] + pty[c];
+                ptz[c] = R[6] * sx; ptz[c] += R[7] * sy; ptz[c] += R[8] * sz; ptz[c] = V[2] + ptz[c];
+                rho_p[c] = 1 / ptz[c];
+                const double pz_zf = a.zfm * rho_p[c];
+                pix[c] = pz_zf * ptx[c];
+                piy[c] = pz_zf * pty[c];
+                px[c] = pix[c] + (double)a.ppx; py[c] = piy[c] + (double)a.ppy;
+                const int x = x86_cvttsd2si(px[c] + 0.5), y = x86_cvttsd2si(py[c] + 0.5);
+                inimg[c] = !(x < 1 || y < 1 || x >= a.w - 1 || y >= a.h - 1);
+                fidx[c] = inimg[c] ? field16_index(x, y, a.f16tx) : (size_t)0;
+                rmx[c] = (float)(RM[0] * (double)klm.x + RM[1] * (double)klm.y);
+                rmy[c] = (float)(RM[2] * (double)klm.x + RM[3] * (double)klm.y);
+                fm[c] = a.max_r;
+                status[c] = inimg[c] ? 3 : 1;
+            }
+            // the two gathers of the two chains, level by level: both field reads are in flight together, then both records
+            // (unconditional loads: an out-of-image projection reads pixel 0, an empty pixel record 0 — results unused)
+            const uint16_t *fld = a.field16 + (size_t)seq * a.f16stride;
+            const uint32_t f0 = fld[fidx[0]], f1 = fld[fidx[1]];
+            const bool hit0 = inimg[0] && f0 != 0u, hit1 = inimg[1] && f1 != 0u;
+            const int ikf0 = hit0 ? (int)f0 - 1 : 0, ikf1 = hit1 ? (int)f1 - 1 : 0;
+            float f_cpx[2], f_cpy[2], f_mx[2], f_my[2], f_ux[2] = {0, 0}, f_uy[2] = {0, 0};
+            if (GREC) {
+                const float4 g0 = a.kl_new[seq].grec[ikf0], g1 = a.kl_new[seq].grec[ikf1];
+                f_cpx[0] = g0.x; f_cpy[0] = g0.y; f_mx[0] = g0.z; f_my[0] = g0.w;
+                f_cpx[1] = g1.x; f_cpy[1] = g1.y; f_mx[1] = g1.z; f_my[1] = g1.w;
+            } else {
+                const MatchRec r0 = a.kl_new[seq].rec[ikf0], r1 = a.kl_new[seq].rec[ikf1];
+                f_cpx[0] = r0.c_px; f_cpy[0] = r0.c_py; f_mx[0] = r0.m_mx; f_my[0] = r0.m_my; f_ux[0] = r0.u_mx; f_uy[0] = r0.u_my;
+                f_cpx[1] = r1.c_px; f_cpy[1] = r1.c_py; f_mx[1] = r1.m_mx; f_my[1] = r1.m_my; f_ux[1] = r1.u_mx; f_uy[1] = r1.u_my;
+            }
+            const double p_n2 = (double)(knm * knm);
+#pragma unroll
+            for (int c = 0; c < 2; c++) {
+                if (c ? hit1 : hit0) {
+                    // Test_f_k (float arithmetic inside, compared in double)
+                    const double p_esc = (double)(rmx[c] * f_mx[c] + rmy[c] * f_my[c]);
+                    if (!(fabs(p_esc - p_n2) > a.match_thresh * p_n2)) {
+                        if (GREC) {
+                            const float n2m = f_mx[c] * f_mx[c] + f_my[c] * f_my[c];
+                            const float nm = sqrtf(n2m);
+                            f_ux[c] = f_mx[c] / nm; f_uy[c] = f_my[c] / nm;
+                        }
+                        const double dx = px[c] - (double)f_cpx[c], dy = py[c] - (double)f_cpy[c];
+                        fi[c] = dx * (double)f_ux[c] + dy * (double)f_uy[c];
+                        dfx[c] = (double)f_ux[c];
+                        dfy[c] = (double)f_uy[c];
+                        fm[c] = fi[c];
+                        status[c] = 2;
+                    }
+                }
+            }
+        }
+    }
+
+    // ---- DResidualNew of both chains: "last valid fi" propagation (KeyLine order = wave, lane), one barrier for the two ----
+    unsigned long long below[2];
+    double inh[2];
+#pragma unroll
+    for (int c = 0; c < 2; c++) {
+        const unsigned long long vmask = __ballot(status[c] == 2);
+        below[c] = vmask & ((1ull << lane) - 1ull);
+        const int src = below[c] ? 63 - __clzll(below[c]) : 0;
+        inh[c] = __shfl(fi[c], src, 64);
+        const int top = vmask ? 63 - __clzll(vmask) : 0;
+        const double wl = __shfl(fi[c], top, 64);
+        if (lane == 0) {
+            s_whas[c][wave] = vmask != 0;
+            s_wlast[c][wave] = wl;
+        }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int c = 0; c < 2; c++) {
+        double *rout = c ? rout1 : rout0;
+        if (status[c] == 3) {
+            double v = marker;   // no valid KeyLine before this one inside the block: resolved from the block carries
+            bool have = false;
+            if (below[c]) { v = inh[c]; have = true; }
+            for (int pw = wave - 1; pw >= 0 && !have; pw--)
+                if (s_whas[c][pw]) { v = s_wlast[c][pw]; have = true; }
+            rout[ikl] = v;
+        } else if (status[c] == 2) {
+            rout[ikl] = fi[c];
+        } else if (status[c] == 1) {
+            rout[ikl] = a.max_r;
+        } else if (ikl < kn) {
+            rout[ikl] = 0.0;   // a KeyLine the gates skip: whole-line stores (tvr_body)
+        }
+    }
+    if (tid == 0) {
+#pragma unroll
+        for (int c = 0; c < 2; c++) {
+            double bl = marker;
+            for (int pw = NW - 1; pw >= 0; pw--)
+                if (s_whas[c][pw]) { bl = s_wlast[c][pw]; break; }
+            (c ? a.block_last : a.block_last_z)[(size_t)seq * a.nblk + blk] = bl;
+        }
+    }
+
+    // ---- Jacobian rows, uncertainty scaling, the 28 sums: chain by chain ----
+    // The transposed reduction holds 28 products (56 registers) of one chain; what the other chain needs for its own row would
+    // have to stay alive beside them (87 registers, 5 waves per SIMD instead of 8).  So both rows are formed first, chain 1's seven
+    // values (J0..J5, f) wait in LDS ([7][256]: conflict-free) while chain 0's products are reduced, and come back for their turn.
+    __shared__ double s_red[2][NW][32];
+#if EDGEHIP_TVR2_PARK
+    __shared__ double s_park[PROCJF ? 7 : 1][kTvrThreads];
+#endif
+    const double inv_q = 1.0 / s_rho;
+    double Jc[2][6], fmc[2];
+#pragma unroll
+    for (int c = 0; c < 2; c++) {
+        double *J = Jc[c];
+#pragma unroll
+        for (int j = 0; j < 6; j++) J[j] = 0;
+        fmc[c] = fm[c];
+        if (ikl < kn) {
+            if (PROCJF) {
+                double t0 = a.zfm * rho_p[c];
+                J[0] = t0 * dfx[c];
+                J[1] = t0 * dfy[c];
+                t0 = rho_p[c] * pix[c];
+                J[2] = t0 * dfx[c];
+                t0 = rho_p[c] * piy[c];
+                J[2] += t0 * dfy[c];
+                J[3] = J[1] * ptz[c]; J[3] += J[2] * pty[c];
+                J[4] = J[0] * ptz[c]; J[4] += J[2] * ptx[c];
+                t0 = J[0] * pty[c];
+                J[5] = -1 * t0; J[5] += J[1] * ptx[c];
+#pragma unroll
+                for (int j = 0; j < 6; j++) J[j] *= inv_q;
+            }
+            fmc[c] *= inv_q;
+        }
+    }
+#if EDGEHIP_TVR2_PARK
+    if (PROCJF) {
+#pragma unroll
+        for (int j = 0; j < 6; j++) s_park[j][tid] = Jc[1][j];
+        s_park[6][tid] = fmc[1];
+    }
+#endif
+#pragma unroll
+    for (int c = 0; c < 2; c++) {
+        if (PROCJF) {
+            double J[6], f;
+#if EDGEHIP_TVR2_PARK
+            if (c == 1) {   // own entries: no barrier needed
+#pragma unroll
+                for (int j = 0; j < 6; j++) J[j] = s_park[j][tid];
+                f = s_park[6][tid];
+            } else
+#endif
+            {
+#pragma unroll
+                for (int j = 0; j < 6; j++) J[j] = Jc[c][j];
+                f = fmc[c];
+            }
+            double sums[kNumSums];
+            int ns = 0;
+#pragma unroll
+            for (int i = 0; i < 6; i++)
+#pragma unroll
+                for (int j = i; j < 6; j++) sums[ns++] = 0.0 + J[i] * J[j];
+#pragma unroll
+            for (int i = 0; i < 6; i++) sums[ns++] = 0.0 + J[i] * f;
+            sums[ns] = 0.0 + f * f;
+            const int idx = wave_reduce28(sums, lane);
+            if ((lane & 1) == 0) s_red[c][wave][idx] = sums[0];
+        } else {
+            double v = 0.0 + fmc[c] * fmc[c];
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+            if (lane == 0) s_red[c][wave][kNumSums - 1] = v;
+        }
+    }
+    __syncthreads();
+    // wave 0 finishes chain 1, wave 1 chain 0 (fixed order over the block's waves: deterministic)
+    if (wave < 2) {
+        const int c = 1 - wave;
+        if (PROCJF ? lane < kNumSums : lane == kNumSums - 1) {
+            double v = s_red[c][0][lane];
+#pragma unroll
+            for (int wv = 1; wv < NW; wv++) v += s_red[c][wv][lane];
+            (c ? a.partials : a.partials_z)[((size_t)seq * a.nblk + blk) * kNumSums + lane] = v;
+        }
+    }
+}
+
+#ifndef EDGEHIP_TVR2_WAVES
+#define EDGEHIP_TVR2_WAVES 0   // > 0: occupancy the two-chain evaluation is compiled for (waves per SIMD), A/B experiments
+#endif
+template <bool PROCJF, bool GREC>
+__global__ __launch_bounds__(kTvrThreads)
+#if EDGEHIP_TVR2_WAVES > 0
+__attribute__((amdgpu_waves_per_eu(EDGEHIP_TVR2_WAVES, EDGEHIP_TVR2_WAVES)))
+#endif
+void k_try_velrot2(TvrArgs a) {
+    tvr2_body<PROCJF, GREC>(a, blockIdx.z, blockIdx.x, threadIdx.x);
+}
+
+// ---------------------------------------------------------------------------------------------------
 // 6x6 linear algebra for the LM step (single lane)
 // ---------------------------------------------------------------------------------------------------
 // Symmetric eigen-decomposition by cyclic Jacobi; A = V diag(e) V^T.  Stands in for LAPACK dgesvd_ behind
@@ -1208,12 +1474,16 @@ enum LmOps : unsigned {
     LM_PHASE_BC = 1u << 17,    // next evaluation writes ResidualNew
     LM_BEGIN_KF = 1u << 18,    // kfvo::Minimizer_RV_KF: X and the uncertainty gate come with the request (kfvo.cpp:1737-1738)
     LM_FINISH_KF = 1u << 19,   // ... and the result goes to the caller, not into the sequence state (:1808-1821)
+    // Two-chain initialisation (k_try_velrot2 / k_lm_step2): both chains of TrackerInitType = 2 advance in the same launches
+    LM_BEGIN2 = 1u << 20,      // with LM_BEGIN: X = 0 for the zero-init chain, X = (Vel, W0) for the running one, both transforms set up
+    LM_PICK2 = 1u << 21,       // k_lm_step2 only: keep the better of the two chains (global_tracker.cpp:740-752), swap residual buffers
 };
 
 struct LmArgs {
     SeqDev *seq;
     const double *partials;   // [B][nblk][kNumSums]
     const double *block_last; // [B][nblk]
+    const double *partials_z = nullptr, *block_last_z = nullptr;   // the zero-init chain's (k_lm_step2)
     double *resid_carry;      // [kResidBufs][B][nblk]
     uint32_t *framecount;     // [B] of the new slot
     int nblk, nseq;
@@ -1237,8 +1507,15 @@ __device__ __forceinline__ void lm_sync() {
 
 // One wave per sequence.  WAVE_ONLY: the caller is a single wave of a larger workgroup (k_minimizer_persistent), so the
 // points where the lanes hand data to each other through LDS are wave-level fences instead of workgroup barriers.
-template <bool WAVE_ONLY>
-__device__ __forceinline__ void lm_body(const LmArgs &a, const int seq, const int lane) {
+// DUAL (k_lm_step2, 128 threads): the step of both chains of a two-chain initialisation at once — wave 0 runs the step on the
+// running (prior-init) chain's locals, wave 1 the same operations on the zero-init chain's (SeqDev::z*), each reducing its own
+// partial sums and resolving the carries of its own residual buffer; LM_PICK2 follows on wave 0 when both are done.
+template <bool WAVE_ONLY, bool DUAL = false>
+__device__ __forceinline__ void lm_body(const LmArgs &a, const int seq, const int tid) {
+    static_assert(!(WAVE_ONLY && DUAL), "the two chains meet at workgroup barriers");
+    constexpr int NT = DUAL ? 128 : 64;
+    const int lane = tid & 63;
+    const int ch = DUAL ? tid >> 6 : 0;      // 1 = zero-init chain
     const unsigned ops = a.ops;
     // The sequence state is staged in LDS for the whole step: the serial LM logic touches it hundreds of
     // times and a global round trip per access was the dominant cost of this kernel.
@@ -1246,6 +1523,8 @@ __device__ __forceinline__ void lm_body(const LmArgs &a, const int seq, const in
     constexpr int kWords = sizeof(SeqDev) / 8;
     __shared__ unsigned long long s_state[kWords];
     unsigned long long *gstate = reinterpret_cast<unsigned long long *>(a.seq + seq);
+    const double *a_partials = ch ? a.partials_z : a.partials;
+    const double *a_block_last = ch ? a.block_last_z : a.block_last;
     // Everything the step reads from global memory is requested here, in one go: the sequence state, the evaluation's
     // per-block partial sums and the blocks' last residuals.  The step is one wave per sequence and nothing but latency —
     // it used to pay the state's round trip, then (the block count comes out of the state) four more for the partials in
@@ -1258,29 +1537,36 @@ __device__ __forceinline__ void lm_body(const LmArgs &a, const int seq, const in
     double pv[kPre];
     double bl_pre = 0;
     if (prefetch) {
-        const double *pp = a.partials + (size_t)seq * a.nblk * kNumSums;
+        const double *pp = a_partials + (size_t)seq * a.nblk * kNumSums;
 #pragma unroll
         for (int j = 0; j < kPre; j++) {
             const int b = pv_g + 2 * j;
             pv[j] = (pv_on && b < a.nblk) ? pp[(size_t)b * kNumSums + pv_v] : 0.0;
         }
-        if (lane < a.nblk) bl_pre = a.block_last[(size_t)seq * a.nblk + lane];
+        if (lane < a.nblk) bl_pre = a_block_last[(size_t)seq * a.nblk + lane];
     }
-    for (int i = lane; i < kWords; i += 64) s_state[i] = gstate[i];
+    for (int i = tid; i < kWords; i += NT) s_state[i] = gstate[i];
     lm_sync<WAVE_ONLY>();
     SeqDev *sq = reinterpret_cast<SeqDev *>(s_state);
     if (a.kn_src) {
-        if (lane == 0) sq->kn_old = a.kn_src[seq];
+        if (tid == 0) sq->kn_old = a.kn_src[seq];
         lm_sync<WAVE_ONLY>();
     }
     const int kn = sq->kn_old;
     if (ops & LM_BEGIN) {
-        if (lane == 0) {
+        if (tid == 0) {
             sq->eff_steps = 0;
             sq->v = 2;
             sq->res_cur = 0; sq->res_new = 1; sq->res_t = 2;
             sq->pub.minimizer_evals = 0;
-            if (a.init_type == 1) {
+            if (ops & LM_BEGIN2) {
+                // both chains at once: the zero-init trial (global_tracker.cpp:650) in the z* locals, the prior-init trial
+                // (:698-699) in the running ones — what LM_SAVE_T would set up after the first chain
+                for (int i = 0; i < 6; i++) sq->zX[i] = 0;
+                sq->z_eff_steps = 0;
+                sq->zv = 2;
+                for (int i = 0; i < 3; i++) { sq->X[i] = sq->pub.V[i]; sq->X[3 + i] = sq->pub.W[i]; }
+            } else if (a.init_type == 1) {
                 for (int i = 0; i < 3; i++) { sq->X[i] = sq->pub.V[i]; sq->X[3 + i] = sq->pub.W[i]; }
             } else {
                 for (int i = 0; i < 6; i++) sq->X[i] = 0;
@@ -1307,7 +1593,7 @@ __device__ __forceinline__ void lm_body(const LmArgs &a, const int seq, const in
         o.score_ratio = 0; o.F = 0; o.F0 = 0; o.evals = 0; o.mnum = 0;
     }
     if (kn <= 0) {  // Minimizer_RV returns immediately on an empty list (global_tracker.cpp:597-598)
-        for (int i = lane; i < kWords; i += 64) gstate[i] = s_state[i];
+        for (int i = tid; i < kWords; i += NT) gstate[i] = s_state[i];
         return;
     }
     const int nblk_used = (kn + kTvrBlock - 1) / kTvrBlock;
@@ -1315,12 +1601,24 @@ __device__ __forceinline__ void lm_body(const LmArgs &a, const int seq, const in
     // ---- finish the reduction of the evaluation that just ran (fixed order: deterministic) ----
     // 2 lane groups x 32 value slots: group g sums blocks g, g+2, ... (independent, unrolled loads), then
     // slot v adds the two group sums.
-    __shared__ double s_part[2][32];
-    __shared__ double s_m[4][36], s_v[3][6];  // 6x6 work matrices / vectors of the solves (LDS, not scratch)
-    __shared__ double s_sum[kNumSums];
-    __shared__ double s_bl[256];
+    constexpr int NCH = DUAL ? 2 : 1;
+    __shared__ double s_part_[NCH][2][32];
+    __shared__ double s_m_[NCH][4][36], s_v_[NCH][3][6];  // 6x6 work matrices / vectors of the solves (LDS, not scratch)
+    __shared__ double s_sum_[NCH][kNumSums];
+    __shared__ double s_bl_[NCH][256];
+    double (*s_part)[32] = s_part_[ch];
+    double (*s_m)[36] = s_m_[ch];
+    double (*s_v)[6] = s_v_[ch];
+    double *s_sum = s_sum_[ch], *s_bl = s_bl_[ch];
+    // the chain's locals (LDS copy of the state)
+    double *cX = ch ? sq->zX : sq->X, *cXnew = ch ? sq->zXnew : sq->Xnew, *ch_h = ch ? sq->zh : sq->h;
+    double *cJtJ = ch ? sq->zJtJ : sq->JtJ, *cJtF = ch ? sq->zJtF : sq->JtF;
+    double *cJtJnew = ch ? sq->zJtJnew : sq->JtJnew, *cJtFnew = ch ? sq->zJtFnew : sq->JtFnew;
+    double *cF = ch ? &sq->zF : &sq->F, *cFnew = ch ? &sq->zFnew : &sq->Fnew, *cF0 = ch ? &sq->zF0 : &sq->F0;
+    double *cu = ch ? &sq->zu : &sq->u, *cv = ch ? &sq->zv : &sq->v, *cgain = ch ? &sq->zgain : &sq->gain;
+    int32_t *c_eff = ch ? &sq->z_eff_steps : &sq->eff_steps;
     if (ops & (LM_REDUCE_CUR | LM_REDUCE_NEW)) {
-        const double *pp = a.partials + (size_t)seq * a.nblk * kNumSums;
+        const double *pp = a_partials + (size_t)seq * a.nblk * kNumSums;
         const int v = lane & 31, g = lane >> 5;
         double acc = 0;
         if (prefetch) {
@@ -1332,9 +1630,9 @@ __device__ __forceinline__ void lm_body(const LmArgs &a, const int seq, const in
             for (int b = g; b < nblk_used; b += 2) acc += pp[(size_t)b * kNumSums + v];
         }
         s_part[g][v] = acc;
-        const int res_out = sq->lm_phase == 0 ? sq->res_t : sq->res_new;
+        const int res_out = DUAL ? (ch ? sq->res_t : sq->res_new) : (sq->lm_phase == 0 ? sq->res_t : sq->res_new);
         double *cr = a.resid_carry + ((size_t)res_out * a.nseq + seq) * a.nblk;
-        const double *bl = a.block_last + (size_t)seq * a.nblk;
+        const double *bl = a_block_last + (size_t)seq * a.nblk;
         if (prefetch) {
             // resolve the carries across the lanes: block b starts from the last valid residual of the blocks before it
             // (fi = 0 at the top): the newest valid lane below b, found in the ballot
@@ -1369,11 +1667,11 @@ __device__ __forceinline__ void lm_body(const LmArgs &a, const int seq, const in
     // left in LDS every one of its ~1000 dependent accesses paid an LDS round trip (~25 us per step).
     double JtJ[36], JtF[6], X[6], Xn[6], hh[6];
 #pragma unroll
-    for (int i = 0; i < 36; i++) JtJ[i] = sq->JtJ[i];
+    for (int i = 0; i < 36; i++) JtJ[i] = cJtJ[i];
 #pragma unroll
-    for (int i = 0; i < 6; i++) { JtF[i] = sq->JtF[i]; X[i] = sq->X[i]; Xn[i] = sq->Xnew[i]; hh[i] = sq->h[i]; }
-    double F = sq->F, Fnew = sq->Fnew, F0 = sq->F0, u = sq->u, v = sq->v;
-    int eff_steps = sq->eff_steps, res_cur = sq->res_cur, res_new = sq->res_new, res_t = sq->res_t;
+    for (int i = 0; i < 6; i++) { JtF[i] = cJtF[i]; X[i] = cX[i]; Xn[i] = cXnew[i]; hh[i] = ch_h[i]; }
+    double F = *cF, Fnew = *cFnew, F0 = *cF0, u = *cu, v = *cv;
+    int eff_steps = *c_eff, res_cur = sq->res_cur, res_new = sq->res_new, res_t = sq->res_t;
 
     if (ops & (LM_REDUCE_CUR | LM_REDUCE_NEW)) {
         double Jn[36], Fn6[6];
@@ -1407,13 +1705,14 @@ __device__ __forceinline__ void lm_body(const LmArgs &a, const int seq, const in
                 for (int i = 0; i < 6; i++) JtF[i] = Fn6[i];
             } else {
 #pragma unroll
-                for (int i = 0; i < 36; i++) sq->JtJnew[i] = Jn[i];
+                for (int i = 0; i < 36; i++) cJtJnew[i] = Jn[i];
 #pragma unroll
-                for (int i = 0; i < 6; i++) sq->JtFnew[i] = Fn6[i];
+                for (int i = 0; i < 6; i++) cJtFnew[i] = Fn6[i];
             }
         }
         if (ops & LM_REDUCE_CUR) F = s_sum[kNumSums - 1]; else Fnew = s_sum[kNumSums - 1];
-        sq->pub.minimizer_evals++;
+        if (!DUAL) sq->pub.minimizer_evals++;
+        else if (ch == 0) sq->pub.minimizer_evals += 2;   // the launch evaluated both chains
     }
     const double tau = 1e-3;
     if (ops & LM_INIT) {
@@ -1433,13 +1732,13 @@ __device__ __forceinline__ void lm_body(const LmArgs &a, const int seq, const in
             for (int i = 0; i < 6; i++) den += (0.5 * hh[i]) * (u * hh[i] - JtF[i]);
             gain = (F - Fnew) / den;
         }
-        sq->gain = gain;
+        *cgain = gain;
         if (gain > 0) {
             F = Fnew;
 #pragma unroll
-            for (int i = 0; i < 6; i++) { X[i] = Xn[i]; JtF[i] = sq->JtFnew[i]; }
+            for (int i = 0; i < 6; i++) { X[i] = Xn[i]; JtF[i] = cJtFnew[i]; }
 #pragma unroll
-            for (int i = 0; i < 36; i++) JtJ[i] = sq->JtJnew[i];
+            for (int i = 0; i < 36; i++) JtJ[i] = cJtJnew[i];
             const double g = 2 * gain - 1;
             const double m = 1 - (g * g * g);
             u *= (0.33 > m ? 0.33 : m);   // std::max(0.33, ...)
@@ -1521,21 +1820,37 @@ __device__ __forceinline__ void lm_body(const LmArgs &a, const int seq, const in
     }
     // registers -> state
 #pragma unroll
-    for (int i = 0; i < 36; i++) sq->JtJ[i] = JtJ[i];
+    for (int i = 0; i < 36; i++) cJtJ[i] = JtJ[i];
 #pragma unroll
-    for (int i = 0; i < 6; i++) { sq->JtF[i] = JtF[i]; sq->X[i] = X[i]; sq->Xnew[i] = Xn[i]; sq->h[i] = hh[i]; }
-    sq->F = F; sq->Fnew = Fnew; sq->F0 = F0; sq->u = u; sq->v = v;
-    sq->eff_steps = eff_steps; sq->res_cur = res_cur; sq->res_new = res_new; sq->res_t = res_t;
+    for (int i = 0; i < 6; i++) { cJtF[i] = JtF[i]; cX[i] = X[i]; cXnew[i] = Xn[i]; ch_h[i] = hh[i]; }
+    *cF = F; *cFnew = Fnew; *cF0 = F0; *cu = u; *cv = v;
+    *c_eff = eff_steps;
+    if (ch == 0) { sq->res_cur = res_cur; sq->res_new = res_new; sq->res_t = res_t; }
     }  // lane 0
     lm_sync<WAVE_ONLY>();
-    if (ops & (LM_SETUP_X | LM_SETUP_XNEW)) {
-        tvr_setup2(sq, (ops & LM_SETUP_XNEW) ? sq->Xnew : sq->X, lane);
+    if (DUAL && (ops & LM_PICK2)) {
+        // "Check for the lowerst score, and use it" (global_tracker.cpp:740-752): F of the prior-init chain against the zero-init
+        // chain's; the loser's residual buffer is dropped (ResidualNew = Rest), then std::swap(ResidualNew, Residual)
+        if (tid == 0) {
+            if (sq->F > sq->zF) {
+                for (int i = 0; i < 6; i++) sq->X[i] = sq->zX[i];
+                sq->F = sq->zF; sq->F0 = sq->zF0; sq->u = sq->zu; sq->v = sq->zv; sq->eff_steps = sq->z_eff_steps;
+                const int t = sq->res_new; sq->res_new = sq->res_t; sq->res_t = t;
+            }
+            const int t = sq->res_new; sq->res_new = sq->res_cur; sq->res_cur = t;
+        }
         lm_sync<WAVE_ONLY>();
     }
-    for (int i = lane; i < kWords; i += 64) gstate[i] = s_state[i];
+    if (ops & (LM_SETUP_X | LM_SETUP_XNEW)) {
+        tvr_setup2(sq, (ops & LM_SETUP_XNEW) ? cXnew : cX, lane, ch != 0);
+        if (!DUAL && (ops & LM_BEGIN2)) tvr_setup2(sq, sq->zX, lane, true, 2);   // the zero-init chain's first transform, lanes 2 and 3
+        lm_sync<WAVE_ONLY>();
+    }
+    for (int i = tid; i < kWords; i += NT) gstate[i] = s_state[i];
 }
 
 __global__ __launch_bounds__(64) void k_lm_step(LmArgs a) { lm_body<false>(a, blockIdx.x, threadIdx.x); }
+__global__ __launch_bounds__(128) void k_lm_step2(LmArgs a) { lm_body<false, true>(a, blockIdx.x, threadIdx.x); }
 
 // k_tvr_prepare and the step that opens a minimisation (LM_BEGIN: initial X, the transform of the first evaluation — no
 // evaluation precedes it, so it reads nothing the preparation writes) in one launch: the first wave of a sequence's first
@@ -2019,6 +2334,8 @@ static TvrArgs make_tvr_args(edgehip_ctx *c, int slot_new, int slot_old, double 
     a.kn_old = c->kn_slot + (size_t)slot_old * pl.nseq;
     a.field16 = c->field16; a.f16stride = pl.f16stride; a.f16tx = pl.f16tx; a.P0 = c->P0; a.resid = c->resid; a.resid_carry = c->resid_carry;
     a.block_last = c->block_last; a.partials = c->partials; a.seq = c->seq;
+    a.block_last_z = c->block_last + (size_t)pl.nseq * c->nblk_tvr;
+    a.partials_z = c->partials + (size_t)pl.nseq * c->nblk_tvr * kNumSums;
     a.framecount = c->framecount + (size_t)c->fc_index * pl.nseq;
     a.w = pl.w; a.h = pl.h; a.cap = pl.cap; a.nblk = c->nblk_tvr; a.nseq = pl.nseq;
     a.zfm = pl.zfm; a.max_r = (double)c->field_radius; a.match_thresh = match_thresh; a.k_huber = k_huber; a.inv_k_huber = 1.0 / k_huber;
@@ -2053,14 +2370,32 @@ static int launch_tvr(edgehip_ctx *c, const TvrArgs &a, bool reweight, bool proc
     return 0;
 }
 
-static int launch_lm(edgehip_ctx *c, int slot_new, unsigned ops) {
+static int launch_lm(edgehip_ctx *c, int slot_new, unsigned ops, bool two_chains = false) {
     ProfScope ps(c, PROF_B_LMSTEP);
     LmArgs a;
     a.seq = c->seq; a.partials = c->partials; a.block_last = c->block_last; a.resid_carry = c->resid_carry;
+    a.block_last_z = c->block_last + (size_t)c->plan.nseq * c->nblk_tvr;
+    a.partials_z = c->partials + (size_t)c->plan.nseq * c->nblk_tvr * kNumSums;
     a.framecount = c->framecount + (size_t)c->fc_index * c->plan.nseq;
     a.nblk = c->nblk_tvr; a.nseq = c->plan.nseq; a.ops = ops; a.init_type = c->p.tracker_init_type;
     a.kf_in = c->kf_req_dev; a.kf_out = c->kf_res_dev;
-    hipLaunchKernelGGL(k_lm_step, dim3(c->plan.nseq), dim3(64), 0, c->stream, a);
+    if (two_chains) hipLaunchKernelGGL(k_lm_step2, dim3(c->plan.nseq), dim3(128), 0, c->stream, a);
+    else hipLaunchKernelGGL(k_lm_step, dim3(c->plan.nseq), dim3(64), 0, c->stream, a);
+    EH_LAUNCH_CHECK();
+    return 0;
+}
+
+// one launch for evaluation i of both initialisation chains (tvr2_body)
+static int launch_tvr2(edgehip_ctx *c, const TvrArgs &a, bool procjf) {
+    ProfScope ps(c, PROF_B_TRYVELROT);
+    dim3 g(c->nblk_tvr, 1, c->plan.nseq), b(kTvrThreads);
+    if (a.use_grec) {
+        if (procjf) hipLaunchKernelGGL((k_try_velrot2<true, true>), g, b, 0, c->stream, a);
+        else hipLaunchKernelGGL((k_try_velrot2<false, true>), g, b, 0, c->stream, a);
+    } else {
+        if (procjf) hipLaunchKernelGGL((k_try_velrot2<true, false>), g, b, 0, c->stream, a);
+        else hipLaunchKernelGGL((k_try_velrot2<false, false>), g, b, 0, c->stream, a);
+    }
     EH_LAUNCH_CHECK();
     return 0;
 }
@@ -2123,7 +2458,12 @@ int minimizer_enqueue(edgehip_ctx *c, int slot_new, int slot_old, int fc_index) 
     int e;
     // A few sequences: the step that opens the minimisation rides on the preparation's launch (one dependent launch fewer).  Whole
     // batches: the step's ~230 registers cost the preparation more than the launch saves (measured at 1024 sequences: +90 us against -26).
-    const unsigned begin_ops = LM_BEGIN | LM_SETUP_X | (p.tracker_init_type >= 2 ? LM_PHASE_A : LM_PHASE_BC);
+    // Small batches: an evaluation is held back until the LM step that follows it is known, and both go out as one launch.
+    const bool fuse = c->persist_lm_max > 0 && c->plan.nseq <= c->persist_lm_max;
+    // TrackerInitType = 2: the zero-init and the prior-init chain advance in the same launches (k_try_velrot2 / k_lm_step2)
+    const bool two_chains = p.tracker_init_type >= 2 && c->dual_init && !fuse;
+    const unsigned begin_ops = two_chains ? (LM_BEGIN | LM_BEGIN2 | LM_SETUP_X | LM_PHASE_BC)
+                                          : (LM_BEGIN | LM_SETUP_X | (p.tracker_init_type >= 2 ? LM_PHASE_A : LM_PHASE_BC));
     const bool begin_rides = c->plan.nseq <= 64;
     if ((e = tvr_prepare_enqueue(c, slot_old, begin_rides ? begin_ops : 0u))) return e;
     if (!begin_rides && (e = edgehip::launch_lm(c, slot_new, begin_ops))) return e;
@@ -2131,8 +2471,6 @@ int minimizer_enqueue(edgehip_ctx *c, int slot_new, int slot_old, int fc_index) 
     const int I = p.tracker_init_iter_num, M = p.tracker_iter_num;
     const int total_evals = (p.tracker_init_type >= 2 ? 2 * (1 + (I > 0 ? I : 0)) : 0) + 1 + (M > 0 ? M : 0);
     int evals = 0;
-    // Small batches: an evaluation is held back until the LM step that follows it is known, and both go out as one launch.
-    const bool fuse = c->persist_lm_max > 0 && c->plan.nseq <= c->persist_lm_max;
     struct { bool on, rw, jf; int write_mid; } held = {false, false, false, 0};
     auto eval = [&](bool rw, bool jf) -> int {
         evals++;
@@ -2169,7 +2507,26 @@ int minimizer_enqueue(edgehip_ctx *c, int slot_new, int slot_old, int fc_index) 
         return 0;
     };
 #define EH_TRY(x) if ((e = (x)) != 0) return e
-    if (p.tracker_init_type >= 2) {
+    if (two_chains) {
+        // evaluation i of both chains per launch; the step kernel runs the same operations on both chains' locals and, behind
+        // the last one, picks the better end point (the tails LM_SAVE_T / LM_PICK of the launch chain below)
+        auto eval2 = [&](bool jf) -> int {
+            evals += 2;
+            TvrArgs a = make_tvr_args(c, slot_new, slot_old, p.tracker_match_thresh, p.reweight_distance, p.match_num_thresh, 0);
+            return launch_tvr2(c, a, jf);
+        };
+        EH_TRY(eval2(true));
+        unsigned ops = LM_REDUCE_CUR | LM_INIT | LM_RESET_V;
+        ops |= I > 0 ? (LM_SOLVE_SVD | LM_SETUP_XNEW) : (LM_PICK2 | LM_SETUP_X);
+        EH_TRY(edgehip::launch_lm(c, slot_new, ops, true));
+        for (int i = 0; i < I; i++) {
+            const bool last = (i == I - 1);
+            EH_TRY(eval2(!last));
+            ops = LM_REDUCE_NEW | (last ? (LM_NOJAC | LM_GAIN_DIFF) : LM_GAIN_RATIO);
+            ops |= !last ? (LM_SOLVE_SVD | LM_SETUP_XNEW) : (LM_PICK2 | LM_SETUP_X);
+            EH_TRY(edgehip::launch_lm(c, slot_new, ops, true));
+        }
+    } else if (p.tracker_init_type >= 2) {
         for (int trial = 0; trial < 2; trial++) {
             const unsigned phase = trial == 0 ? LM_PHASE_A : LM_PHASE_BC;
             (void)phase;   // trial 0: LM_BEGIN | LM_SETUP_X | LM_PHASE_A went out with tvr_prepare_enqueue

@@ -253,3 +253,32 @@ def test_fused_evaluation_and_lm_step_is_bit_identical_to_the_launch_chain(monke
     if nseq == 1:
         monkeypatch.setenv("EDGEHIP_PERSIST_LM", "8")
         _run(w, h, 6)     # the fused path against the reference
+
+
+@pytest.mark.parametrize("nseq,over", [(1, {}), (3, {}), (70, {}), (2, {"tracker_init_iter_num": 0}), (2, {"tracker_init_iter_num": 4})])
+def test_two_chain_evaluation_is_bit_identical_to_the_launch_chain(monkeypatch, nseq, over):
+    """TrackerInitType = 2: evaluation i of the zero-init chain and of the prior-init chain of Minimizer_RV
+    (global_tracker.cpp:649-692 / 698-738) go out as ONE launch (k_try_velrot2 + k_lm_step2, the default) — 9 dependent
+    evaluations instead of 12.  Per chain the arithmetic and the summation order are the launch chain's (EDGEHIP_DUAL_INIT=0),
+    so every nav record and the whole depth map must agree bit for bit; the evaluation count the records carry stays the
+    reference's.  nseq 70: past the batch size where the opening step rides on the preparation launch."""
+    w, h, n = 376, 240, 9
+    frames = [f for f, _, _ in synth.billboard_sequence(w, h, n + min(nseq, 8))]
+    outs = []
+    for mode in ("0", "1"):
+        monkeypatch.setenv("EDGEHIP_DUAL_INIT", mode)
+        eh = edgehip.EdgeHip(edgehip.euroc_params(w, h, **over), nseq=nseq, nslots=3)
+        eh.set_nav_log(n)
+        for k in range(n):
+            eh.upload_rgb(eh.next_slot(), np.stack([frames[k + s % 8] for s in range(nseq)]))
+            eh.process_frame(0.05 * k)
+        log = eh.read_nav_log_array(0, n)
+        kl = [eh.download_keylines(s, eh.cur_slot())[0] for s in range(min(nseq, 4))]
+        outs.append((log, kl))
+        eh.close()
+    (la, ka), (lb, kb) = outs
+    assert la.tobytes() == lb.tobytes()
+    for x, y in zip(ka, kb):
+        assert x.tobytes() == y.tobytes()
+    evals = 2 * (1 + over.get("tracker_init_iter_num", 2)) + 1 + 5
+    assert np.all(la["estimation_ok"][2:] == 1) and np.all(la["minimizer_evals"][1:] == evals)
