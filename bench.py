@@ -61,8 +61,11 @@ def tri(k, n):
     return k if k < n else p - k
 
 
-def algorithmic_bytes(group, kn, n_px, radius, nseq):
-    """Compulsory bytes per launch of a kernel group, for `nseq` batched sequences."""
+def algorithmic_bytes(group, kn, n_px, radius, nseq, evals_per_launch=1.0):
+    """Compulsory bytes per launch of a kernel group, for `nseq` batched sequences.
+    evals_per_launch: TryVelRot evaluations one k_try_velrot launch carries on average — 12 evaluations go out as 9 launches
+    since the two initialisation chains share theirs (SURVEY 8(d) prices an EVALUATION at 84 B per KeyLine; a two-chain
+    launch is two of them, although it streams the KeyLine's own 40 bytes once: `traffic` shows what it really moves)."""
     per_seq = {
         # stage A pieces: inputs/outputs each kernel cannot avoid
         "A.rgb_rowscan": 3 * n_px + 4 * n_px,                 # RGB24 in, row-prefix plane out
@@ -78,7 +81,7 @@ def algorithmic_bytes(group, kn, n_px, radius, nseq):
         "A.fused": 3 * n_px + 4 * n_px + 24 * kn,
         "A.join_retune": (24 + 3 * 4) * kn + (168 - 24) * kn,
         # 84 B per KeyLine and evaluation (fp64 variant)
-        "B.try_velrot": 84 * kn,
+        "B.try_velrot": 84 * kn * evals_per_launch,
         "B.build_field": 4 * n_px + 4 * 2 * radius * kn,     # clear + scattered 4-byte atomics (packed field)
         "B.tvr_prepare": 0,   # per-sequence set-up of the minimisation since P0 is rebuilt in registers by k_try_velrot (latency, no stream)
         "B.lm_step": 0,
@@ -87,7 +90,10 @@ def algorithmic_bytes(group, kn, n_px, radius, nseq):
         "C.rotate": (8 + 16 + 8 + 8 + 16 + 8 + 8) * kn,
         "C.directed_matching": (4 * 40 + 2 * 168) * kn,
         "C.regularize_ekf": (3 * 16 + 16 + 100) * kn,
-        "C.rescale": 5 * 32 * kn,
+        # SURVEY 8(d) prices EstimateReScalingOpt at five passes over 32 B per KeyLine; the kernel keeps a sequence's KeyLines in
+        # registers / LDS across the passes, so what a launch has to move is ONE pass (a fraction of the roofline above 1 would
+        # only say that the formula counts bytes nobody moves)
+        "C.rescale": 32 * kn,
         "C.pose": 0,
     }
     return per_seq.get(group, 0) * nseq
@@ -161,7 +167,7 @@ def pmc_counters(group, nseq):
     return (ft, wt) if found else None
 
 
-def calibrated_traffic(group, nseq, kn, calib):
+def calibrated_traffic(group, nseq, kn, calib, stream_per_kl=None):
     """HBM bytes per launch of `group` from the committed counters and the calibration of profiles/fetch_calibration.json
     (see GROUP_STREAM_BYTES_PER_KL); (bytes, description of the formula) or (None, None)."""
     c = pmc_counters(group, nseq)
@@ -170,7 +176,7 @@ def calibrated_traffic(group, nseq, kn, calib):
     fetch, write = c
     fs, fg, fw = calib.get("stream", 2.0), calib.get("gather16", 1.0), calib.get("write", 1.0)
     if group in GROUP_STREAM_BYTES_PER_KL and "gather16" in calib:
-        stream = GROUP_STREAM_BYTES_PER_KL[group] * kn * nseq
+        stream = (stream_per_kl or GROUP_STREAM_BYTES_PER_KL[group]) * kn * nseq
         gather = max(0.0, fetch - stream / fs) * fg
         return int(stream + gather + fw * write), (f"streams {stream / 1e6:.0f} MB (known) + {fg:.2f} x (FETCH_SIZE - streams / {fs:.2f}) "
                                                    f"= {gather / 1e6:.0f} MB of gathers + {fw:.2f} x WRITE_SIZE")
@@ -321,6 +327,88 @@ def _cpu_worker(job):
     idx = [tri(k, len(frames)) for k in range(8 + nfr)]
     done, _ = orc.run_sequence(frames, idx, threads=threads)
     return float(done[-1] - done[7])
+
+
+_PARITY = {}
+
+
+def _parity_init(frames_arr, cfg):
+    """Pool initialiser of wide_parity: the frame pool and the parameter set, once per worker process."""
+    _PARITY["frames"], _PARITY["cfg"] = frames_arr, cfg
+
+
+def _parity_worker(job):
+    """The CPU reference on one sequence of a batch (frame indices `idx` into the shared pool), from frame 0: per-frame V, W,
+    Pos, Pose, the counts, and the frames whose result the reference's own arithmetic leaves undecided (a KeyLine detected
+    exactly on a half pixel whose re-projection at X = 0 rounds either way: oracle.half_pixel_keylines)."""
+    s_, idx = job
+    from oracle import oracle
+    kind, w, h = _PARITY["cfg"]
+    op = oracle.tum_params(w, h, use_undistort=1) if kind == "tum" else oracle.euroc_params(w, h)
+    orc = oracle.Oracle("ref", op)
+    fr = _PARITY["frames"]
+    V, Wv, Pos, Pose, cnt, knife = [], [], [], [], [], []
+    for k, i in enumerate(idx):
+        old = orc.keylines(orc.cur_slot()).copy() if k else None
+        _, nav = orc.process_frame(fr[i], 0.05 * k)
+        V.append(nav.V[:]); Wv.append(nav.W[:]); Pos.append(nav.Pos[:]); Pose.append(nav.Pose[:])
+        cnt.append((nav.kn, nav.klm_num, nav.estimation_ok))
+        if k and oracle.half_pixel_keylines(old, orc.field(orc.cur_slot())[:, :, 1], op.ppx, op.ppy, nav.s_rho_q, op.w, op.h):
+            knife.append(k)
+    orc.close()
+    return s_, np.array(V), np.array(Wv), np.array(Pos), np.array(Pose).reshape(-1, 3, 3), np.array(cnt), knife
+
+
+def wide_parity(log, seqs, idx_of, frames_arr, cfg, first_timed, procs):
+    """Free-running parity of MANY sequences of a batch against the CPU reference replaying the same frames from frame 0, in a
+    pool of `procs` reference processes.  log: the device's nav records of frames 0..n-1 ([n, nseq] structured array);
+    idx_of(s) -> the n pool indices of sequence s.  Per frame the tests' bound: |dV|, |dW| <= 1e-6 * step + 1e-9 (and the same
+    KeyLine count).  Returns (summary, {s: (Pos, Pose, V, W) reference trajectory over the timed frames}).
+    A sequence that leaves the reference does so for good (discrete match decisions differ from then on), so what is
+    reported is how many are outside tolerance at the last frame, where each of those first left, and whether that frame is
+    one the reference itself leaves undecided (a knife-edge frame: two runs of the reference — another LAPACK, another CPU
+    model — part on the same frames, profiles/r03_knife_edge_*)."""
+    import multiprocessing as mp
+    n = log.shape[0]
+    jobs = [(int(s_), [int(i) for i in idx_of(s_)]) for s_ in seqs]
+    with mp.get_context("spawn").Pool(max(1, min(procs, len(jobs))), initializer=_parity_init, initargs=(frames_arr, cfg)) as pool_:
+        res = pool_.map(_parity_worker, jobs)
+    trajs, departed, frames_out = {}, [], 0
+    max_dv_inside = 0.0
+    for s_, V, Wv, Pos, Pose, cnt, knife in res:
+        trajs[s_] = {k - first_timed: (Pos[k], Pose[k], V[k], Wv[k]) for k in range(first_timed, n)}
+        first = None
+        path = 0.0
+        for k in range(1, n):
+            if not (np.all(np.isfinite(V[k])) and np.all(np.isfinite(Wv[k]))):
+                continue
+            tol = 1e-6 * (np.linalg.norm(V[k]) + np.linalg.norm(Wv[k])) + 1e-9
+            d = max(np.max(np.abs(log[k, s_]["V"] - V[k])), np.max(np.abs(log[k, s_]["W"] - Wv[k])))
+            bad = d > tol or int(log[k, s_]["kn"]) != int(cnt[k][0])
+            if bad:
+                frames_out += 1
+                if first is None:
+                    first = k
+            elif first is None:
+                max_dv_inside = max(max_dv_inside, float(d))
+            path += float(np.linalg.norm(V[k]))
+        last = n - 1
+        tol_l = 1e-6 * (np.linalg.norm(V[last]) + np.linalg.norm(Wv[last])) + 1e-9
+        out_last = bool(max(np.max(np.abs(log[last, s_]["V"] - V[last])), np.max(np.abs(log[last, s_]["W"] - Wv[last]))) > tol_l or
+                        np.max(np.abs(log[last, s_]["Pos"] - Pos[last])) > 1e-6 * path + 1e-9)
+        if first is not None or out_last:
+            departed.append({"sequence": s_, "first_frame_outside_tolerance": first, "knife_edge_frame": bool(first in knife) if first is not None else None,
+                             "outside_tolerance_at_last_frame": out_last,
+                             "position_error_at_last_frame": float(np.linalg.norm(log[last, s_]["Pos"] - Pos[last])),
+                             "knife_edge_frames_of_the_reference": knife[:12]})
+    summary = {"sequences_checked": len(res), "frames_per_sequence": n, "reference_processes": min(procs, len(jobs)),
+               "sequences_outside_tolerance_at_last_frame": int(sum(d_["outside_tolerance_at_last_frame"] for d_ in departed)),
+               "departures": departed,
+               "departures_on_knife_edge_frames": int(sum(1 for d_ in departed if d_["knife_edge_frame"])),
+               "departures_elsewhere": int(sum(1 for d_ in departed if d_["knife_edge_frame"] is False)),
+               "max_abs_dVW_while_inside_tolerance": max_dv_inside,
+               "tolerance": "per frame |dV|, |dW| <= 1e-6 * (|V| + |W|) + 1e-9 and the same KeyLine count; last frame also |dPos| <= 1e-6 * path + 1e-9"}
+    return summary, trajs
 
 
 def pose_rmse(gpu_trajs, cpu_trajs, kind):
@@ -481,12 +569,33 @@ def main():
     if backend != "nccl":
         local_rank %= torch.cuda.device_count()
     torch.cuda.set_device(local_rank)
+    # One rank, full path: the N > 1 code path is taken all the same (BENCH_FORCE_MOVER=0 turns it off) — a one-rank process
+    # group over RCCL, shard.NavMover on its own communicator and thread, barriers, the max-over-ranks all-reduce — so that the
+    # line a 1-GPU run prints has exercised what an 8-GPU run does, minus the peers (`nav_gather` in the line).  A box on which
+    # RCCL does not come up still measures: `nav_gather` then says why.
+    force_mover = world == 1 and args.config == "full" and os.environ.get("BENCH_FORCE_MOVER", "1") != "0"
+    dist_on = world > 1
+    dist_note = None
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         if backend == "nccl":
             dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
         else:
             dist.init_process_group(backend, rank=rank, world_size=world)
+    elif force_mover:
+        try:
+            import socket
+            os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+            if "MASTER_PORT" not in os.environ:
+                sk = socket.socket(); sk.bind(("127.0.0.1", 0)); os.environ["MASTER_PORT"] = str(sk.getsockname()[1]); sk.close()
+            os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+            if backend == "nccl":
+                dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", local_rank))
+            else:
+                dist.init_process_group(backend, rank=0, world_size=1)
+            dist_on = True
+        except Exception as ex:
+            dist_note = f"unavailable: {type(ex).__name__}: {str(ex)[:120]}"
 
     if args.overlap:
         os.environ["EDGEHIP_OVERLAP"] = "1"
@@ -626,12 +735,12 @@ def main():
 
     # ============================ the full path ============================
     for e in ehs:
-        e.set_nav_log(K)
+        e.set_nav_log(Wm + K)   # the whole replay from frame 0: the parity leg looks for the first frame a sequence leaves the reference on
 
     def barrier():
         rp.sync()
         torch.cuda.synchronize()
-        if world > 1:
+        if dist_on:
             dist.barrier()
 
     # ---- warmup (also finds the dominant kernel group with the built-in HIP-event profiler) ----
@@ -655,8 +764,8 @@ def main():
         eh.profile_enable(True)
     # N > 1: the nav records of a step travel to rank 0 in blocks of `blk` steps on a side stream (RCCL gather issued
     # while the next block is being computed; two buffers), the last block after the timed region's last step
-    mover = shard.NavMover(world, rank, backend, device=local_rank if backend == "nccl" else None) if world > 1 else None
-    nav_gather = None
+    mover = shard.NavMover(world, rank, backend, device=local_rank if backend == "nccl" else None) if dist_on else None
+    nav_gather = dist_note
     blk = max(1, K // 4)
     barrier()
     t0 = time.perf_counter()
@@ -680,19 +789,34 @@ def main():
     barrier()
     dt = time.perf_counter() - t0
     # ---- end of timed region ----
-    if world > 1:
+    if dist_on:
         tmax = torch.tensor([dt], dtype=torch.float64, device="cuda" if backend == "nccl" else "cpu")
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         dt = float(tmax.item())
+    nav_gather_info = None
+    if mover is not None and nav_gather == "ok" and rank == 0:
+        # what arrived on rank 0 is what the contexts logged (every block, every rank's sequences, in order)
+        got = np.concatenate([b[0] for b in mover.blocks], axis=0) if world == 1 and C == 1 else None
+        nav_gather_info = {"backend": "rccl" if backend == "nccl" else backend, "ranks": world, "blocks": len(mover.blocks),
+                           "records": int(sum(b.shape[0] * b.shape[1] * b.shape[2] for b in mover.blocks))}
+        if got is not None:
+            direct = shard.nav_records(eh.read_nav_log_array(Wm, K), rank, list(range(B)))
+            nav_gather_info["equals_device_log"] = bool(got.shape == direct.shape and np.array_equal(got, direct))
+    if dist_on and world == 1:
+        dist.destroy_process_group()
+        dist_on = False
 
     dom_ms, dom_calls = (0.0, 0)
     if dominant and not args.no_roofline_events:
         dom_ms, dom_calls = eh.profile_read()[dominant]
         eh.profile_enable(False)
-    check_seqs = sorted({0, B // 2, B - 1})   # sequences of context 0 compared with the CPU reference below
+    # sequences of context 0 compared with the CPU reference below: every 32nd (32 of 1024) and the last one
+    check_seqs = sorted(set(range(0, B, max(1, B // 32))) | {B - 1})
     gpu_traj = None
+    log_all = None
     if cpu_legs:
-        log0 = eh.read_nav_log_array(Wm, K)
+        log_all = eh.read_nav_log_array(0, Wm + K)
+        log0 = log_all[Wm:]
         gpu_traj = {s: _traj_of_log(log0, s) for s in check_seqs}
     elif cpu_legs_imu:   # ImuMode > 0: the gravity-aligned pose, metric velocity and rotation of NavData (rebvo_second_t.cpp:519-606)
         log0 = eh.read_nav_log_array(Wm, K)
@@ -700,7 +824,7 @@ def main():
                          log0[k, s]["RotLie"].copy()) for k in range(K)] for s in check_seqs}
     last = [n for e in ehs for n in e.read_nav()]
     kn_mean = float(np.mean([n.kn for n in last]))
-    kn_timed = float(np.mean(eh.read_nav_log_array(Wm, K)["kn"])) if rank == 0 else kn_mean   # over every timed frame, context 0
+    kn_timed = float(np.mean((log_all[Wm:] if log_all is not None else eh.read_nav_log_array(Wm, K))["kn"])) if rank == 0 else kn_mean   # over every timed frame, context 0
     ok = int(sum(n.estimation_ok for n in last))
     evals = last[0].minimizer_evals
 
@@ -727,16 +851,22 @@ def main():
     roof = None
     if dominant and dom_calls:
         per_launch_s = dom_ms * 1e-3 / dom_calls
-        abytes = algorithmic_bytes(dominant, kn_mean, n_px, radius, B)
+        # bytes of THESE launches / time of THESE launches: the KeyLine count of the timed frames (kn_timed), and for the
+        # tracker the evaluations a launch carries (evals per frame / launches per frame over the timed region)
+        epl_timed = evals * K / dom_calls if dominant == "B.try_velrot" and dom_calls else 1.0
+        abytes = algorithmic_bytes(dominant, kn_timed, n_px, radius, B, epl_timed)
         ach = abytes / per_launch_s / 1e9 if per_launch_s > 0 else 0.0
-        traffic, formula = calibrated_traffic(dominant, B, kn_mean, calib)
+        # the KeyLine's own streams per launch: 40 B, + the 8-byte residual of the iteration before in the reweighted launches
+        tvr_stream = 40 + 8 * min(1.0, (1 + params.tracker_iter_num) * K / dom_calls) if dominant == "B.try_velrot" else None
+        traffic, formula = calibrated_traffic(dominant, B, kn_timed, calib, tvr_stream)
         roof = {"bound": "hbm", "kernel": dominant, "achieved": round(ach, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": round(ach / HBM_PEAK_GBS, 5), "traffic": traffic,
                 "traffic_source": PMC_FILE + " (rocprofv3 --pmc passes of this command committed with the code; not measured in this run)",
                 "traffic_calibration": {"factors_true_over_reported": {k: round(v, 3) for k, v in calib.items()}, "formula": formula,
                                         "source": calib_src},
                 "launch_us": round(per_launch_s * 1e6, 2), "algorithmic_bytes_per_launch": int(abytes),
-                "launches_timed": dom_calls}
+                "launches_timed": dom_calls, "keylines_per_frame_of_these_launches": round(kn_timed, 1),
+                "evaluations_per_launch": round(epl_timed, 3)}
     # The committed counters were taken in a run of their own: a group's traffic is compared with the algorithmic bytes at THAT
     # run's KeyLine count (pmc_latest.json:_kn), and scaled to this run's for the absolute figure.  Where a kernel moves LESS
     # than SURVEY 8(d)'s formula (build_field: the formula describes the reference's scatter, the LDS rasteriser writes half of
@@ -745,11 +875,12 @@ def main():
     roof_all = {}
     traffic_step = 0.0
     for g, (ms, calls) in groups.items():
-        ab = algorithmic_bytes(g, kn_mean, n_px, radius, B)
+        epl = evals * prof_steps / calls if g == "B.try_velrot" and calls else 1.0
+        ab = algorithmic_bytes(g, kn_mean, n_px, radius, B, epl)
         if ab and calls:
             per = ms * 1e-3 / calls
-            tr, _ = calibrated_traffic(g, B, kn_pmc, calib)
-            ab_pmc = algorithmic_bytes(g, kn_pmc, n_px, radius, B)
+            tr, _ = calibrated_traffic(g, B, kn_pmc, calib, 40 + 8 * min(1.0, (1 + params.tracker_iter_num) * prof_steps / calls) if g == "B.try_velrot" else None)
+            ab_pmc = algorithmic_bytes(g, kn_pmc, n_px, radius, B, epl)
             ratio = tr / ab_pmc if tr and ab_pmc else None
             roof_all[g] = {"launch_us": round(per * 1e6, 1), "launches_per_step": calls // prof_steps,
                            "achieved_GBs": round(ab / per / 1e9, 1), "frac": round(ab / per / 1e9 / HBM_PEAK_GBS, 4),
@@ -759,7 +890,7 @@ def main():
                 traffic_step += ratio * ab * (calls // prof_steps)
     if roof and roof.get("traffic") and dominant in roof_all and roof_all[dominant].get("traffic_over_algorithmic"):
         roof["traffic"] = int(roof_all[dominant]["traffic_over_algorithmic"] * roof["algorithmic_bytes_per_launch"])
-        roof["traffic_kn"] = {"counters_taken_at": round(float(kn_pmc), 1), "this_run": round(kn_mean, 1),
+        roof["traffic_kn"] = {"counters_taken_at": round(float(kn_pmc), 1), "this_run": round(kn_timed, 1),
                               "note": "traffic = (counter bytes / algorithmic bytes at the counters' KeyLine count) x this run's algorithmic bytes"}
     # whole-frame algorithmic bytes, SURVEY.md §8(d) formulas with the measured kn and evaluation count
     r = radius
@@ -779,9 +910,16 @@ def main():
             oparams = oracle.tum_params(w, h, use_undistort=1) if tum else oracle.euroc_params(w, h)
             kind = "reference" if oracle.available("ref") else ("port" if oracle.available("port") else None)
             if kind:
-                cpu_trajs = {s_: _cpu_traj(oracle, oparams, lambda k, s_=s_: frames[tri(k + int(offs[s_]), args.pool)], Wm, K)
-                             for s_ in check_seqs}
+                parity = None
+                if kind == "reference":
+                    parity, cpu_trajs = wide_parity(log_all, check_seqs, lambda s_: [tri(k + int(offs[s_]), args.pool) for k in range(Wm + K)],
+                                                    np.stack(frames), ("tum" if tum else "euroc", w, h), Wm, max(1, _usable_cores() - 1))
+                else:
+                    cpu_trajs = {s_: _cpu_traj(oracle, oparams, lambda k, s_=s_: frames[tri(k + int(offs[s_]), args.pool)], Wm, K)
+                                 for s_ in check_seqs[:3]}
                 pose = pose_rmse(gpu_traj, cpu_trajs, kind)
+                if parity:
+                    pose["free_running_parity"] = parity
                 ncores, model = _usable_cores(), _cpu_model()
                 if kind == "reference":
                     host_pool = np.stack(frames)
@@ -924,12 +1062,21 @@ def main():
                       "estimation_ok": f"{int(sum(x.estimation_ok for x in lst))}/{n}"}
             if cpu_legs and oparams is not None:
                 from oracle import oracle
-                hs = sorted({0, 5, n - 1})   # 5: a sequence with the scene cut
+                hs = sorted({0, 5, n - 1})   # teacher-forced below (5: a sequence with the scene cut)
                 hframes = [f for sc in scenes for f in sc]
                 logh = r3.ehs[0].read_nav_log_array(0, Wm + K)
                 r3.close()
                 r3 = None
-                gt = {s: _traj_of_log(logh[Wm:], s) for s in hs}
+                wide = None
+                if oracle.available("ref"):
+                    # free-running, every 32nd sequence (+ the scene-cut one): how many leave the reference, where, and whether
+                    # on a frame the reference itself leaves undecided
+                    hw = sorted(set(range(0, n, max(1, n // 32))) | {5, n - 1})
+                    wide, wide_trajs = wide_parity(logh, hw, lambda s_: [hidx(k, s_) for k in range(Wm + K)], np.stack(hframes),
+                                                   ("euroc", w, h), Wm, max(1, _usable_cores() - 1))
+                    # ... and every departed sequence (up to four more) joins the teacher-forced replay
+                    hs = sorted(set(hs) | {d_["sequence"] for d_ in wide["departures"][:4]})
+                gt = {s: _traj_of_log(logh[Wm:], s) for s in (hw if wide else hs)}
                 if oracle.available("ref"):
                     # One pass of the reference per checked sequence serves three comparisons (oracle/teacher.py):
                     #  * free-running: the batch's own trajectory against the reference's (pose_rmse, as in the main leg);
@@ -963,7 +1110,8 @@ def main():
                         depart[int(s)] = None if first is None else {
                             "frame": first, "knife_edge_frame": first in kef,
                             "keylines": next((f["keylines"] for f in tf["knife_edge_frames"] if f["frame"] == first), None)}
-                    hetero["pose_rmse"] = pose_rmse(gt, ref_trajs, "reference")
+                    hetero["pose_rmse"] = pose_rmse(gt, wide_trajs if wide else ref_trajs, "reference")
+                    hetero["free_running_parity"] = wide
                     hetero["teacher_forced"] = {
                         "what": "reference state injected before every frame (previous edge map with depths, velocity prior, pose, "
                                 "threshold), one frame run, |dV|,|dW| <= 1e-6*step + 1e-9 and identical kn / klm_num / EstimationOK required",
@@ -998,7 +1146,7 @@ def main():
                                 "image, GlobalConfig_desk.txt params, UseUndistort=1 with the EuRoC distortion (SURVEY 8d scene S3), "
                                 "undistortion fused into the stage-A load"),
                    "sequences_per_gpu": B * C, "contexts_per_gpu": C, "sequences_per_launch": B,
-                   "stream_overlap": bool(args.overlap), "nav_gather": nav_gather,
+                   "stream_overlap": bool(args.overlap), "nav_gather": nav_gather, "nav_gather_info": nav_gather_info,
                    "frames_per_step": B * C * world, "keylines_per_frame": round(kn_mean, 1),
                    "keylines_per_frame_timed_mean": round(kn_timed, 1),
                    "tryvelrot_evals_per_frame": evals, "estimation_ok": f"{ok}/{B * C}",

@@ -74,3 +74,42 @@ def test_committed_counters_carry_the_keyline_count_they_were_taken_at():
     tr, _ = bench.calibrated_traffic("B.try_velrot", nseq, js["_kn"], calib)
     ab = bench.algorithmic_bytes("B.try_velrot", js["_kn"], 752 * 480, 40, nseq)
     assert 0.9 < tr / ab < 1.6
+
+
+def test_algorithmic_bytes_of_launches_that_carry_two_evaluations():
+    kn, n, r, B = 12000, 752 * 480, 40, 1024
+    # 12 evaluations in 9 launches (the two initialisation chains of Minimizer_RV share theirs)
+    assert bench.algorithmic_bytes("B.try_velrot", kn, n, r, B, 12 / 9) == 84 * kn * B * 12 / 9
+    assert bench.algorithmic_bytes("C.rescale", kn, n, r, 1) == 32 * kn     # one pass: the kernel keeps the KeyLines on chip
+
+
+def test_wide_parity_counts_departures_and_attributes_them():
+    """bench.py's free-running parity of many sequences: fed the reference's own records it reports nothing; a sequence whose
+    velocity is off by more than the per-frame tolerance from some frame on is reported with that frame, and as outside
+    tolerance at the last frame."""
+    import pytest
+    from oracle import oracle
+    from rebvo_amd import edgehip, synth
+    if not oracle.available("ref"):
+        pytest.skip("oracle/_ref not built")
+    w, h, n = 188, 120, 5
+    frames = np.stack([f for f, _, _ in synth.billboard_sequence(w, h, 6)])
+    idx_of = lambda s: [bench.tri(k + s, 6) for k in range(n)]
+    log = np.zeros((n, 3), dtype=edgehip.NAV_DTYPE)
+    for s in range(3):
+        orc = oracle.Oracle("ref", oracle.euroc_params(w, h))
+        for k, i in enumerate(idx_of(s)):
+            _, nav = orc.process_frame(frames[i], 0.05 * k)
+            log[k, s]["V"], log[k, s]["W"], log[k, s]["Pos"], log[k, s]["kn"] = nav.V[:], nav.W[:], nav.Pos[:], nav.kn
+        orc.close()
+    summary, trajs = bench.wide_parity(log, [0, 1, 2], idx_of, frames, ("euroc", w, h), 2, 2)
+    assert summary["sequences_checked"] == 3 and summary["departures"] == [] and summary["sequences_outside_tolerance_at_last_frame"] == 0
+    assert sorted(trajs) == [0, 1, 2] and sorted(trajs[1]) == [0, 1, 2]
+    assert np.array_equal(trajs[2][2][2], log[4, 2]["V"])
+    bad = log.copy()
+    bad["V"][3:, 1, 0] += 1e-3
+    summary, _ = bench.wide_parity(bad, [0, 1, 2], idx_of, frames, ("euroc", w, h), 2, 2)
+    assert [d["sequence"] for d in summary["departures"]] == [1]
+    d = summary["departures"][0]
+    assert d["first_frame_outside_tolerance"] == 3 and d["outside_tolerance_at_last_frame"] and d["knife_edge_frame"] in (True, False)
+    assert summary["sequences_outside_tolerance_at_last_frame"] == 1

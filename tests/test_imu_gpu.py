@@ -233,6 +233,20 @@ def test_imu_mode1_pushimu_matches_reference(tmp_path):
 
 
 def test_imu_branch_batched_on_the_device_matches_reference(tmp_path):
+    _batched_branch(tmp_path, 8, range(8))
+
+
+@pytest.mark.parametrize("w,h,B,check", [(752, 480, 8, (0, 3, 7)), (376, 240, 200, (0, 5, 67, 199)), (752, 480, 192, (1, 190))])
+def test_imu_branch_batched_at_the_baseline_size_and_behind_the_one_kernel_stage_a(tmp_path, monkeypatch, w, h, B, check):
+    """The same replay at BASELINE's 752x480, and with >= 192 sequences per launch, where stage A is the one-kernel form
+    (k_stage_a_fused: EDGEHIP_FUSED_MIN_BATCH) in front of the IMU branch; a few sequences of the batch against the reference."""
+    mod = sys.modules[__name__]
+    monkeypatch.setattr(mod, "W", w)
+    monkeypatch.setattr(mod, "H", h)
+    _batched_branch(tmp_path, B, check)
+
+
+def _batched_branch(tmp_path, B, check):
     """ImuMode > 0 for a whole batch inside edgehip_process_frame (edgehip_imu_enable / edgehip_set_imu): eight sequences —
     the same data set entered 0..7 frames late, so that bias start-up, scale filter and map are in a different state in
     every one of them at any time — advance in lock-step with no host synchronisation between the stages; the filters run
@@ -242,8 +256,8 @@ def test_imu_branch_batched_on_the_device_matches_reference(tmp_path):
     if not oracle.available("ref"):
         pytest.fail("needs oracle/_ref" " — a broken snapshot, not a reason to skip: run __graft_entry__.build(), where the reference tree is present")
     global N
-    B, n_run = 8, N
-    n_all = n_run + B - 1
+    n_run = N
+    n_all = n_run + 8 - 1      # sequence s enters the data set (s % 8) frames late
     N_keep = N
     try:
         N = n_all
@@ -267,19 +281,20 @@ def test_imu_branch_batched_on_the_device_matches_reference(tmp_path):
     eh.imu_enable(edgehip.euroc_imu_params(init_bias_frame_num=INIT_BIAS_FRAMES))
     got = []
     for k in range(n_run):
-        eh.upload_rgb(eh.next_slot(), np.stack([frames[k + s] for s in range(B)]))
-        eh.set_imu([edgehip.ImuIntegrated.from_row(imu_rows[k + s]) for s in range(B)])
-        eh.process_frame(np.array([t[k + s] for s in range(B)]))
+        eh.upload_rgb(eh.next_slot(), np.stack([frames[k + s % 8] for s in range(B)]))
+        eh.set_imu([edgehip.ImuIntegrated.from_row(imu_rows[k + s % 8]) for s in range(B)])
+        eh.process_frame(np.array([t[k + s % 8] for s in range(B)]))
         got.append((eh.read_nav(), eh.read_nav_imu()))
     eh.close()
 
     def close(a, b, rtol, atol):
         return np.allclose(np.array(a[:]) if hasattr(a, "__len__") else a, b, rtol=rtol, atol=atol)
 
-    for s in range(B):
+    for s in check:
         sub = tmp_path / f"seq{s}"
         sub.mkdir()
-        o = _run_reference(sub, frames[s:s + n_run], t[s:s + n_run], imu_rows[s:s + n_run], {"init_bias_frame_num": INIT_BIAS_FRAMES})
+        s8 = s % 8
+        o = _run_reference(sub, frames[s8:s8 + n_run], t[s8:s8 + n_run], imu_rows[s8:s8 + n_run], {"init_bias_frame_num": INIT_BIAS_FRAMES})
         filter_frames = 0
         for k in range(1, n_run):
             nav, ni = got[k][0][s], got[k][1][s]

@@ -157,6 +157,35 @@ def test_minimizer_rv_kf(pair, X0, Kr, rho_tol, match_mod, iters, mnt):
     assert got["evals"][0] == iters + 1
 
 
+def test_minimizer_rv_kf_at_the_baseline_size():
+    """The key-frame tracker at BASELINE's 752x480 (the cases above run at 376x240): ~13 k KeyLines per list, 50+ evaluation
+    blocks per sequence, the field's 8x4-pixel tiles over the whole EuRoC image."""
+    from oracle import oracle
+    if not oracle.available("ref"):
+        pytest.fail("oracle/_ref not built" " — a broken snapshot, not a reason to skip: run __graft_entry__.build()")
+    w, h = 752, 480
+    orc, so, sn, nav, frames = oracle_pair(w, h, 3)
+    eh = edgehip.EdgeHip(edgehip.euroc_params(w, h), nseq=1, nslots=2)
+    try:
+        inject_pair(eh, orc, so, sn)
+        orc.build_field(sn, 40, orc.retuned(sn))
+        s_rho_q = orc.quantile(so)
+        ang = 30.0 * np.pi / 180.0
+        X0 = (0.004, -0.002, 0.003, 0.002, -0.003, 0.001)
+        ref = orc.minimizer_rv_kf(sn, so, X0, 1.05, s_rho_q, 5.0, ang, 5.0, 6, 2.0, 0)
+        got = eh.minimizer_rv_kf(1, 0, X0, 1.05, s_rho_q, 5.0, ang, 5.0, 6, 2.0, 0)
+        assert ref["mnum"] > 3000, ref["mnum"]
+        assert got["mnum"][0] == ref["mnum"], (got["mnum"][0], ref["mnum"])
+        kg, _ = eh.download_keylines(0, 0)
+        assert np.array_equal(kg["m_id_f"], orc.keylines(so)["m_id_f"])
+        assert np.allclose(got["X"][0], ref["X"], rtol=1e-9, atol=1e-12), (got["X"][0], ref["X"])
+        assert abs(got["score_ratio"][0] - ref["score_ratio"]) <= 1e-9 * abs(ref["score_ratio"])
+        assert rel_err(got["RRV"][0], ref["RRV"]) < 1e-7
+        assert got["evals"][0] == 7
+    finally:
+        eh.close()
+
+
 def test_minimizer_rv_kf_batched_requests(pair):
     """Three sequences with the same KeyLines and three different requests (start pose, scale ratio, uncertainty gate) in
     one call: every sequence must come out as the reference does for ITS request."""

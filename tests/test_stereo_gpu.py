@@ -168,10 +168,16 @@ def test_directed_matching_stereo_mode():
     assert np.array_equal(kr["rho"][m], ko["rho0"][kr["m_id"][m]])
 
 
-def test_stereo_whole_frame_matches_reference():
+@pytest.mark.parametrize("w,h,nseq", [(376, 240, 2), (752, 480, 2), (376, 240, 200)])
+def test_stereo_whole_frame_matches_reference(monkeypatch, w, h, nseq):
     """edgehip_process_frame with a stereo rig (stage A of the pair image, stereo-mode directed matching, stereo match,
-    fuse, Kp = 1) against the reference's SecondThread order with StereoAvaiable, frame by frame; two sequences in the
-    batch stay identical."""
+    fuse, Kp = 1) against the reference's SecondThread order with StereoAvaiable, frame by frame; the sequences of the
+    batch stay identical.  Also at BASELINE's 752x480, and with 200 sequences per launch, where both images of the pair go
+    through the one-kernel stage A (k_stage_a_fused)."""
+    import sys
+    mod = sys.modules[__name__]
+    monkeypatch.setattr(mod, "W", w)
+    monkeypatch.setattr(mod, "H", h)
     from oracle import oracle
     if not oracle.available("ref"):
         pytest.fail("oracle/_ref not built" " — a broken snapshot, not a reason to skip: run __graft_entry__.build(), where the reference tree is present")
@@ -179,19 +185,20 @@ def test_stereo_whole_frame_matches_reference():
     p, frames, pairs, pc = make_data(all_pairs=True, nf=nf)
     orc = oracle.Oracle("ref", oracle.euroc_params(W, H))
     orc.enable_stereo(pc["ppx"], pc["ppy"], pc["zfx"], pc["zfy"], T_PAIR, R_PAIR, 100.0)
-    eh = edgehip.EdgeHip(edgehip.euroc_params(W, H, stereo_available=1), nseq=2, nslots=4)
+    eh = edgehip.EdgeHip(edgehip.euroc_params(W, H, stereo_available=1), nseq=nseq, nslots=4)
     eh.set_slot_camera(3, pc["ppx"], pc["ppy"], pc["zfx"], pc["zfy"])
     eh.set_stereo_rig(3, T_PAIR, R_PAIR, 100.0)
     path = 0.0
     for k in range(nf):
         _, nr = orc.process_frame_stereo(frames[k], pairs[k], 0.05 * k)
         assert eh.next_slot() == k % 3                     # the ring leaves the pair slot alone
-        eh.upload_rgb(eh.next_slot(), np.stack([frames[k]] * 2))
-        eh.upload_rgb(3, np.stack([pairs[k]] * 2))
+        eh.upload_rgb(eh.next_slot(), np.stack([frames[k]] * nseq))
+        eh.upload_rgb(3, np.stack([pairs[k]] * nseq))
         eh.process_frame(0.05 * k)
         navs = eh.read_nav()
         nm = eh.get_stereo_matches()
-        for s, ng in enumerate(navs):
+        assert all(n_.V[:] == navs[0].V[:] and n_.kn == navs[0].kn for n_ in navs)
+        for s, ng in list(enumerate(navs))[:2]:
             assert ng.kn == nr.kn and ng.tresh == nr.tresh, k   # the pair image went through the shared threshold state
             if k == 0:
                 continue
@@ -208,7 +215,7 @@ def test_stereo_whole_frame_matches_reference():
             assert np.allclose(navs[0].Pos[:], nr.Pos[:], atol=1e-6 * path + 1e-9)
         assert navs[0].V[:] == navs[1].V[:]
     assert nr.pad0 > 1000
-    kg, mask = eh.download_keylines(0, eh.cur_slot())
+    kg, mask = eh.download_keylines(nseq - 1, eh.cur_slot())
     kr = orc.keylines(orc.cur_slot())
     assert np.array_equal(mask, orc.mask(orc.cur_slot()).reshape(H, W))
     same = (kg["m_id"] == kr["m_id"]) & (kg["stereo_m_id"] == kr["stereo_m_id"])
