@@ -521,6 +521,13 @@ def timed_replay(rp, K, Wm, profile=False):
 
 
 def main():
+    # ONE JSON line on stdout, whatever the libraries underneath print: RCCL writes a version banner to the C-level stdout of
+    # the process when its first communicator comes up.  File descriptor 1 is pointed at stderr for the rest of the run and
+    # Python's own sys.stdout (the line at the end) keeps the real one.
+    sys.stdout.flush()
+    real_stdout = os.dup(1)
+    os.dup2(2, 1)
+    sys.stdout = os.fdopen(real_stdout, "w")
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=40)

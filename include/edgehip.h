@@ -115,7 +115,8 @@ typedef struct edgehip_nav {
     double t, dt;
     double V[3], W[3], P_V[9], P_W[9];
     double Rot[9], RotLie[3], Vel[3], Pose[9], PoseLie[3], Pos[3];
-    double Kp, RKp, s_rho_q, tresh, score, rel_error, rel_error_score;
+    double Kp, RKp, s_rho_q, tresh, score, rel_error, rel_error_score;   /* tresh: FirstThr's threshold state behind the frame's detection(s) —
+                                                                           with a stereo rig, behind the pair image's (rebvo_first_t.cpp:266-290) */
     float retuned_thresh;
     int32_t kn, klm_fwd, klm_num, kf_matchs, estimation_ok, frame, minimizer_evals;
 } edgehip_nav;
@@ -284,7 +285,10 @@ int edgehip_regularize_ekf(edgehip_ctx *ctx, int slot, int do_regularize, int do
  * The per-KeyLine rows and the 27 sums run on the device, the 6x6 SVD solve on the host.  Synchronises. */
 int edgehip_ext_rot_vel(edgehip_ctx *ctx, int slot, const double *vel, double loc_unc, double hub_reweight, double *X,
                         double *Wx, double *Rx, int32_t *ok);
-/* EstimateReScalingOpt (rebvo_second_t.cpp:487; edge_tracker.cpp:1104-1140) -> seq_state.Kp, P_Kp. */
+/* EstimateReScalingOpt (rebvo_second_t.cpp:487; edge_tracker.cpp:1104-1140) -> seq_state.Kp, P_Kp.
+ * Parity: the five dependent weighted sums are block reductions in a fixed order (the reference adds KeyLine by KeyLine) and
+ * the per-KeyLine divisions are reciprocal + Newton steps (an ulp or two each), so Kp — and every rho that DoReScaling
+ * multiplies by it — follows the reference to about 1e-10 relative, not bit for bit (tests/test_stage_c_gpu.py: 1e-10). */
 int edgehip_rescale(edgehip_ctx *ctx, int slot);
 
 /* ---- stereo depth (REBVO/StereoAvaiable, experimental upstream) ------------- */

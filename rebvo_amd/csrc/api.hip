@@ -24,6 +24,20 @@ int wait_pinned_ring(edgehip_ctx *c) {
     return 0;
 }
 
+// Before the page-locked index row of a binding is rewritten: stage A reads the row in place, so if `pi` is the row the slot is
+// bound through right now, whoever may still be reading it has to finish first — a stage A enqueued by the stage-level entry
+// point (bind; edgehip_stage_a; bind again with no synchronisation in between: frames_seen has not moved, it is the same
+// row), or, for a binding kept across frames (a pair slot bound once), the frame that last ran in this slot, whose ring entry
+// comes round again eight frames later.  The steady replay (a new binding per frame) never waits here: its previous binding
+// of the slot lives in another row.
+static int wait_idx_row(edgehip_ctx *c, int slot, const int32_t *pi) {
+    if (c->slot_src[slot].idx_row != pi) return 0;
+    if (c->a_api_valid[slot]) EH_CHECK(hipEventSynchronize(c->ev_a[slot]));
+    const int r = c->slot_ring[slot];
+    if (r >= 0 && c->ring_valid[r]) EH_CHECK(hipEventSynchronize(c->ev_ring[r]));
+    return 0;
+}
+
 int wait_upload(edgehip_ctx *c, int slot, hipStream_t st) {
     if (slot >= 0 && slot < 4 && c->up_valid[slot]) {
         EH_CHECK(hipStreamWaitEvent(st, c->ev_up[slot], 0));
@@ -310,6 +324,16 @@ int edgehip_create(const edgehip_params *params, int nseq, int nslots, int devic
         return EDGEHIP_ERR_DEVICE;
     }
     EH_CHECK(hipSetDevice(device));
+    {   // the kernels are written for gfx950: k_stage_a_fused and k_rescale opt into 128-160 KB of LDS per workgroup and have no
+        // smaller form — a device without it is refused here instead of failing at the first frame
+        int lds_max = 0;
+        (void)hipDeviceGetAttribute(&lds_max, hipDeviceAttributeMaxSharedMemoryPerBlock, device);
+        if (lds_max > 0 && lds_max < 160 * 1024) {
+            set_error("edgehip_create: device " + std::to_string(device) + " offers " + std::to_string(lds_max) +
+                      " B of LDS per workgroup; libedgehip is built for MI355X / gfx950 (160 KB)");
+            return EDGEHIP_ERR_DEVICE;
+        }
+    }
     edgehip_ctx *c = new edgehip_ctx();
     CtxAllocs *al = new CtxAllocs();
     {
@@ -470,7 +494,7 @@ static int create_body(edgehip_ctx *c, CtxAllocs *al, const edgehip_params &p, i
     c->no_grec = getenv("EDGEHIP_NO_GREC") && atoi(getenv("EDGEHIP_NO_GREC")) != 0;
     c->level_mode = getenv("EDGEHIP_LEVEL_MODE") ? atoi(getenv("EDGEHIP_LEVEL_MODE")) : 0;
     c->fwd_mode = getenv("EDGEHIP_FWD_MODE") ? atoi(getenv("EDGEHIP_FWD_MODE")) : 0;
-    c->fused_min_batch = getenv("EDGEHIP_FUSED_MIN_BATCH") ? atoi(getenv("EDGEHIP_FUSED_MIN_BATCH")) : 192;   // one workgroup per sequence: pays from about 3/4 of the 256 CUs on (tools/experiments/ab_level_mode.sh)
+    c->fused_min_batch = fused_min_env;   // one workgroup per sequence: pays from about 3/4 of the 256 CUs on (tools/experiments/ab_level_mode.sh)
     c->dual_init = getenv("EDGEHIP_DUAL_INIT") ? atoi(getenv("EDGEHIP_DUAL_INIT")) : 1;
     c->persist_lm_max = getenv("EDGEHIP_PERSIST_LM") ? atoi(getenv("EDGEHIP_PERSIST_LM")) : 0;   // measured: no gain (tools/experiments/exp_single_latency.py), so off
     EH_TRY(dmalloc(c, &c->sync_cnt, B, al->dev, 0));
@@ -633,6 +657,11 @@ int edgehip_reset(edgehip_ctx *c) {
     EH_CHECK(hipStreamSynchronize(c->stream));
     c->frame_slot = -1;
     c->frames_seen = 0;
+    {   // frame numbers start over: so does the log
+        std::lock_guard<std::mutex> g(c->log_mu);
+        c->frames_logged = 0;
+        c->log_first = 0; c->log_last = -1;
+    }
     return 0;
 }
 
@@ -728,14 +757,14 @@ int edgehip_upload_grey8(edgehip_ctx *c, int slot, const uint8_t *grey8, int seq
     if (int e = check_slot(c, slot)) return e;
     if (!grey8 || seq_first < 0 || count < 1 || seq_first + count > c->plan.nseq) { set_error("upload_grey8: bad range"); return EDGEHIP_ERR_ARG; }
     if (int e = ensure_grey8(c)) return e;
-    unbind_rgb(c, slot, true);
-    if (int e = wait_upload(c, slot, c->stream_a)) return e;
     const size_t fb = c->plan.n;
-    if (!c->pinned_grey8) {
+    if (!c->pinned_grey8) {   // everything that can fail comes before the slot changes its format: a failed call leaves the slot as it was
         void *q = nullptr;
         EH_CHECK(hipHostMalloc(&q, fb * c->plan.nseq, hipHostMallocDefault));
         c->pinned_grey8 = (uint8_t *)q;
     }
+    if (int e = wait_upload(c, slot, c->stream_a)) return e;
+    unbind_rgb(c, slot, true);
     if (c->stage8_busy) EH_CHECK(hipEventSynchronize(c->ev_stage8));   // the staging buffer is reused: wait for the previous copy out of it
     memcpy(c->pinned_grey8 + fb * seq_first, grey8, fb * count);
     EH_CHECK(hipMemcpyAsync(c->grey8 + ((size_t)slot * c->plan.nseq + seq_first) * fb, c->pinned_grey8 + fb * seq_first, fb * count,
@@ -766,10 +795,10 @@ int edgehip_bind_grey8_indexed(edgehip_ctx *c, int slot, const void *pool_dev, i
     const int B = c->plan.nseq;
     int32_t *pi = c->pinned_idx + ((size_t)(c->frames_seen % 8) * 4 + slot) * B;
     if (int e = wait_pinned_ring(c)) return e;
-    for (int s = 0; s < B; s++) {
+    for (int s = 0; s < B; s++)    // validate first: a rejected call leaves the current binding's row alone
         if (idx[s] < 0 || idx[s] >= pool_frames) { set_error("bind_grey8_indexed: index out of range"); return EDGEHIP_ERR_ARG; }
-        pi[s] = idx[s];
-    }
+    if (int e = wait_idx_row(c, slot, pi)) return e;
+    for (int s = 0; s < B; s++) pi[s] = idx[s];
     // stage A reads the row in place (page-locked, device-visible): no copy on the frame's critical path.  The row belongs to
     // this ring entry until the frame that uses it has run (wait_pinned_ring).
     edgehip_ctx::SlotSrc &ss = c->slot_src[slot];
@@ -822,10 +851,10 @@ int edgehip_bind_rgb_indexed(edgehip_ctx *c, int slot, const void *pool_dev, int
     // stereo pair slot, a prefetch), and each copy out of the ring is asynchronous.
     int32_t *pi = c->pinned_idx + ((size_t)(c->frames_seen % 8) * 4 + slot) * B;
     if (int e = wait_pinned_ring(c)) return e;
-    for (int s = 0; s < B; s++) {
+    for (int s = 0; s < B; s++)    // validate first: a rejected call leaves the current binding's row alone
         if (idx[s] < 0 || idx[s] >= pool_frames) { set_error("bind_rgb_indexed: index out of range"); return EDGEHIP_ERR_ARG; }
-        pi[s] = idx[s];
-    }
+    if (int e = wait_idx_row(c, slot, pi)) return e;
+    for (int s = 0; s < B; s++) pi[s] = idx[s];
     // stage A reads the row in place (page-locked, device-visible): no copy on the frame's critical path.  The row belongs to
     // this ring entry until the frame that uses it has run (wait_pinned_ring).
     edgehip_ctx::SlotSrc &ss = c->slot_src[slot];
@@ -847,6 +876,7 @@ int edgehip_set_nav_log(edgehip_ctx *c, int len) {
     if (c->nav_log) { (void)hipFree(c->nav_log); c->nav_log = nullptr; }
     c->nav_log_len = 0;
     c->frames_logged = 0;
+    c->log_first = 0; c->log_last = -1;
     if (len > 0 && !c->stream_log) {
         EH_CHECK(hipStreamCreateWithFlags(&c->stream_log, hipStreamNonBlocking));
         EH_CHECK(hipEventCreateWithFlags(&c->ev_log, hipEventDisableTiming));
@@ -871,9 +901,17 @@ int edgehip_read_nav_log(edgehip_ctx *c, int first, int count, edgehip_nav *out)
     // Records of frames that were never enqueued do not exist; `first` counts frames since edgehip_reset / the first frame
     // (edgehip_nav::frame), the counter frames since edgehip_set_nav_log — equal when the log is set before the first frame.
     const size_t B = c->plan.nseq;
+    // [first, first + count) must be frames whose records exist: enqueued since the log was set, and not yet overwritten by a
+    // frame one ring length later.  Anything else used to come back as stale or zero records with rc 0.
+    auto in_ring = [&](long long last) { return (long long)first + count - 1 <= last && (long long)first > last - c->nav_log_len; };
     {
         std::lock_guard<std::mutex> g(c->log_mu);
         if (c->frames_logged.load() < 1) { set_error("read_nav_log: no frame has been enqueued since the log was set"); return EDGEHIP_ERR_STATE; }
+        if ((long long)first < c->log_first || !in_ring(c->log_last)) {
+            set_error("read_nav_log: frames " + std::to_string(first) + ".." + std::to_string(first + count - 1) + " are not in the log (it holds " +
+                      std::to_string(std::max(c->log_first, c->log_last - c->nav_log_len + 1)) + ".." + std::to_string(c->log_last) + ")");
+            return EDGEHIP_ERR_STATE;
+        }
         EH_CHECK(hipStreamWaitEvent(c->stream_log, c->ev_log, 0));   // every frame enqueued so far, on whichever stream wrote its record
     }
     for (int k = 0; k < count; k++) {
@@ -881,6 +919,10 @@ int edgehip_read_nav_log(edgehip_ctx *c, int first, int count, edgehip_nav *out)
         EH_CHECK(hipMemcpyAsync(out + (size_t)k * B, c->nav_log + (size_t)slot * B, sizeof(edgehip_nav) * B, hipMemcpyDeviceToHost, c->stream_log));
     }
     EH_CHECK(hipStreamSynchronize(c->stream_log));
+    {   // the thread that enqueues frames may have gone on meanwhile: a frame one ring length ahead writes the entries just copied
+        std::lock_guard<std::mutex> g(c->log_mu);
+        if (!in_ring(c->log_last)) { set_error("read_nav_log: the ring was overwritten during the read (frames enqueued more than its length ahead)"); return EDGEHIP_ERR_STATE; }
+    }
     return 0;
 }
 

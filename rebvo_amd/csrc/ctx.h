@@ -276,6 +276,7 @@ struct edgehip_ctx {
     hipEvent_t ev_log = nullptr;
     std::mutex log_mu;
     std::atomic<long long> frames_logged{0};   // frames enqueued since the log was set
+    long long log_first = 0, log_last = -1;    // frame numbers (frames_seen at enqueue) of the first / newest logged frame (under log_mu)
     int32_t *idx_dev;      // [B] frame-pool indices of upload_rgb_indexed
     int32_t *stereo_cnt;   // [B] stereo match counters (params.stereo_available)
     // host staging

@@ -1276,12 +1276,22 @@ __global__ __launch_bounds__(256) void k_expand_grey8(const uint8_t *__restrict_
 // ---------------------------------------------------------------------------------------------------
 // host side
 // ---------------------------------------------------------------------------------------------------
+// out_dev: 3 N bytes at the start of the stage-A scratch (c->ii, 16 N bytes per sequence); a mono slot's frame is expanded to
+// RGB24 behind it first (r = g = b = v, what the undistorting load of stage A sees of it)
 int undistort_frame_enqueue(edgehip_ctx *c, int seq, int slot, uint8_t *out_dev) {
     const DevicePlan &pl = c->plan;
-    hipLaunchKernelGGL(k_undistort_frame, dim3((pl.n + 255) / 256), dim3(256), 0, c->stream_a,
-                       c->slot_src[slot].base ? c->slot_src[slot].base + (size_t)c->slot_src[slot].host_idx[seq] * pl.n * 3
-                                              : rgbof(c, slot) + (size_t)seq * pl.n * 3,
-                       out_dev, pl.w, pl.n, c->und_base, c->und_iw);
+    const edgehip_ctx::SlotSrc &ss = c->slot_src[slot];
+    const uint8_t *src;
+    if (ss.grey8) {
+        const uint8_t *g8 = ss.base ? ss.base + (size_t)ss.host_idx[seq] * pl.n : c->grey8 + ((size_t)slot * pl.nseq + seq) * pl.n;
+        uint8_t *rgb = out_dev + (((size_t)pl.n * 3 + 255) & ~(size_t)255);
+        hipLaunchKernelGGL(k_expand_grey8, dim3((unsigned)((pl.n / 4 + 255) / 256), 1, 1), dim3(256), 0, c->stream_a, g8, (const int32_t *)nullptr, rgb, pl.n);
+        EH_LAUNCH_CHECK();
+        src = rgb;
+    } else {
+        src = ss.base ? ss.base + (size_t)ss.host_idx[seq] * pl.n * 3 : rgbof(c, slot) + (size_t)seq * pl.n * 3;
+    }
+    hipLaunchKernelGGL(k_undistort_frame, dim3((pl.n + 255) / 256), dim3(256), 0, c->stream_a, src, out_dev, pl.w, pl.n, c->und_base, c->und_iw);
     EH_LAUNCH_CHECK();
     return 0;
 }

@@ -1218,7 +1218,10 @@ int rescale_enqueue(edgehip_ctx *c, int slot, bool frame_ends) {
     if (frame_ends) {
         fe.nav = c->nav_dev;
         fe.kn_new = c->kn_slot + (size_t)slot * pl.nseq;
-        fe.tresh_new = c->tresh_slot + (size_t)slot * pl.nseq;
+        // the detector's threshold state behind the frame's stage A: with a stereo rig the pair image is detected after the frame's
+        // own, through the same controller (rebvo_first_t.cpp:275-290), so the state is the one the pair slot was detected with
+        const int slot_t = c->rig.enabled && c->rig.slot_pair >= 0 ? c->rig.slot_pair : slot;
+        fe.tresh_new = c->tresh_slot + (size_t)slot_t * pl.nseq;
         fe.retuned_new = c->retuned_slot + (size_t)slot * pl.nseq;
         fe.nav_log = c->nav_log; fe.nav_log_len = c->nav_log_len; fe.nseq = pl.nseq; fe.have_pair = 1;
     }
@@ -1669,6 +1672,8 @@ int edgehip_process_frame(edgehip_ctx *c, const double *t) {
     if (c->nav_log) {   // edgehip_read_nav_log (possibly another thread) orders its copies after this frame's record
         std::lock_guard<std::mutex> g(c->log_mu);
         EH_CHECK(hipEventRecord(c->ev_log, c->stream_imu ? c->stream_imu : c->stream));
+        if (c->frames_logged.load() == 0) c->log_first = c->frames_seen - 1;
+        c->log_last = c->frames_seen - 1;
         c->frames_logged++;
     }
     return 0;

@@ -293,6 +293,62 @@ def test_two_slots_bound_between_frames_keep_their_own_indices():
     eh.close()
 
 
+def test_rebinding_a_slot_without_a_sync_does_not_disturb_the_stage_a_in_flight():
+    """Regression (ADVICE r3): stage A reads a binding's index row in place from page-locked memory.  bind(slot, ia);
+    stage_a(slot); bind(slot, ib) with no synchronisation in between writes the SAME row (frames_seen has not moved) while the
+    first stage A may still be reading it — the second bind has to wait for it.  Large batch, so that the kernel is still
+    running when the second bind arrives; the KeyLine counts of the first stage A must be those of `ia`."""
+    import torch
+    w, h, npool, B = 256, 192, 6, 256
+    frames = [f for f, _, _ in synth.billboard_sequence(w, h, npool, seed=5)]
+    host = np.stack(frames)
+    pool = torch.empty(host.size + 16, dtype=torch.uint8, device="cuda")
+    pool[:host.size] = torch.from_numpy(host.reshape(-1)).cuda()
+    torch.cuda.synchronize()
+    eh = edgehip.EdgeHip(edgehip.euroc_params(w, h, auto_gain=0.0), nseq=B, nslots=3)
+    ref = []
+    for i in range(npool):
+        eh.bind_rgb_indexed(2, pool.data_ptr(), npool, np.full(B, i, np.int32))
+        eh.stage_a(2)
+        ref.append(int(eh.get_kn(2)[0]))
+    assert len(set(ref)) > 1, ref
+    ia = np.array([s % npool for s in range(B)], np.int32)
+    ib = np.array([(s + 3) % npool for s in range(B)], np.int32)
+    for rep in range(10):
+        eh.bind_rgb_indexed(0, pool.data_ptr(), npool, ia)
+        eh.stage_a(0)
+        eh.bind_rgb_indexed(0, pool.data_ptr(), npool, ib)      # no sync since the stage A above
+        # the slot's KeyLine counts are still those of the first stage A (nothing has run on the new binding yet)
+        assert [int(v) for v in eh.get_kn(0)] == [ref[i] for i in ia], rep
+        eh.stage_a(0)
+        assert [int(v) for v in eh.get_kn(0)] == [ref[i] for i in ib], rep
+    eh.close()
+
+
+def test_nav_log_reads_outside_the_logged_frames_are_refused():
+    """Regression: edgehip_read_nav_log returned stale or zero records with rc 0 for frames that were never
+    enqueued, or that a frame one ring length later had already overwritten."""
+    w, h = 188, 120
+    frames = [f for f, _, _ in synth.billboard_sequence(w, h, 6)]
+    eh = edgehip.EdgeHip(edgehip.euroc_params(w, h), nseq=2, nslots=3)
+    eh.set_nav_log(4)
+    with pytest.raises(RuntimeError):
+        eh.read_nav_log_array(0, 1)                    # nothing enqueued yet
+    for k in range(3):
+        eh.upload_rgb(eh.next_slot(), np.stack([frames[k]] * 2))
+        eh.process_frame(0.05 * k)
+    assert list(eh.read_nav_log_array(0, 3)["frame"][:, 0]) == [0, 1, 2]
+    with pytest.raises(RuntimeError, match="not in the log"):
+        eh.read_nav_log_array(1, 3)                    # frame 3 has not been enqueued
+    for k in range(3, 6):
+        eh.upload_rgb(eh.next_slot(), np.stack([frames[k]] * 2))
+        eh.process_frame(0.05 * k)
+    assert list(eh.read_nav_log_array(2, 4)["frame"][:, 1]) == [2, 3, 4, 5]
+    with pytest.raises(RuntimeError, match="not in the log"):
+        eh.read_nav_log_array(1, 2)                    # frame 1 left the 4-entry ring when frame 5 was written
+    eh.close()
+
+
 @pytest.mark.parametrize("kind", ["noise", "shuffled"])
 def test_frames_the_tracker_cannot_explain_finish_in_bounded_time(kind):
     """White noise, and a scene that jumps by a hundred pixels every frame: the minimiser diverges, velocity estimates go

@@ -132,3 +132,31 @@ def test_grey8_with_the_undistorting_load(mode, monkeypatch):
         res.append((navs, kl.tobytes(), mask))
         eh.close()
     assert res[0][0] == res[1][0] and res[0][1] == res[1][1] and np.array_equal(res[0][2], res[1][2])
+
+
+def test_undistorted_download_of_a_mono_slot():
+    """Regression: edgehip_download_undistorted took every slot for RGB24 — for a slot fed 8-bit mono frames
+    (uploaded, or bound to a pool of mono frames) it resampled the wrong bytes and, for a bound pool, read past its end.  The
+    mono slot's download must equal the RGB24 slot's (r = g = b = v), whether or not stage A has run on it."""
+    import torch
+    w, h = 640, 480
+    frames = [f for f, _, _ in synth.billboard_sequence(w, h, 3, fx=525.0, fy=525.0, cx=320.0, cy=240.0, seed=3)]
+    mono = [np.ascontiguousarray(f[:, :, 0]) for f in frames]
+    p = edgehip.tum_params(w, h, use_undistort=1)
+    eh = edgehip.EdgeHip(p, nseq=2, nslots=3)
+    eh.upload_rgb(0, np.stack([frames[0], frames[1]]))
+    want = [eh.download_undistorted(s, 0) for s in range(2)]
+    assert not np.array_equal(want[0], want[1])
+    eh.upload_grey8(1, np.stack([mono[0], mono[1]]))
+    for s in range(2):
+        assert np.array_equal(eh.download_undistorted(s, 1), want[s])     # straight after the upload, before any stage A
+    eh.stage_a(1)
+    for s in range(2):
+        assert np.array_equal(eh.download_undistorted(s, 1), want[s])
+    host = np.stack(mono)
+    pool = torch.empty(host.size + 16, dtype=torch.uint8, device="cuda")
+    pool[:host.size] = torch.from_numpy(host.reshape(-1)).cuda()
+    torch.cuda.synchronize()
+    eh.bind_grey8_indexed(2, pool.data_ptr(), 3, np.array([1, 0], np.int32))     # index 2 * n * 3 would lie outside the mono pool
+    assert np.array_equal(eh.download_undistorted(0, 2), want[1]) and np.array_equal(eh.download_undistorted(1, 2), want[0])
+    eh.close()
