@@ -10,6 +10,7 @@
 #include <mutex>
 
 #include "ctx.h"
+#include "stage_a_dev.h"
 
 namespace edgehip {
 
@@ -308,12 +309,20 @@ static int create_body(edgehip_ctx *c, CtxAllocs *al, const edgehip_params &p, i
 int edgehip_create(const edgehip_params *params, int nseq, int nslots, int device, edgehip_ctx **out) {
     if (!params || !out || nseq < 1 || nslots < 2) { set_error("edgehip_create: bad argument"); return EDGEHIP_ERR_ARG; }
     const edgehip_params &p = *params;
-    if (((size_t)p.w * p.h * 3) % 16 != 0) { set_error("edgehip_create: w*h*3 must be a multiple of 16"); return EDGEHIP_ERR_ARG; }
-    if (p.w < 16 || p.h < 16 || (p.w % 4) != 0 || p.w > 1024) {
-        set_error("edgehip_create: image width must be a multiple of 4 in [16,1024], height >= 16");
+    // Any image size the reference's own containers take (iimage / sspace / edge_finder are sized from Size2D, iimage.cpp:53-128),
+    // up to 2048 columns (the row-prefix kernel keeps at most 32 pixels of a row per lane) and 2^31 bytes per frame.  The
+    // one-kernel stage A and the one-pass level kernel serve widths that are a multiple of 4 (up to 788 / 1536 columns); every
+    // other width takes the multi-kernel path.
+    if (p.w < 16 || p.h < 16 || p.w > 2048 || (size_t)p.w * p.h * 3 >= ((size_t)1 << 31)) {
+        set_error("edgehip_create: image width must be in [16,2048], height >= 16, w*h*3 < 2^31");
         return EDGEHIP_ERR_ARG;
     }
-    if (p.plane_fit_size != 2) { set_error("edgehip_create: only DetectorPlaneFitSize=2 is supported"); return EDGEHIP_ERR_ARG; }
+    // DetectorPlaneFitSize (win_s of edge_finder::build_mask): the 3x3, 5x5 and 7x7 windows
+    if (p.plane_fit_size < 1 || p.plane_fit_size > 3) { set_error("edgehip_create: DetectorPlaneFitSize must be 1, 2 or 3"); return EDGEHIP_ERR_ARG; }
+    if (2 * p.plane_fit_size >= p.h || 2 * p.plane_fit_size >= p.w || detect_band_rows(p.w, p.plane_fit_size) == 0) {
+        set_error("edgehip_create: image too small / too wide for this DetectorPlaneFitSize");
+        return EDGEHIP_ERR_ARG;
+    }
     if (p.max_points < 1 || p.qcut_nbins < 1 || p.qcut_nbins > 256 || p.search_range < 1 || p.search_range > 255) {
         set_error("edgehip_create: max_points>=1, 1<=QCutOffNumBins<=256, 1<=SearchRange<=255 required");
         return EDGEHIP_ERR_ARG;
@@ -455,7 +464,7 @@ static int create_body(edgehip_ctx *c, CtxAllocs *al, const edgehip_params &p, i
         EH_CHECK(hipMemcpy(c->und_iw, iw.data(), sizeof(uint32_t) * 4 * N, hipMemcpyHostToDevice));
     }
     EH_TRY(dmalloc(c, &c->div_lut, kDivLutMax, al->dev));
-    EH_TRY(dmalloc(c, &c->pinv, 75, al->dev));
+    EH_TRY(dmalloc(c, &c->pinv, 3 * 49, al->dev, 0));
     EH_TRY(dmalloc(c, &c->seq, B, al->dev, 0));
     EH_TRY(dmalloc(c, &c->seqa, B, al->dev, 0));
     EH_TRY(dmalloc(c, &c->tresh_slot, S * B, al->dev, 0));
@@ -464,9 +473,10 @@ static int create_body(edgehip_ctx *c, CtxAllocs *al, const edgehip_params &p, i
     EH_TRY(dmalloc(c, &c->framecount, (size_t)c->fc_rows * B, al->dev, 0));
     EH_TRY(dmalloc(c, &c->kn_slot, S * B, al->dev, 0));
     EH_TRY(dmalloc(c, &c->retuned_slot, S * B, al->dev, 0));
-    c->nbands = (p.h - 4 + kBandRows - 1) / kBandRows;
+    c->band_rows = detect_band_rows(p.w, p.plane_fit_size);
+    c->nbands = (p.h - 2 * p.plane_fit_size + c->band_rows - 1) / c->band_rows;
     {
-        const int npx = kBandRows * p.w, nchunk = (npx + 63) / 64, cpw = (nchunk + kDetWaves - 1) / kDetWaves;
+        const int npx = c->band_rows * p.w, nchunk = (npx + 63) / 64, cpw = (nchunk + kDetWaves - 1) / kDetWaves;
         c->band_cap = cpw * 64;
     }
     const size_t nstrips = (size_t)c->nbands * kDetWaves;
@@ -552,19 +562,21 @@ static int create_body(edgehip_ctx *c, CtxAllocs *al, const edgehip_params &p, i
         std::vector<float> lut(kDivLutMax, 0.f);
         for (int k = 1; k < kDivLutMax; k++) lut[k] = (float)(1.0 / (double)(float)k);  // iimage.cpp:176-178
         EH_CHECK(hipMemcpyAsync(c->div_lut, lut.data(), sizeof(float) * kDivLutMax, hipMemcpyHostToDevice, c->stream));
-        double pinv[75];
-        plane_fit_pinv(2, pinv);
-        // k_detect keeps PInv as 5 + 5 + 1 coefficients: row 0 varies with the window column only, row 1 with the
-        // window row only, row 2 is constant (symmetric window).  Verify instead of assuming.
-        for (int i = 0; i < 5; i++)
-            for (int j = 0; j < 5; j++) {
-                const int k = i * 5 + j;
-                if (!(pinv[k] == pinv[j] && pinv[25 + k] == pinv[25 + 5 * i] && pinv[50 + k] == pinv[50])) {
-                    set_error("edgehip_create: plane-fit pseudo inverse lost its separable structure");
-                    return EDGEHIP_ERR_STATE;
+        double pinv[3 * 49] = {0};
+        plane_fit_pinv(p.plane_fit_size, pinv);
+        // The 5x5 window (what every shipped configuration uses): k_detect<2> and the one-kernel stage A keep PInv as 5 + 5 + 1
+        // coefficients — row 0 varies with the window column only, row 1 with the window row only, row 2 is constant
+        // (symmetric window).  Verify instead of assuming.  Other windows are applied as the 3 x n matrix they are.
+        if (p.plane_fit_size == 2)
+            for (int i = 0; i < 5; i++)
+                for (int j = 0; j < 5; j++) {
+                    const int k = i * 5 + j;
+                    if (!(pinv[k] == pinv[j] && pinv[25 + k] == pinv[25 + 5 * i] && pinv[50 + k] == pinv[50])) {
+                        set_error("edgehip_create: plane-fit pseudo inverse lost its separable structure");
+                        return EDGEHIP_ERR_STATE;
+                    }
                 }
-            }
-        memcpy(c->pinv_host, pinv, sizeof pinv);
+        memcpy(c->pinv_host, pinv, sizeof c->pinv_host);
         EH_CHECK(hipMemcpyAsync(c->pinv, pinv, sizeof pinv, hipMemcpyHostToDevice, c->stream));
         EH_CHECK(hipStreamSynchronize(c->stream));  // lut/pinv are stack temporaries
     }
@@ -834,10 +846,16 @@ int edgehip_upload_rgb_indexed(edgehip_ctx *c, int slot, const void *pool_dev, i
         if (idx[s] < 0 || idx[s] >= pool_frames) { set_error("upload_rgb_indexed: index out of range"); return EDGEHIP_ERR_ARG; }
         pi[s] = idx[s];
     }
+    const size_t fbytes = (size_t)c->plan.n * 3;
+    if (fbytes % 16 != 0 || ((uintptr_t)pool_dev & 15) != 0) {
+        // frames that are not whole 16-byte vectors (or a pool that does not start on one): one device copy per sequence
+        for (int s = 0; s < B; s++)
+            EH_CHECK(hipMemcpyAsync(rgbof(c, slot) + fbytes * s, (const uint8_t *)pool_dev + fbytes * idx[s], fbytes, hipMemcpyDeviceToDevice, c->stream_a));
+        return 0;
+    }
     EH_CHECK(hipMemcpyAsync(c->idx_dev, pi, sizeof(int32_t) * B, hipMemcpyHostToDevice, c->stream_a));
-    const size_t frame_vec = (size_t)c->plan.n * 3 / 16;  // w % 4 == 0 => n*3 % 4 == 0; need %16: checked at create
     hipLaunchKernelGGL(k_gather_frames, dim3(64, B), dim3(256), 0, c->stream_a, (const uint4 *)pool_dev, c->idx_dev,
-                       (uint4 *)rgbof(c, slot), frame_vec);
+                       (uint4 *)rgbof(c, slot), fbytes / 16);
     EH_LAUNCH_CHECK();
     return 0;
 }

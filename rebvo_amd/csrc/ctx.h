@@ -217,6 +217,7 @@ struct edgehip_ctx {
     int32_t *band_off;     // [B][nbands]
     void *band_stage;      // [B][nbands][band_cap] candidate records
     int nbands, band_cap;
+    int band_rows;         // image rows per k_detect band (kBandRows, fewer for images too wide for 12-row planes in LDS)
     int32_t *histo;        // [B][256] scratch histograms
     // stage B scratch
     double *P0;            // [B][3][CAP]

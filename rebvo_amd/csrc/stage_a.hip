@@ -93,8 +93,11 @@ __global__ __launch_bounds__(256) void k_rgb_rowscan(const uint8_t *__restrict__
                 sbw[x * 3] = c.x; sbw[x * 3 + 1] = c.y; sbw[x * 3 + 2] = c.z;
             }
         } else {
-            const uint32_t *src = reinterpret_cast<const uint32_t *>(rgb + (size_t)y * row_bytes);
-            for (int i = lane; i < row_dw; i += 64) stage[i] = src[i];  // w % 4 == 0 -> rows are dword aligned
+            // dword loads from the row's first byte: aligned when w % 4 == 0, any byte address otherwise (gfx9 global loads take
+            // it); the last dword of a row whose length is not a multiple of 4 reads up to 3 bytes of the next row / of the 16
+            // bytes of slack every frame store has behind it — staged, never used
+            const uint8_t *src = rgb + (size_t)y * row_bytes;
+            for (int i = lane; i < row_dw; i += 64) { uint32_t v; __builtin_memcpy(&v, src + 4 * (size_t)i, 4); stage[i] = v; }
         }
     }
     __syncthreads();
@@ -120,16 +123,22 @@ __global__ __launch_bounds__(256) void k_rgb_rowscan(const uint8_t *__restrict__
     }
     const int base = tot - run;
     float *out = dst + (size_t)seq * n + (size_t)y * w + x0;
+    if ((w & 3) == 0) {
 #pragma unroll
-    for (int i = 0; i < CH; i += 4) {
-        if (x0 + i < w) {  // w % 4 == 0: whole float4 or nothing
-            float4 o;
-            o.x = (float)(v[i] + base);
-            o.y = (float)(v[i + 1] + base);
-            o.z = (float)(v[i + 2] + base);
-            o.w = (float)(v[i + 3] + base);
-            *reinterpret_cast<float4 *>(out + i) = o;
+        for (int i = 0; i < CH; i += 4) {
+            if (x0 + i < w) {  // w % 4 == 0: whole float4 or nothing (rows and x0 are 16-byte aligned)
+                float4 o;
+                o.x = (float)(v[i] + base);
+                o.y = (float)(v[i + 1] + base);
+                o.z = (float)(v[i + 2] + base);
+                o.w = (float)(v[i + 3] + base);
+                *reinterpret_cast<float4 *>(out + i) = o;
+            }
         }
+    } else {   // any other width: rows start at any float, the last group of a row may be partial
+#pragma unroll
+        for (int i = 0; i < CH; i++)
+            if (x0 + i < w) out[i] = (float)(v[i] + base);
     }
 }
 
@@ -690,25 +699,31 @@ struct DetectArgs {
     double gain, tmax, tmin;
     int kl_ref;
     float dog_thresh_f;        // (float)DetectorDoGThresh
-    double pn_thresh;          // (double)(25.0f * (float)DetectorPosNegThresh)
+    double pn_thresh;          // (double)((float)((2 win_s + 1)^2) * (float)DetectorPosNegThresh)
     int ablate;                // debug: bit0 skip phase 1 math, bit1 skip 2a, bit2 skip 2b
+    int band_rows;             // image rows per band (edgehip_ctx::band_rows: as many as the LDS planes of this width allow)
 };
 
+// WS = DetectorPlaneFitSize (win_s of build_mask, edge_finder.cpp:67-100): the DoG window of the sign balance and of the plane
+// fit is (2 WS + 1)^2, rows / columns closer than WS to the border are not scanned (:110-111).
+template <int WS>
 __global__ __launch_bounds__(kDetWaves * 64) void k_detect(DetectArgs a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    constexpr int WIN = 2 * WS + 1, NW2 = WIN * WIN;
     const int w = a.w, h = a.h;
-    constexpr int HR = kBandRows + 4;  // rows held in LDS
+    const int BR = a.band_rows;
+    const int HR = BR + 2 * WS;        // rows held in LDS
     float *s_img0 = reinterpret_cast<float *>(smem);   // [HR][w]
     float *s_dog = s_img0 + (size_t)HR * w;            // [HR][w]
-    __shared__ double s_pinv[75];
+    __shared__ double s_pinv[3 * NW2];
     __shared__ float s_lut[kDivLutMax];
     const int seq = blockIdx.z, band = blockIdx.x;
     const int tid = threadIdx.x;
-    const int y0 = 2 + band * kBandRows;  // first output row of the band
-    const int yb0 = y0 - 2;               // first LDS row
+    const int y0 = WS + band * BR;        // first output row of the band
+    const int yb0 = y0 - WS;              // first LDS row
     const size_t so = (size_t)seq * a.n;
     const float *iic0 = a.iic0 + so, *iic1 = a.iic1 + so;
-    if (tid < 75) s_pinv[tid] = a.pinv[tid];
+    if (tid < 3 * NW2) s_pinv[tid] = a.pinv[tid];
     if (tid < kDivLutMax) s_lut[tid] = a.lut[tid];
     __syncthreads();
 
@@ -761,6 +776,7 @@ __global__ __launch_bounds__(kDetWaves * 64) void k_detect(DetectArgs a) {
 #pragma unroll
             for (int i = 0; i < 4; i++) {
                 const int r = r0 + i, y = yb0 + r;
+                if (r >= HR) continue;     // HR is a multiple of 4 for the default band (12 + 4), not for every band height / window
                 float g[2];
                 if (interior) {
 #pragma unroll
@@ -770,8 +786,8 @@ __global__ __launch_bounds__(kDetWaves * 64) void k_detect(DetectArgs a) {
                     }
                     s_img0[r * w + x] = g[0];
                     s_dog[r * w + x] = g[1] - g[0];                                    // sspace.cpp:66
-                    if (a.planes && ((y >= y0 && y < y0 + kBandRows) || (band == 0 && y < 2) ||
-                                     (y >= 2 + (int)gridDim.x * kBandRows))) {
+                    if (a.planes && ((y >= y0 && y < y0 + BR) || (band == 0 && y < WS) ||
+                                     (y >= WS + (int)gridDim.x * BR))) {
                         float *pl = a.planes + so;
                         const size_t pstride = (size_t)a.nseq * a.n;
                         pl[0 * pstride + (size_t)y * w + x] = g[0];
@@ -799,8 +815,8 @@ __global__ __launch_bounds__(kDetWaves * 64) void k_detect(DetectArgs a) {
                 s_img0[r * w + x] = inimg ? g[0] : 0.f;
                 s_dog[r * w + x] = inimg ? g[1] - g[0] : 0.f;                          // sspace.cpp:66
                 // every image row is written to the debug planes by exactly one band
-                if (a.planes && inimg && ((y >= y0 && y < y0 + kBandRows) || (band == 0 && y < 2) ||
-                                          (y >= 2 + (int)gridDim.x * kBandRows))) {
+                if (a.planes && inimg && ((y >= y0 && y < y0 + BR) || (band == 0 && y < WS) ||
+                                          (y >= WS + (int)gridDim.x * BR))) {
                     float *pl = a.planes + so;
                     const size_t pstride = (size_t)a.nseq * a.n;
                     pl[0 * pstride + (size_t)y * w + x] = g[0];
@@ -822,7 +838,7 @@ __global__ __launch_bounds__(kDetWaves * 64) void k_detect(DetectArgs a) {
 
     // ---- phase 2: tests, raster order inside the wave's quarter of the band ----
     const int wave = tid >> 6, lane = tid & 63;
-    const int npx = kBandRows * w;
+    const int npx = BR * w;
     const int nchunk = (npx + 63) >> 6;
     const int cpw = (nchunk + kDetWaves - 1) / kDetWaves;  // chunks per wave
     const int strip = band * kDetWaves + wave;
@@ -835,20 +851,20 @@ __global__ __launch_bounds__(kDetWaves * 64) void k_detect(DetectArgs a) {
     int nlist = 0;
     if (!(a.ablate & 2)) {
         // A band is a contiguous run of image rows and its LDS planes have the image's row pitch: pixel q of the band (in
-        // raster order) is image pixel y0*w + q and LDS element 2*w + q — no (row, column) arithmetic per pixel.  Only
-        // the column is tracked, for the two border columns on either side.
+        // raster order) is image pixel y0*w + q and LDS element WS*w + q — no (row, column) arithmetic per pixel.  Only
+        // the column is tracked, for the WS border columns on either side.
         int q = wave * cpw * 64 + lane;
         int x = q % w;                                           // one division per thread; then advance by 64 pixels per chunk
-        const int q_end = min(npx, (h - 2 - y0) * w);            // rows y >= h-2 are not scanned (edge_finder.cpp:105)
+        const int q_end = min(npx, (h - WS - y0) * w);           // rows y >= h-WS are not scanned (edge_finder.cpp:110)
         int32_t *mrow = mask + (size_t)y0 * w;
-        const float *img0c = s_img0 + 2 * w;
+        const float *img0c = s_img0 + WS * w;
         for (int ci = 0; ci < cpw; ci++, q += 64, x += 64) {
             while (x >= w) x -= w;
             bool pass = false;
             if (q < q_end) {
                 // default: no KeyLine (edge_finder.cpp:109); border columns are never KeyLines either
                 mrow[q] = -1;
-                if (x >= 2 && x < w - 2) {
+                if (x >= WS && x < w - WS) {
                     const float *c0 = img0c + q;
                     const float dx = c0[1] - c0[-1];   // sspace.cpp:80
                     const float dy = c0[w] - c0[-w];   // sspace.cpp:81
@@ -871,10 +887,11 @@ __global__ __launch_bounds__(kDetWaves * 64) void k_detect(DetectArgs a) {
     // PInv(0,k) depends on the window column only, PInv(1,k) on the window row only, PInv(2,k) is constant (the
     // window is symmetric; checked on the host when the table is built): 11 coefficients live in registers
     // instead of 75 LDS reads per candidate.  The accumulation order over k is unchanged.
+    // (WS = 2, what every shipped configuration uses; other windows take the matrix as it is.)
     double pc0[5], pc1[5];
 #pragma unroll
-    for (int j = 0; j < 5; j++) { pc0[j] = s_pinv[j]; pc1[j] = s_pinv[25 + 5 * j]; }
-    const double pc2 = s_pinv[50];
+    for (int j = 0; j < 5; j++) { pc0[j] = WS == 2 ? s_pinv[j] : 0.0; pc1[j] = WS == 2 ? s_pinv[25 + 5 * j] : 0.0; }
+    const double pc2 = WS == 2 ? s_pinv[50] : 0.0;
     // 2b': the DoG sign-balance test (:125-137) needs no arithmetic: run it first and compact the list once more
     // (in place: the write index never passes the read index), so the fp64 plane fit below runs with full lanes on
     // the pixels that can still become KeyLines.
@@ -886,13 +903,13 @@ __global__ __launch_bounds__(kDetWaves * 64) void k_detect(DetectArgs a) {
             uint16_t qv = 0;
             if (li < nlist) {
                 qv = s_list[li];
-                const float *dg = s_dog + 2 * w + (int)qv;   // band pixel q = LDS element 2*w + q
-                int npos = 0;   // pn = (#positive) - (#not positive) = 2*npos - 25
+                const float *dg = s_dog + WS * w + (int)qv;   // band pixel q = LDS element WS*w + q
+                int npos = 0;   // pn = (#positive) - (#not positive) = 2*npos - (2 WS + 1)^2
 #pragma unroll
-                for (int i = -2; i <= 2; i++)
+                for (int i = -WS; i <= WS; i++)
 #pragma unroll
-                    for (int j = -2; j <= 2; j++) npos += (dg[i * w + j] > 0) ? 1 : 0;
-                const int pn = 2 * npos - 25;
+                    for (int j = -WS; j <= WS; j++) npos += (dg[i * w + j] > 0) ? 1 : 0;
+                const int pn = 2 * npos - NW2;
                 const int apn = pn < 0 ? -pn : pn;
                 keep = !((double)apn > a.pn_thresh);
             }
@@ -911,17 +928,23 @@ __global__ __launch_bounds__(kDetWaves * 64) void k_detect(DetectArgs a) {
         if (li < nlist) {
             const int q = s_list[li];
             pix = y0 * w + q;                                // = (y0 + r) * w + x
-            const float *dg = s_dog + 2 * w + q;
+            const float *dg = s_dog + WS * w + q;
             double t0 = 0, t1 = 0, t2 = 0;
 #pragma unroll
-            for (int i = -2, k = 0; i <= 2; i++) {
+            for (int i = -WS, k = 0; i <= WS; i++) {
 #pragma unroll
-                for (int j = -2; j <= 2; j++, k++) {
+                for (int j = -WS; j <= WS; j++, k++) {
                     const float v = dg[i * w + j];
                     const double yv = (double)v;
-                    t0 += pc0[j + 2] * yv;         // TooN dot product: result += a[i]*b[i], k = 0..24 in order
-                    t1 += pc1[i + 2] * yv;
-                    t2 += pc2 * yv;
+                    if (WS == 2) {
+                        t0 += pc0[j + 2] * yv;         // TooN dot product: result += a[i]*b[i], k = 0..24 in order
+                        t1 += pc1[i + 2] * yv;
+                        t2 += pc2 * yv;
+                    } else {                           // theta = PInv * Y (edge_finder.cpp:144), row by row in the same order
+                        t0 += s_pinv[k] * yv;
+                        t1 += s_pinv[NW2 + k] * yv;
+                        t2 += s_pinv[2 * NW2 + k] * yv;
+                    }
                 }
             }
             {
@@ -1264,6 +1287,13 @@ __global__ __launch_bounds__(256) void k_expand_grey8(const uint8_t *__restrict_
     uint8_t *dst = rgb + (size_t)seq * (size_t)n * 3;
     const int q = blockIdx.x * 256 + threadIdx.x;          // four pixels per thread: 4 B in, 12 B out
     if (q * 4 >= n) return;
+    if ((n & 3) != 0) {     // frames of n % 4 != 0 pixels start off a dword boundary and end inside one: byte by byte
+        for (int i = q * 4; i < min(n, q * 4 + 4); i++) {
+            const uint8_t g = src[i];
+            dst[(size_t)i * 3] = g; dst[(size_t)i * 3 + 1] = g; dst[(size_t)i * 3 + 2] = g;
+        }
+        return;
+    }
     const uint32_t v = *reinterpret_cast<const uint32_t *>(src + (size_t)q * 4);
     const uint32_t a = v & 0xFFu, b = (v >> 8) & 0xFFu, c2 = (v >> 16) & 0xFFu, d = v >> 24;
     uint3 o;
@@ -1354,7 +1384,8 @@ int stage_a_enqueue(edgehip_ctx *c, int slot, bool fwd_fills, bool defer_retune)
 
     float *cur[2] = {ii[0], ii[0]};
     const int planes_in_flight = B * 2;
-    const bool use_level = c->level_mode == 2 || (c->level_mode == 0 && planes_in_flight >= 192 && w <= LV_NC * LV_MAXCOL);
+    // (k_level's row scan walks float4 steps: widths that are not a multiple of 4 take the multi-pass kernels)
+    const bool use_level = (w & 3) == 0 && w <= LV_NC * LV_MAXCOL && (c->level_mode == 2 || (c->level_mode == 0 && planes_in_flight >= 192));
     if (use_level) {
         // one pass per level and plane (k_level): grey -> integral #1, then the box levels
         const size_t sm = ((size_t)2 * LV_RB * level_row_stride(w) + 32 + kDivLutMax) * sizeof(float);   // + scan tail pad + LUT copy
@@ -1548,16 +1579,28 @@ int stage_a_enqueue(edgehip_ctx *c, int slot, bool fwd_fills, bool defer_retune)
 #else
         a.ablate = 0;
 #endif
-        const int npx_b = kBandRows * w, cpw_b = (((npx_b + 63) >> 6) + kDetWaves - 1) / kDetWaves;
-        const size_t sm = (size_t)2 * (kBandRows + 4) * w * sizeof(float) + (size_t)kDetWaves * cpw_b * 64 * sizeof(uint16_t);
+        a.band_rows = c->band_rows;
+        const size_t sm = detect_lds_bytes(w, c->band_rows, ws);
+        void (*fn)(DetectArgs) = ws == 1 ? k_detect<1> : ws == 3 ? k_detect<3> : k_detect<2>;
         if (sm > 64 * 1024) {
             bool &done = c->lds_optin_detect;
             if (!done) {
-                EH_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_detect), hipFuncAttributeMaxDynamicSharedMemorySize, 158 * 1024));
+                // (the limit is 160 KB minus the kernel's static LDS: the pseudo inverse and the reciprocal table, 1.2-2.2 KB)
+                hipFuncAttributes fa;
+                EH_CHECK(hipFuncGetAttributes(&fa, reinterpret_cast<const void *>(fn)));
+                const int dyn_max = 160 * 1024 - (int)fa.sharedSizeBytes;   // the same for every context of the process: the attribute belongs to the kernel
+                const hipError_t ae = (size_t)dyn_max < sm ? hipErrorInvalidValue
+                                                           : hipFuncSetAttribute(reinterpret_cast<const void *>(fn), hipFuncAttributeMaxDynamicSharedMemorySize, dyn_max);
+                if (ae != hipSuccess) {
+                    (void)hipGetLastError();
+                    set_error("stage A: the detector's LDS planes (" + std::to_string(sm) + " B for a " + std::to_string(w) + "-column band of " +
+                              std::to_string(c->band_rows) + " rows, window " + std::to_string(ws) + ") were refused: " + hipGetErrorString(ae));
+                    return EDGEHIP_ERR_DEVICE;
+                }
                 done = true;
             }
         }
-        hipLaunchKernelGGL(k_detect, dim3(nbands, 1, B), dim3(kDetWaves * 64), sm, st, a);
+        hipLaunchKernelGGL(fn, dim3(nbands, 1, B), dim3(kDetWaves * 64), sm, st, a);
         EH_LAUNCH_CHECK();
     }
     {

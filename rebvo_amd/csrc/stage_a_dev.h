@@ -53,6 +53,19 @@ struct FusedArgs {
     int ablate;                // timing experiments (EXPERIMENTS builds only)
 };
 
+// LDS of k_detect<WS> for a band of `band_rows` image rows: img0 and DoG of the band + WS halo rows either side, and the
+// per-wave candidate lists (one 16-bit entry per band pixel)
+inline size_t detect_lds_bytes(int w, int band_rows, int ws) {
+    const int npx = band_rows * w, cpw = (((npx + 63) >> 6) + kDetWaves - 1) / kDetWaves;
+    return (size_t)2 * (band_rows + 2 * ws) * w * sizeof(float) + (size_t)kDetWaves * cpw * 64 * sizeof(uint16_t);
+}
+// the tallest band (12, 8, 4 or 2 rows) whose planes fit the LDS the kernel may opt into; 0 if not even two rows do
+inline int detect_band_rows(int w, int ws) {
+    for (int br : {kBandRows, 8, 4, 2})
+        if (detect_lds_bytes(w, br, ws) <= (size_t)156 * 1024) return br;   // + up to 2.2 KB of static LDS (pseudo inverse, reciprocal table) <= 160 KB
+    return 0;
+}
+
 bool fused_supported(const edgehip_ctx *c);
 // what the fused kernel's first load reads: the RGB24 frame (ConvertRGB2BW fused: b+g+r), the 16-bit grey plane of
 // k_undistort_grey, or an 8-bit mono frame (b+g+r of r = g = b = v: 3 v, the same integer ConvertRGB2BW computes from the

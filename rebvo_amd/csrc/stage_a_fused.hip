@@ -775,6 +775,7 @@ bool fused_supported(const edgehip_ctx *c) {
     if (pl.box[0][0] != 3 || pl.box[0][1] != 3 || pl.box[0][2] != 5) return false;
     if (pl.box[1][0] != 3 || pl.box[1][1] != 5 || pl.box[1][2] != 5) return false;
     if (c->p.plane_fit_size != 2) return false;
+    if ((pl.w & 3) != 0) return false;                       // column pairs, float4 scan steps
     if (c->pinv_host[2] != 0.0 || c->pinv_host[25 + 10] != 0.0) return false;   // plane_fit5 skips these terms
     const int nw = fused_col_waves(pl.w);
     if (nw + 2 > 8) return false;                           // column waves + scan wave + fit wave; 256 VGPRs per thread need <= 8 waves per workgroup

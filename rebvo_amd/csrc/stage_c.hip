@@ -1261,8 +1261,9 @@ static int ext_rotvel_enqueue(edgehip_ctx *c, int slot) {
 
 static int glue(edgehip_ctx *c, int mode, int slot_new, int have_pair) {
     const DevicePlan &pl = c->plan;
+    const int slot_t = c->rig.enabled && c->rig.slot_pair >= 0 ? c->rig.slot_pair : slot_new;   // see rescale_enqueue
     hipLaunchKernelGGL(k_frame_glue, dim3((pl.nseq + 63) / 64), dim3(64), 0, c->stream, c->seq, c->t_src, c->nav_dev,
-                       c->kn_slot + (size_t)slot_new * pl.nseq, c->tresh_slot + (size_t)slot_new * pl.nseq,
+                       c->kn_slot + (size_t)slot_new * pl.nseq, c->tresh_slot + (size_t)slot_t * pl.nseq,
                        c->retuned_slot + (size_t)slot_new * pl.nseq, pl.nseq, mode, c->p.config_fps, c->p.global_match_threshold,
                        have_pair, c->nav_log, c->nav_log_len);
     EH_LAUNCH_CHECK();

@@ -46,7 +46,7 @@ def test_create_fails_loudly_without_gpu_or_on_bad_args():
     import ctypes as C
     lib = edgehip.load_library()
     ctx = C.c_void_p()
-    p = edgehip.euroc_params(190, 144)  # width not a multiple of 4 -> argument error, never a CPU fallback
+    p = edgehip.euroc_params(190, 144, plane_fit_size=4)  # no such detector window -> argument error, never a CPU fallback
     rc = lib.edgehip_create(C.byref(p), 1, 2, 0, C.byref(ctx))
     assert rc < 0 and not ctx.value
     assert lib.edgehip_last_error()
