@@ -52,6 +52,52 @@ sys.path.insert(0, ROOT)
 
 W, H = 752, 480
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+FRAME_DT = 0.05        # seconds between frames of a replay (EuRoC: 20 Hz); a mounted data set sets its own mean interval
+
+
+def find_dataset(path):
+    """The image list of a mounted data set in the layouts the reference's DataSetCam configs point at (datasetcam.cpp:51-85):
+    EuRoC `<path>/mav0/cam0/data.csv` + `data/` (also `<path>/cam0/...` or the cam0 directory itself; nanosecond stamps) or TUM
+    `<path>/rgb.txt` (seconds, names relative to <path>).  -> (kind, DataSetDir, DataSetFile, TimeScale) or None."""
+    if not path or not os.path.isdir(path):
+        return None
+    for sub in ("mav0/cam0", "cam0", ""):
+        d = os.path.join(path, sub) if sub else path
+        if os.path.isfile(os.path.join(d, "data.csv")) and os.path.isdir(os.path.join(d, "data")):
+            return "euroc", os.path.join(d, "data") + "/", os.path.join(d, "data.csv"), 1e-9
+    if os.path.isfile(os.path.join(path, "rgb.txt")):
+        return "tum", path.rstrip("/") + "/", os.path.join(path, "rgb.txt"), 1.0
+    return None
+
+
+def load_dataset(found, w, h, max_frames):
+    """The first `max_frames` images of the list through the host library's own DataSetCam (rebvo/dataset_c.h: list parser, time
+    stamps, PNG / PGM / PPM decoder — the code dataset_replay feeds the tracker with).  -> (frames [n][h][w][3] u8, stamps [n])."""
+    import ctypes as C
+    kind, ddir, dfile, scale = found
+    lib = C.CDLL(os.path.join(ROOT, "rebvo_amd", "lib", "librebvohost.so"))
+    lib.rebvo_dataset_open.restype = C.c_void_p
+    lib.rebvo_dataset_open.argtypes = [C.c_char_p, C.c_char_p, C.c_int, C.c_int, C.c_double]
+    lib.rebvo_dataset_frames.argtypes = [C.c_void_p]
+    lib.rebvo_dataset_grab.argtypes = [C.c_void_p, C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_int)]
+    lib.rebvo_dataset_close.argtypes = [C.c_void_p]
+    ds = lib.rebvo_dataset_open(ddir.encode(), dfile.encode(), w, h, scale)
+    if not ds:
+        raise SystemExit(f"bench.py: --dataset: cannot read the image list {dfile}")
+    n = min(int(lib.rebvo_dataset_frames(ds)), max_frames)
+    frames = np.zeros((n, h, w, 3), np.uint8)
+    ts = np.zeros(n)
+    t, mono = C.c_double(), C.c_int()
+    for k in range(n):
+        if lib.rebvo_dataset_grab(ds, frames[k].ctypes.data, C.byref(t), C.byref(mono)) != 0:
+            lib.rebvo_dataset_close(ds)
+            raise SystemExit(f"bench.py: --dataset: frame {k} of {dfile} could not be read as a {w}x{h} image "
+                             "(EuRoC is 752x480: the default line; TUM 640x480: --config tum_undistort)")
+        ts[k] = t.value
+    lib.rebvo_dataset_close(ds)
+    if n < 8:
+        raise SystemExit(f"bench.py: --dataset: {n} frames in {dfile}; at least 8 are needed")
+    return frames, ts
 
 
 def tri(k, n):
@@ -263,7 +309,7 @@ def pcie_inclusive(edgehip, params, frames, offs, nseq, steps, warmup, device):
 
             def step(k):
                 up(eh.next_slot(), bufs[tri(k, P)][1])
-                eh.process_frame(0.05 * k)
+                eh.process_frame(FRAME_DT * k)
             for k in range(warmup):
                 step(k)
             eh.sync()
@@ -343,14 +389,14 @@ def _parity_worker(job):
     exactly on a half pixel whose re-projection at X = 0 rounds either way: oracle.half_pixel_keylines)."""
     s_, idx = job
     from oracle import oracle
-    kind, w, h = _PARITY["cfg"]
+    kind, w, h, dt = _PARITY["cfg"]
     op = oracle.tum_params(w, h, use_undistort=1) if kind == "tum" else oracle.euroc_params(w, h)
     orc = oracle.Oracle("ref", op)
     fr = _PARITY["frames"]
     V, Wv, Pos, Pose, cnt, knife = [], [], [], [], [], []
     for k, i in enumerate(idx):
         old = orc.keylines(orc.cur_slot()).copy() if k else None
-        _, nav = orc.process_frame(fr[i], 0.05 * k)
+        _, nav = orc.process_frame(fr[i], dt * k)
         V.append(nav.V[:]); Wv.append(nav.W[:]); Pos.append(nav.Pos[:]); Pose.append(nav.Pose[:])
         cnt.append((nav.kn, nav.klm_num, nav.estimation_ok))
         if k and oracle.half_pixel_keylines(old, orc.field(orc.cur_slot())[:, :, 1], op.ppx, op.ppy, nav.s_rho_q, op.w, op.h):
@@ -454,7 +500,7 @@ def _cpu_traj(oracle, params, frames_of_step, first, count, kind=None):
     orc = oracle.Oracle(kind or ("ref" if oracle.available("ref") else "port"), params)
     out = {}
     for k in range(first + count):
-        _, nav = orc.process_frame(frames_of_step(k), 0.05 * k)
+        _, nav = orc.process_frame(frames_of_step(k), FRAME_DT * k)
         if k >= first:
             out[k - first] = (np.array(nav.Pos[:]), np.array(nav.Pose[:]).reshape(3, 3), np.array(nav.V[:]), np.array(nav.W[:]))
     orc.close()
@@ -482,7 +528,7 @@ class Replay:
             e.bind_rgb_indexed(e.next_slot(), self.pool_t.data_ptr(), self.pool_frames, idx[ci * self.B:(ci + 1) * self.B])
             if imu is not None:
                 e.set_imu(imu[ci * self.B:(ci + 1) * self.B])
-            e.process_frame(0.05 * k)
+            e.process_frame(FRAME_DT * k)
 
     def sync(self):
         for e in self.ehs:
@@ -552,6 +598,13 @@ def main():
                          "Minimizer_V, ExtRotVel, BiasCorrect, scale filter, gravity-aligned pose — batched on the device; the "
                          "integrated IMU data of every frame interval is synthesised from the known camera motion")
     ap.add_argument("--no-extras", action="store_true", help="skip the batch sweep and the heterogeneous batch")
+    ap.add_argument("--dataset", default=os.environ.get("REBVO_DATASET_DIR") or os.environ.get("REBVO_EUROC_DIR") or os.environ.get("REBVO_TUM_DIR"),
+                    help="a mounted EuRoC sequence (the directory that holds mav0/cam0/data.csv, 752x480: the default line) or TUM "
+                         "sequence (rgb.txt, 640x480: --config tum_undistort): its images, read by the library's own DataSetCam, are "
+                         "the frame pool instead of the synthetic billboards — sequence s of the batch starts at its own frame of the "
+                         "list; the pose check runs the CPU reference on the same files.  Also REBVO_DATASET_DIR / REBVO_EUROC_DIR / "
+                         "REBVO_TUM_DIR.  Absent or not a data set: the synthetic scenes, silently")
+    ap.add_argument("--dataset-frames", type=int, default=96, help="images of the list that make the HBM-resident pool")
     ap.add_argument("--no-roofline-events", action="store_true")
     args = ap.parse_args()
 
@@ -627,9 +680,21 @@ def main():
         t[:host.size] = torch.from_numpy(host.reshape(-1)).cuda()
         return t
 
-    # ---- synthetic frame pool, resident in HBM ----
+    # ---- frame pool, resident in HBM: a mounted data set when there is one, the synthetic billboards otherwise ----
     intr = dict(fx=float(params.zfx), fy=float(params.zfy), cx=float(params.ppx), cy=float(params.ppy))
-    frames = [f for f, _, _ in synth.billboard_sequence(w, h, args.pool, seed=11 + rank, **intr)]
+    global FRAME_DT
+    data_kind, data_note = "synthetic", None
+    found = find_dataset(args.dataset) if args.config != "stage_a" or args.dataset else None
+    if found and not args.imu:
+        ds_frames, ds_t = load_dataset(found, w, h, max(8, args.dataset_frames))
+        frames = list(ds_frames)
+        args.pool = len(frames)
+        FRAME_DT = float(np.mean(np.diff(ds_t)))
+        data_kind = found[0]
+        data_note = {"list": found[2], "frames_in_pool": len(frames), "mean_frame_interval_s": round(FRAME_DT, 6),
+                     "first_stamp": float(ds_t[0]), "reader": "rebvo::DataSetCam of librebvohost.so (rebvo/dataset_c.h)"}
+    else:
+        frames = [f for f, _, _ in synth.billboard_sequence(w, h, args.pool, seed=11 + rank, **intr)]
     pool = to_pool(frames)
     torch.cuda.synchronize()
     # every sequence starts at its own phase of the pool
@@ -920,7 +985,7 @@ def main():
                 parity = None
                 if kind == "reference":
                     parity, cpu_trajs = wide_parity(log_all, check_seqs, lambda s_: [tri(k + int(offs[s_]), args.pool) for k in range(Wm + K)],
-                                                    np.stack(frames), ("tum" if tum else "euroc", w, h), Wm, max(1, _usable_cores() - 1))
+                                                    np.stack(frames), ("tum" if tum else "euroc", w, h, FRAME_DT), Wm, max(1, _usable_cores() - 1))
                 else:
                     cpu_trajs = {s_: _cpu_traj(oracle, oparams, lambda k, s_=s_: frames[tri(k + int(offs[s_]), args.pool)], Wm, K)
                                  for s_ in check_seqs[:3]}
@@ -934,7 +999,7 @@ def main():
                     modes = {}
                     for name, th in (("serial_1_core", 1), ("reference_threads_2_cores", 2)):
                         orc = oracle.Oracle("ref", oparams)
-                        done, _ = orc.run_sequence(host_pool, idx, threads=th)
+                        done, _ = orc.run_sequence(host_pool, idx, dt=FRAME_DT, threads=th)
                         orc.close()
                         modes[name] = frame_stats(done, 10)
                         modes[name]["cores"] = th
@@ -949,7 +1014,7 @@ def main():
                     orc = oracle.Oracle("port", oparams)
                     ts = []
                     for k in range(10 + args.cpu_frames):
-                        _, nav = orc.process_frame(frames[tri(k, args.pool)], 0.05 * k)
+                        _, nav = orc.process_frame(frames[tri(k, args.pool)], FRAME_DT * k)
                         ts.append(nav.dtp0 + nav.dtp1)
                     done = np.cumsum(ts)
                     cpu = frame_stats(done, 10)
@@ -1080,7 +1145,7 @@ def main():
                     # on a frame the reference itself leaves undecided
                     hw = sorted(set(range(0, n, max(1, n // 32))) | {5, n - 1})
                     wide, wide_trajs = wide_parity(logh, hw, lambda s_: [hidx(k, s_) for k in range(Wm + K)], np.stack(hframes),
-                                                   ("euroc", w, h), Wm, max(1, _usable_cores() - 1))
+                                                   ("euroc", w, h, FRAME_DT), Wm, max(1, _usable_cores() - 1))
                     # ... and every departed sequence (up to four more) joins the teacher-forced replay
                     hs = sorted(set(hs) | {d_["sequence"] for d_ in wide["departures"][:4]})
                 gt = {s: _traj_of_log(logh[Wm:], s) for s in (hw if wide else hs)}
@@ -1144,14 +1209,16 @@ def main():
                   "frames/sec (undistort+DoG+extract+track+depth) 640x480 TUM",
         "value": round(value, 1), "unit": "frames/s", "n_gpus": world, "steps": K, "warmup": Wm,
         "ms_per_step": round(dt / K * 1e3, 4), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-        "dtype": "f32 scale-space / f64 tracker+EKF", "data": "synthetic",
-        "config": {"workload": ("full path (configs[2] at configs[1] size): 752x480 synthetic EuRoC-intrinsics "
+        "dtype": "f32 scale-space / f64 tracker+EKF", "data": data_kind,
+        "config": {"workload": ("full path (configs[2] at configs[1] size): 752x480 " + ("synthetic EuRoC-intrinsics " if data_kind == "synthetic" else
+                                f"{data_kind} data set (sequences of the batch start at staggered frames of the mounted list) ") +
                                 "sequences, GlobalConfig_EuRoC params, " + ("ImuMode=2: the IMU branch of SecondThread (gyro pre-rotation, "
                                 "Minimizer_V, ExtRotVel, BiasCorrect, scale filter, gravity-aligned pose) batched on the device, integrated "
                                 "IMU data synthesised from the camera motion" if args.imu else "ImuMode=0")) if not tum else
                                ("BASELINE configs[3]: 640x480 synthetic TUM-intrinsics sequences taken as the distorted camera "
                                 "image, GlobalConfig_desk.txt params, UseUndistort=1 with the EuRoC distortion (SURVEY 8d scene S3), "
                                 "undistortion fused into the stage-A load"),
+                   "dataset": data_note,
                    "sequences_per_gpu": B * C, "contexts_per_gpu": C, "sequences_per_launch": B,
                    "stream_overlap": bool(args.overlap), "nav_gather": nav_gather, "nav_gather_info": nav_gather_info,
                    "frames_per_step": B * C * world, "keylines_per_frame": round(kn_mean, 1),

@@ -168,6 +168,11 @@ bool LoadImageRGB24(const std::string &file, std::vector<RGB24Pixel> &out, unsig
         err = "out of memory while decoding " + file;
         return false;
     }
+    if (d.size() > 2 && d[0] == 0xFF && d[1] == 0xD8) {
+        err = "JPEG image: " + file + " — this library decodes PNG / PGM / PPM (the reference reads JPEG through libgd, datasetcam.cpp:128-131); "
+              "convert the data set once with tools/jpeg_to_png.py <DataSetDir> <DataSetFile> <out_dir>";
+        return false;
+    }
     err = "unsupported image format (PNG, PGM, PPM are read; the reference's JPEG path needs libgd): " + file;
     return false;
 }

@@ -64,7 +64,7 @@ def test_image_reader_matches_pil(tmp_path, mode):
 def test_unreadable_image_and_bad_list(tmp_path):
     (tmp_path / "x.jpg").write_bytes(b"\xff\xd8\xff\xe0 not really a jpeg")
     r = subprocess.run([EXE, "--decode", str(tmp_path / "x.jpg"), str(tmp_path / "o")], capture_output=True, text=True)
-    assert r.returncode == 6 and "unsupported image format" in r.stdout
+    assert r.returncode == 6 and "JPEG image" in r.stdout and "tools/jpeg_to_png.py" in r.stdout
     # dataset config whose list file is missing / malformed: Init() fails like the reference's camera error
     p = edgehip.euroc_params(64, 48)
     for content in (None, "# header\nnot_a_number,frame.png\n"):
@@ -79,3 +79,88 @@ def test_unreadable_image_and_bad_list(tmp_path):
         r = subprocess.run([EXE, str(cfg)], capture_output=True, text=True, timeout=60)
         assert r.returncode == 4, r.stdout
         assert "Failed to open file" in r.stdout or "sintax error" in r.stdout
+
+
+def test_dataset_c_api_and_layout_detection(tmp_path):
+    """rebvo/dataset_c.h — what bench.py --dataset reads a mounted data set with: the host library's own DataSetCam behind a flat
+    C view.  An EuRoC-layout tree (nanosecond stamps, grey PNGs) and a TUM-layout one (rgb.txt, seconds, colour PNGs); frames
+    equal to PIL's decoding, stamps scaled, the end of the list and a wrong image size reported."""
+    import ctypes as C
+    import sys
+    sys.path.insert(0, ROOT)
+    import bench
+    rs = np.random.RandomState(3)
+    w, h, n = 64, 48, 9
+    grey = [rs.randint(0, 256, (h, w)).astype(np.uint8) for _ in range(n)]
+    euroc = tmp_path / "MH_01"
+    (euroc / "mav0" / "cam0" / "data").mkdir(parents=True)
+    t_ns = [1403636579763555584 + 50_000_000 * k for k in range(n)]
+    with open(euroc / "mav0" / "cam0" / "data.csv", "w") as f:
+        f.write("#timestamp [ns],filename\r\n")
+        for k in range(n):
+            PIL.fromarray(grey[k], "L").save(euroc / "mav0" / "cam0" / "data" / f"{t_ns[k]}.png")
+            f.write(f"{t_ns[k]},{t_ns[k]}.png\r\n")
+    tum = tmp_path / "fr2_desk"
+    (tum / "rgb").mkdir(parents=True)
+    rgb = [rs.randint(0, 256, (h, w, 3)).astype(np.uint8) for _ in range(n)]
+    with open(tum / "rgb.txt", "w") as f:
+        f.write("# color images\n# timestamp filename\n")
+        for k in range(n):
+            PIL.fromarray(rgb[k], "RGB").save(tum / "rgb" / f"{1311868164.36 + k / 30:.6f}.png")
+            f.write(f"{1311868164.36 + k / 30:.6f} rgb/{1311868164.36 + k / 30:.6f}.png\n")
+    found = bench.find_dataset(str(euroc))
+    assert found[0] == "euroc" and found[3] == 1e-9 and found[2].endswith("mav0/cam0/data.csv")
+    assert bench.find_dataset(str(euroc / "mav0" / "cam0"))[0] == "euroc"
+    fr, ts = bench.load_dataset(found, w, h, 100)
+    assert fr.shape == (n, h, w, 3) and all(np.array_equal(fr[k], np.repeat(grey[k][:, :, None], 3, 2)) for k in range(n))
+    assert np.array_equal(ts, np.array([float(np.float64(t) * 1e-9) for t in t_ns]))
+    found_t = bench.find_dataset(str(tum))
+    assert found_t[0] == "tum" and found_t[3] == 1.0
+    assert bench.find_dataset(str(tmp_path)) is None and bench.find_dataset(str(tmp_path / "nothing")) is None and bench.find_dataset(None) is None
+    lib = C.CDLL(os.path.join(ROOT, "rebvo_amd", "lib", "librebvohost.so"))
+    lib.rebvo_dataset_open.restype = C.c_void_p
+    lib.rebvo_dataset_open.argtypes = [C.c_char_p, C.c_char_p, C.c_int, C.c_int, C.c_double]
+    lib.rebvo_dataset_frames.argtypes = [C.c_void_p]
+    lib.rebvo_dataset_grab.argtypes = [C.c_void_p, C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_int)]
+    lib.rebvo_dataset_close.argtypes = [C.c_void_p]
+    ds = lib.rebvo_dataset_open(found_t[1].encode(), found_t[2].encode(), w, h, found_t[3])
+    assert ds and lib.rebvo_dataset_frames(ds) == n
+    buf = np.zeros((h, w, 3), np.uint8)
+    t, mono = C.c_double(), C.c_int(7)
+    for k in range(n):
+        assert lib.rebvo_dataset_grab(ds, buf.ctypes.data, C.byref(t), C.byref(mono)) == 0
+        assert np.array_equal(buf, rgb[k]) and mono.value == 0 and abs(t.value - (1311868164.36 + k / 30)) < 1e-5
+    assert lib.rebvo_dataset_grab(ds, buf.ctypes.data, C.byref(t), C.byref(mono)) == -1      # end of the list
+    lib.rebvo_dataset_close(ds)
+    ds = lib.rebvo_dataset_open(found_t[1].encode(), found_t[2].encode(), w + 2, h, found_t[3])   # not the images' size
+    assert ds
+    big = np.zeros((h, w + 2, 3), np.uint8)
+    assert lib.rebvo_dataset_grab(ds, big.ctypes.data, C.byref(t), None) == -1
+    lib.rebvo_dataset_close(ds)
+    assert not lib.rebvo_dataset_open(b"/nonexistent/", b"/nonexistent/list.txt", w, h, 1.0)
+
+
+def test_jpeg_conversion_tool(tmp_path):
+    """The reference reads JPEG through libgd; here a JPEG data set is converted once (tools/jpeg_to_png.py) and the converted
+    list reads back through the library's DataSetCam as PIL decodes the JPEGs."""
+    import sys
+    sys.path.insert(0, ROOT)
+    import bench
+    rs = np.random.RandomState(9)
+    w, h, n = 96, 64, 8
+    src = tmp_path / "jpg"
+    src.mkdir()
+    imgs = []
+    with open(tmp_path / "list.txt", "w") as f:
+        for k in range(n):
+            a = np.add.outer(np.arange(h) * 2 + 7 * k, np.arange(w) * 3) % 256
+            PIL.fromarray(np.stack([a, a[::-1], rs.randint(0, 256, (h, w))], 2).astype(np.uint8), "RGB").save(src / f"{k:04d}.jpg", quality=92)
+            imgs.append(np.asarray(PIL.open(src / f"{k:04d}.jpg").convert("RGB")))
+            f.write(f"{10.0 + 0.05 * k:.6f} {k:04d}.jpg\n")
+    out = tmp_path / "png"
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "jpeg_to_png.py"), str(src) + "/", str(tmp_path / "list.txt"), str(out)],
+                       capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0 and f"{n} images" in r.stdout, r.stdout + r.stderr
+    fr, ts = bench.load_dataset(("tum", str(out) + "/", str(out / "list.txt"), 1.0), w, h, 100)
+    assert fr.shape[0] == n and all(np.array_equal(fr[k], imgs[k]) for k in range(n))
+    assert np.allclose(ts, 10.0 + 0.05 * np.arange(n))

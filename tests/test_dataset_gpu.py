@@ -112,3 +112,33 @@ def test_multi_device_replay_two_sequences(tmp_path):
                     assert np.allclose(row[5:8], prev.Pos[:], atol=1e-6 * path + 1e-9)
             prev = nav
         orc.close()
+
+
+def test_bench_replays_a_mounted_dataset(tmp_path):
+    """bench.py --dataset: a data set in the EuRoC layout is read through the library's own DataSetCam, replayed
+    as the sequences of the batch at staggered start frames inside the same timed region, and the pose check runs the CPU
+    reference on the same files — `data: "euroc"` in the line.  A path that is not a data set leaves the synthetic scenes."""
+    import json
+    import sys
+    w, h, n = 752, 480, 12
+    frames = [f for f, _, _ in synth.billboard_sequence(w, h, n, seed=23)]
+    _write_euroc_set(tmp_path / "MH_xx", frames, 1403636579763555584)
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--nseq", "6", "--steps", "6", "--warmup", "4", "--no-extras", "--cpu-frames", "8",
+           "--cpu-procs", "0"]
+    env = dict(os.environ, BENCH_FORCE_MOVER="0")
+    r = subprocess.run(cmd + ["--dataset", str(tmp_path / "MH_xx")], capture_output=True, text=True, timeout=600, cwd=ROOT, env=env)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.strip()]
+    assert len(lines) == 1, lines                      # one JSON line on stdout
+    js = json.loads(lines[0])
+    assert js["data"] == "euroc" and js["config"]["dataset"]["frames_in_pool"] == n
+    assert abs(js["config"]["dataset"]["mean_frame_interval_s"] - 0.05) < 1e-6
+    assert js["config"]["estimation_ok"] == "6/6" and js["config"]["keylines_per_frame"] > 5000
+    par = js["pose_rmse"]["free_running_parity"]
+    assert par["sequences_checked"] == 6 and par["departures_elsewhere"] == 0
+    assert js["pose_rmse"]["position"] < 1e-6 or par["departures_on_knife_edge_frames"] > 0
+    assert js["cpu_baseline"]["kind"] == "reference" and js["cpu_baseline"]["value"] > 0
+    r = subprocess.run(cmd + ["--dataset", str(tmp_path / "not_there"), "--cpu-frames", "0"], capture_output=True, text=True, timeout=600, cwd=ROOT, env=env)
+    assert r.returncode == 0, r.stderr[-3000:]
+    js = json.loads([ln for ln in r.stdout.splitlines() if ln.strip()][0])
+    assert js["data"] == "synthetic" and js["config"]["dataset"] is None
