@@ -420,9 +420,12 @@ __global__ __launch_bounds__(512) void k_stage_a_fused(FusedArgs a) {
                 code_nxt = code_of(1);
                 request(code_cur, wv_cur);
             }
-            auto chunks = [&](int c0, int c1) __attribute__((always_inline)) {
-                for (int c = c0; c < c1; c++) {
-                    if (c + 1 < nchunks) request(code_nxt, wv_nxt);
+#ifndef EDGEHIP_FIT_UNROLL
+#define EDGEHIP_FIT_UNROLL 1   // 2785 -> 2733 us per 1024 frames (same-box A/B, tools/gpu_r04_g.sh)
+#endif
+            // one chunk: evaluate the window in `wc` (requested one chunk earlier) while the next chunk's window lands in `wn`
+            auto one_chunk = [&](int c, float (&wc)[25], float (&wn)[25]) __attribute__((always_inline)) {
+                    if (c + 1 < nchunks) request(code_nxt, wn);
                     code_nn = code_of(c + 2);
                     __builtin_amdgcn_sched_barrier(0);
                     const bool on = c * 64 + lane < ncand;
@@ -430,7 +433,7 @@ __global__ __launch_bounds__(512) void k_stage_a_fused(FusedArgs a) {
                     const int i = code >> 10, x = code & 1023;
                     FitOut f;
                     if (ABL & 256) { f.cand = (code & 1) != 0; f.mx = 3.f; f.my = 4.f; f.xs = 0.f; f.ys = 0.f; }
-                    else f = fit_eval(wv_cur, fc, thr_d);
+                    else f = fit_eval(wc, fc, thr_d);
                     const bool fin = on && f.cand;
                     const unsigned long long bal = __ballot(fin);
                     const int id = total + below(bal);
@@ -447,11 +450,18 @@ __global__ __launch_bounds__(512) void k_stage_a_fused(FusedArgs a) {
                     }
                     total += __popcll(bal);
                     __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-                    for (int k = 0; k < 25; k++) wv_cur[k] = wv_nxt[k];
                     code_cur = code_nxt;
                     code_nxt = code_nn;
-                }
+            };
+            static_assert(EDGEHIP_FIT_UNROLL == 1, "the copying form (wv_cur = wv_nxt after every chunk: 25 moves) is gone");
+            // the window buffers swap roles from chunk to chunk: two chunks per trip, no copy of the 25 values in between (the
+            // buffer a run of chunks starts with is whichever the chunks before it left the requested window in)
+            bool in_cur = true;
+            auto chunks = [&](int c0, int c1) __attribute__((always_inline)) {
+                int c = c0;
+                if (c < c1 && !in_cur) { one_chunk(c, wv_nxt, wv_cur); in_cur = true; c++; }
+                for (; c + 1 < c1; c += 2) { one_chunk(c, wv_cur, wv_nxt); one_chunk(c + 1, wv_nxt, wv_cur); }
+                if (c < c1) { one_chunk(c, wv_cur, wv_nxt); in_cur = false; }
             };
             const int half = nchunks >> 1;
             chunks(0, half);

@@ -387,6 +387,11 @@ __global__ __launch_bounds__(256) void k_field_raster(const KlSoA *kls, int32_t 
 #ifndef EDGEHIP_FSPLIT
 #define EDGEHIP_FSPLIT 2   // measured at r = 40 after the cheaper tile range: 1: 1296, 2: 1260, 3: 1292, 4: 1310, 8: 1538, 16: 2054 us per 1024 frames
 #endif
+#ifndef EDGEHIP_RASTER_UNROLL
+#define EDGEHIP_RASTER_UNROLL 2   // 1198 -> 1156 us per 1024 frames (same-box A/B, tools/gpu_r04_g.sh)
+#endif
+    // (A split chosen per tile so that the last round of 256 threads is as full as possible — 1..4 parts, block-uniform —
+    // measured slower, 1198 -> 1283 us: the run-time divisor costs every item more than the fuller rounds save.)
     constexpr int FSPLIT = EDGEHIP_FSPLIT;
     // The hardware rounding differs from round() in a way that matters only for a coordinate of exactly -0.5 (pixel 0
     // instead of -1, ctx.h): that can only be accepted by a tile that starts at column / row 0, so only the tiles on
@@ -407,16 +412,25 @@ __global__ __launch_bounds__(256) void k_field_raster(const KlSoA *kls, int32_t 
             // t runs as a float (|t| <= 255: every value and the increment are exact), so the reference's (float)t costs
             // nothing and |t| is an operand modifier of the one conversion back
             const float t1f = (float)t1;
-            for (float tf = (float)t0; tf <= t1f; tf += 1.f) {
+            auto sample = [&](const float tf) __attribute__((always_inline)) {
                 const float fx = r.u_mx * tf + r.c_px;   // global_tracker.cpp:78, same float expression
                 const float fy = r.u_my * tf + r.c_py;
                 // Image::GetIndexRC uses round()
                 const int lx = (decltype(fix_x)::value ? round_half_away_i(fx) : round_ties_up_i(fx)) - tx0;
                 const int ly = (decltype(fix_y)::value ? round_half_away_i(fy) : round_ties_up_i(fy)) - ty0;
-                if ((unsigned)lx >= ex || (unsigned)ly >= ey) continue;
+                if ((unsigned)lx >= ex || (unsigned)ly >= ey) return;
                 const uint32_t at = (uint32_t)fabsf(tf);
                 atomicMin(&s_tile[ly * FT + lx], (at << 16) | idk);
-            }
+            };
+#if EDGEHIP_RASTER_UNROLL == 2
+            // two samples per trip: the loop's own bookkeeping (exec-mask save / restore, compare, branch: as many scalar
+            // instructions as the sample's arithmetic) is paid once per pair
+            float tf = (float)t0;
+            for (; tf + 1.f <= t1f; tf += 2.f) { sample(tf); sample(tf + 1.f); }
+            if (tf <= t1f) sample(tf);
+#else
+            for (float tf = (float)t0; tf <= t1f; tf += 1.f) sample(tf);
+#endif
         }
     };
     using T = std::true_type;
