@@ -253,6 +253,7 @@ struct edgehip_ctx {
     int32_t *bin_cnt;      // [B][256] KeyLines binned per field tile
     int32_t *bins;         // [B][256][CAP] KeyLine ids per field tile (allocated for the tiles in use)
     int nblk_tvr;
+    int tvr_rw2;           // EDGEHIP_TVR_RW2: from this many evaluation blocks per launch on, the reweighted evaluation takes two KeyLines per thread (0 = never)
     int dual_init;         // EDGEHIP_DUAL_INIT (default 1): the two initialisation chains of TrackerInitType = 2 share their launches (stage_b.hip tvr2_body)
     int persist_lm_max;    // batches up to this many sequences fuse every TryVelRot evaluation with the LM step after it (EDGEHIP_PERSIST_LM, 0 = never)
     unsigned *sync_cnt;    // [B] per-sequence block tickets of k_try_velrot_lm (0 between launches)

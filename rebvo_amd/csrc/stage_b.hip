@@ -1191,6 +1191,236 @@ __device__ __forceinline__ void tvr2_body(const TvrArgs &a, const int seq, const
     }
 }
 
+// ---------------------------------------------------------------------------------------------------
+// The reweighted evaluation with TWO KeyLines per thread (whole batches): thread t of block b owns KeyLines 512 b + t and
+// 512 b + 256 + t and walks them level by level like tvr2_body walks its two chains — both KeyLines' streams, then both field
+// reads, then both records in flight together — so that a thread has two independent chains of dependent gathers outstanding
+// instead of one, and the 28 products of both accumulate in registers before ONE transposed wave reduction (the reduction is
+// a quarter of the one-KeyLine kernel's instructions).  The residual buffers, their "last valid residual" markers and the
+// per-256-KeyLine carries are exactly the one-KeyLine kernel's (each half is a block of its own for that purpose: the LM step
+// and the next evaluation see no difference); the partial sums are one row per 512 KeyLines (the odd row is zero), i.e. the
+// 28 sums are added in another — fixed — order: same tolerance against the reference, not the same bits as tvr_body.
+// Measured (round 4): no gain at 1024 sequences — the kernel is not short of loads in flight at 8 waves per SIMD, and at 84
+// registers it runs 5 — so it is an option (EDGEHIP_TVR_RW2 = smallest launch, in evaluation blocks, that takes it), not the default.
+// ---------------------------------------------------------------------------------------------------
+template <bool GREC>
+__device__ __forceinline__ void tvr_rw2_body(const TvrArgs &a, const int seq, const int blk, const int tid) {
+    const int lane = tid & 63, wave = tid >> 6;
+    SeqDev *sq = a.seq + seq;
+    const int kn = a.kn_old[seq];
+    if (blk * 2 * kTvrBlock >= kn) return;  // whole block beyond the list (block-uniform)
+    static_assert(kTvrPasses == 1 && kTvrThreads == kTvrBlock, "one KeyLine per thread and carry granule");
+    const KlSoA &ko = a.kl_old[seq];
+    const int res_in = sq->res_cur, res_out = sq->lm_phase == 0 ? sq->res_t : sq->res_new;
+    const double *rin = a.resid + ((size_t)res_in * a.nseq + seq) * a.cap;
+    double *rout = a.resid + ((size_t)res_out * a.nseq + seq) * a.cap;
+    const double *carry_row = a.resid_carry + ((size_t)res_in * a.nseq + seq) * a.nblk;
+    const double marker = __longlong_as_double((long long)resid_carry_bits());
+    constexpr int NW = kTvrThreads / 64;
+    __shared__ double s_wlast[2][NW];
+    __shared__ int s_whas[2][NW];
+
+    int ikl[2];
+    double fm[2] = {0, 0}, dfx[2] = {0, 0}, dfy[2] = {0, 0}, fi[2] = {0, 0};
+    double ptx[2] = {0, 0}, pty[2] = {0, 0}, ptz[2] = {1, 1}, pix[2] = {0, 0}, piy[2] = {0, 0}, rho_p[2] = {1, 1};
+    double s_rho[2] = {1, 1}, inv_w2[2] = {1, 1}, rho_own[2] = {0, 0};
+    int status[2] = {0, 0}, mid_f[2] = {-1, -1};
+    // ---- level 0: both KeyLines' streams ----
+    int32_t mnum[2] = {0, 0};
+    float2 pm0[2], klm[2];
+    float knm[2] = {1.f, 1.f};
+    double rprev[2] = {0, 0}, cin[2] = {0, 0};
+#pragma unroll
+    for (int c = 0; c < 2; c++) {
+        ikl[c] = (2 * blk + c) * kTvrBlock + tid;
+        pm0[c] = make_float2(0.f, 0.f); klm[c] = make_float2(0.f, 0.f);
+        if (ikl[c] < kn) {
+            s_rho[c] = ko.s_rho[ikl[c]];
+            mnum[c] = ko.m_num[ikl[c]];
+            pm0[c] = ko.p_m[ikl[c]];
+            rho_own[c] = ko.rho[ikl[c]];
+            klm[c] = ko.m_m[ikl[c]];
+            knm[c] = ko.n_m[ikl[c]];
+            rprev[c] = rin[ikl[c]];
+        }
+        cin[c] = 2 * blk + c < a.nblk ? carry_row[2 * blk + c] : 0.0;
+    }
+    const uint32_t fc = a.framecount[seq];
+    const uint32_t mthr = a.match_num_thresh < fc ? a.match_num_thresh : fc;
+    // ---- level 1: both projections, both field reads ----
+    double px[2] = {0, 0}, py[2] = {0, 0};
+    bool live[2], inimg[2];
+    size_t fidx[2];
+    float rmx[2], rmy[2];
+    const double *R = sq->Rt, *V = sq->Vt, *RM = sq->RM;
+#pragma unroll
+    for (int c = 0; c < 2; c++) {
+        live[c] = ikl[c] < kn && !(s_rho[c] > sq->s_rho_min_eval || (uint32_t)mnum[c] < mthr);
+        inimg[c] = false;
+        fidx[c] = 0;
+        rmx[c] = rmy[c] = 0.f;
+        if (live[c]) {
+            const double sz = 1 / rho_own[c];
+            const double pz_zf0 = (1 / a.zfm) * sz;
+            const double sx = pz_zf0 * (double)pm0[c].x, sy = pz_zf0 * (double)pm0[c].y;
+            ptx[c] = R[0] * sx; ptx[c] += R[1] * sy; ptx[c] += R[2] * sz; ptx[c] = V[0] + ptx[c];
+            pty[c] = R[3] * sx; pty[c] += R[4] * sy; pty[c] += R[5] * sz; pty[c] = V[1] + pty[c];
+            ptz[c] = R[6] * sx; ptz[c] += R[7] * sy; ptz[c] += R[8] * sz; ptz[c] = V[2] + ptz[c];
+            rho_p[c] = 1 / ptz[c];
+            const double pz_zf = a.zfm * rho_p[c];
+            pix[c] = pz_zf * ptx[c];
+            piy[c] = pz_zf * pty[c];
+            px[c] = pix[c] + (double)a.ppx; py[c] = piy[c] + (double)a.ppy;
+            const int x = x86_cvttsd2si(px[c] + 0.5), y = x86_cvttsd2si(py[c] + 0.5);
+            double rp = rprev[c];
+            if (is_carry(rp)) rp = cin[c];
+            if (fabs(rp) > a.k_huber) { const double rk = fabs(rp) * a.inv_k_huber; inv_w2[c] = rk * rk; }
+            inimg[c] = !(x < 1 || y < 1 || x >= a.w - 1 || y >= a.h - 1);
+            fidx[c] = inimg[c] ? field16_index(x, y, a.f16tx) : (size_t)0;
+            rmx[c] = (float)(RM[0] * (double)klm[c].x + RM[1] * (double)klm[c].y);
+            rmy[c] = (float)(RM[2] * (double)klm[c].x + RM[3] * (double)klm[c].y);
+            fm[c] = a.max_r;
+            status[c] = inimg[c] ? 3 : 1;
+        }
+    }
+    const uint16_t *fld = a.field16 + (size_t)seq * a.f16stride;
+    const uint32_t f0 = fld[fidx[0]], f1 = fld[fidx[1]];
+    // ---- level 2: both records ----
+    const bool hit0 = inimg[0] && f0 != 0u, hit1 = inimg[1] && f1 != 0u;
+    const int ikf0 = hit0 ? (int)f0 - 1 : 0, ikf1 = hit1 ? (int)f1 - 1 : 0;
+    float f_cpx[2], f_cpy[2], f_mx[2], f_my[2], f_ux[2] = {0, 0}, f_uy[2] = {0, 0};
+    if (GREC) {
+        const float4 g0 = a.kl_new[seq].grec[ikf0], g1 = a.kl_new[seq].grec[ikf1];
+        f_cpx[0] = g0.x; f_cpy[0] = g0.y; f_mx[0] = g0.z; f_my[0] = g0.w;
+        f_cpx[1] = g1.x; f_cpy[1] = g1.y; f_mx[1] = g1.z; f_my[1] = g1.w;
+    } else {
+        const MatchRec r0 = a.kl_new[seq].rec[ikf0], r1 = a.kl_new[seq].rec[ikf1];
+        f_cpx[0] = r0.c_px; f_cpy[0] = r0.c_py; f_mx[0] = r0.m_mx; f_my[0] = r0.m_my; f_ux[0] = r0.u_mx; f_uy[0] = r0.u_my;
+        f_cpx[1] = r1.c_px; f_cpy[1] = r1.c_py; f_mx[1] = r1.m_mx; f_my[1] = r1.m_my; f_ux[1] = r1.u_mx; f_uy[1] = r1.u_my;
+    }
+#pragma unroll
+    for (int c = 0; c < 2; c++) {
+        if (c ? hit1 : hit0) {
+            const double p_n2 = (double)(knm[c] * knm[c]);
+            const double p_esc = (double)(rmx[c] * f_mx[c] + rmy[c] * f_my[c]);
+            if (!(fabs(p_esc - p_n2) > a.match_thresh * p_n2)) {
+                if (GREC) {
+                    const float n2m = f_mx[c] * f_mx[c] + f_my[c] * f_my[c];
+                    const float nm = sqrtf(n2m);
+                    f_ux[c] = f_mx[c] / nm; f_uy[c] = f_my[c] / nm;
+                }
+                const double dx = px[c] - (double)f_cpx[c], dy = py[c] - (double)f_cpy[c];
+                fi[c] = dx * (double)f_ux[c] + dy * (double)f_uy[c];
+                dfx[c] = (double)f_ux[c];
+                dfy[c] = (double)f_uy[c];
+                fm[c] = fi[c];
+                mid_f[c] = c ? ikf1 : ikf0;
+                status[c] = 2;
+            }
+        }
+    }
+    // ---- DResidualNew: each half is a block of its own for the "last valid fi" propagation (tvr_body's rule) ----
+    unsigned long long below[2];
+    double inh[2];
+#pragma unroll
+    for (int c = 0; c < 2; c++) {
+        const unsigned long long vmask = __ballot(status[c] == 2);
+        below[c] = vmask & ((1ull << lane) - 1ull);
+        const int src = below[c] ? 63 - __clzll(below[c]) : 0;
+        inh[c] = __shfl(fi[c], src, 64);
+        const int top = vmask ? 63 - __clzll(vmask) : 0;
+        const double wl = __shfl(fi[c], top, 64);
+        if (lane == 0) {
+            s_whas[c][wave] = vmask != 0;
+            s_wlast[c][wave] = wl;
+        }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int c = 0; c < 2; c++) {
+        if (status[c] == 3) {
+            double v = marker;
+            bool have = false;
+            if (below[c]) { v = inh[c]; have = true; }
+            for (int pw = wave - 1; pw >= 0 && !have; pw--)
+                if (s_whas[c][pw]) { v = s_wlast[c][pw]; have = true; }
+            rout[ikl[c]] = v;
+        } else if (status[c] == 2) {
+            rout[ikl[c]] = fi[c];
+        } else if (status[c] == 1) {
+            rout[ikl[c]] = a.max_r;
+        } else if (ikl[c] < kn) {
+            rout[ikl[c]] = 0.0;
+        }
+        if (a.write_mid && ikl[c] < kn) {
+            ko.m_id_f[ikl[c]] = mid_f[c];
+            if (a.fwd_key && mid_f[c] >= 0) atomicMax(&a.fwd_key[(size_t)seq * a.cap + mid_f[c]], ord_bits(rho_own[c]));
+        }
+    }
+    if (tid == 0) {
+#pragma unroll
+        for (int c = 0; c < 2; c++) {
+            if ((2 * blk + c) * kTvrBlock >= kn || 2 * blk + c >= a.nblk) continue;
+            double bl = marker;
+            for (int pw = NW - 1; pw >= 0; pw--)
+                if (s_whas[c][pw]) { bl = s_wlast[c][pw]; break; }
+            a.block_last[(size_t)seq * a.nblk + 2 * blk + c] = bl;
+        }
+    }
+    // ---- Jacobian rows, weights, the 28 sums of both KeyLines, one reduction ----
+    double sums[kNumSums];
+#pragma unroll
+    for (int i = 0; i < kNumSums; i++) sums[i] = 0;
+#pragma unroll
+    for (int c = 0; c < 2; c++) {
+        double J[6] = {0, 0, 0, 0, 0, 0};
+        double fmc = fm[c];
+        if (ikl[c] < kn) {
+            double t0 = a.zfm * rho_p[c];
+            J[0] = t0 * dfx[c];
+            J[1] = t0 * dfy[c];
+            t0 = rho_p[c] * pix[c];
+            J[2] = t0 * dfx[c];
+            t0 = rho_p[c] * piy[c];
+            J[2] += t0 * dfy[c];
+            J[3] = J[1] * ptz[c]; J[3] += J[2] * pty[c];
+            J[4] = J[0] * ptz[c]; J[4] += J[2] * ptx[c];
+            t0 = J[0] * pty[c];
+            J[5] = -1 * t0; J[5] += J[1] * ptx[c];
+            const double qvel = (a.zfm * dfx[c] * V[0] + a.zfm * dfy[c] * V[1] + (pix[c] * dfx[c] + piy[c] * dfy[c]) * V[2]);
+            const double sq_ = s_rho[c] * qvel;
+            const double inv_q = rsqrt_f64(sq_ * sq_ + inv_w2[c]);
+#pragma unroll
+            for (int j = 0; j < 6; j++) J[j] *= inv_q;
+            fmc *= inv_q;
+        }
+        int ns = 0;
+#pragma unroll
+        for (int i = 0; i < 6; i++)
+#pragma unroll
+            for (int j = i; j < 6; j++) sums[ns++] += J[i] * J[j];
+#pragma unroll
+        for (int i = 0; i < 6; i++) sums[ns++] += J[i] * fmc;
+        sums[ns] += fmc * fmc;
+    }
+    __shared__ double s_red[NW][32];
+    const int idx = wave_reduce28(sums, lane);
+    if ((lane & 1) == 0) s_red[wave][idx] = sums[0];
+    __syncthreads();
+    if (tid < kNumSums) {
+        double v = s_red[0][tid];
+#pragma unroll
+        for (int wv = 1; wv < NW; wv++) v += s_red[wv][tid];
+        a.partials[((size_t)seq * a.nblk + 2 * blk) * kNumSums + tid] = v;
+        if (2 * blk + 1 < a.nblk) a.partials[((size_t)seq * a.nblk + 2 * blk + 1) * kNumSums + tid] = 0.0;   // the LM step adds one row per 256 KeyLines
+    }
+}
+
+template <bool GREC>
+__global__ __launch_bounds__(kTvrThreads) void k_try_velrot_rw2(TvrArgs a) {
+    tvr_rw2_body<GREC>(a, blockIdx.z, blockIdx.x, threadIdx.x);
+}
+
 #ifndef EDGEHIP_TVR2_WAVES
 #define EDGEHIP_TVR2_WAVES 0   // > 0: occupancy the two-chain evaluation is compiled for (waves per SIMD), A/B experiments
 #endif
@@ -2363,6 +2593,15 @@ static TvrArgs make_tvr_args(edgehip_ctx *c, int slot_new, int slot_old, double 
 static int launch_tvr(edgehip_ctx *c, const TvrArgs &a, bool reweight, bool procjf) {
     ProfScope ps(c, PROF_B_TRYVELROT);
     dim3 g(c->nblk_tvr, 1, c->plan.nseq), b(kTvrThreads);
+    // whole batches: the reweighted evaluation with two KeyLines per thread (tvr_rw2_body); a few sequences keep one KeyLine per
+    // thread (half the blocks would leave most CUs idle, and a block's own latency is what a single camera waits for)
+    if (reweight && procjf && c->tvr_rw2 && (size_t)c->nblk_tvr * c->plan.nseq >= (size_t)c->tvr_rw2) {
+        dim3 g2((c->nblk_tvr + 1) / 2, 1, c->plan.nseq);
+        if (a.use_grec) hipLaunchKernelGGL((k_try_velrot_rw2<true>), g2, b, 0, c->stream, a);
+        else hipLaunchKernelGGL((k_try_velrot_rw2<false>), g2, b, 0, c->stream, a);
+        EH_LAUNCH_CHECK();
+        return 0;
+    }
 #ifdef EDGEHIP_EXPERIMENTS
     // occupancy experiment (tools/experiments): unused dynamic LDS per block caps the resident blocks per CU
     static const size_t dyn_lds = getenv("EDGEHIP_TVR_LDS") ? (size_t)atoi(getenv("EDGEHIP_TVR_LDS")) : 0;

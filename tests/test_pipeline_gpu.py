@@ -282,3 +282,31 @@ def test_two_chain_evaluation_is_bit_identical_to_the_launch_chain(monkeypatch, 
         assert x.tobytes() == y.tobytes()
     evals = 2 * (1 + over.get("tracker_init_iter_num", 2)) + 1 + 5
     assert np.all(la["estimation_ok"][2:] == 1) and np.all(la["minimizer_evals"][1:] == evals)
+
+
+@pytest.mark.parametrize("w,h,n", [(376, 240, 10), (752, 480, 5)])
+def test_reweighted_evaluation_with_two_keylines_per_thread(monkeypatch, w, h, n):
+    """The reweighted TryVelRot evaluations with two KeyLines per thread (k_try_velrot_rw2: both KeyLines' gathers in flight
+    together, one reduction for the two; EDGEHIP_TVR_RW2 = smallest launch that takes it; measured no faster, so off by default).
+    Forced on for a small batch: the path follows the reference inside the usual tolerance, and agrees with the one-KeyLine
+    kernel to rounding (the 28 sums are added in another order) with identical discrete results — KeyLine counts, match counts,
+    forward matches, EstimationOK."""
+    monkeypatch.setenv("EDGEHIP_TVR_RW2", "1")
+    _run(w, h, n, nseq=2)
+    frames = [f for f, _, _ in synth.billboard_sequence(w, h, n + 2)]
+    outs = []
+    for mode in ("0", "1"):
+        monkeypatch.setenv("EDGEHIP_TVR_RW2", mode)
+        eh = edgehip.EdgeHip(edgehip.euroc_params(w, h), nseq=3, nslots=3)
+        eh.set_nav_log(n)
+        for k in range(n):
+            eh.upload_rgb(eh.next_slot(), np.stack([frames[k + s] for s in range(3)]))
+            eh.process_frame(0.05 * k)
+        outs.append((eh.read_nav_log_array(0, n), [eh.download_keylines(s, eh.cur_slot())[0] for s in range(3)]))
+        eh.close()
+    (la, ka), (lb, kb) = outs
+    for f in ("kn", "klm_num", "klm_fwd", "estimation_ok", "minimizer_evals"):
+        assert np.array_equal(la[f], lb[f]), f
+    assert np.allclose(la["V"], lb["V"], rtol=1e-9, atol=1e-13) and np.allclose(la["W"], lb["W"], rtol=1e-9, atol=1e-13)
+    for x, y in zip(ka, kb):
+        assert np.array_equal(x["m_id"], y["m_id"]) and np.allclose(x["rho"], y["rho"], rtol=1e-9, atol=1e-13)
