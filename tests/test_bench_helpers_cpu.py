@@ -102,13 +102,13 @@ def test_wide_parity_counts_departures_and_attributes_them():
             _, nav = orc.process_frame(frames[i], 0.05 * k)
             log[k, s]["V"], log[k, s]["W"], log[k, s]["Pos"], log[k, s]["kn"] = nav.V[:], nav.W[:], nav.Pos[:], nav.kn
         orc.close()
-    summary, trajs = bench.wide_parity(log, [0, 1, 2], idx_of, frames, ("euroc", w, h), 2, 2)
+    summary, trajs = bench.wide_parity(log, [0, 1, 2], idx_of, frames, ("euroc", w, h, 0.05), 2, 2)
     assert summary["sequences_checked"] == 3 and summary["departures"] == [] and summary["sequences_outside_tolerance_at_last_frame"] == 0
     assert sorted(trajs) == [0, 1, 2] and sorted(trajs[1]) == [0, 1, 2]
     assert np.array_equal(trajs[2][2][2], log[4, 2]["V"])
     bad = log.copy()
     bad["V"][3:, 1, 0] += 1e-3
-    summary, _ = bench.wide_parity(bad, [0, 1, 2], idx_of, frames, ("euroc", w, h), 2, 2)
+    summary, _ = bench.wide_parity(bad, [0, 1, 2], idx_of, frames, ("euroc", w, h, 0.05), 2, 2)
     assert [d["sequence"] for d in summary["departures"]] == [1]
     d = summary["departures"][0]
     assert d["first_frame_outside_tolerance"] == 3 and d["outside_tolerance_at_last_frame"] and d["knife_edge_frame"] in (True, False)
