@@ -40,7 +40,7 @@ def test_bench_uses_the_oracle_only_as_checker():
     for m in re.finditer(r"^( *)from oracle import oracle", src, re.M):
         before = src[:m.start()]
         encl = re.findall(r"^def (\w+)", before, re.M)          # the top-level function the import sits in
-        in_worker = bool(encl) and encl[-1] in ("_cpu_worker", "_cpu_imu_worker")
+        in_worker = bool(encl) and encl[-1] in ("_cpu_worker", "_cpu_imu_worker", "_parity_worker")   # _parity_worker: wide_parity's pool (pose-RMSE leg)
         guarded = "cpu_legs" in before[max(0, before.rfind("\n    if ", 0, m.start() - 1) - 2000):]
         assert in_worker or guarded, src[m.start() - 200:m.start() + 40]
 
