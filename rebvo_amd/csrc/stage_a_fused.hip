@@ -193,19 +193,23 @@ __global__ __launch_bounds__(512) void k_stage_a_fused(FusedArgs a) {
     float *s_set = smem;                                            // [2][4][RB][WP]
     float *s_dog = s_set + (size_t)2 * 4 * RB * WP;                 // [RING][WP]
     float *s_lut = s_dog + (size_t)RING * WP + 32;                  // [kDivLutMax]   (+32: read overrun of the last scanned row)
-    float *s_edge = s_lut + kDivLutMax;                             // [RB][NW][2] img0 at the first / last column of every wave
-    int *s_sedge = reinterpret_cast<int *>(s_edge + (size_t)RB * NW * 2);   // [RB][NW][2] DoG sign bits of the first / last column pair of every wave
-    float *s_red = reinterpret_cast<float *>(s_sedge + RB * NW * 2);   // [4] n_m extremes, the frame's candidate count (end of frame)
+    // [RB][NW + 2][2] {img0, DoG sign bits} at the first / last column (pair) of every wave, with an all-zero entry either side
+    // of the image (waves -1 and NW: what the gate reads left of column 0 and right of column w-1), so that the reader needs no
+    // "is there a wave next to me" test
+    uint2 *s_edge2 = reinterpret_cast<uint2 *>(s_lut + kDivLutMax);
+    float *s_red = reinterpret_cast<float *>(s_edge2 + (size_t)RB * (NW + 2) * 2);   // [4] n_m extremes, the frame's candidate count (end of frame)
     // candidates of a tick's tested rows, published by the column waves for the fit wave, double-buffered by tick parity: per
     // (row, wave) segment the number of survivors of the two dense gates and their codes (row << 10 | x) in column order
     int *s_ccnt = reinterpret_cast<int *>(s_red + 4);                                   // [2][RB*NW]
     uint16_t *s_clist = reinterpret_cast<uint16_t *>(s_ccnt + 2 * RB * NW);             // [2][RB*NW][128]
     uint16_t *s_res = s_clist + (size_t)2 * NW * RB * 128;          // [2 (tick parity)][RB][NW*128] id + 1 of the KeyLine at a tested pixel, 0 = none
+    uint16_t *s_dummy = s_res + (size_t)2 * NW * RB * 128;          // [4] where the lanes without a candidate "publish" (a store needs no branch then)
     // ---- set-up -------------------------------------------------------------------------------------------------------
     for (int i = tid; i < 2 * 4 * RB * PAD; i += blockDim.x) s_set[(size_t)(i / PAD) * WP + (i % PAD)] = 0.f;   // left pads: taps left of column 0
     for (int i = tid; i < kDivLutMax - 2; i += blockDim.x) s_lut[i] = a.lut[i];   // (indices reach 15 * 15; the last two entries carry the threshold, below)
     for (int i = tid; i < 2 * NW * RB * 128; i += blockDim.x) s_res[i] = 0;
     for (int i = tid; i < 2 * RB * NW; i += blockDim.x) s_ccnt[i] = 0;
+    for (int i = tid; i < RB * (NW + 2) * 2; i += blockDim.x) s_edge2[i] = make_uint2(0u, 0u);
     for (int i = tid; i < 256; i += blockDim.x) a.histo[(size_t)seq * 256 + i] = 0;   // reEstimateThresh's histogram (k_join_histo fills it)
     SeqA *sq = a.seq + seq;
     // wave-uniform floats are computed by the vector ALU and would sit in (scarce) vector registers: readfirstlane moves them
@@ -482,24 +486,22 @@ __global__ __launch_bounds__(512) void k_stage_a_fused(FusedArgs a) {
     const int x0 = 2 * (wv * 64 + lane);        // owned columns x0, x0 + 1
     const bool act = x0 < w;                    // w % 4 == 0: both or neither
     const int xr0 = act ? x0 : w - 2;           // address column of inactive threads
+    // ... and where their LDS stores go: the first two floats of the row's right pad.  In the row sets the scan wave writes the
+    // row's total there AFTER the column waves have stored the row (one tick later), in the DoG ring nobody reads the pad — so the
+    // stores of a tick need no "is this lane inside the image" mask
+    const int xs0 = act ? x0 : w;
     auto CX = [&](int x, int r) { const int rr = x + r < w - 1 ? x + r : w - 1; const int l = x - r - 1; return rr - (l > -1 ? l : -1); };   // box width along x
     // div(x,y) of rows with the full box height: (float)(1.0/(d*d)), except in the few columns at the left and right image border
-    // whose box is clipped in x; the waves that own such columns (wave-uniform) read it from the table per row.
-    const float mu1 = uni(s_lut[D1 * D1]), mu2a = uni(s_lut[D2A * D2A]), mu2b = uni(s_lut[D2B * D2B]), mu3a = uni(s_lut[D3A * D3A]), mu3b = uni(s_lut[D3B * D3B]);
-    constexpr int RMAX = R3B > R2B ? (R3B > R1 ? R3B : R1) : (R2B > R1 ? R2B : R1);
-    const bool wave_clip = wv * 128 - RMAX - 1 < 0 || wv * 128 + 127 + RMAX > w - 1;
-    // box widths along x of the owned columns for r = 1, 2, 3 (3 bits each; column x0 in bits 0-8, x0+1 in bits 9-17)
-    uint32_t cxpack = 0;
-#pragma unroll
-    for (int r = 1; r <= 3; r++) cxpack |= ((uint32_t)CX(xr0, r) << (3 * (r - 1))) | ((uint32_t)CX(xr0 + 1, r) << (9 + 3 * (r - 1)));
-    auto MROW = [&](int r, int d, float mu) __attribute__((always_inline)) {   // div(x,y) of the two owned columns, full box height d
-        v2f m = {mu, mu};
-        if (wave_clip) {
-            m.x = s_lut[((cxpack >> (3 * (r - 1))) & 7u) * d];
-            m.y = s_lut[((cxpack >> (9 + 3 * (r - 1))) & 7u) * d];
-        }
+    // whose box is clipped in x.  A per-thread constant of (box radius, box width): read from the table once, here (the five levels
+    // have two distinct (r, d) pairs with the shipped box widths — four registers; reading it per row cost the two waves that own
+    // border columns 40 LDS reads a tick, and every tick waits for its slowest wave).
+    auto mrow_of = [&](int r, int d) __attribute__((always_inline)) {
+        v2f m;
+        m.x = s_lut[CX(xr0, r) * d];
+        m.y = s_lut[CX(xr0 + 1, r) * d];
         return m;
     };
+    const v2f m1 = mrow_of(R1, D1), m2a = mrow_of(R2A, D2A), m2b = mrow_of(R2B, D2B), m3a = mrow_of(R3A, D3A), m3b = mrow_of(R3B, D3B);
     TapRing<L1> H1;
     TapRing<L2A> H2A;
     TapRing<L2B> H2B;
@@ -541,6 +543,11 @@ __global__ __launch_bounds__(512) void k_stage_a_fused(FusedArgs a) {
     float *pl = DBG && a.planes ? a.planes + so : nullptr;
     const size_t pstride = (size_t)a.nseq * a.n;
 
+    // (Round 4: a second copy of the tick for the ~110 of 137 ticks whose rows are all interior image rows — the ~70 wave-uniform
+    // row tests and the general form of the box average folded away at compile time — measured SLOWER, 2610-2674 -> 2676-2738 us
+    // per 1024 frames, profiles/r04_k_fused_branch_free_ab.txt: scalar compares and uniform branches ride along with the other wave's
+    // vector instructions for free, a second 16 KB loop body does not.  What did pay is below: no divergent region around the
+    // LDS stores and the neighbour reads of the two gates.)
     auto tick = [&](const int t, auto tt_tag) __attribute__((always_inline)) {
         constexpr int TT = decltype(tt_tag)::value;     // t & 1: the buffer set, and the half of the long tap rings this tick writes
         constexpr int set = TT;
@@ -592,11 +599,11 @@ __global__ __launch_bounds__(512) void k_stage_a_fused(FusedArgs a) {
             const v2f t1_r = ld2(P0 + j * WP + (PAD + R1)), t1_l = ld2(P0 + j * WP + (PAD - R1 - 1));
             v2f i0n, i1;
             if (steady) {
-                i0n = ring_row_steady<D3A, L3A>(H3A, q % L3A, t3a_r, t3a_l, MROW(R3A, D3A, mu3a));   // img0 = G(sigma0) of row ydog+1
-                i1 = ring_row_steady<D3B, L3B>(H3B, q % L3B, t3b_r, t3b_l, MROW(R3B, D3B, mu3b));    // img1 = G(sigma1) of row ydog
-                l2a[j] = ring_row_steady<D2A, L2A>(H2A, q % L2A, t2a_r, t2a_l, MROW(R2A, D2A, mu2a));   // the two filters part ways at level 2
-                l2b[j] = ring_row_steady<D2B, L2B>(H2B, q % L2B, t2b_r, t2b_l, MROW(R2B, D2B, mu2b));
-                l1[j] = ring_row_steady<D1, L1>(H1, q % L1, t1_r, t1_l, MROW(R1, D1, mu1));          // level 1 is shared by both filters
+                i0n = ring_row_steady<D3A, L3A>(H3A, q % L3A, t3a_r, t3a_l, m3a);   // img0 = G(sigma0) of row ydog+1
+                i1 = ring_row_steady<D3B, L3B>(H3B, q % L3B, t3b_r, t3b_l, m3b);    // img1 = G(sigma1) of row ydog
+                l2a[j] = ring_row_steady<D2A, L2A>(H2A, q % L2A, t2a_r, t2a_l, m2a);   // the two filters part ways at level 2
+                l2b[j] = ring_row_steady<D2B, L2B>(H2B, q % L2B, t2b_r, t2b_l, m2b);
+                l1[j] = ring_row_steady<D1, L1>(H1, q % L1, t1_r, t1_l, m1);          // level 1 is shared by both filters
             } else {
                 i0n = ring_row_general<D3A, L3A>(H3A, q % L3A, t3a_r, t3a_l, CX(xr0, R3A), CX(xr0 + 1, R3A), s_lut, y3ain0 + j, h);
                 i1 = ring_row_general<D3B, L3B>(H3B, q % L3B, t3b_r, t3b_l, CX(xr0, R3B), CX(xr0 + 1, R3B), s_lut, y3bin0 + j, h);
@@ -607,7 +614,7 @@ __global__ __launch_bounds__(512) void k_stage_a_fused(FusedArgs a) {
             {
                 const int yd = ydog0 + j;                   // DoG row; iv[j+1] = img0 of that row
                 const v2f dg = i1 - iv[j + 1];              // sspace.cpp:66
-                if (act) *reinterpret_cast<v2f *>(smem + x0 + (2 * 4 * RB * WP + PAD) + slot * WP) = dg;
+                *reinterpret_cast<v2f *>(smem + xs0 + (2 * 4 * RB * WP + PAD) + slot * WP) = dg;
                 ppack |= ((act && dg.x > 0 ? 1u : 0u) | (act && dg.y > 0 ? 2u : 0u)) << (2 * j);
                 iv[j + 2] = i0n;
                 if (DBG && pl && act) {
@@ -622,10 +629,9 @@ __global__ __launch_bounds__(512) void k_stage_a_fused(FusedArgs a) {
         // img0 at the first / last column of every wave, rows of steps 0..RB-1 (iv[1..RB]): the gate's x-neighbours
         if (lane == 0 || lane == 63) {
 #pragma unroll
-            for (int j = 0; j < RB; j++) {
-                s_edge[((size_t)j * NW + wv) * 2 + (lane ? 1 : 0)] = lane ? iv[j + 1].y : iv[j + 1].x;
-                s_sedge[((size_t)j * NW + wv) * 2 + (lane ? 1 : 0)] = (int)((ppack >> (2 * j)) & 3u);
-            }
+            for (int j = 0; j < RB; j++)
+                s_edge2[((size_t)j * (NW + 2) + wv + 1) * 2 + (lane ? 1 : 0)] =
+                    make_uint2(__float_as_uint(lane ? iv[j + 1].y : iv[j + 1].x), (ppack >> (2 * j)) & 3u);
         }
         lds_barrier();
         // ================= phase 2 ==============================================================================================
@@ -645,10 +651,10 @@ __global__ __launch_bounds__(512) void k_stage_a_fused(FusedArgs a) {
                 pre[j] = *reinterpret_cast<const uint2 *>(frame + (byte0 & ~3u));
             }
         }
-        if (act) {
-            float *Q1 = smem + x0 + (((set * 4 + 1) * RB) * WP + PAD);
-            float *Q2A = smem + x0 + (((set * 4 + 2) * RB) * WP + PAD);
-            float *Q2B = smem + x0 + (((set * 4 + 3) * RB) * WP + PAD);
+        {
+            float *Q1 = smem + xs0 + (((set * 4 + 1) * RB) * WP + PAD);
+            float *Q2A = smem + xs0 + (((set * 4 + 2) * RB) * WP + PAD);
+            float *Q2B = smem + xs0 + (((set * 4 + 3) * RB) * WP + PAD);
 #pragma unroll
             for (int j = 0; j < RB; j++) {
                 *reinterpret_cast<v2f *>(Q1 + j * WP) = l1[j];
@@ -668,13 +674,13 @@ __global__ __launch_bounds__(512) void k_stage_a_fused(FusedArgs a) {
             const uint32_t pj = (ppack >> (2 * j)) & 3u;    // DoG > 0 at (x0, x0+1) in row y
             uint32_t pL = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)pj, 0x138, 0xf, 0xf, false);
             uint32_t pR = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)pj, 0x130, 0xf, 0xf, false);
-            if (lane == 0) {
-                lft = wv > 0 ? s_edge[((size_t)j * NW + wv - 1) * 2 + 1] : 0.f;
-                pL = wv > 0 ? (uint32_t)s_sedge[((size_t)j * NW + wv - 1) * 2 + 1] : 0u;
-            }
-            if (lane == 63) {
-                rgt = wv + 1 < NW ? s_edge[((size_t)j * NW + wv + 1) * 2 + 0] : 0.f;
-                pR = wv + 1 < NW ? (uint32_t)s_sedge[((size_t)j * NW + wv + 1) * 2 + 0] : 0u;
+            {   // every lane reads the two records (wave-uniform addresses: LDS broadcasts), lanes 0 / 63 keep them: no branch
+                const uint2 eL = s_edge2[((size_t)j * (NW + 2) + wv) * 2 + 1];        // last column of the wave to the left (zeros left of the image)
+                const uint2 eR = s_edge2[((size_t)j * (NW + 2) + wv + 2) * 2 + 0];    // first column of the wave to the right
+                lft = lane == 0 ? __uint_as_float(eL.x) : lft;
+                pL = lane == 0 ? eL.y : pL;
+                rgt = lane == 63 ? __uint_as_float(eR.x) : rgt;
+                pR = lane == 63 ? eR.y : pR;
             }
             {   // positives among columns x-2..x+2 of this row, for x = x0 (pL, pj, low bit of pR) and x0+1 (high bit of pL, pj, pR)
                 const uint32_t he = __popc((pL & 3u) | (pj << 2) | ((pR & 1u) << 4));
@@ -714,13 +720,16 @@ __global__ __launch_bounds__(512) void k_stage_a_fused(FusedArgs a) {
                 const int pos = (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(b0 >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)b0, 0u)) +
                                 (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(b1 >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)b1, 0u));
                 const int code = (i << 10) | (wv * 128 + 2 * lane);
-                if (p0) seg[pos] = (uint16_t)code;
-                if (p1) seg[pos + (p0 ? 1 : 0)] = (uint16_t)(code | 1);
-                if (lane == 0) s_ccnt[set * RB * NW + sgm] = __popcll(b0) + __popcll(b1);
+                // (stores without a branch: a lane with nothing to publish writes the dummy slot, every lane the segment's count)
+                uint16_t *d0 = p0 ? seg + pos : s_dummy;
+                uint16_t *d1 = p1 ? seg + pos + (p0 ? 1 : 0) : s_dummy + 1;
+                *d0 = (uint16_t)code;
+                *d1 = (uint16_t)(code | 1);
+                s_ccnt[set * RB * NW + sgm] = __popcll(b0) + __popcll(b1);
             }
         }
-        if (act) {   // grey of batch t -> plane 0 of the buffer set (b+g+r, image.h:197-203: integers, exact in float)
-            float *Q0 = smem + x0 + (((set * 4 + 0) * RB) * WP + PAD);
+        {   // grey of batch t -> plane 0 of the buffer set (b+g+r, image.h:197-203: integers, exact in float)
+            float *Q0 = smem + xs0 + (((set * 4 + 0) * RB) * WP + PAD);
 #pragma unroll
             for (int j = 0; j < RB; j++) {
                 int y = t * RB + j;
@@ -776,8 +785,8 @@ static int fused_col_waves(int w) { return (w + 127) / 128; }
 
 size_t fused_lds_bytes(int w) {
     const int nw = fused_col_waves(w), WP = fused_row_stride(w), RB = kFusedRB;
-    const size_t fl = (size_t)2 * 4 * RB * WP + (size_t)(2 * RB + 4) * WP + 32 + kDivLutMax + (size_t)RB * nw * 4 + 4 + (size_t)2 * RB * nw;
-    return fl * 4 + (size_t)4 * nw * RB * 128 * 2;
+    const size_t fl = (size_t)2 * 4 * RB * WP + (size_t)(2 * RB + 4) * WP + 32 + kDivLutMax + (size_t)RB * (nw + 2) * 4 + 4 + (size_t)2 * RB * nw;
+    return fl * 4 + (size_t)4 * nw * RB * 128 * 2 + 8;
 }
 
 bool fused_supported(const edgehip_ctx *c) {
