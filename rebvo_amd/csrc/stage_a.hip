@@ -930,20 +930,27 @@ __global__ __launch_bounds__(kDetWaves * 64) void k_detect(DetectArgs a) {
             pix = y0 * w + q;                                // = (y0 + r) * w + x
             const float *dg = s_dog + WS * w + q;
             double t0 = 0, t1 = 0, t2 = 0;
+            if constexpr (WS == 2) {
 #pragma unroll
-            for (int i = -WS, k = 0; i <= WS; i++) {
+                for (int i = -WS; i <= WS; i++) {
 #pragma unroll
-                for (int j = -WS; j <= WS; j++, k++) {
-                    const float v = dg[i * w + j];
-                    const double yv = (double)v;
-                    if (WS == 2) {
+                    for (int j = -WS; j <= WS; j++) {
+                        const double yv = (double)dg[i * w + j];
                         t0 += pc0[j + 2] * yv;         // TooN dot product: result += a[i]*b[i], k = 0..24 in order
                         t1 += pc1[i + 2] * yv;
                         t2 += pc2 * yv;
-                    } else {                           // theta = PInv * Y (edge_finder.cpp:144), row by row in the same order
-                        t0 += s_pinv[k] * yv;
-                        t1 += s_pinv[NW2 + k] * yv;
-                        t2 += s_pinv[2 * NW2 + k] * yv;
+                    }
+                }
+            } else {                                   // theta = PInv * Y (edge_finder.cpp:144), row by row in the same order; window rows
+#pragma nounroll                                       // as a loop: 49 values x 3 rows unrolled is more than the register file holds
+                for (int i = -WS; i <= WS; i++) {
+                    const int k0 = (i + WS) * WIN;
+#pragma unroll
+                    for (int j = -WS; j <= WS; j++) {
+                        const double yv = (double)dg[i * w + j];
+                        t0 += s_pinv[k0 + j + WS] * yv;
+                        t1 += s_pinv[NW2 + k0 + j + WS] * yv;
+                        t2 += s_pinv[2 * NW2 + k0 + j + WS] * yv;
                     }
                 }
             }

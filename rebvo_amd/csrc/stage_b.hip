@@ -388,7 +388,7 @@ __global__ __launch_bounds__(256) void k_field_raster(const KlSoA *kls, int32_t 
 #define EDGEHIP_FSPLIT 2   // measured at r = 40 after the cheaper tile range: 1: 1296, 2: 1260, 3: 1292, 4: 1310, 8: 1538, 16: 2054 us per 1024 frames
 #endif
 #ifndef EDGEHIP_RASTER_UNROLL
-#define EDGEHIP_RASTER_UNROLL 2   // 1198 -> 1156 us per 1024 frames (same-box A/B, tools/gpu_r04_g.sh)
+#define EDGEHIP_RASTER_UNROLL 2   // 1198 -> 1156 us per 1024 frames (same-box A/B, tools/experiments/gpu_r04_g.sh)
 #endif
     // (A split chosen per tile so that the last round of 256 threads is as full as possible — 1..4 parts, block-uniform —
     // measured slower, 1198 -> 1283 us: the run-time divisor costs every item more than the fuller rounds save.)
