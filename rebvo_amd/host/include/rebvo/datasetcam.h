@@ -1,7 +1,8 @@
 // datasetcam.h — image-list camera for EuRoC / TUM style datasets: same constructor, list-file format and
 // GrabBuffer/ReleaseBuffer contract as the reference's DataSetCam (include/VideoLib/datasetcam.h:36-74,
 // src/VideoLib/datasetcam.cpp:32-220), without libgd: PNG (what both datasets ship) is decoded with zlib by
-// png_reader.cpp; binary PGM/PPM are accepted too.  JPEG is not (the reference relies on libgd for it).
+// png_reader.cpp, baseline JPEG by jpeg_reader.cpp (libjpeg's integer IDCT / fancy upsampling / colour tables restated: the
+// pixels libgd hands the reference); binary PGM/PPM are accepted too.  Progressive JPEG is not (tools/jpeg_to_png.py).
 #ifndef REBVO_AMD_HOST_DATASETCAM_H
 #define REBVO_AMD_HOST_DATASETCAM_H
 
@@ -12,7 +13,7 @@
 
 namespace rebvo {
 
-// Decode a PNG / PGM / PPM file into RGB24 (grey replicated, alpha dropped, 16-bit samples reduced to their high
+// Decode a PNG / baseline JPEG / PGM / PPM file into RGB24 (grey replicated, alpha dropped, 16-bit samples reduced to their high
 // byte — what libgd's truecolor conversion yields).  Returns false with a message in `err`.
 // `mono` (optional): the file stores one grey channel (PNG colour types 0 / 4, PGM), i.e. r = g = b for every pixel.
 bool LoadImageRGB24(const std::string &file, std::vector<RGB24Pixel> &out, unsigned &w, unsigned &h, std::string &err, bool *mono = nullptr);

@@ -12,6 +12,7 @@
 #include "rebvo/datasetcam.h"
 
 namespace rebvo {
+bool decode_jpeg(const std::vector<unsigned char> &d, std::vector<RGB24Pixel> &out, unsigned &w, unsigned &h, std::string &err, bool *mono);   // jpeg_reader.cpp
 namespace {
 
 bool read_file(const std::string &file, std::vector<unsigned char> &buf, std::string &err) {
@@ -164,16 +165,17 @@ bool LoadImageRGB24(const std::string &file, std::vector<RGB24Pixel> &out, unsig
     try {   // an allocation failure is a camera error (DataSetCam ends the sequence), not std::terminate in the track thread
         if (d.size() > 8 && d[0] == 137 && d[1] == 'P') return decode_png(d, out, w, h, err, mono);
         if (d.size() > 2 && d[0] == 'P' && (d[1] == '5' || d[1] == '6')) return decode_pnm(d, out, w, h, err, mono);
+        if (d.size() > 2 && d[0] == 0xFF && d[1] == 0xD8) {   // datasetcam.cpp:128-131 (gdImageCreateFromJpeg): baseline JPEG, jpeg_reader.cpp
+            if (decode_jpeg(d, out, w, h, err, mono)) return true;
+            err = file + ": " + err;
+            return false;
+        }
     } catch (const std::bad_alloc &) {
         err = "out of memory while decoding " + file;
         return false;
     }
-    if (d.size() > 2 && d[0] == 0xFF && d[1] == 0xD8) {
-        err = "JPEG image: " + file + " — this library decodes PNG / PGM / PPM (the reference reads JPEG through libgd, datasetcam.cpp:128-131); "
-              "convert the data set once with tools/jpeg_to_png.py <DataSetDir> <DataSetFile> <out_dir>";
-        return false;
-    }
-    err = "unsupported image format (PNG, PGM, PPM are read; the reference's JPEG path needs libgd): " + file;
+
+    err = "unsupported image format (PNG, baseline JPEG, PGM, PPM are read): " + file;
     return false;
 }
 

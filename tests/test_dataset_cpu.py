@@ -61,10 +61,40 @@ def test_image_reader_matches_pil(tmp_path, mode):
     assert np.array_equal(_decode(path, tmp_path), expect)
 
 
+@pytest.mark.parametrize("size", [(64, 48), (37, 53), (130, 67), (1, 1)])
+@pytest.mark.parametrize("kind", ["smooth", "noise"])
+def test_jpeg_reader_matches_libjpeg(tmp_path, size, kind):
+    """Baseline JPEG (round 4; the reference reads it through libgd = libjpeg, datasetcam.cpp:128-131): the decoder restates
+    libjpeg's integer IDCT, fancy upsampling and YCbCr tables, so every pixel must equal PIL's (libjpeg-turbo) decoding — grey,
+    4:4:4, 4:2:2, 4:2:0, low / high quality, optimised Huffman tables, restart intervals, odd sizes."""
+    w, h = size
+    rs = np.random.RandomState(w * 131 + h)
+    yy, xx = np.mgrid[0:h, 0:w]
+    a = (np.stack([(xx * 3 + yy) % 256, (xx + yy * 2) % 256, (255 - xx * 2) % 256], 2) if kind == "smooth" else rs.randint(0, 256, (h, w, 3))).astype(np.uint8)
+    n = 0
+    for grey in (False, True):
+        for sub in ((0,) if grey else (0, 1, 2)):
+            for q, opt, rst in ((30, False, 0), (75, True, 0), (95, False, 2), (100, True, 1)):
+                kw = dict(quality=q, optimize=opt)
+                if not grey:
+                    kw["subsampling"] = sub
+                if rst:
+                    kw["restart_marker_blocks"] = rst
+                path = tmp_path / f"i_{int(grey)}_{sub}_{q}.jpg".replace(":", "")
+                (PIL.fromarray(a[:, :, 0], "L") if grey else PIL.fromarray(a, "RGB")).save(path, **kw)
+                assert np.array_equal(_decode(path, tmp_path), np.asarray(PIL.open(path).convert("RGB"))), (grey, sub, q, opt, rst)
+                n += 1
+    assert n == 16
+
+
 def test_unreadable_image_and_bad_list(tmp_path):
     (tmp_path / "x.jpg").write_bytes(b"\xff\xd8\xff\xe0 not really a jpeg")
     r = subprocess.run([EXE, "--decode", str(tmp_path / "x.jpg"), str(tmp_path / "o")], capture_output=True, text=True)
-    assert r.returncode == 6 and "JPEG image" in r.stdout and "tools/jpeg_to_png.py" in r.stdout
+    assert r.returncode == 6 and "JPEG" in r.stdout
+    rs = np.random.RandomState(0)
+    PIL.fromarray(rs.randint(0, 256, (24, 24, 3)).astype(np.uint8), "RGB").save(tmp_path / "p.jpg", progressive=True)
+    r = subprocess.run([EXE, "--decode", str(tmp_path / "p.jpg"), str(tmp_path / "o")], capture_output=True, text=True)
+    assert r.returncode == 6 and "progressive" in r.stdout and "tools/jpeg_to_png.py" in r.stdout
     # dataset config whose list file is missing / malformed: Init() fails like the reference's camera error
     p = edgehip.euroc_params(64, 48)
     for content in (None, "# header\nnot_a_number,frame.png\n"):
