@@ -625,6 +625,25 @@ __device__ __forceinline__ bool is_carry(double v) { return __double_as_longlong
 #ifndef EDGEHIP_TVR_MFMA
 #define EDGEHIP_TVR_MFMA 0   // 1: the 28 sums as a Gram matrix on the f64 matrix core (measured 4 % slower on gfx950, see tvr_body)
 #endif
+// Weight and uncertainty scaling of the residual and the Jacobian row.
+//   1: the reference's own sequence of roundings (global_tracker.cpp:370-372, 399-404, 452-463): weight = k / |r| by division, applied
+//      to the residual and the gradient BEFORE the Jacobian row is formed, q_rho = sqrt(s_rho qvel s_rho qvel + 1) from the weighted
+//      gradient, seven quotients by q_rho (div_rn below: all seven share one reciprocal and still round like IEEE division).
+//   0: one scale factor w / q_rho = rsqrt((s_rho qvel)^2 + 1 / w^2) and seven products: the same real number, an ulp or two away
+//      in each value, ~10 % less time in the evaluation.  Measured side by side (profiles/r04_n_rounding_order.txt): the ulp is enough to
+//      decide WHICH knife-edge frames tip a free-running sequence away from the reference (TUM leg: 2 of 33 sequences leave with 0, none
+//      with 1; default batch: one transient departure more with 1), and inside tolerance 1 stays 1e5 times closer on the TUM leg.
+#ifndef EDGEHIP_TVR_REF_ORDER
+#define EDGEHIP_TVR_REF_ORDER 1
+#endif
+// a / b rounded as IEEE division rounds it, given rb = RN(1 / b): the closing step of the division sequence the compiler itself
+// emits (quotient estimate, exact remainder by fma, correction by fma), without its scaling (no operand here is near the exponent
+// range's ends).  Against a / b on 4e8 random and adversarial pairs (significands near 1, near 2, short): no difference.
+__device__ __forceinline__ double div_rn(const double a, const double b, const double rb) {
+    const double q = a * rb;
+    const double e = __builtin_fma(-q, b, a);
+    return __builtin_fma(e, rb, q);
+}
 #ifndef EDGEHIP_TVR_ABL
 #define EDGEHIP_TVR_ABL 0   // timing experiments only (tools/experiments/exp_tvr_ablate.sh): 1 no cross-lane reduction, 2 no div/sqrt,
 #endif                      // 4 no matched-KeyLine gather, 8 no field gather, 16 no residual stream
@@ -663,7 +682,11 @@ __device__ __forceinline__ void tvr_body(const TvrArgs &a, const int seq, const 
         double J[6] = {0, 0, 0, 0, 0, 0};
         double fm = 0, dfx = 0, dfy = 0;
         double ptx = 0, pty = 0, ptz = 1, pix = 0, piy = 0, rho_p = 1, s_rho = 1;
+#if EDGEHIP_TVR_REF_ORDER
+        double wgt_ref = 1;  // the Huber weight (REWEIGHT)
+#else
         double inv_w2 = 1;   // 1 / weight^2 (REWEIGHT)
+#endif
         int mid_f = -1;
         // status: 0 = skipped (no residual written), 1 = out of image (max_r), 2 = evaluated & matched (own fi),
         //         3 = evaluated, unmatched (inherits the previous valid fi)
@@ -706,12 +729,14 @@ __device__ __forceinline__ void tvr_body(const TvrArgs &a, const int seq, const 
                 const int x = x86_cvttsd2si(px + 0.5), y = x86_cvttsd2si(py + 0.5);
                 // Huber weight k / |r| of the previous iteration's residual (global_tracker.cpp:370-372).  It multiplies the
                 // residual and the gradient, the uncertainty scaling q_rho = sqrt((s_rho w qvel)^2 + 1) divides them again
-                // (:452-463): together w / q_rho = 1 / sqrt((s_rho qvel)^2 + 1 / w^2) — one reciprocal square root instead of
-                // a division, a square root and a division, all fp64 (8 % of the reweighted evaluation by the ablation).
-                // Differs from the reference's order of roundings by an ulp or two of the scale factor.
+                // (:452-463): together w / q_rho = 1 / sqrt((s_rho qvel)^2 + 1 / w^2), what EDGEHIP_TVR_REF_ORDER 0 computes.
                 if (REWEIGHT) {
                     if (is_carry(rprev)) rprev = carry_in_prev;
+#if EDGEHIP_TVR_REF_ORDER
+                    if (fabs(rprev) > a.k_huber) wgt_ref = a.k_huber / fabs(rprev);
+#else
                     if (fabs(rprev) > a.k_huber && !(ABL & 2)) { const double rk = fabs(rprev) * a.inv_k_huber; inv_w2 = rk * rk; }
+#endif
                 }
                 if (x < 1 || y < 1 || x >= a.w - 1 || y >= a.h - 1) {
                     fm = a.max_r;
@@ -820,6 +845,9 @@ __device__ __forceinline__ void tvr_body(const TvrArgs &a, const int seq, const 
 
         // ---- Jacobian row, uncertainty scaling (global_tracker.cpp:419-463) ----
         if (ikl < kn) {
+#if EDGEHIP_TVR_REF_ORDER
+            if (REWEIGHT) { fm *= wgt_ref; dfx *= wgt_ref; dfy *= wgt_ref; }
+#endif
             if (PROCJF) {
                 double t0 = a.zfm * rho_p;
                 J[0] = t0 * dfx;
@@ -834,9 +862,16 @@ __device__ __forceinline__ void tvr_body(const TvrArgs &a, const int seq, const 
                 J[5] = -1 * t0; J[5] += J[1] * ptx;
             }
             const double qvel = (a.zfm * dfx * sq->Vt[0] + a.zfm * dfy * sq->Vt[1] + (pix * dfx + piy * dfy) * sq->Vt[2]);
-            // The reference divides the seven values by q_rho one by one; one scale factor and seven products differ
-            // from that by at most an ulp or two per value (well inside the fp32-level pose tolerance) and remove the fp64
-            // divisions from a kernel that is bound by fp64 issue.  (qvel here is the unweighted one, see above.)
+            // the reference divides the seven values by q_rho one by one (EDGEHIP_TVR_REF_ORDER above; with 0 qvel is the unweighted one)
+#if EDGEHIP_TVR_REF_ORDER
+            const double q_rho = REWEIGHT ? sqrt(s_rho * qvel * s_rho * qvel + 1) : s_rho;
+            const double r_q = 1.0 / q_rho;
+            if (PROCJF) {
+#pragma unroll
+                for (int j = 0; j < 6; j++) J[j] = div_rn(J[j], q_rho, r_q);
+            }
+            fm = div_rn(fm, q_rho, r_q);
+#else
             double inv_q;
             if (REWEIGHT) {
                 const double sq = s_rho * qvel;
@@ -849,6 +884,7 @@ __device__ __forceinline__ void tvr_body(const TvrArgs &a, const int seq, const 
                 for (int j = 0; j < 6; j++) J[j] *= inv_q;
             }
             fm *= inv_q;
+#endif
         }
         if (GRAM_MFMA) {
             // the KeyLine's row (J0..J5, fm, 0) for the Gram matrix below; rows of skipped / absent KeyLines are zero
@@ -1131,10 +1167,19 @@ __device__ __forceinline__ void tvr2_body(const TvrArgs &a, const int seq, const
                 J[4] = J[0] * ptz[c]; J[4] += J[2] * ptx[c];
                 t0 = J[0] * pty[c];
                 J[5] = -1 * t0; J[5] += J[1] * ptx[c];
+#if EDGEHIP_TVR_REF_ORDER
+#pragma unroll
+                for (int j = 0; j < 6; j++) J[j] = div_rn(J[j], s_rho, inv_q);   // the reference's seven quotients (see div_rn)
+#else
 #pragma unroll
                 for (int j = 0; j < 6; j++) J[j] *= inv_q;
+#endif
             }
+#if EDGEHIP_TVR_REF_ORDER
+            fmc[c] = div_rn(fmc[c], s_rho, inv_q);
+#else
             fmc[c] *= inv_q;
+#endif
         }
     }
 #if EDGEHIP_TVR2_PARK
@@ -1274,7 +1319,14 @@ __device__ __forceinline__ void tvr_rw2_body(const TvrArgs &a, const int seq, co
             const int x = x86_cvttsd2si(px[c] + 0.5), y = x86_cvttsd2si(py[c] + 0.5);
             double rp = rprev[c];
             if (is_carry(rp)) rp = cin[c];
-            if (fabs(rp) > a.k_huber) { const double rk = fabs(rp) * a.inv_k_huber; inv_w2[c] = rk * rk; }
+            if (fabs(rp) > a.k_huber) {
+#if EDGEHIP_TVR_REF_ORDER
+                inv_w2[c] = a.k_huber / fabs(rp);   // the weight itself here
+#else
+                const double rk = fabs(rp) * a.inv_k_huber;
+                inv_w2[c] = rk * rk;
+#endif
+            }
             inimg[c] = !(x < 1 || y < 1 || x >= a.w - 1 || y >= a.h - 1);
             fidx[c] = inimg[c] ? field16_index(x, y, a.f16tx) : (size_t)0;
             rmx[c] = (float)(RM[0] * (double)klm[c].x + RM[1] * (double)klm[c].y);
@@ -1376,6 +1428,9 @@ __device__ __forceinline__ void tvr_rw2_body(const TvrArgs &a, const int seq, co
         double J[6] = {0, 0, 0, 0, 0, 0};
         double fmc = fm[c];
         if (ikl[c] < kn) {
+#if EDGEHIP_TVR_REF_ORDER
+            fmc *= inv_w2[c]; dfx[c] *= inv_w2[c]; dfy[c] *= inv_w2[c];
+#endif
             double t0 = a.zfm * rho_p[c];
             J[0] = t0 * dfx[c];
             J[1] = t0 * dfy[c];
@@ -1388,11 +1443,18 @@ __device__ __forceinline__ void tvr_rw2_body(const TvrArgs &a, const int seq, co
             t0 = J[0] * pty[c];
             J[5] = -1 * t0; J[5] += J[1] * ptx[c];
             const double qvel = (a.zfm * dfx[c] * V[0] + a.zfm * dfy[c] * V[1] + (pix[c] * dfx[c] + piy[c] * dfy[c]) * V[2]);
+#if EDGEHIP_TVR_REF_ORDER
+            const double q_rho = sqrt(s_rho[c] * qvel * s_rho[c] * qvel + 1), r_q = 1.0 / q_rho;
+#pragma unroll
+            for (int j = 0; j < 6; j++) J[j] = div_rn(J[j], q_rho, r_q);
+            fmc = div_rn(fmc, q_rho, r_q);
+#else
             const double sq_ = s_rho[c] * qvel;
             const double inv_q = rsqrt_f64(sq_ * sq_ + inv_w2[c]);
 #pragma unroll
             for (int j = 0; j < 6; j++) J[j] *= inv_q;
             fmc *= inv_q;
+#endif
         }
         int ns = 0;
 #pragma unroll
