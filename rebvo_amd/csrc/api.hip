@@ -507,6 +507,7 @@ static int create_body(edgehip_ctx *c, CtxAllocs *al, const edgehip_params &p, i
     c->fused_min_batch = fused_min_env;   // one workgroup per sequence: pays from about 3/4 of the 256 CUs on (tools/experiments/ab_level_mode.sh)
     // measured at 1024 sequences (tools/experiments/gpu_r04_j.sh, same box, three rounds): the step 10.53 / 10.50 / 10.43 ms without, 10.48 / 10.39 / 10.39 ms with —
     // inside the run-to-run spread, while the group's own HIP-event time went UP (2.62 -> 2.73 ms: 84 registers, 5 waves per SIMD).  Off by default.
+    c->fused_undist = getenv("EDGEHIP_FUSED_UNDIST") && atoi(getenv("EDGEHIP_FUSED_UNDIST")) != 0;
     c->tvr_rw2 = getenv("EDGEHIP_TVR_RW2") ? atoi(getenv("EDGEHIP_TVR_RW2")) : 0;
     c->dual_init = getenv("EDGEHIP_DUAL_INIT") ? atoi(getenv("EDGEHIP_DUAL_INIT")) : 1;
     c->persist_lm_max = getenv("EDGEHIP_PERSIST_LM") ? atoi(getenv("EDGEHIP_PERSIST_LM")) : 0;   // measured: no gain (tools/experiments/exp_single_latency.py), so off

@@ -253,6 +253,7 @@ struct edgehip_ctx {
     int32_t *bin_cnt;      // [B][256] KeyLines binned per field tile
     int32_t *bins;         // [B][256][CAP] KeyLine ids per field tile (allocated for the tiles in use)
     int nblk_tvr;
+    bool fused_undist;     // EDGEHIP_FUSED_UNDIST=1: the one-kernel stage A resamples through the distortion map inside its load (default: k_undistort_grey first)
     int tvr_rw2;           // EDGEHIP_TVR_RW2: from this many evaluation blocks per launch on, the reweighted evaluation takes two KeyLines per thread (0 = never)
     int dual_init;         // EDGEHIP_DUAL_INIT (default 1): the two initialisation chains of TrackerInitType = 2 share their launches (stage_b.hip tvr2_body)
     int persist_lm_max;    // batches up to this many sequences fuse every TryVelRot evaluation with the LM step after it (EDGEHIP_PERSIST_LM, 0 = never)

@@ -43,32 +43,7 @@ namespace edgehip {
 // stays below 2^24 and float addition of these integers is exact: any order gives the reference's bits
 // (iimage.cpp:56-61).  Each lane owns CH consecutive pixels; wave-level exclusive scan of lane totals.
 // ---------------------------------------------------------------------------------------------------
-// image_undistort::biInterp for RGB24 (include/VideoLib/image_undistort.h:66-79): integer 16.16 weights, >>16,
-// truncation to 8 bits.  Taps sit at base, base+1, base+w, base+w+1; an invalid tap has weight 0.
-// The two pixels of a tap row are six consecutive bytes: one unaligned 8-byte load per row (gfx9 global loads take any byte
-// address) instead of six byte loads behind a branch on the weight.  Unconditional: a tap with weight 0 may lie outside the frame,
-// so the load is kept inside the frame's 3n bytes and its bytes are shifted to where the taps expect them (the bytes that
-// fall off belong to pixels outside the frame, whose weight is 0); the products are exact integers either way.
-__device__ __forceinline__ uint64_t undist_row6(const uint8_t *__restrict__ frame, int pi, int n) {
-    pi = pi < -2 ? -2 : (pi > n ? n : pi);              // further out both pixels are outside
-    const int want = pi * 3, last = n * 3 - 8;
-    const int at = want < 0 ? 0 : (want < last ? want : last);
-    uint64_t v;
-    __builtin_memcpy(&v, frame + at, 8);
-    const int d = want - at;                            // -6 ... 8 bytes: the load was moved to stay inside the frame
-    return d >= 0 ? (d < 8 ? v >> (8 * d) : 0) : v << (8 * -d);   // e.g. pi = -1: pixel 0 is the row's SECOND tap
-}
-__device__ __forceinline__ uchar3 undist_mix(const uint64_t t, const uint64_t u, const uint4 iw) {
-    const int w0 = (int)iw.x, w1 = (int)iw.y, w2 = (int)iw.z, w3 = (int)iw.w;
-    const int r = w0 * (int)(t & 0xFF) + w1 * (int)((t >> 24) & 0xFF) + w2 * (int)(u & 0xFF) + w3 * (int)((u >> 24) & 0xFF);
-    const int g = w0 * (int)((t >> 8) & 0xFF) + w1 * (int)((t >> 32) & 0xFF) + w2 * (int)((u >> 8) & 0xFF) + w3 * (int)((u >> 32) & 0xFF);
-    const int b = w0 * (int)((t >> 16) & 0xFF) + w1 * (int)((t >> 40) & 0xFF) + w2 * (int)((u >> 16) & 0xFF) + w3 * (int)((u >> 40) & 0xFF);
-    return make_uchar3((unsigned char)(r >> 16), (unsigned char)(g >> 16), (unsigned char)(b >> 16));
-}
-__device__ __forceinline__ uchar3 undist_rgb(const uint8_t *__restrict__ frame, int32_t base, uint4 iw, int w, int n) {
-    return undist_mix(undist_row6(frame, base, n), undist_row6(frame, base + w, n), iw);
-}
-
+// (undist_row6 / undist_mix / undist_rgb: stage_a_dev.h — the one-kernel stage A resamples with them too)
 template <int CH, bool UNDIST>
 __global__ __launch_bounds__(256) void k_rgb_rowscan(const uint8_t *__restrict__ rgb, const int32_t *__restrict__ fidx,
                                                      float *__restrict__ dst, int w, int h, size_t n,
@@ -1366,7 +1341,8 @@ int stage_a_enqueue(edgehip_ctx *c, int slot, bool fwd_fills, bool defer_retune)
     }
     if (use_fused) {
         const uint16_t *grey16 = nullptr;
-        if (c->und_base) {   // UseUndistort: resample + grey first (the integral-image scratch is free on this path)
+        const bool und_in_load = c->und_base && c->fused_undist;
+        if (c->und_base && !und_in_load) {   // UseUndistort: resample + grey first (the integral-image scratch is free on this path)
             ProfScope ps(c, PROF_A_ROWSCAN, st);
             uint16_t *g16 = reinterpret_cast<uint16_t *>(c->ii);
             hipLaunchKernelGGL(k_undistort_grey<8>, dim3((unsigned)((n + 255) / 256), 1, (B + 7) / 8), dim3(256), 0, st, rgb_base, rgb_idx, g16, w,
@@ -1374,7 +1350,7 @@ int stage_a_enqueue(edgehip_ctx *c, int slot, bool fwd_fills, bool defer_retune)
             EH_LAUNCH_CHECK();
             grey16 = g16;
         }
-        if (int e = stage_a_fused_enqueue(c, slot, rgb_base, rgb_idx, grey16, grey8)) return e;
+        if (int e = stage_a_fused_enqueue(c, slot, rgb_base, rgb_idx, grey16, grey8, und_in_load)) return e;
         ProfScope ps(c, PROF_A_JOIN, st);
         hipLaunchKernelGGL((k_join_histo<true, true>), dim3((pl.cap + 255) / 256, 1, B), dim3(256), 0, st, kldev(c, slot),
                            maskof(c, slot), c->seqa, c->histo, w, n, c->p.qcut_nbins, c->slot_cam[slot].ppx, c->slot_cam[slot].ppy,

@@ -31,6 +31,8 @@ struct FusedArgs {
     const uint8_t *rgb;        // frames of the slot (sequence-major) or a bound pool
     const int32_t *fidx;       // [B] frame index inside the pool, or null
     const uint16_t *grey16;    // [B][N] b+g+r of the undistorted frame (SRC_GREY16 instantiations), or null
+    const int32_t *und_base;   // [N] first tap of every pixel / [N] its four 16.16 weights (SRC_UNDIST instantiations), or null
+    const uint4 *und_iw;
     const uint8_t *grey8;      // 8-bit mono frames, 1 B per pixel (SRC_GREY8 instantiations: frame = grey8 + (fidx ? fidx[seq] : seq) * n), or null
     const float *lut;          // [kDivLutMax] (float)(1.0/count)
     float *planes;             // optional debug planes [5][B][N]
@@ -66,12 +68,40 @@ inline int detect_band_rows(int w, int ws) {
     return 0;
 }
 
+// image_undistort::biInterp for RGB24 (include/VideoLib/image_undistort.h:66-79): integer 16.16 weights, >>16,
+// truncation to 8 bits.  Taps sit at base, base+1, base+w, base+w+1; an invalid tap has weight 0.
+// The two pixels of a tap row are six consecutive bytes: one unaligned 8-byte load per row (gfx9 global loads take any byte
+// address) instead of six byte loads behind a branch on the weight.  Unconditional: a tap with weight 0 may lie outside the frame,
+// so the load is kept inside the frame's 3n bytes and its bytes are shifted to where the taps expect them (the bytes that
+// fall off belong to pixels outside the frame, whose weight is 0); the products are exact integers either way.
+__device__ __forceinline__ uint64_t undist_row6(const uint8_t *__restrict__ frame, int pi, int n) {
+    pi = pi < -2 ? -2 : (pi > n ? n : pi);              // further out both pixels are outside
+    const int want = pi * 3, last = n * 3 - 8;
+    const int at = want < 0 ? 0 : (want < last ? want : last);
+    uint64_t v;
+    __builtin_memcpy(&v, frame + at, 8);
+    const int d = want - at;                            // -6 ... 8 bytes: the load was moved to stay inside the frame
+    return d >= 0 ? (d < 8 ? v >> (8 * d) : 0) : v << (8 * -d);   // e.g. pi = -1: pixel 0 is the row's SECOND tap
+}
+__device__ __forceinline__ uchar3 undist_mix(const uint64_t t, const uint64_t u, const uint4 iw) {
+    const int w0 = (int)iw.x, w1 = (int)iw.y, w2 = (int)iw.z, w3 = (int)iw.w;
+    const int r = w0 * (int)(t & 0xFF) + w1 * (int)((t >> 24) & 0xFF) + w2 * (int)(u & 0xFF) + w3 * (int)((u >> 24) & 0xFF);
+    const int g = w0 * (int)((t >> 8) & 0xFF) + w1 * (int)((t >> 32) & 0xFF) + w2 * (int)((u >> 8) & 0xFF) + w3 * (int)((u >> 32) & 0xFF);
+    const int b = w0 * (int)((t >> 16) & 0xFF) + w1 * (int)((t >> 40) & 0xFF) + w2 * (int)((u >> 16) & 0xFF) + w3 * (int)((u >> 40) & 0xFF);
+    return make_uchar3((unsigned char)(r >> 16), (unsigned char)(g >> 16), (unsigned char)(b >> 16));
+}
+__device__ __forceinline__ uchar3 undist_rgb(const uint8_t *__restrict__ frame, int32_t base, uint4 iw, int w, int n) {
+    return undist_mix(undist_row6(frame, base, n), undist_row6(frame, base + w, n), iw);
+}
+
 bool fused_supported(const edgehip_ctx *c);
 // what the fused kernel's first load reads: the RGB24 frame (ConvertRGB2BW fused: b+g+r), the 16-bit grey plane of
 // k_undistort_grey, or an 8-bit mono frame (b+g+r of r = g = b = v: 3 v, the same integer ConvertRGB2BW computes from the
 // RGB24 expansion DataSetCam makes of a mono image, image.h:197-203)
-enum FusedSrc { SRC_RGB24 = 0, SRC_GREY16 = 1, SRC_GREY8 = 2 };
+// SRC_UNDIST: the RGB24 frame resampled through the distortion map inside the load (image_undistort::undistort<true>, 4 taps with 16.16
+// weights, then b+g+r) — EDGEHIP_FUSED_UNDIST=1; the default for UseUndistort stays k_undistort_grey + SRC_GREY16 (measured faster)
+enum FusedSrc { SRC_RGB24 = 0, SRC_GREY16 = 1, SRC_GREY8 = 2, SRC_UNDIST = 3 };
 int stage_a_fused_enqueue(edgehip_ctx *c, int slot, const uint8_t *rgb_base, const int32_t *rgb_idx, const uint16_t *grey16,
-                          const uint8_t *grey8 = nullptr);
+                          const uint8_t *grey8 = nullptr, bool undist_in_load = false);
 
 }  // namespace edgehip

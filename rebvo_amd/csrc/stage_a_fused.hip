@@ -162,7 +162,7 @@ __device__ __forceinline__ FitOut fit_eval(const float (&v)[25], const FitCoef &
 // the frame after k_undistort_grey, image_undistort fused with ConvertRGB2BW), or an 8-bit mono frame (a.grey8: 3 v).
 template <int W, bool DBG, int SRC, int RB, int D1, int D2A, int D2B, int D3A, int D3B>
 __global__ __launch_bounds__(512) void k_stage_a_fused(FusedArgs a) {
-    constexpr bool GREY16 = SRC == SRC_GREY16, GREY8 = SRC == SRC_GREY8;
+    constexpr bool GREY16 = SRC == SRC_GREY16, GREY8 = SRC == SRC_GREY8, UND = SRC == SRC_UNDIST;
     constexpr int R1 = D1 / 2, R2A = D2A / 2, R2B = D2B / 2, R3A = D3A / 2, R3B = D3B / 2;
     constexpr int LB = R1 + R2B + R3B;                  // rows img1 trails the input by
     static_assert(R1 + R2A + R3A + 1 == LB, "img0 must lead img1 by exactly one row (it is held for one step)");
@@ -642,7 +642,11 @@ __global__ __launch_bounds__(512) void k_stage_a_fused(FusedArgs a) {
             if (ABL & 16) { pre[j] = make_uint2(0, 0); continue; }
             int y = t * RB + j;
             y = y < h ? y : h - 1;
-            if (GREY16) {
+            if (UND) {
+                // the first taps of the two pixels (the map is the same for every sequence: L2 hits); their weights and the taps
+                // themselves follow at the end of the phase — a dependent round trip nothing hides (16 + 16 registers per row)
+                pre[j] = *reinterpret_cast<const uint2 *>(a.und_base + (y * w + xr0));
+            } else if (GREY16) {
                 pre[j] = make_uint2(*reinterpret_cast<const uint32_t *>(frame + (uint32_t)(y * w + xr0) * 2u), 0u);   // two 16-bit values
             } else if (GREY8) {
                 pre[j] = make_uint2(*reinterpret_cast<const uint16_t *>(frame + (uint32_t)(y * w + xr0)), 0u);        // two 8-bit values
@@ -728,7 +732,31 @@ __global__ __launch_bounds__(512) void k_stage_a_fused(FusedArgs a) {
                 s_ccnt[set * RB * NW + sgm] = __popcll(b0) + __popcll(b1);
             }
         }
-        {   // grey of batch t -> plane 0 of the buffer set (b+g+r, image.h:197-203: integers, exact in float)
+        if (UND) {   // image_undistort::undistort<true> (image_undistort.h:105-122) + ConvertRGB2BW for the thread's 2 x RB pixels
+            float *Q0 = smem + xs0 + (((set * 4 + 0) * RB) * WP + PAD);
+            uint4 iw[RB][2];
+            uint64_t tt[RB][2], tu[RB][2];
+#pragma unroll
+            for (int j = 0; j < RB; j++) {
+                int y = t * RB + j;
+                y = y < h ? y : h - 1;
+                const uint4 *wp = a.und_iw + (y * w + xr0);
+                iw[j][0] = wp[0];
+                iw[j][1] = wp[1];
+                tt[j][0] = undist_row6(frame, (int)pre[j].x, (int)a.n);
+                tu[j][0] = undist_row6(frame, (int)pre[j].x + w, (int)a.n);
+                tt[j][1] = undist_row6(frame, (int)pre[j].y, (int)a.n);
+                tu[j][1] = undist_row6(frame, (int)pre[j].y + w, (int)a.n);
+            }
+#pragma unroll
+            for (int j = 0; j < RB; j++) {
+                const uchar3 c0 = undist_mix(tt[j][0], tu[j][0], iw[j][0]), c1 = undist_mix(tt[j][1], tu[j][1], iw[j][1]);
+                v2f g;
+                g.x = (float)((int)c0.x + (int)c0.y + (int)c0.z);
+                g.y = (float)((int)c1.x + (int)c1.y + (int)c1.z);
+                *reinterpret_cast<v2f *>(Q0 + j * WP) = g;
+            }
+        } else {   // grey of batch t -> plane 0 of the buffer set (b+g+r, image.h:197-203: integers, exact in float)
             float *Q0 = smem + xs0 + (((set * 4 + 0) * RB) * WP + PAD);
 #pragma unroll
             for (int j = 0; j < RB; j++) {
@@ -805,7 +833,7 @@ bool fused_supported(const edgehip_ctx *c) {
 }
 
 int stage_a_fused_enqueue(edgehip_ctx *c, int slot, const uint8_t *rgb_base, const int32_t *rgb_idx, const uint16_t *grey16,
-                          const uint8_t *grey8) {
+                          const uint8_t *grey8, bool undist_in_load) {
     const DevicePlan &pl = c->plan;
     const int B = pl.nseq;
     const int nw = fused_col_waves(pl.w);
@@ -836,11 +864,17 @@ int stage_a_fused_enqueue(edgehip_ctx *c, int slot, const uint8_t *rgb_base, con
     const size_t sm = fused_lds_bytes(pl.w);
     a.grey16 = grey16;
     a.grey8 = grey8;
+    a.und_base = undist_in_load ? c->und_base : nullptr;
+    a.und_iw = undist_in_load ? c->und_iw : nullptr;
     // the shipped image sizes get their own instantiation (EuRoC 752 from RGB or mono, TUM 640 from the undistorted grey
     // plane), any other width — and contexts with debug planes — the generic ones
 #define EH_FUSED(WW, DBG, SRC) k_stage_a_fused<WW, DBG, SRC, kFusedRB, 3, 3, 5, 5, 5>
     void (*fn)(FusedArgs);
-    if (grey16) {
+    if (undist_in_load) {
+        fn = EH_FUSED(0, false, SRC_UNDIST);
+        if (c->planes) fn = EH_FUSED(0, true, SRC_UNDIST);
+        else if (pl.w == 640) fn = EH_FUSED(640, false, SRC_UNDIST);
+    } else if (grey16) {
         fn = EH_FUSED(0, false, SRC_GREY16);
         if (c->planes) fn = EH_FUSED(0, true, SRC_GREY16);
         else if (pl.w == 640) fn = EH_FUSED(640, false, SRC_GREY16);
@@ -855,7 +889,9 @@ int stage_a_fused_enqueue(edgehip_ctx *c, int slot, const uint8_t *rgb_base, con
         else if (pl.w == 640) fn = EH_FUSED(640, false, SRC_RGB24);
     }
     if (!c->lds_optin_fused) {
-        const void *fns[10] = {(const void *)EH_FUSED(0, false, SRC_RGB24), (const void *)EH_FUSED(0, true, SRC_RGB24),
+        const void *fns[13] = {(const void *)EH_FUSED(0, false, SRC_UNDIST), (const void *)EH_FUSED(0, true, SRC_UNDIST),
+                               (const void *)EH_FUSED(640, false, SRC_UNDIST),
+                               (const void *)EH_FUSED(0, false, SRC_RGB24), (const void *)EH_FUSED(0, true, SRC_RGB24),
                                (const void *)EH_FUSED(752, false, SRC_RGB24), (const void *)EH_FUSED(640, false, SRC_RGB24),
                                (const void *)EH_FUSED(0, false, SRC_GREY16), (const void *)EH_FUSED(0, true, SRC_GREY16),
                                (const void *)EH_FUSED(640, false, SRC_GREY16), (const void *)EH_FUSED(0, false, SRC_GREY8),
