@@ -387,11 +387,19 @@ __global__ __launch_bounds__(256) void k_field_raster(const KlSoA *kls, int32_t 
 #ifndef EDGEHIP_FSPLIT
 #define EDGEHIP_FSPLIT 2   // measured at r = 40 after the cheaper tile range: 1: 1296, 2: 1260, 3: 1292, 4: 1310, 8: 1538, 16: 2054 us per 1024 frames
 #endif
+#ifndef EDGEHIP_RASTER_ABL
+#define EDGEHIP_RASTER_ABL 0   // timing experiments only, wrong fields by design (tools/experiments/gpu_r04_r.sh): 1 plain store for
+#endif                         // the atomic, 2 no LDS access, 3 no samples, 4 = 3 and no output stage, 5 = 3 and no record gather, 6 = 5 and no bin read
 #ifndef EDGEHIP_RASTER_UNROLL
 #define EDGEHIP_RASTER_UNROLL 2   // 1198 -> 1156 us per 1024 frames (same-box A/B, tools/experiments/gpu_r04_g.sh)
 #endif
     // (A split chosen per tile so that the last round of 256 threads is as full as possible — 1..4 parts, block-uniform —
-    // measured slower, 1198 -> 1283 us: the run-time divisor costs every item more than the fuller rounds save.)
+    // measured slower, 1198 -> 1283 us: the run-time divisor costs every item more than the fuller rounds save.  So did dealing the
+    // samples of 256 KeyLines to the threads in equal shares (ranges parked in LDS, a scan of their lengths, one binary search per
+    // thread, then a flat walk over samples and KeyLines): 1158 -> 1434 us — the ablations say why: the sample loop already runs at
+    // ~17 lane-cycles per sample for ~16 vector instructions, i.e. with nearly full lanes; the flat walk adds instructions to every
+    // sample and saves waiting that is not there.  Where the kernel's ~970 us go (r = 40, 15.4 k KeyLines, profiles/r04_r_raster_ablations.txt):
+    // samples 526, the 16-bit plane's store 160 (0.74 GB: the HBM rate), record gathers 104, bin reads 57, tile clear / ranges / ramp ~120.)
     constexpr int FSPLIT = EDGEHIP_FSPLIT;
     // The hardware rounding differs from round() in a way that matters only for a coordinate of exactly -0.5 (pixel 0
     // instead of -1, ctx.h): that can only be accepted by a tile that starts at column / row 0, so only the tiles on
@@ -399,8 +407,17 @@ __global__ __launch_bounds__(256) void k_field_raster(const KlSoA *kls, int32_t 
     auto raster = [&](auto fix_x, auto fix_y) {
         for (int wi = tid; wi < cnt * FSPLIT; wi += 256) {
             const int li = wi / FSPLIT, part = wi - li * FSPLIT;
+#if EDGEHIP_RASTER_ABL == 6     // no bin read
+            const int ikl = li * 7;
+#else
             const int ikl = list[li];
+#endif
+#if EDGEHIP_RASTER_ABL >= 5     // no record gather
+            MatchRec r;
+            r.c_px = (float)(tx0 + (ikl & 63)); r.c_py = (float)(ty0 + ((ikl >> 6) & 63)); r.u_mx = 0.6f; r.u_my = 0.8f;
+#else
             const MatchRec r = k.rec[ikl];
+#endif
             int t0, t1;
             if (!tile_trange(r, tx0, ty0, radius, t0, t1)) continue;
             {
@@ -409,6 +426,13 @@ __global__ __launch_bounds__(256) void k_field_raster(const KlSoA *kls, int32_t 
                 t1 = min(t1, t0 + chunk - 1);
             }
             const uint32_t idk = (uint32_t)(0xFFFF - ikl);
+#if EDGEHIP_RASTER_ABL == 2
+            uint32_t acc_abl = 0;
+#endif
+#if EDGEHIP_RASTER_ABL >= 3      // the set-up only, no samples
+            if (t0 == 12345) s_tile[0] = idk;
+            continue;
+#endif
             // t runs as a float (|t| <= 255: every value and the increment are exact), so the reference's (float)t costs
             // nothing and |t| is an operand modifier of the one conversion back
             const float t1f = (float)t1;
@@ -420,7 +444,13 @@ __global__ __launch_bounds__(256) void k_field_raster(const KlSoA *kls, int32_t 
                 const int ly = (decltype(fix_y)::value ? round_half_away_i(fy) : round_ties_up_i(fy)) - ty0;
                 if ((unsigned)lx >= ex || (unsigned)ly >= ey) return;
                 const uint32_t at = (uint32_t)fabsf(tf);
+#if EDGEHIP_RASTER_ABL == 1      // a plain store instead of the atomic
+                s_tile[ly * FT + lx] = (at << 16) | idk;
+#elif EDGEHIP_RASTER_ABL == 2    // no LDS access at all
+                acc_abl += (at << 16) | idk | (uint32_t)(ly * FT + lx);
+#else
                 atomicMin(&s_tile[ly * FT + lx], (at << 16) | idk);
+#endif
             };
 #if EDGEHIP_RASTER_UNROLL == 2
             // two samples per trip: the loop's own bookkeeping (exec-mask save / restore, compare, branch: as many scalar
@@ -431,6 +461,9 @@ __global__ __launch_bounds__(256) void k_field_raster(const KlSoA *kls, int32_t 
 #else
             for (float tf = (float)t0; tf <= t1f; tf += 1.f) sample(tf);
 #endif
+#if EDGEHIP_RASTER_ABL == 2
+            if (acc_abl == 0x12345u) s_tile[1] = acc_abl;
+#endif
         }
     };
     using T = std::true_type;
@@ -439,6 +472,9 @@ __global__ __launch_bounds__(256) void k_field_raster(const KlSoA *kls, int32_t 
     else { if (ty0 == 0) raster(F{}, T{}); else raster(F{}, F{}); }
     __syncthreads();
     if (tid == 0) bin_cnt[(size_t)seq * kMaxTiles + tile] = 0;   // every tile's count is consumed by exactly this block: ready for the next k_field_bin (no memset launch)
+#if EDGEHIP_RASTER_ABL == 4
+    if (s_tile[tid] != 0x12345u) return;
+#endif
     // store in the 4x4-tiled layout: 16 consecutive threads write one 64-B tile, a tile row of the block is 1 KB
     // contiguous (FT and the block origin are multiples of 4)
     // (the {dist, ikl} form is kept only for edgehip_download_field: params.debug_planes)
