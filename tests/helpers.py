@@ -122,3 +122,13 @@ def hetero_sequence(s, w=752, h=480, scenes=6, pool=12):
     frames = [f for f, _, _ in synth.billboard_sequence(w, h, pool, seed=101 + 7 * (s % scenes), traj_seed=29 + (s % scenes), **intr)]
     ph = (s // scenes) % (2 * (pool - 1))
     return lambda k: frames[tri(k + ph, pool)]
+
+
+def depths_agree(kg, kr, same):
+    """Depth maps of the device (kg) and the reference (kr) on the KeyLines with identical matches: |d rho| <= 1e-5 |rho| + 1e-7 +
+    1e-5 s_rho.  The last term: the EKF's gain for a KeyLine that knows nothing about its depth (s_rho of the order of rho or above) is
+    close to 1 and its measurement divides by u . (V_xy zf - V_z q0) (edge_tracker.cpp:978-1003), small when the edge runs along the
+    epipolar line — a velocity that differs by 1e-9 of the step moves such a depth by 1e-5 of its value and 1e-5 of its own sigma
+    (one KeyLine of 16 000 at 1280 x 720, tools/experiments/exp_pipeline_closeness.py)."""
+    d = np.abs(kg["rho"][same] - kr["rho"][same])
+    return bool(np.all(d <= 1e-5 * np.abs(kr["rho"][same]) + 1e-7 + 1e-5 * kr["s_rho"][same]))
