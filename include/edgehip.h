@@ -216,6 +216,9 @@ int edgehip_build_field(edgehip_ctx *ctx, int slot, int radius, float min_mod);
  * the old slot's KeyLines against the new slot's field, at state X[nseq][6].  Residual buffers are
  * device-resident and named by index 0..2 (Res0/Res1/Rest of Minimizer_RV, :611-612); resid_in < 0 means
  * all-zero.  out[nseq][43] = JtJ(36, row-major, sign-fixed and symmetrised) | JtF(6) | score.
+ * Parity: every per-KeyLine value (projection, match, residual, Huber weight k/|r|, q_rho, the seven quotients by q_rho) is formed
+ * by the reference's own sequence of IEEE operations (:363-463; ne10wrapper.h:414-424), so the residual memory is bit-identical;
+ * the 28 sums are added in another (fixed) pair-wise tree than ne10wrapper.h:333-362 and agree to ~4e-16 relative.
  * Synchronises. */
 int edgehip_try_velrot(edgehip_ctx *ctx, int slot_new, int slot_old, const double *X, int reweight, int procjf,
                        double match_thresh, const double *s_rho_min, uint32_t match_num_thresh, double k_huber,
