@@ -133,7 +133,7 @@ def algorithmic_bytes(group, kn, n_px, radius, nseq, evals_per_launch=1.0):
         "B.lm_step": 0,
         "B.quantile": 8 * kn,
         "C.forward_match": (4 + 8 + 8 + 4 + 100) * kn,
-        "C.rotate": (8 + 16 + 8 + 8 + 16 + 8 + 8) * kn,
+        "C.rotate": 2 * (8 + 16 + 8) * kn,                   # p_m, rho, s_rho, m_m in and out (the gather record's copy of m_m is no longer rewritten)
         "C.directed_matching": (4 * 40 + 2 * 168) * kn,
         "C.regularize_ekf": (3 * 16 + 16 + 100) * kn,
         # SURVEY 8(d) prices EstimateReScalingOpt at five passes over 32 B per KeyLine; the kernel keeps a sequence's KeyLines in

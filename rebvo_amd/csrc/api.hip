@@ -409,7 +409,7 @@ static int create_body(edgehip_ctx *c, CtxAllocs *al, const edgehip_params &p, i
         }
     }
     EH_CHECK(hipStreamCreateWithFlags(&c->stream_up, hipStreamNonBlocking));
-    for (int i = 0; i < 4; i++) { EH_CHECK(hipEventCreateWithFlags(&c->ev_up[i], hipEventDisableTiming)); c->up_valid[i] = false; c->slot_ring[i] = -1; c->a_api_valid[i] = false; c->grec_ok[i] = false; }
+    for (int i = 0; i < 4; i++) { EH_CHECK(hipEventCreateWithFlags(&c->ev_up[i], hipEventDisableTiming)); c->up_valid[i] = false; c->slot_ring[i] = -1; c->a_api_valid[i] = false; c->rec_stale[i] = false; c->grec_ok[i] = false; }
     for (int i = 0; i < 4; i++) {
         EH_CHECK(hipEventCreateWithFlags(&c->ev_a[i], hipEventDisableTiming));
         EH_CHECK(hipEventCreateWithFlags(&c->ev_use[i], hipEventDisableTiming));

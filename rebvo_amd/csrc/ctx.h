@@ -176,6 +176,8 @@ struct edgehip_ctx {
     int slot_ring[4];      // [slot] ev_ring entry of the last frame processed in this slot (-1: none)
     bool no_grec;          // EDGEHIP_NO_GREC=1: always gather the 32-byte record (A/B measurements)
     bool grec_ok[4];       // [slot] KlSoA::grec describes the slot's KeyLines (all sequences)
+    bool rec_stale[4];     // [slot] rotate_keylines has turned m_m since KlSoA::rec was written: rec.m_m is behind (rec_refresh_enqueue brings
+                           // it up to date for the rare reader — a rotated slot used as the tracker's field side, a key frame, a stereo pair)
     bool a_api_valid[4];   // [slot] ev_a was recorded by the stage-level edgehip_stage_a (an upload must wait for it)
     hipEvent_t ev_ring[8]; // [frame % 8] the frame that used this entry of the pinned time-stamp / frame-index rings is done
     bool ring_valid[8];
@@ -409,6 +411,7 @@ int minimizer_v_enqueue(edgehip_ctx *c, int slot_new, int slot_old, int fc_index
 int forward_match_enqueue(edgehip_ctx *c, int slot_old, int slot_new, bool keys_posted = false, bool frame_tail = false);
 int forward_rotate_enqueue(edgehip_ctx *c, int slot_old, int slot_new);   // FordwardMatch (keys already posted by the minimiser) + rotate_keylines(exp(W))
 int rotate_enqueue(edgehip_ctx *c, int slot, const double *R_host, bool R_in_buf = false);
+int rec_refresh_enqueue(edgehip_ctx *c, int slot);   // KlSoA::rec's copy of m_m, if rotate_keylines has turned m_m since (edgehip_ctx::rec_stale)
 int directed_enqueue(edgehip_ctx *c, int slot_new, int slot_old);
 int regekf_enqueue(edgehip_ctx *c, int slot, int do_reg, int do_ekf, bool frame_glue = false);
 int rescale_enqueue(edgehip_ctx *c, int slot, bool frame_ends = false);

@@ -1601,6 +1601,7 @@ int stage_a_enqueue(edgehip_ctx *c, int slot, bool fwd_fills, bool defer_retune)
         hipLaunchKernelGGL(k_emit, dim3((pl.cap + 255) / 256, 1, B), dim3(256), 0, st, e);
         EH_LAUNCH_CHECK();
         c->grec_ok[slot] = true;   // freshly detected KeyLines: u_m = m_m / |m_m| holds for all of them
+        c->rec_stale[slot] = false;
     }
     {
         ProfScope ps(c, PROF_A_JOIN, st);

@@ -906,6 +906,7 @@ int stage_a_fused_enqueue(edgehip_ctx *c, int slot, const uint8_t *rgb_base, con
         EH_LAUNCH_CHECK();
     }
     c->grec_ok[slot] = true;   // freshly detected KeyLines: u_m = m_m / |m_m| holds for all of them
+    c->rec_stale[slot] = false;
     return 0;
 }
 

@@ -2771,6 +2771,7 @@ int minimizer_kf_enqueue(edgehip_ctx *c, int slot_kf, int slot_cur, double match
     int e;
     c->fc_index = slot_kf;   // not read by the KF evaluation, not written by LM_FINISH_KF
 #define EH_TRY(x) if ((e = (x)) != 0) return e
+    EH_TRY(rec_refresh_enqueue(c, slot_kf));   // a key frame has been the old slot of a later frame: its gradients were turned
     EH_TRY(tvr_prepare_enqueue(c, slot_cur));
     auto eval = [&](bool last) -> int {
         TvrArgs a = make_tvr_args(c, slot_kf, slot_cur, 0.0, reweight_distance, match_num_thresh, last ? 1 : 0);
@@ -2807,6 +2808,7 @@ int minimizer_enqueue(edgehip_ctx *c, int slot_new, int slot_old, int fc_index) 
     const edgehip_params &p = c->p;
     c->fc_index = fc_index;
     int e;
+    if ((e = rec_refresh_enqueue(c, slot_new))) return e;   // (never on the frame path: the new slot's KeyLines were detected this frame)
     // A few sequences: the step that opens the minimisation rides on the preparation's launch (one dependent launch fewer).  Whole
     // batches: the step's ~230 registers cost the preparation more than the launch saves (measured at 1024 sequences: +90 us against -26).
     // Small batches: an evaluation is held back until the LM step that follows it is known, and both go out as one launch.
@@ -2923,6 +2925,7 @@ int minimizer_v_enqueue(edgehip_ctx *c, int slot_new, int slot_old, int fc_index
     if (nblk256 > c->nblk_tvr * (kTvrBlock / 256)) { set_error("minimizer_v: block tables too small"); return EDGEHIP_ERR_STATE; }
     // per-256-KeyLine tables live in the buffers sized for TryVelRot (nblk_tvr >= nblk256 because kTvrBlock == 256)
     static_assert(kTvrBlock == 256, "k_try_vel shares the per-block tables of k_try_velrot");
+    if (int e = rec_refresh_enqueue(c, slot_new)) return e;
     EH_CHECK(hipMemsetAsync(c->resid, 0, sizeof(double) * pl.nseq * pl.cap, c->stream));   // residuals[i] = 0
     TvrArgs a = make_tvr_args(c, slot_new, slot_old, match_thresh, reweight_distance, match_num_thresh, 1);
     a.fwd_key = nullptr;
@@ -3003,6 +3006,7 @@ int edgehip_try_velrot(edgehip_ctx *c, int slot_new, int slot_old, const double 
     const int B = c->plan.nseq;
     int e;
     c->fc_index = slot_new;
+    if ((e = rec_refresh_enqueue(c, slot_new))) return e;
     // P0 is rebuilt every call (the old slot may have been edited through upload_keylines)
     if (resid_in < 0) {
         if ((e = tvr_prepare_enqueue(c, slot_old))) return e;  // also zeroes buffer 0

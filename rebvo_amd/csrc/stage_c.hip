@@ -120,10 +120,8 @@ __global__ __launch_bounds__(256) void k_rotate(const KlSoA *kls, const int32_t 
     const float2 pm = k.p_m[i];
     const float2 m = k.m_m[i];                       // all loads before the first store (a load behind a store waits for it)
     const double rho = k.rho[i], s_rho = k.s_rho[i];
-    // the gather record is rewritten whole (32 B per lane, full sectors) instead of patching 8 of its bytes: its other fields
-    // mirror c_p, u_m and n_m, which nothing changes after detection
-    const float2 cp = k.c_p[i], um = k.u_m[i];
-    const float nm = k.n_m[i];
+    // (the gather record's copy of m_m is NOT kept up to date here — 20 B read and 32 B written per KeyLine for a field whose only
+    // reader on the frame path, search_match, finds the turned gradient in m_m itself; edgehip_ctx::rec_stale, k_rec_refresh)
     const double v0 = (double)pm.x / zf, v1 = (double)pm.y / zf, v2 = 1;
     double q0 = 0, q1 = 0, q2 = 0;  // TooN matrix*vector: row dot products accumulated from 0
     q0 += R[0] * v0; q0 += R[1] * v1; q0 += R[2] * v2;
@@ -140,10 +138,28 @@ __global__ __launch_bounds__(256) void k_rotate(const KlSoA *kls, const int32_t 
     r1 += R[3] * m0; r1 += R[4] * m1; r1 += R[5] * 0.0;
     const float2 mr = make_float2((float)r0, (float)r1);
     k.m_m[i] = mr;
+}
+
+// KlSoA::rec after rotate_keylines: the record's m_m from the KeyLine's (whole records: full sectors)
+__global__ __launch_bounds__(256) void k_rec_refresh(const KlSoA *kls, const int32_t *__restrict__ kns) {
+    const int seq = blockIdx.z, i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= kns[seq]) return;
+    const KlSoA &k = kls[seq];
+    const float2 cp = k.c_p[i], um = k.u_m[i], m = k.m_m[i];
+    const float nm = k.n_m[i];
     MatchRec rec;
     rec.c_px = cp.x; rec.c_py = cp.y; rec.u_mx = um.x; rec.u_my = um.y;
-    rec.m_mx = mr.x; rec.m_my = mr.y; rec.n_m = nm; rec.pad = 0.f;
+    rec.m_mx = m.x; rec.m_my = m.y; rec.n_m = nm; rec.pad = 0.f;
     k.rec[i] = rec;
+}
+int rec_refresh_enqueue(edgehip_ctx *c, int slot) {
+    if (!c->rec_stale[slot]) return 0;
+    const DevicePlan &pl = c->plan;
+    hipLaunchKernelGGL(k_rec_refresh, dim3((pl.cap + 255) / 256, 1, pl.nseq), dim3(256), 0, c->stream, kldev(c, slot),
+                       c->kn_slot + (size_t)slot * pl.nseq);
+    EH_LAUNCH_CHECK();
+    c->rec_stale[slot] = false;
+    return 0;
 }
 
 // FordwardMatch's copy (edge_tracker.cpp:396-432) and rotate_keylines (:42-76) in ONE pass over the OLD KeyLines.  The
@@ -196,9 +212,7 @@ __global__ __launch_bounds__(256) void k_fwd_apply_rotate(const KlSoA *kl_old, c
         r0 += R[0] * m0; r0 += R[1] * m1; r0 += R[2] * 0.0;
         r1 += R[3] * m0; r1 += R[4] * m1; r1 += R[5] * 0.0;
         const float2 mr = make_float2((float)r0, (float)r1);
-        o.m_m[i] = mr;
-        o.rec[i].m_mx = mr.x;
-        o.rec[i].m_my = mr.y;
+        o.m_m[i] = mr;   // (the record's copy: edgehip_ctx::rec_stale)
     }
     const int cnt = __popcll(__ballot(hit));
     if ((threadIdx.x & 63) == 0 && cnt) atomicAdd(&seqs[seq].pub.klm_fwd, cnt);
@@ -433,9 +447,12 @@ __global__ __launch_bounds__(256) void k_directed(DirArgs a) {
                     const int j = jm[c][dir];
                     if (j < 0 || found >= 0) continue;
                     const double t = tv[c][dir];
-                    const MatchRec r = ko.rec[j];
-                    const double norm_m0 = (double)r.n_m;
-                    const double cang = (double)(r.m_mx * kmm.x + r.m_my * kmm.y) / (norm_m0 * norm_m);
+                    // the old KeyLine's (turned) gradient from m_m / n_m themselves: neighbouring threads test neighbouring old KeyLines,
+                    // so the 8- and 4-byte gathers share their 64-byte lines at least as well as the 32-byte records did, and
+                    // rotate_keylines no longer has to rewrite a record per KeyLine
+                    const float2 omm = ko.m_m[j];
+                    const double norm_m0 = (double)ko.n_m[j];
+                    const double cang = (double)(omm.x * kmm.x + omm.y * kmm.y) / (norm_m0 * norm_m);
                     if (cang < a.cang_min_edge || fabs(norm_m0 / norm_m - 1) > a.min_thr_mod) continue;
                     const double s_rho = ko.s_rho[j], rho = ko.rho[j];
                     const double v_rho_dr = (a.loc_unc * a.loc_unc + s_rho * s_rho * norm_t * norm_t + sigma2_t * rho * rho);
@@ -1003,6 +1020,7 @@ int forward_match_enqueue(edgehip_ctx *c, int slot_old, int slot_new, bool keys_
 // arbitration keys were posted by the minimiser's last evaluation (TvrArgs::fwd_key; cleared in minimizer_enqueue).
 int forward_rotate_enqueue(edgehip_ctx *c, int slot_old, int slot_new) {
     c->grec_ok[slot_old] = false;   // m_m turns, u_m does not
+    c->rec_stale[slot_old] = true;
     const DevicePlan &pl = c->plan;
     const size_t B = pl.nseq;
     dim3 g((pl.cap + 255) / 256, 1, pl.nseq), b(256);
@@ -1026,6 +1044,7 @@ int forward_rotate_enqueue(edgehip_ctx *c, int slot_old, int slot_new) {
 // R_in_buf: rot_buf already holds the rotations (k_fwd_win's frame tail)
 int rotate_enqueue(edgehip_ctx *c, int slot, const double *R_host, bool R_in_buf) {
     c->grec_ok[slot] = false;   // m_m turns, u_m does not (edge_tracker.cpp:42-76): u_m can no longer be recomputed from m_m
+    c->rec_stale[slot] = true;
     ProfScope ps(c, PROF_C_ROTATE);
     const DevicePlan &pl = c->plan;
     double *Rbuf = c->rot_buf;
@@ -1241,6 +1260,7 @@ int rescale_enqueue(edgehip_ctx *c, int slot, bool frame_ends) {
 // rotate_keylines with the rotations a device kernel left in rot_buf (the IMU branch of the frame driver)
 static int rotate_buf_enqueue(edgehip_ctx *c, int slot) {
     c->grec_ok[slot] = false;
+    c->rec_stale[slot] = true;
     ProfScope ps(c, PROF_C_ROTATE);
     const DevicePlan &pl = c->plan;
     hipLaunchKernelGGL(k_rotate, dim3((pl.cap + 255) / 256, 1, pl.nseq), dim3(256), 0, c->stream, kldev(c, slot),
@@ -1321,6 +1341,7 @@ int edgehip_set_slot_camera(edgehip_ctx *c, int slot, double ppx, double ppy, do
 static int stereo_enqueue(edgehip_ctx *c, int slot, int slot_pair, const double *t, const double *R, double min_thr_mod,
                           double min_thr_ang, double max_radius, double loc_unc, double loc_unc_model, bool frame_driver) {
     const DevicePlan &pl = c->plan;
+    if (int e = rec_refresh_enqueue(c, slot_pair)) return e;   // (a pair slot somebody rotated through the stage-level API)
     StereoArgs a;
     a.kl = kldev(c, slot); a.kl_pair = kldev(c, slot_pair);
     a.kn = c->kn_slot + (size_t)slot * pl.nseq;
@@ -1655,9 +1676,9 @@ int edgehip_process_frame(edgehip_ctx *c, const double *t) {
         if (int e = order_a_after_bc(c)) return e;
         // host-side bookkeeping the replayed enqueue code would have done (stage A: fresh KeyLines; rotate_keylines
         // of the old slot)
-        c->grec_ok[sn] = true;
-        if (sp >= 0) c->grec_ok[sp] = true;
-        if (have_pair && so >= 0) c->grec_ok[so] = false;
+        c->grec_ok[sn] = true; c->rec_stale[sn] = false;
+        if (sp >= 0) { c->grec_ok[sp] = true; c->rec_stale[sp] = false; }
+        if (have_pair && so >= 0) { c->grec_ok[so] = false; c->rec_stale[so] = true; }
     } else {
         if (int e = frame_enqueue(c, sn, so, sp, have_pair, tp)) return e;
     }
