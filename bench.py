@@ -107,6 +107,11 @@ def tri(k, n):
     return k if k < n else p - k
 
 
+# Matching in one pass (the library's default for ImuMode 0 without a stereo pair, EDGEHIP_FUSE_MATCH): FordwardMatch's copy of the
+# ten fields happens inside k_directed, so its 100 bytes per KeyLine are that group's, and C.forward_match is the arbitration alone.
+ONE_PASS_MATCHING = os.environ.get("EDGEHIP_FUSE_MATCH", "1") != "0"
+
+
 def algorithmic_bytes(group, kn, n_px, radius, nseq, evals_per_launch=1.0):
     """Compulsory bytes per launch of a kernel group, for `nseq` batched sequences.
     evals_per_launch: TryVelRot evaluations one k_try_velrot launch carries on average — 12 evaluations go out as 9 launches
@@ -132,9 +137,9 @@ def algorithmic_bytes(group, kn, n_px, radius, nseq, evals_per_launch=1.0):
         "B.tvr_prepare": 0,   # per-sequence set-up of the minimisation since P0 is rebuilt in registers by k_try_velrot (latency, no stream)
         "B.lm_step": 0,
         "B.quantile": 8 * kn,
-        "C.forward_match": (4 + 8 + 8 + 4 + 100) * kn,
+        "C.forward_match": (4 + 8 + 8 + 4 + (0 if ONE_PASS_MATCHING else 100)) * kn,
         "C.rotate": 2 * (8 + 16 + 8) * kn,                   # p_m, rho, s_rho, m_m in and out (the gather record's copy of m_m is no longer rewritten)
-        "C.directed_matching": (4 * 40 + 2 * 168) * kn,
+        "C.directed_matching": (4 * 40 + 2 * 168 + (100 if ONE_PASS_MATCHING else 0)) * kn,      # SURVEY.md §8(d) (+ the forward copy)
         "C.regularize_ekf": (3 * 16 + 16 + 100) * kn,
         # SURVEY 8(d) prices EstimateReScalingOpt at five passes over 32 B per KeyLine; the kernel keeps a sequence's KeyLines in
         # registers / LDS across the passes, so what a launch has to move is ONE pass (a fraction of the roofline above 1 would
@@ -671,6 +676,8 @@ def main():
     cpu_legs_imu = cpu_legs_any and args.imu
     if args.imu:
         args.no_extras = True   # the CPU legs and the other batch shapes are those of the ImuMode=0 line
+        global ONE_PASS_MATCHING
+        ONE_PASS_MATCHING = False   # ExtRotVel reads the forward matches between FordwardMatch and directed_matching: three kernels
 
     def to_pool(frames_list):
         """HBM-resident frame pool; stage A reads each sequence's frame in place (edgehip_bind_rgb_indexed: no gather

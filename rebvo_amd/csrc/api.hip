@@ -515,6 +515,11 @@ static int create_body(edgehip_ctx *c, CtxAllocs *al, const edgehip_params &p, i
     EH_TRY(dmalloc(c, &c->fwd_key, B * CAP, al->dev, 0));
     EH_TRY(dmalloc(c, &c->fwd_win, B * CAP, al->dev, 0xFF));
     EH_TRY(dmalloc(c, &c->rs_tmp, B * 2 * CAP, al->dev, 0));
+    c->fuse_match = !(getenv("EDGEHIP_FUSE_MATCH") && atoi(getenv("EDGEHIP_FUSE_MATCH")) == 0);
+    if (c->fuse_match) {
+        EH_TRY(dmalloc(c, &c->rot_pm, S * B * CAP, al->dev, 0)); EH_TRY(dmalloc(c, &c->rot_mm, S * B * CAP, al->dev, 0));
+        EH_TRY(dmalloc(c, &c->rot_rho, S * B * CAP, al->dev, 0)); EH_TRY(dmalloc(c, &c->rot_srho, S * B * CAP, al->dev, 0));
+    }
     EH_TRY(dmalloc(c, &c->rot_buf, B * 9, al->dev, 0));
     EH_TRY(dmalloc(c, &c->nav_dev, B, al->dev, 0));
     EH_TRY(dmalloc(c, &c->idx_dev, B, al->dev, 0));
@@ -1030,6 +1035,7 @@ int edgehip_download_keylines(edgehip_ctx *c, int seq, int slot, edgehip_keyline
     if (int e = check_seq(c, seq)) return e;
     if (int e = check_slot(c, slot)) return e;
     if (!kl || !kn_out) return EDGEHIP_ERR_ARG;
+    if (int e = rot_materialize_enqueue(c, slot)) return e;   // a slot the whole-frame driver rotated out of place (ctx.h: fuse_match)
     if (int e = sync_all(c)) return e;
     int32_t kn = 0;
     EH_CHECK(hipMemcpyAsync(&kn, c->kn_slot + (size_t)slot * c->plan.nseq + seq, 4, hipMemcpyDeviceToHost, c->stream));
@@ -1079,6 +1085,7 @@ int edgehip_upload_keylines(edgehip_ctx *c, int seq, int slot, const edgehip_key
     EH_ENTER(c);
     if (int e = check_seq(c, seq)) return e;
     if (int e = check_slot(c, slot)) return e;
+    if (int e = rot_materialize_enqueue(c, slot)) return e;   // the other sequences of the slot keep their (turned) KeyLines
     if (!kl || kn < 0 || kn > c->plan.cap) { set_error("upload_keylines: kn exceeds capacity"); return EDGEHIP_ERR_ARG; }
     if (int e = sync_all(c)) return e;
     const KlSoA &k = klof(c, slot, seq);

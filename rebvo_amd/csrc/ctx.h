@@ -264,6 +264,16 @@ struct edgehip_ctx {
     int32_t *fwd_win;      // [B][CAP]
     int fwd_mode = 0;              // EDGEHIP_FWD_MODE: 0 keys by the minimiser + k_fwd_win / k_fwd_apply / k_rotate, 1 the round-2 chain (own key pass),
                                    // 2 keys by the minimiser + k_fwd_win + k_fwd_apply_rotate (one scattering pass over the old KeyLines)
+    // Matching in one pass (whole-frame driver, ImuMode 0, no stereo pair; EDGEHIP_FUSE_MATCH=0 keeps the three-kernel form): rotate_keylines
+    // writes the turned p_m / m_m / rho / s_rho of the old slot into rot_* instead of in place, and k_directed — which visits every new
+    // KeyLine anyway — takes the search prior and, where it finds no match, FordwardMatch's ten fields from the UNTURNED old KeyLine
+    // that won the forward arbitration: k_fwd_apply's pass (ten gathers and ten stores per KeyLine, nine tenths of them overwritten by
+    // directed_matching a kernel later) is gone.  rot_pending[slot]: the slot's own arrays still hold the unturned values; whoever else
+    // wants the slot (any stage-level entry point, a download) gets them turned first (rot_materialize_enqueue).
+    bool fuse_match = true;
+    float2 *rot_pm = nullptr, *rot_mm = nullptr;     // [S][B][CAP]
+    double *rot_rho = nullptr, *rot_srho = nullptr;
+    bool rot_pending[4] = {false, false, false, false};
     bool fwd_fill[4] = {false, false, false, false};   // [slot] its detector left the forwarded KeyLine fields to FordwardMatch (fill mode)
     bool fwd_cleared = false;      // fwd_key / fwd_win of the new edge map were reset by k_field_bin (whole-frame driver)
     bool fwd_keys_posted = false;   // minimizer_v_enqueue: its last evaluation posted FordwardMatch's keys
@@ -408,11 +418,12 @@ int tvr_prepare_enqueue(edgehip_ctx *c, int slot_old, unsigned begin_ops = 0);  
 int minimizer_enqueue(edgehip_ctx *c, int slot_new, int slot_old, int fc_index);
 int minimizer_v_enqueue(edgehip_ctx *c, int slot_new, int slot_old, int fc_index, int iter_max, double match_thresh,
                          uint32_t match_num_thresh, double reweight_distance);
-int forward_match_enqueue(edgehip_ctx *c, int slot_old, int slot_new, bool keys_posted = false, bool frame_tail = false);
+int forward_match_enqueue(edgehip_ctx *c, int slot_old, int slot_new, bool keys_posted = false, bool frame_tail = false, bool apply = true);
 int forward_rotate_enqueue(edgehip_ctx *c, int slot_old, int slot_new);   // FordwardMatch (keys already posted by the minimiser) + rotate_keylines(exp(W))
-int rotate_enqueue(edgehip_ctx *c, int slot, const double *R_host, bool R_in_buf = false);
+int rotate_enqueue(edgehip_ctx *c, int slot, const double *R_host, bool R_in_buf = false, bool out_of_place = false);
+int rot_materialize_enqueue(edgehip_ctx *c, int slot);   // rot_pending[slot]: the turned values into the slot's own arrays
 int rec_refresh_enqueue(edgehip_ctx *c, int slot);   // KlSoA::rec's copy of m_m, if rotate_keylines has turned m_m since (edgehip_ctx::rec_stale)
-int directed_enqueue(edgehip_ctx *c, int slot_new, int slot_old);
+int directed_enqueue(edgehip_ctx *c, int slot_new, int slot_old, bool fused = false);
 int regekf_enqueue(edgehip_ctx *c, int slot, int do_reg, int do_ekf, bool frame_glue = false);
 int rescale_enqueue(edgehip_ctx *c, int slot, bool frame_ends = false);
 int pose_enqueue(edgehip_ctx *c, int slot_new, const double *t_host);

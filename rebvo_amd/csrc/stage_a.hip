@@ -1602,6 +1602,7 @@ int stage_a_enqueue(edgehip_ctx *c, int slot, bool fwd_fills, bool defer_retune)
         EH_LAUNCH_CHECK();
         c->grec_ok[slot] = true;   // freshly detected KeyLines: u_m = m_m / |m_m| holds for all of them
         c->rec_stale[slot] = false;
+        c->rot_pending[slot] = false;
     }
     {
         ProfScope ps(c, PROF_A_JOIN, st);

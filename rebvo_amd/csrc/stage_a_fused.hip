@@ -907,6 +907,7 @@ int stage_a_fused_enqueue(edgehip_ctx *c, int slot, const uint8_t *rgb_base, con
     }
     c->grec_ok[slot] = true;   // freshly detected KeyLines: u_m = m_m / |m_m| holds for all of them
     c->rec_stale[slot] = false;
+    c->rot_pending[slot] = false;
     return 0;
 }
 

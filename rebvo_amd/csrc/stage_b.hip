@@ -2965,6 +2965,7 @@ extern "C" {
 int edgehip_quantile(edgehip_ctx *c, int slot, double a, double b, double pct, int n) {
     EH_ENTER(c);
     if (!c || slot < 0 || slot >= c->plan.nslots) return EDGEHIP_ERR_ARG;
+    if (int e = rot_materialize_enqueue(c, slot)) return e;   // s_rho of a slot the whole-frame driver rotated out of place
     return quantile_enqueue(c, slot, a, b, pct, n);
 }
 int edgehip_build_field(edgehip_ctx *c, int slot, int r, float m) {
@@ -3006,6 +3007,7 @@ int edgehip_try_velrot(edgehip_ctx *c, int slot_new, int slot_old, const double 
     const int B = c->plan.nseq;
     int e;
     c->fc_index = slot_new;
+    if ((e = rot_materialize_enqueue(c, slot_old))) return e;
     if ((e = rec_refresh_enqueue(c, slot_new))) return e;
     // P0 is rebuilt every call (the old slot may have been edited through upload_keylines)
     if (resid_in < 0) {
@@ -3073,6 +3075,7 @@ int edgehip_minimizer_v(edgehip_ctx *c, int slot_new, int slot_old, double *V, c
         set_error("minimizer_v: bad argument");
         return EDGEHIP_ERR_ARG;
     }
+    if (int e = rot_materialize_enqueue(c, slot_old)) return e;
     const int B = c->plan.nseq;
     EH_CHECK(hipMemcpyAsync(c->pinned_seq, c->seq, sizeof(SeqDev) * B, hipMemcpyDeviceToHost, c->stream));
     EH_CHECK(hipStreamSynchronize(c->stream));
@@ -3115,6 +3118,7 @@ int edgehip_minimizer_rv_kf(edgehip_ctx *c, int slot_kf, int slot_cur, const edg
         if (hipMalloc(&q, sizeof(edgehip_kf_result) * B) != hipSuccess) { (void)hipGetLastError(); set_error("kf result alloc failed"); return EDGEHIP_ERR_MEMORY; }
         c->kf_res_dev = (edgehip_kf_result *)q;
     }
+    if (int e = rot_materialize_enqueue(c, slot_cur)) return e;
     if (int e = sync_all(c)) return e;   // the request comes from pageable memory and the field is about to be rebuilt
     EH_CHECK(hipMemcpy(c->kf_req_dev, req, sizeof(edgehip_kf_request) * B, hipMemcpyHostToDevice));
     // the key frame's global_tracker: the field of ITS KeyLines, as built when the frame was current (rebvo_second_t.cpp:177;
@@ -3129,6 +3133,7 @@ int edgehip_minimizer_rv_kf(edgehip_ctx *c, int slot_kf, int slot_cur, const edg
 int edgehip_minimizer_rv(edgehip_ctx *c, int slot_new, int slot_old) {
     EH_ENTER(c);
     if (!c || slot_new < 0 || slot_old < 0 || slot_new >= c->plan.nslots || slot_old >= c->plan.nslots) return EDGEHIP_ERR_ARG;
+    if (int e = rot_materialize_enqueue(c, slot_old)) return e;
     return minimizer_enqueue(c, slot_new, slot_old, slot_new);
 }
 

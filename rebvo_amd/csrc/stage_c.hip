@@ -111,8 +111,14 @@ __global__ __launch_bounds__(256) void k_fwd_apply(const KlSoA *kl_old, const Kl
 // ---------------------------------------------------------------------------------------------------
 __device__ inline void so3_exp_c(const double w[3], double R[9]);
 
+// The turned values of a (slot, sequence) next to its own arrays (edgehip_ctx::rot_*; matching in one pass)
+struct RotOut {
+    float2 *p_m, *m_m;   // null: rotate in place
+    double *rho, *s_rho;
+};
+template <bool OUT>
 __global__ __launch_bounds__(256) void k_rotate(const KlSoA *kls, const int32_t *__restrict__ kns, const double *__restrict__ Rin,
-                                                double zf) {
+                                                double zf, RotOut out, int cap) {
     const int seq = blockIdx.z, i = blockIdx.x * 256 + threadIdx.x;
     if (i >= kns[seq]) return;
     const double *R = Rin + (size_t)seq * 9;
@@ -127,17 +133,53 @@ __global__ __launch_bounds__(256) void k_rotate(const KlSoA *kls, const int32_t 
     q0 += R[0] * v0; q0 += R[1] * v1; q0 += R[2] * v2;
     q1 += R[3] * v0; q1 += R[4] * v1; q1 += R[5] * v2;
     q2 += R[6] * v0; q2 += R[7] * v1; q2 += R[8] * v2;
-    if (fabs(q2) > 0) {
-        k.p_m[i] = make_float2((float)(q0 / q2 * zf), (float)(q1 / q2 * zf));
-        k.rho[i] = rho / q2;
-        k.s_rho[i] = s_rho / q2;
-    }
     const double m0 = (double)m.x, m1 = (double)m.y;
     double r0 = 0, r1 = 0;
     r0 += R[0] * m0; r0 += R[1] * m1; r0 += R[2] * 0.0;
     r1 += R[3] * m0; r1 += R[4] * m1; r1 += R[5] * 0.0;
     const float2 mr = make_float2((float)r0, (float)r1);
+    if (OUT) {
+        // every KeyLine's four values, turned or (q2 == 0: the reference leaves them) as they are: whole lines
+        const size_t o = (size_t)seq * cap + i;
+        const bool turn = fabs(q2) > 0;
+        out.p_m[o] = turn ? make_float2((float)(q0 / q2 * zf), (float)(q1 / q2 * zf)) : pm;
+        out.rho[o] = turn ? rho / q2 : rho;
+        out.s_rho[o] = turn ? s_rho / q2 : s_rho;
+        out.m_m[o] = mr;
+        return;
+    }
+    if (fabs(q2) > 0) {
+        k.p_m[i] = make_float2((float)(q0 / q2 * zf), (float)(q1 / q2 * zf));
+        k.rho[i] = rho / q2;
+        k.s_rho[i] = s_rho / q2;
+    }
     k.m_m[i] = mr;
+}
+
+// rot_pending: the turned values into the slot's own arrays (what rotate_keylines in place would have left)
+__global__ __launch_bounds__(256) void k_rot_materialize(const KlSoA *kls, const int32_t *__restrict__ kns, RotOut src, int cap) {
+    const int seq = blockIdx.z, i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= kns[seq]) return;
+    const KlSoA &k = kls[seq];
+    const size_t o = (size_t)seq * cap + i;
+    const float2 pm = src.p_m[o], mm = src.m_m[o];
+    const double rho = src.rho[o], s_rho = src.s_rho[o];
+    k.p_m[i] = pm; k.m_m[i] = mm; k.rho[i] = rho; k.s_rho[i] = s_rho;
+}
+static RotOut rot_of(edgehip_ctx *c, int slot) {
+    const size_t off = (size_t)slot * c->plan.nseq * c->plan.cap;
+    RotOut r;
+    r.p_m = c->rot_pm + off; r.m_m = c->rot_mm + off; r.rho = c->rot_rho + off; r.s_rho = c->rot_srho + off;
+    return r;
+}
+int rot_materialize_enqueue(edgehip_ctx *c, int slot) {
+    if (slot < 0 || slot >= c->plan.nslots || !c->rot_pending[slot]) return 0;
+    const DevicePlan &pl = c->plan;
+    hipLaunchKernelGGL(k_rot_materialize, dim3((pl.cap + 255) / 256, 1, pl.nseq), dim3(256), 0, c->stream, kldev(c, slot),
+                       c->kn_slot + (size_t)slot * pl.nseq, rot_of(c, slot), pl.cap);
+    EH_LAUNCH_CHECK();
+    c->rot_pending[slot] = false;
+    return 0;
 }
 
 // KlSoA::rec after rotate_keylines: the record's m_m from the KeyLine's (whole records: full sectors)
@@ -153,6 +195,7 @@ __global__ __launch_bounds__(256) void k_rec_refresh(const KlSoA *kls, const int
     k.rec[i] = rec;
 }
 int rec_refresh_enqueue(edgehip_ctx *c, int slot) {
+    if (int e = rot_materialize_enqueue(c, slot)) return e;
     if (!c->rec_stale[slot]) return 0;
     const DevicePlan &pl = c->plan;
     hipLaunchKernelGGL(k_rec_refresh, dim3((pl.cap + 255) / 256, 1, pl.nseq), dim3(256), 0, c->stream, kldev(c, slot),
@@ -291,14 +334,27 @@ struct DirArgs {
     double zfm, min_thr_mod, cang_min_edge, max_radius, loc_unc;
     float ppx, ppy;
     int stereo_mode;          // REBVO/StereoAvaiable: clone rho0/s_rho0 instead of rho/s_rho (edge_tracker.cpp:343-351)
+    // matching in one pass (FUSED instantiations; edgehip_ctx::fuse_match)
+    const int32_t *win;       // [B][CAP] FordwardMatch's winner (old KeyLine) of every new KeyLine, -1 none
+    RotOut rot;               // the old slot's turned p_m / m_m / rho / s_rho (its own arrays still hold the unturned ones)
+    int cap;
 };
 
-__global__ __launch_bounds__(256) void k_directed(DirArgs a) {
+// FUSED: FordwardMatch's copy (edge_tracker.cpp:380-436) and directed_matching in one visit of the new KeyLine.  The reference copies the
+// forwarded fields first, turns the old KeyLines, and then lets directed_matching overwrite the same ten fields wherever it finds a
+// match (~90 % of the KeyLines).  Here the search prior (rho, s_rho of the forward match) and, where the search fails, the other
+// eight fields are read from the old KeyLine that won the forward arbitration — its arrays are still unturned, k_rotate<OUT> put the
+// turned values the candidates are tested with into `rot` — and every new KeyLine's ten fields are written once: the match's, the
+// forward match's, or (FILL: the detector left them to this kernel) a fresh KeyLine's.  Same values, same bits.  A sequence whose
+// tracker returned NaN (skip_match) gets the forward copy alone, as the reference's FordwardMatch has already happened by then.
+template <bool FUSED, bool FILL>
+__device__ __forceinline__ void directed_body(const DirArgs &a) {
     const int seq = blockIdx.z, ik = blockIdx.x * 256 + threadIdx.x;
     SeqDev *sq = a.seq + seq;
-    if (sq->skip_match) return;
+    const bool searching = !sq->skip_match;   // block-uniform
+    if (!FUSED && !searching) return;
     __shared__ double s_v[3], s_rv[9], s_br[9];
-    if (threadIdx.x == 0) {
+    if (threadIdx.x == 0 && searching) {
         // Vel = BackRot*Vel; RVel = BackRot*RVel*BackRot.T()  (edge_tracker.cpp:323-324)
         const double *BR = sq->pub.R, *V = sq->pub.V, *P = sq->pub.P_V;
         for (int i = 0; i < 9; i++) s_br[i] = BR[i];
@@ -322,14 +378,27 @@ __global__ __launch_bounds__(256) void k_directed(DirArgs a) {
             }
     }
     __syncthreads();
-    int matched = 0, kfm = 0;
+    int matched = 0, kfm = 0, fwd = 0;
     if (ik < a.kn_new[seq]) {
         const KlSoA &kn = a.kl_new[seq], &ko = a.kl_old[seq];
         const int32_t *mask = a.mask_old + (size_t)seq * a.n;
+        const size_t ro = (size_t)seq * a.cap;   // FUSED: this sequence's turned values
         const float2 kpm = kn.p_m[ik];
         const float2 kmm = kn.m_m[ik];
         const float knm = kn.n_m[ik];
-        const double krho = kn.rho[ik], ksrho = kn.s_rho[ik];
+        int iw = -1;
+        double krho, ksrho;
+        if (FUSED) {
+            iw = a.win[ro + ik];
+            fwd = iw >= 0;
+            if (iw >= 0) { krho = ko.rho[iw]; ksrho = ko.s_rho[iw]; }                 // what FordwardMatch copies: the unturned values
+            else if (FILL) { krho = kRhoInit; ksrho = kRhoMax; }                      // a fresh KeyLine (edge_finder.cpp:178-196)
+            else { krho = kn.rho[ik]; ksrho = kn.s_rho[ik]; }                         // ... which its detector wrote itself
+        } else {
+            krho = kn.rho[ik]; ksrho = kn.s_rho[ik];
+        }
+        int found = -1;
+        if (searching) {
         const double zf = a.zfm;
         double p3[3];
         for (int i = 0; i < 3; i++) {
@@ -383,7 +452,6 @@ __global__ __launch_bounds__(256) void k_directed(DirArgs a) {
             t_steps = (int)dq_max;
         }
         const double norm_m = (double)knm;
-        int found = -1;
         // search_match walks t_i = 0,1,2,... probing first tn = dq_rho - t_i, then tp = dq_rho + 1 + t_i, and stops at
         // the first candidate that passes the tests (edge_tracker.cpp:239-292).  The probe POSITIONS do not depend
         // on earlier probes, so the mask reads of DM_CH steps (2*DM_CH gathers) are issued together and only then
@@ -450,11 +518,11 @@ __global__ __launch_bounds__(256) void k_directed(DirArgs a) {
                     // the old KeyLine's (turned) gradient from m_m / n_m themselves: neighbouring threads test neighbouring old KeyLines,
                     // so the 8- and 4-byte gathers share their 64-byte lines at least as well as the 32-byte records did, and
                     // rotate_keylines no longer has to rewrite a record per KeyLine
-                    const float2 omm = ko.m_m[j];
+                    const float2 omm = FUSED ? a.rot.m_m[ro + j] : ko.m_m[j];
                     const double norm_m0 = (double)ko.n_m[j];
                     const double cang = (double)(omm.x * kmm.x + omm.y * kmm.y) / (norm_m0 * norm_m);
                     if (cang < a.cang_min_edge || fabs(norm_m0 / norm_m - 1) > a.min_thr_mod) continue;
-                    const double s_rho = ko.s_rho[j], rho = ko.rho[j];
+                    const double s_rho = FUSED ? a.rot.s_rho[ro + j] : ko.s_rho[j], rho = FUSED ? a.rot.rho[ro + j] : ko.rho[j];
                     const double v_rho_dr = (a.loc_unc * a.loc_unc + s_rho * s_rho * norm_t * norm_t + sigma2_t * rho * rho);
                     const double dd = t - norm_t * rho;
                     if (dd * dd > v_rho_dr) continue;
@@ -463,7 +531,41 @@ __global__ __launch_bounds__(256) void k_directed(DirArgs a) {
             }
         }
         }
-        if (found >= 0) {
+        }   // searching
+        if (FUSED) {
+            // the ten fields of this KeyLine, written once: every gather first, then every store
+            const int src = found >= 0 ? found : iw;
+            if (src >= 0 || FILL) {
+                double rho = kRhoInit, s_rho = kRhoMax, rho_nr = kRhoInit, s_rho_nr = kRhoMax;
+                int32_t m_num = -1, m_id_kf = -1;
+                float2 pm, mm = make_float2(0.f, 0.f);
+                float nm = 0.f;
+                if (src < 0) {
+                    pm = kn.p_m[ik];                             // p_m_0 of a fresh KeyLine is its own p_m (re-read: not held across the walk)
+                } else {
+                    const bool turned = found >= 0;              // a directed match clones the turned old KeyLine (edge_tracker.cpp:343-366)
+                    rho = turned ? a.rot.rho[ro + src] : ko.rho[src];
+                    s_rho = turned ? a.rot.s_rho[ro + src] : ko.s_rho[src];
+                    pm = turned ? a.rot.p_m[ro + src] : ko.p_m[src];
+                    mm = turned ? a.rot.m_m[ro + src] : ko.m_m[src];
+                    rho_nr = ko.rho_nr[src]; s_rho_nr = ko.s_rho_nr[src];
+                    m_num = ko.m_num[src]; m_id_kf = ko.m_id_kf[src];
+                    nm = ko.n_m[src];
+                }
+                kn.rho[ik] = rho;
+                kn.s_rho[ik] = s_rho;
+                kn.rho_nr[ik] = rho_nr;
+                kn.s_rho_nr[ik] = s_rho_nr;
+                kn.m_num[ik] = m_num + 1;
+                kn.m_id[ik] = src;
+                kn.p_m_0[ik] = pm;
+                kn.m_m0[ik] = mm;
+                kn.n_m0[ik] = (double)nm;
+                kn.m_id_kf[ik] = m_id_kf;
+                matched = found >= 0;
+                kfm = matched && m_id_kf >= 0;
+            }
+        } else if (found >= 0) {
             const int j = found;
             // gathers first, stores after (a load behind a store waits for the store)
             const double c_rho = a.stereo_mode ? ko.rho0[j] : ko.rho[j], c_srho = a.stereo_mode ? ko.s_rho0[j] : ko.s_rho[j];
@@ -488,12 +590,20 @@ __global__ __launch_bounds__(256) void k_directed(DirArgs a) {
             kfm = mk >= 0;
         }
     }
-    const int c1 = __popcll(__ballot(matched)), c2 = __popcll(__ballot(kfm));
+    const int c1 = __popcll(__ballot(matched)), c2 = __popcll(__ballot(kfm)), c3 = FUSED ? __popcll(__ballot(fwd)) : 0;
     if ((threadIdx.x & 63) == 0) {
         if (c1) atomicAdd(&sq->pub.klm_num, c1);
         if (c2) atomicAdd(&sq->pub.kf_matchs, c2);
+        if (c3) atomicAdd(&sq->pub.klm_fwd, c3);
     }
 }
+__global__ __launch_bounds__(256) void k_directed(DirArgs a) { directed_body<false, false>(a); }
+// The one-pass form holds two registers more than fit 7 waves per SIMD (74); compiled for 7 its small per-thread arrays move to LDS
+// (2 KB per block) and the walk gains what an eighth more waves in flight hide: 1148 -> 1066 us per 1024 frames, same box
+// (profiles/r04_z_matching_in_one_pass_ab.txt).
+template <bool FILL>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(7, 8))) void k_directed_fused(DirArgs a) { directed_body<true, FILL>(a); }
+
 
 // ---------------------------------------------------------------------------------------------------
 // Regularize_1_iter -> scratch (r, s), then the EKF consumes the scratch
@@ -996,7 +1106,8 @@ __global__ __launch_bounds__(256) void k_depth_reset(const KlSoA *kls, const int
 // host side
 // ---------------------------------------------------------------------------------------------------
 // keys_posted: the minimiser's last evaluation already left the arbitration keys in fwd_key (TvrArgs::fwd_key)
-int forward_match_enqueue(edgehip_ctx *c, int slot_old, int slot_new, bool keys_posted, bool frame_tail) {
+// apply = false (matching in one pass): the arbitration only; k_directed<FUSED> copies
+int forward_match_enqueue(edgehip_ctx *c, int slot_old, int slot_new, bool keys_posted, bool frame_tail, bool apply) {
     ProfScope ps(c, PROF_C_FORWARD);
     const DevicePlan &pl = c->plan;
     const size_t B = pl.nseq;
@@ -1009,6 +1120,7 @@ int forward_match_enqueue(edgehip_ctx *c, int slot_old, int slot_new, bool keys_
     if (!keys_posted) hipLaunchKernelGGL(k_fwd_key, g, b, 0, c->stream, kldev(c, slot_old), kno, knn, c->fwd_key, pl.cap);
     hipLaunchKernelGGL(k_fwd_win, g, b, 0, c->stream, kldev(c, slot_old), kno, knn, c->fwd_key, c->fwd_win, pl.cap,
                        frame_tail ? c->seq : (SeqDev *)nullptr, frame_tail ? c->rot_buf : (double *)nullptr);
+    if (!apply) { EH_LAUNCH_CHECK(); return 0; }   // (fwd_fill[slot_new] stays set: k_directed<FUSED, FILL> is the one that fills)
     if (c->fwd_fill[slot_new]) hipLaunchKernelGGL(k_fwd_apply<true>, g, b, 0, c->stream, kldev(c, slot_old), kldev(c, slot_new), knn, c->fwd_win, c->seq, pl.cap);
     else hipLaunchKernelGGL(k_fwd_apply<false>, g, b, 0, c->stream, kldev(c, slot_old), kldev(c, slot_new), knn, c->fwd_win, c->seq, pl.cap);
     c->fwd_fill[slot_new] = false;
@@ -1042,7 +1154,8 @@ int forward_rotate_enqueue(edgehip_ctx *c, int slot_old, int slot_new) {
 }
 
 // R_in_buf: rot_buf already holds the rotations (k_fwd_win's frame tail)
-int rotate_enqueue(edgehip_ctx *c, int slot, const double *R_host, bool R_in_buf) {
+int rotate_enqueue(edgehip_ctx *c, int slot, const double *R_host, bool R_in_buf, bool out_of_place) {
+    if (int e = rot_materialize_enqueue(c, slot)) return e;   // (a second rotation of a slot whose first one is still pending)
     c->grec_ok[slot] = false;   // m_m turns, u_m does not (edge_tracker.cpp:42-76): u_m can no longer be recomputed from m_m
     c->rec_stale[slot] = true;
     ProfScope ps(c, PROF_C_ROTATE);
@@ -1055,8 +1168,14 @@ int rotate_enqueue(edgehip_ctx *c, int slot, const double *R_host, bool R_in_buf
     } else if (!R_in_buf) {
         hipLaunchKernelGGL(k_rot_from_state, dim3((pl.nseq + 63) / 64), dim3(64), 0, c->stream, c->seq, Rbuf, pl.nseq);
     }
-    hipLaunchKernelGGL(k_rotate, dim3((pl.cap + 255) / 256, 1, pl.nseq), dim3(256), 0, c->stream, kldev(c, slot),
-                       c->kn_slot + (size_t)slot * pl.nseq, Rbuf, pl.zfm);
+    if (out_of_place) {
+        hipLaunchKernelGGL(k_rotate<true>, dim3((pl.cap + 255) / 256, 1, pl.nseq), dim3(256), 0, c->stream, kldev(c, slot),
+                           c->kn_slot + (size_t)slot * pl.nseq, Rbuf, pl.zfm, rot_of(c, slot), pl.cap);
+        c->rot_pending[slot] = true;
+    } else {
+        hipLaunchKernelGGL(k_rotate<false>, dim3((pl.cap + 255) / 256, 1, pl.nseq), dim3(256), 0, c->stream, kldev(c, slot),
+                           c->kn_slot + (size_t)slot * pl.nseq, Rbuf, pl.zfm, RotOut{nullptr, nullptr, nullptr, nullptr}, pl.cap);
+    }
     EH_LAUNCH_CHECK();
     return 0;
 }
@@ -1198,9 +1317,11 @@ __global__ __launch_bounds__(256) void k_fuse_stereo(const KlSoA *kls, const int
     k.rho[i] = (r0 / (s0 * s0) + sr / (ss * ss)) * (s * s);
 }
 
-int directed_enqueue(edgehip_ctx *c, int slot_new, int slot_old) {
+// fused: matching in one pass — FordwardMatch's arbitration has run (fwd_win), rotate_keylines has written rot_of(slot_old)
+int directed_enqueue(edgehip_ctx *c, int slot_new, int slot_old, bool fused) {
     ProfScope ps(c, PROF_C_DIRECTED);
     const DevicePlan &pl = c->plan;
+    if (!fused) { if (int e = rot_materialize_enqueue(c, slot_old)) return e; }
     DirArgs a;
     a.kl_new = kldev(c, slot_new); a.kl_old = kldev(c, slot_old);
     a.kn_new = c->kn_slot + (size_t)slot_new * pl.nseq;
@@ -1212,7 +1333,16 @@ int directed_enqueue(edgehip_ctx *c, int slot_new, int slot_old) {
     a.loc_unc = c->p.loc_unc_match;
     a.ppx = pl.ppx; a.ppy = pl.ppy;
     a.stereo_mode = c->p.stereo_available != 0;
-    hipLaunchKernelGGL(k_directed, dim3((pl.cap + 255) / 256, 1, pl.nseq), dim3(256), 0, c->stream, a);
+    a.win = c->fwd_win; a.cap = pl.cap;
+    a.rot = fused ? rot_of(c, slot_old) : RotOut{nullptr, nullptr, nullptr, nullptr};
+    const dim3 g((pl.cap + 255) / 256, 1, pl.nseq), b(256);
+    if (fused) {
+        if (c->fwd_fill[slot_new]) hipLaunchKernelGGL(k_directed_fused<true>, g, b, 0, c->stream, a);
+        else hipLaunchKernelGGL(k_directed_fused<false>, g, b, 0, c->stream, a);
+        c->fwd_fill[slot_new] = false;
+    } else {
+        hipLaunchKernelGGL(k_directed, g, b, 0, c->stream, a);
+    }
     EH_LAUNCH_CHECK();
     return 0;
 }
@@ -1259,12 +1389,13 @@ int rescale_enqueue(edgehip_ctx *c, int slot, bool frame_ends) {
 
 // rotate_keylines with the rotations a device kernel left in rot_buf (the IMU branch of the frame driver)
 static int rotate_buf_enqueue(edgehip_ctx *c, int slot) {
+    if (int e = rot_materialize_enqueue(c, slot)) return e;
     c->grec_ok[slot] = false;
     c->rec_stale[slot] = true;
     ProfScope ps(c, PROF_C_ROTATE);
     const DevicePlan &pl = c->plan;
-    hipLaunchKernelGGL(k_rotate, dim3((pl.cap + 255) / 256, 1, pl.nseq), dim3(256), 0, c->stream, kldev(c, slot),
-                       c->kn_slot + (size_t)slot * pl.nseq, c->rot_buf, pl.zfm);
+    hipLaunchKernelGGL(k_rotate<false>, dim3((pl.cap + 255) / 256, 1, pl.nseq), dim3(256), 0, c->stream, kldev(c, slot),
+                       c->kn_slot + (size_t)slot * pl.nseq, c->rot_buf, pl.zfm, RotOut{nullptr, nullptr, nullptr, nullptr}, pl.cap);
     EH_LAUNCH_CHECK();
     return 0;
 }
@@ -1298,7 +1429,9 @@ extern "C" {
 
 static int chk2(edgehip_ctx *c, int a, int b) {
     if (!c || a < 0 || b < 0 || a >= c->plan.nslots || b >= c->plan.nslots) { set_error("slot out of range"); return EDGEHIP_ERR_ARG; }
-    return 0;
+    // a slot the whole-frame driver rotated out of place: the stage-level calls work on the slot's own arrays
+    if (int e = rot_materialize_enqueue(c, a)) return e;
+    return rot_materialize_enqueue(c, b);
 }
 
 int edgehip_forward_match(edgehip_ctx *c, int slot_old, int slot_new) {
@@ -1517,6 +1650,7 @@ int edgehip_depth_reset(edgehip_ctx *c, int seq) {
 int edgehip_depth_reset_slot(edgehip_ctx *c, int seq, int slot) {
     EH_ENTER(c);
     if (!c || seq >= c->plan.nseq || slot < 0 || slot >= c->plan.nslots) return EDGEHIP_ERR_ARG;
+    if (int e = rot_materialize_enqueue(c, slot)) return e;
     const DevicePlan &pl = c->plan;
     hipLaunchKernelGGL(k_depth_reset, dim3((pl.cap + 255) / 256, 1, pl.nseq), dim3(256), 0, c->stream, kldev(c, slot),
                        c->kn_slot + (size_t)slot * pl.nseq, c->seq, seq, c->imu_enabled ? 0 : 1);
@@ -1590,14 +1724,16 @@ static int frame_enqueue(edgehip_ctx *c, int sn, int so, int sp, int have_pair, 
         e = minimizer_enqueue(c, sn, so, c->frames_seen % kRefRing);                              // :346
         c->fwd_key_in_tvr = false;
         if (e) return e;
+        // matching in one pass (ctx.h: fuse_match): the forward copy waits for k_directed, which needs the unturned old KeyLines for it
+        const bool one_pass = c->fuse_match && c->fwd_mode == 0 && sp < 0 && !c->p.stereo_available;
         if (c->fwd_mode == 2) {
             EH_TRY(forward_rotate_enqueue(c, so, sn));                                           // :354-369
         } else {
-            EH_TRY(forward_match_enqueue(c, so, sn, c->fwd_mode != 1, true));                    // :354 (+ exp(W) and :387-397 in k_fwd_win's tail)
-            EH_TRY(rotate_enqueue(c, so, nullptr, true));                                        // :360-369
+            EH_TRY(forward_match_enqueue(c, so, sn, c->fwd_mode != 1, true, !one_pass));         // :354 (+ exp(W) and :387-397 in k_fwd_win's tail)
+            EH_TRY(rotate_enqueue(c, so, nullptr, true, one_pass));                              // :360-369
         }
         if (c->fwd_mode == 2) { ProfScope ps(c, PROF_C_POSE); EH_TRY(glue(c, 1, sn, have_pair)); }   // :387-397
-        EH_TRY(directed_enqueue(c, sn, so));                                                     // :410
+        EH_TRY(directed_enqueue(c, sn, so, one_pass));                                           // :410
         EH_TRY(regekf_enqueue(c, sn, 1, 1, true));                                               // :412-422 (in k_regularize), :453, :460
         if (sp >= 0) {                                                                           // :465-486
             EH_TRY(stereo_enqueue(c, sn, sp, c->rig.t, c->rig.R, c->p.match_thresh_module, c->p.match_thresh_angle, c->rig.max_radius,
@@ -1676,9 +1812,12 @@ int edgehip_process_frame(edgehip_ctx *c, const double *t) {
         if (int e = order_a_after_bc(c)) return e;
         // host-side bookkeeping the replayed enqueue code would have done (stage A: fresh KeyLines; rotate_keylines
         // of the old slot)
-        c->grec_ok[sn] = true; c->rec_stale[sn] = false;
-        if (sp >= 0) { c->grec_ok[sp] = true; c->rec_stale[sp] = false; }
-        if (have_pair && so >= 0) { c->grec_ok[so] = false; c->rec_stale[so] = true; }
+        c->grec_ok[sn] = true; c->rec_stale[sn] = false; c->rot_pending[sn] = false;
+        if (sp >= 0) { c->grec_ok[sp] = true; c->rec_stale[sp] = false; c->rot_pending[sp] = false; }
+        if (have_pair && so >= 0) {
+            c->grec_ok[so] = false; c->rec_stale[so] = true;
+            c->rot_pending[so] = !c->imu_enabled && c->fuse_match && c->fwd_mode == 0 && sp < 0 && !c->p.stereo_available;
+        }
     } else {
         if (int e = frame_enqueue(c, sn, so, sp, have_pair, tp)) return e;
     }

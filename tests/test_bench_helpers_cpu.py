@@ -36,7 +36,13 @@ def test_algorithmic_bytes_follow_the_survey_formulas():
     kn, n, r, B = 12000, 752 * 480, 40, 1024
     assert bench.algorithmic_bytes("B.try_velrot", kn, n, r, B) == 84 * kn * B
     assert bench.algorithmic_bytes("B.build_field", kn, n, r, B) == (4 * n + 4 * 2 * r * kn) * B
-    assert bench.algorithmic_bytes("C.directed_matching", kn, n, r, 1) == (4 * 40 + 2 * 168) * kn
+    # FordwardMatch's copy of the ten fields (100 B) is priced where it happens: inside k_directed when matching runs in one pass
+    both = (4 * 40 + 2 * 168) * kn + (4 + 8 + 8 + 4 + 100) * kn
+    for one_pass in (True, False):
+        bench.ONE_PASS_MATCHING = one_pass
+        d, f = bench.algorithmic_bytes("C.directed_matching", kn, n, r, 1), bench.algorithmic_bytes("C.forward_match", kn, n, r, 1)
+        assert d + f == both and d == (4 * 40 + 2 * 168 + (100 if one_pass else 0)) * kn
+    bench.ONE_PASS_MATCHING = os.environ.get("EDGEHIP_FUSE_MATCH", "1") != "0"
     assert bench.algorithmic_bytes("no.such.group", kn, n, r, B) == 0
 
 

@@ -285,6 +285,48 @@ def test_two_chain_evaluation_is_bit_identical_to_the_launch_chain(monkeypatch, 
     assert np.all(la["estimation_ok"][2:] == 1) and np.all(la["minimizer_evals"][1:] == evals)
 
 
+@pytest.mark.parametrize("w,h,nseq,nslots", [(376, 240, 3, 3), (376, 240, 1, 2), (752, 480, 200, 3)])
+def test_matching_in_one_pass_is_bit_identical_to_the_three_kernels(monkeypatch, w, h, nseq, nslots):
+    """ImuMode 0 without a stereo pair: FordwardMatch's copy, rotate_keylines and directed_matching as k_fwd_win + k_rotate<out of
+    place> + k_directed<FUSED> (the default: every new KeyLine's ten matching fields written once, by the kernel that visits it
+    anyway) against k_fwd_win + k_fwd_apply + k_rotate + k_directed (EDGEHIP_FUSE_MATCH=0).  The same values travel by another
+    route, so every nav record, the new edge map and — after the turned values have been brought into the old slot's own arrays on
+    demand — the old edge map must agree bit for bit.  200 sequences: the one-kernel stage A (fill mode) in front; one sequence with
+    two slots: the old slot is the one the next frame's detector overwrites; a frame of noise in the middle: a sequence whose tracker
+    gives up (no directed matching, the forward copy alone) and restarts."""
+    n = 7
+    frames = [f for f, _, _ in synth.billboard_sequence(w, h, n + min(nseq, 8))]
+    rs = np.random.RandomState(5)
+    noise = rs.randint(0, 255, size=frames[0].shape).astype(np.uint8)
+    outs = []
+    for mode in ("0", "1"):
+        monkeypatch.setenv("EDGEHIP_FUSE_MATCH", mode)
+        eh = edgehip.EdgeHip(edgehip.euroc_params(w, h), nseq=nseq, nslots=nslots)
+        eh.set_nav_log(n)
+        olds = []
+        for k in range(n):
+            batch = [frames[k + s % 8] for s in range(nseq)]
+            if k == 4:
+                batch[0] = noise          # sequence 0 loses track on this frame
+            prev = eh.cur_slot()
+            eh.upload_rgb(eh.next_slot(), np.stack(batch))
+            eh.process_frame(0.05 * k)
+            if k in (2, 5):               # the old edge map right after a frame: turned p_m / m_m / rho / s_rho
+                olds.append([eh.download_keylines(s, prev)[0] for s in range(min(nseq, 2))])
+        log = eh.read_nav_log_array(0, n)
+        kl = [eh.download_keylines(s, eh.cur_slot())[0] for s in range(min(nseq, 3))]
+        outs.append((log, kl, olds))
+        eh.close()
+    (la, ka, oa), (lb, kb, ob) = outs
+    assert la.tobytes() == lb.tobytes()
+    for x, y in zip(ka, kb):
+        assert x.tobytes() == y.tobytes()
+    for fa, fb in zip(oa, ob):
+        for x, y in zip(fa, fb):
+            assert len(x) > 1000 and x.tobytes() == y.tobytes()
+    assert np.all(la["klm_num"][2:4] > 1000)
+
+
 @pytest.mark.parametrize("w,h,n", [(376, 240, 10), (752, 480, 5)])
 def test_reweighted_evaluation_with_two_keylines_per_thread(monkeypatch, w, h, n):
     """The reweighted TryVelRot evaluations with two KeyLines per thread (k_try_velrot_rw2: both KeyLines' gathers in flight
