@@ -108,7 +108,8 @@ def tri(k, n):
 
 
 # Matching in one pass (the library's default for ImuMode 0 without a stereo pair, EDGEHIP_FUSE_MATCH): FordwardMatch's copy of the
-# ten fields happens inside k_directed, so its 100 bytes per KeyLine are that group's, and C.forward_match is the arbitration alone.
+# ten fields happens inside k_directed, so its 100 bytes per KeyLine are that group's, and its arbitration (24 bytes) rides on the
+# rotate_keylines pass: no C.forward_match group is launched.
 ONE_PASS_MATCHING = os.environ.get("EDGEHIP_FUSE_MATCH", "1") != "0"
 
 
@@ -138,7 +139,8 @@ def algorithmic_bytes(group, kn, n_px, radius, nseq, evals_per_launch=1.0):
         "B.lm_step": 0,
         "B.quantile": 8 * kn,
         "C.forward_match": (4 + 8 + 8 + 4 + (0 if ONE_PASS_MATCHING else 100)) * kn,
-        "C.rotate": 2 * (8 + 16 + 8) * kn,                   # p_m, rho, s_rho, m_m in and out (the gather record's copy of m_m is no longer rewritten)
+        # p_m, rho, s_rho, m_m in and out (the gather record's copy of m_m is no longer rewritten); one pass: + m_id_f, key, win
+        "C.rotate": (2 * (8 + 16 + 8) + (4 + 8 + 8 + 4 if ONE_PASS_MATCHING else 0)) * kn,
         "C.directed_matching": (4 * 40 + 2 * 168 + (100 if ONE_PASS_MATCHING else 0)) * kn,      # SURVEY.md §8(d) (+ the forward copy)
         "C.regularize_ekf": (3 * 16 + 16 + 100) * kn,
         # SURVEY 8(d) prices EstimateReScalingOpt at five passes over 32 B per KeyLine; the kernel keeps a sequence's KeyLines in

@@ -116,12 +116,49 @@ struct RotOut {
     float2 *p_m, *m_m;   // null: rotate in place
     double *rho, *s_rho;
 };
-template <bool OUT>
+// WIN (matching in one pass): this pass over the old KeyLines is also FordwardMatch's arbitration (k_fwd_win) and the per-sequence
+// scalar work behind the minimiser that used to ride on that kernel — R0 = exp(W) and the NaN check of rebvo_second_t.cpp:387-397.
+// Every block forms R0 for itself from the sequence's W (nothing in this kernel writes W); the sequence's first block also stores it
+// (state.R, Rbuf) and runs the check.
+struct WinArgs {
+    const int32_t *kn_new;
+    const unsigned long long *key;   // [B][CAP] arbitration keys the minimiser's last evaluation posted
+    int32_t *win;                    // [B][CAP]
+    SeqDev *seqs;
+    double *Rbuf;
+};
+template <bool OUT, bool WIN>
 __global__ __launch_bounds__(256) void k_rotate(const KlSoA *kls, const int32_t *__restrict__ kns, const double *__restrict__ Rin,
-                                                double zf, RotOut out, int cap) {
+                                                double zf, RotOut out, int cap, WinArgs wa) {
     const int seq = blockIdx.z, i = blockIdx.x * 256 + threadIdx.x;
+    __shared__ double s_R[9];
+    if (WIN) {
+        if (blockIdx.x * 256 >= kns[seq] && blockIdx.x != 0) return;   // block-uniform
+        if (threadIdx.x == 0) {
+            SeqDev *sq = wa.seqs + seq;
+            double R0[9];
+            so3_exp_c(sq->pub.W, R0);
+            for (int q = 0; q < 9; q++) s_R[q] = R0[q];
+            if (blockIdx.x == 0) {   // rot_from_state + glue_after_tracking
+                for (int q = 0; q < 9; q++) wa.Rbuf[(size_t)seq * 9 + q] = R0[q];
+                for (int a = 0; a < 3; a++)
+                    for (int b = 0; b < 3; b++) sq->pub.R[a * 3 + b] = R0[b * 3 + a];
+                glue_after_tracking(sq);
+            }
+        }
+        __syncthreads();
+    }
     if (i >= kns[seq]) return;
-    const double *R = Rin + (size_t)seq * 9;
+    double Rw[9];
+    if (WIN) {   // block-uniform values: back into scalar registers
+#pragma unroll
+        for (int q = 0; q < 9; q++) {
+            const double v = s_R[q];
+            const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)__double2loint(v)), hi = __builtin_amdgcn_readfirstlane((unsigned)__double2hiint(v));
+            Rw[q] = __hiloint2double((int)hi, (int)lo);
+        }
+    }
+    const double *R = WIN ? Rw : Rin + (size_t)seq * 9;
     const KlSoA &k = kls[seq];
     const float2 pm = k.p_m[i];
     const float2 m = k.m_m[i];                       // all loads before the first store (a load behind a store waits for it)
@@ -138,6 +175,10 @@ __global__ __launch_bounds__(256) void k_rotate(const KlSoA *kls, const int32_t 
     r0 += R[0] * m0; r0 += R[1] * m1; r0 += R[2] * 0.0;
     r1 += R[3] * m0; r1 += R[4] * m1; r1 += R[5] * 0.0;
     const float2 mr = make_float2((float)r0, (float)r1);
+    if (WIN) {   // k_fwd_win's rule: among the old KeyLines that point at new KeyLine f the largest rho wins, ties the largest index
+        const int f = k.m_id_f[i];
+        if (f >= 0 && f < wa.kn_new[seq] && wa.key[(size_t)seq * cap + f] == ord_bits(rho)) atomicMax(&wa.win[(size_t)seq * cap + f], i);
+    }
     if (OUT) {
         // every KeyLine's four values, turned or (q2 == 0: the reference leaves them) as they are: whole lines
         const size_t o = (size_t)seq * cap + i;
@@ -1153,6 +1194,27 @@ int forward_rotate_enqueue(edgehip_ctx *c, int slot_old, int slot_new) {
     return 0;
 }
 
+// Matching in one pass, the old KeyLines' side: FordwardMatch's arbitration (keys posted by the minimiser's last evaluation), R0 = exp(W),
+// the NaN check, and rotate_keylines(R0) out of place — one launch (k_rotate<OUT, WIN>)
+static int forward_rotate_one_pass_enqueue(edgehip_ctx *c, int slot_old, int slot_new) {
+    if (int e = rot_materialize_enqueue(c, slot_old)) return e;
+    const DevicePlan &pl = c->plan;
+    const size_t B = pl.nseq;
+    const bool cleared = c->fwd_cleared;   // k_field_bin reset the arbitration entries of the new edge map
+    c->fwd_cleared = false;
+    if (!cleared) EH_CHECK(hipMemsetAsync(c->fwd_win, 0xFF, sizeof(int32_t) * B * pl.cap, c->stream));
+    c->grec_ok[slot_old] = false;
+    c->rec_stale[slot_old] = true;
+    ProfScope ps(c, PROF_C_ROTATE);
+    WinArgs wa;
+    wa.kn_new = c->kn_slot + slot_new * B; wa.key = c->fwd_key; wa.win = c->fwd_win; wa.seqs = c->seq; wa.Rbuf = c->rot_buf;
+    hipLaunchKernelGGL((k_rotate<true, true>), dim3((pl.cap + 255) / 256, 1, pl.nseq), dim3(256), 0, c->stream, kldev(c, slot_old),
+                       c->kn_slot + slot_old * B, (const double *)nullptr, pl.zfm, rot_of(c, slot_old), pl.cap, wa);
+    EH_LAUNCH_CHECK();
+    c->rot_pending[slot_old] = true;
+    return 0;
+}
+
 // R_in_buf: rot_buf already holds the rotations (k_fwd_win's frame tail)
 int rotate_enqueue(edgehip_ctx *c, int slot, const double *R_host, bool R_in_buf, bool out_of_place) {
     if (int e = rot_materialize_enqueue(c, slot)) return e;   // (a second rotation of a slot whose first one is still pending)
@@ -1169,12 +1231,12 @@ int rotate_enqueue(edgehip_ctx *c, int slot, const double *R_host, bool R_in_buf
         hipLaunchKernelGGL(k_rot_from_state, dim3((pl.nseq + 63) / 64), dim3(64), 0, c->stream, c->seq, Rbuf, pl.nseq);
     }
     if (out_of_place) {
-        hipLaunchKernelGGL(k_rotate<true>, dim3((pl.cap + 255) / 256, 1, pl.nseq), dim3(256), 0, c->stream, kldev(c, slot),
-                           c->kn_slot + (size_t)slot * pl.nseq, Rbuf, pl.zfm, rot_of(c, slot), pl.cap);
+        hipLaunchKernelGGL((k_rotate<true, false>), dim3((pl.cap + 255) / 256, 1, pl.nseq), dim3(256), 0, c->stream, kldev(c, slot),
+                           c->kn_slot + (size_t)slot * pl.nseq, Rbuf, pl.zfm, rot_of(c, slot), pl.cap, WinArgs{});
         c->rot_pending[slot] = true;
     } else {
-        hipLaunchKernelGGL(k_rotate<false>, dim3((pl.cap + 255) / 256, 1, pl.nseq), dim3(256), 0, c->stream, kldev(c, slot),
-                           c->kn_slot + (size_t)slot * pl.nseq, Rbuf, pl.zfm, RotOut{nullptr, nullptr, nullptr, nullptr}, pl.cap);
+        hipLaunchKernelGGL((k_rotate<false, false>), dim3((pl.cap + 255) / 256, 1, pl.nseq), dim3(256), 0, c->stream, kldev(c, slot),
+                           c->kn_slot + (size_t)slot * pl.nseq, Rbuf, pl.zfm, RotOut{nullptr, nullptr, nullptr, nullptr}, pl.cap, WinArgs{});
     }
     EH_LAUNCH_CHECK();
     return 0;
@@ -1394,8 +1456,8 @@ static int rotate_buf_enqueue(edgehip_ctx *c, int slot) {
     c->rec_stale[slot] = true;
     ProfScope ps(c, PROF_C_ROTATE);
     const DevicePlan &pl = c->plan;
-    hipLaunchKernelGGL(k_rotate<false>, dim3((pl.cap + 255) / 256, 1, pl.nseq), dim3(256), 0, c->stream, kldev(c, slot),
-                       c->kn_slot + (size_t)slot * pl.nseq, c->rot_buf, pl.zfm, RotOut{nullptr, nullptr, nullptr, nullptr}, pl.cap);
+    hipLaunchKernelGGL((k_rotate<false, false>), dim3((pl.cap + 255) / 256, 1, pl.nseq), dim3(256), 0, c->stream, kldev(c, slot),
+                       c->kn_slot + (size_t)slot * pl.nseq, c->rot_buf, pl.zfm, RotOut{nullptr, nullptr, nullptr, nullptr}, pl.cap, WinArgs{});
     EH_LAUNCH_CHECK();
     return 0;
 }
@@ -1728,9 +1790,11 @@ static int frame_enqueue(edgehip_ctx *c, int sn, int so, int sp, int have_pair, 
         const bool one_pass = c->fuse_match && c->fwd_mode == 0 && sp < 0 && !c->p.stereo_available;
         if (c->fwd_mode == 2) {
             EH_TRY(forward_rotate_enqueue(c, so, sn));                                           // :354-369
+        } else if (one_pass) {
+            EH_TRY(forward_rotate_one_pass_enqueue(c, so, sn));                                  // :354 (arbitration), :360-369, :387-397
         } else {
-            EH_TRY(forward_match_enqueue(c, so, sn, c->fwd_mode != 1, true, !one_pass));         // :354 (+ exp(W) and :387-397 in k_fwd_win's tail)
-            EH_TRY(rotate_enqueue(c, so, nullptr, true, one_pass));                              // :360-369
+            EH_TRY(forward_match_enqueue(c, so, sn, c->fwd_mode != 1, true));                    // :354 (+ exp(W) and :387-397 in k_fwd_win's tail)
+            EH_TRY(rotate_enqueue(c, so, nullptr, true));                                        // :360-369
         }
         if (c->fwd_mode == 2) { ProfScope ps(c, PROF_C_POSE); EH_TRY(glue(c, 1, sn, have_pair)); }   // :387-397
         EH_TRY(directed_enqueue(c, sn, so, one_pass));                                           // :410
