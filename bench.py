@@ -160,7 +160,7 @@ GROUP_KERNELS = {
     "B.quantile": ["k_quantile"], "B.build_field": ["k_field_bin", "k_field_raster"], "B.tvr_prepare": ["k_tvr_prepare"],
     "B.try_velrot": ["k_try_velrot"], "B.lm_step": ["k_lm_step"], "B.minimizer": ["k_minimizer"],
     "C.forward_match": ["k_fwd_key", "k_fwd_win", "k_fwd_apply"], "C.rotate": ["k_rot_from_state", "k_rotate", "k_fwd_apply_rotate"],
-    "C.directed_matching": ["k_directed"], "C.regularize_ekf": ["k_regularize", "k_ekf"], "C.rescale": ["k_rescale"],
+    "C.directed_matching": ["k_directed", "k_directed_fused"], "C.regularize_ekf": ["k_regularize", "k_ekf"], "C.rescale": ["k_rescale"],
 }
 
 PMC_FILE = os.path.join("profiles", "pmc_latest.json")
