@@ -669,7 +669,7 @@ int edgehip_reset(edgehip_ctx *c) {
     const size_t B = c->plan.nseq, S = c->plan.nslots;
     if (int e = sync_all(c)) return e;
     for (size_t i = 0; i < B; i++) { init_state(c->p, &c->pinned_seq[i]); init_state_a(c->p, &c->pinned_seqa[i]); }
-    for (int i = 0; i < 4; i++) c->use_valid[i] = false;
+    for (int i = 0; i < 4; i++) { c->use_valid[i] = false; c->rot_pending[i] = false; c->rec_stale[i] = false; }   // (every slot is empty from here on)
     EH_CHECK(hipMemcpyAsync(c->seq, c->pinned_seq, sizeof(SeqDev) * B, hipMemcpyHostToDevice, c->stream));
     EH_CHECK(hipMemcpyAsync(c->seqa, c->pinned_seqa, sizeof(SeqA) * B, hipMemcpyHostToDevice, c->stream));
     EH_CHECK(hipMemsetAsync(c->framecount, 0, sizeof(uint32_t) * c->fc_rows * B, c->stream));

@@ -418,9 +418,9 @@ int tvr_prepare_enqueue(edgehip_ctx *c, int slot_old, unsigned begin_ops = 0);  
 int minimizer_enqueue(edgehip_ctx *c, int slot_new, int slot_old, int fc_index);
 int minimizer_v_enqueue(edgehip_ctx *c, int slot_new, int slot_old, int fc_index, int iter_max, double match_thresh,
                          uint32_t match_num_thresh, double reweight_distance);
-int forward_match_enqueue(edgehip_ctx *c, int slot_old, int slot_new, bool keys_posted = false, bool frame_tail = false, bool apply = true);
+int forward_match_enqueue(edgehip_ctx *c, int slot_old, int slot_new, bool keys_posted = false, bool frame_tail = false);
 int forward_rotate_enqueue(edgehip_ctx *c, int slot_old, int slot_new);   // FordwardMatch (keys already posted by the minimiser) + rotate_keylines(exp(W))
-int rotate_enqueue(edgehip_ctx *c, int slot, const double *R_host, bool R_in_buf = false, bool out_of_place = false);
+int rotate_enqueue(edgehip_ctx *c, int slot, const double *R_host, bool R_in_buf = false);
 int rot_materialize_enqueue(edgehip_ctx *c, int slot);   // rot_pending[slot]: the turned values into the slot's own arrays
 int rec_refresh_enqueue(edgehip_ctx *c, int slot);   // KlSoA::rec's copy of m_m, if rotate_keylines has turned m_m since (edgehip_ctx::rec_stale)
 int directed_enqueue(edgehip_ctx *c, int slot_new, int slot_old, bool fused = false);

@@ -1147,8 +1147,7 @@ __global__ __launch_bounds__(256) void k_depth_reset(const KlSoA *kls, const int
 // host side
 // ---------------------------------------------------------------------------------------------------
 // keys_posted: the minimiser's last evaluation already left the arbitration keys in fwd_key (TvrArgs::fwd_key)
-// apply = false (matching in one pass): the arbitration only; k_directed<FUSED> copies
-int forward_match_enqueue(edgehip_ctx *c, int slot_old, int slot_new, bool keys_posted, bool frame_tail, bool apply) {
+int forward_match_enqueue(edgehip_ctx *c, int slot_old, int slot_new, bool keys_posted, bool frame_tail) {
     ProfScope ps(c, PROF_C_FORWARD);
     const DevicePlan &pl = c->plan;
     const size_t B = pl.nseq;
@@ -1161,7 +1160,6 @@ int forward_match_enqueue(edgehip_ctx *c, int slot_old, int slot_new, bool keys_
     if (!keys_posted) hipLaunchKernelGGL(k_fwd_key, g, b, 0, c->stream, kldev(c, slot_old), kno, knn, c->fwd_key, pl.cap);
     hipLaunchKernelGGL(k_fwd_win, g, b, 0, c->stream, kldev(c, slot_old), kno, knn, c->fwd_key, c->fwd_win, pl.cap,
                        frame_tail ? c->seq : (SeqDev *)nullptr, frame_tail ? c->rot_buf : (double *)nullptr);
-    if (!apply) { EH_LAUNCH_CHECK(); return 0; }   // (fwd_fill[slot_new] stays set: k_directed<FUSED, FILL> is the one that fills)
     if (c->fwd_fill[slot_new]) hipLaunchKernelGGL(k_fwd_apply<true>, g, b, 0, c->stream, kldev(c, slot_old), kldev(c, slot_new), knn, c->fwd_win, c->seq, pl.cap);
     else hipLaunchKernelGGL(k_fwd_apply<false>, g, b, 0, c->stream, kldev(c, slot_old), kldev(c, slot_new), knn, c->fwd_win, c->seq, pl.cap);
     c->fwd_fill[slot_new] = false;
@@ -1216,7 +1214,7 @@ static int forward_rotate_one_pass_enqueue(edgehip_ctx *c, int slot_old, int slo
 }
 
 // R_in_buf: rot_buf already holds the rotations (k_fwd_win's frame tail)
-int rotate_enqueue(edgehip_ctx *c, int slot, const double *R_host, bool R_in_buf, bool out_of_place) {
+int rotate_enqueue(edgehip_ctx *c, int slot, const double *R_host, bool R_in_buf) {
     if (int e = rot_materialize_enqueue(c, slot)) return e;   // (a second rotation of a slot whose first one is still pending)
     c->grec_ok[slot] = false;   // m_m turns, u_m does not (edge_tracker.cpp:42-76): u_m can no longer be recomputed from m_m
     c->rec_stale[slot] = true;
@@ -1230,14 +1228,8 @@ int rotate_enqueue(edgehip_ctx *c, int slot, const double *R_host, bool R_in_buf
     } else if (!R_in_buf) {
         hipLaunchKernelGGL(k_rot_from_state, dim3((pl.nseq + 63) / 64), dim3(64), 0, c->stream, c->seq, Rbuf, pl.nseq);
     }
-    if (out_of_place) {
-        hipLaunchKernelGGL((k_rotate<true, false>), dim3((pl.cap + 255) / 256, 1, pl.nseq), dim3(256), 0, c->stream, kldev(c, slot),
-                           c->kn_slot + (size_t)slot * pl.nseq, Rbuf, pl.zfm, rot_of(c, slot), pl.cap, WinArgs{});
-        c->rot_pending[slot] = true;
-    } else {
-        hipLaunchKernelGGL((k_rotate<false, false>), dim3((pl.cap + 255) / 256, 1, pl.nseq), dim3(256), 0, c->stream, kldev(c, slot),
-                           c->kn_slot + (size_t)slot * pl.nseq, Rbuf, pl.zfm, RotOut{nullptr, nullptr, nullptr, nullptr}, pl.cap, WinArgs{});
-    }
+    hipLaunchKernelGGL((k_rotate<false, false>), dim3((pl.cap + 255) / 256, 1, pl.nseq), dim3(256), 0, c->stream, kldev(c, slot),
+                       c->kn_slot + (size_t)slot * pl.nseq, Rbuf, pl.zfm, RotOut{nullptr, nullptr, nullptr, nullptr}, pl.cap, WinArgs{});
     EH_LAUNCH_CHECK();
     return 0;
 }
