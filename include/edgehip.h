@@ -374,7 +374,10 @@ int edgehip_get_framecount(edgehip_ctx *ctx, int seq, int slot, uint32_t *fc);  
 int edgehip_set_framecount(edgehip_ctx *ctx, int seq, int slot, uint32_t fc);
 /* AoS KeyLine list + img_mask_kl of one sequence/slot, as the output callback sees them
  * (PipeBuffer::ef, include/rebvo/rebvo.h:312-351).  kl has room for max_points entries; mask (h*w int32)
- * may be NULL.  Synchronises.  Returns kn through *kn_out. */
+ * may be NULL.  Synchronises.  Returns kn through *kn_out.
+ * The OLD slot of a frame edgehip_process_frame() has run holds what old_buf.ef holds after rotate_keylines (rebvo_second_t.cpp:369):
+ * the frame driver keeps the turned p_m / m_m / rho / s_rho next to the slot's arrays for its own matching kernel and brings them in
+ * when anybody else — this call, any stage-level entry point — asks for the slot. */
 int edgehip_download_keylines(edgehip_ctx *ctx, int seq, int slot, edgehip_keyline *kl, int32_t *mask,
                               int32_t *kn_out);
 /* Inject a KeyLine list (+ mask) into a slot: stage-isolated parity tests. */
