@@ -17,6 +17,11 @@
 //    the order-preserving bit pattern of rho, then on the KeyLine index among those that hold the maximum.
 //  * directed_matching / Regularize / EKF are independent per KeyLine (Regularize reads the PRE-update
 //    neighbour values: its results go through a scratch array before the EKF consumes them).
+//  * Whole frames (ImuMode 0, no stereo pair) match in one pass: the arbitration rides on rotate_keylines' pass over the old
+//    KeyLines, which writes the turned values next to the slot's own arrays (k_rotate<OUT, WIN>), and FordwardMatch's copy
+//    happens inside the directed-matching kernel (k_directed_fused), which writes every new KeyLine's ten matching fields
+//    once — the directed match's, else the forward match's, else a fresh KeyLine's.  The three-kernel form below
+//    (k_fwd_win, k_fwd_apply, k_rotate in place, k_directed) serves the stage-level entry points, the IMU branch and stereo.
 
 #include <math.h>
 #include <string.h>
