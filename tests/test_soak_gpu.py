@@ -59,16 +59,17 @@ def test_tum_parameters_with_undistortion():
     _replay(frames, edgehip.tum_params(640, 480, use_undistort=1), oracle.tum_params(640, 480, use_undistort=1), 30, [0, 4], 0.02)
 
 
-@pytest.mark.parametrize("mode", ["default", "EDGEHIP_OVERLAP", "EDGEHIP_GRAPH", "EDGEHIP_FWD_MODE=1", "EDGEHIP_FWD_MODE=2"])
+@pytest.mark.parametrize("mode", ["default", "EDGEHIP_OVERLAP", "EDGEHIP_GRAPH", "EDGEHIP_FWD_MODE=1", "EDGEHIP_FWD_MODE=2", "EDGEHIP_FUSE_MATCH=0"])
 def test_small_frames_sixty_deep(mode, monkeypatch):
     """Also under the two optional execution modes read at edgehip_create() time: stage A of frame k+1 overlapped with
     B/C of frame k on a second stream, and the per-frame HIP graphs (whose stage A runs on the main stream: uploads for
-    later frames must not overtake the graphs that still read a slot); and with the two alternative arrangements of
-    FordwardMatch / rotate_keylines (EDGEHIP_FWD_MODE, ctx.h)."""
+    later frames must not overtake the graphs that still read a slot); with the two alternative arrangements of
+    FordwardMatch / rotate_keylines (EDGEHIP_FWD_MODE, ctx.h); and with the three-kernel matching the one-pass form
+    replaced as the default (EDGEHIP_FUSE_MATCH=0: k_fwd_win, k_fwd_apply, k_rotate in place, k_directed)."""
     from oracle import oracle
     if mode != "default":
-        name, _, val = mode.partition("=")
-        monkeypatch.setenv(name, val or "1")
+        name, sep, val = mode.partition("=")
+        monkeypatch.setenv(name, val if sep else "1")
     frames = [f for f, _, _ in synth.billboard_sequence(376, 240, 12, seed=5)]
     _replay(frames, edgehip.euroc_params(376, 240), oracle.euroc_params(376, 240), 60, [0, 2, 7], 0.05)
 
