@@ -327,6 +327,47 @@ def test_matching_in_one_pass_is_bit_identical_to_the_three_kernels(monkeypatch,
     assert np.all(la["klm_num"][2:4] > 1000)
 
 
+def test_stage_level_calls_on_a_slot_the_frame_driver_rotated_out_of_place(monkeypatch):
+    """After a whole frame in the one-pass form the old slot's own arrays still hold the unturned KeyLines (the turned values wait
+    next to them).  Whatever touches that slot through the stage-level API must see what rotate_keylines would have left in place:
+    EstimateQuantile on it, an upload into ONE of its sequences (the other sequences keep their turned KeyLines), a depth reset of
+    one sequence, a second rotation.  Each against the same calls on a context running the three-kernel form (EDGEHIP_FUSE_MATCH=0)."""
+    w, h, n, nseq = 376, 240, 4, 3
+    frames = [f for f, _, _ in synth.billboard_sequence(w, h, n + nseq)]
+    Rz = np.array([[np.cos(0.01), -np.sin(0.01), 0], [np.sin(0.01), np.cos(0.01), 0], [0, 0, 1.0]])
+    outs = []
+    for mode in ("0", "1"):
+        monkeypatch.setenv("EDGEHIP_FUSE_MATCH", mode)
+        eh = edgehip.EdgeHip(edgehip.euroc_params(w, h), nseq=nseq, nslots=3)
+        for k in range(n):
+            prev = eh.cur_slot()
+            eh.upload_rgb(eh.next_slot(), np.stack([frames[k + s] for s in range(nseq)]))
+            eh.process_frame(0.05 * k)
+        got = {}
+        eh.quantile(prev)                                           # s_rho of the OLD slot: turned (scaled by 1 / q_z)
+        got["s_rho_q"] = [eh.get_state(s).s_rho_q for s in range(nseq)]
+        kl0, m0 = eh.download_keylines(0, prev)
+        eh.upload_keylines(1, prev, kl0[:100], m0)                  # sequence 1 of the old slot replaced ...
+        got["kl2_after_upload"] = eh.download_keylines(2, prev)[0].tobytes()   # ... sequence 2 keeps its turned KeyLines
+        got["kl1_after_upload"] = eh.download_keylines(1, prev)[0].tobytes()
+        outs.append(got)
+        eh.close()
+        # a fresh context for the calls that write the slot before anything has read it
+        eh = edgehip.EdgeHip(edgehip.euroc_params(w, h), nseq=nseq, nslots=3)
+        for k in range(n):
+            prev = eh.cur_slot()
+            eh.upload_rgb(eh.next_slot(), np.stack([frames[k + s] for s in range(nseq)]))
+            eh.process_frame(0.05 * k)
+        eh.depth_reset_slot(prev, 0)
+        eh.rotate_keylines(prev, Rz)
+        got["after_reset_and_rotation"] = [eh.download_keylines(s, prev)[0].tobytes() for s in range(nseq)]
+        eh.close()
+    a, b = outs
+    assert a["s_rho_q"] == b["s_rho_q"]
+    for key in ("kl2_after_upload", "kl1_after_upload", "after_reset_and_rotation"):
+        assert a[key] == b[key], key
+
+
 @pytest.mark.parametrize("w,h,n", [(376, 240, 10), (752, 480, 5)])
 def test_reweighted_evaluation_with_two_keylines_per_thread(monkeypatch, w, h, n):
     """The reweighted TryVelRot evaluations with two KeyLines per thread (k_try_velrot_rw2: both KeyLines' gathers in flight
