@@ -107,17 +107,24 @@ def tri(k, n):
     return k if k < n else p - k
 
 
+def tri_v(k, n):
+    """tri() of an integer array."""
+    p = 2 * (n - 1)
+    k = np.asarray(k, dtype=np.int64) % p
+    return np.where(k < n, k, p - k)
+
+
 # Matching in one pass (the library's default for ImuMode 0 without a stereo pair, EDGEHIP_FUSE_MATCH): FordwardMatch's copy of the
 # ten fields happens inside k_directed, so its 100 bytes per KeyLine are that group's, and its arbitration (24 bytes) rides on the
 # rotate_keylines pass: no C.forward_match group is launched.
 ONE_PASS_MATCHING = os.environ.get("EDGEHIP_FUSE_MATCH", "1") != "0"
 
 
-def algorithmic_bytes(group, kn, n_px, radius, nseq, evals_per_launch=1.0):
-    """Compulsory bytes per launch of a kernel group, for `nseq` batched sequences.
-    evals_per_launch: TryVelRot evaluations one k_try_velrot launch carries on average — 12 evaluations go out as 9 launches
-    since the two initialisation chains share theirs (SURVEY 8(d) prices an EVALUATION at 84 B per KeyLine; a two-chain
-    launch is two of them, although it streams the KeyLine's own 40 bytes once: `traffic` shows what it really moves)."""
+def algorithmic_bytes(group, kn, n_px, radius, nseq):
+    """Compulsory bytes per launch of a kernel group, for `nseq` batched sequences: what THIS launch cannot
+    avoid moving.  A TryVelRot evaluation is 84 B per KeyLine: 40 B of the KeyLine's own streams + 44 B
+    gathered per evaluation; the two-chain launch (k_try_velrot2, group B.try_velrot2) carries two evaluations but streams the
+    KeyLine's 40 B once: 40 + 2 x 44 = 128 B.  survey_bytes() keeps SURVEY 8(d)'s 84 B x evaluations for `frac_survey_formula`."""
     per_seq = {
         # stage A pieces: inputs/outputs each kernel cannot avoid
         "A.rgb_rowscan": 3 * n_px + 4 * n_px,                 # RGB24 in, row-prefix plane out
@@ -132,8 +139,8 @@ def algorithmic_bytes(group, kn, n_px, radius, nseq, evals_per_launch=1.0):
         # the rest (168 - 24 B), after reading those 24 B back and probing three mask neighbours
         "A.fused": 3 * n_px + 4 * n_px + 24 * kn,
         "A.join_retune": (24 + 3 * 4) * kn + (168 - 24) * kn,
-        # 84 B per KeyLine and evaluation (fp64 variant)
-        "B.try_velrot": 84 * kn * evals_per_launch,
+        "B.try_velrot": 84 * kn,
+        "B.try_velrot2": (40 + 2 * 44) * kn,
         "B.build_field": 4 * n_px + 4 * 2 * radius * kn,     # clear + scattered 4-byte atomics (packed field)
         "B.tvr_prepare": 0,   # per-sequence set-up of the minimisation since P0 is rebuilt in registers by k_try_velrot (latency, no stream)
         "B.lm_step": 0,
@@ -152,13 +159,21 @@ def algorithmic_bytes(group, kn, n_px, radius, nseq, evals_per_launch=1.0):
     return per_seq.get(group, 0) * nseq
 
 
+def survey_bytes(group, kn, n_px, radius, nseq):
+    """SURVEY.md 8(d)'s own per-unit figure where it differs from what a launch must move (`frac_survey_formula`): 84 B per
+    KeyLine and EVALUATION, so 168 B for a two-chain launch; five passes over 32 B for EstimateReScalingOpt."""
+    over = {"B.try_velrot2": 2 * 84 * kn, "C.rescale": 5 * 32 * kn}
+    return over[group] * nseq if group in over else algorithmic_bytes(group, kn, n_px, radius, nseq)
+
+
 # kernel names (substrings of the rocprofv3 kernel name) behind each HIP-event group
 GROUP_KERNELS = {
     "A.rgb_rowscan": ["k_rgb_rowscan"], "A.colscan": ["k_colscan"], "A.avg_rowscan": ["k_avg_rowscan"],
     "A.detect": ["k_detect"], "A.compact": ["k_strip_scan", "k_emit"], "A.join_retune": ["k_join_histo", "k_retune"],
     "A.level": ["k_level"], "A.fused": ["k_stage_a_fused"],
     "B.quantile": ["k_quantile"], "B.build_field": ["k_field_bin", "k_field_raster"], "B.tvr_prepare": ["k_tvr_prepare"],
-    "B.try_velrot": ["k_try_velrot"], "B.lm_step": ["k_lm_step"], "B.minimizer": ["k_minimizer"],
+    "B.try_velrot": ["k_try_velrot", "k_try_velrot_rw2"], "B.try_velrot2": ["k_try_velrot2"], "B.lm_step": ["k_lm_step", "k_lm_step2"],
+    "B.minimizer": ["k_try_velrot_lm"],
     "C.forward_match": ["k_fwd_key", "k_fwd_win", "k_fwd_apply"], "C.rotate": ["k_rot_from_state", "k_rotate", "k_fwd_apply_rotate"],
     "C.directed_matching": ["k_directed", "k_directed_fused"], "C.regularize_ekf": ["k_regularize", "k_ekf"], "C.rescale": ["k_rescale"],
 }
@@ -182,24 +197,21 @@ def fetch_calibration():
 # streams.  FETCH_SIZE counts a request of a wide stream at half its bytes and a small random read at the 64 bytes it
 # moves (profiles/fetch_calibration.json), so the counter R of such a kernel is stream/f_stream + gather/f_gather and the
 # bytes it really moved are  stream + f_gather * (R - stream / f_stream)  with the stream bytes known exactly.
-GROUP_STREAM_BYTES_PER_KL = {"B.try_velrot": 8 + 4 + 8 + 8 + 8 + 4 + 8}   # s_rho, m_num, p_m, rho, m_m, n_m, residual in
+GROUP_STREAM_BYTES_PER_KL = {"B.try_velrot": 8 + 4 + 8 + 8 + 8 + 4 + 8,   # s_rho, m_num, p_m, rho, m_m, n_m, residual in (reweighted)
+                             "B.try_velrot2": 8 + 4 + 8 + 8 + 8 + 4}       # the initialisation chains are not reweighted: no residual in
 
 
-def pmc_kn():
+def pmc_kn(check_stamp=True):
     """KeyLines per frame of the run the committed counters were taken in (tools/gpu_round.sh stamps it), or None."""
-    try:
-        return json.load(open(os.path.join(ROOT, PMC_FILE))).get("_kn")
-    except (OSError, ValueError):
-        return None
+    js = _pmc_file(check_stamp)
+    return js.get("_kn") if js else None
 
 
-def pmc_counters(group, nseq):
-    """(FETCH_SIZE, WRITE_SIZE) in bytes per launch of `group`, raw, from the committed PMC passes; None if unavailable."""
-    path = os.path.join(ROOT, PMC_FILE)
-    if not os.path.exists(path):
-        return None
-    js = json.load(open(path))
-    if js.get("_nseq") != nseq:
+def pmc_counters(group, nseq, check_stamp=True):
+    """(FETCH_SIZE, WRITE_SIZE) in bytes per launch of `group`, raw, from the committed PMC passes; None if unavailable, taken at
+    another batch size, or (check_stamp) taken with other sources than the running library's."""
+    js = _pmc_file(check_stamp)
+    if not js or js.get("_nseq") != nseq:
         return None
     ft = wt = 0.0
     found = False
@@ -220,10 +232,10 @@ def pmc_counters(group, nseq):
     return (ft, wt) if found else None
 
 
-def calibrated_traffic(group, nseq, kn, calib, stream_per_kl=None):
+def calibrated_traffic(group, nseq, kn, calib, stream_per_kl=None, check_stamp=True):
     """HBM bytes per launch of `group` from the committed counters and the calibration of profiles/fetch_calibration.json
     (see GROUP_STREAM_BYTES_PER_KL); (bytes, description of the formula) or (None, None)."""
-    c = pmc_counters(group, nseq)
+    c = pmc_counters(group, nseq, check_stamp)
     if c is None:
         return None, None
     fetch, write = c
@@ -236,16 +248,13 @@ def calibrated_traffic(group, nseq, kn, calib, stream_per_kl=None):
     return int(fs * fetch + fw * write), f"{fs:.2f} x FETCH_SIZE + {fw:.2f} x WRITE_SIZE (coalesced streams)"
 
 
-def pmc_traffic(group, nseq, factor=2.0):
+def pmc_traffic(group, nseq, factor=2.0, check_stamp=True):
     """HBM bytes per launch of `group` from the committed rocprofv3 PMC passes (profiles/pmc_latest.json, made by
     tools/gpu_round.sh: separate `--pmc FETCH_SIZE` and `--pmc WRITE_SIZE` runs of this same command).
     FETCH_SIZE/WRITE_SIZE are KiB; FETCH_SIZE is scaled by `factor` (2 = the gfx950 note in MI355X_MICROARCH.md).  None
     when the file is missing, was taken at another batch size, or lacks the kernel."""
-    path = os.path.join(ROOT, PMC_FILE)
-    if not os.path.exists(path):
-        return None
-    js = json.load(open(path))
-    if js.get("_nseq") != nseq:
+    js = _pmc_file(check_stamp)
+    if not js or js.get("_nseq") != nseq:
         return None
     total, found = 0.0, False
     for sub in GROUP_KERNELS.get(group, []):
@@ -573,6 +582,200 @@ def timed_replay(rp, K, Wm, profile=False):
     return time.perf_counter() - t0, breakdown
 
 
+LINE_LIMIT = 4096      # bytes of the one JSON line (the driver reads it out of a bounded stdout tail: round 4's 22 KB line did not parse)
+EXTRAS_FILE = "bench_extras.json"
+
+
+def _r(x, nd=4):
+    """Numbers of the one line: rounded to what they are known to."""
+    if isinstance(x, float):
+        return float(f"{x:.{nd}g}")
+    return x
+
+
+def compact_line(full):
+    """The ONE line on stdout, <= LINE_LIMIT bytes: the contract's keys, `config` (the workload named), `roofline` of the dominant
+    kernel, `cpu_baseline` with the three modes as three numbers, `pose_rmse` with the parity counts, and the single-camera and
+    plugin-surface figures.  Everything else — per-kernel rooflines, per-sequence maps, the sweep, notes, the `--extras` legs — is
+    in bench_extras.json next to this file (and on stderr)."""
+    c = full.get("config") or {}
+    line = {k: full.get(k) for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better",
+                                     "scaling", "vs_baseline", "dtype", "data")}
+    wl = str(c.get("workload") or "")
+    line["config"] = {"workload": wl if len(wl) <= 300 else wl[:297] + "...",
+                      "input": (str(c["input"])[:160] if c.get("input") else None)}
+    for k in ("sequences_per_gpu", "frames_per_step", "keylines_per_frame", "keylines_per_frame_timed_mean", "tryvelrot_evals_per_frame",
+              "estimation_ok", "nav_gather", "algorithmic_MB_per_frame", "whole_path_hbm_frac", "frames_per_s"):
+        if c.get(k) is not None:
+            line["config"][k] = c[k]
+    if isinstance(c.get("nav_gather_info"), dict):
+        line["config"]["nav_gather_equals_device_log"] = c["nav_gather_info"].get("equals_device_log")
+    rf = full.get("roofline")
+    if isinstance(rf, dict):
+        line["roofline"] = {k: _r(rf.get(k), 5) for k in ("bound", "kernel", "achieved", "peak", "unit", "frac", "frac_on_traffic",
+                                                         "frac_survey_formula", "traffic", "launch_us", "algorithmic_bytes_per_launch",
+                                                         "launches_timed", "issue_frac") if k in rf}
+        if rf.get("traffic") is None and rf.get("traffic_note"):
+            line["roofline"]["traffic_note"] = str(rf["traffic_note"])[:120]
+    else:
+        line["roofline"] = None
+    cb = full.get("cpu_baseline")
+    if isinstance(cb, dict):
+        o = {k: cb.get(k) for k in ("value", "unit", "cores", "kind", "ms_per_frame", "median_ms", "p95_ms", "usable_cores", "cpu_model") if k in cb}
+        if cb.get("sample"):
+            o["sample"] = str(cb["sample"])[:200]
+        if cb.get("error"):
+            o["error"] = str(cb["error"])[:120]
+        if isinstance(cb.get("modes"), dict):
+            o["modes"] = {k: (v.get("value") if isinstance(v, dict) else v) for k, v in cb["modes"].items()}
+            ns = cb["modes"].get("node_saturating")
+            if isinstance(ns, dict) and ns.get("cores"):
+                o["node_saturating_cores"] = ns["cores"]
+        line["cpu_baseline"] = o
+    else:
+        line["cpu_baseline"] = None
+    pr = full.get("pose_rmse")
+    if isinstance(pr, dict):
+        o = {k: _r(pr.get(k)) for k in ("position", "rotation_rad", "V", "W", "position_rel", "frames", "ranks", "error") if pr.get(k) is not None}
+        par = pr.get("free_running_parity") or {}
+        seqs = pr.get("sequences")
+        o["sequences_checked"] = par.get("sequences_checked", pr.get("sequences_checked", len(seqs) if seqs else None))
+        o["outside_tolerance"] = par.get("sequences_outside_tolerance_at_last_frame")
+        o["departures_on_knife_edge_frames"] = par.get("departures_on_knife_edge_frames")
+        o["departures_elsewhere"] = par.get("departures_elsewhere")
+        if par.get("max_abs_dVW_while_inside_tolerance") is not None:
+            o["max_abs_dVW_inside_tolerance"] = _r(par["max_abs_dVW_while_inside_tolerance"])
+        o["tolerance"] = "per frame |dV|,|dW| <= 1e-6*(|V|+|W|)+1e-9 and equal KeyLine count"
+        line["pose_rmse"] = o
+    else:
+        line["pose_rmse"] = None
+    for k in ("stage_a_hbm_frac", "single_sequence_ms_per_frame", "scaling_measured"):
+        if full.get(k) is not None:
+            line[k] = full[k]
+    hs = full.get("host_surface")
+    if isinstance(hs, dict):
+        line["host_surface"] = {k: v for k, v in hs.items() if isinstance(v, (int, float, str, bool)) and len(str(v)) <= 80}
+    kus = full.get("kernel_us_per_step")
+    if isinstance(kus, dict):   # the five heaviest groups, us per step
+        line["kernel_us_per_step_top"] = dict(sorted(kus.items(), key=lambda kv: -kv[1])[:5])
+    line["extras_file"] = EXTRAS_FILE
+    # the bound holds whatever the run produced: drop the optional objects, longest first, until the line fits
+    for k in ("kernel_us_per_step_top", "host_surface", "extras_file"):
+        if len(json.dumps(line)) <= LINE_LIMIT:
+            break
+        line.pop(k, None)
+    if len(json.dumps(line)) > LINE_LIMIT:
+        line["config"] = {"workload": wl[:120]}
+    return line
+
+
+def emit(full):
+    """bench_extras.json + stderr get everything; stdout gets compact_line(full), one line."""
+    text = json.dumps(full, indent=1, default=str)
+    try:
+        with open(os.path.join(ROOT, EXTRAS_FILE), "w") as f:
+            f.write(text + "\n")
+    except OSError as e:
+        print(f"bench.py: {EXTRAS_FILE} not written: {e}", file=sys.stderr)
+    print(text, file=sys.stderr)
+    out = json.dumps(compact_line(full), allow_nan=False, default=str)
+    print(out)
+    sys.stdout.flush()
+
+
+def library_source_sha():
+    """First 16 hex digits of the sha256 over the library's sources (rebvo_amd/csrc/*.hip, *.h, include/edgehip.h, in name order):
+    the identity of the code the committed counters were taken with (a rebuilt .so of the same sources keeps it)."""
+    import glob
+    import hashlib
+    hsh = hashlib.sha256()
+    files = sorted(glob.glob(os.path.join(ROOT, "rebvo_amd", "csrc", "*.hip")) + glob.glob(os.path.join(ROOT, "rebvo_amd", "csrc", "*.h")))
+    for fn in files + [os.path.join(ROOT, "include", "edgehip.h")]:
+        try:
+            hsh.update(os.path.basename(fn).encode() + b"\0" + open(fn, "rb").read())
+        except OSError:
+            return None
+    return hsh.hexdigest()[:16]
+
+
+_PMC_CACHE = {}
+
+
+def _pmc_file(check_stamp=True):
+    """profiles/pmc_latest.json if it exists and (check_stamp) was taken with the sources of the library that is running."""
+    key = bool(check_stamp)
+    if key not in _PMC_CACHE:
+        js = None
+        try:
+            js = json.load(open(os.path.join(ROOT, PMC_FILE)))
+            if check_stamp and (not js.get("_src_sha") or js.get("_src_sha") != library_source_sha()):
+                js = None
+        except (OSError, ValueError):
+            js = None
+        _PMC_CACHE[key] = js
+    return _PMC_CACHE[key]
+
+
+def pmc_stamp_note():
+    try:
+        js = json.load(open(os.path.join(ROOT, PMC_FILE)))
+    except (OSError, ValueError):
+        return "no committed counters"
+    have, want = js.get("_src_sha"), library_source_sha()
+    return f"counters stamped {have}, library sources {want}: " + ("match" if have and have == want else "NO match, traffic = null")
+
+
+def issue_fracs():
+    """{group: share of the kernel's busy cycles in which VALU instructions issue} from the committed SQ-counter passes
+    (profiles/sq_latest.json, tools/gpu_round.sh), under the same source stamp as the HBM counters; {} otherwise."""
+    try:
+        js = json.load(open(os.path.join(ROOT, "profiles", "sq_latest.json")))
+        if not js.get("_src_sha") or js.get("_src_sha") != library_source_sha():
+            return {}
+        return {g: v for g, v in js.get("issue_frac", {}).items()}
+    except (OSError, ValueError):
+        return {}
+
+
+def other_configs(args):
+    """--extras: the other BASELINE configurations and the ImuMode=2 line, each measured by this same file in a process of its own
+    (short runs in the driver's form); each entry is that run's own record, condensed."""
+    import subprocess
+    extras = {}
+    cf = str(min(args.cpu_frames, 60))
+
+    def run(flags, timeout):
+        out = subprocess.run([sys.executable, os.path.abspath(__file__)] + flags, capture_output=True, text=True, timeout=timeout)
+        for ln in reversed(out.stdout.splitlines()):
+            if ln.startswith("{"):
+                return json.loads(ln)
+        raise RuntimeError(f"no JSON line (rc {out.returncode}): {out.stderr[-200:]}")
+    for name, flags in (("stage_a", ["--config", "stage_a", "--cpu-frames", cf]),
+                        ("tum_undistort", ["--config", "tum_undistort", "--cpu-frames", cf, "--cpu-procs", "0"]),
+                        ("imu", ["--imu", "--cpu-frames", cf, "--cpu-procs", "0"])):
+        try:
+            t_sub = time.perf_counter()
+            js = run(["--no-extras", "--steps", "20", "--warmup", "5", "--nseq", str(args.nseq)] + flags, 420)
+            extras[name] = js
+            extras[name]["command"] = "python bench.py --no-extras --steps 20 --warmup 5 " + " ".join(flags)
+            extras[name]["wall_s"] = round(time.perf_counter() - t_sub, 1)
+        except Exception as e:
+            extras[name] = {"value": None, "error": f"{type(e).__name__}: {e}"[:300]}
+    # ... and what GlobalConfig_EuRoC ships with for ONE camera (ImuMode=2, one sequence per launch; best of three: a single
+    # camera's rate moves with the host's launch speed and with the clocks a lightly loaded GPU settles at)
+    try:
+        best = None
+        for _ in range(3):
+            js = run(["--no-extras", "--imu", "--nseq", "1", "--steps", "200", "--warmup", "12", "--cpu-frames", "0"], 300)
+            best = js["ms_per_step"] if best is None else min(best, js["ms_per_step"])
+        if isinstance(extras.get("imu"), dict):
+            extras["imu"]["single_sequence_ms_per_frame"] = best
+    except Exception as e:
+        if isinstance(extras.get("imu"), dict):
+            extras["imu"]["single_sequence_error"] = f"{type(e).__name__}: {e}"[:200]
+    return extras
+
+
 def main():
     # ONE JSON line on stdout, whatever the libraries underneath print: RCCL writes a version banner to the C-level stdout of
     # the process when its first communicator comes up.  File descriptor 1 is pointed at stderr for the rest of the run and
@@ -593,7 +796,15 @@ def main():
                          "run concurrently, which hides the serial LM-step kernels and launch tails of one context "
                          "behind the bandwidth-bound kernels of the other")
     ap.add_argument("--pool", type=int, default=24, help="rendered frames in the HBM pool")
-    ap.add_argument("--cpu-frames", type=int, default=200, help="frames of the CPU-baseline sample (0 = skip the CPU legs)")
+    ap.add_argument("--cpu-frames", type=int, default=100, help="frames of the CPU-baseline sample (0 = skip the CPU legs)")
+    ap.add_argument("--input", default="distinct", choices=["distinct", "pool"],
+                    help="where the resident frames of the timed region live: distinct = every sequence reads its OWN copy of its frames "
+                         "(sequences x pool frames x 3 B per pixel: 26.6 GB at the defaults, far beyond L2 + Infinity Cache, so stage A's "
+                         "input really comes from HBM); pool = all sequences read one shared pool of --pool frames (26 MB: cache-served)")
+    ap.add_argument("--extras", action="store_true",
+                    help="also measure (into bench_extras.json, never into the one line): the heterogeneous batch with its teacher-forced "
+                         "replay, the PCIe-inclusive legs, and the other BASELINE configurations (stage_a, tum_undistort, ImuMode=2) each "
+                         "in a process of its own.  Minutes of wall time; off by default")
     ap.add_argument("--overlap", action="store_true",
                     help="EDGEHIP_OVERLAP=1: stage A of frame k+1 under stages B/C of frame k (two streams per context). "
                          "Faster, but per-kernel HIP-event times (the roofline object) stop being attributable, so off by default")
@@ -604,7 +815,7 @@ def main():
                     help="ImuMode=2 (what the shipped GlobalConfig_EuRoC runs): the IMU branch of the tracker — gyro pre-rotation, "
                          "Minimizer_V, ExtRotVel, BiasCorrect, scale filter, gravity-aligned pose — batched on the device; the "
                          "integrated IMU data of every frame interval is synthesised from the known camera motion")
-    ap.add_argument("--no-extras", action="store_true", help="skip the batch sweep and the heterogeneous batch")
+    ap.add_argument("--no-extras", action="store_true", help="skip the small-batch sweep and the plugin-surface legs as well (profiling runs)")
     ap.add_argument("--dataset", default=os.environ.get("REBVO_DATASET_DIR") or os.environ.get("REBVO_EUROC_DIR") or os.environ.get("REBVO_TUM_DIR"),
                     help="a mounted EuRoC sequence (the directory that holds mav0/cam0/data.csv, 752x480: the default line) or TUM "
                          "sequence (rgb.txt, 640x480: --config tum_undistort): its images, read by the library's own DataSetCam, are "
@@ -673,9 +884,10 @@ def main():
     radius = params.search_range
     C = max(1, args.contexts)
     B, K, Wm = args.nseq // C, args.steps, args.warmup   # B = sequences per context
-    cpu_legs_any = rank == 0 and args.cpu_frames > 0 and (world == 1 or os.environ.get("BENCH_CPU_BASELINE_ALWAYS"))
-    cpu_legs = cpu_legs_any and not args.imu
-    cpu_legs_imu = cpu_legs_any and args.imu
+    # every rank checks a sample of its own sequences against the CPU reference (pose RMSE); rank 0 also times the reference
+    cpu_any = args.cpu_frames > 0
+    cpu_legs = cpu_any and not args.imu
+    cpu_legs_imu = cpu_any and args.imu and rank == 0 and world == 1
     if args.imu:
         args.no_extras = True   # the CPU legs and the other batch shapes are those of the ImuMode=0 line
         global ONE_PASS_MATCHING
@@ -708,6 +920,25 @@ def main():
     torch.cuda.synchronize()
     # every sequence starts at its own phase of the pool
     offs = np.arange(B * C, dtype=np.int64) % (2 * (args.pool - 1))
+    # --input distinct: sequence s reads frame i of the pool from ITS OWN copy (frame s * pool + i of a B*C*pool-frame array), as B*C
+    # cameras' buffers would lie in memory: the same pixels as the shared pool (so the CPU reference replays the same frames), at
+    # addresses nobody else touches — at the defaults 26.6 GB are swept per pass over the pool, against 256 MB of Infinity Cache
+    fb = int(frames[0].size)
+    in_pool, in_frames, in_note = pool, args.pool, f"one shared pool of {args.pool} RGB24 frames ({args.pool * fb / 1e6:.0f} MB: cache-served)"
+    seq_base = np.zeros(B * C, dtype=np.int64)
+    if args.input == "distinct" and B * C * args.pool * fb <= 96e9 and B * C * args.pool < 2 ** 31:
+        nS = B * C
+        big = torch.empty(nS * args.pool * fb + 16, dtype=torch.uint8, device="cuda")
+        big[:nS * args.pool * fb].view(nS, args.pool * fb).copy_(pool[:args.pool * fb].view(1, -1).expand(nS, -1))
+        torch.cuda.synchronize()
+        in_pool, in_frames = big, nS * args.pool
+        del big
+        seq_base = np.arange(nS, dtype=np.int64) * args.pool
+        in_note = (f"every sequence reads its own RGB24 copy of its frames: {nS} x {args.pool} frames = {nS * args.pool * fb / 1e9:.1f} GB "
+                   "resident, read in place by stage A")
+
+    def index_of(k):
+        return seq_base + tri_v(k + offs, args.pool)
     imu_params = imu_of = None
     if args.imu:
         # Integrated IMU data (rebvo::IntegratedImuData) of every transition between two pool frames, from the known motion:
@@ -737,17 +968,16 @@ def main():
 
         def imu_of(k):
             return [trans[(tri(k - 1 + o, args.pool) if k > 0 else tri(k + o, args.pool), tri(k + o, args.pool))] for o in offs]
-    rp = Replay(edgehip, params, B * C, pool, args.pool, lambda k: [tri(k + o, args.pool) for o in offs], local_rank, C,
-                imu_params=imu_params, imu_of=imu_of)
+    rp = Replay(edgehip, params, B * C, in_pool, in_frames, index_of, local_rank, C, imu_params=imu_params, imu_of=imu_of)
     ehs, eh = rp.ehs, rp.ehs[0]   # eh: the context whose streams carry the HIP-event profiler
 
     # ============================ --config stage_a: DoG + KeyLine extraction alone (configs[1]) ============================
     if args.config == "stage_a":
         def stage_a_step(k):
-            idx = np.array([tri(k + o, args.pool) for o in offs[:B]], dtype=np.int32)
-            for e in ehs:
+            idx = np.ascontiguousarray(index_of(k), dtype=np.int32)
+            for ci, e in enumerate(ehs):
                 s = k % 3
-                e.bind_rgb_indexed(s, pool.data_ptr(), args.pool, idx)
+                e.bind_rgb_indexed(s, in_pool.data_ptr(), in_frames, idx[ci * B:(ci + 1) * B])
                 e.stage_a(s)
         for k in range(Wm):
             stage_a_step(k)
@@ -891,8 +1121,10 @@ def main():
     if dominant and not args.no_roofline_events:
         dom_ms, dom_calls = eh.profile_read()[dominant]
         eh.profile_enable(False)
-    # sequences of context 0 compared with the CPU reference below: every 32nd (32 of 1024) and the last one
-    check_seqs = sorted(set(range(0, B, max(1, B // 32))) | {B - 1})
+    # sequences of context 0 compared with the CPU reference below: N = 1 every 32nd (32 of 1024) and the last one; N > 1 four
+    # (and the last) on EVERY rank, so that a --gpus 8 line carries a pose check of all eight shards
+    n_check = 32 if world == 1 else 4
+    check_seqs = sorted(set(range(0, B, max(1, B // n_check))) | {B - 1})
     gpu_traj = None
     log_all = None
     if cpu_legs:
@@ -908,6 +1140,46 @@ def main():
     kn_timed = float(np.mean((log_all[Wm:] if log_all is not None else eh.read_nav_log_array(Wm, K))["kn"])) if rank == 0 else kn_mean   # over every timed frame, context 0
     ok = int(sum(n.estimation_ok for n in last))
     evals = last[0].minimizer_evals
+
+    # ---- pose RMSE vs the CPU reference (BASELINE.json's metric): every rank checks its own sample, rank 0 holds the sum ----
+    pose = None
+    parity = None
+    oparams = None
+    kind = None
+    if cpu_legs:
+        try:
+            from oracle import oracle
+            oparams = oracle.tum_params(w, h, use_undistort=1) if tum else oracle.euroc_params(w, h)
+            kind = "reference" if oracle.available("ref") else ("port" if oracle.available("port") else None)
+            if kind == "reference":
+                parity, cpu_trajs = wide_parity(log_all, check_seqs, lambda s_: [tri(k + int(offs[s_]), args.pool) for k in range(Wm + K)],
+                                                np.stack(frames), ("tum" if tum else "euroc", w, h, FRAME_DT), Wm,
+                                                max(1, (_usable_cores() - 1) // world))
+            elif kind:
+                cpu_trajs = {s_: _cpu_traj(oracle, oparams, lambda k, s_=s_: frames[tri(k + int(offs[s_]), args.pool)], Wm, K)
+                             for s_ in check_seqs[:3]}
+            if kind:
+                pose = pose_rmse(gpu_traj, cpu_trajs, kind)
+                if pose and parity:
+                    pose["free_running_parity"] = parity
+        except Exception as e:  # the oracle is optional test infrastructure; never fatal for the bench
+            pose = {"error": f"{type(e).__name__}: {e}"[:200]}
+    if world > 1 and cpu_any:
+        # sum over ranks: squared errors and counts (a rank whose check failed contributes nothing and is counted in `ranks_failed`)
+        good = bool(pose and "position" in pose)
+        par = (pose or {}).get("free_running_parity") or {}
+        vec = [pose["position"] ** 2 * pose["frames"], pose["rotation_rad"] ** 2 * pose["frames"], pose["frames"], len(pose["sequences"]),
+               par.get("sequences_outside_tolerance_at_last_frame", 0), par.get("departures_elsewhere", 0),
+               par.get("departures_on_knife_edge_frames", 0), 0.0] if good else [0.0] * 7 + [1.0]
+        t_ = torch.tensor(vec, dtype=torch.float64, device="cuda" if backend == "nccl" else "cpu")
+        dist.all_reduce(t_, op=dist.ReduceOp.SUM)
+        v_ = [float(x) for x in t_.tolist()]
+        if v_[2] > 0:
+            pose = {"position": float(np.sqrt(v_[0] / v_[2])), "rotation_rad": float(np.sqrt(v_[1] / v_[2])), "frames": int(v_[2]),
+                    "sequences_checked": int(v_[3]), "ranks": world, "ranks_failed": int(v_[7]),
+                    "vs": f"CPU reference on the same frames, {n_check + 1} sequences of every rank's shard",
+                    "free_running_parity": {"sequences_checked": int(v_[3]), "sequences_outside_tolerance_at_last_frame": int(v_[4]),
+                                            "departures_elsewhere": int(v_[5]), "departures_on_knife_edge_frames": int(v_[6])}}
 
     if rank != 0:
         if world > 1:
@@ -928,51 +1200,52 @@ def main():
     groups = {g: (ms, calls) for g, (ms, calls) in prof.items() if calls}
     breakdown = {g: round(ms / prof_steps * 1e3, 1) for g, (ms, calls) in groups.items()}  # us per step
     # ---- roofline of the dominant kernel group, and of all of them ----
+    # `frac` = compulsory bytes of what is launched / launch time / 8 TB/s; `frac_survey_formula` = the same with SURVEY 8(d)'s
+    # per-unit figure where that counts bytes a launch does not have to move; `frac_on_traffic` = the rate at which the kernel
+    # really moves bytes (committed PMC passes — used only when they were taken with THIS library's sources, else null);
+    # `issue_frac` = share of the kernel's cycles in which its SIMDs issue VALU work (committed SQ counters, same rule): a kernel
+    # priced only against a roofline it is not bound by tells nobody anything.
     calib, calib_src = fetch_calibration()
+    kn_pmc = pmc_kn() or kn_mean
+    issue = issue_fracs()
+
+    def roof_of(g, ms, calls, kn):
+        ab = algorithmic_bytes(g, kn, n_px, radius, B)
+        if not ab or not calls:
+            return None
+        per = ms * 1e-3 / calls
+        r_ = {"launch_us": round(per * 1e6, 1), "achieved_GBs": round(ab / per / 1e9, 1), "frac": round(ab / per / 1e9 / HBM_PEAK_GBS, 4),
+              "algorithmic_bytes_per_launch": int(ab)}
+        sb = survey_bytes(g, kn, n_px, radius, B)
+        if sb != ab:
+            r_["frac_survey_formula"] = round(sb / per / 1e9 / HBM_PEAK_GBS, 4)
+        tr, _ = calibrated_traffic(g, B, kn_pmc, calib)
+        ab_pmc = algorithmic_bytes(g, kn_pmc, n_px, radius, B)
+        if tr and ab_pmc:   # counters taken at another KeyLine count: the ratio to the algorithmic bytes there, applied here
+            r_["traffic"] = int(tr / ab_pmc * ab)
+            r_["frac_on_traffic"] = round(tr / ab_pmc * ab / per / 1e9 / HBM_PEAK_GBS, 4)
+        if g in issue:
+            r_["issue_frac"] = issue[g]
+        return r_
     roof = None
     if dominant and dom_calls:
-        per_launch_s = dom_ms * 1e-3 / dom_calls
-        # bytes of THESE launches / time of THESE launches: the KeyLine count of the timed frames (kn_timed), and for the
-        # tracker the evaluations a launch carries (evals per frame / launches per frame over the timed region)
-        epl_timed = evals * K / dom_calls if dominant == "B.try_velrot" and dom_calls else 1.0
-        abytes = algorithmic_bytes(dominant, kn_timed, n_px, radius, B, epl_timed)
-        ach = abytes / per_launch_s / 1e9 if per_launch_s > 0 else 0.0
-        # the KeyLine's own streams per launch: 40 B, + the 8-byte residual of the iteration before in the reweighted launches
-        tvr_stream = 40 + 8 * min(1.0, (1 + params.tracker_iter_num) * K / dom_calls) if dominant == "B.try_velrot" else None
-        traffic, formula = calibrated_traffic(dominant, B, kn_timed, calib, tvr_stream)
-        roof = {"bound": "hbm", "kernel": dominant, "achieved": round(ach, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                "frac": round(ach / HBM_PEAK_GBS, 5), "traffic": traffic,
-                "traffic_source": PMC_FILE + " (rocprofv3 --pmc passes of this command committed with the code; not measured in this run)",
-                "traffic_calibration": {"factors_true_over_reported": {k: round(v, 3) for k, v in calib.items()}, "formula": formula,
-                                        "source": calib_src},
-                "launch_us": round(per_launch_s * 1e6, 2), "algorithmic_bytes_per_launch": int(abytes),
-                "launches_timed": dom_calls, "keylines_per_frame_of_these_launches": round(kn_timed, 1),
-                "evaluations_per_launch": round(epl_timed, 3)}
-    # The committed counters were taken in a run of their own: a group's traffic is compared with the algorithmic bytes at THAT
-    # run's KeyLine count (pmc_latest.json:_kn), and scaled to this run's for the absolute figure.  Where a kernel moves LESS
-    # than SURVEY 8(d)'s formula (build_field: the formula describes the reference's scatter, the LDS rasteriser writes half of
-    # it), `frac` on the algorithmic bytes flatters it: `frac_on_traffic` is the rate at which it really moves bytes.
-    kn_pmc = pmc_kn() or kn_mean
+        # bytes of THESE launches / time of THESE launches: the KeyLine count of the timed frames (kn_timed)
+        rd = roof_of(dominant, dom_ms, dom_calls, kn_timed)
+        if rd:
+            roof = {"bound": "hbm", "kernel": dominant, "achieved": rd["achieved_GBs"], "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                    "frac": rd["frac"], "frac_on_traffic": rd.get("frac_on_traffic"), "traffic": rd.get("traffic"),
+                    "launch_us": rd["launch_us"], "algorithmic_bytes_per_launch": rd["algorithmic_bytes_per_launch"],
+                    "launches_timed": dom_calls, "issue_frac": rd.get("issue_frac")}
+            if "frac_survey_formula" in rd:
+                roof["frac_survey_formula"] = rd["frac_survey_formula"]
+            if roof["traffic"] is None:
+                roof["traffic_note"] = pmc_stamp_note()
     roof_all = {}
-    traffic_step = 0.0
     for g, (ms, calls) in groups.items():
-        epl = evals * prof_steps / calls if g == "B.try_velrot" and calls else 1.0
-        ab = algorithmic_bytes(g, kn_mean, n_px, radius, B, epl)
-        if ab and calls:
-            per = ms * 1e-3 / calls
-            tr, _ = calibrated_traffic(g, B, kn_pmc, calib, 40 + 8 * min(1.0, (1 + params.tracker_iter_num) * prof_steps / calls) if g == "B.try_velrot" else None)
-            ab_pmc = algorithmic_bytes(g, kn_pmc, n_px, radius, B, epl)
-            ratio = tr / ab_pmc if tr and ab_pmc else None
-            roof_all[g] = {"launch_us": round(per * 1e6, 1), "launches_per_step": calls // prof_steps,
-                           "achieved_GBs": round(ab / per / 1e9, 1), "frac": round(ab / per / 1e9 / HBM_PEAK_GBS, 4),
-                           "traffic_over_algorithmic": round(ratio, 2) if ratio else None}
-            if ratio:
-                roof_all[g]["frac_on_traffic"] = round(ratio * ab / per / 1e9 / HBM_PEAK_GBS, 4)
-                traffic_step += ratio * ab * (calls // prof_steps)
-    if roof and roof.get("traffic") and dominant in roof_all and roof_all[dominant].get("traffic_over_algorithmic"):
-        roof["traffic"] = int(roof_all[dominant]["traffic_over_algorithmic"] * roof["algorithmic_bytes_per_launch"])
-        roof["traffic_kn"] = {"counters_taken_at": round(float(kn_pmc), 1), "this_run": round(kn_timed, 1),
-                              "note": "traffic = (counter bytes / algorithmic bytes at the counters' KeyLine count) x this run's algorithmic bytes"}
+        rg = roof_of(g, ms, calls, kn_mean)
+        if rg:
+            rg["launches_per_step"] = calls // prof_steps
+            roof_all[g] = rg
     # whole-frame algorithmic bytes, SURVEY.md §8(d) formulas with the measured kn and evaluation count
     r = radius
     frame_bytes = (3 * n_px + 4 * n_px + 168 * kn_mean) + (8 * n_px + 8 * 2 * r * kn_mean + evals * 84 * kn_mean) + \
@@ -980,58 +1253,46 @@ def main():
     if tum:
         frame_bytes += 36 * n_px    # the undistortion map read
     rp.close()
+    rp.pool_t = None
+    del in_pool
+    torch.cuda.empty_cache()
 
-    # ---- CPU baseline: the reference's own code on the host cores of this box, three ways; pose RMSE ----
+    # ---- CPU baseline: the reference's own code on the host cores of this box (rank 0): one core, the reference's own two-thread
+    # overlap, node-saturating.  N > 1: the one-core leg only, on a shorter sample (the other ranks wait at the last barrier) ----
     cpu = None
-    pose = None
-    oparams = None
-    if cpu_legs:
+    if cpu_legs and kind:
         try:
             from oracle import oracle
-            oparams = oracle.tum_params(w, h, use_undistort=1) if tum else oracle.euroc_params(w, h)
-            kind = "reference" if oracle.available("ref") else ("port" if oracle.available("port") else None)
-            if kind:
-                parity = None
-                if kind == "reference":
-                    parity, cpu_trajs = wide_parity(log_all, check_seqs, lambda s_: [tri(k + int(offs[s_]), args.pool) for k in range(Wm + K)],
-                                                    np.stack(frames), ("tum" if tum else "euroc", w, h, FRAME_DT), Wm, max(1, _usable_cores() - 1))
-                else:
-                    cpu_trajs = {s_: _cpu_traj(oracle, oparams, lambda k, s_=s_: frames[tri(k + int(offs[s_]), args.pool)], Wm, K)
-                                 for s_ in check_seqs[:3]}
-                pose = pose_rmse(gpu_traj, cpu_trajs, kind)
-                if parity:
-                    pose["free_running_parity"] = parity
-                ncores, model = _usable_cores(), _cpu_model()
-                if kind == "reference":
-                    host_pool = np.stack(frames)
-                    idx = [tri(k, args.pool) for k in range(10 + args.cpu_frames)]   # the first 10: first touch of the ring + MKL init
-                    modes = {}
-                    for name, th in (("serial_1_core", 1), ("reference_threads_2_cores", 2)):
-                        orc = oracle.Oracle("ref", oparams)
-                        done, _ = orc.run_sequence(host_pool, idx, dt=FRAME_DT, threads=th)
-                        orc.close()
-                        modes[name] = frame_stats(done, 10)
-                        modes[name]["cores"] = th
-                    cpu = dict(modes["serial_1_core"])
-                    cpu.update({"cores": 1, "kind": kind, "cpu_model": model, "usable_cores": ncores,
-                                "sample": f"{args.cpu_frames} frames of sequence 0 (same {w}x{h} pool), stage A + B/C back to back on 1 "
-                                          f"of {ncores} usable host cores ({model}); `modes` adds the reference's own threading "
-                                          "(FirstThr next to SecondThread, rebvo_first_t.cpp:134 / rebvo_second_t.cpp:102) and the "
-                                          "node-saturating run",
-                                "modes": modes})
-                else:
-                    orc = oracle.Oracle("port", oparams)
-                    ts = []
-                    for k in range(10 + args.cpu_frames):
-                        _, nav = orc.process_frame(frames[tri(k, args.pool)], FRAME_DT * k)
-                        ts.append(nav.dtp0 + nav.dtp1)
-                    done = np.cumsum(ts)
-                    cpu = frame_stats(done, 10)
-                    cpu.update({"cores": 1, "kind": kind, "cpu_model": model, "usable_cores": ncores,
-                                "sample": f"{args.cpu_frames} frames of sequence 0, restatement oracle on 1 core"})
+            ncores, model = _usable_cores(), _cpu_model()
+            nfr_cpu = args.cpu_frames if world == 1 else min(args.cpu_frames, 60)
+            if kind == "reference":
+                host_pool = np.stack(frames)
+                idx = [tri(k, args.pool) for k in range(10 + nfr_cpu)]   # the first 10: first touch of the ring + MKL init
+                modes = {}
+                for name, th in (("serial_1_core", 1), ("reference_threads_2_cores", 2))[:2 if world == 1 else 1]:
+                    orc = oracle.Oracle("ref", oparams)
+                    done, _ = orc.run_sequence(host_pool, idx, dt=FRAME_DT, threads=th)
+                    orc.close()
+                    modes[name] = frame_stats(done, 10)
+                    modes[name]["cores"] = th
+                cpu = dict(modes["serial_1_core"])
+                cpu.update({"cores": 1, "kind": kind, "cpu_model": model, "usable_cores": ncores,
+                            "sample": f"{nfr_cpu} frames of sequence 0 (same {w}x{h} frames), reference mtracklib stage A + B/C back to "
+                                      f"back on 1 of {ncores} host cores ({model})",
+                            "modes": modes})
+            else:
+                orc = oracle.Oracle("port", oparams)
+                ts = []
+                for k in range(10 + nfr_cpu):
+                    _, nav = orc.process_frame(frames[tri(k, args.pool)], FRAME_DT * k)
+                    ts.append(nav.dtp0 + nav.dtp1)
+                done = np.cumsum(ts)
+                cpu = frame_stats(done, 10)
+                cpu.update({"cores": 1, "kind": kind, "cpu_model": model, "usable_cores": ncores,
+                            "sample": f"{nfr_cpu} frames of sequence 0, restatement oracle on 1 core"})
         except Exception as e:  # the oracle is optional test infrastructure; never fatal for the bench
             cpu = {"value": None, "error": str(e)[:200]}
-        if cpu and cpu.get("value") and cpu.get("kind") == "reference" and args.cpu_procs and not tum:
+        if cpu and cpu.get("value") and cpu.get("kind") == "reference" and args.cpu_procs and not tum and world == 1:
             # node-saturating mode (SURVEY 8d iii): P independent sequences in parallel processes, each with the
             # reference's two compute threads (its third thread only ships results)
             try:
@@ -1106,7 +1367,7 @@ def main():
 
     # ---- the other batch shapes (N = 1, after the timed region) ----
     sweep = hetero = None
-    if world == 1 and not args.no_extras:
+    if world == 1 and not args.no_extras and not args.imu:
         sweep = []
         for n in (1, 8, 64):
             o = np.arange(n, dtype=np.int64) % (2 * (args.pool - 1))
@@ -1116,6 +1377,8 @@ def main():
             sweep.append({"sequences_per_launch": n, "frames_per_s": round(n * k2 / dt2, 1), "ms_per_step": round(dt2 / k2 * 1e3, 4)})
             r2.close()
         sweep.append({"sequences_per_launch": B, "frames_per_s": round(value, 1), "ms_per_step": round(dt / K * 1e3, 4)})
+    surface = None
+    if world == 1 and args.extras and not args.no_extras and not args.imu:
         # heterogeneous batch: six scenes with their own trajectories, every sequence at its own phase of its scene, one
         # sequence in sixteen cuts to another scene half-way through the timed region (estimation restart)
         try:
@@ -1212,7 +1475,7 @@ def main():
             hetero = dict(hetero or {"value": None})
             hetero["error"] = f"{type(e).__name__}: {e}"[:300]
 
-    line = {
+    full = {
         "metric": ("frames/sec (DoG+extract+track+depth, ImuMode=2) 752x480 EuRoC" if args.imu else
                    "frames/sec (DoG+extract+track+depth) 752x480 EuRoC") if not tum else
                   "frames/sec (undistort+DoG+extract+track+depth) 640x480 TUM",
@@ -1221,13 +1484,11 @@ def main():
         "dtype": "f32 scale-space / f64 tracker+EKF", "data": data_kind,
         "config": {"workload": ("full path (configs[2] at configs[1] size): 752x480 " + ("synthetic EuRoC-intrinsics " if data_kind == "synthetic" else
                                 f"{data_kind} data set (sequences of the batch start at staggered frames of the mounted list) ") +
-                                "sequences, GlobalConfig_EuRoC params, " + ("ImuMode=2: the IMU branch of SecondThread (gyro pre-rotation, "
-                                "Minimizer_V, ExtRotVel, BiasCorrect, scale filter, gravity-aligned pose) batched on the device, integrated "
-                                "IMU data synthesised from the camera motion" if args.imu else "ImuMode=0")) if not tum else
+                                "sequences, GlobalConfig_EuRoC params, " + ("ImuMode=2 (the IMU branch of SecondThread batched on the device, "
+                                "integrated IMU data synthesised from the camera motion)" if args.imu else "ImuMode=0")) if not tum else
                                ("BASELINE configs[3]: 640x480 synthetic TUM-intrinsics sequences taken as the distorted camera "
-                                "image, GlobalConfig_desk.txt params, UseUndistort=1 with the EuRoC distortion (SURVEY 8d scene S3), "
-                                "undistortion fused into the stage-A load"),
-                   "dataset": data_note,
+                                "image, GlobalConfig_desk.txt params, UseUndistort=1 with the EuRoC distortion (SURVEY 8d scene S3)"),
+                   "input": in_note, "dataset": data_note,
                    "sequences_per_gpu": B * C, "contexts_per_gpu": C, "sequences_per_launch": B,
                    "stream_overlap": bool(args.overlap), "nav_gather": nav_gather, "nav_gather_info": nav_gather_info,
                    "frames_per_step": B * C * world, "keylines_per_frame": round(kn_mean, 1),
@@ -1239,69 +1500,31 @@ def main():
         "kernel_us_per_step_source": "HIP events of the 4 steps that follow the timed region (profiler on every kernel group; the timed "
                                      "region itself carries events on the dominant group only)",
         "roofline_kernels": roof_all,
+        # no SCALE record of this repository exists (the driver's 8-GPU node has not been available): N > 1 is covered by the gloo
+        # tests and a 2-rank dry run, not by a measured curve
+        "scaling_measured": False,
+        "traffic_source": PMC_FILE + " (rocprofv3 --pmc passes of this command, committed; used only when stamped with the sources of "
+                                     "the library that is running: " + pmc_stamp_note() + ")",
+        "traffic_calibration": {"factors_true_over_reported": {k: round(v, 3) for k, v in calib.items()}, "source": calib_src},
     }
-    if world == 1 and not args.no_extras and args.config == "full" and not args.imu:
-        # The other BASELINE configurations and the ImuMode=2 line, each measured by this same file in a process of its own
-        # (short runs in the driver's form), so that the one default command covers configs[1], configs[3] and what
-        # GlobalConfig_EuRoC actually ships with.  Each entry is that run's own JSON line, condensed.
-        import subprocess
-        extras = {}
-        cf = str(min(args.cpu_frames, 60))
-        for name, flags in (("stage_a", ["--config", "stage_a", "--cpu-frames", cf]),
-                            ("tum_undistort", ["--config", "tum_undistort", "--cpu-frames", cf, "--cpu-procs", "0"]),
-                            ("imu", ["--imu", "--cpu-frames", cf, "--cpu-procs", "0"])):
-            try:
-                t_sub = time.perf_counter()
-                out = subprocess.run([sys.executable, os.path.abspath(__file__), "--no-extras", "--steps", "20", "--warmup", "5",
-                                      "--nseq", str(args.nseq)] + flags, capture_output=True, text=True, timeout=420)
-                js = None
-                for ln in reversed(out.stdout.splitlines()):
-                    if ln.startswith("{"):
-                        js = json.loads(ln)
-                        break
-                if js is None:
-                    raise RuntimeError(f"no JSON line (rc {out.returncode}): {out.stderr[-200:]}")
-                keep = ("metric", "value", "unit", "steps", "warmup", "ms_per_step", "roofline", "cpu_baseline", "pose_rmse",
-                        "stage_a_hbm_frac", "kernel_us_per_step")
-                extras[name] = {k: js[k] for k in keep if k in js}
-                extras[name]["workload"] = js.get("config", {}).get("workload")
-                extras[name]["keylines_per_frame"] = js.get("config", {}).get("keylines_per_frame")
-                extras[name]["command"] = "python bench.py --no-extras --steps 20 --warmup 5 " + " ".join(flags)
-                extras[name]["wall_s"] = round(time.perf_counter() - t_sub, 1)
-            except Exception as e:
-                extras[name] = {"value": None, "error": f"{type(e).__name__}: {e}"[:300]}
-        # ... and what GlobalConfig_EuRoC ships with for ONE camera (ImuMode=2, one sequence per launch)
-        try:
-            best = None
-            # (a single camera's frame is ~60 small launches: its rate moves with the host's launch speed, with a second process
-            # holding the device — this one — and with the clocks a lightly loaded GPU settles at: 0.33 ms per frame measured right
-            # after a loaded phase in a lone process, ~0.5 here; best of three)
-            for _ in range(3):
-                out = subprocess.run([sys.executable, os.path.abspath(__file__), "--no-extras", "--imu", "--nseq", "1", "--steps", "200",
-                                      "--warmup", "12", "--cpu-frames", "0"], capture_output=True, text=True, timeout=300)
-                js = next(json.loads(ln) for ln in reversed(out.stdout.splitlines()) if ln.startswith("{"))
-                best = js["ms_per_step"] if best is None else min(best, js["ms_per_step"])
-            if isinstance(extras.get("imu"), dict):
-                extras["imu"]["single_sequence_ms_per_frame"] = best
-        except Exception as e:
-            if isinstance(extras.get("imu"), dict):
-                extras["imu"]["single_sequence_error"] = f"{type(e).__name__}: {e}"[:200]
-        line["extras"] = extras
-    if world == 1 and not args.no_extras and args.config == "full" and not args.imu:
-        line["pcie_inclusive"] = pcie_inclusive(edgehip, params, frames, offs, B, K, max(Wm, 4), local_rank)
-        if line["pcie_inclusive"].get("grey8", {}).get("value"):
-            line["pcie_inclusive"]["grey8_over_resident"] = round(line["pcie_inclusive"]["grey8"]["value"] / value, 3)
-        line["pcie_inclusive"]["note"] = ("`value` (the headline) has its inputs resident in HBM before the timed region, as the bench "
+    if surface:
+        full["host_surface"] = surface
+    if world == 1 and args.extras and not args.no_extras and args.config == "full" and not args.imu:
+        full["extras"] = other_configs(args)
+        full["pcie_inclusive"] = pcie_inclusive(edgehip, params, frames, offs, B, K, max(Wm, 4), local_rank)
+        if full["pcie_inclusive"].get("grey8", {}).get("value"):
+            full["pcie_inclusive"]["grey8_over_resident"] = round(full["pcie_inclusive"]["grey8"]["value"] / value, 3)
+        full["pcie_inclusive"]["note"] = ("`value` (the headline) has its inputs resident in HBM before the timed region, as the bench "
                                           "contract asks; these are the same replay with every frame crossing the link inside it")
     if sweep:
-        line["batch_sweep"] = sweep
-        line["single_sequence_ms_per_frame"] = sweep[0]["ms_per_step"]
-        line["single_sequence_note"] = ("rate of back-to-back frames of one sequence; for batches below the one-kernel stage A's threshold the "
+        full["batch_sweep"] = sweep
+        full["single_sequence_ms_per_frame"] = sweep[0]["ms_per_step"]
+        full["single_sequence_note"] = ("rate of back-to-back frames of one sequence; for batches below the one-kernel stage A's threshold the "
                                         "library runs the next frame's detection beside this frame's tracking and mapping (EDGEHIP_OVERLAP "
                                         "default), so one frame's way through the path is ~15 % longer than this figure")
     if hetero:
-        line["heterogeneous"] = hetero
-    print(json.dumps(line))
+        full["heterogeneous"] = hetero
+    emit(full)
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()

@@ -92,7 +92,7 @@ static const char *kProfNames[PROF_COUNT] = {
     "A.rgb_rowscan", "A.colscan", "A.avg_rowscan", "A.detect", "A.compact", "A.join_retune",
     "B.quantile", "B.build_field", "B.tvr_prepare", "B.try_velrot", "B.lm_step",
     "C.forward_match", "C.rotate", "C.directed_matching", "C.regularize_ekf", "C.rescale", "C.pose",
-    "A.level", "B.minimizer", "A.fused", "IMU.bias_rototranslation", "IMU.scale_filter_pose", "B.minimizer_v", "C.ext_rot_vel"};
+    "A.level", "B.minimizer", "A.fused", "IMU.bias_rototranslation", "IMU.scale_filter_pose", "B.minimizer_v", "C.ext_rot_vel", "B.try_velrot2"};
 
 ProfScope::ProfScope(edgehip_ctx *ctx, int pid, hipStream_t stream) : c(ctx), id(pid), st(stream ? stream : ctx->stream) {
     Profiler *p = c->prof;

@@ -366,6 +366,7 @@ enum ProfId {
     PROF_B_QUANTILE, PROF_B_FIELD, PROF_B_PREP, PROF_B_TRYVELROT, PROF_B_LMSTEP,
     PROF_C_FORWARD, PROF_C_ROTATE, PROF_C_DIRECTED, PROF_C_REGEKF, PROF_C_RESCALE, PROF_C_POSE,
     PROF_A_LEVEL, PROF_B_MINIMIZER, PROF_A_FUSED, PROF_IMU_FILTERS, PROF_IMU_SCALE_POSE, PROF_B_MINIMIZER_V, PROF_C_EXTROTVEL,
+    PROF_B_TRYVELROT2,   // the two-chain evaluation (k_try_velrot2): its own bytes per KeyLine (40 + 2 x 44)
     PROF_COUNT
 };
 struct Profiler {

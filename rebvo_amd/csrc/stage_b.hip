@@ -2738,7 +2738,7 @@ static int launch_lm(edgehip_ctx *c, int slot_new, unsigned ops, bool two_chains
 
 // one launch for evaluation i of both initialisation chains (tvr2_body)
 static int launch_tvr2(edgehip_ctx *c, const TvrArgs &a, bool procjf) {
-    ProfScope ps(c, PROF_B_TRYVELROT);
+    ProfScope ps(c, PROF_B_TRYVELROT2);
     dim3 g(c->nblk_tvr, 1, c->plan.nseq), b(kTvrThreads);
     if (a.use_grec) {
         if (procjf) hipLaunchKernelGGL((k_try_velrot2<true, true>), g, b, 0, c->stream, a);
