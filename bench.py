@@ -610,6 +610,9 @@ def compact_line(full):
             line["config"][k] = c[k]
     if isinstance(c.get("nav_gather_info"), dict):
         line["config"]["nav_gather_equals_device_log"] = c["nav_gather_info"].get("equals_device_log")
+    ds = c.get("dataset")
+    line["config"]["dataset"] = ({"list": str(ds.get("list"))[-80:], "frames_in_pool": ds.get("frames_in_pool"),
+                                  "mean_frame_interval_s": ds.get("mean_frame_interval_s")} if isinstance(ds, dict) else None)
     rf = full.get("roofline")
     if isinstance(rf, dict):
         line["roofline"] = {k: _r(rf.get(k), 5) for k in ("bound", "kernel", "achieved", "peak", "unit", "frac", "frac_on_traffic",
@@ -673,7 +676,7 @@ def emit(full):
     """bench_extras.json + stderr get everything; stdout gets compact_line(full), one line."""
     text = json.dumps(full, indent=1, default=str)
     try:
-        with open(os.path.join(ROOT, EXTRAS_FILE), "w") as f:
+        with open(os.environ.get("BENCH_EXTRAS_FILE") or os.path.join(ROOT, EXTRAS_FILE), "w") as f:
             f.write(text + "\n")
     except OSError as e:
         print(f"bench.py: {EXTRAS_FILE} not written: {e}", file=sys.stderr)
