@@ -582,6 +582,44 @@ def timed_replay(rp, K, Wm, profile=False):
     return time.perf_counter() - t0, breakdown
 
 
+def host_surface(params, frames, w, h):
+    """Frames per second THROUGH the plugin surface (requestCustomCamBuffer -> copyFrom -> releaseCustomCamBuffer, results
+    through getNav; include/rebvo/rebvo.h:548-609 of the reference): rebvo_amd/lib/surface_replay drives 1, 8 and 64
+    rebvo::REBVO objects, the 8 and the 64 as ONE batch group each (&GPU BatchGroup: one shared context, lock-step, page-locked
+    camera rings, asynchronous uploads under the frames before; rebvo_amd/host/src/batch_group.cpp).  Every frame crosses PCIe
+    inside the timed region (RGB24, 1.08 MB), so these are PCIe-inclusive figures by construction.  No callback is registered
+    for the three headline numbers (KeyLines stay in HBM); `objects_8_with_callbacks_fps` adds one per object (AoS KeyLines back
+    to the host for every frame)."""
+    import subprocess
+    import tempfile
+    from rebvo_amd import config
+    exe = os.path.join(ROOT, "rebvo_amd", "lib", "surface_replay")
+    if not os.path.exists(exe):
+        return {"error": "rebvo_amd/lib/surface_replay not built"}
+    out = {"what": "frames/s through requestCustomCamBuffer/getNav, PCIe inside; 8 and 64 objects = one batch group each"}
+    with tempfile.TemporaryDirectory() as td:
+        cfg, raw = os.path.join(td, "cfg"), os.path.join(td, "frames.rgb24")
+        config.write_global_config(cfg, params)
+        np.stack(frames).tofile(raw)
+        for name, n, k, wm, extra in (("single_camera_fps", 1, 240, 40, []), ("objects_8_fps", 8, 70, 10, ["--group", "g8"]),
+                                      ("objects_64_fps", 64, 36, 6, ["--group", "g64"]),
+                                      ("objects_8_with_callbacks_fps", 8, 40, 8, ["--group", "g8cb", "--callback"])):
+            try:
+                r = subprocess.run([exe, cfg, raw, str(len(frames)), str(n), str(k), "0", str(FRAME_DT), "--warmup", str(wm),
+                                    "--threads", str(min(8, n))] + extra, capture_output=True, text=True, timeout=240)
+                js = json.loads(r.stdout.strip().splitlines()[-1]) if r.returncode == 0 else None
+                if js is None:
+                    raise RuntimeError(f"rc {r.returncode}: {(r.stdout + r.stderr)[-200:]}")
+                out[name] = js["fps"]
+                out.setdefault("detail", {})[name] = js
+            except Exception as e:
+                out[name] = None
+                out.setdefault("errors", {})[name] = f"{type(e).__name__}: {e}"[:200]
+    if out.get("single_camera_fps"):
+        out["single_camera_ms_per_frame"] = round(1e3 / out["single_camera_fps"], 4)
+    return out
+
+
 LINE_LIMIT = 4096      # bytes of the one JSON line (the driver reads it out of a bounded stdout tail: round 4's 22 KB line did not parse)
 EXTRAS_FILE = "bench_extras.json"
 
@@ -1381,6 +1419,11 @@ def main():
             r2.close()
         sweep.append({"sequences_per_launch": B, "frames_per_s": round(value, 1), "ms_per_step": round(dt / K * 1e3, 4)})
     surface = None
+    if world == 1 and not args.no_extras and not args.imu and args.config == "full" and not tum:
+        try:
+            surface = host_surface(params, frames, w, h)
+        except Exception as e:
+            surface = {"error": f"{type(e).__name__}: {e}"[:200]}
     if world == 1 and args.extras and not args.no_extras and not args.imu:
         # heterogeneous batch: six scenes with their own trajectories, every sequence at its own phase of its scene, one
         # sequence in sixteen cuts to another scene half-way through the timed region (estimation restart)

@@ -46,7 +46,7 @@ typedef struct edgehip_params {
     double ppx, ppy, zfx, zfy;    /* PPx, PPy, ZfX, ZfY (stored as float like REBVOParameters does) */
     double kc[5];                 /* KcR2 KcR4 KcR6 KcP1 KcP2 */
     double sigma0, ksigma;        /* Sigma0, KSigma */
-    int32_t plane_fit_size;       /* DetectorPlaneFitSize (only 2 is supported: 5x5 window) */
+    int32_t plane_fit_size;       /* DetectorPlaneFitSize: 1, 2 or 3 = a 3x3, 5x5 or 7x7 plane-fit window (edge_finder.cpp:110-137) */
     double pos_neg_thresh, dog_thresh;
     int32_t max_points, reference_points, track_points;
     double detector_thresh, auto_gain, max_thresh, min_thresh;
@@ -178,6 +178,10 @@ int edgehip_upload_rgb_device(edgehip_ctx *ctx, int slot, const void *rgb24_dev)
 int edgehip_alloc_pinned(size_t bytes, void **out);
 int edgehip_free_pinned(void *p);
 int edgehip_upload_rgb_pinned(edgehip_ctx *ctx, int slot, const uint8_t *rgb24_pinned, int seq_first, int count);
+/* Block the caller until the page-locked sources of every *_pinned upload enqueued so far have been read (the copies on the upload
+ * stream are done) — the point at which a camera ring may hand the buffers back to the application
+ * (cam_pipe.ReleaseBuffer, src/VideoLib/customcam.cpp:70-76).  The frames' processing is NOT waited for. */
+int edgehip_upload_sync(edgehip_ctx *ctx);
 
 /* Bench/replay helper: frame pool resident in HBM ([pool_frames][h][w][3]); sequence s takes frame
  * idx[s] (host array, nseq entries).  One gather kernel on the context stream. */

@@ -756,6 +756,13 @@ int edgehip_free_pinned(void *p) {
     if (p) EH_CHECK(hipHostFree(p));
     return 0;
 }
+// the page-locked sources of every *_pinned upload so far have been read; the frames themselves may still be in flight
+int edgehip_upload_sync(edgehip_ctx *c) {
+    EH_ENTER(c);
+    if (!c) return EDGEHIP_ERR_ARG;
+    if (c->stream_up) EH_CHECK(hipStreamSynchronize(c->stream_up));
+    return 0;
+}
 int edgehip_upload_rgb_pinned(edgehip_ctx *c, int slot, const uint8_t *rgb24_pinned, int seq_first, int count) {
     EH_ENTER(c);
     if (int e = check_slot(c, slot)) return e;

@@ -1,0 +1,165 @@
+// surface_replay — N rebvo::REBVO objects fed through the plugin surface only (requestCustomCamBuffer / releaseCustomCamBuffer,
+// setOutputCallback, getNav: include/rebvo/rebvo.h:548-609 of the reference), optionally as ONE batch group (&GPU BatchGroup:
+// the objects share a device context of N sequences, rebvo_amd/host/src/batch_group.cpp).  Used by tests/test_batch_group_gpu.py
+// (per-object results against the reference) and by bench.py's `host_surface` leg (frames per second through the surface).
+//
+//   surface_replay <GlobalConfig> <frames.rgb24> <pool_frames> <objects> <frames_per_object> <t0> <dt>
+//                  [--group NAME] [--callback] [--dump PREFIX] [--threads T] [--warmup W] [--leave I:F]
+//
+// frames.rgb24 = pool_frames x ImageHeight x ImageWidth x 3 bytes.  Object i's frame k is pool frame tri(k + i): the triangle wave
+// over the pool bench.py uses (forward then backward: continuous motion), every object at its own phase.  Frame k of every object
+// carries the time stamp t0 + k dt.  --group puts all objects into one batch group of that name; without it every object has its
+// own context.  --callback registers an output callback per object (KeyLines come back as AoS); --dump PREFIX makes it write
+// PREFIX.<i>.txt, one line per delivered frame in custom_cam_replay's columns.  T producer threads feed the objects (object i
+// belongs to thread i % T), each with one copyFrom() per frame like the reference's example.  The last line on stdout is JSON:
+//   {"objects": N, "frames_per_object": K, "timed_frames": ..., "seconds": ..., "fps": ..., "callbacks": ..., "group": ...}
+// --leave I:F: object I calls CleanUp() after its frame F-1 (a camera that goes away; the others carry on).
+// timed over the frames after the first W of every object (default 0), from the submission of frame W to the moment every
+// object's getNav() shows its last frame.
+#include <atomic>
+#include <chrono>
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <fstream>
+#include <iomanip>
+#include <iostream>
+#include <memory>
+#include <string>
+#include <thread>
+#include <vector>
+
+#include "rebvo/rebvo.h"
+
+using namespace rebvo;
+
+static int tri(long k, int n) {
+    if (n < 2) return 0;
+    const int p = 2 * (n - 1);
+    const int r = (int)(k % p);
+    return r < n ? r : p - r;
+}
+
+struct Sink {
+    std::ofstream dump;
+    std::atomic<int> calls{0};
+    bool cb(PipeBuffer &p) {
+        calls++;
+        if (!dump.is_open()) {
+            volatile int kn = p.ef->KNum();   // a consumer that looks at the edge map
+            (void)kn;
+            return true;
+        }
+        double sr = 0, ss = 0;
+        for (KeyLine &kl : *p.ef) { sr += kl.rho; ss += kl.s_rho; }
+        dump << std::setprecision(17) << p.p_id << " " << p.t << " " << p.ef->KNum() << " " << p.ef->NumMatches() << " " << (int)p.EstimationOK;
+        for (int i = 0; i < 3; i++) dump << " " << p.nav.Pos[i];
+        for (int i = 0; i < 3; i++) dump << " " << p.nav.PoseLie[i];
+        for (int i = 0; i < 3; i++) dump << " " << p.nav.Vel[i];
+        dump << " " << sr << " " << ss << "\n";
+        return true;
+    }
+};
+
+static double now_s() { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
+
+int main(int argn, char **argv) {
+    if (argn < 8) {
+        std::cout << "usage: surface_replay <GlobalConfig> <frames.rgb24> <pool_frames> <objects> <frames_per_object> <t0> <dt> "
+                     "[--group NAME] [--callback] [--dump PREFIX] [--threads T] [--warmup W]\n";
+        return 2;
+    }
+    const int pool_frames = atoi(argv[3]), N = atoi(argv[4]), K = atoi(argv[5]);
+    const double t0 = atof(argv[6]), dt = atof(argv[7]);
+    std::string group, dump_prefix;
+    bool want_cb = false;
+    int T = 1, W = 0, leave_obj = -1, leave_at = 0;
+    for (int a = 8; a < argn; a++) {
+        const std::string s = argv[a];
+        if (s == "--group" && a + 1 < argn) group = argv[++a];
+        else if (s == "--callback") want_cb = true;
+        else if (s == "--dump" && a + 1 < argn) { dump_prefix = argv[++a]; want_cb = true; }
+        else if (s == "--threads" && a + 1 < argn) T = atoi(argv[++a]);
+        else if (s == "--warmup" && a + 1 < argn) W = atoi(argv[++a]);
+        else if (s == "--leave" && a + 1 < argn) { if (std::sscanf(argv[++a], "%d:%d", &leave_obj, &leave_at) != 2) return 2; }
+        else { std::cout << "unknown argument " << s << "\n"; return 2; }
+    }
+    if (pool_frames < 1 || N < 1 || K < 2 || T < 1 || W < 0 || W >= K - 1) { std::cout << "bad counts\n"; return 2; }
+    T = std::min(T, N);
+
+    REBVO proto(argv[1]);
+    if (!proto.isInitOk()) { std::cout << "config error\n"; return 3; }
+    REBVOParameters prm = proto.getParams();
+    if (!group.empty()) { prm.GpuBatchGroup = group; prm.GpuBatchSize = N; }
+    const Size2D sz = prm.ImageSize;
+    const size_t fb = (size_t)sz.w * sz.h * 3;
+    std::vector<uint8_t> pool(fb * pool_frames);
+    {
+        std::ifstream in(argv[2], std::ios::binary);
+        if (!in.is_open()) { std::cout << "cannot open " << argv[2] << "\n"; return 5; }
+        in.read(reinterpret_cast<char *>(pool.data()), (std::streamsize)pool.size());
+        if ((size_t)in.gcount() != pool.size()) { std::cout << "short read of " << argv[2] << "\n"; return 5; }
+    }
+
+    std::vector<std::unique_ptr<REBVO>> obj;
+    std::vector<std::unique_ptr<Sink>> sink;
+    for (int i = 0; i < N; i++) {
+        obj.emplace_back(new REBVO(prm));
+        sink.emplace_back(new Sink);
+        if (!obj[i]->isInitOk()) { std::cout << "object " << i << ": bad parameters\n"; return 3; }
+        if (!dump_prefix.empty()) sink[i]->dump.open(dump_prefix + "." + std::to_string(i) + ".txt");
+        if (want_cb) obj[i]->setOutputCallback(&Sink::cb, sink[i].get());
+    }
+    for (int i = 0; i < N; i++)
+        if (!obj[i]->Init()) { std::cout << "object " << i << ": Init failed: " << obj[i]->lastError() << "\n"; return 4; }
+
+    std::atomic<bool> bad{false};
+    std::atomic<int> at_warm{0};
+    double t_start = 0;
+    std::atomic<bool> go{false};
+    auto producer = [&](int tid) {
+        for (int k = 0; k < K && !bad; k++) {
+            if (k == W) {   // all producers line up behind the warm-up frames: the clock starts when the first timed frame is submitted
+                if (++at_warm == T) { t_start = now_s(); go = true; }
+                while (!go && !bad) std::this_thread::yield();
+            }
+            for (int i = tid; i < N && !bad; i += T) {
+                if (i == leave_obj && k >= leave_at) {
+                    if (k == leave_at) obj[i]->CleanUp();
+                    continue;
+                }
+                std::shared_ptr<Image<RGB24Pixel>> ptr;
+                while (!obj[i]->requestCustomCamBuffer(ptr, t0 + dt * k, 0.1))
+                    if (!obj[i]->Running()) { bad = true; break; }
+                if (bad) break;
+                (*ptr).copyFrom(reinterpret_cast<const RGB24Pixel *>(pool.data() + fb * tri((long)k + i, pool_frames)));
+                obj[i]->releaseCustomCamBuffer();
+            }
+        }
+    };
+    std::vector<std::thread> thr;
+    for (int t = 0; t < T; t++) thr.emplace_back(producer, t);
+    for (auto &t : thr) t.join();
+    // every object's record of its last frame
+    const double t_last = t0 + dt * (K - 1);
+    const double deadline = now_s() + 120;
+    for (int i = 0; i < N && !bad; i++)
+        while (i != leave_obj && obj[i]->getNav().t < t_last - 1e-9 * (1 + std::fabs(t_last))) {
+            if (!obj[i]->Running() || now_s() > deadline) { bad = true; break; }
+            std::this_thread::sleep_for(std::chrono::microseconds(50));
+        }
+    const double seconds = now_s() - t_start;
+    std::vector<NavData> navs;
+    for (int i = 0; i < N; i++) navs.push_back(obj[i]->getNav());
+    for (int i = 0; i < N; i++) obj[i]->CleanUp();
+    int calls = 0;
+    for (int i = 0; i < N; i++) calls += sink[i]->calls;
+    if (bad) { std::cout << "an object stopped before its last frame\n"; return 6; }
+    for (int i = 0; i < N; i++)
+        std::cout << "object " << i << " final Pos = " << std::setprecision(17) << navs[i].Pos[0] << " " << navs[i].Pos[1] << " " << navs[i].Pos[2] << "\n";
+    const long timed = (long)N * (K - W);
+    std::printf("{\"objects\": %d, \"frames_per_object\": %d, \"timed_frames\": %ld, \"seconds\": %.6f, \"fps\": %.1f, \"callbacks\": %d, "
+                "\"group\": %s, \"producer_threads\": %d, \"ms_per_step\": %.4f}\n",
+                N, K, timed, seconds, timed / seconds, calls, group.empty() ? "null" : ("\"" + group + "\"").c_str(), T, seconds / (K - W) * 1e3);
+    return 0;
+}

@@ -28,7 +28,16 @@
 //    layout of TooN::Vector<3> / TooN::Matrix<3,3>; compile with -DREBVO_HAVE_TOON to get the TooN types.
 //  * Only the config keys that reach this path are mandatory; keys of subsystems that do not exist here
 //    (UDP, encoders, SimuCamera, ProcesorConfig ...) are accepted and ignored.  Optional section:
-//        &GPU  Device=0
+//        &GPU  Device=0  BatchGroup=<name>  BatchSize=<N>
+//  * Batch groups (CameraType 3, ImuMode 0, mono).  N rebvo::REBVO objects whose configs name the same &GPU BatchGroup share ONE
+//    edgehip context of N sequences: the group's tracker thread takes the newest frame of every member's camera ring and runs them
+//    through one edgehip_process_frame (every kernel launch carries the N cameras), each object keeps its own ring, callback, log and
+//    getNav().  The members advance in lock-step — one frame of every running member per step, like a synchronised camera rig or a
+//    multi-sequence replay (BASELINE configs[4]); the group starts once BatchSize members have called Init() and a member that calls
+//    CleanUp() leaves it.  Camera buffers are page-locked and go to the device by asynchronous copies that run under the frames
+//    before (the reference's T0 || T1, rebvo_first_t.cpp:134 / rebvo_second_t.cpp:102); the host waits for a frame's record only
+//    when the next one is already enqueued (or no further frame is waiting), and KeyLines come back as AoS only for a member with a
+//    callback.  An object without a BatchGroup is a group of one: the same engine.
 #ifndef REBVO_AMD_HOST_REBVO_H
 #define REBVO_AMD_HOST_REBVO_H
 
@@ -242,6 +251,9 @@ struct REBVOParameters {
     double DoReScaling = 0;
     // extension: HIP device ordinal (optional config section &GPU, key Device)
     int GpuDevice = 0;
+    // extension: objects with the same non-empty GpuBatchGroup share one device context of GpuBatchSize sequences (&GPU BatchGroup / BatchSize)
+    std::string GpuBatchGroup;
+    int GpuBatchSize = 0;
 };
 
 // Filter state SecondThread keeps in the IMU branch (reference include/rebvo/rebvo.h:239-290, same member names).
@@ -331,6 +343,14 @@ class REBVO {
     struct ImuTrack;               // SecondThread's IMU-branch locals (rebvo_imu.cpp)
     ImuTrack *imutrack = nullptr;
     std::string last_error;
+    class BatchGroup;              // batch_group.cpp: the shared-context engine behind CameraType 3 / ImuMode 0 / mono objects
+    friend class BatchGroup;
+    BatchGroup *group = nullptr;
+    int group_seat = -1;
+    void *cam_pinned = nullptr;    // page-locked storage of the camera ring (custom camera), or null: plain heap images
+    bool groupAttach();            // Init() of such an object
+    void groupDetach();            // CleanUp()
+    bool useGroupEngine() const { return params.CameraType == 3 && params.ImuMode == 0 && !params.StereoAvaiable; }
 
     // the stereo rig SecondThread hard-codes (rebvo_second_t.cpp:466-470; EuRoC cam0 -> cam1)
     static const double kRCam2Pair[9], kTCam2Pair[3];

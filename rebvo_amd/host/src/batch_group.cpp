@@ -1,0 +1,416 @@
+// batch_group.cpp — one device context shared by N rebvo::REBVO objects (CameraType 3, ImuMode 0, mono), and the pipelined
+// frame loop behind them.  The plugin surface stays per object (requestCustomCamBuffer / releaseCustomCamBuffer,
+// setOutputCallback, getNav: include/rebvo/rebvo.h:548-609 of the reference); what FirstThr and SecondThread do per frame
+// (src/rebvo/rebvo_first_t.cpp:87-337, src/rebvo/rebvo_second_t.cpp:43-636) happens once per STEP for every member at once:
+//
+//   gather    the newest frame of every running member's camera ring (customcam.cpp:56-68: 1 ms time-outs; the soft-FPS drop
+//             of rebvo_first_t.cpp:146,172-177 per member)
+//   enqueue   N asynchronous copies out of the page-locked rings into the context's next slot (upload stream: they run under
+//             the kernels of the frames before), one edgehip_process_frame for all members
+//   release   the camera buffers, once the copies have read them (edgehip_upload_sync: the frames themselves are still running)
+//   complete  the PREVIOUS step: its per-sequence records out of the device's nav log (edgehip_read_nav_log waits for that frame
+//             only), NavData / PipeBuffer of every member, and the hand-off of the frame before to the member's output thread —
+//             with its KeyLines as AoS only if that member has a callback
+//
+// so the host works on step k-1's results while the device runs step k, and frame k+1 crosses PCIe under frame k: the
+// reference's T0 || T1.  When no further frame is waiting, the pending step is completed at once — a lone camera at 20 Hz sees
+// its record as soon as the frame is done, not a frame later.
+//
+// Hand-off order is the reference's (rebvo_second_t.cpp:622-623): frame j reaches a member's callback after frame j+1 has been
+// tracked against it, carrying its own record and its edge map as the tracker left it; the last frame is never delivered.
+#include <algorithm>
+#include <condition_variable>
+#include <cstring>
+#include <iostream>
+#include <map>
+#include <mutex>
+#include <thread>
+#include <vector>
+
+#include "edgehip.h"
+#include "rebvo/rebvo.h"
+#include "rebvo_internal.h"
+
+namespace rebvo {
+
+class REBVO::BatchGroup {
+public:
+    struct Seat {
+        REBVO *cf = nullptr;
+        bool running = false;      // attached, tracked by the group thread
+        bool closed = true;        // the group thread no longer touches cf
+        std::thread out_thread;    // the member's ThirdThread
+        customCam::CustomCamPipeBuffer *cbuf = nullptr;   // frame gathered for the step being assembled
+        double t_frame = 0, t0 = 0;
+        int p_num = 0;
+        long frames = 0;           // frames of this member enqueued so far
+        PipeBuffer *buf_enq = nullptr;    // PipeBuffer of the step in flight (released by player 0, not yet requested by player 1)
+        bool have_prev = false;    // a completed frame waits (as player 1's next buffer) for its successor before it is delivered
+        int slot_prev = -1;        // ring slot of that frame
+    };
+
+    std::string name;
+    int cap = 0, device = 0;
+    edgehip_params hp;
+    edgehip_ctx *hip = nullptr;
+    std::vector<Seat> seats;
+    int attached = 0;
+    std::thread thr;
+    std::mutex mut;
+    std::condition_variable cv;
+    bool started = false, failed = false;
+    std::string error;
+
+    // ---- registry of named groups ----
+    static std::mutex &regMutex() { static std::mutex m; return m; }
+    static std::map<std::string, BatchGroup *> &registry() { static std::map<std::string, BatchGroup *> r; return r; }
+
+    static constexpr int kNavLog = 8;
+
+    void threadMain();
+    bool gather(bool block, bool &any_running);
+    int enqueue(long step, std::vector<double> &ts, int &slot);
+    int complete(long step, int slot, std::vector<edgehip_nav> &navs);
+    void closeSeat(Seat &st);
+};
+
+// ---- attach / detach (application threads) -----------------------------------------------------------------------------
+bool REBVO::groupAttach() {
+    edgehip_params hp;
+    detail::fill_hip_params(params, hp);
+    hp.stereo_available = 0;
+    const bool named = !params.GpuBatchGroup.empty();
+    const int want = named ? params.GpuBatchSize : 1;
+    auto fail = [&](const std::string &msg) {
+        last_error = msg;
+        std::cout << last_error << "\n";
+        return false;
+    };
+    if (want < 1) return fail("REBVO(hip): &GPU BatchGroup needs BatchSize >= 1 (the number of objects that share the context)");
+    std::unique_lock<std::mutex> reg(BatchGroup::regMutex());
+    BatchGroup *g = nullptr;
+    if (named) {
+        auto it = BatchGroup::registry().find(params.GpuBatchGroup);
+        if (it != BatchGroup::registry().end()) g = it->second;
+    }
+    if (!g) {
+        g = new BatchGroup;
+        g->name = params.GpuBatchGroup;
+        g->cap = want;
+        g->device = params.GpuDevice;
+        g->hp = hp;
+        g->seats.resize(want);
+        // ring of 3 frame slots per sequence, `want` sequences.  No CPU fallback: fail loudly.
+        int rc = edgehip_create(&hp, want, 3, params.GpuDevice, &g->hip);
+        if (rc == 0) rc = edgehip_set_nav_log(g->hip, BatchGroup::kNavLog);
+        if (rc != 0) {
+            const std::string msg = std::string("REBVO(hip): edgehip_create failed: ") + edgehip_last_error();
+            if (g->hip) edgehip_destroy(g->hip);
+            delete g;
+            return fail(msg);
+        }
+        if (named) BatchGroup::registry()[g->name] = g;
+    } else {
+        if (g->cap != want || g->device != params.GpuDevice || std::memcmp(&g->hp, &hp, sizeof hp) != 0)
+            return fail("REBVO(hip): BatchGroup '" + g->name + "': every member needs the same BatchSize, Device, camera and detector / tracker parameters");
+    }
+    std::unique_lock<std::mutex> lk(g->mut);
+    if (g->started && g->attached >= g->cap) {
+        lk.unlock();
+        return fail("REBVO(hip): BatchGroup '" + g->name + "' is full (a group is made of the objects that Init() before it starts; nobody joins later)");
+    }
+    int seat = -1;
+    for (int i = 0; i < g->cap; i++)
+        if (!g->seats[i].cf) { seat = i; break; }
+    if (seat < 0 || g->started) {
+        lk.unlock();
+        return fail("REBVO(hip): BatchGroup '" + g->name + "' has no free seat");
+    }
+    BatchGroup::Seat &st = g->seats[seat];
+    st = BatchGroup::Seat();
+    st.cf = this;
+    st.running = true;
+    st.closed = false;
+    group = g;
+    group_seat = seat;
+    quit = false;
+    st.out_thread = std::thread(ThirdThread, this);
+    g->attached++;
+    if (g->attached == g->cap) {   // the group is complete: its tracker thread starts
+        g->started = true;
+        g->thr = std::thread([g] { g->threadMain(); });
+    }
+    return true;
+}
+
+void REBVO::groupDetach() {
+    BatchGroup *g = group;
+    if (!g) return;
+    BatchGroup::Seat &st = g->seats[group_seat];
+    bool last = false;
+    {
+        std::unique_lock<std::mutex> lk(g->mut);
+        if (!g->started) {
+            // the group never became complete: nobody is tracking this member; pass the quit flag down its ring ourselves
+            PipeBuffer &b = pipe.RequestBuffer(0);
+            b.quit = true;
+            pipe.ReleaseBuffer(0);
+            PipeBuffer &b1 = pipe.RequestBuffer(1);
+            b1.quit = true;
+            pipe.ReleaseBuffer(1);
+            st.running = false;
+            st.closed = true;
+        } else {
+            g->cv.wait(lk, [&] { return st.closed; });   // the group thread saw cf->quit and let go of this member
+        }
+    }
+    if (st.out_thread.joinable()) st.out_thread.join();
+    {
+        std::unique_lock<std::mutex> reg(BatchGroup::regMutex());
+        std::unique_lock<std::mutex> lk(g->mut);
+        st.cf = nullptr;
+        g->attached--;
+        last = g->attached == 0;
+        if (last && !g->name.empty()) BatchGroup::registry().erase(g->name);
+    }
+    group = nullptr;
+    group_seat = -1;
+    if (last) {   // the last member out stops the thread and frees the context
+        if (g->thr.joinable()) g->thr.join();
+        if (g->hip) edgehip_destroy(g->hip);
+        delete g;
+    }
+}
+
+// ---- the group's tracker thread -------------------------------------------------------------------------------------------
+void REBVO::BatchGroup::closeSeat(Seat &st) {
+    // shutdown of one member: the frame still held for it is not delivered (as in the reference); pass the quit flag on
+    REBVO *cf = st.cf;
+    if (st.cbuf) { cf->cam_pipe.ReleaseBuffer(1); st.cbuf = nullptr; }
+    if (st.frames == 0) {   // nothing ever went through player 0: open the ring for player 1
+        PipeBuffer &b = cf->pipe.RequestBuffer(0);
+        b.quit = true;
+        cf->pipe.ReleaseBuffer(0);
+    }
+    PipeBuffer &b1 = cf->pipe.RequestBuffer(1);   // the newest frame (completed or still in flight), or the flag carrier above
+    b1.quit = true;
+    cf->pipe.ReleaseBuffer(1);
+    cf->quit = true;
+    {
+        std::lock_guard<std::mutex> lk(mut);
+        st.running = false;
+        st.closed = true;
+    }
+    cv.notify_all();
+}
+
+// One frame of every running member, or false.  block: wait (in 1 ms slices, watching the quit flags) until they are all there;
+// otherwise a single pass.  Members that quit are closed here.
+bool REBVO::BatchGroup::gather(bool block, bool &any_running) {
+    while (true) {
+        bool all = true;
+        any_running = false;
+        for (Seat &st : seats) {
+            if (!st.running) continue;
+            REBVO *cf = st.cf;
+            if (cf->quit) { closeSeat(st); continue; }
+            any_running = true;
+            const double min_frame_dt = 1.0 / cf->params.soft_fps - 0.5 / cf->params.config_fps;   // rebvo_first_t.cpp:146
+            while (!st.cbuf) {
+                customCam::CustomCamPipeBuffer *cb = cf->cam_pipe.RequestBufferTimeoutable(1, block ? 0.001 : 0.0);
+                if (!cb) break;
+                st.p_num++;
+                if (cb->timestamp - st.t0 < min_frame_dt) { cf->cam_pipe.ReleaseBuffer(1); continue; }   // soft-FPS drop, :172-177
+                st.cbuf = cb;
+                st.t_frame = cb->timestamp;
+            }
+            if (!st.cbuf) all = false;
+        }
+        if (!any_running) return false;
+        if (all) return true;
+        if (!block) return false;
+    }
+}
+
+int REBVO::BatchGroup::enqueue(long step, std::vector<double> &ts, int &slot) {
+    slot = edgehip_next_slot(hip);
+    int rc = 0;
+    const double tp0 = detail::now_s();
+    for (int i = 0; i < cap && rc == 0; i++) {
+        Seat &st = seats[i];
+        if (!st.running) continue;   // a member that left: its sequence keeps running on whatever the slot holds, nobody reads it
+        REBVO *cf = st.cf;
+        const uint8_t *src = reinterpret_cast<const uint8_t *>(st.cbuf->img->Data());
+        rc = cf->cam_pinned ? edgehip_upload_rgb_pinned(hip, slot, src, i, 1) : edgehip_upload_rgb(hip, slot, src, i, 1);
+        ts[i] = st.t_frame;
+    }
+    if (rc == 0) rc = edgehip_process_frame(hip, ts.data());
+    if (rc != 0) return rc;
+    // the members' PipeBuffers of this step (player 0), and — while the copies run — the image for a callback's PipeBuffer::imgc
+    for (int i = 0; i < cap; i++) {
+        Seat &st = seats[i];
+        if (!st.running) continue;
+        REBVO *cf = st.cf;
+        PipeBuffer &nb = cf->pipe.RequestBuffer(0);
+        nb.t = st.t_frame;
+        nb.p_id = st.p_num - 1;
+        nb.quit = false;
+        nb.dtp0 = 0;
+        nb.dtp1 = tp0;   // start of the step; complete() turns it into the step's duration
+        if (cf->haveCallBack()) std::memcpy(nb.imgc->Data(), st.cbuf->img->Data(), (size_t)cf->params.ImageSize.w * cf->params.ImageSize.h * 3);
+        cf->pipe.ReleaseBuffer(0);
+        st.buf_enq = &nb;
+        st.t0 = st.t_frame;
+        if (cf->system_reset) {   // rebvo_second_t.cpp:609-620: behind this frame, before the next
+            rc = edgehip_depth_reset(hip, i);
+            cf->system_reset = false;
+            if (rc != 0) return rc;
+        }
+    }
+    // hand the camera buffers back as soon as the copies have read them (the frames are still being processed)
+    bool any_pinned = false;
+    for (Seat &st : seats) any_pinned |= st.running && st.cf->cam_pinned;
+    if (any_pinned && (rc = edgehip_upload_sync(hip)) != 0) return rc;
+    for (Seat &st : seats) {
+        if (!st.running) continue;
+        st.cf->cam_pipe.ReleaseBuffer(1);
+        st.cbuf = nullptr;
+        st.frames++;
+    }
+    (void)step;
+    return 0;
+}
+
+int REBVO::BatchGroup::complete(long step, int slot, std::vector<edgehip_nav> &navs) {
+    int rc = edgehip_read_nav_log(hip, (int)step, 1, navs.data());   // waits for this frame, not for the one enqueued behind it
+    if (rc != 0) return rc;
+    const double now = detail::now_s();
+    for (int i = 0; i < cap; i++) {
+        Seat &st = seats[i];
+        if (!st.running || !st.buf_enq) continue;
+        REBVO *cf = st.cf;
+        PipeBuffer &nb = *st.buf_enq;
+        st.buf_enq = nullptr;
+        const edgehip_nav &n = navs[i];
+        const bool first = !st.have_prev;   // this member's first frame: "dummy processing" (rebvo_second_t.cpp:108-121)
+        nb.dt = n.dt;
+        nb.K = 1; nb.Kp = n.Kp; nb.RKp = n.RKp;
+        nb.s_rho_p = n.s_rho_q;
+        nb.EstimationOK = n.estimation_ok != 0;
+        nb.ef->nmatch = n.klm_num;
+        nb.ef->reTunedThresh = n.retuned_thresh;
+        nb.ef->kn = n.kn;
+        if (!first) detail::fill_nav(n, nb.nav);
+        else nb.nav = NavData();
+        nb.stereo_match_num = 0;
+        nb.dtp1 = now - nb.dtp1;
+        if (!first) cf->pushNav(nb.nav);
+        if (st.have_prev) {   // the frame before goes to the output thread, with its edge map as this frame's tracking left it
+            PipeBuffer &ob = cf->pipe.RequestBuffer(1);
+            if (cf->haveCallBack()) {
+                int32_t kn = 0;
+                rc = edgehip_download_keylines(hip, i, st.slot_prev, reinterpret_cast<edgehip_keyline *>(ob.ef->kl.data()), nullptr, &kn);
+                if (rc != 0) {
+                    std::cout << "\nREBVO: edgehip_download_keylines failed: " << edgehip_last_error() << "\n";
+                    ob.ef->kn = 0;
+                    cf->pipe.ReleaseBuffer(1);
+                    return rc;
+                }
+                ob.ef->kn = kn;
+                const RGB24Pixel *c = ob.imgc->Data();   // Image<float>::ConvertRGB2BW (include/VideoLib/image.h:197-203)
+                float *bw = ob.img->Data();
+                for (uint k = 0; k < ob.img->bSize(); k++) bw[k] = (float)(c[k].pix.r + c[k].pix.g + c[k].pix.b);
+            }
+            cf->pipe.ReleaseBuffer(1);
+        }
+        st.have_prev = true;
+        st.slot_prev = slot;
+    }
+    return 0;
+}
+
+void REBVO::BatchGroup::threadMain() {
+    static_assert(sizeof(KeyLine) == sizeof(edgehip_keyline), "KeyLine mirrors edgehip_keyline");
+    std::vector<double> ts(cap, 0.0);
+    std::vector<edgehip_nav> navs(cap);
+    long step = 0;           // frames of the context enqueued so far
+    long pending = -1;       // step enqueued and not yet completed
+    int pending_slot = -1;
+    int rc = 0;
+    while (rc == 0) {
+        bool any = false;
+        // with a step in flight a single pass decides: either the next frames are all waiting (enqueue them under it), or its
+        // record is read now
+        bool ready = gather(pending < 0, any);
+        if (!ready && pending >= 0) {
+            rc = complete(pending, pending_slot, navs);
+            pending = -1;
+            continue;
+        }
+        if (!any) break;
+        if (!ready) continue;
+        int slot = -1;
+        rc = enqueue(step, ts, slot);
+        if (rc != 0) break;
+        if (pending >= 0) rc = complete(pending, pending_slot, navs);
+        pending = step;
+        pending_slot = slot;
+        step++;
+    }
+    if (rc == 0 && pending >= 0) rc = complete(pending, pending_slot, navs);
+    if (rc != 0) {
+        std::cout << "REBVO(hip): " << edgehip_last_error() << "\n";
+        std::lock_guard<std::mutex> lk(mut);
+        failed = true;
+        error = edgehip_last_error();
+    }
+    for (Seat &st : seats)
+        if (st.running) closeSeat(st);
+}
+
+}  // namespace rebvo
+
+// ---- flat C hook for the tests (ctypes): who may sit together -------------------------------------------------------------------
+// Builds objects from one GlobalConfig and tries to seat them in one group: same parameters and BatchSize -> accepted; another
+// tracker parameter, another BatchSize, or one object too many -> Init() returns false with the reason in lastError(), and the
+// group that is left incomplete (or running without frames) shuts down cleanly.  Returns 0 when every step went as it must,
+// otherwise the number of the step that did not.
+extern "C" int rebvo_group_selftest(const char *config_file) {
+    using namespace rebvo;
+    REBVO proto(config_file);
+    if (!proto.isInitOk()) return 1;
+    REBVOParameters p = proto.getParams();
+    p.CameraType = 3; p.ImuMode = 0; p.StereoAvaiable = false;
+    p.GpuBatchGroup = "selftest";
+    p.GpuBatchSize = 2;
+    REBVO a(p);
+    if (!a.Init()) return 2;                                   // first member: the context exists, the group waits for its partner
+    REBVOParameters q = p;
+    q.TrackerIterNum += 1;
+    REBVO b(q);
+    if (b.Init() || b.lastError().find("same") == std::string::npos) return 3;        // another tracker parameter
+    q = p;
+    q.GpuBatchSize = 3;
+    REBVO c(q);
+    if (c.Init() || c.lastError().find("same") == std::string::npos) return 4;        // another BatchSize
+    q = p;
+    q.ImuMode = 1;
+    REBVO d(q);
+    if (d.Init() || d.lastError().find("BatchGroup") == std::string::npos) return 5;  // a group member must be CameraType 3 / ImuMode 0 / mono
+    REBVO e(p);
+    if (!e.Init()) return 6;                                   // the partner: the group is complete and starts
+    REBVO f(p);
+    if (f.Init() || f.lastError().find("selftest") == std::string::npos) return 7;   // one too many: nobody joins a running group
+    if (!a.Running() || !e.Running()) return 8;
+    a.CleanUp();                                               // leaves; the group carries on with e alone
+    if (!e.Running()) return 9;
+    e.CleanUp();
+    REBVO g(p), h(p);                                          // the name is free again once the last member has gone
+    if (!g.Init() || !h.Init()) return 10;
+    g.CleanUp();
+    h.CleanUp();
+    p.GpuBatchSize = 0;
+    REBVO z(p);
+    if (z.Init()) return 11;                                   // a named group needs BatchSize >= 1
+    return 0;
+}

@@ -21,6 +21,7 @@
 
 #include "edgehip.h"
 #include "rebvo/datasetcam.h"
+#include "rebvo_internal.h"
 
 namespace rebvo {
 
@@ -92,6 +93,16 @@ public:
     }
 };
 
+// util::LieRot2Quaternion (include/UtilLib/toon_util.h:63-72)
+void lie2quat(const Vector3 &W, double q[4]) {
+    const double angle = std::sqrt(W[0] * W[0] + W[1] * W[1] + W[2] * W[2]);
+    for (int i = 0; i < 3; i++) q[i] = angle > 0 ? W[i] / angle * std::sin(angle / 2) : 0.0;
+    q[3] = std::cos(angle / 2);
+}
+
+}  // namespace
+
+namespace detail {
 double now_s() {
     return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count();
 }
@@ -121,14 +132,18 @@ void fill_hip_params(const REBVOParameters &p, edgehip_params &h) {
     h.use_undistort = p.useUndistort ? 1 : 0;
 }
 
-// util::LieRot2Quaternion (include/UtilLib/toon_util.h:63-72)
-void lie2quat(const Vector3 &W, double q[4]) {
-    const double angle = std::sqrt(W[0] * W[0] + W[1] * W[1] + W[2] * W[2]);
-    for (int i = 0; i < 3; i++) q[i] = angle > 0 ? W[i] / angle * std::sin(angle / 2) : 0.0;
-    q[3] = std::cos(angle / 2);
+void fill_nav(const edgehip_nav &n, NavData &nav) {
+    nav.t = n.t; nav.dt = n.dt; nav.scale = 1;
+    for (int i = 0; i < 3; i++) {
+        nav.RotLie[i] = n.RotLie[i]; nav.Vel[i] = n.Vel[i]; nav.PoseLie[i] = n.PoseLie[i]; nav.Pos[i] = n.Pos[i];
+        nav.RotGiro[i] = 0; nav.g[i] = 0;
+        for (int j = 0; j < 3; j++) { nav.Rot(i, j) = n.Rot[i * 3 + j]; nav.Pose(i, j) = n.Pose[i * 3 + j]; }
+    }
 }
-
-}  // namespace
+}  // namespace detail
+using detail::fill_hip_params;
+using detail::fill_nav;
+using detail::now_s;
 
 const double REBVO::kRCam2Pair[9] = {0.999997256477450, 0.002312067192420, 0.000376008102351,
                                      -0.002317135723285, 0.999898048506528, 0.014089835846697,
@@ -243,6 +258,8 @@ REBVO::REBVO(const char *configFile)
         p.StereoAvaiable = false;
     }
     config.get("GPU", "Device", p.GpuDevice, false);
+    config.get("GPU", "BatchGroup", p.GpuBatchGroup, false);
+    config.get("GPU", "BatchSize", p.GpuBatchSize, false);
     construct();
 }
 
@@ -282,8 +299,18 @@ void REBVO::construct() {
     }
     default: break;
     }
-    for (unsigned i = 0; i < cam_pipe.Size(); i++)   // rebvo.cpp:284-285
-        cam_pipe[i].img = std::make_shared<Image<RGB24Pixel>>(params.ImageSize);
+    // rebvo.cpp:284-285.  The custom camera's ring is page-locked when the device runtime is there (edgehip_alloc_pinned): the
+    // application's copyFrom() then writes where the asynchronous upload reads, and no staging copy exists.  Plain heap images
+    // otherwise (a host without a device: Init() will fail, the ring still works).
+    const size_t cam_frame_bytes = (size_t)params.ImageSize.w * params.ImageSize.h * sizeof(RGB24Pixel);
+    if (useGroupEngine() && edgehip_alloc_pinned(cam_frame_bytes * cam_pipe.Size(), &cam_pinned) != 0) cam_pinned = nullptr;
+    for (unsigned i = 0; i < cam_pipe.Size(); i++) {
+        if (cam_pinned)
+            cam_pipe[i].img = std::make_shared<Image<RGB24Pixel>>(
+                reinterpret_cast<RGB24Pixel *>(static_cast<uint8_t *>(cam_pinned) + cam_frame_bytes * i), params.ImageSize);
+        else
+            cam_pipe[i].img = std::make_shared<Image<RGB24Pixel>>(params.ImageSize);
+    }
     cam_stereo = cam;
     if (params.StereoAvaiable) {
         cam_stereo = cam_model({params.pp_x_stereo, params.pp_y_stereo}, {params.z_f_x_stereo, params.z_f_y_stereo}, params.kc_stereo,
@@ -303,6 +330,10 @@ void REBVO::construct() {
 
 REBVO::~REBVO() {
     if (!quit) CleanUp();
+    if (cam_pinned) {   // applications may still hold shared_ptrs to the ring's images: those are views, the storage goes with the object
+        edgehip_free_pinned(cam_pinned);
+        cam_pinned = nullptr;
+    }
     delete imu;
     if (InitOK)
         for (PipeBuffer &pbuf : pipe) {
@@ -333,6 +364,12 @@ bool REBVO::Init() {
     }
     if (params.ImuMode < 0 || params.ImuMode > 2) {
         last_error = "REBVO(hip): ImuMode must be 0, 1 (pushIMU) or 2 (IMU data set file)";
+        std::cout << last_error << "\n";
+        return false;
+    }
+    if (useGroupEngine()) return groupAttach();   // batch_group.cpp: the (possibly shared) context and its tracker thread
+    if (!params.GpuBatchGroup.empty()) {
+        last_error = "REBVO(hip): &GPU BatchGroup needs CameraType=3, ImuMode=0 and no stereo pair";
         std::cout << last_error << "\n";
         return false;
     }
@@ -371,6 +408,7 @@ bool REBVO::Init() {
 
 bool REBVO::CleanUp() {
     quit = true;
+    if (group) groupDetach();
     if (Thr0.joinable()) Thr0.join();
     if (hip) { edgehip_destroy(hip); hip = nullptr; }
     imuTrackFree();
@@ -380,15 +418,6 @@ bool REBVO::CleanUp() {
 }
 
 // ---- tracking thread ----------------------------------------------------------------------------------------
-static void fill_nav(const edgehip_nav &n, NavData &nav) {
-    nav.t = n.t; nav.dt = n.dt; nav.scale = 1;
-    for (int i = 0; i < 3; i++) {
-        nav.RotLie[i] = n.RotLie[i]; nav.Vel[i] = n.Vel[i]; nav.PoseLie[i] = n.PoseLie[i]; nav.Pos[i] = n.Pos[i];
-        nav.RotGiro[i] = 0; nav.g[i] = 0;
-        for (int j = 0; j < 3; j++) { nav.Rot(i, j) = n.Rot[i * 3 + j]; nav.Pose(i, j) = n.Pose[i * 3 + j]; }
-    }
-}
-
 void REBVO::TrackThread(REBVO *cf) {
     std::thread Thr2(ThirdThread, cf);
     const size_t frame_bytes = (size_t)cf->params.ImageSize.w * cf->params.ImageSize.h * 3;

@@ -1,0 +1,16 @@
+// rebvo_internal.h — helpers shared by the translation units of librebvohost (not installed)
+#ifndef REBVO_AMD_HOST_INTERNAL_H
+#define REBVO_AMD_HOST_INTERNAL_H
+#include "edgehip.h"
+#include "rebvo/rebvo.h"
+
+namespace rebvo {
+namespace detail {
+double now_s();
+// REBVOParameters -> the fields of edgehip_params that reach the hot path (include/rebvo/rebvo.h:64-235)
+void fill_hip_params(const REBVOParameters &p, edgehip_params &h);
+// edgehip_nav -> NavData, ImuMode 0 (rebvo_second_t.cpp:550-606)
+void fill_nav(const edgehip_nav &n, NavData &nav);
+}  // namespace detail
+}  // namespace rebvo
+#endif
