@@ -605,8 +605,8 @@ def host_surface(params, frames, w, h):
                                       ("objects_64_fps", 64, 36, 6, ["--group", "g64"]),
                                       ("objects_8_with_callbacks_fps", 8, 40, 8, ["--group", "g8cb", "--callback"])):
             try:
-                r = subprocess.run([exe, cfg, raw, str(len(frames)), str(n), str(k), "0", str(FRAME_DT), "--warmup", str(wm),
-                                    "--threads", str(min(8, n))] + extra, capture_output=True, text=True, timeout=240)
+                r = subprocess.run([exe, cfg, raw, str(len(frames)), str(n), str(k), "1", str(FRAME_DT), "--warmup", str(wm),
+                                    "--threads", str(min(8, n))] + extra, capture_output=True, text=True, timeout=90)
                 js = json.loads(r.stdout.strip().splitlines()[-1]) if r.returncode == 0 else None
                 if js is None:
                     raise RuntimeError(f"rc {r.returncode}: {(r.stdout + r.stderr)[-200:]}")

@@ -142,7 +142,7 @@ int main(int argn, char **argv) {
     for (auto &t : thr) t.join();
     // every object's record of its last frame
     const double t_last = t0 + dt * (K - 1);
-    const double deadline = now_s() + 120;
+    const double deadline = now_s() + 30;
     for (int i = 0; i < N && !bad; i++)
         while (i != leave_obj && obj[i]->getNav().t < t_last - 1e-9 * (1 + std::fabs(t_last))) {
             if (!obj[i]->Running() || now_s() > deadline) { bad = true; break; }

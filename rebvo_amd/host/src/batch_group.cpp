@@ -44,7 +44,8 @@ public:
         double t_frame = 0, t0 = 0;
         int p_num = 0;
         long frames = 0;           // frames of this member enqueued so far
-        PipeBuffer *buf_enq = nullptr;    // PipeBuffer of the step in flight (released by player 0, not yet requested by player 1)
+        PipeBuffer *buf_of[2] = {nullptr, nullptr};   // [step & 1] PipeBuffer of a step in flight (released by player 0, not yet requested by
+                                                      // player 1): step k + 1 is enqueued before step k is completed
         bool have_prev = false;    // a completed frame waits (as player 1's next buffer) for its successor before it is delivered
         int slot_prev = -1;        // ring slot of that frame
     };
@@ -259,7 +260,7 @@ int REBVO::BatchGroup::enqueue(long step, std::vector<double> &ts, int &slot) {
         nb.dtp1 = tp0;   // start of the step; complete() turns it into the step's duration
         if (cf->haveCallBack()) std::memcpy(nb.imgc->Data(), st.cbuf->img->Data(), (size_t)cf->params.ImageSize.w * cf->params.ImageSize.h * 3);
         cf->pipe.ReleaseBuffer(0);
-        st.buf_enq = &nb;
+        st.buf_of[step & 1] = &nb;
         st.t0 = st.t_frame;
         if (cf->system_reset) {   // rebvo_second_t.cpp:609-620: behind this frame, before the next
             rc = edgehip_depth_reset(hip, i);
@@ -277,7 +278,6 @@ int REBVO::BatchGroup::enqueue(long step, std::vector<double> &ts, int &slot) {
         st.cbuf = nullptr;
         st.frames++;
     }
-    (void)step;
     return 0;
 }
 
@@ -287,10 +287,10 @@ int REBVO::BatchGroup::complete(long step, int slot, std::vector<edgehip_nav> &n
     const double now = detail::now_s();
     for (int i = 0; i < cap; i++) {
         Seat &st = seats[i];
-        if (!st.running || !st.buf_enq) continue;
+        if (!st.running || !st.buf_of[step & 1]) continue;
         REBVO *cf = st.cf;
-        PipeBuffer &nb = *st.buf_enq;
-        st.buf_enq = nullptr;
+        PipeBuffer &nb = *st.buf_of[step & 1];
+        st.buf_of[step & 1] = nullptr;
         const edgehip_nav &n = navs[i];
         const bool first = !st.have_prev;   // this member's first frame: "dummy processing" (rebvo_second_t.cpp:108-121)
         nb.dt = n.dt;

@@ -23,6 +23,13 @@ def test_hip_matches_golden(path):
     frames = g["frames"]
     n, h, w = frames.shape
     eh = edgehip.EdgeHip(edgehip.euroc_params(w, h, debug_planes=1, **over), nseq=1, nslots=3)
+    # Attribution instead of a tolerance on the discrete results.  The only discrete decisions the reference itself leaves to
+    # rounding noise are those of KeyLines detected exactly on a half pixel whose re-projection at X = 0 rounds either way
+    # (oracle.half_pixel_keylines); tools/make_golden.py stores them per frame (`knife_edge`: frame, old
+    # KeyLine).  Up to the first such frame every match count and every match id must be the reference's; from it on, the
+    # counts may move by the number of such KeyLines and every differing id must sit on one of them or on a KeyLine it matched.
+    knife = [tuple(r) for r in g["knife_edge"].tolist()] if "knife_edge" in g.files else []
+    first_knife = min((k for k, _ in knife), default=None)
     for k in range(n):
         f = np.repeat(frames[k][:, :, None], 3, axis=2)
         eh.upload_rgb(eh.next_slot(), f)
@@ -40,7 +47,10 @@ def test_hip_matches_golden(path):
         step = np.linalg.norm(g["V"][k]) + np.linalg.norm(g["W"][k])
         assert np.allclose(nav.V[:], g["V"][k], rtol=0, atol=1e-6 * step + 1e-9)
         assert np.allclose(nav.W[:], g["W"][k], rtol=0, atol=1e-6 * step + 1e-9)
-        assert abs(nav.klm_num - g["klm_num"][k]) <= 2
+        if first_knife is None or k < first_knife:
+            assert nav.klm_num == g["klm_num"][k], f"frame {k}: {nav.klm_num} matches, the reference has {g['klm_num'][k]}, and no knife-edge KeyLine so far"
+        else:
+            assert abs(nav.klm_num - g["klm_num"][k]) <= sum(1 for kk, _ in knife if kk <= k)
         assert nav.estimation_ok == g["ok"][k]
     kl, mask = eh.download_keylines(0, eh.cur_slot())
     gk = np.frombuffer(g["last_keylines"].tobytes(), dtype=edgehip.KEYLINE_DTYPE)
@@ -48,7 +58,10 @@ def test_hip_matches_golden(path):
     for fld in ("p_inx", "m_m", "u_m", "n_m", "c_p", "p_m", "p_id", "n_id"):
         assert np.array_equal(kl[fld], gk[fld]), fld
     same = kl["m_id"] == gk["m_id"]
-    assert same.mean() > 0.995
+    if first_knife is None:
+        assert same.all(), f"match ids differ at KeyLines {np.where(~same)[0][:10]} ({(~same).sum()} of {len(same)}) with no knife-edge KeyLine in the sequence"
+    else:
+        assert (~same).sum() <= 4 * len(knife), f"{(~same).sum()} match ids differ, {len(knife)} knife-edge KeyLines in the sequence"
     assert np.allclose(kl["rho"][same], gk["rho"][same], rtol=1e-6, atol=1e-8)
     if "kf_X" in g.files:
         # key-frame tracker against the reference's results stored with the fixture (tools/make_golden.py): the previous

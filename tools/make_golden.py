@@ -31,11 +31,16 @@ def make(name, w, h, frames, **over):
     rec = dict(kn=[], tresh=[], retuned=[], mask_sha=[], dog_sha=[], img0_sha=[], V=[], W=[], Pos=[], klm_num=[],
                klm_fwd=[], s_rho_q=[], Kp=[], RKp=[], ok=[], score=[])
     prev = -1
+    op = orc.p
+    knife = []      # (frame, old KeyLine) pairs whose first TryVelRot evaluation the reference's own rounding noise decides
     for k, f in enumerate(frames):
         if k == len(frames) - 1:
             prev = orc.cur_slot()
+        old = orc.keylines(orc.cur_slot()).copy() if k else None
         _, nav = orc.process_frame(f, 0.05 * k)
         s = orc.cur_slot()
+        if k:
+            knife += [(k, i) for i, _ in oracle.half_pixel_keylines(old, orc.field(s)[:, :, 1], op.ppx, op.ppy, nav.s_rho_q, op.w, op.h)]
         rec["kn"].append(nav.kn); rec["tresh"].append(nav.tresh); rec["retuned"].append(nav.retuned_thresh)
         rec["mask_sha"].append(sha(orc.mask(s))); rec["dog_sha"].append(sha(orc.plane(s, "dog")))
         rec["img0_sha"].append(sha(orc.plane(s, "img0")))
@@ -50,6 +55,7 @@ def make(name, w, h, frames, **over):
     out["last_mask"] = orc.mask(s).astype(np.int32)
     out["frames"] = np.stack([f[:, :, 0] for f in frames]).astype(np.uint8)  # r=g=b
     out["over"] = np.array(repr(sorted(over.items())))
+    out["knife_edge"] = np.array(knife, dtype=np.int32).reshape(-1, 2)
     # key-frame tracker (kfvo::Minimizer_RV_KF): the previous frame's KeyLines against the field of the last
     # frame's, with the arguments kfvo::OptimizePosGT passes (kfvo.cpp:74) and two start poses
     kf = dict(X=[], RRV=[], ratio=[], mnum=[], mid_sha=[])
@@ -61,7 +67,7 @@ def make(name, w, h, frames, **over):
         out["kf_" + k2] = np.array(v)
     path = os.path.join(ROOT, "tests", "golden", name + ".npz")
     np.savez_compressed(path, **out)
-    print(name, "kn", rec["kn"], "klm", rec["klm_num"], os.path.getsize(path), "bytes")
+    print(name, "kn", rec["kn"], "klm", rec["klm_num"], "knife-edge (frame, KeyLine):", knife, os.path.getsize(path), "bytes")
 
 
 if __name__ == "__main__":
