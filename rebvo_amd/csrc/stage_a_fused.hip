@@ -861,7 +861,13 @@ int stage_a_fused_enqueue(edgehip_ctx *c, int slot, const uint8_t *rgb_base, con
 #else
     a.ablate = 0;
 #endif
-    const size_t sm = fused_lds_bytes(pl.w);
+    size_t sm = fused_lds_bytes(pl.w);
+#ifdef EDGEHIP_EXPERIMENTS
+    // occupancy experiment (tools/experiments/exp_fused_occupancy.sh): at narrow widths two workgroups fit a CU's LDS; unused dynamic
+    // LDS on top forces one per CU again, so the same kernel can be timed at one and at two resident workgroups per CU
+    static const size_t lds_pad = getenv("EDGEHIP_FUSED_LDS_PAD") ? (size_t)atoi(getenv("EDGEHIP_FUSED_LDS_PAD")) : 0;
+    if (sm + lds_pad <= 160 * 1024) sm += lds_pad;
+#endif
     a.grey16 = grey16;
     a.grey8 = grey8;
     a.und_base = undist_in_load ? c->und_base : nullptr;

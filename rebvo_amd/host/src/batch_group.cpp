@@ -46,6 +46,7 @@ public:
         long frames = 0;           // frames of this member enqueued so far
         PipeBuffer *buf_of[2] = {nullptr, nullptr};   // [step & 1] PipeBuffer of a step in flight (released by player 0, not yet requested by
                                                       // player 1): step k + 1 is enqueued before step k is completed
+        bool leaving = false;      // cf->quit seen: the seat closes once the step in flight (which may carry its last frame) is done
         bool have_prev = false;    // a completed frame waits (as player 1's next buffer) for its successor before it is delivered
         int slot_prev = -1;        // ring slot of that frame
     };
@@ -69,7 +70,7 @@ public:
     static constexpr int kNavLog = 8;
 
     void threadMain();
-    bool gather(bool block, bool &any_running);
+    bool gather(bool block, bool &any_running, bool &any_leaving);
     int enqueue(long step, std::vector<double> &ts, int &slot);
     int complete(long step, int slot, std::vector<edgehip_nav> &navs);
     void closeSeat(Seat &st);
@@ -206,15 +207,18 @@ void REBVO::BatchGroup::closeSeat(Seat &st) {
 }
 
 // One frame of every running member, or false.  block: wait (in 1 ms slices, watching the quit flags) until they are all there;
-// otherwise a single pass.  Members that quit are closed here.
-bool REBVO::BatchGroup::gather(bool block, bool &any_running) {
+// otherwise a single pass.  A member whose quit flag is up is marked `leaving` and the call returns at once: the caller finishes
+// the step in flight — that member's last submitted frame may be in it, and a frame that was taken from the ring is tracked to
+// the end, as in the reference, where CleanUp() joins a thread that is never interrupted inside a frame — and closes the seat.
+bool REBVO::BatchGroup::gather(bool block, bool &any_running, bool &any_leaving) {
     while (true) {
         bool all = true;
         any_running = false;
+        any_leaving = false;
         for (Seat &st : seats) {
             if (!st.running) continue;
             REBVO *cf = st.cf;
-            if (cf->quit) { closeSeat(st); continue; }
+            if (cf->quit) { st.leaving = true; any_leaving = true; continue; }
             any_running = true;
             const double min_frame_dt = 1.0 / cf->params.soft_fps - 0.5 / cf->params.config_fps;   // rebvo_first_t.cpp:146
             while (!st.cbuf) {
@@ -227,7 +231,7 @@ bool REBVO::BatchGroup::gather(bool block, bool &any_running) {
             }
             if (!st.cbuf) all = false;
         }
-        if (!any_running) return false;
+        if (any_leaving || !any_running) return false;
         if (all) return true;
         if (!block) return false;
     }
@@ -338,13 +342,18 @@ void REBVO::BatchGroup::threadMain() {
     int pending_slot = -1;
     int rc = 0;
     while (rc == 0) {
-        bool any = false;
+        bool any = false, leaving = false;
         // with a step in flight a single pass decides: either the next frames are all waiting (enqueue them under it), or its
         // record is read now
-        bool ready = gather(pending < 0, any);
+        bool ready = gather(pending < 0, any, leaving);
         if (!ready && pending >= 0) {
             rc = complete(pending, pending_slot, navs);
             pending = -1;
+            if (rc != 0) break;
+        }
+        if (leaving) {   // (nothing of theirs is in flight any more)
+            for (Seat &st : seats)
+                if (st.running && st.leaving) closeSeat(st);
             continue;
         }
         if (!any) break;

@@ -3,8 +3,10 @@ sys.path.insert(0, '.')
 import numpy as np
 from rebvo_amd import edgehip, synth
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 1
-frames = [f for f, _, _ in synth.billboard_sequence(752, 480, 3)]
-eh = edgehip.EdgeHip(edgehip.euroc_params(), nseq=B, nslots=2)
+W = int(sys.argv[2]) if len(sys.argv) > 2 else 752
+H = int(sys.argv[3]) if len(sys.argv) > 3 else 480
+frames = [f for f, _, _ in synth.billboard_sequence(W, H, 3)]
+eh = edgehip.EdgeHip(edgehip.euroc_params(W, H), nseq=B, nslots=2)
 for k in range(2):
     eh.upload_rgb(k, np.stack([frames[k]] * B))
 for it in range(3):
