@@ -152,6 +152,9 @@ int edgehip_create(const edgehip_params *params, int nseq, int nslots, int devic
 int edgehip_destroy(edgehip_ctx *ctx);
 const char *edgehip_last_error(void);
 int edgehip_abi_version(void);
+/* 1 if the library was built with `make EXPERIMENTS=1`: it then also holds the alternative kernels that measured slower than the
+ * defaults and reads their EDGEHIP_* switches (timing experiments; the tests of those paths need such a build). */
+int edgehip_experiments(void);
 /* Block the caller until everything enqueued so far has finished. */
 int edgehip_sync(edgehip_ctx *ctx);
 /* The hipStream_t the tracker / mapper kernels (and, for whole batches, everything) are launched on, as an opaque pointer (for event

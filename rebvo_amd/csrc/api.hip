@@ -88,6 +88,18 @@ void enter_ctx(edgehip_ctx *c) {
     (void)hipGetLastError();
 }
 
+// Alternatives that were built, measured slower than (or equal to) what runs by default, and kept for A/B measurements — the
+// global-atomic field scatter (EDGEHIP_FIELD_MODE=1), the two other arrangements of FordwardMatch / rotate_keylines
+// (EDGEHIP_FWD_MODE=1,2), two KeyLines per thread in the reweighted evaluation (EDGEHIP_TVR_RW2), evaluation + LM step in one launch
+// (EDGEHIP_PERSIST_LM), the undistortion inside the one-kernel stage A's load (EDGEHIP_FUSED_UNDIST), disjoint CU sets for the two
+// streams (EDGEHIP_A_CUS) — are compiled only by `make EXPERIMENTS=1`; the default library neither contains them nor reads their
+// switches (edgehip_experiments() says which build this is).
+#ifdef EDGEHIP_EXPERIMENTS
+#define EH_EXP_ENV(name, dflt) (getenv(name) ? atoi(getenv(name)) : (dflt))
+#else
+#define EH_EXP_ENV(name, dflt) (dflt)
+#endif
+
 static const char *kProfNames[PROF_COUNT] = {
     "A.rgb_rowscan", "A.colscan", "A.avg_rowscan", "A.detect", "A.compact", "A.join_retune",
     "B.quantile", "B.build_field", "B.tvr_prepare", "B.try_velrot", "B.lm_step",
@@ -335,8 +347,12 @@ int edgehip_create(const edgehip_params *params, int nseq, int nslots, int devic
     EH_CHECK(hipSetDevice(device));
     {   // the kernels are written for gfx950: k_stage_a_fused and k_rescale opt into 128-160 KB of LDS per workgroup and have no
         // smaller form — a device without it is refused here instead of failing at the first frame
-        int lds_max = 0;
+        // (stacks that report only the default, non-opt-in limit under MaxSharedMemoryPerBlock: the opt-in figure counts too — the
+        // kernels obtain their LDS through hipFuncAttributeMaxDynamicSharedMemorySize)
+        int lds_max = 0, lds_optin = 0;
         (void)hipDeviceGetAttribute(&lds_max, hipDeviceAttributeMaxSharedMemoryPerBlock, device);
+        if (hipDeviceGetAttribute(&lds_optin, hipDeviceAttributeSharedMemPerBlockOptin, device) != hipSuccess) { (void)hipGetLastError(); lds_optin = 0; }
+        if (lds_optin > lds_max) lds_max = lds_optin;
         if (lds_max > 0 && lds_max < 160 * 1024) {
             set_error("edgehip_create: device " + std::to_string(device) + " offers " + std::to_string(lds_max) +
                       " B of LDS per workgroup; libedgehip is built for MI355X / gfx950 (160 KB)");
@@ -389,7 +405,7 @@ static int create_body(edgehip_ctx *c, CtxAllocs *al, const edgehip_params &p, i
     const int ovl_below = fused_min_env > ncu_dev ? fused_min_env : ncu_dev;
     const bool ovl = getenv("EDGEHIP_OVERLAP") ? atoi(getenv("EDGEHIP_OVERLAP")) != 0 : (nseq < ovl_below && !c->use_graph);
     c->overlap = ovl ? 1 : 0;
-    const int a_cus = (ovl && getenv("EDGEHIP_A_CUS")) ? atoi(getenv("EDGEHIP_A_CUS")) : 0;
+    const int a_cus = ovl ? EH_EXP_ENV("EDGEHIP_A_CUS", 0) : 0;
     if (a_cus > 0) {
         hipDeviceProp_t prop;
         EH_CHECK(hipGetDeviceProperties(&prop, device));
@@ -500,17 +516,17 @@ static int create_body(edgehip_ctx *c, CtxAllocs *al, const edgehip_params &p, i
         EH_TRY(dmalloc(c, &c->bins, B * ntiles * CAP, al->dev));
     }
     c->field_radius = p.search_range;
-    c->field_mode = getenv("EDGEHIP_FIELD_MODE") ? atoi(getenv("EDGEHIP_FIELD_MODE")) : 0;
+    c->field_mode = EH_EXP_ENV("EDGEHIP_FIELD_MODE", 0);
     c->no_grec = getenv("EDGEHIP_NO_GREC") && atoi(getenv("EDGEHIP_NO_GREC")) != 0;
     c->level_mode = getenv("EDGEHIP_LEVEL_MODE") ? atoi(getenv("EDGEHIP_LEVEL_MODE")) : 0;
-    c->fwd_mode = getenv("EDGEHIP_FWD_MODE") ? atoi(getenv("EDGEHIP_FWD_MODE")) : 0;
+    c->fwd_mode = EH_EXP_ENV("EDGEHIP_FWD_MODE", 0);
     c->fused_min_batch = fused_min_env;   // one workgroup per sequence: pays from about 3/4 of the 256 CUs on (tools/experiments/ab_level_mode.sh)
     // measured at 1024 sequences (tools/experiments/gpu_r04_j.sh, same box, three rounds): the step 10.53 / 10.50 / 10.43 ms without, 10.48 / 10.39 / 10.39 ms with —
     // inside the run-to-run spread, while the group's own HIP-event time went UP (2.62 -> 2.73 ms: 84 registers, 5 waves per SIMD).  Off by default.
-    c->fused_undist = getenv("EDGEHIP_FUSED_UNDIST") && atoi(getenv("EDGEHIP_FUSED_UNDIST")) != 0;
-    c->tvr_rw2 = getenv("EDGEHIP_TVR_RW2") ? atoi(getenv("EDGEHIP_TVR_RW2")) : 0;
+    c->fused_undist = EH_EXP_ENV("EDGEHIP_FUSED_UNDIST", 0) != 0;
+    c->tvr_rw2 = EH_EXP_ENV("EDGEHIP_TVR_RW2", 0);
     c->dual_init = getenv("EDGEHIP_DUAL_INIT") ? atoi(getenv("EDGEHIP_DUAL_INIT")) : 1;
-    c->persist_lm_max = getenv("EDGEHIP_PERSIST_LM") ? atoi(getenv("EDGEHIP_PERSIST_LM")) : 0;   // measured: no gain (tools/experiments/exp_single_latency.py), so off
+    c->persist_lm_max = EH_EXP_ENV("EDGEHIP_PERSIST_LM", 0);   // measured: no gain (tools/experiments/exp_single_latency.py), so off
     EH_TRY(dmalloc(c, &c->sync_cnt, B, al->dev, 0));
     EH_TRY(dmalloc(c, &c->fwd_key, B * CAP, al->dev, 0));
     EH_TRY(dmalloc(c, &c->fwd_win, B * CAP, al->dev, 0xFF));
@@ -1238,6 +1254,13 @@ int edgehip_profile_select(edgehip_ctx *c, uint64_t mask) {
     return 0;
 }
 int edgehip_profile_count(void) { return PROF_COUNT; }
+int edgehip_experiments(void) {
+#ifdef EDGEHIP_EXPERIMENTS
+    return 1;
+#else
+    return 0;
+#endif
+}
 const char *edgehip_profile_name(int i) { return (i >= 0 && i < PROF_COUNT) ? kProfNames[i] : ""; }
 int edgehip_profile_read(edgehip_ctx *c, double *ms, int64_t *calls) {
     EH_ENTER(c);

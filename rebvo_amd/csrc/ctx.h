@@ -251,7 +251,7 @@ struct edgehip_ctx {
     int field_mode;        // 0 = binned tiles (default), 1 = global-atomic scatter, 2 = mask-scan tiles (A/B)
     int level_mode;        // stage A: 0 = auto (fused kernel from fused_min_batch sequences on, else one-pass k_level when >= 192 planes in flight), 1 = multi-pass, 2 = k_level, 3 = fused
     int fused_min_batch;   // EDGEHIP_FUSED_MIN_BATCH
-    double pinv_host[75];  // plane-fit pseudo inverse (kernel argument of the fused stage A)
+    double pinv_host[3 * 49];  // plane-fit pseudo inverse, host copy: 3 x (2 ws + 1)^2 values, ws <= 3 (the fused stage A reads the 5x5 one)
     int32_t *bin_cnt;      // [B][256] KeyLines binned per field tile
     int32_t *bins;         // [B][256][CAP] KeyLine ids per field tile (allocated for the tiles in use)
     int nblk_tvr;

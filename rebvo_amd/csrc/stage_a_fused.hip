@@ -876,11 +876,16 @@ int stage_a_fused_enqueue(edgehip_ctx *c, int slot, const uint8_t *rgb_base, con
     // plane), any other width — and contexts with debug planes — the generic ones
 #define EH_FUSED(WW, DBG, SRC) k_stage_a_fused<WW, DBG, SRC, kFusedRB, 3, 3, 5, 5, 5>
     void (*fn)(FusedArgs);
+#ifdef EDGEHIP_EXPERIMENTS   // the undistortion inside this kernel's load: measured 14 % slower than the pre-pass (EDGEHIP_FUSED_UNDIST)
     if (undist_in_load) {
         fn = EH_FUSED(0, false, SRC_UNDIST);
         if (c->planes) fn = EH_FUSED(0, true, SRC_UNDIST);
         else if (pl.w == 640) fn = EH_FUSED(640, false, SRC_UNDIST);
-    } else if (grey16) {
+    } else
+#else
+    if (undist_in_load) { set_error("stage A: the undistortion inside the one-kernel load is an EXPERIMENTS build option"); return EDGEHIP_ERR_STATE; }
+#endif
+    if (grey16) {
         fn = EH_FUSED(0, false, SRC_GREY16);
         if (c->planes) fn = EH_FUSED(0, true, SRC_GREY16);
         else if (pl.w == 640) fn = EH_FUSED(640, false, SRC_GREY16);
@@ -895,8 +900,11 @@ int stage_a_fused_enqueue(edgehip_ctx *c, int slot, const uint8_t *rgb_base, con
         else if (pl.w == 640) fn = EH_FUSED(640, false, SRC_RGB24);
     }
     if (!c->lds_optin_fused) {
-        const void *fns[13] = {(const void *)EH_FUSED(0, false, SRC_UNDIST), (const void *)EH_FUSED(0, true, SRC_UNDIST),
+        const void *fns[] = {
+#ifdef EDGEHIP_EXPERIMENTS
+                               (const void *)EH_FUSED(0, false, SRC_UNDIST), (const void *)EH_FUSED(0, true, SRC_UNDIST),
                                (const void *)EH_FUSED(640, false, SRC_UNDIST),
+#endif
                                (const void *)EH_FUSED(0, false, SRC_RGB24), (const void *)EH_FUSED(0, true, SRC_RGB24),
                                (const void *)EH_FUSED(752, false, SRC_RGB24), (const void *)EH_FUSED(640, false, SRC_RGB24),
                                (const void *)EH_FUSED(0, false, SRC_GREY16), (const void *)EH_FUSED(0, true, SRC_GREY16),

@@ -139,6 +139,7 @@ __global__ __launch_bounds__(NT) void k_quantile(const KlSoA *kls, const int32_t
     }
 }
 
+#ifdef EDGEHIP_EXPERIMENTS   // reference-shaped scatter with global atomics: A/B measurements only (EDGEHIP_FIELD_MODE=1)
 // ---------------------------------------------------------------------------------------------------
 // build_field: thread per (KeyLine, t) pair, t in [-r, r)
 // ---------------------------------------------------------------------------------------------------
@@ -163,6 +164,7 @@ __global__ __launch_bounds__(256) void k_field_scatter(const KlSoA *kls, const i
     const uint32_t at = (uint32_t)(t < 0 ? -t : t);
     atomicMin(&field[(size_t)seq * fstride + field_index(xi, yi, ftx)], (at << 16) | (uint32_t)(0xFFFF - ikl));
 }
+#endif   // EDGEHIP_EXPERIMENTS
 
 // ---------------------------------------------------------------------------------------------------
 // build_field, tiled: one block per FT x FT pixel tile.  The per-pixel result of the sequential scatter is
@@ -1272,6 +1274,7 @@ __device__ __forceinline__ void tvr2_body(const TvrArgs &a, const int seq, const
     }
 }
 
+#ifdef EDGEHIP_EXPERIMENTS   // two KeyLines per thread in the reweighted evaluation: measured no faster (EDGEHIP_TVR_RW2)
 // ---------------------------------------------------------------------------------------------------
 // The reweighted evaluation with TWO KeyLines per thread (whole batches): thread t of block b owns KeyLines 512 b + t and
 // 512 b + 256 + t and walks them level by level like tvr2_body walks its two chains — both KeyLines' streams, then both field
@@ -1518,6 +1521,7 @@ template <bool GREC>
 __global__ __launch_bounds__(kTvrThreads) void k_try_velrot_rw2(TvrArgs a) {
     tvr_rw2_body<GREC>(a, blockIdx.z, blockIdx.x, threadIdx.x);
 }
+#endif   // EDGEHIP_EXPERIMENTS
 
 #ifndef EDGEHIP_TVR2_WAVES
 #define EDGEHIP_TVR2_WAVES 0   // > 0: occupancy the two-chain evaluation is compiled for (waves per SIMD), A/B experiments
@@ -2207,6 +2211,7 @@ __global__ __launch_bounds__(256) void k_tvr_prepare_begin(const int32_t *__rest
     if (blockIdx.x == 0 && threadIdx.x < 64) lm_body<true>(l, seq, threadIdx.x);   // l.kn_src = kns: the state's kn_old
 }
 
+#ifdef EDGEHIP_EXPERIMENTS   // evaluation + LM step in one launch for small batches: measured no faster (EDGEHIP_PERSIST_LM)
 // ---------------------------------------------------------------------------------------------------
 // k_try_velrot_lm: an evaluation and the LM step that follows it in ONE launch, for small batches.  A single camera (or
 // one sequence per GPU, BASELINE config 5) is bound by the chain of dependent launches of the minimiser (evaluate -> LM
@@ -2234,6 +2239,7 @@ __global__ __launch_bounds__(kTvrThreads) void k_try_velrot_lm(TvrArgs a, LmArgs
     lm_body<true>(l, seq, tid);
     if (tid == 0) cnt[seq] = 0;                                    // for the next launch (stream order)
 }
+#endif   // EDGEHIP_EXPERIMENTS
 
 // ---------------------------------------------------------------------------------------------------
 // IMU-branch tracker: global_tracker::TryVel<double> + Calc_f_J (global_tracker.cpp:830-934, 178-219) and
@@ -2630,12 +2636,17 @@ int build_field_enqueue(edgehip_ctx *c, int slot, int radius, float min_mod, boo
         hipLaunchKernelGGL(k_field_tiles, dim3((pl.w + FT - 1) / FT, (pl.h + FT - 1) / FT, pl.nseq), dim3(256), 0, c->stream,
                            kldev(c, slot), maskof(c, slot), c->retuned_slot + (size_t)slot * pl.nseq, c->field, pl.w, pl.h,
                            pl.fstride, pl.ftx, radius, min_mod);
-    } else {  // reference-shaped scatter with global atomics (kept for A/B measurements: EDGEHIP_FIELD_MODE=1)
+    } else {
+#ifdef EDGEHIP_EXPERIMENTS   // reference-shaped scatter with global atomics (EDGEHIP_FIELD_MODE=1)
         EH_CHECK(hipMemsetAsync(c->field, 0xFF, sizeof(uint32_t) * pl.nseq * pl.fstride, c->stream));
         const long long threads = (long long)pl.cap * 2 * radius;
         hipLaunchKernelGGL(k_field_scatter, dim3((unsigned)((threads + 255) / 256), 1, pl.nseq), dim3(256), 0, c->stream,
                            kldev(c, slot), c->kn_slot + (size_t)slot * pl.nseq, c->retuned_slot + (size_t)slot * pl.nseq,
                            c->field, pl.w, pl.h, pl.fstride, pl.ftx, radius, min_mod);
+#else
+        set_error("build_field: unknown field mode");
+        return EDGEHIP_ERR_STATE;
+#endif
     }
     EH_LAUNCH_CHECK();
     // the other two builders produce the {dist, ikl} field; the tracker's index plane is derived from it
@@ -2693,6 +2704,7 @@ static int launch_tvr(edgehip_ctx *c, const TvrArgs &a, bool reweight, bool proc
     dim3 g(c->nblk_tvr, 1, c->plan.nseq), b(kTvrThreads);
     // whole batches: the reweighted evaluation with two KeyLines per thread (tvr_rw2_body); a few sequences keep one KeyLine per
     // thread (half the blocks would leave most CUs idle, and a block's own latency is what a single camera waits for)
+#ifdef EDGEHIP_EXPERIMENTS
     if (reweight && procjf && c->tvr_rw2 && (size_t)c->nblk_tvr * c->plan.nseq >= (size_t)c->tvr_rw2) {
         dim3 g2((c->nblk_tvr + 1) / 2, 1, c->plan.nseq);
         if (a.use_grec) hipLaunchKernelGGL((k_try_velrot_rw2<true>), g2, b, 0, c->stream, a);
@@ -2700,6 +2712,7 @@ static int launch_tvr(edgehip_ctx *c, const TvrArgs &a, bool reweight, bool proc
         EH_LAUNCH_CHECK();
         return 0;
     }
+#endif
 #ifdef EDGEHIP_EXPERIMENTS
     // occupancy experiment (tools/experiments): unused dynamic LDS per block caps the resident blocks per CU
     static const size_t dyn_lds = getenv("EDGEHIP_TVR_LDS") ? (size_t)atoi(getenv("EDGEHIP_TVR_LDS")) : 0;
@@ -2837,6 +2850,10 @@ int minimizer_enqueue(edgehip_ctx *c, int slot_new, int slot_old, int fc_index) 
     };
     auto launch_lm = [&](edgehip_ctx *cc, int sn, unsigned ops) -> int {   // shadows the free function
         if (!held.on) return edgehip::launch_lm(cc, sn, ops);
+#ifndef EDGEHIP_EXPERIMENTS
+        set_error("minimizer: the fused evaluation + step launch is an EXPERIMENTS build option");
+        return EDGEHIP_ERR_STATE;
+#else
         held.on = false;
         ProfScope ps(c, PROF_B_MINIMIZER);
         TvrArgs a = make_tvr_args(c, slot_new, slot_old, p.tracker_match_thresh, p.reweight_distance, p.match_num_thresh, held.write_mid);
@@ -2858,6 +2875,7 @@ int minimizer_enqueue(edgehip_ctx *c, int slot_new, int slot_old, int fc_index) 
 #undef EH_TVLM
         EH_LAUNCH_CHECK();
         return 0;
+#endif
     };
 #define EH_TRY(x) if ((e = (x)) != 0) return e
     if (two_chains) {

@@ -251,6 +251,7 @@ int rec_refresh_enqueue(edgehip_ctx *c, int slot) {
     return 0;
 }
 
+#ifdef EDGEHIP_EXPERIMENTS   // FordwardMatch + rotate_keylines in one scattering pass: EDGEHIP_FWD_MODE=2, measured slower than the one-pass matching
 // FordwardMatch's copy (edge_tracker.cpp:396-432) and rotate_keylines (:42-76) in ONE pass over the OLD KeyLines.  The
 // reference copies first (old values), then rotates the old list in place; a thread that owns old KeyLine i does both for
 // its own KeyLine: if it is the winner of its target (win[f] == i, decided by k_fwd_win before this launch) it scatters its
@@ -306,6 +307,7 @@ __global__ __launch_bounds__(256) void k_fwd_apply_rotate(const KlSoA *kl_old, c
     const int cnt = __popcll(__ballot(hit));
     if ((threadIdx.x & 63) == 0 && cnt) atomicAdd(&seqs[seq].pub.klm_fwd, cnt);
 }
+#endif   // EDGEHIP_EXPERIMENTS
 
 // TooN SO3 exp / ln (so3.h:203-285, 288-334), device copies used by the frame glue
 __device__ inline void so3_exp_c(const double w[3], double R[9]) {
@@ -1172,6 +1174,7 @@ int forward_match_enqueue(edgehip_ctx *c, int slot_old, int slot_new, bool keys_
     return 0;
 }
 
+#ifdef EDGEHIP_EXPERIMENTS
 // Whole-frame driver, ImuMode == 0 (rebvo_second_t.cpp:354-369): FordwardMatch + R0 = exp(W) + rotate_keylines(R0).  The
 // arbitration keys were posted by the minimiser's last evaluation (TvrArgs::fwd_key; cleared in minimizer_enqueue).
 int forward_rotate_enqueue(edgehip_ctx *c, int slot_old, int slot_new) {
@@ -1195,6 +1198,14 @@ int forward_rotate_enqueue(edgehip_ctx *c, int slot_old, int slot_new) {
                        c->rot_buf, pl.zfm, pl.cap);
     EH_LAUNCH_CHECK();
     return 0;
+}
+#endif   // EDGEHIP_EXPERIMENTS
+
+// Does the whole-frame driver (ImuMode 0) match this frame in one pass — rotate_keylines out of place, FordwardMatch's copy inside
+// k_directed_fused?  ONE definition for frame_enqueue and for the graph replay's bookkeeping of rot_pending: the flag must say what
+// the captured launches did.
+static inline bool frame_matches_in_one_pass(const edgehip_ctx *c, int slot_pair) {
+    return c->fuse_match && c->fwd_mode == 0 && slot_pair < 0 && !c->p.stereo_available;
 }
 
 // Matching in one pass, the old KeyLines' side: FordwardMatch's arbitration (keys posted by the minimiser's last evaluation), R0 = exp(W),
@@ -1784,10 +1795,13 @@ static int frame_enqueue(edgehip_ctx *c, int sn, int so, int sp, int have_pair, 
         c->fwd_key_in_tvr = false;
         if (e) return e;
         // matching in one pass (ctx.h: fuse_match): the forward copy waits for k_directed, which needs the unturned old KeyLines for it
-        const bool one_pass = c->fuse_match && c->fwd_mode == 0 && sp < 0 && !c->p.stereo_available;
+        const bool one_pass = frame_matches_in_one_pass(c, sp);
+#ifdef EDGEHIP_EXPERIMENTS
         if (c->fwd_mode == 2) {
             EH_TRY(forward_rotate_enqueue(c, so, sn));                                           // :354-369
-        } else if (one_pass) {
+        } else
+#endif
+        if (one_pass) {
             EH_TRY(forward_rotate_one_pass_enqueue(c, so, sn));                                  // :354 (arbitration), :360-369, :387-397
         } else {
             EH_TRY(forward_match_enqueue(c, so, sn, c->fwd_mode != 1, true));                    // :354 (+ exp(W) and :387-397 in k_fwd_win's tail)
@@ -1877,7 +1891,7 @@ int edgehip_process_frame(edgehip_ctx *c, const double *t) {
         if (sp >= 0) { c->grec_ok[sp] = true; c->rec_stale[sp] = false; c->rot_pending[sp] = false; }
         if (have_pair && so >= 0) {
             c->grec_ok[so] = false; c->rec_stale[so] = true;
-            c->rot_pending[so] = !c->imu_enabled && c->fuse_match && c->fwd_mode == 0 && sp < 0 && !c->p.stereo_available;
+            c->rot_pending[so] = !c->imu_enabled && frame_matches_in_one_pass(c, sp);   // what the captured frame_enqueue decided
         }
     } else {
         if (int e = frame_enqueue(c, sn, so, sp, have_pair, tp)) return e;

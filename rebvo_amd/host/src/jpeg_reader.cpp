@@ -33,6 +33,7 @@ struct Comp {
     int wblocks = 0, hblocks = 0;          // allocated size in blocks (whole MCUs)
     int cw = 0, ch = 0;                    // true component size in samples: ceil(image * samp / max samp)
     int pred = 0;
+    bool scanned = false;                  // a scan has carried this component's data
     std::vector<unsigned char> plane;      // [hblocks * 8][wblocks * 8]
 };
 
@@ -108,7 +109,7 @@ void idct_islow(const int *coef /* natural order, dequantised */, unsigned char 
         const int *in = coef + c;
         int *w = ws + c;
         if (in[8] == 0 && in[16] == 0 && in[24] == 0 && in[32] == 0 && in[40] == 0 && in[48] == 0 && in[56] == 0) {
-            const int dc = in[0] * (1 << P1);
+            const int dc = (int)((int64_t)in[0] * (1 << P1));   // (|in[0]| <= 2^24: the decoder rejects larger coefficients)
             for (int r = 0; r < 8; r++) w[8 * r] = dc;
             continue;
         }
@@ -254,6 +255,7 @@ bool decode_jpeg(const std::vector<unsigned char> &d, std::vector<RGB24Pixel> &o
             break;
         }
         case 0xC0: case 0xC1: {   // SOF0 / SOF1: sequential, Huffman
+            if (have_sof) { err = "JPEG: a second frame header"; return false; }   // (libjpeg: JERR_SOF_DUPLICATE)
             if (n < 6 || s[0] != 8) { err = "JPEG: only 8-bit samples are decoded"; return false; }
             h = be16(pos + 3); w = be16(pos + 5);
             const int nf = s[5];
@@ -280,6 +282,7 @@ bool decode_jpeg(const std::vector<unsigned char> &d, std::vector<RGB24Pixel> &o
         case 0xEE: if (n >= 12 && !memcmp(s, "Adobe", 5)) adobe_transform = s[11]; break;
         case 0xDA: {   // SOS + entropy-coded data
             if (!have_sof) { err = "JPEG: scan before frame header"; return false; }
+            if (n < 1) { err = "JPEG: bad SOS"; return false; }   // (the component count is the segment's first byte)
             const int ns = s[0];
             if (ns < 1 || ns > (int)comps.size() || n < 1u + 2u * ns + 3u) { err = "JPEG: bad SOS"; return false; }
             std::vector<Comp *> sc;
@@ -290,6 +293,7 @@ bool decode_jpeg(const std::vector<unsigned char> &d, std::vector<RGB24Pixel> &o
                 c->td = s[2 + 2 * i] >> 4; c->ta = s[2 + 2 * i] & 15;
                 if (c->td > 3 || c->ta > 3 || !hdc[c->td].set || !hac[c->ta].set || !qt_set[c->tq]) { err = "JPEG: scan uses an undefined table"; return false; }
                 c->pred = 0;
+                c->scanned = true;
                 sc.push_back(c);
             }
             Bits b;
@@ -319,8 +323,14 @@ bool decode_jpeg(const std::vector<unsigned char> &d, std::vector<RGB24Pixel> &o
                                 const int t = decode_sym(b, hdc[c->td]);
                                 if (t < 0 || t > 11) { err = "JPEG: corrupt DC code"; return false; }
                                 c->pred += t ? extend(b.receive(t), t) : 0;
+                                // the DC value of 8-bit data lies in [-2^11, 2^11): a prediction that runs away is a corrupt stream, and
+                                // bounding it (and with it every product with a 16-bit quantiser) keeps the integer IDCT inside int
+                                if (c->pred < -32768 || c->pred > 32767) { err = "JPEG: DC prediction out of range"; return false; }
                                 const uint16_t *q = qt[c->tq];
-                                coef[0] = c->pred * q[0];
+                                // (dequantised coefficients of 8-bit data stay below 2^15; anything beyond 2^24 is a corrupt stream, and
+                                // refusing it keeps every product of the integer IDCT inside its type)
+                                auto dequant = [&](int v, int qv, int &dst) { const int64_t x = (int64_t)v * qv; dst = (int)x; return x >= -(1 << 24) && x <= (1 << 24); };
+                                if (!dequant(c->pred, q[0], coef[0])) { err = "JPEG: coefficient out of range"; return false; }
                                 for (int k = 1; k < 64;) {
                                     const int rs = decode_sym(b, hac[c->ta]);
                                     if (rs < 0) { err = "JPEG: corrupt AC code"; return false; }
@@ -332,7 +342,7 @@ bool decode_jpeg(const std::vector<unsigned char> &d, std::vector<RGB24Pixel> &o
                                     }
                                     k += r;
                                     if (k > 63) { err = "JPEG: corrupt block"; return false; }
-                                    coef[kZigzag[k]] = extend(b.receive(sz), sz) * q[kZigzag[k]];
+                                    if (!dequant(extend(b.receive(sz), sz), q[kZigzag[k]], coef[kZigzag[k]])) { err = "JPEG: coefficient out of range"; return false; }
                                     k++;
                                 }
                                 const int col = (inter ? mx * c->h + bx : mx), row = (inter ? my * c->v + by : my);
@@ -353,6 +363,8 @@ bool decode_jpeg(const std::vector<unsigned char> &d, std::vector<RGB24Pixel> &o
         pos += len;
     }
     if (!have_sof) { err = "JPEG: no frame header"; return false; }
+    for (const Comp &c : comps)   // a truncated file (no scan, or a component no scan covered) is a camera error, not a black frame
+        if (!c.scanned) { err = "JPEG: no image data"; return false; }
     // ---- upsampling (jdsample.c) and colour conversion (jdcolor.c) ----
     const int W = (int)w, H = (int)h;
     out.assign((size_t)W * H, RGB24Pixel{0, 0, 0});

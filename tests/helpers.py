@@ -41,6 +41,15 @@ def rel_err(a, b):
 from rebvo_amd.config import write_global_config  # noqa: E402,F401  (the writer lives with the package: bench.py uses it too)
 
 
+def needs_experiments():
+    """Tests of the alternative kernels that measured slower than the defaults (round 4 verdict, item 10): those kernels and their
+    EDGEHIP_* switches exist only in a library built with `make -C rebvo_amd/csrc EXPERIMENTS=1` (edgehip_experiments() == 1)."""
+    import pytest
+    from rebvo_amd import edgehip
+    if not edgehip.load_library().edgehip_experiments():
+        pytest.skip("alternative kernel behind `make EXPERIMENTS=1`: not in the default build")
+
+
 def require_ref():
     """GPU parity tests need oracle/_ref (the reference compiled in place; it travels to the GPU box prebuilt).  Its absence
     is a broken snapshot, not a reason to go green by skipping."""

@@ -100,6 +100,8 @@ def test_fused_with_the_undistortion_inside_its_load(monkeypatch):
     """EDGEHIP_FUSED_UNDIST=1 (BASELINE config 4 as north_star words it): the four taps and their 16.16 weights gathered by the
     one-kernel stage A itself (SRC_UNDIST), no k_undistort_grey and no 16-bit plane — planes, mask and KeyLines against the
     reference.  Measured slower than the pre-pass (DESIGN.md section 3a''), so it is an option, not the default."""
+    from tests.helpers import needs_experiments
+    needs_experiments()
     monkeypatch.setenv("EDGEHIP_FUSED_UNDIST", "1")
     tlk._scale_space_case("tum_undistort_640x480", 640, 480, True, {})
     tlk._scale_space_case("tum_undistort_320x240", 320, 240, True, {})
@@ -110,6 +112,9 @@ def test_fused_tum_product_instantiation_matches_the_multi_kernel_path(monkeypat
     """TUM 640x480 + undistort at a batch that takes the fused path by default (the W = 640 / grey-plane instantiation, no debug
     planes; in_load = 1: the W = 640 instantiation that resamples inside its load) against the same batch on the forced multi-kernel
     path: identical nav records and depth maps."""
+    if in_load == "1":
+        from tests.helpers import needs_experiments
+        needs_experiments()
     monkeypatch.setenv("EDGEHIP_FUSED_UNDIST", in_load)
     w, h, B = 640, 480, 192
     pool = [f for f, _, _ in synth.billboard_sequence(w, h, 4, fx=525.0, fy=525.0, cx=320.0, cy=240.0)]

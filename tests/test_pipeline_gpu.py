@@ -232,6 +232,8 @@ def test_fused_evaluation_and_lm_step_is_bit_identical_to_the_launch_chain(monke
     that finishes last runs the step; EDGEHIP_PERSIST_LM = largest batch that does; off by default: it measured no faster).  Same code, same schedule,
     same reduction order as the chain of separate launches: every nav record and the depth map must be identical bit for
     bit — and both follow the reference."""
+    from tests.helpers import needs_experiments
+    needs_experiments()
     w, h, n = 376, 240, 10
     frames = [f for f, _, _ in synth.billboard_sequence(w, h, n + nseq)]
     outs = []
@@ -375,6 +377,8 @@ def test_reweighted_evaluation_with_two_keylines_per_thread(monkeypatch, w, h, n
     Forced on for a small batch: the path follows the reference inside the usual tolerance, and agrees with the one-KeyLine
     kernel to rounding (the 28 sums are added in another order) with identical discrete results — KeyLine counts, match counts,
     forward matches, EstimationOK."""
+    from tests.helpers import needs_experiments
+    needs_experiments()
     monkeypatch.setenv("EDGEHIP_TVR_RW2", "1")
     _run(w, h, n, nseq=2)
     frames = [f for f, _, _ in synth.billboard_sequence(w, h, n + 2)]

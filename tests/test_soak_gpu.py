@@ -67,6 +67,9 @@ def test_small_frames_sixty_deep(mode, monkeypatch):
     FordwardMatch / rotate_keylines (EDGEHIP_FWD_MODE, ctx.h); and with the three-kernel matching the one-pass form
     replaced as the default (EDGEHIP_FUSE_MATCH=0: k_fwd_win, k_fwd_apply, k_rotate in place, k_directed)."""
     from oracle import oracle
+    if mode.startswith("EDGEHIP_FWD_MODE"):
+        from tests.helpers import needs_experiments
+        needs_experiments()
     if mode != "default":
         name, sep, val = mode.partition("=")
         monkeypatch.setenv(name, val if sep else "1")

@@ -225,6 +225,8 @@ def test_build_field_segments_that_round_across_a_tile_boundary(w, h, mode, monk
     if not oracle.available("ref"):
         pytest.fail("oracle/_ref not built" " — a broken snapshot, not a reason to skip: run __graft_entry__.build(), where the reference tree is present")
     if mode in ("1", "2"):
+        from tests.helpers import needs_experiments
+        needs_experiments()      # the builder is chosen by the image size in the default build (the 1024 x 1104 case takes the mask-scan tiles)
         monkeypatch.setenv("EDGEHIP_FIELD_MODE", mode)
     r = 40
     rs = np.random.RandomState(5)
