@@ -347,7 +347,7 @@ class REBVO {
     friend class BatchGroup;
     BatchGroup *group = nullptr;
     int group_seat = -1;
-    void *cam_pinned = nullptr;    // page-locked storage of the camera ring (custom camera), or null: plain heap images
+    bool cam_pinned = false;       // the camera ring's images are page-locked views of the group's ring (batch_group.cpp), not heap images
     bool groupAttach();            // Init() of such an object
     void groupDetach();            // CleanUp()
     bool useGroupEngine() const { return params.CameraType == 3 && params.ImuMode == 0 && !params.StereoAvaiable; }

@@ -5,16 +5,21 @@
 //
 //   gather    the newest frame of every running member's camera ring (customcam.cpp:56-68: 1 ms time-outs; the soft-FPS drop
 //             of rebvo_first_t.cpp:146,172-177 per member)
-//   enqueue   N asynchronous copies out of the page-locked rings into the context's next slot (upload stream: they run under
-//             the kernels of the frames before), one edgehip_process_frame for all members
+//   enqueue   the members' frames go out of ONE page-locked ring the group owns ([ring entry][member][frame]: every member's camera
+//             buffers are views of it, so the application's copyFrom() writes where the DMA reads, and members that are at the
+//             same ring entry — all of them, unless somebody dropped a frame — go up in a single asynchronous copy on the upload
+//             stream, under the kernels of the frames before), then one edgehip_process_frame for all members
 //   release   the camera buffers, once the copies have read them (edgehip_upload_sync: the frames themselves are still running)
 //   complete  the PREVIOUS step: its per-sequence records out of the device's nav log (edgehip_read_nav_log waits for that frame
 //             only), NavData / PipeBuffer of every member, and the hand-off of the frame before to the member's output thread —
 //             with its KeyLines as AoS only if that member has a callback
 //
-// so the host works on step k-1's results while the device runs step k, and frame k+1 crosses PCIe under frame k: the
-// reference's T0 || T1.  When no further frame is waiting, the pending step is completed at once — a lone camera at 20 Hz sees
-// its record as soon as the frame is done, not a frame later.
+// so the host works on earlier steps' results while the device runs the newest, and frame k+1 crosses PCIe under frame k: the
+// reference's T0 || T1.  Up to two steps stay in flight when nobody has a callback (a single camera's frame is ~40 dependent
+// launches: the host needs as long to enqueue one as the device to run it, and one step of slack is not enough to keep the device
+// fed); one with callbacks, because the edge map a callback receives lives in a ring slot the step after next overwrites.  When
+// no further frame is waiting, everything in flight is completed at once — a lone camera at 20 Hz sees its record as soon as
+// the frame is done, not a frame later.
 //
 // Hand-off order is the reference's (rebvo_second_t.cpp:622-623): frame j reaches a member's callback after frame j+1 has been
 // tracked against it, carrying its own record and its edge map as the tracker left it; the last frame is never delivered.
@@ -44,8 +49,9 @@ public:
         double t_frame = 0, t0 = 0;
         int p_num = 0;
         long frames = 0;           // frames of this member enqueued so far
-        PipeBuffer *buf_of[2] = {nullptr, nullptr};   // [step & 1] PipeBuffer of a step in flight (released by player 0, not yet requested by
-                                                      // player 1): step k + 1 is enqueued before step k is completed
+        PipeBuffer *buf_of[4] = {nullptr, nullptr, nullptr, nullptr};   // [step & 3] PipeBuffer of a step in flight (released by player 0,
+                                                                        // not yet requested by player 1): later steps are enqueued first
+        int ring_idx = -1;         // ring entry of the gathered frame (page-locked ring), -1: a heap image
         bool leaving = false;      // cf->quit seen: the seat closes once the step in flight (which may carry its last frame) is done
         bool have_prev = false;    // a completed frame waits (as player 1's next buffer) for its successor before it is delivered
         int slot_prev = -1;        // ring slot of that frame
@@ -62,6 +68,9 @@ public:
     std::condition_variable cv;
     bool started = false, failed = false;
     std::string error;
+    uint8_t *ring = nullptr;       // page-locked [CCAMBUFSIZE][cap][frame]: the members' camera buffers (null: heap images, staged uploads)
+    size_t frame_bytes = 0;
+    long newest = -1;              // newest step enqueued
 
     // ---- registry of named groups ----
     static std::mutex &regMutex() { static std::mutex m; return m; }
@@ -73,6 +82,7 @@ public:
     bool gather(bool block, bool &any_running, bool &any_leaving);
     int enqueue(long step, std::vector<double> &ts, int &slot);
     int complete(long step, int slot, std::vector<edgehip_nav> &navs);
+    uint8_t *ringImage(int entry, int seat) { return ring + ((size_t)entry * cap + seat) * frame_bytes; }
     void closeSeat(Seat &st);
 };
 
@@ -105,8 +115,12 @@ bool REBVO::groupAttach() {
         // ring of 3 frame slots per sequence, `want` sequences.  No CPU fallback: fail loudly.
         int rc = edgehip_create(&hp, want, 3, params.GpuDevice, &g->hip);
         if (rc == 0) rc = edgehip_set_nav_log(g->hip, BatchGroup::kNavLog);
+        g->frame_bytes = (size_t)params.ImageSize.w * params.ImageSize.h * sizeof(RGB24Pixel);
+        void *ringp = nullptr;
+        if (rc == 0 && edgehip_alloc_pinned(g->frame_bytes * CCAMBUFSIZE * want, &ringp) == 0) g->ring = static_cast<uint8_t *>(ringp);
         if (rc != 0) {
             const std::string msg = std::string("REBVO(hip): edgehip_create failed: ") + edgehip_last_error();
+            if (g->ring) edgehip_free_pinned(g->ring);
             if (g->hip) edgehip_destroy(g->hip);
             delete g;
             return fail(msg);
@@ -135,6 +149,11 @@ bool REBVO::groupAttach() {
     st.closed = false;
     group = g;
     group_seat = seat;
+    if (g->ring) {   // the camera ring's images become views of the group's page-locked ring: entry j of this member = ring[j][seat]
+        for (unsigned j = 0; j < cam_pipe.Size(); j++)
+            cam_pipe[j].img = std::make_shared<Image<RGB24Pixel>>(reinterpret_cast<RGB24Pixel *>(g->ringImage((int)j, seat)), params.ImageSize);
+        cam_pinned = true;
+    }
     quit = false;
     st.out_thread = std::thread(ThirdThread, this);
     g->attached++;
@@ -177,9 +196,14 @@ void REBVO::groupDetach() {
     }
     group = nullptr;
     group_seat = -1;
+    if (cam_pinned) {   // the ring goes with the group: this object's camera buffers are heap images again
+        for (unsigned j = 0; j < cam_pipe.Size(); j++) cam_pipe[j].img = std::make_shared<Image<RGB24Pixel>>(params.ImageSize);
+        cam_pinned = false;
+    }
     if (last) {   // the last member out stops the thread and frees the context
         if (g->thr.joinable()) g->thr.join();
         if (g->hip) edgehip_destroy(g->hip);
+        if (g->ring) edgehip_free_pinned(g->ring);
         delete g;
     }
 }
@@ -228,6 +252,11 @@ bool REBVO::BatchGroup::gather(bool block, bool &any_running, bool &any_leaving)
                 if (cb->timestamp - st.t0 < min_frame_dt) { cf->cam_pipe.ReleaseBuffer(1); continue; }   // soft-FPS drop, :172-177
                 st.cbuf = cb;
                 st.t_frame = cb->timestamp;
+                st.ring_idx = -1;
+                if (ring) {
+                    const uint8_t *p = reinterpret_cast<const uint8_t *>(cb->img->Data());
+                    if (p >= ring && p < ring + frame_bytes * CCAMBUFSIZE * cap) st.ring_idx = (int)((size_t)(p - ring) / (frame_bytes * cap));
+                }
             }
             if (!st.cbuf) all = false;
         }
@@ -241,13 +270,21 @@ int REBVO::BatchGroup::enqueue(long step, std::vector<double> &ts, int &slot) {
     slot = edgehip_next_slot(hip);
     int rc = 0;
     const double tp0 = detail::now_s();
-    for (int i = 0; i < cap && rc == 0; i++) {
+    // runs of neighbouring members whose frames sit in the same entry of the page-locked ring are contiguous memory: one copy each
+    // (in lock-step without drops: one copy for the whole group); a heap image goes through the library's staging buffer
+    for (int i = 0; i < cap && rc == 0;) {
         Seat &st = seats[i];
-        if (!st.running) continue;   // a member that left: its sequence keeps running on whatever the slot holds, nobody reads it
-        REBVO *cf = st.cf;
-        const uint8_t *src = reinterpret_cast<const uint8_t *>(st.cbuf->img->Data());
-        rc = cf->cam_pinned ? edgehip_upload_rgb_pinned(hip, slot, src, i, 1) : edgehip_upload_rgb(hip, slot, src, i, 1);
+        if (!st.running) { i++; continue; }   // a member that left: its sequence keeps running on whatever the slot holds, nobody reads it
         ts[i] = st.t_frame;
+        if (st.ring_idx < 0) {
+            rc = edgehip_upload_rgb(hip, slot, reinterpret_cast<const uint8_t *>(st.cbuf->img->Data()), i, 1);
+            i++;
+            continue;
+        }
+        int n = 1;
+        while (i + n < cap && seats[i + n].running && seats[i + n].ring_idx == st.ring_idx) { ts[i + n] = seats[i + n].t_frame; n++; }
+        rc = edgehip_upload_rgb_pinned(hip, slot, ringImage(st.ring_idx, i), i, n);
+        i += n;
     }
     if (rc == 0) rc = edgehip_process_frame(hip, ts.data());
     if (rc != 0) return rc;
@@ -264,7 +301,7 @@ int REBVO::BatchGroup::enqueue(long step, std::vector<double> &ts, int &slot) {
         nb.dtp1 = tp0;   // start of the step; complete() turns it into the step's duration
         if (cf->haveCallBack()) std::memcpy(nb.imgc->Data(), st.cbuf->img->Data(), (size_t)cf->params.ImageSize.w * cf->params.ImageSize.h * 3);
         cf->pipe.ReleaseBuffer(0);
-        st.buf_of[step & 1] = &nb;
+        st.buf_of[step & 3] = &nb;
         st.t0 = st.t_frame;
         if (cf->system_reset) {   // rebvo_second_t.cpp:609-620: behind this frame, before the next
             rc = edgehip_depth_reset(hip, i);
@@ -273,9 +310,8 @@ int REBVO::BatchGroup::enqueue(long step, std::vector<double> &ts, int &slot) {
         }
     }
     // hand the camera buffers back as soon as the copies have read them (the frames are still being processed)
-    bool any_pinned = false;
-    for (Seat &st : seats) any_pinned |= st.running && st.cf->cam_pinned;
-    if (any_pinned && (rc = edgehip_upload_sync(hip)) != 0) return rc;
+    if (ring && (rc = edgehip_upload_sync(hip)) != 0) return rc;
+    newest = step;
     for (Seat &st : seats) {
         if (!st.running) continue;
         st.cf->cam_pipe.ReleaseBuffer(1);
@@ -291,10 +327,10 @@ int REBVO::BatchGroup::complete(long step, int slot, std::vector<edgehip_nav> &n
     const double now = detail::now_s();
     for (int i = 0; i < cap; i++) {
         Seat &st = seats[i];
-        if (!st.running || !st.buf_of[step & 1]) continue;
+        if (!st.running || !st.buf_of[step & 3]) continue;
         REBVO *cf = st.cf;
-        PipeBuffer &nb = *st.buf_of[step & 1];
-        st.buf_of[step & 1] = nullptr;
+        PipeBuffer &nb = *st.buf_of[step & 3];
+        st.buf_of[step & 3] = nullptr;
         const edgehip_nav &n = navs[i];
         const bool first = !st.have_prev;   // this member's first frame: "dummy processing" (rebvo_second_t.cpp:108-121)
         nb.dt = n.dt;
@@ -311,7 +347,11 @@ int REBVO::BatchGroup::complete(long step, int slot, std::vector<edgehip_nav> &n
         if (!first) cf->pushNav(nb.nav);
         if (st.have_prev) {   // the frame before goes to the output thread, with its edge map as this frame's tracking left it
             PipeBuffer &ob = cf->pipe.RequestBuffer(1);
-            if (cf->haveCallBack()) {
+            if (cf->haveCallBack() && newest - step >= 2) {
+                // a callback registered while two steps were in flight: the frame before's ring slot has been detected into again;
+                // this one delivery carries no KeyLines (from the next on the group keeps one step in flight)
+                ob.ef->kn = 0;
+            } else if (cf->haveCallBack()) {
                 int32_t kn = 0;
                 rc = edgehip_download_keylines(hip, i, st.slot_prev, reinterpret_cast<edgehip_keyline *>(ob.ef->kl.data()), nullptr, &kn);
                 if (rc != 0) {
@@ -337,18 +377,22 @@ void REBVO::BatchGroup::threadMain() {
     static_assert(sizeof(KeyLine) == sizeof(edgehip_keyline), "KeyLine mirrors edgehip_keyline");
     std::vector<double> ts(cap, 0.0);
     std::vector<edgehip_nav> navs(cap);
-    long step = 0;           // frames of the context enqueued so far
-    long pending = -1;       // step enqueued and not yet completed
-    int pending_slot = -1;
+    long step = 0;                       // frames of the context enqueued so far
+    struct InFlight { long step; int slot; };
+    std::vector<InFlight> pending;       // steps enqueued and not yet completed, oldest first (at most 2)
     int rc = 0;
+    auto complete_oldest = [&]() {
+        const InFlight f = pending.front();
+        pending.erase(pending.begin());
+        return complete(f.step, f.slot, navs);
+    };
     while (rc == 0) {
         bool any = false, leaving = false;
-        // with a step in flight a single pass decides: either the next frames are all waiting (enqueue them under it), or its
-        // record is read now
-        bool ready = gather(pending < 0, any, leaving);
-        if (!ready && pending >= 0) {
-            rc = complete(pending, pending_slot, navs);
-            pending = -1;
+        // with steps in flight a single pass decides: either the next frames are all waiting (enqueue them under what runs), or
+        // the records of what is in flight are read now
+        bool ready = gather(pending.empty(), any, leaving);
+        if (!ready) {
+            while (rc == 0 && !pending.empty()) rc = complete_oldest();
             if (rc != 0) break;
         }
         if (leaving) {   // (nothing of theirs is in flight any more)
@@ -358,15 +402,17 @@ void REBVO::BatchGroup::threadMain() {
         }
         if (!any) break;
         if (!ready) continue;
+        bool callbacks = false;
+        for (Seat &st : seats) callbacks |= st.running && st.cf->haveCallBack();
+        const size_t depth = callbacks ? 1 : 2;
         int slot = -1;
         rc = enqueue(step, ts, slot);
         if (rc != 0) break;
-        if (pending >= 0) rc = complete(pending, pending_slot, navs);
-        pending = step;
-        pending_slot = slot;
+        pending.push_back({step, slot});
         step++;
+        while (rc == 0 && pending.size() > depth) rc = complete_oldest();
     }
-    if (rc == 0 && pending >= 0) rc = complete(pending, pending_slot, navs);
+    while (rc == 0 && !pending.empty()) rc = complete_oldest();
     if (rc != 0) {
         std::cout << "REBVO(hip): " << edgehip_last_error() << "\n";
         std::lock_guard<std::mutex> lk(mut);

@@ -299,18 +299,9 @@ void REBVO::construct() {
     }
     default: break;
     }
-    // rebvo.cpp:284-285.  The custom camera's ring is page-locked when the device runtime is there (edgehip_alloc_pinned): the
-    // application's copyFrom() then writes where the asynchronous upload reads, and no staging copy exists.  Plain heap images
-    // otherwise (a host without a device: Init() will fail, the ring still works).
-    const size_t cam_frame_bytes = (size_t)params.ImageSize.w * params.ImageSize.h * sizeof(RGB24Pixel);
-    if (useGroupEngine() && edgehip_alloc_pinned(cam_frame_bytes * cam_pipe.Size(), &cam_pinned) != 0) cam_pinned = nullptr;
-    for (unsigned i = 0; i < cam_pipe.Size(); i++) {
-        if (cam_pinned)
-            cam_pipe[i].img = std::make_shared<Image<RGB24Pixel>>(
-                reinterpret_cast<RGB24Pixel *>(static_cast<uint8_t *>(cam_pinned) + cam_frame_bytes * i), params.ImageSize);
-        else
-            cam_pipe[i].img = std::make_shared<Image<RGB24Pixel>>(params.ImageSize);
-    }
+    // rebvo.cpp:284-285.  (An object that runs on the group engine gets page-locked views of its group's ring in their place when
+    // it attaches: Init(), batch_group.cpp.)
+    for (unsigned i = 0; i < cam_pipe.Size(); i++) cam_pipe[i].img = std::make_shared<Image<RGB24Pixel>>(params.ImageSize);
     cam_stereo = cam;
     if (params.StereoAvaiable) {
         cam_stereo = cam_model({params.pp_x_stereo, params.pp_y_stereo}, {params.z_f_x_stereo, params.z_f_y_stereo}, params.kc_stereo,
@@ -330,10 +321,6 @@ void REBVO::construct() {
 
 REBVO::~REBVO() {
     if (!quit) CleanUp();
-    if (cam_pinned) {   // applications may still hold shared_ptrs to the ring's images: those are views, the storage goes with the object
-        edgehip_free_pinned(cam_pinned);
-        cam_pinned = nullptr;
-    }
     delete imu;
     if (InitOK)
         for (PipeBuffer &pbuf : pipe) {
