@@ -358,9 +358,10 @@ int edgehip_read_nav_imu(edgehip_ctx *ctx, edgehip_nav_imu *out);
  * replay can run many frames without reading back; edgehip_read_nav_log copies records of frames
  * [first, first+count) as out[count][nseq]; the frames must have been enqueued (EDGEHIP_ERR_STATE before the first one).
  * Threading: a context is driven by ONE thread at a time — with this exception: edgehip_read_nav_log may be called from a
- * second thread while the first keeps enqueueing frames (the nav gather of a multi-GPU replay does).  It waits on a stream
- * of its own for the frames enqueued when it was called and never touches the context's frame streams (which may be
- * capturing a frame graph).  edgehip_set_nav_log itself belongs to the driving thread, with no reader active. */
+ * second thread while the first keeps enqueueing frames (the nav gather of a multi-GPU replay does).  It waits, on a stream
+ * of its own, for the newest frame it is asked for — not for frames enqueued behind it, so a caller may keep frames in flight
+ * and read the records one or two frames late — and never touches the context's frame streams (which may be capturing a
+ * frame graph).  edgehip_set_nav_log itself belongs to the driving thread, with no reader active. */
 int edgehip_set_nav_log(edgehip_ctx *ctx, int len);
 int edgehip_read_nav_log(edgehip_ctx *ctx, int first, int count, edgehip_nav *out);
 /* Restart every sequence from scratch: state as after edgehip_create (thresholds, priors, pose, frame

@@ -652,7 +652,10 @@ int edgehip_destroy(edgehip_ctx *c) {
         for (auto e : c->prof->pool) (void)hipEventDestroy(e);
         delete c->prof;
     }
-    if (c->stream_log) { (void)hipStreamSynchronize(c->stream_log); (void)hipStreamDestroy(c->stream_log); (void)hipEventDestroy(c->ev_log); }
+    if (c->stream_log) {
+        (void)hipStreamSynchronize(c->stream_log); (void)hipStreamDestroy(c->stream_log); (void)hipEventDestroy(c->ev_log);
+        for (hipEvent_t e : c->ev_log_ring) if (e) (void)hipEventDestroy(e);
+    }
     if (c->grey8) (void)hipFree(c->grey8);
     if (c->pinned_grey8) (void)hipHostFree(c->pinned_grey8);
     if (c->nav_log) (void)hipFree(c->nav_log);
@@ -930,6 +933,7 @@ int edgehip_set_nav_log(edgehip_ctx *c, int len) {
     if (len > 0 && !c->stream_log) {
         EH_CHECK(hipStreamCreateWithFlags(&c->stream_log, hipStreamNonBlocking));
         EH_CHECK(hipEventCreateWithFlags(&c->ev_log, hipEventDisableTiming));
+        for (hipEvent_t &e : c->ev_log_ring) EH_CHECK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
     }
     if (len > 0) {
         void *q;
@@ -962,7 +966,12 @@ int edgehip_read_nav_log(edgehip_ctx *c, int first, int count, edgehip_nav *out)
                       std::to_string(std::max(c->log_first, c->log_last - c->nav_log_len + 1)) + ".." + std::to_string(c->log_last) + ")");
             return EDGEHIP_ERR_STATE;
         }
-        EH_CHECK(hipStreamWaitEvent(c->stream_log, c->ev_log, 0));   // every frame enqueued so far, on whichever stream wrote its record
+        // the newest frame asked for, on whichever stream wrote its record — not everything enqueued since: a caller that keeps
+        // frames in flight reads the record of frame k while k + 1 and k + 2 run.  (The ring's events are re-recorded eight frames
+        // later: a frame older than that is covered by the newest event.)
+        const long long want = (long long)first + count - 1;
+        hipEvent_t ev = c->log_last - want < 8 ? c->ev_log_ring[want % 8] : c->ev_log;
+        EH_CHECK(hipStreamWaitEvent(c->stream_log, ev, 0));
     }
     for (int k = 0; k < count; k++) {
         const int slot = (first + k) % c->nav_log_len;

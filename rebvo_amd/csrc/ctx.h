@@ -289,6 +289,7 @@ struct edgehip_ctx {
     // it never touches c->stream, which may be capturing a frame graph.  log_mu orders the record / wait pair on the event.
     hipStream_t stream_log = nullptr;
     hipEvent_t ev_log = nullptr;
+    hipEvent_t ev_log_ring[8] = {};            // [frame % 8] behind that frame's record: a reader of frames up to f waits for f, not for everything enqueued since
     std::mutex log_mu;
     std::atomic<long long> frames_logged{0};   // frames enqueued since the log was set
     long long log_first = 0, log_last = -1;    // frame numbers (frames_seen at enqueue) of the first / newest logged frame (under log_mu)

@@ -1908,6 +1908,7 @@ int edgehip_process_frame(edgehip_ctx *c, const double *t) {
     if (c->nav_log) {   // edgehip_read_nav_log (possibly another thread) orders its copies after this frame's record
         std::lock_guard<std::mutex> g(c->log_mu);
         EH_CHECK(hipEventRecord(c->ev_log, c->stream_imu ? c->stream_imu : c->stream));
+        EH_CHECK(hipEventRecord(c->ev_log_ring[(c->frames_seen - 1) % 8], c->stream_imu ? c->stream_imu : c->stream));
         if (c->frames_logged.load() == 0) c->log_first = c->frames_seen - 1;
         c->log_last = c->frames_seen - 1;
         c->frames_logged++;
