@@ -4,7 +4,7 @@
 // (per-object results against the reference) and by bench.py's `host_surface` leg (frames per second through the surface).
 //
 //   surface_replay <GlobalConfig> <frames.rgb24> <pool_frames> <objects> <frames_per_object> <t0> <dt>
-//                  [--group NAME] [--callback] [--dump PREFIX] [--threads T] [--warmup W] [--leave I:F]
+//                  [--group NAME] [--callback] [--dump PREFIX] [--threads T] [--warmup W] [--leave I:F] [--step-mode] [--snapshot-at F]
 //
 // frames.rgb24 = pool_frames x ImageHeight x ImageWidth x 3 bytes.  Object i's frame k is pool frame tri(k + i): the triangle wave
 // over the pool bench.py uses (forward then backward: continuous motion), every object at its own phase.  Frame k of every object
@@ -14,6 +14,8 @@
 // belongs to thread i % T), each with one copyFrom() per frame like the reference's example.  The last line on stdout is JSON:
 //   {"objects": N, "frames_per_object": K, "timed_frames": ..., "seconds": ..., "fps": ..., "callbacks": ..., "group": ...}
 // --leave I:F: object I calls CleanUp() after its frame F-1 (a camera that goes away; the others carry on).
+// --step-mode: object 0 runs frame by frame (toggleFrameByFrame; its producer calls advanceFrameByFrame() before every frame).
+// --snapshot-at F: object 0's TakeSnapshot() is called before its frame F is submitted (Snap0.ppm in the working directory).
 // timed over the frames after the first W of every object (default 0), from the submission of frame W to the moment every
 // object's getNav() shows its last frame.
 #include <atomic>
@@ -73,7 +75,8 @@ int main(int argn, char **argv) {
     const double t0 = atof(argv[6]), dt = atof(argv[7]);
     std::string group, dump_prefix;
     bool want_cb = false;
-    int T = 1, W = 0, leave_obj = -1, leave_at = 0;
+    int T = 1, W = 0, leave_obj = -1, leave_at = 0, snapshot_at = -1;
+    bool step_mode = false;
     for (int a = 8; a < argn; a++) {
         const std::string s = argv[a];
         if (s == "--group" && a + 1 < argn) group = argv[++a];
@@ -81,6 +84,8 @@ int main(int argn, char **argv) {
         else if (s == "--dump" && a + 1 < argn) { dump_prefix = argv[++a]; want_cb = true; }
         else if (s == "--threads" && a + 1 < argn) T = atoi(argv[++a]);
         else if (s == "--warmup" && a + 1 < argn) W = atoi(argv[++a]);
+        else if (s == "--step-mode") step_mode = true;
+        else if (s == "--snapshot-at" && a + 1 < argn) snapshot_at = atoi(argv[++a]);
         else if (s == "--leave" && a + 1 < argn) { if (std::sscanf(argv[++a], "%d:%d", &leave_obj, &leave_at) != 2) return 2; }
         else { std::cout << "unknown argument " << s << "\n"; return 2; }
     }
@@ -113,6 +118,7 @@ int main(int argn, char **argv) {
     for (int i = 0; i < N; i++)
         if (!obj[i]->Init()) { std::cout << "object " << i << ": Init failed: " << obj[i]->lastError() << "\n"; return 4; }
 
+    if (step_mode && !obj[0]->toggleFrameByFrame()) { std::cout << "toggleFrameByFrame did not switch on\n"; return 7; }
     std::atomic<bool> bad{false};
     std::atomic<int> at_warm{0};
     double t_start = 0;
@@ -128,6 +134,8 @@ int main(int argn, char **argv) {
                     if (k == leave_at) obj[i]->CleanUp();
                     continue;
                 }
+                if (i == 0 && k == snapshot_at) obj[0]->TakeSnapshot();
+                if (i == 0 && step_mode) obj[0]->advanceFrameByFrame();
                 std::shared_ptr<Image<RGB24Pixel>> ptr;
                 while (!obj[i]->requestCustomCamBuffer(ptr, t0 + dt * k, 0.1))
                     if (!obj[i]->Running()) { bad = true; break; }

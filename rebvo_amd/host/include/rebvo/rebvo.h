@@ -330,6 +330,9 @@ class REBVO {
     std::atomic_bool quit;
     Pipeline<PipeBuffer> pipe;
     std::atomic_bool system_reset;
+    std::atomic_bool saveImg{false};
+    int snap_n = 0;
+    std::atomic_bool frame_by_frame{false}, frame_by_frame_advance{false};
     Pipeline<customCam::CustomCamPipeBuffer> cam_pipe;
     Pipeline<customCam::CustomCamPipeBuffer> cam_pipe_stereo;   // pair camera (StereoAvaiable, CameraType 3)
     cam_model cam;
@@ -386,14 +389,17 @@ public:
     bool CleanUp();
 
     void StartSimSave() {}
-    void TakeSnapshot() {}
+    // the next delivered frame's image is written as Snap<n>.ppm into the working directory (rebvo.h:459, rebvo_third_t.cpp:335-343);
+    // with the group engine the image is kept for the output thread only while a callback is registered or a snapshot is pending
+    void TakeSnapshot() { saveImg = true; }
     void Reset() { system_reset = true; }
     bool Running() { return !quit; }
     void startKeyFrames() {}
     void endKeyFrames() {}
     bool toggleKeyFrames() { return false; }
-    bool toggleFrameByFrame() { return false; }
-    bool advanceFrameByFrame() { return false; }
+    // frame-by-frame mode: no new frame is taken from the camera until advanceFrameByFrame() (rebvo.h:481-488, rebvo_first_t.cpp:154-159)
+    bool toggleFrameByFrame() { return frame_by_frame = !frame_by_frame; }
+    bool advanceFrameByFrame() { return frame_by_frame_advance = true; }
 
     NavData getNav() {
         std::lock_guard<std::mutex> locker(nav_mutex);

@@ -24,6 +24,7 @@
 // Hand-off order is the reference's (rebvo_second_t.cpp:622-623): frame j reaches a member's callback after frame j+1 has been
 // tracked against it, carrying its own record and its edge map as the tracker left it; the last frame is never delivered.
 #include <algorithm>
+#include <chrono>
 #include <condition_variable>
 #include <cstring>
 #include <iostream>
@@ -245,6 +246,15 @@ bool REBVO::BatchGroup::gather(bool block, bool &any_running, bool &any_leaving)
             if (cf->quit) { st.leaving = true; any_leaving = true; continue; }
             any_running = true;
             const double min_frame_dt = 1.0 / cf->params.soft_fps - 0.5 / cf->params.config_fps;   // rebvo_first_t.cpp:146
+            if (!st.cbuf && cf->frame_by_frame) {   // frame-by-frame mode (rebvo_first_t.cpp:154-159): no new frame until the application says so
+                if (!cf->frame_by_frame_advance) {
+                    all = false;
+                    if (block) std::this_thread::sleep_for(std::chrono::milliseconds(1));
+                    continue;
+                }
+                cf->frame_by_frame_advance = false;
+                std::cout << "Advancing frame...\n";
+            }
             while (!st.cbuf) {
                 customCam::CustomCamPipeBuffer *cb = cf->cam_pipe.RequestBufferTimeoutable(1, block ? 0.001 : 0.0);
                 if (!cb) break;
@@ -299,7 +309,7 @@ int REBVO::BatchGroup::enqueue(long step, std::vector<double> &ts, int &slot) {
         nb.quit = false;
         nb.dtp0 = 0;
         nb.dtp1 = tp0;   // start of the step; complete() turns it into the step's duration
-        if (cf->haveCallBack()) std::memcpy(nb.imgc->Data(), st.cbuf->img->Data(), (size_t)cf->params.ImageSize.w * cf->params.ImageSize.h * 3);
+        if (cf->haveCallBack() || cf->saveImg) std::memcpy(nb.imgc->Data(), st.cbuf->img->Data(), (size_t)cf->params.ImageSize.w * cf->params.ImageSize.h * 3);
         cf->pipe.ReleaseBuffer(0);
         st.buf_of[step & 3] = &nb;
         st.t0 = st.t_frame;

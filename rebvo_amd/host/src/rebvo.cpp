@@ -11,6 +11,7 @@
 #include "rebvo/rebvo.h"
 
 #include <chrono>
+#include <cstdio>
 #include <cmath>
 #include <fstream>
 #include <iomanip>
@@ -417,6 +418,11 @@ void REBVO::TrackThread(REBVO *cf) {
     bool failed = false;
     while (!cf->quit && !failed) {
         PipeBuffer &new_buf = cf->pipe.RequestBuffer(0);
+        if (cf->frame_by_frame) {   // rebvo_first_t.cpp:154-159
+            while (!cf->frame_by_frame_advance && !cf->quit) std::this_thread::sleep_for(std::chrono::milliseconds(10));
+            cf->frame_by_frame_advance = false;
+            std::cout << "Advancing frame...\n";
+        }
         // ---- grab: custom camera ring (src/VideoLib/customcam.cpp:56-68: 1 ms time-out, retry) or dataset list ----
         customCam::CustomCamPipeBuffer *cbuf = nullptr;
         const RGB24Pixel *data = nullptr;
@@ -644,6 +650,19 @@ void REBVO::ThirdThread(REBVO *cf) {
         }
         cf->callCallBack(pbuf);   // :329, under call_mutex
         t_proc_last = now_s() - ts;
+        if (cf->saveImg) {   // rebvo_third_t.cpp:335-343 (SavePPM, video_io.cpp:230-244)
+            cf->saveImg = false;
+            char name[128];
+            snprintf(name, sizeof(name), "Snap%d.ppm", cf->snap_n);
+            std::cout << "\nCamara Frontal: Tomando foto" << cf->snap_n++ << "\n";
+            if (FILE *fout = fopen(name, "w")) {
+                fprintf(fout, "P6\n%d %d 255\n", (int)cf->params.ImageSize.w, (int)cf->params.ImageSize.h);
+                fwrite(pbuf.imgc->Data(), (size_t)cf->params.ImageSize.w * cf->params.ImageSize.h * sizeof(RGB24Pixel), 1, fout);
+                fclose(fout);
+            } else {
+                perror("Video Out: Cannot open image!");
+            }
+        }
         cf->pipe.ReleaseBuffer(2);
     }
     if (a_log.is_open()) a_log.close();

@@ -150,3 +150,29 @@ def test_members_that_do_not_fit_are_refused(tmp_path):
     lib.rebvo_group_selftest.restype = C.c_int
     lib.rebvo_group_selftest.argtypes = [C.c_char_p]
     assert lib.rebvo_group_selftest(str(tmp_path / "cfg").encode()) == 0
+
+
+def test_frame_by_frame_mode_and_a_snapshot(tmp_path):
+    """toggleFrameByFrame / advanceFrameByFrame (rebvo.h:481-488, rebvo_first_t.cpp:154-159): an object in step mode takes a frame only
+    after the application has said so — here before every frame, so the run is the same run; TakeSnapshot (rebvo.h:459,
+    rebvo_third_t.cpp:335-343): the next delivered frame's image lands in Snap0.ppm, the reference's P6 file."""
+    n_obj, n_fr, pool = 2, 6, 6
+    frames = [f for f, _, _ in synth.billboard_sequence(W, H, pool, seed=13)]
+    np.stack(frames).tofile(tmp_path / "frames.rgb24")
+    cfg = tmp_path / "cfg"
+    write_global_config(cfg, edgehip.euroc_params(W, H))
+    r = subprocess.run([EXE, str(cfg), str(tmp_path / "frames.rgb24"), str(pool), str(n_obj), str(n_fr), str(T0), str(DT), "--group", "steps",
+                        "--dump", str(tmp_path / "run"), "--step-mode", "--snapshot-at", "2"], capture_output=True, text=True, timeout=300, cwd=tmp_path)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-1000:]
+    assert r.stdout.count("Advancing frame...") == n_fr
+    dumps = [np.loadtxt(f"{tmp_path}/run.{i}.txt", ndmin=2) for i in range(n_obj)]
+    navs, kls = _ctypes_batch(frames, n_obj, n_fr)
+    for i in range(n_obj):
+        _check_against_batch(dumps[i], navs, kls, i, n_fr - 1)
+    snap = (tmp_path / "Snap0.ppm").read_bytes()
+    head = f"P6\n{W} {H} 255\n".encode()
+    assert snap.startswith(head) and len(snap) == len(head) + W * H * 3
+    img = np.frombuffer(snap[len(head):], np.uint8).reshape(H, W, 3)
+    # the request came before frame 2 was submitted: the output thread honours it with the frame it delivers next — one of object 0's
+    # frames up to 2 (delivery runs a frame or two behind submission)
+    assert any(np.array_equal(img, frames[tri(k + 0, pool)]) for k in range(0, 3))
