@@ -14,7 +14,7 @@
 // belongs to thread i % T), each with one copyFrom() per frame like the reference's example.  The last line on stdout is JSON:
 //   {"objects": N, "frames_per_object": K, "timed_frames": ..., "seconds": ..., "fps": ..., "callbacks": ..., "group": ...}
 // --leave I:F: object I calls CleanUp() after its frame F-1 (a camera that goes away; the others carry on).
-// --step-mode: object 0 runs frame by frame (toggleFrameByFrame; its producer calls advanceFrameByFrame() before every frame).
+// --step-mode: object 0 runs frame by frame (toggleFrameByFrame; a helper thread calls advanceFrameByFrame() every millisecond).
 // --snapshot-at F: object 0's TakeSnapshot() is called before its frame F is submitted (Snap0.ppm in the working directory).
 // timed over the frames after the first W of every object (default 0), from the submission of frame W to the moment every
 // object's getNav() shows its last frame.
@@ -135,7 +135,6 @@ int main(int argn, char **argv) {
                     continue;
                 }
                 if (i == 0 && k == snapshot_at) obj[0]->TakeSnapshot();
-                if (i == 0 && step_mode) obj[0]->advanceFrameByFrame();
                 std::shared_ptr<Image<RGB24Pixel>> ptr;
                 while (!obj[i]->requestCustomCamBuffer(ptr, t0 + dt * k, 0.1))
                     if (!obj[i]->Running()) { bad = true; break; }
@@ -145,6 +144,9 @@ int main(int argn, char **argv) {
             }
         }
     };
+    // step mode: somebody presses "advance" every millisecond (the flag is a level, not a counter: rebvo.h:485-488)
+    std::atomic<bool> stepping{step_mode};
+    std::thread stepper([&] { while (stepping) { obj[0]->advanceFrameByFrame(); std::this_thread::sleep_for(std::chrono::milliseconds(1)); } });
     std::vector<std::thread> thr;
     for (int t = 0; t < T; t++) thr.emplace_back(producer, t);
     for (auto &t : thr) t.join();
@@ -157,6 +159,8 @@ int main(int argn, char **argv) {
             std::this_thread::sleep_for(std::chrono::microseconds(50));
         }
     const double seconds = now_s() - t_start;
+    stepping = false;
+    stepper.join();
     std::vector<NavData> navs;
     for (int i = 0; i < N; i++) navs.push_back(obj[i]->getNav());
     for (int i = 0; i < N; i++) obj[i]->CleanUp();
