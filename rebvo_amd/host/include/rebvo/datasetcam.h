@@ -2,7 +2,7 @@
 // GrabBuffer/ReleaseBuffer contract as the reference's DataSetCam (include/VideoLib/datasetcam.h:36-74,
 // src/VideoLib/datasetcam.cpp:32-220), without libgd: PNG (what both datasets ship) is decoded with zlib by
 // png_reader.cpp, baseline JPEG by jpeg_reader.cpp (libjpeg's integer IDCT / fancy upsampling / colour tables restated: the
-// pixels libgd hands the reference); binary PGM/PPM are accepted too.  Progressive JPEG is not (tools/jpeg_to_png.py).
+// pixels libgd hands the reference); binary PGM/PPM are accepted too.  Baseline and progressive JPEG both decode (jpeg_reader.cpp); arithmetic-coded / 12-bit / CMYK files do not (tools/jpeg_to_png.py).
 #ifndef REBVO_AMD_HOST_DATASETCAM_H
 #define REBVO_AMD_HOST_DATASETCAM_H
 

@@ -1,4 +1,4 @@
-// jpeg_reader.cpp — baseline (sequential, Huffman, 8-bit) JPEG decoder for the dataset camera.
+// jpeg_reader.cpp — baseline and progressive (Huffman, 8-bit) JPEG decoder for the dataset camera.
 //
 // The reference reads JPEG frames through libgd (src/VideoLib/datasetcam.cpp:128-131: gdImageCreateFromJpeg), i.e. through
 // libjpeg with its default settings: the slow-but-accurate integer IDCT (jidctint.c), "fancy" triangle-filter upsampling of
@@ -7,8 +7,12 @@
 // three published integer algorithms (Independent JPEG Group / libjpeg-turbo, whose outputs agree bit for bit); the test
 // (tests/test_dataset_cpu.py) compares it with PIL's libjpeg-turbo on grey, 4:4:4, 4:2:2 and 4:2:0 images, odd sizes, restart
 // intervals and optimised Huffman tables (the vertical-only 4:4:0 form follows libjpeg-turbo's h1v2_fancy_upsample; no encoder
-// at hand writes it, so that one is untested).  Not decoded: progressive / arithmetic / lossless / 12-bit / CMYK files (a clear
-// message; tools/jpeg_to_png.py converts anything PIL reads).
+// at hand writes it, so that one is untested).  Progressive files (SOF2; round 5) are decoded scan by scan into coefficient planes —
+// spectral selection and successive approximation as ITU T.81 G.1.2 / libjpeg's jdphuff.c describe them (DC first / refinement, AC
+// first with end-of-band runs, AC refinement with its correction bits) — and go through the same IDCT, upsampling and colour
+// conversion once the last scan is in: a complete file decodes to libjpeg's pixels (its inter-block smoothing only applies to files
+// that end early).  Not decoded: arithmetic / lossless / 12-bit / CMYK files (a clear message; tools/jpeg_to_png.py converts
+// anything PIL reads).
 #include <cstdint>
 #include <cstring>
 #include <new>
@@ -35,6 +39,9 @@ struct Comp {
     int pred = 0;
     bool scanned = false;                  // a scan has carried this component's data
     std::vector<unsigned char> plane;      // [hblocks * 8][wblocks * 8]
+    std::vector<int> coef;                 // progressive: [hblocks][wblocks][64] quantised coefficients, natural order
+    uint16_t q[64];                        // progressive: the quantiser as it stood at the component's first scan (libjpeg latches it there)
+    bool q_latched = false;
 };
 
 struct Bits {
@@ -212,7 +219,7 @@ bool decode_jpeg(const std::vector<unsigned char> &d, std::vector<RGB24Pixel> &o
     Huff hdc[4], hac[4];
     std::vector<Comp> comps;
     int restart = 0, adobe_transform = -1;
-    bool have_sof = false, decoded = false;
+    bool have_sof = false, decoded = false, progressive = false;
     size_t pos = 2;
     auto be16 = [&](size_t p) { return (unsigned)d[p] << 8 | d[p + 1]; };
     int hmax = 1, vmax = 1, mcux = 0, mcuy = 0;
@@ -254,7 +261,8 @@ bool decode_jpeg(const std::vector<unsigned char> &d, std::vector<RGB24Pixel> &o
             }
             break;
         }
-        case 0xC0: case 0xC1: {   // SOF0 / SOF1: sequential, Huffman
+        case 0xC0: case 0xC1: case 0xC2: {   // SOF0 / SOF1: sequential, SOF2: progressive; Huffman
+            progressive = m == 0xC2;
             if (have_sof) { err = "JPEG: a second frame header"; return false; }   // (libjpeg: JERR_SOF_DUPLICATE)
             if (n < 6 || s[0] != 8) { err = "JPEG: only 8-bit samples are decoded"; return false; }
             h = be16(pos + 3); w = be16(pos + 5);
@@ -271,12 +279,13 @@ bool decode_jpeg(const std::vector<unsigned char> &d, std::vector<RGB24Pixel> &o
                 c.wblocks = mcux * c.h; c.hblocks = mcuy * c.v;
                 c.cw = ((int)w * c.h + hmax - 1) / hmax; c.ch = ((int)h * c.v + vmax - 1) / vmax;
                 c.plane.assign((size_t)c.wblocks * 8 * c.hblocks * 8, 0);
+                if (progressive) c.coef.assign((size_t)c.wblocks * c.hblocks * 64, 0);
             }
             have_sof = true;
             break;
         }
-        case 0xC2: case 0xC3: case 0xC5: case 0xC6: case 0xC7: case 0xC9: case 0xCA: case 0xCB: case 0xCD: case 0xCE: case 0xCF:
-            err = "JPEG: progressive / lossless / arithmetic-coded files are not decoded (baseline only; tools/jpeg_to_png.py converts them)";
+        case 0xC3: case 0xC5: case 0xC6: case 0xC7: case 0xC9: case 0xCA: case 0xCB: case 0xCD: case 0xCE: case 0xCF:
+            err = "JPEG: lossless / hierarchical / arithmetic-coded files are not decoded (Huffman baseline and progressive only; tools/jpeg_to_png.py converts them)";
             return false;
         case 0xDD: if (n >= 2) restart = be16(pos + 2); break;
         case 0xEE: if (n >= 12 && !memcmp(s, "Adobe", 5)) adobe_transform = s[11]; break;
@@ -291,7 +300,8 @@ bool decode_jpeg(const std::vector<unsigned char> &d, std::vector<RGB24Pixel> &o
                 for (Comp &k : comps) if (k.id == s[1 + 2 * i]) c = &k;
                 if (!c) { err = "JPEG: scan names an unknown component"; return false; }
                 c->td = s[2 + 2 * i] >> 4; c->ta = s[2 + 2 * i] & 15;
-                if (c->td > 3 || c->ta > 3 || !hdc[c->td].set || !hac[c->ta].set || !qt_set[c->tq]) { err = "JPEG: scan uses an undefined table"; return false; }
+                if (c->td > 3 || c->ta > 3 || !qt_set[c->tq] || (!progressive && (!hdc[c->td].set || !hac[c->ta].set))) { err = "JPEG: scan uses an undefined table"; return false; }
+                if (progressive && !c->q_latched) { memcpy(c->q, qt[c->tq], sizeof c->q); c->q_latched = true; }
                 c->pred = 0;
                 c->scanned = true;
                 sc.push_back(c);
@@ -303,6 +313,104 @@ bool decode_jpeg(const std::vector<unsigned char> &d, std::vector<RGB24Pixel> &o
             // (its own blocks in raster order, only those that hold image samples: ceil(cw / 8) x ceil(ch / 8))
             const bool inter = ns > 1;
             const int gx = inter ? mcux : (sc[0]->cw + 7) / 8, gy = inter ? mcuy : (sc[0]->ch + 7) / 8;
+            if (progressive) {
+                // ---- one progressive scan: spectral band [Ss, Se], successive approximation Ah -> Al (T.81 G.1.2, jdphuff.c) ----
+                const int Ss = s[1 + 2 * ns], Se = s[2 + 2 * ns], Ah = s[3 + 2 * ns] >> 4, Al = s[3 + 2 * ns] & 15;
+                if (Ss > Se || Se > 63 || Al > 13 || (Ss == 0 && Se != 0) || (Ss > 0 && ns != 1) || (Ah != 0 && Ah != Al + 1)) { err = "JPEG: bad progressive scan parameters"; return false; }
+                for (Comp *c : sc)
+                    if (Ss == 0 ? (Ah == 0 && !hdc[c->td].set) : !hac[c->ta].set) { err = "JPEG: scan uses an undefined table"; return false; }
+                int until = restart, eobrun = 0;
+                const int p1 = 1 << Al, m1 = -(1 << Al);
+                for (int my = 0; my < gy; my++)
+                    for (int mx = 0; mx < gx; mx++) {
+                        if (restart && until == 0) {
+                            b.reset();
+                            while (b.p + 1 < b.end && !(b.p[0] == 0xFF && b.p[1] >= 0xD0 && b.p[1] <= 0xD7)) b.p++;
+                            if (b.p + 1 < b.end) b.p += 2;
+                            for (Comp *c : sc) c->pred = 0;
+                            eobrun = 0;
+                            until = restart;
+                        }
+                        until--;
+                        for (Comp *c : sc) {
+                            const int bh = inter ? c->h : 1, bv = inter ? c->v : 1;
+                            for (int by = 0; by < bv; by++)
+                                for (int bx = 0; bx < bh; bx++) {
+                                    const int col = (inter ? mx * c->h + bx : mx), row = (inter ? my * c->v + by : my);
+                                    int *cf = &c->coef[((size_t)row * c->wblocks + col) * 64];
+                                    if (Ss == 0) {
+                                        if (Ah == 0) {   // DC, first pass
+                                            const int t = decode_sym(b, hdc[c->td]);
+                                            if (t < 0 || t > 11) { err = "JPEG: corrupt DC code"; return false; }
+                                            c->pred += t ? extend(b.receive(t), t) : 0;
+                                            if (c->pred < -32768 || c->pred > 32767) { err = "JPEG: DC prediction out of range"; return false; }
+                                            cf[0] = c->pred * (1 << Al);
+                                        } else if (b.bit()) {   // DC refinement: one more bit
+                                            cf[0] |= p1;
+                                        }
+                                    } else if (Ah == 0) {   // AC, first pass
+                                        if (eobrun > 0) { eobrun--; continue; }
+                                        for (int k = Ss; k <= Se; k++) {
+                                            const int rs = decode_sym(b, hac[c->ta]);
+                                            if (rs < 0) { err = "JPEG: corrupt AC code"; return false; }
+                                            const int r = rs >> 4, sz = rs & 15;
+                                            if (sz) {
+                                                k += r;
+                                                if (k > Se) { err = "JPEG: corrupt block"; return false; }
+                                                cf[kZigzag[k]] = extend(b.receive(sz), sz) * (1 << Al);
+                                            } else if (r == 15) {
+                                                k += 15;
+                                            } else {   // EOBr: this block and (2^r + bits - 1) more end here
+                                                eobrun = (1 << r) - 1;
+                                                if (r) eobrun += b.receive(r);
+                                                break;
+                                            }
+                                        }
+                                    } else {   // AC refinement (jdphuff.c: decode_mcu_AC_refine)
+                                        auto correct = [&](int &v) { if (b.bit() && (v & p1) == 0) v += v >= 0 ? p1 : m1; };
+                                        int k = Ss;
+                                        if (eobrun == 0) {
+                                            for (; k <= Se; k++) {
+                                                const int rs = decode_sym(b, hac[c->ta]);
+                                                if (rs < 0) { err = "JPEG: corrupt AC code"; return false; }
+                                                int r = rs >> 4, val = 0;
+                                                if (rs & 15) {
+                                                    if ((rs & 15) != 1) { err = "JPEG: corrupt refinement scan"; return false; }
+                                                    val = b.bit() ? p1 : m1;
+                                                } else if (r != 15) {
+                                                    eobrun = 1 << r;
+                                                    if (r) eobrun += b.receive(r);
+                                                    break;   // the rest of the band is handled below
+                                                }
+                                                // over the coefficients that are already non-zero (a correction bit each) and r that are still zero
+                                                do {
+                                                    int &v = cf[kZigzag[k]];
+                                                    if (v != 0) correct(v);
+                                                    else if (--r < 0) break;
+                                                    k++;
+                                                } while (k <= Se);
+                                                if (val) {
+                                                    if (k > Se) { err = "JPEG: corrupt block"; return false; }
+                                                    cf[kZigzag[k]] = val;
+                                                }
+                                            }
+                                        }
+                                        if (eobrun > 0) {   // inside an end-of-band run: only correction bits for what is non-zero already
+                                            for (; k <= Se; k++) {
+                                                int &v = cf[kZigzag[k]];
+                                                if (v != 0) correct(v);
+                                            }
+                                            eobrun--;
+                                        }
+                                    }
+                                }
+                        }
+                    }
+                size_t q2 = b.p - d.data();
+                while (q2 + 1 < d.size() && !(d[q2] == 0xFF && d[q2 + 1] != 0x00 && !(d[q2 + 1] >= 0xD0 && d[q2 + 1] <= 0xD7))) q2++;
+                pos = q2;
+                continue;
+            }
             int coef[64];
             int until_restart = restart;
             for (int my = 0; my < gy; my++)
@@ -365,6 +473,19 @@ bool decode_jpeg(const std::vector<unsigned char> &d, std::vector<RGB24Pixel> &o
     if (!have_sof) { err = "JPEG: no frame header"; return false; }
     for (const Comp &c : comps)   // a truncated file (no scan, or a component no scan covered) is a camera error, not a black frame
         if (!c.scanned) { err = "JPEG: no image data"; return false; }
+    if (progressive)   // every scan is in: the coefficient planes through the quantiser and the IDCT, block by block
+        for (Comp &c : comps)
+            for (int row = 0; row < c.hblocks; row++)
+                for (int col = 0; col < c.wblocks; col++) {
+                    const int *cf = &c.coef[((size_t)row * c.wblocks + col) * 64];
+                    int dq[64];
+                    for (int k = 0; k < 64; k++) {
+                        const int64_t x = (int64_t)cf[k] * c.q[k];
+                        if (x < -(1 << 24) || x > (1 << 24)) { err = "JPEG: coefficient out of range"; return false; }
+                        dq[k] = (int)x;
+                    }
+                    idct_islow(dq, &c.plane[((size_t)row * 8) * (c.wblocks * 8) + (size_t)col * 8], c.wblocks * 8);
+                }
     // ---- upsampling (jdsample.c) and colour conversion (jdcolor.c) ----
     const int W = (int)w, H = (int)h;
     out.assign((size_t)W * H, RGB24Pixel{0, 0, 0});

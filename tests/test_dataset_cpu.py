@@ -83,6 +83,12 @@ def test_jpeg_reader_matches_libjpeg(tmp_path, size, kind):
                 path = tmp_path / f"i_{int(grey)}_{sub}_{q}.jpg".replace(":", "")
                 (PIL.fromarray(a[:, :, 0], "L") if grey else PIL.fromarray(a, "RGB")).save(path, **kw)
                 assert np.array_equal(_decode(path, tmp_path), np.asarray(PIL.open(path).convert("RGB"))), (grey, sub, q, opt, rst)
+                # ... and the progressive form of the same image (round 5: SOF2 — DC / AC scans, successive approximation, end-of-band
+                # runs, refinement passes; libgd decodes it in place, datasetcam.cpp:109-171): libjpeg's pixels again
+                pp = tmp_path / f"p_{int(grey)}_{sub}_{q}.jpg"
+                (PIL.fromarray(a[:, :, 0], "L") if grey else PIL.fromarray(a, "RGB")).save(pp, progressive=True, **kw)
+                assert b"\xff\xc2" in pp.read_bytes()[:2000]
+                assert np.array_equal(_decode(pp, tmp_path), np.asarray(PIL.open(pp).convert("RGB"))), ("progressive", grey, sub, q, opt, rst)
                 n += 1
     assert n == 16
 
@@ -93,8 +99,18 @@ def test_unreadable_image_and_bad_list(tmp_path):
     assert r.returncode == 6 and "JPEG" in r.stdout
     rs = np.random.RandomState(0)
     PIL.fromarray(rs.randint(0, 256, (24, 24, 3)).astype(np.uint8), "RGB").save(tmp_path / "p.jpg", progressive=True)
+    whole = (tmp_path / "p.jpg").read_bytes()
     r = subprocess.run([EXE, "--decode", str(tmp_path / "p.jpg"), str(tmp_path / "o")], capture_output=True, text=True)
-    assert r.returncode == 6 and "progressive" in r.stdout and "tools/jpeg_to_png.py" in r.stdout
+    assert r.returncode == 0, r.stdout                      # progressive files decode (round 5)
+    # a file that ends before any scan, and one without an end: a camera error with a message, never a black frame
+    sos = whole.index(b"\xff\xda")
+    (tmp_path / "t.jpg").write_bytes(whole[:sos] + b"\xff\xd9")
+    r = subprocess.run([EXE, "--decode", str(tmp_path / "t.jpg"), str(tmp_path / "o")], capture_output=True, text=True)
+    assert r.returncode == 6 and "no image data" in r.stdout
+    arith = whole.replace(b"\xff\xc2", b"\xff\xc9", 1)    # SOF9: arithmetic coding
+    (tmp_path / "a.jpg").write_bytes(arith)
+    r = subprocess.run([EXE, "--decode", str(tmp_path / "a.jpg"), str(tmp_path / "o")], capture_output=True, text=True)
+    assert r.returncode == 6 and "arithmetic" in r.stdout and "tools/jpeg_to_png.py" in r.stdout
     # dataset config whose list file is missing / malformed: Init() fails like the reference's camera error
     p = edgehip.euroc_params(64, 48)
     for content in (None, "# header\nnot_a_number,frame.png\n"):

@@ -2,9 +2,9 @@
 """Convert the JPEG images of a data set to PNG, in place or into another directory, and rewrite its image list.
 
 The reference's DataSetCam reads JPEG through libgd (src/VideoLib/datasetcam.cpp:128-131, gdImageCreateFromJpeg = libjpeg);
-the host library of this repository decodes PNG / PGM / PPM and baseline JPEG itself (rebvo_amd/host/src/png_reader.cpp,
+the host library of this repository decodes PNG / PGM / PPM and baseline and progressive JPEG itself (rebvo_amd/host/src/png_reader.cpp,
 jpeg_reader.cpp) — EuRoC and TUM, the data sets of every BASELINE configuration, ship PNG.  For what the JPEG reader does not
-take (progressive, arithmetic-coded, CMYK, 12-bit files), decode once with this tool (PIL = libjpeg(-turbo), the decoder family libgd uses) and point DataSetDir / DataSetFile at the result:
+take (arithmetic-coded, CMYK, 12-bit files), decode once with this tool (PIL = libjpeg(-turbo), the decoder family libgd uses) and point DataSetDir / DataSetFile at the result:
 
     tools/jpeg_to_png.py <DataSetDir> <DataSetFile> <out_dir>
 
