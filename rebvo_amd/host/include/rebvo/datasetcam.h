@@ -19,16 +19,16 @@ namespace rebvo {
 bool LoadImageRGB24(const std::string &file, std::vector<RGB24Pixel> &out, unsigned &w, unsigned &h, std::string &err, bool *mono = nullptr);
 
 class DataSetCam {
-    bool error = true;
-    bool frm_pending = false;
-    Image<RGB24Pixel> buffer;
-    std::vector<uint8_t> grey;   // the frame as 8-bit mono when the file stores one grey channel (EuRoC), else empty
-    double time = 0;
-    std::string strDir;
-    std::vector<std::string> img_list;
-    std::vector<double> img_time;
-    unsigned img_inx = 0;
-    unsigned paknum = 0;
+    struct ListedFrame { double stamp; std::string path; };   // one line of the list: time stamp (scaled), DataSetDir + file name
+    std::vector<ListedFrame> listed;
+    size_t cursor = 0;             // next entry of the list to load
+    bool error = true;             // the camera is unusable: list unreadable, end of list reached, an image that does not load
+    bool loaded = false;           // `frame` holds an image nobody has grabbed yet
+    Image<RGB24Pixel> frame;
+    std::vector<uint8_t> grey;     // the frame as 8-bit mono when the file stores one grey channel (EuRoC), else empty
+    double stamp = 0;
+    unsigned grabbed = 0;          // frames handed out (PakNum)
+    bool ensureLoaded();           // a frame is waiting, or the next one of the list has been loaded; false: camera error
 
 public:
     // List file: one "<timestamp>[,| ]<file name>" per line, '#' comments (EuRoC data.csv, TUM rgb.txt);
@@ -44,8 +44,8 @@ public:
     // the 8-bit plane (edgehip_upload_grey8: a third of the bytes, identical results).
     const uint8_t *GreyBuffer() const { return grey.empty() ? nullptr : grey.data(); }
     const bool &Error() { return error; }
-    unsigned PakNum() const { return paknum; }
-    size_t NumFrames() const { return img_list.size() < img_time.size() ? img_list.size() : img_time.size(); }
+    unsigned PakNum() const { return grabbed; }
+    size_t NumFrames() const { return listed.size(); }
 };
 
 }  // namespace rebvo

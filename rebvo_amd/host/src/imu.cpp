@@ -4,6 +4,7 @@
 #include "rebvo/imu.h"
 
 #include <cstdio>
+#include <cstdlib>
 #include <fstream>
 #include <iostream>
 #include <string>
@@ -39,67 +40,80 @@ ImuGrabber::ImuGrabber(const std::vector<ImuData> &data_set_data)
     }
 }
 
-static std::string shrink_ws(const std::string &s) {   // Configurator::ShrinkWS (configurator.cpp:33-48)
-    size_t p1 = 0;
-    while (p1 < s.size() && (s[p1] == ' ' || s[p1] == 0x09)) p1++;
-    if (p1 == s.size()) return std::string();
-    size_t p2 = s.size() - 1;
-    while (p2 > p1 && (s[p2] == ' ' || s[p2] == 0x09)) p2--;
-    return s.substr(p1, p2 - p1 + 1);
+namespace {
+
+// Blanks and tabs off both ends of a line (what Configurator::ShrinkWS does to it, configurator.cpp:33-48).
+std::string trimmed(const std::string &s) {
+    const size_t first = s.find_first_not_of(" \t");
+    return first == std::string::npos ? std::string() : s.substr(first, s.find_last_not_of(" \t") - first + 1);
 }
 
-// imugrabber.cpp:80-131
+// The leading comma-separated numbers of a text line into out[0..n): as many as are there.  This is what the reference's
+// sscanf("%lf,%lf,...") leaves in its arguments (imugrabber.cpp:108-116) — a field that is missing or unreadable, and every field
+// behind it, keeps the value it had; blanks in front of a number are skipped, blanks in front of a comma end the record.
+int leading_numbers(const std::string &line, double *out, int n) {
+    const char *at = line.c_str();
+    int got = 0;
+    for (; got < n; got++) {
+        char *behind = nullptr;
+        const double v = std::strtod(at, &behind);
+        if (behind == at) break;
+        out[got] = v;
+        at = behind;
+        if (*at != ',') { got++; break; }
+        at++;
+    }
+    return got;
+}
+
+}  // namespace
+
+// The IMU data set of ImuMode 2: one sample per line, "t,gx,gy,gz,ax,ay,az[,cx,cy,cz]", '#' lines and empty lines skipped, the time
+// stamp scaled to seconds (imugrabber.cpp:80-131; EuRoC's imu0/data.csv with TimeScale 1e-9).  Same messages as the reference.
 std::vector<ImuData> ImuGrabber::LoadDataSet(const char *data_file, bool comp_data, double time_scale, bool &error) {
-    std::ifstream ifile(data_file);
-    error = false;
-    if (!ifile.is_open()) {
+    std::vector<ImuData> samples;
+    std::ifstream in(data_file);
+    error = !in.is_open();
+    if (error) {
         std::cout << "\nImuGrabber: Failed to open file " << data_file << "\n";
-        error = true;
-        return std::vector<ImuData>();
+        return samples;
     }
-    std::vector<ImuData> vector_data;
-    int lines = 0;
-    while (!ifile.eof()) {
-        std::string line;
-        std::getline(ifile, line);
-        line = shrink_ws(line);
-        if (line.size() == 0) continue;
-        if (line[0] == '#') continue;
+    for (std::string raw; std::getline(in, raw);) {
+        const std::string line = trimmed(raw);
+        if (line.empty() || line.front() == '#') continue;
         ImuData d;
-        if (comp_data)
-            std::sscanf(line.c_str(), "%lf,%lf,%lf,%lf,%lf,%lf,%lf,%lf,%lf,%lf", &d.tstamp, &d.giro[0], &d.giro[1], &d.giro[2], &d.acel[0],
-                        &d.acel[1], &d.acel[2], &d.comp[0], &d.comp[1], &d.comp[2]);
-        else
-            std::sscanf(line.c_str(), "%lf,%lf,%lf,%lf,%lf,%lf,%lf", &d.tstamp, &d.giro[0], &d.giro[1], &d.giro[2], &d.acel[0],
-                        &d.acel[1], &d.acel[2]);
-        d.tstamp *= time_scale;
-        lines++;
-        vector_data.push_back(d);
+        double f[10] = {d.tstamp, d.giro[0], d.giro[1], d.giro[2], d.acel[0], d.acel[1], d.acel[2], d.comp[0], d.comp[1], d.comp[2]};
+        leading_numbers(line, f, comp_data ? 10 : 7);
+        d.tstamp = f[0] * time_scale;
+        for (int k = 0; k < 3; k++) { d.giro[k] = f[1 + k]; d.acel[k] = f[4 + k]; d.comp[k] = f[7 + k]; }
+        samples.push_back(d);
     }
-    std::cout << "\nImugrabber: Loaded " << lines << " datums\n";
-    return vector_data;
+    std::cout << "\nImugrabber: Loaded " << samples.size() << " datums\n";
+    return samples;
 }
 
-// imugrabber.cpp:133-158
+// Cam-IMU transformation from a text file of twelve comma-separated numbers, row by row [R | t] (imugrabber.cpp:133-158: every
+// number is what std::stod makes of the text up to the next comma).  false, with a message, on a missing or malformed file.
 bool ImuGrabber::LoadCamImuSE3(const char *se3_file) {
-    std::ifstream file(se3_file);
-    if (!file.is_open()) {
+    std::ifstream in(se3_file);
+    if (!in.is_open()) {
         std::cout << "LoadCamImuSE3: could not open SE3 file" << se3_file << " \n";
         return false;
     }
-    std::string num;
-    try {
-        for (int i = 0; i < 3; i++) {
-            for (int j = 0; j < 3; j++) {
-                std::getline(file, num, ',');
-                RDataSetCam2IMU(i, j) = std::stod(num);
-            }
-            std::getline(file, num, ',');
-            TDataSetCam2IMU[i] = std::stod(num);
+    double rt[12];
+    for (double &v : rt) {
+        std::string field;
+        std::getline(in, field, ',');
+        char *behind = nullptr;
+        v = std::strtod(field.c_str(), &behind);
+        if (behind == field.c_str()) {   // (the reference lets std::stod throw out of the constructor chain)
+            std::cout << "LoadCamImuSE3: malformed SE3 file " << se3_file << "\n";
+            return false;
         }
-    } catch (const std::exception &) {   // the reference lets std::stod throw out of the constructor chain
-        std::cout << "LoadCamImuSE3: malformed SE3 file " << se3_file << "\n";
-        return false;
+    }
+    for (int r = 0; r < 3; r++) {
+        for (int c = 0; c < 3; c++) RDataSetCam2IMU(r, c) = rt[4 * r + c];
+        TDataSetCam2IMU[r] = rt[4 * r + 3];
     }
     return true;
 }
