@@ -632,6 +632,8 @@ struct TvrArgs {
     size_t f16stride;          // index-plane elements per sequence
     int f16tx;                 // 8x4-pixel tiles per tile row
     double zfm, max_r, match_thresh, k_huber, inv_k_huber;
+    double inv_zfm;            // 1 / zfm as IEEE division gives it (the host's): the kernels formed it per KeyLine and evaluation, a full fp64
+                               // division sequence (~22 of ~600 vector instructions of an evaluation that is vector-ALU-bound)
     float ppx, ppy;
     uint32_t match_num_thresh;
     int write_mid;             // store kl.m_id_f (only the last evaluation of a minimisation needs to)
@@ -751,7 +753,7 @@ __device__ __forceinline__ void tvr_body(const TvrArgs &a, const int seq, const 
                 // KltoI3PMatrix + ProyI3Pto3PMatrix (global_tracker.cpp:553-570, ne10wrapper.h:414-424): P0 = (x z / zf, y z / zf, z),
                 // z = 1 / rho — from p_m and rho (16 B) instead of a stored P0 (24 B): one fp64 division for a third less traffic
                 const double sz = 1 / rho0;
-                const double pz_zf0 = (1 / a.zfm) * sz;
+                const double pz_zf0 = a.inv_zfm * sz;
                 const double sx = pz_zf0 * (double)pm0.x, sy = pz_zf0 * (double)pm0.y;
                 const double *R = sq->Rt, *V = sq->Vt;
                 // Ne10::SE3on3PMatrix: dst = R(i,0)*x; dst += R(i,1)*y; dst += R(i,2)*z; dst = V + dst
@@ -1066,7 +1068,7 @@ __device__ __forceinline__ void tvr2_body(const TvrArgs &a, const int seq, const
         const bool skip = s_rho > sq->s_rho_min_eval || (uint32_t)mnum < mthr;  // int vs uint compare
         if (!skip) {
             const double sz = 1 / rho0;
-            const double pz_zf0 = (1 / a.zfm) * sz;
+            const double pz_zf0 = a.inv_zfm * sz;
             const double sx = pz_zf0 * (double)pm0.x, sy = pz_zf0 * (double)pm0.y;
             double px[2], py[2];
             bool inimg[2];
@@ -1345,7 +1347,7 @@ __device__ __forceinline__ void tvr_rw2_body(const TvrArgs &a, const int seq, co
         rmx[c] = rmy[c] = 0.f;
         if (live[c]) {
             const double sz = 1 / rho_own[c];
-            const double pz_zf0 = (1 / a.zfm) * sz;
+            const double pz_zf0 = a.inv_zfm * sz;
             const double sx = pz_zf0 * (double)pm0[c].x, sy = pz_zf0 * (double)pm0[c].y;
             ptx[c] = R[0] * sx; ptx[c] += R[1] * sy; ptx[c] += R[2] * sz; ptx[c] = V[0] + ptx[c];
             pty[c] = R[3] * sx; pty[c] += R[4] * sy; pty[c] += R[5] * sz; pty[c] = V[1] + pty[c];
@@ -2691,7 +2693,7 @@ static TvrArgs make_tvr_args(edgehip_ctx *c, int slot_new, int slot_old, double 
     a.partials_z = c->partials + (size_t)pl.nseq * c->nblk_tvr * kNumSums;
     a.framecount = c->framecount + (size_t)c->fc_index * pl.nseq;
     a.w = pl.w; a.h = pl.h; a.cap = pl.cap; a.nblk = c->nblk_tvr; a.nseq = pl.nseq;
-    a.zfm = pl.zfm; a.max_r = (double)c->field_radius; a.match_thresh = match_thresh; a.k_huber = k_huber; a.inv_k_huber = 1.0 / k_huber;
+    a.zfm = pl.zfm; a.inv_zfm = 1.0 / pl.zfm; a.max_r = (double)c->field_radius; a.match_thresh = match_thresh; a.k_huber = k_huber; a.inv_k_huber = 1.0 / k_huber;
     a.ppx = pl.ppx; a.ppy = pl.ppy; a.match_num_thresh = match_num_thresh; a.write_mid = write_mid;
     a.use_grec = c->grec_ok[slot_new] && !c->no_grec;
     a.kf = nullptr; a.kf_match_mod = a.kf_match_cang = a.kf_rho_tol = 0;
