@@ -53,6 +53,7 @@ public:
         PipeBuffer *buf_of[4] = {nullptr, nullptr, nullptr, nullptr};   // [step & 3] PipeBuffer of a step in flight (released by player 0,
                                                                         // not yet requested by player 1): later steps are enqueued first
         int ring_idx = -1;         // ring entry of the gathered frame (page-locked ring), -1: a heap image
+        bool step_granted = false; // frame-by-frame mode: the application's "advance" has been taken for the frame about to be grabbed
         bool leaving = false;      // cf->quit seen: the seat closes once the step in flight (which may carry its last frame) is done
         bool have_prev = false;    // a completed frame waits (as player 1's next buffer) for its successor before it is delivered
         int slot_prev = -1;        // ring slot of that frame
@@ -246,13 +247,14 @@ bool REBVO::BatchGroup::gather(bool block, bool &any_running, bool &any_leaving)
             if (cf->quit) { st.leaving = true; any_leaving = true; continue; }
             any_running = true;
             const double min_frame_dt = 1.0 / cf->params.soft_fps - 0.5 / cf->params.config_fps;   // rebvo_first_t.cpp:146
-            if (!st.cbuf && cf->frame_by_frame) {   // frame-by-frame mode (rebvo_first_t.cpp:154-159): no new frame until the application says so
+            if (!st.cbuf && cf->frame_by_frame && !st.step_granted) {   // frame-by-frame mode (rebvo_first_t.cpp:154-159): no new frame until the application says so
                 if (!cf->frame_by_frame_advance) {
                     all = false;
                     if (block) std::this_thread::sleep_for(std::chrono::milliseconds(1));
                     continue;
                 }
                 cf->frame_by_frame_advance = false;
+                st.step_granted = true;   // one "advance" = one frame, however long the frame takes to arrive
                 std::cout << "Advancing frame...\n";
             }
             while (!st.cbuf) {
@@ -261,6 +263,7 @@ bool REBVO::BatchGroup::gather(bool block, bool &any_running, bool &any_leaving)
                 st.p_num++;
                 if (cb->timestamp - st.t0 < min_frame_dt) { cf->cam_pipe.ReleaseBuffer(1); continue; }   // soft-FPS drop, :172-177
                 st.cbuf = cb;
+                st.step_granted = false;
                 st.t_frame = cb->timestamp;
                 st.ring_idx = -1;
                 if (ring) {
