@@ -2,41 +2,39 @@
 """bench.py — frames/sec of the REBVO edge pipeline (DoG + extract + track + depth EKF) on MI355X.
 
 Contract (see the task statement): `python bench.py --gpus N --steps K --warmup W`; for N>1 it is launched
-by torch.distributed.run with one rank per GPU.  One JSON line on rank 0.
+by torch.distributed.run with one rank per GPU.  ONE JSON line on rank 0's stdout, at most 4096 bytes
+(`compact_line`); the full record of the run goes to bench_extras.json next to this file, and to stderr.
 
 Workload of the default line (BASELINE.json configs[2] at the EuRoC size of configs[1]): `--nseq` independent synthetic
 752x480 sequences per GPU ("billboards": textured quads at different depths seen by a moving pinhole camera, EuRoC
 intrinsics and GlobalConfig_EuRoC parameters, ImuMode=0).  One step = one new frame of EVERY sequence through the full
 path: RGB->grey, scale space, DoG, KeyLine extraction, distance field, Minimizer_RV (12 TryVelRot evaluations +
 device-side LM), forward match, rotate, directed matching, regularise, EKF, rescale, pose integration.  Frames are
-resident in HBM before the timed region (a pool of rendered frames, read in place by the first kernel of each sequence);
-nothing is skipped inside it and there is no host synchronisation per step.  Sequences shard across GPUs with no
-data-path collective ("weak" scaling: the per-GPU work is fixed); the per-frame nav records go to rank 0 over RCCL on a
-side stream, double buffered, off the timed critical path.
+resident in HBM before the timed region — every sequence reads its frames from its own copy (`--input distinct`: 26.6 GB
+at the defaults, so stage A's input comes out of HBM, not out of a cache-resident pool) — nothing is skipped inside it and
+there is no host synchronisation per step.  Sequences shard across GPUs with no data-path collective ("weak" scaling: the
+per-GPU work is fixed); the per-frame nav records go to rank 0 over RCCL on a side stream, double buffered, off the timed
+critical path.
 
-Extra objects on the JSON line (rank 0, N = 1):
-  roofline         the kernel group with the most time (HIP events on the stream it runs on, over the timed region): its
-                   algorithmic bytes per launch / mean launch duration against 8 TB/s; `traffic` =
-                   HBM bytes per launch from the committed rocprofv3 PMC passes of this same command (a replayed number:
-                   `traffic_source`), with the calibration of the FETCH_SIZE counter it uses
-  roofline_kernels the same figure for every kernel group of the step
+On the line (rank 0):
+  roofline         the kernel group with the most time (HIP events on the stream it runs on, over the timed region): the bytes
+                   one launch cannot avoid moving (DESIGN.md section 3) / mean launch duration against 8 TB/s = `frac`;
+                   `frac_survey_formula` where SURVEY 8(d)'s per-unit figure counts more; `traffic` / `frac_on_traffic` from the
+                   committed rocprofv3 PMC passes of this command, `issue_frac` (vector-ALU-busy share of all SIMD cycles) from the
+                   committed SQ passes — both used only when stamped with the sha of the library sources that are running
   cpu_baseline     the reference's own mtracklib (oracle/_ref, compiled in place from the reference sources) on the host
-                   cores of this box, three ways: one core, the reference's own two-thread overlap,
-                   node-saturating; median and p95 per frame
-  pose_rmse        BASELINE.json's "pose RMSE vs CPU ref": sequences of the batch against the CPU reference on the same frames
-  batch_sweep      the same full path with 1 / 8 / 64 sequences per launch (1 = a single camera: `single_sequence_ms_per_frame`)
-  heterogeneous    the same batch size with every sequence in its own state: six different scenes, different phases,
-                   a scene cut (estimation restart) in some, KeyLine counts spread — throughput, pose RMSE, and for the
-                   checked sequences a teacher-forced replay (reference state injected before every frame: every frame
-                   must agree) plus the attribution of any free-running departure to a knife-edge frame of the reference
-                   (oracle/teacher.py)
-  extras           the other BASELINE configurations and ImuMode=2, each measured by this file in a process of its own and
-                   condensed: stage_a (configs[1], HBM GB/s), tum_undistort (configs[3]), imu (what GlobalConfig_EuRoC ships),
-                   each with its roofline, cpu_baseline and (where a pose exists) pose_rmse
+                   cores of this box: one core (value), the reference's own two-thread overlap, node-saturating (`modes`)
+  pose_rmse        BASELINE.json's "pose RMSE vs CPU ref": 33 sequences of the batch (N > 1: five per rank, summed over the
+                   ranks) against the CPU reference on the same frames, with the free-running parity counts
+  single_sequence_ms_per_frame   one sequence per launch: the literal form of configs[2] / [4]
+  host_surface     frames/s through the rebvo::REBVO plugin surface (requestCustomCamBuffer -> getNav) for 1 / 8 / 64 objects,
+                   the 8 and the 64 as one batch group each (rebvo_amd/host/src/batch_group.cpp), RGB24 crossing PCIe inside
+In bench_extras.json only: roofline_kernels (every group: frac, traffic, issue_frac), kernel_us_per_step, batch_sweep, the
+per-sequence parity details, and with `--extras` the heterogeneous batch with its teacher-forced replay, the PCIe-inclusive
+legs and the other BASELINE configurations (stage_a, tum_undistort, ImuMode=2), each in a process of its own.
 
 `--config stage_a` (BASELINE configs[1]): DoG + edge_finder KeyLine extraction alone, reported as HBM GB/s.
-`--config tum_undistort` (BASELINE configs[3]): TUM 640x480, GlobalConfig_desk.txt parameters, the undistortion fused
-into the stage-A load.
+`--config tum_undistort` (BASELINE configs[3]): TUM 640x480, GlobalConfig_desk.txt parameters, undistortion on.
 """
 import argparse
 import json
