@@ -4,11 +4,13 @@
 // what the reference would need N processes of rebvorun for (app/rebvorun/main.cpp:58-140, one camera each) is N objects of
 // the same library here, each with its own threads, its own device context and its own callback.
 //
-//   multi_device_replay [--devices D] [--dump PREFIX] <GlobalConfig_0> [<GlobalConfig_1> ...]
+//   multi_device_replay [--devices D] [--group] [--dump PREFIX] <GlobalConfig_0> [<GlobalConfig_1> ...]
 //
 // Every config names its own data set (CameraType=2: DataSetDir / DataSetFile / TimeScale).  --devices D overrides the number of
 // HIP devices the sequences are dealt over (default: all visible ones); a `&GPU Device=` in a config is replaced by the dealt
-// ordinal.  Prints one line per sequence and the node aggregate: frames delivered to the callbacks / wall time from the first
+// ordinal.  --group: the sequences dealt to one device form one batch group there (&GPU BatchGroup, rebvo/rebvo.h: one shared context, one
+// launch set per step for all of them, lock-step; a sequence leaves the group when its list ends) instead of a context each.
+// Prints one line per sequence and the node aggregate: frames delivered to the callbacks / wall time from the first
 // Init() to the last sequence's end.  --dump PREFIX writes PREFIX<i>.txt: frame id, time stamp, KeyLines, matches, EstimationOK,
 // Pos, PoseLie, Vel per delivered frame (the first 14 columns of dataset_replay's dump).
 #include <hip/hip_runtime_api.h>
@@ -56,16 +58,18 @@ struct Sequence {
 
 int main(int argn, char **argv) {
     int devices = -1;
+    bool grouped = false;
     std::string dump_prefix;
     std::vector<std::string> configs;
     for (int i = 1; i < argn; i++) {
         const std::string a = argv[i];
         if (a == "--devices" && i + 1 < argn) devices = std::atoi(argv[++i]);
         else if (a == "--dump" && i + 1 < argn) dump_prefix = argv[++i];
+        else if (a == "--group") grouped = true;
         else configs.push_back(a);
     }
     if (configs.empty()) {
-        std::cout << "usage: multi_device_replay [--devices D] [--dump PREFIX] <GlobalConfig_0> [<GlobalConfig_1> ...]\n";
+        std::cout << "usage: multi_device_replay [--devices D] [--group] [--dump PREFIX] <GlobalConfig_0> [<GlobalConfig_1> ...]\n";
         return 2;
     }
     int visible = 0;
@@ -85,6 +89,10 @@ int main(int argn, char **argv) {
         }
         REBVOParameters p = parsed.getParams();
         p.GpuDevice = (int)(i % (size_t)devices);          // sequence id -> device id
+        if (grouped) {                                      // ... and the sequences of a device into one batch group
+            p.GpuBatchGroup = "device" + std::to_string(p.GpuDevice);
+            p.GpuBatchSize = (int)((configs.size() - (size_t)p.GpuDevice + (size_t)devices - 1) / (size_t)devices);
+        }
         auto s = std::make_unique<Sequence>();
         s->id = (int)i;
         s->device = p.GpuDevice;

@@ -34,7 +34,8 @@
 //    through one edgehip_process_frame (every kernel launch carries the N cameras), each object keeps its own ring, callback, log and
 //    getNav().  The members advance in lock-step — one frame of every running member per step, like a synchronised camera rig or a
 //    multi-sequence replay (BASELINE configs[4]); the group starts once BatchSize members have called Init() and a member that calls
-//    CleanUp() leaves it.  Camera buffers are page-locked and go to the device by asynchronous copies that run under the frames
+//    CleanUp() leaves it; a DataSetCam (CameraType 2) may be a member too — N data sets replayed as one batch on one device, each
+//    through its own object — and leaves when its list ends.  Camera buffers are page-locked and go to the device by asynchronous copies that run under the frames
 //    before (the reference's T0 || T1, rebvo_first_t.cpp:134 / rebvo_second_t.cpp:102); the host waits for a frame's record only
 //    when the next one is already enqueued (or no further frame is waiting), and KeyLines come back as AoS only for a member with a
 //    callback.  An object without a BatchGroup is a group of one: the same engine.
@@ -353,7 +354,13 @@ class REBVO {
     bool cam_pinned = false;       // the camera ring's images are page-locked views of the group's ring (batch_group.cpp), not heap images
     bool groupAttach();            // Init() of such an object
     void groupDetach();            // CleanUp()
-    bool useGroupEngine() const { return params.CameraType == 3 && params.ImuMode == 0 && !params.StereoAvaiable; }
+    // the custom camera always; a DataSetCam when its config names a BatchGroup (a multi-sequence replay on one device): its images
+    // then reach the group through the object's own camera ring, put there by a feeder thread
+    bool useGroupEngine() const {
+        return (params.CameraType == 3 || (params.CameraType == 2 && !params.GpuBatchGroup.empty())) && params.ImuMode == 0 && !params.StereoAvaiable;
+    }
+    std::thread feeder;            // CameraType 2 in a batch group: DataSetCam -> camera ring
+    static void FeedThread(REBVO *cf);
 
     // the stereo rig SecondThread hard-codes (rebvo_second_t.cpp:466-470; EuRoC cam0 -> cam1)
     static const double kRCam2Pair[9], kTCam2Pair[3];

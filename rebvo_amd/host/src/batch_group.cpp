@@ -34,6 +34,7 @@
 #include <vector>
 
 #include "edgehip.h"
+#include "rebvo/datasetcam.h"
 #include "rebvo/rebvo.h"
 #include "rebvo_internal.h"
 
@@ -158,6 +159,7 @@ bool REBVO::groupAttach() {
     }
     quit = false;
     st.out_thread = std::thread(ThirdThread, this);
+    if (dscam) feeder = std::thread(FeedThread, this);
     g->attached++;
     if (g->attached == g->cap) {   // the group is complete: its tracker thread starts
         g->started = true;
@@ -166,9 +168,37 @@ bool REBVO::groupAttach() {
     return true;
 }
 
+// A DataSetCam as a group member: the list's images go through the object's own camera ring, as an application's would
+// (DataSetCam::GrabBuffer decodes; one copy into the page-locked ring).  At the end of the list — or at an image that does not load:
+// the camera's error state — the frames still in the ring are let through (a full round of requests stamped in the past, which the
+// soft-FPS gate drops, succeeds only when everything before has been taken), then the object quits, as REBVO does on a camera
+// error (rebvo_first_t.cpp:165-170): the group lets it go and carries on.
+void REBVO::FeedThread(REBVO *cf) {
+    auto slot = [&](double stamp) -> customCam::CustomCamPipeBuffer * {
+        customCam::CustomCamPipeBuffer *b = nullptr;
+        while (!cf->quit && (b = cf->cam_pipe.RequestBufferTimeoutable(0, 0.01)) == nullptr) {}
+        if (b) b->timestamp = stamp;
+        return b;
+    };
+    while (!cf->quit) {
+        double ts = 0;
+        const RGB24Pixel *data = cf->dscam->GrabBuffer(ts, false);
+        if (!data) break;
+        customCam::CustomCamPipeBuffer *b = slot(ts);
+        if (!b) return;
+        b->img->copyFrom(data);
+        cf->cam_pipe.ReleaseBuffer(0);
+        cf->dscam->ReleaseBuffer();
+    }
+    for (int i = 0; i < CCAMBUFSIZE && !cf->quit; i++)
+        if (slot(-1e300)) cf->cam_pipe.ReleaseBuffer(0);
+    cf->quit = true;
+}
+
 void REBVO::groupDetach() {
     BatchGroup *g = group;
     if (!g) return;
+    if (feeder.joinable()) feeder.join();   // (quit is up: CleanUp() set it)
     BatchGroup::Seat &st = g->seats[group_seat];
     bool last = false;
     {

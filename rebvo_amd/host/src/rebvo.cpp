@@ -357,7 +357,7 @@ bool REBVO::Init() {
     }
     if (useGroupEngine()) return groupAttach();   // batch_group.cpp: the (possibly shared) context and its tracker thread
     if (!params.GpuBatchGroup.empty()) {
-        last_error = "REBVO(hip): &GPU BatchGroup needs CameraType=3, ImuMode=0 and no stereo pair";
+        last_error = "REBVO(hip): &GPU BatchGroup needs ImuMode=0 and no stereo pair";
         std::cout << last_error << "\n";
         return false;
     }

@@ -144,3 +144,33 @@ def test_bench_replays_a_mounted_dataset(tmp_path):
     assert r.returncode == 0, r.stderr[-3000:]
     js = json.loads([ln for ln in r.stdout.splitlines() if ln.strip()][0])
     assert js["data"] == "synthetic" and js["config"]["dataset"] is None
+
+
+def test_data_sets_as_one_batch_group_on_a_device(tmp_path):
+    """multi_device_replay --group (round 5): the sequences dealt to one device form one batch group (&GPU BatchGroup): DataSetCam
+    objects whose images reach the shared N-sequence context through their own camera rings, one launch set per step for all of them.
+    Three data sets of different lengths (a member leaves the group when its list ends, the others carry on): every sequence's dump
+    must equal, number for number, the dump of the same sequence replayed by an object of its own."""
+    exe = os.path.join(ROOT, "rebvo_amd", "lib", "multi_device_replay")
+    if not os.path.exists(exe):
+        pytest.fail("needs multi_device_replay — a broken snapshot, not a reason to skip: run __graft_entry__.build()")
+    w, h = 376, 240
+    p = edgehip.euroc_params(w, h)
+    cfgs, lens = [], (7, 5, 6)
+    for i, n in enumerate(lens):
+        frames = [f for f, _, _ in synth.billboard_sequence(w, h, n, seed=31 + 3 * i)]
+        d, lst, t_ns = _write_euroc_set(tmp_path / f"seq{i}", frames, 1403636579763555584 + 11 * i)
+        cfg = tmp_path / f"cfg{i}"
+        write_global_config(cfg, p, camera_type=2, dataset=(d, lst, 1e-9))
+        cfgs.append(str(cfg))
+    outs = {}
+    for tag, extra in (("alone", []), ("group", ["--group"])):
+        r = subprocess.run([exe, "--devices", "1", "--dump", str(tmp_path / tag), *extra, *cfgs], capture_output=True, text=True, timeout=300)
+        assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-1000:]
+        outs[tag] = r.stdout
+        for i, n in enumerate(lens):
+            assert f"sequence {i} device 0: frames delivered {n - 1}" in r.stdout, r.stdout
+    for i, n in enumerate(lens):
+        a = np.loadtxt(str(tmp_path / "alone") + f"{i}.txt", ndmin=2)
+        g = np.loadtxt(str(tmp_path / "group") + f"{i}.txt", ndmin=2)
+        assert a.shape == g.shape == (n - 1, 14) and np.array_equal(a, g), i
