@@ -388,6 +388,10 @@ int edgehip_set_framecount(edgehip_ctx *ctx, int seq, int slot, uint32_t fc);
  * when anybody else — this call, any stage-level entry point — asks for the slot. */
 int edgehip_download_keylines(edgehip_ctx *ctx, int seq, int slot, edgehip_keyline *kl, int32_t *mask,
                               int32_t *kn_out);
+/* The same lists for several sequences of one slot in ONE packing kernel and one copy per list (the output callbacks of a batch of cameras,
+ * rebvo_amd/host/src/batch_group.cpp): seqs[n] sequence indices, kl[n] destinations of max_points entries each, kn_out[n].  Record for record what
+ * edgehip_download_keylines returns (no mask).  Synchronises. */
+int edgehip_download_keylines_batch(edgehip_ctx *ctx, int slot, int n, const int32_t *seqs, edgehip_keyline *const *kl, int32_t *kn_out);
 /* Inject a KeyLine list (+ mask) into a slot: stage-isolated parity tests. */
 int edgehip_upload_keylines(edgehip_ctx *ctx, int seq, int slot, const edgehip_keyline *kl, int32_t kn,
                             const int32_t *mask, float retuned_thresh);

@@ -652,6 +652,7 @@ int edgehip_destroy(edgehip_ctx *c) {
         for (auto e : c->prof->pool) (void)hipEventDestroy(e);
         delete c->prof;
     }
+    if (c->aos_dev) { (void)hipFree(c->aos_dev); (void)hipHostFree(c->aos_host); (void)hipFree(c->aos_req_dev); (void)hipHostFree(c->aos_req_host); }
     if (c->stream_log) {
         (void)hipStreamSynchronize(c->stream_log); (void)hipStreamDestroy(c->stream_log); (void)hipEventDestroy(c->ev_log);
         for (hipEvent_t e : c->ev_log_ring) if (e) (void)hipEventDestroy(e);
@@ -1110,6 +1111,77 @@ int edgehip_download_keylines(edgehip_ctx *c, int seq, int slot, edgehip_keyline
         if (k.stereo_m_id) { o.stereo_m_id = st_id[i]; o.stereo_rho = st_rho[i]; o.stereo_s_rho = st_srho[i]; }
     }
     *kn_out = kn;
+    return 0;
+}
+
+// One KeyLine of one requested sequence as the reference's 168-byte record (edge_finder.h:45-91): the SoA fields, and the constants
+// edgehip_download_keylines gives the fields the device does not keep (score, net_id, the stereo defaults of edge_finder.cpp:183-194)
+__global__ __launch_bounds__(256) void k_pack_keylines(const KlSoA *kls, const int32_t *__restrict__ kns, const int32_t *__restrict__ req,
+                                                       int32_t *__restrict__ kn_out, edgehip_keyline *__restrict__ out, int cap) {
+    const int j = blockIdx.y, seq = req[j];
+    const int kn = kns[seq];
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i == 0) kn_out[j] = kn;
+    if (i >= kn) return;
+    const KlSoA &k = kls[seq];
+    edgehip_keyline o;
+    o.p_inx = k.p_inx[i];
+    const float2 m_m = k.m_m[i], u_m = k.u_m[i], c_p = k.c_p[i], p_m = k.p_m[i], p_m_0 = k.p_m_0[i], m_m0 = k.m_m0[i];
+    o.m_m[0] = m_m.x; o.m_m[1] = m_m.y; o.u_m[0] = u_m.x; o.u_m[1] = u_m.y;
+    o.n_m = k.n_m[i]; o.score = 0.f;
+    o.c_p[0] = c_p.x; o.c_p[1] = c_p.y;
+    o.rho = k.rho[i]; o.s_rho = k.s_rho[i]; o.rho_nr = k.rho_nr[i]; o.s_rho_nr = k.s_rho_nr[i]; o.rho0 = k.rho0[i]; o.s_rho0 = k.s_rho0[i];
+    o.p_m[0] = p_m.x; o.p_m[1] = p_m.y; o.p_m_0[0] = p_m_0.x; o.p_m_0[1] = p_m_0.y;
+    o.m_id = k.m_id[i]; o.m_id_f = k.m_id_f[i]; o.m_id_kf = k.m_id_kf[i]; o.m_num = k.m_num[i];
+    o.m_m0[0] = m_m0.x; o.m_m0[1] = m_m0.y; o.n_m0 = k.n_m0[i];
+    o.p_id = k.p_id[i]; o.n_id = k.n_id[i];
+    o.net_id = -1; o.stereo_m_id = -1; o.stereo_rho = 1.0; o.stereo_s_rho = 20.0;
+    if (k.stereo_m_id) { o.stereo_m_id = k.stereo_m_id[i]; o.stereo_rho = k.stereo_rho[i]; o.stereo_s_rho = k.stereo_s_rho[i]; }
+    out[(size_t)j * cap + i] = o;
+}
+
+int edgehip_download_keylines_batch(edgehip_ctx *c, int slot, int n, const int32_t *seqs, edgehip_keyline *const *kl, int32_t *kn_out) {
+    EH_ENTER(c);
+    if (int e = check_slot(c, slot)) return e;
+    if (n < 1 || !seqs || !kl || !kn_out) { set_error("download_keylines_batch: bad argument"); return EDGEHIP_ERR_ARG; }
+    for (int j = 0; j < n; j++) {
+        if (int e = check_seq(c, seqs[j])) return e;
+        if (!kl[j]) { set_error("download_keylines_batch: null destination"); return EDGEHIP_ERR_ARG; }
+    }
+    const size_t cap = (size_t)c->plan.cap;
+    if (n > c->aos_requests) {   // staging for n requests (grown, never shrunk)
+        if (c->aos_dev) { (void)hipFree(c->aos_dev); (void)hipHostFree(c->aos_host); (void)hipFree(c->aos_req_dev); (void)hipHostFree(c->aos_req_host); }
+        c->aos_dev = nullptr; c->aos_host = nullptr; c->aos_req_dev = nullptr; c->aos_req_host = nullptr; c->aos_requests = 0;
+        void *q = nullptr;
+        if (hipMalloc(&q, sizeof(edgehip_keyline) * cap * n) != hipSuccess) { (void)hipGetLastError(); set_error("download_keylines_batch: staging alloc failed"); return EDGEHIP_ERR_MEMORY; }
+        c->aos_dev = (edgehip_keyline *)q;
+        if (hipHostMalloc(&q, sizeof(edgehip_keyline) * cap * n, hipHostMallocDefault) != hipSuccess) { (void)hipGetLastError(); set_error("download_keylines_batch: pinned alloc failed"); return EDGEHIP_ERR_MEMORY; }
+        c->aos_host = (edgehip_keyline *)q;
+        if (hipMalloc(&q, sizeof(int32_t) * 2 * n) != hipSuccess) { (void)hipGetLastError(); set_error("download_keylines_batch: staging alloc failed"); return EDGEHIP_ERR_MEMORY; }
+        c->aos_req_dev = (int32_t *)q;
+        if (hipHostMalloc(&q, sizeof(int32_t) * 2 * n, hipHostMallocDefault) != hipSuccess) { (void)hipGetLastError(); set_error("download_keylines_batch: pinned alloc failed"); return EDGEHIP_ERR_MEMORY; }
+        c->aos_req_host = (int32_t *)q;
+        c->aos_requests = n;
+    }
+    if (int e = rot_materialize_enqueue(c, slot)) return e;   // a slot the whole-frame driver rotated out of place (ctx.h: fuse_match)
+    if (int e = sync_all(c)) return e;                        // both frame streams: the slot's producers
+    for (int j = 0; j < n; j++) c->aos_req_host[j] = seqs[j];
+    EH_CHECK(hipMemcpyAsync(c->aos_req_dev, c->aos_req_host, sizeof(int32_t) * n, hipMemcpyHostToDevice, c->stream));
+    hipLaunchKernelGGL(k_pack_keylines, dim3((unsigned)((cap + 255) / 256), (unsigned)n), dim3(256), 0, c->stream, kldev(c, slot),
+                       c->kn_slot + (size_t)slot * c->plan.nseq, c->aos_req_dev, c->aos_req_dev + n, c->aos_dev, (int)cap);
+    EH_LAUNCH_CHECK();
+    EH_CHECK(hipMemcpyAsync(c->aos_req_host + n, c->aos_req_dev + n, sizeof(int32_t) * n, hipMemcpyDeviceToHost, c->stream));
+    EH_CHECK(hipStreamSynchronize(c->stream));
+    for (int j = 0; j < n; j++) {   // only the records that exist cross the link
+        const int32_t kn = c->aos_req_host[n + j];
+        if (kn > 0) EH_CHECK(hipMemcpyAsync(c->aos_host + (size_t)j * cap, c->aos_dev + (size_t)j * cap, sizeof(edgehip_keyline) * kn, hipMemcpyDeviceToHost, c->stream));
+    }
+    EH_CHECK(hipStreamSynchronize(c->stream));
+    for (int j = 0; j < n; j++) {
+        const int32_t kn = c->aos_req_host[n + j];
+        if (kn > 0) memcpy(kl[j], c->aos_host + (size_t)j * cap, sizeof(edgehip_keyline) * kn);
+        kn_out[j] = kn;
+    }
     return 0;
 }
 

@@ -281,6 +281,11 @@ struct edgehip_ctx {
     double *rs_tmp;        // [B][2][CAP] regularised (rho, s_rho) ping-pong
     double *rot_buf;       // [B][9] rotation applied by rotate_keylines
     const double *t_src = nullptr;   // page-locked time stamps of the frame being enqueued (read in place by k_frame_glue mode 0)
+    // edgehip_download_keylines_batch: AoS staging on the device ([requests][CAP] KeyLine records), request lists, page-locked mirror
+    edgehip_keyline *aos_dev = nullptr;
+    edgehip_keyline *aos_host = nullptr;   // page-locked, same shape
+    int32_t *aos_req_dev = nullptr, *aos_req_host = nullptr;   // [2][requests]: sequence ids | KeyLine counts (host side page-locked)
+    int aos_requests = 0;
     edgehip_nav *nav_dev;  // [B] per-frame record
     edgehip_nav *nav_log;  // [nav_log_len][B] ring of per-frame records (optional)
     int nav_log_len;

@@ -199,7 +199,7 @@ EXPORTS = [
     "edgehip_download_resid", "edgehip_minimizer_rv", "edgehip_forward_match", "edgehip_rotate_keylines",
     "edgehip_directed_matching", "edgehip_regularize_ekf", "edgehip_rescale", "edgehip_process_frame",
     "edgehip_next_slot", "edgehip_cur_slot", "edgehip_read_nav", "edgehip_reset", "edgehip_get_state",
-    "edgehip_set_state", "edgehip_get_framecount", "edgehip_set_framecount", "edgehip_download_keylines",
+    "edgehip_set_state", "edgehip_get_framecount", "edgehip_set_framecount", "edgehip_download_keylines", "edgehip_download_keylines_batch",
     "edgehip_upload_keylines", "edgehip_download_plane", "edgehip_download_field", "edgehip_profile_enable",
     "edgehip_profile_count", "edgehip_profile_name", "edgehip_profile_read", "edgehip_profile_select",
     "edgehip_upload_rgb_indexed", "edgehip_bind_rgb_indexed", "edgehip_set_nav_log", "edgehip_read_nav_log",
@@ -561,6 +561,16 @@ class EdgeHip:
                                                     None if mask is None else mask.ctypes.data_as(C.c_void_p),
                                                     C.byref(kn)))
         return kl[:kn.value].copy(), mask
+
+    def download_keylines_batch(self, slot, seqs):
+        """AoS KeyLine lists of several sequences of one slot, one packing kernel (edgehip_download_keylines_batch)."""
+        seqs = np.ascontiguousarray(seqs, dtype=np.int32)
+        n = len(seqs)
+        bufs = [np.zeros(self.cap, KEYLINE_DTYPE) for _ in range(n)]
+        ptrs = (C.c_void_p * n)(*[b.ctypes.data for b in bufs])
+        kn = np.zeros(n, np.int32)
+        self._ck(self.lib.edgehip_download_keylines_batch(self.ctx, slot, n, seqs.ctypes.data_as(C.c_void_p), ptrs, kn.ctypes.data_as(C.c_void_p)))
+        return [b[:k].copy() for b, k in zip(bufs, kn)]
 
     def upload_keylines(self, seq, slot, kl, mask=None, retuned=0.0):
         kl = np.ascontiguousarray(kl, dtype=KEYLINE_DTYPE)

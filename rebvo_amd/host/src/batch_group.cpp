@@ -365,9 +365,14 @@ int REBVO::BatchGroup::enqueue(long step, std::vector<double> &ts, int &slot) {
 }
 
 int REBVO::BatchGroup::complete(long step, int slot, std::vector<edgehip_nav> &navs) {
-    int rc = edgehip_read_nav_log(hip, (int)step, 1, navs.data());   // waits for this frame, not for the one enqueued behind it
+    int rc = edgehip_read_nav_log(hip, (int)step, 1, navs.data());   // waits for this frame, not for the ones enqueued behind it
     if (rc != 0) return rc;
     const double now = detail::now_s();
+    // the members' records; who gets the frame before delivered with its KeyLines
+    std::vector<int32_t> cb_seq;
+    std::vector<edgehip_keyline *> cb_dst;
+    std::vector<PipeBuffer *> cb_buf, deliver(cap, nullptr);
+    int slot_before = -1;
     for (int i = 0; i < cap; i++) {
         Seat &st = seats[i];
         if (!st.running || !st.buf_of[step & 3]) continue;
@@ -390,30 +395,30 @@ int REBVO::BatchGroup::complete(long step, int slot, std::vector<edgehip_nav> &n
         if (!first) cf->pushNav(nb.nav);
         if (st.have_prev) {   // the frame before goes to the output thread, with its edge map as this frame's tracking left it
             PipeBuffer &ob = cf->pipe.RequestBuffer(1);
+            deliver[i] = &ob;
             if (cf->haveCallBack() && newest - step >= 2) {
                 // a callback registered while two steps were in flight: the frame before's ring slot has been detected into again;
                 // this one delivery carries no KeyLines (from the next on the group keeps one step in flight)
                 ob.ef->kn = 0;
             } else if (cf->haveCallBack()) {
-                int32_t kn = 0;
-                rc = edgehip_download_keylines(hip, i, st.slot_prev, reinterpret_cast<edgehip_keyline *>(ob.ef->kl.data()), nullptr, &kn);
-                if (rc != 0) {
-                    std::cout << "\nREBVO: edgehip_download_keylines failed: " << edgehip_last_error() << "\n";
-                    ob.ef->kn = 0;
-                    cf->pipe.ReleaseBuffer(1);
-                    return rc;
-                }
-                ob.ef->kn = kn;
-                const RGB24Pixel *c = ob.imgc->Data();   // Image<float>::ConvertRGB2BW (include/VideoLib/image.h:197-203)
-                float *bw = ob.img->Data();
-                for (uint k = 0; k < ob.img->bSize(); k++) bw[k] = (float)(c[k].pix.r + c[k].pix.g + c[k].pix.b);
+                cb_seq.push_back(i);
+                cb_dst.push_back(reinterpret_cast<edgehip_keyline *>(ob.ef->kl.data()));
+                cb_buf.push_back(&ob);
+                slot_before = st.slot_prev;   // (lock-step: the same slot for every member)
             }
-            cf->pipe.ReleaseBuffer(1);
         }
         st.have_prev = true;
         st.slot_prev = slot;
     }
-    return 0;
+    if (!cb_seq.empty()) {   // AoS KeyLines of every member with a callback: one packing kernel, one copy per list
+        std::vector<int32_t> kn(cb_seq.size(), 0);
+        rc = edgehip_download_keylines_batch(hip, slot_before, (int)cb_seq.size(), cb_seq.data(), cb_dst.data(), kn.data());
+        if (rc != 0) std::cout << "\nREBVO: edgehip_download_keylines_batch failed: " << edgehip_last_error() << "\n";
+        for (size_t j = 0; j < cb_buf.size(); j++) cb_buf[j]->ef->kn = rc == 0 ? kn[j] : 0;
+    }
+    for (int i = 0; i < cap; i++)   // (PipeBuffer::img, the grey image a callback may look at, is formed by the member's output thread)
+        if (deliver[i]) seats[i].cf->pipe.ReleaseBuffer(1);
+    return rc;
 }
 
 void REBVO::BatchGroup::threadMain() {

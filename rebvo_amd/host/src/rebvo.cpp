@@ -553,10 +553,7 @@ void REBVO::TrackThread(REBVO *cf) {
                 } else {
                     old_buf->ef->kn = kn;
                 }
-                // Image<float>::ConvertRGB2BW (include/VideoLib/image.h:197-203)
-                const RGB24Pixel *c = old_buf->imgc->Data();
-                float *bw = old_buf->img->Data();
-                for (uint i = 0; i < old_buf->img->bSize(); i++) bw[i] = (float)(c[i].pix.r + c[i].pix.g + c[i].pix.b);
+                // (PipeBuffer::img for the callback: ConvertRGB2BW runs on the output thread, beside the next frame's tracking)
             } else {
                 // nobody reads the KeyLine payload: skip the download, but keep edge_finder::KNum() as it was set when the frame was
                 // detected — the .m log reports it (rebvo_third_t.cpp:280)
@@ -647,6 +644,12 @@ void REBVO::ThirdThread(REBVO *cf) {
             lie2quat(nv.PoseLie, q);
             t_log << std::scientific << std::setprecision(18) << pbuf.t / cf->params.ImuTimeScale << " " << nv.Pos[0] << " "
                   << nv.Pos[1] << " " << nv.Pos[2] << " " << q[0] << " " << q[1] << " " << q[2] << " " << q[3] << "\n";
+        }
+        if (cf->haveCallBack()) {   // Image<float>::ConvertRGB2BW (include/VideoLib/image.h:197-203): the grey image a consumer may look at
+            const RGB24Pixel *c = pbuf.imgc->Data();
+            float *bw = pbuf.img->Data();
+            const uint npx = pbuf.img->bSize();
+            for (uint i = 0; i < npx; i++) bw[i] = (float)(c[i].pix.r + c[i].pix.g + c[i].pix.b);
         }
         cf->callCallBack(pbuf);   // :329, under call_mutex
         t_proc_last = now_s() - ts;

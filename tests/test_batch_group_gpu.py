@@ -176,3 +176,21 @@ def test_frame_by_frame_mode_and_a_snapshot(tmp_path):
     # the request came before frame 2 was submitted: the output thread honours it with the frame it delivers next — one of object 0's
     # frames up to 2 (delivery runs a frame or two behind submission)
     assert any(np.array_equal(img, frames[tri(k + 0, pool)]) for k in range(0, 3))
+
+
+def test_batched_keyline_download_equals_the_single_one():
+    """edgehip_download_keylines_batch (what a group's callbacks are served from): one packing kernel for several sequences — record
+    for record, byte for byte, what edgehip_download_keylines returns, on the slot the frame driver rotated out of place and on the newest."""
+    n_obj, pool = 5, 6
+    frames = [f for f, _, _ in synth.billboard_sequence(W, H, pool, seed=21)]
+    eh = edgehip.EdgeHip(edgehip.euroc_params(W, H), nseq=n_obj, nslots=3, device=0)
+    for k in range(4):
+        eh.upload_rgb(eh.next_slot(), np.stack([frames[tri(k + i, pool)] for i in range(n_obj)]))
+        eh.process_frame(np.full(n_obj, T0 + DT * k))
+    for slot in ((eh.cur_slot() + 2) % 3, eh.cur_slot()):
+        seqs = [4, 0, 2]
+        got = eh.download_keylines_batch(slot, seqs)
+        for s_, kl in zip(seqs, got):
+            ref = eh.download_keylines(s_, slot, want_mask=False)[0]
+            assert len(kl) == len(ref) > 1000 and kl.tobytes() == ref.tobytes()
+    eh.close()
