@@ -545,7 +545,9 @@ void REBVO::TrackThread(REBVO *cf) {
             if (want) {
                 const int so = (slot + 2) % 3;   // ring of 3: the slot before `slot`
                 int32_t kn = 0;
-                rc = edgehip_download_keylines(cf->hip, 0, so, reinterpret_cast<edgehip_keyline *>(old_buf->ef->kl.data()), nullptr, &kn);
+                const int32_t seq0 = 0;
+                edgehip_keyline *dst = reinterpret_cast<edgehip_keyline *>(old_buf->ef->kl.data());
+                rc = edgehip_download_keylines_batch(cf->hip, so, 1, &seq0, &dst, &kn);   // (one packing kernel + one page-locked copy)
                 if (rc != 0) {   // a failed download is a device error like any other: report it and stop (no silent empty map)
                     std::cout << "\nREBVO: edgehip_download_keylines failed: " << edgehip_last_error() << "\n";
                     failed = true;
