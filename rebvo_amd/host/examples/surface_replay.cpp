@@ -4,7 +4,7 @@
 // (per-object results against the reference) and by bench.py's `host_surface` leg (frames per second through the surface).
 //
 //   surface_replay <GlobalConfig> <frames.rgb24> <pool_frames> <objects> <frames_per_object> <t0> <dt>
-//                  [--group NAME] [--callback] [--dump PREFIX] [--threads T] [--warmup W] [--leave I:F] [--step-mode] [--snapshot-at F]
+//                  [--group NAME] [--callback] [--dump PREFIX] [--threads T] [--warmup W] [--leave I:F] [--step-mode] [--snapshot-at F] [--dup I:F]
 //
 // frames.rgb24 = pool_frames x ImageHeight x ImageWidth x 3 bytes.  Object i's frame k is pool frame tri(k + i): the triangle wave
 // over the pool bench.py uses (forward then backward: continuous motion), every object at its own phase.  Frame k of every object
@@ -15,6 +15,8 @@
 //   {"objects": N, "frames_per_object": K, "timed_frames": ..., "seconds": ..., "fps": ..., "callbacks": ..., "group": ...}
 // --leave I:F: object I calls CleanUp() after its frame F-1 (a camera that goes away; the others carry on).
 // --step-mode: object 0 runs frame by frame (toggleFrameByFrame; a helper thread calls advanceFrameByFrame() every millisecond).
+// --dup I:F: object I submits one more frame in front of its frame F, stamped like frame F-1: the soft-FPS gate drops it (rebvo_first_t.cpp:172-177)
+//   and the object's camera ring runs one entry ahead of the others' from then on (the group then copies its frames separately).
 // --snapshot-at F: object 0's TakeSnapshot() is called before its frame F is submitted (Snap0.ppm in the working directory).
 // timed over the frames after the first W of every object (default 0), from the submission of frame W to the moment every
 // object's getNav() shows its last frame.
@@ -75,7 +77,7 @@ int main(int argn, char **argv) {
     const double t0 = atof(argv[6]), dt = atof(argv[7]);
     std::string group, dump_prefix;
     bool want_cb = false;
-    int T = 1, W = 0, leave_obj = -1, leave_at = 0, snapshot_at = -1;
+    int T = 1, W = 0, leave_obj = -1, leave_at = 0, snapshot_at = -1, dup_obj = -1, dup_at = 0;
     bool step_mode = false;
     for (int a = 8; a < argn; a++) {
         const std::string s = argv[a];
@@ -86,6 +88,7 @@ int main(int argn, char **argv) {
         else if (s == "--warmup" && a + 1 < argn) W = atoi(argv[++a]);
         else if (s == "--step-mode") step_mode = true;
         else if (s == "--snapshot-at" && a + 1 < argn) snapshot_at = atoi(argv[++a]);
+        else if (s == "--dup" && a + 1 < argn) { if (std::sscanf(argv[++a], "%d:%d", &dup_obj, &dup_at) != 2) return 2; }
         else if (s == "--leave" && a + 1 < argn) { if (std::sscanf(argv[++a], "%d:%d", &leave_obj, &leave_at) != 2) return 2; }
         else { std::cout << "unknown argument " << s << "\n"; return 2; }
     }
@@ -133,6 +136,14 @@ int main(int argn, char **argv) {
                 if (i == leave_obj && k >= leave_at) {
                     if (k == leave_at) obj[i]->CleanUp();
                     continue;
+                }
+                if (i == dup_obj && k == dup_at && k > 0) {   // a frame the soft-FPS gate drops: same stamp as the one before
+                    std::shared_ptr<Image<RGB24Pixel>> dp;
+                    while (!obj[i]->requestCustomCamBuffer(dp, t0 + dt * (k - 1), 0.1))
+                        if (!obj[i]->Running()) { bad = true; break; }
+                    if (bad) break;
+                    (*dp).copyFrom(reinterpret_cast<const RGB24Pixel *>(pool.data()));
+                    obj[i]->releaseCustomCamBuffer();
                 }
                 if (i == 0 && k == snapshot_at) obj[0]->TakeSnapshot();
                 std::shared_ptr<Image<RGB24Pixel>> ptr;

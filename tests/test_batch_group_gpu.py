@@ -194,3 +194,19 @@ def test_batched_keyline_download_equals_the_single_one():
             ref = eh.download_keylines(s_, slot, want_mask=False)[0]
             assert len(kl) == len(ref) > 1000 and kl.tobytes() == ref.tobytes()
     eh.close()
+
+
+def test_a_member_whose_ring_runs_ahead_after_a_dropped_frame(tmp_path):
+    """The soft-FPS gate (rebvo_first_t.cpp:146, 172-177) per member: one object submits a frame too many (stamped like the one
+    before it) — dropped, and from then on that object's camera ring stands one entry ahead of the others', so its frames no longer
+    lie next to theirs in the group's page-locked ring and go up in a copy of their own.  Results: as if nothing had happened."""
+    n_obj, n_fr, pool = 4, 7, 6
+    frames = [f for f, _, _ in synth.billboard_sequence(W, H, pool, seed=17)]
+    js, dumps, out = _run(tmp_path, frames, n_obj, n_fr, ["--group", "drop", "--dup", "2:3"])
+    navs, kls = _ctypes_batch(frames, n_obj, n_fr)
+    for i in range(n_obj):
+        rows = dumps[i].copy()
+        if i == 2:      # the dropped frame took a camera sequence number (p_id counts frames grabbed, rebvo_first_t.cpp:89)
+            assert [int(r[0]) for r in rows] == [0, 1, 2, 4, 5, 6][:len(rows)]
+            rows[:, 0] = np.arange(len(rows))
+        _check_against_batch(rows, navs, kls, i, n_fr - 1)
