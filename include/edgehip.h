@@ -185,6 +185,9 @@ int edgehip_upload_rgb_pinned(edgehip_ctx *ctx, int slot, const uint8_t *rgb24_p
  * stream are done) — the point at which a camera ring may hand the buffers back to the application
  * (cam_pipe.ReleaseBuffer, src/VideoLib/customcam.cpp:70-76).  The frames' processing is NOT waited for. */
 int edgehip_upload_sync(edgehip_ctx *ctx);
+/* The same for the *_pinned uploads into ONE slot: copies into other slots enqueued behind them keep running.  A camera ring whose
+ * frame k+1 is already going up behind frame k hands frame k's buffers back with this (rebvo_amd/host/src/batch_group.cpp). */
+int edgehip_upload_wait(edgehip_ctx *ctx, int slot);
 
 /* Bench/replay helper: frame pool resident in HBM ([pool_frames][h][w][3]); sequence s takes frame
  * idx[s] (host array, nseq entries).  One gather kernel on the context stream. */

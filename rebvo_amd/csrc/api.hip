@@ -783,6 +783,13 @@ int edgehip_upload_sync(edgehip_ctx *c) {
     if (c->stream_up) EH_CHECK(hipStreamSynchronize(c->stream_up));
     return 0;
 }
+// the page-locked sources of the copies into ONE slot have been read (copies into other slots issued behind them may still run)
+int edgehip_upload_wait(edgehip_ctx *c, int slot) {
+    EH_ENTER(c);
+    if (int e = check_slot(c, slot)) return e;
+    EH_CHECK(hipEventSynchronize(c->ev_up[slot]));   // (an event that was never recorded counts as complete)
+    return 0;
+}
 int edgehip_upload_rgb_pinned(edgehip_ctx *c, int slot, const uint8_t *rgb24_pinned, int seq_first, int count) {
     EH_ENTER(c);
     if (int e = check_slot(c, slot)) return e;

@@ -38,6 +38,16 @@ public:
         cv.notify_all();
     }
 
+    // A player that holds more than one buffer (it requested the next before it was done with the one before) releases the older
+    // ones by address, oldest first.  Not in the reference: its players hold one buffer at a time.
+    void ReleaseBufferAt(unsigned PlayerId, const OPipe *buf) {
+        {
+            std::lock_guard<std::mutex> locker(mut);
+            CircPlayer[(size_t)(buf - CircBuff.data())] = PlayerId;
+        }
+        cv.notify_all();
+    }
+
     OPipe &RequestBuffer(int PlayerId) {
         std::unique_lock<std::mutex> lk(mut);
         const unsigned next = (PlayerPos[PlayerId] + 1) % CircSize;

@@ -9,7 +9,10 @@
 //             buffers are views of it, so the application's copyFrom() writes where the DMA reads, and members that are at the
 //             same ring entry — all of them, unless somebody dropped a frame — go up in a single asynchronous copy on the upload
 //             stream, under the kernels of the frames before), then one edgehip_process_frame for all members
-//   release   the camera buffers, once the copies have read them (edgehip_upload_sync: the frames themselves are still running)
+//   look ahead: if every member's next frame is waiting already, it goes up at once, behind this step's copy (the link stays busy
+//             while this thread turns to the results of earlier steps)
+//   release   this step's camera buffers, once the copies have read them (edgehip_upload_wait: the frames themselves are still
+//             running, and so may the next step's copies)
 //   complete  the PREVIOUS step: its per-sequence records out of the device's nav log (edgehip_read_nav_log waits for that frame
 //             only), NavData / PipeBuffer of every member, and the hand-off of the frame before to the member's output thread —
 //             with its KeyLines as AoS only if that member has a callback
@@ -24,8 +27,11 @@
 // Hand-off order is the reference's (rebvo_second_t.cpp:622-623): frame j reaches a member's callback after frame j+1 has been
 // tracked against it, carrying its own record and its edge map as the tracker left it; the last frame is never delivered.
 #include <algorithm>
+#include <array>
 #include <chrono>
 #include <condition_variable>
+#include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <iostream>
 #include <map>
@@ -48,6 +54,7 @@ public:
         bool closed = true;        // the group thread no longer touches cf
         std::thread out_thread;    // the member's ThirdThread
         customCam::CustomCamPipeBuffer *cbuf = nullptr;   // frame gathered for the step being assembled
+        customCam::CustomCamPipeBuffer *chold = nullptr;  // frame of the step launched last: held until its copy has read it
         double t_frame = 0, t0 = 0;
         int p_num = 0;
         long frames = 0;           // frames of this member enqueued so far
@@ -74,6 +81,9 @@ public:
     uint8_t *ring = nullptr;       // page-locked [CCAMBUFSIZE][cap][frame]: the members' camera buffers (null: heap images, staged uploads)
     size_t frame_bytes = 0;
     long newest = -1;              // newest step enqueued
+    // where the group thread's time goes (REBVO_GROUP_TIMING=1 prints it when the thread ends)
+    struct Timing { double gather = 0, upload = 0, process = 0, buffers = 0, ahead = 0, held = 0, records = 0, handoff = 0; long steps = 0, ahead_hits = 0; } tm;
+    std::vector<std::array<double, 5>> tlog;   // REBVO_GROUP_TIMING=2: when things happened on the group thread, step by step
 
     // ---- registry of named groups ----
     static std::mutex &regMutex() { static std::mutex m; return m; }
@@ -83,7 +93,9 @@ public:
 
     void threadMain();
     bool gather(bool block, bool &any_running, bool &any_leaving);
-    int enqueue(long step, std::vector<double> &ts, int &slot);
+    int upload(std::vector<double> &ts, int &slot);
+    int launch(long step, const std::vector<double> &ts);
+    int releaseHeld(int slot);
     int complete(long step, int slot, std::vector<edgehip_nav> &navs);
     uint8_t *ringImage(int entry, int seat) { return ring + ((size_t)entry * cap + seat) * frame_bytes; }
     void closeSeat(Seat &st);
@@ -244,7 +256,8 @@ void REBVO::groupDetach() {
 void REBVO::BatchGroup::closeSeat(Seat &st) {
     // shutdown of one member: the frame still held for it is not delivered (as in the reference); pass the quit flag on
     REBVO *cf = st.cf;
-    if (st.cbuf) { cf->cam_pipe.ReleaseBuffer(1); st.cbuf = nullptr; }
+    if (st.chold) { cf->cam_pipe.ReleaseBufferAt(1, st.chold); st.chold = nullptr; }
+    if (st.cbuf) { cf->cam_pipe.ReleaseBufferAt(1, st.cbuf); st.cbuf = nullptr; }
     if (st.frames == 0) {   // nothing ever went through player 0: open the ring for player 1
         PipeBuffer &b = cf->pipe.RequestBuffer(0);
         b.quit = true;
@@ -309,10 +322,10 @@ bool REBVO::BatchGroup::gather(bool block, bool &any_running, bool &any_leaving)
     }
 }
 
-int REBVO::BatchGroup::enqueue(long step, std::vector<double> &ts, int &slot) {
+// The gathered frames of one step go up, into the slot the next edgehip_process_frame will take.
+int REBVO::BatchGroup::upload(std::vector<double> &ts, int &slot) {
     slot = edgehip_next_slot(hip);
     int rc = 0;
-    const double tp0 = detail::now_s();
     // runs of neighbouring members whose frames sit in the same entry of the page-locked ring are contiguous memory: one copy each
     // (in lock-step without drops: one copy for the whole group); a heap image goes through the library's staging buffer
     for (int i = 0; i < cap && rc == 0;) {
@@ -329,8 +342,16 @@ int REBVO::BatchGroup::enqueue(long step, std::vector<double> &ts, int &slot) {
         rc = edgehip_upload_rgb_pinned(hip, slot, ringImage(st.ring_idx, i), i, n);
         i += n;
     }
-    if (rc == 0) rc = edgehip_process_frame(hip, ts.data());
+    return rc;
+}
+
+// One edgehip_process_frame for the step whose frames upload() sent, and the members' PipeBuffers of it.
+int REBVO::BatchGroup::launch(long step, const std::vector<double> &ts) {
+    const double tp0 = detail::now_s();
+    int rc = edgehip_process_frame(hip, ts.data());
     if (rc != 0) return rc;
+    const double tp1 = detail::now_s();
+    tm.process += tp1 - tp0;
     // the members' PipeBuffers of this step (player 0), and — while the copies run — the image for a callback's PipeBuffer::imgc
     for (int i = 0; i < cap; i++) {
         Seat &st = seats[i];
@@ -351,23 +372,40 @@ int REBVO::BatchGroup::enqueue(long step, std::vector<double> &ts, int &slot) {
             cf->system_reset = false;
             if (rc != 0) return rc;
         }
-    }
-    // hand the camera buffers back as soon as the copies have read them (the frames are still being processed)
-    if (ring && (rc = edgehip_upload_sync(hip)) != 0) return rc;
-    newest = step;
-    for (Seat &st : seats) {
-        if (!st.running) continue;
-        st.cf->cam_pipe.ReleaseBuffer(1);
+        st.chold = st.cbuf;   // the copy may still be reading it: releaseHeld()
         st.cbuf = nullptr;
         st.frames++;
+    }
+    newest = step;
+    tm.buffers += detail::now_s() - tp1;
+    tm.steps++;
+    return 0;
+}
+
+// Hand the camera buffers of the step launched last back as soon as the copies into its slot have read them (the frames are still
+// being processed, and the next step's copies may already run behind).
+int REBVO::BatchGroup::releaseHeld(int slot) {
+    const double t0 = detail::now_s();
+    struct Acc { double &a; double t; ~Acc() { a += detail::now_s() - t; } } acc{tm.held, t0};
+    if (ring) {
+        const int rc = edgehip_upload_wait(hip, slot);
+        if (rc != 0) return rc;
+    }
+    for (Seat &st : seats) {
+        if (!st.chold) continue;
+        st.cf->cam_pipe.ReleaseBufferAt(1, st.chold);
+        st.chold = nullptr;
     }
     return 0;
 }
 
 int REBVO::BatchGroup::complete(long step, int slot, std::vector<edgehip_nav> &navs) {
+    const double tr0 = detail::now_s();
     int rc = edgehip_read_nav_log(hip, (int)step, 1, navs.data());   // waits for this frame, not for the ones enqueued behind it
     if (rc != 0) return rc;
     const double now = detail::now_s();
+    tm.records += now - tr0;
+    struct Acc { double &a; double t; ~Acc() { a += detail::now_s() - t; } } acc{tm.handoff, now};
     // the members' records; who gets the frame before delivered with its KeyLines
     std::vector<int32_t> cb_seq;
     std::vector<edgehip_keyline *> cb_dst;
@@ -434,31 +472,63 @@ void REBVO::BatchGroup::threadMain() {
         pending.erase(pending.begin());
         return complete(f.step, f.slot, navs);
     };
+    const bool look_ahead = !getenv("REBVO_GROUP_LOOKAHEAD") || atoi(getenv("REBVO_GROUP_LOOKAHEAD")) != 0;   // (0: A/B measurements)
+    bool have_next = false;              // the next step's frames are gathered and on their way up (slot_next)
+    int slot_next = -1;
     while (rc == 0) {
-        bool any = false, leaving = false;
-        // with steps in flight a single pass decides: either the next frames are all waiting (enqueue them under what runs), or
-        // the records of what is in flight are read now
-        bool ready = gather(pending.empty(), any, leaving);
-        if (!ready) {
-            while (rc == 0 && !pending.empty()) rc = complete_oldest();
+        if (!have_next) {
+            bool any = false, leaving = false;
+            // with steps in flight a single pass decides: either the next frames are all waiting (enqueue them under what runs), or
+            // the records of what is in flight are read now
+            const double tg0 = detail::now_s();
+            bool ready = gather(pending.empty(), any, leaving);
+            tm.gather += detail::now_s() - tg0;
+            if (!ready) {
+                while (rc == 0 && !pending.empty()) rc = complete_oldest();
+                if (rc != 0) break;
+            }
+            if (leaving) {   // (nothing of theirs is in flight any more)
+                for (Seat &st : seats)
+                    if (st.running && st.leaving) closeSeat(st);
+                continue;
+            }
+            if (!any) break;
+            if (!ready) continue;
+            const double tu0 = detail::now_s();
+            rc = upload(ts, slot_next);
+            tm.upload += detail::now_s() - tu0;
             if (rc != 0) break;
         }
-        if (leaving) {   // (nothing of theirs is in flight any more)
-            for (Seat &st : seats)
-                if (st.running && st.leaving) closeSeat(st);
-            continue;
-        }
-        if (!any) break;
-        if (!ready) continue;
+        have_next = false;
         bool callbacks = false;
         for (Seat &st : seats) callbacks |= st.running && st.cf->haveCallBack();
         const size_t depth = callbacks ? 1 : 2;
-        int slot = -1;
-        rc = enqueue(step, ts, slot);
+        const int slot = slot_next;
+        std::array<double, 5> tl{};
+        tl[0] = detail::now_s();
+        rc = launch(step, ts);
         if (rc != 0) break;
+        tl[1] = detail::now_s();
         pending.push_back({step, slot});
         step++;
+        {   // look ahead: if every member's next frame is waiting already, its copy goes behind this step's on the upload stream
+            // — before this thread turns to the records of the steps in flight, so the link does not idle while the host works
+            bool any = false, leaving = false;
+            const double ta0 = detail::now_s();
+            if (look_ahead && gather(false, any, leaving)) {
+                rc = upload(ts, slot_next);
+                if (rc != 0) break;
+                have_next = true;
+                tm.ahead_hits++;
+            }
+            tm.ahead += detail::now_s() - ta0;
+        }
+        tl[2] = detail::now_s();
+        rc = releaseHeld(slot);
+        tl[3] = detail::now_s();
         while (rc == 0 && pending.size() > depth) rc = complete_oldest();
+        tl[4] = detail::now_s();
+        if (tlog.size() < 64) tlog.push_back(tl);
     }
     while (rc == 0 && !pending.empty()) rc = complete_oldest();
     if (rc != 0) {
@@ -469,6 +539,18 @@ void REBVO::BatchGroup::threadMain() {
     }
     for (Seat &st : seats)
         if (st.running) closeSeat(st);
+    if (getenv("REBVO_GROUP_TIMING") && tm.steps > 0) {
+        const double k = 1e6 / tm.steps;
+        std::printf("REBVO(hip) group '%s': %ld steps, look-ahead copies %ld; us per step on the group thread: gather %.0f, upload calls %.0f, "
+                    "process_frame %.0f, PipeBuffers %.0f, look-ahead %.0f, wait for the copy + release %.0f, wait for the records %.0f, hand-off %.0f\n",
+                    name.c_str(), tm.steps, tm.ahead_hits, tm.gather * k, tm.upload * k, tm.process * k, tm.buffers * k, tm.ahead * k, tm.held * k,
+                    tm.records * k, tm.handoff * k);
+        if (atoi(getenv("REBVO_GROUP_TIMING")) > 1)
+            for (size_t j = tlog.size() > 12 ? tlog.size() - 12 : 0; j < tlog.size(); j++)
+                std::printf("  step %2zu: launch %8.0f..%8.0f  look-ahead copy issued %8.0f  this step's copy done %8.0f  records of step-2 read %8.0f  (us)\n", j,
+                            (tlog[j][0] - tlog[0][0]) * 1e6, (tlog[j][1] - tlog[0][0]) * 1e6, (tlog[j][2] - tlog[0][0]) * 1e6, (tlog[j][3] - tlog[0][0]) * 1e6,
+                            (tlog[j][4] - tlog[0][0]) * 1e6);
+    }
 }
 
 }  // namespace rebvo
@@ -516,4 +598,39 @@ extern "C" int rebvo_group_selftest(const char *config_file) {
     REBVO z(p);
     if (z.Init()) return 11;                                   // a named group needs BatchSize >= 1
     return 0;
+}
+
+// ---- flat C hook for the CPU tests: the ring of players, with one player holding two buffers ---------------------------------------
+// Player 0 writes 0, 1, 2, ... into a Pipeline<long> of four entries; player 1 takes the next entry BEFORE it lets go of the one
+// before (ReleaseBufferAt: what the group thread does with the camera rings while a copy still reads the older frame) and checks
+// that the values arrive in order and that an entry it still holds is never written.  0 = as it must be.
+extern "C" int rebvo_pipeline_selftest(int count) {
+    using namespace rebvo;
+    Pipeline<long> pipe(4, 2);
+    for (unsigned j = 0; j < pipe.Size(); j++) pipe[j] = -1;
+    std::thread producer([&] {
+        for (long v = 0; v < count; v++) {
+            long &b = pipe.RequestBuffer(0);
+            b = v;
+            pipe.ReleaseBuffer(0);
+        }
+    });
+    int bad = 0;
+    long *held = nullptr;
+    long held_value = -1;
+    for (long v = 0; v < count && !bad; v++) {
+        long *b = pipe.RequestBufferTimeoutable(1, 5.0);
+        if (!b) { bad = 1; break; }                                // the producer starved although an entry was free
+        if (*b != v) bad = 2;                                      // out of order
+        if (held && *held != held_value) bad = 3;                  // written while held
+        if (held) pipe.ReleaseBufferAt(1, held);
+        held = b;
+        held_value = v;
+    }
+    if (held) pipe.ReleaseBufferAt(1, held);
+    if (bad == 1) {   // let the producer run out: hand everything back as it comes
+        for (;;) { long *b = pipe.RequestBufferTimeoutable(1, 0.2); if (!b) break; pipe.ReleaseBuffer(1); }
+    }
+    producer.join();
+    return bad;
 }

@@ -374,3 +374,40 @@ def test_frames_the_tracker_cannot_explain_finish_in_bounded_time(kind):
         assert all(x.kn > 0 for x in eh.read_nav())
     finally:
         eh.close()
+
+
+def test_upload_wait_hands_one_slots_buffer_back_while_the_next_copy_runs():
+    """edgehip_upload_wait(slot): the page-locked source of the copies into THAT slot has been read — the copy into the next slot,
+    enqueued behind it, may still run.  The batch group's order (rebvo_amd/host/src/batch_group.cpp): process frame k, send frame
+    k+1 up, wait for frame k's copy, give its buffer back — here the buffer is scribbled over at once, and the records must equal
+    the plain upload_rgb / process_frame run bit for bit."""
+    w, h, B, nf = 376, 240, 6, 9
+    frames = [f for f, _, _ in synth.billboard_sequence(w, h, 5, seed=23)]
+    tri = lambda k: (k % 8) if (k % 8) < 5 else 8 - (k % 8)
+    batch = lambda k: np.stack([frames[tri(k + s)] for s in range(B)])
+    ref = edgehip.EdgeHip(edgehip.euroc_params(w, h), nseq=B, nslots=3)
+    ref.set_nav_log(nf)
+    for k in range(nf):
+        ref.upload_rgb(ref.next_slot(), batch(k))
+        ref.process_frame(0.05 * k)
+    want = ref.read_nav_log_array(0, nf)
+    ref.close()
+    eh = edgehip.EdgeHip(edgehip.euroc_params(w, h), nseq=B, nslots=3)
+    eh.set_nav_log(nf)
+    bufs = [eh.alloc_pinned_frames() for _ in range(2)]
+    bufs[0][0][...] = batch(0)
+    eh.upload_rgb_pinned(eh.next_slot(), bufs[0][1])
+    for k in range(nf):
+        slot = eh.next_slot()
+        eh.process_frame(0.05 * k)
+        if k + 1 < nf:
+            bufs[(k + 1) % 2][0][...] = batch(k + 1)
+            eh.upload_rgb_pinned(eh.next_slot(), bufs[(k + 1) % 2][1])
+        assert eh.lib.edgehip_upload_wait(eh.ctx, slot) == 0
+        bufs[k % 2][0][...] = 0x5a            # the application writes its next frame here
+    got = eh.read_nav_log_array(0, nf)
+    assert got.tobytes() == want.tobytes()
+    assert eh.lib.edgehip_upload_wait(eh.ctx, 7) != 0   # no such slot
+    for _, ptr in bufs:
+        eh.free_pinned(ptr)
+    eh.close()

@@ -97,3 +97,13 @@ def test_stereo_config_errors(exe, tmp_path):
     write_global_config(cfg, p, camera_type=2, dataset=ds, stereo=st)
     r = _run(cfg, "/dev/null", 0, 1.0, 0.05)
     assert r.returncode == 4 and "Failed to initialize the main camera" in r.stdout
+
+
+def test_a_player_that_holds_two_buffers_of_the_ring():
+    """Pipeline::ReleaseBufferAt (rebvo/pipeline.h; not in the reference, whose players hold one buffer at a time): the group thread
+    takes a member's next camera frame while the copy of the one before still reads it.  Order kept, a held entry never written."""
+    import ctypes as C
+    lib = C.CDLL(os.path.join(ROOT, "rebvo_amd", "lib", "librebvohost.so"))
+    lib.rebvo_pipeline_selftest.restype = C.c_int
+    lib.rebvo_pipeline_selftest.argtypes = [C.c_int]
+    assert lib.rebvo_pipeline_selftest(20000) == 0
