@@ -587,7 +587,9 @@ def host_surface(params, frames, w, h):
     camera rings, asynchronous uploads under the frames before; rebvo_amd/host/src/batch_group.cpp).  Every frame crosses PCIe
     inside the timed region (RGB24, 1.08 MB), so these are PCIe-inclusive figures by construction.  No callback is registered
     for the three headline numbers (KeyLines stay in HBM); `objects_8_with_callbacks_fps` adds one per object (AoS KeyLines back
-    to the host for every frame)."""
+    to the host for every frame).  Run lengths: 600 / 400 / 240 / 150 frames per object, the first 60 / 50 / 40 / 20 untimed — the
+    application runs up to three frames ahead of the tracker (the camera ring) and the last frames drain, which weighed 15-30 % in
+    the 36-frame runs of the first version of this leg."""
     import subprocess
     import tempfile
     from rebvo_amd import config
@@ -599,9 +601,9 @@ def host_surface(params, frames, w, h):
         cfg, raw = os.path.join(td, "cfg"), os.path.join(td, "frames.rgb24")
         config.write_global_config(cfg, params)
         np.stack(frames).tofile(raw)
-        for name, n, k, wm, extra in (("single_camera_fps", 1, 240, 40, []), ("objects_8_fps", 8, 70, 10, ["--group", "g8"]),
-                                      ("objects_64_fps", 64, 36, 6, ["--group", "g64"]),
-                                      ("objects_8_with_callbacks_fps", 8, 40, 8, ["--group", "g8cb", "--callback"])):
+        for name, n, k, wm, extra in (("single_camera_fps", 1, 600, 60, []), ("objects_8_fps", 8, 400, 50, ["--group", "g8"]),
+                                      ("objects_64_fps", 64, 240, 40, ["--group", "g64"]),
+                                      ("objects_8_with_callbacks_fps", 8, 150, 20, ["--group", "g8cb", "--callback"])):
             try:
                 r = subprocess.run([exe, cfg, raw, str(len(frames)), str(n), str(k), "1", str(FRAME_DT), "--warmup", str(wm),
                                     "--threads", str(min(8, n))] + extra, capture_output=True, text=True, timeout=90)

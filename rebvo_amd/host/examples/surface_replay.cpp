@@ -4,7 +4,7 @@
 // (per-object results against the reference) and by bench.py's `host_surface` leg (frames per second through the surface).
 //
 //   surface_replay <GlobalConfig> <frames.rgb24> <pool_frames> <objects> <frames_per_object> <t0> <dt>
-//                  [--group NAME] [--callback] [--dump PREFIX] [--threads T] [--warmup W] [--leave I:F] [--step-mode] [--snapshot-at F] [--dup I:F]
+//                  [--group NAME] [--callback] [--dump PREFIX] [--threads T] [--warmup W] [--leave I:F] [--step-mode] [--snapshot-at F] [--dup I:F] [--tint I:F]
 //
 // frames.rgb24 = pool_frames x ImageHeight x ImageWidth x 3 bytes.  Object i's frame k is pool frame tri(k + i): the triangle wave
 // over the pool bench.py uses (forward then backward: continuous motion), every object at its own phase.  Frame k of every object
@@ -17,6 +17,7 @@
 // --step-mode: object 0 runs frame by frame (toggleFrameByFrame; a helper thread calls advanceFrameByFrame() every millisecond).
 // --dup I:F: object I submits one more frame in front of its frame F, stamped like frame F-1: the soft-FPS gate drops it (rebvo_first_t.cpp:172-177)
 //   and the object's camera ring runs one entry ahead of the others' from then on (the group then copies its frames separately).
+// --tint I:F: the first byte of object I's frame F is flipped (^ 0x80): a coloured pixel in an otherwise mono frame — that step crosses PCIe as RGB24.
 // --snapshot-at F: object 0's TakeSnapshot() is called before its frame F is submitted (Snap0.ppm in the working directory).
 // timed over the frames after the first W of every object (default 0), from the submission of frame W to the moment every
 // object's getNav() shows its last frame.
@@ -77,7 +78,7 @@ int main(int argn, char **argv) {
     const double t0 = atof(argv[6]), dt = atof(argv[7]);
     std::string group, dump_prefix;
     bool want_cb = false;
-    int T = 1, W = 0, leave_obj = -1, leave_at = 0, snapshot_at = -1, dup_obj = -1, dup_at = 0;
+    int T = 1, W = 0, leave_obj = -1, leave_at = 0, snapshot_at = -1, dup_obj = -1, dup_at = 0, tint_obj = -1, tint_at = 0;
     bool step_mode = false;
     for (int a = 8; a < argn; a++) {
         const std::string s = argv[a];
@@ -88,6 +89,7 @@ int main(int argn, char **argv) {
         else if (s == "--warmup" && a + 1 < argn) W = atoi(argv[++a]);
         else if (s == "--step-mode") step_mode = true;
         else if (s == "--snapshot-at" && a + 1 < argn) snapshot_at = atoi(argv[++a]);
+        else if (s == "--tint" && a + 1 < argn) { if (std::sscanf(argv[++a], "%d:%d", &tint_obj, &tint_at) != 2) return 2; }
         else if (s == "--dup" && a + 1 < argn) { if (std::sscanf(argv[++a], "%d:%d", &dup_obj, &dup_at) != 2) return 2; }
         else if (s == "--leave" && a + 1 < argn) { if (std::sscanf(argv[++a], "%d:%d", &leave_obj, &leave_at) != 2) return 2; }
         else { std::cout << "unknown argument " << s << "\n"; return 2; }
@@ -151,6 +153,7 @@ int main(int argn, char **argv) {
                     if (!obj[i]->Running()) { bad = true; break; }
                 if (bad) break;
                 (*ptr).copyFrom(reinterpret_cast<const RGB24Pixel *>(pool.data() + fb * tri((long)k + i, pool_frames)));
+                if (i == tint_obj && k == tint_at) *reinterpret_cast<uint8_t *>((*ptr).Data()) ^= 0x80;
                 obj[i]->releaseCustomCamBuffer();
             }
         }

@@ -255,6 +255,9 @@ struct REBVOParameters {
     // extension: objects with the same non-empty GpuBatchGroup share one device context of GpuBatchSize sequences (&GPU BatchGroup / BatchSize)
     std::string GpuBatchGroup;
     int GpuBatchSize = 0;
+    // extension: frames whose pixels all have R = G = B (a mono camera's, tripled to fit the RGB24 surface) cross PCIe as their 8-bit
+    // plane when every frame of a step is such a frame (&GPU MonoUpload, default 1; src/mono_pack.cpp, batch_group.cpp)
+    bool GpuMonoUpload = true;
 };
 
 // Filter state SecondThread keeps in the IMU branch (reference include/rebvo/rebvo.h:239-290, same member names).
@@ -351,6 +354,8 @@ class REBVO {
     friend class BatchGroup;
     BatchGroup *group = nullptr;
     int group_seat = -1;
+    customCam::CustomCamPipeBuffer *cam_cur = nullptr;   // the buffer the application holds between request and releaseCustomCamBuffer
+    void groupFrameWritten(customCam::CustomCamPipeBuffer *b);
     bool cam_pinned = false;       // the camera ring's images are page-locked views of the group's ring (batch_group.cpp), not heap images
     bool groupAttach();            // Init() of such an object
     void groupDetach();            // CleanUp()
@@ -428,9 +433,14 @@ public:
         if (ccpb == nullptr) return false;
         ptr = (*ccpb).img;
         (*ccpb).timestamp = time_stamp;
+        cam_cur = ccpb;
         return true;
     }
-    void releaseCustomCamBuffer() { cam_pipe.ReleaseBuffer(0); }
+    void releaseCustomCamBuffer() {
+        if (group && cam_cur) groupFrameWritten(cam_cur);   // (a mono frame's 8-bit plane, on this thread: src/mono_pack.cpp)
+        cam_cur = nullptr;
+        cam_pipe.ReleaseBuffer(0);
+    }
     // the pair camera's ring (reference rebvo.h:570-586); one pair frame is consumed per accepted main frame
     bool requestStereoCustomCamBuffer(std::shared_ptr<Image<RGB24Pixel>> &ptr, double time_stamp, double timeout_secs = 0) {
         customCam::CustomCamPipeBuffer *ccpb = cam_pipe_stereo.RequestBufferTimeoutable(0, timeout_secs);

@@ -44,6 +44,8 @@
 #include "rebvo/rebvo.h"
 #include "rebvo_internal.h"
 
+extern "C" int rebvo_pack_mono(const uint8_t *rgb, size_t npix, uint8_t *grey);   // mono_pack.cpp
+
 namespace rebvo {
 
 class REBVO::BatchGroup {
@@ -61,6 +63,9 @@ public:
         PipeBuffer *buf_of[4] = {nullptr, nullptr, nullptr, nullptr};   // [step & 3] PipeBuffer of a step in flight (released by player 0,
                                                                         // not yet requested by player 1): later steps are enqueued first
         int ring_idx = -1;         // ring entry of the gathered frame (page-locked ring), -1: a heap image
+        uint8_t mono_of[CCAMBUFSIZE] = {};   // per ring entry: the frame in it is mono and its 8-bit plane is in grey_ring (written by the
+                                             // application's thread before it releases the entry, read by the group thread after it took it)
+        bool mono = false;         // ... of the gathered frame
         bool step_granted = false; // frame-by-frame mode: the application's "advance" has been taken for the frame about to be grabbed
         bool leaving = false;      // cf->quit seen: the seat closes once the step in flight (which may carry its last frame) is done
         bool have_prev = false;    // a completed frame waits (as player 1's next buffer) for its successor before it is delivered
@@ -80,6 +85,9 @@ public:
     std::string error;
     uint8_t *ring = nullptr;       // page-locked [CCAMBUFSIZE][cap][frame]: the members' camera buffers (null: heap images, staged uploads)
     size_t frame_bytes = 0;
+    uint8_t *grey_ring = nullptr;  // page-locked [CCAMBUFSIZE][cap][w * h]: 8-bit planes of the mono frames among them (null: MonoUpload off)
+    size_t grey_bytes = 0;
+    long mono_steps = 0;           // steps that went up as 8-bit planes
     long newest = -1;              // newest step enqueued
     // where the group thread's time goes (REBVO_GROUP_TIMING=1 prints it when the thread ends)
     struct Timing { double gather = 0, upload = 0, process = 0, buffers = 0, ahead = 0, held = 0, records = 0, handoff = 0; long steps = 0, ahead_hits = 0; } tm;
@@ -98,6 +106,8 @@ public:
     int releaseHeld(int slot);
     int complete(long step, int slot, std::vector<edgehip_nav> &navs);
     uint8_t *ringImage(int entry, int seat) { return ring + ((size_t)entry * cap + seat) * frame_bytes; }
+    uint8_t *greyImage(int entry, int seat) { return grey_ring + ((size_t)entry * cap + seat) * grey_bytes; }
+    int ringEntryOf(const uint8_t *p) const { return ring && p >= ring && p < ring + frame_bytes * CCAMBUFSIZE * cap ? (int)((size_t)(p - ring) / (frame_bytes * cap)) : -1; }
     void closeSeat(Seat &st);
 };
 
@@ -133,9 +143,13 @@ bool REBVO::groupAttach() {
         g->frame_bytes = (size_t)params.ImageSize.w * params.ImageSize.h * sizeof(RGB24Pixel);
         void *ringp = nullptr;
         if (rc == 0 && edgehip_alloc_pinned(g->frame_bytes * CCAMBUFSIZE * want, &ringp) == 0) g->ring = static_cast<uint8_t *>(ringp);
+        g->grey_bytes = (size_t)params.ImageSize.w * params.ImageSize.h;
+        void *greyp = nullptr;
+        if (rc == 0 && g->ring && params.GpuMonoUpload && edgehip_alloc_pinned(g->grey_bytes * CCAMBUFSIZE * want, &greyp) == 0) g->grey_ring = static_cast<uint8_t *>(greyp);
         if (rc != 0) {
             const std::string msg = std::string("REBVO(hip): edgehip_create failed: ") + edgehip_last_error();
             if (g->ring) edgehip_free_pinned(g->ring);
+            if (g->grey_ring) edgehip_free_pinned(g->grey_ring);
             if (g->hip) edgehip_destroy(g->hip);
             delete g;
             return fail(msg);
@@ -199,6 +213,7 @@ void REBVO::FeedThread(REBVO *cf) {
         customCam::CustomCamPipeBuffer *b = slot(ts);
         if (!b) return;
         b->img->copyFrom(data);
+        cf->groupFrameWritten(b);
         cf->cam_pipe.ReleaseBuffer(0);
         cf->dscam->ReleaseBuffer();
     }
@@ -248,8 +263,20 @@ void REBVO::groupDetach() {
         if (g->thr.joinable()) g->thr.join();
         if (g->hip) edgehip_destroy(g->hip);
         if (g->ring) edgehip_free_pinned(g->ring);
+        if (g->grey_ring) edgehip_free_pinned(g->grey_ring);
         delete g;
     }
+}
+
+// The application (or the feeder thread) has written a frame into one of this member's camera buffers and is about to release it:
+// if the frame is a mono camera's, its 8-bit plane goes into the group's second page-locked ring (src/mono_pack.cpp).
+void REBVO::groupFrameWritten(customCam::CustomCamPipeBuffer *b) {
+    BatchGroup *g = group;
+    if (!g || !g->grey_ring || !b || !b->img) return;
+    const uint8_t *p = reinterpret_cast<const uint8_t *>(b->img->Data());
+    const int entry = g->ringEntryOf(p);
+    if (entry < 0) return;
+    g->seats[group_seat].mono_of[entry] = (uint8_t)rebvo_pack_mono(p, g->grey_bytes, g->greyImage(entry, group_seat));
 }
 
 // ---- the group's tracker thread -------------------------------------------------------------------------------------------
@@ -309,10 +336,8 @@ bool REBVO::BatchGroup::gather(bool block, bool &any_running, bool &any_leaving)
                 st.step_granted = false;
                 st.t_frame = cb->timestamp;
                 st.ring_idx = -1;
-                if (ring) {
-                    const uint8_t *p = reinterpret_cast<const uint8_t *>(cb->img->Data());
-                    if (p >= ring && p < ring + frame_bytes * CCAMBUFSIZE * cap) st.ring_idx = (int)((size_t)(p - ring) / (frame_bytes * cap));
-                }
+                st.ring_idx = ringEntryOf(reinterpret_cast<const uint8_t *>(cb->img->Data()));
+                st.mono = grey_ring && st.ring_idx >= 0 && st.mono_of[st.ring_idx] != 0;
             }
             if (!st.cbuf) all = false;
         }
@@ -326,6 +351,10 @@ bool REBVO::BatchGroup::gather(bool block, bool &any_running, bool &any_leaving)
 int REBVO::BatchGroup::upload(std::vector<double> &ts, int &slot) {
     slot = edgehip_next_slot(hip);
     int rc = 0;
+    // a step whose frames are ALL mono goes up as 8-bit planes (a third of the bytes; the slot's format is one per step)
+    bool all_mono = grey_ring != nullptr;
+    for (const Seat &st : seats) all_mono = all_mono && (!st.running || st.mono);
+    if (all_mono) mono_steps++;
     // runs of neighbouring members whose frames sit in the same entry of the page-locked ring are contiguous memory: one copy each
     // (in lock-step without drops: one copy for the whole group); a heap image goes through the library's staging buffer
     for (int i = 0; i < cap && rc == 0;) {
@@ -339,7 +368,8 @@ int REBVO::BatchGroup::upload(std::vector<double> &ts, int &slot) {
         }
         int n = 1;
         while (i + n < cap && seats[i + n].running && seats[i + n].ring_idx == st.ring_idx) { ts[i + n] = seats[i + n].t_frame; n++; }
-        rc = edgehip_upload_rgb_pinned(hip, slot, ringImage(st.ring_idx, i), i, n);
+        rc = all_mono ? edgehip_upload_grey8_pinned(hip, slot, greyImage(st.ring_idx, i), i, n)
+                      : edgehip_upload_rgb_pinned(hip, slot, ringImage(st.ring_idx, i), i, n);
         i += n;
     }
     return rc;
@@ -541,9 +571,9 @@ void REBVO::BatchGroup::threadMain() {
         if (st.running) closeSeat(st);
     if (getenv("REBVO_GROUP_TIMING") && tm.steps > 0) {
         const double k = 1e6 / tm.steps;
-        std::printf("REBVO(hip) group '%s': %ld steps, look-ahead copies %ld; us per step on the group thread: gather %.0f, upload calls %.0f, "
+        std::printf("REBVO(hip) group '%s': %ld steps (%ld as 8-bit planes), look-ahead copies %ld; us per step on the group thread: gather %.0f, upload calls %.0f, "
                     "process_frame %.0f, PipeBuffers %.0f, look-ahead %.0f, wait for the copy + release %.0f, wait for the records %.0f, hand-off %.0f\n",
-                    name.c_str(), tm.steps, tm.ahead_hits, tm.gather * k, tm.upload * k, tm.process * k, tm.buffers * k, tm.ahead * k, tm.held * k,
+                    name.c_str(), tm.steps, mono_steps, tm.ahead_hits, tm.gather * k, tm.upload * k, tm.process * k, tm.buffers * k, tm.ahead * k, tm.held * k,
                     tm.records * k, tm.handoff * k);
         if (atoi(getenv("REBVO_GROUP_TIMING")) > 1)
             for (size_t j = tlog.size() > 12 ? tlog.size() - 12 : 0; j < tlog.size(); j++)

@@ -261,6 +261,10 @@ REBVO::REBVO(const char *configFile)
     config.get("GPU", "Device", p.GpuDevice, false);
     config.get("GPU", "BatchGroup", p.GpuBatchGroup, false);
     config.get("GPU", "BatchSize", p.GpuBatchSize, false);
+    {
+        int mono = 1;
+        if (config.get("GPU", "MonoUpload", mono, false)) p.GpuMonoUpload = mono != 0;
+    }
     construct();
 }
 

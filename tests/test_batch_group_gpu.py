@@ -31,26 +31,29 @@ def tri(k, n):
     return k if k < n else p - k
 
 
-def _run(tmp_path, frames, n_obj, n_fr, extra, tag="run"):
+def _run(tmp_path, frames, n_obj, n_fr, extra, tag="run", gpu=None, env=None):
     if not os.path.exists(EXE):
         pytest.fail("surface_replay not built — a broken snapshot: run __graft_entry__.build()")
     np.stack(frames).tofile(tmp_path / "frames.rgb24")
     cfg = tmp_path / "cfg"
-    write_global_config(cfg, edgehip.euroc_params(W, H))
+    write_global_config(cfg, edgehip.euroc_params(W, H), gpu=gpu)
     prefix = tmp_path / tag
     r = subprocess.run([EXE, str(cfg), str(tmp_path / "frames.rgb24"), str(len(frames)), str(n_obj), str(n_fr), str(T0), str(DT),
-                        "--dump", str(prefix)] + extra, capture_output=True, text=True, timeout=600)
+                        "--dump", str(prefix)] + extra, capture_output=True, text=True, timeout=600, env=dict(os.environ, **(env or {})))
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
     js = json.loads(r.stdout.strip().splitlines()[-1])
     return js, [np.loadtxt(f"{prefix}.{i}.txt", ndmin=2) for i in range(n_obj)], r.stdout
 
 
-def _ctypes_batch(frames, n_obj, n_fr):
-    """The same sequences as one batch through the C-ABI: per step the nav records, and the old slot's KeyLines after the step."""
+def _ctypes_batch(frames, n_obj, n_fr, tint=None):
+    """The same sequences as one batch through the C-ABI: per step the nav records, and the old slot's KeyLines after the step.
+    tint = (object, frame): that frame's first byte flipped, as surface_replay --tint does."""
     eh = edgehip.EdgeHip(edgehip.euroc_params(W, H), nseq=n_obj, nslots=3, device=0)
     navs, kls = [], []
     for k in range(n_fr):
         batch = np.stack([frames[tri(k + i, len(frames))] for i in range(n_obj)])
+        if tint is not None and tint[1] == k:
+            batch[tint[0]].reshape(-1)[0] ^= 0x80
         eh.upload_rgb(eh.next_slot(), batch)
         eh.process_frame(np.full(n_obj, T0 + DT * k))
         navs.append([(np.array(n.Pos[:]), np.array(n.PoseLie[:]), np.array(n.Vel[:]), n.kn, n.klm_num, n.estimation_ok) for n in eh.read_nav()])
@@ -210,3 +213,26 @@ def test_a_member_whose_ring_runs_ahead_after_a_dropped_frame(tmp_path):
             assert [int(r[0]) for r in rows] == [0, 1, 2, 4, 5, 6][:len(rows)]
             rows[:, 0] = np.arange(len(rows))
         _check_against_batch(rows, navs, kls, i, n_fr - 1)
+
+
+def test_mono_frames_cross_pcie_as_8_bit_planes_and_nothing_else_changes(tmp_path):
+    """&GPU MonoUpload (default on; rebvo_amd/host/src/mono_pack.cpp): a step whose frames all have R = G = B goes up as 8-bit planes
+    (edgehip_upload_grey8_pinned), any other step as RGB24 — per step, so one coloured pixel in one member's frame sends that step's
+    frames up in full.  The records and KeyLines are those of the RGB24 batch either way, bit for bit."""
+    import re
+    n_obj, n_fr, pool = 4, 7, 6
+    frames = [f for f, _, _ in synth.billboard_sequence(W, H, pool, seed=29)]
+    assert all(np.array_equal(f[..., 0], f[..., 1]) and np.array_equal(f[..., 1], f[..., 2]) for f in frames)
+    timing = {"REBVO_GROUP_TIMING": "1"}
+    planes = lambda out: int(re.search(r"(\d+) steps \((\d+) as 8-bit planes\)", out).group(2))
+    navs, kls = _ctypes_batch(frames, n_obj, n_fr)
+    for tag, gpu, want in (("mono", dict(group="m", size=n_obj), n_fr), ("rgb", dict(group="m", size=n_obj, mono=0), 0)):
+        js, dumps, out = _run(tmp_path, frames, n_obj, n_fr, [], tag=tag, gpu=gpu, env=timing)
+        assert planes(out) == want, out[-600:]
+        for i in range(n_obj):
+            _check_against_batch(dumps[i], navs, kls, i, n_fr - 1)
+    navs, kls = _ctypes_batch(frames, n_obj, n_fr, tint=(1, 3))
+    js, dumps, out = _run(tmp_path, frames, n_obj, n_fr, ["--tint", "1:3"], tag="tint", gpu=dict(group="m", size=n_obj), env=timing)
+    assert planes(out) == n_fr - 1, out[-600:]
+    for i in range(n_obj):
+        _check_against_batch(dumps[i], navs, kls, i, n_fr - 1)

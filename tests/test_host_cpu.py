@@ -107,3 +107,26 @@ def test_a_player_that_holds_two_buffers_of_the_ring():
     lib.rebvo_pipeline_selftest.restype = C.c_int
     lib.rebvo_pipeline_selftest.argtypes = [C.c_int]
     assert lib.rebvo_pipeline_selftest(20000) == 0
+
+
+def test_mono_frames_are_recognised_and_packed():
+    """rebvo_pack_mono (rebvo_amd/host/src/mono_pack.cpp): 1 and the 8-bit plane when every pixel of an RGB24 frame has R = G = B,
+    0 at the first coloured pixel — wherever it sits (inside a 16-pixel block of the SSSE3 loop, in the scalar tail), for sizes
+    that are not a multiple of 16."""
+    import ctypes as C
+    import numpy as np
+    lib = C.CDLL(os.path.join(ROOT, "rebvo_amd", "lib", "librebvohost.so"))
+    lib.rebvo_pack_mono.restype = C.c_int
+    lib.rebvo_pack_mono.argtypes = [C.c_void_p, C.c_size_t, C.c_void_p]
+    rng = np.random.default_rng(5)
+    for n in (0, 1, 15, 16, 17, 47, 48, 1000, 752 * 480, 376 * 240 + 5):
+        g = rng.integers(0, 256, n, dtype=np.uint8)
+        rgb = np.repeat(g[:, None], 3, axis=1).copy()
+        out = np.full(n + 16, 0xEE, np.uint8)
+        assert lib.rebvo_pack_mono(rgb.ctypes.data, n, out.ctypes.data) == 1, n
+        assert np.array_equal(out[:n], g) and np.all(out[n:] == 0xEE), n
+        for pix in sorted({0, n // 2, max(n - 1, 0), max(n - 17, 0)} if n else set()):
+            for ch in range(3):
+                bad = rgb.copy()
+                bad[pix, ch] ^= 1 << int(rng.integers(0, 8))
+                assert lib.rebvo_pack_mono(bad.ctypes.data, n, out.ctypes.data) == 0, (n, pix, ch)
