@@ -585,7 +585,9 @@ def host_surface(params, frames, w, h):
     through getNav; include/rebvo/rebvo.h:548-609 of the reference): rebvo_amd/lib/surface_replay drives 1, 8 and 64
     rebvo::REBVO objects, the 8 and the 64 as ONE batch group each (&GPU BatchGroup: one shared context, lock-step, page-locked
     camera rings, asynchronous uploads under the frames before; rebvo_amd/host/src/batch_group.cpp).  Every frame crosses PCIe
-    inside the timed region (RGB24, 1.08 MB), so these are PCIe-inclusive figures by construction.  No callback is registered
+    inside the timed region, so these are PCIe-inclusive figures by construction: the application writes RGB24 (1.08 MB per frame,
+    one copyFrom each, up to 16 producer threads); the synthetic frames are mono (R = G = B), so with &GPU MonoUpload at its default
+    the group sends their 8-bit planes (0.36 MB; `objects_64_rgb24_fps` is the same run with MonoUpload = 0: 1.08 MB per frame).  No callback is registered
     for the three headline numbers (KeyLines stay in HBM); `objects_8_with_callbacks_fps` adds one per object (AoS KeyLines back
     to the host for every frame).  Run lengths: 600 / 400 / 240 / 150 frames per object, the first 60 / 50 / 40 / 20 untimed — the
     application runs up to three frames ahead of the tracker (the camera ring) and the last frames drain, which weighed 15-30 % in
@@ -596,17 +598,22 @@ def host_surface(params, frames, w, h):
     exe = os.path.join(ROOT, "rebvo_amd", "lib", "surface_replay")
     if not os.path.exists(exe):
         return {"error": "rebvo_amd/lib/surface_replay not built"}
-    out = {"what": "frames/s through requestCustomCamBuffer/getNav, PCIe inside; 8 and 64 objects = one batch group each"}
+    out = {"what": "frames/s through requestCustomCamBuffer/getNav, PCIe inside (mono frames as 8-bit planes; *_rgb24: as RGB24); 8 and 64 objects = one batch group each"}
     with tempfile.TemporaryDirectory() as td:
         cfg, raw = os.path.join(td, "cfg"), os.path.join(td, "frames.rgb24")
         config.write_global_config(cfg, params)
         np.stack(frames).tofile(raw)
         for name, n, k, wm, extra in (("single_camera_fps", 1, 600, 60, []), ("objects_8_fps", 8, 400, 50, ["--group", "g8"]),
                                       ("objects_64_fps", 64, 240, 40, ["--group", "g64"]),
-                                      ("objects_8_with_callbacks_fps", 8, 150, 20, ["--group", "g8cb", "--callback"])):
+                                      ("objects_8_with_callbacks_fps", 8, 150, 20, ["--group", "g8cb", "--callback"]),
+                                      ("objects_64_rgb24_fps", 64, 240, 40, ["--group", "g64c", "--rgb24"])):
             try:
+                if "--rgb24" in extra:
+                    cfg = os.path.join(td, "cfg_rgb24")
+                    config.write_global_config(cfg, params, gpu=dict(mono=0))
+                    extra = [e for e in extra if e != "--rgb24"]
                 r = subprocess.run([exe, cfg, raw, str(len(frames)), str(n), str(k), "1", str(FRAME_DT), "--warmup", str(wm),
-                                    "--threads", str(min(8, n))] + extra, capture_output=True, text=True, timeout=90)
+                                    "--threads", str(min(16, n))] + extra, capture_output=True, text=True, timeout=90)
                 js = json.loads(r.stdout.strip().splitlines()[-1]) if r.returncode == 0 else None
                 if js is None:
                     raise RuntimeError(f"rc {r.returncode}: {(r.stdout + r.stderr)[-200:]}")
