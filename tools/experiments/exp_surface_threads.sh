@@ -20,7 +20,7 @@ with tempfile.TemporaryDirectory() as td:
     for n, k, wm in ast.literal_eval(os.environ.get('CASES', '((64, 36, 6), (128, 30, 6))')):
         for t in ast.literal_eval(os.environ.get('THREADS', '(4, 8, 16, 32, 64)')):
             for rep in range(int(os.environ.get('REPS', '2'))):
-                r = subprocess.run([exe, cfg, raw, str(len(frames)), str(n), str(k), '1', str(bench.FRAME_DT), '--warmup', str(wm), '--threads', str(t), '--group', 'g'],
+                r = subprocess.run([exe, cfg, raw, str(len(frames)), str(n), str(k), '1', str(bench.FRAME_DT), '--warmup', str(wm), '--threads', str(t), '--group', 'g'] + os.environ.get('EXTRA', '').split(),
                                    capture_output=True, text=True, timeout=120)
                 try:
                     js = json.loads(r.stdout.strip().splitlines()[-1])
