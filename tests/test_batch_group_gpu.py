@@ -236,3 +236,36 @@ def test_mono_frames_cross_pcie_as_8_bit_planes_and_nothing_else_changes(tmp_pat
     assert planes(out) == n_fr - 1, out[-600:]
     for i in range(n_obj):
         _check_against_batch(dumps[i], navs, kls, i, n_fr - 1)
+
+
+def test_without_callbacks_two_steps_in_flight_final_poses_equal_the_batch(tmp_path):
+    """The configuration bench.py's host_surface times: no callback, so two steps in flight, the next step's copy enqueued ahead, mono
+    frames as 8-bit planes — 32 objects over 60 frames, four producer threads.  What getNav() shows at the end must be the ctypes
+    batch's last record, digit for digit; and again with RGB24 uploads (MonoUpload=0)."""
+    import re
+    n_obj, n_fr, pool = 32, 60, 8
+    frames = [f for f, _, _ in synth.billboard_sequence(W, H, pool, seed=31)]
+    eh = edgehip.EdgeHip(edgehip.euroc_params(W, H), nseq=n_obj, nslots=3, device=0)
+    for k in range(n_fr):
+        eh.upload_rgb(eh.next_slot(), np.stack([frames[tri(k + i, pool)] for i in range(n_obj)]))
+        eh.process_frame(np.full(n_obj, T0 + DT * k))
+    want = [np.array(n.Pos[:]) for n in eh.read_nav()]
+    oks = sum(n.estimation_ok for n in eh.read_nav())
+    eh.close()
+    assert oks == n_obj
+    np.stack(frames).tofile(tmp_path / "frames.rgb24")
+    for tag, gpu, planes in (("mono", dict(group="q", size=n_obj), n_fr), ("rgb", dict(group="q", size=n_obj, mono=0), 0)):
+        cfg = tmp_path / f"cfg_{tag}"
+        write_global_config(cfg, edgehip.euroc_params(W, H), gpu=gpu)
+        r = subprocess.run([EXE, str(cfg), str(tmp_path / "frames.rgb24"), str(pool), str(n_obj), str(n_fr), str(T0), str(DT), "--threads", "4"],
+                           capture_output=True, text=True, timeout=600, env=dict(os.environ, REBVO_GROUP_TIMING="1"))
+        assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
+        js = json.loads(r.stdout.strip().splitlines()[-1])
+        assert js["callbacks"] == 0 and js["objects"] == n_obj
+        m = re.search(r"(\d+) steps \((\d+) as 8-bit planes\), look-ahead copies (\d+)", r.stdout)
+        assert m and int(m.group(1)) == n_fr and int(m.group(2)) == planes, r.stdout[-800:]
+        got = {int(a): np.array([float(x), float(y), float(z)]) for a, x, y, z in
+               re.findall(r"object (\d+) final Pos = (\S+) (\S+) (\S+)", r.stdout)}
+        assert len(got) == n_obj
+        for i in range(n_obj):
+            assert np.array_equal(got[i], want[i]), (tag, i, got[i], want[i])
