@@ -1,12 +1,13 @@
 """GlobalConfig files in the reference's format, written from an edgehip Params struct (tests, bench.py, examples)."""
 
 
-def write_global_config(path, p, log_file="", tray_file="", save_log=0, camera_type=3, drop=(), dataset=None, imu=None, stereo=None, gpu=None):
+def write_global_config(path, p, log_file="", tray_file="", save_log=0, camera_type=3, drop=(), dataset=None, imu=None, stereo=None, gpu=None, affinity=None):
     """A GlobalConfig file in the reference's format (app/rebvorun/GlobalConfig_EuRoC) from a Params struct.
     `drop` lists "Section/Key" entries to leave out (missing-key error tests).  `imu` = dict(mode=1|2, file=..., se3=...,
     time_scale=..., plus any key of the &IMU section to override) switches the IMU branch on.  `stereo` = dict(dir=..., file=...,
     ppx=, ppy=, zfx=, zfy=) sets StereoAvaiable with the pair camera's list and the &Stereo intrinsics.  `gpu` = dict(device=,
-    group=, size=, mono=) writes the optional &GPU section (Device, BatchGroup, BatchSize, MonoUpload: rebvo_amd/host/include/rebvo/rebvo.h)."""
+    group=, size=, mono=) writes the optional &GPU section (Device, BatchGroup, BatchSize, MonoUpload: rebvo_amd/host/include/rebvo/rebvo.h).
+    `affinity` = (CamaraT1, CamaraT2, CamaraT3) writes &ProcesorConfig with SetAffinity=1."""
     sec = {
         "Detector": [("Sigma0", p.sigma0), ("KSigma", p.ksigma), ("ReferencePoints", p.reference_points),
                      ("MaxPoints", p.max_points), ("TrackPoints", p.track_points), ("DetectorThresh", p.detector_thresh),
@@ -50,6 +51,8 @@ def write_global_config(path, p, log_file="", tray_file="", save_log=0, camera_t
         sec["DataSetCamera"] = [("DataSetDir", dataset[0]), ("DataSetFile", dataset[1]), ("TimeScale", dataset[2])]
         if stereo is not None:
             sec["DataSetCamera"] += [("DataSetDirStereo", stereo["dir"]), ("DataSetFileStereo", stereo["file"])]
+    if affinity is not None:
+        sec["ProcesorConfig"] = [("SetAffinity", 1), ("CamaraT1", affinity[0]), ("CamaraT2", affinity[1]), ("CamaraT3", affinity[2])]
     if gpu is not None:
         sec["GPU"] = [(k_, gpu[g_]) for k_, g_ in (("Device", "device"), ("BatchGroup", "group"), ("BatchSize", "size"), ("MonoUpload", "mono")) if g_ in gpu]
     with open(path, "w") as f:

@@ -493,6 +493,12 @@ void REBVO::BatchGroup::threadMain() {
     static_assert(sizeof(KeyLine) == sizeof(edgehip_keyline), "KeyLine mirrors edgehip_keyline");
     std::vector<double> ts(cap, 0.0);
     std::vector<edgehip_nav> navs(cap);
+    // &ProcesorConfig: the group's thread is every member's "first thread"; the first member's CamaraT1 places it (rebvo_first_t.cpp:136-141)
+    if (seats[0].cf && seats[0].cf->params.cpuSetAffinity && !detail::set_affinity(seats[0].cf->params.cpu0)) {
+        std::cout << "REBVO: Cannot set cpu affinity on the first thread";
+        for (Seat &st : seats)
+            if (st.running) st.cf->quit = true;
+    }
     long step = 0;                       // frames of the context enqueued so far
     struct InFlight { long step; int slot; };
     std::vector<InFlight> pending;       // steps enqueued and not yet completed, oldest first (at most 2)

@@ -10,6 +10,9 @@
 
 #include "rebvo/rebvo.h"
 
+#include <pthread.h>
+#include <sched.h>
+
 #include <chrono>
 #include <cstdio>
 #include <cmath>
@@ -106,6 +109,14 @@ void lie2quat(const Vector3 &W, double q[4]) {
 namespace detail {
 double now_s() {
     return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count();
+}
+
+bool set_affinity(int cpu) {
+    if (cpu < 0 || cpu >= CPU_SETSIZE) return false;
+    cpu_set_t set;
+    CPU_ZERO(&set);
+    CPU_SET(cpu, &set);
+    return pthread_setaffinity_np(pthread_self(), sizeof(cpu_set_t), &set) == 0;
 }
 
 void fill_hip_params(const REBVOParameters &p, edgehip_params &h) {
@@ -258,6 +269,13 @@ REBVO::REBVO(const char *configFile)
     } else {
         p.StereoAvaiable = false;
     }
+    // &ProcesorConfig (src/rebvo/rebvo.cpp:101-104): honoured when present.  CamaraT1 is the thread that takes frames and tracks them
+    // (FirstThr and SecondThread of the reference are one thread here: the device does their work), CamaraT3 the output thread;
+    // CamaraT2 is read and unused.
+    config.get("ProcesorConfig", "SetAffinity", p.cpuSetAffinity, false);
+    config.get("ProcesorConfig", "CamaraT1", p.cpu0, false);
+    config.get("ProcesorConfig", "CamaraT2", p.cpu1, false);
+    config.get("ProcesorConfig", "CamaraT3", p.cpu2, false);
     config.get("GPU", "Device", p.GpuDevice, false);
     config.get("GPU", "BatchGroup", p.GpuBatchGroup, false);
     config.get("GPU", "BatchSize", p.GpuBatchSize, false);
@@ -412,6 +430,10 @@ bool REBVO::CleanUp() {
 // ---- tracking thread ----------------------------------------------------------------------------------------
 void REBVO::TrackThread(REBVO *cf) {
     std::thread Thr2(ThirdThread, cf);
+    if (cf->params.cpuSetAffinity && !detail::set_affinity(cf->params.cpu0)) {   // rebvo_first_t.cpp:136-141
+        std::cout << "REBVO: Cannot set cpu affinity on the first thread";
+        cf->quit = true;
+    }
     const size_t frame_bytes = (size_t)cf->params.ImageSize.w * cf->params.ImageSize.h * 3;
     static_assert(sizeof(KeyLine) == sizeof(edgehip_keyline), "KeyLine mirrors edgehip_keyline");
     double t0 = 0;
@@ -590,6 +612,10 @@ void REBVO::TrackThread(REBVO *cf) {
 
 // ---- output thread (src/rebvo/rebvo_third_t.cpp:172-347) -------------------------------------------------------
 void REBVO::ThirdThread(REBVO *cf) {
+    if (cf->params.cpuSetAffinity && !detail::set_affinity(cf->params.cpu2)) {   // rebvo_third_t.cpp:54-59
+        std::cout << "REBVO: Cannot set cpu affinity on the third thread";
+        cf->quit = true;
+    }
     std::ofstream a_log, t_log;
     if (cf->params.SaveLog) {
         a_log.open(cf->params.LogFile.c_str());

@@ -11,6 +11,8 @@ double now_s();
 void fill_hip_params(const REBVOParameters &p, edgehip_params &h);
 // edgehip_nav -> NavData, ImuMode 0 (rebvo_second_t.cpp:550-606)
 void fill_nav(const edgehip_nav &n, NavData &nav);
+// REBVO::setAffinity (include/rebvo/rebvo.h:424-430): the calling thread onto one CPU; false when the kernel refuses (or cpu is no CPU)
+bool set_affinity(int cpu);
 }  // namespace detail
 }  // namespace rebvo
 #endif

@@ -61,3 +61,30 @@ def test_custom_cam_replay_matches_reference(tmp_path):
     assert np.allclose(tr[:, 0], t0 + dt * np.arange(n - 1))
     assert np.allclose(np.linalg.norm(tr[:, 4:8], axis=1), 1.0)
     assert np.allclose(tr[-1, 1:4], navs[n - 2].Pos[:], atol=1e-6 * path + 1e-9)
+
+
+def test_processor_config_places_the_threads(tmp_path):
+    """&ProcesorConfig SetAffinity / CamaraT1 / CamaraT3 (src/rebvo/rebvo.cpp:101-104, rebvo_first_t.cpp:136-141,
+    rebvo_third_t.cpp:54-59): the tracking and the output thread are pinned where the config says — same results —
+    and a CPU that does not exist stops the object with the reference's message."""
+    if not os.path.exists(EXE):
+        pytest.fail("custom_cam_replay not built — a broken snapshot: run __graft_entry__.build()")
+    w, h, n, t0, dt = 376, 240, 6, 1.0, 0.05
+    frames = [f for f, _, _ in synth.billboard_sequence(w, h, n)]
+    np.stack(frames).tofile(tmp_path / "frames.rgb24")
+    cpus = sorted(os.sched_getaffinity(0))
+    outs = []
+    for tag, aff in (("free", None), ("pinned", (cpus[0], cpus[0], cpus[-1]))):
+        cfg, dump = tmp_path / f"cfg_{tag}", tmp_path / f"dump_{tag}.txt"
+        write_global_config(cfg, edgehip.euroc_params(w, h), affinity=aff)
+        r = subprocess.run([EXE, str(cfg), str(tmp_path / "frames.rgb24"), str(n), str(t0), str(dt), str(dump)],
+                           capture_output=True, text=True, timeout=300)
+        assert r.returncode == 0 and "Cannot set cpu affinity" not in r.stdout, r.stdout + r.stderr
+        outs.append(open(dump).read())
+    assert outs[0] == outs[1] and len(outs[0].splitlines()) == n - 1
+    cfg = tmp_path / "cfg_bad"
+    write_global_config(cfg, edgehip.euroc_params(w, h), affinity=(100000, 0, 100000))
+    r = subprocess.run([EXE, str(cfg), str(tmp_path / "frames.rgb24"), str(n), str(t0), str(dt), str(tmp_path / "dump_bad.txt")],
+                       capture_output=True, text=True, timeout=300)
+    assert "Cannot set cpu affinity" in r.stdout, r.stdout + r.stderr
+    assert r.returncode != 0 or len(open(tmp_path / "dump_bad.txt").read().splitlines()) < n - 1
