@@ -395,6 +395,12 @@ int edgehip_download_keylines(edgehip_ctx *ctx, int seq, int slot, edgehip_keyli
  * rebvo_amd/host/src/batch_group.cpp): seqs[n] sequence indices, kl[n] destinations of max_points entries each, kn_out[n].  Record for record what
  * edgehip_download_keylines returns (no mask).  Synchronises. */
 int edgehip_download_keylines_batch(edgehip_ctx *ctx, int slot, int n, const int32_t *seqs, edgehip_keyline *const *kl, int32_t *kn_out);
+/* Page-lock host memory the caller owns, in place (hipHostRegister), so that edgehip_download_keylines_batch copies straight into
+ * it: a destination inside a registered range skips the library's staging buffer and the host memcpy behind it (2.4 MB per list of
+ * 14 k KeyLines).  What a batch group does with the KeyLine arrays of the members that have an output callback
+ * (PipeBuffer::ef of setOutputCallback, include/rebvo/rebvo.h:595-609).  Unregister before the memory is freed. */
+int edgehip_register_host(void *p, size_t bytes);
+int edgehip_unregister_host(void *p);
 /* Inject a KeyLine list (+ mask) into a slot: stage-isolated parity tests. */
 int edgehip_upload_keylines(edgehip_ctx *ctx, int seq, int slot, const edgehip_keyline *kl, int32_t kn,
                             const int32_t *mask, float retuned_thresh);

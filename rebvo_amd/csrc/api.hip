@@ -776,6 +776,38 @@ int edgehip_free_pinned(void *p) {
     if (p) EH_CHECK(hipHostFree(p));
     return 0;
 }
+// Host memory the caller owns, page-locked in place (hipHostRegister): edgehip_download_keylines_batch copies straight into a
+// destination that lies in a registered range instead of through its own staging buffer and a host memcpy.
+static std::mutex g_reg_mu;
+static std::vector<std::pair<const char *, size_t>> g_reg;
+int edgehip_register_host(void *p, size_t bytes) {
+    if (!p || bytes == 0) { set_error("register_host: null range"); return EDGEHIP_ERR_ARG; }
+    if (hipHostRegister(p, bytes, hipHostRegisterPortable) != hipSuccess) {
+        (void)hipGetLastError();
+        set_error("register_host: hipHostRegister refused the range");
+        return EDGEHIP_ERR_MEMORY;
+    }
+    std::lock_guard<std::mutex> g(g_reg_mu);
+    g_reg.emplace_back(static_cast<const char *>(p), bytes);
+    return 0;
+}
+int edgehip_unregister_host(void *p) {
+    {
+        std::lock_guard<std::mutex> g(g_reg_mu);
+        auto it = std::find_if(g_reg.begin(), g_reg.end(), [&](const std::pair<const char *, size_t> &r) { return r.first == p; });
+        if (it == g_reg.end()) { set_error("unregister_host: not a registered range"); return EDGEHIP_ERR_ARG; }
+        g_reg.erase(it);
+    }
+    EH_CHECK(hipHostUnregister(p));
+    return 0;
+}
+static bool host_registered(const void *p, size_t bytes) {
+    std::lock_guard<std::mutex> g(g_reg_mu);
+    const char *q = static_cast<const char *>(p);
+    for (const auto &r : g_reg)
+        if (q >= r.first && q + bytes <= r.first + r.second) return true;
+    return false;
+}
 // the page-locked sources of every *_pinned upload so far have been read; the frames themselves may still be in flight
 int edgehip_upload_sync(edgehip_ctx *c) {
     EH_ENTER(c);
@@ -1179,14 +1211,20 @@ int edgehip_download_keylines_batch(edgehip_ctx *c, int slot, int n, const int32
     EH_LAUNCH_CHECK();
     EH_CHECK(hipMemcpyAsync(c->aos_req_host + n, c->aos_req_dev + n, sizeof(int32_t) * n, hipMemcpyDeviceToHost, c->stream));
     EH_CHECK(hipStreamSynchronize(c->stream));
-    for (int j = 0; j < n; j++) {   // only the records that exist cross the link
+    // only the records that exist cross the link — straight into a destination the caller has page-locked (edgehip_register_host),
+    // through the staging buffer and a host copy otherwise
+    std::vector<char> direct(n, 0);
+    for (int j = 0; j < n; j++) {
         const int32_t kn = c->aos_req_host[n + j];
-        if (kn > 0) EH_CHECK(hipMemcpyAsync(c->aos_host + (size_t)j * cap, c->aos_dev + (size_t)j * cap, sizeof(edgehip_keyline) * kn, hipMemcpyDeviceToHost, c->stream));
+        if (kn <= 0) continue;
+        direct[j] = host_registered(kl[j], sizeof(edgehip_keyline) * kn) ? 1 : 0;
+        edgehip_keyline *dst = direct[j] ? kl[j] : c->aos_host + (size_t)j * cap;
+        EH_CHECK(hipMemcpyAsync(dst, c->aos_dev + (size_t)j * cap, sizeof(edgehip_keyline) * kn, hipMemcpyDeviceToHost, c->stream));
     }
     EH_CHECK(hipStreamSynchronize(c->stream));
     for (int j = 0; j < n; j++) {
         const int32_t kn = c->aos_req_host[n + j];
-        if (kn > 0) memcpy(kl[j], c->aos_host + (size_t)j * cap, sizeof(edgehip_keyline) * kn);
+        if (kn > 0 && !direct[j]) memcpy(kl[j], c->aos_host + (size_t)j * cap, sizeof(edgehip_keyline) * kn);
         kn_out[j] = kn;
     }
     return 0;

@@ -204,7 +204,7 @@ EXPORTS = [
     "edgehip_profile_count", "edgehip_profile_name", "edgehip_profile_read", "edgehip_profile_select",
     "edgehip_upload_rgb_indexed", "edgehip_bind_rgb_indexed", "edgehip_set_nav_log", "edgehip_read_nav_log",
     "edgehip_build_undistort_map", "edgehip_download_undistorted", "edgehip_depth_reset", "edgehip_depth_reset_slot", "edgehip_set_slot_camera", "edgehip_directed_matching_stereo",
-    "edgehip_alloc_pinned", "edgehip_free_pinned", "edgehip_upload_rgb_pinned", "edgehip_upload_sync", "edgehip_upload_wait", "edgehip_experiments", "edgehip_fuse_stereo_depth", "edgehip_set_stereo_rig", "edgehip_get_stereo_matches", "edgehip_minimizer_v", "edgehip_ext_rot_vel",
+    "edgehip_alloc_pinned", "edgehip_free_pinned", "edgehip_upload_rgb_pinned", "edgehip_upload_sync", "edgehip_upload_wait", "edgehip_register_host", "edgehip_unregister_host", "edgehip_experiments", "edgehip_fuse_stereo_depth", "edgehip_set_stereo_rig", "edgehip_get_stereo_matches", "edgehip_minimizer_v", "edgehip_ext_rot_vel",
     "edgehip_imu_enable", "edgehip_set_imu", "edgehip_read_nav_imu", "edgehip_minimizer_rv_kf", "edgehip_lm_solve",
     "edgehip_upload_grey8", "edgehip_upload_grey8_pinned", "edgehip_bind_grey8_indexed",
 ]
@@ -562,14 +562,21 @@ class EdgeHip:
                                                     C.byref(kn)))
         return kl[:kn.value].copy(), mask
 
-    def download_keylines_batch(self, slot, seqs):
-        """AoS KeyLine lists of several sequences of one slot, one packing kernel (edgehip_download_keylines_batch)."""
+    def download_keylines_batch(self, slot, seqs, registered=()):
+        """AoS KeyLine lists of several sequences of one slot, one packing kernel (edgehip_download_keylines_batch).  `registered`:
+        positions in `seqs` whose destination is page-locked first (edgehip_register_host: the copy lands in it directly)."""
         seqs = np.ascontiguousarray(seqs, dtype=np.int32)
         n = len(seqs)
         bufs = [np.zeros(self.cap, KEYLINE_DTYPE) for _ in range(n)]
+        for j in registered:
+            self._ck(self.lib.edgehip_register_host(C.c_void_p(bufs[j].ctypes.data), C.c_size_t(bufs[j].nbytes)))
         ptrs = (C.c_void_p * n)(*[b.ctypes.data for b in bufs])
         kn = np.zeros(n, np.int32)
-        self._ck(self.lib.edgehip_download_keylines_batch(self.ctx, slot, n, seqs.ctypes.data_as(C.c_void_p), ptrs, kn.ctypes.data_as(C.c_void_p)))
+        try:
+            self._ck(self.lib.edgehip_download_keylines_batch(self.ctx, slot, n, seqs.ctypes.data_as(C.c_void_p), ptrs, kn.ctypes.data_as(C.c_void_p)))
+        finally:
+            for j in registered:
+                self._ck(self.lib.edgehip_unregister_host(C.c_void_p(bufs[j].ctypes.data)))
         return [b[:k].copy() for b, k in zip(bufs, kn)]
 
     def upload_keylines(self, seq, slot, kl, mask=None, retuned=0.0):

@@ -66,6 +66,13 @@ public:
         uint8_t mono_of[CCAMBUFSIZE] = {};   // per ring entry: the frame in it is mono and its 8-bit plane is in grey_ring (written by the
                                              // application's thread before it releases the entry, read by the group thread after it took it)
         bool mono = false;         // ... of the gathered frame
+        // With an output callback (or a pending snapshot) PipeBuffer::imgc must hold the frame.  The application's thread copies it
+        // into side_img[ring entry] when it releases the camera buffer, and the group thread SWAPS that image into the step's
+        // PipeBuffer (1 MB per member and step that the group thread used to copy itself).
+        Image<RGB24Pixel> *side_img[CCAMBUFSIZE] = {};
+        uint8_t side_ok[CCAMBUFSIZE] = {};
+        bool kl_pinned = false;    // the KeyLine arrays of this member's PipeBuffers are page-locked (edgehip_register_host): AoS lists
+                                   // for its callback land in them without a staging copy
         bool step_granted = false; // frame-by-frame mode: the application's "advance" has been taken for the frame about to be grabbed
         bool leaving = false;      // cf->quit seen: the seat closes once the step in flight (which may carry its last frame) is done
         bool have_prev = false;    // a completed frame waits (as player 1's next buffer) for its successor before it is delivered
@@ -109,6 +116,7 @@ public:
     uint8_t *greyImage(int entry, int seat) { return grey_ring + ((size_t)entry * cap + seat) * grey_bytes; }
     int ringEntryOf(const uint8_t *p) const { return ring && p >= ring && p < ring + frame_bytes * CCAMBUFSIZE * cap ? (int)((size_t)(p - ring) / (frame_bytes * cap)) : -1; }
     void closeSeat(Seat &st);
+    void pinKeyLines(Seat &st, bool pin);
 };
 
 // ---- attach / detach (application threads) -----------------------------------------------------------------------------
@@ -245,6 +253,7 @@ void REBVO::groupDetach() {
         }
     }
     if (st.out_thread.joinable()) st.out_thread.join();
+    for (Image<RGB24Pixel> *&im : st.side_img) { delete im; im = nullptr; }
     {
         std::unique_lock<std::mutex> reg(BatchGroup::regMutex());
         std::unique_lock<std::mutex> lk(g->mut);
@@ -272,17 +281,38 @@ void REBVO::groupDetach() {
 // if the frame is a mono camera's, its 8-bit plane goes into the group's second page-locked ring (src/mono_pack.cpp).
 void REBVO::groupFrameWritten(customCam::CustomCamPipeBuffer *b) {
     BatchGroup *g = group;
-    if (!g || !g->grey_ring || !b || !b->img) return;
+    if (!g || !b || !b->img) return;
     const uint8_t *p = reinterpret_cast<const uint8_t *>(b->img->Data());
     const int entry = g->ringEntryOf(p);
     if (entry < 0) return;
-    g->seats[group_seat].mono_of[entry] = (uint8_t)rebvo_pack_mono(p, g->grey_bytes, g->greyImage(entry, group_seat));
+    BatchGroup::Seat &st = g->seats[group_seat];
+    if (g->grey_ring) st.mono_of[entry] = (uint8_t)rebvo_pack_mono(p, g->grey_bytes, g->greyImage(entry, group_seat));
+    st.side_ok[entry] = 0;
+    if (haveCallBack() || saveImg) {   // the frame for PipeBuffer::imgc, copied here instead of on the group's thread
+        if (!st.side_img[entry]) st.side_img[entry] = new Image<RGB24Pixel>(params.ImageSize);
+        std::memcpy(st.side_img[entry]->Data(), p, g->frame_bytes);
+        st.side_ok[entry] = 1;
+    }
 }
 
 // ---- the group's tracker thread -------------------------------------------------------------------------------------------
+// Page-lock (or release) the KeyLine arrays of a member's PipeBuffers.  A range the driver refuses stays pageable: the lists then
+// come through the library's staging buffer as before.
+void REBVO::BatchGroup::pinKeyLines(Seat &st, bool pin) {
+    REBVO *cf = st.cf;
+    for (unsigned j = 0; j < cf->pipe.Size(); j++) {
+        std::vector<KeyLine> &kl = cf->pipe[j].ef->kl;
+        if (kl.empty()) continue;
+        if (pin) (void)edgehip_register_host(kl.data(), kl.size() * sizeof(KeyLine));
+        else (void)edgehip_unregister_host(kl.data());
+    }
+    st.kl_pinned = pin;
+}
+
 void REBVO::BatchGroup::closeSeat(Seat &st) {
     // shutdown of one member: the frame still held for it is not delivered (as in the reference); pass the quit flag on
     REBVO *cf = st.cf;
+    if (st.kl_pinned) pinKeyLines(st, false);
     if (st.chold) { cf->cam_pipe.ReleaseBufferAt(1, st.chold); st.chold = nullptr; }
     if (st.cbuf) { cf->cam_pipe.ReleaseBufferAt(1, st.cbuf); st.cbuf = nullptr; }
     if (st.frames == 0) {   // nothing ever went through player 0: open the ring for player 1
@@ -393,7 +423,14 @@ int REBVO::BatchGroup::launch(long step, const std::vector<double> &ts) {
         nb.quit = false;
         nb.dtp0 = 0;
         nb.dtp1 = tp0;   // start of the step; complete() turns it into the step's duration
-        if (cf->haveCallBack() || cf->saveImg) std::memcpy(nb.imgc->Data(), st.cbuf->img->Data(), (size_t)cf->params.ImageSize.w * cf->params.ImageSize.h * 3);
+        if (cf->haveCallBack() || cf->saveImg) {
+            if (st.ring_idx >= 0 && st.side_ok[st.ring_idx]) {   // the application's thread made the copy: take it
+                std::swap(nb.imgc, st.side_img[st.ring_idx]);
+                st.side_ok[st.ring_idx] = 0;
+            } else {
+                std::memcpy(nb.imgc->Data(), st.cbuf->img->Data(), (size_t)cf->params.ImageSize.w * cf->params.ImageSize.h * 3);
+            }
+        }
         cf->pipe.ReleaseBuffer(0);
         st.buf_of[step & 3] = &nb;
         st.t0 = st.t_frame;
@@ -469,6 +506,7 @@ int REBVO::BatchGroup::complete(long step, int slot, std::vector<edgehip_nav> &n
                 // this one delivery carries no KeyLines (from the next on the group keeps one step in flight)
                 ob.ef->kn = 0;
             } else if (cf->haveCallBack()) {
+                if (!st.kl_pinned) pinKeyLines(st, true);
                 cb_seq.push_back(i);
                 cb_dst.push_back(reinterpret_cast<edgehip_keyline *>(ob.ef->kl.data()));
                 cb_buf.push_back(&ob);

@@ -192,10 +192,14 @@ def test_batched_keyline_download_equals_the_single_one():
         eh.process_frame(np.full(n_obj, T0 + DT * k))
     for slot in ((eh.cur_slot() + 2) % 3, eh.cur_slot()):
         seqs = [4, 0, 2]
-        got = eh.download_keylines_batch(slot, seqs)
-        for s_, kl in zip(seqs, got):
-            ref = eh.download_keylines(s_, slot, want_mask=False)[0]
-            assert len(kl) == len(ref) > 1000 and kl.tobytes() == ref.tobytes()
+        for registered in ((), (0, 2)):      # (0, 2): those two destinations page-locked in place, the copy lands in them directly
+            got = eh.download_keylines_batch(slot, seqs, registered=registered)
+            for s_, kl in zip(seqs, got):
+                ref = eh.download_keylines(s_, slot, want_mask=False)[0]
+                assert len(kl) == len(ref) > 1000 and kl.tobytes() == ref.tobytes()
+    import ctypes as C
+    assert eh.lib.edgehip_unregister_host(C.c_void_p(12345)) != 0      # not a registered range
+    assert eh.lib.edgehip_register_host(None, C.c_size_t(0)) != 0
     eh.close()
 
 
