@@ -697,7 +697,11 @@ def compact_line(full):
         line["pose_rmse"] = o
     else:
         line["pose_rmse"] = None
-    for k in ("stage_a_hbm_frac", "single_sequence_ms_per_frame", "scaling_measured"):
+    if isinstance(c.get("nav_gather_info"), dict):
+        for k in ("ranks", "records", "device_to_wire"):
+            if c["nav_gather_info"].get(k) is not None:
+                line["config"]["nav_gather_" + k] = c["nav_gather_info"][k]
+    for k in ("stage_a_hbm_frac", "single_sequence_ms_per_frame", "scaling_measured", "invalid_as_measurement", "launched_by"):
         if full.get(k) is not None:
             line[k] = full[k]
     hs = full.get("host_surface")
@@ -824,6 +828,59 @@ def other_configs(args):
     return extras
 
 
+def launch_ranks(n, argv, rank0_stdout):
+    """`python bench.py --gpus N` with N > 1 and no launcher around it: this process becomes the launcher — N copies of this
+    command, one rank per GPU (RANK / LOCAL_RANK / WORLD_SIZE / MASTER_ADDR / MASTER_PORT in their environment, what
+    torch.distributed.run would set), rank 0's stdout is this process's stdout (the ONE line), the other ranks' goes to stderr.
+    Fails loudly (exit code != 0, nothing on stdout) when the box has fewer than N devices: a `--gpus 8` command never turns
+    into a one-GPU number.  BENCH_BACKEND=gloo lets the ranks share the devices there are (a dry run of the control flow)."""
+    import socket
+    import subprocess
+    backend = os.environ.get("BENCH_BACKEND", "nccl")
+    stub = os.environ.get("BENCH_STUB_DEVICE") == "1"
+    if not stub:
+        import torch
+        ndev = torch.cuda.device_count() if torch.cuda.is_available() else 0
+        if ndev < 1:
+            print(f"bench.py: --gpus {n} but this box has no usable GPU; there is no CPU path", file=sys.stderr)
+            return 2
+        if backend == "nccl" and ndev < n:
+            print(f"bench.py: --gpus {n} but only {ndev} device(s) are visible: one rank per GPU over RCCL needs {n}.  Nothing was "
+                  f"measured.  (BENCH_BACKEND=gloo runs {n} ranks on the devices there are, as a dry run of the control flow.)", file=sys.stderr)
+            return 2
+    elif backend == "nccl":
+        print("bench.py: BENCH_STUB_DEVICE=1 is a CPU dry run of the launcher and needs BENCH_BACKEND=gloo", file=sys.stderr)
+        return 2
+    sk = socket.socket()
+    sk.bind(("127.0.0.1", 0))
+    port = sk.getsockname()[1]
+    sk.close()
+    procs = []
+    for r in range(n):
+        env = dict(os.environ)
+        env.update({"RANK": str(r), "LOCAL_RANK": str(r), "WORLD_SIZE": str(n), "LOCAL_WORLD_SIZE": str(n), "MASTER_ADDR": "127.0.0.1",
+                    "MASTER_PORT": str(port), "BENCH_SELF_LAUNCHED": "1"})
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        env.setdefault("OMP_NUM_THREADS", str(max(1, _usable_cores() // n)))
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + list(argv), env=env,
+                                      stdout=rank0_stdout if r == 0 else sys.stderr, stderr=sys.stderr))
+    # a rank that dies takes the others with it (they would wait for it in the next collective until the store times out)
+    rc, alive = 0, list(procs)
+    while alive:
+        for p_ in list(alive):
+            code = p_.poll()
+            if code is None:
+                continue
+            alive.remove(p_)
+            if code != 0 and rc == 0:
+                rc = code if code > 0 else 1
+                print(f"bench.py: rank {procs.index(p_)} ended with exit code {code}; stopping the other ranks", file=sys.stderr)
+                for q_ in alive:
+                    q_.terminate()
+        time.sleep(0.05)
+    return rc
+
+
 def main():
     # ONE JSON line on stdout, whatever the libraries underneath print: RCCL writes a version banner to the C-level stdout of
     # the process when its first communicator comes up.  File descriptor 1 is pointed at stderr for the rest of the run and
@@ -874,32 +931,52 @@ def main():
     ap.add_argument("--no-roofline-events", action="store_true")
     args = ap.parse_args()
 
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        # no launcher around this command (the driver runs `python bench.py --gpus N` as it runs `--gpus 1`): be the launcher
+        sys.exit(launch_ranks(args.gpus, sys.argv[1:], sys.stdout))
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
-        if rank == 0:
-            print(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}; launch with torch.distributed.run", file=sys.stderr)
-        args.gpus = world
+        # never a number for another rank count than the command names
+        print(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world} in the environment: launch `--gpus N` with N ranks "
+              "(torch.distributed.run --nproc-per-node N), or without a launcher (bench.py then starts its own N ranks)", file=sys.stderr)
+        sys.exit(2)
 
     import torch
     import torch.distributed as dist
 
     from rebvo_amd import edgehip, shard, synth
 
-    if not torch.cuda.is_available():
-        raise SystemExit("bench.py needs an MI355X (torch.cuda.is_available() is False); there is no CPU path")
-    # BENCH_BACKEND=gloo is a dry run of the multi-rank control flow on a box with fewer GPUs than ranks (ranks share
-    # devices); the real thing is nccl (= RCCL), one rank per GPU
+    # BENCH_STUB_DEVICE=1 (tests/test_bench_launcher_cpu.py): the control flow of an N-rank run on a box without a GPU, with
+    # tests/stub_device.py in the place of the device context.  Nothing is measured; the line says so.
+    stub = os.environ.get("BENCH_STUB_DEVICE") == "1"
     backend = os.environ.get("BENCH_BACKEND", "nccl")
-    if backend != "nccl":
-        local_rank %= torch.cuda.device_count()
-    torch.cuda.set_device(local_rank)
+    dev = "cpu" if stub else "cuda"
+    if stub:
+        from tests import stub_device
+        import types
+        if backend == "nccl" or args.config != "full" or args.imu:
+            raise SystemExit("BENCH_STUB_DEVICE=1: the dry run covers the default configuration over BENCH_BACKEND=gloo only")
+        edgehip_dev = types.SimpleNamespace(EdgeHip=lambda params, nseq, nslots, device: stub_device.EdgeHip(params, nseq, nslots, rank))
+        torch.cuda.synchronize = lambda *a, **k: None
+        args.input, args.cpu_frames, args.no_extras, args.no_roofline_events = "pool", 0, True, True
+    else:
+        edgehip_dev = edgehip
+        if not torch.cuda.is_available():
+            raise SystemExit("bench.py needs an MI355X (torch.cuda.is_available() is False); there is no CPU path")
+        # BENCH_BACKEND=gloo is a dry run of the multi-rank control flow on a box with fewer GPUs than ranks (ranks share
+        # devices); the real thing is nccl (= RCCL), one rank per GPU
+        if backend != "nccl":
+            local_rank %= torch.cuda.device_count()
+        elif local_rank >= torch.cuda.device_count():
+            raise SystemExit(f"bench.py: rank {rank} wants device {local_rank} but only {torch.cuda.device_count()} are visible")
+        torch.cuda.set_device(local_rank)
     # One rank, full path: the N > 1 code path is taken all the same (BENCH_FORCE_MOVER=0 turns it off) — a one-rank process
     # group over RCCL, shard.NavMover on its own communicator and thread, barriers, the max-over-ranks all-reduce — so that the
     # line a 1-GPU run prints has exercised what an 8-GPU run does, minus the peers (`nav_gather` in the line).  A box on which
     # RCCL does not come up still measures: `nav_gather` then says why.
-    force_mover = world == 1 and args.config == "full" and os.environ.get("BENCH_FORCE_MOVER", "1") != "0"
+    force_mover = world == 1 and args.config == "full" and os.environ.get("BENCH_FORCE_MOVER", "1") != "0" and not stub
     dist_on = world > 1
     dist_note = None
     if world > 1:
@@ -945,8 +1022,8 @@ def main():
         """HBM-resident frame pool; stage A reads each sequence's frame in place (edgehip_bind_rgb_indexed: no gather
         copy, like ConvertRGB2BW reading the camera buffer).  16 B of slack: pixels are fetched as aligned 8-byte words."""
         host = np.stack(frames_list)
-        t = torch.empty(host.size + 16, dtype=torch.uint8, device="cuda")
-        t[:host.size] = torch.from_numpy(host.reshape(-1)).cuda()
+        t = torch.empty(host.size + 16, dtype=torch.uint8, device=dev)
+        t[:host.size] = torch.from_numpy(host.reshape(-1)).to(dev)
         return t
 
     # ---- frame pool, resident in HBM: a mounted data set when there is one, the synthetic billboards otherwise ----
@@ -966,6 +1043,8 @@ def main():
         frames = [f for f, _, _ in synth.billboard_sequence(w, h, args.pool, seed=11 + rank, **intr)]
     pool = to_pool(frames)
     torch.cuda.synchronize()
+    if stub:
+        data_kind = "stub"
     # every sequence starts at its own phase of the pool
     offs = np.arange(B * C, dtype=np.int64) % (2 * (args.pool - 1))
     # --input distinct: sequence s reads frame i of the pool from ITS OWN copy (frame s * pool + i of a B*C*pool-frame array), as B*C
@@ -1016,7 +1095,7 @@ def main():
 
         def imu_of(k):
             return [trans[(tri(k - 1 + o, args.pool) if k > 0 else tri(k + o, args.pool), tri(k + o, args.pool))] for o in offs]
-    rp = Replay(edgehip, params, B * C, in_pool, in_frames, index_of, local_rank, C, imu_params=imu_params, imu_of=imu_of)
+    rp = Replay(edgehip_dev, params, B * C, in_pool, in_frames, index_of, local_rank, C, imu_params=imu_params, imu_of=imu_of)
     ehs, eh = rp.ehs, rp.ehs[0]   # eh: the context whose streams carry the HIP-event profiler
 
     # ============================ --config stage_a: DoG + KeyLine extraction alone (configs[1]) ============================
@@ -1157,7 +1236,15 @@ def main():
         # what arrived on rank 0 is what the contexts logged (every block, every rank's sequences, in order)
         got = np.concatenate([b[0] for b in mover.blocks], axis=0) if world == 1 and C == 1 else None
         nav_gather_info = {"backend": "rccl" if backend == "nccl" else backend, "ranks": world, "blocks": len(mover.blocks),
-                           "records": int(sum(b.shape[0] * b.shape[1] * b.shape[2] for b in mover.blocks))}
+                           "records": int(sum(b.shape[0] * b.shape[1] * b.shape[2] for b in mover.blocks)),
+                           # RCCL: every block went device log -> device tensor -> communicator (edgehip_read_nav_log_device), no host bounce
+                           "device_to_wire": bool(backend == "nccl" and mover.device_path_blocks == len(mover.blocks) > 0)}
+        if world > 1:
+            # every rank's every sequence, every timed step, once: (rank, sequence id, frame) of what arrived
+            allrec = np.concatenate([b for b in mover.blocks], axis=1)          # [world, K, B, 16] (C == 1) or per-context blocks
+            want_ranks = sorted(set(int(x) for x in allrec[..., 14].reshape(-1)))
+            nav_gather_info["ranks_seen"] = want_ranks
+            nav_gather_info["every_rank_delivered"] = want_ranks == list(range(world))
         if got is not None:
             direct = shard.nav_records(eh.read_nav_log_array(Wm, K), rank, list(range(B)))
             nav_gather_info["equals_device_log"] = bool(got.shape == direct.shape and np.array_equal(got, direct))
@@ -1560,6 +1647,14 @@ def main():
                                      "the library that is running: " + pmc_stamp_note() + ")",
         "traffic_calibration": {"factors_true_over_reported": {k: round(v, 3) for k, v in calib.items()}, "source": calib_src},
     }
+    full["launched_by"] = "bench.py itself (no launcher around the command)" if os.environ.get("BENCH_SELF_LAUNCHED") == "1" else \
+                          ("torch.distributed.run" if "TORCHELASTIC_RUN_ID" in os.environ else "direct")
+    if stub:
+        full["invalid_as_measurement"] = True
+        full["data"] = "stub"
+        full["config"]["workload"] = ("LAUNCHER / CONTROL-FLOW DRY RUN on tests/stub_device.py: no device work, `value` is not a measurement "
+                                      "(self-launch of the ranks, process group, barriers, nav gather, max-over-ranks timing, one line)")
+        full["dtype"] = "none (tests/stub_device.py: no device work)"
     if surface:
         full["host_surface"] = surface
     if world == 1 and args.extras and not args.no_extras and args.config == "full" and not args.imu:

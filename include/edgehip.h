@@ -367,6 +367,10 @@ int edgehip_read_nav_imu(edgehip_ctx *ctx, edgehip_nav_imu *out);
  * frame graph).  edgehip_set_nav_log itself belongs to the driving thread, with no reader active. */
 int edgehip_set_nav_log(edgehip_ctx *ctx, int len);
 int edgehip_read_nav_log(edgehip_ctx *ctx, int first, int count, edgehip_nav *out);
+/* The same records into DEVICE memory of the context's GPU (out_dev[count][nseq] edgehip_nav, e.g. a tensor the caller's RCCL
+ * communicator sends from): the multi-GPU nav gather of SURVEY.md section 8(e) takes its payload from HBM to the wire without a
+ * host bounce (rebvo_amd/shard.py NavMover).  Same waiting, threading and range rules; the copy is complete on return. */
+int edgehip_read_nav_log_device(edgehip_ctx *ctx, int first, int count, void *out_dev);
 /* Restart every sequence from scratch: state as after edgehip_create (thresholds, priors, pose, frame
  * counters) and an empty ring.  Not something the reference does at run time (it would re-construct REBVO). */
 int edgehip_reset(edgehip_ctx *ctx);

@@ -989,7 +989,8 @@ int edgehip_set_nav_log(edgehip_ctx *c, int len) {
     return 0;
 }
 
-int edgehip_read_nav_log(edgehip_ctx *c, int first, int count, edgehip_nav *out) {
+// Shared body of edgehip_read_nav_log (host destination) and edgehip_read_nav_log_device (device destination).
+static int read_nav_log_impl(edgehip_ctx *c, int first, int count, edgehip_nav *out, hipMemcpyKind kind) {
     EH_ENTER(c);
     if (!c || !out || !c->nav_log || first < 0 || count < 1 || count > c->nav_log_len) { set_error("read_nav_log: bad range or log disabled"); return EDGEHIP_ERR_ARG; }
     // Records of frames that were never enqueued do not exist; `first` counts frames since edgehip_reset / the first frame
@@ -1015,7 +1016,7 @@ int edgehip_read_nav_log(edgehip_ctx *c, int first, int count, edgehip_nav *out)
     }
     for (int k = 0; k < count; k++) {
         const int slot = (first + k) % c->nav_log_len;
-        EH_CHECK(hipMemcpyAsync(out + (size_t)k * B, c->nav_log + (size_t)slot * B, sizeof(edgehip_nav) * B, hipMemcpyDeviceToHost, c->stream_log));
+        EH_CHECK(hipMemcpyAsync(out + (size_t)k * B, c->nav_log + (size_t)slot * B, sizeof(edgehip_nav) * B, kind, c->stream_log));
     }
     EH_CHECK(hipStreamSynchronize(c->stream_log));
     {   // the thread that enqueues frames may have gone on meanwhile: a frame one ring length ahead writes the entries just copied
@@ -1023,6 +1024,12 @@ int edgehip_read_nav_log(edgehip_ctx *c, int first, int count, edgehip_nav *out)
         if (!in_ring(c->log_last)) { set_error("read_nav_log: the ring was overwritten during the read (frames enqueued more than its length ahead)"); return EDGEHIP_ERR_STATE; }
     }
     return 0;
+}
+
+int edgehip_read_nav_log(edgehip_ctx *c, int first, int count, edgehip_nav *out) { return read_nav_log_impl(c, first, count, out, hipMemcpyDeviceToHost); }
+
+int edgehip_read_nav_log_device(edgehip_ctx *c, int first, int count, void *out_dev) {
+    return read_nav_log_impl(c, first, count, (edgehip_nav *)out_dev, hipMemcpyDeviceToDevice);
 }
 
 int edgehip_stage_a(edgehip_ctx *c, int slot) {

@@ -37,6 +37,27 @@ def nav_records(navs, rank, seq_ids):
     return rec
 
 
+def nav_records_device(raw, rank, seq_ids):
+    """The same [steps, nseq, 16] float64 records as nav_records(), formed ON THE DEVICE from the raw edgehip_nav structs that
+    edgehip_read_nav_log_device copied out of the context's log (raw: uint8 tensor [steps, nseq, sizeof(edgehip_nav)]): column
+    picks on two reinterpreting views, no host round trip — the tensor that comes out is what RCCL sends."""
+    import torch
+    from .edgehip import NAV_DTYPE
+    steps, nseq, nbytes = raw.shape
+    assert nbytes == NAV_DTYPE.itemsize and nbytes % 8 == 0
+    f64 = raw.view(torch.float64)             # [steps, nseq, nbytes / 8]
+    i32 = raw.view(torch.int32)               # [steps, nseq, nbytes / 4]
+    off = {name: NAV_DTYPE.fields[name][1] for name in NAV_DTYPE.names}
+    rec = torch.zeros((steps, nseq, NAV_FIELDS), dtype=torch.float64, device=raw.device)
+    for j, f in enumerate(("frame", "kn", "klm_num", "estimation_ok")):
+        rec[:, :, j] = i32[:, :, off[f] // 4].to(torch.float64)
+    for j, f in ((4, "Pos"), (7, "V"), (10, "W")):
+        rec[:, :, j:j + 3] = f64[:, :, off[f] // 8: off[f] // 8 + 3]
+    rec[:, :, 13] = torch.as_tensor(list(seq_ids), dtype=torch.float64, device=raw.device)[None, :]
+    rec[:, :, 14] = float(rank)
+    return rec
+
+
 def gather_records(rec, dst=0, group=None):
     """Gather equally-shaped record tensors to `dst` (torch.distributed must be initialised).
 
@@ -44,8 +65,8 @@ def gather_records(rec, dst=0, group=None):
     import torch
     import torch.distributed as dist
     world, rank = dist.get_world_size(group), dist.get_rank()
-    t = torch.as_tensor(rec)
-    if dist.get_backend(group) == "nccl":
+    t = rec if isinstance(rec, torch.Tensor) else torch.as_tensor(rec)
+    if dist.get_backend(group) == "nccl" and not t.is_cuda:
         t = t.cuda()
     out = [torch.empty_like(t) for _ in range(world)] if rank == dst else None
     dist.gather(t, out, dst=dst, group=group)
@@ -70,6 +91,7 @@ class NavMover:
         self.group = dist.new_group(ranks=list(range(world)), backend=backend)   # collective: all ranks call it
         self.blocks = []                      # on dst: one [world, steps, nseq, NAV_FIELDS] array per posted block
         self.error = None
+        self.device_path_blocks = 0           # blocks whose records went from the device log to the communicator without touching the host
         self._q = queue.Queue(maxsize=2)
         self._t = threading.Thread(target=self._run, daemon=True)
         self._t.start()
@@ -110,7 +132,16 @@ class NavMover:
             rec = None
             try:
                 reader, first, count, seq_ids = item
-                rec = nav_records(reader.read_nav_log_array(first, count), self.rank, seq_ids)
+                if self.device is not None and hasattr(reader, "read_nav_log_device"):
+                    # RCCL: HBM -> wire.  The raw records are copied device-to-device out of the context's log (on the log's own
+                    # stream, complete on return), the 16 fields are picked on the device, and that tensor is what the gather sends.
+                    from .edgehip import NAV_DTYPE
+                    raw = torch.empty((count, len(seq_ids), NAV_DTYPE.itemsize), dtype=torch.uint8, device=torch.device("cuda", self.device))
+                    reader.read_nav_log_device(first, count, raw.data_ptr())
+                    rec = nav_records_device(raw, self.rank, seq_ids)
+                    self.device_path_blocks += 1
+                else:
+                    rec = nav_records(reader.read_nav_log_array(first, count), self.rank, seq_ids)
             except Exception as e:            # surfaces in post() / finish(); the replay itself must not be torn down by the transport
                 self.error = e
             try:
