@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""SQ counters of a tools/gpu_round5.sh `sq` stage -> profiles/sq_latest.json + a readable table.
+"""SQ counters of a tools/gpu_round.sh `sq` stage -> profiles/sq_latest.json + a readable table.
 
 usage: tools/sq_summary.py gpurun_out/<tag>/sq.json profiles/sq_latest.json [profiles/<name>.txt]
 
