@@ -399,6 +399,20 @@ int edgehip_download_keylines(edgehip_ctx *ctx, int seq, int slot, edgehip_keyli
  * rebvo_amd/host/src/batch_group.cpp): seqs[n] sequence indices, kl[n] destinations of max_points entries each, kn_out[n].  Record for record what
  * edgehip_download_keylines returns (no mask).  Synchronises. */
 int edgehip_download_keylines_batch(edgehip_ctx *ctx, int slot, int n, const int32_t *seqs, edgehip_keyline *const *kl, int32_t *kn_out);
+/* Output callbacks at full pipeline depth (round 6; the consumer: setOutputCallback, include/rebvo/rebvo.h:595-609, called by
+ * REBVO::ThirdThread, src/rebvo/rebvo_third_t.cpp:174 — every real user of the surface has one, ros/src/rebvo_ros/src/rebvo_nodelet.cpp:146-242).
+ * A callback gets frame k-1's edge map as frame k's tracking left it: the OLD slot of the frame processed last.
+ *   edgehip_export_keylines  right after edgehip_process_frame(k): packs that slot's KeyLines of sequences seqs[n] as AoS records into a
+ *                            device-side staging ring, in-stream behind the frame (no synchronisation; the ring slot itself is free for
+ *                            the frame after next).  Returns a ticket; at most four may be outstanding.
+ *   edgehip_export_fetch     once the caller knows the lists' lengths (kn[j] = edgehip_nav::kn of frame k-1 for seqs[j]): enqueues the copies
+ *                            of exactly kn[j] records into dst[j] on a stream of their own (page-locked destinations — edgehip_register_host —
+ *                            are written by DMA under the frames that follow; pageable ones work, slower).  Does not block.
+ *   edgehip_export_wait      blocks until the ticket's copies have landed and releases the ticket (never fetched: just releases it).
+ * Record for record what edgehip_download_keylines_batch returns for the same slot at the same point. */
+int edgehip_export_keylines(edgehip_ctx *ctx, int n, const int32_t *seqs, int *ticket_out);
+int edgehip_export_fetch(edgehip_ctx *ctx, int ticket, const int32_t *kn, edgehip_keyline *const *dst);
+int edgehip_export_wait(edgehip_ctx *ctx, int ticket);
 /* Page-lock host memory the caller owns, in place (hipHostRegister), so that edgehip_download_keylines_batch copies straight into
  * it: a destination inside a registered range skips the library's staging buffer and the host memcpy behind it (2.4 MB per list of
  * 14 k KeyLines).  What a batch group does with the KeyLine arrays of the members that have an output callback

@@ -48,6 +48,10 @@ int wait_upload(edgehip_ctx *c, int slot, hipStream_t st) {
 }
 
 void drop_frame_graphs(edgehip_ctx *c) {
+    if (c->frame_graphs.empty()) return;
+    // a graph launched for the frame before may still be executing (a caller with look-ahead uploads re-binds a slot right behind
+    // edgehip_process_frame): an exec is destroyed only once the stream it was launched on has drained
+    (void)hipStreamSynchronize(c->stream);
     for (auto &kv : c->frame_graphs) (void)hipGraphExecDestroy(kv.second);
     c->frame_graphs.clear();
 }
@@ -653,6 +657,16 @@ int edgehip_destroy(edgehip_ctx *c) {
         delete c->prof;
     }
     if (c->aos_dev) { (void)hipFree(c->aos_dev); (void)hipHostFree(c->aos_host); (void)hipFree(c->aos_req_dev); (void)hipHostFree(c->aos_req_host); }
+    if (c->kl_export) {
+        auto *x = c->kl_export;
+        if (x->stream) { (void)hipStreamSynchronize(x->stream); (void)hipStreamDestroy(x->stream); }
+        for (hipEvent_t e : x->ev_pack) if (e) (void)hipEventDestroy(e);
+        for (hipEvent_t e : x->ev_done) if (e) (void)hipEventDestroy(e);
+        if (x->dev) (void)hipFree(x->dev);
+        if (x->req) (void)hipHostFree(x->req);
+        delete x;
+        c->kl_export = nullptr;
+    }
     if (c->stream_log) {
         (void)hipStreamSynchronize(c->stream_log); (void)hipStreamDestroy(c->stream_log); (void)hipEventDestroy(c->ev_log);
         for (hipEvent_t e : c->ev_log_ring) if (e) (void)hipEventDestroy(e);
@@ -1167,10 +1181,10 @@ __global__ __launch_bounds__(256) void k_pack_keylines(const KlSoA *kls, const i
     const int j = blockIdx.y, seq = req[j];
     const int kn = kns[seq];
     const int i = blockIdx.x * 256 + threadIdx.x;
-    if (i == 0) kn_out[j] = kn;
+    if (i == 0 && kn_out) kn_out[j] = kn;
     if (i >= kn) return;
     const KlSoA &k = kls[seq];
-    edgehip_keyline o;
+    edgehip_keyline o = {};   // (the staging buffers are also zeroed when allocated: the record's padding never carries stale device memory)
     o.p_inx = k.p_inx[i];
     const float2 m_m = k.m_m[i], u_m = k.u_m[i], c_p = k.c_p[i], p_m = k.p_m[i], p_m_0 = k.p_m_0[i], m_m0 = k.m_m0[i];
     o.m_m[0] = m_m.x; o.m_m[1] = m_m.y; o.u_m[0] = u_m.x; o.u_m[1] = u_m.y;
@@ -1201,6 +1215,7 @@ int edgehip_download_keylines_batch(edgehip_ctx *c, int slot, int n, const int32
         void *q = nullptr;
         if (hipMalloc(&q, sizeof(edgehip_keyline) * cap * n) != hipSuccess) { (void)hipGetLastError(); set_error("download_keylines_batch: staging alloc failed"); return EDGEHIP_ERR_MEMORY; }
         c->aos_dev = (edgehip_keyline *)q;
+        EH_CHECK(hipMemset(c->aos_dev, 0, sizeof(edgehip_keyline) * cap * n));
         if (hipHostMalloc(&q, sizeof(edgehip_keyline) * cap * n, hipHostMallocDefault) != hipSuccess) { (void)hipGetLastError(); set_error("download_keylines_batch: pinned alloc failed"); return EDGEHIP_ERR_MEMORY; }
         c->aos_host = (edgehip_keyline *)q;
         if (hipMalloc(&q, sizeof(int32_t) * 2 * n) != hipSuccess) { (void)hipGetLastError(); set_error("download_keylines_batch: staging alloc failed"); return EDGEHIP_ERR_MEMORY; }
@@ -1234,6 +1249,105 @@ int edgehip_download_keylines_batch(edgehip_ctx *c, int slot, int n, const int32
         if (kn > 0 && !direct[j]) memcpy(kl[j], c->aos_host + (size_t)j * cap, sizeof(edgehip_keyline) * kn);
         kn_out[j] = kn;
     }
+    return 0;
+}
+
+// ---- output callbacks at full pipeline depth (round 6) ----------------------------------------------------------------------------
+// What a callback receives of frame k-1 is its edge map as frame k's tracking left it (rebvo_second_t.cpp:622-623; rebvo_third_t.cpp:174):
+// the OLD slot of the frame processed last.  edgehip_download_keylines_batch reads it behind a synchronisation of both frame streams,
+// and the frame after next detects into that slot — so a caller that wanted KeyLines could keep only one frame in flight.  Here the
+// lists are packed in-stream, right behind the frame, into a staging ring of their own; the slot is free again as far as callbacks go,
+// the copies to the host run on a stream of their own under the frames that follow, and nothing synchronises the frame streams.
+int edgehip_export_keylines(edgehip_ctx *c, int n, const int32_t *seqs, int *ticket_out) {
+    EH_ENTER(c);
+    if (!c || n < 1 || !seqs || !ticket_out) { set_error("export_keylines: bad argument"); return EDGEHIP_ERR_ARG; }
+    for (int j = 0; j < n; j++)
+        if (int e = check_seq(c, seqs[j])) return e;
+    if (c->frames_seen < 2 || c->frame_slot < 0) { set_error("export_keylines: needs two processed frames (the old slot of a frame pair)"); return EDGEHIP_ERR_STATE; }
+    if (!c->kl_export) c->kl_export = new edgehip_ctx::KlExport;
+    auto *x = c->kl_export;
+    constexpr int R = edgehip_ctx::KlExport::R;
+    const size_t cap = (size_t)c->plan.cap;
+    if (!x->stream) {
+        EH_CHECK(hipStreamCreateWithFlags(&x->stream, hipStreamNonBlocking));
+        for (int i = 0; i < R; i++) {
+            EH_CHECK(hipEventCreateWithFlags(&x->ev_pack[i], hipEventDisableTiming));
+            EH_CHECK(hipEventCreateWithFlags(&x->ev_done[i], hipEventDisableTiming));
+        }
+    }
+    if (n > x->n_cap) {   // staging for n lists per ticket (grown, never shrunk): only with no ticket outstanding
+        for (auto &t : x->t)
+            if (t.id >= 0) { set_error("export_keylines: more lists than before while tickets are outstanding"); return EDGEHIP_ERR_STATE; }
+        EH_CHECK(hipStreamSynchronize(c->stream));
+        EH_CHECK(hipStreamSynchronize(x->stream));
+        if (x->dev) { (void)hipFree(x->dev); x->dev = nullptr; }
+        if (x->req) { (void)hipHostFree(x->req); x->req = nullptr; }
+        x->n_cap = 0;
+        void *q = nullptr;
+        if (hipMalloc(&q, sizeof(edgehip_keyline) * cap * n * R) != hipSuccess) { (void)hipGetLastError(); set_error("export_keylines: staging alloc failed"); return EDGEHIP_ERR_MEMORY; }
+        x->dev = (edgehip_keyline *)q;
+        EH_CHECK(hipMemset(x->dev, 0, sizeof(edgehip_keyline) * cap * n * R));
+        if (hipHostMalloc(&q, sizeof(int32_t) * n * R, hipHostMallocDefault) != hipSuccess) { (void)hipGetLastError(); set_error("export_keylines: pinned alloc failed"); return EDGEHIP_ERR_MEMORY; }
+        x->req = (int32_t *)q;
+        x->n_cap = n;
+    }
+    const int e = (int)(x->next % R);
+    if (x->t[e].id >= 0) { set_error("export_keylines: four tickets outstanding (edgehip_export_wait releases one)"); return EDGEHIP_ERR_STATE; }
+    const int so = (c->frame_slot - 1 + c->ring_slots) % c->ring_slots;
+    if (int er = rot_materialize_enqueue(c, so)) return er;   // a slot the whole-frame driver rotated out of place (ctx.h: fuse_match)
+    int32_t *req = x->req + (size_t)e * x->n_cap;
+    for (int j = 0; j < n; j++) req[j] = seqs[j];
+    hipLaunchKernelGGL(k_pack_keylines, dim3((unsigned)((cap + 255) / 256), (unsigned)n), dim3(256), 0, c->stream, kldev(c, so),
+                       c->kn_slot + (size_t)so * c->plan.nseq, req, (int32_t *)nullptr, x->dev + (size_t)e * x->n_cap * cap, (int)cap);
+    EH_LAUNCH_CHECK();
+    EH_CHECK(hipEventRecord(x->ev_pack[e], c->stream));
+    if (c->stream_a != c->stream) {   // the frame after next detects into this slot on the stage-A stream: not before the lists are out
+        EH_CHECK(hipEventRecord(c->ev_use[so], c->stream));
+        c->use_valid[so] = true;
+    }
+    x->t[e].id = x->next;
+    x->t[e].n = n;
+    x->t[e].fetched = false;
+    *ticket_out = (int)(x->next & 0x7fffffff);
+    x->next++;
+    return 0;
+}
+
+static edgehip_ctx::KlExport::Ticket *export_ticket(edgehip_ctx *c, int ticket, int &e) {
+    auto *x = c ? c->kl_export : nullptr;
+    if (!x) return nullptr;
+    for (e = 0; e < edgehip_ctx::KlExport::R; e++)
+        if (x->t[e].id >= 0 && (int)(x->t[e].id & 0x7fffffff) == ticket) return &x->t[e];
+    return nullptr;
+}
+
+int edgehip_export_fetch(edgehip_ctx *c, int ticket, const int32_t *kn, edgehip_keyline *const *dst) {
+    EH_ENTER(c);
+    int e = 0;
+    auto *t = export_ticket(c, ticket, e);
+    if (!t || !kn || !dst) { set_error("export_fetch: unknown ticket or null argument"); return EDGEHIP_ERR_ARG; }
+    if (t->fetched) { set_error("export_fetch: ticket already fetched"); return EDGEHIP_ERR_STATE; }
+    auto *x = c->kl_export;
+    const size_t cap = (size_t)c->plan.cap;
+    for (int j = 0; j < t->n; j++)
+        if (kn[j] < 0 || (size_t)kn[j] > cap || (kn[j] > 0 && !dst[j])) { set_error("export_fetch: KeyLine count beyond the capacity, or null destination"); return EDGEHIP_ERR_ARG; }
+    EH_CHECK(hipStreamWaitEvent(x->stream, x->ev_pack[e], 0));
+    for (int j = 0; j < t->n; j++)
+        if (kn[j] > 0)
+            EH_CHECK(hipMemcpyAsync(dst[j], x->dev + ((size_t)e * x->n_cap + j) * cap, sizeof(edgehip_keyline) * kn[j], hipMemcpyDeviceToHost, x->stream));
+    EH_CHECK(hipEventRecord(x->ev_done[e], x->stream));
+    t->fetched = true;
+    return 0;
+}
+
+int edgehip_export_wait(edgehip_ctx *c, int ticket) {
+    EH_ENTER(c);
+    int e = 0;
+    auto *t = export_ticket(c, ticket, e);
+    if (!t) { set_error("export_wait: unknown ticket"); return EDGEHIP_ERR_ARG; }
+    if (t->fetched) EH_CHECK(hipEventSynchronize(c->kl_export->ev_done[e]));
+    t->id = -1;          // (a ticket that was never fetched is simply dropped: its staging entry is free again)
+    t->fetched = false;
     return 0;
 }
 

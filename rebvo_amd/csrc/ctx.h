@@ -286,6 +286,18 @@ struct edgehip_ctx {
     edgehip_keyline *aos_host = nullptr;   // page-locked, same shape
     int32_t *aos_req_dev = nullptr, *aos_req_host = nullptr;   // [2][requests]: sequence ids | KeyLine counts (host side page-locked)
     int aos_requests = 0;
+    // edgehip_export_keylines / _fetch / _wait: the AoS KeyLine lists of output callbacks without a host synchronisation — packed
+    // in-stream behind the frame that finishes with the slot into a staging ring on the device, copied out on a stream of their own
+    struct KlExport {
+        static constexpr int R = 4;                 // tickets in flight (a group keeps at most three: two steps in flight + the one being delivered)
+        hipStream_t stream = nullptr;               // the copies to the host (never the log's stream: edgehip_read_nav_log synchronises that one)
+        edgehip_keyline *dev = nullptr;             // [R][n_cap][CAP]
+        int32_t *req = nullptr;                     // page-locked [R][n_cap]: sequence ids, read in place by the packing kernel
+        int n_cap = 0;
+        hipEvent_t ev_pack[R] = {}, ev_done[R] = {};
+        struct Ticket { long long id = -1; int n = 0; bool fetched = false; } t[R];
+        long long next = 0;
+    } *kl_export = nullptr;
     edgehip_nav *nav_dev;  // [B] per-frame record
     edgehip_nav *nav_log;  // [nav_log_len][B] ring of per-frame records (optional)
     int nav_log_len;

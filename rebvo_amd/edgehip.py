@@ -202,7 +202,7 @@ EXPORTS = [
     "edgehip_set_state", "edgehip_get_framecount", "edgehip_set_framecount", "edgehip_download_keylines", "edgehip_download_keylines_batch",
     "edgehip_upload_keylines", "edgehip_download_plane", "edgehip_download_field", "edgehip_profile_enable",
     "edgehip_profile_count", "edgehip_profile_name", "edgehip_profile_read", "edgehip_profile_select",
-    "edgehip_upload_rgb_indexed", "edgehip_bind_rgb_indexed", "edgehip_set_nav_log", "edgehip_read_nav_log", "edgehip_read_nav_log_device",
+    "edgehip_upload_rgb_indexed", "edgehip_bind_rgb_indexed", "edgehip_set_nav_log", "edgehip_read_nav_log", "edgehip_read_nav_log_device", "edgehip_export_keylines", "edgehip_export_fetch", "edgehip_export_wait",
     "edgehip_build_undistort_map", "edgehip_download_undistorted", "edgehip_depth_reset", "edgehip_depth_reset_slot", "edgehip_set_slot_camera", "edgehip_directed_matching_stereo",
     "edgehip_alloc_pinned", "edgehip_free_pinned", "edgehip_upload_rgb_pinned", "edgehip_upload_sync", "edgehip_upload_wait", "edgehip_register_host", "edgehip_unregister_host", "edgehip_experiments", "edgehip_fuse_stereo_depth", "edgehip_set_stereo_rig", "edgehip_get_stereo_matches", "edgehip_minimizer_v", "edgehip_ext_rot_vel",
     "edgehip_imu_enable", "edgehip_set_imu", "edgehip_read_nav_imu", "edgehip_minimizer_rv_kf", "edgehip_lm_solve",
@@ -583,6 +583,37 @@ class EdgeHip:
             for j in registered:
                 self._ck(self.lib.edgehip_unregister_host(C.c_void_p(bufs[j].ctypes.data)))
         return [b[:k].copy() for b, k in zip(bufs, kn)]
+
+    def export_keylines(self, seqs):
+        """edgehip_export_keylines: the OLD slot of the frame processed last, packed in-stream (no synchronisation) -> ticket."""
+        seqs = np.ascontiguousarray(seqs, dtype=np.int32)
+        t = C.c_int(0)
+        self._ck(self.lib.edgehip_export_keylines(self.ctx, len(seqs), seqs.ctypes.data_as(C.c_void_p), C.byref(t)))
+        return (t.value, len(seqs))
+
+    def export_fetch(self, ticket, kns, registered=True):
+        """Enqueue the copies of kns[j] records per list (does not block); returns the destination arrays, valid after export_wait."""
+        tid, n = ticket
+        kns = np.ascontiguousarray(kns, dtype=np.int32)
+        assert len(kns) == n
+        bufs = [np.zeros(self.cap, KEYLINE_DTYPE) for _ in range(n)]
+        if registered:
+            for b in bufs:
+                self._ck(self.lib.edgehip_register_host(C.c_void_p(b.ctypes.data), C.c_size_t(b.nbytes)))
+        ptrs = (C.c_void_p * n)(*[b.ctypes.data for b in bufs])
+        self._ck(self.lib.edgehip_export_fetch(self.ctx, tid, kns.ctypes.data_as(C.c_void_p), ptrs))
+        return {"bufs": bufs, "kns": kns, "registered": registered, "ticket": ticket}
+
+    def export_wait(self, fetched):
+        """Block until the ticket's copies have landed; returns the lists."""
+        self._ck(self.lib.edgehip_export_wait(self.ctx, fetched["ticket"][0]))
+        if fetched["registered"]:
+            for b in fetched["bufs"]:
+                self._ck(self.lib.edgehip_unregister_host(C.c_void_p(b.ctypes.data)))
+        return [b[:k].copy() for b, k in zip(fetched["bufs"], fetched["kns"])]
+
+    def export_drop(self, ticket):
+        self._ck(self.lib.edgehip_export_wait(self.ctx, ticket[0]))
 
     def upload_keylines(self, seq, slot, kl, mask=None, retuned=0.0):
         kl = np.ascontiguousarray(kl, dtype=KEYLINE_DTYPE)

@@ -313,6 +313,8 @@ struct PipeBuffer {
     bool quit = false;
     int stereo_match_num = 0;
     IntegratedImuData imu;
+    bool imgc_valid = true;   // (mirror only) imgc holds THIS frame: the group engine copies the frame for the output thread only when a
+                              // callback or a snapshot request is pending at launch time — per frame, not per object
 };
 
 namespace customCam {

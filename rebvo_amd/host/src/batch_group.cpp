@@ -20,9 +20,12 @@
 // so the host works on earlier steps' results while the device runs the newest, and frame k+1 crosses PCIe under frame k: the
 // reference's T0 || T1.  Up to two steps stay in flight when nobody has a callback (a single camera's frame is ~40 dependent
 // launches: the host needs as long to enqueue one as the device to run it, and one step of slack is not enough to keep the device
-// fed); one with callbacks, because the edge map a callback receives lives in a ring slot the step after next overwrites.  When
-// no further frame is waiting, everything in flight is completed at once — a lone camera at 20 Hz sees its record as soon as
-// the frame is done, not a frame later.
+// fed) — with callbacks too (round 6): the edge map a callback receives lives in a ring slot the step after next overwrites, so its
+// AoS KeyLine lists are packed on the device right behind the step that finishes with the slot (edgehip_export_keylines: in-stream,
+// a staging ring of its own), copied out on a stream of their own into the members' page-locked PipeBuffer arrays while the next
+// steps run (edgehip_export_fetch, issued one completion ahead, as soon as the list lengths are known), and only waited for when the
+// frame is handed to the member's output thread (edgehip_export_wait).  When no further frame is waiting, everything in flight is
+// completed at once — a lone camera at 20 Hz sees its record as soon as the frame is done, not a frame later.
 //
 // Hand-off order is the reference's (rebvo_second_t.cpp:622-623): frame j reaches a member's callback after frame j+1 has been
 // tracked against it, carrying its own record and its edge map as the tracker left it; the last frame is never delivered.
@@ -90,6 +93,13 @@ public:
     std::condition_variable cv;
     bool started = false, failed = false;
     std::string error;
+    // The page-locked rings live as long as anybody can reach them: the group holds one reference, every camera-buffer view handed
+    // out through requestCustomCamBuffer another (the application's shared_ptr may outlive CleanUp(), as a heap image's would).
+    struct RingOwner {
+        uint8_t *ring = nullptr, *grey = nullptr;
+        ~RingOwner() { if (ring) edgehip_free_pinned(ring); if (grey) edgehip_free_pinned(grey); }
+    };
+    std::shared_ptr<RingOwner> ring_owner;
     uint8_t *ring = nullptr;       // page-locked [CCAMBUFSIZE][cap][frame]: the members' camera buffers (null: heap images, staged uploads)
     size_t frame_bytes = 0;
     uint8_t *grey_ring = nullptr;  // page-locked [CCAMBUFSIZE][cap][w * h]: 8-bit planes of the mono frames among them (null: MonoUpload off)
@@ -106,7 +116,15 @@ public:
 
     static constexpr int kNavLog = 8;
 
+    // AoS KeyLine lists for the members' callbacks, one export per step (edgehip_export_keylines right behind the step's
+    // edgehip_process_frame): which seats it covers, and whether its copies have been enqueued yet
+    struct Export { long step = -1; int ticket = 0; std::vector<int32_t> seats; bool fetched = false; };
+    Export exp_of[4];              // [step & 3]
+    int cb_depth = 2;              // steps in flight when somebody has a callback (REBVO_GROUP_CB_DEPTH=1: the round-5 behaviour, A/B)
+
     void threadMain();
+    int exportFetch(Export &ex, const std::vector<int32_t> &kn, const std::vector<edgehip_keyline *> &dst);
+    void dropExports();
     bool gather(bool block, bool &any_running, bool &any_leaving);
     int upload(std::vector<double> &ts, int &slot);
     int launch(long step, const std::vector<double> &ts);
@@ -154,10 +172,12 @@ bool REBVO::groupAttach() {
         g->grey_bytes = (size_t)params.ImageSize.w * params.ImageSize.h;
         void *greyp = nullptr;
         if (rc == 0 && g->ring && params.GpuMonoUpload && edgehip_alloc_pinned(g->grey_bytes * CCAMBUFSIZE * want, &greyp) == 0) g->grey_ring = static_cast<uint8_t *>(greyp);
+        g->ring_owner = std::make_shared<BatchGroup::RingOwner>();
+        g->ring_owner->ring = g->ring;
+        g->ring_owner->grey = g->grey_ring;
         if (rc != 0) {
             const std::string msg = std::string("REBVO(hip): edgehip_create failed: ") + edgehip_last_error();
-            if (g->ring) edgehip_free_pinned(g->ring);
-            if (g->grey_ring) edgehip_free_pinned(g->grey_ring);
+            g->ring_owner.reset();
             if (g->hip) edgehip_destroy(g->hip);
             delete g;
             return fail(msg);
@@ -187,8 +207,10 @@ bool REBVO::groupAttach() {
     group = g;
     group_seat = seat;
     if (g->ring) {   // the camera ring's images become views of the group's page-locked ring: entry j of this member = ring[j][seat]
+        std::shared_ptr<BatchGroup::RingOwner> owner = g->ring_owner;
         for (unsigned j = 0; j < cam_pipe.Size(); j++)
-            cam_pipe[j].img = std::make_shared<Image<RGB24Pixel>>(reinterpret_cast<RGB24Pixel *>(g->ringImage((int)j, seat)), params.ImageSize);
+            cam_pipe[j].img = std::shared_ptr<Image<RGB24Pixel>>(new Image<RGB24Pixel>(reinterpret_cast<RGB24Pixel *>(g->ringImage((int)j, seat)), params.ImageSize),
+                                                                 [owner](Image<RGB24Pixel> *p) { delete p; });   // the view keeps the ring alive
         cam_pinned = true;
     }
     quit = false;
@@ -271,8 +293,7 @@ void REBVO::groupDetach() {
     if (last) {   // the last member out stops the thread and frees the context
         if (g->thr.joinable()) g->thr.join();
         if (g->hip) edgehip_destroy(g->hip);
-        if (g->ring) edgehip_free_pinned(g->ring);
-        if (g->grey_ring) edgehip_free_pinned(g->grey_ring);
+        g->ring_owner.reset();   // freed with the last view of it (normally: here)
         delete g;
     }
 }
@@ -423,7 +444,10 @@ int REBVO::BatchGroup::launch(long step, const std::vector<double> &ts) {
         nb.quit = false;
         nb.dtp0 = 0;
         nb.dtp1 = tp0;   // start of the step; complete() turns it into the step's duration
+        nb.imgc_valid = false;
         if (cf->haveCallBack() || cf->saveImg) {
+            nb.imgc_valid = true;   // the output thread converts / saves only a frame that was really kept (a request that arrives after the
+                                    // launch is honoured by the first later frame launched with it pending)
             if (st.ring_idx >= 0 && st.side_ok[st.ring_idx]) {   // the application's thread made the copy: take it
                 std::swap(nb.imgc, st.side_img[st.ring_idx]);
                 st.side_ok[st.ring_idx] = 0;
@@ -444,9 +468,39 @@ int REBVO::BatchGroup::launch(long step, const std::vector<double> &ts) {
         st.frames++;
     }
     newest = step;
+    // the callbacks' KeyLine lists of the frame BEFORE this one (the old slot, as this step's tracking leaves it): packed in-stream now
+    Export &ex = exp_of[step & 3];
+    ex.step = -1;
+    if (step >= 1 && cb_depth > 1) {
+        ex.seats.clear();
+        for (int i = 0; i < cap; i++) {
+            Seat &st = seats[i];
+            if (!st.running || !st.cf->haveCallBack() || st.frames < 2) continue;   // (frames counts this step's frame already)
+            if (!st.kl_pinned) pinKeyLines(st, true);
+            ex.seats.push_back(i);
+        }
+        if (!ex.seats.empty()) {
+            rc = edgehip_export_keylines(hip, (int)ex.seats.size(), ex.seats.data(), &ex.ticket);
+            if (rc != 0) return rc;
+            ex.step = step;
+            ex.fetched = false;
+        }
+    }
     tm.buffers += detail::now_s() - tp1;
     tm.steps++;
     return 0;
+}
+
+int REBVO::BatchGroup::exportFetch(Export &ex, const std::vector<int32_t> &kn, const std::vector<edgehip_keyline *> &dst) {
+    const int rc = edgehip_export_fetch(hip, ex.ticket, kn.data(), dst.data());
+    if (rc == 0) ex.fetched = true;
+    return rc;
+}
+
+// Every export still outstanding is waited for (or dropped): before KeyLine arrays are unpinned, a copy must not be on its way into them.
+void REBVO::BatchGroup::dropExports() {
+    for (Export &ex : exp_of)
+        if (ex.step >= 0) { (void)edgehip_export_wait(hip, ex.ticket); ex.step = -1; }
 }
 
 // Hand the camera buffers of the step launched last back as soon as the copies into its slot have read them (the frames are still
@@ -476,14 +530,18 @@ int REBVO::BatchGroup::complete(long step, int slot, std::vector<edgehip_nav> &n
     // the members' records; who gets the frame before delivered with its KeyLines
     std::vector<int32_t> cb_seq;
     std::vector<edgehip_keyline *> cb_dst;
-    std::vector<PipeBuffer *> cb_buf, deliver(cap, nullptr);
+    std::vector<PipeBuffer *> cb_buf, deliver(cap, nullptr), mine(cap, nullptr);
     int slot_before = -1;
+    Export &ex = exp_of[step & 3];
+    const bool have_ex = ex.step == step;
+    auto in_export = [&](int seat) { return have_ex && std::find(ex.seats.begin(), ex.seats.end(), seat) != ex.seats.end(); };
     for (int i = 0; i < cap; i++) {
         Seat &st = seats[i];
         if (!st.running || !st.buf_of[step & 3]) continue;
         REBVO *cf = st.cf;
         PipeBuffer &nb = *st.buf_of[step & 3];
         st.buf_of[step & 3] = nullptr;
+        mine[i] = &nb;
         const edgehip_nav &n = navs[i];
         const bool first = !st.have_prev;   // this member's first frame: "dummy processing" (rebvo_second_t.cpp:108-121)
         nb.dt = n.dt;
@@ -501,9 +559,11 @@ int REBVO::BatchGroup::complete(long step, int slot, std::vector<edgehip_nav> &n
         if (st.have_prev) {   // the frame before goes to the output thread, with its edge map as this frame's tracking left it
             PipeBuffer &ob = cf->pipe.RequestBuffer(1);
             deliver[i] = &ob;
-            if (cf->haveCallBack() && newest - step >= 2) {
-                // a callback registered while two steps were in flight: the frame before's ring slot has been detected into again;
-                // this one delivery carries no KeyLines (from the next on the group keeps one step in flight)
+            if (cf->haveCallBack() && cb_depth > 1) {
+                // the lists were packed behind this step (launch()); a callback registered after that gets this one delivery without
+                // KeyLines — the ring slot may have been detected into again — and the next with them
+                if (!in_export(i)) ob.ef->kn = 0;
+            } else if (cf->haveCallBack() && newest - step >= 2) {
                 ob.ef->kn = 0;
             } else if (cf->haveCallBack()) {
                 if (!st.kl_pinned) pinKeyLines(st, true);
@@ -516,11 +576,41 @@ int REBVO::BatchGroup::complete(long step, int slot, std::vector<edgehip_nav> &n
         st.have_prev = true;
         st.slot_prev = slot;
     }
-    if (!cb_seq.empty()) {   // AoS KeyLines of every member with a callback: one packing kernel, one copy per list
+    if (!cb_seq.empty()) {   // (REBVO_GROUP_CB_DEPTH=1) AoS KeyLines of every member with a callback: one packing kernel, one copy per list, synchronising
         std::vector<int32_t> kn(cb_seq.size(), 0);
         rc = edgehip_download_keylines_batch(hip, slot_before, (int)cb_seq.size(), cb_seq.data(), cb_dst.data(), kn.data());
         if (rc != 0) std::cout << "\nREBVO: edgehip_download_keylines_batch failed: " << edgehip_last_error() << "\n";
         for (size_t j = 0; j < cb_buf.size(); j++) cb_buf[j]->ef->kn = rc == 0 ? kn[j] : 0;
+    }
+    if (have_ex) {
+        // this step's export: the lists of the frames about to be delivered.  Normally its copies were enqueued one completion ago
+        // (below) and have landed under the steps since; a step completed right behind its launch enqueues them now.
+        if (!ex.fetched) {
+            std::vector<int32_t> kn(ex.seats.size(), 0);
+            std::vector<edgehip_keyline *> dst(ex.seats.size(), nullptr);
+            for (size_t j = 0; j < ex.seats.size(); j++)
+                if (PipeBuffer *ob = deliver[ex.seats[j]]) { kn[j] = ob->ef->kn; dst[j] = reinterpret_cast<edgehip_keyline *>(ob->ef->kl.data()); }
+            rc = exportFetch(ex, kn, dst);
+        }
+        const int rw = edgehip_export_wait(hip, ex.ticket);
+        ex.step = -1;
+        if (rc == 0) rc = rw;
+        if (rc != 0) {
+            std::cout << "\nREBVO: KeyLine export failed: " << edgehip_last_error() << "\n";
+            for (int seat : ex.seats) if (deliver[seat]) deliver[seat]->ef->kn = 0;
+        }
+    }
+    {   // the NEXT step's export (already packed if that step has been launched): its lists belong to the frames whose records were just
+        // read — the lengths are known now, the destinations are these frames' PipeBuffers — so its copies go out at once and run under
+        // the steps in flight
+        Export &nx = exp_of[(step + 1) & 3];
+        if (rc == 0 && nx.step == step + 1 && !nx.fetched) {
+            std::vector<int32_t> kn(nx.seats.size(), 0);
+            std::vector<edgehip_keyline *> dst(nx.seats.size(), nullptr);
+            for (size_t j = 0; j < nx.seats.size(); j++)
+                if (PipeBuffer *nb = mine[nx.seats[j]]) { kn[j] = nb->ef->kn; dst[j] = reinterpret_cast<edgehip_keyline *>(nb->ef->kl.data()); }
+            rc = exportFetch(nx, kn, dst);
+        }
     }
     for (int i = 0; i < cap; i++)   // (PipeBuffer::img, the grey image a callback may look at, is formed by the member's output thread)
         if (deliver[i]) seats[i].cf->pipe.ReleaseBuffer(1);
@@ -537,6 +627,7 @@ void REBVO::BatchGroup::threadMain() {
         for (Seat &st : seats)
             if (st.running) st.cf->quit = true;
     }
+    if (const char *e = getenv("REBVO_GROUP_CB_DEPTH")) cb_depth = std::max(1, std::min(2, atoi(e)));
     long step = 0;                       // frames of the context enqueued so far
     struct InFlight { long step; int slot; };
     std::vector<InFlight> pending;       // steps enqueued and not yet completed, oldest first (at most 2)
@@ -562,6 +653,7 @@ void REBVO::BatchGroup::threadMain() {
                 if (rc != 0) break;
             }
             if (leaving) {   // (nothing of theirs is in flight any more)
+                dropExports();
                 for (Seat &st : seats)
                     if (st.running && st.leaving) closeSeat(st);
                 continue;
@@ -576,7 +668,7 @@ void REBVO::BatchGroup::threadMain() {
         have_next = false;
         bool callbacks = false;
         for (Seat &st : seats) callbacks |= st.running && st.cf->haveCallBack();
-        const size_t depth = callbacks ? 1 : 2;
+        const size_t depth = callbacks ? (size_t)cb_depth : 2;
         const int slot = slot_next;
         std::array<double, 5> tl{};
         tl[0] = detail::now_s();
@@ -611,6 +703,8 @@ void REBVO::BatchGroup::threadMain() {
         failed = true;
         error = edgehip_last_error();
     }
+    if (rc != 0) (void)edgehip_sync(hip);
+    dropExports();
     for (Seat &st : seats)
         if (st.running) closeSeat(st);
     if (getenv("REBVO_GROUP_TIMING") && tm.steps > 0) {

@@ -377,7 +377,16 @@ bool REBVO::Init() {
         std::cout << last_error << "\n";
         return false;
     }
-    if (useGroupEngine()) return groupAttach();   // batch_group.cpp: the (possibly shared) context and its tracker thread
+    if (group) {   // Init() again without CleanUp() (e.g. after a device error closed the seat): let go of the old seat first
+        quit = true;
+        groupDetach();
+    }
+    if (useGroupEngine()) {   // batch_group.cpp: the (possibly shared) context and its tracker thread
+        if (groupAttach()) return true;
+        delete dscam;         // a refused member (parameter mismatch, full group, edgehip_create failure) keeps nothing
+        dscam = nullptr;
+        return false;
+    }
     if (!params.GpuBatchGroup.empty()) {
         last_error = "REBVO(hip): &GPU BatchGroup needs ImuMode=0 and no stereo pair";
         std::cout << last_error << "\n";
@@ -508,6 +517,7 @@ void REBVO::TrackThread(REBVO *cf) {
         int rc = grey ? edgehip_upload_grey8(cf->hip, slot, grey, 0, 1)
                       : edgehip_upload_rgb(cf->hip, slot, reinterpret_cast<const uint8_t *>(data), 0, 1);
         std::memcpy(new_buf.imgc->Data(), data, frame_bytes);
+        new_buf.imgc_valid = true;
         if (cbuf) cf->cam_pipe.ReleaseBuffer(1);
         else cf->dscam->ReleaseBuffer();
         if (data_pair) {   // the pair image goes to the slot behind the ring
@@ -677,7 +687,7 @@ void REBVO::ThirdThread(REBVO *cf) {
             t_log << std::scientific << std::setprecision(18) << pbuf.t / cf->params.ImuTimeScale << " " << nv.Pos[0] << " "
                   << nv.Pos[1] << " " << nv.Pos[2] << " " << q[0] << " " << q[1] << " " << q[2] << " " << q[3] << "\n";
         }
-        if (cf->haveCallBack()) {   // Image<float>::ConvertRGB2BW (include/VideoLib/image.h:197-203): the grey image a consumer may look at
+        if (cf->haveCallBack() && pbuf.imgc_valid) {   // Image<float>::ConvertRGB2BW (include/VideoLib/image.h:197-203): the grey image a consumer may look at
             const RGB24Pixel *c = pbuf.imgc->Data();
             float *bw = pbuf.img->Data();
             const uint npx = pbuf.img->bSize();
@@ -685,7 +695,8 @@ void REBVO::ThirdThread(REBVO *cf) {
         }
         cf->callCallBack(pbuf);   // :329, under call_mutex
         t_proc_last = now_s() - ts;
-        if (cf->saveImg) {   // rebvo_third_t.cpp:335-343 (SavePPM, video_io.cpp:230-244)
+        if (cf->saveImg && pbuf.imgc_valid) {   // rebvo_third_t.cpp:335-343 (SavePPM, video_io.cpp:230-244); a frame launched before the request
+                                                // carries no image (group engine): the next one that does is saved
             cf->saveImg = false;
             char name[128];
             snprintf(name, sizeof(name), "Snap%d.ppm", cf->snap_n);

@@ -203,6 +203,76 @@ def test_batched_keyline_download_equals_the_single_one():
     eh.close()
 
 
+def test_in_stream_keyline_export_equals_the_synchronising_download_with_frames_in_flight():
+    """edgehip_export_keylines / _fetch / _wait (what a group's callbacks are served from since round 6): the old slot's lists packed
+    behind frame k without a synchronisation, fetched and waited for only after frames k+1 and k+2 have been enqueued — k+2 detects
+    into the very slot the lists came from.  Byte for byte what edgehip_download_keylines returned for that slot right behind frame k
+    (a second context run in lock-step provides that)."""
+    import ctypes as C
+    n_obj, pool, n_fr = 5, 6, 9
+    frames = [f for f, _, _ in synth.billboard_sequence(W, H, pool, seed=23)]
+    p = edgehip.euroc_params(W, H)
+    eh, ref = edgehip.EdgeHip(p, nseq=n_obj, nslots=3, device=0), edgehip.EdgeHip(p, nseq=n_obj, nslots=3, device=0)
+    seqs = [4, 0, 2]
+    want, tickets, got = {}, {}, {}
+
+    def collect(k):
+        kns = [len(want[k][j]) for j in range(len(seqs))]
+        f = eh.export_fetch(tickets.pop(k), kns, registered=(k % 2 == 0))      # page-locked and pageable destinations alike
+        got[k] = eh.export_wait(f)
+    for k in range(n_fr):
+        batch = np.stack([frames[tri(k + i, pool)] for i in range(n_obj)])
+        for e in (eh, ref):
+            e.upload_rgb(e.next_slot(), batch)
+            e.process_frame(np.full(n_obj, T0 + DT * k))
+        if k >= 1:
+            tickets[k] = eh.export_keylines(seqs)                               # in-stream, no synchronisation
+            want[k] = [ref.download_keylines(s_, (ref.cur_slot() + 2) % 3, want_mask=False)[0] for s_ in seqs]
+        if k >= 3:
+            collect(k - 2)                                                      # two frames later: its slot has been detected into again
+    for k in list(tickets):
+        collect(k)
+    assert sorted(got) == list(range(1, n_fr))
+    for k in got:
+        for a, b in zip(got[k], want[k]):
+            assert len(a) == len(b) > 1000 and a.tobytes() == b.tobytes(), k
+    # the ticket discipline: a fifth outstanding ticket is refused, an unknown one too, a dropped one frees its entry
+    held = [eh.export_keylines(seqs) for _ in range(4)]
+    t = C.c_int(0)
+    arr = np.array(seqs, np.int32)
+    assert eh.lib.edgehip_export_keylines(eh.ctx, 3, arr.ctypes.data_as(C.c_void_p), C.byref(t)) != 0
+    assert eh.lib.edgehip_export_wait(eh.ctx, 123456) != 0
+    for h in held:
+        eh.export_drop(h)
+    eh.export_drop(eh.export_keylines(seqs))
+    fresh = edgehip.EdgeHip(p, nseq=2, nslots=3, device=0)
+    assert fresh.lib.edgehip_export_keylines(fresh.ctx, 1, arr.ctypes.data_as(C.c_void_p), C.byref(t)) != 0      # no frame pair yet
+    for e in (eh, ref, fresh):
+        e.close()
+
+
+def test_a_snapshot_without_a_callback_holds_a_real_frame(tmp_path):
+    """TakeSnapshot() on an object that has NO output callback: the group engine keeps a frame's image for the output
+    thread only when a callback or a snapshot request is pending when the frame is launched, and delivery runs behind launch — the
+    snapshot must wait for a frame launched after the request and hold that frame, not the stale image of one launched before it."""
+    n_obj, n_fr, pool = 2, 7, 6
+    frames = [f for f, _, _ in synth.billboard_sequence(W, H, pool, seed=13)]
+    np.stack(frames).tofile(tmp_path / "frames.rgb24")
+    cfg = tmp_path / "cfg"
+    write_global_config(cfg, edgehip.euroc_params(W, H))
+    r = subprocess.run([EXE, str(cfg), str(tmp_path / "frames.rgb24"), str(pool), str(n_obj), str(n_fr), str(T0), str(DT), "--group", "snap",
+                        "--snapshot-at", "4"], capture_output=True, text=True, timeout=300, cwd=tmp_path)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-1000:]
+    assert json.loads(r.stdout.strip().splitlines()[-1])["callbacks"] == 0
+    snap = (tmp_path / "Snap0.ppm").read_bytes()
+    head = f"P6\n{W} {H} 255\n".encode()
+    assert snap.startswith(head) and len(snap) == len(head) + W * H * 3
+    img = np.frombuffer(snap[len(head):], np.uint8).reshape(H, W, 3)
+    assert img.any()
+    # a frame submitted at or after the request (frames 4, 5, 6 = pool images 4, 5, 4), never an earlier one (pool images 0..3)
+    assert any(np.array_equal(img, frames[tri(k, pool)]) for k in range(4, n_fr))
+
+
 def test_a_member_whose_ring_runs_ahead_after_a_dropped_frame(tmp_path):
     """The soft-FPS gate (rebvo_first_t.cpp:146, 172-177) per member: one object submits a frame too many (stamped like the one
     before it) — dropped, and from then on that object's camera ring stands one entry ahead of the others', so its frames no longer
