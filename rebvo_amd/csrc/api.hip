@@ -664,6 +664,7 @@ int edgehip_destroy(edgehip_ctx *c) {
         for (hipEvent_t e : x->ev_done) if (e) (void)hipEventDestroy(e);
         if (x->dev) (void)hipFree(x->dev);
         if (x->req) (void)hipHostFree(x->req);
+        for (edgehip_keyline *h : x->host) if (h) (void)hipHostFree(h);
         delete x;
         c->kl_export = nullptr;
     }
@@ -996,7 +997,8 @@ int edgehip_set_nav_log(edgehip_ctx *c, int len) {
             set_error("nav log alloc failed");
             return EDGEHIP_ERR_MEMORY;
         }
-        EH_CHECK(hipMemset(q, 0, sizeof(edgehip_nav) * (size_t)len * c->plan.nseq));
+        EH_CHECK(hipMemsetAsync(q, 0, sizeof(edgehip_nav) * (size_t)len * c->plan.nseq, c->stream));
+        EH_CHECK(hipStreamSynchronize(c->stream));
         c->nav_log = (edgehip_nav *)q;
         c->nav_log_len = len;
     }
@@ -1215,7 +1217,7 @@ int edgehip_download_keylines_batch(edgehip_ctx *c, int slot, int n, const int32
         void *q = nullptr;
         if (hipMalloc(&q, sizeof(edgehip_keyline) * cap * n) != hipSuccess) { (void)hipGetLastError(); set_error("download_keylines_batch: staging alloc failed"); return EDGEHIP_ERR_MEMORY; }
         c->aos_dev = (edgehip_keyline *)q;
-        EH_CHECK(hipMemset(c->aos_dev, 0, sizeof(edgehip_keyline) * cap * n));
+        EH_CHECK(hipMemsetAsync(c->aos_dev, 0, sizeof(edgehip_keyline) * cap * n, c->stream));
         if (hipHostMalloc(&q, sizeof(edgehip_keyline) * cap * n, hipHostMallocDefault) != hipSuccess) { (void)hipGetLastError(); set_error("download_keylines_batch: pinned alloc failed"); return EDGEHIP_ERR_MEMORY; }
         c->aos_host = (edgehip_keyline *)q;
         if (hipMalloc(&q, sizeof(int32_t) * 2 * n) != hipSuccess) { (void)hipGetLastError(); set_error("download_keylines_batch: staging alloc failed"); return EDGEHIP_ERR_MEMORY; }
@@ -1282,11 +1284,13 @@ int edgehip_export_keylines(edgehip_ctx *c, int n, const int32_t *seqs, int *tic
         EH_CHECK(hipStreamSynchronize(x->stream));
         if (x->dev) { (void)hipFree(x->dev); x->dev = nullptr; }
         if (x->req) { (void)hipHostFree(x->req); x->req = nullptr; }
+        for (edgehip_keyline *&h : x->host) if (h) { (void)hipHostFree(h); h = nullptr; }
         x->n_cap = 0;
         void *q = nullptr;
         if (hipMalloc(&q, sizeof(edgehip_keyline) * cap * n * R) != hipSuccess) { (void)hipGetLastError(); set_error("export_keylines: staging alloc failed"); return EDGEHIP_ERR_MEMORY; }
         x->dev = (edgehip_keyline *)q;
-        EH_CHECK(hipMemset(x->dev, 0, sizeof(edgehip_keyline) * cap * n * R));
+        EH_CHECK(hipMemsetAsync(x->dev, 0, sizeof(edgehip_keyline) * cap * n * R, c->stream));   // on the stream the packing kernel follows on (hipMemset
+                                                                                                   // runs on the null stream, which a non-blocking stream does not wait for)
         if (hipHostMalloc(&q, sizeof(int32_t) * n * R, hipHostMallocDefault) != hipSuccess) { (void)hipGetLastError(); set_error("export_keylines: pinned alloc failed"); return EDGEHIP_ERR_MEMORY; }
         x->req = (int32_t *)q;
         x->n_cap = n;
@@ -1332,9 +1336,24 @@ int edgehip_export_fetch(edgehip_ctx *c, int ticket, const int32_t *kn, edgehip_
     for (int j = 0; j < t->n; j++)
         if (kn[j] < 0 || (size_t)kn[j] > cap || (kn[j] > 0 && !dst[j])) { set_error("export_fetch: KeyLine count beyond the capacity, or null destination"); return EDGEHIP_ERR_ARG; }
     EH_CHECK(hipStreamWaitEvent(x->stream, x->ev_pack[e], 0));
-    for (int j = 0; j < t->n; j++)
-        if (kn[j] > 0)
-            EH_CHECK(hipMemcpyAsync(dst[j], x->dev + ((size_t)e * x->n_cap + j) * cap, sizeof(edgehip_keyline) * kn[j], hipMemcpyDeviceToHost, x->stream));
+    t->staged_dst.assign(t->n, nullptr);
+    t->staged_kn.assign(t->n, 0);
+    for (int j = 0; j < t->n; j++) {
+        if (kn[j] <= 0) continue;
+        edgehip_keyline *to = dst[j];
+        if (!host_registered(dst[j], sizeof(edgehip_keyline) * kn[j])) {
+            // a pageable destination: through a page-locked staging list of the ticket, and a host copy in edgehip_export_wait
+            if (!x->host[e]) {
+                void *q = nullptr;
+                if (hipHostMalloc(&q, sizeof(edgehip_keyline) * cap * x->n_cap, hipHostMallocDefault) != hipSuccess) { (void)hipGetLastError(); set_error("export_fetch: pinned alloc failed"); return EDGEHIP_ERR_MEMORY; }
+                x->host[e] = (edgehip_keyline *)q;
+            }
+            to = x->host[e] + (size_t)j * cap;
+            t->staged_dst[j] = dst[j];
+            t->staged_kn[j] = kn[j];
+        }
+        EH_CHECK(hipMemcpyAsync(to, x->dev + ((size_t)e * x->n_cap + j) * cap, sizeof(edgehip_keyline) * kn[j], hipMemcpyDeviceToHost, x->stream));
+    }
     EH_CHECK(hipEventRecord(x->ev_done[e], x->stream));
     t->fetched = true;
     return 0;
@@ -1345,7 +1364,11 @@ int edgehip_export_wait(edgehip_ctx *c, int ticket) {
     int e = 0;
     auto *t = export_ticket(c, ticket, e);
     if (!t) { set_error("export_wait: unknown ticket"); return EDGEHIP_ERR_ARG; }
-    if (t->fetched) EH_CHECK(hipEventSynchronize(c->kl_export->ev_done[e]));
+    if (t->fetched) {
+        EH_CHECK(hipEventSynchronize(c->kl_export->ev_done[e]));
+        for (int j = 0; j < t->n; j++)
+            if (t->staged_dst[j]) memcpy(t->staged_dst[j], c->kl_export->host[e] + (size_t)j * c->plan.cap, sizeof(edgehip_keyline) * t->staged_kn[j]);
+    }
     t->id = -1;          // (a ticket that was never fetched is simply dropped: its staging entry is free again)
     t->fetched = false;
     return 0;

@@ -295,7 +295,8 @@ struct edgehip_ctx {
         int32_t *req = nullptr;                     // page-locked [R][n_cap]: sequence ids, read in place by the packing kernel
         int n_cap = 0;
         hipEvent_t ev_pack[R] = {}, ev_done[R] = {};
-        struct Ticket { long long id = -1; int n = 0; bool fetched = false; } t[R];
+        edgehip_keyline *host[R] = {};              // page-locked [n_cap][CAP] per ticket, allocated when a destination is not page-locked itself
+        struct Ticket { long long id = -1; int n = 0; bool fetched = false; std::vector<edgehip_keyline *> staged_dst; std::vector<int32_t> staged_kn; } t[R];
         long long next = 0;
     } *kl_export = nullptr;
     edgehip_nav *nav_dev;  // [B] per-frame record
