@@ -371,6 +371,10 @@ int edgehip_read_nav_log(edgehip_ctx *ctx, int first, int count, edgehip_nav *ou
  * communicator sends from): the multi-GPU nav gather of SURVEY.md section 8(e) takes its payload from HBM to the wire without a
  * host bounce (rebvo_amd/shard.py NavMover).  Same waiting, threading and range rules; the copy is complete on return. */
 int edgehip_read_nav_log_device(edgehip_ctx *ctx, int first, int count, void *out_dev);
+/* ImuMode > 0: the IMU part of the logged records (what edgehip_read_nav_imu returns for the newest frame), frames [first, first+count)
+ * as out[count][nseq] — same ring, same waiting and threading rules as edgehip_read_nav_log.  A caller that keeps frames in flight
+ * (a batch group of ImuMode = 1 / 2 objects, rebvo_amd/host/src/batch_group.cpp) reads both halves of frame k while k+1 and k+2 run. */
+int edgehip_read_nav_imu_log(edgehip_ctx *ctx, int first, int count, edgehip_nav_imu *out);
 /* Restart every sequence from scratch: state as after edgehip_create (thresholds, priors, pose, frame
  * counters) and an empty ring.  Not something the reference does at run time (it would re-construct REBVO). */
 int edgehip_reset(edgehip_ctx *ctx);

@@ -675,6 +675,7 @@ int edgehip_destroy(edgehip_ctx *c) {
     if (c->grey8) (void)hipFree(c->grey8);
     if (c->pinned_grey8) (void)hipHostFree(c->pinned_grey8);
     if (c->nav_log) (void)hipFree(c->nav_log);
+    if (c->nav_imu_log) (void)hipFree(c->nav_imu_log);
     if (c->stream_imu) { (void)hipStreamSynchronize(c->stream_imu); (void)hipStreamDestroy(c->stream_imu); for (int i = 0; i < 2; i++) { (void)hipEventDestroy(c->ev_imu_snap[i]); (void)hipEventDestroy(c->ev_imu_post[i]); (void)hipEventDestroy(c->ev_imu_mid[i]); } }
     if (c->kf_req_dev) (void)hipFree(c->kf_req_dev);
     if (c->kf_res_dev) (void)hipFree(c->kf_res_dev);
@@ -982,6 +983,7 @@ int edgehip_set_nav_log(edgehip_ctx *c, int len) {
     drop_frame_graphs(c);   // the per-frame record kernel takes the log pointer as an argument
     if (c->stream_log) EH_CHECK(hipStreamSynchronize(c->stream_log));
     if (c->nav_log) { (void)hipFree(c->nav_log); c->nav_log = nullptr; }
+    if (c->nav_imu_log) { (void)hipFree(c->nav_imu_log); c->nav_imu_log = nullptr; }
     c->nav_log_len = 0;
     c->frames_logged = 0;
     c->log_first = 0; c->log_last = -1;
@@ -1000,14 +1002,28 @@ int edgehip_set_nav_log(edgehip_ctx *c, int len) {
         EH_CHECK(hipMemsetAsync(q, 0, sizeof(edgehip_nav) * (size_t)len * c->plan.nseq, c->stream));
         EH_CHECK(hipStreamSynchronize(c->stream));
         c->nav_log = (edgehip_nav *)q;
+        if (c->imu_enabled) {   // ImuMode > 0: the IMU half of the records in a ring of the same length
+            if (hipMalloc(&q, sizeof(edgehip_nav_imu) * (size_t)len * c->plan.nseq) != hipSuccess) {
+                (void)hipGetLastError();
+                set_error("nav log alloc failed");
+                return EDGEHIP_ERR_MEMORY;
+            }
+            EH_CHECK(hipMemsetAsync(q, 0, sizeof(edgehip_nav_imu) * (size_t)len * c->plan.nseq, c->stream));
+            EH_CHECK(hipStreamSynchronize(c->stream));
+            c->nav_imu_log = (edgehip_nav_imu *)q;
+        }
         c->nav_log_len = len;
     }
     return 0;
 }
 
 // Shared body of edgehip_read_nav_log (host destination) and edgehip_read_nav_log_device (device destination).
-static int read_nav_log_impl(edgehip_ctx *c, int first, int count, edgehip_nav *out, hipMemcpyKind kind) {
+static int read_nav_log_impl(edgehip_ctx *c, int first, int count, void *out_v, hipMemcpyKind kind, bool imu_half = false) {
     EH_ENTER(c);
+    if (imu_half && c && !c->nav_imu_log) { set_error("read_nav_imu_log: needs edgehip_imu_enable and edgehip_set_nav_log"); return EDGEHIP_ERR_STATE; }
+    const size_t rec = imu_half ? sizeof(edgehip_nav_imu) : sizeof(edgehip_nav);
+    char *out = static_cast<char *>(out_v);
+    const char *log = c ? (imu_half ? reinterpret_cast<const char *>(c->nav_imu_log) : reinterpret_cast<const char *>(c->nav_log)) : nullptr;
     if (!c || !out || !c->nav_log || first < 0 || count < 1 || count > c->nav_log_len) { set_error("read_nav_log: bad range or log disabled"); return EDGEHIP_ERR_ARG; }
     // Records of frames that were never enqueued do not exist; `first` counts frames since edgehip_reset / the first frame
     // (edgehip_nav::frame), the counter frames since edgehip_set_nav_log — equal when the log is set before the first frame.
@@ -1032,7 +1048,7 @@ static int read_nav_log_impl(edgehip_ctx *c, int first, int count, edgehip_nav *
     }
     for (int k = 0; k < count; k++) {
         const int slot = (first + k) % c->nav_log_len;
-        EH_CHECK(hipMemcpyAsync(out + (size_t)k * B, c->nav_log + (size_t)slot * B, sizeof(edgehip_nav) * B, kind, c->stream_log));
+        EH_CHECK(hipMemcpyAsync(out + (size_t)k * B * rec, log + (size_t)slot * B * rec, rec * B, kind, c->stream_log));
     }
     EH_CHECK(hipStreamSynchronize(c->stream_log));
     {   // the thread that enqueues frames may have gone on meanwhile: a frame one ring length ahead writes the entries just copied
@@ -1045,7 +1061,10 @@ static int read_nav_log_impl(edgehip_ctx *c, int first, int count, edgehip_nav *
 int edgehip_read_nav_log(edgehip_ctx *c, int first, int count, edgehip_nav *out) { return read_nav_log_impl(c, first, count, out, hipMemcpyDeviceToHost); }
 
 int edgehip_read_nav_log_device(edgehip_ctx *c, int first, int count, void *out_dev) {
-    return read_nav_log_impl(c, first, count, (edgehip_nav *)out_dev, hipMemcpyDeviceToDevice);
+    return read_nav_log_impl(c, first, count, out_dev, hipMemcpyDeviceToDevice);
+}
+int edgehip_read_nav_imu_log(edgehip_ctx *c, int first, int count, edgehip_nav_imu *out) {
+    return read_nav_log_impl(c, first, count, out, hipMemcpyDeviceToHost, true);
 }
 
 int edgehip_stage_a(edgehip_ctx *c, int slot) {

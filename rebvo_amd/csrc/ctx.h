@@ -301,6 +301,7 @@ struct edgehip_ctx {
     } *kl_export = nullptr;
     edgehip_nav *nav_dev;  // [B] per-frame record
     edgehip_nav *nav_log;  // [nav_log_len][B] ring of per-frame records (optional)
+    edgehip_nav_imu *nav_imu_log = nullptr;   // the IMU part of the same records, same ring (allocated when both the log and the IMU branch are on)
     int nav_log_len;
     // The log is read by a thread of its own while another enqueues frames (shard.NavMover): the read-out has its own stream,
     // ordered after the frames it covers by ev_log (re-recorded behind every frame on the stream that writes the records);

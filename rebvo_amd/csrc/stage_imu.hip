@@ -309,7 +309,7 @@ __global__ __launch_bounds__(64) void k_imu_filter(SeqDev *seqs, ImuFilterDev *f
 }
 
 __global__ __launch_bounds__(64) void k_imu_record(const ImuFilterDev *__restrict__ filters, const ImuSnap *__restrict__ snaps, edgehip_nav *__restrict__ nav,
-                           edgehip_nav_imu *__restrict__ nav_imu, edgehip_nav *__restrict__ nav_log, int nav_log_len, int nseq) {
+                           edgehip_nav_imu *__restrict__ nav_imu, edgehip_nav *__restrict__ nav_log, edgehip_nav_imu *__restrict__ nav_imu_log, int nav_log_len, int nseq) {
     const int seq = blockIdx.x * blockDim.x + threadIdx.x;
     if (seq >= nseq) return;
     const ImuFilterDev &s = filters[seq];
@@ -353,6 +353,7 @@ __global__ __launch_bounds__(64) void k_imu_record(const ImuFilterDev *__restric
     o.estimation_ok = have_pair ? oi.estimation_ok : 0;
     o.frame = sn.frame; o.minimizer_evals = sn.minimizer_evals;
     if (nav_log_len > 0) nav_log[(size_t)(sn.frame % nav_log_len) * nseq + seq] = o;
+    if (nav_log_len > 0 && nav_imu_log) nav_imu_log[(size_t)(sn.frame % nav_log_len) * nseq + seq] = oi;
 }
 
 // REBVO::Reset() (rebvo_second_t.cpp:609-620): pose and position start over; they are this stream's
@@ -426,7 +427,7 @@ int imu_post_enqueue(edgehip_ctx *c, int slot_new, int have_pair) {
     EH_CHECK(hipEventRecord(c->ev_imu_snap[b], c->stream));
     EH_CHECK(hipStreamWaitEvent(c->stream_imu, c->ev_imu_snap[b], 0));
     hipLaunchKernelGGL(k_imu_record, dim3((B + 63) / 64), dim3(64), 0, c->stream_imu, (const ImuFilterDev *)c->imu_filter, snap_of(c),
-                       c->nav_dev, c->nav_imu_dev, c->nav_log, c->nav_log_len, B);
+                       c->nav_dev, c->nav_imu_dev, c->nav_log, c->nav_imu_log, c->nav_log_len, B);
     EH_LAUNCH_CHECK();
     EH_CHECK(hipEventRecord(c->ev_imu_post[b], c->stream_imu));
     c->imu_post_valid[b] = true;
@@ -475,6 +476,12 @@ int edgehip_imu_enable(edgehip_ctx *c, const edgehip_imu_params *imu) {
         c->stream_imu = st;
         for (int i = 0; i < 2; i++) { c->ev_imu_snap[i] = ev[i]; c->ev_imu_post[i] = ev[2 + i]; c->ev_imu_mid[i] = ev[4 + i]; c->imu_post_valid[i] = false; }
         c->imu_pinned_ok = true;
+    }
+    if (c->nav_log_len > 0 && !c->nav_imu_log) {   // a log set before the branch was switched on: its IMU half (edgehip_read_nav_imu_log)
+        void *q = nullptr;
+        if (hipMalloc(&q, sizeof(edgehip_nav_imu) * (size_t)c->nav_log_len * B) != hipSuccess) { (void)hipGetLastError(); set_error("edgehip_imu_enable: nav log alloc failed"); return EDGEHIP_ERR_MEMORY; }
+        EH_CHECK(hipMemsetAsync(q, 0, sizeof(edgehip_nav_imu) * (size_t)c->nav_log_len * B, c->stream));
+        c->nav_imu_log = (edgehip_nav_imu *)q;
     }
     c->imu_params = *imu;
     c->imu_enabled = true;

@@ -18,6 +18,8 @@
 // --dup I:F: object I submits one more frame in front of its frame F, stamped like frame F-1: the soft-FPS gate drops it (rebvo_first_t.cpp:172-177)
 //   and the object's camera ring runs one entry ahead of the others' from then on (the group then copies its frames separately).
 // --tint I:F: the first byte of object I's frame F is flipped (^ 0x80): a coloured pixel in an otherwise mono frame — that step crosses PCIe as RGB24.
+// --stagger: object i's frame k carries the stamp t0 + dt (k + i) (object i enters the common time line i frames late: with one IMU file
+// for all objects — ImuMode=2 — every object's images then agree with the IMU samples of its own stamps).
 // --snapshot-at F: object 0's TakeSnapshot() is called before its frame F is submitted (Snap0.ppm in the working directory).
 // timed over the frames after the first W of every object (default 0), from the submission of frame W to the moment every
 // object's getNav() shows its last frame.
@@ -61,7 +63,18 @@ struct Sink {
         for (int i = 0; i < 3; i++) dump << " " << p.nav.Pos[i];
         for (int i = 0; i < 3; i++) dump << " " << p.nav.PoseLie[i];
         for (int i = 0; i < 3; i++) dump << " " << p.nav.Vel[i];
-        dump << " " << sr << " " << ss << "\n";
+        dump << " " << sr << " " << ss;
+        // columns 16..48 as dataset_replay writes them: RotLie, RotGiro, g, scale, K, Kp, RKp, then the IMU-branch state (zero with ImuMode = 0), dt
+        for (int i = 0; i < 3; i++) dump << " " << p.nav.RotLie[i];
+        for (int i = 0; i < 3; i++) dump << " " << p.nav.RotGiro[i];
+        for (int i = 0; i < 3; i++) dump << " " << p.nav.g[i];
+        dump << " " << p.nav.scale << " " << p.K << " " << p.Kp << " " << p.RKp;
+        for (int i = 0; i < 3; i++) dump << " " << p.imustate.Vg[i];
+        for (int i = 0; i < 3; i++) dump << " " << p.imustate.Bg[i];
+        for (int i = 0; i < 7; i++) dump << " " << p.imustate.X[i];
+        for (int i = 0; i < 3; i++) dump << " " << p.imustate.b_est[i];
+        for (int i = 0; i < 3; i++) dump << " " << p.imustate.u_est[i];
+        dump << " " << p.dt << "\n";
         return true;
     }
 };
@@ -79,7 +92,7 @@ int main(int argn, char **argv) {
     std::string group, dump_prefix;
     bool want_cb = false;
     int T = 1, W = 0, leave_obj = -1, leave_at = 0, snapshot_at = -1, dup_obj = -1, dup_at = 0, tint_obj = -1, tint_at = 0;
-    bool step_mode = false;
+    bool step_mode = false, stagger = false;
     for (int a = 8; a < argn; a++) {
         const std::string s = argv[a];
         if (s == "--group" && a + 1 < argn) group = argv[++a];
@@ -88,6 +101,7 @@ int main(int argn, char **argv) {
         else if (s == "--threads" && a + 1 < argn) T = atoi(argv[++a]);
         else if (s == "--warmup" && a + 1 < argn) W = atoi(argv[++a]);
         else if (s == "--step-mode") step_mode = true;
+        else if (s == "--stagger") stagger = true;
         else if (s == "--snapshot-at" && a + 1 < argn) snapshot_at = atoi(argv[++a]);
         else if (s == "--tint" && a + 1 < argn) { if (std::sscanf(argv[++a], "%d:%d", &tint_obj, &tint_at) != 2) return 2; }
         else if (s == "--dup" && a + 1 < argn) { if (std::sscanf(argv[++a], "%d:%d", &dup_obj, &dup_at) != 2) return 2; }
@@ -149,7 +163,7 @@ int main(int argn, char **argv) {
                 }
                 if (i == 0 && k == snapshot_at) obj[0]->TakeSnapshot();
                 std::shared_ptr<Image<RGB24Pixel>> ptr;
-                while (!obj[i]->requestCustomCamBuffer(ptr, t0 + dt * k, 0.1))
+                while (!obj[i]->requestCustomCamBuffer(ptr, stagger ? t0 + dt * (k + i) : t0 + dt * k, 0.1))
                     if (!obj[i]->Running()) { bad = true; break; }
                 if (bad) break;
                 (*ptr).copyFrom(reinterpret_cast<const RGB24Pixel *>(pool.data() + fb * tri((long)k + i, pool_frames)));
@@ -165,13 +179,14 @@ int main(int argn, char **argv) {
     for (int t = 0; t < T; t++) thr.emplace_back(producer, t);
     for (auto &t : thr) t.join();
     // every object's record of its last frame
-    const double t_last = t0 + dt * (K - 1);
     const double deadline = now_s() + 30;
-    for (int i = 0; i < N && !bad; i++)
+    for (int i = 0; i < N && !bad; i++) {
+        const double t_last = stagger ? t0 + dt * (K - 1 + i) : t0 + dt * (K - 1);
         while (i != leave_obj && obj[i]->getNav().t < t_last - 1e-9 * (1 + std::fabs(t_last))) {
             if (!obj[i]->Running() || now_s() > deadline) { bad = true; break; }
             std::this_thread::sleep_for(std::chrono::microseconds(50));
         }
+    }
     const double seconds = now_s() - t_start;
     stepping = false;
     stepper.join();

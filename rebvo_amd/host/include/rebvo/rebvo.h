@@ -364,7 +364,10 @@ class REBVO {
     // the custom camera always; a DataSetCam when its config names a BatchGroup (a multi-sequence replay on one device): its images
     // then reach the group through the object's own camera ring, put there by a feeder thread
     bool useGroupEngine() const {
-        return (params.CameraType == 3 || (params.CameraType == 2 && !params.GpuBatchGroup.empty())) && params.ImuMode == 0 && !params.StereoAvaiable;
+        // ImuMode 1 / 2 (round 6): members of a NAMED group run the device-side IMU branch for the whole batch (edgehip_imu_enable /
+        // edgehip_set_imu; the group thread grabs every member's inter-frame IMU data); an object alone keeps the host-side filters
+        return (params.CameraType == 3 || (params.CameraType == 2 && !params.GpuBatchGroup.empty())) && !params.StereoAvaiable &&
+               (params.ImuMode == 0 || !params.GpuBatchGroup.empty());
     }
     std::thread feeder;            // CameraType 2 in a batch group: DataSetCam -> camera ring
     static void FeedThread(REBVO *cf);

@@ -1,4 +1,5 @@
-// batch_group.cpp — one device context shared by N rebvo::REBVO objects (CameraType 3, ImuMode 0, mono), and the pipelined
+// batch_group.cpp — one device context shared by N rebvo::REBVO objects (CameraType 3 or a DataSetCam; ImuMode 0, or — all members
+// alike — 1 / 2 with the IMU branch of SecondThread batched on the device, round 6; mono), and the pipelined
 // frame loop behind them.  The plugin surface stays per object (requestCustomCamBuffer / releaseCustomCamBuffer,
 // setOutputCallback, getNav: include/rebvo/rebvo.h:548-609 of the reference); what FirstThr and SecondThread do per frame
 // (src/rebvo/rebvo_first_t.cpp:87-337, src/rebvo/rebvo_second_t.cpp:43-636) happens once per STEP for every member at once:
@@ -78,6 +79,7 @@ public:
                                    // for its callback land in them without a staging copy
         bool step_granted = false; // frame-by-frame mode: the application's "advance" has been taken for the frame about to be grabbed
         bool leaving = false;      // cf->quit seen: the seat closes once the step in flight (which may carry its last frame) is done
+        IntegratedImuData imu_data;   // ImuMode > 0: the integrated IMU data of the interval that ends with the gathered frame (rebvo_first_t.cpp:294-304)
         bool have_prev = false;    // a completed frame waits (as player 1's next buffer) for its successor before it is delivered
         int slot_prev = -1;        // ring slot of that frame
     };
@@ -85,6 +87,10 @@ public:
     std::string name;
     int cap = 0, device = 0;
     edgehip_params hp;
+    bool imu_mode = false;         // every member has ImuMode 1 or 2: the context runs the device-side IMU branch (edgehip_imu_enable)
+    edgehip_imu_params ip;
+    std::vector<edgehip_imu_integrated> imu_in;   // [cap] what edgehip_set_imu takes for the step being launched
+    std::vector<edgehip_nav_imu> navs_imu;        // [cap] the IMU half of a completed step's records
     edgehip_ctx *hip = nullptr;
     std::vector<Seat> seats;
     int attached = 0;
@@ -144,6 +150,17 @@ bool REBVO::groupAttach() {
     hp.stereo_available = 0;
     const bool named = !params.GpuBatchGroup.empty();
     const int want = named ? params.GpuBatchSize : 1;
+    const bool imu_mode = params.ImuMode > 0;
+    edgehip_imu_params ip;
+    std::memset(&ip, 0, sizeof ip);
+    if (imu_mode) {   // the &IMU keys SecondThread uses (include/rebvo/rebvo.h:172-199 of the reference), as edgehip.h names them
+        ip.giro_meas_std = params.GiroMeasStdDev; ip.giro_bias_std = params.GiroBiasStdDev;
+        ip.init_bias = params.InitBias ? 1 : 0; ip.init_bias_frame_num = params.InitBiasFrameNum;
+        for (int i = 0; i < 3; i++) ip.bias_init_guess[i] = params.BiasInitGuess[i];
+        ip.acel_meas_std = params.AcelMeasStdDev; ip.g_module = params.g_module; ip.g_module_uncer = params.g_module_uncer;
+        ip.g_uncert = params.g_uncert; ip.vbias_std = params.VBiasStdDev;
+        ip.scale_std_mult = params.ScaleStdDevMult; ip.scale_std_max = params.ScaleStdDevMax; ip.scale_std_init = params.ScaleStdDevInit;
+    }
     auto fail = [&](const std::string &msg) {
         last_error = msg;
         std::cout << last_error << "\n";
@@ -164,7 +181,17 @@ bool REBVO::groupAttach() {
         g->hp = hp;
         g->seats.resize(want);
         // ring of 3 frame slots per sequence, `want` sequences.  No CPU fallback: fail loudly.
+        g->imu_mode = imu_mode;
+        g->ip = ip;
+        g->imu_in.resize(want);
+        g->navs_imu.resize(want);
+        for (edgehip_imu_integrated &r : g->imu_in) {   // (a seat nobody sits on: a record that integrates to nothing)
+            std::memset(&r, 0, sizeof r);
+            r.n = 1; r.dt = 1.0 / params.config_fps;
+            r.Rot[0] = r.Rot[4] = r.Rot[8] = 1;
+        }
         int rc = edgehip_create(&hp, want, 3, params.GpuDevice, &g->hip);
+        if (rc == 0 && imu_mode) rc = edgehip_imu_enable(g->hip, &ip);
         if (rc == 0) rc = edgehip_set_nav_log(g->hip, BatchGroup::kNavLog);
         g->frame_bytes = (size_t)params.ImageSize.w * params.ImageSize.h * sizeof(RGB24Pixel);
         void *ringp = nullptr;
@@ -186,6 +213,8 @@ bool REBVO::groupAttach() {
     } else {
         if (g->cap != want || g->device != params.GpuDevice || std::memcmp(&g->hp, &hp, sizeof hp) != 0)
             return fail("REBVO(hip): BatchGroup '" + g->name + "': every member needs the same BatchSize, Device, camera and detector / tracker parameters");
+        if (g->imu_mode != imu_mode || (imu_mode && std::memcmp(&g->ip, &ip, sizeof ip) != 0))
+            return fail("REBVO(hip): BatchGroup '" + g->name + "': every member needs the same ImuMode (0, or 1 / 2) and the same &IMU filter parameters");
     }
     std::unique_lock<std::mutex> lk(g->mut);
     if (g->started && g->attached >= g->cap) {
@@ -386,6 +415,13 @@ bool REBVO::BatchGroup::gather(bool block, bool &any_running, bool &any_leaving)
                 st.cbuf = cb;
                 st.step_granted = false;
                 st.t_frame = cb->timestamp;
+                if (imu_mode) {   // inter-frame IMU data, waiting for the samples to arrive (rebvo_first_t.cpp:294-304)
+                    while (!cf->quit) {
+                        st.imu_data = cf->imu->GrabAndIntegrate(st.t0 + cf->params.TimeDesinc, st.t_frame + cf->params.TimeDesinc);
+                        if (st.imu_data.n > 0) break;
+                        std::this_thread::sleep_for(std::chrono::duration<double>(cf->params.SampleTime));
+                    }
+                }
                 st.ring_idx = -1;
                 st.ring_idx = ringEntryOf(reinterpret_cast<const uint8_t *>(cb->img->Data()));
                 st.mono = grey_ring && st.ring_idx >= 0 && st.mono_of[st.ring_idx] != 0;
@@ -429,7 +465,22 @@ int REBVO::BatchGroup::upload(std::vector<double> &ts, int &slot) {
 // One edgehip_process_frame for the step whose frames upload() sent, and the members' PipeBuffers of it.
 int REBVO::BatchGroup::launch(long step, const std::vector<double> &ts) {
     const double tp0 = detail::now_s();
-    int rc = edgehip_process_frame(hip, ts.data());
+    int rc = 0;
+    if (imu_mode) {   // every member's integrated IMU data of the interval that ends with this step's frame (edgehip_set_imu)
+        for (int i = 0; i < cap; i++) {
+            const Seat &st = seats[i];
+            if (!st.running) continue;
+            const IntegratedImuData &d = st.imu_data;
+            edgehip_imu_integrated &o = imu_in[i];
+            o.n = d.n; o.pad = 0; o.dt = d.dt;
+            std::memcpy(o.Rot, d.Rot.a, sizeof o.Rot);
+            std::memcpy(o.giro, d.giro.v, sizeof o.giro); std::memcpy(o.acel, d.acel.v, sizeof o.acel); std::memcpy(o.comp, d.comp.v, sizeof o.comp);
+            std::memcpy(o.dgiro, d.dgiro.v, sizeof o.dgiro); std::memcpy(o.cacel, d.cacel.v, sizeof o.cacel);
+        }
+        rc = edgehip_set_imu(hip, imu_in.data());
+        if (rc != 0) return rc;
+    }
+    rc = edgehip_process_frame(hip, ts.data());
     if (rc != 0) return rc;
     const double tp1 = detail::now_s();
     tm.process += tp1 - tp0;
@@ -444,6 +495,7 @@ int REBVO::BatchGroup::launch(long step, const std::vector<double> &ts) {
         nb.quit = false;
         nb.dtp0 = 0;
         nb.dtp1 = tp0;   // start of the step; complete() turns it into the step's duration
+        if (imu_mode) nb.imu = st.imu_data;
         nb.imgc_valid = false;
         if (cf->haveCallBack() || cf->saveImg) {
             nb.imgc_valid = true;   // the output thread converts / saves only a frame that was really kept (a request that arrives after the
@@ -523,6 +575,7 @@ int REBVO::BatchGroup::releaseHeld(int slot) {
 int REBVO::BatchGroup::complete(long step, int slot, std::vector<edgehip_nav> &navs) {
     const double tr0 = detail::now_s();
     int rc = edgehip_read_nav_log(hip, (int)step, 1, navs.data());   // waits for this frame, not for the ones enqueued behind it
+    if (rc == 0 && imu_mode) rc = edgehip_read_nav_imu_log(hip, (int)step, 1, navs_imu.data());
     if (rc != 0) return rc;
     const double now = detail::now_s();
     tm.records += now - tr0;
@@ -553,6 +606,11 @@ int REBVO::BatchGroup::complete(long step, int slot, std::vector<edgehip_nav> &n
         nb.ef->kn = n.kn;
         if (!first) detail::fill_nav(n, nb.nav);
         else nb.nav = NavData();
+        if (imu_mode && !first) {   // the IMU branch's hand-over (rebvo_second_t.cpp:550-606): gravity-aligned pose, metric velocity, filter state
+            const edgehip_nav_imu &ni = navs_imu[i];
+            detail::fill_nav_imu(ni, nb);
+            nb.ef->nmatch = ni.klm_num;
+        }
         nb.stereo_match_num = 0;
         nb.dtp1 = now - nb.dtp1;
         if (!first) cf->pushNav(nb.nav);

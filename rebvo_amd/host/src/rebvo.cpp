@@ -152,6 +152,26 @@ void fill_nav(const edgehip_nav &n, NavData &nav) {
         for (int j = 0; j < 3; j++) { nav.Rot(i, j) = n.Rot[i * 3 + j]; nav.Pose(i, j) = n.Pose[i * 3 + j]; }
     }
 }
+void fill_nav_imu(const edgehip_nav_imu &n, PipeBuffer &pb) {
+    NavData &nav = pb.nav;
+    nav.dt = n.dt; nav.scale = n.scale;
+    for (int i = 0; i < 3; i++) {
+        nav.RotLie[i] = n.RotLie[i]; nav.RotGiro[i] = n.RotGiro[i]; nav.Vel[i] = n.Vel[i]; nav.PoseLie[i] = n.PoseLie[i]; nav.Pos[i] = n.Pos[i];
+        nav.g[i] = n.g[i];
+        for (int j = 0; j < 3; j++) { nav.Rot(i, j) = n.Rot[i * 3 + j]; nav.Pose(i, j) = n.Pose[i * 3 + j]; }
+    }
+    pb.dt = n.dt;
+    pb.K = n.K; pb.Kp = n.Kp; pb.RKp = n.RKp;
+    pb.s_rho_p = n.s_rho_q;
+    pb.EstimationOK = n.estimation_ok != 0;   // (the match count, edge_tracker::nmatch, is the caller's to set: it is a friend)
+    IMUState &is = pb.imustate;
+    for (int i = 0; i < 3; i++) {
+        is.Vg[i] = n.Vg[i]; is.Bg[i] = n.Bg[i]; is.dVv[i] = n.dVv[i]; is.dWv[i] = n.dWv[i]; is.Vgv[i] = n.Vgv[i]; is.Vgva[i] = n.Vgva[i];
+        is.Av[i] = n.Av[i]; is.As[i] = n.As[i]; is.b_est[i] = n.b_est[i]; is.u_est[i] = n.u_est[i]; is.g_est[i] = n.g[i];
+    }
+    for (int i = 0; i < 7; i++) is.X[i] = n.X[i];
+    is.init = n.init != 0;
+}
 }  // namespace detail
 using detail::fill_hip_params;
 using detail::fill_nav;
@@ -388,7 +408,7 @@ bool REBVO::Init() {
         return false;
     }
     if (!params.GpuBatchGroup.empty()) {
-        last_error = "REBVO(hip): &GPU BatchGroup needs ImuMode=0 and no stereo pair";
+        last_error = "REBVO(hip): &GPU BatchGroup does not take a stereo pair";
         std::cout << last_error << "\n";
         return false;
     }

@@ -319,3 +319,124 @@ def _batched_branch(tmp_path, B, check):
             assert abs(ni.s_rho_q - o["s_rho_q"][k]) < 1e-9
             filter_frames += int(o["scale"][k] != 1.0)
         assert int(o["estimation_ok"][1:n_run].sum()) >= n_run - 6 and filter_frames >= 4, (s, filter_frames)
+
+
+def test_eight_imu_objects_in_one_batch_group(tmp_path):
+    """ImuMode = 2 behind the plugin surface as ONE batch (round 6: `&GPU BatchGroup` admits ImuMode 1 / 2 members): eight rebvo::REBVO
+    objects, custom cameras, one IMU file; object i enters the common time line i frames late (surface_replay --stagger), so bias
+    start-up, scale filter and map are in a different state in every member at any step.  The group's thread grabs every member's
+    inter-frame IMU data (ImuGrabber::GrabAndIntegrate, src/UtilLib/imugrabber.cpp:178-268), hands the batch to edgehip_set_imu and the
+    device runs SecondThread's ImuMode > 0 branch for all of them (rebvo_second_t.cpp:182-336, 519-544).  Checked: every object's callback
+    rows (a) bit-identical to the same eight sequences run as one ctypes IMU batch fed the same integrated records, and (b) against the
+    reference's own ImuMode > 0 frame order within the bounds of the tests above."""
+    from oracle import oracle
+    exe = os.path.join(ROOT, "rebvo_amd", "lib", "surface_replay")
+    if not oracle.available("ref") or not os.path.exists(exe):
+        pytest.fail("needs oracle/_ref and surface_replay — a broken snapshot: run __graft_entry__.build()")
+    global N
+    B, n_run, N_keep = 8, N, N
+    n_all = n_run + B - 1
+    try:
+        N = n_all
+        frames, t_ns, cam0, imu_csv_ns, se3 = _write_dataset(tmp_path)
+    finally:
+        N = N_keep
+    t0, dt = 10.0, 0.05
+    t = [t0 + dt * k for k in range(n_all)]                      # (the expression surface_replay --stagger evaluates)
+    raw = np.loadtxt(imu_csv_ns, delimiter=",", comments="#")
+    raw[:, 0] = t0 + (raw[:, 0] - T0_NS) * 1e-9
+    imu_csv = tmp_path / "imu_s.csv"
+    with open(imu_csv, "w") as f:
+        for r in raw:
+            f.write(",".join("%.17g" % v for v in r) + "\n")
+    np.stack(frames).tofile(tmp_path / "frames.rgb24")
+    cfg = tmp_path / "cfg"
+    write_global_config(cfg, edgehip.euroc_params(W, H), camera_type=3, gpu=dict(group="imu8", size=B),
+                        imu=dict(mode=2, file=str(imu_csv), se3=str(se3), time_scale=1.0, InitBiasFrameNum=INIT_BIAS_FRAMES))
+    prefix = tmp_path / "run"
+    r = subprocess.run([exe, str(cfg), str(tmp_path / "frames.rgb24"), str(n_all), str(B), str(n_run), repr(t0), repr(dt), "--stagger",
+                        "--dump", str(prefix), "--threads", "3"], capture_output=True, text=True, timeout=600,
+                       env=dict(os.environ, REBVO_GROUP_TIMING="1"))
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
+    js = json.loads(r.stdout.strip().splitlines()[-1])
+    assert js["objects"] == B and js["callbacks"] == B * (n_run - 1), r.stdout[-1500:]
+    assert f"group 'imu8': {n_run} steps" in r.stdout, r.stdout[-1500:]          # ONE context, one launch set per step for the eight
+    dumps = [np.loadtxt(f"{prefix}.{i}.txt", ndmin=2) for i in range(B)]
+
+    # (a) the same eight sequences as one ctypes IMU batch, fed by the host library's own grabber (what the group's thread calls)
+    host = C.CDLL(os.path.join(ROOT, "rebvo_amd", "lib", "librebvohost.so"))
+    host.rebvo_imu_grabber_load.restype = C.c_void_p
+    ghs = [C.c_void_p(host.rebvo_imu_grabber_load(str(imu_csv).encode(), C.c_double(1.0))) for _ in range(B)]   # a grabber reads forward only: one per sequence
+    assert all(g_.value and host.rebvo_imu_grabber_load_se3(g_, str(se3).encode()) == 1 for g_ in ghs)
+
+    def grab(s_, ta, tb):
+        d = edgehip.ImuIntegrated()
+        host.rebvo_imu_grabber_grab(ghs[s_], C.c_double(ta), C.c_double(tb), C.byref(d))
+        assert d.n > 0
+        return d
+    eh = edgehip.EdgeHip(edgehip.euroc_params(W, H), nseq=B, nslots=3)
+    eh.imu_enable(edgehip.euroc_imu_params(init_bias_frame_num=INIT_BIAS_FRAMES))      # the &IMU section write_global_config wrote
+    got, kls = [], []
+    for k in range(n_run):
+        eh.upload_rgb(eh.next_slot(), np.stack([frames[k + s] for s in range(B)]))
+        eh.set_imu([grab(s, t[k + s - 1] if k else 0.0, t[k + s]) for s in range(B)])
+        eh.process_frame(np.array([t[k + s] for s in range(B)]))
+        got.append((eh.read_nav(), eh.read_nav_imu()))
+        if k:
+            kls.append([eh.download_keylines(s, (eh.cur_slot() + 2) % 3, want_mask=False)[0] for s in range(B)])
+    eh.close()
+    arr = lambda v: np.array(v[:])
+    for s in range(B):
+        rows = dumps[s]
+        assert len(rows) == n_run - 1
+        for j in range(n_run - 1):                 # frame j is delivered once frame j + 1 has been tracked
+            row, kl = rows[j], kls[j][s]
+            assert int(row[0]) == j and row[1] == t[j + s] and int(row[2]) == len(kl)
+            assert row[14] == np.cumsum(kl["rho"])[-1] and row[15] == np.cumsum(kl["s_rho"])[-1], (s, j)
+            if j == 0:
+                continue
+            nav, ni = got[j][0][s], got[j][1][s]
+            assert int(row[3]) == ni.klm_num and int(row[4]) == ni.estimation_ok, (s, j)
+            for a, b in ((row[5:8], ni.Pos), (row[8:11], ni.PoseLie), (row[11:14], ni.Vel), (row[16:19], ni.RotLie), (row[19:22], ni.RotGiro),
+                         (row[22:25], ni.g), (row[29:32], ni.Vg), (row[32:35], ni.Bg), (row[35:42], ni.X), (row[42:45], ni.b_est), (row[45:48], ni.u_est)):
+                assert np.array_equal(a, arr(b)), (s, j, a, arr(b))
+            assert np.array_equal(row[25:29], [ni.scale, ni.K, ni.Kp, ni.RKp]) and row[48] == ni.dt, (s, j)
+
+    # (b) members against the reference's ImuMode > 0 branch on their own frames, stamps and (reference-grabbed) IMU data
+    ref = C.CDLL(os.path.join(ROOT, "oracle", "_ref", "libreforacle.so"), mode=C.RTLD_GLOBAL)
+    ref.ref_imu_grabber_load.restype = C.c_void_p
+    for s in (0, 3, 7):
+        g = C.c_void_p(ref.ref_imu_grabber_load(str(imu_csv).encode(), C.c_double(1.0)))
+        assert g.value and ref.ref_imu_grabber_load_se3(g, str(se3).encode()) == 1
+        imu_rows, t_prev = [], 0.0
+        for k in range(n_run):
+            d = oracle.ImuIntegrated()
+            ref.ref_imu_grabber_grab(g, C.c_double(t_prev), C.c_double(t[k + s]), C.byref(d))
+            assert d.n > 0
+            imu_rows.append(d.as_row())
+            t_prev = t[k + s]
+        sub = tmp_path / f"ref{s}"
+        sub.mkdir()
+        o = _run_reference(sub, frames[s:s + n_run], t[s:s + n_run], imu_rows, {"init_bias_frame_num": INIT_BIAS_FRAMES})
+        # the bounds of _batched_branch (the device-side filters: gravity components against the vector's size, the visual bias at 1e-4)
+        close = lambda a, b, rtol, atol: np.allclose(a, b, rtol=rtol, atol=atol)
+        filter_frames = 0
+        for k in range(1, n_run - 1):
+            row = dumps[s][k]
+            assert int(row[0]) == k and int(row[2]) == int(o["klprev_n"][k + 1])
+            assert int(row[4]) == int(o["estimation_ok"][k]) and int(row[3]) == int(o["klm_num"][k]), (s, k)
+            assert abs(row[48] - o["dt"][k]) < 1e-12
+            assert close(row[29:32], o["Vg"][k], 1e-6, 1e-9) and close(row[32:35], o["Bg"][k], 1e-6, 1e-10), (s, k)
+            assert close(row[16:19], o["RotLie"][k], 1e-6, 1e-8) and close(row[19:22], o["RotGiro"][k], 1e-6, 1e-7), (s, k)
+            assert close(row[11:14], o["Vel"][k], 1e-5, 1e-7), (s, k)
+            assert close(row[25:29], [o["scale"][k], o["K"][k], o["Kp"][k], o["RKp"][k]], 1e-5, 1e-12), (s, k)
+            Xg, Xr = row[35:42], np.array(o["X"][k])
+            assert abs(Xg[0] - Xr[0]) <= 1e-5 * abs(Xr[0]) + 1e-9, (s, k, Xg, Xr)
+            assert np.allclose(Xg[1:4], Xr[1:4], rtol=0, atol=1e-7 * 9.8) and np.allclose(Xg[4:7], Xr[4:7], rtol=1e-4, atol=1e-8), (s, k, Xg, Xr)
+            assert np.allclose(row[22:25], o["g"][k], rtol=0, atol=1e-7 * 9.8) and close(row[45:48], o["u_est"][k], 1e-5, 1e-7), (s, k)
+            assert close(row[5:8], o["Pos"][k], 1e-5, 1e-7) and close(row[8:11], o["PoseLie"][k], 1e-5, 1e-7), (s, k)
+            assert close(row[42:45], o["b_est"][k], 1e-4, 1e-9), (s, k)
+            sr = o["klprev_rho_sum"][k + 1]
+            assert abs(row[14] - sr) <= 1e-6 * abs(sr) + 1e-9
+            filter_frames += int(o["scale"][k] != 1.0)
+        assert int(o["estimation_ok"][1:n_run - 1].sum()) >= n_run - 6 and filter_frames >= 4, (s, filter_frames)
