@@ -580,6 +580,28 @@ def timed_replay(rp, K, Wm, profile=False):
     return time.perf_counter() - t0, breakdown
 
 
+def _write_surface_imu_csv(path, pool, n_intervals, t0, dt, rate_hz=200.0):
+    """IMU samples (EuRoC csv: t, gyro xyz, accel xyz; seconds) for a camera that walks the `pool` rendered frames back and forth
+    (frame of time index m = tri(m, pool)): the body rate of interval m-1 -> m from the known rotation between the two frames, a
+    constant gyro bias on top, gravity in the camera frame of the frame the interval ends at (as bench.py --imu synthesises its
+    integrated records)."""
+    from rebvo_amd import synth
+    tw = synth.smooth_trajectory(pool, 13)
+    poses = [R for _, R, _ in synth.billboard_sequence(8, 8, pool, seed=11)]
+    bias = np.array([0.004, -0.002, 0.003])
+    with open(path, "w") as f:
+        f.write("#timestamp [s],w_x,w_y,w_z,a_x,a_y,a_z\n")
+        ts, step = t0 - 12.0 / rate_hz, 1.0 / rate_hz
+        while ts < t0 + dt * n_intervals:
+            m = max(int(np.floor((ts - t0) / dt)) + 1, 1)          # the interval (m-1, m] this sample lies in
+            a, b = tri(m - 1, pool), tri(m, pool)
+            rot = tw[a, 3:] if b > a else (-tw[b, 3:] if b < a else np.zeros(3))
+            gyro = -rot / dt + bias
+            acc = -(poses[b] @ np.array([0.0, 9.8, 0.0]))
+            f.write("%.9f,%.17g,%.17g,%.17g,%.17g,%.17g,%.17g\n" % (ts, *gyro, *acc))
+            ts += step
+
+
 def host_surface(params, frames, w, h):
     """Frames per second THROUGH the plugin surface (requestCustomCamBuffer -> copyFrom -> releaseCustomCamBuffer, results
     through getNav; include/rebvo/rebvo.h:548-609 of the reference): rebvo_amd/lib/surface_replay drives 1, 8 and 64
@@ -589,7 +611,9 @@ def host_surface(params, frames, w, h):
     one copyFrom each, up to 16 producer threads); the synthetic frames are mono (R = G = B), so with &GPU MonoUpload at its default
     the group sends their 8-bit planes (0.36 MB; `objects_64_rgb24_fps` is the same run with MonoUpload = 0: 1.08 MB per frame).  No callback is registered
     for the three headline numbers (KeyLines stay in HBM); `objects_8_with_callbacks_fps` adds one per object (AoS KeyLines back
-    to the host for every frame).  Run lengths: 600 / 400 / 240 / 150 frames per object, the first 60 / 50 / 40 / 20 untimed — the
+    to the host for every frame; two steps in flight since round 6: edgehip_export_keylines), `objects_8_imu_fps` is eight ImuMode = 2
+    members in one group (the device-side IMU branch behind the surface), `objects_256_fps` / `objects_1024_fps` the same leg with 256 /
+    1024 cameras and 16 producer threads (`detail` carries where the producers' time goes).  Run lengths: 600 / 400 / 240 / 300 frames per object, the first 60 / 50 / 40 / 40 untimed — the
     application runs up to three frames ahead of the tracker (the camera ring) and the last frames drain, which weighed 15-30 % in
     the 36-frame runs of the first version of this leg."""
     import subprocess
@@ -603,17 +627,31 @@ def host_surface(params, frames, w, h):
         cfg, raw = os.path.join(td, "cfg"), os.path.join(td, "frames.rgb24")
         config.write_global_config(cfg, params)
         np.stack(frames).tofile(raw)
+        cfg_mono = cfg
         for name, n, k, wm, extra in (("single_camera_fps", 1, 600, 60, []), ("objects_8_fps", 8, 400, 50, ["--group", "g8"]),
                                       ("objects_64_fps", 64, 240, 40, ["--group", "g64"]),
-                                      ("objects_8_with_callbacks_fps", 8, 150, 20, ["--group", "g8cb", "--callback"]),
-                                      ("objects_64_rgb24_fps", 64, 240, 40, ["--group", "g64c", "--rgb24"])):
+                                      ("objects_8_with_callbacks_fps", 8, 300, 40, ["--group", "g8cb", "--callback"]),
+                                      ("single_camera_with_callback_fps", 1, 600, 60, ["--callback"]),
+                                      ("objects_64_rgb24_fps", 64, 240, 40, ["--group", "g64c", "--rgb24"]),
+                                      ("objects_8_imu_fps", 8, 300, 40, ["--group", "g8imu", "--imu"]),
+                                      ("objects_256_fps", 256, 120, 30, ["--group", "g256"]),
+                                      ("objects_1024_fps", 1024, 60, 15, ["--group", "g1024"])):
             try:
+                cfg = cfg_mono
                 if "--rgb24" in extra:
                     cfg = os.path.join(td, "cfg_rgb24")
                     config.write_global_config(cfg, params, gpu=dict(mono=0))
                     extra = [e for e in extra if e != "--rgb24"]
+                if "--imu" in extra:
+                    # ImuMode = 2 members (what GlobalConfig_EuRoC ships with) in one group: one IMU file on the common time line, object i
+                    # enters it i frames late (--stagger), the gyro / accelerometer samples synthesised from the known camera motion
+                    cfg = os.path.join(td, "cfg_imu")
+                    imu_csv = os.path.join(td, "imu.csv")
+                    _write_surface_imu_csv(imu_csv, len(frames), k + n + 2, 1.0, FRAME_DT)
+                    config.write_global_config(cfg, params, imu=dict(mode=2, file=imu_csv, time_scale=1.0, InitBiasFrameNum=3))
+                    extra = [e for e in extra if e != "--imu"] + ["--stagger"]
                 r = subprocess.run([exe, cfg, raw, str(len(frames)), str(n), str(k), "1", str(FRAME_DT), "--warmup", str(wm),
-                                    "--threads", str(min(16, n))] + extra, capture_output=True, text=True, timeout=90)
+                                    "--threads", str(min(16, n))] + extra, capture_output=True, text=True, timeout=120)
                 js = json.loads(r.stdout.strip().splitlines()[-1]) if r.returncode == 0 else None
                 if js is None:
                     raise RuntimeError(f"rc {r.returncode}: {(r.stdout + r.stderr)[-200:]}")

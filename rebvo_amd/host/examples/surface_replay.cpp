@@ -23,6 +23,7 @@
 // --snapshot-at F: object 0's TakeSnapshot() is called before its frame F is submitted (Snap0.ppm in the working directory).
 // timed over the frames after the first W of every object (default 0), from the submission of frame W to the moment every
 // object's getNav() shows its last frame.
+#include <array>
 #include <atomic>
 #include <chrono>
 #include <cmath>
@@ -142,6 +143,9 @@ int main(int argn, char **argv) {
     std::atomic<int> at_warm{0};
     double t_start = 0;
     std::atomic<bool> go{false};
+    // where the application's threads spend a frame: waiting for a free camera buffer, writing the frame (copyFrom), handing it over
+    // (releaseCustomCamBuffer: the library's mono test + 8-bit plane).  Summed over the timed frames of all threads.
+    std::vector<std::array<double, 3>> ptime(T, std::array<double, 3>{0, 0, 0});
     auto producer = [&](int tid) {
         for (int k = 0; k < K && !bad; k++) {
             if (k == W) {   // all producers line up behind the warm-up frames: the clock starts when the first timed frame is submitted
@@ -163,12 +167,16 @@ int main(int argn, char **argv) {
                 }
                 if (i == 0 && k == snapshot_at) obj[0]->TakeSnapshot();
                 std::shared_ptr<Image<RGB24Pixel>> ptr;
+                const double tq0 = now_s();
                 while (!obj[i]->requestCustomCamBuffer(ptr, stagger ? t0 + dt * (k + i) : t0 + dt * k, 0.1))
                     if (!obj[i]->Running()) { bad = true; break; }
                 if (bad) break;
+                const double tq1 = now_s();
                 (*ptr).copyFrom(reinterpret_cast<const RGB24Pixel *>(pool.data() + fb * tri((long)k + i, pool_frames)));
                 if (i == tint_obj && k == tint_at) *reinterpret_cast<uint8_t *>((*ptr).Data()) ^= 0x80;
+                const double tq2 = now_s();
                 obj[i]->releaseCustomCamBuffer();
+                if (k >= W) { const double tq3 = now_s(); ptime[tid][0] += tq1 - tq0; ptime[tid][1] += tq2 - tq1; ptime[tid][2] += tq3 - tq2; }
             }
         }
     };
@@ -199,8 +207,12 @@ int main(int argn, char **argv) {
     for (int i = 0; i < N; i++)
         std::cout << "object " << i << " final Pos = " << std::setprecision(17) << navs[i].Pos[0] << " " << navs[i].Pos[1] << " " << navs[i].Pos[2] << "\n";
     const long timed = (long)N * (K - W);
+    double pw = 0, pc = 0, pr = 0;
+    for (auto &a : ptime) { pw += a[0]; pc += a[1]; pr += a[2]; }
     std::printf("{\"objects\": %d, \"frames_per_object\": %d, \"timed_frames\": %ld, \"seconds\": %.6f, \"fps\": %.1f, \"callbacks\": %d, "
-                "\"group\": %s, \"producer_threads\": %d, \"ms_per_step\": %.4f}\n",
-                N, K, timed, seconds, timed / seconds, calls, group.empty() ? "null" : ("\"" + group + "\"").c_str(), T, seconds / (K - W) * 1e3);
+                "\"group\": %s, \"producer_threads\": %d, \"ms_per_step\": %.4f, \"producer_us_per_frame\": {\"wait_for_buffer\": %.1f, \"copyFrom\": %.1f, "
+                "\"releaseCustomCamBuffer\": %.1f}, \"producer_busy_share\": %.3f}\n",
+                N, K, timed, seconds, timed / seconds, calls, group.empty() ? "null" : ("\"" + group + "\"").c_str(), T, seconds / (K - W) * 1e3,
+                pw / timed * 1e6, pc / timed * 1e6, pr / timed * 1e6, (pc + pr) / (seconds * T));
     return 0;
 }

@@ -193,10 +193,15 @@ class edge_tracker {
     int kn = 0;
     int nmatch = 0;
     float reTunedThresh = 0;
+    int kl_cap = 0;
     friend class REBVO;
 
 public:
     edge_tracker(const cam_model &cam, int kl_num_max) : cam_mod(cam), kl(kl_num_max) {}
+    // (mirror only) an object on the group engine gets its 2.7 MB KeyLine array when somebody wants KeyLines — the first output
+    // callback — not at construction: a thousand cameras without callbacks are a thousand objects without 8 x 5 MB of host views each
+    edge_tracker(const cam_model &cam, int kl_num_max, bool lazy) : cam_mod(cam), kl(lazy ? 0 : kl_num_max), kl_cap(kl_num_max) {}
+    void ensureKeyLines() { if (kl.size() < (size_t)kl_cap) kl.resize((size_t)kl_cap); }
     cam_model &GetCam() { return cam_mod; }
     int KNum() const { return kn; }
     int NumMatches() const { return nmatch; }
@@ -409,6 +414,9 @@ public:
     // the next delivered frame's image is written as Snap<n>.ppm into the working directory (rebvo.h:459, rebvo_third_t.cpp:335-343);
     // with the group engine the image is kept for the output thread only while a callback is registered or a snapshot is pending
     void TakeSnapshot() { saveImg = true; }
+    // (mirror only) the host views of a PipeBuffer that exist only for an output callback / a snapshot — the KeyLine array, the grey
+    // image, the colour image — allocated on first use by an object on the group engine (batch_group.cpp)
+    void ensureHostViews(PipeBuffer &pb, bool keylines);
     void Reset() { system_reset = true; }
     bool Running() { return !quit; }
     void startKeyFrames() {}

@@ -80,6 +80,8 @@ public:
         bool step_granted = false; // frame-by-frame mode: the application's "advance" has been taken for the frame about to be grabbed
         bool leaving = false;      // cf->quit seen: the seat closes once the step in flight (which may carry its last frame) is done
         IntegratedImuData imu_data;   // ImuMode > 0: the integrated IMU data of the interval that ends with the gathered frame (rebvo_first_t.cpp:294-304)
+        bool out_inline = false;   // nobody listens to this member (no callback, no log file, no snapshot pending): it has no output thread,
+                                   // the group's thread passes its frames through the third player's position itself
         bool have_prev = false;    // a completed frame waits (as player 1's next buffer) for its successor before it is delivered
         int slot_prev = -1;        // ring slot of that frame
     };
@@ -190,7 +192,10 @@ bool REBVO::groupAttach() {
             r.n = 1; r.dt = 1.0 / params.config_fps;
             r.Rot[0] = r.Rot[4] = r.Rot[8] = 1;
         }
+        const bool dbg = getenv("REBVO_GROUP_TIMING") && atoi(getenv("REBVO_GROUP_TIMING")) >= 3;
+        const double tc0 = detail::now_s();
         int rc = edgehip_create(&hp, want, 3, params.GpuDevice, &g->hip);
+        if (dbg) std::fprintf(stderr, "REBVO(hip) group '%s': edgehip_create(%d sequences) took %.2f s\n", g->name.c_str(), want, detail::now_s() - tc0);
         if (rc == 0 && imu_mode) rc = edgehip_imu_enable(g->hip, &ip);
         if (rc == 0) rc = edgehip_set_nav_log(g->hip, BatchGroup::kNavLog);
         g->frame_bytes = (size_t)params.ImageSize.w * params.ImageSize.h * sizeof(RGB24Pixel);
@@ -202,6 +207,8 @@ bool REBVO::groupAttach() {
         g->ring_owner = std::make_shared<BatchGroup::RingOwner>();
         g->ring_owner->ring = g->ring;
         g->ring_owner->grey = g->grey_ring;
+        if (dbg) std::fprintf(stderr, "REBVO(hip) group '%s': page-locked rings %s / %s after %.2f s\n", g->name.c_str(), g->ring ? "ok" : "NONE", g->grey_ring ? "ok" : "none",
+                              detail::now_s() - tc0);
         if (rc != 0) {
             const std::string msg = std::string("REBVO(hip): edgehip_create failed: ") + edgehip_last_error();
             g->ring_owner.reset();
@@ -243,7 +250,11 @@ bool REBVO::groupAttach() {
         cam_pinned = true;
     }
     quit = false;
-    st.out_thread = std::thread(ThirdThread, this);
+    // The output thread exists to call the callback, write the log and save snapshots (rebvo_third_t.cpp:174-343).  A member that has
+    // none of these gets no thread (a thousand cameras are not a thousand threads woken per step); the group's thread starts one the
+    // moment a callback or a snapshot request shows up (launch()).
+    st.out_inline = !haveCallBack() && !params.SaveLog && !saveImg && !params.cpuSetAffinity;
+    if (!st.out_inline) st.out_thread = std::thread(ThirdThread, this);
     if (dscam) feeder = std::thread(FeedThread, this);
     g->attached++;
     if (g->attached == g->cap) {   // the group is complete: its tracker thread starts
@@ -351,6 +362,7 @@ void REBVO::groupFrameWritten(customCam::CustomCamPipeBuffer *b) {
 void REBVO::BatchGroup::pinKeyLines(Seat &st, bool pin) {
     REBVO *cf = st.cf;
     for (unsigned j = 0; j < cf->pipe.Size(); j++) {
+        if (pin) cf->pipe[j].ef->ensureKeyLines();
         std::vector<KeyLine> &kl = cf->pipe[j].ef->kl;
         if (kl.empty()) continue;
         if (pin) (void)edgehip_register_host(kl.data(), kl.size() * sizeof(KeyLine));
@@ -388,7 +400,10 @@ void REBVO::BatchGroup::closeSeat(Seat &st) {
 // the end, as in the reference, where CleanUp() joins a thread that is never interrupted inside a frame — and closes the seat.
 bool REBVO::BatchGroup::gather(bool block, bool &any_running, bool &any_leaving) {
     while (true) {
-        bool all = true;
+        bool all = true, waited = false;   // a blocking pass waits (1 ms at most) on the FIRST member whose frame is missing and only looks at the
+                                           // others: a pass never takes longer than that, however many members there are (the quit flags
+                                           // are read at the head of every pass — a thousand 1 ms waits in a row made CleanUp() of a
+                                           // 1024-member group take a second per member)
         any_running = false;
         any_leaving = false;
         for (Seat &st : seats) {
@@ -400,7 +415,7 @@ bool REBVO::BatchGroup::gather(bool block, bool &any_running, bool &any_leaving)
             if (!st.cbuf && cf->frame_by_frame && !st.step_granted) {   // frame-by-frame mode (rebvo_first_t.cpp:154-159): no new frame until the application says so
                 if (!cf->frame_by_frame_advance) {
                     all = false;
-                    if (block) std::this_thread::sleep_for(std::chrono::milliseconds(1));
+                    if (block && !waited) { std::this_thread::sleep_for(std::chrono::milliseconds(1)); waited = true; }
                     continue;
                 }
                 cf->frame_by_frame_advance = false;
@@ -408,8 +423,8 @@ bool REBVO::BatchGroup::gather(bool block, bool &any_running, bool &any_leaving)
                 std::cout << "Advancing frame...\n";
             }
             while (!st.cbuf) {
-                customCam::CustomCamPipeBuffer *cb = cf->cam_pipe.RequestBufferTimeoutable(1, block ? 0.001 : 0.0);
-                if (!cb) break;
+                customCam::CustomCamPipeBuffer *cb = cf->cam_pipe.RequestBufferTimeoutable(1, block && !waited ? 0.001 : 0.0);
+                if (!cb) { waited = true; break; }
                 st.p_num++;
                 if (cb->timestamp - st.t0 < min_frame_dt) { cf->cam_pipe.ReleaseBuffer(1); continue; }   // soft-FPS drop, :172-177
                 st.cbuf = cb;
@@ -497,7 +512,13 @@ int REBVO::BatchGroup::launch(long step, const std::vector<double> &ts) {
         nb.dtp1 = tp0;   // start of the step; complete() turns it into the step's duration
         if (imu_mode) nb.imu = st.imu_data;
         nb.imgc_valid = false;
-        if (cf->haveCallBack() || cf->saveImg) {
+        const bool listened = cf->haveCallBack() || cf->saveImg;
+        if (st.out_inline && listened) {   // somebody listens now: from here on this member has its output thread
+            st.out_inline = false;
+            st.out_thread = std::thread(ThirdThread, cf);
+        }
+        if (listened) {
+            cf->ensureHostViews(nb, false);
             nb.imgc_valid = true;   // the output thread converts / saves only a frame that was really kept (a request that arrives after the
                                     // launch is honoured by the first later frame launched with it pending)
             if (st.ring_idx >= 0 && st.side_ok[st.ring_idx]) {   // the application's thread made the copy: take it
@@ -670,8 +691,15 @@ int REBVO::BatchGroup::complete(long step, int slot, std::vector<edgehip_nav> &n
             rc = exportFetch(nx, kn, dst);
         }
     }
-    for (int i = 0; i < cap; i++)   // (PipeBuffer::img, the grey image a callback may look at, is formed by the member's output thread)
-        if (deliver[i]) seats[i].cf->pipe.ReleaseBuffer(1);
+    for (int i = 0; i < cap; i++) {   // (PipeBuffer::img, the grey image a callback may look at, is formed by the member's output thread)
+        if (!deliver[i]) continue;
+        REBVO *cf = seats[i].cf;
+        cf->pipe.ReleaseBuffer(1);
+        if (seats[i].out_inline) {    // nobody listens: the frame passes the third player's position right here
+            (void)cf->pipe.RequestBuffer(2);
+            cf->pipe.ReleaseBuffer(2);
+        }
+    }
     return rc;
 }
 
@@ -753,6 +781,9 @@ void REBVO::BatchGroup::threadMain() {
         while (rc == 0 && pending.size() > depth) rc = complete_oldest();
         tl[4] = detail::now_s();
         if (tlog.size() < 64) tlog.push_back(tl);
+        if (getenv("REBVO_GROUP_TIMING") && atoi(getenv("REBVO_GROUP_TIMING")) >= 3)
+            std::fprintf(stderr, "REBVO(hip) group '%s': step %ld launched %.3f ms, look-ahead %.3f, copy done %.3f, completed %.3f (since launch start)\n", name.c_str(), step - 1,
+                         (tl[1] - tl[0]) * 1e3, (tl[2] - tl[0]) * 1e3, (tl[3] - tl[0]) * 1e3, (tl[4] - tl[0]) * 1e3);
     }
     while (rc == 0 && !pending.empty()) rc = complete_oldest();
     if (rc != 0) {

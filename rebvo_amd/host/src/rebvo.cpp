@@ -352,10 +352,11 @@ void REBVO::construct() {
         for (unsigned i = 0; i < cam_pipe_stereo.Size(); i++)
             cam_pipe_stereo[i].img = std::make_shared<Image<RGB24Pixel>>(params.ImageSize);
     }
+    const bool lazy_views = useGroupEngine();        // (what only a callback or a snapshot looks at is allocated when one appears)
     for (PipeBuffer &pbuf : pipe) {                  // rebvo.cpp:297-312 (host views only; the rest lives in HBM)
-        pbuf.ef = new edge_tracker(cam, params.MaxPoints > 0 ? params.MaxPoints : 1);
-        pbuf.img = new Image<float>(params.ImageSize);
-        pbuf.imgc = new Image<RGB24Pixel>(params.ImageSize);
+        pbuf.ef = new edge_tracker(cam, params.MaxPoints > 0 ? params.MaxPoints : 1, lazy_views);
+        pbuf.img = lazy_views ? nullptr : new Image<float>(params.ImageSize);
+        pbuf.imgc = lazy_views ? nullptr : new Image<RGB24Pixel>(params.ImageSize);
         pbuf.imgc_pair = params.StereoAvaiable ? new Image<RGB24Pixel>(params.ImageSize) : nullptr;
         pbuf.ss = nullptr;
         pbuf.gt = nullptr;
@@ -443,6 +444,12 @@ bool REBVO::Init() {
     quit = false;
     Thr0 = std::thread(TrackThread, this);
     return true;
+}
+
+void REBVO::ensureHostViews(PipeBuffer &pb, bool keylines) {
+    if (!pb.img) pb.img = new Image<float>(params.ImageSize);
+    if (!pb.imgc) pb.imgc = new Image<RGB24Pixel>(params.ImageSize);
+    if (keylines) pb.ef->ensureKeyLines();
 }
 
 bool REBVO::CleanUp() {
