@@ -650,12 +650,14 @@ def host_surface(params, frames, w, h):
                     _write_surface_imu_csv(imu_csv, len(frames), k + n + 2, 1.0, FRAME_DT)
                     config.write_global_config(cfg, params, imu=dict(mode=2, file=imu_csv, time_scale=1.0, InitBiasFrameNum=3))
                     extra = [e for e in extra if e != "--imu"] + ["--stagger"]
+                t_leg = time.perf_counter()
                 r = subprocess.run([exe, cfg, raw, str(len(frames)), str(n), str(k), "1", str(FRAME_DT), "--warmup", str(wm),
                                     "--threads", str(min(16, n))] + extra, capture_output=True, text=True, timeout=120)
                 js = json.loads(r.stdout.strip().splitlines()[-1]) if r.returncode == 0 else None
                 if js is None:
                     raise RuntimeError(f"rc {r.returncode}: {(r.stdout + r.stderr)[-200:]}")
                 out[name] = js["fps"]
+                js["process_wall_s"] = round(time.perf_counter() - t_leg, 2)   # start-up, the run, shutdown of the whole process
                 out.setdefault("detail", {})[name] = js
             except Exception as e:
                 out[name] = None

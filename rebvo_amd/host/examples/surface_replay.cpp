@@ -126,6 +126,8 @@ int main(int argn, char **argv) {
         if ((size_t)in.gcount() != pool.size()) { std::cout << "short read of " << argv[2] << "\n"; return 5; }
     }
 
+    const double t_phase0 = now_s();
+    auto phase = [&](const char *what) { if (getenv("SURFACE_REPLAY_PHASES")) std::fprintf(stderr, "surface_replay: %-28s at %8.3f s\n", what, now_s() - t_phase0); };
     std::vector<std::unique_ptr<REBVO>> obj;
     std::vector<std::unique_ptr<Sink>> sink;
     for (int i = 0; i < N; i++) {
@@ -135,8 +137,10 @@ int main(int argn, char **argv) {
         if (!dump_prefix.empty()) sink[i]->dump.open(dump_prefix + "." + std::to_string(i) + ".txt");
         if (want_cb) obj[i]->setOutputCallback(&Sink::cb, sink[i].get());
     }
+    phase("objects constructed");
     for (int i = 0; i < N; i++)
         if (!obj[i]->Init()) { std::cout << "object " << i << ": Init failed: " << obj[i]->lastError() << "\n"; return 4; }
+    phase("Init() of every object done");
 
     if (step_mode && !obj[0]->toggleFrameByFrame()) { std::cout << "toggleFrameByFrame did not switch on\n"; return 7; }
     std::atomic<bool> bad{false};
@@ -186,6 +190,7 @@ int main(int argn, char **argv) {
     std::vector<std::thread> thr;
     for (int t = 0; t < T; t++) thr.emplace_back(producer, t);
     for (auto &t : thr) t.join();
+    phase("producers done");
     // every object's record of its last frame
     const double deadline = now_s() + 30;
     for (int i = 0; i < N && !bad; i++) {
@@ -198,9 +203,11 @@ int main(int argn, char **argv) {
     const double seconds = now_s() - t_start;
     stepping = false;
     stepper.join();
+    phase("last records seen");
     std::vector<NavData> navs;
     for (int i = 0; i < N; i++) navs.push_back(obj[i]->getNav());
     for (int i = 0; i < N; i++) obj[i]->CleanUp();
+    phase("CleanUp() of every object done");
     int calls = 0;
     for (int i = 0; i < N; i++) calls += sink[i]->calls;
     if (bad) { std::cout << "an object stopped before its last frame\n"; return 6; }

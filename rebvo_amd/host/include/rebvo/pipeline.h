@@ -59,9 +59,11 @@ public:
     OPipe *RequestBufferTimeoutable(int PlayerId, double timeout_secs = 0) {
         std::unique_lock<std::mutex> lk(mut);
         const unsigned next = (PlayerPos[PlayerId] + 1) % CircSize;
-        if (!cv.wait_for(lk, std::chrono::duration<double>(timeout_secs > 0 ? timeout_secs : 0.0),
-                         [&] { return ready(PlayerId, next); }))
-            return nullptr;
+        if (timeout_secs > 0) {
+            if (!cv.wait_for(lk, std::chrono::duration<double>(timeout_secs), [&] { return ready(PlayerId, next); })) return nullptr;
+        } else if (!ready(PlayerId, next)) {   // a single try is a look at the ring, not a timed wait that has already expired (tens of
+            return nullptr;                    // microseconds in the C library: a batch group polls a thousand rings per pass)
+        }
         PlayerPos[PlayerId] = next;
         return &CircBuff[next];
     }

@@ -444,6 +444,7 @@ public:
     bool requestCustomCamBuffer(std::shared_ptr<Image<RGB24Pixel>> &ptr, double time_stamp, double timeout_secs = 0) {
         customCam::CustomCamPipeBuffer *ccpb = cam_pipe.RequestBufferTimeoutable(0, timeout_secs);
         if (ccpb == nullptr) return false;
+        if (!(*ccpb).img) (*ccpb).img = std::make_shared<Image<RGB24Pixel>>(params.ImageSize);   // (an object on the group engine outside Init()..CleanUp(): no ring yet)
         ptr = (*ccpb).img;
         (*ccpb).timestamp = time_stamp;
         cam_cur = ccpb;

@@ -248,6 +248,9 @@ bool REBVO::groupAttach() {
             cam_pipe[j].img = std::shared_ptr<Image<RGB24Pixel>>(new Image<RGB24Pixel>(reinterpret_cast<RGB24Pixel *>(g->ringImage((int)j, seat)), params.ImageSize),
                                                                  [owner](Image<RGB24Pixel> *p) { delete p; });   // the view keeps the ring alive
         cam_pinned = true;
+    } else {   // no page-locked ring (the allocation failed): heap images, staged uploads
+        for (unsigned j = 0; j < cam_pipe.Size(); j++)
+            if (!cam_pipe[j].img) cam_pipe[j].img = std::make_shared<Image<RGB24Pixel>>(params.ImageSize);
     }
     quit = false;
     // The output thread exists to call the callback, write the log and save snapshots (rebvo_third_t.cpp:174-343).  A member that has
@@ -326,8 +329,8 @@ void REBVO::groupDetach() {
     }
     group = nullptr;
     group_seat = -1;
-    if (cam_pinned) {   // the ring goes with the group: this object's camera buffers are heap images again
-        for (unsigned j = 0; j < cam_pipe.Size(); j++) cam_pipe[j].img = std::make_shared<Image<RGB24Pixel>>(params.ImageSize);
+    if (cam_pinned) {   // the ring goes with the group (with the last view of it): this object has no camera buffers until it is Init()ed again
+        for (unsigned j = 0; j < cam_pipe.Size(); j++) cam_pipe[j].img.reset();
         cam_pinned = false;
     }
     if (last) {   // the last member out stops the thread and frees the context

@@ -344,7 +344,9 @@ void REBVO::construct() {
     }
     // rebvo.cpp:284-285.  (An object that runs on the group engine gets page-locked views of its group's ring in their place when
     // it attaches: Init(), batch_group.cpp.)
-    for (unsigned i = 0; i < cam_pipe.Size(); i++) cam_pipe[i].img = std::make_shared<Image<RGB24Pixel>>(params.ImageSize);
+    // (... so it gets no heap images here: 4 x 1 MB per object that would be thrown away at Init() — a thousand cameras, 4 GB of page faults)
+    if (!useGroupEngine())
+        for (unsigned i = 0; i < cam_pipe.Size(); i++) cam_pipe[i].img = std::make_shared<Image<RGB24Pixel>>(params.ImageSize);
     cam_stereo = cam;
     if (params.StereoAvaiable) {
         cam_stereo = cam_model({params.pp_x_stereo, params.pp_y_stereo}, {params.z_f_x_stereo, params.z_f_y_stereo}, params.kc_stereo,

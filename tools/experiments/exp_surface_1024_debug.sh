@@ -13,7 +13,7 @@ np.stack(frames).tofile("/tmp/f8.rgb24")
 config.write_global_config("/tmp/cfg_s", p)
 PY
 date +%s.%N
-REBVO_GROUP_TIMING=3 timeout $LIM rebvo_amd/lib/surface_replay /tmp/cfg_s /tmp/f8.rgb24 8 $N $K 1 0.05 --warmup 10 --threads $T --group big > /tmp/sr.out 2> /tmp/sr.err
+SURFACE_REPLAY_PHASES=1 REBVO_GROUP_TIMING=1 timeout $LIM rebvo_amd/lib/surface_replay /tmp/cfg_s /tmp/f8.rgb24 8 $N $K 1 0.05 --warmup 10 --threads $T --group big > /tmp/sr.out 2> /tmp/sr.err
 echo "exit $?"; date +%s.%N
 tail -3 /tmp/sr.out | cut -c1-600
 grep -c "step" /tmp/sr.err; head -4 /tmp/sr.err; sed -n '5,12p' /tmp/sr.err; tail -4 /tmp/sr.err
