@@ -139,7 +139,13 @@ def algorithmic_bytes(group, kn, n_px, radius, nseq):
         "A.join_retune": (24 + 3 * 4) * kn + (168 - 24) * kn,
         "B.try_velrot": 84 * kn,
         "B.try_velrot2": (40 + 2 * 44) * kn,
-        "B.build_field": 4 * n_px + 4 * 2 * radius * kn,     # clear + scattered 4-byte atomics (packed field)
+        # What the binned builder (k_field_bin + k_field_raster) has to move: every KeyLine's 32-byte record in and the 12 bytes of
+        # FordwardMatch's arbitration reset out (k_field_bin), one 4-byte bin entry written and read back plus the record gathered
+        # again per (KeyLine, tile) pair — a +-r segment crosses 1 + 2r (|u_x| + |u_y|) / 64 tiles of 64 px, 1 + 2r (4/pi) / 64 on
+        # average over directions — and the 2-byte KeyLine-index plane out.  SURVEY 8(d)'s 8N + 8*2r*kn (a cleared 8-byte field and one
+        # 8-byte store per sample) describes the reference's scatter; in the tiled form the samples never leave LDS, and pricing the
+        # launch on them flattered it 2x: kept as frac_survey_formula.
+        "B.build_field": 2 * n_px + (32 + 12) * kn + (4 + 4 + 32) * kn * (1 + 2 * radius * (4 / np.pi) / 64),
         "B.tvr_prepare": 0,   # per-sequence set-up of the minimisation since P0 is rebuilt in registers by k_try_velrot (latency, no stream)
         "B.lm_step": 0,
         "B.quantile": 8 * kn,
@@ -160,7 +166,7 @@ def algorithmic_bytes(group, kn, n_px, radius, nseq):
 def survey_bytes(group, kn, n_px, radius, nseq):
     """SURVEY.md 8(d)'s own per-unit figure where it differs from what a launch must move (`frac_survey_formula`): 84 B per
     KeyLine and EVALUATION, so 168 B for a two-chain launch; five passes over 32 B for EstimateReScalingOpt."""
-    over = {"B.try_velrot2": 2 * 84 * kn, "C.rescale": 5 * 32 * kn}
+    over = {"B.try_velrot2": 2 * 84 * kn, "C.rescale": 5 * 32 * kn, "B.build_field": 8 * n_px + 8 * 2 * radius * kn}
     return over[group] * nseq if group in over else algorithmic_bytes(group, kn, n_px, radius, nseq)
 
 

@@ -370,12 +370,21 @@ __global__ __launch_bounds__(256) void k_field_raster(const KlSoA *kls, int32_t 
                                                       const int32_t *__restrict__ bins, uint32_t *__restrict__ field,
                                                       uint16_t *__restrict__ field16, size_t f16stride, int f16tx, int keep32,
                                                       int w, int h, size_t fstride, int ftx, int radius, int ntx, int bin_cap) {
-    __shared__ uint32_t s_tile[FT * FT];
+    // Row stride FT + 2 words, not FT (round 6): the 32-bit LDS atomics of a wave are served in two groups of 32 lanes on 32 banks, and
+    // neighbouring lanes rasterise neighbouring KeyLines of one edge at the same t — samples one pixel apart along the edge.  With a
+    // 64-word row a vertical edge puts all 32 lanes of a group on ONE bank (32-way); at 66 words the bank moves by 2 per row, by 1 per
+    // column and by 3 / 1 per diagonal step: at most 2-way for any edge direction (SQ_LDS_BANK_CONFLICT of this kernel: a third of its
+    // LDS cycles before).  65 would make vertical edges free and anti-diagonal ones 32-way.
+#ifndef EDGEHIP_RASTER_PAD
+#define EDGEHIP_RASTER_PAD 2
+#endif
+    constexpr int TS = FT + EDGEHIP_RASTER_PAD;
+    __shared__ uint32_t s_tile[FT * TS];
     const int ntiles = ntx * gridDim.y;
     const int seq = blockIdx.z, tid = threadIdx.x;
     const int tx0 = blockIdx.x * FT, ty0 = blockIdx.y * FT;
     const int tile = blockIdx.y * ntx + blockIdx.x;
-    for (int i = tid; i < FT * FT; i += 256) s_tile[i] = 0xFFFFFFFFu;
+    for (int i = tid; i < FT * TS; i += 256) s_tile[i] = 0xFFFFFFFFu;
     __syncthreads();
     const int cnt = min(bin_cnt[(size_t)seq * kMaxTiles + tile], bin_cap);
     const int32_t *list = bins + ((size_t)seq * ntiles + tile) * bin_cap;
@@ -438,20 +447,35 @@ __global__ __launch_bounds__(256) void k_field_raster(const KlSoA *kls, int32_t 
             // t runs as a float (|t| <= 255: every value and the increment are exact), so the reference's (float)t costs
             // nothing and |t| is an operand modifier of the one conversion back
             const float t1f = (float)t1;
+#ifndef EDGEHIP_RASTER_PK
+#define EDGEHIP_RASTER_PK 0   // 1: x and y of a sample as one packed pair (v_pk_mul_f32 + v_pk_add_f32, each component rounded like the scalar op): two
+                              // instructions fewer per sample on paper, 6 % SLOWER measured (B.build_field 1155 -> 1230 us per 1024 frames, same box,
+                              // profiles/r06_raster_pad_and_packed_ab.txt): the packed forms issue at half rate and want their operands in register pairs
+#endif
+#if EDGEHIP_RASTER_PK
+            typedef float v2f __attribute__((ext_vector_type(2)));
+            const v2f u2 = {r.u_mx, r.u_my}, c2 = {r.c_px, r.c_py};
+#endif
             auto sample = [&](const float tf) __attribute__((always_inline)) {
+#if EDGEHIP_RASTER_PK
+                const v2f t2 = {tf, tf};
+                const v2f f2 = u2 * t2 + c2;             // global_tracker.cpp:78, the same two float expressions (no contraction: -ffp-contract=off)
+                const float fx = f2.x, fy = f2.y;
+#else
                 const float fx = r.u_mx * tf + r.c_px;   // global_tracker.cpp:78, same float expression
                 const float fy = r.u_my * tf + r.c_py;
+#endif
                 // Image::GetIndexRC uses round()
                 const int lx = (decltype(fix_x)::value ? round_half_away_i(fx) : round_ties_up_i(fx)) - tx0;
                 const int ly = (decltype(fix_y)::value ? round_half_away_i(fy) : round_ties_up_i(fy)) - ty0;
                 if ((unsigned)lx >= ex || (unsigned)ly >= ey) return;
                 const uint32_t at = (uint32_t)fabsf(tf);
 #if EDGEHIP_RASTER_ABL == 1      // a plain store instead of the atomic
-                s_tile[ly * FT + lx] = (at << 16) | idk;
+                s_tile[ly * TS + lx] = (at << 16) | idk;
 #elif EDGEHIP_RASTER_ABL == 2    // no LDS access at all
-                acc_abl += (at << 16) | idk | (uint32_t)(ly * FT + lx);
+                acc_abl += (at << 16) | idk | (uint32_t)(ly * TS + lx);
 #else
-                atomicMin(&s_tile[ly * FT + lx], (at << 16) | idk);
+                atomicMin(&s_tile[ly * TS + lx], (at << 16) | idk);
 #endif
             };
 #if EDGEHIP_RASTER_UNROLL == 2
@@ -486,7 +510,7 @@ __global__ __launch_bounds__(256) void k_field_raster(const KlSoA *kls, int32_t 
             const int st = i >> 4, in = i & 15;
             const int lx = ((st % (FT / 4)) << 2) | (in & 3), ly = ((st / (FT / 4)) << 2) | (in >> 2);
             const int x = tx0 + lx, y = ty0 + ly;
-            if (x < w && y < h) out[field_index(x, y, ftx)] = s_tile[ly * FT + lx];
+            if (x < w && y < h) out[field_index(x, y, ftx)] = s_tile[ly * TS + lx];
         }
     }
     // What the tracker gathers: the KeyLine-index plane, ikl + 1 (0 = empty) in 8x4-pixel tiles of 64 B; a thread
@@ -498,7 +522,7 @@ __global__ __launch_bounds__(256) void k_field_raster(const KlSoA *kls, int32_t 
         const int lx = ((st % (FT / 8)) << 3) | ((in & 3) << 1), ly = ((st / (FT / 8)) << 2) | (in >> 2);
         const int x = tx0 + lx, y = ty0 + ly;
         if (x < w && y < h) {
-            const uint32_t v0 = s_tile[ly * FT + lx], v1 = s_tile[ly * FT + lx + 1];
+            const uint32_t v0 = s_tile[ly * TS + lx], v1 = s_tile[ly * TS + lx + 1];
             // low half = 0xFFFF - ikl  ->  ikl + 1 = 0x10000 - low half (mod 2^16); empty (all ones) -> 0
             const uint32_t a0 = v0 == 0xFFFFFFFFu ? 0u : ((0x10000u - (v0 & 0xFFFFu)) & 0xFFFFu);
             const uint32_t a1 = v1 == 0xFFFFFFFFu ? 0u : ((0x10000u - (v1 & 0xFFFFu)) & 0xFFFFu);
