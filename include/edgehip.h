@@ -239,6 +239,14 @@ int edgehip_download_resid(edgehip_ctx *ctx, int which, double *resid);
  * whole Levenberg-Marquardt loop runs on the device (evaluate kernels + a one-wave solve kernel between
  * them, no host round trip).  Reads seq_state.V/W/s_rho_q, writes V, W, P_V, P_W, score, rel_error*. */
 int edgehip_minimizer_rv(edgehip_ctx *ctx, int slot_new, int slot_old);
+/* Which instantiation of the tracker edgehip_minimizer_rv / edgehip_process_frame run: 64 (default) = global_tracker::Minimizer_RV<double>,
+ * what the reference runs on x86 (rebvo_second_t.cpp:346); 32 = Minimizer_RV<float> with TryVelRot<float, ...> (global_tracker.cpp:824), what
+ * the reference runs when it is built with USE_NE10 (rebvo_second_t.cpp:339-343: NEON only does float).  Everything the reference declares
+ * as T (P0, the transformed points, residuals, gradients, Jacobian rows, the 28 sums, JtJ / JtF / h / X) is then computed and rounded in
+ * float; the uncertainty gate, q_rho, the 6x6 solves and the Levenberg-Marquardt scalars stay double, as there.  Results follow the
+ * reference's float instantiation to float accuracy (the 28 float sums are added in another tree than PairWiseVAdd<float>):
+ * tests/test_tracker_f32_gpu.py states the tolerance.  The depth filter, the matcher and the detector are not affected.  ImuMode 0 only. */
+int edgehip_set_tracker_precision(edgehip_ctx *ctx, int bits);
 /* The 6x6 solve between two evaluations, n independent systems (A [n][36] row-major, b [n][6], h [n][6], host pointers):
  * svd_rule = 0: h = TooN::Cholesky<6>(A).backsub(b) (global_tracker.cpp:767-768); svd_rule = 1: h = TooN::SVD<>(A).backsub(b) with
  * its condition_no = 1e9 cut-off (global_tracker.cpp:660-661, 711-712; TooN/SVD.h:37, 179).  Exposed so that the parity tests can

@@ -460,6 +460,12 @@ class Oracle:
         f.restype, f.argtypes = None, [C.c_void_p, C.c_int] + [C.c_double] * 4
         f(self.ctx, slot, ppx, ppy, zfx, zfy)
 
+    def set_tracker_f32(self, on):
+        """Reference oracle only: the tracker's float instantiation, Minimizer_RV<float> (what USE_NE10 builds run)."""
+        f = self.lib.ref_set_tracker_f32
+        f.restype, f.argtypes = None, [C.c_void_p, C.c_int]
+        f(self.ctx, int(on))
+
     def set_stereo_mode(self, on):
         f = self.lib.ref_set_stereo_mode
         f.restype, f.argtypes = None, [C.c_void_p, C.c_int]

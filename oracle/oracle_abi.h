@@ -166,6 +166,8 @@ double ref_minimizer_rv_kf(void *ctx, int slot_kf, int slot_cur, double X[6], do
 
 /* ---- stereo depth (REBVO/StereoAvaiable): reference only ---- */
 void ref_set_slot_cam(void *ctx, int slot, double ppx, double ppy, double zfx, double zfy);   /* pair camera intrinsics */
+void ref_set_tracker_f32(void *ctx, int on);   /* reference oracle only: Minimizer_RV<float> (global_tracker.cpp:824, USE_NE10) instead of <double>,
+                                                  in ref_minimizer_rv and in the whole-frame drivers */
 void ref_set_stereo_mode(void *ctx, int on);   /* the stereo_mode argument ref_directed_matching passes on */
 int ref_directed_matching_stereo(void *ctx, int slot, int slot_pair, const double t[3], const double R[9], double min_thr_mod,
                                  double min_thr_ang, double max_radius, double loc_unc, double q_abs, double q_rel,

@@ -190,6 +190,7 @@ struct Ctx {
     Vector<3> giro_init, g_init;
     Matrix<3, 3> Rgva;
     bool stereo_mode;                 // REBVO/StereoAvaiable as directed_matching sees it
+    bool tracker_f32;                 // Minimizer_RV<float> in place of Minimizer_RV<double>: what USE_NE10 selects (rebvo_second_t.cpp:339-343)
     int ring;                         // slots of the frame ring (a stereo pair slot, if any, sits behind them)
     bool rig;                         // whole-frame stereo (ref_enable_stereo)
     Vector<3> rig_t;
@@ -257,6 +258,7 @@ void *ref_create(const OrcParams *p, int nslots) {
     c->undist = nullptr;
     c->img_dist = nullptr;
     c->stereo_mode = false;
+    c->tracker_f32 = false;
     c->ring = nslots;
     c->rig = false;
     c->pair_rgb = nullptr;
@@ -429,7 +431,16 @@ double ref_minimizer_rv(void *ctx, int slot_new, int slot_old, double V[3], doub
     Vector<3> Vv = v3(V), Wv = v3(W);
     Matrix<3, 3> RV = m3(RVel), RW = m3(RW0);
     Matrix<6, 6, double> W_X = Zeros;
-    double F = c->slots[slot_new].gt->Minimizer_RV<double>(Vv, Wv, RV, RW, *c->slots[slot_old].ef, match_thresh,
+    double F;
+    if (c->tracker_f32) {   // the reference's float instantiation (global_tracker.cpp:824), its own code
+        Matrix<6, 6, float> W_Xf = Zeros;
+        F = c->slots[slot_new].gt->Minimizer_RV<float>(Vv, Wv, RV, RW, *c->slots[slot_old].ef, match_thresh, iter_max, init_type,
+                                                       reweight_distance, *rel_error, *rel_error_score, max_s_rho, match_num_thresh,
+                                                       init_iter, W_Xf);
+        for (int i = 0; i < 6; i++)
+            for (int j = 0; j < 6; j++) W_X(i, j) = W_Xf(i, j);
+    } else
+    F = c->slots[slot_new].gt->Minimizer_RV<double>(Vv, Wv, RV, RW, *c->slots[slot_old].ef, match_thresh,
                                                            iter_max, init_type, reweight_distance, *rel_error,
                                                            *rel_error_score, max_s_rho, match_num_thresh,
                                                            init_iter, W_X);
@@ -521,6 +532,7 @@ void ref_set_slot_cam(void *ctx, int slot, double ppx, double ppy, double zfx, d
     memset(s.gt->field.Data(), 0, sizeof(gt_field_data) * p.w * p.h);
 }
 void ref_set_stereo_mode(void *ctx, int on) { ((Ctx *)ctx)->stereo_mode = on != 0; }
+void ref_set_tracker_f32(void *ctx, int on) { ((Ctx *)ctx)->tracker_f32 = on != 0; }
 int ref_directed_matching_stereo(void *ctx, int slot, int slot_pair, const double t[3], const double R[9], double min_thr_mod,
                                  double min_thr_ang, double max_radius, double loc_unc, double q_abs, double q_rel,
                                  double loc_unc_model) {
@@ -614,6 +626,12 @@ static int frame_bc(Ctx *c, const ARec &rec, double t, OrcNav *nav) {
     double s_rho_q = ob.ef->EstimateQuantile(RHO_MIN, RHO_MAX, p.qcut_quantile, p.qcut_nbins);  // :172
     nb.gt->build_field(*nb.ef, p.search_range, nb.ef->getThresh());                            // :177
     TooN::Matrix<6, 6, double> W_X;
+    if (c->tracker_f32) {
+        TooN::Matrix<6, 6, float> W_Xf;
+        nav->score = nb.gt->Minimizer_RV<float>(V, W, P_V, P_W, *ob.ef, p.tracker_match_thresh, p.tracker_iter_num,
+                                                p.tracker_init_type, p.reweight_distance, error_vel, error_score,
+                                                s_rho_q, p.match_num_thresh, p.tracker_init_iter_num, W_Xf);  // :343 (USE_NE10)
+    } else
     nav->score = nb.gt->Minimizer_RV<double>(V, W, P_V, P_W, *ob.ef, p.tracker_match_thresh, p.tracker_iter_num,
                                              p.tracker_init_type, p.reweight_distance, error_vel, error_score,
                                              s_rho_q, p.match_num_thresh, p.tracker_init_iter_num, W_X);  // :346

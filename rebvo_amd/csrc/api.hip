@@ -976,6 +976,16 @@ int edgehip_bind_rgb_indexed(edgehip_ctx *c, int slot, const void *pool_dev, int
     return 0;
 }
 
+int edgehip_set_tracker_precision(edgehip_ctx *c, int bits) {
+    EH_ENTER(c);
+    if (!c || (bits != 32 && bits != 64)) { set_error("set_tracker_precision: 32 or 64"); return EDGEHIP_ERR_ARG; }
+    if (bits == 32 && (c->imu_enabled || c->rig.enabled)) { set_error("set_tracker_precision: the float tracker is Minimizer_RV<float> (ImuMode 0, no stereo rig)"); return EDGEHIP_ERR_STATE; }
+    EH_CHECK(hipStreamSynchronize(c->stream));
+    drop_frame_graphs(c);   // a captured frame holds the kernels of the other precision
+    c->tracker_f32 = bits == 32;
+    return 0;
+}
+
 int edgehip_set_nav_log(edgehip_ctx *c, int len) {
     EH_ENTER(c);
     if (!c || len < 0) return EDGEHIP_ERR_ARG;

@@ -257,6 +257,7 @@ struct edgehip_ctx {
     int nblk_tvr;
     bool fused_undist;     // EDGEHIP_FUSED_UNDIST=1: the one-kernel stage A resamples through the distortion map inside its load (default: k_undistort_grey first)
     int tvr_rw2;           // EDGEHIP_TVR_RW2: from this many evaluation blocks per launch on, the reweighted evaluation takes two KeyLines per thread (0 = never)
+    bool tracker_f32 = false;   // edgehip_set_tracker_precision(ctx, 32): Minimizer_RV<float> / TryVelRot<float> (k_try_velrot_f32), the reference's USE_NE10 instantiation
     int dual_init;         // EDGEHIP_DUAL_INIT (default 1): the two initialisation chains of TrackerInitType = 2 share their launches (stage_b.hip tvr2_body)
     int persist_lm_max;    // batches up to this many sequences fuse every TryVelRot evaluation with the LM step after it (EDGEHIP_PERSIST_LM, 0 = never)
     unsigned *sync_cnt;    // [B] per-sequence block tickets of k_try_velrot_lm (0 between launches)

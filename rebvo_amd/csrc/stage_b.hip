@@ -1043,6 +1043,224 @@ __global__ __launch_bounds__(kTvrThreads) void k_try_velrot_kf(TvrArgs a) {
 }
 
 // ---------------------------------------------------------------------------------------------------
+// global_tracker::TryVelRot<float, ReWeight, ProcJF, false> — the reference's OTHER instantiation of the tracker
+// (global_tracker.cpp:824: Minimizer_RV<float>, selected by USE_NE10 at rebvo_second_t.cpp:339-343; NEON only does float).  Round 6,
+// a second configuration next to the fp64 one (edgehip_set_tracker_precision(ctx, 32)); the headline stays fp64.
+// Everything the reference declares as T is a float here and rounds where the reference's float code rounds: P0 = ((1/zf) z) x with
+// z = 1 / (float)rho (KltoI3PMatrix<float>, ProyI3Pto3PMatrix<float>: ne10wrapper.h:414-424), the SE(3) transform and the
+// projection as float multiply / add chains (SE3on3PMatrix, ProyP3toI3PMatrix), Hom2Img, the z-rotated gradient, Test_f_k<float>,
+// the residual and its gradient (Calc_f_J2<float>), the Huber weight, the Jacobian row (MulVect / MlAcVect chains); what the
+// reference keeps in double stays double: the uncertainty gate, round2int_positive's + 0.5, q_rho = sqrt(s_rho qvel s_rho qvel + 1)
+// and the seven quotients by it (float / double, rounded back to float).  The 28 products are float and are summed in float in the
+// fixed halving tree of wave_reduce.h (the reference: PairWiseVAdd<float>) — float sums of ~14 k terms agree to ~1e-6 relative, not
+// bit for bit, which is what the float tolerance of the tests states.  The residual memory keeps its fp64 buffers (float values,
+// exactly representable): the marker / carry logic of the "last valid fi" propagation is shared with the fp64 kernels.
+// ---------------------------------------------------------------------------------------------------
+template <bool REWEIGHT, bool PROCJF, bool GREC>
+__device__ __forceinline__ void tvr_body_f32(const TvrArgs &a, const int seq, const int blk, const int tid) {
+    static_assert(kTvrPasses == 1, "one KeyLine per thread");
+    const int lane = tid & 63, wave = tid >> 6;
+    SeqDev *sq = a.seq + seq;
+    const int kn = a.kn_old[seq];
+    if (blk * kTvrBlock >= kn) return;
+    const KlSoA &ko = a.kl_old[seq];
+    const int res_in = sq->res_cur, res_out = sq->lm_phase == 0 ? sq->res_t : sq->res_new;
+    const double *rin = a.resid + ((size_t)res_in * a.nseq + seq) * a.cap;
+    double *rout = a.resid + ((size_t)res_out * a.nseq + seq) * a.cap;
+    const double carry_in_prev = a.resid_carry[((size_t)res_in * a.nseq + seq) * a.nblk + blk];
+    const double marker = __longlong_as_double((long long)resid_carry_bits());
+    constexpr int NW = kTvrThreads / 64;
+    __shared__ float s_wlast[NW];
+    __shared__ int s_whas[NW];
+    float sums[kNumSums];
+#pragma unroll
+    for (int i = 0; i < kNumSums; i++) sums[i] = 0.f;
+
+    const int ikl = blk * kTvrBlock + tid;
+    float J[6] = {0, 0, 0, 0, 0, 0};
+    float fm = 0, dfx = 0, dfy = 0;
+    float ptx = 0, pty = 0, ptz = 1, pix = 0, piy = 0, rho_p = 1;
+    double s_rho = 1;
+    float wgt = 1;
+    int mid_f = -1, status = 0;
+    float fi = 0;
+    double rho_own = 0;
+    const float zf = (float)a.zfm, max_r = (float)a.max_r, k_huber = (float)a.k_huber, simil_t = (float)a.match_thresh;
+    float Vt0 = 0, Vt1 = 0, Vt2 = 0;
+    if (ikl < kn) {
+        s_rho = ko.s_rho[ikl];
+        const int32_t mnum = ko.m_num[ikl];
+        const float2 pm0 = ko.p_m[ikl];
+        const double rho0 = ko.rho[ikl];
+        rho_own = rho0;
+        const float2 klm = ko.m_m[ikl];
+        const float knm = ko.n_m[ikl];
+        double rprev_d = 0;
+        if (REWEIGHT) rprev_d = rin[ikl];
+        const uint32_t fc = a.framecount[seq];
+        const uint32_t mthr = a.match_num_thresh < fc ? a.match_num_thresh : fc;
+        const bool skip = s_rho > sq->s_rho_min_eval || (uint32_t)mnum < mthr;
+        Vt0 = (float)sq->Vt[0]; Vt1 = (float)sq->Vt[1]; Vt2 = (float)sq->Vt[2];
+        if (!skip) {
+            const float sz = 1.f / (float)rho0;
+            const float pz_zf0 = (1.f / zf) * sz;
+            const float sx = pz_zf0 * pm0.x, sy = pz_zf0 * pm0.y;
+            const double *Rd = sq->Rt;
+            const float R0 = (float)Rd[0], R1 = (float)Rd[1], R2 = (float)Rd[2], R3 = (float)Rd[3], R4 = (float)Rd[4], R5 = (float)Rd[5],
+                        R6 = (float)Rd[6], R7 = (float)Rd[7], R8 = (float)Rd[8];
+            ptx = R0 * sx; ptx += R1 * sy; ptx += R2 * sz; ptx = Vt0 + ptx;
+            pty = R3 * sx; pty += R4 * sy; pty += R5 * sz; pty = Vt1 + pty;
+            ptz = R6 * sx; ptz += R7 * sy; ptz += R8 * sz; ptz = Vt2 + ptz;
+            rho_p = 1.f / ptz;
+            const float pz_zf = zf * rho_p;
+            pix = pz_zf * ptx;
+            piy = pz_zf * pty;
+            const float px = pix + a.ppx, py = piy + a.ppy;
+            const int x = x86_cvttsd2si((double)px + 0.5), y = x86_cvttsd2si((double)py + 0.5);
+            if (REWEIGHT) {
+                if (is_carry(rprev_d)) rprev_d = carry_in_prev;
+                const float rprev = (float)rprev_d;
+                if (fabsf(rprev) > k_huber) wgt = k_huber / fabsf(rprev);
+            }
+            if (x < 1 || y < 1 || x >= a.w - 1 || y >= a.h - 1) {
+                fm = max_r;
+                status = 1;
+            } else {
+                status = 3;
+                fm = max_r;
+                const float rmx = (float)sq->RM[0] * klm.x + (float)sq->RM[1] * klm.y;   // Matrix<2,2,float> RM (global_tracker.cpp:318, 386-388)
+                const float rmy = (float)sq->RM[2] * klm.x + (float)sq->RM[3] * klm.y;
+                const uint32_t f = a.field16[(size_t)seq * a.f16stride + field16_index(x, y, a.f16tx)];
+                if (f != 0u) {
+                    const int ikf = (int)f - 1;
+                    float f_cpx, f_cpy, f_mx, f_my, f_ux, f_uy;
+                    if (GREC) {
+                        const float4 g = a.kl_new[seq].grec[ikf];
+                        f_cpx = g.x; f_cpy = g.y; f_mx = g.z; f_my = g.w;
+                    } else {
+                        const MatchRec fr = a.kl_new[seq].rec[ikf];
+                        f_cpx = fr.c_px; f_cpy = fr.c_py; f_mx = fr.m_mx; f_my = fr.m_my; f_ux = fr.u_mx; f_uy = fr.u_my;
+                    }
+                    const float p_n2 = knm * knm;                      // Test_f_k<float> (global_tracker.h:90-104)
+                    const float p_esc = rmx * f_mx + rmy * f_my;
+                    if (!(fabsf(p_esc - p_n2) > simil_t * p_n2)) {
+                        if (GREC) {
+                            const float n2m = f_mx * f_mx + f_my * f_my;
+                            const float nm = sqrtf(n2m);
+                            f_ux = f_mx / nm; f_uy = f_my / nm;
+                        }
+                        const float dx = px - f_cpx, dy = py - f_cpy;    // Calc_f_J2<float> (global_tracker.cpp:228-271)
+                        fi = dx * f_ux + dy * f_uy;
+                        dfx = f_ux;
+                        dfy = f_uy;
+                        fm = fi;
+                        mid_f = ikf;
+                        status = 2;
+                    }
+                }
+            }
+        }
+    }
+    // ---- DResidualNew: "last valid fi" propagation (KeyLine order = wave, lane), as in tvr_body ----
+    {
+        const unsigned long long vmask = __ballot(status == 2);
+        const unsigned long long below = vmask & ((1ull << lane) - 1ull);
+        const int src = below ? 63 - __clzll(below) : 0;
+        const float inh = __shfl(fi, src, 64);
+        const int top = vmask ? 63 - __clzll(vmask) : 0;
+        const float wl = __shfl(fi, top, 64);
+        if (lane == 0) {
+            s_whas[wave] = vmask != 0;
+            s_wlast[wave] = wl;
+        }
+        __syncthreads();
+        if (status == 3) {
+            double v = marker;
+            bool have = false;
+            if (below) { v = (double)inh; have = true; }
+            for (int pw = wave - 1; pw >= 0 && !have; pw--)
+                if (s_whas[pw]) { v = (double)s_wlast[pw]; have = true; }
+            rout[ikl] = v;
+        } else if (status == 2) {
+            rout[ikl] = (double)fi;
+        } else if (status == 1) {
+            rout[ikl] = (double)max_r;
+        } else if (ikl < kn) {
+            rout[ikl] = 0.0;
+        }
+    }
+    if (a.write_mid && ikl < kn) {
+        ko.m_id_f[ikl] = mid_f;
+        if (a.fwd_key && mid_f >= 0) atomicMax(&a.fwd_key[(size_t)seq * a.cap + mid_f], ord_bits(rho_own));
+    }
+    // ---- Jacobian row, uncertainty scaling (global_tracker.cpp:399-463 with T = float) ----
+    if (ikl < kn) {
+        if (REWEIGHT) { fm *= wgt; dfx *= wgt; dfy *= wgt; }
+        if (PROCJF) {
+            float t0 = zf * rho_p;
+            J[0] = t0 * dfx;
+            J[1] = t0 * dfy;
+            t0 = rho_p * pix;
+            J[2] = t0 * dfx;
+            t0 = rho_p * piy;
+            J[2] += t0 * dfy;
+            J[3] = J[1] * ptz; J[3] += J[2] * pty;
+            J[4] = J[0] * ptz; J[4] += J[2] * ptx;
+            t0 = J[0] * pty;
+            J[5] = -1.f * t0; J[5] += J[1] * ptx;
+        }
+        // qvel: a float expression (zfm, the derivatives, PtIm and Vt are floats) assigned to a double (:452-453); q_rho in double
+        const double qvel = (double)(zf * dfx * Vt0 + zf * dfy * Vt1 + (pix * dfx + piy * dfy) * Vt2);
+        const double q_rho = REWEIGHT ? sqrt(s_rho * qvel * s_rho * qvel + 1) : s_rho;
+        const double r_q = 1.0 / q_rho;
+        if (PROCJF) {
+#pragma unroll
+            for (int j = 0; j < 6; j++) J[j] = (float)div_rn((double)J[j], q_rho, r_q);   // float /= double: the quotient in double, rounded to float
+        }
+        fm = (float)div_rn((double)fm, q_rho, r_q);
+    }
+    {
+        int ns = 0;
+        if (PROCJF) {
+#pragma unroll
+            for (int i = 0; i < 6; i++)
+#pragma unroll
+                for (int j = i; j < 6; j++) sums[ns++] = J[i] * J[j];
+#pragma unroll
+            for (int i = 0; i < 6; i++) sums[ns++] = J[i] * fm;
+        }
+        sums[PROCJF ? ns : kNumSums - 1] = fm * fm;
+    }
+    if (tid == 0) {
+        double bl = marker;
+        for (int pw = NW - 1; pw >= 0; pw--)
+            if (s_whas[pw]) { bl = (double)s_wlast[pw]; break; }
+        a.block_last[(size_t)seq * a.nblk + blk] = bl;
+    }
+    __shared__ float s_red[NW][32];
+    if (PROCJF) {
+        const int idx = wave_reduce28_f32(sums, lane);
+        if ((lane & 1) == 0) s_red[wave][idx] = sums[0];
+    } else {
+        float v = sums[kNumSums - 1];
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+        if (lane == 0) s_red[wave][kNumSums - 1] = v;
+    }
+    __syncthreads();
+    if (PROCJF ? tid < kNumSums : tid == kNumSums - 1) {
+        float v = s_red[0][tid];
+#pragma unroll
+        for (int wv = 1; wv < NW; wv++) v += s_red[wv][tid];
+        a.partials[((size_t)seq * a.nblk + blk) * kNumSums + tid] = (double)v;   // the step kernel adds the blocks' sums (in double) and rounds to float
+    }
+}
+template <bool REWEIGHT, bool PROCJF, bool GREC>
+__global__ __launch_bounds__(kTvrThreads) void k_try_velrot_f32(TvrArgs a) {
+    tvr_body_f32<REWEIGHT, PROCJF, GREC>(a, blockIdx.z, blockIdx.x, threadIdx.x);
+}
+
+// ---------------------------------------------------------------------------------------------------
 // Two evaluations in one launch: TrackerInitType = 2 runs `init_iter + 1` un-reweighted evaluations from X = 0 and the same
 // number from the prior (Vel, W0) and keeps the better end point (global_tracker.cpp:649-692, 698-738, 740-749).  The two
 // chains are independent: neither reads a residual buffer (ReWeight = false), they write different ones (Rest /
@@ -1865,7 +2083,10 @@ struct LmArgs {
     edgehip_kf_result *kf_out;         // [B] (LM_FINISH_KF)
     const int32_t *kn_src = nullptr;   // [B] or null: KeyLine count of the tracked edge map, when the step runs in the launch that would
                                        // otherwise have left it in the state (k_tvr_prepare_begin)
+    int f32 = 0;                       // Minimizer_RV<float>: what the reference declares as T — JtJ, JtF, ApI, h, X, Xnew (global_tracker.cpp:601-603) —
+                                       // is rounded to float where the reference's assignments round it; the solves, u, v, gain and F stay double
 };
+__device__ __forceinline__ double lm_rt(const double x, const int f32) { return f32 ? (double)(float)x : x; }
 
 template <bool WAVE_ONLY>
 __device__ __forceinline__ void lm_sync() {
@@ -1937,9 +2158,9 @@ __device__ __forceinline__ void lm_body(const LmArgs &a, const int seq, const in
                 for (int i = 0; i < 6; i++) sq->zX[i] = 0;
                 sq->z_eff_steps = 0;
                 sq->zv = 2;
-                for (int i = 0; i < 3; i++) { sq->X[i] = sq->pub.V[i]; sq->X[3 + i] = sq->pub.W[i]; }
+                for (int i = 0; i < 3; i++) { sq->X[i] = lm_rt(sq->pub.V[i], a.f32); sq->X[3 + i] = lm_rt(sq->pub.W[i], a.f32); }
             } else if (a.init_type == 1) {
-                for (int i = 0; i < 3; i++) { sq->X[i] = sq->pub.V[i]; sq->X[3 + i] = sq->pub.W[i]; }
+                for (int i = 0; i < 3; i++) { sq->X[i] = lm_rt(sq->pub.V[i], a.f32); sq->X[3 + i] = lm_rt(sq->pub.W[i], a.f32); }
             } else {
                 for (int i = 0; i < 6; i++) sq->X[i] = 0;
             }
@@ -2053,9 +2274,9 @@ __device__ __forceinline__ void lm_body(const LmArgs &a, const int seq, const in
 #pragma unroll
                 for (int i = 0; i < 6; i++)
 #pragma unroll
-                    for (int j = i; j < 6; j++) Jn[i * 6 + j] = s_sum[ns++];
+                    for (int j = i; j < 6; j++) Jn[i * 6 + j] = lm_rt(s_sum[ns++], a.f32);
 #pragma unroll
-                for (int i = 0; i < 6; i++) Fn6[i] = s_sum[ns++];
+                for (int i = 0; i < 6; i++) Fn6[i] = lm_rt(s_sum[ns++], a.f32);
             }
 #pragma unroll
             for (int i = 0; i < 2; i++) {  // sign fix-ups, global_tracker.cpp:484-490
@@ -2082,7 +2303,7 @@ __device__ __forceinline__ void lm_body(const LmArgs &a, const int seq, const in
                 for (int i = 0; i < 6; i++) cJtFnew[i] = Fn6[i];
             }
         }
-        if (ops & LM_REDUCE_CUR) F = s_sum[kNumSums - 1]; else Fnew = s_sum[kNumSums - 1];
+        if (ops & LM_REDUCE_CUR) F = lm_rt(s_sum[kNumSums - 1], a.f32); else Fnew = lm_rt(s_sum[kNumSums - 1], a.f32);
         if (!DUAL) sq->pub.minimizer_evals++;
         else if (ch == 0) sq->pub.minimizer_evals += 2;   // the launch evaluated both chains
     }
@@ -2128,7 +2349,7 @@ __device__ __forceinline__ void lm_body(const LmArgs &a, const int seq, const in
         sq->Ft = F; sq->F0t = F0; sq->ut = u; sq->vt = v; sq->eff_steps_t = eff_steps;
         eff_steps = 0;
 #pragma unroll
-        for (int i = 0; i < 3; i++) { X[i] = sq->pub.V[i]; X[3 + i] = sq->pub.W[i]; }
+        for (int i = 0; i < 3; i++) { X[i] = lm_rt(sq->pub.V[i], a.f32); X[3 + i] = lm_rt(sq->pub.W[i], a.f32); }
     }
     if (ops & LM_PICK) {
         if (F > sq->Ft) {
@@ -2144,10 +2365,10 @@ __device__ __forceinline__ void lm_body(const LmArgs &a, const int seq, const in
 #pragma unroll
         for (int i = 0; i < 36; i++) ApI[i] = JtJ[i];
 #pragma unroll
-        for (int i = 0; i < 6; i++) { ApI[i * 7] = JtJ[i * 7] + 1.0 * u; nb[i] = -JtF[i]; }
+        for (int i = 0; i < 6; i++) { ApI[i * 7] = lm_rt(JtJ[i * 7] + 1.0 * u, a.f32); nb[i] = -JtF[i]; }
         lm_solve6(ApI, nb, (ops & LM_SOLVE_SVD) != 0, hh, s_m, s_v);
 #pragma unroll
-        for (int i = 0; i < 6; i++) Xn[i] = X[i] + hh[i];
+        for (int i = 0; i < 6; i++) { hh[i] = lm_rt(hh[i], a.f32); Xn[i] = lm_rt(X[i] + hh[i], a.f32); }
     }
     if (ops & LM_PHASE_A) sq->lm_phase = 0;
     if (ops & LM_PHASE_BC) sq->lm_phase = 1;
@@ -2693,6 +2914,7 @@ int tvr_prepare_enqueue(edgehip_ctx *c, int slot_old, unsigned begin_ops) {
         l.nblk = c->nblk_tvr; l.nseq = pl.nseq; l.ops = begin_ops; l.init_type = c->p.tracker_init_type;
         l.kf_in = c->kf_req_dev; l.kf_out = c->kf_res_dev;
         l.kn_src = c->kn_slot + (size_t)slot_old * pl.nseq;
+        l.f32 = c->tracker_f32 ? 1 : 0;
         hipLaunchKernelGGL(k_tvr_prepare_begin, dim3((pl.cap + 255) / 256, 1, pl.nseq), dim3(256), 0, c->stream, l.kn_src, c->resid,
                            c->resid_carry, pl.cap, c->nblk_tvr, l);
         EH_LAUNCH_CHECK();
@@ -2745,6 +2967,20 @@ static int launch_tvr(edgehip_ctx *c, const TvrArgs &a, bool reweight, bool proc
 #else
     constexpr size_t dyn_lds = 0;
 #endif
+    if (c->tracker_f32) {   // Minimizer_RV<float> (edgehip_set_tracker_precision)
+#define EH_TVF(RW, JF)                                                                                                   \
+    do {                                                                                                                 \
+        if (a.use_grec) hipLaunchKernelGGL((k_try_velrot_f32<RW, JF, true>), g, b, 0, c->stream, a);                      \
+        else hipLaunchKernelGGL((k_try_velrot_f32<RW, JF, false>), g, b, 0, c->stream, a);                                \
+    } while (0)
+        if (reweight && procjf) EH_TVF(true, true);
+        else if (reweight) EH_TVF(true, false);
+        else if (procjf) EH_TVF(false, true);
+        else EH_TVF(false, false);
+#undef EH_TVF
+        EH_LAUNCH_CHECK();
+        return 0;
+    }
     if (a.use_grec) {
         if (reweight && procjf) hipLaunchKernelGGL((k_try_velrot<true, true, true>), g, b, dyn_lds, c->stream, a);
         else if (reweight) hipLaunchKernelGGL((k_try_velrot<true, false, true>), g, b, dyn_lds, c->stream, a);
@@ -2769,6 +3005,7 @@ static int launch_lm(edgehip_ctx *c, int slot_new, unsigned ops, bool two_chains
     a.framecount = c->framecount + (size_t)c->fc_index * c->plan.nseq;
     a.nblk = c->nblk_tvr; a.nseq = c->plan.nseq; a.ops = ops; a.init_type = c->p.tracker_init_type;
     a.kf_in = c->kf_req_dev; a.kf_out = c->kf_res_dev;
+    a.f32 = c->tracker_f32 ? 1 : 0;
     if (two_chains) hipLaunchKernelGGL(k_lm_step2, dim3(c->plan.nseq), dim3(128), 0, c->stream, a);
     else hipLaunchKernelGGL(k_lm_step, dim3(c->plan.nseq), dim3(64), 0, c->stream, a);
     EH_LAUNCH_CHECK();
@@ -2853,7 +3090,7 @@ int minimizer_enqueue(edgehip_ctx *c, int slot_new, int slot_old, int fc_index) 
     // Small batches: an evaluation is held back until the LM step that follows it is known, and both go out as one launch.
     const bool fuse = c->persist_lm_max > 0 && c->plan.nseq <= c->persist_lm_max;
     // TrackerInitType = 2: the zero-init and the prior-init chain advance in the same launches (k_try_velrot2 / k_lm_step2)
-    const bool two_chains = p.tracker_init_type >= 2 && c->dual_init && !fuse;
+    const bool two_chains = p.tracker_init_type >= 2 && c->dual_init && !fuse && !c->tracker_f32;   // (the float tracker runs the launch chain)
     const unsigned begin_ops = two_chains ? (LM_BEGIN | LM_BEGIN2 | LM_SETUP_X | LM_PHASE_BC)
                                           : (LM_BEGIN | LM_SETUP_X | (p.tracker_init_type >= 2 ? LM_PHASE_A : LM_PHASE_BC));
     const bool begin_rides = c->plan.nseq <= 64;

@@ -76,6 +76,55 @@ __device__ __forceinline__ int wave_reduce28(double (&s)[kNumSums], int lane) {
     return low == 7 ? 31 : low + 7 * b4 + 14 * b5;
 }
 
+// ---- the same halving reduction for 28 fp32 values (the float tracker, Minimizer_RV<float>): one 32-bit swap / DPP move per value ----
+template <int N, bool ROWS16>
+__device__ __forceinline__ void halve_swap_f32(float *v) {
+#pragma unroll
+    for (int i = 0; i < N; i++) {
+        const unsigned a = __float_as_uint(v[i]), b = __float_as_uint(v[i + N]);
+        const auto r = ROWS16 ? __builtin_amdgcn_permlane16_swap(a, b, false, false) : __builtin_amdgcn_permlane32_swap(a, b, false, false);
+        v[i] = __uint_as_float(r[0]) + __uint_as_float(r[1]);
+    }
+}
+template <int CTRL>
+__device__ __forceinline__ float dpp_mov_f32(float x) {
+    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(x), CTRL, 0xf, 0xf, false));
+}
+template <int N, int CTRL>
+__device__ __forceinline__ void halve_dpp_f32(float *v, int lane, int off) {
+    const bool hi = (lane & off) != 0;
+#pragma unroll
+    for (int i = 0; i < N; i++) {
+        const float send = hi ? v[i] : v[i + N];
+        const float keep = hi ? v[i + N] : v[i];
+        v[i] = keep + dpp_mov_f32<CTRL>(send);
+    }
+}
+__device__ __forceinline__ int wave_reduce28_f32(float (&s)[kNumSums], int lane) {
+    float v[32];
+#pragma unroll
+    for (int i = 0; i < kNumSums; i++) v[i] = s[i];
+    halve_swap_f32<14, false>(v);
+    halve_swap_f32<7, true>(v);
+    v[7] = 0.f;
+    halve_dpp_f32<4, 0x128>(v, lane, 8);
+    {   // lane ^ 4: ds_bpermute
+        const bool hi = (lane & 4) != 0;
+#pragma unroll
+        for (int i = 0; i < 2; i++) {
+            const float send = hi ? v[i] : v[i + 2];
+            const float keep = hi ? v[i + 2] : v[i];
+            v[i] = keep + __shfl_xor(send, 4, 64);
+        }
+    }
+    halve_dpp_f32<1, 0x4E>(v, lane, 2);
+    v[0] += dpp_mov_f32<0xB1>(v[0]);
+    s[0] = v[0];
+    const int b1 = (lane >> 1) & 1, b2 = (lane >> 2) & 1, b3 = (lane >> 3) & 1, b4 = (lane >> 4) & 1, b5 = (lane >> 5) & 1;
+    const int low = b1 + 2 * b2 + 4 * b3;
+    return low == 7 ? 31 : low + 7 * b4 + 14 * b5;
+}
+
 // The same for up to 16 values (the 3-DoF tracker's 10): 16 -> 8 -> 4 -> 2 -> 1 over lane ^ 32, 16, 8, 4, then the two
 // remaining butterfly steps (lane ^ 2, lane ^ 1) on the single value.  On return v[0] of lane l is the full sum of value
 //     idx = 8*b5 + 4*b4 + 2*b3 + b2      (b_k = bit k of l), the same in all four lanes of a quad.

@@ -202,7 +202,7 @@ EXPORTS = [
     "edgehip_set_state", "edgehip_get_framecount", "edgehip_set_framecount", "edgehip_download_keylines", "edgehip_download_keylines_batch",
     "edgehip_upload_keylines", "edgehip_download_plane", "edgehip_download_field", "edgehip_profile_enable",
     "edgehip_profile_count", "edgehip_profile_name", "edgehip_profile_read", "edgehip_profile_select",
-    "edgehip_upload_rgb_indexed", "edgehip_bind_rgb_indexed", "edgehip_set_nav_log", "edgehip_read_nav_log", "edgehip_read_nav_log_device", "edgehip_read_nav_imu_log", "edgehip_export_keylines", "edgehip_export_fetch", "edgehip_export_wait",
+    "edgehip_upload_rgb_indexed", "edgehip_bind_rgb_indexed", "edgehip_set_nav_log", "edgehip_read_nav_log", "edgehip_read_nav_log_device", "edgehip_read_nav_imu_log", "edgehip_set_tracker_precision", "edgehip_export_keylines", "edgehip_export_fetch", "edgehip_export_wait",
     "edgehip_build_undistort_map", "edgehip_download_undistorted", "edgehip_depth_reset", "edgehip_depth_reset_slot", "edgehip_set_slot_camera", "edgehip_directed_matching_stereo",
     "edgehip_alloc_pinned", "edgehip_free_pinned", "edgehip_upload_rgb_pinned", "edgehip_upload_sync", "edgehip_upload_wait", "edgehip_register_host", "edgehip_unregister_host", "edgehip_experiments", "edgehip_fuse_stereo_depth", "edgehip_set_stereo_rig", "edgehip_get_stereo_matches", "edgehip_minimizer_v", "edgehip_ext_rot_vel",
     "edgehip_imu_enable", "edgehip_set_imu", "edgehip_read_nav_imu", "edgehip_minimizer_rv_kf", "edgehip_lm_solve",
@@ -400,6 +400,10 @@ class EdgeHip:
         assert idx.shape == (self.nseq,)
         self._ck(self.lib.edgehip_upload_rgb_indexed(self.ctx, slot, C.c_void_p(pool_dev_ptr), pool_frames,
                                                      idx.ctypes.data_as(C.c_void_p)))
+
+    def set_tracker_precision(self, bits):
+        """32: Minimizer_RV<float> / TryVelRot<float> (the reference's USE_NE10 instantiation); 64: the default."""
+        self._ck(self.lib.edgehip_set_tracker_precision(self.ctx, bits))
 
     def set_nav_log(self, length):
         self._ck(self.lib.edgehip_set_nav_log(self.ctx, length))
