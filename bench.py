@@ -409,9 +409,11 @@ def _parity_worker(job):
     exactly on a half pixel whose re-projection at X = 0 rounds either way: oracle.half_pixel_keylines)."""
     s_, idx = job
     from oracle import oracle
-    kind, w, h, dt = _PARITY["cfg"]
+    kind, w, h, dt = _PARITY["cfg"][:4]
     op = oracle.tum_params(w, h, use_undistort=1) if kind == "tum" else oracle.euroc_params(w, h)
     orc = oracle.Oracle("ref", op)
+    if len(_PARITY["cfg"]) > 4 and _PARITY["cfg"][4]:
+        orc.set_tracker_f32(1)   # the reference's float instantiation of the tracker (--tracker-f32)
     fr = _PARITY["frames"]
     V, Wv, Pos, Pose, cnt, knife = [], [], [], [], [], []
     for k, i in enumerate(idx):
@@ -425,7 +427,7 @@ def _parity_worker(job):
     return s_, np.array(V), np.array(Wv), np.array(Pos), np.array(Pose).reshape(-1, 3, 3), np.array(cnt), knife
 
 
-def wide_parity(log, seqs, idx_of, frames_arr, cfg, first_timed, procs):
+def wide_parity(log, seqs, idx_of, frames_arr, cfg, first_timed, procs, tol_rel=1e-6, tol_abs=1e-9):
     """Free-running parity of MANY sequences of a batch against the CPU reference replaying the same frames from frame 0, in a
     pool of `procs` reference processes.  log: the device's nav records of frames 0..n-1 ([n, nseq] structured array);
     idx_of(s) -> the n pool indices of sequence s.  Per frame the tests' bound: |dV|, |dW| <= 1e-6 * step + 1e-9 (and the same
@@ -448,7 +450,7 @@ def wide_parity(log, seqs, idx_of, frames_arr, cfg, first_timed, procs):
         for k in range(1, n):
             if not (np.all(np.isfinite(V[k])) and np.all(np.isfinite(Wv[k]))):
                 continue
-            tol = 1e-6 * (np.linalg.norm(V[k]) + np.linalg.norm(Wv[k])) + 1e-9
+            tol = tol_rel * (np.linalg.norm(V[k]) + np.linalg.norm(Wv[k])) + tol_abs
             d = max(np.max(np.abs(log[k, s_]["V"] - V[k])), np.max(np.abs(log[k, s_]["W"] - Wv[k])))
             bad = d > tol or int(log[k, s_]["kn"]) != int(cnt[k][0])
             if bad:
@@ -459,9 +461,9 @@ def wide_parity(log, seqs, idx_of, frames_arr, cfg, first_timed, procs):
                 max_dv_inside = max(max_dv_inside, float(d))
             path += float(np.linalg.norm(V[k]))
         last = n - 1
-        tol_l = 1e-6 * (np.linalg.norm(V[last]) + np.linalg.norm(Wv[last])) + 1e-9
+        tol_l = tol_rel * (np.linalg.norm(V[last]) + np.linalg.norm(Wv[last])) + tol_abs
         out_last = bool(max(np.max(np.abs(log[last, s_]["V"] - V[last])), np.max(np.abs(log[last, s_]["W"] - Wv[last]))) > tol_l or
-                        np.max(np.abs(log[last, s_]["Pos"] - Pos[last])) > 1e-6 * path + 1e-9)
+                        np.max(np.abs(log[last, s_]["Pos"] - Pos[last])) > tol_rel * path + tol_abs)
         if first is not None or out_last:
             departed.append({"sequence": s_, "first_frame_outside_tolerance": first, "knife_edge_frame": bool(first in knife) if first is not None else None,
                              "outside_tolerance_at_last_frame": out_last,
@@ -473,7 +475,7 @@ def wide_parity(log, seqs, idx_of, frames_arr, cfg, first_timed, procs):
                "departures_on_knife_edge_frames": int(sum(1 for d_ in departed if d_["knife_edge_frame"])),
                "departures_elsewhere": int(sum(1 for d_ in departed if d_["knife_edge_frame"] is False)),
                "max_abs_dVW_while_inside_tolerance": max_dv_inside,
-               "tolerance": "per frame |dV|, |dW| <= 1e-6 * (|V| + |W|) + 1e-9 and the same KeyLine count; last frame also |dPos| <= 1e-6 * path + 1e-9"}
+               "tolerance": f"per frame |dV|, |dW| <= {tol_rel:g} * (|V| + |W|) + {tol_abs:g} and the same KeyLine count; last frame also |dPos| <= {tol_rel:g} * path + {tol_abs:g}"}
     return summary, trajs
 
 
@@ -696,7 +698,7 @@ def compact_line(full):
     line["config"] = {"workload": wl if len(wl) <= 300 else wl[:297] + "...",
                       "input": (str(c["input"])[:160] if c.get("input") else None)}
     for k in ("sequences_per_gpu", "frames_per_step", "keylines_per_frame", "keylines_per_frame_timed_mean", "tryvelrot_evals_per_frame",
-              "estimation_ok", "nav_gather", "algorithmic_MB_per_frame", "whole_path_hbm_frac", "frames_per_s"):
+              "estimation_ok", "nav_gather", "algorithmic_MB_per_frame", "whole_path_hbm_frac", "frames_per_s", "tracker"):
         if c.get(k) is not None:
             line["config"][k] = c[k]
     if isinstance(c.get("nav_gather_info"), dict):
@@ -739,7 +741,10 @@ def compact_line(full):
         o["departures_elsewhere"] = par.get("departures_elsewhere")
         if par.get("max_abs_dVW_while_inside_tolerance") is not None:
             o["max_abs_dVW_inside_tolerance"] = _r(par["max_abs_dVW_while_inside_tolerance"])
-        o["tolerance"] = "per frame |dV|,|dW| <= 1e-6*(|V|+|W|)+1e-9 and equal KeyLine count"
+        o["tolerance"] = str(par.get("tolerance") or "per frame |dV|,|dW| <= 1e-6*(|V|+|W|)+1e-9 and equal KeyLine count")[:110]
+        tfz = pr.get("teacher_forced")
+        if isinstance(tfz, dict):
+            o["teacher_forced"] = {k: _r(tfz.get(k)) for k in ("sequences", "frames", "frames_outside_tolerance", "max_rel_dX", "tolerance") if k in tfz}
         line["pose_rmse"] = o
     else:
         line["pose_rmse"] = None
@@ -850,7 +855,8 @@ def other_configs(args):
         raise RuntimeError(f"no JSON line (rc {out.returncode}): {out.stderr[-200:]}")
     for name, flags in (("stage_a", ["--config", "stage_a", "--cpu-frames", cf]),
                         ("tum_undistort", ["--config", "tum_undistort", "--cpu-frames", cf, "--cpu-procs", "0"]),
-                        ("imu", ["--imu", "--cpu-frames", cf, "--cpu-procs", "0"])):
+                        ("imu", ["--imu", "--cpu-frames", cf, "--cpu-procs", "0"]),
+                        ("tracker_f32", ["--tracker-f32", "--cpu-frames", cf, "--cpu-procs", "0"])):
         try:
             t_sub = time.perf_counter()
             js = run(["--no-extras", "--steps", "20", "--warmup", "5", "--nseq", str(args.nseq)] + flags, 420)
@@ -966,6 +972,11 @@ def main():
                     help="ImuMode=2 (what the shipped GlobalConfig_EuRoC runs): the IMU branch of the tracker — gyro pre-rotation, "
                          "Minimizer_V, ExtRotVel, BiasCorrect, scale filter, gravity-aligned pose — batched on the device; the "
                          "integrated IMU data of every frame interval is synthesised from the known camera motion")
+    ap.add_argument("--tracker-f32", action="store_true",
+                    help="a SECOND configuration, never the headline: the tracker's float instantiation, Minimizer_RV<float> / TryVelRot<float> "
+                         "(global_tracker.cpp:824; what the reference runs when built with USE_NE10, rebvo_second_t.cpp:339-343) — "
+                         "edgehip_set_tracker_precision(ctx, 32).  Pose RMSE and the CPU baseline are then taken against the reference's own "
+                         "float instantiation; the line's dtype says so")
     ap.add_argument("--no-extras", action="store_true", help="skip the small-batch sweep and the plugin-surface legs as well (profiling runs)")
     ap.add_argument("--dataset", default=os.environ.get("REBVO_DATASET_DIR") or os.environ.get("REBVO_EUROC_DIR") or os.environ.get("REBVO_TUM_DIR"),
                     help="a mounted EuRoC sequence (the directory that holds mav0/cam0/data.csv, 752x480: the default line) or TUM "
@@ -1143,6 +1154,13 @@ def main():
             return [trans[(tri(k - 1 + o, args.pool) if k > 0 else tri(k + o, args.pool), tri(k + o, args.pool))] for o in offs]
     rp = Replay(edgehip_dev, params, B * C, in_pool, in_frames, index_of, local_rank, C, imu_params=imu_params, imu_of=imu_of)
     ehs, eh = rp.ehs, rp.ehs[0]   # eh: the context whose streams carry the HIP-event profiler
+    f32 = bool(args.tracker_f32)
+    if f32:
+        if args.imu or args.config == "stage_a" or stub:
+            raise SystemExit("--tracker-f32 is the ImuMode = 0 tracker's float instantiation (full path only)")
+        for e in ehs:
+            e.set_tracker_precision(32)
+        args.no_extras = True
 
     # ============================ --config stage_a: DoG + KeyLine extraction alone (configs[1]) ============================
     if args.config == "stage_a":
@@ -1334,8 +1352,48 @@ def main():
             kind = "reference" if oracle.available("ref") else ("port" if oracle.available("port") else None)
             if kind == "reference":
                 parity, cpu_trajs = wide_parity(log_all, check_seqs, lambda s_: [tri(k + int(offs[s_]), args.pool) for k in range(Wm + K)],
-                                                np.stack(frames), ("tum" if tum else "euroc", w, h, FRAME_DT), Wm,
-                                                max(1, (_usable_cores() - 1) // world))
+                                                np.stack(frames), ("tum" if tum else "euroc", w, h, FRAME_DT, f32), Wm,
+                                                max(1, (_usable_cores() - 1) // world),
+                                                **(dict(tol_rel=1e-4, tol_abs=1e-7) if f32 else {}))
+                if f32 and parity and rank == 0:
+                    # the parity statement of the float configuration: teacher-forced (oracle/teacher.py) — the reference's float state
+                    # injected before every frame — on three sequences of the batch, every frame within a few float ulps and the
+                    # discrete counts identical; and, as the yardstick for a free-running float trajectory, how far the reference's own
+                    # float and double instantiations are apart on the same frames at the last frame
+                    from oracle import teacher
+                    tf_out, tf_max, tf_frames, yard, tf_list = 0, 0.0, 0, [], []
+                    tf_seqs = check_seqs[:3]
+                    for s_ in tf_seqs:
+                        o32 = oracle.Oracle("ref", oparams)
+                        o32.set_tracker_f32(1)
+                        e1 = edgehip.EdgeHip(params, nseq=1, nslots=3, device=local_rank)
+                        e1.set_tracker_precision(32)
+                        tfr = teacher.teacher_forced_replay(e1, o32, lambda k, s_=s_: frames[tri(k + int(offs[s_]), args.pool)], Wm + K, dt=FRAME_DT,
+                                                            tol_rel=2e-5, tol_abs=2e-8)
+                        e1.close()
+                        o32.close()
+                        tf_out += len(tfr["outside_tolerance"])
+                        tf_list += [{"sequence": int(s_), "frame": o_["frame"], "dV": o_.get("dV"), "dW": o_.get("dW"), "kn_ok_klm": o_.get("kn_ok_klm")}
+                                    for o_ in tfr["outside_tolerance"]]
+                        tf_frames += tfr["frames"]
+                        for dv_, dw_, r_ in zip(tfr["dV"][1:], tfr["dW"][1:], tfr["ref"][1:]):
+                            tf_max = max(tf_max, max(dv_, dw_) / (np.linalg.norm(r_[2]) + np.linalg.norm(r_[3]) + 1e-30))
+                        o64 = oracle.Oracle("ref", oparams)
+                        p64 = None
+                        for k in range(Wm + K):
+                            _, n64 = o64.process_frame(frames[tri(k + int(offs[s_]), args.pool)], FRAME_DT * k)
+                            p64 = np.array(n64.Pos[:])
+                        o64.close()
+                        yard.append(float(np.linalg.norm(p64 - tfr["ref"][-1][0])))
+                    parity["teacher_forced"] = {"sequences": [int(x) for x in tf_seqs], "frames": tf_frames, "frames_outside_tolerance": tf_out,
+                                                "max_rel_dX": tf_max, "tolerance": "every frame |dV|,|dW| <= 2e-5*(|V|+|W|)+2e-8, identical kn / klm / EstimationOK",
+                                                "reference_float_vs_reference_double_position_at_last_frame": yard, "outside": tf_list[:12]}
+                if f32 and parity:
+                    parity["note"] = ("float tracker against the reference's float instantiation: per frame the two agree to a few float ulps "
+                                      "(teacher-forced: <= 4e-6 |X|, tests/test_tracker_f32_gpu.py); a free-running float trajectory leaves the other "
+                                      "at the first Levenberg-Marquardt / initialisation decision that hangs on the last bits of a float sum — the "
+                                      "reference's own float and double instantiations part the same way — so `departures_elsewhere` counts such "
+                                      "decisions here, not defects")
             elif kind:
                 cpu_trajs = {s_: _cpu_traj(oracle, oparams, lambda k, s_=s_: frames[tri(k + int(offs[s_]), args.pool)], Wm, K)
                              for s_ in check_seqs[:3]}
@@ -1343,6 +1401,8 @@ def main():
                 pose = pose_rmse(gpu_traj, cpu_trajs, kind)
                 if pose and parity:
                     pose["free_running_parity"] = parity
+                    if parity.get("teacher_forced"):
+                        pose["teacher_forced"] = parity["teacher_forced"]
         except Exception as e:  # the oracle is optional test infrastructure; never fatal for the bench
             pose = {"error": f"{type(e).__name__}: {e}"[:200]}
     if world > 1 and cpu_any:
@@ -1452,6 +1512,8 @@ def main():
                 modes = {}
                 for name, th in (("serial_1_core", 1), ("reference_threads_2_cores", 2))[:2 if world == 1 else 1]:
                     orc = oracle.Oracle("ref", oparams)
+                    if f32:
+                        orc.set_tracker_f32(1)
                     done, _ = orc.run_sequence(host_pool, idx, dt=FRAME_DT, threads=th)
                     orc.close()
                     modes[name] = frame_stats(done, 10)
@@ -1473,7 +1535,9 @@ def main():
                             "sample": f"{nfr_cpu} frames of sequence 0, restatement oracle on 1 core"})
         except Exception as e:  # the oracle is optional test infrastructure; never fatal for the bench
             cpu = {"value": None, "error": str(e)[:200]}
-        if cpu and cpu.get("value") and cpu.get("kind") == "reference" and args.cpu_procs and not tum and world == 1:
+        if cpu and f32:
+            cpu["sample"] = cpu["sample"].replace("reference mtracklib", "reference mtracklib with Minimizer_RV<float> (its USE_NE10 tracker)")
+        if cpu and cpu.get("value") and cpu.get("kind") == "reference" and args.cpu_procs and not tum and world == 1 and not f32:
             # node-saturating mode (SURVEY 8d iii): P independent sequences in parallel processes, each with the
             # reference's two compute threads (its third thread only ships results)
             try:
@@ -1695,6 +1759,11 @@ def main():
     }
     full["launched_by"] = "bench.py itself (no launcher around the command)" if os.environ.get("BENCH_SELF_LAUNCHED") == "1" else \
                           ("torch.distributed.run" if "TORCHELASTIC_RUN_ID" in os.environ else "direct")
+    if f32:
+        full["metric"] = full["metric"].replace("(DoG+extract+track+depth", "(float tracker: DoG+extract+track+depth")
+        full["dtype"] = "f32 scale-space / f32 tracker (Minimizer_RV<float>, TryVelRot<float>) / f64 matcher+EKF"
+        full["config"]["workload"] += "; SECOND CONFIGURATION: the tracker's float instantiation (global_tracker.cpp:824, the reference's USE_NE10 build)"
+        full["config"]["tracker"] = "Minimizer_RV<float>: 12 single-chain evaluations per frame (k_try_velrot_f32), LM step rounding JtJ / JtF / h / X to float"
     if stub:
         full["invalid_as_measurement"] = True
         full["data"] = "stub"
