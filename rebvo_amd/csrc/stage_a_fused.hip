@@ -898,12 +898,19 @@ int stage_a_fused_enqueue(edgehip_ctx *c, int slot, const uint8_t *rgb_base, con
         if (c->planes) fn = EH_FUSED(0, true, SRC_RGB24);
         else if (pl.w == 752) fn = EH_FUSED(752, false, SRC_RGB24);
         else if (pl.w == 640) fn = EH_FUSED(640, false, SRC_RGB24);
+#ifdef EDGEHIP_EXPERIMENTS   // the occupancy experiment's widths with compile-time LDS offsets (the generic instantiation is several times slower)
+        else if (pl.w == 256) fn = EH_FUSED(256, false, SRC_RGB24);
+        else if (pl.w == 384) fn = EH_FUSED(384, false, SRC_RGB24);
+#endif
     }
     if (!c->lds_optin_fused) {
         const void *fns[] = {
 #ifdef EDGEHIP_EXPERIMENTS
                                (const void *)EH_FUSED(0, false, SRC_UNDIST), (const void *)EH_FUSED(0, true, SRC_UNDIST),
                                (const void *)EH_FUSED(640, false, SRC_UNDIST),
+#endif
+#ifdef EDGEHIP_EXPERIMENTS
+                               (const void *)EH_FUSED(256, false, SRC_RGB24), (const void *)EH_FUSED(384, false, SRC_RGB24),
 #endif
                                (const void *)EH_FUSED(0, false, SRC_RGB24), (const void *)EH_FUSED(0, true, SRC_RGB24),
                                (const void *)EH_FUSED(752, false, SRC_RGB24), (const void *)EH_FUSED(640, false, SRC_RGB24),
