@@ -1763,7 +1763,7 @@ def main():
         full["metric"] = full["metric"].replace("(DoG+extract+track+depth", "(float tracker: DoG+extract+track+depth")
         full["dtype"] = "f32 scale-space / f32 tracker (Minimizer_RV<float>, TryVelRot<float>) / f64 matcher+EKF"
         full["config"]["workload"] += "; SECOND CONFIGURATION: the tracker's float instantiation (global_tracker.cpp:824, the reference's USE_NE10 build)"
-        full["config"]["tracker"] = "Minimizer_RV<float>: 12 single-chain evaluations per frame (k_try_velrot_f32), LM step rounding JtJ / JtF / h / X to float"
+        full["config"]["tracker"] = "Minimizer_RV<float>: 12 evaluations per frame in 9 launches (k_try_velrot2_f32 x3, k_try_velrot_f32 x6), LM step rounding JtJ / JtF / h / X to float"
     if stub:
         full["invalid_as_measurement"] = True
         full["data"] = "stub"

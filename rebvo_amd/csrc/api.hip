@@ -525,7 +525,7 @@ static int create_body(edgehip_ctx *c, CtxAllocs *al, const edgehip_params &p, i
     c->level_mode = getenv("EDGEHIP_LEVEL_MODE") ? atoi(getenv("EDGEHIP_LEVEL_MODE")) : 0;
     c->fwd_mode = EH_EXP_ENV("EDGEHIP_FWD_MODE", 0);
     c->fused_min_batch = fused_min_env;   // one workgroup per sequence: pays from about 3/4 of the 256 CUs on (tools/experiments/ab_level_mode.sh)
-    // measured at 1024 sequences (tools/experiments/gpu_r04_j.sh, same box, three rounds): the step 10.53 / 10.50 / 10.43 ms without, 10.48 / 10.39 / 10.39 ms with —
+    // measured at 1024 sequences (tools/experiments/CALLS.md: r04_j, same box, three rounds): the step 10.53 / 10.50 / 10.43 ms without, 10.48 / 10.39 / 10.39 ms with —
     // inside the run-to-run spread, while the group's own HIP-event time went UP (2.62 -> 2.73 ms: 84 registers, 5 waves per SIMD).  Off by default.
     c->fused_undist = EH_EXP_ENV("EDGEHIP_FUSED_UNDIST", 0) != 0;
     c->tvr_rw2 = EH_EXP_ENV("EDGEHIP_TVR_RW2", 0);

@@ -425,7 +425,7 @@ __global__ __launch_bounds__(512) void k_stage_a_fused(FusedArgs a) {
                 request(code_cur, wv_cur);
             }
 #ifndef EDGEHIP_FIT_UNROLL
-#define EDGEHIP_FIT_UNROLL 1   // 2785 -> 2733 us per 1024 frames (same-box A/B, tools/experiments/gpu_r04_g.sh)
+#define EDGEHIP_FIT_UNROLL 1   // 2785 -> 2733 us per 1024 frames (same-box A/B, tools/experiments/CALLS.md: r04_g)
 #endif
             // one chunk: evaluate the window in `wc` (requested one chunk earlier) while the next chunk's window lands in `wn`
             auto one_chunk = [&](int c, float (&wc)[25], float (&wn)[25]) __attribute__((always_inline)) {

@@ -399,10 +399,10 @@ __global__ __launch_bounds__(256) void k_field_raster(const KlSoA *kls, int32_t 
 #define EDGEHIP_FSPLIT 2   // measured at r = 40 after the cheaper tile range: 1: 1296, 2: 1260, 3: 1292, 4: 1310, 8: 1538, 16: 2054 us per 1024 frames
 #endif
 #ifndef EDGEHIP_RASTER_ABL
-#define EDGEHIP_RASTER_ABL 0   // timing experiments only, wrong fields by design (tools/experiments/gpu_r04_r.sh): 1 plain store for
+#define EDGEHIP_RASTER_ABL 0   // timing experiments only, wrong fields by design (tools/experiments/CALLS.md: r04_r): 1 plain store for
 #endif                         // the atomic, 2 no LDS access, 3 no samples, 4 = 3 and no output stage, 5 = 3 and no record gather, 6 = 5 and no bin read
 #ifndef EDGEHIP_RASTER_UNROLL
-#define EDGEHIP_RASTER_UNROLL 2   // 1198 -> 1156 us per 1024 frames (same-box A/B, tools/experiments/gpu_r04_g.sh)
+#define EDGEHIP_RASTER_UNROLL 2   // 1198 -> 1156 us per 1024 frames (same-box A/B, tools/experiments/CALLS.md: r04_g)
 #endif
     // (A split chosen per tile so that the last round of 256 threads is as full as possible — 1..4 parts, block-uniform —
     // measured slower, 1198 -> 1283 us: the run-time divisor costs every item more than the fuller rounds save.  So did dealing the
@@ -1516,6 +1516,205 @@ __device__ __forceinline__ void tvr2_body(const TvrArgs &a, const int seq, const
             (c ? a.partials : a.partials_z)[((size_t)seq * a.nblk + blk) * kNumSums + lane] = v;
         }
     }
+}
+
+// tvr2_body for the float tracker: evaluation i of both initialisation chains of Minimizer_RV<float> in one launch — the KeyLine's
+// streams loaded once, the two transforms walked side by side through the two gathers — per chain the arithmetic of tvr_body_f32<false, ...>,
+// expression for expression (un-reweighted: q_rho = s_rho, a double; the seven quotients are float / double rounded back to float).
+template <bool PROCJF, bool GREC>
+__device__ __forceinline__ void tvr2_body_f32(const TvrArgs &a, const int seq, const int blk, const int tid) {
+    const int lane = tid & 63, wave = tid >> 6;
+    SeqDev *sq = a.seq + seq;
+    const int kn = a.kn_old[seq];
+    if (blk * kTvrBlock >= kn) return;
+    static_assert(kTvrPasses == 1, "one KeyLine per thread");
+    const KlSoA &ko = a.kl_old[seq];
+    double *rout0 = a.resid + ((size_t)sq->res_t * a.nseq + seq) * a.cap;
+    double *rout1 = a.resid + ((size_t)sq->res_new * a.nseq + seq) * a.cap;
+    const double marker = __longlong_as_double((long long)resid_carry_bits());
+    constexpr int NW = kTvrThreads / 64;
+    __shared__ float s_wlast[2][NW];
+    __shared__ int s_whas[2][NW];
+    const float zf = (float)a.zfm, max_r = (float)a.max_r, simil_t = (float)a.match_thresh;
+
+    const int ikl = blk * kTvrBlock + tid;
+    float fm[2] = {0, 0}, dfx[2] = {0, 0}, dfy[2] = {0, 0}, fi[2] = {0, 0};
+    float ptx[2] = {0, 0}, pty[2] = {0, 0}, ptz[2] = {1, 1}, pix[2] = {0, 0}, piy[2] = {0, 0}, rho_p[2] = {1, 1};
+    int status[2] = {0, 0};
+    double s_rho = 1;
+    if (ikl < kn) {
+        s_rho = ko.s_rho[ikl];
+        const int32_t mnum = ko.m_num[ikl];
+        const float2 pm0 = ko.p_m[ikl];
+        const double rho0 = ko.rho[ikl];
+        const float2 klm = ko.m_m[ikl];
+        const float knm = ko.n_m[ikl];
+        const uint32_t fc = a.framecount[seq];
+        const uint32_t mthr = a.match_num_thresh < fc ? a.match_num_thresh : fc;
+        const bool skip = s_rho > sq->s_rho_min_eval || (uint32_t)mnum < mthr;
+        if (!skip) {
+            const float sz = 1.f / (float)rho0;
+            const float pz_zf0 = (1.f / zf) * sz;
+            const float sx = pz_zf0 * pm0.x, sy = pz_zf0 * pm0.y;
+            float px[2], py[2];
+            bool inimg[2];
+            size_t fidx[2];
+            float rmx[2], rmy[2];
+#pragma unroll
+            for (int c = 0; c < 2; c++) {
+                const double *R = c ? sq->Rt : sq->zRt, *V = c ? sq->Vt : sq->zVt, *RM = c ? sq->RM : sq->zRM;
+                ptx[c] = (float)R[0] * sx; ptx[c] += (float)R[1] * sy; ptx[c] += (float)R[2] * sz; ptx[c] = (float)V[0] + ptx[c];
+                pty[c] = (float)R[3] * sx; pty[c] += (float)R[4] * sy; pty[c] += (float)R[5] * sz; pty[c] = (float)V[1] + pty[c];
+                ptz[c] = (float)R[6] * sx; ptz[c] += (float)R[7] * sy; ptz[c] += (float)R[8] * sz; ptz[c] = (float)V[2] + ptz[c];
+                rho_p[c] = 1.f / ptz[c];
+                const float pz_zf = zf * rho_p[c];
+                pix[c] = pz_zf * ptx[c];
+                piy[c] = pz_zf * pty[c];
+                px[c] = pix[c] + a.ppx; py[c] = piy[c] + a.ppy;
+                const int x = x86_cvttsd2si((double)px[c] + 0.5), y = x86_cvttsd2si((double)py[c] + 0.5);
+                inimg[c] = !(x < 1 || y < 1 || x >= a.w - 1 || y >= a.h - 1);
+                fidx[c] = inimg[c] ? field16_index(x, y, a.f16tx) : (size_t)0;
+                rmx[c] = (float)RM[0] * klm.x + (float)RM[1] * klm.y;
+                rmy[c] = (float)RM[2] * klm.x + (float)RM[3] * klm.y;
+                fm[c] = max_r;
+                status[c] = inimg[c] ? 3 : 1;
+            }
+            const uint16_t *fld = a.field16 + (size_t)seq * a.f16stride;
+            const uint32_t f0 = fld[fidx[0]], f1 = fld[fidx[1]];
+            const bool hit0 = inimg[0] && f0 != 0u, hit1 = inimg[1] && f1 != 0u;
+            const int ikf0 = hit0 ? (int)f0 - 1 : 0, ikf1 = hit1 ? (int)f1 - 1 : 0;
+            float f_cpx[2], f_cpy[2], f_mx[2], f_my[2], f_ux[2] = {0, 0}, f_uy[2] = {0, 0};
+            if (GREC) {
+                const float4 g0 = a.kl_new[seq].grec[ikf0], g1 = a.kl_new[seq].grec[ikf1];
+                f_cpx[0] = g0.x; f_cpy[0] = g0.y; f_mx[0] = g0.z; f_my[0] = g0.w;
+                f_cpx[1] = g1.x; f_cpy[1] = g1.y; f_mx[1] = g1.z; f_my[1] = g1.w;
+            } else {
+                const MatchRec r0 = a.kl_new[seq].rec[ikf0], r1 = a.kl_new[seq].rec[ikf1];
+                f_cpx[0] = r0.c_px; f_cpy[0] = r0.c_py; f_mx[0] = r0.m_mx; f_my[0] = r0.m_my; f_ux[0] = r0.u_mx; f_uy[0] = r0.u_my;
+                f_cpx[1] = r1.c_px; f_cpy[1] = r1.c_py; f_mx[1] = r1.m_mx; f_my[1] = r1.m_my; f_ux[1] = r1.u_mx; f_uy[1] = r1.u_my;
+            }
+            const float p_n2 = knm * knm;
+#pragma unroll
+            for (int c = 0; c < 2; c++) {
+                if (c ? hit1 : hit0) {
+                    const float p_esc = rmx[c] * f_mx[c] + rmy[c] * f_my[c];
+                    if (!(fabsf(p_esc - p_n2) > simil_t * p_n2)) {
+                        if (GREC) {
+                            const float n2m = f_mx[c] * f_mx[c] + f_my[c] * f_my[c];
+                            const float nm = sqrtf(n2m);
+                            f_ux[c] = f_mx[c] / nm; f_uy[c] = f_my[c] / nm;
+                        }
+                        const float dx = px[c] - f_cpx[c], dy = py[c] - f_cpy[c];
+                        fi[c] = dx * f_ux[c] + dy * f_uy[c];
+                        dfx[c] = f_ux[c];
+                        dfy[c] = f_uy[c];
+                        fm[c] = fi[c];
+                        status[c] = 2;
+                    }
+                }
+            }
+        }
+    }
+    unsigned long long below[2];
+    float inh[2];
+#pragma unroll
+    for (int c = 0; c < 2; c++) {
+        const unsigned long long vmask = __ballot(status[c] == 2);
+        below[c] = vmask & ((1ull << lane) - 1ull);
+        const int src = below[c] ? 63 - __clzll(below[c]) : 0;
+        inh[c] = __shfl(fi[c], src, 64);
+        const int top = vmask ? 63 - __clzll(vmask) : 0;
+        const float wl = __shfl(fi[c], top, 64);
+        if (lane == 0) {
+            s_whas[c][wave] = vmask != 0;
+            s_wlast[c][wave] = wl;
+        }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int c = 0; c < 2; c++) {
+        double *rout = c ? rout1 : rout0;
+        if (status[c] == 3) {
+            double v = marker;
+            bool have = false;
+            if (below[c]) { v = (double)inh[c]; have = true; }
+            for (int pw = wave - 1; pw >= 0 && !have; pw--)
+                if (s_whas[c][pw]) { v = (double)s_wlast[c][pw]; have = true; }
+            rout[ikl] = v;
+        } else if (status[c] == 2) {
+            rout[ikl] = (double)fi[c];
+        } else if (status[c] == 1) {
+            rout[ikl] = (double)max_r;
+        } else if (ikl < kn) {
+            rout[ikl] = 0.0;
+        }
+    }
+    if (tid == 0) {
+#pragma unroll
+        for (int c = 0; c < 2; c++) {
+            double bl = marker;
+            for (int pw = NW - 1; pw >= 0; pw--)
+                if (s_whas[c][pw]) { bl = (double)s_wlast[c][pw]; break; }
+            (c ? a.block_last : a.block_last_z)[(size_t)seq * a.nblk + blk] = bl;
+        }
+    }
+    __shared__ float s_red[2][NW][32];
+    const double inv_q = 1.0 / s_rho;
+#pragma unroll
+    for (int c = 0; c < 2; c++) {
+        float J[6] = {0, 0, 0, 0, 0, 0};
+        float f = fm[c];
+        if (ikl < kn) {
+            if (PROCJF) {
+                float t0 = zf * rho_p[c];
+                J[0] = t0 * dfx[c];
+                J[1] = t0 * dfy[c];
+                t0 = rho_p[c] * pix[c];
+                J[2] = t0 * dfx[c];
+                t0 = rho_p[c] * piy[c];
+                J[2] += t0 * dfy[c];
+                J[3] = J[1] * ptz[c]; J[3] += J[2] * pty[c];
+                J[4] = J[0] * ptz[c]; J[4] += J[2] * ptx[c];
+                t0 = J[0] * pty[c];
+                J[5] = -1.f * t0; J[5] += J[1] * ptx[c];
+#pragma unroll
+                for (int j = 0; j < 6; j++) J[j] = (float)div_rn((double)J[j], s_rho, inv_q);
+            }
+            f = (float)div_rn((double)f, s_rho, inv_q);
+        }
+        if (PROCJF) {
+            float sums[kNumSums];
+            int ns = 0;
+#pragma unroll
+            for (int i = 0; i < 6; i++)
+#pragma unroll
+                for (int j = i; j < 6; j++) sums[ns++] = J[i] * J[j];
+#pragma unroll
+            for (int i = 0; i < 6; i++) sums[ns++] = J[i] * f;
+            sums[ns] = f * f;
+            const int idx = wave_reduce28_f32(sums, lane);
+            if ((lane & 1) == 0) s_red[c][wave][idx] = sums[0];
+        } else {
+            float v = f * f;
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+            if (lane == 0) s_red[c][wave][kNumSums - 1] = v;
+        }
+    }
+    __syncthreads();
+    if (wave < 2) {
+        const int c = 1 - wave;
+        if (PROCJF ? lane < kNumSums : lane == kNumSums - 1) {
+            float v = s_red[c][0][lane];
+#pragma unroll
+            for (int wv = 1; wv < NW; wv++) v += s_red[c][wv][lane];
+            (c ? a.partials : a.partials_z)[((size_t)seq * a.nblk + blk) * kNumSums + lane] = (double)v;
+        }
+    }
+}
+template <bool PROCJF, bool GREC>
+__global__ __launch_bounds__(kTvrThreads) void k_try_velrot2_f32(TvrArgs a) {
+    tvr2_body_f32<PROCJF, GREC>(a, blockIdx.z, blockIdx.x, threadIdx.x);
 }
 
 #ifdef EDGEHIP_EXPERIMENTS   // two KeyLines per thread in the reweighted evaluation: measured no faster (EDGEHIP_TVR_RW2)
@@ -3016,6 +3215,17 @@ static int launch_lm(edgehip_ctx *c, int slot_new, unsigned ops, bool two_chains
 static int launch_tvr2(edgehip_ctx *c, const TvrArgs &a, bool procjf) {
     ProfScope ps(c, PROF_B_TRYVELROT2);
     dim3 g(c->nblk_tvr, 1, c->plan.nseq), b(kTvrThreads);
+    if (c->tracker_f32) {
+        if (a.use_grec) {
+            if (procjf) hipLaunchKernelGGL((k_try_velrot2_f32<true, true>), g, b, 0, c->stream, a);
+            else hipLaunchKernelGGL((k_try_velrot2_f32<false, true>), g, b, 0, c->stream, a);
+        } else {
+            if (procjf) hipLaunchKernelGGL((k_try_velrot2_f32<true, false>), g, b, 0, c->stream, a);
+            else hipLaunchKernelGGL((k_try_velrot2_f32<false, false>), g, b, 0, c->stream, a);
+        }
+        EH_LAUNCH_CHECK();
+        return 0;
+    }
     if (a.use_grec) {
         if (procjf) hipLaunchKernelGGL((k_try_velrot2<true, true>), g, b, 0, c->stream, a);
         else hipLaunchKernelGGL((k_try_velrot2<false, true>), g, b, 0, c->stream, a);
@@ -3090,7 +3300,7 @@ int minimizer_enqueue(edgehip_ctx *c, int slot_new, int slot_old, int fc_index) 
     // Small batches: an evaluation is held back until the LM step that follows it is known, and both go out as one launch.
     const bool fuse = c->persist_lm_max > 0 && c->plan.nseq <= c->persist_lm_max;
     // TrackerInitType = 2: the zero-init and the prior-init chain advance in the same launches (k_try_velrot2 / k_lm_step2)
-    const bool two_chains = p.tracker_init_type >= 2 && c->dual_init && !fuse && !c->tracker_f32;   // (the float tracker runs the launch chain)
+    const bool two_chains = p.tracker_init_type >= 2 && c->dual_init && !fuse;
     const unsigned begin_ops = two_chains ? (LM_BEGIN | LM_BEGIN2 | LM_SETUP_X | LM_PHASE_BC)
                                           : (LM_BEGIN | LM_SETUP_X | (p.tracker_init_type >= 2 ? LM_PHASE_A : LM_PHASE_BC));
     const bool begin_rides = c->plan.nseq <= 64;

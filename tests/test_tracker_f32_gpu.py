@@ -56,7 +56,7 @@ def test_minimizer_rv_float_against_the_reference_float_instantiation(w, h, init
     assert np.max(np.abs(X - Xr)) <= tol, (X, Xr, tol)
     assert rel_err(g.score, ref["F"]) < 1e-4
     assert rel_err(np.array(g.P_V[:]).reshape(3, 3), ref["RVel"]) < 1e-3 and rel_err(np.array(g.P_W[:]).reshape(3, 3), ref["RW0"]) < 1e-3
-    assert g.minimizer_evals == (12 if init_type == 2 else 6)
+    assert g.minimizer_evals == (12 if init_type == 2 else 6)      # (init type 2: six of the twelve in three two-chain launches, k_try_velrot2_f32)
     # what the float tracker returns IS float: V, W are float values exactly (X is a Vector<6, float> in the reference)
     assert np.array_equal(X, X.astype(np.float32).astype(np.float64))
     kl_ref = orc.keylines(so)

@@ -1,6 +1,6 @@
 """How close is one TryVelRot evaluation to the reference's?  Prints max relative errors of F, J^T J, J^T F and whether the
 residual memory is bit-identical, for the three template variants at three states (the fixture of tests/test_stage_b_gpu.py).
-Run on the GPU box with the library under test in rebvo_amd/lib (tools/experiments/gpu_r04_s.sh)."""
+Run on the GPU box with the library under test in rebvo_amd/lib (tools/experiments/CALLS.md: r04_s)."""
 import os, sys
 import numpy as np
 sys.path.insert(0, os.path.join(os.path.dirname(__file__), "..", "..", "tests"))
