@@ -6,7 +6,7 @@ def write_global_config(path, p, log_file="", tray_file="", save_log=0, camera_t
     `drop` lists "Section/Key" entries to leave out (missing-key error tests).  `imu` = dict(mode=1|2, file=..., se3=...,
     time_scale=..., plus any key of the &IMU section to override) switches the IMU branch on.  `stereo` = dict(dir=..., file=...,
     ppx=, ppy=, zfx=, zfy=) sets StereoAvaiable with the pair camera's list and the &Stereo intrinsics.  `gpu` = dict(device=,
-    group=, size=, mono=) writes the optional &GPU section (Device, BatchGroup, BatchSize, MonoUpload: rebvo_amd/host/include/rebvo/rebvo.h).
+    group=, size=, mono=, tracker_precision=) writes the optional &GPU section (Device, BatchGroup, BatchSize, MonoUpload, TrackerPrecision: rebvo_amd/host/include/rebvo/rebvo.h).
     `affinity` = (CamaraT1, CamaraT2, CamaraT3) writes &ProcesorConfig with SetAffinity=1."""
     sec = {
         "Detector": [("Sigma0", p.sigma0), ("KSigma", p.ksigma), ("ReferencePoints", p.reference_points),
@@ -54,7 +54,8 @@ def write_global_config(path, p, log_file="", tray_file="", save_log=0, camera_t
     if affinity is not None:
         sec["ProcesorConfig"] = [("SetAffinity", 1), ("CamaraT1", affinity[0]), ("CamaraT2", affinity[1]), ("CamaraT3", affinity[2])]
     if gpu is not None:
-        sec["GPU"] = [(k_, gpu[g_]) for k_, g_ in (("Device", "device"), ("BatchGroup", "group"), ("BatchSize", "size"), ("MonoUpload", "mono")) if g_ in gpu]
+        sec["GPU"] = [(k_, gpu[g_]) for k_, g_ in (("Device", "device"), ("BatchGroup", "group"), ("BatchSize", "size"), ("MonoUpload", "mono"),
+                                                       ("TrackerPrecision", "tracker_precision")) if g_ in gpu]
     with open(path, "w") as f:
         f.write("// generated by rebvo_amd/config.py\n")
         for name, items in sec.items():

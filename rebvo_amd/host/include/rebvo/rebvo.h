@@ -263,6 +263,10 @@ struct REBVOParameters {
     // extension: frames whose pixels all have R = G = B (a mono camera's, tripled to fit the RGB24 surface) cross PCIe as their 8-bit
     // plane when every frame of a step is such a frame (&GPU MonoUpload, default 1; src/mono_pack.cpp, batch_group.cpp)
     bool GpuMonoUpload = true;
+    // &GPU TrackerPrecision (64, or 32): which instantiation of the tracker the device runs — global_tracker::Minimizer_RV<double> (the x86
+    // reference, rebvo_second_t.cpp:346) or Minimizer_RV<float> (what a USE_NE10 build of the reference runs, :339-343) — the run-time form of
+    // the reference's compile-time switch (edgehip_set_tracker_precision).  ImuMode 0 only; members of a batch group must agree.
+    int GpuTrackerPrecision = 64;
 };
 
 // Filter state SecondThread keeps in the IMU branch (reference include/rebvo/rebvo.h:239-290, same member names).

@@ -89,6 +89,7 @@ public:
     std::string name;
     int cap = 0, device = 0;
     edgehip_params hp;
+    int tracker_bits = 64;         // &GPU TrackerPrecision of the member that created the context
     bool imu_mode = false;         // every member has ImuMode 1 or 2: the context runs the device-side IMU branch (edgehip_imu_enable)
     edgehip_imu_params ip;
     std::vector<edgehip_imu_integrated> imu_in;   // [cap] what edgehip_set_imu takes for the step being launched
@@ -196,6 +197,8 @@ bool REBVO::groupAttach() {
         const double tc0 = detail::now_s();
         int rc = edgehip_create(&hp, want, 3, params.GpuDevice, &g->hip);
         if (dbg) std::fprintf(stderr, "REBVO(hip) group '%s': edgehip_create(%d sequences) took %.2f s\n", g->name.c_str(), want, detail::now_s() - tc0);
+        g->tracker_bits = params.GpuTrackerPrecision;
+        if (rc == 0 && params.GpuTrackerPrecision != 64) rc = edgehip_set_tracker_precision(g->hip, params.GpuTrackerPrecision);
         if (rc == 0 && imu_mode) rc = edgehip_imu_enable(g->hip, &ip);
         if (rc == 0) rc = edgehip_set_nav_log(g->hip, BatchGroup::kNavLog);
         g->frame_bytes = (size_t)params.ImageSize.w * params.ImageSize.h * sizeof(RGB24Pixel);
@@ -220,6 +223,8 @@ bool REBVO::groupAttach() {
     } else {
         if (g->cap != want || g->device != params.GpuDevice || std::memcmp(&g->hp, &hp, sizeof hp) != 0)
             return fail("REBVO(hip): BatchGroup '" + g->name + "': every member needs the same BatchSize, Device, camera and detector / tracker parameters");
+        if (g->tracker_bits != params.GpuTrackerPrecision)
+            return fail("REBVO(hip): BatchGroup '" + g->name + "': every member needs the same &GPU TrackerPrecision");
         if (g->imu_mode != imu_mode || (imu_mode && std::memcmp(&g->ip, &ip, sizeof ip) != 0))
             return fail("REBVO(hip): BatchGroup '" + g->name + "': every member needs the same ImuMode (0, or 1 / 2) and the same &IMU filter parameters");
     }

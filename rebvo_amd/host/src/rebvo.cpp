@@ -302,6 +302,8 @@ REBVO::REBVO(const char *configFile)
     {
         int mono = 1;
         if (config.get("GPU", "MonoUpload", mono, false)) p.GpuMonoUpload = mono != 0;
+        int tprec = 64;
+        if (config.get("GPU", "TrackerPrecision", tprec, false)) p.GpuTrackerPrecision = tprec;
     }
     construct();
 }
@@ -431,6 +433,7 @@ bool REBVO::Init() {
     hp.stereo_available = params.StereoAvaiable ? 1 : 0;
     // ring of 3 frame slots; with a stereo pair one more slot, behind the ring, holds the pair image's edge map
     int rc = edgehip_create(&hp, 1, params.StereoAvaiable ? 4 : 3, params.GpuDevice, &hip);
+    if (rc == 0 && params.GpuTrackerPrecision != 64) rc = edgehip_set_tracker_precision(hip, params.GpuTrackerPrecision);   // (refused with ImuMode > 0 / a stereo rig)
     if (rc == 0 && params.StereoAvaiable) {
         // search radius 100 (rebvo_second_t.cpp:473); with the IMU branch the host drives the stereo stages itself
         rc = edgehip_set_slot_camera(hip, 3, params.pp_x_stereo, params.pp_y_stereo, params.z_f_x_stereo, params.z_f_y_stereo);

@@ -45,10 +45,12 @@ def _run(tmp_path, frames, n_obj, n_fr, extra, tag="run", gpu=None, env=None, pa
     return js, [np.loadtxt(f"{prefix}.{i}.txt", ndmin=2) for i in range(n_obj)], r.stdout
 
 
-def _ctypes_batch(frames, n_obj, n_fr, tint=None, params=None):
+def _ctypes_batch(frames, n_obj, n_fr, tint=None, params=None, tracker_bits=64):
     """The same sequences as one batch through the C-ABI: per step the nav records, and the old slot's KeyLines after the step.
     tint = (object, frame): that frame's first byte flipped, as surface_replay --tint does."""
     eh = edgehip.EdgeHip(params if params is not None else edgehip.euroc_params(W, H), nseq=n_obj, nslots=3, device=0)
+    if tracker_bits != 64:
+        eh.set_tracker_precision(tracker_bits)
     navs, kls = [], []
     for k in range(n_fr):
         batch = np.stack([frames[tri(k + i, len(frames))] for i in range(n_obj)])
@@ -389,3 +391,17 @@ def test_tum_configuration_with_undistortion_through_the_surface(tmp_path):
                 assert np.allclose(row[5:8], rn[j].Pos[:], atol=1e-6 * path + 1e-9), (i, j)
                 assert np.allclose(row[8:11], rn[j].PoseLie[:], atol=1e-7), (i, j)
         orc.close()
+
+
+def test_the_float_tracker_behind_the_surface(tmp_path):
+    """&GPU TrackerPrecision=32 (the run-time form of the reference's USE_NE10 switch, rebvo_second_t.cpp:339-346): three objects in a group
+    run Minimizer_RV<float> on the device; every object's callback rows are those of the ctypes batch with edgehip_set_tracker_precision(32),
+    bit for bit — and not those of the fp64 tracker.  (Parity of the float tracker itself: tests/test_tracker_f32_gpu.py.)"""
+    n_obj, n_fr, pool = 3, 7, 6
+    frames = [f for f, _, _ in synth.billboard_sequence(W, H, pool, seed=41)]
+    js, dumps, out = _run(tmp_path, frames, n_obj, n_fr, [], gpu=dict(group="f32", size=n_obj, tracker_precision=32))
+    navs, kls = _ctypes_batch(frames, n_obj, n_fr, tracker_bits=32)
+    for i in range(n_obj):
+        _check_against_batch(dumps[i], navs, kls, i, n_fr - 1)
+    navs64, _ = _ctypes_batch(frames, n_obj, n_fr)
+    assert any(not np.array_equal(dumps[0][j][5:8], navs64[j][0][0]) for j in range(1, n_fr - 1))
