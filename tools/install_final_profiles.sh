@@ -1,9 +1,9 @@
 #!/bin/bash
-# gpurun_out/<tag> (a full tools/gpu_round5.sh run) -> the tracked records under profiles/: the stamped counters the bench line reads
+# gpurun_out/<tag> (a full tools/gpu_round.sh run) -> the tracked records under profiles/: the stamped counters the bench line reads
 # (pmc_latest.json, sq_latest.json) and the round's final bench line, kernel stats, counter tables, GPU suite tail and smoke log.
-#   tools/install_final_profiles.sh r05_final4 [r05_final]
+#   tools/install_final_profiles.sh r06_final [r06_final]
 set -e
-SRC=gpurun_out/$1; P=profiles/${2:-r05_final}
+SRC=gpurun_out/$1; P=profiles/${2:-r06_final}
 cp $SRC/pmc.json profiles/pmc_latest.json
 python tools/sq_summary.py $SRC/sq.json profiles/sq_latest.json ${P}_sq_counters.txt > /dev/null
 cp $SRC/bench.json ${P}_bench_line.json
