@@ -18,7 +18,9 @@ with tempfile.TemporaryDirectory() as td:
         n = int(rng.integers(1, 17)); k = int(rng.integers(4, 40)); t = int(rng.integers(1, min(n, 8) + 1))
         mono = int(rng.integers(0, 2))
         cfg = f"{td}/cfg{it}"
-        config.write_global_config(cfg, edgehip.euroc_params(W, H), gpu=dict(mono=mono))
+        gpu = dict(mono=mono)
+        if rng.random() < 0.25: gpu["tracker_precision"] = 32          # (round 6) the float tracker behind the surface
+        config.write_global_config(cfg, edgehip.euroc_params(W, H), gpu=gpu)
         args = [exe, cfg, td + "/frames.rgb24", "8", str(n), str(k), "1", "0.05", "--threads", str(t), "--group", f"s{it}"]
         if rng.random() < 0.5: args.append("--callback")
         if n > 1 and rng.random() < 0.5: args += ["--leave", f"{int(rng.integers(0, n))}:{int(rng.integers(1, k))}"]
