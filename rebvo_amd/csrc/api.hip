@@ -1300,7 +1300,16 @@ int edgehip_export_keylines(edgehip_ctx *c, int n, const int32_t *seqs, int *tic
     constexpr int R = edgehip_ctx::KlExport::R;
     const size_t cap = (size_t)c->plan.cap;
     if (!x->stream) {
-        EH_CHECK(hipStreamCreateWithFlags(&x->stream, hipStreamNonBlocking));
+        // Which hardware queue the copies land on decides what waits behind them (HIP maps a context's streams onto four queues per priority
+        // class; stage_imu.hip imu_stream_create).  Measured with eight cameras that take every frame's KeyLines: ImuMode 0 — default
+        // priority 16.8-17.2 k frames/s, highest 5.6 k (the copies' event waits stall the frame streams); ImuMode 2, where the frame streams
+        // are idle half the step under the scale filter — default 5.5-6.1 k, highest 11.3 k.  So: a queue class of its own beside the IMU branch.
+        int least = 0, greatest = 0;
+        if (!(c->imu_enabled && hipDeviceGetStreamPriorityRange(&least, &greatest) == hipSuccess && least != greatest &&
+              hipStreamCreateWithPriority(&x->stream, hipStreamNonBlocking, greatest) == hipSuccess)) {
+            (void)hipGetLastError();
+            EH_CHECK(hipStreamCreateWithFlags(&x->stream, hipStreamNonBlocking));
+        }
         for (int i = 0; i < R; i++) {
             EH_CHECK(hipEventCreateWithFlags(&x->ev_pack[i], hipEventDisableTiming));
             EH_CHECK(hipEventCreateWithFlags(&x->ev_done[i], hipEventDisableTiming));

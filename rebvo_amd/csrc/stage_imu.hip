@@ -440,6 +440,21 @@ using namespace edgehip;
 
 extern "C" {
 
+// The scale filter is ONE long kernel per frame (~0.5 ms, a thread per sequence) that is meant to run UNDER the next frames' kernels.  HIP
+// maps its streams onto a handful of hardware queues (four by default); a context has up to six streams (frames, stage A, uploads, the
+// nav log, the KeyLine export, this one), and whichever stream lands on the filter's queue waits behind it — behind a batch group
+// (upload stream + log stream in use) the next frame's copy / stage A did: a step of eight sequences took frame + filter = 1.1 ms instead
+// of max(frame, filter) = 0.58.  A stream of another PRIORITY gets a hardware queue of its own kind: the filter runs at the lowest
+// priority (it has a whole frame of slack), everything else stays where it was.
+static bool imu_stream_create(hipStream_t *st) {
+    int least = 0, greatest = 0;
+    if (hipDeviceGetStreamPriorityRange(&least, &greatest) == hipSuccess && least != greatest &&
+        hipStreamCreateWithPriority(st, hipStreamNonBlocking, least) == hipSuccess)
+        return true;
+    (void)hipGetLastError();
+    return hipStreamCreateWithFlags(st, hipStreamNonBlocking) == hipSuccess;
+}
+
 int edgehip_imu_enable(edgehip_ctx *c, const edgehip_imu_params *imu) {
     EH_ENTER(c);
     if (!imu) return EDGEHIP_ERR_ARG;
@@ -457,7 +472,7 @@ int edgehip_imu_enable(edgehip_ctx *c, const edgehip_imu_params *imu) {
                   hipMalloc(&nav_dev, sizeof(edgehip_nav_imu) * B) == hipSuccess &&
                   hipHostMalloc(&pin_in, sizeof(edgehip_imu_integrated) * B * 8, hipHostMallocDefault) == hipSuccess &&
                   hipHostMalloc(&pin_nav, sizeof(edgehip_nav_imu) * B, hipHostMallocDefault) == hipSuccess &&
-                  hipStreamCreateWithFlags(&st, hipStreamNonBlocking) == hipSuccess;
+                  imu_stream_create(&st);
         for (int i = 0; ok && i < 6; i++) ok = hipEventCreateWithFlags(&ev[i], hipEventDisableTiming) == hipSuccess;
         if (ok) ok = hipMemsetAsync(nav_dev, 0, sizeof(edgehip_nav_imu) * B, c->stream) == hipSuccess;
         if (!ok) {

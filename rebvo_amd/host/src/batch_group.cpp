@@ -722,6 +722,8 @@ void REBVO::BatchGroup::threadMain() {
             if (st.running) st.cf->quit = true;
     }
     if (const char *e = getenv("REBVO_GROUP_CB_DEPTH")) cb_depth = std::max(1, std::min(2, atoi(e)));
+    int base_depth = imu_mode ? 3 : 2;
+    if (const char *e = getenv("REBVO_GROUP_DEPTH")) base_depth = std::max(1, std::min(3, atoi(e)));   // (A/B measurements)
     long step = 0;                       // frames of the context enqueued so far
     struct InFlight { long step; int slot; };
     std::vector<InFlight> pending;       // steps enqueued and not yet completed, oldest first (at most 2)
@@ -762,7 +764,10 @@ void REBVO::BatchGroup::threadMain() {
         have_next = false;
         bool callbacks = false;
         for (Seat &st : seats) callbacks |= st.running && st.cf->haveCallBack();
-        const size_t depth = callbacks ? (size_t)cb_depth : 2;
+        // steps in flight.  ImuMode > 0: a frame's record exists only behind the scale filter, which runs on a stream of its own for ~0.5 ms per
+        // step (one thread per sequence) under the NEXT frames — two steps of slack left the device idle between filters (1.09 ms per step for
+        // eight members against 0.58 through the C-ABI); three cover it
+        const size_t depth = callbacks && cb_depth < 2 ? 1 : (size_t)base_depth;
         const int slot = slot_next;
         std::array<double, 5> tl{};
         tl[0] = detail::now_s();
