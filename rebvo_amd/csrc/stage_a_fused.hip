@@ -104,6 +104,9 @@ __device__ __forceinline__ v2f ring_row_general(TapRing<L> &H, int P, v2f vr, v2
 
 // build_mask's plane fit on the 5x5 DoG window (edge_finder.cpp:139-159) from the LDS ring: ro[k] = element offset of
 // window row k, x = column.  Same operation order as k_detect (TooN dot product, k = 0..24).
+#ifndef EDGEHIP_FIT_SHARED_PRODUCT
+#define EDGEHIP_FIT_SHARED_PRODUCT 1
+#endif
 struct FitOut { bool cand; float mx, my, xs, ys; };
 // The 11 coefficients of the pseudo inverse that are not zero / not repeated (row 0 depends on the window column only, row 1
 // on the window row, row 2 is constant: checked at create), loaded ONCE by the wave that fits — a load inside the fit would
@@ -137,9 +140,27 @@ __device__ __forceinline__ FitOut fit_eval(const float (&v)[25], const FitCoef &
         // ten terms are skipped; the sums keep their bits.  Same operation order as k_detect (TooN dot product, k = 0..24).
         for (int j = 0; j < 5; j++) {
             const double yv = (double)v[i * 5 + j];
+#if EDGEHIP_FIT_SHARED_PRODUCT
+            // The coefficients of the symmetric 5x5 window are {-2u, -u, 0, u, 2u} along a row of PInv's row 0 (and down a column of
+            // its row 1) and 2u everywhere in row 2, u = fl(1/50) (fused_supported checks exactly that): a scaling by two is exact, so
+            // the three rounded products of a window value are -+q, -+2q and 2q with ONE rounded product q = u * yv, and a sum plus
+            // the exact 2q rounds once — as an fma of (q, 2, sum) — to what the reference's sum plus its rounded product rounds to.
+            const double q = pc0[3] * yv;
+            if (j == 0) t0 = __builtin_fma(q, -2.0, t0);
+            if (j == 1) t0 = t0 - q;
+            if (j == 3) t0 = t0 + q;
+            if (j == 4) t0 = __builtin_fma(q, 2.0, t0);
+            if (i == 0) t1 = __builtin_fma(q, -2.0, t1);
+            if (i == 1) t1 = t1 - q;
+            if (i == 3) t1 = t1 + q;
+            if (i == 4) t1 = __builtin_fma(q, 2.0, t1);
+            t2 = __builtin_fma(q, 2.0, t2);
+            (void)pc1; (void)pc2;
+#else
             if (j != 2) t0 += pc0[j] * yv;
             if (i != 2) t1 += pc1[i] * yv;
             t2 += pc2 * yv;
+#endif
         }
     }
     FitOut o;
@@ -244,6 +265,9 @@ __global__ __launch_bounds__(512) void k_stage_a_fused(FusedArgs a) {
 #ifndef EDGEHIP_FUSED_FITPRIO
 #define EDGEHIP_FUSED_FITPRIO 2
 #endif
+#ifndef EDGEHIP_SCAN_ASM
+#define EDGEHIP_SCAN_ASM 0
+#endif
     const int scan_wave = NW >= EDGEHIP_FUSED_SCANW ? EDGEHIP_FUSED_SCANW : NW;
     if (wave == scan_wave) {
         // ---- the scan wave: the serial left-to-right prefix of iimage::load (iimage.cpp:56-61) for the 4 RB rows of the buffer
@@ -280,7 +304,11 @@ __global__ __launch_bounds__(512) void k_stage_a_fused(FusedArgs a) {
             auto step = [&](float4 (&v)[4], float4 (&nx)[4], int ss) __attribute__((always_inline)) {
                 load(nx, ss + 1);
 // the chain runs through the elements' own registers (x' = carry + x, y' = x' + y, ...): one instruction per element
+#if EDGEHIP_SCAN_ASM
 #define EH_ADDC(DST, PREV) asm volatile("v_add_f32 %0, %1, %0" : "+v"(DST) : "v"(PREV));
+#else
+#define EH_ADDC(DST, PREV) DST = (PREV) + DST;
+#endif
 #define EH_ADD4(I, CARRY) EH_ADDC(v[I].x, CARRY) EH_ADDC(v[I].y, v[I].x) EH_ADDC(v[I].z, v[I].y) EH_ADDC(v[I].w, v[I].z)
 #define EH_PHASE(P)                                                                                  \
     {                                                                                                \
@@ -824,6 +852,13 @@ bool fused_supported(const edgehip_ctx *c) {
     if (c->p.plane_fit_size != 2) return false;
     if ((pl.w & 3) != 0) return false;                       // column pairs, float4 scan steps
     if (c->pinv_host[2] != 0.0 || c->pinv_host[25 + 10] != 0.0) return false;   // plane_fit5 skips these terms
+    {   // ... and forms the three products of a window value from one (fit_eval): PInv = {-2u, -u, 0, u, 2u} x / y, 2u
+        const double *pv = c->pinv_host, u = pv[3];
+        const double want[5] = {-2 * u, -u, 0.0, u, 2 * u};
+        for (int j = 0; j < 5; j++)
+            if (pv[j] != want[j] || pv[25 + 5 * j] != want[j]) return false;
+        if (pv[50] != 2 * u || !(u > 0)) return false;
+    }
     const int nw = fused_col_waves(pl.w);
     if (nw + 2 > 8) return false;                           // column waves + scan wave + fit wave; 256 VGPRs per thread need <= 8 waves per workgroup
     if (pl.w > 1023) return false;                          // candidate codes carry x in 10 bits

@@ -397,7 +397,7 @@ struct DirArgs {
 // tracker returned NaN (skip_match) gets the forward copy alone, as the reference's FordwardMatch has already happened by then.
 template <bool FUSED, bool FILL>
 __device__ __forceinline__ void directed_body(const DirArgs &a) {
-    const int seq = blockIdx.z, ik = blockIdx.x * 256 + threadIdx.x;
+    const int seq = blockIdx.z, ik = blockIdx.x * (int)blockDim.x + threadIdx.x;
     SeqDev *sq = a.seq + seq;
     const bool searching = !sq->skip_match;   // block-uniform
     if (!FUSED && !searching) return;
@@ -1405,7 +1405,13 @@ int directed_enqueue(edgehip_ctx *c, int slot_new, int slot_old, bool fused) {
     a.stereo_mode = c->p.stereo_available != 0;
     a.win = c->fwd_win; a.cap = pl.cap;
     a.rot = fused ? rot_of(c, slot_old) : RotOut{nullptr, nullptr, nullptr, nullptr};
-    const dim3 g((pl.cap + 255) / 256, 1, pl.nseq), b(256);
+    // Block size of the walk (EDGEHIP_DIRECTED_BLOCK, a build option for A/Bs): a wave is as long as its longest lane's walk and a block
+    // holds its wave slots until its last wave is done
+#ifndef EDGEHIP_DIRECTED_BLOCK
+#define EDGEHIP_DIRECTED_BLOCK 128
+#endif
+    constexpr int kDirBlock = EDGEHIP_DIRECTED_BLOCK;
+    const dim3 g((pl.cap + kDirBlock - 1) / kDirBlock, 1, pl.nseq), b(kDirBlock);
     if (fused) {
         if (c->fwd_fill[slot_new]) hipLaunchKernelGGL(k_directed_fused<true>, g, b, 0, c->stream, a);
         else hipLaunchKernelGGL(k_directed_fused<false>, g, b, 0, c->stream, a);
