@@ -56,6 +56,29 @@ namespace edgehip {
 
 typedef float v2f __attribute__((ext_vector_type(2)));   // the two adjacent columns of a thread: packed fp32 math
 
+// Timing experiments (-DEDGEHIP_FUSED_TSTAMP=k builds only; tools/experiments/exp_fused_where.sh, exp_fused_roles.sh): kn_out returns a time instead of
+// kn.  k = 1..6: an interval of the workgroup's life in 10 ns units (1 set-up, 2 ticks 0-9, 3 ticks 10-109, 4 ticks 110-end, 5 after the loop, 6 all).
+// k = RX: a role's cycles per tick, mean over ticks 10..109 — R: 1 / 4 / 5 = column waves 0 / 2 / 5, 2 = the scan wave, 3 = the fit wave; X: 1 work before
+// the middle barrier, 2 wait there, 3 work before the end barrier, 4 wait there.  EH_TS_BAR stands where the roles' loops call lds_barrier().
+#ifdef EDGEHIP_FUSED_TSTAMP
+#define EH_TS_DECL long long tsw[4] = {0, 0, 0, 0}, ts_mark = 0;
+#define EH_TS_BEGIN(t) if ((t) >= 10 && (t) < 110) ts_mark = clock64();
+#define EH_TS_BAR(i, t)                                                   \
+    {                                                                     \
+        const long long ts_x = clock64();                                 \
+        lds_barrier();                                                    \
+        const long long ts_y = clock64();                                 \
+        if ((t) >= 10 && (t) < 110) { tsw[i] += ts_x - ts_mark; tsw[(i) + 1] += ts_y - ts_x; } \
+        ts_mark = ts_y;                                                   \
+    }
+#define EH_TS_OUT(role) if (lane == 0 && EDGEHIP_FUSED_TSTAMP / 10 == (role)) a.kn_out[seq] = (int)(tsw[EDGEHIP_FUSED_TSTAMP % 10 - 1] / 100);
+#else
+#define EH_TS_DECL
+#define EH_TS_BEGIN(t)
+#define EH_TS_BAR(i, t) lds_barrier();
+#define EH_TS_OUT(role)
+#endif
+
 // Running column sums of a level's tap columns x+r (a) and x-r-1 (b), for the last L integral rows, as a ring with static
 // positions: row q of the unrolled tick pair lives at position q % L.
 template <int L>
@@ -201,6 +224,9 @@ __global__ __launch_bounds__(512) void k_stage_a_fused(FusedArgs a) {
 #endif
 
     extern __shared__ __attribute__((aligned(16))) float smem[];
+#ifdef EDGEHIP_FUSED_TSTAMP
+    long long ts_start = wall_clock64(), ts_pro = 0, ts_a = 0, ts_b = 0, ts_loop = 0;
+#endif
     const int w = W ? W : a.w, h = a.h;
     const int WP = fused_row_stride(w);
     const int tid = threadIdx.x, lane = tid & 63;
@@ -249,6 +275,9 @@ __global__ __launch_bounds__(512) void k_stage_a_fused(FusedArgs a) {
         thr_d = uni(gt2 * gt2);
     }
     __syncthreads();
+#ifdef EDGEHIP_FUSED_TSTAMP
+    ts_pro = wall_clock64();
+#endif
 
     // number of ticks: the tests of tick t cover rows (t-6)*RB - LB - 2 + [0, RB), their KeyLines are emitted in tick t+1
     const int t_last = 6 + (h - 1 + LB + 2) / RB;                   // tick that tests row h-1
@@ -265,6 +294,9 @@ __global__ __launch_bounds__(512) void k_stage_a_fused(FusedArgs a) {
 #ifndef EDGEHIP_FUSED_FITPRIO
 #define EDGEHIP_FUSED_FITPRIO 2
 #endif
+#ifndef EDGEHIP_FUSED_SCANPRIO
+#define EDGEHIP_FUSED_SCANPRIO 3
+#endif
 #ifndef EDGEHIP_SCAN_ASM
 #define EDGEHIP_SCAN_ASM 0
 #endif
@@ -280,7 +312,7 @@ __global__ __launch_bounds__(512) void k_stage_a_fused(FusedArgs a) {
         // else (the earlier form — every lane running the whole chain and selecting its four sums — spent 28 vector
         // instructions per 16 floats, 13-15 cycles per element; this one is bound by the chain).  After the last chunk the
         // row's total goes into the right pad (taps right of w-1).
-        __builtin_amdgcn_s_setprio(3);
+        __builtin_amdgcn_s_setprio(EDGEHIP_FUSED_SCANPRIO);
         static_assert(4 * RB <= 16, "one quad per row");
         const int n16 = w >> 4;                 // full 16-float chunks
         const int rem4 = (w & 15) >> 2;         // float4s of the last, partial chunk (w % 4 == 0)
@@ -290,7 +322,9 @@ __global__ __launch_bounds__(512) void k_stage_a_fused(FusedArgs a) {
         const int srow = lane >> 2, sq = lane & 3;
         const bool on = srow < 4 * RB && !(ABL & 1);
 #define EH_BC(val, k) __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(val), (k) * 0x55, 0xf, 0xf, false))
+        EH_TS_DECL
         for (int t = 0; t < nticks; t++) {
+            EH_TS_BEGIN(t)
             float *row = s_set + ((size_t)((t + 1) & 1) * 4 * RB + (srow < 4 * RB ? srow : 0)) * WP + PAD;
             float acc = 0.f;
             float4 cur[4], nxt[4];
@@ -358,11 +392,12 @@ __global__ __launch_bounds__(512) void k_stage_a_fused(FusedArgs a) {
             };
             if (on) load(cur, 0);
             steps64(0, half_ss);
-            lds_barrier();
+            EH_TS_BAR(0, t)
             steps64(half_ss, nss);
             if (on && sq == 3) *reinterpret_cast<float4 *>(row + w) = make_float4(acc, acc, acc, acc);
-            lds_barrier();
+            EH_TS_BAR(2, t)
         }
+        EH_TS_OUT(2)
 #undef EH_BC
     } else if (wave == NW + 1) {
         // ---- the fit wave: the sparse part of build_mask (edge_finder.cpp:139-209), one tick behind the column waves ----------
@@ -387,7 +422,9 @@ __global__ __launch_bounds__(512) void k_stage_a_fused(FusedArgs a) {
         auto below = [&](unsigned long long m) __attribute__((always_inline)) {   // set bits of a wave mask below this lane
             return (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
         };
+        EH_TS_DECL
         for (int t = 0; t < nticks; t++) {
+            EH_TS_BEGIN(t)
             // the rows tested in tick t-1: ytest0 + [0, RB); their 5x5 DoG windows sit in ring slots rq - 4 .. rq + RB - 1 with
             // rq = slot of tick t-1's first DoG row, untouched by the rows tick t writes (slots rq + RB ..)
             const int ytest0 = (t - 7) * RB - LB - 2;
@@ -497,10 +534,11 @@ __global__ __launch_bounds__(512) void k_stage_a_fused(FusedArgs a) {
             };
             const int half = nchunks >> 1;
             chunks(0, half);
-            lds_barrier();
+            EH_TS_BAR(0, t)
             chunks(half, nchunks);
-            lds_barrier();
+            EH_TS_BAR(2, t)
         }
+        EH_TS_OUT(3)
         // end of frame: reEstimateThresh's extremes (edge_finder.cpp:376-382) and the candidate count
 #pragma unroll
         for (int o = 32; o > 0; o >>= 1) {
@@ -576,8 +614,10 @@ __global__ __launch_bounds__(512) void k_stage_a_fused(FusedArgs a) {
     // per 1024 frames, profiles/r04_k_fused_branch_free_ab.txt: scalar compares and uniform branches ride along with the other wave's
     // vector instructions for free, a second 16 KB loop body does not.  What did pay is below: no divergent region around the
     // LDS stores and the neighbour reads of the two gates.)
+    EH_TS_DECL
     auto tick = [&](const int t, auto tt_tag) __attribute__((always_inline)) {
         constexpr int TT = decltype(tt_tag)::value;     // t & 1: the buffer set, and the half of the long tap rings this tick writes
+        EH_TS_BEGIN(t)
         constexpr int set = TT;
         // ================= phase 1a: img_mask_kl rows of the rows tested in tick t-2 ====================================
         // (the fit wave put the ids of their KeyLines into s_res during tick t-1), written once: KeyLine id or -1
@@ -661,7 +701,7 @@ __global__ __launch_bounds__(512) void k_stage_a_fused(FusedArgs a) {
                 s_edge2[((size_t)j * (NW + 2) + wv + 1) * 2 + (lane ? 1 : 0)] =
                     make_uint2(__float_as_uint(lane ? iv[j + 1].y : iv[j + 1].x), (ppack >> (2 * j)) & 3u);
         }
-        lds_barrier();
+        EH_TS_BAR(0, t)
         // ================= phase 2 ==============================================================================================
         // RGB rows of batch t: the loads fly under the stores and tests below and are used at the end of the phase
         uint2 pre[RB];                          // the 8 bytes that hold the two pixels' 6
@@ -809,12 +849,22 @@ __global__ __launch_bounds__(512) void k_stage_a_fused(FusedArgs a) {
         }
         rq0 += RB;
         rq0 -= rq0 >= RING ? RING : 0;
-        lds_barrier();
+        EH_TS_BAR(2, t)
     };
     for (int t = 0; t < nticks; t += 2) {
+#ifdef EDGEHIP_FUSED_TSTAMP
+        if (t == 10) ts_a = wall_clock64();
+        if (t == 110) ts_b = wall_clock64();
+#endif
         tick(t, std::integral_constant<int, 0>{});
         tick(t + 1, std::integral_constant<int, 1>{});
     }
+#ifdef EDGEHIP_FUSED_TSTAMP
+    ts_loop = wall_clock64();
+    if (wv == 0) { EH_TS_OUT(1) }
+    if (wv == 2) { EH_TS_OUT(4) }
+    if (wv == 5) { EH_TS_OUT(5) }
+#endif
 
     }   // column waves
     __syncthreads();
@@ -828,9 +878,20 @@ __global__ __launch_bounds__(512) void k_stage_a_fused(FusedArgs a) {
         a.tresh_out[seq] = tresh;
         sq->l_kl_num = kn;
         sq->kn_new = kn;
+#if !defined(EDGEHIP_FUSED_TSTAMP) || EDGEHIP_FUSED_TSTAMP < 10
         a.kn_out[seq] = kn;
+#endif
         sq->nm_max = nm_mx;
         sq->nm_min = nm_mn;
+#ifdef EDGEHIP_FUSED_TSTAMP
+        {
+            const long long ts_end = wall_clock64();
+            const int sel = EDGEHIP_FUSED_TSTAMP;
+            const long long v = sel == 1 ? ts_pro - ts_start : sel == 2 ? ts_a - ts_pro : sel == 3 ? ts_b - ts_a : sel == 4 ? ts_loop - ts_b
+                              : sel == 5 ? ts_end - ts_loop : ts_end - ts_start;
+            if (sel < 10) a.kn_out[seq] = (int)v;
+        }
+#endif
     }
 }
 
