@@ -127,6 +127,9 @@ __device__ __forceinline__ v2f ring_row_general(TapRing<L> &H, int P, v2f vr, v2
 
 // build_mask's plane fit on the 5x5 DoG window (edge_finder.cpp:139-159) from the LDS ring: ro[k] = element offset of
 // window row k, x = column.  Same operation order as k_detect (TooN dot product, k = 0..24).
+#ifndef EDGEHIP_FIT_INTERLEAVE
+#define EDGEHIP_FIT_INTERLEAVE 1
+#endif
 #ifndef EDGEHIP_FIT_SHARED_PRODUCT
 #define EDGEHIP_FIT_SHARED_PRODUCT 1
 #endif
@@ -150,7 +153,10 @@ __device__ __forceinline__ void fit_load(const float *s_dog, const int ro[5], in
 #pragma unroll
         for (int j = 0; j < 5; j++) v[i * 5 + j] = s_dog[ro[i] + x + j - 2];
 }
-__device__ __forceinline__ FitOut fit_eval(const float (&v)[25], const FitCoef &fc, float thr_d) {
+// between(i) runs after window row i's terms: the fit wave puts the steps of the NEXT chunks' list search there, so that the LDS round trip of a
+// step passes under a row's arithmetic instead of in front of the whole fit.
+template <class Between>
+__device__ __forceinline__ FitOut fit_eval(const float (&v)[25], const FitCoef &fc, float thr_d, Between between) {
     double t0 = 0, t1 = 0, t2 = 0;
     const double (&pc0)[5] = fc.pc0;
     const double (&pc1)[5] = fc.pc1;
@@ -185,6 +191,15 @@ __device__ __forceinline__ FitOut fit_eval(const float (&v)[25], const FitCoef &
             t2 += pc2 * yv;
 #endif
         }
+#if EDGEHIP_FIT_INTERLEAVE
+        // (empty statements that "use" the three sums: the row's arithmetic has to stand in front of the first, the next row's behind the second —
+        // left alone, the compiler lines up all five steps of the search and then the whole fit)
+        asm volatile("" : "+v"(t0), "+v"(t1), "+v"(t2));
+        between(i);
+        asm volatile("" : "+v"(t0), "+v"(t1), "+v"(t2));
+#else
+        between(i);
+#endif
     }
     FitOut o;
     o.cand = false;
@@ -494,15 +509,41 @@ __global__ __launch_bounds__(512) void k_stage_a_fused(FusedArgs a) {
 #endif
             // one chunk: evaluate the window in `wc` (requested one chunk earlier) while the next chunk's window lands in `wn`
             auto one_chunk = [&](int c, float (&wc)[25], float (&wn)[25]) __attribute__((always_inline)) {
+#if EDGEHIP_FIT_INTERLEAVE
+                    // the list search of chunk c + 2 (code_of), one step per window row of this chunk's fit; its first probe goes out
+                    // ahead of the next chunk's 25 window reads (LDS answers in order: a probe behind them would wait for all of them)
+                    const int li2 = (c + 2) * 64 + lane;
+                    int s_lo = 0, s_e = __shfl(seg_end, 15, 64), s_sh = 0;
+                    if (c + 1 < nchunks) request(code_nxt, wn);
+#else
                     if (c + 1 < nchunks) request(code_nxt, wn);
                     code_nn = code_of(c + 2);
                     __builtin_amdgcn_sched_barrier(0);
+#endif
                     const bool on = c * 64 + lane < ncand;
                     const int code = code_cur;
                     const int i = code >> 10, x = code & 1023;
                     FitOut f;
                     if (ABL & 256) { f.cand = (code & 1) != 0; f.mx = 3.f; f.my = 4.f; f.xs = 0.f; f.ys = 0.f; }
-                    else f = fit_eval(wc, fc, thr_d);
+#if EDGEHIP_FIT_INTERLEAVE
+                    else f = fit_eval(wc, fc, thr_d, [&](int i) __attribute__((always_inline)) {
+                        __builtin_amdgcn_sched_barrier(0);   // (the scheduler would gather the five steps in front of the arithmetic again)
+                        if (i == 0) { s_lo += s_e <= li2 ? 16 : 0; s_e = __shfl(seg_end, s_lo + 7, 64); }
+                        if (i == 1) { s_lo += s_e <= li2 ? 8 : 0; s_e = __shfl(seg_end, s_lo + 3, 64); }
+                        if (i == 2) { s_lo += s_e <= li2 ? 4 : 0; s_e = __shfl(seg_end, s_lo + 1, 64); }
+                        if (i == 3) { s_lo += s_e <= li2 ? 2 : 0; s_e = __shfl(seg_end, s_lo, 64); }
+                        if (i == 4) { s_lo += s_e <= li2 ? 1 : 0; s_sh = __shfl(seg_shift, s_lo, 64); }
+                        __builtin_amdgcn_sched_barrier(0);
+                    });
+                    if (ABL & 256) {   // (the search alone, for the timing experiment without the plane fit)
+                        s_lo = 0;
+                        for (int step = 16; step > 0; step >>= 1) s_lo += __shfl(seg_end, s_lo + step - 1, 64) <= li2 ? step : 0;
+                        s_sh = __shfl(seg_shift, s_lo, 64);
+                    }
+                    code_nn = li2 < ncand ? (int)clist[li2 + s_sh] : 2;
+#else
+                    else f = fit_eval(wc, fc, thr_d, [](int) {});
+#endif
                     const bool fin = on && f.cand;
                     const unsigned long long bal = __ballot(fin);
                     const int id = total + below(bal);
