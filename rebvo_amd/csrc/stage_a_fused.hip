@@ -127,9 +127,6 @@ __device__ __forceinline__ v2f ring_row_general(TapRing<L> &H, int P, v2f vr, v2
 
 // build_mask's plane fit on the 5x5 DoG window (edge_finder.cpp:139-159) from the LDS ring: ro[k] = element offset of
 // window row k, x = column.  Same operation order as k_detect (TooN dot product, k = 0..24).
-#ifndef EDGEHIP_FIT_INTERLEAVE
-#define EDGEHIP_FIT_INTERLEAVE 1
-#endif
 #ifndef EDGEHIP_FIT_SHARED_PRODUCT
 #define EDGEHIP_FIT_SHARED_PRODUCT 1
 #endif
@@ -191,15 +188,11 @@ __device__ __forceinline__ FitOut fit_eval(const float (&v)[25], const FitCoef &
             t2 += pc2 * yv;
 #endif
         }
-#if EDGEHIP_FIT_INTERLEAVE
         // (empty statements that "use" the three sums: the row's arithmetic has to stand in front of the first, the next row's behind the second —
         // left alone, the compiler lines up all five steps of the search and then the whole fit)
         asm volatile("" : "+v"(t0), "+v"(t1), "+v"(t2));
         between(i);
         asm volatile("" : "+v"(t0), "+v"(t1), "+v"(t2));
-#else
-        between(i);
-#endif
     }
     FitOut o;
     o.cand = false;
@@ -312,9 +305,6 @@ __global__ __launch_bounds__(512) void k_stage_a_fused(FusedArgs a) {
 #ifndef EDGEHIP_FUSED_SCANPRIO
 #define EDGEHIP_FUSED_SCANPRIO 3
 #endif
-#ifndef EDGEHIP_SCAN_ASM
-#define EDGEHIP_SCAN_ASM 0
-#endif
     const int scan_wave = NW >= EDGEHIP_FUSED_SCANW ? EDGEHIP_FUSED_SCANW : NW;
     if (wave == scan_wave) {
         // ---- the scan wave: the serial left-to-right prefix of iimage::load (iimage.cpp:56-61) for the 4 RB rows of the buffer
@@ -353,11 +343,10 @@ __global__ __launch_bounds__(512) void k_stage_a_fused(FusedArgs a) {
             auto step = [&](float4 (&v)[4], float4 (&nx)[4], int ss) __attribute__((always_inline)) {
                 load(nx, ss + 1);
 // the chain runs through the elements' own registers (x' = carry + x, y' = x' + y, ...): one instruction per element
-#if EDGEHIP_SCAN_ASM
-#define EH_ADDC(DST, PREV) asm volatile("v_add_f32 %0, %1, %0" : "+v"(DST) : "v"(PREV));
-#else
+// (plain C: as one asm statement per add — the round-2 form, to pin the in-register chain — every add drew an s_nop 0 behind it, the hazard
+// recogniser's assumption about an opaque VALU write; the compiler emits the same sixteen back-to-back v_add_f32 by itself: 15.8 -> 11.5 cycles
+// per element in tools/experiments/ubench_scan2.hip, A.fused 2750 -> 2580 us per 1024 frames)
 #define EH_ADDC(DST, PREV) DST = (PREV) + DST;
-#endif
 #define EH_ADD4(I, CARRY) EH_ADDC(v[I].x, CARRY) EH_ADDC(v[I].y, v[I].x) EH_ADDC(v[I].z, v[I].y) EH_ADDC(v[I].w, v[I].z)
 #define EH_PHASE(P)                                                                                  \
     {                                                                                                \
@@ -473,18 +462,22 @@ __global__ __launch_bounds__(512) void k_stage_a_fused(FusedArgs a) {
             float wv_cur[25], wv_nxt[25];
             int code_cur = 0, code_nxt = 0, code_nn = 0;
             const uint16_t *clist = s_clist + (size_t)((t - 1) & 1) * RB * NW * 128;
-            auto code_of = [&](int c) __attribute__((always_inline)) {
-                const int li = c * 64 + lane;
-                // the segment of entry li = the first lane whose segment ends beyond li: binary search over the (non-decreasing)
-                // ends held in lanes 0..31 (RB * NW <= 32), five lane reads
-                int lo = 0;
+            // The segment of list entry li = the first lane whose segment ends beyond li: a binary search over the (non-decreasing) ends
+            // held in lanes 0..31 (RB * NW <= 32), five lane reads, then the entry itself — six LDS round trips in a row.  The tick's first
+            // two chunks are searched side by side (two probes per round trip); every later chunk's search is spread over the plane fit
+            // two chunks ahead of it (one_chunk).
+            auto code_of2 = [&](int ca, int cb, int &code_a, int &code_b) __attribute__((always_inline)) {
+                const int la = ca * 64 + lane, lb = cb * 64 + lane;
+                int loa = 0, lob = 0;
 #pragma unroll
                 for (int step = 16; step > 0; step >>= 1) {
-                    const int e = __shfl(seg_end, lo + step - 1, 64);
-                    lo += e <= li ? step : 0;
+                    const int ea = __shfl(seg_end, loa + step - 1, 64), eb = __shfl(seg_end, lob + step - 1, 64);
+                    loa += ea <= la ? step : 0;
+                    lob += eb <= lb ? step : 0;
                 }
-                const int sh = __shfl(seg_shift, lo, 64);
-                return li < ncand ? (int)clist[li + sh] : 2;    // (padding lanes: row 0, column 2, an address that exists)
+                const int sha = __shfl(seg_shift, loa, 64), shb = __shfl(seg_shift, lob, 64);
+                code_a = la < ncand ? (int)clist[la + sha] : 2;     // (padding lanes: row 0, column 2, an address that exists)
+                code_b = lb < ncand ? (int)clist[lb + shb] : 2;
             };
             auto request = [&](int code, float (&v)[25]) __attribute__((always_inline)) {
                 const int i = code >> 10, x = code & 1023;
@@ -500,8 +493,7 @@ __global__ __launch_bounds__(512) void k_stage_a_fused(FusedArgs a) {
                 fit_load(s_dog, ro, x, v);
             };
             if (nchunks > 0) {
-                code_cur = code_of(0);
-                code_nxt = code_of(1);
+                code_of2(0, 1, code_cur, code_nxt);
                 request(code_cur, wv_cur);
             }
 #ifndef EDGEHIP_FIT_UNROLL
@@ -509,23 +501,18 @@ __global__ __launch_bounds__(512) void k_stage_a_fused(FusedArgs a) {
 #endif
             // one chunk: evaluate the window in `wc` (requested one chunk earlier) while the next chunk's window lands in `wn`
             auto one_chunk = [&](int c, float (&wc)[25], float (&wn)[25]) __attribute__((always_inline)) {
-#if EDGEHIP_FIT_INTERLEAVE
-                    // the list search of chunk c + 2 (code_of), one step per window row of this chunk's fit; its first probe goes out
-                    // ahead of the next chunk's 25 window reads (LDS answers in order: a probe behind them would wait for all of them)
+                    // the list search of chunk c + 2, one step per window row of this chunk's fit: a step's LDS round trip passes under a
+                    // row's arithmetic (2440 -> 2350 us per 1024 frames against the search in one piece in front of the fit, same box,
+                    // profiles/r06_fused_scan_fit_directed_ab.txt).  Its first probe goes out ahead of the next chunk's 25 window reads:
+                    // LDS answers in order, a probe behind them would wait for all of them.
                     const int li2 = (c + 2) * 64 + lane;
                     int s_lo = 0, s_e = __shfl(seg_end, 15, 64), s_sh = 0;
                     if (c + 1 < nchunks) request(code_nxt, wn);
-#else
-                    if (c + 1 < nchunks) request(code_nxt, wn);
-                    code_nn = code_of(c + 2);
-                    __builtin_amdgcn_sched_barrier(0);
-#endif
                     const bool on = c * 64 + lane < ncand;
                     const int code = code_cur;
                     const int i = code >> 10, x = code & 1023;
                     FitOut f;
                     if (ABL & 256) { f.cand = (code & 1) != 0; f.mx = 3.f; f.my = 4.f; f.xs = 0.f; f.ys = 0.f; }
-#if EDGEHIP_FIT_INTERLEAVE
                     else f = fit_eval(wc, fc, thr_d, [&](int i) __attribute__((always_inline)) {
                         __builtin_amdgcn_sched_barrier(0);   // (the scheduler would gather the five steps in front of the arithmetic again)
                         if (i == 0) { s_lo += s_e <= li2 ? 16 : 0; s_e = __shfl(seg_end, s_lo + 7, 64); }
@@ -541,9 +528,6 @@ __global__ __launch_bounds__(512) void k_stage_a_fused(FusedArgs a) {
                         s_sh = __shfl(seg_shift, s_lo, 64);
                     }
                     code_nn = li2 < ncand ? (int)clist[li2 + s_sh] : 2;
-#else
-                    else f = fit_eval(wc, fc, thr_d, [](int) {});
-#endif
                     const bool fin = on && f.cand;
                     const unsigned long long bal = __ballot(fin);
                     const int id = total + below(bal);
