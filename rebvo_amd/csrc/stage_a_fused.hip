@@ -417,9 +417,14 @@ __global__ __launch_bounds__(512) void k_stage_a_fused(FusedArgs a) {
         // the three arrays the wave stores to, and the fit's coefficients: fetched once, before the tick loop (inside it every
         // load would wait for the KeyLine stores in flight: vmcnt counts loads and stores alike)
         const KlSoA &klr = a.kl[seq];
-        int32_t *const k_pinx = klr.p_inx;
-        int32_t *const k_pid = klr.p_id;
-        float4 *const k_grec = klr.grec;
+        // (as global-memory pointers: loaded from the KlSoA record they are generic to the compiler, and a FLAT store also counts on the LDS
+        // counter — every wait for an LDS answer behind it waits for the store's address check as well)
+        typedef int32_t __attribute__((address_space(1))) gi32;
+        typedef float f4v __attribute__((ext_vector_type(4)));
+        typedef f4v __attribute__((address_space(1))) gf4;
+        gi32 *const k_pinx = (gi32 *)klr.p_inx;
+        gi32 *const k_pid = (gi32 *)klr.p_id;
+        gf4 *const k_grec = (gf4 *)klr.grec;
         const FitCoef fc = load_fit_coef(a.pinv);
         const int WRES = NW * 128;                  // row stride of s_res
         __builtin_amdgcn_s_setprio(EDGEHIP_FUSED_FITPRIO);   // behind the scan wave's chain, ahead of the column waves
@@ -535,7 +540,7 @@ __global__ __launch_bounds__(512) void k_stage_a_fused(FusedArgs a) {
                         // KeyLine `id` (edge_finder.cpp:166-200): what the fit produced; k_join_histo<true, true> derives the rest
                         const int y = ytest0 + i;
                         k_pinx[id] = y * w + x;
-                        k_grec[id] = make_float4(f.xs, f.ys, f.mx, f.my);
+                        k_grec[id] = f4v{f.xs, f.ys, f.mx, f.my};
                         k_pid[id] = -1;        // join_edges' atomicMax needs it before any thread of k_join_histo runs
                         const float n2m = f.mx * f.mx + f.my * f.my;   // n_m = sqrtf(n2m) is monotonic in n2m: extremes of n2m here,
                         nm_mx = fmaxf(nm_mx, n2m);                     // one square root at the end of the frame
@@ -557,7 +562,10 @@ __global__ __launch_bounds__(512) void k_stage_a_fused(FusedArgs a) {
                 for (; c + 1 < c1; c += 2) { one_chunk(c, wv_cur, wv_nxt); one_chunk(c + 1, wv_nxt, wv_cur); }
                 if (c < c1) { one_chunk(c, wv_cur, wv_nxt); in_cur = false; }
             };
-            const int half = nchunks >> 1;
+#ifndef EDGEHIP_FIT_SPLIT
+#define EDGEHIP_FIT_SPLIT -1   // the first half of the tick also holds the tick's set-up (segment scan, the first two searches): one chunk fewer there, 2301 -> 2273 us per 1024 frames
+#endif
+            const int half = (nchunks + EDGEHIP_FIT_SPLIT > 0 ? nchunks + EDGEHIP_FIT_SPLIT : 0) >> 1;
             chunks(0, half);
             EH_TS_BAR(0, t)
             chunks(half, nchunks);

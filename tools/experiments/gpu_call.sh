@@ -36,7 +36,7 @@ fi
 if [ -n "$LIBS" ]; then
   cp rebvo_amd/lib/libedgehip.so /tmp/keep.so
   for r in $(seq $ROUNDS); do for n in $LIBS; do
-    cp tools/experiments/bin/libedgehip_$n.so rebvo_amd/lib/libedgehip.so
+    cp tools/experiments/bin/libedgehip_$n.so rebvo_amd/lib/libedgehip.so || { echo "cp of variant $n failed"; df -h . /tmp; ls -la rebvo_amd/lib tools/experiments/bin; cp /tmp/keep.so rebvo_amd/lib/libedgehip.so; exit 3; }
     echo -n "[$n]  "; line
   done; done 2>&1 | tee "$OUT/ab_libs.txt"
   cp /tmp/keep.so rebvo_amd/lib/libedgehip.so
