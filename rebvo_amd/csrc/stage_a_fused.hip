@@ -144,11 +144,13 @@ __device__ __forceinline__ FitCoef load_fit_coef(const double *__restrict__ pinv
 }
 // The window is loaded (fit_load) and evaluated (fit_eval) separately so that the fit wave can request the next chunk's 25
 // values before it evaluates the current one: it is a single wave, nobody else hides its LDS round trips.
-__device__ __forceinline__ void fit_load(const float *s_dog, const int ro[5], int x, float (&v)[25]) {
+__device__ __forceinline__ void fit_load(const float *s_dog, const int ro[5], float (&v)[25]) {   // ro[k]: element offset of window row k at column x - 2
 #pragma unroll
-    for (int i = 0; i < 5; i++)
+    for (int i = 0; i < 5; i++) {
+        const float *rp = s_dog + ro[i];        // one address per window row, the five columns as immediate offsets
 #pragma unroll
-        for (int j = 0; j < 5; j++) v[i * 5 + j] = s_dog[ro[i] + x + j - 2];
+        for (int j = 0; j < 5; j++) v[i * 5 + j] = rp[j];
+    }
 }
 // between(i) runs after window row i's terms: the fit wave puts the steps of the NEXT chunks' list search there, so that the LDS round trip of a
 // step passes under a row's arithmetic instead of in front of the whole fit.
@@ -489,13 +491,13 @@ __global__ __launch_bounds__(512) void k_stage_a_fused(FusedArgs a) {
                 int ro[5];
                 int s0 = rq + i - 4;                    // slot of y_i - 2
                 s0 += s0 < 0 ? RING : 0;
+                // window row k sits in slot (s0 + k) mod RING: one 24-bit product for the first row (a 32-bit integer multiply runs at a quarter of
+                // the rate), the others a constant further on, less the ring's length from the row on that wraps
+                const int base = (int)__umul24((unsigned)s0, (unsigned)WP) + (PAD - 2) + x, kw = RING - s0;
+                ro[0] = base;
 #pragma unroll
-                for (int k = 0; k < 5; k++) {
-                    int sk = s0 + k;
-                    sk -= sk >= RING ? RING : 0;
-                    ro[k] = sk * WP + PAD;
-                }
-                fit_load(s_dog, ro, x, v);
+                for (int k = 1; k < 5; k++) ro[k] = (k >= kw ? base - RING * WP : base) + k * WP;
+                fit_load(s_dog, ro, v);
             };
             if (nchunks > 0) {
                 code_of2(0, 1, code_cur, code_nxt);
