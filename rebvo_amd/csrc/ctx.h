@@ -155,6 +155,18 @@ __host__ __device__ __forceinline__ size_t field16_index(int x, int y, int f16tx
     return (((size_t)(y >> 2) * (size_t)f16tx + (size_t)(x >> 3)) << 5) | (size_t)(((y & 3) << 3) | (x & 7));
 }
 
+// Streaming ("nontemporal") stores for arrays a kernel writes once, front to back, and that exceed the caches many times over before anyone reads them.
+// Build switches EDGEHIP_NT_* choose per kernel (A/Bs in profiles/r06_nontemporal_stores_ab.txt).
+template <class T> __device__ __forceinline__ void st_stream(T *p, T v) { __builtin_nontemporal_store(v, p); }
+__device__ __forceinline__ void st_stream(float2 *p, float2 v) {
+    typedef float f2v __attribute__((ext_vector_type(2)));
+    __builtin_nontemporal_store(f2v{v.x, v.y}, reinterpret_cast<f2v *>(p));
+}
+__device__ __forceinline__ void st_stream(int2 *p, int2 v) {
+    typedef int i2v __attribute__((ext_vector_type(2)));
+    __builtin_nontemporal_store(i2v{v.x, v.y}, reinterpret_cast<i2v *>(p));
+}
+
 struct Profiler;
 
 }  // namespace edgehip

@@ -1111,6 +1111,9 @@ __device__ __forceinline__ int x86_cvttss2si(float f) {
 // records) is computed here, at full lanes and streaming, instead of by one wave of the detector at a third of its lanes.
 // fwd_fills (with DEFAULTS): the whole-frame driver's FordwardMatch will write the ten fields it forwards for EVERY new KeyLine
 // (k_fwd_apply's fill mode: the forwarded values or these defaults), so they are not written here — 68 of the 180 bytes.
+#ifndef EDGEHIP_JOIN_NT
+#define EDGEHIP_JOIN_NT 1
+#endif
 template <bool DEFAULTS, bool DERIVE = false>
 __global__ __launch_bounds__(256) void k_join_histo(KlSoA *kls, const int32_t *__restrict__ masks, SeqA *seqs,
                                                     int32_t *histo, int w, size_t n, int nbins, float ppx = 0.f, float ppy = 0.f,
@@ -1153,6 +1156,20 @@ __global__ __launch_bounds__(256) void k_join_histo(KlSoA *kls, const int32_t *_
         if (j < 0) j = mask[(size_t)(y + sy) * w + x];
         if (j < 0) j = mask[(size_t)(y + sy) * w + (x + sx)];
         if (DERIVE) {
+#if EDGEHIP_JOIN_NT   // streaming stores for the 1.7 GB this kernel writes per 1024 frames: 507 -> 465 us (same box, profiles/r06_nontemporal_stores_ab.txt)
+            typedef float f2v __attribute__((ext_vector_type(2)));
+            typedef float f4v __attribute__((ext_vector_type(4)));
+            __builtin_nontemporal_store(f2v{m.x, m.y}, reinterpret_cast<f2v *>(k.m_m + i));
+            __builtin_nontemporal_store(nm_i, k.n_m + i);
+            __builtin_nontemporal_store(f2v{u_d.x, u_d.y}, reinterpret_cast<f2v *>(k.u_m + i));
+            __builtin_nontemporal_store(f2v{cp.x, cp.y}, reinterpret_cast<f2v *>(k.c_p + i));
+            __builtin_nontemporal_store(f2v{pm_d.x, pm_d.y}, reinterpret_cast<f2v *>(k.p_m + i));
+            if (!fwd_fills) k.p_m_0[i] = pm_d;
+            f4v *rp = reinterpret_cast<f4v *>(k.rec + i);
+            __builtin_nontemporal_store(f4v{cp.x, cp.y, u_d.x, u_d.y}, rp);
+            __builtin_nontemporal_store(f4v{m.x, m.y, nm_i, 0.f}, rp + 1);
+            __builtin_nontemporal_store(f4v{cp.x, cp.y, m.x, m.y}, reinterpret_cast<f4v *>(k.grec + i));
+#else
             k.m_m[i] = m;
             k.n_m[i] = nm_i;
             k.u_m[i] = u_d;
@@ -1164,6 +1181,7 @@ __global__ __launch_bounds__(256) void k_join_histo(KlSoA *kls, const int32_t *_
             rec.m_mx = m.x; rec.m_my = m.y; rec.n_m = nm_i; rec.pad = 0.f;
             k.rec[i] = rec;
             k.grec[i] = make_float4(cp.x, cp.y, m.x, m.y);
+#endif
         }
         if (DEFAULTS) {
             if (!fwd_fills) {
@@ -1177,11 +1195,19 @@ __global__ __launch_bounds__(256) void k_join_histo(KlSoA *kls, const int32_t *_
                 k.m_m0[i] = make_float2(0.f, 0.f);
                 k.n_m0[i] = 0.0;
             }
+#if EDGEHIP_JOIN_NT
+            __builtin_nontemporal_store(1.0, k.rho0 + i);
+            __builtin_nontemporal_store(20.0, k.s_rho0 + i);
+            if (k.stereo_m_id) { k.stereo_m_id[i] = -1; k.stereo_rho[i] = 1.0; k.stereo_s_rho[i] = 20.0; }
+            __builtin_nontemporal_store(-1, k.m_id_f + i);
+            __builtin_nontemporal_store(j, k.n_id + i);
+#else
             k.rho0[i] = 1.0;
             k.s_rho0[i] = 20.0;
             if (k.stereo_m_id) { k.stereo_m_id[i] = -1; k.stereo_rho[i] = 1.0; k.stereo_s_rho[i] = 20.0; }
             k.m_id_f[i] = -1;
             k.n_id[i] = j;           // -1 without a neighbour
+#endif
         } else if (j >= 0) k.n_id[i] = j;
         if (j >= 0) atomicMax(&k.p_id[j], i);
         // histogram position, edge_finder.cpp:392

@@ -667,6 +667,7 @@ __global__ __launch_bounds__(512) void k_stage_a_fused(FusedArgs a) {
                     const uint32_t r2 = rp[i * (NW * 64)];
                     rp[i * (NW * 64)] = 0;
                     if (y >= 0 && y < h && act)
+                        // (a plain store: as a streaming store the kernel gains 0.5 % and k_join_histo, whose probes read these rows next, loses as much)
                         *reinterpret_cast<int2 *>(mask + (uint32_t)(y * w + x0)) = make_int2((int)(r2 & 0xFFFFu) - 1, (int)(r2 >> 16) - 1);
                 }
             }

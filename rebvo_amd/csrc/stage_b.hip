@@ -366,6 +366,9 @@ __global__ __launch_bounds__(256) void k_field_bin(const KlSoA *kls, const int32
     if (fwd_key && i < kn) { fwd_key[(size_t)seq * bin_cap + i] = 0ull; fwd_win[(size_t)seq * bin_cap + i] = -1; }
 }
 
+#ifndef EDGEHIP_NT_RASTER
+#define EDGEHIP_NT_RASTER 1   // the 16-bit plane as streaming stores: B.build_field 1162 -> 1154 us, the evaluations that gather from it unchanged
+#endif
 __global__ __launch_bounds__(256) void k_field_raster(const KlSoA *kls, int32_t *__restrict__ bin_cnt,
                                                       const int32_t *__restrict__ bins, uint32_t *__restrict__ field,
                                                       uint16_t *__restrict__ field16, size_t f16stride, int f16tx, int keep32,
@@ -526,7 +529,11 @@ __global__ __launch_bounds__(256) void k_field_raster(const KlSoA *kls, int32_t 
             // low half = 0xFFFF - ikl  ->  ikl + 1 = 0x10000 - low half (mod 2^16); empty (all ones) -> 0
             const uint32_t a0 = v0 == 0xFFFFFFFFu ? 0u : ((0x10000u - (v0 & 0xFFFFu)) & 0xFFFFu);
             const uint32_t a1 = v1 == 0xFFFFFFFFu ? 0u : ((0x10000u - (v1 & 0xFFFFu)) & 0xFFFFu);
+#if EDGEHIP_NT_RASTER
+            st_stream(reinterpret_cast<uint32_t *>(o16 + field16_index(x, y, f16tx)), a0 | (a1 << 16));
+#else
             *reinterpret_cast<uint32_t *>(o16 + field16_index(x, y, f16tx)) = a0 | (a1 << 16);
+#endif
         }
     }
 }

@@ -395,6 +395,9 @@ struct DirArgs {
 // turned values the candidates are tested with into `rot` — and every new KeyLine's ten fields are written once: the match's, the
 // forward match's, or (FILL: the detector left them to this kernel) a fresh KeyLine's.  Same values, same bits.  A sequence whose
 // tracker returned NaN (skip_match) gets the forward copy alone, as the reference's FordwardMatch has already happened by then.
+#ifndef EDGEHIP_NT_DIRECTED
+#define EDGEHIP_NT_DIRECTED 1   // 1.1 GB per 1024 frames written once, read by the next kernels long after the caches have turned over: 1055 -> 1018 us
+#endif
 template <bool FUSED, bool FILL>
 __device__ __forceinline__ void directed_body(const DirArgs &a) {
     const int seq = blockIdx.z, ik = blockIdx.x * (int)blockDim.x + threadIdx.x;
@@ -600,6 +603,18 @@ __device__ __forceinline__ void directed_body(const DirArgs &a) {
                     m_num = ko.m_num[src]; m_id_kf = ko.m_id_kf[src];
                     nm = ko.n_m[src];
                 }
+#if EDGEHIP_NT_DIRECTED
+                st_stream(kn.rho + ik, rho);
+                st_stream(kn.s_rho + ik, s_rho);
+                st_stream(kn.rho_nr + ik, rho_nr);
+                st_stream(kn.s_rho_nr + ik, s_rho_nr);
+                st_stream(kn.m_num + ik, m_num + 1);
+                st_stream(kn.m_id + ik, src);
+                st_stream(kn.p_m_0 + ik, pm);
+                st_stream(kn.m_m0 + ik, mm);
+                st_stream(kn.n_m0 + ik, (double)nm);
+                st_stream(kn.m_id_kf + ik, m_id_kf);
+#else
                 kn.rho[ik] = rho;
                 kn.s_rho[ik] = s_rho;
                 kn.rho_nr[ik] = rho_nr;
@@ -610,6 +625,7 @@ __device__ __forceinline__ void directed_body(const DirArgs &a) {
                 kn.m_m0[ik] = mm;
                 kn.n_m0[ik] = (double)nm;
                 kn.m_id_kf[ik] = m_id_kf;
+#endif
                 matched = found >= 0;
                 kfm = matched && m_id_kf >= 0;
             }
