@@ -127,6 +127,9 @@ __device__ __forceinline__ v2f ring_row_general(TapRing<L> &H, int P, v2f vr, v2
 
 // build_mask's plane fit on the 5x5 DoG window (edge_finder.cpp:139-159) from the LDS ring: ro[k] = element offset of
 // window row k, x = column.  Same operation order as k_detect (TooN dot product, k = 0..24).
+#ifndef EDGEHIP_NT_EMIT
+#define EDGEHIP_NT_EMIT 1   // the fit wave's KeyLine stores as streaming stores: A.fused 2202 -> 2186 us, k_join_histo unchanged
+#endif
 #ifndef EDGEHIP_FIT_SHARED_PRODUCT
 #define EDGEHIP_FIT_SHARED_PRODUCT 1
 #endif
@@ -541,9 +544,15 @@ __global__ __launch_bounds__(512) void k_stage_a_fused(FusedArgs a) {
                     if (fin && id < a.kl_max && !(ABL & 128)) {
                         // KeyLine `id` (edge_finder.cpp:166-200): what the fit produced; k_join_histo<true, true> derives the rest
                         const int y = ytest0 + i;
+#if EDGEHIP_NT_EMIT
+                        __builtin_nontemporal_store(y * w + x, k_pinx + id);
+                        __builtin_nontemporal_store(f4v{f.xs, f.ys, f.mx, f.my}, k_grec + id);
+                        __builtin_nontemporal_store(-1, k_pid + id);
+#else
                         k_pinx[id] = y * w + x;
                         k_grec[id] = f4v{f.xs, f.ys, f.mx, f.my};
                         k_pid[id] = -1;        // join_edges' atomicMax needs it before any thread of k_join_histo runs
+#endif
                         const float n2m = f.mx * f.mx + f.my * f.my;   // n_m = sqrtf(n2m) is monotonic in n2m: extremes of n2m here,
                         nm_mx = fmaxf(nm_mx, n2m);                     // one square root at the end of the frame
                         nm_mn = fminf(nm_mn, n2m);

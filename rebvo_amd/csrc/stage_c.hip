@@ -188,10 +188,17 @@ __global__ __launch_bounds__(256) void k_rotate(const KlSoA *kls, const int32_t 
         // every KeyLine's four values, turned or (q2 == 0: the reference leaves them) as they are: whole lines
         const size_t o = (size_t)seq * cap + i;
         const bool turn = fabs(q2) > 0;
+#if EDGEHIP_NT_ROT
+        st_stream(out.p_m + o, turn ? make_float2((float)(q0 / q2 * zf), (float)(q1 / q2 * zf)) : pm);
+        st_stream(out.rho + o, turn ? rho / q2 : rho);
+        st_stream(out.s_rho + o, turn ? s_rho / q2 : s_rho);
+        st_stream(out.m_m + o, mr);
+#else
         out.p_m[o] = turn ? make_float2((float)(q0 / q2 * zf), (float)(q1 / q2 * zf)) : pm;
         out.rho[o] = turn ? rho / q2 : rho;
         out.s_rho[o] = turn ? s_rho / q2 : s_rho;
         out.m_m[o] = mr;
+#endif
         return;
     }
     if (fabs(q2) > 0) {
@@ -395,6 +402,12 @@ struct DirArgs {
 // turned values the candidates are tested with into `rot` — and every new KeyLine's ten fields are written once: the match's, the
 // forward match's, or (FILL: the detector left them to this kernel) a fresh KeyLine's.  Same values, same bits.  A sequence whose
 // tracker returned NaN (skip_match) gets the forward copy alone, as the reference's FordwardMatch has already happened by then.
+#ifndef EDGEHIP_NT_ROT
+#define EDGEHIP_NT_ROT 1   // C.rotate 218 -> 210 us, the walk that gathers from these arrays unchanged
+#endif
+#ifndef EDGEHIP_NT_EKF
+#define EDGEHIP_NT_EKF 1   // C.regularize_ekf 382 -> 367 us and C.rescale, which reads these arrays next, 202 -> 170 us
+#endif
 #ifndef EDGEHIP_NT_DIRECTED
 #define EDGEHIP_NT_DIRECTED 1   // 1.1 GB per 1024 frames written once, read by the next kernels long after the caches have turned over: 1055 -> 1018 us
 #endif
@@ -708,7 +721,7 @@ __global__ __launch_bounds__(256) void k_regularize(const KlSoA *kls, const int3
             }
         }
     }
-    rs[(size_t)seq * 2 * cap + i] = r;
+    rs[(size_t)seq * 2 * cap + i] = r;     // (plain stores: the EKF reads them back at once; as streaming stores nothing moved)
     rs[(size_t)seq * 2 * cap + cap + i] = s;
 }
 
@@ -754,11 +767,19 @@ __global__ __launch_bounds__(256) void k_ekf(const KlSoA *kls, const int32_t *__
             rho = kRhoInit;
             s_rho = kRhoMax;
         }
+#if EDGEHIP_NT_EKF
+        st_stream(K.rho0 + i, rho0);
+        st_stream(K.s_rho0 + i, s_rho0);
+    }
+    st_stream(K.rho + i, rho);
+    st_stream(K.s_rho + i, s_rho);
+#else
         K.rho0[i] = rho0;
         K.s_rho0[i] = s_rho0;
     }
     K.rho[i] = rho;
     K.s_rho[i] = s_rho;
+#endif
 }
 
 // ---------------------------------------------------------------------------------------------------
