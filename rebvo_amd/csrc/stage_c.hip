@@ -569,7 +569,7 @@ __device__ __forceinline__ void directed_body(const DirArgs &a) {
                     const float fx = (float)(t_x * t + (double)pi0x), fy = (float)(t_y * t + (double)pi0y);
                     const int xi = round_half_away_i(fx), yi = round_half_away_i(fy);
                     if (xi >= a.w || yi >= a.h || xi < 0 || yi < 0) continue;
-                    jm[c][dir] = mask[(size_t)yi * a.w + xi];
+                    jm[c][dir] = mask[__umul24((unsigned)yi, (unsigned)a.w) + (unsigned)xi];   // (a 24-bit product: the 64-bit one is two quarter-rate multiplies per probe)
                 }
             }
 #pragma unroll
