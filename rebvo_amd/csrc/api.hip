@@ -402,7 +402,10 @@ static int create_body(edgehip_ctx *c, CtxAllocs *al, const edgehip_params &p, i
     // of the device idle, so the next frame's detection runs beside this frame's tracking and mapping — what the reference's first
     // and second thread do — 0.36 -> 0.32 ms per frame for one sequence, 0.47 -> 0.39 for eight.  Off for whole batches, whose
     // stage A fills every CU by itself (+-0, and per-kernel times stop being attributable), and under frame graphs (one stream).
-    const int fused_min_env = getenv("EDGEHIP_FUSED_MIN_BATCH") ? atoi(getenv("EDGEHIP_FUSED_MIN_BATCH")) : 192;
+    // From 32 sequences per launch on stage A is the one-kernel form (one workgroup per sequence, ~0.55 ms whatever the batch) running beside the previous
+    // frame's tracking and mapping on the CUs it leaves free: 64 sequences 62.1 -> 89.9 k frames/s, 128: 85.4 -> 107.3 k, 32: 52.3 -> 56.5 k, 24: 45.2 -> 42.7 k
+    // (tools/experiments/exp_fused_threshold.sh, profiles/r06_fused_threshold.txt).  It was 192 until round 6: set when the kernel took 0.68 ms.
+    const int fused_min_env = getenv("EDGEHIP_FUSED_MIN_BATCH") ? atoi(getenv("EDGEHIP_FUSED_MIN_BATCH")) : 32;
     int ncu_dev = 0;
     (void)hipDeviceGetAttribute(&ncu_dev, hipDeviceAttributeMultiprocessorCount, device);
     // (the one-kernel stage A is one workgroup per sequence: below one sequence per CU it leaves CUs idle too — 192 sequences: 86.8 -> 96.0 k frames/s)
@@ -524,7 +527,7 @@ static int create_body(edgehip_ctx *c, CtxAllocs *al, const edgehip_params &p, i
     c->no_grec = getenv("EDGEHIP_NO_GREC") && atoi(getenv("EDGEHIP_NO_GREC")) != 0;
     c->level_mode = getenv("EDGEHIP_LEVEL_MODE") ? atoi(getenv("EDGEHIP_LEVEL_MODE")) : 0;
     c->fwd_mode = EH_EXP_ENV("EDGEHIP_FWD_MODE", 0);
-    c->fused_min_batch = fused_min_env;   // one workgroup per sequence: pays from about 3/4 of the 256 CUs on (tools/experiments/ab_level_mode.sh)
+    c->fused_min_batch = fused_min_env;
     // measured at 1024 sequences (tools/experiments/CALLS.md: r04_j, same box, three rounds): the step 10.53 / 10.50 / 10.43 ms without, 10.48 / 10.39 / 10.39 ms with —
     // inside the run-to-run spread, while the group's own HIP-event time went UP (2.62 -> 2.73 ms: 84 registers, 5 waves per SIMD).  Off by default.
     c->fused_undist = EH_EXP_ENV("EDGEHIP_FUSED_UNDIST", 0) != 0;
