@@ -1,7 +1,7 @@
 #!/bin/bash
 # Small batches: per-group kernel time against the step, at 1 / 8 / 64 sequences per launch (what the plugin surface's single camera and small groups run)
 cd "${GRAFT_REPO_ROOT:-.}"
-for n in 1 8 64 192 256; do
+for n in ${NSEQS:-1 8 64 192 256}; do
   timeout 300 python bench.py --nseq $n --steps 200 --warmup 30 --no-extras --cpu-frames 0 2>/dev/null | python -c "
 import sys, json
 l = sys.stdin.read(); j = json.loads(l[l.index('{'):]); k = json.load(open('bench_extras.json'))['kernel_us_per_step']

@@ -11,11 +11,13 @@ W, H = 376, 240
 exe = "rebvo_amd/lib/surface_replay"
 rng = np.random.default_rng(int(sys.argv[1]) if len(sys.argv) > 1 else 1)
 frames = [f for f, _, _ in synth.billboard_sequence(W, H, 8, seed=41)]
+NMIN = int(sys.argv[3]) if len(sys.argv) > 3 else 1      # group sizes: 1..16 by default; 30..80 takes the groups through the one-kernel stage A (from 32 members on)
+NMAX = int(sys.argv[4]) if len(sys.argv) > 4 else 16
 bad = 0
 with tempfile.TemporaryDirectory() as td:
     np.stack(frames).tofile(td + "/frames.rgb24")
     for it in range(int(sys.argv[2]) if len(sys.argv) > 2 else 40):
-        n = int(rng.integers(1, 17)); k = int(rng.integers(4, 40)); t = int(rng.integers(1, min(n, 8) + 1))
+        n = int(rng.integers(NMIN, NMAX + 1)); k = int(rng.integers(4, 40)); t = int(rng.integers(1, min(n, 8) + 1))
         mono = int(rng.integers(0, 2))
         cfg = f"{td}/cfg{it}"
         gpu = dict(mono=mono)
