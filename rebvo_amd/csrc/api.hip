@@ -410,7 +410,12 @@ static int create_body(edgehip_ctx *c, CtxAllocs *al, const edgehip_params &p, i
     (void)hipDeviceGetAttribute(&ncu_dev, hipDeviceAttributeMultiprocessorCount, device);
     // (the one-kernel stage A is one workgroup per sequence: below one sequence per CU it leaves CUs idle too — 192 sequences: 86.8 -> 96.0 k frames/s)
     const int ovl_below = fused_min_env > ncu_dev ? fused_min_env : ncu_dev;
-    const bool ovl = getenv("EDGEHIP_OVERLAP") ? atoi(getenv("EDGEHIP_OVERLAP")) != 0 : (nseq < ovl_below && !c->use_graph);
+    // ... and above it whenever the one-kernel stage A's last round of workgroups is a partial one (one workgroup per sequence and CU: 288 sequences are
+    // a full round and one of 32 — the CUs it leaves idle take the previous frame's tracking): 288 sequences 95.8 -> 112.2 k frames/s, 384: 107.5 -> 119.0 k,
+    // 640: 114.2 -> 123.7 k (tools/experiments/exp_batch_size.sh, profiles/r06_batch_size_and_overlap.txt).  Whole multiples of the CU count stay on one stream:
+    // +1..3 % there, and the kernels' own durations stop being attributable (A.fused 2.14 -> 3.54 ms per launch at 1024 under overlap).
+    const bool partial_round = ncu_dev > 0 && nseq > ncu_dev && (nseq % ncu_dev) != 0;
+    const bool ovl = getenv("EDGEHIP_OVERLAP") ? atoi(getenv("EDGEHIP_OVERLAP")) != 0 : ((nseq < ovl_below || partial_round) && !c->use_graph);
     c->overlap = ovl ? 1 : 0;
     const int a_cus = ovl ? EH_EXP_ENV("EDGEHIP_A_CUS", 0) : 0;
     if (a_cus > 0) {

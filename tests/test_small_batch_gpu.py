@@ -23,10 +23,14 @@ def _run(w, h, B, pool, nframes, params):
     return navs, kls
 
 
-@pytest.mark.parametrize("w,h,B", [(376, 240, 200), (752, 480, 72)], ids=["fused_stage_a_200", "multi_kernel_72"])
+@pytest.mark.parametrize("w,h,B", [(376, 240, 200), (752, 480, 72), (752, 480, 40), (376, 240, 24), (376, 240, 300)],
+                         ids=["one_kernel_stage_a_200", "one_kernel_stage_a_72", "one_kernel_stage_a_40_small_batch_kernels", "multi_kernel_24",
+                              "partial_second_round_300"])
 def test_a_sequence_does_not_depend_on_the_batch_it_runs_in(w, h, B):
-    """B = 200 takes the one-kernel stage A and every whole-batch kernel; 72 the multi-kernel stage A with the whole-batch
-    k_rescale / k_quantile / minimiser launches; 2 takes every small-batch kernel."""
+    """2 takes every small-batch kernel.  B = 200 and 72 take the one-kernel stage A (from 32 sequences on, beside the previous frame's tracking below one
+    sequence per CU) and every whole-batch kernel (k_rescale / k_quantile / minimiser launches: above 64 sequences); 40 the one-kernel stage A with the
+    small-batch forms of those; 24 the multi-kernel stage A; 300 a full round of the one-kernel stage A's workgroups and a partial one, where the library
+    again runs stage A beside the previous frame's tracking (api.hip: partial_round)."""
     pool = [f for f, _, _ in synth.billboard_sequence(w, h, 6, seed=4)]
     params = edgehip.euroc_params(w, h)
     n_small, k_small = _run(w, h, 2, pool, 7, params)
