@@ -973,6 +973,16 @@ bool fused_supported(const edgehip_ctx *c) {
     return fused_lds_bytes(pl.w) <= 160 * 1024;
 }
 
+// Does the launch below pick an instantiation with the image width as a compile-time constant?  (The dispatch rule of stage_a.hip: those are fast enough to
+// run from 32 sequences per launch on; the run-time-width ones, several times slower per pixel, from 192.)  Mirrors the selection in stage_a_fused_enqueue.
+bool fused_fixed_width(const edgehip_ctx *c, bool grey16, bool grey8) {
+    const int w = c->plan.w;
+    if (c->planes) return false;
+    if (grey16) return w == 640;
+    if (grey8) return w == 752;
+    return w == 752 || w == 640;
+}
+
 int stage_a_fused_enqueue(edgehip_ctx *c, int slot, const uint8_t *rgb_base, const int32_t *rgb_idx, const uint16_t *grey16,
                           const uint8_t *grey8, bool undist_in_load) {
     const DevicePlan &pl = c->plan;

@@ -1,5 +1,5 @@
-"""GPU: the fused stage-A kernel (stage_a_fused.hip, EDGEHIP_LEVEL_MODE=3; the default from EDGEHIP_FUSED_MIN_BATCH = 32
-sequences on) against the reference, with the bar of the multi-kernel path it replaces: img0 / img1 / DoG / gradient
+"""GPU: the fused stage-A kernel (stage_a_fused.hip, EDGEHIP_LEVEL_MODE=3; the default from 32 sequences per launch on at widths 752 / 640, from 192 at others; EDGEHIP_FUSED_MIN_BATCH
+overrides) against the reference, with the bar of the multi-kernel path it replaces: img0 / img1 / DoG / gradient
 planes, img_mask_kl, kn, every KeyLine field stage A defines, the threshold state and reTunedThresh — all bit-exact.
 Sizes cover: the bench size, heights that are not a multiple of the 4-row tick, widths that are not a multiple of 64
 or 16, an image narrower than one column group, the kl_max truncation, empty images, and a batch of different frames."""

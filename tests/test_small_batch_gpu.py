@@ -27,7 +27,7 @@ def _run(w, h, B, pool, nframes, params):
                          ids=["one_kernel_stage_a_200", "one_kernel_stage_a_72", "one_kernel_stage_a_40_small_batch_kernels", "multi_kernel_24",
                               "partial_second_round_300"])
 def test_a_sequence_does_not_depend_on_the_batch_it_runs_in(w, h, B):
-    """2 takes every small-batch kernel.  B = 200 and 72 take the one-kernel stage A (from 32 sequences on, beside the previous frame's tracking below one
+    """2 takes every small-batch kernel.  B = 200 (any width: from 192 sequences on) and 72 (width 752: from 32 on) take the one-kernel stage A (beside the previous frame's tracking below one
     sequence per CU) and every whole-batch kernel (k_rescale / k_quantile / minimiser launches: above 64 sequences); 40 the one-kernel stage A with the
     small-batch forms of those; 24 the multi-kernel stage A; 300 a full round of the one-kernel stage A's workgroups and a partial one, where the library
     again runs stage A beside the previous frame's tracking (api.hip: partial_round)."""
