@@ -404,9 +404,8 @@ static int create_body(edgehip_ctx *c, CtxAllocs *al, const edgehip_params &p, i
     // stage A fills every CU by itself (+-0, and per-kernel times stop being attributable), and under frame graphs (one stream).
     // From 32 sequences per launch on stage A is the one-kernel form (one workgroup per sequence, ~0.55 ms whatever the batch) running beside the previous
     // frame's tracking and mapping on the CUs it leaves free: 64 sequences 62.1 -> 89.9 k frames/s, 128: 85.4 -> 107.3 k, 32: 52.3 -> 56.5 k, 24: 45.2 -> 42.7 k
-    // (tools/experiments/exp_fused_threshold.sh, profiles/r06_fused_threshold.txt).  It was 192 until round 6: set when the kernel took 0.68 ms.  That holds for
-    // the widths the kernel is instantiated for at compile time (752, 640): the run-time-width instantiation is several times slower per pixel and keeps 192
-    // (376 x 240, 48 sequences: 68.9 k frames/s on the multi-kernel path, 37.7 k on the one-kernel one; profiles/r06_fused_threshold.txt).  0 = that rule;
+    // (tools/experiments/exp_fused_threshold.sh, profiles/r06_fused_threshold.txt).  It was 192 until round 6: set when the kernel took 0.68 ms.  The number
+    // depends on the instantiation (fused_min_batch_for, stage_a_fused.hip: 32 at widths 752 / 640, 64 at 320, 192 for the run-time-width ones).  0 = that rule;
     // EDGEHIP_FUSED_MIN_BATCH sets one number for every width.
     const int fused_min_env = getenv("EDGEHIP_FUSED_MIN_BATCH") ? atoi(getenv("EDGEHIP_FUSED_MIN_BATCH")) : 0;
     int ncu_dev = 0;

@@ -1351,7 +1351,7 @@ int stage_a_enqueue(edgehip_ctx *c, int slot, bool fwd_fills, bool defer_retune)
     // Batches that fill the GPU with one workgroup per sequence: the whole of stage A up to the KeyLine records in one
     // kernel (stage_a_fused.hip); level_mode 3 forces it, 1 / 2 keep the multi-kernel path (A/B measurements, tests).
     const int fused_min = c->fused_min_batch > 0 ? c->fused_min_batch
-                                                 : (fused_fixed_width(c, c->und_base != nullptr && !c->fused_undist, c->slot_src[slot].grey8 && !c->und_base) ? 32 : 192);
+                                                 : fused_min_batch_for(c, c->und_base != nullptr && !c->fused_undist, c->slot_src[slot].grey8 && !c->und_base);
     const bool use_fused = fused_supported(c) && (c->level_mode == 3 || (c->level_mode == 0 && B >= fused_min));
     // 8-bit mono frames: the one-kernel stage A reads them as they are; every other path gets the RGB24 expansion first
     const uint8_t *grey8 = nullptr;

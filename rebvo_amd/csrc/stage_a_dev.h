@@ -95,7 +95,7 @@ __device__ __forceinline__ uchar3 undist_rgb(const uint8_t *__restrict__ frame, 
 }
 
 bool fused_supported(const edgehip_ctx *c);
-bool fused_fixed_width(const edgehip_ctx *c, bool grey16, bool grey8);   // the launch would take a compile-time-width instantiation (dispatch rule)
+int fused_min_batch_for(const edgehip_ctx *c, bool grey16, bool grey8);   // the dispatch rule: sequences per launch from which the one-kernel stage A runs
 // what the fused kernel's first load reads: the RGB24 frame (ConvertRGB2BW fused: b+g+r), the 16-bit grey plane of
 // k_undistort_grey, or an 8-bit mono frame (b+g+r of r = g = b = v: 3 v, the same integer ConvertRGB2BW computes from the
 // RGB24 expansion DataSetCam makes of a mono image, image.h:197-203)

@@ -973,14 +973,18 @@ bool fused_supported(const edgehip_ctx *c) {
     return fused_lds_bytes(pl.w) <= 160 * 1024;
 }
 
-// Does the launch below pick an instantiation with the image width as a compile-time constant?  (The dispatch rule of stage_a.hip: those are fast enough to
-// run from 32 sequences per launch on; the run-time-width ones, several times slower per pixel, from 192.)  Mirrors the selection in stage_a_fused_enqueue.
-bool fused_fixed_width(const edgehip_ctx *c, bool grey16, bool grey8) {
+// From how many sequences per launch on the one-kernel stage A is the better choice (the dispatch rule of stage_a.hip; EDGEHIP_FUSED_MIN_BATCH overrides it with
+// one number).  A workgroup's life does not depend on the batch, the multi-kernel path's time does, and below one sequence per CU the workgroups leave CUs to
+// the previous frame's tracking.  Measured per instantiation (profiles/r06_fused_threshold.txt): the compile-time widths 752 / 640 from 32 sequences on (64
+// sequences 62 -> 90 k frames/s); 320 (the reference's default GlobalConfig) from 64 (stage A alone: 32 sequences 221 us multi-kernel against 315, 64: 307 / 324,
+// 128: 427 / 351, 256: 699 / 377); the run-time-width instantiations, several times slower per pixel, from 192 (376 x 240, 48 sequences: 68.9 k frames/s
+// multi-kernel, 37.7 k one-kernel; 160: equal).  Mirrors the selection in stage_a_fused_enqueue.
+int fused_min_batch_for(const edgehip_ctx *c, bool grey16, bool grey8) {
     const int w = c->plan.w;
-    if (c->planes) return false;
-    if (grey16) return w == 640;
-    if (grey8) return w == 752;
-    return w == 752 || w == 640;
+    if (c->planes) return 192;
+    if (grey16) return w == 640 ? 32 : 192;
+    if (grey8) return w == 752 ? 32 : (w == 320 ? 64 : 192);
+    return (w == 752 || w == 640) ? 32 : (w == 320 ? 64 : 192);
 }
 
 int stage_a_fused_enqueue(edgehip_ctx *c, int slot, const uint8_t *rgb_base, const int32_t *rgb_idx, const uint16_t *grey16,
@@ -1024,7 +1028,7 @@ int stage_a_fused_enqueue(edgehip_ctx *c, int slot, const uint8_t *rgb_base, con
     a.und_base = undist_in_load ? c->und_base : nullptr;
     a.und_iw = undist_in_load ? c->und_iw : nullptr;
     // the shipped image sizes get their own instantiation (EuRoC 752 from RGB or mono, TUM 640 from the undistorted grey
-    // plane), any other width — and contexts with debug planes — the generic ones
+    // plane, the default GlobalConfig's 320 from RGB or mono), any other width — and contexts with debug planes — the generic ones
 #define EH_FUSED(WW, DBG, SRC) k_stage_a_fused<WW, DBG, SRC, kFusedRB, 3, 3, 5, 5, 5>
     void (*fn)(FusedArgs);
 #ifdef EDGEHIP_EXPERIMENTS   // the undistortion inside this kernel's load: measured 14 % slower than the pre-pass (EDGEHIP_FUSED_UNDIST)
@@ -1044,11 +1048,13 @@ int stage_a_fused_enqueue(edgehip_ctx *c, int slot, const uint8_t *rgb_base, con
         fn = EH_FUSED(0, false, SRC_GREY8);
         if (c->planes) fn = EH_FUSED(0, true, SRC_GREY8);
         else if (pl.w == 752) fn = EH_FUSED(752, false, SRC_GREY8);
+        else if (pl.w == 320) fn = EH_FUSED(320, false, SRC_GREY8);
     } else {
         fn = EH_FUSED(0, false, SRC_RGB24);
         if (c->planes) fn = EH_FUSED(0, true, SRC_RGB24);
         else if (pl.w == 752) fn = EH_FUSED(752, false, SRC_RGB24);
         else if (pl.w == 640) fn = EH_FUSED(640, false, SRC_RGB24);
+        else if (pl.w == 320) fn = EH_FUSED(320, false, SRC_RGB24);   // the reference's default GlobalConfig (320 x 240: a live camera)
 #ifdef EDGEHIP_EXPERIMENTS   // the occupancy experiment's widths with compile-time LDS offsets (the generic instantiation is several times slower)
         else if (pl.w == 256) fn = EH_FUSED(256, false, SRC_RGB24);
         else if (pl.w == 384) fn = EH_FUSED(384, false, SRC_RGB24);
@@ -1065,6 +1071,7 @@ int stage_a_fused_enqueue(edgehip_ctx *c, int slot, const uint8_t *rgb_base, con
 #endif
                                (const void *)EH_FUSED(0, false, SRC_RGB24), (const void *)EH_FUSED(0, true, SRC_RGB24),
                                (const void *)EH_FUSED(752, false, SRC_RGB24), (const void *)EH_FUSED(640, false, SRC_RGB24),
+                               (const void *)EH_FUSED(320, false, SRC_RGB24), (const void *)EH_FUSED(320, false, SRC_GREY8),
                                (const void *)EH_FUSED(0, false, SRC_GREY16), (const void *)EH_FUSED(0, true, SRC_GREY16),
                                (const void *)EH_FUSED(640, false, SRC_GREY16), (const void *)EH_FUSED(0, false, SRC_GREY8),
                                (const void *)EH_FUSED(0, true, SRC_GREY8), (const void *)EH_FUSED(752, false, SRC_GREY8)};

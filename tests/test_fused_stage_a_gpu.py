@@ -1,4 +1,4 @@
-"""GPU: the fused stage-A kernel (stage_a_fused.hip, EDGEHIP_LEVEL_MODE=3; the default from 32 sequences per launch on at widths 752 / 640, from 192 at others; EDGEHIP_FUSED_MIN_BATCH
+"""GPU: the fused stage-A kernel (stage_a_fused.hip, EDGEHIP_LEVEL_MODE=3; the default from 32 sequences per launch on at widths 752 / 640, 64 at 320, 192 at others; EDGEHIP_FUSED_MIN_BATCH
 overrides) against the reference, with the bar of the multi-kernel path it replaces: img0 / img1 / DoG / gradient
 planes, img_mask_kl, kn, every KeyLine field stage A defines, the threshold state and reTunedThresh — all bit-exact.
 Sizes cover: the bench size, heights that are not a multiple of the 4-row tick, widths that are not a multiple of 64
@@ -38,7 +38,7 @@ def test_fused_planes_mask_keylines_bit_exact(w, h):
     tsa._run(w, h, frames)
 
 
-@pytest.mark.parametrize("w,h", [(752, 480), (640, 480)], ids=["euroc_752", "tum_640"])
+@pytest.mark.parametrize("w,h", [(752, 480), (640, 480), (320, 240)], ids=["euroc_752", "tum_640", "default_config_320"])
 def test_fused_product_instantiations_without_debug_planes(w, h):
     """The shipped widths have their own instantiation (compile-time LDS offsets, no debug-plane code): mask, kn, KeyLines,
     threshold state against the reference."""

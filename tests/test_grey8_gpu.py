@@ -45,8 +45,8 @@ def _same(a, b):
             assert bytes(x) == bytes(y)      # the whole record, bit for bit
 
 
-@pytest.mark.parametrize("mode,w,h", [("3", 752, 480), ("3", 200, 152), ("1", 376, 240), ("0", 200, 152)],
-                         ids=["fused_752", "fused_generic", "multi_kernel", "auto_small_batch"])
+@pytest.mark.parametrize("mode,w,h", [("3", 752, 480), ("3", 320, 240), ("3", 200, 152), ("1", 376, 240), ("0", 200, 152)],
+                         ids=["fused_752", "fused_320", "fused_generic", "multi_kernel", "auto_small_batch"])
 def test_grey8_upload_is_bit_identical_to_the_rgb24_expansion(mode, w, h, monkeypatch):
     monkeypatch.setenv("EDGEHIP_LEVEL_MODE", mode)
     mono, rgb = _mono_frames(w, h, 4)
