@@ -478,7 +478,7 @@ __global__ __launch_bounds__(256) void k_field_raster(const KlSoA *kls, int32_t 
 #elif EDGEHIP_RASTER_ABL == 2    // no LDS access at all
                 acc_abl += (at << 16) | idk | (uint32_t)(ly * TS + lx);
 #else
-                atomicMin(&s_tile[ly * TS + lx], (at << 16) | idk);
+                atomicMin(&s_tile[__umul24((unsigned)ly, (unsigned)TS) + (unsigned)lx], (at << 16) | idk);   // (a 24-bit product: the 32-bit one runs at a quarter of the rate, once per sample)
 #endif
             };
 #if EDGEHIP_RASTER_UNROLL == 2
