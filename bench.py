@@ -710,7 +710,7 @@ def compact_line(full):
     if isinstance(rf, dict):
         line["roofline"] = {k: _r(rf.get(k), 5) for k in ("bound", "kernel", "achieved", "peak", "unit", "frac", "frac_on_traffic",
                                                          "frac_survey_formula", "traffic", "launch_us", "algorithmic_bytes_per_launch",
-                                                         "launches_timed", "issue_frac") if k in rf}
+                                                         "launches_timed", "issue_frac", "traffic_live", "issue_live") if k in rf}
         if rf.get("traffic") is None and rf.get("traffic_note"):
             line["roofline"]["traffic_note"] = str(rf["traffic_note"])[:120]
     else:
@@ -819,6 +819,100 @@ def _pmc_file(check_stamp=True):
     return _PMC_CACHE[key]
 
 
+LIVE_PMC = {"used": False, "note": "not attempted", "issue": None}
+
+
+def live_pmc_passes(child_argv, nseq, budget_s=150):
+    """The counters of THIS run, observed by the command itself: more processes of this file under `rocprofv3 --kernel-trace --pmc ...`
+    (no trace domain besides the kernel trace), same batch, steps and warm-up as the parent, CPU legs and extras off:
+      FETCH_SIZE, WRITE_SIZE  (separate passes: the two do not share one on gfx950) -> their per-kernel means replace
+                              profiles/pmc_latest.json for the rest of this process (same format, same calibration), so
+                              `roofline.traffic` is what the driver's own box moved, not a committed constant;
+      SQ_ACTIVE_INST_VALU + GRBM_GUI_ACTIVE (one pass, optional) -> `issue_frac` per kernel group (tools/sq_summary.py's definition,
+                              weighted by cycles) instead of profiles/sq_latest.json.
+    Any failure of the first two (no rocprofv3, a pass that times out or leaves no csv) keeps the committed counters under their
+    source stamp; LIVE_PMC says which it was."""
+    import csv
+    import glob
+    import shutil
+    import subprocess
+    import tempfile
+    exe = shutil.which("rocprofv3")
+    if not exe:
+        LIVE_PMC["note"] = "rocprofv3 not on PATH"
+        return False
+    js = {}
+    t_all = time.time()
+    kn = None
+    tmp = tempfile.mkdtemp(prefix="bench_pmc_", dir=os.environ.get("TMPDIR") or "/tmp")
+
+    def one_pass(tag, counters):
+        nonlocal kn
+        out = os.path.join(tmp, tag)
+        cmd = [exe, "--kernel-trace", "--pmc"] + list(counters) + ["--output-format", "csv", "-d", out, "-o", "pmc", "--",
+                                                                  sys.executable, os.path.abspath(__file__)] + child_argv
+        env = dict(os.environ, BENCH_LIVE_PMC_CHILD="1", BENCH_EXTRAS_FILE=os.path.join(tmp, tag + "_extras.json"), TMPDIR=tmp)
+        left = budget_s - (time.time() - t_all)
+        if left < 20:
+            return f"no time left for the {tag} pass"
+        try:
+            r = subprocess.run(cmd, cwd=tmp, env=env, capture_output=True, text=True, timeout=left, start_new_session=True)
+        except subprocess.TimeoutExpired:
+            return f"the {tag} pass did not finish in {left:.0f} s"
+        if r.returncode != 0:
+            return f"the {tag} pass exited {r.returncode}: " + (r.stderr or "")[-160:].replace("\n", " ")
+        try:
+            line = r.stdout[r.stdout.rindex('{"metric"'):]
+            kn = json.loads(line)["config"].get("keylines_per_frame_timed_mean") or kn
+        except (ValueError, KeyError):
+            pass
+        acc = {}
+        for fn in glob.glob(os.path.join(out, "**", "*counter_collection.csv"), recursive=True):
+            for row in csv.DictReader(open(fn)):
+                if row.get("Counter_Name") not in counters:
+                    continue
+                a_ = acc.setdefault((row["Kernel_Name"], row["Counter_Name"]), [0, 0.0])
+                a_[0] += 1
+                a_[1] += float(row["Counter_Value"])
+        if not acc:
+            return f"the {tag} pass left no counter_collection.csv rows"
+        for (k, c), (n, tot) in acc.items():
+            js.setdefault(k, {})[c] = {"calls": n, "mean": tot / n}
+        return None
+    try:
+        for counter in ("FETCH_SIZE", "WRITE_SIZE"):
+            err = one_pass(counter, (counter,))
+            if err:
+                LIVE_PMC["note"] = err
+                return False
+        err = one_pass("SQ", ("SQ_ACTIVE_INST_VALU", "GRBM_GUI_ACTIVE"))
+        if err:
+            LIVE_PMC["issue_note"] = err
+        else:
+            issue = {}
+            for g, subs in GROUP_KERNELS.items():
+                busy = cyc = 0.0
+                for k, c in js.items():
+                    if "SQ_ACTIVE_INST_VALU" in c and "GRBM_GUI_ACTIVE" in c and any(re.search(r"\b" + s_ + r"\b", k) for s_ in subs):
+                        n = c["GRBM_GUI_ACTIVE"]["calls"]
+                        busy += n * 4.0 * c["SQ_ACTIVE_INST_VALU"]["mean"] / 1024.0
+                        cyc += n * c["GRBM_GUI_ACTIVE"]["mean"] / 8.0
+                if cyc > 0:
+                    issue[g] = round(busy / cyc, 4)
+            LIVE_PMC["issue"] = issue or None
+    finally:
+        shutil.rmtree(tmp, ignore_errors=True)
+    js["_nseq"] = nseq
+    js["_kn"] = kn
+    js["_src_sha"] = library_source_sha()
+    js["_command"] = "live: python bench.py " + " ".join(child_argv)
+    _PMC_CACHE[True] = _PMC_CACHE[False] = js
+    LIVE_PMC.update(used=True, seconds=round(time.time() - t_all, 1), kernels=len([k for k in js if not k.startswith("_")]),
+                    note="FETCH_SIZE and WRITE_SIZE passes" + (" and an SQ_ACTIVE_INST_VALU + GRBM_GUI_ACTIVE pass" if LIVE_PMC["issue"] else "") +
+                         " of this command, run by this process on this box")
+    return True
+
+
 def pmc_stamp_note():
     try:
         js = json.load(open(os.path.join(ROOT, PMC_FILE)))
@@ -829,8 +923,10 @@ def pmc_stamp_note():
 
 
 def issue_fracs():
-    """{group: share of the kernel's busy cycles in which VALU instructions issue} from the committed SQ-counter passes
-    (profiles/sq_latest.json, tools/gpu_round.sh), under the same source stamp as the HBM counters; {} otherwise."""
+    """{group: share of the kernel's busy cycles in which VALU instructions issue} from this run's own SQ pass (live_pmc_passes) or from
+    the committed SQ-counter passes (profiles/sq_latest.json, tools/gpu_round.sh), under the same source stamp as the HBM counters; {} otherwise."""
+    if LIVE_PMC.get("issue"):
+        return dict(LIVE_PMC["issue"])
     try:
         js = json.load(open(os.path.join(ROOT, "profiles", "sq_latest.json")))
         if not js.get("_src_sha") or js.get("_src_sha") != library_source_sha():
@@ -986,6 +1082,9 @@ def main():
                          "REBVO_TUM_DIR.  Absent or not a data set: the synthetic scenes, silently")
     ap.add_argument("--dataset-frames", type=int, default=96, help="images of the list that make the HBM-resident pool")
     ap.add_argument("--no-roofline-events", action="store_true")
+    ap.add_argument("--no-live-pmc", action="store_true",
+                    help="do not run the two rocprofv3 counter passes of this command (N = 1 only) that make roofline.traffic an observation of "
+                         "this run; the committed counters of profiles/pmc_latest.json are used instead, under their source stamp")
     args = ap.parse_args()
 
     if "WORLD_SIZE" not in os.environ and args.gpus > 1:
@@ -1446,6 +1545,15 @@ def main():
     # really moves bytes (committed PMC passes — used only when they were taken with THIS library's sources, else null);
     # `issue_frac` = share of the kernel's cycles in which its SIMDs issue VALU work (committed SQ counters, same rule): a kernel
     # priced only against a roofline it is not bound by tells nobody anything.
+    under_profiler = any("rocprof" in os.environ.get(v, "") for v in ("LD_PRELOAD", "ROCP_TOOL_LIBRARIES", "HSA_TOOLS_LIB"))
+    if (world == 1 and not stub and not args.no_live_pmc and not args.no_extras and not os.environ.get("BENCH_LIVE_PMC_CHILD")
+            and not under_profiler and args.config == "full"):
+        child = [a for a in sys.argv[1:] if a != "--extras"] + ["--gpus", "1", "--nseq", str(B * C), "--steps", str(K), "--warmup", str(Wm),
+                                                                "--cpu-frames", "0", "--no-extras", "--no-roofline-events", "--no-live-pmc"]
+        torch.cuda.synchronize()
+        live_pmc_passes(child, B)
+    elif not LIVE_PMC["used"]:
+        LIVE_PMC["note"] = "switched off (--no-live-pmc / --no-extras / N > 1 / a profiler around this process)"
     calib, calib_src = fetch_calibration()
     kn_pmc = pmc_kn() or kn_mean
     issue = issue_fracs()
@@ -1479,6 +1587,8 @@ def main():
                     "launches_timed": dom_calls, "issue_frac": rd.get("issue_frac")}
             if "frac_survey_formula" in rd:
                 roof["frac_survey_formula"] = rd["frac_survey_formula"]
+            roof["traffic_live"] = bool(LIVE_PMC["used"]) and roof["traffic"] is not None
+            roof["issue_live"] = bool(LIVE_PMC.get("issue")) and roof.get("issue_frac") is not None
             if roof["traffic"] is None:
                 roof["traffic_note"] = pmc_stamp_note()
     roof_all = {}
@@ -1753,8 +1863,9 @@ def main():
         # no SCALE record of this repository exists (the driver's 8-GPU node has not been available): N > 1 is covered by the gloo
         # tests and a 2-rank dry run, not by a measured curve
         "scaling_measured": False,
-        "traffic_source": PMC_FILE + " (rocprofv3 --pmc passes of this command, committed; used only when stamped with the sources of "
-                                     "the library that is running: " + pmc_stamp_note() + ")",
+        "traffic_source": ("live: " + LIVE_PMC["note"] + f" ({LIVE_PMC.get('seconds')} s, {LIVE_PMC.get('kernels')} kernels)") if LIVE_PMC["used"] else
+                          (PMC_FILE + " (rocprofv3 --pmc passes of this command, committed; used only when stamped with the sources of "
+                                      "the library that is running: " + pmc_stamp_note() + "); live passes: " + LIVE_PMC["note"]),
         "traffic_calibration": {"factors_true_over_reported": {k: round(v, 3) for k, v in calib.items()}, "source": calib_src},
     }
     full["launched_by"] = "bench.py itself (no launcher around the command)" if os.environ.get("BENCH_SELF_LAUNCHED") == "1" else \

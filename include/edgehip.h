@@ -383,6 +383,10 @@ int edgehip_read_nav_log_device(edgehip_ctx *ctx, int first, int count, void *ou
  * as out[count][nseq] — same ring, same waiting and threading rules as edgehip_read_nav_log.  A caller that keeps frames in flight
  * (a batch group of ImuMode = 1 / 2 objects, rebvo_amd/host/src/batch_group.cpp) reads both halves of frame k while k+1 and k+2 run. */
 int edgehip_read_nav_imu_log(edgehip_ctx *ctx, int first, int count, edgehip_nav_imu *out);
+/* With a stereo rig (edgehip_set_stereo_rig): stereo_match_num (rebvo_second_t.cpp:471-477, what edgehip_get_stereo_matches returns for the
+ * newest frame) of the logged frames [first, first+count) as out[count][nseq] — same ring, same waiting and threading rules as
+ * edgehip_read_nav_log; 0 for a sequence's first frame.  A batch group of StereoAvaiable objects reads it with frames in flight. */
+int edgehip_read_stereo_matches_log(edgehip_ctx *ctx, int first, int count, int32_t *out);
 /* Restart every sequence from scratch: state as after edgehip_create (thresholds, priors, pose, frame
  * counters) and an empty ring.  Not something the reference does at run time (it would re-construct REBVO). */
 int edgehip_reset(edgehip_ctx *ctx);

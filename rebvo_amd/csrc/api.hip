@@ -686,6 +686,7 @@ int edgehip_destroy(edgehip_ctx *c) {
     if (c->pinned_grey8) (void)hipHostFree(c->pinned_grey8);
     if (c->nav_log) (void)hipFree(c->nav_log);
     if (c->nav_imu_log) (void)hipFree(c->nav_imu_log);
+    if (c->stereo_log) (void)hipFree(c->stereo_log);
     if (c->stream_imu) { (void)hipStreamSynchronize(c->stream_imu); (void)hipStreamDestroy(c->stream_imu); for (int i = 0; i < 2; i++) { (void)hipEventDestroy(c->ev_imu_snap[i]); (void)hipEventDestroy(c->ev_imu_post[i]); (void)hipEventDestroy(c->ev_imu_mid[i]); } }
     if (c->kf_req_dev) (void)hipFree(c->kf_req_dev);
     if (c->kf_res_dev) (void)hipFree(c->kf_res_dev);
@@ -1004,6 +1005,7 @@ int edgehip_set_nav_log(edgehip_ctx *c, int len) {
     if (c->stream_log) EH_CHECK(hipStreamSynchronize(c->stream_log));
     if (c->nav_log) { (void)hipFree(c->nav_log); c->nav_log = nullptr; }
     if (c->nav_imu_log) { (void)hipFree(c->nav_imu_log); c->nav_imu_log = nullptr; }
+    if (c->stereo_log) { (void)hipFree(c->stereo_log); c->stereo_log = nullptr; }
     c->nav_log_len = 0;
     c->frames_logged = 0;
     c->log_first = 0; c->log_last = -1;
@@ -1032,18 +1034,31 @@ int edgehip_set_nav_log(edgehip_ctx *c, int len) {
             EH_CHECK(hipStreamSynchronize(c->stream));
             c->nav_imu_log = (edgehip_nav_imu *)q;
         }
+        if (c->stereo_cnt) {   // StereoAvaiable: stereo_match_num of every logged frame (edgehip_read_stereo_matches_log)
+            if (hipMalloc(&q, sizeof(int32_t) * (size_t)len * c->plan.nseq) != hipSuccess) {
+                (void)hipGetLastError();
+                set_error("nav log alloc failed");
+                return EDGEHIP_ERR_MEMORY;
+            }
+            EH_CHECK(hipMemsetAsync(q, 0, sizeof(int32_t) * (size_t)len * c->plan.nseq, c->stream));
+            EH_CHECK(hipStreamSynchronize(c->stream));
+            c->stereo_log = (int32_t *)q;
+        }
         c->nav_log_len = len;
     }
     return 0;
 }
 
 // Shared body of edgehip_read_nav_log (host destination) and edgehip_read_nav_log_device (device destination).
-static int read_nav_log_impl(edgehip_ctx *c, int first, int count, void *out_v, hipMemcpyKind kind, bool imu_half = false) {
+enum LogPart { LOG_NAV = 0, LOG_IMU = 1, LOG_STEREO = 2 };
+static int read_nav_log_impl(edgehip_ctx *c, int first, int count, void *out_v, hipMemcpyKind kind, LogPart part = LOG_NAV) {
     EH_ENTER(c);
-    if (imu_half && c && !c->nav_imu_log) { set_error("read_nav_imu_log: needs edgehip_imu_enable and edgehip_set_nav_log"); return EDGEHIP_ERR_STATE; }
-    const size_t rec = imu_half ? sizeof(edgehip_nav_imu) : sizeof(edgehip_nav);
+    if (part == LOG_IMU && c && !c->nav_imu_log) { set_error("read_nav_imu_log: needs edgehip_imu_enable and edgehip_set_nav_log"); return EDGEHIP_ERR_STATE; }
+    if (part == LOG_STEREO && c && !c->stereo_log) { set_error("read_stereo_matches_log: needs a context with stereo_available and edgehip_set_nav_log"); return EDGEHIP_ERR_STATE; }
+    const size_t rec = part == LOG_IMU ? sizeof(edgehip_nav_imu) : part == LOG_STEREO ? sizeof(int32_t) : sizeof(edgehip_nav);
     char *out = static_cast<char *>(out_v);
-    const char *log = c ? (imu_half ? reinterpret_cast<const char *>(c->nav_imu_log) : reinterpret_cast<const char *>(c->nav_log)) : nullptr;
+    const char *log = !c ? nullptr : part == LOG_IMU ? reinterpret_cast<const char *>(c->nav_imu_log) : part == LOG_STEREO ? reinterpret_cast<const char *>(c->stereo_log)
+                                                                                                   : reinterpret_cast<const char *>(c->nav_log);
     if (!c || !out || !c->nav_log || first < 0 || count < 1 || count > c->nav_log_len) { set_error("read_nav_log: bad range or log disabled"); return EDGEHIP_ERR_ARG; }
     // Records of frames that were never enqueued do not exist; `first` counts frames since edgehip_reset / the first frame
     // (edgehip_nav::frame), the counter frames since edgehip_set_nav_log — equal when the log is set before the first frame.
@@ -1084,7 +1099,10 @@ int edgehip_read_nav_log_device(edgehip_ctx *c, int first, int count, void *out_
     return read_nav_log_impl(c, first, count, out_dev, hipMemcpyDeviceToDevice);
 }
 int edgehip_read_nav_imu_log(edgehip_ctx *c, int first, int count, edgehip_nav_imu *out) {
-    return read_nav_log_impl(c, first, count, out, hipMemcpyDeviceToHost, true);
+    return read_nav_log_impl(c, first, count, out, hipMemcpyDeviceToHost, LOG_IMU);
+}
+int edgehip_read_stereo_matches_log(edgehip_ctx *c, int first, int count, int32_t *out) {
+    return read_nav_log_impl(c, first, count, out, hipMemcpyDeviceToHost, LOG_STEREO);
 }
 
 int edgehip_stage_a(edgehip_ctx *c, int slot) {

@@ -316,6 +316,7 @@ struct edgehip_ctx {
     edgehip_nav *nav_log;  // [nav_log_len][B] ring of per-frame records (optional)
     edgehip_nav_imu *nav_imu_log = nullptr;   // the IMU part of the same records, same ring (allocated when both the log and the IMU branch are on)
     int nav_log_len;
+    int32_t *stereo_log = nullptr;   // [nav_log_len][B] stereo_match_num of the logged frames (a context with stereo_available and a log)
     // The log is read by a thread of its own while another enqueues frames (shard.NavMover): the read-out has its own stream,
     // ordered after the frames it covers by ev_log (re-recorded behind every frame on the stream that writes the records);
     // it never touches c->stream, which may be capturing a frame graph.  log_mu orders the record / wait pair on the event.

@@ -1089,7 +1089,8 @@ __device__ inline void frame_end(SeqDev *sq, const int seq, const FrameEndArgs &
 __global__ void k_frame_glue(SeqDev *seqs, const double *__restrict__ t_in, edgehip_nav *__restrict__ nav,
                              const int32_t *__restrict__ kn_new, const double *__restrict__ tresh_new,
                              const float *__restrict__ retuned_new, int nseq, int mode, double fps, int match_threshold,
-                             int have_pair, edgehip_nav *__restrict__ nav_log, int nav_log_len) {
+                             int have_pair, edgehip_nav *__restrict__ nav_log, int nav_log_len, const int32_t *__restrict__ stereo_cnt,
+                             int32_t *__restrict__ stereo_log) {
     const int seq = blockIdx.x * blockDim.x + threadIdx.x;
     if (seq >= nseq) return;
     SeqDev *sq = seqs + seq;
@@ -1104,6 +1105,8 @@ __global__ void k_frame_glue(SeqDev *seqs, const double *__restrict__ t_in, edge
         FrameEndArgs fe;
         fe.nav = nav; fe.kn_new = kn_new; fe.tresh_new = tresh_new; fe.retuned_new = retuned_new;
         fe.nav_log = nav_log; fe.nav_log_len = nav_log_len; fe.nseq = nseq; fe.have_pair = have_pair;
+        // (with a stereo rig and a log: the frame's stereo_match_num beside its record, before frame_end moves p.frame on)
+        if (stereo_log && nav_log_len > 0) stereo_log[(size_t)(p.frame % nav_log_len) * nseq + seq] = have_pair ? stereo_cnt[seq] : 0;
         frame_end(sq, seq, fe);
     }
 }
@@ -1529,7 +1532,7 @@ static int glue(edgehip_ctx *c, int mode, int slot_new, int have_pair) {
     hipLaunchKernelGGL(k_frame_glue, dim3((pl.nseq + 63) / 64), dim3(64), 0, c->stream, c->seq, c->t_src, c->nav_dev,
                        c->kn_slot + (size_t)slot_new * pl.nseq, c->tresh_slot + (size_t)slot_t * pl.nseq,
                        c->retuned_slot + (size_t)slot_new * pl.nseq, pl.nseq, mode, c->p.config_fps, c->p.global_match_threshold,
-                       have_pair, c->nav_log, c->nav_log_len);
+                       have_pair, c->nav_log, c->nav_log_len, c->stereo_cnt, c->rig.enabled ? c->stereo_log : nullptr);
     EH_LAUNCH_CHECK();
     return 0;
 }

@@ -202,7 +202,7 @@ EXPORTS = [
     "edgehip_set_state", "edgehip_get_framecount", "edgehip_set_framecount", "edgehip_download_keylines", "edgehip_download_keylines_batch",
     "edgehip_upload_keylines", "edgehip_download_plane", "edgehip_download_field", "edgehip_profile_enable",
     "edgehip_profile_count", "edgehip_profile_name", "edgehip_profile_read", "edgehip_profile_select",
-    "edgehip_upload_rgb_indexed", "edgehip_bind_rgb_indexed", "edgehip_set_nav_log", "edgehip_read_nav_log", "edgehip_read_nav_log_device", "edgehip_read_nav_imu_log", "edgehip_set_tracker_precision", "edgehip_export_keylines", "edgehip_export_fetch", "edgehip_export_wait",
+    "edgehip_upload_rgb_indexed", "edgehip_bind_rgb_indexed", "edgehip_set_nav_log", "edgehip_read_nav_log", "edgehip_read_nav_log_device", "edgehip_read_nav_imu_log", "edgehip_read_stereo_matches_log", "edgehip_set_tracker_precision", "edgehip_export_keylines", "edgehip_export_fetch", "edgehip_export_wait",
     "edgehip_build_undistort_map", "edgehip_download_undistorted", "edgehip_depth_reset", "edgehip_depth_reset_slot", "edgehip_set_slot_camera", "edgehip_directed_matching_stereo",
     "edgehip_alloc_pinned", "edgehip_free_pinned", "edgehip_upload_rgb_pinned", "edgehip_upload_sync", "edgehip_upload_wait", "edgehip_register_host", "edgehip_unregister_host", "edgehip_experiments", "edgehip_fuse_stereo_depth", "edgehip_set_stereo_rig", "edgehip_get_stereo_matches", "edgehip_minimizer_v", "edgehip_ext_rot_vel",
     "edgehip_imu_enable", "edgehip_set_imu", "edgehip_read_nav_imu", "edgehip_minimizer_rv_kf", "edgehip_lm_solve",
@@ -425,6 +425,12 @@ class EdgeHip:
         out = (NavImu * (count * self.nseq))()
         self._ck(self.lib.edgehip_read_nav_imu_log(self.ctx, first, count, out))
         return [[out[k * self.nseq + s] for s in range(self.nseq)] for k in range(count)]
+
+    def read_stereo_matches_log(self, first, count):
+        """stereo_match_num of the logged frames [first, first+count) (a context with a stereo rig): int32 array [count, nseq]."""
+        out = np.zeros((count, self.nseq), dtype=np.int32)
+        self._ck(self.lib.edgehip_read_stereo_matches_log(self.ctx, first, count, out.ctypes.data_as(C.c_void_p)))
+        return out
 
     def read_nav_log_device(self, first, count, out_dev_ptr):
         """Records of frames [first, first+count) as raw edgehip_nav structs into device memory ([count][nseq][NAV_DTYPE.itemsize]

@@ -20,6 +20,9 @@
 // --tint I:F: the first byte of object I's frame F is flipped (^ 0x80): a coloured pixel in an otherwise mono frame — that step crosses PCIe as RGB24.
 // --stagger: object i's frame k carries the stamp t0 + dt (k + i) (object i enters the common time line i frames late: with one IMU file
 // for all objects — ImuMode=2 — every object's images then agree with the IMU samples of its own stamps).
+// --stereo PAIRS.rgb24: every object has a stereo pair (the config's StereoAvaiable=1 and &Stereo section): pool_frames pair images, pair
+//   frame j belongs to pool frame j; each object's pair frame goes in through requestStereoCustomCamBuffer / releaseStereoCustomCamBuffer
+//   right before its main frame, with the same stamp.  The dump's last column is PipeBuffer::stereo_match_num.
 // --snapshot-at F: object 0's TakeSnapshot() is called before its frame F is submitted (Snap0.ppm in the working directory).
 // timed over the frames after the first W of every object (default 0), from the submission of frame W to the moment every
 // object's getNav() shows its last frame.
@@ -75,7 +78,7 @@ struct Sink {
         for (int i = 0; i < 7; i++) dump << " " << p.imustate.X[i];
         for (int i = 0; i < 3; i++) dump << " " << p.imustate.b_est[i];
         for (int i = 0; i < 3; i++) dump << " " << p.imustate.u_est[i];
-        dump << " " << p.dt << "\n";
+        dump << " " << p.dt << " " << p.stereo_match_num << "\n";
         return true;
     }
 };
@@ -90,7 +93,7 @@ int main(int argn, char **argv) {
     }
     const int pool_frames = atoi(argv[3]), N = atoi(argv[4]), K = atoi(argv[5]);
     const double t0 = atof(argv[6]), dt = atof(argv[7]);
-    std::string group, dump_prefix;
+    std::string group, dump_prefix, pair_file;
     bool want_cb = false;
     int T = 1, W = 0, leave_obj = -1, leave_at = 0, snapshot_at = -1, dup_obj = -1, dup_at = 0, tint_obj = -1, tint_at = 0;
     bool step_mode = false, stagger = false;
@@ -103,6 +106,7 @@ int main(int argn, char **argv) {
         else if (s == "--warmup" && a + 1 < argn) W = atoi(argv[++a]);
         else if (s == "--step-mode") step_mode = true;
         else if (s == "--stagger") stagger = true;
+        else if (s == "--stereo" && a + 1 < argn) pair_file = argv[++a];
         else if (s == "--snapshot-at" && a + 1 < argn) snapshot_at = atoi(argv[++a]);
         else if (s == "--tint" && a + 1 < argn) { if (std::sscanf(argv[++a], "%d:%d", &tint_obj, &tint_at) != 2) return 2; }
         else if (s == "--dup" && a + 1 < argn) { if (std::sscanf(argv[++a], "%d:%d", &dup_obj, &dup_at) != 2) return 2; }
@@ -124,6 +128,15 @@ int main(int argn, char **argv) {
         if (!in.is_open()) { std::cout << "cannot open " << argv[2] << "\n"; return 5; }
         in.read(reinterpret_cast<char *>(pool.data()), (std::streamsize)pool.size());
         if ((size_t)in.gcount() != pool.size()) { std::cout << "short read of " << argv[2] << "\n"; return 5; }
+    }
+
+    std::vector<uint8_t> pair_pool;
+    if (!pair_file.empty()) {
+        if (!prm.StereoAvaiable) { std::cout << "--stereo needs StereoAvaiable=1 in the config\n"; return 3; }
+        pair_pool.resize(fb * pool_frames);
+        std::ifstream in(pair_file, std::ios::binary);
+        in.read(reinterpret_cast<char *>(pair_pool.data()), (std::streamsize)pair_pool.size());
+        if (!in.is_open() || (size_t)in.gcount() != pair_pool.size()) { std::cout << "cannot read " << pair_file << "\n"; return 5; }
     }
 
     const double t_phase0 = now_s();
@@ -170,6 +183,14 @@ int main(int argn, char **argv) {
                     obj[i]->releaseCustomCamBuffer();
                 }
                 if (i == 0 && k == snapshot_at) obj[0]->TakeSnapshot();
+                if (!pair_pool.empty()) {   // the pair camera's frame of this instant
+                    std::shared_ptr<Image<RGB24Pixel>> pp;
+                    while (!obj[i]->requestStereoCustomCamBuffer(pp, stagger ? t0 + dt * (k + i) : t0 + dt * k, 0.1))
+                        if (!obj[i]->Running()) { bad = true; break; }
+                    if (bad) break;
+                    (*pp).copyFrom(reinterpret_cast<const RGB24Pixel *>(pair_pool.data() + fb * tri((long)k + i, pool_frames)));
+                    obj[i]->releaseStereoCustomCamBuffer();
+                }
                 std::shared_ptr<Image<RGB24Pixel>> ptr;
                 const double tq0 = now_s();
                 while (!obj[i]->requestCustomCamBuffer(ptr, stagger ? t0 + dt * (k + i) : t0 + dt * k, 0.1))

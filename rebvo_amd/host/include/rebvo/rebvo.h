@@ -366,7 +366,8 @@ class REBVO {
     BatchGroup *group = nullptr;
     int group_seat = -1;
     customCam::CustomCamPipeBuffer *cam_cur = nullptr;   // the buffer the application holds between request and releaseCustomCamBuffer
-    void groupFrameWritten(customCam::CustomCamPipeBuffer *b);
+    customCam::CustomCamPipeBuffer *cam_cur_pair = nullptr;   // ... and between requestStereoCustomCamBuffer and releaseStereoCustomCamBuffer
+    void groupFrameWritten(customCam::CustomCamPipeBuffer *b, bool pair = false);
     bool cam_pinned = false;       // the camera ring's images are page-locked views of the group's ring (batch_group.cpp), not heap images
     bool groupAttach();            // Init() of such an object
     void groupDetach();            // CleanUp()
@@ -374,9 +375,13 @@ class REBVO {
     // then reach the group through the object's own camera ring, put there by a feeder thread
     bool useGroupEngine() const {
         // ImuMode 1 / 2 (round 6): members of a NAMED group run the device-side IMU branch for the whole batch (edgehip_imu_enable /
-        // edgehip_set_imu; the group thread grabs every member's inter-frame IMU data); an object alone keeps the host-side filters
-        return (params.CameraType == 3 || (params.CameraType == 2 && !params.GpuBatchGroup.empty())) && !params.StereoAvaiable &&
-               (params.ImuMode == 0 || !params.GpuBatchGroup.empty());
+        // edgehip_set_imu; the group thread grabs every member's inter-frame IMU data); an object alone keeps the host-side filters.
+        // StereoAvaiable: members of a NAMED group (ImuMode 0) share a context with a pair slot and the rig inside
+        // edgehip_process_frame, their pair frames cross in the group's second page-locked ring; an object alone keeps its own thread.
+        const bool named = !params.GpuBatchGroup.empty();
+        if (!(params.CameraType == 3 || (params.CameraType == 2 && named))) return false;
+        if (params.StereoAvaiable) return named && params.ImuMode == 0;
+        return params.ImuMode == 0 || named;
     }
     std::thread feeder;            // CameraType 2 in a batch group: DataSetCam -> camera ring
     static void FeedThread(REBVO *cf);
@@ -463,11 +468,17 @@ public:
     bool requestStereoCustomCamBuffer(std::shared_ptr<Image<RGB24Pixel>> &ptr, double time_stamp, double timeout_secs = 0) {
         customCam::CustomCamPipeBuffer *ccpb = cam_pipe_stereo.RequestBufferTimeoutable(0, timeout_secs);
         if (ccpb == nullptr) return false;
+        if (!(*ccpb).img) (*ccpb).img = std::make_shared<Image<RGB24Pixel>>(params.ImageSize);   // (group engine outside Init()..CleanUp())
         ptr = (*ccpb).img;
         (*ccpb).timestamp = time_stamp;
+        cam_cur_pair = ccpb;
         return true;
     }
-    void releaseStereoCustomCamBuffer() { cam_pipe_stereo.ReleaseBuffer(0); }
+    void releaseStereoCustomCamBuffer() {
+        if (group && cam_cur_pair) groupFrameWritten(cam_cur_pair, true);   // (a mono pair frame's 8-bit plane, like releaseCustomCamBuffer)
+        cam_cur_pair = nullptr;
+        cam_pipe_stereo.ReleaseBuffer(0);
+    }
 
     template <typename T>
     void setOutputCallback(bool (T::*method)(PipeBuffer &), T *obj) {

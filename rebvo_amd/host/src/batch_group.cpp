@@ -1,5 +1,7 @@
 // batch_group.cpp — one device context shared by N rebvo::REBVO objects (CameraType 3 or a DataSetCam; ImuMode 0, or — all members
-// alike — 1 / 2 with the IMU branch of SecondThread batched on the device, round 6; mono), and the pipelined
+// alike — 1 / 2 with the IMU branch of SecondThread batched on the device, round 6; mono, or — all members alike, ImuMode 0 — a stereo
+// rig each: one pair frame per accepted main frame (rebvo_first_t.cpp:183-199) through a second page-locked ring into the context's pair
+// slot, the stereo steps of SecondThread (rebvo_second_t.cpp:465-486) inside the group's edgehip_process_frame), and the pipelined
 // frame loop behind them.  The plugin surface stays per object (requestCustomCamBuffer / releaseCustomCamBuffer,
 // setOutputCallback, getNav: include/rebvo/rebvo.h:548-609 of the reference); what FirstThr and SecondThread do per frame
 // (src/rebvo/rebvo_first_t.cpp:87-337, src/rebvo/rebvo_second_t.cpp:43-636) happens once per STEP for every member at once:
@@ -33,6 +35,7 @@
 #include <algorithm>
 #include <array>
 #include <chrono>
+#include <cmath>
 #include <condition_variable>
 #include <cstdio>
 #include <cstdlib>
@@ -79,6 +82,11 @@ public:
                                    // for its callback land in them without a staging copy
         bool step_granted = false; // frame-by-frame mode: the application's "advance" has been taken for the frame about to be grabbed
         bool leaving = false;      // cf->quit seen: the seat closes once the step in flight (which may carry its last frame) is done
+        // StereoAvaiable: the pair frame that goes with the gathered main frame, and the one held for the step launched last
+        customCam::CustomCamPipeBuffer *cbuf_pair = nullptr, *chold_pair = nullptr;
+        int pair_idx = -1;         // entry of the pair ring the gathered pair frame sits in (-1: a heap image)
+        uint8_t pair_mono_of[CCAMBUFSIZE] = {};
+        bool pair_mono = false;
         IntegratedImuData imu_data;   // ImuMode > 0: the integrated IMU data of the interval that ends with the gathered frame (rebvo_first_t.cpp:294-304)
         bool out_inline = false;   // nobody listens to this member (no callback, no log file, no snapshot pending): it has no output thread,
                                    // the group's thread passes its frames through the third player's position itself
@@ -94,6 +102,10 @@ public:
     edgehip_imu_params ip;
     std::vector<edgehip_imu_integrated> imu_in;   // [cap] what edgehip_set_imu takes for the step being launched
     std::vector<edgehip_nav_imu> navs_imu;        // [cap] the IMU half of a completed step's records
+    bool stereo = false;           // every member has a stereo pair (ImuMode 0): a fourth slot behind the ring holds the pair images' edge maps
+    float stereo_cam[4] = {0, 0, 0, 0};   // &Stereo PPx, PPy, ZfX, ZfY (the same for every member: edgehip_set_slot_camera is per context)
+    std::vector<int32_t> stereo_nm;       // [cap] stereo_match_num of a completed step
+    static constexpr int kPairSlot = 3;
     edgehip_ctx *hip = nullptr;
     std::vector<Seat> seats;
     int attached = 0;
@@ -105,14 +117,18 @@ public:
     // The page-locked rings live as long as anybody can reach them: the group holds one reference, every camera-buffer view handed
     // out through requestCustomCamBuffer another (the application's shared_ptr may outlive CleanUp(), as a heap image's would).
     struct RingOwner {
-        uint8_t *ring = nullptr, *grey = nullptr;
-        ~RingOwner() { if (ring) edgehip_free_pinned(ring); if (grey) edgehip_free_pinned(grey); }
+        uint8_t *ring = nullptr, *grey = nullptr, *pair = nullptr, *pair_grey = nullptr;
+        ~RingOwner() {
+            for (uint8_t *p : {ring, grey, pair, pair_grey})
+                if (p) edgehip_free_pinned(p);
+        }
     };
     std::shared_ptr<RingOwner> ring_owner;
     uint8_t *ring = nullptr;       // page-locked [CCAMBUFSIZE][cap][frame]: the members' camera buffers (null: heap images, staged uploads)
     size_t frame_bytes = 0;
     uint8_t *grey_ring = nullptr;  // page-locked [CCAMBUFSIZE][cap][w * h]: 8-bit planes of the mono frames among them (null: MonoUpload off)
     size_t grey_bytes = 0;
+    uint8_t *pair_ring = nullptr, *pair_grey_ring = nullptr;   // the same two rings for the members' pair cameras (StereoAvaiable)
     long mono_steps = 0;           // steps that went up as 8-bit planes
     long newest = -1;              // newest step enqueued
     // where the group thread's time goes (REBVO_GROUP_TIMING=1 prints it when the thread ends)
@@ -142,6 +158,12 @@ public:
     uint8_t *ringImage(int entry, int seat) { return ring + ((size_t)entry * cap + seat) * frame_bytes; }
     uint8_t *greyImage(int entry, int seat) { return grey_ring + ((size_t)entry * cap + seat) * grey_bytes; }
     int ringEntryOf(const uint8_t *p) const { return ring && p >= ring && p < ring + frame_bytes * CCAMBUFSIZE * cap ? (int)((size_t)(p - ring) / (frame_bytes * cap)) : -1; }
+    uint8_t *pairImage(int entry, int seat) { return pair_ring + ((size_t)entry * cap + seat) * frame_bytes; }
+    uint8_t *pairGrey(int entry, int seat) { return pair_grey_ring + ((size_t)entry * cap + seat) * grey_bytes; }
+    int pairEntryOf(const uint8_t *p) const {
+        return pair_ring && p >= pair_ring && p < pair_ring + frame_bytes * CCAMBUFSIZE * cap ? (int)((size_t)(p - pair_ring) / (frame_bytes * cap)) : -1;
+    }
+    int uploadRuns(int slot, bool pair);
     void closeSeat(Seat &st);
     void pinKeyLines(Seat &st, bool pin);
 };
@@ -150,7 +172,9 @@ public:
 bool REBVO::groupAttach() {
     edgehip_params hp;
     detail::fill_hip_params(params, hp);
-    hp.stereo_available = 0;
+    hp.stereo_available = params.StereoAvaiable ? 1 : 0;
+    const bool stereo = params.StereoAvaiable;
+    const float stereo_cam[4] = {params.pp_x_stereo, params.pp_y_stereo, params.z_f_x_stereo, params.z_f_y_stereo};
     const bool named = !params.GpuBatchGroup.empty();
     const int want = named ? params.GpuBatchSize : 1;
     const bool imu_mode = params.ImuMode > 0;
@@ -188,6 +212,9 @@ bool REBVO::groupAttach() {
         g->ip = ip;
         g->imu_in.resize(want);
         g->navs_imu.resize(want);
+        g->stereo = stereo;
+        std::memcpy(g->stereo_cam, stereo_cam, sizeof stereo_cam);
+        g->stereo_nm.assign(want, 0);
         for (edgehip_imu_integrated &r : g->imu_in) {   // (a seat nobody sits on: a record that integrates to nothing)
             std::memset(&r, 0, sizeof r);
             r.n = 1; r.dt = 1.0 / params.config_fps;
@@ -195,11 +222,16 @@ bool REBVO::groupAttach() {
         }
         const bool dbg = getenv("REBVO_GROUP_TIMING") && atoi(getenv("REBVO_GROUP_TIMING")) >= 3;
         const double tc0 = detail::now_s();
-        int rc = edgehip_create(&hp, want, 3, params.GpuDevice, &g->hip);
+        // with stereo pairs one more slot, behind the ring, holds the pair images' edge maps (as REBVO::Init does for an object alone)
+        int rc = edgehip_create(&hp, want, stereo ? 4 : 3, params.GpuDevice, &g->hip);
         if (dbg) std::fprintf(stderr, "REBVO(hip) group '%s': edgehip_create(%d sequences) took %.2f s\n", g->name.c_str(), want, detail::now_s() - tc0);
         g->tracker_bits = params.GpuTrackerPrecision;
         if (rc == 0 && params.GpuTrackerPrecision != 64) rc = edgehip_set_tracker_precision(g->hip, params.GpuTrackerPrecision);
         if (rc == 0 && imu_mode) rc = edgehip_imu_enable(g->hip, &ip);
+        if (rc == 0 && stereo) {   // the pair camera's intrinsics for stage A of the pair slot; rig and search radius of rebvo_second_t.cpp:466-473
+            rc = edgehip_set_slot_camera(g->hip, BatchGroup::kPairSlot, stereo_cam[0], stereo_cam[1], stereo_cam[2], stereo_cam[3]);
+            if (rc == 0) rc = edgehip_set_stereo_rig(g->hip, BatchGroup::kPairSlot, kTCam2Pair, kRCam2Pair, 100.0);
+        }
         if (rc == 0) rc = edgehip_set_nav_log(g->hip, BatchGroup::kNavLog);
         g->frame_bytes = (size_t)params.ImageSize.w * params.ImageSize.h * sizeof(RGB24Pixel);
         void *ringp = nullptr;
@@ -207,9 +239,16 @@ bool REBVO::groupAttach() {
         g->grey_bytes = (size_t)params.ImageSize.w * params.ImageSize.h;
         void *greyp = nullptr;
         if (rc == 0 && g->ring && params.GpuMonoUpload && edgehip_alloc_pinned(g->grey_bytes * CCAMBUFSIZE * want, &greyp) == 0) g->grey_ring = static_cast<uint8_t *>(greyp);
+        if (rc == 0 && stereo && g->ring) {   // the pair cameras' rings (without them: heap images, staged uploads)
+            void *pp = nullptr, *pg = nullptr;
+            if (edgehip_alloc_pinned(g->frame_bytes * CCAMBUFSIZE * want, &pp) == 0) g->pair_ring = static_cast<uint8_t *>(pp);
+            if (g->pair_ring && g->grey_ring && edgehip_alloc_pinned(g->grey_bytes * CCAMBUFSIZE * want, &pg) == 0) g->pair_grey_ring = static_cast<uint8_t *>(pg);
+        }
         g->ring_owner = std::make_shared<BatchGroup::RingOwner>();
         g->ring_owner->ring = g->ring;
         g->ring_owner->grey = g->grey_ring;
+        g->ring_owner->pair = g->pair_ring;
+        g->ring_owner->pair_grey = g->pair_grey_ring;
         if (dbg) std::fprintf(stderr, "REBVO(hip) group '%s': page-locked rings %s / %s after %.2f s\n", g->name.c_str(), g->ring ? "ok" : "NONE", g->grey_ring ? "ok" : "none",
                               detail::now_s() - tc0);
         if (rc != 0) {
@@ -227,6 +266,8 @@ bool REBVO::groupAttach() {
             return fail("REBVO(hip): BatchGroup '" + g->name + "': every member needs the same &GPU TrackerPrecision");
         if (g->imu_mode != imu_mode || (imu_mode && std::memcmp(&g->ip, &ip, sizeof ip) != 0))
             return fail("REBVO(hip): BatchGroup '" + g->name + "': every member needs the same ImuMode (0, or 1 / 2) and the same &IMU filter parameters");
+        if (g->stereo != stereo || (stereo && std::memcmp(g->stereo_cam, stereo_cam, sizeof stereo_cam) != 0))
+            return fail("REBVO(hip): BatchGroup '" + g->name + "': every member needs the same StereoAvaiable and the same &Stereo intrinsics");
     }
     std::unique_lock<std::mutex> lk(g->mut);
     if (g->started && g->attached >= g->cap) {
@@ -256,6 +297,15 @@ bool REBVO::groupAttach() {
     } else {   // no page-locked ring (the allocation failed): heap images, staged uploads
         for (unsigned j = 0; j < cam_pipe.Size(); j++)
             if (!cam_pipe[j].img) cam_pipe[j].img = std::make_shared<Image<RGB24Pixel>>(params.ImageSize);
+    }
+    if (stereo && g->pair_ring) {
+        std::shared_ptr<BatchGroup::RingOwner> owner = g->ring_owner;
+        for (unsigned j = 0; j < cam_pipe_stereo.Size(); j++)
+            cam_pipe_stereo[j].img = std::shared_ptr<Image<RGB24Pixel>>(new Image<RGB24Pixel>(reinterpret_cast<RGB24Pixel *>(g->pairImage((int)j, seat)), params.ImageSize),
+                                                                        [owner](Image<RGB24Pixel> *p) { delete p; });
+    } else if (stereo) {
+        for (unsigned j = 0; j < cam_pipe_stereo.Size(); j++)
+            if (!cam_pipe_stereo[j].img) cam_pipe_stereo[j].img = std::make_shared<Image<RGB24Pixel>>(params.ImageSize);
     }
     quit = false;
     // The output thread exists to call the callback, write the log and save snapshots (rebvo_third_t.cpp:174-343).  A member that has
@@ -294,6 +344,19 @@ void REBVO::FeedThread(REBVO *cf) {
         cf->groupFrameWritten(b);
         cf->cam_pipe.ReleaseBuffer(0);
         cf->dscam->ReleaseBuffer();
+        if (cf->dscam_pair) {   // the pair list, image by image beside the main one (REBVO::initPairCamera, rebvo_first_t.cpp:64-76, 183-199)
+            double tp = 0;
+            const RGB24Pixel *dp = cf->dscam_pair->GrabBuffer(tp, false);
+            if (!dp) { std::cout << "bye bye cruel world on stereo\n"; break; }
+            customCam::CustomCamPipeBuffer *pb = nullptr;
+            while (!cf->quit && (pb = cf->cam_pipe_stereo.RequestBufferTimeoutable(0, 0.01)) == nullptr) {}
+            if (!pb) return;
+            pb->timestamp = tp;
+            pb->img->copyFrom(dp);
+            cf->groupFrameWritten(pb, true);
+            cf->cam_pipe_stereo.ReleaseBuffer(0);
+            cf->dscam_pair->ReleaseBuffer();
+        }
     }
     for (int i = 0; i < CCAMBUFSIZE && !cf->quit; i++)
         if (slot(-1e300)) cf->cam_pipe.ReleaseBuffer(0);
@@ -336,6 +399,8 @@ void REBVO::groupDetach() {
     group_seat = -1;
     if (cam_pinned) {   // the ring goes with the group (with the last view of it): this object has no camera buffers until it is Init()ed again
         for (unsigned j = 0; j < cam_pipe.Size(); j++) cam_pipe[j].img.reset();
+        if (params.StereoAvaiable)
+            for (unsigned j = 0; j < cam_pipe_stereo.Size(); j++) cam_pipe_stereo[j].img.reset();
         cam_pinned = false;
     }
     if (last) {   // the last member out stops the thread and frees the context
@@ -348,10 +413,15 @@ void REBVO::groupDetach() {
 
 // The application (or the feeder thread) has written a frame into one of this member's camera buffers and is about to release it:
 // if the frame is a mono camera's, its 8-bit plane goes into the group's second page-locked ring (src/mono_pack.cpp).
-void REBVO::groupFrameWritten(customCam::CustomCamPipeBuffer *b) {
+void REBVO::groupFrameWritten(customCam::CustomCamPipeBuffer *b, bool pair) {
     BatchGroup *g = group;
     if (!g || !b || !b->img) return;
     const uint8_t *p = reinterpret_cast<const uint8_t *>(b->img->Data());
+    if (pair) {   // the pair camera's frame: its 8-bit plane only (PipeBuffer::imgc_pair is copied by the group's thread, for listeners)
+        const int pe = g->pairEntryOf(p);
+        if (pe >= 0 && g->pair_grey_ring) g->seats[group_seat].pair_mono_of[pe] = (uint8_t)rebvo_pack_mono(p, g->grey_bytes, g->pairGrey(pe, group_seat));
+        return;
+    }
     const int entry = g->ringEntryOf(p);
     if (entry < 0) return;
     BatchGroup::Seat &st = g->seats[group_seat];
@@ -385,6 +455,8 @@ void REBVO::BatchGroup::closeSeat(Seat &st) {
     if (st.kl_pinned) pinKeyLines(st, false);
     if (st.chold) { cf->cam_pipe.ReleaseBufferAt(1, st.chold); st.chold = nullptr; }
     if (st.cbuf) { cf->cam_pipe.ReleaseBufferAt(1, st.cbuf); st.cbuf = nullptr; }
+    if (st.chold_pair) { cf->cam_pipe_stereo.ReleaseBufferAt(1, st.chold_pair); st.chold_pair = nullptr; }
+    if (st.cbuf_pair) { cf->cam_pipe_stereo.ReleaseBufferAt(1, st.cbuf_pair); st.cbuf_pair = nullptr; }
     if (st.frames == 0) {   // nothing ever went through player 0: open the ring for player 1
         PipeBuffer &b = cf->pipe.RequestBuffer(0);
         b.quit = true;
@@ -449,7 +521,19 @@ bool REBVO::BatchGroup::gather(bool block, bool &any_running, bool &any_leaving)
                 st.ring_idx = ringEntryOf(reinterpret_cast<const uint8_t *>(cb->img->Data()));
                 st.mono = grey_ring && st.ring_idx >= 0 && st.mono_of[st.ring_idx] != 0;
             }
-            if (!st.cbuf) all = false;
+            if (stereo && st.cbuf && !st.cbuf_pair) {   // one pair frame per accepted main frame, no drop logic (rebvo_first_t.cpp:183-199)
+                customCam::CustomCamPipeBuffer *pb = cf->cam_pipe_stereo.RequestBufferTimeoutable(1, block && !waited ? 0.001 : 0.0);
+                if (!pb) {
+                    waited = true;
+                } else {
+                    st.cbuf_pair = pb;
+                    if (std::fabs(st.t_frame - pb->timestamp) > 0.5 / cf->params.config_fps)
+                        std::cout << "REBVO Warning: cameras are unsync: " << st.t_frame - pb->timestamp << "\n";
+                    st.pair_idx = pairEntryOf(reinterpret_cast<const uint8_t *>(pb->img->Data()));
+                    st.pair_mono = pair_grey_ring && st.pair_idx >= 0 && st.pair_mono_of[st.pair_idx] != 0;
+                }
+            }
+            if (!st.cbuf || (stereo && !st.cbuf_pair)) all = false;
         }
         if (any_leaving || !any_running) return false;
         if (all) return true;
@@ -457,29 +541,42 @@ bool REBVO::BatchGroup::gather(bool block, bool &any_running, bool &any_leaving)
     }
 }
 
-// The gathered frames of one step go up, into the slot the next edgehip_process_frame will take.
+// The gathered frames of one step go up, into the slot the next edgehip_process_frame will take (and, with stereo pairs, their pair
+// frames into the slot behind the ring).
 int REBVO::BatchGroup::upload(std::vector<double> &ts, int &slot) {
     slot = edgehip_next_slot(hip);
+    for (int i = 0; i < cap; i++)
+        if (seats[i].running) ts[i] = seats[i].t_frame;
+    int rc = uploadRuns(slot, false);
+    // the pair frames: the copy into the pair slot waits by itself (on the upload stream) for the frame that used the slot last —
+    // the step before — so it runs behind that step, not under it; the main frames' copies of the step after queue up behind it
+    if (rc == 0 && stereo) rc = uploadRuns(kPairSlot, true);
+    return rc;
+}
+
+int REBVO::BatchGroup::uploadRuns(int slot, bool pair) {
     int rc = 0;
+    uint8_t *const grey_r = pair ? pair_grey_ring : grey_ring;
+    auto idx_of = [&](const Seat &st) { return pair ? st.pair_idx : st.ring_idx; };
     // a step whose frames are ALL mono goes up as 8-bit planes (a third of the bytes; the slot's format is one per step)
-    bool all_mono = grey_ring != nullptr;
-    for (const Seat &st : seats) all_mono = all_mono && (!st.running || st.mono);
-    if (all_mono) mono_steps++;
+    bool all_mono = grey_r != nullptr;
+    for (const Seat &st : seats) all_mono = all_mono && (!st.running || (pair ? st.pair_mono : st.mono));
+    if (all_mono && !pair) mono_steps++;
     // runs of neighbouring members whose frames sit in the same entry of the page-locked ring are contiguous memory: one copy each
     // (in lock-step without drops: one copy for the whole group); a heap image goes through the library's staging buffer
     for (int i = 0; i < cap && rc == 0;) {
         Seat &st = seats[i];
         if (!st.running) { i++; continue; }   // a member that left: its sequence keeps running on whatever the slot holds, nobody reads it
-        ts[i] = st.t_frame;
-        if (st.ring_idx < 0) {
-            rc = edgehip_upload_rgb(hip, slot, reinterpret_cast<const uint8_t *>(st.cbuf->img->Data()), i, 1);
+        const int e = idx_of(st);
+        if (e < 0) {
+            rc = edgehip_upload_rgb(hip, slot, reinterpret_cast<const uint8_t *>((pair ? st.cbuf_pair : st.cbuf)->img->Data()), i, 1);
             i++;
             continue;
         }
         int n = 1;
-        while (i + n < cap && seats[i + n].running && seats[i + n].ring_idx == st.ring_idx) { ts[i + n] = seats[i + n].t_frame; n++; }
-        rc = all_mono ? edgehip_upload_grey8_pinned(hip, slot, greyImage(st.ring_idx, i), i, n)
-                      : edgehip_upload_rgb_pinned(hip, slot, ringImage(st.ring_idx, i), i, n);
+        while (i + n < cap && seats[i + n].running && idx_of(seats[i + n]) == e) n++;
+        rc = all_mono ? edgehip_upload_grey8_pinned(hip, slot, pair ? pairGrey(e, i) : greyImage(e, i), i, n)
+                      : edgehip_upload_rgb_pinned(hip, slot, pair ? pairImage(e, i) : ringImage(e, i), i, n);
         i += n;
     }
     return rc;
@@ -535,6 +632,8 @@ int REBVO::BatchGroup::launch(long step, const std::vector<double> &ts) {
             } else {
                 std::memcpy(nb.imgc->Data(), st.cbuf->img->Data(), (size_t)cf->params.ImageSize.w * cf->params.ImageSize.h * 3);
             }
+            if (stereo && nb.imgc_pair && st.cbuf_pair)   // rebvo_first_t.cpp:259 ((*pbuf.imgc_pair) = data_pair), for listeners only
+                std::memcpy(nb.imgc_pair->Data(), st.cbuf_pair->img->Data(), frame_bytes);
         }
         cf->pipe.ReleaseBuffer(0);
         st.buf_of[step & 3] = &nb;
@@ -546,6 +645,8 @@ int REBVO::BatchGroup::launch(long step, const std::vector<double> &ts) {
         }
         st.chold = st.cbuf;   // the copy may still be reading it: releaseHeld()
         st.cbuf = nullptr;
+        st.chold_pair = st.cbuf_pair;
+        st.cbuf_pair = nullptr;
         st.frames++;
     }
     newest = step;
@@ -590,10 +691,12 @@ int REBVO::BatchGroup::releaseHeld(int slot) {
     const double t0 = detail::now_s();
     struct Acc { double &a; double t; ~Acc() { a += detail::now_s() - t; } } acc{tm.held, t0};
     if (ring) {
-        const int rc = edgehip_upload_wait(hip, slot);
+        int rc = edgehip_upload_wait(hip, slot);
+        if (rc == 0 && stereo) rc = edgehip_upload_wait(hip, kPairSlot);
         if (rc != 0) return rc;
     }
     for (Seat &st : seats) {
+        if (st.chold_pair) { st.cf->cam_pipe_stereo.ReleaseBufferAt(1, st.chold_pair); st.chold_pair = nullptr; }
         if (!st.chold) continue;
         st.cf->cam_pipe.ReleaseBufferAt(1, st.chold);
         st.chold = nullptr;
@@ -605,6 +708,7 @@ int REBVO::BatchGroup::complete(long step, int slot, std::vector<edgehip_nav> &n
     const double tr0 = detail::now_s();
     int rc = edgehip_read_nav_log(hip, (int)step, 1, navs.data());   // waits for this frame, not for the ones enqueued behind it
     if (rc == 0 && imu_mode) rc = edgehip_read_nav_imu_log(hip, (int)step, 1, navs_imu.data());
+    if (rc == 0 && stereo) rc = edgehip_read_stereo_matches_log(hip, (int)step, 1, stereo_nm.data());
     if (rc != 0) return rc;
     const double now = detail::now_s();
     tm.records += now - tr0;
@@ -640,7 +744,7 @@ int REBVO::BatchGroup::complete(long step, int slot, std::vector<edgehip_nav> &n
             detail::fill_nav_imu(ni, nb);
             nb.ef->nmatch = ni.klm_num;
         }
-        nb.stereo_match_num = 0;
+        nb.stereo_match_num = stereo && !first && n.estimation_ok ? stereo_nm[i] : 0;   // rebvo_second_t.cpp:471-477
         nb.dtp1 = now - nb.dtp1;
         if (!first) cf->pushNav(nb.nav);
         if (st.have_prev) {   // the frame before goes to the output thread, with its edge map as this frame's tracking left it

@@ -353,8 +353,9 @@ void REBVO::construct() {
     if (params.StereoAvaiable) {
         cam_stereo = cam_model({params.pp_x_stereo, params.pp_y_stereo}, {params.z_f_x_stereo, params.z_f_y_stereo}, params.kc_stereo,
                                params.ImageSize);
-        for (unsigned i = 0; i < cam_pipe_stereo.Size(); i++)
-            cam_pipe_stereo[i].img = std::make_shared<Image<RGB24Pixel>>(params.ImageSize);
+        if (!useGroupEngine())   // (a group member's pair ring: views of the group's second page-locked ring, like the main one)
+            for (unsigned i = 0; i < cam_pipe_stereo.Size(); i++)
+                cam_pipe_stereo[i].img = std::make_shared<Image<RGB24Pixel>>(params.ImageSize);
     }
     const bool lazy_views = useGroupEngine();        // (what only a callback or a snapshot looks at is allocated when one appears)
     for (PipeBuffer &pbuf : pipe) {                  // rebvo.cpp:297-312 (host views only; the rest lives in HBM)
@@ -402,6 +403,18 @@ bool REBVO::Init() {
         std::cout << last_error << "\n";
         return false;
     }
+    if (params.CameraType == 2 && params.StereoAvaiable) {   // REBVO::initPairCamera, src/rebvo/rebvo_first_t.cpp:64-76
+        dscam_pair = new DataSetCam(params.DataSetDirStereo.data(), params.DataSetFileStereo.data(), params.ImageSize, params.CamTimeScale);
+        if (dscam_pair->Error()) {
+            last_error = "REBVO: Failed to initialize the stereo camera (dataset list " + params.DataSetFileStereo + ")";
+            std::cout << last_error << "\n";
+            delete dscam_pair;
+            dscam_pair = nullptr;
+            delete dscam;
+            dscam = nullptr;
+            return false;
+        }
+    }
     if (group) {   // Init() again without CleanUp() (e.g. after a device error closed the seat): let go of the old seat first
         quit = true;
         groupDetach();
@@ -410,24 +423,20 @@ bool REBVO::Init() {
         if (groupAttach()) return true;
         delete dscam;         // a refused member (parameter mismatch, full group, edgehip_create failure) keeps nothing
         dscam = nullptr;
+        delete dscam_pair;
+        dscam_pair = nullptr;
         return false;
     }
     if (!params.GpuBatchGroup.empty()) {
-        last_error = "REBVO(hip): &GPU BatchGroup does not take a stereo pair";
+        last_error = "REBVO(hip): &GPU BatchGroup does not take a stereo pair together with ImuMode > 0 (the device-side IMU branch does not run the stereo rig)";
         std::cout << last_error << "\n";
+        delete dscam;
+        dscam = nullptr;
+        delete dscam_pair;
+        dscam_pair = nullptr;
         return false;
     }
     if (params.ImuMode > 0) imuTrackInit();
-    if (params.CameraType == 2 && params.StereoAvaiable) {   // REBVO::initPairCamera, src/rebvo/rebvo_first_t.cpp:64-76
-        dscam_pair = new DataSetCam(params.DataSetDirStereo.data(), params.DataSetFileStereo.data(), params.ImageSize, params.CamTimeScale);
-        if (dscam_pair->Error()) {
-            last_error = "REBVO: Failed to initialize the stereo camera (dataset list " + params.DataSetFileStereo + ")";
-            std::cout << last_error << "\n";
-            delete dscam_pair;
-            dscam_pair = nullptr;
-            return false;
-        }
-    }
     edgehip_params hp;
     fill_hip_params(params, hp);
     hp.stereo_available = params.StereoAvaiable ? 1 : 0;

@@ -242,3 +242,55 @@ def test_wide_parity_counts_departures_and_attributes_them():
     d = summary["departures"][0]
     assert d["first_frame_outside_tolerance"] == 3 and d["outside_tolerance_at_last_frame"] and d["knife_edge_frame"] in (True, False)
     assert summary["sequences_outside_tolerance_at_last_frame"] == 1
+
+
+def test_live_counter_passes_replace_the_committed_constants(tmp_path, monkeypatch):
+    """bench.live_pmc_passes: the command runs itself under `rocprofv3 --kernel-trace --pmc ...` three times (FETCH_SIZE, WRITE_SIZE,
+    SQ_ACTIVE_INST_VALU + GRBM_GUI_ACTIVE) and uses what those passes counted.  Here rocprofv3 is a stand-in script that writes the csv
+    a pass would leave (test infrastructure: no device), so the parsing, the per-kernel means, the stamp and the fall-back are covered;
+    the real thing runs on the GPU box in the default bench command."""
+    fake = tmp_path / "bin"
+    fake.mkdir()
+    (fake / "rocprofv3").write_text('''#!/usr/bin/env python3
+import os, sys
+a = sys.argv[1:]
+d = a[a.index("-d") + 1]
+counters = a[a.index("--pmc") + 1:a.index("--output-format")]
+if os.environ.get("FAKE_FAIL") in counters:
+    sys.exit(3)
+os.makedirs(os.path.join(d, "host", "1"), exist_ok=True)
+vals = {"FETCH_SIZE": 1000.0, "WRITE_SIZE": 500.0, "SQ_ACTIVE_INST_VALU": 256.0 * 1000, "GRBM_GUI_ACTIVE": 8.0 * 2000}
+with open(os.path.join(d, "host", "1", "pmc_counter_collection.csv"), "w") as f:
+    f.write('"Kernel_Name","Counter_Name","Counter_Value"\\n')
+    for kern, scale in (("void edgehip::k_stage_a_fused<752, 5>(edgehip::FusedArgs)", 1.0), ("edgehip::k_try_velrot(edgehip::TvrArgs)", 2.0)):
+        for rep in range(3):
+            for c in counters:
+                f.write('"%s","%s",%r\\n' % (kern, c, vals[c] * scale))
+print('noise {"metric": "frames_per_second", "config": {"keylines_per_frame_timed_mean": 14321.5}}')
+''')
+    os.chmod(fake / "rocprofv3", 0o755)
+    monkeypatch.setenv("PATH", str(fake) + os.pathsep + os.environ["PATH"])
+    monkeypatch.setattr(bench, "LIVE_PMC", {"used": False, "note": "not attempted", "issue": None})
+    bench._PMC_CACHE.clear()
+    try:
+        assert bench.live_pmc_passes(["--steps", "2"], 1024, budget_s=120)
+        assert bench.LIVE_PMC["used"] and bench.LIVE_PMC["kernels"] == 2
+        assert bench.pmc_kn() == 14321.5
+        assert bench.pmc_counters("A.fused", 1024) == (1000.0 * 1024, 500.0 * 1024)          # KiB -> bytes, per launch
+        assert bench.pmc_counters("B.try_velrot", 1024) == (2000.0 * 1024, 1000.0 * 1024)
+        assert bench.pmc_counters("A.fused", 512) is None                                     # another batch size: not these counters
+        # 4 x 256000 / 1024 quad-cycles busy over 2000 cycles
+        assert bench.issue_fracs()["A.fused"] == 0.5 and bench.issue_fracs()["B.try_velrot"] == 0.5
+        # a failing SQ pass keeps the live HBM counters and says so; a failing FETCH pass keeps the committed constants
+        bench._PMC_CACHE.clear()
+        monkeypatch.setattr(bench, "LIVE_PMC", {"used": False, "note": "not attempted", "issue": None})
+        monkeypatch.setenv("FAKE_FAIL", "GRBM_GUI_ACTIVE")
+        assert bench.live_pmc_passes(["--steps", "2"], 1024, budget_s=120)
+        assert bench.LIVE_PMC["issue"] is None and "exited 3" in bench.LIVE_PMC["issue_note"]
+        bench._PMC_CACHE.clear()
+        monkeypatch.setattr(bench, "LIVE_PMC", {"used": False, "note": "not attempted", "issue": None})
+        monkeypatch.setenv("FAKE_FAIL", "FETCH_SIZE")
+        assert not bench.live_pmc_passes(["--steps", "2"], 1024, budget_s=120)
+        assert not bench.LIVE_PMC["used"] and "exited 3" in bench.LIVE_PMC["note"] and True not in bench._PMC_CACHE
+    finally:
+        bench._PMC_CACHE.clear()

@@ -273,3 +273,97 @@ def test_host_stereo_replay(tmp_path):
         assert abs(row[14] - kl["rho"].sum()) <= 1e-6 * abs(kl["rho"].sum()) + 1e-9
         prev = nav
     assert "Loaded 8 File names" in r.stdout
+
+
+@pytest.mark.parametrize("mono_upload", [1, 0])
+def test_stereo_objects_in_one_batch_group(tmp_path, mono_upload):
+    """StereoAvaiable behind the plugin surface as ONE batch (`&GPU BatchGroup` admits stereo members, ImuMode 0): four rebvo::REBVO
+    objects, custom cameras, each fed a pair frame (requestStereoCustomCamBuffer) and a main frame per instant, object i at its own
+    phase of the pool.  The group's context has the pair slot behind its ring and the rig inside edgehip_process_frame
+    (rebvo_second_t.cpp:465-486); pair frames cross in the group's second page-locked ring — as 8-bit planes (mono_upload = 1)
+    or RGB24.  Checked: every object's callback rows bit-identical to the same four sequences run as one ctypes batch with the rig
+    (records, KeyLine sums, stereo_match_num per frame although two steps are in flight), and object 0 / 3 against the reference's
+    own SecondThread order with StereoAvaiable within the bounds of the tests above."""
+    import json
+    from oracle import oracle
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exe = os.path.join(root, "rebvo_amd", "lib", "surface_replay")
+    if not oracle.available("ref") or not os.path.exists(exe):
+        pytest.fail("needs oracle/_ref and surface_replay — a broken snapshot: run __graft_entry__.build()")
+    B, n_fr, pool = 4, 8, 7
+    p, frames, pairs, pc = make_data(all_pairs=True, nf=pool)
+    t0, dt = 1.0, 0.05
+
+    def tri(k, n):
+        q = 2 * (n - 1)
+        k %= q
+        return k if k < n else q - k
+    np.stack(frames).tofile(tmp_path / "frames.rgb24")
+    np.stack(pairs).tofile(tmp_path / "pairs.rgb24")
+    cfg = tmp_path / "cfg"
+    write_global_config(cfg, edgehip.euroc_params(W, H), camera_type=3, dataset=("unused/", "unused.csv", 1.0),
+                        stereo=dict(dir="unused/", file="unused.csv", **pc), gpu=dict(group="st4", size=B, mono=mono_upload))
+    prefix = tmp_path / "run"
+    r = subprocess.run([exe, str(cfg), str(tmp_path / "frames.rgb24"), str(pool), str(B), str(n_fr), repr(t0), repr(dt),
+                        "--group", "st4", "--stereo", str(tmp_path / "pairs.rgb24"), "--dump", str(prefix), "--threads", "2"],
+                       capture_output=True, text=True, timeout=600, env=dict(os.environ, REBVO_GROUP_TIMING="1"))
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
+    js = json.loads(r.stdout.strip().splitlines()[-1])
+    assert js["objects"] == B and js["callbacks"] == B * (n_fr - 1), r.stdout[-1500:]
+    assert f"group 'st4': {n_fr} steps ({n_fr if mono_upload else 0} as 8-bit planes)" in r.stdout, r.stdout[-1500:]
+    dumps = [np.loadtxt(f"{prefix}.{i}.txt", ndmin=2) for i in range(B)]
+
+    # (a) the same four sequences as one ctypes batch with the rig
+    eh = edgehip.EdgeHip(edgehip.euroc_params(W, H, stereo_available=1), nseq=B, nslots=4)
+    eh.set_slot_camera(3, pc["ppx"], pc["ppy"], pc["zfx"], pc["zfy"])
+    eh.set_stereo_rig(3, T_PAIR, R_PAIR, 100.0)
+    eh.set_nav_log(8)
+    navs, kls, nms = [], [], []
+    for k in range(n_fr):
+        eh.upload_rgb(eh.next_slot(), np.stack([frames[tri(k + i, pool)] for i in range(B)]))
+        eh.upload_rgb(3, np.stack([pairs[tri(k + i, pool)] for i in range(B)]))
+        eh.process_frame(np.full(B, t0 + dt * k))
+        navs.append(eh.read_nav())
+        nms.append(eh.get_stereo_matches())
+        assert np.array_equal(eh.read_stereo_matches_log(k, 1)[0], nms[-1] if k else np.zeros(B, np.int32))   # the log = the counter, frame by frame
+        if k:
+            kls.append([eh.download_keylines(i, (eh.cur_slot() + 2) % 3, want_mask=False)[0] for i in range(B)])
+    eh.close()
+    assert min(int(v) for v in nms[-1]) > 500
+    arr = lambda v: np.array(v[:])
+    for i in range(B):
+        rows = dumps[i]
+        assert len(rows) == n_fr - 1
+        for j in range(n_fr - 1):                 # frame j is delivered once frame j + 1 has been tracked
+            row, kl = rows[j], kls[j][i]
+            assert int(row[0]) == j and abs(row[1] - (t0 + dt * j)) < 1e-12 and int(row[2]) == len(kl)
+            assert row[14] == np.cumsum(kl["rho"])[-1] and row[15] == np.cumsum(kl["s_rho"])[-1], (i, j)
+            if j == 0:
+                assert int(row[-1]) == 0
+                continue
+            n = navs[j][i]
+            assert int(row[3]) == n.klm_num and int(row[4]) == n.estimation_ok == 1, (i, j)
+            assert np.array_equal(row[5:8], arr(n.Pos)) and np.array_equal(row[8:11], arr(n.PoseLie)) and np.array_equal(row[11:14], arr(n.Vel)), (i, j)
+            assert row[27] == 1.0                  # Kp = 1 with stereo (rebvo_second_t.cpp:486)
+            assert int(row[-1]) == int(nms[j][i]), (i, j, row[-1], nms[j])
+
+    # (b) against the reference's own stereo frame order, object by object
+    for i in (0, 3):
+        orc = oracle.Oracle("ref", oracle.euroc_params(W, H))
+        orc.enable_stereo(pc["ppx"], pc["ppy"], pc["zfx"], pc["zfy"], T_PAIR, R_PAIR, 100.0)
+        path, prev = 0.0, None
+        for k in range(n_fr):
+            _, nav = orc.process_frame_stereo(frames[tri(k + i, pool)], pairs[tri(k + i, pool)], t0 + dt * k)
+            if k == 0:
+                prev = nav
+                continue
+            row = dumps[i][k - 1]
+            kl = orc.keylines((k - 1) % 8)
+            assert int(row[2]) == len(kl)
+            if k - 1 > 0:
+                path += np.linalg.norm(prev.V[:])
+                assert np.allclose(row[5:8], prev.Pos[:], atol=1e-6 * path + 1e-9)
+                assert abs(int(row[-1]) - prev.pad0) <= max(2, prev.pad0 // 500), (i, k, row[-1], prev.pad0)
+            assert abs(row[14] - kl["rho"].sum()) <= 1e-6 * abs(kl["rho"].sum()) + 1e-9
+            prev = nav
+        orc.close()
