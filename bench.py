@@ -620,7 +620,8 @@ def host_surface(params, frames, w, h):
     the group sends their 8-bit planes (0.36 MB; `objects_64_rgb24_fps` is the same run with MonoUpload = 0: 1.08 MB per frame).  No callback is registered
     for the three headline numbers (KeyLines stay in HBM); `objects_8_with_callbacks_fps` adds one per object (AoS KeyLines back
     to the host for every frame; two steps in flight since round 6: edgehip_export_keylines), `objects_8_imu_fps` is eight ImuMode = 2
-    members in one group (the device-side IMU branch behind the surface), `objects_256_fps` / `objects_1024_fps` the same leg with 256 /
+    members in one group (the device-side IMU branch behind the surface), `objects_8_stereo_fps` eight StereoAvaiable members in one group (a pair
+    frame per main frame; the pair images are the main images: the pair path's cost, not a depth result), `objects_256_fps` / `objects_1024_fps` the same leg with 256 /
     1024 cameras and 16 producer threads (`detail` carries where the producers' time goes).  Run lengths: 600 / 400 / 240 / 300 frames per object, the first 60 / 50 / 40 / 40 untimed — the
     application runs up to three frames ahead of the tracker (the camera ring) and the last frames drain, which weighed 15-30 % in
     the 36-frame runs of the first version of this leg."""
@@ -642,6 +643,7 @@ def host_surface(params, frames, w, h):
                                       ("single_camera_with_callback_fps", 1, 600, 60, ["--callback"]),
                                       ("objects_64_rgb24_fps", 64, 240, 40, ["--group", "g64c", "--rgb24"]),
                                       ("objects_8_imu_fps", 8, 300, 40, ["--group", "g8imu", "--imu"]),
+                                      ("objects_8_stereo_fps", 8, 300, 40, ["--group", "g8st", "--stereo"]),
                                       ("objects_256_fps", 256, 120, 30, ["--group", "g256"]),
                                       ("objects_1024_fps", 1024, 60, 15, ["--group", "g1024"])):
             try:
@@ -658,6 +660,14 @@ def host_surface(params, frames, w, h):
                     _write_surface_imu_csv(imu_csv, len(frames), k + n + 2, 1.0, FRAME_DT)
                     config.write_global_config(cfg, params, imu=dict(mode=2, file=imu_csv, time_scale=1.0, InitBiasFrameNum=3))
                     extra = [e for e in extra if e != "--imu"] + ["--stagger"]
+                if "--stereo" in extra:
+                    # StereoAvaiable members in one group (round 6): a pair frame per main frame through requestStereoCustomCamBuffer, the rig
+                    # inside the group's edgehip_process_frame.  The pair images ARE the main images here (the same file): this leg times the
+                    # pair path (second ring, second copy, stage A of the pair slot, stereo matching, fusion), it is not a depth result
+                    cfg = os.path.join(td, "cfg_stereo")
+                    config.write_global_config(cfg, params, dataset=("unused/", "unused.csv", 1.0),
+                                               stereo=dict(dir="unused/", file="unused.csv", ppx=params.ppx, ppy=params.ppy, zfx=params.zfx, zfy=params.zfy))
+                    extra = [e for e in extra if e != "--stereo"] + ["--stereo", raw]
                 t_leg = time.perf_counter()
                 r = subprocess.run([exe, cfg, raw, str(len(frames)), str(n), str(k), "1", str(FRAME_DT), "--warmup", str(wm),
                                     "--threads", str(min(16, n))] + extra, capture_output=True, text=True, timeout=120)

@@ -13,6 +13,7 @@ rng = np.random.default_rng(int(sys.argv[1]) if len(sys.argv) > 1 else 1)
 frames = [f for f, _, _ in synth.billboard_sequence(W, H, 8, seed=41)]
 NMIN = int(sys.argv[3]) if len(sys.argv) > 3 else 1      # group sizes: 1..16 by default; 30..80 takes the groups through the one-kernel stage A (from 32 members on)
 NMAX = int(sys.argv[4]) if len(sys.argv) > 4 else 16
+STEREO_P = float(sys.argv[5]) if len(sys.argv) > 5 else 0.3
 bad = 0
 with tempfile.TemporaryDirectory() as td:
     np.stack(frames).tofile(td + "/frames.rgb24")
@@ -21,9 +22,13 @@ with tempfile.TemporaryDirectory() as td:
         mono = int(rng.integers(0, 2))
         cfg = f"{td}/cfg{it}"
         gpu = dict(mono=mono)
-        if rng.random() < 0.25: gpu["tracker_precision"] = 32          # (round 6) the float tracker behind the surface
-        config.write_global_config(cfg, edgehip.euroc_params(W, H), gpu=gpu)
+        stereo = rng.random() < STEREO_P                                # (round 6) StereoAvaiable members: a pair frame per main frame (the pair images = the main images)
+        if not stereo and rng.random() < 0.25: gpu["tracker_precision"] = 32          # (round 6) the float tracker behind the surface (refused with a stereo rig)
+        pp = edgehip.euroc_params(W, H)
+        config.write_global_config(cfg, pp, gpu=gpu, **(dict(dataset=("unused/", "unused.csv", 1.0), stereo=dict(dir="unused/", file="unused.csv", ppx=pp.ppx + 3,
+                                                                                                              ppy=pp.ppy + 2, zfx=pp.zfx, zfy=pp.zfy)) if stereo else {}))
         args = [exe, cfg, td + "/frames.rgb24", "8", str(n), str(k), "1", "0.05", "--threads", str(t), "--group", f"s{it}"]
+        if stereo: args += ["--stereo", td + "/frames.rgb24"]
         if rng.random() < 0.5: args.append("--callback")
         if n > 1 and rng.random() < 0.5: args += ["--leave", f"{int(rng.integers(0, n))}:{int(rng.integers(1, k))}"]
         if rng.random() < 0.4: args += ["--dup", f"{int(rng.integers(0, n))}:{int(rng.integers(1, k))}"]
