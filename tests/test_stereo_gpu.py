@@ -367,3 +367,45 @@ def test_stereo_objects_in_one_batch_group(tmp_path, mono_upload):
             assert abs(row[14] - kl["rho"].sum()) <= 1e-6 * abs(kl["rho"].sum()) + 1e-9
             prev = nav
         orc.close()
+
+
+def test_stereo_data_sets_as_one_batch_group(tmp_path):
+    """DataSetCam members with a stereo pair in one batch group (multi_device_replay --group): the feeder thread of each member puts
+    the cam0 list's images into the member's camera ring and the cam1 list's into its pair ring (REBVO::initPairCamera,
+    rebvo_first_t.cpp:64-76, 183-199); two data sets of different lengths (a member leaves when its lists end).  Every sequence's dump
+    must equal, number for number, the dump of the same data set replayed by an object of its own (its own thread and one-sequence
+    context with the rig: the path test_host_stereo_replay checks against the reference)."""
+    PIL = pytest.importorskip("PIL.Image")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exe = os.path.join(root, "rebvo_amd", "lib", "multi_device_replay")
+    if not os.path.exists(exe):
+        pytest.fail("needs multi_device_replay — a broken snapshot, not a reason to skip: run __graft_entry__.build()")
+    p, frames, pairs, pc = make_data(all_pairs=True, nf=8)
+    cfgs, lens = [], (8, 6)
+    for i, n in enumerate(lens):
+        t_ns = [1403636579763555584 + 7 * i + 50_000_000 * k for k in range(n)]
+        dirs = {}
+        for cam, imgs in (("cam0", frames[i:i + n] if i + n <= 8 else frames[:n]), ("cam1", pairs[i:i + n] if i + n <= 8 else pairs[:n])):
+            d = tmp_path / f"seq{i}" / "mav0" / cam
+            (d / "data").mkdir(parents=True)
+            with open(d / "data.csv", "w") as f:
+                f.write("#timestamp [ns],filename\n")
+                for k, fr in enumerate(imgs):
+                    PIL.fromarray(fr[:, :, 0], "L").save(d / "data" / f"{t_ns[k]}.png")
+                    f.write(f"{t_ns[k]},{t_ns[k]}.png\n")
+            dirs[cam] = d
+        cfg = tmp_path / f"cfg{i}"
+        write_global_config(cfg, edgehip.euroc_params(W, H), camera_type=2,
+                            dataset=(str(dirs["cam0"] / "data") + "/", str(dirs["cam0"] / "data.csv"), 1e-9),
+                            stereo=dict(dir=str(dirs["cam1"] / "data") + "/", file=str(dirs["cam1"] / "data.csv"), **pc))
+        cfgs.append(str(cfg))
+    for tag, extra in (("alone", []), ("group", ["--group"])):
+        r = subprocess.run([exe, "--devices", "1", "--dump", str(tmp_path / tag), *extra, *cfgs], capture_output=True, text=True, timeout=300)
+        assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-1000:]
+        for i, n in enumerate(lens):
+            assert f"sequence {i} device 0: frames delivered {n - 1}" in r.stdout, r.stdout[-2000:]
+    for i, n in enumerate(lens):
+        a = np.loadtxt(str(tmp_path / "alone") + f"{i}.txt", ndmin=2)
+        g = np.loadtxt(str(tmp_path / "group") + f"{i}.txt", ndmin=2)
+        assert a.shape == g.shape == (n - 1, 14) and np.array_equal(a, g), (i, a, g)
+        assert np.abs(a[2:, 5:8]).max() > 0          # poses that moved
