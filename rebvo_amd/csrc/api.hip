@@ -857,7 +857,8 @@ int edgehip_upload_rgb_pinned(edgehip_ctx *c, int slot, const uint8_t *rgb24_pin
     const size_t fb = (size_t)c->plan.n * 3;
     // On the upload stream: the copy of frame k+1 runs under stage A AND stages B/C of frame k.  It may start once the
     // last frame that was processed in this slot is done (nothing reads a slot's RGB after its own stage A).
-    if (c->slot_ring[slot] >= 0) EH_CHECK(hipStreamWaitEvent(c->stream_up, c->ev_ring[c->slot_ring[slot]], 0));
+    if (c->rig.enabled && slot == c->rig.slot_pair && c->rig_a_valid) EH_CHECK(hipStreamWaitEvent(c->stream_up, c->ev_a[slot], 0));   // the pair slot: free behind its own stage A
+    else if (c->slot_ring[slot] >= 0) EH_CHECK(hipStreamWaitEvent(c->stream_up, c->ev_ring[c->slot_ring[slot]], 0));
     if (c->a_api_valid[slot]) { EH_CHECK(hipStreamWaitEvent(c->stream_up, c->ev_a[slot], 0)); c->a_api_valid[slot] = false; }
     EH_CHECK(hipMemcpyAsync(rgbof(c, slot) + fb * seq_first, rgb24_pinned, fb * count, hipMemcpyHostToDevice, c->stream_up));
     EH_CHECK(hipEventRecord(c->ev_up[slot], c->stream_up));
@@ -895,7 +896,8 @@ int edgehip_upload_grey8_pinned(edgehip_ctx *c, int slot, const uint8_t *grey8_p
     unbind_rgb(c, slot, true);
     const size_t fb = c->plan.n;
     // on the upload stream, like edgehip_upload_rgb_pinned: the copy of frame k+1 runs under the whole of frame k
-    if (c->slot_ring[slot] >= 0) EH_CHECK(hipStreamWaitEvent(c->stream_up, c->ev_ring[c->slot_ring[slot]], 0));
+    if (c->rig.enabled && slot == c->rig.slot_pair && c->rig_a_valid) EH_CHECK(hipStreamWaitEvent(c->stream_up, c->ev_a[slot], 0));   // the pair slot: free behind its own stage A
+    else if (c->slot_ring[slot] >= 0) EH_CHECK(hipStreamWaitEvent(c->stream_up, c->ev_ring[c->slot_ring[slot]], 0));
     if (c->a_api_valid[slot]) { EH_CHECK(hipStreamWaitEvent(c->stream_up, c->ev_a[slot], 0)); c->a_api_valid[slot] = false; }
     EH_CHECK(hipMemcpyAsync(c->grey8 + ((size_t)slot * c->plan.nseq + seq_first) * fb, grey8_pinned, fb * count, hipMemcpyHostToDevice, c->stream_up));
     EH_CHECK(hipEventRecord(c->ev_up[slot], c->stream_up));

@@ -190,6 +190,9 @@ struct edgehip_ctx {
     bool grec_ok[4];       // [slot] KlSoA::grec describes the slot's KeyLines (all sequences)
     bool rec_stale[4];     // [slot] rotate_keylines has turned m_m since KlSoA::rec was written: rec.m_m is behind (rec_refresh_enqueue brings
                            // it up to date for the rare reader — a rotated slot used as the tracker's field side, a key frame, a stereo pair)
+    bool rig_a_valid = false;   // ev_a[pair slot] was recorded behind the pair image's stage A by the whole-frame driver (not while capturing): the NEXT pair
+                                // frame's copy waits for that, not for the end of the frame (nothing reads a slot's frame storage after its own stage A)
+    bool capturing = false;     // edgehip_process_frame is capturing a frame graph (events recorded now are graph edges, not events)
     bool a_api_valid[4];   // [slot] ev_a was recorded by the stage-level edgehip_stage_a (an upload must wait for it)
     hipEvent_t ev_ring[8]; // [frame % 8] the frame that used this entry of the pinned time-stamp / frame-index rings is done
     bool ring_valid[8];

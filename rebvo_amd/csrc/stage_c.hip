@@ -1802,6 +1802,13 @@ static int frame_enqueue(edgehip_ctx *c, int sn, int so, int sp, int have_pair, 
     const bool retune_in_quantile = begin_in_quantile && sp < 0 && !c->overlap;
     EH_TRY(stage_a_enqueue(c, sn, have_pair && c->fwd_mode != 2, retune_in_quantile));
     if (sp >= 0) EH_TRY(stage_a_enqueue(c, sp));   // the pair image, after the main one as in rebvo_first_t.cpp:259-290
+    if (sp >= 0) {   // the pair slot's frame storage is free from here on: the next pair frame's copy may run under the rest of this frame
+        c->rig_a_valid = false;
+        if (!c->capturing) {
+            EH_CHECK(hipEventRecord(c->ev_a[sp], c->stream_a));
+            c->rig_a_valid = true;
+        }
+    }
     if (c->stream_a != c->stream) {   // (one stream: already in order, and an event record is a packet the device has to work through)
         EH_CHECK(hipEventRecord(c->ev_a[sn], c->stream_a));
         EH_CHECK(hipStreamWaitEvent(c->stream, c->ev_a[sn], 0));
@@ -1914,7 +1921,9 @@ int edgehip_process_frame(edgehip_ctx *c, const double *t) {
         if (it == c->frame_graphs.end()) {
             hipGraph_t graph = nullptr;
             EH_CHECK(hipStreamBeginCapture(c->stream, hipStreamCaptureModeThreadLocal));
+            c->capturing = true;
             const int rc = frame_enqueue(c, sn, so, sp, have_pair, tp);
+            c->capturing = false;
             const hipError_t ce = hipStreamEndCapture(c->stream, &graph);
             if (rc != 0 || ce != hipSuccess || !graph) {
                 if (graph) (void)hipGraphDestroy(graph);
@@ -1928,6 +1937,7 @@ int edgehip_process_frame(edgehip_ctx *c, const double *t) {
             it = c->frame_graphs.emplace(key, exec).first;
         }
         EH_CHECK(hipGraphLaunch(it->second, c->stream));
+        c->rig_a_valid = false;   // (a replayed graph records no event behind the pair's stage A: pair uploads wait for the frame's end)
         // stage A ran inside the graph, on this stream: the caller's next uploads (stage-A stream) may overwrite a
         // frame slot only after the graphs that read it (a caller that never synchronises is several frames ahead)
         if (int e = order_a_after_bc(c)) return e;

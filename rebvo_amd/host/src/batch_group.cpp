@@ -82,8 +82,10 @@ public:
                                    // for its callback land in them without a staging copy
         bool step_granted = false; // frame-by-frame mode: the application's "advance" has been taken for the frame about to be grabbed
         bool leaving = false;      // cf->quit seen: the seat closes once the step in flight (which may carry its last frame) is done
-        // StereoAvaiable: the pair frame that goes with the gathered main frame, and the one held for the step launched last
-        customCam::CustomCamPipeBuffer *cbuf_pair = nullptr, *chold_pair = nullptr;
+        // StereoAvaiable: the pair frame that goes with the gathered main frame, and the ones of the steps in flight ([step & 3]).  A pair
+        // frame's copy into the ONE pair slot waits for the frame before to finish, so "the copy has read it" is known without another
+        // wait only when the step's record is read (complete()): the buffer is held until then — three of the ring's four at most
+        customCam::CustomCamPipeBuffer *cbuf_pair = nullptr, *pair_of[4] = {nullptr, nullptr, nullptr, nullptr};
         int pair_idx = -1;         // entry of the pair ring the gathered pair frame sits in (-1: a heap image)
         uint8_t pair_mono_of[CCAMBUFSIZE] = {};
         bool pair_mono = false;
@@ -455,7 +457,8 @@ void REBVO::BatchGroup::closeSeat(Seat &st) {
     if (st.kl_pinned) pinKeyLines(st, false);
     if (st.chold) { cf->cam_pipe.ReleaseBufferAt(1, st.chold); st.chold = nullptr; }
     if (st.cbuf) { cf->cam_pipe.ReleaseBufferAt(1, st.cbuf); st.cbuf = nullptr; }
-    if (st.chold_pair) { cf->cam_pipe_stereo.ReleaseBufferAt(1, st.chold_pair); st.chold_pair = nullptr; }
+    for (customCam::CustomCamPipeBuffer *&pb : st.pair_of)   // oldest first (the ring hands buffers out and takes them back in order)
+        if (pb) { cf->cam_pipe_stereo.ReleaseBufferAt(1, pb); pb = nullptr; }
     if (st.cbuf_pair) { cf->cam_pipe_stereo.ReleaseBufferAt(1, st.cbuf_pair); st.cbuf_pair = nullptr; }
     if (st.frames == 0) {   // nothing ever went through player 0: open the ring for player 1
         PipeBuffer &b = cf->pipe.RequestBuffer(0);
@@ -645,7 +648,7 @@ int REBVO::BatchGroup::launch(long step, const std::vector<double> &ts) {
         }
         st.chold = st.cbuf;   // the copy may still be reading it: releaseHeld()
         st.cbuf = nullptr;
-        st.chold_pair = st.cbuf_pair;
+        st.pair_of[step & 3] = st.cbuf_pair;
         st.cbuf_pair = nullptr;
         st.frames++;
     }
@@ -691,12 +694,10 @@ int REBVO::BatchGroup::releaseHeld(int slot) {
     const double t0 = detail::now_s();
     struct Acc { double &a; double t; ~Acc() { a += detail::now_s() - t; } } acc{tm.held, t0};
     if (ring) {
-        int rc = edgehip_upload_wait(hip, slot);
-        if (rc == 0 && stereo) rc = edgehip_upload_wait(hip, kPairSlot);
+        const int rc = edgehip_upload_wait(hip, slot);
         if (rc != 0) return rc;
     }
     for (Seat &st : seats) {
-        if (st.chold_pair) { st.cf->cam_pipe_stereo.ReleaseBufferAt(1, st.chold_pair); st.chold_pair = nullptr; }
         if (!st.chold) continue;
         st.cf->cam_pipe.ReleaseBufferAt(1, st.chold);
         st.chold = nullptr;
@@ -745,6 +746,10 @@ int REBVO::BatchGroup::complete(long step, int slot, std::vector<edgehip_nav> &n
             nb.ef->nmatch = ni.klm_num;
         }
         nb.stereo_match_num = stereo && !first && n.estimation_ok ? stereo_nm[i] : 0;   // rebvo_second_t.cpp:471-477
+        if (st.pair_of[step & 3]) {   // this step's pair frame: its copy ran before the step's stage A, the step is done
+            cf->cam_pipe_stereo.ReleaseBufferAt(1, st.pair_of[step & 3]);
+            st.pair_of[step & 3] = nullptr;
+        }
         nb.dtp1 = now - nb.dtp1;
         if (!first) cf->pushNav(nb.nav);
         if (st.have_prev) {   // the frame before goes to the output thread, with its edge map as this frame's tracking left it
