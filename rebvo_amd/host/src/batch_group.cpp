@@ -961,6 +961,12 @@ extern "C" int rebvo_group_selftest(const char *config_file) {
     q.ImuMode = 1;
     REBVO d(q);
     if (d.Init() || d.lastError().find("BatchGroup") == std::string::npos) return 5;  // a group member must be CameraType 3 / ImuMode 0 / mono
+    q = p;
+    q.StereoAvaiable = true;                                   // a stereo member does not sit with mono members (nor one with other &Stereo intrinsics
+    q.pp_x_stereo = p.pp_x; q.pp_y_stereo = p.pp_y;            // with stereo members: the pair slot's camera is one per context)
+    q.z_f_x_stereo = p.z_f_x; q.z_f_y_stereo = p.z_f_y;
+    REBVO s(q);
+    if (s.Init() || s.lastError().find("same") == std::string::npos) return 12;
     REBVO e(p);
     if (!e.Init()) return 6;                                   // the partner: the group is complete and starts
     REBVO f(p);
