@@ -874,14 +874,22 @@ def live_pmc_passes(child_argv, nseq, budget_s=150):
         left = budget_s - (time.time() - t_all)
         if left < 20:
             return f"no time left for the {tag} pass"
+        # (a process group of its own: a pass that overruns is ended as a whole — rocprofv3 AND the bench process under it)
+        proc = subprocess.Popen(cmd, cwd=tmp, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, start_new_session=True)
         try:
-            r = subprocess.run(cmd, cwd=tmp, env=env, capture_output=True, text=True, timeout=left, start_new_session=True)
+            p_out, p_err = proc.communicate(timeout=left)
         except subprocess.TimeoutExpired:
+            import signal
+            try:
+                os.killpg(proc.pid, signal.SIGKILL)
+            except OSError:
+                proc.kill()
+            proc.communicate()
             return f"the {tag} pass did not finish in {left:.0f} s"
-        if r.returncode != 0:
-            return f"the {tag} pass exited {r.returncode}: " + (r.stderr or "")[-160:].replace("\n", " ")
+        if proc.returncode != 0:
+            return f"the {tag} pass exited {proc.returncode}: " + (p_err or "")[-160:].replace("\n", " ")
         try:
-            line = r.stdout[r.stdout.rindex('{"metric"'):]
+            line = p_out[p_out.rindex('{"metric"'):]
             kn = json.loads(line)["config"].get("keylines_per_frame_timed_mean") or kn
         except (ValueError, KeyError):
             pass

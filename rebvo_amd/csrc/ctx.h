@@ -167,6 +167,82 @@ __device__ __forceinline__ void st_stream(int2 *p, int2 v) {
     __builtin_nontemporal_store(i2v{v.x, v.y}, reinterpret_cast<i2v *>(p));
 }
 
+// Loads through pointers that come out of a KlSoA record (or any other device-memory table of pointers) are GENERIC to the compiler: it
+// emits FLAT loads, which take the address-space check and count on the LDS counter as well as on the vector-memory one (a wait for an LDS
+// or scalar-load answer behind them waits for them too).  Everything a KlSoA points to is global memory: ldg() says so.
+// EDGEHIP_GLOBAL_LD=0 keeps the generic form (A/B).
+#ifndef EDGEHIP_GLOBAL_LD
+#define EDGEHIP_GLOBAL_LD 1
+#endif
+#ifdef __HIPCC__
+template <class T> __device__ __forceinline__ T ldg(const T *p, size_t i) {
+#if EDGEHIP_GLOBAL_LD
+    typedef const T __attribute__((address_space(1))) G;
+    return ((G *)p)[i];
+#else
+    return p[i];
+#endif
+}
+__device__ __forceinline__ float2 ldg(const float2 *p, size_t i) {
+#if EDGEHIP_GLOBAL_LD
+    typedef float f2v __attribute__((ext_vector_type(2)));
+    typedef const f2v __attribute__((address_space(1))) G;
+    const f2v v = ((G *)p)[i];
+    return make_float2(v.x, v.y);
+#else
+    return p[i];
+#endif
+}
+__device__ __forceinline__ float4 ldg(const float4 *p, size_t i) {
+#if EDGEHIP_GLOBAL_LD
+    typedef float f4v __attribute__((ext_vector_type(4)));
+    typedef const f4v __attribute__((address_space(1))) G;
+    const f4v v = ((G *)p)[i];
+    return make_float4(v.x, v.y, v.z, v.w);
+#else
+    return p[i];
+#endif
+}
+#endif
+
+#ifdef __HIPCC__
+// ... and the stores (plain and streaming) through such pointers
+template <class T> __device__ __forceinline__ void stg(T *p, size_t i, T v) {
+#if EDGEHIP_GLOBAL_LD
+    typedef T __attribute__((address_space(1))) G;
+    ((G *)p)[i] = v;
+#else
+    p[i] = v;
+#endif
+}
+__device__ __forceinline__ void stg(float2 *p, size_t i, float2 v) {
+#if EDGEHIP_GLOBAL_LD
+    typedef float f2v __attribute__((ext_vector_type(2)));
+    typedef f2v __attribute__((address_space(1))) G;
+    ((G *)p)[i] = f2v{v.x, v.y};
+#else
+    p[i] = v;
+#endif
+}
+template <class T> __device__ __forceinline__ void stg_stream(T *p, size_t i, T v) {
+#if EDGEHIP_GLOBAL_LD
+    typedef T __attribute__((address_space(1))) G;
+    __builtin_nontemporal_store(v, (G *)p + i);
+#else
+    st_stream(p + i, v);
+#endif
+}
+__device__ __forceinline__ void stg_stream(float2 *p, size_t i, float2 v) {
+#if EDGEHIP_GLOBAL_LD
+    typedef float f2v __attribute__((ext_vector_type(2)));
+    typedef f2v __attribute__((address_space(1))) G;
+    __builtin_nontemporal_store(f2v{v.x, v.y}, (G *)p + i);
+#else
+    st_stream(p + i, v);
+#endif
+}
+#endif
+
 struct Profiler;
 
 }  // namespace edgehip

@@ -768,13 +768,13 @@ __device__ __forceinline__ void tvr_body(const TvrArgs &a, const int seq, const 
             // Everything the KeyLine streams in is requested here, before the first use: the skip test, the projection, the
             // in-image test and the two gathers are a chain of dependent memory round trips, and with the loads inside the
             // branches each level of the chain paid its own.  (The ~10 % of KeyLines the tests drop load 36 B in vain.)
-            s_rho = ko.s_rho[ikl];
-            const int32_t mnum = ko.m_num[ikl];
-            const float2 pm0 = ko.p_m[ikl];
-            const double rho0 = ko.rho[ikl];
+            s_rho = ldg(ko.s_rho, ikl);
+            const int32_t mnum = ldg(ko.m_num, ikl);
+            const float2 pm0 = ldg(ko.p_m, ikl);
+            const double rho0 = ldg(ko.rho, ikl);
             rho_own = rho0;
-            const float2 klm = ko.m_m[ikl];
-            const float knm = ko.n_m[ikl];
+            const float2 klm = ldg(ko.m_m, ikl);
+            const float knm = ldg(ko.n_m, ikl);
             double rprev = 0;
             if (REWEIGHT && !(ABL & 16)) rprev = rin[ikl];
             const uint32_t fc = KF ? 0xFFFFFFFFu : a.framecount[seq];
@@ -849,7 +849,7 @@ __device__ __forceinline__ void tvr_body(const TvrArgs &a, const int seq, const 
                         if (ABL & 4) {
                             f_cpx = (float)px; f_cpy = (float)py; f_mx = klm.x; f_my = klm.y; f_ux = 1.f; f_uy = 0.f;
                         } else if (GREC) {
-                            const float4 g = a.kl_new[seq].grec[ikf];
+                            const float4 g = ldg(a.kl_new[seq].grec, ikf);
                             f_cpx = g.x; f_cpy = g.y; f_mx = g.z; f_my = g.w;
                         } else {
                             const MatchRec fr = a.kl_new[seq].rec[ikf];
@@ -1095,13 +1095,13 @@ __device__ __forceinline__ void tvr_body_f32(const TvrArgs &a, const int seq, co
     const float zf = (float)a.zfm, max_r = (float)a.max_r, k_huber = (float)a.k_huber, simil_t = (float)a.match_thresh;
     float Vt0 = 0, Vt1 = 0, Vt2 = 0;
     if (ikl < kn) {
-        s_rho = ko.s_rho[ikl];
-        const int32_t mnum = ko.m_num[ikl];
-        const float2 pm0 = ko.p_m[ikl];
-        const double rho0 = ko.rho[ikl];
+        s_rho = ldg(ko.s_rho, ikl);
+        const int32_t mnum = ldg(ko.m_num, ikl);
+        const float2 pm0 = ldg(ko.p_m, ikl);
+        const double rho0 = ldg(ko.rho, ikl);
         rho_own = rho0;
-        const float2 klm = ko.m_m[ikl];
-        const float knm = ko.n_m[ikl];
+        const float2 klm = ldg(ko.m_m, ikl);
+        const float knm = ldg(ko.n_m, ikl);
         double rprev_d = 0;
         if (REWEIGHT) rprev_d = rin[ikl];
         const uint32_t fc = a.framecount[seq];
@@ -1142,7 +1142,7 @@ __device__ __forceinline__ void tvr_body_f32(const TvrArgs &a, const int seq, co
                     const int ikf = (int)f - 1;
                     float f_cpx, f_cpy, f_mx, f_my, f_ux, f_uy;
                     if (GREC) {
-                        const float4 g = a.kl_new[seq].grec[ikf];
+                        const float4 g = ldg(a.kl_new[seq].grec, ikf);
                         f_cpx = g.x; f_cpy = g.y; f_mx = g.z; f_my = g.w;
                     } else {
                         const MatchRec fr = a.kl_new[seq].rec[ikf];
@@ -1306,12 +1306,12 @@ __device__ __forceinline__ void tvr2_body(const TvrArgs &a, const int seq, const
     int status[2] = {0, 0};   // 0 skipped, 1 out of image, 2 matched, 3 evaluated and unmatched (tvr_body)
     double s_rho = 1;
     if (ikl < kn) {
-        s_rho = ko.s_rho[ikl];
-        const int32_t mnum = ko.m_num[ikl];
-        const float2 pm0 = ko.p_m[ikl];
-        const double rho0 = ko.rho[ikl];
-        const float2 klm = ko.m_m[ikl];
-        const float knm = ko.n_m[ikl];
+        s_rho = ldg(ko.s_rho, ikl);
+        const int32_t mnum = ldg(ko.m_num, ikl);
+        const float2 pm0 = ldg(ko.p_m, ikl);
+        const double rho0 = ldg(ko.rho, ikl);
+        const float2 klm = ldg(ko.m_m, ikl);
+        const float knm = ldg(ko.n_m, ikl);
         const uint32_t fc = a.framecount[seq];
         const uint32_t mthr = a.match_num_thresh < fc ? a.match_num_thresh : fc;
         const bool skip = s_rho > sq->s_rho_min_eval || (uint32_t)mnum < mthr;  // int vs uint compare
@@ -1350,7 +1350,7 @@ __device__ __forceinline__ void tvr2_body(const TvrArgs &a, const int seq, const
             const int ikf0 = hit0 ? (int)f0 - 1 : 0, ikf1 = hit1 ? (int)f1 - 1 : 0;
             float f_cpx[2], f_cpy[2], f_mx[2], f_my[2], f_ux[2] = {0, 0}, f_uy[2] = {0, 0};
             if (GREC) {
-                const float4 g0 = a.kl_new[seq].grec[ikf0], g1 = a.kl_new[seq].grec[ikf1];
+                const float4 g0 = ldg(a.kl_new[seq].grec, ikf0), g1 = ldg(a.kl_new[seq].grec, ikf1);
                 f_cpx[0] = g0.x; f_cpy[0] = g0.y; f_mx[0] = g0.z; f_my[0] = g0.w;
                 f_cpx[1] = g1.x; f_cpy[1] = g1.y; f_mx[1] = g1.z; f_my[1] = g1.w;
             } else {
@@ -1550,12 +1550,12 @@ __device__ __forceinline__ void tvr2_body_f32(const TvrArgs &a, const int seq, c
     int status[2] = {0, 0};
     double s_rho = 1;
     if (ikl < kn) {
-        s_rho = ko.s_rho[ikl];
-        const int32_t mnum = ko.m_num[ikl];
-        const float2 pm0 = ko.p_m[ikl];
-        const double rho0 = ko.rho[ikl];
-        const float2 klm = ko.m_m[ikl];
-        const float knm = ko.n_m[ikl];
+        s_rho = ldg(ko.s_rho, ikl);
+        const int32_t mnum = ldg(ko.m_num, ikl);
+        const float2 pm0 = ldg(ko.p_m, ikl);
+        const double rho0 = ldg(ko.rho, ikl);
+        const float2 klm = ldg(ko.m_m, ikl);
+        const float knm = ldg(ko.n_m, ikl);
         const uint32_t fc = a.framecount[seq];
         const uint32_t mthr = a.match_num_thresh < fc ? a.match_num_thresh : fc;
         const bool skip = s_rho > sq->s_rho_min_eval || (uint32_t)mnum < mthr;
@@ -1592,7 +1592,7 @@ __device__ __forceinline__ void tvr2_body_f32(const TvrArgs &a, const int seq, c
             const int ikf0 = hit0 ? (int)f0 - 1 : 0, ikf1 = hit1 ? (int)f1 - 1 : 0;
             float f_cpx[2], f_cpy[2], f_mx[2], f_my[2], f_ux[2] = {0, 0}, f_uy[2] = {0, 0};
             if (GREC) {
-                const float4 g0 = a.kl_new[seq].grec[ikf0], g1 = a.kl_new[seq].grec[ikf1];
+                const float4 g0 = ldg(a.kl_new[seq].grec, ikf0), g1 = ldg(a.kl_new[seq].grec, ikf1);
                 f_cpx[0] = g0.x; f_cpy[0] = g0.y; f_mx[0] = g0.z; f_my[0] = g0.w;
                 f_cpx[1] = g1.x; f_cpy[1] = g1.y; f_mx[1] = g1.z; f_my[1] = g1.w;
             } else {
@@ -1769,12 +1769,12 @@ __device__ __forceinline__ void tvr_rw2_body(const TvrArgs &a, const int seq, co
         ikl[c] = (2 * blk + c) * kTvrBlock + tid;
         pm0[c] = make_float2(0.f, 0.f); klm[c] = make_float2(0.f, 0.f);
         if (ikl[c] < kn) {
-            s_rho[c] = ko.s_rho[ikl[c]];
-            mnum[c] = ko.m_num[ikl[c]];
-            pm0[c] = ko.p_m[ikl[c]];
-            rho_own[c] = ko.rho[ikl[c]];
-            klm[c] = ko.m_m[ikl[c]];
-            knm[c] = ko.n_m[ikl[c]];
+            s_rho[c] = ldg(ko.s_rho, ikl[c]);
+            mnum[c] = ldg(ko.m_num, ikl[c]);
+            pm0[c] = ldg(ko.p_m, ikl[c]);
+            rho_own[c] = ldg(ko.rho, ikl[c]);
+            klm[c] = ldg(ko.m_m, ikl[c]);
+            knm[c] = ldg(ko.n_m, ikl[c]);
             rprev[c] = rin[ikl[c]];
         }
         cin[c] = 2 * blk + c < a.nblk ? carry_row[2 * blk + c] : 0.0;
@@ -1831,7 +1831,7 @@ __device__ __forceinline__ void tvr_rw2_body(const TvrArgs &a, const int seq, co
     const int ikf0 = hit0 ? (int)f0 - 1 : 0, ikf1 = hit1 ? (int)f1 - 1 : 0;
     float f_cpx[2], f_cpy[2], f_mx[2], f_my[2], f_ux[2] = {0, 0}, f_uy[2] = {0, 0};
     if (GREC) {
-        const float4 g0 = a.kl_new[seq].grec[ikf0], g1 = a.kl_new[seq].grec[ikf1];
+        const float4 g0 = ldg(a.kl_new[seq].grec, ikf0), g1 = ldg(a.kl_new[seq].grec, ikf1);
         f_cpx[0] = g0.x; f_cpy[0] = g0.y; f_mx[0] = g0.z; f_my[0] = g0.w;
         f_cpx[1] = g1.x; f_cpy[1] = g1.y; f_mx[1] = g1.z; f_my[1] = g1.w;
     } else {
@@ -2727,14 +2727,14 @@ __global__ __launch_bounds__(256) void k_try_vel(TvrArgs a) {
     if (ikl < kn) {
         // everything the KeyLine streams in is requested before the first use (as in k_try_velrot): with the loads inside the
         // branches the skip test, the projection and the two gathers each paid their own memory round trip
-        const float nm = ko.n_m[ikl];
-        const double s_rho = ko.s_rho[ikl];
-        const int32_t mnum = ko.m_num[ikl];
+        const float nm = ldg(ko.n_m, ikl);
+        const double s_rho = ldg(ko.s_rho, ikl);
+        const int32_t mnum = ldg(ko.m_num, ikl);
         const double res_in = res[ikl];
         res_old = res_in;
-        const float2 pm_in = ko.p_m[ikl];
-        const double rho_in = ko.rho[ikl];
-        const float2 klm_in = ko.m_m[ikl];
+        const float2 pm_in = ldg(ko.p_m, ikl);
+        const double rho_in = ldg(ko.rho, ikl);
+        const float2 klm_in = ldg(ko.m_m, ikl);
         const uint32_t fc = a.framecount[seq];
         const uint32_t mthr = a.match_num_thresh < fc ? a.match_num_thresh : fc;
         const float min_mod = sq->mv_min_mod;
@@ -2781,7 +2781,7 @@ __global__ __launch_bounds__(256) void k_try_vel(TvrArgs a) {
                     // float expressions when nothing has rotated the new edge map since detection (a.use_grec), as in k_try_velrot
                     MatchRec fr;
                     if (a.use_grec) {
-                        const float4 g = a.kl_new[seq].grec[ikf];
+                        const float4 g = ldg(a.kl_new[seq].grec, ikf);
                         fr.c_px = g.x; fr.c_py = g.y; fr.m_mx = g.z; fr.m_my = g.w;
                         const float n2m = g.z * g.z + g.w * g.w;
                         const float nmf = sqrtf(n2m);

@@ -447,19 +447,19 @@ __device__ __forceinline__ void directed_body(const DirArgs &a) {
         const KlSoA &kn = a.kl_new[seq], &ko = a.kl_old[seq];
         const int32_t *mask = a.mask_old + (size_t)seq * a.n;
         const size_t ro = (size_t)seq * a.cap;   // FUSED: this sequence's turned values
-        const float2 kpm = kn.p_m[ik];
-        const float2 kmm = kn.m_m[ik];
-        const float knm = kn.n_m[ik];
+        const float2 kpm = ldg(kn.p_m, ik);
+        const float2 kmm = ldg(kn.m_m, ik);
+        const float knm = ldg(kn.n_m, ik);
         int iw = -1;
         double krho, ksrho;
         if (FUSED) {
             iw = a.win[ro + ik];
             fwd = iw >= 0;
-            if (iw >= 0) { krho = ko.rho[iw]; ksrho = ko.s_rho[iw]; }                 // what FordwardMatch copies: the unturned values
+            if (iw >= 0) { krho = ldg(ko.rho, iw); ksrho = ldg(ko.s_rho, iw); }                 // what FordwardMatch copies: the unturned values
             else if (FILL) { krho = kRhoInit; ksrho = kRhoMax; }                      // a fresh KeyLine (edge_finder.cpp:178-196)
-            else { krho = kn.rho[ik]; ksrho = kn.s_rho[ik]; }                         // ... which its detector wrote itself
+            else { krho = ldg(kn.rho, ik); ksrho = ldg(kn.s_rho, ik); }                         // ... which its detector wrote itself
         } else {
-            krho = kn.rho[ik]; ksrho = kn.s_rho[ik];
+            krho = ldg(kn.rho, ik); ksrho = ldg(kn.s_rho, ik);
         }
         int found = -1;
         if (searching) {
@@ -582,11 +582,11 @@ __device__ __forceinline__ void directed_body(const DirArgs &a) {
                     // the old KeyLine's (turned) gradient from m_m / n_m themselves: neighbouring threads test neighbouring old KeyLines,
                     // so the 8- and 4-byte gathers share their 64-byte lines at least as well as the 32-byte records did, and
                     // rotate_keylines no longer has to rewrite a record per KeyLine
-                    const float2 omm = FUSED ? a.rot.m_m[ro + j] : ko.m_m[j];
-                    const double norm_m0 = (double)ko.n_m[j];
+                    const float2 omm = FUSED ? ldg(a.rot.m_m, ro + j) : ldg(ko.m_m, j);
+                    const double norm_m0 = (double)ldg(ko.n_m, j);
                     const double cang = (double)(omm.x * kmm.x + omm.y * kmm.y) / (norm_m0 * norm_m);
                     if (cang < a.cang_min_edge || fabs(norm_m0 / norm_m - 1) > a.min_thr_mod) continue;
-                    const double s_rho = FUSED ? a.rot.s_rho[ro + j] : ko.s_rho[j], rho = FUSED ? a.rot.rho[ro + j] : ko.rho[j];
+                    const double s_rho = FUSED ? ldg(a.rot.s_rho, ro + j) : ldg(ko.s_rho, j), rho = FUSED ? ldg(a.rot.rho, ro + j) : ldg(ko.rho, j);
                     const double v_rho_dr = (a.loc_unc * a.loc_unc + s_rho * s_rho * norm_t * norm_t + sigma2_t * rho * rho);
                     const double dd = t - norm_t * rho;
                     if (dd * dd > v_rho_dr) continue;
@@ -605,39 +605,39 @@ __device__ __forceinline__ void directed_body(const DirArgs &a) {
                 float2 pm, mm = make_float2(0.f, 0.f);
                 float nm = 0.f;
                 if (src < 0) {
-                    pm = kn.p_m[ik];                             // p_m_0 of a fresh KeyLine is its own p_m (re-read: not held across the walk)
+                    pm = ldg(kn.p_m, ik);                             // p_m_0 of a fresh KeyLine is its own p_m (re-read: not held across the walk)
                 } else {
                     const bool turned = found >= 0;              // a directed match clones the turned old KeyLine (edge_tracker.cpp:343-366)
-                    rho = turned ? a.rot.rho[ro + src] : ko.rho[src];
-                    s_rho = turned ? a.rot.s_rho[ro + src] : ko.s_rho[src];
-                    pm = turned ? a.rot.p_m[ro + src] : ko.p_m[src];
-                    mm = turned ? a.rot.m_m[ro + src] : ko.m_m[src];
-                    rho_nr = ko.rho_nr[src]; s_rho_nr = ko.s_rho_nr[src];
-                    m_num = ko.m_num[src]; m_id_kf = ko.m_id_kf[src];
-                    nm = ko.n_m[src];
+                    rho = turned ? ldg(a.rot.rho, ro + src) : ldg(ko.rho, src);
+                    s_rho = turned ? ldg(a.rot.s_rho, ro + src) : ldg(ko.s_rho, src);
+                    pm = turned ? ldg(a.rot.p_m, ro + src) : ldg(ko.p_m, src);
+                    mm = turned ? ldg(a.rot.m_m, ro + src) : ldg(ko.m_m, src);
+                    rho_nr = ldg(ko.rho_nr, src); s_rho_nr = ldg(ko.s_rho_nr, src);
+                    m_num = ldg(ko.m_num, src); m_id_kf = ldg(ko.m_id_kf, src);
+                    nm = ldg(ko.n_m, src);
                 }
 #if EDGEHIP_NT_DIRECTED
-                st_stream(kn.rho + ik, rho);
-                st_stream(kn.s_rho + ik, s_rho);
-                st_stream(kn.rho_nr + ik, rho_nr);
-                st_stream(kn.s_rho_nr + ik, s_rho_nr);
-                st_stream(kn.m_num + ik, m_num + 1);
-                st_stream(kn.m_id + ik, src);
-                st_stream(kn.p_m_0 + ik, pm);
-                st_stream(kn.m_m0 + ik, mm);
-                st_stream(kn.n_m0 + ik, (double)nm);
-                st_stream(kn.m_id_kf + ik, m_id_kf);
+                stg_stream(kn.rho, ik, rho);
+                stg_stream(kn.s_rho, ik, s_rho);
+                stg_stream(kn.rho_nr, ik, rho_nr);
+                stg_stream(kn.s_rho_nr, ik, s_rho_nr);
+                stg_stream(kn.m_num, ik, m_num + 1);
+                stg_stream(kn.m_id, ik, src);
+                stg_stream(kn.p_m_0, ik, pm);
+                stg_stream(kn.m_m0, ik, mm);
+                stg_stream(kn.n_m0, ik, (double)nm);
+                stg_stream(kn.m_id_kf, ik, m_id_kf);
 #else
-                kn.rho[ik] = rho;
-                kn.s_rho[ik] = s_rho;
-                kn.rho_nr[ik] = rho_nr;
-                kn.s_rho_nr[ik] = s_rho_nr;
-                kn.m_num[ik] = m_num + 1;
-                kn.m_id[ik] = src;
-                kn.p_m_0[ik] = pm;
-                kn.m_m0[ik] = mm;
-                kn.n_m0[ik] = (double)nm;
-                kn.m_id_kf[ik] = m_id_kf;
+                stg(kn.rho, ik, rho);
+                stg(kn.s_rho, ik, s_rho);
+                stg(kn.rho_nr, ik, rho_nr);
+                stg(kn.s_rho_nr, ik, s_rho_nr);
+                stg(kn.m_num, ik, m_num + 1);
+                stg(kn.m_id, ik, src);
+                stg(kn.p_m_0, ik, pm);
+                stg(kn.m_m0, ik, mm);
+                stg(kn.n_m0, ik, (double)nm);
+                stg(kn.m_id_kf, ik, m_id_kf);
 #endif
                 matched = found >= 0;
                 kfm = matched && m_id_kf >= 0;
@@ -645,24 +645,24 @@ __device__ __forceinline__ void directed_body(const DirArgs &a) {
         } else if (found >= 0) {
             const int j = found;
             // gathers first, stores after (a load behind a store waits for the store)
-            const double c_rho = a.stereo_mode ? ko.rho0[j] : ko.rho[j], c_srho = a.stereo_mode ? ko.s_rho0[j] : ko.s_rho[j];
+            const double c_rho = a.stereo_mode ? ldg(ko.rho0, j) : ldg(ko.rho, j), c_srho = a.stereo_mode ? ldg(ko.s_rho0, j) : ldg(ko.s_rho, j);
             double c_rho_nr = 0, c_srho_nr = 0;
-            if (!a.stereo_mode) { c_rho_nr = ko.rho_nr[j]; c_srho_nr = ko.s_rho_nr[j]; }
-            const int32_t c_mnum = ko.m_num[j], mk = ko.m_id_kf[j];
-            const float2 c_pm = ko.p_m[j], c_mm = ko.m_m[j];
-            const float c_nm = ko.n_m[j];
-            kn.rho[ik] = c_rho;
-            kn.s_rho[ik] = c_srho;
+            if (!a.stereo_mode) { c_rho_nr = ldg(ko.rho_nr, j); c_srho_nr = ldg(ko.s_rho_nr, j); }
+            const int32_t c_mnum = ldg(ko.m_num, j), mk = ldg(ko.m_id_kf, j);
+            const float2 c_pm = ldg(ko.p_m, j), c_mm = ldg(ko.m_m, j);
+            const float c_nm = ldg(ko.n_m, j);
+            stg(kn.rho, ik, c_rho);
+            stg(kn.s_rho, ik, c_srho);
             if (!a.stereo_mode) {
-                kn.rho_nr[ik] = c_rho_nr;
-                kn.s_rho_nr[ik] = c_srho_nr;
+                stg(kn.rho_nr, ik, c_rho_nr);
+                stg(kn.s_rho_nr, ik, c_srho_nr);
             }
-            kn.m_id[ik] = j;
-            kn.m_num[ik] = c_mnum + 1;
-            kn.p_m_0[ik] = c_pm;
-            kn.m_m0[ik] = c_mm;
-            kn.n_m0[ik] = (double)c_nm;
-            kn.m_id_kf[ik] = mk;
+            stg(kn.m_id, ik, j);
+            stg(kn.m_num, ik, c_mnum + 1);
+            stg(kn.p_m_0, ik, c_pm);
+            stg(kn.m_m0, ik, c_mm);
+            stg(kn.n_m0, ik, (double)c_nm);
+            stg(kn.m_id_kf, ik, mk);
             matched = 1;
             kfm = mk >= 0;
         }
@@ -701,15 +701,15 @@ __global__ __launch_bounds__(256) void k_regularize(const KlSoA *kls, const int3
     if (skip) return;
     if (i >= kns[seq]) return;
     const KlSoA &K = kls[seq];
-    double r = K.rho[i], s = K.s_rho[i];
-    const int ni = K.n_id[i], pi = K.p_id[i];
+    double r = ldg(K.rho, i), s = ldg(K.s_rho, i);
+    const int ni = ldg(K.n_id, i), pi = ldg(K.p_id, i);
     if (enabled && ni >= 0 && pi >= 0) {
-        const double nrho = K.rho[ni], prho = K.rho[pi], nsr = K.s_rho[ni], psr = K.s_rho[pi];
+        const double nrho = ldg(K.rho, ni), prho = ldg(K.rho, pi), nsr = ldg(K.s_rho, ni), psr = ldg(K.s_rho, pi);
         const double d = nrho - prho;
         if (!(d * d > nsr * nsr + psr * psr)) {
-            const float2 nm = K.m_m[ni], pm = K.m_m[pi];
+            const float2 nm = ldg(K.m_m, ni), pm = ldg(K.m_m, pi);
             // all-float expression converted to double afterwards (edge_tracker.cpp:119)
-            double alpha = (double)((nm.x * pm.x + nm.y * pm.y) / (K.n_m[ni] * K.n_m[pi]));
+            double alpha = (double)((nm.x * pm.x + nm.y * pm.y) / (ldg(K.n_m, ni) * ldg(K.n_m, pi)));
             if (!(alpha - thresh < 0)) {
                 alpha = (alpha - thresh) / (1 - thresh);
                 alpha /= fabs(nrho - prho) / (nsr + psr) + 1;
@@ -733,14 +733,14 @@ __global__ __launch_bounds__(256) void k_ekf(const KlSoA *kls, const int32_t *__
     if (i >= kns[seq]) return;
     const KlSoA &K = kls[seq];
     double rho = rs[(size_t)seq * 2 * cap + i], s_rho = rs[(size_t)seq * 2 * cap + cap + i];
-    if (do_ekf && K.m_id[i] >= 0) {
+    if (do_ekf && ldg(K.m_id, i) >= 0) {
         // UpdateInverseDepthKalmanARLU, edge_tracker.cpp:954-1055
         const double v0 = sq->pub.V[0], v1 = sq->pub.V[1], v2 = sq->pub.V[2];
         const double s_rho0 = s_rho;
-        const float2 q = K.p_m[i], q0 = K.p_m_0[i], mm0 = K.m_m0[i];
+        const float2 q = ldg(K.p_m, i), q0 = ldg(K.p_m_0, i), mm0 = ldg(K.m_m0, i);
         const double qx = q.x, qy = q.y, q0x = q0.x, q0y = q0.y;
         double v_rho = s_rho * s_rho;
-        const double nm0 = K.n_m0[i];
+        const double nm0 = ldg(K.n_m0, i);
         const double u_x = (double)mm0.x / nm0, u_y = (double)mm0.y / nm0;
         const double Y = u_x * (qx - q0x) + u_y * (qy - q0y);
         const double H = u_x * (v0 * zf - v2 * q0x) + u_y * (v1 * zf - v2 * q0y);
@@ -768,17 +768,17 @@ __global__ __launch_bounds__(256) void k_ekf(const KlSoA *kls, const int32_t *__
             s_rho = kRhoMax;
         }
 #if EDGEHIP_NT_EKF
-        st_stream(K.rho0 + i, rho0);
-        st_stream(K.s_rho0 + i, s_rho0);
+        stg_stream(K.rho0, i, rho0);
+        stg_stream(K.s_rho0, i, s_rho0);
     }
-    st_stream(K.rho + i, rho);
-    st_stream(K.s_rho + i, s_rho);
+    stg_stream(K.rho, i, rho);
+    stg_stream(K.s_rho, i, s_rho);
 #else
-        K.rho0[i] = rho0;
-        K.s_rho0[i] = s_rho0;
+        stg(K.rho0, i, rho0);
+        stg(K.s_rho0, i, s_rho0);
     }
-    K.rho[i] = rho;
-    K.s_rho[i] = s_rho;
+    stg(K.rho, i, rho);
+    stg(K.s_rho, i, s_rho);
 #endif
 }
 
@@ -842,7 +842,7 @@ __global__ __launch_bounds__(NT) void k_rescale(const KlSoA *kls, const int32_t 
 #pragma unroll
             for (int q = 0; q < LB; q++) {
                 const int i = min(tid + v * NT + (j0 + q) * 1024, kn - 1);
-                l_sr0[q] = K.s_rho0[i]; l_sr[q] = K.s_rho[i]; l_mn[q] = K.m_num[i]; l_rho[q] = K.rho[i]; l_rho0[q] = K.rho0[i];
+                l_sr0[q] = ldg(K.s_rho0, i); l_sr[q] = ldg(K.s_rho, i); l_mn[q] = ldg(K.m_num, i); l_rho[q] = ldg(K.rho, i); l_rho0[q] = ldg(K.rho0, i);
             }
 #pragma unroll
             for (int q = 0; q < LB; q++) {
@@ -866,7 +866,7 @@ __global__ __launch_bounds__(NT) void k_rescale(const KlSoA *kls, const int32_t 
 #pragma unroll
             for (int q = 0; q < LJ; q++) {
                 const int i = min(tid + v * NT + (PER + q) * 1024, kn - 1);
-                l_sr0[q] = K.s_rho0[i]; l_sr[q] = K.s_rho[i]; l_mn[q] = K.m_num[i]; l_rho[q] = K.rho[i]; l_rho0[q] = K.rho0[i];
+                l_sr0[q] = ldg(K.s_rho0, i); l_sr[q] = ldg(K.s_rho, i); l_mn[q] = ldg(K.m_num, i); l_rho[q] = ldg(K.rho, i); l_rho0[q] = ldg(K.rho0, i);
             }
 #pragma unroll
             for (int q = 0; q < LJ; q++) {
@@ -904,11 +904,11 @@ __global__ __launch_bounds__(NT) void k_rescale(const KlSoA *kls, const int32_t 
                 b += s_tail[LJ * 1024 + at] * inv;
             }
             for (int i = tid + v * NT + (PER + LJ) * 1024; i < kn; i += 1024) {
-                const double sr0 = K.s_rho0[i], sr = K.s_rho[i];
-                if ((unsigned)K.m_num[i] < match_num_min || sr0 <= 0 || sr > s_rho_min) continue;
+                const double sr0 = ldg(K.s_rho0, i), sr = ldg(K.s_rho, i);
+                if ((unsigned)ldg(K.m_num, i) < match_num_min || sr0 <= 0 || sr > s_rho_min) continue;
                 const double s2t = sr * sr, s02t = sr0 * sr0;   // the same expressions as the register path: the result does not depend on PER
                 const double inv = recip_f64(s2t + kp2 * s02t);
-                const double rho = K.rho[i], rho0 = K.rho0[i];
+                const double rho = ldg(K.rho, i), rho0 = ldg(K.rho0, i);
                 a += (rho * rho) * inv;
                 b += (rho0 * rho0) * inv;
             }
@@ -935,12 +935,12 @@ __global__ __launch_bounds__(NT) void k_rescale(const KlSoA *kls, const int32_t 
 #pragma unroll
             for (int q = 0; q < SB; q++) {
                 const int i = min(i0 + q * NT, kn - 1);
-                a_[q] = K.rho[i]; b_[q] = K.s_rho[i];
+                a_[q] = ldg(K.rho, i); b_[q] = ldg(K.s_rho, i);
             }
 #pragma unroll
             for (int q = 0; q < SB; q++) {
                 const int i = i0 + q * NT;
-                if (i < kn) { K.rho[i] = a_[q] / Kp; K.s_rho[i] = b_[q] / Kp; }
+                if (i < kn) { stg(K.rho, i, a_[q] / Kp); stg(K.s_rho, i, b_[q] / Kp); }
             }
         }
     }

@@ -1,5 +1,6 @@
 """bench.py's host-side helpers (CPU): the numbers it reports next to `value` must mean what DESIGN.md says."""
 import json
+import time
 import os
 import sys
 
@@ -258,6 +259,9 @@ d = a[a.index("-d") + 1]
 counters = a[a.index("--pmc") + 1:a.index("--output-format")]
 if os.environ.get("FAKE_FAIL") in counters:
     sys.exit(3)
+if os.environ.get("FAKE_HANG") in counters:
+    import time
+    time.sleep(600)
 os.makedirs(os.path.join(d, "host", "1"), exist_ok=True)
 vals = {"FETCH_SIZE": 1000.0, "WRITE_SIZE": 500.0, "SQ_ACTIVE_INST_VALU": 256.0 * 1000, "GRBM_GUI_ACTIVE": 8.0 * 2000}
 with open(os.path.join(d, "host", "1", "pmc_counter_collection.csv"), "w") as f:
@@ -292,5 +296,12 @@ print('noise {"metric": "frames_per_second", "config": {"keylines_per_frame_time
         monkeypatch.setenv("FAKE_FAIL", "FETCH_SIZE")
         assert not bench.live_pmc_passes(["--steps", "2"], 1024, budget_s=120)
         assert not bench.LIVE_PMC["used"] and "exited 3" in bench.LIVE_PMC["note"] and True not in bench._PMC_CACHE
+        # a pass that hangs is ended with its whole process group when the budget is up, and the committed constants stay
+        monkeypatch.delenv("FAKE_FAIL")
+        monkeypatch.setenv("FAKE_HANG", "WRITE_SIZE")
+        monkeypatch.setattr(bench, "LIVE_PMC", {"used": False, "note": "not attempted", "issue": None})
+        t0 = time.time()
+        assert not bench.live_pmc_passes(["--steps", "2"], 1024, budget_s=22)
+        assert time.time() - t0 < 40 and "did not finish" in bench.LIVE_PMC["note"] and True not in bench._PMC_CACHE
     finally:
         bench._PMC_CACHE.clear()
