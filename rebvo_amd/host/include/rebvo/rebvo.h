@@ -29,7 +29,8 @@
 //  * Only the config keys that reach this path are mandatory; keys of subsystems that do not exist here
 //    (UDP, encoders, SimuCamera, ProcesorConfig ...) are accepted and ignored.  Optional section:
 //        &GPU  Device=0  BatchGroup=<name>  BatchSize=<N>
-//  * Batch groups (CameraType 3, ImuMode 0, mono).  N rebvo::REBVO objects whose configs name the same &GPU BatchGroup share ONE
+//  * Batch groups (CameraType 3 or 2; all members alike: ImuMode 0, or ImuMode 1 / 2 with the IMU branch batched on the device, or — ImuMode 0 —
+//    StereoAvaiable with a pair frame per main frame through requestStereoCustomCamBuffer).  N rebvo::REBVO objects whose configs name the same &GPU BatchGroup share ONE
 //    edgehip context of N sequences: the group's tracker thread takes the newest frame of every member's camera ring and runs them
 //    through one edgehip_process_frame (every kernel launch carries the N cameras), each object keeps its own ring, callback, log and
 //    getNav().  The members advance in lock-step — one frame of every running member per step, like a synchronised camera rig or a
