@@ -409,3 +409,38 @@ def test_stereo_data_sets_as_one_batch_group(tmp_path):
         g = np.loadtxt(str(tmp_path / "group") + f"{i}.txt", ndmin=2)
         assert a.shape == g.shape == (n - 1, 14) and np.array_equal(a, g), (i, a, g)
         assert np.abs(a[2:, 5:8]).max() > 0          # poses that moved
+
+
+def test_stereo_matches_log_needs_a_stereo_context_a_log_and_logged_frames():
+    """edgehip_read_stereo_matches_log fails loudly where it has nothing to return: a context without stereo_available, a stereo context
+    without a log, a frame that was never enqueued — and works across a ring wrap (frames older than the ring are refused, as for the nav log)."""
+    p, frames, pairs, pc = make_data(all_pairs=True, nf=6)
+    eh = edgehip.EdgeHip(edgehip.euroc_params(W, H), nseq=1, nslots=3)
+    eh.set_nav_log(4)
+    with pytest.raises(edgehip.EdgeHipError, match="stereo_available"):
+        eh.read_stereo_matches_log(0, 1)
+    eh.close()
+    eh = edgehip.EdgeHip(edgehip.euroc_params(W, H, stereo_available=1), nseq=2, nslots=4)
+    eh.set_slot_camera(3, pc["ppx"], pc["ppy"], pc["zfx"], pc["zfy"])
+    eh.set_stereo_rig(3, T_PAIR, R_PAIR, 100.0)
+    with pytest.raises(edgehip.EdgeHipError):
+        eh.read_stereo_matches_log(0, 1)                      # no log yet
+    eh.set_nav_log(4)
+    with pytest.raises(edgehip.EdgeHipError, match="no frame"):
+        eh.read_stereo_matches_log(0, 1)
+    seen = []
+    for k in range(6):
+        eh.upload_rgb(eh.next_slot(), np.stack([frames[k]] * 2))
+        eh.upload_rgb(3, np.stack([pairs[k]] * 2))
+        eh.process_frame(0.05 * k)
+        seen.append(eh.get_stereo_matches().copy())
+    got = eh.read_stereo_matches_log(2, 4)                     # frames 2..5: the ring's whole length
+    assert got.shape == (4, 2)
+    for j, k in enumerate(range(2, 6)):
+        assert np.array_equal(got[j], seen[k]), (k, got[j], seen[k])
+    assert int(got[-1][0]) > 500 and got[-1][0] == got[-1][1]
+    with pytest.raises(edgehip.EdgeHipError, match="not in the log"):
+        eh.read_stereo_matches_log(1, 1)                      # overwritten by frame 5
+    with pytest.raises(edgehip.EdgeHipError):
+        eh.read_stereo_matches_log(6, 1)                      # never enqueued
+    eh.close()
