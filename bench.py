@@ -841,7 +841,7 @@ def _pmc_file(check_stamp=True):
 LIVE_PMC = {"used": False, "note": "not attempted", "issue": None}
 
 
-def live_pmc_passes(child_argv, nseq, budget_s=150):
+def live_pmc_passes(child_argv, nseq, budget_s=90):
     """The counters of THIS run, observed by the command itself: more processes of this file under `rocprofv3 --kernel-trace --pmc ...`
     (no trace domain besides the kernel trace), same batch, steps and warm-up as the parent, CPU legs and extras off:
       FETCH_SIZE, WRITE_SIZE  (separate passes: the two do not share one on gfx950) -> their per-kernel means replace
