@@ -418,7 +418,12 @@ __global__ __launch_bounds__(256) void k_field_raster(const KlSoA *kls, int32_t 
     // The hardware rounding differs from round() in a way that matters only for a coordinate of exactly -0.5 (pixel 0
     // instead of -1, ctx.h): that can only be accepted by a tile that starts at column / row 0, so only the tiles on
     // the left / top image border pay for the fix-up.  (Block-uniform choice of one of four loop bodies.)
-    auto raster = [&](auto fix_x, auto fix_y) {
+#ifndef EDGEHIP_RASTER_LEAN
+#define EDGEHIP_RASTER_LEAN 1
+#endif
+    const unsigned ex4 = ex << 2;
+    const int neg4tx0 = -4 * tx0;
+    auto raster = [&](auto fix_x, auto fix_y, auto narrow) {
         for (int wi = tid; wi < cnt * FSPLIT; wi += 256) {
             const int li = wi / FSPLIT, part = wi - li * FSPLIT;
 #if EDGEHIP_RASTER_ABL == 6     // no bin read
@@ -469,6 +474,18 @@ __global__ __launch_bounds__(256) void k_field_raster(const KlSoA *kls, int32_t 
                 const float fy = r.u_my * tf + r.c_py;
 #endif
                 // Image::GetIndexRC uses round()
+#if EDGEHIP_RASTER_LEAN && EDGEHIP_RASTER_ABL == 0
+                // Two vector instructions fewer per in-tile sample (of ~16; the loop runs the vector ALU at 1.0): the column comes out as a BYTE offset
+                // in one shift-add — (round(fx) << 2) - 4 tx0, compared against 4 ex: the same test, |lx| is far below 2^29 — and |t|, an exact small
+                // integer in a float, goes into byte 2 of the stored word with v_cvt_pk_u8_f32 (one instruction for the conversion, the shift and the OR;
+                // |t| <= radius <= 255 is the host's condition for this form: `narrow`).
+                const int rx = decltype(fix_x)::value ? round_half_away_i(fx) : round_ties_up_i(fx);
+                const int ly = (decltype(fix_y)::value ? round_half_away_i(fy) : round_ties_up_i(fy)) - ty0;
+                const unsigned lx4 = (unsigned)((rx << 2) + neg4tx0);
+                if (lx4 >= ex4 || (unsigned)ly >= ey) return;
+                const uint32_t val = decltype(narrow)::value ? __builtin_amdgcn_cvt_pk_u8_f32(fabsf(tf), 2u, idk) : (((uint32_t)fabsf(tf) << 16) | idk);
+                atomicMin(reinterpret_cast<uint32_t *>(reinterpret_cast<char *>(s_tile) + (__umul24((unsigned)ly, (unsigned)(TS * 4)) + lx4)), val);
+#else
                 const int lx = (decltype(fix_x)::value ? round_half_away_i(fx) : round_ties_up_i(fx)) - tx0;
                 const int ly = (decltype(fix_y)::value ? round_half_away_i(fy) : round_ties_up_i(fy)) - ty0;
                 if ((unsigned)lx >= ex || (unsigned)ly >= ey) return;
@@ -479,6 +496,7 @@ __global__ __launch_bounds__(256) void k_field_raster(const KlSoA *kls, int32_t 
                 acc_abl += (at << 16) | idk | (uint32_t)(ly * TS + lx);
 #else
                 atomicMin(&s_tile[__umul24((unsigned)ly, (unsigned)TS) + (unsigned)lx], (at << 16) | idk);   // (a 24-bit product: the 32-bit one runs at a quarter of the rate, once per sample)
+#endif
 #endif
             };
 #if EDGEHIP_RASTER_UNROLL == 2
@@ -497,8 +515,13 @@ __global__ __launch_bounds__(256) void k_field_raster(const KlSoA *kls, int32_t 
     };
     using T = std::true_type;
     using F = std::false_type;
-    if (tx0 == 0) { if (ty0 == 0) raster(T{}, T{}); else raster(T{}, F{}); }
-    else { if (ty0 == 0) raster(F{}, T{}); else raster(F{}, F{}); }
+    if (radius <= 255) {
+        if (tx0 == 0) { if (ty0 == 0) raster(T{}, T{}, T{}); else raster(T{}, F{}, T{}); }
+        else { if (ty0 == 0) raster(F{}, T{}, T{}); else raster(F{}, F{}, T{}); }
+    } else {
+        if (tx0 == 0) { if (ty0 == 0) raster(T{}, T{}, F{}); else raster(T{}, F{}, F{}); }
+        else { if (ty0 == 0) raster(F{}, T{}, F{}); else raster(F{}, F{}, F{}); }
+    }
     __syncthreads();
     if (tid == 0) bin_cnt[(size_t)seq * kMaxTiles + tile] = 0;   // every tile's count is consumed by exactly this block: ready for the next k_field_bin (no memset launch)
 #if EDGEHIP_RASTER_ABL == 4
@@ -968,13 +991,15 @@ __device__ __forceinline__ void tvr_body(const TvrArgs &a, const int seq, const 
             int ns = 0;
             if (PROCJF) {
 #pragma unroll
+                // (one KeyLine per thread: the product IS the lane's term — `0.0 + product` would cost an add per sum, 28 of the evaluation's ~600
+                // vector instructions, to turn a -0.0 product into +0.0, which the reference's PairWiseVAdd over the bare products does not do either)
                 for (int i = 0; i < 6; i++)
 #pragma unroll
-                    for (int j = i; j < 6; j++) sums[ns++] += J[i] * J[j];
+                    for (int j = i; j < 6; j++) { const double pr = J[i] * J[j]; sums[ns] = kTvrPasses == 1 ? pr : sums[ns] + pr; ns++; }
 #pragma unroll
-                for (int i = 0; i < 6; i++) sums[ns++] += J[i] * fm;
+                for (int i = 0; i < 6; i++) { const double pr = J[i] * fm; sums[ns] = kTvrPasses == 1 ? pr : sums[ns] + pr; ns++; }
             }
-            sums[PROCJF ? ns : kNumSums - 1] += fm * fm;
+            { const double pr = fm * fm; const int at = PROCJF ? ns : kNumSums - 1; sums[at] = kTvrPasses == 1 ? pr : sums[at] + pr; }
         }
     }
 
@@ -1499,14 +1524,14 @@ __device__ __forceinline__ void tvr2_body(const TvrArgs &a, const int seq, const
 #pragma unroll
             for (int i = 0; i < 6; i++)
 #pragma unroll
-                for (int j = i; j < 6; j++) sums[ns++] = 0.0 + J[i] * J[j];
+                for (int j = i; j < 6; j++) sums[ns++] = J[i] * J[j];   // (the bare products, as tvr_body's)
 #pragma unroll
-            for (int i = 0; i < 6; i++) sums[ns++] = 0.0 + J[i] * f;
-            sums[ns] = 0.0 + f * f;
+            for (int i = 0; i < 6; i++) sums[ns++] = J[i] * f;
+            sums[ns] = f * f;
             const int idx = wave_reduce28(sums, lane);
             if ((lane & 1) == 0) s_red[c][wave][idx] = sums[0];
         } else {
-            double v = 0.0 + fmc[c] * fmc[c];
+            double v = fmc[c] * fmc[c];
 #pragma unroll
             for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
             if (lane == 0) s_red[c][wave][kNumSums - 1] = v;
