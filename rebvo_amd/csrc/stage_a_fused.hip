@@ -331,7 +331,7 @@ __global__ __launch_bounds__(512) void k_stage_a_fused(FusedArgs a) {
         const int half_ss = nss >> 1;
         const int srow = lane >> 2, sq = lane & 3;
         const bool on = srow < 4 * RB && !(ABL & 1);
-#define EH_BC(val, k) __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(val), (k) * 0x55, 0xf, 0xf, false))
+#define EH_BC(val, k) __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(val), (k) * 0x55, 0xf, 0xf, true))
         EH_TS_DECL
         for (int t = 0; t < nticks; t++) {
             EH_TS_BEGIN(t)
@@ -786,11 +786,11 @@ __global__ __launch_bounds__(512) void k_stage_a_fused(FusedArgs a) {
             const int y = ydog0 + j;
             const v2f cv = iv[j + 1];                       // img0 of row y at columns x0, x0+1
             // neighbours in x: lane l-1 / l+1 of the wave (DPP wave shifts), the adjacent wave's edge lane through LDS
-            float lft = __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(cv.y), 0x138, 0xf, 0xf, false));   // wave_shr:1 -> column x0 - 1
-            float rgt = __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(cv.x), 0x130, 0xf, 0xf, false));   // wave_shl:1 -> column x0 + 2
+            float lft = __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(cv.y), 0x138, 0xf, 0xf, true));   // wave_shr:1 -> column x0 - 1
+            float rgt = __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(cv.x), 0x130, 0xf, 0xf, true));   // wave_shl:1 -> column x0 + 2
             const uint32_t pj = (ppack >> (2 * j)) & 3u;    // DoG > 0 at (x0, x0+1) in row y
-            uint32_t pL = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)pj, 0x138, 0xf, 0xf, false);
-            uint32_t pR = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)pj, 0x130, 0xf, 0xf, false);
+            uint32_t pL = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)pj, 0x138, 0xf, 0xf, true);
+            uint32_t pR = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)pj, 0x130, 0xf, 0xf, true);
             {   // every lane reads the two records (wave-uniform addresses: LDS broadcasts), lanes 0 / 63 keep them: no branch
                 const uint2 eL = s_edge2[((size_t)j * (NW + 2) + wv) * 2 + 1];        // last column of the wave to the left (zeros left of the image)
                 const uint2 eR = s_edge2[((size_t)j * (NW + 2) + wv + 2) * 2 + 0];    // first column of the wave to the right

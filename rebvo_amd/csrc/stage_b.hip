@@ -774,10 +774,13 @@ __device__ __forceinline__ void tvr_body(const TvrArgs &a, const int seq, const 
         if (base >= kn) break;               // block-uniform
         const int ikl = base + tid;
         double J[6] = {0, 0, 0, 0, 0, 0};
-        double fm = 0, dfx = 0, dfy = 0;
-        double ptx = 0, pty = 0, ptz = 1, pix = 0, piy = 0, rho_p = 1, s_rho = 1;
+        double fm, dfx, dfy;   // (set where the evaluation begins: `if (!skip)`)
+        // What only an evaluated KeyLine (status != 0) reads further down is left without a default: a default is a register move at every
+        // level of the nest below (the compiler materialised 44 v_mov_b64 for them, 8 % of the evaluation's vector instructions), and the
+        // Jacobian section now runs for evaluated KeyLines only (a skipped one contributed exact zeros: J = 0, fm = 0 stand for it).
+        double ptx, pty, ptz, pix, piy, rho_p, s_rho;
 #if EDGEHIP_TVR_REF_ORDER
-        double wgt_ref = 1;  // the Huber weight (REWEIGHT)
+        double wgt_ref;      // the Huber weight (REWEIGHT)
 #else
         double inv_w2 = 1;   // 1 / weight^2 (REWEIGHT)
 #endif
@@ -785,8 +788,8 @@ __device__ __forceinline__ void tvr_body(const TvrArgs &a, const int seq, const 
         // status: 0 = skipped (no residual written), 1 = out of image (max_r), 2 = evaluated & matched (own fi),
         //         3 = evaluated, unmatched (inherits the previous valid fi)
         int status = 0;
-        double fi = 0;
-        double rho_own = 0;   // the KeyLine's rho, kept for the key post of the last evaluation (no load behind the residual store)
+        double fi = 0;        // (every lane hands it to the shuffles below: it keeps its default)
+        double rho_own;       // the KeyLine's rho, kept for the key post of the last evaluation (no load behind the residual store); read with mid_f >= 0 only
         if (ikl < kn) {
             // Everything the KeyLine streams in is requested here, before the first use: the skip test, the projection, the
             // in-image test and the two gathers are a chain of dependent memory round trips, and with the loads inside the
@@ -824,6 +827,10 @@ __device__ __forceinline__ void tvr_body(const TvrArgs &a, const int seq, const 
                 // Huber weight k / |r| of the previous iteration's residual (global_tracker.cpp:370-372).  It multiplies the
                 // residual and the gradient, the uncertainty scaling q_rho = sqrt((s_rho w qvel)^2 + 1) divides them again
                 // (:452-463): together w / q_rho = 1 / sqrt((s_rho qvel)^2 + 1 / w^2), what EDGEHIP_TVR_REF_ORDER 0 computes.
+                dfx = 0; dfy = 0;
+#if EDGEHIP_TVR_REF_ORDER
+                wgt_ref = 1;
+#endif
                 if (REWEIGHT) {
                     if (is_carry(rprev)) rprev = carry_in_prev;
 #if EDGEHIP_TVR_REF_ORDER
@@ -832,12 +839,11 @@ __device__ __forceinline__ void tvr_body(const TvrArgs &a, const int seq, const 
                     if (fabs(rprev) > a.k_huber && !(ABL & 2)) { const double rk = fabs(rprev) * a.inv_k_huber; inv_w2 = rk * rk; }
 #endif
                 }
+                fm = a.max_r;
                 if (x < 1 || y < 1 || x >= a.w - 1 || y >= a.h - 1) {
-                    fm = a.max_r;
                     status = 1;
                 } else {
                     status = 3;
-                    fm = a.max_r;
                     // temporarily z-rotated gradient, stored back into a float Point2DF (:386-388)
                     const float rmx = KF ? klm.x : (float)(sq->RM[0] * (double)klm.x + sq->RM[1] * (double)klm.y);
                     const float rmy = KF ? klm.y : (float)(sq->RM[2] * (double)klm.x + sq->RM[3] * (double)klm.y);
@@ -863,8 +869,10 @@ __device__ __forceinline__ void tvr_body(const TvrArgs &a, const int seq, const 
                                 status = 2;
                             }
                         }
-                    } else if (f != 0u) {
-                        const int ikf = (int)f - 1;
+                    } else {
+                        // (an empty field entry reads record 0 and fails the test below by `f != 0`: one level of the nest less — each level costs
+                        // the moves of everything it may leave unchanged — and record 0's line is the same for every such lane)
+                        const int ikf = f != 0u ? (int)f - 1 : 0;
                         // The matched KeyLine's c_p, m_m, u_m.  GREC: a 16-byte record (four records share the 64 bytes
                         // a random gather moves, instead of two) and u_m recomputed with the detector's own float
                         // expressions (k_emit; edge_finder.cpp:166-200), valid for KeyLines nothing has rotated since.
@@ -881,7 +889,7 @@ __device__ __forceinline__ void tvr_body(const TvrArgs &a, const int seq, const 
                         // Test_f_k (float arithmetic inside, compared in double)
                         const double p_n2 = (double)(knm * knm);
                         const double p_esc = (double)(rmx * f_mx + rmy * f_my);
-                        if (!(fabs(p_esc - p_n2) > a.match_thresh * p_n2)) {
+                        if (f != 0u && !(fabs(p_esc - p_n2) > a.match_thresh * p_n2)) {
                             if (GREC) {
                                 const float n2m = f_mx * f_mx + f_my * f_my;
                                 const float nm = sqrtf(n2m);
@@ -938,7 +946,8 @@ __device__ __forceinline__ void tvr_body(const TvrArgs &a, const int seq, const 
         }
 
         // ---- Jacobian row, uncertainty scaling (global_tracker.cpp:419-463) ----
-        if (ikl < kn) {
+        double fs = 0;   // the scaled residual: the row's seventh value (zero, like J, for a KeyLine that was not evaluated)
+        if (status != 0) {
 #if EDGEHIP_TVR_REF_ORDER
             if (REWEIGHT) { fm *= wgt_ref; dfx *= wgt_ref; dfy *= wgt_ref; }
 #endif
@@ -964,7 +973,7 @@ __device__ __forceinline__ void tvr_body(const TvrArgs &a, const int seq, const 
 #pragma unroll
                 for (int j = 0; j < 6; j++) J[j] = div_rn(J[j], q_rho, r_q);
             }
-            fm = div_rn(fm, q_rho, r_q);
+            fs = div_rn(fm, q_rho, r_q);
 #else
             double inv_q;
             if (REWEIGHT) {
@@ -977,7 +986,7 @@ __device__ __forceinline__ void tvr_body(const TvrArgs &a, const int seq, const 
 #pragma unroll
                 for (int j = 0; j < 6; j++) J[j] *= inv_q;
             }
-            fm *= inv_q;
+            fs = fm * inv_q;
 #endif
         }
         if (GRAM_MFMA) {
@@ -986,7 +995,7 @@ __device__ __forceinline__ void tvr_body(const TvrArgs &a, const int seq, const 
             row[0] = make_double2(J[0], J[1]);
             row[1] = make_double2(J[2], J[3]);
             row[2] = make_double2(J[4], J[5]);
-            row[3] = make_double2(fm, 0.0);
+            row[3] = make_double2(fs, 0.0);
         } else {
             int ns = 0;
             if (PROCJF) {
@@ -997,9 +1006,9 @@ __device__ __forceinline__ void tvr_body(const TvrArgs &a, const int seq, const 
 #pragma unroll
                     for (int j = i; j < 6; j++) { const double pr = J[i] * J[j]; sums[ns] = kTvrPasses == 1 ? pr : sums[ns] + pr; ns++; }
 #pragma unroll
-                for (int i = 0; i < 6; i++) { const double pr = J[i] * fm; sums[ns] = kTvrPasses == 1 ? pr : sums[ns] + pr; ns++; }
+                for (int i = 0; i < 6; i++) { const double pr = J[i] * fs; sums[ns] = kTvrPasses == 1 ? pr : sums[ns] + pr; ns++; }
             }
-            { const double pr = fm * fm; const int at = PROCJF ? ns : kNumSums - 1; sums[at] = kTvrPasses == 1 ? pr : sums[at] + pr; }
+            { const double pr = fs * fs; const int at = PROCJF ? ns : kNumSums - 1; sums[at] = kTvrPasses == 1 ? pr : sums[at] + pr; }
         }
     }
 
@@ -1326,8 +1335,9 @@ __device__ __forceinline__ void tvr2_body(const TvrArgs &a, const int seq, const
 
     const int ikl = blk * kTvrBlock + tid;
     // per chain: what tvr_body keeps per KeyLine
-    double fm[2] = {0, 0}, dfx[2] = {0, 0}, dfy[2] = {0, 0}, fi[2] = {0, 0};
-    double ptx[2] = {0, 0}, pty[2] = {0, 0}, ptz[2] = {1, 1}, pix[2] = {0, 0}, piy[2] = {0, 0}, rho_p[2] = {1, 1};
+    // (no defaults for what only an evaluated KeyLine — status != 0 — reads in the Jacobian section: see tvr_body)
+    double fm[2], dfx[2], dfy[2], fi[2] = {0, 0};
+    double ptx[2], pty[2], ptz[2], pix[2], piy[2], rho_p[2];
     int status[2] = {0, 0};   // 0 skipped, 1 out of image, 2 matched, 3 evaluated and unmatched (tvr_body)
     double s_rho = 1;
     if (ikl < kn) {
@@ -1365,6 +1375,7 @@ __device__ __forceinline__ void tvr2_body(const TvrArgs &a, const int seq, const
                 rmx[c] = (float)(RM[0] * (double)klm.x + RM[1] * (double)klm.y);
                 rmy[c] = (float)(RM[2] * (double)klm.x + RM[3] * (double)klm.y);
                 fm[c] = a.max_r;
+                dfx[c] = 0; dfy[c] = 0;
                 status[c] = inimg[c] ? 3 : 1;
             }
             // the two gathers of the two chains, level by level: both field reads are in flight together, then both records
@@ -1467,8 +1478,9 @@ __device__ __forceinline__ void tvr2_body(const TvrArgs &a, const int seq, const
         double *J = Jc[c];
 #pragma unroll
         for (int j = 0; j < 6; j++) J[j] = 0;
-        fmc[c] = fm[c];
-        if (ikl < kn) {
+        fmc[c] = 0;
+        if (status[c] != 0) {   // (a skipped KeyLine's row is exact zeros)
+            fmc[c] = fm[c];
             if (PROCJF) {
                 double t0 = a.zfm * rho_p[c];
                 J[0] = t0 * dfx[c];

@@ -13,9 +13,10 @@ namespace edgehip {
 // full sum of value
 //     idx = b1 + 2*b2 + 4*b3 + 7*b4 + 14*b5      (b_k = bit k of l; lanes with b1+2*b2+4*b3 == 7 hold padding)
 // and lanes l, l^1 hold the same value.  Fixed order => bit-reproducible from run to run.
-// The exchanges themselves: v_permlane32_swap / v_permlane16_swap (gfx950) for the two big steps, DPP moves for lane ^ 8, 2, 1,
-// ds_bpermute only for lane ^ 4 — a shuffle through the LDS crossbar costs an LDS instruction each way and was most of the
-// reduction's time when every step used it.
+// The exchanges themselves: v_permlane32_swap / v_permlane16_swap (gfx950) for the two big steps, DPP moves for lane ^ 8, 4, 2, 1
+// (no ds_bpermute: a shuffle through the LDS crossbar costs an LDS instruction each way and was most of the reduction's time when
+// every step used it).  The DPP moves carry bound_ctrl: every lane has a source, so the flag changes no value — it tells the compiler
+// that the destination's old content is dead, which saves the `v_mov_b32 v, 0` it otherwise puts in front of every one of them.
 // ---------------------------------------------------------------------------------------------------
 template <int N>
 __device__ __forceinline__ void halve_step(double *v, int lane, int off) {
@@ -45,8 +46,8 @@ __device__ __forceinline__ void halve_swap(double *v) {
 // partner = lane ^ 8 is a rotation by 8 inside a row of 16, lane ^ 2 / lane ^ 1 are quad permutations: DPP moves
 template <int CTRL>
 __device__ __forceinline__ double dpp_mov_f64(double x) {
-    const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(x), CTRL, 0xf, 0xf, false);
-    const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(x), CTRL, 0xf, 0xf, false);
+    const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(x), CTRL, 0xf, 0xf, true);
+    const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(x), CTRL, 0xf, 0xf, true);
     return __hiloint2double(hi, lo);
 }
 template <int N, int CTRL>
@@ -59,6 +60,32 @@ __device__ __forceinline__ void halve_dpp(double *v, int lane, int off) {
         v[i] = keep + dpp_mov_f64<CTRL>(send);
     }
 }
+// partner = lane ^ 4: the lower four lanes of every group of eight read four lanes up (row_shl:4), the upper four read four lanes down
+// (row_shr:4) — two DPP moves with complementary bank masks, and because each move names its own source register the "send" select of the
+// halving step disappears: lower lanes receive the partner's v[i], upper lanes the partner's v[i + N].  Same pairs, same sums as the
+// ds_bpermute form it replaces (halve_step), without the LDS round trip in the reduction's tail.
+#ifndef EDGEHIP_REDUCE_DPP4
+#define EDGEHIP_REDUCE_DPP4 1
+#endif
+__device__ __forceinline__ int dpp_xor4(int from_lower_rule, int from_upper_rule) {
+    const int r = __builtin_amdgcn_update_dpp(0, from_lower_rule, 0x104, 0xf, 0xf, true);   // row_shl:4: lane l <- l + 4 (the upper banks are overwritten next)
+    return __builtin_amdgcn_update_dpp(r, from_upper_rule, 0x114, 0xf, 0xa, false);          // row_shr:4 into banks 1 and 3: lane l <- l - 4
+}
+template <int N>
+__device__ __forceinline__ void halve_dpp4(double *v, int lane) {
+#if EDGEHIP_REDUCE_DPP4
+    const bool hi = (lane & 4) != 0;
+#pragma unroll
+    for (int i = 0; i < N; i++) {
+        const double keep = hi ? v[i + N] : v[i];
+        const int lo = dpp_xor4(__double2loint(v[i]), __double2loint(v[i + N]));
+        const int hw = dpp_xor4(__double2hiint(v[i]), __double2hiint(v[i + N]));
+        v[i] = keep + __hiloint2double(hw, lo);
+    }
+#else
+    halve_step<N>(v, lane, 4);
+#endif
+}
 __device__ __forceinline__ int wave_reduce28(double (&s)[kNumSums], int lane) {
     double v[32];
 #pragma unroll
@@ -67,7 +94,7 @@ __device__ __forceinline__ int wave_reduce28(double (&s)[kNumSums], int lane) {
     halve_swap<7, true>(v);        // 14 -> 7    (lane ^ 16)
     v[7] = 0.0;
     halve_dpp<4, 0x128>(v, lane, 8);   // 8 -> 4   row_ror:8
-    halve_step<2>(v, lane, 4);         // 4 -> 2   (no DPP pattern for lane ^ 4: ds_bpermute)
+    halve_dpp4<2>(v, lane);            // 4 -> 2   row_shl:4 / row_shr:4 by bank
     halve_dpp<1, 0x4E>(v, lane, 2);    // 2 -> 1   quad_perm:[2,3,0,1]
     v[0] += dpp_mov_f64<0xB1>(v[0]);   //          quad_perm:[1,0,3,2]
     s[0] = v[0];
@@ -88,7 +115,7 @@ __device__ __forceinline__ void halve_swap_f32(float *v) {
 }
 template <int CTRL>
 __device__ __forceinline__ float dpp_mov_f32(float x) {
-    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(x), CTRL, 0xf, 0xf, false));
+    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(x), CTRL, 0xf, 0xf, true));
 }
 template <int N, int CTRL>
 __device__ __forceinline__ void halve_dpp_f32(float *v, int lane, int off) {
@@ -108,13 +135,17 @@ __device__ __forceinline__ int wave_reduce28_f32(float (&s)[kNumSums], int lane)
     halve_swap_f32<7, true>(v);
     v[7] = 0.f;
     halve_dpp_f32<4, 0x128>(v, lane, 8);
-    {   // lane ^ 4: ds_bpermute
+    {   // lane ^ 4: row_shl:4 / row_shr:4 by bank (halve_dpp4)
         const bool hi = (lane & 4) != 0;
 #pragma unroll
         for (int i = 0; i < 2; i++) {
-            const float send = hi ? v[i] : v[i + 2];
             const float keep = hi ? v[i + 2] : v[i];
+#if EDGEHIP_REDUCE_DPP4
+            v[i] = keep + __int_as_float(dpp_xor4(__float_as_int(v[i]), __float_as_int(v[i + 2])));
+#else
+            const float send = hi ? v[i] : v[i + 2];
             v[i] = keep + __shfl_xor(send, 4, 64);
+#endif
         }
     }
     halve_dpp_f32<1, 0x4E>(v, lane, 2);
@@ -133,7 +164,7 @@ __device__ __forceinline__ int wave_reduce16(double (&v)[16], int lane) {
     halve_swap<8, false>(v);           // 16 -> 8   (lane ^ 32)
     halve_swap<4, true>(v);            // 8 -> 4    (lane ^ 16)
     halve_dpp<2, 0x128>(v, lane, 8);   // 4 -> 2    row_ror:8
-    halve_step<1>(v, lane, 4);         // 2 -> 1    ds_bpermute
+    halve_dpp4<1>(v, lane);            // 2 -> 1    row_shl:4 / row_shr:4 by bank
     v[0] += dpp_mov_f64<0x4E>(v[0]);   // lane ^ 2
     v[0] += dpp_mov_f64<0xB1>(v[0]);   // lane ^ 1
     return 8 * ((lane >> 5) & 1) + 4 * ((lane >> 4) & 1) + 2 * ((lane >> 3) & 1) + ((lane >> 2) & 1);
