@@ -738,6 +738,86 @@ __device__ __forceinline__ double div_rn(const double a, const double b, const d
     const double e = __builtin_fma(-q, b, a);
     return __builtin_fma(e, rb, q);
 }
+// The evaluations' own fp64 quotients (1 / rho, 1 / z, k / |r|, 1 / q_rho): the compiler's division is v_div_scale x 2, v_rcp_f64, two
+// Newton steps, quotient, remainder, v_div_fmas, v_div_fixup — 11 instructions and the vcc traffic of the scaling.  The two v_div_scale and
+// v_div_fmas only move operands whose exponents sit near the ends of the range (|exponent| beyond ~ 900) back to the middle; for every other
+// pair they are the identity, and what remains is the same chain of fma's on the same values: the same bits.  No operand here comes near
+// those ends (inverse depths, camera-frame depths, residuals in pixels, q_rho >= 1), so the scaling is dropped; v_div_fixup stays for the
+// zeros, infinities and NaNs (a KeyLine exactly on the camera plane still gets its IEEE infinity).
+#ifndef EDGEHIP_TVR_FASTDIV
+#define EDGEHIP_TVR_FASTDIV 1
+#endif
+// 1 / b as the division sequence has it before its last correction (v_rcp_f64 and two Newton steps): what div_rn takes as `rb`
+__device__ __forceinline__ double rcp_nr(const double b) {
+    double r = __builtin_amdgcn_rcp(b);
+    double e = __builtin_fma(-b, r, 1.0);
+    r = __builtin_fma(r, e, r);
+    e = __builtin_fma(-b, r, 1.0);
+    return __builtin_fma(r, e, r);
+}
+__device__ __forceinline__ double div_mid(const double a, const double b) {   // a / b, operands in the middle of the exponent range
+#if EDGEHIP_TVR_FASTDIV
+    const double r = rcp_nr(b);
+    const double q = a * r;
+    const double e = __builtin_fma(-b, q, a);
+    return __builtin_amdgcn_div_fixup(__builtin_fma(e, r, q), b, a);
+#else
+    return a / b;
+#endif
+}
+__device__ __forceinline__ double inv_mid(const double b) {   // 1 / b, likewise (the quotient estimate 1 * r is r itself)
+#if EDGEHIP_TVR_FASTDIV
+    const double r = rcp_nr(b);
+    const double e = __builtin_fma(-b, r, 1.0);
+    return __builtin_amdgcn_div_fixup(__builtin_fma(e, r, r), b, 1.0);
+#else
+    return 1.0 / b;
+#endif
+}
+// sqrt(x) for x >= 1 (q_rho^2 = (s_rho qvel)^2 + 1): the compiler's own sequence (v_rsq_f64, one coupled Newton step on the root and its
+// half reciprocal, two corrections from the exact remainder) without what it wraps around it for arguments below 2^-767 (a compare, two
+// selects, two v_ldexp_f64 by 0 here) — same values through the same fma's; +inf is the one special value left above 1.
+__device__ __forceinline__ double sqrt_ge1(const double x) {
+#if EDGEHIP_TVR_FASTDIV
+    const double y = __builtin_amdgcn_rsq(x);
+    double g = x * y, h = y * 0.5;
+    const double r = __builtin_fma(-h, g, 0.5);
+    g = __builtin_fma(g, r, g);
+    h = __builtin_fma(h, r, h);
+    double d = __builtin_fma(-g, g, x);
+    g = __builtin_fma(d, h, g);
+    d = __builtin_fma(-g, g, x);
+    g = __builtin_fma(d, h, g);
+    return __builtin_isinf(x) ? x : g;
+#else
+    return sqrt(x);
+#endif
+}
+// The matched KeyLine's unit gradient u_m = m_m / |m_m| (float, as the detector computes it): two float quotients by the same divisor.
+// The compiler's float division is the double one's shape (v_div_scale x 2, v_rcp_f32, one Newton step, quotient, two corrections,
+// v_div_fmas, v_div_fixup); the divisor's part — the reciprocal and its Newton step — is shared here and the scaling dropped as above
+// (|m_m| is a gradient modulus that passed the detector's threshold: the middle of the range).
+__device__ __forceinline__ void div2_mid_f32(const float n0, const float n1, const float d, float &q0, float &q1) {
+#if EDGEHIP_TVR_FASTDIV
+    float r = __builtin_amdgcn_rcpf(d);
+    r = __builtin_fmaf(__builtin_fmaf(-d, r, 1.f), r, r);
+    float q = n0 * r;
+    q = __builtin_fmaf(__builtin_fmaf(-d, q, n0), r, q);
+    q0 = __builtin_amdgcn_div_fixupf(__builtin_fmaf(__builtin_fmaf(-d, q, n0), r, q), d, n0);
+    q = n1 * r;
+    q = __builtin_fmaf(__builtin_fmaf(-d, q, n1), r, q);
+    q1 = __builtin_amdgcn_div_fixupf(__builtin_fmaf(__builtin_fmaf(-d, q, n1), r, q), d, n1);
+#else
+    q0 = n0 / d; q1 = n1 / d;
+#endif
+}
+__device__ __forceinline__ double rcp_for_div_rn(const double b) {   // div_rn's `rb`: the sequence's own reciprocal is enough (and is what a / b uses)
+#if EDGEHIP_TVR_FASTDIV
+    return rcp_nr(b);
+#else
+    return 1.0 / b;
+#endif
+}
 #ifndef EDGEHIP_TVR_ABL
 #define EDGEHIP_TVR_ABL 0   // timing experiments only (tools/experiments/exp_tvr_ablate.sh): 1 no cross-lane reduction, 2 no div/sqrt,
 #endif                      // 4 no matched-KeyLine gather, 8 no field gather, 16 no residual stream
@@ -809,7 +889,7 @@ __device__ __forceinline__ void tvr_body(const TvrArgs &a, const int seq, const 
             if (!skip) {
                 // KltoI3PMatrix + ProyI3Pto3PMatrix (global_tracker.cpp:553-570, ne10wrapper.h:414-424): P0 = (x z / zf, y z / zf, z),
                 // z = 1 / rho — from p_m and rho (16 B) instead of a stored P0 (24 B): one fp64 division for a third less traffic
-                const double sz = 1 / rho0;
+                const double sz = inv_mid(rho0);
                 const double pz_zf0 = a.inv_zfm * sz;
                 const double sx = pz_zf0 * (double)pm0.x, sy = pz_zf0 * (double)pm0.y;
                 const double *R = sq->Rt, *V = sq->Vt;
@@ -818,7 +898,7 @@ __device__ __forceinline__ void tvr_body(const TvrArgs &a, const int seq, const 
                 pty = R[3] * sx; pty += R[4] * sy; pty += R[5] * sz; pty = V[1] + pty;
                 ptz = R[6] * sx; ptz += R[7] * sy; ptz += R[8] * sz; ptz = V[2] + ptz;
                 // Ne10::ProyP3toI3PMatrix
-                rho_p = 1 / ptz;
+                rho_p = inv_mid(ptz);
                 const double pz_zf = a.zfm * rho_p;
                 pix = pz_zf * ptx;
                 piy = pz_zf * pty;
@@ -834,7 +914,7 @@ __device__ __forceinline__ void tvr_body(const TvrArgs &a, const int seq, const 
                 if (REWEIGHT) {
                     if (is_carry(rprev)) rprev = carry_in_prev;
 #if EDGEHIP_TVR_REF_ORDER
-                    if (fabs(rprev) > a.k_huber) wgt_ref = a.k_huber / fabs(rprev);
+                    if (fabs(rprev) > a.k_huber) wgt_ref = div_mid(a.k_huber, fabs(rprev));
 #else
                     if (fabs(rprev) > a.k_huber && !(ABL & 2)) { const double rk = fabs(rprev) * a.inv_k_huber; inv_w2 = rk * rk; }
 #endif
@@ -893,7 +973,7 @@ __device__ __forceinline__ void tvr_body(const TvrArgs &a, const int seq, const 
                             if (GREC) {
                                 const float n2m = f_mx * f_mx + f_my * f_my;
                                 const float nm = sqrtf(n2m);
-                                f_ux = f_mx / nm; f_uy = f_my / nm;
+                                div2_mid_f32(f_mx, f_my, nm, f_ux, f_uy);
                             }
                             const double dx = px - (double)f_cpx, dy = py - (double)f_cpy;
                             fi = dx * (double)f_ux + dy * (double)f_uy;
@@ -967,8 +1047,8 @@ __device__ __forceinline__ void tvr_body(const TvrArgs &a, const int seq, const 
             const double qvel = (a.zfm * dfx * sq->Vt[0] + a.zfm * dfy * sq->Vt[1] + (pix * dfx + piy * dfy) * sq->Vt[2]);
             // the reference divides the seven values by q_rho one by one (EDGEHIP_TVR_REF_ORDER above; with 0 qvel is the unweighted one)
 #if EDGEHIP_TVR_REF_ORDER
-            const double q_rho = REWEIGHT ? sqrt(s_rho * qvel * s_rho * qvel + 1) : s_rho;
-            const double r_q = 1.0 / q_rho;
+            const double q_rho = REWEIGHT ? sqrt_ge1(s_rho * qvel * s_rho * qvel + 1) : s_rho;
+            const double r_q = rcp_for_div_rn(q_rho);
             if (PROCJF) {
 #pragma unroll
                 for (int j = 0; j < 6; j++) J[j] = div_rn(J[j], q_rho, r_q);
@@ -1351,7 +1431,7 @@ __device__ __forceinline__ void tvr2_body(const TvrArgs &a, const int seq, const
         const uint32_t mthr = a.match_num_thresh < fc ? a.match_num_thresh : fc;
         const bool skip = s_rho > sq->s_rho_min_eval || (uint32_t)mnum < mthr;  // int vs uint compare
         if (!skip) {
-            const double sz = 1 / rho0;
+            const double sz = inv_mid(rho0);
             const double pz_zf0 = a.inv_zfm * sz;
             const double sx = pz_zf0 * (double)pm0.x, sy = pz_zf0 * (double)pm0.y;
             double px[2], py[2];
@@ -1364,7 +1444,7 @@ __device__ __forceinline__ void tvr2_body(const TvrArgs &a, const int seq, const
                 ptx[c] = R[0] * sx; ptx[c] += R[1] * sy; ptx[c] += R[2] * sz; ptx[c] = V[0] + ptx[c];
                 pty[c] = R[3] * sx; pty[c] += R[4] * sy; pty[c] += R[5] * sz; pty[c] = V[1] + pty[c];
                 ptz[c] = R[6] * sx; ptz[c] += R[7] * sy; ptz[c] += R[8] * sz; ptz[c] = V[2] + ptz[c];
-                rho_p[c] = 1 / ptz[c];
+                rho_p[c] = inv_mid(ptz[c]);
                 const double pz_zf = a.zfm * rho_p[c];
                 pix[c] = pz_zf * ptx[c];
                 piy[c] = pz_zf * pty[c];
@@ -1404,7 +1484,7 @@ __device__ __forceinline__ void tvr2_body(const TvrArgs &a, const int seq, const
                         if (GREC) {
                             const float n2m = f_mx[c] * f_mx[c] + f_my[c] * f_my[c];
                             const float nm = sqrtf(n2m);
-                            f_ux[c] = f_mx[c] / nm; f_uy[c] = f_my[c] / nm;
+                            div2_mid_f32(f_mx[c], f_my[c], nm, f_ux[c], f_uy[c]);
                         }
                         const double dx = px[c] - (double)f_cpx[c], dy = py[c] - (double)f_cpy[c];
                         fi[c] = dx * (double)f_ux[c] + dy * (double)f_uy[c];
@@ -1471,7 +1551,7 @@ __device__ __forceinline__ void tvr2_body(const TvrArgs &a, const int seq, const
 #if EDGEHIP_TVR2_PARK
     __shared__ double s_park[PROCJF ? 7 : 1][kTvrThreads];
 #endif
-    const double inv_q = 1.0 / s_rho;
+    const double inv_q = rcp_for_div_rn(s_rho);
     double Jc[2][6], fmc[2];
 #pragma unroll
     for (int c = 0; c < 2; c++) {
