@@ -129,6 +129,15 @@ __device__ __forceinline__ int x86_cvttsd2si(double f) {
     return (int)f;
 }
 
+// The same conversion where its result only feeds an in-image test (1 <= x < w - 1): the bare v_cvt_i32_f64, which saturates (INT_MAX /
+// INT_MIN, 0 for a NaN) where cvttsd2si answers INT_MIN — every one of those values fails the test exactly as INT_MIN does, so the
+// range check in front of the conversion (two fp64 compares and a select per coordinate) buys nothing there.
+__device__ __forceinline__ int cvt_trunc_sat_i32(double f) {
+    int r;
+    asm("v_cvt_i32_f64 %0, %1" : "=v"(r) : "v"(f));
+    return r;
+}
+
 // round() as Image::GetIndexRC uses it (half away from zero) for pixel coordinates, in 3 instructions.
 // v_cvt_rpi_i32_f32 converts with "round to nearest, ties towards +infinity", evaluated exactly (not as a float
 // addition of 0.5): for v >= 0 that IS half-away-from-zero; for v < 0 the two differ only on exact ties, where both
