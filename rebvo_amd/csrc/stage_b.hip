@@ -1199,15 +1199,16 @@ __device__ __forceinline__ void tvr_body_f32(const TvrArgs &a, const int seq, co
 
     const int ikl = blk * kTvrBlock + tid;
     float J[6] = {0, 0, 0, 0, 0, 0};
-    float fm = 0, dfx = 0, dfy = 0;
-    float ptx = 0, pty = 0, ptz = 1, pix = 0, piy = 0, rho_p = 1;
-    double s_rho = 1;
-    float wgt = 1;
+    // (no defaults for what only an evaluated KeyLine — status != 0 — reads in the Jacobian section: see tvr_body)
+    float fm, dfx, dfy;
+    float ptx, pty, ptz, pix, piy, rho_p;
+    double s_rho;
+    float wgt;
     int mid_f = -1, status = 0;
     float fi = 0;
-    double rho_own = 0;
+    double rho_own;
     const float zf = (float)a.zfm, max_r = (float)a.max_r, k_huber = (float)a.k_huber, simil_t = (float)a.match_thresh;
-    float Vt0 = 0, Vt1 = 0, Vt2 = 0;
+    float Vt0, Vt1, Vt2;
     if (ikl < kn) {
         s_rho = ldg(ko.s_rho, ikl);
         const int32_t mnum = ldg(ko.m_num, ikl);
@@ -1237,23 +1238,23 @@ __device__ __forceinline__ void tvr_body_f32(const TvrArgs &a, const int seq, co
             pix = pz_zf * ptx;
             piy = pz_zf * pty;
             const float px = pix + a.ppx, py = piy + a.ppy;
-            const int x = x86_cvttsd2si((double)px + 0.5), y = x86_cvttsd2si((double)py + 0.5);
+            const int x = cvt_trunc_sat_i32((double)px + 0.5), y = cvt_trunc_sat_i32((double)py + 0.5);   // (read by the in-image test only)
+            dfx = 0; dfy = 0; wgt = 1;
             if (REWEIGHT) {
                 if (is_carry(rprev_d)) rprev_d = carry_in_prev;
                 const float rprev = (float)rprev_d;
                 if (fabsf(rprev) > k_huber) wgt = k_huber / fabsf(rprev);
             }
+            fm = max_r;
             if (x < 1 || y < 1 || x >= a.w - 1 || y >= a.h - 1) {
-                fm = max_r;
                 status = 1;
             } else {
                 status = 3;
-                fm = max_r;
                 const float rmx = (float)sq->RM[0] * klm.x + (float)sq->RM[1] * klm.y;   // Matrix<2,2,float> RM (global_tracker.cpp:318, 386-388)
                 const float rmy = (float)sq->RM[2] * klm.x + (float)sq->RM[3] * klm.y;
                 const uint32_t f = a.field16[(size_t)seq * a.f16stride + field16_index(x, y, a.f16tx)];
-                if (f != 0u) {
-                    const int ikf = (int)f - 1;
+                {
+                    const int ikf = f != 0u ? (int)f - 1 : 0;   // (an empty entry reads record 0 and fails by `f != 0` below: tvr_body)
                     float f_cpx, f_cpy, f_mx, f_my, f_ux, f_uy;
                     if (GREC) {
                         const float4 g = ldg(a.kl_new[seq].grec, ikf);
@@ -1264,11 +1265,11 @@ __device__ __forceinline__ void tvr_body_f32(const TvrArgs &a, const int seq, co
                     }
                     const float p_n2 = knm * knm;                      // Test_f_k<float> (global_tracker.h:90-104)
                     const float p_esc = rmx * f_mx + rmy * f_my;
-                    if (!(fabsf(p_esc - p_n2) > simil_t * p_n2)) {
+                    if ((f != 0u) & !(fabsf(p_esc - p_n2) > simil_t * p_n2)) {
                         if (GREC) {
                             const float n2m = f_mx * f_mx + f_my * f_my;
                             const float nm = sqrtf(n2m);
-                            f_ux = f_mx / nm; f_uy = f_my / nm;
+                            div2_mid_f32(f_mx, f_my, nm, f_ux, f_uy);
                         }
                         const float dx = px - f_cpx, dy = py - f_cpy;    // Calc_f_J2<float> (global_tracker.cpp:228-271)
                         fi = dx * f_ux + dy * f_uy;
@@ -1315,7 +1316,8 @@ __device__ __forceinline__ void tvr_body_f32(const TvrArgs &a, const int seq, co
         if (a.fwd_key && mid_f >= 0) atomicMax(&a.fwd_key[(size_t)seq * a.cap + mid_f], ord_bits(rho_own));
     }
     // ---- Jacobian row, uncertainty scaling (global_tracker.cpp:399-463 with T = float) ----
-    if (ikl < kn) {
+    float fs = 0.f;   // the scaled residual (zero, like J, for a KeyLine that was not evaluated)
+    if (status != 0) {
         if (REWEIGHT) { fm *= wgt; dfx *= wgt; dfy *= wgt; }
         if (PROCJF) {
             float t0 = zf * rho_p;
@@ -1332,13 +1334,13 @@ __device__ __forceinline__ void tvr_body_f32(const TvrArgs &a, const int seq, co
         }
         // qvel: a float expression (zfm, the derivatives, PtIm and Vt are floats) assigned to a double (:452-453); q_rho in double
         const double qvel = (double)(zf * dfx * Vt0 + zf * dfy * Vt1 + (pix * dfx + piy * dfy) * Vt2);
-        const double q_rho = REWEIGHT ? sqrt(s_rho * qvel * s_rho * qvel + 1) : s_rho;
-        const double r_q = 1.0 / q_rho;
+        const double q_rho = REWEIGHT ? sqrt_ge1(s_rho * qvel * s_rho * qvel + 1) : s_rho;
+        const double r_q = rcp_for_div_rn(q_rho);
         if (PROCJF) {
 #pragma unroll
             for (int j = 0; j < 6; j++) J[j] = (float)div_rn((double)J[j], q_rho, r_q);   // float /= double: the quotient in double, rounded to float
         }
-        fm = (float)div_rn((double)fm, q_rho, r_q);
+        fs = (float)div_rn((double)fm, q_rho, r_q);
     }
     {
         int ns = 0;
@@ -1348,9 +1350,9 @@ __device__ __forceinline__ void tvr_body_f32(const TvrArgs &a, const int seq, co
 #pragma unroll
                 for (int j = i; j < 6; j++) sums[ns++] = J[i] * J[j];
 #pragma unroll
-            for (int i = 0; i < 6; i++) sums[ns++] = J[i] * fm;
+            for (int i = 0; i < 6; i++) sums[ns++] = J[i] * fs;
         }
-        sums[PROCJF ? ns : kNumSums - 1] = fm * fm;
+        sums[PROCJF ? ns : kNumSums - 1] = fs * fs;
     }
     if (tid == 0) {
         double bl = marker;
@@ -1477,10 +1479,10 @@ __device__ __forceinline__ void tvr2_body(const TvrArgs &a, const int seq, const
             const double p_n2 = (double)(knm * knm);
 #pragma unroll
             for (int c = 0; c < 2; c++) {
-                if (c ? hit1 : hit0) {
-                    // Test_f_k (float arithmetic inside, compared in double)
+                {
+                    // Test_f_k (float arithmetic inside, compared in double); `&`: one level of the nest for the hit and the test (tvr_body)
                     const double p_esc = (double)(rmx[c] * f_mx[c] + rmy[c] * f_my[c]);
-                    if (!(fabs(p_esc - p_n2) > a.match_thresh * p_n2)) {
+                    if ((c ? hit1 : hit0) & !(fabs(p_esc - p_n2) > a.match_thresh * p_n2)) {
                         if (GREC) {
                             const float n2m = f_mx[c] * f_mx[c] + f_my[c] * f_my[c];
                             const float nm = sqrtf(n2m);
@@ -1662,6 +1664,7 @@ __device__ __forceinline__ void tvr2_body_f32(const TvrArgs &a, const int seq, c
     const float zf = (float)a.zfm, max_r = (float)a.max_r, simil_t = (float)a.match_thresh;
 
     const int ikl = blk * kTvrBlock + tid;
+    // (tvr_body's "no defaults / status != 0" form measured 2 % SLOWER here, 774 -> 791 us per step, profiles/r06_tvr_mid_range_quotients_ab.txt: kept as it was)
     float fm[2] = {0, 0}, dfx[2] = {0, 0}, dfy[2] = {0, 0}, fi[2] = {0, 0};
     float ptx[2] = {0, 0}, pty[2] = {0, 0}, ptz[2] = {1, 1}, pix[2] = {0, 0}, piy[2] = {0, 0}, rho_p[2] = {1, 1};
     int status[2] = {0, 0};
@@ -1726,7 +1729,7 @@ __device__ __forceinline__ void tvr2_body_f32(const TvrArgs &a, const int seq, c
                         if (GREC) {
                             const float n2m = f_mx[c] * f_mx[c] + f_my[c] * f_my[c];
                             const float nm = sqrtf(n2m);
-                            f_ux[c] = f_mx[c] / nm; f_uy[c] = f_my[c] / nm;
+                            div2_mid_f32(f_mx[c], f_my[c], nm, f_ux[c], f_uy[c]);
                         }
                         const float dx = px[c] - f_cpx[c], dy = py[c] - f_cpy[c];
                         fi[c] = dx * f_ux[c] + dy * f_uy[c];
