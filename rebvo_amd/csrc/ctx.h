@@ -138,6 +138,56 @@ __device__ __forceinline__ int cvt_trunc_sat_i32(double f) {
     return r;
 }
 
+// fp64 quotients whose operands sit in the middle of the exponent range (the evaluations' 1 / rho, 1 / z, k / |r|, 1 / q_rho in stage_b.hip; the plane
+// fit's sub-pixel offsets in stage_a_fused.hip): the compiler's division is v_div_scale x 2, v_rcp_f64, two
+// Newton steps, quotient, remainder, v_div_fmas, v_div_fixup — 11 instructions and the vcc traffic of the scaling.  The two v_div_scale and
+// v_div_fmas only move operands whose exponents sit near the ends of the range (|exponent| beyond ~ 900) back to the middle; for every other
+// pair they are the identity, and what remains is the same chain of fma's on the same values: the same bits.  No operand here comes near
+// those ends (inverse depths, camera-frame depths, residuals in pixels, q_rho >= 1), so the scaling is dropped; v_div_fixup stays for the
+// zeros, infinities and NaNs (a KeyLine exactly on the camera plane still gets its IEEE infinity).
+#ifndef EDGEHIP_FASTDIV
+#define EDGEHIP_FASTDIV 1
+#endif
+// 1 / b as the division sequence has it before its last correction (v_rcp_f64 and two Newton steps): what div_rn takes as `rb`
+__device__ __forceinline__ double rcp_nr(const double b) {
+    double r = __builtin_amdgcn_rcp(b);
+    double e = __builtin_fma(-b, r, 1.0);
+    r = __builtin_fma(r, e, r);
+    e = __builtin_fma(-b, r, 1.0);
+    return __builtin_fma(r, e, r);
+}
+__device__ __forceinline__ double div_mid(const double a, const double b) {   // a / b, operands in the middle of the exponent range
+#if EDGEHIP_FASTDIV
+    const double r = rcp_nr(b);
+    const double q = a * r;
+    const double e = __builtin_fma(-b, q, a);
+    return __builtin_amdgcn_div_fixup(__builtin_fma(e, r, q), b, a);
+#else
+    return a / b;
+#endif
+}
+// two quotients by the same divisor: its reciprocal and Newton steps once (the plane fit's xs, ys = -t0 t2 / den, -t1 t2 / den)
+__device__ __forceinline__ void div2_mid(const double a0, const double a1, const double b, double &q0, double &q1) {
+#if EDGEHIP_FASTDIV
+    const double r = rcp_nr(b);
+    double q = a0 * r;
+    q0 = __builtin_amdgcn_div_fixup(__builtin_fma(__builtin_fma(-b, q, a0), r, q), b, a0);
+    q = a1 * r;
+    q1 = __builtin_amdgcn_div_fixup(__builtin_fma(__builtin_fma(-b, q, a1), r, q), b, a1);
+#else
+    q0 = a0 / b; q1 = a1 / b;
+#endif
+}
+__device__ __forceinline__ double inv_mid(const double b) {   // 1 / b, likewise (the quotient estimate 1 * r is r itself)
+#if EDGEHIP_FASTDIV
+    const double r = rcp_nr(b);
+    const double e = __builtin_fma(-b, r, 1.0);
+    return __builtin_amdgcn_div_fixup(__builtin_fma(e, r, r), b, 1.0);
+#else
+    return 1.0 / b;
+#endif
+}
+
 // round() as Image::GetIndexRC uses it (half away from zero) for pixel coordinates, in 3 instructions.
 // v_cvt_rpi_i32_f32 converts with "round to nearest, ties towards +infinity", evaluated exactly (not as a float
 // addition of 0.5): for v >= 0 that IS half-away-from-zero; for v < 0 the two differ only on exact ties, where both

@@ -738,47 +738,12 @@ __device__ __forceinline__ double div_rn(const double a, const double b, const d
     const double e = __builtin_fma(-q, b, a);
     return __builtin_fma(e, rb, q);
 }
-// The evaluations' own fp64 quotients (1 / rho, 1 / z, k / |r|, 1 / q_rho): the compiler's division is v_div_scale x 2, v_rcp_f64, two
-// Newton steps, quotient, remainder, v_div_fmas, v_div_fixup — 11 instructions and the vcc traffic of the scaling.  The two v_div_scale and
-// v_div_fmas only move operands whose exponents sit near the ends of the range (|exponent| beyond ~ 900) back to the middle; for every other
-// pair they are the identity, and what remains is the same chain of fma's on the same values: the same bits.  No operand here comes near
-// those ends (inverse depths, camera-frame depths, residuals in pixels, q_rho >= 1), so the scaling is dropped; v_div_fixup stays for the
-// zeros, infinities and NaNs (a KeyLine exactly on the camera plane still gets its IEEE infinity).
-#ifndef EDGEHIP_TVR_FASTDIV
-#define EDGEHIP_TVR_FASTDIV 1
-#endif
-// 1 / b as the division sequence has it before its last correction (v_rcp_f64 and two Newton steps): what div_rn takes as `rb`
-__device__ __forceinline__ double rcp_nr(const double b) {
-    double r = __builtin_amdgcn_rcp(b);
-    double e = __builtin_fma(-b, r, 1.0);
-    r = __builtin_fma(r, e, r);
-    e = __builtin_fma(-b, r, 1.0);
-    return __builtin_fma(r, e, r);
-}
-__device__ __forceinline__ double div_mid(const double a, const double b) {   // a / b, operands in the middle of the exponent range
-#if EDGEHIP_TVR_FASTDIV
-    const double r = rcp_nr(b);
-    const double q = a * r;
-    const double e = __builtin_fma(-b, q, a);
-    return __builtin_amdgcn_div_fixup(__builtin_fma(e, r, q), b, a);
-#else
-    return a / b;
-#endif
-}
-__device__ __forceinline__ double inv_mid(const double b) {   // 1 / b, likewise (the quotient estimate 1 * r is r itself)
-#if EDGEHIP_TVR_FASTDIV
-    const double r = rcp_nr(b);
-    const double e = __builtin_fma(-b, r, 1.0);
-    return __builtin_amdgcn_div_fixup(__builtin_fma(e, r, r), b, 1.0);
-#else
-    return 1.0 / b;
-#endif
-}
+// (div_mid / inv_mid / rcp_nr — the division sequence without its exponent scaling — are in ctx.h: the one-kernel stage A's plane fit uses them too)
 // sqrt(x) for x >= 1 (q_rho^2 = (s_rho qvel)^2 + 1): the compiler's own sequence (v_rsq_f64, one coupled Newton step on the root and its
 // half reciprocal, two corrections from the exact remainder) without what it wraps around it for arguments below 2^-767 (a compare, two
 // selects, two v_ldexp_f64 by 0 here) — same values through the same fma's; +inf is the one special value left above 1.
 __device__ __forceinline__ double sqrt_ge1(const double x) {
-#if EDGEHIP_TVR_FASTDIV
+#if EDGEHIP_FASTDIV
     const double y = __builtin_amdgcn_rsq(x);
     double g = x * y, h = y * 0.5;
     const double r = __builtin_fma(-h, g, 0.5);
@@ -798,7 +763,7 @@ __device__ __forceinline__ double sqrt_ge1(const double x) {
 // v_div_fmas, v_div_fixup); the divisor's part — the reciprocal and its Newton step — is shared here and the scaling dropped as above
 // (|m_m| is a gradient modulus that passed the detector's threshold: the middle of the range).
 __device__ __forceinline__ void div2_mid_f32(const float n0, const float n1, const float d, float &q0, float &q1) {
-#if EDGEHIP_TVR_FASTDIV
+#if EDGEHIP_FASTDIV
     float r = __builtin_amdgcn_rcpf(d);
     r = __builtin_fmaf(__builtin_fmaf(-d, r, 1.f), r, r);
     float q = n0 * r;
@@ -812,7 +777,7 @@ __device__ __forceinline__ void div2_mid_f32(const float n0, const float n1, con
 #endif
 }
 __device__ __forceinline__ double rcp_for_div_rn(const double b) {   // div_rn's `rb`: the sequence's own reciprocal is enough (and is what a / b uses)
-#if EDGEHIP_TVR_FASTDIV
+#if EDGEHIP_FASTDIV
     return rcp_nr(b);
 #else
     return 1.0 / b;
