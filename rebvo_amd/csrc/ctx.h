@@ -178,6 +178,19 @@ __device__ __forceinline__ void div2_mid(const double a0, const double a1, const
     q0 = a0 / b; q1 = a1 / b;
 #endif
 }
+// several quotients by one divisor: MidDivisor d(b); d(a0), d(a1), ... — each is a / b to the bit (operands in the middle of the range)
+struct MidDivisor {
+    double b, r;
+    __device__ __forceinline__ explicit MidDivisor(const double b_) : b(b_), r(EDGEHIP_FASTDIV ? rcp_nr(b_) : 0.0) {}
+    __device__ __forceinline__ double operator()(const double a) const {
+#if EDGEHIP_FASTDIV
+        const double q = a * r;
+        return __builtin_amdgcn_div_fixup(__builtin_fma(__builtin_fma(-b, q, a), r, q), b, a);
+#else
+        return a / b;
+#endif
+    }
+};
 __device__ __forceinline__ double inv_mid(const double b) {   // 1 / b, likewise (the quotient estimate 1 * r is r itself)
 #if EDGEHIP_FASTDIV
     const double r = rcp_nr(b);

@@ -472,9 +472,12 @@ __device__ __forceinline__ void directed_body(const DirArgs &a) {
             d += s_br[i * 3 + 2] * zf;
             p3[i] = d;
         }
-        const float pmx = (float)(p3[0] * zf / p3[2]);
-        const float pmy = (float)(p3[1] * zf / p3[2]);
-        const double k_rho = krho * zf / p3[2];
+        // (three quotients by p3[2] — a depth in units of the focal length, ~ zf — and two by norm_t below: the divisor's reciprocal once each,
+        // MidDivisor in ctx.h: the division sequence itself without its exponent scaling, the same bits)
+        const MidDivisor by_z(p3[2]);
+        const float pmx = (float)by_z(p3[0] * zf);
+        const float pmy = (float)by_z(p3[1] * zf);
+        const double k_rho = by_z(krho * zf);
         const float pi0x = pmx + a.ppx, pi0y = pmy + a.ppy;
         double t_x = -(s_v[0] * zf - s_v[2] * (double)pmx);
         double t_y = -(s_v[1] * zf - s_v[2] * (double)pmy);
@@ -492,8 +495,9 @@ __device__ __forceinline__ void directed_body(const DirArgs &a) {
         double dq_min, dq_max, dq_rho;
         int t_steps;
         if (norm_t > 1e-6) {
-            t_x /= norm_t;
-            t_y /= norm_t;
+            const MidDivisor by_n(norm_t);
+            t_x = by_n(t_x);
+            t_y = by_n(t_y);
             dq_rho = norm_t * k_rho;
             dq_min = fmax(0.0, norm_t * (k_rho - ksrho)) - a.loc_unc;
             dq_max = fmin(a.max_radius, norm_t * (k_rho + ksrho)) + a.loc_unc;
@@ -507,8 +511,9 @@ __device__ __forceinline__ void directed_body(const DirArgs &a) {
             t_x = (double)kmm.x;
             t_y = (double)kmm.y;
             norm_t = (double)knm;
-            t_x /= norm_t;
-            t_y /= norm_t;
+            const MidDivisor by_n(norm_t);
+            t_x = by_n(t_x);
+            t_y = by_n(t_y);
             norm_t = 1;
             dq_min = -a.max_radius - a.loc_unc;
             dq_max = a.max_radius + a.loc_unc;
@@ -584,7 +589,7 @@ __device__ __forceinline__ void directed_body(const DirArgs &a) {
                     // rotate_keylines no longer has to rewrite a record per KeyLine
                     const float2 omm = FUSED ? ldg(a.rot.m_m, ro + j) : ldg(ko.m_m, j);
                     const double norm_m0 = (double)ldg(ko.n_m, j);
-                    const double cang = (double)(omm.x * kmm.x + omm.y * kmm.y) / (norm_m0 * norm_m);
+                    const double cang = div_mid((double)(omm.x * kmm.x + omm.y * kmm.y), norm_m0 * norm_m);
                     if (cang < a.cang_min_edge || fabs(norm_m0 / norm_m - 1) > a.min_thr_mod) continue;
                     const double s_rho = FUSED ? ldg(a.rot.s_rho, ro + j) : ldg(ko.s_rho, j), rho = FUSED ? ldg(a.rot.rho, ro + j) : ldg(ko.rho, j);
                     const double v_rho_dr = (a.loc_unc * a.loc_unc + s_rho * s_rho * norm_t * norm_t + sigma2_t * rho * rho);
