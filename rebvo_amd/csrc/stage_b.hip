@@ -758,6 +758,22 @@ __device__ __forceinline__ double sqrt_ge1(const double x) {
     return sqrt(x);
 #endif
 }
+// sqrtf(x) for a float in the middle of the range (|m_m|^2 of a KeyLine that passed the detector's threshold): the compiler's sequence — v_sqrt_f32
+// (1 ulp), then the neighbour below / above if the exact remainder says so — without the scaling it wraps around it for x < 2^-96 and without the
+// class test behind it (zero and +inf come out of the sequence as themselves: the remainders are NaN or -0 there and select nothing).
+__device__ __forceinline__ float sqrtf_mid(const float x) {
+#if EDGEHIP_FASTDIV
+    const float s = __builtin_amdgcn_sqrtf(x);
+    const float s_dn = __int_as_float(__float_as_int(s) - 1), s_up = __int_as_float(__float_as_int(s) + 1);
+    const float r_dn = __builtin_fmaf(-s_dn, s, x);
+    const float r_up = __builtin_fmaf(-s_up, s, x);
+    float r = r_dn <= 0.f ? s_dn : s;
+    r = r_up > 0.f ? s_up : r;
+    return r;
+#else
+    return sqrtf(x);
+#endif
+}
 // The matched KeyLine's unit gradient u_m = m_m / |m_m| (float, as the detector computes it): two float quotients by the same divisor.
 // The compiler's float division is the double one's shape (v_div_scale x 2, v_rcp_f32, one Newton step, quotient, two corrections,
 // v_div_fmas, v_div_fixup); the divisor's part — the reciprocal and its Newton step — is shared here and the scaling dropped as above
@@ -937,7 +953,7 @@ __device__ __forceinline__ void tvr_body(const TvrArgs &a, const int seq, const 
                         if ((f != 0u) & !(fabs(p_esc - p_n2) > a.match_thresh * p_n2)) {   // (`&`: one level, the record's load is not conditional)
                             if (GREC) {
                                 const float n2m = f_mx * f_mx + f_my * f_my;
-                                const float nm = sqrtf(n2m);
+                                const float nm = sqrtf_mid(n2m);
                                 div2_mid_f32(f_mx, f_my, nm, f_ux, f_uy);
                             }
                             const double dx = px - (double)f_cpx, dy = py - (double)f_cpy;
@@ -986,7 +1002,7 @@ __device__ __forceinline__ void tvr_body(const TvrArgs &a, const int seq, const 
             }
         }
         if (a.write_mid && ikl < kn) {
-            ko.m_id_f[ikl] = mid_f;
+            stg(ko.m_id_f, ikl, mid_f);   // (a global store: the FLAT one also counts on the LDS counter, ctx.h)
             if (!KF && a.fwd_key && mid_f >= 0) atomicMax(&a.fwd_key[(size_t)seq * a.cap + mid_f], ord_bits(rho_own));
         }
 
@@ -1233,7 +1249,7 @@ __device__ __forceinline__ void tvr_body_f32(const TvrArgs &a, const int seq, co
                     if ((f != 0u) & !(fabsf(p_esc - p_n2) > simil_t * p_n2)) {
                         if (GREC) {
                             const float n2m = f_mx * f_mx + f_my * f_my;
-                            const float nm = sqrtf(n2m);
+                            const float nm = sqrtf_mid(n2m);
                             div2_mid_f32(f_mx, f_my, nm, f_ux, f_uy);
                         }
                         const float dx = px - f_cpx, dy = py - f_cpy;    // Calc_f_J2<float> (global_tracker.cpp:228-271)
@@ -1277,7 +1293,7 @@ __device__ __forceinline__ void tvr_body_f32(const TvrArgs &a, const int seq, co
         }
     }
     if (a.write_mid && ikl < kn) {
-        ko.m_id_f[ikl] = mid_f;
+        stg(ko.m_id_f, ikl, mid_f);
         if (a.fwd_key && mid_f >= 0) atomicMax(&a.fwd_key[(size_t)seq * a.cap + mid_f], ord_bits(rho_own));
     }
     // ---- Jacobian row, uncertainty scaling (global_tracker.cpp:399-463 with T = float) ----
@@ -1450,7 +1466,7 @@ __device__ __forceinline__ void tvr2_body(const TvrArgs &a, const int seq, const
                     if ((c ? hit1 : hit0) & !(fabs(p_esc - p_n2) > a.match_thresh * p_n2)) {
                         if (GREC) {
                             const float n2m = f_mx[c] * f_mx[c] + f_my[c] * f_my[c];
-                            const float nm = sqrtf(n2m);
+                            const float nm = sqrtf_mid(n2m);
                             div2_mid_f32(f_mx[c], f_my[c], nm, f_ux[c], f_uy[c]);
                         }
                         const double dx = px[c] - (double)f_cpx[c], dy = py[c] - (double)f_cpy[c];
@@ -1693,7 +1709,7 @@ __device__ __forceinline__ void tvr2_body_f32(const TvrArgs &a, const int seq, c
                     if (!(fabsf(p_esc - p_n2) > simil_t * p_n2)) {
                         if (GREC) {
                             const float n2m = f_mx[c] * f_mx[c] + f_my[c] * f_my[c];
-                            const float nm = sqrtf(n2m);
+                            const float nm = sqrtf_mid(n2m);
                             div2_mid_f32(f_mx[c], f_my[c], nm, f_ux[c], f_uy[c]);
                         }
                         const float dx = px[c] - f_cpx[c], dy = py[c] - f_cpy[c];
@@ -1932,7 +1948,7 @@ __device__ __forceinline__ void tvr_rw2_body(const TvrArgs &a, const int seq, co
             if (!(fabs(p_esc - p_n2) > a.match_thresh * p_n2)) {
                 if (GREC) {
                     const float n2m = f_mx[c] * f_mx[c] + f_my[c] * f_my[c];
-                    const float nm = sqrtf(n2m);
+                    const float nm = sqrtf_mid(n2m);
                     f_ux[c] = f_mx[c] / nm; f_uy[c] = f_my[c] / nm;
                 }
                 const double dx = px[c] - (double)f_cpx[c], dy = py[c] - (double)f_cpy[c];
