@@ -435,7 +435,9 @@ __global__ __launch_bounds__(256) void k_field_raster(const KlSoA *kls, int32_t 
             MatchRec r;
             r.c_px = (float)(tx0 + (ikl & 63)); r.c_py = (float)(ty0 + ((ikl >> 6) & 63)); r.u_mx = 0.6f; r.u_my = 0.8f;
 #else
-            const MatchRec r = k.rec[ikl];
+            // (the record's first half — c_p, u_m: all the rasteriser reads — as a global load: a FLAT one makes the wait behind it a wait for the tile's LDS atomics too)
+            MatchRec r;
+            { const float4 q = ldg(reinterpret_cast<const float4 *>(k.rec), 2 * (size_t)ikl); r.c_px = q.x; r.c_py = q.y; r.u_mx = q.z; r.u_my = q.w; }
 #endif
             int t0, t1;
             if (!tile_trange(r, tx0, ty0, radius, t0, t1)) continue;
