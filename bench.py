@@ -623,7 +623,7 @@ def host_surface(params, frames, w, h):
     to the host for every frame; two steps in flight since round 6: edgehip_export_keylines), `objects_8_imu_fps` is eight ImuMode = 2
     members in one group (the device-side IMU branch behind the surface), `objects_8_stereo_fps` eight StereoAvaiable members in one group (a pair
     frame per main frame; the pair images are the main images: the pair path's cost, not a depth result), `objects_256_fps` / `objects_1024_fps` the same leg with 256 /
-    1024 cameras and 16 producer threads (the better of two runs each, both in `detail.*.fps_of_each_run`; `detail` carries where the producers' time goes).  Run lengths: 600 / 400 / 240 / 300 frames per object, the first 60 / 50 / 40 / 40 untimed — the
+    1024 cameras and 16 producer threads (the better of two runs each — and so for the 64-object legs —, both in `detail.*.fps_of_each_run`; `detail` carries where the producers' time goes).  Run lengths: 600 / 400 / 240 / 300 frames per object, the first 60 / 50 / 40 / 40 untimed — the
     application runs up to three frames ahead of the tracker (the camera ring) and the last frames drain, which weighed 15-30 % in
     the 36-frame runs of the first version of this leg."""
     import subprocess
@@ -672,7 +672,7 @@ def host_surface(params, frames, w, h):
                 # the 256- and 1024-camera legs are bound by the application's 16 producer threads (copyFrom + the mono test: ~2.5 MB of host
                 # memory traffic per frame) on a host this process shares with other tenants: two runs, the better one reported, both kept
                 runs = []
-                for _ in range(2 if n >= 256 else 1):
+                for _ in range(2 if n >= 64 else 1):   # (64 objects too: 39.6 … 82 k frames/s over the round's runs with the same binaries, a leg bound by the producers' side)
                     t_leg = time.perf_counter()
                     r = subprocess.run([exe, cfg, raw, str(len(frames)), str(n), str(k), "1", str(FRAME_DT), "--warmup", str(wm),
                                         "--threads", str(min(16, n))] + extra, capture_output=True, text=True, timeout=120)
