@@ -732,75 +732,9 @@ __device__ __forceinline__ bool is_carry(double v) { return __double_as_longlong
 #ifndef EDGEHIP_TVR_REF_ORDER
 #define EDGEHIP_TVR_REF_ORDER 1
 #endif
-// a / b rounded as IEEE division rounds it, given rb = RN(1 / b): the closing step of the division sequence the compiler itself
-// emits (quotient estimate, exact remainder by fma, correction by fma), without its scaling (no operand here is near the exponent
-// range's ends).  Against a / b on 4e8 random and adversarial pairs (significands near 1, near 2, short): no difference.
-__device__ __forceinline__ double div_rn(const double a, const double b, const double rb) {
-    const double q = a * rb;
-    const double e = __builtin_fma(-q, b, a);
-    return __builtin_fma(e, rb, q);
-}
-// (div_mid / inv_mid / rcp_nr — the division sequence without its exponent scaling — are in ctx.h: the one-kernel stage A's plane fit uses them too)
-// sqrt(x) for x >= 1 (q_rho^2 = (s_rho qvel)^2 + 1): the compiler's own sequence (v_rsq_f64, one coupled Newton step on the root and its
-// half reciprocal, two corrections from the exact remainder) without what it wraps around it for arguments below 2^-767 (a compare, two
-// selects, two v_ldexp_f64 by 0 here) — same values through the same fma's; +inf is the one special value left above 1.
-__device__ __forceinline__ double sqrt_ge1(const double x) {
-#if EDGEHIP_FASTDIV
-    const double y = __builtin_amdgcn_rsq(x);
-    double g = x * y, h = y * 0.5;
-    const double r = __builtin_fma(-h, g, 0.5);
-    g = __builtin_fma(g, r, g);
-    h = __builtin_fma(h, r, h);
-    double d = __builtin_fma(-g, g, x);
-    g = __builtin_fma(d, h, g);
-    d = __builtin_fma(-g, g, x);
-    g = __builtin_fma(d, h, g);
-    return __builtin_isinf(x) ? x : g;
-#else
-    return sqrt(x);
-#endif
-}
-// sqrtf(x) for a float in the middle of the range (|m_m|^2 of a KeyLine that passed the detector's threshold): the compiler's sequence — v_sqrt_f32
-// (1 ulp), then the neighbour below / above if the exact remainder says so — without the scaling it wraps around it for x < 2^-96 and without the
-// class test behind it (zero and +inf come out of the sequence as themselves: the remainders are NaN or -0 there and select nothing).
-__device__ __forceinline__ float sqrtf_mid(const float x) {
-#if EDGEHIP_FASTDIV
-    const float s = __builtin_amdgcn_sqrtf(x);
-    const float s_dn = __int_as_float(__float_as_int(s) - 1), s_up = __int_as_float(__float_as_int(s) + 1);
-    const float r_dn = __builtin_fmaf(-s_dn, s, x);
-    const float r_up = __builtin_fmaf(-s_up, s, x);
-    float r = r_dn <= 0.f ? s_dn : s;
-    r = r_up > 0.f ? s_up : r;
-    return r;
-#else
-    return sqrtf(x);
-#endif
-}
-// The matched KeyLine's unit gradient u_m = m_m / |m_m| (float, as the detector computes it): two float quotients by the same divisor.
-// The compiler's float division is the double one's shape (v_div_scale x 2, v_rcp_f32, one Newton step, quotient, two corrections,
-// v_div_fmas, v_div_fixup); the divisor's part — the reciprocal and its Newton step — is shared here and the scaling dropped as above
-// (|m_m| is a gradient modulus that passed the detector's threshold: the middle of the range).
-__device__ __forceinline__ void div2_mid_f32(const float n0, const float n1, const float d, float &q0, float &q1) {
-#if EDGEHIP_FASTDIV
-    float r = __builtin_amdgcn_rcpf(d);
-    r = __builtin_fmaf(__builtin_fmaf(-d, r, 1.f), r, r);
-    float q = n0 * r;
-    q = __builtin_fmaf(__builtin_fmaf(-d, q, n0), r, q);
-    q0 = __builtin_amdgcn_div_fixupf(__builtin_fmaf(__builtin_fmaf(-d, q, n0), r, q), d, n0);
-    q = n1 * r;
-    q = __builtin_fmaf(__builtin_fmaf(-d, q, n1), r, q);
-    q1 = __builtin_amdgcn_div_fixupf(__builtin_fmaf(__builtin_fmaf(-d, q, n1), r, q), d, n1);
-#else
-    q0 = n0 / d; q1 = n1 / d;
-#endif
-}
-__device__ __forceinline__ double rcp_for_div_rn(const double b) {   // div_rn's `rb`: the sequence's own reciprocal is enough (and is what a / b uses)
-#if EDGEHIP_FASTDIV
-    return rcp_nr(b);
-#else
-    return 1.0 / b;
-#endif
-}
+// (div_rn, div_mid / inv_mid / rcp_nr / MidDivisor, sqrt_ge1, sqrtf_mid, div2_mid_f32 — the division and square-root sequences without their exponent
+// scaling — are in ctx.h: the one-kernel stage A's plane fit and the matcher use them too, and tools/experiments/mid_range_ops_check.hip compares each of
+// them with the compiler's own operation bit for bit)
 #ifndef EDGEHIP_TVR_ABL
 #define EDGEHIP_TVR_ABL 0   // timing experiments only (tools/experiments/exp_tvr_ablate.sh): 1 no cross-lane reduction, 2 no div/sqrt,
 #endif                      // 4 no matched-KeyLine gather, 8 no field gather, 16 no residual stream
